@@ -1,0 +1,253 @@
+#!/usr/bin/env python
+"""bench.py -- ranked (1+K)-tuples/sec of the BPRMF training hot path on MI355X.
+
+Workload = BASELINE.json configs[1]: BPRMF emb_size=64, num_neg=99, synthetic 10M-item Zipf
+catalogue, one GPU.  A "step" is one BaseRunner.fit iteration (forward, BPR loss, backward,
+optimizer row update) over one batch of B synthetic (user, pos, neg[K]) tuples whose ids are
+already resident in HBM.  Prints ONE JSON line (rank 0).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--opt SGD|Adam|Adagrad]
+
+N > 1 is launched by torch.distributed.run (one rank per GPU).  Round 1: ranks run independent
+table replicas on disjoint batch streams (no data-path collective yet).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=65536, help="tuples per step per GPU")
+    ap.add_argument("--num-neg", type=int, default=99)
+    ap.add_argument("--emb-size", type=int, default=64)
+    ap.add_argument("--items", type=int, default=10_000_001)
+    ap.add_argument("--users", type=int, default=1_000_001)
+    ap.add_argument("--opt", default="SGD", choices=["SGD", "Adam", "Adagrad"])
+    ap.add_argument("--lr", type=float, default=1e-3)
+    ap.add_argument("--l2", type=float, default=0.0)
+    ap.add_argument("--pool", type=int, default=8, help="distinct pre-generated batches (cycled)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    return ap.parse_args()
+
+
+def zipf_ids(n_rows, size, gen, device):
+    """Zipf(alpha=1) ranks (density ~ 1/r on [1, n_rows)) mapped to ids by a fixed bijection so
+    hot rows are spread over the id space.  n_rows-1 must be coprime
+    with the multiplier (true for 10^k)."""
+    u = torch.rand(size, generator=gen, device=device, dtype=torch.float64)
+    ranks = torch.exp(u * np.log(n_rows - 1)).to(torch.int64).clamp_(1, n_rows - 1)
+    return (ranks * 2654435761) % (n_rows - 1) + 1
+
+
+def make_batches(args, device, seed):
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    out = []
+    for _ in range(args.pool):
+        uid = zipf_ids(args.users, (args.batch,), gen, device)
+        pos = zipf_ids(args.items, (args.batch, 1), gen, device)
+        # negatives: uniform randint(1, n_items), models/BaseModel.py:207
+        neg = torch.randint(1, args.items, (args.batch, args.num_neg), generator=gen, device=device)
+        out.append((uid.contiguous(), torch.cat([pos, neg], dim=1).contiguous()))
+    return out
+
+
+def algorithmic_bytes(args, batches):
+    """ALGORITHMIC HBM bytes per launch of each phase: every byte the
+    phase must move at least once, table rows counted once per distinct row per step."""
+    B, C, d = args.batch, args.num_neg + 1, args.emb_size
+    n_occ = B * C
+    ui = float(np.mean([torch.unique(i).numel() for _, i in batches]))
+    uu = float(np.mean([torch.unique(u).numel() for u, _ in batches]))
+    row = 4 * d
+    fused = (8 * B + 8 * n_occ          # uid, iid
+             + uu * row + ui * row      # distinct user / item rows, read once
+             + 4 * n_occ + B * row + 4 * B)   # gpred, ugrad, loss_vec written
+    item_update = (12 * n_occ + 8 * B   # keys, perm, gpred per occurrence; uid
+                   + uu * row           # U rows rebuilt into g*U: distinct rows once
+                   + 2 * ui * row)      # item row read + written once per distinct row
+    user_update = 8 * B + B * row + 2 * uu * row
+    sort_items = 8 * n_occ + 8 * n_occ  # ids in, keys+perm out (one ideal pass)
+    return {"fused_fwd_bwd": fused, "item_update": item_update, "user_update": user_update,
+            "sort_items": sort_items, "uniq_items": ui, "uniq_users": uu}
+
+
+def load_pmc_traffic(kernel):
+    """HBM bytes per launch from committed rocprofv3 PMC passes (profiles/pmc_latest.json), if any."""
+    p = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    if not os.path.exists(p):
+        return None
+    try:
+        return json.load(open(p)).get(kernel, {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def cpu_baseline(args):
+    """The torch-CPU port of the reference's fit() iteration (oracle/torch_port.py), same table
+    sizes and batch shape, a bounded number of steps on the host cores."""
+    from oracle.torch_port import BprmfTorchPort
+    torch.manual_seed(0)
+    cores = torch.get_num_threads()
+    t_init = time.perf_counter()
+    model = BprmfTorchPort(args.users, args.items, args.emb_size)
+    optim = model.make_optimizer(args.opt, args.lr, args.l2)
+    gen = torch.Generator()
+    gen.manual_seed(1)
+    cpu = torch.device("cpu")
+    steps = []
+    n = 0
+    for s in range(args.cpu_steps + 1):  # first step is warm-up (page faults, thread pool)
+        uid = zipf_ids(args.users, (args.batch,), gen, cpu)
+        pos = zipf_ids(args.items, (args.batch, 1), gen, cpu)
+        neg = torch.randint(1, args.items, (args.batch, args.num_neg), generator=gen)
+        iid = torch.cat([pos, neg], dim=1)
+        t0 = time.perf_counter()
+        model.fit_step(optim, uid, iid)
+        dt = time.perf_counter() - t0
+        if s > 0:
+            steps.append(dt)
+            n += args.batch
+        if time.perf_counter() - t_init > 90 and steps:
+            break
+    v = n / sum(steps)
+    return {"value": v, "unit": "tuples/s", "cores": cores, "kind": "port",
+            "sample": f"{len(steps)} fit() iterations of oracle/torch_port.py (torch {torch.__version__} CPU, "
+                      f"{cores} threads, dense grads + dense torch.optim.{args.opt} over all rows like the "
+                      f"reference) at B={args.batch}, K={args.num_neg}, d={args.emb_size}, "
+                      f"{args.items} items, {args.users} users; {sum(steps):.1f} s"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 "
+                         "--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from rechorus_amd import engine
+
+    gen = torch.Generator(device=device)
+    gen.manual_seed(1234 + rank)
+    U = torch.empty((args.users, args.emb_size), device=device).normal_(0, 0.01, generator=gen)
+    I = torch.empty((args.items, args.emb_size), device=device).normal_(0, 0.01, generator=gen)
+    batches = make_batches(args, device, seed=99 + rank)
+    trainer = engine.BprmfTrainer(U, I, opt=args.opt, lr=args.lr, l2=args.l2)
+
+    def sync():
+        torch.cuda.synchronize(device)
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize(device)
+
+    for s in range(args.warmup):
+        trainer.step(*batches[s % len(batches)])
+    sync()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        trainer.step(*batches[s % len(batches)])
+    sync()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss = float(trainer.loss.item())
+    if not np.isfinite(loss):
+        raise SystemExit(f"non-finite loss {loss}")
+
+    tuples = args.batch * args.steps * world
+    out = {
+        "metric": "ranked (1+K)-tuples/sec",
+        "value": tuples / elapsed,
+        "unit": "tuples/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": f"BPRMF fit step: emb_size={args.emb_size}, num_neg={args.num_neg}, "
+                        f"{args.items}-item / {args.users}-user tables, Zipf(1.0) users+positives, "
+                        f"uniform negatives, B={args.batch} tuples/GPU/step, optimizer={args.opt} "
+                        f"(row-wise, l2={args.l2:g}), int64 ids, fp32",
+            "batch_per_gpu": args.batch, "num_neg": args.num_neg, "emb_size": args.emb_size,
+            "n_items": args.items, "n_users": args.users, "optimizer": args.opt,
+            "parallelism": "single GPU" if world == 1 else f"{world} independent replicas",
+        },
+        "final_loss": loss,
+    }
+
+    if rank == 0 and not args.no_roofline:
+        # per-phase hipEvent timing on the launch stream, measured live (profiling steps are
+        # outside the timed region above)
+        acc = {}
+        reps = 10
+        for s in range(reps):
+            ph = trainer.profile_step(*batches[s % len(batches)])
+            for k, v in ph.items():
+                acc[k] = acc.get(k, 0.0) + v / reps
+        ab = algorithmic_bytes(args, batches)
+        mine = {k: acc[k] for k in ("fused_fwd_bwd", "item_update", "user_update")}
+        dom = max(mine, key=mine.get)
+        achieved = ab[dom] / (acc[dom] * 1e-3) / 1e9
+        out["roofline"] = {
+            "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBPS, "traffic": load_pmc_traffic(dom),
+            "algorithmic_bytes_per_launch": ab[dom], "avg_ms": acc[dom],
+        }
+        out["phases_ms"] = {k: round(v, 4) for k, v in acc.items()}
+        out["phases_gbps"] = {k: round(ab[k] / (acc[k] * 1e-3) / 1e9, 1)
+                              for k in ("fused_fwd_bwd", "item_update", "user_update", "sort_items")}
+        out["uniq_rows_per_step"] = {"items": ab["uniq_items"], "users": ab["uniq_users"]}
+        # compulsory bytes of the whole fused fwd+bwd+SGD step, rows once per
+        # distinct row: read + write each touched row, ids, pred
+        whole = 2 * (ab["uniq_items"] + ab["uniq_users"]) * 4 * args.emb_size + \
+            8 * args.batch * (args.num_neg + 2) + 4 * args.batch * (args.num_neg + 1)
+        out["step_effective_gbps"] = whole / (out["ms_per_step"] * 1e-3) / 1e9
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args)
+
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,163 @@
+/*
+ * rechorus_hip.h -- C ABI of librechorus_hip.so, the MI355X (gfx950) engine for the
+ * ReChorus ranking hot path:  embedding gather (user, pos, neg[K]) -> interaction head
+ * -> BPR loss -> embedding-gradient segmented scatter + optimizer row update.
+ *
+ * The reference (THUwangcy/ReChorus) has no FFI: every operation below is an *implicit*
+ * ATen kernel group dispatched from Python.  Each entry point cites the reference lines
+ * whose arithmetic it replaces (paths relative to the reference's src/).
+ *
+ * Conventions
+ *  - every pointer except `const char*` results and `phase_ms` is a DEVICE pointer
+ *    (a torch tensor's data_ptr()); buffers are caller-owned, nothing is allocated here;
+ *  - tables are row-major fp32 [n_rows, d]; ids are int64 (the reference layout,
+ *    models/BaseModel.py:198) and must lie in [0, n_rows);  ids are NOT range-checked
+ *    on the device (the reference asserts this on the host, helpers/BaseReader.py:59);
+ *  - kernels are enqueued on `stream` (a hipStream_t passed as void*) and never
+ *    synchronise, unless a `phase_ms` host pointer is given (profiling mode);
+ *  - every function returns RC_OK (0) or a negative rc_status; the text of the last
+ *    failure on the calling thread is rc_last_error_string();
+ *  - scratch comes from the caller: rc_*_workspace_bytes() gives the size.
+ */
+#ifndef RECHORUS_HIP_H
+#define RECHORUS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* rc_stream_t; /* hipStream_t */
+
+enum rc_status {
+  RC_OK = 0,
+  RC_ERR_INVALID_ARG = -1, /* bad shape / null pointer / unsupported combination      */
+  RC_ERR_WORKSPACE = -2,   /* workspace too small                                    */
+  RC_ERR_HIP = -3,         /* a HIP runtime call or kernel launch failed             */
+  RC_ERR_UNSUPPORTED = -4  /* valid request the engine has no kernel for             */
+};
+
+/* optimizers of helpers/BaseRunner.py:110-114 (eval('torch.optim.<name>')) */
+enum rc_opt {
+  RC_OPT_SGD = 0,     /* torch.optim.SGD, no momentum                                 */
+  RC_OPT_ADAM = 1,    /* torch.optim.Adam (amsgrad off)                               */
+  RC_OPT_ADAGRAD = 2  /* torch.optim.Adagrad (lr_decay 0, initial accumulator 0)      */
+};
+
+/* hyper-parameters of one optimizer step.  `step` is the 1-based step count t used for
+ * Adam's bias correction (1 - beta^t); weight decay `l2` is added to the gradient
+ * (g += l2 * w) exactly as torch does for weight_decay (helpers/BaseRunner.py:112-113). */
+typedef struct rc_opt_hyper {
+  int opt;      /* enum rc_opt */
+  int reserved; /* 0 */
+  double lr;    /* doubles, like the Python floats torch.optim receives; the engine     */
+  double l2;    /* narrows the derived scalars to fp32 at the same points torch does    */
+  double beta1; /* Adam */
+  double beta2; /* Adam */
+  double eps;   /* Adam 1e-8, Adagrad 1e-10 */
+  int64_t step; /* t >= 1 */
+} rc_opt_hyper;
+
+/* ---- library ------------------------------------------------------------------- */
+int rc_version(void);                    /* ABI version, currently 1                  */
+const char* rc_last_error_string(void);  /* thread-local text of the last failure     */
+int rc_device_count(void);               /* >= 0, or a negative rc_status             */
+
+/* ---- forward ------------------------------------------------------------------- */
+
+/* nn.Embedding forward, out[i,:] = W[ids[i],:]      (models/general/BPRMF.py:39-40) */
+int rc_gather_rows(const float* W, int d, const int64_t* ids, int64_t n, float* out,
+                   rc_stream_t stream);
+
+/* BPRMF scores, pred[b,c] = <U[uid[b]], I[iid[b,c]]>  (models/general/BPRMF.py:39-42).
+ * Any C >= 1 (eval uses C = 100 or C = n_items-1 with --test_all).                  */
+int rc_gather_dot_fwd(const float* U, const float* I, const int64_t* uid,
+                      const int64_t* iid, int B, int C, int d, float* pred,
+                      rc_stream_t stream);
+
+/* ---- loss ---------------------------------------------------------------------- */
+
+/* GeneralModel.loss (models/BaseModel.py:182-185): softmax-weighted multi-negative BPR.
+ * pred [B,C] (column 0 = positive, C >= 2).  Writes the per-row loss
+ *   loss_vec[b] = -log(clamp(sum_k softmax(neg)_k * sigmoid(pos - neg_k), 1e-8, 1-1e-8))
+ * and, if gpred != NULL, gpred[b,c] = d(inv_b * sum_b loss_vec[b]) / d pred[b,c]
+ * (inv_b = 1/B gives the reference's .mean()).                                       */
+int rc_bpr_loss_fwd_bwd(const float* pred, int B, int C, float inv_b, float* loss_vec,
+                        float* gpred, rc_stream_t stream);
+
+/* out[0] = scale * sum_i x[i], fixed summation order (deterministic).  Used for the
+ * batch mean of loss_vec (models/BaseModel.py:185 `.mean()`).                         */
+int rc_reduce_sum(const float* x, int64_t n, float scale, float* out, rc_stream_t stream);
+
+/* ---- fused BPRMF forward + loss + backward-to-rows ------------------------------- */
+
+/* One pass over the (1+K) candidate rows of every tuple, rows held in registers:
+ *   pred (optional, may be NULL), loss_vec[B], gpred[B,C] = dL/dpred,
+ *   ugrad[B,d] = sum_c gpred[b,c] * I[iid[b,c]]   (the per-tuple user-row gradient).
+ * Replaces BPRMF.forward + GeneralModel.loss + the MulBackward/SumBackward half of
+ * autograd (models/general/BPRMF.py:34-45, models/BaseModel.py:182-185).  The item-row
+ * gradients g[b,c]*U[uid[b]] are NOT materialised; rc_segmented_update rebuilds them. */
+int rc_bprmf_fwd_bwd(const float* U, const float* I, const int64_t* uid,
+                     const int64_t* iid, int B, int C, int d, float inv_b, float* pred,
+                     float* loss_vec, float* gpred, float* ugrad, rc_stream_t stream);
+
+/* ---- index sort (the atomic-free replacement of embedding_dense_backward's index_add) */
+
+size_t rc_sort_workspace_bytes(int64_t n);
+
+/* keys_out = ids sorted ascending (as uint32), perm_out = stable sorting permutation
+ * (perm_out[j] = position in `ids` of the j-th smallest).  n_rows bounds the ids
+ * (only ceil(log2 n_rows) key bits are sorted).  n < 2^31, n_rows <= 2^32.            */
+int rc_sort_ids(const int64_t* ids, int64_t n, int64_t n_rows, uint32_t* keys_out,
+                uint32_t* perm_out, void* ws, size_t ws_bytes, rc_stream_t stream);
+
+/* ---- segmented gradient reduction + optimizer row update -------------------------- */
+
+size_t rc_segmented_workspace_bytes(int64_t n_occ);
+
+/* For every distinct row r in sorted `keys` (with occurrences o = perm[j], j in the
+ * segment of r, visited in ascending j => fixed summation order, no float atomics):
+ *     grad_r = sum_o  coef[o] * Src[ srow(o), : ],
+ *     srow(o) = src_index ? src_index[o / div] : o / div        (coef NULL => 1)
+ * then, if `dense_grad` != NULL:  dense_grad[r,:] = grad_r   (torch-compatible dense
+ * .grad; caller zero-fills it; replaces aten::embedding_dense_backward), else applies
+ * the optimizer `h` to row r of W in place (and to rows r of the state tables m, v:
+ * Adam exp_avg / exp_avg_sq, Adagrad sum in `m`), i.e. a row-wise ("lazy") version of
+ * helpers/BaseRunner.py:206 that only touches rows present in the batch.
+ * Src must not alias W.  ws from rc_segmented_workspace_bytes(n_occ).                 */
+int rc_segmented_update(float* W, float* m, float* v, int d, const uint32_t* keys,
+                        const uint32_t* perm, int64_t n_occ, const float* coef,
+                        const float* src, const int64_t* src_index, int div,
+                        const rc_opt_hyper* h, float* dense_grad, void* ws,
+                        size_t ws_bytes, rc_stream_t stream);
+
+/* Exact dense optimizer step over all n elements (torch.optim semantics incl. weight
+ * decay on every element, helpers/BaseRunner.py:110-114,206).  m/v as above.         */
+int rc_dense_update(float* W, const float* G, float* m, float* v, int64_t n,
+                    const rc_opt_hyper* h, rc_stream_t stream);
+
+/* ---- whole BPRMF training step ----------------------------------------------------- */
+
+size_t rc_bprmf_step_workspace_bytes(int B, int C, int d);
+
+/* One BaseRunner.fit iteration for BPRMF (helpers/BaseRunner.py:193-206 with
+ * models/general/BPRMF.py:34-45 and models/BaseModel.py:182-185), row-wise optimizer:
+ * sort ids -> fused fwd/loss/bwd -> item-row update -> user-row update.
+ * loss_out[0] = mean_b loss (device float).  pred may be NULL.
+ * state tables (mU,vU,mI,vI) may be NULL for SGD.
+ * phase_ms: NULL, or a HOST float[8] filled with per-phase milliseconds measured with
+ * hipEvents on `stream` (the call then synchronises):
+ *   [0] sort item ids [1] sort user ids [2] fused fwd/bwd [3] loss mean
+ *   [4] item-row update [5] user-row update [6] total [7] reserved                    */
+int rc_bprmf_train_step(float* U, float* I, float* mU, float* vU, float* mI, float* vI,
+                        const int64_t* uid, const int64_t* iid, int B, int C, int d,
+                        int64_t n_users, int64_t n_items, const rc_opt_hyper* h,
+                        float inv_b, float* loss_out, float* pred, void* ws,
+                        size_t ws_bytes, rc_stream_t stream, float* phase_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RECHORUS_HIP_H */

@@ -1,0 +1,102 @@
+"""ctypes binding of librechorus_hip.so (the C ABI declared in include/rechorus_hip.h).
+
+There is deliberately no fallback: if the HIP library is missing, importing fails loudly
+(`RechorusHipMissing`) instead of routing through torch or the CPU oracle.
+"""
+import ctypes as C
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "librechorus_hip.so")
+
+RC_OK = 0
+RC_OPT_SGD, RC_OPT_ADAM, RC_OPT_ADAGRAD = 0, 1, 2
+OPT_BY_NAME = {"SGD": RC_OPT_SGD, "Adam": RC_OPT_ADAM, "Adagrad": RC_OPT_ADAGRAD}
+
+
+class RechorusHipMissing(ImportError):
+    pass
+
+
+class RechorusHipError(RuntimeError):
+    def __init__(self, fn, code, text):
+        super().__init__(f"{fn} failed (rc_status {code}): {text}")
+        self.code = code
+
+
+class OptHyper(C.Structure):
+    """struct rc_opt_hyper"""
+    _fields_ = [
+        ("opt", C.c_int),
+        ("reserved", C.c_int),
+        ("lr", C.c_double),
+        ("l2", C.c_double),
+        ("beta1", C.c_double),
+        ("beta2", C.c_double),
+        ("eps", C.c_double),
+        ("step", C.c_int64),
+    ]
+
+
+_p = C.c_void_p
+_i = C.c_int
+_i64 = C.c_int64
+_f = C.c_float
+_sz = C.c_size_t
+_hp = C.POINTER(OptHyper)
+
+# name -> (restype, argtypes); must list every symbol include/rechorus_hip.h declares
+SIGNATURES = {
+    "rc_version": (_i, []),
+    "rc_last_error_string": (C.c_char_p, []),
+    "rc_device_count": (_i, []),
+    "rc_gather_rows": (_i, [_p, _i, _p, _i64, _p, _p]),
+    "rc_gather_dot_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _p]),
+    "rc_bpr_loss_fwd_bwd": (_i, [_p, _i, _i, _f, _p, _p, _p]),
+    "rc_reduce_sum": (_i, [_p, _i64, _f, _p, _p]),
+    "rc_bprmf_fwd_bwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _f, _p, _p, _p, _p, _p]),
+    "rc_sort_workspace_bytes": (_sz, [_i64]),
+    "rc_sort_ids": (_i, [_p, _i64, _i64, _p, _p, _p, _sz, _p]),
+    "rc_segmented_workspace_bytes": (_sz, [_i64]),
+    "rc_segmented_update": (_i, [_p, _p, _p, _i, _p, _p, _i64, _p, _p, _p, _i, _hp, _p, _p, _sz, _p]),
+    "rc_dense_update": (_i, [_p, _p, _p, _p, _i64, _hp, _p]),
+    "rc_bprmf_step_workspace_bytes": (_sz, [_i, _i, _i]),
+    "rc_bprmf_train_step": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i64, _i64, _hp, _f,
+                                 _p, _p, _p, _sz, _p, C.POINTER(C.c_float)]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen the library once and attach the prototypes."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RechorusHipMissing(
+            f"{LIB_PATH} not found: build it with `python -m rechorus_amd.csrc.build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU/torch fallback for the hot path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise RechorusHipMissing(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(fn_name, code):
+    if code != RC_OK:
+        text = load().rc_last_error_string()
+        raise RechorusHipError(fn_name, code, text.decode() if text else "")
+
+
+def call(fn_name, *args):
+    """Call an int-returning entry point and raise on a non-zero status."""
+    lib = load()
+    code = getattr(lib, fn_name)(*args)
+    check(fn_name, code)

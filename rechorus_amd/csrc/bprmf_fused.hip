@@ -1,0 +1,285 @@
+// bprmf_fused.hip -- phase A of a BPRMF training step: gather + GMF dot + BPR loss +
+// backward to per-tuple row gradients, in ONE pass over HBM.
+//
+// Reference arithmetic: models/general/BPRMF.py:34-45 (gather, broadcast mul, sum),
+// models/BaseModel.py:182-185 (loss) and the MulBackward/SumBackward nodes autograd
+// derives from them.
+//
+// Layout.  A tuple's C = 1+K candidate rows are the unit of work.  A row of D fp32 is
+// owned by LPR = D/4 consecutive lanes (one float4 each -> one coalesced D*4-byte
+// segment per row); a tuple is owned by GS such lane-groups (S = LPR*GS lanes), each
+// group holding CPL = ceil(C/GS) candidate rows *in registers* (CPL float4 per lane).
+// D=64, C=100: LPR=16, GS=4, CPL=25 -> the whole 25.6 KB candidate block of a tuple
+// lives in one wave's VGPRs (100 VGPRs/lane), so the backward pass (user-row gradient
+// sum_c g_c * I_c, which needs every row again after the softmax over all K negatives is
+// known) re-reads nothing from HBM, LDS is not needed at all, and the only cross-lane
+// traffic is DPP row reductions + a few ds_bpermute across the GS groups.
+// Small C packs several tuples per wave (C=2: two 32-lane tuples).
+#include "bpr_math.hpp"
+#include "common.hpp"
+
+namespace rc {
+
+template <int D, int GS, int CPL>
+__global__ __launch_bounds__(kBlock) void bprmf_fwd_bwd_kernel(
+    const float* __restrict__ U, const float* __restrict__ I,
+    const int64_t* __restrict__ uid, const int64_t* __restrict__ iid, int B, int C,
+    float inv_b, float* __restrict__ pred, float* __restrict__ loss_vec,
+    float* __restrict__ gpred, float* __restrict__ ugrad) {
+  constexpr int LPR = D / 4;
+  constexpr int S = LPR * GS;
+  static_assert(S <= 64 && (64 % S) == 0, "tuple must fit a wave");
+  constexpr int TPW = 64 / S;  // tuples per wave
+
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  const int64_t t_raw = wave * TPW + lane / S;
+  const bool tv = t_raw < B;
+  const int64_t t = tv ? t_raw : (int64_t)B - 1;  // clamp: every lane stays in the shuffles
+  const int sub = lane % S;
+  const int grp = sub / LPR;
+  const int l = sub % LPR;
+
+  // ---- gather: user row, then this group's CPL candidate rows, all loads in flight
+  const int64_t u = uid[t];
+  const float4 u4 = reinterpret_cast<const float4*>(U + u * D)[l];
+  const int64_t* ids = iid + t * C;
+  float4 r[CPL];
+#pragma unroll
+  for (int j = 0; j < CPL; ++j) {
+    const int c = j * GS + grp;
+    const int64_t id = ids[c < C ? c : 0];  // slots past C re-read candidate 0; masked below
+    r[j] = reinterpret_cast<const float4*>(I + id * D)[l];
+  }
+
+  // ---- scores
+  float p[CPL];
+#pragma unroll
+  for (int j = 0; j < CPL; ++j) p[j] = row_allreduce_sum<LPR>(dot4(u4, r[j]));
+  const float pos = __shfl(p[0], (lane / S) * S, 64);  // candidate 0 lives in group 0, j=0
+
+  if (pred != nullptr && tv && l == 0) {
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+      const int c = j * GS + grp;
+      if (c < C) pred[t * C + c] = p[j];
+    }
+  }
+
+  // ---- loss: softmax over the negatives, P = sum w*sigmoid(pos-neg)
+  float mx = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < CPL; ++j) {
+    const int c = j * GS + grp;
+    if (c >= 1 && c < C) mx = fmaxf(mx, p[j]);
+  }
+  mx = groups_allreduce_max<LPR, S>(mx);
+  float e[CPL];
+  float se = 0.f;
+#pragma unroll
+  for (int j = 0; j < CPL; ++j) {
+    const int c = j * GS + grp;
+    e[j] = (c >= 1 && c < C) ? expf(p[j] - mx) : 0.f;
+    se += e[j];
+  }
+  se = groups_allreduce_sum<LPR, S>(se);
+  const float inv_se = 1.0f / se;
+  float P = 0.f, A = 0.f;
+  float sg[CPL];
+#pragma unroll
+  for (int j = 0; j < CPL; ++j) {
+    e[j] *= inv_se;  // softmax weight w_j (0 on masked slots)
+    sg[j] = sigmoidf_(pos - p[j]);
+    P = fmaf(e[j], sg[j], P);
+    A = fmaf(e[j], sg[j] * (1.0f - sg[j]), A);
+  }
+  P = groups_allreduce_sum<LPR, S>(P);
+  A = groups_allreduce_sum<LPR, S>(A);
+  const BprRow br = bpr_row(P, inv_b);
+  if (tv && sub == 0) loss_vec[t] = br.loss;
+
+  // ---- backward: g_c = dL/dpred[t,c]; user-row gradient = sum_c g_c * I_c
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int j = 0; j < CPL; ++j) {
+    const int c = j * GS + grp;
+    float g = br.dLdP * bpr_dP_dneg(e[j], sg[j], P);  // 0 on masked slots (w = 0)
+    if (c == 0) g = br.dLdP * A;
+    if (c >= C) g = 0.f;
+    acc.x = fmaf(g, r[j].x, acc.x);
+    acc.y = fmaf(g, r[j].y, acc.y);
+    acc.z = fmaf(g, r[j].z, acc.z);
+    acc.w = fmaf(g, r[j].w, acc.w);
+    if (tv && l == 0 && c < C) gpred[t * C + c] = g;
+  }
+  acc.x = groups_allreduce_sum<LPR, S>(acc.x);
+  acc.y = groups_allreduce_sum<LPR, S>(acc.y);
+  acc.z = groups_allreduce_sum<LPR, S>(acc.z);
+  acc.w = groups_allreduce_sum<LPR, S>(acc.w);
+  if (tv && grp == 0) reinterpret_cast<float4*>(ugrad + t * D)[l] = acc;
+}
+
+// Any d, any 2 <= C <= kGenericMaxC: one wave per tuple, scores staged in LDS, candidate
+// rows re-gathered (from L2/MALL) for the backward sum.  Correctness fall-back.
+constexpr int kGenericMaxC = 4096;
+constexpr int kGenericMaxDChunks = 8;  // d <= 512
+
+__global__ __launch_bounds__(kBlock) void bprmf_fwd_bwd_generic_kernel(
+    const float* __restrict__ U, const float* __restrict__ I,
+    const int64_t* __restrict__ uid, const int64_t* __restrict__ iid, int B, int C, int d,
+    float inv_b, float* __restrict__ pred, float* __restrict__ loss_vec,
+    float* __restrict__ gpred, float* __restrict__ ugrad) {
+  extern __shared__ float smem[];  // [waves per block][C]
+  const int lane = threadIdx.x & 63;
+  const int wib = threadIdx.x >> 6;
+  const int64_t t_raw = (int64_t)blockIdx.x * (kBlock / 64) + wib;
+  const bool tv = t_raw < B;  // wave-uniform; no early return (block barriers below)
+  const int64_t t = tv ? t_raw : (int64_t)B - 1;
+  float* sp = smem + (size_t)wib * C;
+  const float* ur = U + uid[t] * d;
+  const int64_t* ids = iid + t * C;
+  for (int c = 0; c < C; ++c) {
+    const float* ir = I + ids[c] * d;
+    float a = 0.f;
+    for (int k = lane; k < d; k += 64) a = fmaf(ur[k], ir[k], a);
+    a = wave_allreduce_sum(a);
+    if (lane == 0) sp[c] = a;
+  }
+  __syncthreads();
+  const float pos = sp[0];
+  float mx = -INFINITY;
+  for (int c = 1 + lane; c < C; c += 64) mx = fmaxf(mx, sp[c]);
+  mx = wave_allreduce_max(mx);
+  float se = 0.f;
+  for (int c = 1 + lane; c < C; c += 64) se += expf(sp[c] - mx);
+  se = wave_allreduce_sum(se);
+  const float inv_se = 1.0f / se;
+  float P = 0.f, A = 0.f;
+  for (int c = 1 + lane; c < C; c += 64) {
+    const float w = expf(sp[c] - mx) * inv_se;
+    const float s = sigmoidf_(pos - sp[c]);
+    P = fmaf(w, s, P);
+    A = fmaf(w, s * (1.0f - s), A);
+  }
+  P = wave_allreduce_sum(P);
+  A = wave_allreduce_sum(A);
+  const BprRow br = bpr_row(P, inv_b);
+  if (tv && lane == 0) loss_vec[t] = br.loss;
+  __syncthreads();  // all lanes have read sp[] as scores
+  for (int c = lane; c < C; c += 64) {
+    const float pc = sp[c];
+    if (pred && tv) pred[t * C + c] = pc;
+    float g;
+    if (c == 0) {
+      g = br.dLdP * A;
+    } else {
+      const float w = expf(pc - mx) * inv_se;
+      const float s = sigmoidf_(pos - pc);
+      g = br.dLdP * bpr_dP_dneg(w, s, P);
+    }
+    if (tv) gpred[t * C + c] = g;
+    sp[c] = g;
+  }
+  __syncthreads();
+  float acc[kGenericMaxDChunks];
+#pragma unroll
+  for (int q = 0; q < kGenericMaxDChunks; ++q) acc[q] = 0.f;
+  for (int c = 0; c < C; ++c) {
+    const float* ir = I + ids[c] * d;
+    const float g = sp[c];
+#pragma unroll
+    for (int q = 0; q < kGenericMaxDChunks; ++q) {
+      const int k = lane + 64 * q;
+      if (k < d) acc[q] = fmaf(g, ir[k], acc[q]);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < kGenericMaxDChunks; ++q) {
+    const int k = lane + 64 * q;
+    if (tv && k < d) ugrad[t * d + k] = acc[q];
+  }
+}
+
+template <int D, int GS, int CPL>
+static int launch_fused(const float* U, const float* I, const int64_t* uid, const int64_t* iid,
+                        int B, int C, float inv_b, float* pred, float* loss_vec, float* gpred,
+                        float* ugrad, hipStream_t s) {
+  constexpr int TPW = 64 / ((D / 4) * GS);
+  constexpr int TPB = TPW * (kBlock / 64);
+  const int blocks = (B + TPB - 1) / TPB;
+  hipLaunchKernelGGL((bprmf_fwd_bwd_kernel<D, GS, CPL>), dim3(blocks), dim3(kBlock), 0, s, U, I,
+                     uid, iid, B, C, inv_b, pred, loss_vec, gpred, ugrad);
+  RC_LAUNCH_CHECK();
+  return RC_OK;
+}
+
+// pick (GS, CPL) for C candidates when a wave offers G = 64/LPR lane-groups
+template <int D>
+static int dispatch_fused(const float* U, const float* I, const int64_t* uid,
+                          const int64_t* iid, int B, int C, float inv_b, float* pred,
+                          float* loss_vec, float* gpred, float* ugrad, hipStream_t s,
+                          bool* handled) {
+  constexpr int G = 64 / (D / 4);
+  *handled = true;
+#define RC_FUSED(GS_, CPL_) \
+  return launch_fused<D, GS_, CPL_>(U, I, uid, iid, B, C, inv_b, pred, loss_vec, gpred, ugrad, s)
+  if (G >= 2 && C <= 2) { RC_FUSED((G >= 2 ? 2 : 1), 1); }
+  if (G >= 4 && C <= 4) { RC_FUSED((G >= 4 ? 4 : 1), 1); }
+  if (G >= 8 && C <= 8) { RC_FUSED((G >= 8 ? 8 : 1), 1); }
+  if (G >= 16 && C <= 16) { RC_FUSED((G >= 16 ? 16 : 1), 1); }
+  const int cpl = (C + G - 1) / G;
+  if (cpl <= 1) { RC_FUSED(G, 1); }
+  if (cpl <= 2) { RC_FUSED(G, 2); }
+  if (cpl <= 3) { RC_FUSED(G, 3); }
+  if (cpl <= 4) { RC_FUSED(G, 4); }
+  if (cpl <= 6) { RC_FUSED(G, 6); }
+  if (cpl <= 8) { RC_FUSED(G, 8); }
+  if (cpl <= 13) { RC_FUSED(G, 13); }
+  if (cpl <= 16) { RC_FUSED(G, 16); }
+  if (cpl <= 20) { RC_FUSED(G, 20); }
+  if (cpl <= 25) { RC_FUSED(G, 25); }
+  if (cpl <= 32) { RC_FUSED(G, 32); }
+#undef RC_FUSED
+  *handled = false;
+  return RC_OK;
+}
+
+}  // namespace rc
+
+using namespace rc;
+
+extern "C" int rc_bprmf_fwd_bwd(const float* U, const float* I, const int64_t* uid,
+                                const int64_t* iid, int B, int C, int d, float inv_b,
+                                float* pred, float* loss_vec, float* gpred, float* ugrad,
+                                rc_stream_t stream) {
+  RC_REQUIRE(U && I && uid && iid && loss_vec && gpred && ugrad, "rc_bprmf_fwd_bwd: null pointer");
+  RC_REQUIRE(B >= 0 && C >= 2 && d >= 1,
+             "rc_bprmf_fwd_bwd: need C >= 2 (one negative), got B=%d C=%d d=%d", B, C, d);
+  if (B == 0) return RC_OK;
+  hipStream_t s = as_stream(stream);
+  const bool aligned = (reinterpret_cast<uintptr_t>(U) % 16 == 0) &&
+                       (reinterpret_cast<uintptr_t>(I) % 16 == 0) &&
+                       (reinterpret_cast<uintptr_t>(ugrad) % 16 == 0);
+  bool handled = false;
+  if (aligned) {
+    int rc_ = RC_OK;
+    switch (d) {
+      case 16: rc_ = dispatch_fused<16>(U, I, uid, iid, B, C, inv_b, pred, loss_vec, gpred, ugrad, s, &handled); break;
+      case 32: rc_ = dispatch_fused<32>(U, I, uid, iid, B, C, inv_b, pred, loss_vec, gpred, ugrad, s, &handled); break;
+      case 64: rc_ = dispatch_fused<64>(U, I, uid, iid, B, C, inv_b, pred, loss_vec, gpred, ugrad, s, &handled); break;
+      case 128: rc_ = dispatch_fused<128>(U, I, uid, iid, B, C, inv_b, pred, loss_vec, gpred, ugrad, s, &handled); break;
+      default: break;
+    }
+    if (handled) return rc_;
+  }
+  if (C > kGenericMaxC || d > 64 * kGenericMaxDChunks)
+    return fail(RC_ERR_UNSUPPORTED,
+                "rc_bprmf_fwd_bwd: no kernel for C=%d d=%d (generic path: C<=%d, d<=%d)", C, d,
+                kGenericMaxC, 64 * kGenericMaxDChunks);
+  const int blocks = (B + (kBlock / 64) - 1) / (kBlock / 64);
+  const size_t shmem = (size_t)(kBlock / 64) * C * sizeof(float);
+  hipLaunchKernelGGL(bprmf_fwd_bwd_generic_kernel, dim3(blocks), dim3(kBlock), shmem, s, U, I,
+                     uid, iid, B, C, d, inv_b, pred, loss_vec, gpred, ugrad);
+  RC_LAUNCH_CHECK();
+  return RC_OK;
+}

@@ -1,0 +1,98 @@
+"""Build librechorus_hip.so (gfx950) in-tree with hipcc.
+
+Usage:  python -m rechorus_amd.csrc.build [--force] [--no-dpp] [--resource-usage]
+
+hipcc cross-compiles for gfx950 without a GPU.  Objects go to rechorus_amd/csrc/build/,
+the library to rechorus_amd/librechorus_hip.so (git-ignored, shipped to the GPU box by
+gpurun).  Only this target exists: no other --offload-arch, no CPU fall-back.
+"""
+import argparse
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.dirname(HERE)
+OBJ_DIR = os.path.join(HERE, "build")
+LIB_PATH = os.path.join(PKG, "librechorus_hip.so")
+ARCH = "gfx950"
+
+SOURCES = [
+    "library.hip",
+    "gather_dot.hip",
+    "bpr_loss.hip",
+    "bprmf_fused.hip",
+    "sort_ids.hip",
+    "seg_update.hip",
+    "train_step.hip",
+]
+HEADERS = ["common.hpp", "bpr_math.hpp", os.path.join("..", "..", "include", "rechorus_hip.h")]
+
+
+def _hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found (need ROCm with a gfx950 target)")
+    return exe
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return False
+    t = os.path.getmtime(target)
+    return all(os.path.getmtime(d) <= t for d in deps)
+
+
+def build(force=False, no_dpp=False, resource_usage=False, verbose=True):
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    hipcc = _hipcc()
+    flags = ["-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-Wall", "-Wno-unused-function"]
+    if no_dpp:
+        flags.append("-DRC_NO_DPP")
+    if resource_usage:
+        flags.append("-Rpass-analysis=kernel-resource-usage")
+    tag = os.path.join(OBJ_DIR, ".flags")
+    flag_str = " ".join(flags)
+    if not os.path.exists(tag) or open(tag).read() != flag_str:
+        force = True
+    hdrs = [os.path.join(HERE, h) for h in HEADERS]
+
+    def compile_one(src):
+        s = os.path.join(HERE, src)
+        o = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
+        if not force and _newer(o, [s] + hdrs):
+            return o, None
+        cmd = [hipcc] + flags + ["-c", s, "-o", o]
+        p = subprocess.run(cmd, capture_output=True, text=True)
+        if p.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {src}:\n{p.stderr[-8000:]}")
+        return o, p.stderr
+
+    with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
+        results = list(ex.map(compile_one, SOURCES))
+    objs = [o for o, _ in results]
+    if resource_usage:
+        for _, err in results:
+            if err:
+                sys.stderr.write(err)
+    if force or not _newer(LIB_PATH, objs):
+        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB_PATH] + objs
+        p = subprocess.run(cmd, capture_output=True, text=True)
+        if p.returncode != 0:
+            raise RuntimeError(f"link failed:\n{p.stderr[-8000:]}")
+    with open(tag, "w") as f:
+        f.write(flag_str)
+    if verbose:
+        print(f"built {LIB_PATH} ({os.path.getsize(LIB_PATH) >> 10} KiB)")
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--force", action="store_true")
+    ap.add_argument("--no-dpp", action="store_true", help="debug: DPP reductions via ds_bpermute")
+    ap.add_argument("--resource-usage", action="store_true")
+    a = ap.parse_args()
+    build(force=a.force, no_dpp=a.no_dpp, resource_usage=a.resource_usage)

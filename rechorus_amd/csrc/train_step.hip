@@ -1,0 +1,111 @@
+// train_step.hip -- one BaseRunner.fit iteration for BPRMF as a single C-ABI call
+// (reference: helpers/BaseRunner.py:193-206 around models/general/BPRMF.py:34-45 and
+// models/BaseModel.py:182-185).  All phases are enqueued on the caller's stream with no
+// host synchronisation (grid sizes depend only on B, C), so the call can be captured in a
+// hipGraph; with `phase_ms` it brackets the phases with hipEvents and synchronises.
+//
+//   phase 0  sort item ids (B*C)          phase 3  loss mean (deterministic)
+//   phase 1  sort user ids (B)            phase 4  item rows: segmented grad + update
+//   phase 2  fused gather/dot/loss/bwd    phase 5  user rows: segmented grad + update
+//
+// Ordering constraints: phase 4 reads U (pre-step values, to rebuild g*U[u]) so it runs
+// before phase 5 rewrites U; phase 2 reads both tables before either is updated.
+#include "common.hpp"
+
+using namespace rc;
+
+namespace {
+struct StepWs {
+  uint32_t* keys_i;
+  uint32_t* perm_i;
+  uint32_t* keys_u;
+  uint32_t* perm_u;
+  float* gpred;
+  float* ugrad;
+  float* loss_vec;
+  void* sort_ws;
+  size_t sort_ws_bytes;
+  void* seg_ws;
+  size_t seg_ws_bytes;
+  size_t total;
+};
+
+StepWs carve_step_ws(void* base, int B, int C, int d) {
+  const size_t n_i = (size_t)B * C;
+  Carver cv(base);
+  StepWs w;
+  w.keys_i = cv.take<uint32_t>(n_i);
+  w.perm_i = cv.take<uint32_t>(n_i);
+  w.keys_u = cv.take<uint32_t>((size_t)B);
+  w.perm_u = cv.take<uint32_t>((size_t)B);
+  w.gpred = cv.take<float>(n_i);
+  w.ugrad = cv.take<float>((size_t)B * d);
+  w.loss_vec = cv.take<float>((size_t)B);
+  w.sort_ws_bytes = rc_sort_workspace_bytes((int64_t)n_i);
+  w.sort_ws = cv.take<char>(w.sort_ws_bytes);
+  w.seg_ws_bytes = rc_segmented_workspace_bytes((int64_t)n_i);
+  w.seg_ws = cv.take<char>(w.seg_ws_bytes);
+  w.total = cv.off;
+  return w;
+}
+}  // namespace
+
+extern "C" size_t rc_bprmf_step_workspace_bytes(int B, int C, int d) {
+  if (B < 1 || C < 1 || d < 1) return 0;
+  return carve_step_ws(nullptr, B, C, d).total;
+}
+
+extern "C" int rc_bprmf_train_step(float* U, float* I, float* mU, float* vU, float* mI, float* vI,
+                                   const int64_t* uid, const int64_t* iid, int B, int C, int d,
+                                   int64_t n_users, int64_t n_items, const rc_opt_hyper* h,
+                                   float inv_b, float* loss_out, float* pred, void* ws,
+                                   size_t ws_bytes, rc_stream_t stream, float* phase_ms) {
+  RC_REQUIRE(U && I && uid && iid && h && loss_out && ws, "rc_bprmf_train_step: null pointer");
+  RC_REQUIRE(B >= 1 && C >= 2 && d >= 1, "rc_bprmf_train_step: bad shape B=%d C=%d d=%d", B, C, d);
+  RC_REQUIRE((int64_t)B * C < ((int64_t)1 << 31), "rc_bprmf_train_step: B*C too large");
+  RC_REQUIRE(U != I, "rc_bprmf_train_step: user and item tables must be distinct");
+  const StepWs w = carve_step_ws(ws, B, C, d);
+  if (ws_bytes < w.total)
+    return fail(RC_ERR_WORKSPACE, "rc_bprmf_train_step: workspace %zu < %zu", ws_bytes, w.total);
+  hipStream_t s = as_stream(stream);
+  const int64_t n_i = (int64_t)B * C;
+
+  constexpr int kPhases = 6;
+  hipEvent_t ev[kPhases + 1];
+  const bool prof = phase_ms != nullptr;
+  if (prof)
+    for (int i = 0; i <= kPhases; ++i) RC_HIP(hipEventCreate(&ev[i]));
+#define RC_MARK(i)                                \
+  do {                                            \
+    if (prof) RC_HIP(hipEventRecord(ev[i], s));   \
+  } while (0)
+
+  RC_MARK(0);
+  RC_TRY(rc_sort_ids(iid, n_i, n_items, w.keys_i, w.perm_i, w.sort_ws, w.sort_ws_bytes, stream));
+  RC_MARK(1);
+  RC_TRY(rc_sort_ids(uid, B, n_users, w.keys_u, w.perm_u, w.sort_ws, w.sort_ws_bytes, stream));
+  RC_MARK(2);
+  RC_TRY(rc_bprmf_fwd_bwd(U, I, uid, iid, B, C, d, inv_b, pred, w.loss_vec, w.gpred, w.ugrad,
+                          stream));
+  RC_MARK(3);
+  RC_TRY(rc_reduce_sum(w.loss_vec, B, inv_b, loss_out, stream));
+  RC_MARK(4);
+  // item rows: grad_r = sum_{(b,c): iid[b,c]=r} g[b,c] * U[uid[b]]
+  RC_TRY(rc_segmented_update(I, mI, vI, d, w.keys_i, w.perm_i, n_i, w.gpred, U, uid, C, h,
+                             nullptr, w.seg_ws, w.seg_ws_bytes, stream));
+  RC_MARK(5);
+  // user rows: grad_r = sum_{b: uid[b]=r} ugrad[b]
+  RC_TRY(rc_segmented_update(U, mU, vU, d, w.keys_u, w.perm_u, B, nullptr, w.ugrad, nullptr, 1, h,
+                             nullptr, w.seg_ws, w.seg_ws_bytes, stream));
+  RC_MARK(6);
+#undef RC_MARK
+
+  if (prof) {
+    RC_HIP(hipEventSynchronize(ev[kPhases]));
+    for (int i = 0; i < kPhases; ++i) RC_HIP(hipEventElapsedTime(&phase_ms[i], ev[i], ev[i + 1]));
+    RC_HIP(hipEventElapsedTime(&phase_ms[6], ev[0], ev[kPhases]));
+    phase_ms[7] = 0.f;
+    for (int i = 0; i <= kPhases; ++i) RC_HIP(hipEventDestroy(ev[i]));
+  }
+  return RC_OK;
+}

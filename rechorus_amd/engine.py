@@ -1,0 +1,241 @@
+"""Tensor-level access to the HIP engine: torch tensors are only typed device buffers
+(`data_ptr()`), every FLOP happens in librechorus_hip.so on torch's current HIP stream.
+
+Nothing here falls back to torch arithmetic: a missing library, a CPU tensor or an
+unsupported shape raises.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import OptHyper, OPT_BY_NAME
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t, dtype, name, allow_none=False):
+    if t is None:
+        if allow_none:
+            return C.c_void_p(0)
+        raise ValueError(f"{name} is required")
+    if not t.is_cuda:
+        raise ValueError(f"{name} must live on the GPU (got {t.device}); the HIP engine has no CPU path")
+    if t.dtype != dtype:
+        raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+    return C.c_void_p(t.data_ptr())
+
+
+def make_hyper(opt="SGD", lr=1e-3, l2=0.0, beta1=0.9, beta2=0.999, eps=None, step=1):
+    """rc_opt_hyper with torch.optim's defaults (Adam eps 1e-8, Adagrad eps 1e-10)."""
+    if opt not in OPT_BY_NAME:
+        raise ValueError(f"optimizer {opt!r} not supported by the HIP engine (SGD, Adam, Adagrad)")
+    if eps is None:
+        eps = 1e-10 if opt == "Adagrad" else 1e-8
+    return OptHyper(OPT_BY_NAME[opt], 0, float(lr), float(l2), float(beta1), float(beta2),
+                    float(eps), int(step))
+
+
+_ws_cache = {}
+
+
+def workspace(nbytes, device, tag="default"):
+    """Cached uint8 scratch buffer (grow-only) per (device, tag)."""
+    key = (str(device), tag)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+# ---- forward ---------------------------------------------------------------------------
+
+def gather_rows(W, ids):
+    """nn.Embedding forward: W[ids] (reference: models/general/BPRMF.py:39-40)."""
+    ids_flat = ids.reshape(-1)
+    d = W.shape[1]
+    out = torch.empty((ids_flat.numel(), d), dtype=torch.float32, device=W.device)
+    _lib.call("rc_gather_rows", _ptr(W, torch.float32, "W"), d, _ptr(ids_flat, torch.int64, "ids"),
+              ids_flat.numel(), _ptr(out, torch.float32, "out"), _stream())
+    return out.view(*ids.shape, d)
+
+
+def gather_dot(U, I, uid, iid):
+    """pred[b,c] = <U[uid[b]], I[iid[b,c]]> (reference: models/general/BPRMF.py:39-42)."""
+    B, Cn = iid.shape
+    d = U.shape[1]
+    if I.shape[1] != d:
+        raise ValueError("user and item tables need the same emb_size")
+    pred = torch.empty((B, Cn), dtype=torch.float32, device=U.device)
+    _lib.call("rc_gather_dot_fwd", _ptr(U, torch.float32, "U"), _ptr(I, torch.float32, "I"),
+              _ptr(uid, torch.int64, "uid"), _ptr(iid, torch.int64, "iid"), B, Cn, d,
+              _ptr(pred, torch.float32, "pred"), _stream())
+    return pred
+
+
+# ---- loss ------------------------------------------------------------------------------
+
+def reduce_sum(x, scale=1.0):
+    out = torch.empty(1, dtype=torch.float32, device=x.device)
+    _lib.call("rc_reduce_sum", _ptr(x, torch.float32, "x"), x.numel(), float(scale),
+              _ptr(out, torch.float32, "out"), _stream())
+    return out
+
+
+def bpr_loss(pred, inv_b=None, need_grad=True):
+    """GeneralModel.loss (models/BaseModel.py:182-185) -> (loss[1], loss_vec[B], gpred|None)."""
+    B, Cn = pred.shape
+    if inv_b is None:
+        inv_b = 1.0 / B
+    loss_vec = torch.empty(B, dtype=torch.float32, device=pred.device)
+    gpred = torch.empty_like(pred) if need_grad else None
+    _lib.call("rc_bpr_loss_fwd_bwd", _ptr(pred, torch.float32, "pred"), B, Cn, float(inv_b),
+              _ptr(loss_vec, torch.float32, "loss_vec"),
+              _ptr(gpred, torch.float32, "gpred", allow_none=True), _stream())
+    return reduce_sum(loss_vec, inv_b), loss_vec, gpred
+
+
+def bprmf_fwd_bwd(U, I, uid, iid, inv_b=None, want_pred=True):
+    """Fused gather + dot + BPR loss + backward to rows.
+    Returns (pred|None, loss_vec[B], gpred[B,C], ugrad[B,d])."""
+    B, Cn = iid.shape
+    d = U.shape[1]
+    if inv_b is None:
+        inv_b = 1.0 / B
+    dev = U.device
+    pred = torch.empty((B, Cn), dtype=torch.float32, device=dev) if want_pred else None
+    loss_vec = torch.empty(B, dtype=torch.float32, device=dev)
+    gpred = torch.empty((B, Cn), dtype=torch.float32, device=dev)
+    ugrad = torch.empty((B, d), dtype=torch.float32, device=dev)
+    _lib.call("rc_bprmf_fwd_bwd", _ptr(U, torch.float32, "U"), _ptr(I, torch.float32, "I"),
+              _ptr(uid, torch.int64, "uid"), _ptr(iid, torch.int64, "iid"), B, Cn, d, float(inv_b),
+              _ptr(pred, torch.float32, "pred", allow_none=True),
+              _ptr(loss_vec, torch.float32, "loss_vec"), _ptr(gpred, torch.float32, "gpred"),
+              _ptr(ugrad, torch.float32, "ugrad"), _stream())
+    return pred, loss_vec, gpred, ugrad
+
+
+# ---- sort + segmented update --------------------------------------------------------------
+
+def sort_ids(ids, n_rows):
+    """Stable sort of a flat id list -> (keys uint32-as-int32 tensor, perm)."""
+    ids_flat = ids.reshape(-1)
+    n = ids_flat.numel()
+    dev = ids.device
+    keys = torch.empty(n, dtype=torch.int32, device=dev)  # bit pattern is uint32
+    perm = torch.empty(n, dtype=torch.int32, device=dev)
+    nbytes = _lib.load().rc_sort_workspace_bytes(n)
+    ws = workspace(nbytes, dev, "sort")
+    _lib.call("rc_sort_ids", _ptr(ids_flat, torch.int64, "ids"), n, int(n_rows),
+              _ptr(keys, torch.int32, "keys"), _ptr(perm, torch.int32, "perm"),
+              C.c_void_p(ws.data_ptr()), ws.numel(), _stream())
+    return keys, perm
+
+
+def segmented_update(keys, perm, src, hyper=None, W=None, m=None, v=None, coef=None,
+                     src_index=None, div=1, dense_grad=None):
+    """rc_segmented_update: per distinct row r, grad_r = sum coef[o]*src[srow(o)], then either
+    write dense_grad[r] or apply the optimizer to W[r] (and m, v) in place."""
+    n_occ = keys.numel()
+    d = src.shape[-1]
+    dev = keys.device
+    lib = _lib.load()
+    ws = workspace(lib.rc_segmented_workspace_bytes(n_occ), dev, "seg")
+    hp = C.byref(hyper) if hyper is not None else None
+    _lib.call("rc_segmented_update",
+              _ptr(W, torch.float32, "W", allow_none=True),
+              _ptr(m, torch.float32, "m", allow_none=True),
+              _ptr(v, torch.float32, "v", allow_none=True), d,
+              _ptr(keys, torch.int32, "keys"), _ptr(perm, torch.int32, "perm"), n_occ,
+              _ptr(coef, torch.float32, "coef", allow_none=True), _ptr(src, torch.float32, "src"),
+              _ptr(src_index, torch.int64, "src_index", allow_none=True), int(div), hp,
+              _ptr(dense_grad, torch.float32, "dense_grad", allow_none=True),
+              C.c_void_p(ws.data_ptr()), ws.numel(), _stream())
+
+
+def embedding_dense_backward(grad_out, ids, n_rows):
+    """Dense [n_rows,d] gradient of W[ids] (aten::embedding_dense_backward semantics),
+    computed by sort + segmented sum instead of atomics / index_add."""
+    d = grad_out.shape[-1]
+    g2 = grad_out.reshape(-1, d)
+    if not g2.is_contiguous():
+        g2 = g2.contiguous()
+    keys, perm = sort_ids(ids, n_rows)
+    dense = torch.zeros((n_rows, d), dtype=torch.float32, device=grad_out.device)
+    segmented_update(keys, perm, g2, dense_grad=dense)
+    return dense
+
+
+def dense_update(W, G, hyper, m=None, v=None):
+    """Exact torch.optim step over a whole tensor (helpers/BaseRunner.py:206)."""
+    _lib.call("rc_dense_update", _ptr(W, torch.float32, "W"), _ptr(G, torch.float32, "G"),
+              _ptr(m, torch.float32, "m", allow_none=True),
+              _ptr(v, torch.float32, "v", allow_none=True), W.numel(), C.byref(hyper), _stream())
+
+
+# ---- whole BPRMF step -----------------------------------------------------------------------
+
+class BprmfTrainer:
+    """Row-wise-optimizer BPRMF training on device tables U [n_users,d], I [n_items,d].
+
+    One `step(uid, iid)` = one iteration of BaseRunner.fit's batch loop
+    (helpers/BaseRunner.py:193-206) for models/general/BPRMF.py, as one C-ABI call.
+    """
+
+    def __init__(self, U, I, opt="SGD", lr=1e-3, l2=0.0, beta1=0.9, beta2=0.999, eps=None):
+        if U.shape[1] != I.shape[1]:
+            raise ValueError("user and item tables need the same emb_size")
+        self.U, self.I = U, I
+        self.d = U.shape[1]
+        self.opt = opt
+        self.hyper = make_hyper(opt, lr, l2, beta1, beta2, eps, step=0)
+        self.mU = self.vU = self.mI = self.vI = None
+        if opt in ("Adam", "Adagrad"):
+            self.mU, self.mI = torch.zeros_like(U), torch.zeros_like(I)
+        if opt == "Adam":
+            self.vU, self.vI = torch.zeros_like(U), torch.zeros_like(I)
+        self.loss = torch.zeros(1, dtype=torch.float32, device=U.device)
+        self._ws = None
+        self._ws_shape = None
+
+    def _workspace(self, B, Cn):
+        if self._ws_shape != (B, Cn):
+            nbytes = _lib.load().rc_bprmf_step_workspace_bytes(B, Cn, self.d)
+            if nbytes == 0:
+                raise _lib.RechorusHipError("rc_bprmf_step_workspace_bytes", -1, "bad shape")
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.U.device)
+            self._ws_shape = (B, Cn)
+        return self._ws
+
+    def step(self, uid, iid, inv_b=None, pred=None, phase_ms=None):
+        """Runs one training step; returns the device loss tensor (shape [1], no sync).
+        phase_ms: optional ctypes float[8] to receive per-phase hipEvent timings."""
+        B, Cn = iid.shape
+        if inv_b is None:
+            inv_b = 1.0 / B
+        ws = self._workspace(B, Cn)
+        self.hyper.step += 1
+        f32 = torch.float32
+        _lib.call("rc_bprmf_train_step",
+                  _ptr(self.U, f32, "U"), _ptr(self.I, f32, "I"),
+                  _ptr(self.mU, f32, "mU", True), _ptr(self.vU, f32, "vU", True),
+                  _ptr(self.mI, f32, "mI", True), _ptr(self.vI, f32, "vI", True),
+                  _ptr(uid, torch.int64, "uid"), _ptr(iid, torch.int64, "iid"), B, Cn, self.d,
+                  self.U.shape[0], self.I.shape[0], C.byref(self.hyper), float(inv_b),
+                  _ptr(self.loss, f32, "loss"), _ptr(pred, f32, "pred", True),
+                  C.c_void_p(ws.data_ptr()), ws.numel(), _stream(),
+                  phase_ms if phase_ms is not None else None)
+        return self.loss
+
+    def profile_step(self, uid, iid):
+        """One step with hipEvent phase timing -> dict of milliseconds (synchronises)."""
+        buf = (C.c_float * 8)()
+        self.step(uid, iid, phase_ms=buf)
+        names = ["sort_items", "sort_users", "fused_fwd_bwd", "loss_mean", "item_update",
+                 "user_update", "total"]
+        return {n: float(buf[i]) for i, n in enumerate(names)}

@@ -1,0 +1,69 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` via gpurun)")
+
+
+def golden_cases():
+    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz"))
+
+
+def load_golden(name):
+    with np.load(os.path.join(GOLDEN_DIR, name + ".npz")) as z:
+        return {k: z[k] for k in z.files}
+
+
+def assert_close(got, want, rtol=1e-5, atol_scale=1e-5, what=""):
+    """|got-want| <= rtol*|want| + atol_scale*max|want|  (north_star: 1e-5 relative fp32;
+    the absolute term covers near-cancelling dot products whose magnitude is far below the
+    tensor's scale)."""
+    got = np.asarray(got, dtype=np.float64)
+    want = np.asarray(want, dtype=np.float64)
+    assert got.shape == want.shape, f"{what}: shape {got.shape} != {want.shape}"
+    scale = float(np.max(np.abs(want))) if want.size else 0.0
+    err = np.abs(got - want)
+    tol = rtol * np.abs(want) + atol_scale * scale
+    bad = err > tol
+    if bad.any():
+        i = np.unravel_index(np.argmax(err - tol), err.shape)
+        raise AssertionError(
+            f"{what}: {int(bad.sum())}/{bad.size} elements off; worst at {i}: got {got[i]!r} "
+            f"want {want[i]!r} err {err[i]:.3e} tol {tol[i]:.3e} (scale {scale:.3e})")
+
+
+def assert_update_close(W, W0, Wref, what="", rtol=1e-4, extra_atol=0.0):
+    """Compare the optimizer UPDATE (W - W0 vs Wref - W0), not just the weights: weights are
+    ~1e-2 and a wrong 1e-4-sized step would hide inside a weight-relative tolerance.  The
+    subtraction itself is only exact to a few ulp of the weights, which the floor covers.
+    extra_atol: Adam's / Adagrad's step lr*g/(sqrt(v)+eps) is ill-conditioned where |g| ~ eps (a
+    1e-7-relative change of a 2e-8 gradient, i.e. a different fp32 summation order, moves the
+    step by 1e-4 relative), so those callers pass 1e-3*lr: 0.1 % of the largest possible step."""
+    W, W0, Wref = (np.asarray(a, dtype=np.float64) for a in (W, W0, Wref))
+    got, want = W - W0, Wref - W0
+    floor = 8 * np.finfo(np.float32).eps * float(np.max(np.abs(Wref)))
+    err = np.abs(got - want)
+    tol = rtol * np.abs(want) + 1e-5 * float(np.max(np.abs(want))) + floor + extra_atol
+    bad = err > tol
+    if bad.any():
+        i = np.unravel_index(np.argmax(err - tol), err.shape)
+        raise AssertionError(f"{what}: {int(bad.sum())}/{bad.size} update elements off; worst at {i}: "
+                             f"got {got[i]!r} want {want[i]!r} err {err[i]:.3e} tol {tol[i]:.3e}")
+
+
+@pytest.fixture(scope="session")
+def cuda():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")

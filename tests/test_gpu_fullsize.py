@@ -1,0 +1,145 @@
+"""GPU, BASELINE.json configs[1] sizes (BPRMF d=64, K=99, 10M-item catalogue): the oracle
+cannot finish these in seconds, so parity is checked through size-independent properties of
+the training step (consistency between independent kernels, conservation of the SGD update,
+untouched rows, permutation invariance, sortedness, bit-reproducibility) plus an oracle
+comparison on a random SAMPLE of tuples and rows."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_close, assert_update_close
+from oracle import bprmf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+N_ITEMS, N_USERS, D, B, K = 10_000_001, 1_000_001, 64, 8192, 99
+LR = 0.05
+
+
+@pytest.fixture(scope="module")
+def world(cuda):
+    from rechorus_amd import engine
+    g = torch.Generator(device=cuda)
+    g.manual_seed(0)
+    U = torch.empty((N_USERS, D), device=cuda).normal_(0, 0.01, generator=g)
+    I = torch.empty((N_ITEMS, D), device=cuda).normal_(0, 0.01, generator=g)
+    rng = np.random.default_rng(0)
+    # Zipf(1.0) users / positives over seeded rank->id permutations, uniform negatives
+    # (models/BaseModel.py:207), as BASELINE.md section 3 prescribes
+    def zipf(n_rows, size):
+        ranks = np.exp(rng.uniform(0, np.log(n_rows - 1), size=size)).astype(np.int64)  # ~1/r
+        return (ranks * 2654435761 % (n_rows - 1)) + 1
+    uid = torch.from_numpy(zipf(N_USERS, B)).to(cuda)
+    pos = zipf(N_ITEMS, B)
+    neg = rng.integers(1, N_ITEMS, size=(B, K))
+    iid = torch.from_numpy(np.concatenate([pos[:, None], neg], axis=1)).to(cuda)
+    return dict(eng=engine, U=U, I=I, uid=uid, iid=iid)
+
+
+def test_fused_agrees_with_unfused_kernels(world):
+    e = world["eng"]
+    U, I, uid, iid = (world[k] for k in ("U", "I", "uid", "iid"))
+    pred, loss_vec, gpred, ugrad = e.bprmf_fwd_bwd(U, I, uid, iid)
+    pred2 = e.gather_dot(U, I, uid, iid)
+    assert_close(pred.cpu().numpy(), pred2.cpu().numpy(), rtol=1e-6, atol_scale=1e-6, what="pred")
+    loss2, lv2, gp2 = e.bpr_loss(pred2)
+    assert_close(loss_vec.cpu().numpy(), lv2.cpu().numpy(), what="loss_vec")
+    assert_close(gpred.cpu().numpy(), gp2.cpu().numpy(), what="gpred")
+    # oracle on a sample of tuples
+    idx = np.random.default_rng(1).choice(B, size=64, replace=False)
+    u_s, i_s = uid[idx].cpu().numpy(), iid[idx].cpu().numpy()
+    rows_u, inv_u = np.unique(u_s, return_inverse=True)
+    rows_i, inv_i = np.unique(i_s, return_inverse=True)
+    Us, Is = U[rows_u].cpu().numpy(), I[rows_i].cpu().numpy()
+    want = O.gather_dot(Us, Is, inv_u, inv_i.reshape(i_s.shape))
+    assert_close(pred[idx].cpu().numpy(), want, what="pred(sample)")
+    assert_close(gpred[idx].cpu().numpy(), O.bpr_loss_grad(want, inv_b=1.0 / B), what="gpred(sample)")
+    gu, _ = O.bprmf_row_grads(Us, Is, inv_u, inv_i.reshape(i_s.shape), O.bpr_loss_grad(want, inv_b=1.0 / B))
+    assert_close(ugrad[idx].cpu().numpy(), gu, what="ugrad(sample)")
+
+
+def test_sorted_keys_and_permutation(world):
+    e = world["eng"]
+    iid = world["iid"]
+    keys, perm = e.sort_ids(iid, N_ITEMS)
+    k = keys.to(torch.int64) & 0xFFFFFFFF
+    p = perm.to(torch.int64) & 0xFFFFFFFF
+    assert bool((k[1:] >= k[:-1]).all()), "keys not sorted"
+    assert torch.equal(iid.reshape(-1)[p], k), "perm does not map ids to sorted keys"
+    same = k[1:] == k[:-1]
+    assert bool((p[1:][same] > p[:-1][same]).all()), "sort is not stable"
+    assert torch.equal(torch.sort(p).values, torch.arange(p.numel(), device=p.device))
+
+
+def test_sgd_step_conservation_untouched_rows_and_reproducibility(world):
+    e = world["eng"]
+    U0, I0, uid, iid = (world[k] for k in ("U", "I", "uid", "iid"))
+    _, _, gpred, ugrad = e.bprmf_fwd_bwd(U0, I0, uid, iid, want_pred=False)
+    results = []
+    for _ in range(2):
+        U, I = U0.clone(), I0.clone()
+        tr = e.BprmfTrainer(U, I, opt="SGD", lr=LR, l2=0.0)
+        loss = tr.step(uid, iid)
+        results.append((U, I, loss.clone()))
+    U, I, loss = results[0]
+    assert torch.equal(U, results[1][0]) and torch.equal(I, results[1][1]), "not bit-reproducible"
+    assert torch.equal(loss, results[1][2])
+    # conservation: sum over rows of the update == -lr * sum over occurrences of the row grads
+    dI = (I.double() - I0.double()).sum(0)
+    want_dI = -LR * (gpred.double().sum(1)[:, None] * U0[uid].double()).sum(0)
+    assert_close(dI.cpu().numpy(), want_dI.cpu().numpy(), rtol=1e-4, atol_scale=1e-4, what="sum dI")
+    dU = (U.double() - U0.double()).sum(0)
+    want_dU = -LR * ugrad.double().sum(0)
+    assert_close(dU.cpu().numpy(), want_dU.cpu().numpy(), rtol=1e-4, atol_scale=1e-4, what="sum dU")
+    # rows outside the batch are bit-identical
+    touched = torch.zeros(N_ITEMS, dtype=torch.bool, device=I.device)
+    touched[iid.reshape(-1)] = True
+    assert torch.equal(I[~touched], I0[~touched])
+    assert int((I[touched] != I0[touched]).any(dim=1).sum()) > 0.99 * int(touched.sum())
+    # oracle on a sample of touched item rows: rebuild their gradient from (gpred, U0, uid)
+    rows = torch.unique(iid.reshape(-1))[:: max(1, int(touched.sum()) // 200)][:200]
+    flat = iid.reshape(-1)
+    for r in rows[:50].tolist():
+        occ = torch.nonzero(flat == r).reshape(-1)
+        g = (gpred.reshape(-1)[occ][:, None] * U0[uid[occ // (K + 1)]]).sum(0)
+        want = I0[r] - LR * g
+        assert_update_close(I[r].cpu().numpy(), I0[r].cpu().numpy(), want.cpu().numpy(), what=f"item row {r}")
+
+
+def test_negative_permutation_invariance(world):
+    """permuting the K negatives inside each tuple changes nothing but fp summation order"""
+    e = world["eng"]
+    U0, I0, uid, iid = (world[k] for k in ("U", "I", "uid", "iid"))
+    g = torch.Generator(device=iid.device)
+    g.manual_seed(3)
+    order = torch.argsort(torch.rand((B, K), device=iid.device, generator=g), dim=1) + 1
+    iid_p = torch.cat([iid[:, :1], torch.gather(iid, 1, order)], dim=1).contiguous()
+    outs = []
+    for ids in (iid, iid_p):
+        U, I = U0.clone(), I0.clone()
+        loss = e.BprmfTrainer(U, I, opt="SGD", lr=LR).step(uid, ids).clone()
+        outs.append((U, I, loss))
+    assert_close(outs[1][2].cpu().numpy(), outs[0][2].cpu().numpy(), rtol=1e-6, what="loss")
+    for a, b, a0, nm in ((outs[0][0], outs[1][0], U0, "U"), (outs[0][1], outs[1][1], I0, "I")):
+        d0, d1 = (a - a0), (b - a0)
+        err = (d0 - d1).abs().max().item()
+        assert err <= 1e-5 * d0.abs().max().item() + 1e-9, f"{nm}: update changed by {err}"
+
+
+def test_adam_rowwise_step_sample_vs_oracle(world):
+    e = world["eng"]
+    U0, I0, uid, iid = (world[k] for k in ("U", "I", "uid", "iid"))
+    U, I = U0.clone(), I0.clone()
+    tr = e.BprmfTrainer(U, I, opt="Adam", lr=1e-3, l2=1e-6)
+    tr.step(uid, iid)
+    _, _, gpred, ugrad = e.bprmf_fwd_bwd(U0, I0, uid, iid, want_pred=False)
+    flat = iid.reshape(-1)
+    for r in torch.unique(flat)[::40000][:20].tolist():
+        occ = torch.nonzero(flat == r).reshape(-1)
+        g = (gpred.reshape(-1)[occ][:, None] * U0[uid[occ // (K + 1)]]).sum(0).cpu().numpy()
+        W = I0[r].cpu().numpy()[None].copy()
+        st = {"m": np.zeros_like(W), "v": np.zeros_like(W)}
+        O.opt_step_dense(W, g[None], st, "Adam", 1e-3, 1e-6, step=1)
+        assert_update_close(I[r].cpu().numpy()[None], I0[r].cpu().numpy()[None], W, what=f"row {r}",
+                            extra_atol=1e-6)
+        assert_close(tr.mI[r].cpu().numpy()[None], st["m"], what="exp_avg", atol_scale=1e-4)
