@@ -170,7 +170,8 @@ def test_fused_shapes_vs_oracle(d, B, C, cuda, eng):
     ragged tails"""
     rng = np.random.default_rng(1000 * d + 10 * B + C)
     U, I, uid, iid = _random_problem(rng, 11, 50, d, B, C)
-    U *= 30  # scores O(1): exercises the softmax / sigmoid far from the linear regime
+    U *= 30
+    I *= 30  # scores O(1): exercises the softmax / sigmoid far from the linear regime
     pred, loss_vec, gpred, ugrad = eng.bprmf_fwd_bwd(*(dev(a, cuda) for a in (U, I, uid, iid)))
     want_pred = O.gather_dot(U, I, uid, iid)
     assert_close(host(pred), want_pred, what="pred")
