@@ -73,19 +73,29 @@ def algorithmic_bytes(args, batches):
     phase must move at least once, table rows counted once per distinct row per step."""
     B, C, d = args.batch, args.num_neg + 1, args.emb_size
     n_occ = B * C
-    ui = float(np.mean([torch.unique(i).numel() for _, i in batches]))
+    ui = us = um = mo = 0.0
+    for _, i in batches:
+        cnt = torch.unique(i, return_counts=True)[1]
+        ui += cnt.numel() / len(batches)                      # distinct item rows
+        us += int((cnt == 1).sum()) / len(batches)            # ... occurring once
+        um += int((cnt > 1).sum()) / len(batches)             # ... occurring several times
+        mo += int(cnt[cnt > 1].sum()) / len(batches)          # occurrences of the latter
     uu = float(np.mean([torch.unique(u).numel() for u, _ in batches]))
     row = 4 * d
-    fused = (8 * B + 8 * n_occ          # uid, iid
+    fused = (8 * B + 8 * n_occ + n_occ  # uid, iid, singleton flags
              + uu * row + ui * row      # distinct user / item rows, read once
+             + us * row                 # single-occurrence item rows written back updated
              + 4 * n_occ + B * row + 4 * B)   # gpred, ugrad, loss_vec written
-    item_update = (12 * n_occ + 8 * B   # keys, perm, gpred per occurrence; uid
+    item_update = (8 * n_occ            # keys + perm of every sorted position
+                   + 12 * mo + 8 * B    # gpred + uid lookups of multi-occurrence rows
                    + uu * row           # U rows rebuilt into g*U: distinct rows once
-                   + 2 * ui * row)      # item row read + written once per distinct row
+                   + 2 * um * row)      # multi-occurrence item rows: read + written once
     user_update = 8 * B + B * row + 2 * uu * row
     sort_items = 8 * n_occ + 8 * n_occ  # ids in, keys+perm out (one ideal pass)
+    mark = 8 * n_occ + n_occ            # keys + perm in, one flag byte out
     return {"fused_fwd_bwd": fused, "item_update": item_update, "user_update": user_update,
-            "sort_items": sort_items, "uniq_items": ui, "uniq_users": uu}
+            "sort_items": sort_items, "mark_singletons": mark, "uniq_items": ui, "uniq_users": uu,
+            "single_items": us, "multi_items": um, "multi_item_occurrences": mo}
 
 
 def load_pmc_traffic(kernel):
@@ -231,8 +241,11 @@ def main():
         }
         out["phases_ms"] = {k: round(v, 4) for k, v in acc.items()}
         out["phases_gbps"] = {k: round(ab[k] / (acc[k] * 1e-3) / 1e9, 1)
-                              for k in ("fused_fwd_bwd", "item_update", "user_update", "sort_items")}
-        out["uniq_rows_per_step"] = {"items": ab["uniq_items"], "users": ab["uniq_users"]}
+                              for k in ("fused_fwd_bwd", "item_update", "user_update", "sort_items",
+                                        "mark_singletons") if acc.get(k, 0) > 0}
+        out["uniq_rows_per_step"] = {"items": ab["uniq_items"], "users": ab["uniq_users"],
+                                     "items_single": ab["single_items"], "items_multi": ab["multi_items"],
+                                     "multi_item_occurrences": ab["multi_item_occurrences"]}
         # compulsory bytes of the whole fused fwd+bwd+SGD step, rows once per
         # distinct row: read + write each touched row, ids, pred
         whole = 2 * (ab["uniq_items"] + ab["uniq_users"]) * 4 * args.emb_size + \

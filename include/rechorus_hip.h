@@ -103,6 +103,22 @@ int rc_bprmf_fwd_bwd(const float* U, const float* I, const int64_t* uid,
                      const int64_t* iid, int B, int C, int d, float inv_b, float* pred,
                      float* loss_vec, float* gpred, float* ugrad, rc_stream_t stream);
 
+/* 1 if (d, C) has a register-resident fused kernel (d in {16,32,64,128}, C <= 32*256/d),
+ * i.e. rc_bprmf_fwd_bwd_update is available; rc_bprmf_fwd_bwd always has the LDS fall-back. */
+int rc_bprmf_fused_supported(int d, int C);
+
+/* rc_bprmf_fwd_bwd that ALSO applies the optimizer `h` to every item row occurring exactly
+ * once in the batch (single[b*C+c] != 0, from rc_mark_singletons): such a row is read by no
+ * other tuple, its whole gradient g[b,c]*U[uid[b]] is known while the row is still in
+ * registers, so it is updated and written back here -- one HBM read and one write per step.
+ * Rows with several occurrences are left for rc_segmented_update(RC_SEG_SKIP_SINGLETONS).
+ * I (and mI, vI) are updated in place; the arithmetic is the one of rc_segmented_update.   */
+int rc_bprmf_fwd_bwd_update(const float* U, float* I, float* mI, float* vI,
+                            const int64_t* uid, const int64_t* iid, const uint8_t* single,
+                            int B, int C, int d, float inv_b, const rc_opt_hyper* h,
+                            float* pred, float* loss_vec, float* gpred, float* ugrad,
+                            rc_stream_t stream);
+
 /* ---- index sort (the atomic-free replacement of embedding_dense_backward's index_add) */
 
 size_t rc_sort_workspace_bytes(int64_t n);
@@ -112,6 +128,11 @@ size_t rc_sort_workspace_bytes(int64_t n);
  * (only ceil(log2 n_rows) key bits are sorted).  n < 2^31, n_rows <= 2^32.            */
 int rc_sort_ids(const int64_t* ids, int64_t n, int64_t n_rows, uint32_t* keys_out,
                 uint32_t* perm_out, void* ws, size_t ws_bytes, rc_stream_t stream);
+
+/* single[o] = 1 iff occurrence o = perm[j] is the only one of its row (keys/perm from
+ * rc_sort_ids), else 0.                                                                  */
+int rc_mark_singletons(const uint32_t* keys, const uint32_t* perm, int64_t n_occ,
+                       uint8_t* single, rc_stream_t stream);
 
 /* ---- segmented gradient reduction + optimizer row update -------------------------- */
 
@@ -126,11 +147,14 @@ size_t rc_segmented_workspace_bytes(int64_t n_occ);
  * the optimizer `h` to row r of W in place (and to rows r of the state tables m, v:
  * Adam exp_avg / exp_avg_sq, Adagrad sum in `m`), i.e. a row-wise ("lazy") version of
  * helpers/BaseRunner.py:206 that only touches rows present in the batch.
+ * flags: RC_SEG_SKIP_SINGLETONS leaves rows with exactly one occurrence untouched (they
+ * were updated by rc_bprmf_fwd_bwd_update).
  * Src must not alias W.  ws from rc_segmented_workspace_bytes(n_occ).                 */
+enum rc_seg_flags { RC_SEG_SKIP_SINGLETONS = 1 };
 int rc_segmented_update(float* W, float* m, float* v, int d, const uint32_t* keys,
                         const uint32_t* perm, int64_t n_occ, const float* coef,
                         const float* src, const int64_t* src_index, int div,
-                        const rc_opt_hyper* h, float* dense_grad, void* ws,
+                        const rc_opt_hyper* h, float* dense_grad, int flags, void* ws,
                         size_t ws_bytes, rc_stream_t stream);
 
 /* Exact dense optimizer step over all n elements (torch.optim semantics incl. weight
@@ -144,13 +168,14 @@ size_t rc_bprmf_step_workspace_bytes(int B, int C, int d);
 
 /* One BaseRunner.fit iteration for BPRMF (helpers/BaseRunner.py:193-206 with
  * models/general/BPRMF.py:34-45 and models/BaseModel.py:182-185), row-wise optimizer:
- * sort ids -> fused fwd/loss/bwd -> item-row update -> user-row update.
+ * sort ids -> mark single-occurrence item rows -> fused fwd/loss/bwd (+ update of those
+ * rows) -> segmented update of the remaining item rows -> segmented update of user rows.
  * loss_out[0] = mean_b loss (device float).  pred may be NULL.
  * state tables (mU,vU,mI,vI) may be NULL for SGD.
  * phase_ms: NULL, or a HOST float[8] filled with per-phase milliseconds measured with
  * hipEvents on `stream` (the call then synchronises):
  *   [0] sort item ids [1] sort user ids [2] fused fwd/bwd [3] loss mean
- *   [4] item-row update [5] user-row update [6] total [7] reserved                    */
+ *   [4] item-row update [5] user-row update [6] total [7] mark singletons              */
 int rc_bprmf_train_step(float* U, float* I, float* mU, float* vU, float* mI, float* vI,
                         const int64_t* uid, const int64_t* iid, int B, int C, int d,
                         int64_t n_users, int64_t n_items, const rc_opt_hyper* h,

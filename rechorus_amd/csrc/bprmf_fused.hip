@@ -15,17 +15,33 @@
 // known) re-reads nothing from HBM, LDS is not needed at all, and the only cross-lane
 // traffic is DPP row reductions + a few ds_bpermute across the GS groups.
 // Small C packs several tuples per wave (C=2: two 32-lane tuples).
+//
+// Singleton rows (MODE != MODE_NONE).  An item row that occurs exactly once in the batch is
+// read by nobody else in this step, and its complete gradient g_c * U[u] is known right
+// here, where the row itself is still in registers: the kernel applies the optimizer and
+// writes the new row, so the row crosses HBM once in each direction per step (the
+// compulsory traffic).  `single[o]` comes from rc_mark_singletons on the sorted ids; rows
+// with several occurrences are left to the segmented update (seg_update.hip).
 #include "bpr_math.hpp"
 #include "common.hpp"
+#include "opt_math.hpp"
 
 namespace rc {
 
-template <int D, int GS, int CPL>
+struct FusedUpd {     // singleton-row update (unused when MODE == MODE_NONE)
+  float* I;           // the item table again, writable (no __restrict__: aliases the input)
+  float* M;
+  float* V;
+  const uint8_t* single;
+  OptScalars o;
+};
+
+template <int D, int GS, int CPL, int MODE>
 __global__ __launch_bounds__(kBlock) void bprmf_fwd_bwd_kernel(
-    const float* __restrict__ U, const float* __restrict__ I,
+    const float* __restrict__ U, const float* I,
     const int64_t* __restrict__ uid, const int64_t* __restrict__ iid, int B, int C,
     float inv_b, float* __restrict__ pred, float* __restrict__ loss_vec,
-    float* __restrict__ gpred, float* __restrict__ ugrad) {
+    float* __restrict__ gpred, float* __restrict__ ugrad, FusedUpd upd) {
   constexpr int LPR = D / 4;
   constexpr int S = LPR * GS;
   static_assert(S <= 64 && (64 % S) == 0, "tuple must fit a wave");
@@ -50,6 +66,14 @@ __global__ __launch_bounds__(kBlock) void bprmf_fwd_bwd_kernel(
     const int c = j * GS + grp;
     const int64_t id = ids[c < C ? c : 0];  // slots past C re-read candidate 0; masked below
     r[j] = reinterpret_cast<const float4*>(I + id * D)[l];
+  }
+  unsigned smask = 0;  // bit j: candidate slot j of this group is a singleton row
+  if (MODE != MODE_NONE) {
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+      const int c = j * GS + grp;
+      if (tv && c < C && upd.single[t * C + c]) smask |= 1u << j;
+    }
   }
 
   // ---- scores
@@ -111,6 +135,13 @@ __global__ __launch_bounds__(kBlock) void bprmf_fwd_bwd_kernel(
     acc.z = fmaf(g, r[j].z, acc.z);
     acc.w = fmaf(g, r[j].w, acc.w);
     if (tv && l == 0 && c < C) gpred[t * C + c] = g;
+    if (MODE != MODE_NONE) {
+      if (smask & (1u << j)) {  // whole lane-group takes the branch together
+        const int64_t id = ids[c];
+        const float4 gi = make_float4(g * u4.x, g * u4.y, g * u4.z, g * u4.w);
+        opt_row4<MODE>(upd.o, upd.I, upd.M, upd.V, (size_t)id * LPR + l, r[j], gi);
+      }
+    }
   }
   acc.x = groups_allreduce_sum<LPR, S>(acc.x);
   acc.y = groups_allreduce_sum<LPR, S>(acc.y);
@@ -200,29 +231,49 @@ __global__ __launch_bounds__(kBlock) void bprmf_fwd_bwd_generic_kernel(
   }
 }
 
+struct FusedCall {
+  const float* U;
+  const float* I;
+  const int64_t* uid;
+  const int64_t* iid;
+  int B, C;
+  float inv_b;
+  float* pred;
+  float* loss_vec;
+  float* gpred;
+  float* ugrad;
+  int mode;  // MODE_NONE or the optimizer mode of the singleton update
+  FusedUpd upd;
+  hipStream_t s;
+};
+
 template <int D, int GS, int CPL>
-static int launch_fused(const float* U, const float* I, const int64_t* uid, const int64_t* iid,
-                        int B, int C, float inv_b, float* pred, float* loss_vec, float* gpred,
-                        float* ugrad, hipStream_t s) {
+static int launch_fused(const FusedCall& f) {
   constexpr int TPW = 64 / ((D / 4) * GS);
   constexpr int TPB = TPW * (kBlock / 64);
-  const int blocks = (B + TPB - 1) / TPB;
-  hipLaunchKernelGGL((bprmf_fwd_bwd_kernel<D, GS, CPL>), dim3(blocks), dim3(kBlock), 0, s, U, I,
-                     uid, iid, B, C, inv_b, pred, loss_vec, gpred, ugrad);
+  const int blocks = (f.B + TPB - 1) / TPB;
+#define RC_GO(MODE_)                                                                          \
+  hipLaunchKernelGGL((bprmf_fwd_bwd_kernel<D, GS, CPL, MODE_>), dim3(blocks), dim3(kBlock), 0, \
+                     f.s, f.U, f.I, f.uid, f.iid, f.B, f.C, f.inv_b, f.pred, f.loss_vec,       \
+                     f.gpred, f.ugrad, f.upd)
+  switch (f.mode) {
+    case MODE_SGD: RC_GO(MODE_SGD); break;
+    case MODE_ADAM: RC_GO(MODE_ADAM); break;
+    case MODE_ADAGRAD: RC_GO(MODE_ADAGRAD); break;
+    default: RC_GO(MODE_NONE); break;
+  }
+#undef RC_GO
   RC_LAUNCH_CHECK();
   return RC_OK;
 }
 
 // pick (GS, CPL) for C candidates when a wave offers G = 64/LPR lane-groups
 template <int D>
-static int dispatch_fused(const float* U, const float* I, const int64_t* uid,
-                          const int64_t* iid, int B, int C, float inv_b, float* pred,
-                          float* loss_vec, float* gpred, float* ugrad, hipStream_t s,
-                          bool* handled) {
+static int dispatch_fused(const FusedCall& f, bool* handled) {
   constexpr int G = 64 / (D / 4);
+  const int C = f.C;
   *handled = true;
-#define RC_FUSED(GS_, CPL_) \
-  return launch_fused<D, GS_, CPL_>(U, I, uid, iid, B, C, inv_b, pred, loss_vec, gpred, ugrad, s)
+#define RC_FUSED(GS_, CPL_) return launch_fused<D, GS_, CPL_>(f)
   if (G >= 2 && C <= 2) { RC_FUSED((G >= 2 ? 2 : 1), 1); }
   if (G >= 4 && C <= 4) { RC_FUSED((G >= 4 ? 4 : 1), 1); }
   if (G >= 8 && C <= 8) { RC_FUSED((G >= 8 ? 8 : 1), 1); }
@@ -244,32 +295,48 @@ static int dispatch_fused(const float* U, const float* I, const int64_t* uid,
   return RC_OK;
 }
 
+static bool register_path_ok(int d, int C) {
+  if (d != 16 && d != 32 && d != 64 && d != 128) return false;
+  const int G = 64 / (d / 4);
+  return (C + G - 1) / G <= 32;
+}
+
+static int run_fused(const FusedCall& f, int d, bool* handled) {
+  *handled = false;
+  switch (d) {
+    case 16: return dispatch_fused<16>(f, handled);
+    case 32: return dispatch_fused<32>(f, handled);
+    case 64: return dispatch_fused<64>(f, handled);
+    case 128: return dispatch_fused<128>(f, handled);
+    default: return RC_OK;
+  }
+}
+
 }  // namespace rc
 
 using namespace rc;
+
+static bool aligned16(const void* p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; }
+
+extern "C" int rc_bprmf_fused_supported(int d, int C) { return register_path_ok(d, C) ? 1 : 0; }
 
 extern "C" int rc_bprmf_fwd_bwd(const float* U, const float* I, const int64_t* uid,
                                 const int64_t* iid, int B, int C, int d, float inv_b,
                                 float* pred, float* loss_vec, float* gpred, float* ugrad,
                                 rc_stream_t stream) {
-  RC_REQUIRE(U && I && uid && iid && loss_vec && gpred && ugrad, "rc_bprmf_fwd_bwd: null pointer");
-  RC_REQUIRE(B >= 0 && C >= 2 && d >= 1,
-             "rc_bprmf_fwd_bwd: need C >= 2 (one negative), got B=%d C=%d d=%d", B, C, d);
   if (B == 0) return RC_OK;
+  RC_REQUIRE(U && I && uid && iid && loss_vec && gpred && ugrad, "rc_bprmf_fwd_bwd: null pointer");
+  RC_REQUIRE(B > 0 && C >= 2 && d >= 1,
+             "rc_bprmf_fwd_bwd: need C >= 2 (one negative), got B=%d C=%d d=%d", B, C, d);
   hipStream_t s = as_stream(stream);
-  const bool aligned = (reinterpret_cast<uintptr_t>(U) % 16 == 0) &&
-                       (reinterpret_cast<uintptr_t>(I) % 16 == 0) &&
-                       (reinterpret_cast<uintptr_t>(ugrad) % 16 == 0);
-  bool handled = false;
-  if (aligned) {
-    int rc_ = RC_OK;
-    switch (d) {
-      case 16: rc_ = dispatch_fused<16>(U, I, uid, iid, B, C, inv_b, pred, loss_vec, gpred, ugrad, s, &handled); break;
-      case 32: rc_ = dispatch_fused<32>(U, I, uid, iid, B, C, inv_b, pred, loss_vec, gpred, ugrad, s, &handled); break;
-      case 64: rc_ = dispatch_fused<64>(U, I, uid, iid, B, C, inv_b, pred, loss_vec, gpred, ugrad, s, &handled); break;
-      case 128: rc_ = dispatch_fused<128>(U, I, uid, iid, B, C, inv_b, pred, loss_vec, gpred, ugrad, s, &handled); break;
-      default: break;
-    }
+  if (aligned16(U) && aligned16(I) && aligned16(ugrad) && register_path_ok(d, C)) {
+    FusedCall f;
+    memset(&f, 0, sizeof(f));
+    f.U = U; f.I = I; f.uid = uid; f.iid = iid; f.B = B; f.C = C; f.inv_b = inv_b;
+    f.pred = pred; f.loss_vec = loss_vec; f.gpred = gpred; f.ugrad = ugrad;
+    f.mode = MODE_NONE; f.s = s;
+    bool handled = false;
+    const int rc_ = run_fused(f, d, &handled);
     if (handled) return rc_;
   }
   if (C > kGenericMaxC || d > 64 * kGenericMaxDChunks)
@@ -282,4 +349,35 @@ extern "C" int rc_bprmf_fwd_bwd(const float* U, const float* I, const int64_t* u
                      uid, iid, B, C, d, inv_b, pred, loss_vec, gpred, ugrad);
   RC_LAUNCH_CHECK();
   return RC_OK;
+}
+
+extern "C" int rc_bprmf_fwd_bwd_update(const float* U, float* I, float* mI, float* vI,
+                                       const int64_t* uid, const int64_t* iid,
+                                       const uint8_t* single, int B, int C, int d, float inv_b,
+                                       const rc_opt_hyper* h, float* pred, float* loss_vec,
+                                       float* gpred, float* ugrad, rc_stream_t stream) {
+  if (B == 0) return RC_OK;
+  RC_REQUIRE(U && I && uid && iid && single && h && loss_vec && gpred && ugrad,
+             "rc_bprmf_fwd_bwd_update: null pointer");
+  RC_REQUIRE(B > 0 && C >= 2 && d >= 1, "rc_bprmf_fwd_bwd_update: bad shape B=%d C=%d d=%d", B, C, d);
+  if (!register_path_ok(d, C))
+    return fail(RC_ERR_UNSUPPORTED,
+                "rc_bprmf_fwd_bwd_update: no register-resident kernel for d=%d C=%d "
+                "(check rc_bprmf_fused_supported; use rc_bprmf_fwd_bwd + rc_segmented_update)", d, C);
+  FusedCall f;
+  memset(&f, 0, sizeof(f));
+  RC_TRY(fill_opt_scalars(h, &f.upd.o));
+  f.mode = mode_of(h);
+  RC_REQUIRE(f.mode != MODE_ADAM || (mI && vI), "rc_bprmf_fwd_bwd_update: Adam needs mI and vI");
+  RC_REQUIRE(f.mode != MODE_ADAGRAD || mI, "rc_bprmf_fwd_bwd_update: Adagrad needs mI");
+  RC_REQUIRE(aligned16(U) && aligned16(I) && aligned16(ugrad) && aligned16(mI) && aligned16(vI),
+             "rc_bprmf_fwd_bwd_update: tables must be 16-byte aligned");
+  f.U = U; f.I = I; f.uid = uid; f.iid = iid; f.B = B; f.C = C; f.inv_b = inv_b;
+  f.pred = pred; f.loss_vec = loss_vec; f.gpred = gpred; f.ugrad = ugrad;
+  f.upd.I = I; f.upd.M = mI; f.upd.V = vI; f.upd.single = single;
+  f.s = as_stream(stream);
+  bool handled = false;
+  const int rc_ = run_fused(f, d, &handled);
+  if (!handled) return fail(RC_ERR_UNSUPPORTED, "rc_bprmf_fwd_bwd_update: dispatch failed");
+  return rc_;
 }

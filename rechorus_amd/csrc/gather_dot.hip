@@ -107,9 +107,9 @@ using namespace rc;
 
 extern "C" int rc_gather_rows(const float* W, int d, const int64_t* ids, int64_t n,
                               float* out, rc_stream_t stream) {
+  if (n == 0) return RC_OK;  // empty batch: nothing to check, nothing to do
   RC_REQUIRE(W && ids && out, "rc_gather_rows: null pointer");
-  RC_REQUIRE(d >= 1 && n >= 0, "rc_gather_rows: bad shape d=%d n=%lld", d, (long long)n);
-  if (n == 0) return RC_OK;
+  RC_REQUIRE(d >= 1 && n > 0, "rc_gather_rows: bad shape d=%d n=%lld", d, (long long)n);
   hipStream_t s = as_stream(stream);
   const bool vec = (d % 4 == 0) && (reinterpret_cast<uintptr_t>(W) % 16 == 0) &&
                    (reinterpret_cast<uintptr_t>(out) % 16 == 0);
@@ -131,9 +131,9 @@ extern "C" int rc_gather_rows(const float* W, int d, const int64_t* ids, int64_t
 extern "C" int rc_gather_dot_fwd(const float* U, const float* I, const int64_t* uid,
                                  const int64_t* iid, int B, int C, int d, float* pred,
                                  rc_stream_t stream) {
-  RC_REQUIRE(U && I && uid && iid && pred, "rc_gather_dot_fwd: null pointer");
-  RC_REQUIRE(B >= 0 && C >= 1 && d >= 1, "rc_gather_dot_fwd: bad shape B=%d C=%d d=%d", B, C, d);
   if (B == 0) return RC_OK;
+  RC_REQUIRE(U && I && uid && iid && pred, "rc_gather_dot_fwd: null pointer");
+  RC_REQUIRE(B > 0 && C >= 1 && d >= 1, "rc_gather_dot_fwd: bad shape B=%d C=%d d=%d", B, C, d);
   hipStream_t s = as_stream(stream);
   const int64_t n_pairs = (int64_t)B * C;
   const bool aligned = (reinterpret_cast<uintptr_t>(U) % 16 == 0) &&

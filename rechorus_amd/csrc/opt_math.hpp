@@ -1,0 +1,88 @@
+// opt_math.hpp -- element-wise optimizer arithmetic shared by every kernel that updates a
+// table row (segmented update, dense update, the fused BPRMF singleton path).
+// Formulas: torch/optim/{sgd,adam,adagrad}.py single-tensor paths, which the reference
+// reaches through helpers/BaseRunner.py:110-114 (construction) and :206 (step).
+#pragma once
+#include "common.hpp"
+
+namespace rc {
+
+enum { MODE_SGD = 0, MODE_ADAM = 1, MODE_ADAGRAD = 2, MODE_DENSE_GRAD = 3, MODE_NONE = 4 };
+
+// python-double hyper-parameters narrowed to fp32 at the points where torch narrows them
+struct OptScalars {
+  float neg_lr;    // SGD/Adagrad: -lr
+  float l2;        // weight_decay
+  float one_m_b1;  // Adam: 1 - beta1
+  float b2;        // Adam: beta2
+  float one_m_b2;  // Adam: 1 - beta2
+  float neg_step;  // Adam: -(lr / (1 - beta1^t))
+  float bc2_sqrt;  // Adam: sqrt(1 - beta2^t)
+  float eps;
+};
+
+inline int fill_opt_scalars(const rc_opt_hyper* h, OptScalars* a) {
+  RC_REQUIRE(h != nullptr, "optimizer hyper-parameters missing");
+  RC_REQUIRE(h->opt == RC_OPT_SGD || h->opt == RC_OPT_ADAM || h->opt == RC_OPT_ADAGRAD,
+             "unknown optimizer %d", h->opt);
+  a->l2 = (float)h->l2;
+  a->neg_lr = (float)(-h->lr);
+  a->eps = (float)h->eps;
+  a->one_m_b1 = a->b2 = a->one_m_b2 = a->neg_step = 0.f;
+  a->bc2_sqrt = 1.f;
+  if (h->opt == RC_OPT_ADAM) {
+    RC_REQUIRE(h->step >= 1, "Adam needs step >= 1 (got %lld)", (long long)h->step);
+    const double bc1 = 1.0 - pow(h->beta1, (double)h->step);
+    const double bc2 = 1.0 - pow(h->beta2, (double)h->step);
+    a->one_m_b1 = (float)(1.0 - h->beta1);
+    a->b2 = (float)h->beta2;
+    a->one_m_b2 = (float)(1.0 - h->beta2);
+    a->neg_step = (float)(-(h->lr / bc1));
+    a->bc2_sqrt = (float)sqrt(bc2);
+  }
+  return RC_OK;
+}
+
+inline int mode_of(const rc_opt_hyper* h) {
+  return h->opt == RC_OPT_SGD ? MODE_SGD : (h->opt == RC_OPT_ADAM ? MODE_ADAM : MODE_ADAGRAD);
+}
+
+#if defined(__HIPCC__)
+template <int MODE>
+__device__ __forceinline__ void opt_elem(const OptScalars& a, float g, float& w, float& m,
+                                         float& v) {
+  if (MODE == MODE_SGD) {
+    g = fmaf(a.l2, w, g);  // grad.add(param, alpha=weight_decay)
+    w = fmaf(a.neg_lr, g, w);
+  } else if (MODE == MODE_ADAM) {
+    g = fmaf(a.l2, w, g);
+    m = fmaf(a.one_m_b1, g - m, m);         // exp_avg.lerp_(grad, 1-beta1)
+    v = fmaf(a.one_m_b2, g * g, v * a.b2);  // mul_(beta2).addcmul_(g, g, 1-beta2)
+    const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
+    w = fmaf(a.neg_step, m / denom, w);     // addcdiv_(exp_avg, denom, -step_size)
+  } else if (MODE == MODE_ADAGRAD) {
+    g = fmaf(a.l2, w, g);
+    m = fmaf(g, g, m);                      // state_sum.addcmul_(g, g, 1)
+    w = fmaf(a.neg_lr, g / (sqrtf(m) + a.eps), w);
+  }
+}
+
+// update one float4 slice of a table row in place (row index `row`, slice l of LPR)
+template <int MODE>
+__device__ __forceinline__ void opt_row4(const OptScalars& a, float* __restrict__ W,
+                                         float* __restrict__ M, float* __restrict__ V, size_t idx4,
+                                         float4 w, const float4& g) {
+  float4 m = make_float4(0, 0, 0, 0), v = make_float4(0, 0, 0, 0);
+  if (MODE == MODE_ADAM || MODE == MODE_ADAGRAD) m = reinterpret_cast<const float4*>(M)[idx4];
+  if (MODE == MODE_ADAM) v = reinterpret_cast<const float4*>(V)[idx4];
+  opt_elem<MODE>(a, g.x, w.x, m.x, v.x);
+  opt_elem<MODE>(a, g.y, w.y, m.y, v.y);
+  opt_elem<MODE>(a, g.z, w.z, m.z, v.z);
+  opt_elem<MODE>(a, g.w, w.w, m.w, v.w);
+  reinterpret_cast<float4*>(W)[idx4] = w;
+  if (MODE == MODE_ADAM || MODE == MODE_ADAGRAD) reinterpret_cast<float4*>(M)[idx4] = m;
+  if (MODE == MODE_ADAM) reinterpret_cast<float4*>(V)[idx4] = v;
+}
+#endif
+
+}  // namespace rc

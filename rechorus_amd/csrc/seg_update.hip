@@ -16,12 +16,11 @@
 // kernel that strides 256/LPR lane-groups over the segment and combines their partials in
 // a fixed LDS tree.  The only atomics are integer appends to the deferred-row list.
 #include "common.hpp"
+#include "opt_math.hpp"
 
 namespace rc {
 
 constexpr int kLongSeg = 32;  // occurrences handled sequentially by one lane-group
-
-enum { MODE_SGD = 0, MODE_ADAM = 1, MODE_ADAGRAD = 2, MODE_DENSE_GRAD = 3 };
 
 struct SegArgs {
   float* W;
@@ -39,62 +38,34 @@ struct SegArgs {
   uint32_t* long_list;
   uint32_t* n_long;
   uint32_t long_cap;
-  // optimizer scalars, narrowed to fp32 where torch narrows them
-  float neg_lr;        // SGD/Adagrad: -lr
-  float l2;            // weight_decay
-  float one_m_b1;      // Adam: 1 - beta1
-  float b2;            // Adam: beta2
-  float one_m_b2;      // Adam: 1 - beta2
-  float neg_step;      // Adam: -(lr / (1 - beta1^t))
-  float bc2_sqrt;      // Adam: sqrt(1 - beta2^t)
-  float eps;
+  int skip_single;  // 1: single-occurrence rows were already updated by the fused kernel
+  OptScalars o;
 };
 
-// element-wise optimizer maths (torch/optim/{sgd,adam,adagrad}.py single-tensor paths)
-template <int MODE>
-__device__ __forceinline__ void opt_elem(const SegArgs& a, float g, float& w, float& m, float& v) {
-  if (MODE == MODE_SGD) {
-    g = fmaf(a.l2, w, g);  // grad.add(param, alpha=weight_decay)
-    w = fmaf(a.neg_lr, g, w);
-  } else if (MODE == MODE_ADAM) {
-    g = fmaf(a.l2, w, g);
-    m = fmaf(a.one_m_b1, g - m, m);               // exp_avg.lerp_(grad, 1-beta1)
-    v = fmaf(a.one_m_b2, g * g, v * a.b2);        // mul_(beta2).addcmul_(g, g, 1-beta2)
-    const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
-    w = fmaf(a.neg_step, m / denom, w);           // addcdiv_(exp_avg, denom, -step_size)
-  } else if (MODE == MODE_ADAGRAD) {
-    g = fmaf(a.l2, w, g);
-    m = fmaf(g, g, m);                            // state_sum.addcmul_(g, g, 1)
-    w = fmaf(a.neg_lr, g / (sqrtf(m) + a.eps), w);
-  }
-}
-
+// apply the reduced gradient g to row `key` (w = current row slice, already loaded)
 template <int D, int MODE>
-__device__ __forceinline__ void apply_row4(const SegArgs& a, uint32_t key, int l, float4 g) {
+__device__ __forceinline__ void apply_row4(const SegArgs& a, uint32_t key, int l, float4 w,
+                                           const float4& g) {
   constexpr int LPR = D / 4;
   const size_t idx = (size_t)key * LPR + l;
   if (MODE == MODE_DENSE_GRAD) {
     reinterpret_cast<float4*>(a.dense_grad)[idx] = g;
     return;
   }
-  float4 w = reinterpret_cast<const float4*>(a.W)[idx];
-  float4 m = make_float4(0, 0, 0, 0), v = make_float4(0, 0, 0, 0);
-  if (MODE == MODE_ADAM || MODE == MODE_ADAGRAD) m = reinterpret_cast<const float4*>(a.M)[idx];
-  if (MODE == MODE_ADAM) v = reinterpret_cast<const float4*>(a.V)[idx];
-  opt_elem<MODE>(a, g.x, w.x, m.x, v.x);
-  opt_elem<MODE>(a, g.y, w.y, m.y, v.y);
-  opt_elem<MODE>(a, g.z, w.z, m.z, v.z);
-  opt_elem<MODE>(a, g.w, w.w, m.w, v.w);
-  reinterpret_cast<float4*>(a.W)[idx] = w;
-  if (MODE == MODE_ADAM || MODE == MODE_ADAGRAD) reinterpret_cast<float4*>(a.M)[idx] = m;
-  if (MODE == MODE_ADAM) reinterpret_cast<float4*>(a.V)[idx] = v;
+  opt_row4<MODE>(a.o, a.W, a.M, a.V, idx, w, g);
 }
 
-// gradient row of sorted position jj, lane's float4
-template <int D>
-__device__ __forceinline__ float4 occ_grad4(const SegArgs& a, int64_t jj, int l) {
+template <int D, int MODE>
+__device__ __forceinline__ float4 load_row4(const SegArgs& a, uint32_t key, int l) {
   constexpr int LPR = D / 4;
-  const uint32_t o = a.perm[jj];
+  if (MODE == MODE_DENSE_GRAD) return make_float4(0, 0, 0, 0);
+  return reinterpret_cast<const float4*>(a.W)[(size_t)key * LPR + l];
+}
+
+// gradient row of occurrence o (= perm[j]), lane's float4
+template <int D>
+__device__ __forceinline__ float4 occ_grad4_o(const SegArgs& a, uint32_t o, int l) {
+  constexpr int LPR = D / 4;
   const float c = a.coef ? a.coef[o] : 1.0f;
   int64_t sr = (a.div == 1) ? (int64_t)o : (int64_t)(o / (uint32_t)a.div);
   if (a.src_index) sr = a.src_index[sr];
@@ -102,31 +73,56 @@ __device__ __forceinline__ float4 occ_grad4(const SegArgs& a, int64_t jj, int l)
   s.x *= c; s.y *= c; s.z *= c; s.w *= c;
   return s;
 }
+template <int D>
+__device__ __forceinline__ float4 occ_grad4(const SegArgs& a, int64_t jj, int l) {
+  return occ_grad4_o<D>(a, a.perm[jj], l);
+}
 
-template <int D, int MODE>
+__device__ __forceinline__ void add4(float4& x, const float4& y) {
+  x.x += y.x; x.y += y.y; x.z += y.z; x.w += y.w;
+}
+
+// SKIP = true: single-occurrence rows were updated upstream (fused BPRMF kernel), every
+// surviving head has >= 2 occurrences, so the first two gradient rows are fetched together.
+// Dependent-load depth per row: {keys[j-1..j+1], perm[j], perm[j+1]} -> {W row, coef, index}
+// -> {src rows} -> store.
+template <int D, int MODE, bool SKIP>
 __global__ __launch_bounds__(kBlock) void seg_update_kernel(SegArgs a) {
   constexpr int LPR = D / 4;
   constexpr int GPB = kBlock / LPR;
   const int l = threadIdx.x % LPR;
+  const int64_t n = a.n_occ;
   const int64_t j = (int64_t)blockIdx.x * GPB + threadIdx.x / LPR;
-  if (j >= a.n_occ) return;  // no cross-lane ops in this kernel
+  if (j >= n) return;  // no cross-lane ops in this kernel
+  const bool has_next = j + 1 < n;
   const uint32_t key = a.keys[j];
-  if (j > 0 && a.keys[j - 1] == key) return;  // not a segment head
-  float4 acc = occ_grad4<D>(a, j, l);
-  int64_t jj = j + 1;
-  while (jj < a.n_occ && a.keys[jj] == key) {
-    if (jj - j >= kLongSeg) {  // hot row: hand over to the workgroup-per-row kernel
-      if (l == 0) {
-        const uint32_t slot = atomicAdd(a.n_long, 1u);
-        if (slot < a.long_cap) a.long_list[slot] = (uint32_t)j;
+  const uint32_t kprev = j > 0 ? a.keys[j - 1] : ~key;
+  const uint32_t knext = has_next ? a.keys[j + 1] : ~key;
+  const uint32_t o0 = a.perm[j];
+  const uint32_t o1 = a.perm[has_next ? j + 1 : j];
+  if (kprev == key) return;  // not a segment head
+  const bool multi = knext == key;
+  if (SKIP && !multi) return;  // singleton: already updated by the fused kernel
+  const float4 w = load_row4<D, MODE>(a, key, l);
+  float4 acc = occ_grad4_o<D>(a, o0, l);
+  if (SKIP || multi) {
+    const float4 s1 = occ_grad4_o<D>(a, o1, l);
+    add4(acc, s1);
+    int64_t jj = j + 2;
+    while (jj < n && a.keys[jj] == key) {
+      if (jj - j >= kLongSeg) {  // hot row: hand over to the workgroup-per-row kernel
+        if (l == 0) {
+          const uint32_t slot = atomicAdd(a.n_long, 1u);
+          if (slot < a.long_cap) a.long_list[slot] = (uint32_t)j;
+        }
+        return;
       }
-      return;
+      const float4 s = occ_grad4<D>(a, jj, l);
+      add4(acc, s);
+      ++jj;
     }
-    const float4 s = occ_grad4<D>(a, jj, l);
-    acc.x += s.x; acc.y += s.y; acc.z += s.z; acc.w += s.w;
-    ++jj;
   }
-  apply_row4<D, MODE>(a, key, l, acc);
+  apply_row4<D, MODE>(a, key, l, w, acc);
 }
 
 // end of the segment that starts at j0 (first index with a different key)
@@ -164,10 +160,15 @@ __global__ __launch_bounds__(kBlock) void seg_update_long_kernel(SegArgs a) {
     if (threadIdx.x == 0) s_end = segment_end(a.keys, a.n_occ, j0);
     __syncthreads();
     const int64_t end = s_end;
+    // four independent occurrences per lane-group per trip (fixed pattern -> fixed order)
     float4 acc = make_float4(0, 0, 0, 0);
-    for (int64_t jj = j0 + g; jj < end; jj += GPB) {
-      const float4 s = occ_grad4<D>(a, jj, l);
-      acc.x += s.x; acc.y += s.y; acc.z += s.z; acc.w += s.w;
+    for (int64_t jj = j0 + g; jj < end; jj += 4 * GPB) {
+      const float4 z = make_float4(0, 0, 0, 0);
+      const float4 s0 = occ_grad4<D>(a, jj, l);
+      const float4 s1 = (jj + GPB < end) ? occ_grad4<D>(a, jj + GPB, l) : z;
+      const float4 s2 = (jj + 2 * GPB < end) ? occ_grad4<D>(a, jj + 2 * GPB, l) : z;
+      const float4 s3 = (jj + 3 * GPB < end) ? occ_grad4<D>(a, jj + 3 * GPB, l) : z;
+      add4(acc, s0); add4(acc, s1); add4(acc, s2); add4(acc, s3);
     }
     part[threadIdx.x] = acc;
     __syncthreads();
@@ -180,7 +181,10 @@ __global__ __launch_bounds__(kBlock) void seg_update_long_kernel(SegArgs a) {
       }
       __syncthreads();
     }
-    if (g == 0) apply_row4<D, MODE>(a, a.keys[j0], l, part[threadIdx.x]);
+    if (g == 0) {
+      const uint32_t key = a.keys[j0];
+      apply_row4<D, MODE>(a, key, l, load_row4<D, MODE>(a, key, l), part[threadIdx.x]);
+    }
     __syncthreads();  // part[] and s_end are reused by the next row
   }
 }
@@ -203,7 +207,7 @@ __device__ __forceinline__ void apply_row_generic(const SegArgs& a, uint32_t key
     float w = a.W[idx], m = 0.f, v = 0.f;
     if (MODE == MODE_ADAM || MODE == MODE_ADAGRAD) m = a.M[idx];
     if (MODE == MODE_ADAM) v = a.V[idx];
-    opt_elem<MODE>(a, acc[q], w, m, v);
+    opt_elem<MODE>(a.o, acc[q], w, m, v);
     a.W[idx] = w;
     if (MODE == MODE_ADAM || MODE == MODE_ADAGRAD) a.M[idx] = m;
     if (MODE == MODE_ADAM) a.V[idx] = v;
@@ -232,6 +236,7 @@ __global__ __launch_bounds__(kBlock) void seg_update_generic_kernel(SegArgs a) {
   if (j >= a.n_occ) return;
   const uint32_t key = a.keys[j];
   if (j > 0 && a.keys[j - 1] == key) return;
+  if (a.skip_single && !(j + 1 < a.n_occ && a.keys[j + 1] == key)) return;
   float acc[kGenChunks];
 #pragma unroll
   for (int q = 0; q < kGenChunks; ++q) acc[q] = 0.f;
@@ -245,7 +250,10 @@ static int launch_seg(const SegArgs& a, hipStream_t s) {
   const int64_t blocks = (a.n_occ + GPB - 1) / GPB;
   if (blocks > kMaxGridX) return fail(RC_ERR_UNSUPPORTED, "seg_update: grid too large");
   RC_HIP(hipMemsetAsync(a.n_long, 0, sizeof(uint32_t), s));
-  hipLaunchKernelGGL((seg_update_kernel<D, MODE>), dim3((unsigned)blocks), dim3(kBlock), 0, s, a);
+  if (a.skip_single)
+    hipLaunchKernelGGL((seg_update_kernel<D, MODE, true>), dim3((unsigned)blocks), dim3(kBlock), 0, s, a);
+  else
+    hipLaunchKernelGGL((seg_update_kernel<D, MODE, false>), dim3((unsigned)blocks), dim3(kBlock), 0, s, a);
   RC_LAUNCH_CHECK();
   unsigned lblocks = a.long_cap < 1024u ? a.long_cap : 1024u;
   if (lblocks == 0) lblocks = 1;
@@ -276,30 +284,6 @@ static int launch_seg_mode(const SegArgs& a, bool aligned, hipStream_t s) {
   return RC_OK;
 }
 
-// fill the fp32 scalars of SegArgs from the double hyper-parameters, narrowing where
-// torch narrows (python-float scalar -> fp32 at the tensor op)
-int fill_opt_scalars(const rc_opt_hyper* h, SegArgs* a) {
-  RC_REQUIRE(h != nullptr, "optimizer hyper-parameters missing");
-  RC_REQUIRE(h->opt == RC_OPT_SGD || h->opt == RC_OPT_ADAM || h->opt == RC_OPT_ADAGRAD,
-             "unknown optimizer %d", h->opt);
-  a->l2 = (float)h->l2;
-  a->neg_lr = (float)(-h->lr);
-  a->eps = (float)h->eps;
-  a->one_m_b1 = a->b2 = a->one_m_b2 = a->neg_step = 0.f;
-  a->bc2_sqrt = 1.f;
-  if (h->opt == RC_OPT_ADAM) {
-    RC_REQUIRE(h->step >= 1, "Adam needs step >= 1 (got %lld)", (long long)h->step);
-    const double bc1 = 1.0 - pow(h->beta1, (double)h->step);
-    const double bc2 = 1.0 - pow(h->beta2, (double)h->step);
-    a->one_m_b1 = (float)(1.0 - h->beta1);
-    a->b2 = (float)h->beta2;
-    a->one_m_b2 = (float)(1.0 - h->beta2);
-    a->neg_step = (float)(-(h->lr / bc1));
-    a->bc2_sqrt = (float)sqrt(bc2);
-  }
-  return RC_OK;
-}
-
 // ---- dense (exact torch semantics) optimizer step over a whole tensor -------------------
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void dense_update_kernel(SegArgs a, const float* __restrict__ G,
@@ -312,10 +296,10 @@ __global__ __launch_bounds__(kBlock) void dense_update_kernel(SegArgs a, const f
     float4 m = make_float4(0, 0, 0, 0), v = make_float4(0, 0, 0, 0);
     if (MODE == MODE_ADAM || MODE == MODE_ADAGRAD) m = reinterpret_cast<const float4*>(a.M)[i];
     if (MODE == MODE_ADAM) v = reinterpret_cast<const float4*>(a.V)[i];
-    opt_elem<MODE>(a, g.x, w.x, m.x, v.x);
-    opt_elem<MODE>(a, g.y, w.y, m.y, v.y);
-    opt_elem<MODE>(a, g.z, w.z, m.z, v.z);
-    opt_elem<MODE>(a, g.w, w.w, m.w, v.w);
+    opt_elem<MODE>(a.o, g.x, w.x, m.x, v.x);
+    opt_elem<MODE>(a.o, g.y, w.y, m.y, v.y);
+    opt_elem<MODE>(a.o, g.z, w.z, m.z, v.z);
+    opt_elem<MODE>(a.o, g.w, w.w, m.w, v.w);
     reinterpret_cast<float4*>(a.W)[i] = w;
     if (MODE == MODE_ADAM || MODE == MODE_ADAGRAD) reinterpret_cast<float4*>(a.M)[i] = m;
     if (MODE == MODE_ADAM) reinterpret_cast<float4*>(a.V)[i] = v;
@@ -326,7 +310,7 @@ __global__ __launch_bounds__(kBlock) void dense_update_kernel(SegArgs a, const f
     float w = a.W[i], m = 0.f, v = 0.f;
     if (MODE == MODE_ADAM || MODE == MODE_ADAGRAD) m = a.M[i];
     if (MODE == MODE_ADAM) v = a.V[i];
-    opt_elem<MODE>(a, G[i], w, m, v);
+    opt_elem<MODE>(a.o, G[i], w, m, v);
     a.W[i] = w;
     if (MODE == MODE_ADAM || MODE == MODE_ADAGRAD) a.M[i] = m;
     if (MODE == MODE_ADAM) a.V[i] = v;
@@ -342,7 +326,7 @@ __global__ __launch_bounds__(kBlock) void dense_update_scalar_kernel(SegArgs a,
     float w = a.W[i], m = 0.f, v = 0.f;
     if (MODE == MODE_ADAM || MODE == MODE_ADAGRAD) m = a.M[i];
     if (MODE == MODE_ADAM) v = a.V[i];
-    opt_elem<MODE>(a, G[i], w, m, v);
+    opt_elem<MODE>(a.o, G[i], w, m, v);
     a.W[i] = w;
     if (MODE == MODE_ADAM || MODE == MODE_ADAGRAD) a.M[i] = m;
     if (MODE == MODE_ADAM) a.V[i] = v;
@@ -367,6 +351,31 @@ static int launch_dense(const SegArgs& a, const float* G, int64_t n, bool aligne
 
 using namespace rc;
 
+// flag[o] = 1 iff occurrence o is the only one of its row in the batch
+__global__ __launch_bounds__(rc::kBlock) void mark_singletons_kernel(
+    const uint32_t* __restrict__ keys, const uint32_t* __restrict__ perm, int64_t n,
+    uint8_t* __restrict__ flag) {
+  for (int64_t j = (int64_t)blockIdx.x * rc::kBlock + threadIdx.x; j < n;
+       j += (int64_t)gridDim.x * rc::kBlock) {
+    const uint32_t k = keys[j];
+    const bool single = (j == 0 || keys[j - 1] != k) && (j + 1 >= n || keys[j + 1] != k);
+    flag[perm[j]] = single ? 1 : 0;
+  }
+}
+
+extern "C" int rc_mark_singletons(const uint32_t* keys, const uint32_t* perm, int64_t n_occ,
+                                  uint8_t* flag, rc_stream_t stream) {
+  if (n_occ == 0) return RC_OK;
+  RC_REQUIRE(keys && perm && flag, "rc_mark_singletons: null pointer");
+  RC_REQUIRE(n_occ > 0 && n_occ < ((int64_t)1 << 31), "rc_mark_singletons: bad n_occ");
+  int64_t blocks = (n_occ + kBlock - 1) / kBlock;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(mark_singletons_kernel, dim3((unsigned)blocks), dim3(kBlock), 0,
+                     as_stream(stream), keys, perm, n_occ, flag);
+  RC_LAUNCH_CHECK();
+  return RC_OK;
+}
+
 extern "C" size_t rc_segmented_workspace_bytes(int64_t n_occ) {
   if (n_occ < 1) n_occ = 1;
   const size_t cap = (size_t)(n_occ / kLongSeg) + 1;
@@ -376,8 +385,9 @@ extern "C" size_t rc_segmented_workspace_bytes(int64_t n_occ) {
 extern "C" int rc_segmented_update(float* W, float* m, float* v, int d, const uint32_t* keys,
                                    const uint32_t* perm, int64_t n_occ, const float* coef,
                                    const float* src, const int64_t* src_index, int div,
-                                   const rc_opt_hyper* h, float* dense_grad, void* ws,
+                                   const rc_opt_hyper* h, float* dense_grad, int flags, void* ws,
                                    size_t ws_bytes, rc_stream_t stream) {
+  if (n_occ == 0) return RC_OK;
   RC_REQUIRE(keys && perm && src && ws, "rc_segmented_update: null pointer");
   RC_REQUIRE(d >= 1 && div >= 1 && n_occ >= 0 && n_occ < ((int64_t)1 << 31),
              "rc_segmented_update: bad shape d=%d div=%d n_occ=%lld", d, div, (long long)n_occ);
@@ -392,6 +402,7 @@ extern "C" int rc_segmented_update(float* W, float* m, float* v, int d, const ui
   a.keys = keys; a.perm = perm; a.n_occ = n_occ;
   a.coef = coef; a.src = src; a.src_index = src_index; a.div = div; a.d = d;
   a.dense_grad = dense_grad;
+  a.skip_single = (flags & RC_SEG_SKIP_SINGLETONS) ? 1 : 0;
   Carver cv(ws);
   a.n_long = cv.take<uint32_t>(1);
   a.long_cap = (uint32_t)(n_occ / kLongSeg) + 1;
@@ -402,7 +413,7 @@ extern "C" int rc_segmented_update(float* W, float* m, float* v, int d, const ui
     aligned = aligned && (reinterpret_cast<uintptr_t>(dense_grad) % 16 == 0);
     return launch_seg_mode<MODE_DENSE_GRAD>(a, aligned, s);
   }
-  RC_TRY(fill_opt_scalars(h, &a));
+  RC_TRY(fill_opt_scalars(h, &a.o));
   aligned = aligned && (reinterpret_cast<uintptr_t>(W) % 16 == 0);
   switch (h->opt) {
     case RC_OPT_SGD:
@@ -423,13 +434,13 @@ extern "C" int rc_segmented_update(float* W, float* m, float* v, int d, const ui
 
 extern "C" int rc_dense_update(float* W, const float* G, float* m, float* v, int64_t n,
                                const rc_opt_hyper* h, rc_stream_t stream) {
-  RC_REQUIRE(W && G, "rc_dense_update: null pointer");
-  RC_REQUIRE(n >= 0, "rc_dense_update: n < 0");
   if (n == 0) return RC_OK;
+  RC_REQUIRE(W && G, "rc_dense_update: null pointer");
+  RC_REQUIRE(n > 0, "rc_dense_update: n < 0");
   SegArgs a;
   memset(&a, 0, sizeof(a));
   a.W = W; a.M = m; a.V = v;
-  RC_TRY(fill_opt_scalars(h, &a));
+  RC_TRY(fill_opt_scalars(h, &a.o));
   hipStream_t s = as_stream(stream);
   bool aligned = (reinterpret_cast<uintptr_t>(W) % 16 == 0) && (reinterpret_cast<uintptr_t>(G) % 16 == 0);
   switch (h->opt) {

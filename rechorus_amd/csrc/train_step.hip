@@ -5,8 +5,10 @@
 // hipGraph; with `phase_ms` it brackets the phases with hipEvents and synchronises.
 //
 //   phase 0  sort item ids (B*C)          phase 3  loss mean (deterministic)
-//   phase 1  sort user ids (B)            phase 4  item rows: segmented grad + update
+//   phase 7  mark single-occurrence rows  phase 4  item rows with >= 2 occurrences:
+//   phase 1  sort user ids (B)                     segmented grad + update
 //   phase 2  fused gather/dot/loss/bwd    phase 5  user rows: segmented grad + update
+//            (+ update of singleton item rows, still in registers)
 //
 // Ordering constraints: phase 4 reads U (pre-step values, to rebuild g*U[u]) so it runs
 // before phase 5 rewrites U; phase 2 reads both tables before either is updated.
@@ -23,6 +25,7 @@ struct StepWs {
   float* gpred;
   float* ugrad;
   float* loss_vec;
+  uint8_t* single;
   void* sort_ws;
   size_t sort_ws_bytes;
   void* seg_ws;
@@ -41,6 +44,7 @@ StepWs carve_step_ws(void* base, int B, int C, int d) {
   w.gpred = cv.take<float>(n_i);
   w.ugrad = cv.take<float>((size_t)B * d);
   w.loss_vec = cv.take<float>((size_t)B);
+  w.single = cv.take<uint8_t>(n_i);
   w.sort_ws_bytes = rc_sort_workspace_bytes((int64_t)n_i);
   w.sort_ws = cv.take<char>(w.sort_ws_bytes);
   w.seg_ws_bytes = rc_segmented_workspace_bytes((int64_t)n_i);
@@ -70,42 +74,52 @@ extern "C" int rc_bprmf_train_step(float* U, float* I, float* mU, float* vU, flo
   hipStream_t s = as_stream(stream);
   const int64_t n_i = (int64_t)B * C;
 
-  constexpr int kPhases = 6;
-  hipEvent_t ev[kPhases + 1];
+  constexpr int kMarks = 8;
+  hipEvent_t ev[kMarks];
   const bool prof = phase_ms != nullptr;
   if (prof)
-    for (int i = 0; i <= kPhases; ++i) RC_HIP(hipEventCreate(&ev[i]));
+    for (int i = 0; i < kMarks; ++i) RC_HIP(hipEventCreate(&ev[i]));
 #define RC_MARK(i)                                \
   do {                                            \
     if (prof) RC_HIP(hipEventRecord(ev[i], s));   \
   } while (0)
 
+  const bool fused_upd = rc_bprmf_fused_supported(d, C) != 0;
   RC_MARK(0);
   RC_TRY(rc_sort_ids(iid, n_i, n_items, w.keys_i, w.perm_i, w.sort_ws, w.sort_ws_bytes, stream));
   RC_MARK(1);
-  RC_TRY(rc_sort_ids(uid, B, n_users, w.keys_u, w.perm_u, w.sort_ws, w.sort_ws_bytes, stream));
+  if (fused_upd) RC_TRY(rc_mark_singletons(w.keys_i, w.perm_i, n_i, w.single, stream));
   RC_MARK(2);
-  RC_TRY(rc_bprmf_fwd_bwd(U, I, uid, iid, B, C, d, inv_b, pred, w.loss_vec, w.gpred, w.ugrad,
-                          stream));
+  RC_TRY(rc_sort_ids(uid, B, n_users, w.keys_u, w.perm_u, w.sort_ws, w.sort_ws_bytes, stream));
   RC_MARK(3);
-  RC_TRY(rc_reduce_sum(w.loss_vec, B, inv_b, loss_out, stream));
+  if (fused_upd)
+    RC_TRY(rc_bprmf_fwd_bwd_update(U, I, mI, vI, uid, iid, w.single, B, C, d, inv_b, h, pred,
+                                   w.loss_vec, w.gpred, w.ugrad, stream));
+  else
+    RC_TRY(rc_bprmf_fwd_bwd(U, I, uid, iid, B, C, d, inv_b, pred, w.loss_vec, w.gpred, w.ugrad,
+                            stream));
   RC_MARK(4);
+  RC_TRY(rc_reduce_sum(w.loss_vec, B, inv_b, loss_out, stream));
+  RC_MARK(5);
   // item rows: grad_r = sum_{(b,c): iid[b,c]=r} g[b,c] * U[uid[b]]
   RC_TRY(rc_segmented_update(I, mI, vI, d, w.keys_i, w.perm_i, n_i, w.gpred, U, uid, C, h,
-                             nullptr, w.seg_ws, w.seg_ws_bytes, stream));
-  RC_MARK(5);
+                             nullptr, fused_upd ? RC_SEG_SKIP_SINGLETONS : 0, w.seg_ws,
+                             w.seg_ws_bytes, stream));
+  RC_MARK(6);
   // user rows: grad_r = sum_{b: uid[b]=r} ugrad[b]
   RC_TRY(rc_segmented_update(U, mU, vU, d, w.keys_u, w.perm_u, B, nullptr, w.ugrad, nullptr, 1, h,
-                             nullptr, w.seg_ws, w.seg_ws_bytes, stream));
-  RC_MARK(6);
+                             nullptr, 0, w.seg_ws, w.seg_ws_bytes, stream));
+  RC_MARK(7);
 #undef RC_MARK
 
   if (prof) {
-    RC_HIP(hipEventSynchronize(ev[kPhases]));
-    for (int i = 0; i < kPhases; ++i) RC_HIP(hipEventElapsedTime(&phase_ms[i], ev[i], ev[i + 1]));
-    RC_HIP(hipEventElapsedTime(&phase_ms[6], ev[0], ev[kPhases]));
-    phase_ms[7] = 0.f;
-    for (int i = 0; i <= kPhases; ++i) RC_HIP(hipEventDestroy(ev[i]));
+    RC_HIP(hipEventSynchronize(ev[kMarks - 1]));
+    // event i opens: 0 sort items, 1 mark singletons, 2 sort users, 3 fused, 4 loss mean,
+    // 5 item update, 6 user update; reported in the header's slot order
+    const int slot[7] = {0, 7, 1, 2, 3, 4, 5};
+    for (int i = 0; i < 7; ++i) RC_HIP(hipEventElapsedTime(&phase_ms[slot[i]], ev[i], ev[i + 1]));
+    RC_HIP(hipEventElapsedTime(&phase_ms[6], ev[0], ev[kMarks - 1]));
+    for (int i = 0; i < kMarks; ++i) RC_HIP(hipEventDestroy(ev[i]));
   }
   return RC_OK;
 }

@@ -137,8 +137,37 @@ def sort_ids(ids, n_rows):
     return keys, perm
 
 
+def mark_singletons(keys, perm):
+    """uint8 flag per occurrence: 1 iff its row occurs exactly once in the batch."""
+    flag = torch.empty(keys.numel(), dtype=torch.uint8, device=keys.device)
+    _lib.call("rc_mark_singletons", _ptr(keys, torch.int32, "keys"), _ptr(perm, torch.int32, "perm"),
+              keys.numel(), _ptr(flag, torch.uint8, "flag"), _stream())
+    return flag
+
+
+def bprmf_fwd_bwd_update(U, I, uid, iid, single, hyper, mI=None, vI=None, inv_b=None, want_pred=False):
+    """Fused fwd/loss/bwd that also applies the optimizer to single-occurrence item rows."""
+    B, Cn = iid.shape
+    d = U.shape[1]
+    if inv_b is None:
+        inv_b = 1.0 / B
+    dev = U.device
+    f32 = torch.float32
+    pred = torch.empty((B, Cn), dtype=f32, device=dev) if want_pred else None
+    loss_vec = torch.empty(B, dtype=f32, device=dev)
+    gpred = torch.empty((B, Cn), dtype=f32, device=dev)
+    ugrad = torch.empty((B, d), dtype=f32, device=dev)
+    _lib.call("rc_bprmf_fwd_bwd_update", _ptr(U, f32, "U"), _ptr(I, f32, "I"),
+              _ptr(mI, f32, "mI", True), _ptr(vI, f32, "vI", True),
+              _ptr(uid, torch.int64, "uid"), _ptr(iid, torch.int64, "iid"),
+              _ptr(single, torch.uint8, "single"), B, Cn, d, float(inv_b), C.byref(hyper),
+              _ptr(pred, f32, "pred", True), _ptr(loss_vec, f32, "loss_vec"),
+              _ptr(gpred, f32, "gpred"), _ptr(ugrad, f32, "ugrad"), _stream())
+    return pred, loss_vec, gpred, ugrad
+
+
 def segmented_update(keys, perm, src, hyper=None, W=None, m=None, v=None, coef=None,
-                     src_index=None, div=1, dense_grad=None):
+                     src_index=None, div=1, dense_grad=None, skip_singletons=False):
     """rc_segmented_update: per distinct row r, grad_r = sum coef[o]*src[srow(o)], then either
     write dense_grad[r] or apply the optimizer to W[r] (and m, v) in place."""
     n_occ = keys.numel()
@@ -155,6 +184,7 @@ def segmented_update(keys, perm, src, hyper=None, W=None, m=None, v=None, coef=N
               _ptr(coef, torch.float32, "coef", allow_none=True), _ptr(src, torch.float32, "src"),
               _ptr(src_index, torch.int64, "src_index", allow_none=True), int(div), hp,
               _ptr(dense_grad, torch.float32, "dense_grad", allow_none=True),
+              _lib.RC_SEG_SKIP_SINGLETONS if skip_singletons else 0,
               C.c_void_p(ws.data_ptr()), ws.numel(), _stream())
 
 
@@ -237,5 +267,5 @@ class BprmfTrainer:
         buf = (C.c_float * 8)()
         self.step(uid, iid, phase_ms=buf)
         names = ["sort_items", "sort_users", "fused_fwd_bwd", "loss_mean", "item_update",
-                 "user_update", "total"]
+                 "user_update", "total", "mark_singletons"]
         return {n: float(buf[i]) for i, n in enumerate(names)}

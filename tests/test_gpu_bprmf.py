@@ -266,3 +266,36 @@ def test_embedding_dense_backward_vs_index_add(cuda, eng):
         want = np.zeros((n_rows, d), dtype=np.float64)
         np.add.at(want, ids, go.astype(np.float64))
         assert_close(host(G), want, what=f"dense grad d={d}")
+
+
+@pytest.mark.parametrize("opt,lr,l2", [("SGD", 0.05, 1e-3), ("Adam", 1e-3, 1e-4), ("Adagrad", 0.01, 1e-4)])
+@pytest.mark.parametrize("d,B,C,n_items", [(64, 300, 100, 20000), (64, 513, 2, 700), (32, 100, 9, 300),
+                                           (128, 64, 40, 2000), (16, 50, 100, 4000)])
+def test_singleton_fast_path_is_bit_identical_to_segmented_path(opt, lr, l2, d, B, C, n_items, cuda, eng):
+    """rows that occur once are updated inside the fused kernel; the result must equal the
+    all-segmented pipeline bit for bit (same arithmetic, same operands)"""
+    rng = np.random.default_rng(d + B + C)
+    U, I, uid, iid = _random_problem(rng, 40, n_items, d, B, C)
+    uid_d, iid_d = dev(uid, cuda), dev(iid, cuda)
+    keys, perm = eng.sort_ids(iid_d, n_items)
+    single = eng.mark_singletons(keys, perm)
+    cnt = np.bincount(iid.ravel(), minlength=n_items)
+    assert np.array_equal(host(single).reshape(B, C), (cnt[iid] == 1).astype(np.uint8))
+    assert 0 < int(host(single).sum()) < B * C or C == 2
+    h = eng.make_hyper(opt, lr=lr, l2=l2, step=3)
+    res = []
+    for fast in (False, True):
+        Ud, Id = dev(U, cuda), dev(I, cuda)
+        m = torch.full_like(Id, 0.25e-6) if opt != "SGD" else None
+        v = torch.full_like(Id, 1e-9) if opt == "Adam" else None
+        if fast:
+            _, lv, gp, ug = eng.bprmf_fwd_bwd_update(Ud, Id, uid_d, iid_d, single, h, mI=m, vI=v)
+        else:
+            _, lv, gp, ug = eng.bprmf_fwd_bwd(Ud, Id, uid_d, iid_d, want_pred=False)
+        eng.segmented_update(keys, perm, Ud, hyper=h, W=Id, m=m, v=v, coef=gp.reshape(-1),
+                             src_index=uid_d, div=C, skip_singletons=fast)
+        res.append((Id, m, v, lv, gp, ug))
+    for a, b in zip(res[0], res[1]):
+        if a is not None:
+            assert torch.equal(a, b)
+    assert not torch.equal(res[0][0], dev(I, cuda))

@@ -13,7 +13,7 @@ from oracle import bprmf_oracle as O
 pytestmark = pytest.mark.gpu
 
 N_ITEMS, N_USERS, D, B, K = 10_000_001, 1_000_001, 64, 8192, 99
-LR = 0.05
+LR = 200.0  # large on purpose: every update must be >> 1 fp32 ulp of the weights (see conservation test)
 
 
 @pytest.fixture(scope="module")
@@ -84,13 +84,23 @@ def test_sgd_step_conservation_untouched_rows_and_reproducibility(world):
     U, I, loss = results[0]
     assert torch.equal(U, results[1][0]) and torch.equal(I, results[1][1]), "not bit-reproducible"
     assert torch.equal(loss, results[1][2])
-    # conservation: sum over rows of the update == -lr * sum over occurrences of the row grads
+    # conservation: sum over rows of the update == -lr * sum over occurrences of the row grads.
+    # LR is chosen so every per-element update is >> 1 ulp of the weights (with a realistic lr
+    # the K tiny negative updates round away individually and the sum is dominated by fp32
+    # rounding, in the reference too).  Tolerance: 1e-5 of the absolute-value sum of the
+    # contributions + the rounding of n_touched fp32 stores.
+    ulp = float(np.finfo(np.float32).eps) * float(I0.abs().max())
+    contrib = gpred.double().abs().sum(1)[:, None] * U0[uid].double().abs()
     dI = (I.double() - I0.double()).sum(0)
     want_dI = -LR * (gpred.double().sum(1)[:, None] * U0[uid].double()).sum(0)
-    assert_close(dI.cpu().numpy(), want_dI.cpu().numpy(), rtol=1e-4, atol_scale=1e-4, what="sum dI")
+    n_touched = int(torch.unique(iid).numel())
+    tol_I = 1e-5 * LR * contrib.sum(0) + 8 * np.sqrt(n_touched) * ulp
+    assert bool(((dI - want_dI).abs() <= tol_I).all()), f"sum dI off by {(dI - want_dI).abs().max().item():.3e}"
     dU = (U.double() - U0.double()).sum(0)
     want_dU = -LR * ugrad.double().sum(0)
-    assert_close(dU.cpu().numpy(), want_dU.cpu().numpy(), rtol=1e-4, atol_scale=1e-4, what="sum dU")
+    tol_U = 1e-5 * LR * ugrad.double().abs().sum(0) + 8 * np.sqrt(B) * ulp
+    assert bool(((dU - want_dU).abs() <= tol_U).all()), f"sum dU off by {(dU - want_dU).abs().max().item():.3e}"
+    assert float(dU.abs().max()) > 100 * float(tol_U.max()), "conservation check is vacuous"
     # rows outside the batch are bit-identical
     touched = torch.zeros(N_ITEMS, dtype=torch.bool, device=I.device)
     touched[iid.reshape(-1)] = True
