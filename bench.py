@@ -92,9 +92,9 @@ def algorithmic_bytes(args, batches):
                    + 2 * um * row)      # multi-occurrence item rows: read + written once
     user_update = 8 * B + B * row + 2 * uu * row
     sort_items = 8 * n_occ + 8 * n_occ  # ids in, keys+perm out (one ideal pass)
-    mark = 8 * n_occ + n_occ            # keys + perm in, one flag byte out
+    mark = 8 * n_occ + n_occ + 4 * um   # keys + perm in, one flag byte out, multi-row heads out
     return {"fused_fwd_bwd": fused, "item_update": item_update, "user_update": user_update,
-            "sort_items": sort_items, "mark_singletons": mark, "uniq_items": ui, "uniq_users": uu,
+            "sort_items": sort_items, "segment_heads": mark, "uniq_items": ui, "uniq_users": uu,
             "single_items": us, "multi_items": um, "multi_item_occurrences": mo}
 
 
@@ -242,7 +242,7 @@ def main():
         out["phases_ms"] = {k: round(v, 4) for k, v in acc.items()}
         out["phases_gbps"] = {k: round(ab[k] / (acc[k] * 1e-3) / 1e9, 1)
                               for k in ("fused_fwd_bwd", "item_update", "user_update", "sort_items",
-                                        "mark_singletons") if acc.get(k, 0) > 0}
+                                        "segment_heads") if acc.get(k, 0) > 0}
         out["uniq_rows_per_step"] = {"items": ab["uniq_items"], "users": ab["uniq_users"],
                                      "items_single": ab["single_items"], "items_multi": ab["multi_items"],
                                      "multi_item_occurrences": ab["multi_item_occurrences"]}

@@ -108,7 +108,7 @@ int rc_bprmf_fwd_bwd(const float* U, const float* I, const int64_t* uid,
 int rc_bprmf_fused_supported(int d, int C);
 
 /* rc_bprmf_fwd_bwd that ALSO applies the optimizer `h` to every item row occurring exactly
- * once in the batch (single[b*C+c] != 0, from rc_mark_singletons): such a row is read by no
+ * once in the batch (single[b*C+c] != 0, from rc_segment_heads): such a row is read by no
  * other tuple, its whole gradient g[b,c]*U[uid[b]] is known while the row is still in
  * registers, so it is updated and written back here -- one HBM read and one write per step.
  * Rows with several occurrences are left for rc_segmented_update(RC_SEG_SKIP_SINGLETONS).
@@ -129,14 +129,18 @@ size_t rc_sort_workspace_bytes(int64_t n);
 int rc_sort_ids(const int64_t* ids, int64_t n, int64_t n_rows, uint32_t* keys_out,
                 uint32_t* perm_out, void* ws, size_t ws_bytes, rc_stream_t stream);
 
-/* single[o] = 1 iff occurrence o = perm[j] is the only one of its row (keys/perm from
- * rc_sort_ids), else 0.                                                                  */
-int rc_mark_singletons(const uint32_t* keys, const uint32_t* perm, int64_t n_occ,
-                       uint8_t* single, rc_stream_t stream);
+/* One pass over the sorted ids (keys/perm from rc_sort_ids) that
+ *  - if single != NULL: single[o] = 1 iff occurrence o = perm[j] is the only one of its row;
+ *  - if heads  != NULL: appends to heads[] the sorted positions j that start a segment
+ *    (only_multi != 0: only segments with >= 2 occurrences) and counts them in n_heads[0]
+ *    (device uint32, zeroed here).  The list order is unspecified (integer atomics); no
+ *    floating-point result depends on it.  heads needs room for n_occ entries.            */
+int rc_segment_heads(const uint32_t* keys, const uint32_t* perm, int64_t n_occ, int only_multi,
+                     uint8_t* single, uint32_t* heads, uint32_t* n_heads, rc_stream_t stream);
 
 /* ---- segmented gradient reduction + optimizer row update -------------------------- */
 
-size_t rc_segmented_workspace_bytes(int64_t n_occ);
+size_t rc_segmented_workspace_bytes(int64_t n_occ, int d);
 
 /* For every distinct row r in sorted `keys` (with occurrences o = perm[j], j in the
  * segment of r, visited in ascending j => fixed summation order, no float atomics):
@@ -147,15 +151,18 @@ size_t rc_segmented_workspace_bytes(int64_t n_occ);
  * the optimizer `h` to row r of W in place (and to rows r of the state tables m, v:
  * Adam exp_avg / exp_avg_sq, Adagrad sum in `m`), i.e. a row-wise ("lazy") version of
  * helpers/BaseRunner.py:206 that only touches rows present in the batch.
+ * heads/n_heads: NULL, or the list made by rc_segment_heads (with only_multi set iff
+ * RC_SEG_SKIP_SINGLETONS is given) -- saves re-deriving it.
  * flags: RC_SEG_SKIP_SINGLETONS leaves rows with exactly one occurrence untouched (they
  * were updated by rc_bprmf_fwd_bwd_update).
- * Src must not alias W.  ws from rc_segmented_workspace_bytes(n_occ).                 */
+ * Src must not alias W.  ws from rc_segmented_workspace_bytes(n_occ, d).              */
 enum rc_seg_flags { RC_SEG_SKIP_SINGLETONS = 1 };
 int rc_segmented_update(float* W, float* m, float* v, int d, const uint32_t* keys,
                         const uint32_t* perm, int64_t n_occ, const float* coef,
                         const float* src, const int64_t* src_index, int div,
-                        const rc_opt_hyper* h, float* dense_grad, int flags, void* ws,
-                        size_t ws_bytes, rc_stream_t stream);
+                        const rc_opt_hyper* h, float* dense_grad, const uint32_t* heads,
+                        const uint32_t* n_heads, int flags, void* ws, size_t ws_bytes,
+                        rc_stream_t stream);
 
 /* Exact dense optimizer step over all n elements (torch.optim semantics incl. weight
  * decay on every element, helpers/BaseRunner.py:110-114,206).  m/v as above.         */
@@ -175,7 +182,7 @@ size_t rc_bprmf_step_workspace_bytes(int B, int C, int d);
  * phase_ms: NULL, or a HOST float[8] filled with per-phase milliseconds measured with
  * hipEvents on `stream` (the call then synchronises):
  *   [0] sort item ids [1] sort user ids [2] fused fwd/bwd [3] loss mean
- *   [4] item-row update [5] user-row update [6] total [7] mark singletons              */
+ *   [4] item-row update [5] user-row update [6] total [7] segment heads / singletons   */
 int rc_bprmf_train_step(float* U, float* I, float* mU, float* vU, float* mI, float* vI,
                         const int64_t* uid, const int64_t* iid, int B, int C, int d,
                         int64_t n_users, int64_t n_items, const rc_opt_hyper* h,

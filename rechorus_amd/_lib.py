@@ -58,11 +58,11 @@ SIGNATURES = {
     "rc_bprmf_fwd_bwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _f, _p, _p, _p, _p, _p]),
     "rc_bprmf_fused_supported": (_i, [_i, _i]),
     "rc_bprmf_fwd_bwd_update": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _hp, _p, _p, _p, _p, _p]),
-    "rc_mark_singletons": (_i, [_p, _p, _i64, _p, _p]),
+    "rc_segment_heads": (_i, [_p, _p, _i64, _i, _p, _p, _p, _p]),
     "rc_sort_workspace_bytes": (_sz, [_i64]),
     "rc_sort_ids": (_i, [_p, _i64, _i64, _p, _p, _p, _sz, _p]),
-    "rc_segmented_workspace_bytes": (_sz, [_i64]),
-    "rc_segmented_update": (_i, [_p, _p, _p, _i, _p, _p, _i64, _p, _p, _p, _i, _hp, _p, _i, _p, _sz, _p]),
+    "rc_segmented_workspace_bytes": (_sz, [_i64, _i]),
+    "rc_segmented_update": (_i, [_p, _p, _p, _i, _p, _p, _i64, _p, _p, _p, _i, _hp, _p, _p, _p, _i, _p, _sz, _p]),
     "rc_dense_update": (_i, [_p, _p, _p, _p, _i64, _hp, _p]),
     "rc_bprmf_step_workspace_bytes": (_sz, [_i, _i, _i]),
     "rc_bprmf_train_step": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i64, _i64, _hp, _f,

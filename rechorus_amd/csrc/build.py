@@ -26,9 +26,10 @@ SOURCES = [
     "bprmf_fused.hip",
     "sort_ids.hip",
     "seg_update.hip",
+    "dense_opt.hip",
     "train_step.hip",
 ]
-HEADERS = ["common.hpp", "bpr_math.hpp", os.path.join("..", "..", "include", "rechorus_hip.h")]
+HEADERS = ["common.hpp", "bpr_math.hpp", "opt_math.hpp", os.path.join("..", "..", "include", "rechorus_hip.h")]
 
 
 def _hipcc():
@@ -48,7 +49,10 @@ def _newer(target, deps):
 def build(force=False, no_dpp=False, resource_usage=False, verbose=True):
     os.makedirs(OBJ_DIR, exist_ok=True)
     hipcc = _hipcc()
-    flags = ["-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-Wall", "-Wno-unused-function"]
+    # -ffp-contract=off: only the fmaf() calls written in the kernels fuse, so every template
+    # instantiation of the same expression rounds identically (bit-reproducible across paths)
+    flags = ["-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-Wall", "-Wno-unused-function",
+             "-ffp-contract=off"]
     if no_dpp:
         flags.append("-DRC_NO_DPP")
     if resource_usage:

@@ -6,21 +6,36 @@
 // occurrence) followed by torch.optim's step over the table
 // (helpers/BaseRunner.py:193,205-206; optimizer built at :110-114).
 //
-// Input is the stably sorted id list of the batch (sort_ids.hip).  The lane-group at
-// sorted position j owns row keys[j] iff j is the head of its segment; it sums the
-// segment's per-occurrence gradient rows in ascending j (fixed order -> bit-reproducible,
-// no float atomics), then reads the table row once, applies the update, writes it once.
-// The per-occurrence gradient row is rebuilt on the fly as coef[o] * Src[srow(o)]
-// (for BPRMF items: g[b,c] * U[uid[b]]), so it never exists in HBM.
-// Segments longer than kLongSeg (hot Zipf rows) are deferred to a workgroup-per-row
-// kernel that strides 256/LPR lane-groups over the segment and combines their partials in
-// a fixed LDS tree.  The only atomics are integer appends to the deferred-row list.
+// Input: the stably sorted id list of the batch (sort_ids.hip).  Pipeline:
+//   1. segment_heads_kernel   one thread per sorted position: flags single-occurrence rows
+//                             (for the fused BPRMF kernel) and appends the positions that
+//                             start a segment to a COMPACT list, so that in step 2 every
+//                             lane-group of every wave has a row to work on.
+//   2. seg_update_kernel      one lane-group (d/4 lanes, a float4 each) per listed head:
+//                             sums the segment's gradient rows in ascending sorted position
+//                             (fixed order => bit-reproducible, no float atomics), reads the
+//                             table row once, applies the optimizer, writes it once.  The
+//                             per-occurrence gradient row is rebuilt as coef[o]*Src[srow(o)]
+//                             (BPRMF items: g[b,c] * U[uid[b]], U rows come from L2) and never
+//                             exists in HBM.
+//   3. hot rows (> kLongSeg occurrences, the head of a Zipf distribution) are cut into
+//      kChunk-occurrence chunks (long_plan), each chunk reduced by one workgroup with a
+//      fixed LDS tree (long_chunk), the chunk partials of a row combined in chunk order
+//      (long_final).  Work per block is bounded whatever the skew.
+// The only atomics are INTEGER appends / slot reservations (list order does not influence
+// any floating-point result).
 #include "common.hpp"
 #include "opt_math.hpp"
 
 namespace rc {
 
-constexpr int kLongSeg = 32;  // occurrences handled sequentially by one lane-group
+constexpr int kLongSeg = 32;  // occurrences one lane-group sums sequentially
+constexpr int kChunk = 256;   // occurrences per workgroup for hot rows
+
+struct RowInfo { uint32_t j0, end, pbase, nchunks; };
+struct ChunkInfo { uint32_t row, k; };
+
+enum { CNT_LONG = 0, CNT_CHUNKS = 1, CNT_PARTIAL = 2, CNT_HEADS = 3, CNT_N = 4 };
 
 struct SegArgs {
   float* W;
@@ -35,14 +50,41 @@ struct SegArgs {
   int div;
   int d;  // generic kernels only
   float* dense_grad;
+  const uint32_t* heads;
+  const uint32_t* n_heads;
+  uint32_t* counters;  // CNT_*
   uint32_t* long_list;
-  uint32_t* n_long;
-  uint32_t long_cap;
-  int skip_single;  // 1: single-occurrence rows were already updated by the fused kernel
+  RowInfo* rows;
+  ChunkInfo* chunks;
+  float* partial;
+  uint32_t long_cap, chunk_cap, partial_cap;
+  int skip_single;
   OptScalars o;
 };
 
-// apply the reduced gradient g to row `key` (w = current row slice, already loaded)
+__device__ __forceinline__ void add4(float4& x, const float4& y) {
+  x.x += y.x; x.y += y.y; x.z += y.z; x.w += y.w;
+}
+
+// ---- 1. heads -------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void segment_heads_kernel(
+    const uint32_t* __restrict__ keys, const uint32_t* __restrict__ perm, int64_t n,
+    int only_multi, uint8_t* __restrict__ single, uint32_t* __restrict__ heads,
+    uint32_t* __restrict__ n_heads) {
+  for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < n;
+       j += (int64_t)gridDim.x * kBlock) {
+    const uint32_t k = keys[j];
+    const bool head = j == 0 || keys[j - 1] != k;
+    const bool multi = j + 1 < n && keys[j + 1] == k;
+    if (single) single[perm[j]] = (head && !multi) ? 1 : 0;
+    if (heads && head && (multi || !only_multi)) {
+      const uint32_t slot = atomicAdd(n_heads, 1u);  // wave-aggregated by the compiler
+      heads[slot] = (uint32_t)j;
+    }
+  }
+}
+
+// ---- 2. one lane-group per head ---------------------------------------------------------
 template <int D, int MODE>
 __device__ __forceinline__ void apply_row4(const SegArgs& a, uint32_t key, int l, float4 w,
                                            const float4& g) {
@@ -62,7 +104,7 @@ __device__ __forceinline__ float4 load_row4(const SegArgs& a, uint32_t key, int 
   return reinterpret_cast<const float4*>(a.W)[(size_t)key * LPR + l];
 }
 
-// gradient row of occurrence o (= perm[j]), lane's float4
+// gradient row of occurrence o (= perm[j]), this lane's float4
 template <int D>
 __device__ __forceinline__ float4 occ_grad4_o(const SegArgs& a, uint32_t o, int l) {
   constexpr int LPR = D / 4;
@@ -78,41 +120,35 @@ __device__ __forceinline__ float4 occ_grad4(const SegArgs& a, int64_t jj, int l)
   return occ_grad4_o<D>(a, a.perm[jj], l);
 }
 
-__device__ __forceinline__ void add4(float4& x, const float4& y) {
-  x.x += y.x; x.y += y.y; x.z += y.z; x.w += y.w;
-}
-
-// SKIP = true: single-occurrence rows were updated upstream (fused BPRMF kernel), every
-// surviving head has >= 2 occurrences, so the first two gradient rows are fetched together.
-// Dependent-load depth per row: {keys[j-1..j+1], perm[j], perm[j+1]} -> {W row, coef, index}
-// -> {src rows} -> store.
-template <int D, int MODE, bool SKIP>
+// ONLY_MULTI: the list holds only heads with >= 2 occurrences (singletons were updated by
+// the fused BPRMF kernel), so the first two gradient rows are always fetched together.
+// Dependent-load depth: heads[g] -> {keys[j], keys[j+1], perm[j], perm[j+1]} ->
+// {W row, coef, index} -> {src rows} -> store.
+template <int D, int MODE, bool ONLY_MULTI>
 __global__ __launch_bounds__(kBlock) void seg_update_kernel(SegArgs a) {
   constexpr int LPR = D / 4;
   constexpr int GPB = kBlock / LPR;
   const int l = threadIdx.x % LPR;
   const int64_t n = a.n_occ;
-  const int64_t j = (int64_t)blockIdx.x * GPB + threadIdx.x / LPR;
-  if (j >= n) return;  // no cross-lane ops in this kernel
+  const int64_t g = (int64_t)blockIdx.x * GPB + threadIdx.x / LPR;
+  if (g >= (int64_t)*a.n_heads) return;  // no cross-lane ops in this kernel
+  const int64_t j = a.heads[g];
   const bool has_next = j + 1 < n;
   const uint32_t key = a.keys[j];
-  const uint32_t kprev = j > 0 ? a.keys[j - 1] : ~key;
   const uint32_t knext = has_next ? a.keys[j + 1] : ~key;
   const uint32_t o0 = a.perm[j];
   const uint32_t o1 = a.perm[has_next ? j + 1 : j];
-  if (kprev == key) return;  // not a segment head
   const bool multi = knext == key;
-  if (SKIP && !multi) return;  // singleton: already updated by the fused kernel
   const float4 w = load_row4<D, MODE>(a, key, l);
   float4 acc = occ_grad4_o<D>(a, o0, l);
-  if (SKIP || multi) {
+  if (ONLY_MULTI || multi) {
     const float4 s1 = occ_grad4_o<D>(a, o1, l);
     add4(acc, s1);
     int64_t jj = j + 2;
     while (jj < n && a.keys[jj] == key) {
-      if (jj - j >= kLongSeg) {  // hot row: hand over to the workgroup-per-row kernel
+      if (jj - j >= kLongSeg) {  // hot row: hand over to the chunked path
         if (l == 0) {
-          const uint32_t slot = atomicAdd(a.n_long, 1u);
+          const uint32_t slot = atomicAdd(&a.counters[CNT_LONG], 1u);
           if (slot < a.long_cap) a.long_list[slot] = (uint32_t)j;
         }
         return;
@@ -125,7 +161,8 @@ __global__ __launch_bounds__(kBlock) void seg_update_kernel(SegArgs a) {
   apply_row4<D, MODE>(a, key, l, w, acc);
 }
 
-// end of the segment that starts at j0 (first index with a different key)
+// ---- 3. hot rows ----------------------------------------------------------------------------
+// end of the segment that starts at j0 (first index with a different key): gallop + bisect
 __device__ __forceinline__ int64_t segment_end(const uint32_t* __restrict__ keys, int64_t n,
                                                int64_t j0) {
   const uint32_t key = keys[j0];
@@ -145,24 +182,63 @@ __device__ __forceinline__ int64_t segment_end(const uint32_t* __restrict__ keys
   return hi;
 }
 
+__global__ __launch_bounds__(kBlock) void long_plan_kernel(SegArgs a) {
+  uint32_t n_long = a.counters[CNT_LONG];
+  if (n_long > a.long_cap) n_long = a.long_cap;
+  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n_long; i += gridDim.x * kBlock) {
+    const int64_t j0 = a.long_list[i];
+    const int64_t end = segment_end(a.keys, a.n_occ, j0);
+    const uint32_t nch = (uint32_t)((end - j0 + kChunk - 1) / kChunk);
+    RowInfo r;
+    r.j0 = (uint32_t)j0;
+    r.end = (uint32_t)end;
+    r.nchunks = nch;
+    r.pbase = nch >= 2 ? atomicAdd(&a.counters[CNT_PARTIAL], nch) : 0xFFFFFFFFu;
+    a.rows[i] = r;
+    const uint32_t cbase = atomicAdd(&a.counters[CNT_CHUNKS], nch);
+    for (uint32_t k = 0; k < nch; ++k)
+      if (cbase + k < a.chunk_cap) {
+        ChunkInfo c;
+        c.row = i;
+        c.k = k;
+        a.chunks[cbase + k] = c;
+      }
+  }
+}
+
+// LDS tree over the GPB lane-groups of a block, fixed order; result in group 0's slots
+template <int LPR>
+__device__ __forceinline__ void block_tree_sum(float4* part, int g) {
+  constexpr int GPB = kBlock / LPR;
+#pragma unroll
+  for (int off = GPB / 2; off >= 1; off >>= 1) {
+    __syncthreads();
+    if (g < off) {
+      float4 x = part[threadIdx.x];
+      add4(x, part[threadIdx.x + off * LPR]);
+      part[threadIdx.x] = x;
+    }
+  }
+  __syncthreads();
+}
+
 template <int D, int MODE>
-__global__ __launch_bounds__(kBlock) void seg_update_long_kernel(SegArgs a) {
+__global__ __launch_bounds__(kBlock) void long_chunk_kernel(SegArgs a) {
   constexpr int LPR = D / 4;
   constexpr int GPB = kBlock / LPR;
   __shared__ float4 part[kBlock];
-  __shared__ int64_t s_end;
   const int l = threadIdx.x % LPR;
   const int g = threadIdx.x / LPR;
-  uint32_t n_long = *a.n_long;
-  if (n_long > a.long_cap) n_long = a.long_cap;
-  for (uint32_t i = blockIdx.x; i < n_long; i += gridDim.x) {
-    const int64_t j0 = a.long_list[i];
-    if (threadIdx.x == 0) s_end = segment_end(a.keys, a.n_occ, j0);
-    __syncthreads();
-    const int64_t end = s_end;
+  uint32_t n_chunks = a.counters[CNT_CHUNKS];
+  if (n_chunks > a.chunk_cap) n_chunks = a.chunk_cap;
+  for (uint32_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+    const ChunkInfo ci = a.chunks[c];
+    const RowInfo ri = a.rows[ci.row];
+    const int64_t start = (int64_t)ri.j0 + (int64_t)ci.k * kChunk;
+    const int64_t end = (start + kChunk < (int64_t)ri.end) ? start + kChunk : (int64_t)ri.end;
     // four independent occurrences per lane-group per trip (fixed pattern -> fixed order)
     float4 acc = make_float4(0, 0, 0, 0);
-    for (int64_t jj = j0 + g; jj < end; jj += 4 * GPB) {
+    for (int64_t jj = start + g; jj < end; jj += 4 * GPB) {
       const float4 z = make_float4(0, 0, 0, 0);
       const float4 s0 = occ_grad4<D>(a, jj, l);
       const float4 s1 = (jj + GPB < end) ? occ_grad4<D>(a, jj + GPB, l) : z;
@@ -171,21 +247,42 @@ __global__ __launch_bounds__(kBlock) void seg_update_long_kernel(SegArgs a) {
       add4(acc, s0); add4(acc, s1); add4(acc, s2); add4(acc, s3);
     }
     part[threadIdx.x] = acc;
-    __syncthreads();
-    for (int off = GPB / 2; off >= 1; off >>= 1) {
-      if (g < off) {
-        float4 x = part[threadIdx.x];
-        const float4 y = part[threadIdx.x + off * LPR];
-        x.x += y.x; x.y += y.y; x.z += y.z; x.w += y.w;
-        part[threadIdx.x] = x;
-      }
-      __syncthreads();
-    }
+    block_tree_sum<LPR>(part, g);
     if (g == 0) {
-      const uint32_t key = a.keys[j0];
+      if (ri.nchunks == 1) {
+        const uint32_t key = a.keys[ri.j0];
+        apply_row4<D, MODE>(a, key, l, load_row4<D, MODE>(a, key, l), part[threadIdx.x]);
+      } else if (ri.pbase + ci.k < a.partial_cap) {
+        reinterpret_cast<float4*>(a.partial)[(size_t)(ri.pbase + ci.k) * LPR + l] = part[threadIdx.x];
+      }
+    }
+    __syncthreads();  // part[] is reused by the next chunk
+  }
+}
+
+template <int D, int MODE>
+__global__ __launch_bounds__(kBlock) void long_final_kernel(SegArgs a) {
+  constexpr int LPR = D / 4;
+  constexpr int GPB = kBlock / LPR;
+  __shared__ float4 part[kBlock];
+  const int l = threadIdx.x % LPR;
+  const int g = threadIdx.x / LPR;
+  uint32_t n_long = a.counters[CNT_LONG];
+  if (n_long > a.long_cap) n_long = a.long_cap;
+  for (uint32_t i = blockIdx.x; i < n_long; i += gridDim.x) {
+    const RowInfo ri = a.rows[i];
+    if (ri.nchunks < 2) continue;  // block-uniform
+    float4 acc = make_float4(0, 0, 0, 0);
+    for (uint32_t k = g; k < ri.nchunks; k += GPB)
+      if (ri.pbase + k < a.partial_cap)
+        add4(acc, reinterpret_cast<const float4*>(a.partial)[(size_t)(ri.pbase + k) * LPR + l]);
+    part[threadIdx.x] = acc;
+    block_tree_sum<LPR>(part, g);
+    if (g == 0) {
+      const uint32_t key = a.keys[ri.j0];
       apply_row4<D, MODE>(a, key, l, load_row4<D, MODE>(a, key, l), part[threadIdx.x]);
     }
-    __syncthreads();  // part[] and s_end are reused by the next row
+    __syncthreads();
   }
 }
 
@@ -228,7 +325,7 @@ __device__ __forceinline__ void occ_grad_generic(const SegArgs& a, int64_t jj, i
   }
 }
 
-// generic path handles segments of any length sequentially (correctness fall-back)
+// generic path: position-indexed, segments of any length summed sequentially (fall-back)
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void seg_update_generic_kernel(SegArgs a) {
   const int lane = threadIdx.x & 63;
@@ -244,27 +341,44 @@ __global__ __launch_bounds__(kBlock) void seg_update_generic_kernel(SegArgs a) {
   apply_row_generic<MODE>(a, key, lane, acc);
 }
 
+// ---- launchers ------------------------------------------------------------------------------
+static int launch_heads(const uint32_t* keys, const uint32_t* perm, int64_t n, int only_multi,
+                        uint8_t* single, uint32_t* heads, uint32_t* n_heads, hipStream_t s) {
+  if (heads) RC_HIP(hipMemsetAsync(n_heads, 0, sizeof(uint32_t), s));
+  int64_t blocks = (n + kBlock - 1) / kBlock;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(segment_heads_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, s, keys, perm,
+                     n, only_multi, single, heads, n_heads);
+  RC_LAUNCH_CHECK();
+  return RC_OK;
+}
+
 template <int D, int MODE>
 static int launch_seg(const SegArgs& a, hipStream_t s) {
   constexpr int GPB = kBlock / (D / 4);
-  const int64_t blocks = (a.n_occ + GPB - 1) / GPB;
+  // upper bound on the number of listed heads: every position, or every second one
+  const int64_t max_heads = a.skip_single ? (a.n_occ + 1) / 2 : a.n_occ;
+  const int64_t blocks = (max_heads + GPB - 1) / GPB;
   if (blocks > kMaxGridX) return fail(RC_ERR_UNSUPPORTED, "seg_update: grid too large");
-  RC_HIP(hipMemsetAsync(a.n_long, 0, sizeof(uint32_t), s));
   if (a.skip_single)
     hipLaunchKernelGGL((seg_update_kernel<D, MODE, true>), dim3((unsigned)blocks), dim3(kBlock), 0, s, a);
   else
     hipLaunchKernelGGL((seg_update_kernel<D, MODE, false>), dim3((unsigned)blocks), dim3(kBlock), 0, s, a);
   RC_LAUNCH_CHECK();
-  unsigned lblocks = a.long_cap < 1024u ? a.long_cap : 1024u;
-  if (lblocks == 0) lblocks = 1;
-  hipLaunchKernelGGL((seg_update_long_kernel<D, MODE>), dim3(lblocks), dim3(kBlock), 0, s, a);
-  RC_LAUNCH_CHECK();
+  if (a.n_occ > kLongSeg) {  // otherwise no segment can be long
+    hipLaunchKernelGGL(long_plan_kernel, dim3(64), dim3(kBlock), 0, s, a);
+    RC_LAUNCH_CHECK();
+    hipLaunchKernelGGL((long_chunk_kernel<D, MODE>), dim3(1024), dim3(kBlock), 0, s, a);
+    RC_LAUNCH_CHECK();
+    hipLaunchKernelGGL((long_final_kernel<D, MODE>), dim3(256), dim3(kBlock), 0, s, a);
+    RC_LAUNCH_CHECK();
+  }
   return RC_OK;
 }
 
 template <int MODE>
-static int launch_seg_mode(const SegArgs& a, bool aligned, hipStream_t s) {
-  if (aligned) {
+static int launch_seg_mode(const SegArgs& a, bool vec_ok, hipStream_t s) {
+  if (vec_ok) {
     switch (a.d) {
       case 16: return launch_seg<16, MODE>(a, s);
       case 32: return launch_seg<32, MODE>(a, s);
@@ -284,118 +398,76 @@ static int launch_seg_mode(const SegArgs& a, bool aligned, hipStream_t s) {
   return RC_OK;
 }
 
-// ---- dense (exact torch semantics) optimizer step over a whole tensor -------------------
-template <int MODE>
-__global__ __launch_bounds__(kBlock) void dense_update_kernel(SegArgs a, const float* __restrict__ G,
-                                                              int64_t n) {
-  const int64_t n4 = n / 4;
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n4;
-       i += (int64_t)gridDim.x * kBlock) {
-    const float4 g = reinterpret_cast<const float4*>(G)[i];
-    float4 w = reinterpret_cast<const float4*>(a.W)[i];
-    float4 m = make_float4(0, 0, 0, 0), v = make_float4(0, 0, 0, 0);
-    if (MODE == MODE_ADAM || MODE == MODE_ADAGRAD) m = reinterpret_cast<const float4*>(a.M)[i];
-    if (MODE == MODE_ADAM) v = reinterpret_cast<const float4*>(a.V)[i];
-    opt_elem<MODE>(a.o, g.x, w.x, m.x, v.x);
-    opt_elem<MODE>(a.o, g.y, w.y, m.y, v.y);
-    opt_elem<MODE>(a.o, g.z, w.z, m.z, v.z);
-    opt_elem<MODE>(a.o, g.w, w.w, m.w, v.w);
-    reinterpret_cast<float4*>(a.W)[i] = w;
-    if (MODE == MODE_ADAM || MODE == MODE_ADAGRAD) reinterpret_cast<float4*>(a.M)[i] = m;
-    if (MODE == MODE_ADAM) reinterpret_cast<float4*>(a.V)[i] = v;
-  }
-  // tail (n % 4 elements)
-  const int64_t i = n4 * 4 + (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (i < n) {
-    float w = a.W[i], m = 0.f, v = 0.f;
-    if (MODE == MODE_ADAM || MODE == MODE_ADAGRAD) m = a.M[i];
-    if (MODE == MODE_ADAM) v = a.V[i];
-    opt_elem<MODE>(a.o, G[i], w, m, v);
-    a.W[i] = w;
-    if (MODE == MODE_ADAM || MODE == MODE_ADAGRAD) a.M[i] = m;
-    if (MODE == MODE_ADAM) a.V[i] = v;
-  }
-}
+static bool vector_kernel_for(int d) { return d == 16 || d == 32 || d == 64 || d == 128 || d == 256; }
 
-template <int MODE>
-__global__ __launch_bounds__(kBlock) void dense_update_scalar_kernel(SegArgs a,
-                                                                     const float* __restrict__ G,
-                                                                     int64_t n) {
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n;
-       i += (int64_t)gridDim.x * kBlock) {
-    float w = a.W[i], m = 0.f, v = 0.f;
-    if (MODE == MODE_ADAM || MODE == MODE_ADAGRAD) m = a.M[i];
-    if (MODE == MODE_ADAM) v = a.V[i];
-    opt_elem<MODE>(a.o, G[i], w, m, v);
-    a.W[i] = w;
-    if (MODE == MODE_ADAM || MODE == MODE_ADAGRAD) a.M[i] = m;
-    if (MODE == MODE_ADAM) a.V[i] = v;
-  }
-}
+struct SegWs {
+  uint32_t* counters;
+  uint32_t* heads;
+  uint32_t* long_list;
+  RowInfo* rows;
+  ChunkInfo* chunks;
+  float* partial;
+  uint32_t long_cap, chunk_cap, partial_cap;
+  size_t total;
+};
 
-template <int MODE>
-static int launch_dense(const SegArgs& a, const float* G, int64_t n, bool aligned, hipStream_t s) {
-  int64_t work = aligned ? (n / 4 > 0 ? n / 4 : 1) : n;
-  int64_t blocks = (work + kBlock - 1) / kBlock;
-  if (blocks > 256 * 16) blocks = 256 * 16;
-  if (blocks < 1) blocks = 1;
-  if (aligned)
-    hipLaunchKernelGGL((dense_update_kernel<MODE>), dim3((unsigned)blocks), dim3(kBlock), 0, s, a, G, n);
-  else
-    hipLaunchKernelGGL((dense_update_scalar_kernel<MODE>), dim3((unsigned)blocks), dim3(kBlock), 0, s, a, G, n);
-  RC_LAUNCH_CHECK();
-  return RC_OK;
+static SegWs carve_seg_ws(void* base, int64_t n_occ, int d) {
+  Carver cv(base);
+  SegWs w;
+  w.long_cap = (uint32_t)(n_occ / kLongSeg) + 1;
+  w.chunk_cap = (uint32_t)(n_occ / kChunk) + w.long_cap + 1;
+  w.partial_cap = 2 * (uint32_t)(n_occ / kChunk) + 2;
+  w.counters = cv.take<uint32_t>(CNT_N);
+  w.heads = cv.take<uint32_t>((size_t)n_occ);
+  w.long_list = cv.take<uint32_t>(w.long_cap);
+  w.rows = cv.take<RowInfo>(w.long_cap);
+  w.chunks = cv.take<ChunkInfo>(w.chunk_cap);
+  w.partial = cv.take<float>((size_t)w.partial_cap * (size_t)d);
+  w.total = cv.off;
+  return w;
 }
 
 }  // namespace rc
 
 using namespace rc;
 
-// flag[o] = 1 iff occurrence o is the only one of its row in the batch
-__global__ __launch_bounds__(rc::kBlock) void mark_singletons_kernel(
-    const uint32_t* __restrict__ keys, const uint32_t* __restrict__ perm, int64_t n,
-    uint8_t* __restrict__ flag) {
-  for (int64_t j = (int64_t)blockIdx.x * rc::kBlock + threadIdx.x; j < n;
-       j += (int64_t)gridDim.x * rc::kBlock) {
-    const uint32_t k = keys[j];
-    const bool single = (j == 0 || keys[j - 1] != k) && (j + 1 >= n || keys[j + 1] != k);
-    flag[perm[j]] = single ? 1 : 0;
+extern "C" int rc_segment_heads(const uint32_t* keys, const uint32_t* perm, int64_t n_occ,
+                                int only_multi, uint8_t* single, uint32_t* heads,
+                                uint32_t* n_heads, rc_stream_t stream) {
+  RC_REQUIRE(n_occ >= 0 && n_occ < ((int64_t)1 << 31), "rc_segment_heads: bad n_occ");
+  RC_REQUIRE((heads == nullptr) == (n_heads == nullptr), "rc_segment_heads: heads and n_heads go together");
+  if (n_occ == 0) {
+    if (n_heads) RC_HIP(hipMemsetAsync(n_heads, 0, sizeof(uint32_t), as_stream(stream)));
+    return RC_OK;
   }
+  RC_REQUIRE(keys && perm, "rc_segment_heads: null pointer");
+  RC_REQUIRE(single || heads, "rc_segment_heads: nothing to compute");
+  return launch_heads(keys, perm, n_occ, only_multi, single, heads, n_heads, as_stream(stream));
 }
 
-extern "C" int rc_mark_singletons(const uint32_t* keys, const uint32_t* perm, int64_t n_occ,
-                                  uint8_t* flag, rc_stream_t stream) {
-  if (n_occ == 0) return RC_OK;
-  RC_REQUIRE(keys && perm && flag, "rc_mark_singletons: null pointer");
-  RC_REQUIRE(n_occ > 0 && n_occ < ((int64_t)1 << 31), "rc_mark_singletons: bad n_occ");
-  int64_t blocks = (n_occ + kBlock - 1) / kBlock;
-  if (blocks > 256 * 16) blocks = 256 * 16;
-  hipLaunchKernelGGL(mark_singletons_kernel, dim3((unsigned)blocks), dim3(kBlock), 0,
-                     as_stream(stream), keys, perm, n_occ, flag);
-  RC_LAUNCH_CHECK();
-  return RC_OK;
-}
-
-extern "C" size_t rc_segmented_workspace_bytes(int64_t n_occ) {
+extern "C" size_t rc_segmented_workspace_bytes(int64_t n_occ, int d) {
   if (n_occ < 1) n_occ = 1;
-  const size_t cap = (size_t)(n_occ / kLongSeg) + 1;
-  return align_up(cap * sizeof(uint32_t), 256) + 256;
+  if (d < 1) d = 1;
+  return carve_seg_ws(nullptr, n_occ, d).total;
 }
 
 extern "C" int rc_segmented_update(float* W, float* m, float* v, int d, const uint32_t* keys,
                                    const uint32_t* perm, int64_t n_occ, const float* coef,
                                    const float* src, const int64_t* src_index, int div,
-                                   const rc_opt_hyper* h, float* dense_grad, int flags, void* ws,
-                                   size_t ws_bytes, rc_stream_t stream) {
+                                   const rc_opt_hyper* h, float* dense_grad,
+                                   const uint32_t* heads, const uint32_t* n_heads, int flags,
+                                   void* ws, size_t ws_bytes, rc_stream_t stream) {
   if (n_occ == 0) return RC_OK;
   RC_REQUIRE(keys && perm && src && ws, "rc_segmented_update: null pointer");
-  RC_REQUIRE(d >= 1 && div >= 1 && n_occ >= 0 && n_occ < ((int64_t)1 << 31),
+  RC_REQUIRE(d >= 1 && div >= 1 && n_occ > 0 && n_occ < ((int64_t)1 << 31),
              "rc_segmented_update: bad shape d=%d div=%d n_occ=%lld", d, div, (long long)n_occ);
   RC_REQUIRE(dense_grad != nullptr || W != nullptr, "rc_segmented_update: no output (W or dense_grad)");
-  if (n_occ == 0) return RC_OK;
-  if (ws_bytes < rc_segmented_workspace_bytes(n_occ))
-    return fail(RC_ERR_WORKSPACE, "rc_segmented_update: workspace %zu < %zu", ws_bytes,
-                rc_segmented_workspace_bytes(n_occ));
+  RC_REQUIRE((heads == nullptr) == (n_heads == nullptr),
+             "rc_segmented_update: heads and n_heads go together");
+  const SegWs w = carve_seg_ws(ws, n_occ, d);
+  if (ws_bytes < w.total)
+    return fail(RC_ERR_WORKSPACE, "rc_segmented_update: workspace %zu < %zu", ws_bytes, w.total);
+  hipStream_t s = as_stream(stream);
   SegArgs a;
   memset(&a, 0, sizeof(a));
   a.W = W; a.M = m; a.V = v;
@@ -403,59 +475,37 @@ extern "C" int rc_segmented_update(float* W, float* m, float* v, int d, const ui
   a.coef = coef; a.src = src; a.src_index = src_index; a.div = div; a.d = d;
   a.dense_grad = dense_grad;
   a.skip_single = (flags & RC_SEG_SKIP_SINGLETONS) ? 1 : 0;
-  Carver cv(ws);
-  a.n_long = cv.take<uint32_t>(1);
-  a.long_cap = (uint32_t)(n_occ / kLongSeg) + 1;
-  a.long_list = cv.take<uint32_t>(a.long_cap);
-  hipStream_t s = as_stream(stream);
-  bool aligned = (d % 4 == 0) && (reinterpret_cast<uintptr_t>(src) % 16 == 0);
+  a.counters = w.counters; a.long_list = w.long_list; a.rows = w.rows; a.chunks = w.chunks;
+  a.partial = w.partial;
+  a.long_cap = w.long_cap; a.chunk_cap = w.chunk_cap; a.partial_cap = w.partial_cap;
+  auto al = [](const void* p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; };
+  bool vec_ok = vector_kernel_for(d) && al(src);
+  int mode = MODE_DENSE_GRAD;
   if (dense_grad) {
-    aligned = aligned && (reinterpret_cast<uintptr_t>(dense_grad) % 16 == 0);
-    return launch_seg_mode<MODE_DENSE_GRAD>(a, aligned, s);
+    vec_ok = vec_ok && al(dense_grad);
+  } else {
+    RC_TRY(fill_opt_scalars(h, &a.o));
+    mode = mode_of(h);
+    RC_REQUIRE(mode != MODE_ADAM || (m && v), "rc_segmented_update: Adam needs m and v");
+    RC_REQUIRE(mode != MODE_ADAGRAD || m, "rc_segmented_update: Adagrad needs m (state_sum)");
+    vec_ok = vec_ok && al(W) && al(m) && al(v);
   }
-  RC_TRY(fill_opt_scalars(h, &a.o));
-  aligned = aligned && (reinterpret_cast<uintptr_t>(W) % 16 == 0);
-  switch (h->opt) {
-    case RC_OPT_SGD:
-      return launch_seg_mode<MODE_SGD>(a, aligned, s);
-    case RC_OPT_ADAM:
-      RC_REQUIRE(m && v, "rc_segmented_update: Adam needs m and v");
-      aligned = aligned && (reinterpret_cast<uintptr_t>(m) % 16 == 0) &&
-                (reinterpret_cast<uintptr_t>(v) % 16 == 0);
-      return launch_seg_mode<MODE_ADAM>(a, aligned, s);
-    case RC_OPT_ADAGRAD:
-      RC_REQUIRE(m, "rc_segmented_update: Adagrad needs m (state_sum)");
-      aligned = aligned && (reinterpret_cast<uintptr_t>(m) % 16 == 0);
-      return launch_seg_mode<MODE_ADAGRAD>(a, aligned, s);
-    default:
-      return fail(RC_ERR_INVALID_ARG, "rc_segmented_update: unknown optimizer %d", h->opt);
+  RC_HIP(hipMemsetAsync(w.counters, 0, CNT_N * sizeof(uint32_t), s));
+  if (vec_ok) {
+    if (heads) {
+      a.heads = heads;
+      a.n_heads = n_heads;
+    } else {  // build the compact head list here
+      RC_TRY(launch_heads(keys, perm, n_occ, a.skip_single, nullptr, w.heads,
+                          &w.counters[CNT_HEADS], s));
+      a.heads = w.heads;
+      a.n_heads = &w.counters[CNT_HEADS];
+    }
   }
-}
-
-extern "C" int rc_dense_update(float* W, const float* G, float* m, float* v, int64_t n,
-                               const rc_opt_hyper* h, rc_stream_t stream) {
-  if (n == 0) return RC_OK;
-  RC_REQUIRE(W && G, "rc_dense_update: null pointer");
-  RC_REQUIRE(n > 0, "rc_dense_update: n < 0");
-  SegArgs a;
-  memset(&a, 0, sizeof(a));
-  a.W = W; a.M = m; a.V = v;
-  RC_TRY(fill_opt_scalars(h, &a.o));
-  hipStream_t s = as_stream(stream);
-  bool aligned = (reinterpret_cast<uintptr_t>(W) % 16 == 0) && (reinterpret_cast<uintptr_t>(G) % 16 == 0);
-  switch (h->opt) {
-    case RC_OPT_SGD:
-      return launch_dense<MODE_SGD>(a, G, n, aligned, s);
-    case RC_OPT_ADAM:
-      RC_REQUIRE(m && v, "rc_dense_update: Adam needs m and v");
-      aligned = aligned && (reinterpret_cast<uintptr_t>(m) % 16 == 0) &&
-                (reinterpret_cast<uintptr_t>(v) % 16 == 0);
-      return launch_dense<MODE_ADAM>(a, G, n, aligned, s);
-    case RC_OPT_ADAGRAD:
-      RC_REQUIRE(m, "rc_dense_update: Adagrad needs m (state_sum)");
-      aligned = aligned && (reinterpret_cast<uintptr_t>(m) % 16 == 0);
-      return launch_dense<MODE_ADAGRAD>(a, G, n, aligned, s);
-    default:
-      return fail(RC_ERR_INVALID_ARG, "rc_dense_update: unknown optimizer %d", h->opt);
+  switch (mode) {
+    case MODE_DENSE_GRAD: return launch_seg_mode<MODE_DENSE_GRAD>(a, vec_ok, s);
+    case MODE_SGD: return launch_seg_mode<MODE_SGD>(a, vec_ok, s);
+    case MODE_ADAM: return launch_seg_mode<MODE_ADAM>(a, vec_ok, s);
+    default: return launch_seg_mode<MODE_ADAGRAD>(a, vec_ok, s);
   }
 }

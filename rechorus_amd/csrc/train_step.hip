@@ -26,6 +26,8 @@ struct StepWs {
   float* ugrad;
   float* loss_vec;
   uint8_t* single;
+  uint32_t* heads_i;
+  uint32_t* n_heads_i;
   void* sort_ws;
   size_t sort_ws_bytes;
   void* seg_ws;
@@ -45,9 +47,11 @@ StepWs carve_step_ws(void* base, int B, int C, int d) {
   w.ugrad = cv.take<float>((size_t)B * d);
   w.loss_vec = cv.take<float>((size_t)B);
   w.single = cv.take<uint8_t>(n_i);
+  w.heads_i = cv.take<uint32_t>(n_i);
+  w.n_heads_i = cv.take<uint32_t>(1);
   w.sort_ws_bytes = rc_sort_workspace_bytes((int64_t)n_i);
   w.sort_ws = cv.take<char>(w.sort_ws_bytes);
-  w.seg_ws_bytes = rc_segmented_workspace_bytes((int64_t)n_i);
+  w.seg_ws_bytes = rc_segmented_workspace_bytes((int64_t)n_i, d);
   w.seg_ws = cv.take<char>(w.seg_ws_bytes);
   w.total = cv.off;
   return w;
@@ -88,7 +92,8 @@ extern "C" int rc_bprmf_train_step(float* U, float* I, float* mU, float* vU, flo
   RC_MARK(0);
   RC_TRY(rc_sort_ids(iid, n_i, n_items, w.keys_i, w.perm_i, w.sort_ws, w.sort_ws_bytes, stream));
   RC_MARK(1);
-  if (fused_upd) RC_TRY(rc_mark_singletons(w.keys_i, w.perm_i, n_i, w.single, stream));
+  if (fused_upd)
+    RC_TRY(rc_segment_heads(w.keys_i, w.perm_i, n_i, 1, w.single, w.heads_i, w.n_heads_i, stream));
   RC_MARK(2);
   RC_TRY(rc_sort_ids(uid, B, n_users, w.keys_u, w.perm_u, w.sort_ws, w.sort_ws_bytes, stream));
   RC_MARK(3);
@@ -103,12 +108,14 @@ extern "C" int rc_bprmf_train_step(float* U, float* I, float* mU, float* vU, flo
   RC_MARK(5);
   // item rows: grad_r = sum_{(b,c): iid[b,c]=r} g[b,c] * U[uid[b]]
   RC_TRY(rc_segmented_update(I, mI, vI, d, w.keys_i, w.perm_i, n_i, w.gpred, U, uid, C, h,
-                             nullptr, fused_upd ? RC_SEG_SKIP_SINGLETONS : 0, w.seg_ws,
-                             w.seg_ws_bytes, stream));
+                             nullptr, fused_upd ? w.heads_i : nullptr,
+                             fused_upd ? w.n_heads_i : nullptr,
+                             fused_upd ? RC_SEG_SKIP_SINGLETONS : 0, w.seg_ws, w.seg_ws_bytes,
+                             stream));
   RC_MARK(6);
   // user rows: grad_r = sum_{b: uid[b]=r} ugrad[b]
   RC_TRY(rc_segmented_update(U, mU, vU, d, w.keys_u, w.perm_u, B, nullptr, w.ugrad, nullptr, 1, h,
-                             nullptr, 0, w.seg_ws, w.seg_ws_bytes, stream));
+                             nullptr, nullptr, nullptr, 0, w.seg_ws, w.seg_ws_bytes, stream));
   RC_MARK(7);
 #undef RC_MARK
 

@@ -137,12 +137,23 @@ def sort_ids(ids, n_rows):
     return keys, perm
 
 
+def segment_heads(keys, perm, only_multi=False, want_single=True, want_heads=True):
+    """One pass over sorted ids -> (single uint8[n]|None, heads int32[n]|None, n_heads int32[1]|None)."""
+    n = keys.numel()
+    dev = keys.device
+    single = torch.empty(n, dtype=torch.uint8, device=dev) if want_single else None
+    heads = torch.empty(max(n, 1), dtype=torch.int32, device=dev) if want_heads else None
+    n_heads = torch.zeros(1, dtype=torch.int32, device=dev) if want_heads else None
+    _lib.call("rc_segment_heads", _ptr(keys, torch.int32, "keys"), _ptr(perm, torch.int32, "perm"), n,
+              1 if only_multi else 0, _ptr(single, torch.uint8, "single", True),
+              _ptr(heads, torch.int32, "heads", True), _ptr(n_heads, torch.int32, "n_heads", True),
+              _stream())
+    return single, heads, n_heads
+
+
 def mark_singletons(keys, perm):
     """uint8 flag per occurrence: 1 iff its row occurs exactly once in the batch."""
-    flag = torch.empty(keys.numel(), dtype=torch.uint8, device=keys.device)
-    _lib.call("rc_mark_singletons", _ptr(keys, torch.int32, "keys"), _ptr(perm, torch.int32, "perm"),
-              keys.numel(), _ptr(flag, torch.uint8, "flag"), _stream())
-    return flag
+    return segment_heads(keys, perm, want_heads=False)[0]
 
 
 def bprmf_fwd_bwd_update(U, I, uid, iid, single, hyper, mI=None, vI=None, inv_b=None, want_pred=False):
@@ -167,14 +178,15 @@ def bprmf_fwd_bwd_update(U, I, uid, iid, single, hyper, mI=None, vI=None, inv_b=
 
 
 def segmented_update(keys, perm, src, hyper=None, W=None, m=None, v=None, coef=None,
-                     src_index=None, div=1, dense_grad=None, skip_singletons=False):
+                     src_index=None, div=1, dense_grad=None, skip_singletons=False, heads=None,
+                     n_heads=None):
     """rc_segmented_update: per distinct row r, grad_r = sum coef[o]*src[srow(o)], then either
     write dense_grad[r] or apply the optimizer to W[r] (and m, v) in place."""
     n_occ = keys.numel()
     d = src.shape[-1]
     dev = keys.device
     lib = _lib.load()
-    ws = workspace(lib.rc_segmented_workspace_bytes(n_occ), dev, "seg")
+    ws = workspace(lib.rc_segmented_workspace_bytes(n_occ, d), dev, "seg")
     hp = C.byref(hyper) if hyper is not None else None
     _lib.call("rc_segmented_update",
               _ptr(W, torch.float32, "W", allow_none=True),
@@ -184,6 +196,7 @@ def segmented_update(keys, perm, src, hyper=None, W=None, m=None, v=None, coef=N
               _ptr(coef, torch.float32, "coef", allow_none=True), _ptr(src, torch.float32, "src"),
               _ptr(src_index, torch.int64, "src_index", allow_none=True), int(div), hp,
               _ptr(dense_grad, torch.float32, "dense_grad", allow_none=True),
+              _ptr(heads, torch.int32, "heads", True), _ptr(n_heads, torch.int32, "n_heads", True),
               _lib.RC_SEG_SKIP_SINGLETONS if skip_singletons else 0,
               C.c_void_p(ws.data_ptr()), ws.numel(), _stream())
 
@@ -267,5 +280,5 @@ class BprmfTrainer:
         buf = (C.c_float * 8)()
         self.step(uid, iid, phase_ms=buf)
         names = ["sort_items", "sort_users", "fused_fwd_bwd", "loss_mean", "item_update",
-                 "user_update", "total", "mark_singletons"]
+                 "user_update", "total", "segment_heads"]
         return {n: float(buf[i]) for i, n in enumerate(names)}

@@ -295,7 +295,14 @@ def test_singleton_fast_path_is_bit_identical_to_segmented_path(opt, lr, l2, d, 
         eng.segmented_update(keys, perm, Ud, hyper=h, W=Id, m=m, v=v, coef=gp.reshape(-1),
                              src_index=uid_d, div=C, skip_singletons=fast)
         res.append((Id, m, v, lv, gp, ug))
-    for a, b in zip(res[0], res[1]):
-        if a is not None:
-            assert torch.equal(a, b)
+    names = ("I", "m", "v", "loss_vec", "gpred", "ugrad")
+    for nm, a, b in zip(names, res[0], res[1]):
+        if a is None or torch.equal(a, b):
+            continue
+        diff = (a != b)
+        msg = f"{nm}: {int(diff.sum())} elements differ, max |diff| {(a - b).abs().max().item():.3e}"
+        if a.dim() == 2 and a.shape[0] == n_items:
+            rows = torch.nonzero(diff.any(dim=1)).reshape(-1).cpu().numpy()
+            msg += f"; rows differing: {len(rows)} of which singleton {int((cnt[rows] == 1).sum())}, multi {int((cnt[rows] > 1).sum())}"
+        raise AssertionError(msg)
     assert not torch.equal(res[0][0], dev(I, cuda))
