@@ -103,8 +103,14 @@ def load_pmc_traffic(kernel):
     p = os.path.join(ROOT, "profiles", "pmc_latest.json")
     if not os.path.exists(p):
         return None
+    prefix = {"fused_fwd_bwd": "bprmf_fwd_bwd_kernel", "item_update": "seg_update_kernel",
+              "user_update": "seg_update_kernel"}.get(kernel, kernel)
     try:
-        return json.load(open(p)).get(kernel, {}).get("hbm_bytes_per_launch")
+        rows = [v["hbm_bytes_per_launch"] for k, v in json.load(open(p)).items()
+                if k.startswith(prefix) and isinstance(v, dict) and v.get("hbm_bytes_per_launch")]
+        if not rows:
+            return None
+        return min(rows) if kernel == "user_update" else max(rows)  # item phase = the big launches
     except Exception:
         return None
 

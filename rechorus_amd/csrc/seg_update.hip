@@ -67,19 +67,58 @@ __device__ __forceinline__ void add4(float4& x, const float4& y) {
 }
 
 // ---- 1. heads -------------------------------------------------------------------------
+// A workgroup owns a tile of kHeadIters*256 consecutive sorted positions and reserves its
+// slice of the list with ONE atomicAdd (a device-scope counter retires only ~80 atomics/us,
+// MI355X_MICROARCH.md "fanin"/"dequeue": one atomic per head, even wave-aggregated, cost
+// 1.2 ms here).  Inside the tile the list keeps sorted-position order (ballot + popcount
+// prefix), so neighbouring lane-groups of seg_update_kernel read neighbouring keys/perm.
+constexpr int kHeadIters = 16;
+
 __global__ __launch_bounds__(kBlock) void segment_heads_kernel(
     const uint32_t* __restrict__ keys, const uint32_t* __restrict__ perm, int64_t n,
     int only_multi, uint8_t* __restrict__ single, uint32_t* __restrict__ heads,
     uint32_t* __restrict__ n_heads) {
-  for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < n;
-       j += (int64_t)gridDim.x * kBlock) {
-    const uint32_t k = keys[j];
-    const bool head = j == 0 || keys[j - 1] != k;
-    const bool multi = j + 1 < n && keys[j + 1] == k;
-    if (single) single[perm[j]] = (head && !multi) ? 1 : 0;
-    if (heads && head && (multi || !only_multi)) {
-      const uint32_t slot = atomicAdd(n_heads, 1u);  // wave-aggregated by the compiler
-      heads[slot] = (uint32_t)j;
+  constexpr int kWaves = kBlock / 64;
+  __shared__ uint32_t s_cnt[kHeadIters * kWaves];
+  __shared__ uint32_t s_base;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int64_t tile0 = (int64_t)blockIdx.x * (kHeadIters * kBlock);
+  unsigned long long ballots[kHeadIters];
+#pragma unroll
+  for (int it = 0; it < kHeadIters; ++it) {
+    const int64_t j = tile0 + (int64_t)it * kBlock + threadIdx.x;
+    bool listed = false;
+    if (j < n) {
+      const uint32_t k = keys[j];
+      const bool head = j == 0 || keys[j - 1] != k;
+      const bool multi = j + 1 < n && keys[j + 1] == k;
+      if (single) single[perm[j]] = (head && !multi) ? 1 : 0;
+      listed = head && (multi || !only_multi);
+    }
+    ballots[it] = __ballot(listed);
+    if (lane == 0) s_cnt[it * kWaves + wave] = (uint32_t)__popcll(ballots[it]);
+  }
+  if (heads == nullptr) return;  // block-uniform
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t total = 0;
+    for (int i = 0; i < kHeadIters * kWaves; ++i) {  // exclusive scan, (it, wave) order
+      const uint32_t c = s_cnt[i];
+      s_cnt[i] = total;
+      total += c;
+    }
+    s_base = total ? atomicAdd(n_heads, total) : 0u;
+  }
+  __syncthreads();
+  const uint32_t base = s_base;
+#pragma unroll
+  for (int it = 0; it < kHeadIters; ++it) {
+    const unsigned long long b = ballots[it];
+    if ((b >> lane) & 1ull) {
+      const uint32_t below = (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
+      const int64_t j = tile0 + (int64_t)it * kBlock + threadIdx.x;
+      heads[base + s_cnt[it * kWaves + wave] + below] = (uint32_t)j;
     }
   }
 }
@@ -345,8 +384,8 @@ __global__ __launch_bounds__(kBlock) void seg_update_generic_kernel(SegArgs a) {
 static int launch_heads(const uint32_t* keys, const uint32_t* perm, int64_t n, int only_multi,
                         uint8_t* single, uint32_t* heads, uint32_t* n_heads, hipStream_t s) {
   if (heads) RC_HIP(hipMemsetAsync(n_heads, 0, sizeof(uint32_t), s));
-  int64_t blocks = (n + kBlock - 1) / kBlock;
-  if (blocks > 256 * 16) blocks = 256 * 16;
+  const int64_t tile = (int64_t)kHeadIters * kBlock;
+  const int64_t blocks = (n + tile - 1) / tile;
   hipLaunchKernelGGL(segment_heads_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, s, keys, perm,
                      n, only_multi, single, heads, n_heads);
   RC_LAUNCH_CHECK();

@@ -1,0 +1,34 @@
+"""Workload for the rocprofv3 PMC passes: a calibration copy of known size (torch copy of the
+item table: 2.56 GB read + 2.56 GB written, streaming) followed by a few BPRMF training steps
+at the bench shape.  Run under `rocprofv3 --pmc <COUNTER> --kernel-trace`."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from rechorus_amd import engine  # noqa: E402
+
+
+def main():
+    args = bench.parse()
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234)
+    U = torch.empty((args.users, args.emb_size), device=dev).normal_(0, 0.01, generator=gen)
+    I = torch.empty((args.items, args.emb_size), device=dev).normal_(0, 0.01, generator=gen)
+    I2 = torch.empty_like(I)
+    for _ in range(3):
+        I2.copy_(I)  # calibration: known bytes
+    del I2
+    batches = bench.make_batches(args, dev, seed=99)
+    tr = engine.BprmfTrainer(U, I, opt=args.opt, lr=args.lr, l2=args.l2)
+    for s in range(6):
+        tr.step(*batches[s % len(batches)])
+    torch.cuda.synchronize()
+    print("pmc workload done; table bytes", I.numel() * 4)
+
+
+if __name__ == "__main__":
+    main()
