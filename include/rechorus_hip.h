@@ -77,6 +77,11 @@ int rc_gather_dot_fwd(const float* U, const float* I, const int64_t* uid,
                       const int64_t* iid, int B, int C, int d, float* pred,
                       rc_stream_t stream);
 
+/* out[b,:] = sum_c coef[b,c] * W[ids[b,c],:] -- the user-row half of autograd's backward of
+ * BPRMF.py:42 (d pred / d u_vectors), for callers that get dL/dpred from an arbitrary loss.   */
+int rc_weighted_row_sum(const float* W, const int64_t* ids, const float* coef, int B, int C,
+                        int d, float* out, rc_stream_t stream);
+
 /* ---- loss ---------------------------------------------------------------------- */
 
 /* GeneralModel.loss (models/BaseModel.py:182-185): softmax-weighted multi-negative BPR.

@@ -86,6 +86,52 @@ __global__ __launch_bounds__(kBlock) void gather_dot_fwd_generic_kernel(
   }
 }
 
+// ---- rc_weighted_row_sum: out[b,:] = sum_c coef[b,c] * W[ids[b,c],:] ---------------------
+// (the user-side half of MulBackward/SumBackward of BPRMF.py:42).  One wave per tuple, its
+// 64/LPR lane-groups stride over the candidates, partial sums combined across groups.
+template <int D>
+__global__ __launch_bounds__(kBlock) void weighted_row_sum_kernel(
+    const float* __restrict__ W, const int64_t* __restrict__ ids, const float* __restrict__ coef,
+    int B, int C, float* __restrict__ out) {
+  constexpr int LPR = D / 4;
+  constexpr int G = 64 / LPR;
+  const int lane = threadIdx.x & 63;
+  const int grp = lane / LPR;
+  const int l = lane % LPR;
+  const int64_t t_raw = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  const bool tv = t_raw < B;  // wave-uniform
+  const int64_t t = tv ? t_raw : (int64_t)B - 1;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int c = grp; c < C; c += G) {
+    const float g = coef[t * C + c];
+    const float4 r = reinterpret_cast<const float4*>(W + ids[t * C + c] * D)[l];
+    acc.x = fmaf(g, r.x, acc.x);
+    acc.y = fmaf(g, r.y, acc.y);
+    acc.z = fmaf(g, r.z, acc.z);
+    acc.w = fmaf(g, r.w, acc.w);
+  }
+  acc.x = groups_allreduce_sum<LPR, 64>(acc.x);
+  acc.y = groups_allreduce_sum<LPR, 64>(acc.y);
+  acc.z = groups_allreduce_sum<LPR, 64>(acc.z);
+  acc.w = groups_allreduce_sum<LPR, 64>(acc.w);
+  if (tv && grp == 0) reinterpret_cast<float4*>(out + t * D)[l] = acc;
+}
+
+__global__ __launch_bounds__(kBlock) void weighted_row_sum_generic_kernel(
+    const float* __restrict__ W, const int64_t* __restrict__ ids, const float* __restrict__ coef,
+    int B, int C, int d, float* __restrict__ out) {
+  // one thread per output element; candidates summed sequentially
+  const int64_t total = (int64_t)B * d;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * kBlock) {
+    const int64_t t = i / d;
+    const int k = (int)(i - t * d);
+    float acc = 0.f;
+    for (int c = 0; c < C; ++c) acc = fmaf(coef[t * C + c], W[ids[t * C + c] * d + k], acc);
+    out[i] = acc;
+  }
+}
+
 template <int D>
 static int launch_gather_dot(const float* U, const float* I, const int64_t* uid,
                              const int64_t* iid, int64_t n_pairs, int C, float* pred,
@@ -152,6 +198,39 @@ extern "C" int rc_gather_dot_fwd(const float* U, const float* I, const int64_t* 
   if (blocks > 256 * 32) blocks = 256 * 32;
   hipLaunchKernelGGL(gather_dot_fwd_generic_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, s,
                      U, I, uid, iid, n_pairs, C, d, pred);
+  RC_LAUNCH_CHECK();
+  return RC_OK;
+}
+
+extern "C" int rc_weighted_row_sum(const float* W, const int64_t* ids, const float* coef, int B,
+                                   int C, int d, float* out, rc_stream_t stream) {
+  if (B == 0) return RC_OK;
+  RC_REQUIRE(W && ids && coef && out, "rc_weighted_row_sum: null pointer");
+  RC_REQUIRE(B > 0 && C >= 1 && d >= 1, "rc_weighted_row_sum: bad shape B=%d C=%d d=%d", B, C, d);
+  hipStream_t s = as_stream(stream);
+  const bool aligned = (reinterpret_cast<uintptr_t>(W) % 16 == 0) &&
+                       (reinterpret_cast<uintptr_t>(out) % 16 == 0);
+  const int blocks = (B + (kBlock / 64) - 1) / (kBlock / 64);
+#define RC_WRS(D_)                                                                           \
+  hipLaunchKernelGGL((weighted_row_sum_kernel<D_>), dim3(blocks), dim3(kBlock), 0, s, W, ids, \
+                     coef, B, C, out);                                                       \
+  RC_LAUNCH_CHECK();                                                                         \
+  return RC_OK
+  if (aligned) {
+    switch (d) {
+      case 16: RC_WRS(16);
+      case 32: RC_WRS(32);
+      case 64: RC_WRS(64);
+      case 128: RC_WRS(128);
+      case 256: RC_WRS(256);
+      default: break;
+    }
+  }
+#undef RC_WRS
+  int64_t gblocks = ((int64_t)B * d + kBlock - 1) / kBlock;
+  if (gblocks > 256 * 32) gblocks = 256 * 32;
+  hipLaunchKernelGGL(weighted_row_sum_generic_kernel, dim3((unsigned)gblocks), dim3(kBlock), 0, s, W,
+                     ids, coef, B, C, d, out);
   RC_LAUNCH_CHECK();
   return RC_OK;
 }

@@ -78,6 +78,16 @@ def gather_dot(U, I, uid, iid):
     return pred
 
 
+def weighted_row_sum(W, ids, coef):
+    """out[b] = sum_c coef[b,c] * W[ids[b,c]]  (user-row gradient of the GMF dot)."""
+    B, Cn = ids.shape
+    d = W.shape[1]
+    out = torch.empty((B, d), dtype=torch.float32, device=W.device)
+    _lib.call("rc_weighted_row_sum", _ptr(W, torch.float32, "W"), _ptr(ids, torch.int64, "ids"),
+              _ptr(coef, torch.float32, "coef"), B, Cn, d, _ptr(out, torch.float32, "out"), _stream())
+    return out
+
+
 # ---- loss ------------------------------------------------------------------------------
 
 def reduce_sum(x, scale=1.0):

@@ -1,0 +1,141 @@
+"""torch.nn-shaped front of the HIP engine: what a ReChorus model file touches.
+
+`HipEmbedding` is a drop-in for `nn.Embedding` (same `.weight` Parameter, same state_dict key)
+whose forward and backward run in librechorus_hip.so; `bprmf_scores` / `bpr_loss` are the fused
+head and loss as autograd Functions, so the reference's call order
+`model(batch) -> model.loss(out) -> loss.backward() -> optimizer.step()`
+(helpers/BaseRunner.py:193-206) keeps working unchanged while every FLOP is HIP.
+
+Gradients reaching a table are DENSE `[n_rows, d]` tensors like autograd's
+(aten::embedding_dense_backward semantics), built by sort + segmented sum (no atomics), so any
+torch optimizer or `HipOptimizer` (rc_dense_update, exact torch.optim maths) can consume them.
+The large-table row-wise path bypasses autograd entirely (`engine.BprmfTrainer`).
+"""
+import torch
+import torch.nn as nn
+
+from . import engine
+
+
+class _EmbeddingFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, weight, ids):
+        ctx.save_for_backward(ids)
+        ctx.n_rows = weight.shape[0]
+        return engine.gather_rows(weight.detach(), ids)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (ids,) = ctx.saved_tensors
+        g = engine.embedding_dense_backward(grad_out.contiguous(), ids, ctx.n_rows)
+        return g, None
+
+
+class HipEmbedding(nn.Module):
+    """nn.Embedding(num_embeddings, embedding_dim) on the HIP engine (reference call sites:
+    models/general/BPRMF.py:31-32,39-40 and the 88 other `nn.Embedding` definitions)."""
+
+    def __init__(self, num_embeddings, embedding_dim):
+        super().__init__()
+        self.num_embeddings, self.embedding_dim = num_embeddings, embedding_dim
+        self.weight = nn.Parameter(torch.empty(num_embeddings, embedding_dim))
+        nn.init.normal_(self.weight)  # nn.Embedding's default; models re-init via init_weights
+
+    def forward(self, ids):
+        if not self.weight.is_cuda:
+            raise RuntimeError("HipEmbedding runs on the GPU only (move the model to cuda)")
+        return _EmbeddingFn.apply(self.weight, ids.contiguous())
+
+    def extra_repr(self):
+        return f"{self.num_embeddings}, {self.embedding_dim} [HIP]"
+
+
+class _BprmfScoreFn(torch.autograd.Function):
+    """prediction[b,c] = <U[uid[b]], I[iid[b,c]]>  (models/general/BPRMF.py:39-42)."""
+
+    @staticmethod
+    def forward(ctx, U, I, uid, iid):
+        ctx.save_for_backward(U, I, uid, iid)
+        return engine.gather_dot(U.detach(), I.detach(), uid, iid)
+
+    @staticmethod
+    def backward(ctx, gpred):
+        U, I, uid, iid = ctx.saved_tensors
+        Ud, Id = U.detach(), I.detach()
+        gpred = gpred.contiguous()
+        C = iid.shape[1]
+        # dL/dI[r] = sum_{(b,c): iid[b,c]=r} g[b,c] * U[uid[b]]  (rows rebuilt on the fly)
+        keys, perm = engine.sort_ids(iid, I.shape[0])
+        GI = torch.zeros_like(Id)
+        engine.segmented_update(keys, perm, Ud, coef=gpred.reshape(-1), src_index=uid, div=C,
+                                dense_grad=GI)
+        # dL/dU[r] = sum_{b: uid[b]=r} sum_c g[b,c] * I[iid[b,c]]
+        ug = engine.weighted_row_sum(Id, iid, gpred)
+        GU = engine.embedding_dense_backward(ug, uid, U.shape[0])
+        return GU, GI, None, None
+
+
+def bprmf_scores(U, I, uid, iid):
+    return _BprmfScoreFn.apply(U, I, uid.contiguous(), iid.contiguous())
+
+
+class _BprLossFn(torch.autograd.Function):
+    """GeneralModel.loss (models/BaseModel.py:182-185), closed-form backward."""
+
+    @staticmethod
+    def forward(ctx, pred):
+        loss, _, gpred = engine.bpr_loss(pred.detach().contiguous())
+        ctx.save_for_backward(gpred)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        (gpred,) = ctx.saved_tensors
+        return gpred * grad_loss
+
+
+def bpr_loss(pred):
+    return _BprLossFn.apply(pred)
+
+
+class HipOptimizer:
+    """torch.optim.{SGD,Adam,Adagrad} semantics (dense, weight decay per param group) executed by
+    rc_dense_update.  Built by the runner in place of `eval('torch.optim.X')`
+    (helpers/BaseRunner.py:110-114); accepts the same param-group list
+    (`model.customize_parameters()`, models/BaseModel.py:64-73)."""
+
+    def __init__(self, param_groups, name="Adam", lr=1e-3, weight_decay=0.0):
+        if name not in ("SGD", "Adam", "Adagrad"):
+            raise ValueError(f"HipOptimizer: optimizer {name!r} not built (SGD, Adam, Adagrad)")
+        self.name, self.lr = name, lr
+        self.param_groups = []
+        for g in param_groups:
+            g = dict(g)
+            g.setdefault("lr", lr)
+            g.setdefault("weight_decay", weight_decay)
+            g["params"] = list(g["params"])
+            self.param_groups.append(g)
+        self.state = {}
+        self.step_count = 0
+
+    def zero_grad(self, set_to_none=True):
+        for g in self.param_groups:
+            for p in g["params"]:
+                p.grad = None
+
+    @torch.no_grad()
+    def step(self):
+        self.step_count += 1
+        for g in self.param_groups:
+            for p in g["params"]:
+                if p.grad is None:
+                    continue
+                st = self.state.setdefault(p, {})
+                m = v = None
+                if self.name in ("Adam", "Adagrad"):
+                    m = st.setdefault("m", torch.zeros_like(p))
+                if self.name == "Adam":
+                    v = st.setdefault("v", torch.zeros_like(p))
+                h = engine.make_hyper(self.name, lr=g["lr"], l2=g["weight_decay"], step=self.step_count)
+                grad = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                engine.dense_update(p.data, grad, h, m, v)

@@ -1,0 +1,226 @@
+"""BaseRunner on the HIP engine (mirror of the reference's helpers/BaseRunner.py: same flags,
+`train / fit / evaluate / predict / print_res / evaluate_method` signatures, same log lines).
+
+What changed underneath `fit` (reference :174-208):
+  * the optimizer is `HipOptimizer` (rc_dense_update: exact torch.optim SGD/Adam/Adagrad maths);
+    models exposing `hip_train_step` can run a whole iteration as one fused C-ABI call with a
+    row-wise update (--engine rowwise; 'auto' picks it for tables above 2^20 rows);
+  * the per-batch loss stays on the GPU; one D2H copy per epoch instead of one sync per step;
+  * the candidate-column shuffle (:187-202) is skipped for models that declare
+    `candidate_permutation_equivariant` (a dot/MLP head scores each candidate independently).
+"""
+import gc
+import logging
+import os
+from time import time
+from typing import Dict, List
+
+import numpy as np
+import torch
+from torch.utils.data import DataLoader
+
+from models.BaseModel import BaseModel
+from rechorus_amd import nn as hnn
+from utils import utils
+
+
+class BaseRunner(object):
+    @staticmethod
+    def parse_runner_args(parser):
+        parser.add_argument('--epoch', type=int, default=200, help='Number of epochs.')
+        parser.add_argument('--check_epoch', type=int, default=1, help='Check some tensors every check_epoch.')
+        parser.add_argument('--test_epoch', type=int, default=-1, help='Print test results every test_epoch (-1 means no print).')
+        parser.add_argument('--early_stop', type=int, default=10, help='The number of epochs when dev results drop continuously.')
+        parser.add_argument('--lr', type=float, default=1e-3, help='Learning rate.')
+        parser.add_argument('--l2', type=float, default=0, help='Weight decay in optimizer.')
+        parser.add_argument('--batch_size', type=int, default=256, help='Batch size during training.')
+        parser.add_argument('--eval_batch_size', type=int, default=256, help='Batch size during testing.')
+        parser.add_argument('--optimizer', type=str, default='Adam', help='optimizer: SGD, Adam, Adagrad, Adadelta')
+        parser.add_argument('--num_workers', type=int, default=5, help='Number of processors when prepare batches in DataLoader')
+        parser.add_argument('--pin_memory', type=int, default=0, help='pin_memory in DataLoader')
+        parser.add_argument('--topk', type=str, default='5,10,20,50', help='The number of items recommended to each user.')
+        parser.add_argument('--metric', type=str, default='NDCG,HR', help='metrics: NDCG, HR')
+        parser.add_argument('--main_metric', type=str, default='', help='Main metric to determine the best model.')
+        # additive, engine-specific
+        parser.add_argument('--engine', type=str, default='auto',
+                            help='dense: exact reference optimizer semantics; rowwise: fused step, update touched rows only; auto')
+        return parser
+
+    @staticmethod
+    def evaluate_method(predictions: np.ndarray, topk: list, metrics: list) -> Dict[str, float]:
+        """predictions [-1, n_candidates], column 0 = ground truth.  rank = #candidates scoring
+        >= the target (ties count against it, reference :63); HR@k, NDCG@k."""
+        rank = (predictions >= predictions[:, :1]).sum(axis=-1)
+        res = dict()
+        for k in topk:
+            hit = rank <= k
+            for metric in metrics:
+                key = '{}@{}'.format(metric, k)
+                if metric == 'HR':
+                    res[key] = hit.mean()
+                elif metric == 'NDCG':
+                    res[key] = (hit / np.log2(rank + 1)).mean()
+                else:
+                    raise ValueError('Undefined evaluation metric: {}.'.format(metric))
+        return res
+
+    def __init__(self, args):
+        self.train_models = args.train
+        self.epoch, self.check_epoch, self.test_epoch = args.epoch, args.check_epoch, args.test_epoch
+        self.early_stop = args.early_stop
+        self.learning_rate, self.l2 = args.lr, args.l2
+        self.batch_size, self.eval_batch_size = args.batch_size, args.eval_batch_size
+        self.optimizer_name = args.optimizer
+        self.num_workers, self.pin_memory = args.num_workers, args.pin_memory
+        self.engine = getattr(args, 'engine', 'auto')
+        self.topk = [int(x) for x in args.topk.split(',')]
+        self.metrics = [m.strip().upper() for m in args.metric.split(',')]
+        self.main_metric = args.main_metric if len(args.main_metric) else '{}@{}'.format(self.metrics[0], self.topk[0])
+        self.main_topk = int(self.main_metric.split('@')[1]) if '@' in self.main_metric else 0
+        self.time = None  # [start, last checkpoint]
+        self.log_path = os.path.dirname(args.log_file)
+        self.save_appendix = args.log_file.split('/')[-1].split('.')[0]
+
+    def _check_time(self, start=False):
+        now = time()
+        if self.time is None or start:
+            self.time = [now, now]
+            return now
+        last, self.time[1] = self.time[1], now
+        return now - last
+
+    def _build_optimizer(self, model):
+        logging.info('Optimizer: ' + self.optimizer_name)
+        on_gpu = next(model.parameters()).is_cuda
+        if on_gpu and self.optimizer_name in ('SGD', 'Adam', 'Adagrad'):
+            return hnn.HipOptimizer(model.customize_parameters(), self.optimizer_name,
+                                    lr=self.learning_rate, weight_decay=self.l2)
+        # anything else (Adadelta, CPU debugging) keeps torch's implementation
+        return getattr(torch.optim, self.optimizer_name)(
+            model.customize_parameters(), lr=self.learning_rate, weight_decay=self.l2)
+
+    def _use_rowwise(self, model) -> bool:
+        if not hasattr(model, 'hip_train_step') or self.optimizer_name not in ('SGD', 'Adam', 'Adagrad'):
+            return False
+        if self.engine == 'rowwise':
+            return True
+        if self.engine == 'dense':
+            return False
+        return max(p.shape[0] for p in model.parameters() if p.dim() == 2) > (1 << 20)
+
+    def train(self, data_dict: Dict[str, BaseModel.Dataset]):
+        model = data_dict['train'].model
+        main_results, dev_results = list(), list()
+        self._check_time(start=True)
+        try:
+            for epoch in range(self.epoch):
+                self._check_time()
+                gc.collect()
+                loss = self.fit(data_dict['train'], epoch=epoch + 1)
+                if np.isnan(loss):
+                    logging.info('Loss is Nan. Stop training at %d.' % (epoch + 1))
+                    break
+                training_time = self._check_time()
+
+                if len(model.check_list) > 0 and self.check_epoch > 0 and epoch % self.check_epoch == 0:
+                    utils.check(model.check_list)
+
+                dev_result = self.evaluate(data_dict['dev'], [self.main_topk], self.metrics)
+                dev_results.append(dev_result)
+                main_results.append(dev_result[self.main_metric])
+                log = 'Epoch {:<5} loss={:<.4f} [{:<3.1f} s]\tdev=({})'.format(
+                    epoch + 1, loss, training_time, utils.format_metric(dev_result))
+                if self.test_epoch > 0 and epoch % self.test_epoch == 0:
+                    test_result = self.evaluate(data_dict['test'], self.topk[:1], self.metrics)
+                    log += ' test=({})'.format(utils.format_metric(test_result))
+                log += ' [{:<.1f} s]'.format(self._check_time())
+
+                if max(main_results) == main_results[-1] or (hasattr(model, 'stage') and model.stage == 1):
+                    model.save_model()
+                    log += ' *'
+                logging.info(log)
+
+                if self.early_stop > 0 and self.eval_termination(main_results):
+                    logging.info('Early stop at %d based on dev result.' % (epoch + 1))
+                    break
+        except KeyboardInterrupt:
+            logging.info('Early stop manually')
+            if input('Exit completely without evaluation? (y/n) (default n):').lower().startswith('y'):
+                logging.info(os.linesep + '-' * 45 + ' END: ' + utils.get_time() + ' ' + '-' * 45)
+                exit(1)
+
+        best = main_results.index(max(main_results))
+        logging.info(os.linesep + 'Best Iter(dev)={:>5}\t dev=({}) [{:<.1f} s] '.format(
+            best + 1, utils.format_metric(dev_results[best]), self.time[1] - self.time[0]))
+        model.load_model()
+
+    def fit(self, dataset: BaseModel.Dataset, epoch=-1) -> float:
+        model = dataset.model
+        rowwise = self._use_rowwise(model)
+        if model.optimizer is None and not rowwise:
+            model.optimizer = self._build_optimizer(model)
+        dataset.actions_before_epoch()  # negative sampling happens before workers fork
+
+        model.train()
+        losses = list()
+        dl = DataLoader(dataset, batch_size=self.batch_size, shuffle=True, num_workers=self.num_workers,
+                        collate_fn=dataset.collate_batch, pin_memory=self.pin_memory)
+        equivariant = getattr(model, 'candidate_permutation_equivariant', False)
+        for batch in dl:
+            batch = utils.batch_to_gpu(batch, model.device)
+            if rowwise:
+                losses.append(model.hip_train_step(batch, self.optimizer_name, self.learning_rate, self.l2).clone())
+                continue
+            item_ids = batch['item_id']
+            indices = None
+            if not equivariant:
+                # shuffle candidate columns so a model cannot learn "column 0 is the target"
+                indices = torch.argsort(torch.rand(*item_ids.shape), dim=-1).to(item_ids.device)
+                batch['item_id'] = torch.gather(item_ids, 1, indices)
+            model.optimizer.zero_grad()
+            out_dict = model(batch)
+            pred = out_dict['prediction']
+            if indices is not None and pred.dim() == 2:
+                restored = torch.zeros_like(pred)
+                restored.scatter_(1, indices, pred)  # undo the shuffle: column 0 is the target again
+                out_dict['prediction'] = restored
+            loss = model.loss(out_dict)
+            loss.backward()
+            model.optimizer.step()
+            losses.append(loss.detach().reshape(1))
+        # epoch loss = mean of per-batch means (reference :207-208); one D2H copy per epoch
+        return float(torch.cat([l.reshape(1) for l in losses]).mean().item()) if losses else float('nan')
+
+    def eval_termination(self, criterion: List[float]) -> bool:
+        if len(criterion) > self.early_stop and utils.non_increasing(criterion[-self.early_stop:]):
+            return True
+        return len(criterion) - criterion.index(max(criterion)) > self.early_stop
+
+    def evaluate(self, dataset: BaseModel.Dataset, topks: list, metrics: list) -> Dict[str, float]:
+        return self.evaluate_method(self.predict(dataset), topks, metrics)
+
+    def predict(self, dataset: BaseModel.Dataset, save_prediction: bool = False) -> np.ndarray:
+        """[n_instances, n_candidates] scores, ground truth in column 0 (reference :225-252)"""
+        model = dataset.model
+        model.eval()
+        chunks = list()
+        dl = DataLoader(dataset, batch_size=self.eval_batch_size, shuffle=False, num_workers=self.num_workers,
+                        collate_fn=dataset.collate_batch, pin_memory=self.pin_memory)
+        with torch.no_grad():
+            for batch in dl:
+                batch = utils.batch_to_gpu(batch, model.device)
+                out = model.inference(batch) if hasattr(model, 'inference') else model(batch)
+                chunks.append(out['prediction'])
+        predictions = torch.cat(chunks).cpu().numpy()  # one D2H copy
+
+        if model.test_all:  # mask items the user already interacted with
+            rows, cols = list(), list()
+            for i, u in enumerate(dataset.data['user_id']):
+                seen = list(dataset.corpus.train_clicked_set[u] | dataset.corpus.residual_clicked_set[u])
+                rows.extend([i] * len(seen))
+                cols.extend(seen)
+            predictions[rows, cols] = -np.inf
+        return predictions
+
+    def print_res(self, dataset: BaseModel.Dataset) -> str:
+        return '(' + utils.format_metric(self.evaluate(dataset, self.topk, self.metrics)) + ')'

@@ -1,0 +1,115 @@
+"""GPU: the plugin surface end to end -- HipEmbedding autograd, BaseRunner-style training loop in
+dense (exact reference semantics) and row-wise mode, and the CLI driver on a synthetic dataset."""
+import argparse
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, assert_close, assert_update_close, load_golden
+from synth_data import make_dataset
+
+pytestmark = pytest.mark.gpu
+
+PLUGIN = os.path.join(ROOT, "rechorus_amd", "rechorus")
+if PLUGIN not in sys.path:
+    sys.path.insert(0, PLUGIN)
+
+
+def test_hip_embedding_forward_backward(cuda):
+    from rechorus_amd.nn import HipEmbedding
+    rng = np.random.default_rng(0)
+    for n_rows, d, shape in ((50, 64, (7, 5)), (9, 48, (33,)), (300, 128, (4, 3, 2))):
+        emb = HipEmbedding(n_rows, d).to(cuda)
+        W = emb.weight.detach().cpu().numpy()
+        ids = rng.integers(0, n_rows, size=shape).astype(np.int64)
+        out = emb(torch.from_numpy(ids).to(cuda))
+        assert out.shape == shape + (d,)
+        assert np.array_equal(out.detach().cpu().numpy(), W[ids])
+        coef = rng.normal(size=shape + (d,)).astype(np.float32)
+        (out * torch.from_numpy(coef).to(cuda)).sum().backward()
+        want = np.zeros((n_rows, d), dtype=np.float64)
+        np.add.at(want, ids.reshape(-1), coef.reshape(-1, d).astype(np.float64))
+        assert_close(emb.weight.grad.cpu().numpy(), want, what="dense grad")
+    assert "weight" in dict(emb.named_parameters())  # state_dict key as nn.Embedding
+
+
+def _bprmf(cuda, n_users, n_items, d, K):
+    from models.general.BPRMF import BPRMF
+    args = argparse.Namespace(device=cuda, model_path="", buffer=1, num_neg=K, dropout=0, test_all=0, emb_size=d)
+    corpus = argparse.Namespace(n_users=n_users, n_items=n_items)
+    return BPRMF(args, corpus).to(cuda)
+
+
+def _runner(opt, lr, l2, engine="dense"):
+    from helpers.BaseRunner import BaseRunner
+    p = BaseRunner.parse_runner_args(argparse.ArgumentParser())
+    a = p.parse_args([])
+    a.train, a.log_file = 1, "/tmp/rechorus_amd_test/log.txt"
+    a.optimizer, a.lr, a.l2, a.engine = opt, lr, l2, engine
+    return BaseRunner(a)
+
+
+@pytest.mark.parametrize("case", ["bprmf_k1_d64", "bprmf_k99_d64_zipf", "bprmf_k5_d48"])
+@pytest.mark.parametrize("tag,opt", [("SGD_l20.001", "SGD"), ("Adam_l20.0001", "Adam"), ("Adagrad_l20.0001", "Adagrad")])
+def test_model_loss_backward_optimizer_matches_reference_fit(case, tag, opt, cuda):
+    """the reference's call order model(batch) -> model.loss -> backward -> optimizer.step through
+    the plugin classes (autograd Functions + HipOptimizer) vs the reference's own fit() results"""
+    g = load_golden(case)
+    lr, l2 = (float(x) for x in g[tag + "_hyper"])
+    n_users, n_items, d = g["U0"].shape[0], g["I0"].shape[0], g["U0"].shape[1]
+    model = _bprmf(cuda, n_users, n_items, d, g["iid"].shape[1] - 1)
+    sd = model.state_dict()
+    assert set(sd) == {"u_embeddings.weight", "i_embeddings.weight"}  # reference checkpoint keys
+    model.load_state_dict({"u_embeddings.weight": torch.from_numpy(g["U0"]),
+                           "i_embeddings.weight": torch.from_numpy(g["I0"])})
+    runner = _runner(opt, lr, l2)
+    model.optimizer = runner._build_optimizer(model)
+    for step, (u, i) in enumerate(((g["uid"], g["iid"]), (g["uid2"], g["iid2"])), 1):
+        batch = {"user_id": torch.from_numpy(u).to(cuda), "item_id": torch.from_numpy(i).to(cuda),
+                 "batch_size": len(u), "phase": "train"}
+        model.optimizer.zero_grad()
+        out = model(batch)
+        if step == 1:
+            assert_close(out["prediction"].detach().cpu().numpy(), g["pred"], what="prediction")
+        loss = model.loss(out)
+        loss.backward()
+        if step == 1:
+            assert_close(model.u_embeddings.weight.grad.cpu().numpy(), g["GU"], what="GU")
+            assert_close(model.i_embeddings.weight.grad.cpu().numpy(), g["GI"], what="GI")
+        model.optimizer.step()
+        assert_close(loss.item(), g[tag + "_losses"][step - 1], what=f"loss {step}")
+    ex = 1e-3 * lr if opt in ("Adam", "Adagrad") else 0.0
+    assert_update_close(model.u_embeddings.weight.detach().cpu().numpy(), g["U0"], g[tag + "_U2"], what="dU", extra_atol=ex)
+    assert_update_close(model.i_embeddings.weight.detach().cpu().numpy(), g["I0"], g[tag + "_I2"], what="dI", extra_atol=ex)
+
+
+@pytest.fixture(scope="module")
+def dataset_root(tmp_path_factory):
+    root = str(tmp_path_factory.mktemp("data"))
+    make_dataset(root, "synth", n_users=400, n_items=300, per_user=14, seed=1)
+    return root
+
+
+@pytest.mark.parametrize("engine,opt,lr", [("dense", "Adam", "5e-3"), ("rowwise", "SGD", "0.5")])
+def test_cli_trains_and_reports_like_the_reference(engine, opt, lr, dataset_root, tmp_path, cuda):
+    import main
+    log = str(tmp_path / "log" / "run.txt")
+    res = main.run(["--model_name", "BPRMF", "--emb_size", "32", "--lr", lr, "--l2", "0", "--dataset", "synth",
+                    "--path", dataset_root + "/", "--epoch", "6", "--num_neg", "4", "--batch_size", "128",
+                    "--num_workers", "0", "--optimizer", opt, "--engine", engine, "--regenerate", "1",
+                    "--log_file", log, "--model_path", str(tmp_path / "model" / "m.pt"), "--topk", "5,10",
+                    "--save_final_results", "1"])
+    text = open(log).read()
+    before = float(re.search(r"Test Before Training: \(HR@5:([0-9.]+)", text).group(1))
+    losses = [float(x) for x in re.findall(r"Epoch \d+\s+loss=([0-9.]+)", text)]
+    assert len(losses) >= 2 and losses[-1] < losses[0], losses
+    assert "Best Iter(dev)=" in text and "Test After Training: (HR@5:" in text
+    after = float(re.search(r"HR@5:([0-9.]+)", res["test"]).group(1))
+    assert 0.0 <= before <= 1.0 and after > before, (before, after)
+    assert os.path.exists(str(tmp_path / "model" / "m.pt"))
+    rec = tmp_path / "log" / "run" / "rec-BPRMF-test.csv"
+    assert rec.exists() and len(open(rec).read().splitlines()) == 401

@@ -1,0 +1,114 @@
+"""CPU: host-side plugin surface (readers, datasets, sampler, metrics, arg surface) -- the parts
+of the mirror that never touch the GPU."""
+import argparse
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from synth_data import make_dataset
+
+PLUGIN = os.path.join(ROOT, "rechorus_amd", "rechorus")
+if PLUGIN not in sys.path:
+    sys.path.insert(0, PLUGIN)
+
+
+@pytest.fixture(scope="module")
+def corpus(tmp_path_factory):
+    from helpers.SeqReader import SeqReader
+    root = str(tmp_path_factory.mktemp("data"))
+    make_dataset(root, "synth")
+    args = argparse.Namespace(path=root + "/", dataset="synth", sep="\t")
+    return SeqReader(args)
+
+
+def test_reader_statistics_and_history(corpus):
+    assert corpus.n_users == 61 and corpus.n_items <= 201
+    assert set(corpus.data_df) == {"train", "dev", "test"}
+    assert len(corpus.data_df["dev"]) == 60 and len(corpus.data_df["test"]) == 60
+    u = 7
+    his = corpus.user_his[u]
+    assert [t for _, t in his] == sorted(t for _, t in his)
+    train_items = set(corpus.data_df["train"].query("user_id == @u")["item_id"])
+    assert corpus.train_clicked_set[u] == train_items
+    assert len(corpus.residual_clicked_set[u]) == 2
+    # position = index of the interaction in the user's time-ordered history
+    row = corpus.data_df["test"].query("user_id == @u").iloc[0]
+    assert his[row["position"]][0] == row["item_id"] and row["position"] == len(his) - 1
+
+
+def _model_stub(corpus, num_neg=4, history_max=5):
+    return argparse.Namespace(buffer=1, num_neg=num_neg, test_all=0, history_max=history_max)
+
+
+def test_negative_sampler_and_collate(corpus):
+    from models.BaseModel import GeneralModel, SequentialModel
+    ds = GeneralModel.Dataset(_model_stub(corpus), corpus, "train")
+    np.random.seed(0)
+    ds.actions_before_epoch()
+    negs = np.asarray(ds.data["neg_items"])
+    assert negs.shape == (len(ds), 4) and negs.min() >= 1 and negs.max() < corpus.n_items
+    for u, row in zip(ds.data["user_id"], negs):
+        assert not (set(row.tolist()) & corpus.train_clicked_set[u])
+    batch = ds.collate_batch([ds[i] for i in range(10)])
+    assert batch["item_id"].shape == (10, 5) and batch["user_id"].shape == (10,)
+    assert batch["batch_size"] == 10 and batch["phase"] == "train"
+    # negatives are uniform over non-clicked items: chi-square-ish sanity on a big sample
+    big = GeneralModel.Dataset(_model_stub(corpus, num_neg=400), corpus, "train")
+    big.actions_before_epoch()
+    counts = np.bincount(np.asarray(big.data["neg_items"]).ravel(), minlength=corpus.n_items)[1:]
+    assert counts.std() / counts.mean() < 0.1
+
+    sds = SequentialModel.Dataset(_model_stub(corpus), corpus, "train")
+    sds.actions_before_epoch()
+    feeds = [sds[i] for i in range(12)]
+    b = sds.collate_batch(feeds)
+    L = max(f["lengths"] for f in feeds)
+    assert b["history_items"].shape == (12, L) and L <= 5
+    for r, f in enumerate(feeds):
+        assert (b["history_items"][r, :f["lengths"]].numpy() == f["history_items"]).all()
+        assert (b["history_items"][r, f["lengths"]:] == 0).all()  # right padding with 0
+    dev = GeneralModel.Dataset(_model_stub(corpus), corpus, "dev")
+    dev.prepare()
+    assert dev[0]["item_id"].shape == (100,)
+
+
+def test_metrics_and_formatting():
+    from helpers.BaseRunner import BaseRunner
+    from oracle import bprmf_oracle as O
+    from utils import utils
+    rng = np.random.default_rng(0)
+    pred = rng.normal(size=(200, 100)).astype(np.float32)
+    pred[::7, 3] = pred[::7, 0]  # ties count against the target
+    got = BaseRunner.evaluate_method(pred, [1, 5, 10], ["HR", "NDCG"])
+    want = O.evaluate_method(pred, [1, 5, 10], ["HR", "NDCG"])
+    assert got.keys() == want.keys() and all(abs(got[k] - want[k]) < 1e-12 for k in got)
+    with pytest.raises(ValueError):
+        BaseRunner.evaluate_method(pred, [5], ["MAP"])
+    s = utils.format_metric({"HR@5": 0.25, "NDCG@5": 0.125, "HR@10": 0.5, "NDCG@10": 0.25})
+    assert s == "HR@5:0.2500,NDCG@5:0.1250,HR@10:0.5000,NDCG@10:0.2500"
+    assert utils.non_increasing([3, 2, 3, 1]) and not utils.non_increasing([1, 2])
+
+
+def test_cli_flag_surface_matches_reference():
+    """same flag names/defaults as docs/Main_Arguments.md of the reference"""
+    from helpers.BaseReader import BaseReader
+    from helpers.BaseRunner import BaseRunner
+    from models.general.BPRMF import BPRMF
+    import main
+    p = argparse.ArgumentParser()
+    p = main.parse_global_args(p)
+    p = BaseReader.parse_data_args(p)
+    p = BaseRunner.parse_runner_args(p)
+    p = BPRMF.parse_model_args(p)
+    a = p.parse_args([])
+    want = dict(gpu="0", random_seed=0, load=0, train=1, regenerate=0, path="data/", sep="\t",
+                dataset="Grocery_and_Gourmet_Food", epoch=200, early_stop=10, lr=1e-3, l2=0, batch_size=256,
+                eval_batch_size=256, optimizer="Adam", num_workers=5, topk="5,10,20,50", metric="NDCG,HR",
+                emb_size=64, num_neg=1, dropout=0, test_all=0, buffer=1, model_path="")
+    for k, v in want.items():
+        assert getattr(a, k) == v, k
+    assert BPRMF.reader == "BaseReader" and BPRMF.runner == "BaseRunner"
+    assert BPRMF.extra_log_args == ["emb_size", "batch_size"]
