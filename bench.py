@@ -8,8 +8,9 @@ already resident in HBM.  Prints ONE JSON line (rank 0).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--opt SGD|Adam|Adagrad]
 
-N > 1 is launched by torch.distributed.run (one rank per GPU).  Round 1: ranks run independent
-table replicas on disjoint batch streams (no data-path collective yet).
+N > 1 is launched by torch.distributed.run (one rank per GPU): the tables are row-sharded over
+the ranks and every step trains ONE global batch of N*B tuples (rechorus_amd/sharded.py; DESIGN.md
+section 7).  --parallel replicas runs N independent single-GPU jobs instead (no exchange).
 """
 import argparse
 import json
@@ -43,6 +44,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--parallel", default="sharded", choices=["sharded", "replicas"],
+                    help="N>1: row-sharded tables + owner-computes exchange (default), or independent replicas")
     return ap.parse_args()
 
 
@@ -172,12 +175,25 @@ def main():
 
     from rechorus_amd import engine
 
-    gen = torch.Generator(device=device)
-    gen.manual_seed(1234 + rank)
-    U = torch.empty((args.users, args.emb_size), device=device).normal_(0, 0.01, generator=gen)
-    I = torch.empty((args.items, args.emb_size), device=device).normal_(0, 0.01, generator=gen)
     batches = make_batches(args, device, seed=99 + rank)
-    trainer = engine.BprmfTrainer(U, I, opt=args.opt, lr=args.lr, l2=args.l2)
+    if world == 1 or args.parallel == "replicas":
+        gen = torch.Generator(device=device)
+        gen.manual_seed(1234 + rank)
+        U = torch.empty((args.users, args.emb_size), device=device).normal_(0, 0.01, generator=gen)
+        I = torch.empty((args.items, args.emb_size), device=device).normal_(0, 0.01, generator=gen)
+        trainer = engine.BprmfTrainer(U, I, opt=args.opt, lr=args.lr, l2=args.l2)
+    else:
+        # tables row-sharded over the ranks (id mod W), one GLOBAL batch of W*B tuples per step
+        from rechorus_amd.sharded import ShardedBprmf
+        trainer = ShardedBprmf(args.users, args.items, args.emb_size, opt=args.opt, lr=args.lr, l2=args.l2,
+                               device=device, seed=1234)
+        trainer.loss = None
+        _step = trainer.step
+
+        def step_and_keep(uid, iid, _step=_step):
+            trainer.loss = _step(uid, iid)
+            return trainer.loss
+        trainer.step = step_and_keep
 
     def sync():
         torch.cuda.synchronize(device)
@@ -222,12 +238,15 @@ def main():
                         f"(row-wise, l2={args.l2:g}), int64 ids, fp32",
             "batch_per_gpu": args.batch, "num_neg": args.num_neg, "emb_size": args.emb_size,
             "n_items": args.items, "n_users": args.users, "optimizer": args.opt,
-            "parallelism": "single GPU" if world == 1 else f"{world} independent replicas",
+            "parallelism": "single GPU" if world == 1 else (
+                f"{world} independent replicas" if args.parallel == "replicas" else
+                f"tables row-sharded over {world} GPUs (id mod W), owner-computes exchange over RCCL, "
+                f"global batch {world * args.batch}"),
         },
         "final_loss": loss,
     }
 
-    if rank == 0 and not args.no_roofline:
+    if rank == 0 and not args.no_roofline and hasattr(trainer, "profile_step"):
         # per-phase hipEvent timing on the launch stream, measured live (profiling steps are
         # outside the timed region above)
         acc = {}

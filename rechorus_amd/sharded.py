@@ -1,0 +1,276 @@
+"""Row-sharded BPRMF training across W GPUs (one process per GPU, torch.distributed over RCCL/xGMI).
+
+The reference is single-device; this layer is new.  Tables are sharded by row,
+owner(id) = id mod W, local row = id div W (hashing the Zipf head across ranks).  A tuple touches
+1+K item rows but only ONE user row, and xGMI is per-link bound (~64 GB/s per direction per peer),
+so rows are not moved to the tuples (25.6 KB per tuple at K=99, d=64); the tuples' user rows are
+moved to the item rows' owners instead ("owner computes"):
+
+  1. fetch   user rows of the local batch from their owners        all_to_all  (ids, rows)
+  2. share   all_gather the batch's user rows  Uall [W*B, d]        all_gather  (256 B / tuple / peer)
+  3. route   every candidate occurrence (tuple index, local row) to the item's owner   all_to_all
+  4. score   owner: s = <Uall[t], I_loc[row]>;  scores return home   all_to_all  (4 B / occurrence)
+  5. loss    home: BPR loss + g = dL/ds on its own tuples; loss all_reduce;  g goes back to owners
+  6. update  owner: item rows  += opt(sum_occ g*Uall[t])  (segmented, atomic-free, local);
+             partial user grads  PUG[t] = sum_{occ at this owner} g*I_loc[row]
+  7. reduce  reduce_scatter PUG -> ugrad of the home's tuples;  route to the user rows' owners,
+             owner applies the segmented update.
+
+≈5 KB of traffic per tuple instead of ≈45 KB for moving rows both ways.  With W = 1 every collective
+is the identity and the arithmetic equals engine.BprmfTrainer's (same kernels).
+
+Local arithmetic goes through an `ops` object: `HipOps` (the C ABI, default) on GPUs; the CPU tests
+inject an oracle-backed implementation so the routing can be verified with gloo, world_size 2.
+"""
+import torch
+import torch.distributed as dist
+
+
+class HipOps:
+    """local kernels of the sharded step, all through librechorus_hip.so"""
+
+    def __init__(self):
+        from . import engine
+        self.e = engine
+
+    def gather_rows(self, W, rows):
+        return self.e.gather_rows(W, rows)
+
+    def dot_rows(self, Uall, t_idx, I_loc, rows):
+        return self.e.gather_dot(Uall, I_loc, t_idx, rows.reshape(-1, 1)).reshape(-1)
+
+    def bpr_loss(self, pred, inv_b):
+        _, loss_vec, g = self.e.bpr_loss(pred, inv_b=inv_b)
+        return loss_vec, g
+
+    def partial_user_grads(self, I_loc, rows, g, t_idx, n_tuples):
+        out = torch.zeros((n_tuples, I_loc.shape[1]), dtype=torch.float32, device=I_loc.device)
+        if t_idx.numel():
+            keys, perm = self.e.sort_ids(t_idx, n_tuples)
+            self.e.segmented_update(keys, perm, I_loc, coef=g, src_index=rows, div=1, dense_grad=out)
+        return out
+
+    def update_rows(self, W, state, rows, src, hyper, coef=None, src_index=None):
+        """W[r] <- opt(W[r], sum_{o: rows[o]=r} coef[o] * src[src_index[o] or o])"""
+        if rows.numel() == 0:
+            return
+        keys, perm = self.e.sort_ids(rows, W.shape[0])
+        self.e.segmented_update(keys, perm, src, hyper=hyper, W=W, m=state.get("m"), v=state.get("v"),
+                                coef=coef, src_index=src_index, div=1)
+
+    def make_hyper(self, **kw):
+        return self.e.make_hyper(**kw)
+
+    def new_state(self, W, opt):
+        st = {}
+        if opt in ("Adam", "Adagrad"):
+            st["m"] = torch.zeros_like(W)
+        if opt == "Adam":
+            st["v"] = torch.zeros_like(W)
+        return st
+
+
+def _is_nccl(group):
+    return dist.get_backend(group) == "nccl"
+
+
+def _all_to_all_v(out, inp, out_splits, in_splits, group):
+    """all_to_all_single with split sizes.  RCCL does it natively; gloo (CPU tests) has no
+    all_to_all, so it is emulated there with point-to-point sends."""
+    if _is_nccl(group):
+        dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
+        return
+    if inp.is_cuda:  # gloo moves host memory: stage through the CPU (test configurations only)
+        out_h = torch.empty(out.shape, dtype=out.dtype)
+        _all_to_all_v(out_h, inp.cpu(), out_splits, in_splits, group)
+        out.copy_(out_h)
+        return
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    ins = list(torch.split(inp, in_splits)) if inp.shape[0] else [inp[:0]] * world
+    outs = list(torch.split(out, out_splits)) if out.shape[0] else [out[:0]] * world
+    reqs = []
+    for peer in range(world):
+        if peer == rank:
+            outs[peer].copy_(ins[peer])
+            continue
+        if in_splits[peer]:
+            reqs.append(dist.isend(ins[peer].contiguous(), peer, group=group))
+    for peer in range(world):
+        if peer != rank and out_splits[peer]:
+            buf = torch.empty_like(outs[peer])
+            dist.recv(buf, peer, group=group)
+            outs[peer].copy_(buf)
+    for r in reqs:
+        r.wait()
+
+
+def _exchange(send, send_counts, group=None, recv_counts=None):
+    """variable all_to_all along dim 0: `send` is grouped by destination (send_counts per rank).
+    Returns (recv, recv_counts).  One host sync for the counts unless recv_counts is given."""
+    world = dist.get_world_size(group)
+    if recv_counts is None:
+        sc = torch.as_tensor(send_counts, dtype=torch.int64, device=send.device)
+        rc = torch.empty_like(sc)
+        _all_to_all_v(rc, sc, [1] * world, [1] * world, group)
+        recv_counts = rc.tolist()
+    recv = torch.empty((sum(recv_counts),) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
+    _all_to_all_v(recv, send.contiguous(), list(recv_counts), list(send_counts), group)
+    return recv, recv_counts
+
+
+def _exchange_back(payload, recv_counts, send_counts, group=None):
+    """reverse direction of a previous _exchange: payload is ordered like what was received"""
+    out, _ = _exchange(payload, recv_counts, group, recv_counts=send_counts)
+    return out
+
+
+def _all_gather_rows(x, world, group):
+    out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+    if _is_nccl(group):
+        dist.all_gather_into_tensor(out, x.contiguous(), group=group)
+    else:
+        xh = x.cpu().contiguous()
+        parts = [torch.empty_like(xh) for _ in range(world)]
+        dist.all_gather(parts, xh, group=group)
+        out.copy_(torch.cat(parts, dim=0))
+    return out
+
+
+def _all_reduce_sum(x, group):
+    if _is_nccl(group) or not x.is_cuda:
+        dist.all_reduce(x, group=group)
+        return x
+    h = x.cpu()
+    dist.all_reduce(h, group=group)
+    x.copy_(h)
+    return x
+
+
+def _reduce_scatter_rows(x, world, group):
+    """sum over ranks of x [world*n, ...]; rank r keeps rows [r*n, (r+1)*n)"""
+    n = x.shape[0] // world
+    if _is_nccl(group):
+        out = torch.empty((n,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        dist.reduce_scatter_tensor(out, x.contiguous(), group=group)
+        return out
+    y = _all_reduce_sum(x.clone(), group)
+    r = dist.get_rank(group)
+    return y[r * n:(r + 1) * n].clone()
+
+
+def _group_by_owner(ids, world):
+    """stable grouping of ids by id mod world -> (order, counts); order[j] = original position"""
+    owner = ids % world
+    order = torch.sort(owner, stable=True).indices
+    counts = torch.bincount(owner, minlength=world).tolist()
+    return order, counts
+
+
+class ShardedBprmf:
+    def __init__(self, n_users, n_items, emb_size, opt="SGD", lr=1e-3, l2=0.0, device=None, ops=None,
+                 group=None, init_std=0.01, seed=0):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.n_users, self.n_items, self.d = n_users, n_items, emb_size
+        self.ops = ops if ops is not None else HipOps()
+        self.opt, self.lr, self.l2 = opt, lr, l2
+        self.device = device
+        W = self.world
+        self.rows_u = (n_users + W - 1) // W
+        self.rows_i = (n_items + W - 1) // W
+        g = torch.Generator(device=device if device is not None else "cpu")
+        g.manual_seed(seed * 1000 + self.rank)
+        self.U = torch.empty((self.rows_u, emb_size), device=device).normal_(0, init_std, generator=g)
+        self.I = torch.empty((self.rows_i, emb_size), device=device).normal_(0, init_std, generator=g)
+        self.sU = self.ops.new_state(self.U, opt)
+        self.sI = self.ops.new_state(self.I, opt)
+        self.step_count = 0
+
+    # ---- shard <-> global helpers (tests, checkpoints) --------------------------------------
+    def load_global(self, U, I):
+        """take this rank's rows out of full tables (global row id = local*W + rank)"""
+        W, r = self.world, self.rank
+        self.U.zero_()
+        self.I.zero_()
+        u, i = U[r::W], I[r::W]
+        self.U[: u.shape[0]].copy_(u)
+        self.I[: i.shape[0]].copy_(i)
+
+    def gather_global(self):
+        """all ranks -> full [n_users,d], [n_items,d] tables (gather-on-save)"""
+        out = []
+        for shard, n in ((self.U, self.n_users), (self.I, self.n_items)):
+            if self.world == 1:
+                out.append(shard[:n].clone())
+                continue
+            allg = _all_gather_rows(shard, self.world, self.group).view(self.world, shard.shape[0], self.d)
+            full = allg.permute(1, 0, 2).reshape(-1, self.d)  # global row l*W + k  <-  rank k, local l
+            out.append(full[:n].clone())
+        return out
+
+    # ---- one training step ------------------------------------------------------------------------
+    def step(self, uid, iid):
+        """uid [B] int64, iid [B, C] int64: this rank's tuples (same B on every rank).
+        Returns the GLOBAL mean loss as a python-free device tensor [1]."""
+        W, ops = self.world, self.ops
+        B, C = iid.shape
+        n_tuples = W * B
+        self.step_count += 1
+        hyper = ops.make_hyper(opt=self.opt, lr=self.lr, l2=self.l2, step=self.step_count)
+        if W == 1:
+            return self._step_single(uid, iid, hyper)
+
+        # 1. fetch the batch's user rows from their owners
+        order_u, cnt_u = _group_by_owner(uid, W)
+        req_u, rcnt_u = _exchange((uid[order_u] // W), cnt_u, self.group)
+        rows_back = _exchange_back(ops.gather_rows(self.U, req_u), rcnt_u, cnt_u, self.group)
+        Ub = torch.empty((B, self.d), dtype=torch.float32, device=uid.device)
+        Ub[order_u] = rows_back
+
+        # 2. every owner needs every tuple's user row
+        Uall = _all_gather_rows(Ub, W, self.group)
+
+        # 3. route candidate occurrences to the item's owner: (global tuple index, local row)
+        flat = iid.reshape(-1)
+        order_i, cnt_i = _group_by_owner(flat, W)
+        t_global = self.rank * B + order_i // C
+        packed = (t_global << 32) | (flat[order_i] // W)
+        recv, rcnt_i = _exchange(packed, cnt_i, self.group)
+        t_idx, rows = recv >> 32, recv & 0xFFFFFFFF
+
+        # 4. owner scores its rows; scores go home
+        scores = ops.dot_rows(Uall, t_idx.contiguous(), self.I, rows.contiguous())
+        s_home = _exchange_back(scores, rcnt_i, cnt_i, self.group)
+        pred = torch.empty(B * C, dtype=torch.float32, device=uid.device)
+        pred[order_i] = s_home
+        pred = pred.view(B, C)
+
+        # 5. loss and dL/dscore at home (mean over the GLOBAL batch)
+        loss_vec, g = ops.bpr_loss(pred, 1.0 / n_tuples)
+        loss = _all_reduce_sum(loss_vec.sum().reshape(1) / n_tuples, self.group)
+        g_own, _ = _exchange(g.reshape(-1)[order_i], cnt_i, self.group, recv_counts=rcnt_i)  # routing of step 3
+
+        # 6. owner: partial user grads (needs pre-step item rows), then the item-row update
+        pug = ops.partial_user_grads(self.I, rows, g_own, t_idx, n_tuples)
+        ops.update_rows(self.I, self.sI, rows, Uall, hyper, coef=g_own, src_index=t_idx)
+
+        # 7. sum the partial user grads at the tuples' home, route them to the user rows' owners
+        ugrad = _reduce_scatter_rows(pug, W, self.group)
+        ug_own, _ = _exchange(ugrad[order_u], cnt_u, self.group, recv_counts=rcnt_u)
+        ops.update_rows(self.U, self.sU, req_u, ug_own, hyper)
+        return loss
+
+    def _step_single(self, uid, iid, hyper):
+        """W = 1: the same arithmetic without any exchange (reference point for the tests)"""
+        ops = self.ops
+        B, C = iid.shape
+        flat = iid.reshape(-1)
+        t_idx = torch.arange(B, device=uid.device).repeat_interleave(C)
+        Ub = ops.gather_rows(self.U, uid)
+        pred = ops.dot_rows(Ub, t_idx, self.I, flat).view(B, C)
+        loss_vec, g = ops.bpr_loss(pred, 1.0 / B)
+        pug = ops.partial_user_grads(self.I, flat, g.reshape(-1), t_idx, B)
+        ops.update_rows(self.I, self.sI, flat, Ub, hyper, coef=g.reshape(-1), src_index=t_idx)
+        ops.update_rows(self.U, self.sU, uid, pug, hyper)
+        return loss_vec.sum().reshape(1) / B

@@ -113,3 +113,29 @@ def test_cli_trains_and_reports_like_the_reference(engine, opt, lr, dataset_root
     assert os.path.exists(str(tmp_path / "model" / "m.pt"))
     rec = tmp_path / "log" / "run" / "rec-BPRMF-test.csv"
     assert rec.exists() and len(open(rec).read().splitlines()) == 401
+
+
+def test_sharded_engine_single_rank_on_hip(cuda):
+    """ShardedBprmf's local ops on the HIP engine (W = 1: no collectives) vs the oracle; the
+    routing itself is covered by the gloo tests (tests/test_sharded_gloo.py)"""
+    from oracle import bprmf_oracle as O
+    from rechorus_amd.sharded import ShardedBprmf
+    rng = np.random.default_rng(11)
+    n_users, n_items, d, B, C = 57, 300, 64, 64, 20
+    U = rng.normal(0, 0.05, (n_users, d)).astype(np.float32)
+    I = rng.normal(0, 0.05, (n_items, d)).astype(np.float32)
+    for opt, lr, l2 in (("SGD", 0.1, 1e-3), ("Adam", 1e-2, 0.0)):
+        m = ShardedBprmf(n_users, n_items, d, opt=opt, lr=lr, l2=l2, device=cuda)
+        m.load_global(torch.from_numpy(U).to(cuda), torch.from_numpy(I).to(cuda))
+        Un, In = U.copy(), I.copy()
+        sU, sI = O.new_state(Un, opt), O.new_state(In, opt)
+        for step in (1, 2):
+            uid = rng.integers(0, n_users, size=B).astype(np.int64)
+            iid = rng.integers(0, n_items, size=(B, C)).astype(np.int64)
+            loss = float(m.step(torch.from_numpy(uid).to(cuda), torch.from_numpy(iid).to(cuda)))
+            want, _ = O.bprmf_train_step(Un, In, sU, sI, uid, iid, opt=opt, lr=lr, l2=l2, step=step, rowwise=True)
+            assert_close(loss, want, what=f"{opt} loss {step}")
+        Ug, Ig = m.gather_global()
+        ex = 1e-3 * lr if opt == "Adam" else 0.0
+        assert_update_close(Ug.cpu().numpy(), U, Un, what="dU", extra_atol=ex)
+        assert_update_close(Ig.cpu().numpy(), I, In, what="dI", extra_atol=ex)
