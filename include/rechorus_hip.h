@@ -176,6 +176,31 @@ int rc_dense_update(float* W, const float* G, float* m, float* v, int64_t n,
 
 /* ---- whole BPRMF training step ----------------------------------------------------- */
 
+/* ---- NeuMF head (models/general/NeuMF.py:56-76), one hidden layer, dropout 0 ------------- */
+
+/* 1 iff the fp32-MFMA kernels cover (emb_size d, hidden size l1): d, l1 in {32,64,128} and the
+ * LDS image (W1 + a 64-candidate tile) fits 160 KB.  Other shapes: use rc_gather_rows + any GEMM. */
+int rc_neumf_supported(int d, int l1);
+
+/* pred[b,c] = w_out[:d].(mf_u[u_b]*mf_i[i_bc]) + w_out[d:].relu(W1 [mlp_u[u_b];mlp_i[i_bc]] + b1)
+ * (NeuMF.py:61-75; W1 = mlp.0.weight [l1, 2d], b1 = mlp.0.bias, w_out = prediction.weight[0]).  */
+int rc_neumf_fwd(const float* mf_u, const float* mf_i, const float* mlp_u, const float* mlp_i,
+                 const float* W1, const float* b1, const float* w_out, const int64_t* uid,
+                 const int64_t* iid, int B, int C, int d, int l1, float* pred,
+                 rc_stream_t stream);
+
+size_t rc_neumf_workspace_bytes(int B, int C, int d, int l1);
+
+/* Backward of rc_neumf_fwd for dL/dpred = gpred [B,C] (what autograd derives from NeuMF.py:61-75):
+ * per-OCCURRENCE gradients of the four table rows, g_*[b*C+c, :]  (feed them to
+ * rc_segmented_update with keys = sorted uid-per-candidate / iid), and the dense gradients
+ * dW1 [l1,2d], db1 [l1], dw_out [d+l1] (summed over workgroups in fixed order).              */
+int rc_neumf_bwd(const float* mf_u, const float* mf_i, const float* mlp_u, const float* mlp_i,
+                 const float* W1, const float* b1, const float* w_out, const int64_t* uid,
+                 const int64_t* iid, const float* gpred, int B, int C, int d, int l1,
+                 float* g_mf_u, float* g_mf_i, float* g_mlp_u, float* g_mlp_i, float* dW1,
+                 float* db1, float* dw_out, void* ws, size_t ws_bytes, rc_stream_t stream);
+
 size_t rc_bprmf_step_workspace_bytes(int B, int C, int d);
 
 /* One BaseRunner.fit iteration for BPRMF (helpers/BaseRunner.py:193-206 with

@@ -65,6 +65,10 @@ SIGNATURES = {
     "rc_segmented_workspace_bytes": (_sz, [_i64, _i]),
     "rc_segmented_update": (_i, [_p, _p, _p, _i, _p, _p, _i64, _p, _p, _p, _i, _hp, _p, _p, _p, _i, _p, _sz, _p]),
     "rc_dense_update": (_i, [_p, _p, _p, _p, _i64, _hp, _p]),
+    "rc_neumf_supported": (_i, [_i, _i]),
+    "rc_neumf_fwd": (_i, [_p] * 9 + [_i, _i, _i, _i, _p, _p]),
+    "rc_neumf_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "rc_neumf_bwd": (_i, [_p] * 10 + [_i, _i, _i, _i] + [_p] * 7 + [_p, _sz, _p]),
     "rc_bprmf_step_workspace_bytes": (_sz, [_i, _i, _i]),
     "rc_bprmf_train_step": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i64, _i64, _hp, _f,
                                  _p, _p, _p, _sz, _p, C.POINTER(C.c_float)]),

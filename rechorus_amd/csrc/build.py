@@ -28,6 +28,7 @@ SOURCES = [
     "seg_update.hip",
     "dense_opt.hip",
     "train_step.hip",
+    "neumf.hip",
 ]
 HEADERS = ["common.hpp", "bpr_math.hpp", "opt_math.hpp", os.path.join("..", "..", "include", "rechorus_hip.h")]
 

@@ -1,0 +1,421 @@
+// neumf.hip -- the NeuMF interaction head (reference: models/general/NeuMF.py:56-76), one
+// hidden MLP layer (the reference's default `--layers [64]`), forward and backward, fp32.
+//
+//   mf   = mf_u[u] * mf_i[i]                          (GMF branch, d)
+//   h0   = [mlp_u[u] ; mlp_i[i]]                      (2d)
+//   h1   = relu(W1 h0 + b1)                           (L1; dropout p = 0)
+//   pred = w_out[:d] . mf + w_out[d:] . h1            (Linear(d+L1, 1, bias=False))
+//
+// 33 kFLOP (fwd) per candidate against 1 KB of gathered rows at d=128: the MLP sits on the
+// fp32 ridge of the chip, so it runs on the fp32 MATRIX cores: v_mfma_f32_32x32x2_f32 (exact
+// f32 FMA chains -- same rounding class as the reference's addmm) with both operands in LDS.
+//
+// A persistent workgroup keeps W1 in LDS (padded stride 2d+1: conflict-free ds_read_b32 for the
+// MFMA operand fetch, lane <-> row) and walks 64-candidate tiles:
+//   gather   lane-group (d/4 lanes) per candidate: 4 table rows; mf dot by DPP row reduction;
+//            h0 tile -> LDS As[64][2d+1]
+//   fwd      Z1^T[L1 x 64] = W1 . h0^T        (A = W1 block, B = h0^T block, K = 2d)
+//   (bwd)    dz1 = g * w_h * relu'            -> LDS Zs[L1][65]
+//            dh0^T[2d x 64] = W1^T . dz1      (K = L1)   -> per-occurrence row gradients
+//            dW1[L1 x 2d] += dz1 . h0         (K = 64)   accumulators persist across tiles
+// The backward kernel recomputes the forward GEMM instead of storing activations.  Dense
+// parameter gradients leave the kernel as per-workgroup partials summed in fixed order by
+// neumf_reduce_partials_kernel (deterministic, no float atomics).  Table-row gradients are
+// written per occurrence ([B*C, d] x 4) and consumed by rc_segmented_update.
+#include "common.hpp"
+
+namespace rc {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kTileM = 64;
+
+struct NeumfArgs {
+  const float* mf_u;
+  const float* mf_i;
+  const float* mlp_u;
+  const float* mlp_i;
+  const float* W1;     // [L1, 2d] (nn.Linear.weight)
+  const float* b1;     // [L1]
+  const float* w_out;  // [d + L1]  (prediction.weight[0])
+  const int64_t* uid;
+  const int64_t* iid;
+  int B, C;
+  int64_t n;           // B*C
+  float* pred;         // fwd
+  const float* gpred;  // bwd
+  float* g_mf_u;       // bwd: [n, d] per-occurrence row gradients
+  float* g_mf_i;
+  float* g_mlp_u;
+  float* g_mlp_i;
+  float* pW1;          // bwd: per-workgroup partials [n_wg][L1*2d], [n_wg][L1], [n_wg][d+L1]
+  float* pb1;
+  float* pwout;
+};
+
+template <int D, int L1>
+struct NeumfCfg {
+  static constexpr int K0 = 2 * D;
+  static constexpr int SW = K0 + 1;      // LDS row stride of Ws / As (floats)
+  static constexpr int SZ = kTileM + 1;  // LDS row stride of Zs
+  static constexpr int NRB = L1 / 32;    // 32-row blocks of hidden features
+  static constexpr int NKB = K0 / 32;    // 32-row blocks of h0 features
+  static constexpr int LPR = D / 4;      // lanes per table row
+  static constexpr int NG = kBlock / LPR;
+  static constexpr int kLdsFloats = L1 * SW + kTileM * SW + L1 * SZ + L1 + (D + L1) + 2 * kTileM +
+                                    NRB * kTileM + kBlock * 4;
+  static_assert(D % 32 == 0 && L1 % 32 == 0, "NeuMF MFMA path needs d and L1 multiples of 32");
+};
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// accumulator register r of lane -> row inside a 32x32 block (column = lane & 31)
+__device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+template <int D, int L1, bool BWD>
+__global__ __launch_bounds__(kBlock) void neumf_kernel(NeumfArgs a) {
+  using Cfg = NeumfCfg<D, L1>;
+  constexpr int K0 = Cfg::K0, SW = Cfg::SW, SZ = Cfg::SZ, NRB = Cfg::NRB, NKB = Cfg::NKB;
+  constexpr int LPR = Cfg::LPR, NG = Cfg::NG, M = kTileM;
+  constexpr int NB_F = NRB * 2, QF = (NB_F + 3) / 4;    // fwd blocks (rb, cb)
+  constexpr int NB_H = NKB * 2, QH = (NB_H + 3) / 4;    // dh0 blocks (kb, cb)
+  constexpr int NB_W = NRB * NKB, QW = (NB_W + 3) / 4;  // dW1 blocks (rb, kb)
+
+  extern __shared__ float lds[];
+  float* Ws = lds;
+  float* As = Ws + L1 * SW;
+  float* Zs = As + M * SW;
+  float* sb1 = Zs + L1 * SZ;
+  float* swo = sb1 + L1;
+  float* sg = swo + (D + L1);
+  float* smf = sg + M;
+  float* spp = smf + M;          // [NRB][M]
+  float* sred = spp + NRB * M;   // [kBlock*4] scratch for the final reductions
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int grp = tid / LPR;
+  const int l = tid % LPR;
+
+  for (int i = tid; i < L1 * K0; i += kBlock) Ws[(i / K0) * SW + (i % K0)] = a.W1[i];
+  for (int i = tid; i < L1; i += kBlock) sb1[i] = a.b1[i];
+  for (int i = tid; i < D + L1; i += kBlock) swo[i] = a.w_out[i];
+  __syncthreads();
+  const float4 wm = make_float4(swo[4 * l], swo[4 * l + 1], swo[4 * l + 2], swo[4 * l + 3]);
+
+  f32x16 accW[QW];
+  float db1acc[QF][16], dwhacc[QF][16];
+  float4 accwm = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (BWD) {
+#pragma unroll
+    for (int s = 0; s < QW; ++s)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accW[s][r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < QF; ++s)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) db1acc[s][r] = dwhacc[s][r] = 0.f;
+  }
+
+  const int64_t n_tiles = (a.n + M - 1) / M;
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int64_t n0 = tile * M;
+    // ---- gather: one lane-group per candidate (uniform trip count: NG divides M) -------------
+    for (int cc = grp; cc < M; cc += NG) {
+      const int64_t n = n0 + cc;
+      const bool valid = n < a.n;
+      const int64_t nn = valid ? n : a.n - 1;
+      const int64_t u = a.uid[nn / a.C];
+      const int64_t it = a.iid[nn];
+      const float4 mu = reinterpret_cast<const float4*>(a.mf_u + u * D)[l];
+      const float4 mi = reinterpret_cast<const float4*>(a.mf_i + it * D)[l];
+      float4 hu = reinterpret_cast<const float4*>(a.mlp_u + u * D)[l];
+      float4 hi = reinterpret_cast<const float4*>(a.mlp_i + it * D)[l];
+      if (!valid) hu = hi = make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 mm = make_float4(mu.x * mi.x, mu.y * mi.y, mu.z * mi.z, mu.w * mi.w);
+      const float dot = row_allreduce_sum<LPR>(dot4(wm, mm));
+      if (l == 0) smf[cc] = dot;
+      float* arow = As + cc * SW;
+      arow[4 * l + 0] = hu.x; arow[4 * l + 1] = hu.y; arow[4 * l + 2] = hu.z; arow[4 * l + 3] = hu.w;
+      arow[D + 4 * l + 0] = hi.x; arow[D + 4 * l + 1] = hi.y; arow[D + 4 * l + 2] = hi.z; arow[D + 4 * l + 3] = hi.w;
+      if (BWD) {
+        const float g = valid ? a.gpred[nn] : 0.f;
+        if (l == 0) sg[cc] = g;
+        if (valid) {  // d pred / d mf rows: g * w_mf * (other row)
+          const float4 gw = make_float4(g * wm.x, g * wm.y, g * wm.z, g * wm.w);
+          reinterpret_cast<float4*>(a.g_mf_u + n * D)[l] = make_float4(gw.x * mi.x, gw.y * mi.y, gw.z * mi.z, gw.w * mi.w);
+          reinterpret_cast<float4*>(a.g_mf_i + n * D)[l] = make_float4(gw.x * mu.x, gw.y * mu.y, gw.z * mu.z, gw.w * mu.w);
+        }
+        accwm.x = fmaf(g, mm.x, accwm.x); accwm.y = fmaf(g, mm.y, accwm.y);
+        accwm.z = fmaf(g, mm.z, accwm.z); accwm.w = fmaf(g, mm.w, accwm.w);
+      }
+    }
+    __syncthreads();
+
+    // ---- forward GEMM  Z1^T = W1 . h0^T, epilogue ---------------------------------------------
+#pragma unroll
+    for (int s = 0; s < QF; ++s) {
+      const int q = wave + 4 * s;
+      if (q < NB_F) {  // wave-uniform
+        const int rb = q % NRB, cb = q / NRB;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const float* wa = Ws + (rb * 32 + (lane & 31)) * SW + (lane >> 5);
+        const float* hb = As + (cb * 32 + (lane & 31)) * SW + (lane >> 5);
+#pragma unroll 8
+        for (int k0 = 0; k0 < K0; k0 += 2) acc = mfma32(wa[k0], hb[k0], acc);
+        const int cand = cb * 32 + (lane & 31);
+        const float gj = BWD ? sg[cand] : 0.f;
+        float pp = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int f = rb * 32 + acc_row(r, lane);
+          const float z = acc[r] + sb1[f];
+          const float h = fmaxf(z, 0.f);
+          const float wh = swo[D + f];
+          pp = fmaf(wh, h, pp);
+          if (BWD) {
+            const float dz = z > 0.f ? gj * wh : 0.f;
+            Zs[f * SZ + cand] = dz;
+            db1acc[s][r] += dz;
+            dwhacc[s][r] = fmaf(gj, h, dwhacc[s][r]);
+          }
+        }
+        pp += __shfl_xor(pp, 32, 64);
+        if (lane < 32) spp[rb * M + cand] = pp;
+      }
+    }
+    __syncthreads();
+
+    if (!BWD) {
+      for (int cc = tid; cc < M; cc += kBlock) {
+        const int64_t n = n0 + cc;
+        if (n < a.n) {
+          float p = smf[cc];
+#pragma unroll
+          for (int rb = 0; rb < NRB; ++rb) p += spp[rb * M + cc];
+          a.pred[n] = p;
+        }
+      }
+    } else {
+      // ---- dh0^T = W1^T . dz1  ->  per-occurrence gradients of the mlp_u / mlp_i rows ----------
+#pragma unroll
+      for (int s = 0; s < QH; ++s) {
+        const int q = wave + 4 * s;
+        if (q < NB_H) {
+          const int kb = q % NKB, cb = q / NKB;
+          f32x16 acc;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+          const float* wa = Ws + (lane >> 5) * SW + kb * 32 + (lane & 31);
+          const float* zb = Zs + (lane >> 5) * SZ + cb * 32 + (lane & 31);
+#pragma unroll 8
+          for (int f0 = 0; f0 < L1; f0 += 2) acc = mfma32(wa[f0 * SW], zb[f0 * SZ], acc);
+          const int64_t n = n0 + cb * 32 + (lane & 31);
+          if (n < a.n) {
+            float* base = (kb * 32 < D) ? (a.g_mlp_u + n * D + kb * 32) : (a.g_mlp_i + n * D + (kb * 32 - D));
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq)
+              reinterpret_cast<float4*>(base + 8 * rq + 4 * (lane >> 5))[0] =
+                  make_float4(acc[4 * rq], acc[4 * rq + 1], acc[4 * rq + 2], acc[4 * rq + 3]);
+          }
+        }
+      }
+      // ---- dW1 += dz1 . h0 (accumulators live across tiles) -------------------------------------
+#pragma unroll
+      for (int s = 0; s < QW; ++s) {
+        const int q = wave + 4 * s;
+        if (q < NB_W) {
+          const int rb = q % NRB, kb = q / NRB;
+          const float* za = Zs + (rb * 32 + (lane & 31)) * SZ + (lane >> 5);
+          const float* hb = As + (lane >> 5) * SW + kb * 32 + (lane & 31);
+#pragma unroll 8
+          for (int c0 = 0; c0 < M; c0 += 2) accW[s] = mfma32(za[c0], hb[c0 * SW], accW[s]);
+        }
+      }
+    }
+    __syncthreads();  // As / Zs / sg / spp are rewritten by the next tile
+  }
+
+  if (BWD) {
+    const size_t wg = blockIdx.x;
+    // dW1 partial: block (rb, kb): row = hidden feature, column = h0 feature
+#pragma unroll
+    for (int s = 0; s < QW; ++s) {
+      const int q = wave + 4 * s;
+      if (q < NB_W) {
+        const int rb = q % NRB, kb = q / NRB;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          a.pW1[wg * (L1 * K0) + (size_t)(rb * 32 + acc_row(r, lane)) * K0 + kb * 32 + (lane & 31)] = accW[s][r];
+      }
+    }
+    // db1 / dw_h: sum the per-lane partials over the 32 candidate columns, then over the
+    // column blocks (different waves) through LDS, fixed order
+    for (int i = tid; i < 2 * L1 * 2; i += kBlock) sred[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < QF; ++s) {
+      const int q = wave + 4 * s;
+      if (q < NB_F) {
+        const int rb = q % NRB, cb = q / NRB;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float x = db1acc[s][r], y = dwhacc[s][r];
+#pragma unroll
+          for (int off = 16; off >= 1; off >>= 1) {
+            x += __shfl_xor(x, off, 64);
+            y += __shfl_xor(y, off, 64);
+          }
+          if ((lane & 31) == 0) {
+            const int f = rb * 32 + acc_row(r, lane);
+            sred[(cb * 2 + 0) * L1 + f] = x;   // [cb][0: db1, 1: dwh][f]
+            sred[(cb * 2 + 1) * L1 + f] = y;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    for (int f = tid; f < L1; f += kBlock) {
+      a.pb1[wg * L1 + f] = sred[0 * L1 + f] + sred[2 * L1 + f];
+      a.pwout[wg * (D + L1) + D + f] = sred[1 * L1 + f] + sred[3 * L1 + f];
+    }
+    __syncthreads();
+    // dw_mf: per-lane float4 partials -> sum over the NG lane-groups in group order
+    reinterpret_cast<float4*>(sred)[tid] = accwm;
+    __syncthreads();
+    for (int k = tid; k < D; k += kBlock) {
+      float acc = 0.f;
+      for (int g2 = 0; g2 < NG; ++g2) acc += sred[(g2 * LPR + k / 4) * 4 + (k & 3)];
+      a.pwout[wg * (D + L1) + k] = acc;
+    }
+  }
+}
+
+// out[i] = sum_w p[w][i], w ascending (deterministic)
+__global__ __launch_bounds__(kBlock) void neumf_reduce_partials_kernel(const float* __restrict__ p,
+                                                                       int n_wg, int count,
+                                                                       float* __restrict__ out) {
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < count; i += gridDim.x * kBlock) {
+    float acc = 0.f;
+    for (int w = 0; w < n_wg; ++w) acc += p[(size_t)w * count + i];
+    out[i] = acc;
+  }
+}
+
+template <int D, int L1, bool BWD>
+static int launch_neumf(const NeumfArgs& a, int n_wg, hipStream_t s) {
+  using Cfg = NeumfCfg<D, L1>;
+  const size_t lds_bytes = (size_t)Cfg::kLdsFloats * sizeof(float);
+  auto kern = neumf_kernel<D, L1, BWD>;
+  RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int)lds_bytes));
+  hipLaunchKernelGGL(kern, dim3(n_wg), dim3(kBlock), lds_bytes, s, a);
+  RC_LAUNCH_CHECK();
+  return RC_OK;
+}
+
+static size_t neumf_lds_bytes(int d, int l1) {
+  const size_t k0 = 2 * (size_t)d;
+  return sizeof(float) * ((size_t)l1 * (k0 + 1) + kTileM * (k0 + 1) + (size_t)l1 * (kTileM + 1) + l1 + (d + l1) +
+                          2 * kTileM + (l1 / 32) * kTileM + kBlock * 4);
+}
+
+static bool neumf_supported(int d, int l1) {
+  const bool shape = (d == 32 || d == 64 || d == 128) && (l1 == 32 || l1 == 64 || l1 == 128);
+  return shape && neumf_lds_bytes(d, l1) <= 160 * 1024;
+}
+
+static int neumf_grid(int64_t n, int d, int l1) {
+  const int64_t tiles = (n + kTileM - 1) / kTileM;
+  const int per_cu = (int)((160 * 1024) / neumf_lds_bytes(d, l1));
+  int64_t g = 256 * (int64_t)(per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu));
+  if (g > tiles) g = tiles;
+  return (int)(g < 1 ? 1 : g);
+}
+
+template <bool BWD>
+static int dispatch_neumf(const NeumfArgs& a, int d, int l1, int n_wg, hipStream_t s) {
+#define RC_NM(D_, L_) \
+  if (d == D_ && l1 == L_) return launch_neumf<D_, L_, BWD>(a, n_wg, s)
+  RC_NM(32, 32); RC_NM(32, 64); RC_NM(32, 128);
+  RC_NM(64, 32); RC_NM(64, 64); RC_NM(64, 128);
+  RC_NM(128, 32); RC_NM(128, 64);
+#undef RC_NM
+  return fail(RC_ERR_UNSUPPORTED, "NeuMF: no kernel for d=%d, hidden=%d", d, l1);
+}
+
+}  // namespace rc
+
+using namespace rc;
+
+extern "C" int rc_neumf_supported(int d, int l1) {
+  return (neumf_supported(d, l1) && !(d == 128 && l1 == 128)) ? 1 : 0;
+}
+
+extern "C" size_t rc_neumf_workspace_bytes(int B, int C, int d, int l1) {
+  if (!rc_neumf_supported(d, l1) || B < 1 || C < 1) return 0;
+  const int n_wg = neumf_grid((int64_t)B * C, d, l1);
+  const size_t per = (size_t)l1 * 2 * d + l1 + (d + l1);
+  return align_up((size_t)n_wg * per * sizeof(float), 256) + 256;
+}
+
+extern "C" int rc_neumf_fwd(const float* mf_u, const float* mf_i, const float* mlp_u,
+                            const float* mlp_i, const float* W1, const float* b1,
+                            const float* w_out, const int64_t* uid, const int64_t* iid, int B,
+                            int C, int d, int l1, float* pred, rc_stream_t stream) {
+  if (B == 0) return RC_OK;
+  RC_REQUIRE(mf_u && mf_i && mlp_u && mlp_i && W1 && b1 && w_out && uid && iid && pred,
+             "rc_neumf_fwd: null pointer");
+  RC_REQUIRE(B > 0 && C >= 1, "rc_neumf_fwd: bad shape B=%d C=%d", B, C);
+  if (!rc_neumf_supported(d, l1))
+    return fail(RC_ERR_UNSUPPORTED, "rc_neumf_fwd: d=%d hidden=%d not supported (d, hidden in {32,64,128}, LDS <= 160 KB)", d, l1);
+  NeumfArgs a;
+  memset(&a, 0, sizeof(a));
+  a.mf_u = mf_u; a.mf_i = mf_i; a.mlp_u = mlp_u; a.mlp_i = mlp_i; a.W1 = W1; a.b1 = b1; a.w_out = w_out;
+  a.uid = uid; a.iid = iid; a.B = B; a.C = C; a.n = (int64_t)B * C; a.pred = pred;
+  return dispatch_neumf<false>(a, d, l1, neumf_grid(a.n, d, l1), as_stream(stream));
+}
+
+extern "C" int rc_neumf_bwd(const float* mf_u, const float* mf_i, const float* mlp_u,
+                            const float* mlp_i, const float* W1, const float* b1,
+                            const float* w_out, const int64_t* uid, const int64_t* iid,
+                            const float* gpred, int B, int C, int d, int l1, float* g_mf_u,
+                            float* g_mf_i, float* g_mlp_u, float* g_mlp_i, float* dW1, float* db1,
+                            float* dw_out, void* ws, size_t ws_bytes, rc_stream_t stream) {
+  if (B == 0) return RC_OK;
+  RC_REQUIRE(mf_u && mf_i && mlp_u && mlp_i && W1 && b1 && w_out && uid && iid && gpred && g_mf_u &&
+                 g_mf_i && g_mlp_u && g_mlp_i && dW1 && db1 && dw_out && ws,
+             "rc_neumf_bwd: null pointer");
+  RC_REQUIRE(B > 0 && C >= 1, "rc_neumf_bwd: bad shape B=%d C=%d", B, C);
+  if (!rc_neumf_supported(d, l1))
+    return fail(RC_ERR_UNSUPPORTED, "rc_neumf_bwd: d=%d hidden=%d not supported", d, l1);
+  if (ws_bytes < rc_neumf_workspace_bytes(B, C, d, l1))
+    return fail(RC_ERR_WORKSPACE, "rc_neumf_bwd: workspace %zu < %zu", ws_bytes,
+                rc_neumf_workspace_bytes(B, C, d, l1));
+  hipStream_t s = as_stream(stream);
+  NeumfArgs a;
+  memset(&a, 0, sizeof(a));
+  a.mf_u = mf_u; a.mf_i = mf_i; a.mlp_u = mlp_u; a.mlp_i = mlp_i; a.W1 = W1; a.b1 = b1; a.w_out = w_out;
+  a.uid = uid; a.iid = iid; a.B = B; a.C = C; a.n = (int64_t)B * C; a.gpred = gpred;
+  a.g_mf_u = g_mf_u; a.g_mf_i = g_mf_i; a.g_mlp_u = g_mlp_u; a.g_mlp_i = g_mlp_i;
+  const int n_wg = neumf_grid(a.n, d, l1);
+  const int cW = l1 * 2 * d, cb = l1, co = d + l1;
+  float* p = reinterpret_cast<float*>(ws);
+  a.pW1 = p;
+  a.pb1 = p + (size_t)n_wg * cW;
+  a.pwout = a.pb1 + (size_t)n_wg * cb;
+  RC_TRY(dispatch_neumf<true>(a, d, l1, n_wg, s));
+  hipLaunchKernelGGL(neumf_reduce_partials_kernel, dim3((cW + kBlock - 1) / kBlock), dim3(kBlock), 0, s,
+                     a.pW1, n_wg, cW, dW1);
+  RC_LAUNCH_CHECK();
+  hipLaunchKernelGGL(neumf_reduce_partials_kernel, dim3(1), dim3(kBlock), 0, s, a.pb1, n_wg, cb, db1);
+  RC_LAUNCH_CHECK();
+  hipLaunchKernelGGL(neumf_reduce_partials_kernel, dim3(1), dim3(kBlock), 0, s, a.pwout, n_wg, co, dw_out);
+  RC_LAUNCH_CHECK();
+  return RC_OK;
+}

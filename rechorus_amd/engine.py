@@ -292,3 +292,86 @@ class BprmfTrainer:
         names = ["sort_items", "sort_users", "fused_fwd_bwd", "loss_mean", "item_update",
                  "user_update", "total", "segment_heads"]
         return {n: float(buf[i]) for i, n in enumerate(names)}
+
+
+# ---- NeuMF head ----------------------------------------------------------------------------------
+
+def neumf_supported(d, l1):
+    return bool(_lib.load().rc_neumf_supported(int(d), int(l1)))
+
+
+def _neumf_ptrs(P):
+    f32 = torch.float32
+    return [_ptr(P[k], f32, k) for k in ("mf_u", "mf_i", "mlp_u", "mlp_i", "W1", "b1", "w_out")]
+
+
+def neumf_fwd(P, uid, iid):
+    """P: dict mf_u, mf_i, mlp_u, mlp_i [rows,d], W1 [l1,2d], b1 [l1], w_out [d+l1] -> pred [B,C]
+    (models/general/NeuMF.py:61-75)."""
+    B, Cn = iid.shape
+    d, l1 = P["mf_u"].shape[1], P["W1"].shape[0]
+    pred = torch.empty((B, Cn), dtype=torch.float32, device=iid.device)
+    _lib.call("rc_neumf_fwd", *_neumf_ptrs(P), _ptr(uid, torch.int64, "uid"), _ptr(iid, torch.int64, "iid"),
+              B, Cn, d, l1, _ptr(pred, torch.float32, "pred"), _stream())
+    return pred
+
+
+def neumf_bwd(P, uid, iid, gpred):
+    """-> (per-occurrence row grads dict g_mf_u, g_mf_i, g_mlp_u, g_mlp_i [B*C,d], dense grads dict W1, b1, w_out)"""
+    B, Cn = iid.shape
+    d, l1 = P["mf_u"].shape[1], P["W1"].shape[0]
+    dev, f32 = iid.device, torch.float32
+    rows = {k: torch.empty((B * Cn, d), dtype=f32, device=dev) for k in ("g_mf_u", "g_mf_i", "g_mlp_u", "g_mlp_i")}
+    dense = {"W1": torch.empty_like(P["W1"]), "b1": torch.empty_like(P["b1"]), "w_out": torch.empty_like(P["w_out"])}
+    ws = workspace(_lib.load().rc_neumf_workspace_bytes(B, Cn, d, l1), dev, "neumf")
+    _lib.call("rc_neumf_bwd", *_neumf_ptrs(P), _ptr(uid, torch.int64, "uid"), _ptr(iid, torch.int64, "iid"),
+              _ptr(gpred, f32, "gpred"), B, Cn, d, l1,
+              *[_ptr(rows[k], f32, k) for k in ("g_mf_u", "g_mf_i", "g_mlp_u", "g_mlp_i")],
+              _ptr(dense["W1"], f32, "dW1"), _ptr(dense["b1"], f32, "db1"), _ptr(dense["w_out"], f32, "dw_out"),
+              C.c_void_p(ws.data_ptr()), ws.numel(), _stream())
+    return rows, dense
+
+
+class NeumfTrainer:
+    """One BaseRunner.fit iteration for NeuMF (single hidden layer) on device tensors:
+    forward (MFMA) -> BPR loss -> backward (MFMA) -> row-wise segmented update of the four tables
+    -> dense optimizer step of W1, b1, w_out.  P as in neumf_fwd; updated in place."""
+
+    def __init__(self, P, opt="Adam", lr=1e-3, l2=0.0, rowwise=True):
+        self.P, self.opt, self.lr, self.l2, self.rowwise = P, opt, lr, l2, rowwise
+        self.state = {}
+        for k, t in P.items():
+            st = {}
+            if opt in ("Adam", "Adagrad"):
+                st["m"] = torch.zeros_like(t)
+            if opt == "Adam":
+                st["v"] = torch.zeros_like(t)
+            self.state[k] = st
+        self.step_count = 0
+        self.loss = None
+
+    def step(self, uid, iid):
+        P = self.P
+        B, Cn = iid.shape
+        self.step_count += 1
+        pred = neumf_fwd(P, uid, iid)
+        self.loss, _, gpred = bpr_loss(pred)
+        rows, dense = neumf_bwd(P, uid, iid, gpred)
+        h = make_hyper(self.opt, lr=self.lr, l2=self.l2, step=self.step_count)
+        h0 = make_hyper(self.opt, lr=self.lr, l2=0.0, step=self.step_count)  # 'bias' params: no weight decay
+        uid_occ = uid.repeat_interleave(Cn)
+        ku, pu = sort_ids(uid_occ, P["mf_u"].shape[0])
+        ki, pi = sort_ids(iid, P["mf_i"].shape[0])
+        for tab, grad, keys, perm in (("mf_u", "g_mf_u", ku, pu), ("mlp_u", "g_mlp_u", ku, pu),
+                                      ("mf_i", "g_mf_i", ki, pi), ("mlp_i", "g_mlp_i", ki, pi)):
+            st = self.state[tab]
+            if self.rowwise:
+                segmented_update(keys, perm, rows[grad], hyper=h, W=P[tab], m=st.get("m"), v=st.get("v"))
+            else:
+                G = torch.zeros_like(P[tab])
+                segmented_update(keys, perm, rows[grad], dense_grad=G)
+                dense_update(P[tab], G, h, st.get("m"), st.get("v"))
+        for k in ("W1", "b1", "w_out"):
+            st = self.state[k]
+            dense_update(P[k], dense[k], h0 if k == "b1" else h, st.get("m"), st.get("v"))
+        return self.loss

@@ -1,0 +1,92 @@
+"""GPU parity of the NeuMF head kernels (fp32 MFMA) vs the reference's own outputs
+(tests/golden/neumf_*.npz) and the numpy oracle."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_close, assert_update_close, load_golden
+from oracle import neumf_oracle as NO
+from test_oracle_neumf import CASES, params
+
+pytestmark = pytest.mark.gpu
+
+NAMES = {"mf_u": "mf_u_embeddings.weight", "mf_i": "mf_i_embeddings.weight", "mlp_u": "mlp_u_embeddings.weight",
+         "mlp_i": "mlp_i_embeddings.weight", "W1": "mlp.0.weight", "b1": "mlp.0.bias", "w_out": "prediction.weight"}
+
+
+def to_dev(P, cuda):
+    return {k: torch.from_numpy(np.ascontiguousarray(P[v].reshape(-1) if k == "w_out" else P[v])).to(cuda)
+            for k, v in NAMES.items()}
+
+
+@pytest.fixture(scope="module")
+def eng(cuda):
+    from rechorus_amd import engine
+    return engine
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_neumf_forward_backward(case, cuda, eng):
+    g = load_golden(case)
+    P = to_dev(params(g), cuda)
+    uid, iid = torch.from_numpy(g["uid"]).to(cuda), torch.from_numpy(g["iid"]).to(cuda)
+    B, C = g["iid"].shape
+    assert eng.neumf_supported(P["mf_u"].shape[1], P["W1"].shape[0])
+    pred = eng.neumf_fwd(P, uid, iid)
+    assert_close(pred.cpu().numpy(), g["pred"], what="pred")
+    rows, dense = eng.neumf_bwd(P, uid, iid, torch.from_numpy(g["gpred"]).to(cuda))
+    G = params(g, "G/")
+    assert_close(dense["W1"].cpu().numpy(), G["mlp.0.weight"], what="dW1", atol_scale=2e-5)
+    assert_close(dense["b1"].cpu().numpy(), G["mlp.0.bias"], what="db1", atol_scale=2e-5)
+    assert_close(dense["w_out"].cpu().numpy(), G["prediction.weight"][0], what="dw_out", atol_scale=2e-5)
+    uid_occ = uid.repeat_interleave(C)
+    for tab, key, ids in (("mf_u", "g_mf_u", uid_occ), ("mlp_u", "g_mlp_u", uid_occ),
+                          ("mf_i", "g_mf_i", iid), ("mlp_i", "g_mlp_i", iid)):
+        dense_tab = eng.embedding_dense_backward(rows[key], ids, P[tab].shape[0])
+        assert_close(dense_tab.cpu().numpy(), G[NAMES[tab]], what="grad " + tab, atol_scale=2e-5)
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("tag,opt", [("SGD_l20.001", "SGD"), ("Adam_l20.0001", "Adam")])
+def test_neumf_two_fit_iterations_match_reference(case, tag, opt, cuda, eng):
+    g = load_golden(case)
+    lr, l2 = (float(x) for x in g[tag + "_hyper"])
+    P0 = params(g)
+    P = to_dev(P0, cuda)
+    tr = eng.NeumfTrainer(P, opt=opt, lr=lr, l2=l2, rowwise=False)  # dense = exact reference semantics
+    for step, (u, i) in enumerate(((g["uid"], g["iid"]), (g["uid2"], g["iid2"])), 1):
+        loss = tr.step(torch.from_numpy(u).to(cuda), torch.from_numpy(i).to(cuda))
+        assert_close(loss.cpu().numpy()[0], g[tag + "_losses"][step - 1], what=f"loss {step}")
+    want = params(g, tag + "/")
+    ex = 1e-3 * lr if opt == "Adam" else 0.0
+    for k, name in NAMES.items():
+        w0 = P0[name].reshape(-1) if k == "w_out" else P0[name]
+        w1 = want[name].reshape(-1) if k == "w_out" else want[name]
+        assert_update_close(P[k].cpu().numpy(), w0, w1, what=k, extra_atol=ex)
+
+
+def test_neumf_random_shapes_vs_oracle(cuda, eng):
+    rng = np.random.default_rng(3)
+    for d, l1, B, C in ((32, 64, 7, 3), (64, 32, 33, 5), (64, 128, 20, 13), (128, 32, 65, 2), (32, 128, 3, 70)):
+        P = {"mf_u_embeddings.weight": rng.normal(0, 0.3, (17, d)), "mf_i_embeddings.weight": rng.normal(0, 0.3, (40, d)),
+             "mlp_u_embeddings.weight": rng.normal(0, 0.3, (17, d)), "mlp_i_embeddings.weight": rng.normal(0, 0.3, (40, d)),
+             "mlp.0.weight": rng.normal(0, 0.2, (l1, 2 * d)), "mlp.0.bias": rng.normal(0, 0.2, l1),
+             "prediction.weight": rng.normal(0, 0.2, (1, d + l1))}
+        P = {k: v.astype(np.float32) for k, v in P.items()}
+        uid = rng.integers(0, 17, size=B).astype(np.int64)
+        iid = rng.integers(0, 40, size=(B, C)).astype(np.int64)
+        gp = rng.normal(size=(B, C)).astype(np.float32)
+        Pd = to_dev(P, cuda)
+        u, i = torch.from_numpy(uid).to(cuda), torch.from_numpy(iid).to(cuda)
+        pred = eng.neumf_fwd(Pd, u, i)
+        want_pred, G = NO.backward(P, uid, iid, gp)
+        assert_close(pred.cpu().numpy(), want_pred, what=f"pred d={d} l1={l1}", atol_scale=2e-5)
+        rows, dense = eng.neumf_bwd(Pd, u, i, torch.from_numpy(gp).to(cuda))
+        assert_close(dense["W1"].cpu().numpy(), G["mlp.0.weight"], what="dW1", atol_scale=3e-5)
+        assert_close(dense["b1"].cpu().numpy(), G["mlp.0.bias"], what="db1", atol_scale=3e-5)
+        assert_close(dense["w_out"].cpu().numpy(), G["prediction.weight"][0], what="dw_out", atol_scale=3e-5)
+        t = eng.embedding_dense_backward(rows["g_mlp_i"], i, 40)
+        assert_close(t.cpu().numpy(), G["mlp_i_embeddings.weight"], what="grad mlp_i", atol_scale=3e-5)
+        t = eng.embedding_dense_backward(rows["g_mf_u"], u.repeat_interleave(C), 17)
+        assert_close(t.cpu().numpy(), G["mf_u_embeddings.weight"], what="grad mf_u", atol_scale=3e-5)
+    assert not eng.neumf_supported(48, 64) and not eng.neumf_supported(128, 128)
