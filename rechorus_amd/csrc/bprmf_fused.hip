@@ -65,7 +65,7 @@ __global__ __launch_bounds__(kBlock) void bprmf_fwd_bwd_kernel(
   for (int j = 0; j < CPL; ++j) {
     const int c = j * GS + grp;
     const int64_t id = ids[c < C ? c : 0];  // slots past C re-read candidate 0; masked below
-    r[j] = reinterpret_cast<const float4*>(I + id * D)[l];
+    r[j] = load_stream4(reinterpret_cast<const float4*>(I + id * D) + l);
   }
   unsigned smask = 0;  // bit j: candidate slot j of this group is a singleton row
   if (MODE != MODE_NONE) {

@@ -47,7 +47,7 @@ def _newer(target, deps):
     return all(os.path.getmtime(d) <= t for d in deps)
 
 
-def build(force=False, no_dpp=False, resource_usage=False, verbose=True):
+def build(force=False, no_dpp=False, resource_usage=False, verbose=True, defines=()):
     os.makedirs(OBJ_DIR, exist_ok=True)
     hipcc = _hipcc()
     # -ffp-contract=off: only the fmaf() calls written in the kernels fuse, so every template
@@ -56,6 +56,7 @@ def build(force=False, no_dpp=False, resource_usage=False, verbose=True):
              "-ffp-contract=off"]
     if no_dpp:
         flags.append("-DRC_NO_DPP")
+    flags += ["-D" + d for d in defines]
     if resource_usage:
         flags.append("-Rpass-analysis=kernel-resource-usage")
     tag = os.path.join(OBJ_DIR, ".flags")
@@ -99,5 +100,6 @@ if __name__ == "__main__":
     ap.add_argument("--force", action="store_true")
     ap.add_argument("--no-dpp", action="store_true", help="debug: DPP reductions via ds_bpermute")
     ap.add_argument("--resource-usage", action="store_true")
+    ap.add_argument("--define", action="append", default=[], help="extra -D (experiment switches, e.g. RC_NT)")
     a = ap.parse_args()
-    build(force=a.force, no_dpp=a.no_dpp, resource_usage=a.resource_usage)
+    build(force=a.force, no_dpp=a.no_dpp, resource_usage=a.resource_usage, defines=a.define)

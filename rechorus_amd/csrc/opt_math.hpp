@@ -67,6 +67,17 @@ __device__ __forceinline__ void opt_elem(const OptScalars& a, float g, float& w,
   }
 }
 
+// row write-back: the row is not read again in this step -> non-temporal store (-DRC_NO_NT: plain)
+__device__ __forceinline__ void store_row4(float4* p, const float4& x) {
+#ifndef RC_NO_NT
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  v4f v = {x.x, x.y, x.z, x.w};
+  __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(p));
+#else
+  *p = x;
+#endif
+}
+
 // update one float4 slice of a table row in place (row index `row`, slice l of LPR)
 template <int MODE>
 __device__ __forceinline__ void opt_row4(const OptScalars& a, float* __restrict__ W,
@@ -79,9 +90,9 @@ __device__ __forceinline__ void opt_row4(const OptScalars& a, float* __restrict_
   opt_elem<MODE>(a, g.y, w.y, m.y, v.y);
   opt_elem<MODE>(a, g.z, w.z, m.z, v.z);
   opt_elem<MODE>(a, g.w, w.w, m.w, v.w);
-  reinterpret_cast<float4*>(W)[idx4] = w;
-  if (MODE == MODE_ADAM || MODE == MODE_ADAGRAD) reinterpret_cast<float4*>(M)[idx4] = m;
-  if (MODE == MODE_ADAM) reinterpret_cast<float4*>(V)[idx4] = v;
+  store_row4(reinterpret_cast<float4*>(W) + idx4, w);
+  if (MODE == MODE_ADAM || MODE == MODE_ADAGRAD) store_row4(reinterpret_cast<float4*>(M) + idx4, m);
+  if (MODE == MODE_ADAM) store_row4(reinterpret_cast<float4*>(V) + idx4, v);
 }
 #endif
 
