@@ -24,16 +24,18 @@ def load_golden(name):
         return {k: z[k] for k in z.files}
 
 
-def assert_close(got, want, rtol=1e-5, atol_scale=1e-5, what=""):
+def assert_close(got, want, rtol=1e-5, atol_scale=1e-5, what="", abs_floor=0.0):
     """|got-want| <= rtol*|want| + atol_scale*max|want|  (north_star: 1e-5 relative fp32;
     the absolute term covers near-cancelling dot products whose magnitude is far below the
-    tensor's scale)."""
+    tensor's scale).  abs_floor: for tensors that are pure round-off in the reference (e.g. the
+    key-bias gradient of softmax attention, exactly 0 in exact arithmetic), a floor tied to the
+    magnitude of the sibling gradients."""
     got = np.asarray(got, dtype=np.float64)
     want = np.asarray(want, dtype=np.float64)
     assert got.shape == want.shape, f"{what}: shape {got.shape} != {want.shape}"
     scale = float(np.max(np.abs(want))) if want.size else 0.0
     err = np.abs(got - want)
-    tol = rtol * np.abs(want) + atol_scale * scale
+    tol = rtol * np.abs(want) + atol_scale * scale + abs_floor
     bad = err > tol
     if bad.any():
         i = np.unravel_index(np.argmax(err - tol), err.shape)

@@ -1,0 +1,93 @@
+"""Golden vectors for SASRec FROM THE REFERENCE (models/sequential/SASRec.py + utils/layers.py),
+build container only:   PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden_sasrec.py"""
+import os
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from make_golden import HERE, _import_reference, _runner_args  # noqa: E402
+
+
+def make_case(name, n_items, d, n_layers, n_heads, hist_max, B, K, seed):
+    torch, _, BaseRunner = _import_reference()
+    from models.sequential.SASRec import SASRec
+    torch.manual_seed(seed)
+    rng = np.random.default_rng(seed)
+    args = SimpleNamespace(device=torch.device("cpu"), model_path="", buffer=1, num_neg=K, dropout=0, test_all=0,
+                           emb_size=d, num_layers=n_layers, num_heads=n_heads, history_max=hist_max)
+    corpus = SimpleNamespace(n_users=10, n_items=n_items)
+    model = SASRec(args, corpus)
+    with torch.no_grad():  # std 0.01 init keeps attention uniform and ReLUs half-dead: scale up
+        for n, p in model.named_parameters():
+            if "layer_norm" not in n:
+                p.mul_(12.0)
+            else:
+                p.add_(torch.randn_like(p) * 0.1)
+    P0 = {k: v.detach().numpy().copy() for k, v in model.state_dict().items()}
+    out = {"meta": np.array([n_items, d, n_layers, n_heads, hist_max, B, K, seed], dtype=np.int64)}
+    for k, v in P0.items():
+        out["P0/" + k] = v
+
+    def batch():
+        lengths = rng.integers(1, hist_max + 1, size=B).astype(np.int64)
+        lengths[0] = hist_max
+        L = int(lengths.max())
+        hist = np.zeros((B, L), dtype=np.int64)
+        for b in range(B):
+            hist[b, :lengths[b]] = rng.integers(1, n_items, size=lengths[b])
+        iid = rng.integers(1, n_items, size=(B, 1 + K)).astype(np.int64)
+        return hist, lengths, iid
+    b1, b2 = batch(), batch()
+    for tag, (h, ln, i) in (("", b1), ("2", b2)):
+        out["hist" + tag], out["len" + tag], out["iid" + tag] = h, ln, i
+
+    def feed(h, ln, i):
+        return {"history_items": torch.from_numpy(h), "lengths": torch.from_numpy(ln), "item_id": torch.from_numpy(i),
+                "user_id": torch.zeros(len(ln), dtype=torch.long), "batch_size": len(ln), "phase": "train"}
+
+    model.zero_grad()
+    o = model(feed(*b1))
+    pred = o["prediction"]
+    pred.retain_grad()
+    loss = model.loss(o)
+    loss.backward()
+    out["pred"], out["loss"], out["gpred"] = pred.detach().numpy().copy(), np.float32(loss.item()), pred.grad.numpy().copy()
+    for k, p in model.named_parameters():
+        out["G/" + k] = p.grad.numpy().copy()
+
+    for opt_name, lr, l2 in (("SGD", 0.05, 1e-3), ("Adam", 1e-3, 1e-4)):
+        m = SASRec(args, corpus)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in P0.items()})
+        runner = BaseRunner(_runner_args(BaseRunner, opt_name, lr, l2))
+        m.optimizer = runner._build_optimizer(m)
+        tag = "{}_l2{:g}".format(opt_name, l2)
+        losses = []
+        for bt in (b1, b2):
+            m.optimizer.zero_grad()
+            od = m(feed(*bt))
+            ls = m.loss(od)
+            ls.backward()
+            m.optimizer.step()
+            losses.append(ls.item())
+        for k, v in m.state_dict().items():
+            out["{}/{}".format(tag, k)] = v.detach().numpy().copy()
+        out[tag + "_losses"] = np.array(losses, dtype=np.float32)
+        out[tag + "_hyper"] = np.array([lr, l2], dtype=np.float64)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) >> 10, "KiB")
+
+
+CASES = [
+    # name,                 n_items, d, layers, heads, hist_max, B, K, seed
+    ("sasrec_d64_l1_h1",       80, 64, 1, 1, 20, 12, 9, 31),
+    ("sasrec_d64_l1_h4_L50",  120, 64, 1, 4, 50, 8, 19, 32),
+    ("sasrec_d64_l2_h2",       80, 64, 2, 2, 12, 10, 5, 33),
+    ("sasrec_d32_l1_h4",       60, 32, 1, 4, 7, 9, 3, 34),
+]
+
+if __name__ == "__main__":
+    for c in CASES:
+        make_case(*c)
