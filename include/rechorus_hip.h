@@ -176,6 +176,41 @@ int rc_dense_update(float* W, const float* G, float* m, float* v, int64_t n,
 
 /* ---- whole BPRMF training step ----------------------------------------------------- */
 
+/* rc_segmented_update with a SECOND gradient source: occurrences o >= n_split take the plain row
+ * src2[o - n_split, :] instead of coef[o]*Src[srow(o)].  SASRec updates its item table from the
+ * candidates (g[b,c] * encoder output, rebuilt on the fly) and from the history positions
+ * (gradient rows written by the encoder backward) in ONE pass, so the optimizer sees each row once. */
+int rc_segmented_update2(float* W, float* m, float* v, int d, const uint32_t* keys,
+                         const uint32_t* perm, int64_t n_occ, const float* coef, const float* src,
+                         const int64_t* src_index, int div, const float* src2, int64_t n_split,
+                         const rc_opt_hyper* h, float* dense_grad, const uint32_t* heads,
+                         const uint32_t* n_heads, int flags, void* ws, size_t ws_bytes,
+                         rc_stream_t stream);
+
+/* ---- SASRec encoder (models/sequential/SASRec.py:51-86, utils/layers.py:9-63,92-118) ------- */
+
+/* 1 iff the kernels cover the shape: d in {32,64}, 1..4 layers, heads | d, L <= 64, dropout 0.   */
+int rc_sasrec_supported(int d, int n_layers, int n_heads, int L);
+/* floats per layer in the dense-gradient block of rc_sasrec_bwd: 5*d*d + 9*d, in the order
+ * Wq bq Wk bk Wv bv ln1.w ln1.b W1 b1 W2 b2 ln2.w ln2.b                                          */
+int rc_sasrec_dense_param_count(int d);
+size_t rc_sasrec_workspace_bytes(int B, int d, int n_layers);
+
+/* hv[b,:] = encoder output at position lengths[b]-1 (SASRec.py:58-76).  layer_params: HOST array of
+ * 14*n_layers DEVICE pointers in the order above (nn.Linear weights [out,in]).  hist [B,L] is right
+ * padded with 0.  xsave: NULL (inference) or [B, n_layers, L, d] scratch that receives every layer's
+ * input for rc_sasrec_bwd.  Scores are then rc_gather_dot_fwd(U=hv, uid=arange(B)) (SASRec.py:80-81). */
+int rc_sasrec_fwd(const float* item_emb, const float* pos_emb, const float* const* layer_params,
+                  int n_layers, int n_heads, const int64_t* hist, const int64_t* lengths, int B, int L,
+                  int d, float* hv, float* xsave, rc_stream_t stream);
+
+/* Backward of rc_sasrec_fwd for dL/dhv = dhv [B,d]: g_hist [B,L,d] = gradient of the layer-0 input
+ * rows (= per-occurrence gradients of item_emb[hist] AND pos_emb[position]; 0 past the length) and
+ * dense_grads [n_layers, 5*d*d+9*d] in the canonical order.                                        */
+int rc_sasrec_bwd(const float* const* layer_params, int n_layers, int n_heads, const int64_t* lengths,
+                  int B, int L, int d, const float* xsave, const float* dhv, float* g_hist,
+                  float* dense_grads, void* ws, size_t ws_bytes, rc_stream_t stream);
+
 /* ---- NeuMF head (models/general/NeuMF.py:56-76), one hidden layer, dropout 0 ------------- */
 
 /* 1 iff the fp32-MFMA kernels cover (emb_size d, hidden size l1): d, l1 in {32,64,128} and the

@@ -65,6 +65,13 @@ SIGNATURES = {
     "rc_segmented_workspace_bytes": (_sz, [_i64, _i]),
     "rc_segmented_update": (_i, [_p, _p, _p, _i, _p, _p, _i64, _p, _p, _p, _i, _hp, _p, _p, _p, _i, _p, _sz, _p]),
     "rc_dense_update": (_i, [_p, _p, _p, _p, _i64, _hp, _p]),
+    "rc_segmented_update2": (_i, [_p, _p, _p, _i, _p, _p, _i64, _p, _p, _p, _i, _p, _i64, _hp, _p, _p, _p, _i,
+                                  _p, _sz, _p]),
+    "rc_sasrec_supported": (_i, [_i, _i, _i, _i]),
+    "rc_sasrec_dense_param_count": (_i, [_i]),
+    "rc_sasrec_workspace_bytes": (_sz, [_i, _i, _i]),
+    "rc_sasrec_fwd": (_i, [_p, _p, _p, _i, _i, _p, _p, _i, _i, _i, _p, _p, _p]),
+    "rc_sasrec_bwd": (_i, [_p, _i, _i, _p, _i, _i, _i, _p, _p, _p, _p, _p, _sz, _p]),
     "rc_neumf_supported": (_i, [_i, _i]),
     "rc_neumf_fwd": (_i, [_p] * 9 + [_i, _i, _i, _i, _p, _p]),
     "rc_neumf_workspace_bytes": (_sz, [_i, _i, _i, _i]),

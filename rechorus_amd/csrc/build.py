@@ -29,6 +29,7 @@ SOURCES = [
     "dense_opt.hip",
     "train_step.hip",
     "neumf.hip",
+    "sasrec.hip",
 ]
 HEADERS = ["common.hpp", "bpr_math.hpp", "opt_math.hpp", os.path.join("..", "..", "include", "rechorus_hip.h")]
 

@@ -47,6 +47,8 @@ struct SegArgs {
   const float* coef;
   const float* src;
   const int64_t* src_index;
+  const float* src2;   // optional second source: occurrences o >= n_split read src2[o - n_split]
+  uint32_t n_split;
   int div;
   int d;  // generic kernels only
   float* dense_grad;
@@ -147,6 +149,8 @@ __device__ __forceinline__ float4 load_row4(const SegArgs& a, uint32_t key, int 
 template <int D>
 __device__ __forceinline__ float4 occ_grad4_o(const SegArgs& a, uint32_t o, int l) {
   constexpr int LPR = D / 4;
+  if (a.src2 && o >= a.n_split)  // second source: plain gradient rows, one per occurrence
+    return reinterpret_cast<const float4*>(a.src2)[(size_t)(o - a.n_split) * LPR + l];
   const float c = a.coef ? a.coef[o] : 1.0f;
   int64_t sr = (a.div == 1) ? (int64_t)o : (int64_t)(o / (uint32_t)a.div);
   if (a.src_index) sr = a.src_index[sr];
@@ -353,10 +357,14 @@ __device__ __forceinline__ void apply_row_generic(const SegArgs& a, uint32_t key
 __device__ __forceinline__ void occ_grad_generic(const SegArgs& a, int64_t jj, int lane,
                                                  float* acc) {
   const uint32_t o = a.perm[jj];
-  const float c = a.coef ? a.coef[o] : 1.0f;
+  float c = a.coef ? a.coef[o] : 1.0f;
   int64_t sr = (a.div == 1) ? (int64_t)o : (int64_t)(o / (uint32_t)a.div);
   if (a.src_index) sr = a.src_index[sr];
   const float* s = a.src + (size_t)sr * a.d;
+  if (a.src2 && o >= a.n_split) {
+    s = a.src2 + (size_t)(o - a.n_split) * a.d;
+    c = 1.0f;
+  }
 #pragma unroll
   for (int q = 0; q < kGenChunks; ++q) {
     const int k = lane + 64 * q;
@@ -496,7 +504,18 @@ extern "C" int rc_segmented_update(float* W, float* m, float* v, int d, const ui
                                    const rc_opt_hyper* h, float* dense_grad,
                                    const uint32_t* heads, const uint32_t* n_heads, int flags,
                                    void* ws, size_t ws_bytes, rc_stream_t stream) {
+  return rc_segmented_update2(W, m, v, d, keys, perm, n_occ, coef, src, src_index, div, nullptr, n_occ, h,
+                              dense_grad, heads, n_heads, flags, ws, ws_bytes, stream);
+}
+
+extern "C" int rc_segmented_update2(float* W, float* m, float* v, int d, const uint32_t* keys,
+                                    const uint32_t* perm, int64_t n_occ, const float* coef,
+                                    const float* src, const int64_t* src_index, int div,
+                                    const float* src2, int64_t n_split, const rc_opt_hyper* h,
+                                    float* dense_grad, const uint32_t* heads, const uint32_t* n_heads,
+                                    int flags, void* ws, size_t ws_bytes, rc_stream_t stream) {
   if (n_occ == 0) return RC_OK;
+  RC_REQUIRE(n_split >= 0 && n_split <= n_occ, "rc_segmented_update2: n_split out of range");
   RC_REQUIRE(keys && perm && src && ws, "rc_segmented_update: null pointer");
   RC_REQUIRE(d >= 1 && div >= 1 && n_occ > 0 && n_occ < ((int64_t)1 << 31),
              "rc_segmented_update: bad shape d=%d div=%d n_occ=%lld", d, div, (long long)n_occ);
@@ -512,13 +531,14 @@ extern "C" int rc_segmented_update(float* W, float* m, float* v, int d, const ui
   a.W = W; a.M = m; a.V = v;
   a.keys = keys; a.perm = perm; a.n_occ = n_occ;
   a.coef = coef; a.src = src; a.src_index = src_index; a.div = div; a.d = d;
+  a.src2 = src2; a.n_split = (uint32_t)n_split;
   a.dense_grad = dense_grad;
   a.skip_single = (flags & RC_SEG_SKIP_SINGLETONS) ? 1 : 0;
   a.counters = w.counters; a.long_list = w.long_list; a.rows = w.rows; a.chunks = w.chunks;
   a.partial = w.partial;
   a.long_cap = w.long_cap; a.chunk_cap = w.chunk_cap; a.partial_cap = w.partial_cap;
   auto al = [](const void* p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; };
-  bool vec_ok = vector_kernel_for(d) && al(src);
+  bool vec_ok = vector_kernel_for(d) && al(src) && al(src2);
   int mode = MODE_DENSE_GRAD;
   if (dense_grad) {
     vec_ok = vec_ok && al(dense_grad);

@@ -375,3 +375,131 @@ class NeumfTrainer:
             st = self.state[k]
             dense_update(P[k], dense[k], h0 if k == "b1" else h, st.get("m"), st.get("v"))
         return self.loss
+
+
+# ---- SASRec encoder ---------------------------------------------------------------------------------
+
+SAS_LAYER_KEYS = ("Wq", "bq", "Wk", "bk", "Wv", "bv", "ln1w", "ln1b", "W1", "b1", "W2", "b2", "ln2w", "ln2b")
+SAS_NO_DECAY = ("bq", "bk", "bv", "ln1b", "b1", "b2", "ln2b")  # names containing 'bias' (BaseModel.py:64-73)
+
+
+def sasrec_supported(d, n_layers, n_heads, L):
+    return bool(_lib.load().rc_sasrec_supported(int(d), int(n_layers), int(n_heads), int(L)))
+
+
+def _sas_ptr_table(layers):
+    tab = (C.c_void_p * (14 * len(layers)))()
+    for l, lay in enumerate(layers):
+        for k, name in enumerate(SAS_LAYER_KEYS):
+            tab[14 * l + k] = _ptr(lay[name], torch.float32, f"layer{l}.{name}").value
+    return tab
+
+
+def sasrec_fwd(item_emb, pos_emb, layers, n_heads, hist, lengths, save=False):
+    """-> (hv [B,d], xsave|None): encoder output at position length-1 (SASRec.py:58-76)"""
+    B, L = hist.shape
+    d = item_emb.shape[1]
+    dev, f32 = hist.device, torch.float32
+    hv = torch.empty((B, d), dtype=f32, device=dev)
+    xsave = torch.empty((B, len(layers), L, d), dtype=f32, device=dev) if save else None
+    _lib.call("rc_sasrec_fwd", _ptr(item_emb, f32, "item_emb"), _ptr(pos_emb, f32, "pos_emb"),
+              _sas_ptr_table(layers), len(layers), int(n_heads), _ptr(hist, torch.int64, "hist"),
+              _ptr(lengths, torch.int64, "lengths"), B, L, d, _ptr(hv, f32, "hv"),
+              _ptr(xsave, f32, "xsave", True), _stream())
+    return hv, xsave
+
+
+def sasrec_bwd(layers, n_heads, lengths, xsave, dhv):
+    """-> (g_hist [B,L,d], list of per-layer dicts of dense gradients)"""
+    B, n_layers, L, d = xsave.shape
+    dev, f32 = xsave.device, torch.float32
+    g_hist = torch.empty((B, L, d), dtype=f32, device=dev)
+    pl = _lib.load().rc_sasrec_dense_param_count(d)
+    dense = torch.empty((n_layers, pl), dtype=f32, device=dev)
+    ws = workspace(_lib.load().rc_sasrec_workspace_bytes(B, d, n_layers), dev, "sasrec")
+    _lib.call("rc_sasrec_bwd", _sas_ptr_table(layers), n_layers, int(n_heads), _ptr(lengths, torch.int64, "lengths"),
+              B, L, d, _ptr(xsave, f32, "xsave"), _ptr(dhv, f32, "dhv"), _ptr(g_hist, f32, "g_hist"),
+              _ptr(dense, f32, "dense"), C.c_void_p(ws.data_ptr()), ws.numel(), _stream())
+    grads = []
+    for l in range(n_layers):
+        off, g = 0, {}
+        for name in SAS_LAYER_KEYS:
+            n = d * d if name.startswith("W") else d
+            g[name] = dense[l, off:off + n].view(d, d) if name.startswith("W") else dense[l, off:off + n]
+            off += n
+        grads.append(g)
+    return g_hist, grads
+
+
+def segmented_update2(keys, perm, src, src2, n_split, hyper=None, W=None, m=None, v=None, coef=None,
+                      src_index=None, div=1, dense_grad=None):
+    """rc_segmented_update2: occurrences >= n_split take plain rows src2[o - n_split]"""
+    n_occ = keys.numel()
+    d = src.shape[-1]
+    ws = workspace(_lib.load().rc_segmented_workspace_bytes(n_occ, d), keys.device, "seg")
+    f32 = torch.float32
+    _lib.call("rc_segmented_update2", _ptr(W, f32, "W", True), _ptr(m, f32, "m", True), _ptr(v, f32, "v", True), d,
+              _ptr(keys, torch.int32, "keys"), _ptr(perm, torch.int32, "perm"), n_occ,
+              _ptr(coef, f32, "coef", True), _ptr(src, f32, "src"), _ptr(src_index, torch.int64, "src_index", True),
+              int(div), _ptr(src2, f32, "src2"), int(n_split), C.byref(hyper) if hyper is not None else None,
+              _ptr(dense_grad, f32, "dense_grad", True), None, None, 0, C.c_void_p(ws.data_ptr()), ws.numel(), _stream())
+
+
+class SasrecTrainer:
+    """One BaseRunner.fit iteration for SASRec on device tensors.
+    P = {"item_emb": [n_items,d], "pos_emb": [max_his+1,d], "layers": [dict(SAS_LAYER_KEYS) ...]}."""
+
+    def __init__(self, P, n_heads, opt="Adam", lr=1e-3, l2=0.0, rowwise=False):
+        self.P, self.n_heads, self.opt, self.lr, self.l2, self.rowwise = P, n_heads, opt, lr, l2, rowwise
+        self.step_count = 0
+        self.loss = None
+        self.state = {}
+
+    def _st(self, t):
+        st = self.state.get(t.data_ptr())
+        if st is None:
+            st = {}
+            if self.opt in ("Adam", "Adagrad"):
+                st["m"] = torch.zeros_like(t)
+            if self.opt == "Adam":
+                st["v"] = torch.zeros_like(t)
+            self.state[t.data_ptr()] = st
+        return st
+
+    def step(self, hist, lengths, iid):
+        P = self.P
+        I, Pe, layers = P["item_emb"], P["pos_emb"], P["layers"]
+        B, L = hist.shape
+        Cn = iid.shape[1]
+        d = I.shape[1]
+        self.step_count += 1
+        h = make_hyper(self.opt, lr=self.lr, l2=self.l2, step=self.step_count)
+        h0 = make_hyper(self.opt, lr=self.lr, l2=0.0, step=self.step_count)
+        hv, xsave = sasrec_fwd(I, Pe, layers, self.n_heads, hist, lengths, save=True)
+        rows = torch.arange(B, device=hist.device)
+        pred = gather_dot(hv, I, rows, iid)                       # SASRec.py:80-81
+        self.loss, _, gpred = bpr_loss(pred)
+        dhv = weighted_row_sum(I, iid, gpred)
+        g_hist, dgrads = sasrec_bwd(layers, self.n_heads, lengths, xsave, dhv)
+        # item table: candidate occurrences (g * hv, rebuilt on the fly) + history occurrences (g_hist rows)
+        ids = torch.cat([iid.reshape(-1), hist.reshape(-1)])
+        keys, perm = sort_ids(ids, I.shape[0])
+        st = self._st(I)
+        if self.rowwise:
+            segmented_update2(keys, perm, hv, g_hist.view(-1, d), B * Cn, hyper=h, W=I, m=st.get("m"), v=st.get("v"),
+                              coef=gpred.reshape(-1), div=Cn)
+        else:
+            G = torch.zeros_like(I)
+            segmented_update2(keys, perm, hv, g_hist.view(-1, d), B * Cn, coef=gpred.reshape(-1), div=Cn, dense_grad=G)
+            dense_update(I, G, h, st.get("m"), st.get("v"))
+        # position table (tiny): dense gradient, dense step
+        valid = (hist > 0).to(torch.int64)
+        position = ((lengths[:, None] - torch.arange(L, device=hist.device)[None, :]) * valid).contiguous()
+        Gp = embedding_dense_backward(g_hist, position, Pe.shape[0])
+        st = self._st(Pe)
+        dense_update(Pe, Gp, h, st.get("m"), st.get("v"))
+        for lay, g in zip(layers, dgrads):
+            for name in SAS_LAYER_KEYS:
+                st = self._st(lay[name])
+                dense_update(lay[name], g[name].contiguous(), h0 if name in SAS_NO_DECAY else h, st.get("m"), st.get("v"))
+        return self.loss

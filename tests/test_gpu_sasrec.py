@@ -1,0 +1,87 @@
+"""GPU parity of the SASRec encoder kernels vs the reference's own outputs
+(tests/golden/sasrec_*.npz): forward scores, every parameter gradient, two fit() iterations."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_close, assert_update_close, load_golden
+from test_oracle_sasrec import CASES, params
+
+pytestmark = pytest.mark.gpu
+
+LAYER_NAMES = {"Wq": "masked_attn_head.q_linear.weight", "bq": "masked_attn_head.q_linear.bias",
+               "Wk": "masked_attn_head.k_linear.weight", "bk": "masked_attn_head.k_linear.bias",
+               "Wv": "masked_attn_head.v_linear.weight", "bv": "masked_attn_head.v_linear.bias",
+               "ln1w": "layer_norm1.weight", "ln1b": "layer_norm1.bias", "W1": "linear1.weight", "b1": "linear1.bias",
+               "W2": "linear2.weight", "b2": "linear2.bias", "ln2w": "layer_norm2.weight", "ln2b": "layer_norm2.bias"}
+
+
+def to_dev(P, n_layers, cuda):
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
+    return {"item_emb": t(P["i_embeddings.weight"]), "pos_emb": t(P["p_embeddings.weight"]),
+            "layers": [{k: t(P["transformer_block.%d.%s" % (l, v)]) for k, v in LAYER_NAMES.items()}
+                       for l in range(n_layers)]}
+
+
+@pytest.fixture(scope="module")
+def eng(cuda):
+    from rechorus_amd import engine
+    return engine
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_sasrec_forward_backward(case, cuda, eng):
+    g = load_golden(case)
+    n_layers, n_heads = int(g["meta"][2]), int(g["meta"][3])
+    P = to_dev(params(g), n_layers, cuda)
+    hist, lengths, iid = (torch.from_numpy(g[k]).to(cuda) for k in ("hist", "len", "iid"))
+    B, L = g["hist"].shape
+    C, d = g["iid"].shape[1], P["item_emb"].shape[1]
+    assert eng.sasrec_supported(d, n_layers, n_heads, L)
+    hv, xsave = eng.sasrec_fwd(P["item_emb"], P["pos_emb"], P["layers"], n_heads, hist, lengths, save=True)
+    rows = torch.arange(B, device=cuda)
+    pred = eng.gather_dot(hv, P["item_emb"], rows, iid)
+    assert_close(pred.cpu().numpy(), g["pred"], what="pred", atol_scale=2e-5)
+    hv2, _ = eng.sasrec_fwd(P["item_emb"], P["pos_emb"], P["layers"], n_heads, hist, lengths, save=False)
+    assert torch.equal(hv, hv2)
+
+    gpred = torch.from_numpy(g["gpred"]).to(cuda)
+    dhv = eng.weighted_row_sum(P["item_emb"], iid, gpred)
+    g_hist, dg = eng.sasrec_bwd(P["layers"], n_heads, lengths, xsave, dhv)
+    G = params(g, "G/")
+    floor = 1e-6 * max(float(np.abs(v).max()) for v in G.values())
+    for l in range(n_layers):
+        for k, name in LAYER_NAMES.items():
+            assert_close(dg[l][k].cpu().numpy(), G["transformer_block.%d.%s" % (l, name)], what=f"layer {l} d{k}",
+                         rtol=2e-5, atol_scale=5e-5, abs_floor=floor)
+    ids = torch.cat([iid.reshape(-1), hist.reshape(-1)])
+    keys, perm = eng.sort_ids(ids, P["item_emb"].shape[0])
+    GI = torch.zeros_like(P["item_emb"])
+    eng.segmented_update2(keys, perm, hv, g_hist.view(-1, d), B * C, coef=gpred.reshape(-1), div=C, dense_grad=GI)
+    assert_close(GI.cpu().numpy(), G["i_embeddings.weight"], what="d item_emb", rtol=2e-5, atol_scale=5e-5)
+    valid = (hist > 0).to(torch.int64)
+    position = ((lengths[:, None] - torch.arange(L, device=cuda)[None, :]) * valid).contiguous()
+    GP = eng.embedding_dense_backward(g_hist, position, P["pos_emb"].shape[0])
+    assert_close(GP.cpu().numpy(), G["p_embeddings.weight"], what="d pos_emb", rtol=2e-5, atol_scale=5e-5)
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("tag,opt", [("SGD_l20.001", "SGD"), ("Adam_l20.0001", "Adam")])
+def test_sasrec_two_fit_iterations_match_reference(case, tag, opt, cuda, eng):
+    g = load_golden(case)
+    lr, l2 = (float(x) for x in g[tag + "_hyper"])
+    n_layers, n_heads = int(g["meta"][2]), int(g["meta"][3])
+    P0 = params(g)
+    P = to_dev(P0, n_layers, cuda)
+    tr = eng.SasrecTrainer(P, n_heads, opt=opt, lr=lr, l2=l2, rowwise=False)
+    for step, sfx in enumerate(("", "2"), 1):
+        hist, lengths, iid = (torch.from_numpy(g[k + sfx]).to(cuda) for k in ("hist", "len", "iid"))
+        loss = tr.step(hist, lengths, iid)
+        assert_close(loss.cpu().numpy()[0], g[tag + "_losses"][step - 1], what=f"loss {step}", rtol=2e-5)
+    want = params(g, tag + "/")
+    ex = 2e-3 * lr if opt == "Adam" else 0.0
+    checks = [("item_emb", "i_embeddings.weight", P["item_emb"]), ("pos_emb", "p_embeddings.weight", P["pos_emb"])]
+    for l in range(n_layers):
+        checks += [(f"L{l}.{k}", "transformer_block.%d.%s" % (l, v), P["layers"][l][k]) for k, v in LAYER_NAMES.items()]
+    for what, name, t in checks:
+        assert_update_close(t.cpu().numpy(), P0[name], want[name], what=what, extra_atol=ex, rtol=2e-4)
