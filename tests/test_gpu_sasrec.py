@@ -84,4 +84,11 @@ def test_sasrec_two_fit_iterations_match_reference(case, tag, opt, cuda, eng):
     for l in range(n_layers):
         checks += [(f"L{l}.{k}", "transformer_block.%d.%s" % (l, v), P["layers"][l][k]) for k, v in LAYER_NAMES.items()]
     for what, name, t in checks:
-        assert_update_close(t.cpu().numpy(), P0[name], want[name], what=what, extra_atol=ex, rtol=2e-4)
+        if opt == "Adam" and name.endswith("k_linear.bias"):
+            # d/d(key bias) is exactly 0 in exact arithmetic (softmax is shift invariant along the
+            # keys); in fp32 it is ~1e-10 round-off whose SIGN Adam turns into +-lr steps -- in the
+            # reference as well.  Not a comparable quantity; bounded by lr instead.
+            assert float(np.abs(t.cpu().numpy() - P0[name]).max()) <= 2.5 * lr
+            continue
+        assert_update_close(t.cpu().numpy(), P0[name], want[name], what=what, extra_atol=ex, rtol=2e-4,
+                            outlier_atol=2 * lr if opt == "Adam" else 0.0)
