@@ -98,6 +98,87 @@ def bpr_loss(pred):
     return _BprLossFn.apply(pred)
 
 
+class _NeumfFn(torch.autograd.Function):
+    """NeuMF head, one hidden layer (models/general/NeuMF.py:61-75): rc_neumf_fwd / rc_neumf_bwd."""
+
+    @staticmethod
+    def forward(ctx, mf_u, mf_i, mlp_u, mlp_i, W1, b1, w_out, uid, iid):
+        P = {"mf_u": mf_u.detach(), "mf_i": mf_i.detach(), "mlp_u": mlp_u.detach(), "mlp_i": mlp_i.detach(),
+             "W1": W1.detach().contiguous(), "b1": b1.detach().contiguous(),
+             "w_out": w_out.detach().reshape(-1).contiguous()}
+        ctx.P, ctx.uid, ctx.iid, ctx.wshape = P, uid, iid, w_out.shape
+        return engine.neumf_fwd(P, uid, iid)
+
+    @staticmethod
+    def backward(ctx, gpred):
+        P, uid, iid = ctx.P, ctx.uid, ctx.iid
+        rows, dense = engine.neumf_bwd(P, uid, iid, gpred.contiguous())
+        uid_occ = uid.repeat_interleave(iid.shape[1])
+        ku, pu = engine.sort_ids(uid_occ, P["mf_u"].shape[0])
+        ki, pi = engine.sort_ids(iid, P["mf_i"].shape[0])
+
+        def dense_tab(tab, key, keys, perm):
+            G = torch.zeros_like(P[tab])
+            engine.segmented_update(keys, perm, rows[key], dense_grad=G)
+            return G
+        return (dense_tab("mf_u", "g_mf_u", ku, pu), dense_tab("mf_i", "g_mf_i", ki, pi),
+                dense_tab("mlp_u", "g_mlp_u", ku, pu), dense_tab("mlp_i", "g_mlp_i", ki, pi),
+                dense["W1"], dense["b1"], dense["w_out"].view(ctx.wshape), None, None)
+
+
+def neumf_scores(mf_u, mf_i, mlp_u, mlp_i, W1, b1, w_out, uid, iid):
+    return _NeumfFn.apply(mf_u, mf_i, mlp_u, mlp_i, W1, b1, w_out, uid.contiguous(), iid.contiguous())
+
+
+_SAS_ATTRS = (("Wq", "masked_attn_head.q_linear.weight"), ("bq", "masked_attn_head.q_linear.bias"),
+              ("Wk", "masked_attn_head.k_linear.weight"), ("bk", "masked_attn_head.k_linear.bias"),
+              ("Wv", "masked_attn_head.v_linear.weight"), ("bv", "masked_attn_head.v_linear.bias"),
+              ("ln1w", "layer_norm1.weight"), ("ln1b", "layer_norm1.bias"), ("W1", "linear1.weight"),
+              ("b1", "linear1.bias"), ("W2", "linear2.weight"), ("b2", "linear2.bias"),
+              ("ln2w", "layer_norm2.weight"), ("ln2b", "layer_norm2.bias"))
+
+
+def _get_attr(mod, path):
+    for part in path.split("."):
+        mod = getattr(mod, part)
+    return mod
+
+
+class _SasrecEncodeFn(torch.autograd.Function):
+    """SASRec encoder (models/sequential/SASRec.py:58-76): rc_sasrec_fwd / rc_sasrec_bwd.
+    Inputs: item table, position table, then 14 parameters per block in engine.SAS_LAYER_KEYS order."""
+
+    @staticmethod
+    def forward(ctx, item_emb, pos_emb, n_heads, hist, lengths, *flat):
+        n_layers = len(flat) // 14
+        layers = [{k: flat[14 * l + j].detach().contiguous() for j, (k, _) in enumerate(_SAS_ATTRS)}
+                  for l in range(n_layers)]
+        need_grad = any(t.requires_grad for t in (item_emb, pos_emb) + tuple(flat))
+        hv, xsave = engine.sasrec_fwd(item_emb.detach(), pos_emb.detach(), layers, n_heads, hist, lengths,
+                                      save=need_grad)
+        ctx.layers, ctx.n_heads, ctx.hist, ctx.lengths, ctx.xsave = layers, n_heads, hist, lengths, xsave
+        ctx.n_items, ctx.n_pos = item_emb.shape[0], pos_emb.shape[0]
+        return hv
+
+    @staticmethod
+    def backward(ctx, dhv):
+        hist, lengths = ctx.hist, ctx.lengths
+        g_hist, dgrads = engine.sasrec_bwd(ctx.layers, ctx.n_heads, lengths, ctx.xsave, dhv.contiguous())
+        L = hist.shape[1]
+        GI = engine.embedding_dense_backward(g_hist, hist, ctx.n_items)
+        valid = (hist > 0).to(torch.int64)
+        position = ((lengths[:, None] - torch.arange(L, device=hist.device)[None, :]) * valid).contiguous()
+        GP = engine.embedding_dense_backward(g_hist, position, ctx.n_pos)
+        flat = [g[k].contiguous() for g in dgrads for k, _ in _SAS_ATTRS]
+        return (GI, GP, None, None, None) + tuple(flat)
+
+
+def sasrec_encode(item_emb, pos_emb, blocks, n_heads, hist, lengths):
+    """blocks: nn.ModuleList of utils.layers.TransformerLayer (parameters only are used)"""
+    flat = [_get_attr(b, path) for b in blocks for _, path in _SAS_ATTRS]
+    return _SasrecEncodeFn.apply(item_emb, pos_emb, n_heads, hist.contiguous(), lengths.contiguous(), *flat)
+
+
 class HipOptimizer:
     """torch.optim.{SGD,Adam,Adagrad} semantics (dense, weight decay per param group) executed by
     rc_dense_update.  Built by the runner in place of `eval('torch.optim.X')`

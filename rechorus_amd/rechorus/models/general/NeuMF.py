@@ -1,0 +1,68 @@
+""" NeuMF on the HIP engine
+Reference: "Neural Collaborative Filtering", Xiangnan He et al., WWW'2017.
+Mirror of the reference's models/general/NeuMF.py (same class / arg / state_dict names):
+    python main.py --model_name NeuMF --emb_size 64 --layers '[64]' --lr 5e-4 --l2 1e-7 --dataset 'Grocery_and_Gourmet_Food'
+With one hidden layer, emb_size and layer size in {32, 64, 128} and no active dropout, the whole
+head (:61-75: four gathers, GMF product, MLP, prediction layer) is the fp32-MFMA kernel pair
+rc_neumf_fwd / rc_neumf_bwd.  Any other configuration runs the same parameters through
+HipEmbedding gathers + torch layers.
+"""
+import torch
+import torch.nn as nn
+
+from models.BaseModel import GeneralModel
+from rechorus_amd import engine, nn as hnn
+
+
+class NeuMF(GeneralModel):
+    reader = 'BaseReader'
+    runner = 'BaseRunner'
+    extra_log_args = ['emb_size', 'layers']
+    candidate_permutation_equivariant = True
+
+    @staticmethod
+    def parse_model_args(parser):
+        parser.add_argument('--emb_size', type=int, default=64, help='Size of embedding vectors.')
+        parser.add_argument('--layers', type=str, default='[64]', help="Size of each layer.")
+        return GeneralModel.parse_model_args(parser)
+
+    def __init__(self, args, corpus):
+        super().__init__(args, corpus)
+        self.emb_size = args.emb_size
+        self.layers = eval(args.layers)
+        self._define_params()
+        self.apply(self.init_weights)
+
+    def _define_params(self):
+        self.mf_u_embeddings = hnn.HipEmbedding(self.user_num, self.emb_size)
+        self.mf_i_embeddings = hnn.HipEmbedding(self.item_num, self.emb_size)
+        self.mlp_u_embeddings = hnn.HipEmbedding(self.user_num, self.emb_size)
+        self.mlp_i_embeddings = hnn.HipEmbedding(self.item_num, self.emb_size)
+        self.mlp = nn.ModuleList([])
+        pre_size = 2 * self.emb_size
+        for layer_size in self.layers:
+            self.mlp.append(nn.Linear(pre_size, layer_size))
+            pre_size = layer_size
+        self.dropout_layer = nn.Dropout(p=self.dropout)
+        self.prediction = nn.Linear(pre_size + self.emb_size, 1, bias=False)
+
+    def _fused_ok(self):
+        return (len(self.layers) == 1 and engine.neumf_supported(self.emb_size, self.layers[0])
+                and (self.dropout == 0 or not self.training))
+
+    def forward(self, feed_dict):
+        self.check_list = []
+        u_ids = feed_dict['user_id']  # [batch_size]
+        i_ids = feed_dict['item_id']  # [batch_size, n_candidates]
+        if self._fused_ok():
+            pred = hnn.neumf_scores(self.mf_u_embeddings.weight, self.mf_i_embeddings.weight,
+                                    self.mlp_u_embeddings.weight, self.mlp_i_embeddings.weight,
+                                    self.mlp[0].weight, self.mlp[0].bias, self.prediction.weight, u_ids, i_ids)
+            return {'prediction': pred.view(feed_dict['batch_size'], -1)}
+        u_rep = u_ids.unsqueeze(-1).repeat((1, i_ids.shape[1]))
+        mf = self.mf_u_embeddings(u_rep) * self.mf_i_embeddings(i_ids)
+        h = torch.cat([self.mlp_u_embeddings(u_rep), self.mlp_i_embeddings(i_ids)], dim=-1)
+        for layer in self.mlp:
+            h = self.dropout_layer(layer(h).relu())
+        pred = self.prediction(torch.cat([mf, h], dim=-1))
+        return {'prediction': pred.view(feed_dict['batch_size'], -1)}

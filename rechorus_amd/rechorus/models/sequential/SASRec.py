@@ -1,0 +1,87 @@
+""" SASRec on the HIP engine
+Reference: "Self-attentive Sequential Recommendation", Kang et al., IEEE ICDM'2018.
+Mirror of the reference's models/sequential/SASRec.py (same class / arg / state_dict names):
+    python main.py --model_name SASRec --emb_size 64 --num_layers 1 --num_heads 1 --lr 1e-4 --l2 1e-6 \
+        --history_max 20 --dataset 'Grocery_and_Gourmet_Food'
+The encoder of :58-76 (history + position gather, causal self-attention blocks, last valid row) is
+rc_sasrec_fwd / rc_sasrec_bwd; the candidate scoring of :80-81 is the BPRMF gather-dot kernel with
+the encoder output as the "user" row.  Unsupported shapes (dropout > 0 in training, emb_size not in
+{32, 64}, history longer than 64) run the same parameters through torch layers.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from models.BaseModel import SequentialModel
+from rechorus_amd import engine, nn as hnn
+from utils import layers
+
+
+class SASRecBase(object):
+    @staticmethod
+    def parse_model_args(parser):
+        parser.add_argument('--emb_size', type=int, default=64, help='Size of embedding vectors.')
+        parser.add_argument('--num_layers', type=int, default=1, help='Number of self-attention layers.')
+        parser.add_argument('--num_heads', type=int, default=4, help='Number of attention heads.')
+        return parser
+
+    def _base_init(self, args, corpus):
+        self.emb_size, self.max_his = args.emb_size, args.history_max
+        self.num_layers, self.num_heads = args.num_layers, args.num_heads
+        self._base_define_params()
+        self.apply(self.init_weights)
+
+    def _base_define_params(self):
+        self.i_embeddings = hnn.HipEmbedding(self.item_num, self.emb_size)
+        self.p_embeddings = hnn.HipEmbedding(self.max_his + 1, self.emb_size)
+        self.transformer_block = nn.ModuleList([
+            layers.TransformerLayer(d_model=self.emb_size, d_ff=self.emb_size, n_heads=self.num_heads,
+                                    dropout=self.dropout, kq_same=False)
+            for _ in range(self.num_layers)])
+
+    def _encode_torch(self, history, lengths):
+        batch_size, seq_len = history.shape
+        valid = (history > 0).long()
+        position = (lengths[:, None] - torch.arange(seq_len, device=history.device)[None, :]) * valid
+        his = self.i_embeddings(history) + self.p_embeddings(position)
+        mask = torch.tril(torch.ones((1, 1, seq_len, seq_len), dtype=torch.long, device=history.device))
+        for block in self.transformer_block:
+            his = block(his, mask)
+        his = his * valid[:, :, None].float()
+        return his[torch.arange(batch_size, device=history.device), lengths - 1, :]
+
+    def forward(self, feed_dict):
+        self.check_list = []
+        i_ids = feed_dict['item_id']            # [batch_size, n_candidates]
+        history = feed_dict['history_items']    # [batch_size, <= history_max], right padded with 0
+        lengths = feed_dict['lengths']          # [batch_size]
+        batch_size, seq_len = history.shape
+        fused = engine.sasrec_supported(self.emb_size, self.num_layers, self.num_heads, seq_len) and \
+            (self.dropout == 0 or not self.training)
+        if fused:
+            his_vector = hnn.sasrec_encode(self.i_embeddings.weight, self.p_embeddings.weight,
+                                           self.transformer_block, self.num_heads, history, lengths)
+        else:
+            his_vector = self._encode_torch(history, lengths)
+        rows = torch.arange(batch_size, device=i_ids.device)
+        prediction = hnn.bprmf_scores(his_vector, self.i_embeddings.weight, rows, i_ids)
+        return {'prediction': prediction.view(batch_size, -1)}
+
+
+class SASRec(SequentialModel, SASRecBase):
+    reader = 'SeqReader'
+    runner = 'BaseRunner'
+    extra_log_args = ['emb_size', 'num_layers', 'num_heads']
+    candidate_permutation_equivariant = True
+
+    @staticmethod
+    def parse_model_args(parser):
+        parser = SASRecBase.parse_model_args(parser)
+        return SequentialModel.parse_model_args(parser)
+
+    def __init__(self, args, corpus):
+        SequentialModel.__init__(self, args, corpus)
+        self._base_init(args, corpus)
+
+    def forward(self, feed_dict):
+        return SASRecBase.forward(self, feed_dict)

@@ -139,3 +139,78 @@ def test_sharded_engine_single_rank_on_hip(cuda):
         ex = 1e-3 * lr if opt == "Adam" else 0.0
         assert_update_close(Ug.cpu().numpy(), U, Un, what="dU", extra_atol=ex)
         assert_update_close(Ig.cpu().numpy(), I, In, what="dI", extra_atol=ex)
+
+
+# ---- NeuMF / SASRec model files of the mirror: reference checkpoints load, same outputs -----------
+
+def _load_state(model, g, cuda):
+    sd = {k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("P0/")}
+    assert set(sd) == set(model.state_dict()), "state_dict keys differ from the reference's"
+    model.load_state_dict(sd)
+    return model.to(cuda)
+
+
+@pytest.mark.parametrize("case", ["neumf_d64_l64_k4", "neumf_d128_l64_k4", "neumf_d32_l32_k9"])
+def test_neumf_model_file_matches_reference(case, cuda):
+    from models.general.NeuMF import NeuMF
+    g = load_golden(case)
+    n_users, n_items, d = g["P0/mf_u_embeddings.weight"].shape[0], g["P0/mf_i_embeddings.weight"].shape[0], int(g["meta"][2])
+    layers = [int(x) for x in g["meta"][6:]]
+    args = argparse.Namespace(device=cuda, model_path="", buffer=1, num_neg=4, dropout=0, test_all=0, emb_size=d,
+                              layers=str(layers))
+    model = _load_state(NeuMF(args, argparse.Namespace(n_users=n_users, n_items=n_items)), g, cuda)
+    batch = {"user_id": torch.from_numpy(g["uid"]).to(cuda), "item_id": torch.from_numpy(g["iid"]).to(cuda),
+             "batch_size": len(g["uid"]), "phase": "train"}
+    out = model(batch)
+    assert_close(out["prediction"].detach().cpu().numpy(), g["pred"], what="prediction")
+    loss = model.loss(out)
+    loss.backward()
+    assert_close(loss.item(), g["loss"], what="loss")
+    for name, p in model.named_parameters():
+        assert_close(p.grad.cpu().numpy(), g["G/" + name], what="grad " + name, atol_scale=2e-5)
+
+
+@pytest.mark.parametrize("case", ["sasrec_d64_l1_h1", "sasrec_d64_l1_h4_L50", "sasrec_d64_l2_h2", "sasrec_d32_l1_h4"])
+def test_sasrec_model_file_matches_reference(case, cuda):
+    from models.sequential.SASRec import SASRec
+    g = load_golden(case)
+    n_items, d, n_layers, n_heads, hist_max = (int(x) for x in g["meta"][:5])
+    args = argparse.Namespace(device=cuda, model_path="", buffer=1, num_neg=4, dropout=0, test_all=0, emb_size=d,
+                              num_layers=n_layers, num_heads=n_heads, history_max=hist_max)
+    model = _load_state(SASRec(args, argparse.Namespace(n_users=10, n_items=n_items)), g, cuda)
+    batch = {"history_items": torch.from_numpy(g["hist"]).to(cuda), "lengths": torch.from_numpy(g["len"]).to(cuda),
+             "item_id": torch.from_numpy(g["iid"]).to(cuda), "user_id": torch.zeros(len(g["len"]), dtype=torch.long, device=cuda),
+             "batch_size": len(g["len"]), "phase": "train"}
+    out = model(batch)
+    assert_close(out["prediction"].detach().cpu().numpy(), g["pred"], what="prediction", atol_scale=2e-5)
+    loss = model.loss(out)
+    loss.backward()
+    assert_close(loss.item(), g["loss"], what="loss", rtol=2e-5)
+    G = {k[2:]: v for k, v in g.items() if k.startswith("G/")}
+    floor = 1e-6 * max(float(np.abs(v).max()) for v in G.values())
+    for name, p in model.named_parameters():
+        assert_close(p.grad.cpu().numpy(), G[name], what="grad " + name, rtol=2e-5, atol_scale=5e-5, abs_floor=floor)
+    # the torch fall-back of the same module (what unsupported shapes use) agrees with the HIP encoder
+    hv_hip = model.forward(batch)["prediction"].detach()
+    hv_torch = model._encode_torch(batch["history_items"], batch["lengths"]).detach()
+    pred_torch = (hv_torch[:, None, :] * model.i_embeddings.weight.detach()[batch["item_id"]]).sum(-1)
+    assert_close(hv_hip.cpu().numpy(), pred_torch.cpu().numpy(), what="hip vs torch encoder", rtol=1e-4, atol_scale=1e-4)
+
+
+@pytest.mark.parametrize("model_args", [
+    ["--model_name", "NeuMF", "--emb_size", "32", "--layers", "[32]", "--lr", "5e-3"],
+    ["--model_name", "SASRec", "--emb_size", "32", "--num_layers", "1", "--num_heads", "2", "--history_max", "10", "--lr", "3e-3"],
+])
+def test_cli_neumf_and_sasrec(model_args, dataset_root, tmp_path, cuda):
+    import main
+    log = str(tmp_path / "log" / "run.txt")
+    res = main.run(model_args + ["--l2", "1e-6", "--dataset", "synth", "--path", dataset_root + "/", "--epoch", "5",
+                                 "--num_neg", "4", "--batch_size", "128", "--num_workers", "0", "--regenerate", "1",
+                                 "--log_file", log, "--model_path", str(tmp_path / "model" / "m.pt"), "--topk", "5,10",
+                                 "--save_final_results", "0"])
+    text = open(log).read()
+    losses = [float(x) for x in re.findall(r"Epoch \d+\s+loss=([0-9.]+)", text)]
+    assert len(losses) >= 2 and losses[-1] < losses[0], losses
+    before = float(re.search(r"Test Before Training: \(HR@5:([0-9.]+)", text).group(1))
+    after = float(re.search(r"HR@5:([0-9.]+)", res["test"]).group(1))
+    assert after > before, (before, after)
