@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--graph", action="store_true", help="replay each step from a captured hipGraph (small batches)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL (the only measurement mode); gloo only to smoke-test N>1 on one GPU")
     ap.add_argument("--parallel", default="sharded", choices=["sharded", "replicas"],
@@ -210,12 +211,32 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(device)
 
+    run_step = lambda s: trainer.step(*batches[s % len(batches)])
+    if args.graph and world == 1:
+        # the whole step (about 20 launches, no host sync, shape-only grids) captured once per pooled
+        # batch in a hipGraph and replayed: removes per-launch host cost, which dominates at B=256
+        trainer.hyper.step = 1  # SGD/Adagrad ignore the step count; Adam's bias correction would freeze
+        if args.opt == "Adam":
+            raise SystemExit("--graph: Adam's bias-correction scalars are kernel arguments; use SGD/Adagrad")
+        run_step(0)
+        torch.cuda.synchronize(device)
+        graphs = []
+        side = torch.cuda.Stream(device=device)
+        with torch.cuda.stream(side):
+            for b in range(len(batches)):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=side):
+                    trainer.step(*batches[b])
+                graphs.append(g)
+        torch.cuda.synchronize(device)
+        run_step = lambda s: graphs[s % len(graphs)].replay()
+
     for s in range(args.warmup):
-        trainer.step(*batches[s % len(batches)])
+        run_step(s)
     sync()
     t0 = time.perf_counter()
     for s in range(args.steps):
-        trainer.step(*batches[s % len(batches)])
+        run_step(s)
     sync()
     elapsed = time.perf_counter() - t0
     if dist is not None:
