@@ -199,10 +199,10 @@ size_t rc_sasrec_workspace_bytes(int B, int d, int n_layers);
 /* hv[b,:] = encoder output at position lengths[b]-1 (SASRec.py:58-76).  layer_params: HOST array of
  * 14*n_layers DEVICE pointers in the order above (nn.Linear weights [out,in]).  hist [B,L] is right
  * padded with 0.  xsave: NULL (inference) or [B, n_layers, L, d] scratch that receives every layer's
- * input for rc_sasrec_bwd.  Scores are then rc_gather_dot_fwd(U=hv, uid=arange(B)) (SASRec.py:80-81). */
+ * input for rc_sasrec_bwd.  ws: rc_sasrec_workspace_bytes (holds transposed weight copies).  Scores are then rc_gather_dot_fwd(U=hv, uid=arange(B)) (SASRec.py:80-81). */
 int rc_sasrec_fwd(const float* item_emb, const float* pos_emb, const float* const* layer_params,
                   int n_layers, int n_heads, const int64_t* hist, const int64_t* lengths, int B, int L,
-                  int d, float* hv, float* xsave, rc_stream_t stream);
+                  int d, float* hv, float* xsave, void* ws, size_t ws_bytes, rc_stream_t stream);
 
 /* Backward of rc_sasrec_fwd for dL/dhv = dhv [B,d]: g_hist [B,L,d] = gradient of the layer-0 input
  * rows (= per-occurrence gradients of item_emb[hist] AND pos_emb[position]; 0 past the length) and

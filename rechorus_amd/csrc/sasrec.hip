@@ -27,6 +27,9 @@ constexpr float kLnEps = 1e-5f;   // nn.LayerNorm default
 
 struct SasLayer {  // device pointers, nn.Linear layout [out, in]
   const float *Wq, *bq, *Wk, *bk, *Wv, *bv, *ln1w, *ln1b, *W1, *b1, *W2, *b2, *ln2w, *ln2b;
+  // [in, out] copies made once per call (sas_transpose_kernel): in x W^T the lanes run over the
+  // output feature, so W^T[k][o] is the coalesced operand (W[o][k] puts every lane on its own line)
+  const float *WqT, *WkT, *WvT, *W1T, *W2T;
 };
 
 struct SasArgs {
@@ -60,18 +63,17 @@ struct SasCfg {
 
 // ---- building blocks (all threads of the workgroup call them; n = valid rows) ----------------
 
-// out[i][o] = (RELU) b[o] + sum_k in[i][k] * W[o][k]
+// out[i][o] = (RELU) b[o] + sum_k in[i][k] * W[o][k], with WT = W^T ([in, out]) as the operand
 template <int D, bool RELU>
-__device__ __forceinline__ void sas_linear(float* out, const float* in, const float* __restrict__ W,
+__device__ __forceinline__ void sas_linear(float* out, const float* in, const float* __restrict__ WT,
                                            const float* __restrict__ b, int n) {
   constexpr int SD = SasCfg<D>::SD;
   for (int idx = threadIdx.x; idx < n * D; idx += kBlock) {
     const int i = idx / D, o = idx % D;
     const float* x = in + i * SD;
-    const float* w = W + o * D;
     float acc = b[o];
 #pragma unroll 8
-    for (int k = 0; k < D; ++k) acc = fmaf(x[k], w[k], acc);
+    for (int k = 0; k < D; ++k) acc = fmaf(x[k], WT[k * D + o], acc);
     out[i * SD + o] = RELU ? fmaxf(acc, 0.f) : acc;
   }
 }
@@ -140,9 +142,9 @@ __device__ void sas_layer_forward(const SasLayer& p, float* X, float* Q, float* 
   constexpr int SD = SasCfg<D>::SD, SA = SasCfg<D>::SA;
   const int dk = D / n_heads;
   const float sqrt_dk = sqrtf((float)dk);
-  sas_linear<D, false>(Q, X, p.Wq, p.bq, n);
-  sas_linear<D, false>(K, X, p.Wk, p.bk, n);
-  sas_linear<D, false>(V, X, p.Wv, p.bv, n);
+  sas_linear<D, false>(Q, X, p.WqT, p.bq, n);
+  sas_linear<D, false>(K, X, p.WkT, p.bk, n);
+  sas_linear<D, false>(V, X, p.WvT, p.bv, n);
   __syncthreads();
   for (int hh = 0; hh < n_heads; ++hh) {
     sas_attn_probs<D>(A, Q, K, n, hh, dk, sqrt_dk);
@@ -156,15 +158,14 @@ __device__ void sas_layer_forward(const SasLayer& p, float* X, float* Q, float* 
   }
   sas_layernorm<D>(C, rstd1, Y, p.ln1w, p.ln1b, n);  // C <- xhat1, Y <- y1
   __syncthreads();
-  sas_linear<D, true>(H, Y, p.W1, p.b1, n);
+  sas_linear<D, true>(H, Y, p.W1T, p.b1, n);
   __syncthreads();
   for (int idx = threadIdx.x; idx < n * D; idx += kBlock) {  // z2 = H W2^T + b2 + y1, in place in Y
     const int i = idx / D, o = idx % D;
     const float* h = H + i * SD;
-    const float* w = p.W2 + o * D;
     float acc = p.b2[o];
 #pragma unroll 8
-    for (int k = 0; k < D; ++k) acc = fmaf(h[k], w[k], acc);
+    for (int k = 0; k < D; ++k) acc = fmaf(h[k], p.W2T[k * D + o], acc);
     Y[i * SD + o] += acc;  // each thread owns its element of Y
   }
   __syncthreads();
@@ -438,6 +439,35 @@ __global__ __launch_bounds__(kBlock) void sas_reduce_partials_kernel(const float
   }
 }
 
+// dst[l][m][k][o] = W_m[o][k] for the five square weights of every layer
+__global__ __launch_bounds__(kBlock) void sas_transpose_kernel(SasArgs a, float* dst, int D) {
+  const int per = 5 * D * D;
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < a.n_layers * per; i += gridDim.x * kBlock) {
+    const int l = i / per, r = i % per, m = r / (D * D), e = r % (D * D), k = e / D, o = e % D;
+    const SasLayer& p = a.layer[l];
+    const float* W = m == 0 ? p.Wq : m == 1 ? p.Wk : m == 2 ? p.Wv : m == 3 ? p.W1 : p.W2;
+    dst[i] = W[o * D + k];
+  }
+}
+
+// transposed copies live at the start of the workspace: [n_layers][5][D][D]
+static int sas_make_transposes(SasArgs* a, int D, float* dst, hipStream_t s) {
+  const int total = a->n_layers * 5 * D * D;
+  hipLaunchKernelGGL(sas_transpose_kernel, dim3((total + kBlock - 1) / kBlock), dim3(kBlock), 0, s, *a, dst, D);
+  RC_LAUNCH_CHECK();
+  for (int l = 0; l < a->n_layers; ++l) {
+    float* base = dst + (size_t)l * 5 * D * D;
+    a->layer[l].WqT = base;
+    a->layer[l].WkT = base + D * D;
+    a->layer[l].WvT = base + 2 * D * D;
+    a->layer[l].W1T = base + 3 * D * D;
+    a->layer[l].W2T = base + 4 * D * D;
+  }
+  return RC_OK;
+}
+
+static size_t sas_transpose_floats(int d, int n_layers) { return (size_t)n_layers * 5 * d * d; }
+
 static int sas_grid(int B) { return B < 512 ? (B < 1 ? 1 : B) : 512; }
 
 static int sas_fill_layers(SasArgs* a, const float* const* layer_params, int n_layers) {
@@ -499,14 +529,16 @@ extern "C" int rc_sasrec_dense_param_count(int d) { return 5 * d * d + 9 * d; }
 
 extern "C" size_t rc_sasrec_workspace_bytes(int B, int d, int n_layers) {
   if (B < 1 || d < 1 || n_layers < 1) return 0;
-  return align_up((size_t)sas_grid(B) * n_layers * (5 * (size_t)d * d + 9 * d) * sizeof(float), 256) + 256;
+  return align_up(sas_transpose_floats(d, n_layers) * sizeof(float), 256) +
+         align_up((size_t)sas_grid(B) * n_layers * (5 * (size_t)d * d + 9 * d) * sizeof(float), 256) + 256;
 }
 
 extern "C" int rc_sasrec_fwd(const float* item_emb, const float* pos_emb, const float* const* layer_params,
                              int n_layers, int n_heads, const int64_t* hist, const int64_t* lengths, int B,
-                             int L, int d, float* hv, float* xsave, rc_stream_t stream) {
+                             int L, int d, float* hv, float* xsave, void* ws, size_t ws_bytes,
+                             rc_stream_t stream) {
   if (B == 0) return RC_OK;
-  RC_REQUIRE(item_emb && pos_emb && hist && lengths && hv, "rc_sasrec_fwd: null pointer");
+  RC_REQUIRE(item_emb && pos_emb && hist && lengths && hv && ws, "rc_sasrec_fwd: null pointer");
   if (!rc_sasrec_supported(d, n_layers, n_heads, L))
     return fail(RC_ERR_UNSUPPORTED, "rc_sasrec_fwd: d=%d layers=%d heads=%d L=%d not supported (d in {32,64}, L<=%d)",
                 d, n_layers, n_heads, L, kSasLP);
@@ -516,6 +548,9 @@ extern "C" int rc_sasrec_fwd(const float* item_emb, const float* pos_emb, const 
   a.item_emb = item_emb; a.pos_emb = pos_emb; a.n_heads = n_heads; a.hist = hist; a.lengths = lengths;
   a.B = B; a.L = L; a.hv = hv; a.xsave = xsave;
   hipStream_t s = as_stream(stream);
+  if (ws_bytes < sas_transpose_floats(d, n_layers) * sizeof(float))
+    return fail(RC_ERR_WORKSPACE, "rc_sasrec_fwd: workspace %zu too small (rc_sasrec_workspace_bytes)", ws_bytes);
+  RC_TRY(sas_make_transposes(&a, d, reinterpret_cast<float*>(ws), s));
   return d == 64 ? sas_launch_fwd<64>(a, xsave != nullptr, s) : sas_launch_fwd<32>(a, xsave != nullptr, s);
 }
 
@@ -532,7 +567,10 @@ extern "C" int rc_sasrec_bwd(const float* const* layer_params, int n_layers, int
   memset(&a, 0, sizeof(a));
   RC_TRY(sas_fill_layers(&a, layer_params, n_layers));
   a.n_heads = n_heads; a.lengths = lengths; a.B = B; a.L = L;
-  a.xsave = const_cast<float*>(xsave); a.dhv = dhv; a.g_hist = g_hist; a.part = reinterpret_cast<float*>(ws);
+  a.xsave = const_cast<float*>(xsave); a.dhv = dhv; a.g_hist = g_hist;
   hipStream_t s = as_stream(stream);
+  RC_TRY(sas_make_transposes(&a, d, reinterpret_cast<float*>(ws), s));
+  a.part = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) +
+                                    align_up(sas_transpose_floats(d, n_layers) * sizeof(float), 256));
   return d == 64 ? sas_launch_bwd<64>(a, dense_grads, s) : sas_launch_bwd<32>(a, dense_grads, s);
 }

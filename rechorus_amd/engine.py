@@ -402,10 +402,11 @@ def sasrec_fwd(item_emb, pos_emb, layers, n_heads, hist, lengths, save=False):
     dev, f32 = hist.device, torch.float32
     hv = torch.empty((B, d), dtype=f32, device=dev)
     xsave = torch.empty((B, len(layers), L, d), dtype=f32, device=dev) if save else None
+    ws = workspace(_lib.load().rc_sasrec_workspace_bytes(B, d, len(layers)), dev, "sasrec")
     _lib.call("rc_sasrec_fwd", _ptr(item_emb, f32, "item_emb"), _ptr(pos_emb, f32, "pos_emb"),
               _sas_ptr_table(layers), len(layers), int(n_heads), _ptr(hist, torch.int64, "hist"),
               _ptr(lengths, torch.int64, "lengths"), B, L, d, _ptr(hv, f32, "hv"),
-              _ptr(xsave, f32, "xsave", True), _stream())
+              _ptr(xsave, f32, "xsave", True), C.c_void_p(ws.data_ptr()), ws.numel(), _stream())
     return hv, xsave
 
 
