@@ -2,24 +2,31 @@
 // utils/layers.py TransformerLayer :92-118 and MultiHeadAttention :9-63), forward and backward,
 // fp32, dropout 0.  One workgroup per sequence; the whole [len, d] working set of a layer
 // (X, Q, K, V, attention probabilities of one head, LayerNorm-normalised activations, FFN hidden)
-// lives in LDS (8 buffers x 16.6 KB at d = 64), weights are read from L2.
+// lives in LDS (8 buffers x 16.6 KB at d = 64).
+//
+// Every contraction -- the five d x d projections, QK^T, AV and their backward counterparts -- runs
+// on the fp32 matrix cores: v_mfma_f32_32x32x2_f32, i.e. exact f32 FMA chains (1e-5 parity with
+// the reference's fp32 matmuls; there is no reduced-precision path).  Operands are fetched
+// straight from LDS (row stride d+1 / len+1: conflict-free for lane <-> row) or, for the weights,
+// from L2 with the lanes running along the contiguous dimension ([in,out] transposed copies are
+// made once per call for the forward direction).  A 4-wave workgroup owns the 32x32 output blocks
+// round-robin; blocks above the causal diagonal are skipped.
 //
 // Reference quirks kept: causal mask only (padding is on the right, so valid rows never see it);
 // position id = length - index; no attention output projection; softmax after subtracting a
 // maximum (the reference's global max is a mathematical no-op; the row max is used); rows past
 // the sequence length are never computed because the reference zeroes them (SASRec.py:74) and
-// nothing valid attends to them.  Only rows < length are touched here.
+// nothing valid attends to them.
 //
 // The backward kernel re-runs each layer's forward from the saved layer input (written by the
 // forward kernel in training mode) instead of storing activations, then walks the layer backwards.
 // Dense-parameter gradients are accumulated per workgroup in a private slice of a partial buffer
 // and summed over workgroups in fixed order afterwards (no float atomics, bit-reproducible).
-//
-// This first version is VALU-only (per-thread dot products over LDS operands); the QK^T / AV
-// contractions are the candidates for the fp32 MFMA path.
 #include "common.hpp"
 
 namespace rc {
+
+typedef float sas_f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kSasLP = 64;        // max rows (history length) per sequence
 constexpr int kSasMaxLayers = 4;
@@ -27,9 +34,7 @@ constexpr float kLnEps = 1e-5f;   // nn.LayerNorm default
 
 struct SasLayer {  // device pointers, nn.Linear layout [out, in]
   const float *Wq, *bq, *Wk, *bk, *Wv, *bv, *ln1w, *ln1b, *W1, *b1, *W2, *b2, *ln2w, *ln2b;
-  // [in, out] copies made once per call (sas_transpose_kernel): in x W^T the lanes run over the
-  // output feature, so W^T[k][o] is the coalesced operand (W[o][k] puts every lane on its own line)
-  const float *WqT, *WkT, *WvT, *W1T, *W2T;
+  const float *WqT, *WkT, *WvT, *W1T, *W2T;  // [in, out] copies (sas_transpose_kernel)
 };
 
 struct SasArgs {
@@ -61,38 +66,52 @@ struct SasCfg {
   static constexpr int kLdsFloats = 8 * BUF + 2 * kSasLP;
 };
 
-// ---- building blocks (all threads of the workgroup call them; n = valid rows) ----------------
+// ---- C[M x N] = A[M x K] . B[K x N] on v_mfma_f32_32x32x2_f32 -------------------------------------
+struct MatA { const float* p; int si, sk; };  // a(i,k) = p[i*si + k*sk]
+struct MatB { const float* p; int sk, sj; };  // b(k,j) = p[k*sk + j*sj]
 
-// out[i][o] = (RELU) b[o] + sum_k in[i][k] * W[o][k], with WT = W^T ([in, out]) as the operand
-template <int D, bool RELU>
-__device__ __forceinline__ void sas_linear(float* out, const float* in, const float* __restrict__ WT,
-                                           const float* __restrict__ b, int n) {
-  constexpr int SD = SasCfg<D>::SD;
-  for (int idx = threadIdx.x; idx < n * D; idx += kBlock) {
-    const int i = idx / D, o = idx % D;
-    const float* x = in + i * SD;
-    float acc = b[o];
-#pragma unroll 8
-    for (int k = 0; k < D; ++k) acc = fmaf(x[k], WT[k * D + o], acc);
-    out[i * SD + o] = RELU ? fmaxf(acc, 0.f) : acc;
+// Every wave of the workgroup calls this; 32x32 output blocks are dealt round-robin to the 4 waves.
+// epi(i, j, value) runs once per valid output element.  causal: skip blocks entirely above the
+// diagonal (their elements are never read).  Out-of-range rows / columns only ever influence
+// out-of-range outputs (discarded), so only the K range needs exact masking.
+template <typename Epi>
+__device__ __forceinline__ void sas_mm(MatA A, MatB B, int M, int N, int K, bool causal, Epi epi) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nrb = (M + 31) >> 5, ncb = (N + 31) >> 5;
+  for (int q = wave; q < nrb * ncb; q += kBlock / 64) {
+    const int rb = q % nrb, cb = q / nrb;
+    if (causal && cb > rb) continue;  // wave-uniform
+    const int i = rb * 32 + (lane & 31), j = cb * 32 + (lane & 31), kh = lane >> 5;
+    const float* ap = A.p + (i < M ? i : M - 1) * A.si + kh * A.sk;
+    const float* bp = B.p + (j < N ? j : N - 1) * B.sj + kh * B.sk;
+    sas_f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    int k0 = 0;
+#pragma unroll 4
+    for (; k0 + 2 <= K; k0 += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[k0 * A.sk], bp[k0 * B.sk], acc, 0, 0, 0);
+    if (k0 < K) {  // odd K: the kh = 1 half has no column left and must feed zeros
+      const float av = kh == 0 ? ap[k0 * A.sk] : 0.f;
+      const float bv = kh == 0 ? bp[k0 * B.sk] : 0.f;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ii = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+      if (ii < M && j < N) epi(ii, j, acc[r]);
+    }
   }
 }
 
-// attention probabilities of head hh into A[i][j] (j <= i), rows [0, n)
+// ---- building blocks (all threads of the workgroup call them; n = valid rows) ----------------
+
+// attention probabilities of head hh into A[i][j] (0 for j > i), rows [0, n)
 template <int D>
 __device__ __forceinline__ void sas_attn_probs(float* A, const float* Q, const float* K, int n, int hh,
                                                int dk, float sqrt_dk) {
   constexpr int SD = SasCfg<D>::SD, SA = SasCfg<D>::SA;
-  for (int idx = threadIdx.x; idx < n * n; idx += kBlock) {
-    const int i = idx / n, j = idx % n;
-    if (j <= i) {
-      const float* q = Q + i * SD + hh * dk;
-      const float* k = K + j * SD + hh * dk;
-      float acc = 0.f;
-      for (int c = 0; c < dk; ++c) acc = fmaf(q[c], k[c], acc);
-      A[i * SA + j] = acc / sqrt_dk;
-    }
-  }
+  sas_mm(MatA{Q + hh * dk, SD, 1}, MatB{K + hh * dk, 1, SD}, n, n, dk, true,
+         [&](int i, int j, float v) { A[i * SA + j] = v / sqrt_dk; });
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int i = wave; i < n; i += kBlock / 64) {  // one wave per row; n <= 64 = wave width
@@ -142,32 +161,26 @@ __device__ void sas_layer_forward(const SasLayer& p, float* X, float* Q, float* 
   constexpr int SD = SasCfg<D>::SD, SA = SasCfg<D>::SA;
   const int dk = D / n_heads;
   const float sqrt_dk = sqrtf((float)dk);
-  sas_linear<D, false>(Q, X, p.WqT, p.bq, n);
-  sas_linear<D, false>(K, X, p.WkT, p.bk, n);
-  sas_linear<D, false>(V, X, p.WvT, p.bv, n);
+  const MatA aX{X, SD, 1};
+  sas_mm(aX, MatB{p.WqT, D, 1}, n, D, D, false, [&](int i, int o, float v) { Q[i * SD + o] = v + p.bq[o]; });
+  sas_mm(aX, MatB{p.WkT, D, 1}, n, D, D, false, [&](int i, int o, float v) { K[i * SD + o] = v + p.bk[o]; });
+  sas_mm(aX, MatB{p.WvT, D, 1}, n, D, D, false, [&](int i, int o, float v) { V[i * SD + o] = v + p.bv[o]; });
   __syncthreads();
   for (int hh = 0; hh < n_heads; ++hh) {
     sas_attn_probs<D>(A, Q, K, n, hh, dk, sqrt_dk);
-    for (int idx = threadIdx.x; idx < n * dk; idx += kBlock) {  // ctx_h = A . V_h, + residual
-      const int i = idx / dk, c = hh * dk + idx % dk;
-      float acc = 0.f;
-      for (int j = 0; j <= i; ++j) acc = fmaf(A[i * SA + j], V[j * SD + c], acc);
-      C[i * SD + c] = acc + X[i * SD + c];
-    }
+    const int hc = hh * dk;  // ctx_h = A . V_h, + residual
+    sas_mm(MatA{A, SA, 1}, MatB{V + hc, SD, 1}, n, dk, n, false,
+           [&](int i, int c, float v) { C[i * SD + hc + c] = v + X[i * SD + hc + c]; });
     __syncthreads();
   }
   sas_layernorm<D>(C, rstd1, Y, p.ln1w, p.ln1b, n);  // C <- xhat1, Y <- y1
   __syncthreads();
-  sas_linear<D, true>(H, Y, p.W1T, p.b1, n);
+  sas_mm(MatA{Y, SD, 1}, MatB{p.W1T, D, 1}, n, D, D, false,
+         [&](int i, int o, float v) { H[i * SD + o] = fmaxf(v + p.b1[o], 0.f); });
   __syncthreads();
-  for (int idx = threadIdx.x; idx < n * D; idx += kBlock) {  // z2 = H W2^T + b2 + y1, in place in Y
-    const int i = idx / D, o = idx % D;
-    const float* h = H + i * SD;
-    float acc = p.b2[o];
-#pragma unroll 8
-    for (int k = 0; k < D; ++k) acc = fmaf(h[k], p.W2T[k * D + o], acc);
-    Y[i * SD + o] += acc;  // each thread owns its element of Y
-  }
+  // z2 = H W2^T + b2 + y1: Y is only touched by the epilogue (own element), H is the operand
+  sas_mm(MatA{H, SD, 1}, MatB{p.W2T, D, 1}, n, D, D, false,
+         [&](int i, int o, float v) { Y[i * SD + o] += v + p.b2[o]; });
   __syncthreads();
   // KEEP: Y <- xhat2 (what LayerNorm2's backward needs); else Y <- layer output
   sas_layernorm<D>(Y, rstd2, KEEP ? nullptr : Y, p.ln2w, p.ln2b, n);
@@ -212,17 +225,7 @@ __global__ __launch_bounds__(kBlock) void sasrec_fwd_kernel(SasArgs a) {
 
 // ---- backward helpers ---------------------------------------------------------------------------
 
-// gW[o][k] += sum_i da[i][o] * xb[i][k]   (gW: this workgroup's private slice in global memory)
-template <int D>
-__device__ __forceinline__ void sas_accum_outer(float* gW, const float* da, const float* xb, int n) {
-  constexpr int SD = SasCfg<D>::SD;
-  for (int e = threadIdx.x; e < D * D; e += kBlock) {
-    const int o = e / D, k = e % D;
-    float acc = 0.f;
-    for (int i = 0; i < n; ++i) acc = fmaf(da[i * SD + o], xb[i * SD + k], acc);
-    gW[e] += acc;
-  }
-}
+// gb[k] += sum_i da[i][k]
 template <int D>
 __device__ __forceinline__ void sas_accum_colsum(float* gb, const float* da, int n) {
   constexpr int SD = SasCfg<D>::SD;
@@ -232,18 +235,17 @@ __device__ __forceinline__ void sas_accum_colsum(float* gb, const float* da, int
     gb[k] += acc;
   }
 }
-// G[i][k] += sum_o da[i][o] * W[o][k]
+// gW[o][k] += sum_i da[i][o] * xb[i][k]   (gW: this workgroup's private slice in global memory)
+template <int D>
+__device__ __forceinline__ void sas_accum_outer(float* gW, const float* da, const float* xb, int n) {
+  constexpr int SD = SasCfg<D>::SD;
+  sas_mm(MatA{da, 1, SD}, MatB{xb, SD, 1}, D, D, n, false, [&](int o, int k, float v) { gW[o * D + k] += v; });
+}
+// G[i][k] += sum_o da[i][o] * W[o][k]   (W: nn.Linear weight [out, in] in global memory)
 template <int D>
 __device__ __forceinline__ void sas_backprop_linear(float* G, const float* da, const float* __restrict__ W, int n) {
   constexpr int SD = SasCfg<D>::SD;
-  for (int idx = threadIdx.x; idx < n * D; idx += kBlock) {
-    const int i = idx / D, k = idx % D;
-    const float* d = da + i * SD;
-    float acc = 0.f;
-#pragma unroll 8
-    for (int o = 0; o < D; ++o) acc = fmaf(d[o], W[o * D + k], acc);
-    G[i * SD + k] += acc;
-  }
+  sas_mm(MatA{da, SD, 1}, MatB{W, D, 1}, n, D, D, false, [&](int i, int k, float v) { G[i * SD + k] += v; });
 }
 // LayerNorm backward in place: G holds dY on entry, dZ on exit; gw/gb accumulate d(weight)/d(bias)
 template <int D>
@@ -282,11 +284,10 @@ template <int D>
 __global__ __launch_bounds__(kBlock) void sasrec_bwd_kernel(SasArgs a) {
   using Cfg = SasCfg<D>;
   constexpr int SD = Cfg::SD, SA = Cfg::SA, BUF = Cfg::BUF, PL = Cfg::PL;
-  constexpr int RMAX = (kSasLP * D + kBlock - 1) / kBlock;  // per-thread elements of an [n][dk<=D] tile
   extern __shared__ float lds[];
   float *X = lds, *Q = X + BUF, *K = Q + BUF, *V = K + BUF, *G = V + BUF, *C = G + BUF, *H = C + BUF,
         *Y = H + BUF, *rstd1 = Y + BUF, *rstd2 = rstd1 + kSasLP;
-  float* A = Y;  // attention probabilities reuse Y (xhat2) once LayerNorm2's backward is done
+  float* A = Y;  // attention probabilities reuse Y once the FFN backward no longer needs y1
   float* T = H;  // dA / dS reuse H once the FFN backward is done
   float* part = a.part + (size_t)blockIdx.x * a.n_layers * PL;
   for (int64_t b = blockIdx.x; b < a.B; b += gridDim.x) {
@@ -305,7 +306,7 @@ __global__ __launch_bounds__(kBlock) void sasrec_bwd_kernel(SasArgs a) {
       for (int idx = threadIdx.x; idx < n * D; idx += kBlock) X[(idx / D) * SD + idx % D] = xs[idx];
       __syncthreads();
       // forward of this layer again: C = xhat1, H = relu hidden, Y = xhat2, Q/K/V, rstd1/2
-      // (G, the incoming gradient, is untouched)
+      // (G, the incoming gradient, is untouched; H doubles as the attention scratch)
       sas_layer_forward<D, true>(p, X, Q, K, V, /*A scratch = */ H, C, H, Y, rstd1, rstd2, n, a.n_heads);
       // ---- LayerNorm2, FFN ------------------------------------------------------------------
       sas_layernorm_bwd<D>(G, Y, rstd2, p.ln2w, gp + Cfg::oln2w, gp + Cfg::oln2b, n);  // G = dZ2
@@ -316,14 +317,9 @@ __global__ __launch_bounds__(kBlock) void sasrec_bwd_kernel(SasArgs a) {
         Y[i * SD + k] = fmaf(C[i * SD + k], p.ln1w[k], p.ln1b[k]);
       }
       __syncthreads();
-      for (int idx = threadIdx.x; idx < n * D; idx += kBlock) {  // H <- dHpre = (dZ2 W2) * relu'
-        const int i = idx / D, k = idx % D;
-        const float* d = G + i * SD;
-        float acc = 0.f;
-#pragma unroll 8
-        for (int o = 0; o < D; ++o) acc = fmaf(d[o], p.W2[o * D + k], acc);
-        H[i * SD + k] = H[i * SD + k] > 0.f ? acc : 0.f;
-      }
+      // H <- dHpre = (dZ2 . W2) * relu'(H): the epilogue owns its element of H, operands are G, W2
+      sas_mm(MatA{G, SD, 1}, MatB{p.W2, D, 1}, n, D, D, false,
+             [&](int i, int k, float v) { H[i * SD + k] = H[i * SD + k] > 0.f ? v : 0.f; });
       __syncthreads();
       sas_accum_outer<D>(gp + Cfg::oW1, H, Y, n);
       sas_accum_colsum<D>(gp + Cfg::ob1, H, n);
@@ -331,35 +327,20 @@ __global__ __launch_bounds__(kBlock) void sasrec_bwd_kernel(SasArgs a) {
       __syncthreads();
       // ---- LayerNorm1 ----------------------------------------------------------------------------
       sas_layernorm_bwd<D>(G, C, rstd1, p.ln1w, gp + Cfg::oln1w, gp + Cfg::oln1b, n);  // G = dZ1 = dCtx = dX(residual)
-      // ---- attention, head by head; dV, dQ, dK overwrite V, Q, K in place ---------------------------
+      // ---- attention, head by head.  dV, dK overwrite V, K in place; dQ goes to C (xhat1 is dead) ---
       const int dk = D / a.n_heads;
       const float sqrt_dk = sqrtf((float)dk);
       for (int hh = 0; hh < a.n_heads; ++hh) {
+        const int hc = hh * dk;
         sas_attn_probs<D>(A, Q, K, n, hh, dk, sqrt_dk);
-        for (int idx = threadIdx.x; idx < n * n; idx += kBlock) {  // dA = dCtx_h V_h^T
-          const int i = idx / n, j = idx % n;
-          float acc = 0.f;
-          if (j <= i) {
-            const float* g = G + i * SD + hh * dk;
-            const float* v = V + j * SD + hh * dk;
-            for (int c = 0; c < dk; ++c) acc = fmaf(g[c], v[c], acc);
-          }
-          T[i * SA + j] = acc;
-        }
+        // dA = dCtx_h . V_h^T (lower triangle)
+        sas_mm(MatA{G + hc, SD, 1}, MatB{V + hc, 1, SD}, n, n, dk, true,
+               [&](int i, int j, float v) { T[i * SA + j] = v; });
         __syncthreads();
-        float rv[RMAX], rq[RMAX];
-#pragma unroll
-        for (int r = 0; r < RMAX; ++r) {  // dV_h[j][c] = sum_{i>=j} A[i][j] dCtx[i][c]
-          const int idx = threadIdx.x + r * kBlock;
-          rv[r] = 0.f;
-          if (idx < n * dk) {
-            const int j = idx / dk, c = hh * dk + idx % dk;
-            float acc = 0.f;
-            for (int i = j; i < n; ++i) acc = fmaf(A[i * SA + j], G[i * SD + c], acc);
-            rv[r] = acc;
-          }
-        }
-        {  // dS = A * (dA - rowsum(dA*A)) / sqrt(dk), in place in T, one wave per row
+        // dV_h = A^T . dCtx_h, in place (V_h is not read again)
+        sas_mm(MatA{A, 1, SA}, MatB{G + hc, SD, 1}, n, dk, n, false,
+               [&](int j, int c, float v) { V[j * SD + hc + c] = v; });
+        {  // dS = A * (dA - rowsum(dA*A)) / sqrt(dk), in place in T, one wave per row, 0 above the diagonal
           const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
           for (int i = wave; i < n; i += kBlock / 64) {
             const bool on = lane <= i;
@@ -370,50 +351,23 @@ __global__ __launch_bounds__(kBlock) void sasrec_bwd_kernel(SasArgs a) {
           }
         }
         __syncthreads();
-#pragma unroll
-        for (int r = 0; r < RMAX; ++r) {  // dQ_h = dS K_h ; dK_h = dS^T Q_h  (into registers)
-          const int idx = threadIdx.x + r * kBlock;
-          rq[r] = 0.f;
-          if (idx < n * dk) {
-            const int i = idx / dk, c = hh * dk + idx % dk;
-            float aq = 0.f;
-            for (int j = 0; j <= i; ++j) aq = fmaf(T[i * SA + j], K[j * SD + c], aq);
-            rq[r] = aq;
-          }
-        }
-        float rk[RMAX];
-#pragma unroll
-        for (int r = 0; r < RMAX; ++r) {
-          const int idx = threadIdx.x + r * kBlock;
-          rk[r] = 0.f;
-          if (idx < n * dk) {
-            const int j = idx / dk, c = hh * dk + idx % dk;
-            float ak = 0.f;
-            for (int i = j; i < n; ++i) ak = fmaf(T[i * SA + j], Q[i * SD + c], ak);
-            rk[r] = ak;
-          }
-        }
+        // dQ_h = dS . K_h  -> C[:, head columns]
+        sas_mm(MatA{T, SA, 1}, MatB{K + hc, SD, 1}, n, dk, n, false,
+               [&](int i, int c, float v) { C[i * SD + hc + c] = v; });
         __syncthreads();
-#pragma unroll
-        for (int r = 0; r < RMAX; ++r) {
-          const int idx = threadIdx.x + r * kBlock;
-          if (idx < n * dk) {
-            const int i = idx / dk, c = hh * dk + idx % dk;
-            V[i * SD + c] = rv[r];
-            Q[i * SD + c] = rq[r];
-            K[i * SD + c] = rk[r];
-          }
-        }
+        // dK_h = dS^T . Q_h, in place over K_h (dQ_h above was its last reader)
+        sas_mm(MatA{T, 1, SA}, MatB{Q + hc, SD, 1}, n, dk, n, false,
+               [&](int j, int c, float v) { K[j * SD + hc + c] = v; });
         __syncthreads();
       }
-      // ---- projections: parameter grads and dX = dZ1 + dQ Wq + dK Wk + dV Wv ------------------------
-      sas_accum_outer<D>(gp + Cfg::oWq, Q, X, n);
-      sas_accum_colsum<D>(gp + Cfg::obq, Q, n);
+      // ---- projections: parameter grads and dX = dZ1 + dQ Wq + dK Wk + dV Wv  (dQ lives in C) ---------
+      sas_accum_outer<D>(gp + Cfg::oWq, C, X, n);
+      sas_accum_colsum<D>(gp + Cfg::obq, C, n);
       sas_accum_outer<D>(gp + Cfg::oWk, K, X, n);
       sas_accum_colsum<D>(gp + Cfg::obk, K, n);
       sas_accum_outer<D>(gp + Cfg::oWv, V, X, n);
       sas_accum_colsum<D>(gp + Cfg::obv, V, n);
-      sas_backprop_linear<D>(G, Q, p.Wq, n);
+      sas_backprop_linear<D>(G, C, p.Wq, n);
       __syncthreads();
       sas_backprop_linear<D>(G, K, p.Wk, n);
       __syncthreads();
