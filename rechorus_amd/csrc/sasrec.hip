@@ -55,16 +55,19 @@ struct SasArgs {
 template <int D>
 struct SasCfg {
   static constexpr int SD = D + 1;                               // row stride of [rows][D] buffers
-  static constexpr int SA = kSasLP + 1;                          // row stride of the [rows][rows] buffer
-  static constexpr int BUF = kSasLP * (SD > SA ? SD : SA);       // floats per LDS buffer
   static constexpr int PL = 5 * D * D + 9 * D;                   // dense-parameter floats per layer
   // offsets inside one layer's parameter-gradient block (canonical order)
   static constexpr int oWq = 0, obq = oWq + D * D, oWk = obq + D, obk = oWk + D * D, oWv = obk + D,
                        obv = oWv + D * D, oln1w = obv + D, oln1b = oln1w + D, oW1 = oln1b + D,
                        ob1 = oW1 + D * D, oW2 = ob1 + D, ob2 = oW2 + D * D, oln2w = ob2 + D,
                        oln2b = oln2w + D;
-  static constexpr int kLdsFloats = 8 * BUF + 2 * kSasLP;
 };
+
+// LDS geometry depends on the padded row count: 32 rows (history_max <= 32: 8 buffers = 66 KB, two
+// workgroups per CU) or 64 rows (133 KB, one per CU).  sa = row stride of the [rows][rows] buffer.
+__host__ __device__ inline int sas_lp(int L) { return L <= 32 ? 32 : kSasLP; }
+__host__ __device__ inline int sas_buf_floats(int D, int lp) { return lp * ((D + 1) > (lp + 1) ? (D + 1) : (lp + 1)); }
+__host__ __device__ inline int sas_lds_floats(int D, int lp) { return 8 * sas_buf_floats(D, lp) + 2 * lp; }
 
 // ---- C[M x N] = A[M x K] . B[K x N] on v_mfma_f32_32x32x2_f32 -------------------------------------
 struct MatA { const float* p; int si, sk; };  // a(i,k) = p[i*si + k*sk]
@@ -88,7 +91,28 @@ __device__ __forceinline__ void sas_mm(MatA A, MatB B, int M, int N, int K, bool
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     int k0 = 0;
-#pragma unroll 4
+    // a workgroup is alone on its CU (LDS), so nothing else hides operand latency: fetch the
+    // operands of 16 (then 4) MFMAs before issuing them -- 32 independent loads in flight
+    for (; k0 + 32 <= K; k0 += 32) {
+      float av[16], bv[16];
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        av[t] = ap[(k0 + 2 * t) * A.sk];
+        bv[t] = bp[(k0 + 2 * t) * B.sk];
+      }
+#pragma unroll
+      for (int t = 0; t < 16; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[t], acc, 0, 0, 0);
+    }
+    for (; k0 + 8 <= K; k0 += 8) {
+      float av[4], bv[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        av[t] = ap[(k0 + 2 * t) * A.sk];
+        bv[t] = bp[(k0 + 2 * t) * B.sk];
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[t], acc, 0, 0, 0);
+    }
     for (; k0 + 2 <= K; k0 += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[k0 * A.sk], bp[k0 * B.sk], acc, 0, 0, 0);
     if (k0 < K) {  // odd K: the kh = 1 half has no column left and must feed zeros
       const float av = kh == 0 ? ap[k0 * A.sk] : 0.f;
@@ -108,8 +132,8 @@ __device__ __forceinline__ void sas_mm(MatA A, MatB B, int M, int N, int K, bool
 // attention probabilities of head hh into A[i][j] (0 for j > i), rows [0, n)
 template <int D>
 __device__ __forceinline__ void sas_attn_probs(float* A, const float* Q, const float* K, int n, int hh,
-                                               int dk, float sqrt_dk) {
-  constexpr int SD = SasCfg<D>::SD, SA = SasCfg<D>::SA;
+                                               int dk, float sqrt_dk, int SA) {
+  constexpr int SD = SasCfg<D>::SD;
   sas_mm(MatA{Q + hh * dk, SD, 1}, MatB{K + hh * dk, 1, SD}, n, n, dk, true,
          [&](int i, int j, float v) { A[i * SA + j] = v / sqrt_dk; });
   __syncthreads();
@@ -157,8 +181,8 @@ __device__ __forceinline__ void sas_layernorm(float* z, float* rstd, float* yout
 template <int D, bool KEEP>
 __device__ void sas_layer_forward(const SasLayer& p, float* X, float* Q, float* K, float* V, float* A,
                                   float* C, float* H, float* Y, float* rstd1, float* rstd2, int n,
-                                  int n_heads) {
-  constexpr int SD = SasCfg<D>::SD, SA = SasCfg<D>::SA;
+                                  int n_heads, int SA) {
+  constexpr int SD = SasCfg<D>::SD;
   const int dk = D / n_heads;
   const float sqrt_dk = sqrtf((float)dk);
   const MatA aX{X, SD, 1};
@@ -167,7 +191,7 @@ __device__ void sas_layer_forward(const SasLayer& p, float* X, float* Q, float* 
   sas_mm(aX, MatB{p.WvT, D, 1}, n, D, D, false, [&](int i, int o, float v) { V[i * SD + o] = v + p.bv[o]; });
   __syncthreads();
   for (int hh = 0; hh < n_heads; ++hh) {
-    sas_attn_probs<D>(A, Q, K, n, hh, dk, sqrt_dk);
+    sas_attn_probs<D>(A, Q, K, n, hh, dk, sqrt_dk, SA);
     const int hc = hh * dk;  // ctx_h = A . V_h, + residual
     sas_mm(MatA{A, SA, 1}, MatB{V + hc, SD, 1}, n, dk, n, false,
            [&](int i, int c, float v) { C[i * SD + hc + c] = v + X[i * SD + hc + c]; });
@@ -200,10 +224,11 @@ __device__ __forceinline__ void sas_load_input(const SasArgs& a, int64_t b, int 
 template <int D, bool SAVE>
 __global__ __launch_bounds__(kBlock) void sasrec_fwd_kernel(SasArgs a) {
   using Cfg = SasCfg<D>;
-  constexpr int SD = Cfg::SD, BUF = Cfg::BUF;
+  constexpr int SD = Cfg::SD;
+  const int LP = sas_lp(a.L), SA = LP + 1, BUF = sas_buf_floats(D, LP);
   extern __shared__ float lds[];
   float *X = lds, *Q = X + BUF, *K = Q + BUF, *V = K + BUF, *A = V + BUF, *C = A + BUF, *H = C + BUF,
-        *Y = H + BUF, *rstd1 = Y + BUF, *rstd2 = rstd1 + kSasLP;
+        *Y = H + BUF, *rstd1 = Y + BUF, *rstd2 = rstd1 + LP;
   for (int64_t b = blockIdx.x; b < a.B; b += gridDim.x) {
     int n = (int)a.lengths[b];
     if (n > a.L) n = a.L;
@@ -214,7 +239,7 @@ __global__ __launch_bounds__(kBlock) void sasrec_fwd_kernel(SasArgs a) {
         float* xs = a.xsave + ((size_t)b * a.n_layers + l) * a.L * D;
         for (int idx = threadIdx.x; idx < n * D; idx += kBlock) xs[idx] = X[(idx / D) * SD + idx % D];
       }
-      sas_layer_forward<D, false>(a.layer[l], X, Q, K, V, A, C, H, Y, rstd1, rstd2, n, a.n_heads);
+      sas_layer_forward<D, false>(a.layer[l], X, Q, K, V, A, C, H, Y, rstd1, rstd2, n, a.n_heads, SA);
       for (int idx = threadIdx.x; idx < n * D; idx += kBlock) X[(idx / D) * SD + idx % D] = Y[(idx / D) * SD + idx % D];
       __syncthreads();
     }
@@ -283,10 +308,11 @@ __device__ __forceinline__ void sas_layernorm_bwd(float* G, const float* xhat, c
 template <int D>
 __global__ __launch_bounds__(kBlock) void sasrec_bwd_kernel(SasArgs a) {
   using Cfg = SasCfg<D>;
-  constexpr int SD = Cfg::SD, SA = Cfg::SA, BUF = Cfg::BUF, PL = Cfg::PL;
+  constexpr int SD = Cfg::SD, PL = Cfg::PL;
+  const int LP = sas_lp(a.L), SA = LP + 1, BUF = sas_buf_floats(D, LP);
   extern __shared__ float lds[];
   float *X = lds, *Q = X + BUF, *K = Q + BUF, *V = K + BUF, *G = V + BUF, *C = G + BUF, *H = C + BUF,
-        *Y = H + BUF, *rstd1 = Y + BUF, *rstd2 = rstd1 + kSasLP;
+        *Y = H + BUF, *rstd1 = Y + BUF, *rstd2 = rstd1 + LP;
   float* A = Y;  // attention probabilities reuse Y once the FFN backward no longer needs y1
   float* T = H;  // dA / dS reuse H once the FFN backward is done
   float* part = a.part + (size_t)blockIdx.x * a.n_layers * PL;
@@ -307,7 +333,7 @@ __global__ __launch_bounds__(kBlock) void sasrec_bwd_kernel(SasArgs a) {
       __syncthreads();
       // forward of this layer again: C = xhat1, H = relu hidden, Y = xhat2, Q/K/V, rstd1/2
       // (G, the incoming gradient, is untouched; H doubles as the attention scratch)
-      sas_layer_forward<D, true>(p, X, Q, K, V, /*A scratch = */ H, C, H, Y, rstd1, rstd2, n, a.n_heads);
+      sas_layer_forward<D, true>(p, X, Q, K, V, /*A scratch = */ H, C, H, Y, rstd1, rstd2, n, a.n_heads, SA);
       // ---- LayerNorm2, FFN ------------------------------------------------------------------
       sas_layernorm_bwd<D>(G, Y, rstd2, p.ln2w, gp + Cfg::oln2w, gp + Cfg::oln2b, n);  // G = dZ2
       sas_accum_outer<D>(gp + Cfg::oW2, G, H, n);
@@ -332,7 +358,7 @@ __global__ __launch_bounds__(kBlock) void sasrec_bwd_kernel(SasArgs a) {
       const float sqrt_dk = sqrtf((float)dk);
       for (int hh = 0; hh < a.n_heads; ++hh) {
         const int hc = hh * dk;
-        sas_attn_probs<D>(A, Q, K, n, hh, dk, sqrt_dk);
+        sas_attn_probs<D>(A, Q, K, n, hh, dk, sqrt_dk, SA);
         // dA = dCtx_h . V_h^T (lower triangle)
         sas_mm(MatA{G + hc, SD, 1}, MatB{V + hc, 1, SD}, n, n, dk, true,
                [&](int i, int j, float v) { T[i * SA + j] = v; });
@@ -422,7 +448,10 @@ static int sas_make_transposes(SasArgs* a, int D, float* dst, hipStream_t s) {
 
 static size_t sas_transpose_floats(int d, int n_layers) { return (size_t)n_layers * 5 * d * d; }
 
-static int sas_grid(int B) { return B < 512 ? (B < 1 ? 1 : B) : 512; }
+static int sas_grid(int B, int L) {
+  const int cap = sas_lp(L) == 32 ? 1024 : 512;  // two resident workgroups per CU at 66 KB of LDS
+  return B < cap ? (B < 1 ? 1 : B) : cap;
+}
 
 static int sas_fill_layers(SasArgs* a, const float* const* layer_params, int n_layers) {
   RC_REQUIRE(n_layers >= 1 && n_layers <= kSasMaxLayers, "SASRec: num_layers must be in [1, %d]", kSasMaxLayers);
@@ -440,15 +469,15 @@ static int sas_fill_layers(SasArgs* a, const float* const* layer_params, int n_l
 
 template <int D>
 static int sas_launch_fwd(const SasArgs& a, bool save, hipStream_t s) {
-  const size_t lds_bytes = (size_t)SasCfg<D>::kLdsFloats * sizeof(float);
+  const size_t lds_bytes = (size_t)sas_lds_floats(D, sas_lp(a.L)) * sizeof(float);
   if (save) {
     auto kern = sasrec_fwd_kernel<D, true>;
     RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    hipLaunchKernelGGL(kern, dim3(sas_grid(a.B)), dim3(kBlock), lds_bytes, s, a);
+    hipLaunchKernelGGL(kern, dim3(sas_grid(a.B, a.L)), dim3(kBlock), lds_bytes, s, a);
   } else {
     auto kern = sasrec_fwd_kernel<D, false>;
     RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    hipLaunchKernelGGL(kern, dim3(sas_grid(a.B)), dim3(kBlock), lds_bytes, s, a);
+    hipLaunchKernelGGL(kern, dim3(sas_grid(a.B, a.L)), dim3(kBlock), lds_bytes, s, a);
   }
   RC_LAUNCH_CHECK();
   return RC_OK;
@@ -456,8 +485,8 @@ static int sas_launch_fwd(const SasArgs& a, bool save, hipStream_t s) {
 
 template <int D>
 static int sas_launch_bwd(const SasArgs& a, float* dense_out, hipStream_t s) {
-  const size_t lds_bytes = (size_t)SasCfg<D>::kLdsFloats * sizeof(float);
-  const int n_wg = sas_grid(a.B);
+  const size_t lds_bytes = (size_t)sas_lds_floats(D, sas_lp(a.L)) * sizeof(float);
+  const int n_wg = sas_grid(a.B, a.L);
   const int count = a.n_layers * SasCfg<D>::PL;
   RC_HIP(hipMemsetAsync(a.part, 0, (size_t)n_wg * count * sizeof(float), s));
   auto kern = sasrec_bwd_kernel<D>;
@@ -484,7 +513,7 @@ extern "C" int rc_sasrec_dense_param_count(int d) { return 5 * d * d + 9 * d; }
 extern "C" size_t rc_sasrec_workspace_bytes(int B, int d, int n_layers) {
   if (B < 1 || d < 1 || n_layers < 1) return 0;
   return align_up(sas_transpose_floats(d, n_layers) * sizeof(float), 256) +
-         align_up((size_t)sas_grid(B) * n_layers * (5 * (size_t)d * d + 9 * d) * sizeof(float), 256) + 256;
+         align_up((size_t)1024 * n_layers * (5 * (size_t)d * d + 9 * d) * sizeof(float), 256) + 256;
 }
 
 extern "C" int rc_sasrec_fwd(const float* item_emb, const float* pos_emb, const float* const* layer_params,
