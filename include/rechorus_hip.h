@@ -134,6 +134,14 @@ size_t rc_sort_workspace_bytes(int64_t n);
 int rc_sort_ids(const int64_t* ids, int64_t n, int64_t n_rows, uint32_t* keys_out,
                 uint32_t* perm_out, void* ws, size_t ws_bytes, rc_stream_t stream);
 
+/* Two id lists sorted in ONE call as the virtual concatenation [ids_a ; key_offset_b + ids_b]
+ * (keys < key_range).  With key_offset_b >= every id of list a, the first n_a sorted positions are
+ * list a's segment and the tail is list b's (perm values n_a .. n_a+n_b-1): a BPRMF step sorts its
+ * item and user ids together and hands the two slices to rc_segmented_update2(key_base, occ_base). */
+int rc_sort_ids2(const int64_t* ids_a, int64_t n_a, const int64_t* ids_b, int64_t n_b,
+                 int64_t key_offset_b, int64_t key_range, uint32_t* keys_out, uint32_t* perm_out,
+                 void* ws, size_t ws_bytes, rc_stream_t stream);
+
 /* One pass over the sorted ids (keys/perm from rc_sort_ids) that
  *  - if single != NULL: single[o] = 1 iff occurrence o = perm[j] is the only one of its row;
  *  - if heads  != NULL: appends to heads[] the sorted positions j that start a segment
@@ -179,13 +187,15 @@ int rc_dense_update(float* W, const float* G, float* m, float* v, int64_t n,
 /* rc_segmented_update with a SECOND gradient source: occurrences o >= n_split take the plain row
  * src2[o - n_split, :] instead of coef[o]*Src[srow(o)].  SASRec updates its item table from the
  * candidates (g[b,c] * encoder output, rebuilt on the fly) and from the history positions
- * (gradient rows written by the encoder backward) in ONE pass, so the optimizer sees each row once. */
+ * (gradient rows written by the encoder backward) in ONE pass, so the optimizer sees each row once.
+ * key_base / occ_base: keys and perm may be a SLICE of a joint sort (rc_sort_ids2): the table row
+ * is keys[j] - key_base, the occurrence index perm[j] - occ_base (0, 0 for a plain sort).           */
 int rc_segmented_update2(float* W, float* m, float* v, int d, const uint32_t* keys,
                          const uint32_t* perm, int64_t n_occ, const float* coef, const float* src,
                          const int64_t* src_index, int div, const float* src2, int64_t n_split,
-                         const rc_opt_hyper* h, float* dense_grad, const uint32_t* heads,
-                         const uint32_t* n_heads, int flags, void* ws, size_t ws_bytes,
-                         rc_stream_t stream);
+                         int64_t key_base, int64_t occ_base, const rc_opt_hyper* h,
+                         float* dense_grad, const uint32_t* heads, const uint32_t* n_heads, int flags,
+                         void* ws, size_t ws_bytes, rc_stream_t stream);
 
 /* ---- SASRec encoder (models/sequential/SASRec.py:51-86, utils/layers.py:9-63,92-118) ------- */
 

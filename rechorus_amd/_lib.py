@@ -65,8 +65,9 @@ SIGNATURES = {
     "rc_segmented_workspace_bytes": (_sz, [_i64, _i]),
     "rc_segmented_update": (_i, [_p, _p, _p, _i, _p, _p, _i64, _p, _p, _p, _i, _hp, _p, _p, _p, _i, _p, _sz, _p]),
     "rc_dense_update": (_i, [_p, _p, _p, _p, _i64, _hp, _p]),
-    "rc_segmented_update2": (_i, [_p, _p, _p, _i, _p, _p, _i64, _p, _p, _p, _i, _p, _i64, _hp, _p, _p, _p, _i,
-                                  _p, _sz, _p]),
+    "rc_segmented_update2": (_i, [_p, _p, _p, _i, _p, _p, _i64, _p, _p, _p, _i, _p, _i64, _i64, _i64, _hp, _p, _p,
+                                  _p, _i, _p, _sz, _p]),
+    "rc_sort_ids2": (_i, [_p, _i64, _p, _i64, _i64, _i64, _p, _p, _p, _sz, _p]),
     "rc_sasrec_supported": (_i, [_i, _i, _i, _i]),
     "rc_sasrec_dense_param_count": (_i, [_i]),
     "rc_sasrec_workspace_bytes": (_sz, [_i, _i, _i]),

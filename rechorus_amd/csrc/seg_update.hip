@@ -49,6 +49,8 @@ struct SegArgs {
   const int64_t* src_index;
   const float* src2;   // optional second source: occurrences o >= n_split read src2[o - n_split]
   uint32_t n_split;
+  uint32_t key_base;   // table row = key - key_base   (keys / perm may be a slice of a joint sort)
+  uint32_t occ_base;   // occurrence = perm[j] - occ_base
   int div;
   int d;  // generic kernels only
   float* dense_grad;
@@ -95,7 +97,9 @@ __global__ __launch_bounds__(kBlock) void segment_heads_kernel(
       const uint32_t k = keys[j];
       const bool head = j == 0 || keys[j - 1] != k;
       const bool multi = j + 1 < n && keys[j + 1] == k;
-      if (single) single[perm[j]] = (head && !multi) ? 1 : 0;
+      // flags are pre-set to 1 (hipMemsetAsync); only members of multi-occurrence segments are
+      // cleared, which halves the scattered byte stores when most rows occur once
+      if (single && (multi || !head)) single[perm[j]] = 0;
       listed = head && (multi || !only_multi);
     }
     ballots[it] = __ballot(listed);
@@ -130,7 +134,7 @@ template <int D, int MODE>
 __device__ __forceinline__ void apply_row4(const SegArgs& a, uint32_t key, int l, float4 w,
                                            const float4& g) {
   constexpr int LPR = D / 4;
-  const size_t idx = (size_t)key * LPR + l;
+  const size_t idx = (size_t)(key - a.key_base) * LPR + l;
   if (MODE == MODE_DENSE_GRAD) {
     reinterpret_cast<float4*>(a.dense_grad)[idx] = g;
     return;
@@ -142,13 +146,14 @@ template <int D, int MODE>
 __device__ __forceinline__ float4 load_row4(const SegArgs& a, uint32_t key, int l) {
   constexpr int LPR = D / 4;
   if (MODE == MODE_DENSE_GRAD) return make_float4(0, 0, 0, 0);
-  return reinterpret_cast<const float4*>(a.W)[(size_t)key * LPR + l];
+  return reinterpret_cast<const float4*>(a.W)[(size_t)(key - a.key_base) * LPR + l];
 }
 
 // gradient row of occurrence o (= perm[j]), this lane's float4
 template <int D>
 __device__ __forceinline__ float4 occ_grad4_o(const SegArgs& a, uint32_t o, int l) {
   constexpr int LPR = D / 4;
+  o -= a.occ_base;
   if (a.src2 && o >= a.n_split)  // second source: plain gradient rows, one per occurrence
     return reinterpret_cast<const float4*>(a.src2)[(size_t)(o - a.n_split) * LPR + l];
   const float c = a.coef ? a.coef[o] : 1.0f;
@@ -339,7 +344,7 @@ __device__ __forceinline__ void apply_row_generic(const SegArgs& a, uint32_t key
   for (int q = 0; q < kGenChunks; ++q) {
     const int k = lane + 64 * q;
     if (k >= a.d) continue;
-    const size_t idx = (size_t)key * a.d + k;
+    const size_t idx = (size_t)(key - a.key_base) * a.d + k;
     if (MODE == MODE_DENSE_GRAD) {
       a.dense_grad[idx] = acc[q];
       continue;
@@ -356,7 +361,7 @@ __device__ __forceinline__ void apply_row_generic(const SegArgs& a, uint32_t key
 
 __device__ __forceinline__ void occ_grad_generic(const SegArgs& a, int64_t jj, int lane,
                                                  float* acc) {
-  const uint32_t o = a.perm[jj];
+  const uint32_t o = a.perm[jj] - a.occ_base;
   float c = a.coef ? a.coef[o] : 1.0f;
   int64_t sr = (a.div == 1) ? (int64_t)o : (int64_t)(o / (uint32_t)a.div);
   if (a.src_index) sr = a.src_index[sr];
@@ -392,6 +397,7 @@ __global__ __launch_bounds__(kBlock) void seg_update_generic_kernel(SegArgs a) {
 static int launch_heads(const uint32_t* keys, const uint32_t* perm, int64_t n, int only_multi,
                         uint8_t* single, uint32_t* heads, uint32_t* n_heads, hipStream_t s) {
   if (heads) RC_HIP(hipMemsetAsync(n_heads, 0, sizeof(uint32_t), s));
+  if (single) RC_HIP(hipMemsetAsync(single, 1, (size_t)n, s));
   const int64_t tile = (int64_t)kHeadIters * kBlock;
   const int64_t blocks = (n + tile - 1) / tile;
   hipLaunchKernelGGL(segment_heads_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, s, keys, perm,
@@ -504,18 +510,21 @@ extern "C" int rc_segmented_update(float* W, float* m, float* v, int d, const ui
                                    const rc_opt_hyper* h, float* dense_grad,
                                    const uint32_t* heads, const uint32_t* n_heads, int flags,
                                    void* ws, size_t ws_bytes, rc_stream_t stream) {
-  return rc_segmented_update2(W, m, v, d, keys, perm, n_occ, coef, src, src_index, div, nullptr, n_occ, h,
-                              dense_grad, heads, n_heads, flags, ws, ws_bytes, stream);
+  return rc_segmented_update2(W, m, v, d, keys, perm, n_occ, coef, src, src_index, div, nullptr, n_occ, 0, 0,
+                              h, dense_grad, heads, n_heads, flags, ws, ws_bytes, stream);
 }
 
 extern "C" int rc_segmented_update2(float* W, float* m, float* v, int d, const uint32_t* keys,
                                     const uint32_t* perm, int64_t n_occ, const float* coef,
                                     const float* src, const int64_t* src_index, int div,
-                                    const float* src2, int64_t n_split, const rc_opt_hyper* h,
-                                    float* dense_grad, const uint32_t* heads, const uint32_t* n_heads,
-                                    int flags, void* ws, size_t ws_bytes, rc_stream_t stream) {
+                                    const float* src2, int64_t n_split, int64_t key_base,
+                                    int64_t occ_base, const rc_opt_hyper* h, float* dense_grad,
+                                    const uint32_t* heads, const uint32_t* n_heads, int flags,
+                                    void* ws, size_t ws_bytes, rc_stream_t stream) {
   if (n_occ == 0) return RC_OK;
   RC_REQUIRE(n_split >= 0 && n_split <= n_occ, "rc_segmented_update2: n_split out of range");
+  RC_REQUIRE(key_base >= 0 && occ_base >= 0 && key_base < ((int64_t)1 << 32) && occ_base < ((int64_t)1 << 31),
+             "rc_segmented_update2: key_base / occ_base out of range");
   RC_REQUIRE(keys && perm && src && ws, "rc_segmented_update: null pointer");
   RC_REQUIRE(d >= 1 && div >= 1 && n_occ > 0 && n_occ < ((int64_t)1 << 31),
              "rc_segmented_update: bad shape d=%d div=%d n_occ=%lld", d, div, (long long)n_occ);
@@ -532,6 +541,7 @@ extern "C" int rc_segmented_update2(float* W, float* m, float* v, int d, const u
   a.keys = keys; a.perm = perm; a.n_occ = n_occ;
   a.coef = coef; a.src = src; a.src_index = src_index; a.div = div; a.d = d;
   a.src2 = src2; a.n_split = (uint32_t)n_split;
+  a.key_base = (uint32_t)key_base; a.occ_base = (uint32_t)occ_base;
   a.dense_grad = dense_grad;
   a.skip_single = (flags & RC_SEG_SKIP_SINGLETONS) ? 1 : 0;
   a.counters = w.counters; a.long_list = w.long_list; a.rows = w.rows; a.chunks = w.chunks;

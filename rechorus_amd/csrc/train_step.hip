@@ -4,9 +4,9 @@
 // host synchronisation (grid sizes depend only on B, C), so the call can be captured in a
 // hipGraph; with `phase_ms` it brackets the phases with hipEvents and synchronises.
 //
-//   phase 0  sort item ids (B*C)          phase 3  loss mean (deterministic)
+//   phase 0  sort item + user ids jointly phase 3  loss mean (deterministic)
 //   phase 7  mark single-occurrence rows  phase 4  item rows with >= 2 occurrences:
-//   phase 1  sort user ids (B)                     segmented grad + update
+//   phase 1  (merged into phase 0)                 segmented grad + update
 //   phase 2  fused gather/dot/loss/bwd    phase 5  user rows: segmented grad + update
 //            (+ update of singleton item rows, still in registers)
 //
@@ -39,17 +39,18 @@ StepWs carve_step_ws(void* base, int B, int C, int d) {
   const size_t n_i = (size_t)B * C;
   Carver cv(base);
   StepWs w;
-  w.keys_i = cv.take<uint32_t>(n_i);
-  w.perm_i = cv.take<uint32_t>(n_i);
-  w.keys_u = cv.take<uint32_t>((size_t)B);
-  w.perm_u = cv.take<uint32_t>((size_t)B);
+  // item and user ids are sorted together: [0, n_i) is the item segment, [n_i, n_i+B) the users'
+  w.keys_i = cv.take<uint32_t>(n_i + (size_t)B);
+  w.perm_i = cv.take<uint32_t>(n_i + (size_t)B);
+  w.keys_u = w.keys_i + n_i;
+  w.perm_u = w.perm_i + n_i;
   w.gpred = cv.take<float>(n_i);
   w.ugrad = cv.take<float>((size_t)B * d);
   w.loss_vec = cv.take<float>((size_t)B);
   w.single = cv.take<uint8_t>(n_i);
   w.heads_i = cv.take<uint32_t>(n_i);
   w.n_heads_i = cv.take<uint32_t>(1);
-  w.sort_ws_bytes = rc_sort_workspace_bytes((int64_t)n_i);
+  w.sort_ws_bytes = rc_sort_workspace_bytes((int64_t)n_i + B);
   w.sort_ws = cv.take<char>(w.sort_ws_bytes);
   w.seg_ws_bytes = rc_segmented_workspace_bytes((int64_t)n_i, d);
   w.seg_ws = cv.take<char>(w.seg_ws_bytes);
@@ -90,13 +91,15 @@ extern "C" int rc_bprmf_train_step(float* U, float* I, float* mU, float* vU, flo
 
   const bool fused_upd = rc_bprmf_fused_supported(d, C) != 0;
   RC_MARK(0);
-  RC_TRY(rc_sort_ids(iid, n_i, n_items, w.keys_i, w.perm_i, w.sort_ws, w.sort_ws_bytes, stream));
+  // one joint radix sort: keys = item id | n_items + user id (all user keys sort after all item keys)
+  RC_REQUIRE(n_items + n_users <= ((int64_t)1 << 32), "rc_bprmf_train_step: n_items + n_users exceeds 2^32");
+  RC_TRY(rc_sort_ids2(iid, n_i, uid, B, n_items, n_items + n_users, w.keys_i, w.perm_i, w.sort_ws,
+                      w.sort_ws_bytes, stream));
   RC_MARK(1);
   if (fused_upd)
     RC_TRY(rc_segment_heads(w.keys_i, w.perm_i, n_i, 1, w.single, w.heads_i, w.n_heads_i, stream));
   RC_MARK(2);
-  RC_TRY(rc_sort_ids(uid, B, n_users, w.keys_u, w.perm_u, w.sort_ws, w.sort_ws_bytes, stream));
-  RC_MARK(3);
+  RC_MARK(3);  // (the user ids were sorted with the item ids)
   if (fused_upd)
     RC_TRY(rc_bprmf_fwd_bwd_update(U, I, mI, vI, uid, iid, w.single, B, C, d, inv_b, h, pred,
                                    w.loss_vec, w.gpred, w.ugrad, stream));
@@ -114,8 +117,9 @@ extern "C" int rc_bprmf_train_step(float* U, float* I, float* mU, float* vU, flo
                              stream));
   RC_MARK(6);
   // user rows: grad_r = sum_{b: uid[b]=r} ugrad[b]
-  RC_TRY(rc_segmented_update(U, mU, vU, d, w.keys_u, w.perm_u, B, nullptr, w.ugrad, nullptr, 1, h,
-                             nullptr, nullptr, nullptr, 0, w.seg_ws, w.seg_ws_bytes, stream));
+  RC_TRY(rc_segmented_update2(U, mU, vU, d, w.keys_u, w.perm_u, B, nullptr, w.ugrad, nullptr, 1, nullptr, B,
+                              /*key_base=*/n_items, /*occ_base=*/n_i, h, nullptr, nullptr, nullptr, 0,
+                              w.seg_ws, w.seg_ws_bytes, stream));
   RC_MARK(7);
 #undef RC_MARK
 

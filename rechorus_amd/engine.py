@@ -442,7 +442,7 @@ def segmented_update2(keys, perm, src, src2, n_split, hyper=None, W=None, m=None
     _lib.call("rc_segmented_update2", _ptr(W, f32, "W", True), _ptr(m, f32, "m", True), _ptr(v, f32, "v", True), d,
               _ptr(keys, torch.int32, "keys"), _ptr(perm, torch.int32, "perm"), n_occ,
               _ptr(coef, f32, "coef", True), _ptr(src, f32, "src"), _ptr(src_index, torch.int64, "src_index", True),
-              int(div), _ptr(src2, f32, "src2"), int(n_split), C.byref(hyper) if hyper is not None else None,
+              int(div), _ptr(src2, f32, "src2"), int(n_split), 0, 0, C.byref(hyper) if hyper is not None else None,
               _ptr(dense_grad, f32, "dense_grad", True), None, None, 0, C.c_void_p(ws.data_ptr()), ws.numel(), _stream())
 
 
