@@ -135,12 +135,14 @@ __global__ __launch_bounds__(kBlock) void bprmf_fwd_bwd_kernel(
     acc.z = fmaf(g, r[j].z, acc.z);
     acc.w = fmaf(g, r[j].w, acc.w);
     if (tv && l == 0 && c < C) gpred[t * C + c] = g;
-    if (MODE != MODE_NONE) {
+    if (MODE == MODE_SGD) {
       if (smask & (1u << j)) {  // whole lane-group takes the branch together
         const int64_t id = ids[c];
         const float4 gi = make_float4(g * u4.x, g * u4.y, g * u4.z, g * u4.w);
         opt_row4<MODE>(upd.o, upd.I, upd.M, upd.V, (size_t)id * LPR + l, r[j], gi);
       }
+    } else if (MODE != MODE_NONE) {
+      p[j] = g;  // stateful optimizers: updated below, state rows fetched in batches
     }
   }
   acc.x = groups_allreduce_sum<LPR, S>(acc.x);
@@ -148,6 +150,41 @@ __global__ __launch_bounds__(kBlock) void bprmf_fwd_bwd_kernel(
   acc.z = groups_allreduce_sum<LPR, S>(acc.z);
   acc.w = groups_allreduce_sum<LPR, S>(acc.w);
   if (tv && grp == 0) reinterpret_cast<float4*>(ugrad + t * D)[l] = acc;
+
+  if (MODE == MODE_ADAM || MODE == MODE_ADAGRAD) {
+    // singleton rows under Adam / Adagrad: the m (and v) rows of GRP candidates are requested
+    // together before any is used -- one memory round trip per batch instead of one per row
+    constexpr int GRP = 5;
+#pragma unroll
+    for (int j0 = 0; j0 < CPL; j0 += GRP) {
+      float4 mm[GRP], vv[GRP];
+      size_t idx[GRP];
+#pragma unroll
+      for (int q = 0; q < GRP; ++q) {
+        const int j = j0 + q;
+        mm[q] = vv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        idx[q] = 0;
+        if (j < CPL && ((smask >> j) & 1u)) {
+          idx[q] = (size_t)ids[j * GS + grp] * LPR + l;
+          mm[q] = reinterpret_cast<const float4*>(upd.M)[idx[q]];
+          if (MODE == MODE_ADAM) vv[q] = reinterpret_cast<const float4*>(upd.V)[idx[q]];
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < GRP; ++q) {
+        const int j = j0 + q;
+        if (j < CPL && ((smask >> j) & 1u)) {
+          const float g = p[j];
+          const float4 gi = make_float4(g * u4.x, g * u4.y, g * u4.z, g * u4.w);
+          float4 w = r[j];
+          opt_apply4<MODE>(upd.o, w, mm[q], vv[q], gi);
+          store_row4(reinterpret_cast<float4*>(upd.I) + idx[q], w);
+          store_row4(reinterpret_cast<float4*>(upd.M) + idx[q], mm[q]);
+          if (MODE == MODE_ADAM) store_row4(reinterpret_cast<float4*>(upd.V) + idx[q], vv[q]);
+        }
+      }
+    }
+  }
 }
 
 // Any d, any 2 <= C <= kGenericMaxC: one wave per tuple, scores staged in LDS, candidate

@@ -78,6 +78,15 @@ __device__ __forceinline__ void store_row4(float4* p, const float4& x) {
 #endif
 }
 
+// the optimizer on one float4 slice held in registers (state already loaded)
+template <int MODE>
+__device__ __forceinline__ void opt_apply4(const OptScalars& a, float4& w, float4& m, float4& v, const float4& g) {
+  opt_elem<MODE>(a, g.x, w.x, m.x, v.x);
+  opt_elem<MODE>(a, g.y, w.y, m.y, v.y);
+  opt_elem<MODE>(a, g.z, w.z, m.z, v.z);
+  opt_elem<MODE>(a, g.w, w.w, m.w, v.w);
+}
+
 // update one float4 slice of a table row in place (row index `row`, slice l of LPR)
 template <int MODE>
 __device__ __forceinline__ void opt_row4(const OptScalars& a, float* __restrict__ W,
