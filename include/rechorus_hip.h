@@ -92,6 +92,14 @@ int rc_weighted_row_sum(const float* W, const int64_t* ids, const float* coef, i
 int rc_bpr_loss_fwd_bwd(const float* pred, int B, int C, float inv_b, float* loss_vec,
                         float* gpred, rc_stream_t stream);
 
+/* List-wise softmax cross-entropy over an impression list (ImpressionModel.loss, loss_n='softmaxCE',
+ * models/BaseImpressionModel.py:96-107).  pred [B,n]; target [B,n] int64 in {1,0,-1} (-1 = padding),
+ * the first max_pos columns are the positive slots.  loss_vec[b] is row b's contribution (their sum
+ * is the loss: rc_reduce_sum(loss_vec, B, 1)); h_sum[0] receives sum_b [row b has a negative];
+ * gpred (optional) = d loss / d pred.                                                             */
+int rc_softmax_ce_fwd_bwd(const float* pred, const int64_t* target, int B, int n, int max_pos,
+                          float* loss_vec, float* h_sum, float* gpred, rc_stream_t stream);
+
 /* out[0] = scale * sum_i x[i], fixed summation order (deterministic).  Used for the
  * batch mean of loss_vec (models/BaseModel.py:185 `.mean()`).                         */
 int rc_reduce_sum(const float* x, int64_t n, float scale, float* out, rc_stream_t stream);

@@ -166,8 +166,8 @@ __global__ __launch_bounds__(kBlock) void bprmf_fwd_bwd_kernel(
         idx[q] = 0;
         if (j < CPL && ((smask >> j) & 1u)) {
           idx[q] = (size_t)ids[j * GS + grp] * LPR + l;
-          mm[q] = reinterpret_cast<const float4*>(upd.M)[idx[q]];
-          if (MODE == MODE_ADAM) vv[q] = reinterpret_cast<const float4*>(upd.V)[idx[q]];
+          mm[q] = load_stream4(reinterpret_cast<const float4*>(upd.M) + idx[q]);
+          if (MODE == MODE_ADAM) vv[q] = load_stream4(reinterpret_cast<const float4*>(upd.V) + idx[q]);
         }
       }
 #pragma unroll

@@ -30,6 +30,7 @@ SOURCES = [
     "train_step.hip",
     "neumf.hip",
     "sasrec.hip",
+    "listwise_loss.hip",
 ]
 HEADERS = ["common.hpp", "bpr_math.hpp", "opt_math.hpp", os.path.join("..", "..", "include", "rechorus_hip.h")]
 

@@ -1,0 +1,93 @@
+// listwise_loss.hip -- list-wise softmax cross-entropy over an impression list, forward and the
+// closed-form gradient (reference: ImpressionModel.loss, loss_n == 'softmaxCE',
+// models/BaseImpressionModel.py:44-48,96-107; labels built in helpers/ImpressionRunner.py:187-190).
+//
+//   mask = target != -1;  have_neg_b = mask[b, P]            (P = train_max_pos_item)
+//   p = softmax over the valid columns of row b (row max subtracted)
+//   row_b = -(sum_{i < P, mask} log p_i) / #(target == 1)
+//   loss = sum_b row_b * have_neg_b / sum_b have_neg_b
+//   dloss/dx_bj = -(have_neg_b / H / n_b) * (1[j in S_b] - |S_b| p_bj)  on valid columns, 0 on padding
+//
+// One wave per row (lists are 40 ... a few hundred entries), shuffle reductions; the normaliser
+// H = sum_b have_neg_b is produced by a first single-workgroup kernel (deterministic).
+#include "common.hpp"
+
+namespace rc {
+
+__global__ __launch_bounds__(kBlock) void listwise_count_kernel(const int64_t* __restrict__ target, int B,
+                                                                int n, int P, float* __restrict__ h_out) {
+  __shared__ float sm[kBlock];
+  float acc = 0.f;
+  for (int b = threadIdx.x; b < B; b += kBlock) acc += target[(size_t)b * n + P] != -1 ? 1.f : 0.f;
+  sm[threadIdx.x] = acc;
+  __syncthreads();
+  for (int off = kBlock / 2; off >= 1; off >>= 1) {
+    if ((int)threadIdx.x < off) sm[threadIdx.x] += sm[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) h_out[0] = sm[0];
+}
+
+__global__ __launch_bounds__(kBlock) void listwise_softmax_ce_kernel(
+    const float* __restrict__ pred, const int64_t* __restrict__ target, int B, int n, int P,
+    const float* __restrict__ h_sum, float* __restrict__ loss_vec, float* __restrict__ gpred) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (row >= B) return;  // wave-uniform
+  const float* x = pred + row * n;
+  const int64_t* tg = target + row * n;
+  float mx = -INFINITY;
+  for (int j = lane; j < n; j += 64)
+    if (tg[j] != -1) mx = fmaxf(mx, x[j]);
+  mx = wave_allreduce_max(mx);
+  float se = 0.f, n_pos = 0.f, s_cnt = 0.f;
+  for (int j = lane; j < n; j += 64) {
+    const int64_t t = tg[j];
+    if (t != -1) se += expf(x[j] - mx);
+    if (t == 1) n_pos += 1.f;
+    if (j < P && t != -1) s_cnt += 1.f;
+  }
+  se = wave_allreduce_sum(se);
+  n_pos = wave_allreduce_sum(n_pos);
+  s_cnt = wave_allreduce_sum(s_cnt);
+  const float log_se = logf(se);
+  float lsum = 0.f;  // sum over valid positive slots of log p_i = (x_i - mx) - log(se)
+  for (int j = lane; j < P && j < n; j += 64)
+    if (tg[j] != -1) lsum += (x[j] - mx) - log_se;
+  lsum = wave_allreduce_sum(lsum);
+  const float have_neg = tg[P] != -1 ? 1.f : 0.f;
+  const float H = h_sum[0];
+  const float row_loss = -lsum / n_pos;
+  if (lane == 0) loss_vec[row] = row_loss * have_neg / H;  // summing loss_vec gives the loss
+  if (gpred) {
+    const float coef = -(have_neg / H) / n_pos;
+    for (int j = lane; j < n; j += 64) {
+      float g = 0.f;
+      if (tg[j] != -1) {
+        const float p = expf(x[j] - mx) / se;
+        g = coef * ((j < P ? 1.f : 0.f) - s_cnt * p);
+      }
+      gpred[row * n + j] = g;
+    }
+  }
+}
+
+}  // namespace rc
+
+using namespace rc;
+
+extern "C" int rc_softmax_ce_fwd_bwd(const float* pred, const int64_t* target, int B, int n, int max_pos,
+                                     float* loss_vec, float* h_sum, float* gpred, rc_stream_t stream) {
+  if (B == 0) return RC_OK;
+  RC_REQUIRE(pred && target && loss_vec && h_sum, "rc_softmax_ce_fwd_bwd: null pointer");
+  RC_REQUIRE(B > 0 && n >= 2 && max_pos >= 1 && max_pos < n,
+             "rc_softmax_ce_fwd_bwd: need 1 <= max_pos < n (got B=%d n=%d max_pos=%d)", B, n, max_pos);
+  hipStream_t s = as_stream(stream);
+  hipLaunchKernelGGL(listwise_count_kernel, dim3(1), dim3(kBlock), 0, s, target, B, n, max_pos, h_sum);
+  RC_LAUNCH_CHECK();
+  const int blocks = (B + (kBlock / 64) - 1) / (kBlock / 64);
+  hipLaunchKernelGGL(listwise_softmax_ce_kernel, dim3(blocks), dim3(kBlock), 0, s, pred, target, B, n, max_pos,
+                     h_sum, loss_vec, gpred);
+  RC_LAUNCH_CHECK();
+  return RC_OK;
+}

@@ -93,8 +93,8 @@ __device__ __forceinline__ void opt_row4(const OptScalars& a, float* __restrict_
                                          float* __restrict__ M, float* __restrict__ V, size_t idx4,
                                          float4 w, const float4& g) {
   float4 m = make_float4(0, 0, 0, 0), v = make_float4(0, 0, 0, 0);
-  if (MODE == MODE_ADAM || MODE == MODE_ADAGRAD) m = reinterpret_cast<const float4*>(M)[idx4];
-  if (MODE == MODE_ADAM) v = reinterpret_cast<const float4*>(V)[idx4];
+  if (MODE == MODE_ADAM || MODE == MODE_ADAGRAD) m = load_stream4(reinterpret_cast<const float4*>(M) + idx4);
+  if (MODE == MODE_ADAM) v = load_stream4(reinterpret_cast<const float4*>(V) + idx4);
   opt_elem<MODE>(a, g.x, w.x, m.x, v.x);
   opt_elem<MODE>(a, g.y, w.y, m.y, v.y);
   opt_elem<MODE>(a, g.z, w.z, m.z, v.z);

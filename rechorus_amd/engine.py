@@ -504,3 +504,18 @@ class SasrecTrainer:
                 st = self._st(lay[name])
                 dense_update(lay[name], g[name].contiguous(), h0 if name in SAS_NO_DECAY else h, st.get("m"), st.get("v"))
         return self.loss
+
+
+# ---- list-wise softmax cross-entropy -------------------------------------------------------------------
+
+def softmax_ce(pred, target, max_pos, need_grad=True):
+    """ImpressionModel.loss with loss_n='softmaxCE' (models/BaseImpressionModel.py:96-107).
+    pred [B,n] fp32, target [B,n] int64 in {1,0,-1}; -> (loss [1], gpred | None)"""
+    B, n = pred.shape
+    dev, f32 = pred.device, torch.float32
+    loss_vec = torch.empty(B, dtype=f32, device=dev)
+    h_sum = torch.empty(1, dtype=f32, device=dev)
+    gpred = torch.empty_like(pred) if need_grad else None
+    _lib.call("rc_softmax_ce_fwd_bwd", _ptr(pred, f32, "pred"), _ptr(target, torch.int64, "target"), B, n, int(max_pos),
+              _ptr(loss_vec, f32, "loss_vec"), _ptr(h_sum, f32, "h_sum"), _ptr(gpred, f32, "gpred", True), _stream())
+    return reduce_sum(loss_vec, 1.0), gpred
