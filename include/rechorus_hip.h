@@ -92,6 +92,20 @@ int rc_weighted_row_sum(const float* W, const int64_t* ids, const float* coef, i
 int rc_bpr_loss_fwd_bwd(const float* pred, int B, int C, float inv_b, float* loss_vec,
                         float* gpred, rc_stream_t stream);
 
+/* Factorization-machine second-order term over stacked field vectors V [n, F, d]
+ * (FMBase.forward / DeepFMBase.forward, models/context/FM.py:59-63, DeepFM.py:19-23):
+ *   out[i] = sum_k 0.5*((sum_f V[i,f,k])^2 - sum_f V[i,f,k]^2);   dV[i,f,k] = gout[i]*((sum_f' V[i,f',k]) - V[i,f,k]).
+ * d in {16,32,64,128}.                                                                              */
+int rc_fm_second_order_fwd(const float* V, int64_t n, int F, int d, float* out, rc_stream_t stream);
+int rc_fm_second_order_bwd(const float* V, const float* gout, int64_t n, int F, int d, float* dV,
+                           rc_stream_t stream);
+
+/* nn.BCELoss on probabilities (CTRModel.loss, models/BaseModel.py:259-267), torch's log clamp (-100) and
+ * backward denominator clamp (1e-12): loss_vec[i] = -(y log p + (1-y) log(1-p)); gp[i] = dmean/dp_i
+ * with inv_n = 1/n.  The loss is rc_reduce_sum(loss_vec, n, inv_n).                                    */
+int rc_bce_prob_fwd_bwd(const float* p, const float* y, int64_t n, float inv_n, float* loss_vec, float* gp,
+                        rc_stream_t stream);
+
 /* List-wise softmax cross-entropy over an impression list (ImpressionModel.loss, loss_n='softmaxCE',
  * models/BaseImpressionModel.py:96-107).  pred [B,n]; target [B,n] int64 in {1,0,-1} (-1 = padding),
  * the first max_pos columns are the positive slots.  loss_vec[b] is row b's contribution (their sum

@@ -31,6 +31,7 @@ SOURCES = [
     "neumf.hip",
     "sasrec.hip",
     "listwise_loss.hip",
+    "fm_bce.hip",
 ]
 HEADERS = ["common.hpp", "bpr_math.hpp", "opt_math.hpp", os.path.join("..", "..", "include", "rechorus_hip.h")]
 

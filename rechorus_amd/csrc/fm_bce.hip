@@ -1,0 +1,121 @@
+// fm_bce.hip -- the factorization-machine second-order term over stacked field vectors and the
+// binary cross-entropy of the CTR task, forward and closed-form backward.
+//
+// Reference: FMBase.forward / DeepFMBase.forward (models/context/FM.py:59-63, DeepFM.py:19-23):
+//     fm[n] = sum_k 0.5 * ((sum_f v[n,f,k])^2 - sum_f v[n,f,k]^2)
+//   d fm[n] / d v[n,f,k] = (sum_f' v[n,f',k]) - v[n,f,k]
+// and CTRModel.loss with nn.BCELoss (models/BaseModel.py:259-267) on probabilities p = sigmoid(.):
+//     L = mean_i -( y_i * max(log p_i, -100) + (1-y_i) * max(log1p(-p_i), -100) )     (torch clamps the logs)
+//   dL/dp_i = (p_i - y_i) / max(p_i (1-p_i), 1e-12) / n                               (torch's backward)
+//
+// Both are HBM-bound streaming kernels: one lane-group (d/4 lanes, a float4 each) per instance walks
+// the F field vectors once (forward) or twice (backward: the field sum, then the per-field gradient).
+#include "common.hpp"
+
+namespace rc {
+
+template <int D>
+__global__ __launch_bounds__(kBlock) void fm2_fwd_kernel(const float* __restrict__ V, int64_t n, int F,
+                                                         float* __restrict__ out) {
+  constexpr int LPR = D / 4;
+  constexpr int GPB = kBlock / LPR;
+  const int l = threadIdx.x % LPR;
+  const int64_t i_raw = (int64_t)blockIdx.x * GPB + threadIdx.x / LPR;
+  const int64_t i = i_raw < n ? i_raw : n - 1;  // keep every lane in the DPP reduction
+  const float4* v = reinterpret_cast<const float4*>(V + i * F * D) + l;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = s;
+  for (int f = 0; f < F; ++f) {
+    const float4 x = v[f * LPR];
+    s.x += x.x; s.y += x.y; s.z += x.z; s.w += x.w;
+    q.x = fmaf(x.x, x.x, q.x); q.y = fmaf(x.y, x.y, q.y); q.z = fmaf(x.z, x.z, q.z); q.w = fmaf(x.w, x.w, q.w);
+  }
+  float part = 0.5f * (s.x * s.x - q.x) + 0.5f * (s.y * s.y - q.y) + 0.5f * (s.z * s.z - q.z) +
+               0.5f * (s.w * s.w - q.w);
+  part = row_allreduce_sum<LPR>(part);
+  if (l == 0 && i_raw < n) out[i] = part;
+}
+
+template <int D>
+__global__ __launch_bounds__(kBlock) void fm2_bwd_kernel(const float* __restrict__ V, const float* __restrict__ g,
+                                                         int64_t n, int F, float* __restrict__ dV) {
+  constexpr int LPR = D / 4;
+  constexpr int GPB = kBlock / LPR;
+  const int l = threadIdx.x % LPR;
+  const int64_t i = (int64_t)blockIdx.x * GPB + threadIdx.x / LPR;
+  if (i >= n) return;  // no cross-lane ops here
+  const float4* v = reinterpret_cast<const float4*>(V + i * F * D) + l;
+  float4* dv = reinterpret_cast<float4*>(dV + i * F * D) + l;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int f = 0; f < F; ++f) {
+    const float4 x = v[f * LPR];
+    s.x += x.x; s.y += x.y; s.z += x.z; s.w += x.w;
+  }
+  const float gi = g[i];
+  for (int f = 0; f < F; ++f) {
+    const float4 x = v[f * LPR];
+    dv[f * LPR] = make_float4(gi * (s.x - x.x), gi * (s.y - x.y), gi * (s.z - x.z), gi * (s.w - x.w));
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void bce_prob_kernel(const float* __restrict__ p, const float* __restrict__ y,
+                                                          int64_t n, float inv_n, float* __restrict__ loss_vec,
+                                                          float* __restrict__ gp) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    const float pi = p[i], yi = y[i];
+    const float lp = fmaxf(logf(pi), -100.f), lq = fmaxf(log1pf(-pi), -100.f);
+    loss_vec[i] = -(yi * lp + (1.0f - yi) * lq);
+    if (gp) gp[i] = (pi - yi) / fmaxf((1.0f - pi) * pi, 1e-12f) * inv_n;
+  }
+}
+
+}  // namespace rc
+
+using namespace rc;
+
+#define RC_FM_DISPATCH(KERN, ...)                                                                   \
+  switch (d) {                                                                                      \
+    case 16: hipLaunchKernelGGL((KERN<16>), dim3(blocks(16)), dim3(kBlock), 0, s, __VA_ARGS__); break; \
+    case 32: hipLaunchKernelGGL((KERN<32>), dim3(blocks(32)), dim3(kBlock), 0, s, __VA_ARGS__); break; \
+    case 64: hipLaunchKernelGGL((KERN<64>), dim3(blocks(64)), dim3(kBlock), 0, s, __VA_ARGS__); break; \
+    case 128: hipLaunchKernelGGL((KERN<128>), dim3(blocks(128)), dim3(kBlock), 0, s, __VA_ARGS__); break; \
+    default: return fail(RC_ERR_UNSUPPORTED, "FM second-order kernels need emb_size in {16,32,64,128}, got %d", d); \
+  }
+
+extern "C" int rc_fm_second_order_fwd(const float* V, int64_t n, int F, int d, float* out, rc_stream_t stream) {
+  if (n == 0) return RC_OK;
+  RC_REQUIRE(V && out, "rc_fm_second_order_fwd: null pointer");
+  RC_REQUIRE(n > 0 && F >= 1, "rc_fm_second_order_fwd: bad shape n=%lld F=%d", (long long)n, F);
+  RC_REQUIRE(reinterpret_cast<uintptr_t>(V) % 16 == 0, "rc_fm_second_order_fwd: V must be 16-byte aligned");
+  hipStream_t s = as_stream(stream);
+  auto blocks = [&](int dd) { return (unsigned)((n + (kBlock / (dd / 4)) - 1) / (kBlock / (dd / 4))); };
+  RC_FM_DISPATCH(fm2_fwd_kernel, V, n, F, out);
+  RC_LAUNCH_CHECK();
+  return RC_OK;
+}
+
+extern "C" int rc_fm_second_order_bwd(const float* V, const float* gout, int64_t n, int F, int d, float* dV,
+                                      rc_stream_t stream) {
+  if (n == 0) return RC_OK;
+  RC_REQUIRE(V && gout && dV, "rc_fm_second_order_bwd: null pointer");
+  RC_REQUIRE(n > 0 && F >= 1, "rc_fm_second_order_bwd: bad shape n=%lld F=%d", (long long)n, F);
+  RC_REQUIRE(reinterpret_cast<uintptr_t>(V) % 16 == 0 && reinterpret_cast<uintptr_t>(dV) % 16 == 0,
+             "rc_fm_second_order_bwd: V and dV must be 16-byte aligned");
+  hipStream_t s = as_stream(stream);
+  auto blocks = [&](int dd) { return (unsigned)((n + (kBlock / (dd / 4)) - 1) / (kBlock / (dd / 4))); };
+  RC_FM_DISPATCH(fm2_bwd_kernel, V, gout, n, F, dV);
+  RC_LAUNCH_CHECK();
+  return RC_OK;
+}
+
+extern "C" int rc_bce_prob_fwd_bwd(const float* p, const float* y, int64_t n, float inv_n, float* loss_vec,
+                                   float* gp, rc_stream_t stream) {
+  if (n == 0) return RC_OK;
+  RC_REQUIRE(p && y && loss_vec, "rc_bce_prob_fwd_bwd: null pointer");
+  RC_REQUIRE(n > 0, "rc_bce_prob_fwd_bwd: n < 0");
+  int64_t blocks = (n + kBlock - 1) / kBlock;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(bce_prob_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, as_stream(stream), p, y, n, inv_n,
+                     loss_vec, gp);
+  RC_LAUNCH_CHECK();
+  return RC_OK;
+}

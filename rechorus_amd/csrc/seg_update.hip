@@ -393,6 +393,43 @@ __global__ __launch_bounds__(kBlock) void seg_update_generic_kernel(SegArgs a) {
   apply_row_generic<MODE>(a, key, lane, acc);
 }
 
+// narrow rows (d <= 4, e.g. the [vocab, 1] first-order tables of FM-family models, whose few
+// rows each collect thousands of occurrences): lanes stride over the SEGMENT, then one wave
+// all-reduce per element.  Fixed order -> deterministic.
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void seg_update_narrow_kernel(SegArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int64_t j = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (j >= a.n_occ) return;
+  const uint32_t key = a.keys[j];
+  if (j > 0 && a.keys[j - 1] == key) return;
+  if (a.skip_single && !(j + 1 < a.n_occ && a.keys[j + 1] == key)) return;
+  float part[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int64_t jj = j + lane; jj < a.n_occ && a.keys[jj] == key; jj += 64) {
+    const uint32_t o = a.perm[jj] - a.occ_base;
+    float c = a.coef ? a.coef[o] : 1.0f;
+    int64_t sr = (a.div == 1) ? (int64_t)o : (int64_t)(o / (uint32_t)a.div);
+    if (a.src_index) sr = a.src_index[sr];
+    const float* s = a.src + (size_t)sr * a.d;
+    if (a.src2 && o >= a.n_split) {
+      s = a.src2 + (size_t)(o - a.n_split) * a.d;
+      c = 1.0f;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (k < a.d) part[k] += c * s[k];
+  }
+  float acc[kGenChunks];
+#pragma unroll
+  for (int q = 0; q < kGenChunks; ++q) acc[q] = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float t = wave_allreduce_sum(part[k]);
+    if (lane == k) acc[0] = t;
+  }
+  apply_row_generic<MODE>(a, key, lane, acc);
+}
+
 // ---- launchers ------------------------------------------------------------------------------
 static int launch_heads(const uint32_t* keys, const uint32_t* perm, int64_t n, int only_multi,
                         uint8_t* single, uint32_t* heads, uint32_t* n_heads, hipStream_t s) {
@@ -445,8 +482,12 @@ static int launch_seg_mode(const SegArgs& a, bool vec_ok, hipStream_t s) {
     return fail(RC_ERR_UNSUPPORTED, "rc_segmented_update: d=%d > %d", a.d, 64 * kGenChunks);
   const int64_t blocks = (a.n_occ + (kBlock / 64) - 1) / (kBlock / 64);
   if (blocks > kMaxGridX) return fail(RC_ERR_UNSUPPORTED, "seg_update: grid too large");
-  hipLaunchKernelGGL((seg_update_generic_kernel<MODE>), dim3((unsigned)blocks), dim3(kBlock), 0, s,
-                     a);
+  if (a.d <= 4)
+    hipLaunchKernelGGL((seg_update_narrow_kernel<MODE>), dim3((unsigned)blocks), dim3(kBlock), 0, s,
+                       a);
+  else
+    hipLaunchKernelGGL((seg_update_generic_kernel<MODE>), dim3((unsigned)blocks), dim3(kBlock), 0,
+                       s, a);
   RC_LAUNCH_CHECK();
   return RC_OK;
 }

@@ -519,3 +519,35 @@ def softmax_ce(pred, target, max_pos, need_grad=True):
     _lib.call("rc_softmax_ce_fwd_bwd", _ptr(pred, f32, "pred"), _ptr(target, torch.int64, "target"), B, n, int(max_pos),
               _ptr(loss_vec, f32, "loss_vec"), _ptr(h_sum, f32, "h_sum"), _ptr(gpred, f32, "gpred", True), _stream())
     return reduce_sum(loss_vec, 1.0), gpred
+
+
+# ---- factorization-machine term, BCE ----------------------------------------------------------------------
+
+def fm_second_order(V):
+    """V [..., F, d] stacked field vectors -> 0.5*sum_k((sum_f v)^2 - sum_f v^2), shape [...]
+    (models/context/FM.py:61, DeepFM.py:22-23)"""
+    F, d = V.shape[-2], V.shape[-1]
+    n = V.numel() // (F * d)
+    out = torch.empty(V.shape[:-2], dtype=torch.float32, device=V.device)
+    _lib.call("rc_fm_second_order_fwd", _ptr(V, torch.float32, "V"), n, F, d, _ptr(out, torch.float32, "out"), _stream())
+    return out
+
+
+def fm_second_order_bwd(V, gout):
+    F, d = V.shape[-2], V.shape[-1]
+    n = V.numel() // (F * d)
+    dV = torch.empty_like(V)
+    _lib.call("rc_fm_second_order_bwd", _ptr(V, torch.float32, "V"), _ptr(gout, torch.float32, "gout"), n, F, d,
+              _ptr(dV, torch.float32, "dV"), _stream())
+    return dV
+
+
+def bce_prob(p, y, need_grad=True):
+    """nn.BCELoss()(p, y) on probabilities (models/BaseModel.py:259-267) -> (loss [1], dloss/dp | None)"""
+    n = p.numel()
+    f32 = torch.float32
+    loss_vec = torch.empty(n, dtype=f32, device=p.device)
+    gp = torch.empty_like(p) if need_grad else None
+    _lib.call("rc_bce_prob_fwd_bwd", _ptr(p, f32, "p"), _ptr(y, f32, "y"), n, 1.0 / n, _ptr(loss_vec, f32, "loss_vec"),
+              _ptr(gp, f32, "gp", True), _stream())
+    return reduce_sum(loss_vec, 1.0 / n), gp

@@ -98,6 +98,49 @@ def bpr_loss(pred):
     return _BprLossFn.apply(pred)
 
 
+class _FmSecondOrderFn(torch.autograd.Function):
+    """0.5 * sum_k ((sum_f v)^2 - sum_f v^2) over stacked field vectors (models/context/FM.py:61)."""
+
+    @staticmethod
+    def forward(ctx, V):
+        Vc = V.detach().contiguous()
+        ctx.save_for_backward(Vc)
+        return engine.fm_second_order(Vc)
+
+    @staticmethod
+    def backward(ctx, gout):
+        (Vc,) = ctx.saved_tensors
+        return engine.fm_second_order_bwd(Vc, gout.contiguous())
+
+
+def fm_second_order(V):
+    if not V.is_cuda:
+        raise RuntimeError("fm_second_order runs on the GPU only (no CPU path)")
+    if V.shape[-1] in (16, 32, 64, 128):
+        return _FmSecondOrderFn.apply(V)
+    # other embedding sizes: the same expression as device-side torch ops
+    return (0.5 * (V.sum(dim=-2).pow(2) - V.pow(2).sum(dim=-2))).sum(dim=-1)
+
+
+class _BceProbFn(torch.autograd.Function):
+    """nn.BCELoss on probabilities (models/BaseModel.py:259-267), closed-form backward."""
+
+    @staticmethod
+    def forward(ctx, p, y):
+        loss, gp = engine.bce_prob(p.detach().contiguous(), y.detach().contiguous().float())
+        ctx.save_for_backward(gp)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        (gp,) = ctx.saved_tensors
+        return gp * grad_loss, None
+
+
+def bce_loss(p, y):
+    return _BceProbFn.apply(p, y)
+
+
 class _NeumfFn(torch.autograd.Function):
     """NeuMF head, one hidden layer (models/general/NeuMF.py:61-75): rc_neumf_fwd / rc_neumf_bwd."""
 

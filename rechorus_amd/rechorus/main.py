@@ -27,7 +27,7 @@ for p in (HERE, ROOT):
 
 from utils import utils  # noqa: E402
 
-MODEL_PACKAGES = ('models.general', 'models.sequential')
+MODEL_PACKAGES = ('models.general', 'models.sequential', 'models.context')
 
 
 def parse_global_args(parser):

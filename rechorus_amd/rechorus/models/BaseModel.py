@@ -232,6 +232,8 @@ class CTRModel(GeneralModel):
     def loss(self, out_dict: dict) -> torch.Tensor:
         """BCE / MSE on (prediction, label), reference :262-274 (torch ops: not on the ranking path)"""
         if self.loss_n == 'BCE':
+            if out_dict['prediction'].is_cuda:  # one HIP kernel, closed-form backward
+                return hnn.bce_loss(out_dict['prediction'], out_dict['label'])
             return self.loss_fn(out_dict['prediction'], out_dict['label'].float())
         if self.loss_n == 'MSE':
             return ((out_dict['prediction'] - out_dict['label']) ** 2).mean()
@@ -241,3 +243,6 @@ class CTRModel(GeneralModel):
         def _get_feed_dict(self, index):
             return {'user_id': self.data['user_id'][index], 'item_id': [self.data['item_id'][index]],
                     'label': [self.data['label'][index]]}
+
+        def actions_before_epoch(self):  # labelled data: no negative sampling
+            pass

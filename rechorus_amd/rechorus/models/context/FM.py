@@ -1,0 +1,107 @@
+""" FM on the HIP engine
+Reference: 'Factorization Machines', Steffen Rendle, ICDM 2010.
+Mirror of the reference's models/context/FM.py (same class / arg / state_dict names):
+    python main.py --model_name FM --model_mode CTR --emb_size 64 --lr 5e-4 --l2 0 --dataset MIND_Large/MINDCTR \
+        --include_item_features 1 --include_situation_features 1 --metric AUC,ACC
+Every categorical field ('*_c', '*_id') owns two tables: context_embedding[f] [feature_max[f], d]
+and linear_embedding[f] [feature_max[f], 1]; their lookups (:49-55) are rc_gather_rows, their
+gradients the atomic-free sort + segmented sum.  The pairwise-interaction term (:61)
+    0.5 * sum_k ((sum_f v_fk)^2 - sum_f v_fk^2)
+is one kernel pair (rc_fm_second_order_fwd / _bwd) over the stacked field vectors.  Numeric
+fields keep the reference's Linear(1, d, bias=False).
+"""
+import torch
+import torch.nn as nn
+
+from models.BaseContextModel import ContextCTRModel, ContextModel
+from rechorus_amd import nn as hnn
+
+
+def is_categorical(feature_name):
+    return feature_name.endswith('_c') or feature_name.endswith('_id')
+
+
+class FMBase(object):
+    @staticmethod
+    def parse_model_args_FM(parser):
+        parser.add_argument('--emb_size', type=int, default=64, help='Size of embedding vectors.')
+        return parser
+
+    def _define_init_params(self, args, corpus):
+        self.vec_size = args.emb_size
+        self._define_params_FM()
+        self.apply(self.init_weights)
+
+    def _define_init(self, args, corpus):
+        self._define_init_params(args, corpus)
+        self._define_params_FM()
+        self.apply(self.init_weights)
+
+    def _define_params_FM(self):
+        self.context_embedding = nn.ModuleDict()
+        self.linear_embedding = nn.ModuleDict()
+        for f in self.context_features:
+            if is_categorical(f):
+                self.context_embedding[f] = hnn.HipEmbedding(self.feature_max[f], self.vec_size)
+                self.linear_embedding[f] = hnn.HipEmbedding(self.feature_max[f], 1)
+            else:
+                self.context_embedding[f] = nn.Linear(1, self.vec_size, bias=False)
+                self.linear_embedding[f] = nn.Linear(1, 1, bias=False)
+        self.overall_bias = torch.nn.Parameter(torch.tensor([0.01]), requires_grad=True)
+
+    def _lookup(self, tables, feed_dict, n_cand):
+        """per field: [B, C, w] (per-user / per-row fields broadcast over the C candidates)"""
+        out = []
+        for f in self.context_features:
+            x = feed_dict[f]
+            v = tables[f](x) if is_categorical(f) else tables[f](x.float().unsqueeze(-1))
+            out.append(v if v.dim() == 3 else v.unsqueeze(-2).expand(-1, n_cand, -1))
+        return out
+
+    def _get_embeddings_FM(self, feed_dict):
+        """-> field vectors [B, C, F, d], first-order term [B, C]"""
+        n_cand = feed_dict['item_id'].shape[1]
+        fm_vectors = torch.stack(self._lookup(self.context_embedding, feed_dict, n_cand), dim=-2)
+        linear_value = torch.cat(self._lookup(self.linear_embedding, feed_dict, n_cand), dim=-1)
+        return fm_vectors, self.overall_bias + linear_value.sum(dim=-1)
+
+    def forward(self, feed_dict):
+        fm_vectors, linear_value = self._get_embeddings_FM(feed_dict)
+        return {'prediction': linear_value + hnn.fm_second_order(fm_vectors)}
+
+
+class FMCTR(ContextCTRModel, FMBase):
+    reader, runner = 'ContextReader', 'CTRRunner'
+    extra_log_args = ['emb_size', 'loss_n']
+
+    @staticmethod
+    def parse_model_args(parser):
+        parser = FMBase.parse_model_args_FM(parser)
+        return ContextCTRModel.parse_model_args(parser)
+
+    def __init__(self, args, corpus):
+        ContextCTRModel.__init__(self, args, corpus)
+        self._define_init(args, corpus)
+
+    def forward(self, feed_dict):
+        out_dict = FMBase.forward(self, feed_dict)
+        out_dict['prediction'] = out_dict['prediction'].view(-1).sigmoid()
+        out_dict['label'] = feed_dict['label'].view(-1)
+        return out_dict
+
+
+class FMTopK(ContextModel, FMBase):
+    reader, runner = 'ContextReader', 'BaseRunner'
+    extra_log_args = ['emb_size', 'loss_n']
+
+    @staticmethod
+    def parse_model_args(parser):
+        parser = FMBase.parse_model_args_FM(parser)
+        return ContextModel.parse_model_args(parser)
+
+    def __init__(self, args, corpus):
+        ContextModel.__init__(self, args, corpus)
+        self._define_init(args, corpus)
+
+    def forward(self, feed_dict):
+        return FMBase.forward(self, feed_dict)

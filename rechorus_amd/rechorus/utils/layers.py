@@ -58,3 +58,63 @@ class TransformerLayer(nn.Module):
         ctx = self.layer_norm1(self.dropout1(ctx) + seq)
         out = self.linear2(self.linear1(ctx).relu())
         return self.layer_norm2(self.dropout2(out) + ctx)
+
+
+class Dice(nn.Module):
+    """DIN's data-adaptive activation: p = sigmoid(BN(x)), out = p*x + alpha*(1-p)*x (reference :246-288)"""
+
+    def __init__(self, emb_size, dim=2, epsilon=1e-8, device='cpu'):
+        super().__init__()
+        assert dim in (2, 3)
+        self.dim = dim
+        self.bn = nn.BatchNorm1d(emb_size, eps=epsilon)
+        self.alpha = nn.Parameter(torch.zeros((emb_size,) if dim == 2 else (emb_size, 1), device=device))
+
+    def forward(self, x):
+        assert x.dim() == self.dim
+        if self.dim == 3:
+            x = x.transpose(1, 2)
+        p = torch.sigmoid(self.bn(x))
+        out = p * x + self.alpha * (1 - p) * x
+        return out.transpose(1, 2) if self.dim == 3 else out
+
+
+class MLP_Block(nn.Module):
+    """Linear -> [norm] -> activation -> [norm] -> [dropout] per hidden layer, optional output
+    layer / activation (reference :201-243; parameters live in `self.mlp`, an nn.Sequential with
+    the same module order so state_dict keys `mlp.<k>.weight` interchange).  Dense GEMMs: rocBLAS."""
+
+    def __init__(self, input_dim, hidden_units=[], hidden_activations="ReLU", output_dim=None,
+                 output_activation=None, dropout_rates=0.0, batch_norm=False, layer_norm=False,
+                 norm_before_activation=True, use_bias=True):
+        super().__init__()
+        n = len(hidden_units)
+        rates = dropout_rates if isinstance(dropout_rates, list) else [dropout_rates] * n
+        acts = hidden_activations if isinstance(hidden_activations, list) else [hidden_activations] * n
+        widths = [input_dim] + list(hidden_units)
+
+        def norm(width):
+            if batch_norm:
+                return [nn.BatchNorm1d(width)]
+            return [nn.LayerNorm(width)] if layer_norm else []
+
+        mods = []
+        for k in range(n):
+            act = Dice(widths[k + 1]) if acts[k] == "Dice" else (getattr(nn, acts[k])() if acts[k] else None)
+            mods.append(nn.Linear(widths[k], widths[k + 1], bias=use_bias))
+            if norm_before_activation:
+                mods += norm(widths[k + 1])
+            if act is not None:
+                mods.append(act)
+            if not norm_before_activation:
+                mods += norm(widths[k + 1])
+            if rates[k] > 0:
+                mods.append(nn.Dropout(p=rates[k]))
+        if output_dim is not None:
+            mods.append(nn.Linear(widths[-1], output_dim, bias=use_bias))
+        if output_activation is not None:
+            mods.append(getattr(nn, output_activation)())
+        self.mlp = nn.Sequential(*mods)
+
+    def forward(self, inputs):
+        return self.mlp(inputs)

@@ -36,3 +36,51 @@ def make_dataset(root, name="synth", n_users=60, n_items=200, per_user=12, n_neg
             df["neg_items"] = negs
         df.to_csv(os.path.join(d, phase + ".csv"), sep="\t", index=False)
     return d
+
+
+def make_context_dataset(root, name="synth_ctx", n_users=80, n_items=120, per_user=16, ctr=True, n_neg=20, seed=0):
+    """Context-aware data in the reference's layout (data/README.md, MIND_Large/MINDCTR):
+    interactions carry situation columns c_*_c; item_meta.csv / user_meta.csv carry i_*_c / u_*_c.
+    ctr=True: every row has a binary `label` (clicks depend on user-group x item-category affinity);
+    ctr=False: top-k format (positives only, neg_items lists in dev/test)."""
+    rng = np.random.default_rng(seed)
+    n_cat, n_age = 6, 5
+    item_cat = rng.integers(0, n_cat, size=n_items + 1)
+    user_age = rng.integers(0, n_age, size=n_users + 1)
+    user_gender = rng.integers(0, 2, size=n_users + 1)
+    affinity = rng.normal(0, 1.5, size=(n_age, n_cat))
+    rows = {"train": [], "dev": [], "test": []}
+    clicked = {}
+    for u in range(1, n_users + 1):
+        times = np.sort(rng.integers(1_000_000, 2_000_000, size=per_user))
+        for k, t in enumerate(times):
+            i = int(rng.integers(1, n_items + 1))
+            hour, weekday = int(t // 3600 % 24), int(t // 86400 % 7)
+            logit = affinity[user_age[u], item_cat[i]] + 0.3 * (hour > 12)
+            label = int(rng.random() < 1.0 / (1.0 + np.exp(-logit)))
+            if not ctr:
+                # positives only: resample the item towards the user's preferred categories
+                best = np.argsort(-affinity[user_age[u]])[:2]
+                cand = np.nonzero(np.isin(item_cat[1:], best))[0] + 1
+                i = int(rng.choice(cand))
+            phase = "test" if k >= per_user - 2 else ("dev" if k >= per_user - 4 else "train")
+            rows[phase].append((u, i, int(t), label, hour, weekday))
+            clicked.setdefault(u, set()).add(i)
+    d = os.path.join(root, name)
+    os.makedirs(d, exist_ok=True)
+    for phase, r in rows.items():
+        df = pd.DataFrame(r, columns=["user_id", "item_id", "time", "label", "c_hour_c", "c_weekday_c"])
+        if not ctr:
+            df = df.drop(columns=["label"])
+            if phase != "train":
+                negs = []
+                for u in df["user_id"]:
+                    cand = np.setdiff1d(np.arange(1, n_items + 1), np.fromiter(clicked[u], dtype=int))
+                    negs.append(rng.choice(cand, size=min(n_neg, len(cand)), replace=False).tolist())
+                df["neg_items"] = negs
+        df.to_csv(os.path.join(d, phase + ".csv"), sep="\t", index=False)
+    pd.DataFrame({"item_id": np.arange(1, n_items + 1), "i_category_c": item_cat[1:]}).to_csv(
+        os.path.join(d, "item_meta.csv"), sep="\t", index=False)
+    pd.DataFrame({"user_id": np.arange(1, n_users + 1), "u_age_c": user_age[1:], "u_gender_c": user_gender[1:]}).to_csv(
+        os.path.join(d, "user_meta.csv"), sep="\t", index=False)
+    return d

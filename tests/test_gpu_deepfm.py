@@ -1,0 +1,217 @@
+"""GPU parity of the FM-family path: rc_fm_second_order_* and rc_bce_prob_fwd_bwd vs the numpy oracle,
+the narrow-row (d <= 4) segmented sum behind the [vocab, 1] first-order tables, and the mirror's
+FM / WideDeep / DeepFM model files vs the reference's own outputs (tests/golden/deepfm_*.npz)."""
+import argparse
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, assert_close, assert_update_close, load_golden
+from oracle import deepfm_oracle as DO
+from test_oracle_deepfm import CASES, batch, cancel_floor, params
+
+pytestmark = pytest.mark.gpu
+
+PLUGIN = os.path.join(ROOT, "rechorus_amd", "rechorus")
+if PLUGIN not in sys.path:
+    sys.path.insert(0, PLUGIN)
+
+
+@pytest.fixture(scope="module")
+def eng(cuda):
+    from rechorus_amd import engine
+    return engine
+
+
+@pytest.mark.parametrize("d", [16, 32, 64, 128])
+def test_fm_second_order_vs_oracle(d, cuda, eng):
+    rng = np.random.default_rng(d)
+    for shape, F in (((1,), 1), ((63,), 2), ((33, 5), 7), ((1000,), 39), ((7, 100), 3)):
+        V = rng.normal(0, 0.5, size=shape + (F, d)).astype(np.float32)
+        gout = rng.normal(size=shape).astype(np.float32)
+        Vd = torch.from_numpy(V).to(cuda)
+        out = eng.fm_second_order(Vd)
+        assert out.shape == shape
+        # cancellation: 0.5((sum v)^2 - sum v^2) is a difference of two O(F d) sums
+        floor = 4e-7 * float((V.astype(np.float64) ** 2).sum(axis=(-1, -2)).max())
+        assert_close(out.cpu().numpy(), DO.fm_second_order(V), what=f"fm2 F={F}", abs_floor=floor)
+        dV = eng.fm_second_order_bwd(Vd, torch.from_numpy(gout).to(cuda))
+        assert_close(dV.cpu().numpy(), DO.fm_second_order_bwd(V, gout), what=f"dV F={F}", atol_scale=1e-6)
+    empty = eng.fm_second_order(torch.empty((0, 3, d), device=cuda))
+    assert empty.shape == (0,)
+
+
+def test_fm_second_order_autograd_and_unsupported_width(cuda):
+    from rechorus_amd import nn as hnn
+    rng = np.random.default_rng(1)
+    for d in (64, 24):  # 24: device-side torch expression (no kernel for that width)
+        V = torch.from_numpy(rng.normal(size=(9, 4, 5, d)).astype(np.float32)).to(cuda).requires_grad_(True)
+        w = torch.from_numpy(rng.normal(size=(9, 4)).astype(np.float32)).to(cuda)
+        (hnn.fm_second_order(V) * w).sum().backward()
+        want = DO.fm_second_order_bwd(V.detach().cpu().numpy(), w.cpu().numpy())
+        assert_close(V.grad.cpu().numpy(), want, what=f"autograd d={d}", atol_scale=2e-6)
+
+
+def test_bce_vs_oracle_and_torch_clamps(cuda, eng):
+    rng = np.random.default_rng(2)
+    for n in (1, 77, 4096, 100003):
+        p = (1.0 / (1.0 + np.exp(-rng.normal(0, 3, size=n)))).astype(np.float32)
+        y = rng.integers(0, 2, size=n).astype(np.float32)
+        loss, gp = eng.bce_prob(torch.from_numpy(p).to(cuda), torch.from_numpy(y).to(cuda))
+        assert_close(loss.cpu().numpy()[0], DO.bce(p, y), what=f"bce n={n}", rtol=2e-5)
+        assert_close(gp.cpu().numpy(), DO.bce_grad(p, y), what=f"dbce n={n}", rtol=2e-5)
+    # saturated probabilities: torch clamps log at -100 and p(1-p) at 1e-12
+    p = torch.tensor([0.0, 1.0, 1e-30, 1.0, 0.0, 1e-8], device=cuda)
+    y = torch.tensor([1.0, 0.0, 1.0, 1.0, 0.0, 0.0], device=cuda)
+    loss, gp = eng.bce_prob(p, y)
+    pt = p.detach().clone().requires_grad_(True)
+    want = torch.nn.functional.binary_cross_entropy(pt, y)
+    want.backward()
+    assert_close(loss.cpu().numpy()[0], want.item(), what="clamped loss")
+    assert_close(gp.cpu().numpy(), pt.grad.cpu().numpy(), what="clamped grad")
+    loss, none = eng.bce_prob(p, y, need_grad=False)
+    assert none is None and abs(loss.item() - want.item()) < 1e-4
+
+
+@pytest.mark.parametrize("d", [1, 2, 3, 4])
+def test_narrow_tables_with_hot_rows(d, cuda):
+    """[vocab, 1] first-order tables: a handful of rows, each hit thousands of times"""
+    from rechorus_amd.nn import HipEmbedding
+    rng = np.random.default_rng(d)
+    for n_rows, shape in ((3, (5000,)), (24, (4096, 1)), (7, (300, 11)), (1000, (50,))):
+        emb = HipEmbedding(n_rows, d).to(cuda)
+        ids = rng.integers(0, n_rows, size=shape).astype(np.int64)
+        ids.reshape(-1)[:3] = n_rows - 1
+        out = emb(torch.from_numpy(ids).to(cuda))
+        assert np.array_equal(out.detach().cpu().numpy(), emb.weight.detach().cpu().numpy()[ids])
+        coef = rng.normal(size=shape + (d,)).astype(np.float32)
+        (out * torch.from_numpy(coef).to(cuda)).sum().backward()
+        want = np.zeros((n_rows, d), dtype=np.float64)
+        np.add.at(want, ids.reshape(-1), coef.reshape(-1, d).astype(np.float64))
+        # thousands of signed terms per row: the floor is the round-off of that sum, not of the result
+        floor = 2e-7 * float(np.abs(coef).sum()) / n_rows
+        assert_close(emb.weight.grad.cpu().numpy(), want, what=f"narrow grad rows={n_rows}", abs_floor=floor)
+
+
+# ---- model files ---------------------------------------------------------------------------------------
+
+VOCAB = {"u_age_c": 7, "u_gender_c": 3, "i_category_c": 11, "c_hour_c": 24, "c_weekday_c": 7}
+
+
+def _build(case, g, cuda, loss_n=None):
+    import importlib
+    cls_name = {"deepfm_ctr": "DeepFMCTR", "deepfm_fm_ctr": "FMCTR", "deepfm_wd_ctr": "WideDeepCTR",
+                "deepfm_topk": "DeepFMTopK", "deepfm_fm_topk": "FMTopK"}[re.match(r"(.*?)_d\d+", case).group(1)]
+    module = cls_name.replace("CTR", "").replace("TopK", "")
+    cls = getattr(importlib.import_module("models.context." + module), cls_name)
+    n_users, n_items, d, B, C = (int(x) for x in g["meta"][:5])
+    layers = [int(x) for x in g["meta"][6:]]
+    ctr = cls_name.endswith("CTR")
+    args = argparse.Namespace(device=cuda, model_path="", buffer=1, num_neg=C - 1, dropout=0, test_all=0, emb_size=d,
+                              layers=str(layers), loss_n="BCE" if ctr else "BPR")
+    corpus = argparse.Namespace(n_users=n_users, n_items=n_items, user_feature_names=["u_age_c", "u_gender_c"],
+                                item_feature_names=["i_category_c"], situation_feature_names=["c_hour_c", "c_weekday_c"],
+                                feature_max=dict(VOCAB, user_id=n_users, item_id=n_items))
+    model = cls(args, corpus)
+    assert model.context_features == [str(f) for f in g["fields"]]
+    sd = {k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("P0/")}
+    assert set(sd) == set(model.state_dict()), "state_dict keys differ from the reference's"
+    model.load_state_dict(sd)
+    return model.to(cuda), B
+
+
+def _feed(g, n, B, cuda):
+    f = {k: torch.from_numpy(v).to(cuda) for k, v in batch(g, n).items()}
+    f.update(batch_size=B, phase="train")
+    return f
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_model_file_matches_reference(case, cuda):
+    g = load_golden(case)
+    model, B = _build(case, g, cuda)
+    out = model(_feed(g, 1, B, cuda))
+    out["prediction"].retain_grad()
+    assert_close(out["prediction"].detach().cpu().numpy(), g["pred"], what="prediction", rtol=2e-5)
+    loss = model.loss(out)
+    loss.backward()
+    assert_close(loss.item(), g["loss"], what="loss", rtol=2e-5)
+    assert_close(out["prediction"].grad.cpu().numpy(), g["gpred"], what="dloss/dprediction", rtol=2e-5)
+    b = batch(g, 1)
+    for name, p in model.named_parameters():
+        assert_close(p.grad.cpu().numpy(), g["G/" + name], what="grad " + name, rtol=2e-5, atol_scale=5e-5,
+                     abs_floor=cancel_floor(name, g, b))
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("tag,opt", [("SGD_l20.001", "SGD"), ("Adam_l20.0001", "Adam")])
+def test_two_fit_iterations_match_reference(case, tag, opt, cuda):
+    """model(batch) -> loss -> backward -> HipOptimizer.step twice, vs the reference's own fit()"""
+    from helpers.BaseRunner import BaseRunner
+    g = load_golden(case)
+    lr, l2 = (float(x) for x in g[tag + "_hyper"])
+    model, B = _build(case, g, cuda)
+    a = BaseRunner.parse_runner_args(argparse.ArgumentParser()).parse_args([])
+    a.train, a.log_file, a.optimizer, a.lr, a.l2, a.engine = 1, "/tmp/rechorus_amd_test/log.txt", opt, lr, l2, "dense"
+    model.optimizer = BaseRunner(a)._build_optimizer(model)
+    for step in (1, 2):
+        model.optimizer.zero_grad()
+        loss = model.loss(model(_feed(g, step, B, cuda)))
+        loss.backward()
+        model.optimizer.step()
+        assert_close(loss.item(), g[tag + "_losses"][step - 1], what=f"loss {step}", rtol=5e-5)
+    P0, want = params(g), params(g, tag + "/")
+    ex = 1e-3 * lr if opt == "Adam" else 0.0
+    for name, p in model.state_dict().items():
+        # Adam normalises analytically-zero gradients (see cancel_floor) to +-lr: not comparable
+        if opt == "Adam" and cancel_floor(name, g, batch(g, 1)) > 0:
+            assert np.abs(p.cpu().numpy() - P0[name]).max() <= 2.5 * lr
+            continue
+        assert_update_close(p.cpu().numpy(), P0[name], want[name], what=name, extra_atol=ex, outlier_atol=2 * lr)
+
+
+# ---- CLI ------------------------------------------------------------------------------------------------
+
+@pytest.fixture(scope="module")
+def ctx_root(tmp_path_factory):
+    from synth_data import make_context_dataset
+    root = str(tmp_path_factory.mktemp("ctxdata"))
+    make_context_dataset(root, "ctr", n_users=300, n_items=150, per_user=20, ctr=True, seed=3)
+    make_context_dataset(root, "topk", n_users=300, n_items=150, per_user=12, ctr=False, seed=4)
+    return root
+
+
+def test_cli_deepfm_ctr(ctx_root, tmp_path, cuda):
+    import main
+    log = str(tmp_path / "log" / "run.txt")
+    res = main.run(["--model_name", "DeepFM", "--model_mode", "CTR", "--emb_size", "16", "--layers", "[32]", "--lr", "5e-3",
+                    "--l2", "0", "--loss_n", "BCE", "--dataset", "ctr", "--path", ctx_root + "/", "--epoch", "8",
+                    "--batch_size", "256", "--num_workers", "0", "--regenerate", "1", "--metric", "AUC,ACC,LOG_LOSS",
+                    "--include_item_features", "1", "--include_user_features", "1", "--include_situation_features", "1",
+                    "--log_file", log, "--model_path", str(tmp_path / "model" / "m.pt"), "--save_final_results", "0"])
+    text = open(log).read()
+    losses = [float(x) for x in re.findall(r"Epoch \d+\s+loss=([0-9.]+)", text)]
+    assert len(losses) >= 2 and losses[-1] < losses[0], losses
+    before = float(re.search(r"Test Before Training: \(.*?AUC:([0-9.]+)", text).group(1))
+    after = float(re.search(r"AUC:([0-9.]+)", res["test"]).group(1))
+    assert after > 0.6 and after > before, (before, after)  # clicks follow user-age x item-category affinity
+
+
+def test_cli_fm_topk_with_context(ctx_root, tmp_path, cuda):
+    import main
+    log = str(tmp_path / "log" / "run.txt")
+    res = main.run(["--model_name", "FM", "--model_mode", "TopK", "--emb_size", "32", "--lr", "5e-3", "--l2", "0",
+                    "--dataset", "topk", "--path", ctx_root + "/", "--epoch", "6", "--num_neg", "2", "--batch_size", "256",
+                    "--num_workers", "0", "--regenerate", "1", "--topk", "5,10", "--include_item_features", "1",
+                    "--include_user_features", "1", "--log_file", log, "--model_path", str(tmp_path / "model" / "m.pt"),
+                    "--save_final_results", "0"])
+    text = open(log).read()
+    losses = [float(x) for x in re.findall(r"Epoch \d+\s+loss=([0-9.]+)", text)]
+    assert len(losses) >= 2 and losses[-1] < losses[0], losses
+    before = float(re.search(r"Test Before Training: \(HR@5:([0-9.]+)", text).group(1))
+    after = float(re.search(r"HR@5:([0-9.]+)", res["test"]).group(1))
+    assert after > before, (before, after)

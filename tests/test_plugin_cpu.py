@@ -112,3 +112,70 @@ def test_cli_flag_surface_matches_reference():
         assert getattr(a, k) == v, k
     assert BPRMF.reader == "BaseReader" and BPRMF.runner == "BaseRunner"
     assert BPRMF.extra_log_args == ["emb_size", "batch_size"]
+
+
+# ---- context-aware / CTR surface ------------------------------------------------------------------
+
+@pytest.fixture(scope="module")
+def ctx_corpus(tmp_path_factory):
+    from helpers.ContextReader import ContextReader
+    from synth_data import make_context_dataset
+    root = str(tmp_path_factory.mktemp("ctx"))
+    make_context_dataset(root, "synth_ctx", ctr=True)
+    args = argparse.Namespace(path=root + "/", dataset="synth_ctx", sep="\t", include_item_features=1,
+                              include_user_features=1, include_situation_features=1)
+    return ContextReader(args)
+
+
+def test_context_reader_collects_features(ctx_corpus):
+    c = ctx_corpus
+    assert c.item_feature_names == ["i_category_c"] and c.user_feature_names == ["u_age_c", "u_gender_c"]
+    assert c.situation_feature_names == ["c_hour_c", "c_weekday_c"]
+    assert c.feature_max["user_id"] == c.n_users and c.feature_max["item_id"] == c.n_items
+    assert c.feature_max["c_hour_c"] <= 24 and c.feature_max["c_weekday_c"] <= 7 and c.feature_max["u_gender_c"] == 2
+    assert set(c.item_features[5]) == {"i_category_c"} and set(c.user_features[3]) == {"u_age_c", "u_gender_c"}
+    assert "label" in c.all_df.columns
+
+
+def test_context_ctr_dataset_feed_and_flags(ctx_corpus):
+    from models.BaseContextModel import ContextCTRModel
+    from models.context.DeepFM import DeepFMCTR, DeepFMTopK
+    from models.context.FM import FMCTR
+    ds = ContextCTRModel.Dataset(argparse.Namespace(buffer=0), ctx_corpus, "train")
+    ds.actions_before_epoch()  # labelled data: nothing to sample
+    feeds = [ds[i] for i in range(9)]
+    b = ds.collate_batch(feeds)
+    assert b["item_id"].shape == (9, 1) and b["label"].shape == (9, 1) and b["i_category_c"].shape == (9, 1)
+    assert b["u_age_c"].shape == (9,) and b["c_hour_c"].shape == (9,)
+    row = ctx_corpus.data_df["train"].iloc[0]
+    assert feeds[0]["c_hour_c"] == ds.data["c_hour_c"][0]
+    assert feeds[0]["i_category_c"][0] == ctx_corpus.item_features[feeds[0]["item_id"][0]]["i_category_c"]
+    # flag surface / class wiring as in the reference
+    assert (DeepFMCTR.reader, DeepFMCTR.runner) == ("ContextReader", "CTRRunner")
+    assert (DeepFMTopK.reader, DeepFMTopK.runner) == ("ContextReader", "BaseRunner")
+    a = DeepFMCTR.parse_model_args(argparse.ArgumentParser()).parse_args([])
+    assert (a.emb_size, a.layers, a.loss_n) == (64, "[64]", "BPR")  # reference quirk: WideDeepCTR inherits 'BPR'
+    assert FMCTR.parse_model_args(argparse.ArgumentParser()).parse_args([]).loss_n == "BCE"
+
+
+def test_ctr_metrics():
+    from helpers.CTRRunner import CTRRunner
+    p = np.array([0.9, 0.2, 0.6, 0.4, 0.0, 1.0])
+    y = np.array([1, 0, 0, 1, 0, 1])
+    r = CTRRunner.evaluate_method(p, y, ["ACC", "AUC", "F1_SCORE", "LOG_LOSS"])
+    assert abs(r["ACC"] - 4 / 6) < 1e-12
+    assert abs(r["AUC"] - 8 / 9) < 1e-12  # 8 of the 9 (pos, neg) pairs ordered correctly
+    assert abs(r["F1_SCORE"] - 2 * (2 / 3) * (2 / 3) / (4 / 3)) < 1e-12
+    q = np.clip(p, 1e-7, 1 - 1e-7)
+    assert abs(r["LOG_LOSS"] + (np.log(q) * y + np.log(1 - q) * (1 - y)).mean()) < 1e-12
+    with pytest.raises(ValueError):
+        CTRRunner.evaluate_method(p, y, ["HR"])
+
+
+def test_mlp_block_layout_matches_reference_keys():
+    from utils.layers import MLP_Block
+    m = MLP_Block(12, [8, 4], hidden_activations="ReLU", dropout_rates=0.2, output_dim=1)
+    # Linear, ReLU, Dropout, Linear, ReLU, Dropout, Linear  -> the reference's state_dict indices
+    assert sorted(m.state_dict()) == ["mlp.0.bias", "mlp.0.weight", "mlp.3.bias", "mlp.3.weight", "mlp.6.bias", "mlp.6.weight"]
+    m = MLP_Block(12, [8], hidden_activations="Dice", batch_norm=True, output_dim=None)
+    assert "mlp.2.alpha" in m.state_dict() and "mlp.1.running_mean" in m.state_dict()
