@@ -268,6 +268,47 @@ int rc_neumf_bwd(const float* mf_u, const float* mf_i, const float* mlp_u, const
                  float* g_mf_u, float* g_mf_i, float* g_mlp_u, float* g_mlp_i, float* dW1,
                  float* db1, float* dw_out, void* ws, size_t ws_bytes, rc_stream_t stream);
 
+/* ---- training-batch assembly on the device (csrc/sampler.hip) -------------------------------- */
+
+/* GeneralModel.Dataset.actions_before_epoch (models/BaseModel.py:206-214): neg[i,k] ~ uniform over
+ * [1, n_items) minus the TRAIN clicked set of users[i] (rejection sampling).  The clicked sets are a CSR
+ * over user ids: clicked_items[clicked_ptr[u] .. clicked_ptr[u+1]) sorted ascending (both NULL: no
+ * rejection).  Counter-based Philox4x32-10: element e = i*K + k of this call uses the stream
+ * (seed, base_index + e), so results do not depend on launch geometry and calls with disjoint
+ * [base_index, base_index + n*K) ranges are independent.                                            */
+int rc_sample_negatives(const int64_t* users, int64_t n, int K, int64_t n_items, const int64_t* clicked_ptr,
+                        const int64_t* clicked_items, uint64_t seed, uint64_t base_index, int64_t* neg,
+                        rc_stream_t stream);
+
+/* One shuffled batch of GeneralModel.Dataset rows (models/BaseModel.py:192-203 + collate_batch :135-152):
+ * users_out[b] = users[idx[b]]; cand_out[b,0] = items[idx[b]], cand_out[b,1+k] = neg[idx[b],k].       */
+int rc_assemble_candidates(const int64_t* idx, int64_t B, int K, const int64_t* users, const int64_t* items,
+                           const int64_t* neg, int64_t* users_out, int64_t* cand_out, rc_stream_t stream);
+
+/* SequentialModel.Dataset._get_feed_dict (models/BaseModel.py:236-245): for row i = idx[b] (idx NULL:
+ * i = b) with user u = users[i] and history position p = position[i], len = min(p, L):
+ * hist[b, t] = his_items[his_ptr[u] + p - len + t] for t < len, 0 beyond (right padding, as
+ * pad_sequence in collate_batch); times (optional) likewise from his_times; lengths[b] = len.          */
+int rc_gather_history(const int64_t* idx, int64_t B, int L, const int64_t* users, const int64_t* position,
+                      const int64_t* his_ptr, const int64_t* his_items, const int64_t* his_times, int64_t* hist,
+                      int64_t* times, int64_t* lengths, rc_stream_t stream);
+
+/* ---- evaluation (csrc/eval_rank.hip) ------------------------------------------------------------- */
+
+/* BaseRunner.evaluate_method (helpers/BaseRunner.py:62-63): rank[i] = #{c : pred[i,c] >= pred[i,0]}
+ * (ground truth in column 0, ties count against it).  HR@k / NDCG@k are means over rank.             */
+int rc_target_rank(const float* pred, int64_t n, int C, int32_t* rank, rc_stream_t stream);
+
+/* --test_all (models/BaseModel.py:194-195, helpers/BaseRunner.py:243-250) for dot-product heads
+ * (BPRMF: Uvec = gathered user rows; SASRec: the encoder outputs) without materialising [N, n_items]:
+ * rank[i] = 1 + #{j in [1,n_items), j != targets[i], j not in clicked(users[i]) : <Uvec[i], I[j]> >= <Uvec[i], I[targets[i]]>}
+ * clicked = CSR over user ids, sorted (train + residual clicked sets; NULL = no masking).  fp32 MFMA
+ * over the catalogue; target_score [N] is an output (scratch).  d in {32, 64, 128}.                   */
+int rc_full_catalogue_rank_supported(int d);
+int rc_full_catalogue_rank(const float* Uvec, const float* I, const int64_t* users, const int64_t* targets, int64_t N,
+                           int64_t n_items, int d, const int64_t* clicked_ptr, const int64_t* clicked_items,
+                           float* target_score, int32_t* rank, rc_stream_t stream);
+
 size_t rc_bprmf_step_workspace_bytes(int B, int C, int d);
 
 /* One BaseRunner.fit iteration for BPRMF (helpers/BaseRunner.py:193-206 with

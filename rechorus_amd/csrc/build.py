@@ -32,6 +32,8 @@ SOURCES = [
     "sasrec.hip",
     "listwise_loss.hip",
     "fm_bce.hip",
+    "sampler.hip",
+    "eval_rank.hip",
 ]
 HEADERS = ["common.hpp", "bpr_math.hpp", "opt_math.hpp", os.path.join("..", "..", "include", "rechorus_hip.h")]
 

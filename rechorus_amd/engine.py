@@ -551,3 +551,88 @@ def bce_prob(p, y, need_grad=True):
     _lib.call("rc_bce_prob_fwd_bwd", _ptr(p, f32, "p"), _ptr(y, f32, "y"), n, 1.0 / n, _ptr(loss_vec, f32, "loss_vec"),
               _ptr(gp, f32, "gp", True), _stream())
     return reduce_sum(loss_vec, 1.0 / n), gp
+
+
+# ---- batch assembly on the device (csrc/sampler.hip) -------------------------------------------------------
+
+def sample_negatives(users, K, n_items, clicked_ptr=None, clicked_items=None, seed=0, base_index=0, out=None):
+    """neg [n, K] int64: uniform over [1, n_items) minus the user's clicked set (models/BaseModel.py:206-214)"""
+    n = users.numel()
+    i64 = torch.int64
+    neg = out if out is not None else torch.empty((n, K), dtype=i64, device=users.device)
+    _lib.call("rc_sample_negatives", _ptr(users, i64, "users"), n, int(K), int(n_items),
+              _ptr(clicked_ptr, i64, "clicked_ptr", True), _ptr(clicked_items, i64, "clicked_items", True),
+              C.c_uint64(int(seed) & (2**64 - 1)), C.c_uint64(int(base_index)), _ptr(neg, i64, "neg"), _stream())
+    return neg
+
+
+def assemble_candidates(idx, users, items, neg):
+    """(user_id [B], item_id [B, 1+K]) for the rows idx of a training set (models/BaseModel.py:192-203)"""
+    B = idx.numel()
+    K = 0 if neg is None else neg.shape[1]
+    i64 = torch.int64
+    u = torch.empty(B, dtype=i64, device=idx.device)
+    cand = torch.empty((B, 1 + K), dtype=i64, device=idx.device)
+    _lib.call("rc_assemble_candidates", _ptr(idx, i64, "idx"), B, K, _ptr(users, i64, "users"), _ptr(items, i64, "items"),
+              _ptr(neg, i64, "neg", True), _ptr(u, i64, "users_out"), _ptr(cand, i64, "cand_out"), _stream())
+    return u, cand
+
+
+def gather_history(idx, users, position, his_ptr, his_items, L, his_times=None):
+    """-> (history_items [B, L] right-padded with 0, history_times | None, lengths [B])  (models/BaseModel.py:236-245)"""
+    B = idx.numel() if idx is not None else users.numel()
+    i64 = torch.int64
+    dev = users.device
+    hist = torch.empty((B, L), dtype=i64, device=dev)
+    times = torch.empty((B, L), dtype=i64, device=dev) if his_times is not None else None
+    lengths = torch.empty(B, dtype=i64, device=dev)
+    _lib.call("rc_gather_history", _ptr(idx, i64, "idx", True), B, int(L), _ptr(users, i64, "users"),
+              _ptr(position, i64, "position"), _ptr(his_ptr, i64, "his_ptr"), _ptr(his_items, i64, "his_items"),
+              _ptr(his_times, i64, "his_times", True), _ptr(hist, i64, "hist"), _ptr(times, i64, "times", True),
+              _ptr(lengths, i64, "lengths"), _stream())
+    return hist, times, lengths
+
+
+# ---- evaluation (csrc/eval_rank.hip) ---------------------------------------------------------------------------
+
+def target_rank(pred):
+    """rank of column 0 among the row's candidates, ties against it (helpers/BaseRunner.py:62-63) -> int32 [n]"""
+    n, Cn = pred.shape
+    rank = torch.empty(n, dtype=torch.int32, device=pred.device)
+    _lib.call("rc_target_rank", _ptr(pred, torch.float32, "pred"), n, Cn, _ptr(rank, torch.int32, "rank"), _stream())
+    return rank
+
+
+def full_catalogue_rank_supported(d):
+    return bool(_lib.load().rc_full_catalogue_rank_supported(int(d)))
+
+
+def full_catalogue_rank(Uvec, I, users, targets, clicked_ptr=None, clicked_items=None):
+    """--test_all rank of the target among ALL items, clicked items masked -> (rank int32 [N], target_score [N])"""
+    N, d = Uvec.shape
+    i64, f32 = torch.int64, torch.float32
+    rank = torch.empty(N, dtype=torch.int32, device=Uvec.device)
+    tscore = torch.empty(N, dtype=f32, device=Uvec.device)
+    _lib.call("rc_full_catalogue_rank", _ptr(Uvec, f32, "Uvec"), _ptr(I, f32, "I"), _ptr(users, i64, "users", True),
+              _ptr(targets, i64, "targets"), N, I.shape[0], d, _ptr(clicked_ptr, i64, "clicked_ptr", True),
+              _ptr(clicked_items, i64, "clicked_items", True), _ptr(tscore, f32, "target_score"),
+              _ptr(rank, torch.int32, "rank"), _stream())
+    return rank, tscore
+
+
+def rank_metrics(rank, topk, metrics):
+    """HR@k / NDCG@k from gt ranks (helpers/BaseRunner.py:64-76); a few scalar reductions, one D2H copy"""
+    rank = rank.to(torch.float64)
+    keys, vals = [], []
+    for k in topk:
+        hit = (rank <= k).to(torch.float64)
+        for metric in metrics:
+            if metric == "HR":
+                vals.append(hit.mean())
+            elif metric == "NDCG":
+                vals.append((hit / torch.log2(rank + 1)).mean())
+            else:
+                raise ValueError("Undefined evaluation metric: {}.".format(metric))
+            keys.append("{}@{}".format(metric, k))
+    out = torch.stack(vals).cpu().numpy() if vals else []
+    return {k: float(v) for k, v in zip(keys, out)}
