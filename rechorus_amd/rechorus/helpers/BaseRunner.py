@@ -7,7 +7,13 @@ What changed underneath `fit` (reference :174-208):
     row-wise update (--engine rowwise; 'auto' picks it for tables above 2^20 rows);
   * the per-batch loss stays on the GPU; one D2H copy per epoch instead of one sync per step;
   * the candidate-column shuffle (:187-202) is skipped for models that declare
-    `candidate_permutation_equivariant` (a dot/MLP head scores each candidate independently).
+    `candidate_permutation_equivariant` (a dot/MLP head scores each candidate independently);
+  * standard General / Sequential datasets never touch the host after start-up (--device_pipeline,
+    rechorus_amd/pipeline.py): negatives are sampled by rc_sample_negatives once per epoch, batches
+    are assembled by rc_assemble_candidates / rc_gather_history; custom datasets keep the DataLoader.
+And underneath `evaluate` (:217-252): predictions stay on the GPU, the rank of the ground truth is
+rc_target_rank, and `--test_all` on dot-product heads is rc_full_catalogue_rank (fp32 MFMA over the
+catalogue, the [N, n_items] matrix never exists); `predict` still returns the reference's ndarray.
 """
 import gc
 import logging
@@ -20,7 +26,7 @@ import torch
 from torch.utils.data import DataLoader
 
 from models.BaseModel import BaseModel
-from rechorus_amd import nn as hnn
+from rechorus_amd import engine, nn as hnn, pipeline
 from utils import utils
 
 
@@ -44,6 +50,8 @@ class BaseRunner(object):
         # additive, engine-specific
         parser.add_argument('--engine', type=str, default='auto',
                             help='dense: exact reference optimizer semantics; rowwise: fused step, update touched rows only; auto')
+        parser.add_argument('--device_pipeline', type=int, default=1,
+                            help='1: sample negatives / assemble batches on the GPU for standard datasets; 0: DataLoader')
         return parser
 
     @staticmethod
@@ -73,6 +81,7 @@ class BaseRunner(object):
         self.optimizer_name = args.optimizer
         self.num_workers, self.pin_memory = args.num_workers, args.pin_memory
         self.engine = getattr(args, 'engine', 'auto')
+        self.device_pipeline = bool(getattr(args, 'device_pipeline', 1))
         self.topk = [int(x) for x in args.topk.split(',')]
         self.metrics = [m.strip().upper() for m in args.metric.split(',')]
         self.main_metric = args.main_metric if len(args.main_metric) else '{}@{}'.format(self.metrics[0], self.topk[0])
@@ -154,20 +163,37 @@ class BaseRunner(object):
             best + 1, utils.format_metric(dev_results[best]), self.time[1] - self.time[0]))
         model.load_model()
 
+    def _on_device(self, dataset) -> bool:
+        return (self.device_pipeline and torch.device(dataset.model.device).type == 'cuda'
+                and pipeline.eligible(dataset))
+
+    def _batches(self, dataset, batch_size, train):
+        """feed dicts on the model's device: assembled there when the dataset is a standard one,
+        else DataLoader -> collate_batch -> batch_to_gpu exactly like the reference (:182-186)"""
+        model = dataset.model
+        if self._on_device(dataset):
+            dd = pipeline.device_dataset(dataset, torch.device(model.device))
+            if train:
+                dd.sample_negatives(seed=int(np.random.randint(0, 2 ** 31 - 1)))  # follows --random_seed
+            yield from dd.batches(batch_size, shuffle=train)
+            return
+        if train:
+            dataset.actions_before_epoch()  # negative sampling happens before workers fork
+        dl = DataLoader(dataset, batch_size=batch_size, shuffle=train, num_workers=self.num_workers,
+                        collate_fn=dataset.collate_batch, pin_memory=self.pin_memory)
+        for batch in dl:
+            yield utils.batch_to_gpu(batch, model.device)
+
     def fit(self, dataset: BaseModel.Dataset, epoch=-1) -> float:
         model = dataset.model
         rowwise = self._use_rowwise(model)
         if model.optimizer is None and not rowwise:
             model.optimizer = self._build_optimizer(model)
-        dataset.actions_before_epoch()  # negative sampling happens before workers fork
 
         model.train()
         losses = list()
-        dl = DataLoader(dataset, batch_size=self.batch_size, shuffle=True, num_workers=self.num_workers,
-                        collate_fn=dataset.collate_batch, pin_memory=self.pin_memory)
         equivariant = getattr(model, 'candidate_permutation_equivariant', False)
-        for batch in dl:
-            batch = utils.batch_to_gpu(batch, model.device)
+        for batch in self._batches(dataset, self.batch_size, train=True):
             if rowwise:
                 losses.append(model.hip_train_step(batch, self.optimizer_name, self.learning_rate, self.l2).clone())
                 continue
@@ -197,29 +223,70 @@ class BaseRunner(object):
         return len(criterion) - criterion.index(max(criterion)) > self.early_stop
 
     def evaluate(self, dataset: BaseModel.Dataset, topks: list, metrics: list) -> Dict[str, float]:
-        return self.evaluate_method(self.predict(dataset), topks, metrics)
+        """same numbers as evaluate_method(predict(dataset)), computed where the scores are"""
+        model = dataset.model
+        if torch.device(model.device).type != 'cuda':
+            return self.evaluate_method(self.predict(dataset), topks, metrics)
+        if model.test_all and hasattr(model, 'full_catalogue_vectors'):
+            rank = self._full_catalogue_ranks(dataset)
+            if rank is not None:
+                return engine.rank_metrics(rank, topks, metrics)
+        pred = self._predict_device(dataset)
+        if model.test_all:
+            rows, cols = self._clicked_cells(dataset, pred.device)
+            pred[rows, cols] = -float('inf')
+        return engine.rank_metrics(engine.target_rank(pred.contiguous()), topks, metrics)
 
-    def predict(self, dataset: BaseModel.Dataset, save_prediction: bool = False) -> np.ndarray:
-        """[n_instances, n_candidates] scores, ground truth in column 0 (reference :225-252)"""
+    def _predict_device(self, dataset) -> torch.Tensor:
+        """[n_instances, n_candidates] scores on the GPU, ground truth in column 0"""
         model = dataset.model
         model.eval()
         chunks = list()
-        dl = DataLoader(dataset, batch_size=self.eval_batch_size, shuffle=False, num_workers=self.num_workers,
-                        collate_fn=dataset.collate_batch, pin_memory=self.pin_memory)
         with torch.no_grad():
-            for batch in dl:
-                batch = utils.batch_to_gpu(batch, model.device)
+            for batch in self._batches(dataset, self.eval_batch_size, train=False):
                 out = model.inference(batch) if hasattr(model, 'inference') else model(batch)
                 chunks.append(out['prediction'])
-        predictions = torch.cat(chunks).cpu().numpy()  # one D2H copy
+        return torch.cat(chunks)
 
-        if model.test_all:  # mask items the user already interacted with
-            rows, cols = list(), list()
-            for i, u in enumerate(dataset.data['user_id']):
-                seen = list(dataset.corpus.train_clicked_set[u] | dataset.corpus.residual_clicked_set[u])
-                rows.extend([i] * len(seen))
-                cols.extend(seen)
-            predictions[rows, cols] = -np.inf
+    @staticmethod
+    def _clicked_cells(dataset, device):
+        """(row, column) of every item a user already interacted with (reference :243-250)"""
+        rows, cols = list(), list()
+        for i, u in enumerate(dataset.data['user_id']):
+            seen = list(dataset.corpus.train_clicked_set[u] | dataset.corpus.residual_clicked_set[u])
+            rows.extend([i] * len(seen))
+            cols.extend(seen)
+        return torch.tensor(rows, dtype=torch.long, device=device), torch.tensor(cols, dtype=torch.long, device=device)
+
+    def _full_catalogue_ranks(self, dataset):
+        """--test_all for dot-product heads: the model hands over its query vectors and item table
+        (`full_catalogue_vectors`), rc_full_catalogue_rank streams the catalogue through MFMA tiles"""
+        model = dataset.model
+        if not self._on_device(dataset):
+            return None
+        dev = torch.device(model.device)
+        dd = pipeline.device_dataset(dataset, dev)
+        ptr, flat = pipeline.clicked_csr(dataset.corpus, dev, 'all')
+        model.eval()
+        ranks = list()
+        with torch.no_grad():
+            n = len(dd)
+            for s in range(0, n, self.eval_batch_size):
+                idx = torch.arange(s, min(n, s + self.eval_batch_size), device=dev)
+                feed = dd.feed_without_candidates(idx)
+                vec, table = model.full_catalogue_vectors(feed)
+                if not engine.full_catalogue_rank_supported(vec.shape[1]):
+                    return None
+                rank, _ = engine.full_catalogue_rank(vec.contiguous(), table, feed['user_id'], dd.items[idx].contiguous(), ptr, flat)
+                ranks.append(rank)
+        return torch.cat(ranks)
+
+    def predict(self, dataset: BaseModel.Dataset, save_prediction: bool = False) -> np.ndarray:
+        """[n_instances, n_candidates] scores, ground truth in column 0 (reference :225-252)"""
+        predictions = self._predict_device(dataset).cpu().numpy()  # one D2H copy
+        if dataset.model.test_all:  # mask items the user already interacted with
+            rows, cols = self._clicked_cells(dataset, 'cpu')
+            predictions[rows.numpy(), cols.numpy()] = -np.inf
         return predictions
 
     def print_res(self, dataset: BaseModel.Dataset) -> str:

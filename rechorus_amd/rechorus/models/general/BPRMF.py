@@ -53,6 +53,10 @@ class BPRMF(GeneralModel, BPRMFBase):
     def forward(self, feed_dict):
         return BPRMFBase.forward(self, feed_dict)
 
+    def full_catalogue_vectors(self, feed_dict):
+        """(query vectors [B, d], item table) of the dot-product head, for --test_all ranking"""
+        return engine.gather_rows(self.u_embeddings.weight.detach(), feed_dict['user_id']), self.i_embeddings.weight.detach()
+
     # ---- large-table mode: the whole fit() iteration as one C-ABI call ---------------------
     def hip_train_step(self, feed_dict, opt_name, lr, l2):
         """forward + BPR loss + backward + row-wise optimizer update (rc_bprmf_train_step);

@@ -50,19 +50,25 @@ class SASRecBase(object):
         his = his * valid[:, :, None].float()
         return his[torch.arange(batch_size, device=history.device), lengths - 1, :]
 
+    def _encode(self, feed_dict):
+        history = feed_dict['history_items']    # [batch_size, <= history_max], right padded with 0
+        lengths = feed_dict['lengths']          # [batch_size]
+        fused = engine.sasrec_supported(self.emb_size, self.num_layers, self.num_heads, history.shape[1]) and \
+            (self.dropout == 0 or not self.training)
+        if fused:
+            return hnn.sasrec_encode(self.i_embeddings.weight, self.p_embeddings.weight,
+                                     self.transformer_block, self.num_heads, history, lengths)
+        return self._encode_torch(history, lengths)
+
+    def full_catalogue_vectors(self, feed_dict):
+        """(sequence vectors [B, d], item table) of the dot-product head, for --test_all ranking"""
+        return self._encode(feed_dict).detach(), self.i_embeddings.weight.detach()
+
     def forward(self, feed_dict):
         self.check_list = []
         i_ids = feed_dict['item_id']            # [batch_size, n_candidates]
-        history = feed_dict['history_items']    # [batch_size, <= history_max], right padded with 0
-        lengths = feed_dict['lengths']          # [batch_size]
-        batch_size, seq_len = history.shape
-        fused = engine.sasrec_supported(self.emb_size, self.num_layers, self.num_heads, seq_len) and \
-            (self.dropout == 0 or not self.training)
-        if fused:
-            his_vector = hnn.sasrec_encode(self.i_embeddings.weight, self.p_embeddings.weight,
-                                           self.transformer_block, self.num_heads, history, lengths)
-        else:
-            his_vector = self._encode_torch(history, lengths)
+        batch_size = i_ids.shape[0]
+        his_vector = self._encode(feed_dict)
         rows = torch.arange(batch_size, device=i_ids.device)
         prediction = hnn.bprmf_scores(his_vector, self.i_embeddings.weight, rows, i_ids)
         return {'prediction': prediction.view(batch_size, -1)}

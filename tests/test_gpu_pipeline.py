@@ -1,0 +1,150 @@
+"""GPU: the device-resident data pipeline (rechorus_amd/pipeline.py) against the mirror's own CPU
+Dataset / collate path (which restates the reference's), and the on-device evaluation against
+evaluate_method(predict())."""
+import argparse
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+from synth_data import make_dataset
+
+pytestmark = pytest.mark.gpu
+
+PLUGIN = os.path.join(ROOT, "rechorus_amd", "rechorus")
+if PLUGIN not in sys.path:
+    sys.path.insert(0, PLUGIN)
+
+
+@pytest.fixture(scope="module")
+def data_root(tmp_path_factory):
+    root = str(tmp_path_factory.mktemp("pipe"))
+    make_dataset(root, "synth", n_users=150, n_items=260, per_user=13, n_neg=99, seed=5)
+    return root
+
+
+def _setup(data_root, cuda, model_name, extra=(), test_all=0, device_pipeline=1):
+    import importlib
+    import main
+    from helpers.BaseRunner import BaseRunner
+    model_cls = main.find_class("model", (model_name, ""))
+    reader_cls = main.find_class("helper", model_cls.reader)
+    p = main.parse_global_args(argparse.ArgumentParser())
+    p = reader_cls.parse_data_args(p)
+    p = BaseRunner.parse_runner_args(p)
+    p = model_cls.parse_model_args(p)
+    args = p.parse_args(["--path", data_root + "/", "--dataset", "synth", "--num_neg", "6", "--emb_size", "32",
+                         "--test_all", str(test_all), "--device_pipeline", str(device_pipeline), "--num_workers", "0",
+                         "--topk", "5,10,50", "--eval_batch_size", "64"] + list(extra))
+    args.device, args.model_path, args.log_file, args.train = cuda, "/tmp/rechorus_amd_test/m.pt", "/tmp/rechorus_amd_test/l.txt", 1
+    corpus = reader_cls(args)
+    torch.manual_seed(0)
+    model = model_cls(args, corpus).to(cuda)
+    with torch.no_grad():
+        for prm in model.parameters():
+            prm.mul_(15.0)
+    data = {ph: model_cls.Dataset(model, corpus, ph) for ph in ("train", "dev", "test")}
+    for d in data.values():
+        d.prepare()
+    return args, corpus, model, data, BaseRunner(args)
+
+
+@pytest.mark.parametrize("model_name,extra", [("BPRMF", []), ("SASRec", ["--history_max", "8", "--num_heads", "2"])])
+def test_device_batches_equal_the_collated_ones(model_name, extra, data_root, cuda):
+    from rechorus_amd import pipeline
+    args, corpus, model, data, runner = _setup(data_root, cuda, model_name, extra)
+    for phase in ("dev", "test"):
+        ds = data[phase]
+        assert pipeline.eligible(ds)
+        dd = pipeline.device_dataset(ds, cuda)
+        idx = torch.arange(len(ds), device=cuda)
+        feed = dd.feed(idx)
+        want = ds.collate_batch([ds[i] for i in range(len(ds))])
+        assert feed["batch_size"] == want["batch_size"] and feed["phase"] == phase
+        assert torch.equal(feed["user_id"].cpu(), want["user_id"]) and torch.equal(feed["item_id"].cpu(), want["item_id"])
+        if model_name == "SASRec":
+            w = want["history_items"].shape[1]  # the reference pads to the batch maximum, the device to history_max
+            assert torch.equal(feed["lengths"].cpu(), want["lengths"])
+            assert torch.equal(feed["history_items"][:, :w].cpu(), want["history_items"]) and not feed["history_items"][:, w:].any()
+            assert torch.equal(feed["history_times"][:, :w].cpu(), want["history_times"])
+    # training epoch: every row once, fresh negatives never in the user's train clicked set
+    tr = data["train"]
+    np.random.seed(3)
+    seen_rows, all_neg = [], []
+    for batch in runner._batches(tr, 64, train=True):
+        assert batch["item_id"].shape[1] == 7 and batch["user_id"].is_cuda
+        seen_rows.append(torch.stack([batch["user_id"], batch["item_id"][:, 0]], dim=1).cpu())
+        all_neg.append((batch["user_id"].cpu(), batch["item_id"][:, 1:].cpu()))
+    got = torch.cat(seen_rows).numpy()
+    want = np.stack([np.asarray(tr.data["user_id"], dtype=np.int64), np.asarray(tr.data["item_id"], dtype=np.int64)], axis=1)
+    assert sorted(map(tuple, got)) == sorted(map(tuple, want))
+    assert not np.array_equal(got, want)  # shuffled
+    for users, negs in all_neg:
+        assert negs.min() >= 1 and negs.max() < corpus.n_items
+        for u, row in zip(users.tolist(), negs.tolist()):
+            assert not (set(row) & corpus.train_clicked_set[u])
+    first = torch.cat([n for _, n in all_neg])
+    second = torch.cat([b["item_id"][:, 1:].cpu() for b in runner._batches(tr, 64, train=True)])
+    assert not torch.equal(first, second)  # a new epoch draws new negatives
+
+
+@pytest.mark.parametrize("model_name,extra", [("BPRMF", []), ("NeuMF", ["--layers", "[32]"]),
+                                              ("SASRec", ["--history_max", "8", "--num_heads", "2"])])
+def test_device_evaluate_equals_evaluate_method_of_predict(model_name, extra, data_root, cuda):
+    args, corpus, model, data, runner = _setup(data_root, cuda, model_name, extra)
+    for phase in ("dev", "test"):
+        pred = runner.predict(data[phase])
+        assert pred.shape == (len(data[phase]), 100)
+        want = runner.evaluate_method(pred, runner.topk, runner.metrics)
+        got = runner.evaluate(data[phase], runner.topk, runner.metrics)
+        assert got.keys() == want.keys() and all(abs(got[k] - want[k]) < 1e-9 for k in got), (got, want)
+    # the DataLoader path (what custom datasets use) produces the same predictions
+    args0, corpus0, model0, data0, runner0 = _setup(data_root, cuda, model_name, extra, device_pipeline=0)
+    model0.load_state_dict(model.state_dict())
+    assert np.allclose(runner0.predict(data0["test"]), runner.predict(data["test"]), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("model_name,extra", [("BPRMF", []), ("SASRec", ["--history_max", "8", "--num_heads", "2"])])
+def test_test_all_full_catalogue_rank_matches_materialised_path(model_name, extra, data_root, cuda):
+    """--test_all: rc_full_catalogue_rank (no [N, n_items] matrix) vs masking the full score matrix"""
+    args, corpus, model, data, runner = _setup(data_root, cuda, model_name, extra, test_all=1)
+    ds = data["test"]
+    assert hasattr(model, "full_catalogue_vectors")
+    fast = runner.evaluate(ds, runner.topk, runner.metrics)
+    pred = runner.predict(ds)  # reference semantics: [N, n_items], clicked columns -inf
+    assert pred.shape == (len(ds), corpus.n_items) and np.isinf(pred).any()
+    slow = runner.evaluate_method(pred, runner.topk, runner.metrics)
+    # fp32 summation order differs between the MFMA kernel and the gather-dot kernel: exact ties aside
+    rank_fast = runner._full_catalogue_ranks(ds).cpu().numpy()
+    rank_slow = (pred >= pred[:, :1]).sum(axis=-1)
+    assert (rank_fast == rank_slow).mean() > 0.97 and np.abs(rank_fast - rank_slow).max() <= 2
+    for k in fast:
+        assert abs(fast[k] - slow[k]) < 0.02, (k, fast[k], slow[k])
+
+
+def test_cli_dataloader_path_still_trains(data_root, tmp_path, cuda):
+    import main
+    log = str(tmp_path / "log" / "run.txt")
+    res = main.run(["--model_name", "BPRMF", "--emb_size", "32", "--lr", "5e-3", "--l2", "0", "--dataset", "synth",
+                    "--path", data_root + "/", "--epoch", "4", "--num_neg", "4", "--batch_size", "128", "--num_workers", "0",
+                    "--device_pipeline", "0", "--regenerate", "1", "--log_file", log, "--topk", "5,10",
+                    "--model_path", str(tmp_path / "model" / "m.pt"), "--save_final_results", "0"])
+    losses = [float(x) for x in re.findall(r"Epoch \d+\s+loss=([0-9.]+)", open(log).read())]
+    assert len(losses) >= 2 and losses[-1] < losses[0], losses
+
+
+def test_cli_test_all_runs(data_root, tmp_path, cuda):
+    import main
+    log = str(tmp_path / "log" / "run.txt")
+    res = main.run(["--model_name", "BPRMF", "--emb_size", "32", "--lr", "5e-3", "--l2", "0", "--dataset", "synth",
+                    "--path", data_root + "/", "--epoch", "4", "--num_neg", "4", "--batch_size", "128", "--num_workers", "0",
+                    "--test_all", "1", "--regenerate", "1", "--log_file", log, "--topk", "5,10",
+                    "--model_path", str(tmp_path / "model" / "m.pt"), "--save_final_results", "0"])
+    text = open(log).read()
+    before = float(re.search(r"Test Before Training: \(HR@5:([0-9.]+)", text).group(1))
+    after = float(re.search(r"HR@5:([0-9.]+)", res["test"]).group(1))
+    assert after >= before
