@@ -308,6 +308,19 @@ def main():
             8 * args.batch * (args.num_neg + 2) + 4 * args.batch * (args.num_neg + 1)
         out["step_effective_gbps"] = whole / (out["ms_per_step"] * 1e-3) / 1e9
 
+    if world > 1 and args.parallel == "sharded" and not args.no_roofline:
+        # where a sharded step spends its time (cuda events on every rank, outside the timed region):
+        # collectives are inside the phases, so this also shows what xGMI costs
+        trainer.timing = []
+        acc, reps = {}, 3
+        for s in range(reps):
+            run_step(s)
+            for k, v in trainer.timing_ms().items():
+                acc[k] = acc.get(k, 0.0) + v / reps
+        trainer.timing = None
+        if rank == 0:
+            out["sharded_phases_ms"] = {k: round(v, 4) for k, v in acc.items()}
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args)
 

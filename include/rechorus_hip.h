@@ -309,6 +309,37 @@ int rc_full_catalogue_rank(const float* Uvec, const float* I, const int64_t* use
                            int64_t n_items, int d, const int64_t* clicked_ptr, const int64_t* clicked_items,
                            float* target_score, int32_t* rank, rc_stream_t stream);
 
+/* ---- row-sharded training: local kernels of the "owner computes" step (csrc/owner_step.hip) ------------
+ * New with the multi-GPU engine (the reference is single-device).  Tables are sharded by
+ * row: owner(id) = id mod world, local row = id div world.                                               */
+
+size_t rc_route_workspace_bytes(int64_t n, int world);
+
+/* Stable grouping of ids[n] by owner rank: order[j] = position of the j-th id in (owner, position) order,
+ * counts[w] = ids owned by rank w (device int64[world]); optional messages for the owners:
+ * packed[j] = ((tuple_base + order[j] / div) << 32) | (ids[order[j]] / world)   (items: tuple + local row)
+ * local_row[j] = ids[order[j]] / world                                           (users: local row)
+ * Placement is computed without atomics, so the result is deterministic.  world <= 64.                   */
+int rc_route_by_owner(const int64_t* ids, int64_t n, int world, int64_t tuple_base, int div, uint32_t* order,
+                      int64_t* packed, int64_t* local_row, int64_t* counts, void* ws, size_t ws_bytes,
+                      rc_stream_t stream);
+
+/* received packed messages -> t_idx[n] (int64 tuple index), rows[n] (int64 local row), t32[n] (uint32 t_idx) */
+int rc_owner_unpack(const int64_t* packed, int64_t n, int64_t* t_idx, int64_t* rows, uint32_t* t32,
+                    rc_stream_t stream);
+
+size_t rc_owner_backward_workspace_bytes(int64_t n);
+
+/* Owner-side backward of the sharded BPRMF step over the n occurrences this rank received (grouped by
+ * tuple: t32 non-decreasing): pug[t] = sum_{j: t32[j]=t} g[j] * I[rows[j]]  (pug [n_tuples,d], zero for
+ * tuples with no row here), and -- when `single` is given -- the optimizer update of rows with
+ * single[j] != 0 (rows occurring once on this owner this step) with gradient g[j] * Uall[t32[j]], using the
+ * pre-step row values for pug.  Rows occurring more than once are NOT updated (rc_segmented_update with
+ * RC_SEG_SKIP_SINGLETONS does that).  d in {16,32,64,128,256}.                                           */
+int rc_owner_backward(float* I, float* mI, float* vI, int d, const float* Uall, const uint32_t* t32,
+                      const int64_t* rows, const float* g, const uint8_t* single, int64_t n, int64_t n_tuples,
+                      const rc_opt_hyper* h, float* pug, void* ws, size_t ws_bytes, rc_stream_t stream);
+
 size_t rc_bprmf_step_workspace_bytes(int B, int C, int d);
 
 /* One BaseRunner.fit iteration for BPRMF (helpers/BaseRunner.py:193-206 with

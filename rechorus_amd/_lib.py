@@ -65,6 +65,11 @@ SIGNATURES = {
     "rc_target_rank": (_i, [_p, _i64, _i, _p, _p]),
     "rc_full_catalogue_rank_supported": (_i, [_i]),
     "rc_full_catalogue_rank": (_i, [_p, _p, _p, _p, _i64, _i64, _i, _p, _p, _p, _p, _p]),
+    "rc_route_workspace_bytes": (_sz, [_i64, _i]),
+    "rc_route_by_owner": (_i, [_p, _i64, _i, _i64, _i, _p, _p, _p, _p, _p, _sz, _p]),
+    "rc_owner_unpack": (_i, [_p, _i64, _p, _p, _p, _p]),
+    "rc_owner_backward_workspace_bytes": (_sz, [_i64]),
+    "rc_owner_backward": (_i, [_p, _p, _p, _i, _p, _p, _p, _p, _p, _i64, _i64, _hp, _p, _p, _sz, _p]),
     "rc_reduce_sum": (_i, [_p, _i64, _f, _p, _p]),
     "rc_bprmf_fwd_bwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _f, _p, _p, _p, _p, _p]),
     "rc_bprmf_fused_supported": (_i, [_i, _i]),

@@ -34,6 +34,7 @@ SOURCES = [
     "fm_bce.hip",
     "sampler.hip",
     "eval_rank.hip",
+    "owner_step.hip",
 ]
 HEADERS = ["common.hpp", "bpr_math.hpp", "opt_math.hpp", os.path.join("..", "..", "include", "rechorus_hip.h")]
 

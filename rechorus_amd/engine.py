@@ -636,3 +636,55 @@ def rank_metrics(rank, topk, metrics):
             keys.append("{}@{}".format(metric, k))
     out = torch.stack(vals).cpu().numpy() if vals else []
     return {k: float(v) for k, v in zip(keys, out)}
+
+
+# ---- row-sharded step: local kernels (csrc/owner_step.hip) --------------------------------------------------
+
+def route_by_owner(ids, world, tuple_base=None, div=1):
+    """stable grouping of ids by id % world -> (order int32 [n], counts int64 [world] on the device, payload
+    int64 [n]: local rows id // world, or (tuple_base + position // div) << 32 | local row)"""
+    ids = ids.reshape(-1)
+    n = ids.numel()
+    dev, i64 = ids.device, torch.int64
+    order = torch.empty(n, dtype=torch.int32, device=dev)
+    payload = torch.empty(n, dtype=i64, device=dev)
+    counts = torch.empty(world, dtype=i64, device=dev)
+    lib = _lib.load()
+    ws = workspace(lib.rc_route_workspace_bytes(n, world), dev, "route")
+    packed = tuple_base is not None
+    _lib.call("rc_route_by_owner", _ptr(ids, i64, "ids"), n, int(world), int(tuple_base or 0), int(div),
+              _ptr(order, torch.int32, "order"), _ptr(payload if packed else None, i64, "packed", True),
+              _ptr(None if packed else payload, i64, "local_row", True), _ptr(counts, i64, "counts"),
+              C.c_void_p(ws.data_ptr()), ws.numel(), _stream())
+    return order, counts, payload
+
+
+def owner_unpack(recv):
+    """(tuple << 32 | row) messages -> (t_idx int64, rows int64, t32 int32-typed uint32)"""
+    n = recv.numel()
+    dev, i64 = recv.device, torch.int64
+    t_idx, rows = torch.empty(n, dtype=i64, device=dev), torch.empty(n, dtype=i64, device=dev)
+    t32 = torch.empty(n, dtype=torch.int32, device=dev)
+    _lib.call("rc_owner_unpack", _ptr(recv, i64, "packed"), n, _ptr(t_idx, i64, "t_idx"), _ptr(rows, i64, "rows"),
+              _ptr(t32, torch.int32, "t32"), _stream())
+    return t_idx, rows, t32
+
+
+def owner_backward_supported(d):
+    return int(d) in (16, 32, 64, 128, 256)
+
+
+def owner_backward(I, mI, vI, Uall, t32, rows, g, single, n_tuples, hyper):
+    """pug [n_tuples, d] = per-tuple sum of g * I[row]; rows flagged in `single` are updated in place"""
+    n = rows.numel()
+    d = I.shape[1]
+    f32 = torch.float32
+    pug = torch.empty((n_tuples, d), dtype=f32, device=I.device)
+    lib = _lib.load()
+    ws = workspace(lib.rc_owner_backward_workspace_bytes(n), I.device, "owner")
+    _lib.call("rc_owner_backward", _ptr(I, f32, "I"), _ptr(mI, f32, "mI", True), _ptr(vI, f32, "vI", True), d,
+              _ptr(Uall, f32, "Uall"), _ptr(t32, torch.int32, "t32"), _ptr(rows, torch.int64, "rows"),
+              _ptr(g, f32, "g"), _ptr(single, torch.uint8, "single", True), n, int(n_tuples),
+              C.byref(hyper) if hyper is not None else None, _ptr(pug, f32, "pug"),
+              C.c_void_p(ws.data_ptr()), ws.numel(), _stream())
+    return pug

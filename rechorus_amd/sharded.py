@@ -58,6 +58,35 @@ class HipOps:
         self.e.segmented_update(keys, perm, src, hyper=hyper, W=W, m=state.get("m"), v=state.get("v"),
                                 coef=coef, src_index=src_index, div=1)
 
+    # ---- fast path (csrc/owner_step.hip); ShardedBprmf falls back to torch / the two calls above
+    #      for ops objects that do not provide these (the oracle-backed ops of the CPU tests)
+    def route(self, ids, world, tuple_base=None, div=1):
+        """stable grouping by owner -> (order int32 [n], counts int64 [world] (device), payload int64 [n]);
+        payload = local rows (users) or (tuple << 32 | local row) messages (items, tuple_base given)"""
+        return self.e.route_by_owner(ids, world, tuple_base, div)
+
+    def unpack(self, recv):
+        return self.e.owner_unpack(recv)
+
+    def prepare_owner(self, rows, n_rows):
+        """sort of the received rows + singleton flags + multi-occurrence heads (independent of the
+        scores: issued while they travel)"""
+        keys, perm = self.e.sort_ids(rows, n_rows)
+        single, heads, n_heads = self.e.segment_heads(keys, perm, only_multi=True)
+        return keys, perm, single, heads, n_heads
+
+    def owner_backward(self, I_loc, state, rows, g, t_idx, t32, Uall, n_tuples, hyper, prep):
+        """partial user grads + the item-row update in two passes over the received occurrences"""
+        if not self.e.owner_backward_supported(I_loc.shape[1]):
+            pug = self.partial_user_grads(I_loc, rows, g, t_idx, n_tuples)
+            self.update_rows(I_loc, state, rows, Uall, hyper, coef=g, src_index=t_idx)
+            return pug
+        keys, perm, single, heads, n_heads = prep
+        pug = self.e.owner_backward(I_loc, state.get("m"), state.get("v"), Uall, t32, rows, g, single, n_tuples, hyper)
+        self.e.segmented_update(keys, perm, Uall, hyper=hyper, W=I_loc, m=state.get("m"), v=state.get("v"), coef=g,
+                                src_index=t_idx, div=1, skip_singletons=True, heads=heads, n_heads=n_heads)
+        return pug
+
     def make_hyper(self, **kw):
         return self.e.make_hyper(**kw)
 
@@ -118,6 +147,19 @@ def _exchange(send, send_counts, group=None, recv_counts=None):
     return recv, recv_counts
 
 
+def _exchange_counts(count_tensors, group=None):
+    """one all_to_all for the split sizes of several exchanges -> ([send lists], [recv lists]); ONE host sync"""
+    world = dist.get_world_size(group)
+    k = len(count_tensors)
+    sc = torch.stack([c.to(torch.int64) for c in count_tensors], dim=1).contiguous()  # [world, k]
+    rc = torch.empty_like(sc)
+    _all_to_all_v(rc, sc, [1] * world, [1] * world, group)
+    both = torch.cat([sc, rc], dim=1).tolist()
+    send = [[row[j] for row in both] for j in range(k)]
+    recv = [[row[k + j] for row in both] for j in range(k)]
+    return send, recv
+
+
 def _exchange_back(payload, recv_counts, send_counts, group=None):
     """reverse direction of a previous _exchange: payload is ordered like what was received"""
     out, _ = _exchange(payload, recv_counts, group, recv_counts=send_counts)
@@ -168,8 +210,10 @@ def _group_by_owner(ids, world):
 
 class ShardedBprmf:
     def __init__(self, n_users, n_items, emb_size, opt="SGD", lr=1e-3, l2=0.0, device=None, ops=None,
-                 group=None, init_std=0.01, seed=0):
+                 group=None, init_std=0.01, seed=0, force_exchange=False, timing=False):
         self.group = group
+        self.force_exchange = force_exchange  # W = 1 through the general path (loop-back profiling)
+        self.timing = [] if timing else None   # [(label, cuda event)] of the last step
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.n_users, self.n_items, self.d = n_users, n_items, emb_size
@@ -218,48 +262,97 @@ class ShardedBprmf:
         n_tuples = W * B
         self.step_count += 1
         hyper = ops.make_hyper(opt=self.opt, lr=self.lr, l2=self.l2, step=self.step_count)
-        if W == 1:
+        if W == 1 and not self.force_exchange:
             return self._step_single(uid, iid, hyper)
+        if self.timing is not None:
+            self.timing.clear()
+        mark = self._mark
+        mark("start")
+
+        # 0. group user ids and candidate occurrences by owner; ONE exchange of all split sizes
+        flat = iid.reshape(-1)
+        order_u, cnt_u, req_local = self._route(uid)
+        order_i, cnt_i, packed = self._route(flat, tuple_base=self.rank * B, div=C)
+        (cnt_u, cnt_i), (rcnt_u, rcnt_i) = _exchange_counts([cnt_u, cnt_i], self.group)
+        mark("0 group by owner")
 
         # 1. fetch the batch's user rows from their owners
-        order_u, cnt_u = _group_by_owner(uid, W)
-        req_u, rcnt_u = _exchange((uid[order_u] // W), cnt_u, self.group)
+        req_u, _ = _exchange(req_local, cnt_u, self.group, recv_counts=rcnt_u)
         rows_back = _exchange_back(ops.gather_rows(self.U, req_u), rcnt_u, cnt_u, self.group)
         Ub = torch.empty((B, self.d), dtype=torch.float32, device=uid.device)
         Ub[order_u] = rows_back
+        mark("1 fetch user rows")
 
         # 2. every owner needs every tuple's user row
         Uall = _all_gather_rows(Ub, W, self.group)
+        mark("2 all_gather user rows")
 
-        # 3. route candidate occurrences to the item's owner: (global tuple index, local row)
-        flat = iid.reshape(-1)
-        order_i, cnt_i = _group_by_owner(flat, W)
-        t_global = self.rank * B + order_i // C
-        packed = (t_global << 32) | (flat[order_i] // W)
-        recv, rcnt_i = _exchange(packed, cnt_i, self.group)
-        t_idx, rows = recv >> 32, recv & 0xFFFFFFFF
+        # 3. route candidate occurrences to the item's owner: (global tuple index, local row).  Every
+        #    source sends in batch order, so the owner receives them grouped by tuple (t_idx ascending)
+        recv, _ = _exchange(packed, cnt_i, self.group, recv_counts=rcnt_i)
+        t_idx, rows, t32 = self._unpack(recv)
+        prep = ops.prepare_owner(rows, self.I.shape[0]) if hasattr(ops, "prepare_owner") else None
+        mark("3 route occurrences")
 
         # 4. owner scores its rows; scores go home
-        scores = ops.dot_rows(Uall, t_idx.contiguous(), self.I, rows.contiguous())
+        scores = ops.dot_rows(Uall, t_idx, self.I, rows)
         s_home = _exchange_back(scores, rcnt_i, cnt_i, self.group)
         pred = torch.empty(B * C, dtype=torch.float32, device=uid.device)
         pred[order_i] = s_home
         pred = pred.view(B, C)
+        mark("4 score + scores home")
 
         # 5. loss and dL/dscore at home (mean over the GLOBAL batch)
         loss_vec, g = ops.bpr_loss(pred, 1.0 / n_tuples)
         loss = _all_reduce_sum(loss_vec.sum().reshape(1) / n_tuples, self.group)
         g_own, _ = _exchange(g.reshape(-1)[order_i], cnt_i, self.group, recv_counts=rcnt_i)  # routing of step 3
+        mark("5 loss + g to owners")
 
-        # 6. owner: partial user grads (needs pre-step item rows), then the item-row update
-        pug = ops.partial_user_grads(self.I, rows, g_own, t_idx, n_tuples)
-        ops.update_rows(self.I, self.sI, rows, Uall, hyper, coef=g_own, src_index=t_idx)
+        # 6. owner: partial user grads (from pre-step item rows) and the item-row update
+        if hasattr(ops, "owner_backward"):
+            pug = ops.owner_backward(self.I, self.sI, rows, g_own, t_idx, t32, Uall, n_tuples, hyper, prep)
+        else:
+            pug = ops.partial_user_grads(self.I, rows, g_own, t_idx, n_tuples)
+            ops.update_rows(self.I, self.sI, rows, Uall, hyper, coef=g_own, src_index=t_idx)
+        mark("6 owner backward + item-row update")
 
         # 7. sum the partial user grads at the tuples' home, route them to the user rows' owners
         ugrad = _reduce_scatter_rows(pug, W, self.group)
         ug_own, _ = _exchange(ugrad[order_u], cnt_u, self.group, recv_counts=rcnt_u)
         ops.update_rows(self.U, self.sU, req_u, ug_own, hyper)
+        mark("7 user grads reduce + update")
         return loss
+
+    def _route(self, ids, tuple_base=None, div=1):
+        """(order, counts tensor [W], payload grouped by owner): HIP counting sort, or torch for test ops"""
+        W = self.world
+        if hasattr(self.ops, "route"):
+            return self.ops.route(ids, W, tuple_base, div)
+        owner = ids % W
+        order = torch.sort(owner, stable=True).indices
+        counts = torch.bincount(owner, minlength=W)
+        local = ids[order] // W
+        if tuple_base is None:
+            return order, counts, local
+        return order, counts, ((tuple_base + order // div) << 32) | local
+
+    def _unpack(self, recv):
+        if hasattr(self.ops, "unpack"):
+            return self.ops.unpack(recv)
+        t_idx = (recv >> 32).contiguous()
+        return t_idx, (recv & 0xFFFFFFFF).contiguous(), t_idx.to(torch.int32)
+
+    def _mark(self, label):
+        if self.timing is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self.timing.append((label, ev))
+
+    def timing_ms(self):
+        """per-phase milliseconds of the last step (timing=True); synchronises"""
+        torch.cuda.synchronize()
+        t = self.timing
+        return {t[i][0]: t[i - 1][1].elapsed_time(t[i][1]) for i in range(1, len(t))}
 
     def _step_single(self, uid, iid, hyper):
         """W = 1: the same arithmetic without any exchange (reference point for the tests)"""

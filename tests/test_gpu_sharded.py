@@ -58,3 +58,138 @@ def test_two_ranks_hip_ops_equal_single_table_training(opt, lr, l2, cuda):
     atol = 2e-5 if opt == "Adam" else 5e-7  # Adam: |g| ~ eps elements (see conftest.assert_update_close)
     np.testing.assert_allclose(Ug, U, rtol=1e-4, atol=atol)
     np.testing.assert_allclose(Ig, I, rtol=1e-4, atol=atol)
+
+
+# ---- local kernels of the sharded step (csrc/owner_step.hip) -------------------------------------------------
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8, 64])
+def test_route_by_owner_is_a_stable_counting_sort(world, cuda):
+    from rechorus_amd import engine
+    rng = np.random.default_rng(world)
+    for n in (1, 63, 4095, 4096, 4097, 300_001):
+        ids = rng.integers(0, 10_000_000, size=n).astype(np.int64)
+        ids[: n // 3] = ids[: n // 3] % 5  # hot ids: long same-owner runs
+        order, counts, local = engine.route_by_owner(torch.from_numpy(ids).to(cuda), world)
+        want_order = np.argsort(ids % world, kind="stable")
+        assert np.array_equal(order.cpu().numpy(), want_order)
+        assert np.array_equal(counts.cpu().numpy(), np.bincount(ids % world, minlength=world))
+        assert np.array_equal(local.cpu().numpy(), ids[want_order] // world)
+        C, base = 7, 1000
+        order2, counts2, packed = engine.route_by_owner(torch.from_numpy(ids).to(cuda), world, tuple_base=base, div=C)
+        assert torch.equal(order2, order) and torch.equal(counts2, counts)
+        assert np.array_equal(packed.cpu().numpy(), ((base + want_order // C) << 32) | (ids[want_order] // world))
+        t_idx, rows, t32 = engine.owner_unpack(packed)
+        assert np.array_equal(t_idx.cpu().numpy(), base + want_order // C) and np.array_equal(rows.cpu().numpy(), ids[want_order] // world)
+        assert np.array_equal(t32.cpu().numpy(), (base + want_order // C).astype(np.int32))
+    order, counts, local = engine.route_by_owner(torch.zeros(0, dtype=torch.int64, device=cuda), world)
+    assert order.numel() == 0 and int(counts.sum()) == 0
+
+
+@pytest.mark.parametrize("opt,d", [("SGD", 64), ("Adam", 32), ("Adagrad", 128)])
+def test_owner_backward_equals_the_unfused_owner_ops(opt, d, cuda):
+    """rc_owner_backward + skip-singleton segmented update == partial_user_grads + full update_rows"""
+    from rechorus_amd import engine
+    from rechorus_amd.sharded import HipOps
+    from conftest import assert_close, assert_update_close
+    rng = np.random.default_rng(d)
+    n_rows, n_tuples, n = 5000, 300, 4000
+    I0 = rng.normal(0, 0.1, (n_rows, d)).astype(np.float32)
+    Uall = torch.from_numpy(rng.normal(0, 0.1, (n_tuples, d)).astype(np.float32)).to(cuda)
+    t = np.sort(rng.integers(0, n_tuples, size=n)).astype(np.int64)   # grouped by tuple, some tuples absent
+    t[t == 17] = 18
+    rows = rng.integers(0, n_rows, size=n).astype(np.int64)
+    rows[::9] = rows[::9] % 11                                          # rows shared by many occurrences
+    g = rng.normal(0, 1, size=n).astype(np.float32)
+    dev = lambda x: torch.from_numpy(x).to(cuda)
+    ops = HipOps()
+    res = []
+    for fused in (False, True):
+        I = dev(I0.copy())
+        st = ops.new_state(I, opt)
+        hyper = ops.make_hyper(opt=opt, lr=0.05, l2=1e-3, step=1)
+        if fused:
+            prep = ops.prepare_owner(dev(rows), n_rows)
+            pug = ops.owner_backward(I, st, dev(rows), dev(g), dev(t), dev(t.astype(np.int32)), Uall, n_tuples, hyper, prep)
+        else:
+            pug = ops.partial_user_grads(I, dev(rows), dev(g), dev(t), n_tuples)
+            ops.update_rows(I, st, dev(rows), Uall, hyper, coef=dev(g), src_index=dev(t))
+        res.append((pug.cpu().numpy(), I.cpu().numpy(), {k: v.cpu().numpy() for k, v in st.items()}))
+    (pug_a, I_a, st_a), (pug_b, I_b, st_b) = res
+    assert np.abs(pug_b[17]).max() == 0 and np.abs(pug_b[18]).max() > 0
+    assert_close(pug_b, pug_a, what="pug", atol_scale=1e-6)
+    ex = 1e-3 * 0.05 if opt != "SGD" else 0.0
+    assert_update_close(I_b, I0, I_a, what="item rows", extra_atol=ex)
+    untouched = np.setdiff1d(np.arange(n_rows), rows)
+    assert np.array_equal(I_b[untouched], I0[untouched])
+    for k in st_a:
+        assert_close(st_b[k], st_a[k], what="state " + k, atol_scale=1e-5)
+
+
+def _loopback_worker(port, out_q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        from oracle import bprmf_oracle as O
+        from rechorus_amd.sharded import ShardedBprmf
+        dev = torch.device("cuda:0")
+        rng = np.random.default_rng(8)
+        n_users, n_items, d, B, C = 301, 2003, 64, 256, 30
+        U = rng.normal(0, 0.1, (n_users, d)).astype(np.float32)
+        I = rng.normal(0, 0.1, (n_items, d)).astype(np.float32)
+        out = {}
+        for opt, lr in (("SGD", 0.1), ("Adam", 1e-2)):
+            m = ShardedBprmf(n_users, n_items, d, opt=opt, lr=lr, l2=1e-4, device=dev, force_exchange=True, timing=True)
+            m.load_global(torch.from_numpy(U).to(dev), torch.from_numpy(I).to(dev))
+            Un, In = U.copy(), I.copy()
+            sU, sI = O.new_state(Un, opt), O.new_state(In, opt)
+            losses = []
+            for step in (1, 2):
+                uid = rng.integers(0, n_users, size=B).astype(np.int64)
+                iid = rng.integers(0, n_items, size=(B, C)).astype(np.int64)
+                iid[:, 0] %= 9
+                loss = float(m.step(torch.from_numpy(uid).to(dev), torch.from_numpy(iid).to(dev)))
+                want, _ = O.bprmf_train_step(Un, In, sU, sI, uid, iid, opt=opt, lr=lr, l2=1e-4, step=step, rowwise=True)
+                losses.append((loss, float(want)))
+            Ug, Ig = m.gather_global()
+            out[opt] = (losses, Ug.cpu().numpy(), Un, Ig.cpu().numpy(), In, sorted(m.timing_ms()))
+        out_q.put((U, I, out))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world_of_one_through_the_exchange_path(cuda):
+    """force_exchange: the full routed step (HIP counting sort, unpack, owner backward) on one rank vs the oracle"""
+    from conftest import assert_update_close
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_loopback_worker, args=(_free_port(), q))
+    p.start()
+    U0, I0, out = q.get(timeout=300)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    for opt, (losses, Ug, Un, Ig, In, phases) in out.items():
+        for got, want in losses:
+            assert abs(got - want) <= 1e-5 * abs(want)
+        ex = 1e-3 * 1e-2 if opt == "Adam" else 0.0
+        assert_update_close(Ug, U0, Un, what=opt + " dU", extra_atol=ex)
+        assert_update_close(Ig, I0, In, what=opt + " dI", extra_atol=ex)
+        assert len(phases) == 8
+
+
+def test_bench_multi_rank_code_path_on_one_gpu(cuda):
+    """the driver's N > 1 launch line with both ranks on cuda:0 and gloo collectives (RC_BENCH_ONE_DEVICE):
+    not a measurement, but every line of bench.py's sharded branch runs"""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, RC_BENCH_ONE_DEVICE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--dist-backend", "gloo", "--batch", "2048", "--num-neg", "19", "--items", "200001", "--users", "20001"]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0 and np.isfinite(out["final_loss"])
+    assert len(out["sharded_phases_ms"]) == 8
