@@ -216,6 +216,11 @@ class _SasrecEncodeFn(torch.autograd.Function):
         return (GI, GP, None, None, None) + tuple(flat)
 
 
+def sasrec_layer_params(blocks):
+    """[{engine.SAS_LAYER_KEYS name: parameter storage}] of utils.layers.TransformerLayer blocks (no copies)"""
+    return [{k: _get_attr(b, path).data for k, path in _SAS_ATTRS} for b in blocks]
+
+
 def sasrec_encode(item_emb, pos_emb, blocks, n_heads, hist, lengths):
     """blocks: nn.ModuleList of utils.layers.TransformerLayer (parameters only are used)"""
     flat = [_get_attr(b, path) for b in blocks for _, path in _SAS_ATTRS]

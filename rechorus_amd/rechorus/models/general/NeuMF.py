@@ -66,3 +66,21 @@ class NeuMF(GeneralModel):
             h = self.dropout_layer(layer(h).relu())
         pred = self.prediction(torch.cat([mf, h], dim=-1))
         return {'prediction': pred.view(feed_dict['batch_size'], -1)}
+
+    # ---- large-table mode: row-wise update of the four tables, no dense [n_rows, d] gradient -----------
+    def hip_train_step(self, feed_dict, opt_name, lr, l2):
+        """forward (MFMA) + BPR loss + backward (MFMA) + row-wise segmented update of touched table rows
+        + dense step of the MLP (engine.NeumfTrainer); returns the device loss tensor"""
+        if not self._fused_ok():
+            raise RuntimeError('NeuMF --engine rowwise needs the fused head: one hidden layer, emb_size and layer '
+                               'size in {32, 64, 128}, no active dropout')
+        tr = getattr(self, '_trainer', None)
+        if tr is None or tr.opt != opt_name:
+            P = {'mf_u': self.mf_u_embeddings.weight.data, 'mf_i': self.mf_i_embeddings.weight.data,
+                 'mlp_u': self.mlp_u_embeddings.weight.data, 'mlp_i': self.mlp_i_embeddings.weight.data,
+                 'W1': self.mlp[0].weight.data, 'b1': self.mlp[0].bias.data,
+                 'w_out': self.prediction.weight.data.view(-1)}
+            tr = self._trainer = engine.NeumfTrainer(P, opt=opt_name, lr=lr, l2=l2, rowwise=True)
+        with torch.no_grad():
+            return tr.step(feed_dict['user_id'].contiguous(), feed_dict['item_id'].contiguous())
+

@@ -91,3 +91,21 @@ class SASRec(SequentialModel, SASRecBase):
 
     def forward(self, feed_dict):
         return SASRecBase.forward(self, feed_dict)
+
+    # ---- large-table mode: row-wise update of the item table, dense step of everything small -----------
+    def hip_train_step(self, feed_dict, opt_name, lr, l2):
+        """encoder fwd/bwd (MFMA) + scoring + BPR loss + ONE segmented pass over candidate and history
+        occurrences of the item table (engine.SasrecTrainer); returns the device loss tensor"""
+        history, lengths = feed_dict['history_items'], feed_dict['lengths']
+        if not (engine.sasrec_supported(self.emb_size, self.num_layers, self.num_heads, history.shape[1])
+                and self.dropout == 0):
+            raise RuntimeError('SASRec --engine rowwise needs the fused encoder: emb_size in {32, 64}, history <= 64, '
+                               'dropout 0')
+        tr = getattr(self, '_trainer', None)
+        if tr is None or tr.opt != opt_name:
+            P = {'item_emb': self.i_embeddings.weight.data, 'pos_emb': self.p_embeddings.weight.data,
+                 'layers': hnn.sasrec_layer_params(self.transformer_block)}
+            tr = self._trainer = engine.SasrecTrainer(P, self.num_heads, opt=opt_name, lr=lr, l2=l2, rowwise=True)
+        with torch.no_grad():
+            return tr.step(history.contiguous(), lengths.contiguous(), feed_dict['item_id'].contiguous())
+
