@@ -89,7 +89,17 @@ extern "C" int rc_bprmf_train_step(float* U, float* I, float* mU, float* vU, flo
     if (prof) RC_HIP(hipEventRecord(ev[i], s));   \
   } while (0)
 
+  // The singleton fast path (update single-occurrence item rows inside the fused kernel) pays for
+  // SGD only: with optimizer state the m/v rows have to be fetched at the kernel's tail, where nothing
+  // hides their latency (measured at config 2, Adam: 2.98 ms/step fused vs 2.31 ms through the
+  // segmented update, which already streams 6 row-units per touched row at the HBM rate).
+#if defined(RC_FUSED_UPD_NEVER)
+  const bool fused_upd = false;
+#elif defined(RC_FUSED_UPD_ALWAYS)
   const bool fused_upd = rc_bprmf_fused_supported(d, C) != 0;
+#else
+  const bool fused_upd = rc_bprmf_fused_supported(d, C) != 0 && h->opt == RC_OPT_SGD;
+#endif
   RC_MARK(0);
   // one joint radix sort: keys = item id | n_items + user id (all user keys sort after all item keys)
   RC_REQUIRE(n_items + n_users <= ((int64_t)1 << 32), "rc_bprmf_train_step: n_items + n_users exceeds 2^32");
