@@ -100,6 +100,17 @@ int rc_fm_second_order_fwd(const float* V, int64_t n, int F, int d, float* out, 
 int rc_fm_second_order_bwd(const float* V, const float* gout, int64_t n, int F, int d, float* dV,
                            rc_stream_t stream);
 
+/* All F categorical field lookups of a context model in one launch (FMBase._get_embeddings_FM,
+ * models/context/FM.py:44-57): tables / ids / per_row / row_offset are HOST arrays of length F holding device
+ * pointers (tables[f]: [vocab_f, d] fp32; ids[f]: int64 [B] if per_row[f] else [B, C]) and per-field
+ * constants.  out [B, C, F, d] = the stacked field vectors (per-row fields broadcast over the C candidates);
+ * cid [B, C, F] (optional) = row_offset[f] + id, the composite row index of a virtual table that
+ * concatenates all fields -- the sort key for ONE rc_sort_ids + rc_segmented_update(dense_grad) pass that
+ * yields every field's dense gradient.  F <= 48.                                                          */
+int rc_gather_fields(const float* const* tables, const int64_t* const* ids, const int* per_row,
+                     const int64_t* row_offset, int F, int64_t B, int C, int d, float* out, int64_t* cid,
+                     rc_stream_t stream);
+
 /* nn.BCELoss on probabilities (CTRModel.loss, models/BaseModel.py:259-267), torch's log clamp (-100) and
  * backward denominator clamp (1e-12): loss_vec[i] = -(y log p + (1-y) log(1-p)); gp[i] = dmean/dp_i
  * with inv_n = 1/n.  The loss is rc_reduce_sum(loss_vec, n, inv_n).                                    */
@@ -203,6 +214,13 @@ int rc_segmented_update(float* W, float* m, float* v, int d, const uint32_t* key
  * decay on every element, helpers/BaseRunner.py:110-114,206).  m/v as above.         */
 int rc_dense_update(float* W, const float* G, float* m, float* v, int64_t n,
                     const rc_opt_hyper* h, rc_stream_t stream);
+
+/* The same step over n_tensors tensors in one launch per 36 tensors (a model's whole optimizer.step()):
+ * W, G, m, v, n and h are HOST arrays of length n_tensors (m / v may be NULL for SGD; h[t] carries the
+ * tensor's lr and weight decay -- 'bias' parameters have l2 = 0, models/BaseModel.py:64-73 -- all h[t].opt
+ * equal).  Element arithmetic identical to rc_dense_update.                                              */
+int rc_dense_update_multi(float* const* W, const float* const* G, float* const* m, float* const* v,
+                          const int64_t* n, const rc_opt_hyper* h, int n_tensors, rc_stream_t stream);
 
 /* ---- whole BPRMF training step ----------------------------------------------------- */
 

@@ -58,6 +58,7 @@ SIGNATURES = {
     "rc_softmax_ce_fwd_bwd": (_i, [_p, _p, _i, _i, _i, _p, _p, _p, _p]),
     "rc_fm_second_order_fwd": (_i, [_p, _i64, _i, _i, _p, _p]),
     "rc_fm_second_order_bwd": (_i, [_p, _p, _i64, _i, _i, _p, _p]),
+    "rc_gather_fields": (_i, [_p, _p, _p, _p, _i, _i64, _i, _i, _p, _p, _p]),
     "rc_bce_prob_fwd_bwd": (_i, [_p, _p, _i64, _f, _p, _p, _p]),
     "rc_sample_negatives": (_i, [_p, _i64, _i, _i64, _p, _p, C.c_uint64, C.c_uint64, _p, _p]),
     "rc_assemble_candidates": (_i, [_p, _i64, _i, _p, _p, _p, _p, _p, _p]),
@@ -80,6 +81,7 @@ SIGNATURES = {
     "rc_segmented_workspace_bytes": (_sz, [_i64, _i]),
     "rc_segmented_update": (_i, [_p, _p, _p, _i, _p, _p, _i64, _p, _p, _p, _i, _hp, _p, _p, _p, _i, _p, _sz, _p]),
     "rc_dense_update": (_i, [_p, _p, _p, _p, _i64, _hp, _p]),
+    "rc_dense_update_multi": (_i, [_p, _p, _p, _p, _p, _p, _i, _p]),
     "rc_segmented_update2": (_i, [_p, _p, _p, _i, _p, _p, _i64, _p, _p, _p, _i, _p, _i64, _i64, _i64, _hp, _p, _p,
                                   _p, _i, _p, _sz, _p]),
     "rc_sort_ids2": (_i, [_p, _i64, _p, _i64, _i64, _i64, _p, _p, _p, _sz, _p]),

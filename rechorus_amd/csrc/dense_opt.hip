@@ -65,6 +65,67 @@ static int launch_dense(const OptScalars& o, float* W, const float* G, float* M,
   return RC_OK;
 }
 
+// ---- many tensors, one launch ---------------------------------------------------------------------------
+// A model's optimizer.step() touches every parameter tensor; one launch per tensor is ~10 us each of pure
+// latency for the small ones (biases, LayerNorms, [vocab,1] tables).  Here up to kMultiMax tensors share a
+// launch: a workgroup owns a 4096-element chunk of one tensor (found by a scan of <= kMultiMax block
+// offsets), the arithmetic is opt_elem, exactly as in the single-tensor kernels.
+constexpr int kMultiMax = 36;
+constexpr int kMultiChunk = kBlock * 16;
+
+struct MultiArgs {
+  float* W[kMultiMax];
+  const float* G[kMultiMax];
+  float* M[kMultiMax];
+  float* V[kMultiMax];
+  int64_t n[kMultiMax];
+  OptScalars o[kMultiMax];
+  uint32_t blk0[kMultiMax + 1];
+  uint8_t aligned[kMultiMax];
+  int T;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void dense_update_multi_kernel(MultiArgs a) {
+  int t = 0;
+  while (t + 1 < a.T && blockIdx.x >= a.blk0[t + 1]) ++t;  // block-uniform
+  const int64_t base = (int64_t)(blockIdx.x - a.blk0[t]) * kMultiChunk;
+  const int64_t n = a.n[t];
+  const int64_t end = base + kMultiChunk < n ? base + kMultiChunk : n;
+  float* W = a.W[t];
+  const float* G = a.G[t];
+  float* M = a.M[t];
+  float* V = a.V[t];
+  const OptScalars o = a.o[t];
+  if (a.aligned[t]) {
+    const int64_t end4 = base + ((end - base) / 4) * 4;
+    for (int64_t i = base + 4 * (int64_t)threadIdx.x; i < end4; i += 4 * kBlock) {
+      const float4 g = *reinterpret_cast<const float4*>(G + i);
+      const float4 w = *reinterpret_cast<const float4*>(W + i);
+      opt_row4<MODE>(o, W, M, V, (size_t)(i / 4), w, g);
+    }
+    for (int64_t i = end4 + threadIdx.x; i < end; i += kBlock) {
+      float w = W[i], m = 0.f, v = 0.f;
+      if (MODE == MODE_ADAM || MODE == MODE_ADAGRAD) m = M[i];
+      if (MODE == MODE_ADAM) v = V[i];
+      opt_elem<MODE>(o, G[i], w, m, v);
+      W[i] = w;
+      if (MODE == MODE_ADAM || MODE == MODE_ADAGRAD) M[i] = m;
+      if (MODE == MODE_ADAM) V[i] = v;
+    }
+  } else {
+    for (int64_t i = base + threadIdx.x; i < end; i += kBlock) {
+      float w = W[i], m = 0.f, v = 0.f;
+      if (MODE == MODE_ADAM || MODE == MODE_ADAGRAD) m = M[i];
+      if (MODE == MODE_ADAM) v = V[i];
+      opt_elem<MODE>(o, G[i], w, m, v);
+      W[i] = w;
+      if (MODE == MODE_ADAM || MODE == MODE_ADAGRAD) M[i] = m;
+      if (MODE == MODE_ADAM) V[i] = v;
+    }
+  }
+}
+
 }  // namespace rc
 
 using namespace rc;
@@ -91,4 +152,55 @@ extern "C" int rc_dense_update(float* W, const float* G, float* m, float* v, int
     default:
       return fail(RC_ERR_INVALID_ARG, "rc_dense_update: unknown optimizer %d", h->opt);
   }
+}
+
+extern "C" int rc_dense_update_multi(float* const* W, const float* const* G, float* const* m, float* const* v,
+                                     const int64_t* n, const rc_opt_hyper* h, int n_tensors, rc_stream_t stream) {
+  if (n_tensors == 0) return RC_OK;
+  RC_REQUIRE(W && G && n && h && n_tensors > 0, "rc_dense_update_multi: bad arguments");
+  hipStream_t s = as_stream(stream);
+  auto al = [](const void* p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; };
+  const int opt = h[0].opt;
+  for (int t0 = 0; t0 < n_tensors; t0 += kMultiMax) {
+    MultiArgs a;
+    memset(&a, 0, sizeof(a));
+    uint32_t blocks = 0;
+    int T = 0;
+    for (int t = t0; t < n_tensors && T < kMultiMax; ++t) {
+      RC_REQUIRE(h[t].opt == opt, "rc_dense_update_multi: one optimizer kind per call");
+      RC_REQUIRE(n[t] >= 0, "rc_dense_update_multi: n < 0");
+      if (n[t] == 0) continue;
+      RC_REQUIRE(W[t] && G[t], "rc_dense_update_multi: null pointer (tensor %d)", t);
+      float* mt = m ? m[t] : nullptr;
+      float* vt = v ? v[t] : nullptr;
+      RC_REQUIRE(opt != RC_OPT_ADAM || (mt && vt), "rc_dense_update_multi: Adam needs m and v (tensor %d)", t);
+      RC_REQUIRE(opt != RC_OPT_ADAGRAD || mt, "rc_dense_update_multi: Adagrad needs m (tensor %d)", t);
+      a.W[T] = W[t]; a.G[T] = G[t]; a.M[T] = mt; a.V[T] = vt; a.n[T] = n[t];
+      RC_TRY(fill_opt_scalars(&h[t], &a.o[T]));
+      a.aligned[T] = al(W[t]) && al(G[t]) && al(mt) && al(vt);
+      a.blk0[T] = blocks;
+      const int64_t nb = (n[t] + kMultiChunk - 1) / kMultiChunk;
+      RC_REQUIRE(nb < ((int64_t)1 << 30) - blocks, "rc_dense_update_multi: grid too large");
+      blocks += (uint32_t)nb;
+      ++T;
+    }
+    if (T == 0) continue;
+    a.blk0[T] = blocks;
+    a.T = T;
+    switch (opt) {
+      case RC_OPT_SGD:
+        hipLaunchKernelGGL((dense_update_multi_kernel<MODE_SGD>), dim3(blocks), dim3(kBlock), 0, s, a);
+        break;
+      case RC_OPT_ADAM:
+        hipLaunchKernelGGL((dense_update_multi_kernel<MODE_ADAM>), dim3(blocks), dim3(kBlock), 0, s, a);
+        break;
+      case RC_OPT_ADAGRAD:
+        hipLaunchKernelGGL((dense_update_multi_kernel<MODE_ADAGRAD>), dim3(blocks), dim3(kBlock), 0, s, a);
+        break;
+      default:
+        return fail(RC_ERR_INVALID_ARG, "rc_dense_update_multi: unknown optimizer %d", opt);
+    }
+    RC_LAUNCH_CHECK();
+  }
+  return RC_OK;
 }

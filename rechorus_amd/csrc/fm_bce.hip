@@ -119,3 +119,75 @@ extern "C" int rc_bce_prob_fwd_bwd(const float* p, const float* y, int64_t n, fl
   RC_LAUNCH_CHECK();
   return RC_OK;
 }
+
+// ---- all F field lookups of a context model in one launch ------------------------------------------------
+// FMBase._get_embeddings_FM (models/context/FM.py:44-57) gathers field by field and stacks; here one
+// kernel walks a table-pointer array and writes the stacked block out[B, C, F, d] directly, plus the
+// composite row id cid[B, C, F] = row_offset[f] + id (the sort key of the backward pass, which then needs
+// ONE sort + ONE segmented sum for all F dense gradients instead of F of each).
+namespace rc {
+
+constexpr int kMaxFields = 48;
+
+struct FieldArgs {
+  const float* table[kMaxFields];
+  const int64_t* ids[kMaxFields];
+  int64_t row_offset[kMaxFields];
+  int per_row[kMaxFields];  // 1: ids [B] (user / situation field, broadcast over candidates); 0: ids [B, C]
+  int F;
+  int C;
+  int d;
+  int64_t n;  // B * C
+};
+
+// one thread per float4 (d % 4 == 0) or per float of the output
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void gather_fields_kernel(FieldArgs a, float* __restrict__ out,
+                                                               int64_t* __restrict__ cid) {
+  const int dq = a.d / VEC;
+  const int64_t total = a.n * a.F * dq;
+  for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += (int64_t)gridDim.x * kBlock) {
+    const int q = (int)(e % dq);
+    const int64_t rf = e / dq;          // (row, field)
+    const int f = (int)(rf % a.F);
+    const int64_t r = rf / a.F;         // b * C + c
+    const int64_t id = a.ids[f][a.per_row[f] ? r / a.C : r];
+    if (VEC == 4)
+      reinterpret_cast<float4*>(out)[e] = reinterpret_cast<const float4*>(a.table[f])[id * dq + q];
+    else
+      out[e] = a.table[f][id * dq + q];
+    if (q == 0 && cid) cid[rf] = a.row_offset[f] + id;
+  }
+}
+
+}  // namespace rc
+
+extern "C" int rc_gather_fields(const float* const* tables, const int64_t* const* ids, const int* per_row,
+                                const int64_t* row_offset, int F, int64_t B, int C, int d, float* out, int64_t* cid,
+                                rc_stream_t stream) {
+  if (B == 0) return RC_OK;
+  RC_REQUIRE(tables && ids && per_row && row_offset && out, "rc_gather_fields: null pointer");
+  RC_REQUIRE(F >= 1 && F <= kMaxFields, "rc_gather_fields: F must be in [1, %d], got %d", kMaxFields, F);
+  RC_REQUIRE(B > 0 && C >= 1 && d >= 1, "rc_gather_fields: bad shape B=%lld C=%d d=%d", (long long)B, C, d);
+  FieldArgs a;
+  memset(&a, 0, sizeof(a));
+  bool vec = d % 4 == 0 && reinterpret_cast<uintptr_t>(out) % 16 == 0;
+  for (int f = 0; f < F; ++f) {
+    RC_REQUIRE(tables[f] && ids[f], "rc_gather_fields: null table / ids for field %d", f);
+    a.table[f] = tables[f];
+    a.ids[f] = ids[f];
+    a.row_offset[f] = row_offset[f];
+    a.per_row[f] = per_row[f];
+    vec = vec && reinterpret_cast<uintptr_t>(tables[f]) % 16 == 0;
+  }
+  a.F = F; a.C = C; a.d = d; a.n = B * C;
+  const int64_t total = a.n * F * (vec ? d / 4 : d);
+  int64_t blocks = (total + kBlock - 1) / kBlock;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  if (vec)
+    hipLaunchKernelGGL((gather_fields_kernel<4>), dim3((unsigned)blocks), dim3(kBlock), 0, as_stream(stream), a, out, cid);
+  else
+    hipLaunchKernelGGL((gather_fields_kernel<1>), dim3((unsigned)blocks), dim3(kBlock), 0, as_stream(stream), a, out, cid);
+  RC_LAUNCH_CHECK();
+  return RC_OK;
+}

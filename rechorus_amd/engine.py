@@ -231,6 +231,21 @@ def dense_update(W, G, hyper, m=None, v=None):
               _ptr(v, torch.float32, "v", allow_none=True), W.numel(), C.byref(hyper), _stream())
 
 
+def dense_update_multi(items, opt):
+    """items: list of (W, G, hyper, m | None, v | None) -> one launch per 36 tensors (rc_dense_update_multi)"""
+    T = len(items)
+    if T == 0:
+        return
+    f32 = torch.float32
+    Wa = (C.c_void_p * T)(*[_ptr(w, f32, "W").value for w, _, _, _, _ in items])
+    Ga = (C.c_void_p * T)(*[_ptr(g, f32, "G").value for _, g, _, _, _ in items])
+    Ma = (C.c_void_p * T)(*[_ptr(m, f32, "m", True).value for _, _, _, m, _ in items])
+    Va = (C.c_void_p * T)(*[_ptr(v, f32, "v", True).value for _, _, _, _, v in items])
+    na = (C.c_int64 * T)(*[w.numel() for w, _, _, _, _ in items])
+    ha = (OptHyper * T)(*[h for _, _, h, _, _ in items])
+    _lib.call("rc_dense_update_multi", Wa, Ga, Ma, Va, na, ha, T, _stream())
+
+
 # ---- whole BPRMF step -----------------------------------------------------------------------
 
 class BprmfTrainer:
@@ -371,9 +386,8 @@ class NeumfTrainer:
                 G = torch.zeros_like(P[tab])
                 segmented_update(keys, perm, rows[grad], dense_grad=G)
                 dense_update(P[tab], G, h, st.get("m"), st.get("v"))
-        for k in ("W1", "b1", "w_out"):
-            st = self.state[k]
-            dense_update(P[k], dense[k], h0 if k == "b1" else h, st.get("m"), st.get("v"))
+        dense_update_multi([(P[k], dense[k], h0 if k == "b1" else h, self.state[k].get("m"), self.state[k].get("v"))
+                            for k in ("W1", "b1", "w_out")], self.opt)
         return self.loss
 
 
@@ -498,11 +512,12 @@ class SasrecTrainer:
         position = ((lengths[:, None] - torch.arange(L, device=hist.device)[None, :]) * valid).contiguous()
         Gp = embedding_dense_backward(g_hist, position, Pe.shape[0])
         st = self._st(Pe)
-        dense_update(Pe, Gp, h, st.get("m"), st.get("v"))
+        items = [(Pe, Gp, h, st.get("m"), st.get("v"))]
         for lay, g in zip(layers, dgrads):
             for name in SAS_LAYER_KEYS:
                 st = self._st(lay[name])
-                dense_update(lay[name], g[name].contiguous(), h0 if name in SAS_NO_DECAY else h, st.get("m"), st.get("v"))
+                items.append((lay[name], g[name].contiguous(), h0 if name in SAS_NO_DECAY else h, st.get("m"), st.get("v")))
+        dense_update_multi(items, self.opt)  # position table + every block parameter: one launch
         return self.loss
 
 
@@ -540,6 +555,30 @@ def fm_second_order_bwd(V, gout):
     _lib.call("rc_fm_second_order_bwd", _ptr(V, torch.float32, "V"), _ptr(gout, torch.float32, "gout"), n, F, d,
               _ptr(dV, torch.float32, "dV"), _stream())
     return dV
+
+
+def gather_fields(tables, ids, n_cand, want_cid=True):
+    """tables: list of F [vocab_f, d] tensors; ids: list of F int64 tensors, [B] (per-row field) or [B, C]
+    -> (out [B, C, F, d], cid [B, C, F] | None, row_offset list): all field lookups in one launch"""
+    F = len(tables)
+    d = tables[0].shape[1]
+    B = ids[0].shape[0]
+    dev, f32, i64 = tables[0].device, torch.float32, torch.int64
+    out = torch.empty((B, n_cand, F, d), dtype=f32, device=dev)
+    cid = torch.empty((B, n_cand, F), dtype=i64, device=dev) if want_cid else None
+    offs, run = [], 0
+    for t in tables:
+        if t.shape[1] != d:
+            raise ValueError("gather_fields: all tables need the same width")
+        offs.append(run)
+        run += t.shape[0]
+    tab_arr = (C.c_void_p * F)(*[_ptr(t, f32, "table").value for t in tables])
+    ids_arr = (C.c_void_p * F)(*[_ptr(x, i64, "ids").value for x in ids])
+    per_row = (C.c_int * F)(*[1 if x.dim() == 1 else 0 for x in ids])
+    off_arr = (C.c_int64 * F)(*offs)
+    _lib.call("rc_gather_fields", tab_arr, ids_arr, per_row, off_arr, F, B, int(n_cand), d, _ptr(out, f32, "out"),
+              _ptr(cid, i64, "cid", True), _stream())
+    return out, cid, offs + [run]
 
 
 def bce_prob(p, y, need_grad=True):

@@ -122,6 +122,30 @@ def fm_second_order(V):
     return (0.5 * (V.sum(dim=-2).pow(2) - V.pow(2).sum(dim=-2))).sum(dim=-1)
 
 
+class _FieldGatherFn(torch.autograd.Function):
+    """stacked field vectors [B, C, F, d] of F embedding tables (models/context/FM.py:49-52); the backward
+    builds all F dense gradients with one sort + one segmented sum over the composite (field, id) key."""
+
+    @staticmethod
+    def forward(ctx, n_cand, n_fields, *args):
+        ids, tables = args[:n_fields], args[n_fields:]
+        out, cid, offs = engine.gather_fields([t.detach() for t in tables], [x.contiguous() for x in ids], n_cand)
+        ctx.cid, ctx.offs = cid, offs
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        offs = ctx.offs
+        G = engine.embedding_dense_backward(gout.contiguous(), ctx.cid, offs[-1])  # virtual concatenated table
+        grads = tuple(G[offs[f]:offs[f + 1]] for f in range(len(offs) - 1))
+        return (None, None) + (None,) * len(grads) + grads
+
+
+def gather_fields(tables, ids, n_cand):
+    """tables: F HipEmbedding weights of equal width; ids: F int64 tensors ([B] or [B, C])"""
+    return _FieldGatherFn.apply(n_cand, len(tables), *ids, *tables)
+
+
 class _BceProbFn(torch.autograd.Function):
     """nn.BCELoss on probabilities (models/BaseModel.py:259-267), closed-form backward."""
 
@@ -254,8 +278,11 @@ class HipOptimizer:
 
     @torch.no_grad()
     def step(self):
+        """every parameter with a gradient in ONE rc_dense_update_multi call (per 36 tensors)"""
         self.step_count += 1
+        items = []
         for g in self.param_groups:
+            h = engine.make_hyper(self.name, lr=g["lr"], l2=g["weight_decay"], step=self.step_count)
             for p in g["params"]:
                 if p.grad is None:
                     continue
@@ -265,6 +292,6 @@ class HipOptimizer:
                     m = st.setdefault("m", torch.zeros_like(p))
                 if self.name == "Adam":
                     v = st.setdefault("v", torch.zeros_like(p))
-                h = engine.make_hyper(self.name, lr=g["lr"], l2=g["weight_decay"], step=self.step_count)
                 grad = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-                engine.dense_update(p.data, grad, h, m, v)
+                items.append((p.data, grad, h, m, v))
+        engine.dense_update_multi(items, self.name)

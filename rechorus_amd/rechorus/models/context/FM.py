@@ -4,8 +4,10 @@ Mirror of the reference's models/context/FM.py (same class / arg / state_dict na
     python main.py --model_name FM --model_mode CTR --emb_size 64 --lr 5e-4 --l2 0 --dataset MIND_Large/MINDCTR \
         --include_item_features 1 --include_situation_features 1 --metric AUC,ACC
 Every categorical field ('*_c', '*_id') owns two tables: context_embedding[f] [feature_max[f], d]
-and linear_embedding[f] [feature_max[f], 1]; their lookups (:49-55) are rc_gather_rows, their
-gradients the atomic-free sort + segmented sum.  The pairwise-interaction term (:61)
+and linear_embedding[f] [feature_max[f], 1]; all F lookups of a table family (:49-55) are ONE
+rc_gather_fields launch writing the stacked [B, C, F, d] block, their gradients ONE atomic-free
+sort + segmented sum over the composite (field, id) key (per-field rc_gather_rows when a numeric
+field is present).  The pairwise-interaction term (:61)
     0.5 * sum_k ((sum_f v_fk)^2 - sum_f v_fk^2)
 is one kernel pair (rc_fm_second_order_fwd / _bwd) over the stacked field vectors.  Numeric
 fields keep the reference's Linear(1, d, bias=False).
@@ -61,6 +63,13 @@ class FMBase(object):
     def _get_embeddings_FM(self, feed_dict):
         """-> field vectors [B, C, F, d], first-order term [B, C]"""
         n_cand = feed_dict['item_id'].shape[1]
+        if all(is_categorical(f) for f in self.context_features) and self.overall_bias.is_cuda:
+            # every field in ONE gather launch per table family (rc_gather_fields); the backward is one
+            # composite-key sort + segmented sum for all F dense gradients
+            ids = [feed_dict[f] for f in self.context_features]
+            fm_vectors = hnn.gather_fields([self.context_embedding[f].weight for f in self.context_features], ids, n_cand)
+            linear_value = hnn.gather_fields([self.linear_embedding[f].weight for f in self.context_features], ids, n_cand)
+            return fm_vectors, self.overall_bias + linear_value.squeeze(-1).sum(dim=-1)
         fm_vectors = torch.stack(self._lookup(self.context_embedding, feed_dict, n_cand), dim=-2)
         linear_value = torch.cat(self._lookup(self.linear_embedding, feed_dict, n_cand), dim=-1)
         return fm_vectors, self.overall_bias + linear_value.sum(dim=-1)

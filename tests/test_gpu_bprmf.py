@@ -306,3 +306,31 @@ def test_singleton_fast_path_is_bit_identical_to_segmented_path(opt, lr, l2, d, 
             msg += f"; rows differing: {len(rows)} of which singleton {int((cnt[rows] == 1).sum())}, multi {int((cnt[rows] > 1).sum())}"
         raise AssertionError(msg)
     assert not torch.equal(res[0][0], dev(I, cuda))
+
+
+def test_dense_update_multi_equals_single_tensor_updates(cuda):
+    """rc_dense_update_multi (one launch for a model's whole optimizer.step) == rc_dense_update per tensor,
+    bit for bit, including unaligned views, tails and > 36 tensors"""
+    from rechorus_amd import engine
+    rng = np.random.default_rng(21)
+    sizes = [1, 3, 4, 5, 64, 4096, 4097, 100_003, 7, 8192] * 5  # 50 tensors
+    for opt in ("SGD", "Adam", "Adagrad"):
+        big = torch.from_numpy(rng.normal(size=sum(sizes) + 64).astype(np.float32)).to(cuda)
+        items_a, items_b = [], []
+        off = 1  # views at odd offsets: not 16-byte aligned
+        for k, n in enumerate(sizes):
+            W = big[off:off + n] if k % 3 == 0 else torch.from_numpy(rng.normal(size=n).astype(np.float32)).to(cuda)
+            off += n
+            G = torch.from_numpy(rng.normal(size=n).astype(np.float32)).to(cuda)
+            h = engine.make_hyper(opt, lr=0.01 * (1 + k % 3), l2=1e-3 if k % 2 else 0.0, step=3)
+            m = torch.rand(n, device=cuda) if opt != "SGD" else None
+            v = torch.rand(n, device=cuda) if opt == "Adam" else None
+            items_a.append((W, G, h, m, v))
+            items_b.append((W.clone(), G, h, None if m is None else m.clone(), None if v is None else v.clone()))
+        engine.dense_update_multi(items_a, opt)
+        for W, G, h, m, v in items_b:
+            engine.dense_update(W, G, h, m, v)
+        for (Wa, _, _, ma, va), (Wb, _, _, mb, vb) in zip(items_a, items_b):
+            assert torch.equal(Wa, Wb)
+            assert ma is None or torch.equal(ma, mb)
+            assert va is None or torch.equal(va, vb)

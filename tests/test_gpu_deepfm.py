@@ -215,3 +215,32 @@ def test_cli_fm_topk_with_context(ctx_root, tmp_path, cuda):
     before = float(re.search(r"Test Before Training: \(HR@5:([0-9.]+)", text).group(1))
     after = float(re.search(r"HR@5:([0-9.]+)", res["test"]).group(1))
     assert after > before, (before, after)
+
+
+def test_gather_fields_equals_per_field_gathers(cuda):
+    """rc_gather_fields (one launch, table-pointer array) == stacking F rc_gather_rows; its composite-key
+    backward == F separate embedding backwards"""
+    from rechorus_amd import nn as hnn
+    rng = np.random.default_rng(12)
+    for d, B, C in ((64, 33, 5), (1, 40, 1), (6, 7, 3), (16, 1, 1)):
+        vocab = [11, 300, 5, 70, 2]
+        per_row = [True, False, True, False, False]
+        tables = [torch.from_numpy(rng.normal(size=(v, d)).astype(np.float32)).to(cuda).requires_grad_(True) for v in vocab]
+        ids = [torch.from_numpy(rng.integers(0, v, size=(B,) if pr else (B, C)).astype(np.int64)).to(cuda)
+               for v, pr in zip(vocab, per_row)]
+        out = hnn.gather_fields(tables, ids, C)
+        assert out.shape == (B, C, len(vocab), d)
+        want = torch.stack([t.detach()[x] if x.dim() == 2 else t.detach()[x][:, None, :].expand(-1, C, -1)
+                            for t, x in zip(tables, ids)], dim=-2)
+        assert torch.equal(out.detach(), want)
+        w = torch.from_numpy(rng.normal(size=(B, C, len(vocab), d)).astype(np.float32)).to(cuda)
+        (out * w).sum().backward()
+        for f, (t, x) in enumerate(zip(tables, ids)):
+            G = np.zeros(t.shape, dtype=np.float64)
+            wf = w[:, :, f, :].cpu().numpy().astype(np.float64)
+            xi = x.cpu().numpy()
+            if xi.ndim == 1:
+                np.add.at(G, xi, wf.sum(axis=1))
+            else:
+                np.add.at(G, xi.reshape(-1), wf.reshape(-1, d))
+            assert_close(t.grad.cpu().numpy(), G, what=f"field {f} grad d={d}", abs_floor=1e-6 * float(np.abs(wf).sum()) / t.shape[0])
