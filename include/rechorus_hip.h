@@ -125,6 +125,15 @@ int rc_bce_prob_fwd_bwd(const float* p, const float* y, int64_t n, float inv_n, 
 int rc_softmax_ce_fwd_bwd(const float* pred, const int64_t* target, int B, int n, int max_pos,
                           float* loss_vec, float* h_sum, float* gpred, rc_stream_t stream);
 
+/* List-level BPR over an impression list (ImpressionModel.loss with loss_n 'BPR' or 'BPRhard' -- the default
+ * loss of every *Impression model, models/BaseImpressionModel.py:50-89): per row
+ *   Q = sum_{i pos} a_i sum_{j neg} b_j sigmoid(pred_i - pred_j),  a / b = softmax weights over the valid
+ *   positives (of -pred when hard != 0) / negatives;  loss_vec[b] = -log Q_b (the loss is their mean:
+ *   rc_reduce_sum(loss_vec, B, inv_b));  gpred (optional) = d(inv_b * sum_b loss_vec[b]) / d pred, through
+ *   the softmax weights as well (autograd semantics).  Layout and target as in rc_softmax_ce_fwd_bwd.     */
+int rc_list_bpr_fwd_bwd(const float* pred, const int64_t* target, int B, int n, int max_pos, int hard,
+                        float inv_b, float* loss_vec, float* gpred, rc_stream_t stream);
+
 /* out[0] = scale * sum_i x[i], fixed summation order (deterministic).  Used for the
  * batch mean of loss_vec (models/BaseModel.py:185 `.mean()`).                         */
 int rc_reduce_sum(const float* x, int64_t n, float scale, float* out, rc_stream_t stream);

@@ -72,6 +72,81 @@ __global__ __launch_bounds__(kBlock) void listwise_softmax_ce_kernel(
   }
 }
 
+// ---- list-level BPR (ImpressionModel.loss, loss_n 'BPR' / 'BPRhard': models/BaseImpressionModel.py:50-89) ----
+//   valid positives i (columns < P, target != -1), valid negatives j (columns >= P, target != -1)
+//   a = softmax over the positives of s (of -s for 'hard'),  b = softmax over the negatives of s
+//   Q = sum_i a_i sum_j b_j sigmoid(s_i - s_j);   row loss = -log Q;   loss = mean over rows
+// Both softmax weights are differentiated through, as autograd does in the reference:
+//   dQ/ds_i =  a_i sum_j b_j sig'_ij  +/- a_i (Q_i - Q)       Q_i = sum_j b_j sig_ij   (- for 'hard')
+//   dQ/ds_j = -b_j sum_i a_i sig'_ij  +   b_j (R_j - Q)       R_j = sum_i a_i sig_ij
+// One wave per row; lanes stride over the positives (then the negatives) and loop over the other side,
+// O(P * N) sigmoids per row (400 at the default 20 + 20).
+__global__ __launch_bounds__(kBlock) void list_bpr_kernel(const float* __restrict__ pred,
+                                                          const int64_t* __restrict__ target, int B, int n, int P,
+                                                          int hard, float inv_b, float* __restrict__ loss_vec,
+                                                          float* __restrict__ gpred) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (row >= B) return;  // wave-uniform
+  const float* x = pred + row * n;
+  const int64_t* tg = target + row * n;
+  const float sgn = hard ? -1.f : 1.f;
+  float ma = -INFINITY, mb = -INFINITY;
+  for (int j = lane; j < n; j += 64) {
+    if (tg[j] == -1) continue;
+    if (j < P) ma = fmaxf(ma, sgn * x[j]); else mb = fmaxf(mb, x[j]);
+  }
+  ma = wave_allreduce_max(ma);
+  mb = wave_allreduce_max(mb);
+  float sa = 0.f, sb = 0.f;
+  for (int j = lane; j < n; j += 64) {
+    if (tg[j] == -1) continue;
+    if (j < P) sa += expf(sgn * x[j] - ma); else sb += expf(x[j] - mb);
+  }
+  sa = wave_allreduce_sum(sa);
+  sb = wave_allreduce_sum(sb);
+  // Q = sum_i a_i Q_i
+  float q_part = 0.f;
+  for (int i = lane; i < P && i < n; i += 64) {
+    if (tg[i] == -1) continue;
+    float qi = 0.f;
+    for (int j = P; j < n; ++j)
+      if (tg[j] != -1) qi += (expf(x[j] - mb) / sb) * sigmoidf_(x[i] - x[j]);
+    q_part += (expf(sgn * x[i] - ma) / sa) * qi;
+  }
+  const float Q = wave_allreduce_sum(q_part);
+  if (lane == 0) loss_vec[row] = -logf(Q);
+  if (!gpred) return;
+  const float dLdQ = -inv_b / Q;
+  for (int c = lane; c < n; c += 64) {
+    float g = 0.f;
+    if (tg[c] != -1) {
+      if (c < P) {  // positive i = c
+        const float a = expf(sgn * x[c] - ma) / sa;
+        float qi = 0.f, di = 0.f;
+        for (int j = P; j < n; ++j)
+          if (tg[j] != -1) {
+            const float b = expf(x[j] - mb) / sb, sg = sigmoidf_(x[c] - x[j]);
+            qi += b * sg;
+            di += b * sg * (1.f - sg);
+          }
+        g = dLdQ * (a * di + sgn * a * (qi - Q));
+      } else {  // negative j = c
+        const float b = expf(x[c] - mb) / sb;
+        float rj = 0.f, ej = 0.f;
+        for (int i = 0; i < P; ++i)
+          if (tg[i] != -1) {
+            const float a = expf(sgn * x[i] - ma) / sa, sg = sigmoidf_(x[i] - x[c]);
+            rj += a * sg;
+            ej += a * sg * (1.f - sg);
+          }
+        g = dLdQ * (b * (rj - Q) - b * ej);
+      }
+    }
+    gpred[row * n + c] = g;
+  }
+}
+
 }  // namespace rc
 
 using namespace rc;
@@ -88,6 +163,19 @@ extern "C" int rc_softmax_ce_fwd_bwd(const float* pred, const int64_t* target, i
   const int blocks = (B + (kBlock / 64) - 1) / (kBlock / 64);
   hipLaunchKernelGGL(listwise_softmax_ce_kernel, dim3(blocks), dim3(kBlock), 0, s, pred, target, B, n, max_pos,
                      h_sum, loss_vec, gpred);
+  RC_LAUNCH_CHECK();
+  return RC_OK;
+}
+
+extern "C" int rc_list_bpr_fwd_bwd(const float* pred, const int64_t* target, int B, int n, int max_pos, int hard,
+                                   float inv_b, float* loss_vec, float* gpred, rc_stream_t stream) {
+  if (B == 0) return RC_OK;
+  RC_REQUIRE(pred && target && loss_vec, "rc_list_bpr_fwd_bwd: null pointer");
+  RC_REQUIRE(B > 0 && n >= 2 && max_pos >= 1 && max_pos < n,
+             "rc_list_bpr_fwd_bwd: need 1 <= max_pos < n (got B=%d n=%d max_pos=%d)", B, n, max_pos);
+  const int blocks = (B + (kBlock / 64) - 1) / (kBlock / 64);
+  hipLaunchKernelGGL(list_bpr_kernel, dim3(blocks), dim3(kBlock), 0, as_stream(stream), pred, target, B, n, max_pos,
+                     hard, inv_b, loss_vec, gpred);
   RC_LAUNCH_CHECK();
   return RC_OK;
 }

@@ -536,6 +536,18 @@ def softmax_ce(pred, target, max_pos, need_grad=True):
     return reduce_sum(loss_vec, 1.0), gpred
 
 
+def list_bpr(pred, target, max_pos, hard=False, need_grad=True):
+    """ImpressionModel.loss with loss_n 'BPR' / 'BPRhard' (models/BaseImpressionModel.py:50-89)
+    -> (loss [1], gpred | None)"""
+    B, n = pred.shape
+    f32 = torch.float32
+    loss_vec = torch.empty(B, dtype=f32, device=pred.device)
+    gpred = torch.empty_like(pred) if need_grad else None
+    _lib.call("rc_list_bpr_fwd_bwd", _ptr(pred, f32, "pred"), _ptr(target, torch.int64, "target"), B, n, int(max_pos),
+              1 if hard else 0, 1.0 / B, _ptr(loss_vec, f32, "loss_vec"), _ptr(gpred, f32, "gpred", True), _stream())
+    return reduce_sum(loss_vec, 1.0 / B), gpred
+
+
 # ---- factorization-machine term, BCE ----------------------------------------------------------------------
 
 def fm_second_order(V):

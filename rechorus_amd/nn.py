@@ -98,6 +98,30 @@ def bpr_loss(pred):
     return _BprLossFn.apply(pred)
 
 
+class _ListLossFn(torch.autograd.Function):
+    """list-wise losses of ImpressionModel.loss on the HIP engine: 'BPR', 'BPRhard' (rc_list_bpr_fwd_bwd) and
+    'softmaxCE' (rc_softmax_ce_fwd_bwd); closed-form backward"""
+
+    @staticmethod
+    def forward(ctx, pred, target, max_pos, kind):
+        p, t = pred.detach().contiguous(), target.contiguous()
+        if kind == 'softmaxCE':
+            loss, gpred = engine.softmax_ce(p, t, max_pos)
+        else:
+            loss, gpred = engine.list_bpr(p, t, max_pos, hard=(kind == 'BPRhard'))
+        ctx.save_for_backward(gpred)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        (gpred,) = ctx.saved_tensors
+        return gpred * grad_loss, None, None, None
+
+
+def list_loss(pred, target, max_pos, kind):
+    return _ListLossFn.apply(pred, target, max_pos, kind)
+
+
 class _FmSecondOrderFn(torch.autograd.Function):
     """0.5 * sum_k ((sum_f v)^2 - sum_f v^2) over stacked field vectors (models/context/FM.py:61)."""
 

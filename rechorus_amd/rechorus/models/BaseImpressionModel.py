@@ -1,0 +1,115 @@
+"""Impression-based ranking base (mirror of the reference's models/BaseImpressionModel.py:9-214): each
+instance scores a list of up to --*_max_pos_item positives followed by up to --*_max_neg_item negatives
+(right-padded with item 0), `loss(out_dict, target)` takes the runner's {1, 0, -1} labels.
+
+Losses: 'BPR' / 'BPRhard' (list-level BPR, the default of every *Impression model) and 'softmaxCE' are
+single HIP kernels with closed-form backward (rc_list_bpr_fwd_bwd, rc_softmax_ce_fwd_bwd); the rarely
+used re-weighting variants ('BPR...after/before/simple'), 'listnet' and 'attention_rank' are the same
+formulas as device-side torch ops.  The history-aware ImpressionSeqModel (reader ImpressionSeqReader) is
+not part of this engine's path yet.
+"""
+from typing import List
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from models.BaseModel import GeneralModel
+from rechorus_amd import nn as hnn
+
+
+class ImpressionModel(GeneralModel):
+    reader = 'ImpressionReader'
+    runner = 'ImpressionRunner'
+
+    @staticmethod
+    def parse_model_args(parser):
+        parser.add_argument('--loss_n', type=str, default='BPR',
+                            help='BPR[hard][after|before|simple], listnet, softmaxCE or attention_rank')
+        parser.add_argument('--train_max_pos_item', type=int, default=20, help='max positive item sample for training')
+        parser.add_argument('--train_max_neg_item', type=int, default=20, help='max negative item sample for training')
+        parser.add_argument('--test_max_pos_item', type=int, default=20, help='max positive item sample for evaluation')
+        parser.add_argument('--test_max_neg_item', type=int, default=20, help='max negative item sample for evaluation')
+        return GeneralModel.parse_model_args(parser)
+
+    def __init__(self, args, corpus):
+        super().__init__(args, corpus)
+        self.loss_n = args.loss_n
+        self.train_max_pos_item, self.train_max_neg_item = args.train_max_pos_item, args.train_max_neg_item
+        self.test_max_pos_item, self.test_max_neg_item = args.test_max_pos_item, args.test_max_neg_item
+
+    def loss(self, out_dict: dict, target=None):
+        pred, P = out_dict['prediction'], self.train_max_pos_item
+        name = self.loss_n
+        if pred.is_cuda and name in ('BPR', 'BPRhard', 'softmaxCE'):
+            return hnn.list_loss(pred, target.long(), P, name)
+        valid = (target != -1)
+        have_neg = valid[:, P].float()
+        col = torch.arange(pred.shape[1], device=pred.device)[None, :]
+        is_pos, is_neg = (col < P) & valid, (col >= P) & valid
+        ninf = torch.tensor(float('-inf'), device=pred.device)
+
+        def reweight(row_loss):  # rows without negatives are weighted out (:93,105,125)
+            return (row_loss * have_neg / have_neg.sum() * len(have_neg)).mean()
+
+        if 'BPR' in name:
+            pair = is_pos[:, :, None] & is_neg[:, None, :]                  # [B, i, j]: i positive, j negative
+            diff = (pred[:, :, None] - pred[:, None, :]) * pair
+            w_neg = torch.where(is_neg, pred, ninf).softmax(dim=1)
+            w_pos = torch.where(is_pos, -pred if 'hard' in name else pred, ninf).softmax(dim=1)
+            if 'after' in name:
+                return ((F.softplus(-diff) * w_neg[:, None, :]).sum(-1) * w_pos).sum(-1).mean()
+            if 'before' in name:
+                return F.softplus(-(diff * w_neg[:, None, :]).sum(-1) * w_pos).sum(-1).mean()
+            if 'simple' in name:
+                return (F.softplus(-diff) * pair).sum(-1).sum(-1)
+            sig = torch.where(pair, diff, ninf).sigmoid()
+            return -((sig * w_neg[:, None, :]).sum(-1) * w_pos).sum(-1).log().mean()
+        if name in ('listnet', 'attention_rank'):
+            t_soft = torch.where(valid, target.float(), ninf).softmax(dim=1)
+            if name == 'listnet':
+                p_soft = (pred - pred.max()).softmax(dim=1)                 # over ALL columns, like the reference :87
+                p_soft = torch.where(valid, p_soft, torch.ones_like(p_soft))
+                return reweight(-(t_soft * p_soft.log()).sum(dim=1))
+            p_soft = torch.where(valid, pred, ninf).softmax(dim=1)
+            p1 = torch.where(valid, p_soft, torch.ones_like(p_soft))
+            p2 = torch.where(valid & (p_soft != 1), p_soft, torch.zeros_like(p_soft))
+            return reweight(-(t_soft * p1.log()).sum(dim=1) - ((1 - t_soft) * (1 - p2).log()).sum(dim=1))
+        if name == 'softmaxCE':  # CPU debugging only; CUDA tensors took the kernel above
+            p_soft = torch.where(valid, pred, ninf).softmax(dim=1)[:, :P]
+            p_soft = torch.where(valid[:, :P], p_soft, torch.ones_like(p_soft))
+            return reweight(-p_soft.log().sum(dim=1) / (target == 1).sum(dim=1))
+        raise ValueError('Undefined loss function: {}'.format(self.loss_n))
+
+    class Dataset(GeneralModel.Dataset):
+        def __init__(self, model, corpus, phase: str):
+            super().__init__(model, corpus, phase)
+            train = self.phase == 'train'
+            self.pos_len = model.train_max_pos_item if train else model.test_max_pos_item
+            self.neg_len = model.train_max_neg_item if train else model.test_max_neg_item
+
+        def _get_feed_dict(self, index):
+            if self.phase != 'train' and self.model.test_all:
+                negs = np.arange(1, self.corpus.n_items)
+            else:
+                negs = self.data['neg_items'][index]
+            return {'user_id': self.data['user_id'][index],
+                    'pos_items': np.array(self.data['pos_items'][index][:self.pos_len]),
+                    'neg_items': np.array(negs[:self.neg_len]),
+                    'pos_num': min(self.data['pos_num'][index], self.pos_len),
+                    'neg_num': min(self.data['neg_num'][index], self.neg_len)}
+
+        def collate_batch(self, feed_dicts: List[dict]):
+            batch = super().collate_batch(feed_dicts)
+
+            def padded(x, width):  # ragged lists were padded to the batch maximum; now to the fixed width
+                x = x.long()
+                if x.shape[-1] < width:
+                    x = torch.cat([x, torch.zeros(x.shape[0], width - x.shape[-1], dtype=torch.long)], dim=-1)
+                return x
+            batch['item_id'] = torch.cat([padded(batch.pop('pos_items'), self.pos_len),
+                                          padded(batch.pop('neg_items'), self.neg_len)], dim=-1)
+            return batch
+
+        def actions_before_epoch(self):  # impressions bring their own negatives: nothing to sample
+            pass

@@ -7,6 +7,7 @@ The gather + dot of :39-42 is one HIP kernel (rc_gather_dot_fwd) with a HIP back
 """
 import torch
 
+from models.BaseImpressionModel import ImpressionModel
 from models.BaseModel import GeneralModel
 from rechorus_amd import engine, nn as hnn
 
@@ -66,3 +67,24 @@ class BPRMF(GeneralModel, BPRMFBase):
                                                 opt=opt_name, lr=lr, l2=l2)
         with torch.no_grad():
             return self._trainer.step(feed_dict['user_id'].contiguous(), feed_dict['item_id'].contiguous())
+
+
+class BPRMFImpression(ImpressionModel, BPRMFBase):
+    """BPRMF scored over impression lists (reference :65-80).  The `u_v` / `i_v` tensors the reference also
+    returns are consumed by reranker models only and are not materialised here."""
+    reader = 'ImpressionReader'
+    runner = 'ImpressionRunner'
+    extra_log_args = ['emb_size', 'batch_size']
+
+    @staticmethod
+    def parse_model_args(parser):
+        parser = BPRMFBase.parse_model_args(parser)
+        return ImpressionModel.parse_model_args(parser)
+
+    def __init__(self, args, corpus):
+        ImpressionModel.__init__(self, args, corpus)
+        self._base_init(args, corpus)
+
+    def forward(self, feed_dict):
+        return BPRMFBase.forward(self, feed_dict)
+

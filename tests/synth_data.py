@@ -84,3 +84,36 @@ def make_context_dataset(root, name="synth_ctx", n_users=80, n_items=120, per_us
     pd.DataFrame({"user_id": np.arange(1, n_users + 1), "u_age_c": user_age[1:], "u_gender_c": user_gender[1:]}).to_csv(
         os.path.join(d, "user_meta.csv"), sep="\t", index=False)
     return d
+
+
+def make_impression_dataset(root, name="synth_imp", n_users=40, n_items=90, n_imp=9, seed=0):
+    """Impression data in the reference's layout (data/README.md "Impression-based"; ML_1MCTR / MINDCTR):
+    every row is (user_id, item_id, time, label); rows of one request share (user_id, time).  Includes the
+    corner cases the reader has to handle: impressions with only negatives or only positives (dropped),
+    repeated items inside an impression, a single-row impression."""
+    rng = np.random.default_rng(seed)
+    taste = rng.normal(size=(n_users + 1, 4))
+    feat = rng.normal(size=(n_items + 1, 4))
+    rows = {"train": [], "dev": [], "test": []}
+    for u in range(1, n_users + 1):
+        times = np.sort(rng.choice(np.arange(1000, 100000), size=n_imp, replace=False))
+        for k, t in enumerate(times):
+            phase = "test" if k == n_imp - 1 else ("dev" if k == n_imp - 2 else "train")
+            size = int(rng.integers(1, 9))
+            items = rng.integers(1, n_items + 1, size=size)          # repeats possible
+            logits = feat[items] @ taste[u]
+            labels = (rng.random(size) < 1 / (1 + np.exp(-logits))).astype(int)
+            kind = (u * 7 + k) % 11
+            if kind == 0:
+                labels[:] = 0                                         # only negatives
+            elif kind == 1:
+                labels[:] = 1                                         # only positives
+            for i, l in zip(items, labels):
+                rows[phase].append((u, int(i), int(t), int(l)))
+    d = os.path.join(root, name)
+    os.makedirs(d, exist_ok=True)
+    for phase, r in rows.items():
+        df = pd.DataFrame(r, columns=["user_id", "item_id", "time", "label"])
+        df = df.sample(frac=1.0, random_state=seed).reset_index(drop=True)  # the reader must sort
+        df.to_csv(os.path.join(d, phase + ".csv"), sep="\t", index=False)
+    return d

@@ -1,0 +1,95 @@
+"""CPU: the impression path -- list-BPR oracle, the mirror's reader / metrics / torch-op loss variants --
+vs outputs of the reference itself (tests/golden/impression_*.{npz,json})."""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN_DIR, ROOT, assert_close
+from oracle import impression_oracle as IO
+from oracle import listwise_oracle as LO
+from synth_data import make_impression_dataset
+
+PLUGIN = os.path.join(ROOT, "rechorus_amd", "rechorus")
+if PLUGIN not in sys.path:
+    sys.path.insert(0, PLUGIN)
+
+G = dict(np.load(os.path.join(GOLDEN_DIR, "impression_losses_metrics.npz")))
+LOSS_CASES = sorted({k.rsplit("/", 1)[0] for k in G if k.startswith("loss/")})
+METRIC_CASES = sorted({"/".join(k.split("/")[:2]) for k in G if k.startswith("metric/")})
+
+
+def case(prefix):
+    return {k[len(prefix) + 1:]: v for k, v in G.items() if k.startswith(prefix + "/")}
+
+
+@pytest.mark.parametrize("key", [k for k in LOSS_CASES if k.endswith(("/BPR", "/BPRhard", "/softmaxCE"))])
+def test_oracle_list_losses_match_the_reference(key):
+    c = case(key)
+    name = key.split("/")[-1]
+    if name == "softmaxCE":
+        loss, _, _ = LO.softmax_ce(c["pred"], c["target"], int(c["max_pos"]))
+        g = LO.softmax_ce_grad(c["pred"], c["target"], int(c["max_pos"]))
+    else:
+        loss, _, g = IO.list_bpr(c["pred"], c["target"], int(c["max_pos"]), hard=(name == "BPRhard"))
+    assert_close(loss, c["loss"], what="loss " + key)
+    assert_close(g, c["gpred"], what="grad " + key, atol_scale=2e-5)
+
+
+@pytest.mark.parametrize("key", LOSS_CASES)
+def test_mirror_loss_formulas_match_the_reference(key):
+    """every loss name through the mirror's ImpressionModel.loss (device-side torch-op formulas; on CUDA
+    tensors BPR / BPRhard / softmaxCE take the HIP kernels instead, tests/test_gpu_impression.py)"""
+    from models.BaseImpressionModel import ImpressionModel
+    c = case(key)
+    stub = argparse.Namespace(loss_n=key.split("/")[-1], train_max_pos_item=int(c["max_pos"]))
+    p = torch.from_numpy(c["pred"]).requires_grad_(True)
+    loss = ImpressionModel.loss(stub, {"prediction": p}, torch.from_numpy(c["target"]))
+    loss.backward()
+    assert_close(loss.item(), c["loss"], what="loss " + key, rtol=2e-5)
+    assert_close(p.grad.numpy(), c["gpred"], what="grad " + key, rtol=2e-5, atol_scale=2e-5)
+
+
+@pytest.mark.parametrize("key", METRIC_CASES)
+def test_list_metrics_match_the_reference(key):
+    from helpers.ImpressionRunner import ImpressionRunner
+    c = case(key)
+    topk = [1, 2, 3, 5, 10]
+    want = {k[4:]: v for k, v in c.items() if k.startswith("res/")}
+    got = ImpressionRunner.evaluate_method(c["pred"], topk, ["NDCG", "HR"], False, c["neg_num"], int(c["max_pos"]),
+                                           c["pos_num"], ret_all=1)
+    ora = IO.list_metrics(c["pred"], c["pos_num"], c["neg_num"], int(c["max_pos"]), topk)
+    assert list(got) == ["%s@%d" % (m, k) for m in ("NDCG", "MAP", "HR") for k in topk]
+    for k, v in want.items():
+        assert np.allclose(got[k], v, atol=1e-12), k
+        assert np.allclose(ora[k], v, atol=1e-12), k
+    mean = ImpressionRunner.evaluate_method(c["pred"], topk, ["NDCG"], False, c["neg_num"], int(c["max_pos"]), c["pos_num"])
+    assert abs(mean["NDCG@2"] - want["NDCG@2"].mean()) < 1e-12
+
+
+def test_impression_reader_matches_the_reference(tmp_path):
+    from helpers.ImpressionReader import ImpressionReader
+    from models.BaseImpressionModel import ImpressionModel
+    want = json.load(open(os.path.join(GOLDEN_DIR, "impression_reader.json")))
+    make_impression_dataset(str(tmp_path), "synth_imp")
+    corpus = ImpressionReader(argparse.Namespace(path=str(tmp_path) + "/", dataset="synth_imp", sep="\t", impression_idkey="time"))
+    assert corpus.n_users == want["n_users"] and corpus.n_items == want["n_items"]
+    for phase in ("train", "dev", "test"):
+        df = corpus.data_df[phase]
+        got = [[int(u), int(t), list(p), list(n), int(pn), int(nn)] for u, t, p, n, pn, nn in
+               zip(df["user_id"], df["time"], df["pos_items"], df["neg_items"], df["pos_num"], df["neg_num"])]
+        assert got == want[phase], phase
+    # dataset: fixed-width lists, positives first
+    model = argparse.Namespace(buffer=0, num_neg=1, test_all=0, train_max_pos_item=3, train_max_neg_item=4,
+                               test_max_pos_item=3, test_max_neg_item=4)
+    ds = ImpressionModel.Dataset(model, corpus, "train")
+    batch = ds.collate_batch([ds[i] for i in range(16)])
+    assert batch["item_id"].shape == (16, 7) and batch["item_id"].dtype == torch.long
+    for r in range(16):
+        pn, nn = int(batch["pos_num"][r]), int(batch["neg_num"][r])
+        assert (batch["item_id"][r, :pn] > 0).all() and (batch["item_id"][r, pn:3] == 0).all()
+        assert (batch["item_id"][r, 3:3 + nn] > 0).all() and (batch["item_id"][r, 3 + nn:] == 0).all()
