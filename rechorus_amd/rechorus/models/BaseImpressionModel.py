@@ -5,8 +5,8 @@ instance scores a list of up to --*_max_pos_item positives followed by up to --*
 Losses: 'BPR' / 'BPRhard' (list-level BPR, the default of every *Impression model) and 'softmaxCE' are
 single HIP kernels with closed-form backward (rc_list_bpr_fwd_bwd, rc_softmax_ce_fwd_bwd); the rarely
 used re-weighting variants ('BPR...after/before/simple'), 'listnet' and 'attention_rank' are the same
-formulas as device-side torch ops.  The history-aware ImpressionSeqModel (reader ImpressionSeqReader) is
-not part of this engine's path yet.
+formulas as device-side torch ops.  ImpressionSeqModel adds the clicked / skipped item histories
+(reader ImpressionSeqReader) for sequential heads such as SASRecImpression.
 """
 from typing import List
 
@@ -14,7 +14,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from models.BaseModel import GeneralModel
+from models.BaseModel import GeneralModel, SequentialModel
 from rechorus_amd import nn as hnn
 
 
@@ -100,16 +100,63 @@ class ImpressionModel(GeneralModel):
                     'neg_num': min(self.data['neg_num'][index], self.neg_len)}
 
         def collate_batch(self, feed_dicts: List[dict]):
-            batch = super().collate_batch(feed_dicts)
-
-            def padded(x, width):  # ragged lists were padded to the batch maximum; now to the fixed width
-                x = x.long()
-                if x.shape[-1] < width:
-                    x = torch.cat([x, torch.zeros(x.shape[0], width - x.shape[-1], dtype=torch.long)], dim=-1)
-                return x
-            batch['item_id'] = torch.cat([padded(batch.pop('pos_items'), self.pos_len),
-                                          padded(batch.pop('neg_items'), self.neg_len)], dim=-1)
-            return batch
+            return _fixed_width_lists(super().collate_batch(feed_dicts), self.pos_len, self.neg_len)
 
         def actions_before_epoch(self):  # impressions bring their own negatives: nothing to sample
             pass
+
+
+def _fixed_width_lists(batch, pos_len, neg_len):
+    """item_id = [positives padded to pos_len | negatives padded to neg_len] (reference :190-201)"""
+    def padded(x, width):  # ragged lists were padded to the batch maximum; now to the fixed width
+        x = x.long()
+        if x.shape[-1] < width:
+            x = torch.cat([x, torch.zeros(x.shape[0], width - x.shape[-1], dtype=torch.long)], dim=-1)
+        return x
+    batch['item_id'] = torch.cat([padded(batch.pop('pos_items'), pos_len), padded(batch.pop('neg_items'), neg_len)], dim=-1)
+    return batch
+
+
+class ImpressionSeqModel(ImpressionModel):
+    reader = 'ImpressionSeqReader'
+    runner = 'ImpressionRunner'
+
+    @staticmethod
+    def parse_model_args(parser):
+        parser.add_argument('--history_max', type=int, default=20, help='Maximum length of history.')
+        return ImpressionModel.parse_model_args(parser)
+
+    def __init__(self, args, corpus):
+        super().__init__(args, corpus)
+        self.history_max = args.history_max
+
+    class Dataset(SequentialModel.Dataset):
+        def __init__(self, model, corpus, phase):
+            super().__init__(model, corpus, phase)  # drops impressions with an empty click history
+            train = self.phase == 'train'
+            self.pos_len = model.train_max_pos_item if train else model.test_max_pos_item
+            self.neg_len = model.train_max_neg_item if train else model.test_max_neg_item
+
+        def _get_feed_dict(self, index):
+            feed = ImpressionModel.Dataset._get_feed_dict(self, index)
+            his = self.corpus.user_his[feed['user_id']]
+            clicked = his['pos'][:self.data['position'][index]]
+            skipped = his['neg'][:self.data['neg_position'][index]]
+            if self.model.history_max > 0:
+                clicked, skipped = clicked[-self.model.history_max:], skipped[-self.model.history_max:]
+            feed['history_items'] = np.array([x[0] for x in clicked])
+            feed['neg_history_items'] = np.array([x[0] for x in skipped])
+            feed['history_times'] = np.array([x[1] for x in clicked])
+            feed['neg_history_times'] = np.array([x[1] for x in skipped])
+            feed['lengths'], feed['neg_lengths'] = len(clicked), len(skipped)
+            return feed
+
+        def collate_batch(self, feed_dicts: List[dict]):
+            batch = _fixed_width_lists(super().collate_batch(feed_dicts), self.pos_len, self.neg_len)
+            batch['history_items'] = batch['history_items'].long()
+            batch['neg_history_items'] = batch['neg_history_items'].long()
+            return batch
+
+        def actions_before_epoch(self):
+            pass
+

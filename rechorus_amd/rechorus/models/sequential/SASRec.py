@@ -12,6 +12,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from models.BaseImpressionModel import ImpressionSeqModel
 from models.BaseModel import SequentialModel
 from rechorus_amd import engine, nn as hnn
 from utils import layers
@@ -108,4 +109,23 @@ class SASRec(SequentialModel, SASRecBase):
             tr = self._trainer = engine.SasrecTrainer(P, self.num_heads, opt=opt_name, lr=lr, l2=l2, rowwise=True)
         with torch.no_grad():
             return tr.step(history.contiguous(), lengths.contiguous(), feed_dict['item_id'].contiguous())
+
+
+class SASRecImpression(ImpressionSeqModel, SASRecBase):
+    """SASRec scored over impression lists (reference :107-122); list-level BPR by default"""
+    reader = 'ImpressionSeqReader'
+    runner = 'ImpressionRunner'
+    extra_log_args = ['emb_size', 'num_layers', 'num_heads']
+
+    @staticmethod
+    def parse_model_args(parser):
+        parser = SASRecBase.parse_model_args(parser)
+        return ImpressionSeqModel.parse_model_args(parser)
+
+    def __init__(self, args, corpus):
+        ImpressionSeqModel.__init__(self, args, corpus)
+        self._base_init(args, corpus)
+
+    def forward(self, feed_dict):
+        return SASRecBase.forward(self, feed_dict)
 

@@ -78,6 +78,15 @@ def main():
         dump[phase] = [[int(u), int(t), sorted(int(x) for x in p), sorted(int(x) for x in n), int(pn), int(nn)]
                        for u, t, p, n, pn, nn in zip(df["user_id"], df["time"], df["pos_items"], df["neg_items"],
                                                      df["pos_num"], df["neg_num"])]
+    # history-aware reader: positions and the (time, item)-sorted histories (within one impression the
+    # reference's order is Python-set iteration order, which is not part of the contract)
+    from helpers.ImpressionSeqReader import ImpressionSeqReader
+    seq = ImpressionSeqReader(args)
+    dump["seq"] = {phase: [[int(u), int(t), int(p), int(q)] for u, t, p, q in
+                           zip(seq.data_df[phase]["user_id"], seq.data_df[phase]["time"], seq.data_df[phase]["position"],
+                               seq.data_df[phase]["neg_position"])] for phase in ("train", "dev", "test")}
+    dump["seq_his"] = {str(int(u)): {k: sorted([int(t), int(i)] for i, t in v[k]) for k in ("pos", "neg")}
+                       for u, v in seq.user_his.items()}
     json.dump(dump, open(os.path.join(HERE, "impression_reader.json"), "w"))
     print("wrote impression goldens:", len(out), "arrays;", {p: len(dump[p]) for p in ("train", "dev", "test")})
 

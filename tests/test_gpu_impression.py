@@ -69,3 +69,18 @@ def test_cli_bprmf_impression(tmp_path, cuda):
     after = float(re.search(r"NDCG@2:([0-9.]+)", res["test"]).group(1))
     assert after > before, (before, after)  # clicks follow a user x item affinity
     assert "MAP@2" in res["test"]
+
+
+def test_cli_sasrec_impression(tmp_path, cuda):
+    import main
+    make_impression_dataset(str(tmp_path), "imp", n_users=300, n_items=120, n_imp=12, seed=2)
+    log = str(tmp_path / "log" / "run.txt")
+    res = main.run(["--model_name", "SASRec", "--model_mode", "Impression", "--emb_size", "32", "--num_layers", "1",
+                    "--num_heads", "2", "--history_max", "10", "--lr", "3e-3", "--l2", "0", "--loss_n", "BPR", "--dataset", "imp",
+                    "--path", str(tmp_path) + "/", "--epoch", "6", "--batch_size", "128", "--num_workers", "0", "--regenerate", "1",
+                    "--metric", "NDCG,HR", "--topk", "1,2,3,5", "--main_metric", "NDCG@2", "--log_file", log,
+                    "--model_path", str(tmp_path / "model" / "m.pt"), "--save_final_results", "0"])
+    text = open(log).read()
+    losses = [float(x) for x in re.findall(r"Epoch \d+\s+loss=([0-9.]+)", text)]
+    assert len(losses) >= 2 and losses[-1] < losses[0], losses
+    assert "NDCG@2" in res["test"] and "MAP@5" in res["test"]

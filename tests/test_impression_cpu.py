@@ -93,3 +93,28 @@ def test_impression_reader_matches_the_reference(tmp_path):
         pn, nn = int(batch["pos_num"][r]), int(batch["neg_num"][r])
         assert (batch["item_id"][r, :pn] > 0).all() and (batch["item_id"][r, pn:3] == 0).all()
         assert (batch["item_id"][r, 3:3 + nn] > 0).all() and (batch["item_id"][r, 3 + nn:] == 0).all()
+
+
+def test_impression_seq_reader_matches_the_reference(tmp_path):
+    from helpers.ImpressionSeqReader import ImpressionSeqReader
+    from models.BaseImpressionModel import ImpressionSeqModel
+    want = json.load(open(os.path.join(GOLDEN_DIR, "impression_reader.json")))
+    make_impression_dataset(str(tmp_path), "synth_imp")
+    corpus = ImpressionSeqReader(argparse.Namespace(path=str(tmp_path) + "/", dataset="synth_imp", sep="\t", impression_idkey="time"))
+    for phase in ("train", "dev", "test"):
+        df = corpus.data_df[phase]
+        got = [[int(u), int(t), int(p), int(q)] for u, t, p, q in zip(df["user_id"], df["time"], df["position"], df["neg_position"])]
+        assert got == want["seq"][phase], phase
+    for u, his in corpus.user_his.items():
+        for k in ("pos", "neg"):
+            assert sorted([int(t), int(i)] for i, t in his[k]) == want["seq_his"][str(int(u))][k]
+    model = argparse.Namespace(buffer=0, num_neg=1, test_all=0, history_max=4, train_max_pos_item=3, train_max_neg_item=4,
+                               test_max_pos_item=3, test_max_neg_item=4)
+    ds = ImpressionSeqModel.Dataset(model, corpus, "train")
+    assert all(p > 0 for p in ds.data["position"])  # impressions without a click history are dropped
+    batch = ds.collate_batch([ds[i] for i in range(12)])
+    assert batch["item_id"].shape == (12, 7) and batch["history_items"].shape[1] <= 4
+    assert (batch["lengths"] >= 1).all() and batch["history_items"].dtype == torch.long
+    f0 = ds[0]
+    u, pos = f0["user_id"], ds.data["position"][0]
+    assert f0["history_items"].tolist() == [x[0] for x in corpus.user_his[u]["pos"][:pos]][-4:]
