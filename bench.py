@@ -12,6 +12,10 @@ N > 1 is launched by torch.distributed.run (one rank per GPU): the tables are ro
 the ranks and every step trains ONE global batch of N*B tuples (rechorus_amd/sharded.py; DESIGN.md
 section 7).  --parallel replicas runs N independent single-GPU jobs instead (no exchange).
 """
+import os as _os
+
+# hipGraph launches must use the runtime's regular path (rechorus_amd/graph.py); set before HIP initialises
+_os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
 import argparse
 import json
 import os

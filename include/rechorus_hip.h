@@ -231,6 +231,14 @@ int rc_dense_update(float* W, const float* G, float* m, float* v, int64_t n,
 int rc_dense_update_multi(float* const* W, const float* const* G, float* const* m, float* const* v,
                           const int64_t* n, const rc_opt_hyper* h, int n_tensors, rc_stream_t stream);
 
+/* hipGraph-capturable variant: for Adam the step count t is read from DEVICE memory (step_dev, int64) and the
+ * bias corrections 1 - beta^t are derived in the kernel (h[t].step is ignored), so a captured training step
+ * replays correctly; rc_step_increment bumps the counter on the stream.  step_dev NULL = rc_dense_update_multi. */
+int rc_dense_update_multi_dev(float* const* W, const float* const* G, float* const* m, float* const* v,
+                              const int64_t* n, const rc_opt_hyper* h, int n_tensors, const int64_t* step_dev,
+                              rc_stream_t stream);
+int rc_step_increment(int64_t* step_dev, rc_stream_t stream);
+
 /* ---- whole BPRMF training step ----------------------------------------------------- */
 
 /* rc_segmented_update with a SECOND gradient source: occurrences o >= n_split take the plain row

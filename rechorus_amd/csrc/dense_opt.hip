@@ -83,6 +83,11 @@ struct MultiArgs {
   uint32_t blk0[kMultiMax + 1];
   uint8_t aligned[kMultiMax];
   int T;
+  // capturable mode (hipGraph replay): Adam's step count lives in device memory and the two
+  // bias-correction scalars are derived from it in the kernel instead of on the host
+  const int64_t* step_dev;
+  double beta1, beta2;
+  float lr[kMultiMax];
 };
 
 template <int MODE>
@@ -96,7 +101,14 @@ __global__ __launch_bounds__(kBlock) void dense_update_multi_kernel(MultiArgs a)
   const float* G = a.G[t];
   float* M = a.M[t];
   float* V = a.V[t];
-  const OptScalars o = a.o[t];
+  OptScalars o = a.o[t];
+  if (MODE == MODE_ADAM && a.step_dev != nullptr) {
+    // same expressions as fill_opt_scalars (double, then narrowed like torch does)
+    const double step = (double)*a.step_dev;
+    const double bc1 = 1.0 - pow(a.beta1, step), bc2 = 1.0 - pow(a.beta2, step);
+    o.neg_step = (float)(-((double)a.lr[t] / bc1));
+    o.bc2_sqrt = (float)sqrt(bc2);
+  }
   if (a.aligned[t]) {
     const int64_t end4 = base + ((end - base) / 4) * 4;
     for (int64_t i = base + 4 * (int64_t)threadIdx.x; i < end4; i += 4 * kBlock) {
@@ -154,8 +166,23 @@ extern "C" int rc_dense_update(float* W, const float* G, float* m, float* v, int
   }
 }
 
+__global__ void step_increment_kernel(int64_t* step) { *step += 1; }
+
+extern "C" int rc_step_increment(int64_t* step_dev, rc_stream_t stream) {
+  RC_REQUIRE(step_dev != nullptr, "rc_step_increment: null pointer");
+  hipLaunchKernelGGL(step_increment_kernel, dim3(1), dim3(1), 0, as_stream(stream), step_dev);
+  RC_LAUNCH_CHECK();
+  return RC_OK;
+}
+
 extern "C" int rc_dense_update_multi(float* const* W, const float* const* G, float* const* m, float* const* v,
                                      const int64_t* n, const rc_opt_hyper* h, int n_tensors, rc_stream_t stream) {
+  return rc_dense_update_multi_dev(W, G, m, v, n, h, n_tensors, nullptr, stream);
+}
+
+extern "C" int rc_dense_update_multi_dev(float* const* W, const float* const* G, float* const* m, float* const* v,
+                                         const int64_t* n, const rc_opt_hyper* h, int n_tensors,
+                                         const int64_t* step_dev, rc_stream_t stream) {
   if (n_tensors == 0) return RC_OK;
   RC_REQUIRE(W && G && n && h && n_tensors > 0, "rc_dense_update_multi: bad arguments");
   hipStream_t s = as_stream(stream);
@@ -177,6 +204,9 @@ extern "C" int rc_dense_update_multi(float* const* W, const float* const* G, flo
       RC_REQUIRE(opt != RC_OPT_ADAGRAD || mt, "rc_dense_update_multi: Adagrad needs m (tensor %d)", t);
       a.W[T] = W[t]; a.G[T] = G[t]; a.M[T] = mt; a.V[T] = vt; a.n[T] = n[t];
       RC_TRY(fill_opt_scalars(&h[t], &a.o[T]));
+      a.lr[T] = (float)h[t].lr;
+      RC_REQUIRE(step_dev == nullptr || (h[t].beta1 == h[0].beta1 && h[t].beta2 == h[0].beta2),
+                 "rc_dense_update_multi_dev: one (beta1, beta2) per call");
       a.aligned[T] = al(W[t]) && al(G[t]) && al(mt) && al(vt);
       a.blk0[T] = blocks;
       const int64_t nb = (n[t] + kMultiChunk - 1) / kMultiChunk;
@@ -187,6 +217,9 @@ extern "C" int rc_dense_update_multi(float* const* W, const float* const* G, flo
     if (T == 0) continue;
     a.blk0[T] = blocks;
     a.T = T;
+    a.step_dev = step_dev;
+    a.beta1 = h[0].beta1;
+    a.beta2 = h[0].beta2;
     switch (opt) {
       case RC_OPT_SGD:
         hipLaunchKernelGGL((dense_update_multi_kernel<MODE_SGD>), dim3(blocks), dim3(kBlock), 0, s, a);

@@ -41,13 +41,21 @@ def make_hyper(opt="SGD", lr=1e-3, l2=0.0, beta1=0.9, beta2=0.999, eps=None, ste
 
 
 _ws_cache = {}
+_ws_retired = []
 
 
 def workspace(nbytes, device, tag="default"):
-    """Cached uint8 scratch buffer (grow-only) per (device, tag)."""
+    """Cached uint8 scratch buffer (grow-only) per (device, tag).  A buffer that is outgrown is RETIRED, not
+    freed: a captured hipGraph (rechorus_amd/graph.py) holds raw pointers into the buffers that were current
+    at capture time, and a later, larger request (another batch shape, an evaluation pass) must not pull
+    that memory from under its replays.  Growth is geometric, so retired buffers total less than the
+    live one."""
     key = (str(device), tag)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
+        if buf is not None:
+            _ws_retired.append(buf)
+            nbytes = max(int(nbytes), 2 * buf.numel())
         buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
         _ws_cache[key] = buf
     return buf
@@ -231,8 +239,10 @@ def dense_update(W, G, hyper, m=None, v=None):
               _ptr(v, torch.float32, "v", allow_none=True), W.numel(), C.byref(hyper), _stream())
 
 
-def dense_update_multi(items, opt):
-    """items: list of (W, G, hyper, m | None, v | None) -> one launch per 36 tensors (rc_dense_update_multi)"""
+def dense_update_multi(items, opt, step_dev=None):
+    """items: list of (W, G, hyper, m | None, v | None) -> one launch per 36 tensors (rc_dense_update_multi).
+    step_dev: int64 device tensor [1] holding Adam's step count (hipGraph-capturable mode): it is incremented
+    on the stream, then read by the update kernel"""
     T = len(items)
     if T == 0:
         return
@@ -243,7 +253,11 @@ def dense_update_multi(items, opt):
     Va = (C.c_void_p * T)(*[_ptr(v, f32, "v", True).value for _, _, _, _, v in items])
     na = (C.c_int64 * T)(*[w.numel() for w, _, _, _, _ in items])
     ha = (OptHyper * T)(*[h for _, _, h, _, _ in items])
-    _lib.call("rc_dense_update_multi", Wa, Ga, Ma, Va, na, ha, T, _stream())
+    if step_dev is None:
+        _lib.call("rc_dense_update_multi", Wa, Ga, Ma, Va, na, ha, T, _stream())
+        return
+    _lib.call("rc_step_increment", _ptr(step_dev, torch.int64, "step_dev"), _stream())
+    _lib.call("rc_dense_update_multi_dev", Wa, Ga, Ma, Va, na, ha, T, _ptr(step_dev, torch.int64, "step_dev"), _stream())
 
 
 # ---- whole BPRMF step -----------------------------------------------------------------------
@@ -276,7 +290,10 @@ class BprmfTrainer:
             nbytes = _lib.load().rc_bprmf_step_workspace_bytes(B, Cn, self.d)
             if nbytes == 0:
                 raise _lib.RechorusHipError("rc_bprmf_step_workspace_bytes", -1, "bad shape")
-            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.U.device)
+            if self._ws is None or self._ws.numel() < nbytes:
+                if self._ws is not None:
+                    _ws_retired.append(self._ws)  # a captured hipGraph may still point into it
+                self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.U.device)
             self._ws_shape = (B, Cn)
         return self._ws
 

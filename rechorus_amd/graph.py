@@ -1,0 +1,113 @@
+"""hipGraph replay of the dense training step (model(batch) -> loss -> backward -> optimizer.step).
+
+At the reference's default batch size (256) a step is ~25 kernels of a few microseconds each, and the Python
+between them (autograd Functions, module calls, ctypes) costs several times more than the GPU work.  The
+whole step is therefore recorded ONCE per batch shape with HIP stream capture (torch.cuda.CUDAGraph: the
+engine launches on torch's current stream, takes its scratch from caches that are warm by then, never
+synchronises) and replayed with the next batch copied into static input buffers.  Adam's step count lives
+in device memory (HipOptimizer(capturable=True), rc_dense_update_multi_dev), so bias correction advances
+across replays.  Eligibility is decided by the runner (helpers/BaseRunner.py): deterministic forward
+(no dropout, no host-side candidate shuffle), HipOptimizer, CUDA tensors.
+
+ROCm caveat (measured on ROCm 7.0 / MI355X, repro: tools/repro_hipgraph_fault.py): with the runtime's
+default "AQL packet capture" fast path for graphs, ONE device-to-host copy on the default stream between
+two launches of an instantiated graph (a `.item()` on any tensor, e.g. the epoch loss) makes the next
+launch fault ("Memory access fault by GPU").  DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 selects the runtime's
+regular graph launch path, which does not have the problem.  The variable is read when HIP initialises,
+so `enable()` sets it at package import if the process has not touched the GPU yet, and `usable()` tells
+the runner whether graphs may be used in this process; otherwise training stays eager.
+"""
+import os
+import warnings
+
+import torch
+
+_ENV = "DEBUG_CLR_GRAPH_PACKET_CAPTURE"
+_OK = False
+
+
+def _hsa_initialised():
+    """the ROCm runtime opens /dev/kfd when it initialises; after that its environment flags are frozen"""
+    try:
+        for fd in os.listdir("/proc/self/fd"):
+            try:
+                if os.readlink(os.path.join("/proc/self/fd", fd)) == "/dev/kfd":
+                    return True
+            except OSError:
+                pass
+    except OSError:
+        return True  # cannot tell: assume the worst
+    return False
+
+
+def enable():
+    """select the safe graph launch path for this process (called at package import).  If the variable is
+    already 0 (launcher, tests/conftest.py, bench.py) nothing is to do; if the runtime is already up without
+    it, graphs stay disabled for this process."""
+    global _OK
+    if os.environ.get(_ENV) == "0":
+        _OK = True
+    elif _hsa_initialised():
+        _OK = False
+    else:
+        os.environ[_ENV] = "0"
+        _OK = True
+
+
+def usable():
+    return _OK
+
+
+class GraphedStep:
+    """captured training step for one feed-dict shape; `run(batch)` trains on `batch` and returns the loss"""
+
+    WARMUP = 2  # eager steps before capture: optimizer state, workspaces and autotuned paths exist by then
+
+    def __init__(self, model):
+        self.model = model
+        self.seen = 0
+        self.graph = None
+        self.static = None
+        self.loss = None
+
+    @staticmethod
+    def signature(batch):
+        return tuple((k, tuple(v.shape), v.dtype) for k, v in sorted(batch.items()) if isinstance(v, torch.Tensor))
+
+    def _eager(self, batch):
+        model = self.model
+        model.optimizer.zero_grad()
+        loss = model.loss(model(batch))
+        loss.backward()
+        model.optimizer.step()
+        return loss.detach().reshape(1)
+
+    def run(self, batch):
+        """warm-up steps and replays run on the caller's current stream; only the capture itself happens on
+        the side stream torch.cuda.graph provides"""
+        if self.graph is None:
+            self.seen += 1
+            if self.seen <= self.WARMUP:
+                return self._eager(batch)
+            self._capture(batch)
+        else:
+            for k, v in self.static.items():
+                if isinstance(v, torch.Tensor):
+                    v.copy_(batch[k])
+        self.graph.replay()
+        return self.loss.detach().reshape(1).clone()
+
+    def _capture(self, batch):
+        model = self.model
+        self.static = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
+        model.optimizer.zero_grad()  # grads must be None: the captured backward allocates them in the graph's pool
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with warnings.catch_warnings():
+            # autograd notes that the AccumulateGrad nodes were created on the default stream (warm-up); the
+            # capture stream joins it before and after, which is what we want
+            warnings.simplefilter('ignore', UserWarning)
+            with torch.cuda.graph(self.graph):
+                self.loss = model.loss(model(self.static))
+                self.loss.backward()
+                model.optimizer.step()

@@ -281,10 +281,13 @@ class HipOptimizer:
     (helpers/BaseRunner.py:110-114); accepts the same param-group list
     (`model.customize_parameters()`, models/BaseModel.py:64-73)."""
 
-    def __init__(self, param_groups, name="Adam", lr=1e-3, weight_decay=0.0):
+    def __init__(self, param_groups, name="Adam", lr=1e-3, weight_decay=0.0, capturable=False):
         if name not in ("SGD", "Adam", "Adagrad"):
             raise ValueError(f"HipOptimizer: optimizer {name!r} not built (SGD, Adam, Adagrad)")
         self.name, self.lr = name, lr
+        # capturable: Adam's step count lives on the device, so step() can be recorded in a hipGraph
+        self.capturable = capturable
+        self._step_dev = None
         self.param_groups = []
         for g in param_groups:
             g = dict(g)
@@ -305,8 +308,9 @@ class HipOptimizer:
         """every parameter with a gradient in ONE rc_dense_update_multi call (per 36 tensors)"""
         self.step_count += 1
         items = []
+        dev = None
         for g in self.param_groups:
-            h = engine.make_hyper(self.name, lr=g["lr"], l2=g["weight_decay"], step=self.step_count)
+            h = engine.make_hyper(self.name, lr=g["lr"], l2=g["weight_decay"], step=max(self.step_count, 1))
             for p in g["params"]:
                 if p.grad is None:
                     continue
@@ -318,4 +322,10 @@ class HipOptimizer:
                     v = st.setdefault("v", torch.zeros_like(p))
                 grad = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                 items.append((p.data, grad, h, m, v))
-        engine.dense_update_multi(items, self.name)
+                dev = p.device
+        if self.capturable and items:
+            if self._step_dev is None:  # (allocated outside any capture: the first step runs eagerly)
+                self._step_dev = torch.full((1,), self.step_count - 1, dtype=torch.int64, device=dev)
+            engine.dense_update_multi(items, self.name, step_dev=self._step_dev)
+        else:
+            engine.dense_update_multi(items, self.name)

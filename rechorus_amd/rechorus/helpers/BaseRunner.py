@@ -26,7 +26,7 @@ import torch
 from torch.utils.data import DataLoader
 
 from models.BaseModel import BaseModel
-from rechorus_amd import engine, nn as hnn, pipeline
+from rechorus_amd import engine, graph as hgraph, nn as hnn, pipeline
 from utils import utils
 
 
@@ -50,6 +50,8 @@ class BaseRunner(object):
         # additive, engine-specific
         parser.add_argument('--engine', type=str, default='auto',
                             help='dense: exact reference optimizer semantics; rowwise: fused step, update touched rows only; auto')
+        parser.add_argument('--graph', type=int, default=1,
+                            help='1: replay the dense training step from a hipGraph when the model allows it; 0: eager')
         parser.add_argument('--device_pipeline', type=int, default=1,
                             help='1: sample negatives / assemble batches on the GPU for standard datasets; 0: DataLoader')
         return parser
@@ -82,6 +84,8 @@ class BaseRunner(object):
         self.num_workers, self.pin_memory = args.num_workers, args.pin_memory
         self.engine = getattr(args, 'engine', 'auto')
         self.device_pipeline = bool(getattr(args, 'device_pipeline', 1))
+        self.use_graph = bool(getattr(args, 'graph', 1))
+        self._graphed = {}
         self.topk = [int(x) for x in args.topk.split(',')]
         self.metrics = [m.strip().upper() for m in args.metric.split(',')]
         self.main_metric = args.main_metric if len(args.main_metric) else '{}@{}'.format(self.metrics[0], self.topk[0])
@@ -103,7 +107,7 @@ class BaseRunner(object):
         on_gpu = next(model.parameters()).is_cuda
         if on_gpu and self.optimizer_name in ('SGD', 'Adam', 'Adagrad'):
             return hnn.HipOptimizer(model.customize_parameters(), self.optimizer_name,
-                                    lr=self.learning_rate, weight_decay=self.l2)
+                                    lr=self.learning_rate, weight_decay=self.l2, capturable=self.use_graph)
         # anything else (Adadelta, CPU debugging) keeps torch's implementation
         return getattr(torch.optim, self.optimizer_name)(
             model.customize_parameters(), lr=self.learning_rate, weight_decay=self.l2)
@@ -193,9 +197,21 @@ class BaseRunner(object):
         model.train()
         losses = list()
         equivariant = getattr(model, 'candidate_permutation_equivariant', False)
+        # hipGraph replay of the dense step: needs a deterministic, host-free step (no dropout, no
+        # host-side candidate shuffle) and the capturable optimizer; one graph per feed-dict shape
+        graphable = (self.use_graph and not rowwise and equivariant and getattr(model, 'dropout', 0) == 0
+                     and isinstance(model.optimizer, hnn.HipOptimizer) and model.optimizer.capturable
+                     and torch.device(model.device).type == 'cuda' and hgraph.usable())
         for batch in self._batches(dataset, self.batch_size, train=True):
             if rowwise:
                 losses.append(model.hip_train_step(batch, self.optimizer_name, self.learning_rate, self.l2).clone())
+                continue
+            if graphable:
+                key = (id(model), hgraph.GraphedStep.signature(batch))
+                step = self._graphed.get(key)
+                if step is None:
+                    step = self._graphed[key] = hgraph.GraphedStep(model)
+                losses.append(step.run(batch))
                 continue
             item_ids = batch['item_id']
             indices = None

@@ -1,3 +1,7 @@
+import os as _os
+
+# hipGraph launches must use the runtime's regular path (rechorus_amd/graph.py); set before HIP initialises
+_os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
 import os
 import sys
 
