@@ -125,6 +125,12 @@ int rc_bce_prob_fwd_bwd(const float* p, const float* y, int64_t n, float inv_n, 
 int rc_softmax_ce_fwd_bwd(const float* pred, const int64_t* target, int B, int n, int max_pos,
                           float* loss_vec, float* h_sum, float* gpred, rc_stream_t stream);
 
+/* Point-wise BCE over a ranking list (ContextModel.loss with loss_n 'BCE', models/BaseContextModel.py:53-56):
+ * loss_vec[b] = -(log sigmoid(pred[b,0]) + sum_{k>=1} log(1 - sigmoid(pred[b,k]))); the loss is their mean
+ * (rc_reduce_sum(loss_vec, B, inv_b)); gpred (optional) = d(mean)/d pred.                                  */
+int rc_bce_ranking_fwd_bwd(const float* pred, int64_t B, int C, float inv_b, float* loss_vec, float* gpred,
+                           rc_stream_t stream);
+
 /* List-level BPR over an impression list (ImpressionModel.loss with loss_n 'BPR' or 'BPRhard' -- the default
  * loss of every *Impression model, models/BaseImpressionModel.py:50-89): per row
  *   Q = sum_{i pos} a_i sum_{j neg} b_j sigmoid(pred_i - pred_j),  a / b = softmax weights over the valid

@@ -60,6 +60,7 @@ SIGNATURES = {
     "rc_fm_second_order_fwd": (_i, [_p, _i64, _i, _i, _p, _p]),
     "rc_fm_second_order_bwd": (_i, [_p, _p, _i64, _i, _i, _p, _p]),
     "rc_gather_fields": (_i, [_p, _p, _p, _p, _i, _i64, _i, _i, _p, _p, _p]),
+    "rc_bce_ranking_fwd_bwd": (_i, [_p, _i64, _i, _f, _p, _p, _p]),
     "rc_bce_prob_fwd_bwd": (_i, [_p, _p, _i64, _f, _p, _p, _p]),
     "rc_sample_negatives": (_i, [_p, _i64, _i, _i64, _p, _p, C.c_uint64, C.c_uint64, _p, _p]),
     "rc_assemble_candidates": (_i, [_p, _i64, _i, _p, _p, _p, _p, _p, _p]),

@@ -191,3 +191,39 @@ extern "C" int rc_gather_fields(const float* const* tables, const int64_t* const
   RC_LAUNCH_CHECK();
   return RC_OK;
 }
+
+// ---- point-wise BCE over a ranking list (ContextModel.loss, loss_n == 'BCE': models/BaseContextModel.py:53-56)
+//   p = sigmoid(prediction);  loss = -mean_b [ log p_b0 + sum_{k>=1} log(1 - p_bk) ]
+// computed through the sigmoid like the reference (not the softplus form), gradient as autograd derives it:
+//   d/dx_b0 = -(1 - p_b0) / B,   d/dx_bk = p_bk / B.   One wave per row.
+namespace rc {
+__global__ __launch_bounds__(kBlock) void bce_ranking_kernel(const float* __restrict__ pred, int64_t B, int C,
+                                                             float inv_b, float* __restrict__ loss_vec,
+                                                             float* __restrict__ gpred) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (row >= B) return;  // wave-uniform
+  const float* x = pred + row * C;
+  float acc = 0.f;
+  for (int c = lane; c < C; c += 64) {
+    const float p = sigmoidf_(x[c]);
+    acc += c == 0 ? logf(p) : logf(1.0f - p);
+    if (gpred) gpred[row * C + c] = (c == 0 ? -(1.0f - p) : p) * inv_b;
+  }
+  acc = wave_allreduce_sum(acc);
+  if (lane == 0) loss_vec[row] = -acc;
+}
+}  // namespace rc
+
+extern "C" int rc_bce_ranking_fwd_bwd(const float* pred, int64_t B, int C, float inv_b, float* loss_vec, float* gpred,
+                                      rc_stream_t stream) {
+  if (B == 0) return RC_OK;
+  RC_REQUIRE(pred && loss_vec, "rc_bce_ranking_fwd_bwd: null pointer");
+  RC_REQUIRE(B > 0 && C >= 1, "rc_bce_ranking_fwd_bwd: bad shape B=%lld C=%d", (long long)B, C);
+  const int64_t blocks = (B + (kBlock / 64) - 1) / (kBlock / 64);
+  RC_REQUIRE(blocks <= kMaxGridX, "rc_bce_ranking_fwd_bwd: too many rows");
+  hipLaunchKernelGGL(bce_ranking_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, as_stream(stream), pred, B, C, inv_b,
+                     loss_vec, gpred);
+  RC_LAUNCH_CHECK();
+  return RC_OK;
+}

@@ -586,6 +586,17 @@ def fm_second_order_bwd(V, gout):
     return dV
 
 
+def bce_ranking(pred, need_grad=True):
+    """ContextModel.loss with loss_n 'BCE' (models/BaseContextModel.py:53-56) -> (loss [1], gpred | None)"""
+    B, Cn = pred.shape
+    f32 = torch.float32
+    loss_vec = torch.empty(B, dtype=f32, device=pred.device)
+    gpred = torch.empty_like(pred) if need_grad else None
+    _lib.call("rc_bce_ranking_fwd_bwd", _ptr(pred, f32, "pred"), B, Cn, 1.0 / B, _ptr(loss_vec, f32, "loss_vec"),
+              _ptr(gpred, f32, "gpred", True), _stream())
+    return reduce_sum(loss_vec, 1.0 / B), gpred
+
+
 def gather_fields(tables, ids, n_cand, want_cid=True):
     """tables: list of F [vocab_f, d] tensors; ids: list of F int64 tensors, [B] (per-row field) or [B, C]
     -> (out [B, C, F, d], cid [B, C, F] | None, row_offset list): all field lookups in one launch"""

@@ -189,6 +189,25 @@ def bce_loss(p, y):
     return _BceProbFn.apply(p, y)
 
 
+class _BceRankingFn(torch.autograd.Function):
+    """ContextModel.loss, loss_n 'BCE' (models/BaseContextModel.py:53-56), closed-form backward"""
+
+    @staticmethod
+    def forward(ctx, pred):
+        loss, gpred = engine.bce_ranking(pred.detach().contiguous())
+        ctx.save_for_backward(gpred)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        (gpred,) = ctx.saved_tensors
+        return gpred * grad_loss
+
+
+def bce_ranking_loss(pred):
+    return _BceRankingFn.apply(pred)
+
+
 class _NeumfFn(torch.autograd.Function):
     """NeuMF head, one hidden layer (models/general/NeuMF.py:61-75): rc_neumf_fwd / rc_neumf_bwd."""
 

@@ -10,6 +10,7 @@ import numpy as np
 import torch
 
 from models.BaseModel import GeneralModel, CTRModel
+from rechorus_amd import nn as hnn
 
 
 def get_context_feature(feed_dict, index, corpus, data):
@@ -51,6 +52,8 @@ class ContextModel(GeneralModel):
         if self.loss_n == 'BPR':
             return super().loss(out_dict)
         if self.loss_n == 'BCE':
+            if out_dict['prediction'].is_cuda:  # one HIP kernel, closed-form backward
+                return hnn.bce_ranking_loss(out_dict['prediction'])
             p = out_dict['prediction'].sigmoid()
             return -(p[:, 0].log() + (1 - p[:, 1:]).log().sum(dim=1)).mean()
         raise ValueError('Undefined loss function: {}'.format(self.loss_n))

@@ -244,3 +244,15 @@ def test_gather_fields_equals_per_field_gathers(cuda):
             else:
                 np.add.at(G, xi.reshape(-1), wf.reshape(-1, d))
             assert_close(t.grad.cpu().numpy(), G, what=f"field {f} grad d={d}", abs_floor=1e-6 * float(np.abs(wf).sum()) / t.shape[0])
+
+
+def test_bce_ranking_kernel_matches_the_reference(cuda):
+    """rc_bce_ranking_fwd_bwd through ContextModel.loss (loss_n='BCE') vs the reference's loss / autograd"""
+    from models.BaseContextModel import ContextModel
+    g = load_golden("context_bce_ranking")
+    for i in range(4):
+        p = torch.from_numpy(g["%d/pred" % i]).to(cuda).requires_grad_(True)
+        loss = ContextModel.loss(argparse.Namespace(loss_n="BCE"), {"prediction": p})
+        loss.backward()
+        assert_close(loss.item(), g["%d/loss" % i], what="loss", rtol=2e-5)
+        assert_close(p.grad.cpu().numpy(), g["%d/gpred" % i], what="grad", rtol=2e-5, atol_scale=2e-5)
