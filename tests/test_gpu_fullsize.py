@@ -153,3 +153,30 @@ def test_adam_rowwise_step_sample_vs_oracle(world):
         assert_update_close(I[r].cpu().numpy()[None], I0[r].cpu().numpy()[None], W, what=f"row {r}",
                             extra_atol=1e-6)
         assert_close(tr.mI[r].cpu().numpy()[None], st["m"], what="exp_avg", atol_scale=1e-4)
+
+
+def test_bench_contract_line(cuda):
+    import os
+    """bench.py prints ONE JSON line with the driver's keys, the roofline object and the CPU baseline"""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--batch", "4096",
+                        "--items", "300001", "--users", "30001", "--cpu-steps", "1"], cwd=ROOT, capture_output=True, text=True,
+                       timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in out, k
+    assert out["n_gpus"] == 1 and out["steps"] == 4 and out["warmup"] == 2 and out["higher_is_better"] is True
+    assert out["vs_baseline"] is None and out["dtype"] == "f32" and out["data"] == "synthetic" and "workload" in out["config"]
+    r = out["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert "traffic" in r and r["achieved"] > 0
+    c = out["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == out["unit"] and c["sample"]
+    assert out["value"] > c["value"]
