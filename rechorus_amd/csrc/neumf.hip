@@ -296,14 +296,48 @@ __global__ __launch_bounds__(kBlock) void neumf_kernel(NeumfArgs a) {
   }
 }
 
-// out[i] = sum_w p[w][i], w ascending (deterministic)
-__global__ __launch_bounds__(kBlock) void neumf_reduce_partials_kernel(const float* __restrict__ p,
-                                                                       int n_wg, int count,
-                                                                       float* __restrict__ out) {
-  for (int i = blockIdx.x * kBlock + threadIdx.x; i < count; i += gridDim.x * kBlock) {
-    float acc = 0.f;
-    for (int w = 0; w < n_wg; ++w) acc += p[(size_t)w * count + i];
-    out[i] = acc;
+// out[i] = sum_w p[w][i] for the three partial arrays of one backward call, in ONE launch.
+// A workgroup owns 64 consecutive outputs: wave v sums the partials w = v, v+4, v+8, ... with four
+// interleaved accumulators (16 independent chains of n_wg/16 adds instead of one chain of n_wg -- the
+// serial version cost 60 us per array, pure latency), then the 16 chain sums are combined in a FIXED
+// order through LDS: deterministic, no float atomics.
+struct ReduceArgs {
+  const float* p[3];
+  float* out[3];
+  int count[3];
+  int first_block[4];  // block ranges of the three arrays
+  int n_wg;
+};
+
+__global__ __launch_bounds__(kBlock) void neumf_reduce_partials_kernel(ReduceArgs r) {
+  __shared__ float sm[4][4][64];
+  int which = 0;
+  while (which < 2 && (int)blockIdx.x >= r.first_block[which + 1]) ++which;  // block-uniform
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int count = r.count[which];
+  const int i = ((int)blockIdx.x - r.first_block[which]) * 64 + lane;
+  const float* __restrict__ p = r.p[which];
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  if (i < count) {
+    int w = wave;
+    for (; w + 12 < r.n_wg; w += 16) {
+      acc[0] += p[(size_t)w * count + i];
+      acc[1] += p[(size_t)(w + 4) * count + i];
+      acc[2] += p[(size_t)(w + 8) * count + i];
+      acc[3] += p[(size_t)(w + 12) * count + i];
+    }
+    for (int k = 0; w < r.n_wg; w += 4, ++k) acc[k] += p[(size_t)w * count + i];
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) sm[wave][k][lane] = acc[k];
+  __syncthreads();
+  if (wave == 0 && i < count) {
+    float total = 0.f;
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) total += sm[v][k][lane];
+    r.out[which][i] = total;
   }
 }
 
@@ -410,12 +444,14 @@ extern "C" int rc_neumf_bwd(const float* mf_u, const float* mf_i, const float* m
   a.pb1 = p + (size_t)n_wg * cW;
   a.pwout = a.pb1 + (size_t)n_wg * cb;
   RC_TRY(dispatch_neumf<true>(a, d, l1, n_wg, s));
-  hipLaunchKernelGGL(neumf_reduce_partials_kernel, dim3((cW + kBlock - 1) / kBlock), dim3(kBlock), 0, s,
-                     a.pW1, n_wg, cW, dW1);
-  RC_LAUNCH_CHECK();
-  hipLaunchKernelGGL(neumf_reduce_partials_kernel, dim3(1), dim3(kBlock), 0, s, a.pb1, n_wg, cb, db1);
-  RC_LAUNCH_CHECK();
-  hipLaunchKernelGGL(neumf_reduce_partials_kernel, dim3(1), dim3(kBlock), 0, s, a.pwout, n_wg, co, dw_out);
+  ReduceArgs r;
+  r.p[0] = a.pW1; r.p[1] = a.pb1; r.p[2] = a.pwout;
+  r.out[0] = dW1; r.out[1] = db1; r.out[2] = dw_out;
+  r.count[0] = cW; r.count[1] = cb; r.count[2] = co;
+  r.first_block[0] = 0;
+  for (int k = 0; k < 3; ++k) r.first_block[k + 1] = r.first_block[k] + (r.count[k] + 63) / 64;
+  r.n_wg = n_wg;
+  hipLaunchKernelGGL(neumf_reduce_partials_kernel, dim3(r.first_block[3]), dim3(kBlock), 0, s, r);
   RC_LAUNCH_CHECK();
   return RC_OK;
 }
