@@ -410,12 +410,36 @@ __global__ __launch_bounds__(kBlock) void sasrec_bwd_kernel(SasArgs a) {
   }
 }
 
+// out[i] = sum_w p[w][i].  A workgroup owns 64 consecutive outputs; wave v sums the partials w = v, v+4, ...
+// with four interleaved accumulators (16 independent chains of n_wg/16 adds instead of ONE chain of n_wg,
+// which was pure load/add latency), then the 16 chain sums are combined in a fixed order through LDS:
+// deterministic, no float atomics.
 __global__ __launch_bounds__(kBlock) void sas_reduce_partials_kernel(const float* __restrict__ p, int n_wg,
                                                                      int count, float* __restrict__ out) {
-  for (int i = blockIdx.x * kBlock + threadIdx.x; i < count; i += gridDim.x * kBlock) {
-    float acc = 0.f;
-    for (int w = 0; w < n_wg; ++w) acc += p[(size_t)w * count + i];
-    out[i] = acc;
+  __shared__ float sm[4][4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = (int)blockIdx.x * 64 + lane;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  if (i < count) {
+    int w = wave;
+    for (; w + 12 < n_wg; w += 16) {
+      acc[0] += p[(size_t)w * count + i];
+      acc[1] += p[(size_t)(w + 4) * count + i];
+      acc[2] += p[(size_t)(w + 8) * count + i];
+      acc[3] += p[(size_t)(w + 12) * count + i];
+    }
+    for (int k = 0; w < n_wg; w += 4, ++k) acc[k] += p[(size_t)w * count + i];
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) sm[wave][k][lane] = acc[k];
+  __syncthreads();
+  if (wave == 0 && i < count) {
+    float total = 0.f;
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) total += sm[v][k][lane];
+    out[i] = total;
   }
 }
 
@@ -493,7 +517,7 @@ static int sas_launch_bwd(const SasArgs& a, float* dense_out, hipStream_t s) {
   RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   hipLaunchKernelGGL(kern, dim3(n_wg), dim3(kBlock), lds_bytes, s, a);
   RC_LAUNCH_CHECK();
-  hipLaunchKernelGGL(sas_reduce_partials_kernel, dim3((count + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a.part,
+  hipLaunchKernelGGL(sas_reduce_partials_kernel, dim3((count + 63) / 64), dim3(kBlock), 0, s, a.part,
                      n_wg, count, dense_out);
   RC_LAUNCH_CHECK();
   return RC_OK;
