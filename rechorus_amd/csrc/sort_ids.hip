@@ -36,11 +36,23 @@ static int key_bits(int64_t key_range) {
   return bits;
 }
 
+// rocPRIM switches from merge sort (block sort + ~log2(n/1024) merge passes, two launches each) to
+// onesweep radix passes at `merge_sort_limit` items, 1 M by default.  Ids are <= 24-bit keys (three 8-bit
+// onesweep passes), and a BPRMF batch of 8,192 tuples x 100 candidates is 0.8 M items: measured there,
+// merge sort is 20 launches / 132 us of a 419 us step.  Measured step times (tools/exp_sort_limit.sh),
+// merge sort vs onesweep: 0.8 M items 0.381 vs 0.345 ms, 0.2 M items 0.214 vs 0.225 ms, 0.1 M items 0.160 vs
+// 0.205 ms -> the switch sits at 512 K items.
+#ifndef RC_MERGE_SORT_LIMIT
+#define RC_MERGE_SORT_LIMIT (512 * 1024)
+#endif
+using SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                              rocprim::default_config, RC_MERGE_SORT_LIMIT>;
+
 static hipError_t sort_call(void* temp, size_t& bytes, const ConcatKey& f, uint32_t* keys_out,
                             uint32_t* perm_out, size_t n, unsigned bits, hipStream_t s) {
   KeyIt keys_in(CountIt(0), f);
   CountIt vals_in(0);
-  return rocprim::radix_sort_pairs(temp, bytes, keys_in, keys_out, vals_in, perm_out, n, 0u, bits, s);
+  return rocprim::radix_sort_pairs<SortConfig>(temp, bytes, keys_in, keys_out, vals_in, perm_out, n, 0u, bits, s);
 }
 
 static size_t rocprim_temp_bytes(int64_t n) {
