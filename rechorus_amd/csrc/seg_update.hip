@@ -211,6 +211,68 @@ __global__ __launch_bounds__(kBlock) void seg_update_kernel(SegArgs a) {
   apply_row4<D, MODE>(a, key, l, w, acc);
 }
 
+// Two heads per lane-group (ONLY_MULTI lists: every head has >= 2 occurrences).  The kernel is bound by
+// the latency of its dependent gathers (head -> keys/perm -> coef/index -> source row), not by bandwidth:
+// interleaving two independent heads doubles the loads in flight per lane.  Same summation order per row as
+// seg_update_kernel, so results are bit-identical.
+template <int D, int MODE>
+__device__ __forceinline__ bool seg_tail(const SegArgs& a, int64_t j, uint32_t key, int l, float4& acc) {
+  const int64_t n = a.n_occ;
+  int64_t jj = j + 2;
+  while (jj < n && a.keys[jj] == key) {
+    if (jj - j >= kLongSeg) {  // hot row: hand over to the chunked path
+      if (l == 0) {
+        const uint32_t slot = atomicAdd(&a.counters[CNT_LONG], 1u);
+        if (slot < a.long_cap) a.long_list[slot] = (uint32_t)j;
+      }
+      return true;
+    }
+    const float4 s = occ_grad4<D>(a, jj, l);
+    add4(acc, s);
+    ++jj;
+  }
+  return false;
+}
+
+#ifndef RC_SEG_HPG
+#define RC_SEG_HPG 2
+#endif
+constexpr int kSegHpg = RC_SEG_HPG;  // heads per lane-group
+
+template <int D, int MODE>
+__global__ __launch_bounds__(kBlock) void seg_update_multi_x2_kernel(SegArgs a) {
+  constexpr int LPR = D / 4;
+  constexpr int GPB = kBlock / LPR;
+  constexpr int H = kSegHpg;
+  const int l = threadIdx.x % LPR;
+  const int64_t nh = (int64_t)*a.n_heads;
+  const int64_t g = ((int64_t)blockIdx.x * GPB + threadIdx.x / LPR) * H;
+  if (g >= nh) return;  // no cross-lane ops in this kernel
+  int64_t j[H];
+  uint32_t key[H], o0[H], o1[H];
+  float4 w[H], acc[H], s1[H];
+#pragma unroll
+  for (int h = 0; h < H; ++h) j[h] = a.heads[g + h < nh ? g + h : g];
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    key[h] = a.keys[j[h]];
+    o0[h] = a.perm[j[h]];
+    o1[h] = a.perm[j[h] + 1];
+  }
+#pragma unroll
+  for (int h = 0; h < H; ++h) w[h] = load_row4<D, MODE>(a, key[h], l);
+#pragma unroll
+  for (int h = 0; h < H; ++h) acc[h] = occ_grad4_o<D>(a, o0[h], l);
+#pragma unroll
+  for (int h = 0; h < H; ++h) s1[h] = occ_grad4_o<D>(a, o1[h], l);
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    if (g + h >= nh) break;
+    add4(acc[h], s1[h]);
+    if (!seg_tail<D, MODE>(a, j[h], key[h], l, acc[h])) apply_row4<D, MODE>(a, key[h], l, w[h], acc[h]);
+  }
+}
+
 // ---- 3. hot rows ----------------------------------------------------------------------------
 // end of the segment that starts at j0 (first index with a different key): gallop + bisect
 __device__ __forceinline__ int64_t segment_end(const uint32_t* __restrict__ keys, int64_t n,
@@ -452,8 +514,15 @@ static int launch_seg(const SegArgs& a, hipStream_t s) {
   const int64_t max_heads = a.skip_single ? (a.n_occ + 1) / 2 : a.n_occ;
   const int64_t blocks = (max_heads + GPB - 1) / GPB;
   if (blocks > kMaxGridX) return fail(RC_ERR_UNSUPPORTED, "seg_update: grid too large");
+#ifndef RC_SEG_X1
+  if (a.skip_single) {
+    const int64_t blocks2 = (max_heads + kSegHpg * GPB - 1) / (kSegHpg * GPB);
+    hipLaunchKernelGGL((seg_update_multi_x2_kernel<D, MODE>), dim3((unsigned)blocks2), dim3(kBlock), 0, s, a);
+  }
+#else
   if (a.skip_single)
     hipLaunchKernelGGL((seg_update_kernel<D, MODE, true>), dim3((unsigned)blocks), dim3(kBlock), 0, s, a);
+#endif
   else
     hipLaunchKernelGGL((seg_update_kernel<D, MODE, false>), dim3((unsigned)blocks), dim3(kBlock), 0, s, a);
   RC_LAUNCH_CHECK();
