@@ -92,15 +92,20 @@ def algorithmic_bytes(args, batches):
         mo += int(cnt[cnt > 1].sum()) / len(batches)          # occurrences of the latter
     uu = float(np.mean([torch.unique(u).numel() for u, _ in batches]))
     row = 4 * d
-    fused = (8 * B + 8 * n_occ + n_occ  # uid, iid, singleton flags
+    # SGD: single-occurrence rows are updated inside the fused kernel; with optimizer state (Adam: m, v;
+    # Adagrad: state_sum) every touched row goes through the segmented update (csrc/train_step.hip)
+    fast_path = args.opt == "SGD"
+    n_state = {"SGD": 0, "Adagrad": 1, "Adam": 2}[args.opt]
+    fused = (8 * B + 8 * n_occ + (n_occ if fast_path else 0)  # uid, iid, singleton flags
              + uu * row + ui * row      # distinct user / item rows, read once
-             + us * row                 # single-occurrence item rows written back updated
+             + (us * row if fast_path else 0)   # single-occurrence item rows written back updated
              + 4 * n_occ + B * row + 4 * B)   # gpred, ugrad, loss_vec written
+    upd_rows, upd_occ = (um, mo) if fast_path else (ui, float(n_occ))
     item_update = (8 * n_occ            # keys + perm of every sorted position
-                   + 12 * mo + 8 * B    # gpred + uid lookups of multi-occurrence rows
+                   + 12 * upd_occ + 8 * B   # gpred + uid lookups of the rows updated here
                    + uu * row           # U rows rebuilt into g*U: distinct rows once
-                   + 2 * um * row)      # multi-occurrence item rows: read + written once
-    user_update = 8 * B + B * row + 2 * uu * row
+                   + 2 * (1 + n_state) * upd_rows * row)  # row (+ state rows): read + written once
+    user_update = 8 * B + B * row + 2 * (1 + n_state) * uu * row
     sort_items = 8 * n_occ + 8 * n_occ  # ids in, keys+perm out (one ideal pass)
     mark = 8 * n_occ + n_occ + 4 * um   # keys + perm in, one flag byte out, multi-row heads out
     return {"fused_fwd_bwd": fused, "item_update": item_update, "user_update": user_update,
@@ -108,12 +113,17 @@ def algorithmic_bytes(args, batches):
             "single_items": us, "multi_items": um, "multi_item_occurrences": mo}
 
 
+def default_workload(args):
+    return (args.opt == "SGD" and args.batch == 65536 and args.num_neg == 99 and args.emb_size == 64
+            and args.items == 10_000_001 and args.users == 1_000_001)
+
+
 def load_pmc_traffic(kernel):
     """HBM bytes per launch from committed rocprofv3 PMC passes (profiles/pmc_latest.json), if any."""
     p = os.path.join(ROOT, "profiles", "pmc_latest.json")
     if not os.path.exists(p):
         return None
-    prefix = {"fused_fwd_bwd": "bprmf_fwd_bwd_kernel", "item_update": "seg_update_kernel",
+    prefix = {"fused_fwd_bwd": "bprmf_fwd_bwd_kernel", "item_update": "seg_update_multi_x2_kernel",
               "user_update": "seg_update_kernel"}.get(kernel, kernel)
     try:
         rows = [v["hbm_bytes_per_launch"] for k, v in json.load(open(p)).items()
@@ -296,7 +306,9 @@ def main():
         achieved = ab[dom] / (acc[dom] * 1e-3) / 1e9
         out["roofline"] = {
             "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBPS, "traffic": load_pmc_traffic(dom),
+            "frac": achieved / HBM_PEAK_GBPS,
+            # the committed PMC passes (tools/pmc_collect.sh) were taken on the default SGD workload
+            "traffic": load_pmc_traffic(dom) if default_workload(args) else None,
             "algorithmic_bytes_per_launch": ab[dom], "avg_ms": acc[dom],
         }
         out["phases_ms"] = {k: round(v, 4) for k, v in acc.items()}
