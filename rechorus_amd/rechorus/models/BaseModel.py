@@ -21,6 +21,36 @@ from rechorus_amd import nn as hnn
 from utils import utils
 
 
+def task_variant(name, task_base, head, reader, runner, log_args, module, forward=None, parse_from=None, doc=None):
+    """Build the class `name` = task base (GeneralModel, SequentialModel, ImpressionModel, ContextCTRModel, ...)
+    + head mixin (the object that owns parameters and scoring: BPRMFBase, SASRecBase, DeepFMBase, ...).
+
+    Every model file of the reference spells this combination out by hand once per task (TopK / Impression
+    / CTR): class attributes, a parse_model_args that chains the two parsers, an __init__ that runs the task
+    base and then the head's `_base_init`, a forward that delegates to the head.  Here it is one call;
+    the resulting class is what main.py looks up by name, with the same attributes.
+      forward    : optional wrapper `f(self, feed_dict, head_forward)` (the CTR variants squash and flatten)
+      parse_from : class whose parse_model_args supplies the task flags (defaults to task_base)"""
+    flags_from = parse_from or task_base
+
+    def parse_model_args(parser):
+        return flags_from.parse_model_args(head.parse_model_args(parser))
+
+    def __init__(self, args, corpus):
+        task_base.__init__(self, args, corpus)
+        self._base_init(args, corpus)
+
+    if forward is None:
+        def run(self, feed_dict):
+            return head.forward(self, feed_dict)
+    else:
+        def run(self, feed_dict):
+            return forward(self, feed_dict, head.forward)
+    body = dict(reader=reader, runner=runner, extra_log_args=list(log_args), __init__=__init__, forward=run,
+                parse_model_args=staticmethod(parse_model_args), __module__=module, __doc__=doc)
+    return type(name, (task_base, head), body)
+
+
 class BaseModel(nn.Module):
     reader, runner = None, None  # helper class names, chosen by concrete models
     extra_log_args = []

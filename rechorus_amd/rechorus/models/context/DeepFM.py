@@ -1,43 +1,25 @@
 """ DeepFM on the HIP engine
 Reference: 'DeepFM: A Factorization-Machine based Neural Network for CTR Prediction', Guo et al., IJCAI 2017.
-Mirror of the reference's models/context/DeepFM.py (same class / arg / state_dict names):
-    python main.py --model_name DeepFM --model_mode CTR --emb_size 64 --layers '[64,64]' --lr 5e-4 --l2 0 \
+Counterpart of the reference's models/context/DeepFM.py (same class / flag / state_dict names), e.g.
+    python main.py --model_name DeepFM --model_mode CTR --emb_size 64 --layers '[512,64]' --loss_n BCE --lr 5e-4 \
         --dataset MIND_Large/MINDCTR --include_item_features 1 --include_situation_features 1 --metric AUC,ACC
-prediction = first-order + FM pairwise term (rc_fm_second_order_*) + MLP over the same stacked
-field vectors (:19-28); the field vectors are gathered once and shared by both branches.
+prediction = first-order term + FM pairwise term (rc_fm_second_order_*) + MLP, all three over the SAME
+stacked field vectors (:19-28), which are gathered once.
 """
-from models.context.WideDeep import WideDeepBase, WideDeepCTR, WideDeepTopK
+from models.BaseContextModel import ContextCTRModel, ContextModel
+from models.BaseModel import task_variant
+from models.context.FM import ctr_forward
+from models.context.WideDeep import WideDeepBase
 from rechorus_amd import nn as hnn
 
 
 class DeepFMBase(WideDeepBase):
     def forward(self, feed_dict):
-        context_vectors, linear_vectors = self._get_embeddings_FM(feed_dict)
-        fm_prediction = hnn.fm_second_order(context_vectors) + linear_vectors
-        deep_prediction = self.deep_layers(context_vectors.flatten(start_dim=-2)).squeeze(dim=-1)
-        return {'prediction': fm_prediction + deep_prediction}
+        field_vectors, first_order = self._get_embeddings_FM(feed_dict)
+        return {'prediction': first_order + hnn.fm_second_order(field_vectors) + self._deep(field_vectors)}
 
 
-class DeepFMCTR(WideDeepCTR, DeepFMBase):
-    reader, runner = 'ContextReader', 'CTRRunner'
-    extra_log_args = ['emb_size', 'layers', 'loss_n']
-
-    def __init__(self, args, corpus):
-        WideDeepCTR.__init__(self, args, corpus)
-
-    def forward(self, feed_dict):
-        out_dict = DeepFMBase.forward(self, feed_dict)
-        out_dict['prediction'] = out_dict['prediction'].view(-1).sigmoid()
-        out_dict['label'] = feed_dict['label'].view(-1)
-        return out_dict
-
-
-class DeepFMTopK(WideDeepTopK, DeepFMBase):
-    reader, runner = 'ContextReader', 'BaseRunner'
-    extra_log_args = ['emb_size', 'layers', 'loss_n']
-
-    def __init__(self, args, corpus):
-        WideDeepTopK.__init__(self, args, corpus)
-
-    def forward(self, feed_dict):
-        return DeepFMBase.forward(self, feed_dict)
+_LOG = ['emb_size', 'layers', 'loss_n']
+DeepFMCTR = task_variant('DeepFMCTR', ContextCTRModel, DeepFMBase, 'ContextReader', 'CTRRunner', _LOG, __name__,
+                         forward=ctr_forward, parse_from=ContextModel)  # (--loss_n quirk: see WideDeep.py)
+DeepFMTopK = task_variant('DeepFMTopK', ContextModel, DeepFMBase, 'ContextReader', 'BaseRunner', _LOG, __name__)

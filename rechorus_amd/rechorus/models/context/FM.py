@@ -16,6 +16,7 @@ import torch
 import torch.nn as nn
 
 from models.BaseContextModel import ContextCTRModel, ContextModel
+from models.BaseModel import task_variant
 from rechorus_amd import nn as hnn
 
 
@@ -28,6 +29,11 @@ class FMBase(object):
     def parse_model_args_FM(parser):
         parser.add_argument('--emb_size', type=int, default=64, help='Size of embedding vectors.')
         return parser
+
+    parse_model_args = parse_model_args_FM  # the head's flags, under the name task_variant chains
+
+    def _base_init(self, args, corpus):
+        self._define_init(args, corpus)
 
     def _define_init_params(self, args, corpus):
         self.vec_size = args.emb_size
@@ -79,38 +85,14 @@ class FMBase(object):
         return {'prediction': linear_value + hnn.fm_second_order(fm_vectors)}
 
 
-class FMCTR(ContextCTRModel, FMBase):
-    reader, runner = 'ContextReader', 'CTRRunner'
-    extra_log_args = ['emb_size', 'loss_n']
-
-    @staticmethod
-    def parse_model_args(parser):
-        parser = FMBase.parse_model_args_FM(parser)
-        return ContextCTRModel.parse_model_args(parser)
-
-    def __init__(self, args, corpus):
-        ContextCTRModel.__init__(self, args, corpus)
-        self._define_init(args, corpus)
-
-    def forward(self, feed_dict):
-        out_dict = FMBase.forward(self, feed_dict)
-        out_dict['prediction'] = out_dict['prediction'].view(-1).sigmoid()
-        out_dict['label'] = feed_dict['label'].view(-1)
-        return out_dict
+def ctr_forward(self, feed_dict, head_forward):
+    """CTR variants: one candidate per row, probability out, label passed through (reference :74-78)"""
+    out = head_forward(self, feed_dict)
+    out['prediction'] = out['prediction'].view(-1).sigmoid()
+    out['label'] = feed_dict['label'].view(-1)
+    return out
 
 
-class FMTopK(ContextModel, FMBase):
-    reader, runner = 'ContextReader', 'BaseRunner'
-    extra_log_args = ['emb_size', 'loss_n']
-
-    @staticmethod
-    def parse_model_args(parser):
-        parser = FMBase.parse_model_args_FM(parser)
-        return ContextModel.parse_model_args(parser)
-
-    def __init__(self, args, corpus):
-        ContextModel.__init__(self, args, corpus)
-        self._define_init(args, corpus)
-
-    def forward(self, feed_dict):
-        return FMBase.forward(self, feed_dict)
+_LOG = ['emb_size', 'loss_n']
+FMCTR = task_variant('FMCTR', ContextCTRModel, FMBase, 'ContextReader', 'CTRRunner', _LOG, __name__, forward=ctr_forward)
+FMTopK = task_variant('FMTopK', ContextModel, FMBase, 'ContextReader', 'BaseRunner', _LOG, __name__)

@@ -13,12 +13,14 @@ import torch
 import torch.nn as nn
 
 from models.BaseImpressionModel import ImpressionSeqModel
-from models.BaseModel import SequentialModel
+from models.BaseModel import SequentialModel, task_variant
 from rechorus_amd import engine, nn as hnn
 from utils import layers
 
 
 class SASRecBase(object):
+    candidate_permutation_equivariant = True  # every candidate is scored on its own
+
     @staticmethod
     def parse_model_args(parser):
         parser.add_argument('--emb_size', type=int, default=64, help='Size of embedding vectors.')
@@ -74,25 +76,6 @@ class SASRecBase(object):
         prediction = hnn.bprmf_scores(his_vector, self.i_embeddings.weight, rows, i_ids)
         return {'prediction': prediction.view(batch_size, -1)}
 
-
-class SASRec(SequentialModel, SASRecBase):
-    reader = 'SeqReader'
-    runner = 'BaseRunner'
-    extra_log_args = ['emb_size', 'num_layers', 'num_heads']
-    candidate_permutation_equivariant = True
-
-    @staticmethod
-    def parse_model_args(parser):
-        parser = SASRecBase.parse_model_args(parser)
-        return SequentialModel.parse_model_args(parser)
-
-    def __init__(self, args, corpus):
-        SequentialModel.__init__(self, args, corpus)
-        self._base_init(args, corpus)
-
-    def forward(self, feed_dict):
-        return SASRecBase.forward(self, feed_dict)
-
     # ---- large-table mode: row-wise update of the item table, dense step of everything small -----------
     def hip_train_step(self, feed_dict, opt_name, lr, l2):
         """encoder fwd/bwd (MFMA) + scoring + BPR loss + ONE segmented pass over candidate and history
@@ -111,21 +94,8 @@ class SASRec(SequentialModel, SASRecBase):
             return tr.step(history.contiguous(), lengths.contiguous(), feed_dict['item_id'].contiguous())
 
 
-class SASRecImpression(ImpressionSeqModel, SASRecBase):
-    """SASRec scored over impression lists (reference :107-122); list-level BPR by default"""
-    reader = 'ImpressionSeqReader'
-    runner = 'ImpressionRunner'
-    extra_log_args = ['emb_size', 'num_layers', 'num_heads']
-
-    @staticmethod
-    def parse_model_args(parser):
-        parser = SASRecBase.parse_model_args(parser)
-        return ImpressionSeqModel.parse_model_args(parser)
-
-    def __init__(self, args, corpus):
-        ImpressionSeqModel.__init__(self, args, corpus)
-        self._base_init(args, corpus)
-
-    def forward(self, feed_dict):
-        return SASRecBase.forward(self, feed_dict)
-
+_LOG = ['emb_size', 'num_layers', 'num_heads']
+SASRec = task_variant('SASRec', SequentialModel, SASRecBase, 'SeqReader', 'BaseRunner', _LOG, __name__,
+                      doc='next-item recommendation with sampled negatives (BPR loss)')
+SASRecImpression = task_variant('SASRecImpression', ImpressionSeqModel, SASRecBase, 'ImpressionSeqReader', 'ImpressionRunner',
+                                _LOG, __name__, doc='SASRec scored over impression lists (list-level BPR by default)')

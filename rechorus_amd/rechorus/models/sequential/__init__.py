@@ -1,6 +1,5 @@
-# model modules are discovered by name, as in the reference (models/general/__init__.py:1-7)
-from os.path import basename, dirname, isfile, join
-import glob
+"""`from models.<package> import *` exposes every model module of this package by name (the reference's
+main.py resolves model classes that way); main.py here imports the module it needs directly."""
+import pkgutil
 
-__all__ = [basename(f)[:-3] for f in glob.glob(join(dirname(__file__), "*.py"))
-           if isfile(f) and not f.endswith('__init__.py')]
+__all__ = [m.name for m in pkgutil.iter_modules(__path__)]
