@@ -172,17 +172,36 @@ __global__ __launch_bounds__(kBlock) void owner_backward_kernel(OwnerArgs a) {
   const uint32_t t = a.t32[j0];
   const float4 u = reinterpret_cast<const float4*>(a.Uall)[(size_t)t * LPR + l];
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int64_t j = j0; j < a.n && a.t32[j] == t; ++j) {
-    const size_t idx = (size_t)a.rows[j] * LPR + l;
-    const float gj = a.g[j];
-    const float4 x = load_stream4(reinterpret_cast<const float4*>(a.I) + idx);
-    float4 s = x;
-    s.x *= gj; s.y *= gj; s.z *= gj; s.w *= gj;
-    acc.x += s.x; acc.y += s.y; acc.z += s.z; acc.w += s.w;
-    if (MODE != MODE_NONE && a.single[j]) {  // nobody else reads or writes this row in this step
-      const float4 grad = make_float4(u.x * gj, u.y * gj, u.z * gj, u.w * gj);
-      opt_row4<MODE>(a.o, a.I, a.M, a.V, idx, x, grad);
+  // four occurrences per trip: their row ids, coefficients and rows are requested together (the loop is
+  // bound by the latency of the dependent loads rows[j] -> I[row]); accumulation stays in ascending order
+  constexpr int U4 = 4;
+  int64_t j = j0;
+  while (j < a.n && a.t32[j] == t) {
+    size_t idx[U4];
+    float gj[U4];
+    float4 x[U4];
+    bool on[U4];
+#pragma unroll
+    for (int q = 0; q < U4; ++q) {
+      on[q] = j + q < a.n && a.t32[j + q] == t;
+      idx[q] = on[q] ? (size_t)a.rows[j + q] * LPR + l : 0;
+      gj[q] = on[q] ? a.g[j + q] : 0.f;
     }
+#pragma unroll
+    for (int q = 0; q < U4; ++q)
+      x[q] = on[q] ? load_stream4(reinterpret_cast<const float4*>(a.I) + idx[q]) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int q = 0; q < U4; ++q) {
+      if (!on[q]) break;  // a run is contiguous: once off, the rest is off
+      float4 s = x[q];
+      s.x *= gj[q]; s.y *= gj[q]; s.z *= gj[q]; s.w *= gj[q];
+      acc.x += s.x; acc.y += s.y; acc.z += s.z; acc.w += s.w;
+      if (MODE != MODE_NONE && a.single[j + q]) {  // nobody else reads or writes this row in this step
+        const float4 grad = make_float4(u.x * gj[q], u.y * gj[q], u.z * gj[q], u.w * gj[q]);
+        opt_row4<MODE>(a.o, a.I, a.M, a.V, idx[q], x[q], grad);
+      }
+    }
+    j += U4;
   }
   reinterpret_cast<float4*>(a.pug)[(size_t)t * LPR + l] = acc;
 }
