@@ -51,6 +51,10 @@ def parse():
     ap.add_argument("--graph", action="store_true", help="replay each step from a captured hipGraph (small batches)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL (the only measurement mode); gloo only to smoke-test N>1 on one GPU")
+    ap.add_argument("--workload", default="bprmf", choices=["bprmf", "neumf"],
+                    help="bprmf = BASELINE configs[1] (the contract workload); neumf = configs[3]: NeuMF emb_size 128, "
+                         "num_neg 4, hidden 64 (pass --items 100000001 --users 10000001 --num-neg 4 --emb-size 128)")
+    ap.add_argument("--hidden", type=int, default=64, help="neumf: size of the hidden layer")
     ap.add_argument("--parallel", default="sharded", choices=["sharded", "replicas"],
                     help="N>1: row-sharded tables + owner-computes exchange (default), or independent replicas")
     return ap.parse_args()
@@ -76,6 +80,29 @@ def make_batches(args, device, seed):
         neg = torch.randint(1, args.items, (args.batch, args.num_neg), generator=gen, device=device)
         out.append((uid.contiguous(), torch.cat([pos, neg], dim=1).contiguous()))
     return out
+
+
+def make_neumf_trainer(args, world, device, engine):
+    """BASELINE configs[3]: NeuMF with its four tables on one GPU (engine.NeumfTrainer) or row-sharded over
+    the ranks with the rows travelling over RCCL (rechorus_amd.sharded.ShardedNeumf)"""
+    d, l1 = args.emb_size, args.hidden
+    if world == 1:
+        gen = torch.Generator(device=device)
+        gen.manual_seed(1234)
+        mk = lambda *shape: torch.empty(shape, device=device).normal_(0, 0.01, generator=gen)
+        P = {"mf_u": mk(args.users, d), "mlp_u": mk(args.users, d), "mf_i": mk(args.items, d), "mlp_i": mk(args.items, d),
+             "W1": mk(l1, 2 * d), "b1": mk(l1), "w_out": mk(d + l1)}
+        return engine.NeumfTrainer(P, opt=args.opt, lr=args.lr, l2=args.l2, rowwise=True)
+    from rechorus_amd.sharded import ShardedNeumf
+    trainer = ShardedNeumf(args.users, args.items, d, l1, opt=args.opt, lr=args.lr, l2=args.l2, device=device, seed=1234)
+    trainer.loss = None
+    _step = trainer.step
+
+    def step_and_keep(uid, iid, _step=_step):
+        trainer.loss = _step(uid, iid)
+        return trainer.loss
+    trainer.step = step_and_keep
+    return trainer
 
 
 def algorithmic_bytes(args, batches):
@@ -200,7 +227,9 @@ def main():
     from rechorus_amd import engine
 
     batches = make_batches(args, device, seed=99 + rank)
-    if world == 1 or args.parallel == "replicas":
+    if args.workload == "neumf":
+        trainer = make_neumf_trainer(args, world, device, engine)
+    elif world == 1 or args.parallel == "replicas":
         gen = torch.Generator(device=device)
         gen.manual_seed(1234 + rank)
         U = torch.empty((args.users, args.emb_size), device=device).normal_(0, 0.01, generator=gen)
@@ -277,7 +306,7 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": f"BPRMF fit step: emb_size={args.emb_size}, num_neg={args.num_neg}, "
+            "workload": f"{'NeuMF (hidden ' + str(args.hidden) + ')' if args.workload == 'neumf' else 'BPRMF'} fit step: emb_size={args.emb_size}, num_neg={args.num_neg}, "
                         f"{args.items}-item / {args.users}-user tables, Zipf(1.0) users+positives, "
                         f"uniform negatives, B={args.batch} tuples/GPU/step, optimizer={args.opt} "
                         f"(row-wise, l2={args.l2:g}), int64 ids, fp32",
@@ -285,7 +314,7 @@ def main():
             "n_items": args.items, "n_users": args.users, "optimizer": args.opt,
             "parallelism": "single GPU" if world == 1 else (
                 f"{world} independent replicas" if args.parallel == "replicas" else
-                f"tables row-sharded over {world} GPUs (id mod W), owner-computes exchange over RCCL, "
+                f"tables row-sharded over {world} GPUs (id mod W), {'rows travel' if args.workload == 'neumf' else 'owner-computes exchange'} over RCCL, "
                 f"global batch {world * args.batch}"),
         },
         "final_loss": loss,
@@ -324,7 +353,7 @@ def main():
             8 * args.batch * (args.num_neg + 2) + 4 * args.batch * (args.num_neg + 1)
         out["step_effective_gbps"] = whole / (out["ms_per_step"] * 1e-3) / 1e9
 
-    if world > 1 and args.parallel == "sharded" and not args.no_roofline:
+    if world > 1 and args.parallel == "sharded" and not args.no_roofline and hasattr(trainer, "timing_ms"):
         # where a sharded step spends its time (cuda events on every rank, outside the timed region):
         # collectives are inside the phases, so this also shows what xGMI costs
         trainer.timing = []
@@ -337,7 +366,7 @@ def main():
         if rank == 0:
             out["sharded_phases_ms"] = {k: round(v, 4) for k, v in acc.items()}
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "bprmf":
         out["cpu_baseline"] = cpu_baseline(args)
 
     if dist is not None:

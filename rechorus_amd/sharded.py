@@ -87,6 +87,16 @@ class HipOps:
                                 src_index=t_idx, div=1, skip_singletons=True, heads=heads, n_heads=n_heads)
         return pug
 
+    # ---- NeuMF head on rows that were moved to the tuples (ShardedNeumf) ------------------------------
+    def neumf_fwd(self, P, uid, iid):
+        return self.e.neumf_fwd(P, uid, iid)
+
+    def neumf_bwd(self, P, uid, iid, gpred):
+        return self.e.neumf_bwd(P, uid, iid, gpred)
+
+    def dense_update(self, W, G, hyper, state):
+        self.e.dense_update(W, G, hyper, state.get("m"), state.get("v"))
+
     def make_hyper(self, **kw):
         return self.e.make_hyper(**kw)
 
@@ -367,3 +377,138 @@ class ShardedBprmf:
         ops.update_rows(self.I, self.sI, flat, Ub, hyper, coef=g.reshape(-1), src_index=t_idx)
         ops.update_rows(self.U, self.sU, uid, pug, hyper)
         return loss_vec.sum().reshape(1) / B
+
+
+# ---- "move the rows": generic row-sharded tables, used where a tuple touches few, wide rows (NeuMF) -------------
+
+class _Route:
+    """where the ids of one lookup live: send order, split sizes both ways, the rows the owner has to read"""
+
+    def __init__(self, ids, world, ops, group):
+        if hasattr(ops, "route"):
+            order, counts, local = ops.route(ids, world, None, 1)
+        else:
+            owner = ids % world
+            order = torch.sort(owner, stable=True).indices
+            counts, local = torch.bincount(owner, minlength=world), ids[order] // world
+        (self.send,), (self.recv,) = _exchange_counts([counts], group)
+        self.order, self.group = order, group
+        self.req, _ = _exchange(local, self.send, group, recv_counts=self.recv)  # local rows this rank must serve
+
+    def fetch(self, tables, ops):
+        """rows of `tables` (this rank's shards, same row space) for the ids of the lookup, in lookup order"""
+        served = torch.cat([ops.gather_rows(T, self.req) for T in tables], dim=1)
+        back = _exchange_back(served, self.recv, self.send, self.group)
+        out = torch.empty_like(back)
+        out[self.order] = back
+        return out
+
+    def push(self, grads):
+        """per-lookup-position gradient rows -> the owners, aligned with self.req"""
+        own, _ = _exchange(grads[self.order], self.send, self.group, recv_counts=self.recv)
+        return own
+
+
+class ShardedNeumf:
+    """NeuMF (one hidden layer) with its four tables sharded by row over W ranks (BASELINE config 4: d = 128,
+    K = 4, 100 M items).  A tuple touches 2 user rows and 2(1+K) item rows of 512 B each, so here the ROWS
+    travel: ids are routed to their owners (rc_route_by_owner + all_to_all), owners gather
+    (rc_gather_rows) and send the rows back, the MFMA head kernels (rc_neumf_fwd / rc_neumf_bwd) run on the
+    compact per-batch row blocks with positional ids, per-occurrence row gradients return along the same
+    route and the owners apply the atomic-free segmented update.  The MLP is replicated: its gradients are
+    all-reduced and every rank takes the same dense step.  One step equals single-table training on the
+    concatenated global batch (tests/test_sharded_gloo.py)."""
+
+    TABLES = ("mf_u", "mlp_u", "mf_i", "mlp_i")
+
+    def __init__(self, n_users, n_items, emb_size, hidden, opt="SGD", lr=1e-3, l2=0.0, device=None, ops=None,
+                 group=None, init_std=0.01, seed=0):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.n_users, self.n_items, self.d, self.l1 = n_users, n_items, emb_size, hidden
+        self.ops = ops if ops is not None else HipOps()
+        self.opt, self.lr, self.l2, self.device = opt, lr, l2, device
+        W = self.world
+        g = torch.Generator(device=device if device is not None else "cpu")
+        g.manual_seed(seed * 1000 + self.rank)
+        mk = lambda *shape: torch.empty(shape, device=device).normal_(0, init_std, generator=g)
+        ru, ri = (n_users + W - 1) // W, (n_items + W - 1) // W
+        self.P = {"mf_u": mk(ru, emb_size), "mlp_u": mk(ru, emb_size), "mf_i": mk(ri, emb_size), "mlp_i": mk(ri, emb_size)}
+        g.manual_seed(seed * 1000 + 999)  # replicated parameters: identical on every rank
+        self.P.update(W1=mk(hidden, 2 * emb_size), b1=mk(hidden), w_out=mk(emb_size + hidden))
+        self.state = {k: self.ops.new_state(v, opt) for k, v in self.P.items()}
+        self.step_count = 0
+
+    def load_global(self, P):
+        """full tables / MLP -> this rank's shards (global row = local * W + rank)"""
+        W, r = self.world, self.rank
+        for k in self.TABLES:
+            shard = P[k][r::W]
+            self.P[k].zero_()
+            self.P[k][: shard.shape[0]].copy_(shard)
+        for k in ("W1", "b1", "w_out"):
+            self.P[k].copy_(P[k].reshape(self.P[k].shape))
+
+    def gather_global(self):
+        out = {}
+        for k in self.TABLES:
+            n = self.n_users if k.endswith("_u") else self.n_items
+            shard = self.P[k]
+            if self.world == 1:
+                out[k] = shard[:n].clone()
+                continue
+            allg = _all_gather_rows(shard, self.world, self.group).view(self.world, shard.shape[0], self.d)
+            out[k] = allg.permute(1, 0, 2).reshape(-1, self.d)[:n].clone()
+        for k in ("W1", "b1", "w_out"):
+            out[k] = self.P[k].clone()
+        return out
+
+    def step(self, uid, iid):
+        """uid [B], iid [B, C]: this rank's tuples (same B everywhere) -> global mean loss, device tensor [1]"""
+        W, ops, d = self.world, self.ops, self.d
+        B, C = iid.shape
+        n_tuples = W * B
+        self.step_count += 1
+        hyper = ops.make_hyper(opt=self.opt, lr=self.lr, l2=self.l2, step=self.step_count)
+        hyper0 = ops.make_hyper(opt=self.opt, lr=self.lr, l2=0.0, step=self.step_count)  # 'bias': no weight decay
+        dev = uid.device
+        if W == 1:
+            ru = rv = None
+            urows = torch.cat([ops.gather_rows(self.P[k], uid) for k in ("mf_u", "mlp_u")], dim=1)
+            irows = torch.cat([ops.gather_rows(self.P[k], iid.reshape(-1)) for k in ("mf_i", "mlp_i")], dim=1)
+        else:
+            ru, rv = _Route(uid, W, ops, self.group), _Route(iid.reshape(-1), W, ops, self.group)
+            urows = ru.fetch([self.P["mf_u"], self.P["mlp_u"]], ops)      # [B, 2d]
+            irows = rv.fetch([self.P["mf_i"], self.P["mlp_i"]], ops)      # [B*C, 2d]
+        # the head kernels see per-batch row blocks as their "tables", ids are positions in them
+        loc = {"mf_u": urows[:, :d].contiguous(), "mlp_u": urows[:, d:].contiguous(),
+               "mf_i": irows[:, :d].contiguous(), "mlp_i": irows[:, d:].contiguous(),
+               "W1": self.P["W1"], "b1": self.P["b1"], "w_out": self.P["w_out"]}
+        pos_u = torch.arange(B, device=dev)
+        pos_i = torch.arange(B * C, device=dev).view(B, C)
+        pred = ops.neumf_fwd(loc, pos_u, pos_i)
+        loss_vec, g = ops.bpr_loss(pred, 1.0 / n_tuples)
+        loss = loss_vec.sum().reshape(1) / n_tuples
+        rows, dense = ops.neumf_bwd(loc, pos_u, pos_i, g)
+        gu = torch.cat([rows["g_mf_u"].view(B, C, d).sum(dim=1), rows["g_mlp_u"].view(B, C, d).sum(dim=1)], dim=1)
+        gi = torch.cat([rows["g_mf_i"], rows["g_mlp_i"]], dim=1)
+        if W > 1:
+            loss = _all_reduce_sum(loss, self.group)
+            own_u, own_i, req_u, req_i = ru.push(gu), rv.push(gi), ru.req, rv.req
+            flat = torch.cat([dense[k].reshape(-1) for k in ("W1", "b1", "w_out")])
+            flat = _all_reduce_sum(flat, self.group)  # replicated MLP: summed gradients, identical step everywhere
+            o = 0
+            for k in ("W1", "b1", "w_out"):
+                n = dense[k].numel()
+                dense[k] = flat[o:o + n].view(dense[k].shape)
+                o += n
+        else:
+            own_u, own_i, req_u, req_i = gu, gi, uid, iid.reshape(-1)
+        for tab, own, req, lo in (("mf_u", own_u, req_u, 0), ("mlp_u", own_u, req_u, d),
+                                  ("mf_i", own_i, req_i, 0), ("mlp_i", own_i, req_i, d)):
+            ops.update_rows(self.P[tab], self.state[tab], req, own[:, lo:lo + d].contiguous(), hyper)
+        for k in ("W1", "b1", "w_out"):
+            ops.dense_update(self.P[k], dense[k].contiguous(), hyper0 if k == "b1" else hyper, self.state[k])
+        return loss
+

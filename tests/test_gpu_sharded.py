@@ -193,3 +193,49 @@ def test_bench_multi_rank_code_path_on_one_gpu(cuda):
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0 and np.isfinite(out["final_loss"])
     assert len(out["sharded_phases_ms"]) == 8
+
+
+def _neumf_worker(rank, world, port, opt, lr, l2, n_users, n_items, d, l1, B, C, steps, out_q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from rechorus_amd.sharded import ShardedNeumf
+        from test_sharded_gloo import _neumf_problem
+        dev = torch.device("cuda:0")
+        rng, P = _neumf_problem(n_users, n_items, d, l1)
+        m = ShardedNeumf(n_users, n_items, d, l1, opt=opt, lr=lr, l2=l2, device=dev)
+        m.load_global({k: torch.from_numpy(v).to(dev) for k, v in P.items()})
+        losses = []
+        for s in range(steps):
+            uid = rng.integers(0, n_users, size=(world, B)).astype(np.int64)
+            iid = rng.integers(0, n_items, size=(world, B, C)).astype(np.int64)
+            iid[:, :, 0] %= 5
+            losses.append(float(m.step(torch.from_numpy(uid[rank]).to(dev), torch.from_numpy(iid[rank]).to(dev))))
+        G = m.gather_global()
+        if rank == 0:
+            out_q.put((losses, {k: v.cpu().numpy() for k, v in G.items()}))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,opt,lr,l2", [(2, "SGD", 0.1, 1e-3), (2, "Adam", 1e-2, 0.0), (1, "SGD", 0.1, 1e-3)])
+def test_sharded_neumf_hip_ops_equal_single_table_training(world, opt, lr, l2, cuda):
+    """ShardedNeumf with the real kernels (routing, gathers, MFMA head on per-batch row blocks, segmented
+    updates), ranks sharing cuda:0 over gloo, vs single-table training of the global batch (numpy oracle)"""
+    from test_sharded_gloo import _neumf_reference
+    shape = dict(n_users=203, n_items=1001, d=64, l1=32, B=96, C=5, steps=2)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_neumf_worker, args=(r, world, port, opt, lr, l2, *shape.values(), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    losses, G = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want_losses, P = _neumf_reference(world, opt, lr, l2, **shape)
+    np.testing.assert_allclose(losses, want_losses, rtol=2e-5)
+    atol = 3e-5 if opt == "Adam" else 2e-6  # Adam: |g| ~ eps elements (see conftest.assert_update_close)
+    for k, v in P.items():
+        np.testing.assert_allclose(G[k], v, rtol=1e-4, atol=atol, err_msg=k)

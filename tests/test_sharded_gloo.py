@@ -135,3 +135,137 @@ def test_single_rank_path_matches_oracle():
     Ug, Ig = m.gather_global()
     np.testing.assert_allclose(Ug.numpy(), U, rtol=1e-5, atol=2e-7)
     np.testing.assert_allclose(Ig.numpy(), I, rtol=1e-5, atol=2e-7)
+
+
+# ---- ShardedNeumf: the rows travel, the MFMA head runs on per-batch row blocks ------------------------------
+
+from oracle import neumf_oracle as NO  # noqa: E402
+
+_NAMES = {"mf_u": "mf_u_embeddings.weight", "mf_i": "mf_i_embeddings.weight", "mlp_u": "mlp_u_embeddings.weight",
+          "mlp_i": "mlp_i_embeddings.weight", "W1": "mlp.0.weight", "b1": "mlp.0.bias"}
+
+
+def _ref_params(P):
+    out = {v: P[k].numpy() if hasattr(P[k], "numpy") else P[k] for k, v in _NAMES.items()}
+    w = P["w_out"].numpy() if hasattr(P["w_out"], "numpy") else P["w_out"]
+    out["prediction.weight"] = w.reshape(1, -1)
+    return out
+
+
+class NeumfOracleOps(OracleOps):
+    """adds the NeuMF head (numpy oracle) and the dense optimizer step to the test double"""
+
+    def neumf_fwd(self, P, uid, iid):
+        pred, _ = NO.forward(_ref_params(P), uid.numpy(), iid.numpy())
+        return torch.from_numpy(pred)
+
+    def neumf_bwd(self, P, uid, iid, gpred):
+        _, G = NO.backward(_ref_params(P), uid.numpy(), iid.numpy(), gpred.numpy())
+        B, C = iid.shape
+        d = P["mf_u"].shape[1]
+
+        def per_occurrence(dense_u):  # the user "table" is the batch block [B, d]: put its gradient on candidate 0
+            out = np.zeros((B, C, d), dtype=np.float32)
+            out[:, 0, :] = dense_u
+            return torch.from_numpy(out.reshape(B * C, d))
+        rows = {"g_mf_u": per_occurrence(G[_NAMES["mf_u"]]), "g_mlp_u": per_occurrence(G[_NAMES["mlp_u"]]),
+                "g_mf_i": torch.from_numpy(G[_NAMES["mf_i"]]), "g_mlp_i": torch.from_numpy(G[_NAMES["mlp_i"]])}
+        dense = {"W1": torch.from_numpy(G["mlp.0.weight"]), "b1": torch.from_numpy(G["mlp.0.bias"]),
+                 "w_out": torch.from_numpy(G["prediction.weight"][0].copy())}
+        return rows, dense
+
+    def dense_update(self, W, G, hyper, state):
+        O.opt_step_dense(W.numpy(), G.numpy(), {k: v.numpy() for k, v in state.items()}, hyper["opt"], hyper["lr"],
+                         hyper["l2"], step=hyper["step"])
+
+
+def _neumf_problem(n_users, n_items, d, l1):
+    rng = np.random.default_rng(9)
+    P = {"mf_u": rng.normal(0, 0.3, (n_users, d)), "mlp_u": rng.normal(0, 0.3, (n_users, d)),
+         "mf_i": rng.normal(0, 0.3, (n_items, d)), "mlp_i": rng.normal(0, 0.3, (n_items, d)),
+         "W1": rng.normal(0, 0.3, (l1, 2 * d)), "b1": rng.normal(0, 0.3, l1), "w_out": rng.normal(0, 0.3, d + l1)}
+    return rng, {k: v.astype(np.float32) for k, v in P.items()}
+
+
+def _neumf_worker(rank, world, port, opt, lr, l2, n_users, n_items, d, l1, B, C, steps, out_q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from rechorus_amd.sharded import ShardedNeumf
+        rng, P = _neumf_problem(n_users, n_items, d, l1)
+        m = ShardedNeumf(n_users, n_items, d, l1, opt=opt, lr=lr, l2=l2, ops=NeumfOracleOps())
+        m.load_global({k: torch.from_numpy(v) for k, v in P.items()})
+        losses = []
+        for s in range(steps):
+            uid = rng.integers(0, n_users, size=(world, B)).astype(np.int64)
+            iid = rng.integers(0, n_items, size=(world, B, C)).astype(np.int64)
+            iid[:, :, 0] %= 5
+            losses.append(float(m.step(torch.from_numpy(uid[rank]), torch.from_numpy(iid[rank]))))
+        G = m.gather_global()
+        if rank == 0:
+            out_q.put((losses, {k: v.numpy() for k, v in G.items()}))
+    finally:
+        dist.destroy_process_group()
+
+
+def _neumf_reference(world, opt, lr, l2, n_users, n_items, d, l1, B, C, steps):
+    """single-table training on the concatenated global batch: row-wise update of the touched table rows,
+    dense step of the MLP ('bias' parameter without weight decay)"""
+    rng, P = _neumf_problem(n_users, n_items, d, l1)
+    st = {k: O.new_state(v, opt) for k, v in P.items()}
+    losses = []
+    for s in range(steps):
+        uid = rng.integers(0, n_users, size=(world, B)).astype(np.int64).reshape(-1)
+        iid = rng.integers(0, n_items, size=(world, B, C)).astype(np.int64)
+        iid[:, :, 0] %= 5
+        iid = iid.reshape(-1, C)
+        R = _ref_params(P)
+        pred, _ = NO.forward(R, uid, iid)
+        losses.append(float(O.bpr_loss(pred)))
+        _, G = NO.backward(R, uid, iid, O.bpr_loss_grad(pred))
+        for k in ("mf_u", "mlp_u"):
+            O.opt_step_dense(P[k], G[_NAMES[k]], st[k], opt, lr, l2, step=s + 1, rows=np.unique(uid))
+        for k in ("mf_i", "mlp_i"):
+            O.opt_step_dense(P[k], G[_NAMES[k]], st[k], opt, lr, l2, step=s + 1, rows=np.unique(iid))
+        O.opt_step_dense(P["W1"], G["mlp.0.weight"], st["W1"], opt, lr, l2, step=s + 1)
+        O.opt_step_dense(P["b1"], G["mlp.0.bias"], st["b1"], opt, lr, 0.0, step=s + 1)
+        O.opt_step_dense(P["w_out"], G["prediction.weight"][0], st["w_out"], opt, lr, l2, step=s + 1)
+    return losses, P
+
+
+@pytest.mark.parametrize("world,opt,lr,l2", [(2, "SGD", 0.1, 1e-3), (3, "Adam", 1e-2, 1e-4)])
+def test_sharded_neumf_equals_single_table_training(world, opt, lr, l2):
+    shape = dict(n_users=19, n_items=37, d=8, l1=6, B=7, C=4, steps=3)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_neumf_worker, args=(r, world, port, opt, lr, l2, *shape.values(), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    losses, G = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want_losses, P = _neumf_reference(world, opt, lr, l2, **shape)
+    np.testing.assert_allclose(losses, want_losses, rtol=5e-6)
+    for k, v in P.items():
+        np.testing.assert_allclose(G[k], v, rtol=2e-5, atol=1e-6, err_msg=k)
+
+
+def test_sharded_neumf_single_rank():
+    from rechorus_amd.sharded import ShardedNeumf
+    shape = dict(n_users=19, n_items=37, d=8, l1=6, B=7, C=4, steps=2)
+    rng, P = _neumf_problem(19, 37, 8, 6)
+    m = ShardedNeumf(19, 37, 8, 6, opt="SGD", lr=0.1, l2=1e-3, ops=NeumfOracleOps())
+    m.load_global({k: torch.from_numpy(v) for k, v in P.items()})
+    losses = []
+    for s in range(2):
+        uid = rng.integers(0, 19, size=(1, 7)).astype(np.int64)
+        iid = rng.integers(0, 37, size=(1, 7, 4)).astype(np.int64)
+        iid[:, :, 0] %= 5
+        losses.append(float(m.step(torch.from_numpy(uid[0]), torch.from_numpy(iid[0]))))
+    want_losses, Pw = _neumf_reference(1, "SGD", 0.1, 1e-3, **shape)
+    np.testing.assert_allclose(losses, want_losses, rtol=5e-6)
+    G = m.gather_global()
+    for k, v in Pw.items():
+        np.testing.assert_allclose(G[k].numpy(), v, rtol=2e-5, atol=1e-6, err_msg=k)
