@@ -10,8 +10,10 @@ time-ordered histories (CSR) are uploaded once; per epoch one kernel samples all
 (rc_sample_negatives) and per batch one or two kernels emit the feed dict on the device
 (rc_assemble_candidates, rc_gather_history).
 
-Only datasets whose feed dict is exactly the reference's standard one are eligible (`eligible()`):
-a model file that overrides `_get_feed_dict` / `collate_batch` keeps the DataLoader path.
+Only datasets whose feed dict is exactly one of the reference's standard ones are eligible (`dataset_kind()`:
+General, Sequential, Context top-k, Context CTR -- the latter two add the user / item / situation feature
+columns, gathered on the device from dense per-id tables); a model file that overrides `_get_feed_dict` /
+`collate_batch` keeps the DataLoader path.
 """
 import numpy as np
 import torch
@@ -77,15 +79,49 @@ def history_csr(corpus, device):
     return cache['history']
 
 
-def eligible(dataset):
-    """True iff the dataset produces exactly the reference's standard General / Sequential feed dict"""
+def dataset_kind(dataset):
+    """'general' | 'sequential' | 'context' | 'ctr' when the dataset produces exactly one of the reference's
+    standard feed dicts (so it can be assembled on the device), else None (DataLoader path)"""
     from models.BaseModel import BaseModel, GeneralModel, SequentialModel  # plugin surface (on sys.path)
+    from models.BaseModel import CTRModel
+    from models.BaseContextModel import ContextCTRModel, ContextModel
     cls = type(dataset)
-    std_feed = (GeneralModel.Dataset._get_feed_dict, SequentialModel.Dataset._get_feed_dict)
-    return (cls._get_feed_dict in std_feed
-            and cls.collate_batch is BaseModel.Dataset.collate_batch
-            and cls.actions_before_epoch is GeneralModel.Dataset.actions_before_epoch
-            and cls.__getitem__ is BaseModel.Dataset.__getitem__)
+    if cls.collate_batch is not BaseModel.Dataset.collate_batch or cls.__getitem__ is not BaseModel.Dataset.__getitem__:
+        return None
+    feed = cls._get_feed_dict
+    sampled = cls.actions_before_epoch is GeneralModel.Dataset.actions_before_epoch
+    if feed is GeneralModel.Dataset._get_feed_dict and sampled:
+        return 'general'
+    if feed is SequentialModel.Dataset._get_feed_dict and sampled:
+        return 'sequential'
+    if feed is ContextModel.Dataset._get_feed_dict and sampled:
+        return 'context'
+    unsampled = cls.actions_before_epoch in (BaseModel.Dataset.actions_before_epoch, CTRModel.Dataset.actions_before_epoch)
+    if feed in (ContextCTRModel.Dataset._get_feed_dict, CTRModel.Dataset._get_feed_dict) and unsampled:
+        return 'ctr'
+    return None
+
+
+def eligible(dataset):
+    return dataset_kind(dataset) is not None
+
+
+def _feature_table(by_id, name, n_rows, device):
+    """{id: {feature: value}} -> dense column [n_rows] on the device (ids without metadata read 0)"""
+    vals = [v[name] for v in by_id.values()]
+    col = np.zeros(n_rows, dtype=np.float64 if any(isinstance(x, float) for x in vals) else np.int64)
+    for i, v in by_id.items():
+        col[i] = v[name]
+    return torch.from_numpy(col).to(device)
+
+
+def context_tables(corpus, device):
+    cache = _corpus_cache(corpus, device)
+    if 'context' not in cache:
+        user = {f: _feature_table(corpus.user_features, f, corpus.n_users, device) for f in corpus.user_feature_names}
+        item = {f: _feature_table(corpus.item_features, f, corpus.n_items, device) for f in corpus.item_feature_names}
+        cache['context'] = (user, item)
+    return cache['context']
 
 
 class DeviceDataset:
@@ -102,14 +138,23 @@ class DeviceDataset:
             return torch.from_numpy(np.asarray(dataset.data[name], dtype=np.int64)).to(device)
 
         self.users, self.items = col('user_id'), col('item_id')
-        self.sequential = type(dataset)._get_feed_dict is SequentialModel.Dataset._get_feed_dict
+        self.kind = dataset_kind(dataset)
+        self.sequential = self.kind == 'sequential'
+        self.labels = col('label') if self.kind == 'ctr' else None
+        self.user_feat = self.item_feat = self.situation = None
+        from models.BaseModel import CTRModel
+        with_features = self.kind == 'context' or (self.kind == 'ctr' and type(dataset)._get_feed_dict
+                                                    is not CTRModel.Dataset._get_feed_dict)
+        if with_features:  # models/BaseContextModel.py:16-30: features next to the ids
+            self.user_feat, self.item_feat = context_tables(corpus, device)
+            self.situation = {f: torch.from_numpy(np.asarray(dataset.data[f])).to(device) for f in corpus.situation_feature_names}
         if self.sequential:
             self.position = col('position')
             self.his_ptr, self.his_items, self.his_times = history_csr(corpus, device)
             self.max_his = model.history_max if model.history_max > 0 else max(1, int(self.position.max()))
         self.neg = None
         self.test_all = bool(getattr(model, 'test_all', 0)) and not self.train
-        if not self.train and not self.test_all:
+        if not self.train and not self.test_all and self.kind != 'ctr':
             self.neg = torch.from_numpy(np.asarray(dataset.data['neg_items'], dtype=np.int64)).to(device).contiguous()
         self._draws = 0
 
@@ -118,6 +163,8 @@ class DeviceDataset:
 
     def sample_negatives(self, seed):
         """all negatives of one epoch, like actions_before_epoch (models/BaseModel.py:206-214)"""
+        if self.kind == 'ctr':  # labelled data: nothing to sample
+            return None
         ptr, flat = clicked_csr(self.dataset.corpus, self.device, 'train')
         self.neg = engine.sample_negatives(self.users, self.num_neg, self.n_items, ptr, flat, seed=seed,
                                            base_index=self._draws, out=self.neg)
@@ -127,7 +174,9 @@ class DeviceDataset:
     def feed(self, idx):
         """the feed dict of rows `idx` (int64 device tensor), as collate_batch would build it"""
         B = idx.numel()
-        if self.test_all:  # candidates = target + every item (models/BaseModel.py:194-195)
+        if self.kind == 'ctr':  # one labelled (user, item) pair per row (models/BaseModel.py:276-284)
+            user_id, item_id = self.users[idx], self.items[idx, None]
+        elif self.test_all:  # candidates = target + every item (models/BaseModel.py:194-195)
             user_id = self.users[idx]
             everything = torch.arange(1, self.n_items, device=self.device).expand(B, -1)
             item_id = torch.cat([self.items[idx, None], everything], dim=1)
@@ -138,6 +187,15 @@ class DeviceDataset:
             hist, times, lengths = engine.gather_history(idx, self.users, self.position, self.his_ptr, self.his_items,
                                                          self.max_his, his_times=self.his_times)
             feed.update(history_items=hist, history_times=times, lengths=lengths)
+        if self.labels is not None:
+            feed['label'] = self.labels[idx, None]
+        if self.user_feat is not None:
+            for f, col in self.user_feat.items():
+                feed[f] = col[user_id]              # [B]
+            for f, col in self.situation.items():
+                feed[f] = col[idx]                  # [B]
+            for f, col in self.item_feat.items():
+                feed[f] = col[item_id]              # [B, C]
         feed['batch_size'] = B
         feed['phase'] = self.phase
         return feed

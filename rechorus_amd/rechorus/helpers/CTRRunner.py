@@ -6,11 +6,9 @@ from typing import Dict
 
 import numpy as np
 import torch
-from torch.utils.data import DataLoader
 
 from helpers.BaseRunner import BaseRunner
 from models.BaseModel import BaseModel
-from utils import utils
 
 
 class CTRRunner(BaseRunner):
@@ -48,11 +46,8 @@ class CTRRunner(BaseRunner):
         model.eval()
         model.phase = 'eval'
         preds, labels = list(), list()
-        dl = DataLoader(dataset, batch_size=self.eval_batch_size, shuffle=False, num_workers=self.num_workers,
-                        collate_fn=dataset.collate_batch, pin_memory=self.pin_memory)
         with torch.no_grad():
-            for batch in dl:
-                batch = utils.batch_to_gpu(batch, model.device)
+            for batch in self._batches(dataset, self.eval_batch_size, train=False):  # device pipeline or DataLoader
                 out = model.inference(batch) if hasattr(model, 'inference') else model(batch)
                 preds.append(out['prediction'].reshape(-1))
                 labels.append(out['label'].reshape(-1))

@@ -23,3 +23,4 @@ _LOG = ['emb_size', 'layers', 'loss_n']
 DeepFMCTR = task_variant('DeepFMCTR', ContextCTRModel, DeepFMBase, 'ContextReader', 'CTRRunner', _LOG, __name__,
                          forward=ctr_forward, parse_from=ContextModel)  # (--loss_n quirk: see WideDeep.py)
 DeepFMTopK = task_variant('DeepFMTopK', ContextModel, DeepFMBase, 'ContextReader', 'BaseRunner', _LOG, __name__)
+DeepFMCTR.candidate_permutation_equivariant = True  # one candidate per row: nothing to shuffle in fit()

@@ -96,3 +96,4 @@ def ctr_forward(self, feed_dict, head_forward):
 _LOG = ['emb_size', 'loss_n']
 FMCTR = task_variant('FMCTR', ContextCTRModel, FMBase, 'ContextReader', 'CTRRunner', _LOG, __name__, forward=ctr_forward)
 FMTopK = task_variant('FMTopK', ContextModel, FMBase, 'ContextReader', 'BaseRunner', _LOG, __name__)
+FMCTR.candidate_permutation_equivariant = True  # one candidate per row: nothing to shuffle in fit()

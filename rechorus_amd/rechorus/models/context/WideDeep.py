@@ -47,3 +47,4 @@ _LOG = ['emb_size', 'layers', 'loss_n']
 WideDeepCTR = task_variant('WideDeepCTR', ContextCTRModel, WideDeepBase, 'ContextReader', 'CTRRunner', _LOG, __name__,
                            forward=ctr_forward, parse_from=ContextModel)
 WideDeepTopK = task_variant('WideDeepTopK', ContextModel, WideDeepBase, 'ContextReader', 'BaseRunner', _LOG, __name__)
+WideDeepCTR.candidate_permutation_equivariant = True  # one candidate per row: nothing to shuffle in fit()

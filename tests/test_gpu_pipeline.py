@@ -181,3 +181,55 @@ def test_graph_replayed_training_equals_eager_training(model_name, extra, opt, d
         assert np.allclose(a, b, rtol=1e-4, atol=2e-6), (k, np.abs(a - b).max())
         if opt == "SGD":
             assert np.array_equal(a, b), k  # same kernels, same order: bit-identical
+
+
+@pytest.fixture(scope="module")
+def ctx_root(tmp_path_factory):
+    from synth_data import make_context_dataset
+    root = str(tmp_path_factory.mktemp("pipe_ctx"))
+    make_context_dataset(root, "ctr", n_users=90, n_items=70, per_user=12, ctr=True, seed=3)
+    make_context_dataset(root, "topk", n_users=90, n_items=70, per_user=10, ctr=False, seed=4)
+    return root
+
+
+@pytest.mark.parametrize("mode,dataset", [("CTR", "ctr"), ("TopK", "topk")])
+def test_context_device_batches_equal_the_collated_ones(mode, dataset, ctx_root, cuda):
+    """context features (user / item / situation columns) gathered on the device == the reference-style
+    Dataset -> collate_batch path, for the CTR and the top-k feed dicts"""
+    import main
+    from helpers.BaseRunner import BaseRunner
+    from rechorus_amd import pipeline
+    model_cls = main.find_class("model", ("DeepFM", mode))
+    reader_cls = main.find_class("helper", model_cls.reader)
+    runner_cls = main.find_class("helper", model_cls.runner)
+    p = main.parse_global_args(argparse.ArgumentParser())
+    p = reader_cls.parse_data_args(p)
+    p = runner_cls.parse_runner_args(p)
+    p = model_cls.parse_model_args(p)
+    args = p.parse_args(["--path", ctx_root + "/", "--dataset", dataset, "--emb_size", "16", "--layers", "[16]", "--num_neg", "3",
+                         "--loss_n", "BCE" if mode == "CTR" else "BPR", "--num_workers", "0", "--include_item_features", "1",
+                         "--include_user_features", "1", "--include_situation_features", "1", "--metric", "AUC" if mode == "CTR" else "NDCG,HR"])
+    args.device, args.model_path, args.log_file, args.train = cuda, "/tmp/rechorus_amd_test/m.pt", "/tmp/rechorus_amd_test/l.txt", 1
+    corpus = reader_cls(args)
+    model = model_cls(args, corpus).to(cuda)
+    runner = runner_cls(args)
+    for phase in ("dev", "test") + (("train",) if mode == "CTR" else ()):
+        ds = model_cls.Dataset(model, corpus, phase)
+        ds.prepare()
+        assert pipeline.dataset_kind(ds) == ("ctr" if mode == "CTR" else "context")
+        dd = pipeline.device_dataset(ds, cuda)
+        feed = dd.feed(torch.arange(len(ds), device=cuda))
+        want = ds.collate_batch([ds[i] for i in range(len(ds))])
+        assert set(feed) == set(want), (sorted(feed), sorted(want))
+        for k, v in want.items():
+            if isinstance(v, torch.Tensor):
+                assert torch.equal(feed[k].cpu(), v), k
+            else:
+                assert feed[k] == v, k
+    # and training runs on it
+    tr = model_cls.Dataset(model, corpus, "train")
+    l1 = runner.fit(tr, epoch=1)
+    l2 = runner.fit(tr, epoch=2)
+    assert np.isfinite(l1) and np.isfinite(l2)
+    res = runner.evaluate(model_cls.Dataset(model, corpus, "dev"), [5], runner.metrics)
+    assert all(np.isfinite(v) for v in res.values())
