@@ -60,7 +60,28 @@ def clicked_csr(corpus, device, which='train'):
     return cache[key]
 
 
-def history_csr(corpus, device):
+def _padded(lists, width):
+    out = np.zeros((len(lists), width), dtype=np.int64)
+    for r, items in enumerate(lists):
+        items = items[:width]
+        out[r, :len(items)] = items
+    return out
+
+
+def history_csr(corpus, device, which=None):
+    """time-ordered (item, time) histories as CSR; `which` = 'pos' / 'neg' for the impression readers, whose
+    user_his holds clicked and skipped items separately (helpers/ImpressionSeqReader.py)"""
+    if which is not None:
+        cache = _corpus_cache(corpus, device)
+        key = 'history_' + which
+        if key not in cache:
+            class _View:  # same shape as SeqReader.user_his
+                pass
+            view = _View()
+            view.n_users = corpus.n_users
+            view.user_his = {u: h[which] for u, h in corpus.user_his.items()}
+            cache[key] = history_csr(view, device)
+        return cache[key]
     cache = _corpus_cache(corpus, device)
     if 'history' not in cache:
         n = corpus.n_users
@@ -86,9 +107,11 @@ def dataset_kind(dataset):
     from models.BaseModel import CTRModel
     from models.BaseContextModel import ContextCTRModel, ContextModel
     cls = type(dataset)
-    if cls.collate_batch is not BaseModel.Dataset.collate_batch or cls.__getitem__ is not BaseModel.Dataset.__getitem__:
+    if cls.__getitem__ is not BaseModel.Dataset.__getitem__:
         return None
     feed = cls._get_feed_dict
+    if cls.collate_batch is not BaseModel.Dataset.collate_batch:
+        return _impression_kind(cls, feed)
     sampled = cls.actions_before_epoch is GeneralModel.Dataset.actions_before_epoch
     if feed is GeneralModel.Dataset._get_feed_dict and sampled:
         return 'general'
@@ -99,6 +122,17 @@ def dataset_kind(dataset):
     unsampled = cls.actions_before_epoch in (BaseModel.Dataset.actions_before_epoch, CTRModel.Dataset.actions_before_epoch)
     if feed in (ContextCTRModel.Dataset._get_feed_dict, CTRModel.Dataset._get_feed_dict) and unsampled:
         return 'ctr'
+    return None
+
+
+def _impression_kind(cls, feed):
+    from models.BaseImpressionModel import ImpressionModel, ImpressionSeqModel
+    listed = cls.actions_before_epoch in (ImpressionModel.Dataset.actions_before_epoch,
+                                          ImpressionSeqModel.Dataset.actions_before_epoch)
+    if listed and feed is ImpressionModel.Dataset._get_feed_dict and cls.collate_batch is ImpressionModel.Dataset.collate_batch:
+        return 'impression'
+    if listed and feed is ImpressionSeqModel.Dataset._get_feed_dict and cls.collate_batch is ImpressionSeqModel.Dataset.collate_batch:
+        return 'impression_seq'
     return None
 
 
@@ -152,9 +186,20 @@ class DeviceDataset:
             self.position = col('position')
             self.his_ptr, self.his_items, self.his_times = history_csr(corpus, device)
             self.max_his = model.history_max if model.history_max > 0 else max(1, int(self.position.max()))
+        self.impression = self.kind in ('impression', 'impression_seq')
+        if self.impression:  # fixed-width positive / negative lists, right-padded with item 0 (collate_batch :190-201)
+            self.lists = torch.from_numpy(np.concatenate(
+                [_padded(dataset.data['pos_items'], dataset.pos_len), _padded(dataset.data['neg_items'], dataset.neg_len)],
+                axis=1)).to(device)
+            self.pos_num = torch.clamp(col('pos_num'), max=dataset.pos_len)
+            self.neg_num = torch.clamp(col('neg_num'), max=dataset.neg_len)
+        if self.kind == 'impression_seq':
+            self.position, self.neg_position = col('position'), col('neg_position')
+            self.his_pos, self.his_neg = history_csr(corpus, device, 'pos'), history_csr(corpus, device, 'neg')
+            self.max_his = model.history_max if model.history_max > 0 else max(1, int(self.position.max()))
         self.neg = None
         self.test_all = bool(getattr(model, 'test_all', 0)) and not self.train
-        if not self.train and not self.test_all and self.kind != 'ctr':
+        if not self.train and not self.test_all and self.kind != 'ctr' and not self.impression:
             self.neg = torch.from_numpy(np.asarray(dataset.data['neg_items'], dtype=np.int64)).to(device).contiguous()
         self._draws = 0
 
@@ -163,7 +208,7 @@ class DeviceDataset:
 
     def sample_negatives(self, seed):
         """all negatives of one epoch, like actions_before_epoch (models/BaseModel.py:206-214)"""
-        if self.kind == 'ctr':  # labelled data: nothing to sample
+        if self.kind == 'ctr' or self.impression:  # labelled data / impressions bring their own negatives
             return None
         ptr, flat = clicked_csr(self.dataset.corpus, self.device, 'train')
         self.neg = engine.sample_negatives(self.users, self.num_neg, self.n_items, ptr, flat, seed=seed,
@@ -174,6 +219,8 @@ class DeviceDataset:
     def feed(self, idx):
         """the feed dict of rows `idx` (int64 device tensor), as collate_batch would build it"""
         B = idx.numel()
+        if self.impression:
+            return self._impression_feed(idx)
         if self.kind == 'ctr':  # one labelled (user, item) pair per row (models/BaseModel.py:276-284)
             user_id, item_id = self.users[idx], self.items[idx, None]
         elif self.test_all:  # candidates = target + every item (models/BaseModel.py:194-195)
@@ -197,6 +244,19 @@ class DeviceDataset:
             for f, col in self.item_feat.items():
                 feed[f] = col[item_id]              # [B, C]
         feed['batch_size'] = B
+        feed['phase'] = self.phase
+        return feed
+
+    def _impression_feed(self, idx):
+        """models/BaseImpressionModel.py Dataset._get_feed_dict + collate_batch: positives then negatives"""
+        feed = {'user_id': self.users[idx], 'item_id': self.lists[idx], 'pos_num': self.pos_num[idx],
+                'neg_num': self.neg_num[idx]}
+        if self.kind == 'impression_seq':
+            for prefix, position, (ptr, items, times) in (('', self.position, self.his_pos),
+                                                          ('neg_', self.neg_position, self.his_neg)):
+                hist, tms, lengths = engine.gather_history(idx, self.users, position, ptr, items, self.max_his, his_times=times)
+                feed[prefix + 'history_items'], feed[prefix + 'history_times'], feed[prefix + 'lengths'] = hist, tms, lengths
+        feed['batch_size'] = idx.numel()
         feed['phase'] = self.phase
         return feed
 

@@ -11,11 +11,9 @@ from typing import Dict
 
 import numpy as np
 import torch
-from torch.utils.data import DataLoader
 
 from helpers.BaseRunner import BaseRunner
 from models.BaseModel import BaseModel
-from utils import utils
 
 
 def _ranked_labels(predictions, pos_num, neg_num, pos_num_max):
@@ -100,13 +98,9 @@ class ImpressionRunner(BaseRunner):
         model = data.model
         if model.optimizer is None:
             model.optimizer = self._build_optimizer(model)
-        data.actions_before_epoch()
         model.train()
         losses = list()
-        dl = DataLoader(data, batch_size=self.batch_size, shuffle=True, num_workers=self.num_workers,
-                        collate_fn=data.collate_batch, pin_memory=self.pin_memory)
-        for batch in dl:
-            batch = utils.batch_to_gpu(batch, model.device)
+        for batch in self._batches(data, self.batch_size, train=True):  # device pipeline, or DataLoader for custom datasets
             model.optimizer.zero_grad()
             out_dict = model(batch)
             pred = out_dict['prediction']

@@ -84,3 +84,44 @@ def test_cli_sasrec_impression(tmp_path, cuda):
     losses = [float(x) for x in re.findall(r"Epoch \d+\s+loss=([0-9.]+)", text)]
     assert len(losses) >= 2 and losses[-1] < losses[0], losses
     assert "NDCG@2" in res["test"] and "MAP@5" in res["test"]
+
+
+@pytest.mark.parametrize("model_name,extra", [("BPRMF", []), ("SASRec", ["--history_max", "5", "--num_heads", "2"])])
+def test_impression_device_batches_equal_the_collated_ones(model_name, extra, tmp_path, cuda):
+    """impression lists (+ clicked / skipped histories) assembled on the device == Dataset -> collate_batch"""
+    import main
+    from rechorus_amd import pipeline
+    make_impression_dataset(str(tmp_path), "imp", n_users=60, n_items=80, n_imp=9, seed=6)
+    model_cls = main.find_class("model", (model_name, "Impression"))
+    reader_cls = main.find_class("helper", model_cls.reader)
+    runner_cls = main.find_class("helper", model_cls.runner)
+    p = main.parse_global_args(argparse.ArgumentParser())
+    p = reader_cls.parse_data_args(p)
+    p = runner_cls.parse_runner_args(p)
+    p = model_cls.parse_model_args(p)
+    args = p.parse_args(["--path", str(tmp_path) + "/", "--dataset", "imp", "--emb_size", "32", "--num_workers", "0",
+                         "--train_max_pos_item", "3", "--train_max_neg_item", "4", "--test_max_pos_item", "2",
+                         "--test_max_neg_item", "5", "--metric", "NDCG,HR", "--topk", "1,2"] + extra)
+    args.device, args.model_path, args.log_file, args.train = cuda, "/tmp/rechorus_amd_test/m.pt", "/tmp/rechorus_amd_test/l.txt", 1
+    corpus = reader_cls(args)
+    model = model_cls(args, corpus).to(cuda)
+    runner = runner_cls(args)
+    for phase in ("train", "dev"):
+        ds = model_cls.Dataset(model, corpus, phase)
+        ds.prepare()
+        assert pipeline.dataset_kind(ds) == ("impression" if model_name == "BPRMF" else "impression_seq")
+        feed = pipeline.device_dataset(ds, cuda).feed(torch.arange(len(ds), device=cuda))
+        want = ds.collate_batch([ds[i] for i in range(len(ds))])
+        assert set(feed) == set(want), (sorted(feed), sorted(want))
+        for k, v in want.items():
+            if not isinstance(v, torch.Tensor):
+                assert feed[k] == v, k
+            elif "history" in k:  # the reference pads to the batch maximum, the device to history_max
+                w = v.shape[1]
+                assert torch.equal(feed[k][:, :w].cpu(), v) and not feed[k][:, w:].any(), k
+            else:
+                assert torch.equal(feed[k].cpu(), v), k
+    tr = model_cls.Dataset(model, corpus, "train")
+    assert np.isfinite(runner.fit(tr, epoch=1))
+    res = runner.evaluate(model_cls.Dataset(model, corpus, "dev"), [1, 2], ["NDCG", "HR"])
+    assert set(res) == {"NDCG@1", "NDCG@2", "MAP@1", "MAP@2", "HR@1", "HR@2"}
