@@ -57,20 +57,40 @@ def find_class(kind, name):
 
 
 def save_rec_results(args, init_args, dataset, runner, topk):
-    """top-k recommendation lists per test/dev instance (TopK mode of the reference :98-153)"""
+    """per-instance predictions of the dev / test set as csv (reference main.py:98-153): top-k lists for
+    ranking models, pCTR + label for CTR models, the scored positive / negative lists for impression models"""
     name = init_args.model_name + init_args.model_mode
     path = os.path.join(runner.log_path, runner.save_appendix, 'rec-{}-{}.csv'.format(name, dataset.phase))
     utils.check_dir(path)
-    if init_args.model_mode not in ('TopK', ''):
+    mode = init_args.model_mode
+    if mode == 'CTR':
+        logging.info('Saving CTR prediction results to: {}'.format(path))
+        predictions, labels = runner.predict(dataset)
+        df = pd.DataFrame({'user_id': dataset.data['user_id'], 'item_id': dataset.data['item_id'],
+                           'pCTR': predictions, 'label': labels})
+    elif mode in ('TopK', ''):
+        logging.info('Saving top-{} recommendation results to: {}'.format(topk, path))
+        predictions = runner.predict(dataset)
+        rows = []
+        for i in range(len(dataset)):
+            info = dataset[i]
+            order = (-predictions[i]).argsort(kind='stable')[:topk]
+            rows.append((info['user_id'], [info['item_id'][j] for j in order], [predictions[i][j] for j in order]))
+        df = pd.DataFrame(rows, columns=['user_id', 'rec_items', 'rec_predictions'])
+    elif mode in ('Impression', 'General', 'Sequential'):
+        logging.info('Saving all recommendation results to: {}'.format(path))
+        predictions = runner.predict(dataset)
+        rows = []
+        for i in range(len(dataset)):
+            info = dataset[i]
+            # (the reference writes predictions[i][:neg_len] into neg_predictions, i.e. the POSITIVE slots
+            # again, main.py:143; the negatives' own scores start at pos_len)
+            rows.append((info['user_id'], list(info['pos_items']), list(predictions[i][:dataset.pos_len]),
+                         list(info['neg_items']), list(predictions[i][dataset.pos_len:dataset.pos_len + dataset.neg_len])))
+        df = pd.DataFrame(rows, columns=['user_id', 'pos_items', 'pos_predictions', 'neg_items', 'neg_predictions'])
+    else:
         return 0
-    logging.info('Saving top-{} recommendation results to: {}'.format(topk, path))
-    predictions = runner.predict(dataset)
-    rows = []
-    for i in range(len(dataset)):
-        info = dataset[i]
-        order = (-predictions[i]).argsort(kind='stable')[:topk]
-        rows.append((info['user_id'], [info['item_id'][j] for j in order], [predictions[i][j] for j in order]))
-    pd.DataFrame(rows, columns=['user_id', 'rec_items', 'rec_predictions']).to_csv(path, sep=args.sep, index=False)
+    df.to_csv(path, sep=args.sep, index=False)
     logging.info('{} Prediction results saved!'.format(dataset.phase))
 
 

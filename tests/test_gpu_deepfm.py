@@ -192,8 +192,10 @@ def test_cli_deepfm_ctr(ctx_root, tmp_path, cuda):
                     "--l2", "0", "--loss_n", "BCE", "--dataset", "ctr", "--path", ctx_root + "/", "--epoch", "8",
                     "--batch_size", "256", "--num_workers", "0", "--regenerate", "1", "--metric", "AUC,ACC,LOG_LOSS",
                     "--include_item_features", "1", "--include_user_features", "1", "--include_situation_features", "1",
-                    "--log_file", log, "--model_path", str(tmp_path / "model" / "m.pt"), "--save_final_results", "0"])
+                    "--log_file", log, "--model_path", str(tmp_path / "model" / "m.pt"), "--save_final_results", "1"])
     text = open(log).read()
+    rec = (tmp_path / "log" / "run" / "rec-DeepFMCTR-test.csv").read_text().splitlines()
+    assert rec[0].split("\t") == ["user_id", "item_id", "pCTR", "label"] and len(rec) > 100
     losses = [float(x) for x in re.findall(r"Epoch \d+\s+loss=([0-9.]+)", text)]
     assert len(losses) >= 2 and losses[-1] < losses[0], losses
     before = float(re.search(r"Test Before Training: \(.*?AUC:([0-9.]+)", text).group(1))

@@ -61,8 +61,10 @@ def test_cli_bprmf_impression(tmp_path, cuda):
     res = main.run(["--model_name", "BPRMF", "--model_mode", "Impression", "--emb_size", "32", "--lr", "5e-3", "--l2", "0",
                     "--loss_n", "BPR", "--dataset", "imp", "--path", str(tmp_path) + "/", "--epoch", "8", "--batch_size", "128",
                     "--num_workers", "0", "--regenerate", "1", "--metric", "NDCG,HR", "--topk", "1,2,3,5", "--main_metric", "NDCG@2",
-                    "--log_file", log, "--model_path", str(tmp_path / "model" / "m.pt"), "--save_final_results", "0"])
+                    "--log_file", log, "--model_path", str(tmp_path / "model" / "m.pt"), "--save_final_results", "1"])
     text = open(log).read()
+    rec = (tmp_path / "log" / "run" / "rec-BPRMFImpression-dev.csv").read_text().splitlines()
+    assert rec[0].split("\t") == ["user_id", "pos_items", "pos_predictions", "neg_items", "neg_predictions"] and len(rec) > 10
     losses = [float(x) for x in re.findall(r"Epoch \d+\s+loss=([0-9.]+)", text)]
     assert len(losses) >= 2 and losses[-1] < losses[0], losses
     before = float(re.search(r"Test Before Training: \(.*?NDCG@2:([0-9.]+)", text).group(1))
