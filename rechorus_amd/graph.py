@@ -24,6 +24,9 @@ import torch
 
 _ENV = "DEBUG_CLR_GRAPH_PACKET_CAPTURE"
 _OK = False
+# eager steps on the default stream after a capture (the last, smaller batch of an epoch) meet AccumulateGrad
+# nodes that autograd created on the capture stream; the streams are joined correctly, the notice is noise
+warnings.filterwarnings("ignore", message="The AccumulateGrad node's stream does not match")
 
 
 def _hsa_initialised():
