@@ -179,3 +179,35 @@ def test_mlp_block_layout_matches_reference_keys():
     assert sorted(m.state_dict()) == ["mlp.0.bias", "mlp.0.weight", "mlp.3.bias", "mlp.3.weight", "mlp.6.bias", "mlp.6.weight"]
     m = MLP_Block(12, [8], hidden_activations="Dice", batch_norm=True, output_dim=None)
     assert "mlp.2.alpha" in m.state_dict() and "mlp.1.running_mean" in m.state_dict()
+
+
+def test_pipeline_host_side_pieces(corpus, ctx_corpus, tmp_path):
+    """rechorus_amd.pipeline: which datasets may be assembled on the device, and its host-built tables"""
+    import torch
+    from models.BaseContextModel import ContextCTRModel, ContextModel
+    from models.BaseModel import GeneralModel, SequentialModel
+    from rechorus_amd import pipeline
+    stub = _model_stub(corpus)
+    assert pipeline.dataset_kind(GeneralModel.Dataset(stub, corpus, "train")) == "general"
+    assert pipeline.dataset_kind(SequentialModel.Dataset(stub, corpus, "dev")) == "sequential"
+    assert pipeline.dataset_kind(ContextCTRModel.Dataset(argparse.Namespace(buffer=0), ctx_corpus, "train")) == "ctr"
+
+    class Custom(GeneralModel.Dataset):  # a model file with its own feed dict keeps the DataLoader path
+        def _get_feed_dict(self, index):
+            return super()._get_feed_dict(index)
+    assert pipeline.dataset_kind(Custom(stub, corpus, "train")) is None and not pipeline.eligible(Custom(stub, corpus, "train"))
+
+    ptr, flat = pipeline._csr({1: {5, 3, 9}, 3: {2}}, 5, torch.device("cpu"))
+    assert ptr.tolist() == [0, 0, 3, 3, 4, 4] and flat.tolist() == [3, 5, 9, 2]
+    ptr, flat = pipeline.clicked_csr(corpus, torch.device("cpu"), "train")
+    u = 7
+    assert set(flat[ptr[u]:ptr[u + 1]].tolist()) == corpus.train_clicked_set[u]
+    ptr_all, flat_all = pipeline.clicked_csr(corpus, torch.device("cpu"), "all")
+    assert set(flat_all[ptr_all[u]:ptr_all[u + 1]].tolist()) == corpus.train_clicked_set[u] | corpus.residual_clicked_set[u]
+    hp, hi, ht = pipeline.history_csr(corpus, torch.device("cpu"))
+    assert hi[hp[u]:hp[u + 1]].tolist() == [x[0] for x in corpus.user_his[u]]
+    assert ht[hp[u]:hp[u + 1]].tolist() == [x[1] for x in corpus.user_his[u]]
+    assert pipeline._padded([[4, 5, 6], [], [7]], 2).tolist() == [[4, 5], [0, 0], [7, 0]]
+    user, item = pipeline.context_tables(ctx_corpus, torch.device("cpu"))
+    assert int(item["i_category_c"][5]) == ctx_corpus.item_features[5]["i_category_c"]
+    assert int(user["u_age_c"][3]) == ctx_corpus.user_features[3]["u_age_c"]
