@@ -6,8 +6,8 @@ whole step is therefore recorded ONCE per batch shape with HIP stream capture (t
 engine launches on torch's current stream, takes its scratch from caches that are warm by then, never
 synchronises) and replayed with the next batch copied into static input buffers.  Adam's step count lives
 in device memory (HipOptimizer(capturable=True), rc_dense_update_multi_dev), so bias correction advances
-across replays.  Eligibility is decided by the runner (helpers/BaseRunner.py): deterministic forward
-(no dropout, no host-side candidate shuffle), HipOptimizer, CUDA tensors.
+across replays.  Eligibility is decided by the runner (helpers/BaseRunner.py): host-free forward
+(no host-side candidate shuffle; torch's dropout replays with a fresh Philox offset), HipOptimizer, CUDA tensors.
 
 ROCm caveat (measured on ROCm 7.0 / MI355X, repro: tools/repro_hipgraph_fault.py): with the runtime's
 default "AQL packet capture" fast path for graphs, ONE device-to-host copy on the default stream between

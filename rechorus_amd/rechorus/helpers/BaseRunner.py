@@ -197,9 +197,10 @@ class BaseRunner(object):
         model.train()
         losses = list()
         equivariant = getattr(model, 'candidate_permutation_equivariant', False)
-        # hipGraph replay of the dense step: needs a deterministic, host-free step (no dropout, no
-        # host-side candidate shuffle) and the capturable optimizer; one graph per feed-dict shape
-        graphable = (self.use_graph and not rowwise and equivariant and getattr(model, 'dropout', 0) == 0
+        # hipGraph replay of the dense step: needs a host-free step (no host-side candidate shuffle; torch's
+        # dropout is fine, its Philox offset advances per replay) and the capturable optimizer; one graph per
+        # feed-dict shape
+        graphable = (self.use_graph and not rowwise and equivariant
                      and isinstance(model.optimizer, hnn.HipOptimizer) and model.optimizer.capturable
                      and torch.device(model.device).type == 'cuda' and hgraph.usable())
         for batch in self._batches(dataset, self.batch_size, train=True):

@@ -233,3 +233,22 @@ def test_context_device_batches_equal_the_collated_ones(mode, dataset, ctx_root,
     assert np.isfinite(l1) and np.isfinite(l2)
     res = runner.evaluate(model_cls.Dataset(model, corpus, "dev"), [5], runner.metrics)
     assert all(np.isfinite(v) for v in res.values())
+
+
+def test_graph_replay_with_dropout_draws_fresh_masks(data_root, cuda):
+    """models with nn.Dropout are captured too: torch advances the generator offset per replay, so every
+    step sees a new mask (the loss of identical batches differs) and training still converges"""
+    from rechorus_amd import graph as hgraph
+    args, corpus, model, data, runner = _setup(data_root, cuda, "NeuMF", ["--layers", "[32]", "--dropout", "0.3", "--lr", "0.01",
+                                                                         "--batch_size", "128"])
+    model.optimizer = runner._build_optimizer(model)
+    model.train()
+    step = hgraph.GraphedStep(model)
+    batch = next(iter(runner._batches(data["train"], 128, train=True)))
+    losses = [float(step.run({k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in batch.items()})) for _ in range(8)]
+    assert step.graph is not None
+    replayed = losses[3:]
+    assert len(set(round(x, 7) for x in replayed)) > 1  # same batch, different dropout masks
+    first = runner.fit(data["train"], epoch=1)
+    last = [runner.fit(data["train"], epoch=e) for e in range(2, 6)][-1]
+    assert last < first
