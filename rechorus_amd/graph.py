@@ -66,8 +66,10 @@ class GraphedStep:
 
     WARMUP = 2  # eager steps before capture: optimizer state, workspaces and autotuned paths exist by then
 
-    def __init__(self, model):
+    def __init__(self, model, loss_of=None):
         self.model = model
+        # loss_of(model, batch) -> scalar loss; default: the reference's `model.loss(model(batch))`
+        self.loss_of = loss_of or (lambda m, b: m.loss(m(b)))
         self.seen = 0
         self.graph = None
         self.static = None
@@ -80,7 +82,7 @@ class GraphedStep:
     def _eager(self, batch):
         model = self.model
         model.optimizer.zero_grad()
-        loss = model.loss(model(batch))
+        loss = self.loss_of(model, batch)
         loss.backward()
         model.optimizer.step()
         return loss.detach().reshape(1)
@@ -111,6 +113,6 @@ class GraphedStep:
             # capture stream joins it before and after, which is what we want
             warnings.simplefilter('ignore', UserWarning)
             with torch.cuda.graph(self.graph):
-                self.loss = model.loss(model(self.static))
+                self.loss = self.loss_of(model, self.static)
                 self.loss.backward()
                 model.optimizer.step()

@@ -13,6 +13,7 @@ import numpy as np
 import torch
 
 from helpers.BaseRunner import BaseRunner
+from rechorus_amd import graph as hgraph, nn as hnn
 from models.BaseModel import BaseModel
 
 
@@ -100,7 +101,20 @@ class ImpressionRunner(BaseRunner):
             model.optimizer = self._build_optimizer(model)
         model.train()
         losses = list()
+
+        def list_loss(m, batch):  # forward + the runner-built {1, 0, -1} labels + the model's list-wise loss
+            out = m(batch)
+            return m.loss(out, self._labels(batch, out['prediction'].shape[1], m.train_max_pos_item, out['prediction'].device))
+        graphable = (self.use_graph and hgraph.usable() and isinstance(model.optimizer, hnn.HipOptimizer)
+                     and model.optimizer.capturable and torch.device(model.device).type == 'cuda')
         for batch in self._batches(data, self.batch_size, train=True):  # device pipeline, or DataLoader for custom datasets
+            if graphable:  # hipGraph replay of the whole step, one graph per batch shape (rechorus_amd/graph.py)
+                key = (id(model), hgraph.GraphedStep.signature(batch))
+                step = self._graphed.get(key)
+                if step is None:
+                    step = self._graphed[key] = hgraph.GraphedStep(model, loss_of=list_loss)
+                losses.append(step.run(batch))
+                continue
             model.optimizer.zero_grad()
             out_dict = model(batch)
             pred = out_dict['prediction']

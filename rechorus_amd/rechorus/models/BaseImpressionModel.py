@@ -47,7 +47,7 @@ class ImpressionModel(GeneralModel):
         have_neg = valid[:, P].float()
         col = torch.arange(pred.shape[1], device=pred.device)[None, :]
         is_pos, is_neg = (col < P) & valid, (col >= P) & valid
-        ninf = torch.tensor(float('-inf'), device=pred.device)
+        ninf = torch.full((), float('-inf'), device=pred.device)  # a fill kernel (capturable), not a host copy
 
         def reweight(row_loss):  # rows without negatives are weighted out (:93,105,125)
             return (row_loss * have_neg / have_neg.sum() * len(have_neg)).mean()
