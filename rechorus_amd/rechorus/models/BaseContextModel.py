@@ -51,11 +51,10 @@ class ContextModel(GeneralModel):
         """BPR (the HIP loss kernel of GeneralModel) or point-wise BCE over pos + negs (:49-63)"""
         if self.loss_n == 'BPR':
             return super().loss(out_dict)
-        if self.loss_n == 'BCE':
-            if out_dict['prediction'].is_cuda:  # one HIP kernel, closed-form backward
-                return hnn.bce_ranking_loss(out_dict['prediction'])
-            p = out_dict['prediction'].sigmoid()
-            return -(p[:, 0].log() + (1 - p[:, 1:]).log().sum(dim=1)).mean()
+        if self.loss_n == 'BCE':  # one HIP kernel, closed-form backward
+            if not out_dict['prediction'].is_cuda:
+                raise RuntimeError('ContextModel.loss: the HIP engine needs CUDA tensors (no CPU path)')
+            return hnn.bce_ranking_loss(out_dict['prediction'])
         raise ValueError('Undefined loss function: {}'.format(self.loss_n))
 
     class Dataset(GeneralModel.Dataset):

@@ -41,8 +41,14 @@ class ImpressionModel(GeneralModel):
     def loss(self, out_dict: dict, target=None):
         pred, P = out_dict['prediction'], self.train_max_pos_item
         name = self.loss_n
-        if pred.is_cuda and name in ('BPR', 'BPRhard', 'softmaxCE'):
-            return hnn.list_loss(pred, target.long(), P, name)
+        # like the reference (:50-89), any name containing 'BPR' without after / before / simple is the
+        # "between" re-weighting, 'hard' anywhere in it flips the positive weights
+        between = 'BPR' in name and not any(k in name for k in ('after', 'before', 'simple'))
+        if between or name == 'softmaxCE':
+            if not pred.is_cuda:
+                raise RuntimeError('ImpressionModel.loss: the HIP engine needs CUDA tensors (no CPU path)')
+            kind = 'softmaxCE' if name == 'softmaxCE' else ('BPRhard' if 'hard' in name else 'BPR')
+            return hnn.list_loss(pred, target.long(), P, kind)
         valid = (target != -1)
         have_neg = valid[:, P].float()
         col = torch.arange(pred.shape[1], device=pred.device)[None, :]
@@ -61,10 +67,7 @@ class ImpressionModel(GeneralModel):
                 return ((F.softplus(-diff) * w_neg[:, None, :]).sum(-1) * w_pos).sum(-1).mean()
             if 'before' in name:
                 return F.softplus(-(diff * w_neg[:, None, :]).sum(-1) * w_pos).sum(-1).mean()
-            if 'simple' in name:
-                return (F.softplus(-diff) * pair).sum(-1).sum(-1)
-            sig = torch.where(pair, diff, ninf).sigmoid()
-            return -((sig * w_neg[:, None, :]).sum(-1) * w_pos).sum(-1).log().mean()
+            return (F.softplus(-diff) * pair).sum(-1).sum(-1)  # 'simple': per-row sums, not reduced (reference :84)
         if name in ('listnet', 'attention_rank'):
             t_soft = torch.where(valid, target.float(), ninf).softmax(dim=1)
             if name == 'listnet':
@@ -75,10 +78,6 @@ class ImpressionModel(GeneralModel):
             p1 = torch.where(valid, p_soft, torch.ones_like(p_soft))
             p2 = torch.where(valid & (p_soft != 1), p_soft, torch.zeros_like(p_soft))
             return reweight(-(t_soft * p1.log()).sum(dim=1) - ((1 - t_soft) * (1 - p2).log()).sum(dim=1))
-        if name == 'softmaxCE':  # CPU debugging only; CUDA tensors took the kernel above
-            p_soft = torch.where(valid, pred, ninf).softmax(dim=1)[:, :P]
-            p_soft = torch.where(valid[:, :P], p_soft, torch.ones_like(p_soft))
-            return reweight(-p_soft.log().sum(dim=1) / (target == 1).sum(dim=1))
         raise ValueError('Undefined loss function: {}'.format(self.loss_n))
 
     class Dataset(GeneralModel.Dataset):

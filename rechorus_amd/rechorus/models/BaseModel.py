@@ -256,15 +256,13 @@ class CTRModel(GeneralModel):
     def __init__(self, args, corpus):
         super().__init__(args, corpus)
         self.loss_n = args.loss_n
-        if self.loss_n == 'BCE':
-            self.loss_fn = nn.BCELoss()
 
     def loss(self, out_dict: dict) -> torch.Tensor:
         """BCE / MSE on (prediction, label), reference :262-274 (torch ops: not on the ranking path)"""
-        if self.loss_n == 'BCE':
-            if out_dict['prediction'].is_cuda:  # one HIP kernel, closed-form backward
-                return hnn.bce_loss(out_dict['prediction'], out_dict['label'])
-            return self.loss_fn(out_dict['prediction'], out_dict['label'].float())
+        if self.loss_n == 'BCE':  # one HIP kernel, closed-form backward
+            if not out_dict['prediction'].is_cuda:
+                raise RuntimeError('CTRModel.loss: the HIP engine needs CUDA tensors (no CPU path)')
+            return hnn.bce_loss(out_dict['prediction'], out_dict['label'])
         if self.loss_n == 'MSE':
             return ((out_dict['prediction'] - out_dict['label']) ** 2).mean()
         raise ValueError('Undefined loss function: {}'.format(self.loss_n))

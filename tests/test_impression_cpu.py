@@ -40,10 +40,22 @@ def test_oracle_list_losses_match_the_reference(key):
     assert_close(g, c["gpred"], what="grad " + key, atol_scale=2e-5)
 
 
-@pytest.mark.parametrize("key", LOSS_CASES)
+KERNEL_LOSSES = ("BPR", "BPRhard", "softmaxCE")  # HIP kernels, no torch form: tests/test_gpu_impression.py
+
+
+def test_kernel_backed_losses_refuse_cpu_tensors():
+    from models.BaseImpressionModel import ImpressionModel
+    c = case(LOSS_CASES[0])
+    for name in KERNEL_LOSSES:
+        with pytest.raises(RuntimeError):
+            ImpressionModel.loss(argparse.Namespace(loss_n=name, train_max_pos_item=int(c["max_pos"])),
+                                 {"prediction": torch.from_numpy(c["pred"])}, torch.from_numpy(c["target"]))
+
+
+@pytest.mark.parametrize("key", [k for k in LOSS_CASES if k.split("/")[-1] not in KERNEL_LOSSES])
 def test_mirror_loss_formulas_match_the_reference(key):
-    """every loss name through the mirror's ImpressionModel.loss (device-side torch-op formulas; on CUDA
-    tensors BPR / BPRhard / softmaxCE take the HIP kernels instead, tests/test_gpu_impression.py)"""
+    """the loss names without a kernel (re-weighting variants, listnet, attention_rank) through the mirror's
+    ImpressionModel.loss: device-agnostic torch formulas, checked here on CPU tensors"""
     from models.BaseImpressionModel import ImpressionModel
     c = case(key)
     stub = argparse.Namespace(loss_n=key.split("/")[-1], train_max_pos_item=int(c["max_pos"]))
