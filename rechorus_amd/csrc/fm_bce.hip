@@ -57,6 +57,43 @@ __global__ __launch_bounds__(kBlock) void fm2_bwd_kernel(const float* __restrict
   }
 }
 
+// any emb_size: one wave per instance, lanes stride over the d components (correctness path for widths
+// without a float4 lane-group tiling)
+__global__ __launch_bounds__(kBlock) void fm2_fwd_generic_kernel(const float* __restrict__ V, int64_t n, int F, int d,
+                                                                 float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t i = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (i >= n) return;  // wave-uniform
+  const float* v = V + i * F * d;
+  float part = 0.f;
+  for (int k = lane; k < d; k += 64) {
+    float s = 0.f, q = 0.f;
+    for (int f = 0; f < F; ++f) {
+      const float x = v[f * d + k];
+      s += x;
+      q = fmaf(x, x, q);
+    }
+    part += 0.5f * (s * s - q);
+  }
+  part = wave_allreduce_sum(part);
+  if (lane == 0) out[i] = part;
+}
+
+__global__ __launch_bounds__(kBlock) void fm2_bwd_generic_kernel(const float* __restrict__ V, const float* __restrict__ g,
+                                                                 int64_t n, int F, int d, float* __restrict__ dV) {
+  const int lane = threadIdx.x & 63;
+  const int64_t i = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const float* v = V + i * F * d;
+  float* dv = dV + i * F * d;
+  const float gi = g[i];
+  for (int k = lane; k < d; k += 64) {
+    float s = 0.f;
+    for (int f = 0; f < F; ++f) s += v[f * d + k];
+    for (int f = 0; f < F; ++f) dv[f * d + k] = gi * (s - v[f * d + k]);
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void bce_prob_kernel(const float* __restrict__ p, const float* __restrict__ y,
                                                           int64_t n, float inv_n, float* __restrict__ loss_vec,
                                                           float* __restrict__ gp) {
@@ -78,17 +115,22 @@ using namespace rc;
     case 32: hipLaunchKernelGGL((KERN<32>), dim3(blocks(32)), dim3(kBlock), 0, s, __VA_ARGS__); break; \
     case 64: hipLaunchKernelGGL((KERN<64>), dim3(blocks(64)), dim3(kBlock), 0, s, __VA_ARGS__); break; \
     case 128: hipLaunchKernelGGL((KERN<128>), dim3(blocks(128)), dim3(kBlock), 0, s, __VA_ARGS__); break; \
-    default: return fail(RC_ERR_UNSUPPORTED, "FM second-order kernels need emb_size in {16,32,64,128}, got %d", d); \
+    default: generic = true; break;                                                                 \
   }
 
 extern "C" int rc_fm_second_order_fwd(const float* V, int64_t n, int F, int d, float* out, rc_stream_t stream) {
   if (n == 0) return RC_OK;
   RC_REQUIRE(V && out, "rc_fm_second_order_fwd: null pointer");
   RC_REQUIRE(n > 0 && F >= 1, "rc_fm_second_order_fwd: bad shape n=%lld F=%d", (long long)n, F);
-  RC_REQUIRE(reinterpret_cast<uintptr_t>(V) % 16 == 0, "rc_fm_second_order_fwd: V must be 16-byte aligned");
+  RC_REQUIRE(reinterpret_cast<uintptr_t>(V) % 16 == 0 || d % 4 != 0, "rc_fm_second_order_fwd: V must be 16-byte aligned");
   hipStream_t s = as_stream(stream);
   auto blocks = [&](int dd) { return (unsigned)((n + (kBlock / (dd / 4)) - 1) / (kBlock / (dd / 4))); };
+  bool generic = false;
   RC_FM_DISPATCH(fm2_fwd_kernel, V, n, F, out);
+  if (generic) {
+    RC_REQUIRE(d >= 1, "rc_fm_second_order_fwd: bad emb_size %d", d);
+    hipLaunchKernelGGL(fm2_fwd_generic_kernel, dim3((unsigned)((n + 3) / 4)), dim3(kBlock), 0, s, V, n, F, d, out);
+  }
   RC_LAUNCH_CHECK();
   return RC_OK;
 }
@@ -102,7 +144,12 @@ extern "C" int rc_fm_second_order_bwd(const float* V, const float* gout, int64_t
              "rc_fm_second_order_bwd: V and dV must be 16-byte aligned");
   hipStream_t s = as_stream(stream);
   auto blocks = [&](int dd) { return (unsigned)((n + (kBlock / (dd / 4)) - 1) / (kBlock / (dd / 4))); };
+  bool generic = false;
   RC_FM_DISPATCH(fm2_bwd_kernel, V, gout, n, F, dV);
+  if (generic) {
+    RC_REQUIRE(d >= 1, "rc_fm_second_order_bwd: bad emb_size %d", d);
+    hipLaunchKernelGGL(fm2_bwd_generic_kernel, dim3((unsigned)((n + 3) / 4)), dim3(kBlock), 0, s, V, gout, n, F, d, dV);
+  }
   RC_LAUNCH_CHECK();
   return RC_OK;
 }

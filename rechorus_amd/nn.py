@@ -140,10 +140,7 @@ class _FmSecondOrderFn(torch.autograd.Function):
 def fm_second_order(V):
     if not V.is_cuda:
         raise RuntimeError("fm_second_order runs on the GPU only (no CPU path)")
-    if V.shape[-1] in (16, 32, 64, 128):
-        return _FmSecondOrderFn.apply(V)
-    # other embedding sizes: the same expression as device-side torch ops
-    return (0.5 * (V.sum(dim=-2).pow(2) - V.pow(2).sum(dim=-2))).sum(dim=-1)
+    return _FmSecondOrderFn.apply(V)  # float4 lane-group kernels for emb_size 16/32/64/128, a generic kernel otherwise
 
 
 class _FieldGatherFn(torch.autograd.Function):

@@ -27,7 +27,7 @@ def eng(cuda):
     return engine
 
 
-@pytest.mark.parametrize("d", [16, 32, 64, 128])
+@pytest.mark.parametrize("d", [16, 32, 64, 128, 24, 5, 200])
 def test_fm_second_order_vs_oracle(d, cuda, eng):
     rng = np.random.default_rng(d)
     for shape, F in (((1,), 1), ((63,), 2), ((33, 5), 7), ((1000,), 39), ((7, 100), 3)):
@@ -48,7 +48,7 @@ def test_fm_second_order_vs_oracle(d, cuda, eng):
 def test_fm_second_order_autograd_and_unsupported_width(cuda):
     from rechorus_amd import nn as hnn
     rng = np.random.default_rng(1)
-    for d in (64, 24):  # 24: device-side torch expression (no kernel for that width)
+    for d in (64, 24):  # 24: the generic-width kernel
         V = torch.from_numpy(rng.normal(size=(9, 4, 5, d)).astype(np.float32)).to(cuda).requires_grad_(True)
         w = torch.from_numpy(rng.normal(size=(9, 4)).astype(np.float32)).to(cuda)
         (hnn.fm_second_order(V) * w).sum().backward()
