@@ -284,7 +284,7 @@ int rc_sasrec_bwd(const float* const* layer_params, int n_layers, int n_heads, c
                   int B, int L, int d, const float* xsave, const float* dhv, float* g_hist,
                   float* dense_grads, void* ws, size_t ws_bytes, rc_stream_t stream);
 
-/* ---- NeuMF head (models/general/NeuMF.py:56-76), one hidden layer, dropout 0 ------------- */
+/* ---- NeuMF head (models/general/NeuMF.py:56-76), one hidden layer ------------------------- */
 
 /* 1 iff the fp32-MFMA kernels cover (emb_size d, hidden size l1): d, l1 in {32,64,128} and the
  * LDS image (W1 + a 64-candidate tile) fits 160 KB.  Other shapes: use rc_gather_rows + any GEMM. */
@@ -308,6 +308,25 @@ int rc_neumf_bwd(const float* mf_u, const float* mf_i, const float* mlp_u, const
                  const int64_t* iid, const float* gpred, int B, int C, int d, int l1,
                  float* g_mf_u, float* g_mf_i, float* g_mlp_u, float* g_mlp_i, float* dW1,
                  float* db1, float* dw_out, void* ws, size_t ws_bytes, rc_stream_t stream);
+
+/* The same head in TRAINING mode with dropout p on the hidden layer (NeuMF.py:58 nn.Dropout after the
+ * ReLU, the reference's demo runs --dropout 0.2): hidden feature f of candidate n = b*C+c is zeroed iff
+ * word (f & 3) of Philox4x32-10(key = *seed_dev, counter = (n, f >> 2)) < p * 2^32, kept values are scaled
+ * by 1/(1-p).  The mask is never stored: the backward regenerates it from the same *seed_dev, which
+ * therefore must not change between the two calls; bump it (rc_step_increment) once per step, also inside a
+ * captured graph.  The stream differs from torch's Philox dropout: parity with the reference is
+ * distributional, parity with oracle/neumf_oracle.py (same counter scheme) is exact in the mask.
+ * p = 0 (seed_dev may then be NULL) is rc_neumf_fwd / rc_neumf_bwd bit for bit.                          */
+int rc_neumf_fwd_dropout(const float* mf_u, const float* mf_i, const float* mlp_u, const float* mlp_i,
+                         const float* W1, const float* b1, const float* w_out, const int64_t* uid,
+                         const int64_t* iid, int B, int C, int d, int l1, float drop_p,
+                         const uint64_t* seed_dev, float* pred, rc_stream_t stream);
+int rc_neumf_bwd_dropout(const float* mf_u, const float* mf_i, const float* mlp_u, const float* mlp_i,
+                         const float* W1, const float* b1, const float* w_out, const int64_t* uid,
+                         const int64_t* iid, const float* gpred, int B, int C, int d, int l1,
+                         float drop_p, const uint64_t* seed_dev, float* g_mf_u, float* g_mf_i,
+                         float* g_mlp_u, float* g_mlp_i, float* dW1, float* db1, float* dw_out,
+                         void* ws, size_t ws_bytes, rc_stream_t stream);
 
 /* ---- training-batch assembly on the device (csrc/sampler.hip) -------------------------------- */
 

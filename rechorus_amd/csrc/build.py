@@ -36,7 +36,7 @@ SOURCES = [
     "eval_rank.hip",
     "owner_step.hip",
 ]
-HEADERS = ["common.hpp", "bpr_math.hpp", "opt_math.hpp", os.path.join("..", "..", "include", "rechorus_hip.h")]
+HEADERS = ["common.hpp", "bpr_math.hpp", "opt_math.hpp", "philox.hpp", os.path.join("..", "..", "include", "rechorus_hip.h")]
 
 
 def _hipcc():

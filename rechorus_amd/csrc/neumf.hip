@@ -23,6 +23,7 @@
 // neumf_reduce_partials_kernel (deterministic, no float atomics).  Table-row gradients are
 // written per occurrence ([B*C, d] x 4) and consumed by rc_segmented_update.
 #include "common.hpp"
+#include "philox.hpp"
 
 namespace rc {
 
@@ -51,6 +52,13 @@ struct NeumfArgs {
   float* pW1;          // bwd: per-workgroup partials [n_wg][L1*2d], [n_wg][L1], [n_wg][d+L1]
   float* pb1;
   float* pwout;
+  // dropout on the hidden layer (NeuMF.py:70, nn.Dropout after the ReLU): element (candidate n, feature f) is
+  // dropped iff word (f & 3) of Philox(seed, n, f >> 2) < drop_thresh; kept values are scaled by keep_scale.
+  // seed_dev == nullptr: no dropout.  The seed is read from device memory so that a captured step replays
+  // with a new mask once the host (or the graph) has bumped it.
+  const uint64_t* seed_dev;
+  uint32_t drop_thresh;
+  float keep_scale;
 };
 
 template <int D, int L1>
@@ -74,7 +82,7 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 // accumulator register r of lane -> row inside a 32x32 block (column = lane & 31)
 __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
-template <int D, int L1, bool BWD>
+template <int D, int L1, bool BWD, bool DROP>
 __global__ __launch_bounds__(kBlock) void neumf_kernel(NeumfArgs a) {
   using Cfg = NeumfCfg<D, L1>;
   constexpr int K0 = Cfg::K0, SW = Cfg::SW, SZ = Cfg::SZ, NRB = Cfg::NRB, NKB = Cfg::NKB;
@@ -198,15 +206,28 @@ __global__ __launch_bounds__(kBlock) void neumf_kernel(NeumfArgs a) {
         const int cand = cb * 32 + (lane & 31);
         const float gj = BWD ? sg[cand] : 0.f;
         float pp = 0.f;
+        float keep[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) keep[r] = 1.0f;
+        if (DROP) {  // 4 Philox blocks per lane, one per run of 4 consecutive features
+          const uint64_t seed = *a.seed_dev;
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4) {
+            uint32_t w[4];
+            philox4x32_10(seed, (uint64_t)(n0 + cand), (uint32_t)((rb * 32 + acc_row(4 * q4, lane)) >> 2), w);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) keep[4 * q4 + e] = w[e] < a.drop_thresh ? 0.f : a.keep_scale;
+          }
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int f = rb * 32 + acc_row(r, lane);
           const float z = acc[r] + sb1[f];
-          const float h = fmaxf(z, 0.f);
+          const float h = fmaxf(z, 0.f) * keep[r];
           const float wh = swo[D + f];
           pp = fmaf(wh, h, pp);
           if (BWD) {
-            const float dz = z > 0.f ? gj * wh : 0.f;
+            const float dz = z > 0.f ? gj * wh * keep[r] : 0.f;
             Zs[f * SZ + cand] = dz;
             db1acc[s][r] += dz;
             dwhacc[s][r] = fmaf(gj, h, dwhacc[s][r]);
@@ -368,11 +389,11 @@ __global__ __launch_bounds__(kBlock) void neumf_reduce_partials_kernel(ReduceArg
   }
 }
 
-template <int D, int L1, bool BWD>
+template <int D, int L1, bool BWD, bool DROP>
 static int launch_neumf(const NeumfArgs& a, int n_wg, hipStream_t s) {
   using Cfg = NeumfCfg<D, L1>;
   const size_t lds_bytes = (size_t)Cfg::kLdsFloats * sizeof(float);
-  auto kern = neumf_kernel<D, L1, BWD>;
+  auto kern = neumf_kernel<D, L1, BWD, DROP>;
   RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                              (int)lds_bytes));
   hipLaunchKernelGGL(kern, dim3(n_wg), dim3(kBlock), lds_bytes, s, a);
@@ -402,7 +423,8 @@ static int neumf_grid(int64_t n, int d, int l1) {
 template <bool BWD>
 static int dispatch_neumf(const NeumfArgs& a, int d, int l1, int n_wg, hipStream_t s) {
 #define RC_NM(D_, L_) \
-  if (d == D_ && l1 == L_) return launch_neumf<D_, L_, BWD>(a, n_wg, s)
+  if (d == D_ && l1 == L_)                                                                 \
+    return a.seed_dev ? launch_neumf<D_, L_, BWD, true>(a, n_wg, s) : launch_neumf<D_, L_, BWD, false>(a, n_wg, s)
   RC_NM(32, 32); RC_NM(32, 64); RC_NM(32, 128);
   RC_NM(64, 32); RC_NM(64, 64); RC_NM(64, 128);
   RC_NM(128, 32); RC_NM(128, 64);
@@ -425,10 +447,30 @@ extern "C" size_t rc_neumf_workspace_bytes(int B, int C, int d, int l1) {
   return align_up((size_t)n_wg * per * sizeof(float), 256) + 256;
 }
 
+// dropout arguments -> kernel fields; p == 0 or seed_dev == nullptr switches the mask off
+static int set_dropout(NeumfArgs& a, float drop_p, const uint64_t* seed_dev, const char* who) {
+  if (!(drop_p >= 0.f && drop_p < 1.f)) return fail(RC_ERR_INVALID_ARG, "%s: dropout p=%g outside [0, 1)", who, (double)drop_p);
+  if (drop_p > 0.f && seed_dev == nullptr) return fail(RC_ERR_INVALID_ARG, "%s: dropout p=%g needs a device seed", who, (double)drop_p);
+  if (drop_p > 0.f) {
+    a.seed_dev = seed_dev;
+    a.drop_thresh = (uint32_t)((double)drop_p * 4294967296.0);
+    a.keep_scale = 1.0f / (1.0f - drop_p);
+  }
+  return RC_OK;
+}
+
 extern "C" int rc_neumf_fwd(const float* mf_u, const float* mf_i, const float* mlp_u,
                             const float* mlp_i, const float* W1, const float* b1,
                             const float* w_out, const int64_t* uid, const int64_t* iid, int B,
                             int C, int d, int l1, float* pred, rc_stream_t stream) {
+  return rc_neumf_fwd_dropout(mf_u, mf_i, mlp_u, mlp_i, W1, b1, w_out, uid, iid, B, C, d, l1, 0.f, nullptr, pred, stream);
+}
+
+extern "C" int rc_neumf_fwd_dropout(const float* mf_u, const float* mf_i, const float* mlp_u,
+                                    const float* mlp_i, const float* W1, const float* b1,
+                                    const float* w_out, const int64_t* uid, const int64_t* iid, int B,
+                                    int C, int d, int l1, float drop_p, const uint64_t* seed_dev,
+                                    float* pred, rc_stream_t stream) {
   if (B == 0) return RC_OK;
   RC_REQUIRE(mf_u && mf_i && mlp_u && mlp_i && W1 && b1 && w_out && uid && iid && pred,
              "rc_neumf_fwd: null pointer");
@@ -439,6 +481,7 @@ extern "C" int rc_neumf_fwd(const float* mf_u, const float* mf_i, const float* m
   memset(&a, 0, sizeof(a));
   a.mf_u = mf_u; a.mf_i = mf_i; a.mlp_u = mlp_u; a.mlp_i = mlp_i; a.W1 = W1; a.b1 = b1; a.w_out = w_out;
   a.uid = uid; a.iid = iid; a.B = B; a.C = C; a.n = (int64_t)B * C; a.pred = pred;
+  RC_TRY(set_dropout(a, drop_p, seed_dev, "rc_neumf_fwd"));
   return dispatch_neumf<false>(a, d, l1, neumf_grid(a.n, d, l1), as_stream(stream));
 }
 
@@ -448,6 +491,17 @@ extern "C" int rc_neumf_bwd(const float* mf_u, const float* mf_i, const float* m
                             const float* gpred, int B, int C, int d, int l1, float* g_mf_u,
                             float* g_mf_i, float* g_mlp_u, float* g_mlp_i, float* dW1, float* db1,
                             float* dw_out, void* ws, size_t ws_bytes, rc_stream_t stream) {
+  return rc_neumf_bwd_dropout(mf_u, mf_i, mlp_u, mlp_i, W1, b1, w_out, uid, iid, gpred, B, C, d, l1, 0.f, nullptr,
+                              g_mf_u, g_mf_i, g_mlp_u, g_mlp_i, dW1, db1, dw_out, ws, ws_bytes, stream);
+}
+
+extern "C" int rc_neumf_bwd_dropout(const float* mf_u, const float* mf_i, const float* mlp_u,
+                                    const float* mlp_i, const float* W1, const float* b1,
+                                    const float* w_out, const int64_t* uid, const int64_t* iid,
+                                    const float* gpred, int B, int C, int d, int l1, float drop_p,
+                                    const uint64_t* seed_dev, float* g_mf_u, float* g_mf_i, float* g_mlp_u,
+                                    float* g_mlp_i, float* dW1, float* db1, float* dw_out, void* ws,
+                                    size_t ws_bytes, rc_stream_t stream) {
   if (B == 0) return RC_OK;
   RC_REQUIRE(mf_u && mf_i && mlp_u && mlp_i && W1 && b1 && w_out && uid && iid && gpred && g_mf_u &&
                  g_mf_i && g_mlp_u && g_mlp_i && dW1 && db1 && dw_out && ws,
@@ -464,6 +518,7 @@ extern "C" int rc_neumf_bwd(const float* mf_u, const float* mf_i, const float* m
   a.mf_u = mf_u; a.mf_i = mf_i; a.mlp_u = mlp_u; a.mlp_i = mlp_i; a.W1 = W1; a.b1 = b1; a.w_out = w_out;
   a.uid = uid; a.iid = iid; a.B = B; a.C = C; a.n = (int64_t)B * C; a.gpred = gpred;
   a.g_mf_u = g_mf_u; a.g_mf_i = g_mf_i; a.g_mlp_u = g_mlp_u; a.g_mlp_i = g_mlp_i;
+  RC_TRY(set_dropout(a, drop_p, seed_dev, "rc_neumf_bwd"));
   const int n_wg = neumf_grid(a.n, d, l1);
   const int cW = l1 * 2 * d, cb = l1, co = d + l1;
   float* p = reinterpret_cast<float*>(ws);

@@ -337,27 +337,43 @@ def _neumf_ptrs(P):
     return [_ptr(P[k], f32, k) for k in ("mf_u", "mf_i", "mlp_u", "mlp_i", "W1", "b1", "w_out")]
 
 
-def neumf_fwd(P, uid, iid):
+def _drop_args(drop_p, seed):
+    """(p, device pointer to the 64-bit mask seed); seed = int64 tensor [1] on the device, read by the kernels"""
+    if not drop_p:
+        return C.c_float(0.0), C.c_void_p(0)
+    if seed is None:
+        raise ValueError("NeuMF dropout needs a device seed tensor (int64 [1])")
+    return C.c_float(float(drop_p)), _ptr(seed, torch.int64, "seed")
+
+
+def step_increment(counter):
+    """counter[0] += 1 on the device (rc_step_increment): Adam's step, the dropout seed; capturable"""
+    _lib.call("rc_step_increment", _ptr(counter, torch.int64, "counter"), _stream())
+
+
+def neumf_fwd(P, uid, iid, drop_p=0.0, seed=None):
     """P: dict mf_u, mf_i, mlp_u, mlp_i [rows,d], W1 [l1,2d], b1 [l1], w_out [d+l1] -> pred [B,C]
-    (models/general/NeuMF.py:61-75)."""
+    (models/general/NeuMF.py:61-75).  drop_p > 0: training-mode dropout on the hidden layer, mask drawn from
+    the counter-based stream keyed by seed[0] (rc_neumf_fwd_dropout)."""
     B, Cn = iid.shape
     d, l1 = P["mf_u"].shape[1], P["W1"].shape[0]
     pred = torch.empty((B, Cn), dtype=torch.float32, device=iid.device)
-    _lib.call("rc_neumf_fwd", *_neumf_ptrs(P), _ptr(uid, torch.int64, "uid"), _ptr(iid, torch.int64, "iid"),
-              B, Cn, d, l1, _ptr(pred, torch.float32, "pred"), _stream())
+    _lib.call("rc_neumf_fwd_dropout", *_neumf_ptrs(P), _ptr(uid, torch.int64, "uid"), _ptr(iid, torch.int64, "iid"),
+              B, Cn, d, l1, *_drop_args(drop_p, seed), _ptr(pred, torch.float32, "pred"), _stream())
     return pred
 
 
-def neumf_bwd(P, uid, iid, gpred):
-    """-> (per-occurrence row grads dict g_mf_u, g_mf_i, g_mlp_u, g_mlp_i [B*C,d], dense grads dict W1, b1, w_out)"""
+def neumf_bwd(P, uid, iid, gpred, drop_p=0.0, seed=None):
+    """-> (per-occurrence row grads dict g_mf_u, g_mf_i, g_mlp_u, g_mlp_i [B*C,d], dense grads dict W1, b1, w_out);
+    drop_p / seed as given to the forward this is the backward of (the mask is regenerated, not stored)"""
     B, Cn = iid.shape
     d, l1 = P["mf_u"].shape[1], P["W1"].shape[0]
     dev, f32 = iid.device, torch.float32
     rows = {k: torch.empty((B * Cn, d), dtype=f32, device=dev) for k in ("g_mf_u", "g_mf_i", "g_mlp_u", "g_mlp_i")}
     dense = {"W1": torch.empty_like(P["W1"]), "b1": torch.empty_like(P["b1"]), "w_out": torch.empty_like(P["w_out"])}
     ws = workspace(_lib.load().rc_neumf_workspace_bytes(B, Cn, d, l1), dev, "neumf")
-    _lib.call("rc_neumf_bwd", *_neumf_ptrs(P), _ptr(uid, torch.int64, "uid"), _ptr(iid, torch.int64, "iid"),
-              _ptr(gpred, f32, "gpred"), B, Cn, d, l1,
+    _lib.call("rc_neumf_bwd_dropout", *_neumf_ptrs(P), _ptr(uid, torch.int64, "uid"), _ptr(iid, torch.int64, "iid"),
+              _ptr(gpred, f32, "gpred"), B, Cn, d, l1, *_drop_args(drop_p, seed),
               *[_ptr(rows[k], f32, k) for k in ("g_mf_u", "g_mf_i", "g_mlp_u", "g_mlp_i")],
               _ptr(dense["W1"], f32, "dW1"), _ptr(dense["b1"], f32, "db1"), _ptr(dense["w_out"], f32, "dw_out"),
               C.c_void_p(ws.data_ptr()), ws.numel(), _stream())
@@ -367,10 +383,13 @@ def neumf_bwd(P, uid, iid, gpred):
 class NeumfTrainer:
     """One BaseRunner.fit iteration for NeuMF (single hidden layer) on device tensors:
     forward (MFMA) -> BPR loss -> backward (MFMA) -> row-wise segmented update of the four tables
-    -> dense optimizer step of W1, b1, w_out.  P as in neumf_fwd; updated in place."""
+    -> dense optimizer step of W1, b1, w_out.  P as in neumf_fwd; updated in place.
+    dropout > 0: hidden-layer dropout with a fresh mask per step (device seed counter, bumped every step)."""
 
-    def __init__(self, P, opt="Adam", lr=1e-3, l2=0.0, rowwise=True):
+    def __init__(self, P, opt="Adam", lr=1e-3, l2=0.0, rowwise=True, dropout=0.0, seed=0):
         self.P, self.opt, self.lr, self.l2, self.rowwise = P, opt, lr, l2, rowwise
+        self.dropout = float(dropout)
+        self.seed = torch.tensor([seed], dtype=torch.int64, device=P["W1"].device) if self.dropout > 0 else None
         self.state = {}
         for k, t in P.items():
             st = {}
@@ -386,9 +405,11 @@ class NeumfTrainer:
         P = self.P
         B, Cn = iid.shape
         self.step_count += 1
-        pred = neumf_fwd(P, uid, iid)
+        if self.seed is not None:
+            step_increment(self.seed)
+        pred = neumf_fwd(P, uid, iid, self.dropout, self.seed)
         self.loss, _, gpred = bpr_loss(pred)
-        rows, dense = neumf_bwd(P, uid, iid, gpred)
+        rows, dense = neumf_bwd(P, uid, iid, gpred, self.dropout, self.seed)
         h = make_hyper(self.opt, lr=self.lr, l2=self.l2, step=self.step_count)
         h0 = make_hyper(self.opt, lr=self.lr, l2=0.0, step=self.step_count)  # 'bias' params: no weight decay
         uid_occ = uid.repeat_interleave(Cn)

@@ -209,17 +209,18 @@ class _NeumfFn(torch.autograd.Function):
     """NeuMF head, one hidden layer (models/general/NeuMF.py:61-75): rc_neumf_fwd / rc_neumf_bwd."""
 
     @staticmethod
-    def forward(ctx, mf_u, mf_i, mlp_u, mlp_i, W1, b1, w_out, uid, iid):
+    def forward(ctx, mf_u, mf_i, mlp_u, mlp_i, W1, b1, w_out, uid, iid, drop_p=0.0, seed=None):
         P = {"mf_u": mf_u.detach(), "mf_i": mf_i.detach(), "mlp_u": mlp_u.detach(), "mlp_i": mlp_i.detach(),
              "W1": W1.detach().contiguous(), "b1": b1.detach().contiguous(),
              "w_out": w_out.detach().reshape(-1).contiguous()}
         ctx.P, ctx.uid, ctx.iid, ctx.wshape = P, uid, iid, w_out.shape
-        return engine.neumf_fwd(P, uid, iid)
+        ctx.drop = (drop_p, seed)  # the backward regenerates the mask from the same device seed
+        return engine.neumf_fwd(P, uid, iid, drop_p, seed)
 
     @staticmethod
     def backward(ctx, gpred):
         P, uid, iid = ctx.P, ctx.uid, ctx.iid
-        rows, dense = engine.neumf_bwd(P, uid, iid, gpred.contiguous())
+        rows, dense = engine.neumf_bwd(P, uid, iid, gpred.contiguous(), *ctx.drop)
         uid_occ = uid.repeat_interleave(iid.shape[1])
         ku, pu = engine.sort_ids(uid_occ, P["mf_u"].shape[0])
         ki, pi = engine.sort_ids(iid, P["mf_i"].shape[0])
@@ -230,11 +231,13 @@ class _NeumfFn(torch.autograd.Function):
             return G
         return (dense_tab("mf_u", "g_mf_u", ku, pu), dense_tab("mf_i", "g_mf_i", ki, pi),
                 dense_tab("mlp_u", "g_mlp_u", ku, pu), dense_tab("mlp_i", "g_mlp_i", ki, pi),
-                dense["W1"], dense["b1"], dense["w_out"].view(ctx.wshape), None, None)
+                dense["W1"], dense["b1"], dense["w_out"].view(ctx.wshape), None, None, None, None)
 
 
-def neumf_scores(mf_u, mf_i, mlp_u, mlp_i, W1, b1, w_out, uid, iid):
-    return _NeumfFn.apply(mf_u, mf_i, mlp_u, mlp_i, W1, b1, w_out, uid.contiguous(), iid.contiguous())
+def neumf_scores(mf_u, mf_i, mlp_u, mlp_i, W1, b1, w_out, uid, iid, drop_p=0.0, seed=None):
+    """drop_p > 0 (training): hidden-layer dropout inside the kernels; `seed` int64 [1] device tensor the caller
+    bumps once per forward (engine.step_increment)"""
+    return _NeumfFn.apply(mf_u, mf_i, mlp_u, mlp_i, W1, b1, w_out, uid.contiguous(), iid.contiguous(), drop_p, seed)
 
 
 _SAS_ATTRS = (("Wq", "masked_attn_head.q_linear.weight"), ("bq", "masked_attn_head.q_linear.bias"),

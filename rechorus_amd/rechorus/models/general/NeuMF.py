@@ -2,10 +2,11 @@
 Reference: "Neural Collaborative Filtering", Xiangnan He et al., WWW'2017.
 Mirror of the reference's models/general/NeuMF.py (same class / arg / state_dict names):
     python main.py --model_name NeuMF --emb_size 64 --layers '[64]' --lr 5e-4 --l2 1e-7 --dataset 'Grocery_and_Gourmet_Food'
-With one hidden layer, emb_size and layer size in {32, 64, 128} and no active dropout, the whole
-head (:61-75: four gathers, GMF product, MLP, prediction layer) is the fp32-MFMA kernel pair
-rc_neumf_fwd / rc_neumf_bwd.  Any other configuration runs the same parameters through
-HipEmbedding gathers + torch layers.
+With one hidden layer and emb_size and layer size in {32, 64, 128}, the whole head (:61-75: four
+gathers, GMF product, MLP, dropout, prediction layer) is the fp32-MFMA kernel pair rc_neumf_fwd(_dropout)
+/ rc_neumf_bwd(_dropout); the dropout mask comes from a counter-based stream keyed by a device-side seed
+that is bumped every training forward (so a captured step replays with fresh masks).  Any other
+configuration runs the same parameters through HipEmbedding gathers + torch layers.
 """
 import torch
 import torch.nn as nn
@@ -45,19 +46,27 @@ class NeuMF(GeneralModel):
             pre_size = layer_size
         self.dropout_layer = nn.Dropout(p=self.dropout)
         self.prediction = nn.Linear(pre_size + self.emb_size, 1, bias=False)
+        # key of the dropout mask stream; not a parameter and not in the state_dict (the reference has no such key)
+        self.register_buffer('drop_seed', torch.randint(0, 2 ** 62, (1,), dtype=torch.int64), persistent=False)
 
     def _fused_ok(self):
-        return (len(self.layers) == 1 and engine.neumf_supported(self.emb_size, self.layers[0])
-                and (self.dropout == 0 or not self.training))
+        return len(self.layers) == 1 and engine.neumf_supported(self.emb_size, self.layers[0])
+
+    def _drop_p(self):
+        return float(self.dropout) if self.training else 0.0
 
     def forward(self, feed_dict):
         self.check_list = []
         u_ids = feed_dict['user_id']  # [batch_size]
         i_ids = feed_dict['item_id']  # [batch_size, n_candidates]
         if self._fused_ok():
+            p = self._drop_p()
+            if p > 0:
+                engine.step_increment(self.drop_seed)  # new mask for this forward; its backward reads the same value
             pred = hnn.neumf_scores(self.mf_u_embeddings.weight, self.mf_i_embeddings.weight,
                                     self.mlp_u_embeddings.weight, self.mlp_i_embeddings.weight,
-                                    self.mlp[0].weight, self.mlp[0].bias, self.prediction.weight, u_ids, i_ids)
+                                    self.mlp[0].weight, self.mlp[0].bias, self.prediction.weight, u_ids, i_ids,
+                                    p, self.drop_seed if p > 0 else None)
             return {'prediction': pred.view(feed_dict['batch_size'], -1)}
         u_rep = u_ids.unsqueeze(-1).repeat((1, i_ids.shape[1]))
         mf = self.mf_u_embeddings(u_rep) * self.mf_i_embeddings(i_ids)
@@ -73,14 +82,15 @@ class NeuMF(GeneralModel):
         + dense step of the MLP (engine.NeumfTrainer); returns the device loss tensor"""
         if not self._fused_ok():
             raise RuntimeError('NeuMF --engine rowwise needs the fused head: one hidden layer, emb_size and layer '
-                               'size in {32, 64, 128}, no active dropout')
+                               'size in {32, 64, 128}')
         tr = getattr(self, '_trainer', None)
         if tr is None or tr.opt != opt_name:
             P = {'mf_u': self.mf_u_embeddings.weight.data, 'mf_i': self.mf_i_embeddings.weight.data,
                  'mlp_u': self.mlp_u_embeddings.weight.data, 'mlp_i': self.mlp_i_embeddings.weight.data,
                  'W1': self.mlp[0].weight.data, 'b1': self.mlp[0].bias.data,
                  'w_out': self.prediction.weight.data.view(-1)}
-            tr = self._trainer = engine.NeumfTrainer(P, opt=opt_name, lr=lr, l2=l2, rowwise=True)
+            tr = self._trainer = engine.NeumfTrainer(P, opt=opt_name, lr=lr, l2=l2, rowwise=True,
+                                                     dropout=self.dropout, seed=int(self.drop_seed.item()))
         with torch.no_grad():
             return tr.step(feed_dict['user_id'].contiguous(), feed_dict['item_id'].contiguous())
 

@@ -90,3 +90,107 @@ def test_neumf_random_shapes_vs_oracle(cuda, eng):
         t = eng.embedding_dense_backward(rows["g_mf_u"], u.repeat_interleave(C), 17)
         assert_close(t.cpu().numpy(), G["mf_u_embeddings.weight"], what="grad mf_u", atol_scale=3e-5)
     assert not eng.neumf_supported(48, 64) and not eng.neumf_supported(128, 128)
+
+
+# ---- hidden-layer dropout inside the kernels (rc_neumf_fwd_dropout / rc_neumf_bwd_dropout) ---------------------
+
+def _seed(cuda, value):
+    return torch.tensor([value], dtype=torch.int64, device=cuda)
+
+
+def _check_against(eng, P, Pd, uid, iid, gp, keep, p, seed, tol, cuda, what):
+    u, i = torch.from_numpy(uid).to(cuda), torch.from_numpy(iid).to(cuda)
+    C = iid.shape[1]
+    pred = eng.neumf_fwd(Pd, u, i, p, seed)
+    want_pred, G = NO.backward(P, uid, iid, gp, keep)
+    assert_close(pred.cpu().numpy(), want_pred, what=what + " pred", atol_scale=tol)
+    rows, dense = eng.neumf_bwd(Pd, u, i, torch.from_numpy(gp).to(cuda), p, seed)
+    assert_close(dense["W1"].cpu().numpy(), G["mlp.0.weight"], what=what + " dW1", atol_scale=tol)
+    assert_close(dense["b1"].cpu().numpy(), G["mlp.0.bias"], what=what + " db1", atol_scale=tol)
+    assert_close(dense["w_out"].cpu().numpy(), G["prediction.weight"][0], what=what + " dw_out", atol_scale=tol)
+    uid_occ = u.repeat_interleave(C)
+    for tab, key, ids in (("mf_u", "g_mf_u", uid_occ), ("mlp_u", "g_mlp_u", uid_occ),
+                          ("mf_i", "g_mf_i", i), ("mlp_i", "g_mlp_i", i)):
+        t = eng.embedding_dense_backward(rows[key], ids, Pd[tab].shape[0])
+        assert_close(t.cpu().numpy(), G[NAMES[tab]], what=what + " grad " + tab, atol_scale=tol)
+    return pred
+
+
+from test_oracle_neumf import DROP_CASES  # noqa: E402
+
+
+@pytest.mark.parametrize("case", DROP_CASES)
+def test_neumf_dropout_matches_reference_run_with_the_same_mask(case, cuda, eng):
+    g = load_golden(case)
+    P = params(g)
+    B, C = g["iid"].shape
+    p, seed = float(g["p"]), _seed(cuda, int(g["mask_seed"]))
+    pred = eng.neumf_fwd(to_dev(P, cuda), torch.from_numpy(g["uid"]).to(cuda), torch.from_numpy(g["iid"]).to(cuda), p, seed)
+    assert_close(pred.cpu().numpy(), g["pred"], what="pred")  # the reference's own output
+    keep = NO.dropout_keep(int(g["mask_seed"]), B * C, P["mlp.0.weight"].shape[0], p)
+    _check_against(eng, P, to_dev(P, cuda), g["uid"], g["iid"], g["gpred"], keep, p, seed, 2e-5, cuda, case)
+    G = params(g, "G/")
+    _, dense = eng.neumf_bwd(to_dev(P, cuda), torch.from_numpy(g["uid"]).to(cuda), torch.from_numpy(g["iid"]).to(cuda),
+                             torch.from_numpy(g["gpred"]).to(cuda), p, seed)
+    assert_close(dense["W1"].cpu().numpy(), G["mlp.0.weight"], what="dW1 vs reference", atol_scale=2e-5)
+
+
+def test_neumf_dropout_all_shapes_vs_oracle_and_p0_is_the_plain_head(cuda, eng):
+    rng = np.random.default_rng(11)
+    shapes = [(d, l1) for d in (32, 64, 128) for l1 in (32, 64, 128) if (d, l1) != (128, 128)]
+    for k, (d, l1) in enumerate(shapes):
+        B, C = 5 + 9 * k, 1 + (k * 5) % 13   # tiles with ragged tails, several tiles per workgroup
+        P = {"mf_u_embeddings.weight": rng.normal(0, 0.3, (17, d)), "mf_i_embeddings.weight": rng.normal(0, 0.3, (40, d)),
+             "mlp_u_embeddings.weight": rng.normal(0, 0.3, (17, d)), "mlp_i_embeddings.weight": rng.normal(0, 0.3, (40, d)),
+             "mlp.0.weight": rng.normal(0, 0.2, (l1, 2 * d)), "mlp.0.bias": rng.normal(0, 0.2, l1),
+             "prediction.weight": rng.normal(0, 0.2, (1, d + l1))}
+        P = {kk: v.astype(np.float32) for kk, v in P.items()}
+        uid = rng.integers(0, 17, size=B).astype(np.int64)
+        iid = rng.integers(0, 40, size=(B, C)).astype(np.int64)
+        gp = rng.normal(size=(B, C)).astype(np.float32)
+        Pd = to_dev(P, cuda)
+        p, sv = (0.2, 0.5, 0.75)[k % 3], 1000003 * (k + 1) + (k << 40)
+        keep = NO.dropout_keep(sv, B * C, l1, p)
+        _check_against(eng, P, Pd, uid, iid, gp, keep, p, _seed(cuda, sv), 3e-5, cuda, f"d={d} l1={l1} p={p}")
+        # p = 0 through the dropout entry points == the plain entry points, bit for bit
+        u, i = torch.from_numpy(uid).to(cuda), torch.from_numpy(iid).to(cuda)
+        a, b = eng.neumf_fwd(Pd, u, i), eng.neumf_fwd(Pd, u, i, 0.0, _seed(cuda, 5))
+        assert torch.equal(a, b)
+        # same seed -> same mask, other seed -> other prediction
+        s1 = eng.neumf_fwd(Pd, u, i, p, _seed(cuda, sv))
+        assert torch.equal(s1, eng.neumf_fwd(Pd, u, i, p, _seed(cuda, sv)))
+        assert not torch.equal(s1, eng.neumf_fwd(Pd, u, i, p, _seed(cuda, sv + 1)))
+
+
+def test_neumf_dropout_rejects_bad_arguments(cuda, eng):
+    g = load_golden(CASES[0])
+    P = to_dev(params(g), cuda)
+    uid, iid = torch.from_numpy(g["uid"]).to(cuda), torch.from_numpy(g["iid"]).to(cuda)
+    with pytest.raises(ValueError):
+        eng.neumf_fwd(P, uid, iid, 0.2, None)
+    with pytest.raises(RuntimeError, match="outside"):
+        eng.neumf_fwd(P, uid, iid, 1.0, _seed(cuda, 1))
+
+
+def test_neumf_trainer_with_dropout_draws_a_new_mask_every_step(cuda, eng):
+    """NeumfTrainer(dropout=p, seed=s): step k uses the mask of seed s + k; parameters after two SGD steps
+    equal the oracle's with those two masks"""
+    from oracle import bprmf_oracle as BO
+    g = load_golden(CASES[0])
+    P0 = params(g)
+    P = to_dev(P0, cuda)
+    p, s, lr = 0.3, 4242, 0.05
+    tr = eng.NeumfTrainer(P, opt="SGD", lr=lr, l2=0.0, rowwise=False, dropout=p, seed=s)
+    W = {k: v.copy() for k, v in P0.items()}
+    for step, (u, i) in enumerate(((g["uid"], g["iid"]), (g["uid2"], g["iid2"])), 1):
+        loss = tr.step(torch.from_numpy(u).to(cuda), torch.from_numpy(i).to(cuda))
+        keep = NO.dropout_keep(s + step, i.size, W["mlp.0.weight"].shape[0], p)
+        pred, _ = NO.forward(W, u, i, keep)
+        assert_close(loss.cpu().numpy()[0], BO.bpr_loss(pred), what=f"loss {step}")
+        _, G = NO.backward(W, u, i, BO.bpr_loss_grad(pred), keep)
+        W = {k: (v - np.float32(lr) * G[k]).astype(np.float32) for k, v in W.items()}
+    assert int(tr.seed.item()) == s + 2
+    for k, name in NAMES.items():
+        w0 = P0[name].reshape(-1) if k == "w_out" else P0[name]
+        w1 = W[name].reshape(-1) if k == "w_out" else W[name]
+        assert_update_close(P[k].cpu().numpy(), w0, w1, what=k)

@@ -236,8 +236,10 @@ def test_context_device_batches_equal_the_collated_ones(mode, dataset, ctx_root,
 
 
 def test_graph_replay_with_dropout_draws_fresh_masks(data_root, cuda):
-    """models with nn.Dropout are captured too: torch advances the generator offset per replay, so every
-    step sees a new mask (the loss of identical batches differs) and training still converges"""
+    """models with dropout are captured too: the NeuMF head kernels key their mask by a device-side seed that
+    the captured step bumps itself (engine.step_increment), torch's nn.Dropout advances its generator offset
+    per replay; either way every step sees a new mask (the loss of identical batches differs) and training
+    still converges"""
     from rechorus_amd import graph as hgraph
     args, corpus, model, data, runner = _setup(data_root, cuda, "NeuMF", ["--layers", "[32]", "--dropout", "0.3", "--lr", "0.01",
                                                                          "--batch_size", "128"])

@@ -171,6 +171,49 @@ def test_neumf_model_file_matches_reference(case, cuda):
         assert_close(p.grad.cpu().numpy(), g["G/" + name], what="grad " + name, atol_scale=2e-5)
 
 
+@pytest.mark.parametrize("case", ["neumfdrop_d64_l64_k4_p0.2", "neumfdrop_d32_l128_k9_p0.5"])
+def test_neumf_model_file_trains_with_dropout_in_the_kernels(case, cuda):
+    """--dropout p: train mode runs rc_neumf_fwd_dropout / rc_neumf_bwd_dropout (no torch layers); with the
+    model's mask seed set to the golden's, prediction and autograd gradients equal the reference's run with
+    that mask; eval mode is the plain head"""
+    from models.general.NeuMF import NeuMF
+    from rechorus_amd import nn as hnn
+    g = load_golden(case)
+    n_users, n_items, d, l1 = (g["P0/mf_u_embeddings.weight"].shape[0], g["P0/mf_i_embeddings.weight"].shape[0],
+                               int(g["meta"][2]), int(g["meta"][6]))
+    args = argparse.Namespace(device=cuda, model_path="", buffer=1, num_neg=4, dropout=float(g["p"]), test_all=0, emb_size=d,
+                              layers=str([l1]))
+    model = NeuMF(args, argparse.Namespace(n_users=n_users, n_items=n_items))
+    assert "drop_seed" not in model.state_dict()  # checkpoints keep the reference's keys
+    model = _load_state(model, g, cuda)
+    batch = {"user_id": torch.from_numpy(g["uid"]).to(cuda), "item_id": torch.from_numpy(g["iid"]).to(cuda),
+             "batch_size": len(g["uid"]), "phase": "train"}
+    model.train()
+    calls = []
+    real = hnn.engine.neumf_fwd
+    hnn.engine.neumf_fwd = lambda *a, **k: calls.append(a[3:]) or real(*a, **k)
+    try:
+        model.drop_seed.fill_(int(g["mask_seed"]) - 1)  # forward() bumps it once
+        out = model(batch)
+    finally:
+        hnn.engine.neumf_fwd = real
+    assert calls and calls[0][0] == pytest.approx(float(g["p"]))
+    assert_close(out["prediction"].detach().cpu().numpy(), g["pred"], what="prediction")
+    loss = model.loss(out)
+    loss.backward()
+    assert_close(loss.item(), g["loss"], what="loss")
+    for name, p in model.named_parameters():
+        assert_close(p.grad.cpu().numpy(), g["G/" + name], what="grad " + name, atol_scale=2e-5)
+    again = model(batch)["prediction"].detach()
+    assert not torch.equal(again, out["prediction"].detach())  # next forward, next mask
+    model.eval()
+    e1, e2 = model(batch)["prediction"].detach(), model(batch)["prediction"].detach()
+    assert torch.equal(e1, e2)
+    want_eval, _ = __import__("oracle.neumf_oracle", fromlist=["x"]).forward({k[3:]: v for k, v in g.items() if k.startswith("P0/")},
+                                                                          g["uid"], g["iid"])
+    assert_close(e1.cpu().numpy(), want_eval, what="eval prediction")
+
+
 @pytest.mark.parametrize("case", ["sasrec_d64_l1_h1", "sasrec_d64_l1_h4_L50", "sasrec_d64_l2_h2", "sasrec_d32_l1_h4"])
 def test_sasrec_model_file_matches_reference(case, cuda):
     from models.sequential.SASRec import SASRec
@@ -202,6 +245,8 @@ def test_sasrec_model_file_matches_reference(case, cuda):
     ["--model_name", "NeuMF", "--emb_size", "32", "--layers", "[32]", "--lr", "5e-3"],
     ["--model_name", "SASRec", "--emb_size", "32", "--num_layers", "1", "--num_heads", "2", "--history_max", "10", "--lr", "3e-3"],
     ["--model_name", "NeuMF", "--emb_size", "32", "--layers", "[32]", "--lr", "5e-3", "--engine", "rowwise"],
+    ["--model_name", "NeuMF", "--emb_size", "32", "--layers", "[32]", "--lr", "5e-3", "--dropout", "0.2"],
+    ["--model_name", "NeuMF", "--emb_size", "32", "--layers", "[32]", "--lr", "5e-3", "--dropout", "0.2", "--engine", "rowwise"],
     ["--model_name", "SASRec", "--emb_size", "32", "--num_layers", "1", "--num_heads", "2", "--history_max", "10", "--lr", "3e-3",
      "--engine", "rowwise"],
 ])
