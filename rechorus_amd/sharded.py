@@ -16,8 +16,17 @@ moved to the item rows' owners instead ("owner computes"):
   7. reduce  reduce_scatter PUG -> ugrad of the home's tuples;  route to the user rows' owners,
              owner applies the segmented update.
 
-≈5 KB of traffic per tuple instead of ≈45 KB for moving rows both ways.  With W = 1 every collective
-is the identity and the arithmetic equals engine.BprmfTrainer's (same kernels).
+≈5 KB of traffic per tuple instead of ≈45 KB for moving rows both ways at K = 99, W = 8.  The all_gather /
+reduce_scatter pair costs 2 (W-1) d 4 bytes per tuple whatever K is, though, so with FEW candidates per tuple
+(BASELINE's headline configuration has K = 1) moving the rows is the cheaper plan and the step switches to it
+(`mode="auto"`, ShardedBprmf._plan):
+
+  rows travel:  ids -> owners, owners gather and return the 1 + (1+K) rows of every tuple; home runs the fused
+                gather-dot / loss / backward kernel on the compact row blocks; per-occurrence row gradients
+                return along the same routes; owners apply the segmented update.   2 (2+K) d 4 bytes / tuple,
+                independent of W.
+
+With W = 1 every collective is the identity and the arithmetic equals engine.BprmfTrainer's (same kernels).
 
 Local arithmetic goes through an `ops` object: `HipOps` (the C ABI, default) on GPUs; the CPU tests
 inject an oracle-backed implementation so the routing can be verified with gloo, world_size 2.
@@ -96,6 +105,17 @@ class HipOps:
 
     def dense_update(self, W, G, hyper, state):
         self.e.dense_update(W, G, hyper, state.get("m"), state.get("v"))
+
+    # ---- BPRMF on rows that were moved to the tuples (ShardedBprmf, mode "rows") ----------------------
+    def rows_fwd_bwd(self, Ub, Ib, pos_u, pos_i, inv_b):
+        """fused gather-dot + BPR loss + backward on compact row blocks -> (loss_vec [B], g [B,C], ugrad [B,d])"""
+        _, loss_vec, g, ugrad = self.e.bprmf_fwd_bwd(Ub, Ib, pos_u, pos_i, inv_b=inv_b, want_pred=False)
+        return loss_vec, g, ugrad
+
+    def scaled_rows(self, src, idx, coef):
+        """out[o] = coef[o] * src[idx[o]]  (the item-row gradient g * u of every occurrence, in send order)"""
+        n = idx.numel()
+        return self.e.weighted_row_sum(src, idx.reshape(n, 1), coef.reshape(n, 1))
 
     def make_hyper(self, **kw):
         return self.e.make_hyper(**kw)
@@ -220,7 +240,10 @@ def _group_by_owner(ids, world):
 
 class ShardedBprmf:
     def __init__(self, n_users, n_items, emb_size, opt="SGD", lr=1e-3, l2=0.0, device=None, ops=None,
-                 group=None, init_std=0.01, seed=0, force_exchange=False, timing=False):
+                 group=None, init_std=0.01, seed=0, force_exchange=False, timing=False, mode="auto"):
+        if mode not in ("auto", "owner", "rows"):
+            raise ValueError("ShardedBprmf mode must be auto | owner | rows, got {!r}".format(mode))
+        self.mode = mode
         self.group = group
         self.force_exchange = force_exchange  # W = 1 through the general path (loop-back profiling)
         self.timing = [] if timing else None   # [(label, cuda event)] of the last step
@@ -278,6 +301,8 @@ class ShardedBprmf:
             self.timing.clear()
         mark = self._mark
         mark("start")
+        if self._plan(C) == "rows":
+            return self._step_rows(uid, iid, hyper)
 
         # 0. group user ids and candidate occurrences by owner; ONE exchange of all split sizes
         flat = iid.reshape(-1)
@@ -331,6 +356,69 @@ class ShardedBprmf:
         ug_own, _ = _exchange(ugrad[order_u], cnt_u, self.group, recv_counts=rcnt_u)
         ops.update_rows(self.U, self.sU, req_u, ug_own, hyper)
         mark("7 user grads reduce + update")
+        return loss
+
+    def _plan(self, C):
+        """which side travels: bytes over the links per tuple, (W-1)/W of the traffic of either plan"""
+        if self.mode != "auto":
+            return self.mode
+        W, row = self.world, 4 * self.d
+        rows_plan = 2 * (1 + C) * row * (W - 1) / W                      # fetch + gradient push of 1 + C rows
+        owner_plan = 2 * (W - 1) * row + (2 * row + 16 * C) * (W - 1) / W  # all_gather + reduce_scatter + the small routes
+        return "rows" if rows_plan < owner_plan else "owner"
+
+    def _step_rows(self, uid, iid, hyper):
+        """the rows travel to the tuples (few candidates per tuple); see the module docstring"""
+        W, ops, group = self.world, self.ops, self.group
+        B, C = iid.shape
+        n_tuples = W * B
+        dev = uid.device
+        mark = self._mark
+        # 0. group both lookups by owner; ONE exchange of all split sizes
+        order_u, cnt_u, loc_u = self._route(uid)
+        order_i, cnt_i, loc_i = self._route(iid.reshape(-1))
+        (cnt_u, cnt_i), (rcnt_u, rcnt_i) = _exchange_counts([cnt_u, cnt_i], group)
+        mark("0 group by owner")
+
+        # 1. owners serve the rows; they come back in SEND order (grouped by owner), the kernels below
+        #    address them through the inverse permutation instead of un-permuting 256 B rows
+        req_u, _ = _exchange(loc_u, cnt_u, group, recv_counts=rcnt_u)
+        req_i, _ = _exchange(loc_i, cnt_i, group, recv_counts=rcnt_i)
+        back_u = _exchange_back(ops.gather_rows(self.U, req_u), rcnt_u, cnt_u, group)  # [B, d]
+        back_i = _exchange_back(ops.gather_rows(self.I, req_i), rcnt_i, cnt_i, group)  # [B*C, d]
+        pos_u = torch.empty(B, dtype=torch.int64, device=dev)
+        pos_u[order_u] = torch.arange(B, device=dev)
+        pos_i = torch.empty(B * C, dtype=torch.int64, device=dev)
+        pos_i[order_i] = torch.arange(B * C, device=dev)
+        mark("1 fetch rows")
+
+        # 2. home: scores, loss (mean over the GLOBAL batch), dL/dscore and the user-row gradients
+        if hasattr(ops, "rows_fwd_bwd"):
+            loss_vec, g, ugrad = ops.rows_fwd_bwd(back_u, back_i, pos_u, pos_i.view(B, C), 1.0 / n_tuples)
+        else:
+            t_idx = torch.arange(B, device=dev).repeat_interleave(C)
+            pred = ops.dot_rows(back_u, pos_u[t_idx], back_i, pos_i).view(B, C)
+            loss_vec, g = ops.bpr_loss(pred, 1.0 / n_tuples)
+            ugrad = ops.partial_user_grads(back_i, pos_i, g.reshape(-1), t_idx, B)
+        loss = _all_reduce_sum(loss_vec.sum().reshape(1) / n_tuples, group)
+        mark("2 score + loss + backward")
+
+        # 3. row gradients, produced directly in send order, go to the owners
+        order_i64 = order_i.to(torch.int64)
+        src_pos, coef = pos_u[order_i64 // C], g.reshape(-1)[order_i64]
+        if hasattr(ops, "scaled_rows"):
+            gi_send = ops.scaled_rows(back_u, src_pos, coef)
+        else:
+            gi_send = coef[:, None] * back_u[src_pos]
+        gu_send = ops.gather_rows(ugrad, order_u.to(torch.int64))
+        own_u, _ = _exchange(gu_send, cnt_u, group, recv_counts=rcnt_u)
+        own_i, _ = _exchange(gi_send, cnt_i, group, recv_counts=rcnt_i)
+        mark("3 push row gradients")
+
+        # 4. owners: atomic-free segmented update of the rows they serve
+        ops.update_rows(self.I, self.sI, req_i, own_i, hyper)
+        ops.update_rows(self.U, self.sU, req_u, own_u, hyper)
+        mark("4 owner updates")
         return loss
 
     def _route(self, ids, tuple_base=None, div=1):

@@ -125,7 +125,7 @@ def test_owner_backward_equals_the_unfused_owner_ops(opt, d, cuda):
         assert_close(st_b[k], st_a[k], what="state " + k, atol_scale=1e-5)
 
 
-def _loopback_worker(port, out_q):
+def _loopback_worker(port, out_q, mode="owner", C=30):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=0, world_size=1)
     try:
@@ -133,12 +133,13 @@ def _loopback_worker(port, out_q):
         from rechorus_amd.sharded import ShardedBprmf
         dev = torch.device("cuda:0")
         rng = np.random.default_rng(8)
-        n_users, n_items, d, B, C = 301, 2003, 64, 256, 30
+        n_users, n_items, d, B = 301, 2003, 64, 256
         U = rng.normal(0, 0.1, (n_users, d)).astype(np.float32)
         I = rng.normal(0, 0.1, (n_items, d)).astype(np.float32)
         out = {}
         for opt, lr in (("SGD", 0.1), ("Adam", 1e-2)):
-            m = ShardedBprmf(n_users, n_items, d, opt=opt, lr=lr, l2=1e-4, device=dev, force_exchange=True, timing=True)
+            m = ShardedBprmf(n_users, n_items, d, opt=opt, lr=lr, l2=1e-4, device=dev, force_exchange=True, timing=True,
+                             mode=mode)
             m.load_global(torch.from_numpy(U).to(dev), torch.from_numpy(I).to(dev))
             Un, In = U.copy(), I.copy()
             sU, sI = O.new_state(Un, opt), O.new_state(In, opt)
@@ -157,12 +158,14 @@ def _loopback_worker(port, out_q):
         dist.destroy_process_group()
 
 
-def test_world_of_one_through_the_exchange_path(cuda):
-    """force_exchange: the full routed step (HIP counting sort, unpack, owner backward) on one rank vs the oracle"""
+@pytest.mark.parametrize("mode,C,n_phases", [("owner", 30, 8), ("rows", 30, 5), ("rows", 2, 5)])
+def test_world_of_one_through_the_exchange_path(mode, C, n_phases, cuda):
+    """force_exchange: the full routed step on one rank vs the oracle, both plans -- "owner" (HIP counting sort,
+    unpack, owner backward) and "rows" (routes, row fetch, fused kernel on compact row blocks, gradient push)"""
     from conftest import assert_update_close
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    p = ctx.Process(target=_loopback_worker, args=(_free_port(), q))
+    p = ctx.Process(target=_loopback_worker, args=(_free_port(), q, mode, C))
     p.start()
     U0, I0, out = q.get(timeout=300)
     p.join(timeout=60)
@@ -173,7 +176,7 @@ def test_world_of_one_through_the_exchange_path(cuda):
         ex = 1e-3 * 1e-2 if opt == "Adam" else 0.0
         assert_update_close(Ug, U0, Un, what=opt + " dU", extra_atol=ex)
         assert_update_close(Ig, I0, In, what=opt + " dI", extra_atol=ex)
-        assert len(phases) == 8
+        assert len(phases) == n_phases
 
 
 def test_bench_multi_rank_code_path_on_one_gpu(cuda):

@@ -60,7 +60,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, opt, lr, l2, n_users, n_items, d, B, C, steps, out_q):
+def _worker(rank, world, port, opt, lr, l2, n_users, n_items, d, B, C, steps, out_q, mode="owner"):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -68,7 +68,7 @@ def _worker(rank, world, port, opt, lr, l2, n_users, n_items, d, B, C, steps, ou
         rng = np.random.default_rng(5)  # same global problem on every rank
         U = rng.normal(0, 0.1, (n_users, d)).astype(np.float32)
         I = rng.normal(0, 0.1, (n_items, d)).astype(np.float32)
-        m = ShardedBprmf(n_users, n_items, d, opt=opt, lr=lr, l2=l2, ops=OracleOps())
+        m = ShardedBprmf(n_users, n_items, d, opt=opt, lr=lr, l2=l2, ops=OracleOps(), mode=mode)
         m.load_global(torch.from_numpy(U), torch.from_numpy(I))
         losses = []
         for s in range(steps):
@@ -100,13 +100,16 @@ def _reference(world, opt, lr, l2, n_users, n_items, d, B, C, steps):
     return losses, U, I
 
 
-@pytest.mark.parametrize("world,opt,lr,l2", [(2, "SGD", 0.1, 1e-3), (2, "Adam", 1e-2, 0.0), (3, "Adagrad", 0.05, 1e-4)])
-def test_sharded_step_equals_single_table_training(world, opt, lr, l2):
+@pytest.mark.parametrize("world,opt,lr,l2,mode", [(2, "SGD", 0.1, 1e-3, "owner"), (2, "Adam", 1e-2, 0.0, "owner"),
+                                                  (3, "Adagrad", 0.05, 1e-4, "owner"), (2, "SGD", 0.1, 1e-3, "rows"),
+                                                  (3, "Adam", 1e-2, 1e-4, "rows")])
+def test_sharded_step_equals_single_table_training(world, opt, lr, l2, mode):
+    """both plans of the step -- user rows to the item owners ("owner"), all rows to the tuples ("rows")"""
     shape = dict(n_users=23, n_items=41, d=16, B=9, C=6, steps=3)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, opt, lr, l2, *shape.values(), q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, opt, lr, l2, *shape.values(), q, mode)) for r in range(world)]
     for p in procs:
         p.start()
     losses, Ug, Ig = q.get(timeout=120)
@@ -117,6 +120,19 @@ def test_sharded_step_equals_single_table_training(world, opt, lr, l2):
     np.testing.assert_allclose(losses, want_losses, rtol=2e-6)
     np.testing.assert_allclose(Ug, U, rtol=1e-5, atol=2e-7)
     np.testing.assert_allclose(Ig, I, rtol=1e-5, atol=2e-7)
+
+
+def test_plan_follows_the_traffic_model():
+    """auto mode: few candidates per tuple -> the rows travel; many -> the user rows go to the item owners"""
+    from rechorus_amd.sharded import ShardedBprmf
+    m = ShardedBprmf(23, 41, 64, ops=OracleOps())
+    for world, C, want in ((8, 2, "rows"), (8, 100, "owner"), (2, 3, "owner"), (4, 2, "rows"), (8, 5, "rows"), (4, 8, "owner")):
+        m.world = world
+        assert m._plan(C) == want, (world, C)
+    m.mode = "owner"
+    assert m._plan(2) == "owner"
+    with pytest.raises(ValueError):
+        ShardedBprmf(23, 41, 64, ops=OracleOps(), mode="sideways")
 
 
 def test_single_rank_path_matches_oracle():
