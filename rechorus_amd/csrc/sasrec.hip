@@ -50,6 +50,10 @@ struct SasArgs {
   const float* dhv;        // bwd in: [B, D]
   float* g_hist;           // bwd out: [B, L, D] gradient of the layer-0 input rows (0 past length)
   float* part;             // bwd: per-workgroup partial dense grads [n_wg][n_layers * PL]
+  // one launch covers the sequences seq_list[0 .. *seq_count) (nullptr: all B) with `lp` padded rows
+  int lp;
+  const int32_t* seq_list;
+  const int32_t* seq_count;
 };
 
 template <int D>
@@ -63,9 +67,10 @@ struct SasCfg {
                        oln2b = oln2w + D;
 };
 
-// LDS geometry depends on the padded row count: 32 rows (history_max <= 32: 8 buffers = 66 KB, two
-// workgroups per CU) or 64 rows (133 KB, one per CU).  sa = row stride of the [rows][rows] buffer.
-__host__ __device__ inline int sas_lp(int L) { return L <= 32 ? 32 : kSasLP; }
+// LDS geometry depends on the padded row count: 32 rows (8 buffers = 66 KB, two workgroups per CU) or 64
+// rows (133 KB, one per CU).  sa = row stride of the [rows][rows] buffer.  With history_max > 32 the batch
+// is split by length on the device (sas_bucket_kernel) and the sequences of <= 32 items -- most of them in
+// practice -- run the 32-row geometry in their own launch.
 __host__ __device__ inline int sas_buf_floats(int D, int lp) { return lp * ((D + 1) > (lp + 1) ? (D + 1) : (lp + 1)); }
 __host__ __device__ inline int sas_lds_floats(int D, int lp) { return 8 * sas_buf_floats(D, lp) + 2 * lp; }
 
@@ -225,11 +230,13 @@ template <int D, bool SAVE>
 __global__ __launch_bounds__(kBlock) void sasrec_fwd_kernel(SasArgs a) {
   using Cfg = SasCfg<D>;
   constexpr int SD = Cfg::SD;
-  const int LP = sas_lp(a.L), SA = LP + 1, BUF = sas_buf_floats(D, LP);
+  const int LP = a.lp, SA = LP + 1, BUF = sas_buf_floats(D, LP);
   extern __shared__ float lds[];
   float *X = lds, *Q = X + BUF, *K = Q + BUF, *V = K + BUF, *A = V + BUF, *C = A + BUF, *H = C + BUF,
         *Y = H + BUF, *rstd1 = Y + BUF, *rstd2 = rstd1 + LP;
-  for (int64_t b = blockIdx.x; b < a.B; b += gridDim.x) {
+  const int todo = a.seq_count ? *a.seq_count : a.B;
+  for (int w = blockIdx.x; w < todo; w += gridDim.x) {
+    const int64_t b = a.seq_list ? a.seq_list[w] : w;
     int n = (int)a.lengths[b];
     if (n > a.L) n = a.L;
     sas_load_input<D>(a, b, n, X);
@@ -309,14 +316,16 @@ template <int D>
 __global__ __launch_bounds__(kBlock) void sasrec_bwd_kernel(SasArgs a) {
   using Cfg = SasCfg<D>;
   constexpr int SD = Cfg::SD, PL = Cfg::PL;
-  const int LP = sas_lp(a.L), SA = LP + 1, BUF = sas_buf_floats(D, LP);
+  const int LP = a.lp, SA = LP + 1, BUF = sas_buf_floats(D, LP);
   extern __shared__ float lds[];
   float *X = lds, *Q = X + BUF, *K = Q + BUF, *V = K + BUF, *G = V + BUF, *C = G + BUF, *H = C + BUF,
         *Y = H + BUF, *rstd1 = Y + BUF, *rstd2 = rstd1 + LP;
   float* A = Y;  // attention probabilities reuse Y once the FFN backward no longer needs y1
   float* T = H;  // dA / dS reuse H once the FFN backward is done
   float* part = a.part + (size_t)blockIdx.x * a.n_layers * PL;
-  for (int64_t b = blockIdx.x; b < a.B; b += gridDim.x) {
+  const int todo = a.seq_count ? *a.seq_count : a.B;
+  for (int w = blockIdx.x; w < todo; w += gridDim.x) {
+    const int64_t b = a.seq_list ? a.seq_list[w] : w;
     int n = (int)a.lengths[b];
     if (n > a.L) n = a.L;
     // dL/d(output of the last layer): only row n-1 (SASRec.py:76), everything else 0
@@ -472,9 +481,71 @@ static int sas_make_transposes(SasArgs* a, int D, float* dst, hipStream_t s) {
 
 static size_t sas_transpose_floats(int d, int n_layers) { return (size_t)n_layers * 5 * d * d; }
 
-static int sas_grid(int B, int L) {
-  const int cap = sas_lp(L) == 32 ? 1024 : 512;  // two resident workgroups per CU at 66 KB of LDS
+static int sas_grid(int B, int lp) {
+  const int cap = lp == 32 ? 1024 : 512;  // two resident workgroups per CU at 66 KB of LDS
   return B < cap ? (B < 1 ? 1 : B) : cap;
+}
+
+// Split the batch by length: list[0 .. count[0]) = sequences of <= 32 items in batch order, list[B ..
+// B + count[1]) = the longer ones.  One workgroup, ballot compaction, order-preserving: the assignment of
+// sequences to workgroups (and with it the summation order of the dense-gradient partials) is fixed.
+__global__ __launch_bounds__(kBlock) void sas_bucket_kernel(const int64_t* __restrict__ lengths, int B,
+                                                            int32_t* __restrict__ list, int32_t* __restrict__ count) {
+  __shared__ int s_wave[2][kBlock / 64];
+  __shared__ int s_base[2];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x < 2) s_base[threadIdx.x] = 0;
+  __syncthreads();
+  for (int b0 = 0; b0 < B; b0 += kBlock) {
+    const int b = b0 + threadIdx.x;
+    const bool in = b < B;
+    const bool is_short = in && lengths[b] <= 32;
+    const unsigned long long ms = __ballot(is_short), ml = __ballot(in && !is_short);
+    if (lane == 0) {
+      s_wave[0][wave] = __popcll(ms);
+      s_wave[1][wave] = __popcll(ml);
+    }
+    __syncthreads();
+    if (in) {
+      const int k = is_short ? 0 : 1;
+      int off = s_base[k] + __popcll((k == 0 ? ms : ml) & ((1ull << lane) - 1ull));
+      for (int v = 0; v < wave; ++v) off += s_wave[k][v];
+      list[(size_t)k * B + off] = b;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+      int t = 0;
+      for (int v = 0; v < kBlock / 64; ++v) t += s_wave[threadIdx.x][v];
+      s_base[threadIdx.x] += t;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < 2) count[threadIdx.x] = s_base[threadIdx.x];
+}
+
+static size_t sas_bucket_bytes(int B) { return align_up((size_t)(2 * (size_t)B + 64) * sizeof(int32_t), 256); }
+
+// the launches of one pass: everything at 32 rows when history_max <= 32, else short and long buckets
+struct SasPlan {
+  int n;
+  int lp[2];
+  const int32_t* list[2];
+  const int32_t* count[2];
+};
+static int sas_plan(const SasArgs& a, void* bucket_ws, hipStream_t s, SasPlan* plan) {
+  if (a.L <= 32) {
+    plan->n = 1;
+    plan->lp[0] = 32; plan->list[0] = nullptr; plan->count[0] = nullptr;
+    return RC_OK;
+  }
+  int32_t* list = static_cast<int32_t*>(bucket_ws);
+  int32_t* count = list + 2 * (size_t)a.B;
+  hipLaunchKernelGGL(sas_bucket_kernel, dim3(1), dim3(kBlock), 0, s, a.lengths, a.B, list, count);
+  RC_LAUNCH_CHECK();
+  plan->n = 2;
+  plan->lp[0] = 32; plan->list[0] = list; plan->count[0] = count;
+  plan->lp[1] = kSasLP; plan->list[1] = list + a.B; plan->count[1] = count + 1;
+  return RC_OK;
 }
 
 static int sas_fill_layers(SasArgs* a, const float* const* layer_params, int n_layers) {
@@ -492,31 +563,38 @@ static int sas_fill_layers(SasArgs* a, const float* const* layer_params, int n_l
 }
 
 template <int D>
-static int sas_launch_fwd(const SasArgs& a, bool save, hipStream_t s) {
-  const size_t lds_bytes = (size_t)sas_lds_floats(D, sas_lp(a.L)) * sizeof(float);
-  if (save) {
-    auto kern = sasrec_fwd_kernel<D, true>;
-    RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    hipLaunchKernelGGL(kern, dim3(sas_grid(a.B, a.L)), dim3(kBlock), lds_bytes, s, a);
-  } else {
-    auto kern = sasrec_fwd_kernel<D, false>;
-    RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    hipLaunchKernelGGL(kern, dim3(sas_grid(a.B, a.L)), dim3(kBlock), lds_bytes, s, a);
+static int sas_launch_fwd(SasArgs a, bool save, void* bucket_ws, hipStream_t s) {
+  SasPlan plan;
+  RC_TRY(sas_plan(a, bucket_ws, s, &plan));
+  auto kern = save ? sasrec_fwd_kernel<D, true> : sasrec_fwd_kernel<D, false>;
+  const size_t lds_max = (size_t)sas_lds_floats(D, plan.lp[plan.n - 1]) * sizeof(float);
+  RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+  for (int k = 0; k < plan.n; ++k) {
+    a.lp = plan.lp[k]; a.seq_list = plan.list[k]; a.seq_count = plan.count[k];
+    const size_t lds_bytes = (size_t)sas_lds_floats(D, a.lp) * sizeof(float);
+    hipLaunchKernelGGL(kern, dim3(sas_grid(a.B, a.lp)), dim3(kBlock), lds_bytes, s, a);
+    RC_LAUNCH_CHECK();
   }
-  RC_LAUNCH_CHECK();
   return RC_OK;
 }
 
 template <int D>
-static int sas_launch_bwd(const SasArgs& a, float* dense_out, hipStream_t s) {
-  const size_t lds_bytes = (size_t)sas_lds_floats(D, sas_lp(a.L)) * sizeof(float);
-  const int n_wg = sas_grid(a.B, a.L);
+static int sas_launch_bwd(SasArgs a, float* dense_out, void* bucket_ws, hipStream_t s) {
+  SasPlan plan;
+  RC_TRY(sas_plan(a, bucket_ws, s, &plan));
+  int n_wg = 0;
+  for (int k = 0; k < plan.n; ++k) n_wg = sas_grid(a.B, plan.lp[k]) > n_wg ? sas_grid(a.B, plan.lp[k]) : n_wg;
   const int count = a.n_layers * SasCfg<D>::PL;
   RC_HIP(hipMemsetAsync(a.part, 0, (size_t)n_wg * count * sizeof(float), s));
   auto kern = sasrec_bwd_kernel<D>;
-  RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-  hipLaunchKernelGGL(kern, dim3(n_wg), dim3(kBlock), lds_bytes, s, a);
-  RC_LAUNCH_CHECK();
+  const size_t lds_max = (size_t)sas_lds_floats(D, plan.lp[plan.n - 1]) * sizeof(float);
+  RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+  for (int k = 0; k < plan.n; ++k) {  // same stream: the second launch adds to the partial slots of the first
+    a.lp = plan.lp[k]; a.seq_list = plan.list[k]; a.seq_count = plan.count[k];
+    const size_t lds_bytes = (size_t)sas_lds_floats(D, a.lp) * sizeof(float);
+    hipLaunchKernelGGL(kern, dim3(sas_grid(a.B, a.lp)), dim3(kBlock), lds_bytes, s, a);
+    RC_LAUNCH_CHECK();
+  }
   hipLaunchKernelGGL(sas_reduce_partials_kernel, dim3((count + 63) / 64), dim3(kBlock), 0, s, a.part,
                      n_wg, count, dense_out);
   RC_LAUNCH_CHECK();
@@ -536,7 +614,7 @@ extern "C" int rc_sasrec_dense_param_count(int d) { return 5 * d * d + 9 * d; }
 
 extern "C" size_t rc_sasrec_workspace_bytes(int B, int d, int n_layers) {
   if (B < 1 || d < 1 || n_layers < 1) return 0;
-  return align_up(sas_transpose_floats(d, n_layers) * sizeof(float), 256) +
+  return align_up(sas_transpose_floats(d, n_layers) * sizeof(float), 256) + sas_bucket_bytes(B) +
          align_up((size_t)1024 * n_layers * (5 * (size_t)d * d + 9 * d) * sizeof(float), 256) + 256;
 }
 
@@ -555,10 +633,12 @@ extern "C" int rc_sasrec_fwd(const float* item_emb, const float* pos_emb, const 
   a.item_emb = item_emb; a.pos_emb = pos_emb; a.n_heads = n_heads; a.hist = hist; a.lengths = lengths;
   a.B = B; a.L = L; a.hv = hv; a.xsave = xsave;
   hipStream_t s = as_stream(stream);
-  if (ws_bytes < sas_transpose_floats(d, n_layers) * sizeof(float))
+  const size_t t_bytes = align_up(sas_transpose_floats(d, n_layers) * sizeof(float), 256);
+  if (ws_bytes < t_bytes + sas_bucket_bytes(B))
     return fail(RC_ERR_WORKSPACE, "rc_sasrec_fwd: workspace %zu too small (rc_sasrec_workspace_bytes)", ws_bytes);
   RC_TRY(sas_make_transposes(&a, d, reinterpret_cast<float*>(ws), s));
-  return d == 64 ? sas_launch_fwd<64>(a, xsave != nullptr, s) : sas_launch_fwd<32>(a, xsave != nullptr, s);
+  void* bucket_ws = reinterpret_cast<char*>(ws) + t_bytes;
+  return d == 64 ? sas_launch_fwd<64>(a, xsave != nullptr, bucket_ws, s) : sas_launch_fwd<32>(a, xsave != nullptr, bucket_ws, s);
 }
 
 extern "C" int rc_sasrec_bwd(const float* const* layer_params, int n_layers, int n_heads, const int64_t* lengths,
@@ -577,7 +657,8 @@ extern "C" int rc_sasrec_bwd(const float* const* layer_params, int n_layers, int
   a.xsave = const_cast<float*>(xsave); a.dhv = dhv; a.g_hist = g_hist;
   hipStream_t s = as_stream(stream);
   RC_TRY(sas_make_transposes(&a, d, reinterpret_cast<float*>(ws), s));
-  a.part = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) +
-                                    align_up(sas_transpose_floats(d, n_layers) * sizeof(float), 256));
-  return d == 64 ? sas_launch_bwd<64>(a, dense_grads, s) : sas_launch_bwd<32>(a, dense_grads, s);
+  const size_t t_bytes = align_up(sas_transpose_floats(d, n_layers) * sizeof(float), 256);
+  void* bucket_ws = reinterpret_cast<char*>(ws) + t_bytes;
+  a.part = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + t_bytes + sas_bucket_bytes(B));
+  return d == 64 ? sas_launch_bwd<64>(a, dense_grads, bucket_ws, s) : sas_launch_bwd<32>(a, dense_grads, bucket_ws, s);
 }

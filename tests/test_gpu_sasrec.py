@@ -92,3 +92,62 @@ def test_sasrec_two_fit_iterations_match_reference(case, tag, opt, cuda, eng):
             continue
         assert_update_close(t.cpu().numpy(), P0[name], want[name], what=what, extra_atol=ex, rtol=2e-4,
                             outlier_atol=2 * lr if opt == "Adam" else 0.0)
+
+
+def _random_sasrec(rng, n_items, d, n_layers, L):
+    P = {"i_embeddings.weight": rng.normal(0, 0.3, (n_items, d)), "p_embeddings.weight": rng.normal(0, 0.3, (L + 1, d))}
+    for l in range(n_layers):
+        pre = "transformer_block.%d." % l
+        for nm in ("masked_attn_head.q_linear", "masked_attn_head.k_linear", "masked_attn_head.v_linear", "linear1", "linear2"):
+            P[pre + nm + ".weight"] = rng.normal(0, 0.15, (d, d))
+            P[pre + nm + ".bias"] = rng.normal(0, 0.1, d)
+        for nm in ("layer_norm1", "layer_norm2"):
+            P[pre + nm + ".weight"] = 1 + rng.normal(0, 0.1, d)
+            P[pre + nm + ".bias"] = rng.normal(0, 0.1, d)
+    return {k: v.astype(np.float32) for k, v in P.items()}
+
+
+def test_sasrec_length_buckets_vs_oracle(cuda, eng):
+    """history_max > 32: the batch is split on the device into sequences of <= 32 items (32-row LDS geometry)
+    and longer ones (64 rows), two launches per pass.  700 sequences (three rounds of the compaction kernel)
+    with lengths on both sides of the boundary vs the oracle; the short ones must equal, bit for bit, what a
+    history_max = 32 call computes for them."""
+    from oracle import sasrec_oracle as SO
+    rng = np.random.default_rng(17)
+    B, L, d, n_layers, n_heads, C, n_items = 700, 50, 64, 2, 2, 3, 500
+    P = _random_sasrec(rng, n_items, d, n_layers, L)
+    lengths = rng.integers(1, L + 1, size=B).astype(np.int64)
+    lengths[:6] = (32, 33, 1, 50, 31, 34)
+    hist = rng.integers(1, n_items, size=(B, L)).astype(np.int64) * (np.arange(L)[None, :] < lengths[:, None])
+    iid = rng.integers(1, n_items, size=(B, C)).astype(np.int64)
+    gpred = rng.normal(size=(B, C)).astype(np.float32)
+    Pd = to_dev(P, n_layers, cuda)
+    h_d, l_d, i_d = (torch.from_numpy(x).to(cuda) for x in (hist, lengths, iid))
+    hv, xsave = eng.sasrec_fwd(Pd["item_emb"], Pd["pos_emb"], Pd["layers"], n_heads, h_d, l_d, save=True)
+    want_pred, cache = SO.forward(P, hist, lengths, iid, n_heads, keep=True)
+    assert_close(hv.cpu().numpy(), cache["hv"], what="hv", rtol=2e-5, atol_scale=3e-5)
+    gp_d = torch.from_numpy(gpred).to(cuda)
+    dhv = eng.weighted_row_sum(Pd["item_emb"], i_d, gp_d)
+    g_hist, dg = eng.sasrec_bwd(Pd["layers"], n_heads, l_d, xsave, dhv)
+    _, G = SO.backward(P, hist, lengths, iid, n_heads, gpred)
+    floor = 1e-6 * max(float(np.abs(v).max()) for v in G.values())
+    for l in range(n_layers):
+        for k, name in LAYER_NAMES.items():
+            assert_close(dg[l][k].cpu().numpy(), G["transformer_block.%d.%s" % (l, name)], what=f"layer {l} d{k}",
+                         rtol=3e-5, atol_scale=1e-4, abs_floor=floor)
+    valid = (h_d > 0).to(torch.int64)
+    position = ((l_d[:, None] - torch.arange(L, device=cuda)[None, :]) * valid).contiguous()
+    GP = eng.embedding_dense_backward(g_hist, position, Pd["pos_emb"].shape[0])
+    assert_close(GP.cpu().numpy(), G["p_embeddings.weight"], what="d pos_emb", rtol=3e-5, atol_scale=1e-4)
+    # the short bucket runs the same geometry as a history_max = 32 call
+    short = np.nonzero(lengths <= 32)[0]
+    assert 0 < len(short) < B
+    hs = torch.from_numpy(np.ascontiguousarray(hist[short][:, :32])).to(cuda)
+    ls = torch.from_numpy(lengths[short]).to(cuda)
+    hv32, _ = eng.sasrec_fwd(Pd["item_emb"], Pd["pos_emb"], Pd["layers"], n_heads, hs, ls)
+    assert torch.equal(hv32, hv[torch.from_numpy(short).to(cuda)])
+    # deterministic
+    hv_b, xs_b = eng.sasrec_fwd(Pd["item_emb"], Pd["pos_emb"], Pd["layers"], n_heads, h_d, l_d, save=True)
+    g_hist_b, dg_b = eng.sasrec_bwd(Pd["layers"], n_heads, l_d, xs_b, dhv)
+    assert torch.equal(hv, hv_b) and torch.equal(g_hist, g_hist_b)
+    assert all(torch.equal(dg[l][k], dg_b[l][k]) for l in range(n_layers) for k in LAYER_NAMES)
