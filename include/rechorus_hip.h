@@ -284,6 +284,21 @@ int rc_sasrec_bwd(const float* const* layer_params, int n_layers, int n_heads, c
                   int B, int L, int d, const float* xsave, const float* dhv, float* g_hist,
                   float* dense_grads, void* ws, size_t ws_bytes, rc_stream_t stream);
 
+/* The same encoder decomposed at batch level (csrc/sasrec_batch.hip): the valid history rows of the batch form
+ * one compact row space [sum len, d]; projections, LayerNorms and the FFN are streaming kernels over it with the
+ * weights in LDS, only the attention runs per sequence.  Same arithmetic and results (to fp32 summation order)
+ * as rc_sasrec_fwd / rc_sasrec_bwd, several times faster from a few hundred sequences up; the forward pass
+ * SAVES the activations the backward needs in `state` (rc_sasrec_batch_state_floats floats, caller-owned)
+ * instead of the backward recomputing them.  dense_grads / g_hist / hv as in rc_sasrec_fwd / rc_sasrec_bwd.   */
+size_t rc_sasrec_batch_state_floats(int B, int L, int d, int n_layers);
+size_t rc_sasrec_batch_workspace_bytes(int B, int L, int d, int n_layers);
+int rc_sasrec_batch_fwd(const float* item_emb, const float* pos_emb, const float* const* layer_params,
+                        int n_layers, int n_heads, const int64_t* hist, const int64_t* lengths, int B, int L,
+                        int d, float* hv, float* state, void* ws, size_t ws_bytes, rc_stream_t stream);
+int rc_sasrec_batch_bwd(const float* const* layer_params, int n_layers, int n_heads, const int64_t* lengths,
+                        int B, int L, int d, const float* state, const float* dhv, float* g_hist,
+                        float* dense_grads, void* ws, size_t ws_bytes, rc_stream_t stream);
+
 /* ---- NeuMF head (models/general/NeuMF.py:56-76), one hidden layer ------------------------- */
 
 /* 1 iff the fp32-MFMA kernels cover (emb_size d, hidden size l1): d, l1 in {32,64,128} and the

@@ -29,14 +29,14 @@ SOURCES = [
     "dense_opt.hip",
     "train_step.hip",
     "neumf.hip",
-    "sasrec.hip",
+    "sasrec.hip", "sasrec_batch.hip",
     "listwise_loss.hip",
     "fm_bce.hip",
     "sampler.hip",
     "eval_rank.hip",
     "owner_step.hip",
 ]
-HEADERS = ["common.hpp", "bpr_math.hpp", "opt_math.hpp", "philox.hpp", os.path.join("..", "..", "include", "rechorus_hip.h")]
+HEADERS = ["common.hpp", "bpr_math.hpp", "opt_math.hpp", "philox.hpp", "sas_mma.hpp", os.path.join("..", "..", "include", "rechorus_hip.h")]
 
 
 def _hipcc():

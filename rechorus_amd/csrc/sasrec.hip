@@ -23,19 +23,9 @@
 // Dense-parameter gradients are accumulated per workgroup in a private slice of a partial buffer
 // and summed over workgroups in fixed order afterwards (no float atomics, bit-reproducible).
 #include "common.hpp"
+#include "sas_mma.hpp"
 
 namespace rc {
-
-typedef float sas_f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int kSasLP = 64;        // max rows (history length) per sequence
-constexpr int kSasMaxLayers = 4;
-constexpr float kLnEps = 1e-5f;   // nn.LayerNorm default
-
-struct SasLayer {  // device pointers, nn.Linear layout [out, in]
-  const float *Wq, *bq, *Wk, *bk, *Wv, *bv, *ln1w, *ln1b, *W1, *b1, *W2, *b2, *ln2w, *ln2b;
-  const float *WqT, *WkT, *WvT, *W1T, *W2T;  // [in, out] copies (sas_transpose_kernel)
-};
 
 struct SasArgs {
   const float* item_emb;   // [n_items, D]
@@ -56,17 +46,6 @@ struct SasArgs {
   const int32_t* seq_count;
 };
 
-template <int D>
-struct SasCfg {
-  static constexpr int SD = D + 1;                               // row stride of [rows][D] buffers
-  static constexpr int PL = 5 * D * D + 9 * D;                   // dense-parameter floats per layer
-  // offsets inside one layer's parameter-gradient block (canonical order)
-  static constexpr int oWq = 0, obq = oWq + D * D, oWk = obq + D, obk = oWk + D * D, oWv = obk + D,
-                       obv = oWv + D * D, oln1w = obv + D, oln1b = oln1w + D, oW1 = oln1b + D,
-                       ob1 = oW1 + D * D, oW2 = ob1 + D, ob2 = oW2 + D * D, oln2w = ob2 + D,
-                       oln2b = oln2w + D;
-};
-
 // LDS geometry depends on the padded row count: 32 rows (8 buffers = 66 KB, two workgroups per CU) or 64
 // rows (133 KB, one per CU).  sa = row stride of the [rows][rows] buffer.  With history_max > 32 the batch
 // is split by length on the device (sas_bucket_kernel) and the sequences of <= 32 items -- most of them in
@@ -74,85 +53,7 @@ struct SasCfg {
 __host__ __device__ inline int sas_buf_floats(int D, int lp) { return lp * ((D + 1) > (lp + 1) ? (D + 1) : (lp + 1)); }
 __host__ __device__ inline int sas_lds_floats(int D, int lp) { return 8 * sas_buf_floats(D, lp) + 2 * lp; }
 
-// ---- C[M x N] = A[M x K] . B[K x N] on v_mfma_f32_32x32x2_f32 -------------------------------------
-struct MatA { const float* p; int si, sk; };  // a(i,k) = p[i*si + k*sk]
-struct MatB { const float* p; int sk, sj; };  // b(k,j) = p[k*sk + j*sj]
-
-// Every wave of the workgroup calls this; 32x32 output blocks are dealt round-robin to the 4 waves.
-// epi(i, j, value) runs once per valid output element.  causal: skip blocks entirely above the
-// diagonal (their elements are never read).  Out-of-range rows / columns only ever influence
-// out-of-range outputs (discarded), so only the K range needs exact masking.
-template <typename Epi>
-__device__ __forceinline__ void sas_mm(MatA A, MatB B, int M, int N, int K, bool causal, Epi epi) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int nrb = (M + 31) >> 5, ncb = (N + 31) >> 5;
-  for (int q = wave; q < nrb * ncb; q += kBlock / 64) {
-    const int rb = q % nrb, cb = q / nrb;
-    if (causal && cb > rb) continue;  // wave-uniform
-    const int i = rb * 32 + (lane & 31), j = cb * 32 + (lane & 31), kh = lane >> 5;
-    const float* ap = A.p + (i < M ? i : M - 1) * A.si + kh * A.sk;
-    const float* bp = B.p + (j < N ? j : N - 1) * B.sj + kh * B.sk;
-    sas_f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    int k0 = 0;
-    // a workgroup is alone on its CU (LDS), so nothing else hides operand latency: fetch the
-    // operands of 16 (then 4) MFMAs before issuing them -- 32 independent loads in flight
-    for (; k0 + 32 <= K; k0 += 32) {
-      float av[16], bv[16];
-#pragma unroll
-      for (int t = 0; t < 16; ++t) {
-        av[t] = ap[(k0 + 2 * t) * A.sk];
-        bv[t] = bp[(k0 + 2 * t) * B.sk];
-      }
-#pragma unroll
-      for (int t = 0; t < 16; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[t], acc, 0, 0, 0);
-    }
-    for (; k0 + 8 <= K; k0 += 8) {
-      float av[4], bv[4];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        av[t] = ap[(k0 + 2 * t) * A.sk];
-        bv[t] = bp[(k0 + 2 * t) * B.sk];
-      }
-#pragma unroll
-      for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[t], acc, 0, 0, 0);
-    }
-    for (; k0 + 2 <= K; k0 += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[k0 * A.sk], bp[k0 * B.sk], acc, 0, 0, 0);
-    if (k0 < K) {  // odd K: the kh = 1 half has no column left and must feed zeros
-      const float av = kh == 0 ? ap[k0 * A.sk] : 0.f;
-      const float bv = kh == 0 ? bp[k0 * B.sk] : 0.f;
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int ii = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-      if (ii < M && j < N) epi(ii, j, acc[r]);
-    }
-  }
-}
-
 // ---- building blocks (all threads of the workgroup call them; n = valid rows) ----------------
-
-// attention probabilities of head hh into A[i][j] (0 for j > i), rows [0, n)
-template <int D>
-__device__ __forceinline__ void sas_attn_probs(float* A, const float* Q, const float* K, int n, int hh,
-                                               int dk, float sqrt_dk, int SA) {
-  constexpr int SD = SasCfg<D>::SD;
-  sas_mm(MatA{Q + hh * dk, SD, 1}, MatB{K + hh * dk, 1, SD}, n, n, dk, true,
-         [&](int i, int j, float v) { A[i * SA + j] = v / sqrt_dk; });
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int i = wave; i < n; i += kBlock / 64) {  // one wave per row; n <= 64 = wave width
-    const bool on = lane <= i;
-    const float s = on ? A[i * SA + lane] : -INFINITY;
-    const float m = wave_allreduce_max(s);
-    const float e = on ? expf(s - m) : 0.f;
-    const float z = wave_allreduce_sum(e);
-    if (lane < n) A[i * SA + lane] = e / z;
-  }
-  __syncthreads();
-}
 
 // LayerNorm of rows z[i][:] -> xhat (in place) and rstd[i]; optionally y = w*xhat + b into yout
 template <int D>
@@ -375,15 +276,9 @@ __global__ __launch_bounds__(kBlock) void sasrec_bwd_kernel(SasArgs a) {
         // dV_h = A^T . dCtx_h, in place (V_h is not read again)
         sas_mm(MatA{A, 1, SA}, MatB{G + hc, SD, 1}, n, dk, n, false,
                [&](int j, int c, float v) { V[j * SD + hc + c] = v; });
-        {  // dS = A * (dA - rowsum(dA*A)) / sqrt(dk), in place in T, one wave per row, 0 above the diagonal
-          const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-          for (int i = wave; i < n; i += kBlock / 64) {
-            const bool on = lane <= i;
-            const float pa = on ? A[i * SA + lane] : 0.f;
-            const float da = on ? T[i * SA + lane] : 0.f;
-            const float dot = wave_allreduce_sum(pa * da);
-            if (lane < n) T[i * SA + lane] = on ? pa * (da - dot) / sqrt_dk : 0.f;
-          }
+        {  // dS = A * (dA - rowsum(dA*A)) / sqrt(dk), in place in T, 0 above the diagonal
+          const int rows_here = LP / (kBlock / 64);
+          sas_softmax_bwd_rows(T, A, n, SA, sqrt_dk, (int)(threadIdx.x >> 6) * rows_here, rows_here);
         }
         __syncthreads();
         // dQ_h = dS . K_h  -> C[:, head columns]
@@ -416,39 +311,6 @@ __global__ __launch_bounds__(kBlock) void sasrec_bwd_kernel(SasArgs a) {
       gh[idx] = i < n ? G[i * SD + idx % D] : 0.f;
     }
     __syncthreads();
-  }
-}
-
-// out[i] = sum_w p[w][i].  A workgroup owns 64 consecutive outputs; wave v sums the partials w = v, v+4, ...
-// with four interleaved accumulators (16 independent chains of n_wg/16 adds instead of ONE chain of n_wg,
-// which was pure load/add latency), then the 16 chain sums are combined in a fixed order through LDS:
-// deterministic, no float atomics.
-__global__ __launch_bounds__(kBlock) void sas_reduce_partials_kernel(const float* __restrict__ p, int n_wg,
-                                                                     int count, float* __restrict__ out) {
-  __shared__ float sm[4][4][64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int i = (int)blockIdx.x * 64 + lane;
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  if (i < count) {
-    int w = wave;
-    for (; w + 12 < n_wg; w += 16) {
-      acc[0] += p[(size_t)w * count + i];
-      acc[1] += p[(size_t)(w + 4) * count + i];
-      acc[2] += p[(size_t)(w + 8) * count + i];
-      acc[3] += p[(size_t)(w + 12) * count + i];
-    }
-    for (int k = 0; w < n_wg; w += 4, ++k) acc[k] += p[(size_t)w * count + i];
-  }
-#pragma unroll
-  for (int k = 0; k < 4; ++k) sm[wave][k][lane] = acc[k];
-  __syncthreads();
-  if (wave == 0 && i < count) {
-    float total = 0.f;
-#pragma unroll
-    for (int v = 0; v < 4; ++v)
-#pragma unroll
-      for (int k = 0; k < 4; ++k) total += sm[v][k][lane];
-    out[i] = total;
   }
 }
 
@@ -485,45 +347,6 @@ static int sas_grid(int B, int lp) {
   const int cap = lp == 32 ? 1024 : 512;  // two resident workgroups per CU at 66 KB of LDS
   return B < cap ? (B < 1 ? 1 : B) : cap;
 }
-
-// Split the batch by length: list[0 .. count[0]) = sequences of <= 32 items in batch order, list[B ..
-// B + count[1]) = the longer ones.  One workgroup, ballot compaction, order-preserving: the assignment of
-// sequences to workgroups (and with it the summation order of the dense-gradient partials) is fixed.
-__global__ __launch_bounds__(kBlock) void sas_bucket_kernel(const int64_t* __restrict__ lengths, int B,
-                                                            int32_t* __restrict__ list, int32_t* __restrict__ count) {
-  __shared__ int s_wave[2][kBlock / 64];
-  __shared__ int s_base[2];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (threadIdx.x < 2) s_base[threadIdx.x] = 0;
-  __syncthreads();
-  for (int b0 = 0; b0 < B; b0 += kBlock) {
-    const int b = b0 + threadIdx.x;
-    const bool in = b < B;
-    const bool is_short = in && lengths[b] <= 32;
-    const unsigned long long ms = __ballot(is_short), ml = __ballot(in && !is_short);
-    if (lane == 0) {
-      s_wave[0][wave] = __popcll(ms);
-      s_wave[1][wave] = __popcll(ml);
-    }
-    __syncthreads();
-    if (in) {
-      const int k = is_short ? 0 : 1;
-      int off = s_base[k] + __popcll((k == 0 ? ms : ml) & ((1ull << lane) - 1ull));
-      for (int v = 0; v < wave; ++v) off += s_wave[k][v];
-      list[(size_t)k * B + off] = b;
-    }
-    __syncthreads();
-    if (threadIdx.x < 2) {
-      int t = 0;
-      for (int v = 0; v < kBlock / 64; ++v) t += s_wave[threadIdx.x][v];
-      s_base[threadIdx.x] += t;
-    }
-    __syncthreads();
-  }
-  if (threadIdx.x < 2) count[threadIdx.x] = s_base[threadIdx.x];
-}
-
-static size_t sas_bucket_bytes(int B) { return align_up((size_t)(2 * (size_t)B + 64) * sizeof(int32_t), 256); }
 
 // the launches of one pass: everything at 32 rows when history_max <= 32, else short and long buckets
 struct SasPlan {

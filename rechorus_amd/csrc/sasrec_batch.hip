@@ -1,0 +1,827 @@
+// sasrec_batch.hip -- the SASRec encoder (models/sequential/SASRec.py:51-86, utils/layers.py:9-63,92-118)
+// decomposed at BATCH level: the valid history rows of the whole batch form one compact row space
+// [R = sum len, d]; everything that is row-wise (the five d x d projections, both LayerNorms, the FFN) is a
+// streaming kernel over that space with the weights resident in LDS, and only the attention itself runs per
+// sequence.  sasrec.hip keeps a sequence's whole layer in LDS and pays ~30 barrier-separated phases per
+// sequence on one workgroup per CU (matrix cores busy 7 % of the time); here every phase is one launch over
+// ~100 K rows, bound by HBM streaming of [R, d] activations (26 MB each at B = 4096, mean length 25).
+//
+// Same arithmetic as sasrec.hip: fp32 v_mfma_f32_32x32x2_f32 for every contraction, LayerNorm with biased
+// variance and eps 1e-5, causal mask only, position id = length - index, no attention output projection,
+// dropout 0.  Activations needed by the backward pass (layer input, q, k, v, xhat1, y1, relu hidden, xhat2,
+// the two rstd vectors) are SAVED by the forward pass -- they are its natural intermediates -- instead of being
+// recomputed.  Dense-parameter gradients: per-workgroup partials in private slices, summed in fixed order
+// (sas_reduce_partials_kernel); no float atomics anywhere.
+#include "common.hpp"
+#include "sas_mma.hpp"
+
+namespace rc {
+
+constexpr int kSbTile = 64;  // rows per tile of the row-space kernels
+
+// ---- row space ---------------------------------------------------------------------------------------
+
+// off[b] = sum_{b' < b} min(len[b'], L) (exclusive), off[B] = R.  One workgroup; B <= 2^24.
+__global__ __launch_bounds__(kBlock) void sb_offsets_kernel(const int64_t* __restrict__ lengths, int B, int L,
+                                                            int32_t* __restrict__ off) {
+  __shared__ int s_sum[kBlock];
+  const int per = (B + kBlock - 1) / kBlock;
+  const int lo = min((int)threadIdx.x * per, B), hi = min(lo + per, B);
+  int s = 0;
+  for (int b = lo; b < hi; ++b) {
+    const int64_t n = lengths[b];
+    s += (int)(n < 0 ? 0 : (n > L ? L : n));
+  }
+  s_sum[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int t = 0; t < kBlock; ++t) {
+      const int c = s_sum[t];
+      s_sum[t] = run;
+      run += c;
+    }
+    off[B] = run;
+  }
+  __syncthreads();
+  int run = s_sum[threadIdx.x];
+  for (int b = lo; b < hi; ++b) {
+    off[b] = run;
+    const int64_t n = lengths[b];
+    run += (int)(n < 0 ? 0 : (n > L ? L : n));
+  }
+}
+
+__device__ __forceinline__ int sb_len(const int64_t* lengths, int b, int L) {
+  const int64_t n = lengths[b];
+  return (int)(n < 0 ? 0 : (n > L ? L : n));
+}
+
+// X[off[b] + i] = item_emb[hist[b, i]] + pos_emb[len - i]  (SASRec.py:62-66)
+template <int D>
+__global__ __launch_bounds__(kBlock) void sb_embed_kernel(const float* __restrict__ item_emb,
+                                                          const float* __restrict__ pos_emb,
+                                                          const int64_t* __restrict__ hist,
+                                                          const int64_t* __restrict__ lengths, int B, int L,
+                                                          const int32_t* __restrict__ off, float* __restrict__ X) {
+  constexpr int LPR = D / 4;
+  const int l = threadIdx.x % LPR;
+  const int64_t total = (int64_t)B * L;
+  for (int64_t e = (int64_t)blockIdx.x * (kBlock / LPR) + threadIdx.x / LPR; e < total;
+       e += (int64_t)gridDim.x * (kBlock / LPR)) {
+    const int b = (int)(e / L), i = (int)(e - (int64_t)b * L);
+    const int n = sb_len(lengths, b, L);
+    if (i >= n) continue;
+    const int64_t r = off[b] + i;
+    const float4 a = reinterpret_cast<const float4*>(item_emb)[hist[e] * LPR + l];
+    const float4 p = reinterpret_cast<const float4*>(pos_emb)[(int64_t)(n - i) * LPR + l];
+    reinterpret_cast<float4*>(X)[r * LPR + l] = make_float4(a.x + p.x, a.y + p.y, a.z + p.z, a.w + p.w);
+  }
+}
+
+// ---- Y_w = epilogue(X . W_w^T)  or  X . W_w  over the row space, W_w resident in LDS ---------------------
+
+struct SbLinArgs {
+  const float* X;       // [R, D]
+  const float* W[3];    // nn.Linear weights [out, in]
+  const float* bias[3]; // may be null
+  float* Y[3];          // [R, D]
+  const float* res;     // optional: Y += res            (same row space)
+  const float* mask;    // optional: Y = mask > 0 ? Y : 0 (ReLU backward)
+  int relu;
+  const int32_t* off;
+  int B;
+};
+
+template <int D, int NW, bool TRANS>
+__global__ __launch_bounds__(kBlock) void sb_linear_kernel(SbLinArgs a) {
+  constexpr int SD = D + 1;
+  extern __shared__ float lds[];
+  float* Ws = lds;                    // [NW][D][SD]
+  float* Xs = lds + NW * D * SD;      // [kSbTile][SD]
+  for (int w = 0; w < NW; ++w)
+    for (int idx = threadIdx.x; idx < D * D; idx += kBlock) Ws[w * D * SD + (idx / D) * SD + idx % D] = a.W[w][idx];
+  const int R = a.off[a.B];
+  const int tiles = (R + kSbTile - 1) / kSbTile;
+  for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const int r0 = tile * kSbTile;
+    const int m = min(kSbTile, R - r0);
+    __syncthreads();  // previous tile's readers are done (and the weights are in place)
+    for (int idx = threadIdx.x; idx < m * (D / 4); idx += kBlock) {
+      const int i = idx / (D / 4), c = idx % (D / 4);
+      const float4 v = reinterpret_cast<const float4*>(a.X)[(size_t)(r0 + i) * (D / 4) + c];
+      float* d = Xs + i * SD + 4 * c;
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const float* Wl = Ws + w * D * SD;
+      const MatB mb = TRANS ? MatB{Wl, SD, 1} : MatB{Wl, 1, SD};  // dx = dy . W   |   y = x . W^T
+      const float* bias = a.bias[w];
+      float* Y = a.Y[w];
+      sas_mm(MatA{Xs, SD, 1}, mb, m, D, D, false, [&](int i, int j, float v) {
+        const size_t e = (size_t)(r0 + i) * D + j;
+        if (bias) v += bias[j];
+        if (a.relu) v = fmaxf(v, 0.f);
+        if (a.mask) v = a.mask[e] > 0.f ? v : 0.f;
+        if (a.res) v += a.res[e];
+        Y[e] = v;
+      });
+    }
+  }
+}
+
+// ---- LayerNorm over rows: z = A (+ Bv) -> xhat, rstd, y = w * xhat + b ----------------------------------
+
+template <int D>
+__global__ __launch_bounds__(kBlock) void sb_ln_fwd_kernel(const float* __restrict__ A, const float* __restrict__ Bv,
+                                                           const float* __restrict__ w, const float* __restrict__ bb,
+                                                           const int32_t* __restrict__ off, int B,
+                                                           float* __restrict__ xhat, float* __restrict__ rstd,
+                                                           float* __restrict__ y) {
+  constexpr int LPR = D / 4;
+  const int l = threadIdx.x % LPR;
+  const int R = off[B];
+  const float4 wv = reinterpret_cast<const float4*>(w)[l], bv = reinterpret_cast<const float4*>(bb)[l];
+  for (int64_t r = (int64_t)blockIdx.x * (kBlock / LPR) + threadIdx.x / LPR; r < R; r += (int64_t)gridDim.x * (kBlock / LPR)) {
+    float4 z = reinterpret_cast<const float4*>(A)[r * LPR + l];
+    if (Bv) {
+      const float4 t = reinterpret_cast<const float4*>(Bv)[r * LPR + l];
+      z.x += t.x; z.y += t.y; z.z += t.z; z.w += t.w;
+    }
+    const float mu = row_allreduce_sum<LPR>((z.x + z.y) + (z.z + z.w)) / D;
+    const float cx = z.x - mu, cy = z.y - mu, cz = z.z - mu, cw = z.w - mu;
+    const float var = row_allreduce_sum<LPR>(fmaf(cx, cx, fmaf(cy, cy, fmaf(cz, cz, cw * cw)))) / D;
+    const float rs = 1.0f / sqrtf(var + kLnEps);
+    const float4 xh = make_float4(cx * rs, cy * rs, cz * rs, cw * rs);
+    reinterpret_cast<float4*>(xhat)[r * LPR + l] = xh;
+    if (l == 0) rstd[r] = rs;
+    reinterpret_cast<float4*>(y)[r * LPR + l] =
+        make_float4(fmaf(xh.x, wv.x, bv.x), fmaf(xh.y, wv.y, bv.y), fmaf(xh.z, wv.z, bv.z), fmaf(xh.w, wv.w, bv.w));
+  }
+}
+
+// LayerNorm backward in place: G holds dY on entry, dZ on exit; per-workgroup partial d(weight), d(bias) go to
+// gw[blockIdx][:D], gb[blockIdx][:D] (stride = part_stride floats between workgroups)
+template <int D>
+__global__ __launch_bounds__(kBlock) void sb_ln_bwd_kernel(float* __restrict__ G, const float* __restrict__ xhat,
+                                                           const float* __restrict__ rstd, const float* __restrict__ w,
+                                                           const int32_t* __restrict__ off, int B,
+                                                           float* __restrict__ gw, float* __restrict__ gb,
+                                                           size_t part_stride) {
+  constexpr int LPR = D / 4, GPB = kBlock / LPR;
+  __shared__ float s_red[2][GPB][D + 1];
+  const int l = threadIdx.x % LPR, grp = threadIdx.x / LPR;
+  const int R = off[B];
+  const float4 wv = reinterpret_cast<const float4*>(w)[l];
+  float4 aw = make_float4(0.f, 0.f, 0.f, 0.f), ab = aw;
+  for (int64_t r = (int64_t)blockIdx.x * GPB + grp; r < R; r += (int64_t)gridDim.x * GPB) {
+    const float4 g = reinterpret_cast<const float4*>(G)[r * LPR + l];
+    const float4 xh = reinterpret_cast<const float4*>(xhat)[r * LPR + l];
+    aw.x = fmaf(g.x, xh.x, aw.x); aw.y = fmaf(g.y, xh.y, aw.y); aw.z = fmaf(g.z, xh.z, aw.z); aw.w = fmaf(g.w, xh.w, aw.w);
+    ab.x += g.x; ab.y += g.y; ab.z += g.z; ab.w += g.w;
+    const float4 dx = make_float4(g.x * wv.x, g.y * wv.y, g.z * wv.z, g.w * wv.w);
+    const float m1 = row_allreduce_sum<LPR>((dx.x + dx.y) + (dx.z + dx.w)) / D;
+    const float m2 = row_allreduce_sum<LPR>(fmaf(dx.x, xh.x, fmaf(dx.y, xh.y, fmaf(dx.z, xh.z, dx.w * xh.w)))) / D;
+    const float rs = rstd[r];
+    reinterpret_cast<float4*>(G)[r * LPR + l] =
+        make_float4(rs * (dx.x - m1 - xh.x * m2), rs * (dx.y - m1 - xh.y * m2), rs * (dx.z - m1 - xh.z * m2),
+                    rs * (dx.w - m1 - xh.w * m2));
+  }
+  float* sw = &s_red[0][grp][4 * l];
+  float* sb = &s_red[1][grp][4 * l];
+  sw[0] = aw.x; sw[1] = aw.y; sw[2] = aw.z; sw[3] = aw.w;
+  sb[0] = ab.x; sb[1] = ab.y; sb[2] = ab.z; sb[3] = ab.w;
+  __syncthreads();
+  for (int k = threadIdx.x; k < 2 * D; k += kBlock) {  // fixed order over the groups
+    const int which = k / D, c = k % D;
+    float t = 0.f;
+    for (int g2 = 0; g2 < GPB; ++g2) t += s_red[which][g2][c];
+    (which == 0 ? gw : gb)[(size_t)blockIdx.x * part_stride + c] = t;
+  }
+}
+
+// ---- attention per sequence: ctx = softmax(causal(Q K^T / sqrt(dk))) V, head by head ---------------------
+
+struct SbAttnArgs {
+  const float *q, *k, *v;   // [R, D]
+  float* ctx;               // fwd out [R, D]
+  const float* dctx;        // bwd in  [R, D]
+  float *dq, *dk, *dv;      // bwd out [R, D]
+  const int64_t* lengths;
+  const int32_t* off;
+  int B, L, n_heads, lp;
+  const int32_t* seq_list;  // sequences of this launch (nullptr: all), see sas_bucket_kernel
+  const int32_t* seq_count;
+};
+
+__host__ __device__ inline int sb_buf_floats(int D, int lp) { return lp * ((D + 1) > (lp + 1) ? (D + 1) : (lp + 1)); }
+
+template <int D>
+__device__ __forceinline__ void sb_load_rows(float* dst, const float* __restrict__ src, int64_t r0, int n) {
+  constexpr int SD = D + 1;
+  for (int idx = threadIdx.x; idx < n * (D / 4); idx += kBlock) {
+    const int i = idx / (D / 4), c = idx % (D / 4);
+    const float4 v = reinterpret_cast<const float4*>(src)[(size_t)(r0 + i) * (D / 4) + c];
+    float* d = dst + i * SD + 4 * c;
+    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+  }
+}
+template <int D>
+__device__ __forceinline__ void sb_store_rows(float* __restrict__ dst, const float* src, int64_t r0, int n) {
+  constexpr int SD = D + 1;
+  for (int idx = threadIdx.x; idx < n * (D / 4); idx += kBlock) {
+    const int i = idx / (D / 4), c = idx % (D / 4);
+    const float* s = src + i * SD + 4 * c;
+    reinterpret_cast<float4*>(dst)[(size_t)(r0 + i) * (D / 4) + c] = make_float4(s[0], s[1], s[2], s[3]);
+  }
+}
+
+template <int D>
+__global__ __launch_bounds__(kBlock) void sb_attn_fwd_kernel(SbAttnArgs a) {
+  constexpr int SD = D + 1;
+  const int LP = a.lp, SA = LP + 1, BUF = sb_buf_floats(D, LP);
+  extern __shared__ float lds[];
+  float *Q = lds, *K = Q + BUF, *V = K + BUF, *A = V + BUF, *C = A + BUF;
+  const int dk = D / a.n_heads;
+  const float sqrt_dk = sqrtf((float)dk);
+  const int todo = a.seq_count ? *a.seq_count : a.B;
+  for (int w = blockIdx.x; w < todo; w += gridDim.x) {
+    const int b = a.seq_list ? a.seq_list[w] : w;
+    const int n = sb_len(a.lengths, b, a.L);
+    if (n == 0) continue;  // workgroup-uniform
+    const int64_t r0 = a.off[b];
+    sb_load_rows<D>(Q, a.q, r0, n);
+    sb_load_rows<D>(K, a.k, r0, n);
+    sb_load_rows<D>(V, a.v, r0, n);
+    __syncthreads();
+    for (int hh = 0; hh < a.n_heads; ++hh) {
+      sas_attn_probs<D>(A, Q, K, n, hh, dk, sqrt_dk, SA);
+      const int hc = hh * dk;
+      sas_mm(MatA{A, SA, 1}, MatB{V + hc, SD, 1}, n, dk, n, false, [&](int i, int c, float v) { C[i * SD + hc + c] = v; });
+      __syncthreads();
+    }
+    sb_store_rows<D>(a.ctx, C, r0, n);
+    __syncthreads();
+  }
+}
+
+// backward of the above: dq, dk, dv from dctx (probabilities are recomputed from q, k)
+template <int D>
+__global__ __launch_bounds__(kBlock) void sb_attn_bwd_kernel(SbAttnArgs a) {
+  constexpr int SD = D + 1;
+  const int LP = a.lp, SA = LP + 1, BUF = sb_buf_floats(D, LP);
+  extern __shared__ float lds[];
+  float *Q = lds, *K = Q + BUF, *V = K + BUF, *G = V + BUF, *C = G + BUF, *A = C + BUF, *T = A + BUF;
+  const int dk = D / a.n_heads;
+  const float sqrt_dk = sqrtf((float)dk);
+  const int todo = a.seq_count ? *a.seq_count : a.B;
+  for (int w = blockIdx.x; w < todo; w += gridDim.x) {
+    const int b = a.seq_list ? a.seq_list[w] : w;
+    const int n = sb_len(a.lengths, b, a.L);
+    if (n == 0) continue;
+    const int64_t r0 = a.off[b];
+    sb_load_rows<D>(Q, a.q, r0, n);
+    sb_load_rows<D>(K, a.k, r0, n);
+    sb_load_rows<D>(V, a.v, r0, n);
+    sb_load_rows<D>(G, a.dctx, r0, n);
+    __syncthreads();
+    for (int hh = 0; hh < a.n_heads; ++hh) {  // dV, dK overwrite V, K in place; dQ goes to C
+      const int hc = hh * dk;
+      sas_attn_probs<D>(A, Q, K, n, hh, dk, sqrt_dk, SA);
+      sas_mm(MatA{G + hc, SD, 1}, MatB{V + hc, 1, SD}, n, n, dk, true, [&](int i, int j, float v) { T[i * SA + j] = v; });
+      __syncthreads();
+      sas_mm(MatA{A, 1, SA}, MatB{G + hc, SD, 1}, n, dk, n, false, [&](int j, int c, float v) { V[j * SD + hc + c] = v; });
+      {  // dS = A * (dA - rowsum(dA*A)) / sqrt(dk), in place in T, 0 above the diagonal
+        const int rows_here = LP / (kBlock / 64);
+        sas_softmax_bwd_rows(T, A, n, SA, sqrt_dk, (int)(threadIdx.x >> 6) * rows_here, rows_here);
+      }
+      __syncthreads();
+      sas_mm(MatA{T, SA, 1}, MatB{K + hc, SD, 1}, n, dk, n, false, [&](int i, int c, float v) { C[i * SD + hc + c] = v; });
+      __syncthreads();
+      sas_mm(MatA{T, 1, SA}, MatB{Q + hc, SD, 1}, n, dk, n, false, [&](int j, int c, float v) { K[j * SD + hc + c] = v; });
+      __syncthreads();
+    }
+    sb_store_rows<D>(a.dq, C, r0, n);
+    sb_store_rows<D>(a.dk, K, r0, n);
+    sb_store_rows<D>(a.dv, V, r0, n);
+    __syncthreads();
+  }
+}
+
+// ---- one WAVE per head: no workgroup barrier between the phases of a head -------------------------------------
+// blockDim = 64 * n_heads (n_heads <= 4).  Q, K, V (and dctx) of the sequence are staged once for all heads; each
+// wave owns its head's probability (and dA / dS) scratch and writes its column slice of the outputs straight to
+// global memory.  Two barriers per sequence instead of three (five in the backward) per head.
+
+template <int D>
+__device__ __forceinline__ void sb_load_rows_n(float* dst, const float* __restrict__ src, int64_t r0, int n) {
+  constexpr int SD = D + 1;
+  for (int idx = threadIdx.x; idx < n * (D / 4); idx += blockDim.x) {
+    const int i = idx / (D / 4), c = idx % (D / 4);
+    const float4 v = reinterpret_cast<const float4*>(src)[(size_t)(r0 + i) * (D / 4) + c];
+    float* d = dst + i * SD + 4 * c;
+    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+  }
+}
+
+template <int D>
+__global__ __launch_bounds__(kBlock) void sb_attn_fwd_wave_kernel(SbAttnArgs a) {
+  constexpr int SD = D + 1;
+  const int LP = a.lp, SA = LP + 1, BUF = sb_buf_floats(D, LP);
+  extern __shared__ float lds[];
+  float *Q = lds, *K = Q + BUF, *V = K + BUF;
+  const int hh = threadIdx.x >> 6;
+  float* A = V + BUF + hh * LP * SA;
+  const int dk = D / a.n_heads, hc = hh * dk;
+  const float sqrt_dk = sqrtf((float)dk);
+  const int todo = a.seq_count ? *a.seq_count : a.B;
+  for (int w = blockIdx.x; w < todo; w += gridDim.x) {
+    const int b = a.seq_list ? a.seq_list[w] : w;
+    const int n = sb_len(a.lengths, b, a.L);
+    if (n == 0) continue;  // workgroup-uniform
+    const int64_t r0 = a.off[b];
+    __syncthreads();  // the previous sequence's readers are done
+    sb_load_rows_n<D>(Q, a.q, r0, n);
+    sb_load_rows_n<D>(K, a.k, r0, n);
+    sb_load_rows_n<D>(V, a.v, r0, n);
+    __syncthreads();
+    sas_attn_probs_wave<D>(A, Q, K, n, hh, dk, sqrt_dk, SA);
+    sas_mm_wave(MatA{A, SA, 1}, MatB{V + hc, SD, 1}, n, dk, n, false,
+                [&](int i, int c, float v) { a.ctx[(size_t)(r0 + i) * D + hc + c] = v; });
+  }
+}
+
+template <int D>
+__global__ __launch_bounds__(kBlock) void sb_attn_bwd_wave_kernel(SbAttnArgs a) {
+  constexpr int SD = D + 1;
+  const int LP = a.lp, SA = LP + 1, BUF = sb_buf_floats(D, LP);
+  extern __shared__ float lds[];
+  float *Q = lds, *K = Q + BUF, *V = K + BUF, *G = V + BUF;
+  const int hh = threadIdx.x >> 6;
+  float* A = G + BUF + (2 * hh) * LP * SA;
+  float* T = A + LP * SA;
+  const int dk = D / a.n_heads, hc = hh * dk;
+  const float sqrt_dk = sqrtf((float)dk);
+  const int todo = a.seq_count ? *a.seq_count : a.B;
+  for (int w = blockIdx.x; w < todo; w += gridDim.x) {
+    const int b = a.seq_list ? a.seq_list[w] : w;
+    const int n = sb_len(a.lengths, b, a.L);
+    if (n == 0) continue;
+    const int64_t r0 = a.off[b];
+    __syncthreads();
+    sb_load_rows_n<D>(Q, a.q, r0, n);
+    sb_load_rows_n<D>(K, a.k, r0, n);
+    sb_load_rows_n<D>(V, a.v, r0, n);
+    sb_load_rows_n<D>(G, a.dctx, r0, n);
+    __syncthreads();
+    sas_attn_probs_wave<D>(A, Q, K, n, hh, dk, sqrt_dk, SA);
+    // dA = dCtx_h . V_h^T (lower triangle)
+    sas_mm_wave(MatA{G + hc, SD, 1}, MatB{V + hc, 1, SD}, n, n, dk, true, [&](int i, int j, float v) { T[i * SA + j] = v; });
+    // dV_h = A^T . dCtx_h
+    sas_mm_wave(MatA{A, 1, SA}, MatB{G + hc, SD, 1}, n, dk, n, false,
+                [&](int j, int c, float v) { a.dv[(size_t)(r0 + j) * D + hc + c] = v; });
+    sas_softmax_bwd_rows(T, A, n, SA, sqrt_dk, 0, LP);  // dS in place in T
+    // dQ_h = dS . K_h,  dK_h = dS^T . Q_h
+    sas_mm_wave(MatA{T, SA, 1}, MatB{K + hc, SD, 1}, n, dk, n, false,
+                [&](int i, int c, float v) { a.dq[(size_t)(r0 + i) * D + hc + c] = v; });
+    sas_mm_wave(MatA{T, 1, SA}, MatB{Q + hc, SD, 1}, n, dk, n, false,
+                [&](int j, int c, float v) { a.dk[(size_t)(r0 + j) * D + hc + c] = v; });
+  }
+}
+
+// ---- weight gradients: dW[o][k] = sum_r dY[r][o] X[r][k], db[o] = sum_r dY[r][o] --------------------------
+// NP (dY, X) pairs that share X are handled by one launch (dq, dk, dv against the layer input).  Each workgroup
+// keeps its accumulators in registers over all of its row tiles and writes ONE partial block per pair.
+
+struct SbWgradArgs {
+  const float* dY[3];
+  const float* X;
+  float* gW[3];  // this workgroup's slice = gW[p] + blockIdx.x * part_stride
+  float* gb[3];
+  size_t part_stride;
+  const int32_t* off;
+  int B;
+};
+
+template <int D, int NP>
+__global__ __launch_bounds__(kBlock) void sb_wgrad_kernel(SbWgradArgs a) {
+  constexpr int SD = D + 1, NB = D / 32;  // NB x NB output blocks of 32 x 32
+  extern __shared__ float lds[];
+  float* Xs = lds;                 // [kSbTile][SD]
+  float* Ys = lds + kSbTile * SD;  // [NP][kSbTile][SD]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int R = a.off[a.B];
+  const int tiles = (R + kSbTile - 1) / kSbTile;
+  // output blocks q = (pair, rb, cb) are dealt round-robin to the waves; NP * NB * NB <= 12 -> at most 3 per wave
+  constexpr int NQ = NP * NB * NB, QPW = (NQ + 3) / 4;
+  sas_f32x16 acc[QPW];
+#pragma unroll
+  for (int s = 0; s < QPW; ++s)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
+  float bsum[NP];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) bsum[p] = 0.f;
+
+  for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const int r0 = tile * kSbTile;
+    const int m = min(kSbTile, R - r0);
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < kSbTile * (D / 4); idx += kBlock) {  // rows past m are zero-filled
+      const int i = idx / (D / 4), c = idx % (D / 4);
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i < m) v = reinterpret_cast<const float4*>(a.X)[(size_t)(r0 + i) * (D / 4) + c];
+      float* d = Xs + i * SD + 4 * c;
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        float4 u = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < m) u = reinterpret_cast<const float4*>(a.dY[p])[(size_t)(r0 + i) * (D / 4) + c];
+        float* e = Ys + (p * kSbTile + i) * SD + 4 * c;
+        e[0] = u.x; e[1] = u.y; e[2] = u.z; e[3] = u.w;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < QPW; ++s) {
+      const int q = wave + 4 * s;
+      if (q < NQ) {  // wave-uniform
+        const int p = q / (NB * NB), rb = (q % (NB * NB)) % NB, cb = (q % (NB * NB)) / NB;
+        const int kh = lane >> 5;
+        // a(o, r) = dY[r][o]: lanes run along o;  b(r, k) = X[r][k]: lanes run along k
+        const float* ap = Ys + (p * kSbTile) * SD + rb * 32 + (lane & 31) + kh * SD;
+        const float* bp = Xs + cb * 32 + (lane & 31) + kh * SD;
+#pragma unroll
+        for (int k0 = 0; k0 < kSbTile; k0 += 32) {
+          float av[16], bv[16];
+#pragma unroll
+          for (int t = 0; t < 16; ++t) {
+            av[t] = ap[(k0 + 2 * t) * SD];
+            bv[t] = bp[(k0 + 2 * t) * SD];
+          }
+#pragma unroll
+          for (int t = 0; t < 16; ++t) acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[t], acc[s], 0, 0, 0);
+        }
+      }
+    }
+    if ((int)threadIdx.x < D) {  // bias: column sums of dY, rows in ascending order
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        float t = 0.f;
+        for (int i = 0; i < m; ++i) t += Ys[(p * kSbTile + i) * SD + threadIdx.x];
+        bsum[p] += t;
+      }
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < QPW; ++s) {
+    const int q = wave + 4 * s;
+    if (q < NQ) {
+      const int p = q / (NB * NB), rb = (q % (NB * NB)) % NB, cb = (q % (NB * NB)) / NB;
+      float* out = a.gW[p] + (size_t)blockIdx.x * a.part_stride;
+      const int k = cb * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int o = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        out[o * D + k] = acc[s][r];
+      }
+    }
+  }
+  if ((int)threadIdx.x < D)
+#pragma unroll
+    for (int p = 0; p < NP; ++p) (a.gb[p] + (size_t)blockIdx.x * a.part_stride)[threadIdx.x] = bsum[p];
+}
+
+// ---- small row kernels -------------------------------------------------------------------------------
+
+// hv[b] = X[off[b] + len - 1] (0 for an empty history)   (SASRec.py:76)
+template <int D>
+__global__ __launch_bounds__(kBlock) void sb_last_rows_kernel(const float* __restrict__ X, const int64_t* __restrict__ lengths,
+                                                              const int32_t* __restrict__ off, int B, int L,
+                                                              float* __restrict__ hv) {
+  constexpr int LPR = D / 4;
+  const int l = threadIdx.x % LPR;
+  for (int b = blockIdx.x * (kBlock / LPR) + threadIdx.x / LPR; b < B; b += gridDim.x * (kBlock / LPR)) {
+    const int n = sb_len(lengths, b, L);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (n > 0) v = reinterpret_cast<const float4*>(X)[(size_t)(off[b] + n - 1) * LPR + l];
+    reinterpret_cast<float4*>(hv)[(size_t)b * LPR + l] = v;
+  }
+}
+
+// G[off[b] + i] = dhv[b] on the last row (i = len - 1) of sequence b, 0 on its other rows
+template <int D>
+__global__ __launch_bounds__(kBlock) void sb_seed_kernel(const float* __restrict__ dhv, const int64_t* __restrict__ lengths,
+                                                         const int32_t* __restrict__ off, int B, int L,
+                                                         float* __restrict__ G) {
+  constexpr int LPR = D / 4;
+  const int l = threadIdx.x % LPR;
+  const int64_t total = (int64_t)B * L;
+  for (int64_t e = (int64_t)blockIdx.x * (kBlock / LPR) + threadIdx.x / LPR; e < total;
+       e += (int64_t)gridDim.x * (kBlock / LPR)) {
+    const int b = (int)(e / L), i = (int)(e - (int64_t)b * L);
+    const int n = sb_len(lengths, b, L);
+    if (i >= n) continue;
+    reinterpret_cast<float4*>(G)[(size_t)(off[b] + i) * LPR + l] =
+        i == n - 1 ? reinterpret_cast<const float4*>(dhv)[(size_t)b * LPR + l] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+
+// g_hist[b, i] = i < len ? G[off[b] + i] : 0   (padded layout the table update consumes)
+template <int D>
+__global__ __launch_bounds__(kBlock) void sb_unpack_kernel(const float* __restrict__ G, const int64_t* __restrict__ lengths,
+                                                           const int32_t* __restrict__ off, int B, int L,
+                                                           float* __restrict__ g_hist) {
+  constexpr int LPR = D / 4;
+  const int l = threadIdx.x % LPR;
+  const int64_t total = (int64_t)B * L;
+  for (int64_t e = (int64_t)blockIdx.x * (kBlock / LPR) + threadIdx.x / LPR; e < total;
+       e += (int64_t)gridDim.x * (kBlock / LPR)) {
+    const int b = (int)(e / L), i = (int)(e - (int64_t)b * L);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < sb_len(lengths, b, L)) v = reinterpret_cast<const float4*>(G)[(size_t)(off[b] + i) * LPR + l];
+    reinterpret_cast<float4*>(g_hist)[e * LPR + l] = v;
+  }
+}
+
+// ---- host side: buffer layout and launch sequences ---------------------------------------------------------
+
+static int sb_fill_layers(SasLayer* layer, const float* const* layer_params, int n_layers) {
+  RC_REQUIRE(n_layers >= 1 && n_layers <= kSasMaxLayers, "SASRec: num_layers must be in [1, %d]", kSasMaxLayers);
+  RC_REQUIRE(layer_params != nullptr, "SASRec: layer parameter table missing");
+  for (int l = 0; l < n_layers; ++l) {
+    const float* const* q = layer_params + 14 * l;
+    for (int k = 0; k < 14; ++k) RC_REQUIRE(q[k] != nullptr, "SASRec: layer %d parameter %d is null", l, k);
+    SasLayer& s = layer[l];
+    memset(&s, 0, sizeof(s));
+    s.Wq = q[0]; s.bq = q[1]; s.Wk = q[2]; s.bk = q[3]; s.Wv = q[4]; s.bv = q[5]; s.ln1w = q[6]; s.ln1b = q[7];
+    s.W1 = q[8]; s.b1 = q[9]; s.W2 = q[10]; s.b2 = q[11]; s.ln2w = q[12]; s.ln2b = q[13];
+  }
+  return RC_OK;
+}
+
+// saved activations of one layer, [Rmax, D] each (+ two [Rmax] vectors); Rmax = B * L
+struct SbSaved {
+  float *x, *q, *k, *v, *xh1, *y1, *h, *xh2, *rstd1, *rstd2;
+};
+static size_t sb_layer_floats(size_t rmax, int d) { return 8 * rmax * d + 2 * rmax; }
+static SbSaved sb_saved(float* state, int l, size_t rmax, int d) {
+  float* p = state + (size_t)l * sb_layer_floats(rmax, d);
+  SbSaved s;
+  s.x = p; s.q = s.x + rmax * d; s.k = s.q + rmax * d; s.v = s.k + rmax * d; s.xh1 = s.v + rmax * d;
+  s.y1 = s.xh1 + rmax * d; s.h = s.y1 + rmax * d; s.xh2 = s.h + rmax * d; s.rstd1 = s.xh2 + rmax * d;
+  s.rstd2 = s.rstd1 + rmax;
+  return s;
+}
+
+constexpr int kSbPartWg = 512;  // workgroups that own a partial-gradient slice
+
+struct SbWs {
+  int32_t *off, *bucket;
+  float *t0, *t1, *t2, *t3;  // [Rmax, D] scratch
+  float* part;               // [kSbPartWg][n_layers * PL]
+  size_t total;
+};
+static SbWs sb_carve(void* base, int B, int L, int d, int n_layers, bool bwd) {
+  Carver cv(base);
+  SbWs w;
+  const size_t rmax = (size_t)B * L;
+  w.off = cv.take<int32_t>((size_t)B + 1);
+  w.bucket = cv.take<int32_t>(2 * (size_t)B + 64);
+  w.t0 = cv.take<float>(rmax * d);
+  w.t1 = bwd ? cv.take<float>(rmax * d) : nullptr;
+  w.t2 = bwd ? cv.take<float>(rmax * d) : nullptr;
+  w.t3 = bwd ? cv.take<float>(rmax * d) : nullptr;
+  w.part = bwd ? cv.take<float>((size_t)kSbPartWg * n_layers * (5 * (size_t)d * d + 9 * d)) : nullptr;
+  w.total = cv.off;
+  return w;
+}
+
+static int sb_row_grid(int64_t rows, int lpr) {
+  int64_t g = (rows + (kBlock / lpr) - 1) / (kBlock / lpr);
+  if (g > 256 * 8) g = 256 * 8;
+  return (int)(g < 1 ? 1 : g);
+}
+
+template <int D, int NW, bool TRANS>
+static int sb_linear(const SbLinArgs& a, int64_t rmax, hipStream_t s) {
+  const size_t lds = (size_t)(NW * D + kSbTile) * (D + 1) * sizeof(float);
+  auto kern = sb_linear_kernel<D, NW, TRANS>;
+  RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  int64_t tiles = (rmax + kSbTile - 1) / kSbTile;
+  const int per_cu = (int)((160 * 1024) / lds);
+  const int64_t cap = 256 * (int64_t)(per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu));
+  if (tiles > cap) tiles = cap;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(tiles < 1 ? 1 : tiles)), dim3(kBlock), lds, s, a);
+  RC_LAUNCH_CHECK();
+  return RC_OK;
+}
+
+// attention launches: one geometry when history_max <= 32, else the short / long buckets of sas_bucket_kernel.
+// Up to 4 heads run one wave per head (sb_attn_*_wave_kernel) when the per-head scratch fits the LDS; otherwise
+// (more heads; the backward of the 64-row bucket) the four waves of the workgroup share each head's blocks.
+template <int D, bool BWD>
+static int sb_attention(SbAttnArgs a, int32_t* bucket, hipStream_t s) {
+  const int n_launch = a.L <= 32 ? 1 : 2;
+  if (n_launch == 2) {
+    hipLaunchKernelGGL(sas_bucket_kernel, dim3(1), dim3(kBlock), 0, s, a.lengths, a.B, bucket, bucket + 2 * (size_t)a.B);
+    RC_LAUNCH_CHECK();
+  }
+  for (int k = 0; k < n_launch; ++k) {
+    a.lp = k == 0 ? 32 : kSasLP;
+    a.seq_list = n_launch == 2 ? bucket + (size_t)k * a.B : nullptr;
+    a.seq_count = n_launch == 2 ? bucket + 2 * (size_t)a.B + k : nullptr;
+    const size_t buf = (size_t)sb_buf_floats(D, a.lp) * sizeof(float);
+    const size_t head = (size_t)a.lp * (a.lp + 1) * sizeof(float);
+    const size_t lds_wave = (BWD ? 4 : 3) * buf + (BWD ? 2 : 1) * a.n_heads * head;
+    const bool per_wave = a.n_heads <= 4 && lds_wave <= 160 * 1024;
+    const size_t lds = per_wave ? lds_wave : (size_t)(BWD ? 7 : 5) * buf;
+    auto kern = per_wave ? (BWD ? sb_attn_bwd_wave_kernel<D> : sb_attn_fwd_wave_kernel<D>)
+                         : (BWD ? sb_attn_bwd_kernel<D> : sb_attn_fwd_kernel<D>);
+    RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int per_cu = (int)((160 * 1024) / lds);
+    int grid = 256 * (per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu));
+    if (grid > a.B) grid = a.B;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(per_wave ? 64 * a.n_heads : kBlock), lds, s, a);
+    RC_LAUNCH_CHECK();
+  }
+  return RC_OK;
+}
+
+template <int D>
+static int sb_forward(const float* item_emb, const float* pos_emb, const SasLayer* layer, int n_layers, int n_heads,
+                      const int64_t* hist, const int64_t* lengths, int B, int L, float* hv, float* state,
+                      const SbWs& w, hipStream_t s) {
+  constexpr int LPR = D / 4;
+  const size_t rmax = (size_t)B * L;
+  hipLaunchKernelGGL(sb_offsets_kernel, dim3(1), dim3(kBlock), 0, s, lengths, B, L, w.off);
+  RC_LAUNCH_CHECK();
+  SbSaved sv = sb_saved(state, 0, rmax, D);
+  hipLaunchKernelGGL((sb_embed_kernel<D>), dim3(sb_row_grid((int64_t)rmax, LPR)), dim3(kBlock), 0, s, item_emb, pos_emb, hist,
+                     lengths, B, L, w.off, sv.x);
+  RC_LAUNCH_CHECK();
+  for (int l = 0; l < n_layers; ++l) {
+    const SasLayer& p = layer[l];
+    sv = sb_saved(state, l, rmax, D);
+    float* xnext = l + 1 < n_layers ? sb_saved(state, l + 1, rmax, D).x : state + (size_t)n_layers * sb_layer_floats(rmax, D);
+    SbLinArgs a;
+    memset(&a, 0, sizeof(a));
+    a.off = w.off; a.B = B;
+    a.X = sv.x; a.W[0] = p.Wq; a.W[1] = p.Wk; a.W[2] = p.Wv; a.bias[0] = p.bq; a.bias[1] = p.bk; a.bias[2] = p.bv;
+    a.Y[0] = sv.q; a.Y[1] = sv.k; a.Y[2] = sv.v;
+    RC_TRY((sb_linear<D, 3, false>(a, (int64_t)rmax, s)));
+    SbAttnArgs at;
+    memset(&at, 0, sizeof(at));
+    at.q = sv.q; at.k = sv.k; at.v = sv.v; at.ctx = w.t0; at.lengths = lengths; at.off = w.off; at.B = B; at.L = L;
+    at.n_heads = n_heads;
+    RC_TRY((sb_attention<D, false>(at, w.bucket, s)));
+    hipLaunchKernelGGL((sb_ln_fwd_kernel<D>), dim3(sb_row_grid((int64_t)rmax, LPR)), dim3(kBlock), 0, s, w.t0, sv.x, p.ln1w,
+                       p.ln1b, w.off, B, sv.xh1, sv.rstd1, sv.y1);
+    RC_LAUNCH_CHECK();
+    memset(&a, 0, sizeof(a));
+    a.off = w.off; a.B = B;
+    a.X = sv.y1; a.W[0] = p.W1; a.bias[0] = p.b1; a.Y[0] = sv.h; a.relu = 1;
+    RC_TRY((sb_linear<D, 1, false>(a, (int64_t)rmax, s)));
+    a.X = sv.h; a.W[0] = p.W2; a.bias[0] = p.b2; a.Y[0] = w.t0; a.relu = 0; a.res = sv.y1;
+    RC_TRY((sb_linear<D, 1, false>(a, (int64_t)rmax, s)));
+    hipLaunchKernelGGL((sb_ln_fwd_kernel<D>), dim3(sb_row_grid((int64_t)rmax, LPR)), dim3(kBlock), 0, s, w.t0,
+                       static_cast<const float*>(nullptr), p.ln2w, p.ln2b, w.off, B, sv.xh2, sv.rstd2, xnext);
+    RC_LAUNCH_CHECK();
+  }
+  const float* xout = state + (size_t)n_layers * sb_layer_floats(rmax, D);
+  hipLaunchKernelGGL((sb_last_rows_kernel<D>), dim3(sb_row_grid(B, LPR)), dim3(kBlock), 0, s, xout, lengths, w.off, B, L, hv);
+  RC_LAUNCH_CHECK();
+  return RC_OK;
+}
+
+template <int D, int NP>
+static int sb_wgrad(const SbWgradArgs& a, int64_t rmax, hipStream_t s) {
+  const size_t lds = (size_t)(1 + NP) * kSbTile * (D + 1) * sizeof(float);
+  auto kern = sb_wgrad_kernel<D, NP>;
+  RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  int64_t tiles = (rmax + kSbTile - 1) / kSbTile;
+  if (tiles > kSbPartWg) tiles = kSbPartWg;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(tiles < 1 ? 1 : tiles)), dim3(kBlock), lds, s, a);
+  RC_LAUNCH_CHECK();
+  return RC_OK;
+}
+
+template <int D>
+static int sb_backward(const SasLayer* layer, int n_layers, int n_heads, const int64_t* lengths, int B, int L,
+                       const float* state, const float* dhv, float* g_hist, float* dense_out, const SbWs& w,
+                       hipStream_t s) {
+  using Cfg = SasCfg<D>;
+  constexpr int LPR = D / 4, PL = Cfg::PL;
+  const size_t rmax = (size_t)B * L;
+  const size_t stride = (size_t)n_layers * PL;  // floats between the slices of consecutive workgroups
+  hipLaunchKernelGGL(sb_offsets_kernel, dim3(1), dim3(kBlock), 0, s, lengths, B, L, w.off);
+  RC_LAUNCH_CHECK();
+  RC_HIP(hipMemsetAsync(w.part, 0, (size_t)kSbPartWg * stride * sizeof(float), s));
+  float* G = w.t0;
+  hipLaunchKernelGGL((sb_seed_kernel<D>), dim3(sb_row_grid((int64_t)rmax, LPR)), dim3(kBlock), 0, s, dhv, lengths, w.off, B, L, G);
+  RC_LAUNCH_CHECK();
+  const int ln_grid = sb_row_grid((int64_t)rmax, LPR) < kSbPartWg ? sb_row_grid((int64_t)rmax, LPR) : kSbPartWg;
+  for (int l = n_layers - 1; l >= 0; --l) {
+    const SasLayer& p = layer[l];
+    const SbSaved sv = sb_saved(const_cast<float*>(state), l, rmax, D);
+    float* gp = w.part + (size_t)l * PL;
+    // LayerNorm2
+    hipLaunchKernelGGL((sb_ln_bwd_kernel<D>), dim3(ln_grid), dim3(kBlock), 0, s, G, sv.xh2, sv.rstd2, p.ln2w, w.off, B,
+                       gp + Cfg::oln2w, gp + Cfg::oln2b, stride);
+    RC_LAUNCH_CHECK();
+    // FFN: dW2, db2; dHpre = (dZ2 . W2) * relu'(h); dW1, db1; dY1 = dZ2 + dHpre . W1
+    SbWgradArgs g;
+    memset(&g, 0, sizeof(g));
+    g.off = w.off; g.B = B; g.part_stride = stride;
+    g.dY[0] = G; g.X = sv.h; g.gW[0] = gp + Cfg::oW2; g.gb[0] = gp + Cfg::ob2;
+    RC_TRY((sb_wgrad<D, 1>(g, (int64_t)rmax, s)));
+    SbLinArgs a;
+    memset(&a, 0, sizeof(a));
+    a.off = w.off; a.B = B;
+    a.X = G; a.W[0] = p.W2; a.Y[0] = w.t1; a.mask = sv.h;
+    RC_TRY((sb_linear<D, 1, true>(a, (int64_t)rmax, s)));
+    g.dY[0] = w.t1; g.X = sv.y1; g.gW[0] = gp + Cfg::oW1; g.gb[0] = gp + Cfg::ob1;
+    RC_TRY((sb_wgrad<D, 1>(g, (int64_t)rmax, s)));
+    a.X = w.t1; a.W[0] = p.W1; a.Y[0] = G; a.mask = nullptr; a.res = G;
+    RC_TRY((sb_linear<D, 1, true>(a, (int64_t)rmax, s)));
+    // LayerNorm1: G = dZ1 = dCtx = the residual branch of dX
+    hipLaunchKernelGGL((sb_ln_bwd_kernel<D>), dim3(ln_grid), dim3(kBlock), 0, s, G, sv.xh1, sv.rstd1, p.ln1w, w.off, B,
+                       gp + Cfg::oln1w, gp + Cfg::oln1b, stride);
+    RC_LAUNCH_CHECK();
+    // attention
+    SbAttnArgs at;
+    memset(&at, 0, sizeof(at));
+    at.q = sv.q; at.k = sv.k; at.v = sv.v; at.dctx = G; at.dq = w.t1; at.dk = w.t2; at.dv = w.t3;
+    at.lengths = lengths; at.off = w.off; at.B = B; at.L = L; at.n_heads = n_heads;
+    RC_TRY((sb_attention<D, true>(at, w.bucket, s)));
+    // projections: parameter gradients against the layer input, dX = dZ1 + dQ Wq + dK Wk + dV Wv
+    g.dY[0] = w.t1; g.dY[1] = w.t2; g.dY[2] = w.t3; g.X = sv.x;
+    g.gW[0] = gp + Cfg::oWq; g.gb[0] = gp + Cfg::obq; g.gW[1] = gp + Cfg::oWk; g.gb[1] = gp + Cfg::obk;
+    g.gW[2] = gp + Cfg::oWv; g.gb[2] = gp + Cfg::obv;
+    RC_TRY((sb_wgrad<D, 3>(g, (int64_t)rmax, s)));
+    const float* dproj[3] = {w.t1, w.t2, w.t3};
+    const float* wproj[3] = {p.Wq, p.Wk, p.Wv};
+    for (int k = 0; k < 3; ++k) {
+      a.X = dproj[k]; a.W[0] = wproj[k]; a.Y[0] = G; a.res = G;
+      RC_TRY((sb_linear<D, 1, true>(a, (int64_t)rmax, s)));
+    }
+  }
+  hipLaunchKernelGGL((sb_unpack_kernel<D>), dim3(sb_row_grid((int64_t)rmax, LPR)), dim3(kBlock), 0, s, G, lengths, w.off, B, L,
+                     g_hist);
+  RC_LAUNCH_CHECK();
+  const int count = n_layers * PL;
+  hipLaunchKernelGGL(sas_reduce_partials_kernel, dim3((count + 63) / 64), dim3(kBlock), 0, s, w.part, kSbPartWg, count,
+                     dense_out);
+  RC_LAUNCH_CHECK();
+  return RC_OK;
+}
+
+}  // namespace rc
+
+using namespace rc;
+
+extern "C" size_t rc_sasrec_batch_state_floats(int B, int L, int d, int n_layers) {
+  if (B < 1 || L < 1 || d < 1 || n_layers < 1) return 0;
+  const size_t rmax = (size_t)B * L;
+  return (size_t)n_layers * sb_layer_floats(rmax, d) + rmax * d;
+}
+
+extern "C" size_t rc_sasrec_batch_workspace_bytes(int B, int L, int d, int n_layers) {
+  if (B < 1 || L < 1 || d < 1 || n_layers < 1) return 0;
+  return sb_carve(nullptr, B, L, d, n_layers, true).total + 256;
+}
+
+extern "C" int rc_sasrec_batch_fwd(const float* item_emb, const float* pos_emb, const float* const* layer_params,
+                                   int n_layers, int n_heads, const int64_t* hist, const int64_t* lengths, int B, int L,
+                                   int d, float* hv, float* state, void* ws, size_t ws_bytes, rc_stream_t stream) {
+  if (B == 0) return RC_OK;
+  RC_REQUIRE(item_emb && pos_emb && hist && lengths && hv && state && ws, "rc_sasrec_batch_fwd: null pointer");
+  if (!rc_sasrec_supported(d, n_layers, n_heads, L))
+    return fail(RC_ERR_UNSUPPORTED, "rc_sasrec_batch_fwd: d=%d layers=%d heads=%d L=%d not supported", d, n_layers, n_heads, L);
+  RC_REQUIRE((int64_t)B * L < ((int64_t)1 << 31), "rc_sasrec_batch_fwd: B * L too large");
+  SasLayer layer[kSasMaxLayers];
+  RC_TRY(sb_fill_layers(layer, layer_params, n_layers));
+  const SbWs w = sb_carve(ws, B, L, d, n_layers, false);
+  if (ws_bytes < w.total) return fail(RC_ERR_WORKSPACE, "rc_sasrec_batch_fwd: workspace %zu < %zu", ws_bytes, w.total);
+  hipStream_t s = as_stream(stream);
+  return d == 64 ? sb_forward<64>(item_emb, pos_emb, layer, n_layers, n_heads, hist, lengths, B, L, hv, state, w, s)
+                 : sb_forward<32>(item_emb, pos_emb, layer, n_layers, n_heads, hist, lengths, B, L, hv, state, w, s);
+}
+
+extern "C" int rc_sasrec_batch_bwd(const float* const* layer_params, int n_layers, int n_heads, const int64_t* lengths,
+                                   int B, int L, int d, const float* state, const float* dhv, float* g_hist,
+                                   float* dense_grads, void* ws, size_t ws_bytes, rc_stream_t stream) {
+  if (B == 0) return RC_OK;
+  RC_REQUIRE(lengths && state && dhv && g_hist && dense_grads && ws, "rc_sasrec_batch_bwd: null pointer");
+  if (!rc_sasrec_supported(d, n_layers, n_heads, L))
+    return fail(RC_ERR_UNSUPPORTED, "rc_sasrec_batch_bwd: d=%d layers=%d heads=%d L=%d not supported", d, n_layers, n_heads, L);
+  SasLayer layer[kSasMaxLayers];
+  RC_TRY(sb_fill_layers(layer, layer_params, n_layers));
+  const SbWs w = sb_carve(ws, B, L, d, n_layers, true);
+  if (ws_bytes < w.total) return fail(RC_ERR_WORKSPACE, "rc_sasrec_batch_bwd: workspace %zu < %zu", ws_bytes, w.total);
+  hipStream_t s = as_stream(stream);
+  return d == 64 ? sb_backward<64>(layer, n_layers, n_heads, lengths, B, L, state, dhv, g_hist, dense_grads, w, s)
+                 : sb_backward<32>(layer, n_layers, n_heads, lengths, B, L, state, dhv, g_hist, dense_grads, w, s);
+}

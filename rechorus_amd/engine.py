@@ -5,6 +5,7 @@ Nothing here falls back to torch arithmetic: a missing library, a CPU tensor or 
 unsupported shape raises.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -447,32 +448,74 @@ def _sas_ptr_table(layers):
     return tab
 
 
-def sasrec_fwd(item_emb, pos_emb, layers, n_heads, hist, lengths, save=False):
-    """-> (hv [B,d], xsave|None): encoder output at position length-1 (SASRec.py:58-76)"""
+class SasSaved:
+    """what one forward pass keeps for its backward: layer inputs only (`sequence` kernels, the backward recomputes
+    the rest) or every intermediate activation over the compact row space (`batch` kernels)"""
+
+    def __init__(self, impl, data, B, n_layers, L, d):
+        self.impl, self.data, self.B, self.n_layers, self.L, self.d = impl, data, B, n_layers, L, d
+
+
+SASREC_BATCH_MIN_ROWS = 4096  # B * history_max from which the batch-level kernels are used (launch-bound below)
+
+
+def _sasrec_impl(B, L, impl):
+    impl = impl or os.environ.get("RC_SASREC_IMPL", "auto")
+    if impl == "auto":
+        return "batch" if B * L >= SASREC_BATCH_MIN_ROWS else "sequence"
+    if impl not in ("batch", "sequence"):
+        raise ValueError("SASRec impl must be auto | batch | sequence, got {!r}".format(impl))
+    return impl
+
+
+def sasrec_fwd(item_emb, pos_emb, layers, n_heads, hist, lengths, save=False, impl=None):
+    """-> (hv [B,d], SasSaved|None): encoder output at position length-1 (SASRec.py:58-76).
+    impl: 'sequence' (csrc/sasrec.hip, one workgroup per sequence), 'batch' (csrc/sasrec_batch.hip, row-space
+    kernels), default by batch size."""
     B, L = hist.shape
     d = item_emb.shape[1]
     dev, f32 = hist.device, torch.float32
     hv = torch.empty((B, d), dtype=f32, device=dev)
+    lib = _lib.load()
+    impl = _sasrec_impl(B, L, impl)
+    if impl == "batch":
+        # eval passes reuse one scratch state; training passes own theirs until the backward has run
+        n_state = lib.rc_sasrec_batch_state_floats(B, L, d, len(layers))
+        state = (torch.empty(n_state, dtype=f32, device=dev) if save
+                 else workspace(4 * n_state, dev, "sasrec_state").view(f32)[:n_state])
+        ws = workspace(lib.rc_sasrec_batch_workspace_bytes(B, L, d, len(layers)), dev, "sasrec_batch")
+        _lib.call("rc_sasrec_batch_fwd", _ptr(item_emb, f32, "item_emb"), _ptr(pos_emb, f32, "pos_emb"),
+                  _sas_ptr_table(layers), len(layers), int(n_heads), _ptr(hist, torch.int64, "hist"),
+                  _ptr(lengths, torch.int64, "lengths"), B, L, d, _ptr(hv, f32, "hv"), _ptr(state, f32, "state"),
+                  C.c_void_p(ws.data_ptr()), ws.numel(), _stream())
+        return hv, (SasSaved("batch", state, B, len(layers), L, d) if save else None)
     xsave = torch.empty((B, len(layers), L, d), dtype=f32, device=dev) if save else None
-    ws = workspace(_lib.load().rc_sasrec_workspace_bytes(B, d, len(layers)), dev, "sasrec")
+    ws = workspace(lib.rc_sasrec_workspace_bytes(B, d, len(layers)), dev, "sasrec")
     _lib.call("rc_sasrec_fwd", _ptr(item_emb, f32, "item_emb"), _ptr(pos_emb, f32, "pos_emb"),
               _sas_ptr_table(layers), len(layers), int(n_heads), _ptr(hist, torch.int64, "hist"),
               _ptr(lengths, torch.int64, "lengths"), B, L, d, _ptr(hv, f32, "hv"),
               _ptr(xsave, f32, "xsave", True), C.c_void_p(ws.data_ptr()), ws.numel(), _stream())
-    return hv, xsave
+    return hv, (SasSaved("sequence", xsave, B, len(layers), L, d) if save else None)
 
 
-def sasrec_bwd(layers, n_heads, lengths, xsave, dhv):
-    """-> (g_hist [B,L,d], list of per-layer dicts of dense gradients)"""
-    B, n_layers, L, d = xsave.shape
-    dev, f32 = xsave.device, torch.float32
+def sasrec_bwd(layers, n_heads, lengths, saved, dhv):
+    """-> (g_hist [B,L,d], list of per-layer dicts of dense gradients); `saved` from sasrec_fwd(save=True)"""
+    B, n_layers, L, d = saved.B, saved.n_layers, saved.L, saved.d
+    dev, f32 = dhv.device, torch.float32
     g_hist = torch.empty((B, L, d), dtype=f32, device=dev)
-    pl = _lib.load().rc_sasrec_dense_param_count(d)
+    lib = _lib.load()
+    pl = lib.rc_sasrec_dense_param_count(d)
     dense = torch.empty((n_layers, pl), dtype=f32, device=dev)
-    ws = workspace(_lib.load().rc_sasrec_workspace_bytes(B, d, n_layers), dev, "sasrec")
-    _lib.call("rc_sasrec_bwd", _sas_ptr_table(layers), n_layers, int(n_heads), _ptr(lengths, torch.int64, "lengths"),
-              B, L, d, _ptr(xsave, f32, "xsave"), _ptr(dhv, f32, "dhv"), _ptr(g_hist, f32, "g_hist"),
-              _ptr(dense, f32, "dense"), C.c_void_p(ws.data_ptr()), ws.numel(), _stream())
+    if saved.impl == "batch":
+        ws = workspace(lib.rc_sasrec_batch_workspace_bytes(B, L, d, n_layers), dev, "sasrec_batch")
+        _lib.call("rc_sasrec_batch_bwd", _sas_ptr_table(layers), n_layers, int(n_heads), _ptr(lengths, torch.int64, "lengths"),
+                  B, L, d, _ptr(saved.data, f32, "state"), _ptr(dhv, f32, "dhv"), _ptr(g_hist, f32, "g_hist"),
+                  _ptr(dense, f32, "dense"), C.c_void_p(ws.data_ptr()), ws.numel(), _stream())
+    else:
+        ws = workspace(lib.rc_sasrec_workspace_bytes(B, d, n_layers), dev, "sasrec")
+        _lib.call("rc_sasrec_bwd", _sas_ptr_table(layers), n_layers, int(n_heads), _ptr(lengths, torch.int64, "lengths"),
+                  B, L, d, _ptr(saved.data, f32, "xsave"), _ptr(dhv, f32, "dhv"), _ptr(g_hist, f32, "g_hist"),
+                  _ptr(dense, f32, "dense"), C.c_void_p(ws.data_ptr()), ws.numel(), _stream())
     grads = []
     for l in range(n_layers):
         off, g = 0, {}

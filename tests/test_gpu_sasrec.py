@@ -29,8 +29,11 @@ def eng(cuda):
     return engine
 
 
+@pytest.mark.parametrize("impl", ["sequence", "batch"])
 @pytest.mark.parametrize("case", CASES)
-def test_sasrec_forward_backward(case, cuda, eng):
+def test_sasrec_forward_backward(case, impl, cuda, eng):
+    """both implementations of the encoder (one workgroup per sequence / batch-level row-space kernels) against
+    the reference's own outputs"""
     g = load_golden(case)
     n_layers, n_heads = int(g["meta"][2]), int(g["meta"][3])
     P = to_dev(params(g), n_layers, cuda)
@@ -38,11 +41,11 @@ def test_sasrec_forward_backward(case, cuda, eng):
     B, L = g["hist"].shape
     C, d = g["iid"].shape[1], P["item_emb"].shape[1]
     assert eng.sasrec_supported(d, n_layers, n_heads, L)
-    hv, xsave = eng.sasrec_fwd(P["item_emb"], P["pos_emb"], P["layers"], n_heads, hist, lengths, save=True)
+    hv, xsave = eng.sasrec_fwd(P["item_emb"], P["pos_emb"], P["layers"], n_heads, hist, lengths, save=True, impl=impl)
     rows = torch.arange(B, device=cuda)
     pred = eng.gather_dot(hv, P["item_emb"], rows, iid)
     assert_close(pred.cpu().numpy(), g["pred"], what="pred", atol_scale=2e-5)
-    hv2, _ = eng.sasrec_fwd(P["item_emb"], P["pos_emb"], P["layers"], n_heads, hist, lengths, save=False)
+    hv2, _ = eng.sasrec_fwd(P["item_emb"], P["pos_emb"], P["layers"], n_heads, hist, lengths, save=False, impl=impl)
     assert torch.equal(hv, hv2)
 
     gpred = torch.from_numpy(g["gpred"]).to(cuda)
@@ -107,7 +110,8 @@ def _random_sasrec(rng, n_items, d, n_layers, L):
     return {k: v.astype(np.float32) for k, v in P.items()}
 
 
-def test_sasrec_length_buckets_vs_oracle(cuda, eng):
+@pytest.mark.parametrize("impl", ["sequence", "batch"])
+def test_sasrec_length_buckets_vs_oracle(impl, cuda, eng):
     """history_max > 32: the batch is split on the device into sequences of <= 32 items (32-row LDS geometry)
     and longer ones (64 rows), two launches per pass.  700 sequences (three rounds of the compaction kernel)
     with lengths on both sides of the boundary vs the oracle; the short ones must equal, bit for bit, what a
@@ -123,7 +127,7 @@ def test_sasrec_length_buckets_vs_oracle(cuda, eng):
     gpred = rng.normal(size=(B, C)).astype(np.float32)
     Pd = to_dev(P, n_layers, cuda)
     h_d, l_d, i_d = (torch.from_numpy(x).to(cuda) for x in (hist, lengths, iid))
-    hv, xsave = eng.sasrec_fwd(Pd["item_emb"], Pd["pos_emb"], Pd["layers"], n_heads, h_d, l_d, save=True)
+    hv, xsave = eng.sasrec_fwd(Pd["item_emb"], Pd["pos_emb"], Pd["layers"], n_heads, h_d, l_d, save=True, impl=impl)
     want_pred, cache = SO.forward(P, hist, lengths, iid, n_heads, keep=True)
     assert_close(hv.cpu().numpy(), cache["hv"], what="hv", rtol=2e-5, atol_scale=3e-5)
     gp_d = torch.from_numpy(gpred).to(cuda)
@@ -144,10 +148,43 @@ def test_sasrec_length_buckets_vs_oracle(cuda, eng):
     assert 0 < len(short) < B
     hs = torch.from_numpy(np.ascontiguousarray(hist[short][:, :32])).to(cuda)
     ls = torch.from_numpy(lengths[short]).to(cuda)
-    hv32, _ = eng.sasrec_fwd(Pd["item_emb"], Pd["pos_emb"], Pd["layers"], n_heads, hs, ls)
-    assert torch.equal(hv32, hv[torch.from_numpy(short).to(cuda)])
+    hv32, _ = eng.sasrec_fwd(Pd["item_emb"], Pd["pos_emb"], Pd["layers"], n_heads, hs, ls, impl=impl)
+    if impl == "sequence":  # (the batch kernels tile the row space, so a row's tile-mates differ between the calls)
+        assert torch.equal(hv32, hv[torch.from_numpy(short).to(cuda)])
+    else:
+        assert_close(hv32.cpu().numpy(), hv[torch.from_numpy(short).to(cuda)].cpu().numpy(), what="hv32", rtol=1e-6, atol_scale=1e-6)
     # deterministic
-    hv_b, xs_b = eng.sasrec_fwd(Pd["item_emb"], Pd["pos_emb"], Pd["layers"], n_heads, h_d, l_d, save=True)
+    hv_b, xs_b = eng.sasrec_fwd(Pd["item_emb"], Pd["pos_emb"], Pd["layers"], n_heads, h_d, l_d, save=True, impl=impl)
     g_hist_b, dg_b = eng.sasrec_bwd(Pd["layers"], n_heads, l_d, xs_b, dhv)
     assert torch.equal(hv, hv_b) and torch.equal(g_hist, g_hist_b)
     assert all(torch.equal(dg[l][k], dg_b[l][k]) for l in range(n_layers) for k in LAYER_NAMES)
+
+
+def test_sasrec_batch_kernels_edge_shapes_vs_sequence_kernels(cuda, eng):
+    """d = 32 and 64, 1..3 layers, empty histories, a single row, history_max = 20 (one attention geometry) and 64"""
+    rng = np.random.default_rng(23)
+    for d, n_layers, n_heads, L, B in ((32, 1, 4, 20, 70), (64, 3, 1, 64, 37), (32, 2, 2, 50, 300), (64, 1, 4, 7, 1)):
+        n_items = 200
+        P = _random_sasrec(rng, n_items, d, n_layers, L)
+        lengths = rng.integers(0, L + 1, size=B).astype(np.int64)
+        lengths[0] = L
+        if B > 3:
+            lengths[1], lengths[2] = 0, 1
+        hist = rng.integers(1, n_items, size=(B, L)).astype(np.int64) * (np.arange(L)[None, :] < lengths[:, None])
+        Pd = to_dev(P, n_layers, cuda)
+        h_d, l_d = torch.from_numpy(hist).to(cuda), torch.from_numpy(lengths).to(cuda)
+        dhv = torch.from_numpy(rng.normal(size=(B, d)).astype(np.float32)).to(cuda)
+        out = {}
+        for impl in ("sequence", "batch"):
+            hv, saved = eng.sasrec_fwd(Pd["item_emb"], Pd["pos_emb"], Pd["layers"], n_heads, h_d, l_d, save=True, impl=impl)
+            g_hist, dg = eng.sasrec_bwd(Pd["layers"], n_heads, l_d, saved, dhv)
+            out[impl] = (hv.cpu().numpy(), g_hist.cpu().numpy(), [{k: v.cpu().numpy() for k, v in g.items()} for g in dg])
+        what = f"d={d} layers={n_layers} heads={n_heads} L={L} B={B}"
+        assert_close(out["batch"][0], out["sequence"][0], what=what + " hv", rtol=2e-5, atol_scale=2e-5)
+        assert_close(out["batch"][1], out["sequence"][1], what=what + " g_hist", rtol=5e-5, atol_scale=5e-5)
+        floor = 1e-6 * max(float(np.abs(v).max()) for g in out["sequence"][2] for v in g.values())
+        for l in range(n_layers):
+            for k in LAYER_NAMES:
+                assert_close(out["batch"][2][l][k], out["sequence"][2][l][k], what=f"{what} layer {l} d{k}", rtol=5e-5,
+                             atol_scale=1e-4, abs_floor=floor)
+        assert np.all(out["batch"][0][lengths == 0] == 0) and np.all(out["batch"][1][lengths == 0] == 0)

@@ -21,7 +21,10 @@ def main():
     ap.add_argument("--hist", type=int, default=50)
     ap.add_argument("--num-neg", type=int, default=99)
     ap.add_argument("--items", type=int, default=8714)
+    ap.add_argument("--impl", default="auto", choices=["auto", "batch", "sequence"],
+                    help="encoder kernels: one workgroup per sequence, batch-level row-space kernels, or by batch size")
     a = ap.parse_args()
+    os.environ["RC_SASREC_IMPL"] = a.impl
     dev = torch.device("cuda:0")
     B, L, d, C = a.batch, a.hist, a.emb_size, a.num_neg + 1
     gen = torch.Generator(device=dev)
@@ -39,7 +42,7 @@ def main():
     hist = torch.randint(1, a.items, (B, L), generator=gen, device=dev)
     hist = hist * (torch.arange(L, device=dev)[None, :] < lengths[:, None])
     iid = torch.randint(1, a.items, (B, C), generator=gen, device=dev)
-    out = {"B": B, "L": L, "d": d, "heads": a.heads, "layers": a.layers, "mean_len": float(lengths.float().mean())}
+    out = {"impl": engine._sasrec_impl(B, L, None), "B": B, "L": L, "d": d, "heads": a.heads, "layers": a.layers, "mean_len": float(lengths.float().mean())}
     ms = timeit(lambda: engine.sasrec_fwd(P["item_emb"], P["pos_emb"], layers, a.heads, hist, lengths), iters=10)
     out["fwd_ms"] = ms
     flops = float((lengths.double() * (10 * d * d) + lengths.double() ** 2 * 2 * d).sum()) * a.layers  # MAC*2 approx
