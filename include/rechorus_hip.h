@@ -299,6 +299,13 @@ int rc_sasrec_batch_bwd(const float* const* layer_params, int n_layers, int n_he
                         int B, int L, int d, const float* state, const float* dhv, float* g_hist,
                         float* dense_grads, void* ws, size_t ws_bytes, rc_stream_t stream);
 
+/* Gradient of the position table p_embeddings (SASRec.py:64: position id = length - index on valid slots, 0 on
+ * padding): grad_pos[p] = sum_b g_hist[b, len_b - p] over the sequences with len_b >= p, rows 0 and > L are zero.
+ * Replaces aten::embedding_dense_backward on the [B, L] position ids; fixed summation order.                  */
+size_t rc_sasrec_pos_grad_workspace_bytes(int B, int L, int d);
+int rc_sasrec_pos_grad(const float* g_hist, const int64_t* lengths, int B, int L, int d, int n_pos,
+                       float* grad_pos, void* ws, size_t ws_bytes, rc_stream_t stream);
+
 /* ---- NeuMF head (models/general/NeuMF.py:56-76), one hidden layer ------------------------- */
 
 /* 1 iff the fp32-MFMA kernels cover (emb_size d, hidden size l1): d, l1 in {32,64,128} and the

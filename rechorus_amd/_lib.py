@@ -94,6 +94,8 @@ SIGNATURES = {
     "rc_sasrec_workspace_bytes": (_sz, [_i, _i, _i]),
     "rc_sasrec_fwd": (_i, [_p, _p, _p, _i, _i, _p, _p, _i, _i, _i, _p, _p, _p, _sz, _p]),
     "rc_sasrec_bwd": (_i, [_p, _i, _i, _p, _i, _i, _i, _p, _p, _p, _p, _p, _sz, _p]),
+    "rc_sasrec_pos_grad_workspace_bytes": (_sz, [_i, _i, _i]),
+    "rc_sasrec_pos_grad": (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _sz, _p]),
     "rc_sasrec_batch_state_floats": (_sz, [_i, _i, _i, _i]),
     "rc_sasrec_batch_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "rc_sasrec_batch_fwd": (_i, [_p, _p, _p, _i, _i, _p, _p, _i, _i, _i, _p, _p, _p, _sz, _p]),

@@ -153,7 +153,7 @@ __device__ __forceinline__ void sas_attn_probs(float* A, const float* Q, const f
   sas_mm(MatA{Q + hh * dk, SD, 1}, MatB{K + hh * dk, 1, SD}, n, n, dk, true,
          [&](int i, int j, float v) { A[i * SA + j] = v / sqrt_dk; });
   __syncthreads();
-  const int rows_here = (SA - 1) / (kBlock / 64);  // 8 rows per wave in the 32-row geometry, 16 in the 64-row one
+  const int rows_here = SA - 1 <= 32 ? 8 : 16;  // rows per wave: 4 waves cover 32 rows, or up to 64
   sas_softmax_causal_rows(A, n, SA, (int)(threadIdx.x >> 6) * rows_here, rows_here);
   __syncthreads();
 }
@@ -166,7 +166,7 @@ __device__ __forceinline__ void sas_attn_probs_wave(float* A, const float* Q, co
   constexpr int SD = SasCfg<D>::SD;
   sas_mm_wave(MatA{Q + hh * dk, SD, 1}, MatB{K + hh * dk, 1, SD}, n, n, dk, true,
               [&](int i, int j, float v) { A[i * SA + j] = v / sqrt_dk; });
-  sas_softmax_causal_rows(A, n, SA, 0, SA - 1);
+  sas_softmax_causal_rows(A, n, SA, 0, SA - 1 <= 32 ? 32 : 64);
 }
 
 // out[i] = sum_w p[w][i].  A workgroup owns 64 consecutive outputs; wave v sums the partials w = v, v+4, ...

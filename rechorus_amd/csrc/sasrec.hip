@@ -277,7 +277,7 @@ __global__ __launch_bounds__(kBlock) void sasrec_bwd_kernel(SasArgs a) {
         sas_mm(MatA{A, 1, SA}, MatB{G + hc, SD, 1}, n, dk, n, false,
                [&](int j, int c, float v) { V[j * SD + hc + c] = v; });
         {  // dS = A * (dA - rowsum(dA*A)) / sqrt(dk), in place in T, 0 above the diagonal
-          const int rows_here = LP / (kBlock / 64);
+          const int rows_here = LP <= 32 ? 8 : 16;
           sas_softmax_bwd_rows(T, A, n, SA, sqrt_dk, (int)(threadIdx.x >> 6) * rows_here, rows_here);
         }
         __syncthreads();

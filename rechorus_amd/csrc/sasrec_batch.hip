@@ -294,7 +294,7 @@ __global__ __launch_bounds__(kBlock) void sb_attn_bwd_kernel(SbAttnArgs a) {
       __syncthreads();
       sas_mm(MatA{A, 1, SA}, MatB{G + hc, SD, 1}, n, dk, n, false, [&](int j, int c, float v) { V[j * SD + hc + c] = v; });
       {  // dS = A * (dA - rowsum(dA*A)) / sqrt(dk), in place in T, 0 above the diagonal
-        const int rows_here = LP / (kBlock / 64);
+        const int rows_here = LP <= 32 ? 8 : 16;
         sas_softmax_bwd_rows(T, A, n, SA, sqrt_dk, (int)(threadIdx.x >> 6) * rows_here, rows_here);
       }
       __syncthreads();
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(kBlock) void sb_attn_bwd_wave_kernel(SbAttnArgs a) 
     // dV_h = A^T . dCtx_h
     sas_mm_wave(MatA{A, 1, SA}, MatB{G + hc, SD, 1}, n, dk, n, false,
                 [&](int j, int c, float v) { a.dv[(size_t)(r0 + j) * D + hc + c] = v; });
-    sas_softmax_bwd_rows(T, A, n, SA, sqrt_dk, 0, LP);  // dS in place in T
+    sas_softmax_bwd_rows(T, A, n, SA, sqrt_dk, 0, LP <= 32 ? 32 : 64);  // dS in place in T
     // dQ_h = dS . K_h,  dK_h = dS^T . Q_h
     sas_mm_wave(MatA{T, SA, 1}, MatB{K + hc, SD, 1}, n, dk, n, false,
                 [&](int i, int c, float v) { a.dq[(size_t)(r0 + i) * D + hc + c] = v; });
@@ -546,6 +546,49 @@ __global__ __launch_bounds__(kBlock) void sb_unpack_kernel(const float* __restri
   }
 }
 
+// ---- position-table gradient --------------------------------------------------------------------------------
+// dP[p] = sum over sequences b with len_b >= p of g_hist[b, len_b - p]  (position id = len - index, SASRec.py:64;
+// id 0 = padding, whose slots carry zero gradient).  The key range is tiny (history_max + 1 rows), each row
+// collects up to B occurrences: instead of the generic sort + segmented sum, one workgroup per (position, chunk of
+// 1024 sequences) adds its rows in fixed order, a second pass adds the chunks.
+constexpr int kPosChunk = 1024;
+
+template <int D>
+__global__ __launch_bounds__(kBlock) void sb_pos_grad_kernel(const float* __restrict__ g_hist, const int64_t* __restrict__ lengths,
+                                                             int B, int L, float* __restrict__ part /*[chunks][L+1][D]*/) {
+  constexpr int LPR = D / 4, GPB = kBlock / LPR;
+  __shared__ float s_red[GPB][D + 4];
+  const int p = blockIdx.x, chunk = blockIdx.y;
+  const int l = threadIdx.x % LPR, grp = threadIdx.x / LPR;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int b_end = min(B, (chunk + 1) * kPosChunk);
+  if (p >= 1)
+    for (int b = chunk * kPosChunk + grp; b < b_end; b += GPB) {
+      const int n = sb_len(lengths, b, L);
+      if (n >= p) {
+        const float4 v = reinterpret_cast<const float4*>(g_hist)[((size_t)b * L + (n - p)) * LPR + l];
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
+    }
+  float* sr = &s_red[grp][4 * l];
+  sr[0] = acc.x; sr[1] = acc.y; sr[2] = acc.z; sr[3] = acc.w;
+  __syncthreads();
+  for (int k = threadIdx.x; k < D; k += kBlock) {
+    float t = 0.f;
+    for (int g = 0; g < GPB; ++g) t += s_red[g][k];
+    part[((size_t)chunk * (L + 1) + p) * D + k] = t;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void sb_pos_reduce_kernel(const float* __restrict__ part, int chunks, int count,
+                                                               float* __restrict__ out) {
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < count; i += gridDim.x * kBlock) {
+    float t = 0.f;
+    for (int c = 0; c < chunks; ++c) t += part[(size_t)c * count + i];
+    out[i] = t;
+  }
+}
+
 // ---- host side: buffer layout and launch sequences ---------------------------------------------------------
 
 static int sb_fill_layers(SasLayer* layer, const float* const* layer_params, int n_layers) {
@@ -630,7 +673,9 @@ static int sb_attention(SbAttnArgs a, int32_t* bucket, hipStream_t s) {
     RC_LAUNCH_CHECK();
   }
   for (int k = 0; k < n_launch; ++k) {
-    a.lp = k == 0 ? 32 : kSasLP;
+    // rows of LDS per sequence: 32 for the short bucket, history_max (rounded up to even: odd row strides) for the
+    // long one -- at history_max = 50 the long bucket fits two workgroups per CU and the backward fits one wave per head
+    a.lp = k == 0 ? 32 : (a.L + 1) / 2 * 2;
     a.seq_list = n_launch == 2 ? bucket + (size_t)k * a.B : nullptr;
     a.seq_count = n_launch == 2 ? bucket + 2 * (size_t)a.B + k : nullptr;
     const size_t buf = (size_t)sb_buf_floats(D, a.lp) * sizeof(float);
@@ -824,4 +869,35 @@ extern "C" int rc_sasrec_batch_bwd(const float* const* layer_params, int n_layer
   hipStream_t s = as_stream(stream);
   return d == 64 ? sb_backward<64>(layer, n_layers, n_heads, lengths, B, L, state, dhv, g_hist, dense_grads, w, s)
                  : sb_backward<32>(layer, n_layers, n_heads, lengths, B, L, state, dhv, g_hist, dense_grads, w, s);
+}
+
+extern "C" size_t rc_sasrec_pos_grad_workspace_bytes(int B, int L, int d) {
+  if (B < 1 || L < 1 || d < 1) return 0;
+  const size_t chunks = ((size_t)B + kPosChunk - 1) / kPosChunk;
+  return align_up(chunks * (size_t)(L + 1) * d * sizeof(float), 256);
+}
+
+extern "C" int rc_sasrec_pos_grad(const float* g_hist, const int64_t* lengths, int B, int L, int d, int n_pos,
+                                  float* grad_pos, void* ws, size_t ws_bytes, rc_stream_t stream) {
+  RC_REQUIRE(grad_pos != nullptr && n_pos >= L + 1 && L >= 1 && (d == 32 || d == 64),
+             "rc_sasrec_pos_grad: bad arguments (n_pos=%d, L=%d, d=%d)", n_pos, L, d);
+  hipStream_t s = as_stream(stream);
+  RC_HIP(hipMemsetAsync(grad_pos, 0, (size_t)n_pos * d * sizeof(float), s));  // rows past history_max, and B == 0
+  if (B == 0) return RC_OK;
+  RC_REQUIRE(g_hist && lengths && ws, "rc_sasrec_pos_grad: null pointer");
+  if (ws_bytes < rc_sasrec_pos_grad_workspace_bytes(B, L, d))
+    return fail(RC_ERR_WORKSPACE, "rc_sasrec_pos_grad: workspace %zu < %zu", ws_bytes, rc_sasrec_pos_grad_workspace_bytes(B, L, d));
+  const int chunks = (B + kPosChunk - 1) / kPosChunk;
+  float* part = chunks == 1 ? grad_pos : static_cast<float*>(ws);
+  if (d == 64)
+    hipLaunchKernelGGL((sb_pos_grad_kernel<64>), dim3(L + 1, chunks), dim3(kBlock), 0, s, g_hist, lengths, B, L, part);
+  else
+    hipLaunchKernelGGL((sb_pos_grad_kernel<32>), dim3(L + 1, chunks), dim3(kBlock), 0, s, g_hist, lengths, B, L, part);
+  RC_LAUNCH_CHECK();
+  if (chunks > 1) {
+    const int count = (L + 1) * d;
+    hipLaunchKernelGGL(sb_pos_reduce_kernel, dim3((count + kBlock - 1) / kBlock), dim3(kBlock), 0, s, part, chunks, count, grad_pos);
+    RC_LAUNCH_CHECK();
+  }
+  return RC_OK;
 }

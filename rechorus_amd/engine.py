@@ -527,6 +527,17 @@ def sasrec_bwd(layers, n_heads, lengths, saved, dhv):
     return g_hist, grads
 
 
+def sasrec_pos_grad(g_hist, lengths, n_pos):
+    """dense gradient [n_pos, d] of the position table from the history-row gradients g_hist [B, L, d]
+    (position id = length - index, SASRec.py:64)"""
+    B, L, d = g_hist.shape
+    out = torch.empty((n_pos, d), dtype=torch.float32, device=g_hist.device)
+    ws = workspace(_lib.load().rc_sasrec_pos_grad_workspace_bytes(B, L, d), g_hist.device, "sasrec_pos")
+    _lib.call("rc_sasrec_pos_grad", _ptr(g_hist, torch.float32, "g_hist"), _ptr(lengths, torch.int64, "lengths"), B, L, d,
+              int(n_pos), _ptr(out, torch.float32, "grad_pos"), C.c_void_p(ws.data_ptr()), ws.numel(), _stream())
+    return out
+
+
 def segmented_update2(keys, perm, src, src2, n_split, hyper=None, W=None, m=None, v=None, coef=None,
                       src_index=None, div=1, dense_grad=None):
     """rc_segmented_update2: occurrences >= n_split take plain rows src2[o - n_split]"""
@@ -589,9 +600,7 @@ class SasrecTrainer:
             segmented_update2(keys, perm, hv, g_hist.view(-1, d), B * Cn, coef=gpred.reshape(-1), div=Cn, dense_grad=G)
             dense_update(I, G, h, st.get("m"), st.get("v"))
         # position table (tiny): dense gradient, dense step
-        valid = (hist > 0).to(torch.int64)
-        position = ((lengths[:, None] - torch.arange(L, device=hist.device)[None, :]) * valid).contiguous()
-        Gp = embedding_dense_backward(g_hist, position, Pe.shape[0])
+        Gp = sasrec_pos_grad(g_hist, lengths, Pe.shape[0])
         st = self._st(Pe)
         items = [(Pe, Gp, h, st.get("m"), st.get("v"))]
         for lay, g in zip(layers, dgrads):

@@ -274,11 +274,8 @@ class _SasrecEncodeFn(torch.autograd.Function):
     def backward(ctx, dhv):
         hist, lengths = ctx.hist, ctx.lengths
         g_hist, dgrads = engine.sasrec_bwd(ctx.layers, ctx.n_heads, lengths, ctx.xsave, dhv.contiguous())
-        L = hist.shape[1]
         GI = engine.embedding_dense_backward(g_hist, hist, ctx.n_items)
-        valid = (hist > 0).to(torch.int64)
-        position = ((lengths[:, None] - torch.arange(L, device=hist.device)[None, :]) * valid).contiguous()
-        GP = engine.embedding_dense_backward(g_hist, position, ctx.n_pos)
+        GP = engine.sasrec_pos_grad(g_hist, lengths, ctx.n_pos)
         flat = [g[k].contiguous() for g in dgrads for k, _ in _SAS_ATTRS]
         return (GI, GP, None, None, None) + tuple(flat)
 

@@ -66,6 +66,8 @@ def test_sasrec_forward_backward(case, impl, cuda, eng):
     position = ((lengths[:, None] - torch.arange(L, device=cuda)[None, :]) * valid).contiguous()
     GP = eng.embedding_dense_backward(g_hist, position, P["pos_emb"].shape[0])
     assert_close(GP.cpu().numpy(), G["p_embeddings.weight"], what="d pos_emb", rtol=2e-5, atol_scale=5e-5)
+    GP2 = eng.sasrec_pos_grad(g_hist, lengths, P["pos_emb"].shape[0])  # the dedicated kernel the trainers use
+    assert_close(GP2.cpu().numpy(), G["p_embeddings.weight"], what="d pos_emb (rc_sasrec_pos_grad)", rtol=2e-5, atol_scale=5e-5)
 
 
 @pytest.mark.parametrize("case", CASES)
@@ -188,3 +190,18 @@ def test_sasrec_batch_kernels_edge_shapes_vs_sequence_kernels(cuda, eng):
                 assert_close(out["batch"][2][l][k], out["sequence"][2][l][k], what=f"{what} layer {l} d{k}", rtol=5e-5,
                              atol_scale=1e-4, abs_floor=floor)
         assert np.all(out["batch"][0][lengths == 0] == 0) and np.all(out["batch"][1][lengths == 0] == 0)
+
+
+def test_sasrec_pos_grad_chunks(cuda, eng):
+    """more than 1024 sequences: several chunks per position + the chunk reduction; vs the generic sort + segmented sum"""
+    rng = np.random.default_rng(4)
+    for B, L, d in ((2500, 50, 64), (1030, 7, 32), (3, 20, 64)):
+        lengths = torch.from_numpy(rng.integers(0, L + 1, size=B).astype(np.int64)).to(cuda)
+        g_hist = torch.from_numpy(rng.normal(size=(B, L, d)).astype(np.float32)).to(cuda)
+        g_hist = (g_hist * (torch.arange(L, device=cuda)[None, :, None] < lengths[:, None, None])).contiguous()
+        position = ((lengths[:, None] - torch.arange(L, device=cuda)[None, :]).clamp(min=0)).contiguous()
+        want = eng.embedding_dense_backward(g_hist, position, L + 3)
+        got = eng.sasrec_pos_grad(g_hist, lengths, L + 3)
+        assert torch.equal(got[0], torch.zeros_like(got[0])) and torch.equal(got[L + 1:], torch.zeros_like(got[L + 1:]))
+        assert_close(got[1:].cpu().numpy(), want[1:].cpu().numpy(), what=f"pos grad B={B}", rtol=1e-5, atol_scale=2e-5)
+        assert torch.equal(got, eng.sasrec_pos_grad(g_hist, lengths, L + 3))
