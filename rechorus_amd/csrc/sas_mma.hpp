@@ -118,10 +118,12 @@ __device__ __forceinline__ void sas_softmax_causal_rows(float* A, int n, int SA,
   const bool on = i < n;
   float m = -INFINITY;
   if (on)
+#pragma unroll 4
     for (int j = p; j <= i; j += parts) m = fmaxf(m, A[i * SA + j]);
   m = sas_parts_max(m, rows_here);
   float z = 0.f;
   if (on)
+#pragma unroll 4
     for (int j = p; j <= i; j += parts) {
       const float e = expf(A[i * SA + j] - m);
       A[i * SA + j] = e;
@@ -129,6 +131,7 @@ __device__ __forceinline__ void sas_softmax_causal_rows(float* A, int n, int SA,
     }
   z = sas_parts_sum(z, rows_here);
   if (on)
+#pragma unroll 4
     for (int j = p; j < n; j += parts) A[i * SA + j] = j <= i ? A[i * SA + j] / z : 0.f;
 }
 // softmax backward in place: T[i][j] <- A[i][j] * (T[i][j] - sum_j' A[i][j'] T[i][j']) / sqrt_dk for j <= i, else 0
@@ -139,9 +142,11 @@ __device__ __forceinline__ void sas_softmax_bwd_rows(float* T, const float* A, i
   const bool on = i < n;
   float dot = 0.f;
   if (on)
+#pragma unroll 4
     for (int j = p; j <= i; j += parts) dot = fmaf(A[i * SA + j], T[i * SA + j], dot);
   dot = sas_parts_sum(dot, rows_here);
   if (on)
+#pragma unroll 4
     for (int j = p; j < n; j += parts) T[i * SA + j] = j <= i ? A[i * SA + j] * (T[i * SA + j] - dot) / sqrt_dk : 0.f;
 }
 
@@ -166,7 +171,8 @@ __device__ __forceinline__ void sas_attn_probs_wave(float* A, const float* Q, co
   constexpr int SD = SasCfg<D>::SD;
   sas_mm_wave(MatA{Q + hh * dk, SD, 1}, MatB{K + hh * dk, 1, SD}, n, n, dk, true,
               [&](int i, int j, float v) { A[i * SA + j] = v / sqrt_dk; });
-  sas_softmax_causal_rows(A, n, SA, 0, SA - 1 <= 32 ? 32 : 64);
+  sas_softmax_causal_rows(A, n, SA, 0, 32);  // two lanes per row
+  if (n > 32) sas_softmax_causal_rows(A, n, SA, 32, 32);
 }
 
 // out[i] = sum_w p[w][i].  A workgroup owns 64 consecutive outputs; wave v sums the partials w = v, v+4, ...

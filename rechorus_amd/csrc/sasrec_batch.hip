@@ -382,7 +382,8 @@ __global__ __launch_bounds__(kBlock) void sb_attn_bwd_wave_kernel(SbAttnArgs a) 
     // dV_h = A^T . dCtx_h
     sas_mm_wave(MatA{A, 1, SA}, MatB{G + hc, SD, 1}, n, dk, n, false,
                 [&](int j, int c, float v) { a.dv[(size_t)(r0 + j) * D + hc + c] = v; });
-    sas_softmax_bwd_rows(T, A, n, SA, sqrt_dk, 0, LP <= 32 ? 32 : 64);  // dS in place in T
+    sas_softmax_bwd_rows(T, A, n, SA, sqrt_dk, 0, 32);  // dS in place in T, two lanes per row
+    if (n > 32) sas_softmax_bwd_rows(T, A, n, SA, sqrt_dk, 32, 32);
     // dQ_h = dS . K_h,  dK_h = dS^T . Q_h
     sas_mm_wave(MatA{T, SA, 1}, MatB{K + hc, SD, 1}, n, dk, n, false,
                 [&](int i, int c, float v) { a.dq[(size_t)(r0 + i) * D + hc + c] = v; });
@@ -621,18 +622,23 @@ static SbSaved sb_saved(float* state, int l, size_t rmax, int d) {
 
 constexpr int kSbPartWg = 512;  // workgroups that own a partial-gradient slice
 
+// the row-space offsets and the length buckets are computed by the forward pass and kept in the tail of the saved
+// state: the backward pass reads them back instead of recomputing them
+static size_t sb_state_act_floats(size_t rmax, int d, int n_layers) { return (size_t)n_layers * sb_layer_floats(rmax, d) + rmax * d; }
+static size_t sb_state_int_floats(int B) { return 3 * (size_t)B + 72; }
+
 struct SbWs {
-  int32_t *off, *bucket;
+  int32_t *off, *bucket;  // live in the state buffer
   float *t0, *t1, *t2, *t3;  // [Rmax, D] scratch
   float* part;               // [kSbPartWg][n_layers * PL]
   size_t total;
 };
-static SbWs sb_carve(void* base, int B, int L, int d, int n_layers, bool bwd) {
+static SbWs sb_carve(void* base, float* state, int B, int L, int d, int n_layers, bool bwd) {
   Carver cv(base);
   SbWs w;
   const size_t rmax = (size_t)B * L;
-  w.off = cv.take<int32_t>((size_t)B + 1);
-  w.bucket = cv.take<int32_t>(2 * (size_t)B + 64);
+  w.off = state ? reinterpret_cast<int32_t*>(state + sb_state_act_floats(rmax, d, n_layers)) : nullptr;
+  w.bucket = state ? w.off + (size_t)B + 4 : nullptr;
   w.t0 = cv.take<float>(rmax * d);
   w.t1 = bwd ? cv.take<float>(rmax * d) : nullptr;
   w.t2 = bwd ? cv.take<float>(rmax * d) : nullptr;
@@ -666,9 +672,9 @@ static int sb_linear(const SbLinArgs& a, int64_t rmax, hipStream_t s) {
 // Up to 4 heads run one wave per head (sb_attn_*_wave_kernel) when the per-head scratch fits the LDS; otherwise
 // (more heads; the backward of the 64-row bucket) the four waves of the workgroup share each head's blocks.
 template <int D, bool BWD>
-static int sb_attention(SbAttnArgs a, int32_t* bucket, hipStream_t s) {
+static int sb_attention(SbAttnArgs a, int32_t* bucket, bool make_buckets, hipStream_t s) {
   const int n_launch = a.L <= 32 ? 1 : 2;
-  if (n_launch == 2) {
+  if (n_launch == 2 && make_buckets) {
     hipLaunchKernelGGL(sas_bucket_kernel, dim3(1), dim3(kBlock), 0, s, a.lengths, a.B, bucket, bucket + 2 * (size_t)a.B);
     RC_LAUNCH_CHECK();
   }
@@ -721,7 +727,7 @@ static int sb_forward(const float* item_emb, const float* pos_emb, const SasLaye
     memset(&at, 0, sizeof(at));
     at.q = sv.q; at.k = sv.k; at.v = sv.v; at.ctx = w.t0; at.lengths = lengths; at.off = w.off; at.B = B; at.L = L;
     at.n_heads = n_heads;
-    RC_TRY((sb_attention<D, false>(at, w.bucket, s)));
+    RC_TRY((sb_attention<D, false>(at, w.bucket, l == 0, s)));
     hipLaunchKernelGGL((sb_ln_fwd_kernel<D>), dim3(sb_row_grid((int64_t)rmax, LPR)), dim3(kBlock), 0, s, w.t0, sv.x, p.ln1w,
                        p.ln1b, w.off, B, sv.xh1, sv.rstd1, sv.y1);
     RC_LAUNCH_CHECK();
@@ -761,8 +767,6 @@ static int sb_backward(const SasLayer* layer, int n_layers, int n_heads, const i
   constexpr int LPR = D / 4, PL = Cfg::PL;
   const size_t rmax = (size_t)B * L;
   const size_t stride = (size_t)n_layers * PL;  // floats between the slices of consecutive workgroups
-  hipLaunchKernelGGL(sb_offsets_kernel, dim3(1), dim3(kBlock), 0, s, lengths, B, L, w.off);
-  RC_LAUNCH_CHECK();
   RC_HIP(hipMemsetAsync(w.part, 0, (size_t)kSbPartWg * stride * sizeof(float), s));
   float* G = w.t0;
   hipLaunchKernelGGL((sb_seed_kernel<D>), dim3(sb_row_grid((int64_t)rmax, LPR)), dim3(kBlock), 0, s, dhv, lengths, w.off, B, L, G);
@@ -800,7 +804,7 @@ static int sb_backward(const SasLayer* layer, int n_layers, int n_heads, const i
     memset(&at, 0, sizeof(at));
     at.q = sv.q; at.k = sv.k; at.v = sv.v; at.dctx = G; at.dq = w.t1; at.dk = w.t2; at.dv = w.t3;
     at.lengths = lengths; at.off = w.off; at.B = B; at.L = L; at.n_heads = n_heads;
-    RC_TRY((sb_attention<D, true>(at, w.bucket, s)));
+    RC_TRY((sb_attention<D, true>(at, w.bucket, false, s)));
     // projections: parameter gradients against the layer input, dX = dZ1 + dQ Wq + dK Wk + dV Wv
     g.dY[0] = w.t1; g.dY[1] = w.t2; g.dY[2] = w.t3; g.X = sv.x;
     g.gW[0] = gp + Cfg::oWq; g.gb[0] = gp + Cfg::obq; g.gW[1] = gp + Cfg::oWk; g.gb[1] = gp + Cfg::obk;
@@ -829,13 +833,12 @@ using namespace rc;
 
 extern "C" size_t rc_sasrec_batch_state_floats(int B, int L, int d, int n_layers) {
   if (B < 1 || L < 1 || d < 1 || n_layers < 1) return 0;
-  const size_t rmax = (size_t)B * L;
-  return (size_t)n_layers * sb_layer_floats(rmax, d) + rmax * d;
+  return sb_state_act_floats((size_t)B * L, d, n_layers) + sb_state_int_floats(B);
 }
 
 extern "C" size_t rc_sasrec_batch_workspace_bytes(int B, int L, int d, int n_layers) {
   if (B < 1 || L < 1 || d < 1 || n_layers < 1) return 0;
-  return sb_carve(nullptr, B, L, d, n_layers, true).total + 256;
+  return sb_carve(nullptr, nullptr, B, L, d, n_layers, true).total + 256;
 }
 
 extern "C" int rc_sasrec_batch_fwd(const float* item_emb, const float* pos_emb, const float* const* layer_params,
@@ -848,7 +851,7 @@ extern "C" int rc_sasrec_batch_fwd(const float* item_emb, const float* pos_emb, 
   RC_REQUIRE((int64_t)B * L < ((int64_t)1 << 31), "rc_sasrec_batch_fwd: B * L too large");
   SasLayer layer[kSasMaxLayers];
   RC_TRY(sb_fill_layers(layer, layer_params, n_layers));
-  const SbWs w = sb_carve(ws, B, L, d, n_layers, false);
+  const SbWs w = sb_carve(ws, state, B, L, d, n_layers, false);
   if (ws_bytes < w.total) return fail(RC_ERR_WORKSPACE, "rc_sasrec_batch_fwd: workspace %zu < %zu", ws_bytes, w.total);
   hipStream_t s = as_stream(stream);
   return d == 64 ? sb_forward<64>(item_emb, pos_emb, layer, n_layers, n_heads, hist, lengths, B, L, hv, state, w, s)
@@ -864,7 +867,7 @@ extern "C" int rc_sasrec_batch_bwd(const float* const* layer_params, int n_layer
     return fail(RC_ERR_UNSUPPORTED, "rc_sasrec_batch_bwd: d=%d layers=%d heads=%d L=%d not supported", d, n_layers, n_heads, L);
   SasLayer layer[kSasMaxLayers];
   RC_TRY(sb_fill_layers(layer, layer_params, n_layers));
-  const SbWs w = sb_carve(ws, B, L, d, n_layers, true);
+  const SbWs w = sb_carve(ws, const_cast<float*>(state), B, L, d, n_layers, true);
   if (ws_bytes < w.total) return fail(RC_ERR_WORKSPACE, "rc_sasrec_batch_bwd: workspace %zu < %zu", ws_bytes, w.total);
   hipStream_t s = as_stream(stream);
   return d == 64 ? sb_backward<64>(layer, n_layers, n_heads, lengths, B, L, state, dhv, g_hist, dense_grads, w, s)
