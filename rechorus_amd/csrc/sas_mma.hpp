@@ -247,4 +247,47 @@ static __global__ __launch_bounds__(kBlock) void sas_bucket_kernel(const int64_t
 
 static size_t sas_bucket_bytes(int B) { return align_up((size_t)(2 * (size_t)B + 64) * sizeof(int32_t), 256); }
 
+
+// The same for up to 4 length classes: class k holds the sequences with thr[k-1] < len <= thr[k] (thr ascending, the
+// last one >= the longest history); list[k * B ...], count[k].
+struct SasBuckets { int n; int thr[4]; };
+static __global__ __launch_bounds__(kBlock) void sas_bucket_n_kernel(const int64_t* __restrict__ lengths, int B, SasBuckets bk,
+                                                                     int32_t* __restrict__ list, int32_t* __restrict__ count) {
+  __shared__ int s_wave[4][kBlock / 64];
+  __shared__ int s_base[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x < 4) s_base[threadIdx.x] = 0;
+  __syncthreads();
+  for (int b0 = 0; b0 < B; b0 += kBlock) {
+    const int b = b0 + threadIdx.x;
+    int cls = -1;
+    if (b < B) {
+      const int64_t n = lengths[b];
+      cls = bk.n - 1;
+      for (int k = bk.n - 2; k >= 0; --k)
+        if (n <= bk.thr[k]) cls = k;
+    }
+    unsigned long long mine = 0;
+    for (int k = 0; k < bk.n; ++k) {
+      const unsigned long long m = __ballot(cls == k);
+      if (cls == k) mine = m;
+      if (lane == 0) s_wave[k][wave] = __popcll(m);
+    }
+    __syncthreads();
+    if (cls >= 0) {
+      int off = s_base[cls] + __popcll(mine & ((1ull << lane) - 1ull));
+      for (int v = 0; v < wave; ++v) off += s_wave[cls][v];
+      list[(size_t)cls * B + off] = b;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < bk.n) {
+      int t = 0;
+      for (int v = 0; v < kBlock / 64; ++v) t += s_wave[threadIdx.x][v];
+      s_base[threadIdx.x] += t;
+    }
+    __syncthreads();
+  }
+  if ((int)threadIdx.x < bk.n) count[threadIdx.x] = s_base[threadIdx.x];
+}
+
 }  // namespace rc

@@ -625,7 +625,7 @@ constexpr int kSbPartWg = 512;  // workgroups that own a partial-gradient slice
 // the row-space offsets and the length buckets are computed by the forward pass and kept in the tail of the saved
 // state: the backward pass reads them back instead of recomputing them
 static size_t sb_state_act_floats(size_t rmax, int d, int n_layers) { return (size_t)n_layers * sb_layer_floats(rmax, d) + rmax * d; }
-static size_t sb_state_int_floats(int B) { return 3 * (size_t)B + 72; }
+static size_t sb_state_int_floats(int B) { return 5 * (size_t)B + 72; }
 
 struct SbWs {
   int32_t *off, *bucket;  // live in the state buffer
@@ -668,27 +668,40 @@ static int sb_linear(const SbLinArgs& a, int64_t rmax, hipStream_t s) {
   return RC_OK;
 }
 
-// attention launches: one geometry when history_max <= 32, else the short / long buckets of sas_bucket_kernel.
+// attention launches.  Sequences are split on the device into length classes <= 16, <= 32, <= history_max
+// (sas_bucket_n_kernel); a class runs with as many LDS rows as its longest member, so the short histories that
+// dominate real data get many resident workgroups per CU (17 KB forward, 25 KB backward at 16 rows, d = 64).
 // Up to 4 heads run one wave per head (sb_attn_*_wave_kernel) when the per-head scratch fits the LDS; otherwise
-// (more heads; the backward of the 64-row bucket) the four waves of the workgroup share each head's blocks.
+// the four waves of the workgroup share each head's blocks.
+static SasBuckets sb_buckets(int L) {
+  SasBuckets bk;
+  bk.n = 0;
+  for (int t : {16, 32})
+    if (t < L) bk.thr[bk.n++] = t;
+  bk.thr[bk.n++] = L;
+  return bk;
+}
+
 template <int D, bool BWD>
 static int sb_attention(SbAttnArgs a, int32_t* bucket, bool make_buckets, hipStream_t s) {
-  const int n_launch = a.L <= 32 ? 1 : 2;
-  if (n_launch == 2 && make_buckets) {
-    hipLaunchKernelGGL(sas_bucket_kernel, dim3(1), dim3(kBlock), 0, s, a.lengths, a.B, bucket, bucket + 2 * (size_t)a.B);
+  const SasBuckets bk = sb_buckets(a.L);
+  int32_t* count = bucket + 4 * (size_t)a.B;
+  if (make_buckets) {
+    hipLaunchKernelGGL(sas_bucket_n_kernel, dim3(1), dim3(kBlock), 0, s, a.lengths, a.B, bk, bucket, count);
     RC_LAUNCH_CHECK();
   }
-  for (int k = 0; k < n_launch; ++k) {
-    // rows of LDS per sequence: 32 for the short bucket, history_max (rounded up to even: odd row strides) for the
-    // long one -- at history_max = 50 the long bucket fits two workgroups per CU and the backward fits one wave per head
-    a.lp = k == 0 ? 32 : (a.L + 1) / 2 * 2;
-    a.seq_list = n_launch == 2 ? bucket + (size_t)k * a.B : nullptr;
-    a.seq_count = n_launch == 2 ? bucket + 2 * (size_t)a.B + k : nullptr;
+  for (int k = 0; k < bk.n; ++k) {
+    a.lp = (bk.thr[k] + 1) / 2 * 2;  // even: odd LDS row strides
+    a.seq_list = bucket + (size_t)k * a.B;
+    a.seq_count = count + k;
     const size_t buf = (size_t)sb_buf_floats(D, a.lp) * sizeof(float);
     const size_t head = (size_t)a.lp * (a.lp + 1) * sizeof(float);
     const size_t lds_wave = (BWD ? 4 : 3) * buf + (BWD ? 2 : 1) * a.n_heads * head;
     const bool per_wave = a.n_heads <= 4 && lds_wave <= 160 * 1024;
-    const size_t lds = per_wave ? lds_wave : (size_t)(BWD ? 7 : 5) * buf;
+    const bool block_ok = a.lp == 32 || a.lp == 64;  // the shared-block kernels split 32 / 64 rows over 4 waves
+    if (!per_wave && !block_ok) a.lp = a.lp <= 32 ? 32 : 64;
+    const size_t buf2 = (size_t)sb_buf_floats(D, a.lp) * sizeof(float);
+    const size_t lds = per_wave ? lds_wave : (size_t)(BWD ? 7 : 5) * buf2;
     auto kern = per_wave ? (BWD ? sb_attn_bwd_wave_kernel<D> : sb_attn_fwd_wave_kernel<D>)
                          : (BWD ? sb_attn_bwd_kernel<D> : sb_attn_fwd_kernel<D>);
     RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
