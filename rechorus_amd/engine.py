@@ -460,9 +460,14 @@ SASREC_BATCH_MIN_ROWS = 4096  # B * history_max from which the batch-level kerne
 
 
 def _sasrec_impl(B, L, impl):
+    """auto: the per-sequence kernels (3 launches per pass) while the whole batch is ONE round of resident
+    workgroups in the 32-row geometry (B <= 512, history_max <= 32: 0.138 vs 0.173 s per epoch at the reference's
+    demo flags under graph replay), the batch-level kernels (~35 launches, 2-3x the throughput) beyond"""
     impl = impl or os.environ.get("RC_SASREC_IMPL", "auto")
     if impl == "auto":
-        return "batch" if B * L >= SASREC_BATCH_MIN_ROWS else "sequence"
+        if B * L < SASREC_BATCH_MIN_ROWS or (B <= 512 and L <= 32):
+            return "sequence"
+        return "batch"
     if impl not in ("batch", "sequence"):
         raise ValueError("SASRec impl must be auto | batch | sequence, got {!r}".format(impl))
     return impl

@@ -40,6 +40,9 @@ def setup(root, model_name, extra, mode="", dataset="grocery_like"):
 
 def main():
     from synth_data import make_context_dataset, make_dataset
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="", help="run only the configurations whose label contains this text")
+    only = ap.parse_args().only
     root = tempfile.mkdtemp(prefix="rc_bench_")
     t0 = time.perf_counter()
     make_dataset(root, "grocery_like", n_users=14681, n_items=8713, per_user=10, n_neg=99, seed=0)
@@ -61,6 +64,8 @@ def main():
     out = {"dataset": "synthetic, Grocery-sized: 14,681 users, 8,713 items", "generate_s": round(gen_s, 1), "runs": []}
     for cfg in configs:
         label, model_name, extra = cfg[:3]
+        if only and only not in label:
+            continue
         args, model, data, runner = setup(root, model_name, extra, *cfg[3:])
         n = len(data["train"])
         np.random.seed(0)
