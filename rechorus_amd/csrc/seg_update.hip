@@ -274,41 +274,68 @@ __global__ __launch_bounds__(kBlock) void seg_update_multi_x2_kernel(SegArgs a) 
 }
 
 // ---- 3. hot rows ----------------------------------------------------------------------------
-// end of the segment that starts at j0 (first index with a different key): gallop + bisect
-__device__ __forceinline__ int64_t segment_end(const uint32_t* __restrict__ keys, int64_t n,
-                                               int64_t j0) {
+// end of the segment that starts at j0 (first index with a different key), found by the 16 lanes of a group
+// together: every round the lanes probe 16 positions at once and keep the sub-interval that contains the
+// boundary (a one-thread gallop + bisection needs ~2 log2(len) DEPENDENT loads of ~1 us each; this needs
+// ~log16(len) rounds -- the planning kernel went from 32 to ~8 us per table and step).
+__device__ __forceinline__ int group16_first_fail(bool ok, int l) {  // smallest lane index with !ok, 16 if none
+  int v = ok ? 16 : l;
+#pragma unroll
+  for (int off = 8; off >= 1; off >>= 1) v = min(v, __shfl_xor(v, off, 64));
+  return v;
+}
+__device__ __forceinline__ int64_t segment_end16(const uint32_t* __restrict__ keys, int64_t n, int64_t j0, int l) {
   const uint32_t key = keys[j0];
-  int64_t lo = j0;  // keys[lo] == key
-  int64_t step = kLongSeg;
-  int64_t hi = j0 + step;
-  while (hi < n && keys[hi] == key) {
-    lo = hi;
-    step <<= 1;
-    hi = lo + step;
+  int64_t lo = j0, hi = n;  // keys[lo] == key; hi == n or keys[hi] != key
+  // gallop: lane l probes j0 + kLongSeg * 2^l (l < 16), repeated from the last hit while all lanes hit
+  for (;;) {
+    const int64_t p = lo + ((int64_t)kLongSeg << l);
+    const bool ok = p < n && keys[p] == key;
+    const int f = group16_first_fail(ok, l);
+    const int64_t last_ok = __shfl(p, (threadIdx.x & 48) + (f > 0 ? f - 1 : 0), 64);
+    const int64_t first_bad = __shfl(p, (threadIdx.x & 48) + (f < 16 ? f : 15), 64);
+    if (f > 0) lo = last_ok;
+    if (f < 16) {
+      hi = first_bad < n ? first_bad : n;
+      break;
+    }
   }
-  if (hi > n) hi = n;  // keys[hi] != key or hi == n
-  while (hi - lo > 1) {
-    const int64_t mid = lo + (hi - lo) / 2;
-    if (keys[mid] == key) lo = mid; else hi = mid;
+  while (hi - lo > 1) {  // 17-way split of (lo, hi)
+    const int64_t step = (hi - lo + 16) / 17;
+    const int64_t q = lo + (int64_t)(l + 1) * step;
+    const bool ok = q < hi ? keys[q] == key : false;
+    const int f = group16_first_fail(ok, l);
+    const int64_t last_ok = __shfl(q, (threadIdx.x & 48) + (f > 0 ? f - 1 : 0), 64);
+    const int64_t first_bad = __shfl(q, (threadIdx.x & 48) + (f < 16 ? f : 15), 64);
+    if (f > 0) lo = last_ok;
+    if (f < 16 && first_bad < hi) hi = first_bad;
   }
   return hi;
 }
 
+// one 16-lane group per hot row
 __global__ __launch_bounds__(kBlock) void long_plan_kernel(SegArgs a) {
   uint32_t n_long = a.counters[CNT_LONG];
   if (n_long > a.long_cap) n_long = a.long_cap;
-  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n_long; i += gridDim.x * kBlock) {
+  const int l = threadIdx.x & 15;
+  const uint32_t groups = gridDim.x * (kBlock / 16);
+  for (uint32_t i = blockIdx.x * (kBlock / 16) + threadIdx.x / 16; i < n_long; i += groups) {
     const int64_t j0 = a.long_list[i];
-    const int64_t end = segment_end(a.keys, a.n_occ, j0);
+    const int64_t end = segment_end16(a.keys, a.n_occ, j0, l);
     const uint32_t nch = (uint32_t)((end - j0 + kChunk - 1) / kChunk);
-    RowInfo r;
-    r.j0 = (uint32_t)j0;
-    r.end = (uint32_t)end;
-    r.nchunks = nch;
-    r.pbase = nch >= 2 ? atomicAdd(&a.counters[CNT_PARTIAL], nch) : 0xFFFFFFFFu;
-    a.rows[i] = r;
-    const uint32_t cbase = atomicAdd(&a.counters[CNT_CHUNKS], nch);
-    for (uint32_t k = 0; k < nch; ++k)
+    uint32_t pbase = 0xFFFFFFFFu, cbase = 0;
+    if (l == 0) {
+      if (nch >= 2) pbase = atomicAdd(&a.counters[CNT_PARTIAL], nch);
+      cbase = atomicAdd(&a.counters[CNT_CHUNKS], nch);
+      RowInfo r;
+      r.j0 = (uint32_t)j0;
+      r.end = (uint32_t)end;
+      r.nchunks = nch;
+      r.pbase = pbase;
+      a.rows[i] = r;
+    }
+    cbase = __shfl(cbase, threadIdx.x & 48, 64);
+    for (uint32_t k = l; k < nch; k += 16)
       if (cbase + k < a.chunk_cap) {
         ChunkInfo c;
         c.row = i;

@@ -334,3 +334,34 @@ def test_dense_update_multi_equals_single_tensor_updates(cuda):
             assert torch.equal(Wa, Wb)
             assert ma is None or torch.equal(ma, mb)
             assert va is None or torch.equal(va, vb)
+
+
+def test_segment_end_search_over_segment_lengths(cuda, eng):
+    """hot rows of many lengths -- around the 16-lane search's probe points (32 * 2^l), past the range of one
+    gallop round (> 1 M occurrences), odd lengths, one at the very end of the key array -- summed through
+    rc_segmented_update into a dense gradient; expected value from a float64 sum of the same rows"""
+    rng = np.random.default_rng(31)
+    d = 16
+    lengths = [33, 64, 65, 1023, 1024, 1025, 4097, 32 * 2 ** 9, 32 * 2 ** 9 + 1, 70001, 1_200_003, 40, 777]
+    keys = np.concatenate([np.full(n, 3 * k + 1, dtype=np.int64) for k, n in enumerate(lengths)])
+    perm_in = rng.permutation(len(keys))
+    ids = keys[perm_in]                                   # occurrence o has row id ids[o]
+    src = rng.normal(size=(97, d)).astype(np.float32)      # gradient rows, indexed through src_index
+    src_index = rng.integers(0, 97, size=len(ids)).astype(np.int64)
+    coef = rng.normal(size=len(ids)).astype(np.float32)
+    n_rows = 3 * len(lengths) + 2
+    k_d, p_d = eng.sort_ids(dev(ids, cuda), n_rows)
+    G = torch.zeros((n_rows, d), dtype=torch.float32, device=cuda)
+    eng.segmented_update(k_d, p_d, dev(src, cuda), coef=dev(coef, cuda), src_index=dev(src_index, cuda), dense_grad=G)
+    want = np.zeros((n_rows, d))
+    np.add.at(want, ids, coef[:, None].astype(np.float64) * src[src_index])
+    got = host(G)
+    for k, n in enumerate(lengths):
+        r = 3 * k + 1
+        scale = np.abs(coef[ids == r][:, None] * src[src_index[ids == r]]).sum(0).max()
+        assert np.abs(got[r] - want[r]).max() <= 2e-6 * scale, (n, np.abs(got[r] - want[r]).max(), scale)
+    untouched = np.setdiff1d(np.arange(n_rows), 3 * np.arange(len(lengths)) + 1)
+    assert np.all(got[untouched] == 0)
+    G2 = torch.zeros_like(G)
+    eng.segmented_update(k_d, p_d, dev(src, cuda), coef=dev(coef, cuda), src_index=dev(src_index, cuda), dense_grad=G2)
+    assert torch.equal(G, G2)
