@@ -416,14 +416,18 @@ class NeumfTrainer:
         uid_occ = uid.repeat_interleave(Cn)
         ku, pu = sort_ids(uid_occ, P["mf_u"].shape[0])
         ki, pi = sort_ids(iid, P["mf_i"].shape[0])
-        for tab, grad, keys, perm in (("mf_u", "g_mf_u", ku, pu), ("mlp_u", "g_mlp_u", ku, pu),
-                                      ("mf_i", "g_mf_i", ki, pi), ("mlp_i", "g_mlp_i", ki, pi)):
+        # the mf / mlp tables of a side share ids: one sort and ONE head list serve both updates
+        _, hu, nhu = segment_heads(ku, pu, want_single=False)
+        _, hi, nhi = segment_heads(ki, pi, want_single=False)
+        for tab, grad, keys, perm, hd, nh in (("mf_u", "g_mf_u", ku, pu, hu, nhu), ("mlp_u", "g_mlp_u", ku, pu, hu, nhu),
+                                              ("mf_i", "g_mf_i", ki, pi, hi, nhi), ("mlp_i", "g_mlp_i", ki, pi, hi, nhi)):
             st = self.state[tab]
             if self.rowwise:
-                segmented_update(keys, perm, rows[grad], hyper=h, W=P[tab], m=st.get("m"), v=st.get("v"))
+                segmented_update(keys, perm, rows[grad], hyper=h, W=P[tab], m=st.get("m"), v=st.get("v"), heads=hd,
+                                 n_heads=nh)
             else:
                 G = torch.zeros_like(P[tab])
-                segmented_update(keys, perm, rows[grad], dense_grad=G)
+                segmented_update(keys, perm, rows[grad], dense_grad=G, heads=hd, n_heads=nh)
                 dense_update(P[tab], G, h, st.get("m"), st.get("v"))
         dense_update_multi([(P[k], dense[k], h0 if k == "b1" else h, self.state[k].get("m"), self.state[k].get("v"))
                             for k in ("W1", "b1", "w_out")], self.opt)

@@ -225,12 +225,16 @@ class _NeumfFn(torch.autograd.Function):
         ku, pu = engine.sort_ids(uid_occ, P["mf_u"].shape[0])
         ki, pi = engine.sort_ids(iid, P["mf_i"].shape[0])
 
-        def dense_tab(tab, key, keys, perm):
+        # the mf / mlp tables of a side share ids: one sort and one head list serve both
+        _, hu, nhu = engine.segment_heads(ku, pu, want_single=False)
+        _, hi, nhi = engine.segment_heads(ki, pi, want_single=False)
+
+        def dense_tab(tab, key, keys, perm, heads, n_heads):
             G = torch.zeros_like(P[tab])
-            engine.segmented_update(keys, perm, rows[key], dense_grad=G)
+            engine.segmented_update(keys, perm, rows[key], dense_grad=G, heads=heads, n_heads=n_heads)
             return G
-        return (dense_tab("mf_u", "g_mf_u", ku, pu), dense_tab("mf_i", "g_mf_i", ki, pi),
-                dense_tab("mlp_u", "g_mlp_u", ku, pu), dense_tab("mlp_i", "g_mlp_i", ki, pi),
+        return (dense_tab("mf_u", "g_mf_u", ku, pu, hu, nhu), dense_tab("mf_i", "g_mf_i", ki, pi, hi, nhi),
+                dense_tab("mlp_u", "g_mlp_u", ku, pu, hu, nhu), dense_tab("mlp_i", "g_mlp_i", ki, pi, hi, nhi),
                 dense["W1"], dense["b1"], dense["w_out"].view(ctx.wshape), None, None, None, None)
 
 

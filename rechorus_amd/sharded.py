@@ -59,13 +59,23 @@ class HipOps:
             self.e.segmented_update(keys, perm, I_loc, coef=g, src_index=rows, div=1, dense_grad=out)
         return out
 
-    def update_rows(self, W, state, rows, src, hyper, coef=None, src_index=None):
+    def prepare_rows(self, rows, n_rows):
+        """sort + head list of a row-id list, reusable by several update_rows calls on tables that share the ids"""
+        if rows.numel() == 0:
+            return None
+        keys, perm = self.e.sort_ids(rows, n_rows)
+        _, heads, n_heads = self.e.segment_heads(keys, perm, want_single=False)
+        return keys, perm, heads, n_heads
+
+    def update_rows(self, W, state, rows, src, hyper, coef=None, src_index=None, prep=None):
         """W[r] <- opt(W[r], sum_{o: rows[o]=r} coef[o] * src[src_index[o] or o])"""
         if rows.numel() == 0:
             return
-        keys, perm = self.e.sort_ids(rows, W.shape[0])
+        if prep is None:
+            prep = self.prepare_rows(rows, W.shape[0])
+        keys, perm, heads, n_heads = prep
         self.e.segmented_update(keys, perm, src, hyper=hyper, W=W, m=state.get("m"), v=state.get("v"),
-                                coef=coef, src_index=src_index, div=1)
+                                coef=coef, src_index=src_index, div=1, heads=heads, n_heads=n_heads)
 
     # ---- fast path (csrc/owner_step.hip); ShardedBprmf falls back to torch / the two calls above
     #      for ops objects that do not provide these (the oracle-backed ops of the CPU tests)
@@ -593,9 +603,13 @@ class ShardedNeumf:
                 o += n
         else:
             own_u, own_i, req_u, req_i = gu, gi, uid, iid.reshape(-1)
-        for tab, own, req, lo in (("mf_u", own_u, req_u, 0), ("mlp_u", own_u, req_u, d),
-                                  ("mf_i", own_i, req_i, 0), ("mlp_i", own_i, req_i, d)):
-            ops.update_rows(self.P[tab], self.state[tab], req, own[:, lo:lo + d].contiguous(), hyper)
+        shared = hasattr(ops, "prepare_rows")  # one sort + head list per side, used by its mf and mlp table
+        prep_u = ops.prepare_rows(req_u, self.P["mf_u"].shape[0]) if shared else None
+        prep_i = ops.prepare_rows(req_i, self.P["mf_i"].shape[0]) if shared else None
+        for tab, own, req, lo, prep in (("mf_u", own_u, req_u, 0, prep_u), ("mlp_u", own_u, req_u, d, prep_u),
+                                        ("mf_i", own_i, req_i, 0, prep_i), ("mlp_i", own_i, req_i, d, prep_i)):
+            kw = {"prep": prep} if shared else {}
+            ops.update_rows(self.P[tab], self.state[tab], req, own[:, lo:lo + d].contiguous(), hyper, **kw)
         for k in ("W1", "b1", "w_out"):
             ops.dense_update(self.P[k], dense[k].contiguous(), hyper0 if k == "b1" else hyper, self.state[k])
         return loss
