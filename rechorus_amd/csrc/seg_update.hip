@@ -189,6 +189,16 @@ __global__ __launch_bounds__(kBlock) void seg_update_kernel(SegArgs a) {
   const uint32_t o0 = a.perm[j];
   const uint32_t o1 = a.perm[has_next ? j + 1 : j];
   const bool multi = knext == key;
+  // hot row (more than kLongSeg occurrences; keys are sorted, so one probe decides): hand it to the chunked path
+  // BEFORE touching its rows -- tables where most segments are hot (a small catalogue under a large batch) spent
+  // most of this kernel summing 32 occurrences per row only to drop them
+  if (j + kLongSeg < n && a.keys[j + kLongSeg] == key) {
+    if (l == 0) {
+      const uint32_t slot = atomicAdd(&a.counters[CNT_LONG], 1u);
+      if (slot < a.long_cap) a.long_list[slot] = (uint32_t)j;
+    }
+    return;
+  }
   const float4 w = load_row4<D, MODE>(a, key, l);
   float4 acc = occ_grad4_o<D>(a, o0, l);
   if (ONLY_MULTI || multi) {
@@ -259,15 +269,28 @@ __global__ __launch_bounds__(kBlock) void seg_update_multi_x2_kernel(SegArgs a) 
     o0[h] = a.perm[j[h]];
     o1[h] = a.perm[j[h] + 1];
   }
+  bool hot[H];  // more than kLongSeg occurrences: goes to the chunked path untouched (see seg_update_kernel)
 #pragma unroll
-  for (int h = 0; h < H; ++h) w[h] = load_row4<D, MODE>(a, key[h], l);
+  for (int h = 0; h < H; ++h) hot[h] = j[h] + kLongSeg < a.n_occ && a.keys[j[h] + kLongSeg] == key[h];
 #pragma unroll
-  for (int h = 0; h < H; ++h) acc[h] = occ_grad4_o<D>(a, o0[h], l);
+  for (int h = 0; h < H; ++h)
+    if (!hot[h]) w[h] = load_row4<D, MODE>(a, key[h], l);
 #pragma unroll
-  for (int h = 0; h < H; ++h) s1[h] = occ_grad4_o<D>(a, o1[h], l);
+  for (int h = 0; h < H; ++h)
+    if (!hot[h]) acc[h] = occ_grad4_o<D>(a, o0[h], l);
+#pragma unroll
+  for (int h = 0; h < H; ++h)
+    if (!hot[h]) s1[h] = occ_grad4_o<D>(a, o1[h], l);
 #pragma unroll
   for (int h = 0; h < H; ++h) {
     if (g + h >= nh) break;
+    if (hot[h]) {
+      if (l == 0) {
+        const uint32_t slot = atomicAdd(&a.counters[CNT_LONG], 1u);
+        if (slot < a.long_cap) a.long_list[slot] = (uint32_t)j[h];
+      }
+      continue;
+    }
     add4(acc[h], s1[h]);
     if (!seg_tail<D, MODE>(a, j[h], key[h], l, acc[h])) apply_row4<D, MODE>(a, key[h], l, w[h], acc[h]);
   }
