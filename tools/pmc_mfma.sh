@@ -9,7 +9,9 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
 CTRS="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"
+if [ "${2:-all}" != "sasrec" ]; then
 timeout 300 rocprofv3 --pmc $CTRS --kernel-trace -d $OUT/neumf -o n --output-format csv -- python $R/tools/microbench_neumf.py > $OUT/neumf.log 2>&1
+fi
 timeout 300 rocprofv3 --pmc $CTRS --kernel-trace -d $OUT/sasrec -o s --output-format csv -- python $R/tools/microbench_sasrec.py > $OUT/sasrec.log 2>&1
 cd $R
 python - <<PY > $OUT/summary.txt 2>&1
@@ -19,7 +21,7 @@ for wl in ("neumf", "sasrec"):
     for path in glob.glob("$OUT/%s/**/*counter_collection.csv" % wl, recursive=True):
         for row in csv.DictReader(open(path, newline="")):
             k = row["Kernel_Name"]
-            if "neumf_kernel" in k or "sasrec_fwd_kernel" in k or "sasrec_bwd_kernel" in k:
+            if "neumf_kernel" in k or "sasrec_fwd_kernel" in k or "sasrec_bwd_kernel" in k or "rc::sb_" in k:
                 acc[k.split("(")[0][-60:]][row["Counter_Name"]].append(float(row["Counter_Value"]))
     for k, c in acc.items():
         m = {n: sum(v) / len(v) for n, v in c.items()}
@@ -34,4 +36,4 @@ for wl in ("neumf", "sasrec"):
         print(wl, k, line)
 PY
 find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -size +4M -delete
-cat $OUT/summary.txt; tail -2 $OUT/neumf.log
+cat $OUT/summary.txt; tail -2 $OUT/sasrec.log
