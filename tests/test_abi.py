@@ -71,3 +71,15 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(_lib.RechorusHipMissing):
         _lib.load()
+
+
+def test_integration_doc_names_every_entry_point():
+    """INTEGRATION.md's table is the map from reference code to entry points: it has to mention all of them"""
+    import re
+    header = open(os.path.join(ROOT, "include", "rechorus_hip.h")).read()
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    names = sorted(set(re.findall(r"\b(rc_[a-z0-9_]+)\s*\(", header)))
+    missing = [n for n in names if n not in doc and not (n.endswith("_fwd") or n.endswith("_bwd")) ]
+    # `rc_x_fwd/bwd` is written as one cell for pairs
+    missing += [n for n in names if (n.endswith("_fwd") or n.endswith("_bwd")) and n not in doc and n[:-4] + "_fwd/bwd" not in doc]
+    assert not missing, missing
