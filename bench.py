@@ -51,13 +51,22 @@ def parse():
     ap.add_argument("--graph", action="store_true", help="replay each step from a captured hipGraph (small batches)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL (the only measurement mode); gloo only to smoke-test N>1 on one GPU")
-    ap.add_argument("--workload", default="bprmf", choices=["bprmf", "neumf"],
+    ap.add_argument("--workload", default="bprmf", choices=["bprmf", "neumf", "sasrec"],
                     help="bprmf = BASELINE configs[1] (the contract workload); neumf = configs[3]: NeuMF emb_size 128, "
                          "num_neg 4, hidden 64 (pass --items 100000001 --users 10000001 --num-neg 4 --emb-size 128)")
     ap.add_argument("--hidden", type=int, default=64, help="neumf: size of the hidden layer")
+    ap.add_argument("--hist", type=int, default=50, help="sasrec: history_max (BASELINE configs[2])")
+    ap.add_argument("--heads", type=int, default=4, help="sasrec: attention heads")
+    ap.add_argument("--layers", type=int, default=1, help="sasrec: transformer blocks")
     ap.add_argument("--parallel", default="sharded", choices=["sharded", "replicas"],
                     help="N>1: row-sharded tables + owner-computes exchange (default), or independent replicas")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.workload == "sasrec":  # configs[2] is quoted on a Grocery-sized catalogue; keep explicit overrides
+        if args.items == 10_000_001:
+            args.items = 8714
+        if args.batch == 65536:
+            args.batch = 4096
+    return args
 
 
 def zipf_ids(n_rows, size, gen, device):
@@ -80,6 +89,33 @@ def make_batches(args, device, seed):
         neg = torch.randint(1, args.items, (args.batch, args.num_neg), generator=gen, device=device)
         out.append((uid.contiguous(), torch.cat([pos, neg], dim=1).contiguous()))
     return out
+
+
+def make_sasrec(args, device, engine, seed):
+    """BASELINE configs[2]: SASRec emb_size 64, history_max 50, K = 99 on a Grocery-sized catalogue; histories of
+    uniform length 1..history_max (real ones are shorter), Zipf items.  -> (trainer, batches of (hist, lengths, iid))"""
+    d, L = args.emb_size, args.hist
+    gen = torch.Generator(device=device)
+    gen.manual_seed(1234)
+    mk = lambda *shape: torch.empty(shape, device=device).normal_(0, 0.05, generator=gen)
+    layers = []
+    for _ in range(args.layers):
+        lay = {k: (mk(d, d) if k.startswith("W") else mk(d)) for k in engine.SAS_LAYER_KEYS}
+        lay["ln1w"] += 1.0
+        lay["ln2w"] += 1.0
+        layers.append(lay)
+    P = {"item_emb": mk(args.items, d), "pos_emb": mk(L + 1, d), "layers": layers}
+    trainer = engine.SasrecTrainer(P, args.heads, opt=args.opt, lr=args.lr, l2=args.l2, rowwise=True)
+    gen.manual_seed(seed)
+    batches = []
+    for _ in range(args.pool):
+        lengths = torch.randint(1, L + 1, (args.batch,), generator=gen, device=device)
+        hist = zipf_ids(args.items, (args.batch, L), gen, device)
+        hist = (hist * (torch.arange(L, device=device)[None, :] < lengths[:, None])).contiguous()
+        pos = zipf_ids(args.items, (args.batch, 1), gen, device)
+        neg = torch.randint(1, args.items, (args.batch, args.num_neg), generator=gen, device=device)
+        batches.append((hist, lengths, torch.cat([pos, neg], dim=1).contiguous()))
+    return trainer, batches
 
 
 def make_neumf_trainer(args, world, device, engine):
@@ -226,8 +262,12 @@ def main():
 
     from rechorus_amd import engine
 
-    batches = make_batches(args, device, seed=99 + rank)
-    if args.workload == "neumf":
+    batches = make_batches(args, device, seed=99 + rank) if args.workload != "sasrec" else None
+    if args.workload == "sasrec":
+        if world > 1 and args.parallel != "replicas":
+            raise SystemExit("--workload sasrec: the 8.7 K-row item table does not shard; use --parallel replicas for N > 1")
+        trainer, batches = make_sasrec(args, device, engine, seed=99 + rank)
+    elif args.workload == "neumf":
         trainer = make_neumf_trainer(args, world, device, engine)
     elif world == 1 or args.parallel == "replicas":
         gen = torch.Generator(device=device)
@@ -306,7 +346,11 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": f"{'NeuMF (hidden ' + str(args.hidden) + ')' if args.workload == 'neumf' else 'BPRMF'} fit step: emb_size={args.emb_size}, num_neg={args.num_neg}, "
+            "workload": (f"SASRec fit step: emb_size={args.emb_size}, history_max={args.hist} (lengths uniform on 1..{args.hist}), "
+                         f"{args.heads} heads, {args.layers} layer(s), num_neg={args.num_neg}, {args.items}-item table, Zipf(1.0) "
+                         f"histories+positives, uniform negatives, B={args.batch} sequences/GPU/step, optimizer={args.opt} "
+                         f"(row-wise, l2={args.l2:g}), int64 ids, fp32") if args.workload == "sasrec" else
+                        f"{'NeuMF (hidden ' + str(args.hidden) + ')' if args.workload == 'neumf' else 'BPRMF'} fit step: emb_size={args.emb_size}, num_neg={args.num_neg}, "
                         f"{args.items}-item / {args.users}-user tables, Zipf(1.0) users+positives, "
                         f"uniform negatives, B={args.batch} tuples/GPU/step, optimizer={args.opt} "
                         f"(row-wise, l2={args.l2:g}), int64 ids, fp32",

@@ -180,3 +180,22 @@ def test_bench_contract_line(cuda):
     c = out["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == out["unit"] and c["sample"]
     assert out["value"] > c["value"]
+
+
+@pytest.mark.parametrize("workload,extra", [("sasrec", ["--batch", "512", "--hist", "50", "--num-neg", "9"]),
+                                            ("neumf", ["--batch", "2048", "--items", "100001", "--users", "10001", "--num-neg", "4",
+                                                       "--emb-size", "64"])])
+def test_bench_other_workloads(workload, extra, cuda):
+    """BASELINE configs[2] / configs[3] through the same bench.py line (no roofline object: the committed PMC
+    passes are for the contract workload)"""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", workload, "--steps", "3", "--warmup", "2",
+                        "--no-cpu-baseline"] + extra, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = json.loads([l for l in p.stdout.splitlines() if l.strip()][-1])
+    assert out["metric"] == "ranked (1+K)-tuples/sec" and out["value"] > 0 and out["n_gpus"] == 1
+    assert workload.lower() in out["config"]["workload"].lower() and np.isfinite(out["final_loss"])
