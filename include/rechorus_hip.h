@@ -262,6 +262,16 @@ int rc_segmented_update2(float* W, float* m, float* v, int d, const uint32_t* ke
 
 /* ---- SASRec encoder (models/sequential/SASRec.py:51-86, utils/layers.py:9-63,92-118) ------- */
 
+/* Two tables that share their ids (NeuMF's mf / mlp embedding of a user or an item, models/general/NeuMF.py:37-40)
+ * updated in ONE pass over keys / perm / heads; src_a, src_b: per-occurrence gradient rows [n_occ, d]; outputs as
+ * in rc_segmented_update (both dense_grad_*, or W_* (+ m, v) with h).  2 d must be one of 16/32/64/128/256.
+ * Workspace: rc_segmented_workspace_bytes(n_occ, 2 d).                                                      */
+int rc_segmented_update_pair(float* W_a, float* m_a, float* v_a, float* W_b, float* m_b, float* v_b, int d,
+                             const uint32_t* keys, const uint32_t* perm, int64_t n_occ, const float* src_a,
+                             const float* src_b, const rc_opt_hyper* h, float* dense_grad_a, float* dense_grad_b,
+                             const uint32_t* heads, const uint32_t* n_heads, void* ws, size_t ws_bytes,
+                             rc_stream_t stream);
+
 /* 1 iff the kernels cover the shape: d in {32,64}, 1..4 layers, heads | d, L <= 64, dropout 0.   */
 int rc_sasrec_supported(int d, int n_layers, int n_heads, int L);
 /* floats per layer in the dense-gradient block of rc_sasrec_bwd: 5*d*d + 9*d, in the order

@@ -64,7 +64,23 @@ struct SegArgs {
   uint32_t long_cap, chunk_cap, partial_cap;
   int skip_single;
   OptScalars o;
+  // pair mode (rc_segmented_update_pair): two tables of width D/2 that share keys / perm / heads are updated as
+  // ONE row of width D -- the lower half of a row's lanes works on table a (W, M, V, src, dense_grad), the upper
+  // half on table b.  Zero for the ordinary single-table call.
+  int pair;
+  float *Wb, *Mb, *Vb;
+  const float* srcb;
+  float* dense_grad_b;
 };
+
+// pair mode: which table a lane belongs to and its float4 slot inside that table's row
+template <int D>
+__device__ __forceinline__ bool pair_upper(int l, int& ll) {
+  constexpr int H = D / 8;
+  const bool up = l >= H;
+  ll = up ? l - H : l;
+  return up;
+}
 
 __device__ __forceinline__ void add4(float4& x, const float4& y) {
   x.x += y.x; x.y += y.y; x.z += y.z; x.w += y.w;
@@ -134,6 +150,17 @@ template <int D, int MODE>
 __device__ __forceinline__ void apply_row4(const SegArgs& a, uint32_t key, int l, float4 w,
                                            const float4& g) {
   constexpr int LPR = D / 4;
+  if (a.pair) {  // uniform
+    int ll;
+    const bool up = pair_upper<D>(l, ll);
+    const size_t idx = (size_t)(key - a.key_base) * (LPR / 2) + ll;
+    if (MODE == MODE_DENSE_GRAD) {
+      reinterpret_cast<float4*>(up ? a.dense_grad_b : a.dense_grad)[idx] = g;
+      return;
+    }
+    opt_row4<MODE>(a.o, up ? a.Wb : a.W, up ? a.Mb : a.M, up ? a.Vb : a.V, idx, w, g);
+    return;
+  }
   const size_t idx = (size_t)(key - a.key_base) * LPR + l;
   if (MODE == MODE_DENSE_GRAD) {
     reinterpret_cast<float4*>(a.dense_grad)[idx] = g;
@@ -146,6 +173,11 @@ template <int D, int MODE>
 __device__ __forceinline__ float4 load_row4(const SegArgs& a, uint32_t key, int l) {
   constexpr int LPR = D / 4;
   if (MODE == MODE_DENSE_GRAD) return make_float4(0, 0, 0, 0);
+  if (a.pair) {
+    int ll;
+    const bool up = pair_upper<D>(l, ll);
+    return load_stream4(reinterpret_cast<const float4*>(up ? a.Wb : a.W) + (size_t)(key - a.key_base) * (LPR / 2) + ll);
+  }
   // read-once row: non-temporal, so that the gathered source rows (a.src, re-read per occurrence)
   // keep their L2 lines (measured at config 2: item update 0.402 -> 0.384 ms, user update 0.085 -> 0.068)
   return load_stream4(reinterpret_cast<const float4*>(a.W) + (size_t)(key - a.key_base) * LPR + l);
@@ -156,6 +188,11 @@ template <int D>
 __device__ __forceinline__ float4 occ_grad4_o(const SegArgs& a, uint32_t o, int l) {
   constexpr int LPR = D / 4;
   o -= a.occ_base;
+  if (a.pair) {  // plain gradient rows of the two tables, one per occurrence
+    int ll;
+    const bool up = pair_upper<D>(l, ll);
+    return reinterpret_cast<const float4*>(up ? a.srcb : a.src)[(size_t)o * (LPR / 2) + ll];
+  }
   if (a.src2 && o >= a.n_split)  // second source: plain gradient rows, one per occurrence
     return reinterpret_cast<const float4*>(a.src2)[(size_t)(o - a.n_split) * LPR + l];
   const float c = a.coef ? a.coef[o] : 1.0f;  // (a non-temporal load here costs 10 %: measured)
@@ -738,5 +775,61 @@ extern "C" int rc_segmented_update2(float* W, float* m, float* v, int d, const u
     case MODE_SGD: return launch_seg_mode<MODE_SGD>(a, vec_ok, s);
     case MODE_ADAM: return launch_seg_mode<MODE_ADAM>(a, vec_ok, s);
     default: return launch_seg_mode<MODE_ADAGRAD>(a, vec_ok, s);
+  }
+}
+
+// Two tables that share their ids (NeuMF's mf / mlp embedding of a user or an item: models/general/NeuMF.py:37-40
+// looks both up with the same index tensor) updated in ONE pass over keys / perm / heads: the row of width 2 d is
+// the concatenation [table a | table b], every kernel of rc_segmented_update runs unchanged on it.  src_a / src_b:
+// per-occurrence gradient rows [n_occ, d].  Either both dense_grad_* (dense gradients out) or W_* (+ m, v) with h.
+extern "C" int rc_segmented_update_pair(float* W_a, float* m_a, float* v_a, float* W_b, float* m_b, float* v_b, int d,
+                                        const uint32_t* keys, const uint32_t* perm, int64_t n_occ, const float* src_a,
+                                        const float* src_b, const rc_opt_hyper* h, float* dense_grad_a,
+                                        float* dense_grad_b, const uint32_t* heads, const uint32_t* n_heads, void* ws,
+                                        size_t ws_bytes, rc_stream_t stream) {
+  if (n_occ == 0) return RC_OK;
+  RC_REQUIRE(keys && perm && src_a && src_b && ws, "rc_segmented_update_pair: null pointer");
+  RC_REQUIRE(n_occ > 0 && n_occ < ((int64_t)1 << 31), "rc_segmented_update_pair: bad n_occ=%lld", (long long)n_occ);
+  RC_REQUIRE((dense_grad_a != nullptr) == (dense_grad_b != nullptr), "rc_segmented_update_pair: give both dense gradients or none");
+  RC_REQUIRE(dense_grad_a != nullptr || (W_a != nullptr && W_b != nullptr), "rc_segmented_update_pair: no output");
+  RC_REQUIRE((heads == nullptr) == (n_heads == nullptr), "rc_segmented_update_pair: heads and n_heads go together");
+  if (!vector_kernel_for(2 * d))
+    return fail(RC_ERR_UNSUPPORTED, "rc_segmented_update_pair: d=%d (2 d must be 16/32/64/128/256)", d);
+  auto al = [](const void* p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; };
+  RC_REQUIRE(al(W_a) && al(W_b) && al(m_a) && al(m_b) && al(v_a) && al(v_b) && al(src_a) && al(src_b) && al(dense_grad_a) &&
+                 al(dense_grad_b), "rc_segmented_update_pair: buffers must be 16-byte aligned");
+  const SegWs w = carve_seg_ws(ws, n_occ, 2 * d);
+  if (ws_bytes < w.total) return fail(RC_ERR_WORKSPACE, "rc_segmented_update_pair: workspace %zu < %zu", ws_bytes, w.total);
+  hipStream_t s = as_stream(stream);
+  SegArgs a;
+  memset(&a, 0, sizeof(a));
+  a.pair = 1;
+  a.W = W_a; a.M = m_a; a.V = v_a; a.Wb = W_b; a.Mb = m_b; a.Vb = v_b;
+  a.keys = keys; a.perm = perm; a.n_occ = n_occ; a.src = src_a; a.srcb = src_b; a.div = 1; a.d = 2 * d;
+  a.n_split = (uint32_t)n_occ;
+  a.dense_grad = dense_grad_a; a.dense_grad_b = dense_grad_b;
+  a.counters = w.counters; a.long_list = w.long_list; a.rows = w.rows; a.chunks = w.chunks; a.partial = w.partial;
+  a.long_cap = w.long_cap; a.chunk_cap = w.chunk_cap; a.partial_cap = w.partial_cap;
+  int mode = MODE_DENSE_GRAD;
+  if (!dense_grad_a) {
+    RC_TRY(fill_opt_scalars(h, &a.o));
+    mode = mode_of(h);
+    RC_REQUIRE(mode != MODE_ADAM || (m_a && v_a && m_b && v_b), "rc_segmented_update_pair: Adam needs m and v");
+    RC_REQUIRE(mode != MODE_ADAGRAD || (m_a && m_b), "rc_segmented_update_pair: Adagrad needs m (state_sum)");
+  }
+  RC_HIP(hipMemsetAsync(w.counters, 0, CNT_N * sizeof(uint32_t), s));
+  if (heads) {
+    a.heads = heads;
+    a.n_heads = n_heads;
+  } else {
+    RC_TRY(launch_heads(keys, perm, n_occ, 0, nullptr, w.heads, &w.counters[CNT_HEADS], s));
+    a.heads = w.heads;
+    a.n_heads = &w.counters[CNT_HEADS];
+  }
+  switch (mode) {
+    case MODE_DENSE_GRAD: return launch_seg_mode<MODE_DENSE_GRAD>(a, true, s);
+    case MODE_SGD: return launch_seg_mode<MODE_SGD>(a, true, s);
+    case MODE_ADAM: return launch_seg_mode<MODE_ADAM>(a, true, s);
+    default: return launch_seg_mode<MODE_ADAGRAD>(a, true, s);
   }
 }

@@ -220,6 +220,27 @@ def segmented_update(keys, perm, src, hyper=None, W=None, m=None, v=None, coef=N
               C.c_void_p(ws.data_ptr()), ws.numel(), _stream())
 
 
+def segmented_update_pair(keys, perm, src_a, src_b, hyper=None, W=(None, None), m=(None, None), v=(None, None),
+                          dense_grad=(None, None), heads=None, n_heads=None):
+    """rc_segmented_update_pair: two tables with the same ids (NeuMF's mf / mlp embeddings) in one pass.
+    src_a, src_b [n_occ, d] per-occurrence gradient rows; W / m / v / dense_grad are (table a, table b) pairs."""
+    n_occ = keys.numel()
+    d = src_a.shape[-1]
+    f32 = torch.float32
+    ws = workspace(_lib.load().rc_segmented_workspace_bytes(n_occ, 2 * d), keys.device, "seg")
+    _lib.call("rc_segmented_update_pair", _ptr(W[0], f32, "W_a", True), _ptr(m[0], f32, "m_a", True), _ptr(v[0], f32, "v_a", True),
+              _ptr(W[1], f32, "W_b", True), _ptr(m[1], f32, "m_b", True), _ptr(v[1], f32, "v_b", True), d,
+              _ptr(keys, torch.int32, "keys"), _ptr(perm, torch.int32, "perm"), n_occ, _ptr(src_a, f32, "src_a"),
+              _ptr(src_b, f32, "src_b"), C.byref(hyper) if hyper is not None else None,
+              _ptr(dense_grad[0], f32, "dense_grad_a", True), _ptr(dense_grad[1], f32, "dense_grad_b", True),
+              _ptr(heads, torch.int32, "heads", True), _ptr(n_heads, torch.int32, "n_heads", True),
+              C.c_void_p(ws.data_ptr()), ws.numel(), _stream())
+
+
+def segmented_pair_supported(d):
+    return 2 * d in (16, 32, 64, 128, 256)
+
+
 def embedding_dense_backward(grad_out, ids, n_rows):
     """Dense [n_rows,d] gradient of W[ids] (aten::embedding_dense_backward semantics),
     computed by sort + segmented sum instead of atomics / index_add."""
@@ -416,19 +437,30 @@ class NeumfTrainer:
         uid_occ = uid.repeat_interleave(Cn)
         ku, pu = sort_ids(uid_occ, P["mf_u"].shape[0])
         ki, pi = sort_ids(iid, P["mf_i"].shape[0])
-        # the mf / mlp tables of a side share ids: one sort and ONE head list serve both updates
+        # the mf / mlp tables of a side share ids: one sort, ONE head list and ONE update pass serve both
         _, hu, nhu = segment_heads(ku, pu, want_single=False)
         _, hi, nhi = segment_heads(ki, pi, want_single=False)
-        for tab, grad, keys, perm, hd, nh in (("mf_u", "g_mf_u", ku, pu, hu, nhu), ("mlp_u", "g_mlp_u", ku, pu, hu, nhu),
-                                              ("mf_i", "g_mf_i", ki, pi, hi, nhi), ("mlp_i", "g_mlp_i", ki, pi, hi, nhi)):
-            st = self.state[tab]
-            if self.rowwise:
-                segmented_update(keys, perm, rows[grad], hyper=h, W=P[tab], m=st.get("m"), v=st.get("v"), heads=hd,
-                                 n_heads=nh)
+        pair_ok = segmented_pair_supported(P["mf_u"].shape[1])
+        for ta, tb, ga, gb, keys, perm, hd, nh in (("mf_u", "mlp_u", "g_mf_u", "g_mlp_u", ku, pu, hu, nhu),
+                                                   ("mf_i", "mlp_i", "g_mf_i", "g_mlp_i", ki, pi, hi, nhi)):
+            sa, sb = self.state[ta], self.state[tb]
+            G = (torch.zeros_like(P[ta]), torch.zeros_like(P[tb])) if not self.rowwise else (None, None)
+            if pair_ok and self.rowwise:
+                segmented_update_pair(keys, perm, rows[ga], rows[gb], hyper=h, W=(P[ta], P[tb]), m=(sa.get("m"), sb.get("m")),
+                                      v=(sa.get("v"), sb.get("v")), heads=hd, n_heads=nh)
+            elif pair_ok:
+                segmented_update_pair(keys, perm, rows[ga], rows[gb], dense_grad=G, heads=hd, n_heads=nh)
             else:
-                G = torch.zeros_like(P[tab])
-                segmented_update(keys, perm, rows[grad], dense_grad=G, heads=hd, n_heads=nh)
-                dense_update(P[tab], G, h, st.get("m"), st.get("v"))
+                for k, (tab, grad) in enumerate(((ta, ga), (tb, gb))):
+                    st = self.state[tab]
+                    if self.rowwise:
+                        segmented_update(keys, perm, rows[grad], hyper=h, W=P[tab], m=st.get("m"), v=st.get("v"), heads=hd,
+                                         n_heads=nh)
+                    else:
+                        segmented_update(keys, perm, rows[grad], dense_grad=G[k], heads=hd, n_heads=nh)
+            if not self.rowwise:
+                dense_update(P[ta], G[0], h, sa.get("m"), sa.get("v"))
+                dense_update(P[tb], G[1], h, sb.get("m"), sb.get("v"))
         dense_update_multi([(P[k], dense[k], h0 if k == "b1" else h, self.state[k].get("m"), self.state[k].get("v"))
                             for k in ("W1", "b1", "w_out")], self.opt)
         return self.loss

@@ -229,12 +229,17 @@ class _NeumfFn(torch.autograd.Function):
         _, hu, nhu = engine.segment_heads(ku, pu, want_single=False)
         _, hi, nhi = engine.segment_heads(ki, pi, want_single=False)
 
-        def dense_tab(tab, key, keys, perm, heads, n_heads):
-            G = torch.zeros_like(P[tab])
-            engine.segmented_update(keys, perm, rows[key], dense_grad=G, heads=heads, n_heads=n_heads)
-            return G
-        return (dense_tab("mf_u", "g_mf_u", ku, pu, hu, nhu), dense_tab("mf_i", "g_mf_i", ki, pi, hi, nhi),
-                dense_tab("mlp_u", "g_mlp_u", ku, pu, hu, nhu), dense_tab("mlp_i", "g_mlp_i", ki, pi, hi, nhi),
+        def dense_pair(ta, tb, ga, gb, keys, perm, heads, n_heads):  # one pass over the ids for both tables
+            Ga, Gb = torch.zeros_like(P[ta]), torch.zeros_like(P[tb])
+            if engine.segmented_pair_supported(P[ta].shape[1]):
+                engine.segmented_update_pair(keys, perm, rows[ga], rows[gb], dense_grad=(Ga, Gb), heads=heads, n_heads=n_heads)
+            else:
+                engine.segmented_update(keys, perm, rows[ga], dense_grad=Ga, heads=heads, n_heads=n_heads)
+                engine.segmented_update(keys, perm, rows[gb], dense_grad=Gb, heads=heads, n_heads=n_heads)
+            return Ga, Gb
+        g_mf_u, g_mlp_u = dense_pair("mf_u", "mlp_u", "g_mf_u", "g_mlp_u", ku, pu, hu, nhu)
+        g_mf_i, g_mlp_i = dense_pair("mf_i", "mlp_i", "g_mf_i", "g_mlp_i", ki, pi, hi, nhi)
+        return (g_mf_u, g_mf_i, g_mlp_u, g_mlp_i,
                 dense["W1"], dense["b1"], dense["w_out"].view(ctx.wshape), None, None, None, None)
 
 

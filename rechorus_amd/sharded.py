@@ -77,6 +77,17 @@ class HipOps:
         self.e.segmented_update(keys, perm, src, hyper=hyper, W=W, m=state.get("m"), v=state.get("v"),
                                 coef=coef, src_index=src_index, div=1, heads=heads, n_heads=n_heads)
 
+    def update_rows_pair(self, Wa, Wb, sa, sb, rows, src_a, src_b, hyper, prep):
+        """two tables that share `rows` (NeuMF's mf / mlp embeddings) in one pass; False if the width has no pair kernel"""
+        if rows.numel() == 0:
+            return True
+        if not self.e.segmented_pair_supported(Wa.shape[1]):
+            return False
+        keys, perm, heads, n_heads = prep
+        self.e.segmented_update_pair(keys, perm, src_a, src_b, hyper=hyper, W=(Wa, Wb), m=(sa.get("m"), sb.get("m")),
+                                     v=(sa.get("v"), sb.get("v")), heads=heads, n_heads=n_heads)
+        return True
+
     # ---- fast path (csrc/owner_step.hip); ShardedBprmf falls back to torch / the two calls above
     #      for ops objects that do not provide these (the oracle-backed ops of the CPU tests)
     def route(self, ids, world, tuple_base=None, div=1):
@@ -606,10 +617,14 @@ class ShardedNeumf:
         shared = hasattr(ops, "prepare_rows")  # one sort + head list per side, used by its mf and mlp table
         prep_u = ops.prepare_rows(req_u, self.P["mf_u"].shape[0]) if shared else None
         prep_i = ops.prepare_rows(req_i, self.P["mf_i"].shape[0]) if shared else None
-        for tab, own, req, lo, prep in (("mf_u", own_u, req_u, 0, prep_u), ("mlp_u", own_u, req_u, d, prep_u),
-                                        ("mf_i", own_i, req_i, 0, prep_i), ("mlp_i", own_i, req_i, d, prep_i)):
+        for ta, tb, own, req, prep in (("mf_u", "mlp_u", own_u, req_u, prep_u), ("mf_i", "mlp_i", own_i, req_i, prep_i)):
+            ga, gb = own[:, :d].contiguous(), own[:, d:].contiguous()
+            if shared and hasattr(ops, "update_rows_pair") and ops.update_rows_pair(
+                    self.P[ta], self.P[tb], self.state[ta], self.state[tb], req, ga, gb, hyper, prep):
+                continue
             kw = {"prep": prep} if shared else {}
-            ops.update_rows(self.P[tab], self.state[tab], req, own[:, lo:lo + d].contiguous(), hyper, **kw)
+            ops.update_rows(self.P[ta], self.state[ta], req, ga, hyper, **kw)
+            ops.update_rows(self.P[tb], self.state[tb], req, gb, hyper, **kw)
         for k in ("W1", "b1", "w_out"):
             ops.dense_update(self.P[k], dense[k].contiguous(), hyper0 if k == "b1" else hyper, self.state[k])
         return loss

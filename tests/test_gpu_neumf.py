@@ -194,3 +194,59 @@ def test_neumf_trainer_with_dropout_draws_a_new_mask_every_step(cuda, eng):
         w0 = P0[name].reshape(-1) if k == "w_out" else P0[name]
         w1 = W[name].reshape(-1) if k == "w_out" else W[name]
         assert_update_close(P[k].cpu().numpy(), w0, w1, what=k)
+
+
+@pytest.mark.parametrize("d,opt", [(32, "SGD"), (64, "Adam"), (128, "Adagrad"), (64, "dense")])
+def test_segmented_update_pair_equals_two_single_updates(d, opt, cuda, eng):
+    """rc_segmented_update_pair (two tables with the same ids in one pass) vs two rc_segmented_update calls:
+    bit-identical rows, optimizer state and dense gradients for ordinary rows (same sequential sum); hot rows take
+    the chunked path, whose partition depends on the lanes per row, so they agree to rounding"""
+    rng = np.random.default_rng(40 + d)
+    n_rows, n_occ = 300, 20000
+    ids = rng.integers(0, n_rows, size=n_occ).astype(np.int64)
+    ids[:5000] = 7          # one hot row -> chunked path
+    ids[5000:5040] = 9      # just above the 32-occurrence threshold
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
+    src_a, src_b = t(rng.normal(size=(n_occ, d)).astype(np.float32)), t(rng.normal(size=(n_occ, d)).astype(np.float32))
+    keys, perm = eng.sort_ids(t(ids), n_rows)
+    count = torch.from_numpy(np.bincount(ids, minlength=n_rows)).to(cuda)
+    if opt == "dense":
+        Ga, Gb, Ga2, Gb2 = (torch.zeros((n_rows, d), device=cuda) for _ in range(4))
+        eng.segmented_update_pair(keys, perm, src_a, src_b, dense_grad=(Ga, Gb))
+        eng.segmented_update(keys, perm, src_a, dense_grad=Ga2)
+        eng.segmented_update(keys, perm, src_b, dense_grad=Gb2)
+        hot = count > 32
+        assert torch.equal(Ga[~hot], Ga2[~hot]) and torch.equal(Gb[~hot], Gb2[~hot])
+        assert_close(Ga.cpu().numpy(), Ga2.cpu().numpy(), what="Ga", atol_scale=2e-6)
+        assert_close(Gb.cpu().numpy(), Gb2.cpu().numpy(), what="Gb", atol_scale=2e-6)
+        want = np.zeros((n_rows, d))
+        np.add.at(want, ids, src_a.cpu().numpy().astype(np.float64))
+        assert_close(Ga.cpu().numpy(), want.astype(np.float32), what="dense grad", atol_scale=2e-5)
+        return
+    W0 = [rng.normal(size=(n_rows, d)).astype(np.float32) for _ in range(2)]
+    out = []
+    for pair in (True, False):
+        W = [t(w) for w in W0]
+        m = [torch.zeros_like(w) if opt != "SGD" else None for w in W]
+        v = [torch.zeros_like(w) if opt == "Adam" else None for w in W]
+        for step in (1, 2):
+            h = eng.make_hyper(opt, lr=0.05, l2=1e-3, step=step)
+            if pair:
+                eng.segmented_update_pair(keys, perm, src_a, src_b, hyper=h, W=tuple(W), m=tuple(m), v=tuple(v))
+            else:
+                eng.segmented_update(keys, perm, src_a, hyper=h, W=W[0], m=m[0], v=v[0])
+                eng.segmented_update(keys, perm, src_b, hyper=h, W=W[1], m=m[1], v=v[1])
+        out.append((W, m, v))
+    hot = count > 32
+    for k in range(2):
+        assert torch.equal(out[0][0][k][~hot], out[1][0][k][~hot])
+        assert_update_close(out[0][0][k].cpu().numpy(), W0[k], out[1][0][k].cpu().numpy(), what=f"W{k}",
+                            extra_atol=1e-3 * 0.05 if opt != "SGD" else 0.0)
+        assert not torch.equal(out[0][0][k], t(W0[k]))
+        for st in (1, 2):
+            if out[0][st][k] is not None:
+                assert torch.equal(out[0][st][k][~hot], out[1][st][k][~hot])
+                assert_close(out[0][st][k].cpu().numpy(), out[1][st][k].cpu().numpy(), what=f"state {st}", atol_scale=1e-5)
+    untouched = np.setdiff1d(np.arange(n_rows), ids)
+    if len(untouched):
+        assert np.array_equal(out[0][0][0].cpu().numpy()[untouched], W0[0][untouched])
