@@ -103,17 +103,32 @@ __global__ __launch_bounds__(kBlock) void sb_linear_kernel(SbLinArgs a) {
     for (int idx = threadIdx.x; idx < D * D; idx += kBlock) Ws[w * D * SD + (idx / D) * SD + idx % D] = a.W[w][idx];
   const int R = a.off[a.B];
   const int tiles = (R + kSbTile - 1) / kSbTile;
+  // the next tile's rows are requested while the current tile is multiplied: each thread holds its
+  // kSbTile * D / 4 / 256 float4 of the tile in registers between the two barriers
+  constexpr int PF = kSbTile * (D / 4) / kBlock;
+  float4 pf[PF];
+  auto fetch = [&](int tile) {
+    const int r0 = tile * kSbTile;
+    const int m = min(kSbTile, R - r0);
+#pragma unroll
+    for (int q = 0; q < PF; ++q) {
+      const int idx = threadIdx.x + q * kBlock, i = idx / (D / 4), c = idx % (D / 4);
+      pf[q] = i < m ? reinterpret_cast<const float4*>(a.X)[(size_t)(r0 + i) * (D / 4) + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  if ((int)blockIdx.x < tiles) fetch(blockIdx.x);
   for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
     const int r0 = tile * kSbTile;
     const int m = min(kSbTile, R - r0);
     __syncthreads();  // previous tile's readers are done (and the weights are in place)
-    for (int idx = threadIdx.x; idx < m * (D / 4); idx += kBlock) {
-      const int i = idx / (D / 4), c = idx % (D / 4);
-      const float4 v = reinterpret_cast<const float4*>(a.X)[(size_t)(r0 + i) * (D / 4) + c];
+#pragma unroll
+    for (int q = 0; q < PF; ++q) {
+      const int idx = threadIdx.x + q * kBlock, i = idx / (D / 4), c = idx % (D / 4);
       float* d = Xs + i * SD + 4 * c;
-      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+      d[0] = pf[q].x; d[1] = pf[q].y; d[2] = pf[q].z; d[3] = pf[q].w;
     }
     __syncthreads();
+    if (tile + (int)gridDim.x < tiles) fetch(tile + gridDim.x);
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
       const float* Wl = Ws + w * D * SD;
