@@ -441,25 +441,40 @@ __global__ __launch_bounds__(kBlock) void sb_wgrad_kernel(SbWgradArgs a) {
 #pragma unroll
   for (int p = 0; p < NP; ++p) bsum[p] = 0.f;
 
+  // the next tile's rows (X and the NP dY's) are requested while the current tile is multiplied
+  constexpr int PF = kSbTile * (D / 4) / kBlock;
+  float4 pfx[PF], pfy[NP][PF];
+  auto fetch = [&](int tile) {
+    const int r0 = tile * kSbTile;
+    const int m = min(kSbTile, R - r0);
+#pragma unroll
+    for (int q = 0; q < PF; ++q) {
+      const int idx = threadIdx.x + q * kBlock, i = idx / (D / 4), c = idx % (D / 4);
+      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);  // rows past m are zero-filled
+      pfx[q] = i < m ? reinterpret_cast<const float4*>(a.X)[(size_t)(r0 + i) * (D / 4) + c] : z;
+#pragma unroll
+      for (int p = 0; p < NP; ++p)
+        pfy[p][q] = i < m ? reinterpret_cast<const float4*>(a.dY[p])[(size_t)(r0 + i) * (D / 4) + c] : z;
+    }
+  };
+  if ((int)blockIdx.x < tiles) fetch(blockIdx.x);
   for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
     const int r0 = tile * kSbTile;
     const int m = min(kSbTile, R - r0);
     __syncthreads();
-    for (int idx = threadIdx.x; idx < kSbTile * (D / 4); idx += kBlock) {  // rows past m are zero-filled
-      const int i = idx / (D / 4), c = idx % (D / 4);
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (i < m) v = reinterpret_cast<const float4*>(a.X)[(size_t)(r0 + i) * (D / 4) + c];
+#pragma unroll
+    for (int q = 0; q < PF; ++q) {
+      const int idx = threadIdx.x + q * kBlock, i = idx / (D / 4), c = idx % (D / 4);
       float* d = Xs + i * SD + 4 * c;
-      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+      d[0] = pfx[q].x; d[1] = pfx[q].y; d[2] = pfx[q].z; d[3] = pfx[q].w;
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
-        float4 u = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (i < m) u = reinterpret_cast<const float4*>(a.dY[p])[(size_t)(r0 + i) * (D / 4) + c];
         float* e = Ys + (p * kSbTile + i) * SD + 4 * c;
-        e[0] = u.x; e[1] = u.y; e[2] = u.z; e[3] = u.w;
+        e[0] = pfy[p][q].x; e[1] = pfy[p][q].y; e[2] = pfy[p][q].z; e[3] = pfy[p][q].w;
       }
     }
     __syncthreads();
+    if (tile + (int)gridDim.x < tiles) fetch(tile + gridDim.x);
 #pragma unroll
     for (int s = 0; s < QPW; ++s) {
       const int q = wave + 4 * s;
