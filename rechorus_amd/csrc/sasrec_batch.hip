@@ -341,13 +341,22 @@ __device__ __forceinline__ void sb_load_rows_n(float* dst, const float* __restri
   }
 }
 
-template <int D>
-__global__ __launch_bounds__(kBlock) void sb_attn_fwd_wave_kernel(SbAttnArgs a) {
+// WPH waves per head.  WPH = 1: a head's phases need no workgroup barrier at all (the wave is alone on its scratch).
+// WPH = 2 (the long length class, whose LDS footprint allows one or two workgroups per CU only): two waves share a
+// head -- its 32x32 output blocks alternate between them, each takes 32 of the rows in the softmax phases -- and
+// the phases are separated by barriers again, with twice the waves in flight.
+template <typename Epi>
+__device__ __forceinline__ void sb_mm_head(MatA A, MatB B, int M, int N, int K, bool causal, Epi epi, int sub, int wph) {
+  sas_mm_part(A, B, M, N, K, causal, epi, sub, wph);
+}
+
+template <int D, int WPH>
+__global__ __launch_bounds__(256 * WPH) void sb_attn_fwd_wave_kernel(SbAttnArgs a) {
   constexpr int SD = D + 1;
   const int LP = a.lp, SA = LP + 1, BUF = sb_buf_floats(D, LP);
   extern __shared__ float lds[];
   float *Q = lds, *K = Q + BUF, *V = K + BUF;
-  const int hh = threadIdx.x >> 6;
+  const int wave = threadIdx.x >> 6, hh = wave / WPH, sub = wave % WPH;
   float* A = V + BUF + hh * LP * SA;
   const int dk = D / a.n_heads, hc = hh * dk;
   const float sqrt_dk = sqrtf((float)dk);
@@ -362,19 +371,24 @@ __global__ __launch_bounds__(kBlock) void sb_attn_fwd_wave_kernel(SbAttnArgs a) 
     sb_load_rows_n<D>(K, a.k, r0, n);
     sb_load_rows_n<D>(V, a.v, r0, n);
     __syncthreads();
-    sas_attn_probs_wave<D>(A, Q, K, n, hh, dk, sqrt_dk, SA);
-    sas_mm_wave(MatA{A, SA, 1}, MatB{V + hc, SD, 1}, n, dk, n, false,
-                [&](int i, int c, float v) { a.ctx[(size_t)(r0 + i) * D + hc + c] = v; });
+    sb_mm_head(MatA{Q + hc, SD, 1}, MatB{K + hc, 1, SD}, n, n, dk, true, [&](int i, int j, float v) { A[i * SA + j] = v / sqrt_dk; },
+               sub, WPH);
+    if (WPH > 1) __syncthreads();
+    if (32 * sub < n) sas_softmax_causal_rows(A, n, SA, 32 * sub, 32);  // two lanes per row
+    if (WPH == 1 && n > 32) sas_softmax_causal_rows(A, n, SA, 32, 32);
+    if (WPH > 1) __syncthreads();
+    sb_mm_head(MatA{A, SA, 1}, MatB{V + hc, SD, 1}, n, dk, n, false,
+               [&](int i, int c, float v) { a.ctx[(size_t)(r0 + i) * D + hc + c] = v; }, sub, WPH);
   }
 }
 
-template <int D>
-__global__ __launch_bounds__(kBlock) void sb_attn_bwd_wave_kernel(SbAttnArgs a) {
+template <int D, int WPH>
+__global__ __launch_bounds__(256 * WPH) void sb_attn_bwd_wave_kernel(SbAttnArgs a) {
   constexpr int SD = D + 1;
   const int LP = a.lp, SA = LP + 1, BUF = sb_buf_floats(D, LP);
   extern __shared__ float lds[];
   float *Q = lds, *K = Q + BUF, *V = K + BUF, *G = V + BUF;
-  const int hh = threadIdx.x >> 6;
+  const int wave = threadIdx.x >> 6, hh = wave / WPH, sub = wave % WPH;
   float* A = G + BUF + (2 * hh) * LP * SA;
   float* T = A + LP * SA;
   const int dk = D / a.n_heads, hc = hh * dk;
@@ -391,19 +405,26 @@ __global__ __launch_bounds__(kBlock) void sb_attn_bwd_wave_kernel(SbAttnArgs a) 
     sb_load_rows_n<D>(V, a.v, r0, n);
     sb_load_rows_n<D>(G, a.dctx, r0, n);
     __syncthreads();
-    sas_attn_probs_wave<D>(A, Q, K, n, hh, dk, sqrt_dk, SA);
+    sb_mm_head(MatA{Q + hc, SD, 1}, MatB{K + hc, 1, SD}, n, n, dk, true, [&](int i, int j, float v) { A[i * SA + j] = v / sqrt_dk; },
+               sub, WPH);
     // dA = dCtx_h . V_h^T (lower triangle)
-    sas_mm_wave(MatA{G + hc, SD, 1}, MatB{V + hc, 1, SD}, n, n, dk, true, [&](int i, int j, float v) { T[i * SA + j] = v; });
+    sb_mm_head(MatA{G + hc, SD, 1}, MatB{V + hc, 1, SD}, n, n, dk, true, [&](int i, int j, float v) { T[i * SA + j] = v; }, sub, WPH);
+    if (WPH > 1) __syncthreads();
+    if (32 * sub < n) sas_softmax_causal_rows(A, n, SA, 32 * sub, 32);
+    if (WPH == 1 && n > 32) sas_softmax_causal_rows(A, n, SA, 32, 32);
+    if (WPH > 1) __syncthreads();
     // dV_h = A^T . dCtx_h
-    sas_mm_wave(MatA{A, 1, SA}, MatB{G + hc, SD, 1}, n, dk, n, false,
-                [&](int j, int c, float v) { a.dv[(size_t)(r0 + j) * D + hc + c] = v; });
-    sas_softmax_bwd_rows(T, A, n, SA, sqrt_dk, 0, 32);  // dS in place in T, two lanes per row
-    if (n > 32) sas_softmax_bwd_rows(T, A, n, SA, sqrt_dk, 32, 32);
+    sb_mm_head(MatA{A, 1, SA}, MatB{G + hc, SD, 1}, n, dk, n, false,
+               [&](int j, int c, float v) { a.dv[(size_t)(r0 + j) * D + hc + c] = v; }, sub, WPH);
+    // (no barrier: dV reads A and G only, dS below rewrites T and reads A)
+    if (32 * sub < n) sas_softmax_bwd_rows(T, A, n, SA, sqrt_dk, 32 * sub, 32);  // dS in place in T
+    if (WPH == 1 && n > 32) sas_softmax_bwd_rows(T, A, n, SA, sqrt_dk, 32, 32);
+    if (WPH > 1) __syncthreads();
     // dQ_h = dS . K_h,  dK_h = dS^T . Q_h
-    sas_mm_wave(MatA{T, SA, 1}, MatB{K + hc, SD, 1}, n, dk, n, false,
-                [&](int i, int c, float v) { a.dq[(size_t)(r0 + i) * D + hc + c] = v; });
-    sas_mm_wave(MatA{T, 1, SA}, MatB{Q + hc, SD, 1}, n, dk, n, false,
-                [&](int j, int c, float v) { a.dk[(size_t)(r0 + j) * D + hc + c] = v; });
+    sb_mm_head(MatA{T, SA, 1}, MatB{K + hc, SD, 1}, n, dk, n, false,
+               [&](int i, int c, float v) { a.dq[(size_t)(r0 + i) * D + hc + c] = v; }, sub, WPH);
+    sb_mm_head(MatA{T, 1, SA}, MatB{Q + hc, SD, 1}, n, dk, n, false,
+               [&](int j, int c, float v) { a.dk[(size_t)(r0 + j) * D + hc + c] = v; }, sub, WPH);
   }
 }
 
@@ -732,13 +753,17 @@ static int sb_attention(SbAttnArgs a, int32_t* bucket, bool make_buckets, hipStr
     if (!per_wave && !block_ok) a.lp = a.lp <= 32 ? 32 : 64;
     const size_t buf2 = (size_t)sb_buf_floats(D, a.lp) * sizeof(float);
     const size_t lds = per_wave ? lds_wave : (size_t)(BWD ? 7 : 5) * buf2;
-    auto kern = per_wave ? (BWD ? sb_attn_bwd_wave_kernel<D> : sb_attn_fwd_wave_kernel<D>)
-                         : (BWD ? sb_attn_bwd_kernel<D> : sb_attn_fwd_kernel<D>);
-    RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int per_cu = (int)((160 * 1024) / lds);
+    // two waves per head where the LDS footprint leaves the CU short of waves (the long length class)
+    const int wph = per_wave && a.lp > 32 && per_cu <= 2 ? 2 : 1;
+    void (*kern)(SbAttnArgs) =
+        !per_wave ? (BWD ? sb_attn_bwd_kernel<D> : sb_attn_fwd_kernel<D>)
+        : wph == 2 ? (BWD ? sb_attn_bwd_wave_kernel<D, 2> : sb_attn_fwd_wave_kernel<D, 2>)
+                   : (BWD ? sb_attn_bwd_wave_kernel<D, 1> : sb_attn_fwd_wave_kernel<D, 1>);
+    RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int grid = 256 * (per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu));
     if (grid > a.B) grid = a.B;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(per_wave ? 64 * a.n_heads : kBlock), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(per_wave ? 64 * a.n_heads * wph : kBlock), lds, s, a);
     RC_LAUNCH_CHECK();
   }
   return RC_OK;
