@@ -151,7 +151,10 @@ def test_cli_test_all_runs(data_root, tmp_path, cuda):
 
 
 @pytest.mark.parametrize("model_name,extra", [("BPRMF", []), ("NeuMF", ["--layers", "[32]"]),
-                                              ("SASRec", ["--history_max", "8", "--num_heads", "2"])])
+                                              ("SASRec", ["--history_max", "8", "--num_heads", "2"]),
+                                              # B * history_max >= 4096, history_max > 32: the batch-level encoder kernels
+                                              # (device-side row offsets and length classes, some classes empty)
+                                              ("SASRec", ["--history_max", "40", "--num_heads", "2"])])
 @pytest.mark.parametrize("opt", ["Adam", "SGD"])
 def test_graph_replayed_training_equals_eager_training(model_name, extra, opt, data_root, cuda):
     """--graph 1 (hipGraph replay of model -> loss -> backward -> optimizer.step, Adam step count on the
