@@ -117,6 +117,21 @@ class HipOps:
                                 src_index=t_idx, div=1, skip_singletons=True, heads=heads, n_heads=n_heads)
         return pug
 
+    def owner_backward_split(self, I_loc, state, rows, g, t_idx, t32, Uall, n_tuples, hyper, prep):
+        """owner_backward in two parts: -> (pug, finish).  The partial user gradients are complete on return (they
+        go into the reduce_scatter at once); finish() runs the segmented update of the multi-occurrence item rows,
+        which the caller issues while that collective is in flight."""
+        if not self.e.owner_backward_supported(I_loc.shape[1]):
+            pug = self.partial_user_grads(I_loc, rows, g, t_idx, n_tuples)
+            return pug, lambda: self.update_rows(I_loc, state, rows, Uall, hyper, coef=g, src_index=t_idx)
+        keys, perm, single, heads, n_heads = prep
+        pug = self.e.owner_backward(I_loc, state.get("m"), state.get("v"), Uall, t32, rows, g, single, n_tuples, hyper)
+
+        def finish():
+            self.e.segmented_update(keys, perm, Uall, hyper=hyper, W=I_loc, m=state.get("m"), v=state.get("v"), coef=g,
+                                    src_index=t_idx, div=1, skip_singletons=True, heads=heads, n_heads=n_heads)
+        return pug, finish
+
     # ---- NeuMF head on rows that were moved to the tuples (ShardedNeumf) ------------------------------
     def neumf_fwd(self, P, uid, iid):
         return self.e.neumf_fwd(P, uid, iid)
@@ -229,6 +244,33 @@ def _all_gather_rows(x, world, group):
     return out
 
 
+class _Pending:
+    """a collective that may still be in flight on RCCL's stream: wait() makes the current stream wait for it"""
+
+    def __init__(self, out, work=None):
+        self.out, self.work = out, work
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+        return self.out
+
+
+def _all_gather_rows_async(x, world, group):
+    if not _is_nccl(group):
+        return _Pending(_all_gather_rows(x, world, group))
+    out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+    return _Pending(out, dist.all_gather_into_tensor(out, x.contiguous(), group=group, async_op=True))
+
+
+def _reduce_scatter_rows_async(x, world, group):
+    if not _is_nccl(group):
+        return _Pending(_reduce_scatter_rows(x, world, group))
+    out = torch.empty((x.shape[0] // world,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+    return _Pending(out, dist.reduce_scatter_tensor(out, x.contiguous(), group=group, async_op=True))
+
+
 def _all_reduce_sum(x, group):
     if _is_nccl(group) or not x.is_cuda:
         dist.all_reduce(x, group=group)
@@ -339,16 +381,17 @@ class ShardedBprmf:
         Ub[order_u] = rows_back
         mark("1 fetch user rows")
 
-        # 2. every owner needs every tuple's user row
-        Uall = _all_gather_rows(Ub, W, self.group)
-        mark("2 all_gather user rows")
-
         # 3. route candidate occurrences to the item's owner: (global tuple index, local row).  Every
         #    source sends in batch order, so the owner receives them grouped by tuple (t_idx ascending)
         recv, _ = _exchange(packed, cnt_i, self.group, recv_counts=rcnt_i)
+        # 2. every owner needs every tuple's user row: the all_gather (the largest transfer of the step, with the
+        #    reduce_scatter of phase 7) is issued now and travels while the owner unpacks and sorts what it received
+        Uall_pending = _all_gather_rows_async(Ub, W, self.group)
         t_idx, rows, t32 = self._unpack(recv)
         prep = ops.prepare_owner(rows, self.I.shape[0]) if hasattr(ops, "prepare_owner") else None
-        mark("3 route occurrences")
+        mark("3 route occurrences + owner sort")
+        Uall = Uall_pending.wait()
+        mark("2 all_gather user rows (exposed part)")
 
         # 4. owner scores its rows; scores go home
         scores = ops.dot_rows(Uall, t_idx, self.I, rows)
@@ -364,16 +407,22 @@ class ShardedBprmf:
         g_own, _ = _exchange(g.reshape(-1)[order_i], cnt_i, self.group, recv_counts=rcnt_i)  # routing of step 3
         mark("5 loss + g to owners")
 
-        # 6. owner: partial user grads (from pre-step item rows) and the item-row update
-        if hasattr(ops, "owner_backward"):
-            pug = ops.owner_backward(self.I, self.sI, rows, g_own, t_idx, t32, Uall, n_tuples, hyper, prep)
+        # 6. owner: partial user grads (from pre-step item rows) and the item-row update;
+        # 7. the partial user grads are summed at the tuples' home (reduce_scatter, in flight while the owner
+        #    updates its multi-occurrence item rows) and routed to the user rows' owners
+        if hasattr(ops, "owner_backward_split"):
+            pug, finish = ops.owner_backward_split(self.I, self.sI, rows, g_own, t_idx, t32, Uall, n_tuples, hyper, prep)
+            ugrad_pending = _reduce_scatter_rows_async(pug, W, self.group)
+            finish()
         else:
-            pug = ops.partial_user_grads(self.I, rows, g_own, t_idx, n_tuples)
-            ops.update_rows(self.I, self.sI, rows, Uall, hyper, coef=g_own, src_index=t_idx)
+            if hasattr(ops, "owner_backward"):
+                pug = ops.owner_backward(self.I, self.sI, rows, g_own, t_idx, t32, Uall, n_tuples, hyper, prep)
+            else:
+                pug = ops.partial_user_grads(self.I, rows, g_own, t_idx, n_tuples)
+                ops.update_rows(self.I, self.sI, rows, Uall, hyper, coef=g_own, src_index=t_idx)
+            ugrad_pending = _reduce_scatter_rows_async(pug, W, self.group)
         mark("6 owner backward + item-row update")
-
-        # 7. sum the partial user grads at the tuples' home, route them to the user rows' owners
-        ugrad = _reduce_scatter_rows(pug, W, self.group)
+        ugrad = ugrad_pending.wait()
         ug_own, _ = _exchange(ugrad[order_u], cnt_u, self.group, recv_counts=rcnt_u)
         ops.update_rows(self.U, self.sU, req_u, ug_own, hyper)
         mark("7 user grads reduce + update")
