@@ -147,6 +147,92 @@ __global__ __launch_bounds__(kBlock) void sb_linear_kernel(SbLinArgs a) {
   }
 }
 
+// Y = res + X_0 . W_0 + X_1 . W_1 + X_2 . W_2  (dX of the three projections: dZ1 + dQ Wq + dK Wk + dV Wv) in one
+// pass: the accumulators of a wave's 32x32 output block stay in registers across the three inputs, whose tiles
+// are staged one after the other (next one prefetched) -- instead of three launches that each re-read and
+// re-write the [R, D] running sum.
+struct SbSum3Args {
+  const float* X[3];
+  const float* W[3];  // [out, in]: the product uses W as is (dx = dy . W)
+  const float* res;
+  float* Y;
+  const int32_t* off;
+  int B;
+};
+
+template <int D>
+__global__ __launch_bounds__(kBlock) void sb_linear3_sum_kernel(SbSum3Args a) {
+  constexpr int SD = D + 1, NRB = kSbTile / 32, NCB = D / 32, NQ = NRB * NCB;  // NQ <= 4: one block per wave
+  extern __shared__ float lds[];
+  float* Ws = lds;                // [3][D][SD]
+  float* Xs = lds + 3 * D * SD;   // [kSbTile][SD]
+  for (int w = 0; w < 3; ++w)
+    for (int idx = threadIdx.x; idx < D * D; idx += kBlock) Ws[w * D * SD + (idx / D) * SD + idx % D] = a.W[w][idx];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, kh = lane >> 5;
+  const int R = a.off[a.B];
+  const int tiles = (R + kSbTile - 1) / kSbTile;
+  const int my_tiles = (int)blockIdx.x < tiles ? (tiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+  constexpr int PF = kSbTile * (D / 4) / kBlock;
+  float4 pf[PF];
+  auto fetch = [&](int step) {  // step = (tile ordinal, input w)
+    const int tile = blockIdx.x + (step / 3) * gridDim.x, w = step % 3;
+    const int r0 = tile * kSbTile;
+    const int m = min(kSbTile, R - r0);
+#pragma unroll
+    for (int q = 0; q < PF; ++q) {
+      const int idx = threadIdx.x + q * kBlock, i = idx / (D / 4), c = idx % (D / 4);
+      pf[q] = i < m ? reinterpret_cast<const float4*>(a.X[w])[(size_t)(r0 + i) * (D / 4) + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  if (my_tiles > 0) fetch(0);
+  const int rb = wave % NRB, cb = wave / NRB;
+  sas_f32x16 acc;
+  for (int step = 0; step < 3 * my_tiles; ++step) {
+    const int w = step % 3;
+    if (w == 0)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < PF; ++q) {
+      const int idx = threadIdx.x + q * kBlock, i = idx / (D / 4), c = idx % (D / 4);
+      float* d = Xs + i * SD + 4 * c;
+      d[0] = pf[q].x; d[1] = pf[q].y; d[2] = pf[q].z; d[3] = pf[q].w;
+    }
+    __syncthreads();
+    if (step + 1 < 3 * my_tiles) fetch(step + 1);
+    if (wave < NQ) {  // wave-uniform
+      const float* ap = Xs + (rb * 32 + (lane & 31)) * SD + kh;                 // a(i, k) = X[i][k]
+      const float* bp = Ws + w * D * SD + kh * SD + cb * 32 + (lane & 31);      // b(k, j) = W[k][j]
+#pragma unroll
+      for (int k0 = 0; k0 < D; k0 += 32) {
+        float av[16], bv[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+          av[t] = ap[k0 + 2 * t];
+          bv[t] = bp[(k0 + 2 * t) * SD];
+        }
+#pragma unroll
+        for (int t = 0; t < 16; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[t], acc, 0, 0, 0);
+      }
+      if (w == 2) {
+        const int tile = blockIdx.x + (step / 3) * gridDim.x;
+        const int r0 = tile * kSbTile;
+        const int m = min(kSbTile, R - r0);
+        const int j = cb * 32 + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int i = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+          if (i < m) {
+            const size_t e = (size_t)(r0 + i) * D + j;
+            a.Y[e] = acc[r] + a.res[e];
+          }
+        }
+      }
+    }
+  }
+}
+
 // ---- LayerNorm over rows: z = A (+ Bv) -> xhat, rstd, y = w * xhat + b ----------------------------------
 
 template <int D>
@@ -878,11 +964,19 @@ static int sb_backward(const SasLayer* layer, int n_layers, int n_heads, const i
     g.gW[0] = gp + Cfg::oWq; g.gb[0] = gp + Cfg::obq; g.gW[1] = gp + Cfg::oWk; g.gb[1] = gp + Cfg::obk;
     g.gW[2] = gp + Cfg::oWv; g.gb[2] = gp + Cfg::obv;
     RC_TRY((sb_wgrad<D, 3>(g, (int64_t)rmax, s)));
-    const float* dproj[3] = {w.t1, w.t2, w.t3};
-    const float* wproj[3] = {p.Wq, p.Wk, p.Wv};
-    for (int k = 0; k < 3; ++k) {
-      a.X = dproj[k]; a.W[0] = wproj[k]; a.Y[0] = G; a.res = G;
-      RC_TRY((sb_linear<D, 1, true>(a, (int64_t)rmax, s)));
+    {
+      SbSum3Args q;
+      q.X[0] = w.t1; q.X[1] = w.t2; q.X[2] = w.t3; q.W[0] = p.Wq; q.W[1] = p.Wk; q.W[2] = p.Wv;
+      q.res = G; q.Y = G; q.off = w.off; q.B = B;
+      const size_t lds = (size_t)(3 * D + kSbTile) * (D + 1) * sizeof(float);
+      auto kern = sb_linear3_sum_kernel<D>;
+      RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      int64_t tiles = ((int64_t)rmax + kSbTile - 1) / kSbTile;
+      const int per_cu = (int)((160 * 1024) / lds);
+      const int64_t cap = 256 * (int64_t)(per_cu < 1 ? 1 : per_cu);
+      if (tiles > cap) tiles = cap;
+      hipLaunchKernelGGL(kern, dim3((unsigned)(tiles < 1 ? 1 : tiles)), dim3(kBlock), lds, s, q);
+      RC_LAUNCH_CHECK();
     }
   }
   hipLaunchKernelGGL((sb_unpack_kernel<D>), dim3(sb_row_grid((int64_t)rmax, LPR)), dim3(kBlock), 0, s, G, lengths, w.off, B, L,
