@@ -181,7 +181,10 @@ def test_graph_replayed_training_equals_eager_training(model_name, extra, opt, d
             # noise into +-lr steps (tests/test_gpu_sasrec.py), so two correct runs only agree in magnitude
             assert np.abs(a - b).max() <= 3 * 0.01 * 3 * 10
             continue
-        assert np.allclose(a, b, rtol=1e-4, atol=2e-6), (k, np.abs(a - b).max())
+        # Adam: the replayed step takes its bias correction from a device-side step counter (float arithmetic in the
+        # kernel), the eager one from host doubles -- last-bit differences in the step size, accumulated over ~100
+        # steps of size lr = 0.01; SGD has no such term and must agree bit for bit (below)
+        assert np.allclose(a, b, rtol=1e-4, atol=2e-6 if opt == "SGD" else 3e-5), (k, np.abs(a - b).max())
         if opt == "SGD":
             assert np.array_equal(a, b), k  # same kernels, same order: bit-identical
 
