@@ -3,7 +3,8 @@
 //
 //   mf   = mf_u[u] * mf_i[i]                          (GMF branch, d)
 //   h0   = [mlp_u[u] ; mlp_i[i]]                      (2d)
-//   h1   = relu(W1 h0 + b1)                           (L1; dropout p = 0)
+//   h1   = drop(relu(W1 h0 + b1))                     (L1; training-mode dropout p in the DROP instantiations:
+//                                                      counter-based mask keyed by a device-side seed, never stored)
 //   pred = w_out[:d] . mf + w_out[d:] . h1            (Linear(d+L1, 1, bias=False))
 //
 // 33 kFLOP (fwd) per candidate against 1 KB of gathered rows at d=128: the MLP sits on the
@@ -21,7 +22,7 @@
 // The backward kernel recomputes the forward GEMM instead of storing activations.  Dense
 // parameter gradients leave the kernel as per-workgroup partials summed in fixed order by
 // neumf_reduce_partials_kernel (deterministic, no float atomics).  Table-row gradients are
-// written per occurrence ([B*C, d] x 4) and consumed by rc_segmented_update.
+// written per occurrence ([B*C, d] x 4) and consumed by rc_segmented_update_pair (mf / mlp table of a side in one pass).
 #include "common.hpp"
 #include "philox.hpp"
 
