@@ -55,6 +55,9 @@ def parse():
                     help="bprmf = BASELINE configs[1] (the contract workload); neumf = configs[3]: NeuMF emb_size 128, "
                          "num_neg 4, hidden 64 (pass --items 100000001 --users 10000001 --num-neg 4 --emb-size 128)")
     ap.add_argument("--hidden", type=int, default=64, help="neumf: size of the hidden layer")
+    ap.add_argument("--micro-batches", type=int, default=1,
+                    help="neumf, N > 1: chunks of the local batch whose row exchanges overlap the head kernels "
+                         "(ShardedNeumf._step_pipelined); 1 = unpipelined")
     ap.add_argument("--hist", type=int, default=50, help="sasrec: history_max (BASELINE configs[2])")
     ap.add_argument("--heads", type=int, default=4, help="sasrec: attention heads")
     ap.add_argument("--layers", type=int, default=1, help="sasrec: transformer blocks")
@@ -130,7 +133,8 @@ def make_neumf_trainer(args, world, device, engine):
              "W1": mk(l1, 2 * d), "b1": mk(l1), "w_out": mk(d + l1)}
         return engine.NeumfTrainer(P, opt=args.opt, lr=args.lr, l2=args.l2, rowwise=True)
     from rechorus_amd.sharded import ShardedNeumf
-    trainer = ShardedNeumf(args.users, args.items, d, l1, opt=args.opt, lr=args.lr, l2=args.l2, device=device, seed=1234)
+    trainer = ShardedNeumf(args.users, args.items, d, l1, opt=args.opt, lr=args.lr, l2=args.l2, device=device, seed=1234,
+                           micro_batches=args.micro_batches)
     trainer.loss = None
     _step = trainer.step
 

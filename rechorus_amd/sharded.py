@@ -213,6 +213,18 @@ def _exchange(send, send_counts, group=None, recv_counts=None):
     return recv, recv_counts
 
 
+def _exchange_async(send, send_counts, recv_counts, group=None):
+    """_exchange with known split sizes whose transfer may stay in flight (RCCL): -> _Pending of the received rows.
+    Other backends (the gloo emulation of the CPU tests) complete it on the spot."""
+    recv = torch.empty((sum(recv_counts),) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
+    if _is_nccl(group):
+        work = dist.all_to_all_single(recv, send.contiguous(), output_split_sizes=list(recv_counts),
+                                      input_split_sizes=list(send_counts), group=group, async_op=True)
+        return _Pending(recv, work)
+    _all_to_all_v(recv, send.contiguous(), list(recv_counts), list(send_counts), group)
+    return _Pending(recv)
+
+
 def _exchange_counts(count_tensors, group=None):
     """one all_to_all for the split sizes of several exchanges -> ([send lists], [recv lists]); ONE host sync"""
     world = dist.get_world_size(group)
@@ -542,16 +554,36 @@ class ShardedBprmf:
 class _Route:
     """where the ids of one lookup live: send order, split sizes both ways, the rows the owner has to read"""
 
-    def __init__(self, ids, world, ops, group):
-        if hasattr(ops, "route"):
-            order, counts, local = ops.route(ids, world, None, 1)
-        else:
-            owner = ids % world
-            order = torch.sort(owner, stable=True).indices
-            counts, local = torch.bincount(owner, minlength=world), ids[order] // world
-        (self.send,), (self.recv,) = _exchange_counts([counts], group)
+    def __init__(self, ids, world, ops, group, grouped=None, splits=None):
+        order, counts, local = grouped if grouped is not None else self.group_by_owner(ids, world, ops)
+        if splits is None:
+            (self.send,), (self.recv,) = _exchange_counts([counts], group)
+        else:  # split sizes exchanged by the caller together with those of other lookups (one host sync for all)
+            self.send, self.recv = splits
         self.order, self.group = order, group
         self.req, _ = _exchange(local, self.send, group, recv_counts=self.recv)  # local rows this rank must serve
+
+    @staticmethod
+    def group_by_owner(ids, world, ops):
+        """-> (send order, per-owner counts (device tensor), local rows in send order)"""
+        if hasattr(ops, "route"):
+            return ops.route(ids, world, None, 1)
+        owner = ids % world
+        order = torch.sort(owner, stable=True).indices
+        return order, torch.bincount(owner, minlength=world), ids[order] // world
+
+    def fetch_async(self, tables, ops):
+        """fetch() whose rows-back transfer may stay in flight: -> _Pending; finish with rows_in_lookup_order()"""
+        served = torch.cat([ops.gather_rows(T, self.req) for T in tables], dim=1)
+        return _exchange_async(served, self.recv, self.send, self.group)
+
+    def rows_in_lookup_order(self, back):
+        out = torch.empty_like(back)
+        out[self.order] = back
+        return out
+
+    def push_async(self, grads):
+        return _exchange_async(grads[self.order], self.send, self.recv, self.group)
 
     def fetch(self, tables, ops):
         """rows of `tables` (this rank's shards, same row space) for the ids of the lookup, in lookup order"""
@@ -580,7 +612,8 @@ class ShardedNeumf:
     TABLES = ("mf_u", "mlp_u", "mf_i", "mlp_i")
 
     def __init__(self, n_users, n_items, emb_size, hidden, opt="SGD", lr=1e-3, l2=0.0, device=None, ops=None,
-                 group=None, init_std=0.01, seed=0):
+                 group=None, init_std=0.01, seed=0, micro_batches=1):
+        self.micro_batches = max(1, int(micro_batches))
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -631,6 +664,8 @@ class ShardedNeumf:
         hyper = ops.make_hyper(opt=self.opt, lr=self.lr, l2=self.l2, step=self.step_count)
         hyper0 = ops.make_hyper(opt=self.opt, lr=self.lr, l2=0.0, step=self.step_count)  # 'bias': no weight decay
         dev = uid.device
+        if W > 1 and self.micro_batches > 1 and B >= self.micro_batches:
+            return self._step_pipelined(uid, iid, hyper, hyper0)
         if W == 1:
             ru = rv = None
             urows = torch.cat([ops.gather_rows(self.P[k], uid) for k in ("mf_u", "mlp_u")], dim=1)
@@ -678,3 +713,73 @@ class ShardedNeumf:
             ops.dense_update(self.P[k], dense[k].contiguous(), hyper0 if k == "b1" else hyper, self.state[k])
         return loss
 
+    def _step_pipelined(self, uid, iid, hyper, hyper0):
+        """The same step with the local batch cut into `micro_batches` chunks: the row fetch of chunk k+1 and the
+        gradient push of chunk k-1 are in flight (RCCL's stream) while the head kernels of chunk k run.  Every chunk
+        is scored against the pre-step parameters and the owners apply ONE update per table over the gradients of
+        all chunks, so the result equals the unpipelined step (tests/test_sharded_gloo.py).  All split sizes of
+        all chunks travel in one exchange: one host sync per step, as before."""
+        W, ops, d, group = self.world, self.ops, self.d, self.group
+        B, C = iid.shape
+        n_tuples = W * B
+        dev = uid.device
+        M = self.micro_batches
+        uc, ic = torch.chunk(uid, M), torch.chunk(iid, M)
+        M = len(uc)
+        grouped = [(_Route.group_by_owner(u, W, ops), _Route.group_by_owner(i.reshape(-1), W, ops)) for u, i in zip(uc, ic)]
+        sends, recvs = _exchange_counts([g[1] for pair in grouped for g in pair], group)
+        routes = []
+
+        def start(k):  # routes of chunk k, its rows requested (transfers may stay in flight)
+            ru = _Route(uc[k], W, ops, group, grouped=grouped[k][0], splits=(sends[2 * k], recvs[2 * k]))
+            rv = _Route(ic[k].reshape(-1), W, ops, group, grouped=grouped[k][1], splits=(sends[2 * k + 1], recvs[2 * k + 1]))
+            routes.append((ru, rv, ru.fetch_async([self.P["mf_u"], self.P["mlp_u"]], ops),
+                           rv.fetch_async([self.P["mf_i"], self.P["mlp_i"]], ops)))
+
+        start(0)
+        loss = torch.zeros(1, dtype=torch.float32, device=dev)
+        dense_sum, pushes = None, []
+        for k in range(M):
+            if k + 1 < M:
+                start(k + 1)
+            ru, rv, pu, pv = routes[k]
+            urows, irows = ru.rows_in_lookup_order(pu.wait()), rv.rows_in_lookup_order(pv.wait())
+            Bk = uc[k].shape[0]
+            loc = {"mf_u": urows[:, :d].contiguous(), "mlp_u": urows[:, d:].contiguous(),
+                   "mf_i": irows[:, :d].contiguous(), "mlp_i": irows[:, d:].contiguous(),
+                   "W1": self.P["W1"], "b1": self.P["b1"], "w_out": self.P["w_out"]}
+            pos_u = torch.arange(Bk, device=dev)
+            pos_i = torch.arange(Bk * C, device=dev).view(Bk, C)
+            pred = ops.neumf_fwd(loc, pos_u, pos_i)
+            loss_vec, g = ops.bpr_loss(pred, 1.0 / n_tuples)
+            loss = loss + loss_vec.sum().reshape(1) / n_tuples
+            rows, dense = ops.neumf_bwd(loc, pos_u, pos_i, g)
+            gu = torch.cat([rows["g_mf_u"].view(Bk, C, d).sum(dim=1), rows["g_mlp_u"].view(Bk, C, d).sum(dim=1)], dim=1)
+            gi = torch.cat([rows["g_mf_i"], rows["g_mlp_i"]], dim=1)
+            pushes.append((ru.push_async(gu), rv.push_async(gi)))
+            flat = torch.cat([dense[n].reshape(-1) for n in ("W1", "b1", "w_out")])
+            dense_sum = flat if dense_sum is None else dense_sum + flat
+        loss = _all_reduce_sum(loss, group)
+        dense_sum = _all_reduce_sum(dense_sum, group)
+        own_u = torch.cat([p[0].wait() for p in pushes])
+        own_i = torch.cat([p[1].wait() for p in pushes])
+        req_u = torch.cat([r[0].req for r in routes])
+        req_i = torch.cat([r[1].req for r in routes])
+        shared = hasattr(ops, "prepare_rows")
+        prep_u = ops.prepare_rows(req_u, self.P["mf_u"].shape[0]) if shared else None
+        prep_i = ops.prepare_rows(req_i, self.P["mf_i"].shape[0]) if shared else None
+        for ta, tb, own, req, prep in (("mf_u", "mlp_u", own_u, req_u, prep_u), ("mf_i", "mlp_i", own_i, req_i, prep_i)):
+            ga, gb = own[:, :d].contiguous(), own[:, d:].contiguous()
+            if shared and hasattr(ops, "update_rows_pair") and ops.update_rows_pair(
+                    self.P[ta], self.P[tb], self.state[ta], self.state[tb], req, ga, gb, hyper, prep):
+                continue
+            kw = {"prep": prep} if shared else {}
+            ops.update_rows(self.P[ta], self.state[ta], req, ga, hyper, **kw)
+            ops.update_rows(self.P[tb], self.state[tb], req, gb, hyper, **kw)
+        o = 0
+        for n in ("W1", "b1", "w_out"):
+            cnt = self.P[n].numel()
+            ops.dense_update(self.P[n], dense_sum[o:o + cnt].view(self.P[n].shape).contiguous(), hyper0 if n == "b1" else hyper,
+                             self.state[n])
+            o += cnt
+        return loss

@@ -198,7 +198,7 @@ def test_bench_multi_rank_code_path_on_one_gpu(cuda):
     assert len(out["sharded_phases_ms"]) == 8
 
 
-def _neumf_worker(rank, world, port, opt, lr, l2, n_users, n_items, d, l1, B, C, steps, out_q):
+def _neumf_worker(rank, world, port, opt, lr, l2, n_users, n_items, d, l1, B, C, steps, out_q, micro_batches=1):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -206,7 +206,7 @@ def _neumf_worker(rank, world, port, opt, lr, l2, n_users, n_items, d, l1, B, C,
         from test_sharded_gloo import _neumf_problem
         dev = torch.device("cuda:0")
         rng, P = _neumf_problem(n_users, n_items, d, l1)
-        m = ShardedNeumf(n_users, n_items, d, l1, opt=opt, lr=lr, l2=l2, device=dev)
+        m = ShardedNeumf(n_users, n_items, d, l1, opt=opt, lr=lr, l2=l2, device=dev, micro_batches=micro_batches)
         m.load_global({k: torch.from_numpy(v).to(dev) for k, v in P.items()})
         losses = []
         for s in range(steps):
@@ -221,8 +221,9 @@ def _neumf_worker(rank, world, port, opt, lr, l2, n_users, n_items, d, l1, B, C,
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,opt,lr,l2", [(2, "SGD", 0.1, 1e-3), (2, "Adam", 1e-2, 0.0), (1, "SGD", 0.1, 1e-3)])
-def test_sharded_neumf_hip_ops_equal_single_table_training(world, opt, lr, l2, cuda):
+@pytest.mark.parametrize("world,opt,lr,l2,micro_batches", [(2, "SGD", 0.1, 1e-3, 1), (2, "Adam", 1e-2, 0.0, 1), (1, "SGD", 0.1, 1e-3, 1),
+                                                           (2, "SGD", 0.1, 1e-3, 3)])
+def test_sharded_neumf_hip_ops_equal_single_table_training(world, opt, lr, l2, micro_batches, cuda):
     """ShardedNeumf with the real kernels (routing, gathers, MFMA head on per-batch row blocks, segmented
     updates), ranks sharing cuda:0 over gloo, vs single-table training of the global batch (numpy oracle)"""
     from test_sharded_gloo import _neumf_reference
@@ -230,7 +231,8 @@ def test_sharded_neumf_hip_ops_equal_single_table_training(world, opt, lr, l2, c
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_neumf_worker, args=(r, world, port, opt, lr, l2, *shape.values(), q)) for r in range(world)]
+    procs = [ctx.Process(target=_neumf_worker, args=(r, world, port, opt, lr, l2, *shape.values(), q, micro_batches))
+             for r in range(world)]
     for p in procs:
         p.start()
     losses, G = q.get(timeout=300)
