@@ -211,3 +211,37 @@ def test_pipeline_host_side_pieces(corpus, ctx_corpus, tmp_path):
     user, item = pipeline.context_tables(ctx_corpus, torch.device("cpu"))
     assert int(item["i_category_c"][5]) == ctx_corpus.item_features[5]["i_category_c"]
     assert int(user["u_age_c"][3]) == ctx_corpus.user_features[3]["u_age_c"]
+
+
+def test_sasrec_kernel_choice_by_batch_shape(monkeypatch):
+    """engine._sasrec_impl: per-sequence kernels while the batch is one round of resident workgroups in the 32-row
+    geometry, batch-level kernels beyond; explicit choice and the RC_SASREC_IMPL override win"""
+    from rechorus_amd import engine
+    monkeypatch.delenv("RC_SASREC_IMPL", raising=False)
+    assert engine._sasrec_impl(256, 20, None) == "sequence"      # the reference's demo flags
+    assert engine._sasrec_impl(16, 50, None) == "sequence"       # tiny batch
+    assert engine._sasrec_impl(256, 50, None) == "batch"
+    assert engine._sasrec_impl(4096, 20, None) == "batch"
+    assert engine._sasrec_impl(4096, 50, "sequence") == "sequence"
+    monkeypatch.setenv("RC_SASREC_IMPL", "batch")
+    assert engine._sasrec_impl(16, 8, None) == "batch"
+    with pytest.raises(ValueError):
+        engine._sasrec_impl(16, 8, "fastest")
+
+
+def test_bench_workload_defaults(monkeypatch):
+    """bench.py: --workload sasrec switches to the Grocery-sized catalogue and B = 4096 unless told otherwise"""
+    import importlib.util
+    import sys
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--workload", "sasrec"])
+    a = bench.parse()
+    assert (a.items, a.batch, a.hist, a.heads) == (8714, 4096, 50, 4)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--workload", "sasrec", "--items", "50000", "--batch", "1024"])
+    a = bench.parse()
+    assert (a.items, a.batch) == (50000, 1024)
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
+    a = bench.parse()
+    assert (a.workload, a.items, a.batch, a.num_neg, a.emb_size, a.gpus) == ("bprmf", 10_000_001, 65536, 99, 64, 1)
