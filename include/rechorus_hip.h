@@ -432,18 +432,56 @@ int rc_owner_backward(float* I, float* mI, float* vI, int d, const float* Uall, 
                       const int64_t* rows, const float* g, const uint8_t* single, int64_t n, int64_t n_tuples,
                       const rc_opt_hyper* h, float* pug, void* ws, size_t ws_bytes, rc_stream_t stream);
 
+/* ---- bucket plan: the occurrences of a batch's row ids grouped by row, without a device-wide sort ----------
+ * (csrc/bucket_plan.hip).  Replaces the rc_sort_ids + rc_segment_heads pair in front of the row updates that
+ * stand in for aten::embedding_dense_backward's index_add (helpers/BaseRunner.py:205 -> nn.Embedding tables of
+ * models/general/BPRMF.py:31-32).  Two id lists (a: e.g. the B*(1+K) item ids, b: e.g. the B user ids, may be
+ * empty) are planned together; positions are p in [0, n_a) for list a and n_a + j for list b.               */
+typedef struct rc_plan_row {
+  uint32_t row;      /* table row (id)                                                        */
+  uint32_t start;    /* occ[start .. start + n) = the positions that touch the row, ascending  */
+  uint32_t n;        /* occurrences in the batch                                               */
+  uint32_t reserved; /* 0                                                                      */
+} rc_plan_row;
+
+/* 1 when ceil(range_a / 8192) + ceil(range_b / 8192) <= 4096 (one bucket level), else 0 -> use rc_sort_ids */
+int rc_bucket_plan_supported(int64_t n_a, int64_t n_b, int64_t range_a, int64_t range_b);
+size_t rc_bucket_plan_workspace_bytes(int64_t n_a, int64_t n_b);
+size_t rc_bucket_plan_flags_bytes(int64_t n_a); /* size of single_a: n_a rounded up to whole 8,192-byte tiles */
+
+/* ids_a[n_a] in [0, range_a), ids_b[n_b] in [0, range_b) (int64, reference layout).
+ * list_single_a = 0: rows of list a that occur once are NOT listed; instead single_a[p] = 1 at their position
+ *   (0 elsewhere) -- the fused BPRMF kernel updates those rows itself (rc_bprmf_fwd_bwd_update);
+ * list_single_a = 1: every distinct row of list a is listed, single_a may be NULL.
+ * List b always lists every distinct row.  rows_a / rows_b: capacity n_a / n_b records, *n_rows_a / *n_rows_b
+ * (device uint32) receive the counts; the ORDER of the records is unspecified (it influences no result), the
+ * positions of a row are ascending (=> fixed summation order in rc_plan_update).  occ: n_a + n_b entries.
+ * No float arithmetic, integer atomics only.                                                               */
+int rc_bucket_plan(const int64_t* ids_a, int64_t n_a, int64_t range_a, const int64_t* ids_b, int64_t n_b,
+                   int64_t range_b, int list_single_a, uint8_t* single_a, rc_plan_row* rows_a,
+                   uint32_t* n_rows_a, rc_plan_row* rows_b, uint32_t* n_rows_b, uint32_t* occ, void* ws,
+                   size_t ws_bytes, rc_stream_t stream);
+
 size_t rc_bprmf_step_workspace_bytes(int B, int C, int d);
+
+/* Which grouping pipeline rc_bprmf_train_step uses: 0 = automatic (bucket plan where supported), 1 = always
+ * the radix-sort pipeline (the two give bit-identical tables; used by the parity tests and for A/B timing).
+ * Returns the previous setting; any other `mode` only queries.  Process-wide, initial value 0
+ * (1 when the environment has RC_BPRMF_STEP=sort).                                                       */
+int rc_bprmf_step_pipeline(int mode);
 
 /* One BaseRunner.fit iteration for BPRMF (helpers/BaseRunner.py:193-206 with
  * models/general/BPRMF.py:34-45 and models/BaseModel.py:182-185), row-wise optimizer:
- * sort ids -> mark single-occurrence item rows -> fused fwd/loss/bwd (+ update of those
- * rows) -> segmented update of the remaining item rows -> segmented update of user rows.
+ * bucket plan of the item + user ids (rc_bucket_plan; joint radix sort + segment heads where the id space
+ * is too wide for it) -> fused fwd/loss/bwd (+ update of single-occurrence item rows) -> update of the
+ * remaining item rows -> update of the user rows (+ loss mean).
  * loss_out[0] = mean_b loss (device float).  pred may be NULL.
  * state tables (mU,vU,mI,vI) may be NULL for SGD.
  * phase_ms: NULL, or a HOST float[8] filled with per-phase milliseconds measured with
  * hipEvents on `stream` (the call then synchronises):
- *   [0] sort item ids [1] sort user ids [2] fused fwd/bwd [3] loss mean
- *   [4] item-row update [5] user-row update [6] total [7] segment heads / singletons   */
+ *   [0] sort item ids / partition into buckets [1] sort user ids (0: sorted jointly) [2] fused fwd/bwd
+ *   [3] loss mean (0 when folded into the last update launch) [4] item-row update [5] user-row update
+ *   [6] total [7] segment heads / per-bucket grouping + singleton flags                  */
 int rc_bprmf_train_step(float* U, float* I, float* mU, float* vU, float* mI, float* vI,
                         const int64_t* uid, const int64_t* iid, int B, int C, int d,
                         int64_t n_users, int64_t n_items, const rc_opt_hyper* h,

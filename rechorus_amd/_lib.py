@@ -107,7 +107,12 @@ SIGNATURES = {
     "rc_neumf_bwd": (_i, [_p] * 10 + [_i, _i, _i, _i] + [_p] * 7 + [_p, _sz, _p]),
     "rc_neumf_fwd_dropout": (_i, [_p] * 9 + [_i, _i, _i, _i, _f, _p, _p, _p]),
     "rc_neumf_bwd_dropout": (_i, [_p] * 10 + [_i, _i, _i, _i, _f, _p] + [_p] * 7 + [_p, _sz, _p]),
+    "rc_bucket_plan_supported": (_i, [_i64, _i64, _i64, _i64]),
+    "rc_bucket_plan_workspace_bytes": (_sz, [_i64, _i64]),
+    "rc_bucket_plan_flags_bytes": (_sz, [_i64]),
+    "rc_bucket_plan": (_i, [_p, _i64, _i64, _p, _i64, _i64, _i, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "rc_bprmf_step_workspace_bytes": (_sz, [_i, _i, _i]),
+    "rc_bprmf_step_pipeline": (_i, [_i]),
     "rc_bprmf_train_step": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i64, _i64, _hp, _f,
                                  _p, _p, _p, _sz, _p, C.POINTER(C.c_float)]),
 }

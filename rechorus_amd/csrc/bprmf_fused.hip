@@ -36,8 +36,44 @@ struct FusedUpd {     // singleton-row update (unused when MODE == MODE_NONE)
   OptScalars o;
 };
 
+// all-reduce over the S lanes (power of two, S-aligned) that own one tuple
+template <int S>
+__device__ __forceinline__ float tuple_allreduce_sum(float x) {
+  x = row_allreduce_sum<(S < 16 ? S : 16)>(x);
+  if (S >= 32) x += __shfl_xor(x, 16, 64);
+  if (S >= 64) x += __shfl_xor(x, 32, 64);
+  return x;
+}
+template <int S>
+__device__ __forceinline__ float tuple_allreduce_max(float x) {
+  if (S >= 2) x = fmaxf(x, dpp_mov<0xB1>(x));
+  if (S >= 4) x = fmaxf(x, dpp_mov<0x4E>(x));
+  if (S >= 8) x = fmaxf(x, dpp_mov<0x141>(x));
+  if (S >= 16) x = fmaxf(x, dpp_mov<0x140>(x));
+  if (S >= 32) x = fmaxf(x, __shfl_xor(x, 16, 64));
+  if (S >= 64) x = fmaxf(x, __shfl_xor(x, 32, 64));
+  return x;
+}
+
+// The loss of a tuple is scalar work on its C scores.  Every lane of a row's lane-group holds the same
+// score after the DPP row reduction, so computing softmax / sigmoid per register slot repeats each
+// exp / division LPR times (16 x at d = 64) and keeps three CPL-long arrays alive next to the row
+// registers (198 VGPRs -> two waves per SIMD; measured 0.21 ms of VALU time per step that two waves
+// cannot hide).  Here the scores are transposed through a C-float LDS strip per tuple: one lane per
+// candidate evaluates the loss terms (ceil(C / S) per lane instead of CPL), the gradient scalars g_c
+// return through the same strip and are broadcast-read by the lane-groups for the backward pass.
+// Slot order in the strip: s = grp * CPL + j  <->  candidate c = j * GS + grp.
+#ifndef RC_FUSED_MINW
+#define RC_FUSED_MINW 3
+#endif
+// waves per SIMD the register allocation must allow: the candidate block (CPL float4 = 4 CPL VGPRs) is the
+// floor; the stateful singleton paths keep their per-slot gradient scalars as well
+template <int CPL_, int MODE_>
+constexpr int fused_min_waves() {
+  return (MODE_ == MODE_ADAM || MODE_ == MODE_ADAGRAD) ? (CPL_ >= 20 ? 2 : 3) : (CPL_ >= 26 ? 2 : (CPL_ >= 20 ? RC_FUSED_MINW : 4));
+}
 template <int D, int GS, int CPL, int MODE>
-__global__ __launch_bounds__(kBlock) void bprmf_fwd_bwd_kernel(
+__global__ __launch_bounds__(kBlock, (fused_min_waves<CPL, MODE>())) void bprmf_fwd_bwd_kernel(
     const float* __restrict__ U, const float* I,
     const int64_t* __restrict__ uid, const int64_t* __restrict__ iid, int B, int C,
     float inv_b, float* __restrict__ pred, float* __restrict__ loss_vec,
@@ -45,7 +81,10 @@ __global__ __launch_bounds__(kBlock) void bprmf_fwd_bwd_kernel(
   constexpr int LPR = D / 4;
   constexpr int S = LPR * GS;
   static_assert(S <= 64 && (64 % S) == 0, "tuple must fit a wave");
-  constexpr int TPW = 64 / S;  // tuples per wave
+  constexpr int TPW = 64 / S;          // tuples per wave
+  constexpr int SLOTS = GS * CPL;      // strip length (>= C)
+  constexpr int NPL = (SLOTS + S - 1) / S;  // candidates per lane in the loss phase
+  __shared__ float strip_mem[(kBlock / 64) * TPW * SLOTS];
 
   const int lane = threadIdx.x & 63;
   const int64_t wave = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
@@ -55,6 +94,7 @@ __global__ __launch_bounds__(kBlock) void bprmf_fwd_bwd_kernel(
   const int sub = lane % S;
   const int grp = sub / LPR;
   const int l = sub % LPR;
+  float* strip = strip_mem + ((threadIdx.x >> 6) * TPW + lane / S) * SLOTS;
 
   // ---- gather: user row, then this group's CPL candidate rows, all loads in flight
   const int64_t u = uid[t];
@@ -76,65 +116,80 @@ __global__ __launch_bounds__(kBlock) void bprmf_fwd_bwd_kernel(
     }
   }
 
-  // ---- scores
-  float p[CPL];
+  // ---- scores -> strip
 #pragma unroll
-  for (int j = 0; j < CPL; ++j) p[j] = row_allreduce_sum<LPR>(dot4(u4, r[j]));
-  const float pos = __shfl(p[0], (lane / S) * S, 64);  // candidate 0 lives in group 0, j=0
-
-  if (pred != nullptr && tv && l == 0) {
-#pragma unroll
-    for (int j = 0; j < CPL; ++j) {
-      const int c = j * GS + grp;
-      if (c < C) pred[t * C + c] = p[j];
-    }
+  for (int j = 0; j < CPL; ++j) {
+    const float pj = row_allreduce_sum<LPR>(dot4(u4, r[j]));
+    if (l == 0) strip[grp * CPL + j] = pj;
   }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-  // ---- loss: softmax over the negatives, P = sum w*sigmoid(pos-neg)
+  // ---- loss, one lane per candidate: softmax over the negatives, P = sum w * sigmoid(pos - neg)
+  float pc[NPL];
+  int cc[NPL];
+#pragma unroll
+  for (int k = 0; k < NPL; ++k) {
+    const int s = sub + k * S;
+    const int c = (s % CPL) * GS + s / CPL;
+    cc[k] = (s < SLOTS && c < C) ? c : -1;
+    pc[k] = s < SLOTS ? strip[s] : 0.f;
+  }
+  const float pos = strip[0];  // candidate 0 = group 0, j = 0
   float mx = -INFINITY;
 #pragma unroll
-  for (int j = 0; j < CPL; ++j) {
-    const int c = j * GS + grp;
-    if (c >= 1 && c < C) mx = fmaxf(mx, p[j]);
-  }
-  mx = groups_allreduce_max<LPR, S>(mx);
-  float e[CPL];
+  for (int k = 0; k < NPL; ++k)
+    if (cc[k] >= 1) mx = fmaxf(mx, pc[k]);
+  mx = tuple_allreduce_max<S>(mx);
+  float ew[NPL], sg[NPL];
   float se = 0.f;
 #pragma unroll
-  for (int j = 0; j < CPL; ++j) {
-    const int c = j * GS + grp;
-    e[j] = (c >= 1 && c < C) ? expf(p[j] - mx) : 0.f;
-    se += e[j];
+  for (int k = 0; k < NPL; ++k) {
+    ew[k] = cc[k] >= 1 ? expf(pc[k] - mx) : 0.f;
+    se += ew[k];
   }
-  se = groups_allreduce_sum<LPR, S>(se);
+  se = tuple_allreduce_sum<S>(se);
   const float inv_se = 1.0f / se;
   float P = 0.f, A = 0.f;
-  float sg[CPL];
 #pragma unroll
-  for (int j = 0; j < CPL; ++j) {
-    e[j] *= inv_se;  // softmax weight w_j (0 on masked slots)
-    sg[j] = sigmoidf_(pos - p[j]);
-    P = fmaf(e[j], sg[j], P);
-    A = fmaf(e[j], sg[j] * (1.0f - sg[j]), A);
+  for (int k = 0; k < NPL; ++k) {
+    ew[k] *= inv_se;  // softmax weight (0 on the positive and on masked slots)
+    sg[k] = sigmoidf_(pos - pc[k]);
+    P = fmaf(ew[k], sg[k], P);
+    A = fmaf(ew[k], sg[k] * (1.0f - sg[k]), A);
   }
-  P = groups_allreduce_sum<LPR, S>(P);
-  A = groups_allreduce_sum<LPR, S>(A);
+  P = tuple_allreduce_sum<S>(P);
+  A = tuple_allreduce_sum<S>(A);
   const BprRow br = bpr_row(P, inv_b);
   if (tv && sub == 0) loss_vec[t] = br.loss;
+#pragma unroll
+  for (int k = 0; k < NPL; ++k) {
+    const int s = sub + k * S;
+    float g = br.dLdP * bpr_dP_dneg(ew[k], sg[k], P);
+    if (cc[k] == 0) g = br.dLdP * A;
+    if (cc[k] < 0) g = 0.f;
+    if (s < SLOTS) strip[s] = g;
+    if (tv && cc[k] >= 0) {
+      gpred[t * C + cc[k]] = g;
+      if (pred != nullptr) pred[t * C + cc[k]] = pc[k];
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-  // ---- backward: g_c = dL/dpred[t,c]; user-row gradient = sum_c g_c * I_c
+  // ---- backward: user-row gradient = sum_c g_c * I_c; single-occurrence item rows updated in place
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  float gs[CPL];  // stateful optimizers only
 #pragma unroll
   for (int j = 0; j < CPL; ++j) {
     const int c = j * GS + grp;
-    float g = br.dLdP * bpr_dP_dneg(e[j], sg[j], P);  // 0 on masked slots (w = 0)
-    if (c == 0) g = br.dLdP * A;
-    if (c >= C) g = 0.f;
+    const float g = strip[grp * CPL + j];  // broadcast read, 0 on slots past C
     acc.x = fmaf(g, r[j].x, acc.x);
     acc.y = fmaf(g, r[j].y, acc.y);
     acc.z = fmaf(g, r[j].z, acc.z);
     acc.w = fmaf(g, r[j].w, acc.w);
-    if (tv && l == 0 && c < C) gpred[t * C + c] = g;
     if (MODE == MODE_SGD) {
       if (smask & (1u << j)) {  // whole lane-group takes the branch together
         const int64_t id = ids[c];
@@ -142,7 +197,7 @@ __global__ __launch_bounds__(kBlock) void bprmf_fwd_bwd_kernel(
         opt_row4<MODE>(upd.o, upd.I, upd.M, upd.V, (size_t)id * LPR + l, r[j], gi);
       }
     } else if (MODE != MODE_NONE) {
-      p[j] = g;  // stateful optimizers: updated below, state rows fetched in batches
+      gs[j] = g;  // updated below, state rows fetched in batches
     }
   }
   acc.x = groups_allreduce_sum<LPR, S>(acc.x);
@@ -174,7 +229,7 @@ __global__ __launch_bounds__(kBlock) void bprmf_fwd_bwd_kernel(
       for (int q = 0; q < GRP; ++q) {
         const int j = j0 + q;
         if (j < CPL && ((smask >> j) & 1u)) {
-          const float g = p[j];
+          const float g = gs[j];
           const float4 gi = make_float4(g * u4.x, g * u4.y, g * u4.z, g * u4.w);
           float4 w = r[j];
           opt_apply4<MODE>(upd.o, w, mm[q], vv[q], gi);

@@ -1,0 +1,541 @@
+// bucket_plan.hip -- groups the occurrences of a batch's row ids by row, without a device-wide sort.
+//
+// What it replaces in the reference: aten::embedding_dense_backward's index_add over every occurrence
+// (reached through loss.backward(), helpers/BaseRunner.py:205, for the nn.Embedding tables of
+// models/general/BPRMF.py:31-32).  The atomic-free segmented update (plan_update.hip) needs, per distinct
+// row, the list of batch positions that touch it, in ascending position order (fixed summation order =>
+// bit-reproducible gradients).  Round 1 got that from a stable LSD radix sort of all B*(1+K) ids (rocPRIM,
+// three 8-bit passes + histogram + copy-back = 0.25 ms of a 1.33 ms step) followed by a head-marking pass.
+// Ids are small integers (< n_rows), so a full sort is more than is needed:
+//
+//   1. plan_count     per tile of 8,192 positions: LDS histogram over id ranges ("buckets" of 2^shift ids)
+//   2. plan_colscan   per bucket: exclusive scan of its tile counts (one wave per bucket)
+//   3. plan_scatter   stable partition of (id, position) into the buckets: ranks inside a tile come from
+//                     wave-level ballot matching in position order, tile offsets from step 2 -- no atomics
+//                     in the placement, so a bucket holds its keys in ascending position
+//   4. plan_bucket    one wave per bucket: an LDS table indexed by (id - bucket start) counts the bucket's
+//                     ids, a scan turns counts into cursors, and a second pass over the bucket's keys drops
+//                     each position into its row's slot range -- stable again, so every row's positions come
+//                     out ascending.  Emits rc_plan_row {row, start, n} records, the grouped positions
+//                     occ[], and the single-occurrence flags the fused BPRMF kernel consumes.
+//
+// HBM traffic per key: 8 B read twice (ids), 8 B written + read twice (bucketed keys), 4 B written (occ)
+// against 3 x (8 B read + 8 B written) + histogram + copy-back + the marking pass of the sort pipeline.
+// The only atomics are integer: LDS histogram increments (order-free) and one global list reservation per
+// bucket (the ORDER of rows in the list influences no floating-point result).
+#include "plan.hpp"
+
+namespace rc {
+
+int device_cus() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) cus = p.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  return cus;
+}
+
+static int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return (v && *v) ? atoi(v) : dflt;
+}
+
+PlanGeom plan_geometry(int64_t n_a, int64_t n_b, int64_t range_a, int64_t range_b) {
+  PlanGeom g;
+  memset(&g, 0, sizeof(g));
+  g.n = n_a + n_b;
+  if (g.n <= 0 || g.n >= ((int64_t)1 << 31) || range_a < 1 || (n_b > 0 && range_b < 1)) return g;
+  if (n_b == 0) range_b = 0;
+  auto buckets = [&](int shift, uint32_t* na, uint32_t* nbb) {
+    const int64_t w = (int64_t)1 << shift;
+    *na = (uint32_t)((range_a + w - 1) / w);
+    *nbb = (uint32_t)((range_b + w - 1) / w);
+    return (int64_t)*na + *nbb;
+  };
+  uint32_t na, nbb;
+  if (buckets(kPlanMaxShift, &na, &nbb) > kPlanMaxBuckets) return g;  // id space too wide for one level
+  // enough buckets to fill the chip (one wave per bucket in step 4), but not more than the scatter's
+  // write runs can afford: aim at ~8 K keys per bucket, at least 128 buckets
+  int64_t want = g.n / 8192;
+  if (want < 128) want = 128;
+  if (want > 1024) want = 1024;
+  int shift = env_int("RC_PLAN_SHIFT", kPlanMaxShift);
+  if (shift > kPlanMaxShift) shift = kPlanMaxShift;
+  if (shift < kPlanMinShift) shift = kPlanMinShift;
+  while (shift > kPlanMinShift && buckets(shift, &na, &nbb) < want && buckets(shift - 1, &na, &nbb) <= kPlanMaxBuckets) --shift;
+  while (buckets(shift, &na, &nbb) > kPlanMaxBuckets) ++shift;
+  buckets(shift, &na, &nbb);
+  g.shift = shift;
+  g.nb_a = na;
+  g.nb_b = nbb;
+  g.nb = na + nbb;
+  g.base_b = na << shift;
+  g.tiles = (uint32_t)((g.n + kPlanTile - 1) / kPlanTile);
+  g.bucket_bits = 1;
+  while ((1u << g.bucket_bits) < g.nb) ++g.bucket_bits;
+  g.ok = 1;
+  return g;
+}
+
+PlanWs carve_plan_ws(void* base, int64_t n) {
+  Carver cv(base);
+  PlanWs w;
+  if (n < 1) n = 1;
+  const size_t tiles = (size_t)((n + kPlanTile - 1) / kPlanTile);
+  w.hist = cv.take<uint32_t>((size_t)kPlanMaxBuckets * tiles);
+  w.totals = cv.take<uint32_t>(kPlanMaxBuckets);
+  w.bucket_base = cv.take<uint32_t>(kPlanMaxBuckets + 1);
+  w.keys = cv.take<uint64_t>((size_t)n);
+  w.counters = cv.take<uint32_t>(PC_N);
+  w.total = cv.off;
+  return w;
+}
+
+PlanLongWs carve_plan_long_ws(void* base, int64_t n, int d) {
+  Carver cv(base);
+  PlanLongWs w;
+  if (n < 1) n = 1;
+  w.long_cap = (uint32_t)(n / (kPlanLongSeg + 1)) + 1;
+  w.chunk_cap = (uint32_t)(n / kPlanChunk) + w.long_cap + 1;
+  w.lrows = cv.take<PlanLongRow>(w.long_cap);
+  w.chunks = cv.take<PlanChunkInfo>(w.chunk_cap);
+  w.partial = cv.take<float>((size_t)w.chunk_cap * (size_t)d);
+  w.total = cv.off;
+  return w;
+}
+
+// ---- device helpers -----------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t plan_key(const PlanArgs& a, uint32_t p) {
+  return p < a.n_a ? (uint32_t)a.ids_a[p] : a.g.base_b + (uint32_t)a.ids_b[p - a.n_a];
+}
+
+// lanes of the wave (among `valid`) whose v equals this lane's v; v < 2^bits
+__device__ __forceinline__ uint64_t match_lanes(uint32_t v, int bits, uint64_t valid) {
+  uint64_t m = valid;
+  for (int b = 0; b < bits; ++b) {
+    const bool bit = (v >> b) & 1u;
+    const uint64_t bal = __ballot(bit);
+    m &= bit ? bal : ~bal;
+  }
+  return m;
+}
+
+__device__ __forceinline__ uint64_t lanes_below(int lane) { return (1ull << lane) - 1ull; }
+
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t x, int lane) {
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t y = __shfl_up(x, off, 64);
+    if (lane >= off) x += y;
+  }
+  return x;
+}
+
+// ---- 1. per-tile bucket histogram ---------------------------------------------------------------------
+__global__ __launch_bounds__(kPlanThreads) void plan_count_kernel(PlanArgs a) {
+  extern __shared__ uint32_t s_hist[];  // [nb]
+  const uint32_t nb = a.g.nb;
+  for (uint32_t i = threadIdx.x; i < nb; i += kPlanThreads) s_hist[i] = 0;
+  if (blockIdx.x == 0 && threadIdx.x < PC_N) a.w.counters[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t tile0 = blockIdx.x * (uint32_t)kPlanTile;
+  uint32_t key[kPlanRounds];
+#pragma unroll
+  for (int r = 0; r < kPlanRounds; ++r) {
+    const uint32_t p = tile0 + r * kPlanThreads + threadIdx.x;
+    key[r] = p < a.n ? plan_key(a, p) : 0xFFFFFFFFu;
+  }
+  if (a.single_a && tile0 < a.n_a)  // flags of this tile's list-a positions start at 0 (padded buffer: whole uint4s)
+    reinterpret_cast<uint4*>(a.single_a + tile0)[threadIdx.x] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+  for (int r = 0; r < kPlanRounds; ++r) {
+    if (key[r] == 0xFFFFFFFFu) continue;
+    uint32_t b = key[r] >> a.g.shift;
+    if (b >= nb) b = nb - 1;  // an id outside its table: counted in the last bucket (memory-safe), flagged by the scatter
+    atomicAdd(&s_hist[b], 1u);
+  }
+  __syncthreads();
+  for (uint32_t b = threadIdx.x; b < nb; b += kPlanThreads) a.w.hist[(size_t)b * a.g.tiles + blockIdx.x] = s_hist[b];
+}
+
+// ---- 2. per bucket: exclusive scan over the tiles -------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void plan_colscan_kernel(PlanArgs a) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t b = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (b >= a.g.nb) return;
+  uint32_t* h = a.w.hist + (size_t)b * a.g.tiles;
+  uint32_t carry = 0;
+  constexpr int kBatch = 16;  // 1,024 tiles per trip: all loads of a trip in flight together
+  for (uint32_t t0 = 0; t0 < a.g.tiles; t0 += 64 * kBatch) {
+    uint32_t v[kBatch];
+#pragma unroll
+    for (int q = 0; q < kBatch; ++q) {
+      const uint32_t t = t0 + q * 64 + lane;
+      v[q] = t < a.g.tiles ? h[t] : 0u;
+    }
+#pragma unroll
+    for (int q = 0; q < kBatch; ++q) {
+      const uint32_t t = t0 + q * 64 + lane;
+      const uint32_t incl = wave_inclusive_scan(v[q], lane);
+      if (t < a.g.tiles) h[t] = carry + incl - v[q];
+      carry += __shfl(incl, 63, 64);
+    }
+  }
+  if (lane == 0) a.w.totals[b] = carry;
+}
+
+// ---- 3. stable partition into the buckets -----------------------------------------------------------------
+// Ranks inside the tile come from wave-level ballot matching (phase A: position order within a wave, waves in
+// order), tile offsets from step 2.  The keys are first placed into an LDS image of the tile sorted by bucket,
+// then written out in image order: consecutive threads write consecutive addresses inside a bucket's run, so a
+// wave store touches ~tile/nb-key runs instead of 64 scattered 8-byte slots (measured: 85 -> see DESIGN.md).
+// LDS: u16 wave counters [8][nb], u32 run deltas [nb], the image (u32 packed lid|local position + u16 bucket).
+__global__ __launch_bounds__(kPlanThreads) void plan_scatter_kernel(PlanArgs a) {
+  extern __shared__ uint32_t smem[];
+  const uint32_t nb = a.g.nb;
+  const uint32_t nbp = (nb + 1) & ~1u;
+  uint32_t* gdelta = smem;                                   // [nb]   global index of image slot i = gdelta[bucket(i)] + i
+  uint32_t* image = gdelta + nbp;                            // [kPlanTile]
+  uint32_t* wsum = image + kPlanTile;                        // [2 * kPlanWaves]
+  uint16_t* image_b = reinterpret_cast<uint16_t*>(wsum + 2 * kPlanWaves);  // [kPlanTile]
+  uint16_t* cnt = image_b + kPlanTile;                       // [kPlanWaves][nbp]
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  for (uint32_t i = threadIdx.x; i < kPlanWaves * nbp / 2; i += kPlanThreads) reinterpret_cast<uint32_t*>(cnt)[i] = 0;
+
+  // issue this wave's id loads (1,024 consecutive positions) before anything else
+  const uint32_t tile0 = blockIdx.x * (uint32_t)kPlanTile;
+  const uint32_t pos0 = tile0 + wave * (kPlanTile / kPlanWaves);
+  uint32_t key[kPlanRounds];
+#pragma unroll
+  for (int r = 0; r < kPlanRounds; ++r) {
+    const uint32_t p = pos0 + r * 64 + lane;
+    key[r] = p < a.n ? plan_key(a, p) : 0xFFFFFFFFu;
+  }
+
+  // bucket bases: exclusive scan of the bucket totals (nb <= 4096 = 8 consecutive buckets per thread)
+  constexpr int kPer = kPlanMaxBuckets / kPlanThreads;
+  uint32_t tv[kPer];
+  uint32_t tsum = 0;
+#pragma unroll
+  for (int q = 0; q < kPer; ++q) {
+    const uint32_t b = threadIdx.x * kPer + q;
+    tv[q] = b < nb ? a.w.totals[b] : 0u;
+    tsum += tv[q];
+  }
+  uint32_t incl = wave_inclusive_scan(tsum, lane);
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();  // also: cnt[] zeroed
+  uint32_t run = incl - tsum;
+  for (int w = 0; w < wave; ++w) run += wsum[w];
+#pragma unroll
+  for (int q = 0; q < kPer; ++q) {
+    const uint32_t b = threadIdx.x * kPer + q;
+    if (b < nb) {
+      gdelta[b] = run + a.w.hist[(size_t)b * a.g.tiles + blockIdx.x];  // bucket base + this bucket's keys in earlier tiles
+      if (blockIdx.x == 0) a.w.bucket_base[b] = run;
+    }
+    run += tv[q];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == kPlanThreads - 1) a.w.bucket_base[nb] = run;
+
+  // phase A: rank of every key among the keys of its bucket in THIS WAVE's 1,024 positions, in position order
+  uint32_t rank[kPlanRounds];
+  uint16_t* mycnt = cnt + (size_t)wave * nbp;
+#pragma unroll
+  for (int r = 0; r < kPlanRounds; ++r) {
+    const bool valid = key[r] != 0xFFFFFFFFu;
+    uint32_t b = valid ? key[r] >> a.g.shift : 0u;
+    if (b >= nb) {  // id outside its table (nn.Embedding would raise a device assert): stay in bounds, raise the status bit
+      b = nb - 1;
+      a.w.counters[PC_STATUS] = 1u;
+    }
+    const uint64_t m = match_lanes(b, a.g.bucket_bits, __ballot(valid));
+    const uint32_t old = mycnt[b];
+    const uint32_t below = (uint32_t)__popcll(m & lanes_below(lane));
+    if (valid && below == 0) mycnt[b] = (uint16_t)(old + (uint32_t)__popcll(m));
+    rank[r] = old + below;
+  }
+  __syncthreads();
+  // phase B: per bucket, wave counts -> image slots (bucket's run start in the image + keys of earlier waves)
+  uint32_t tc[kPer];
+  uint32_t csum = 0;
+#pragma unroll
+  for (int q = 0; q < kPer; ++q) {
+    const uint32_t b = threadIdx.x * kPer + q;
+    uint32_t c = 0;
+    if (b < nb) {
+#pragma unroll
+      for (int w = 0; w < kPlanWaves; ++w) c += cnt[(size_t)w * nbp + b];
+    }
+    tc[q] = c;
+    csum += c;
+  }
+  incl = wave_inclusive_scan(csum, lane);
+  if (lane == 63) wsum[kPlanWaves + wave] = incl;
+  __syncthreads();
+  uint32_t lrun = incl - csum;
+  for (int w = 0; w < wave; ++w) lrun += wsum[kPlanWaves + w];
+#pragma unroll
+  for (int q = 0; q < kPer; ++q) {
+    const uint32_t b = threadIdx.x * kPer + q;
+    if (b < nb) {
+      gdelta[b] -= lrun;  // (mod 2^32; the sum below is in range again)
+      uint32_t at = lrun;
+#pragma unroll
+      for (int w = 0; w < kPlanWaves; ++w) {
+        const uint32_t c = cnt[(size_t)w * nbp + b];
+        cnt[(size_t)w * nbp + b] = (uint16_t)at;
+        at += c;
+      }
+    }
+    lrun += tc[q];
+  }
+  __syncthreads();
+  // phase C: the tile's image, sorted by bucket, position order inside a bucket
+  const uint32_t lid_mask = (1u << a.g.shift) - 1u;
+#pragma unroll
+  for (int r = 0; r < kPlanRounds; ++r) {
+    if (key[r] == 0xFFFFFFFFu) continue;
+    uint32_t b = key[r] >> a.g.shift;
+    if (b >= nb) b = nb - 1;
+    const uint32_t slot = (uint32_t)mycnt[b] + rank[r];
+    image[slot] = ((key[r] & lid_mask) << 13) | (uint32_t)(wave * (kPlanTile / kPlanWaves) + r * 64 + lane);
+    image_b[slot] = (uint16_t)b;
+  }
+  __syncthreads();
+  // phase D: write the image out; slot i of bucket b goes to gdelta[b] + i
+  const uint32_t tile_n = a.n - tile0 < (uint32_t)kPlanTile ? a.n - tile0 : (uint32_t)kPlanTile;
+  for (uint32_t i = threadIdx.x; i < tile_n; i += kPlanThreads) {
+    const uint32_t e = image[i];
+    a.w.keys[gdelta[image_b[i]] + i] = ((uint64_t)(e >> 13) << 32) | (tile0 + (e & (kPlanTile - 1)));
+  }
+}
+
+// ---- 4. one workgroup per bucket: rows, grouped positions, singleton flags -----------------------------------
+// LDS table indexed by (id - bucket start): occurrence counts (all four waves, order-free LDS atomics), then a
+// block scan turns counts into slot cursors and emits the row records, then wave 0 alone walks the bucket's keys
+// in position order and gives every position the next slot of its row: the returning LDS atomic hands out the
+// slots; when two lanes of a round share a row (the read-back differs from old + 1) the lanes of that row are
+// re-ranked in lane order, so every row's positions come out ascending whatever order the LDS served the atomics in.
+constexpr uint32_t kSingleBit = 0x80000000u;
+constexpr int kBucketThreads = 256;
+constexpr int kBucketBatch = 16;  // rounds of 64 keys per load batch of wave 0 (double-buffered)
+
+__global__ __launch_bounds__(kBucketThreads) void plan_bucket_kernel(PlanArgs a) {
+  extern __shared__ uint32_t tab[];  // (1 << shift) + 256 words, then 16 words of scan scratch
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const uint32_t bkt = blockIdx.x;
+  const int shift = a.g.shift;
+  const uint32_t ids = 1u << shift;
+  const int per_shift = shift - 8;          // ids per thread in the scan = 1 << per_shift
+  const uint32_t per = 1u << per_shift;
+  // thread i owns ids [i*per, (i+1)*per); one pad word per `per` ids (odd stride) keeps the walks off each other's banks
+  auto sidx = [per_shift](uint32_t lid) { return lid + (lid >> per_shift); };
+  uint32_t* scratch = tab + ids + kBucketThreads;
+  const uint32_t beg = a.w.bucket_base[bkt], end = a.w.bucket_base[bkt + 1];
+  if (beg == end) return;  // block-uniform
+  const bool side_b = bkt >= a.g.nb_a;
+  const bool list_all = side_b || a.list_single_a != 0;
+  for (uint32_t i = tid; i < ids + kBucketThreads; i += kBucketThreads) tab[i] = 0;
+  __syncthreads();
+
+  // pass 1: occurrences per id
+  constexpr int kCountBatch = 8;
+  for (uint32_t j0 = beg; j0 < end; j0 += kBucketThreads * kCountBatch) {
+    uint64_t k[kCountBatch];
+#pragma unroll
+    for (int q = 0; q < kCountBatch; ++q) {
+      const uint32_t j = j0 + q * kBucketThreads + tid;
+      k[q] = j < end ? a.w.keys[j] : ~0ull;
+    }
+#pragma unroll
+    for (int q = 0; q < kCountBatch; ++q)
+      if (k[q] != ~0ull) atomicAdd(&tab[sidx((uint32_t)(k[q] >> 32))], 1u);
+  }
+  __syncthreads();
+
+  // scan: counts -> cursors (listed rows) / marker (rows that are only flagged); row records
+  uint32_t my_occ = 0, my_rows = 0;
+  for (uint32_t j = 0; j < per; ++j) {
+    const uint32_t c = tab[sidx(tid * per + j)];
+    if (c != 0 && (list_all || c >= 2)) {
+      my_occ += c;
+      ++my_rows;
+    }
+  }
+  const uint32_t occ_incl = wave_inclusive_scan(my_occ, lane);
+  const uint32_t rows_incl = wave_inclusive_scan(my_rows, lane);
+  if (lane == 63) {
+    scratch[wave] = occ_incl;
+    scratch[4 + wave] = rows_incl;
+  }
+  __syncthreads();
+  uint32_t occ_off = occ_incl - my_occ, row_at = rows_incl - my_rows, total_rows = 0;
+  for (int w = 0; w < kBucketThreads / 64; ++w) {
+    if (w < wave) {
+      occ_off += scratch[w];
+      row_at += scratch[4 + w];
+    }
+    total_rows += scratch[4 + w];
+  }
+  if (tid == 0) scratch[8] = total_rows ? atomicAdd(side_b ? a.n_rows_b : a.n_rows_a, total_rows) : 0u;
+  __syncthreads();
+  row_at += scratch[8];
+  rc_plan_row* rows = side_b ? a.rows_b : a.rows_a;
+  const uint32_t row0 = (bkt - (side_b ? a.g.nb_a : 0u)) << shift;  // table-local id of the bucket's first row
+  for (uint32_t j = 0; j < per; ++j) {
+    const uint32_t lid = tid * per + j;
+    const uint32_t c = tab[sidx(lid)];
+    if (c == 0) continue;
+    if (list_all || c >= 2) {
+      rc_plan_row e;
+      e.row = row0 + lid;
+      e.start = beg + occ_off;
+      e.n = c;
+      e.reserved = 0;
+      rows[row_at++] = e;
+      tab[sidx(lid)] = occ_off;
+      occ_off += c;
+    } else {
+      tab[sidx(lid)] = kSingleBit;
+    }
+  }
+  __syncthreads();
+  if (wave != 0) return;
+
+  // pass 2 (wave 0): positions into their row's slots, ascending
+  uint8_t* single = side_b ? nullptr : a.single_a;
+  const int64_t* src_index = side_b ? nullptr : a.occ_src_index;
+  const uint32_t div = (uint32_t)a.occ_src_div;
+  uint64_t cur_k[kBucketBatch], nxt_k[kBucketBatch];
+#pragma unroll
+  for (int q = 0; q < kBucketBatch; ++q) {
+    const uint32_t j = beg + q * 64 + lane;
+    nxt_k[q] = j < end ? a.w.keys[j] : ~0ull;
+  }
+  for (uint32_t j0 = beg; j0 < end; j0 += 64 * kBucketBatch) {
+#pragma unroll
+    for (int q = 0; q < kBucketBatch; ++q) cur_k[q] = nxt_k[q];
+    const uint32_t jn = j0 + 64 * kBucketBatch;
+#pragma unroll
+    for (int q = 0; q < kBucketBatch; ++q) {  // next batch's keys travel while this one is placed
+      const uint32_t j = jn + q * 64 + lane;
+      nxt_k[q] = j < end ? a.w.keys[j] : ~0ull;
+    }
+    uint32_t srow[kBucketBatch];  // source row of the occurrence (list a only): requested for the whole batch up front
+    if (src_index) {
+#pragma unroll
+      for (int q = 0; q < kBucketBatch; ++q)
+        srow[q] = cur_k[q] != ~0ull ? (uint32_t)src_index[(uint32_t)cur_k[q] / div] : 0u;
+    }
+#pragma unroll
+    for (int q = 0; q < kBucketBatch; ++q) {
+      if (j0 + q * 64 >= end) break;  // wave-uniform
+      const bool valid = cur_k[q] != ~0ull;
+      const uint32_t lid = (uint32_t)(cur_k[q] >> 32);
+      const uint32_t p = (uint32_t)cur_k[q];
+      uint32_t old = 0, now = 1;
+      if (valid) {
+        old = atomicAdd(&tab[sidx(lid)], 1u);
+        now = __hip_atomic_load(&tab[sidx(lid)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // after every lane's add
+      }
+      uint32_t slot = old;
+      uint64_t pending = __ballot(valid && now != old + 1u);  // rows shared by several lanes of this round
+      while (pending) {
+        const int leader = __ffsll((long long)pending) - 1;
+        const uint32_t lid0 = __shfl(lid, leader, 64);
+        const uint32_t now0 = __shfl(now, leader, 64);
+        const uint64_t same = __ballot(valid && lid == lid0);
+        if (valid && lid == lid0) slot = now0 - (uint32_t)__popcll(same) + (uint32_t)__popcll(same & lanes_below(lane));
+        pending &= ~same;
+      }
+      if (!valid) continue;
+      if (slot & kSingleBit) {
+        if (single) single[p] = 1;
+      } else {
+        a.occ[beg + slot] = p;
+        if (src_index) a.occ_src[beg + slot] = srow[q];
+      }
+    }
+  }
+}
+
+int plan_launch(const PlanArgs& a, hipStream_t s, hipEvent_t* ev_after_scatter) {
+  const PlanGeom& g = a.g;
+  const size_t hist_lds = (size_t)g.nb * sizeof(uint32_t);
+  hipLaunchKernelGGL(plan_count_kernel, dim3(g.tiles), dim3(kPlanThreads), hist_lds, s, a);
+  RC_LAUNCH_CHECK();
+  hipLaunchKernelGGL(plan_colscan_kernel, dim3((g.nb + 3) / 4), dim3(kBlock), 0, s, a);
+  RC_LAUNCH_CHECK();
+  const size_t nbp = (g.nb + 1) & ~(size_t)1;
+  const size_t sc_lds = (nbp + kPlanTile + 2 * kPlanWaves) * sizeof(uint32_t) + ((size_t)kPlanTile + kPlanWaves * nbp) * sizeof(uint16_t);
+  hipLaunchKernelGGL(plan_scatter_kernel, dim3(g.tiles), dim3(kPlanThreads), sc_lds, s, a);
+  RC_LAUNCH_CHECK();
+  if (ev_after_scatter) RC_HIP(hipEventRecord(*ev_after_scatter, s));
+  const size_t bk_lds = ((size_t)(1u << g.shift) + kBucketThreads + 16) * sizeof(uint32_t);
+  hipLaunchKernelGGL(plan_bucket_kernel, dim3(g.nb), dim3(kBucketThreads), bk_lds, s, a);
+  RC_LAUNCH_CHECK();
+  return RC_OK;
+}
+
+int plan_prepare() {
+  static bool done = false;
+  if (done) return RC_OK;
+  // the scatter kernel needs up to ~130 KB of dynamic LDS at 4,096 buckets
+  RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(plan_scatter_kernel),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  done = true;
+  return RC_OK;
+}
+
+}  // namespace rc
+
+using namespace rc;
+
+extern "C" int rc_bucket_plan_supported(int64_t n_a, int64_t n_b, int64_t range_a, int64_t range_b) {
+  return plan_geometry(n_a, n_b, range_a, range_b).ok;
+}
+
+extern "C" size_t rc_bucket_plan_workspace_bytes(int64_t n_a, int64_t n_b) {
+  if (n_a < 0 || n_b < 0) return 0;
+  return carve_plan_ws(nullptr, n_a + n_b).total;
+}
+
+extern "C" size_t rc_bucket_plan_flags_bytes(int64_t n_a) {
+  if (n_a < 0) return 0;
+  return align_up((size_t)n_a, kPlanTile);
+}
+
+extern "C" int rc_bucket_plan(const int64_t* ids_a, int64_t n_a, int64_t range_a, const int64_t* ids_b, int64_t n_b,
+                              int64_t range_b, int list_single_a, uint8_t* single_a, rc_plan_row* rows_a,
+                              uint32_t* n_rows_a, rc_plan_row* rows_b, uint32_t* n_rows_b, uint32_t* occ, void* ws,
+                              size_t ws_bytes, rc_stream_t stream) {
+  RC_REQUIRE(n_a >= 0 && n_b >= 0 && n_a + n_b < ((int64_t)1 << 31), "rc_bucket_plan: sizes out of range");
+  hipStream_t s = as_stream(stream);
+  if (n_rows_a) RC_HIP(hipMemsetAsync(n_rows_a, 0, sizeof(uint32_t), s));
+  if (n_rows_b) RC_HIP(hipMemsetAsync(n_rows_b, 0, sizeof(uint32_t), s));
+  if (n_a + n_b == 0) return RC_OK;
+  RC_REQUIRE((n_a == 0 || (ids_a && rows_a && n_rows_a)) && (n_b == 0 || (ids_b && rows_b && n_rows_b)) && occ && ws,
+             "rc_bucket_plan: null pointer");
+  RC_REQUIRE(list_single_a || single_a || n_a == 0, "rc_bucket_plan: single_a is needed when single-occurrence rows are not listed");
+  PlanArgs a;
+  memset(&a, 0, sizeof(a));
+  a.g = plan_geometry(n_a, n_b, range_a, range_b);
+  if (!a.g.ok)
+    return fail(RC_ERR_UNSUPPORTED, "rc_bucket_plan: id ranges %lld + %lld need more than %d buckets of %d ids",
+                (long long)range_a, (long long)range_b, kPlanMaxBuckets, 1 << kPlanMaxShift);
+  a.w = carve_plan_ws(ws, n_a + n_b);
+  if (ws_bytes < a.w.total) return fail(RC_ERR_WORKSPACE, "rc_bucket_plan: workspace %zu < %zu", ws_bytes, a.w.total);
+  RC_TRY(plan_prepare());
+  a.ids_a = ids_a; a.ids_b = ids_b; a.n_a = (uint32_t)n_a; a.n = (uint32_t)(n_a + n_b);
+  a.range_a = range_a; a.range_b = range_b;
+  a.list_single_a = list_single_a; a.single_a = single_a;
+  a.rows_a = rows_a; a.rows_b = rows_b; a.n_rows_a = n_rows_a; a.n_rows_b = n_rows_b; a.occ = occ;
+  return plan_launch(a, s, nullptr);
+}

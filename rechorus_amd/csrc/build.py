@@ -27,6 +27,8 @@ SOURCES = [
     "sort_ids.hip",
     "seg_update.hip",
     "dense_opt.hip",
+    "bucket_plan.hip",
+    "plan_update.hip",
     "train_step.hip",
     "neumf.hip",
     "sasrec.hip", "sasrec_batch.hip",
@@ -36,7 +38,7 @@ SOURCES = [
     "eval_rank.hip",
     "owner_step.hip",
 ]
-HEADERS = ["common.hpp", "bpr_math.hpp", "opt_math.hpp", "philox.hpp", "sas_mma.hpp", os.path.join("..", "..", "include", "rechorus_hip.h")]
+HEADERS = ["common.hpp", "bpr_math.hpp", "opt_math.hpp", "philox.hpp", "sas_mma.hpp", "plan.hpp", os.path.join("..", "..", "include", "rechorus_hip.h")]
 
 
 def _hipcc():

@@ -1,0 +1,94 @@
+// plan.hpp -- internal interface of the bucket plan (bucket_plan.hip) and of the updates that consume it
+// (plan_update.hip); the C ABI on top of it is in include/rechorus_hip.h (rc_bucket_plan, rc_plan_update).
+#pragma once
+#include "common.hpp"
+#include "opt_math.hpp"
+
+namespace rc {
+
+constexpr int kPlanTile = 8192;        // positions per workgroup of the count / scatter kernels
+constexpr int kPlanThreads = 512;
+constexpr int kPlanWaves = kPlanThreads / 64;
+constexpr int kPlanRounds = kPlanTile / kPlanThreads;  // keys per thread
+constexpr int kPlanMaxBuckets = 4096;
+constexpr int kPlanMaxShift = 13;      // ids per bucket <= 8192 (one 32 KiB LDS cursor table per wave)
+constexpr int kPlanMinShift = 8;
+constexpr int kPlanLongSeg = 32;       // occurrences one lane-group sums sequentially
+constexpr int kPlanChunk = 256;        // occurrences per workgroup for hot rows
+
+struct PlanGeom {
+  int ok;
+  int shift;             // ids per bucket = 1 << shift
+  uint32_t nb_a, nb_b, nb;
+  uint32_t base_b;       // key of list b = base_b + id   (a multiple of the bucket width)
+  uint32_t tiles;
+  int bucket_bits;       // bits of a bucket index
+  int64_t n;
+};
+PlanGeom plan_geometry(int64_t n_a, int64_t n_b, int64_t range_a, int64_t range_b);
+
+// counters (device uint32[PC_N]); zeroed by the first kernel of every plan
+enum { PC_ROWS_A = 0, PC_ROWS_B = 1, PC_LONG = 2, PC_CHUNKS = 3, PC_STATUS = 4, PC_N = 8 };
+
+struct PlanWs {            // carved from the caller's workspace
+  uint32_t* hist;          // [nb][tiles] per-tile bucket counts -> exclusive prefixes
+  uint32_t* totals;        // [nb]
+  uint32_t* bucket_base;   // [nb + 1]
+  uint64_t* keys;          // [n] bucketed keys: (id within bucket << 32) | position
+  uint32_t* counters;      // PC_N
+  size_t total;
+};
+PlanWs carve_plan_ws(void* base, int64_t n);
+
+struct PlanArgs {
+  const int64_t* ids_a;
+  const int64_t* ids_b;
+  uint32_t n_a, n;
+  int64_t range_a, range_b;
+  PlanGeom g;
+  PlanWs w;
+  int list_single_a;       // 0: single-occurrence rows of list a are flagged, not listed
+  uint8_t* single_a;       // [round_up(n_a, kPlanTile)] or null
+  rc_plan_row* rows_a;
+  rc_plan_row* rows_b;
+  uint32_t* n_rows_a;      // device counters (may point into w.counters)
+  uint32_t* n_rows_b;
+  uint32_t* occ;           // [n]
+  // optional, list a only: occ_src[slot] = (uint32) occ_src_index[position / occ_src_div] -- the source row of the
+  // occurrence's gradient (BPRMF: the tuple's user id), so the update does not chase it through two gathers
+  const int64_t* occ_src_index;
+  int occ_src_div;
+  uint32_t* occ_src;       // [n]
+};
+int plan_launch(const PlanArgs& a, hipStream_t s, hipEvent_t* ev_after_scatter);
+
+// ---- consumers --------------------------------------------------------------------------------------
+struct PlanTable { float* W; float* M; float* V; };
+
+// gradient row of occurrence o:  o < n_split: coef[o] * src[src_index ? src_index[o / div] : o / div]
+//                                else          src2[o - n_split]
+struct PlanGrad {
+  const float* coef;
+  const float* src;
+  const int64_t* src_index;
+  int div;
+  const float* src2;
+  uint32_t n_split;
+  const uint32_t* occ_src;  // optional: source row per slot of occ[] (PlanArgs::occ_src), replaces src_index[o / div]
+};
+
+struct PlanLongRow { uint32_t row, start, n, cbase, nchunks, side, pad0, pad1; };
+struct PlanChunkInfo { uint32_t lrow, k; };
+
+struct PlanLongWs {
+  PlanLongRow* lrows;
+  PlanChunkInfo* chunks;
+  float* partial;
+  uint32_t long_cap, chunk_cap;
+  size_t total;
+};
+PlanLongWs carve_plan_long_ws(void* base, int64_t n, int d);
+
+int device_cus();
+
+}  // namespace rc

@@ -1,0 +1,333 @@
+// plan_update.hip -- optimizer row updates driven by a bucket plan (bucket_plan.hip): per listed row, the
+// gradient rows of its occurrences are summed in ascending batch position (fixed order, no float atomics),
+// the table row is read once, updated, written once.
+//
+// Reference semantics being replaced: aten::embedding_dense_backward (index_add of every occurrence into a
+// dense [n_rows, d] gradient) followed by torch.optim's step (helpers/BaseRunner.py:193,205-206; optimizer
+// built at :110-114), restricted to the rows the batch touches ("row-wise").
+//
+//   plan_rows_kernel    grid-stride over rc_plan_row records, one lane-group (d/4 lanes, a float4 each) per
+//                       row, two rows per lane-group in flight.  Per-occurrence gradient rows are rebuilt on the
+//                       fly (BPRMF items: g[b,c] * U[uid[b]]) and never exist in HBM.  Rows with more than
+//                       kPlanLongSeg occurrences (the head of a Zipf distribution) are cut into chunks here
+//                       (row record + chunk list, integer atomics only) and left to:
+//   plan_chunk_kernel   one workgroup per 256-occurrence chunk, fixed LDS tree -> partial sums
+//   plan_final_kernel   chunk partials of a row combined in chunk order, optimizer, row written
+#include "plan.hpp"
+
+namespace rc {
+
+struct PlanSide {       // one table and how the gradient rows of its occurrences are obtained
+  PlanTable t;
+  PlanGrad g;
+  const rc_plan_row* rows;
+  const uint32_t* n_rows;
+};
+
+struct PlanUpdArgs {
+  PlanSide side[2];     // BPRMF step: 0 = item table, 1 = user table
+  const uint32_t* occ;
+  uint32_t* counters;   // PC_LONG, PC_CHUNKS
+  PlanLongWs lw;
+  OptScalars o;
+  // loss mean folded into the last launch (one extra workgroup): out[0] = scale * sum(vec[0..n))
+  const float* loss_vec;
+  int64_t loss_n;
+  float loss_scale;
+  float* loss_out;
+};
+
+__device__ __forceinline__ void padd4(float4& x, const float4& y) {
+  x.x += y.x; x.y += y.y; x.z += y.z; x.w += y.w;
+}
+
+// gradient row of the occurrence in slot `slot` of occ[], this lane's float4
+template <int D>
+__device__ __forceinline__ float4 plan_grad4(const PlanGrad& s, const uint32_t* __restrict__ occ, uint32_t slot, int l) {
+  constexpr int LPR = D / 4;
+  const uint32_t o = occ[slot];
+  if (o >= s.n_split) return reinterpret_cast<const float4*>(s.src2)[(size_t)(o - s.n_split) * LPR + l];
+  int64_t sr;
+  if (s.occ_src) {
+    sr = s.occ_src[slot];
+  } else {
+    sr = (s.div == 1) ? (int64_t)o : (int64_t)(o / (uint32_t)s.div);
+    if (s.src_index) sr = s.src_index[sr];
+  }
+  const float c = s.coef ? s.coef[o] : 1.0f;
+  float4 v = reinterpret_cast<const float4*>(s.src)[(size_t)sr * LPR + l];
+  v.x *= c; v.y *= c; v.z *= c; v.w *= c;
+  return v;
+}
+
+// hot row: chunk records for plan_chunk_kernel / plan_final_kernel (lane-group cooperative, l = lane in group)
+template <int LPR>
+__device__ __forceinline__ void plan_long_row(const PlanUpdArgs& a, const rc_plan_row& e, int side, int l) {
+  const uint32_t nch = (e.n + kPlanChunk - 1) / kPlanChunk;
+  uint32_t slot = 0, cbase = 0;
+  if (l == 0) {
+    slot = atomicAdd(&a.counters[PC_LONG], 1u);
+    cbase = atomicAdd(&a.counters[PC_CHUNKS], nch);
+    if (slot < a.lw.long_cap) {
+      PlanLongRow r;
+      r.row = e.row; r.start = e.start; r.n = e.n; r.cbase = cbase; r.nchunks = nch; r.side = (uint32_t)side;
+      r.pad0 = r.pad1 = 0;
+      a.lw.lrows[slot] = r;
+    }
+  }
+  const int src_lane = (threadIdx.x & 63) / LPR * LPR;
+  slot = __shfl(slot, src_lane, 64);
+  cbase = __shfl(cbase, src_lane, 64);
+  for (uint32_t k = l; k < nch; k += LPR)
+    if (cbase + k < a.lw.chunk_cap) {
+      PlanChunkInfo c;
+      c.lrow = slot;
+      c.k = k;
+      a.lw.chunks[cbase + k] = c;
+    }
+}
+
+// SIDE: which table this launch updates.  PLAN_ONLY_OTHER: additionally walk the OTHER side's rows and hand
+// its hot rows to the chunk path without updating anything (BPRMF step: user rows are updated later, but their
+// hot rows have to be planned before plan_chunk_kernel runs).
+template <int D, int MODE>
+__device__ __forceinline__ void plan_rows_body(const PlanUpdArgs& a, int side, bool plan_long, uint32_t first_block,
+                                               uint32_t n_blocks) {
+  constexpr int LPR = D / 4;
+  constexpr int GPB = kBlock / LPR;
+  constexpr int H = 2;
+  const PlanSide& sd = a.side[side];
+  const int l = threadIdx.x % LPR;
+  const uint32_t nr = *sd.n_rows;
+  const uint32_t stride = n_blocks * GPB * H;
+  for (uint32_t g0 = ((blockIdx.x - first_block) * GPB + threadIdx.x / LPR) * H; g0 < nr; g0 += stride) {
+    rc_plan_row e[H];
+    bool act[H];
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      e[h] = sd.rows[g0 + h < nr ? g0 + h : g0];
+      act[h] = g0 + h < nr && e[h].n <= (uint32_t)kPlanLongSeg;
+    }
+    float4 w[H], acc[H], s1[H];
+#pragma unroll
+    for (int h = 0; h < H; ++h)
+      if (act[h]) w[h] = load_stream4(reinterpret_cast<const float4*>(sd.t.W) + (size_t)e[h].row * LPR + l);
+#pragma unroll
+    for (int h = 0; h < H; ++h)
+      if (act[h]) acc[h] = plan_grad4<D>(sd.g, a.occ, e[h].start, l);
+#pragma unroll
+    for (int h = 0; h < H; ++h)
+      if (act[h] && e[h].n > 1) s1[h] = plan_grad4<D>(sd.g, a.occ, e[h].start + 1, l);
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      if (g0 + h >= nr) break;
+      if (!act[h]) {
+        if (plan_long) plan_long_row<LPR>(a, e[h], side, l);
+        continue;
+      }
+      if (e[h].n > 1) padd4(acc[h], s1[h]);
+      for (uint32_t k = 2; k < e[h].n; ++k) padd4(acc[h], plan_grad4<D>(sd.g, a.occ, e[h].start + k, l));
+      opt_row4<MODE>(a.o, sd.t.W, sd.t.M, sd.t.V, (size_t)e[h].row * LPR + l, w[h], acc[h]);
+    }
+  }
+}
+
+// hot rows of `side` only: chunk records, no update
+template <int D>
+__device__ __forceinline__ void plan_long_only_body(const PlanUpdArgs& a, int side, uint32_t first_block,
+                                                    uint32_t n_blocks) {
+  constexpr int LPR = D / 4;
+  constexpr int GPB = kBlock / LPR;
+  const PlanSide& sd = a.side[side];
+  const int l = threadIdx.x % LPR;
+  const uint32_t nr = *sd.n_rows;
+  for (uint32_t g = (blockIdx.x - first_block) * GPB + threadIdx.x / LPR; g < nr; g += n_blocks * GPB) {
+    const rc_plan_row e = sd.rows[g];
+    if (e.n > (uint32_t)kPlanLongSeg) plan_long_row<LPR>(a, e, side, l);
+  }
+}
+
+// launch 1 of the BPRMF step's update: item rows (side 0) updated, hot rows of BOTH sides planned
+template <int D, int MODE>
+__global__ __launch_bounds__(kBlock) void plan_rows_kernel(PlanUpdArgs a, uint32_t blocks_main, int update_side,
+                                                          int plan_other) {
+  if (blockIdx.x < blocks_main) plan_rows_body<D, MODE>(a, update_side, true, 0, blocks_main);
+  else if (plan_other) plan_long_only_body<D>(a, 1 - update_side, blocks_main, gridDim.x - blocks_main);
+}
+
+// LDS tree over the lane-groups of a block, fixed order; result in group 0's slots
+template <int LPR>
+__device__ __forceinline__ void plan_tree_sum(float4* part, int g) {
+  constexpr int GPB = kBlock / LPR;
+#pragma unroll
+  for (int off = GPB / 2; off >= 1; off >>= 1) {
+    __syncthreads();
+    if (g < off) {
+      float4 x = part[threadIdx.x];
+      padd4(x, part[threadIdx.x + off * LPR]);
+      part[threadIdx.x] = x;
+    }
+  }
+  __syncthreads();
+}
+
+template <int D>
+__global__ __launch_bounds__(kBlock) void plan_chunk_kernel(PlanUpdArgs a) {
+  constexpr int LPR = D / 4;
+  constexpr int GPB = kBlock / LPR;
+  __shared__ float4 part[kBlock];
+  const int l = threadIdx.x % LPR;
+  const int g = threadIdx.x / LPR;
+  uint32_t n_chunks = a.counters[PC_CHUNKS];
+  if (n_chunks > a.lw.chunk_cap) n_chunks = a.lw.chunk_cap;
+  for (uint32_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+    const PlanChunkInfo ci = a.lw.chunks[c];
+    const PlanLongRow r = a.lw.lrows[ci.lrow];
+    const PlanGrad& gs = a.side[r.side].g;
+    const uint32_t start = r.start + ci.k * kPlanChunk;
+    const uint32_t end = (start + kPlanChunk < r.start + r.n) ? start + kPlanChunk : r.start + r.n;
+    // four independent occurrences per lane-group per trip (fixed pattern -> fixed order)
+    float4 acc = make_float4(0, 0, 0, 0);
+    for (uint32_t jj = start + g; jj < end; jj += 4 * GPB) {
+      const float4 z = make_float4(0, 0, 0, 0);
+      const float4 s0 = plan_grad4<D>(gs, a.occ, jj, l);
+      const float4 s1 = (jj + GPB < end) ? plan_grad4<D>(gs, a.occ, jj + GPB, l) : z;
+      const float4 s2 = (jj + 2 * GPB < end) ? plan_grad4<D>(gs, a.occ, jj + 2 * GPB, l) : z;
+      const float4 s3 = (jj + 3 * GPB < end) ? plan_grad4<D>(gs, a.occ, jj + 3 * GPB, l) : z;
+      padd4(acc, s0); padd4(acc, s1); padd4(acc, s2); padd4(acc, s3);
+    }
+    part[threadIdx.x] = acc;
+    plan_tree_sum<LPR>(part, g);
+    if (g == 0) reinterpret_cast<float4*>(a.lw.partial)[(size_t)(r.cbase + ci.k) * LPR + l] = part[threadIdx.x];
+    __syncthreads();  // part[] is reused by the next chunk
+  }
+}
+
+// last launch: short rows of `update_side` (BPRMF step: the user table, whose pre-step rows every earlier launch
+// has finished reading), the hot rows of both sides from their chunk partials, and the loss mean
+template <int D, int MODE>
+__global__ __launch_bounds__(kBlock) void plan_final_kernel(PlanUpdArgs a, uint32_t blocks_rows, uint32_t blocks_long,
+                                                           int update_side) {
+  constexpr int LPR = D / 4;
+  constexpr int GPB = kBlock / LPR;
+  __shared__ float4 part[kBlock];
+  if (blockIdx.x < blocks_rows) {
+    if (update_side >= 0) plan_rows_body<D, MODE>(a, update_side, false, 0, blocks_rows);
+    return;
+  }
+  if (blockIdx.x < blocks_rows + blocks_long) {
+    const int l = threadIdx.x % LPR;
+    const int g = threadIdx.x / LPR;
+    uint32_t n_long = a.counters[PC_LONG];
+    if (n_long > a.lw.long_cap) n_long = a.lw.long_cap;
+    for (uint32_t i = blockIdx.x - blocks_rows; i < n_long; i += blocks_long) {
+      const PlanLongRow r = a.lw.lrows[i];
+      float4 acc = make_float4(0, 0, 0, 0);
+      for (uint32_t k = g; k < r.nchunks; k += GPB)
+        if (r.cbase + k < a.lw.chunk_cap)
+          padd4(acc, reinterpret_cast<const float4*>(a.lw.partial)[(size_t)(r.cbase + k) * LPR + l]);
+      part[threadIdx.x] = acc;
+      plan_tree_sum<LPR>(part, g);
+      if (g == 0) {
+        const PlanTable& t = a.side[r.side].t;
+        const size_t idx = (size_t)r.row * LPR + l;
+        opt_row4<MODE>(a.o, t.W, t.M, t.V, idx, load_stream4(reinterpret_cast<const float4*>(t.W) + idx), part[threadIdx.x]);
+      }
+      __syncthreads();
+    }
+    return;
+  }
+  // loss mean: thread t sums elements t, t+256, ... then a fixed LDS tree (same order as reduce_sum_kernel)
+  if (a.loss_out == nullptr) return;
+  float* sm = reinterpret_cast<float*>(part);
+  float acc = 0.f;
+  int64_t done = 0;
+  if (reinterpret_cast<uintptr_t>(a.loss_vec) % 16 == 0) {
+    const int64_t n4 = a.loss_n / 4;
+    const float4* x4 = reinterpret_cast<const float4*>(a.loss_vec);
+#pragma unroll 8
+    for (int64_t i = threadIdx.x; i < n4; i += kBlock) {
+      const float4 v = x4[i];
+      acc += (v.x + v.y) + (v.z + v.w);
+    }
+    done = n4 * 4;
+  }
+  for (int64_t i = done + threadIdx.x; i < a.loss_n; i += kBlock) acc += a.loss_vec[i];
+  sm[threadIdx.x] = acc;
+  __syncthreads();
+  for (int off = kBlock / 2; off >= 1; off >>= 1) {
+    if ((int)threadIdx.x < off) sm[threadIdx.x] += sm[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) a.loss_out[0] = sm[0] * a.loss_scale;
+}
+
+template <int D, int MODE>
+static int launch_step_updates(const PlanUpdArgs& a, int64_t n_occ, hipStream_t s, hipEvent_t* ev_items_done) {
+  const uint32_t cus = (uint32_t)device_cus();
+  const uint32_t blocks_main = cus * 8;
+  const uint32_t blocks_other = 64;
+  hipLaunchKernelGGL((plan_rows_kernel<D, MODE>), dim3(blocks_main + blocks_other), dim3(kBlock), 0, s, a, blocks_main, 0, 1);
+  RC_LAUNCH_CHECK();
+  if (n_occ > kPlanLongSeg) {  // otherwise no row can be hot
+    hipLaunchKernelGGL((plan_chunk_kernel<D>), dim3(1024), dim3(kBlock), 0, s, a);
+    RC_LAUNCH_CHECK();
+  }
+  if (ev_items_done) RC_HIP(hipEventRecord(*ev_items_done, s));
+  const uint32_t blocks_rows = cus * 2;
+  const uint32_t blocks_long = n_occ > kPlanLongSeg ? 256 : 0;
+  hipLaunchKernelGGL((plan_final_kernel<D, MODE>), dim3(blocks_rows + blocks_long + 1), dim3(kBlock), 0, s, a, blocks_rows,
+                     blocks_long, 1);
+  RC_LAUNCH_CHECK();
+  return RC_OK;
+}
+
+template <int MODE>
+static int launch_step_updates_d(const PlanUpdArgs& a, int d, int64_t n_occ, hipStream_t s, hipEvent_t* ev) {
+  switch (d) {
+    case 16: return launch_step_updates<16, MODE>(a, n_occ, s, ev);
+    case 32: return launch_step_updates<32, MODE>(a, n_occ, s, ev);
+    case 64: return launch_step_updates<64, MODE>(a, n_occ, s, ev);
+    case 128: return launch_step_updates<128, MODE>(a, n_occ, s, ev);
+    default: return fail(RC_ERR_UNSUPPORTED, "plan update: d=%d (16/32/64/128)", d);
+  }
+}
+
+// The three update launches of a BPRMF step (train_step.hip): item rows, chunks of hot rows, user rows + hot rows
+// + loss mean.  Item-side gradients read pre-step U rows, so every read of U precedes the last launch.
+int plan_bprmf_step_updates(float* U, float* mU, float* vU, float* I, float* mI, float* vI, int d, const int64_t* uid,
+                            int C, int64_t n_i, int64_t B, const float* gpred, const float* ugrad,
+                            const rc_plan_row* rows_i, const uint32_t* n_rows_i, const rc_plan_row* rows_u,
+                            const uint32_t* n_rows_u, const uint32_t* occ, const uint32_t* occ_src, uint32_t* counters,
+                            const PlanLongWs& lw,
+                            const rc_opt_hyper* h, const float* loss_vec, float loss_scale, float* loss_out,
+                            hipStream_t s, hipEvent_t* ev_items_done) {
+  PlanUpdArgs a;
+  memset(&a, 0, sizeof(a));
+  RC_TRY(fill_opt_scalars(h, &a.o));
+  const int mode = mode_of(h);
+  RC_REQUIRE(mode != MODE_ADAM || (mU && vU && mI && vI), "rc_bprmf_train_step: Adam needs m and v tables");
+  RC_REQUIRE(mode != MODE_ADAGRAD || (mU && mI), "rc_bprmf_train_step: Adagrad needs the state_sum tables");
+  a.side[0].t = PlanTable{I, mI, vI};
+  a.side[0].g = PlanGrad{gpred, U, uid, C, nullptr, 0xFFFFFFFFu, occ_src};
+  a.side[0].rows = rows_i;
+  a.side[0].n_rows = n_rows_i;
+  a.side[1].t = PlanTable{U, mU, vU};
+  a.side[1].g = PlanGrad{nullptr, nullptr, nullptr, 1, ugrad, (uint32_t)n_i, nullptr};  // user occurrence p = n_i + b -> ugrad[b]
+  a.side[1].rows = rows_u;
+  a.side[1].n_rows = n_rows_u;
+  a.occ = occ;
+  a.counters = counters;
+  a.lw = lw;
+  a.loss_vec = loss_vec;
+  a.loss_n = B;
+  a.loss_scale = loss_scale;
+  a.loss_out = loss_out;
+  switch (mode) {
+    case MODE_SGD: return launch_step_updates_d<MODE_SGD>(a, d, n_i + B, s, ev_items_done);
+    case MODE_ADAM: return launch_step_updates_d<MODE_ADAM>(a, d, n_i + B, s, ev_items_done);
+    default: return launch_step_updates_d<MODE_ADAGRAD>(a, d, n_i + B, s, ev_items_done);
+  }
+}
+
+}  // namespace rc

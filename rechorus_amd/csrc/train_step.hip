@@ -13,6 +13,18 @@
 // Ordering constraints: phase 4 reads U (pre-step values, to rebuild g*U[u]) so it runs
 // before phase 5 rewrites U; phase 2 reads both tables before either is updated.
 #include "common.hpp"
+#include "plan.hpp"
+
+namespace rc {
+int plan_bprmf_step_updates(float* U, float* mU, float* vU, float* I, float* mI, float* vI, int d, const int64_t* uid,
+                            int C, int64_t n_i, int64_t B, const float* gpred, const float* ugrad,
+                            const rc_plan_row* rows_i, const uint32_t* n_rows_i, const rc_plan_row* rows_u,
+                            const uint32_t* n_rows_u, const uint32_t* occ, const uint32_t* occ_src, uint32_t* counters,
+                            const PlanLongWs& lw,
+                            const rc_opt_hyper* h, const float* loss_vec, float loss_scale, float* loss_out,
+                            hipStream_t s, hipEvent_t* ev_items_done);
+int plan_prepare();
+}
 
 using namespace rc;
 
@@ -32,6 +44,13 @@ struct StepWs {
   size_t sort_ws_bytes;
   void* seg_ws;
   size_t seg_ws_bytes;
+  // bucket-plan step (the default where the id space allows it)
+  PlanWs plan;
+  PlanLongWs plan_long;
+  rc_plan_row* rows_i;
+  rc_plan_row* rows_u;
+  uint32_t* occ;
+  uint32_t* occ_src;
   size_t total;
 };
 
@@ -47,6 +66,7 @@ StepWs carve_step_ws(void* base, int B, int C, int d) {
   w.gpred = cv.take<float>(n_i);
   w.ugrad = cv.take<float>((size_t)B * d);
   w.loss_vec = cv.take<float>((size_t)B);
+  const size_t plan_off = cv.off;
   w.single = cv.take<uint8_t>(n_i);
   w.heads_i = cv.take<uint32_t>(n_i);
   w.n_heads_i = cv.take<uint32_t>(1);
@@ -54,10 +74,39 @@ StepWs carve_step_ws(void* base, int B, int C, int d) {
   w.sort_ws = cv.take<char>(w.sort_ws_bytes);
   w.seg_ws_bytes = rc_segmented_workspace_bytes((int64_t)n_i, d);
   w.seg_ws = cv.take<char>(w.seg_ws_bytes);
-  w.total = cv.off;
+  // the two pipelines never run in the same call: the plan buffers overlay the sort / segment scratch
+  // (everything after loss_vec)
+  Carver pv(base);
+  pv.off = plan_off;
+  w.single = pv.take<uint8_t>(align_up(n_i, (size_t)kPlanTile));
+  {
+    const PlanWs pw = carve_plan_ws(base ? reinterpret_cast<char*>(base) + pv.off : nullptr, (int64_t)n_i + B);
+    w.plan = pw;
+    pv.off += align_up(pw.total, 256);
+    const PlanLongWs lw = carve_plan_long_ws(base ? reinterpret_cast<char*>(base) + pv.off : nullptr, (int64_t)n_i + B, d);
+    w.plan_long = lw;
+    pv.off += align_up(lw.total, 256);
+  }
+  w.rows_i = pv.take<rc_plan_row>(n_i);
+  w.rows_u = pv.take<rc_plan_row>((size_t)B);
+  w.occ = pv.take<uint32_t>(n_i + (size_t)B);
+  w.occ_src = pv.take<uint32_t>(n_i + (size_t)B);
+  w.total = cv.off > pv.off ? cv.off : pv.off;
   return w;
 }
 }  // namespace
+
+// 0 = automatic, 1 = always the sort pipeline; initial value from RC_BPRMF_STEP=sort
+static int& step_pipeline() {
+  static int mode = [] { const char* v = getenv("RC_BPRMF_STEP"); return (v && strcmp(v, "sort") == 0) ? 1 : 0; }();
+  return mode;
+}
+
+extern "C" int rc_bprmf_step_pipeline(int mode) {
+  const int prev = step_pipeline();
+  if (mode == 0 || mode == 1) step_pipeline() = mode;
+  return prev;
+}
 
 extern "C" size_t rc_bprmf_step_workspace_bytes(int B, int C, int d) {
   if (B < 1 || C < 1 || d < 1) return 0;
@@ -100,6 +149,42 @@ extern "C" int rc_bprmf_train_step(float* U, float* I, float* mU, float* vU, flo
 #else
   const bool fused_upd = rc_bprmf_fused_supported(d, C) != 0 && h->opt == RC_OPT_SGD;
 #endif
+  // Pipeline choice: the bucket plan (bucket_plan.hip + plan_update.hip, 8 launches) where the register-resident
+  // fused kernel exists and the joint id space fits one bucket level; otherwise (and with RC_BPRMF_STEP=sort)
+  // the round-1 pipeline: joint radix sort -> segment heads -> fused -> segmented updates.
+  const bool force_sort = step_pipeline() == 1;
+  const PlanGeom geom = plan_geometry(n_i, B, n_items, n_users);
+  const bool fused_ok = rc_bprmf_fused_supported(d, C) != 0;
+  if (!force_sort && geom.ok && fused_ok && (d == 16 || d == 32 || d == 64 || d == 128)) {
+    RC_TRY(plan_prepare());
+    PlanArgs pa;
+    memset(&pa, 0, sizeof(pa));
+    pa.ids_a = iid; pa.ids_b = uid; pa.n_a = (uint32_t)n_i; pa.n = (uint32_t)(n_i + B);
+    pa.range_a = n_items; pa.range_b = n_users;
+    pa.g = geom;
+    pa.w = w.plan;
+    pa.list_single_a = fused_upd ? 0 : 1;
+    pa.single_a = fused_upd ? w.single : nullptr;
+    pa.rows_a = w.rows_i; pa.rows_b = w.rows_u;
+    pa.n_rows_a = &w.plan.counters[PC_ROWS_A]; pa.n_rows_b = &w.plan.counters[PC_ROWS_B];
+    pa.occ = w.occ;
+    pa.occ_src_index = uid; pa.occ_src_div = C; pa.occ_src = w.occ_src;
+    RC_MARK(0);
+    RC_TRY(plan_launch(pa, s, prof ? &ev[1] : nullptr));   // ev[1]: after the partition, before the bucket kernel
+    RC_MARK(2);
+    RC_MARK(3);
+    if (fused_upd)
+      RC_TRY(rc_bprmf_fwd_bwd_update(U, I, mI, vI, uid, iid, w.single, B, C, d, inv_b, h, pred, w.loss_vec, w.gpred,
+                                     w.ugrad, stream));
+    else
+      RC_TRY(rc_bprmf_fwd_bwd(U, I, uid, iid, B, C, d, inv_b, pred, w.loss_vec, w.gpred, w.ugrad, stream));
+    RC_MARK(4);
+    RC_MARK(5);  // (the loss mean is one workgroup of the last update launch)
+    RC_TRY(plan_bprmf_step_updates(U, mU, vU, I, mI, vI, d, uid, C, n_i, B, w.gpred, w.ugrad, w.rows_i, pa.n_rows_a,
+                                   w.rows_u, pa.n_rows_b, w.occ, w.occ_src, w.plan.counters, w.plan_long, h, w.loss_vec, inv_b,
+                                   loss_out, s, prof ? &ev[6] : nullptr));
+    RC_MARK(7);
+  } else {
   RC_MARK(0);
   // one joint radix sort: keys = item id | n_items + user id (all user keys sort after all item keys)
   RC_REQUIRE(n_items + n_users <= ((int64_t)1 << 32), "rc_bprmf_train_step: n_items + n_users exceeds 2^32");
@@ -131,6 +216,7 @@ extern "C" int rc_bprmf_train_step(float* U, float* I, float* mU, float* vU, flo
                               /*key_base=*/n_items, /*occ_base=*/n_i, h, nullptr, nullptr, nullptr, 0,
                               w.seg_ws, w.seg_ws_bytes, stream));
   RC_MARK(7);
+  }
 #undef RC_MARK
 
   if (prof) {

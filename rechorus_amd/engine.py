@@ -156,6 +156,38 @@ def sort_ids(ids, n_rows):
     return keys, perm
 
 
+def bucket_plan(ids_a, range_a, ids_b=None, range_b=0, list_single_a=True):
+    """rc_bucket_plan: occurrences of the ids grouped by row without a device-wide sort.
+    -> dict(rows_a int32[n_rows_a, 4] (row, start, n, 0), rows_b, occ int32[n_a + n_b], single uint8[n_a] | None)
+    (the uint32 fields are returned as int32 bit patterns; row counts are read back, so this wrapper synchronises --
+    the training step uses the plan through rc_bprmf_train_step without any host round trip)."""
+    a = ids_a.reshape(-1)
+    dev = a.device
+    n_a = a.numel()
+    b = ids_b.reshape(-1) if ids_b is not None else None
+    n_b = b.numel() if b is not None else 0
+    lib = _lib.load()
+    if not lib.rc_bucket_plan_supported(n_a, n_b, int(range_a), int(range_b)):
+        raise _lib.RechorusHipError("rc_bucket_plan_supported", -4, "id ranges too wide for one bucket level")
+    rows_a = torch.zeros((max(n_a, 1), 4), dtype=torch.int32, device=dev)
+    rows_b = torch.zeros((max(n_b, 1), 4), dtype=torch.int32, device=dev)
+    cnt = torch.zeros(2, dtype=torch.int32, device=dev)
+    occ = torch.full((max(n_a + n_b, 1),), -1, dtype=torch.int32, device=dev)
+    single = None
+    if not list_single_a:
+        single = torch.empty(max(lib.rc_bucket_plan_flags_bytes(n_a), 1), dtype=torch.uint8, device=dev)
+    ws = workspace(lib.rc_bucket_plan_workspace_bytes(n_a, n_b), dev, "plan")
+    _lib.call("rc_bucket_plan", _ptr(a, torch.int64, "ids_a") if n_a else None, n_a, int(range_a),
+              _ptr(b, torch.int64, "ids_b") if n_b else None, n_b, int(range_b), 1 if list_single_a else 0,
+              C.c_void_p(single.data_ptr()) if single is not None else None,
+              C.c_void_p(rows_a.data_ptr()), C.c_void_p(cnt.data_ptr()),
+              C.c_void_p(rows_b.data_ptr()), C.c_void_p(cnt[1:].data_ptr()),
+              C.c_void_p(occ.data_ptr()), C.c_void_p(ws.data_ptr()), ws.numel(), _stream())
+    na, nb = (int(x) for x in cnt.tolist())
+    return {"rows_a": rows_a[:na], "rows_b": rows_b[:nb], "occ": occ[:n_a + n_b],
+            "single": None if single is None else single[:n_a]}
+
+
 def segment_heads(keys, perm, only_multi=False, want_single=True, want_heads=True):
     """One pass over sorted ids -> (single uint8[n]|None, heads int32[n]|None, n_heads int32[1]|None)."""
     n = keys.numel()

@@ -1,0 +1,123 @@
+"""GPU parity of the bucket plan (rc_bucket_plan, csrc/bucket_plan.hip) -- integer work, so bit-exact against the
+numpy restatement oracle/plan_oracle.py -- and of the training step that consumes it: rc_bprmf_train_step gives
+bit-identical tables and loss through the plan pipeline and through the radix-sort pipeline."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import plan_oracle as PO
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng(cuda):
+    from rechorus_amd import engine
+    return engine
+
+
+def _check_plan(eng, cuda, ids_a, range_a, ids_b, range_b, list_single_a):
+    a = torch.from_numpy(np.ascontiguousarray(ids_a, dtype=np.int64)).to(cuda)
+    b = None if ids_b is None else torch.from_numpy(np.ascontiguousarray(ids_b, dtype=np.int64)).to(cuda)
+    out = eng.bucket_plan(a, range_a, b, range_b, list_single_a=list_single_a)
+    want_a, want_b, want_single = PO.bucket_plan(ids_a, ids_b, list_single_a)
+    occ = out["occ"].cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+    for rows, want, name in ((out["rows_a"], want_a, "a"), (out["rows_b"], want_b, "b")):
+        r = rows.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+        assert len(r) == len(want), f"list {name}: {len(r)} rows listed, {len(want)} expected"
+        assert len(np.unique(r[:, 0])) == len(r), f"list {name}: a row is listed twice"
+        assert np.all(r[:, 3] == 0)
+        for row, start, n, _ in r:
+            got = occ[start:start + n]
+            exp = want[int(row)]
+            assert np.array_equal(got, exp), f"list {name} row {row}: positions {got[:8]}.. != {exp[:8]}.."
+    if list_single_a:
+        assert out["single"] is None
+    else:
+        assert np.array_equal(out["single"].cpu().numpy(), want_single)
+
+
+@pytest.mark.parametrize("list_single_a", [True, False])
+@pytest.mark.parametrize("case", ["uniform_wide", "zipf_hot", "all_same", "tiny", "small_range", "edges", "no_b",
+                                  "many_buckets", "tile_boundary"])
+def test_bucket_plan_matches_the_oracle(case, list_single_a, cuda, eng):
+    rng = np.random.default_rng(sum(map(ord, case)))
+    if case == "uniform_wide":
+        ra, rb = 10_000_001, 1_000_001
+        a, b = rng.integers(1, ra, size=300_000), rng.integers(1, rb, size=3000)
+    elif case == "zipf_hot":      # rows with thousands of occurrences, straddling the 32 / 256 thresholds
+        ra, rb = 50_000, 2_000
+        a = np.minimum(rng.zipf(1.2, size=120_000), ra - 1)
+        b = np.minimum(rng.zipf(1.1, size=4_000), rb - 1)
+    elif case == "all_same":
+        ra, rb = 77, 5
+        a, b = np.full(20_000, 42), np.full(600, 3)
+    elif case == "tiny":
+        ra, rb = 9, 4
+        a, b = np.array([5, 5, 1]), np.array([2])
+    elif case == "small_range":   # fewer ids than one bucket at the widest shift
+        ra, rb = 50, 20
+        a, b = rng.integers(0, ra, size=10_000), rng.integers(0, rb, size=100)
+    elif case == "edges":         # first / last id of the tables, id 0
+        ra, rb = 1_234_567, 4_097
+        a = np.concatenate([np.zeros(3), np.full(2, ra - 1), rng.integers(0, ra, size=5000)])
+        b = np.array([0, rb - 1, rb - 1, 0, 17])
+    elif case == "no_b":
+        ra, rb = 200_000, 0
+        a, b = rng.integers(0, ra, size=70_000), None
+    elif case == "many_buckets":  # the widest supported id space: 4,096 buckets of 8,192 ids
+        ra, rb = 4000 * 8192, 96 * 8192
+        a, b = rng.integers(0, ra, size=50_000), rng.integers(0, rb, size=1_000)
+    else:                         # tile_boundary: exactly one tile, one over, one under
+        ra, rb = 100_000, 100
+        a, b = rng.integers(0, ra, size=8192 * 2 + 1), rng.integers(0, rb, size=8191)
+    _check_plan(eng, cuda, a, ra, b, rb, list_single_a)
+
+
+def test_bucket_plan_rejects_too_wide_id_spaces(cuda, eng):
+    from rechorus_amd import _lib
+    assert _lib.load().rc_bucket_plan_supported(10, 10, 40_000_000, 10) == 0
+    a = torch.zeros(10, dtype=torch.int64, device=cuda)
+    with pytest.raises(_lib.RechorusHipError):
+        eng.bucket_plan(a, 40_000_000, a, 10)
+
+
+def _zipf(rng, n_rows, size):
+    ranks = np.exp(rng.uniform(0, np.log(n_rows - 1), size=size)).astype(np.int64)
+    return (ranks * 2654435761 % (n_rows - 1)) + 1
+
+
+@pytest.mark.parametrize("opt,lr,l2", [("SGD", 0.05, 0.0), ("SGD", 0.05, 1e-3), ("Adam", 1e-3, 1e-4), ("Adagrad", 0.01, 1e-4)])
+@pytest.mark.parametrize("d,B,C,n_users,n_items", [(64, 2048, 100, 3000, 40_000), (64, 700, 12, 64, 500),
+                                                   (32, 513, 2, 40, 700), (128, 300, 40, 100, 5000),
+                                                   (16, 1000, 100, 50, 100_000)])
+def test_train_step_plan_pipeline_equals_sort_pipeline(opt, lr, l2, d, B, C, n_users, n_items, cuda, eng):
+    """same arithmetic, same summation order: the two pipelines must agree bit for bit (tables, state, loss),
+    hot rows (chunked path) and single-occurrence rows (fused fast path) included"""
+    from rechorus_amd import _lib
+    rng = np.random.default_rng(d + B + C)
+    U0 = rng.normal(0, 0.01, size=(n_users, d)).astype(np.float32)
+    I0 = rng.normal(0, 0.01, size=(n_items, d)).astype(np.float32)
+    batches = []
+    for _ in range(2):
+        uid = _zipf(rng, n_users, B)
+        iid = np.concatenate([_zipf(rng, n_items, (B, 1)), rng.integers(1, n_items, size=(B, C - 1))], axis=1)
+        batches.append((torch.from_numpy(uid).to(cuda), torch.from_numpy(iid).to(cuda)))
+    lib = _lib.load()
+    res = []
+    prev = lib.rc_bprmf_step_pipeline(-1)
+    try:
+        for mode in (1, 0):
+            lib.rc_bprmf_step_pipeline(mode)
+            U, I = torch.from_numpy(U0).to(cuda), torch.from_numpy(I0).to(cuda)
+            tr = eng.BprmfTrainer(U, I, opt=opt, lr=lr, l2=l2)
+            losses = [tr.step(u, i).clone() for u, i in batches]
+            res.append((U, I, tr.mU, tr.vU, tr.mI, tr.vI, torch.cat(losses)))
+    finally:
+        lib.rc_bprmf_step_pipeline(prev)
+    assert lib.rc_bucket_plan_supported(B * C, B, n_items, n_users) == 1
+    for name, x, y in zip(("U", "I", "mU", "vU", "mI", "vI", "loss"), res[0], res[1]):
+        if x is None:
+            continue
+        assert torch.equal(x, y), f"{name}: {int((x != y).sum())} elements differ, max |diff| {(x - y).abs().max().item():.3e}"
+    assert not torch.equal(res[0][1], torch.from_numpy(I0).to(cuda))
