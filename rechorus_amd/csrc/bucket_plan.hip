@@ -321,12 +321,49 @@ __global__ __launch_bounds__(kPlanThreads) void plan_scatter_kernel(PlanArgs a) 
 // in position order and gives every position the next slot of its row: the returning LDS atomic hands out the
 // slots; when two lanes of a round share a row (the read-back differs from old + 1) the lanes of that row are
 // re-ranked in lane order, so every row's positions come out ascending whatever order the LDS served the atomics in.
-constexpr uint32_t kSingleBit = 0x80000000u;
+//
+// Two instantiations.  Buckets of fewer than 32,768 keys (all of them, unless an id range is very hot) keep 16-bit
+// cells, two per LDS word: 17.5 KB of LDS per workgroup, so every bucket of the bench shape is resident at once
+// (with 32-bit cells, 33.8 KB, the 1,344 workgroups ran in two rounds: 107 us; profiled phases, one round each:
+// zeroing 5, count 8, scan + row records 23, ordered pass 46, its scattered stores 26).  Larger buckets -- and the
+// narrowest bucket width, where a thread owns half a word -- are left to the 32-bit instantiation, launched after it.
 constexpr int kBucketThreads = 256;
 constexpr int kBucketBatch = 16;  // rounds of 64 keys per load batch of wave 0 (double-buffered)
+constexpr uint32_t kNarrowLimit = 32768;
 
+template <bool WIDE>
+struct BucketCells {
+  uint32_t* tab;
+  int per_shift;  // ids per scan thread = 1 << per_shift
+  static constexpr uint32_t kSingle = WIDE ? 0x80000000u : 0x8000u;
+  __device__ __forceinline__ uint32_t widx(uint32_t lid) const {
+    if (WIDE) return lid + (lid >> per_shift);
+    const uint32_t w = lid >> 1;
+    return w + (w >> (per_shift - 1));
+  }
+  __device__ __forceinline__ int sh(uint32_t lid) const { return WIDE ? 0 : 16 * (int)(lid & 1u); }
+  __device__ __forceinline__ uint32_t get(uint32_t lid) const {
+    const uint32_t v = tab[widx(lid)];
+    return WIDE ? v : (v >> sh(lid)) & 0xFFFFu;
+  }
+  __device__ __forceinline__ void set(uint32_t lid, uint32_t v) const {  // by the thread that owns lid's whole word
+    if (WIDE) tab[widx(lid)] = v;
+    else tab[widx(lid)] = (tab[widx(lid)] & ~(0xFFFFu << sh(lid))) | (v << sh(lid));
+  }
+  __device__ __forceinline__ void add1(uint32_t lid) const { atomicAdd(&tab[widx(lid)], 1u << sh(lid)); }
+  __device__ __forceinline__ uint32_t add1_rtn(uint32_t lid) const {
+    const uint32_t old = atomicAdd(&tab[widx(lid)], 1u << sh(lid));
+    return WIDE ? old : (old >> sh(lid)) & 0xFFFFu;
+  }
+  __device__ __forceinline__ uint32_t reload(uint32_t lid) const {  // after every lane's add of the round
+    const uint32_t v = __hip_atomic_load(&tab[widx(lid)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return WIDE ? v : (v >> sh(lid)) & 0xFFFFu;
+  }
+};
+
+template <bool WIDE>
 __global__ __launch_bounds__(kBucketThreads) void plan_bucket_kernel(PlanArgs a) {
-  extern __shared__ uint32_t tab[];  // (1 << shift) + 256 words, then 16 words of scan scratch
+  extern __shared__ uint32_t tab[];  // table words + 256 pad words, then 16 words of scan scratch
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -335,14 +372,17 @@ __global__ __launch_bounds__(kBucketThreads) void plan_bucket_kernel(PlanArgs a)
   const uint32_t ids = 1u << shift;
   const int per_shift = shift - 8;          // ids per thread in the scan = 1 << per_shift
   const uint32_t per = 1u << per_shift;
-  // thread i owns ids [i*per, (i+1)*per); one pad word per `per` ids (odd stride) keeps the walks off each other's banks
-  auto sidx = [per_shift](uint32_t lid) { return lid + (lid >> per_shift); };
-  uint32_t* scratch = tab + ids + kBucketThreads;
   const uint32_t beg = a.w.bucket_base[bkt], end = a.w.bucket_base[bkt + 1];
   if (beg == end) return;  // block-uniform
+  if (WIDE != (end - beg >= kNarrowLimit || per_shift < 1)) return;  // the other instantiation's bucket
+  // thread i owns ids [i*per, (i+1)*per); one pad word per thread (odd stride) keeps the walks off each other's banks
+  const uint32_t words = (WIDE ? ids : ids / 2) + kBucketThreads;
+  const BucketCells<WIDE> cells{tab, per_shift};
+  constexpr uint32_t kSingle = BucketCells<WIDE>::kSingle;
+  uint32_t* scratch = tab + words;
   const bool side_b = bkt >= a.g.nb_a;
   const bool list_all = side_b || a.list_single_a != 0;
-  for (uint32_t i = tid; i < ids + kBucketThreads; i += kBucketThreads) tab[i] = 0;
+  for (uint32_t i = tid; i < words; i += kBucketThreads) tab[i] = 0;
   __syncthreads();
 
   // pass 1: occurrences per id
@@ -356,14 +396,14 @@ __global__ __launch_bounds__(kBucketThreads) void plan_bucket_kernel(PlanArgs a)
     }
 #pragma unroll
     for (int q = 0; q < kCountBatch; ++q)
-      if (k[q] != ~0ull) atomicAdd(&tab[sidx((uint32_t)(k[q] >> 32))], 1u);
+      if (k[q] != ~0ull) cells.add1((uint32_t)(k[q] >> 32));
   }
   __syncthreads();
 
   // scan: counts -> cursors (listed rows) / marker (rows that are only flagged); row records
   uint32_t my_occ = 0, my_rows = 0;
   for (uint32_t j = 0; j < per; ++j) {
-    const uint32_t c = tab[sidx(tid * per + j)];
+    const uint32_t c = cells.get(tid * per + j);
     if (c != 0 && (list_all || c >= 2)) {
       my_occ += c;
       ++my_rows;
@@ -391,7 +431,7 @@ __global__ __launch_bounds__(kBucketThreads) void plan_bucket_kernel(PlanArgs a)
   const uint32_t row0 = (bkt - (side_b ? a.g.nb_a : 0u)) << shift;  // table-local id of the bucket's first row
   for (uint32_t j = 0; j < per; ++j) {
     const uint32_t lid = tid * per + j;
-    const uint32_t c = tab[sidx(lid)];
+    const uint32_t c = cells.get(lid);
     if (c == 0) continue;
     if (list_all || c >= 2) {
       rc_plan_row e;
@@ -400,10 +440,10 @@ __global__ __launch_bounds__(kBucketThreads) void plan_bucket_kernel(PlanArgs a)
       e.n = c;
       e.reserved = 0;
       rows[row_at++] = e;
-      tab[sidx(lid)] = occ_off;
+      cells.set(lid, occ_off);
       occ_off += c;
     } else {
-      tab[sidx(lid)] = kSingleBit;
+      cells.set(lid, kSingle);
     }
   }
   __syncthreads();
@@ -411,8 +451,6 @@ __global__ __launch_bounds__(kBucketThreads) void plan_bucket_kernel(PlanArgs a)
 
   // pass 2 (wave 0): positions into their row's slots, ascending
   uint8_t* single = side_b ? nullptr : a.single_a;
-  const int64_t* src_index = side_b ? nullptr : a.occ_src_index;
-  const uint32_t div = (uint32_t)a.occ_src_div;
   uint64_t cur_k[kBucketBatch], nxt_k[kBucketBatch];
 #pragma unroll
   for (int q = 0; q < kBucketBatch; ++q) {
@@ -428,12 +466,6 @@ __global__ __launch_bounds__(kBucketThreads) void plan_bucket_kernel(PlanArgs a)
       const uint32_t j = jn + q * 64 + lane;
       nxt_k[q] = j < end ? a.w.keys[j] : ~0ull;
     }
-    uint32_t srow[kBucketBatch];  // source row of the occurrence (list a only): requested for the whole batch up front
-    if (src_index) {
-#pragma unroll
-      for (int q = 0; q < kBucketBatch; ++q)
-        srow[q] = cur_k[q] != ~0ull ? (uint32_t)src_index[(uint32_t)cur_k[q] / div] : 0u;
-    }
 #pragma unroll
     for (int q = 0; q < kBucketBatch; ++q) {
       if (j0 + q * 64 >= end) break;  // wave-uniform
@@ -442,8 +474,8 @@ __global__ __launch_bounds__(kBucketThreads) void plan_bucket_kernel(PlanArgs a)
       const uint32_t p = (uint32_t)cur_k[q];
       uint32_t old = 0, now = 1;
       if (valid) {
-        old = atomicAdd(&tab[sidx(lid)], 1u);
-        now = __hip_atomic_load(&tab[sidx(lid)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // after every lane's add
+        old = cells.add1_rtn(lid);
+        now = cells.reload(lid);
       }
       uint32_t slot = old;
       uint64_t pending = __ballot(valid && now != old + 1u);  // rows shared by several lanes of this round
@@ -456,11 +488,10 @@ __global__ __launch_bounds__(kBucketThreads) void plan_bucket_kernel(PlanArgs a)
         pending &= ~same;
       }
       if (!valid) continue;
-      if (slot & kSingleBit) {
+      if (slot & kSingle) {
         if (single) single[p] = 1;
       } else {
         a.occ[beg + slot] = p;
-        if (src_index) a.occ_src[beg + slot] = srow[q];
       }
     }
   }
@@ -478,8 +509,13 @@ int plan_launch(const PlanArgs& a, hipStream_t s, hipEvent_t* ev_after_scatter) 
   hipLaunchKernelGGL(plan_scatter_kernel, dim3(g.tiles), dim3(kPlanThreads), sc_lds, s, a);
   RC_LAUNCH_CHECK();
   if (ev_after_scatter) RC_HIP(hipEventRecord(*ev_after_scatter, s));
-  const size_t bk_lds = ((size_t)(1u << g.shift) + kBucketThreads + 16) * sizeof(uint32_t);
-  hipLaunchKernelGGL(plan_bucket_kernel, dim3(g.nb), dim3(kBucketThreads), bk_lds, s, a);
+  const size_t ids = (size_t)1 << g.shift;
+  if (g.shift > 8) {  // 16-bit cells: every bucket below 32,768 keys
+    hipLaunchKernelGGL(plan_bucket_kernel<false>, dim3(g.nb), dim3(kBucketThreads), (ids / 2 + kBucketThreads + 16) * sizeof(uint32_t), s, a);
+    RC_LAUNCH_CHECK();
+  }
+  // 32-bit cells: the remaining buckets (every workgroup of a bucket the other launch took returns at once)
+  hipLaunchKernelGGL(plan_bucket_kernel<true>, dim3(g.nb), dim3(kBucketThreads), (ids + kBucketThreads + 16) * sizeof(uint32_t), s, a);
   RC_LAUNCH_CHECK();
   return RC_OK;
 }

@@ -129,7 +129,7 @@ __device__ __forceinline__ float wave_allreduce_max(float x) {
 
 // streaming row load: read-once table rows; non-temporal (measured: fused BPRMF kernel 0.739 -> 0.629 ms; -DRC_NO_NT restores plain accesses)
 __device__ __forceinline__ float4 load_stream4(const float4* p) {
-#ifndef RC_NO_NT
+#if !defined(RC_NO_NT) && !defined(RC_NO_NT_LOAD)
   typedef float v4f __attribute__((ext_vector_type(4)));
   const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p));
   return make_float4(v.x, v.y, v.z, v.w);

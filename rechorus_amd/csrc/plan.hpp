@@ -54,11 +54,6 @@ struct PlanArgs {
   uint32_t* n_rows_a;      // device counters (may point into w.counters)
   uint32_t* n_rows_b;
   uint32_t* occ;           // [n]
-  // optional, list a only: occ_src[slot] = (uint32) occ_src_index[position / occ_src_div] -- the source row of the
-  // occurrence's gradient (BPRMF: the tuple's user id), so the update does not chase it through two gathers
-  const int64_t* occ_src_index;
-  int occ_src_div;
-  uint32_t* occ_src;       // [n]
 };
 int plan_launch(const PlanArgs& a, hipStream_t s, hipEvent_t* ev_after_scatter);
 
@@ -74,7 +69,6 @@ struct PlanGrad {
   int div;
   const float* src2;
   uint32_t n_split;
-  const uint32_t* occ_src;  // optional: source row per slot of occ[] (PlanArgs::occ_src), replaces src_index[o / div]
 };
 
 struct PlanLongRow { uint32_t row, start, n, cbase, nchunks, side, pad0, pad1; };

@@ -47,13 +47,8 @@ __device__ __forceinline__ float4 plan_grad4(const PlanGrad& s, const uint32_t* 
   constexpr int LPR = D / 4;
   const uint32_t o = occ[slot];
   if (o >= s.n_split) return reinterpret_cast<const float4*>(s.src2)[(size_t)(o - s.n_split) * LPR + l];
-  int64_t sr;
-  if (s.occ_src) {
-    sr = s.occ_src[slot];
-  } else {
-    sr = (s.div == 1) ? (int64_t)o : (int64_t)(o / (uint32_t)s.div);
-    if (s.src_index) sr = s.src_index[sr];
-  }
+  int64_t sr = (s.div == 1) ? (int64_t)o : (int64_t)(o / (uint32_t)s.div);
+  if (s.src_index) sr = s.src_index[sr];
   const float c = s.coef ? s.coef[o] : 1.0f;
   float4 v = reinterpret_cast<const float4*>(s.src)[(size_t)sr * LPR + l];
   v.x *= c; v.y *= c; v.z *= c; v.w *= c;
@@ -298,7 +293,7 @@ static int launch_step_updates_d(const PlanUpdArgs& a, int d, int64_t n_occ, hip
 int plan_bprmf_step_updates(float* U, float* mU, float* vU, float* I, float* mI, float* vI, int d, const int64_t* uid,
                             int C, int64_t n_i, int64_t B, const float* gpred, const float* ugrad,
                             const rc_plan_row* rows_i, const uint32_t* n_rows_i, const rc_plan_row* rows_u,
-                            const uint32_t* n_rows_u, const uint32_t* occ, const uint32_t* occ_src, uint32_t* counters,
+                            const uint32_t* n_rows_u, const uint32_t* occ, uint32_t* counters,
                             const PlanLongWs& lw,
                             const rc_opt_hyper* h, const float* loss_vec, float loss_scale, float* loss_out,
                             hipStream_t s, hipEvent_t* ev_items_done) {
@@ -309,11 +304,11 @@ int plan_bprmf_step_updates(float* U, float* mU, float* vU, float* I, float* mI,
   RC_REQUIRE(mode != MODE_ADAM || (mU && vU && mI && vI), "rc_bprmf_train_step: Adam needs m and v tables");
   RC_REQUIRE(mode != MODE_ADAGRAD || (mU && mI), "rc_bprmf_train_step: Adagrad needs the state_sum tables");
   a.side[0].t = PlanTable{I, mI, vI};
-  a.side[0].g = PlanGrad{gpred, U, uid, C, nullptr, 0xFFFFFFFFu, occ_src};
+  a.side[0].g = PlanGrad{gpred, U, uid, C, nullptr, 0xFFFFFFFFu};
   a.side[0].rows = rows_i;
   a.side[0].n_rows = n_rows_i;
   a.side[1].t = PlanTable{U, mU, vU};
-  a.side[1].g = PlanGrad{nullptr, nullptr, nullptr, 1, ugrad, (uint32_t)n_i, nullptr};  // user occurrence p = n_i + b -> ugrad[b]
+  a.side[1].g = PlanGrad{nullptr, nullptr, nullptr, 1, ugrad, (uint32_t)n_i};  // user occurrence p = n_i + b -> ugrad[b]
   a.side[1].rows = rows_u;
   a.side[1].n_rows = n_rows_u;
   a.occ = occ;

@@ -19,7 +19,7 @@ namespace rc {
 int plan_bprmf_step_updates(float* U, float* mU, float* vU, float* I, float* mI, float* vI, int d, const int64_t* uid,
                             int C, int64_t n_i, int64_t B, const float* gpred, const float* ugrad,
                             const rc_plan_row* rows_i, const uint32_t* n_rows_i, const rc_plan_row* rows_u,
-                            const uint32_t* n_rows_u, const uint32_t* occ, const uint32_t* occ_src, uint32_t* counters,
+                            const uint32_t* n_rows_u, const uint32_t* occ, uint32_t* counters,
                             const PlanLongWs& lw,
                             const rc_opt_hyper* h, const float* loss_vec, float loss_scale, float* loss_out,
                             hipStream_t s, hipEvent_t* ev_items_done);
@@ -50,7 +50,6 @@ struct StepWs {
   rc_plan_row* rows_i;
   rc_plan_row* rows_u;
   uint32_t* occ;
-  uint32_t* occ_src;
   size_t total;
 };
 
@@ -90,7 +89,6 @@ StepWs carve_step_ws(void* base, int B, int C, int d) {
   w.rows_i = pv.take<rc_plan_row>(n_i);
   w.rows_u = pv.take<rc_plan_row>((size_t)B);
   w.occ = pv.take<uint32_t>(n_i + (size_t)B);
-  w.occ_src = pv.take<uint32_t>(n_i + (size_t)B);
   w.total = cv.off > pv.off ? cv.off : pv.off;
   return w;
 }
@@ -168,7 +166,6 @@ extern "C" int rc_bprmf_train_step(float* U, float* I, float* mU, float* vU, flo
     pa.rows_a = w.rows_i; pa.rows_b = w.rows_u;
     pa.n_rows_a = &w.plan.counters[PC_ROWS_A]; pa.n_rows_b = &w.plan.counters[PC_ROWS_B];
     pa.occ = w.occ;
-    pa.occ_src_index = uid; pa.occ_src_div = C; pa.occ_src = w.occ_src;
     RC_MARK(0);
     RC_TRY(plan_launch(pa, s, prof ? &ev[1] : nullptr));   // ev[1]: after the partition, before the bucket kernel
     RC_MARK(2);
@@ -181,7 +178,7 @@ extern "C" int rc_bprmf_train_step(float* U, float* I, float* mU, float* vU, flo
     RC_MARK(4);
     RC_MARK(5);  // (the loss mean is one workgroup of the last update launch)
     RC_TRY(plan_bprmf_step_updates(U, mU, vU, I, mI, vI, d, uid, C, n_i, B, w.gpred, w.ugrad, w.rows_i, pa.n_rows_a,
-                                   w.rows_u, pa.n_rows_b, w.occ, w.occ_src, w.plan.counters, w.plan_long, h, w.loss_vec, inv_b,
+                                   w.rows_u, pa.n_rows_b, w.occ, w.plan.counters, w.plan_long, h, w.loss_vec, inv_b,
                                    loss_out, s, prof ? &ev[6] : nullptr));
     RC_MARK(7);
   } else {

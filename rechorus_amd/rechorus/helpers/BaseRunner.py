@@ -113,13 +113,32 @@ class BaseRunner(object):
             model.customize_parameters(), lr=self.learning_rate, weight_decay=self.l2)
 
     def _use_rowwise(self, model) -> bool:
+        """Row-wise ("lazy") updates through the model's fused `hip_train_step`, or dense torch.optim semantics.
+        'rowwise' / 'dense' are explicit; 'auto' picks row-wise only for tables past 2^20 rows AND only when the
+        model says its fused step handles this configuration (`hip_rowwise_supported`), so that e.g. SASRec with
+        dropout or NeuMF with two hidden layers on a large catalogue trains on the dense path instead of
+        failing in the first fit().  The choice is logged once: row-wise differs from the reference for
+        Adam / Adagrad / l2 > 0 (untouched rows neither decay nor move on stale moments)."""
+        mode = None
         if not hasattr(model, 'hip_train_step') or self.optimizer_name not in ('SGD', 'Adam', 'Adagrad'):
-            return False
-        if self.engine == 'rowwise':
-            return True
-        if self.engine == 'dense':
-            return False
-        return max(p.shape[0] for p in model.parameters() if p.dim() == 2) > (1 << 20)
+            mode = False
+        elif self.engine == 'rowwise':
+            mode = True   # explicit: an unsupported configuration raises in hip_train_step
+        elif self.engine == 'dense':
+            mode = False
+        else:
+            big = max(p.shape[0] for p in model.parameters() if p.dim() == 2) > (1 << 20)
+            ok = getattr(model, 'hip_rowwise_supported', lambda: True)()
+            mode = big and ok
+            if big and not ok and not getattr(self, '_engine_logged', False):
+                logging.warning('engine auto: tables exceed 2^20 rows but this configuration has no fused row-wise '
+                                'step; using dense updates (every row of every table is streamed each step)')
+        if not getattr(self, '_engine_logged', False):
+            self._engine_logged = True
+            logging.info('Engine: %s updates (--engine %s)%s', 'row-wise' if mode else 'dense', self.engine,
+                         '; rows absent from a batch are not touched (differs from torch.optim for Adam / Adagrad / '
+                         'l2 > 0)' if mode else '')
+        return mode
 
     def train(self, data_dict: Dict[str, BaseModel.Dataset]):
         model = data_dict['train'].model

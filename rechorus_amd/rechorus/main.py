@@ -109,7 +109,12 @@ def run(argv=None):
     parser = runner_cls.parse_runner_args(parser)
     parser = model_cls.parse_model_args(parser)
     args, _ = parser.parse_known_args(argv)
+    # cached corpus / log / model files of the context readers depend on which feature groups are loaded
+    # (reference: main.py:176-180)
     args.data_appendix = ''
+    if 'Context' in model_cls.reader:
+        args.data_appendix = '_context%d%d%d' % (args.include_item_features, args.include_user_features,
+                                                 args.include_situation_features)
 
     tag = init_args.model_name + init_args.model_mode
     log_args = [tag, args.dataset + args.data_appendix, str(args.random_seed)]

@@ -77,6 +77,9 @@ class NeuMF(GeneralModel):
         return {'prediction': pred.view(feed_dict['batch_size'], -1)}
 
     # ---- large-table mode: row-wise update of the four tables, no dense [n_rows, d] gradient -----------
+    def hip_rowwise_supported(self):
+        return self._fused_ok()
+
     def hip_train_step(self, feed_dict, opt_name, lr, l2):
         """forward (MFMA) + BPR loss + backward (MFMA) + row-wise segmented update of touched table rows
         + dense step of the MLP (engine.NeumfTrainer); returns the device loss tensor"""

@@ -77,6 +77,9 @@ class SASRecBase(object):
         return {'prediction': prediction.view(batch_size, -1)}
 
     # ---- large-table mode: row-wise update of the item table, dense step of everything small -----------
+    def hip_rowwise_supported(self):
+        return bool(engine.sasrec_supported(self.emb_size, self.num_layers, self.num_heads, self.max_his) and self.dropout == 0)
+
     def hip_train_step(self, feed_dict, opt_name, lr, l2):
         """encoder fwd/bwd (MFMA) + scoring + BPR loss + ONE segmented pass over candidate and history
         occurrences of the item table (engine.SasrecTrainer); returns the device loss tensor"""

@@ -39,7 +39,7 @@ def _check_plan(eng, cuda, ids_a, range_a, ids_b, range_b, list_single_a):
 
 @pytest.mark.parametrize("list_single_a", [True, False])
 @pytest.mark.parametrize("case", ["uniform_wide", "zipf_hot", "all_same", "tiny", "small_range", "edges", "no_b",
-                                  "many_buckets", "tile_boundary"])
+                                  "many_buckets", "tile_boundary", "huge_bucket"])
 def test_bucket_plan_matches_the_oracle(case, list_single_a, cuda, eng):
     rng = np.random.default_rng(sum(map(ord, case)))
     if case == "uniform_wide":
@@ -68,6 +68,11 @@ def test_bucket_plan_matches_the_oracle(case, list_single_a, cuda, eng):
     elif case == "many_buckets":  # the widest supported id space: 4,096 buckets of 8,192 ids
         ra, rb = 4000 * 8192, 96 * 8192
         a, b = rng.integers(0, ra, size=50_000), rng.integers(0, rb, size=1_000)
+    elif case == "huge_bucket":   # one bucket past 32,768 keys (32-bit LDS cells) next to ordinary ones (16-bit cells)
+        ra, rb = 5_000_000, 3_000
+        a = np.concatenate([rng.integers(0, 100, size=40_000), rng.integers(0, ra, size=30_000)])
+        rng.shuffle(a)
+        b = rng.integers(0, rb, size=500)
     else:                         # tile_boundary: exactly one tile, one over, one under
         ra, rb = 100_000, 100
         a, b = rng.integers(0, ra, size=8192 * 2 + 1), rng.integers(0, rb, size=8191)

@@ -245,3 +245,63 @@ def test_bench_workload_defaults(monkeypatch):
     monkeypatch.setattr(sys, "argv", ["bench.py"])
     a = bench.parse()
     assert (a.workload, a.items, a.batch, a.num_neg, a.emb_size, a.gpus) == ("bprmf", 10_000_001, 65536, 99, 64, 1)
+
+
+def test_engine_auto_respects_the_models_rowwise_predicate(caplog):
+    """--engine auto: row-wise only when the tables are large AND the model's fused step supports the configuration
+    (a default SASRec --dropout 0.2 run on a large catalogue must take the dense path, not raise); the choice is logged"""
+    import logging
+    import torch
+    from helpers.BaseRunner import BaseRunner
+
+    class Big(torch.nn.Module):
+        def __init__(self, ok):
+            super().__init__()
+            self.t = torch.nn.Parameter(torch.empty((1 << 20) + 1, 1))
+            self.ok = ok
+
+        def hip_train_step(self, *a):
+            raise RuntimeError("unsupported configuration")
+
+        def hip_rowwise_supported(self):
+            return self.ok
+
+    def runner(engine):
+        r = BaseRunner.__new__(BaseRunner)
+        r.optimizer_name, r.engine = "Adam", engine
+        return r
+
+    with caplog.at_level(logging.INFO):
+        assert runner("auto")._use_rowwise(Big(True)) is True
+        assert runner("auto")._use_rowwise(Big(False)) is False
+        assert runner("rowwise")._use_rowwise(Big(False)) is True     # explicit request: hip_train_step raises later
+        assert runner("dense")._use_rowwise(Big(True)) is False
+    text = caplog.text
+    assert "Engine: row-wise updates" in text and "Engine: dense updates" in text
+    assert "no fused row-wise step" in text
+    small = torch.nn.Linear(4, 4)
+    small.hip_train_step = lambda *a: None
+    assert runner("auto")._use_rowwise(small) is False
+
+
+def test_context_models_get_the_reference_data_appendix(monkeypatch, tmp_path):
+    """reference main.py: readers named *Context* append _context<item><user><situation> to the corpus pickle / log /
+    model names, so runs with different --include_*_features never share a cached corpus"""
+    import main as plugin_main
+    seen = {}
+
+    class Stop(Exception):
+        pass
+
+    def fake_check_dir(path):
+        seen["log"] = path
+        raise Stop
+
+    monkeypatch.setattr(plugin_main.utils, "check_dir", fake_check_dir)
+    with pytest.raises(Stop):
+        plugin_main.run(["--model_name", "DeepFM", "--model_mode", "CTR", "--dataset", "d", "--include_item_features", "1",
+                         "--include_situation_features", "1", "--path", str(tmp_path) + "/"])
+    assert "d_context101" in seen["log"]
+    with pytest.raises(Stop):
+        plugin_main.run(["--model_name", "BPRMF", "--dataset", "d", "--path", str(tmp_path) + "/"])
+    assert "_context" not in seen["log"]
