@@ -260,7 +260,9 @@ __global__ __launch_bounds__(kBlock) void plan_final_kernel(PlanUpdArgs a, uint3
 template <int D, int MODE>
 static int launch_step_updates(const PlanUpdArgs& a, int64_t n_occ, hipStream_t s, hipEvent_t* ev_items_done) {
   const uint32_t cus = (uint32_t)device_cus();
-  const uint32_t blocks_main = cus * 8;
+  // grid-stride over the rows with 4x more workgroups than fit at once: a grid of exactly "8 per CU" ran in two
+  // rounds whenever the kernel's registers allowed only 7 (Adam: 72 VGPRs -> item update 2.05 instead of 1.5 ms)
+  const uint32_t blocks_main = cus * 32;
   const uint32_t blocks_other = 64;
   hipLaunchKernelGGL((plan_rows_kernel<D, MODE>), dim3(blocks_main + blocks_other), dim3(kBlock), 0, s, a, blocks_main, 0, 1);
   RC_LAUNCH_CHECK();

@@ -50,6 +50,28 @@ class HipEmbedding(nn.Module):
         return f"{self.num_embeddings}, {self.embedding_dim} [HIP]"
 
 
+def adopt_embeddings(model):
+    """Make an unmodified ReChorus model file run its table lookups on the HIP engine: every plain `nn.Embedding`
+    submodule (the reference defines all 88 of its tables that way, sparse=False, no padding_idx / max_norm) is
+    replaced by a `HipEmbedding` that SHARES its `weight` Parameter -- state_dict keys, init_weights, optimizer
+    parameter groups and checkpoints stay what the model file expects.  Returns the number of tables adopted;
+    embeddings with options HipEmbedding does not implement are left on torch."""
+    n = 0
+    for parent in list(model.modules()):
+        for name, child in list(parent.named_children()):
+            if type(child) is not nn.Embedding:
+                continue
+            if child.sparse or child.padding_idx is not None or child.max_norm is not None or child.scale_grad_by_freq:
+                continue
+            hip = HipEmbedding.__new__(HipEmbedding)
+            nn.Module.__init__(hip)
+            hip.num_embeddings, hip.embedding_dim = child.num_embeddings, child.embedding_dim
+            hip.weight = child.weight
+            setattr(parent, name, hip)
+            n += 1
+    return n
+
+
 class _BprmfScoreFn(torch.autograd.Function):
     """prediction[b,c] = <U[uid[b]], I[iid[b,c]]>  (models/general/BPRMF.py:39-42)."""
 

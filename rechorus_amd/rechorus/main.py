@@ -11,6 +11,7 @@ chosen model runs in librechorus_hip.so on the GPU.
 """
 import argparse
 import importlib
+import importlib.util
 import logging
 import os
 import pickle
@@ -47,6 +48,15 @@ def find_class(kind, name):
     if kind == 'helper':
         return getattr(importlib.import_module('helpers.' + name), name)
     base, mode = name
+    # user model files outside the package: directories listed in RECHORUS_MODEL_DIRS (os.pathsep separated), each
+    # holding <name>.py written against the reference's plugin surface (`from models.BaseModel import ...`)
+    for d in filter(None, os.environ.get('RECHORUS_MODEL_DIRS', '').split(os.pathsep)):
+        path = os.path.join(d, base + '.py')
+        if os.path.exists(path):
+            spec = importlib.util.spec_from_file_location('rechorus_user_models.' + base, path)
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+            return getattr(mod, base + mode)
     for pkg in MODEL_PACKAGES:
         try:
             mod = importlib.import_module('{}.{}'.format(pkg, base))
@@ -153,6 +163,10 @@ def run(argv=None):
         pickle.dump(corpus, open(corpus_path, 'wb'))
 
     model = model_cls(args, corpus).to(args.device)
+    from rechorus_amd import nn as hnn
+    adopted = hnn.adopt_embeddings(model)  # plain nn.Embedding tables of a model file written for the reference
+    if adopted:
+        logging.info('Adopted {} nn.Embedding table(s) onto the HIP engine'.format(adopted))
     logging.info('#params: {}'.format(model.count_variables()))
     logging.info(model)
 
