@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--pool", type=int, default=8, help="distinct pre-generated batches (cycled)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=5)
     ap.add_argument("--graph", action="store_true", help="replay each step from a captured hipGraph (small batches)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL (the only measurement mode); gloo only to smoke-test N>1 on one GPU")
@@ -168,13 +168,15 @@ def algorithmic_bytes(args, batches):
              + (us * row if fast_path else 0)   # single-occurrence item rows written back updated
              + 4 * n_occ + B * row + 4 * B)   # gpred, ugrad, loss_vec written
     upd_rows, upd_occ = (um, mo) if fast_path else (ui, float(n_occ))
-    item_update = (8 * n_occ            # keys + perm of every sorted position
-                   + 12 * upd_occ + 8 * B   # gpred + uid lookups of the rows updated here
+    item_update = (16 * upd_rows        # row records
+                   + 8 * upd_occ + 8 * B    # grouped positions, gpred + uid lookups of the rows updated here
                    + uu * row           # U rows rebuilt into g*U: distinct rows once
                    + 2 * (1 + n_state) * upd_rows * row)  # row (+ state rows): read + written once
-    user_update = 8 * B + B * row + 2 * (1 + n_state) * uu * row
-    sort_items = 8 * n_occ + 8 * n_occ  # ids in, keys+perm out (one ideal pass)
-    mark = 8 * n_occ + n_occ + 4 * um   # keys + perm in, one flag byte out, multi-row heads out
+    user_update = 16 * uu + 4 * B + B * row + 2 * (1 + n_state) * uu * row
+    # bucket plan: ids read by the count and by the scatter kernel, bucketed keys written; the bucket kernel reads
+    # them twice, writes the flag bytes of single-occurrence rows, the grouped positions and the row records
+    sort_items = 2 * 8 * (n_occ + B) + 8 * (n_occ + B)
+    mark = 2 * 8 * (n_occ + B) + (n_occ if fast_path else 0) + 4 * upd_occ + 16 * (upd_rows + uu)
     return {"fused_fwd_bwd": fused, "item_update": item_update, "user_update": user_update,
             "sort_items": sort_items, "segment_heads": mark, "uniq_items": ui, "uniq_users": uu,
             "single_items": us, "multi_items": um, "multi_item_occurrences": mo}
@@ -231,10 +233,98 @@ def cpu_baseline(args):
             break
     v = n / sum(steps)
     return {"value": v, "unit": "tuples/s", "cores": cores, "kind": "port",
+            "step_s": {"min": min(steps), "median": float(np.median(steps)), "max": max(steps)},
             "sample": f"{len(steps)} fit() iterations of oracle/torch_port.py (torch {torch.__version__} CPU, "
                       f"{cores} threads, dense grads + dense torch.optim.{args.opt} over all rows like the "
                       f"reference) at B={args.batch}, K={args.num_neg}, d={args.emb_size}, "
                       f"{args.items} items, {args.users} users; {sum(steps):.1f} s"}
+
+
+F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32-input MFMA = the fp32 vector rate
+
+
+def cpu_baseline_model(args, batches_cpu):
+    """NeuMF / SASRec: the torch-CPU ports of the reference's modules (oracle/torch_port.py, pinned against the
+    reference-generated goldens in tests/test_torch_ports.py), dense gradients and dense torch.optim like the
+    reference, a bounded number of fit() iterations on the host cores."""
+    from oracle import torch_port as TP
+    torch.manual_seed(0)
+    cores = torch.get_num_threads()
+    d = args.emb_size
+    if args.workload == "neumf":
+        table_bytes = 2 * (args.items + args.users) * d * 4
+        if table_bytes * 3 > 96e9:  # weights + dense gradients + optimizer traffic would not fit / finish on the host
+            return {"value": None, "unit": "tuples/s", "cores": cores, "kind": "port",
+                    "sample": f"skipped: {table_bytes / 1e9:.0f} GB of tables (dense gradient + dense optimizer on the host)"}
+        model = TP.NeumfTorchPort(args.users, args.items, d, layers=(args.hidden,))
+    else:
+        model = TP.SasrecTorchPort(args.items, d, args.hist, n_layers=args.layers, n_heads=args.heads)
+    optim = model.make_optimizer(args.opt, args.lr, args.l2)
+    steps, t_init = [], time.perf_counter()
+    for s, b in enumerate(batches_cpu):
+        t0 = time.perf_counter()
+        model.fit_step(optim, *b)
+        if s > 0:  # first step is warm-up
+            steps.append(time.perf_counter() - t0)
+        if time.perf_counter() - t_init > 60 and steps:
+            break
+    v = args.batch * len(steps) / sum(steps)
+    return {"value": v, "unit": "tuples/s", "cores": cores, "kind": "port",
+            "step_s": {"min": min(steps), "median": float(np.median(steps)), "max": max(steps)},
+            "sample": f"{len(steps)} fit() iterations of oracle/torch_port.py ({type(model).__name__}, torch {torch.__version__} CPU, "
+                      f"{cores} threads, dense grads + dense torch.optim.{args.opt} like the reference) at B={args.batch}, "
+                      f"K={args.num_neg}, d={d}, {args.items} items; {sum(steps):.1f} s"}
+
+
+def model_roofline(args, trainer, batches, engine):
+    """NeuMF / SASRec: live per-phase times (events on the launch stream) -> the dominant phase against its bound:
+    fp32 MFMA for the head / encoder kernels, HBM for the table update."""
+    trainer.timing = {}
+    for s in range(10):
+        trainer.step(*batches[s % len(batches)])
+    ph = engine.phases_ms(trainer)
+    trainer.timing = None
+    B, C, d = args.batch, args.num_neg + 1, args.emb_size
+    out = {"phases_ms": {k: round(v, 4) for k, v in ph.items()}}
+    if args.workload == "neumf":
+        l1 = args.hidden
+        fwd = B * C * (4.0 * d * l1 + 3 * d + 2 * l1)          # GEMM1 + GMF product + output dot
+        bwd = B * C * (12.0 * d * l1 + 6 * d + 4 * l1)         # recomputed GEMM1, dh0 = W1^T dz1, dW1 = dz1 h0^T
+        flops = {"head_fwd": fwd, "head_bwd": bwd}
+        # table update: per-occurrence gradient rows of the four tables read once, distinct rows read + written once
+        ui = float(np.mean([torch.unique(i).numel() for _, i in batches]))
+        uu = float(np.mean([torch.unique(u).numel() for u, _ in batches]))
+        n_state = {"SGD": 0, "Adagrad": 1, "Adam": 2}[args.opt]
+        upd_bytes = 2 * (2 * B * C) * d * 4 + 2 * (1 + n_state) * 2 * (ui + uu) * d * 4 + 2 * 8 * B * C
+        gather_bytes = {"head_fwd": (2 * B * C + 2 * B * C) * d * 4}
+    else:
+        L, nl = args.hist, args.layers
+        R = float(np.mean([int(l.sum()) for _, l, _ in batches]))        # valid history rows of a batch
+        sq = float(np.mean([int((l.to(torch.float64) ** 2).sum()) for _, l, _ in batches]))
+        fwd = nl * (R * (6.0 * d * d + 4.0 * d * d) + 2.0 * sq * d)       # QKV + FFN projections, causal QK^T + AV
+        flops = {"encoder_fwd": fwd, "encoder_bwd": 2.0 * fwd}
+        ids = [torch.cat([i.reshape(-1), h.reshape(-1)]) for h, _, i in batches]
+        ui = float(np.mean([torch.unique(x).numel() for x in ids]))
+        n_state = {"SGD": 0, "Adagrad": 1, "Adam": 2}[args.opt]
+        upd_bytes = 8 * (B * C + B * L) + R * d * 4 + 4 * B * C + 2 * (1 + n_state) * ui * d * 4
+        gather_bytes = {}
+    compute = {k: ph[k] for k in flops if k in ph}
+    dom = max(list(compute) + ["table_update"], key=lambda k: ph.get(k, 0.0))
+    if dom == "table_update":
+        ach = upd_bytes / (ph[dom] * 1e-3) / 1e9
+        out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                           "frac": ach / HBM_PEAK_GBPS, "traffic": None, "algorithmic_bytes_per_launch": upd_bytes,
+                           "avg_ms": ph[dom]}
+    else:
+        ach = flops[dom] / (ph[dom] * 1e-3) / 1e12
+        out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "frac": ach / F32_MFMA_PEAK_TFLOPS, "traffic": None, "algorithmic_flops_per_launch": flops[dom],
+                           "avg_ms": ph[dom]}
+    out["phases_tflops"] = {k: round(flops[k] / (ph[k] * 1e-3) / 1e12, 2) for k in flops if ph.get(k)}
+    out["table_update_gbps"] = round(upd_bytes / (ph["table_update"] * 1e-3) / 1e9, 1) if ph.get("table_update") else None
+    if gather_bytes.get("head_fwd") and ph.get("head_fwd"):
+        out["head_fwd_gather_gbps"] = round(gather_bytes["head_fwd"] / (ph["head_fwd"] * 1e-3) / 1e9, 1)
+    return out
 
 
 def main():
@@ -413,9 +503,19 @@ def main():
         trainer.timing = None
         if rank == 0:
             out["sharded_phases_ms"] = {k: round(v, 4) for k, v in acc.items()}
+    if world > 1 and rank == 0 and getattr(trainer, "wire", None):
+        # bytes rank 0 moved over the links in its last step (ids out, rows in, gradient rows out), after the
+        # per-destination de-duplication of the lookups (rechorus_amd/sharded.py::_Route)
+        out["sharded_wire_bytes_rank0"] = trainer.wire
+
+    if rank == 0 and world == 1 and not args.no_roofline and isinstance(trainer, (engine.NeumfTrainer, engine.SasrecTrainer)):
+        out.update(model_roofline(args, trainer, batches, engine))
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "bprmf":
         out["cpu_baseline"] = cpu_baseline(args)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload in ("neumf", "sasrec"):
+        n_cpu = args.cpu_steps + 1
+        out["cpu_baseline"] = cpu_baseline_model(args, [tuple(t.cpu() for t in batches[s % len(batches)]) for s in range(n_cpu)])
 
     if dist is not None:
         dist.barrier()

@@ -67,3 +67,135 @@ def time_port(n_users, n_items, emb_size, batches, opt="SGD", lr=1e-3, l2=0.0, s
         model.fit_step(optim, uid, iid)
         n += uid.shape[0]
     return time.perf_counter() - t0, n
+
+
+class NeumfTorchPort(nn.Module):
+    """NeuMF with the reference's module names (state_dict compatible) and operator sequence:
+    models/general/NeuMF.py:42-54 (parameters), :56-76 (forward); loss / optimizer as BprmfTorchPort."""
+
+    def __init__(self, n_users, n_items, emb_size, layers=(64,), dropout=0.0):
+        super().__init__()
+        self.mf_u_embeddings = nn.Embedding(n_users, emb_size)
+        self.mf_i_embeddings = nn.Embedding(n_items, emb_size)
+        self.mlp_u_embeddings = nn.Embedding(n_users, emb_size)
+        self.mlp_i_embeddings = nn.Embedding(n_items, emb_size)
+        self.mlp = nn.ModuleList()
+        pre = 2 * emb_size
+        for size in layers:
+            self.mlp.append(nn.Linear(pre, size))
+            pre = size
+        self.dropout_layer = nn.Dropout(p=dropout)
+        self.prediction = nn.Linear(pre + emb_size, 1, bias=False)
+        for m in self.modules():  # init_weights: normal(0, 0.01) for weights AND biases, models/BaseModel.py:29-35
+            if isinstance(m, (nn.Linear, nn.Embedding)):
+                nn.init.normal_(m.weight, mean=0.0, std=0.01)
+                if getattr(m, "bias", None) is not None:
+                    nn.init.normal_(m.bias, mean=0.0, std=0.01)
+
+    def forward(self, user_id, item_id):
+        u_ids = user_id.unsqueeze(-1).repeat((1, item_id.shape[1]))  # NeuMF.py:61
+        mf_u, mf_i = self.mf_u_embeddings(u_ids), self.mf_i_embeddings(item_id)
+        mlp_u, mlp_i = self.mlp_u_embeddings(u_ids), self.mlp_i_embeddings(item_id)
+        mf = mf_u * mf_i
+        h = torch.cat([mlp_u, mlp_i], dim=-1)
+        for layer in self.mlp:
+            h = self.dropout_layer(layer(h).relu())
+        return self.prediction(torch.cat([mf, h], dim=-1)).view(item_id.shape[0], -1)
+
+    loss = staticmethod(BprmfTorchPort.loss)
+
+    def make_optimizer(self, name, lr, l2):
+        # models/BaseModel.py:64-73: parameters whose NAME contains 'bias' get weight_decay 0
+        w = [p for n, p in self.named_parameters() if "bias" not in n]
+        b = [p for n, p in self.named_parameters() if "bias" in n]
+        return getattr(torch.optim, name)([{"params": w}, {"params": b, "weight_decay": 0}], lr=lr, weight_decay=l2)
+
+    def fit_step(self, optimizer, user_id, item_id):
+        optimizer.zero_grad()
+        loss = self.loss(self(user_id, item_id))
+        loss.backward()
+        optimizer.step()
+        return loss.detach()
+
+
+class _MultiHeadAttention(nn.Module):
+    """utils/layers.py:9-63 (kq_same False, no output projection, global-max shift before the row softmax, NaN -> 0)"""
+
+    def __init__(self, d_model, n_heads):
+        super().__init__()
+        self.d_model, self.h, self.d_k = d_model, n_heads, d_model // n_heads
+        self.q_linear = nn.Linear(d_model, d_model)
+        self.k_linear = nn.Linear(d_model, d_model)
+        self.v_linear = nn.Linear(d_model, d_model)
+
+    def _split(self, x):
+        return x.view(*x.size()[:-1], self.h, self.d_k).transpose(-2, -3)
+
+    def forward(self, q, k, v, mask):
+        shape = q.size()
+        q, k, v = self._split(self.q_linear(q)), self._split(self.k_linear(k)), self._split(self.v_linear(v))
+        scores = torch.matmul(q, k.transpose(-2, -1)) / self.d_k ** 0.5
+        scores = scores.masked_fill(mask == 0, -float("inf"))
+        scores = (scores - scores.max()).softmax(dim=-1)
+        scores = scores.masked_fill(torch.isnan(scores), 0)
+        return torch.matmul(scores, v).transpose(-2, -3).reshape(shape)
+
+
+class _TransformerLayer(nn.Module):
+    """utils/layers.py:92-118 (d_ff = d_model in SASRec, models/sequential/SASRec.py:46)"""
+
+    def __init__(self, d_model, d_ff, n_heads, dropout):
+        super().__init__()
+        self.masked_attn_head = _MultiHeadAttention(d_model, n_heads)
+        self.layer_norm1 = nn.LayerNorm(d_model)
+        self.dropout1 = nn.Dropout(dropout)
+        self.linear1 = nn.Linear(d_model, d_ff)
+        self.linear2 = nn.Linear(d_ff, d_model)
+        self.layer_norm2 = nn.LayerNorm(d_model)
+        self.dropout2 = nn.Dropout(dropout)
+
+    def forward(self, seq, mask):
+        context = self.masked_attn_head(seq, seq, seq, mask)
+        context = self.layer_norm1(self.dropout1(context) + seq)
+        out = self.linear2(self.linear1(context).relu())
+        return self.layer_norm2(self.dropout2(out) + context)
+
+
+class SasrecTorchPort(nn.Module):
+    """SASRec with the reference's module names and operator sequence: models/sequential/SASRec.py:36-49
+    (parameters), :51-86 (forward)."""
+
+    def __init__(self, n_items, emb_size, history_max, n_layers=1, n_heads=4, dropout=0.0):
+        super().__init__()
+        self.i_embeddings = nn.Embedding(n_items, emb_size)
+        self.p_embeddings = nn.Embedding(history_max + 1, emb_size)
+        self.transformer_block = nn.ModuleList(
+            [_TransformerLayer(emb_size, emb_size, n_heads, dropout) for _ in range(n_layers)])
+        for m in self.modules():
+            if isinstance(m, (nn.Linear, nn.Embedding)):
+                nn.init.normal_(m.weight, mean=0.0, std=0.01)
+                if getattr(m, "bias", None) is not None:
+                    nn.init.normal_(m.bias, mean=0.0, std=0.01)
+
+    def forward(self, history, lengths, item_id):
+        B, L = history.shape
+        valid = (history > 0).long()
+        his = self.i_embeddings(history)
+        position = (lengths[:, None] - torch.arange(L)[None, :]) * valid   # most recent = 1, padding = 0
+        his = his + self.p_embeddings(position)
+        mask = torch.tril(torch.ones((1, 1, L, L), dtype=torch.int64))
+        for block in self.transformer_block:
+            his = block(his, mask)
+        his = his * valid[:, :, None].float()
+        his_vector = his[torch.arange(B), lengths - 1]
+        return (his_vector[:, None, :] * self.i_embeddings(item_id)).sum(-1)
+
+    loss = staticmethod(BprmfTorchPort.loss)
+    make_optimizer = NeumfTorchPort.make_optimizer
+
+    def fit_step(self, optimizer, history, lengths, item_id):
+        optimizer.zero_grad()
+        loss = self.loss(self(history, lengths, item_id))
+        loss.backward()
+        optimizer.step()
+        return loss.detach()

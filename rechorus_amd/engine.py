@@ -434,6 +434,32 @@ def neumf_bwd(P, uid, iid, gpred, drop_p=0.0, seed=None):
     return rows, dense
 
 
+class _PhaseTimer:
+    """Optional per-phase timing of a trainer step with events on the launch stream (torch's current stream is the
+    stream every kernel of the step is enqueued on).  trainer.timing = {} switches it on; read with phases_ms()."""
+
+    def __init__(self, owner, name):
+        self.t = getattr(owner, "timing", None)
+        self.name = name
+
+    def __enter__(self):
+        if self.t is not None:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.a.record()
+
+    def __exit__(self, *exc):
+        if self.t is not None:
+            b = torch.cuda.Event(enable_timing=True)
+            b.record()
+            self.t.setdefault(self.name, []).append((self.a, b))
+
+
+def phases_ms(trainer):
+    """mean milliseconds per phase of the steps recorded since trainer.timing = {} (synchronises)"""
+    torch.cuda.synchronize()
+    return {k: sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in (trainer.timing or {}).items()}
+
+
 class NeumfTrainer:
     """One BaseRunner.fit iteration for NeuMF (single hidden layer) on device tensors:
     forward (MFMA) -> BPR loss -> backward (MFMA) -> row-wise segmented update of the four tables
@@ -461,18 +487,24 @@ class NeumfTrainer:
         self.step_count += 1
         if self.seed is not None:
             step_increment(self.seed)
-        pred = neumf_fwd(P, uid, iid, self.dropout, self.seed)
-        self.loss, _, gpred = bpr_loss(pred)
-        rows, dense = neumf_bwd(P, uid, iid, gpred, self.dropout, self.seed)
+        with _PhaseTimer(self, "head_fwd"):
+            pred = neumf_fwd(P, uid, iid, self.dropout, self.seed)
+        with _PhaseTimer(self, "loss"):
+            self.loss, _, gpred = bpr_loss(pred)
+        with _PhaseTimer(self, "head_bwd"):
+            rows, dense = neumf_bwd(P, uid, iid, gpred, self.dropout, self.seed)
         h = make_hyper(self.opt, lr=self.lr, l2=self.l2, step=self.step_count)
         h0 = make_hyper(self.opt, lr=self.lr, l2=0.0, step=self.step_count)  # 'bias' params: no weight decay
-        uid_occ = uid.repeat_interleave(Cn)
-        ku, pu = sort_ids(uid_occ, P["mf_u"].shape[0])
-        ki, pi = sort_ids(iid, P["mf_i"].shape[0])
-        # the mf / mlp tables of a side share ids: one sort, ONE head list and ONE update pass serve both
-        _, hu, nhu = segment_heads(ku, pu, want_single=False)
-        _, hi, nhi = segment_heads(ki, pi, want_single=False)
+        with _PhaseTimer(self, "sort"):
+            uid_occ = uid.repeat_interleave(Cn)
+            ku, pu = sort_ids(uid_occ, P["mf_u"].shape[0])
+            ki, pi = sort_ids(iid, P["mf_i"].shape[0])
+            # the mf / mlp tables of a side share ids: one sort, ONE head list and ONE update pass serve both
+            _, hu, nhu = segment_heads(ku, pu, want_single=False)
+            _, hi, nhi = segment_heads(ki, pi, want_single=False)
         pair_ok = segmented_pair_supported(P["mf_u"].shape[1])
+        _upd = _PhaseTimer(self, "table_update")
+        _upd.__enter__()
         for ta, tb, ga, gb, keys, perm, hd, nh in (("mf_u", "mlp_u", "g_mf_u", "g_mlp_u", ku, pu, hu, nhu),
                                                    ("mf_i", "mlp_i", "g_mf_i", "g_mlp_i", ki, pi, hi, nhi)):
             sa, sb = self.state[ta], self.state[tb]
@@ -493,8 +525,10 @@ class NeumfTrainer:
             if not self.rowwise:
                 dense_update(P[ta], G[0], h, sa.get("m"), sa.get("v"))
                 dense_update(P[tb], G[1], h, sb.get("m"), sb.get("v"))
-        dense_update_multi([(P[k], dense[k], h0 if k == "b1" else h, self.state[k].get("m"), self.state[k].get("v"))
-                            for k in ("W1", "b1", "w_out")], self.opt)
+        _upd.__exit__()
+        with _PhaseTimer(self, "dense_update"):
+            dense_update_multi([(P[k], dense[k], h0 if k == "b1" else h, self.state[k].get("m"), self.state[k].get("v"))
+                                for k in ("W1", "b1", "w_out")], self.opt)
         return self.loss
 
 
@@ -655,13 +689,18 @@ class SasrecTrainer:
         self.step_count += 1
         h = make_hyper(self.opt, lr=self.lr, l2=self.l2, step=self.step_count)
         h0 = make_hyper(self.opt, lr=self.lr, l2=0.0, step=self.step_count)
-        hv, xsave = sasrec_fwd(I, Pe, layers, self.n_heads, hist, lengths, save=True)
-        rows = torch.arange(B, device=hist.device)
-        pred = gather_dot(hv, I, rows, iid)                       # SASRec.py:80-81
-        self.loss, _, gpred = bpr_loss(pred)
-        dhv = weighted_row_sum(I, iid, gpred)
-        g_hist, dgrads = sasrec_bwd(layers, self.n_heads, lengths, xsave, dhv)
+        with _PhaseTimer(self, "encoder_fwd"):
+            hv, xsave = sasrec_fwd(I, Pe, layers, self.n_heads, hist, lengths, save=True)
+        with _PhaseTimer(self, "score_loss"):
+            rows = torch.arange(B, device=hist.device)
+            pred = gather_dot(hv, I, rows, iid)                       # SASRec.py:80-81
+            self.loss, _, gpred = bpr_loss(pred)
+            dhv = weighted_row_sum(I, iid, gpred)
+        with _PhaseTimer(self, "encoder_bwd"):
+            g_hist, dgrads = sasrec_bwd(layers, self.n_heads, lengths, xsave, dhv)
         # item table: candidate occurrences (g * hv, rebuilt on the fly) + history occurrences (g_hist rows)
+        _upd = _PhaseTimer(self, "table_update")
+        _upd.__enter__()
         ids = torch.cat([iid.reshape(-1), hist.reshape(-1)])
         keys, perm = sort_ids(ids, I.shape[0])
         st = self._st(I)
@@ -672,7 +711,10 @@ class SasrecTrainer:
             G = torch.zeros_like(I)
             segmented_update2(keys, perm, hv, g_hist.view(-1, d), B * Cn, coef=gpred.reshape(-1), div=Cn, dense_grad=G)
             dense_update(I, G, h, st.get("m"), st.get("v"))
+        _upd.__exit__()
         # position table (tiny): dense gradient, dense step
+        _dns = _PhaseTimer(self, "dense_update")
+        _dns.__enter__()
         Gp = sasrec_pos_grad(g_hist, lengths, Pe.shape[0])
         st = self._st(Pe)
         items = [(Pe, Gp, h, st.get("m"), st.get("v"))]
@@ -681,6 +723,7 @@ class SasrecTrainer:
                 st = self._st(lay[name])
                 items.append((lay[name], g[name].contiguous(), h0 if name in SAS_NO_DECAY else h, st.get("m"), st.get("v")))
         dense_update_multi(items, self.opt)  # position table + every block parameter: one launch
+        _dns.__exit__()
         return self.loss
 
 

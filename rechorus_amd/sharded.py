@@ -59,6 +59,10 @@ class HipOps:
             self.e.segmented_update(keys, perm, I_loc, coef=g, src_index=rows, div=1, dense_grad=out)
         return out
 
+    def sum_rows_by_index(self, rows, index, n_out):
+        """out[k] = sum of rows[p] over p with index[p] = k, in ascending p (atomic-free segmented sum)"""
+        return self.e.embedding_dense_backward(rows.contiguous(), index, n_out)
+
     def prepare_rows(self, rows, n_rows):
         """sort + head list of a row-id list, reusable by several update_rows calls on tables that share the ids"""
         if rows.numel() == 0:
@@ -552,16 +556,37 @@ class ShardedBprmf:
 # ---- "move the rows": generic row-sharded tables, used where a tuple touches few, wide rows (NeuMF) -------------
 
 class _Route:
-    """where the ids of one lookup live: send order, split sizes both ways, the rows the owner has to read"""
+    """where the ids of one lookup live: send order, split sizes both ways, the rows the owner has to read.
 
-    def __init__(self, ids, world, ops, group, grouped=None, splits=None):
-        order, counts, local = grouped if grouped is not None else self.group_by_owner(ids, world, ops)
+    dedup (default): only the DISTINCT ids of the lookup travel -- one row back per distinct id,
+    expanded to lookup order at home (rc_gather_rows by the inverse index), and one gradient row out per distinct id:
+    the per-position gradient rows are summed per id at home in a fixed order (the atomic-free segmented sum that
+    stands in for embedding_dense_backward) before they are pushed.  Under Zipf users / positives that is most of
+    the user-side traffic (27 K distinct of 65 K at the bench shape) and every repeated positive."""
+
+    def __init__(self, ids, world, ops, group, grouped=None, splits=None, dedup=True, prepared=None):
+        if prepared is None:
+            prepared = self.prepare(ids, world, ops, dedup) if grouped is None else (grouped, None, ids.numel())
+        (order, counts, local), self.inverse, self.n_lookup = prepared
         if splits is None:
             (self.send,), (self.recv,) = _exchange_counts([counts], group)
         else:  # split sizes exchanged by the caller together with those of other lookups (one host sync for all)
             self.send, self.recv = splits
         self.order, self.group = order, group
+        self.n_sent = int(order.numel())
+        rank = dist.get_rank(group)
+        self.remote_out = sum(self.send) - self.send[rank]   # ids this rank asks OTHER ranks for
+        self.remote_in = sum(self.recv) - self.recv[rank]    # rows this rank serves to other ranks
         self.req, _ = _exchange(local, self.send, group, recv_counts=self.recv)  # local rows this rank must serve
+
+    @staticmethod
+    def prepare(ids, world, ops, dedup=True):
+        """-> ((send order, per-owner counts, local rows in send order), inverse index | None, lookup length)"""
+        n = ids.numel()
+        inverse = None
+        if dedup:
+            ids, inverse = torch.unique(ids, return_inverse=True)
+        return _Route.group_by_owner(ids, world, ops), inverse, n
 
     @staticmethod
     def group_by_owner(ids, world, ops):
@@ -572,31 +597,41 @@ class _Route:
         order = torch.sort(owner, stable=True).indices
         return order, torch.bincount(owner, minlength=world), ids[order] // world
 
+    def _expand(self, back, ops):
+        out = torch.empty_like(back)
+        out[self.order] = back
+        return out if self.inverse is None else ops.gather_rows(out, self.inverse)
+
+    def _reduce(self, grads, ops):
+        if self.inverse is not None:
+            grads = ops.sum_rows_by_index(grads, self.inverse, self.n_sent)
+        return grads[self.order]
+
     def fetch_async(self, tables, ops):
         """fetch() whose rows-back transfer may stay in flight: -> _Pending; finish with rows_in_lookup_order()"""
         served = torch.cat([ops.gather_rows(T, self.req) for T in tables], dim=1)
         return _exchange_async(served, self.recv, self.send, self.group)
 
-    def rows_in_lookup_order(self, back):
-        out = torch.empty_like(back)
-        out[self.order] = back
-        return out
+    def rows_in_lookup_order(self, back, ops):
+        return self._expand(back, ops)
 
-    def push_async(self, grads):
-        return _exchange_async(grads[self.order], self.send, self.recv, self.group)
+    def push_async(self, grads, ops):
+        return _exchange_async(self._reduce(grads, ops), self.send, self.recv, self.group)
 
     def fetch(self, tables, ops):
         """rows of `tables` (this rank's shards, same row space) for the ids of the lookup, in lookup order"""
         served = torch.cat([ops.gather_rows(T, self.req) for T in tables], dim=1)
-        back = _exchange_back(served, self.recv, self.send, self.group)
-        out = torch.empty_like(back)
-        out[self.order] = back
-        return out
+        return self._expand(_exchange_back(served, self.recv, self.send, self.group), ops)
 
-    def push(self, grads):
-        """per-lookup-position gradient rows -> the owners, aligned with self.req"""
-        own, _ = _exchange(grads[self.order], self.send, self.group, recv_counts=self.recv)
+    def push(self, grads, ops):
+        """per-lookup-position gradient rows -> the owners, aligned with self.req (one row per id sent)"""
+        own, _ = _exchange(self._reduce(grads, ops), self.send, self.group, recv_counts=self.recv)
         return own
+
+    def wire_bytes(self, row_bytes):
+        """bytes this rank moves over the links for this lookup: ids out, rows in, gradient rows out"""
+        return {"ids_out": 8 * self.remote_out, "rows_in": row_bytes * self.remote_out, "grads_out": row_bytes * self.remote_out,
+                "rows_served_out": row_bytes * self.remote_in, "lookups": self.n_lookup, "ids_sent": self.n_sent}
 
 
 class ShardedNeumf:
@@ -612,8 +647,10 @@ class ShardedNeumf:
     TABLES = ("mf_u", "mlp_u", "mf_i", "mlp_i")
 
     def __init__(self, n_users, n_items, emb_size, hidden, opt="SGD", lr=1e-3, l2=0.0, device=None, ops=None,
-                 group=None, init_std=0.01, seed=0, micro_batches=1):
+                 group=None, init_std=0.01, seed=0, micro_batches=1, dedup=True):
         self.micro_batches = max(1, int(micro_batches))
+        self.dedup = bool(dedup)
+        self.wire = None  # {"ids_out", "rows_in", "grads_out", ...} bytes of the last step (this rank), W > 1
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -671,7 +708,11 @@ class ShardedNeumf:
             urows = torch.cat([ops.gather_rows(self.P[k], uid) for k in ("mf_u", "mlp_u")], dim=1)
             irows = torch.cat([ops.gather_rows(self.P[k], iid.reshape(-1)) for k in ("mf_i", "mlp_i")], dim=1)
         else:
-            ru, rv = _Route(uid, W, ops, self.group), _Route(iid.reshape(-1), W, ops, self.group)
+            pu_, pv_ = _Route.prepare(uid, W, ops, self.dedup), _Route.prepare(iid.reshape(-1), W, ops, self.dedup)
+            sends, recvs = _exchange_counts([pu_[0][1], pv_[0][1]], self.group)   # split sizes of both lookups: ONE host sync
+            ru = _Route(uid, W, ops, self.group, splits=(sends[0], recvs[0]), prepared=pu_)
+            rv = _Route(iid.reshape(-1), W, ops, self.group, splits=(sends[1], recvs[1]), prepared=pv_)
+            self._account([ru, rv])
             urows = ru.fetch([self.P["mf_u"], self.P["mlp_u"]], ops)      # [B, 2d]
             irows = rv.fetch([self.P["mf_i"], self.P["mlp_i"]], ops)      # [B*C, 2d]
         # the head kernels see per-batch row blocks as their "tables", ids are positions in them
@@ -688,7 +729,7 @@ class ShardedNeumf:
         gi = torch.cat([rows["g_mf_i"], rows["g_mlp_i"]], dim=1)
         if W > 1:
             loss = _all_reduce_sum(loss, self.group)
-            own_u, own_i, req_u, req_i = ru.push(gu), rv.push(gi), ru.req, rv.req
+            own_u, own_i, req_u, req_i = ru.push(gu, ops), rv.push(gi, ops), ru.req, rv.req
             flat = torch.cat([dense[k].reshape(-1) for k in ("W1", "b1", "w_out")])
             flat = _all_reduce_sum(flat, self.group)  # replicated MLP: summed gradients, identical step everywhere
             o = 0
@@ -713,6 +754,14 @@ class ShardedNeumf:
             ops.dense_update(self.P[k], dense[k].contiguous(), hyper0 if k == "b1" else hyper, self.state[k])
         return loss
 
+    def _account(self, routes):
+        """bytes over the links of this step (this rank): every route moves rows of two tables (mf + mlp), 2 d floats"""
+        tot = {}
+        for r in routes:
+            for k, v in r.wire_bytes(2 * self.d * 4).items():
+                tot[k] = tot.get(k, 0) + v
+        self.wire = tot
+
     def _step_pipelined(self, uid, iid, hyper, hyper0):
         """The same step with the local batch cut into `micro_batches` chunks: the row fetch of chunk k+1 and the
         gradient push of chunk k-1 are in flight (RCCL's stream) while the head kernels of chunk k run.  Every chunk
@@ -726,13 +775,13 @@ class ShardedNeumf:
         M = self.micro_batches
         uc, ic = torch.chunk(uid, M), torch.chunk(iid, M)
         M = len(uc)
-        grouped = [(_Route.group_by_owner(u, W, ops), _Route.group_by_owner(i.reshape(-1), W, ops)) for u, i in zip(uc, ic)]
-        sends, recvs = _exchange_counts([g[1] for pair in grouped for g in pair], group)
+        grouped = [(_Route.prepare(u, W, ops, self.dedup), _Route.prepare(i.reshape(-1), W, ops, self.dedup)) for u, i in zip(uc, ic)]
+        sends, recvs = _exchange_counts([g[0][1] for pair in grouped for g in pair], group)
         routes = []
 
         def start(k):  # routes of chunk k, its rows requested (transfers may stay in flight)
-            ru = _Route(uc[k], W, ops, group, grouped=grouped[k][0], splits=(sends[2 * k], recvs[2 * k]))
-            rv = _Route(ic[k].reshape(-1), W, ops, group, grouped=grouped[k][1], splits=(sends[2 * k + 1], recvs[2 * k + 1]))
+            ru = _Route(uc[k], W, ops, group, prepared=grouped[k][0], splits=(sends[2 * k], recvs[2 * k]))
+            rv = _Route(ic[k].reshape(-1), W, ops, group, prepared=grouped[k][1], splits=(sends[2 * k + 1], recvs[2 * k + 1]))
             routes.append((ru, rv, ru.fetch_async([self.P["mf_u"], self.P["mlp_u"]], ops),
                            rv.fetch_async([self.P["mf_i"], self.P["mlp_i"]], ops)))
 
@@ -743,7 +792,7 @@ class ShardedNeumf:
             if k + 1 < M:
                 start(k + 1)
             ru, rv, pu, pv = routes[k]
-            urows, irows = ru.rows_in_lookup_order(pu.wait()), rv.rows_in_lookup_order(pv.wait())
+            urows, irows = ru.rows_in_lookup_order(pu.wait(), ops), rv.rows_in_lookup_order(pv.wait(), ops)
             Bk = uc[k].shape[0]
             loc = {"mf_u": urows[:, :d].contiguous(), "mlp_u": urows[:, d:].contiguous(),
                    "mf_i": irows[:, :d].contiguous(), "mlp_i": irows[:, d:].contiguous(),
@@ -756,11 +805,12 @@ class ShardedNeumf:
             rows, dense = ops.neumf_bwd(loc, pos_u, pos_i, g)
             gu = torch.cat([rows["g_mf_u"].view(Bk, C, d).sum(dim=1), rows["g_mlp_u"].view(Bk, C, d).sum(dim=1)], dim=1)
             gi = torch.cat([rows["g_mf_i"], rows["g_mlp_i"]], dim=1)
-            pushes.append((ru.push_async(gu), rv.push_async(gi)))
+            pushes.append((ru.push_async(gu, ops), rv.push_async(gi, ops)))
             flat = torch.cat([dense[n].reshape(-1) for n in ("W1", "b1", "w_out")])
             dense_sum = flat if dense_sum is None else dense_sum + flat
         loss = _all_reduce_sum(loss, group)
         dense_sum = _all_reduce_sum(dense_sum, group)
+        self._account([r for pair in routes for r in pair[:2]])
         own_u = torch.cat([p[0].wait() for p in pushes])
         own_i = torch.cat([p[1].wait() for p in pushes])
         req_u = torch.cat([r[0].req for r in routes])

@@ -47,6 +47,11 @@ class OracleOps:
         st = {k: v.numpy() for k, v in state.items()}
         O.opt_step_dense(Wn, G, st, hyper["opt"], hyper["lr"], hyper["l2"], step=hyper["step"], rows=np.unique(r))
 
+    def sum_rows_by_index(self, rows, index, n_out):
+        out = np.zeros((n_out, rows.shape[1]), dtype=np.float32)
+        np.add.at(out, index.numpy(), rows.numpy())
+        return torch.from_numpy(out)
+
     def make_hyper(self, **kw):
         return kw
 
