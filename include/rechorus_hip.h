@@ -462,6 +462,28 @@ int rc_bucket_plan(const int64_t* ids_a, int64_t n_a, int64_t range_a, const int
                    uint32_t* n_rows_a, rc_plan_row* rows_b, uint32_t* n_rows_b, uint32_t* occ, void* ws,
                    size_t ws_bytes, rc_stream_t stream);
 
+/* Optimizer row update of the rows listed by a plan (csrc/plan_update.hip): per row, the gradient rows of its
+ * occurrences are summed in ascending batch position (fixed order, no float atomics), the table row is read once,
+ * updated by `h` (row-wise: only listed rows move) and written once; rows with more than 32 occurrences go
+ * through 256-occurrence chunks.  Same semantics and arguments as rc_segmented_update2 (which it replaces where a
+ * plan exists): the gradient row of the occurrence at position o = occ[slot] is
+ *   o <  n_split:  coef[o] * src[src_index ? src_index[o / div] : o / div]     (coef NULL = 1)
+ *   o >= n_split:  src2[o - n_split]
+ * n_occ = length of occ[] (sizes the hot-row scratch).  d in {16, 32, 64, 128, 256}.                          */
+size_t rc_plan_update_workspace_bytes(int64_t n_occ, int d);
+int rc_plan_update(float* W, float* m, float* v, int d, const rc_plan_row* rows, const uint32_t* n_rows,
+                   const uint32_t* occ, int64_t n_occ, const float* coef, const float* src, const int64_t* src_index,
+                   int div, const float* src2, int64_t n_split, const rc_opt_hyper* h, void* ws, size_t ws_bytes,
+                   rc_stream_t stream);
+
+/* Two tables that share their ids (NeuMF's mf / mlp embedding of a side, models/general/NeuMF.py:37-40) updated in
+ * ONE pass over the plan: per-occurrence gradient rows src_a / src_b [*, d], the occurrence at position o reads row
+ * o - occ_base of both.  Workspace: rc_plan_update_workspace_bytes(n_occ, 2 d).  d in {8, 16, 32, 64, 128}.      */
+int rc_plan_update_pair(float* W_a, float* m_a, float* v_a, float* W_b, float* m_b, float* v_b, int d,
+                        const rc_plan_row* rows, const uint32_t* n_rows, const uint32_t* occ, int64_t n_occ,
+                        const float* src_a, const float* src_b, int64_t occ_base, const rc_opt_hyper* h, void* ws,
+                        size_t ws_bytes, rc_stream_t stream);
+
 size_t rc_bprmf_step_workspace_bytes(int B, int C, int d);
 
 /* Which grouping pipeline rc_bprmf_train_step uses: 0 = automatic (bucket plan where supported), 1 = always

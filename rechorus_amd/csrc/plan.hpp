@@ -69,6 +69,10 @@ struct PlanGrad {
   int div;
   const float* src2;
   uint32_t n_split;
+  // pair mode (two tables of width D/2 that share their ids, e.g. NeuMF's mf / mlp embedding of a side): the row of
+  // width D is [table a | table b]; lanes of the lower half read src2 / update table a, the upper half src2b / table b
+  const float* src2b;
+  int pair;
 };
 
 struct PlanLongRow { uint32_t row, start, n, cbase, nchunks, side, pad0, pad1; };

@@ -19,6 +19,7 @@ namespace rc {
 
 struct PlanSide {       // one table and how the gradient rows of its occurrences are obtained
   PlanTable t;
+  PlanTable tb;         // pair mode: the second table
   PlanGrad g;
   const rc_plan_row* rows;
   const uint32_t* n_rows;
@@ -46,6 +47,11 @@ template <int D>
 __device__ __forceinline__ float4 plan_grad4(const PlanGrad& s, const uint32_t* __restrict__ occ, uint32_t slot, int l) {
   constexpr int LPR = D / 4;
   const uint32_t o = occ[slot];
+  if (s.pair) {  // kernel-uniform
+    constexpr int H = LPR / 2;
+    const bool up = l >= H;
+    return reinterpret_cast<const float4*>(up ? s.src2b : s.src2)[(size_t)(o - s.n_split) * H + (up ? l - H : l)];
+  }
   if (o >= s.n_split) return reinterpret_cast<const float4*>(s.src2)[(size_t)(o - s.n_split) * LPR + l];
   int64_t sr = (s.div == 1) ? (int64_t)o : (int64_t)(o / (uint32_t)s.div);
   if (s.src_index) sr = s.src_index[sr];
@@ -53,6 +59,20 @@ __device__ __forceinline__ float4 plan_grad4(const PlanGrad& s, const uint32_t* 
   float4 v = reinterpret_cast<const float4*>(s.src)[(size_t)sr * LPR + l];
   v.x *= c; v.y *= c; v.z *= c; v.w *= c;
   return v;
+}
+
+// the table (and float4 slot) a lane works on: the side's table, or in pair mode table a / b by lane half
+template <int D>
+__device__ __forceinline__ PlanTable plan_lane_table(const PlanSide& sd, uint32_t row, int l, size_t& idx4) {
+  constexpr int LPR = D / 4;
+  if (!sd.g.pair) {
+    idx4 = (size_t)row * LPR + l;
+    return sd.t;
+  }
+  constexpr int H = LPR / 2;
+  const bool up = l >= H;
+  idx4 = (size_t)row * H + (up ? l - H : l);
+  return up ? sd.tb : sd.t;
 }
 
 // hot row: chunk records for plan_chunk_kernel / plan_final_kernel (lane-group cooperative, l = lane in group)
@@ -104,9 +124,13 @@ __device__ __forceinline__ void plan_rows_body(const PlanUpdArgs& a, int side, b
       act[h] = g0 + h < nr && e[h].n <= (uint32_t)kPlanLongSeg;
     }
     float4 w[H], acc[H], s1[H];
+    PlanTable tab[H];
+    size_t idx4[H];
+#pragma unroll
+    for (int h = 0; h < H; ++h) tab[h] = plan_lane_table<D>(sd, e[h].row, l, idx4[h]);
 #pragma unroll
     for (int h = 0; h < H; ++h)
-      if (act[h]) w[h] = load_stream4(reinterpret_cast<const float4*>(sd.t.W) + (size_t)e[h].row * LPR + l);
+      if (act[h]) w[h] = load_stream4(reinterpret_cast<const float4*>(tab[h].W) + idx4[h]);
 #pragma unroll
     for (int h = 0; h < H; ++h)
       if (act[h]) acc[h] = plan_grad4<D>(sd.g, a.occ, e[h].start, l);
@@ -122,7 +146,7 @@ __device__ __forceinline__ void plan_rows_body(const PlanUpdArgs& a, int side, b
       }
       if (e[h].n > 1) padd4(acc[h], s1[h]);
       for (uint32_t k = 2; k < e[h].n; ++k) padd4(acc[h], plan_grad4<D>(sd.g, a.occ, e[h].start + k, l));
-      opt_row4<MODE>(a.o, sd.t.W, sd.t.M, sd.t.V, (size_t)e[h].row * LPR + l, w[h], acc[h]);
+      opt_row4<MODE>(a.o, tab[h].W, tab[h].M, tab[h].V, idx4[h], w[h], acc[h]);
     }
   }
 }
@@ -224,8 +248,8 @@ __global__ __launch_bounds__(kBlock) void plan_final_kernel(PlanUpdArgs a, uint3
       part[threadIdx.x] = acc;
       plan_tree_sum<LPR>(part, g);
       if (g == 0) {
-        const PlanTable& t = a.side[r.side].t;
-        const size_t idx = (size_t)r.row * LPR + l;
+        size_t idx;
+        const PlanTable t = plan_lane_table<D>(a.side[r.side], r.row, l, idx);
         opt_row4<MODE>(a.o, t.W, t.M, t.V, idx, load_stream4(reinterpret_cast<const float4*>(t.W) + idx), part[threadIdx.x]);
       }
       __syncthreads();
@@ -255,6 +279,34 @@ __global__ __launch_bounds__(kBlock) void plan_final_kernel(PlanUpdArgs a, uint3
     __syncthreads();
   }
   if (threadIdx.x == 0) a.loss_out[0] = sm[0] * a.loss_scale;
+}
+
+// one table (or table pair) updated from its row list: rows, chunks of hot rows, hot rows
+template <int D, int MODE>
+static int launch_side_update(const PlanUpdArgs& a, int64_t n_occ, hipStream_t s) {
+  const uint32_t cus = (uint32_t)device_cus();
+  const uint32_t blocks_main = cus * 32;
+  hipLaunchKernelGGL((plan_rows_kernel<D, MODE>), dim3(blocks_main), dim3(kBlock), 0, s, a, blocks_main, 0, 0);
+  RC_LAUNCH_CHECK();
+  if (n_occ > kPlanLongSeg) {
+    hipLaunchKernelGGL((plan_chunk_kernel<D>), dim3(1024), dim3(kBlock), 0, s, a);
+    RC_LAUNCH_CHECK();
+    hipLaunchKernelGGL((plan_final_kernel<D, MODE>), dim3(256 + 1), dim3(kBlock), 0, s, a, 0u, 256u, -1);
+    RC_LAUNCH_CHECK();
+  }
+  return RC_OK;
+}
+
+template <int MODE>
+static int launch_side_update_d(const PlanUpdArgs& a, int d, int64_t n_occ, hipStream_t s) {
+  switch (d) {
+    case 16: return launch_side_update<16, MODE>(a, n_occ, s);
+    case 32: return launch_side_update<32, MODE>(a, n_occ, s);
+    case 64: return launch_side_update<64, MODE>(a, n_occ, s);
+    case 128: return launch_side_update<128, MODE>(a, n_occ, s);
+    case 256: return launch_side_update<256, MODE>(a, n_occ, s);
+    default: return fail(RC_ERR_UNSUPPORTED, "rc_plan_update: row width %d floats (16/32/64/128/256)", d);
+  }
 }
 
 template <int D, int MODE>
@@ -306,11 +358,11 @@ int plan_bprmf_step_updates(float* U, float* mU, float* vU, float* I, float* mI,
   RC_REQUIRE(mode != MODE_ADAM || (mU && vU && mI && vI), "rc_bprmf_train_step: Adam needs m and v tables");
   RC_REQUIRE(mode != MODE_ADAGRAD || (mU && mI), "rc_bprmf_train_step: Adagrad needs the state_sum tables");
   a.side[0].t = PlanTable{I, mI, vI};
-  a.side[0].g = PlanGrad{gpred, U, uid, C, nullptr, 0xFFFFFFFFu};
+  a.side[0].g = PlanGrad{gpred, U, uid, C, nullptr, 0xFFFFFFFFu, nullptr, 0};
   a.side[0].rows = rows_i;
   a.side[0].n_rows = n_rows_i;
   a.side[1].t = PlanTable{U, mU, vU};
-  a.side[1].g = PlanGrad{nullptr, nullptr, nullptr, 1, ugrad, (uint32_t)n_i};  // user occurrence p = n_i + b -> ugrad[b]
+  a.side[1].g = PlanGrad{nullptr, nullptr, nullptr, 1, ugrad, (uint32_t)n_i, nullptr, 0};  // user occurrence p = n_i + b -> ugrad[b]
   a.side[1].rows = rows_u;
   a.side[1].n_rows = n_rows_u;
   a.occ = occ;
@@ -328,3 +380,92 @@ int plan_bprmf_step_updates(float* U, float* mU, float* vU, float* I, float* mI,
 }
 
 }  // namespace rc
+
+using namespace rc;
+
+namespace {
+struct UpdWs {
+  uint32_t* counters;
+  PlanLongWs lw;
+  size_t total;
+};
+UpdWs carve_upd_ws(void* base, int64_t n_occ, int d) {
+  Carver cv(base);
+  UpdWs w;
+  w.counters = cv.take<uint32_t>(PC_N);
+  const PlanLongWs lw = carve_plan_long_ws(base ? reinterpret_cast<char*>(base) + cv.off : nullptr, n_occ, d);
+  w.lw = lw;
+  w.total = cv.off + lw.total;
+  return w;
+}
+
+int run_side_update(PlanUpdArgs& a, const rc_opt_hyper* h, int d_eff, int64_t n_occ, void* ws, size_t ws_bytes,
+                    rc_stream_t stream, const char* who) {
+  const UpdWs w = carve_upd_ws(ws, n_occ, d_eff);
+  if (ws_bytes < w.total) return fail(RC_ERR_WORKSPACE, "%s: workspace %zu < %zu", who, ws_bytes, w.total);
+  RC_TRY(fill_opt_scalars(h, &a.o));
+  a.counters = w.counters;
+  a.lw = w.lw;
+  hipStream_t s = as_stream(stream);
+  RC_HIP(hipMemsetAsync(w.counters, 0, PC_N * sizeof(uint32_t), s));
+  switch (mode_of(h)) {
+    case MODE_SGD: return launch_side_update_d<MODE_SGD>(a, d_eff, n_occ, s);
+    case MODE_ADAM: return launch_side_update_d<MODE_ADAM>(a, d_eff, n_occ, s);
+    default: return launch_side_update_d<MODE_ADAGRAD>(a, d_eff, n_occ, s);
+  }
+}
+bool al16(const void* p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; }
+}  // namespace
+
+extern "C" size_t rc_plan_update_workspace_bytes(int64_t n_occ, int d) {
+  if (n_occ < 1) n_occ = 1;
+  if (d < 1) d = 1;
+  return carve_upd_ws(nullptr, n_occ, d).total;
+}
+
+extern "C" int rc_plan_update(float* W, float* m, float* v, int d, const rc_plan_row* rows, const uint32_t* n_rows,
+                              const uint32_t* occ, int64_t n_occ, const float* coef, const float* src,
+                              const int64_t* src_index, int div, const float* src2, int64_t n_split,
+                              const rc_opt_hyper* h, void* ws, size_t ws_bytes, rc_stream_t stream) {
+  if (n_occ == 0) return RC_OK;
+  RC_REQUIRE(W && rows && n_rows && occ && h && ws, "rc_plan_update: null pointer");
+  RC_REQUIRE(n_occ > 0 && n_occ < ((int64_t)1 << 31) && div >= 1 && n_split >= 0 && n_split <= n_occ,
+             "rc_plan_update: bad sizes n_occ=%lld div=%d n_split=%lld", (long long)n_occ, div, (long long)n_split);
+  RC_REQUIRE(src || src2, "rc_plan_update: gradient source missing (src for positions < n_split, src2 for the others)");
+  RC_REQUIRE(mode_of(h) != MODE_ADAM || (m && v), "rc_plan_update: Adam needs m and v");
+  RC_REQUIRE(mode_of(h) != MODE_ADAGRAD || m, "rc_plan_update: Adagrad needs m (state_sum)");
+  RC_REQUIRE(al16(W) && al16(m) && al16(v) && al16(src) && al16(src2), "rc_plan_update: buffers must be 16-byte aligned");
+  PlanUpdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.side[0].t = PlanTable{W, m, v};
+  a.side[0].g = PlanGrad{coef, src, src_index, div, src2, (uint32_t)n_split, nullptr, 0};
+  a.side[0].rows = rows;
+  a.side[0].n_rows = n_rows;
+  a.occ = occ;
+  return run_side_update(a, h, d, n_occ, ws, ws_bytes, stream, "rc_plan_update");
+}
+
+extern "C" int rc_plan_update_pair(float* W_a, float* m_a, float* v_a, float* W_b, float* m_b, float* v_b, int d,
+                                   const rc_plan_row* rows, const uint32_t* n_rows, const uint32_t* occ, int64_t n_occ,
+                                   const float* src_a, const float* src_b, int64_t occ_base, const rc_opt_hyper* h,
+                                   void* ws, size_t ws_bytes, rc_stream_t stream) {
+  if (n_occ == 0) return RC_OK;
+  RC_REQUIRE(W_a && W_b && rows && n_rows && occ && src_a && src_b && h && ws, "rc_plan_update_pair: null pointer");
+  RC_REQUIRE(n_occ > 0 && n_occ < ((int64_t)1 << 31) && occ_base >= 0 && occ_base < ((int64_t)1 << 31),
+             "rc_plan_update_pair: bad sizes");
+  RC_REQUIRE(mode_of(h) != MODE_ADAM || (m_a && v_a && m_b && v_b), "rc_plan_update_pair: Adam needs m and v");
+  RC_REQUIRE(mode_of(h) != MODE_ADAGRAD || (m_a && m_b), "rc_plan_update_pair: Adagrad needs m (state_sum)");
+  RC_REQUIRE(al16(W_a) && al16(W_b) && al16(m_a) && al16(m_b) && al16(v_a) && al16(v_b) && al16(src_a) && al16(src_b),
+             "rc_plan_update_pair: buffers must be 16-byte aligned");
+  if (d != 8 && d != 16 && d != 32 && d != 64 && d != 128)
+    return fail(RC_ERR_UNSUPPORTED, "rc_plan_update_pair: d=%d (2 d must be 16/32/64/128/256)", d);
+  PlanUpdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.side[0].t = PlanTable{W_a, m_a, v_a};
+  a.side[0].tb = PlanTable{W_b, m_b, v_b};
+  a.side[0].g = PlanGrad{nullptr, nullptr, nullptr, 1, src_a, (uint32_t)occ_base, src_b, 1};
+  a.side[0].rows = rows;
+  a.side[0].n_rows = n_rows;
+  a.occ = occ;
+  return run_side_update(a, h, 2 * d, n_occ, ws, ws_bytes, stream, "rc_plan_update_pair");
+}

@@ -188,6 +188,68 @@ def bucket_plan(ids_a, range_a, ids_b=None, range_b=0, list_single_a=True):
             "single": None if single is None else single[:n_a]}
 
 
+class Plan:
+    """Device-side result of rc_bucket_plan with every distinct row listed (no host round trip: the row counts stay in
+    device memory and the consumers read them there).  Buffers are cached per (device, tag) and reused every step."""
+
+    def __init__(self, ids_a, range_a, ids_b=None, range_b=0, tag="plan"):
+        a = ids_a.reshape(-1)
+        b = ids_b.reshape(-1) if ids_b is not None else None
+        dev = a.device
+        self.n_a, self.n_b = a.numel(), (b.numel() if b is not None else 0)
+        lib = _lib.load()
+        if not lib.rc_bucket_plan_supported(self.n_a, self.n_b, int(range_a), int(range_b)):
+            raise _lib.RechorusHipError("rc_bucket_plan_supported", -4, "id ranges too wide for one bucket level")
+        n = self.n_a + self.n_b
+        na16, nb16 = 16 * max(self.n_a, 1), 16 * max(self.n_b, 1)
+        r256 = lambda x: (x + 255) // 256 * 256
+        o_b = r256(na16)
+        o_occ = o_b + r256(nb16)
+        o_cnt = o_occ + r256(4 * max(n, 1))
+        buf = workspace(o_cnt + 256, dev, tag + ".out")
+        self.rows_a, self.rows_b = buf[:na16], buf[o_b:o_b + nb16]
+        self.occ, self.cnt = buf[o_occ:o_occ + 4 * max(n, 1)], buf[o_cnt:o_cnt + 8]
+        ws = workspace(lib.rc_bucket_plan_workspace_bytes(self.n_a, self.n_b), dev, tag + ".ws")
+        p = lambda t: C.c_void_p(t.data_ptr())
+        _lib.call("rc_bucket_plan", _ptr(a, torch.int64, "ids_a") if self.n_a else None, self.n_a, int(range_a),
+                  _ptr(b, torch.int64, "ids_b") if self.n_b else None, self.n_b, int(range_b), 1, None,
+                  p(self.rows_a), p(self.cnt), p(self.rows_b), p(self.cnt[4:]), p(self.occ), p(ws), ws.numel(), _stream())
+
+    def _side(self, side):
+        return (self.rows_a, self.cnt, 0) if side == "a" else (self.rows_b, self.cnt[4:], self.n_a)
+
+    def update_pair(self, side, Wa, Wb, src_a, src_b, hyper, ma=None, va=None, mb=None, vb=None):
+        """rc_plan_update_pair on list `side` ('a' | 'b'): two tables sharing the ids, per-occurrence gradient rows"""
+        d = Wa.shape[1]
+        n = self.n_a + self.n_b
+        rows, cnt, base = self._side(side)
+        ws = workspace(_lib.load().rc_plan_update_workspace_bytes(n, 2 * d), Wa.device, "plan.upd")
+        f32 = torch.float32
+        p = lambda t: C.c_void_p(t.data_ptr())
+        _lib.call("rc_plan_update_pair", _ptr(Wa, f32, "W_a"), _ptr(ma, f32, "m_a", True), _ptr(va, f32, "v_a", True),
+                  _ptr(Wb, f32, "W_b"), _ptr(mb, f32, "m_b", True), _ptr(vb, f32, "v_b", True), d, p(rows), p(cnt), p(self.occ), n,
+                  _ptr(src_a, f32, "src_a"), _ptr(src_b, f32, "src_b"), base, C.byref(hyper), p(ws), ws.numel(), _stream())
+
+    def update(self, side, W, hyper, m=None, v=None, coef=None, src=None, src_index=None, div=1, src2=None, n_split=None):
+        """rc_plan_update on list `side`: gradient sources as in segmented_update2 (positions of list b start at n_a)"""
+        d = W.shape[1]
+        n = self.n_a + self.n_b
+        rows, cnt, _ = self._side(side)
+        if n_split is None:
+            n_split = n if src2 is None else 0
+        ws = workspace(_lib.load().rc_plan_update_workspace_bytes(n, d), W.device, "plan.upd")
+        f32 = torch.float32
+        p = lambda t: C.c_void_p(t.data_ptr())
+        _lib.call("rc_plan_update", _ptr(W, f32, "W"), _ptr(m, f32, "m", True), _ptr(v, f32, "v", True), d, p(rows), p(cnt),
+                  p(self.occ), n, _ptr(coef, f32, "coef", True), _ptr(src, f32, "src", True),
+                  _ptr(src_index, torch.int64, "src_index", True), int(div), _ptr(src2, f32, "src2", True), int(n_split),
+                  C.byref(hyper), p(ws), ws.numel(), _stream())
+
+
+def plan_supported(n_a, n_b, range_a, range_b):
+    return bool(_lib.load().rc_bucket_plan_supported(int(n_a), int(n_b), int(range_a), int(range_b)))
+
+
 def segment_heads(keys, perm, only_multi=False, want_single=True, want_heads=True):
     """One pass over sorted ids -> (single uint8[n]|None, heads int32[n]|None, n_heads int32[1]|None)."""
     n = keys.numel()
@@ -495,6 +557,9 @@ class NeumfTrainer:
             rows, dense = neumf_bwd(P, uid, iid, gpred, self.dropout, self.seed)
         h = make_hyper(self.opt, lr=self.lr, l2=self.l2, step=self.step_count)
         h0 = make_hyper(self.opt, lr=self.lr, l2=0.0, step=self.step_count)  # 'bias' params: no weight decay
+        # (a bucket plan + rc_plan_update_pair was measured here at the config-4 shape: 0.70 ms for plan + updates against
+        #  0.69 ms for the two sorts + pair updates -- 0.65 M keys spread over an 11 M-id space leave ~490 keys per bucket,
+        #  and the plan's per-bucket fixed cost (LDS table of 8,192 ids zeroed and scanned) dominates; kept on the sort path)
         with _PhaseTimer(self, "sort"):
             uid_occ = uid.repeat_interleave(Cn)
             ku, pu = sort_ids(uid_occ, P["mf_u"].shape[0])

@@ -126,3 +126,57 @@ def test_train_step_plan_pipeline_equals_sort_pipeline(opt, lr, l2, d, B, C, n_u
             continue
         assert torch.equal(x, y), f"{name}: {int((x != y).sum())} elements differ, max |diff| {(x - y).abs().max().item():.3e}"
     assert not torch.equal(res[0][1], torch.from_numpy(I0).to(cuda))
+
+
+@pytest.mark.parametrize("opt,lr,l2", [("SGD", 0.05, 1e-3), ("Adam", 1e-3, 1e-4), ("Adagrad", 0.01, 1e-4)])
+@pytest.mark.parametrize("d", [16, 64, 128])
+def test_plan_update_matches_the_rowwise_oracle(opt, lr, l2, d, cuda, eng):
+    """rc_plan_update / rc_plan_update_pair (generic plan-driven row updates, hot rows included) vs the numpy oracle:
+    index_add of the per-occurrence gradient rows, then the optimizer on the touched rows"""
+    from conftest import assert_update_close
+    from oracle import bprmf_oracle as O
+    rng = np.random.default_rng(d)
+    n_rows, n_src, n_a, n_b, div = 3000, 50, 20_000, 700, 4
+    ids_a = np.minimum(rng.zipf(1.3, size=n_a), n_rows - 1).astype(np.int64)   # hot rows: thousands of occurrences
+    ids_b = rng.integers(0, 40, size=n_b).astype(np.int64)
+    plan = eng.Plan(torch.from_numpy(ids_a).to(cuda), n_rows, torch.from_numpy(ids_b).to(cuda), 40, tag="test.plan")
+    h = eng.make_hyper(opt, lr=lr, l2=l2, step=2)
+    mk = lambda *s: rng.normal(0, 0.1, size=s).astype(np.float32)
+    ex = 1e-3 * lr if opt != "SGD" else 0.0
+
+    def state(W):
+        st = O.new_state(W, opt)
+        for k in st:
+            st[k] += np.float32(1e-3)
+        return st, {k: torch.from_numpy(v.copy()).to(cuda) for k, v in st.items()}
+
+    # (1) list a, gradient rows rebuilt as coef[o] * src[src_index[o // div]]
+    W0, src, coef = mk(n_rows, d), mk(n_src, d), mk(n_a)
+    src_index = rng.integers(0, n_src, size=(n_a + div - 1) // div).astype(np.int64)
+    st, st_d = state(W0)
+    W = torch.from_numpy(W0.copy()).to(cuda)
+    plan.update("a", W, h, m=st_d.get("m"), v=st_d.get("v"), coef=torch.from_numpy(coef).to(cuda), src=torch.from_numpy(src).to(cuda),
+                src_index=torch.from_numpy(src_index).to(cuda), div=div)
+    Wn = W0.copy()
+    G = O.embedding_dense_backward(coef[:, None] * src[src_index[np.arange(n_a) // div]], ids_a, n_rows)
+    O.opt_step_dense(Wn, G, st, opt, lr, l2, step=2, rows=np.unique(ids_a))
+    assert_update_close(W.cpu().numpy(), W0, Wn, what="plan.update list a", extra_atol=ex)
+    # (2) list b, plain per-occurrence rows (positions of list b start at n_a)
+    Wb0, gb = mk(40, d), mk(n_b, d)
+    st, st_d = state(Wb0)
+    Wb = torch.from_numpy(Wb0.copy()).to(cuda)
+    plan.update("b", Wb, h, m=st_d.get("m"), v=st_d.get("v"), src2=torch.from_numpy(gb).to(cuda), n_split=n_a)
+    Wn = Wb0.copy()
+    O.opt_step_dense(Wn, O.embedding_dense_backward(gb, ids_b, 40), st, opt, lr, l2, step=2, rows=np.unique(ids_b))
+    assert_update_close(Wb.cpu().numpy(), Wb0, Wn, what="plan.update list b", extra_atol=ex)
+    # (3) two tables that share list a's ids, one pass
+    Wa0, Wc0, ga, gc = mk(n_rows, d), mk(n_rows, d), mk(n_a, d), mk(n_a, d)
+    sa, sa_d = state(Wa0)
+    sc, sc_d = state(Wc0)
+    Wa, Wc = torch.from_numpy(Wa0.copy()).to(cuda), torch.from_numpy(Wc0.copy()).to(cuda)
+    plan.update_pair("a", Wa, Wc, torch.from_numpy(ga).to(cuda), torch.from_numpy(gc).to(cuda), h, ma=sa_d.get("m"),
+                     va=sa_d.get("v"), mb=sc_d.get("m"), vb=sc_d.get("v"))
+    for W_, W0_, g_, st_ in ((Wa, Wa0, ga, sa), (Wc, Wc0, gc, sc)):
+        Wn = W0_.copy()
+        O.opt_step_dense(Wn, O.embedding_dense_backward(g_, ids_a, n_rows), st_, opt, lr, l2, step=2, rows=np.unique(ids_a))
+        assert_update_close(W_.cpu().numpy(), W0_, Wn, what="plan.update_pair", extra_atol=ex)
