@@ -43,7 +43,9 @@ enum rc_status {
 enum rc_opt {
   RC_OPT_SGD = 0,     /* torch.optim.SGD, no momentum                                 */
   RC_OPT_ADAM = 1,    /* torch.optim.Adam (amsgrad off)                               */
-  RC_OPT_ADAGRAD = 2  /* torch.optim.Adagrad (lr_decay 0, initial accumulator 0)      */
+  RC_OPT_ADAGRAD = 2, /* torch.optim.Adagrad (lr_decay 0, initial accumulator 0)      */
+  RC_OPT_ADADELTA = 3 /* torch.optim.Adadelta (rho = beta1, eps 1e-6; m = square_avg, v = acc_delta):
+                         dense steps only (rc_dense_update*), the row-wise entry points reject it */
 };
 
 /* hyper-parameters of one optimizer step.  `step` is the 1-based step count t used for

@@ -153,12 +153,22 @@ def opt_step_dense(W, G, state, opt, lr, l2=0.0, beta1=0.9, beta2=0.999, eps=Non
         s = state["m"][sl] + g * g
         W[sl] = w + F32(-lr) * (g / (np.sqrt(s, dtype=F32) + F32(eps)))
         state["m"][sl] = s
+    elif opt == "Adadelta":  # torch/optim/adadelta.py (rho 0.9, eps 1e-6): m = square_avg, v = acc_delta
+        rho = beta1  # Adadelta's rho travels in beta1 (default 0.9)
+        if eps is None:
+            eps = 1e-6
+        sq = state["m"][sl] * F32(rho) + F32(1 - rho) * g * g
+        std = np.sqrt(sq + F32(eps), dtype=F32)
+        delta = np.sqrt(state["v"][sl] + F32(eps), dtype=F32) / std * g
+        state["v"][sl] = state["v"][sl] * F32(rho) + F32(1 - rho) * delta * delta
+        state["m"][sl] = sq
+        W[sl] = w + F32(-lr) * delta
     else:
         raise ValueError("Undefined optimizer: {}".format(opt))
 
 
 def new_state(W, opt):
-    if opt == "Adam":
+    if opt in ("Adam", "Adadelta"):
         return {"m": np.zeros_like(W), "v": np.zeros_like(W)}
     if opt == "Adagrad":
         return {"m": np.zeros_like(W)}

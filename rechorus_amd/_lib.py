@@ -10,9 +10,9 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "librechorus_hip.so")
 
 RC_OK = 0
-RC_OPT_SGD, RC_OPT_ADAM, RC_OPT_ADAGRAD = 0, 1, 2
+RC_OPT_SGD, RC_OPT_ADAM, RC_OPT_ADAGRAD, RC_OPT_ADADELTA = 0, 1, 2, 3
 RC_SEG_SKIP_SINGLETONS = 1
-OPT_BY_NAME = {"SGD": RC_OPT_SGD, "Adam": RC_OPT_ADAM, "Adagrad": RC_OPT_ADAGRAD}
+OPT_BY_NAME = {"SGD": RC_OPT_SGD, "Adam": RC_OPT_ADAM, "Adagrad": RC_OPT_ADAGRAD, "Adadelta": RC_OPT_ADADELTA}
 
 
 class RechorusHipMissing(ImportError):

@@ -24,12 +24,12 @@ __global__ __launch_bounds__(kBlock) void dense_update_kernel(OptScalars o, floa
   const int64_t i = n4 * 4 + (int64_t)blockIdx.x * kBlock + threadIdx.x;  // n % 4 tail
   if (i < n) {
     float w = W[i], m = 0.f, v = 0.f;
-    if (MODE == MODE_ADAM || MODE == MODE_ADAGRAD) m = M[i];
-    if (MODE == MODE_ADAM) v = V[i];
+    if (mode_has_m(MODE)) m = M[i];
+    if (mode_has_v(MODE)) v = V[i];
     opt_elem<MODE>(o, G[i], w, m, v);
     W[i] = w;
-    if (MODE == MODE_ADAM || MODE == MODE_ADAGRAD) M[i] = m;
-    if (MODE == MODE_ADAM) V[i] = v;
+    if (mode_has_m(MODE)) M[i] = m;
+    if (mode_has_v(MODE)) V[i] = v;
   }
 }
 
@@ -40,12 +40,12 @@ __global__ __launch_bounds__(kBlock) void dense_update_scalar_kernel(
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n;
        i += (int64_t)gridDim.x * kBlock) {
     float w = W[i], m = 0.f, v = 0.f;
-    if (MODE == MODE_ADAM || MODE == MODE_ADAGRAD) m = M[i];
-    if (MODE == MODE_ADAM) v = V[i];
+    if (mode_has_m(MODE)) m = M[i];
+    if (mode_has_v(MODE)) v = V[i];
     opt_elem<MODE>(o, G[i], w, m, v);
     W[i] = w;
-    if (MODE == MODE_ADAM || MODE == MODE_ADAGRAD) M[i] = m;
-    if (MODE == MODE_ADAM) V[i] = v;
+    if (mode_has_m(MODE)) M[i] = m;
+    if (mode_has_v(MODE)) V[i] = v;
   }
 }
 
@@ -118,22 +118,22 @@ __global__ __launch_bounds__(kBlock) void dense_update_multi_kernel(MultiArgs a)
     }
     for (int64_t i = end4 + threadIdx.x; i < end; i += kBlock) {
       float w = W[i], m = 0.f, v = 0.f;
-      if (MODE == MODE_ADAM || MODE == MODE_ADAGRAD) m = M[i];
-      if (MODE == MODE_ADAM) v = V[i];
+      if (mode_has_m(MODE)) m = M[i];
+      if (mode_has_v(MODE)) v = V[i];
       opt_elem<MODE>(o, G[i], w, m, v);
       W[i] = w;
-      if (MODE == MODE_ADAM || MODE == MODE_ADAGRAD) M[i] = m;
-      if (MODE == MODE_ADAM) V[i] = v;
+      if (mode_has_m(MODE)) M[i] = m;
+      if (mode_has_v(MODE)) V[i] = v;
     }
   } else {
     for (int64_t i = base + threadIdx.x; i < end; i += kBlock) {
       float w = W[i], m = 0.f, v = 0.f;
-      if (MODE == MODE_ADAM || MODE == MODE_ADAGRAD) m = M[i];
-      if (MODE == MODE_ADAM) v = V[i];
+      if (mode_has_m(MODE)) m = M[i];
+      if (mode_has_v(MODE)) v = V[i];
       opt_elem<MODE>(o, G[i], w, m, v);
       W[i] = w;
-      if (MODE == MODE_ADAM || MODE == MODE_ADAGRAD) M[i] = m;
-      if (MODE == MODE_ADAM) V[i] = v;
+      if (mode_has_m(MODE)) M[i] = m;
+      if (mode_has_v(MODE)) V[i] = v;
     }
   }
 }
@@ -148,7 +148,7 @@ extern "C" int rc_dense_update(float* W, const float* G, float* m, float* v, int
   RC_REQUIRE(W && G, "rc_dense_update: null pointer");
   RC_REQUIRE(n > 0, "rc_dense_update: n < 0");
   OptScalars o;
-  RC_TRY(fill_opt_scalars(h, &o));
+  RC_TRY(fill_opt_scalars(h, &o, /*dense=*/true));
   hipStream_t s = as_stream(stream);
   auto al = [](const void* p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; };
   bool aligned = al(W) && al(G);
@@ -161,6 +161,9 @@ extern "C" int rc_dense_update(float* W, const float* G, float* m, float* v, int
     case RC_OPT_ADAGRAD:
       RC_REQUIRE(m, "rc_dense_update: Adagrad needs m (state_sum)");
       return launch_dense<MODE_ADAGRAD>(o, W, G, m, v, n, aligned && al(m), s);
+    case RC_OPT_ADADELTA:
+      RC_REQUIRE(m && v, "rc_dense_update: Adadelta needs m (square_avg) and v (acc_delta)");
+      return launch_dense<MODE_ADADELTA>(o, W, G, m, v, n, aligned && al(m) && al(v), s);
     default:
       return fail(RC_ERR_INVALID_ARG, "rc_dense_update: unknown optimizer %d", h->opt);
   }
@@ -200,10 +203,10 @@ extern "C" int rc_dense_update_multi_dev(float* const* W, const float* const* G,
       RC_REQUIRE(W[t] && G[t], "rc_dense_update_multi: null pointer (tensor %d)", t);
       float* mt = m ? m[t] : nullptr;
       float* vt = v ? v[t] : nullptr;
-      RC_REQUIRE(opt != RC_OPT_ADAM || (mt && vt), "rc_dense_update_multi: Adam needs m and v (tensor %d)", t);
+      RC_REQUIRE((opt != RC_OPT_ADAM && opt != RC_OPT_ADADELTA) || (mt && vt), "rc_dense_update_multi: Adam / Adadelta need m and v (tensor %d)", t);
       RC_REQUIRE(opt != RC_OPT_ADAGRAD || mt, "rc_dense_update_multi: Adagrad needs m (tensor %d)", t);
       a.W[T] = W[t]; a.G[T] = G[t]; a.M[T] = mt; a.V[T] = vt; a.n[T] = n[t];
-      RC_TRY(fill_opt_scalars(&h[t], &a.o[T]));
+      RC_TRY(fill_opt_scalars(&h[t], &a.o[T], /*dense=*/true));
       a.lr[T] = (float)h[t].lr;
       RC_REQUIRE(step_dev == nullptr || (h[t].beta1 == h[0].beta1 && h[t].beta2 == h[0].beta2),
                  "rc_dense_update_multi_dev: one (beta1, beta2) per call");
@@ -229,6 +232,9 @@ extern "C" int rc_dense_update_multi_dev(float* const* W, const float* const* G,
         break;
       case RC_OPT_ADAGRAD:
         hipLaunchKernelGGL((dense_update_multi_kernel<MODE_ADAGRAD>), dim3(blocks), dim3(kBlock), 0, s, a);
+        break;
+      case RC_OPT_ADADELTA:
+        hipLaunchKernelGGL((dense_update_multi_kernel<MODE_ADADELTA>), dim3(blocks), dim3(kBlock), 0, s, a);
         break;
       default:
         return fail(RC_ERR_INVALID_ARG, "rc_dense_update_multi: unknown optimizer %d", opt);

@@ -7,7 +7,11 @@
 
 namespace rc {
 
-enum { MODE_SGD = 0, MODE_ADAM = 1, MODE_ADAGRAD = 2, MODE_DENSE_GRAD = 3, MODE_NONE = 4 };
+enum { MODE_SGD = 0, MODE_ADAM = 1, MODE_ADAGRAD = 2, MODE_DENSE_GRAD = 3, MODE_NONE = 4, MODE_ADADELTA = 5 };
+
+// which optimizer state tensors a mode reads and writes (m: exp_avg / state_sum / square_avg, v: exp_avg_sq / acc_delta)
+constexpr bool mode_has_m(int mode) { return mode == MODE_ADAM || mode == MODE_ADAGRAD || mode == MODE_ADADELTA; }
+constexpr bool mode_has_v(int mode) { return mode == MODE_ADAM || mode == MODE_ADADELTA; }
 
 // python-double hyper-parameters narrowed to fp32 at the points where torch narrows them
 struct OptScalars {
@@ -21,15 +25,20 @@ struct OptScalars {
   float eps;
 };
 
-inline int fill_opt_scalars(const rc_opt_hyper* h, OptScalars* a) {
+inline int fill_opt_scalars(const rc_opt_hyper* h, OptScalars* a, bool dense = false) {
   RC_REQUIRE(h != nullptr, "optimizer hyper-parameters missing");
-  RC_REQUIRE(h->opt == RC_OPT_SGD || h->opt == RC_OPT_ADAM || h->opt == RC_OPT_ADAGRAD,
-             "unknown optimizer %d", h->opt);
+  RC_REQUIRE(h->opt == RC_OPT_SGD || h->opt == RC_OPT_ADAM || h->opt == RC_OPT_ADAGRAD || (dense && h->opt == RC_OPT_ADADELTA),
+             h->opt == RC_OPT_ADADELTA ? "Adadelta (optimizer %d) is built for dense steps only (rc_dense_update*)"
+                                       : "unknown optimizer %d", h->opt);
   a->l2 = (float)h->l2;
   a->neg_lr = (float)(-h->lr);
   a->eps = (float)h->eps;
   a->one_m_b1 = a->b2 = a->one_m_b2 = a->neg_step = 0.f;
   a->bc2_sqrt = 1.f;
+  if (h->opt == RC_OPT_ADADELTA) {  // torch/optim/adadelta.py: rho in beta1
+    a->b2 = (float)h->beta1;
+    a->one_m_b2 = (float)(1.0 - h->beta1);
+  }
   if (h->opt == RC_OPT_ADAM) {
     RC_REQUIRE(h->step >= 1, "Adam needs step >= 1 (got %lld)", (long long)h->step);
     const double bc1 = 1.0 - pow(h->beta1, (double)h->step);
@@ -44,7 +53,7 @@ inline int fill_opt_scalars(const rc_opt_hyper* h, OptScalars* a) {
 }
 
 inline int mode_of(const rc_opt_hyper* h) {
-  return h->opt == RC_OPT_SGD ? MODE_SGD : (h->opt == RC_OPT_ADAM ? MODE_ADAM : MODE_ADAGRAD);
+  return h->opt == RC_OPT_SGD ? MODE_SGD : (h->opt == RC_OPT_ADAM ? MODE_ADAM : (h->opt == RC_OPT_ADADELTA ? MODE_ADADELTA : MODE_ADAGRAD));
 }
 
 #if defined(__HIPCC__)
@@ -64,6 +73,13 @@ __device__ __forceinline__ void opt_elem(const OptScalars& a, float g, float& w,
     g = fmaf(a.l2, w, g);
     m = fmaf(g, g, m);                      // state_sum.addcmul_(g, g, 1)
     w = fmaf(a.neg_lr, g / (sqrtf(m) + a.eps), w);
+  } else if (MODE == MODE_ADADELTA) {       // torch/optim/adadelta.py, single-tensor path
+    g = fmaf(a.l2, w, g);
+    m = fmaf(a.one_m_b2, g * g, m * a.b2);  // square_avg.mul_(rho).addcmul_(g, g, 1 - rho)
+    const float std = sqrtf(m + a.eps);     // square_avg.add(eps).sqrt_()
+    const float delta = sqrtf(v + a.eps) / std * g;   // acc_delta.add(eps).sqrt_().div_(std).mul_(g)
+    v = fmaf(a.one_m_b2, delta * delta, v * a.b2);    // acc_delta.mul_(rho).addcmul_(delta, delta, 1 - rho)
+    w = fmaf(a.neg_lr, delta, w);           // param.add_(delta, alpha=-lr)
   }
 }
 
@@ -93,15 +109,15 @@ __device__ __forceinline__ void opt_row4(const OptScalars& a, float* __restrict_
                                          float* __restrict__ M, float* __restrict__ V, size_t idx4,
                                          float4 w, const float4& g) {
   float4 m = make_float4(0, 0, 0, 0), v = make_float4(0, 0, 0, 0);
-  if (MODE == MODE_ADAM || MODE == MODE_ADAGRAD) m = load_stream4(reinterpret_cast<const float4*>(M) + idx4);
-  if (MODE == MODE_ADAM) v = load_stream4(reinterpret_cast<const float4*>(V) + idx4);
+  if (mode_has_m(MODE)) m = load_stream4(reinterpret_cast<const float4*>(M) + idx4);
+  if (mode_has_v(MODE)) v = load_stream4(reinterpret_cast<const float4*>(V) + idx4);
   opt_elem<MODE>(a, g.x, w.x, m.x, v.x);
   opt_elem<MODE>(a, g.y, w.y, m.y, v.y);
   opt_elem<MODE>(a, g.z, w.z, m.z, v.z);
   opt_elem<MODE>(a, g.w, w.w, m.w, v.w);
   store_row4(reinterpret_cast<float4*>(W) + idx4, w);
-  if (MODE == MODE_ADAM || MODE == MODE_ADAGRAD) store_row4(reinterpret_cast<float4*>(M) + idx4, m);
-  if (MODE == MODE_ADAM) store_row4(reinterpret_cast<float4*>(V) + idx4, v);
+  if (mode_has_m(MODE)) store_row4(reinterpret_cast<float4*>(M) + idx4, m);
+  if (mode_has_v(MODE)) store_row4(reinterpret_cast<float4*>(V) + idx4, v);
 }
 #endif
 

@@ -32,11 +32,12 @@ def _ptr(t, dtype, name, allow_none=False):
 
 
 def make_hyper(opt="SGD", lr=1e-3, l2=0.0, beta1=0.9, beta2=0.999, eps=None, step=1):
-    """rc_opt_hyper with torch.optim's defaults (Adam eps 1e-8, Adagrad eps 1e-10)."""
+    """rc_opt_hyper with torch.optim's defaults (Adam eps 1e-8, Adagrad eps 1e-10, Adadelta rho 0.9 / eps 1e-6;
+    Adadelta's rho travels in beta1 and is built for dense steps only)."""
     if opt not in OPT_BY_NAME:
-        raise ValueError(f"optimizer {opt!r} not supported by the HIP engine (SGD, Adam, Adagrad)")
+        raise ValueError(f"optimizer {opt!r} not supported by the HIP engine (SGD, Adam, Adagrad, Adadelta)")
     if eps is None:
-        eps = 1e-10 if opt == "Adagrad" else 1e-8
+        eps = {"Adagrad": 1e-10, "Adadelta": 1e-6}.get(opt, 1e-8)
     return OptHyper(OPT_BY_NAME[opt], 0, float(lr), float(l2), float(beta1), float(beta2),
                     float(eps), int(step))
 

@@ -323,14 +323,14 @@ def sasrec_encode(item_emb, pos_emb, blocks, n_heads, hist, lengths):
 
 
 class HipOptimizer:
-    """torch.optim.{SGD,Adam,Adagrad} semantics (dense, weight decay per param group) executed by
+    """torch.optim.{SGD,Adam,Adagrad,Adadelta} semantics (dense, weight decay per param group) executed by
     rc_dense_update.  Built by the runner in place of `eval('torch.optim.X')`
     (helpers/BaseRunner.py:110-114); accepts the same param-group list
     (`model.customize_parameters()`, models/BaseModel.py:64-73)."""
 
     def __init__(self, param_groups, name="Adam", lr=1e-3, weight_decay=0.0, capturable=False):
-        if name not in ("SGD", "Adam", "Adagrad"):
-            raise ValueError(f"HipOptimizer: optimizer {name!r} not built (SGD, Adam, Adagrad)")
+        if name not in ("SGD", "Adam", "Adagrad", "Adadelta"):
+            raise ValueError(f"HipOptimizer: optimizer {name!r} not built (SGD, Adam, Adagrad, Adadelta)")
         self.name, self.lr = name, lr
         # capturable: Adam's step count lives on the device, so step() can be recorded in a hipGraph
         self.capturable = capturable
@@ -363,9 +363,9 @@ class HipOptimizer:
                     continue
                 st = self.state.setdefault(p, {})
                 m = v = None
-                if self.name in ("Adam", "Adagrad"):
+                if self.name in ("Adam", "Adagrad", "Adadelta"):   # exp_avg / state_sum / square_avg
                     m = st.setdefault("m", torch.zeros_like(p))
-                if self.name == "Adam":
+                if self.name in ("Adam", "Adadelta"):              # exp_avg_sq / acc_delta
                     v = st.setdefault("v", torch.zeros_like(p))
                 grad = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                 items.append((p.data, grad, h, m, v))

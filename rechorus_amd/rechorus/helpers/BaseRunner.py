@@ -105,10 +105,10 @@ class BaseRunner(object):
     def _build_optimizer(self, model):
         logging.info('Optimizer: ' + self.optimizer_name)
         on_gpu = next(model.parameters()).is_cuda
-        if on_gpu and self.optimizer_name in ('SGD', 'Adam', 'Adagrad'):
+        if on_gpu and self.optimizer_name in ('SGD', 'Adam', 'Adagrad', 'Adadelta'):  # every --optimizer the reference documents
             return hnn.HipOptimizer(model.customize_parameters(), self.optimizer_name,
                                     lr=self.learning_rate, weight_decay=self.l2, capturable=self.use_graph)
-        # anything else (Adadelta, CPU debugging) keeps torch's implementation
+        # anything else (other torch.optim names, CPU debugging) keeps torch's implementation
         return getattr(torch.optim, self.optimizer_name)(
             model.customize_parameters(), lr=self.learning_rate, weight_decay=self.l2)
 
@@ -219,6 +219,11 @@ class BaseRunner(object):
         # hipGraph replay of the dense step: needs a host-free step (no host-side candidate shuffle; torch's
         # dropout is fine, its Philox offset advances per replay) and the capturable optimizer; one graph per
         # feed-dict shape
+        if self.use_graph and not hgraph.usable() and not getattr(self, '_graph_warned', False):
+            self._graph_warned = True
+            logging.warning('--graph 1 requested but hipGraph replay is disabled: DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 has to be in '
+                            'the environment before HIP initialises (import rechorus_amd before torch touches the GPU, or '
+                            'export it); training runs eagerly (same results, more launch overhead at small batches)')
         graphable = (self.use_graph and not rowwise and equivariant
                      and isinstance(model.optimizer, hnn.HipOptimizer) and model.optimizer.capturable
                      and torch.device(model.device).type == 'cuda' and hgraph.usable())

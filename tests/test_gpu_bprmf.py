@@ -253,7 +253,12 @@ def test_empty_batch_and_bad_arguments(cuda, eng):
         eng.gather_dot(U, I, torch.zeros(2, dtype=torch.int32, device=cuda),
                        torch.zeros((2, 2), dtype=torch.int64, device=cuda))
     with pytest.raises(ValueError, match="not supported"):
-        eng.make_hyper("Adadelta")
+        eng.make_hyper("RMSprop")
+    # Adadelta exists for dense steps only: the row-wise step refuses it instead of guessing a semantics
+    tr = eng.BprmfTrainer(torch.zeros(4, 64, device=cuda), torch.zeros(6, 64, device=cuda), opt="SGD")
+    tr.hyper = eng.make_hyper("Adadelta")
+    with pytest.raises(_lib.RechorusHipError, match="dense steps only"):
+        tr.step(torch.zeros(2, dtype=torch.int64, device=cuda), torch.zeros((2, 3), dtype=torch.int64, device=cuda))
 
 
 def test_embedding_dense_backward_vs_index_add(cuda, eng):

@@ -263,3 +263,29 @@ def test_cli_neumf_and_sasrec(model_args, dataset_root, tmp_path, cuda):
     before = float(re.search(r"Test Before Training: \(HR@5:([0-9.]+)", text).group(1))
     after = float(re.search(r"HR@5:([0-9.]+)", res["test"]).group(1))
     assert after > before, (before, after)
+
+
+@pytest.mark.parametrize("tag,lr,l2", [("lr1_l20.0001", 1.0, 1e-4), ("lr0.001_l20", 1e-3, 0.0)])
+def test_adadelta_through_the_plugin_matches_the_reference(tag, lr, l2, cuda):
+    """--optimizer Adadelta (helpers/BaseRunner.py:37-38): model(batch) -> loss -> backward -> HipOptimizer.step on the
+    engine (rc_dense_update_multi, MODE_ADADELTA) vs three fit() iterations of the reference itself"""
+    from rechorus_amd import nn as hnn
+    g = np.load(os.path.join(ROOT, "tests", "golden", "adadelta_bprmf_d64.npz"))
+    n_users, n_items, d = g["U0"].shape[0], g["I0"].shape[0], g["U0"].shape[1]
+    model = _bprmf(cuda, n_users, n_items, d, g["iid1"].shape[1] - 1)
+    model.load_state_dict({"u_embeddings.weight": torch.from_numpy(g["U0"]), "i_embeddings.weight": torch.from_numpy(g["I0"])})
+    runner = _runner("Adadelta", lr, l2)
+    model.optimizer = runner._build_optimizer(model)
+    assert isinstance(model.optimizer, hnn.HipOptimizer)
+    for step in (1, 2, 3):
+        u, i = g[f"uid{step}"], g[f"iid{step}"]
+        batch = {"user_id": torch.from_numpy(u).to(cuda), "item_id": torch.from_numpy(i).to(cuda), "batch_size": len(u), "phase": "train"}
+        model.optimizer.zero_grad()
+        loss = model.loss(model(batch))
+        loss.backward()
+        model.optimizer.step()
+        assert_close(float(loss), float(g[tag + "_losses"][step - 1]), what=f"loss {step}")
+        assert_update_close(model.u_embeddings.weight.detach().cpu().numpy(), g["U0"], g[f"{tag}_U{step}"], what=f"dU {step}",
+                            extra_atol=1e-6 * lr)
+        assert_update_close(model.i_embeddings.weight.detach().cpu().numpy(), g["I0"], g[f"{tag}_I{step}"], what=f"dI {step}",
+                            extra_atol=1e-6 * lr)

@@ -77,3 +77,20 @@ def test_torch_port_matches_reference(case, tag, opt):
     ex = 1e-3 * lr if opt == "Adam" else 0.0
     assert_update_close(m.u_embeddings.weight.detach().numpy(), g["U0"], g[tag + "_U2"], what="dU", extra_atol=ex)
     assert_update_close(m.i_embeddings.weight.detach().numpy(), g["I0"], g[tag + "_I2"], what="dI", extra_atol=ex)
+
+
+@pytest.mark.parametrize("tag,lr,l2", [("lr1_l20.0001", 1.0, 1e-4), ("lr0.001_l20", 1e-3, 0.0)])
+def test_oracle_adadelta_matches_the_reference(tag, lr, l2):
+    """--optimizer Adadelta: three fit() iterations of the reference (tests/golden/make_golden_adadelta.py) vs the
+    numpy restatement of torch.optim.Adadelta's single-tensor path (dense: every row of both tables steps)"""
+    import os
+    from conftest import ROOT
+    g = np.load(os.path.join(ROOT, "tests", "golden", "adadelta_bprmf_d64.npz"))
+    U, I = g["U0"].copy(), g["I0"].copy()
+    sU, sI = O.new_state(U, "Adadelta"), O.new_state(I, "Adadelta")
+    for step in (1, 2, 3):
+        loss, _ = O.bprmf_train_step(U, I, sU, sI, g[f"uid{step}"], g[f"iid{step}"], opt="Adadelta", lr=lr, l2=l2, step=step,
+                                     rowwise=False)
+        assert_close(loss, g[tag + "_losses"][step - 1], what=f"loss {step}")
+        assert_update_close(U, g["U0"], g[f"{tag}_U{step}"], what=f"dU {step}", extra_atol=1e-3 * lr * 1e-3)
+        assert_update_close(I, g["I0"], g[f"{tag}_I{step}"], what=f"dI {step}", extra_atol=1e-3 * lr * 1e-3)
