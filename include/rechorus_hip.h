@@ -142,6 +142,25 @@ int rc_bce_ranking_fwd_bwd(const float* pred, int64_t B, int C, float inv_b, flo
 int rc_list_bpr_fwd_bwd(const float* pred, const int64_t* target, int B, int n, int max_pos, int hard,
                         float inv_b, float* loss_vec, float* gpred, rc_stream_t stream);
 
+/* Every list-wise loss name of ImpressionModel.loss (models/BaseImpressionModel.py:44-129) behind one entry point
+ * ('BPR...simple', which the reference returns unreduced, excepted).  kind: */
+enum rc_list_kind {
+  RC_LIST_BPR = 0,             /* :82-86  re-weighting between the sigmoid and the log (rc_list_bpr_fwd_bwd)        */
+  RC_LIST_BPR_HARD = 1,        /* :68-70  the same, lower-scored positives weigh more                              */
+  RC_LIST_BPR_AFTER = 2,       /* :76-78  softplus(-(s_i - s_j)) weighted by both softmaxes                          */
+  RC_LIST_BPR_HARD_AFTER = 3,
+  RC_LIST_BPR_BEFORE = 4,      /* :79-81  softplus of the weighted score difference, summed over all n columns      */
+  RC_LIST_BPR_HARD_BEFORE = 5,
+  RC_LIST_LISTNET = 6,         /* :84-94  cross entropy between softmax(labels) and softmax(scores)                 */
+  RC_LIST_SOFTMAX_CE = 7,      /* :96-107 (rc_softmax_ce_fwd_bwd)                                                   */
+  RC_LIST_ATTENTION_RANK = 8   /* :109-126 listnet + the (1 - t) log(1 - p) term                                    */
+};
+/* loss_vec [B]: per-row terms whose fixed-order sum (rc_reduce_sum; scale 1/B for the BPR kinds, which also take
+ * inv_b = 1/B for the gradient; scale 1 for the kinds normalised by the rows that have a negative) is the loss;
+ * h_sum [1]: scratch of those kinds (may be NULL for the BPR kinds); gpred [B, n] (optional) = dloss/dpred.           */
+int rc_list_loss_fwd_bwd(const float* pred, const int64_t* target, int B, int n, int max_pos, int kind, float inv_b,
+                         float* loss_vec, float* h_sum, float* gpred, rc_stream_t stream);
+
 /* out[0] = scale * sum_i x[i], fixed summation order (deterministic).  Used for the
  * batch mean of loss_vec (models/BaseModel.py:185 `.mean()`).                         */
 int rc_reduce_sum(const float* x, int64_t n, float scale, float* out, rc_stream_t stream);

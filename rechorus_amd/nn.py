@@ -121,16 +121,12 @@ def bpr_loss(pred):
 
 
 class _ListLossFn(torch.autograd.Function):
-    """list-wise losses of ImpressionModel.loss on the HIP engine: 'BPR', 'BPRhard' (rc_list_bpr_fwd_bwd) and
-    'softmaxCE' (rc_softmax_ce_fwd_bwd); closed-form backward"""
+    """list-wise losses of ImpressionModel.loss on the HIP engine (rc_list_loss_fwd_bwd): the list-level BPR family with
+    its re-weighting variants, listnet, softmaxCE, attention_rank; closed-form backward.  kind: engine.list_kind(loss_n)"""
 
     @staticmethod
     def forward(ctx, pred, target, max_pos, kind):
-        p, t = pred.detach().contiguous(), target.contiguous()
-        if kind == 'softmaxCE':
-            loss, gpred = engine.softmax_ce(p, t, max_pos)
-        else:
-            loss, gpred = engine.list_bpr(p, t, max_pos, hard=(kind == 'BPRhard'))
+        loss, gpred = engine.list_loss(pred.detach().contiguous(), target.contiguous(), max_pos, kind)
         ctx.save_for_backward(gpred)
         return loss.reshape(())
 

@@ -15,7 +15,7 @@ import torch
 import torch.nn.functional as F
 
 from models.BaseModel import GeneralModel, SequentialModel
-from rechorus_amd import nn as hnn
+from rechorus_amd import engine, nn as hnn
 
 
 class ImpressionModel(GeneralModel):
@@ -41,43 +41,17 @@ class ImpressionModel(GeneralModel):
     def loss(self, out_dict: dict, target=None):
         pred, P = out_dict['prediction'], self.train_max_pos_item
         name = self.loss_n
-        # like the reference (:50-89), any name containing 'BPR' without after / before / simple is the
-        # "between" re-weighting, 'hard' anywhere in it flips the positive weights
-        between = 'BPR' in name and not any(k in name for k in ('after', 'before', 'simple'))
-        if between or name == 'softmaxCE':
+        kind = engine.list_kind(name)   # the reference's substring rules (:50-89)
+        if kind is not None:
             if not pred.is_cuda:
                 raise RuntimeError('ImpressionModel.loss: the HIP engine needs CUDA tensors (no CPU path)')
-            kind = 'softmaxCE' if name == 'softmaxCE' else ('BPRhard' if 'hard' in name else 'BPR')
             return hnn.list_loss(pred, target.long(), P, kind)
-        valid = (target != -1)
-        have_neg = valid[:, P].float()
-        col = torch.arange(pred.shape[1], device=pred.device)[None, :]
-        is_pos, is_neg = (col < P) & valid, (col >= P) & valid
-        ninf = torch.full((), float('-inf'), device=pred.device)  # a fill kernel (capturable), not a host copy
-
-        def reweight(row_loss):  # rows without negatives are weighted out (:93,105,125)
-            return (row_loss * have_neg / have_neg.sum() * len(have_neg)).mean()
-
-        if 'BPR' in name:
-            pair = is_pos[:, :, None] & is_neg[:, None, :]                  # [B, i, j]: i positive, j negative
+        if 'BPR' in name:  # 'simple': every valid (positive, negative) pair, per-row sums left unreduced (reference :84)
+            valid = (target != -1)
+            col = torch.arange(pred.shape[1], device=pred.device)[None, :]
+            pair = ((col < P) & valid)[:, :, None] & ((col >= P) & valid)[:, None, :]
             diff = (pred[:, :, None] - pred[:, None, :]) * pair
-            w_neg = torch.where(is_neg, pred, ninf).softmax(dim=1)
-            w_pos = torch.where(is_pos, -pred if 'hard' in name else pred, ninf).softmax(dim=1)
-            if 'after' in name:
-                return ((F.softplus(-diff) * w_neg[:, None, :]).sum(-1) * w_pos).sum(-1).mean()
-            if 'before' in name:
-                return F.softplus(-(diff * w_neg[:, None, :]).sum(-1) * w_pos).sum(-1).mean()
-            return (F.softplus(-diff) * pair).sum(-1).sum(-1)  # 'simple': per-row sums, not reduced (reference :84)
-        if name in ('listnet', 'attention_rank'):
-            t_soft = torch.where(valid, target.float(), ninf).softmax(dim=1)
-            if name == 'listnet':
-                p_soft = (pred - pred.max()).softmax(dim=1)                 # over ALL columns, like the reference :87
-                p_soft = torch.where(valid, p_soft, torch.ones_like(p_soft))
-                return reweight(-(t_soft * p_soft.log()).sum(dim=1))
-            p_soft = torch.where(valid, pred, ninf).softmax(dim=1)
-            p1 = torch.where(valid, p_soft, torch.ones_like(p_soft))
-            p2 = torch.where(valid & (p_soft != 1), p_soft, torch.zeros_like(p_soft))
-            return reweight(-(t_soft * p1.log()).sum(dim=1) - ((1 - t_soft) * (1 - p2).log()).sum(dim=1))
+            return (F.softplus(-diff) * pair).sum(-1).sum(-1)
         raise ValueError('Undefined loss function: {}'.format(self.loss_n))
 
     class Dataset(GeneralModel.Dataset):

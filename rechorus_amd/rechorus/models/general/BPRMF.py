@@ -35,7 +35,15 @@ class BPRMFBase(object):
         self.check_list = []
         scores = hnn.bprmf_scores(self.u_embeddings.weight, self.i_embeddings.weight,
                                   feed_dict['user_id'], feed_dict['item_id'])  # ids [B], [B, n_candidates]
-        return {'prediction': scores.view(feed_dict['batch_size'], -1)}
+        out = {'prediction': scores.view(feed_dict['batch_size'], -1)}
+        if isinstance(self, ImpressionModel):
+            # the reference's BPRMFImpression.forward hands back the base's whole dict (BPRMF.py:43-45, 79-80): the
+            # rerankers built on a frozen base ranker read u_v / i_v.  BPRMF proper drops them (:61-63), so only the
+            # impression variant pays for the two extra gathers.
+            i_ids = feed_dict['item_id']
+            out['u_v'] = self.u_embeddings(feed_dict['user_id'])[:, None, :].expand(-1, i_ids.shape[1], -1)
+            out['i_v'] = self.i_embeddings(i_ids)
+        return out
 
     def full_catalogue_vectors(self, feed_dict):
         """(query vectors [B, d], item table) of the dot-product head, for --test_all ranking"""

@@ -127,3 +127,24 @@ def test_impression_device_batches_equal_the_collated_ones(model_name, extra, tm
     assert np.isfinite(runner.fit(tr, epoch=1))
     res = runner.evaluate(model_cls.Dataset(model, corpus, "dev"), [1, 2], ["NDCG", "HR"])
     assert set(res) == {"NDCG@1", "NDCG@2", "MAP@1", "MAP@2", "HR@1", "HR@2"}
+
+
+def test_bprmf_impression_returns_u_v_and_i_v(cuda):
+    """reference BPRMF.py:43-45,79-80: the impression variant's forward also returns the tiled user vectors and the
+    gathered item vectors (what the rerankers read); BPRMF proper does not"""
+    from models.general.BPRMF import BPRMF, BPRMFImpression
+    args = argparse.Namespace(device=cuda, model_path="", buffer=1, num_neg=4, dropout=0, test_all=0, emb_size=32,
+                              loss_n="BPR", train_max_pos_item=2, train_max_neg_item=3, test_max_pos_item=2, test_max_neg_item=3)
+    corpus = argparse.Namespace(n_users=11, n_items=23)
+    rng = np.random.default_rng(0)
+    feed = {"user_id": torch.from_numpy(rng.integers(0, 11, size=6)).to(cuda),
+            "item_id": torch.from_numpy(rng.integers(0, 23, size=(6, 5))).to(cuda), "batch_size": 6, "phase": "train"}
+    m = BPRMFImpression(args, corpus).to(cuda)
+    out = m(feed)
+    U, I = m.u_embeddings.weight.detach().cpu().numpy(), m.i_embeddings.weight.detach().cpu().numpy()
+    uid, iid = feed["user_id"].cpu().numpy(), feed["item_id"].cpu().numpy()
+    assert out["u_v"].shape == (6, 5, 32) and out["i_v"].shape == (6, 5, 32)
+    assert np.array_equal(out["u_v"].detach().cpu().numpy(), np.repeat(U[uid][:, None, :], 5, axis=1))
+    assert np.array_equal(out["i_v"].detach().cpu().numpy(), I[iid])
+    assert_close(out["prediction"].detach().cpu().numpy(), (U[uid][:, None, :] * I[iid]).sum(-1), what="prediction")
+    assert set(BPRMF(args, corpus).to(cuda)(feed)) == {"prediction"}
