@@ -51,7 +51,7 @@ def parse():
     ap.add_argument("--graph", action="store_true", help="replay each step from a captured hipGraph (small batches)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL (the only measurement mode); gloo only to smoke-test N>1 on one GPU")
-    ap.add_argument("--workload", default="bprmf", choices=["bprmf", "neumf", "sasrec"],
+    ap.add_argument("--workload", default="bprmf", choices=["bprmf", "neumf", "sasrec", "deepfm"],
                     help="bprmf = BASELINE configs[1] (the contract workload); neumf = configs[3]: NeuMF emb_size 128, "
                          "num_neg 4, hidden 64 (pass --items 100000001 --users 10000001 --num-neg 4 --emb-size 128)")
     ap.add_argument("--hidden", type=int, default=64, help="neumf: size of the hidden layer")
@@ -63,7 +63,15 @@ def parse():
     ap.add_argument("--layers", type=int, default=1, help="sasrec: transformer blocks")
     ap.add_argument("--parallel", default="sharded", choices=["sharded", "replicas"],
                     help="N>1: row-sharded tables + owner-computes exchange (default), or independent replicas")
+    ap.add_argument("--mlp", default="[512,64]", help="deepfm: hidden layers of the deep tower (CTR_MIND.sh:8)")
     args = ap.parse_args()
+    if args.workload == "deepfm":  # configs[4]: the reference's CTR script shape unless overridden
+        if args.batch == 65536:
+            args.batch = 1024
+        if args.opt == "SGD":
+            args.opt = "Adam"
+        if args.lr == 1e-3:
+            args.lr = 5e-4
     if args.workload == "sasrec":  # configs[2] is quoted on a Grocery-sized catalogue; keep explicit overrides
         if args.items == 10_000_001:
             args.items = 8714
@@ -143,6 +151,110 @@ def make_neumf_trainer(args, world, device, engine):
         return trainer.loss
     trainer.step = step_and_keep
     return trainer
+
+
+DEEPFM_VOCAB = {"user_id": 269312, "item_id": 9373, "c_hour_c": 24, "c_weekday_c": 7, "c_period_c": 9,
+                "i_category_c": 18, "i_subcategory_c": 300, "u_group_c": 50}   # MIND-like cardinalities, SURVEY.md 8(d) row 5
+
+
+class DeepfmBench:
+    """BASELINE configs[4] on one GPU: DeepFMCTR (F = 8 single-valued fields, emb_size 64, MLP [512, 64], BCE, dense Adam =
+    the reference's exact optimizer semantics) through the plugin's model file; the step is what BaseRunner.fit runs
+    (model(batch) -> loss -> backward -> optimizer.step), replayed from a hipGraph like the runner does by default."""
+
+    def __init__(self, args, device):
+        import argparse as ap
+        sys.path.insert(0, os.path.join(ROOT, "rechorus_amd", "rechorus"))
+        from helpers.BaseRunner import BaseRunner
+        from models.context.DeepFM import DeepFMCTR
+        from rechorus_amd import graph as hgraph
+        self.vocab = dict(DEEPFM_VOCAB)
+        margs = ap.Namespace(device=device, model_path="", buffer=0, num_neg=0, dropout=0.0, test_all=0, emb_size=args.emb_size,
+                             layers=args.mlp, loss_n="BCE")
+        corpus = ap.Namespace(n_users=self.vocab["user_id"], n_items=self.vocab["item_id"], user_feature_names=["u_group_c"],
+                              item_feature_names=["i_category_c", "i_subcategory_c"],
+                              situation_feature_names=["c_hour_c", "c_period_c", "c_weekday_c"], feature_max=self.vocab)
+        self.model = DeepFMCTR(margs, corpus).to(device)
+        ra = BaseRunner.parse_runner_args(ap.ArgumentParser()).parse_args([])
+        ra.train, ra.log_file, ra.lr, ra.l2, ra.optimizer = 1, "/tmp/rc_bench/l.txt", args.lr, args.l2, args.opt
+        self.model.optimizer = BaseRunner(ra)._build_optimizer(self.model)
+        self.graphed = hgraph.GraphedStep(self.model) if hgraph.usable() else None
+        self.loss = None
+        self.timing = None
+
+    def batches(self, args, device, seed):
+        g = torch.Generator(device=device)
+        g.manual_seed(seed)
+        out = []
+        for _ in range(args.pool):
+            f = {k: torch.randint(0, v, (args.batch, 1) if k.startswith("i") else (args.batch,), device=device, generator=g)
+                 for k, v in self.vocab.items()}
+            f["label"] = torch.randint(0, 2, (args.batch, 1), device=device, generator=g)
+            f["batch_size"], f["phase"] = args.batch, "train"
+            out.append((f,))
+        return out
+
+    def step(self, f):
+        if self.timing is None and self.graphed is not None:
+            self.loss = self.graphed.run(f)
+            return self.loss
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)] if self.timing is not None else None
+        mark = (lambda i: ev[i].record()) if ev else (lambda i: None)
+        m = self.model
+        mark(0)
+        m.optimizer.zero_grad()
+        out = m(f)
+        mark(1)
+        loss = m.loss(out)
+        mark(2)
+        loss.backward()
+        mark(3)
+        m.optimizer.step()
+        mark(4)
+        if ev:
+            for i, name in enumerate(("forward", "loss", "backward", "optimizer")):
+                self.timing.setdefault(name, []).append((ev[i], ev[i + 1]))
+        self.loss = loss.detach().reshape(1)
+        return self.loss
+
+
+def deepfm_roofline(args, trainer, batches, engine):
+    """MLP_Block GEMMs (rocBLAS fp32) against the fp32 MFMA peak, over the eager forward + backward phases"""
+    trainer.timing = {}
+    for s in range(10):
+        trainer.step(*batches[s % len(batches)])
+    ph = engine.phases_ms(trainer)
+    trainer.timing = None
+    F, d = len(DEEPFM_VOCAB), args.emb_size
+    dims = [F * d] + list(eval(args.mlp)) + [1]
+    fwd = 2.0 * args.batch * sum(a * b for a, b in zip(dims[:-1], dims[1:]))
+    t = ph["forward"] + ph["backward"]
+    ach = 3.0 * fwd / (t * 1e-3) / 1e12
+    return {"phases_ms": {k: round(v, 4) for k, v in ph.items()},
+            "roofline": {"bound": "mfma", "kernel": "MLP_Block forward + backward (rocBLAS fp32 GEMMs; eager phases incl. the field "
+                         "gathers, FM term and their backward)", "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": ach / F32_MFMA_PEAK_TFLOPS, "traffic": None, "algorithmic_flops_per_launch": 3.0 * fwd, "avg_ms": t}}
+
+
+def cpu_baseline_deepfm(args, batches_cpu):
+    from oracle.torch_port import DeepfmCtrTorchPort
+    torch.manual_seed(0)
+    cores = torch.get_num_threads()
+    model = DeepfmCtrTorchPort(list(DEEPFM_VOCAB), DEEPFM_VOCAB, args.emb_size, layers=tuple(eval(args.mlp)))
+    optim = model.make_optimizer(args.opt, args.lr, args.l2)
+    steps, t_init = [], time.perf_counter()
+    for s, (f,) in enumerate(batches_cpu):
+        t0 = time.perf_counter()
+        model.fit_step(optim, f)
+        if s > 0:
+            steps.append(time.perf_counter() - t0)
+        if time.perf_counter() - t_init > 60 and steps:
+            break
+    return {"value": args.batch * len(steps) / sum(steps), "unit": "tuples/s", "cores": cores, "kind": "port",
+            "step_s": {"min": min(steps), "median": float(np.median(steps)), "max": max(steps)},
+            "sample": f"{len(steps)} fit() iterations of oracle/torch_port.py (DeepfmCtrTorchPort, torch {torch.__version__} CPU, {cores} "
+                      f"threads, dense torch.optim.{args.opt} like the reference) at B={args.batch}, F={len(DEEPFM_VOCAB)}, d={args.emb_size}, "
+                      f"MLP {args.mlp}; {sum(steps):.1f} s"}
 
 
 def algorithmic_bytes(args, batches):
@@ -356,8 +468,13 @@ def main():
 
     from rechorus_amd import engine
 
-    batches = make_batches(args, device, seed=99 + rank) if args.workload != "sasrec" else None
-    if args.workload == "sasrec":
+    batches = make_batches(args, device, seed=99 + rank) if args.workload not in ("sasrec", "deepfm") else None
+    if args.workload == "deepfm":
+        if world > 1 and args.parallel != "replicas":
+            raise SystemExit("--workload deepfm: one GPU (or --parallel replicas) in bench.py; the data-parallel leg is rechorus_amd/sharded.py::DataParallelDense")
+        trainer = DeepfmBench(args, device)
+        batches = trainer.batches(args, device, seed=99 + rank)
+    elif args.workload == "sasrec":
         if world > 1 and args.parallel != "replicas":
             raise SystemExit("--workload sasrec: the 8.7 K-row item table does not shard; use --parallel replicas for N > 1")
         trainer, batches = make_sasrec(args, device, engine, seed=99 + rank)
@@ -425,6 +542,21 @@ def main():
     if not np.isfinite(loss):
         raise SystemExit(f"non-finite loss {loss}")
 
+    if args.workload == "deepfm":
+        args.items, args.users, args.num_neg = DEEPFM_VOCAB["item_id"], DEEPFM_VOCAB["user_id"], 0
+        workload_text = (f"DeepFMCTR fit step: F={len(DEEPFM_VOCAB)} single-valued fields (MIND-like cardinalities, {DEEPFM_VOCAB['user_id']} users / "
+                         f"{DEEPFM_VOCAB['item_id']} items), emb_size={args.emb_size}, MLP {args.mlp}, BCE, B={args.batch} rows/GPU/step, "
+                         f"optimizer={args.opt} (dense = torch.optim semantics, l2={args.l2:g}), hipGraph replay of the step, int64 ids, fp32")
+    elif args.workload == "sasrec":
+        workload_text = (f"SASRec fit step: emb_size={args.emb_size}, history_max={args.hist} (lengths uniform on 1..{args.hist}), "
+                         f"{args.heads} heads, {args.layers} layer(s), num_neg={args.num_neg}, {args.items}-item table, Zipf(1.0) "
+                         f"histories+positives, uniform negatives, B={args.batch} sequences/GPU/step, optimizer={args.opt} "
+                         f"(row-wise, l2={args.l2:g}), int64 ids, fp32")
+    else:
+        workload_text = (f"{'NeuMF (hidden ' + str(args.hidden) + ')' if args.workload == 'neumf' else 'BPRMF'} fit step: emb_size={args.emb_size}, "
+                         f"num_neg={args.num_neg}, {args.items}-item / {args.users}-user tables, Zipf(1.0) users+positives, "
+                         f"uniform negatives, B={args.batch} tuples/GPU/step, optimizer={args.opt} "
+                         f"(row-wise, l2={args.l2:g}), int64 ids, fp32")
     tuples = args.batch * args.steps * world
     out = {
         "metric": "ranked (1+K)-tuples/sec",
@@ -440,14 +572,7 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": (f"SASRec fit step: emb_size={args.emb_size}, history_max={args.hist} (lengths uniform on 1..{args.hist}), "
-                         f"{args.heads} heads, {args.layers} layer(s), num_neg={args.num_neg}, {args.items}-item table, Zipf(1.0) "
-                         f"histories+positives, uniform negatives, B={args.batch} sequences/GPU/step, optimizer={args.opt} "
-                         f"(row-wise, l2={args.l2:g}), int64 ids, fp32") if args.workload == "sasrec" else
-                        f"{'NeuMF (hidden ' + str(args.hidden) + ')' if args.workload == 'neumf' else 'BPRMF'} fit step: emb_size={args.emb_size}, num_neg={args.num_neg}, "
-                        f"{args.items}-item / {args.users}-user tables, Zipf(1.0) users+positives, "
-                        f"uniform negatives, B={args.batch} tuples/GPU/step, optimizer={args.opt} "
-                        f"(row-wise, l2={args.l2:g}), int64 ids, fp32",
+            "workload": workload_text,
             "batch_per_gpu": args.batch, "num_neg": args.num_neg, "emb_size": args.emb_size,
             "n_items": args.items, "n_users": args.users, "optimizer": args.opt,
             "parallelism": "single GPU" if world == 1 else (
@@ -510,6 +635,15 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_roofline and isinstance(trainer, (engine.NeumfTrainer, engine.SasrecTrainer)):
         out.update(model_roofline(args, trainer, batches, engine))
+
+    if rank == 0 and world == 1 and args.workload == "deepfm":
+        out["metric"] = "labelled rows/sec (CTR: one tuple = one (user, item, context, label) row)"
+        if not args.no_roofline:
+            out.update(deepfm_roofline(args, trainer, batches, engine))
+        if not args.no_cpu_baseline:
+            cpu_b = [({k: (v.cpu() if torch.is_tensor(v) else v) for k, v in batches[s % len(batches)][0].items()},)
+                     for s in range(args.cpu_steps + 1)]
+            out["cpu_baseline"] = cpu_baseline_deepfm(args, cpu_b)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "bprmf":
         out["cpu_baseline"] = cpu_baseline(args)

@@ -199,3 +199,65 @@ class SasrecTorchPort(nn.Module):
         loss.backward()
         optimizer.step()
         return loss.detach()
+
+
+class _MlpBlock(nn.Module):
+    """utils/layers.py:201-243 with the options the context models use (ReLU, no norm): Linear, ReLU, [Dropout] per
+    hidden layer, then Linear(., 1); the Sequential is called `mlp` so the state_dict keys match (`deep_layers.mlp.N.*`)"""
+
+    def __init__(self, input_dim, hidden_units, dropout):
+        super().__init__()
+        layers, pre = [], input_dim
+        for h in hidden_units:
+            layers += [nn.Linear(pre, h), nn.ReLU()]
+            if dropout > 0:
+                layers.append(nn.Dropout(p=dropout))
+            pre = h
+        layers.append(nn.Linear(pre, 1))
+        self.mlp = nn.Sequential(*layers)
+
+    def forward(self, x):
+        return self.mlp(x)
+
+
+class DeepfmCtrTorchPort(nn.Module):
+    """DeepFMCTR over categorical fields with the reference's module names and operator sequence:
+    models/context/FM.py:34-57 (per-field nn.Embedding(vocab, d) + nn.Embedding(vocab, 1), overall_bias, stacking),
+    DeepFM.py:19-28 (FM second order + linear + deep), :37-41 (sigmoid), models/BaseModel.py:259-267 (nn.BCELoss)."""
+
+    def __init__(self, fields, feature_max, emb_size, layers=(512, 64), dropout=0.0):
+        super().__init__()
+        self.fields = list(fields)
+        self.context_embedding = nn.ModuleDict({f: nn.Embedding(feature_max[f], emb_size) for f in self.fields})
+        self.linear_embedding = nn.ModuleDict({f: nn.Embedding(feature_max[f], 1) for f in self.fields})
+        self.overall_bias = nn.Parameter(torch.tensor([0.01]))
+        self.deep_layers = _MlpBlock(len(self.fields) * emb_size, list(layers), dropout)
+        for m in self.modules():
+            if isinstance(m, (nn.Linear, nn.Embedding)):
+                nn.init.normal_(m.weight, mean=0.0, std=0.01)
+                if getattr(m, "bias", None) is not None:
+                    nn.init.normal_(m.bias, mean=0.0, std=0.01)
+
+    def forward(self, feed):
+        item_num = feed["item_id"].shape[1]
+        vec = [self.context_embedding[f](feed[f]) for f in self.fields]
+        vec = torch.stack([v if v.dim() == 3 else v.unsqueeze(-2).repeat(1, item_num, 1) for v in vec], dim=-2)
+        lin = [self.linear_embedding[f](feed[f]) for f in self.fields]
+        lin = torch.cat([v if v.dim() == 3 else v.unsqueeze(-2).repeat(1, item_num, 1) for v in lin], dim=-1)
+        lin = self.overall_bias + lin.sum(dim=-1)
+        fm = 0.5 * (vec.sum(dim=-2).pow(2) - vec.pow(2).sum(dim=-2))
+        deep = self.deep_layers(vec.flatten(start_dim=-2)).squeeze(dim=-1)
+        return (fm.sum(dim=-1) + lin + deep).view(-1).sigmoid()
+
+    @staticmethod
+    def loss(prediction, label):
+        return nn.BCELoss()(prediction, label.view(-1).float())
+
+    make_optimizer = NeumfTorchPort.make_optimizer
+
+    def fit_step(self, optimizer, feed):
+        optimizer.zero_grad()
+        loss = self.loss(self(feed), feed["label"])
+        loss.backward()
+        optimizer.step()
+        return loss.detach()

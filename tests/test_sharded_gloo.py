@@ -297,3 +297,80 @@ def test_sharded_neumf_single_rank():
     G = m.gather_global()
     for k, v in Pw.items():
         np.testing.assert_allclose(G[k].numpy(), v, rtol=2e-5, atol=1e-6, err_msg=k)
+
+
+# ---- data-parallel leg of the replicated-parameter models (config 5) ------------------------------------------------
+
+class _TinyCtr(torch.nn.Module):
+    """embedding + MLP + BCE, plain torch ops (the wrapper under test only touches gradients and the optimizer)"""
+
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(3)
+        self.emb = torch.nn.Embedding(23, 8)
+        self.mlp = torch.nn.Sequential(torch.nn.Linear(16, 12), torch.nn.ReLU(), torch.nn.Linear(12, 1))
+        self.optimizer = None
+
+    def forward(self, b):
+        return self.mlp(self.emb(b["ids"]).flatten(1)).view(-1).sigmoid()
+
+    def loss(self, p):
+        return torch.nn.BCELoss()(p, self._y)
+
+
+def _dp_batches(world, steps, B):
+    rng = np.random.default_rng(11)
+    return [[(rng.integers(0, 23, size=(B, 2)), rng.integers(0, 2, size=B).astype(np.float32)) for _ in range(world)]
+            for _ in range(steps)]
+
+
+def _dp_worker(rank, world, port, opt, out_q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from rechorus_amd.sharded import DataParallelDense
+        m = _TinyCtr()
+        m.optimizer = getattr(torch.optim, opt)(m.parameters(), lr=0.05)
+
+        def loss_of(model, b):
+            model._y = b["y"]
+            return model.loss(model(b))
+        dp = DataParallelDense(m, loss_of=loss_of)
+        losses = []
+        for per_rank in _dp_batches(world, 3, 6):
+            ids, y = per_rank[rank]
+            losses.append(float(dp.step({"ids": torch.from_numpy(ids), "y": torch.from_numpy(y)})))
+        if rank == 0:
+            out_q.put((losses, {k: v.detach().numpy().copy() for k, v in m.state_dict().items()}, dp.bytes_per_step))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,opt", [(2, "SGD"), (3, "Adam")])
+def test_data_parallel_dense_equals_training_on_the_global_batch(world, opt):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_worker, args=(r, world, port, opt, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    losses, sd, nbytes = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref = _TinyCtr()
+    optim = getattr(torch.optim, opt)(ref.parameters(), lr=0.05)
+    want = []
+    for per_rank in _dp_batches(world, 3, 6):
+        ids = torch.from_numpy(np.concatenate([b[0] for b in per_rank]))
+        ref._y = torch.from_numpy(np.concatenate([b[1] for b in per_rank]))
+        optim.zero_grad()
+        loss = ref.loss(ref({"ids": ids}))
+        loss.backward()
+        optim.step()
+        want.append(float(loss))
+    np.testing.assert_allclose(losses, want, rtol=1e-5)
+    for k, v in ref.state_dict().items():
+        np.testing.assert_allclose(sd[k], v.detach().numpy(), rtol=2e-5, atol=2e-6, err_msg=k)
+    n_param = sum(p.numel() for p in ref.parameters())
+    assert nbytes == 2 * (world - 1) * n_param * 4 // world
