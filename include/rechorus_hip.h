@@ -330,6 +330,24 @@ int rc_sasrec_batch_bwd(const float* const* layer_params, int n_layers, int n_he
                         int B, int L, int d, const float* state, const float* dhv, float* g_hist,
                         float* dense_grads, void* ws, size_t ws_bytes, rc_stream_t stream);
 
+/* Training mode with --dropout p (utils/layers.py:104,110 dropout1 on the attention context, :114,117 dropout2 on the
+ * FFN output; SASRec.py:47-49 passes the model's --dropout).  The mask is never stored: element (compact row r,
+ * feature f) of site s = 2 * layer + {0: dropout1, 1: dropout2} is dropped iff word (f & 3) of
+ * Philox4x32-10(key = *seed_dev, counter = (r, s * d/4 + (f >> 2))) < p * 2^32, kept values are scaled by 1/(1-p);
+ * r = (sum of min(len, L) over the sequences before b) + position.  The LayerNorm kernels of both passes
+ * regenerate it; the caller bumps *seed_dev once per step (rc_step_increment, capturable).  As for NeuMF, parity
+ * with the reference is exact given the mask (tests/golden/sasrecdrop_*.npz: the reference in training mode with
+ * its nn.Dropout modules swapped for this mask) and distributional in the mask.  p = 0 (seed_dev may be NULL) is
+ * rc_sasrec_batch_fwd / rc_sasrec_batch_bwd bit for bit.                                                       */
+int rc_sasrec_batch_fwd_dropout(const float* item_emb, const float* pos_emb, const float* const* layer_params,
+                                int n_layers, int n_heads, const int64_t* hist, const int64_t* lengths, int B,
+                                int L, int d, float drop_p, const uint64_t* seed_dev, float* hv, float* state,
+                                void* ws, size_t ws_bytes, rc_stream_t stream);
+int rc_sasrec_batch_bwd_dropout(const float* const* layer_params, int n_layers, int n_heads,
+                                const int64_t* lengths, int B, int L, int d, float drop_p,
+                                const uint64_t* seed_dev, const float* state, const float* dhv, float* g_hist,
+                                float* dense_grads, void* ws, size_t ws_bytes, rc_stream_t stream);
+
 /* Gradient of the position table p_embeddings (SASRec.py:64: position id = length - index on valid slots, 0 on
  * padding): grad_pos[p] = sum_b g_hist[b, len_b - p] over the sequences with len_b >= p, rows 0 and > L are zero.
  * Replaces aten::embedding_dense_backward on the [B, L] position ids; fixed summation order.                  */

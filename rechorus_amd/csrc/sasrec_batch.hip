@@ -13,6 +13,7 @@
 // recomputed.  Dense-parameter gradients: per-workgroup partials in private slices, summed in fixed order
 // (sas_reduce_partials_kernel); no float atomics anywhere.
 #include "common.hpp"
+#include "philox.hpp"
 #include "sas_mma.hpp"
 
 namespace rc {
@@ -235,18 +236,44 @@ __global__ __launch_bounds__(kBlock) void sb_linear3_sum_kernel(SbSum3Args a) {
 
 // ---- LayerNorm over rows: z = A (+ Bv) -> xhat, rstd, y = w * xhat + b ----------------------------------
 
+// Training-mode dropout of the two residual branches of a TransformerLayer (utils/layers.py:104,110 dropout1 on the
+// attention context, :114,117 dropout2 on the FFN output; both feed `layer_norm(drop(branch) + residual)`): the mask
+// is never stored.  Element (compact row r, feature f) of site s = 2 * layer + {0: dropout1, 1: dropout2} is dropped
+// iff word (f & 3) of Philox4x32-10(key = seed, counter = (r, s * D/4 + (f >> 2))) < thresh; kept values are scaled by
+// 1 / (1 - p).  The LayerNorm kernels regenerate it: forward masks the branch before the residual add, backward
+// emits the masked gradient for the branch next to the unmasked one for the residual path.  seed == nullptr: off.
+struct SbDrop {
+  const uint64_t* seed;   // device memory: a captured step replays with a fresh mask once the host bumps it
+  uint32_t thresh;
+  float scale;
+  uint32_t site;
+};
+
+template <int D>
+__device__ __forceinline__ float4 sb_drop_keep4(const SbDrop& dr, uint64_t seed, int64_t r, int l) {
+  uint32_t wd[4];
+  philox4x32_10(seed, (uint64_t)r, dr.site * (uint32_t)(D / 4) + (uint32_t)l, wd);
+  return make_float4(wd[0] < dr.thresh ? 0.f : dr.scale, wd[1] < dr.thresh ? 0.f : dr.scale,
+                     wd[2] < dr.thresh ? 0.f : dr.scale, wd[3] < dr.thresh ? 0.f : dr.scale);
+}
+
 template <int D>
 __global__ __launch_bounds__(kBlock) void sb_ln_fwd_kernel(const float* __restrict__ A, const float* __restrict__ Bv,
                                                            const float* __restrict__ w, const float* __restrict__ bb,
                                                            const int32_t* __restrict__ off, int B,
                                                            float* __restrict__ xhat, float* __restrict__ rstd,
-                                                           float* __restrict__ y) {
+                                                           float* __restrict__ y, SbDrop dr) {
   constexpr int LPR = D / 4;
   const int l = threadIdx.x % LPR;
   const int R = off[B];
   const float4 wv = reinterpret_cast<const float4*>(w)[l], bv = reinterpret_cast<const float4*>(bb)[l];
+  const uint64_t seed = dr.seed ? *dr.seed : 0;
   for (int64_t r = (int64_t)blockIdx.x * (kBlock / LPR) + threadIdx.x / LPR; r < R; r += (int64_t)gridDim.x * (kBlock / LPR)) {
     float4 z = reinterpret_cast<const float4*>(A)[r * LPR + l];
+    if (dr.seed) {
+      const float4 kp = sb_drop_keep4<D>(dr, seed, r, l);
+      z.x *= kp.x; z.y *= kp.y; z.z *= kp.z; z.w *= kp.w;
+    }
     if (Bv) {
       const float4 t = reinterpret_cast<const float4*>(Bv)[r * LPR + l];
       z.x += t.x; z.y += t.y; z.z += t.z; z.w += t.w;
@@ -263,19 +290,21 @@ __global__ __launch_bounds__(kBlock) void sb_ln_fwd_kernel(const float* __restri
   }
 }
 
-// LayerNorm backward in place: G holds dY on entry, dZ on exit; per-workgroup partial d(weight), d(bias) go to
+// LayerNorm backward in place: G holds dY on entry, dZ on exit (with dropout: Gdrop = mask * dZ as well);
+// per-workgroup partial d(weight), d(bias) go to
 // gw[blockIdx][:D], gb[blockIdx][:D] (stride = part_stride floats between workgroups)
 template <int D>
 __global__ __launch_bounds__(kBlock) void sb_ln_bwd_kernel(float* __restrict__ G, const float* __restrict__ xhat,
                                                            const float* __restrict__ rstd, const float* __restrict__ w,
                                                            const int32_t* __restrict__ off, int B,
                                                            float* __restrict__ gw, float* __restrict__ gb,
-                                                           size_t part_stride) {
+                                                           size_t part_stride, SbDrop dr, float* __restrict__ Gdrop) {
   constexpr int LPR = D / 4, GPB = kBlock / LPR;
   __shared__ float s_red[2][GPB][D + 1];
   const int l = threadIdx.x % LPR, grp = threadIdx.x / LPR;
   const int R = off[B];
   const float4 wv = reinterpret_cast<const float4*>(w)[l];
+  const uint64_t seed = dr.seed ? *dr.seed : 0;
   float4 aw = make_float4(0.f, 0.f, 0.f, 0.f), ab = aw;
   for (int64_t r = (int64_t)blockIdx.x * GPB + grp; r < R; r += (int64_t)gridDim.x * GPB) {
     const float4 g = reinterpret_cast<const float4*>(G)[r * LPR + l];
@@ -286,9 +315,13 @@ __global__ __launch_bounds__(kBlock) void sb_ln_bwd_kernel(float* __restrict__ G
     const float m1 = row_allreduce_sum<LPR>((dx.x + dx.y) + (dx.z + dx.w)) / D;
     const float m2 = row_allreduce_sum<LPR>(fmaf(dx.x, xh.x, fmaf(dx.y, xh.y, fmaf(dx.z, xh.z, dx.w * xh.w)))) / D;
     const float rs = rstd[r];
-    reinterpret_cast<float4*>(G)[r * LPR + l] =
-        make_float4(rs * (dx.x - m1 - xh.x * m2), rs * (dx.y - m1 - xh.y * m2), rs * (dx.z - m1 - xh.z * m2),
-                    rs * (dx.w - m1 - xh.w * m2));
+    const float4 dz = make_float4(rs * (dx.x - m1 - xh.x * m2), rs * (dx.y - m1 - xh.y * m2), rs * (dx.z - m1 - xh.z * m2),
+                                  rs * (dx.w - m1 - xh.w * m2));
+    reinterpret_cast<float4*>(G)[r * LPR + l] = dz;
+    if (dr.seed) {  // gradient of the dropped branch: the same mask as the forward pass
+      const float4 kp = sb_drop_keep4<D>(dr, seed, r, l);
+      reinterpret_cast<float4*>(Gdrop)[r * LPR + l] = make_float4(dz.x * kp.x, dz.y * kp.y, dz.z * kp.z, dz.w * kp.w);
+    }
   }
   float* sw = &s_red[0][grp][4 * l];
   float* sb = &s_red[1][grp][4 * l];
@@ -766,7 +799,7 @@ static size_t sb_state_int_floats(int B) { return 5 * (size_t)B + 72; }
 
 struct SbWs {
   int32_t *off, *bucket;  // live in the state buffer
-  float *t0, *t1, *t2, *t3;  // [Rmax, D] scratch
+  float *t0, *t1, *t2, *t3, *t4;  // [Rmax, D] scratch (t4: the masked branch gradient when dropout is on)
   float* part;               // [kSbPartWg][n_layers * PL]
   size_t total;
 };
@@ -780,6 +813,7 @@ static SbWs sb_carve(void* base, float* state, int B, int L, int d, int n_layers
   w.t1 = bwd ? cv.take<float>(rmax * d) : nullptr;
   w.t2 = bwd ? cv.take<float>(rmax * d) : nullptr;
   w.t3 = bwd ? cv.take<float>(rmax * d) : nullptr;
+  w.t4 = bwd ? cv.take<float>(rmax * d) : nullptr;
   w.part = bwd ? cv.take<float>((size_t)kSbPartWg * n_layers * (5 * (size_t)d * d + 9 * d)) : nullptr;
   w.total = cv.off;
   return w;
@@ -858,8 +892,9 @@ static int sb_attention(SbAttnArgs a, int32_t* bucket, bool make_buckets, hipStr
 template <int D>
 static int sb_forward(const float* item_emb, const float* pos_emb, const SasLayer* layer, int n_layers, int n_heads,
                       const int64_t* hist, const int64_t* lengths, int B, int L, float* hv, float* state,
-                      const SbWs& w, hipStream_t s) {
+                      const SbWs& w, SbDrop dr, hipStream_t s) {
   constexpr int LPR = D / 4;
+  const bool drop = dr.seed != nullptr;
   const size_t rmax = (size_t)B * L;
   hipLaunchKernelGGL(sb_offsets_kernel, dim3(1), dim3(kBlock), 0, s, lengths, B, L, w.off);
   RC_LAUNCH_CHECK();
@@ -882,17 +917,22 @@ static int sb_forward(const float* item_emb, const float* pos_emb, const SasLaye
     at.q = sv.q; at.k = sv.k; at.v = sv.v; at.ctx = w.t0; at.lengths = lengths; at.off = w.off; at.B = B; at.L = L;
     at.n_heads = n_heads;
     RC_TRY((sb_attention<D, false>(at, w.bucket, l == 0, s)));
+    dr.site = 2u * (uint32_t)l;      // dropout1 on the attention context (utils/layers.py:110)
     hipLaunchKernelGGL((sb_ln_fwd_kernel<D>), dim3(sb_row_grid((int64_t)rmax, LPR)), dim3(kBlock), 0, s, w.t0, sv.x, p.ln1w,
-                       p.ln1b, w.off, B, sv.xh1, sv.rstd1, sv.y1);
+                       p.ln1b, w.off, B, sv.xh1, sv.rstd1, sv.y1, dr);
     RC_LAUNCH_CHECK();
     memset(&a, 0, sizeof(a));
     a.off = w.off; a.B = B;
     a.X = sv.y1; a.W[0] = p.W1; a.bias[0] = p.b1; a.Y[0] = sv.h; a.relu = 1;
     RC_TRY((sb_linear<D, 1, false>(a, (int64_t)rmax, s)));
-    a.X = sv.h; a.W[0] = p.W2; a.bias[0] = p.b2; a.Y[0] = w.t0; a.relu = 0; a.res = sv.y1;
+    // without dropout the residual y1 is added by the projection's epilogue; with dropout2 (utils/layers.py:117) the
+    // LayerNorm kernel masks the FFN output first and adds the residual itself
+    a.X = sv.h; a.W[0] = p.W2; a.bias[0] = p.b2; a.Y[0] = w.t0; a.relu = 0; a.res = drop ? nullptr : sv.y1;
     RC_TRY((sb_linear<D, 1, false>(a, (int64_t)rmax, s)));
+    dr.site = 2u * (uint32_t)l + 1u;
     hipLaunchKernelGGL((sb_ln_fwd_kernel<D>), dim3(sb_row_grid((int64_t)rmax, LPR)), dim3(kBlock), 0, s, w.t0,
-                       static_cast<const float*>(nullptr), p.ln2w, p.ln2b, w.off, B, sv.xh2, sv.rstd2, xnext);
+                       drop ? static_cast<const float*>(sv.y1) : static_cast<const float*>(nullptr), p.ln2w, p.ln2b, w.off, B,
+                       sv.xh2, sv.rstd2, xnext, dr);
     RC_LAUNCH_CHECK();
   }
   const float* xout = state + (size_t)n_layers * sb_layer_floats(rmax, D);
@@ -916,8 +956,9 @@ static int sb_wgrad(const SbWgradArgs& a, int64_t rmax, hipStream_t s) {
 template <int D>
 static int sb_backward(const SasLayer* layer, int n_layers, int n_heads, const int64_t* lengths, int B, int L,
                        const float* state, const float* dhv, float* g_hist, float* dense_out, const SbWs& w,
-                       hipStream_t s) {
+                       SbDrop dr, hipStream_t s) {
   using Cfg = SasCfg<D>;
+  const bool drop = dr.seed != nullptr;
   constexpr int LPR = D / 4, PL = Cfg::PL;
   const size_t rmax = (size_t)B * L;
   const size_t stride = (size_t)n_layers * PL;  // floats between the slices of consecutive workgroups
@@ -931,32 +972,36 @@ static int sb_backward(const SasLayer* layer, int n_layers, int n_heads, const i
     const SbSaved sv = sb_saved(const_cast<float*>(state), l, rmax, D);
     float* gp = w.part + (size_t)l * PL;
     // LayerNorm2
+    // (dropout: G = dZ2 feeds the residual path, Gb = mask2 * dZ2 the FFN branch)
+    float* Gb = drop ? w.t4 : G;
+    dr.site = 2u * (uint32_t)l + 1u;
     hipLaunchKernelGGL((sb_ln_bwd_kernel<D>), dim3(ln_grid), dim3(kBlock), 0, s, G, sv.xh2, sv.rstd2, p.ln2w, w.off, B,
-                       gp + Cfg::oln2w, gp + Cfg::oln2b, stride);
+                       gp + Cfg::oln2w, gp + Cfg::oln2b, stride, dr, Gb);
     RC_LAUNCH_CHECK();
     // FFN: dW2, db2; dHpre = (dZ2 . W2) * relu'(h); dW1, db1; dY1 = dZ2 + dHpre . W1
     SbWgradArgs g;
     memset(&g, 0, sizeof(g));
     g.off = w.off; g.B = B; g.part_stride = stride;
-    g.dY[0] = G; g.X = sv.h; g.gW[0] = gp + Cfg::oW2; g.gb[0] = gp + Cfg::ob2;
+    g.dY[0] = Gb; g.X = sv.h; g.gW[0] = gp + Cfg::oW2; g.gb[0] = gp + Cfg::ob2;
     RC_TRY((sb_wgrad<D, 1>(g, (int64_t)rmax, s)));
     SbLinArgs a;
     memset(&a, 0, sizeof(a));
     a.off = w.off; a.B = B;
-    a.X = G; a.W[0] = p.W2; a.Y[0] = w.t1; a.mask = sv.h;
+    a.X = Gb; a.W[0] = p.W2; a.Y[0] = w.t1; a.mask = sv.h;
     RC_TRY((sb_linear<D, 1, true>(a, (int64_t)rmax, s)));
     g.dY[0] = w.t1; g.X = sv.y1; g.gW[0] = gp + Cfg::oW1; g.gb[0] = gp + Cfg::ob1;
     RC_TRY((sb_wgrad<D, 1>(g, (int64_t)rmax, s)));
     a.X = w.t1; a.W[0] = p.W1; a.Y[0] = G; a.mask = nullptr; a.res = G;
     RC_TRY((sb_linear<D, 1, true>(a, (int64_t)rmax, s)));
     // LayerNorm1: G = dZ1 = dCtx = the residual branch of dX
+    dr.site = 2u * (uint32_t)l;
     hipLaunchKernelGGL((sb_ln_bwd_kernel<D>), dim3(ln_grid), dim3(kBlock), 0, s, G, sv.xh1, sv.rstd1, p.ln1w, w.off, B,
-                       gp + Cfg::oln1w, gp + Cfg::oln1b, stride);
+                       gp + Cfg::oln1w, gp + Cfg::oln1b, stride, dr, Gb);
     RC_LAUNCH_CHECK();
     // attention
     SbAttnArgs at;
     memset(&at, 0, sizeof(at));
-    at.q = sv.q; at.k = sv.k; at.v = sv.v; at.dctx = G; at.dq = w.t1; at.dk = w.t2; at.dv = w.t3;
+    at.q = sv.q; at.k = sv.k; at.v = sv.v; at.dctx = Gb; at.dq = w.t1; at.dk = w.t2; at.dv = w.t3;
     at.lengths = lengths; at.off = w.off; at.B = B; at.L = L; at.n_heads = n_heads;
     RC_TRY((sb_attention<D, true>(at, w.bucket, false, s)));
     // projections: parameter gradients against the layer input, dX = dZ1 + dQ Wq + dK Wk + dV Wv
@@ -1003,9 +1048,23 @@ extern "C" size_t rc_sasrec_batch_workspace_bytes(int B, int L, int d, int n_lay
   return sb_carve(nullptr, nullptr, B, L, d, n_layers, true).total + 256;
 }
 
-extern "C" int rc_sasrec_batch_fwd(const float* item_emb, const float* pos_emb, const float* const* layer_params,
-                                   int n_layers, int n_heads, const int64_t* hist, const int64_t* lengths, int B, int L,
-                                   int d, float* hv, float* state, void* ws, size_t ws_bytes, rc_stream_t stream) {
+// dropout arguments -> kernel fields; p == 0 switches the mask off
+static int sb_set_dropout(SbDrop& dr, float drop_p, const uint64_t* seed_dev, const char* who) {
+  memset(&dr, 0, sizeof(dr));
+  if (!(drop_p >= 0.f && drop_p < 1.f)) return fail(RC_ERR_INVALID_ARG, "%s: dropout p=%g outside [0, 1)", who, (double)drop_p);
+  if (drop_p > 0.f && seed_dev == nullptr) return fail(RC_ERR_INVALID_ARG, "%s: dropout p=%g needs a device seed", who, (double)drop_p);
+  if (drop_p > 0.f) {
+    dr.seed = seed_dev;
+    dr.thresh = (uint32_t)((double)drop_p * 4294967296.0);
+    dr.scale = 1.0f / (1.0f - drop_p);
+  }
+  return RC_OK;
+}
+
+extern "C" int rc_sasrec_batch_fwd_dropout(const float* item_emb, const float* pos_emb, const float* const* layer_params,
+                                           int n_layers, int n_heads, const int64_t* hist, const int64_t* lengths, int B,
+                                           int L, int d, float drop_p, const uint64_t* seed_dev, float* hv, float* state,
+                                           void* ws, size_t ws_bytes, rc_stream_t stream) {
   if (B == 0) return RC_OK;
   RC_REQUIRE(item_emb && pos_emb && hist && lengths && hv && state && ws, "rc_sasrec_batch_fwd: null pointer");
   if (!rc_sasrec_supported(d, n_layers, n_heads, L))
@@ -1013,27 +1072,46 @@ extern "C" int rc_sasrec_batch_fwd(const float* item_emb, const float* pos_emb, 
   RC_REQUIRE((int64_t)B * L < ((int64_t)1 << 31), "rc_sasrec_batch_fwd: B * L too large");
   SasLayer layer[kSasMaxLayers];
   RC_TRY(sb_fill_layers(layer, layer_params, n_layers));
+  SbDrop dr;
+  RC_TRY(sb_set_dropout(dr, drop_p, seed_dev, "rc_sasrec_batch_fwd"));
   const SbWs w = sb_carve(ws, state, B, L, d, n_layers, false);
   if (ws_bytes < w.total) return fail(RC_ERR_WORKSPACE, "rc_sasrec_batch_fwd: workspace %zu < %zu", ws_bytes, w.total);
   hipStream_t s = as_stream(stream);
-  return d == 64 ? sb_forward<64>(item_emb, pos_emb, layer, n_layers, n_heads, hist, lengths, B, L, hv, state, w, s)
-                 : sb_forward<32>(item_emb, pos_emb, layer, n_layers, n_heads, hist, lengths, B, L, hv, state, w, s);
+  return d == 64 ? sb_forward<64>(item_emb, pos_emb, layer, n_layers, n_heads, hist, lengths, B, L, hv, state, w, dr, s)
+                 : sb_forward<32>(item_emb, pos_emb, layer, n_layers, n_heads, hist, lengths, B, L, hv, state, w, dr, s);
 }
 
-extern "C" int rc_sasrec_batch_bwd(const float* const* layer_params, int n_layers, int n_heads, const int64_t* lengths,
-                                   int B, int L, int d, const float* state, const float* dhv, float* g_hist,
-                                   float* dense_grads, void* ws, size_t ws_bytes, rc_stream_t stream) {
+extern "C" int rc_sasrec_batch_fwd(const float* item_emb, const float* pos_emb, const float* const* layer_params,
+                                   int n_layers, int n_heads, const int64_t* hist, const int64_t* lengths, int B, int L,
+                                   int d, float* hv, float* state, void* ws, size_t ws_bytes, rc_stream_t stream) {
+  return rc_sasrec_batch_fwd_dropout(item_emb, pos_emb, layer_params, n_layers, n_heads, hist, lengths, B, L, d, 0.f, nullptr,
+                                     hv, state, ws, ws_bytes, stream);
+}
+
+extern "C" int rc_sasrec_batch_bwd_dropout(const float* const* layer_params, int n_layers, int n_heads,
+                                           const int64_t* lengths, int B, int L, int d, float drop_p,
+                                           const uint64_t* seed_dev, const float* state, const float* dhv, float* g_hist,
+                                           float* dense_grads, void* ws, size_t ws_bytes, rc_stream_t stream) {
   if (B == 0) return RC_OK;
   RC_REQUIRE(lengths && state && dhv && g_hist && dense_grads && ws, "rc_sasrec_batch_bwd: null pointer");
   if (!rc_sasrec_supported(d, n_layers, n_heads, L))
     return fail(RC_ERR_UNSUPPORTED, "rc_sasrec_batch_bwd: d=%d layers=%d heads=%d L=%d not supported", d, n_layers, n_heads, L);
   SasLayer layer[kSasMaxLayers];
   RC_TRY(sb_fill_layers(layer, layer_params, n_layers));
+  SbDrop dr;
+  RC_TRY(sb_set_dropout(dr, drop_p, seed_dev, "rc_sasrec_batch_bwd"));
   const SbWs w = sb_carve(ws, const_cast<float*>(state), B, L, d, n_layers, true);
   if (ws_bytes < w.total) return fail(RC_ERR_WORKSPACE, "rc_sasrec_batch_bwd: workspace %zu < %zu", ws_bytes, w.total);
   hipStream_t s = as_stream(stream);
-  return d == 64 ? sb_backward<64>(layer, n_layers, n_heads, lengths, B, L, state, dhv, g_hist, dense_grads, w, s)
-                 : sb_backward<32>(layer, n_layers, n_heads, lengths, B, L, state, dhv, g_hist, dense_grads, w, s);
+  return d == 64 ? sb_backward<64>(layer, n_layers, n_heads, lengths, B, L, state, dhv, g_hist, dense_grads, w, dr, s)
+                 : sb_backward<32>(layer, n_layers, n_heads, lengths, B, L, state, dhv, g_hist, dense_grads, w, dr, s);
+}
+
+extern "C" int rc_sasrec_batch_bwd(const float* const* layer_params, int n_layers, int n_heads, const int64_t* lengths,
+                                   int B, int L, int d, const float* state, const float* dhv, float* g_hist,
+                                   float* dense_grads, void* ws, size_t ws_bytes, rc_stream_t stream) {
+  return rc_sasrec_batch_bwd_dropout(layer_params, n_layers, n_heads, lengths, B, L, d, 0.f, nullptr, state, dhv, g_hist,
+                                     dense_grads, ws, ws_bytes, stream);
 }
 
 extern "C" size_t rc_sasrec_pos_grad_workspace_bytes(int B, int L, int d) {

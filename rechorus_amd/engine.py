@@ -459,7 +459,7 @@ def _drop_args(drop_p, seed):
     if not drop_p:
         return C.c_float(0.0), C.c_void_p(0)
     if seed is None:
-        raise ValueError("NeuMF dropout needs a device seed tensor (int64 [1])")
+        raise ValueError("dropout needs a device seed tensor (int64 [1])")
     return C.c_float(float(drop_p)), _ptr(seed, torch.int64, "seed")
 
 
@@ -641,15 +641,21 @@ def _sasrec_impl(B, L, impl):
     return impl
 
 
-def sasrec_fwd(item_emb, pos_emb, layers, n_heads, hist, lengths, save=False, impl=None):
+def sasrec_fwd(item_emb, pos_emb, layers, n_heads, hist, lengths, save=False, impl=None, drop_p=0.0, seed=None):
     """-> (hv [B,d], SasSaved|None): encoder output at position length-1 (SASRec.py:58-76).
     impl: 'sequence' (csrc/sasrec.hip, one workgroup per sequence), 'batch' (csrc/sasrec_batch.hip, row-space
-    kernels), default by batch size."""
+    kernels), default by batch size.  drop_p > 0: training-mode dropout of both residual branches of every layer
+    (utils/layers.py:104-117), mask from the counter-based stream keyed by seed[0] (int64 [1] on the device); only
+    the batch-level kernels carry it (rc_sasrec_batch_fwd_dropout), so dropout selects them."""
     B, L = hist.shape
     d = item_emb.shape[1]
     dev, f32 = hist.device, torch.float32
     hv = torch.empty((B, d), dtype=f32, device=dev)
     lib = _lib.load()
+    if drop_p > 0.0:
+        if impl == "sequence":
+            raise ValueError("SASRec dropout is implemented by the batch-level kernels only (impl='batch')")
+        impl = "batch"
     impl = _sasrec_impl(B, L, impl)
     if impl == "batch":
         # eval passes reuse one scratch state; training passes own theirs until the backward has run
@@ -657,10 +663,10 @@ def sasrec_fwd(item_emb, pos_emb, layers, n_heads, hist, lengths, save=False, im
         state = (torch.empty(n_state, dtype=f32, device=dev) if save
                  else workspace(4 * n_state, dev, "sasrec_state").view(f32)[:n_state])
         ws = workspace(lib.rc_sasrec_batch_workspace_bytes(B, L, d, len(layers)), dev, "sasrec_batch")
-        _lib.call("rc_sasrec_batch_fwd", _ptr(item_emb, f32, "item_emb"), _ptr(pos_emb, f32, "pos_emb"),
+        _lib.call("rc_sasrec_batch_fwd_dropout", _ptr(item_emb, f32, "item_emb"), _ptr(pos_emb, f32, "pos_emb"),
                   _sas_ptr_table(layers), len(layers), int(n_heads), _ptr(hist, torch.int64, "hist"),
-                  _ptr(lengths, torch.int64, "lengths"), B, L, d, _ptr(hv, f32, "hv"), _ptr(state, f32, "state"),
-                  C.c_void_p(ws.data_ptr()), ws.numel(), _stream())
+                  _ptr(lengths, torch.int64, "lengths"), B, L, d, *_drop_args(drop_p, seed), _ptr(hv, f32, "hv"),
+                  _ptr(state, f32, "state"), C.c_void_p(ws.data_ptr()), ws.numel(), _stream())
         return hv, (SasSaved("batch", state, B, len(layers), L, d) if save else None)
     xsave = torch.empty((B, len(layers), L, d), dtype=f32, device=dev) if save else None
     ws = workspace(lib.rc_sasrec_workspace_bytes(B, d, len(layers)), dev, "sasrec")
@@ -671,8 +677,9 @@ def sasrec_fwd(item_emb, pos_emb, layers, n_heads, hist, lengths, save=False, im
     return hv, (SasSaved("sequence", xsave, B, len(layers), L, d) if save else None)
 
 
-def sasrec_bwd(layers, n_heads, lengths, saved, dhv):
-    """-> (g_hist [B,L,d], list of per-layer dicts of dense gradients); `saved` from sasrec_fwd(save=True)"""
+def sasrec_bwd(layers, n_heads, lengths, saved, dhv, drop_p=0.0, seed=None):
+    """-> (g_hist [B,L,d], list of per-layer dicts of dense gradients); `saved` from sasrec_fwd(save=True);
+    drop_p / seed as given to the forward this is the backward of (the mask is regenerated, not stored)"""
     B, n_layers, L, d = saved.B, saved.n_layers, saved.L, saved.d
     dev, f32 = dhv.device, torch.float32
     g_hist = torch.empty((B, L, d), dtype=f32, device=dev)
@@ -681,10 +688,13 @@ def sasrec_bwd(layers, n_heads, lengths, saved, dhv):
     dense = torch.empty((n_layers, pl), dtype=f32, device=dev)
     if saved.impl == "batch":
         ws = workspace(lib.rc_sasrec_batch_workspace_bytes(B, L, d, n_layers), dev, "sasrec_batch")
-        _lib.call("rc_sasrec_batch_bwd", _sas_ptr_table(layers), n_layers, int(n_heads), _ptr(lengths, torch.int64, "lengths"),
-                  B, L, d, _ptr(saved.data, f32, "state"), _ptr(dhv, f32, "dhv"), _ptr(g_hist, f32, "g_hist"),
-                  _ptr(dense, f32, "dense"), C.c_void_p(ws.data_ptr()), ws.numel(), _stream())
+        _lib.call("rc_sasrec_batch_bwd_dropout", _sas_ptr_table(layers), n_layers, int(n_heads),
+                  _ptr(lengths, torch.int64, "lengths"), B, L, d, *_drop_args(drop_p, seed), _ptr(saved.data, f32, "state"),
+                  _ptr(dhv, f32, "dhv"), _ptr(g_hist, f32, "g_hist"), _ptr(dense, f32, "dense"), C.c_void_p(ws.data_ptr()),
+                  ws.numel(), _stream())
     else:
+        if drop_p > 0.0:
+            raise ValueError("SASRec dropout needs the batch-level kernels")
         ws = workspace(lib.rc_sasrec_workspace_bytes(B, d, n_layers), dev, "sasrec")
         _lib.call("rc_sasrec_bwd", _sas_ptr_table(layers), n_layers, int(n_heads), _ptr(lengths, torch.int64, "lengths"),
                   B, L, d, _ptr(saved.data, f32, "xsave"), _ptr(dhv, f32, "dhv"), _ptr(g_hist, f32, "g_hist"),
@@ -727,10 +737,14 @@ def segmented_update2(keys, perm, src, src2, n_split, hyper=None, W=None, m=None
 
 class SasrecTrainer:
     """One BaseRunner.fit iteration for SASRec on device tensors.
-    P = {"item_emb": [n_items,d], "pos_emb": [max_his+1,d], "layers": [dict(SAS_LAYER_KEYS) ...]}."""
+    P = {"item_emb": [n_items,d], "pos_emb": [max_his+1,d], "layers": [dict(SAS_LAYER_KEYS) ...]}.
+    dropout > 0: both residual branches of every layer dropped with a fresh mask per step (device seed counter,
+    bumped every step; batch-level kernels)."""
 
-    def __init__(self, P, n_heads, opt="Adam", lr=1e-3, l2=0.0, rowwise=False):
+    def __init__(self, P, n_heads, opt="Adam", lr=1e-3, l2=0.0, rowwise=False, dropout=0.0, seed=0):
         self.P, self.n_heads, self.opt, self.lr, self.l2, self.rowwise = P, n_heads, opt, lr, l2, rowwise
+        self.dropout = float(dropout)
+        self.seed = torch.tensor([seed], dtype=torch.int64, device=P["item_emb"].device) if self.dropout > 0 else None
         self.step_count = 0
         self.loss = None
         self.state = {}
@@ -755,15 +769,17 @@ class SasrecTrainer:
         self.step_count += 1
         h = make_hyper(self.opt, lr=self.lr, l2=self.l2, step=self.step_count)
         h0 = make_hyper(self.opt, lr=self.lr, l2=0.0, step=self.step_count)
+        if self.seed is not None:
+            step_increment(self.seed)
         with _PhaseTimer(self, "encoder_fwd"):
-            hv, xsave = sasrec_fwd(I, Pe, layers, self.n_heads, hist, lengths, save=True)
+            hv, xsave = sasrec_fwd(I, Pe, layers, self.n_heads, hist, lengths, save=True, drop_p=self.dropout, seed=self.seed)
         with _PhaseTimer(self, "score_loss"):
             rows = torch.arange(B, device=hist.device)
             pred = gather_dot(hv, I, rows, iid)                       # SASRec.py:80-81
             self.loss, _, gpred = bpr_loss(pred)
             dhv = weighted_row_sum(I, iid, gpred)
         with _PhaseTimer(self, "encoder_bwd"):
-            g_hist, dgrads = sasrec_bwd(layers, self.n_heads, lengths, xsave, dhv)
+            g_hist, dgrads = sasrec_bwd(layers, self.n_heads, lengths, xsave, dhv, drop_p=self.dropout, seed=self.seed)
         # item table: candidate occurrences (g * hv, rebuilt on the fly) + history occurrences (g_hist rows)
         _upd = _PhaseTimer(self, "table_update")
         _upd.__enter__()

@@ -286,25 +286,27 @@ class _SasrecEncodeFn(torch.autograd.Function):
     Inputs: item table, position table, then 14 parameters per block in engine.SAS_LAYER_KEYS order."""
 
     @staticmethod
-    def forward(ctx, item_emb, pos_emb, n_heads, hist, lengths, *flat):
+    def forward(ctx, item_emb, pos_emb, n_heads, hist, lengths, drop_p, seed, *flat):
         n_layers = len(flat) // 14
         layers = [{k: flat[14 * l + j].detach().contiguous() for j, (k, _) in enumerate(_SAS_ATTRS)}
                   for l in range(n_layers)]
         need_grad = any(t.requires_grad for t in (item_emb, pos_emb) + tuple(flat))
         hv, xsave = engine.sasrec_fwd(item_emb.detach(), pos_emb.detach(), layers, n_heads, hist, lengths,
-                                      save=need_grad)
+                                      save=need_grad, drop_p=drop_p, seed=seed)
         ctx.layers, ctx.n_heads, ctx.hist, ctx.lengths, ctx.xsave = layers, n_heads, hist, lengths, xsave
+        ctx.drop_p, ctx.seed = drop_p, seed
         ctx.n_items, ctx.n_pos = item_emb.shape[0], pos_emb.shape[0]
         return hv
 
     @staticmethod
     def backward(ctx, dhv):
         hist, lengths = ctx.hist, ctx.lengths
-        g_hist, dgrads = engine.sasrec_bwd(ctx.layers, ctx.n_heads, lengths, ctx.xsave, dhv.contiguous())
+        g_hist, dgrads = engine.sasrec_bwd(ctx.layers, ctx.n_heads, lengths, ctx.xsave, dhv.contiguous(),
+                                           drop_p=ctx.drop_p, seed=ctx.seed)
         GI = engine.embedding_dense_backward(g_hist, hist, ctx.n_items)
         GP = engine.sasrec_pos_grad(g_hist, lengths, ctx.n_pos)
         flat = [g[k].contiguous() for g in dgrads for k, _ in _SAS_ATTRS]
-        return (GI, GP, None, None, None) + tuple(flat)
+        return (GI, GP, None, None, None, None, None) + tuple(flat)
 
 
 def sasrec_layer_params(blocks):
@@ -312,10 +314,12 @@ def sasrec_layer_params(blocks):
     return [{k: _get_attr(b, path).data for k, path in _SAS_ATTRS} for b in blocks]
 
 
-def sasrec_encode(item_emb, pos_emb, blocks, n_heads, hist, lengths):
-    """blocks: nn.ModuleList of utils.layers.TransformerLayer (parameters only are used)"""
+def sasrec_encode(item_emb, pos_emb, blocks, n_heads, hist, lengths, drop_p=0.0, seed=None):
+    """blocks: nn.ModuleList of utils.layers.TransformerLayer (parameters only are used).  drop_p > 0 (training):
+    dropout1 / dropout2 of every block inside the batch-level kernels; `seed` int64 [1] device tensor the caller
+    bumps once per forward (engine.step_increment)"""
     flat = [_get_attr(b, path) for b in blocks for _, path in _SAS_ATTRS]
-    return _SasrecEncodeFn.apply(item_emb, pos_emb, n_heads, hist.contiguous(), lengths.contiguous(), *flat)
+    return _SasrecEncodeFn.apply(item_emb, pos_emb, n_heads, hist.contiguous(), lengths.contiguous(), float(drop_p), seed, *flat)
 
 
 class HipOptimizer:

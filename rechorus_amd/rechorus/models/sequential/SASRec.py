@@ -5,8 +5,11 @@ Mirror of the reference's models/sequential/SASRec.py (same class / arg / state_
         --history_max 20 --dataset 'Grocery_and_Gourmet_Food'
 The encoder of :58-76 (history + position gather, causal self-attention blocks, last valid row) is
 rc_sasrec_fwd / rc_sasrec_bwd; the candidate scoring of :80-81 is the BPRMF gather-dot kernel with
-the encoder output as the "user" row.  Unsupported shapes (dropout > 0 in training, emb_size not in
-{32, 64}, history longer than 64) run the same parameters through torch layers.
+the encoder output as the "user" row.  Training with --dropout p runs the batch-level kernels with the
+two nn.Dropout sites of every TransformerLayer (utils/layers.py:104-117) inside them: the mask comes from a
+counter-based stream keyed by a device-side seed (rc_sasrec_batch_fwd_dropout), never from torch's RNG.
+Unsupported shapes (emb_size not in {32, 64}, history longer than 64) run the same parameters through
+torch layers.
 """
 import numpy as np
 import torch
@@ -41,6 +44,8 @@ class SASRecBase(object):
             layers.TransformerLayer(d_model=self.emb_size, d_ff=self.emb_size, n_heads=self.num_heads,
                                     dropout=self.dropout, kq_same=False)
             for _ in range(self.num_layers)])
+        # key of the dropout mask stream; not a parameter and not in the state_dict (the reference has no such key)
+        self.register_buffer('drop_seed', torch.randint(0, 2 ** 62, (1,), dtype=torch.int64), persistent=False)
 
     def _encode_torch(self, history, lengths):
         batch_size, seq_len = history.shape
@@ -56,11 +61,13 @@ class SASRecBase(object):
     def _encode(self, feed_dict):
         history = feed_dict['history_items']    # [batch_size, <= history_max], right padded with 0
         lengths = feed_dict['lengths']          # [batch_size]
-        fused = engine.sasrec_supported(self.emb_size, self.num_layers, self.num_heads, history.shape[1]) and \
-            (self.dropout == 0 or not self.training)
-        if fused:
+        if engine.sasrec_supported(self.emb_size, self.num_layers, self.num_heads, history.shape[1]):
+            p = float(self.dropout) if self.training else 0.0
+            if p > 0:
+                engine.step_increment(self.drop_seed)  # new mask for this forward; its backward reads the same value
             return hnn.sasrec_encode(self.i_embeddings.weight, self.p_embeddings.weight,
-                                     self.transformer_block, self.num_heads, history, lengths)
+                                     self.transformer_block, self.num_heads, history, lengths,
+                                     p, self.drop_seed if p > 0 else None)
         return self._encode_torch(history, lengths)
 
     def full_catalogue_vectors(self, feed_dict):
@@ -78,21 +85,20 @@ class SASRecBase(object):
 
     # ---- large-table mode: row-wise update of the item table, dense step of everything small -----------
     def hip_rowwise_supported(self):
-        return bool(engine.sasrec_supported(self.emb_size, self.num_layers, self.num_heads, self.max_his) and self.dropout == 0)
+        return bool(engine.sasrec_supported(self.emb_size, self.num_layers, self.num_heads, self.max_his))
 
     def hip_train_step(self, feed_dict, opt_name, lr, l2):
         """encoder fwd/bwd (MFMA) + scoring + BPR loss + ONE segmented pass over candidate and history
         occurrences of the item table (engine.SasrecTrainer); returns the device loss tensor"""
         history, lengths = feed_dict['history_items'], feed_dict['lengths']
-        if not (engine.sasrec_supported(self.emb_size, self.num_layers, self.num_heads, history.shape[1])
-                and self.dropout == 0):
-            raise RuntimeError('SASRec --engine rowwise needs the fused encoder: emb_size in {32, 64}, history <= 64, '
-                               'dropout 0')
+        if not engine.sasrec_supported(self.emb_size, self.num_layers, self.num_heads, history.shape[1]):
+            raise RuntimeError('SASRec --engine rowwise needs the fused encoder: emb_size in {32, 64}, history <= 64')
         tr = getattr(self, '_trainer', None)
         if tr is None or tr.opt != opt_name:
             P = {'item_emb': self.i_embeddings.weight.data, 'pos_emb': self.p_embeddings.weight.data,
                  'layers': hnn.sasrec_layer_params(self.transformer_block)}
-            tr = self._trainer = engine.SasrecTrainer(P, self.num_heads, opt=opt_name, lr=lr, l2=l2, rowwise=True)
+            tr = self._trainer = engine.SasrecTrainer(P, self.num_heads, opt=opt_name, lr=lr, l2=l2, rowwise=True,
+                                                      dropout=self.dropout, seed=int(self.drop_seed.item()))
         with torch.no_grad():
             return tr.step(history.contiguous(), lengths.contiguous(), feed_dict['item_id'].contiguous())
 

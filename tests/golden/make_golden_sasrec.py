@@ -1,5 +1,11 @@
 """Golden vectors for SASRec FROM THE REFERENCE (models/sequential/SASRec.py + utils/layers.py),
-build container only:   PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden_sasrec.py"""
+build container only:   PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden_sasrec.py
+
+sasrecdrop_*: the reference model in TRAINING mode with --dropout p, the two nn.Dropout modules of every
+TransformerLayer (utils/layers.py:104,114) swapped for modules that apply a GIVEN keep-and-scale mask -- the
+counter-based one of rc_sasrec_batch_fwd_dropout (oracle/sasrec_oracle.dropout_keep), since torch's own random
+stream cannot be reproduced by another implementation.  Everything else (the order of operations, LayerNorm,
+autograd) is the reference's."""
 import os
 import sys
 from types import SimpleNamespace
@@ -80,6 +86,63 @@ def make_case(name, n_items, d, n_layers, n_heads, hist_max, B, K, seed):
     print("wrote", path, os.path.getsize(path) >> 10, "KiB")
 
 
+def make_dropout_case(name, n_items, d, n_layers, n_heads, hist_max, B, K, p, seed):
+    torch, _, _ = _import_reference()
+    from models.sequential.SASRec import SASRec
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import sasrec_oracle
+    torch.manual_seed(seed)
+    rng = np.random.default_rng(seed)
+    args = SimpleNamespace(device=torch.device("cpu"), model_path="", buffer=1, num_neg=K, dropout=p, test_all=0,
+                           emb_size=d, num_layers=n_layers, num_heads=n_heads, history_max=hist_max)
+    model = SASRec(args, SimpleNamespace(n_users=10, n_items=n_items))
+    with torch.no_grad():
+        for n, q in model.named_parameters():
+            if "layer_norm" not in n:
+                q.mul_(12.0)
+            else:
+                q.add_(torch.randn_like(q) * 0.1)
+    lengths = rng.integers(1, hist_max + 1, size=B).astype(np.int64)
+    lengths[0] = hist_max
+    L = int(lengths.max())
+    hist = np.zeros((B, L), dtype=np.int64)
+    for b in range(B):
+        hist[b, :lengths[b]] = rng.integers(1, n_items, size=lengths[b])
+    iid = rng.integers(1, n_items, size=(B, 1 + K)).astype(np.int64)
+    mask_seed = int(rng.integers(1, 2 ** 62))
+    keep = sasrec_oracle.dropout_keep(mask_seed, lengths, L, d, n_layers, p)
+
+    class GivenMask(torch.nn.Module):
+        def __init__(self, m):
+            super().__init__()
+            self.m = torch.from_numpy(m)
+
+        def forward(self, x):
+            return x * self.m
+
+    for l, block in enumerate(model.transformer_block):
+        assert isinstance(block.dropout1, torch.nn.Dropout) and block.dropout1.p == p
+        block.dropout1, block.dropout2 = GivenMask(keep[2 * l]), GivenMask(keep[2 * l + 1])
+    model.train()
+    out = {"meta": np.array([n_items, d, n_layers, n_heads, hist_max, B, K, seed], dtype=np.int64),
+           "p": np.float32(p), "mask_seed": np.int64(mask_seed), "hist": hist, "len": lengths, "iid": iid}
+    for k, v in model.state_dict().items():
+        out["P0/" + k] = v.detach().numpy().copy()
+    model.zero_grad()
+    o = model({"history_items": torch.from_numpy(hist), "lengths": torch.from_numpy(lengths), "item_id": torch.from_numpy(iid),
+               "user_id": torch.zeros(B, dtype=torch.long), "batch_size": B, "phase": "train"})
+    pred = o["prediction"]
+    pred.retain_grad()
+    loss = model.loss(o)
+    loss.backward()
+    out["pred"], out["loss"], out["gpred"] = pred.detach().numpy().copy(), np.float32(loss.item()), pred.grad.numpy().copy()
+    for k, q in model.named_parameters():
+        out["G/" + k] = q.grad.numpy().copy()
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) >> 10, "KiB")
+
+
 CASES = [
     # name,                 n_items, d, layers, heads, hist_max, B, K, seed
     ("sasrec_d64_l1_h1",       80, 64, 1, 1, 20, 12, 9, 31),
@@ -88,6 +151,15 @@ CASES = [
     ("sasrec_d32_l1_h4",       60, 32, 1, 4, 7, 9, 3, 34),
 ]
 
+DROP_CASES = [
+    # name,                        n_items, d, layers, heads, hist_max, B, K, p, seed
+    ("sasrecdrop_d64_l1_h4_p0.2",     90, 64, 1, 4, 50, 10, 9, 0.2, 41),
+    ("sasrecdrop_d32_l2_h2_p0.5",     60, 32, 2, 2, 11, 12, 4, 0.5, 42),
+]
+
 if __name__ == "__main__":
-    for c in CASES:
-        make_case(*c)
+    if "--dropout-only" not in sys.argv:
+        for c in CASES:
+            make_case(*c)
+    for c in DROP_CASES:
+        make_dropout_case(*c)

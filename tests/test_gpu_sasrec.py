@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from conftest import assert_close, assert_update_close, load_golden
-from test_oracle_sasrec import CASES, params
+from test_oracle_sasrec import CASES, DROP_CASES, params
 
 pytestmark = pytest.mark.gpu
 
@@ -205,3 +205,75 @@ def test_sasrec_pos_grad_chunks(cuda, eng):
         assert torch.equal(got[0], torch.zeros_like(got[0])) and torch.equal(got[L + 1:], torch.zeros_like(got[L + 1:]))
         assert_close(got[1:].cpu().numpy(), want[1:].cpu().numpy(), what=f"pos grad B={B}", rtol=1e-5, atol_scale=2e-5)
         assert torch.equal(got, eng.sasrec_pos_grad(g_hist, lengths, L + 3))
+
+
+@pytest.mark.parametrize("case", DROP_CASES)
+def test_sasrec_training_mode_dropout_matches_reference(case, cuda, eng):
+    """rc_sasrec_batch_fwd_dropout / _bwd_dropout vs the reference in training mode with its nn.Dropout modules
+    swapped for the same counter-based mask (tests/golden/sasrecdrop_*.npz)"""
+    g = load_golden(case)
+    n_layers, n_heads = int(g["meta"][2]), int(g["meta"][3])
+    P = to_dev(params(g), n_layers, cuda)
+    hist, lengths, iid = (torch.from_numpy(g[k]).to(cuda) for k in ("hist", "len", "iid"))
+    B, L = g["hist"].shape
+    C, d = g["iid"].shape[1], P["item_emb"].shape[1]
+    p = float(g["p"])
+    seed = torch.tensor([int(g["mask_seed"])], dtype=torch.int64, device=cuda)
+    hv, xsave = eng.sasrec_fwd(P["item_emb"], P["pos_emb"], P["layers"], n_heads, hist, lengths, save=True, drop_p=p, seed=seed)
+    assert xsave.impl == "batch"
+    rows = torch.arange(B, device=cuda)
+    pred = eng.gather_dot(hv, P["item_emb"], rows, iid)
+    assert_close(pred.cpu().numpy(), g["pred"], what="pred", atol_scale=2e-5)
+    # p = 0 through the dropout entry point is the plain kernel bit for bit; another seed gives another mask
+    hv0, _ = eng.sasrec_fwd(P["item_emb"], P["pos_emb"], P["layers"], n_heads, hist, lengths, impl="batch")
+    hv0d, _ = eng.sasrec_fwd(P["item_emb"], P["pos_emb"], P["layers"], n_heads, hist, lengths, impl="batch", drop_p=0.0, seed=seed)
+    assert torch.equal(hv0, hv0d) and not torch.equal(hv0, hv)
+    hv_other, _ = eng.sasrec_fwd(P["item_emb"], P["pos_emb"], P["layers"], n_heads, hist, lengths, drop_p=p, seed=seed + 1)
+    assert not torch.equal(hv_other, hv)
+    with pytest.raises(ValueError):
+        eng.sasrec_fwd(P["item_emb"], P["pos_emb"], P["layers"], n_heads, hist, lengths, impl="sequence", drop_p=p, seed=seed)
+
+    gpred = torch.from_numpy(g["gpred"]).to(cuda)
+    dhv = eng.weighted_row_sum(P["item_emb"], iid, gpred)
+    g_hist, dg = eng.sasrec_bwd(P["layers"], n_heads, lengths, xsave, dhv, drop_p=p, seed=seed)
+    G = params(g, "G/")
+    floor = 1e-6 * max(float(np.abs(v).max()) for v in G.values())
+    for l in range(n_layers):
+        for k, name in LAYER_NAMES.items():
+            assert_close(dg[l][k].cpu().numpy(), G["transformer_block.%d.%s" % (l, name)], what=f"layer {l} d{k}",
+                         rtol=2e-5, atol_scale=5e-5, abs_floor=floor)
+    ids = torch.cat([iid.reshape(-1), hist.reshape(-1)])
+    keys, perm = eng.sort_ids(ids, P["item_emb"].shape[0])
+    GI = torch.zeros_like(P["item_emb"])
+    eng.segmented_update2(keys, perm, hv, g_hist.view(-1, d), B * C, coef=gpred.reshape(-1), div=C, dense_grad=GI)
+    assert_close(GI.cpu().numpy(), G["i_embeddings.weight"], what="d item_emb", rtol=2e-5, atol_scale=5e-5)
+    GP = eng.sasrec_pos_grad(g_hist, lengths, P["pos_emb"].shape[0])
+    assert_close(GP.cpu().numpy(), G["p_embeddings.weight"], what="d pos_emb", rtol=2e-5, atol_scale=5e-5)
+
+
+def test_sasrec_trainer_with_dropout_draws_a_fresh_mask_per_step(cuda, eng):
+    """SasrecTrainer(dropout=p): the device seed is bumped every step (two steps from the same state differ from
+    two steps without dropout, and a re-run with the same seed reproduces them bit for bit)"""
+    rng = np.random.default_rng(5)
+    n_items, d, L, B, K = 200, 64, 20, 300, 7  # B * L >= 4096 or not: dropout forces the batch kernels anyway
+    def fresh():
+        r = np.random.default_rng(6)
+        t = lambda *s: torch.from_numpy(r.normal(0, 0.1, s).astype(np.float32)).to(cuda)
+        lay = {k: (t(d, d) if k.startswith("W") else t(d)) for k in eng.SAS_LAYER_KEYS}
+        lay["ln1w"] += 1
+        lay["ln2w"] += 1
+        return {"item_emb": t(n_items, d), "pos_emb": t(L + 1, d), "layers": [lay]}
+    lengths = torch.from_numpy(rng.integers(1, L + 1, B)).to(cuda)
+    hist = torch.zeros((B, L), dtype=torch.int64, device=cuda)
+    for b in range(B):
+        hist[b, :int(lengths[b])] = torch.from_numpy(rng.integers(1, n_items, int(lengths[b]))).to(cuda)
+    iid = torch.from_numpy(rng.integers(1, n_items, (B, 1 + K))).to(cuda)
+    runs = []
+    for p, seed in ((0.3, 11), (0.3, 11), (0.3, 12), (0.0, 11)):
+        P = fresh()
+        tr = eng.SasrecTrainer(P, 2, opt="SGD", lr=0.05, rowwise=True, dropout=p, seed=seed)
+        losses = [float(tr.step(hist, lengths, iid).item()) for _ in range(2)]
+        runs.append((losses, P["item_emb"].clone()))
+    assert runs[0][0] == runs[1][0] and torch.equal(runs[0][1], runs[1][1])
+    assert runs[0][0] != runs[2][0] and runs[0][0] != runs[3][0]
+    assert all(np.isfinite(x) for r in runs for x in r[0])
