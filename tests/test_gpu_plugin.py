@@ -249,6 +249,10 @@ def test_sasrec_model_file_matches_reference(case, cuda):
     ["--model_name", "NeuMF", "--emb_size", "32", "--layers", "[32]", "--lr", "5e-3", "--dropout", "0.2", "--engine", "rowwise"],
     ["--model_name", "SASRec", "--emb_size", "32", "--num_layers", "1", "--num_heads", "2", "--history_max", "10", "--lr", "3e-3",
      "--engine", "rowwise"],
+    ["--model_name", "SASRec", "--emb_size", "32", "--num_layers", "1", "--num_heads", "2", "--history_max", "10", "--lr", "3e-3",
+     "--dropout", "0.2"],
+    ["--model_name", "SASRec", "--emb_size", "32", "--num_layers", "2", "--num_heads", "2", "--history_max", "10", "--lr", "3e-3",
+     "--dropout", "0.2", "--engine", "rowwise"],
 ])
 def test_cli_neumf_and_sasrec(model_args, dataset_root, tmp_path, cuda):
     import main
