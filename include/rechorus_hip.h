@@ -525,10 +525,12 @@ int rc_plan_update_pair(float* W_a, float* m_a, float* v_a, float* W_b, float* m
 
 size_t rc_bprmf_step_workspace_bytes(int B, int C, int d);
 
-/* Which grouping pipeline rc_bprmf_train_step uses: 0 = automatic (bucket plan where supported), 1 = always
- * the radix-sort pipeline (the two give bit-identical tables; used by the parity tests and for A/B timing).
- * Returns the previous setting; any other `mode` only queries.  Process-wide, initial value 0
- * (1 when the environment has RC_BPRMF_STEP=sort).                                                       */
+/* Which grouping pipeline rc_bprmf_train_step uses: 0 = automatic (bucket plan where supported; its per-bucket
+ * pass -- row records and grouped positions, needed only by the updates -- runs on a library-owned second stream
+ * behind the fused kernel, forked and joined by events, so the call stays capturable), 1 = always the radix-sort
+ * pipeline, 2 = bucket plan on the caller's stream only.  All three give bit-identical tables (parity tests, A/B
+ * timing).  Returns the previous setting; any other `mode` only queries.  Process-wide, initial value 0
+ * (1 / 2 when the environment has RC_BPRMF_STEP=sort / serial).                                           */
 int rc_bprmf_step_pipeline(int mode);
 
 /* One BaseRunner.fit iteration for BPRMF (helpers/BaseRunner.py:193-206 with

@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "librechorus_hip.so")
+# RC_LIB_PATH: an experimental build of the same library (tools/build_variant.py, A/B timing); default = in-tree
+LIB_PATH = os.environ.get("RC_LIB_PATH") or os.path.join(_PKG, "librechorus_hip.so")
 
 RC_OK = 0
 RC_OPT_SGD, RC_OPT_ADAM, RC_OPT_ADAGRAD, RC_OPT_ADADELTA = 0, 1, 2, 3

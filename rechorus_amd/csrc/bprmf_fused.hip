@@ -109,10 +109,23 @@ __global__ __launch_bounds__(kBlock, (fused_min_waves<CPL, MODE>())) void bprmf_
   }
   unsigned smask = 0;  // bit j: candidate slot j of this group is a singleton row
   if (MODE != MODE_NONE) {
+    if (S == 64 && GS == 4 && (C & 3) == 0) {
+      // the tuple's C flag bytes as C/4 dwords in ONE coalesced load (lane k holds candidates 4k..4k+3); dword j is
+      // then a wave-uniform value (readlane with a constant lane) whose byte `grp` is this group's candidate j*4+grp.
+      // (25 separate byte loads per lane cost 26 us of the 0.56 ms kernel at config 2.)
+      const uint32_t* f32p = reinterpret_cast<const uint32_t*>(upd.single + t * C);
+      const uint32_t mine = (tv && lane < C / 4) ? f32p[lane] : 0u;
 #pragma unroll
-    for (int j = 0; j < CPL; ++j) {
-      const int c = j * GS + grp;
-      if (tv && c < C && upd.single[t * C + c]) smask |= 1u << j;
+      for (int j = 0; j < CPL; ++j) {
+        const uint32_t wj = (uint32_t)__builtin_amdgcn_readlane((int)mine, j);
+        if ((wj >> (8 * grp)) & 0xFFu) smask |= 1u << j;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) {
+        const int c = j * GS + grp;
+        if (tv && c < C && upd.single[t * C + c]) smask |= 1u << j;
+      }
     }
   }
 
@@ -190,14 +203,18 @@ __global__ __launch_bounds__(kBlock, (fused_min_waves<CPL, MODE>())) void bprmf_
     acc.y = fmaf(g, r[j].y, acc.y);
     acc.z = fmaf(g, r[j].z, acc.z);
     acc.w = fmaf(g, r[j].w, acc.w);
-    if (MODE == MODE_SGD) {
+    if (MODE == MODE_ADAM || MODE == MODE_ADAGRAD) gs[j] = g;  // row updates below
+  }
+  if (MODE == MODE_SGD) {
+    // single-occurrence rows: all write-backs of the wave in one burst after the accumulation
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
       if (smask & (1u << j)) {  // whole lane-group takes the branch together
-        const int64_t id = ids[c];
+        const int64_t id = ids[j * GS + grp];
+        const float g = strip[grp * CPL + j];
         const float4 gi = make_float4(g * u4.x, g * u4.y, g * u4.z, g * u4.w);
         opt_row4<MODE>(upd.o, upd.I, upd.M, upd.V, (size_t)id * LPR + l, r[j], gi);
       }
-    } else if (MODE != MODE_NONE) {
-      gs[j] = g;  // updated below, state rows fetched in batches
     }
   }
   acc.x = groups_allreduce_sum<LPR, S>(acc.x);

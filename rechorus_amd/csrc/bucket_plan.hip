@@ -450,7 +450,7 @@ __global__ __launch_bounds__(kBucketThreads) void plan_bucket_kernel(PlanArgs a)
   if (wave != 0) return;
 
   // pass 2 (wave 0): positions into their row's slots, ascending
-  uint8_t* single = side_b ? nullptr : a.single_a;
+  uint8_t* single = (side_b || a.flags_done) ? nullptr : a.single_a;
   uint64_t cur_k[kBucketBatch], nxt_k[kBucketBatch];
 #pragma unroll
   for (int q = 0; q < kBucketBatch; ++q) {
@@ -497,7 +497,52 @@ __global__ __launch_bounds__(kBucketThreads) void plan_bucket_kernel(PlanArgs a)
   }
 }
 
-int plan_launch(const PlanArgs& a, hipStream_t s, hipEvent_t* ev_after_scatter) {
+// ---- 4a. singleton flags alone (list a), all four waves, no ordering: what the fused BPRMF kernel waits for.
+// The row records and grouped positions (plan_bucket_kernel, whose ordered pass is one wave per bucket) are needed
+// only by the updates AFTER the fused kernel, so the step runs them on a second stream behind it (train_step.hip).
+template <bool WIDE>
+__global__ __launch_bounds__(kBucketThreads) void plan_flags_kernel(PlanArgs a) {
+  extern __shared__ uint32_t tab[];
+  const int tid = threadIdx.x;
+  const uint32_t bkt = blockIdx.x;  // grid = nb_a: buckets of list a only
+  const int shift = a.g.shift;
+  const uint32_t ids = 1u << shift;
+  const int per_shift = shift - 8;
+  const uint32_t beg = a.w.bucket_base[bkt], end = a.w.bucket_base[bkt + 1];
+  if (beg == end) return;
+  if (WIDE != (end - beg >= kNarrowLimit || per_shift < 1)) return;
+  const uint32_t words = (WIDE ? ids : ids / 2) + kBucketThreads;
+  const BucketCells<WIDE> cells{tab, per_shift};
+  for (uint32_t i = tid; i < words; i += kBucketThreads) tab[i] = 0;
+  __syncthreads();
+  constexpr int kBatch = 8;
+  for (uint32_t j0 = beg; j0 < end; j0 += kBucketThreads * kBatch) {
+    uint64_t k[kBatch];
+#pragma unroll
+    for (int q = 0; q < kBatch; ++q) {
+      const uint32_t j = j0 + q * kBucketThreads + tid;
+      k[q] = j < end ? a.w.keys[j] : ~0ull;
+    }
+#pragma unroll
+    for (int q = 0; q < kBatch; ++q)
+      if (k[q] != ~0ull) cells.add1((uint32_t)(k[q] >> 32));
+  }
+  __syncthreads();
+  for (uint32_t j0 = beg; j0 < end; j0 += kBucketThreads * kBatch) {
+    uint64_t k[kBatch];
+#pragma unroll
+    for (int q = 0; q < kBatch; ++q) {
+      const uint32_t j = j0 + q * kBucketThreads + tid;
+      k[q] = j < end ? a.w.keys[j] : ~0ull;
+    }
+#pragma unroll
+    for (int q = 0; q < kBatch; ++q)
+      if (k[q] != ~0ull && cells.get((uint32_t)(k[q] >> 32)) == 1u) a.single_a[(uint32_t)k[q]] = 1;
+  }
+}
+
+// front: histogram, tile offsets, stable partition (+ the singleton flags of list a when `flags` is set)
+int plan_launch_front(const PlanArgs& a, bool flags, hipStream_t s) {
   const PlanGeom& g = a.g;
   const size_t hist_lds = (size_t)g.nb * sizeof(uint32_t);
   hipLaunchKernelGGL(plan_count_kernel, dim3(g.tiles), dim3(kPlanThreads), hist_lds, s, a);
@@ -508,7 +553,21 @@ int plan_launch(const PlanArgs& a, hipStream_t s, hipEvent_t* ev_after_scatter) 
   const size_t sc_lds = (nbp + kPlanTile + 2 * kPlanWaves) * sizeof(uint32_t) + ((size_t)kPlanTile + kPlanWaves * nbp) * sizeof(uint16_t);
   hipLaunchKernelGGL(plan_scatter_kernel, dim3(g.tiles), dim3(kPlanThreads), sc_lds, s, a);
   RC_LAUNCH_CHECK();
-  if (ev_after_scatter) RC_HIP(hipEventRecord(*ev_after_scatter, s));
+  if (flags && a.single_a && g.nb_a > 0) {
+    const size_t ids = (size_t)1 << g.shift;
+    if (g.shift > 8) {
+      hipLaunchKernelGGL(plan_flags_kernel<false>, dim3(g.nb_a), dim3(kBucketThreads), (ids / 2 + kBucketThreads + 16) * sizeof(uint32_t), s, a);
+      RC_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(plan_flags_kernel<true>, dim3(g.nb_a), dim3(kBucketThreads), (ids + kBucketThreads + 16) * sizeof(uint32_t), s, a);
+    RC_LAUNCH_CHECK();
+  }
+  return RC_OK;
+}
+
+// back: per bucket, row records + grouped positions (+ the flags unless a.flags_done)
+int plan_launch_back(const PlanArgs& a, hipStream_t s) {
+  const PlanGeom& g = a.g;
   const size_t ids = (size_t)1 << g.shift;
   if (g.shift > 8) {  // 16-bit cells: every bucket below 32,768 keys
     hipLaunchKernelGGL(plan_bucket_kernel<false>, dim3(g.nb), dim3(kBucketThreads), (ids / 2 + kBucketThreads + 16) * sizeof(uint32_t), s, a);
@@ -518,6 +577,12 @@ int plan_launch(const PlanArgs& a, hipStream_t s, hipEvent_t* ev_after_scatter) 
   hipLaunchKernelGGL(plan_bucket_kernel<true>, dim3(g.nb), dim3(kBucketThreads), (ids + kBucketThreads + 16) * sizeof(uint32_t), s, a);
   RC_LAUNCH_CHECK();
   return RC_OK;
+}
+
+int plan_launch(const PlanArgs& a, hipStream_t s, hipEvent_t* ev_after_scatter) {
+  RC_TRY(plan_launch_front(a, false, s));
+  if (ev_after_scatter) RC_HIP(hipEventRecord(*ev_after_scatter, s));
+  return plan_launch_back(a, s);
 }
 
 int plan_prepare() {

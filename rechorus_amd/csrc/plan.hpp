@@ -54,8 +54,12 @@ struct PlanArgs {
   uint32_t* n_rows_a;      // device counters (may point into w.counters)
   uint32_t* n_rows_b;
   uint32_t* occ;           // [n]
+  int flags_done;          // single_a was filled by plan_launch_front(flags = true): the bucket kernel skips it
 };
 int plan_launch(const PlanArgs& a, hipStream_t s, hipEvent_t* ev_after_scatter);
+// the same plan in two parts, so that a caller can run `back` on another stream (train_step.hip)
+int plan_launch_front(const PlanArgs& a, bool flags, hipStream_t s);
+int plan_launch_back(const PlanArgs& a, hipStream_t s);
 
 // ---- consumers --------------------------------------------------------------------------------------
 struct PlanTable { float* W; float* M; float* V; };

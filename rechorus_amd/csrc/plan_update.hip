@@ -17,6 +17,8 @@
 
 namespace rc {
 
+constexpr bool LPR_OK(int D) { return D / 4 <= 64 && 64 % (D / 4) == 0; }  // a row's lane-group fits a wave
+
 struct PlanSide {       // one table and how the gradient rows of its occurrences are obtained
   PlanTable t;
   PlanTable tb;         // pair mode: the second table
@@ -151,6 +153,114 @@ __device__ __forceinline__ void plan_rows_body(const PlanUpdArgs& a, int side, b
   }
 }
 
+// Fast path for sides whose gradient rows are coef[o] * src[src_index[o / div]] for EVERY occurrence (BPRMF item side:
+// g[b,c] * U[uid[b]]; no pair mode, no second source).  plan_rows_body walks a chain of four dependent loads per row
+// (record -> occ[] -> coef / src_index -> source row) with 8 rows per wave in flight: latency-bound (0.34 ms for the
+// 1.4 M multi-occurrence rows of config 2, 2.1 TB/s).  Here the chain is resolved ONE LANE PER ROW -- 64 rows per wave
+// travel through the three index levels together -- and only then the lane-groups stream the rows: per step a group
+// shuffles the resolved (row, coefficients, source rows) of H rows out of the index lanes and issues the table row,
+// its optimizer state and the first two source rows of all H rows back to back (one memory latency per step).
+// Summation order per row is unchanged (ascending position: occurrence 0, 1, then the rest) => bit-identical.
+template <int D, int MODE>
+__device__ __forceinline__ void plan_rows_indexed_body(const PlanUpdArgs& a, int side, bool plan_long, uint32_t first_block,
+                                                       uint32_t n_blocks) {
+  constexpr int LPR = D / 4;
+  constexpr int GPW = 64 / LPR;   // lane-groups per wave
+  constexpr int H = 2;            // rows per lane-group per step
+  const PlanSide& sd = a.side[side];
+  const PlanGrad& gr = sd.g;
+  const int lane = threadIdx.x & 63;
+  const int l = lane % LPR, grp = lane / LPR;
+  const uint32_t nr = *sd.n_rows;
+  const uint32_t wave = (blockIdx.x - first_block) * (kBlock / 64) + (threadIdx.x >> 6);
+  const uint32_t n_waves = n_blocks * (kBlock / 64);
+  const float4* src4 = reinterpret_cast<const float4*>(gr.src);
+  for (uint32_t base = wave * 64u; base < nr; base += n_waves * 64u) {
+    // ---- index phase: lane i resolves row base + i
+    const uint32_t gi = base + lane;
+    rc_plan_row e;
+    e.row = 0; e.start = 0; e.n = 0; e.reserved = 0;
+    if (gi < nr) e = sd.rows[gi];
+    const bool shortrow = e.n >= 1 && e.n <= (uint32_t)kPlanLongSeg;
+    uint32_t o0 = 0, o1 = 0;
+    if (shortrow) {
+      o0 = a.occ[e.start];
+      if (e.n > 1) o1 = a.occ[e.start + 1];
+    }
+    float c0 = 1.0f, c1 = 1.0f;
+    int64_t s0 = 0, s1 = 0;
+    if (shortrow) {
+      s0 = (gr.div == 1) ? (int64_t)o0 : (int64_t)(o0 / (uint32_t)gr.div);
+      if (gr.src_index) s0 = gr.src_index[s0];
+      if (gr.coef) c0 = gr.coef[o0];
+      if (e.n > 1) {
+        s1 = (gr.div == 1) ? (int64_t)o1 : (int64_t)(o1 / (uint32_t)gr.div);
+        if (gr.src_index) s1 = gr.src_index[s1];
+        if (gr.coef) c1 = gr.coef[o1];
+      }
+    }
+    // ---- data phase: GPW * H rows per step
+    for (int r0 = 0; r0 < 64; r0 += GPW * H) {
+      if (base + (uint32_t)r0 >= nr) break;  // wave-uniform
+      rc_plan_row eh[H];
+      float ch0[H], ch1[H];
+      int64_t sh0[H], sh1[H];
+      bool on[H];
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        const int sl = r0 + h * GPW + grp;
+        eh[h].row = __shfl(e.row, sl, 64);
+        eh[h].start = __shfl(e.start, sl, 64);
+        eh[h].n = __shfl(e.n, sl, 64);
+        eh[h].reserved = 0;
+        ch0[h] = __shfl(c0, sl, 64);
+        ch1[h] = __shfl(c1, sl, 64);
+        sh0[h] = (int64_t)(((uint64_t)(uint32_t)__shfl((int)(uint32_t)(s0 >> 32), sl, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)s0, sl, 64));
+        sh1[h] = (int64_t)(((uint64_t)(uint32_t)__shfl((int)(uint32_t)(s1 >> 32), sl, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)s1, sl, 64));
+        on[h] = eh[h].n >= 1 && eh[h].n <= (uint32_t)kPlanLongSeg;
+      }
+      float4 w[H], m[H], v[H], u0[H], u1[H];
+      size_t idx4[H];
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        idx4[h] = (size_t)eh[h].row * LPR + l;
+        m[h] = v[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (on[h]) {
+          w[h] = load_stream4(reinterpret_cast<const float4*>(sd.t.W) + idx4[h]);
+          if (mode_has_m(MODE)) m[h] = load_stream4(reinterpret_cast<const float4*>(sd.t.M) + idx4[h]);
+          if (mode_has_v(MODE)) v[h] = load_stream4(reinterpret_cast<const float4*>(sd.t.V) + idx4[h]);
+          u0[h] = src4[(size_t)sh0[h] * LPR + l];
+          if (eh[h].n > 1) u1[h] = src4[(size_t)sh1[h] * LPR + l];
+        }
+      }
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        if (!on[h]) {
+          if (plan_long && eh[h].n > (uint32_t)kPlanLongSeg) plan_long_row<LPR>(a, eh[h], side, l);
+          continue;
+        }
+        float4 acc = u0[h];
+        acc.x *= ch0[h]; acc.y *= ch0[h]; acc.z *= ch0[h]; acc.w *= ch0[h];
+        if (eh[h].n > 1) {
+          float4 t = u1[h];
+          t.x *= ch1[h]; t.y *= ch1[h]; t.z *= ch1[h]; t.w *= ch1[h];
+          padd4(acc, t);
+        }
+        for (uint32_t k = 2; k < eh[h].n; ++k) padd4(acc, plan_grad4<D>(gr, a.occ, eh[h].start + k, l));
+        opt_apply4<MODE>(a.o, w[h], m[h], v[h], acc);
+        store_row4(reinterpret_cast<float4*>(sd.t.W) + idx4[h], w[h]);
+        if (mode_has_m(MODE)) store_row4(reinterpret_cast<float4*>(sd.t.M) + idx4[h], m[h]);
+        if (mode_has_v(MODE)) store_row4(reinterpret_cast<float4*>(sd.t.V) + idx4[h], v[h]);
+      }
+    }
+  }
+}
+
+// does `side` qualify for plan_rows_indexed_body?  (kernel-uniform)
+__device__ __forceinline__ bool plan_side_indexed(const PlanSide& sd) {
+  return !sd.g.pair && sd.g.src != nullptr && sd.g.src2 == nullptr;
+}
+
 // hot rows of `side` only: chunk records, no update
 template <int D>
 __device__ __forceinline__ void plan_long_only_body(const PlanUpdArgs& a, int side, uint32_t first_block,
@@ -170,8 +280,10 @@ __device__ __forceinline__ void plan_long_only_body(const PlanUpdArgs& a, int si
 template <int D, int MODE>
 __global__ __launch_bounds__(kBlock) void plan_rows_kernel(PlanUpdArgs a, uint32_t blocks_main, int update_side,
                                                           int plan_other) {
-  if (blockIdx.x < blocks_main) plan_rows_body<D, MODE>(a, update_side, true, 0, blocks_main);
-  else if (plan_other) plan_long_only_body<D>(a, 1 - update_side, blocks_main, gridDim.x - blocks_main);
+  if (blockIdx.x < blocks_main) {
+    if (LPR_OK(D) && plan_side_indexed(a.side[update_side])) plan_rows_indexed_body<D, MODE>(a, update_side, true, 0, blocks_main);
+    else plan_rows_body<D, MODE>(a, update_side, true, 0, blocks_main);
+  } else if (plan_other) plan_long_only_body<D>(a, 1 - update_side, blocks_main, gridDim.x - blocks_main);
 }
 
 // LDS tree over the lane-groups of a block, fixed order; result in group 0's slots

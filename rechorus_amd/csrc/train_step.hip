@@ -26,6 +26,30 @@ int plan_bprmf_step_updates(float* U, float* mU, float* vU, float* I, float* mI,
 int plan_prepare();
 }
 
+// The second stream of the step.  The bucket plan's per-bucket pass (row records + grouped positions) is index work
+// that only the updates need; the fused kernel needs at most the singleton flags.  So the step forks: the fused
+// kernel runs on the caller's stream while plan_launch_back runs on this side stream, and the updates wait for both.
+// Created once per process (non-blocking: the caller's stream may be the legacy null stream); fork / join are
+// event dependencies, so the call stays capturable in a hipGraph.  RC_BPRMF_STEP=serial keeps everything on one stream.
+namespace {
+struct StepSide {
+  hipStream_t stream = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+  bool ok = false;
+};
+StepSide& step_side() {
+  static StepSide sd = [] {
+    StepSide x;
+    if (hipStreamCreateWithFlags(&x.stream, hipStreamNonBlocking) == hipSuccess &&
+        hipEventCreateWithFlags(&x.fork, hipEventDisableTiming) == hipSuccess &&
+        hipEventCreateWithFlags(&x.join, hipEventDisableTiming) == hipSuccess)
+      x.ok = true;
+    return x;
+  }();
+  return sd;
+}
+}  // namespace
+
 using namespace rc;
 
 namespace {
@@ -94,15 +118,19 @@ StepWs carve_step_ws(void* base, int B, int C, int d) {
 }
 }  // namespace
 
-// 0 = automatic, 1 = always the sort pipeline; initial value from RC_BPRMF_STEP=sort
+// 0 = automatic (bucket plan, its per-bucket pass on a second stream behind the fused kernel), 1 = always the sort
+// pipeline, 2 = bucket plan on ONE stream; initial value from RC_BPRMF_STEP=sort|serial
 static int& step_pipeline() {
-  static int mode = [] { const char* v = getenv("RC_BPRMF_STEP"); return (v && strcmp(v, "sort") == 0) ? 1 : 0; }();
+  static int mode = [] {
+    const char* v = getenv("RC_BPRMF_STEP");
+    return (v && strcmp(v, "sort") == 0) ? 1 : ((v && strcmp(v, "serial") == 0) ? 2 : 0);
+  }();
   return mode;
 }
 
 extern "C" int rc_bprmf_step_pipeline(int mode) {
   const int prev = step_pipeline();
-  if (mode == 0 || mode == 1) step_pipeline() = mode;
+  if (mode >= 0 && mode <= 2) step_pipeline() = mode;
   return prev;
 }
 
@@ -166,8 +194,24 @@ extern "C" int rc_bprmf_train_step(float* U, float* I, float* mU, float* vU, flo
     pa.rows_a = w.rows_i; pa.rows_b = w.rows_u;
     pa.n_rows_a = &w.plan.counters[PC_ROWS_A]; pa.n_rows_b = &w.plan.counters[PC_ROWS_B];
     pa.occ = w.occ;
+    StepSide& side = step_side();
+    const bool two_streams = step_pipeline() == 0 && side.ok;
     RC_MARK(0);
-    RC_TRY(plan_launch(pa, s, prof ? &ev[1] : nullptr));   // ev[1]: after the partition, before the bucket kernel
+    if (two_streams) {
+      // caller's stream: partition (+ singleton flags when the fused kernel updates them) -> fused kernel
+      // side stream:     per-bucket pass (row records, grouped positions), joined before the updates
+      // (without the singleton fast path the fused kernel needs nothing from the plan: all of it runs on the side stream)
+      pa.flags_done = fused_upd ? 1 : 0;
+      if (fused_upd) RC_TRY(plan_launch_front(pa, true, s));
+      RC_MARK(1);
+      RC_HIP(hipEventRecord(side.fork, s));
+      RC_HIP(hipStreamWaitEvent(side.stream, side.fork, 0));
+      if (!fused_upd) RC_TRY(plan_launch_front(pa, false, side.stream));
+      RC_TRY(plan_launch_back(pa, side.stream));
+      RC_HIP(hipEventRecord(side.join, side.stream));
+    } else {
+      RC_TRY(plan_launch(pa, s, prof ? &ev[1] : nullptr));   // ev[1]: after the partition, before the bucket kernel
+    }
     RC_MARK(2);
     RC_MARK(3);
     if (fused_upd)
@@ -175,6 +219,7 @@ extern "C" int rc_bprmf_train_step(float* U, float* I, float* mU, float* vU, flo
                                      w.ugrad, stream));
     else
       RC_TRY(rc_bprmf_fwd_bwd(U, I, uid, iid, B, C, d, inv_b, pred, w.loss_vec, w.gpred, w.ugrad, stream));
+    if (two_streams) RC_HIP(hipStreamWaitEvent(s, side.join, 0));
     RC_MARK(4);
     RC_MARK(5);  // (the loss mean is one workgroup of the last update launch)
     RC_TRY(plan_bprmf_step_updates(U, mU, vU, I, mI, vI, d, uid, C, n_i, B, w.gpred, w.ugrad, w.rows_i, pa.n_rows_a,

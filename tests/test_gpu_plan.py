@@ -112,7 +112,7 @@ def test_train_step_plan_pipeline_equals_sort_pipeline(opt, lr, l2, d, B, C, n_u
     res = []
     prev = lib.rc_bprmf_step_pipeline(-1)
     try:
-        for mode in (1, 0):
+        for mode in (1, 0, 2):  # sort pipeline, bucket plan on two streams (default), bucket plan on one stream
             lib.rc_bprmf_step_pipeline(mode)
             U, I = torch.from_numpy(U0).to(cuda), torch.from_numpy(I0).to(cuda)
             tr = eng.BprmfTrainer(U, I, opt=opt, lr=lr, l2=l2)
@@ -121,10 +121,11 @@ def test_train_step_plan_pipeline_equals_sort_pipeline(opt, lr, l2, d, B, C, n_u
     finally:
         lib.rc_bprmf_step_pipeline(prev)
     assert lib.rc_bucket_plan_supported(B * C, B, n_items, n_users) == 1
-    for name, x, y in zip(("U", "I", "mU", "vU", "mI", "vI", "loss"), res[0], res[1]):
-        if x is None:
-            continue
-        assert torch.equal(x, y), f"{name}: {int((x != y).sum())} elements differ, max |diff| {(x - y).abs().max().item():.3e}"
+    for other in (1, 2):
+        for name, x, y in zip(("U", "I", "mU", "vU", "mI", "vI", "loss"), res[0], res[other]):
+            if x is None:
+                continue
+            assert torch.equal(x, y), f"{name} (pipeline {other}): {int((x != y).sum())} elements differ, max |diff| {(x - y).abs().max().item():.3e}"
     assert not torch.equal(res[0][1], torch.from_numpy(I0).to(cuda))
 
 
