@@ -304,8 +304,8 @@ def load_pmc_traffic(kernel):
     p = os.path.join(ROOT, "profiles", "pmc_latest.json")
     if not os.path.exists(p):
         return None
-    prefix = {"fused_fwd_bwd": "bprmf_fwd_bwd_kernel", "item_update": "seg_update_multi_x2_kernel",
-              "user_update": "seg_update_kernel"}.get(kernel, kernel)
+    prefix = {"fused_fwd_bwd": "bprmf_fwd_bwd_kernel", "item_update": "plan_rows_kernel",
+              "user_update": "plan_final_kernel"}.get(kernel, kernel)
     try:
         rows = [v["hbm_bytes_per_launch"] for k, v in json.load(open(p)).items()
                 if k.startswith(prefix) and isinstance(v, dict) and v.get("hbm_bytes_per_launch")]
