@@ -525,12 +525,16 @@ int rc_plan_update_pair(float* W_a, float* m_a, float* v_a, float* W_b, float* m
 
 size_t rc_bprmf_step_workspace_bytes(int B, int C, int d);
 
-/* Which grouping pipeline rc_bprmf_train_step uses: 0 = automatic (bucket plan where supported; its per-bucket
- * pass -- row records and grouped positions, needed only by the updates -- runs on a library-owned second stream
- * behind the fused kernel, forked and joined by events, so the call stays capturable), 1 = always the radix-sort
- * pipeline, 2 = bucket plan on the caller's stream only.  All three give bit-identical tables (parity tests, A/B
- * timing).  Returns the previous setting; any other `mode` only queries.  Process-wide, initial value 0
- * (1 / 2 when the environment has RC_BPRMF_STEP=sort / serial).                                           */
+/* Which pipeline rc_bprmf_train_step uses: 0 = automatic -- batches of at most 32,768 row ids (B (1 + K) + B, e.g. the
+ * reference's default --batch_size 256, helpers/BaseRunner.py:33) take the two-launch small-batch step (ids grouped by
+ * 128 workgroups beside the fused forward / backward, then one update launch); larger ones the bucket plan where
+ * supported, its per-bucket pass -- row records and grouped positions, needed only by the updates -- on a
+ * library-owned second stream behind the fused kernel, forked and joined by events, so the call stays capturable;
+ * 1 = always the radix-sort pipeline, 2 = bucket plan on the caller's stream only, 3 = bucket plan on two streams
+ * whatever the batch size.  1, 2, 3 give bit-identical tables; 0 equals them bit for bit on batches without rows of
+ * more than 32 occurrences and to fp32 summation order otherwise (parity tests, A/B timing).  Returns the previous
+ * setting; any other `mode` only queries.  Process-wide, initial value 0 (1 / 2 / 3 when the environment has
+ * RC_BPRMF_STEP=sort / serial / plan).                                                                      */
 int rc_bprmf_step_pipeline(int mode);
 
 /* One BaseRunner.fit iteration for BPRMF (helpers/BaseRunner.py:193-206 with

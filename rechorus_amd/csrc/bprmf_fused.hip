@@ -22,241 +22,38 @@
 // writes the new row, so the row crosses HBM once in each direction per step (the
 // compulsory traffic).  `single[o]` comes from rc_mark_singletons on the sorted ids; rows
 // with several occurrences are left to the segmented update (seg_update.hip).
-#include "bpr_math.hpp"
-#include "common.hpp"
-#include "opt_math.hpp"
+#include "fused_body.hpp"
+#include "small_plan.hpp"
 
 namespace rc {
 
-struct FusedUpd {     // singleton-row update (unused when MODE == MODE_NONE)
-  float* I;           // the item table again, writable (no __restrict__: aliases the input)
-  float* M;
-  float* V;
-  const uint8_t* single;
-  OptScalars o;
-};
-
-// all-reduce over the S lanes (power of two, S-aligned) that own one tuple
-template <int S>
-__device__ __forceinline__ float tuple_allreduce_sum(float x) {
-  x = row_allreduce_sum<(S < 16 ? S : 16)>(x);
-  if (S >= 32) x += __shfl_xor(x, 16, 64);
-  if (S >= 64) x += __shfl_xor(x, 32, 64);
-  return x;
-}
-template <int S>
-__device__ __forceinline__ float tuple_allreduce_max(float x) {
-  if (S >= 2) x = fmaxf(x, dpp_mov<0xB1>(x));
-  if (S >= 4) x = fmaxf(x, dpp_mov<0x4E>(x));
-  if (S >= 8) x = fmaxf(x, dpp_mov<0x141>(x));
-  if (S >= 16) x = fmaxf(x, dpp_mov<0x140>(x));
-  if (S >= 32) x = fmaxf(x, __shfl_xor(x, 16, 64));
-  if (S >= 64) x = fmaxf(x, __shfl_xor(x, 32, 64));
-  return x;
-}
-
-// The loss of a tuple is scalar work on its C scores.  Every lane of a row's lane-group holds the same
-// score after the DPP row reduction, so computing softmax / sigmoid per register slot repeats each
-// exp / division LPR times (16 x at d = 64) and keeps three CPL-long arrays alive next to the row
-// registers (198 VGPRs -> two waves per SIMD; measured 0.21 ms of VALU time per step that two waves
-// cannot hide).  Here the scores are transposed through a C-float LDS strip per tuple: one lane per
-// candidate evaluates the loss terms (ceil(C / S) per lane instead of CPL), the gradient scalars g_c
-// return through the same strip and are broadcast-read by the lane-groups for the backward pass.
-// Slot order in the strip: s = grp * CPL + j  <->  candidate c = j * GS + grp.
-#ifndef RC_FUSED_MINW
-#define RC_FUSED_MINW 3
-#endif
-// waves per SIMD the register allocation must allow: the candidate block (CPL float4 = 4 CPL VGPRs) is the
-// floor; the stateful singleton paths keep their per-slot gradient scalars as well
-template <int CPL_, int MODE_>
-constexpr int fused_min_waves() {
-  return (MODE_ == MODE_ADAM || MODE_ == MODE_ADAGRAD) ? (CPL_ >= 20 ? 2 : 3) : (CPL_ >= 26 ? 2 : (CPL_ >= 20 ? RC_FUSED_MINW : 4));
-}
 template <int D, int GS, int CPL, int MODE>
 __global__ __launch_bounds__(kBlock, (fused_min_waves<CPL, MODE>())) void bprmf_fwd_bwd_kernel(
     const float* __restrict__ U, const float* I,
     const int64_t* __restrict__ uid, const int64_t* __restrict__ iid, int B, int C,
     float inv_b, float* __restrict__ pred, float* __restrict__ loss_vec,
     float* __restrict__ gpred, float* __restrict__ ugrad, FusedUpd upd) {
-  constexpr int LPR = D / 4;
-  constexpr int S = LPR * GS;
-  static_assert(S <= 64 && (64 % S) == 0, "tuple must fit a wave");
-  constexpr int TPW = 64 / S;          // tuples per wave
-  constexpr int SLOTS = GS * CPL;      // strip length (>= C)
-  constexpr int NPL = (SLOTS + S - 1) / S;  // candidates per lane in the loss phase
-  __shared__ float strip_mem[(kBlock / 64) * TPW * SLOTS];
+  bprmf_fwd_bwd_body<D, GS, CPL, MODE, kBlock>(U, I, uid, iid, B, C, inv_b, pred, loss_vec, gpred, ugrad, upd,
+                                               (int64_t)blockIdx.x, nullptr);
+}
 
-  const int lane = threadIdx.x & 63;
-  const int64_t wave = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-  const int64_t t_raw = wave * TPW + lane / S;
-  const bool tv = t_raw < B;
-  const int64_t t = tv ? t_raw : (int64_t)B - 1;  // clamp: every lane stays in the shuffles
-  const int sub = lane % S;
-  const int grp = sub / LPR;
-  const int l = sub % LPR;
-  float* strip = strip_mem + ((threadIdx.x >> 6) * TPW + lane / S) * SLOTS;
-
-  // ---- gather: user row, then this group's CPL candidate rows, all loads in flight
-  const int64_t u = uid[t];
-  const float4 u4 = reinterpret_cast<const float4*>(U + u * D)[l];
-  const int64_t* ids = iid + t * C;
-  float4 r[CPL];
-#pragma unroll
-  for (int j = 0; j < CPL; ++j) {
-    const int c = j * GS + grp;
-    const int64_t id = ids[c < C ? c : 0];  // slots past C re-read candidate 0; masked below
-    r[j] = load_stream4(reinterpret_cast<const float4*>(I + id * D) + l);
+// First launch of the small-batch step (small_step.hip): workgroups [0, kSmallPlanWgs) group the batch's row ids
+// (small_plan.hpp), the others run the fused forward / loss / backward (read-only: every touched row is updated by the
+// second launch) and snapshot the batch's user rows.  The two parts are independent, so one launch runs them side by side.
+template <int D, int GS, int CPL>
+__global__ __launch_bounds__(kSmallThreads) void small_front_kernel(
+    const float* __restrict__ U, const float* I, const int64_t* __restrict__ uid, const int64_t* __restrict__ iid,
+    int B, int C, float inv_b, float* __restrict__ pred, float* __restrict__ loss_vec, float* __restrict__ gpred,
+    float* __restrict__ ugrad, float* __restrict__ ub, SmallPlanArgs plan) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char small_smem[];
+  if (blockIdx.x < (unsigned)kSmallPlanWgs) {
+    small_plan_block(plan, blockIdx.x, small_smem);
+    return;
   }
-  unsigned smask = 0;  // bit j: candidate slot j of this group is a singleton row
-  if (MODE != MODE_NONE) {
-    if (S == 64 && GS == 4 && (C & 3) == 0) {
-      // the tuple's C flag bytes as C/4 dwords in ONE coalesced load (lane k holds candidates 4k..4k+3); dword j is
-      // then a wave-uniform value (readlane with a constant lane) whose byte `grp` is this group's candidate j*4+grp.
-      // (25 separate byte loads per lane cost 26 us of the 0.56 ms kernel at config 2.)
-      const uint32_t* f32p = reinterpret_cast<const uint32_t*>(upd.single + t * C);
-      const uint32_t mine = (tv && lane < C / 4) ? f32p[lane] : 0u;
-#pragma unroll
-      for (int j = 0; j < CPL; ++j) {
-        const uint32_t wj = (uint32_t)__builtin_amdgcn_readlane((int)mine, j);
-        if ((wj >> (8 * grp)) & 0xFFu) smask |= 1u << j;
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < CPL; ++j) {
-        const int c = j * GS + grp;
-        if (tv && c < C && upd.single[t * C + c]) smask |= 1u << j;
-      }
-    }
-  }
-
-  // ---- scores -> strip
-#pragma unroll
-  for (int j = 0; j < CPL; ++j) {
-    const float pj = row_allreduce_sum<LPR>(dot4(u4, r[j]));
-    if (l == 0) strip[grp * CPL + j] = pj;
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-  // ---- loss, one lane per candidate: softmax over the negatives, P = sum w * sigmoid(pos - neg)
-  float pc[NPL];
-  int cc[NPL];
-#pragma unroll
-  for (int k = 0; k < NPL; ++k) {
-    const int s = sub + k * S;
-    const int c = (s % CPL) * GS + s / CPL;
-    cc[k] = (s < SLOTS && c < C) ? c : -1;
-    pc[k] = s < SLOTS ? strip[s] : 0.f;
-  }
-  const float pos = strip[0];  // candidate 0 = group 0, j = 0
-  float mx = -INFINITY;
-#pragma unroll
-  for (int k = 0; k < NPL; ++k)
-    if (cc[k] >= 1) mx = fmaxf(mx, pc[k]);
-  mx = tuple_allreduce_max<S>(mx);
-  float ew[NPL], sg[NPL];
-  float se = 0.f;
-#pragma unroll
-  for (int k = 0; k < NPL; ++k) {
-    ew[k] = cc[k] >= 1 ? expf(pc[k] - mx) : 0.f;
-    se += ew[k];
-  }
-  se = tuple_allreduce_sum<S>(se);
-  const float inv_se = 1.0f / se;
-  float P = 0.f, A = 0.f;
-#pragma unroll
-  for (int k = 0; k < NPL; ++k) {
-    ew[k] *= inv_se;  // softmax weight (0 on the positive and on masked slots)
-    sg[k] = sigmoidf_(pos - pc[k]);
-    P = fmaf(ew[k], sg[k], P);
-    A = fmaf(ew[k], sg[k] * (1.0f - sg[k]), A);
-  }
-  P = tuple_allreduce_sum<S>(P);
-  A = tuple_allreduce_sum<S>(A);
-  const BprRow br = bpr_row(P, inv_b);
-  if (tv && sub == 0) loss_vec[t] = br.loss;
-#pragma unroll
-  for (int k = 0; k < NPL; ++k) {
-    const int s = sub + k * S;
-    float g = br.dLdP * bpr_dP_dneg(ew[k], sg[k], P);
-    if (cc[k] == 0) g = br.dLdP * A;
-    if (cc[k] < 0) g = 0.f;
-    if (s < SLOTS) strip[s] = g;
-    if (tv && cc[k] >= 0) {
-      gpred[t * C + cc[k]] = g;
-      if (pred != nullptr) pred[t * C + cc[k]] = pc[k];
-    }
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-  // ---- backward: user-row gradient = sum_c g_c * I_c; single-occurrence item rows updated in place
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  float gs[CPL];  // stateful optimizers only
-#pragma unroll
-  for (int j = 0; j < CPL; ++j) {
-    const int c = j * GS + grp;
-    const float g = strip[grp * CPL + j];  // broadcast read, 0 on slots past C
-    acc.x = fmaf(g, r[j].x, acc.x);
-    acc.y = fmaf(g, r[j].y, acc.y);
-    acc.z = fmaf(g, r[j].z, acc.z);
-    acc.w = fmaf(g, r[j].w, acc.w);
-    if (MODE == MODE_ADAM || MODE == MODE_ADAGRAD) gs[j] = g;  // row updates below
-  }
-  if (MODE == MODE_SGD) {
-    // single-occurrence rows: all write-backs of the wave in one burst after the accumulation
-#pragma unroll
-    for (int j = 0; j < CPL; ++j) {
-      if (smask & (1u << j)) {  // whole lane-group takes the branch together
-        const int64_t id = ids[j * GS + grp];
-        const float g = strip[grp * CPL + j];
-        const float4 gi = make_float4(g * u4.x, g * u4.y, g * u4.z, g * u4.w);
-        opt_row4<MODE>(upd.o, upd.I, upd.M, upd.V, (size_t)id * LPR + l, r[j], gi);
-      }
-    }
-  }
-  acc.x = groups_allreduce_sum<LPR, S>(acc.x);
-  acc.y = groups_allreduce_sum<LPR, S>(acc.y);
-  acc.z = groups_allreduce_sum<LPR, S>(acc.z);
-  acc.w = groups_allreduce_sum<LPR, S>(acc.w);
-  if (tv && grp == 0) reinterpret_cast<float4*>(ugrad + t * D)[l] = acc;
-
-  if (MODE == MODE_ADAM || MODE == MODE_ADAGRAD) {
-    // singleton rows under Adam / Adagrad: the m (and v) rows of GRP candidates are requested
-    // together before any is used -- one memory round trip per batch instead of one per row
-    constexpr int GRP = 5;
-#pragma unroll
-    for (int j0 = 0; j0 < CPL; j0 += GRP) {
-      float4 mm[GRP], vv[GRP];
-      size_t idx[GRP];
-#pragma unroll
-      for (int q = 0; q < GRP; ++q) {
-        const int j = j0 + q;
-        mm[q] = vv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-        idx[q] = 0;
-        if (j < CPL && ((smask >> j) & 1u)) {
-          idx[q] = (size_t)ids[j * GS + grp] * LPR + l;
-          mm[q] = load_stream4(reinterpret_cast<const float4*>(upd.M) + idx[q]);
-          if (MODE == MODE_ADAM) vv[q] = load_stream4(reinterpret_cast<const float4*>(upd.V) + idx[q]);
-        }
-      }
-#pragma unroll
-      for (int q = 0; q < GRP; ++q) {
-        const int j = j0 + q;
-        if (j < CPL && ((smask >> j) & 1u)) {
-          const float g = gs[j];
-          const float4 gi = make_float4(g * u4.x, g * u4.y, g * u4.z, g * u4.w);
-          float4 w = r[j];
-          opt_apply4<MODE>(upd.o, w, mm[q], vv[q], gi);
-          store_row4(reinterpret_cast<float4*>(upd.I) + idx[q], w);
-          store_row4(reinterpret_cast<float4*>(upd.M) + idx[q], mm[q]);
-          if (MODE == MODE_ADAM) store_row4(reinterpret_cast<float4*>(upd.V) + idx[q], vv[q]);
-        }
-      }
-    }
-  }
+  FusedUpd none;
+  none.I = nullptr; none.M = nullptr; none.V = nullptr; none.single = nullptr;
+  bprmf_fwd_bwd_body<D, GS, CPL, MODE_NONE, kSmallThreads>(U, I, uid, iid, B, C, inv_b, pred, loss_vec, gpred, ugrad, none,
+                                                           (int64_t)blockIdx.x - kSmallPlanWgs, ub);
 }
 
 // Any d, any 2 <= C <= kGenericMaxC: one wave per tuple, scores staged in LDS, candidate
@@ -354,6 +151,8 @@ struct FusedCall {
   int mode;  // MODE_NONE or the optimizer mode of the singleton update
   FusedUpd upd;
   hipStream_t s;
+  const SmallPlanArgs* small;  // non-null: launch small_front_kernel (plan workgroups + this kernel's body)
+  float* ub;
 };
 
 template <int D, int GS, int CPL>
@@ -361,6 +160,20 @@ static int launch_fused(const FusedCall& f) {
   constexpr int TPW = 64 / ((D / 4) * GS);
   constexpr int TPB = TPW * (kBlock / 64);
   const int blocks = (f.B + TPB - 1) / TPB;
+  if (f.small) {
+    constexpr int TPB_S = TPW * (kSmallThreads / 64);
+    const int fblocks = (f.B + TPB_S - 1) / TPB_S;
+    auto kern = small_front_kernel<D, GS, CPL>;
+    static bool attr_done = false;  // per instantiation
+    if (!attr_done) {
+      RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSmallLdsBytes));
+      attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(kSmallPlanWgs + fblocks), dim3(kSmallThreads), kSmallLdsBytes, f.s, f.U, f.I, f.uid, f.iid,
+                       f.B, f.C, f.inv_b, f.pred, f.loss_vec, f.gpred, f.ugrad, f.ub, *f.small);
+    RC_LAUNCH_CHECK();
+    return RC_OK;
+  }
 #define RC_GO(MODE_)                                                                          \
   hipLaunchKernelGGL((bprmf_fwd_bwd_kernel<D, GS, CPL, MODE_>), dim3(blocks), dim3(kBlock), 0, \
                      f.s, f.U, f.I, f.uid, f.iid, f.B, f.C, f.inv_b, f.pred, f.loss_vec,       \
@@ -490,3 +303,22 @@ extern "C" int rc_bprmf_fwd_bwd_update(const float* U, float* I, float* mI, floa
   if (!handled) return fail(RC_ERR_UNSUPPORTED, "rc_bprmf_fwd_bwd_update: dispatch failed");
   return rc_;
 }
+
+namespace rc {
+// first launch of the small-batch step; the caller (train_step.hip) checked rc_bprmf_fused_supported(d, C)
+int small_front_launch(const float* U, const float* I, const int64_t* uid, const int64_t* iid, int B, int C, int d, float inv_b,
+                       float* pred, float* loss_vec, float* gpred, float* ugrad, float* ub, const SmallPlanArgs& plan,
+                       hipStream_t s) {
+  RC_REQUIRE(aligned16(U) && aligned16(I) && aligned16(ugrad) && aligned16(ub) && register_path_ok(d, C),
+             "small-batch step: unsupported shape or alignment (d=%d C=%d)", d, C);
+  FusedCall f;
+  memset(&f, 0, sizeof(f));
+  f.U = U; f.I = I; f.uid = uid; f.iid = iid; f.B = B; f.C = C; f.inv_b = inv_b;
+  f.pred = pred; f.loss_vec = loss_vec; f.gpred = gpred; f.ugrad = ugrad;
+  f.mode = MODE_NONE; f.s = s; f.small = &plan; f.ub = ub;
+  bool handled = false;
+  const int rc_ = run_fused(f, d, &handled);
+  if (!handled) return fail(RC_ERR_UNSUPPORTED, "small-batch step: dispatch failed (d=%d C=%d)", d, C);
+  return rc_;
+}
+}  // namespace rc

@@ -29,7 +29,7 @@ SOURCES = [
     "dense_opt.hip",
     "bucket_plan.hip",
     "plan_update.hip",
-    "train_step.hip",
+    "train_step.hip", "small_step.hip",
     "neumf.hip",
     "sasrec.hip", "sasrec_batch.hip",
     "listwise_loss.hip",
@@ -38,7 +38,7 @@ SOURCES = [
     "eval_rank.hip",
     "owner_step.hip",
 ]
-HEADERS = ["common.hpp", "bpr_math.hpp", "opt_math.hpp", "philox.hpp", "sas_mma.hpp", "plan.hpp", os.path.join("..", "..", "include", "rechorus_hip.h")]
+HEADERS = ["common.hpp", "bpr_math.hpp", "fused_body.hpp", "small_plan.hpp", "opt_math.hpp", "philox.hpp", "sas_mma.hpp", "plan.hpp", os.path.join("..", "..", "include", "rechorus_hip.h")]
 
 
 def _hipcc():

@@ -1,0 +1,240 @@
+// small_step.hip -- the BPRMF training step for SMALL batches (B (1 + K) + B <= 32,768 row ids, e.g. the reference's
+// default --batch_size 256 with 99 negatives, helpers/BaseRunner.py:33) in TWO launches instead of nine:
+//
+//   launch 1  small_front_kernel (bprmf_fused.hip): 128 workgroups group the ids by row (small_plan.hpp) while the
+//             others run the fused gather / dot / loss / backward and snapshot the batch's user rows
+//   launch 2  small_update_kernel (here): every touched item row (gradient sum_occ g[o] * Ub[o / C] in ascending
+//             position) and user row (sum_b ugrad[b]) read once, updated, written once; the loss mean
+//
+// The step is launch- and latency-bound at this size (103 us for ~20 dependent launches in round 1), not
+// bandwidth-bound, so the design removes dependent launches: no counters to zero, no atomics across workgroups, and the
+// user-row snapshot lets item and user rows update in the same launch (the item side never reads U again).
+// Same arithmetic as the large-batch step for rows of up to 32 occurrences; hotter rows are summed by a whole wave
+// (lane-group g takes occurrences g, g + G, ...; groups combined in a fixed butterfly), still deterministic.
+// Reference semantics: helpers/BaseRunner.py:193-206 around models/general/BPRMF.py:34-45, models/BaseModel.py:182-185.
+#include "opt_math.hpp"
+#include "small_plan.hpp"
+
+namespace rc {
+
+int small_front_launch(const float* U, const float* I, const int64_t* uid, const int64_t* iid, int B, int C, int d, float inv_b,
+                       float* pred, float* loss_vec, float* gpred, float* ugrad, float* ub, const SmallPlanArgs& plan,
+                       hipStream_t s);
+
+struct SmallUpdArgs {
+  float *I, *mI, *vI, *U, *mU, *vU;
+  const rc_plan_row* rows;   // [kSmallPlanWgs][n]
+  const uint32_t* occ;       // [kSmallPlanWgs][n]
+  const SmallCnt* cnt;
+  uint32_t n, n_a;
+  int C;
+  const float* gpred;        // [n_a]
+  const float* ub;           // [B, D] pre-step user rows of the batch
+  const float* ugrad;        // [B, D]
+  OptScalars o;
+  const float* loss_vec;
+  int B;
+  float loss_scale;
+  float* loss_out;
+};
+
+__device__ __forceinline__ void padd4s(float4& x, const float4& y) {
+  x.x += y.x; x.y += y.y; x.z += y.z; x.w += y.w;
+}
+
+constexpr int kSmallSeq = 32;   // occurrences one lane-group sums on its own
+
+// gradient row (this lane's float4) of occurrence slot k of a row
+template <int D>
+__device__ __forceinline__ float4 small_grad4_at(const SmallUpdArgs& a, bool side_b, uint32_t o, int l) {
+  constexpr int LPR = D / 4;
+  if (side_b) return reinterpret_cast<const float4*>(a.ugrad)[(size_t)(o - a.n_a) * LPR + l];
+  const float c = a.gpred[o];
+  float4 v = reinterpret_cast<const float4*>(a.ub)[(size_t)(o / (uint32_t)a.C) * LPR + l];
+  v.x *= c; v.y *= c; v.z *= c; v.w *= c;
+  return v;
+}
+template <int D>
+__device__ __forceinline__ float4 small_grad4(const SmallUpdArgs& a, bool side_b, uint32_t slot, int l) {
+  return small_grad4_at<D>(a, side_b, a.occ[slot], l);
+}
+
+template <int D, int MODE>
+__global__ __launch_bounds__(kBlock) void small_update_kernel(SmallUpdArgs a) {
+  constexpr int LPR = D / 4;
+  constexpr int GPW = 64 / LPR;
+  __shared__ uint32_t pre_a[kSmallPlanWgs + 1], pre_b[kSmallPlanWgs + 1], cnt_a[kSmallPlanWgs];
+  __shared__ float red[kBlock];
+  __shared__ uint32_t wsum[8];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int l = lane % LPR, grp = lane / LPR;
+
+  if (blockIdx.x == gridDim.x - 1) {  // the loss mean: fixed order (thread t sums t, t + 256, ...; LDS tree)
+    if (a.loss_out == nullptr) return;
+    float acc = 0.f;   // same order as plan_final_kernel / reduce_sum_kernel: the step's loss is bit-identical across pipelines
+    int64_t done = 0;
+    if (reinterpret_cast<uintptr_t>(a.loss_vec) % 16 == 0) {
+      const int64_t n4 = a.B / 4;
+      const float4* x4 = reinterpret_cast<const float4*>(a.loss_vec);
+      for (int64_t i = tid; i < n4; i += kBlock) {
+        const float4 v = x4[i];
+        acc += (v.x + v.y) + (v.z + v.w);
+      }
+      done = n4 * 4;
+    }
+    for (int64_t i = done + tid; i < a.B; i += kBlock) acc += a.loss_vec[i];
+    red[tid] = acc;
+    __syncthreads();
+    for (int off = kBlock / 2; off >= 1; off >>= 1) {
+      if (tid < off) red[tid] += red[tid + off];
+      __syncthreads();
+    }
+    if (tid == 0) a.loss_out[0] = red[0] * a.loss_scale;
+    return;
+  }
+
+  {  // exclusive prefix of the per-workgroup row counts: one thread per plan workgroup
+    static_assert(kSmallPlanWgs <= kBlock && kSmallPlanWgs % 64 == 0, "one thread per plan workgroup, whole waves");
+    SmallCnt c;
+    c.rows_a = c.rows_b = c.occ = c.pad = 0;
+    if (tid < kSmallPlanWgs) c = a.cnt[tid];
+    uint32_t xa = c.rows_a, xb = c.rows_b;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t ya = __shfl_up(xa, off, 64), yb = __shfl_up(xb, off, 64);
+      if (lane >= off) { xa += ya; xb += yb; }
+    }
+    if (lane == 63) { wsum[tid >> 6] = xa; wsum[4 + (tid >> 6)] = xb; }
+    __syncthreads();
+    for (int q = 0; q < (tid >> 6); ++q) { xa += wsum[q]; xb += wsum[4 + q]; }
+    if (tid < kSmallPlanWgs) { pre_a[tid] = xa - c.rows_a; pre_b[tid] = xb - c.rows_b; cnt_a[tid] = c.rows_a; }
+    if (tid == kSmallPlanWgs - 1) { pre_a[kSmallPlanWgs] = xa; pre_b[kSmallPlanWgs] = xb; }
+  }
+  __syncthreads();
+  const uint32_t Ra = pre_a[kSmallPlanWgs], R = Ra + pre_b[kSmallPlanWgs];
+  const uint32_t n_waves = (gridDim.x - 1) * (kBlock / 64);
+  const uint32_t wave = blockIdx.x * (kBlock / 64) + (tid >> 6);
+  for (uint32_t r0 = wave * GPW; r0 < R; r0 += n_waves * GPW) {
+    // this lane-group's row: flat index -> (side, plan workgroup, index in its segment)
+    const uint32_t r = r0 + grp;
+    const bool on = r < R;
+    const bool side_b = on && r >= Ra;
+    rc_plan_row e;
+    e.row = 0; e.start = 0; e.n = 0; e.reserved = 0;
+    if (on) {
+      const uint32_t* pre = side_b ? pre_b : pre_a;
+      const uint32_t q = side_b ? r - Ra : r;
+      int lo = 0, hi = kSmallPlanWgs;   // last w with pre[w] <= q
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (pre[mid] <= q) lo = mid; else hi = mid;
+      }
+      const uint32_t j = q - pre[lo] + (side_b ? cnt_a[lo] : 0u);
+      e = a.rows[(size_t)lo * a.n + j];
+    }
+    float* W = side_b ? a.U : a.I;
+    float* M = side_b ? a.mU : a.mI;
+    float* V = side_b ? a.vU : a.vI;
+    const size_t idx4 = (size_t)e.row * LPR + l;
+    float4 w4 = make_float4(0.f, 0.f, 0.f, 0.f), m4 = w4, v4 = w4;
+    if (on) {
+      w4 = reinterpret_cast<const float4*>(W)[idx4];
+      if (mode_has_m(MODE)) m4 = reinterpret_cast<const float4*>(M)[idx4];
+      if (mode_has_v(MODE)) v4 = reinterpret_cast<const float4*>(V)[idx4];
+    }
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool seq = on && e.n <= (uint32_t)kSmallSeq;
+    if (seq) {
+      acc = small_grad4_at<D>(a, side_b, e.reserved, l);   // the record carries the row's first position
+      for (uint32_t k = 1; k < e.n; ++k) padd4s(acc, small_grad4<D>(a, side_b, e.start + k, l));
+    }
+    // hot rows of this wave's groups, one after the other, summed by the whole wave
+    uint64_t hot = __ballot(on && !seq && l == 0);
+    while (hot) {
+      const int src = __ffsll((long long)hot) - 1;   // lane 0 of the owning group
+      hot &= hot - 1;
+      const uint32_t hs = __shfl(e.start, src, 64), hn = __shfl(e.n, src, 64);
+      const bool hb = __shfl((int)side_b, src, 64) != 0;
+      float4 part = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (uint32_t k = grp; k < hn; k += GPW) padd4s(part, small_grad4<D>(a, hb, hs + k, l));
+      part.x = groups_allreduce_sum<LPR, 64>(part.x);
+      part.y = groups_allreduce_sum<LPR, 64>(part.y);
+      part.z = groups_allreduce_sum<LPR, 64>(part.z);
+      part.w = groups_allreduce_sum<LPR, 64>(part.w);
+      if (lane / LPR == src / LPR) acc = part;
+    }
+    if (on) {
+      opt_apply4<MODE>(a.o, w4, m4, v4, acc);
+      reinterpret_cast<float4*>(W)[idx4] = w4;
+      if (mode_has_m(MODE)) reinterpret_cast<float4*>(M)[idx4] = m4;
+      if (mode_has_v(MODE)) reinterpret_cast<float4*>(V)[idx4] = v4;
+    }
+  }
+}
+
+template <int D>
+static int small_update_launch_d(const SmallUpdArgs& a, int mode, hipStream_t s) {
+  // one lane-group per row, a few rows per group: the grid covers the worst case (every key a distinct row)
+  constexpr int GPB = kBlock / (D / 4);
+  unsigned blocks = (a.n + GPB - 1) / GPB;
+  if (blocks > 2048u) blocks = 2048u;
+  if (blocks < 1u) blocks = 1u;
+  switch (mode) {
+    case MODE_SGD: hipLaunchKernelGGL((small_update_kernel<D, MODE_SGD>), dim3(blocks + 1), dim3(kBlock), 0, s, a); break;
+    case MODE_ADAM: hipLaunchKernelGGL((small_update_kernel<D, MODE_ADAM>), dim3(blocks + 1), dim3(kBlock), 0, s, a); break;
+    default: hipLaunchKernelGGL((small_update_kernel<D, MODE_ADAGRAD>), dim3(blocks + 1), dim3(kBlock), 0, s, a); break;
+  }
+  RC_LAUNCH_CHECK();
+  return RC_OK;
+}
+
+// workspace of the small-batch step beyond gpred / ugrad / loss_vec
+size_t small_step_extra_bytes(int64_t n, int64_t B, int d) {
+  size_t t = 0;
+  t += align_up((size_t)B * d * sizeof(float), 256);                                   // ub
+  t += align_up((size_t)kSmallPlanWgs * (size_t)n * sizeof(rc_plan_row), 256);         // rows
+  t += align_up((size_t)kSmallPlanWgs * (size_t)n * sizeof(uint32_t), 256);            // occ
+  t += align_up((size_t)kSmallPlanWgs * sizeof(SmallCnt), 256);                       // cnt
+  return t;
+}
+
+bool small_step_supported(int64_t n_i, int64_t B, int64_t n_items, int64_t n_users, int d) {
+  return n_i + B <= kSmallMaxKeys && n_items + n_users < ((int64_t)1 << 32) && (d == 16 || d == 32 || d == 64 || d == 128);
+}
+
+int small_step_launch(float* U, float* I, float* mU, float* vU, float* mI, float* vI, const int64_t* uid, const int64_t* iid,
+                      int B, int C, int d, int64_t n_items, const rc_opt_hyper* h, float inv_b, float* loss_out, float* pred,
+                      float* gpred, float* ugrad, float* loss_vec, void* extra, hipStream_t s, hipEvent_t* ev_mid) {
+  const int64_t n_i = (int64_t)B * C, n = n_i + B;
+  Carver cv(extra);
+  float* ub = cv.take<float>((size_t)B * d);
+  rc_plan_row* rows = cv.take<rc_plan_row>((size_t)kSmallPlanWgs * (size_t)n);
+  uint32_t* occ = cv.take<uint32_t>((size_t)kSmallPlanWgs * (size_t)n);
+  SmallCnt* cnt = cv.take<SmallCnt>(kSmallPlanWgs);
+  SmallPlanArgs p;
+  memset(&p, 0, sizeof(p));
+  p.ids_a = iid; p.ids_b = uid; p.n_a = (uint32_t)n_i; p.n = (uint32_t)n; p.base_b = (uint32_t)n_items;
+  p.rows = rows; p.occ = occ; p.cnt = cnt;
+  RC_TRY(small_front_launch(U, I, uid, iid, B, C, d, inv_b, pred, loss_vec, gpred, ugrad, ub, p, s));
+  if (ev_mid) {  // two consecutive marks: [0] closes the front launch, [1] opens the update launch
+    RC_HIP(hipEventRecord(ev_mid[0], s));
+    RC_HIP(hipEventRecord(ev_mid[1], s));
+  }
+  SmallUpdArgs a;
+  memset(&a, 0, sizeof(a));
+  RC_TRY(fill_opt_scalars(h, &a.o));
+  const int mode = mode_of(h);
+  RC_REQUIRE(mode != MODE_ADAM || (mU && vU && mI && vI), "rc_bprmf_train_step: Adam needs m and v tables");
+  RC_REQUIRE(mode != MODE_ADAGRAD || (mU && mI), "rc_bprmf_train_step: Adagrad needs the state_sum tables");
+  a.I = I; a.mI = mI; a.vI = vI; a.U = U; a.mU = mU; a.vU = vU;
+  a.rows = rows; a.occ = occ; a.cnt = cnt; a.n = (uint32_t)n; a.n_a = (uint32_t)n_i; a.C = C;
+  a.gpred = gpred; a.ub = ub; a.ugrad = ugrad; a.loss_vec = loss_vec; a.B = B; a.loss_scale = inv_b; a.loss_out = loss_out;
+  switch (d) {
+    case 16: return small_update_launch_d<16>(a, mode, s);
+    case 32: return small_update_launch_d<32>(a, mode, s);
+    case 64: return small_update_launch_d<64>(a, mode, s);
+    default: return small_update_launch_d<128>(a, mode, s);
+  }
+}
+
+}  // namespace rc

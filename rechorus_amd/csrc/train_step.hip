@@ -24,6 +24,12 @@ int plan_bprmf_step_updates(float* U, float* mU, float* vU, float* I, float* mI,
                             const rc_opt_hyper* h, const float* loss_vec, float loss_scale, float* loss_out,
                             hipStream_t s, hipEvent_t* ev_items_done);
 int plan_prepare();
+// small batches (small_step.hip): two launches
+size_t small_step_extra_bytes(int64_t n, int64_t B, int d);
+bool small_step_supported(int64_t n_i, int64_t B, int64_t n_items, int64_t n_users, int d);
+int small_step_launch(float* U, float* I, float* mU, float* vU, float* mI, float* vI, const int64_t* uid, const int64_t* iid,
+                      int B, int C, int d, int64_t n_items, const rc_opt_hyper* h, float inv_b, float* loss_out, float* pred,
+                      float* gpred, float* ugrad, float* loss_vec, void* extra, hipStream_t s, hipEvent_t* ev_mid);
 }
 
 // The second stream of the step.  The bucket plan's per-bucket pass (row records + grouped positions) is index work
@@ -74,6 +80,7 @@ struct StepWs {
   rc_plan_row* rows_i;
   rc_plan_row* rows_u;
   uint32_t* occ;
+  void* small_extra;     // small-batch step (small_step.hip): user-row snapshot, per-workgroup row / position segments
   size_t total;
 };
 
@@ -114,23 +121,30 @@ StepWs carve_step_ws(void* base, int B, int C, int d) {
   w.rows_u = pv.take<rc_plan_row>((size_t)B);
   w.occ = pv.take<uint32_t>(n_i + (size_t)B);
   w.total = cv.off > pv.off ? cv.off : pv.off;
+  // the small-batch step's buffers overlay the same region (the pipelines never run in the same call)
+  w.small_extra = base ? reinterpret_cast<char*>(base) + plan_off : nullptr;
+  if ((int64_t)n_i + B <= 32768) {
+    const size_t need = plan_off + small_step_extra_bytes((int64_t)n_i + B, B, d);
+    if (need > w.total) w.total = need;
+  }
   return w;
 }
 }  // namespace
 
-// 0 = automatic (bucket plan, its per-bucket pass on a second stream behind the fused kernel), 1 = always the sort
-// pipeline, 2 = bucket plan on ONE stream; initial value from RC_BPRMF_STEP=sort|serial
+// 0 = automatic (two-launch step for small batches; else the bucket plan, its per-bucket pass on a second stream behind
+// the fused kernel), 1 = always the sort pipeline, 2 = bucket plan on ONE stream, 3 = bucket plan on two streams whatever
+// the batch size; initial value from RC_BPRMF_STEP=sort|serial|plan
 static int& step_pipeline() {
   static int mode = [] {
     const char* v = getenv("RC_BPRMF_STEP");
-    return (v && strcmp(v, "sort") == 0) ? 1 : ((v && strcmp(v, "serial") == 0) ? 2 : 0);
+    return (v && strcmp(v, "sort") == 0) ? 1 : ((v && strcmp(v, "serial") == 0) ? 2 : ((v && strcmp(v, "plan") == 0) ? 3 : 0));
   }();
   return mode;
 }
 
 extern "C" int rc_bprmf_step_pipeline(int mode) {
   const int prev = step_pipeline();
-  if (mode >= 0 && mode <= 2) step_pipeline() = mode;
+  if (mode >= 0 && mode <= 3) step_pipeline() = mode;
   return prev;
 }
 
@@ -181,6 +195,18 @@ extern "C" int rc_bprmf_train_step(float* U, float* I, float* mU, float* vU, flo
   const bool force_sort = step_pipeline() == 1;
   const PlanGeom geom = plan_geometry(n_i, B, n_items, n_users);
   const bool fused_ok = rc_bprmf_fused_supported(d, C) != 0;
+  // Small batches (<= 32,768 row ids, e.g. the reference's default B = 256 with K = 99): two launches (small_step.hip).
+  if (step_pipeline() == 0 && fused_ok && small_step_supported(n_i, B, n_items, n_users, d) &&
+      reinterpret_cast<uintptr_t>(U) % 16 == 0 && reinterpret_cast<uintptr_t>(I) % 16 == 0) {
+    RC_MARK(0);
+    RC_MARK(1);
+    RC_MARK(2);
+    RC_MARK(3);
+    RC_TRY(small_step_launch(U, I, mU, vU, mI, vI, uid, iid, B, C, d, n_items, h, inv_b, loss_out, pred, w.gpred, w.ugrad,
+                             w.loss_vec, w.small_extra, s, prof ? &ev[4] : nullptr));  // marks 4, 5
+    RC_MARK(6);
+    RC_MARK(7);
+  } else
   if (!force_sort && geom.ok && fused_ok && (d == 16 || d == 32 || d == 64 || d == 128)) {
     RC_TRY(plan_prepare());
     PlanArgs pa;
@@ -195,7 +221,7 @@ extern "C" int rc_bprmf_train_step(float* U, float* I, float* mU, float* vU, flo
     pa.n_rows_a = &w.plan.counters[PC_ROWS_A]; pa.n_rows_b = &w.plan.counters[PC_ROWS_B];
     pa.occ = w.occ;
     StepSide& side = step_side();
-    const bool two_streams = step_pipeline() == 0 && side.ok;
+    const bool two_streams = (step_pipeline() == 0 || step_pipeline() == 3) && side.ok;
     RC_MARK(0);
     if (two_streams) {
       // caller's stream: partition (+ singleton flags when the fused kernel updates them) -> fused kernel

@@ -112,7 +112,7 @@ def test_train_step_plan_pipeline_equals_sort_pipeline(opt, lr, l2, d, B, C, n_u
     res = []
     prev = lib.rc_bprmf_step_pipeline(-1)
     try:
-        for mode in (1, 0, 2):  # sort pipeline, bucket plan on two streams (default), bucket plan on one stream
+        for mode in (1, 3, 2, 0):  # sort pipeline, bucket plan on two streams / on one stream, automatic choice
             lib.rc_bprmf_step_pipeline(mode)
             U, I = torch.from_numpy(U0).to(cuda), torch.from_numpy(I0).to(cuda)
             tr = eng.BprmfTrainer(U, I, opt=opt, lr=lr, l2=l2)
@@ -127,6 +127,17 @@ def test_train_step_plan_pipeline_equals_sort_pipeline(opt, lr, l2, d, B, C, n_u
                 continue
             assert torch.equal(x, y), f"{name} (pipeline {other}): {int((x != y).sum())} elements differ, max |diff| {(x - y).abs().max().item():.3e}"
     assert not torch.equal(res[0][1], torch.from_numpy(I0).to(cuda))
+    # automatic choice: the bucket plan (bit-identical again) or, up to 32,768 row ids, the two-launch small-batch step,
+    # which sums rows of more than 32 occurrences in another (fixed) order: equal to fp32 summation order
+    from conftest import assert_update_close
+    small = B * C + B <= 32768
+    assert torch.equal(res[0][6][0], res[3][6][0]), "loss of the first step"
+    for name, x, y, x0 in (("U", res[0][0], res[3][0], U0), ("I", res[0][1], res[3][1], I0)):
+        if not small:
+            assert torch.equal(x, y), name
+        else:
+            assert_update_close(y.cpu().numpy(), x0, x.cpu().numpy(), what=f"{name} (small-batch step)",
+                                extra_atol=0.0 if opt == "SGD" else 1e-3 * lr)
 
 
 @pytest.mark.parametrize("opt,lr,l2", [("SGD", 0.05, 1e-3), ("Adam", 1e-3, 1e-4), ("Adagrad", 0.01, 1e-4)])
@@ -181,3 +192,61 @@ def test_plan_update_matches_the_rowwise_oracle(opt, lr, l2, d, cuda, eng):
         Wn = W0_.copy()
         O.opt_step_dense(Wn, O.embedding_dense_backward(g_, ids_a, n_rows), st_, opt, lr, l2, step=2, rows=np.unique(ids_a))
         assert_update_close(W_.cpu().numpy(), W0_, Wn, what="plan.update_pair", extra_atol=ex)
+
+
+@pytest.mark.parametrize("opt,lr,l2", [("SGD", 0.05, 1e-3), ("Adam", 1e-3, 1e-4), ("Adagrad", 0.01, 1e-4)])
+@pytest.mark.parametrize("kind", ["default_b256_k99", "duplicates_overflow", "tiny", "d128_users_hot"])
+def test_small_batch_step_vs_oracle(kind, opt, lr, l2, cuda, eng):
+    """the two-launch small-batch step (automatic up to 32,768 row ids) vs the numpy oracle, three steps: the reference's
+    default batch shape, a batch whose ids are thousands of duplicates of a few rows (one plan workgroup overflows its
+    LDS budget and selects its rows by scans; hot rows summed by whole waves), a batch smaller than one workgroup"""
+    from conftest import assert_close, assert_update_close
+    from oracle import bprmf_oracle as O
+    from rechorus_amd import _lib
+    rng = np.random.default_rng(len(kind))
+    if kind == "default_b256_k99":
+        n_users, n_items, d, B, C = 5000, 60_000, 64, 256, 100
+        mk = lambda: (_zipf(rng, n_users, B), np.concatenate([_zipf(rng, n_items, (B, 1)), rng.integers(1, n_items, size=(B, C - 1))], axis=1))
+    elif kind == "duplicates_overflow":
+        n_users, n_items, d, B, C = 40, 3000, 64, 300, 100   # 30,300 ids, almost all of them multiples of 256 (one owner workgroup)
+        def mk():
+            iid = 256 * rng.integers(1, 6, size=(B, C))
+            m = rng.random((B, C)) < 0.05
+            iid[m] = rng.integers(1, n_items, size=int(m.sum()))
+            iid[:, 0] = rng.integers(1, n_items, size=B)
+            return rng.integers(0, 3, size=B).astype(np.int64), iid.astype(np.int64)
+    elif kind == "tiny":
+        n_users, n_items, d, B, C = 9, 30, 32, 3, 5
+        mk = lambda: (rng.integers(0, n_users, size=B).astype(np.int64), rng.integers(0, n_items, size=(B, C)).astype(np.int64))
+    else:
+        n_users, n_items, d, B, C = 6, 900, 128, 500, 4
+        mk = lambda: (rng.integers(0, n_users, size=B).astype(np.int64), rng.integers(0, n_items, size=(B, C)).astype(np.int64))
+    assert B * C + B <= 32768 and _lib.load().rc_bprmf_step_pipeline(-1) == 0
+    U0 = rng.normal(0, 0.01, size=(n_users, d)).astype(np.float32)
+    I0 = rng.normal(0, 0.01, size=(n_items, d)).astype(np.float32)
+    Un, In = U0.copy(), I0.copy()
+    sU, sI = O.new_state(Un, opt), O.new_state(In, opt)
+    U, I = torch.from_numpy(U0).to(cuda), torch.from_numpy(I0).to(cuda)
+    tr = eng.BprmfTrainer(U, I, opt=opt, lr=lr, l2=l2)
+    ex = 1e-3 * lr if opt in ("Adam", "Adagrad") else 0.0
+    seen = []
+    for step in (1, 2, 3):
+        u, i = mk()
+        seen.append(i.ravel())
+        want_loss, _ = O.bprmf_train_step(Un, In, sU, sI, u, i, opt=opt, lr=lr, l2=l2, step=step, rowwise=True)
+        loss = tr.step(torch.from_numpy(u).to(cuda), torch.from_numpy(i).to(cuda))
+        assert_close(loss.cpu().numpy()[0], want_loss, what=f"loss step {step}")
+        assert_update_close(U.cpu().numpy(), U0, Un, what=f"dU step {step}", extra_atol=ex, outlier_atol=lr * step)
+        assert_update_close(I.cpu().numpy(), I0, In, what=f"dI step {step}", extra_atol=ex, outlier_atol=lr * step)
+    mask = np.ones(n_items, dtype=bool)
+    mask[np.unique(np.concatenate(seen))] = False
+    assert np.array_equal(I.cpu().numpy()[mask], I0[mask])   # untouched rows bit-identical
+    # run-to-run reproducibility (deterministic layout, fixed summation orders)
+    U2, I2 = torch.from_numpy(U0).to(cuda), torch.from_numpy(I0).to(cuda)
+    tr2 = eng.BprmfTrainer(U2, I2, opt=opt, lr=lr, l2=l2)
+    rng = np.random.default_rng(len(kind))
+    rng.normal(0, 0.01, size=(n_users, d)); rng.normal(0, 0.01, size=(n_items, d))
+    for step in (1, 2, 3):
+        u, i = mk()
+        tr2.step(torch.from_numpy(u).to(cuda), torch.from_numpy(i).to(cuda))
+    assert torch.equal(U, U2) and torch.equal(I, I2)
