@@ -229,17 +229,42 @@ def _exchange_async(send, send_counts, recv_counts, group=None):
     return _Pending(recv)
 
 
+class _Counts:
+    """split sizes of several exchanges, travelling: the tiny all_to_all is enqueued at construction, the device -> host
+    copy is asynchronous (pinned buffer + event), get() waits for THAT event only.  A step that prepares the NEXT batch's
+    routes before it enqueues its own heavy kernels (`next_batch=` of the sharded steps) finds the sizes on the host when
+    the next step starts, so the host never waits for the device to drain and keeps enqueueing one step ahead."""
+
+    def __init__(self, count_tensors, group=None):
+        world = dist.get_world_size(group)
+        self.k = len(count_tensors)
+        sc = torch.stack([c.to(torch.int64) for c in count_tensors], dim=1).contiguous()  # [world, k]
+        rc = torch.empty_like(sc)
+        _all_to_all_v(rc, sc, [1] * world, [1] * world, group)
+        both = torch.cat([sc, rc], dim=1)
+        self.event = None
+        if both.is_cuda:
+            self.host = torch.empty(both.shape, dtype=both.dtype, pin_memory=True)
+            self.host.copy_(both, non_blocking=True)
+            self.event = torch.cuda.Event()
+            self.event.record()
+        else:
+            self.host = both
+        self._lists = None
+
+    def get(self):
+        """-> ([send lists], [recv lists]); blocks only until the copy of these sizes has landed"""
+        if self._lists is None:
+            if self.event is not None:
+                self.event.synchronize()
+            both, k = self.host.tolist(), self.k
+            self._lists = ([[row[j] for row in both] for j in range(k)], [[row[k + j] for row in both] for j in range(k)])
+        return self._lists
+
+
 def _exchange_counts(count_tensors, group=None):
     """one all_to_all for the split sizes of several exchanges -> ([send lists], [recv lists]); ONE host sync"""
-    world = dist.get_world_size(group)
-    k = len(count_tensors)
-    sc = torch.stack([c.to(torch.int64) for c in count_tensors], dim=1).contiguous()  # [world, k]
-    rc = torch.empty_like(sc)
-    _all_to_all_v(rc, sc, [1] * world, [1] * world, group)
-    both = torch.cat([sc, rc], dim=1).tolist()
-    send = [[row[j] for row in both] for j in range(k)]
-    recv = [[row[k + j] for row in both] for j in range(k)]
-    return send, recv
+    return _Counts(count_tensors, group).get()
 
 
 def _exchange_back(payload, recv_counts, send_counts, group=None):
@@ -366,9 +391,28 @@ class ShardedBprmf:
         return out
 
     # ---- one training step ------------------------------------------------------------------------
-    def step(self, uid, iid):
+    def _prepare(self, uid, iid):
+        """group the batch's ids by owner for the plan of this shape and START the exchange of the split sizes"""
+        B, C = iid.shape
+        plan = self._plan(C)
+        ru = self._route(uid)
+        ri = self._route(iid.reshape(-1)) if plan == "rows" else self._route(iid.reshape(-1), tuple_base=self.rank * B, div=C)
+        return {"key": (uid.data_ptr(), iid.data_ptr(), tuple(iid.shape)), "plan": plan, "u": ru, "i": ri,
+                "counts": _Counts([ru[1], ri[1]], self.group)}
+
+    def _routes_of(self, uid, iid, next_batch):
+        ahead, self._ahead = getattr(self, "_ahead", None), None
+        key = (uid.data_ptr(), iid.data_ptr(), tuple(iid.shape))
+        prep = ahead if (ahead is not None and ahead["key"] == key) else self._prepare(uid, iid)
+        if next_batch is not None:
+            self._ahead = self._prepare(*next_batch)   # enqueued before this step's heavy kernels
+        return prep
+
+    def step(self, uid, iid, next_batch=None):
         """uid [B] int64, iid [B, C] int64: this rank's tuples (same B on every rank).
-        Returns the GLOBAL mean loss as a python-free device tensor [1]."""
+        Returns the GLOBAL mean loss as a python-free device tensor [1].
+        next_batch = (uid, iid) of the following step (optional): routed and its split sizes exchanged ahead of this
+        step's kernels, so the host finds them ready and never waits for the device (see _Counts)."""
         W, ops = self.world, self.ops
         B, C = iid.shape
         n_tuples = W * B
@@ -380,14 +424,14 @@ class ShardedBprmf:
             self.timing.clear()
         mark = self._mark
         mark("start")
-        if self._plan(C) == "rows":
-            return self._step_rows(uid, iid, hyper)
+        prep = self._routes_of(uid, iid, next_batch)
+        if prep["plan"] == "rows":
+            return self._step_rows(uid, iid, hyper, prep)
 
-        # 0. group user ids and candidate occurrences by owner; ONE exchange of all split sizes
-        flat = iid.reshape(-1)
-        order_u, cnt_u, req_local = self._route(uid)
-        order_i, cnt_i, packed = self._route(flat, tuple_base=self.rank * B, div=C)
-        (cnt_u, cnt_i), (rcnt_u, rcnt_i) = _exchange_counts([cnt_u, cnt_i], self.group)
+        # 0. user ids and candidate occurrences grouped by owner; ONE exchange of all split sizes (a step ahead with next_batch)
+        order_u, _, req_local = prep["u"]
+        order_i, _, packed = prep["i"]
+        (cnt_u, cnt_i), (rcnt_u, rcnt_i) = prep["counts"].get()
         mark("0 group by owner")
 
         # 1. fetch the batch's user rows from their owners
@@ -453,17 +497,17 @@ class ShardedBprmf:
         owner_plan = 2 * (W - 1) * row + (2 * row + 16 * C) * (W - 1) / W  # all_gather + reduce_scatter + the small routes
         return "rows" if rows_plan < owner_plan else "owner"
 
-    def _step_rows(self, uid, iid, hyper):
+    def _step_rows(self, uid, iid, hyper, prep):
         """the rows travel to the tuples (few candidates per tuple); see the module docstring"""
         W, ops, group = self.world, self.ops, self.group
         B, C = iid.shape
         n_tuples = W * B
         dev = uid.device
         mark = self._mark
-        # 0. group both lookups by owner; ONE exchange of all split sizes
-        order_u, cnt_u, loc_u = self._route(uid)
-        order_i, cnt_i, loc_i = self._route(iid.reshape(-1))
-        (cnt_u, cnt_i), (rcnt_u, rcnt_i) = _exchange_counts([cnt_u, cnt_i], group)
+        # 0. both lookups grouped by owner; ONE exchange of all split sizes
+        order_u, _, loc_u = prep["u"]
+        order_i, _, loc_i = prep["i"]
+        (cnt_u, cnt_i), (rcnt_u, rcnt_i) = prep["counts"].get()
         mark("0 group by owner")
 
         # 1. owners serve the rows; they come back in SEND order (grouped by owner), the kernels below
@@ -692,8 +736,31 @@ class ShardedNeumf:
             out[k] = self.P[k].clone()
         return out
 
-    def step(self, uid, iid):
-        """uid [B], iid [B, C]: this rank's tuples (same B everywhere) -> global mean loss, device tensor [1]"""
+    # ---- routing of a batch, separable from its step (look-ahead) -------------------------------------------------
+    def _prepare(self, uid, iid):
+        """group the batch's ids by owner (per micro-batch chunk) and START the exchange of the split sizes"""
+        W, ops = self.world, self.ops
+        M = self.micro_batches if (W > 1 and self.micro_batches > 1 and iid.shape[0] >= self.micro_batches) else 1
+        uc, ic = (torch.chunk(uid, M), torch.chunk(iid, M)) if M > 1 else ((uid,), (iid,))
+        grouped = [(_Route.prepare(u, W, ops, self.dedup), _Route.prepare(i.reshape(-1), W, ops, self.dedup)) for u, i in zip(uc, ic)]
+        counts = _Counts([g[0][1] for pair in grouped for g in pair], self.group)
+        return {"key": (uid.data_ptr(), iid.data_ptr(), tuple(iid.shape)), "uc": uc, "ic": ic, "grouped": grouped, "counts": counts}
+
+    def _routes_of(self, uid, iid, next_batch):
+        """the prepared routes of (uid, iid) -- taken from the previous step's look-ahead when it prepared this very
+        batch -- and, FIRST thing in this step's enqueue order, the routes of `next_batch`"""
+        ahead, self._ahead = getattr(self, "_ahead", None), None
+        key = (uid.data_ptr(), iid.data_ptr(), tuple(iid.shape))
+        prep = ahead if (ahead is not None and ahead["key"] == key) else self._prepare(uid, iid)
+        if next_batch is not None and self.world > 1:
+            self._ahead = self._prepare(*next_batch)
+        return prep
+
+    def step(self, uid, iid, next_batch=None):
+        """uid [B], iid [B, C]: this rank's tuples (same B everywhere) -> global mean loss, device tensor [1].
+        next_batch = (uid, iid) of the FOLLOWING step (optional): its ids are grouped by owner and the exchange of its
+        split sizes is started before this step's kernels are enqueued, so the next step finds the sizes on the host and
+        the host never waits for the device (otherwise: one blocking device -> host copy per step)."""
         W, ops, d = self.world, self.ops, self.d
         B, C = iid.shape
         n_tuples = W * B
@@ -702,14 +769,15 @@ class ShardedNeumf:
         hyper0 = ops.make_hyper(opt=self.opt, lr=self.lr, l2=0.0, step=self.step_count)  # 'bias': no weight decay
         dev = uid.device
         if W > 1 and self.micro_batches > 1 and B >= self.micro_batches:
-            return self._step_pipelined(uid, iid, hyper, hyper0)
+            return self._step_pipelined(uid, iid, hyper, hyper0, self._routes_of(uid, iid, next_batch))
         if W == 1:
             ru = rv = None
             urows = torch.cat([ops.gather_rows(self.P[k], uid) for k in ("mf_u", "mlp_u")], dim=1)
             irows = torch.cat([ops.gather_rows(self.P[k], iid.reshape(-1)) for k in ("mf_i", "mlp_i")], dim=1)
         else:
-            pu_, pv_ = _Route.prepare(uid, W, ops, self.dedup), _Route.prepare(iid.reshape(-1), W, ops, self.dedup)
-            sends, recvs = _exchange_counts([pu_[0][1], pv_[0][1]], self.group)   # split sizes of both lookups: ONE host sync
+            prep = self._routes_of(uid, iid, next_batch)
+            (pu_, pv_), = prep["grouped"]
+            sends, recvs = prep["counts"].get()   # split sizes of both lookups (on the host already with look-ahead)
             ru = _Route(uid, W, ops, self.group, splits=(sends[0], recvs[0]), prepared=pu_)
             rv = _Route(iid.reshape(-1), W, ops, self.group, splits=(sends[1], recvs[1]), prepared=pv_)
             self._account([ru, rv])
@@ -762,21 +830,19 @@ class ShardedNeumf:
                 tot[k] = tot.get(k, 0) + v
         self.wire = tot
 
-    def _step_pipelined(self, uid, iid, hyper, hyper0):
+    def _step_pipelined(self, uid, iid, hyper, hyper0, prep):
         """The same step with the local batch cut into `micro_batches` chunks: the row fetch of chunk k+1 and the
         gradient push of chunk k-1 are in flight (RCCL's stream) while the head kernels of chunk k run.  Every chunk
         is scored against the pre-step parameters and the owners apply ONE update per table over the gradients of
         all chunks, so the result equals the unpipelined step (tests/test_sharded_gloo.py).  All split sizes of
-        all chunks travel in one exchange: one host sync per step, as before."""
+        all chunks travel in one exchange (prep["counts"], started by _prepare -- a step earlier with look-ahead)."""
         W, ops, d, group = self.world, self.ops, self.d, self.group
         B, C = iid.shape
         n_tuples = W * B
         dev = uid.device
-        M = self.micro_batches
-        uc, ic = torch.chunk(uid, M), torch.chunk(iid, M)
+        uc, ic, grouped = prep["uc"], prep["ic"], prep["grouped"]
         M = len(uc)
-        grouped = [(_Route.prepare(u, W, ops, self.dedup), _Route.prepare(i.reshape(-1), W, ops, self.dedup)) for u, i in zip(uc, ic)]
-        sends, recvs = _exchange_counts([g[0][1] for pair in grouped for g in pair], group)
+        sends, recvs = prep["counts"].get()
         routes = []
 
         def start(k):  # routes of chunk k, its rows requested (transfers may stay in flight)

@@ -75,12 +75,16 @@ def _worker(rank, world, port, opt, lr, l2, n_users, n_items, d, B, C, steps, ou
         I = rng.normal(0, 0.1, (n_items, d)).astype(np.float32)
         m = ShardedBprmf(n_users, n_items, d, opt=opt, lr=lr, l2=l2, ops=OracleOps(), mode=mode)
         m.load_global(torch.from_numpy(U), torch.from_numpy(I))
-        losses = []
+        losses, batches = [], []
         for s in range(steps):
             uid = rng.integers(0, n_users, size=(world, B)).astype(np.int64)
             iid = rng.integers(0, n_items, size=(world, B, C)).astype(np.int64)
             iid[:, :, 0] = iid[:, :, 0] % 7  # hot positives: duplicates across ranks and owners
-            loss = m.step(torch.from_numpy(uid[rank]), torch.from_numpy(iid[rank]))
+            batches.append((torch.from_numpy(uid[rank].copy()), torch.from_numpy(iid[rank].copy())))
+        for s in range(steps):
+            # odd steps route the following batch one step ahead (next_batch=), even ones on the spot: same result
+            nxt = batches[s + 1] if (s % 2 == 1 and s + 1 < steps) else None
+            loss = m.step(*batches[s], next_batch=nxt)
             losses.append(float(loss))
         Ug, Ig = m.gather_global()
         if rank == 0:
@@ -216,12 +220,15 @@ def _neumf_worker(rank, world, port, opt, lr, l2, n_users, n_items, d, l1, B, C,
         rng, P = _neumf_problem(n_users, n_items, d, l1)
         m = ShardedNeumf(n_users, n_items, d, l1, opt=opt, lr=lr, l2=l2, ops=NeumfOracleOps(), micro_batches=micro_batches)
         m.load_global({k: torch.from_numpy(v) for k, v in P.items()})
-        losses = []
+        losses, batches = [], []
         for s in range(steps):
             uid = rng.integers(0, n_users, size=(world, B)).astype(np.int64)
             iid = rng.integers(0, n_items, size=(world, B, C)).astype(np.int64)
             iid[:, :, 0] %= 5
-            losses.append(float(m.step(torch.from_numpy(uid[rank]), torch.from_numpy(iid[rank]))))
+            batches.append((torch.from_numpy(uid[rank].copy()), torch.from_numpy(iid[rank].copy())))
+        for s in range(steps):
+            nxt = batches[s + 1] if (s % 2 == 0 and s + 1 < steps) else None   # look-ahead routing on every other step
+            losses.append(float(m.step(*batches[s], next_batch=nxt)))
         G = m.gather_global()
         if rank == 0:
             out_q.put((losses, {k: v.numpy() for k, v in G.items()}))
