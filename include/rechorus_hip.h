@@ -399,6 +399,23 @@ int rc_neumf_bwd_dropout(const float* mf_u, const float* mf_i, const float* mlp_
                          float* g_mlp_u, float* g_mlp_i, float* dW1, float* db1, float* dw_out,
                          void* ws, size_t ws_bytes, rc_stream_t stream);
 
+/* ---- dense layers of the heads (csrc/mlp.hip): fp32 MFMA GEMMs ------------------------------------
+ * utils/layers.py:201-243 (MLP_Block: Linear -> ReLU -> Dropout per hidden layer + output Linear; the deep part of
+ * models/context/DeepFM.py:25 / WideDeep.py:42-47) and the NeuMF tower for any --layers
+ * (models/general/NeuMF.py:47-52, 69-72), with nn.Linear's autograd.  Replaces aten::addmm (rocBLAS) + relu + dropout.
+ *   rc_linear_fwd: Y [M, N] = drop(relu(X [M, K] W^T + b)); W [N, K] as nn.Linear.weight; b may be NULL; relu 0 / 1.
+ *     Dropout (training): element (m, n) is dropped iff word (m & 3) of Philox4x32-10(key = *seed_dev,
+ *     counter = (m >> 2, site * 65536 + n)) < drop_p * 2^32, kept values are scaled by 1 / (1 - drop_p); `site`
+ *     distinguishes the layers of one forward pass; the caller bumps *seed_dev once per step (rc_step_increment).
+ *   rc_linear_bwd: given the layer's saved OUTPUT Y (its own mask: dZ = dY * (Y > 0 ? 1/(1-p) : 0); NULL for a plain
+ *     Linear) -> dX [M, K] (NULL: skip), dW [N, K], db [N] (NULL: skip).  The batch reduction of dW / db is cut into
+ *     row ranges whose partial sums are combined in a fixed order (no float atomics).                            */
+int rc_linear_fwd(const float* X, const float* W, const float* b, int64_t M, int N, int K, int relu, float drop_p,
+                  const uint64_t* seed_dev, uint32_t site, float* Y, rc_stream_t stream);
+size_t rc_linear_bwd_workspace_bytes(int64_t M, int N, int K);
+int rc_linear_bwd(const float* X, const float* W, const float* Y, const float* dY, int64_t M, int N, int K,
+                  float drop_p, float* dX, float* dW, float* db, void* ws, size_t ws_bytes, rc_stream_t stream);
+
 /* ---- training-batch assembly on the device (csrc/sampler.hip) -------------------------------- */
 
 /* GeneralModel.Dataset.actions_before_epoch (models/BaseModel.py:206-214): neg[i,k] ~ uniform over

@@ -1,0 +1,321 @@
+// mlp.hip -- the dense layers of the ranking heads as hand-written fp32 MFMA GEMMs (v_mfma_f32_32x32x2_f32: exact
+// f32 FMA chains -- gfx950 has no TF32, and the 1e-5 parity bar rules out bf16).
+//
+// Reference: utils/layers.py:201-243 (MLP_Block: Linear -> ReLU -> Dropout per hidden layer, Linear output layer; the
+// deep part of models/context/DeepFM.py:25, WideDeep.py:42-47 at --layers [512,64]) and models/general/NeuMF.py:47-52,
+// 69-72 (the MLP tower `for layer in self.mlp: h = dropout(relu(layer(h)))` for any --layers) with the autograd of
+// nn.Linear.  Replaces aten::addmm / mm (rocBLAS) + relu + dropout + their backward kernels.
+//
+//   rc_linear_fwd   Y = drop(relu(X W^T + b))                    one GEMM, bias / ReLU / dropout in the epilogue
+//   rc_linear_bwd   dZ = dY * (Y > 0 ? 1/(1-p) : 0)               (elementwise; the saved output IS the mask)
+//                   dX = dZ W                                     GEMM
+//                   [dW | db] = dZ^T [X | 1]                      GEMM over the batch, split into row ranges whose
+//                                                                 partial sums are combined in a fixed order
+//
+// One kernel serves the three products: C[M x N] = A[M x K] B[K x N] with either operand stored reduction-major
+// or reduction-minor.  Tile 64 x 64 per workgroup (2 x 2 waves, one 32 x 32 MFMA block each), K step 32: the tiles are
+// staged in LDS reduction-major ([k][i], row stride 68), K step 32 (two 16-row loader passes), so an MFMA operand fetch is one conflict-free ds_read_b32
+// across the lanes; the next K step's global loads are in flight while the current one is multiplied.
+#include "common.hpp"
+#include "philox.hpp"
+
+namespace rc {
+
+typedef float mlp_f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kMlpBM = 64, kMlpBN = 64, kMlpBK = 32, kMlpLD = 68;   // (K step 16: 22.8 us per GEMM at B = 1024 -- one L2 round trip per 8 MFMAs)
+constexpr int kMlpSub = 16;   // k rows one pass of the loaders covers; a K step is kMlpBK / kMlpSub passes
+
+struct MlpOperand {
+  const float* p;
+  int64_t ld;       // elements between consecutive rows of the STORED matrix
+  int k_major;      // 1: stored [outer][k] (k contiguous);  0: stored [k][outer] (outer contiguous)
+};
+
+struct MlpGemm {
+  MlpOperand A, B;          // A(i, k), B(k, j)
+  int64_t M;
+  int N, K;                 // K: reduction length of ONE split
+  int ones_col;             // >= 0: B(k, ones_col) = 1 for every k (bias gradient rides along), columns beyond it 0
+  float* C;                 // [splits][M][ldc]
+  int64_t ldc;
+  int64_t split_stride_k;   // reduction offset between splits (blockIdx.z)
+  int64_t k_total;          // full reduction length (the last split may be short)
+  // epilogue
+  const float* bias;        // [N] or null
+  int relu;
+  const uint64_t* seed;     // dropout: device seed, null = off
+  uint32_t drop_thresh;
+  float keep_scale;
+  uint32_t site;
+};
+
+// dropout mask of element (m, n): dropped iff word (m & 3) of Philox4x32-10(key = seed, counter = (m >> 2, site * 65536 + n))
+// < p * 2^32 -- four consecutive rows share one Philox call, which is how an MFMA lane holds its accumulator rows
+__device__ __forceinline__ void mlp_keep4(const MlpGemm& g, uint64_t seed, int64_t m4, int n, float keep[4]) {
+  uint32_t w[4];
+  philox4x32_10(seed, (uint64_t)m4, g.site * 65536u + (uint32_t)n, w);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) keep[e] = w[e] < g.drop_thresh ? 0.f : g.keep_scale;
+}
+
+// global -> registers: this thread's float4 of the tile starting at (outer0, k0) of an operand
+__device__ __forceinline__ float4 mlp_load4(const MlpOperand& o, int64_t outer0, int64_t outer_n, int64_t k0, int64_t k_end,
+                                            int ones_col, bool vec_ok) {
+  const int t = threadIdx.x;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (o.k_major) {  // thread -> (outer = t / 4, k = 4 (t % 4) ..)
+    const int64_t i = outer0 + (t >> 2), k = k0 + 4 * (t & 3);
+    if (i < outer_n) {
+      const float* src = o.p + i * o.ld + k;
+      if (vec_ok && k + 3 < k_end) v = *reinterpret_cast<const float4*>(src);
+      else {
+        if (k < k_end) v.x = src[0];
+        if (k + 1 < k_end) v.y = src[1];
+        if (k + 2 < k_end) v.z = src[2];
+        if (k + 3 < k_end) v.w = src[3];
+      }
+    }
+  } else {          // thread -> (k = t / 16, outer = 4 (t % 16) ..)
+    const int64_t k = k0 + (t >> 4), i = outer0 + 4 * (t & 15);
+    if (k < k_end) {
+      const float* src = o.p + k * o.ld + i;
+      if (vec_ok && i + 3 < outer_n) v = *reinterpret_cast<const float4*>(src);
+      else {
+        if (i < outer_n) v.x = src[0];
+        if (i + 1 < outer_n) v.y = src[1];
+        if (i + 2 < outer_n) v.z = src[2];
+        if (i + 3 < outer_n) v.w = src[3];
+      }
+      if (ones_col >= 0) {  // the column of ones (and nothing beyond it)
+        if (i == ones_col) v.x = 1.f;
+        if (i + 1 == ones_col) v.y = 1.f;
+        if (i + 2 == ones_col) v.z = 1.f;
+        if (i + 3 == ones_col) v.w = 1.f;
+      }
+    }
+  }
+  return v;
+}
+
+// registers -> LDS tile [k][outer] (row stride kMlpLD)
+__device__ __forceinline__ void mlp_stage(float* tile, const MlpOperand& o, const float4& v) {
+  const int t = threadIdx.x;
+  if (o.k_major) {
+    const int i = t >> 2, k = 4 * (t & 3);
+    tile[(k + 0) * kMlpLD + i] = v.x;
+    tile[(k + 1) * kMlpLD + i] = v.y;
+    tile[(k + 2) * kMlpLD + i] = v.z;
+    tile[(k + 3) * kMlpLD + i] = v.w;
+  } else {
+    const int k = t >> 4, i = 4 * (t & 15);
+    *reinterpret_cast<float4*>(tile + k * kMlpLD + i) = v;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void mlp_gemm_kernel(MlpGemm g, int vec_a, int vec_b) {
+  __shared__ __attribute__((aligned(16))) float As[2][kMlpBK * kMlpLD];
+  __shared__ __attribute__((aligned(16))) float Bs[2][kMlpBK * kMlpLD];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wr = wave >> 1, wc = wave & 1;                     // this wave's 32 x 32 block of the 64 x 64 tile
+  const int64_t m0 = (int64_t)blockIdx.x * kMlpBM;
+  const int64_t n0 = (int64_t)blockIdx.y * kMlpBN;
+  const int64_t kb = (int64_t)blockIdx.z * g.split_stride_k;
+  const int64_t ke = (kb + g.K < g.k_total) ? kb + g.K : g.k_total;
+  // the B operand's "outer" extent: N real columns, + 1 when the ones column rides along
+  const int64_t bn = g.ones_col >= 0 ? (int64_t)g.ones_col : (int64_t)g.N;
+  mlp_f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+  constexpr int NP = kMlpBK / kMlpSub;   // loader passes per K step
+  float4 ra[NP], rb[NP];
+#pragma unroll
+  for (int q = 0; q < NP; ++q) {
+    ra[q] = mlp_load4(g.A, m0, g.M, kb + q * kMlpSub, ke, -1, vec_a != 0);
+    rb[q] = mlp_load4(g.B, n0, bn, kb + q * kMlpSub, ke, g.ones_col, vec_b != 0);
+  }
+  int buf = 0;
+#pragma unroll
+  for (int q = 0; q < NP; ++q) {
+    mlp_stage(As[0] + q * kMlpSub * kMlpLD, g.A, ra[q]);
+    mlp_stage(Bs[0] + q * kMlpSub * kMlpLD, g.B, rb[q]);
+  }
+  __syncthreads();
+  const int ai = wr * 32 + (lane & 31), bj = wc * 32 + (lane & 31), kh = lane >> 5;
+  for (int64_t k0 = kb; k0 < ke; k0 += kMlpBK) {
+    const bool more = k0 + kMlpBK < ke;
+    if (more) {  // next tiles travel while this one is multiplied
+#pragma unroll
+      for (int q = 0; q < NP; ++q) {
+        ra[q] = mlp_load4(g.A, m0, g.M, k0 + kMlpBK + q * kMlpSub, ke, -1, vec_a != 0);
+        rb[q] = mlp_load4(g.B, n0, bn, k0 + kMlpBK + q * kMlpSub, ke, g.ones_col, vec_b != 0);
+      }
+    }
+    const float* as = As[buf] + kh * kMlpLD + ai;
+    const float* bs = Bs[buf] + kh * kMlpLD + bj;
+    float av[kMlpBK / 2], bv[kMlpBK / 2];
+#pragma unroll
+    for (int t = 0; t < kMlpBK / 2; ++t) {
+      av[t] = as[2 * t * kMlpLD];
+      bv[t] = bs[2 * t * kMlpLD];
+    }
+#pragma unroll
+    for (int t = 0; t < kMlpBK / 2; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[t], acc, 0, 0, 0);
+    if (more) {
+#pragma unroll
+      for (int q = 0; q < NP; ++q) {
+        mlp_stage(As[buf ^ 1] + q * kMlpSub * kMlpLD, g.A, ra[q]);
+        mlp_stage(Bs[buf ^ 1] + q * kMlpSub * kMlpLD, g.B, rb[q]);
+      }
+    }
+    __syncthreads();
+    buf ^= 1;
+  }
+
+  // ---- epilogue: acc[r] is C(m0 + wr*32 + (r & 3) + 8 (r >> 2) + 4 kh, n0 + wc*32 + (lane & 31))
+  const int64_t j = n0 + wc * 32 + (lane & 31);
+  const int64_t ncols = g.ones_col >= 0 ? (int64_t)g.ones_col + 1 : (int64_t)g.N;
+  if (j >= ncols) return;
+  const float bj_ = (g.bias != nullptr && j < g.N) ? g.bias[j] : 0.f;
+  const uint64_t seed = g.seed ? *g.seed : 0;
+  float* C = g.C + (size_t)blockIdx.z * (size_t)g.M * (size_t)g.ldc;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int64_t mb = m0 + wr * 32 + 8 * q + 4 * kh;    // rows mb .. mb + 3 (mb is a multiple of 4)
+    float keep[4] = {1.f, 1.f, 1.f, 1.f};
+    if (g.seed && mb < g.M) mlp_keep4(g, seed, mb >> 2, (int)j, keep);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int64_t m = mb + e;
+      if (m >= g.M) continue;
+      float v = acc[4 * q + e] + bj_;
+      if (g.relu) v = fmaxf(v, 0.f);
+      if (g.seed) v *= keep[e];
+      C[m * g.ldc + j] = v;
+    }
+  }
+}
+
+// dZ = dY * (Y > 0 ? scale : 0): the saved output of drop(relu(.)) is its own mask
+__global__ __launch_bounds__(kBlock) void mlp_mask_kernel(const float* __restrict__ dY, const float* __restrict__ Y, int64_t n,
+                                                          float scale, float* __restrict__ dZ) {
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) dZ[i] = Y[i] > 0.f ? dY[i] * scale : 0.f;
+}
+
+// out[i] = sum_s part[s][i] in split order; rows of width ld_in = K + 1 -> dW [N, K] and db [N]
+__global__ __launch_bounds__(kBlock) void mlp_reduce_kernel(const float* __restrict__ part, int splits, int N, int K,
+                                                            float* __restrict__ dW, float* __restrict__ db) {
+  const int64_t total = (int64_t)N * (K + 1);
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+    float s = 0.f;
+    for (int q = 0; q < splits; ++q) s += part[(size_t)q * total + i];
+    const int n = (int)(i / (K + 1)), k = (int)(i % (K + 1));
+    if (k < K) dW[(size_t)n * K + k] = s;
+    else if (db != nullptr) db[n] = s;
+  }
+}
+
+static bool vec4_ok(const MlpOperand& o) { return reinterpret_cast<uintptr_t>(o.p) % 16 == 0 && o.ld % 4 == 0; }
+
+static int mlp_launch(const MlpGemm& g, int splits, hipStream_t s) {
+  const int64_t ncols = g.ones_col >= 0 ? (int64_t)g.ones_col + 1 : (int64_t)g.N;
+  dim3 grid((unsigned)((g.M + kMlpBM - 1) / kMlpBM), (unsigned)((ncols + kMlpBN - 1) / kMlpBN), (unsigned)splits);
+  hipLaunchKernelGGL(mlp_gemm_kernel, grid, dim3(kBlock), 0, s, g, vec4_ok(g.A) ? 1 : 0, vec4_ok(g.B) ? 1 : 0);
+  RC_LAUNCH_CHECK();
+  return RC_OK;
+}
+
+static int mlp_splits(int64_t M, int N, int K) {
+  const int64_t tiles = ((int64_t)(N + kMlpBM - 1) / kMlpBM) * ((K + 1 + kMlpBN - 1) / kMlpBN);
+  int64_t s = (1024 + tiles - 1) / tiles;              // ~4 workgroups per CU
+  const int64_t max_s = (M + 255) / 256;               // at least 256 batch rows per split
+  if (s > max_s) s = max_s;
+  if (s < 1) s = 1;
+  if (s > 64) s = 64;
+  return (int)s;
+}
+
+}  // namespace rc
+
+using namespace rc;
+
+extern "C" size_t rc_linear_bwd_workspace_bytes(int64_t M, int N, int K) {
+  if (M < 1 || N < 1 || K < 1) return 0;
+  const size_t dz = align_up((size_t)M * N * sizeof(float), 256);
+  const size_t part = align_up((size_t)mlp_splits(M, N, K) * (size_t)N * (size_t)(K + 1) * sizeof(float), 256);
+  return dz + part;
+}
+
+extern "C" int rc_linear_fwd(const float* X, const float* W, const float* b, int64_t M, int N, int K, int relu, float drop_p,
+                             const uint64_t* seed_dev, uint32_t site, float* Y, rc_stream_t stream) {
+  if (M == 0) return RC_OK;
+  RC_REQUIRE(X && W && Y, "rc_linear_fwd: null pointer");
+  RC_REQUIRE(M > 0 && N >= 1 && K >= 1 && N < 65536, "rc_linear_fwd: bad shape M=%lld N=%d K=%d", (long long)M, N, K);
+  RC_REQUIRE(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || seed_dev), "rc_linear_fwd: dropout p=%g needs p in [0, 1) and a device seed", (double)drop_p);
+  MlpGemm g;
+  memset(&g, 0, sizeof(g));
+  g.A = MlpOperand{X, K, 1};
+  g.B = MlpOperand{W, K, 1};
+  g.M = M; g.N = N; g.K = K; g.ones_col = -1; g.C = Y; g.ldc = N; g.split_stride_k = K; g.k_total = K;
+  g.bias = b; g.relu = relu ? 1 : 0; g.site = site;
+  if (drop_p > 0.f) {
+    g.seed = seed_dev;
+    g.drop_thresh = (uint32_t)((double)drop_p * 4294967296.0);
+    g.keep_scale = 1.0f / (1.0f - drop_p);
+  }
+  return mlp_launch(g, 1, as_stream(stream));
+}
+
+extern "C" int rc_linear_bwd(const float* X, const float* W, const float* Y, const float* dY, int64_t M, int N, int K,
+                             float drop_p, float* dX, float* dW, float* db, void* ws, size_t ws_bytes, rc_stream_t stream) {
+  RC_REQUIRE(X && W && dY && dW, "rc_linear_bwd: null pointer");
+  RC_REQUIRE(M >= 0 && N >= 1 && K >= 1, "rc_linear_bwd: bad shape M=%lld N=%d K=%d", (long long)M, N, K);
+  hipStream_t s = as_stream(stream);
+  if (M == 0) {
+    RC_HIP(hipMemsetAsync(dW, 0, (size_t)N * K * sizeof(float), s));
+    if (db) RC_HIP(hipMemsetAsync(db, 0, (size_t)N * sizeof(float), s));
+    return RC_OK;
+  }
+  RC_REQUIRE(ws != nullptr && ws_bytes >= rc_linear_bwd_workspace_bytes(M, N, K), "rc_linear_bwd: workspace %zu < %zu", ws_bytes,
+             rc_linear_bwd_workspace_bytes(M, N, K));
+  RC_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "rc_linear_bwd: dropout p=%g outside [0, 1)", (double)drop_p);
+  float* dz_buf = static_cast<float*>(ws);
+  float* part = reinterpret_cast<float*>(static_cast<char*>(ws) + align_up((size_t)M * N * sizeof(float), 256));
+  const float* dZ = dY;
+  if (Y != nullptr) {  // through drop(relu(.)): the saved output is the mask
+    const int64_t n = M * (int64_t)N;
+    int64_t blocks = (n + kBlock - 1) / kBlock;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(mlp_mask_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, s, dY, Y, n, 1.0f / (1.0f - drop_p), dz_buf);
+    RC_LAUNCH_CHECK();
+    dZ = dz_buf;
+  }
+  if (dX != nullptr) {  // dX[m, k] = sum_n dZ[m, n] W[n, k]
+    MlpGemm g;
+    memset(&g, 0, sizeof(g));
+    g.A = MlpOperand{dZ, N, 1};
+    g.B = MlpOperand{W, K, 0};
+    g.M = M; g.N = K; g.K = N; g.ones_col = -1; g.C = dX; g.ldc = K; g.split_stride_k = N; g.k_total = N;
+    RC_TRY(mlp_launch(g, 1, s));
+  }
+  {  // [dW | db][n, k] = sum_m dZ[m, n] [X | 1][m, k], the batch cut into splits
+    const int splits = mlp_splits(M, N, K);
+    int64_t per = (M + splits - 1) / splits;
+    per = (per + kMlpBK - 1) / kMlpBK * kMlpBK;
+    MlpGemm g;
+    memset(&g, 0, sizeof(g));
+    g.A = MlpOperand{dZ, N, 0};
+    g.B = MlpOperand{X, K, 0};
+    g.M = N; g.N = K; g.K = (int)per; g.ones_col = K; g.C = part; g.ldc = K + 1; g.split_stride_k = per; g.k_total = M;
+    const int used = (int)((M + per - 1) / per);
+    RC_TRY(mlp_launch(g, used, s));
+    const int64_t total = (int64_t)N * (K + 1);
+    int64_t blocks = (total + kBlock - 1) / kBlock;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(mlp_reduce_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, s, part, used, N, K, dW, db);
+    RC_LAUNCH_CHECK();
+  }
+  return RC_OK;
+}

@@ -598,6 +598,37 @@ class NeumfTrainer:
         return self.loss
 
 
+# ---- dense layers (csrc/mlp.hip) -------------------------------------------------------------------------
+
+def linear_fwd(X, W, b=None, relu=False, drop_p=0.0, seed=None, site=0):
+    """Y = drop(relu(X W^T + b)) on the fp32 MFMA GEMM (rc_linear_fwd); X [M, K], W [N, K] (nn.Linear.weight), b [N] | None.
+    drop_p > 0: training-mode dropout keyed by seed[0] (int64 [1] on the device) and the layer index `site`."""
+    f32 = torch.float32
+    M, K = X.shape
+    N = W.shape[0]
+    Y = torch.empty((M, N), dtype=f32, device=X.device)
+    _lib.call("rc_linear_fwd", _ptr(X, f32, "X"), _ptr(W, f32, "W"), _ptr(b, f32, "b", True), M, N, K, 1 if relu else 0,
+              *_drop_args(drop_p, seed), C.c_uint32(int(site)), _ptr(Y, f32, "Y"), _stream())
+    return Y
+
+
+def linear_bwd(X, W, Y, dY, drop_p=0.0, need_dx=True, need_db=True):
+    """backward of linear_fwd -> (dX | None, dW, db | None).  Y: the layer's saved output when it went through
+    relu (+ dropout) -- it is its own mask -- or None for a plain Linear."""
+    f32 = torch.float32
+    M, K = X.shape
+    N = W.shape[0]
+    dev = X.device
+    dX = torch.empty((M, K), dtype=f32, device=dev) if need_dx else None
+    dW = torch.empty((N, K), dtype=f32, device=dev)
+    db = torch.empty(N, dtype=f32, device=dev) if need_db else None
+    ws = workspace(_lib.load().rc_linear_bwd_workspace_bytes(M, N, K), dev, "linear_bwd")
+    _lib.call("rc_linear_bwd", _ptr(X, f32, "X"), _ptr(W, f32, "W"), _ptr(Y, f32, "Y", True), _ptr(dY, f32, "dY"), M, N, K,
+              C.c_float(float(drop_p)), _ptr(dX, f32, "dX", True), _ptr(dW, f32, "dW"), _ptr(db, f32, "db", True),
+              C.c_void_p(ws.data_ptr()), ws.numel(), _stream())
+    return dX, dW, db
+
+
 # ---- SASRec encoder ---------------------------------------------------------------------------------
 
 SAS_LAYER_KEYS = ("Wq", "bq", "Wk", "bk", "Wv", "bv", "ln1w", "ln1b", "W1", "b1", "W2", "b2", "ln2w", "ln2b")

@@ -322,6 +322,61 @@ def sasrec_encode(item_emb, pos_emb, blocks, n_heads, hist, lengths, drop_p=0.0,
     return _SasrecEncodeFn.apply(item_emb, pos_emb, n_heads, hist.contiguous(), lengths.contiguous(), float(drop_p), seed, *flat)
 
 
+class _LinearFn(torch.autograd.Function):
+    """drop(relu(x W^T + b)) as one fp32 MFMA GEMM with the epilogue fused (rc_linear_fwd); backward = mask + two GEMMs
+    (rc_linear_bwd).  The saved output is its own ReLU / dropout mask."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, relu, drop_p, seed, site):
+        xs = x.detach().reshape(-1, x.shape[-1]).contiguous()
+        Wd = W.detach().contiguous()
+        y = engine.linear_fwd(xs, Wd, None if b is None else b.detach().contiguous(), relu, drop_p, seed, site)
+        ctx.save_for_backward(xs, Wd, y if (relu or drop_p > 0) else None)
+        ctx.drop_p, ctx.has_b, ctx.xshape = float(drop_p), b is not None, x.shape
+        ctx.need_dx = x.requires_grad
+        return y.view(*x.shape[:-1], W.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        xs, Wd, y = ctx.saved_tensors
+        dyf = dy.reshape(-1, dy.shape[-1]).contiguous()
+        dX, dW, db = engine.linear_bwd(xs, Wd, y, dyf, ctx.drop_p, need_dx=ctx.need_dx, need_db=ctx.has_b)
+        return (dX.view(ctx.xshape) if dX is not None else None), dW, db, None, None, None, None
+
+
+def linear(x, W, b=None, relu=False, drop_p=0.0, seed=None, site=0):
+    """nn.Linear (+ ReLU + training-mode dropout) on the HIP engine; x [..., K]"""
+    if not x.is_cuda:
+        raise RuntimeError("linear runs on the GPU only (no CPU path)")
+    return _LinearFn.apply(x, W, b, bool(relu), float(drop_p), seed, int(site))
+
+
+def mlp_plan(modules):
+    """[(nn.Linear, relu?, dropout p)] when `modules` (an nn.Sequential's children) is a chain of Linear [-> ReLU] [-> Dropout]
+    groups -- what MLP_Block builds without norms / Dice -- else None (the caller keeps torch's modules)"""
+    plan, i, mods = [], 0, list(modules)
+    while i < len(mods):
+        if type(mods[i]) is not nn.Linear:
+            return None
+        lin, relu, p = mods[i], False, 0.0
+        i += 1
+        if i < len(mods) and type(mods[i]) is nn.ReLU:
+            relu, i = True, i + 1
+        if i < len(mods) and type(mods[i]) is nn.Dropout:
+            if not relu:
+                return None  # the kernels' mask is the saved output: dropout without ReLU would lose the sign information
+            p, i = float(mods[i].p), i + 1
+        plan.append((lin, relu, p))
+    return plan or None
+
+
+def mlp_forward(x, plan, training, seed):
+    """run a mlp_plan: one rc_linear_fwd per layer (dropout only in training mode; `seed` bumped by the caller)"""
+    for site, (lin, relu, p) in enumerate(plan):
+        x = linear(x, lin.weight, lin.bias, relu, p if training else 0.0, seed, site)
+    return x
+
+
 class HipOptimizer:
     """torch.optim.{SGD,Adam,Adagrad,Adadelta} semantics (dense, weight decay per param group) executed by
     rc_dense_update.  Built by the runner in place of `eval('torch.optim.X')`

@@ -68,12 +68,18 @@ class NeuMF(GeneralModel):
                                     self.mlp[0].weight, self.mlp[0].bias, self.prediction.weight, u_ids, i_ids,
                                     p, self.drop_seed if p > 0 else None)
             return {'prediction': pred.view(feed_dict['batch_size'], -1)}
+        # any other tower (--layers '[64,32]', sizes outside {32, 64, 128}): table lookups on HipEmbedding, every
+        # Linear -> ReLU -> Dropout of the loop at reference :69-72 and the prediction layer as fp32 MFMA GEMMs with
+        # the epilogue fused (rc_linear_fwd / rc_linear_bwd); torch only concatenates
         u_rep = u_ids.unsqueeze(-1).repeat((1, i_ids.shape[1]))
         mf = self.mf_u_embeddings(u_rep) * self.mf_i_embeddings(i_ids)
         h = torch.cat([self.mlp_u_embeddings(u_rep), self.mlp_i_embeddings(i_ids)], dim=-1)
-        for layer in self.mlp:
-            h = self.dropout_layer(layer(h).relu())
-        pred = self.prediction(torch.cat([mf, h], dim=-1))
+        p = self._drop_p()
+        if p > 0:
+            engine.step_increment(self.drop_seed)
+        for k, layer in enumerate(self.mlp):
+            h = hnn.linear(h, layer.weight, layer.bias, relu=True, drop_p=p, seed=self.drop_seed if p > 0 else None, site=k)
+        pred = hnn.linear(torch.cat([mf, h], dim=-1), self.prediction.weight, None)
         return {'prediction': pred.view(feed_dict['batch_size'], -1)}
 
     # ---- large-table mode: row-wise update of the four tables, no dense [n_rows, d] gradient -----------

@@ -10,6 +10,8 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from rechorus_amd import engine, nn as hnn
+
 
 class MultiHeadAttention(nn.Module):
     def __init__(self, d_model, n_heads, kq_same=False, bias=True, attention_d=-1):
@@ -115,6 +117,18 @@ class MLP_Block(nn.Module):
         if output_activation is not None:
             mods.append(getattr(nn, output_activation)())
         self.mlp = nn.Sequential(*mods)
+        # Linear [-> ReLU] [-> Dropout] chains (every MLP_Block the context models build) run on the engine's fp32 MFMA
+        # GEMMs with bias / ReLU / dropout fused into the epilogue (rc_linear_fwd / rc_linear_bwd); the parameters stay
+        # in `self.mlp` (state_dict keys `mlp.<k>.weight` unchanged).  Norm layers / Dice keep torch's modules.
+        self._hip_plan = hnn.mlp_plan(mods)
+        if self._hip_plan is not None and any(p > 0 for _, _, p in self._hip_plan):
+            # key of the dropout mask stream; not a parameter and not in the state_dict
+            self.register_buffer('drop_seed', torch.randint(0, 2 ** 62, (1,), dtype=torch.int64), persistent=False)
 
     def forward(self, inputs):
+        if self._hip_plan is not None and inputs.is_cuda and inputs.dtype == torch.float32:
+            seed = getattr(self, 'drop_seed', None)
+            if self.training and seed is not None:
+                engine.step_increment(seed)  # new mask for this forward; its backward reads the saved outputs
+            return hnn.mlp_forward(inputs, self._hip_plan, self.training, seed)
         return self.mlp(inputs)

@@ -132,13 +132,23 @@ CASES = [
     ("neumf_d64_l64_k99", 20, 300, 64, [64], 5, 99, 24),
 ]
 
+# towers with several hidden layers (--layers '[64,32]' ...): the mirror runs them on rc_linear_fwd / rc_linear_bwd
+ML_CASES = [
+    ("neumfml_d32_l64x32_k4", 25, 80, 32, [64, 32], 36, 4, 41),
+    ("neumfml_d64_l128x64x32_k9", 20, 70, 64, [128, 64, 32], 20, 9, 42),
+]
+
 DROPOUT_CASES = [
     ("neumfdrop_d64_l64_k4_p0.2", 30, 90, 64, 64, 40, 4, 0.2, 31),
     ("neumfdrop_d32_l128_k9_p0.5", 20, 60, 32, 128, 16, 9, 0.5, 32),
 ]
 
 if __name__ == "__main__":
-    for c in CASES:
+    if "--ml-only" in sys.argv:
+        for c in ML_CASES:
+            make_case(*c)
+        sys.exit(0)
+    for c in CASES + ML_CASES:
         make_case(*c)
     for c in DROPOUT_CASES:
         make_dropout_case(*c)

@@ -151,7 +151,8 @@ def _load_state(model, g, cuda):
     return model.to(cuda)
 
 
-@pytest.mark.parametrize("case", ["neumf_d64_l64_k4", "neumf_d128_l64_k4", "neumf_d32_l32_k9"])
+@pytest.mark.parametrize("case", ["neumf_d64_l64_k4", "neumf_d128_l64_k4", "neumf_d32_l32_k9",
+                                  "neumfml_d32_l64x32_k4", "neumfml_d64_l128x64x32_k9"])  # ml: --layers with several entries
 def test_neumf_model_file_matches_reference(case, cuda):
     from models.general.NeuMF import NeuMF
     g = load_golden(case)

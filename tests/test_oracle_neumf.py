@@ -9,13 +9,14 @@ from oracle import bprmf_oracle as BO
 from oracle import neumf_oracle as NO
 
 CASES = sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.startswith("neumf_") and f.endswith(".npz"))
+ML_CASES = sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.startswith("neumfml_") and f.endswith(".npz"))  # several hidden layers
 
 
 def params(g, prefix="P0/"):
     return {k[len(prefix):]: v for k, v in g.items() if k.startswith(prefix)}
 
 
-@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("case", CASES + ML_CASES)
 def test_neumf_forward_loss_grads(case):
     g = load_golden(case)
     P = params(g)
