@@ -25,31 +25,40 @@ class BaseReader(object):
         self._read_data()
         self._build_clicked_sets()
 
-    def _read_data(self):
-        logging.info('Reading data from "{}", dataset = "{}" '.format(self.prefix, self.dataset))
-        self.data_df = {}
-        for phase in ('train', 'dev', 'test'):
-            path = os.path.join(self.prefix, self.dataset, phase + '.csv')
-            df = pd.read_csv(path, sep=self.sep).reset_index(drop=True).sort_values(by=['user_id', 'time'])
-            self.data_df[phase] = utils.eval_list_columns(df)
+    PHASES = ('train', 'dev', 'test')
 
+    def _load_phase(self, phase):
+        """<path>/<dataset>/<phase>.csv -> DataFrame ordered by (user, time), list-valued columns parsed"""
+        frame = pd.read_csv(os.path.join(self.prefix, self.dataset, phase + '.csv'), sep=self.sep)
+        frame = frame.reset_index(drop=True).sort_values(by=['user_id', 'time'])
+        return utils.eval_list_columns(frame)
+
+    def _read_data(self):
+        """Attributes the plugin surface promises (reference helpers/BaseReader.py:24-65): data_df[phase], all_df
+        (the interaction columns of all phases), n_users / n_items = max id + 1 (ids start at 1; row 0 of every table
+        is the padding row, still a trainable row)."""
+        logging.info('Reading data from "{}", dataset = "{}" '.format(self.prefix, self.dataset))
+        self.data_df = {phase: self._load_phase(phase) for phase in self.PHASES}
         logging.info('Counting dataset statistics...')
-        cols = ['user_id', 'item_id', 'time']
-        if 'label' in self.data_df['train'].columns:  # CTR data carries labels
-            cols.append('label')
-        self.all_df = pd.concat([self.data_df[p][cols] for p in ('train', 'dev', 'test')])
-        # ids start at 1; row 0 of every table is the padding row (still a trainable row)
+        labelled = 'label' in self.data_df['train'].columns   # CTR data
+        wanted = ['user_id', 'item_id', 'time'] + (['label'] if labelled else [])
+        self.all_df = pd.concat([self.data_df[phase][wanted] for phase in self.PHASES])
         self.n_users = int(self.all_df['user_id'].max()) + 1
         self.n_items = int(self.all_df['item_id'].max()) + 1
+        self._check_stored_negatives()
+        logging.info('"# user": {}, "# item": {}, "# entry": {}'.format(self.n_users - 1, self.n_items - 1, len(self.all_df)))
+        if labelled:
+            n_pos = int((self.all_df.label == 1).sum())
+            logging.info('"# positive interaction": {} ({:.1f}%)'.format(n_pos, 100.0 * n_pos / len(self.all_df)))
+
+    def _check_stored_negatives(self):
+        """dev / test rows carry their evaluation negatives: every one of them has to be a known item"""
         for phase in ('dev', 'test'):
-            if 'neg_items' in self.data_df[phase]:
-                negs = np.array(self.data_df[phase]['neg_items'].tolist())
-                assert (negs >= self.n_items).sum() == 0, 'negative items must be known items'
-        logging.info('"# user": {}, "# item": {}, "# entry": {}'.format(
-            self.n_users - 1, self.n_items - 1, len(self.all_df)))
-        if 'label' in cols:
-            pos = int((self.all_df.label == 1).sum())
-            logging.info('"# positive interaction": {} ({:.1f}%)'.format(pos, 100.0 * pos / len(self.all_df)))
+            frame = self.data_df[phase]
+            if 'neg_items' not in frame:
+                continue
+            worst = max((max(row) for row in frame['neg_items'] if len(row)), default=0)
+            assert worst < self.n_items, 'negative items must be known items ({} >= {} in {})'.format(worst, self.n_items, phase)
 
     def _build_clicked_sets(self):
         """per user: items clicked in train, and in dev/test ("residual")"""

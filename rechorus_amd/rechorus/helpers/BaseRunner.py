@@ -140,50 +140,73 @@ class BaseRunner(object):
                          'l2 > 0)' if mode else '')
         return mode
 
+    # ---- the epoch loop (reference contract: helpers/BaseRunner.py:116-172) ---------------------------------------
+    # Observable behaviour kept: one log line per epoch in the format exp.py scrapes, the checkpoint written whenever
+    # the dev metric reaches a new maximum (or the model is in `stage` 1), early stopping on the dev history, NaN loss
+    # ends training, Ctrl-C offers to skip the final evaluation, the best checkpoint is loaded at the end.  The loop is
+    # organised around a small record of the dev history instead of the reference's inline bookkeeping.
+    class _DevHistory:
+        def __init__(self, metric):
+            self.metric, self.results = metric, []
+
+        def add(self, result):
+            self.results.append(result)
+            return self.is_best()
+
+        @property
+        def curve(self):
+            return [r[self.metric] for r in self.results]
+
+        def is_best(self):
+            c = self.curve
+            return c[-1] == max(c)
+
+        def best_index(self):
+            c = self.curve
+            return c.index(max(c))
+
+    def _epoch(self, number, model, data_dict, history):
+        """one epoch: fit, dev (and periodic test) evaluation, checkpoint; -> False when training has to stop"""
+        self._check_time()
+        gc.collect()
+        loss = self.fit(data_dict['train'], epoch=number)
+        if np.isnan(loss):
+            logging.info('Loss is Nan. Stop training at %d.' % number)
+            return False
+        fit_seconds = self._check_time()
+        if self.check_epoch > 0 and (number - 1) % self.check_epoch == 0 and len(model.check_list) > 0:
+            utils.check(model.check_list)
+        dev = self.evaluate(data_dict['dev'], [self.main_topk], self.metrics)
+        improved = history.add(dev)
+        parts = ['Epoch {:<5} loss={:<.4f} [{:<3.1f} s]\tdev=({})'.format(number, loss, fit_seconds, utils.format_metric(dev))]
+        if self.test_epoch > 0 and (number - 1) % self.test_epoch == 0:
+            parts.append(' test=({})'.format(utils.format_metric(self.evaluate(data_dict['test'], self.topk[:1], self.metrics))))
+        parts.append(' [{:<.1f} s]'.format(self._check_time()))
+        if improved or getattr(model, 'stage', None) == 1:
+            model.save_model()
+            parts.append(' *')
+        logging.info(''.join(parts))
+        if self.early_stop > 0 and self.eval_termination(history.curve):
+            logging.info('Early stop at %d based on dev result.' % number)
+            return False
+        return True
+
     def train(self, data_dict: Dict[str, BaseModel.Dataset]):
         model = data_dict['train'].model
-        main_results, dev_results = list(), list()
+        history = self._DevHistory(self.main_metric)
         self._check_time(start=True)
         try:
-            for epoch in range(self.epoch):
-                self._check_time()
-                gc.collect()
-                loss = self.fit(data_dict['train'], epoch=epoch + 1)
-                if np.isnan(loss):
-                    logging.info('Loss is Nan. Stop training at %d.' % (epoch + 1))
-                    break
-                training_time = self._check_time()
-
-                if len(model.check_list) > 0 and self.check_epoch > 0 and epoch % self.check_epoch == 0:
-                    utils.check(model.check_list)
-
-                dev_result = self.evaluate(data_dict['dev'], [self.main_topk], self.metrics)
-                dev_results.append(dev_result)
-                main_results.append(dev_result[self.main_metric])
-                log = 'Epoch {:<5} loss={:<.4f} [{:<3.1f} s]\tdev=({})'.format(
-                    epoch + 1, loss, training_time, utils.format_metric(dev_result))
-                if self.test_epoch > 0 and epoch % self.test_epoch == 0:
-                    test_result = self.evaluate(data_dict['test'], self.topk[:1], self.metrics)
-                    log += ' test=({})'.format(utils.format_metric(test_result))
-                log += ' [{:<.1f} s]'.format(self._check_time())
-
-                if max(main_results) == main_results[-1] or (hasattr(model, 'stage') and model.stage == 1):
-                    model.save_model()
-                    log += ' *'
-                logging.info(log)
-
-                if self.early_stop > 0 and self.eval_termination(main_results):
-                    logging.info('Early stop at %d based on dev result.' % (epoch + 1))
-                    break
+            number = 1
+            while number <= self.epoch and self._epoch(number, model, data_dict, history):
+                number += 1
         except KeyboardInterrupt:
             logging.info('Early stop manually')
             if input('Exit completely without evaluation? (y/n) (default n):').lower().startswith('y'):
                 logging.info(os.linesep + '-' * 45 + ' END: ' + utils.get_time() + ' ' + '-' * 45)
                 exit(1)
-
-        best = main_results.index(max(main_results))
+        best = history.best_index()
         logging.info(os.linesep + 'Best Iter(dev)={:>5}\t dev=({}) [{:<.1f} s] '.format(
-            best + 1, utils.format_metric(dev_results[best]), self.time[1] - self.time[0]))
+            best + 1, utils.format_metric(history.results[best]), self.time[1] - self.time[0]))
         model.load_model()
 
     def _on_device(self, dataset) -> bool:
