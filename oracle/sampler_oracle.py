@@ -67,6 +67,19 @@ def sample_negatives(users, K, n_items, clicked_ptr=None, clicked_items=None, se
         bad = np.array([_contains(clicked_items, clicked_ptr[uu], clicked_ptr[uu + 1], c) for uu, c in zip(u, cand)],
                        dtype=bool)
         pending = pending[bad]
+    else:
+        # attempts exhausted (the user clicked nearly everything): the r-th non-clicked id, r from a fresh Philox block
+        if clicked_ptr is not None and len(pending):
+            w = _draw(seed, np.uint64(base_index) + pending.astype(np.uint64), MAX_ATTEMPTS >> 1)[0]
+            for e, we in zip(pending, w):
+                uu = users[e // K]
+                cl = np.asarray(clicked_items[clicked_ptr[uu]:clicked_ptr[uu + 1]], dtype=np.int64)
+                free = (n_items - 1) - len(cl)
+                if free <= 0:
+                    continue
+                rank = int(_mulhi64(np.array([we], dtype=np.uint64), free)[0])
+                j = int(np.searchsorted(cl - 1 - np.arange(len(cl)), rank, side="right"))  # smallest j with c_j - 1 - j > rank
+                neg[e] = rank + 1 + j
     return neg.reshape(n, K)
 
 

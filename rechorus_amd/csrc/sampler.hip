@@ -40,14 +40,33 @@ __global__ __launch_bounds__(kBlock) void sample_negatives_kernel(
     const int64_t u = users[e / K];
     const int64_t lo = clicked_ptr ? clicked_ptr[u] : 0, hi = clicked_ptr ? clicked_ptr[u + 1] : 0;
     int64_t cand = 1;
-    for (int attempt = 0; attempt < kMaxAttempts; attempt += 2) {
+    bool found = false;
+    for (int attempt = 0; attempt < kMaxAttempts && !found; attempt += 2) {
       uint32_t r[4];
       philox4x32_10(seed, base_index + (uint64_t)e, (uint32_t)(attempt >> 1), r);
       const uint64_t w0 = ((uint64_t)r[1] << 32) | r[0], w1 = ((uint64_t)r[3] << 32) | r[2];
       cand = 1 + (int64_t)__umul64hi(w0, range);
-      if (!contains_sorted(clicked_items, lo, hi, cand)) break;
+      found = !contains_sorted(clicked_items, lo, hi, cand);
+      if (found) break;
       cand = 1 + (int64_t)__umul64hi(w1, range);
-      if (!contains_sorted(clicked_items, lo, hi, cand)) break;
+      found = !contains_sorted(clicked_items, lo, hi, cand);
+    }
+    if (!found) {
+      // The user clicked (nearly) the whole catalogue: the reference's `while neg in clicked` loop (models/BaseModel.py:
+      // 209-210) would keep drawing; here the r-th NON-clicked id is selected directly, r uniform -- the same
+      // distribution, no loop.  Non-clicked ids before the j-th clicked id c_j (sorted, distinct, >= 1): c_j - 1 - j.
+      const int64_t nc = hi - lo, free_ids = (n_items - 1) - nc;
+      if (free_ids > 0) {
+        uint32_t r[4];
+        philox4x32_10(seed, base_index + (uint64_t)e, (uint32_t)(kMaxAttempts >> 1), r);
+        const int64_t rank = (int64_t)__umul64hi(((uint64_t)r[1] << 32) | r[0], (uint64_t)free_ids);
+        int64_t a = 0, b = nc;  // smallest j with clicked[j] - 1 - j > rank (nc if none)
+        while (a < b) {
+          const int64_t mid = a + ((b - a) >> 1);
+          if (clicked_items[lo + mid] - 1 - mid > rank) b = mid; else a = mid + 1;
+        }
+        cand = rank + 1 + a;
+      }  // (a user who clicked EVERY item keeps the last draw: there is nothing else to return)
     }
     neg[e] = cand;
   }

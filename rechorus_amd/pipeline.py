@@ -171,7 +171,16 @@ class DeviceDataset:
         def col(name):
             return torch.from_numpy(np.asarray(dataset.data[name], dtype=np.int64)).to(device)
 
-        self.users, self.items = col('user_id'), col('item_id')
+        def ids(name, n_rows):
+            """an id column, range-checked once on the host: the kernels index tables with these ids unchecked (nn.Embedding
+            would raise a device assert), e.g. after a stale corpus pickle that does not match the model"""
+            a = np.asarray(dataset.data[name], dtype=np.int64)
+            if a.size and (a.min() < 0 or a.max() >= n_rows):
+                raise ValueError('{} of the {} set outside [0, {}): min {}, max {} (does the corpus match the dataset? '
+                                 'try --regenerate 1)'.format(name, dataset.phase, n_rows, int(a.min()), int(a.max())))
+            return torch.from_numpy(a).to(device)
+
+        self.users, self.items = ids('user_id', corpus.n_users), ids('item_id', corpus.n_items)
         self.kind = dataset_kind(dataset)
         self.sequential = self.kind == 'sequential'
         self.labels = col('label') if self.kind == 'ctr' else None
@@ -200,7 +209,10 @@ class DeviceDataset:
         self.neg = None
         self.test_all = bool(getattr(model, 'test_all', 0)) and not self.train
         if not self.train and not self.test_all and self.kind != 'ctr' and not self.impression:
-            self.neg = torch.from_numpy(np.asarray(dataset.data['neg_items'], dtype=np.int64)).to(device).contiguous()
+            negs = np.asarray(dataset.data['neg_items'], dtype=np.int64)
+            if negs.size and (negs.min() < 0 or negs.max() >= corpus.n_items):
+                raise ValueError('neg_items of the {} set outside [0, {})'.format(dataset.phase, corpus.n_items))
+            self.neg = torch.from_numpy(negs).to(device).contiguous()
         self._draws = 0
 
     def __len__(self):

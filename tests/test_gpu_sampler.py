@@ -36,6 +36,20 @@ def test_sample_negatives_bit_exact(K, cuda, eng):
     assert eng.sample_negatives(dev(users[:0], cuda), K, n_items, seed=3).shape == (0, K)
 
 
+def test_sample_negatives_exhausted_attempts_bit_exact(cuda, eng):
+    """users who clicked (nearly) the whole catalogue: the direct selection after 1,024 rejected draws, bit for bit"""
+    n_items, free = 3001, {17, 2999}
+    clicked = np.array([i for i in range(1, n_items) if i not in free], dtype=np.int64)
+    everything = np.arange(1, n_items, dtype=np.int64)
+    ptr = np.array([0, len(clicked), len(clicked) + len(everything), len(clicked) + len(everything) + 3], dtype=np.int64)
+    items = np.concatenate([clicked, everything, np.array([5, 6, 7], dtype=np.int64)])
+    users = np.array([0, 2, 0, 1, 2, 0], dtype=np.int64)
+    got = eng.sample_negatives(dev(users, cuda), 16, n_items, dev(ptr, cuda), dev(items, cuda), seed=5, base_index=77).cpu().numpy()
+    want = S.sample_negatives(users, 16, n_items, ptr, items, seed=5, base_index=77)
+    assert np.array_equal(got, want)
+    assert set(np.unique(got[users == 0])) == free and not np.isin(got[users == 2], [5, 6, 7]).any()
+
+
 def test_sample_negatives_full_size_properties(cuda, eng):
     """config-2 scale: 65,536 rows x 99 negatives over 10 M items; uniformity, range, exclusion"""
     n_users, n_items, n, K = 100_000, 10_000_001, 65_536, 99

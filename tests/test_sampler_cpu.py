@@ -90,3 +90,20 @@ def test_full_catalogue_rank_masks_clicked_columns():
         s = I.astype(np.float64) @ Uv[r].astype(np.float64)
         others = [j for j in range(1, n_items) if j not in clicked[users[r]]]
         assert got[r] == 1 + sum(s[j] >= s[targets[r]] for j in others)
+
+
+def test_sampler_exhausted_attempts_select_a_non_clicked_item_directly():
+    """a user who clicked all but two items of a 3,000-item catalogue: most elements use up their 1,024 rejection
+    attempts; the r-th non-clicked id is then selected directly (the reference's loop would keep drawing until it hits
+    one, models/BaseModel.py:209-210) -- never a clicked item, both free ids reachable; a user who clicked everything
+    keeps a (clicked) draw instead of hanging"""
+    from oracle import sampler_oracle as S
+    n_items, free = 3001, {17, 2999}
+    clicked = np.array([i for i in range(1, n_items) if i not in free], dtype=np.int64)
+    everything = np.arange(1, n_items, dtype=np.int64)
+    ptr = np.array([0, len(clicked), len(clicked) + len(everything)], dtype=np.int64)
+    items = np.concatenate([clicked, everything])
+    neg = S.sample_negatives(np.zeros(4, dtype=np.int64), 16, n_items, ptr, items, seed=5)
+    assert set(np.unique(neg)) == free
+    neg_all = S.sample_negatives(np.ones(1, dtype=np.int64), 2, n_items, ptr, items, seed=5)
+    assert neg_all.min() >= 1 and neg_all.max() < n_items
