@@ -221,7 +221,7 @@ class DeepfmBench:
 
 
 def deepfm_roofline(args, trainer, batches, engine):
-    """MLP_Block GEMMs (rocBLAS fp32) against the fp32 MFMA peak, over the eager forward + backward phases"""
+    """MLP_Block GEMMs (csrc/mlp.hip, fp32 MFMA) against the fp32 MFMA peak, over the eager forward + backward phases"""
     trainer.timing = {}
     for s in range(10):
         trainer.step(*batches[s % len(batches)])
@@ -233,7 +233,7 @@ def deepfm_roofline(args, trainer, batches, engine):
     t = ph["forward"] + ph["backward"]
     ach = 3.0 * fwd / (t * 1e-3) / 1e12
     return {"phases_ms": {k: round(v, 4) for k, v in ph.items()},
-            "roofline": {"bound": "mfma", "kernel": "MLP_Block forward + backward (rocBLAS fp32 GEMMs; eager phases incl. the field "
+            "roofline": {"bound": "mfma", "kernel": "MLP_Block forward + backward (rc_linear_fwd / rc_linear_bwd, hand-written fp32 MFMA GEMMs; eager phases incl. the field "
                          "gathers, FM term and their backward)", "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / F32_MFMA_PEAK_TFLOPS, "traffic": None, "algorithmic_flops_per_launch": 3.0 * fwd, "avg_ms": t}}
 

@@ -4,7 +4,7 @@ Counterpart of the reference's models/context/WideDeep.py (same class / flag / s
     python main.py --model_name WideDeep --model_mode CTR --emb_size 64 --layers '[64,64]' --loss_n BCE \
         --dataset MIND_Large/MINDCTR --include_item_features 1 --include_situation_features 1
 wide part = FM's first-order term (the [vocab, 1] tables, one rc_gather_fields launch), deep part =
-MLP_Block over the flattened field vectors (a second rc_gather_fields launch feeding rocBLAS GEMMs).
+MLP_Block over the flattened field vectors (a second rc_gather_fields launch feeding the fp32 MFMA GEMMs of csrc/mlp.hip: rc_linear_fwd / rc_linear_bwd).
 """
 from models.BaseContextModel import ContextCTRModel, ContextModel
 from models.BaseModel import task_variant
