@@ -31,6 +31,7 @@ With W = 1 every collective is the identity and the arithmetic equals engine.Bpr
 Local arithmetic goes through an `ops` object: `HipOps` (the C ABI, default) on GPUs; the CPU tests
 inject an oracle-backed implementation so the routing can be verified with gloo, world_size 2.
 """
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -342,12 +343,74 @@ def _group_by_owner(ids, world):
     return order, counts
 
 
-class ShardedBprmf:
+def _record_stream(obj, stream):
+    """tensors of a prepared-routes structure were allocated on the side stream and are consumed on `stream`"""
+    if torch.is_tensor(obj):
+        if obj.is_cuda:
+            obj.record_stream(stream)
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            _record_stream(v, stream)
+    elif isinstance(obj, (list, tuple)):
+        for v in obj:
+            _record_stream(v, stream)
+
+
+class _LookAhead:
+    """Shared by the sharded steps: `step(batch, next_batch=...)` routes the NEXT batch before this step's kernels.
+    The routing needs host-visible sizes (torch.unique, the split sizes of the exchanges); on the caller's stream
+    those device -> host copies would wait for everything enqueued before them, i.e. for the previous step.  So the
+    look-ahead runs on a SIDE stream that depends only on the start of the previous step (the next batch's ids must
+    exist by then: pooled batches, or a loader running at least one step ahead): its host waits are a few small
+    kernels long, and the caller's stream picks the prepared routes up through an event."""
+
+    def _routes_of(self, uid, iid, next_batch):
+        ahead, self._ahead = getattr(self, "_ahead", None), None
+        key = (uid.data_ptr(), iid.data_ptr(), tuple(iid.shape))
+        if ahead is not None and ahead["key"] == key:
+            prep = ahead
+            if prep.get("ready") is not None:
+                main = torch.cuda.current_stream(uid.device)
+                main.wait_event(prep["ready"])
+                _record_stream(prep, main)
+        else:
+            prep = self._prepare(uid, iid)
+        if next_batch is not None and self.world > 1:
+            self._ahead = self._prepare_ahead(*next_batch)
+        return prep
+
+    def _prepare_ahead(self, uid, iid):
+        if not uid.is_cuda:
+            return self._prepare(uid, iid)
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=uid.device)
+        begin = getattr(self, "_step_begin", None)
+        if begin is not None:
+            self._side.wait_event(begin)
+        with torch.cuda.stream(self._side):
+            prep = self._prepare(uid, iid)
+            done = torch.cuda.Event()
+            done.record(self._side)
+        prep["ready"] = done
+        return prep
+
+    def _mark_step_begin(self, ref):
+        if ref.is_cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(ref.device))
+            self._step_begin = ev
+
+
+class ShardedBprmf(_LookAhead):
     def __init__(self, n_users, n_items, emb_size, opt="SGD", lr=1e-3, l2=0.0, device=None, ops=None,
-                 group=None, init_std=0.01, seed=0, force_exchange=False, timing=False, mode="auto"):
+                 group=None, init_std=0.01, seed=0, force_exchange=False, timing=False, mode="auto", dedup_users=True):
         if mode not in ("auto", "owner", "rows"):
             raise ValueError("ShardedBprmf mode must be auto | owner | rows, got {!r}".format(mode))
         self.mode = mode
+        # owner plan: only the DISTINCT user rows of a rank's batch travel (fetch, all_gather, gradient reduction); under
+        # Zipf users 27 K of 65 K at the bench shape, i.e. 58 % less on the two largest transfers of the step
+        self.dedup_users = bool(dedup_users)
+        self.wire = None   # bytes over the links of the last owner-plan step (this rank)
         self.group = group
         self.force_exchange = force_exchange  # W = 1 through the general path (loop-back profiling)
         self.timing = [] if timing else None   # [(label, cuda event)] of the last step
@@ -395,18 +458,18 @@ class ShardedBprmf:
         """group the batch's ids by owner for the plan of this shape and START the exchange of the split sizes"""
         B, C = iid.shape
         plan = self._plan(C)
-        ru = self._route(uid)
+        inv = None
+        counts = []
+        if plan == "owner" and self.dedup_users:
+            uniq, inv = torch.unique(uid, return_inverse=True)   # sorted distinct users of this rank's batch
+            ru = self._route(uniq)
+            # every rank needs every rank's number of distinct users (sizes of the variable "all_gather" / "reduce_scatter")
+            counts.append(torch.full((self.world,), uniq.numel(), dtype=torch.int64, device=uid.device))
+        else:
+            ru = self._route(uid)
         ri = self._route(iid.reshape(-1)) if plan == "rows" else self._route(iid.reshape(-1), tuple_base=self.rank * B, div=C)
-        return {"key": (uid.data_ptr(), iid.data_ptr(), tuple(iid.shape)), "plan": plan, "u": ru, "i": ri,
-                "counts": _Counts([ru[1], ri[1]], self.group)}
-
-    def _routes_of(self, uid, iid, next_batch):
-        ahead, self._ahead = getattr(self, "_ahead", None), None
-        key = (uid.data_ptr(), iid.data_ptr(), tuple(iid.shape))
-        prep = ahead if (ahead is not None and ahead["key"] == key) else self._prepare(uid, iid)
-        if next_batch is not None:
-            self._ahead = self._prepare(*next_batch)   # enqueued before this step's heavy kernels
-        return prep
+        return {"key": (uid.data_ptr(), iid.data_ptr(), tuple(iid.shape)), "plan": plan, "u": ru, "i": ri, "inv": inv,
+                "counts": _Counts([ru[1], ri[1]] + counts, self.group)}
 
     def step(self, uid, iid, next_batch=None):
         """uid [B] int64, iid [B, C] int64: this rank's tuples (same B on every rank).
@@ -424,6 +487,7 @@ class ShardedBprmf:
             self.timing.clear()
         mark = self._mark
         mark("start")
+        self._mark_step_begin(uid)
         prep = self._routes_of(uid, iid, next_batch)
         if prep["plan"] == "rows":
             return self._step_rows(uid, iid, hyper, prep)
@@ -431,26 +495,44 @@ class ShardedBprmf:
         # 0. user ids and candidate occurrences grouped by owner; ONE exchange of all split sizes (a step ahead with next_batch)
         order_u, _, req_local = prep["u"]
         order_i, _, packed = prep["i"]
-        (cnt_u, cnt_i), (rcnt_u, rcnt_i) = prep["counts"].get()
+        inv = prep["inv"]
+        sends, recvs = prep["counts"].get()
+        (cnt_u, cnt_i), (rcnt_u, rcnt_i) = sends[:2], recvs[:2]
+        dev = uid.device
         mark("0 group by owner")
 
-        # 1. fetch the batch's user rows from their owners
+        # 1. fetch the batch's (distinct) user rows from their owners
         req_u, _ = _exchange(req_local, cnt_u, self.group, recv_counts=rcnt_u)
         rows_back = _exchange_back(ops.gather_rows(self.U, req_u), rcnt_u, cnt_u, self.group)
-        Ub = torch.empty((B, self.d), dtype=torch.float32, device=uid.device)
+        n_mine = int(order_u.numel())                     # B, or this rank's number of distinct users
+        Ub = torch.empty((n_mine, self.d), dtype=torch.float32, device=dev)
         Ub[order_u] = rows_back
         mark("1 fetch user rows")
 
         # 3. route candidate occurrences to the item's owner: (global tuple index, local row).  Every
         #    source sends in batch order, so the owner receives them grouped by tuple (t_idx ascending)
         recv, _ = _exchange(packed, cnt_i, self.group, recv_counts=rcnt_i)
-        # 2. every owner needs every tuple's user row: the all_gather (the largest transfer of the step, with the
-        #    reduce_scatter of phase 7) is issued now and travels while the owner unpacks and sorts what it received
-        Uall_pending = _all_gather_rows_async(Ub, W, self.group)
+        # 2. every owner needs every tuple's user row: this gather (the largest transfer of the step, with the
+        #    reduction of phase 7) is issued now and travels while the owner unpacks and sorts what it received.
+        #    With dedup_users only the distinct rows of every rank travel (a variable all_to_all, every rank sending
+        #    its rows to all), plus 8 B per tuple for the tuple -> distinct-row index; the per-tuple block the
+        #    owner-side kernels read is rebuilt locally (rc_gather_rows).
+        if inv is None:
+            Uall_pending = _all_gather_rows_async(Ub, W, self.group)
+        else:
+            d_all = recvs[2]                              # distinct users of every rank
+            Uall_pending = _exchange_async(Ub.repeat(W, 1), [n_mine] * W, d_all, self.group)
+            inv_all = _all_gather_rows(inv.contiguous(), W, self.group)        # [W * B] positions in the source's distinct list
+            offs = torch.tensor([0] + list(np.cumsum(d_all))[:-1], dtype=torch.int64, device=dev)
+            uidx_all = (inv_all + offs.repeat_interleave(B)).contiguous()     # row of the gathered distinct block per tuple
+            self.wire = {"user_rows_gather_in": 4 * self.d * (sum(d_all) - n_mine), "user_grads_reduce_out": 4 * self.d * n_mine * (W - 1),
+                         "tuple_index_in": 8 * B * (W - 1), "without_dedup_each_way": 4 * self.d * B * (W - 1)}
         t_idx, rows, t32 = self._unpack(recv)
         prep = ops.prepare_owner(rows, self.I.shape[0]) if hasattr(ops, "prepare_owner") else None
         mark("3 route occurrences + owner sort")
         Uall = Uall_pending.wait()
+        if inv is not None:
+            Uall = ops.gather_rows(Uall, uidx_all)        # [W * B, d], local
         mark("2 all_gather user rows (exposed part)")
 
         # 4. owner scores its rows; scores go home
@@ -470,9 +552,18 @@ class ShardedBprmf:
         # 6. owner: partial user grads (from pre-step item rows) and the item-row update;
         # 7. the partial user grads are summed at the tuples' home (reduce_scatter, in flight while the owner
         #    updates its multi-occurrence item rows) and routed to the user rows' owners
+        def reduce_users(pug):
+            """partial user gradients [W * B, d] (per tuple, this owner's item rows) -> in flight towards the tuples' home"""
+            if inv is None:
+                return _reduce_scatter_rows_async(pug, W, self.group)
+            # one row per DISTINCT user of every source rank (fixed-order segmented sum), then a variable all_to_all:
+            # block r goes to rank r; home adds the W blocks it receives in rank order
+            pug_d = ops.sum_rows_by_index(pug, uidx_all, int(sum(d_all)))
+            return _exchange_async(pug_d, d_all, [n_mine] * W, self.group)
+
         if hasattr(ops, "owner_backward_split"):
             pug, finish = ops.owner_backward_split(self.I, self.sI, rows, g_own, t_idx, t32, Uall, n_tuples, hyper, prep)
-            ugrad_pending = _reduce_scatter_rows_async(pug, W, self.group)
+            ugrad_pending = reduce_users(pug)
             finish()
         else:
             if hasattr(ops, "owner_backward"):
@@ -480,9 +571,11 @@ class ShardedBprmf:
             else:
                 pug = ops.partial_user_grads(self.I, rows, g_own, t_idx, n_tuples)
                 ops.update_rows(self.I, self.sI, rows, Uall, hyper, coef=g_own, src_index=t_idx)
-            ugrad_pending = _reduce_scatter_rows_async(pug, W, self.group)
+            ugrad_pending = reduce_users(pug)
         mark("6 owner backward + item-row update")
         ugrad = ugrad_pending.wait()
+        if inv is not None:
+            ugrad = ugrad.view(W, n_mine, self.d).sum(dim=0)   # blocks in rank order: a fixed summation order
         ug_own, _ = _exchange(ugrad[order_u], cnt_u, self.group, recv_counts=rcnt_u)
         ops.update_rows(self.U, self.sU, req_u, ug_own, hyper)
         mark("7 user grads reduce + update")
@@ -678,7 +771,7 @@ class _Route:
                 "rows_served_out": row_bytes * self.remote_in, "lookups": self.n_lookup, "ids_sent": self.n_sent}
 
 
-class ShardedNeumf:
+class ShardedNeumf(_LookAhead):
     """NeuMF (one hidden layer) with its four tables sharded by row over W ranks (BASELINE config 4: d = 128,
     K = 4, 100 M items).  A tuple touches 2 user rows and 2(1+K) item rows of 512 B each, so here the ROWS
     travel: ids are routed to their owners (rc_route_by_owner + all_to_all), owners gather
@@ -746,16 +839,6 @@ class ShardedNeumf:
         counts = _Counts([g[0][1] for pair in grouped for g in pair], self.group)
         return {"key": (uid.data_ptr(), iid.data_ptr(), tuple(iid.shape)), "uc": uc, "ic": ic, "grouped": grouped, "counts": counts}
 
-    def _routes_of(self, uid, iid, next_batch):
-        """the prepared routes of (uid, iid) -- taken from the previous step's look-ahead when it prepared this very
-        batch -- and, FIRST thing in this step's enqueue order, the routes of `next_batch`"""
-        ahead, self._ahead = getattr(self, "_ahead", None), None
-        key = (uid.data_ptr(), iid.data_ptr(), tuple(iid.shape))
-        prep = ahead if (ahead is not None and ahead["key"] == key) else self._prepare(uid, iid)
-        if next_batch is not None and self.world > 1:
-            self._ahead = self._prepare(*next_batch)
-        return prep
-
     def step(self, uid, iid, next_batch=None):
         """uid [B], iid [B, C]: this rank's tuples (same B everywhere) -> global mean loss, device tensor [1].
         next_batch = (uid, iid) of the FOLLOWING step (optional): its ids are grouped by owner and the exchange of its
@@ -768,6 +851,7 @@ class ShardedNeumf:
         hyper = ops.make_hyper(opt=self.opt, lr=self.lr, l2=self.l2, step=self.step_count)
         hyper0 = ops.make_hyper(opt=self.opt, lr=self.lr, l2=0.0, step=self.step_count)  # 'bias': no weight decay
         dev = uid.device
+        self._mark_step_begin(uid)
         if W > 1 and self.micro_batches > 1 and B >= self.micro_batches:
             return self._step_pipelined(uid, iid, hyper, hyper0, self._routes_of(uid, iid, next_batch))
         if W == 1:

@@ -65,7 +65,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, opt, lr, l2, n_users, n_items, d, B, C, steps, out_q, mode="owner"):
+def _worker(rank, world, port, opt, lr, l2, n_users, n_items, d, B, C, steps, out_q, mode="owner", dedup_users=True):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -73,13 +73,14 @@ def _worker(rank, world, port, opt, lr, l2, n_users, n_items, d, B, C, steps, ou
         rng = np.random.default_rng(5)  # same global problem on every rank
         U = rng.normal(0, 0.1, (n_users, d)).astype(np.float32)
         I = rng.normal(0, 0.1, (n_items, d)).astype(np.float32)
-        m = ShardedBprmf(n_users, n_items, d, opt=opt, lr=lr, l2=l2, ops=OracleOps(), mode=mode)
+        m = ShardedBprmf(n_users, n_items, d, opt=opt, lr=lr, l2=l2, ops=OracleOps(), mode=mode, dedup_users=dedup_users)
         m.load_global(torch.from_numpy(U), torch.from_numpy(I))
         losses, batches = [], []
         for s in range(steps):
             uid = rng.integers(0, n_users, size=(world, B)).astype(np.int64)
             iid = rng.integers(0, n_items, size=(world, B, C)).astype(np.int64)
             iid[:, :, 0] = iid[:, :, 0] % 7  # hot positives: duplicates across ranks and owners
+            uid[:, : B // 2] %= 3             # hot users: duplicates inside a rank's batch and across ranks
             batches.append((torch.from_numpy(uid[rank].copy()), torch.from_numpy(iid[rank].copy())))
         for s in range(steps):
             # odd steps route the following batch one step ahead (next_batch=), even ones on the spot: same result
@@ -103,6 +104,7 @@ def _reference(world, opt, lr, l2, n_users, n_items, d, B, C, steps):
         uid = rng.integers(0, n_users, size=(world, B)).astype(np.int64)
         iid = rng.integers(0, n_items, size=(world, B, C)).astype(np.int64)
         iid[:, :, 0] = iid[:, :, 0] % 7
+        uid[:, : B // 2] %= 3
         loss, _ = O.bprmf_train_step(U, I, sU, sI, uid.reshape(-1), iid.reshape(-1, C), opt=opt, lr=lr, l2=l2,
                                      step=s + 1, rowwise=True)
         losses.append(float(loss))
@@ -111,14 +113,17 @@ def _reference(world, opt, lr, l2, n_users, n_items, d, B, C, steps):
 
 @pytest.mark.parametrize("world,opt,lr,l2,mode", [(2, "SGD", 0.1, 1e-3, "owner"), (2, "Adam", 1e-2, 0.0, "owner"),
                                                   (3, "Adagrad", 0.05, 1e-4, "owner"), (2, "SGD", 0.1, 1e-3, "rows"),
-                                                  (3, "Adam", 1e-2, 1e-4, "rows")])
+                                                  (3, "Adam", 1e-2, 1e-4, "rows"), (3, "SGD", 0.1, 1e-3, "owner-nodedup")])
 def test_sharded_step_equals_single_table_training(world, opt, lr, l2, mode):
-    """both plans of the step -- user rows to the item owners ("owner"), all rows to the tuples ("rows")"""
+    """both plans of the step -- user rows to the item owners ("owner": only the DISTINCT user rows of a rank's batch
+    travel; "owner-nodedup": every tuple's row, the round-1 exchange), all rows to the tuples ("rows")"""
+    dedup = mode != "owner-nodedup"
+    mode = mode.split("-")[0]
     shape = dict(n_users=23, n_items=41, d=16, B=9, C=6, steps=3)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, opt, lr, l2, *shape.values(), q, mode)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, opt, lr, l2, *shape.values(), q, mode, dedup)) for r in range(world)]
     for p in procs:
         p.start()
     losses, Ug, Ig = q.get(timeout=120)
