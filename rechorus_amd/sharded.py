@@ -375,6 +375,9 @@ class _LookAhead:
                 _record_stream(prep, main)
         else:
             prep = self._prepare(uid, iid)
+            # routed on the caller's stream (first step, or no look-ahead): the side stream's routing of the next batch
+            # shares the engine's cached scratch buffers with it and must start after it
+            self._mark_step_begin(uid)
         if next_batch is not None and self.world > 1:
             self._ahead = self._prepare_ahead(*next_batch)
         return prep
