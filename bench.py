@@ -53,7 +53,7 @@ def parse():
                     help="nccl = RCCL (the only measurement mode); gloo only to smoke-test N>1 on one GPU")
     ap.add_argument("--workload", default="bprmf", choices=["bprmf", "neumf", "sasrec", "deepfm"],
                     help="bprmf = BASELINE configs[1] (the contract workload); neumf = configs[3]: NeuMF emb_size 128, "
-                         "num_neg 4, hidden 64 (pass --items 100000001 --users 10000001 --num-neg 4 --emb-size 128)")
+                         "num_neg 4, hidden 64 by default (the full config-4 tables: --items 100000001 --users 10000001)")
     ap.add_argument("--hidden", type=int, default=64, help="neumf: size of the hidden layer")
     ap.add_argument("--micro-batches", type=int, default=0,
                     help="neumf, N > 1: chunks of the local batch whose row exchanges overlap the head kernels "
@@ -73,6 +73,11 @@ def parse():
             args.opt = "Adam"
         if args.lr == 1e-3:
             args.lr = 5e-4
+    if args.workload == "neumf":  # configs[3]: NeuMF emb_size 128, num_neg 4 unless overridden (tables: --items / --users)
+        if args.emb_size == 64:
+            args.emb_size = 128
+        if args.num_neg == 99:
+            args.num_neg = 4
     if args.workload == "sasrec":  # configs[2] is quoted on a Grocery-sized catalogue; keep explicit overrides
         if args.items == 10_000_001:
             args.items = 8714

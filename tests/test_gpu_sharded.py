@@ -25,12 +25,17 @@ def _worker(rank, world, port, opt, lr, l2, n_users, n_items, d, B, C, steps, ou
         I = rng.normal(0, 0.1, (n_items, d)).astype(np.float32)
         m = ShardedBprmf(n_users, n_items, d, opt=opt, lr=lr, l2=l2, device=dev)
         m.load_global(torch.from_numpy(U).to(dev), torch.from_numpy(I).to(dev))
-        losses = []
+        losses, batches = [], []
         for s in range(steps):
             uid = rng.integers(0, n_users, size=(world, B)).astype(np.int64)
             iid = rng.integers(0, n_items, size=(world, B, C)).astype(np.int64)
             iid[:, :, 0] = iid[:, :, 0] % 7
-            loss = m.step(torch.from_numpy(uid[rank]).to(dev), torch.from_numpy(iid[rank]).to(dev))
+            uid[:, : B // 2] %= 3   # hot users (the same stream of batches as tests/test_sharded_gloo.py::_reference)
+            batches.append((torch.from_numpy(uid[rank]).to(dev), torch.from_numpy(iid[rank]).to(dev)))
+        for s in range(steps):
+            # the first step also routes the second batch ahead, on the side stream (sharded._LookAhead)
+            nxt = batches[s + 1] if (s == 0 and s + 1 < steps) else None
+            loss = m.step(*batches[s], next_batch=nxt)
             losses.append(float(loss))
         Ug, Ig = m.gather_global()
         if rank == 0:

@@ -245,6 +245,9 @@ def test_bench_workload_defaults(monkeypatch):
     monkeypatch.setattr(sys, "argv", ["bench.py"])
     a = bench.parse()
     assert (a.workload, a.items, a.batch, a.num_neg, a.emb_size, a.gpus) == ("bprmf", 10_000_001, 65536, 99, 64, 1)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--workload", "neumf"])   # configs[3] shape
+    a = bench.parse()
+    assert (a.emb_size, a.num_neg, a.hidden, a.batch) == (128, 4, 64, 65536)
 
 
 def test_engine_auto_respects_the_models_rowwise_predicate(caplog):
