@@ -418,10 +418,17 @@ class HipOptimizer:
                     continue
                 st = self.state.setdefault(p, {})
                 m = v = None
+                # (state created once: `st.setdefault(k, torch.zeros_like(p))` would allocate and zero-fill a tensor of the
+                # parameter's size on EVERY step just to throw it away -- 48 fill kernels per DeepFM step, 24 % of its
+                # replayed GPU time in profiles/r02z_deepfm_kernel_stats.csv)
                 if self.name in ("Adam", "Adagrad", "Adadelta"):   # exp_avg / state_sum / square_avg
-                    m = st.setdefault("m", torch.zeros_like(p))
+                    if "m" not in st:
+                        st["m"] = torch.zeros_like(p)
+                    m = st["m"]
                 if self.name in ("Adam", "Adadelta"):              # exp_avg_sq / acc_delta
-                    v = st.setdefault("v", torch.zeros_like(p))
+                    if "v" not in st:
+                        st["v"] = torch.zeros_like(p)
+                    v = st["v"]
                 grad = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                 items.append((p.data, grad, h, m, v))
                 dev = p.device

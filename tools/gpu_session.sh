@@ -21,6 +21,8 @@ timeout 300 python bench.py --steps 300 --warmup 20 --batch 256 --no-cpu-baselin
 timeout 400 python bench.py --workload neumf > $OUT/bench_neumf.json 2> $OUT/bench_neumf.err
 timeout 400 python bench.py --workload sasrec > $OUT/bench_sasrec.json 2> $OUT/bench_sasrec.err
 timeout 400 python bench.py --workload deepfm > $OUT/bench_deepfm.json 2> $OUT/bench_deepfm.err
+timeout 300 python bench.py --workload deepfm --batch 16384 --steps 50 --warmup 5 --no-cpu-baseline > $OUT/bench_deepfm_b16384.json 2> $OUT/bench_deepfm_b16384.err
+timeout 300 python bench.py --workload deepfm --batch 131072 --steps 20 --warmup 3 --no-cpu-baseline > $OUT/bench_deepfm_b131072.json 2> $OUT/bench_deepfm_b131072.err
 
 cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats -d $R/$OUT/prof -o kt --output-format csv -- \
@@ -32,7 +34,7 @@ find $OUT -name "*kernel_trace.csv" -size +20M -delete 2>/dev/null
 bash tools/pmc_collect.sh $TAG/pmc > /dev/null 2>&1
 ls -laR $OUT > $OUT/ls.txt 2>&1
 tail -5 $OUT/pytest_gpu.log; tail -2 $OUT/smoke.log
-for f in bench bench_adam bench_b8192 bench_b256 bench_neumf bench_sasrec bench_deepfm; do
+for f in bench bench_adam bench_b8192 bench_b256 bench_neumf bench_sasrec bench_deepfm bench_deepfm_b16384 bench_deepfm_b131072; do
   python - <<PY
 import json
 try:
