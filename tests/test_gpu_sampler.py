@@ -115,6 +115,23 @@ def test_target_rank_and_metrics(cuda, eng):
         eng.rank_metrics(rank, [5], ["MAP"])
 
 
+@pytest.mark.parametrize("case", ["testall_bprmf_d64", "testall_bprmf_d32"])
+def test_full_catalogue_rank_matches_the_reference_exactly(case, cuda, eng):
+    """rc_full_catalogue_rank vs the ranks the reference's own --test_all evaluation produced (BaseRunner.predict +
+    evaluate_method on its BPRMF, tests/golden/make_golden_testall.py); the fixture has no near-ties, so the ranks are exact"""
+    import os
+    from conftest import GOLDEN_DIR
+    g = np.load(os.path.join(GOLDEN_DIR, case + ".npz"))
+    Uv = g["U"][g["users"]]
+    rank, tscore = eng.full_catalogue_rank(dev(Uv, cuda), dev(g["I"], cuda), dev(g["users"], cuda), dev(g["targets"], cuda),
+                                           dev(g["clicked_ptr"], cuda), dev(g["clicked_items"], cuda))
+    assert np.array_equal(rank.cpu().numpy().astype(np.int64), g["gt_rank"])
+    assert np.allclose(tscore.cpu().numpy(), g["target_score"], rtol=1e-5, atol=1e-6)
+    got = eng.rank_metrics(rank, [5, 10, 50], ["HR", "NDCG"])
+    for k, v in got.items():
+        assert abs(v - float(g["res/" + k])) < 1e-9, k
+
+
 @pytest.mark.parametrize("d", [32, 64, 128])
 def test_full_catalogue_rank_vs_oracle(d, cuda, eng):
     rng = np.random.default_rng(d)

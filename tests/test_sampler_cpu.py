@@ -107,3 +107,24 @@ def test_sampler_exhausted_attempts_select_a_non_clicked_item_directly():
     assert set(np.unique(neg)) == free
     neg_all = S.sample_negatives(np.ones(1, dtype=np.int64), 2, n_items, ptr, items, seed=5)
     assert neg_all.min() >= 1 and neg_all.max() < n_items
+
+
+@pytest.mark.parametrize("case", ["testall_bprmf_d64", "testall_bprmf_d32"])
+def test_full_catalogue_rank_oracle_vs_the_reference(case):
+    """--test_all: the reference's own BaseRunner.predict on its BPRMF (scores over ALL items, clicked items -inf) and the
+    rank rule of evaluate_method, on a dataset without near-ties (tests/golden/make_golden_testall.py): exact ranks"""
+    import os
+    from conftest import GOLDEN_DIR
+    from oracle import bprmf_oracle as BO
+    from oracle import sampler_oracle as S
+    g = np.load(os.path.join(GOLDEN_DIR, case + ".npz"))
+    assert float(g["min_rel_gap"]) > 1e-4
+    ptr, flat = g["clicked_ptr"], g["clicked_items"]
+    sets = [set(flat[ptr[u]:ptr[u + 1]].tolist()) for u in range(len(ptr) - 1)]
+    Uv = g["U"][g["users"]]
+    rank = S.full_catalogue_rank(Uv, g["I"], g["users"], g["targets"], sets)
+    assert np.array_equal(np.asarray(rank, dtype=np.int64), g["gt_rank"])
+    for k in (5, 10, 50):
+        hit = (g["gt_rank"] <= k)
+        assert abs(hit.mean() - float(g[f"res/HR@{k}"])) < 1e-12
+        assert abs((hit / np.log2(g["gt_rank"] + 1)).mean() - float(g[f"res/NDCG@{k}"])) < 1e-12
