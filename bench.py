@@ -514,6 +514,10 @@ def main():
             torch.cuda.synchronize(device)
 
     run_step = lambda s: trainer.step(*batches[s % len(batches)])
+    if world == 1 and args.workload == "bprmf" and not args.graph:
+        # the step is given the following batch's ids (the reference's DataLoader runs ahead of the loop too): their grouping
+        # front runs beside this step's row updates (rc_bprmf_train_step_ahead); same results bit for bit
+        run_step = lambda s: trainer.step(*batches[s % len(batches)], next_batch=batches[(s + 1) % len(batches)])
     if getattr(trainer, "lookahead", False):
         # the sharded steps exchange per-destination split sizes; given the following batch they do that one step ahead
         run_step = lambda s: trainer.step(*batches[s % len(batches)], next_batch=batches[(s + 1) % len(batches)])

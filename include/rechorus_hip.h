@@ -572,6 +572,18 @@ int rc_bprmf_train_step(float* U, float* I, float* mU, float* vU, float* mI, flo
                         float inv_b, float* loss_out, float* pred, void* ws,
                         size_t ws_bytes, rc_stream_t stream, float* phase_ms);
 
+/* rc_bprmf_train_step with a look-ahead: next_uid [B] / next_iid [B, C] are the ids of the FOLLOWING call (same shapes,
+ * same workspace; the reference's loop knows them too -- its DataLoader runs ahead of helpers/BaseRunner.py:186).  The
+ * id-grouping front of that batch (histogram, stable partition, singleton flags) is enqueued on the library's second
+ * stream beside THIS step's row updates, so the following call starts directly with its fused kernel.  Results are
+ * bit-identical to rc_bprmf_train_step; a following call with other ids simply redoes the front.  NULL next pointers,
+ * stream capture, optimizers with state and batches that take the small-batch or the sort pipeline: no look-ahead.   */
+int rc_bprmf_train_step_ahead(float* U, float* I, float* mU, float* vU, float* mI, float* vI,
+                              const int64_t* uid, const int64_t* iid, const int64_t* next_uid,
+                              const int64_t* next_iid, int B, int C, int d, int64_t n_users, int64_t n_items,
+                              const rc_opt_hyper* h, float inv_b, float* loss_out, float* pred, void* ws,
+                              size_t ws_bytes, rc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -40,7 +40,7 @@ int small_step_launch(float* U, float* I, float* mU, float* vU, float* mI, float
 namespace {
 struct StepSide {
   hipStream_t stream = nullptr;
-  hipEvent_t fork = nullptr, join = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr, fork2 = nullptr, front_done = nullptr;
   bool ok = false;
 };
 StepSide& step_side() {
@@ -48,11 +48,28 @@ StepSide& step_side() {
     StepSide x;
     if (hipStreamCreateWithFlags(&x.stream, hipStreamNonBlocking) == hipSuccess &&
         hipEventCreateWithFlags(&x.fork, hipEventDisableTiming) == hipSuccess &&
-        hipEventCreateWithFlags(&x.join, hipEventDisableTiming) == hipSuccess)
+        hipEventCreateWithFlags(&x.join, hipEventDisableTiming) == hipSuccess &&
+        hipEventCreateWithFlags(&x.fork2, hipEventDisableTiming) == hipSuccess &&
+        hipEventCreateWithFlags(&x.front_done, hipEventDisableTiming) == hipSuccess)
       x.ok = true;
     return x;
   }();
   return sd;
+}
+
+// Look-ahead across steps (rc_bprmf_train_step_ahead): the plan's FRONT of the next batch (histogram, partition,
+// singleton flags: 0.155 ms on the critical path of the SGD step at config 2) runs on the side stream beside THIS step's
+// row updates, so that the next call starts with its fused kernel.  What was prepared, for which batch and workspace:
+struct Ahead {
+  bool valid = false;
+  const void* ws = nullptr;
+  const int64_t* uid = nullptr;
+  const int64_t* iid = nullptr;
+  int B = 0, C = 0, slot = 0;
+};
+Ahead& step_ahead() {
+  static Ahead a;
+  return a;
 }
 }  // namespace
 
@@ -81,6 +98,7 @@ struct StepWs {
   rc_plan_row* rows_u;
   uint32_t* occ;
   void* small_extra;     // small-batch step (small_step.hip): user-row snapshot, per-workgroup row / position segments
+  uint32_t* counters2;   // second counter block: the look-ahead front of the next batch zeroes / fills the one this step does not use
   size_t total;
 };
 
@@ -120,6 +138,7 @@ StepWs carve_step_ws(void* base, int B, int C, int d) {
   w.rows_i = pv.take<rc_plan_row>(n_i);
   w.rows_u = pv.take<rc_plan_row>((size_t)B);
   w.occ = pv.take<uint32_t>(n_i + (size_t)B);
+  w.counters2 = pv.take<uint32_t>(PC_N);
   w.total = cv.off > pv.off ? cv.off : pv.off;
   // the small-batch step's buffers overlay the same region (the pipelines never run in the same call)
   w.small_extra = base ? reinterpret_cast<char*>(base) + plan_off : nullptr;
@@ -153,11 +172,12 @@ extern "C" size_t rc_bprmf_step_workspace_bytes(int B, int C, int d) {
   return carve_step_ws(nullptr, B, C, d).total;
 }
 
-extern "C" int rc_bprmf_train_step(float* U, float* I, float* mU, float* vU, float* mI, float* vI,
-                                   const int64_t* uid, const int64_t* iid, int B, int C, int d,
-                                   int64_t n_users, int64_t n_items, const rc_opt_hyper* h,
-                                   float inv_b, float* loss_out, float* pred, void* ws,
-                                   size_t ws_bytes, rc_stream_t stream, float* phase_ms) {
+static int train_step_impl(float* U, float* I, float* mU, float* vU, float* mI, float* vI,
+                           const int64_t* uid, const int64_t* iid, int B, int C, int d,
+                           int64_t n_users, int64_t n_items, const rc_opt_hyper* h,
+                           float inv_b, float* loss_out, float* pred, void* ws,
+                           size_t ws_bytes, rc_stream_t stream, float* phase_ms,
+                           const int64_t* next_uid, const int64_t* next_iid) {
   RC_REQUIRE(U && I && uid && iid && h && loss_out && ws, "rc_bprmf_train_step: null pointer");
   RC_REQUIRE(B >= 1 && C >= 2 && d >= 1, "rc_bprmf_train_step: bad shape B=%d C=%d d=%d", B, C, d);
   RC_REQUIRE((int64_t)B * C < ((int64_t)1 << 31), "rc_bprmf_train_step: B*C too large");
@@ -167,6 +187,13 @@ extern "C" int rc_bprmf_train_step(float* U, float* I, float* mU, float* vU, flo
     return fail(RC_ERR_WORKSPACE, "rc_bprmf_train_step: workspace %zu < %zu", ws_bytes, w.total);
   hipStream_t s = as_stream(stream);
   const int64_t n_i = (int64_t)B * C;
+  // a front prepared ahead by the previous call: usable when it was made for exactly this batch and workspace;
+  // in every case its kernels (side stream) have to be finished before this call touches the plan buffers
+  Ahead& ahead = step_ahead();
+  const bool ahead_hit = ahead.valid && ahead.ws == ws && ahead.uid == uid && ahead.iid == iid && ahead.B == B && ahead.C == C;
+  const int slot = ahead_hit ? ahead.slot : 0;
+  if (ahead.valid) RC_HIP(hipStreamWaitEvent(s, step_side().front_done, 0));
+  ahead.valid = false;
 
   constexpr int kMarks = 8;
   hipEvent_t ev[kMarks];
@@ -215,10 +242,12 @@ extern "C" int rc_bprmf_train_step(float* U, float* I, float* mU, float* vU, flo
     pa.range_a = n_items; pa.range_b = n_users;
     pa.g = geom;
     pa.w = w.plan;
+    uint32_t* ctr = slot ? w.counters2 : w.plan.counters;   // (the other block belongs to a look-ahead front)
+    pa.w.counters = ctr;
     pa.list_single_a = fused_upd ? 0 : 1;
     pa.single_a = fused_upd ? w.single : nullptr;
     pa.rows_a = w.rows_i; pa.rows_b = w.rows_u;
-    pa.n_rows_a = &w.plan.counters[PC_ROWS_A]; pa.n_rows_b = &w.plan.counters[PC_ROWS_B];
+    pa.n_rows_a = &ctr[PC_ROWS_A]; pa.n_rows_b = &ctr[PC_ROWS_B];
     pa.occ = w.occ;
     StepSide& side = step_side();
     const bool two_streams = (step_pipeline() == 0 || step_pipeline() == 3) && side.ok;
@@ -228,7 +257,7 @@ extern "C" int rc_bprmf_train_step(float* U, float* I, float* mU, float* vU, flo
       // side stream:     per-bucket pass (row records, grouped positions), joined before the updates
       // (without the singleton fast path the fused kernel needs nothing from the plan: all of it runs on the side stream)
       pa.flags_done = fused_upd ? 1 : 0;
-      if (fused_upd) RC_TRY(plan_launch_front(pa, true, s));
+      if (fused_upd && !ahead_hit) RC_TRY(plan_launch_front(pa, true, s));   // (ahead_hit: done beside the previous step's updates)
       RC_MARK(1);
       RC_HIP(hipEventRecord(side.fork, s));
       RC_HIP(hipStreamWaitEvent(side.stream, side.fork, 0));
@@ -246,10 +275,29 @@ extern "C" int rc_bprmf_train_step(float* U, float* I, float* mU, float* vU, flo
     else
       RC_TRY(rc_bprmf_fwd_bwd(U, I, uid, iid, B, C, d, inv_b, pred, w.loss_vec, w.gpred, w.ugrad, stream));
     if (two_streams) RC_HIP(hipStreamWaitEvent(s, side.join, 0));
+    if (two_streams && fused_upd && next_uid != nullptr && next_iid != nullptr && !prof) {
+      // Look-ahead: the front of the NEXT batch on the side stream, beside this step's row updates.  It writes the
+      // histogram / bucketed keys / flags (all consumed by this step already: the fused kernel and the per-bucket pass are
+      // behind the join above) and zeroes the OTHER counter block.  Not under stream capture (the next call's wait
+      // on front_done would cross graphs).
+      hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+      if (hipStreamIsCapturing(s, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone) {
+        PlanArgs pn = pa;
+        pn.ids_a = next_iid; pn.ids_b = next_uid;
+        uint32_t* nctr = slot ? w.plan.counters : w.counters2;
+        pn.w.counters = nctr;
+        pn.n_rows_a = &nctr[PC_ROWS_A]; pn.n_rows_b = &nctr[PC_ROWS_B];
+        RC_HIP(hipEventRecord(side.fork2, s));
+        RC_HIP(hipStreamWaitEvent(side.stream, side.fork2, 0));
+        RC_TRY(plan_launch_front(pn, true, side.stream));
+        RC_HIP(hipEventRecord(side.front_done, side.stream));
+        ahead.valid = true; ahead.ws = ws; ahead.uid = next_uid; ahead.iid = next_iid; ahead.B = B; ahead.C = C; ahead.slot = 1 - slot;
+      }
+    }
     RC_MARK(4);
     RC_MARK(5);  // (the loss mean is one workgroup of the last update launch)
     RC_TRY(plan_bprmf_step_updates(U, mU, vU, I, mI, vI, d, uid, C, n_i, B, w.gpred, w.ugrad, w.rows_i, pa.n_rows_a,
-                                   w.rows_u, pa.n_rows_b, w.occ, w.plan.counters, w.plan_long, h, w.loss_vec, inv_b,
+                                   w.rows_u, pa.n_rows_b, w.occ, ctr, w.plan_long, h, w.loss_vec, inv_b,
                                    loss_out, s, prof ? &ev[6] : nullptr));
     RC_MARK(7);
   } else {
@@ -297,4 +345,22 @@ extern "C" int rc_bprmf_train_step(float* U, float* I, float* mU, float* vU, flo
     for (int i = 0; i < kMarks; ++i) RC_HIP(hipEventDestroy(ev[i]));
   }
   return RC_OK;
+}
+
+extern "C" int rc_bprmf_train_step(float* U, float* I, float* mU, float* vU, float* mI, float* vI,
+                                   const int64_t* uid, const int64_t* iid, int B, int C, int d,
+                                   int64_t n_users, int64_t n_items, const rc_opt_hyper* h,
+                                   float inv_b, float* loss_out, float* pred, void* ws,
+                                   size_t ws_bytes, rc_stream_t stream, float* phase_ms) {
+  return train_step_impl(U, I, mU, vU, mI, vI, uid, iid, B, C, d, n_users, n_items, h, inv_b, loss_out, pred, ws, ws_bytes, stream,
+                         phase_ms, nullptr, nullptr);
+}
+
+extern "C" int rc_bprmf_train_step_ahead(float* U, float* I, float* mU, float* vU, float* mI, float* vI,
+                                         const int64_t* uid, const int64_t* iid, const int64_t* next_uid,
+                                         const int64_t* next_iid, int B, int C, int d, int64_t n_users, int64_t n_items,
+                                         const rc_opt_hyper* h, float inv_b, float* loss_out, float* pred, void* ws,
+                                         size_t ws_bytes, rc_stream_t stream) {
+  return train_step_impl(U, I, mU, vU, mI, vI, uid, iid, B, C, d, n_users, n_items, h, inv_b, loss_out, pred, ws, ws_bytes, stream,
+                         nullptr, next_uid, next_iid);
 }

@@ -414,15 +414,29 @@ class BprmfTrainer:
             self._ws_shape = (B, Cn)
         return self._ws
 
-    def step(self, uid, iid, inv_b=None, pred=None, phase_ms=None):
+    def step(self, uid, iid, inv_b=None, pred=None, phase_ms=None, next_batch=None):
         """Runs one training step; returns the device loss tensor (shape [1], no sync).
-        phase_ms: optional ctypes float[8] to receive per-phase hipEvent timings."""
+        phase_ms: optional ctypes float[8] to receive per-phase hipEvent timings.
+        next_batch = (uid, iid) of the FOLLOWING step (same shapes): the grouping front of those ids runs beside this
+        step's row updates (rc_bprmf_train_step_ahead); the tensors must stay alive and unchanged until that step."""
         B, Cn = iid.shape
         if inv_b is None:
             inv_b = 1.0 / B
         ws = self._workspace(B, Cn)
         self.hyper.step += 1
         f32 = torch.float32
+        if next_batch is not None and phase_ms is None and tuple(next_batch[1].shape) == (B, Cn):
+            nu, ni = next_batch
+            _lib.call("rc_bprmf_train_step_ahead",
+                      _ptr(self.U, f32, "U"), _ptr(self.I, f32, "I"),
+                      _ptr(self.mU, f32, "mU", True), _ptr(self.vU, f32, "vU", True),
+                      _ptr(self.mI, f32, "mI", True), _ptr(self.vI, f32, "vI", True),
+                      _ptr(uid, torch.int64, "uid"), _ptr(iid, torch.int64, "iid"),
+                      _ptr(nu, torch.int64, "next_uid"), _ptr(ni, torch.int64, "next_iid"), B, Cn, self.d,
+                      self.U.shape[0], self.I.shape[0], C.byref(self.hyper), float(inv_b),
+                      _ptr(self.loss, f32, "loss"), _ptr(pred, f32, "pred", True),
+                      C.c_void_p(ws.data_ptr()), ws.numel(), _stream())
+            return self.loss
         _lib.call("rc_bprmf_train_step",
                   _ptr(self.U, f32, "U"), _ptr(self.I, f32, "I"),
                   _ptr(self.mU, f32, "mU", True), _ptr(self.vU, f32, "vU", True),

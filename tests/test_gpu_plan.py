@@ -250,3 +250,37 @@ def test_small_batch_step_vs_oracle(kind, opt, lr, l2, cuda, eng):
         u, i = mk()
         tr2.step(torch.from_numpy(u).to(cuda), torch.from_numpy(i).to(cuda))
     assert torch.equal(U, U2) and torch.equal(I, I2)
+
+
+@pytest.mark.parametrize("opt,lr,l2", [("SGD", 0.05, 1e-3), ("Adam", 1e-3, 1e-4)])
+def test_train_step_with_look_ahead_is_bit_identical(opt, lr, l2, cuda, eng):
+    """rc_bprmf_train_step_ahead: the grouping front of the FOLLOWING batch runs beside this step's row updates -- same
+    tables, state and losses bit for bit, whether every step looks ahead, only some do, or the announced batch is not the
+    one that follows (the front is then redone)"""
+    rng = np.random.default_rng(17)
+    n_users, n_items, d, B, C = 3000, 40_000, 64, 2048, 100
+    U0 = rng.normal(0, 0.01, size=(n_users, d)).astype(np.float32)
+    I0 = rng.normal(0, 0.01, size=(n_items, d)).astype(np.float32)
+    batches = []
+    for _ in range(5):
+        uid = _zipf(rng, n_users, B)
+        iid = np.concatenate([_zipf(rng, n_items, (B, 1)), rng.integers(1, n_items, size=(B, C - 1))], axis=1)
+        batches.append((torch.from_numpy(uid).to(cuda), torch.from_numpy(iid).to(cuda)))
+    res = []
+    for mode in ("none", "all", "some", "wrong"):
+        U, I = torch.from_numpy(U0).to(cuda), torch.from_numpy(I0).to(cuda)
+        tr = eng.BprmfTrainer(U, I, opt=opt, lr=lr, l2=l2)
+        losses = []
+        for k, (u, i) in enumerate(batches):
+            nxt = None
+            if mode == "all" or (mode == "some" and k % 2 == 0):
+                nxt = batches[(k + 1) % len(batches)]
+            elif mode == "wrong":
+                nxt = batches[(k + 2) % len(batches)]   # not the batch the next call brings
+            losses.append(tr.step(u, i, next_batch=nxt).clone())
+        torch.cuda.synchronize()
+        res.append((U, I, tr.mI, tr.vI, torch.cat(losses)))
+    for other in res[1:]:
+        for name, x, y in zip(("U", "I", "mI", "vI", "loss"), res[0], other):
+            if x is not None:
+                assert torch.equal(x, y), name
