@@ -12,16 +12,19 @@
 // D=64, C=100: LPR=16, GS=4, CPL=25 -> the whole 25.6 KB candidate block of a tuple
 // lives in one wave's VGPRs (100 VGPRs/lane), so the backward pass (user-row gradient
 // sum_c g_c * I_c, which needs every row again after the softmax over all K negatives is
-// known) re-reads nothing from HBM, LDS is not needed at all, and the only cross-lane
-// traffic is DPP row reductions + a few ds_bpermute across the GS groups.
+// known) re-reads nothing from HBM, and the only cross-lane traffic is DPP row reductions +
+// a few ds_bpermute across the GS groups.  The only LDS use is a strip of C floats per tuple that
+// transposes the scores so that the loss is evaluated one lane per candidate (fused_body.hpp).
 // Small C packs several tuples per wave (C=2: two 32-lane tuples).
 //
 // Singleton rows (MODE != MODE_NONE).  An item row that occurs exactly once in the batch is
 // read by nobody else in this step, and its complete gradient g_c * U[u] is known right
 // here, where the row itself is still in registers: the kernel applies the optimizer and
 // writes the new row, so the row crosses HBM once in each direction per step (the
-// compulsory traffic).  `single[o]` comes from rc_mark_singletons on the sorted ids; rows
-// with several occurrences are left to the segmented update (seg_update.hip).
+// compulsory traffic).  `single[o]` comes from the bucket plan (bucket_plan.hip: plan_flags_kernel;
+// rc_segment_heads on the sorted ids in the sort pipeline); rows with several occurrences are left to
+// the plan-driven row update (plan_update.hip; seg_update.hip in the sort pipeline).  The kernel body
+// lives in fused_body.hpp: small_front_kernel below runs it beside the small-batch plan workgroups.
 #include "fused_body.hpp"
 #include "small_plan.hpp"
 

@@ -4,14 +4,17 @@
 // host synchronisation (grid sizes depend only on B, C), so the call can be captured in a
 // hipGraph; with `phase_ms` it brackets the phases with hipEvents and synchronises.
 //
-//   phase 0  sort item + user ids jointly phase 3  loss mean (deterministic)
-//   phase 7  mark single-occurrence rows  phase 4  item rows with >= 2 occurrences:
-//   phase 1  (merged into phase 0)                 segmented grad + update
-//   phase 2  fused gather/dot/loss/bwd    phase 5  user rows: segmented grad + update
-//            (+ update of singleton item rows, still in registers)
+// Three pipelines (rc_bprmf_step_pipeline):
+//   small batches (<= 32,768 row ids)   two launches: small_step.hip
+//   bucket plan (default otherwise)     partition -> [flags] -> fused kernel || per-bucket pass on a second stream
+//                                       -> row updates; with rc_bprmf_train_step_ahead the front of the NEXT batch runs
+//                                       beside this step's row updates
+//   sort pipeline (wide id spaces)      joint radix sort -> segment heads -> fused kernel -> segmented updates
+// phase_ms slots (all pipelines): [0] sort / partition (+ flags) [7] segment heads / per-bucket pass when on the caller's
+// stream [2] fused kernel [3] loss mean (0 when folded into the last update launch) [4] item-row update [5] user-row update.
 //
-// Ordering constraints: phase 4 reads U (pre-step values, to rebuild g*U[u]) so it runs
-// before phase 5 rewrites U; phase 2 reads both tables before either is updated.
+// Ordering constraints: the item-row update reads U (pre-step values, to rebuild g*U[u]) so it runs
+// before the user rows are rewritten; the fused kernel reads both tables before either is updated.
 #include "common.hpp"
 #include "plan.hpp"
 
