@@ -545,7 +545,7 @@ def main():
     sync()
     t0 = time.perf_counter()
     for s in range(args.steps):
-        run_step(s)
+        run_step(args.warmup + s)   # the batch sequence continues: the last warm-up step announced this step's batch
     sync()
     elapsed = time.perf_counter() - t0
     if dist is not None:
