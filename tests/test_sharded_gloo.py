@@ -234,6 +234,15 @@ def _neumf_worker(rank, world, port, opt, lr, l2, n_users, n_items, d, l1, B, C,
         for s in range(steps):
             nxt = batches[s + 1] if (s % 2 == 0 and s + 1 < steps) else None   # look-ahead routing on every other step
             losses.append(float(m.step(*batches[s], next_batch=nxt)))
+        # bytes over the links of the LAST step vs the model of tools/scale_model.py / DESIGN.md section 7: only the distinct
+        # ids of a lookup that live on OTHER ranks travel, one row of both tables back, one gradient row out
+        if micro_batches == 1 and world > 1:
+            u_last, i_last = (t.numpy() for t in batches[-1])
+            remote = sum(int((np.unique(x) % world != rank).sum()) for x in (u_last, i_last.reshape(-1)))
+            want = {"ids_out": 8 * remote, "rows_in": 2 * d * 4 * remote, "grads_out": 2 * d * 4 * remote}
+            got = {k: m.wire[k] for k in want}
+            assert got == want, (got, want)
+            assert m.wire["ids_sent"] == len(np.unique(u_last)) + len(np.unique(i_last)) < m.wire["lookups"]
         G = m.gather_global()
         if rank == 0:
             out_q.put((losses, {k: v.numpy() for k, v in G.items()}))
