@@ -583,6 +583,9 @@ int rc_bprmf_train_step_ahead(float* U, float* I, float* mU, float* vU, float* m
                               const int64_t* next_iid, int B, int C, int d, int64_t n_users, int64_t n_items,
                               const rc_opt_hyper* h, float inv_b, float* loss_out, float* pred, void* ws,
                               size_t ws_bytes, rc_stream_t stream);
+/* Forget a front prepared by rc_bprmf_train_step_ahead (call before the workspace it was written into is freed or
+ * re-allocated): `stream` waits for the second stream's writes into that workspace.                              */
+int rc_bprmf_step_ahead_reset(rc_stream_t stream);
 
 #ifdef __cplusplus
 }

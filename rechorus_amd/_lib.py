@@ -125,6 +125,7 @@ SIGNATURES = {
     "rc_bprmf_step_pipeline": (_i, [_i]),
     "rc_bprmf_train_step": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i64, _i64, _hp, _f,
                                  _p, _p, _p, _sz, _p, C.POINTER(C.c_float)]),
+    "rc_bprmf_step_ahead_reset": (_i, [_p]),
     "rc_bprmf_train_step_ahead": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i64, _i64, _hp, _f,
                                        _p, _p, _p, _sz, _p]),
 }

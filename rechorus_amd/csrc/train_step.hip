@@ -68,7 +68,8 @@ struct Ahead {
   const void* ws = nullptr;
   const int64_t* uid = nullptr;
   const int64_t* iid = nullptr;
-  int B = 0, C = 0, slot = 0;
+  int B = 0, C = 0, d = 0, slot = 0;
+  int64_t n_users = 0, n_items = 0;
 };
 Ahead& step_ahead() {
   static Ahead a;
@@ -193,7 +194,8 @@ static int train_step_impl(float* U, float* I, float* mU, float* vU, float* mI, 
   // a front prepared ahead by the previous call: usable when it was made for exactly this batch and workspace;
   // in every case its kernels (side stream) have to be finished before this call touches the plan buffers
   Ahead& ahead = step_ahead();
-  const bool ahead_hit = ahead.valid && ahead.ws == ws && ahead.uid == uid && ahead.iid == iid && ahead.B == B && ahead.C == C;
+  const bool ahead_hit = ahead.valid && ahead.ws == ws && ahead.uid == uid && ahead.iid == iid && ahead.B == B && ahead.C == C &&
+                         ahead.d == d && ahead.n_users == n_users && ahead.n_items == n_items;
   const int slot = ahead_hit ? ahead.slot : 0;
   if (ahead.valid) RC_HIP(hipStreamWaitEvent(s, step_side().front_done, 0));
   ahead.valid = false;
@@ -294,7 +296,8 @@ static int train_step_impl(float* U, float* I, float* mU, float* vU, float* mI, 
         RC_HIP(hipStreamWaitEvent(side.stream, side.fork2, 0));
         RC_TRY(plan_launch_front(pn, true, side.stream));
         RC_HIP(hipEventRecord(side.front_done, side.stream));
-        ahead.valid = true; ahead.ws = ws; ahead.uid = next_uid; ahead.iid = next_iid; ahead.B = B; ahead.C = C; ahead.slot = 1 - slot;
+        ahead.valid = true; ahead.ws = ws; ahead.uid = next_uid; ahead.iid = next_iid; ahead.B = B; ahead.C = C; ahead.d = d;
+        ahead.n_users = n_users; ahead.n_items = n_items; ahead.slot = 1 - slot;
       }
     }
     RC_MARK(4);
@@ -366,4 +369,15 @@ extern "C" int rc_bprmf_train_step_ahead(float* U, float* I, float* mU, float* v
                                          size_t ws_bytes, rc_stream_t stream) {
   return train_step_impl(U, I, mU, vU, mI, vI, uid, iid, B, C, d, n_users, n_items, h, inv_b, loss_out, pred, ws, ws_bytes, stream,
                          nullptr, next_uid, next_iid);
+}
+
+// Forget a prepared front (the owner of the workspace goes away or re-allocates it): `stream` is made to wait for the
+// side stream's writes into that workspace, so that whatever reuses the memory afterwards is ordered behind them.
+extern "C" int rc_bprmf_step_ahead_reset(rc_stream_t stream) {
+  Ahead& ahead = step_ahead();
+  if (ahead.valid) {
+    RC_HIP(hipStreamWaitEvent(as_stream(stream), step_side().front_done, 0));
+    ahead.valid = false;
+  }
+  return RC_OK;
 }

@@ -409,10 +409,23 @@ class BprmfTrainer:
                 raise _lib.RechorusHipError("rc_bprmf_step_workspace_bytes", -1, "bad shape")
             if self._ws is None or self._ws.numel() < nbytes:
                 if self._ws is not None:
+                    self._forget_ahead()
                     _ws_retired.append(self._ws)  # a captured hipGraph may still point into it
                 self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.U.device)
             self._ws_shape = (B, Cn)
         return self._ws
+
+    def _forget_ahead(self):
+        """a front prepared by step(next_batch=...) lives in this trainer's workspace: drop it before the memory can be reused"""
+        if getattr(self, "_looked_ahead", False):
+            self._looked_ahead = False
+            try:
+                _lib.call("rc_bprmf_step_ahead_reset", _stream())
+            except Exception:  # interpreter shutdown: the library / torch may be gone already
+                pass
+
+    def __del__(self):
+        self._forget_ahead()
 
     def step(self, uid, iid, inv_b=None, pred=None, phase_ms=None, next_batch=None):
         """Runs one training step; returns the device loss tensor (shape [1], no sync).
@@ -427,6 +440,7 @@ class BprmfTrainer:
         f32 = torch.float32
         if next_batch is not None and phase_ms is None and tuple(next_batch[1].shape) == (B, Cn):
             nu, ni = next_batch
+            self._looked_ahead = True
             _lib.call("rc_bprmf_train_step_ahead",
                       _ptr(self.U, f32, "U"), _ptr(self.I, f32, "I"),
                       _ptr(self.mU, f32, "mU", True), _ptr(self.vU, f32, "vU", True),
