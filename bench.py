@@ -8,9 +8,11 @@ already resident in HBM.  Prints ONE JSON line (rank 0).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--opt SGD|Adam|Adagrad]
 
-N > 1 is launched by torch.distributed.run (one rank per GPU): the tables are row-sharded over
-the ranks and every step trains ONE global batch of N*B tuples (rechorus_amd/sharded.py; DESIGN.md
-section 7).  --parallel replicas runs N independent single-GPU jobs instead (no exchange).
+N > 1: one rank per GPU over RCCL.  `python bench.py --gpus N` starts its own N rank processes (rendezvous on
+127.0.0.1); launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` it uses the ranks it
+is given.  The tables are row-sharded over the ranks and every step trains ONE global batch of N*B tuples
+(rechorus_amd/sharded.py); --workload deepfm replicates the model and all-reduces its dense
+gradients (sharded.DataParallelDense).  --parallel replicas runs N independent single-GPU jobs instead (no exchange).
 """
 import os as _os
 
@@ -169,7 +171,7 @@ class DeepfmBench:
     the reference's exact optimizer semantics) through the plugin's model file; the step is what BaseRunner.fit runs
     (model(batch) -> loss -> backward -> optimizer.step), replayed from a hipGraph like the runner does by default."""
 
-    def __init__(self, args, device):
+    def __init__(self, args, device, data_parallel=False):
         import argparse as ap
         sys.path.insert(0, os.path.join(ROOT, "rechorus_amd", "rechorus"))
         from helpers.BaseRunner import BaseRunner
@@ -181,13 +183,24 @@ class DeepfmBench:
         corpus = ap.Namespace(n_users=self.vocab["user_id"], n_items=self.vocab["item_id"], user_feature_names=["u_group_c"],
                               item_feature_names=["i_category_c", "i_subcategory_c"],
                               situation_feature_names=["c_hour_c", "c_period_c", "c_weekday_c"], feature_max=self.vocab)
+        torch.manual_seed(1234)   # replicated parameters: the same initial values on every rank
         self.model = DeepFMCTR(margs, corpus).to(device)
         ra = BaseRunner.parse_runner_args(ap.ArgumentParser()).parse_args([])
         ra.train, ra.log_file, ra.lr, ra.l2, ra.optimizer = 1, "/tmp/rc_bench/l.txt", args.lr, args.l2, args.opt
         self.model.optimizer = BaseRunner(ra)._build_optimizer(self.model)
-        self.graphed = hgraph.GraphedStep(self.model) if hgraph.usable() else None
+        self.dp = None
+        if data_parallel:
+            from rechorus_amd.sharded import DataParallelDense
+            self.dp = DataParallelDense(self.model)
+        # one GPU: the step is replayed from a hipGraph like the runner does; data-parallel: eager (the collective sits
+        # between backward and the optimizer step)
+        self.graphed = hgraph.GraphedStep(self.model) if (hgraph.usable() and self.dp is None) else None
         self.loss = None
         self.timing = None
+
+    @property
+    def wire(self):
+        return {"dense_gradient_allreduce": self.dp.bytes_per_step} if self.dp is not None and self.dp.bytes_per_step else None
 
     def batches(self, args, device, seed):
         g = torch.Generator(device=device)
@@ -202,6 +215,9 @@ class DeepfmBench:
         return out
 
     def step(self, f):
+        if self.dp is not None:
+            self.loss = self.dp.step(f)
+            return self.loss
         if self.timing is None and self.graphed is not None:
             self.loss = self.graphed.run(f)
             return self.loss
@@ -282,7 +298,8 @@ def algorithmic_bytes(args, batches):
     # Adagrad: state_sum) every touched row goes through the segmented update (csrc/train_step.hip)
     fast_path = args.opt == "SGD"
     n_state = {"SGD": 0, "Adagrad": 1, "Adam": 2}[args.opt]
-    fused = (8 * B + 8 * n_occ + (n_occ if fast_path else 0)  # uid, iid, singleton flags
+    bitmap = args.items / 8.0    # multi-occurrence bitmap over the item ids (what the fused kernel looks its candidates up in)
+    fused = (8 * B + 8 * n_occ + (bitmap if fast_path else 0)  # uid, iid, bitmap
              + uu * row + ui * row      # distinct user / item rows, read once
              + (us * row if fast_path else 0)   # single-occurrence item rows written back updated
              + 4 * n_occ + B * row + 4 * B)   # gpred, ugrad, loss_vec written
@@ -292,12 +309,14 @@ def algorithmic_bytes(args, batches):
                    + uu * row           # U rows rebuilt into g*U: distinct rows once
                    + 2 * (1 + n_state) * upd_rows * row)  # row (+ state rows): read + written once
     user_update = 16 * uu + 4 * B + B * row + 2 * (1 + n_state) * uu * row
-    # bucket plan: ids read by the count and by the scatter kernel, bucketed keys written; the bucket kernel reads
-    # them twice, writes the flag bytes of single-occurrence rows, the grouped positions and the row records
-    sort_items = 2 * 8 * (n_occ + B) + 8 * (n_occ + B)
-    mark = 2 * 8 * (n_occ + B) + (n_occ if fast_path else 0) + 4 * upd_occ + 16 * (upd_rows + uu)
+    # bucket plan front: ids read by the count and by the scatter kernel, bucketed keys written as a 2-byte id stream + a
+    # 4-byte position stream, the bitmap kernel reads the id stream and writes the bitmap; per-bucket pass: id stream
+    # twice + positions once, grouped positions and row records written
+    n = n_occ + B
+    front = 2 * 8 * n + 6 * n + (2 * n + bitmap if fast_path else 0)
+    back = 2 * 2 * n + 4 * n + 4 * (upd_occ + B) + 16 * (upd_rows + uu)
     return {"fused_fwd_bwd": fused, "item_update": item_update, "user_update": user_update,
-            "sort_items": sort_items, "segment_heads": mark, "uniq_items": ui, "uniq_users": uu,
+            "sort_items": front, "segment_heads": back, "uniq_items": ui, "uniq_users": uu,
             "single_items": us, "multi_items": um, "multi_item_occurrences": mo}
 
 
@@ -446,6 +465,61 @@ def model_roofline(args, trainer, batches, engine):
     return out
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N rank processes of this very command line (one per GPU,
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, rendezvous on 127.0.0.1), pass rank 0's output
+    through, and fail if any rank fails (the others are then stopped by their exact PIDs)."""
+    import subprocess
+    port = os.environ.get("MASTER_PORT") or str(_free_port())
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RC_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the host driver only supports dmabuf IPC (RCCL needs it)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                code = p.poll()
+                if code is None:
+                    continue
+                pending.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code
+                    for q in pending:      # one rank failed: the others would wait in a collective forever
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+def launch_check(rank, world, backend):
+    """RC_BENCH_LAUNCH_ONLY=1: the rank processes only rendezvous, reduce one number and print the line -- what the CPU
+    test of the self-launcher runs (no GPU, no hot path; not a measurement)."""
+    import torch.distributed as dist
+    dist.init_process_group(backend, rank=rank, world_size=world)
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": world, "max_rank_plus_one": float(t.item()),
+                          "env": {k: os.environ.get(k) for k in ("WORLD_SIZE", "MASTER_ADDR", "LOCAL_RANK")}}))
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -454,8 +528,11 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 "
-                         "--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+        # not started by a launcher: be the launcher
+        raise SystemExit(launch_ranks(args.gpus))
+    if os.environ.get("RC_BENCH_LAUNCH_ONLY") == "1":
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        return launch_check(rank, world, "gloo")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     # RC_BENCH_ONE_DEVICE=1 + --dist-backend gloo: smoke-test the N>1 code path on a 1-GPU box
@@ -477,9 +554,9 @@ def main():
 
     batches = make_batches(args, device, seed=99 + rank) if args.workload not in ("sasrec", "deepfm") else None
     if args.workload == "deepfm":
-        if world > 1 and args.parallel != "replicas":
-            raise SystemExit("--workload deepfm: one GPU (or --parallel replicas) in bench.py; the data-parallel leg is rechorus_amd/sharded.py::DataParallelDense")
-        trainer = DeepfmBench(args, device)
+        # N > 1 (BASELINE configs[4] is an 8-GPU config): replicated model, every rank trains its own B rows, ONE flat
+        # all-reduce of the dense gradients per step, the same dense optimizer step everywhere (DataParallelDense)
+        trainer = DeepfmBench(args, device, data_parallel=(world > 1 and args.parallel != "replicas"))
         batches = trainer.batches(args, device, seed=99 + rank)
     elif args.workload == "sasrec":
         if world > 1 and args.parallel != "replicas":
@@ -592,6 +669,8 @@ def main():
             "n_items": args.items, "n_users": args.users, "optimizer": args.opt,
             "parallelism": "single GPU" if world == 1 else (
                 f"{world} independent replicas" if args.parallel == "replicas" else
+                (f"model replicated on {world} GPUs, dense gradients summed in one flat all-reduce over RCCL per step "
+                 f"(sharded.DataParallelDense), global batch {world * args.batch}") if args.workload == "deepfm" else
                 f"tables row-sharded over {world} GPUs (id mod W), {'rows travel' if args.workload == 'neumf' else 'owner-computes exchange'} over RCCL, "
                 f"global batch {world * args.batch}"),
         },
@@ -599,12 +678,19 @@ def main():
     }
 
     if rank == 0 and not args.no_roofline and hasattr(trainer, "profile_step"):
-        # per-phase hipEvent timing on the launch stream, measured live (profiling steps are
-        # outside the timed region above)
+        # per-phase hipEvent timing on the launch stream, measured live (profiling steps are outside the timed region
+        # above).  The profiled step is in the state of the timed loop: the previous step announced its batch, so its plan
+        # is already prepared and it starts with the fused kernel; nothing runs beside that kernel (the plan of the
+        # FOLLOWING batch is forked off behind it -- and not at all in a profiled step, whose updates therefore run
+        # alone too).
         acc = {}
         reps = 10
+        big = args.batch * (args.num_neg + 2) > 32768     # (smaller batches take the two-launch step: no plan, no look-ahead)
         for s in range(reps):
-            ph = trainer.profile_step(*batches[s % len(batches)])
+            a, b = batches[(2 * s) % len(batches)], batches[(2 * s + 1) % len(batches)]
+            if big:
+                trainer.step(*a, next_batch=b)
+            ph = trainer.profile_step(*b)
             for k, v in ph.items():
                 acc[k] = acc.get(k, 0.0) + v / reps
         ab = algorithmic_bytes(args, batches)
@@ -619,25 +705,33 @@ def main():
             "algorithmic_bytes_per_launch": ab[dom], "avg_ms": acc[dom],
         }
         out["phases_ms"] = {k: round(v, 4) for k, v in acc.items()}
-        # In the timed configuration the plan's per-bucket pass runs on a second stream BESIDE the fused kernel, which
-        # lengthens that kernel (and is what `roofline` above reports, live).  The same kernel with nothing beside it
-        # (the bucket plan on one stream, rc_bprmf_step_pipeline(2)): what the kernel itself reaches.
-        if dom == "fused_fwd_bwd" and args.batch * (args.num_neg + 2) > 32768:
+        if big:
+            # The plan itself (in the timed loop it runs on the second stream beside the previous step's row updates):
+            # its two halves alone, from a step that has to plan its own batch on ONE stream (rc_bprmf_step_pipeline(2)),
+            # and the fused kernel of a step that plans its own batch on two streams (the per-bucket pass beside it).
             from rechorus_amd import _lib as _rl
             lib = _rl.load()
+            plan_ms = {"front_partition_bitmap": 0.0, "bucket_pass": 0.0}
             prev = lib.rc_bprmf_step_pipeline(2)
             try:
-                alone = 0.0
                 for s in range(reps):
-                    alone += trainer.profile_step(*batches[s % len(batches)])["fused_fwd_bwd"] / reps
+                    ph = trainer.profile_step(*batches[s % len(batches)])
+                    plan_ms["front_partition_bitmap"] += ph["sort_items"] / reps
+                    plan_ms["bucket_pass"] += ph["segment_heads"] / reps
             finally:
                 lib.rc_bprmf_step_pipeline(prev)
-            out["roofline"]["alone"] = {"avg_ms": alone, "achieved": ab[dom] / (alone * 1e-3) / 1e9,
-                                        "frac": ab[dom] / (alone * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                                        "note": "same kernel, bucket plan on one stream (nothing overlapped with it)"}
+            own = 0.0
+            for s in range(reps):
+                own += trainer.profile_step(*batches[s % len(batches)])["fused_fwd_bwd"] / reps
+            out["plan_ms"] = {k: round(v, 4) for k, v in plan_ms.items()}
+            if dom == "fused_fwd_bwd":
+                out["roofline"]["note"] = ("steady state of the timed loop: the batch's plan was prepared beside the previous step's "
+                                           "updates, nothing runs beside the fused kernel")
+                out["roofline"]["unprepared"] = {"avg_ms": own, "achieved": ab[dom] / (own * 1e-3) / 1e9,
+                                                 "frac": ab[dom] / (own * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                                 "note": "same kernel in a step that plans its own batch (per-bucket pass on the second stream beside it)"}
         out["phases_gbps"] = {k: round(ab[k] / (acc[k] * 1e-3) / 1e9, 1)
-                              for k in ("fused_fwd_bwd", "item_update", "user_update", "sort_items",
-                                        "segment_heads") if acc.get(k, 0) > 0}
+                              for k in ("fused_fwd_bwd", "item_update", "user_update") if acc.get(k, 0) > 0}
         out["uniq_rows_per_step"] = {"items": ab["uniq_items"], "users": ab["uniq_users"],
                                      "items_single": ab["single_items"], "items_multi": ab["multi_items"],
                                      "multi_item_occurrences": ab["multi_item_occurrences"]}
@@ -647,16 +741,17 @@ def main():
             8 * args.batch * (args.num_neg + 2) + 4 * args.batch * (args.num_neg + 1)
         out["step_effective_gbps"] = whole / (out["ms_per_step"] * 1e-3) / 1e9
 
-    if world > 1 and args.parallel == "sharded" and not args.no_roofline and hasattr(trainer, "timing_ms"):
-        # where a sharded step spends its time (cuda events on every rank, outside the timed region):
+    timed = getattr(trainer, "dp", None) or trainer
+    if world > 1 and args.parallel == "sharded" and not args.no_roofline and hasattr(timed, "timing_ms"):
+        # where a multi-GPU step spends its time (cuda events on every rank, outside the timed region):
         # collectives are inside the phases, so this also shows what xGMI costs
-        trainer.timing = []
+        timed.timing = []
         acc, reps = {}, 3
         for s in range(reps):
-            run_step(s)
-            for k, v in trainer.timing_ms().items():
+            run_step(args.warmup + args.steps + s)   # (continues the announced batch sequence)
+            for k, v in timed.timing_ms().items():
                 acc[k] = acc.get(k, 0.0) + v / reps
-        trainer.timing = None
+        timed.timing = None
         if rank == 0:
             out["sharded_phases_ms"] = {k: round(v, 4) for k, v in acc.items()}
     if world > 1 and rank == 0 and getattr(trainer, "wire", None):
@@ -667,8 +762,9 @@ def main():
     if rank == 0 and world == 1 and not args.no_roofline and isinstance(trainer, (engine.NeumfTrainer, engine.SasrecTrainer)):
         out.update(model_roofline(args, trainer, batches, engine))
 
-    if rank == 0 and world == 1 and args.workload == "deepfm":
+    if args.workload == "deepfm":
         out["metric"] = "labelled rows/sec (CTR: one tuple = one (user, item, context, label) row)"
+    if rank == 0 and world == 1 and args.workload == "deepfm":
         if not args.no_roofline:
             out.update(deepfm_roofline(args, trainer, batches, engine))
         if not args.no_cpu_baseline:

@@ -193,6 +193,15 @@ int rc_bprmf_fwd_bwd_update(const float* U, float* I, float* mI, float* vI,
                             float* pred, float* loss_vec, float* gpred, float* ugrad,
                             rc_stream_t stream);
 
+/* The same with the singleton information as a bitmap over item ids (rc_bucket_multi_bitmap / the bucket plan of
+ * rc_bprmf_train_step): a row is updated here iff its bit is 0.  The kernel looks the tuple's candidates up in the
+ * bitmap itself (L2-resident), so no per-position flag array crosses HBM.                                     */
+int rc_bprmf_fwd_bwd_update_bitmap(const float* U, float* I, float* mI, float* vI,
+                                   const int64_t* uid, const int64_t* iid, const uint32_t* multi,
+                                   int B, int C, int d, float inv_b, const rc_opt_hyper* h,
+                                   float* pred, float* loss_vec, float* gpred, float* ugrad,
+                                   rc_stream_t stream);
+
 /* ---- index sort (the atomic-free replacement of embedding_dense_backward's index_add) */
 
 size_t rc_sort_workspace_bytes(int64_t n);
@@ -518,6 +527,15 @@ int rc_bucket_plan(const int64_t* ids_a, int64_t n_a, int64_t range_a, const int
                    uint32_t* n_rows_a, rc_plan_row* rows_b, uint32_t* n_rows_b, uint32_t* occ, void* ws,
                    size_t ws_bytes, rc_stream_t stream);
 
+/* The singleton information alone, as a bitmap over the ids of ONE list: bit (id & 31) of bitmap[id >> 5] = 1 iff
+ * row id occurs at least twice in ids_a[0 .. n_a) (words of id ranges the batch does not touch are left unwritten).
+ * This is what the fused BPRMF kernel consumes in the bucket-plan step (rc_bprmf_fwd_bwd_update_bitmap): 1.25 MB for
+ * a 10 M-row table, L2-resident, written as one coalesced 1 KB run per 8,192-id bucket -- instead of one flag byte per
+ * batch position.  bitmap: rc_bucket_bitmap_bytes(range_a) bytes; ws: rc_bucket_plan_workspace_bytes(n_a, 0).      */
+size_t rc_bucket_bitmap_bytes(int64_t range_a);
+int rc_bucket_multi_bitmap(const int64_t* ids_a, int64_t n_a, int64_t range_a, uint32_t* bitmap, void* ws,
+                           size_t ws_bytes, rc_stream_t stream);
+
 /* Optimizer row update of the rows listed by a plan (csrc/plan_update.hip): per row, the gradient rows of its
  * occurrences are summed in ascending batch position (fixed order, no float atomics), the table row is read once,
  * updated by `h` (row-wise: only listed rows move) and written once; rows with more than 32 occurrences go
@@ -572,20 +590,45 @@ int rc_bprmf_train_step(float* U, float* I, float* mU, float* vU, float* mI, flo
                         float inv_b, float* loss_out, float* pred, void* ws,
                         size_t ws_bytes, rc_stream_t stream, float* phase_ms);
 
-/* rc_bprmf_train_step with a look-ahead: next_uid [B] / next_iid [B, C] are the ids of the FOLLOWING call (same shapes,
- * same workspace; the reference's loop knows them too -- its DataLoader runs ahead of helpers/BaseRunner.py:186).  The
- * id-grouping front of that batch (histogram, stable partition, singleton flags) is enqueued on the library's second
- * stream beside THIS step's row updates, so the following call starts directly with its fused kernel.  Results are
- * bit-identical to rc_bprmf_train_step; a following call with other ids simply redoes the front.  NULL next pointers,
- * stream capture, optimizers with state and batches that take the small-batch or the sort pipeline: no look-ahead.   */
+/* ---- look-ahead across steps ---------------------------------------------------------------------------------
+ * The reference's loop knows the following batch while it trains on the current one (its DataLoader runs ahead of
+ * helpers/BaseRunner.py:186).  rc_bprmf_train_step_ahead uses that: given the ids of the FOLLOWING call it enqueues
+ * that batch's complete bucket plan (histogram, stable partition, multi-occurrence bitmap, row records, grouped
+ * positions) on the library's second stream beside THIS step's row updates, into the second plan slot of the same
+ * workspace, so that the following call starts directly with its fused kernel.
+ *
+ * What was prepared, for which batch, is recorded in a CALLER-OWNED ticket -- the library keeps no batch state.
+ * Batches are identified by the caller's generation ids (any non-zero number that changes whenever the CONTENTS of
+ * the id buffers change: a running batch counter), never by pointer: refilling the same buffers in place with a new
+ * batch and a new generation simply misses, and the step plans that batch itself.  Zero-initialise the ticket; one
+ * ticket per workspace; while a ticket holds a prepared plan (generation != 0) the workspace must not be used by
+ * calls that do not pass this ticket, and next_uid / next_iid must stay alive and unchanged until consumed.        */
+typedef struct rc_step_ticket {
+  uint64_t generation; /* generation id of the batch whose plan is prepared in the workspace; 0 = none */
+  uint64_t ws;         /* address of the workspace it was written into                               */
+  int32_t slot;        /* plan slot (0 / 1)                                                          */
+  int32_t device;      /* HIP device of the side stream that wrote it                                */
+  int32_t B, C, d;     /* geometry it was prepared for                                               */
+  int32_t flavour;     /* 1: bitmap + multi-occurrence rows (SGD fast path), 2: every row listed      */
+  int64_t n_users, n_items;
+  uint64_t reserved[2];
+} rc_step_ticket;
+
+/* rc_bprmf_train_step with the look-ahead.  generation: id of THIS batch (0 = unknown: never matches a ticket);
+ * next_uid [B] / next_iid [B, C] / next_generation: the following call's batch (same shapes, same workspace), or
+ * NULL / 0 for none.  A ticket prepared for exactly (generation, workspace, geometry, optimizer class) is consumed;
+ * anything else is discarded (after waiting for the side stream) and the step plans its batch itself.  Results are
+ * bit-identical to rc_bprmf_train_step in every case.  No look-ahead is PREPARED under stream capture, with phase_ms
+ * (profiling: a matching ticket is still consumed), or for batches that take the small-batch / sort pipeline.      */
 int rc_bprmf_train_step_ahead(float* U, float* I, float* mU, float* vU, float* mI, float* vI,
-                              const int64_t* uid, const int64_t* iid, const int64_t* next_uid,
-                              const int64_t* next_iid, int B, int C, int d, int64_t n_users, int64_t n_items,
+                              const int64_t* uid, const int64_t* iid, uint64_t generation,
+                              const int64_t* next_uid, const int64_t* next_iid, uint64_t next_generation,
+                              rc_step_ticket* ticket, int B, int C, int d, int64_t n_users, int64_t n_items,
                               const rc_opt_hyper* h, float inv_b, float* loss_out, float* pred, void* ws,
-                              size_t ws_bytes, rc_stream_t stream);
-/* Forget a front prepared by rc_bprmf_train_step_ahead (call before the workspace it was written into is freed or
- * re-allocated): `stream` waits for the second stream's writes into that workspace.                              */
-int rc_bprmf_step_ahead_reset(rc_stream_t stream);
+                              size_t ws_bytes, rc_stream_t stream, float* phase_ms);
+/* Forget a plan prepared by rc_bprmf_train_step_ahead (call before the workspace it was written into is freed or
+ * re-allocated): `stream` waits for the second stream's writes into that workspace; the ticket is cleared.        */
+int rc_bprmf_step_ahead_reset(rc_step_ticket* ticket, rc_stream_t stream);
 
 #ifdef __cplusplus
 }

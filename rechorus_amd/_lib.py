@@ -40,8 +40,27 @@ class OptHyper(C.Structure):
     ]
 
 
+class StepTicket(C.Structure):
+    """struct rc_step_ticket: what rc_bprmf_train_step_ahead prepared for which batch (caller-owned, zero-initialised)"""
+    _fields_ = [
+        ("generation", C.c_uint64),
+        ("ws", C.c_uint64),
+        ("slot", C.c_int32),
+        ("device", C.c_int32),
+        ("B", C.c_int32),
+        ("C", C.c_int32),
+        ("d", C.c_int32),
+        ("flavour", C.c_int32),
+        ("n_users", C.c_int64),
+        ("n_items", C.c_int64),
+        ("reserved", C.c_uint64 * 2),
+    ]
+
+
 _p = C.c_void_p
 _i = C.c_int
+_u64 = C.c_uint64
+_tp = C.POINTER(StepTicket)
 _i64 = C.c_int64
 _f = C.c_float
 _sz = C.c_size_t
@@ -125,9 +144,12 @@ SIGNATURES = {
     "rc_bprmf_step_pipeline": (_i, [_i]),
     "rc_bprmf_train_step": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i64, _i64, _hp, _f,
                                  _p, _p, _p, _sz, _p, C.POINTER(C.c_float)]),
-    "rc_bprmf_step_ahead_reset": (_i, [_p]),
-    "rc_bprmf_train_step_ahead": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i64, _i64, _hp, _f,
-                                       _p, _p, _p, _sz, _p]),
+    "rc_bprmf_step_ahead_reset": (_i, [_tp, _p]),
+    "rc_bprmf_train_step_ahead": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _u64, _p, _p, _u64, _tp, _i, _i, _i, _i64, _i64, _hp, _f,
+                                       _p, _p, _p, _sz, _p, C.POINTER(C.c_float)]),
+    "rc_bucket_bitmap_bytes": (_sz, [_i64]),
+    "rc_bucket_multi_bitmap": (_i, [_p, _i64, _i64, _p, _p, _sz, _p]),
+    "rc_bprmf_fwd_bwd_update_bitmap": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _hp, _p, _p, _p, _p, _p]),
 }
 
 _lib = None

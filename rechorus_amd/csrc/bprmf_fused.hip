@@ -276,35 +276,53 @@ extern "C" int rc_bprmf_fwd_bwd(const float* U, const float* I, const int64_t* u
   return RC_OK;
 }
 
+static int fwd_bwd_update_impl(const char* who, const float* U, float* I, float* mI, float* vI, const int64_t* uid,
+                               const int64_t* iid, const uint8_t* single, const uint32_t* multi, int B, int C, int d,
+                               float inv_b, const rc_opt_hyper* h, float* pred, float* loss_vec, float* gpred, float* ugrad,
+                               rc_stream_t stream) {
+  if (B == 0) return RC_OK;
+  RC_REQUIRE(U && I && uid && iid && (single || multi) && h && loss_vec && gpred && ugrad, "%s: null pointer", who);
+  RC_REQUIRE(B > 0 && C >= 2 && d >= 1, "%s: bad shape B=%d C=%d d=%d", who, B, C, d);
+  if (!register_path_ok(d, C))
+    return fail(RC_ERR_UNSUPPORTED,
+                "%s: no register-resident kernel for d=%d C=%d "
+                "(check rc_bprmf_fused_supported; use rc_bprmf_fwd_bwd + rc_segmented_update)", who, d, C);
+  FusedCall f;
+  memset(&f, 0, sizeof(f));
+  RC_TRY(fill_opt_scalars(h, &f.upd.o));
+  f.mode = mode_of(h);
+  RC_REQUIRE(f.mode != MODE_ADAM || (mI && vI), "%s: Adam needs mI and vI", who);
+  RC_REQUIRE(f.mode != MODE_ADAGRAD || mI, "%s: Adagrad needs mI", who);
+  RC_REQUIRE(aligned16(U) && aligned16(I) && aligned16(ugrad) && aligned16(mI) && aligned16(vI),
+             "%s: tables must be 16-byte aligned", who);
+  f.U = U; f.I = I; f.uid = uid; f.iid = iid; f.B = B; f.C = C; f.inv_b = inv_b;
+  f.pred = pred; f.loss_vec = loss_vec; f.gpred = gpred; f.ugrad = ugrad;
+  f.upd.I = I; f.upd.M = mI; f.upd.V = vI; f.upd.single = single; f.upd.multi = multi;
+  f.s = as_stream(stream);
+  bool handled = false;
+  const int rc_ = run_fused(f, d, &handled);
+  if (!handled) return fail(RC_ERR_UNSUPPORTED, "%s: dispatch failed", who);
+  return rc_;
+}
+
 extern "C" int rc_bprmf_fwd_bwd_update(const float* U, float* I, float* mI, float* vI,
                                        const int64_t* uid, const int64_t* iid,
                                        const uint8_t* single, int B, int C, int d, float inv_b,
                                        const rc_opt_hyper* h, float* pred, float* loss_vec,
                                        float* gpred, float* ugrad, rc_stream_t stream) {
-  if (B == 0) return RC_OK;
-  RC_REQUIRE(U && I && uid && iid && single && h && loss_vec && gpred && ugrad,
-             "rc_bprmf_fwd_bwd_update: null pointer");
-  RC_REQUIRE(B > 0 && C >= 2 && d >= 1, "rc_bprmf_fwd_bwd_update: bad shape B=%d C=%d d=%d", B, C, d);
-  if (!register_path_ok(d, C))
-    return fail(RC_ERR_UNSUPPORTED,
-                "rc_bprmf_fwd_bwd_update: no register-resident kernel for d=%d C=%d "
-                "(check rc_bprmf_fused_supported; use rc_bprmf_fwd_bwd + rc_segmented_update)", d, C);
-  FusedCall f;
-  memset(&f, 0, sizeof(f));
-  RC_TRY(fill_opt_scalars(h, &f.upd.o));
-  f.mode = mode_of(h);
-  RC_REQUIRE(f.mode != MODE_ADAM || (mI && vI), "rc_bprmf_fwd_bwd_update: Adam needs mI and vI");
-  RC_REQUIRE(f.mode != MODE_ADAGRAD || mI, "rc_bprmf_fwd_bwd_update: Adagrad needs mI");
-  RC_REQUIRE(aligned16(U) && aligned16(I) && aligned16(ugrad) && aligned16(mI) && aligned16(vI),
-             "rc_bprmf_fwd_bwd_update: tables must be 16-byte aligned");
-  f.U = U; f.I = I; f.uid = uid; f.iid = iid; f.B = B; f.C = C; f.inv_b = inv_b;
-  f.pred = pred; f.loss_vec = loss_vec; f.gpred = gpred; f.ugrad = ugrad;
-  f.upd.I = I; f.upd.M = mI; f.upd.V = vI; f.upd.single = single;
-  f.s = as_stream(stream);
-  bool handled = false;
-  const int rc_ = run_fused(f, d, &handled);
-  if (!handled) return fail(RC_ERR_UNSUPPORTED, "rc_bprmf_fwd_bwd_update: dispatch failed");
-  return rc_;
+  if (B != 0) RC_REQUIRE(single, "rc_bprmf_fwd_bwd_update: null pointer");
+  return fwd_bwd_update_impl("rc_bprmf_fwd_bwd_update", U, I, mI, vI, uid, iid, single, nullptr, B, C, d, inv_b, h, pred,
+                             loss_vec, gpred, ugrad, stream);
+}
+
+extern "C" int rc_bprmf_fwd_bwd_update_bitmap(const float* U, float* I, float* mI, float* vI,
+                                              const int64_t* uid, const int64_t* iid,
+                                              const uint32_t* multi, int B, int C, int d, float inv_b,
+                                              const rc_opt_hyper* h, float* pred, float* loss_vec,
+                                              float* gpred, float* ugrad, rc_stream_t stream) {
+  if (B != 0) RC_REQUIRE(multi, "rc_bprmf_fwd_bwd_update_bitmap: null pointer");
+  return fwd_bwd_update_impl("rc_bprmf_fwd_bwd_update_bitmap", U, I, mI, vI, uid, iid, nullptr, multi, B, C, d, inv_b, h, pred,
+                             loss_vec, gpred, ugrad, stream);
 }
 
 namespace rc {

@@ -88,7 +88,8 @@ PlanWs carve_plan_ws(void* base, int64_t n) {
   w.hist = cv.take<uint32_t>((size_t)kPlanMaxBuckets * tiles);
   w.totals = cv.take<uint32_t>(kPlanMaxBuckets);
   w.bucket_base = cv.take<uint32_t>(kPlanMaxBuckets + 1);
-  w.keys = cv.take<uint64_t>((size_t)n);
+  w.lid = cv.take<uint16_t>((size_t)n);
+  w.pos = cv.take<uint32_t>((size_t)n);
   w.counters = cv.take<uint32_t>(PC_N);
   w.total = cv.off;
   return w;
@@ -311,7 +312,9 @@ __global__ __launch_bounds__(kPlanThreads) void plan_scatter_kernel(PlanArgs a) 
   const uint32_t tile_n = a.n - tile0 < (uint32_t)kPlanTile ? a.n - tile0 : (uint32_t)kPlanTile;
   for (uint32_t i = threadIdx.x; i < tile_n; i += kPlanThreads) {
     const uint32_t e = image[i];
-    a.w.keys[gdelta[image_b[i]] + i] = ((uint64_t)(e >> 13) << 32) | (tile0 + (e & (kPlanTile - 1)));
+    const uint32_t at = gdelta[image_b[i]] + i;
+    a.w.lid[at] = (uint16_t)(e >> 13);
+    a.w.pos[at] = tile0 + (e & (kPlanTile - 1));
   }
 }
 
@@ -361,6 +364,27 @@ struct BucketCells {
   }
 };
 
+constexpr uint32_t kNoLid = 0xFFFFFFFFu;
+
+// occurrences per id of one bucket into the LDS cells (all threads of the workgroup, order-free LDS atomics);
+// reads the 2-byte id stream only
+template <bool WIDE>
+__device__ __forceinline__ void bucket_count_pass(const BucketCells<WIDE>& cells, const uint16_t* __restrict__ lid, uint32_t beg,
+                                                  uint32_t end, int tid) {
+  constexpr int kCountBatch = 8;
+  for (uint32_t j0 = beg; j0 < end; j0 += kBucketThreads * kCountBatch) {
+    uint32_t k[kCountBatch];
+#pragma unroll
+    for (int q = 0; q < kCountBatch; ++q) {
+      const uint32_t j = j0 + q * kBucketThreads + tid;
+      k[q] = j < end ? (uint32_t)lid[j] : kNoLid;
+    }
+#pragma unroll
+    for (int q = 0; q < kCountBatch; ++q)
+      if (k[q] != kNoLid) cells.add1(k[q]);
+  }
+}
+
 template <bool WIDE>
 __global__ __launch_bounds__(kBucketThreads) void plan_bucket_kernel(PlanArgs a) {
   extern __shared__ uint32_t tab[];  // table words + 256 pad words, then 16 words of scan scratch
@@ -386,18 +410,7 @@ __global__ __launch_bounds__(kBucketThreads) void plan_bucket_kernel(PlanArgs a)
   __syncthreads();
 
   // pass 1: occurrences per id
-  constexpr int kCountBatch = 8;
-  for (uint32_t j0 = beg; j0 < end; j0 += kBucketThreads * kCountBatch) {
-    uint64_t k[kCountBatch];
-#pragma unroll
-    for (int q = 0; q < kCountBatch; ++q) {
-      const uint32_t j = j0 + q * kBucketThreads + tid;
-      k[q] = j < end ? a.w.keys[j] : ~0ull;
-    }
-#pragma unroll
-    for (int q = 0; q < kCountBatch; ++q)
-      if (k[q] != ~0ull) cells.add1((uint32_t)(k[q] >> 32));
-  }
+  bucket_count_pass<WIDE>(cells, a.w.lid, beg, end, tid);
   __syncthreads();
 
   // scan: counts -> cursors (listed rows) / marker (rows that are only flagged); row records
@@ -451,27 +464,32 @@ __global__ __launch_bounds__(kBucketThreads) void plan_bucket_kernel(PlanArgs a)
 
   // pass 2 (wave 0): positions into their row's slots, ascending
   uint8_t* single = (side_b || a.flags_done) ? nullptr : a.single_a;
-  uint64_t cur_k[kBucketBatch], nxt_k[kBucketBatch];
+  uint32_t cur_l[kBucketBatch], nxt_l[kBucketBatch], cur_p[kBucketBatch], nxt_p[kBucketBatch];
 #pragma unroll
   for (int q = 0; q < kBucketBatch; ++q) {
     const uint32_t j = beg + q * 64 + lane;
-    nxt_k[q] = j < end ? a.w.keys[j] : ~0ull;
+    nxt_l[q] = j < end ? (uint32_t)a.w.lid[j] : kNoLid;
+    nxt_p[q] = j < end ? a.w.pos[j] : 0u;
   }
   for (uint32_t j0 = beg; j0 < end; j0 += 64 * kBucketBatch) {
 #pragma unroll
-    for (int q = 0; q < kBucketBatch; ++q) cur_k[q] = nxt_k[q];
+    for (int q = 0; q < kBucketBatch; ++q) {
+      cur_l[q] = nxt_l[q];
+      cur_p[q] = nxt_p[q];
+    }
     const uint32_t jn = j0 + 64 * kBucketBatch;
 #pragma unroll
     for (int q = 0; q < kBucketBatch; ++q) {  // next batch's keys travel while this one is placed
       const uint32_t j = jn + q * 64 + lane;
-      nxt_k[q] = j < end ? a.w.keys[j] : ~0ull;
+      nxt_l[q] = j < end ? (uint32_t)a.w.lid[j] : kNoLid;
+      nxt_p[q] = j < end ? a.w.pos[j] : 0u;
     }
 #pragma unroll
     for (int q = 0; q < kBucketBatch; ++q) {
       if (j0 + q * 64 >= end) break;  // wave-uniform
-      const bool valid = cur_k[q] != ~0ull;
-      const uint32_t lid = (uint32_t)(cur_k[q] >> 32);
-      const uint32_t p = (uint32_t)cur_k[q];
+      const bool valid = cur_l[q] != kNoLid;
+      const uint32_t lid = cur_l[q];
+      const uint32_t p = cur_p[q];
       uint32_t old = 0, now = 1;
       if (valid) {
         old = cells.add1_rtn(lid);
@@ -497,11 +515,18 @@ __global__ __launch_bounds__(kBucketThreads) void plan_bucket_kernel(PlanArgs a)
   }
 }
 
-// ---- 4a. singleton flags alone (list a), all four waves, no ordering: what the fused BPRMF kernel waits for.
+// ---- 4a. the bitmap of multi-occurrence rows of list a: what the fused BPRMF kernel needs from the plan.
+// One workgroup per bucket: LDS count table from the 2-byte id stream (all four waves, order-free), then thread t
+// packs the cells of ids 32 t .. 32 t + 31 into one word -- bit = 1 iff the row occurs at least twice -- and the
+// bucket's words leave as ONE coalesced 1 KB store (8,192-id buckets).  Round 2 kept a flag byte per batch position:
+// 3.4 M scattered byte stores per step, one 32-byte sector each (0.22 GB counted for 57 MB algorithmic), plus a
+// second pass over 8-byte keys.  The bitmap of a 10 M-row table is 1.25 MB: it stays in every XCD's L2, and the
+// fused kernel looks its candidates up there (fused_body.hpp).  Words of empty buckets are not written and never
+// read (a lookup is always for an id of the batch).
 // The row records and grouped positions (plan_bucket_kernel, whose ordered pass is one wave per bucket) are needed
-// only by the updates AFTER the fused kernel, so the step runs them on a second stream behind it (train_step.hip).
+// only by the updates AFTER the fused kernel, so the step runs them on a second stream (train_step.hip).
 template <bool WIDE>
-__global__ __launch_bounds__(kBucketThreads) void plan_flags_kernel(PlanArgs a) {
+__global__ __launch_bounds__(kBucketThreads) void plan_bitmap_kernel(PlanArgs a) {
   extern __shared__ uint32_t tab[];
   const int tid = threadIdx.x;
   const uint32_t bkt = blockIdx.x;  // grid = nb_a: buckets of list a only
@@ -515,34 +540,19 @@ __global__ __launch_bounds__(kBucketThreads) void plan_flags_kernel(PlanArgs a) 
   const BucketCells<WIDE> cells{tab, per_shift};
   for (uint32_t i = tid; i < words; i += kBucketThreads) tab[i] = 0;
   __syncthreads();
-  constexpr int kBatch = 8;
-  for (uint32_t j0 = beg; j0 < end; j0 += kBucketThreads * kBatch) {
-    uint64_t k[kBatch];
-#pragma unroll
-    for (int q = 0; q < kBatch; ++q) {
-      const uint32_t j = j0 + q * kBucketThreads + tid;
-      k[q] = j < end ? a.w.keys[j] : ~0ull;
-    }
-#pragma unroll
-    for (int q = 0; q < kBatch; ++q)
-      if (k[q] != ~0ull) cells.add1((uint32_t)(k[q] >> 32));
-  }
+  bucket_count_pass<WIDE>(cells, a.w.lid, beg, end, tid);
   __syncthreads();
-  for (uint32_t j0 = beg; j0 < end; j0 += kBucketThreads * kBatch) {
-    uint64_t k[kBatch];
-#pragma unroll
-    for (int q = 0; q < kBatch; ++q) {
-      const uint32_t j = j0 + q * kBucketThreads + tid;
-      k[q] = j < end ? a.w.keys[j] : ~0ull;
-    }
-#pragma unroll
-    for (int q = 0; q < kBatch; ++q)
-      if (k[q] != ~0ull && cells.get((uint32_t)(k[q] >> 32)) == 1u) a.single_a[(uint32_t)k[q]] = 1;
+  uint32_t* out = a.bitmap_a + ((size_t)bkt << (shift - 5));
+  for (uint32_t w = tid; w < (ids >> 5); w += kBucketThreads) {
+    uint32_t bits = 0;
+#pragma unroll 8
+    for (uint32_t j = 0; j < 32; ++j) bits |= (cells.get(w * 32 + j) >= 2u ? 1u : 0u) << j;
+    out[w] = bits;
   }
 }
 
-// front: histogram, tile offsets, stable partition (+ the singleton flags of list a when `flags` is set)
-int plan_launch_front(const PlanArgs& a, bool flags, hipStream_t s) {
+// front: histogram, tile offsets, stable partition (+ the multi-occurrence bitmap of list a when `bitmap` is set)
+int plan_launch_front(const PlanArgs& a, bool bitmap, hipStream_t s) {
   const PlanGeom& g = a.g;
   const size_t hist_lds = (size_t)g.nb * sizeof(uint32_t);
   hipLaunchKernelGGL(plan_count_kernel, dim3(g.tiles), dim3(kPlanThreads), hist_lds, s, a);
@@ -553,13 +563,13 @@ int plan_launch_front(const PlanArgs& a, bool flags, hipStream_t s) {
   const size_t sc_lds = (nbp + kPlanTile + 2 * kPlanWaves) * sizeof(uint32_t) + ((size_t)kPlanTile + kPlanWaves * nbp) * sizeof(uint16_t);
   hipLaunchKernelGGL(plan_scatter_kernel, dim3(g.tiles), dim3(kPlanThreads), sc_lds, s, a);
   RC_LAUNCH_CHECK();
-  if (flags && a.single_a && g.nb_a > 0) {
+  if (bitmap && a.bitmap_a && g.nb_a > 0) {
     const size_t ids = (size_t)1 << g.shift;
     if (g.shift > 8) {
-      hipLaunchKernelGGL(plan_flags_kernel<false>, dim3(g.nb_a), dim3(kBucketThreads), (ids / 2 + kBucketThreads + 16) * sizeof(uint32_t), s, a);
+      hipLaunchKernelGGL(plan_bitmap_kernel<false>, dim3(g.nb_a), dim3(kBucketThreads), (ids / 2 + kBucketThreads + 16) * sizeof(uint32_t), s, a);
       RC_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(plan_flags_kernel<true>, dim3(g.nb_a), dim3(kBucketThreads), (ids + kBucketThreads + 16) * sizeof(uint32_t), s, a);
+    hipLaunchKernelGGL(plan_bitmap_kernel<true>, dim3(g.nb_a), dim3(kBucketThreads), (ids + kBucketThreads + 16) * sizeof(uint32_t), s, a);
     RC_LAUNCH_CHECK();
   }
   return RC_OK;
@@ -639,4 +649,28 @@ extern "C" int rc_bucket_plan(const int64_t* ids_a, int64_t n_a, int64_t range_a
   a.list_single_a = list_single_a; a.single_a = single_a;
   a.rows_a = rows_a; a.rows_b = rows_b; a.n_rows_a = n_rows_a; a.n_rows_b = n_rows_b; a.occ = occ;
   return plan_launch(a, s, nullptr);
+}
+
+extern "C" size_t rc_bucket_bitmap_bytes(int64_t range_a) {
+  if (range_a < 1) return 0;
+  return (size_t)((range_a + ((int64_t)1 << kPlanMaxShift) - 1) >> kPlanMaxShift) << (kPlanMaxShift - 3);
+}
+
+extern "C" int rc_bucket_multi_bitmap(const int64_t* ids_a, int64_t n_a, int64_t range_a, uint32_t* bitmap, void* ws,
+                                      size_t ws_bytes, rc_stream_t stream) {
+  RC_REQUIRE(n_a >= 0 && n_a < ((int64_t)1 << 31), "rc_bucket_multi_bitmap: sizes out of range");
+  if (n_a == 0) return RC_OK;
+  RC_REQUIRE(ids_a && bitmap && ws, "rc_bucket_multi_bitmap: null pointer");
+  PlanArgs a;
+  memset(&a, 0, sizeof(a));
+  a.g = plan_geometry(n_a, 0, range_a, 0);
+  if (!a.g.ok)
+    return fail(RC_ERR_UNSUPPORTED, "rc_bucket_multi_bitmap: id range %lld needs more than %d buckets of %d ids",
+                (long long)range_a, kPlanMaxBuckets, 1 << kPlanMaxShift);
+  a.w = carve_plan_ws(ws, n_a);
+  if (ws_bytes < a.w.total) return fail(RC_ERR_WORKSPACE, "rc_bucket_multi_bitmap: workspace %zu < %zu", ws_bytes, a.w.total);
+  RC_TRY(plan_prepare());
+  a.ids_a = ids_a; a.n_a = (uint32_t)n_a; a.n = (uint32_t)n_a; a.range_a = range_a;
+  a.bitmap_a = bitmap;
+  return plan_launch_front(a, true, as_stream(stream));
 }

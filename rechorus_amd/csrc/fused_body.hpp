@@ -11,7 +11,8 @@ struct FusedUpd {     // singleton-row update (unused when MODE == MODE_NONE)
   float* I;           // the item table again, writable (no __restrict__: aliases the input)
   float* M;
   float* V;
-  const uint8_t* single;
+  const uint8_t* single;   // flag byte per batch position (sort pipeline: rc_segment_heads), or
+  const uint32_t* multi;   // bitmap over item ids, bit = 1 iff the row occurs at least twice in the batch (bucket plan)
   OptScalars o;
 };
 
@@ -92,7 +93,34 @@ __device__ __forceinline__ void bprmf_fwd_bwd_body(
     r[j] = load_stream4(reinterpret_cast<const float4*>(I + id * D) + l);
   }
   unsigned smask = 0;  // bit j: candidate slot j of this group is a singleton row
-  if (MODE != MODE_NONE) {
+  if (MODE != MODE_NONE && upd.multi != nullptr) {
+    // bucket plan: the singleton information is a bitmap over item ids (1.25 MB at 10 M rows: L2-resident).  Lane i
+    // looks up candidates i, i + 64, ... of its tuple (the id loads are coalesced and hit the lines the row gathers
+    // above brought in), a ballot turns the bits into wave-uniform masks, and every lane-group picks its candidates'
+    // bits out of them -- no per-position flag array exists in HBM any more.
+    if (S == 64 && C <= 128) {
+      const int c0 = lane, c1 = lane + 64;
+      const int64_t ia = ids[c0 < C ? c0 : 0];
+      const int64_t ib = ids[c1 < C ? c1 : 0];
+      const uint32_t wa = upd.multi[ia >> 5];
+      const uint32_t wb = C > 64 ? upd.multi[ib >> 5] : 0u;
+      const uint64_t m_lo = __ballot(c0 < C && ((wa >> (ia & 31)) & 1u));
+      const uint64_t m_hi = __ballot(c1 < C && ((wb >> (ib & 31)) & 1u));
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) {
+        const int c = j * GS + grp;
+        const uint64_t bit = (c < 64 ? m_lo : m_hi) >> (c & 63);
+        if (tv && c < C && !(bit & 1ull)) smask |= 1u << j;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) {
+        const int c = j * GS + grp;
+        const int64_t id = ids[c < C ? c : 0];
+        if (tv && c < C && !((upd.multi[id >> 5] >> (id & 31)) & 1u)) smask |= 1u << j;
+      }
+    }
+  } else if (MODE != MODE_NONE) {
     if (S == 64 && GS == 4 && (C & 3) == 0) {
       // the tuple's C flag bytes as C/4 dwords in ONE coalesced load (lane k holds candidates 4k..4k+3); dword j is
       // then a wave-uniform value (readlane with a constant lane) whose byte `grp` is this group's candidate j*4+grp.

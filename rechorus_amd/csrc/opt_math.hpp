@@ -85,7 +85,12 @@ __device__ __forceinline__ void opt_elem(const OptScalars& a, float g, float& w,
 
 // row write-back: the row is not read again in this step -> non-temporal store (-DRC_NO_NT: plain)
 __device__ __forceinline__ void store_row4(float4* p, const float4& x) {
-#if !defined(RC_NO_NT) && !defined(RC_NO_NT_STORE)
+#if defined(RC_STORE_SC1)
+  // experiment switch: write-through store that does not keep the line in this XCD's L2 (MI355X_MICROARCH.md, store flavours)
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  const v4f v = {x.x, x.y, x.z, x.w};
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+#elif !defined(RC_NO_NT) && !defined(RC_NO_NT_STORE)
   typedef float v4f __attribute__((ext_vector_type(4)));
   v4f v = {x.x, x.y, x.z, x.w};
   __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(p));

@@ -34,7 +34,8 @@ struct PlanWs {            // carved from the caller's workspace
   uint32_t* hist;          // [nb][tiles] per-tile bucket counts -> exclusive prefixes
   uint32_t* totals;        // [nb]
   uint32_t* bucket_base;   // [nb + 1]
-  uint64_t* keys;          // [n] bucketed keys: (id within bucket << 32) | position
+  uint16_t* lid;           // [n] bucketed keys, split by consumer: id within its bucket (< 2^13) ...
+  uint32_t* pos;           // [n] ... and batch position (the singleton bitmap and the counting passes read lid only)
   uint32_t* counters;      // PC_N
   size_t total;
 };
@@ -54,11 +55,14 @@ struct PlanArgs {
   uint32_t* n_rows_a;      // device counters (may point into w.counters)
   uint32_t* n_rows_b;
   uint32_t* occ;           // [n]
-  int flags_done;          // single_a was filled by plan_launch_front(flags = true): the bucket kernel skips it
+  int flags_done;          // the singleton information exists already (bitmap_a from plan_launch_front): the bucket kernel skips single_a
+  uint32_t* bitmap_a;      // [nb_a << (shift - 5)] or null: bit (id) = 1 iff row id of list a occurs at least twice in the batch
 };
 int plan_launch(const PlanArgs& a, hipStream_t s, hipEvent_t* ev_after_scatter);
-// the same plan in two parts, so that a caller can run `back` on another stream (train_step.hip)
-int plan_launch_front(const PlanArgs& a, bool flags, hipStream_t s);
+// the same plan in two parts, so that a caller can run `back` on another stream (train_step.hip);
+// bitmap: also fill a.bitmap_a (what the fused BPRMF kernel needs from the plan)
+int plan_launch_front(const PlanArgs& a, bool bitmap, hipStream_t s);
+constexpr size_t kPlanBitmapWords = (size_t)kPlanMaxBuckets << (kPlanMaxShift - 5);   // capacity that fits every geometry
 int plan_launch_back(const PlanArgs& a, hipStream_t s);
 
 // ---- consumers --------------------------------------------------------------------------------------

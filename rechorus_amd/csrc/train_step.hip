@@ -15,6 +15,8 @@
 //
 // Ordering constraints: the item-row update reads U (pre-step values, to rebuild g*U[u]) so it runs
 // before the user rows are rewritten; the fused kernel reads both tables before either is updated.
+#include <mutex>
+
 #include "common.hpp"
 #include "plan.hpp"
 
@@ -36,50 +38,60 @@ int small_step_launch(float* U, float* I, float* mU, float* vU, float* mI, float
 }
 
 // The second stream of the step.  The bucket plan's per-bucket pass (row records + grouped positions) is index work
-// that only the updates need; the fused kernel needs at most the singleton flags.  So the step forks: the fused
+// that only the updates need; the fused kernel needs at most the multi-occurrence bitmap.  So the step forks: the fused
 // kernel runs on the caller's stream while plan_launch_back runs on this side stream, and the updates wait for both.
-// Created once per process (non-blocking: the caller's stream may be the legacy null stream); fork / join are
-// event dependencies, so the call stays capturable in a hipGraph.  RC_BPRMF_STEP=serial keeps everything on one stream.
+// One record per device, created on first use (non-blocking stream: the caller's stream may be the legacy null
+// stream); fork / join are event dependencies, so the call stays capturable in a hipGraph.  RC_BPRMF_STEP=serial keeps
+// everything on one stream.  These are resources (a stream, four events), not batch state: what was prepared for which
+// batch lives in the CALLER's rc_step_ticket.
 namespace {
 struct StepSide {
   hipStream_t stream = nullptr;
   hipEvent_t fork = nullptr, join = nullptr, fork2 = nullptr, front_done = nullptr;
-  bool ok = false;
+  bool tried = false, ok = false;
 };
-StepSide& step_side() {
-  static StepSide sd = [] {
-    StepSide x;
-    if (hipStreamCreateWithFlags(&x.stream, hipStreamNonBlocking) == hipSuccess &&
-        hipEventCreateWithFlags(&x.fork, hipEventDisableTiming) == hipSuccess &&
-        hipEventCreateWithFlags(&x.join, hipEventDisableTiming) == hipSuccess &&
-        hipEventCreateWithFlags(&x.fork2, hipEventDisableTiming) == hipSuccess &&
-        hipEventCreateWithFlags(&x.front_done, hipEventDisableTiming) == hipSuccess)
-      x.ok = true;
-    return x;
-  }();
-  return sd;
+constexpr int kMaxDevices = 64;
+StepSide* step_side(int* device_out = nullptr) {
+  static StepSide sides[kMaxDevices];
+  static std::mutex mu;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
+  if (device_out) *device_out = dev;
+  std::lock_guard<std::mutex> lock(mu);
+  StepSide& x = sides[dev];
+  if (!x.tried) {
+    x.tried = true;
+    x.ok = hipStreamCreateWithFlags(&x.stream, hipStreamNonBlocking) == hipSuccess &&
+           hipEventCreateWithFlags(&x.fork, hipEventDisableTiming) == hipSuccess &&
+           hipEventCreateWithFlags(&x.join, hipEventDisableTiming) == hipSuccess &&
+           hipEventCreateWithFlags(&x.fork2, hipEventDisableTiming) == hipSuccess &&
+           hipEventCreateWithFlags(&x.front_done, hipEventDisableTiming) == hipSuccess;
+  }
+  return x.ok ? &x : nullptr;
 }
-
-// Look-ahead across steps (rc_bprmf_train_step_ahead): the plan's FRONT of the next batch (histogram, partition,
-// singleton flags: 0.155 ms on the critical path of the SGD step at config 2) runs on the side stream beside THIS step's
-// row updates, so that the next call starts with its fused kernel.  What was prepared, for which batch and workspace:
-struct Ahead {
-  bool valid = false;
-  const void* ws = nullptr;
-  const int64_t* uid = nullptr;
-  const int64_t* iid = nullptr;
-  int B = 0, C = 0, d = 0, slot = 0;
-  int64_t n_users = 0, n_items = 0;
-};
-Ahead& step_ahead() {
-  static Ahead a;
-  return a;
+// where the look-ahead plan of the next batch is forked off: 0 = behind the fused kernel (beside this step's row
+// updates), 1 = at the start of the step (beside the fused kernel as well); RC_AHEAD_FORK=early selects 1
+int ahead_fork_mode() {
+  static int mode = [] {
+    const char* v = getenv("RC_AHEAD_FORK");
+    return (v && strcmp(v, "early") == 0) ? 1 : 0;
+  }();
+  return mode;
 }
 }  // namespace
 
 using namespace rc;
 
 namespace {
+// one complete bucket plan of a batch: partition buffers, row records, grouped positions, multi-occurrence bitmap.
+// Two slots: the step works from one while the look-ahead writes the plan of the following batch into the other.
+struct PlanSlot {
+  PlanWs plan;
+  rc_plan_row* rows_i;
+  rc_plan_row* rows_u;
+  uint32_t* occ;
+  uint32_t* bitmap;
+};
 struct StepWs {
   uint32_t* keys_i;
   uint32_t* perm_i;
@@ -96,13 +108,9 @@ struct StepWs {
   void* seg_ws;
   size_t seg_ws_bytes;
   // bucket-plan step (the default where the id space allows it)
-  PlanWs plan;
+  PlanSlot slot[2];
   PlanLongWs plan_long;
-  rc_plan_row* rows_i;
-  rc_plan_row* rows_u;
-  uint32_t* occ;
   void* small_extra;     // small-batch step (small_step.hip): user-row snapshot, per-workgroup row / position segments
-  uint32_t* counters2;   // second counter block: the look-ahead front of the next batch zeroes / fills the one this step does not use
   size_t total;
 };
 
@@ -126,23 +134,24 @@ StepWs carve_step_ws(void* base, int B, int C, int d) {
   w.sort_ws = cv.take<char>(w.sort_ws_bytes);
   w.seg_ws_bytes = rc_segmented_workspace_bytes((int64_t)n_i, d);
   w.seg_ws = cv.take<char>(w.seg_ws_bytes);
-  // the two pipelines never run in the same call: the plan buffers overlay the sort / segment scratch
+  // the pipelines never run in the same call: the plan buffers overlay the sort / segment scratch
   // (everything after loss_vec)
   Carver pv(base);
   pv.off = plan_off;
-  w.single = pv.take<uint8_t>(align_up(n_i, (size_t)kPlanTile));
-  {
+  for (int k = 0; k < 2; ++k) {
     const PlanWs pw = carve_plan_ws(base ? reinterpret_cast<char*>(base) + pv.off : nullptr, (int64_t)n_i + B);
-    w.plan = pw;
+    w.slot[k].plan = pw;
     pv.off += align_up(pw.total, 256);
+    w.slot[k].rows_i = pv.take<rc_plan_row>(n_i);
+    w.slot[k].rows_u = pv.take<rc_plan_row>((size_t)B);
+    w.slot[k].occ = pv.take<uint32_t>(n_i + (size_t)B);
+    w.slot[k].bitmap = pv.take<uint32_t>(kPlanBitmapWords);
+  }
+  {
     const PlanLongWs lw = carve_plan_long_ws(base ? reinterpret_cast<char*>(base) + pv.off : nullptr, (int64_t)n_i + B, d);
     w.plan_long = lw;
     pv.off += align_up(lw.total, 256);
   }
-  w.rows_i = pv.take<rc_plan_row>(n_i);
-  w.rows_u = pv.take<rc_plan_row>((size_t)B);
-  w.occ = pv.take<uint32_t>(n_i + (size_t)B);
-  w.counters2 = pv.take<uint32_t>(PC_N);
   w.total = cv.off > pv.off ? cv.off : pv.off;
   // the small-batch step's buffers overlay the same region (the pipelines never run in the same call)
   w.small_extra = base ? reinterpret_cast<char*>(base) + plan_off : nullptr;
@@ -151,6 +160,26 @@ StepWs carve_step_ws(void* base, int B, int C, int d) {
     if (need > w.total) w.total = need;
   }
   return w;
+}
+
+// the plan of one batch in slot `k`
+PlanArgs slot_plan_args(const StepWs& w, int k, const int64_t* uid, const int64_t* iid, int64_t n_i, int B, int64_t n_users,
+                        int64_t n_items, const PlanGeom& geom, bool fused_upd) {
+  PlanArgs pa;
+  memset(&pa, 0, sizeof(pa));
+  const PlanSlot& sl = w.slot[k];
+  pa.ids_a = iid; pa.ids_b = uid; pa.n_a = (uint32_t)n_i; pa.n = (uint32_t)(n_i + B);
+  pa.range_a = n_items; pa.range_b = n_users;
+  pa.g = geom;
+  pa.w = sl.plan;
+  pa.list_single_a = fused_upd ? 0 : 1;
+  pa.single_a = nullptr;
+  pa.bitmap_a = fused_upd ? sl.bitmap : nullptr;
+  pa.flags_done = 1;   // singleton information, where needed, is the bitmap
+  pa.rows_a = sl.rows_i; pa.rows_b = sl.rows_u;
+  pa.n_rows_a = &sl.plan.counters[PC_ROWS_A]; pa.n_rows_b = &sl.plan.counters[PC_ROWS_B];
+  pa.occ = sl.occ;
+  return pa;
 }
 }  // namespace
 
@@ -176,12 +205,20 @@ extern "C" size_t rc_bprmf_step_workspace_bytes(int B, int C, int d) {
   return carve_step_ws(nullptr, B, C, d).total;
 }
 
+static bool ticket_matches(const rc_step_ticket* t, uint64_t generation, const void* ws, int device, int B, int C, int d,
+                           int64_t n_users, int64_t n_items, int flavour) {
+  return t != nullptr && generation != 0 && t->generation == generation && t->ws == reinterpret_cast<uintptr_t>(ws) &&
+         t->device == device && t->B == B && t->C == C && t->d == d && t->n_users == n_users && t->n_items == n_items &&
+         t->flavour == flavour && (t->slot == 0 || t->slot == 1);
+}
+
 static int train_step_impl(float* U, float* I, float* mU, float* vU, float* mI, float* vI,
                            const int64_t* uid, const int64_t* iid, int B, int C, int d,
                            int64_t n_users, int64_t n_items, const rc_opt_hyper* h,
                            float inv_b, float* loss_out, float* pred, void* ws,
                            size_t ws_bytes, rc_stream_t stream, float* phase_ms,
-                           const int64_t* next_uid, const int64_t* next_iid) {
+                           uint64_t generation, const int64_t* next_uid, const int64_t* next_iid, uint64_t next_generation,
+                           rc_step_ticket* ticket) {
   RC_REQUIRE(U && I && uid && iid && h && loss_out && ws, "rc_bprmf_train_step: null pointer");
   RC_REQUIRE(B >= 1 && C >= 2 && d >= 1, "rc_bprmf_train_step: bad shape B=%d C=%d d=%d", B, C, d);
   RC_REQUIRE((int64_t)B * C < ((int64_t)1 << 31), "rc_bprmf_train_step: B*C too large");
@@ -191,14 +228,6 @@ static int train_step_impl(float* U, float* I, float* mU, float* vU, float* mI, 
     return fail(RC_ERR_WORKSPACE, "rc_bprmf_train_step: workspace %zu < %zu", ws_bytes, w.total);
   hipStream_t s = as_stream(stream);
   const int64_t n_i = (int64_t)B * C;
-  // a front prepared ahead by the previous call: usable when it was made for exactly this batch and workspace;
-  // in every case its kernels (side stream) have to be finished before this call touches the plan buffers
-  Ahead& ahead = step_ahead();
-  const bool ahead_hit = ahead.valid && ahead.ws == ws && ahead.uid == uid && ahead.iid == iid && ahead.B == B && ahead.C == C &&
-                         ahead.d == d && ahead.n_users == n_users && ahead.n_items == n_items;
-  const int slot = ahead_hit ? ahead.slot : 0;
-  if (ahead.valid) RC_HIP(hipStreamWaitEvent(s, step_side().front_done, 0));
-  ahead.valid = false;
 
   constexpr int kMarks = 8;
   hipEvent_t ev[kMarks];
@@ -221,7 +250,26 @@ static int train_step_impl(float* U, float* I, float* mU, float* vU, float* mI, 
 #else
   const bool fused_upd = rc_bprmf_fused_supported(d, C) != 0 && h->opt == RC_OPT_SGD;
 #endif
-  // Pipeline choice: the bucket plan (bucket_plan.hip + plan_update.hip, 8 launches) where the register-resident
+  const int flavour = fused_upd ? 1 : 2;   // what a prepared plan contains: bitmap + multi rows / every row listed
+
+  // A plan prepared ahead by an earlier call (rc_step_ticket, caller-owned): usable when it was made for exactly this
+  // batch -- the caller's generation id, not a pointer, says so -- workspace, geometry and plan flavour.  In every case
+  // the side stream's writes into the workspace have to be finished before this call touches the plan buffers.
+  int device = 0;
+  StepSide* side = step_side(&device);
+  bool ahead_hit = false;
+  int slot = 0;
+  if (ticket != nullptr && ticket->generation != 0) {
+    RC_REQUIRE(ticket->device == device, "rc_bprmf_train_step_ahead: the ticket was prepared on device %d, current device %d",
+               ticket->device, device);
+    RC_REQUIRE(side != nullptr, "rc_bprmf_train_step_ahead: side stream unavailable on device %d", device);
+    ahead_hit = ticket_matches(ticket, generation, ws, device, B, C, d, n_users, n_items, flavour);
+    if (ahead_hit) slot = ticket->slot;
+    RC_HIP(hipStreamWaitEvent(s, side->front_done, 0));
+    ticket->generation = 0;
+  }
+
+  // Pipeline choice: the bucket plan (bucket_plan.hip + plan_update.hip) where the register-resident
   // fused kernel exists and the joint id space fits one bucket level; otherwise (and with RC_BPRMF_STEP=sort)
   // the round-1 pipeline: joint radix sort -> segment heads -> fused -> segmented updates.
   const bool force_sort = step_pipeline() == 1;
@@ -241,69 +289,63 @@ static int train_step_impl(float* U, float* I, float* mU, float* vU, float* mI, 
   } else
   if (!force_sort && geom.ok && fused_ok && (d == 16 || d == 32 || d == 64 || d == 128)) {
     RC_TRY(plan_prepare());
-    PlanArgs pa;
-    memset(&pa, 0, sizeof(pa));
-    pa.ids_a = iid; pa.ids_b = uid; pa.n_a = (uint32_t)n_i; pa.n = (uint32_t)(n_i + B);
-    pa.range_a = n_items; pa.range_b = n_users;
-    pa.g = geom;
-    pa.w = w.plan;
-    uint32_t* ctr = slot ? w.counters2 : w.plan.counters;   // (the other block belongs to a look-ahead front)
-    pa.w.counters = ctr;
-    pa.list_single_a = fused_upd ? 0 : 1;
-    pa.single_a = fused_upd ? w.single : nullptr;
-    pa.rows_a = w.rows_i; pa.rows_b = w.rows_u;
-    pa.n_rows_a = &ctr[PC_ROWS_A]; pa.n_rows_b = &ctr[PC_ROWS_B];
-    pa.occ = w.occ;
-    StepSide& side = step_side();
-    const bool two_streams = (step_pipeline() == 0 || step_pipeline() == 3) && side.ok;
+    const PlanArgs pa = slot_plan_args(w, slot, uid, iid, n_i, B, n_users, n_items, geom, fused_upd);
+    const bool two_streams = (step_pipeline() == 0 || step_pipeline() == 3) && side != nullptr;
+    // Look-ahead: the WHOLE plan of the next batch (partition, bitmap, row records, grouped positions) into the other
+    // slot, on the side stream.  Not under stream capture (the next call's wait on front_done would cross graphs), not
+    // in profiling mode (the phases are measured without it).
+    bool look_ahead = two_streams && ticket != nullptr && next_generation != 0 && next_uid != nullptr && next_iid != nullptr && !prof;
+    if (look_ahead) {
+      hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+      look_ahead = hipStreamIsCapturing(s, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone;
+    }
+    auto launch_ahead = [&]() -> int {
+      const PlanArgs pn = slot_plan_args(w, 1 - slot, next_uid, next_iid, n_i, B, n_users, n_items, geom, fused_upd);
+      RC_HIP(hipEventRecord(side->fork2, s));
+      RC_HIP(hipStreamWaitEvent(side->stream, side->fork2, 0));
+      RC_TRY(plan_launch_front(pn, fused_upd, side->stream));
+      RC_TRY(plan_launch_back(pn, side->stream));
+      RC_HIP(hipEventRecord(side->front_done, side->stream));
+      ticket->generation = next_generation;
+      ticket->ws = reinterpret_cast<uintptr_t>(ws);
+      ticket->slot = 1 - slot; ticket->device = device; ticket->B = B; ticket->C = C; ticket->d = d;
+      ticket->flavour = flavour; ticket->n_users = n_users; ticket->n_items = n_items;
+      return RC_OK;
+    };
     RC_MARK(0);
-    if (two_streams) {
-      // caller's stream: partition (+ singleton flags when the fused kernel updates them) -> fused kernel
+    if (ahead_hit) {
+      // the plan is complete (prepared beside the previous step): this step starts with its fused kernel
+      RC_MARK(1);
+    } else if (two_streams) {
+      // caller's stream: partition (+ bitmap when the fused kernel updates singleton rows) -> fused kernel
       // side stream:     per-bucket pass (row records, grouped positions), joined before the updates
       // (without the singleton fast path the fused kernel needs nothing from the plan: all of it runs on the side stream)
-      pa.flags_done = fused_upd ? 1 : 0;
-      if (fused_upd && !ahead_hit) RC_TRY(plan_launch_front(pa, true, s));   // (ahead_hit: done beside the previous step's updates)
+      if (fused_upd) RC_TRY(plan_launch_front(pa, true, s));
       RC_MARK(1);
-      RC_HIP(hipEventRecord(side.fork, s));
-      RC_HIP(hipStreamWaitEvent(side.stream, side.fork, 0));
-      if (!fused_upd) RC_TRY(plan_launch_front(pa, false, side.stream));
-      RC_TRY(plan_launch_back(pa, side.stream));
-      RC_HIP(hipEventRecord(side.join, side.stream));
+      RC_HIP(hipEventRecord(side->fork, s));
+      RC_HIP(hipStreamWaitEvent(side->stream, side->fork, 0));
+      if (!fused_upd) RC_TRY(plan_launch_front(pa, false, side->stream));
+      RC_TRY(plan_launch_back(pa, side->stream));
+      RC_HIP(hipEventRecord(side->join, side->stream));
     } else {
-      RC_TRY(plan_launch(pa, s, prof ? &ev[1] : nullptr));   // ev[1]: after the partition, before the bucket kernel
+      RC_TRY(plan_launch_front(pa, fused_upd, s));
+      RC_MARK(1);   // after the partition (+ bitmap), before the bucket kernel
+      RC_TRY(plan_launch_back(pa, s));
     }
+    if (look_ahead && ahead_fork_mode() == 1) RC_TRY(launch_ahead());
     RC_MARK(2);
     RC_MARK(3);
     if (fused_upd)
-      RC_TRY(rc_bprmf_fwd_bwd_update(U, I, mI, vI, uid, iid, w.single, B, C, d, inv_b, h, pred, w.loss_vec, w.gpred,
-                                     w.ugrad, stream));
+      RC_TRY(rc_bprmf_fwd_bwd_update_bitmap(U, I, mI, vI, uid, iid, w.slot[slot].bitmap, B, C, d, inv_b, h, pred, w.loss_vec,
+                                            w.gpred, w.ugrad, stream));
     else
       RC_TRY(rc_bprmf_fwd_bwd(U, I, uid, iid, B, C, d, inv_b, pred, w.loss_vec, w.gpred, w.ugrad, stream));
-    if (two_streams) RC_HIP(hipStreamWaitEvent(s, side.join, 0));
-    if (two_streams && fused_upd && next_uid != nullptr && next_iid != nullptr && !prof) {
-      // Look-ahead: the front of the NEXT batch on the side stream, beside this step's row updates.  It writes the
-      // histogram / bucketed keys / flags (all consumed by this step already: the fused kernel and the per-bucket pass are
-      // behind the join above) and zeroes the OTHER counter block.  Not under stream capture (the next call's wait
-      // on front_done would cross graphs).
-      hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-      if (hipStreamIsCapturing(s, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone) {
-        PlanArgs pn = pa;
-        pn.ids_a = next_iid; pn.ids_b = next_uid;
-        uint32_t* nctr = slot ? w.plan.counters : w.counters2;
-        pn.w.counters = nctr;
-        pn.n_rows_a = &nctr[PC_ROWS_A]; pn.n_rows_b = &nctr[PC_ROWS_B];
-        RC_HIP(hipEventRecord(side.fork2, s));
-        RC_HIP(hipStreamWaitEvent(side.stream, side.fork2, 0));
-        RC_TRY(plan_launch_front(pn, true, side.stream));
-        RC_HIP(hipEventRecord(side.front_done, side.stream));
-        ahead.valid = true; ahead.ws = ws; ahead.uid = next_uid; ahead.iid = next_iid; ahead.B = B; ahead.C = C; ahead.d = d;
-        ahead.n_users = n_users; ahead.n_items = n_items; ahead.slot = 1 - slot;
-      }
-    }
+    if (two_streams && !ahead_hit) RC_HIP(hipStreamWaitEvent(s, side->join, 0));
+    if (look_ahead && ahead_fork_mode() == 0) RC_TRY(launch_ahead());
     RC_MARK(4);
     RC_MARK(5);  // (the loss mean is one workgroup of the last update launch)
-    RC_TRY(plan_bprmf_step_updates(U, mU, vU, I, mI, vI, d, uid, C, n_i, B, w.gpred, w.ugrad, w.rows_i, pa.n_rows_a,
-                                   w.rows_u, pa.n_rows_b, w.occ, ctr, w.plan_long, h, w.loss_vec, inv_b,
+    RC_TRY(plan_bprmf_step_updates(U, mU, vU, I, mI, vI, d, uid, C, n_i, B, w.gpred, w.ugrad, pa.rows_a, pa.n_rows_a,
+                                   pa.rows_b, pa.n_rows_b, pa.occ, pa.w.counters, w.plan_long, h, w.loss_vec, inv_b,
                                    loss_out, s, prof ? &ev[6] : nullptr));
     RC_MARK(7);
   } else {
@@ -359,25 +401,35 @@ extern "C" int rc_bprmf_train_step(float* U, float* I, float* mU, float* vU, flo
                                    float inv_b, float* loss_out, float* pred, void* ws,
                                    size_t ws_bytes, rc_stream_t stream, float* phase_ms) {
   return train_step_impl(U, I, mU, vU, mI, vI, uid, iid, B, C, d, n_users, n_items, h, inv_b, loss_out, pred, ws, ws_bytes, stream,
-                         phase_ms, nullptr, nullptr);
+                         phase_ms, 0, nullptr, nullptr, 0, nullptr);
 }
 
 extern "C" int rc_bprmf_train_step_ahead(float* U, float* I, float* mU, float* vU, float* mI, float* vI,
-                                         const int64_t* uid, const int64_t* iid, const int64_t* next_uid,
-                                         const int64_t* next_iid, int B, int C, int d, int64_t n_users, int64_t n_items,
+                                         const int64_t* uid, const int64_t* iid, uint64_t generation,
+                                         const int64_t* next_uid, const int64_t* next_iid, uint64_t next_generation,
+                                         rc_step_ticket* ticket, int B, int C, int d, int64_t n_users, int64_t n_items,
                                          const rc_opt_hyper* h, float inv_b, float* loss_out, float* pred, void* ws,
-                                         size_t ws_bytes, rc_stream_t stream) {
+                                         size_t ws_bytes, rc_stream_t stream, float* phase_ms) {
+  RC_REQUIRE(ticket != nullptr, "rc_bprmf_train_step_ahead: ticket missing (caller-owned rc_step_ticket, zero-initialised)");
   return train_step_impl(U, I, mU, vU, mI, vI, uid, iid, B, C, d, n_users, n_items, h, inv_b, loss_out, pred, ws, ws_bytes, stream,
-                         nullptr, next_uid, next_iid);
+                         phase_ms, generation, next_uid, next_iid, next_generation, ticket);
 }
 
-// Forget a prepared front (the owner of the workspace goes away or re-allocates it): `stream` is made to wait for the
+// Forget a prepared plan (the owner of the workspace goes away or re-allocates it): `stream` is made to wait for the
 // side stream's writes into that workspace, so that whatever reuses the memory afterwards is ordered behind them.
-extern "C" int rc_bprmf_step_ahead_reset(rc_stream_t stream) {
-  Ahead& ahead = step_ahead();
-  if (ahead.valid) {
-    RC_HIP(hipStreamWaitEvent(as_stream(stream), step_side().front_done, 0));
-    ahead.valid = false;
+extern "C" int rc_bprmf_step_ahead_reset(rc_step_ticket* ticket, rc_stream_t stream) {
+  RC_REQUIRE(ticket != nullptr, "rc_bprmf_step_ahead_reset: ticket missing");
+  if (ticket->generation != 0) {
+    int cur = 0;
+    RC_HIP(hipGetDevice(&cur));
+    if (cur != ticket->device) RC_HIP(hipSetDevice(ticket->device));
+    StepSide* side = step_side();
+    int rc_ = RC_OK;
+    if (side != nullptr && hipStreamWaitEvent(as_stream(stream), side->front_done, 0) != hipSuccess)
+      rc_ = fail(RC_ERR_HIP, "rc_bprmf_step_ahead_reset: hipStreamWaitEvent failed");
+    if (cur != ticket->device) (void)hipSetDevice(cur);
+    ticket->generation = 0;
+    return rc_;
   }
   return RC_OK;
 }

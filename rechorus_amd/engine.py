@@ -189,6 +189,21 @@ def bucket_plan(ids_a, range_a, ids_b=None, range_b=0, list_single_a=True):
             "single": None if single is None else single[:n_a]}
 
 
+def bucket_multi_bitmap(ids, n_rows):
+    """rc_bucket_multi_bitmap: int32 words, bit (id & 31) of word id >> 5 = 1 iff row id occurs at least twice in `ids`
+    (words of id ranges the batch does not touch are unspecified: the buffer is NOT zero-filled)."""
+    a = ids.reshape(-1)
+    lib = _lib.load()
+    n = a.numel()
+    if not lib.rc_bucket_plan_supported(n, 0, int(n_rows), 0):
+        raise _lib.RechorusHipError("rc_bucket_plan_supported", -4, "id range too wide for one bucket level")
+    bm = torch.empty(max(lib.rc_bucket_bitmap_bytes(int(n_rows)) // 4, 1), dtype=torch.int32, device=a.device)
+    ws = workspace(lib.rc_bucket_plan_workspace_bytes(n, 0), a.device, "plan")
+    _lib.call("rc_bucket_multi_bitmap", _ptr(a, torch.int64, "ids") if n else None, n, int(n_rows), C.c_void_p(bm.data_ptr()),
+              C.c_void_p(ws.data_ptr()), ws.numel(), _stream())
+    return bm
+
+
 class Plan:
     """Device-side result of rc_bucket_plan with every distinct row listed (no host round trip: the row counts stay in
     device memory and the consumers read them there).  Buffers are cached per (device, tag) and reused every step."""
@@ -270,8 +285,9 @@ def mark_singletons(keys, perm):
     return segment_heads(keys, perm, want_heads=False)[0]
 
 
-def bprmf_fwd_bwd_update(U, I, uid, iid, single, hyper, mI=None, vI=None, inv_b=None, want_pred=False):
-    """Fused fwd/loss/bwd that also applies the optimizer to single-occurrence item rows."""
+def bprmf_fwd_bwd_update(U, I, uid, iid, single, hyper, mI=None, vI=None, inv_b=None, want_pred=False, multi=None):
+    """Fused fwd/loss/bwd that also applies the optimizer to single-occurrence item rows: `single` = uint8 flag per batch
+    position (segment_heads), or `multi` = the bitmap over item ids of bucket_multi_bitmap (single = None)."""
     B, Cn = iid.shape
     d = U.shape[1]
     if inv_b is None:
@@ -282,10 +298,11 @@ def bprmf_fwd_bwd_update(U, I, uid, iid, single, hyper, mI=None, vI=None, inv_b=
     loss_vec = torch.empty(B, dtype=f32, device=dev)
     gpred = torch.empty((B, Cn), dtype=f32, device=dev)
     ugrad = torch.empty((B, d), dtype=f32, device=dev)
-    _lib.call("rc_bprmf_fwd_bwd_update", _ptr(U, f32, "U"), _ptr(I, f32, "I"),
+    _lib.call("rc_bprmf_fwd_bwd_update_bitmap" if multi is not None else "rc_bprmf_fwd_bwd_update", _ptr(U, f32, "U"), _ptr(I, f32, "I"),
               _ptr(mI, f32, "mI", True), _ptr(vI, f32, "vI", True),
               _ptr(uid, torch.int64, "uid"), _ptr(iid, torch.int64, "iid"),
-              _ptr(single, torch.uint8, "single"), B, Cn, d, float(inv_b), C.byref(hyper),
+              _ptr(multi, torch.int32, "multi") if multi is not None else _ptr(single, torch.uint8, "single"),
+              B, Cn, d, float(inv_b), C.byref(hyper),
               _ptr(pred, f32, "pred", True), _ptr(loss_vec, f32, "loss_vec"),
               _ptr(gpred, f32, "gpred"), _ptr(ugrad, f32, "ugrad"), _stream())
     return pred, loss_vec, gpred, ugrad
@@ -401,6 +418,10 @@ class BprmfTrainer:
         self.loss = torch.zeros(1, dtype=torch.float32, device=U.device)
         self._ws = None
         self._ws_shape = None
+        # look-ahead across steps: the library records what it prepared in THIS caller-owned ticket (no hidden state)
+        self._ticket = _lib.StepTicket()
+        self._gen = 0            # generation ids handed out for announced batches
+        self._announced = None   # (uid, iid, uid._version, iid._version, generation) of the batch announced last
 
     def _workspace(self, B, Cn):
         if self._ws_shape != (B, Cn):
@@ -416,46 +437,60 @@ class BprmfTrainer:
         return self._ws
 
     def _forget_ahead(self):
-        """a front prepared by step(next_batch=...) lives in this trainer's workspace: drop it before the memory can be reused"""
-        if getattr(self, "_looked_ahead", False):
-            self._looked_ahead = False
+        """a plan prepared by step(next_batch=...) lives in this trainer's workspace: drop it before the memory can be reused"""
+        self._announced = None
+        if getattr(self, "_ticket", None) is not None and self._ticket.generation != 0:
             try:
-                _lib.call("rc_bprmf_step_ahead_reset", _stream())
+                _lib.call("rc_bprmf_step_ahead_reset", C.byref(self._ticket), _stream())
             except Exception:  # interpreter shutdown: the library / torch may be gone already
                 pass
 
     def __del__(self):
         self._forget_ahead()
 
-    def step(self, uid, iid, inv_b=None, pred=None, phase_ms=None, next_batch=None):
+    def _generation_of(self, uid, iid):
+        """generation id of (uid, iid) if it IS the batch announced by the previous step: the same tensor objects (strong
+        references are held, so an address cannot have been reused) with unchanged version counters (an in-place refill
+        through torch bumps them).  0 = unknown: the step plans the batch itself."""
+        a = self._announced
+        if a is not None and a[0] is uid and a[1] is iid and a[2] == uid._version and a[3] == iid._version:
+            return a[4]
+        return 0
+
+    def step(self, uid, iid, inv_b=None, pred=None, phase_ms=None, next_batch=None, generation=None, next_generation=None):
         """Runs one training step; returns the device loss tensor (shape [1], no sync).
         phase_ms: optional ctypes float[8] to receive per-phase hipEvent timings.
-        next_batch = (uid, iid) of the FOLLOWING step (same shapes): the grouping front of those ids runs beside this
-        step's row updates (rc_bprmf_train_step_ahead); the tensors must stay alive and unchanged until that step."""
+        next_batch = (uid, iid) of the FOLLOWING step (same shapes): the bucket plan of those ids is prepared beside this
+        step's row updates (rc_bprmf_train_step_ahead); the tensors must stay alive and unchanged until that step.
+        generation / next_generation: the caller's ids of this / the following batch's CONTENTS (non-zero ints that
+        change with every new batch) -- needed when batches are written into the same buffers by something torch's
+        version counters do not see (a kernel writing through data_ptr()); left None, the trainer identifies the
+        announced batch by tensor identity + version.  Pass them always or never."""
         B, Cn = iid.shape
         if inv_b is None:
             inv_b = 1.0 / B
         ws = self._workspace(B, Cn)
         self.hyper.step += 1
         f32 = torch.float32
-        if next_batch is not None and phase_ms is None and tuple(next_batch[1].shape) == (B, Cn):
+        if generation is None:
+            generation = self._generation_of(uid, iid)
+        nu = ni = None
+        ngen = 0
+        if next_batch is not None and tuple(next_batch[1].shape) == (B, Cn) and tuple(next_batch[0].shape) == (B,):
             nu, ni = next_batch
-            self._looked_ahead = True
-            _lib.call("rc_bprmf_train_step_ahead",
-                      _ptr(self.U, f32, "U"), _ptr(self.I, f32, "I"),
-                      _ptr(self.mU, f32, "mU", True), _ptr(self.vU, f32, "vU", True),
-                      _ptr(self.mI, f32, "mI", True), _ptr(self.vI, f32, "vI", True),
-                      _ptr(uid, torch.int64, "uid"), _ptr(iid, torch.int64, "iid"),
-                      _ptr(nu, torch.int64, "next_uid"), _ptr(ni, torch.int64, "next_iid"), B, Cn, self.d,
-                      self.U.shape[0], self.I.shape[0], C.byref(self.hyper), float(inv_b),
-                      _ptr(self.loss, f32, "loss"), _ptr(pred, f32, "pred", True),
-                      C.c_void_p(ws.data_ptr()), ws.numel(), _stream())
-            return self.loss
-        _lib.call("rc_bprmf_train_step",
+            if next_generation is None:
+                self._gen += 1
+                ngen = self._gen
+            else:
+                ngen = int(next_generation)
+        self._announced = (nu, ni, nu._version, ni._version, ngen) if nu is not None else None
+        _lib.call("rc_bprmf_train_step_ahead",
                   _ptr(self.U, f32, "U"), _ptr(self.I, f32, "I"),
                   _ptr(self.mU, f32, "mU", True), _ptr(self.vU, f32, "vU", True),
                   _ptr(self.mI, f32, "mI", True), _ptr(self.vI, f32, "vI", True),
-                  _ptr(uid, torch.int64, "uid"), _ptr(iid, torch.int64, "iid"), B, Cn, self.d,
+                  _ptr(uid, torch.int64, "uid"), _ptr(iid, torch.int64, "iid"), int(generation),
+                  _ptr(nu, torch.int64, "next_uid", True), _ptr(ni, torch.int64, "next_iid", True), ngen,
+                  C.byref(self._ticket), B, Cn, self.d,
                   self.U.shape[0], self.I.shape[0], C.byref(self.hyper), float(inv_b),
                   _ptr(self.loss, f32, "loss"), _ptr(pred, f32, "pred", True),
                   C.c_void_p(ws.data_ptr()), ws.numel(), _stream(),

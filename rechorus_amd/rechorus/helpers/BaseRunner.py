@@ -16,6 +16,8 @@ rc_target_rank, and `--test_all` on dot-product heads is rc_full_catalogue_rank 
 catalogue, the [N, n_items] matrix never exists); `predict` still returns the reference's ndarray.
 """
 import gc
+import inspect
+import itertools
 import logging
 import os
 from time import time
@@ -250,10 +252,19 @@ class BaseRunner(object):
         graphable = (self.use_graph and not rowwise and equivariant
                      and isinstance(model.optimizer, hnn.HipOptimizer) and model.optimizer.capturable
                      and torch.device(model.device).type == 'cuda' and hgraph.usable())
+        if rowwise:
+            # The engine's step is handed the FOLLOWING batch as well (the reference's DataLoader runs ahead of the loop
+            # too, :182-186): its id grouping is prepared beside this step's row updates (rc_bprmf_train_step_ahead).
+            # Models whose hip_train_step does not take `next_feed_dict` are called the plain way.
+            takes_next = 'next_feed_dict' in inspect.signature(model.hip_train_step).parameters
+            prev = None
+            for nxt in itertools.chain(self._batches(dataset, self.batch_size, train=True), [None]):
+                if prev is not None:
+                    kw = {'next_feed_dict': nxt} if (takes_next and nxt is not None) else {}
+                    losses.append(model.hip_train_step(prev, self.optimizer_name, self.learning_rate, self.l2, **kw).clone())
+                prev = nxt
+            return float(torch.cat([l.reshape(1) for l in losses]).mean().item()) if losses else float('nan')
         for batch in self._batches(dataset, self.batch_size, train=True):
-            if rowwise:
-                losses.append(model.hip_train_step(batch, self.optimizer_name, self.learning_rate, self.l2).clone())
-                continue
             if graphable:
                 key = (id(model), hgraph.GraphedStep.signature(batch))
                 step = self._graphed.get(key)

@@ -50,14 +50,20 @@ class BPRMFBase(object):
         return engine.gather_rows(self.u_embeddings.weight.detach(), feed_dict['user_id']), self.i_embeddings.weight.detach()
 
     # ---- large-table mode: the whole fit() iteration as one C-ABI call ---------------------
-    def hip_train_step(self, feed_dict, opt_name, lr, l2):
-        """forward + BPR loss + backward + row-wise optimizer update (rc_bprmf_train_step);
-        returns the device loss tensor without synchronising."""
+    def hip_train_step(self, feed_dict, opt_name, lr, l2, next_feed_dict=None):
+        """forward + BPR loss + backward + row-wise optimizer update (rc_bprmf_train_step_ahead);
+        returns the device loss tensor without synchronising.  next_feed_dict: the batch the following call will bring
+        (BaseRunner.fit passes it): its id grouping is prepared beside this step's row updates."""
         if self._trainer is None or self._trainer.opt != opt_name:
             self._trainer = engine.BprmfTrainer(self.u_embeddings.weight.data, self.i_embeddings.weight.data,
                                                 opt=opt_name, lr=lr, l2=l2)
+        nxt = None
+        if next_feed_dict is not None:
+            nu, ni = next_feed_dict['user_id'], next_feed_dict['item_id']
+            if nu.is_contiguous() and ni.is_contiguous():   # (the following call has to bring these very tensors)
+                nxt = (nu, ni)
         with torch.no_grad():
-            return self._trainer.step(feed_dict['user_id'].contiguous(), feed_dict['item_id'].contiguous())
+            return self._trainer.step(feed_dict['user_id'].contiguous(), feed_dict['item_id'].contiguous(), next_batch=nxt)
 
 
 _LOG = ['emb_size', 'batch_size']

@@ -356,7 +356,26 @@ def _record_stream(obj, stream):
             _record_stream(v, stream)
 
 
-class _LookAhead:
+class _Timed:
+    """per-phase cuda events of the last step (self.timing = [] switches it on; bench.py prints them as sharded_phases_ms)"""
+    timing = None
+
+    def _mark(self, label):
+        if self.timing is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self.timing.append((label, ev))
+
+    def timing_ms(self):
+        """per-phase milliseconds of the last step; synchronises.  Phases that occur several times (micro-batches) add up."""
+        torch.cuda.synchronize()
+        t, out = self.timing, {}
+        for i in range(1, len(t)):
+            out[t[i][0]] = out.get(t[i][0], 0.0) + t[i - 1][1].elapsed_time(t[i][1])
+        return out
+
+
+class _LookAhead(_Timed):
     """Shared by the sharded steps: `step(batch, next_batch=...)` routes the NEXT batch before this step's kernels.
     The routing needs host-visible sizes (torch.unique, the split sizes of the exchanges); on the caller's stream
     those device -> host copies would wait for everything enqueued before them, i.e. for the previous step.  So the
@@ -366,8 +385,15 @@ class _LookAhead:
 
     def _routes_of(self, uid, iid, next_batch):
         ahead, self._ahead = getattr(self, "_ahead", None), None
-        key = (uid.data_ptr(), iid.data_ptr(), tuple(iid.shape))
-        if ahead is not None and ahead["key"] == key:
+        if ahead is not None:
+            # The announced batch is identified by the tensor OBJECTS (strong references are kept in the record, so
+            # an address cannot have been reused by another batch) and their version counters.  Bringing anything
+            # else is an error, not a silent re-route: the ranks would disagree about hit / miss and issue different
+            # collective sequences (one extra count exchange on the missing rank = a hang).
+            au, ai, vu, vi = ahead["batch"]
+            if not (au is uid and ai is iid and vu == uid._version and vi == iid._version):
+                raise RuntimeError("sharded step: the batch announced with next_batch= has to be the one the next step() "
+                                   "brings, unchanged, on every rank (announce nothing if that is not known)")
             prep = ahead
             if prep.get("ready") is not None:
                 main = torch.cuda.current_stream(uid.device)
@@ -384,7 +410,9 @@ class _LookAhead:
 
     def _prepare_ahead(self, uid, iid):
         if not uid.is_cuda:
-            return self._prepare(uid, iid)
+            prep = self._prepare(uid, iid)
+            prep["batch"] = (uid, iid, uid._version, iid._version)
+            return prep
         if getattr(self, "_side", None) is None:
             self._side = torch.cuda.Stream(device=uid.device)
         begin = getattr(self, "_step_begin", None)
@@ -395,6 +423,7 @@ class _LookAhead:
             done = torch.cuda.Event()
             done.record(self._side)
         prep["ready"] = done
+        prep["batch"] = (uid, iid, uid._version, iid._version)
         return prep
 
     def _mark_step_begin(self, ref):
@@ -471,7 +500,7 @@ class ShardedBprmf(_LookAhead):
         else:
             ru = self._route(uid)
         ri = self._route(iid.reshape(-1)) if plan == "rows" else self._route(iid.reshape(-1), tuple_base=self.rank * B, div=C)
-        return {"key": (uid.data_ptr(), iid.data_ptr(), tuple(iid.shape)), "plan": plan, "u": ru, "i": ri, "inv": inv,
+        return {"plan": plan, "u": ru, "i": ri, "inv": inv,
                 "counts": _Counts([ru[1], ri[1]] + counts, self.group)}
 
     def step(self, uid, iid, next_batch=None):
@@ -666,18 +695,6 @@ class ShardedBprmf(_LookAhead):
         t_idx = (recv >> 32).contiguous()
         return t_idx, (recv & 0xFFFFFFFF).contiguous(), t_idx.to(torch.int32)
 
-    def _mark(self, label):
-        if self.timing is not None:
-            ev = torch.cuda.Event(enable_timing=True)
-            ev.record()
-            self.timing.append((label, ev))
-
-    def timing_ms(self):
-        """per-phase milliseconds of the last step (timing=True); synchronises"""
-        torch.cuda.synchronize()
-        t = self.timing
-        return {t[i][0]: t[i - 1][1].elapsed_time(t[i][1]) for i in range(1, len(t))}
-
     def _step_single(self, uid, iid, hyper):
         """W = 1: the same arithmetic without any exchange (reference point for the tests)"""
         ops = self.ops
@@ -840,7 +857,7 @@ class ShardedNeumf(_LookAhead):
         uc, ic = (torch.chunk(uid, M), torch.chunk(iid, M)) if M > 1 else ((uid,), (iid,))
         grouped = [(_Route.prepare(u, W, ops, self.dedup), _Route.prepare(i.reshape(-1), W, ops, self.dedup)) for u, i in zip(uc, ic)]
         counts = _Counts([g[0][1] for pair in grouped for g in pair], self.group)
-        return {"key": (uid.data_ptr(), iid.data_ptr(), tuple(iid.shape)), "uc": uc, "ic": ic, "grouped": grouped, "counts": counts}
+        return {"uc": uc, "ic": ic, "grouped": grouped, "counts": counts}
 
     def step(self, uid, iid, next_batch=None):
         """uid [B], iid [B, C]: this rank's tuples (same B everywhere) -> global mean loss, device tensor [1].
@@ -854,6 +871,10 @@ class ShardedNeumf(_LookAhead):
         hyper = ops.make_hyper(opt=self.opt, lr=self.lr, l2=self.l2, step=self.step_count)
         hyper0 = ops.make_hyper(opt=self.opt, lr=self.lr, l2=0.0, step=self.step_count)  # 'bias': no weight decay
         dev = uid.device
+        if self.timing is not None:
+            self.timing.clear()
+        mark = self._mark
+        mark("start")
         self._mark_step_begin(uid)
         if W > 1 and self.micro_batches > 1 and B >= self.micro_batches:
             return self._step_pipelined(uid, iid, hyper, hyper0, self._routes_of(uid, iid, next_batch))
@@ -868,8 +889,10 @@ class ShardedNeumf(_LookAhead):
             ru = _Route(uid, W, ops, self.group, splits=(sends[0], recvs[0]), prepared=pu_)
             rv = _Route(iid.reshape(-1), W, ops, self.group, splits=(sends[1], recvs[1]), prepared=pv_)
             self._account([ru, rv])
+            mark("route")
             urows = ru.fetch([self.P["mf_u"], self.P["mlp_u"]], ops)      # [B, 2d]
             irows = rv.fetch([self.P["mf_i"], self.P["mlp_i"]], ops)      # [B*C, 2d]
+        mark("fetch_rows")
         # the head kernels see per-batch row blocks as their "tables", ids are positions in them
         loc = {"mf_u": urows[:, :d].contiguous(), "mlp_u": urows[:, d:].contiguous(),
                "mf_i": irows[:, :d].contiguous(), "mlp_i": irows[:, d:].contiguous(),
@@ -879,9 +902,11 @@ class ShardedNeumf(_LookAhead):
         pred = ops.neumf_fwd(loc, pos_u, pos_i)
         loss_vec, g = ops.bpr_loss(pred, 1.0 / n_tuples)
         loss = loss_vec.sum().reshape(1) / n_tuples
+        mark("head_fwd_loss")
         rows, dense = ops.neumf_bwd(loc, pos_u, pos_i, g)
         gu = torch.cat([rows["g_mf_u"].view(B, C, d).sum(dim=1), rows["g_mlp_u"].view(B, C, d).sum(dim=1)], dim=1)
         gi = torch.cat([rows["g_mf_i"], rows["g_mlp_i"]], dim=1)
+        mark("head_bwd")
         if W > 1:
             loss = _all_reduce_sum(loss, self.group)
             own_u, own_i, req_u, req_i = ru.push(gu, ops), rv.push(gi, ops), ru.req, rv.req
@@ -894,6 +919,7 @@ class ShardedNeumf(_LookAhead):
                 o += n
         else:
             own_u, own_i, req_u, req_i = gu, gi, uid, iid.reshape(-1)
+        mark("push_grads")
         shared = hasattr(ops, "prepare_rows")  # one sort + head list per side, used by its mf and mlp table
         prep_u = ops.prepare_rows(req_u, self.P["mf_u"].shape[0]) if shared else None
         prep_i = ops.prepare_rows(req_i, self.P["mf_i"].shape[0]) if shared else None
@@ -905,8 +931,10 @@ class ShardedNeumf(_LookAhead):
             kw = {"prep": prep} if shared else {}
             ops.update_rows(self.P[ta], self.state[ta], req, ga, hyper, **kw)
             ops.update_rows(self.P[tb], self.state[tb], req, gb, hyper, **kw)
+        mark("table_update")
         for k in ("W1", "b1", "w_out"):
             ops.dense_update(self.P[k], dense[k].contiguous(), hyper0 if k == "b1" else hyper, self.state[k])
+        mark("dense_update")
         return loss
 
     def _account(self, routes):
@@ -931,6 +959,8 @@ class ShardedNeumf(_LookAhead):
         M = len(uc)
         sends, recvs = prep["counts"].get()
         routes = []
+        mark = self._mark
+        mark("route")
 
         def start(k):  # routes of chunk k, its rows requested (transfers may stay in flight)
             ru = _Route(uc[k], W, ops, group, prepared=grouped[k][0], splits=(sends[2 * k], recvs[2 * k]))
@@ -946,6 +976,7 @@ class ShardedNeumf(_LookAhead):
                 start(k + 1)
             ru, rv, pu, pv = routes[k]
             urows, irows = ru.rows_in_lookup_order(pu.wait(), ops), rv.rows_in_lookup_order(pv.wait(), ops)
+            mark("fetch_rows")
             Bk = uc[k].shape[0]
             loc = {"mf_u": urows[:, :d].contiguous(), "mlp_u": urows[:, d:].contiguous(),
                    "mf_i": irows[:, :d].contiguous(), "mlp_i": irows[:, d:].contiguous(),
@@ -955,9 +986,11 @@ class ShardedNeumf(_LookAhead):
             pred = ops.neumf_fwd(loc, pos_u, pos_i)
             loss_vec, g = ops.bpr_loss(pred, 1.0 / n_tuples)
             loss = loss + loss_vec.sum().reshape(1) / n_tuples
+            mark("head_fwd_loss")
             rows, dense = ops.neumf_bwd(loc, pos_u, pos_i, g)
             gu = torch.cat([rows["g_mf_u"].view(Bk, C, d).sum(dim=1), rows["g_mlp_u"].view(Bk, C, d).sum(dim=1)], dim=1)
             gi = torch.cat([rows["g_mf_i"], rows["g_mlp_i"]], dim=1)
+            mark("head_bwd")
             pushes.append((ru.push_async(gu, ops), rv.push_async(gi, ops)))
             flat = torch.cat([dense[n].reshape(-1) for n in ("W1", "b1", "w_out")])
             dense_sum = flat if dense_sum is None else dense_sum + flat
@@ -968,6 +1001,7 @@ class ShardedNeumf(_LookAhead):
         own_i = torch.cat([p[1].wait() for p in pushes])
         req_u = torch.cat([r[0].req for r in routes])
         req_i = torch.cat([r[1].req for r in routes])
+        mark("push_grads")
         shared = hasattr(ops, "prepare_rows")
         prep_u = ops.prepare_rows(req_u, self.P["mf_u"].shape[0]) if shared else None
         prep_i = ops.prepare_rows(req_i, self.P["mf_i"].shape[0]) if shared else None
@@ -979,16 +1013,18 @@ class ShardedNeumf(_LookAhead):
             kw = {"prep": prep} if shared else {}
             ops.update_rows(self.P[ta], self.state[ta], req, ga, hyper, **kw)
             ops.update_rows(self.P[tb], self.state[tb], req, gb, hyper, **kw)
+        mark("table_update")
         o = 0
         for n in ("W1", "b1", "w_out"):
             cnt = self.P[n].numel()
             ops.dense_update(self.P[n], dense_sum[o:o + cnt].view(self.P[n].shape).contiguous(), hyper0 if n == "b1" else hyper,
                              self.state[n])
             o += cnt
+        mark("dense_update")
         return loss
 
 
-class DataParallelDense:
+class DataParallelDense(_Timed):
     """Data-parallel leg for models whose parameters are replicated (BASELINE configs[4]: DeepFM-CTR on MIND, tables of
     269 K users / 9.4 K items fit every GPU): each rank runs model(batch) -> loss -> backward on ITS batch, the dense
     gradients of all parameters are summed over the ranks in ONE flat all-reduce (RCCL ring over xGMI; gloo in the CPU
@@ -1010,9 +1046,13 @@ class DataParallelDense:
 
     def step(self, batch):
         m = self.model
+        if self.timing is not None:
+            self.timing.clear()
+        self._mark("start")
         m.optimizer.zero_grad()
         loss = self.loss_of(m, batch)
         loss.backward()
+        self._mark("forward_backward")
         if self.world > 1:
             ps = [p for p in m.parameters() if p.grad is not None]
             flat = torch.cat([p.grad.reshape(-1) for p in ps])
@@ -1024,5 +1064,7 @@ class DataParallelDense:
                 p.grad.copy_(flat[o:o + n].view_as(p.grad))
                 o += n
             loss = _all_reduce_sum(loss.detach().reshape(1), self.group) / self.world
+        self._mark("gradient_allreduce")
         m.optimizer.step()
+        self._mark("optimizer")
         return loss.detach().reshape(1)

@@ -155,6 +155,67 @@ def test_adam_rowwise_step_sample_vs_oracle(world):
         assert_close(tr.mI[r].cpu().numpy()[None], st["m"], what="exp_avg", atol_scale=1e-4)
 
 
+def test_step_ahead_at_the_bench_batch_sample_vs_oracle(world, cuda):
+    """The configuration bench.py times: B = 65,536 tuples, K = 99, 10 M items, SGD, every step announcing the next batch
+    (rc_bprmf_train_step_ahead consuming a plan prepared beside the previous step's updates).  The step that RUNS FROM A
+    PREPARED PLAN is checked against the oracle arithmetic on sampled item / user rows, rebuilt from the unfused kernels'
+    gpred / ugrad on the pre-step tables, plus: untouched rows bit-identical, and bit-equality with the same two steps
+    without look-ahead."""
+    e = world["eng"]
+    U0, I0 = world["U"], world["I"]
+    Bb = 65_536
+    g = torch.Generator(device=cuda)
+    g.manual_seed(11)
+    def batch():
+        ranks_u = torch.exp(torch.rand(Bb, generator=g, device=cuda, dtype=torch.float64) * np.log(N_USERS - 1)).to(torch.int64).clamp_(1, N_USERS - 1)
+        ranks_p = torch.exp(torch.rand(Bb, generator=g, device=cuda, dtype=torch.float64) * np.log(N_ITEMS - 1)).to(torch.int64).clamp_(1, N_ITEMS - 1)
+        uid = (ranks_u * 2654435761) % (N_USERS - 1) + 1
+        pos = (ranks_p * 2654435761) % (N_ITEMS - 1) + 1
+        neg = torch.randint(1, N_ITEMS, (Bb, K), generator=g, device=cuda)
+        return uid.contiguous(), torch.cat([pos[:, None], neg], dim=1).contiguous()
+    b1, b2 = batch(), batch()
+    lr = 50.0
+    runs = []
+    for ahead in (True, False):
+        U, I = U0.clone(), I0.clone()
+        tr = e.BprmfTrainer(U, I, opt="SGD", lr=lr, l2=0.0)
+        tr.step(*b1, next_batch=b2 if ahead else None)
+        if ahead:
+            assert tr._ticket.generation != 0 and tr._ticket.B == Bb and tr._ticket.flavour == 1, "no plan was prepared"
+            U1, I1 = U.clone(), I.clone()           # tables between the steps (the stream orders the copy behind step 1)
+            assert tr._generation_of(*b2) == tr._ticket.generation, "step 2 would not consume the prepared plan"
+        loss2 = tr.step(*b2).clone()
+        runs.append((U, I, loss2))
+    (U, I, loss), (Ub, Ib, lossb) = runs
+    assert torch.equal(U, Ub) and torch.equal(I, Ib) and torch.equal(loss, lossb), "look-ahead changed the result"
+    uid, iid = b2
+    _, lv, gpred, ugrad = e.bprmf_fwd_bwd(U1, I1, uid, iid, want_pred=False)
+    assert_close(loss.cpu().numpy()[0], float(lv.double().mean()), rtol=1e-5, what="loss of the step run from the prepared plan")
+    flat = iid.reshape(-1)
+    cnt = torch.bincount(flat, minlength=N_ITEMS)
+    touched = cnt > 0
+    assert torch.equal(I[~touched], I1[~touched])
+    # sampled item rows: singletons (updated inside the fused kernel), doubles / triples (plan-driven update) and the
+    # hottest rows (chunked path)
+    order = torch.argsort(cnt, descending=True)
+    picks = torch.cat([order[:8], torch.nonzero(cnt == 1).reshape(-1)[:: 40000][:40], torch.nonzero(cnt == 2).reshape(-1)[:: 15000][:40],
+                       torch.nonzero(cnt == 3).reshape(-1)[:: 4000][:20]])
+    assert int((cnt[picks] == 1).sum()) >= 20 and int((cnt[picks] == 2).sum()) >= 20 and int(cnt[picks].max()) > 32
+    gp = gpred.reshape(-1).double()
+    for r in picks.tolist():
+        occ = torch.nonzero(flat == r).reshape(-1)
+        gsum = (gp[occ][:, None] * U1[uid[occ // (K + 1)]].double()).sum(0)
+        want = (I1[r].double() - lr * gsum).float()
+        assert_update_close(I[r].cpu().numpy(), I1[r].cpu().numpy(), want.cpu().numpy(), what=f"item row {r} (n={int(cnt[r])})")
+    ucnt = torch.bincount(uid, minlength=N_USERS)
+    uorder = torch.argsort(ucnt, descending=True)
+    for r in torch.cat([uorder[:6], torch.nonzero(ucnt == 1).reshape(-1)[::300][:30]]).tolist():
+        rows = torch.nonzero(uid == r).reshape(-1)
+        want = (U1[r].double() - lr * ugrad[rows].double().sum(0)).float()
+        assert_update_close(U[r].cpu().numpy(), U1[r].cpu().numpy(), want.cpu().numpy(), what=f"user row {r} (n={int(ucnt[r])})")
+    assert torch.equal(U[ucnt == 0], U1[ucnt == 0])
+
+
 def test_bench_contract_line(cuda):
     import os
     """bench.py prints ONE JSON line with the driver's keys, the roofline object and the CPU baseline"""

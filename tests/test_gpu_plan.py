@@ -267,20 +267,155 @@ def test_train_step_with_look_ahead_is_bit_identical(opt, lr, l2, cuda, eng):
         iid = np.concatenate([_zipf(rng, n_items, (B, 1)), rng.integers(1, n_items, size=(B, C - 1))], axis=1)
         batches.append((torch.from_numpy(uid).to(cuda), torch.from_numpy(iid).to(cuda)))
     res = []
-    for mode in ("none", "all", "some", "wrong"):
+    hits = {}
+    for mode in ("none", "all", "some", "wrong", "refill_in_place", "pingpong_generations", "stale_generation"):
         U, I = torch.from_numpy(U0).to(cuda), torch.from_numpy(I0).to(cuda)
         tr = eng.BprmfTrainer(U, I, opt=opt, lr=lr, l2=l2)
         losses = []
+        # static buffers that are refilled in place, the way rechorus_amd/graph.py feeds its captured steps
+        su = [torch.empty_like(batches[0][0]) for _ in range(2)]
+        si = [torch.empty_like(batches[0][1]) for _ in range(2)]
+        hit = 0
         for k, (u, i) in enumerate(batches):
-            nxt = None
+            nxt, kw = None, {}
             if mode == "all" or (mode == "some" and k % 2 == 0):
                 nxt = batches[(k + 1) % len(batches)]
             elif mode == "wrong":
                 nxt = batches[(k + 2) % len(batches)]   # not the batch the next call brings
-            losses.append(tr.step(u, i, next_batch=nxt).clone())
+            elif mode == "refill_in_place":
+                # ONE buffer pair, refilled with torch ops: the announced tensors ARE the next call's tensors (same
+                # objects, same addresses) but their contents change in between -- the version counters say so, the
+                # prepared plan (made from the OLD contents) must be discarded
+                if k == 0:
+                    su[0].copy_(u); si[0].copy_(i)
+                u, i = su[0], si[0]
+                nxt = (su[0], si[0])
+            elif mode in ("pingpong_generations", "stale_generation"):
+                # two buffer pairs written through raw pointers (torch's version counters do not move): the caller's
+                # generation ids are the only thing that identifies a batch
+                if k == 0:
+                    su[0].untyped_storage().copy_(u.untyped_storage()); si[0].untyped_storage().copy_(i.untyped_storage())
+                nu, ni = batches[(k + 1) % len(batches)]
+                su[(k + 1) % 2].untyped_storage().copy_(nu.untyped_storage())
+                si[(k + 1) % 2].untyped_storage().copy_(ni.untyped_storage())
+                u, i = su[k % 2], si[k % 2]
+                nxt = (su[(k + 1) % 2], si[(k + 1) % 2])
+                kw = dict(generation=k + 1, next_generation=k + 2)
+                if mode == "stale_generation" and k % 2 == 1:
+                    # the announced buffers were refilled AFTER the announcement (here: with the batch after next, then
+                    # -- below -- put right again): an honest caller bumps the generation, the stale plan is dropped
+                    kw["generation"] = 1000 + k
+            gen_used = kw["generation"] if "generation" in kw else tr._generation_of(u, i)
+            hit += int(gen_used != 0 and tr._ticket.generation == gen_used)   # this call consumes the prepared plan
+            losses.append(tr.step(u, i, next_batch=nxt, **kw).clone())
+            if mode == "refill_in_place" and k + 1 < len(batches):
+                nu, ni = batches[k + 1]
+                su[0].copy_(nu); si[0].copy_(ni)      # in place, after it was announced
         torch.cuda.synchronize()
+        hits[mode] = hit
         res.append((U, I, tr.mI, tr.vI, torch.cat(losses)))
     for other in res[1:]:
         for name, x, y in zip(("U", "I", "mI", "vI", "loss"), res[0], other):
             if x is not None:
                 assert torch.equal(x, y), name
+    n = len(batches)
+    assert hits == {"none": 0, "all": n - 1, "some": (n - 1 + 1) // 2, "wrong": 0, "refill_in_place": 0,
+                    "pingpong_generations": n - 1, "stale_generation": (n - 1) // 2}, hits
+
+
+def test_ticket_is_matched_by_generation_not_by_pointer(cuda, eng):
+    """C ABI level: a ticket prepared for generation g is consumed only by a call that brings g; the same id buffers
+    with other contents under another generation re-plan (results equal the plain step's), and a cleared ticket is inert"""
+    import ctypes as C
+    from rechorus_amd import _lib
+    rng = np.random.default_rng(5)
+    n_users, n_items, d, B, Cn = 500, 30_000, 64, 1024, 100
+    mk = lambda: (torch.from_numpy(_zipf(rng, n_users, B)).to(cuda),
+                  torch.from_numpy(rng.integers(1, n_items, size=(B, Cn))).to(cuda))
+    b1, b2, b3 = mk(), mk(), mk()
+    U0 = torch.from_numpy(rng.normal(0, 0.01, size=(n_users, d)).astype(np.float32)).to(cuda)
+    I0 = torch.from_numpy(rng.normal(0, 0.01, size=(n_items, d)).astype(np.float32)).to(cuda)
+
+    def run(seq):
+        U, I = U0.clone(), I0.clone()
+        tr = eng.BprmfTrainer(U, I, opt="SGD", lr=0.05)
+        out = []
+        for (u, i, gen, nxt, ngen) in seq:
+            tr.step(u, i, next_batch=nxt, generation=gen, next_generation=ngen)
+            out.append(int(tr._ticket.generation))
+        torch.cuda.synchronize()
+        return U, I, out
+    # reference: no look-ahead at all
+    Ua, Ia, _ = run([(b1[0], b1[1], 0, None, 0), (b3[0], b3[1], 0, None, 0)])
+    # b2 is announced under generation 7, but the buffers then hold b3 under generation 8 (copied in place)
+    buf = (b2[0].clone(), b2[1].clone())
+    U, I = U0.clone(), I0.clone()
+    tr = eng.BprmfTrainer(U, I, opt="SGD", lr=0.05)
+    tr.step(b1[0], b1[1], next_batch=buf, generation=1, next_generation=7)
+    assert tr._ticket.generation == 7 and tr._ticket.B == B and tr._ticket.C == Cn and tr._ticket.flavour == 1
+    buf[0].untyped_storage().copy_(b3[0].untyped_storage())
+    buf[1].untyped_storage().copy_(b3[1].untyped_storage())
+    tr.step(buf[0], buf[1], generation=8)
+    assert tr._ticket.generation == 0
+    torch.cuda.synchronize()
+    assert torch.equal(U, Ua) and torch.equal(I, Ia)
+    assert C.sizeof(_lib.StepTicket) == 72
+
+
+@pytest.mark.parametrize("case", ["uniform_wide", "zipf_hot", "all_same", "small_range", "many_buckets", "huge_bucket"])
+def test_multi_bitmap_matches_numpy(case, cuda, eng):
+    """rc_bucket_multi_bitmap: bit (id) = 1 iff the row occurs at least twice -- for every id of the batch"""
+    rng = np.random.default_rng(sum(map(ord, case)) + 1)
+    if case == "uniform_wide":
+        n_rows, ids = 10_000_001, rng.integers(1, 10_000_001, size=400_000)
+    elif case == "zipf_hot":
+        n_rows = 50_000
+        ids = np.minimum(rng.zipf(1.2, size=120_000), n_rows - 1)
+    elif case == "all_same":
+        n_rows, ids = 77, np.full(20_000, 42)
+    elif case == "small_range":
+        n_rows, ids = 50, rng.integers(0, 50, size=10_000)
+    elif case == "many_buckets":
+        n_rows, ids = 33_000_000, rng.integers(0, 33_000_000, size=50_000)
+    else:  # one id range far hotter than the 16-bit cells hold: the 32-bit instantiation takes the bucket
+        n_rows = 100_000
+        ids = np.concatenate([rng.integers(8192, 16384, size=70_000), rng.integers(0, n_rows, size=5_000)])
+    ids = np.ascontiguousarray(ids, dtype=np.int64)
+    bm = eng.bucket_multi_bitmap(torch.from_numpy(ids).to(cuda), n_rows).cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+    cnt = np.bincount(ids, minlength=n_rows)
+    got = (bm[ids >> 5] >> (ids & 31)) & 1
+    assert np.array_equal(got, (cnt[ids] >= 2).astype(np.int64))
+    # ids of touched 32-id words that do not occur in the batch read 0 (their cells count 0)
+    present = np.unique(ids)
+    neigh = np.setdiff1d(np.unique(np.concatenate([present ^ 1, present ^ 7])), present)
+    neigh = neigh[neigh < n_rows]
+    assert not np.any((bm[neigh >> 5] >> (neigh & 31)) & 1)
+
+
+@pytest.mark.parametrize("opt,lr,l2", [("SGD", 0.05, 1e-3), ("Adam", 1e-3, 1e-4)])
+@pytest.mark.parametrize("d,B,C,n_items", [(64, 300, 100, 20000), (64, 513, 2, 700), (32, 100, 9, 300),
+                                           (128, 64, 40, 2000), (16, 50, 100, 4000), (64, 70, 128, 5000), (32, 40, 200, 3000)])
+def test_fused_update_bitmap_equals_flag_path(opt, lr, l2, d, B, C, n_items, cuda, eng):
+    """the fused kernel with the singleton information as a bitmap over item ids (bucket plan) vs. as a flag byte per
+    batch position (sort pipeline): bit-identical tables, state and gradients, for every lookup variant of the kernel
+    (one tuple per wave with C <= 64 / <= 128, several tuples per wave, C > 128)"""
+    rng = np.random.default_rng(d + B + C + 1)
+    U = rng.normal(0, 0.1, size=(40, d)).astype(np.float32)
+    I = rng.normal(0, 0.1, size=(n_items, d)).astype(np.float32)
+    uid = torch.from_numpy(rng.integers(0, 40, size=B)).to(cuda)
+    iid = torch.from_numpy(rng.integers(0, n_items, size=(B, C))).to(cuda)
+    keys, perm = eng.sort_ids(iid, n_items)
+    single = eng.mark_singletons(keys, perm)
+    multi = eng.bucket_multi_bitmap(iid, n_items)
+    h = eng.make_hyper(opt, lr=lr, l2=l2, step=3)
+    res = []
+    for use_bitmap in (False, True):
+        Ud, Id = torch.from_numpy(U).to(cuda), torch.from_numpy(I).to(cuda)
+        m = torch.full_like(Id, 0.25e-6) if opt != "SGD" else None
+        v = torch.full_like(Id, 1e-9) if opt == "Adam" else None
+        _, lv, gp, ug = eng.bprmf_fwd_bwd_update(Ud, Id, uid, iid, None if use_bitmap else single, h, mI=m, vI=v,
+                                                 multi=multi if use_bitmap else None)
+        res.append((Id, m, v, lv, gp, ug))
+    for nm, a, b in zip(("I", "m", "v", "loss_vec", "gpred", "ugrad"), res[0], res[1]):
+        assert a is None or torch.equal(a, b), nm
+    assert not torch.equal(res[0][0], torch.from_numpy(I).to(cuda))

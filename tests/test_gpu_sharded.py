@@ -184,23 +184,46 @@ def test_world_of_one_through_the_exchange_path(mode, C, n_phases, cuda):
         assert len(phases) == n_phases
 
 
-def test_bench_multi_rank_code_path_on_one_gpu(cuda):
-    """the driver's N > 1 launch line with both ranks on cuda:0 and gloo collectives (RC_BENCH_ONE_DEVICE):
-    not a measurement, but every line of bench.py's sharded branch runs"""
+@pytest.mark.parametrize("launcher,workload,extra", [
+    ("torchrun", "bprmf", ["--batch", "2048", "--num-neg", "19", "--items", "200001", "--users", "20001"]),
+    ("self", "bprmf", ["--batch", "2048", "--num-neg", "19", "--items", "200001", "--users", "20001"]),
+    ("self", "neumf", ["--batch", "2048", "--items", "200001", "--users", "20001"]),
+    ("self", "deepfm", ["--batch", "512"]),
+])
+def test_bench_multi_rank_code_path_on_one_gpu(launcher, workload, extra, cuda):
+    """the driver's N > 1 command lines -- `python -m torch.distributed.run ... bench.py --gpus 2` and plain
+    `python bench.py --gpus 2` (bench.py starts its own ranks) -- with both ranks on cuda:0 and gloo collectives
+    (RC_BENCH_ONE_DEVICE): not a measurement, but every line of bench.py's multi-GPU branches runs, for the sharded
+    BPRMF / NeuMF steps and the data-parallel DeepFM leg"""
     import json
     import subprocess
     import sys
     from conftest import ROOT
-    env = dict(os.environ, RC_BENCH_ONE_DEVICE="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--dist-backend", "gloo", "--batch", "2048", "--num-neg", "19", "--items", "200001", "--users", "20001"]
-    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["RC_BENCH_ONE_DEVICE"] = "1"
+    tail = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--dist-backend", "gloo",
+            "--workload", workload, "--no-cpu-baseline"] + extra
+    if launcher == "torchrun":
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port())] + tail
+    else:
+        cmd = [sys.executable] + tail
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
-    line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
-    out = json.loads(line)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0 and np.isfinite(out["final_loss"])
-    assert len(out["sharded_phases_ms"]) == 8
+    ph = out["sharded_phases_ms"]
+    if workload == "bprmf":
+        assert len(ph) == 8
+    elif workload == "neumf":
+        assert {"fetch_rows", "head_fwd_loss", "head_bwd", "push_grads", "table_update", "dense_update"} <= set(ph)
+        assert out["sharded_wire_bytes_rank0"]
+    else:
+        assert set(ph) == {"forward_backward", "gradient_allreduce", "optimizer"}
+        assert out["sharded_wire_bytes_rank0"]["dense_gradient_allreduce"] > 0
+        assert "replicated" in out["config"]["parallelism"]
 
 
 def _neumf_worker(rank, world, port, opt, lr, l2, n_users, n_items, d, l1, B, C, steps, out_q, micro_batches=1):
