@@ -509,7 +509,9 @@ typedef struct rc_plan_row {
   uint32_t reserved; /* 0                                                                      */
 } rc_plan_row;
 
-/* 1 when ceil(range_a / 8192) + ceil(range_b / 8192) <= 4096 (one bucket level), else 0 -> use rc_sort_ids */
+/* 1 when a plan geometry exists: id-range buckets (ceil(range_a / 8192) + ceil(range_b / 8192) <= 4096; chosen when the
+ * ids are dense enough, range <= 16 n) or hashed buckets with an LDS hash table per bucket (sparse or wider id spaces:
+ * ids < 2^32 - 2, at most 8 M keys per list); else 0 -> use rc_sort_ids.  RC_PLAN_HASHED=0/1 forces a geometry (A/B). */
 int rc_bucket_plan_supported(int64_t n_a, int64_t n_b, int64_t range_a, int64_t range_b);
 size_t rc_bucket_plan_workspace_bytes(int64_t n_a, int64_t n_b);
 size_t rc_bucket_plan_flags_bytes(int64_t n_a); /* size of single_a: n_a rounded up to whole 8,192-byte tiles */
@@ -557,6 +559,21 @@ int rc_plan_update_pair(float* W_a, float* m_a, float* v_a, float* W_b, float* m
                         const rc_plan_row* rows, const uint32_t* n_rows, const uint32_t* occ, int64_t n_occ,
                         const float* src_a, const float* src_b, int64_t occ_base, const rc_opt_hyper* h, void* ws,
                         size_t ws_bytes, rc_stream_t stream);
+
+/* The same walk without an optimizer: out[row, :] = the summed gradient row of every LISTED row (other rows of `out` are
+ * left as they are) -- aten::embedding_dense_backward's index_add (helpers/BaseRunner.py:205) as a plan consumer, and the
+ * "sum rows by inverse index" of the sharded steps' de-duplicated exchanges.  Gradient sources as in rc_plan_update;
+ * workspace rc_plan_update_workspace_bytes(n_occ, d).                                                           */
+int rc_plan_row_sums(float* out, int d, const rc_plan_row* rows, const uint32_t* n_rows, const uint32_t* occ,
+                     int64_t n_occ, const float* coef, const float* src, const int64_t* src_index, int div,
+                     const float* src2, int64_t n_split, void* ws, size_t ws_bytes, rc_stream_t stream);
+
+/* The distinct ids of a planned list and the inverse index -- what torch.unique(ids, return_inverse=True) returns, minus
+ * the sort (the order of uniq is the plan's record order) and minus the host round trip (the count stays in *n_rows):
+ * uniq[r] = id of record r (capacity n_list), inverse[p - occ_base] = r for every position p of record r; occ_base /
+ * n_list: first position and length of the list (list a: 0, n_a; list b: n_a, n_b).                               */
+int rc_plan_distinct(const rc_plan_row* rows, const uint32_t* n_rows, const uint32_t* occ, int64_t occ_base,
+                     int64_t n_list, int64_t* uniq, int64_t* inverse, rc_stream_t stream);
 
 size_t rc_bprmf_step_workspace_bytes(int B, int C, int d);
 

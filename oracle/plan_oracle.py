@@ -13,7 +13,8 @@ def bucket_plan(ids_a, ids_b=None, list_single_a=True):
     """-> (groups_a, groups_b, single_a)
     groups_x: {row id: int64 array of positions, ascending}; positions are p in [0, n_a) for list a and
     n_a + j for list b.  With list_single_a False, rows of list a that occur once are left out of groups_a and
-    flagged instead: single_a[p] = 1 at their position (uint8 [n_a]); single_a is None otherwise."""
+    flagged instead: single_a[p] = 1 at their position (uint8 [n_a]); single_a is None otherwise.
+    Positions with a NEGATIVE id take no part (padding slots of a history window): they appear in no group."""
     a = np.asarray(ids_a, dtype=np.int64).reshape(-1)
     b = np.zeros(0, dtype=np.int64) if ids_b is None else np.asarray(ids_b, dtype=np.int64).reshape(-1)
 
@@ -22,7 +23,7 @@ def bucket_plan(ids_a, ids_b=None, list_single_a=True):
         srt = ids[order]
         cuts = np.flatnonzero(np.concatenate([[True], srt[1:] != srt[:-1]])) if len(srt) else np.zeros(0, np.int64)
         ends = np.concatenate([cuts[1:], [len(srt)]]) if len(srt) else cuts
-        return {int(srt[s]): order[s:e] + base for s, e in zip(cuts, ends)}
+        return {int(srt[s]): order[s:e] + base for s, e in zip(cuts, ends) if srt[s] >= 0}
 
     ga, gb = groups(a, 0), groups(b, len(a))
     single = None

@@ -43,7 +43,7 @@ static int env_int(const char* name, int dflt) {
   return (v && *v) ? atoi(v) : dflt;
 }
 
-PlanGeom plan_geometry(int64_t n_a, int64_t n_b, int64_t range_a, int64_t range_b) {
+PlanGeom plan_geometry(int64_t n_a, int64_t n_b, int64_t range_a, int64_t range_b, int want_mode) {
   PlanGeom g;
   memset(&g, 0, sizeof(g));
   g.n = n_a + n_b;
@@ -56,7 +56,34 @@ PlanGeom plan_geometry(int64_t n_a, int64_t n_b, int64_t range_a, int64_t range_
     return (int64_t)*na + *nbb;
   };
   uint32_t na, nbb;
-  if (buckets(kPlanMaxShift, &na, &nbb) > kPlanMaxBuckets) return g;  // id space too wide for one level
+  g.tiles = (uint32_t)((g.n + kPlanTile - 1) / kPlanTile);
+  // Direct buckets cost table cells in proportion to the id RANGE (every bucket zeroes and scans 8,192 cells), hashed
+  // buckets in proportion to the number of KEYS: hashed where the range is more than 16 cells per key (NeuMF's 0.33 M
+  // item lookups over 10 M - 100 M rows; a rank's lookups in a sharded table) or too wide for one direct level at all.
+  const bool direct_ok = buckets(kPlanMaxShift, &na, &nbb) <= kPlanMaxBuckets;
+  const int force = want_mode >= 0 ? want_mode : env_int("RC_PLAN_HASHED", -1);
+  const bool hashed = force >= 0 ? (force != 0 || !direct_ok) : (!direct_ok || range_a + range_b > 16 * g.n);
+  if (hashed) {
+    auto pow2_for = [](int64_t n_keys, int* lg) {
+      int l = 0;
+      while (((int64_t)kPlanHashKeysPerBucket << l) < n_keys && l < 11) ++l;   // <= 2,048 buckets per list
+      *lg = l;
+      return n_keys > 0 ? (uint32_t)1 << l : 0u;
+    };
+    g.nb_a = pow2_for(n_a, &g.log_nb_a);
+    g.nb_b = pow2_for(n_b, &g.log_nb_b);
+    // keys per bucket beyond what the LDS table holds with room to spare (every key distinct in the worst case)
+    if ((n_a >> g.log_nb_a) > (int64_t)kPlanHashSlots / 2 || (n_b >> g.log_nb_b) > (int64_t)kPlanHashSlots / 2) return g;
+    if (range_a > ((int64_t)1 << 32) - 2 || range_b > ((int64_t)1 << 32) - 2) return g;
+    g.hashed = 1;
+    g.nb = g.nb_a + g.nb_b;
+    g.shift = 0;
+    g.base_b = 0;
+    g.bucket_bits = 1;
+    while ((1u << g.bucket_bits) < g.nb) ++g.bucket_bits;
+    g.ok = 1;
+    return g;
+  }
   // enough buckets to fill the chip (one wave per bucket in step 4), but not more than the scatter's
   // write runs can afford: aim at ~8 K keys per bucket, at least 128 buckets
   int64_t want = g.n / 8192;
@@ -73,7 +100,6 @@ PlanGeom plan_geometry(int64_t n_a, int64_t n_b, int64_t range_a, int64_t range_
   g.nb_b = nbb;
   g.nb = na + nbb;
   g.base_b = na << shift;
-  g.tiles = (uint32_t)((g.n + kPlanTile - 1) / kPlanTile);
   g.bucket_bits = 1;
   while ((1u << g.bucket_bits) < g.nb) ++g.bucket_bits;
   g.ok = 1;
@@ -90,6 +116,7 @@ PlanWs carve_plan_ws(void* base, int64_t n) {
   w.bucket_base = cv.take<uint32_t>(kPlanMaxBuckets + 1);
   w.lid = cv.take<uint16_t>((size_t)n);
   w.pos = cv.take<uint32_t>((size_t)n);
+  w.lid32 = cv.take<uint32_t>((size_t)n);
   w.counters = cv.take<uint32_t>(PC_N);
   w.total = cv.off;
   return w;
@@ -109,8 +136,32 @@ PlanLongWs carve_plan_long_ws(void* base, int64_t n, int d) {
 }
 
 // ---- device helpers -----------------------------------------------------------------------------------
+// the 32-bit key of position p.  Direct geometry: list a = the id, list b = base_b + id (one joint range, bucket = key >>
+// shift).  Hashed geometry: the id itself; the list follows from p.
+// A NEGATIVE id marks a position that takes no part (padding slots of a history window): it yields the "no key" value
+// and is neither counted nor placed.
+template <bool HASHED>
 __device__ __forceinline__ uint32_t plan_key(const PlanArgs& a, uint32_t p) {
-  return p < a.n_a ? (uint32_t)a.ids_a[p] : a.g.base_b + (uint32_t)a.ids_b[p - a.n_a];
+  const int64_t id = p < a.n_a ? a.ids_a[p] : a.ids_b[p - a.n_a];
+  if (id < 0) return 0xFFFFFFFFu;
+  if (HASHED) return (uint32_t)id;
+  return p < a.n_a ? (uint32_t)id : a.g.base_b + (uint32_t)id;
+}
+// bucket of a key (hashed: `side_b` says which list the position belongs to); *bad: an id outside its table (direct only)
+template <bool HASHED>
+__device__ __forceinline__ uint32_t plan_bucket_of(const PlanArgs& a, uint32_t key, bool side_b, bool* bad) {
+  if (HASHED) {
+    const uint32_t h = key * 0x9E3779B1u;
+    const int lg = side_b ? a.g.log_nb_b : a.g.log_nb_a;
+    const uint32_t b = lg ? h >> (32 - lg) : 0u;
+    return side_b ? a.g.nb_a + b : b;
+  }
+  uint32_t b = key >> a.g.shift;
+  if (b >= a.g.nb) {  // memory-safe: counted in the last bucket, flagged by the scatter
+    b = a.g.nb - 1;
+    if (bad) *bad = true;
+  }
+  return b;
 }
 
 // lanes of the wave (among `valid`) whose v equals this lane's v; v < 2^bits
@@ -135,31 +186,48 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t x, int lane) {
   return x;
 }
 
+// Which tile a workgroup of the count / scatter kernels takes.  Workgroup b is observed to run on XCD b mod 8
+// (MI355X_MICROARCH.md; placement only affects speed, never results): every XCD gets a CONTIGUOUS range of tiles, in
+// dispatch order.  The tiles in flight on one XCD are then neighbours, and what neighbouring tiles write lies side
+// by side: a bucket's 6-key run of tile t is followed by the run of tile t + 1 (12 / 24 bytes each), the histogram
+// column entries hist[b][t], hist[b][t + 1] share a sector -- so the XCD's L2 merges them into full lines before they
+// leave for HBM, and the scatter's column reads of the histogram hit it.  (Round 2 handed tiles out round-robin: every
+// partial sector crossed the fabric on its own -- 189 MB counted for 91 MB of keys + ids.)
+// grid = 8 * ceil(tiles / 8); returns tiles (= "none") for the surplus workgroups.
+__device__ __forceinline__ uint32_t plan_tile_of_block(uint32_t b, uint32_t tiles) {
+  const uint32_t per = (tiles + 7u) / 8u;
+  const uint32_t t = (b % 8u) * per + b / 8u;
+  return t < tiles ? t : tiles;
+}
+static inline uint32_t plan_tile_grid(uint32_t tiles) { return 8u * ((tiles + 7u) / 8u); }
+
 // ---- 1. per-tile bucket histogram ---------------------------------------------------------------------
+template <bool HASHED>
 __global__ __launch_bounds__(kPlanThreads) void plan_count_kernel(PlanArgs a) {
   extern __shared__ uint32_t s_hist[];  // [nb]
   const uint32_t nb = a.g.nb;
-  for (uint32_t i = threadIdx.x; i < nb; i += kPlanThreads) s_hist[i] = 0;
   if (blockIdx.x == 0 && threadIdx.x < PC_N) a.w.counters[threadIdx.x] = 0;
+  const uint32_t tile = plan_tile_of_block(blockIdx.x, a.g.tiles);
+  if (tile == a.g.tiles) return;
+  for (uint32_t i = threadIdx.x; i < nb; i += kPlanThreads) s_hist[i] = 0;
   __syncthreads();
-  const uint32_t tile0 = blockIdx.x * (uint32_t)kPlanTile;
+  const uint32_t tile0 = tile * (uint32_t)kPlanTile;
   uint32_t key[kPlanRounds];
 #pragma unroll
   for (int r = 0; r < kPlanRounds; ++r) {
     const uint32_t p = tile0 + r * kPlanThreads + threadIdx.x;
-    key[r] = p < a.n ? plan_key(a, p) : 0xFFFFFFFFu;
+    key[r] = p < a.n ? plan_key<HASHED>(a, p) : 0xFFFFFFFFu;
   }
   if (a.single_a && tile0 < a.n_a)  // flags of this tile's list-a positions start at 0 (padded buffer: whole uint4s)
     reinterpret_cast<uint4*>(a.single_a + tile0)[threadIdx.x] = make_uint4(0, 0, 0, 0);
 #pragma unroll
   for (int r = 0; r < kPlanRounds; ++r) {
     if (key[r] == 0xFFFFFFFFu) continue;
-    uint32_t b = key[r] >> a.g.shift;
-    if (b >= nb) b = nb - 1;  // an id outside its table: counted in the last bucket (memory-safe), flagged by the scatter
-    atomicAdd(&s_hist[b], 1u);
+    const uint32_t p = tile0 + r * kPlanThreads + threadIdx.x;
+    atomicAdd(&s_hist[plan_bucket_of<HASHED>(a, key[r], p >= a.n_a, nullptr)], 1u);
   }
   __syncthreads();
-  for (uint32_t b = threadIdx.x; b < nb; b += kPlanThreads) a.w.hist[(size_t)b * a.g.tiles + blockIdx.x] = s_hist[b];
+  for (uint32_t b = threadIdx.x; b < nb; b += kPlanThreads) a.w.hist[(size_t)b * a.g.tiles + tile] = s_hist[b];
 }
 
 // ---- 2. per bucket: exclusive scan over the tiles -------------------------------------------------------
@@ -193,7 +261,9 @@ __global__ __launch_bounds__(kBlock) void plan_colscan_kernel(PlanArgs a) {
 // order), tile offsets from step 2.  The keys are first placed into an LDS image of the tile sorted by bucket,
 // then written out in image order: consecutive threads write consecutive addresses inside a bucket's run, so a
 // wave store touches ~tile/nb-key runs instead of 64 scattered 8-byte slots (measured: 85 -> see DESIGN.md).
-// LDS: u16 wave counters [8][nb], u32 run deltas [nb], the image (u32 packed lid|local position + u16 bucket).
+// LDS: u16 wave counters [8][nb], u32 run deltas [nb], the image (u32 packed lid|local position + u16 bucket; hashed
+// geometry: u32 id + u16 local position + u16 bucket).
+template <bool HASHED>
 __global__ __launch_bounds__(kPlanThreads) void plan_scatter_kernel(PlanArgs a) {
   extern __shared__ uint32_t smem[];
   const uint32_t nb = a.g.nb;
@@ -202,19 +272,22 @@ __global__ __launch_bounds__(kPlanThreads) void plan_scatter_kernel(PlanArgs a) 
   uint32_t* image = gdelta + nbp;                            // [kPlanTile]
   uint32_t* wsum = image + kPlanTile;                        // [2 * kPlanWaves]
   uint16_t* image_b = reinterpret_cast<uint16_t*>(wsum + 2 * kPlanWaves);  // [kPlanTile]
-  uint16_t* cnt = image_b + kPlanTile;                       // [kPlanWaves][nbp]
+  uint16_t* image_p = image_b + kPlanTile;                   // [kPlanTile] (hashed only)
+  uint16_t* cnt = image_p + (HASHED ? kPlanTile : 0);        // [kPlanWaves][nbp]
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
+  const uint32_t tile = plan_tile_of_block(blockIdx.x, a.g.tiles);
+  if (tile == a.g.tiles) return;
   for (uint32_t i = threadIdx.x; i < kPlanWaves * nbp / 2; i += kPlanThreads) reinterpret_cast<uint32_t*>(cnt)[i] = 0;
 
   // issue this wave's id loads (1,024 consecutive positions) before anything else
-  const uint32_t tile0 = blockIdx.x * (uint32_t)kPlanTile;
+  const uint32_t tile0 = tile * (uint32_t)kPlanTile;
   const uint32_t pos0 = tile0 + wave * (kPlanTile / kPlanWaves);
   uint32_t key[kPlanRounds];
 #pragma unroll
   for (int r = 0; r < kPlanRounds; ++r) {
     const uint32_t p = pos0 + r * 64 + lane;
-    key[r] = p < a.n ? plan_key(a, p) : 0xFFFFFFFFu;
+    key[r] = p < a.n ? plan_key<HASHED>(a, p) : 0xFFFFFFFFu;
   }
 
   // bucket bases: exclusive scan of the bucket totals (nb <= 4096 = 8 consecutive buckets per thread)
@@ -236,12 +309,12 @@ __global__ __launch_bounds__(kPlanThreads) void plan_scatter_kernel(PlanArgs a) 
   for (int q = 0; q < kPer; ++q) {
     const uint32_t b = threadIdx.x * kPer + q;
     if (b < nb) {
-      gdelta[b] = run + a.w.hist[(size_t)b * a.g.tiles + blockIdx.x];  // bucket base + this bucket's keys in earlier tiles
-      if (blockIdx.x == 0) a.w.bucket_base[b] = run;
+      gdelta[b] = run + a.w.hist[(size_t)b * a.g.tiles + tile];  // bucket base + this bucket's keys in earlier tiles
+      if (tile == 0) a.w.bucket_base[b] = run;
     }
     run += tv[q];
   }
-  if (blockIdx.x == 0 && threadIdx.x == kPlanThreads - 1) a.w.bucket_base[nb] = run;
+  if (tile == 0 && threadIdx.x == kPlanThreads - 1) a.w.bucket_base[nb] = run;
 
   // phase A: rank of every key among the keys of its bucket in THIS WAVE's 1,024 positions, in position order
   uint32_t rank[kPlanRounds];
@@ -249,11 +322,9 @@ __global__ __launch_bounds__(kPlanThreads) void plan_scatter_kernel(PlanArgs a) 
 #pragma unroll
   for (int r = 0; r < kPlanRounds; ++r) {
     const bool valid = key[r] != 0xFFFFFFFFu;
-    uint32_t b = valid ? key[r] >> a.g.shift : 0u;
-    if (b >= nb) {  // id outside its table (nn.Embedding would raise a device assert): stay in bounds, raise the status bit
-      b = nb - 1;
-      a.w.counters[PC_STATUS] = 1u;
-    }
+    bool bad = false;
+    const uint32_t b = valid ? plan_bucket_of<HASHED>(a, key[r], pos0 + r * 64 + lane >= a.n_a, &bad) : 0u;
+    if (bad) a.w.counters[PC_STATUS] = 1u;  // id outside its table (nn.Embedding would raise a device assert): kept in bounds, status bit raised
     const uint64_t m = match_lanes(b, a.g.bucket_bits, __ballot(valid));
     const uint32_t old = mycnt[b];
     const uint32_t below = (uint32_t)__popcll(m & lanes_below(lane));
@@ -301,20 +372,31 @@ __global__ __launch_bounds__(kPlanThreads) void plan_scatter_kernel(PlanArgs a) 
 #pragma unroll
   for (int r = 0; r < kPlanRounds; ++r) {
     if (key[r] == 0xFFFFFFFFu) continue;
-    uint32_t b = key[r] >> a.g.shift;
-    if (b >= nb) b = nb - 1;
+    const uint32_t lp = (uint32_t)(wave * (kPlanTile / kPlanWaves) + r * 64 + lane);   // position within the tile
+    const uint32_t b = plan_bucket_of<HASHED>(a, key[r], tile0 + lp >= a.n_a, nullptr);
     const uint32_t slot = (uint32_t)mycnt[b] + rank[r];
-    image[slot] = ((key[r] & lid_mask) << 13) | (uint32_t)(wave * (kPlanTile / kPlanWaves) + r * 64 + lane);
+    if (HASHED) {
+      image[slot] = key[r];
+      image_p[slot] = (uint16_t)lp;
+    } else {
+      image[slot] = ((key[r] & lid_mask) << 13) | lp;
+    }
     image_b[slot] = (uint16_t)b;
   }
   __syncthreads();
   // phase D: write the image out; slot i of bucket b goes to gdelta[b] + i
-  const uint32_t tile_n = a.n - tile0 < (uint32_t)kPlanTile ? a.n - tile0 : (uint32_t)kPlanTile;
+  uint32_t tile_n = 0;   // keys of this tile = all positions except those past n and those with a negative id
+  for (int w = 0; w < kPlanWaves; ++w) tile_n += wsum[kPlanWaves + w];
   for (uint32_t i = threadIdx.x; i < tile_n; i += kPlanThreads) {
     const uint32_t e = image[i];
     const uint32_t at = gdelta[image_b[i]] + i;
-    a.w.lid[at] = (uint16_t)(e >> 13);
-    a.w.pos[at] = tile0 + (e & (kPlanTile - 1));
+    if (HASHED) {
+      a.w.lid32[at] = e;
+      a.w.pos[at] = tile0 + image_p[i];
+    } else {
+      a.w.lid[at] = (uint16_t)(e >> 13);
+      a.w.pos[at] = tile0 + (e & (kPlanTile - 1));
+    }
   }
 }
 
@@ -365,6 +447,27 @@ struct BucketCells {
 };
 
 constexpr uint32_t kNoLid = 0xFFFFFFFFu;
+
+// a listed row with more than kPlanLongSeg occurrences: long-row record + one entry per 256-occurrence chunk (one thread;
+// integer atomics only -- the order of the lists influences no floating-point result: chunks are combined in chunk order)
+__device__ __forceinline__ void plan_register_long(const PlanArgs& a, const rc_plan_row& e, uint32_t side) {
+  const uint32_t nch = (e.n + kPlanChunk - 1) / kPlanChunk;
+  const uint32_t slot = atomicAdd(&a.w.counters[PC_LONG], 1u);
+  const uint32_t cbase = atomicAdd(&a.w.counters[PC_CHUNKS], nch);
+  if (slot < a.lw.long_cap) {
+    PlanLongRow r;
+    r.row = e.row; r.start = e.start; r.n = e.n; r.cbase = cbase; r.nchunks = nch; r.side = side;
+    r.pad0 = r.pad1 = 0;
+    a.lw.lrows[slot] = r;
+  }
+  for (uint32_t k = 0; k < nch; ++k)
+    if (cbase + k < a.lw.chunk_cap) {
+      PlanChunkInfo c;
+      c.lrow = slot;
+      c.k = k;
+      a.lw.chunks[cbase + k] = c;
+    }
+}
 
 // occurrences per id of one bucket into the LDS cells (all threads of the workgroup, order-free LDS atomics);
 // reads the 2-byte id stream only
@@ -453,6 +556,7 @@ __global__ __launch_bounds__(kBucketThreads) void plan_bucket_kernel(PlanArgs a)
       e.n = c;
       e.reserved = 0;
       rows[row_at++] = e;
+      if (a.emit_long && c > (uint32_t)kPlanLongSeg) plan_register_long(a, e, side_b ? 1u : 0u);
       cells.set(lid, occ_off);
       occ_off += c;
     } else {
@@ -515,6 +619,161 @@ __global__ __launch_bounds__(kBucketThreads) void plan_bucket_kernel(PlanArgs a)
   }
 }
 
+// ---- 4h. hashed geometry: one workgroup per bucket, the bucket's ids grouped through an LDS hash table ---------------
+// A bucket holds the keys whose id hashes to it -- any ids of the table, not an id range -- so the count / cursor cell
+// of a row is found by open addressing (linear probing, atomicCAS claims a slot) instead of by index.  Otherwise the
+// passes are those of plan_bucket_kernel: pass 1 counts (all waves, order-free), a scan over the SLOTS turns counts
+// into cursors and emits the row records, wave 0 alone walks the keys in position order and hands out the slots of
+// every row ascending.  8,192 slots for ~1,024 keys per bucket (plan_geometry): load <= 1/8 when all keys differ.
+__device__ __forceinline__ uint32_t hash_slot0(uint32_t id) { return (id * 0x85EBCA6Bu) >> (32 - 13); }
+static_assert(kPlanHashSlots == 8192, "hash_slot0 yields 13 bits");
+
+// slot of `id`, claiming an empty one on first sight (pass 1) -- or kPlanHashSlots when the table is full
+__device__ __forceinline__ uint32_t hash_insert(uint32_t* keys, uint32_t id) {
+  uint32_t h = hash_slot0(id);
+  for (uint32_t probe = 0; probe < kPlanHashSlots; ++probe) {
+    const uint32_t k = __hip_atomic_load(&keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (k == id) return h;
+    if (k == 0xFFFFFFFFu) {
+      const uint32_t old = atomicCAS(&keys[h], 0xFFFFFFFFu, id);
+      if (old == 0xFFFFFFFFu || old == id) return h;
+    }
+    h = (h + 1) & (kPlanHashSlots - 1);
+  }
+  return kPlanHashSlots;
+}
+// slot of an id that pass 1 inserted
+__device__ __forceinline__ uint32_t hash_find(const uint32_t* keys, uint32_t id) {
+  uint32_t h = hash_slot0(id);
+  for (uint32_t probe = 0; probe < kPlanHashSlots; ++probe) {
+    if (keys[h] == id) return h;
+    h = (h + 1) & (kPlanHashSlots - 1);
+  }
+  return 0;
+}
+
+__global__ __launch_bounds__(kBucketThreads) void plan_bucket_hash_kernel(PlanArgs a) {
+  extern __shared__ uint32_t tab[];  // keys [S], cells [S], 16 words of scan scratch
+  constexpr uint32_t S = kPlanHashSlots;
+  constexpr uint32_t kSingle = 0x80000000u;
+  uint32_t* keys = tab;
+  uint32_t* cells = tab + S;
+  uint32_t* scratch = cells + S;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const uint32_t bkt = blockIdx.x;
+  const uint32_t beg = a.w.bucket_base[bkt], end = a.w.bucket_base[bkt + 1];
+  if (beg == end) return;  // block-uniform
+  const bool side_b = bkt >= a.g.nb_a;
+  const bool list_all = side_b || a.list_single_a != 0;
+  for (uint32_t i = tid; i < S; i += kBucketThreads) {
+    keys[i] = 0xFFFFFFFFu;
+    cells[i] = 0;
+  }
+  __syncthreads();
+
+  // pass 1: occurrences per id
+  constexpr int kCountBatch = 8;
+  for (uint32_t j0 = beg; j0 < end; j0 += kBucketThreads * kCountBatch) {
+    uint32_t k[kCountBatch];
+#pragma unroll
+    for (int q = 0; q < kCountBatch; ++q) {
+      const uint32_t j = j0 + q * kBucketThreads + tid;
+      k[q] = j < end ? a.w.lid32[j] : 0xFFFFFFFFu;
+    }
+#pragma unroll
+    for (int q = 0; q < kCountBatch; ++q)
+      if (k[q] != 0xFFFFFFFFu) {
+        const uint32_t h = hash_insert(keys, k[q]);
+        if (h < S) atomicAdd(&cells[h], 1u);
+        else a.w.counters[PC_STATUS] = 2u;   // more distinct rows than slots: the plan is incomplete (never at the sizes plan_geometry admits)
+      }
+  }
+  __syncthreads();
+
+  // scan over the slots: counts -> cursors (listed rows) / marker (rows that are only flagged); row records
+  constexpr uint32_t per = S / kBucketThreads;
+  uint32_t my_occ = 0, my_rows = 0;
+  for (uint32_t j = 0; j < per; ++j) {
+    const uint32_t c = cells[tid * per + j];
+    if (c != 0 && (list_all || c >= 2)) {
+      my_occ += c;
+      ++my_rows;
+    }
+  }
+  const uint32_t occ_incl = wave_inclusive_scan(my_occ, lane);
+  const uint32_t rows_incl = wave_inclusive_scan(my_rows, lane);
+  if (lane == 63) {
+    scratch[wave] = occ_incl;
+    scratch[4 + wave] = rows_incl;
+  }
+  __syncthreads();
+  uint32_t occ_off = occ_incl - my_occ, row_at = rows_incl - my_rows, total_rows = 0;
+  for (int w = 0; w < kBucketThreads / 64; ++w) {
+    if (w < wave) {
+      occ_off += scratch[w];
+      row_at += scratch[4 + w];
+    }
+    total_rows += scratch[4 + w];
+  }
+  if (tid == 0) scratch[8] = total_rows ? atomicAdd(side_b ? a.n_rows_b : a.n_rows_a, total_rows) : 0u;
+  __syncthreads();
+  row_at += scratch[8];
+  rc_plan_row* rows = side_b ? a.rows_b : a.rows_a;
+  for (uint32_t j = 0; j < per; ++j) {
+    const uint32_t sl = tid * per + j;
+    const uint32_t c = cells[sl];
+    if (c == 0) continue;
+    if (list_all || c >= 2) {
+      rc_plan_row e;
+      e.row = keys[sl];
+      e.start = beg + occ_off;
+      e.n = c;
+      e.reserved = 0;
+      rows[row_at++] = e;
+      if (a.emit_long && c > (uint32_t)kPlanLongSeg) plan_register_long(a, e, side_b ? 1u : 0u);
+      cells[sl] = occ_off;
+      occ_off += c;
+    } else {
+      cells[sl] = kSingle;
+    }
+  }
+  __syncthreads();
+  if (wave != 0) return;
+
+  // pass 2 (wave 0): positions into their row's slots, ascending
+  uint8_t* single = (side_b || a.flags_done) ? nullptr : a.single_a;
+  for (uint32_t j0 = beg; j0 < end; j0 += 64) {
+    const uint32_t j = j0 + lane;
+    const bool valid = j < end;
+    const uint32_t lid = valid ? a.w.lid32[j] : 0xFFFFFFFFu;
+    const uint32_t p = valid ? a.w.pos[j] : 0u;
+    uint32_t old = 0, now = 1;
+    if (valid) {
+      const uint32_t h = hash_find(keys, lid);
+      old = atomicAdd(&cells[h], 1u);
+      now = __hip_atomic_load(&cells[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    uint32_t slot = old;
+    uint64_t pending = __ballot(valid && now != old + 1u);  // rows shared by several lanes of this round
+    while (pending) {
+      const int leader = __ffsll((long long)pending) - 1;
+      const uint32_t lid0 = __shfl(lid, leader, 64);
+      const uint32_t now0 = __shfl(now, leader, 64);
+      const uint64_t same = __ballot(valid && lid == lid0);
+      if (valid && lid == lid0) slot = now0 - (uint32_t)__popcll(same) + (uint32_t)__popcll(same & lanes_below(lane));
+      pending &= ~same;
+    }
+    if (!valid) continue;
+    if (slot & kSingle) {
+      if (single) single[p] = 1;
+    } else {
+      a.occ[beg + slot] = p;
+    }
+  }
+}
+
 // ---- 4a. the bitmap of multi-occurrence rows of list a: what the fused BPRMF kernel needs from the plan.
 // One workgroup per bucket: LDS count table from the 2-byte id stream (all four waves, order-free), then thread t
 // packs the cells of ids 32 t .. 32 t + 31 into one word -- bit = 1 iff the row occurs at least twice -- and the
@@ -555,15 +814,19 @@ __global__ __launch_bounds__(kBucketThreads) void plan_bitmap_kernel(PlanArgs a)
 int plan_launch_front(const PlanArgs& a, bool bitmap, hipStream_t s) {
   const PlanGeom& g = a.g;
   const size_t hist_lds = (size_t)g.nb * sizeof(uint32_t);
-  hipLaunchKernelGGL(plan_count_kernel, dim3(g.tiles), dim3(kPlanThreads), hist_lds, s, a);
+  if (g.hashed) hipLaunchKernelGGL(plan_count_kernel<true>, dim3(plan_tile_grid(g.tiles)), dim3(kPlanThreads), hist_lds, s, a);
+  else hipLaunchKernelGGL(plan_count_kernel<false>, dim3(plan_tile_grid(g.tiles)), dim3(kPlanThreads), hist_lds, s, a);
   RC_LAUNCH_CHECK();
   hipLaunchKernelGGL(plan_colscan_kernel, dim3((g.nb + 3) / 4), dim3(kBlock), 0, s, a);
   RC_LAUNCH_CHECK();
   const size_t nbp = (g.nb + 1) & ~(size_t)1;
-  const size_t sc_lds = (nbp + kPlanTile + 2 * kPlanWaves) * sizeof(uint32_t) + ((size_t)kPlanTile + kPlanWaves * nbp) * sizeof(uint16_t);
-  hipLaunchKernelGGL(plan_scatter_kernel, dim3(g.tiles), dim3(kPlanThreads), sc_lds, s, a);
+  const size_t sc_lds = (nbp + kPlanTile + 2 * kPlanWaves) * sizeof(uint32_t) +
+                        ((size_t)kPlanTile * (g.hashed ? 2 : 1) + kPlanWaves * nbp) * sizeof(uint16_t);
+  if (g.hashed) hipLaunchKernelGGL(plan_scatter_kernel<true>, dim3(plan_tile_grid(g.tiles)), dim3(kPlanThreads), sc_lds, s, a);
+  else hipLaunchKernelGGL(plan_scatter_kernel<false>, dim3(plan_tile_grid(g.tiles)), dim3(kPlanThreads), sc_lds, s, a);
   RC_LAUNCH_CHECK();
   if (bitmap && a.bitmap_a && g.nb_a > 0) {
+    if (g.hashed) return fail(RC_ERR_UNSUPPORTED, "bucket plan: the multi-occurrence bitmap needs the direct (id-range) geometry");
     const size_t ids = (size_t)1 << g.shift;
     if (g.shift > 8) {
       hipLaunchKernelGGL(plan_bitmap_kernel<false>, dim3(g.nb_a), dim3(kBucketThreads), (ids / 2 + kBucketThreads + 16) * sizeof(uint32_t), s, a);
@@ -578,6 +841,11 @@ int plan_launch_front(const PlanArgs& a, bool bitmap, hipStream_t s) {
 // back: per bucket, row records + grouped positions (+ the flags unless a.flags_done)
 int plan_launch_back(const PlanArgs& a, hipStream_t s) {
   const PlanGeom& g = a.g;
+  if (g.hashed) {
+    hipLaunchKernelGGL(plan_bucket_hash_kernel, dim3(g.nb), dim3(kBucketThreads), (2 * kPlanHashSlots + 16) * sizeof(uint32_t), s, a);
+    RC_LAUNCH_CHECK();
+    return RC_OK;
+  }
   const size_t ids = (size_t)1 << g.shift;
   if (g.shift > 8) {  // 16-bit cells: every bucket below 32,768 keys
     hipLaunchKernelGGL(plan_bucket_kernel<false>, dim3(g.nb), dim3(kBucketThreads), (ids / 2 + kBucketThreads + 16) * sizeof(uint32_t), s, a);
@@ -596,12 +864,20 @@ int plan_launch(const PlanArgs& a, hipStream_t s, hipEvent_t* ev_after_scatter) 
 }
 
 int plan_prepare() {
-  static bool done = false;
-  if (done) return RC_OK;
-  // the scatter kernel needs up to ~130 KB of dynamic LDS at 4,096 buckets
-  RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(plan_scatter_kernel),
+  // function attributes are per device: once per device of the process
+  static bool done[64] = {};
+  int dev = 0;
+  RC_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64) return fail(RC_ERR_UNSUPPORTED, "bucket plan: device index %d", dev);
+  if (done[dev]) return RC_OK;
+  // the scatter kernel needs up to ~150 KB of dynamic LDS at 4,096 buckets
+  RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(plan_scatter_kernel<false>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  done = true;
+  RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(plan_scatter_kernel<true>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(plan_bucket_hash_kernel),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+  done[dev] = true;
   return RC_OK;
 }
 
@@ -663,8 +939,8 @@ extern "C" int rc_bucket_multi_bitmap(const int64_t* ids_a, int64_t n_a, int64_t
   RC_REQUIRE(ids_a && bitmap && ws, "rc_bucket_multi_bitmap: null pointer");
   PlanArgs a;
   memset(&a, 0, sizeof(a));
-  a.g = plan_geometry(n_a, 0, range_a, 0);
-  if (!a.g.ok)
+  a.g = plan_geometry(n_a, 0, range_a, 0, 0);
+  if (!a.g.ok || a.g.hashed)
     return fail(RC_ERR_UNSUPPORTED, "rc_bucket_multi_bitmap: id range %lld needs more than %d buckets of %d ids",
                 (long long)range_a, kPlanMaxBuckets, 1 << kPlanMaxShift);
   a.w = carve_plan_ws(ws, n_a);

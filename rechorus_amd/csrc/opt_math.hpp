@@ -80,6 +80,8 @@ __device__ __forceinline__ void opt_elem(const OptScalars& a, float g, float& w,
     const float delta = sqrtf(v + a.eps) / std * g;   // acc_delta.add(eps).sqrt_().div_(std).mul_(g)
     v = fmaf(a.one_m_b2, delta * delta, v * a.b2);    // acc_delta.mul_(rho).addcmul_(delta, delta, 1 - rho)
     w = fmaf(a.neg_lr, delta, w);           // param.add_(delta, alpha=-lr)
+  } else if (MODE == MODE_DENSE_GRAD) {     // no optimizer: the "table" is a gradient buffer, its row := the summed gradient
+    w = g;
   }
 }
 

@@ -24,8 +24,17 @@ struct PlanGeom {
   uint32_t tiles;
   int bucket_bits;       // bits of a bucket index
   int64_t n;
+  // hashed buckets (sparse or very wide id spaces, where one bucket per 8,192-id range would cost more table cells than
+  // there are keys): bucket = top bits of id * 0x9E3779B1 (nb_a, nb_b powers of two, list b behind list a), the id itself
+  // is carried as the in-bucket key and grouped through an LDS hash table (plan_bucket_hash_kernel)
+  int hashed;
+  int log_nb_a, log_nb_b;
 };
-PlanGeom plan_geometry(int64_t n_a, int64_t n_b, int64_t range_a, int64_t range_b);
+constexpr uint32_t kPlanHashSlots = 8192;   // LDS hash table of a hashed bucket (keys + cells: 64 KB)
+constexpr int kPlanHashKeysPerBucket = 1024; // sizing target: distinct rows per bucket <= keys per bucket ~ load 1/8
+// want: -1 = by density (hashed buckets where the id range is more than 16 cells per key), 0 = id-range buckets wherever they
+// exist (callers that need the id-indexed bitmap), 1 = hashed
+PlanGeom plan_geometry(int64_t n_a, int64_t n_b, int64_t range_a, int64_t range_b, int want = -1);
 
 // counters (device uint32[PC_N]); zeroed by the first kernel of every plan
 enum { PC_ROWS_A = 0, PC_ROWS_B = 1, PC_LONG = 2, PC_CHUNKS = 3, PC_STATUS = 4, PC_N = 8 };
@@ -36,10 +45,23 @@ struct PlanWs {            // carved from the caller's workspace
   uint32_t* bucket_base;   // [nb + 1]
   uint16_t* lid;           // [n] bucketed keys, split by consumer: id within its bucket (< 2^13) ...
   uint32_t* pos;           // [n] ... and batch position (the singleton bitmap and the counting passes read lid only)
+  uint32_t* lid32;         // [n] hashed geometry: the whole id (aliases nothing; lid is unused then)
   uint32_t* counters;      // PC_N
   size_t total;
 };
 PlanWs carve_plan_ws(void* base, int64_t n);
+
+struct PlanLongRow { uint32_t row, start, n, cbase, nchunks, side, pad0, pad1; };
+struct PlanChunkInfo { uint32_t lrow, k; };
+
+struct PlanLongWs {
+  PlanLongRow* lrows;
+  PlanChunkInfo* chunks;
+  float* partial;
+  uint32_t long_cap, chunk_cap;
+  size_t total;
+};
+PlanLongWs carve_plan_long_ws(void* base, int64_t n, int d);
 
 struct PlanArgs {
   const int64_t* ids_a;
@@ -57,6 +79,12 @@ struct PlanArgs {
   uint32_t* occ;           // [n]
   int flags_done;          // the singleton information exists already (bitmap_a from plan_launch_front): the bucket kernel skips single_a
   uint32_t* bitmap_a;      // [nb_a << (shift - 5)] or null: bit (id) = 1 iff row id of list a occurs at least twice in the batch
+  // hot rows (more than kPlanLongSeg occurrences) of the listed rows: registered by the bucket kernel itself when
+  // emit_long is set (long-row records + chunk list in lw, counters PC_LONG / PC_CHUNKS), so that the consumer can
+  // reduce their chunks in the SAME launch as the short rows (plan_update.hip, BPRMF step); otherwise the row-update
+  // kernel finds them while it walks the records
+  int emit_long;
+  PlanLongWs lw;
 };
 int plan_launch(const PlanArgs& a, hipStream_t s, hipEvent_t* ev_after_scatter);
 // the same plan in two parts, so that a caller can run `back` on another stream (train_step.hip);
@@ -83,17 +111,6 @@ struct PlanGrad {
   int pair;
 };
 
-struct PlanLongRow { uint32_t row, start, n, cbase, nchunks, side, pad0, pad1; };
-struct PlanChunkInfo { uint32_t lrow, k; };
-
-struct PlanLongWs {
-  PlanLongRow* lrows;
-  PlanChunkInfo* chunks;
-  float* partial;
-  uint32_t long_cap, chunk_cap;
-  size_t total;
-};
-PlanLongWs carve_plan_long_ws(void* base, int64_t n, int d);
 
 int device_cus();
 

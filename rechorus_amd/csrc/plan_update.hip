@@ -38,6 +38,9 @@ struct PlanUpdArgs {
   int64_t loss_n;
   float loss_scale;
   float* loss_out;
+  // the plan registered the hot rows already (bucket_plan.hip, emit_long): their chunks are reduced by extra workgroups
+  // of the row-update launch instead of a launch of their own
+  int long_planned;
 };
 
 __device__ __forceinline__ void padd4(float4& x, const float4& y) {
@@ -277,13 +280,20 @@ __device__ __forceinline__ void plan_long_only_body(const PlanUpdArgs& a, int si
 }
 
 // launch 1 of the BPRMF step's update: item rows (side 0) updated, hot rows of BOTH sides planned
+template <int D>
+__device__ __forceinline__ void plan_chunk_body(const PlanUpdArgs& a, uint32_t first_block, uint32_t n_blocks, float4* part);
+
 template <int D, int MODE>
 __global__ __launch_bounds__(kBlock) void plan_rows_kernel(PlanUpdArgs a, uint32_t blocks_main, int update_side,
-                                                          int plan_other) {
+                                                          int plan_other, uint32_t blocks_chunk) {
+  __shared__ float4 part[kBlock];   // chunk workgroups only
+  const bool plan_long = a.long_planned == 0;
   if (blockIdx.x < blocks_main) {
-    if (LPR_OK(D) && plan_side_indexed(a.side[update_side])) plan_rows_indexed_body<D, MODE>(a, update_side, true, 0, blocks_main);
-    else plan_rows_body<D, MODE>(a, update_side, true, 0, blocks_main);
-  } else if (plan_other) plan_long_only_body<D>(a, 1 - update_side, blocks_main, gridDim.x - blocks_main);
+    if (LPR_OK(D) && plan_side_indexed(a.side[update_side])) plan_rows_indexed_body<D, MODE>(a, update_side, plan_long, 0, blocks_main);
+    else plan_rows_body<D, MODE>(a, update_side, plan_long, 0, blocks_main);
+  } else if (blockIdx.x < blocks_main + blocks_chunk) {
+    plan_chunk_body<D>(a, blocks_main, blocks_chunk, part);   // hot rows of BOTH sides, registered by the plan
+  } else if (plan_other) plan_long_only_body<D>(a, 1 - update_side, blocks_main + blocks_chunk, gridDim.x - blocks_main - blocks_chunk);
 }
 
 // LDS tree over the lane-groups of a block, fixed order; result in group 0's slots
@@ -303,15 +313,14 @@ __device__ __forceinline__ void plan_tree_sum(float4* part, int g) {
 }
 
 template <int D>
-__global__ __launch_bounds__(kBlock) void plan_chunk_kernel(PlanUpdArgs a) {
+__device__ __forceinline__ void plan_chunk_body(const PlanUpdArgs& a, uint32_t first_block, uint32_t n_blocks, float4* part) {
   constexpr int LPR = D / 4;
   constexpr int GPB = kBlock / LPR;
-  __shared__ float4 part[kBlock];
   const int l = threadIdx.x % LPR;
   const int g = threadIdx.x / LPR;
   uint32_t n_chunks = a.counters[PC_CHUNKS];
   if (n_chunks > a.lw.chunk_cap) n_chunks = a.lw.chunk_cap;
-  for (uint32_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+  for (uint32_t c = blockIdx.x - first_block; c < n_chunks; c += n_blocks) {
     const PlanChunkInfo ci = a.lw.chunks[c];
     const PlanLongRow r = a.lw.lrows[ci.lrow];
     const PlanGrad& gs = a.side[r.side].g;
@@ -332,6 +341,12 @@ __global__ __launch_bounds__(kBlock) void plan_chunk_kernel(PlanUpdArgs a) {
     if (g == 0) reinterpret_cast<float4*>(a.lw.partial)[(size_t)(r.cbase + ci.k) * LPR + l] = part[threadIdx.x];
     __syncthreads();  // part[] is reused by the next chunk
   }
+}
+
+template <int D>
+__global__ __launch_bounds__(kBlock) void plan_chunk_kernel(PlanUpdArgs a) {
+  __shared__ float4 part[kBlock];
+  plan_chunk_body<D>(a, 0, gridDim.x, part);
 }
 
 // last launch: short rows of `update_side` (BPRMF step: the user table, whose pre-step rows every earlier launch
@@ -398,7 +413,7 @@ template <int D, int MODE>
 static int launch_side_update(const PlanUpdArgs& a, int64_t n_occ, hipStream_t s) {
   const uint32_t cus = (uint32_t)device_cus();
   const uint32_t blocks_main = cus * 32;
-  hipLaunchKernelGGL((plan_rows_kernel<D, MODE>), dim3(blocks_main), dim3(kBlock), 0, s, a, blocks_main, 0, 0);
+  hipLaunchKernelGGL((plan_rows_kernel<D, MODE>), dim3(blocks_main), dim3(kBlock), 0, s, a, blocks_main, 0, 0, 0u);
   RC_LAUNCH_CHECK();
   if (n_occ > kPlanLongSeg) {
     hipLaunchKernelGGL((plan_chunk_kernel<D>), dim3(1024), dim3(kBlock), 0, s, a);
@@ -427,12 +442,21 @@ static int launch_step_updates(const PlanUpdArgs& a, int64_t n_occ, hipStream_t 
   // grid-stride over the rows with 4x more workgroups than fit at once: a grid of exactly "8 per CU" ran in two
   // rounds whenever the kernel's registers allowed only 7 (Adam: 72 VGPRs -> item update 2.05 instead of 1.5 ms)
   const uint32_t blocks_main = cus * 32;
-  const uint32_t blocks_other = 64;
-  hipLaunchKernelGGL((plan_rows_kernel<D, MODE>), dim3(blocks_main + blocks_other), dim3(kBlock), 0, s, a, blocks_main, 0, 1);
-  RC_LAUNCH_CHECK();
-  if (n_occ > kPlanLongSeg) {  // otherwise no row can be hot
-    hipLaunchKernelGGL((plan_chunk_kernel<D>), dim3(1024), dim3(kBlock), 0, s, a);
+  if (a.long_planned) {
+    // hot rows came with the plan: their chunk sums ride in this launch (workgroups behind the row workgroups; they only
+    // read pre-step rows and write the partial buffer, so they need no ordering against the row updates)
+    const uint32_t blocks_chunk = n_occ > kPlanLongSeg ? 512 : 0;
+    hipLaunchKernelGGL((plan_rows_kernel<D, MODE>), dim3(blocks_main + blocks_chunk), dim3(kBlock), 0, s, a, blocks_main, 0, 0,
+                       blocks_chunk);
     RC_LAUNCH_CHECK();
+  } else {
+    const uint32_t blocks_other = 64;
+    hipLaunchKernelGGL((plan_rows_kernel<D, MODE>), dim3(blocks_main + blocks_other), dim3(kBlock), 0, s, a, blocks_main, 0, 1, 0u);
+    RC_LAUNCH_CHECK();
+    if (n_occ > kPlanLongSeg) {  // otherwise no row can be hot
+      hipLaunchKernelGGL((plan_chunk_kernel<D>), dim3(1024), dim3(kBlock), 0, s, a);
+      RC_LAUNCH_CHECK();
+    }
   }
   if (ev_items_done) RC_HIP(hipEventRecord(*ev_items_done, s));
   const uint32_t blocks_rows = cus * 2;
@@ -460,11 +484,12 @@ int plan_bprmf_step_updates(float* U, float* mU, float* vU, float* I, float* mI,
                             int C, int64_t n_i, int64_t B, const float* gpred, const float* ugrad,
                             const rc_plan_row* rows_i, const uint32_t* n_rows_i, const rc_plan_row* rows_u,
                             const uint32_t* n_rows_u, const uint32_t* occ, uint32_t* counters,
-                            const PlanLongWs& lw,
+                            const PlanLongWs& lw, bool long_planned,
                             const rc_opt_hyper* h, const float* loss_vec, float loss_scale, float* loss_out,
                             hipStream_t s, hipEvent_t* ev_items_done) {
   PlanUpdArgs a;
   memset(&a, 0, sizeof(a));
+  a.long_planned = long_planned ? 1 : 0;
   RC_TRY(fill_opt_scalars(h, &a.o));
   const int mode = mode_of(h);
   RC_REQUIRE(mode != MODE_ADAM || (mU && vU && mI && vI), "rc_bprmf_train_step: Adam needs m and v tables");
@@ -511,15 +536,17 @@ UpdWs carve_upd_ws(void* base, int64_t n_occ, int d) {
   return w;
 }
 
+// h == nullptr: no optimizer, the listed rows of "W" receive the summed gradient rows (MODE_DENSE_GRAD)
 int run_side_update(PlanUpdArgs& a, const rc_opt_hyper* h, int d_eff, int64_t n_occ, void* ws, size_t ws_bytes,
                     rc_stream_t stream, const char* who) {
   const UpdWs w = carve_upd_ws(ws, n_occ, d_eff);
   if (ws_bytes < w.total) return fail(RC_ERR_WORKSPACE, "%s: workspace %zu < %zu", who, ws_bytes, w.total);
-  RC_TRY(fill_opt_scalars(h, &a.o));
+  if (h != nullptr) RC_TRY(fill_opt_scalars(h, &a.o));
   a.counters = w.counters;
   a.lw = w.lw;
   hipStream_t s = as_stream(stream);
   RC_HIP(hipMemsetAsync(w.counters, 0, PC_N * sizeof(uint32_t), s));
+  if (h == nullptr) return launch_side_update_d<MODE_DENSE_GRAD>(a, d_eff, n_occ, s);
   switch (mode_of(h)) {
     case MODE_SGD: return launch_side_update_d<MODE_SGD>(a, d_eff, n_occ, s);
     case MODE_ADAM: return launch_side_update_d<MODE_ADAM>(a, d_eff, n_occ, s);
@@ -580,4 +607,54 @@ extern "C" int rc_plan_update_pair(float* W_a, float* m_a, float* v_a, float* W_
   a.side[0].n_rows = n_rows;
   a.occ = occ;
   return run_side_update(a, h, 2 * d, n_occ, ws, ws_bytes, stream, "rc_plan_update_pair");
+}
+
+/* out[row, :] = sum over the row's occurrences of their gradient rows, for the rows the plan lists (other rows of `out`
+ * are left as they are): aten::embedding_dense_backward's index_add as a plan consumer, no optimizer. */
+extern "C" int rc_plan_row_sums(float* out, int d, const rc_plan_row* rows, const uint32_t* n_rows, const uint32_t* occ,
+                                int64_t n_occ, const float* coef, const float* src, const int64_t* src_index, int div,
+                                const float* src2, int64_t n_split, void* ws, size_t ws_bytes, rc_stream_t stream) {
+  if (n_occ == 0) return RC_OK;
+  RC_REQUIRE(out && rows && n_rows && occ && ws, "rc_plan_row_sums: null pointer");
+  RC_REQUIRE(n_occ > 0 && n_occ < ((int64_t)1 << 31) && div >= 1 && n_split >= 0 && n_split <= n_occ,
+             "rc_plan_row_sums: bad sizes n_occ=%lld div=%d n_split=%lld", (long long)n_occ, div, (long long)n_split);
+  RC_REQUIRE(src || src2, "rc_plan_row_sums: gradient source missing (src for positions < n_split, src2 for the others)");
+  RC_REQUIRE(al16(out) && al16(src) && al16(src2), "rc_plan_row_sums: buffers must be 16-byte aligned");
+  PlanUpdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.side[0].t = PlanTable{out, nullptr, nullptr};
+  a.side[0].g = PlanGrad{coef, src, src_index, div, src2, (uint32_t)n_split, nullptr, 0};
+  a.side[0].rows = rows;
+  a.side[0].n_rows = n_rows;
+  a.occ = occ;
+  return run_side_update(a, nullptr, d, n_occ, ws, ws_bytes, stream, "rc_plan_row_sums");
+}
+
+namespace rc {
+// one thread per listed row: its id, and its record index at every position that touches it
+__global__ __launch_bounds__(kBlock) void plan_distinct_kernel(const rc_plan_row* __restrict__ rows, const uint32_t* __restrict__ n_rows,
+                                                               const uint32_t* __restrict__ occ, uint32_t occ_base,
+                                                               int64_t* __restrict__ uniq, int64_t* __restrict__ inverse) {
+  const uint32_t nr = *n_rows;
+  for (uint32_t r = blockIdx.x * kBlock + threadIdx.x; r < nr; r += gridDim.x * kBlock) {
+    const rc_plan_row e = rows[r];
+    uniq[r] = (int64_t)e.row;
+    for (uint32_t k = 0; k < e.n; ++k) inverse[occ[e.start + k] - occ_base] = (int64_t)r;
+  }
+}
+}  // namespace rc
+
+/* The distinct ids of a planned list and the inverse index (torch.unique(return_inverse=True) without the sort: the
+ * order of `uniq` is the plan's record order): uniq[r] = id of record r, inverse[p - occ_base] = r for every position p
+ * of the record.  The count stays on the device (*n_rows).  uniq: capacity = list length. */
+extern "C" int rc_plan_distinct(const rc_plan_row* rows, const uint32_t* n_rows, const uint32_t* occ, int64_t occ_base,
+                                int64_t n_list, int64_t* uniq, int64_t* inverse, rc_stream_t stream) {
+  if (n_list == 0) return RC_OK;
+  RC_REQUIRE(rows && n_rows && occ && uniq && inverse, "rc_plan_distinct: null pointer");
+  RC_REQUIRE(n_list > 0 && occ_base >= 0 && occ_base < ((int64_t)1 << 31), "rc_plan_distinct: bad sizes");
+  const int64_t blocks = (n_list + kBlock - 1) / kBlock;
+  hipLaunchKernelGGL(plan_distinct_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(kBlock), 0, as_stream(stream),
+                     rows, n_rows, occ, (uint32_t)occ_base, uniq, inverse);
+  RC_LAUNCH_CHECK();
+  return RC_OK;
 }

@@ -25,7 +25,7 @@ int plan_bprmf_step_updates(float* U, float* mU, float* vU, float* I, float* mI,
                             int C, int64_t n_i, int64_t B, const float* gpred, const float* ugrad,
                             const rc_plan_row* rows_i, const uint32_t* n_rows_i, const rc_plan_row* rows_u,
                             const uint32_t* n_rows_u, const uint32_t* occ, uint32_t* counters,
-                            const PlanLongWs& lw,
+                            const PlanLongWs& lw, bool long_planned,
                             const rc_opt_hyper* h, const float* loss_vec, float loss_scale, float* loss_out,
                             hipStream_t s, hipEvent_t* ev_items_done);
 int plan_prepare();
@@ -91,6 +91,7 @@ struct PlanSlot {
   rc_plan_row* rows_u;
   uint32_t* occ;
   uint32_t* bitmap;
+  PlanLongWs plan_long;   // hot rows of this plan: long-row records, chunk list (+ the chunk partial sums of its updates)
 };
 struct StepWs {
   uint32_t* keys_i;
@@ -109,7 +110,6 @@ struct StepWs {
   size_t seg_ws_bytes;
   // bucket-plan step (the default where the id space allows it)
   PlanSlot slot[2];
-  PlanLongWs plan_long;
   void* small_extra;     // small-batch step (small_step.hip): user-row snapshot, per-workgroup row / position segments
   size_t total;
 };
@@ -146,10 +146,8 @@ StepWs carve_step_ws(void* base, int B, int C, int d) {
     w.slot[k].rows_u = pv.take<rc_plan_row>((size_t)B);
     w.slot[k].occ = pv.take<uint32_t>(n_i + (size_t)B);
     w.slot[k].bitmap = pv.take<uint32_t>(kPlanBitmapWords);
-  }
-  {
     const PlanLongWs lw = carve_plan_long_ws(base ? reinterpret_cast<char*>(base) + pv.off : nullptr, (int64_t)n_i + B, d);
-    w.plan_long = lw;
+    w.slot[k].plan_long = lw;
     pv.off += align_up(lw.total, 256);
   }
   w.total = cv.off > pv.off ? cv.off : pv.off;
@@ -179,6 +177,8 @@ PlanArgs slot_plan_args(const StepWs& w, int k, const int64_t* uid, const int64_
   pa.rows_a = sl.rows_i; pa.rows_b = sl.rows_u;
   pa.n_rows_a = &sl.plan.counters[PC_ROWS_A]; pa.n_rows_b = &sl.plan.counters[PC_ROWS_B];
   pa.occ = sl.occ;
+  pa.emit_long = 1;
+  pa.lw = sl.plan_long;
   return pa;
 }
 }  // namespace
@@ -243,12 +243,15 @@ static int train_step_impl(float* U, float* I, float* mU, float* vU, float* mI, 
   // SGD only: with optimizer state the m/v rows have to be fetched at the kernel's tail, where nothing
   // hides their latency (measured at config 2, Adam: 2.98 ms/step fused vs 2.31 ms through the
   // segmented update, which already streams 6 row-units per touched row at the HBM rate).
+  // (a hashed plan geometry -- very wide / sparse id spaces -- has no id-indexed bitmap: every row is listed then)
+  const bool want_bitmap = rc_bprmf_fused_supported(d, C) != 0 && h->opt == RC_OPT_SGD;   // -> id-range buckets if at all possible
+  const PlanGeom geom = plan_geometry(n_i, B, n_items, n_users, want_bitmap ? 0 : -1);
 #if defined(RC_FUSED_UPD_NEVER)
   const bool fused_upd = false;
 #elif defined(RC_FUSED_UPD_ALWAYS)
-  const bool fused_upd = rc_bprmf_fused_supported(d, C) != 0;
+  const bool fused_upd = rc_bprmf_fused_supported(d, C) != 0 && !geom.hashed;
 #else
-  const bool fused_upd = rc_bprmf_fused_supported(d, C) != 0 && h->opt == RC_OPT_SGD;
+  const bool fused_upd = rc_bprmf_fused_supported(d, C) != 0 && h->opt == RC_OPT_SGD && !geom.hashed;
 #endif
   const int flavour = fused_upd ? 1 : 2;   // what a prepared plan contains: bitmap + multi rows / every row listed
 
@@ -273,7 +276,6 @@ static int train_step_impl(float* U, float* I, float* mU, float* vU, float* mI, 
   // fused kernel exists and the joint id space fits one bucket level; otherwise (and with RC_BPRMF_STEP=sort)
   // the round-1 pipeline: joint radix sort -> segment heads -> fused -> segmented updates.
   const bool force_sort = step_pipeline() == 1;
-  const PlanGeom geom = plan_geometry(n_i, B, n_items, n_users);
   const bool fused_ok = rc_bprmf_fused_supported(d, C) != 0;
   // Small batches (<= 32,768 row ids, e.g. the reference's default B = 256 with K = 99): two launches (small_step.hip).
   if (step_pipeline() == 0 && fused_ok && small_step_supported(n_i, B, n_items, n_users, d) &&
@@ -345,7 +347,7 @@ static int train_step_impl(float* U, float* I, float* mU, float* vU, float* mI, 
     RC_MARK(4);
     RC_MARK(5);  // (the loss mean is one workgroup of the last update launch)
     RC_TRY(plan_bprmf_step_updates(U, mU, vU, I, mI, vI, d, uid, C, n_i, B, w.gpred, w.ugrad, pa.rows_a, pa.n_rows_a,
-                                   pa.rows_b, pa.n_rows_b, pa.occ, pa.w.counters, w.plan_long, h, w.loss_vec, inv_b,
+                                   pa.rows_b, pa.n_rows_b, pa.occ, pa.w.counters, pa.lw, true, h, w.loss_vec, inv_b,
                                    loss_out, s, prof ? &ev[6] : nullptr));
     RC_MARK(7);
   } else {

@@ -195,8 +195,6 @@ def bucket_multi_bitmap(ids, n_rows):
     a = ids.reshape(-1)
     lib = _lib.load()
     n = a.numel()
-    if not lib.rc_bucket_plan_supported(n, 0, int(n_rows), 0):
-        raise _lib.RechorusHipError("rc_bucket_plan_supported", -4, "id range too wide for one bucket level")
     bm = torch.empty(max(lib.rc_bucket_bitmap_bytes(int(n_rows)) // 4, 1), dtype=torch.int32, device=a.device)
     ws = workspace(lib.rc_bucket_plan_workspace_bytes(n, 0), a.device, "plan")
     _lib.call("rc_bucket_multi_bitmap", _ptr(a, torch.int64, "ids") if n else None, n, int(n_rows), C.c_void_p(bm.data_ptr()),
@@ -205,31 +203,67 @@ def bucket_multi_bitmap(ids, n_rows):
 
 
 class Plan:
-    """Device-side result of rc_bucket_plan with every distinct row listed (no host round trip: the row counts stay in
-    device memory and the consumers read them there).  Buffers are cached per (device, tag) and reused every step."""
+    """Device-side result of rc_bucket_plan (no host round trip: the row counts stay in device memory and the consumers
+    read them there).  Buffers are cached per (device, tag) and reused every step -- two plans that are alive at the same
+    time need different tags.  list_single_a=False: rows of list a that occur once are not listed but flagged in
+    self.single (uint8 per position), for consumers that update them elsewhere (rc_owner_backward).
+    Negative ids take no part."""
 
-    def __init__(self, ids_a, range_a, ids_b=None, range_b=0, tag="plan"):
+    def __init__(self, ids_a, range_a, ids_b=None, range_b=0, tag="plan", list_single_a=True):
         a = ids_a.reshape(-1)
         b = ids_b.reshape(-1) if ids_b is not None else None
         dev = a.device
         self.n_a, self.n_b = a.numel(), (b.numel() if b is not None else 0)
         lib = _lib.load()
         if not lib.rc_bucket_plan_supported(self.n_a, self.n_b, int(range_a), int(range_b)):
-            raise _lib.RechorusHipError("rc_bucket_plan_supported", -4, "id ranges too wide for one bucket level")
+            raise _lib.RechorusHipError("rc_bucket_plan_supported", -4, "no plan geometry for these id ranges / list lengths")
         n = self.n_a + self.n_b
         na16, nb16 = 16 * max(self.n_a, 1), 16 * max(self.n_b, 1)
         r256 = lambda x: (x + 255) // 256 * 256
         o_b = r256(na16)
         o_occ = o_b + r256(nb16)
         o_cnt = o_occ + r256(4 * max(n, 1))
-        buf = workspace(o_cnt + 256, dev, tag + ".out")
+        o_single = o_cnt + 256
+        n_single = 0 if list_single_a else max(int(lib.rc_bucket_plan_flags_bytes(self.n_a)), 1)
+        buf = workspace(o_single + n_single, dev, tag + ".out")
         self.rows_a, self.rows_b = buf[:na16], buf[o_b:o_b + nb16]
         self.occ, self.cnt = buf[o_occ:o_occ + 4 * max(n, 1)], buf[o_cnt:o_cnt + 8]
+        self.single = None if list_single_a else buf[o_single:o_single + n_single][:self.n_a]
+        self.tag, self.device = tag, dev
         ws = workspace(lib.rc_bucket_plan_workspace_bytes(self.n_a, self.n_b), dev, tag + ".ws")
         p = lambda t: C.c_void_p(t.data_ptr())
         _lib.call("rc_bucket_plan", _ptr(a, torch.int64, "ids_a") if self.n_a else None, self.n_a, int(range_a),
-                  _ptr(b, torch.int64, "ids_b") if self.n_b else None, self.n_b, int(range_b), 1, None,
+                  _ptr(b, torch.int64, "ids_b") if self.n_b else None, self.n_b, int(range_b), 1 if list_single_a else 0,
+                  None if list_single_a else p(buf[o_single:]),
                   p(self.rows_a), p(self.cnt), p(self.rows_b), p(self.cnt[4:]), p(self.occ), p(ws), ws.numel(), _stream())
+
+    def row_sums(self, side, out, coef=None, src=None, src_index=None, div=1, src2=None, n_split=None):
+        """rc_plan_row_sums on list `side`: out[row] = summed gradient row of every listed row (other rows untouched)"""
+        d = out.shape[1]
+        n = self.n_a + self.n_b
+        if n == 0:
+            return out
+        rows, cnt, _ = self._side(side)
+        if n_split is None:
+            n_split = n if src2 is None else 0
+        ws = workspace(_lib.load().rc_plan_update_workspace_bytes(n, d), out.device, self.tag + ".upd")
+        f32 = torch.float32
+        p = lambda t: C.c_void_p(t.data_ptr())
+        _lib.call("rc_plan_row_sums", _ptr(out, f32, "out"), d, p(rows), p(cnt), p(self.occ), n, _ptr(coef, f32, "coef", True),
+                  _ptr(src, f32, "src", True), _ptr(src_index, torch.int64, "src_index", True), int(div),
+                  _ptr(src2, f32, "src2", True), int(n_split), p(ws), ws.numel(), _stream())
+        return out
+
+    def distinct(self, side):
+        """-> (uniq int64 [list length] (the first *count entries are valid), inverse int64 [list length], count int32 [1] on the
+        device): the distinct ids of the list in the plan's record order and every position's index into them"""
+        rows, cnt, base = self._side(side)
+        n_list = self.n_a if side == "a" else self.n_b
+        uniq = torch.empty(max(n_list, 1), dtype=torch.int64, device=self.device)
+        inverse = torch.empty(max(n_list, 1), dtype=torch.int64, device=self.device)
+        p = lambda t: C.c_void_p(t.data_ptr())
+        _lib.call("rc_plan_distinct", p(rows), p(cnt), p(self.occ), base, n_list, p(uniq), p(inverse), _stream())
+        return uniq, inverse[:n_list], cnt[:4].view(torch.int32)
 
     def _side(self, side):
         return (self.rows_a, self.cnt, 0) if side == "a" else (self.rows_b, self.cnt[4:], self.n_a)
@@ -239,7 +273,7 @@ class Plan:
         d = Wa.shape[1]
         n = self.n_a + self.n_b
         rows, cnt, base = self._side(side)
-        ws = workspace(_lib.load().rc_plan_update_workspace_bytes(n, 2 * d), Wa.device, "plan.upd")
+        ws = workspace(_lib.load().rc_plan_update_workspace_bytes(n, 2 * d), Wa.device, self.tag + ".upd")
         f32 = torch.float32
         p = lambda t: C.c_void_p(t.data_ptr())
         _lib.call("rc_plan_update_pair", _ptr(Wa, f32, "W_a"), _ptr(ma, f32, "m_a", True), _ptr(va, f32, "v_a", True),
@@ -253,7 +287,7 @@ class Plan:
         rows, cnt, _ = self._side(side)
         if n_split is None:
             n_split = n if src2 is None else 0
-        ws = workspace(_lib.load().rc_plan_update_workspace_bytes(n, d), W.device, "plan.upd")
+        ws = workspace(_lib.load().rc_plan_update_workspace_bytes(n, d), W.device, self.tag + ".upd")
         f32 = torch.float32
         p = lambda t: C.c_void_p(t.data_ptr())
         _lib.call("rc_plan_update", _ptr(W, f32, "W"), _ptr(m, f32, "m", True), _ptr(v, f32, "v", True), d, p(rows), p(cnt),
@@ -353,17 +387,37 @@ def segmented_pair_supported(d):
     return 2 * d in (16, 32, 64, 128, 256)
 
 
+_EDB_PLAN_MIN = int(os.environ.get("RC_EDB_PLAN_MIN", "8192"))
+_USE_PLAN = os.environ.get("RC_TABLE_UPDATE", "plan") != "sort"   # A/B switch: the trainers' table updates behind a radix sort
+
+
+def unique_ids(ids, n_rows, tag="unique"):
+    """distinct ids + inverse index through the bucket plan (rc_bucket_plan + rc_plan_distinct) -- what
+    torch.unique(ids, return_inverse=True) gives, except that the distinct ids come in the plan's order, not sorted.
+    Reads the count back (one host sync, like torch.unique): callers on a hot path run it on a side stream."""
+    flat = ids.reshape(-1)
+    if flat.numel() == 0:
+        return flat.clone(), flat.clone()
+    uniq, inverse, cnt = Plan(flat, n_rows, tag=tag).distinct("a")
+    return uniq[:int(cnt.item())], inverse
+
+
 def embedding_dense_backward(grad_out, ids, n_rows):
-    """Dense [n_rows,d] gradient of W[ids] (aten::embedding_dense_backward semantics),
-    computed by sort + segmented sum instead of atomics / index_add."""
+    """aten::embedding_dense_backward: G [n_rows, d] = index_add of the per-occurrence gradient rows, in ascending
+    position order per row (no float atomics) -- bucket plan + rc_plan_row_sums; radix sort + segmented sum where no
+    plan geometry exists."""
     d = grad_out.shape[-1]
-    g2 = grad_out.reshape(-1, d)
-    if not g2.is_contiguous():
-        g2 = g2.contiguous()
-    keys, perm = sort_ids(ids, n_rows)
-    dense = torch.zeros((n_rows, d), dtype=torch.float32, device=grad_out.device)
-    segmented_update(keys, perm, g2, dense_grad=dense)
-    return dense
+    flat = ids.reshape(-1)
+    G = torch.zeros((n_rows, d), dtype=torch.float32, device=grad_out.device)
+    if flat.numel() == 0:
+        return G
+    go = grad_out.reshape(-1, d).contiguous()
+    # (below a few thousand ids both routes are a handful of latency-bound launches; the plan pays off with the batch)
+    if d in (16, 32, 64, 128, 256) and flat.numel() >= _EDB_PLAN_MIN and plan_supported(flat.numel(), 0, n_rows, 0):
+        return Plan(flat, n_rows, tag="edb").row_sums("a", G, src2=go)
+    keys, perm = sort_ids(flat, n_rows)
+    segmented_update(keys, perm, go, dense_grad=G)
+    return G
 
 
 def dense_update(W, G, hyper, m=None, v=None):
@@ -621,17 +675,37 @@ class NeumfTrainer:
             rows, dense = neumf_bwd(P, uid, iid, gpred, self.dropout, self.seed)
         h = make_hyper(self.opt, lr=self.lr, l2=self.l2, step=self.step_count)
         h0 = make_hyper(self.opt, lr=self.lr, l2=0.0, step=self.step_count)  # 'bias' params: no weight decay
-        # (a bucket plan + rc_plan_update_pair was measured here at the config-4 shape: 0.70 ms for plan + updates against
-        #  0.69 ms for the two sorts + pair updates -- 0.65 M keys spread over an 11 M-id space leave ~490 keys per bucket,
-        #  and the plan's per-bucket fixed cost (LDS table of 8,192 ids zeroed and scanned) dominates; kept on the sort path)
+        pair_ok = segmented_pair_supported(P["mf_u"].shape[1])
+        n_u, n_i = P["mf_u"].shape[0], P["mf_i"].shape[0]
+        uid_occ = uid.repeat_interleave(Cn)
+        if self.rowwise and pair_ok and _USE_PLAN and plan_supported(iid.numel(), uid_occ.numel(), n_i, n_u):
+            # ONE bucket plan of both id lists (round 3: hashed buckets where the id space is wide and sparse -- 0.33 M item
+            # lookups over 10 M - 100 M rows -- so the cost follows the keys, not the id range; round 2's id-range
+            # buckets cost as much as the radix sort here and the sort stayed), then one pair update per side: the
+            # mf / mlp tables of a side share ids, records and positions
+            with _PhaseTimer(self, "sort"):
+                plan = Plan(iid, n_i, uid_occ, n_u, tag="neumf")
+            with _PhaseTimer(self, "table_update"):
+                for side, ta, tb, ga, gb in (("b", "mf_u", "mlp_u", "g_mf_u", "g_mlp_u"), ("a", "mf_i", "mlp_i", "g_mf_i", "g_mlp_i")):
+                    sa, sb = self.state[ta], self.state[tb]
+                    plan.update_pair(side, P[ta], P[tb], rows[ga], rows[gb], h, ma=sa.get("m"), va=sa.get("v"),
+                                     mb=sb.get("m"), vb=sb.get("v"))
+        else:
+            self._step_tables_sorted(P, uid_occ, iid, rows, h, pair_ok)
+        with _PhaseTimer(self, "dense_update"):
+            dense_update_multi([(P[k], dense[k], h0 if k == "b1" else h, self.state[k].get("m"), self.state[k].get("v"))
+                                for k in ("W1", "b1", "w_out")], self.opt)
+        return self.loss
+
+    def _step_tables_sorted(self, P, uid_occ, iid, rows, h, pair_ok):
+        """the table updates behind a radix sort (dense-gradient mode = the reference's exact optimizer semantics, widths
+        without a pair kernel, id spaces no plan geometry covers)"""
         with _PhaseTimer(self, "sort"):
-            uid_occ = uid.repeat_interleave(Cn)
             ku, pu = sort_ids(uid_occ, P["mf_u"].shape[0])
             ki, pi = sort_ids(iid, P["mf_i"].shape[0])
             # the mf / mlp tables of a side share ids: one sort, ONE head list and ONE update pass serve both
             _, hu, nhu = segment_heads(ku, pu, want_single=False)
             _, hi, nhi = segment_heads(ki, pi, want_single=False)
-        pair_ok = segmented_pair_supported(P["mf_u"].shape[1])
         _upd = _PhaseTimer(self, "table_update")
         _upd.__enter__()
         for ta, tb, ga, gb, keys, perm, hd, nh in (("mf_u", "mlp_u", "g_mf_u", "g_mlp_u", ku, pu, hu, nhu),
@@ -655,10 +729,6 @@ class NeumfTrainer:
                 dense_update(P[ta], G[0], h, sa.get("m"), sa.get("v"))
                 dense_update(P[tb], G[1], h, sb.get("m"), sb.get("v"))
         _upd.__exit__()
-        with _PhaseTimer(self, "dense_update"):
-            dense_update_multi([(P[k], dense[k], h0 if k == "b1" else h, self.state[k].get("m"), self.state[k].get("v"))
-                                for k in ("W1", "b1", "w_out")], self.opt)
-        return self.loss
 
 
 # ---- dense layers (csrc/mlp.hip) -------------------------------------------------------------------------
@@ -877,16 +947,34 @@ class SasrecTrainer:
         # item table: candidate occurrences (g * hv, rebuilt on the fly) + history occurrences (g_hist rows)
         _upd = _PhaseTimer(self, "table_update")
         _upd.__enter__()
-        ids = torch.cat([iid.reshape(-1), hist.reshape(-1)])
-        keys, perm = sort_ids(ids, I.shape[0])
         st = self._st(I)
-        if self.rowwise:
-            segmented_update2(keys, perm, hv, g_hist.view(-1, d), B * Cn, hyper=h, W=I, m=st.get("m"), v=st.get("v"),
-                              coef=gpred.reshape(-1), div=Cn)
+        n_occ = B * Cn + hist.numel()
+        if _USE_PLAN and n_occ >= _EDB_PLAN_MIN and plan_supported(n_occ, 0, I.shape[0], 0):
+            # bucket plan of candidate + history ids.  The padding slots of the history windows (id 0, zero gradient rows:
+            # half of B * history_max occurrences of ONE row) are marked "takes no part" (negative id) except the first of
+            # them, which keeps row 0 among the touched rows exactly as before -- a sum of zero rows is zero either way.
+            L = hist.shape[1]
+            pad = torch.arange(L, device=hist.device)[None, :] >= lengths[:, None]
+            hid = torch.where(pad, hist.new_full((), -1), hist).reshape(-1)
+            first_pad = pad.reshape(-1).to(torch.int32).argmax()       # position of the first padding slot (0 if there is none)
+            hid[first_pad] = hist.reshape(-1)[first_pad]
+            plan = Plan(torch.cat([iid.reshape(-1), hid]), I.shape[0], tag="sasrec")
+            src = dict(coef=gpred.reshape(-1), src=hv, div=Cn, src2=g_hist.view(-1, d), n_split=B * Cn)
+            if self.rowwise:
+                plan.update("a", I, h, m=st.get("m"), v=st.get("v"), **src)
+            else:
+                G = plan.row_sums("a", torch.zeros_like(I), **src)
+                dense_update(I, G, h, st.get("m"), st.get("v"))
         else:
-            G = torch.zeros_like(I)
-            segmented_update2(keys, perm, hv, g_hist.view(-1, d), B * Cn, coef=gpred.reshape(-1), div=Cn, dense_grad=G)
-            dense_update(I, G, h, st.get("m"), st.get("v"))
+            ids = torch.cat([iid.reshape(-1), hist.reshape(-1)])
+            keys, perm = sort_ids(ids, I.shape[0])
+            if self.rowwise:
+                segmented_update2(keys, perm, hv, g_hist.view(-1, d), B * Cn, hyper=h, W=I, m=st.get("m"), v=st.get("v"),
+                                  coef=gpred.reshape(-1), div=Cn)
+            else:
+                G = torch.zeros_like(I)
+                segmented_update2(keys, perm, hv, g_hist.view(-1, d), B * Cn, coef=gpred.reshape(-1), div=Cn, dense_grad=G)
+                dense_update(I, G, h, st.get("m"), st.get("v"))
         _upd.__exit__()
         # position table (tiny): dense gradient, dense step
         _dns = _PhaseTimer(self, "dense_update")

@@ -53,34 +53,41 @@ class HipOps:
         _, loss_vec, g = self.e.bpr_loss(pred, inv_b=inv_b)
         return loss_vec, g
 
+    # Grouping occurrences by row is the bucket plan everywhere (engine.Plan: id-range or hashed buckets, no device-wide
+    # sort, no host round trip); tags keep the cached buffers of plans that are alive together apart.
     def partial_user_grads(self, I_loc, rows, g, t_idx, n_tuples):
         out = torch.zeros((n_tuples, I_loc.shape[1]), dtype=torch.float32, device=I_loc.device)
         if t_idx.numel():
-            keys, perm = self.e.sort_ids(t_idx, n_tuples)
-            self.e.segmented_update(keys, perm, I_loc, coef=g, src_index=rows, div=1, dense_grad=out)
+            self.e.Plan(t_idx, n_tuples, tag="pug").row_sums("a", out, coef=g, src=I_loc, src_index=rows, div=1)
         return out
 
     def sum_rows_by_index(self, rows, index, n_out):
         """out[k] = sum of rows[p] over p with index[p] = k, in ascending p (atomic-free segmented sum)"""
-        return self.e.embedding_dense_backward(rows.contiguous(), index, n_out)
+        out = torch.zeros((n_out, rows.shape[1]), dtype=torch.float32, device=rows.device)
+        if index.numel():
+            self.e.Plan(index, n_out, tag="srbi").row_sums("a", out, src2=rows.contiguous())
+        return out
 
-    def prepare_rows(self, rows, n_rows):
-        """sort + head list of a row-id list, reusable by several update_rows calls on tables that share the ids"""
+    def unique(self, ids, n_rows):
+        """distinct ids (in the plan's order) + inverse index; reads the count back (the sharded steps call it one step
+        ahead, on their side stream)"""
+        return self.e.unique_ids(ids, n_rows, tag="route.unique")
+
+    def prepare_rows(self, rows, n_rows, tag="rows"):
+        """bucket plan of a row-id list, reusable by several update_rows calls on tables that share the ids"""
         if rows.numel() == 0:
             return None
-        keys, perm = self.e.sort_ids(rows, n_rows)
-        _, heads, n_heads = self.e.segment_heads(keys, perm, want_single=False)
-        return keys, perm, heads, n_heads
+        return self.e.Plan(rows, n_rows, tag=tag)
 
     def update_rows(self, W, state, rows, src, hyper, coef=None, src_index=None, prep=None):
         """W[r] <- opt(W[r], sum_{o: rows[o]=r} coef[o] * src[src_index[o] or o])"""
         if rows.numel() == 0:
             return
-        if prep is None:
-            prep = self.prepare_rows(rows, W.shape[0])
-        keys, perm, heads, n_heads = prep
-        self.e.segmented_update(keys, perm, src, hyper=hyper, W=W, m=state.get("m"), v=state.get("v"),
-                                coef=coef, src_index=src_index, div=1, heads=heads, n_heads=n_heads)
+        plan = prep if prep is not None else self.prepare_rows(rows, W.shape[0])
+        if coef is None and src_index is None:
+            plan.update("a", W, hyper, m=state.get("m"), v=state.get("v"), src2=src)
+        else:
+            plan.update("a", W, hyper, m=state.get("m"), v=state.get("v"), coef=coef, src=src, src_index=src_index, div=1)
 
     def update_rows_pair(self, Wa, Wb, sa, sb, rows, src_a, src_b, hyper, prep):
         """two tables that share `rows` (NeuMF's mf / mlp embeddings) in one pass; False if the width has no pair kernel"""
@@ -88,13 +95,10 @@ class HipOps:
             return True
         if not self.e.segmented_pair_supported(Wa.shape[1]):
             return False
-        keys, perm, heads, n_heads = prep
-        self.e.segmented_update_pair(keys, perm, src_a, src_b, hyper=hyper, W=(Wa, Wb), m=(sa.get("m"), sb.get("m")),
-                                     v=(sa.get("v"), sb.get("v")), heads=heads, n_heads=n_heads)
+        prep.update_pair("a", Wa, Wb, src_a, src_b, hyper, ma=sa.get("m"), va=sa.get("v"), mb=sb.get("m"), vb=sb.get("v"))
         return True
 
-    # ---- fast path (csrc/owner_step.hip); ShardedBprmf falls back to torch / the two calls above
-    #      for ops objects that do not provide these (the oracle-backed ops of the CPU tests)
+    # ---- csrc/owner_step.hip
     def route(self, ids, world, tuple_base=None, div=1):
         """stable grouping by owner -> (order int32 [n], counts int64 [world] (device), payload int64 [n]);
         payload = local rows (users) or (tuple << 32 | local row) messages (items, tuple_base given)"""
@@ -104,11 +108,9 @@ class HipOps:
         return self.e.owner_unpack(recv)
 
     def prepare_owner(self, rows, n_rows):
-        """sort of the received rows + singleton flags + multi-occurrence heads (independent of the
+        """bucket plan of the received rows: singleton flags + the multi-occurrence rows listed (independent of the
         scores: issued while they travel)"""
-        keys, perm = self.e.sort_ids(rows, n_rows)
-        single, heads, n_heads = self.e.segment_heads(keys, perm, only_multi=True)
-        return keys, perm, single, heads, n_heads
+        return self.e.Plan(rows, n_rows, tag="owner", list_single_a=False)
 
     def owner_backward(self, I_loc, state, rows, g, t_idx, t32, Uall, n_tuples, hyper, prep):
         """partial user grads + the item-row update in two passes over the received occurrences"""
@@ -116,10 +118,8 @@ class HipOps:
             pug = self.partial_user_grads(I_loc, rows, g, t_idx, n_tuples)
             self.update_rows(I_loc, state, rows, Uall, hyper, coef=g, src_index=t_idx)
             return pug
-        keys, perm, single, heads, n_heads = prep
-        pug = self.e.owner_backward(I_loc, state.get("m"), state.get("v"), Uall, t32, rows, g, single, n_tuples, hyper)
-        self.e.segmented_update(keys, perm, Uall, hyper=hyper, W=I_loc, m=state.get("m"), v=state.get("v"), coef=g,
-                                src_index=t_idx, div=1, skip_singletons=True, heads=heads, n_heads=n_heads)
+        pug = self.e.owner_backward(I_loc, state.get("m"), state.get("v"), Uall, t32, rows, g, prep.single, n_tuples, hyper)
+        prep.update("a", I_loc, hyper, m=state.get("m"), v=state.get("v"), coef=g, src=Uall, src_index=t_idx, div=1)
         return pug
 
     def owner_backward_split(self, I_loc, state, rows, g, t_idx, t32, Uall, n_tuples, hyper, prep):
@@ -129,12 +129,10 @@ class HipOps:
         if not self.e.owner_backward_supported(I_loc.shape[1]):
             pug = self.partial_user_grads(I_loc, rows, g, t_idx, n_tuples)
             return pug, lambda: self.update_rows(I_loc, state, rows, Uall, hyper, coef=g, src_index=t_idx)
-        keys, perm, single, heads, n_heads = prep
-        pug = self.e.owner_backward(I_loc, state.get("m"), state.get("v"), Uall, t32, rows, g, single, n_tuples, hyper)
+        pug = self.e.owner_backward(I_loc, state.get("m"), state.get("v"), Uall, t32, rows, g, prep.single, n_tuples, hyper)
 
         def finish():
-            self.e.segmented_update(keys, perm, Uall, hyper=hyper, W=I_loc, m=state.get("m"), v=state.get("v"), coef=g,
-                                    src_index=t_idx, div=1, skip_singletons=True, heads=heads, n_heads=n_heads)
+            prep.update("a", I_loc, hyper, m=state.get("m"), v=state.get("v"), coef=g, src=Uall, src_index=t_idx, div=1)
         return pug, finish
 
     # ---- NeuMF head on rows that were moved to the tuples (ShardedNeumf) ------------------------------
@@ -335,12 +333,10 @@ def _reduce_scatter_rows(x, world, group):
     return y[r * n:(r + 1) * n].clone()
 
 
-def _group_by_owner(ids, world):
-    """stable grouping of ids by id mod world -> (order, counts); order[j] = original position"""
-    owner = ids % world
-    order = torch.sort(owner, stable=True).indices
-    counts = torch.bincount(owner, minlength=world).tolist()
-    return order, counts
+def ops_unique(ops, ids, n_rows):
+    """(distinct ids, inverse index) through the ops object: HipOps = bucket plan + rc_plan_distinct (distinct ids in the
+    plan's order); the CPU tests' oracle ops bring their own.  Nothing in this module sorts."""
+    return ops.unique(ids, n_rows)
 
 
 def _record_stream(obj, stream):
@@ -377,7 +373,7 @@ class _Timed:
 
 class _LookAhead(_Timed):
     """Shared by the sharded steps: `step(batch, next_batch=...)` routes the NEXT batch before this step's kernels.
-    The routing needs host-visible sizes (torch.unique, the split sizes of the exchanges); on the caller's stream
+    The routing needs host-visible sizes (the number of distinct ids, the split sizes of the exchanges); on the caller's stream
     those device -> host copies would wait for everything enqueued before them, i.e. for the previous step.  So the
     look-ahead runs on a SIDE stream that depends only on the start of the previous step (the next batch's ids must
     exist by then: pooled batches, or a loader running at least one step ahead): its host waits are a few small
@@ -493,7 +489,7 @@ class ShardedBprmf(_LookAhead):
         inv = None
         counts = []
         if plan == "owner" and self.dedup_users:
-            uniq, inv = torch.unique(uid, return_inverse=True)   # sorted distinct users of this rank's batch
+            uniq, inv = ops_unique(self.ops, uid, self.n_users)   # distinct users of this rank's batch + inverse index
             ru = self._route(uniq)
             # every rank needs every rank's number of distinct users (sizes of the variable "all_gather" / "reduce_scatter")
             counts.append(torch.full((self.world,), uniq.numel(), dtype=torch.int64, device=uid.device))
@@ -678,16 +674,7 @@ class ShardedBprmf(_LookAhead):
 
     def _route(self, ids, tuple_base=None, div=1):
         """(order, counts tensor [W], payload grouped by owner): HIP counting sort, or torch for test ops"""
-        W = self.world
-        if hasattr(self.ops, "route"):
-            return self.ops.route(ids, W, tuple_base, div)
-        owner = ids % W
-        order = torch.sort(owner, stable=True).indices
-        counts = torch.bincount(owner, minlength=W)
-        local = ids[order] // W
-        if tuple_base is None:
-            return order, counts, local
-        return order, counts, ((tuple_base + order // div) << 32) | local
+        return self.ops.route(ids, self.world, tuple_base, div)
 
     def _unpack(self, recv):
         if hasattr(self.ops, "unpack"):
@@ -721,9 +708,9 @@ class _Route:
     stands in for embedding_dense_backward) before they are pushed.  Under Zipf users / positives that is most of
     the user-side traffic (27 K distinct of 65 K at the bench shape) and every repeated positive."""
 
-    def __init__(self, ids, world, ops, group, grouped=None, splits=None, dedup=True, prepared=None):
+    def __init__(self, ids, world, ops, group, grouped=None, splits=None, dedup=True, prepared=None, n_rows=None):
         if prepared is None:
-            prepared = self.prepare(ids, world, ops, dedup) if grouped is None else (grouped, None, ids.numel())
+            prepared = self.prepare(ids, world, ops, dedup, n_rows) if grouped is None else (grouped, None, ids.numel())
         (order, counts, local), self.inverse, self.n_lookup = prepared
         if splits is None:
             (self.send,), (self.recv,) = _exchange_counts([counts], group)
@@ -737,22 +724,19 @@ class _Route:
         self.req, _ = _exchange(local, self.send, group, recv_counts=self.recv)  # local rows this rank must serve
 
     @staticmethod
-    def prepare(ids, world, ops, dedup=True):
-        """-> ((send order, per-owner counts, local rows in send order), inverse index | None, lookup length)"""
+    def prepare(ids, world, ops, dedup=True, n_rows=None):
+        """-> ((send order, per-owner counts, local rows in send order), inverse index | None, lookup length);
+        n_rows: size of the (global) id space, needed for the de-duplication's bucket plan"""
         n = ids.numel()
         inverse = None
         if dedup:
-            ids, inverse = torch.unique(ids, return_inverse=True)
+            ids, inverse = ops_unique(ops, ids, n_rows)
         return _Route.group_by_owner(ids, world, ops), inverse, n
 
     @staticmethod
     def group_by_owner(ids, world, ops):
         """-> (send order, per-owner counts (device tensor), local rows in send order)"""
-        if hasattr(ops, "route"):
-            return ops.route(ids, world, None, 1)
-        owner = ids % world
-        order = torch.sort(owner, stable=True).indices
-        return order, torch.bincount(owner, minlength=world), ids[order] // world
+        return ops.route(ids, world, None, 1)
 
     def _expand(self, back, ops):
         out = torch.empty_like(back)
@@ -855,7 +839,8 @@ class ShardedNeumf(_LookAhead):
         W, ops = self.world, self.ops
         M = self.micro_batches if (W > 1 and self.micro_batches > 1 and iid.shape[0] >= self.micro_batches) else 1
         uc, ic = (torch.chunk(uid, M), torch.chunk(iid, M)) if M > 1 else ((uid,), (iid,))
-        grouped = [(_Route.prepare(u, W, ops, self.dedup), _Route.prepare(i.reshape(-1), W, ops, self.dedup)) for u, i in zip(uc, ic)]
+        grouped = [(_Route.prepare(u, W, ops, self.dedup, self.n_users), _Route.prepare(i.reshape(-1), W, ops, self.dedup, self.n_items))
+                   for u, i in zip(uc, ic)]
         counts = _Counts([g[0][1] for pair in grouped for g in pair], self.group)
         return {"uc": uc, "ic": ic, "grouped": grouped, "counts": counts}
 
@@ -921,8 +906,8 @@ class ShardedNeumf(_LookAhead):
             own_u, own_i, req_u, req_i = gu, gi, uid, iid.reshape(-1)
         mark("push_grads")
         shared = hasattr(ops, "prepare_rows")  # one sort + head list per side, used by its mf and mlp table
-        prep_u = ops.prepare_rows(req_u, self.P["mf_u"].shape[0]) if shared else None
-        prep_i = ops.prepare_rows(req_i, self.P["mf_i"].shape[0]) if shared else None
+        prep_u = ops.prepare_rows(req_u, self.P["mf_u"].shape[0], tag="rows.u") if shared else None
+        prep_i = ops.prepare_rows(req_i, self.P["mf_i"].shape[0], tag="rows.i") if shared else None
         for ta, tb, own, req, prep in (("mf_u", "mlp_u", own_u, req_u, prep_u), ("mf_i", "mlp_i", own_i, req_i, prep_i)):
             ga, gb = own[:, :d].contiguous(), own[:, d:].contiguous()
             if shared and hasattr(ops, "update_rows_pair") and ops.update_rows_pair(
@@ -1003,8 +988,8 @@ class ShardedNeumf(_LookAhead):
         req_i = torch.cat([r[1].req for r in routes])
         mark("push_grads")
         shared = hasattr(ops, "prepare_rows")
-        prep_u = ops.prepare_rows(req_u, self.P["mf_u"].shape[0]) if shared else None
-        prep_i = ops.prepare_rows(req_i, self.P["mf_i"].shape[0]) if shared else None
+        prep_u = ops.prepare_rows(req_u, self.P["mf_u"].shape[0], tag="rows.u") if shared else None
+        prep_i = ops.prepare_rows(req_i, self.P["mf_i"].shape[0], tag="rows.i") if shared else None
         for ta, tb, own, req, prep in (("mf_u", "mlp_u", own_u, req_u, prep_u), ("mf_i", "mlp_i", own_i, req_i, prep_i)):
             ga, gb = own[:, :d].contiguous(), own[:, d:].contiguous()
             if shared and hasattr(ops, "update_rows_pair") and ops.update_rows_pair(

@@ -39,7 +39,8 @@ def _check_plan(eng, cuda, ids_a, range_a, ids_b, range_b, list_single_a):
 
 @pytest.mark.parametrize("list_single_a", [True, False])
 @pytest.mark.parametrize("case", ["uniform_wide", "zipf_hot", "all_same", "tiny", "small_range", "edges", "no_b",
-                                  "many_buckets", "tile_boundary", "huge_bucket"])
+                                  "many_buckets", "tile_boundary", "huge_bucket", "hashed_100M", "hashed_hot", "hashed_sharded",
+                                  "hashed_2M_keys", "skipped_ids", "skipped_ids_hashed"])
 def test_bucket_plan_matches_the_oracle(case, list_single_a, cuda, eng):
     rng = np.random.default_rng(sum(map(ord, case)))
     if case == "uniform_wide":
@@ -68,6 +69,28 @@ def test_bucket_plan_matches_the_oracle(case, list_single_a, cuda, eng):
     elif case == "many_buckets":  # the widest supported id space: 4,096 buckets of 8,192 ids
         ra, rb = 4000 * 8192, 96 * 8192
         a, b = rng.integers(0, ra, size=50_000), rng.integers(0, rb, size=1_000)
+    elif case == "hashed_100M":   # too wide for id-range buckets (NeuMF config 4: 100 M items): hashed buckets + LDS hash tables
+        ra, rb = 100_000_001, 10_000_001
+        a, b = rng.integers(1, ra, size=327_680), _zipf(rng, rb, 65_536)
+    elif case == "hashed_hot":    # hashed geometry with rows of thousands of occurrences and ids that collide modulo anything
+        ra, rb = 3_000_000_000, 900_000_000
+        a = np.concatenate([np.full(9_000, 2_999_999_999), np.full(300, 7), rng.integers(0, ra, size=40_000),
+                            (np.arange(20_000) * 65_536) % ra])
+        rng.shuffle(a)
+        b = np.concatenate([np.full(33, 899_999_999), rng.integers(0, rb, size=2_000), np.zeros(34)])
+    elif case == "hashed_sharded":  # what a rank of a sharded table plans: its local rows of a global batch, few keys, wide space
+        ra, rb = 12_500_001, 0
+        a, b = rng.integers(0, ra, size=41_000), None
+    elif case == "hashed_2M_keys":  # 2,048 buckets per list, ~1,000 keys each
+        ra, rb = 2_000_000_000, 50
+        a, b = rng.integers(0, ra, size=2_000_000), rng.integers(0, rb, size=3)
+    elif case in ("skipped_ids", "skipped_ids_hashed"):   # negative ids take no part (whole tiles of them, too)
+        ra, rb = (60_000, 900) if case == "skipped_ids" else (90_000_000, 70_000_000)
+        a = rng.integers(0, ra, size=40_000)
+        a[rng.random(40_000) < 0.4] = -1
+        a[8192:3 * 8192] = -1
+        b = rng.integers(0, rb, size=9_000)
+        b[::3] = -1
     elif case == "huge_bucket":   # one bucket past 32,768 keys (32-bit LDS cells) next to ordinary ones (16-bit cells)
         ra, rb = 5_000_000, 3_000
         a = np.concatenate([rng.integers(0, 100, size=40_000), rng.integers(0, ra, size=30_000)])
@@ -79,12 +102,20 @@ def test_bucket_plan_matches_the_oracle(case, list_single_a, cuda, eng):
     _check_plan(eng, cuda, a, ra, b, rb, list_single_a)
 
 
-def test_bucket_plan_rejects_too_wide_id_spaces(cuda, eng):
+def test_bucket_plan_geometry_limits(cuda, eng):
+    """id spaces too wide for id-range buckets take the hashed geometry; what neither geometry covers is refused"""
     from rechorus_amd import _lib
-    assert _lib.load().rc_bucket_plan_supported(10, 10, 40_000_000, 10) == 0
+    lib = _lib.load()
+    assert lib.rc_bucket_plan_supported(10, 10, 40_000_000, 10) == 1          # hashed
+    assert lib.rc_bucket_plan_supported(6_553_600, 65_536, 10_000_001, 1_000_001) == 1   # direct (the bench shape)
+    assert lib.rc_bucket_plan_supported(20_000_000, 10, 3_000_000_000, 10) == 0   # > 4,096 keys per hashed bucket
+    assert lib.rc_bucket_plan_supported(10, 10, 5_000_000_000, 10) == 0           # ids do not fit 32 bits
     a = torch.zeros(10, dtype=torch.int64, device=cuda)
     with pytest.raises(_lib.RechorusHipError):
-        eng.bucket_plan(a, 40_000_000, a, 10)
+        eng.bucket_plan(a, 5_000_000_000, a, 10)
+    # the multi-occurrence bitmap is indexed by id: direct geometry only
+    with pytest.raises(_lib.RechorusHipError):
+        eng.bucket_multi_bitmap(a, 400_000_000)
 
 
 def _zipf(rng, n_rows, size):
@@ -419,3 +450,105 @@ def test_fused_update_bitmap_equals_flag_path(opt, lr, l2, d, B, C, n_items, cud
     for nm, a, b in zip(("I", "m", "v", "loss_vec", "gpred", "ugrad"), res[0], res[1]):
         assert a is None or torch.equal(a, b), nm
     assert not torch.equal(res[0][0], torch.from_numpy(I).to(cuda))
+
+
+@pytest.mark.parametrize("case", ["sparse_hashed", "dense_direct", "hot"])
+@pytest.mark.parametrize("d", [32, 64, 128])
+def test_plan_row_sums_and_distinct(case, d, cuda, eng):
+    """rc_plan_row_sums = index_add in ascending position order (vs numpy, float64 reference + fixed-order fp32 bound);
+    rc_plan_distinct = torch.unique(return_inverse=True) up to the order of the distinct ids"""
+    rng = np.random.default_rng(d + len(case))
+    if case == "sparse_hashed":
+        n_rows, ids = 50_000_000, rng.integers(0, 50_000_000, size=60_000)
+        ids[::7] = ids[0]
+    elif case == "dense_direct":
+        n_rows, ids = 9_000, rng.integers(0, 9_000, size=60_000)
+    else:
+        n_rows = 3_000
+        ids = np.minimum(rng.zipf(1.3, size=40_000), n_rows - 1)
+    ids = np.ascontiguousarray(ids, dtype=np.int64)
+    src = rng.normal(0, 1, size=(len(ids), d)).astype(np.float32)
+    ids_d, src_d = torch.from_numpy(ids).to(cuda), torch.from_numpy(src).to(cuda)
+    # distinct + inverse
+    uniq, inverse = eng.unique_ids(ids_d, n_rows)
+    u, inv = uniq.cpu().numpy(), inverse.cpu().numpy()
+    assert len(u) == len(np.unique(ids)) and len(np.unique(u)) == len(u)
+    assert np.array_equal(u[inv], ids)
+    # row sums through the inverse index (what the sharded steps' de-duplicated exchanges do) and through the ids
+    out = torch.zeros((len(u), d), device=cuda)
+    eng.Plan(inverse, len(u), tag="t.rs").row_sums("a", out, src2=src_d)
+    want = np.zeros((len(u), d), dtype=np.float64)
+    np.add.at(want, inv, src.astype(np.float64))
+    cnt = np.bincount(inv, minlength=len(u))
+    tol = 1e-6 * np.sqrt(cnt)[:, None] * np.abs(src).max() * 4 + 1e-6
+    assert np.all(np.abs(out.cpu().numpy() - want) <= tol + 1e-6 * np.abs(want))
+    if n_rows <= 10_000:
+        G = eng.embedding_dense_backward(src_d, ids_d, n_rows)
+        want = np.zeros((n_rows, d), dtype=np.float64)
+        np.add.at(want, ids, src.astype(np.float64))
+        cnt = np.bincount(ids, minlength=n_rows)
+        tol = 1e-6 * np.sqrt(np.maximum(cnt, 1))[:, None] * np.abs(src).max() * 4 + 1e-6
+        assert np.all(np.abs(G.cpu().numpy() - want) <= tol + 1e-6 * np.abs(want))
+        assert np.all(G.cpu().numpy()[cnt == 0] == 0)
+        # bit-identical to the radix-sort route (same ascending-position order of the sums)
+        keys, perm = eng.sort_ids(ids_d, n_rows)
+        G2 = torch.zeros_like(G)
+        eng.segmented_update(keys, perm, src_d, dense_grad=G2)
+        assert torch.equal(G, G2)
+
+
+def test_neumf_and_sasrec_trainers_plan_equals_sort(cuda, eng, monkeypatch):
+    """the trainers' table updates through the bucket plan (default) and behind the radix sort: bit-identical parameters
+    and state after two steps (both sum a row's gradient rows in ascending batch position)"""
+    rng = np.random.default_rng(3)
+    g = torch.Generator(device=cuda)
+    # NeuMF, row-wise Adam, items sparse enough for the hashed geometry
+    n_users, n_items, d, l1, B, Cn = 30_000, 6_000_000, 128, 64, 4096, 5
+    def neumf(use_plan):
+        monkeypatch.setattr(eng, "_USE_PLAN", use_plan)
+        g.manual_seed(1)
+        mk = lambda *sh: torch.empty(sh, device=cuda).normal_(0, 0.05, generator=g)
+        P = {"mf_u": mk(n_users, d), "mlp_u": mk(n_users, d), "mf_i": mk(n_items, d), "mlp_i": mk(n_items, d),
+             "W1": mk(l1, 2 * d), "b1": mk(l1), "w_out": mk(d + l1)}
+        tr = eng.NeumfTrainer(P, opt="Adam", lr=1e-2, l2=1e-5, rowwise=True)
+        r = np.random.default_rng(4)
+        for _ in range(2):
+            uid = torch.from_numpy(_zipf(r, n_users, B)).to(cuda)
+            iid = torch.from_numpy(np.concatenate([_zipf(r, n_items, (B, 1)), r.integers(1, n_items, size=(B, Cn - 1))], axis=1)).to(cuda)
+            tr.step(uid, iid)
+        torch.cuda.synchronize()
+        return P, tr.state
+    Pa, Sa = neumf(True)
+    Pb, Sb = neumf(False)
+    for k in Pa:
+        assert torch.equal(Pa[k], Pb[k]), k
+        for st in ("m", "v"):
+            assert torch.equal(Sa[k][st], Sb[k][st]), (k, st)
+    del Pa, Pb, Sa, Sb
+    # SASRec, row-wise Adam, padded histories
+    n_items, d, L, B, Cn = 9_000, 64, 50, 1024, 100
+    def sasrec(use_plan):
+        monkeypatch.setattr(eng, "_USE_PLAN", use_plan)
+        g.manual_seed(2)
+        mk = lambda *sh: torch.empty(sh, device=cuda).normal_(0, 0.05, generator=g)
+        lay = {k: (mk(d, d) if k.startswith("W") else mk(d)) for k in eng.SAS_LAYER_KEYS}
+        lay["ln1w"] += 1.0
+        lay["ln2w"] += 1.0
+        P = {"item_emb": mk(n_items, d), "pos_emb": mk(L + 1, d), "layers": [lay]}
+        tr = eng.SasrecTrainer(P, 4, opt="Adam", lr=1e-2, l2=1e-5, rowwise=True)
+        r = np.random.default_rng(6)
+        for _ in range(2):
+            lengths = torch.from_numpy(r.integers(1, L + 1, size=B)).to(cuda)
+            hist = torch.from_numpy(_zipf(r, n_items, (B, L))).to(cuda)
+            hist = (hist * (torch.arange(L, device=cuda)[None, :] < lengths[:, None])).contiguous()
+            iid = torch.from_numpy(np.concatenate([_zipf(r, n_items, (B, 1)), r.integers(1, n_items, size=(B, Cn - 1))], axis=1)).to(cuda)
+            tr.step(hist, lengths, iid)
+        torch.cuda.synchronize()
+        return P, tr
+    Pa, ta = sasrec(True)
+    Pb, tb = sasrec(False)
+    assert torch.equal(Pa["item_emb"], Pb["item_emb"]) and torch.equal(Pa["pos_emb"], Pb["pos_emb"])
+    for k in eng.SAS_LAYER_KEYS:
+        assert torch.equal(Pa["layers"][0][k], Pb["layers"][0][k]), k
+    sa, sb = ta._st(Pa["item_emb"]), tb._st(Pb["item_emb"])
+    assert torch.equal(sa["m"], sb["m"]) and torch.equal(sa["v"], sb["v"])

@@ -58,6 +58,26 @@ class OracleOps:
     def new_state(self, W, opt):
         return {k: torch.from_numpy(v) for k, v in O.new_state(W.numpy(), opt).items()}
 
+    # the integer side of the routing, restated in numpy (HipOps: rc_route_by_owner, bucket plan + rc_plan_distinct)
+    def route(self, ids, world, tuple_base=None, div=1):
+        a = ids.numpy()
+        owner = a % world
+        order = np.argsort(owner, kind="stable")
+        counts = torch.from_numpy(np.bincount(owner, minlength=world).astype(np.int64))
+        local = a[order] // world
+        if tuple_base is None:
+            return torch.from_numpy(order), counts, torch.from_numpy(local)
+        return torch.from_numpy(order), counts, torch.from_numpy(((tuple_base + order // div) << 32) | local)
+
+    def unique(self, ids, n_rows):
+        """distinct ids in ANY order + inverse index (the plan's order is not sorted; a scrambled order here proves that
+        nothing downstream relies on sortedness)"""
+        u, inv = np.unique(ids.numpy(), return_inverse=True)
+        perm = np.random.default_rng(len(u)).permutation(len(u))       # new position k holds u[perm[k]]
+        where = np.empty_like(perm)
+        where[perm] = np.arange(len(u))
+        return torch.from_numpy(u[perm]), torch.from_numpy(where[inv.reshape(-1)].astype(np.int64))
+
 
 def _free_port():
     with socket.socket() as s:
