@@ -61,7 +61,8 @@ PlanGeom plan_geometry(int64_t n_a, int64_t n_b, int64_t range_a, int64_t range_
   // buckets in proportion to the number of KEYS: hashed where the range is more than 16 cells per key (NeuMF's 0.33 M
   // item lookups over 10 M - 100 M rows; a rank's lookups in a sharded table) or too wide for one direct level at all.
   const bool direct_ok = buckets(kPlanMaxShift, &na, &nbb) <= kPlanMaxBuckets;
-  const int force = want_mode >= 0 ? want_mode : env_int("RC_PLAN_HASHED", -1);
+  // want_mode 2: the wide id-range geometry or nothing (bitmap callers)
+  const int force = want_mode == 2 ? 0 : (want_mode >= 0 ? want_mode : env_int("RC_PLAN_HASHED", -1));
   const bool hashed = force >= 0 ? (force != 0 || !direct_ok) : (!direct_ok || range_a + range_b > 16 * g.n);
   if (hashed) {
     auto pow2_for = [](int64_t n_keys, int* lg) {
@@ -83,6 +84,23 @@ PlanGeom plan_geometry(int64_t n_a, int64_t n_b, int64_t range_a, int64_t range_
     while ((1u << g.bucket_bits) < g.nb) ++g.bucket_bits;
     g.ok = 1;
     return g;
+  }
+  // dense batches (>= 4 keys per id of the tables): as many buckets as one level allows, i.e. as few ids per bucket as
+  // possible -- narrow buckets, finished by ballot ranks
+  if (want_mode != 2 && env_int("RC_PLAN_NARROW", 1) != 0 && g.n >= 4 * (range_a + range_b)) {
+    int sh = 0;
+    while (buckets(sh, &na, &nbb) > kPlanMaxBuckets) ++sh;
+    if (sh <= kPlanNarrowMaxShift) {
+      buckets(sh, &na, &nbb);
+      g.narrow = 1;
+      g.shift = sh;
+      g.nb_a = na; g.nb_b = nbb; g.nb = na + nbb;
+      g.base_b = na << sh;
+      g.bucket_bits = 1;
+      while ((1u << g.bucket_bits) < g.nb) ++g.bucket_bits;
+      g.ok = 1;
+      return g;
+    }
   }
   // enough buckets to fill the chip (one wave per bucket in step 4), but not more than the scatter's
   // write runs can afford: aim at ~8 K keys per bucket, at least 128 buckets
@@ -774,6 +792,97 @@ __global__ __launch_bounds__(kBucketThreads) void plan_bucket_hash_kernel(PlanAr
   }
 }
 
+// ---- 4n. narrow geometry: one WAVE per bucket of at most 32 ids, ballot ranks instead of LDS atomics -----------------
+// The keys of a bucket are in position order; lanes of a round that hold the same id find each other with `shift` ballots
+// (match_lanes), the lowest of them (the leader) moves the id's counter / cursor in a 32-entry per-wave LDS table by the
+// size of the group -- distinct ids are distinct cells, so no atomics and nothing serialises on a hot row.
+constexpr int kNarrowBatch = 8;   // rounds of 64 keys requested together
+
+__global__ __launch_bounds__(kBucketThreads) void plan_bucket_narrow_kernel(PlanArgs a) {
+  __shared__ uint32_t tabs[kBucketThreads / 64][32];
+  constexpr uint32_t kSingle = 0x80000000u;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  uint32_t* tab = tabs[wave];
+  const uint32_t bkt = blockIdx.x * (kBucketThreads / 64) + wave;
+  if (bkt >= a.g.nb) return;   // wave-uniform; no workgroup barriers below
+  const uint32_t beg = a.w.bucket_base[bkt], end = a.w.bucket_base[bkt + 1];
+  if (beg == end) return;
+  const int shift = a.g.shift;
+  const uint32_t ids = 1u << shift;
+  const bool side_b = bkt >= a.g.nb_a;
+  const bool list_all = side_b || a.list_single_a != 0;
+  if (lane < 32) tab[lane] = 0;
+
+  // pass A: occurrences per id
+  for (uint32_t j0 = beg; j0 < end; j0 += 64 * kNarrowBatch) {
+    uint32_t k[kNarrowBatch];
+#pragma unroll
+    for (int q = 0; q < kNarrowBatch; ++q) {
+      const uint32_t j = j0 + q * 64 + lane;
+      k[q] = j < end ? (uint32_t)a.w.lid[j] : kNoLid;
+    }
+#pragma unroll
+    for (int q = 0; q < kNarrowBatch; ++q) {
+      if (j0 + q * 64 >= end) break;  // wave-uniform
+      const bool valid = k[q] != kNoLid;
+      const uint64_t m = match_lanes(k[q], shift, __ballot(valid));
+      if (valid && (m & lanes_below(lane)) == 0) tab[k[q]] += (uint32_t)__popcll(m);   // group leader; distinct ids = distinct cells
+    }
+  }
+  // counts -> row records + cursors (lane j < ids owns id j)
+  const uint32_t c = (uint32_t)lane < ids ? tab[lane & 31] : 0u;
+  const bool listed = c != 0 && (list_all || c >= 2);
+  const uint32_t occ_incl = wave_inclusive_scan(listed ? c : 0u, lane);
+  const uint64_t lm = __ballot(listed);
+  const uint32_t n_listed = (uint32_t)__popcll(lm);
+  uint32_t row_base = 0;
+  if (lane == 0 && n_listed) row_base = atomicAdd(side_b ? a.n_rows_b : a.n_rows_a, n_listed);
+  row_base = __shfl(row_base, 0, 64);
+  const uint32_t row0 = (bkt - (side_b ? a.g.nb_a : 0u)) << shift;  // table-local id of the bucket's first row
+  if ((uint32_t)lane < ids) {
+    if (listed) {
+      rc_plan_row e;
+      e.row = row0 + lane;
+      e.start = beg + occ_incl - c;
+      e.n = c;
+      e.reserved = 0;
+      (side_b ? a.rows_b : a.rows_a)[row_base + (uint32_t)__popcll(lm & lanes_below(lane))] = e;
+      if (a.emit_long && c > (uint32_t)kPlanLongSeg) plan_register_long(a, e, side_b ? 1u : 0u);
+      tab[lane] = occ_incl - c;
+    } else {
+      tab[lane] = kSingle;
+    }
+  }
+
+  // pass B: positions into their row's slots, ascending
+  uint8_t* single = (side_b || a.flags_done) ? nullptr : a.single_a;
+  for (uint32_t j0 = beg; j0 < end; j0 += 64 * kNarrowBatch) {
+    uint32_t k[kNarrowBatch], p[kNarrowBatch];
+#pragma unroll
+    for (int q = 0; q < kNarrowBatch; ++q) {
+      const uint32_t j = j0 + q * 64 + lane;
+      k[q] = j < end ? (uint32_t)a.w.lid[j] : kNoLid;
+      p[q] = j < end ? a.w.pos[j] : 0u;
+    }
+#pragma unroll
+    for (int q = 0; q < kNarrowBatch; ++q) {
+      if (j0 + q * 64 >= end) break;  // wave-uniform
+      const bool valid = k[q] != kNoLid;
+      const uint64_t m = match_lanes(k[q], shift, __ballot(valid));
+      if (!valid) continue;
+      const uint32_t cur = tab[k[q]];
+      const uint32_t rank = (uint32_t)__popcll(m & lanes_below(lane));
+      if (cur & kSingle) {
+        if (single) single[p[q]] = 1;
+      } else {
+        a.occ[beg + cur + rank] = p[q];
+        if (rank == 0) tab[k[q]] = cur + (uint32_t)__popcll(m);
+      }
+    }
+  }
+}
+
 // ---- 4a. the bitmap of multi-occurrence rows of list a: what the fused BPRMF kernel needs from the plan.
 // One workgroup per bucket: LDS count table from the 2-byte id stream (all four waves, order-free), then thread t
 // packs the cells of ids 32 t .. 32 t + 31 into one word -- bit = 1 iff the row occurs at least twice -- and the
@@ -826,7 +935,8 @@ int plan_launch_front(const PlanArgs& a, bool bitmap, hipStream_t s) {
   else hipLaunchKernelGGL(plan_scatter_kernel<false>, dim3(plan_tile_grid(g.tiles)), dim3(kPlanThreads), sc_lds, s, a);
   RC_LAUNCH_CHECK();
   if (bitmap && a.bitmap_a && g.nb_a > 0) {
-    if (g.hashed) return fail(RC_ERR_UNSUPPORTED, "bucket plan: the multi-occurrence bitmap needs the direct (id-range) geometry");
+    if (g.hashed || g.narrow)
+      return fail(RC_ERR_UNSUPPORTED, "bucket plan: the multi-occurrence bitmap needs the wide id-range geometry");
     const size_t ids = (size_t)1 << g.shift;
     if (g.shift > 8) {
       hipLaunchKernelGGL(plan_bitmap_kernel<false>, dim3(g.nb_a), dim3(kBucketThreads), (ids / 2 + kBucketThreads + 16) * sizeof(uint32_t), s, a);
@@ -843,6 +953,11 @@ int plan_launch_back(const PlanArgs& a, hipStream_t s) {
   const PlanGeom& g = a.g;
   if (g.hashed) {
     hipLaunchKernelGGL(plan_bucket_hash_kernel, dim3(g.nb), dim3(kBucketThreads), (2 * kPlanHashSlots + 16) * sizeof(uint32_t), s, a);
+    RC_LAUNCH_CHECK();
+    return RC_OK;
+  }
+  if (g.narrow) {
+    hipLaunchKernelGGL(plan_bucket_narrow_kernel, dim3((g.nb + 3) / 4), dim3(kBucketThreads), 0, s, a);
     RC_LAUNCH_CHECK();
     return RC_OK;
   }
@@ -939,8 +1054,8 @@ extern "C" int rc_bucket_multi_bitmap(const int64_t* ids_a, int64_t n_a, int64_t
   RC_REQUIRE(ids_a && bitmap && ws, "rc_bucket_multi_bitmap: null pointer");
   PlanArgs a;
   memset(&a, 0, sizeof(a));
-  a.g = plan_geometry(n_a, 0, range_a, 0, 0);
-  if (!a.g.ok || a.g.hashed)
+  a.g = plan_geometry(n_a, 0, range_a, 0, 2);
+  if (!a.g.ok || a.g.hashed || a.g.narrow)
     return fail(RC_ERR_UNSUPPORTED, "rc_bucket_multi_bitmap: id range %lld needs more than %d buckets of %d ids",
                 (long long)range_a, kPlanMaxBuckets, 1 << kPlanMaxShift);
   a.w = carve_plan_ws(ws, n_a);

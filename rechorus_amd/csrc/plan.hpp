@@ -29,11 +29,18 @@ struct PlanGeom {
   // is carried as the in-bucket key and grouped through an LDS hash table (plan_bucket_hash_kernel)
   int hashed;
   int log_nb_a, log_nb_b;
+  // narrow id-range buckets (shift <= 5: at most 32 ids per bucket) for DENSE batches -- several keys per id of the table,
+  // e.g. 0.6 M candidate + history occurrences over SASRec's 8.7 K items: the partition alone almost groups by row, and
+  // one WAVE per bucket finishes the job with ballot ranks (plan_bucket_narrow_kernel): no LDS atomics, so a row with
+  // tens of thousands of occurrences costs what its keys cost to stream, not a serialised atomic each
+  int narrow;
 };
+constexpr int kPlanNarrowMaxShift = 5;
 constexpr uint32_t kPlanHashSlots = 8192;   // LDS hash table of a hashed bucket (keys + cells: 64 KB)
 constexpr int kPlanHashKeysPerBucket = 1024; // sizing target: distinct rows per bucket <= keys per bucket ~ load 1/8
-// want: -1 = by density (hashed buckets where the id range is more than 16 cells per key), 0 = id-range buckets wherever they
-// exist (callers that need the id-indexed bitmap), 1 = hashed
+// want: -1 = by density (hashed buckets where the id range is more than 16 cells per key, narrow id-range buckets where a
+// batch brings >= 4 keys per id, wide id-range buckets between), 0 = id-range buckets (wide or narrow) wherever they exist,
+// 1 = hashed, 2 = wide id-range buckets or nothing (callers that need the id-indexed bitmap)
 PlanGeom plan_geometry(int64_t n_a, int64_t n_b, int64_t range_a, int64_t range_b, int want = -1);
 
 // counters (device uint32[PC_N]); zeroed by the first kernel of every plan

@@ -283,9 +283,16 @@ __device__ __forceinline__ void plan_long_only_body(const PlanUpdArgs& a, int si
 template <int D>
 __device__ __forceinline__ void plan_chunk_body(const PlanUpdArgs& a, uint32_t first_block, uint32_t n_blocks, float4* part);
 
+// RC_ROWS_WAVES_MAX (experiment switch): cap the waves per SIMD of the row-update kernel, so that a CU keeps wave slots
+// free for the plan kernels of the NEXT batch that run beside it on the second stream
+#ifdef RC_ROWS_WAVES_MAX
+#define RC_ROWS_OCC __attribute__((amdgpu_waves_per_eu(1, RC_ROWS_WAVES_MAX)))
+#else
+#define RC_ROWS_OCC
+#endif
 template <int D, int MODE>
-__global__ __launch_bounds__(kBlock) void plan_rows_kernel(PlanUpdArgs a, uint32_t blocks_main, int update_side,
-                                                          int plan_other, uint32_t blocks_chunk) {
+__global__ __launch_bounds__(kBlock) RC_ROWS_OCC void plan_rows_kernel(PlanUpdArgs a, uint32_t blocks_main, int update_side,
+                                                                      int plan_other, uint32_t blocks_chunk) {
   __shared__ float4 part[kBlock];   // chunk workgroups only
   const bool plan_long = a.long_planned == 0;
   if (blockIdx.x < blocks_main) {

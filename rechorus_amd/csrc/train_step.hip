@@ -61,7 +61,16 @@ StepSide* step_side(int* device_out = nullptr) {
   StepSide& x = sides[dev];
   if (!x.tried) {
     x.tried = true;
-    x.ok = hipStreamCreateWithFlags(&x.stream, hipStreamNonBlocking) == hipSuccess &&
+    // RC_SIDE_PRIO=high: the side stream's workgroups are dispatched ahead of the caller's whenever a CU has room
+    // (the plan kernels are latency-bound index work that has to squeeze in beside bandwidth-bound row kernels)
+    const char* pr = getenv("RC_SIDE_PRIO");
+    bool made = false;
+    if (pr && strcmp(pr, "high") == 0) {
+      int least = 0, greatest = 0;
+      if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess)
+        made = hipStreamCreateWithPriority(&x.stream, hipStreamNonBlocking, greatest) == hipSuccess;
+    }
+    x.ok = (made || hipStreamCreateWithFlags(&x.stream, hipStreamNonBlocking) == hipSuccess) &&
            hipEventCreateWithFlags(&x.fork, hipEventDisableTiming) == hipSuccess &&
            hipEventCreateWithFlags(&x.join, hipEventDisableTiming) == hipSuccess &&
            hipEventCreateWithFlags(&x.fork2, hipEventDisableTiming) == hipSuccess &&
@@ -75,6 +84,16 @@ int ahead_fork_mode() {
   static int mode = [] {
     const char* v = getenv("RC_AHEAD_FORK");
     return (v && strcmp(v, "early") == 0) ? 1 : 0;
+  }();
+  return mode;
+}
+// what the look-ahead prepares: 0 = the whole plan (default), 1 = only its front (partition + bitmap: what the fused
+// kernel needs); the per-bucket pass then runs on the side stream beside the fused kernel of the step that uses it
+// (RC_AHEAD_PART=front)
+int ahead_part_mode() {
+  static int mode = [] {
+    const char* v = getenv("RC_AHEAD_PART");
+    return (v && strcmp(v, "front") == 0) ? 1 : 0;
   }();
   return mode;
 }
@@ -249,11 +268,14 @@ static int train_step_impl(float* U, float* I, float* mU, float* vU, float* mI, 
 #if defined(RC_FUSED_UPD_NEVER)
   const bool fused_upd = false;
 #elif defined(RC_FUSED_UPD_ALWAYS)
-  const bool fused_upd = rc_bprmf_fused_supported(d, C) != 0 && !geom.hashed;
+  const bool fused_upd = rc_bprmf_fused_supported(d, C) != 0 && !geom.hashed && !geom.narrow;
 #else
-  const bool fused_upd = rc_bprmf_fused_supported(d, C) != 0 && h->opt == RC_OPT_SGD && !geom.hashed;
+  // (narrow geometry = dense batch, several occurrences per row of the table: hardly any row occurs once, the singleton
+  //  fast path has nothing to win there)
+  const bool fused_upd = rc_bprmf_fused_supported(d, C) != 0 && h->opt == RC_OPT_SGD && !geom.hashed && !geom.narrow;
 #endif
-  const int flavour = fused_upd ? 1 : 2;   // what a prepared plan contains: bitmap + multi rows / every row listed
+  // what a prepared plan contains: 1 = bitmap + multi rows, 2 = every row listed, 3 = only the front of flavour 1
+  const int flavour = fused_upd ? (ahead_part_mode() == 1 ? 3 : 1) : 2;
 
   // A plan prepared ahead by an earlier call (rc_step_ticket, caller-owned): usable when it was made for exactly this
   // batch -- the caller's generation id, not a pointer, says so -- workspace, geometry and plan flavour.  In every case
@@ -306,7 +328,7 @@ static int train_step_impl(float* U, float* I, float* mU, float* vU, float* mI, 
       RC_HIP(hipEventRecord(side->fork2, s));
       RC_HIP(hipStreamWaitEvent(side->stream, side->fork2, 0));
       RC_TRY(plan_launch_front(pn, fused_upd, side->stream));
-      RC_TRY(plan_launch_back(pn, side->stream));
+      if (flavour != 3) RC_TRY(plan_launch_back(pn, side->stream));
       RC_HIP(hipEventRecord(side->front_done, side->stream));
       ticket->generation = next_generation;
       ticket->ws = reinterpret_cast<uintptr_t>(ws);
@@ -315,7 +337,14 @@ static int train_step_impl(float* U, float* I, float* mU, float* vU, float* mI, 
       return RC_OK;
     };
     RC_MARK(0);
-    if (ahead_hit) {
+    if (ahead_hit && flavour == 3) {
+      // the front is prepared; the per-bucket pass runs on the side stream beside this step's fused kernel
+      RC_MARK(1);
+      RC_HIP(hipEventRecord(side->fork, s));
+      RC_HIP(hipStreamWaitEvent(side->stream, side->fork, 0));
+      RC_TRY(plan_launch_back(pa, side->stream));
+      RC_HIP(hipEventRecord(side->join, side->stream));
+    } else if (ahead_hit) {
       // the plan is complete (prepared beside the previous step): this step starts with its fused kernel
       RC_MARK(1);
     } else if (two_streams) {
@@ -342,7 +371,7 @@ static int train_step_impl(float* U, float* I, float* mU, float* vU, float* mI, 
                                             w.gpred, w.ugrad, stream));
     else
       RC_TRY(rc_bprmf_fwd_bwd(U, I, uid, iid, B, C, d, inv_b, pred, w.loss_vec, w.gpred, w.ugrad, stream));
-    if (two_streams && !ahead_hit) RC_HIP(hipStreamWaitEvent(s, side->join, 0));
+    if (two_streams && (!ahead_hit || flavour == 3)) RC_HIP(hipStreamWaitEvent(s, side->join, 0));
     if (look_ahead && ahead_fork_mode() == 0) RC_TRY(launch_ahead());
     RC_MARK(4);
     RC_MARK(5);  // (the loss mean is one workgroup of the last update launch)

@@ -50,6 +50,20 @@ class HipEmbedding(nn.Module):
         return f"{self.num_embeddings}, {self.embedding_dim} [HIP]"
 
 
+_DROP_SEED_GEN = None
+
+
+def fresh_drop_seed():
+    """int64 [1] seed for a module's counter-based dropout masks, drawn from a generator of its OWN (seeded from torch's
+    initial seed, so runs with the same --random_seed repeat) -- the global RNG stream that initialises the parameters is
+    left exactly as the reference leaves it."""
+    global _DROP_SEED_GEN
+    if _DROP_SEED_GEN is None:
+        _DROP_SEED_GEN = torch.Generator()
+        _DROP_SEED_GEN.manual_seed((torch.initial_seed() * 6364136223846793005 + 1442695040888963407) % (2 ** 63))
+    return torch.randint(0, 2 ** 62, (1,), dtype=torch.int64, generator=_DROP_SEED_GEN)
+
+
 def adopt_embeddings(model):
     """Make an unmodified ReChorus model file run its table lookups on the HIP engine: every plain `nn.Embedding`
     submodule (the reference defines all 88 of its tables that way, sparse=False, no padding_idx / max_norm) is
@@ -348,6 +362,10 @@ def linear(x, W, b=None, relu=False, drop_p=0.0, seed=None, site=0):
     """nn.Linear (+ ReLU + training-mode dropout) on the HIP engine; x [..., K]"""
     if not x.is_cuda:
         raise RuntimeError("linear runs on the GPU only (no CPU path)")
+    if float(drop_p) > 0.0 and not relu:
+        # the backward pass takes the saved output as its own mask (y > 0): without the ReLU a kept negative output would
+        # get a zero gradient -- refuse instead of returning wrong gradients (mlp_plan never builds this combination)
+        raise ValueError("linear: dropout needs relu=True (the kernels' dropout mask is the sign of the saved output)")
     return _LinearFn.apply(x, W, b, bool(relu), float(drop_p), seed, int(site))
 
 

@@ -164,7 +164,9 @@ def run(argv=None):
 
     model = model_cls(args, corpus).to(args.device)
     from rechorus_amd import nn as hnn
-    adopted = hnn.adopt_embeddings(model)  # plain nn.Embedding tables of a model file written for the reference
+    # plain nn.Embedding tables of a model file written for the reference move onto the HIP engine -- on a GPU only: with
+    # --gpu '' an unmodified model file keeps running on torch, as it does in the reference
+    adopted = hnn.adopt_embeddings(model) if torch.device(args.device).type == 'cuda' else 0
     if adopted:
         logging.info('Adopted {} nn.Embedding table(s) onto the HIP engine'.format(adopted))
     logging.info('#params: {}'.format(model.count_variables()))

@@ -47,7 +47,7 @@ class NeuMF(GeneralModel):
         self.dropout_layer = nn.Dropout(p=self.dropout)
         self.prediction = nn.Linear(pre_size + self.emb_size, 1, bias=False)
         # key of the dropout mask stream; not a parameter and not in the state_dict (the reference has no such key)
-        self.register_buffer('drop_seed', torch.randint(0, 2 ** 62, (1,), dtype=torch.int64), persistent=False)
+        self.register_buffer('drop_seed', hnn.fresh_drop_seed(), persistent=False)
 
     def _fused_ok(self):
         return len(self.layers) == 1 and engine.neumf_supported(self.emb_size, self.layers[0])

@@ -45,7 +45,7 @@ class SASRecBase(object):
                                     dropout=self.dropout, kq_same=False)
             for _ in range(self.num_layers)])
         # key of the dropout mask stream; not a parameter and not in the state_dict (the reference has no such key)
-        self.register_buffer('drop_seed', torch.randint(0, 2 ** 62, (1,), dtype=torch.int64), persistent=False)
+        self.register_buffer('drop_seed', hnn.fresh_drop_seed(), persistent=False)
 
     def _encode_torch(self, history, lengths):
         batch_size, seq_len = history.shape

@@ -123,7 +123,7 @@ class MLP_Block(nn.Module):
         self._hip_plan = hnn.mlp_plan(mods)
         if self._hip_plan is not None and any(p > 0 for _, _, p in self._hip_plan):
             # key of the dropout mask stream; not a parameter and not in the state_dict
-            self.register_buffer('drop_seed', torch.randint(0, 2 ** 62, (1,), dtype=torch.int64), persistent=False)
+            self.register_buffer('drop_seed', hnn.fresh_drop_seed(), persistent=False)
 
     def forward(self, inputs):
         if self._hip_plan is not None and inputs.is_cuda and inputs.dtype == torch.float32:

@@ -40,7 +40,8 @@ def _check_plan(eng, cuda, ids_a, range_a, ids_b, range_b, list_single_a):
 @pytest.mark.parametrize("list_single_a", [True, False])
 @pytest.mark.parametrize("case", ["uniform_wide", "zipf_hot", "all_same", "tiny", "small_range", "edges", "no_b",
                                   "many_buckets", "tile_boundary", "huge_bucket", "hashed_100M", "hashed_hot", "hashed_sharded",
-                                  "hashed_2M_keys", "skipped_ids", "skipped_ids_hashed"])
+                                  "hashed_2M_keys", "skipped_ids", "skipped_ids_hashed", "narrow_dense", "narrow_one_id_per_bucket",
+                                  "narrow_max"])
 def test_bucket_plan_matches_the_oracle(case, list_single_a, cuda, eng):
     rng = np.random.default_rng(sum(map(ord, case)))
     if case == "uniform_wide":
@@ -91,6 +92,18 @@ def test_bucket_plan_matches_the_oracle(case, list_single_a, cuda, eng):
         a[8192:3 * 8192] = -1
         b = rng.integers(0, rb, size=9_000)
         b[::3] = -1
+    elif case == "narrow_dense":  # dense batch over a small table (SASRec: candidates + histories over 8.7 K items): narrow buckets,
+        ra, rb = 8_714, 1_500      # ballot ranks; one row with a third of all occurrences, padding ids skipped
+        a = np.minimum(rng.zipf(1.15, size=300_000), ra - 1)
+        a[rng.random(300_000) < 0.3] = 17
+        a[rng.random(300_000) < 0.1] = -1
+        b = np.minimum(rng.zipf(1.3, size=9_000), rb - 1)
+    elif case == "narrow_one_id_per_bucket":
+        ra, rb = 900, 40
+        a, b = rng.integers(0, ra, size=20_000), rng.integers(0, rb, size=3_000)
+    elif case == "narrow_max":    # 32 ids per bucket, 4,096 buckets
+        ra, rb = 120_000, 11_000
+        a, b = rng.integers(0, ra, size=600_000), rng.integers(0, rb, size=2_000)
     elif case == "huge_bucket":   # one bucket past 32,768 keys (32-bit LDS cells) next to ordinary ones (16-bit cells)
         ra, rb = 5_000_000, 3_000
         a = np.concatenate([rng.integers(0, 100, size=40_000), rng.integers(0, ra, size=30_000)])
