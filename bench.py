@@ -679,18 +679,20 @@ def main():
 
     if rank == 0 and not args.no_roofline and hasattr(trainer, "profile_step"):
         # per-phase hipEvent timing on the launch stream, measured live (profiling steps are outside the timed region
-        # above).  The profiled step is in the state of the timed loop: the previous step announced its batch, so its plan
-        # is already prepared and it starts with the fused kernel; nothing runs beside that kernel (the plan of the
-        # FOLLOWING batch is forked off behind it -- and not at all in a profiled step, whose updates therefore run
-        # alone too).
+        # above).  A profiled step is a step of the timed loop's steady state: the previous step announced its batch (its
+        # plan is prepared, it starts with the fused kernel) and it announces the next one, whose plan runs on the second
+        # stream beside these phases -- what the timed steps do.
         acc = {}
         reps = 10
         big = args.batch * (args.num_neg + 2) > 32768     # (smaller batches take the two-launch step: no plan, no look-ahead)
+        nb = len(batches)
         for s in range(reps):
-            a, b = batches[(2 * s) % len(batches)], batches[(2 * s + 1) % len(batches)]
+            a, b, c = batches[(2 * s) % nb], batches[(2 * s + 1) % nb], batches[(2 * s + 2) % nb]
             if big:
                 trainer.step(*a, next_batch=b)
-            ph = trainer.profile_step(*b)
+            ph = trainer.profile_step(*b, next_batch=c if big else None)
+            if big:
+                trainer.step(*c)     # consumes the plan the profiled step prepared
             for k, v in ph.items():
                 acc[k] = acc.get(k, 0.0) + v / reps
         ab = algorithmic_bytes(args, batches)
@@ -706,30 +708,25 @@ def main():
         }
         out["phases_ms"] = {k: round(v, 4) for k, v in acc.items()}
         if big:
-            # The plan itself (in the timed loop it runs on the second stream beside the previous step's row updates):
-            # its two halves alone, from a step that has to plan its own batch on ONE stream (rc_bprmf_step_pipeline(2)),
-            # and the fused kernel of a step that plans its own batch on two streams (the per-bucket pass beside it).
+            # Every kernel of the step with NOTHING beside it: a step that plans its own batch on ONE stream
+            # (rc_bprmf_step_pipeline(2)) -- the plan's two halves, and what the dominant kernel reaches by itself.
             from rechorus_amd import _lib as _rl
             lib = _rl.load()
-            plan_ms = {"front_partition_bitmap": 0.0, "bucket_pass": 0.0}
+            alone = {}
             prev = lib.rc_bprmf_step_pipeline(2)
             try:
                 for s in range(reps):
-                    ph = trainer.profile_step(*batches[s % len(batches)])
-                    plan_ms["front_partition_bitmap"] += ph["sort_items"] / reps
-                    plan_ms["bucket_pass"] += ph["segment_heads"] / reps
+                    for k, v in trainer.profile_step(*batches[s % nb]).items():
+                        alone[k] = alone.get(k, 0.0) + v / reps
             finally:
                 lib.rc_bprmf_step_pipeline(prev)
-            own = 0.0
-            for s in range(reps):
-                own += trainer.profile_step(*batches[s % len(batches)])["fused_fwd_bwd"] / reps
-            out["plan_ms"] = {k: round(v, 4) for k, v in plan_ms.items()}
-            if dom == "fused_fwd_bwd":
-                out["roofline"]["note"] = ("steady state of the timed loop: the batch's plan was prepared beside the previous step's "
-                                           "updates, nothing runs beside the fused kernel")
-                out["roofline"]["unprepared"] = {"avg_ms": own, "achieved": ab[dom] / (own * 1e-3) / 1e9,
-                                                 "frac": ab[dom] / (own * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                                                 "note": "same kernel in a step that plans its own batch (per-bucket pass on the second stream beside it)"}
+            out["plan_ms"] = {"front_partition_bitmap": round(alone["sort_items"], 4), "bucket_pass": round(alone["segment_heads"], 4)}
+            out["phases_alone_ms"] = {k: round(alone[k], 4) for k in ("fused_fwd_bwd", "item_update", "user_update")}
+            out["roofline"]["note"] = ("live hipEvents in a steady-state step of the timed loop: the batch's plan was prepared ahead, the "
+                                       "plan of the following batch runs on the second stream beside the kernel")
+            out["roofline"]["alone"] = {"avg_ms": alone[dom], "achieved": ab[dom] / (alone[dom] * 1e-3) / 1e9,
+                                        "frac": ab[dom] / (alone[dom] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                        "note": "same kernel with nothing beside it (bucket plan on one stream)"}
         out["phases_gbps"] = {k: round(ab[k] / (acc[k] * 1e-3) / 1e9, 1)
                               for k in ("fused_fwd_bwd", "item_update", "user_update") if acc.get(k, 0) > 0}
         out["uniq_rows_per_step"] = {"items": ab["uniq_items"], "users": ab["uniq_users"],

@@ -635,8 +635,9 @@ typedef struct rc_step_ticket {
  * next_uid [B] / next_iid [B, C] / next_generation: the following call's batch (same shapes, same workspace), or
  * NULL / 0 for none.  A ticket prepared for exactly (generation, workspace, geometry, optimizer class) is consumed;
  * anything else is discarded (after waiting for the side stream) and the step plans its batch itself.  Results are
- * bit-identical to rc_bprmf_train_step in every case.  No look-ahead is PREPARED under stream capture, with phase_ms
- * (profiling: a matching ticket is still consumed), or for batches that take the small-batch / sort pipeline.      */
+ * bit-identical to rc_bprmf_train_step in every case.  No look-ahead is PREPARED under stream capture or for batches
+ * that take the small-batch / sort pipeline.  With phase_ms the phases are those of a steady-state step (the plan of
+ * the following batch runs on the second stream beside them).                                                      */
 int rc_bprmf_train_step_ahead(float* U, float* I, float* mU, float* vU, float* mI, float* vI,
                               const int64_t* uid, const int64_t* iid, uint64_t generation,
                               const int64_t* next_uid, const int64_t* next_iid, uint64_t next_generation,

@@ -78,12 +78,14 @@ StepSide* step_side(int* device_out = nullptr) {
   }
   return x.ok ? &x : nullptr;
 }
-// where the look-ahead plan of the next batch is forked off: 0 = behind the fused kernel (beside this step's row
-// updates), 1 = at the start of the step (beside the fused kernel as well); RC_AHEAD_FORK=early selects 1
+// where the look-ahead plan of the next batch is forked off: 1 = at the start of the step (default: the plan's chain of
+// latency-bound kernels stretches about 2.5 x beside the bandwidth-bound row kernels and needs the whole step as its
+// window -- 0.988 -> 0.945 ms/step at config 2, profiles/r03d_ab_overlap.txt), 0 = behind the fused kernel (beside this
+// step's row updates only); RC_AHEAD_FORK=late selects 0
 int ahead_fork_mode() {
   static int mode = [] {
     const char* v = getenv("RC_AHEAD_FORK");
-    return (v && strcmp(v, "early") == 0) ? 1 : 0;
+    return (v && strcmp(v, "late") == 0) ? 0 : 1;
   }();
   return mode;
 }
@@ -316,9 +318,9 @@ static int train_step_impl(float* U, float* I, float* mU, float* vU, float* mI, 
     const PlanArgs pa = slot_plan_args(w, slot, uid, iid, n_i, B, n_users, n_items, geom, fused_upd);
     const bool two_streams = (step_pipeline() == 0 || step_pipeline() == 3) && side != nullptr;
     // Look-ahead: the WHOLE plan of the next batch (partition, bitmap, row records, grouped positions) into the other
-    // slot, on the side stream.  Not under stream capture (the next call's wait on front_done would cross graphs), not
-    // in profiling mode (the phases are measured without it).
-    bool look_ahead = two_streams && ticket != nullptr && next_generation != 0 && next_uid != nullptr && next_iid != nullptr && !prof;
+    // slot, on the side stream.  Not under stream capture (the next call's wait on front_done would cross graphs).
+    // (Also in profiling mode: a profiled step is then exactly a step of the steady state, the next plan beside it.)
+    bool look_ahead = two_streams && ticket != nullptr && next_generation != 0 && next_uid != nullptr && next_iid != nullptr;
     if (look_ahead) {
       hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
       look_ahead = hipStreamIsCapturing(s, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone;

@@ -388,7 +388,12 @@ def segmented_pair_supported(d):
 
 
 _EDB_PLAN_MIN = int(os.environ.get("RC_EDB_PLAN_MIN", "8192"))
-_USE_PLAN = os.environ.get("RC_TABLE_UPDATE", "plan") != "sort"   # A/B switch: the trainers' table updates behind a radix sort
+# A/B switches: RC_TABLE_UPDATE=sort puts every trainer's table update behind the radix sort, =plan behind the bucket plan.
+# Default: NeuMF on the plan (hashed buckets: 0.33 M lookups over 10 M - 100 M rows); SASRec behind the sort -- 0.6 M
+# occurrences over 8.7 K rows are all hot rows, where the sort-driven update measured faster (table_update 0.27 ms against
+# 0.44 ms through the narrow-bucket plan, profiles/r03d_bench_sasrec*.json)
+_USE_PLAN = os.environ.get("RC_TABLE_UPDATE", "auto") != "sort"
+_SASREC_PLAN = os.environ.get("RC_TABLE_UPDATE", "auto") == "plan"
 
 
 def unique_ids(ids, n_rows, tag="unique"):
@@ -551,10 +556,12 @@ class BprmfTrainer:
                   phase_ms if phase_ms is not None else None)
         return self.loss
 
-    def profile_step(self, uid, iid):
-        """One step with hipEvent phase timing -> dict of milliseconds (synchronises)."""
+    def profile_step(self, uid, iid, next_batch=None):
+        """One step with hipEvent phase timing -> dict of milliseconds (synchronises).  With next_batch (and this batch
+        announced by the previous step) the profiled step is a step of the steady state: its plan was prepared ahead, the
+        plan of the following batch runs on the second stream beside its phases."""
         buf = (C.c_float * 8)()
-        self.step(uid, iid, phase_ms=buf)
+        self.step(uid, iid, phase_ms=buf, next_batch=next_batch)
         names = ["sort_items", "sort_users", "fused_fwd_bwd", "loss_mean", "item_update",
                  "user_update", "total", "segment_heads"]
         return {n: float(buf[i]) for i, n in enumerate(names)}
@@ -677,21 +684,27 @@ class NeumfTrainer:
         h0 = make_hyper(self.opt, lr=self.lr, l2=0.0, step=self.step_count)  # 'bias' params: no weight decay
         pair_ok = segmented_pair_supported(P["mf_u"].shape[1])
         n_u, n_i = P["mf_u"].shape[0], P["mf_i"].shape[0]
-        uid_occ = uid.repeat_interleave(Cn)
-        if self.rowwise and pair_ok and _USE_PLAN and plan_supported(iid.numel(), uid_occ.numel(), n_i, n_u):
+        if self.rowwise and pair_ok and _USE_PLAN and plan_supported(iid.numel(), uid.numel(), n_i, n_u):
             # ONE bucket plan of both id lists (round 3: hashed buckets where the id space is wide and sparse -- 0.33 M item
             # lookups over 10 M - 100 M rows -- so the cost follows the keys, not the id range; round 2's id-range
             # buckets cost as much as the radix sort here and the sort stayed), then one pair update per side: the
-            # mf / mlp tables of a side share ids, records and positions
+            # mf / mlp tables of a side share ids, records and positions.  The user side is planned per TUPLE: the head
+            # kernel's per-candidate user gradients are summed over a tuple's candidates first (fixed order c = 0..C-1), so
+            # a hot user contributes B_u occurrences, not C * B_u.
             with _PhaseTimer(self, "sort"):
-                plan = Plan(iid, n_i, uid_occ, n_u, tag="neumf")
+                plan = Plan(iid, n_i, uid, n_u, tag="neumf")
             with _PhaseTimer(self, "table_update"):
-                for side, ta, tb, ga, gb in (("b", "mf_u", "mlp_u", "g_mf_u", "g_mlp_u"), ("a", "mf_i", "mlp_i", "g_mf_i", "g_mlp_i")):
+                key = (B, Cn, str(uid.device))
+                if getattr(self, "_sum_idx", (None,))[0] != key:
+                    self._sum_idx = (key, torch.arange(B * Cn, device=uid.device).view(B, Cn), torch.ones((B, Cn), device=uid.device))
+                _, pos, ones = self._sum_idx
+                gu_a, gu_b = weighted_row_sum(rows["g_mf_u"], pos, ones), weighted_row_sum(rows["g_mlp_u"], pos, ones)
+                for side, ta, tb, ga, gb in (("b", "mf_u", "mlp_u", gu_a, gu_b), ("a", "mf_i", "mlp_i", rows["g_mf_i"], rows["g_mlp_i"])):
                     sa, sb = self.state[ta], self.state[tb]
-                    plan.update_pair(side, P[ta], P[tb], rows[ga], rows[gb], h, ma=sa.get("m"), va=sa.get("v"),
+                    plan.update_pair(side, P[ta], P[tb], ga, gb, h, ma=sa.get("m"), va=sa.get("v"),
                                      mb=sb.get("m"), vb=sb.get("v"))
         else:
-            self._step_tables_sorted(P, uid_occ, iid, rows, h, pair_ok)
+            self._step_tables_sorted(P, uid.repeat_interleave(Cn), iid, rows, h, pair_ok)
         with _PhaseTimer(self, "dense_update"):
             dense_update_multi([(P[k], dense[k], h0 if k == "b1" else h, self.state[k].get("m"), self.state[k].get("v"))
                                 for k in ("W1", "b1", "w_out")], self.opt)
@@ -949,7 +962,7 @@ class SasrecTrainer:
         _upd.__enter__()
         st = self._st(I)
         n_occ = B * Cn + hist.numel()
-        if _USE_PLAN and n_occ >= _EDB_PLAN_MIN and plan_supported(n_occ, 0, I.shape[0], 0):
+        if _SASREC_PLAN and n_occ >= _EDB_PLAN_MIN and plan_supported(n_occ, 0, I.shape[0], 0):
             # bucket plan of candidate + history ids.  The padding slots of the history windows (id 0, zero gradient rows:
             # half of B * history_max occurrences of ONE row) are marked "takes no part" (negative id) except the first of
             # them, which keeps row 0 among the touched rows exactly as before -- a sum of zero rows is zero either way.

