@@ -153,7 +153,9 @@ enum rc_list_kind {
   RC_LIST_BPR_HARD_BEFORE = 5,
   RC_LIST_LISTNET = 6,         /* :84-94  cross entropy between softmax(labels) and softmax(scores)                 */
   RC_LIST_SOFTMAX_CE = 7,      /* :96-107 (rc_softmax_ce_fwd_bwd)                                                   */
-  RC_LIST_ATTENTION_RANK = 8   /* :109-126 listnet + the (1 - t) log(1 - p) term                                    */
+  RC_LIST_ATTENTION_RANK = 8,  /* :109-126 listnet + the (1 - t) log(1 - p) term                                    */
+  RC_LIST_BPR_SIMPLE = 9       /* :82-83  every valid (pos, neg) pair, no re-weighting; the per-row sums are the result
+                                  (unreduced, as the reference returns them): gpred = inv_b * d row / d pred            */
 };
 /* loss_vec [B]: per-row terms whose fixed-order sum (rc_reduce_sum; scale 1/B for the BPR kinds, which also take
  * inv_b = 1/B for the gradient; scale 1 for the kinds normalised by the rows that have a negative) is the loss;

@@ -643,46 +643,58 @@ __global__ __launch_bounds__(kBucketThreads) void plan_bucket_kernel(PlanArgs a)
 // passes are those of plan_bucket_kernel: pass 1 counts (all waves, order-free), a scan over the SLOTS turns counts
 // into cursors and emits the row records, wave 0 alone walks the keys in position order and hands out the slots of
 // every row ascending.  8,192 slots for ~1,024 keys per bucket (plan_geometry): load <= 1/8 when all keys differ.
-__device__ __forceinline__ uint32_t hash_slot0(uint32_t id) { return (id * 0x85EBCA6Bu) >> (32 - 13); }
-static_assert(kPlanHashSlots == 8192, "hash_slot0 yields 13 bits");
+// The table of a bucket has S = 2^lg slots, S >= 2 x its keys (256 .. 8,192): zeroing and scanning follow the bucket's
+// size, not the maximum.
+__device__ __forceinline__ uint32_t hash_slot0(uint32_t id, int lg) { return (id * 0x85EBCA6Bu) >> (32 - lg); }
 
-// slot of `id`, claiming an empty one on first sight (pass 1) -- or kPlanHashSlots when the table is full
-__device__ __forceinline__ uint32_t hash_insert(uint32_t* keys, uint32_t id) {
-  uint32_t h = hash_slot0(id);
-  for (uint32_t probe = 0; probe < kPlanHashSlots; ++probe) {
+// slot of `id`, claiming an empty one on first sight (pass 1) -- or S when the table is full
+__device__ __forceinline__ uint32_t hash_insert(uint32_t* keys, uint32_t id, int lg) {
+  const uint32_t S = 1u << lg;
+  uint32_t h = hash_slot0(id, lg);
+  for (uint32_t probe = 0; probe < S; ++probe) {
     const uint32_t k = __hip_atomic_load(&keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     if (k == id) return h;
     if (k == 0xFFFFFFFFu) {
       const uint32_t old = atomicCAS(&keys[h], 0xFFFFFFFFu, id);
       if (old == 0xFFFFFFFFu || old == id) return h;
     }
-    h = (h + 1) & (kPlanHashSlots - 1);
+    h = (h + 1) & (S - 1);
   }
-  return kPlanHashSlots;
+  return S;
 }
 // slot of an id that pass 1 inserted
-__device__ __forceinline__ uint32_t hash_find(const uint32_t* keys, uint32_t id) {
-  uint32_t h = hash_slot0(id);
-  for (uint32_t probe = 0; probe < kPlanHashSlots; ++probe) {
+__device__ __forceinline__ uint32_t hash_find(const uint32_t* keys, uint32_t id, int lg) {
+  const uint32_t S = 1u << lg;
+  uint32_t h = hash_slot0(id, lg);
+  for (uint32_t probe = 0; probe < S; ++probe) {
     if (keys[h] == id) return h;
-    h = (h + 1) & (kPlanHashSlots - 1);
+    h = (h + 1) & (S - 1);
   }
   return 0;
 }
 
+// Hot rows: when the first valid lane's id is shared by at least kHotGroup lanes of the round (a row with thousands of
+// occurrences fills whole rounds), ONE lane moves the cell for the whole group; 64 same-address LDS atomics would be served
+// one after the other.  -> mask of the lanes that were taken care of (0: nobody)
+constexpr int kHotGroup = 8;
+
+constexpr int kHashBatch = 8;   // rounds of 64 keys requested together by the ordered pass
+
 __global__ __launch_bounds__(kBucketThreads) void plan_bucket_hash_kernel(PlanArgs a) {
-  extern __shared__ uint32_t tab[];  // keys [S], cells [S], 16 words of scan scratch
-  constexpr uint32_t S = kPlanHashSlots;
+  extern __shared__ uint32_t tab[];  // keys [S], cells [S], 16 words of scan scratch (carved for the largest table)
   constexpr uint32_t kSingle = 0x80000000u;
-  uint32_t* keys = tab;
-  uint32_t* cells = tab + S;
-  uint32_t* scratch = cells + S;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const uint32_t bkt = blockIdx.x;
   const uint32_t beg = a.w.bucket_base[bkt], end = a.w.bucket_base[bkt + 1];
   if (beg == end) return;  // block-uniform
+  int lg = 8;
+  while ((1u << lg) < 2u * (end - beg) && lg < 13) ++lg;
+  const uint32_t S = 1u << lg;
+  uint32_t* keys = tab;
+  uint32_t* cells = tab + S;
+  uint32_t* scratch = tab + 2 * kPlanHashSlots;
   const bool side_b = bkt >= a.g.nb_a;
   const bool list_all = side_b || a.list_single_a != 0;
   for (uint32_t i = tid; i < S; i += kBucketThreads) {
@@ -701,17 +713,25 @@ __global__ __launch_bounds__(kBucketThreads) void plan_bucket_hash_kernel(PlanAr
       k[q] = j < end ? a.w.lid32[j] : 0xFFFFFFFFu;
     }
 #pragma unroll
-    for (int q = 0; q < kCountBatch; ++q)
-      if (k[q] != 0xFFFFFFFFu) {
-        const uint32_t h = hash_insert(keys, k[q]);
-        if (h < S) atomicAdd(&cells[h], 1u);
+    for (int q = 0; q < kCountBatch; ++q) {
+      const bool valid = k[q] != 0xFFFFFFFFu;
+      const uint64_t vm = __ballot(valid);
+      if (vm == 0) continue;  // wave-uniform
+      const uint32_t k0 = (uint32_t)__shfl((int)k[q], __ffsll((long long)vm) - 1, 64);
+      const uint64_t grp = __ballot(valid && k[q] == k0);
+      const bool hot = __popcll(grp) >= kHotGroup;
+      const bool mine = valid && (!hot || k[q] != k0 || lane == __ffsll((long long)grp) - 1);
+      if (mine) {
+        const uint32_t h = hash_insert(keys, k[q], lg);
+        if (h < S) atomicAdd(&cells[h], (hot && k[q] == k0) ? (uint32_t)__popcll(grp) : 1u);
         else a.w.counters[PC_STATUS] = 2u;   // more distinct rows than slots: the plan is incomplete (never at the sizes plan_geometry admits)
       }
+    }
   }
   __syncthreads();
 
   // scan over the slots: counts -> cursors (listed rows) / marker (rows that are only flagged); row records
-  constexpr uint32_t per = S / kBucketThreads;
+  const uint32_t per = S / kBucketThreads;
   uint32_t my_occ = 0, my_rows = 0;
   for (uint32_t j = 0; j < per; ++j) {
     const uint32_t c = cells[tid * per + j];
@@ -760,34 +780,58 @@ __global__ __launch_bounds__(kBucketThreads) void plan_bucket_hash_kernel(PlanAr
   __syncthreads();
   if (wave != 0) return;
 
-  // pass 2 (wave 0): positions into their row's slots, ascending
+  // pass 2 (wave 0): positions into their row's slots, ascending; kHashBatch rounds of keys requested together
   uint8_t* single = (side_b || a.flags_done) ? nullptr : a.single_a;
-  for (uint32_t j0 = beg; j0 < end; j0 += 64) {
-    const uint32_t j = j0 + lane;
-    const bool valid = j < end;
-    const uint32_t lid = valid ? a.w.lid32[j] : 0xFFFFFFFFu;
-    const uint32_t p = valid ? a.w.pos[j] : 0u;
-    uint32_t old = 0, now = 1;
-    if (valid) {
-      const uint32_t h = hash_find(keys, lid);
-      old = atomicAdd(&cells[h], 1u);
-      now = __hip_atomic_load(&cells[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  for (uint32_t jb = beg; jb < end; jb += 64 * kHashBatch) {
+    uint32_t kk[kHashBatch], pp[kHashBatch];
+#pragma unroll
+    for (int q = 0; q < kHashBatch; ++q) {
+      const uint32_t j = jb + q * 64 + lane;
+      kk[q] = j < end ? a.w.lid32[j] : 0xFFFFFFFFu;
+      pp[q] = j < end ? a.w.pos[j] : 0u;
     }
-    uint32_t slot = old;
-    uint64_t pending = __ballot(valid && now != old + 1u);  // rows shared by several lanes of this round
-    while (pending) {
-      const int leader = __ffsll((long long)pending) - 1;
-      const uint32_t lid0 = __shfl(lid, leader, 64);
-      const uint32_t now0 = __shfl(now, leader, 64);
-      const uint64_t same = __ballot(valid && lid == lid0);
-      if (valid && lid == lid0) slot = now0 - (uint32_t)__popcll(same) + (uint32_t)__popcll(same & lanes_below(lane));
-      pending &= ~same;
-    }
-    if (!valid) continue;
-    if (slot & kSingle) {
-      if (single) single[p] = 1;
-    } else {
-      a.occ[beg + slot] = p;
+#pragma unroll
+    for (int q = 0; q < kHashBatch; ++q) {
+      if (jb + q * 64 >= end) break;  // wave-uniform
+      const uint32_t lid = kk[q], p = pp[q];
+      const bool valid = lid != 0xFFFFFFFFu;
+      const uint64_t vm = __ballot(valid);
+      if (vm == 0) continue;
+      // hot group of the round's first id: one atomic for all of its lanes
+      const int first = __ffsll((long long)vm) - 1;
+      const uint32_t lid0 = (uint32_t)__shfl((int)lid, first, 64);
+      const uint64_t grp = __ballot(valid && lid == lid0);
+      const bool hot = __popcll(grp) >= kHotGroup;
+      uint32_t slot = 0;
+      if (hot) {
+        uint32_t base = 0;
+        if (lane == first) base = atomicAdd(&cells[hash_find(keys, lid0, lg)], (uint32_t)__popcll(grp));
+        base = (uint32_t)__shfl((int)base, first, 64);
+        if (valid && lid == lid0) slot = base + (uint32_t)__popcll(grp & lanes_below(lane));
+      }
+      const bool rest = valid && !(hot && lid == lid0);
+      uint32_t old = 0, now = 1;
+      if (rest) {
+        const uint32_t h = hash_find(keys, lid, lg);
+        old = atomicAdd(&cells[h], 1u);
+        now = __hip_atomic_load(&cells[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        slot = old;
+      }
+      uint64_t pending = __ballot(rest && now != old + 1u);  // rows shared by several lanes of this round
+      while (pending) {
+        const int leader = __ffsll((long long)pending) - 1;
+        const uint32_t l0 = (uint32_t)__shfl((int)lid, leader, 64);
+        const uint32_t now0 = (uint32_t)__shfl((int)now, leader, 64);
+        const uint64_t same = __ballot(rest && lid == l0);
+        if (rest && lid == l0) slot = now0 - (uint32_t)__popcll(same) + (uint32_t)__popcll(same & lanes_below(lane));
+        pending &= ~same;
+      }
+      if (!valid) continue;
+      if (slot & kSingle) {
+        if (single) single[p] = 1;
+      } else {
+        a.occ[beg + slot] = p;
+      }
     }
   }
 }

@@ -268,6 +268,40 @@ __global__ __launch_bounds__(kBlock) void list_bpr_reweight_kernel(const float* 
   }
 }
 
+// ---- list-level BPR without re-weighting, 'BPR...simple' (models/BaseImpressionModel.py:82-83) ---------------------
+//   row = sum over the valid (positive i, negative j) pairs of softplus(-(s_i - s_j)); the reference returns the rows
+//   UNREDUCED ([B]): loss_vec is the result, gpred[b, c] = scale * d row_b / d s_c  (the caller multiplies by the
+//   incoming gradient of row b):   d/ds_i = -sum_j sigmoid(-d_ij),   d/ds_j = sum_i sigmoid(-d_ij).  One wave per row.
+__global__ __launch_bounds__(kBlock) void list_bpr_simple_kernel(const float* __restrict__ pred, const int64_t* __restrict__ target,
+                                                                int B, int n, int P, float scale, float* __restrict__ loss_vec,
+                                                                float* __restrict__ gpred) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (row >= B) return;  // wave-uniform
+  const float* x = pred + row * n;
+  const int64_t* tg = target + row * n;
+  float l_part = 0.f;
+  for (int c = lane; c < n; c += 64) {
+    float g = 0.f;
+    if (tg[c] != -1) {
+      if (c < P) {
+        for (int j = P; j < n; ++j)
+          if (tg[j] != -1) {
+            const float d = x[c] - x[j];
+            l_part += softplusf_(-d);
+            g -= sigmoidf_(-d);
+          }
+      } else {
+        for (int i = 0; i < P; ++i)
+          if (tg[i] != -1) g += sigmoidf_(-(x[i] - x[c]));
+      }
+    }
+    if (gpred) gpred[row * n + c] = scale * g;
+  }
+  l_part = wave_allreduce_sum(l_part);
+  if (lane == 0) loss_vec[row] = l_part;
+}
+
 // ---- listnet / attention_rank (models/BaseImpressionModel.py:84-94, 109-126) -------------------------------------
 //   t = softmax over the valid columns of the labels (1 / 0);  have_neg, H as for softmaxCE
 //   listnet:        p = softmax of the scores over ALL n columns (the reference does not mask them; padding only drops
@@ -367,9 +401,9 @@ extern "C" int rc_list_bpr_fwd_bwd(const float* pred, const int64_t* target, int
   return RC_OK;
 }
 
-// Every list-wise loss name of ImpressionModel.loss (models/BaseImpressionModel.py:44-129) but 'BPR...simple' (which the
-// reference leaves unreduced): kind = RC_LIST_*.  loss_vec [B] holds per-row terms whose fixed-order sum (rc_reduce_sum,
-// scale 1/B for the BPR kinds, 1 for the others) is the loss; h_sum [1] is scratch for the kinds normalised by the number
+// Every list-wise loss name of ImpressionModel.loss (models/BaseImpressionModel.py:44-129): kind = RC_LIST_*.  loss_vec [B]
+// holds per-row terms whose fixed-order sum (rc_reduce_sum, scale 1/B for the BPR kinds, 1 for the others) is the loss
+// -- except RC_LIST_BPR_SIMPLE, whose rows ARE the result (the reference leaves them unreduced); h_sum [1] is scratch for the kinds normalised by the number
 // of rows that have a negative (softmaxCE, listnet, attention_rank); gpred (optional) = dloss/dpred.
 extern "C" int rc_list_loss_fwd_bwd(const float* pred, const int64_t* target, int B, int n, int max_pos, int kind,
                                     float inv_b, float* loss_vec, float* h_sum, float* gpred, rc_stream_t stream) {
@@ -395,6 +429,9 @@ extern "C" int rc_list_loss_fwd_bwd(const float* pred, const int64_t* target, in
     case RC_LIST_BPR_HARD_BEFORE:
       hipLaunchKernelGGL((list_bpr_reweight_kernel<true>), dim3(blocks), dim3(kBlock), 0, s, pred, target, B, n, max_pos,
                          kind == RC_LIST_BPR_HARD_BEFORE, inv_b, loss_vec, gpred);
+      break;
+    case RC_LIST_BPR_SIMPLE:
+      hipLaunchKernelGGL(list_bpr_simple_kernel, dim3(blocks), dim3(kBlock), 0, s, pred, target, B, n, max_pos, inv_b, loss_vec, gpred);
       break;
     case RC_LIST_LISTNET:
     case RC_LIST_ATTENTION_RANK:

@@ -1032,29 +1032,34 @@ def list_bpr(pred, target, max_pos, hard=False, need_grad=True):
 
 
 LIST_KINDS = {"BPR": 0, "BPRhard": 1, "BPRafter": 2, "BPRhardafter": 3, "BPRbefore": 4, "BPRhardbefore": 5, "listnet": 6,
-              "softmaxCE": 7, "attention_rank": 8}
+              "softmaxCE": 7, "attention_rank": 8, "BPRsimple": 9}
 
 
 def list_kind(loss_n):
     """ImpressionModel's --loss_n -> rc_list_kind, by the reference's own substring rules (models/BaseImpressionModel.py:50-89:
-    any name containing 'BPR'; 'hard' / 'after' / 'before' anywhere in it); None for 'BPR...simple' and unknown names"""
+    any name containing 'BPR'; 'hard' / 'after' / 'before' / 'simple' anywhere in it, in the reference's elif order); None
+    for unknown names"""
     if "BPR" in loss_n:
         if "simple" in loss_n and "after" not in loss_n and "before" not in loss_n:
-            return None
+            return LIST_KINDS["BPRsimple"]
         base = "BPRhard" if "hard" in loss_n else "BPR"
         return LIST_KINDS[base + ("after" if "after" in loss_n else ("before" if "before" in loss_n else ""))]
     return LIST_KINDS.get(loss_n)
 
 
 def list_loss(pred, target, max_pos, kind, need_grad=True):
-    """rc_list_loss_fwd_bwd: any list-wise loss of ImpressionModel.loss -> (loss [1], gpred | None); kind from list_kind()"""
+    """rc_list_loss_fwd_bwd: any list-wise loss of ImpressionModel.loss -> (loss [1] -- [B] unreduced for 'BPR...simple' --,
+    gpred | None); kind from list_kind()"""
     B, n = pred.shape
     dev, f32 = pred.device, torch.float32
     loss_vec = torch.empty(B, dtype=f32, device=dev)
     h_sum = torch.empty(1, dtype=f32, device=dev)
     gpred = torch.empty_like(pred) if need_grad else None
     _lib.call("rc_list_loss_fwd_bwd", _ptr(pred, f32, "pred"), _ptr(target, torch.int64, "target"), B, n, int(max_pos), int(kind),
-              1.0 / B, _ptr(loss_vec, f32, "loss_vec"), _ptr(h_sum, f32, "h_sum"), _ptr(gpred, f32, "gpred", True), _stream())
+              1.0 if kind == LIST_KINDS["BPRsimple"] else 1.0 / B, _ptr(loss_vec, f32, "loss_vec"), _ptr(h_sum, f32, "h_sum"),
+              _ptr(gpred, f32, "gpred", True), _stream())
+    if kind == LIST_KINDS["BPRsimple"]:
+        return loss_vec, gpred        # unreduced rows [B] (reference :83); gpred[b] = d loss_vec[b] / d pred[b]
     return reduce_sum(loss_vec, 1.0 / B if kind <= 5 else 1.0), gpred
 
 

@@ -142,12 +142,13 @@ class _ListLossFn(torch.autograd.Function):
     def forward(ctx, pred, target, max_pos, kind):
         loss, gpred = engine.list_loss(pred.detach().contiguous(), target.contiguous(), max_pos, kind)
         ctx.save_for_backward(gpred)
-        return loss.reshape(())
+        ctx.per_row = kind == engine.LIST_KINDS["BPRsimple"]   # the reference leaves this one unreduced: [B]
+        return loss if ctx.per_row else loss.reshape(())
 
     @staticmethod
     def backward(ctx, grad_loss):
         (gpred,) = ctx.saved_tensors
-        return gpred * grad_loss, None, None, None
+        return gpred * (grad_loss[:, None] if ctx.per_row else grad_loss), None, None, None
 
 
 def list_loss(pred, target, max_pos, kind):

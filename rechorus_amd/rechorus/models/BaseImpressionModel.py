@@ -2,10 +2,10 @@
 instance scores a list of up to --*_max_pos_item positives followed by up to --*_max_neg_item negatives
 (right-padded with item 0), `loss(out_dict, target)` takes the runner's {1, 0, -1} labels.
 
-Losses: 'BPR' / 'BPRhard' (list-level BPR, the default of every *Impression model) and 'softmaxCE' are
-single HIP kernels with closed-form backward (rc_list_bpr_fwd_bwd, rc_softmax_ce_fwd_bwd); the rarely
-used re-weighting variants ('BPR...after/before/simple'), 'listnet' and 'attention_rank' are the same
-formulas as device-side torch ops.  ImpressionSeqModel adds the clicked / skipped item histories
+Losses: every name the reference's substring rules resolve -- list-level BPR (the default of every *Impression
+model) with its 'hard' / 'after' / 'before' / 'simple' variants, 'listnet', 'softmaxCE', 'attention_rank' -- is one
+HIP kernel family with closed-form backward (rc_list_loss_fwd_bwd); 'BPR...simple' returns its per-row sums
+unreduced, as the reference does.  ImpressionSeqModel adds the clicked / skipped item histories
 (reader ImpressionSeqReader) for sequential heads such as SASRecImpression.
 """
 from typing import List
@@ -46,12 +46,6 @@ class ImpressionModel(GeneralModel):
             if not pred.is_cuda:
                 raise RuntimeError('ImpressionModel.loss: the HIP engine needs CUDA tensors (no CPU path)')
             return hnn.list_loss(pred, target.long(), P, kind)
-        if 'BPR' in name:  # 'simple': every valid (positive, negative) pair, per-row sums left unreduced (reference :84)
-            valid = (target != -1)
-            col = torch.arange(pred.shape[1], device=pred.device)[None, :]
-            pair = ((col < P) & valid)[:, :, None] & ((col >= P) & valid)[:, None, :]
-            diff = (pred[:, :, None] - pred[:, None, :]) * pair
-            return (F.softplus(-diff) * pair).sum(-1).sum(-1)
         raise ValueError('Undefined loss function: {}'.format(self.loss_n))
 
     class Dataset(GeneralModel.Dataset):

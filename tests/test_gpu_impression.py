@@ -34,6 +34,25 @@ def test_impression_losses_on_the_device_match_the_reference(key, cuda):
     assert_close(p.grad.cpu().numpy(), c["gpred"], what="grad " + key, rtol=2e-5, atol_scale=2e-5)
 
 
+@pytest.mark.parametrize("name", ["BPRsimple", "BPRhardsimple"])
+def test_bpr_simple_kernel_matches_the_reference(name, cuda):
+    """rc_list_loss_fwd_bwd kind 9 vs the reference's own forward (unreduced rows) and autograd (of rows.sum()), through the
+    mirror's ImpressionModel.loss: values, gradient with a unit and with a per-row incoming gradient"""
+    import argparse
+    from models.BaseImpressionModel import ImpressionModel
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "impression_bpr_simple.npz"))
+    for shape_id in range(3):
+        key = "loss/{}/{}/".format(shape_id, name)
+        stub = argparse.Namespace(loss_n=name, train_max_pos_item=int(g[key + "max_pos"]))
+        p = torch.from_numpy(g[key + "pred"]).to(cuda).requires_grad_(True)
+        rows = ImpressionModel.loss(stub, {"prediction": p}, torch.from_numpy(g[key + "target"]).to(cuda))
+        assert tuple(rows.shape) == (p.shape[0],)
+        assert_close(rows.detach().cpu().numpy(), g[key + "rows"], what=name + " rows")
+        w = torch.linspace(0.5, 2.0, p.shape[0], device=cuda)
+        (rows * w).sum().backward()
+        assert_close(p.grad.cpu().numpy(), g[key + "gpred"] * w.cpu().numpy()[:, None], what=name + " grad", atol_scale=2e-5)
+
+
 def test_list_bpr_kernel_random_shapes_vs_oracle(cuda):
     from rechorus_amd import engine
     rng = np.random.default_rng(3)

@@ -525,7 +525,7 @@ def test_neumf_and_sasrec_trainers_plan_equals_sort(cuda, eng, monkeypatch):
              "W1": mk(l1, 2 * d), "b1": mk(l1), "w_out": mk(d + l1)}
         tr = eng.NeumfTrainer(P, opt="Adam", lr=1e-2, l2=1e-5, rowwise=True)
         r = np.random.default_rng(4)
-        for _ in range(2):
+        for _ in range(1):   # (one step: after it the user tables differ by fp32 association, and with them every later gradient)
             uid = torch.from_numpy(_zipf(r, n_users, B)).to(cuda)
             iid = torch.from_numpy(np.concatenate([_zipf(r, n_items, (B, 1)), r.integers(1, n_items, size=(B, Cn - 1))], axis=1)).to(cuda)
             tr.step(uid, iid)
@@ -539,7 +539,7 @@ def test_neumf_and_sasrec_trainers_plan_equals_sort(cuda, eng, monkeypatch):
             # sums all occurrences of a user in one chain: same numbers up to fp32 association
             # (Adam normalises the step: an element whose gradient is rounding noise may move by lr either way -- allow a few)
             diff = (Pa[k] - Pb[k]).abs()
-            assert float((diff > 1e-6).float().mean()) < 5e-3 and float(diff.max()) <= 2 * 2 * 1e-2 + 1e-6, k
+            assert float((diff > 1e-6).float().mean()) < 5e-3 and float(diff.max()) <= 2 * 1e-2 + 1e-6, k
             continue
         assert torch.equal(Pa[k], Pb[k]), k
         for st in ("m", "v"):

@@ -57,25 +57,26 @@ def test_kernel_backed_losses_refuse_cpu_tensors():
                                  {"prediction": torch.from_numpy(c["pred"])}, torch.from_numpy(c["target"]))
 
 
-def test_bpr_simple_is_the_per_row_pair_sum():
-    """'BPR...simple' (reference :84: every valid (positive, negative) pair, per-row sums left unreduced) is the one
-    name without a kernel: device-agnostic torch ops, checked here against a direct numpy evaluation"""
+def test_bpr_simple_golden_is_the_per_row_pair_sum():
+    """'BPR...simple' (reference :82-83: every valid (positive, negative) pair, per-row sums left unreduced) is kernel kind 9;
+    its reference-generated golden (tests/golden/impression_bpr_simple.npz) agrees with a direct numpy evaluation"""
     from models.BaseImpressionModel import ImpressionModel
     from rechorus_amd import engine
-    assert engine.list_kind("BPRsimple") is None
+    assert engine.list_kind("BPRsimple") == engine.LIST_KINDS["BPRsimple"] == engine.list_kind("BPRhardsimple") == 9
+    assert engine.list_kind("BPRsimpleafter") == engine.LIST_KINDS["BPRafter"]     # the reference's elif order: 'after' wins
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "impression_bpr_simple.npz"))
+    for shape_id in range(3):
+        key = "loss/{}/BPRsimple/".format(shape_id)
+        pred, tgt, P = g[key + "pred"].astype(np.float64), g[key + "target"], int(g[key + "max_pos"])
+        want = np.zeros(pred.shape[0])
+        for b in range(pred.shape[0]):
+            for i in range(P):
+                for j in range(P, pred.shape[1]):
+                    if tgt[b, i] != -1 and tgt[b, j] != -1:
+                        want[b] += np.log1p(np.exp(-(pred[b, i] - pred[b, j])))
+        assert_close(g[key + "rows"], want, what="BPRsimple rows", rtol=2e-5)
     c = case(LOSS_CASES[0])
     P = int(c["max_pos"])
-    stub = argparse.Namespace(loss_n="BPRsimple", train_max_pos_item=P)
-    got = ImpressionModel.loss(stub, {"prediction": torch.from_numpy(c["pred"])}, torch.from_numpy(c["target"])).numpy()
-    pred, tgt = c["pred"].astype(np.float64), c["target"]
-    want = np.zeros(pred.shape[0])
-    for b in range(pred.shape[0]):
-        for i in range(P):
-            for j in range(P, pred.shape[1]):
-                if tgt[b, i] != -1 and tgt[b, j] != -1:
-                    want[b] += np.log1p(np.exp(-(pred[b, i] - pred[b, j])))
-    assert got.shape == want.shape
-    assert_close(got, want, what="BPRsimple", rtol=2e-5)
     with pytest.raises(ValueError):
         ImpressionModel.loss(argparse.Namespace(loss_n="nope", train_max_pos_item=P),
                              {"prediction": torch.from_numpy(c["pred"])}, torch.from_numpy(c["target"]))
