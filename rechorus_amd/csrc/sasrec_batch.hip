@@ -336,6 +336,134 @@ __global__ __launch_bounds__(kBlock) void sb_ln_bwd_kernel(float* __restrict__ G
   }
 }
 
+// ---- the post-attention half of a TransformerLayer in ONE row-space kernel (utils/layers.py:110-118) -------------------
+//   y1 = LayerNorm1(drop1(ctx) + x);  h = relu(y1 W1^T + b1);  t = h W2^T + b2;  xnext = LayerNorm2(drop2(t) + y1)
+// Round 2 ran this as four launches (LayerNorm, two sb_linear, LayerNorm) that handed [R, D] intermediates to each other
+// through HBM: 11 row passes and four fill / drain phases for 16 + 29 + 29 + 16 us at config 3.  Here a 64-row tile stays in
+// LDS from the first LayerNorm to the second: both weight matrices are resident, the row statistics run one lane-group
+// per row on the staged tile, the two products are the same 32x32x2 MFMA tile loops (identical summation order), and
+// only what the backward pass reads later leaves the CU (xhat1, rstd1, y1, h, xhat2, rstd2) beside the layer output.
+// The next tile's ctx / x rows travel while the current tile is multiplied.
+struct SbBlockArgs {
+  const float* ctx;   // [R, D] attention output
+  const float* x;     // [R, D] layer input (residual)
+  const float *ln1w, *ln1b, *W1, *b1, *W2, *b2, *ln2w, *ln2b;
+  float *xh1, *rstd1, *y1, *h, *xh2, *rstd2, *xnext;
+  const int32_t* off;
+  int B;
+  SbDrop dr;          // dr.site = 2 * layer (dropout1); dropout2 uses site + 1
+};
+
+template <int D>
+__global__ __launch_bounds__(kBlock) void sb_block_fwd_kernel(SbBlockArgs a) {
+  constexpr int SD = D + 1, LPR = D / 4, GPB = kBlock / LPR, NPASS = kSbTile / GPB;
+  extern __shared__ float lds[];
+  float* W1s = lds;                       // [D][SD]
+  float* W2s = W1s + D * SD;              // [D][SD]
+  float* Ys = W2s + D * SD;               // [kSbTile][SD]: y1, then (in place) the FFN output t
+  float* Hs = Ys + kSbTile * SD;          // [kSbTile][SD]
+  for (int idx = threadIdx.x; idx < D * D; idx += kBlock) {
+    W1s[(idx / D) * SD + idx % D] = a.W1[idx];
+    W2s[(idx / D) * SD + idx % D] = a.W2[idx];
+  }
+  const int l = threadIdx.x % LPR, grp = threadIdx.x / LPR;
+  const int R = a.off[a.B];
+  const int tiles = (R + kSbTile - 1) / kSbTile;
+  const bool drop = a.dr.seed != nullptr;
+  const uint64_t seed = drop ? *a.dr.seed : 0;
+  SbDrop dr1 = a.dr, dr2 = a.dr;
+  dr2.site = a.dr.site + 1u;
+  const float4 w1v = reinterpret_cast<const float4*>(a.ln1w)[l], b1v = reinterpret_cast<const float4*>(a.ln1b)[l];
+  const float4 w2v = reinterpret_cast<const float4*>(a.ln2w)[l], b2v = reinterpret_cast<const float4*>(a.ln2b)[l];
+  float4 pc[NPASS], px[NPASS];
+  auto fetch = [&](int tile) {
+    const int r0 = tile * kSbTile;
+#pragma unroll
+    for (int q = 0; q < NPASS; ++q) {
+      const int r = r0 + q * GPB + grp;
+      if (r < R) {
+        pc[q] = reinterpret_cast<const float4*>(a.ctx)[(size_t)r * LPR + l];
+        px[q] = reinterpret_cast<const float4*>(a.x)[(size_t)r * LPR + l];
+      }
+    }
+  };
+  if ((int)blockIdx.x < tiles) fetch(blockIdx.x);
+  for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const int r0 = tile * kSbTile;
+    const int m = min(kSbTile, R - r0);
+    __syncthreads();  // the previous tile's readers of Ys / Hs are done (and the weights are in place)
+    // ---- LayerNorm1 on the staged rows: one lane-group per row
+#pragma unroll
+    for (int q = 0; q < NPASS; ++q) {
+      const int i = q * GPB + grp;
+      const int64_t r = (int64_t)r0 + i;
+      float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i < m) {
+        z = pc[q];
+        if (drop) {
+          const float4 kp = sb_drop_keep4<D>(dr1, seed, r, l);
+          z.x *= kp.x; z.y *= kp.y; z.z *= kp.z; z.w *= kp.w;
+        }
+        z.x += px[q].x; z.y += px[q].y; z.z += px[q].z; z.w += px[q].w;
+      }
+      const float mu = row_allreduce_sum<LPR>((z.x + z.y) + (z.z + z.w)) / D;
+      const float cx = z.x - mu, cy = z.y - mu, cz = z.z - mu, cw = z.w - mu;
+      const float var = row_allreduce_sum<LPR>(fmaf(cx, cx, fmaf(cy, cy, fmaf(cz, cz, cw * cw)))) / D;
+      const float rs = 1.0f / sqrtf(var + kLnEps);
+      const float4 xh = make_float4(cx * rs, cy * rs, cz * rs, cw * rs);
+      const float4 y = make_float4(fmaf(xh.x, w1v.x, b1v.x), fmaf(xh.y, w1v.y, b1v.y), fmaf(xh.z, w1v.z, b1v.z), fmaf(xh.w, w1v.w, b1v.w));
+      float* d = Ys + i * SD + 4 * l;
+      d[0] = y.x; d[1] = y.y; d[2] = y.z; d[3] = y.w;   // rows past m: finite filler, their outputs are discarded
+      if (i < m) {
+        reinterpret_cast<float4*>(a.xh1)[(size_t)r * LPR + l] = xh;
+        if (l == 0) a.rstd1[r] = rs;
+        reinterpret_cast<float4*>(a.y1)[(size_t)r * LPR + l] = y;
+      }
+    }
+    __syncthreads();
+    if (tile + (int)gridDim.x < tiles) fetch(tile + gridDim.x);   // travels during the two products
+    // ---- h = relu(y1 W1^T + b1)
+    sas_mm(MatA{Ys, SD, 1}, MatB{W1s, 1, SD}, m, D, D, false, [&](int i, int j, float v) {
+      v = fmaxf(v + a.b1[j], 0.f);
+      Hs[i * SD + j] = v;
+      a.h[(size_t)(r0 + i) * D + j] = v;
+    });
+    __syncthreads();
+    // ---- t = h W2^T + b2 (+ y1: without dropout the residual is added right here), in place over y1
+    sas_mm(MatA{Hs, SD, 1}, MatB{W2s, 1, SD}, m, D, D, false, [&](int i, int j, float v) {
+      v += a.b2[j];
+      if (!drop) v += Ys[i * SD + j];
+      Ys[i * SD + j] = v;
+    });
+    __syncthreads();
+    // ---- LayerNorm2
+#pragma unroll
+    for (int q = 0; q < NPASS; ++q) {
+      const int i = q * GPB + grp;
+      const int64_t r = (int64_t)r0 + i;
+      const float* sp = Ys + i * SD + 4 * l;
+      float4 z = make_float4(sp[0], sp[1], sp[2], sp[3]);
+      if (drop && i < m) {  // drop2(t) + y1 (y1 was overwritten in LDS: read it back, L2-hot)
+        const float4 kp = sb_drop_keep4<D>(dr2, seed, r, l);
+        const float4 y = reinterpret_cast<const float4*>(a.y1)[(size_t)r * LPR + l];
+        z.x *= kp.x; z.y *= kp.y; z.z *= kp.z; z.w *= kp.w;     // (the same two roundings as the unfused kernels)
+        z.x += y.x; z.y += y.y; z.z += y.z; z.w += y.w;
+      }
+      const float mu = row_allreduce_sum<LPR>((z.x + z.y) + (z.z + z.w)) / D;
+      const float cx = z.x - mu, cy = z.y - mu, cz = z.z - mu, cw = z.w - mu;
+      const float var = row_allreduce_sum<LPR>(fmaf(cx, cx, fmaf(cy, cy, fmaf(cz, cz, cw * cw)))) / D;
+      const float rs = 1.0f / sqrtf(var + kLnEps);
+      const float4 xh = make_float4(cx * rs, cy * rs, cz * rs, cw * rs);
+      if (i < m) {
+        reinterpret_cast<float4*>(a.xh2)[(size_t)r * LPR + l] = xh;
+        if (l == 0) a.rstd2[r] = rs;
+        reinterpret_cast<float4*>(a.xnext)[(size_t)r * LPR + l] =
+            make_float4(fmaf(xh.x, w2v.x, b2v.x), fmaf(xh.y, w2v.y, b2v.y), fmaf(xh.z, w2v.z, b2v.z), fmaf(xh.w, w2v.w, b2v.w));
+      }
+    }
+  }
+}
+
 // ---- attention per sequence: ctx = softmax(causal(Q K^T / sqrt(dk))) V, head by head ---------------------
 
 struct SbAttnArgs {
@@ -469,7 +597,45 @@ __device__ __forceinline__ void sb_mm_head(MatA A, MatB B, int M, int N, int K, 
   sas_mm_part(A, B, M, N, K, causal, epi, sub, wph);
 }
 
-template <int D, int WPH>
+// Rows of the NEXT sequence travel (global -> registers) while the current one is multiplied: a workgroup holds one
+// sequence in LDS and one or two workgroups fit a CU, so nothing else covers the load latency -- without this every
+// sequence paid a full memory round trip between its two barriers.  Needs the full complement of 64 * 4 * WPH threads
+// (n_heads = 4): PF float4 per thread and buffer cover lp <= 64 rows.
+template <int D, int NBUF, int PF>
+struct SbRowPrefetch {
+  float4 v[NBUF][PF];
+  int n;
+  int64_t r0;
+  __device__ __forceinline__ void fetch(const float* const* src, int n_, int64_t r0_) {
+    n = n_;
+    r0 = r0_;
+#pragma unroll
+    for (int q = 0; q < PF; ++q) {
+      const int idx = threadIdx.x + q * blockDim.x, i = idx / (D / 4), c = idx % (D / 4);
+      if (i < n) {
+#pragma unroll
+        for (int bq = 0; bq < NBUF; ++bq) v[bq][q] = reinterpret_cast<const float4*>(src[bq])[(size_t)(r0 + i) * (D / 4) + c];
+      }
+    }
+  }
+  __device__ __forceinline__ void stage(float* const* dst) const {
+    constexpr int SD = D + 1;
+#pragma unroll
+    for (int q = 0; q < PF; ++q) {
+      const int idx = threadIdx.x + q * blockDim.x, i = idx / (D / 4), c = idx % (D / 4);
+      if (i < n) {
+#pragma unroll
+        for (int bq = 0; bq < NBUF; ++bq) {
+          float* d = dst[bq] + i * SD + 4 * c;
+          d[0] = v[bq][q].x; d[1] = v[bq][q].y; d[2] = v[bq][q].z; d[3] = v[bq][q].w;
+        }
+      }
+    }
+  }
+};
+
+// PF: float4 per thread and buffer of the prefetch (0 = none): ceil(lp * D / 4 / threads), chosen by the length class
+template <int D, int WPH, int PF>
 __global__ __launch_bounds__(256 * WPH) void sb_attn_fwd_wave_kernel(SbAttnArgs a) {
   constexpr int SD = D + 1;
   const int LP = a.lp, SA = LP + 1, BUF = sb_buf_floats(D, LP);
@@ -480,16 +646,44 @@ __global__ __launch_bounds__(256 * WPH) void sb_attn_fwd_wave_kernel(SbAttnArgs 
   const int dk = D / a.n_heads, hc = hh * dk;
   const float sqrt_dk = sqrtf((float)dk);
   const int todo = a.seq_count ? *a.seq_count : a.B;
-  for (int w = blockIdx.x; w < todo; w += gridDim.x) {
+  const bool prefetch = PF > 0;   // (the launcher picks PF > 0 only with 256 * WPH threads and lp * D / 4 <= PF * threads)
+  SbRowPrefetch<D, 3, (PF > 0 ? PF : 1)> pf;
+  const float* const srcs[3] = {a.q, a.k, a.v};
+  float* const dsts[3] = {Q, K, V};
+  auto seq_of = [&](int w, int* n_out) -> int64_t {
     const int b = a.seq_list ? a.seq_list[w] : w;
-    const int n = sb_len(a.lengths, b, a.L);
-    if (n == 0) continue;  // workgroup-uniform
-    const int64_t r0 = a.off[b];
-    __syncthreads();  // the previous sequence's readers are done
-    sb_load_rows_n<D>(Q, a.q, r0, n);
-    sb_load_rows_n<D>(K, a.k, r0, n);
-    sb_load_rows_n<D>(V, a.v, r0, n);
-    __syncthreads();
+    *n_out = sb_len(a.lengths, b, a.L);
+    return a.off[b];
+  };
+  if (prefetch && (int)blockIdx.x < todo) {
+    int n0;
+    const int64_t r = seq_of(blockIdx.x, &n0);
+    pf.fetch(srcs, n0, r);
+  }
+  for (int w = blockIdx.x; w < todo; w += gridDim.x) {
+    int n;
+    int64_t r0;
+    if (prefetch) {
+      n = pf.n;
+      r0 = pf.r0;
+      __syncthreads();  // the previous sequence's readers are done
+      pf.stage(dsts);
+      __syncthreads();
+      if (w + (int)gridDim.x < todo) {  // the next sequence's rows travel during this one's products
+        int nn;
+        const int64_t r = seq_of(w + gridDim.x, &nn);
+        pf.fetch(srcs, nn, r);
+      }
+      if (n == 0) continue;  // workgroup-uniform
+    } else {
+      r0 = seq_of(w, &n);
+      if (n == 0) continue;  // workgroup-uniform
+      __syncthreads();  // the previous sequence's readers are done
+      sb_load_rows_n<D>(Q, a.q, r0, n);
+      sb_load_rows_n<D>(K, a.k, r0, n);
+      sb_load_rows_n<D>(V, a.v, r0, n);
+      __syncthreads();
+    }
     sb_mm_head(MatA{Q + hc, SD, 1}, MatB{K + hc, 1, SD}, n, n, dk, true, [&](int i, int j, float v) { A[i * SA + j] = v / sqrt_dk; },
                sub, WPH);
     if (WPH > 1) __syncthreads();
@@ -501,7 +695,7 @@ __global__ __launch_bounds__(256 * WPH) void sb_attn_fwd_wave_kernel(SbAttnArgs 
   }
 }
 
-template <int D, int WPH>
+template <int D, int WPH, int PF>
 __global__ __launch_bounds__(256 * WPH) void sb_attn_bwd_wave_kernel(SbAttnArgs a) {
   constexpr int SD = D + 1;
   const int LP = a.lp, SA = LP + 1, BUF = sb_buf_floats(D, LP);
@@ -513,17 +707,45 @@ __global__ __launch_bounds__(256 * WPH) void sb_attn_bwd_wave_kernel(SbAttnArgs 
   const int dk = D / a.n_heads, hc = hh * dk;
   const float sqrt_dk = sqrtf((float)dk);
   const int todo = a.seq_count ? *a.seq_count : a.B;
-  for (int w = blockIdx.x; w < todo; w += gridDim.x) {
+  const bool prefetch = PF > 0;
+  SbRowPrefetch<D, 4, (PF > 0 ? PF : 1)> pf;
+  const float* const srcs[4] = {a.q, a.k, a.v, a.dctx};
+  float* const dsts[4] = {Q, K, V, G};
+  auto seq_of = [&](int w, int* n_out) -> int64_t {
     const int b = a.seq_list ? a.seq_list[w] : w;
-    const int n = sb_len(a.lengths, b, a.L);
-    if (n == 0) continue;
-    const int64_t r0 = a.off[b];
-    __syncthreads();
-    sb_load_rows_n<D>(Q, a.q, r0, n);
-    sb_load_rows_n<D>(K, a.k, r0, n);
-    sb_load_rows_n<D>(V, a.v, r0, n);
-    sb_load_rows_n<D>(G, a.dctx, r0, n);
-    __syncthreads();
+    *n_out = sb_len(a.lengths, b, a.L);
+    return a.off[b];
+  };
+  if (prefetch && (int)blockIdx.x < todo) {
+    int n0;
+    const int64_t r = seq_of(blockIdx.x, &n0);
+    pf.fetch(srcs, n0, r);
+  }
+  for (int w = blockIdx.x; w < todo; w += gridDim.x) {
+    int n;
+    int64_t r0;
+    if (prefetch) {
+      n = pf.n;
+      r0 = pf.r0;
+      __syncthreads();
+      pf.stage(dsts);
+      __syncthreads();
+      if (w + (int)gridDim.x < todo) {
+        int nn;
+        const int64_t r = seq_of(w + gridDim.x, &nn);
+        pf.fetch(srcs, nn, r);
+      }
+      if (n == 0) continue;
+    } else {
+      r0 = seq_of(w, &n);
+      if (n == 0) continue;
+      __syncthreads();
+      sb_load_rows_n<D>(Q, a.q, r0, n);
+      sb_load_rows_n<D>(K, a.k, r0, n);
+      sb_load_rows_n<D>(V, a.v, r0, n);
+      sb_load_rows_n<D>(G, a.dctx, r0, n);
+      __syncthreads();
+    }
     sb_mm_head(MatA{Q + hc, SD, 1}, MatB{K + hc, 1, SD}, n, n, dk, true, [&](int i, int j, float v) { A[i * SA + j] = v / sqrt_dk; },
                sub, WPH);
     // dA = dCtx_h . V_h^T (lower triangle)
@@ -663,6 +885,267 @@ __global__ __launch_bounds__(kBlock) void sb_wgrad_kernel(SbWgradArgs a) {
   if ((int)threadIdx.x < D)
 #pragma unroll
     for (int p = 0; p < NP; ++p) (a.gb[p] + (size_t)blockIdx.x * a.part_stride)[threadIdx.x] = bsum[p];
+}
+
+// ---- backward of the post-attention half in ONE row-space kernel -------------------------------------------------------
+// In: G = d(layer output).  Out: G = dZ1 = d(ctx + x) (Gb = mask1 * dZ1 with dropout), and this workgroup's partial sums of
+// d(ln2 w, b), dW2, db2, dW1, db1, d(ln1 w, b).  Round 2: LayerNorm2 backward, weight gradient, dX product (+ ReLU mask),
+// weight gradient, dX product (+ residual), LayerNorm1 backward -- six launches, each streaming [R, D] operands through
+// HBM (15 + 21 + 28 + 21 + 28 + 15 us at config 3).  Here a 64-row tile goes through all six steps in LDS; the weight-
+// gradient accumulators (2 of the 8 32x32 blocks per wave) live in registers across the tiles, as in sb_wgrad_kernel.
+struct SbBlockBwdArgs {
+  float* G;
+  float* Gb;
+  const float *xh2, *rstd2, *h, *y1, *xh1, *rstd1;
+  const float *ln2w, *W2, *W1, *ln1w;
+  float* part;          // this layer's block of the partial-gradient buffer; slice of workgroup w at + w * part_stride
+  size_t part_stride;
+  const int32_t* off;
+  int B;
+  SbDrop dr;            // dr.site = 2 * layer (dropout1); dropout2 = site + 1
+};
+
+template <int D>
+__global__ __launch_bounds__(kBlock) void sb_block_bwd_kernel(SbBlockBwdArgs a) {
+  using Cfg = SasCfg<D>;
+  constexpr int SD = D + 1, LPR = D / 4, GPB = kBlock / LPR, NPASS = kSbTile / GPB, NB = D / 32;
+  constexpr int NQ = 2 * NB * NB, QPW = (NQ + 3) / 4;   // weight-gradient blocks: (which, rb, cb), which 0 = dW2, 1 = dW1
+  extern __shared__ float lds[];
+  float* W1s = lds;                       // [D][SD]
+  float* W2s = W1s + D * SD;              // [D][SD]
+  float* Gs = W2s + D * SD;               // [kSbTile][SD]: mask2 * dZ2, then dY1
+  float* Hs = Gs + kSbTile * SD;          // [kSbTile][SD]: h, then dHpre = (Gs . W2) * (h > 0)
+  float* Ys = Hs + kSbTile * SD;          // [kSbTile][SD]: y1
+  float* Us = Ys + kSbTile * SD;          // [kSbTile][SD]: unmasked dZ2 (dropout only; else == Gs)
+  for (int idx = threadIdx.x; idx < D * D; idx += kBlock) {
+    W1s[(idx / D) * SD + idx % D] = a.W1[idx];
+    W2s[(idx / D) * SD + idx % D] = a.W2[idx];
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l = threadIdx.x % LPR, grp = threadIdx.x / LPR;
+  const int R = a.off[a.B];
+  const int tiles = (R + kSbTile - 1) / kSbTile;
+  const bool drop = a.dr.seed != nullptr;
+  const uint64_t seed = drop ? *a.dr.seed : 0;
+  SbDrop dr1 = a.dr, dr2 = a.dr;
+  dr2.site = a.dr.site + 1u;
+  if (!drop) Us = Gs;
+  const float4 w2v = reinterpret_cast<const float4*>(a.ln2w)[l], w1v = reinterpret_cast<const float4*>(a.ln1w)[l];
+
+  sas_f32x16 acc[QPW];
+#pragma unroll
+  for (int q = 0; q < QPW; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+  float bsum2 = 0.f, bsum1 = 0.f;   // threads < D: db2[t], db1[t]
+  float4 aw2 = make_float4(0.f, 0.f, 0.f, 0.f), ab2 = aw2, aw1 = aw2, ab1 = aw2;
+
+  float4 pg[NPASS], pxh[NPASS], ph[NPASS], py[NPASS];
+  float prs[NPASS];
+  auto fetch = [&](int tile) {
+    const int r0 = tile * kSbTile;
+#pragma unroll
+    for (int q = 0; q < NPASS; ++q) {
+      const int r = r0 + q * GPB + grp;
+      if (r < R) {
+        pg[q] = reinterpret_cast<const float4*>(a.G)[(size_t)r * LPR + l];
+        pxh[q] = reinterpret_cast<const float4*>(a.xh2)[(size_t)r * LPR + l];
+        ph[q] = reinterpret_cast<const float4*>(a.h)[(size_t)r * LPR + l];
+        py[q] = reinterpret_cast<const float4*>(a.y1)[(size_t)r * LPR + l];
+        prs[q] = a.rstd2[r];
+      }
+    }
+  };
+  if ((int)blockIdx.x < tiles) fetch(blockIdx.x);
+  for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const int r0 = tile * kSbTile;
+    const int m = min(kSbTile, R - r0);
+    __syncthreads();  // the previous tile's readers are done (and the weights are in place)
+    // ---- 1. LayerNorm2 backward, one lane-group per row; stage mask2 * dZ2, h, y1 (rows past m: zeros)
+#pragma unroll
+    for (int q = 0; q < NPASS; ++q) {
+      const int i = q * GPB + grp;
+      const int64_t r = (int64_t)r0 + i;
+      const float4 z0 = make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 dz = z0, dzm = z0, hh = z0, yy = z0;
+      const bool on = i < m;
+      float4 g = z0, xh = z0;
+      if (on) {
+        g = pg[q];
+        xh = pxh[q];
+        hh = ph[q];
+        yy = py[q];
+        aw2.x = fmaf(g.x, xh.x, aw2.x); aw2.y = fmaf(g.y, xh.y, aw2.y); aw2.z = fmaf(g.z, xh.z, aw2.z); aw2.w = fmaf(g.w, xh.w, aw2.w);
+        ab2.x += g.x; ab2.y += g.y; ab2.z += g.z; ab2.w += g.w;
+      }
+      const float4 dx = make_float4(g.x * w2v.x, g.y * w2v.y, g.z * w2v.z, g.w * w2v.w);
+      const float m1 = row_allreduce_sum<LPR>((dx.x + dx.y) + (dx.z + dx.w)) / D;
+      const float m2 = row_allreduce_sum<LPR>(fmaf(dx.x, xh.x, fmaf(dx.y, xh.y, fmaf(dx.z, xh.z, dx.w * xh.w)))) / D;
+      if (on) {
+        const float rs = prs[q];
+        dz = make_float4(rs * (dx.x - m1 - xh.x * m2), rs * (dx.y - m1 - xh.y * m2), rs * (dx.z - m1 - xh.z * m2),
+                         rs * (dx.w - m1 - xh.w * m2));
+        dzm = dz;
+        if (drop) {
+          const float4 kp = sb_drop_keep4<D>(dr2, seed, r, l);
+          dzm = make_float4(dz.x * kp.x, dz.y * kp.y, dz.z * kp.z, dz.w * kp.w);
+        }
+      }
+      float* gd = Gs + i * SD + 4 * l;
+      gd[0] = dzm.x; gd[1] = dzm.y; gd[2] = dzm.z; gd[3] = dzm.w;
+      if (drop) {
+        float* ud = Us + i * SD + 4 * l;
+        ud[0] = dz.x; ud[1] = dz.y; ud[2] = dz.z; ud[3] = dz.w;
+      }
+      float* hd = Hs + i * SD + 4 * l;
+      hd[0] = hh.x; hd[1] = hh.y; hd[2] = hh.z; hd[3] = hh.w;
+      float* yd = Ys + i * SD + 4 * l;
+      yd[0] = yy.x; yd[1] = yy.y; yd[2] = yy.z; yd[3] = yy.w;
+    }
+    __syncthreads();
+    // this tile's LayerNorm1 operands and the next tile's rows travel during the products
+    float4 cxh[NPASS];
+    float crs[NPASS];
+#pragma unroll
+    for (int q = 0; q < NPASS; ++q) {
+      const int r = r0 + q * GPB + grp;
+      if (r < R) {
+        cxh[q] = reinterpret_cast<const float4*>(a.xh1)[(size_t)r * LPR + l];
+        crs[q] = a.rstd1[r];
+      }
+    }
+    if (tile + (int)gridDim.x < tiles) fetch(tile + gridDim.x);
+    // ---- 2. dW2 += (mask2 dZ2)^T . h ;  db2 += column sums
+#pragma unroll
+    for (int sq = 0; sq < QPW; ++sq) {
+      const int q = wave + 4 * sq;
+      if (q < NQ && q < NB * NB) {  // wave-uniform
+        const int rb = q % NB, cb = q / NB, kh = lane >> 5;
+        const float* ap = Gs + rb * 32 + (lane & 31) + kh * SD;
+        const float* bp = Hs + cb * 32 + (lane & 31) + kh * SD;
+#pragma unroll
+        for (int k0 = 0; k0 < kSbTile; k0 += 32) {
+          float av[16], bv[16];
+#pragma unroll
+          for (int t = 0; t < 16; ++t) {
+            av[t] = ap[(k0 + 2 * t) * SD];
+            bv[t] = bp[(k0 + 2 * t) * SD];
+          }
+#pragma unroll
+          for (int t = 0; t < 16; ++t) acc[sq] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[t], acc[sq], 0, 0, 0);
+        }
+      }
+    }
+    if ((int)threadIdx.x < D) {
+      float t = 0.f;
+      for (int i = 0; i < m; ++i) t += Gs[i * SD + threadIdx.x];
+      bsum2 += t;
+    }
+    __syncthreads();  // every reader of h is done: step 3 overwrites it
+    // ---- 3. dHpre = (mask2 dZ2 . W2) * (h > 0), in place over h
+    sas_mm(MatA{Gs, SD, 1}, MatB{W2s, SD, 1}, m, D, D, false, [&](int i, int j, float v) {
+      Hs[i * SD + j] = Hs[i * SD + j] > 0.f ? v : 0.f;
+    });
+    __syncthreads();
+    // ---- 4. dW1 += dHpre^T . y1 ;  db1 += column sums
+#pragma unroll
+    for (int sq = 0; sq < QPW; ++sq) {
+      const int q = wave + 4 * sq;
+      if (q < NQ && q >= NB * NB) {
+        const int qq = q - NB * NB, rb = qq % NB, cb = qq / NB, kh = lane >> 5;
+        const float* ap = Hs + rb * 32 + (lane & 31) + kh * SD;
+        const float* bp = Ys + cb * 32 + (lane & 31) + kh * SD;
+#pragma unroll
+        for (int k0 = 0; k0 < kSbTile; k0 += 32) {
+          float av[16], bv[16];
+#pragma unroll
+          for (int t = 0; t < 16; ++t) {
+            av[t] = ap[(k0 + 2 * t) * SD];
+            bv[t] = bp[(k0 + 2 * t) * SD];
+          }
+#pragma unroll
+          for (int t = 0; t < 16; ++t) acc[sq] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[t], acc[sq], 0, 0, 0);
+        }
+      }
+    }
+    if ((int)threadIdx.x < D) {
+      float t = 0.f;
+      for (int i = 0; i < m; ++i) t += Hs[i * SD + threadIdx.x];
+      bsum1 += t;
+    }
+    // ---- 5. dY1 = dHpre . W1 + dZ2 (the residual path), into Gs (step 4 reads Hs / Ys only: no barrier needed before)
+    sas_mm(MatA{Hs, SD, 1}, MatB{W1s, SD, 1}, m, D, D, false, [&](int i, int j, float v) { Gs[i * SD + j] = v + Us[i * SD + j]; });
+    __syncthreads();
+    // ---- 6. LayerNorm1 backward -> dZ1 (global), mask1 * dZ1 for the attention branch
+#pragma unroll
+    for (int q = 0; q < NPASS; ++q) {
+      const int i = q * GPB + grp;
+      const int64_t r = (int64_t)r0 + i;
+      const bool on = i < m;
+      const float* sp = Gs + i * SD + 4 * l;
+      const float4 z0 = make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 g = z0, xh = z0;
+      if (on) {
+        g = make_float4(sp[0], sp[1], sp[2], sp[3]);
+        xh = cxh[q];
+        aw1.x = fmaf(g.x, xh.x, aw1.x); aw1.y = fmaf(g.y, xh.y, aw1.y); aw1.z = fmaf(g.z, xh.z, aw1.z); aw1.w = fmaf(g.w, xh.w, aw1.w);
+        ab1.x += g.x; ab1.y += g.y; ab1.z += g.z; ab1.w += g.w;
+      }
+      const float4 dx = make_float4(g.x * w1v.x, g.y * w1v.y, g.z * w1v.z, g.w * w1v.w);
+      const float m1 = row_allreduce_sum<LPR>((dx.x + dx.y) + (dx.z + dx.w)) / D;
+      const float m2 = row_allreduce_sum<LPR>(fmaf(dx.x, xh.x, fmaf(dx.y, xh.y, fmaf(dx.z, xh.z, dx.w * xh.w)))) / D;
+      if (on) {
+        const float rs = crs[q];
+        const float4 dz = make_float4(rs * (dx.x - m1 - xh.x * m2), rs * (dx.y - m1 - xh.y * m2), rs * (dx.z - m1 - xh.z * m2),
+                                      rs * (dx.w - m1 - xh.w * m2));
+        reinterpret_cast<float4*>(a.G)[(size_t)r * LPR + l] = dz;
+        if (drop) {
+          const float4 kp = sb_drop_keep4<D>(dr1, seed, r, l);
+          reinterpret_cast<float4*>(a.Gb)[(size_t)r * LPR + l] = make_float4(dz.x * kp.x, dz.y * kp.y, dz.z * kp.z, dz.w * kp.w);
+        }
+      }
+    }
+  }
+  // ---- this workgroup's partial sums
+  float* out = a.part + (size_t)blockIdx.x * a.part_stride;
+#pragma unroll
+  for (int sq = 0; sq < QPW; ++sq) {
+    const int q = wave + 4 * sq;
+    if (q < NQ) {
+      const bool second = q >= NB * NB;
+      const int qq = second ? q - NB * NB : q, rb = qq % NB, cb = qq / NB;
+      float* o = out + (second ? Cfg::oW1 : Cfg::oW2);
+      const int k = cb * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int oo = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        o[oo * D + k] = acc[sq][r];
+      }
+    }
+  }
+  if ((int)threadIdx.x < D) {
+    out[Cfg::ob2 + threadIdx.x] = bsum2;
+    out[Cfg::ob1 + threadIdx.x] = bsum1;
+  }
+  // LayerNorm weight / bias partials: lane-group accumulators combined over the groups in a fixed order through LDS
+  __syncthreads();
+  float* red = Gs;  // [4][GPB][SD] floats: 4 * 16 * 65 <= 2 tiles
+  {
+    const float4 v4[4] = {aw2, ab2, aw1, ab1};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float* d = red + (k * GPB + grp) * SD + 4 * l;
+      d[0] = v4[k].x; d[1] = v4[k].y; d[2] = v4[k].z; d[3] = v4[k].w;
+    }
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < 4 * D; k += kBlock) {
+    const int which = k / D, c = k % D;
+    float t = 0.f;
+    for (int g2 = 0; g2 < GPB; ++g2) t += red[(which * GPB + g2) * SD + c];
+    const int o = which == 0 ? Cfg::oln2w : (which == 1 ? Cfg::oln2b : (which == 2 ? Cfg::oln1w : Cfg::oln1b));
+    out[o + c] = t;
+  }
 }
 
 // ---- small row kernels -------------------------------------------------------------------------------
@@ -876,10 +1359,19 @@ static int sb_attention(SbAttnArgs a, int32_t* bucket, bool make_buckets, hipStr
     const int per_cu = (int)((160 * 1024) / lds);
     // two waves per head where the LDS footprint leaves the CU short of waves (the long length class)
     const int wph = per_wave && a.lp > 32 && per_cu <= 2 ? 2 : 1;
-    void (*kern)(SbAttnArgs) =
-        !per_wave ? (BWD ? sb_attn_bwd_kernel<D> : sb_attn_fwd_kernel<D>)
-        : wph == 2 ? (BWD ? sb_attn_bwd_wave_kernel<D, 2> : sb_attn_fwd_wave_kernel<D, 2>)
-                   : (BWD ? sb_attn_bwd_wave_kernel<D, 1> : sb_attn_fwd_wave_kernel<D, 1>);
+    // prefetch of the next sequence's rows: needs the full 64 * 4 * wph threads; PF float4 per thread and buffer
+    const int threads_w = 64 * a.n_heads * wph;
+    int pfn = 0;
+    if (per_wave && a.n_heads == 4 && getenv("RC_SAS_NO_PREFETCH") == nullptr) {
+      pfn = (a.lp * (D / 4) + threads_w - 1) / threads_w;
+      pfn = pfn <= 1 ? 1 : (pfn <= 2 ? 2 : (pfn <= 4 ? 4 : 0));
+    }
+    void (*kern)(SbAttnArgs) = nullptr;
+    if (!per_wave) kern = BWD ? sb_attn_bwd_kernel<D> : sb_attn_fwd_kernel<D>;
+#define RC_SB_PICK(W_, P_) kern = BWD ? sb_attn_bwd_wave_kernel<D, W_, P_> : sb_attn_fwd_wave_kernel<D, W_, P_>
+    else if (wph == 2) { if (pfn == 1) RC_SB_PICK(2, 1); else if (pfn == 2) RC_SB_PICK(2, 2); else if (pfn == 4) RC_SB_PICK(2, 4); else RC_SB_PICK(2, 0); }
+    else { if (pfn == 1) RC_SB_PICK(1, 1); else if (pfn == 2) RC_SB_PICK(1, 2); else if (pfn == 4) RC_SB_PICK(1, 4); else RC_SB_PICK(1, 0); }
+#undef RC_SB_PICK
     RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int grid = 256 * (per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu));
     if (grid > a.B) grid = a.B;
@@ -887,6 +1379,12 @@ static int sb_attention(SbAttnArgs a, int32_t* bucket, bool make_buckets, hipStr
     RC_LAUNCH_CHECK();
   }
   return RC_OK;
+}
+
+// RC_SAS_FUSED_BLOCK=0: the post-attention half as four launches (round 2), for A/B timing and the equivalence test
+static bool sb_fused_block() {
+  const char* v = getenv("RC_SAS_FUSED_BLOCK");
+  return !(v && v[0] == '0');
 }
 
 template <int D>
@@ -918,6 +1416,22 @@ static int sb_forward(const float* item_emb, const float* pos_emb, const SasLaye
     at.n_heads = n_heads;
     RC_TRY((sb_attention<D, false>(at, w.bucket, l == 0, s)));
     dr.site = 2u * (uint32_t)l;      // dropout1 on the attention context (utils/layers.py:110)
+    if (sb_fused_block()) {          // LayerNorm1 -> FFN -> LayerNorm2 in one launch
+      SbBlockArgs bk;
+      bk.ctx = w.t0; bk.x = sv.x; bk.ln1w = p.ln1w; bk.ln1b = p.ln1b; bk.W1 = p.W1; bk.b1 = p.b1; bk.W2 = p.W2; bk.b2 = p.b2;
+      bk.ln2w = p.ln2w; bk.ln2b = p.ln2b; bk.xh1 = sv.xh1; bk.rstd1 = sv.rstd1; bk.y1 = sv.y1; bk.h = sv.h; bk.xh2 = sv.xh2;
+      bk.rstd2 = sv.rstd2; bk.xnext = xnext; bk.off = w.off; bk.B = B; bk.dr = dr;
+      const size_t lds = (size_t)(2 * D + 2 * kSbTile) * (D + 1) * sizeof(float);
+      auto kern = sb_block_fwd_kernel<D>;
+      RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      int64_t tiles = ((int64_t)rmax + kSbTile - 1) / kSbTile;
+      const int per_cu = (int)((160 * 1024) / lds);
+      const int64_t cap = 256 * (int64_t)(per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu));
+      if (tiles > cap) tiles = cap;
+      hipLaunchKernelGGL(kern, dim3((unsigned)(tiles < 1 ? 1 : tiles)), dim3(kBlock), lds, s, bk);
+      RC_LAUNCH_CHECK();
+      continue;
+    }
     hipLaunchKernelGGL((sb_ln_fwd_kernel<D>), dim3(sb_row_grid((int64_t)rmax, LPR)), dim3(kBlock), 0, s, w.t0, sv.x, p.ln1w,
                        p.ln1b, w.off, B, sv.xh1, sv.rstd1, sv.y1, dr);
     RC_LAUNCH_CHECK();
@@ -974,17 +1488,34 @@ static int sb_backward(const SasLayer* layer, int n_layers, int n_heads, const i
     // LayerNorm2
     // (dropout: G = dZ2 feeds the residual path, Gb = mask2 * dZ2 the FFN branch)
     float* Gb = drop ? w.t4 : G;
+    SbWgradArgs g;
+    SbLinArgs a;
+    if (sb_fused_block()) {   // LayerNorm2 backward -> FFN backward (both weight gradients) -> LayerNorm1 backward: one launch
+      SbBlockBwdArgs bb;
+      bb.G = G; bb.Gb = Gb; bb.xh2 = sv.xh2; bb.rstd2 = sv.rstd2; bb.h = sv.h; bb.y1 = sv.y1; bb.xh1 = sv.xh1; bb.rstd1 = sv.rstd1;
+      bb.ln2w = p.ln2w; bb.W2 = p.W2; bb.W1 = p.W1; bb.ln1w = p.ln1w; bb.part = gp; bb.part_stride = stride; bb.off = w.off; bb.B = B;
+      bb.dr = dr;
+      bb.dr.site = 2u * (uint32_t)l;
+      const size_t lds = (size_t)(2 * D + (drop ? 4 : 3) * kSbTile) * (D + 1) * sizeof(float);
+      auto kern = sb_block_bwd_kernel<D>;
+      RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      int64_t tiles = ((int64_t)rmax + kSbTile - 1) / kSbTile;
+      const int per_cu = (int)((160 * 1024) / lds);
+      int64_t cap = 256 * (int64_t)(per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu));
+      if (cap > kSbPartWg) cap = kSbPartWg;   // one partial-gradient slice per workgroup
+      if (tiles > cap) tiles = cap;
+      hipLaunchKernelGGL(kern, dim3((unsigned)(tiles < 1 ? 1 : tiles)), dim3(kBlock), lds, s, bb);
+      RC_LAUNCH_CHECK();
+    } else {
     dr.site = 2u * (uint32_t)l + 1u;
     hipLaunchKernelGGL((sb_ln_bwd_kernel<D>), dim3(ln_grid), dim3(kBlock), 0, s, G, sv.xh2, sv.rstd2, p.ln2w, w.off, B,
                        gp + Cfg::oln2w, gp + Cfg::oln2b, stride, dr, Gb);
     RC_LAUNCH_CHECK();
     // FFN: dW2, db2; dHpre = (dZ2 . W2) * relu'(h); dW1, db1; dY1 = dZ2 + dHpre . W1
-    SbWgradArgs g;
     memset(&g, 0, sizeof(g));
     g.off = w.off; g.B = B; g.part_stride = stride;
     g.dY[0] = Gb; g.X = sv.h; g.gW[0] = gp + Cfg::oW2; g.gb[0] = gp + Cfg::ob2;
     RC_TRY((sb_wgrad<D, 1>(g, (int64_t)rmax, s)));
-    SbLinArgs a;
     memset(&a, 0, sizeof(a));
     a.off = w.off; a.B = B;
     a.X = Gb; a.W[0] = p.W2; a.Y[0] = w.t1; a.mask = sv.h;
@@ -998,6 +1529,9 @@ static int sb_backward(const SasLayer* layer, int n_layers, int n_heads, const i
     hipLaunchKernelGGL((sb_ln_bwd_kernel<D>), dim3(ln_grid), dim3(kBlock), 0, s, G, sv.xh1, sv.rstd1, p.ln1w, w.off, B,
                        gp + Cfg::oln1w, gp + Cfg::oln1b, stride, dr, Gb);
     RC_LAUNCH_CHECK();
+    }
+    memset(&g, 0, sizeof(g));
+    g.off = w.off; g.B = B; g.part_stride = stride;
     // attention
     SbAttnArgs at;
     memset(&at, 0, sizeof(at));
