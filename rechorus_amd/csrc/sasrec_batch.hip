@@ -100,8 +100,13 @@ __global__ __launch_bounds__(kBlock) void sb_linear_kernel(SbLinArgs a) {
   extern __shared__ float lds[];
   float* Ws = lds;                    // [NW][D][SD]
   float* Xs = lds + NW * D * SD;      // [kSbTile][SD]
-  for (int w = 0; w < NW; ++w)
+  // biases live in LDS too: a global load behind the epilogue's global stores waits for those stores (gfx950 counts
+  // loads and stores in one in-order vmcnt) -- 16 serialised load / store round trips per lane and block otherwise
+  float* Bs = Xs + kSbTile * SD;      // [NW][D]
+  for (int w = 0; w < NW; ++w) {
     for (int idx = threadIdx.x; idx < D * D; idx += kBlock) Ws[w * D * SD + (idx / D) * SD + idx % D] = a.W[w][idx];
+    for (int idx = threadIdx.x; idx < D; idx += kBlock) Bs[w * D + idx] = a.bias[w] ? a.bias[w][idx] : 0.f;
+  }
   const int R = a.off[a.B];
   const int tiles = (R + kSbTile - 1) / kSbTile;
   // the next tile's rows are requested while the current tile is multiplied: each thread holds its
@@ -134,11 +139,11 @@ __global__ __launch_bounds__(kBlock) void sb_linear_kernel(SbLinArgs a) {
     for (int w = 0; w < NW; ++w) {
       const float* Wl = Ws + w * D * SD;
       const MatB mb = TRANS ? MatB{Wl, SD, 1} : MatB{Wl, 1, SD};  // dx = dy . W   |   y = x . W^T
-      const float* bias = a.bias[w];
+      const float* bias = Bs + w * D;
       float* Y = a.Y[w];
       sas_mm(MatA{Xs, SD, 1}, mb, m, D, D, false, [&](int i, int j, float v) {
         const size_t e = (size_t)(r0 + i) * D + j;
-        if (bias) v += bias[j];
+        v += bias[j];
         if (a.relu) v = fmaxf(v, 0.f);
         if (a.mask) v = a.mask[e] > 0.f ? v : 0.f;
         if (a.res) v += a.res[e];
@@ -362,9 +367,14 @@ __global__ __launch_bounds__(kBlock) void sb_block_fwd_kernel(SbBlockArgs a) {
   float* W2s = W1s + D * SD;              // [D][SD]
   float* Ys = W2s + D * SD;               // [kSbTile][SD]: y1, then (in place) the FFN output t
   float* Hs = Ys + kSbTile * SD;          // [kSbTile][SD]
+  float* Bs = Hs + kSbTile * SD;          // [2][D]: b1, b2 (a global load behind the epilogues' global stores would wait for them)
   for (int idx = threadIdx.x; idx < D * D; idx += kBlock) {
     W1s[(idx / D) * SD + idx % D] = a.W1[idx];
     W2s[(idx / D) * SD + idx % D] = a.W2[idx];
+  }
+  for (int idx = threadIdx.x; idx < D; idx += kBlock) {
+    Bs[idx] = a.b1[idx];
+    Bs[D + idx] = a.b2[idx];
   }
   const int l = threadIdx.x % LPR, grp = threadIdx.x / LPR;
   const int R = a.off[a.B];
@@ -387,11 +397,21 @@ __global__ __launch_bounds__(kBlock) void sb_block_fwd_kernel(SbBlockArgs a) {
       }
     }
   };
+#ifdef RC_X_TIMING
+  uint64_t tstamp[6] = {0, 0, 0, 0, 0, 0};
+  uint64_t t_prev = wall_clock64();
+  const uint64_t t_begin = t_prev;
+  int n_my_tiles = 0;
+#define RC_STAMP(k) do { const uint64_t t_now = wall_clock64(); tstamp[k] += t_now - t_prev; t_prev = t_now; } while (0)
+#else
+#define RC_STAMP(k)
+#endif
   if ((int)blockIdx.x < tiles) fetch(blockIdx.x);
   for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
     const int r0 = tile * kSbTile;
     const int m = min(kSbTile, R - r0);
     __syncthreads();  // the previous tile's readers of Ys / Hs are done (and the weights are in place)
+    RC_STAMP(0);
     // ---- LayerNorm1 on the staged rows: one lane-group per row
 #pragma unroll
     for (int q = 0; q < NPASS; ++q) {
@@ -421,21 +441,24 @@ __global__ __launch_bounds__(kBlock) void sb_block_fwd_kernel(SbBlockArgs a) {
       }
     }
     __syncthreads();
+    RC_STAMP(1);
     if (tile + (int)gridDim.x < tiles) fetch(tile + gridDim.x);   // travels during the two products
     // ---- h = relu(y1 W1^T + b1)
     sas_mm(MatA{Ys, SD, 1}, MatB{W1s, 1, SD}, m, D, D, false, [&](int i, int j, float v) {
-      v = fmaxf(v + a.b1[j], 0.f);
+      v = fmaxf(v + Bs[j], 0.f);
       Hs[i * SD + j] = v;
       a.h[(size_t)(r0 + i) * D + j] = v;
     });
     __syncthreads();
+    RC_STAMP(2);
     // ---- t = h W2^T + b2 (+ y1: without dropout the residual is added right here), in place over y1
     sas_mm(MatA{Hs, SD, 1}, MatB{W2s, 1, SD}, m, D, D, false, [&](int i, int j, float v) {
-      v += a.b2[j];
+      v += Bs[D + j];
       if (!drop) v += Ys[i * SD + j];
       Ys[i * SD + j] = v;
     });
     __syncthreads();
+    RC_STAMP(3);
     // ---- LayerNorm2
 #pragma unroll
     for (int q = 0; q < NPASS; ++q) {
@@ -461,7 +484,18 @@ __global__ __launch_bounds__(kBlock) void sb_block_fwd_kernel(SbBlockArgs a) {
             make_float4(fmaf(xh.x, w2v.x, b2v.x), fmaf(xh.y, w2v.y, b2v.y), fmaf(xh.z, w2v.z, b2v.z), fmaf(xh.w, w2v.w, b2v.w));
       }
     }
+    RC_STAMP(4);
+#ifdef RC_X_TIMING
+    ++n_my_tiles;
+#endif
   }
+#ifdef RC_X_TIMING
+  if ((blockIdx.x == 0 || blockIdx.x == 300) && threadIdx.x == 0)
+    printf("sb_block_fwd wg %d: %d tiles, ticks (100 MHz): wait0 %llu ln1 %llu gemm1 %llu gemm2 %llu ln2 %llu total %llu\n", (int)blockIdx.x,
+           n_my_tiles, (unsigned long long)tstamp[0], (unsigned long long)tstamp[1], (unsigned long long)tstamp[2],
+           (unsigned long long)tstamp[3], (unsigned long long)tstamp[4], (unsigned long long)(wall_clock64() - t_begin));
+#endif
+#undef RC_STAMP
 }
 
 // ---- attention per sequence: ctx = softmax(causal(Q K^T / sqrt(dk))) V, head by head ---------------------
@@ -1310,7 +1344,7 @@ static int sb_row_grid(int64_t rows, int lpr) {
 
 template <int D, int NW, bool TRANS>
 static int sb_linear(const SbLinArgs& a, int64_t rmax, hipStream_t s) {
-  const size_t lds = (size_t)(NW * D + kSbTile) * (D + 1) * sizeof(float);
+  const size_t lds = ((size_t)(NW * D + kSbTile) * (D + 1) + (size_t)NW * D) * sizeof(float);
   auto kern = sb_linear_kernel<D, NW, TRANS>;
   RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int64_t tiles = (rmax + kSbTile - 1) / kSbTile;
@@ -1421,7 +1455,7 @@ static int sb_forward(const float* item_emb, const float* pos_emb, const SasLaye
       bk.ctx = w.t0; bk.x = sv.x; bk.ln1w = p.ln1w; bk.ln1b = p.ln1b; bk.W1 = p.W1; bk.b1 = p.b1; bk.W2 = p.W2; bk.b2 = p.b2;
       bk.ln2w = p.ln2w; bk.ln2b = p.ln2b; bk.xh1 = sv.xh1; bk.rstd1 = sv.rstd1; bk.y1 = sv.y1; bk.h = sv.h; bk.xh2 = sv.xh2;
       bk.rstd2 = sv.rstd2; bk.xnext = xnext; bk.off = w.off; bk.B = B; bk.dr = dr;
-      const size_t lds = (size_t)(2 * D + 2 * kSbTile) * (D + 1) * sizeof(float);
+      const size_t lds = ((size_t)(2 * D + 2 * kSbTile) * (D + 1) + 2 * (size_t)D) * sizeof(float);
       auto kern = sb_block_fwd_kernel<D>;
       RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       int64_t tiles = ((int64_t)rmax + kSbTile - 1) / kSbTile;
