@@ -156,7 +156,9 @@ __global__ __launch_bounds__(kBlock) void neumf_kernel(NeumfArgs a) {
   };
   // (forward only: in the backward kernel the prefetch competes with the per-occurrence gradient stores of the
   // current tile and measured slower wherever it is placed -- 0.70 ms right after staging, 0.69 ms under the dW1 GEMM,
-  // against 0.54 ms with the rows requested together at the top of their tile)
+  // against 0.54 ms with the rows requested together at the top of their tile; round 3: also 0.71 ms with the next
+  // tile's rows requested at the TOP of the tile, before any of its stores, into a second register set -- 512
+  // registers, 8-14 spilled)
   if (!BWD && (int64_t)blockIdx.x < n_tiles) fetch(blockIdx.x);
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int64_t n0 = tile * M;

@@ -210,6 +210,21 @@ __global__ __launch_bounds__(kBlock) void sb_linear3_sum_kernel(SbSum3Args a) {
     if (wave < NQ) {  // wave-uniform
       const float* ap = Xs + (rb * 32 + (lane & 31)) * SD + kh;                 // a(i, k) = X[i][k]
       const float* bp = Ws + w * D * SD + kh * SD + cb * 32 + (lane & 31);      // b(k, j) = W[k][j]
+      // the residual values of this block are requested BEFORE the last product (and all of them before the first
+      // store): res may alias Y, so a load behind a store of the epilogue would wait for that store -- 16 serialised
+      // round trips per lane and tile in round 2's `Y[e] = acc + res[e]` loop
+      float rv[16];
+      if (w == 2) {
+        const int tile = blockIdx.x + (step / 3) * gridDim.x;
+        const int r0 = tile * kSbTile;
+        const int m = min(kSbTile, R - r0);
+        const int j = cb * 32 + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int i = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+          rv[r] = i < m ? a.res[(size_t)(r0 + i) * D + j] : 0.f;
+        }
+      }
 #pragma unroll
       for (int k0 = 0; k0 < D; k0 += 32) {
         float av[16], bv[16];
@@ -231,7 +246,7 @@ __global__ __launch_bounds__(kBlock) void sb_linear3_sum_kernel(SbSum3Args a) {
           const int i = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
           if (i < m) {
             const size_t e = (size_t)(r0 + i) * D + j;
-            a.Y[e] = acc[r] + a.res[e];
+            a.Y[e] = acc[r] + rv[r];
           }
         }
       }
