@@ -99,6 +99,12 @@ __device__ __forceinline__ void sas_mm_wave(MatA A, MatB B, int M, int N, int K,
   sas_mm_part(A, B, M, N, K, causal, epi, 0, 1);
 }
 
+// x / sqrt(dk): for dk in {1, 4, 16, 64} the divisor is a power of two and the product with its reciprocal is the same
+// float, bit for bit -- one multiply instead of the ~10-instruction IEEE division sequence per score
+__device__ __forceinline__ float sas_div_scale(float v, float s) {
+  return (s == 4.f || s == 2.f || s == 8.f || s == 1.f) ? v * (1.0f / s) : v / s;
+}
+
 // ---- row-wise phases of the attention: one lane per (row, part), all rows of a wave at once ---------------------
 // The calling wave owns rows [row_base, row_base + rows_here) (rows_here a power of two <= 64); the 64 / rows_here
 // lanes of a row take the columns j = part, part + parts, ... and combine through xor-shuffles.  (One row per
@@ -130,9 +136,10 @@ __device__ __forceinline__ void sas_softmax_causal_rows(float* A, int n, int SA,
       z += e;
     }
   z = sas_parts_sum(z, rows_here);
+  const float rz = 1.0f / z;   // one division per row; the probabilities are e * (1 / z) (within 1 ulp of e / z)
   if (on)
 #pragma unroll 4
-    for (int j = p; j < n; j += parts) A[i * SA + j] = j <= i ? A[i * SA + j] / z : 0.f;
+    for (int j = p; j < n; j += parts) A[i * SA + j] = j <= i ? A[i * SA + j] * rz : 0.f;
 }
 // softmax backward in place: T[i][j] <- A[i][j] * (T[i][j] - sum_j' A[i][j'] T[i][j']) / sqrt_dk for j <= i, else 0
 __device__ __forceinline__ void sas_softmax_bwd_rows(float* T, const float* A, int n, int SA, float sqrt_dk, int row_base,
@@ -147,7 +154,7 @@ __device__ __forceinline__ void sas_softmax_bwd_rows(float* T, const float* A, i
   dot = sas_parts_sum(dot, rows_here);
   if (on)
 #pragma unroll 4
-    for (int j = p; j < n; j += parts) T[i * SA + j] = j <= i ? A[i * SA + j] * (T[i * SA + j] - dot) / sqrt_dk : 0.f;
+    for (int j = p; j < n; j += parts) T[i * SA + j] = j <= i ? sas_div_scale(A[i * SA + j] * (T[i * SA + j] - dot), sqrt_dk) : 0.f;
 }
 
 // attention probabilities of head hh into A[i][j] (0 for j > i), rows [0, n)
@@ -156,7 +163,7 @@ __device__ __forceinline__ void sas_attn_probs(float* A, const float* Q, const f
                                                int dk, float sqrt_dk, int SA) {
   constexpr int SD = SasCfg<D>::SD;
   sas_mm(MatA{Q + hh * dk, SD, 1}, MatB{K + hh * dk, 1, SD}, n, n, dk, true,
-         [&](int i, int j, float v) { A[i * SA + j] = v / sqrt_dk; });
+         [&](int i, int j, float v) { A[i * SA + j] = sas_div_scale(v, sqrt_dk); });
   __syncthreads();
   const int rows_here = SA - 1 <= 32 ? 8 : 16;  // rows per wave: 4 waves cover 32 rows, or up to 64
   sas_softmax_causal_rows(A, n, SA, (int)(threadIdx.x >> 6) * rows_here, rows_here);
@@ -170,7 +177,7 @@ __device__ __forceinline__ void sas_attn_probs_wave(float* A, const float* Q, co
                                                     float sqrt_dk, int SA) {
   constexpr int SD = SasCfg<D>::SD;
   sas_mm_wave(MatA{Q + hh * dk, SD, 1}, MatB{K + hh * dk, 1, SD}, n, n, dk, true,
-              [&](int i, int j, float v) { A[i * SA + j] = v / sqrt_dk; });
+              [&](int i, int j, float v) { A[i * SA + j] = sas_div_scale(v, sqrt_dk); });
   sas_softmax_causal_rows(A, n, SA, 0, 32);  // two lanes per row
   if (n > 32) sas_softmax_causal_rows(A, n, SA, 32, 32);
 }

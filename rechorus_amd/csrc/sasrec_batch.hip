@@ -733,7 +733,7 @@ __global__ __launch_bounds__(256 * WPH) void sb_attn_fwd_wave_kernel(SbAttnArgs 
       sb_load_rows_n<D>(V, a.v, r0, n);
       __syncthreads();
     }
-    sb_mm_head(MatA{Q + hc, SD, 1}, MatB{K + hc, 1, SD}, n, n, dk, true, [&](int i, int j, float v) { A[i * SA + j] = v / sqrt_dk; },
+    sb_mm_head(MatA{Q + hc, SD, 1}, MatB{K + hc, 1, SD}, n, n, dk, true, [&](int i, int j, float v) { A[i * SA + j] = sas_div_scale(v, sqrt_dk); },
                sub, WPH);
     if (WPH > 1) __syncthreads();
     if (32 * sub < n) sas_softmax_causal_rows(A, n, SA, 32 * sub, 32);  // two lanes per row
@@ -765,6 +765,14 @@ __global__ __launch_bounds__(256 * WPH) void sb_attn_bwd_wave_kernel(SbAttnArgs 
     *n_out = sb_len(a.lengths, b, a.L);
     return a.off[b];
   };
+#ifdef RC_X_TIMING
+  uint64_t ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  uint64_t tp = wall_clock64();
+  int n_seq = 0, n_rows = 0;
+#define RC_ST(k) do { const uint64_t tn = wall_clock64(); ts[k] += tn - tp; tp = tn; } while (0)
+#else
+#define RC_ST(k)
+#endif
   if (prefetch && (int)blockIdx.x < todo) {
     int n0;
     const int64_t r = seq_of(blockIdx.x, &n0);
@@ -777,14 +785,19 @@ __global__ __launch_bounds__(256 * WPH) void sb_attn_bwd_wave_kernel(SbAttnArgs 
       n = pf.n;
       r0 = pf.r0;
       __syncthreads();
+      RC_ST(0);
       pf.stage(dsts);
       __syncthreads();
+      RC_ST(1);
       if (w + (int)gridDim.x < todo) {
         int nn;
         const int64_t r = seq_of(w + gridDim.x, &nn);
         pf.fetch(srcs, nn, r);
       }
       if (n == 0) continue;
+#ifdef RC_X_TIMING
+      ++n_seq; n_rows += n;
+#endif
     } else {
       r0 = seq_of(w, &n);
       if (n == 0) continue;
@@ -795,27 +808,39 @@ __global__ __launch_bounds__(256 * WPH) void sb_attn_bwd_wave_kernel(SbAttnArgs 
       sb_load_rows_n<D>(G, a.dctx, r0, n);
       __syncthreads();
     }
-    sb_mm_head(MatA{Q + hc, SD, 1}, MatB{K + hc, 1, SD}, n, n, dk, true, [&](int i, int j, float v) { A[i * SA + j] = v / sqrt_dk; },
+    sb_mm_head(MatA{Q + hc, SD, 1}, MatB{K + hc, 1, SD}, n, n, dk, true, [&](int i, int j, float v) { A[i * SA + j] = sas_div_scale(v, sqrt_dk); },
                sub, WPH);
     // dA = dCtx_h . V_h^T (lower triangle)
     sb_mm_head(MatA{G + hc, SD, 1}, MatB{V + hc, 1, SD}, n, n, dk, true, [&](int i, int j, float v) { T[i * SA + j] = v; }, sub, WPH);
     if (WPH > 1) __syncthreads();
+    RC_ST(2);
     if (32 * sub < n) sas_softmax_causal_rows(A, n, SA, 32 * sub, 32);
     if (WPH == 1 && n > 32) sas_softmax_causal_rows(A, n, SA, 32, 32);
     if (WPH > 1) __syncthreads();
+    RC_ST(3);
     // dV_h = A^T . dCtx_h
     sb_mm_head(MatA{A, 1, SA}, MatB{G + hc, SD, 1}, n, dk, n, false,
                [&](int j, int c, float v) { a.dv[(size_t)(r0 + j) * D + hc + c] = v; }, sub, WPH);
+    RC_ST(4);
     // (no barrier: dV reads A and G only, dS below rewrites T and reads A)
     if (32 * sub < n) sas_softmax_bwd_rows(T, A, n, SA, sqrt_dk, 32 * sub, 32);  // dS in place in T
     if (WPH == 1 && n > 32) sas_softmax_bwd_rows(T, A, n, SA, sqrt_dk, 32, 32);
     if (WPH > 1) __syncthreads();
+    RC_ST(5);
     // dQ_h = dS . K_h,  dK_h = dS^T . Q_h
     sb_mm_head(MatA{T, SA, 1}, MatB{K + hc, SD, 1}, n, dk, n, false,
                [&](int i, int c, float v) { a.dq[(size_t)(r0 + i) * D + hc + c] = v; }, sub, WPH);
     sb_mm_head(MatA{T, 1, SA}, MatB{Q + hc, SD, 1}, n, dk, n, false,
                [&](int j, int c, float v) { a.dk[(size_t)(r0 + j) * D + hc + c] = v; }, sub, WPH);
+    RC_ST(6);
   }
+#ifdef RC_X_TIMING
+  if ((blockIdx.x == 0 || blockIdx.x == 100) && threadIdx.x == 0)
+    printf("attn_bwd<WPH %d PF %d> lp %d wg %d: %d seqs %d rows; ticks(100MHz): wait %llu stage %llu QK+dA %llu softmax %llu dV %llu dS %llu dQ+dK %llu\n",
+           WPH, PF, a.lp, (int)blockIdx.x, n_seq, n_rows, (unsigned long long)ts[0], (unsigned long long)ts[1], (unsigned long long)ts[2],
+           (unsigned long long)ts[3], (unsigned long long)ts[4], (unsigned long long)ts[5], (unsigned long long)ts[6]);
+#endif
+#undef RC_ST
 }
 
 // ---- weight gradients: dW[o][k] = sum_r dY[r][o] X[r][k], db[o] = sum_r dY[r][o] --------------------------
