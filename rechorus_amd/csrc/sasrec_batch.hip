@@ -527,6 +527,10 @@ struct SbAttnArgs {
   const int32_t* seq_count;
 };
 
+}  // namespace rc
+#include "sas_attn_reg.hpp"   // register-resident attention (needs SbAttnArgs, sb_len)
+namespace rc {
+
 __host__ __device__ inline int sb_buf_floats(int D, int lp) { return lp * ((D + 1) > (lp + 1) ? (D + 1) : (lp + 1)); }
 
 template <int D>
@@ -1410,8 +1414,29 @@ static SasBuckets sb_buckets(int L) {
   return bk;
 }
 
+// RC_SAS_REG_ATTN=0: the LDS-tile attention kernels (rounds 1-3) for every shape, for A/B timing and the equivalence test
+static bool sb_reg_attention() {
+  const char* v = getenv("RC_SAS_REG_ATTN");
+  return !(v && v[0] == '0');
+}
+
 template <int D, bool BWD>
 static int sb_attention(SbAttnArgs a, int32_t* bucket, bool make_buckets, hipStream_t s) {
+  if (sb_reg_attention() && sas_reg_attn_fits(D, a.n_heads, a.L)) {   // every (sequence, head) by one wave, operands in registers
+    const int dk = D / a.n_heads;
+    void (*kern)(SbAttnArgs) = nullptr;
+    if (dk == 16) kern = sb_attn_reg_kernel<D, 16, BWD>;
+    else if (dk == 32) kern = sb_attn_reg_kernel<D, 32, BWD>;
+    else if constexpr (D >= 64) kern = sb_attn_reg_kernel<D, 64, BWD>;
+    if (kern != nullptr) {
+      a.seq_list = nullptr;
+      a.seq_count = nullptr;
+      const int64_t items = (int64_t)a.B * a.n_heads;
+      hipLaunchKernelGGL(kern, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s, a);
+      RC_LAUNCH_CHECK();
+      return RC_OK;
+    }
+  }
   const SasBuckets bk = sb_buckets(a.L);
   int32_t* count = bucket + 4 * (size_t)a.B;
   if (make_buckets) {

@@ -192,6 +192,50 @@ def test_sasrec_batch_kernels_edge_shapes_vs_sequence_kernels(cuda, eng):
         assert np.all(out["batch"][0][lengths == 0] == 0) and np.all(out["batch"][1][lengths == 0] == 0)
 
 
+@pytest.mark.parametrize("d,n_layers,n_heads,L,B,fits", [
+    (64, 2, 4, 64, 260, True), (64, 1, 4, 50, 300, True), (64, 1, 2, 32, 90, True), (64, 1, 1, 16, 90, True),
+    (32, 2, 2, 50, 130, True), (32, 1, 1, 20, 70, True), (64, 1, 4, 9, 5, True),
+    (64, 1, 2, 50, 130, False), (32, 1, 4, 20, 70, False)])
+def test_sasrec_register_attention_equals_lds_attention(d, n_layers, n_heads, L, B, fits, cuda, eng, monkeypatch):
+    """the register-resident attention (one wave per (sequence, head), 16 x 16 x 4 MFMA tiles, sas_attn_reg.hpp) against the LDS-tile
+    kernels of rounds 1-3 (RC_SAS_REG_ATTN=0) on every tile count 1..4, lengths on both sides of each 16-row boundary, empty
+    histories; shapes outside its envelope (d_k = 8, or too many operand tiles) must take the LDS kernels either way"""
+    rng = np.random.default_rng(1000 * d + 10 * L + n_heads)
+    n_items = 300
+    P = _random_sasrec(rng, n_items, d, n_layers, L)
+    lengths = rng.integers(0, L + 1, size=B).astype(np.int64)
+    marks = [x for x in (L, 0, 1, 15, 16, 17, 31, 32, 33, 47, 48, 49, 63, 64) if x <= L][:B]
+    lengths[:len(marks)] = marks
+    hist = rng.integers(1, n_items, size=(B, L)).astype(np.int64) * (np.arange(L)[None, :] < lengths[:, None])
+    Pd = to_dev(P, n_layers, cuda)
+    h_d, l_d = torch.from_numpy(hist).to(cuda), torch.from_numpy(lengths).to(cuda)
+    dhv = torch.from_numpy(rng.normal(size=(B, d)).astype(np.float32)).to(cuda)
+    out = {}
+    for mode in ("1", "0", "1"):
+        monkeypatch.setenv("RC_SAS_REG_ATTN", mode)
+        hv, saved = eng.sasrec_fwd(Pd["item_emb"], Pd["pos_emb"], Pd["layers"], n_heads, h_d, l_d, save=True, impl="batch")
+        g_hist, dg = eng.sasrec_bwd(Pd["layers"], n_heads, l_d, saved, dhv)
+        torch.cuda.synchronize()
+        res = (hv.cpu().numpy(), g_hist.cpu().numpy(), [{k: v.cpu().numpy() for k, v in g.items()} for g in dg])
+        if mode in out:   # bit-reproducible
+            assert np.array_equal(res[0], out[mode][0]) and np.array_equal(res[1], out[mode][1])
+            assert all(np.array_equal(res[2][l][k], out[mode][2][l][k]) for l in range(n_layers) for k in LAYER_NAMES)
+        out[mode] = res
+    what = f"d={d} layers={n_layers} heads={n_heads} L={L} B={B}"
+    if not fits:
+        assert np.array_equal(out["1"][0], out["0"][0]) and np.array_equal(out["1"][1], out["0"][1]), what
+        return
+    assert not np.array_equal(out["1"][1], out["0"][1]), what + ": the switch had no effect"
+    assert_close(out["1"][0], out["0"][0], what=what + " hv", rtol=2e-5, atol_scale=2e-5)
+    assert_close(out["1"][1], out["0"][1], what=what + " g_hist", rtol=5e-5, atol_scale=5e-5)
+    floor = 1e-6 * max(float(np.abs(v).max()) for g in out["0"][2] for v in g.values())
+    for l in range(n_layers):
+        for k in LAYER_NAMES:
+            assert_close(out["1"][2][l][k], out["0"][2][l][k], what=f"{what} layer {l} d{k}", rtol=5e-5, atol_scale=1e-4,
+                         abs_floor=floor)
+    assert np.all(out["1"][0][lengths == 0] == 0) and np.all(out["1"][1][lengths == 0] == 0)
+
+
 def test_sasrec_pos_grad_chunks(cuda, eng):
     """more than 1024 sequences: several chunks per position + the chunk reduction; vs the generic sort + segmented sum"""
     rng = np.random.default_rng(4)
