@@ -292,6 +292,19 @@ int rc_segmented_update2(float* W, float* m, float* v, int d, const uint32_t* ke
                          float* dense_grad, const uint32_t* heads, const uint32_t* n_heads, int flags,
                          void* ws, size_t ws_bytes, rc_stream_t stream);
 
+/* rc_segmented_update2 for a table of n_rows rows that collect MANY occurrences each -- a small catalogue under a
+ * large batch, the reference's own datasets (8.7 K items against 0.5 M candidate + history occurrences of one SASRec
+ * step, models/sequential/SASRec.py:51-86 with helpers/BaseRunner.py:193-206): one pass over the sorted keys (plain
+ * rc_sort_ids, keys < n_rows) records each row's [start, end), then ONE wave per table row sums its occurrences
+ * (fixed order, no float atomics) and applies `h` / writes dense_grad; rows with more than 192 occurrences take the
+ * 256-occurrence chunks of rc_segmented_update.  Gradient sources and outputs as there; d in {16, 32, 64, 128, 256},
+ * buffers 16-byte aligned.  Worth it from about eight occurrences per table row.                               */
+size_t rc_segmented_rows_workspace_bytes(int64_t n_rows, int64_t n_occ, int d);
+int rc_segmented_update_rows(float* W, float* m, float* v, int d, int64_t n_rows, const uint32_t* keys,
+                             const uint32_t* perm, int64_t n_occ, const float* coef, const float* src,
+                             const int64_t* src_index, int div, const float* src2, int64_t n_split,
+                             const rc_opt_hyper* h, float* dense_grad, void* ws, size_t ws_bytes, rc_stream_t stream);
+
 /* ---- SASRec encoder (models/sequential/SASRec.py:51-86, utils/layers.py:9-63,92-118) ------- */
 
 /* Two tables that share their ids (NeuMF's mf / mlp embedding of a user or an item, models/general/NeuMF.py:37-40)

@@ -485,6 +485,92 @@ __global__ __launch_bounds__(kBlock) void long_final_kernel(SegArgs a) {
   }
 }
 
+// ---- 4. tables whose rows collect many occurrences each ----------------------------------------
+// A small catalogue under a large batch (the reference's own datasets: 8.7 K items against 0.5 M candidate + history
+// occurrences per SASRec step) makes EVERY row a hot row: the head list + chunk planning above then costs four
+// latency-bound launches and one device-scope atomic per row.  With the number of table rows known, one pass over
+// the sorted keys records each row's [start, end) and ONE wave per table row sums its occurrences: the wave's
+// lane-groups take positions start + g, start + g + G, ... (four trips in flight each), the group sums are
+// combined in a fixed xor tree.  Rows past kRowsWaveMax occurrences are handed to the chunked path.
+constexpr int kRowsWaveMax = 192;
+
+__global__ __launch_bounds__(kBlock) void segment_bounds_kernel(const uint32_t* __restrict__ keys, int64_t n, uint32_t key_base,
+                                                                uint32_t n_rows, uint32_t* __restrict__ start,
+                                                                uint32_t* __restrict__ end) {
+  const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (j >= n) return;
+  const uint32_t k = keys[j];
+  const uint32_t r = k - key_base;
+  if (r >= n_rows) return;   // (keys outside the table: not this call's rows)
+  if (j == 0 || keys[j - 1] != k) start[r] = (uint32_t)j;
+  if (j + 1 == n || keys[j + 1] != k) end[r] = (uint32_t)(j + 1);
+}
+
+template <int D, int MODE>
+__global__ __launch_bounds__(kBlock) void seg_rows_kernel(SegArgs a, const uint32_t* __restrict__ start,
+                                                          const uint32_t* __restrict__ end, uint32_t n_rows) {
+  constexpr int LPR = D / 4;
+  constexpr int G = 64 / LPR;   // lane-groups per wave
+  const int lane = threadIdx.x & 63, l = lane % LPR, g = lane / LPR;
+  const uint32_t r = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (r >= n_rows) return;      // wave-uniform from here on
+  const int64_t j0 = start[r], j1 = end[r];
+  if (j1 <= j0) return;
+  if (j1 - j0 > kRowsWaveMax) {
+    if (lane == 0) {
+      const uint32_t slot = atomicAdd(&a.counters[CNT_LONG], 1u);
+      if (slot < a.long_cap) a.long_list[slot] = (uint32_t)j0;
+    }
+    return;
+  }
+  const uint32_t key = r + a.key_base;
+  const float4 w = load_row4<D, MODE>(a, key, l);
+  float4 acc = make_float4(0, 0, 0, 0);
+  for (int64_t jj = j0 + g; jj < j1; jj += 4 * G) {
+    const float4 z = make_float4(0, 0, 0, 0);
+    const float4 s0 = occ_grad4<D>(a, jj, l);
+    const float4 s1 = (jj + G < j1) ? occ_grad4<D>(a, jj + G, l) : z;
+    const float4 s2 = (jj + 2 * G < j1) ? occ_grad4<D>(a, jj + 2 * G, l) : z;
+    const float4 s3 = (jj + 3 * G < j1) ? occ_grad4<D>(a, jj + 3 * G, l) : z;
+    add4(acc, s0); add4(acc, s1); add4(acc, s2); add4(acc, s3);
+  }
+#pragma unroll
+  for (int off = LPR; off < 64; off <<= 1) {   // both partners form the same sum: every group ends with the row's total
+    acc.x += __shfl_xor(acc.x, off, 64);
+    acc.y += __shfl_xor(acc.y, off, 64);
+    acc.z += __shfl_xor(acc.z, off, 64);
+    acc.w += __shfl_xor(acc.w, off, 64);
+  }
+  if (g == 0) apply_row4<D, MODE>(a, key, l, w, acc);
+}
+
+template <int D, int MODE>
+static int launch_seg_rows(const SegArgs& a, const uint32_t* start, const uint32_t* end, uint32_t n_rows, hipStream_t s) {
+  const unsigned blocks = (n_rows + (kBlock / 64) - 1) / (kBlock / 64);
+  hipLaunchKernelGGL((seg_rows_kernel<D, MODE>), dim3(blocks), dim3(kBlock), 0, s, a, start, end, n_rows);
+  RC_LAUNCH_CHECK();
+  if (a.n_occ > kRowsWaveMax) {   // otherwise no row was handed over
+    hipLaunchKernelGGL(long_plan_kernel, dim3(64), dim3(kBlock), 0, s, a);
+    RC_LAUNCH_CHECK();
+    hipLaunchKernelGGL((long_chunk_kernel<D, MODE>), dim3(1024), dim3(kBlock), 0, s, a);
+    RC_LAUNCH_CHECK();
+    hipLaunchKernelGGL((long_final_kernel<D, MODE>), dim3(256), dim3(kBlock), 0, s, a);
+    RC_LAUNCH_CHECK();
+  }
+  return RC_OK;
+}
+
+template <int MODE>
+static int launch_seg_rows_mode(const SegArgs& a, const uint32_t* start, const uint32_t* end, uint32_t n_rows, hipStream_t s) {
+  switch (a.d) {
+    case 16: return launch_seg_rows<16, MODE>(a, start, end, n_rows, s);
+    case 32: return launch_seg_rows<32, MODE>(a, start, end, n_rows, s);
+    case 64: return launch_seg_rows<64, MODE>(a, start, end, n_rows, s);
+    case 128: return launch_seg_rows<128, MODE>(a, start, end, n_rows, s);
+    default: return launch_seg_rows<256, MODE>(a, start, end, n_rows, s);
+  }
+}
+
 // ---- any d (<= 512): one wave per sorted position, lanes stride over the row ----------
 constexpr int kGenChunks = 8;
 
@@ -775,6 +861,64 @@ extern "C" int rc_segmented_update2(float* W, float* m, float* v, int d, const u
     case MODE_SGD: return launch_seg_mode<MODE_SGD>(a, vec_ok, s);
     case MODE_ADAM: return launch_seg_mode<MODE_ADAM>(a, vec_ok, s);
     default: return launch_seg_mode<MODE_ADAGRAD>(a, vec_ok, s);
+  }
+}
+
+extern "C" size_t rc_segmented_rows_workspace_bytes(int64_t n_rows, int64_t n_occ, int d) {
+  if (n_rows < 1) n_rows = 1;
+  return rc_segmented_workspace_bytes(n_occ, d) + align_up(2 * (size_t)n_rows * sizeof(uint32_t), 256) + 256;
+}
+
+// rc_segmented_update2 for a table of n_rows rows that collect many occurrences each (section 4 above); keys / perm
+// from a plain rc_sort_ids.  Same gradient sources and outputs; d in {16, 32, 64, 128, 256}, 16-byte aligned buffers.
+extern "C" int rc_segmented_update_rows(float* W, float* m, float* v, int d, int64_t n_rows, const uint32_t* keys,
+                                        const uint32_t* perm, int64_t n_occ, const float* coef, const float* src,
+                                        const int64_t* src_index, int div, const float* src2, int64_t n_split,
+                                        const rc_opt_hyper* h, float* dense_grad, void* ws, size_t ws_bytes,
+                                        rc_stream_t stream) {
+  if (n_occ == 0) return RC_OK;
+  RC_REQUIRE(n_split >= 0 && n_split <= n_occ, "rc_segmented_update_rows: n_split out of range");
+  RC_REQUIRE(keys && perm && src && ws, "rc_segmented_update_rows: null pointer");
+  RC_REQUIRE(div >= 1 && n_occ > 0 && n_occ < ((int64_t)1 << 31) && n_rows >= 1 && n_rows < ((int64_t)1 << 31),
+             "rc_segmented_update_rows: bad shape div=%d n_occ=%lld n_rows=%lld", div, (long long)n_occ, (long long)n_rows);
+  RC_REQUIRE(dense_grad != nullptr || W != nullptr, "rc_segmented_update_rows: no output (W or dense_grad)");
+  if (!vector_kernel_for(d)) return fail(RC_ERR_UNSUPPORTED, "rc_segmented_update_rows: d=%d (16/32/64/128/256)", d);
+  auto al = [](const void* p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; };
+  RC_REQUIRE(al(src) && al(src2) && al(W) && al(m) && al(v) && al(dense_grad), "rc_segmented_update_rows: buffers must be 16-byte aligned");
+  if (ws_bytes < rc_segmented_rows_workspace_bytes(n_rows, n_occ, d))
+    return fail(RC_ERR_WORKSPACE, "rc_segmented_update_rows: workspace %zu < %zu", ws_bytes,
+                rc_segmented_rows_workspace_bytes(n_rows, n_occ, d));
+  const SegWs w = carve_seg_ws(ws, n_occ, d);
+  uint32_t* start = reinterpret_cast<uint32_t*>(static_cast<char*>(ws) + align_up(w.total, 256));
+  uint32_t* end = start + n_rows;
+  hipStream_t s = as_stream(stream);
+  SegArgs a;
+  memset(&a, 0, sizeof(a));
+  a.W = W; a.M = m; a.V = v;
+  a.keys = keys; a.perm = perm; a.n_occ = n_occ;
+  a.coef = coef; a.src = src; a.src_index = src_index; a.div = div; a.d = d;
+  a.src2 = src2; a.n_split = (uint32_t)n_split;
+  a.dense_grad = dense_grad;
+  a.counters = w.counters; a.long_list = w.long_list; a.rows = w.rows; a.chunks = w.chunks;
+  a.partial = w.partial;
+  a.long_cap = w.long_cap; a.chunk_cap = w.chunk_cap; a.partial_cap = w.partial_cap;
+  int mode = MODE_DENSE_GRAD;
+  if (!dense_grad) {
+    RC_TRY(fill_opt_scalars(h, &a.o));
+    mode = mode_of(h);
+    RC_REQUIRE(mode != MODE_ADAM || (m && v), "rc_segmented_update_rows: Adam needs m and v");
+    RC_REQUIRE(mode != MODE_ADAGRAD || m, "rc_segmented_update_rows: Adagrad needs m (state_sum)");
+  }
+  RC_HIP(hipMemsetAsync(w.counters, 0, CNT_N * sizeof(uint32_t), s));
+  RC_HIP(hipMemsetAsync(start, 0, 2 * (size_t)n_rows * sizeof(uint32_t), s));   // absent rows: start = end = 0
+  hipLaunchKernelGGL(segment_bounds_kernel, dim3((unsigned)((n_occ + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, keys, n_occ, 0u,
+                     (uint32_t)n_rows, start, end);
+  RC_LAUNCH_CHECK();
+  switch (mode) {
+    case MODE_DENSE_GRAD: return launch_seg_rows_mode<MODE_DENSE_GRAD>(a, start, end, (uint32_t)n_rows, s);
+    case MODE_SGD: return launch_seg_rows_mode<MODE_SGD>(a, start, end, (uint32_t)n_rows, s);
+    case MODE_ADAM: return launch_seg_rows_mode<MODE_ADAM>(a, start, end, (uint32_t)n_rows, s);
+    default: return launch_seg_rows_mode<MODE_ADAGRAD>(a, start, end, (uint32_t)n_rows, s);
   }
 }
 

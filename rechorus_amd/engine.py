@@ -393,6 +393,9 @@ _EDB_PLAN_MIN = int(os.environ.get("RC_EDB_PLAN_MIN", "8192"))
 # occurrences over 8.7 K rows are all hot rows, where the sort-driven update measured faster (table_update 0.27 ms against
 # 0.44 ms through the narrow-bucket plan, profiles/r03d_bench_sasrec*.json)
 _USE_PLAN = os.environ.get("RC_TABLE_UPDATE", "auto") != "sort"
+# sorted ids of a table whose rows collect many occurrences each: rc_segmented_update_rows (RC_SEG_ROWS=0: the head-list route)
+_SEG_ROWS = os.environ.get("RC_SEG_ROWS", "1") != "0"
+_SEG_ROWS_MIN_PER_ROW = int(os.environ.get("RC_SEG_ROWS_MIN_PER_ROW", "8"))
 _SASREC_PLAN = os.environ.get("RC_TABLE_UPDATE", "auto") == "plan"
 
 
@@ -903,8 +906,19 @@ def segmented_update2(keys, perm, src, src2, n_split, hyper=None, W=None, m=None
     """rc_segmented_update2: occurrences >= n_split take plain rows src2[o - n_split]"""
     n_occ = keys.numel()
     d = src.shape[-1]
-    ws = workspace(_lib.load().rc_segmented_workspace_bytes(n_occ, d), keys.device, "seg")
     f32 = torch.float32
+    table = W if W is not None else dense_grad
+    n_rows = table.shape[0]
+    if _SEG_ROWS and d in (16, 32, 64, 128, 256) and n_occ >= _SEG_ROWS_MIN_PER_ROW * n_rows:
+        # every row collects many occurrences (a small catalogue under a large batch): one wave per table row
+        ws = workspace(_lib.load().rc_segmented_rows_workspace_bytes(n_rows, n_occ, d), keys.device, "seg_rows")
+        _lib.call("rc_segmented_update_rows", _ptr(W, f32, "W", True), _ptr(m, f32, "m", True), _ptr(v, f32, "v", True), d,
+                  n_rows, _ptr(keys, torch.int32, "keys"), _ptr(perm, torch.int32, "perm"), n_occ,
+                  _ptr(coef, f32, "coef", True), _ptr(src, f32, "src"), _ptr(src_index, torch.int64, "src_index", True),
+                  int(div), _ptr(src2, f32, "src2"), int(n_split), C.byref(hyper) if hyper is not None else None,
+                  _ptr(dense_grad, f32, "dense_grad", True), C.c_void_p(ws.data_ptr()), ws.numel(), _stream())
+        return
+    ws = workspace(_lib.load().rc_segmented_workspace_bytes(n_occ, d), keys.device, "seg")
     _lib.call("rc_segmented_update2", _ptr(W, f32, "W", True), _ptr(m, f32, "m", True), _ptr(v, f32, "v", True), d,
               _ptr(keys, torch.int32, "keys"), _ptr(perm, torch.int32, "perm"), n_occ,
               _ptr(coef, f32, "coef", True), _ptr(src, f32, "src"), _ptr(src_index, torch.int64, "src_index", True),

@@ -236,6 +236,57 @@ def test_sasrec_register_attention_equals_lds_attention(d, n_layers, n_heads, L,
     assert np.all(out["1"][0][lengths == 0] == 0) and np.all(out["1"][1][lengths == 0] == 0)
 
 
+@pytest.mark.parametrize("d,n_rows,n_a,C,n_b,opt", [(64, 300, 4000, 5, 9000, None), (64, 97, 2000, 4, 1500, "Adam"),
+                                                      (16, 50, 600, 3, 700, "SGD"), (128, 40, 900, 2, 0, "Adagrad"),
+                                                      (32, 1000, 3000, 6, 5000, None)])
+def test_segmented_update_rows_equals_head_list_route(d, n_rows, n_a, C, n_b, opt, cuda, eng, monkeypatch):
+    """rc_segmented_update_rows (one wave per table row, every row collecting many occurrences) against a float64 sum
+    and against rc_segmented_update2's head list: coef * src[o / C] occurrences followed by plain src2 rows, rows that
+    never occur, a row past the 192-occurrence hand-over to the chunked path, dense-gradient and optimizer outputs"""
+    rng = np.random.default_rng(d + n_rows)
+    ids_a = rng.integers(0, n_rows, size=(n_a, C)).astype(np.int64)
+    ids_a[ids_a == 3] = 4                       # row 3 never occurs
+    ids_b = rng.integers(0, n_rows, size=n_b).astype(np.int64)
+    ids_b[ids_b == 3] = 5
+    ids_b[: n_b // 3] = 7                       # a hot row (chunked path)
+    coef = rng.normal(size=(n_a, C)).astype(np.float32)
+    src = rng.normal(size=(n_a, d)).astype(np.float32)
+    src2 = rng.normal(size=(max(n_b, 1), d)).astype(np.float32)
+    ids = np.concatenate([ids_a.reshape(-1), ids_b])
+    want = np.zeros((n_rows, d), np.float64)
+    np.add.at(want, ids_a.reshape(-1), (coef.reshape(-1, 1).astype(np.float64) * np.repeat(src, C, axis=0)))
+    if n_b:
+        np.add.at(want, ids_b, src2[:n_b].astype(np.float64))
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
+    keys, perm = eng.sort_ids(t(ids), n_rows)
+    W0 = rng.normal(size=(n_rows, d)).astype(np.float32)
+    out = {}
+    for mode in ("1", "0", "1"):
+        monkeypatch.setattr(eng, "_SEG_ROWS", mode == "1")
+        if opt is None:
+            G = torch.zeros((n_rows, d), device=cuda)
+            eng.segmented_update2(keys, perm, t(src), t(src2), n_a * C, coef=t(coef).reshape(-1), div=C, dense_grad=G)
+            res = (G.cpu().numpy(),)
+        else:
+            W, m, v = t(W0), torch.zeros((n_rows, d), device=cuda), torch.zeros((n_rows, d), device=cuda)
+            h = eng.make_hyper(opt, lr=0.01, l2=1e-4, step=3)
+            eng.segmented_update2(keys, perm, t(src), t(src2), n_a * C, hyper=h, W=W, m=m if opt != "SGD" else None,
+                                  v=v if opt == "Adam" else None, coef=t(coef).reshape(-1), div=C)
+            res = (W.cpu().numpy(), m.cpu().numpy(), v.cpu().numpy())
+        if mode in out:
+            assert all(np.array_equal(a, b) for a, b in zip(res, out[mode])), "not reproducible"
+        out[mode] = res
+    if opt is None:
+        scale = np.abs(want).max()
+        assert np.abs(out["1"][0] - want).max() <= 2e-6 * scale * np.sqrt(len(ids) / n_rows)
+        assert np.all(out["1"][0][3] == 0)
+    else:
+        assert np.array_equal(out["1"][0][3], W0[3])    # a row without occurrences does not move (row-wise update)
+        assert not np.array_equal(out["1"][0][7], W0[7])
+    for a, b in zip(out["1"], out["0"]):
+        assert_close(a, b, what=f"rows route vs head list (d={d}, opt={opt})", rtol=2e-5, atol_scale=2e-5)
+
+
 def test_sasrec_pos_grad_chunks(cuda, eng):
     """more than 1024 sequences: several chunks per position + the chunk reduction; vs the generic sort + segmented sum"""
     rng = np.random.default_rng(4)
