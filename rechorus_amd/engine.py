@@ -395,6 +395,9 @@ _EDB_PLAN_MIN = int(os.environ.get("RC_EDB_PLAN_MIN", "8192"))
 _USE_PLAN = os.environ.get("RC_TABLE_UPDATE", "auto") != "sort"
 # sorted ids of a table whose rows collect many occurrences each: rc_segmented_update_rows (RC_SEG_ROWS=0: the head-list route)
 _SEG_ROWS = os.environ.get("RC_SEG_ROWS", "1") != "0"
+# SasrecTrainer: id sort beside the encoder, position gradient beside the item update, on a second stream (RC_SAS_OVERLAP=0: one stream)
+_SAS_OVERLAP = os.environ.get("RC_SAS_OVERLAP", "1") != "0"
+_SAS_OVERLAP_MIN = int(os.environ.get("RC_SAS_OVERLAP_MIN", "131072"))   # candidate + history occurrences of the batch
 _SEG_ROWS_MIN_PER_ROW = int(os.environ.get("RC_SEG_ROWS_MIN_PER_ROW", "8"))
 _SASREC_PLAN = os.environ.get("RC_TABLE_UPDATE", "auto") == "plan"
 
@@ -939,6 +942,7 @@ class SasrecTrainer:
         self.step_count = 0
         self.loss = None
         self.state = {}
+        self._side = None
 
     def _st(self, t):
         st = self.state.get(t.data_ptr())
@@ -951,6 +955,13 @@ class SasrecTrainer:
             self.state[t.data_ptr()] = st
         return st
 
+    def _side_stream(self, dev):
+        """the trainer's second stream: the id sort (needs only the batch) runs beside the encoder, the position-table
+        gradient beside the item-table update -- all of them latency-bound launches that leave most of the chip idle"""
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=dev)
+        return self._side
+
     def step(self, hist, lengths, iid):
         P = self.P
         I, Pe, layers = P["item_emb"], P["pos_emb"], P["layers"]
@@ -962,6 +973,18 @@ class SasrecTrainer:
         h0 = make_hyper(self.opt, lr=self.lr, l2=0.0, step=self.step_count)
         if self.seed is not None:
             step_increment(self.seed)
+        n_occ = B * Cn + hist.numel()
+        use_plan = _SASREC_PLAN and n_occ >= _EDB_PLAN_MIN and plan_supported(n_occ, 0, I.shape[0], 0)
+        # (small batches are bound by the host's launch rate: the extra stream switches cost more than the overlap returns --
+        #  B = 256: 0.39 against 0.30 ms; B = 4096: 0.66 against 0.72 ms)
+        overlap = _SAS_OVERLAP and hist.is_cuda and not use_plan and n_occ >= _SAS_OVERLAP_MIN
+        sorted_ids = sort_done = main = side = None
+        if overlap:
+            main, side = torch.cuda.current_stream(hist.device), self._side_stream(hist.device)
+            side.wait_stream(main)   # the batch is ready; last step's readers of the side stream's buffers are done
+            with torch.cuda.stream(side):
+                sorted_ids = sort_ids(torch.cat([iid.reshape(-1), hist.reshape(-1)]), I.shape[0])
+                sort_done = side.record_event()
         with _PhaseTimer(self, "encoder_fwd"):
             hv, xsave = sasrec_fwd(I, Pe, layers, self.n_heads, hist, lengths, save=True, drop_p=self.dropout, seed=self.seed)
         with _PhaseTimer(self, "score_loss"):
@@ -972,11 +995,15 @@ class SasrecTrainer:
         with _PhaseTimer(self, "encoder_bwd"):
             g_hist, dgrads = sasrec_bwd(layers, self.n_heads, lengths, xsave, dhv, drop_p=self.dropout, seed=self.seed)
         # item table: candidate occurrences (g * hv, rebuilt on the fly) + history occurrences (g_hist rows)
+        Gp = None
+        if overlap:
+            side.wait_stream(main)   # g_hist is ready
+            with torch.cuda.stream(side):
+                Gp = sasrec_pos_grad(g_hist, lengths, Pe.shape[0])
         _upd = _PhaseTimer(self, "table_update")
         _upd.__enter__()
         st = self._st(I)
-        n_occ = B * Cn + hist.numel()
-        if _SASREC_PLAN and n_occ >= _EDB_PLAN_MIN and plan_supported(n_occ, 0, I.shape[0], 0):
+        if use_plan:
             # bucket plan of candidate + history ids.  The padding slots of the history windows (id 0, zero gradient rows:
             # half of B * history_max occurrences of ONE row) are marked "takes no part" (negative id) except the first of
             # them, which keeps row 0 among the touched rows exactly as before -- a sum of zero rows is zero either way.
@@ -993,8 +1020,11 @@ class SasrecTrainer:
                 G = plan.row_sums("a", torch.zeros_like(I), **src)
                 dense_update(I, G, h, st.get("m"), st.get("v"))
         else:
-            ids = torch.cat([iid.reshape(-1), hist.reshape(-1)])
-            keys, perm = sort_ids(ids, I.shape[0])
+            if overlap:
+                main.wait_event(sort_done)
+                keys, perm = sorted_ids
+            else:
+                keys, perm = sort_ids(torch.cat([iid.reshape(-1), hist.reshape(-1)]), I.shape[0])
             if self.rowwise:
                 segmented_update2(keys, perm, hv, g_hist.view(-1, d), B * Cn, hyper=h, W=I, m=st.get("m"), v=st.get("v"),
                                   coef=gpred.reshape(-1), div=Cn)
@@ -1006,7 +1036,10 @@ class SasrecTrainer:
         # position table (tiny): dense gradient, dense step
         _dns = _PhaseTimer(self, "dense_update")
         _dns.__enter__()
-        Gp = sasrec_pos_grad(g_hist, lengths, Pe.shape[0])
+        if overlap:
+            main.wait_stream(side)
+        else:
+            Gp = sasrec_pos_grad(g_hist, lengths, Pe.shape[0])
         st = self._st(Pe)
         items = [(Pe, Gp, h, st.get("m"), st.get("v"))]
         for lay, g in zip(layers, dgrads):

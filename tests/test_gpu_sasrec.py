@@ -287,6 +287,36 @@ def test_segmented_update_rows_equals_head_list_route(d, n_rows, n_a, C, n_b, op
         assert_close(a, b, what=f"rows route vs head list (d={d}, opt={opt})", rtol=2e-5, atol_scale=2e-5)
 
 
+@pytest.mark.parametrize("rowwise", [False, True])
+def test_sasrec_trainer_two_streams_equal_one_stream(rowwise, cuda, eng, monkeypatch):
+    """SasrecTrainer sorts the batch's ids beside the encoder and forms the position-table gradient beside the item-table
+    update on a second stream; the kernels and their inputs are the same, so three steps leave every parameter bit-identical
+    to the one-stream order (RC_SAS_OVERLAP=0)"""
+    rng = np.random.default_rng(5)
+    B, L, d, n_layers, n_heads, C, n_items = 600, 50, 64, 2, 4, 20, 400
+    P = _random_sasrec(rng, n_items, d, n_layers, L)
+    batches = []
+    for _ in range(3):
+        lengths = rng.integers(1, L + 1, size=B).astype(np.int64)
+        hist = rng.integers(1, n_items, size=(B, L)).astype(np.int64) * (np.arange(L)[None, :] < lengths[:, None])
+        iid = rng.integers(1, n_items, size=(B, C)).astype(np.int64)
+        batches.append(tuple(torch.from_numpy(x).to(cuda) for x in (hist, lengths, iid)))
+    out = {}
+    for mode in (True, False):
+        monkeypatch.setattr(eng, "_SAS_OVERLAP", mode)
+        monkeypatch.setattr(eng, "_SAS_OVERLAP_MIN", 0)
+        Pd = to_dev(P, n_layers, cuda)
+        tr = eng.SasrecTrainer(Pd, n_heads, opt="Adam", lr=1e-3, l2=1e-5, rowwise=rowwise)
+        losses = [float(tr.step(*b)[0]) for b in batches]
+        torch.cuda.synchronize()
+        assert (tr._side is not None) == mode
+        out[mode] = (losses, Pd["item_emb"].cpu().numpy(), Pd["pos_emb"].cpu().numpy(),
+                     [{k: v.cpu().numpy() for k, v in lay.items()} for lay in Pd["layers"]])
+    assert out[True][0] == out[False][0]
+    assert np.array_equal(out[True][1], out[False][1]) and np.array_equal(out[True][2], out[False][2])
+    assert all(np.array_equal(out[True][3][l][k], out[False][3][l][k]) for l in range(n_layers) for k in LAYER_NAMES)
+
+
 def test_sasrec_pos_grad_chunks(cuda, eng):
     """more than 1024 sequences: several chunks per position + the chunk reduction; vs the generic sort + segmented sum"""
     rng = np.random.default_rng(4)
