@@ -21,16 +21,6 @@
 
 namespace rc {
 
-typedef float sas_f32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ sas_f32x4 sas_mfma16(float a, float b, sas_f32x4 c) {
-  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-}
-__device__ __forceinline__ sas_f32x4 sas_zero4() {
-  sas_f32x4 z = {0.f, 0.f, 0.f, 0.f};
-  return z;
-}
-
 template <int D, int NT, int NC>
 struct SasRegRows {
   float v[NT][NC][4];

@@ -9,6 +9,18 @@ namespace rc {
 
 typedef float sas_f32x16 __attribute__((ext_vector_type(16)));
 
+// v_mfma_f32_16x16x4_f32: lane l supplies A[i = l & 15][k = l >> 4] and B[k = l >> 4][j = l & 15], receives C[4 (l >> 4) + r][l & 15]
+typedef float sas_f32x4 __attribute__((ext_vector_type(4)));
+#if defined(__HIPCC__)
+__device__ __forceinline__ sas_f32x4 sas_mfma16(float a, float b, sas_f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ sas_f32x4 sas_zero4() {
+  sas_f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  return z;
+}
+#endif
+
 constexpr int kSasLP = 64;        // max rows (history length) per sequence
 constexpr int kSasMaxLayers = 4;
 constexpr float kLnEps = 1e-5f;   // nn.LayerNorm default

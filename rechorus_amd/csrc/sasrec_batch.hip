@@ -254,6 +254,165 @@ __global__ __launch_bounds__(kBlock) void sb_linear3_sum_kernel(SbSum3Args a) {
   }
 }
 
+// ---- the two projection kernels on 16 x 16 x 4 tiles, operands straight from global memory ----------------------
+// Y^T = W X^T: a lane (i, g) = (lane & 15, lane >> 4) holds its row's columns 16 c + 4 g .. + 3 as ONE float4 per chunk --
+// the B operand of every MFMA of the tile -- and receives Y[row i][16 n + 4 g .. + 3] as the accumulator: one float4
+// store.  The weights wait in LDS in a layout whose ds_read_b128 is the A operand of four MFMAs (row stride D + 4: the
+// sixteen lanes of a group hit sixteen different 4-bank groups).  No row tile in LDS, no barrier after the weights are
+// staged: a wave streams its 16-row tiles on its own, the other waves of its SIMD cover its loads.  Workgroups of up
+// to 16 waves stage the weights once per CU.  (The 32 x 32 x 2 kernels above staged every 64-row tile through LDS with
+// scalar ds_write / ds_read and two barriers: 51 us for the QKV projection of 104 K rows whose MFMA floor is 16 us.)
+constexpr int kSb16MaxWaves = 16;
+
+template <int D>
+__device__ __forceinline__ void sb16_load_rows(const float* __restrict__ X, int row, int R, int g, float (&x)[D / 16][4]) {
+#pragma unroll
+  for (int c = 0; c < D / 16; ++c) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < R) v = *reinterpret_cast<const float4*>(X + (size_t)row * D + 16 * c + 4 * g);
+    x[c][0] = v.x; x[c][1] = v.y; x[c][2] = v.z; x[c][3] = v.w;
+  }
+}
+
+// acc[n] += W[16 n + i][.] . x over the D input columns, for the output tiles n = N0, N0 + 1 (two independent chains)
+template <int D, int N0>
+__device__ __forceinline__ void sb16_product_pair(const float* Wl, int i, int g, const float (&x)[D / 16][4], sas_f32x4& a0,
+                                                  sas_f32x4& a1) {
+  constexpr int S = D + 4;
+#pragma unroll
+  for (int c = 0; c < D / 16; ++c) {
+    const float4 w0 = *reinterpret_cast<const float4*>(Wl + (16 * N0 + i) * S + 16 * c + 4 * g);
+    const float4 w1 = *reinterpret_cast<const float4*>(Wl + (16 * (N0 + 1) + i) * S + 16 * c + 4 * g);
+    a0 = sas_mfma16(w0.x, x[c][0], a0); a1 = sas_mfma16(w1.x, x[c][0], a1);
+    a0 = sas_mfma16(w0.y, x[c][1], a0); a1 = sas_mfma16(w1.y, x[c][1], a1);
+    a0 = sas_mfma16(w0.z, x[c][2], a0); a1 = sas_mfma16(w1.z, x[c][2], a1);
+    a0 = sas_mfma16(w0.w, x[c][3], a0); a1 = sas_mfma16(w1.w, x[c][3], a1);
+  }
+}
+
+// Y_w = X W_w^T + b_w for the three projections of one pass over X
+template <int D>
+__global__ __launch_bounds__(64 * kSb16MaxWaves) void sb_qkv16_kernel(SbLinArgs a) {
+  constexpr int S = D + 4;
+  extern __shared__ float lds[];
+  float* Ws = lds;               // [3][D][S]
+  float* Bs = lds + 3 * D * S;   // [3][D]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
+  const int nw = blockDim.x >> 6;
+  const int R = a.off[a.B];
+  const int tiles = (R + 15) >> 4;
+  const int stride = (int)gridDim.x * nw;
+  int t = (int)blockIdx.x * nw + wave;
+  float x[D / 16][4], xn[D / 16][4];
+  if (t < tiles) sb16_load_rows<D>(a.X, 16 * t + i, R, g, x);   // the first tile's rows travel while the weights are staged
+  for (int idx = threadIdx.x; idx < 3 * D * (D / 4); idx += blockDim.x) {
+    const int w = idx / (D * (D / 4)), rem = idx % (D * (D / 4)), o = rem / (D / 4), c4 = rem % (D / 4);
+    *reinterpret_cast<float4*>(Ws + (w * D + o) * S + 4 * c4) = reinterpret_cast<const float4*>(a.W[w])[o * (D / 4) + c4];
+  }
+  for (int idx = threadIdx.x; idx < 3 * D; idx += blockDim.x) Bs[idx] = a.bias[idx / D] ? a.bias[idx / D][idx % D] : 0.f;
+  __syncthreads();
+  for (; t < tiles; t += stride) {
+    asm volatile("" ::: "memory");   // the weights are re-read from LDS per tile: hoisted out of this loop they are 192 registers (spills)
+    const int row = 16 * t + i;
+    if (t + stride < tiles) sb16_load_rows<D>(a.X, 16 * (t + stride) + i, R, g, xn);   // requested before this tile's stores
+#pragma unroll
+    for (int w = 0; w < 3; ++w) {
+      const float* Wl = Ws + w * D * S;
+      float* Y = a.Y[w];
+#pragma unroll
+      for (int n = 0; n < D / 16; n += 2) {
+        sas_f32x4 a0 = sas_zero4(), a1 = sas_zero4();
+        if (n == 0) sb16_product_pair<D, 0>(Wl, i, g, x, a0, a1);
+        else if (n == 2) sb16_product_pair<D, (D >= 64 ? 2 : 0)>(Wl, i, g, x, a0, a1);
+        const float4 b0 = *reinterpret_cast<const float4*>(Bs + w * D + 16 * n + 4 * g);
+        const float4 b1 = *reinterpret_cast<const float4*>(Bs + w * D + 16 * (n + 1) + 4 * g);
+        if (row < R) {
+          *reinterpret_cast<float4*>(Y + (size_t)row * D + 16 * n + 4 * g) = make_float4(a0[0] + b0.x, a0[1] + b0.y, a0[2] + b0.z, a0[3] + b0.w);
+          *reinterpret_cast<float4*>(Y + (size_t)row * D + 16 * (n + 1) + 4 * g) = make_float4(a1[0] + b1.x, a1[1] + b1.y, a1[2] + b1.z, a1[3] + b1.w);
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < D / 16; ++c)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) x[c][e] = xn[c][e];
+  }
+}
+
+// Y = res + X_0 W_0 + X_1 W_1 + X_2 W_2 (dx = dy . W): the same tiles with the weights transposed while they are staged
+template <int D>
+__global__ __launch_bounds__(64 * kSb16MaxWaves) void sb_sum3_16_kernel(SbSum3Args a) {
+  constexpr int S = D + 4;
+  extern __shared__ float lds[];
+  float* Ws = lds;               // [3][D (in)][S (out)]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
+  const int nw = blockDim.x >> 6;
+  const int R = a.off[a.B];
+  const int tiles = (R + 15) >> 4;
+  const int stride = (int)gridDim.x * nw;
+  int t = (int)blockIdx.x * nw + wave;
+  float x0[D / 16][4], x1[D / 16][4], x2[D / 16][4], rs[D / 16][4];
+  auto fetch = [&](int tile) {
+    const int row = 16 * tile + i;
+    sb16_load_rows<D>(a.X[0], row, R, g, x0);
+    sb16_load_rows<D>(a.X[1], row, R, g, x1);
+    sb16_load_rows<D>(a.X[2], row, R, g, x2);
+    sb16_load_rows<D>(a.res, row, R, g, rs);   // (res may be Y: a lane reads exactly the float4s it writes, all before its first store)
+  };
+  if (t < tiles) fetch(t);   // the first tile's rows travel while the weights are staged
+  for (int idx = threadIdx.x; idx < 3 * D * D; idx += blockDim.x) {
+    const int w = idx / (D * D), rem = idx % (D * D), o = rem / D, in = rem % D;
+    Ws[(w * D + in) * S + o] = a.W[w][rem];
+  }
+  __syncthreads();
+  bool first = true;
+  for (; t < tiles; t += stride) {
+    asm volatile("" ::: "memory");   // (as above)
+    const int row = 16 * t + i;
+    if (!first) fetch(t);
+    first = false;
+#pragma unroll
+    for (int n = 0; n < D / 16; n += 2) {
+      sas_f32x4 a0 = sas_zero4(), a1 = sas_zero4();
+      if (n == 0) {
+        sb16_product_pair<D, 0>(Ws, i, g, x0, a0, a1);
+        sb16_product_pair<D, 0>(Ws + D * S, i, g, x1, a0, a1);
+        sb16_product_pair<D, 0>(Ws + 2 * D * S, i, g, x2, a0, a1);
+      } else if (n == 2) {
+        sb16_product_pair<D, (D >= 64 ? 2 : 0)>(Ws, i, g, x0, a0, a1);
+        sb16_product_pair<D, (D >= 64 ? 2 : 0)>(Ws + D * S, i, g, x1, a0, a1);
+        sb16_product_pair<D, (D >= 64 ? 2 : 0)>(Ws + 2 * D * S, i, g, x2, a0, a1);
+      }
+      if (row < R) {
+        *reinterpret_cast<float4*>(a.Y + (size_t)row * D + 16 * n + 4 * g) =
+            make_float4(a0[0] + rs[n][0], a0[1] + rs[n][1], a0[2] + rs[n][2], a0[3] + rs[n][3]);
+        *reinterpret_cast<float4*>(a.Y + (size_t)row * D + 16 * (n + 1) + 4 * g) =
+            make_float4(a1[0] + rs[n + 1][0], a1[1] + rs[n + 1][1], a1[2] + rs[n + 1][2], a1[3] + rs[n + 1][3]);
+      }
+    }
+  }
+}
+
+// RC_SAS_ROWS16=0: the 32 x 32 x 2 projection kernels with LDS row tiles (rounds 1-3), for A/B timing and the equivalence test
+static bool sb_rows16() {
+  const char* v = getenv("RC_SAS_ROWS16");
+  return !(v && v[0] == '0');
+}
+// launch geometry of the 16-row-tile kernels: 16 waves per workgroup, one workgroup per CU once there are tiles for all of them
+static void sb_rows16_geometry(int64_t rmax, int* grid, int* block) {
+  const int64_t tiles = (rmax + 15) / 16;
+  int nw = tiles >= 256 * kSb16MaxWaves ? kSb16MaxWaves : 4;
+  if (const char* v = getenv("RC_SB16_WAVES")) {   // experiment switch: 4 / 8 / 16 waves per workgroup
+    const int q = atoi(v);
+    if (q == 4 || q == 8 || q == 16) nw = q;
+  }
+  int64_t gr = (tiles + nw - 1) / nw;
+  const int64_t cap = 256 * (int64_t)(kSb16MaxWaves / nw < 3 ? kSb16MaxWaves / nw : 3);
+  if (gr > cap) gr = cap;
+  *grid = (int)(gr < 1 ? 1 : gr);
+  *block = 64 * nw;
+}
+
 // ---- LayerNorm over rows: z = A (+ Bv) -> xhat, rstd, y = w * xhat + b ----------------------------------
 
 // Training-mode dropout of the two residual branches of a TransformerLayer (utils/layers.py:104,110 dropout1 on the
@@ -1508,7 +1667,17 @@ static int sb_forward(const float* item_emb, const float* pos_emb, const SasLaye
     a.off = w.off; a.B = B;
     a.X = sv.x; a.W[0] = p.Wq; a.W[1] = p.Wk; a.W[2] = p.Wv; a.bias[0] = p.bq; a.bias[1] = p.bk; a.bias[2] = p.bv;
     a.Y[0] = sv.q; a.Y[1] = sv.k; a.Y[2] = sv.v;
-    RC_TRY((sb_linear<D, 3, false>(a, (int64_t)rmax, s)));
+    if (sb_rows16()) {
+      const size_t lds = (size_t)(3 * D * (D + 4) + 3 * D) * sizeof(float);
+      auto kern = sb_qkv16_kernel<D>;
+      RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      int grid, block;
+      sb_rows16_geometry((int64_t)rmax, &grid, &block);
+      hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3((unsigned)block), lds, s, a);
+      RC_LAUNCH_CHECK();
+    } else {
+      RC_TRY((sb_linear<D, 3, false>(a, (int64_t)rmax, s)));
+    }
     SbAttnArgs at;
     memset(&at, 0, sizeof(at));
     at.q = sv.q; at.k = sv.k; at.v = sv.v; at.ctx = w.t0; at.lengths = lengths; at.off = w.off; at.B = B; at.L = L;
@@ -1646,6 +1815,16 @@ static int sb_backward(const SasLayer* layer, int n_layers, int n_heads, const i
       SbSum3Args q;
       q.X[0] = w.t1; q.X[1] = w.t2; q.X[2] = w.t3; q.W[0] = p.Wq; q.W[1] = p.Wk; q.W[2] = p.Wv;
       q.res = G; q.Y = G; q.off = w.off; q.B = B;
+      if (sb_rows16()) {
+        const size_t lds16 = (size_t)(3 * D * (D + 4)) * sizeof(float);
+        auto kern16 = sb_sum3_16_kernel<D>;
+        RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern16), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16));
+        int grid, block;
+        sb_rows16_geometry((int64_t)rmax, &grid, &block);
+        hipLaunchKernelGGL(kern16, dim3((unsigned)grid), dim3((unsigned)block), lds16, s, q);
+        RC_LAUNCH_CHECK();
+        continue;
+      }
       const size_t lds = (size_t)(3 * D + kSbTile) * (D + 1) * sizeof(float);
       auto kern = sb_linear3_sum_kernel<D>;
       RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -317,6 +317,41 @@ def test_sasrec_trainer_two_streams_equal_one_stream(rowwise, cuda, eng, monkeyp
     assert all(np.array_equal(out[True][3][l][k], out[False][3][l][k]) for l in range(n_layers) for k in LAYER_NAMES)
 
 
+@pytest.mark.parametrize("d,n_layers,n_heads,L,B", [(64, 2, 4, 50, 1400), (64, 1, 2, 20, 90), (32, 2, 2, 50, 1400), (32, 1, 1, 7, 3)])
+def test_sasrec_16_row_projection_kernels_equal_lds_tile_kernels(d, n_layers, n_heads, L, B, cuda, eng, monkeypatch):
+    """the QKV projection and the dX = dZ + dQ Wq + dK Wk + dV Wv sum on 16 x 16 x 4 tiles with operands straight from global
+    memory (sb_qkv16_kernel / sb_sum3_16_kernel) against the LDS-tile 32 x 32 x 2 kernels (RC_SAS_ROWS16=0); 16-wave workgroups
+    (B * history_max >= 65,536 rows) and 4-wave ones, ragged last tiles, empty histories"""
+    rng = np.random.default_rng(77 * d + B)
+    n_items = 300
+    P = _random_sasrec(rng, n_items, d, n_layers, L)
+    lengths = rng.integers(0, L + 1, size=B).astype(np.int64)
+    lengths[0] = L
+    hist = rng.integers(1, n_items, size=(B, L)).astype(np.int64) * (np.arange(L)[None, :] < lengths[:, None])
+    Pd = to_dev(P, n_layers, cuda)
+    h_d, l_d = torch.from_numpy(hist).to(cuda), torch.from_numpy(lengths).to(cuda)
+    dhv = torch.from_numpy(rng.normal(size=(B, d)).astype(np.float32)).to(cuda)
+    out = {}
+    for mode in ("1", "0", "1"):
+        monkeypatch.setenv("RC_SAS_ROWS16", mode)
+        hv, saved = eng.sasrec_fwd(Pd["item_emb"], Pd["pos_emb"], Pd["layers"], n_heads, h_d, l_d, save=True, impl="batch")
+        g_hist, dg = eng.sasrec_bwd(Pd["layers"], n_heads, l_d, saved, dhv)
+        torch.cuda.synchronize()
+        res = (hv.cpu().numpy(), g_hist.cpu().numpy(), [{k: v.cpu().numpy() for k, v in g.items()} for g in dg])
+        if mode in out:
+            assert np.array_equal(res[0], out[mode][0]) and np.array_equal(res[1], out[mode][1])
+        out[mode] = res
+    what = f"d={d} layers={n_layers} heads={n_heads} L={L} B={B}"
+    assert not np.array_equal(out["1"][1], out["0"][1]), what + ": the switch had no effect"
+    assert_close(out["1"][0], out["0"][0], what=what + " hv", rtol=2e-5, atol_scale=2e-5)
+    assert_close(out["1"][1], out["0"][1], what=what + " g_hist", rtol=5e-5, atol_scale=5e-5)
+    floor = 1e-6 * max(float(np.abs(v).max()) for g in out["0"][2] for v in g.values())
+    for l in range(n_layers):
+        for k in LAYER_NAMES:
+            assert_close(out["1"][2][l][k], out["0"][2][l][k], what=f"{what} layer {l} d{k}", rtol=5e-5, atol_scale=1e-4, abs_floor=floor)
+    assert np.all(out["1"][0][lengths == 0] == 0) and np.all(out["1"][1][lengths == 0] == 0)
+
+
 def test_sasrec_pos_grad_chunks(cuda, eng):
     """more than 1024 sequences: several chunks per position + the chunk reduction; vs the generic sort + segmented sum"""
     rng = np.random.default_rng(4)

@@ -1,0 +1,31 @@
+#!/bin/bash
+TAG=${1:-r03o}
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+R=$PWD
+export TMPDIR=/tmp
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+timeout 900 python -m pytest tests/test_gpu_sasrec.py tests/test_gpu_plugin.py -m gpu -q --maxfail=30 --tb=short -p no:cacheprovider > $OUT/pytest_gpu.log 2>&1
+echo "pytest exit $?" >> $OUT/pytest_gpu.log
+tail -15 $OUT/pytest_gpu.log
+RC_SAS_ROWS16=0 timeout 900 python -m pytest tests/test_gpu_sasrec.py -m gpu -q --maxfail=30 --tb=short -p no:cacheprovider 2>&1 | tail -3
+line() { python -c "
+import json,sys
+j=json.loads(sys.stdin.readline()); r=j.get('roofline') or {}; print('$1', round(j['ms_per_step'],4), 'ms', round(j['value']/1e6,2), 'M/s', {k:round(v,4) for k,v in (j.get('phases_ms') or {}).items()}, j.get('phases_tflops'))"; }
+for i in 1 2; do
+timeout 300 python bench.py --workload sasrec --no-cpu-baseline 2>$OUT/sasrec.err | tee $OUT/bench_sasrec.json | line sasrec_rows16
+RC_SAS_ROWS16=0 timeout 300 python bench.py --workload sasrec --no-cpu-baseline 2>/dev/null | tee $OUT/bench_sasrec_rows32.json | line sasrec_rows32
+done
+timeout 300 python bench.py --workload sasrec --batch 256 --steps 200 --no-cpu-baseline 2>/dev/null | line sasrec_b256_rows16
+RC_SAS_ROWS16=0 timeout 300 python bench.py --workload sasrec --batch 256 --steps 200 --no-cpu-baseline 2>/dev/null | line sasrec_b256_rows32
+cd /tmp
+timeout 300 rocprofv3 --kernel-trace --stats -d $R/$OUT/prof_sasrec -o kt --output-format csv -- \
+  python $R/bench.py --workload sasrec --steps 20 --warmup 5 --no-cpu-baseline --no-roofline > $R/$OUT/prof_sasrec.log 2>&1
+cd $R
+find $OUT -name "*kernel_trace.csv" -size +20M -delete 2>/dev/null
+python - <<PY
+import csv,glob
+for f in glob.glob("$OUT/prof_sasrec/**/*kernel_stats.csv", recursive=True):
+    for r in list(csv.DictReader(open(f)))[:12]:
+        print(r["Name"][:90], r["Calls"], round(float(r["AverageNs"])/1e3,1), "us", r["Percentage"])
+PY
