@@ -413,7 +413,7 @@ def unique_ids(ids, n_rows, tag="unique"):
     return uniq[:int(cnt.item())], inverse
 
 
-def embedding_dense_backward(grad_out, ids, n_rows):
+def embedding_dense_backward(grad_out, ids, n_rows, route=None):
     """aten::embedding_dense_backward: G [n_rows, d] = index_add of the per-occurrence gradient rows, in ascending
     position order per row (no float atomics) -- bucket plan + rc_plan_row_sums; radix sort + segmented sum where no
     plan geometry exists."""
@@ -424,7 +424,9 @@ def embedding_dense_backward(grad_out, ids, n_rows):
         return G
     go = grad_out.reshape(-1, d).contiguous()
     # (below a few thousand ids both routes are a handful of latency-bound launches; the plan pays off with the batch)
-    if d in (16, 32, 64, 128, 256) and flat.numel() >= _EDB_PLAN_MIN and plan_supported(flat.numel(), 0, n_rows, 0):
+    # route="sort": id lists with very hot rows (the categorical fields of the CTR models: 131,072 occurrences of 7 weekdays) --
+    # a plan bucket counts its ids with LDS atomics, which such a row serialises (15.8 ms per DeepFM step at B = 131,072)
+    if route != "sort" and d in (16, 32, 64, 128, 256) and flat.numel() >= _EDB_PLAN_MIN and plan_supported(flat.numel(), 0, n_rows, 0):
         return Plan(flat, n_rows, tag="edb").row_sums("a", G, src2=go)
     keys, perm = sort_ids(flat, n_rows)
     segmented_update(keys, perm, go, dense_grad=G)

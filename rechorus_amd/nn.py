@@ -185,12 +185,15 @@ class _FieldGatherFn(torch.autograd.Function):
         ids, tables = args[:n_fields], args[n_fields:]
         out, cid, offs = engine.gather_fields([t.detach() for t in tables], [x.contiguous() for x in ids], n_cand)
         ctx.cid, ctx.offs = cid, offs
+        # a field whose vocabulary is small against the batch makes hot rows: the sort-driven reduction handles any skew
+        n_ids = cid.numel() // max(1, n_fields)
+        ctx.route = "sort" if min(t.shape[0] for t in tables) * 8 <= n_ids else None
         return out
 
     @staticmethod
     def backward(ctx, gout):
         offs = ctx.offs
-        G = engine.embedding_dense_backward(gout.contiguous(), ctx.cid, offs[-1])  # virtual concatenated table
+        G = engine.embedding_dense_backward(gout.contiguous(), ctx.cid, offs[-1], route=ctx.route)  # virtual concatenated table
         grads = tuple(G[offs[f]:offs[f + 1]] for f in range(len(offs) - 1))
         return (None, None) + (None,) * len(grads) + grads
 
