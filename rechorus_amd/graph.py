@@ -73,6 +73,7 @@ class GraphedStep:
         self.seen = 0
         self.graph = None
         self.static = None
+        self.groups = None
         self.loss = None
 
     @staticmethod
@@ -96,15 +97,33 @@ class GraphedStep:
                 return self._eager(batch)
             self._capture(batch)
         else:
-            for k, v in self.static.items():
-                if isinstance(v, torch.Tensor):
-                    v.copy_(batch[k])
+            # one launch per dtype: the batch's tensors are concatenated straight into the flat buffer the static inputs view
+            # (ten 4.7 us copies per DeepFM step otherwise -- a tenth of the replayed step at B = 1,024)
+            for flat, keys in self.groups:
+                if len(keys) == 1:
+                    self.static[keys[0]].copy_(batch[keys[0]])
+                else:
+                    torch.cat([batch[k].reshape(-1) for k in keys], out=flat)
         self.graph.replay()
         return self.loss.detach().reshape(1).clone()
 
     def _capture(self, batch):
         model = self.model
-        self.static = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
+        # static inputs: one flat buffer per dtype, every tensor of the feed dict a view into it
+        self.static, self.groups = dict(batch), []
+        by_dtype = {}
+        for k, v in sorted(batch.items()):
+            if isinstance(v, torch.Tensor):
+                by_dtype.setdefault((v.dtype, v.device), []).append(k)
+        for (dtype, dev), keys in by_dtype.items():
+            flat = torch.empty(sum(batch[k].numel() for k in keys), dtype=dtype, device=dev)
+            o = 0
+            for k in keys:
+                n = batch[k].numel()
+                self.static[k] = flat[o:o + n].view(batch[k].shape)
+                self.static[k].copy_(batch[k])
+                o += n
+            self.groups.append((flat, keys))
         model.optimizer.zero_grad()  # grads must be None: the captured backward allocates them in the graph's pool
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()

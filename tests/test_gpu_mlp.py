@@ -19,8 +19,8 @@ def eng(cuda):
 
 SHAPES = [(1, 1, 1), (3, 5, 7), (64, 64, 16), (65, 63, 17), (100, 1, 96), (257, 130, 66), (1024, 512, 512), (777, 64, 512),
           (500, 33, 128), (2048, 32, 64),
-          # 128 x 128 tiles (mlp_gemm_big_kernel: from 512 workgroups), ragged edges in every dimension, bias column in its own tile
-          (16384, 512, 512), (16500, 520, 500), (70000, 130, 127)]
+          # 128 x 128 tiles (mlp_gemm_big_kernel: from 2048 workgroups) in the forward / the dX product, ragged edges, odd K
+          (66000, 512, 96), (66000, 64, 512), (140000, 130, 127)]
 
 
 @pytest.mark.parametrize("M,N,K", SHAPES)

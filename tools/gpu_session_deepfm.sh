@@ -6,7 +6,7 @@ R=$PWD
 export TMPDIR=/tmp
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
-timeout 900 python -m pytest tests/test_gpu_mlp.py tests/test_gpu_deepfm.py -m gpu -q --maxfail=30 --tb=short -p no:cacheprovider 2>&1 | tail -8
+timeout 900 python -m pytest tests/test_gpu_mlp.py tests/test_gpu_deepfm.py tests/test_gpu_plugin.py tests/test_gpu_neumf.py -m gpu -q --maxfail=30 --tb=short -p no:cacheprovider 2>&1 | tail -8
 line() { python -c "
 import json,sys
 j=json.loads(sys.stdin.readline()); r=j.get('roofline') or {}; print('$1', round(j['ms_per_step'],4), 'ms', round(j['value']/1e6,2), 'M rows/s', {k:round(v,4) for k,v in (j.get('phases_ms') or {}).items()}, 'frac', round(r.get('frac') or 0,3))"; }
