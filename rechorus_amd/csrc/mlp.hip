@@ -26,6 +26,9 @@ typedef float mlp_f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kMlpBM = 64, kMlpBN = 64, kMlpBK = 32, kMlpLD = 68;   // (K step 16: 22.8 us per GEMM at B = 1024 -- one L2 round trip per 8 MFMAs)
 constexpr int kMlpSub = 16;   // k rows one pass of the loaders covers; a K step is kMlpBK / kMlpSub passes
 constexpr int kMlpPD = 3;     // K steps in flight between global memory and LDS (register ring)
+// (tried and dropped, round 3: the operands of step s + 1 read from LDS into a second register set before the MFMAs of step s --
+//  2,090 instead of 1,890 cycles per K step, the compiler drains the reads before the first MFMA either way; two accumulator
+//  chains instead of one: no change, the dependent-issue gap is not what the step waits for)
 
 struct MlpOperand {
   const float* p;
@@ -135,9 +138,38 @@ __device__ __forceinline__ MlpFastSrc mlp_fast_src(const MlpOperand& o, int64_t 
   return f;
 }
 
+// LDS tile of one operand, two layouts.  Stored reduction-major ([k][outer] in memory): staged as it comes, [k][outer] with row
+// stride 68, one ds_write_b128 per thread, the MFMA operand of reduction index k is a conflict-free ds_read_b32 of row k.
+// Stored reduction-minor ([outer][k], k contiguous -- X and W of the forward product): staged as it comes as well, [outer][k]
+// with row stride 36 (round 2 transposed it with four scalar ds_write_b32 per float4), and a lane fetches FOUR reduction
+// indices of its row with one ds_read_b128 (the sixteen lanes of a pass start in sixteen different 4-bank groups).  The k-th
+// MFMA of a K step may contract any reduction index as long as both operands agree: MFMA (u, e), u = 0..7, e = 0..3 of a
+// 32-wide step takes k = 8 u + 4 kh + e (kh = lane >> 5).
+constexpr int kMlpLDK = kMlpBK + 4;                        // row stride of the [outer][k] layout
+constexpr int kMlpTile = kMlpBM * kMlpLDK > kMlpBK * kMlpLD ? kMlpBM * kMlpLDK : kMlpBK * kMlpLD;   // floats per buffer
+
+template <bool KM>
+__device__ __forceinline__ void mlp_stage_t(float* tile, const float4& v, int q) {
+  const int t = threadIdx.x;
+  if (KM) *reinterpret_cast<float4*>(tile + (t >> 2) * kMlpLDK + 4 * (t & 3) + q * kMlpSub) = v;
+  else *reinterpret_cast<float4*>(tile + ((t >> 4) + q * kMlpSub) * kMlpLD + 4 * (t & 15)) = v;
+}
+// the four operand values of MFMAs (u, 0..3) for this lane: row / column `o` of the tile
+template <bool KM>
+__device__ __forceinline__ void mlp_operand4(const float* tile, int o, int kh, int u, float (&x)[4]) {
+  if (KM) {
+    const float4 v = *reinterpret_cast<const float4*>(tile + o * kMlpLDK + 8 * u + 4 * kh);
+    x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
+  } else {
+    const float* p = tile + (8 * u + 4 * kh) * kMlpLD + o;
+    x[0] = p[0]; x[1] = p[kMlpLD]; x[2] = p[2 * kMlpLD]; x[3] = p[3 * kMlpLD];
+  }
+}
+
+template <bool AKM, bool BKM>
 __global__ __launch_bounds__(kBlock) void mlp_gemm_kernel(MlpGemm g, int vec_a, int vec_b) {
-  __shared__ __attribute__((aligned(16))) float As[2][kMlpBK * kMlpLD];
-  __shared__ __attribute__((aligned(16))) float Bs[2][kMlpBK * kMlpLD];
+  __shared__ __attribute__((aligned(16))) float As[2][kMlpTile];
+  __shared__ __attribute__((aligned(16))) float Bs[2][kMlpTile];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wr = wave >> 1, wc = wave & 1;                     // this wave's 32 x 32 block of the 64 x 64 tile
   const int64_t m0 = (int64_t)blockIdx.x * kMlpBM;
@@ -207,8 +239,8 @@ __global__ __launch_bounds__(kBlock) void mlp_gemm_kernel(MlpGemm g, int vec_a, 
   int buf = 0;
 #pragma unroll
   for (int q = 0; q < NP; ++q) {
-    mlp_stage(As[0] + q * kMlpSub * kMlpLD, g.A, ra[0][q]);
-    mlp_stage(Bs[0] + q * kMlpSub * kMlpLD, g.B, rb[0][q]);
+    mlp_stage_t<AKM>(As[0], ra[0][q], q);
+    mlp_stage_t<BKM>(Bs[0], rb[0][q], q);
   }
   __syncthreads();
   const int ai = wr * 32 + (lane & 31), bj = wc * 32 + (lane & 31), kh = lane >> 5;
@@ -222,21 +254,21 @@ __global__ __launch_bounds__(kBlock) void mlp_gemm_kernel(MlpGemm g, int vec_a, 
         fetch(ra[sl], rb[sl], k0 + (int64_t)kMlpPD * kMlpBK, off_a, off_b);
         off_a += stride_a;
         off_b += stride_b;
-        const float* as = As[buf] + kh * kMlpLD + ai;
-        const float* bs = Bs[buf] + kh * kMlpLD + bj;
-        float av[kMlpBK / 2], bv[kMlpBK / 2];
+        float av[kMlpBK / 8][4], bv[kMlpBK / 8][4];
 #pragma unroll
-        for (int t = 0; t < kMlpBK / 2; ++t) {
-          av[t] = as[2 * t * kMlpLD];
-          bv[t] = bs[2 * t * kMlpLD];
+        for (int u = 0; u < kMlpBK / 8; ++u) {
+          mlp_operand4<AKM>(As[buf], ai, kh, u, av[u]);
+          mlp_operand4<BKM>(Bs[buf], bj, kh, u, bv[u]);
         }
 #pragma unroll
-        for (int t = 0; t < kMlpBK / 2; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[t], acc, 0, 0, 0);
+        for (int u = 0; u < kMlpBK / 8; ++u)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][e], bv[u][e], acc, 0, 0, 0);
         if (more) {
 #pragma unroll
           for (int q = 0; q < NP; ++q) {
-            mlp_stage(As[buf ^ 1] + q * kMlpSub * kMlpLD, g.A, ra[(sl + 1) % kMlpPD][q]);
-            mlp_stage(Bs[buf ^ 1] + q * kMlpSub * kMlpLD, g.B, rb[(sl + 1) % kMlpPD][q]);
+            mlp_stage_t<AKM>(As[buf ^ 1], ra[(sl + 1) % kMlpPD][q], q);
+            mlp_stage_t<BKM>(Bs[buf ^ 1], rb[(sl + 1) % kMlpPD][q], q);
           }
         }
         __syncthreads();
@@ -521,7 +553,9 @@ static int mlp_launch(const MlpGemm& g, int splits, hipStream_t s) {
     return RC_OK;
   }
   dim3 grid((unsigned)((g.M + kMlpBM - 1) / kMlpBM), (unsigned)((ncols + kMlpBN - 1) / kMlpBN), (unsigned)splits);
-  hipLaunchKernelGGL(mlp_gemm_kernel, grid, dim3(kBlock), 0, s, g, vec4_ok(g.A) ? 1 : 0, vec4_ok(g.B) ? 1 : 0);
+  void (*kern)(MlpGemm, int, int) = g.A.k_major ? (g.B.k_major ? mlp_gemm_kernel<true, true> : mlp_gemm_kernel<true, false>)
+                                                : (g.B.k_major ? mlp_gemm_kernel<false, true> : mlp_gemm_kernel<false, false>);
+  hipLaunchKernelGGL(kern, grid, dim3(kBlock), 0, s, g, vec4_ok(g.A) ? 1 : 0, vec4_ok(g.B) ? 1 : 0);
   RC_LAUNCH_CHECK();
   return RC_OK;
 }
