@@ -397,6 +397,7 @@ _USE_PLAN = os.environ.get("RC_TABLE_UPDATE", "auto") != "sort"
 _SEG_ROWS = os.environ.get("RC_SEG_ROWS", "1") != "0"
 # SasrecTrainer: id sort beside the encoder, position gradient beside the item update, on a second stream (RC_SAS_OVERLAP=0: one stream)
 _SAS_OVERLAP = os.environ.get("RC_SAS_OVERLAP", "1") != "0"
+_NEUMF_OVERLAP = os.environ.get("RC_NEUMF_OVERLAP", "1") != "0"   # NeumfTrainer: bucket plan beside the head kernels
 _SAS_OVERLAP_MIN = int(os.environ.get("RC_SAS_OVERLAP_MIN", "131072"))   # candidate + history occurrences of the batch
 _SEG_ROWS_MIN_PER_ROW = int(os.environ.get("RC_SEG_ROWS_MIN_PER_ROW", "8"))
 _SASREC_PLAN = os.environ.get("RC_TABLE_UPDATE", "auto") == "plan"
@@ -675,6 +676,7 @@ class NeumfTrainer:
             self.state[k] = st
         self.step_count = 0
         self.loss = None
+        self._side = None
 
     def step(self, uid, iid):
         P = self.P
@@ -682,6 +684,21 @@ class NeumfTrainer:
         self.step_count += 1
         if self.seed is not None:
             step_increment(self.seed)
+        pair_ok = segmented_pair_supported(P["mf_u"].shape[1])
+        n_u, n_i = P["mf_u"].shape[0], P["mf_i"].shape[0]
+        use_plan = self.rowwise and pair_ok and _USE_PLAN and plan_supported(iid.numel(), uid.numel(), n_i, n_u)
+        # the bucket plan needs only the ids: on a second stream it runs beside the head kernels (large batches; a small step is
+        # bound by the host's launch rate and the stream switches cost more than they return)
+        overlap = use_plan and _NEUMF_OVERLAP and iid.is_cuda and iid.numel() >= _SAS_OVERLAP_MIN
+        plan = plan_done = main = None
+        if overlap:
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=iid.device)
+            main, side = torch.cuda.current_stream(iid.device), self._side
+            side.wait_stream(main)   # the batch is ready; last step's readers of the plan buffers are done
+            with torch.cuda.stream(side):
+                plan = Plan(iid, n_i, uid, n_u, tag="neumf")
+                plan_done = side.record_event()
         with _PhaseTimer(self, "head_fwd"):
             pred = neumf_fwd(P, uid, iid, self.dropout, self.seed)
         with _PhaseTimer(self, "loss"):
@@ -690,9 +707,7 @@ class NeumfTrainer:
             rows, dense = neumf_bwd(P, uid, iid, gpred, self.dropout, self.seed)
         h = make_hyper(self.opt, lr=self.lr, l2=self.l2, step=self.step_count)
         h0 = make_hyper(self.opt, lr=self.lr, l2=0.0, step=self.step_count)  # 'bias' params: no weight decay
-        pair_ok = segmented_pair_supported(P["mf_u"].shape[1])
-        n_u, n_i = P["mf_u"].shape[0], P["mf_i"].shape[0]
-        if self.rowwise and pair_ok and _USE_PLAN and plan_supported(iid.numel(), uid.numel(), n_i, n_u):
+        if use_plan:
             # ONE bucket plan of both id lists (round 3: hashed buckets where the id space is wide and sparse -- 0.33 M item
             # lookups over 10 M - 100 M rows -- so the cost follows the keys, not the id range; round 2's id-range
             # buckets cost as much as the radix sort here and the sort stayed), then one pair update per side: the
@@ -700,7 +715,10 @@ class NeumfTrainer:
             # kernel's per-candidate user gradients are summed over a tuple's candidates first (fixed order c = 0..C-1), so
             # a hot user contributes B_u occurrences, not C * B_u.
             with _PhaseTimer(self, "sort"):
-                plan = Plan(iid, n_i, uid, n_u, tag="neumf")
+                if overlap:
+                    main.wait_event(plan_done)
+                else:
+                    plan = Plan(iid, n_i, uid, n_u, tag="neumf")
             with _PhaseTimer(self, "table_update"):
                 key = (B, Cn, str(uid.device))
                 if getattr(self, "_sum_idx", (None,))[0] != key:

@@ -510,6 +510,37 @@ def test_plan_row_sums_and_distinct(case, d, cuda, eng):
         assert torch.equal(G, G2)
 
 
+def test_neumf_trainer_plan_on_second_stream_equals_one_stream(cuda, eng, monkeypatch):
+    """NeumfTrainer builds the batch's bucket plan on a second stream beside the head kernels (large batches); same kernels, same
+    inputs: three row-wise Adam steps leave every table, dense parameter and optimizer state bit-identical to the one-stream order"""
+    g = torch.Generator(device=cuda)
+    n_users, n_items, d, l1, B, Cn = 20_000, 3_000_000, 128, 64, 3000, 5
+    def run(overlap):
+        monkeypatch.setattr(eng, "_NEUMF_OVERLAP", overlap)
+        monkeypatch.setattr(eng, "_SAS_OVERLAP_MIN", 0)
+        g.manual_seed(11)
+        mk = lambda *sh: torch.empty(sh, device=cuda).normal_(0, 0.05, generator=g)
+        P = {"mf_u": mk(n_users, d), "mlp_u": mk(n_users, d), "mf_i": mk(n_items, d), "mlp_i": mk(n_items, d),
+             "W1": mk(l1, 2 * d), "b1": mk(l1), "w_out": mk(d + l1)}
+        tr = eng.NeumfTrainer(P, opt="Adam", lr=1e-2, l2=1e-5, rowwise=True)
+        r = np.random.default_rng(12)
+        losses = []
+        for _ in range(3):
+            uid = torch.from_numpy(_zipf(r, n_users, B)).to(cuda)
+            iid = torch.from_numpy(np.concatenate([_zipf(r, n_items, (B, 1)), r.integers(1, n_items, size=(B, Cn - 1))], axis=1)).to(cuda)
+            losses.append(float(tr.step(uid, iid)[0]))
+        torch.cuda.synchronize()
+        assert (tr._side is not None) == overlap
+        return P, tr.state, losses
+    Pa, Sa, La = run(True)
+    Pb, Sb, Lb = run(False)
+    assert La == Lb
+    for k in Pa:
+        assert torch.equal(Pa[k], Pb[k]), k
+        for st in ("m", "v"):
+            assert torch.equal(Sa[k][st], Sb[k][st]), (k, st)
+
+
 def test_neumf_and_sasrec_trainers_plan_equals_sort(cuda, eng, monkeypatch):
     """the trainers' table updates through the bucket plan and behind the radix sort: bit-identical item tables, dense
     parameters and state after two steps (both sum a row's gradient rows in ascending batch position)"""
@@ -549,6 +580,9 @@ def test_neumf_and_sasrec_trainers_plan_equals_sort(cuda, eng, monkeypatch):
     n_items, d, L, B, Cn = 9_000, 64, 50, 1024, 100
     def sasrec(use_plan):
         monkeypatch.setattr(eng, "_SASREC_PLAN", use_plan)
+        # (the sorted route's head list sums in ascending batch position like the plan; its one-wave-per-row variant for small
+        #  catalogues interleaves four lane-groups -- checked against both in tests/test_gpu_sasrec.py, within rounding)
+        monkeypatch.setattr(eng, "_SEG_ROWS", False)
         g.manual_seed(2)
         mk = lambda *sh: torch.empty(sh, device=cuda).normal_(0, 0.05, generator=g)
         lay = {k: (mk(d, d) if k.startswith("W") else mk(d)) for k in eng.SAS_LAYER_KEYS}
