@@ -65,7 +65,10 @@ struct NeumfArgs {
 template <int D, int L1>
 struct NeumfCfg {
   static constexpr int K0 = 2 * D;
-  static constexpr int SW = K0 + 1;      // LDS row stride of Ws / As (floats)
+  // LDS row stride of Ws / As (floats): a multiple of 4 whose quarter is odd -- rows are 16-byte aligned (float4 staging, one
+  // ds_read_b128 = four reduction indices of the forward product's operands) and the sixteen lanes of a ds_read_b128 pass start
+  // in sixteen different 4-bank groups.  (K0 + 1 in rounds 1-2: scalar staging, one ds_read_b32 per operand and MFMA.)
+  static constexpr int SW = K0 + 4;
   static constexpr int SZ = kTileM + 1;  // LDS row stride of Zs
   static constexpr int NRB = L1 / 32;    // 32-row blocks of hidden features
   static constexpr int NKB = K0 / 32;    // 32-row blocks of h0 features
@@ -109,7 +112,8 @@ __global__ __launch_bounds__(kBlock) void neumf_kernel(NeumfArgs a) {
   const int grp = tid / LPR;
   const int l = tid % LPR;
 
-  for (int i = tid; i < L1 * K0; i += kBlock) Ws[(i / K0) * SW + (i % K0)] = a.W1[i];
+  for (int i = tid; i < L1 * K0 / 4; i += kBlock)
+    *reinterpret_cast<float4*>(Ws + (i / (K0 / 4)) * SW + 4 * (i % (K0 / 4))) = reinterpret_cast<const float4*>(a.W1)[i];
   for (int i = tid; i < L1; i += kBlock) sb1[i] = a.b1[i];
   for (int i = tid; i < D + L1; i += kBlock) swo[i] = a.w_out[i];
   __syncthreads();
@@ -176,8 +180,8 @@ __global__ __launch_bounds__(kBlock) void neumf_kernel(NeumfArgs a) {
       const float dot = row_allreduce_sum<LPR>(dot4(wm, mm));
       if (l == 0) smf[cc] = dot;
       float* arow = As + cc * SW;
-      arow[4 * l + 0] = hu.x; arow[4 * l + 1] = hu.y; arow[4 * l + 2] = hu.z; arow[4 * l + 3] = hu.w;
-      arow[D + 4 * l + 0] = hi.x; arow[D + 4 * l + 1] = hi.y; arow[D + 4 * l + 2] = hi.z; arow[D + 4 * l + 3] = hi.w;
+      *reinterpret_cast<float4*>(arow + 4 * l) = hu;
+      *reinterpret_cast<float4*>(arow + D + 4 * l) = hi;
       if (BWD) {
         const float g = pg[it];
         if (l == 0) sg[cc] = g;
@@ -202,10 +206,19 @@ __global__ __launch_bounds__(kBlock) void neumf_kernel(NeumfArgs a) {
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        const float* wa = Ws + (rb * 32 + (lane & 31)) * SW + (lane >> 5);
-        const float* hb = As + (cb * 32 + (lane & 31)) * SW + (lane >> 5);
-#pragma unroll 8
-        for (int k0 = 0; k0 < K0; k0 += 2) acc = mfma32(wa[k0], hb[k0], acc);
+        // both operands run along the reduction index in LDS: one ds_read_b128 each feeds four MFMAs -- MFMA (u, e) contracts
+        // k = 8 u + 4 (lane >> 5) + e (any order of the reduction is a valid product as long as both operands agree)
+        const float* wa = Ws + (rb * 32 + (lane & 31)) * SW + 4 * (lane >> 5);
+        const float* hb = As + (cb * 32 + (lane & 31)) * SW + 4 * (lane >> 5);
+#pragma unroll 4
+        for (int k0 = 0; k0 < K0; k0 += 8) {
+          const float4 w4 = *reinterpret_cast<const float4*>(wa + k0);
+          const float4 h4 = *reinterpret_cast<const float4*>(hb + k0);
+          acc = mfma32(w4.x, h4.x, acc);
+          acc = mfma32(w4.y, h4.y, acc);
+          acc = mfma32(w4.z, h4.z, acc);
+          acc = mfma32(w4.w, h4.w, acc);
+        }
         const int cand = cb * 32 + (lane & 31);
         const float gj = BWD ? sg[cand] : 0.f;
         float pp = 0.f;
@@ -406,7 +419,7 @@ static int launch_neumf(const NeumfArgs& a, int n_wg, hipStream_t s) {
 
 static size_t neumf_lds_bytes(int d, int l1) {
   const size_t k0 = 2 * (size_t)d;
-  return sizeof(float) * ((size_t)l1 * (k0 + 1) + kTileM * (k0 + 1) + (size_t)l1 * (kTileM + 1) + l1 + (d + l1) +
+  return sizeof(float) * ((size_t)l1 * (k0 + 4) + kTileM * (k0 + 4) + (size_t)l1 * (kTileM + 1) + l1 + (d + l1) +
                           2 * kTileM + (l1 / 32) * kTileM + kBlock * 4);
 }
 
