@@ -22,6 +22,7 @@ timeout 400 python bench.py --workload sasrec > $OUT/bench_sasrec.json 2> $OUT/b
 timeout 300 python bench.py --workload sasrec --batch 256 --steps 200 --no-cpu-baseline > $OUT/bench_sasrec_b256.json 2> $OUT/bench_sasrec_b256.err
 timeout 400 python bench.py --workload deepfm > $OUT/bench_deepfm.json 2> $OUT/bench_deepfm.err
 timeout 300 python bench.py --workload deepfm --batch 16384 --steps 50 --warmup 5 --no-cpu-baseline > $OUT/bench_deepfm_b16384.json 2> $OUT/bench_deepfm_b16384.err
+timeout 300 python bench.py --workload deepfm --batch 131072 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_deepfm_b131072.json 2> $OUT/bench_deepfm_b131072.err
 timeout 600 python tools/bench_plugin_epoch.py > $OUT/plugin_epoch.json 2> $OUT/plugin_epoch.err
 cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats -d $R/$OUT/prof -o kt --output-format csv -- \
@@ -30,12 +31,14 @@ timeout 300 rocprofv3 --kernel-trace --stats -d $R/$OUT/prof_sasrec -o kt --outp
   python $R/bench.py --workload sasrec --steps 20 --warmup 5 --no-cpu-baseline --no-roofline > $R/$OUT/prof_sasrec.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats -d $R/$OUT/prof_neumf -o kt --output-format csv -- \
   python $R/bench.py --workload neumf --steps 20 --warmup 5 --no-cpu-baseline --no-roofline > $R/$OUT/prof_neumf.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d $R/$OUT/prof_deepfm -o kt --output-format csv -- \
+  python $R/bench.py --workload deepfm --batch 131072 --steps 20 --warmup 5 --no-cpu-baseline --no-roofline > $R/$OUT/prof_deepfm.log 2>&1
 cd $R
 find $OUT -name "*kernel_trace.csv" -size +20M -delete 2>/dev/null
 bash tools/pmc_collect.sh $TAG/pmc > /dev/null 2>&1
 ls -laR $OUT > $OUT/ls.txt 2>&1
 tail -5 $OUT/pytest_gpu.log; tail -2 $OUT/smoke.log
-for f in bench bench_adam bench_b8192 bench_b256 bench_neumf bench_neumf_100M bench_sasrec bench_sasrec_b256 bench_deepfm bench_deepfm_b16384; do
+for f in bench bench_adam bench_b8192 bench_b256 bench_neumf bench_neumf_100M bench_sasrec bench_sasrec_b256 bench_deepfm bench_deepfm_b16384 bench_deepfm_b131072; do
   python - <<PY
 import json
 try:
