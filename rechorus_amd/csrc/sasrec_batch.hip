@@ -1006,6 +1006,155 @@ __global__ __launch_bounds__(256 * WPH) void sb_attn_bwd_wave_kernel(SbAttnArgs 
 #undef RC_ST
 }
 
+// ---- the same block on 16-row tiles without an LDS row tile (the pattern of sb_qkv16_kernel) ---------------------------------
+// In the Y^T = W X^T form a product's accumulator comes out in the very layout the next product wants as its B operand
+// (lane (i, g): row i, columns 16 n + 4 g .. + 3), so LayerNorm1 -> FFN1 -> FFN2 -> LayerNorm2 chain through REGISTERS: a row's
+// statistics are the lane's sixteen values plus two cross-lane steps, the activations never touch LDS, and a wave walks its
+// tiles without any barrier.  LDS holds the two weight matrices (row stride D + 4: one ds_read_b128 = the A operand of four
+// MFMAs) and the six parameter vectors.
+template <int D>
+__device__ __forceinline__ void sb16_layernorm(float (&z)[D / 16][4], const float* lnw, const float* lnb, int g, float (&xh)[D / 16][4],
+                                               float (&y)[D / 16][4], float* rs_out) {
+  float sum = 0.f;
+#pragma unroll
+  for (int c = 0; c < D / 16; ++c) sum += (z[c][0] + z[c][1]) + (z[c][2] + z[c][3]);
+  const float mu = sas_groups_sum(sum) / D;
+  float sq = 0.f;
+#pragma unroll
+  for (int c = 0; c < D / 16; ++c)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      z[c][e] -= mu;
+      sq = fmaf(z[c][e], z[c][e], sq);
+    }
+  const float rs = 1.0f / sqrtf(sas_groups_sum(sq) / D + kLnEps);
+#pragma unroll
+  for (int c = 0; c < D / 16; ++c) {
+    const float4 w = *reinterpret_cast<const float4*>(lnw + 16 * c + 4 * g), b = *reinterpret_cast<const float4*>(lnb + 16 * c + 4 * g);
+    const float wv[4] = {w.x, w.y, w.z, w.w}, bv[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      xh[c][e] = z[c][e] * rs;
+      y[c][e] = fmaf(xh[c][e], wv[e], bv[e]);
+    }
+  }
+  *rs_out = rs;
+}
+
+template <int D>
+__device__ __forceinline__ void sb16_store_rows(float* __restrict__ Y, int row, int g, const float (&v)[D / 16][4]) {
+#pragma unroll
+  for (int c = 0; c < D / 16; ++c)
+    *reinterpret_cast<float4*>(Y + (size_t)row * D + 16 * c + 4 * g) = make_float4(v[c][0], v[c][1], v[c][2], v[c][3]);
+}
+
+constexpr int kSb16BlockWaves = 8;   // (the block kernel holds five row sets: 256 registers per lane at 8 waves per workgroup)
+
+template <int D>
+__global__ __launch_bounds__(64 * kSb16BlockWaves) void sb_block16_fwd_kernel(SbBlockArgs a) {
+  constexpr int NC = D / 16, S = D + 4;
+  extern __shared__ float lds[];
+  float* W1s = lds;               // [D][S]
+  float* W2s = W1s + D * S;       // [D][S]
+  float* Ps = W2s + D * S;        // [6][D]: b1, b2, ln1w, ln1b, ln2w, ln2b
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
+  const int nw = blockDim.x >> 6;
+  const int R = a.off[a.B];
+  const int tiles = (R + 15) >> 4;
+  const int stride = (int)gridDim.x * nw;
+  int t = (int)blockIdx.x * nw + wave;
+  float zc[NC][4], zx[NC][4];
+  if (t < tiles) {   // the first tile's rows travel while the weights are staged
+    sb16_load_rows<D>(a.ctx, 16 * t + i, R, g, zc);
+    sb16_load_rows<D>(a.x, 16 * t + i, R, g, zx);
+  }
+  for (int idx = threadIdx.x; idx < D * (D / 4); idx += blockDim.x) {
+    const int o = idx / (D / 4), c4 = idx % (D / 4);
+    *reinterpret_cast<float4*>(W1s + o * S + 4 * c4) = reinterpret_cast<const float4*>(a.W1)[idx];
+    *reinterpret_cast<float4*>(W2s + o * S + 4 * c4) = reinterpret_cast<const float4*>(a.W2)[idx];
+  }
+  for (int idx = threadIdx.x; idx < D; idx += blockDim.x) {
+    Ps[idx] = a.b1[idx]; Ps[D + idx] = a.b2[idx];
+    Ps[2 * D + idx] = a.ln1w[idx]; Ps[3 * D + idx] = a.ln1b[idx];
+    Ps[4 * D + idx] = a.ln2w[idx]; Ps[5 * D + idx] = a.ln2b[idx];
+  }
+  __syncthreads();
+  const bool drop = a.dr.seed != nullptr;
+  const uint64_t seed = drop ? *a.dr.seed : 0;
+  SbDrop dr1 = a.dr, dr2 = a.dr;
+  dr2.site = a.dr.site + 1u;
+  bool first = true;
+  for (; t < tiles; t += stride) {
+    asm volatile("" ::: "memory");   // weights and parameters are re-read from LDS per tile (see sb_qkv16_kernel)
+    const int row = 16 * t + i;
+    const bool valid = row < R;
+    if (!first) {
+      sb16_load_rows<D>(a.ctx, row, R, g, zc);
+      sb16_load_rows<D>(a.x, row, R, g, zx);
+    }
+    first = false;
+    // ---- y1 = LayerNorm1(drop1(ctx) + x)
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      if (drop) {
+        const float4 kp = sb_drop_keep4<D>(dr1, seed, row, 4 * c + g);
+        zc[c][0] *= kp.x; zc[c][1] *= kp.y; zc[c][2] *= kp.z; zc[c][3] *= kp.w;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) zc[c][e] += zx[c][e];
+    }
+    float xh[NC][4], y1[NC][4], rs;
+    sb16_layernorm<D>(zc, Ps + 2 * D, Ps + 3 * D, g, xh, y1, &rs);
+    if (valid) {
+      sb16_store_rows<D>(a.xh1, row, g, xh);
+      sb16_store_rows<D>(a.y1, row, g, y1);
+      if (g == 0) a.rstd1[row] = rs;
+    }
+    // ---- h = relu(y1 W1^T + b1): the accumulator of output tile n is the lane's float4 of h[row][16 n + 4 g ..]
+    float h[NC][4];
+#pragma unroll
+    for (int n = 0; n < NC; n += 2) {
+      sas_f32x4 a0 = sas_zero4(), a1 = sas_zero4();
+      if (n == 0) sb16_product_pair<D, 0>(W1s, i, g, y1, a0, a1);
+      else if (n == 2) sb16_product_pair<D, (D >= 64 ? 2 : 0)>(W1s, i, g, y1, a0, a1);
+      const float4 b0 = *reinterpret_cast<const float4*>(Ps + 16 * n + 4 * g), b1 = *reinterpret_cast<const float4*>(Ps + 16 * (n + 1) + 4 * g);
+      h[n][0] = fmaxf(a0[0] + b0.x, 0.f); h[n][1] = fmaxf(a0[1] + b0.y, 0.f); h[n][2] = fmaxf(a0[2] + b0.z, 0.f); h[n][3] = fmaxf(a0[3] + b0.w, 0.f);
+      h[n + 1][0] = fmaxf(a1[0] + b1.x, 0.f); h[n + 1][1] = fmaxf(a1[1] + b1.y, 0.f); h[n + 1][2] = fmaxf(a1[2] + b1.z, 0.f); h[n + 1][3] = fmaxf(a1[3] + b1.w, 0.f);
+    }
+    if (valid) sb16_store_rows<D>(a.h, row, g, h);
+    // ---- t = h W2^T + b2; z2 = drop2(t) + y1  (into zc)
+#pragma unroll
+    for (int n = 0; n < NC; n += 2) {
+      sas_f32x4 a0 = sas_zero4(), a1 = sas_zero4();
+      if (n == 0) sb16_product_pair<D, 0>(W2s, i, g, h, a0, a1);
+      else if (n == 2) sb16_product_pair<D, (D >= 64 ? 2 : 0)>(W2s, i, g, h, a0, a1);
+      const float4 b0 = *reinterpret_cast<const float4*>(Ps + D + 16 * n + 4 * g), b1 = *reinterpret_cast<const float4*>(Ps + D + 16 * (n + 1) + 4 * g);
+      const float bb0[4] = {b0.x, b0.y, b0.z, b0.w}, bb1[4] = {b1.x, b1.y, b1.z, b1.w};
+      float4 k0 = make_float4(1.f, 1.f, 1.f, 1.f), k1 = k0;
+      if (drop) {
+        k0 = sb_drop_keep4<D>(dr2, seed, row, 4 * n + g);
+        k1 = sb_drop_keep4<D>(dr2, seed, row, 4 * (n + 1) + g);
+      }
+      const float kk0[4] = {k0.x, k0.y, k0.z, k0.w}, kk1[4] = {k1.x, k1.y, k1.z, k1.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float v0 = a0[e] + bb0[e], v1 = a1[e] + bb1[e];
+        if (drop) { v0 *= kk0[e]; v1 *= kk1[e]; }
+        zc[n][e] = v0 + y1[n][e];
+        zc[n + 1][e] = v1 + y1[n + 1][e];
+      }
+    }
+    // ---- xnext = LayerNorm2(z2)
+    float xh2[NC][4], yo[NC][4], rs2;
+    sb16_layernorm<D>(zc, Ps + 4 * D, Ps + 5 * D, g, xh2, yo, &rs2);
+    if (valid) {
+      sb16_store_rows<D>(a.xh2, row, g, xh2);
+      sb16_store_rows<D>(a.xnext, row, g, yo);
+      if (g == 0) a.rstd2[row] = rs2;
+    }
+  }
+}
+
 // ---- weight gradients: dW[o][k] = sum_r dY[r][o] X[r][k], db[o] = sum_r dY[r][o] --------------------------
 // NP (dY, X) pairs that share X are handled by one launch (dq, dk, dv against the layer input).  Each workgroup
 // keeps its accumulators in registers over all of its row tiles and writes ONE partial block per pair.
@@ -1689,6 +1838,22 @@ static int sb_forward(const float* item_emb, const float* pos_emb, const SasLaye
       bk.ctx = w.t0; bk.x = sv.x; bk.ln1w = p.ln1w; bk.ln1b = p.ln1b; bk.W1 = p.W1; bk.b1 = p.b1; bk.W2 = p.W2; bk.b2 = p.b2;
       bk.ln2w = p.ln2w; bk.ln2b = p.ln2b; bk.xh1 = sv.xh1; bk.rstd1 = sv.rstd1; bk.y1 = sv.y1; bk.h = sv.h; bk.xh2 = sv.xh2;
       bk.rstd2 = sv.rstd2; bk.xnext = xnext; bk.off = w.off; bk.B = B; bk.dr = dr;
+      if (sb_rows16()) {   // 16-row tiles, activations chained through registers
+        const size_t lds16 = ((size_t)2 * D * (D + 4) + 6 * (size_t)D) * sizeof(float);
+        auto kern16 = sb_block16_fwd_kernel<D>;
+        RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern16), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16));
+        const int64_t tiles16 = ((int64_t)rmax + 15) / 16;
+        // 140 registers per lane: three waves per SIMD.  Four-wave workgroups place one wave on each SIMD, so three of them
+        // share a CU (36 KB of LDS each); an eight-wave workgroup would be alone on its CU with two waves per SIMD
+        int nw = 4;
+        if (const char* v = getenv("RC_SB16_BLOCK_WAVES")) nw = atoi(v) == 8 ? 8 : 4;   // experiment switch
+        int64_t gr = (tiles16 + nw - 1) / nw;
+        const int64_t cap16 = nw == 8 ? 256 : 768;
+        if (gr > cap16) gr = cap16;
+        hipLaunchKernelGGL(kern16, dim3((unsigned)(gr < 1 ? 1 : gr)), dim3(64 * nw), lds16, s, bk);
+        RC_LAUNCH_CHECK();
+        continue;
+      }
       const size_t lds = ((size_t)(2 * D + 2 * kSbTile) * (D + 1) + 2 * (size_t)D) * sizeof(float);
       auto kern = sb_block_fwd_kernel<D>;
       RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
