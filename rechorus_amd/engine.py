@@ -1008,10 +1008,13 @@ class SasrecTrainer:
         with _PhaseTimer(self, "encoder_fwd"):
             hv, xsave = sasrec_fwd(I, Pe, layers, self.n_heads, hist, lengths, save=True, drop_p=self.dropout, seed=self.seed)
         with _PhaseTimer(self, "score_loss"):
-            rows = torch.arange(B, device=hist.device)
-            pred = gather_dot(hv, I, rows, iid)                       # SASRec.py:80-81
-            self.loss, _, gpred = bpr_loss(pred)
-            dhv = weighted_row_sum(I, iid, gpred)
+            # scores, BPR loss, d loss / d pred and d loss / d hv in ONE pass over the candidate rows: the fused BPRMF kernel
+            # with the encoder output as the "user" row (SASRec.py:80-81, BaseModel.py:182-185); three launches and two
+            # more passes over the [B, C] rows before
+            if getattr(self, "_rows", None) is None or self._rows.numel() != B or self._rows.device != hist.device:
+                self._rows = torch.arange(B, device=hist.device)
+            _, loss_vec, gpred, dhv = bprmf_fwd_bwd(hv, I, self._rows, iid, want_pred=False)
+            self.loss = reduce_sum(loss_vec, 1.0 / B)
         with _PhaseTimer(self, "encoder_bwd"):
             g_hist, dgrads = sasrec_bwd(layers, self.n_heads, lengths, xsave, dhv, drop_p=self.dropout, seed=self.seed)
         # item table: candidate occurrences (g * hv, rebuilt on the fly) + history occurrences (g_hist rows)
