@@ -924,6 +924,12 @@ def sasrec_pos_grad(g_hist, lengths, n_pos):
     return out
 
 
+def seg_rows_route(n_occ, n_rows, d):
+    """True iff segmented_update2 takes rc_segmented_update_rows (one wave per table row: every row collects many occurrences).
+    That route ignores keys >= n_rows, which lets a caller park occurrences that must not take part (padding) behind the table."""
+    return _SEG_ROWS and d in (16, 32, 64, 128, 256) and n_occ >= _SEG_ROWS_MIN_PER_ROW * n_rows
+
+
 def segmented_update2(keys, perm, src, src2, n_split, hyper=None, W=None, m=None, v=None, coef=None,
                       src_index=None, div=1, dense_grad=None):
     """rc_segmented_update2: occurrences >= n_split take plain rows src2[o - n_split]"""
@@ -932,7 +938,7 @@ def segmented_update2(keys, perm, src, src2, n_split, hyper=None, W=None, m=None
     f32 = torch.float32
     table = W if W is not None else dense_grad
     n_rows = table.shape[0]
-    if _SEG_ROWS and d in (16, 32, 64, 128, 256) and n_occ >= _SEG_ROWS_MIN_PER_ROW * n_rows:
+    if seg_rows_route(n_occ, n_rows, d):
         # every row collects many occurrences (a small catalogue under a large batch): one wave per table row
         ws = workspace(_lib.load().rc_segmented_rows_workspace_bytes(n_rows, n_occ, d), keys.device, "seg_rows")
         _lib.call("rc_segmented_update_rows", _ptr(W, f32, "W", True), _ptr(m, f32, "m", True), _ptr(v, f32, "v", True), d,
@@ -999,11 +1005,26 @@ class SasrecTrainer:
         #  B = 256: 0.39 against 0.30 ms; B = 4096: 0.66 against 0.72 ms)
         overlap = _SAS_OVERLAP and hist.is_cuda and not use_plan and n_occ >= _SAS_OVERLAP_MIN
         sorted_ids = sort_done = main = side = None
+
+        def sorted_occurrences():
+            """candidate + history ids, sorted.  On the one-wave-per-row route the padding slots of the history windows (id 0, zero
+            gradient rows: half of B * history_max occurrences of ONE row, a 400-chunk hot row) are parked behind the table (key =
+            n_items, ignored there) except the first of them, which keeps row 0 among the touched rows exactly as before -- a sum of
+            zero rows is zero either way."""
+            n_items = I.shape[0]
+            if not seg_rows_route(n_occ, n_items, d):
+                return sort_ids(torch.cat([iid.reshape(-1), hist.reshape(-1)]), n_items)
+            pad = (torch.arange(L, device=hist.device)[None, :] >= lengths[:, None]).reshape(-1)
+            hid = torch.where(pad, hist.new_full((), n_items), hist.reshape(-1))
+            first_pad = pad.to(torch.int32).argmax().reshape(1)   # position of the first padding slot (0 if there is none)
+            hid.scatter_(0, first_pad, hist.reshape(-1).gather(0, first_pad))   # (tensor-indexed assignment would read the index back: a host sync)
+            return sort_ids(torch.cat([iid.reshape(-1), hid]), n_items + 1)
+
         if overlap:
             main, side = torch.cuda.current_stream(hist.device), self._side_stream(hist.device)
             side.wait_stream(main)   # the batch is ready; last step's readers of the side stream's buffers are done
             with torch.cuda.stream(side):
-                sorted_ids = sort_ids(torch.cat([iid.reshape(-1), hist.reshape(-1)]), I.shape[0])
+                sorted_ids = sorted_occurrences()
                 sort_done = side.record_event()
         with _PhaseTimer(self, "encoder_fwd"):
             hv, xsave = sasrec_fwd(I, Pe, layers, self.n_heads, hist, lengths, save=True, drop_p=self.dropout, seed=self.seed)
@@ -1033,8 +1054,8 @@ class SasrecTrainer:
             L = hist.shape[1]
             pad = torch.arange(L, device=hist.device)[None, :] >= lengths[:, None]
             hid = torch.where(pad, hist.new_full((), -1), hist).reshape(-1)
-            first_pad = pad.reshape(-1).to(torch.int32).argmax()       # position of the first padding slot (0 if there is none)
-            hid[first_pad] = hist.reshape(-1)[first_pad]
+            first_pad = pad.reshape(-1).to(torch.int32).argmax().reshape(1)   # position of the first padding slot (0 if there is none)
+            hid.scatter_(0, first_pad, hist.reshape(-1).gather(0, first_pad))   # (no tensor-indexed assignment: it syncs the host)
             plan = Plan(torch.cat([iid.reshape(-1), hid]), I.shape[0], tag="sasrec")
             src = dict(coef=gpred.reshape(-1), src=hv, div=Cn, src2=g_hist.view(-1, d), n_split=B * Cn)
             if self.rowwise:
@@ -1047,7 +1068,7 @@ class SasrecTrainer:
                 main.wait_event(sort_done)
                 keys, perm = sorted_ids
             else:
-                keys, perm = sort_ids(torch.cat([iid.reshape(-1), hist.reshape(-1)]), I.shape[0])
+                keys, perm = sorted_occurrences()
             if self.rowwise:
                 segmented_update2(keys, perm, hv, g_hist.view(-1, d), B * Cn, hyper=h, W=I, m=st.get("m"), v=st.get("v"),
                                   coef=gpred.reshape(-1), div=Cn)

@@ -315,6 +315,24 @@ def test_sasrec_trainer_two_streams_equal_one_stream(rowwise, cuda, eng, monkeyp
     assert out[True][0] == out[False][0]
     assert np.array_equal(out[True][1], out[False][1]) and np.array_equal(out[True][2], out[False][2])
     assert all(np.array_equal(out[True][3][l][k], out[False][3][l][k]) for l in range(n_layers) for k in LAYER_NAMES)
+    # the one-wave-per-row item update parks the padding occurrences behind the table; the head-list route sums them (zeros) into
+    # row 0: same tables up to the summation order of a row's occurrences
+    monkeypatch.setattr(eng, "_SEG_ROWS", False)
+    Pd = to_dev(P, n_layers, cuda)
+    tr = eng.SasrecTrainer(Pd, n_heads, opt="Adam", lr=1e-3, l2=1e-5, rowwise=rowwise)
+    for b in batches[:1]:
+        tr.step(*b)
+    monkeypatch.setattr(eng, "_SEG_ROWS", True)
+    Pd2 = to_dev(P, n_layers, cuda)
+    tr2 = eng.SasrecTrainer(Pd2, n_heads, opt="Adam", lr=1e-3, l2=1e-5, rowwise=rowwise)
+    for b in batches[:1]:
+        tr2.step(*b)
+    torch.cuda.synchronize()
+    d_ref = Pd["item_emb"].cpu().numpy() - P["i_embeddings.weight"]
+    d_got = Pd2["item_emb"].cpu().numpy() - P["i_embeddings.weight"]
+    # Adam normalises the step: an element whose gradient is rounding noise may move by lr either way -- allow a few
+    assert float((np.abs(d_got - d_ref) > 2e-5).mean()) < 5e-3 and float(np.abs(d_got - d_ref).max()) <= 2.5e-3
+    assert np.array_equal(d_got[0] != 0, d_ref[0] != 0)   # row 0 (padding id) is touched by both routes or by neither
 
 
 @pytest.mark.parametrize("d,n_layers,n_heads,L,B", [(64, 2, 4, 50, 1400), (64, 1, 2, 20, 90), (32, 2, 2, 50, 1400), (32, 1, 1, 7, 3)])
