@@ -527,12 +527,19 @@ __global__ __launch_bounds__(kBucketThreads) void plan_bucket_kernel(PlanArgs a)
   uint32_t* scratch = tab + words;
   const bool side_b = bkt >= a.g.nb_a;
   const bool list_all = side_b || a.list_single_a != 0;
+#ifdef RC_X_TIMING
+  uint64_t tq[5];
+  tq[0] = wall_clock64();
+#endif
   for (uint32_t i = tid; i < words; i += kBucketThreads) tab[i] = 0;
   __syncthreads();
 
   // pass 1: occurrences per id
   bucket_count_pass<WIDE>(cells, a.w.lid, beg, end, tid);
   __syncthreads();
+#ifdef RC_X_TIMING
+  tq[1] = wall_clock64();
+#endif
 
   // scan: counts -> cursors (listed rows) / marker (rows that are only flagged); row records
   uint32_t my_occ = 0, my_rows = 0;
@@ -583,6 +590,9 @@ __global__ __launch_bounds__(kBucketThreads) void plan_bucket_kernel(PlanArgs a)
   }
   __syncthreads();
   if (wave != 0) return;
+#ifdef RC_X_TIMING
+  tq[2] = wall_clock64();
+#endif
 
   // pass 2 (wave 0): positions into their row's slots, ascending
   uint8_t* single = (side_b || a.flags_done) ? nullptr : a.single_a;
@@ -635,6 +645,11 @@ __global__ __launch_bounds__(kBucketThreads) void plan_bucket_kernel(PlanArgs a)
       }
     }
   }
+#ifdef RC_X_TIMING
+  if ((bkt == 5 || bkt == 700) && lane == 0)
+    printf("plan_bucket<%d> bkt %u: %u keys; ticks (100 MHz): zero+count %llu scan+rows %llu ordered pass %llu\n", (int)WIDE, bkt, end - beg,
+           (unsigned long long)(tq[1] - tq[0]), (unsigned long long)(tq[2] - tq[1]), (unsigned long long)(wall_clock64() - tq[2]));
+#endif
 }
 
 // ---- 4h. hashed geometry: one workgroup per bucket, the bucket's ids grouped through an LDS hash table ---------------
