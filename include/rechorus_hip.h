@@ -305,6 +305,19 @@ int rc_segmented_update_rows(float* W, float* m, float* v, int d, int64_t n_rows
                              const int64_t* src_index, int div, const float* src2, int64_t n_split,
                              const rc_opt_hyper* h, float* dense_grad, void* ws, size_t ws_bytes, rc_stream_t stream);
 
+/* aten::embedding_dense_backward for a SMALL id list (n <= 32,768; helpers/BaseRunner.py:205 behind loss.backward() at the
+ * reference's own batch sizes: 1,024 rows x 8 fields of a CTR step -- models/context/FM.py:49-52 --, 256 x (1 + K) candidates)
+ * in TWO launches: 128 workgroups group the ids by row in LDS, one lane-group per touched row sums the gradient rows of its
+ * occurrences in ascending position (no float atomics): out[ids[o], :] += ... i.e. out[r, :] = sum over o with ids[o] = r of
+ * src[o, :] for every r that occurs; other rows of `out` are left as they are (the caller zero-fills).
+ * d in {1..4, 16, 32, 64, 128}; src / out 16-byte aligned for d >= 16.  A plan workgroup's buffers hold 8,192 keys: a list
+ * of up to 8,192 ids is grouped in LDS whatever its skew; beyond that a workgroup that owns more than 8,192 keys (one row with
+ * a quarter of the list) selects its rows one by one -- correct, slow (the engine keeps such lists on the sort route).     */
+int rc_small_row_sums_supported(int64_t n, int64_t n_rows, int d);
+size_t rc_small_row_sums_workspace_bytes(int64_t n);
+int rc_small_row_sums(const int64_t* ids, int64_t n, int64_t n_rows, const float* src, int d, float* out, void* ws,
+                      size_t ws_bytes, rc_stream_t stream);
+
 /* ---- SASRec encoder (models/sequential/SASRec.py:51-86, utils/layers.py:9-63,92-118) ------- */
 
 /* Two tables that share their ids (NeuMF's mf / mlp embedding of a user or an item, models/general/NeuMF.py:37-40)

@@ -25,8 +25,15 @@ constexpr int kSmallPlanWgs = 128;         // power of two (owner = key & 127): 
 constexpr int kSmallMaxKeys = 32768;       // positions fit 15 bits
 constexpr int kSmallWaveCap = 256;         // LDS entries per wave region
 constexpr int kSmallCap = 2048;            // entries the sort buffer holds
-constexpr size_t kSmallLdsBytes = ((size_t)kSmallWaves * kSmallWaveCap + kSmallCap) * sizeof(uint64_t) +
-                                  ((size_t)kSmallCap + 2) * sizeof(uint16_t) + 64 * sizeof(uint32_t);
+constexpr size_t small_lds_bytes(int cap, int wave_cap) {
+  return ((size_t)kSmallWaves * wave_cap + cap) * sizeof(uint64_t) + ((size_t)cap + 2) * sizeof(uint16_t) + 64 * sizeof(uint32_t);
+}
+constexpr size_t kSmallLdsBytes = small_lds_bytes(kSmallCap, kSmallWaveCap);
+// the plan-only launch (rc_small_row_sums: no fused workgroups share the launch, one plan workgroup per CU at most) can afford
+// buffers that hold EVERY key of a list of up to 8,192 ids in one workgroup: such a list can never overflow, whatever its skew
+// (a sequence model's padding id collects most of a batch's history slots)
+constexpr int kSmallCapBig = 8192, kSmallWaveCapBig = 1024;
+constexpr size_t kSmallLdsBytesBig = small_lds_bytes(kSmallCapBig, kSmallWaveCapBig);
 
 struct SmallCnt { uint32_t rows_a, rows_b, occ, pad; };   // per plan workgroup
 
@@ -50,8 +57,10 @@ __device__ __forceinline__ uint32_t small_key(const SmallPlanArgs& a, uint32_t p
   return p < a.n_a ? (uint32_t)a.ids_a[p] : a.base_b + (uint32_t)a.ids_b[p - a.n_a];
 }
 
-// one plan workgroup (blockDim = kSmallThreads); smem: kSmallLdsBytes of dynamic LDS
+// one plan workgroup (blockDim = kSmallThreads); smem: small_lds_bytes(CAP, WCAP) of dynamic LDS
+template <int CAP = kSmallCap, int WCAP = kSmallWaveCap>
 __device__ __forceinline__ void small_plan_block(const SmallPlanArgs& a, uint32_t w, unsigned char* smem) {
+  constexpr int kSmallCap = CAP, kSmallWaveCap = WCAP;   // (shadow the defaults below)
   uint64_t* region = reinterpret_cast<uint64_t*>(smem);                       // [kSmallWaves][kSmallWaveCap]
   uint64_t* buf = region + (size_t)kSmallWaves * kSmallWaveCap;               // [kSmallCap]
   uint16_t* hl = reinterpret_cast<uint16_t*>(buf + kSmallCap);                // [kSmallCap + 2] head positions

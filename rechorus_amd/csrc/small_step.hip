@@ -188,6 +188,140 @@ static int small_update_launch_d(const SmallUpdArgs& a, int mode, hipStream_t s)
   return RC_OK;
 }
 
+// ---- aten::embedding_dense_backward for a SMALL id list (<= 32,768 ids) in two launches ---------------------------------
+// The dense gradient of an embedding table (helpers/BaseRunner.py:205 behind loss.backward(): zero-fill + index_add of
+// every occurrence's gradient row) at the reference's own batch sizes -- 1,024 rows x 8 fields of a CTR step, 256 x
+// (1 + K) candidates -- went through the radix sort + head list + chunk planning: 15-20 dependent launches of a few
+// microseconds for a few thousand ids (a third of the replayed DeepFM step).  Here the 128 plan workgroups of
+// small_plan.hpp group the ids (launch 1) and one lane-group per touched row sums its occurrences' gradient rows in
+// ascending position (launch 2); rows past 32 occurrences by a whole wave with a fixed butterfly.  No atomics, no
+// counters to zero, deterministic.  d in {16, 32, 64, 128}; d <= 4 (the [vocab, 1] first-order tables of the FM family):
+// one wave per row, lanes stride over the occurrences.
+__global__ __launch_bounds__(kSmallThreads) void small_plan_kernel(SmallPlanArgs plan) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char small_plan_smem[];
+  small_plan_block<kSmallCapBig, kSmallWaveCapBig>(plan, blockIdx.x, small_plan_smem);
+}
+
+struct SmallSumArgs {
+  const rc_plan_row* rows;   // [kSmallPlanWgs][n]
+  const uint32_t* occ;       // [kSmallPlanWgs][n]
+  const SmallCnt* cnt;
+  uint32_t n;
+  const float* src;          // [n, d] gradient row of every occurrence
+  float* out;                // [n_rows, d]; only touched rows are written
+  int d;
+};
+
+// flat row index -> record (rows of plan workgroup w are the w-th segment; per-workgroup counts prefix-summed here)
+struct SmallRowIndex {
+  uint32_t pre[kSmallPlanWgs + 1];
+};
+__device__ __forceinline__ void small_row_prefix(const SmallCnt* cnt, SmallRowIndex* ix, uint32_t* wsum) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  uint32_t c = tid < kSmallPlanWgs ? cnt[tid].rows_a : 0u, x = c;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t y = __shfl_up(x, off, 64);
+    if (lane >= off) x += y;
+  }
+  if (lane == 63) wsum[tid >> 6] = x;
+  __syncthreads();
+  for (int q = 0; q < (tid >> 6); ++q) x += wsum[q];
+  if (tid < kSmallPlanWgs) ix->pre[tid] = x - c;
+  if (tid == kSmallPlanWgs - 1) ix->pre[kSmallPlanWgs] = x;
+  __syncthreads();
+}
+__device__ __forceinline__ rc_plan_row small_row_at(const SmallSumArgs& a, const SmallRowIndex& ix, uint32_t q) {
+  int lo = 0, hi = kSmallPlanWgs;   // last w with pre[w] <= q
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (ix.pre[mid] <= q) lo = mid; else hi = mid;
+  }
+  return a.rows[(size_t)lo * a.n + (q - ix.pre[lo])];
+}
+
+template <int D>
+__global__ __launch_bounds__(kBlock) void small_row_sums_kernel(SmallSumArgs a) {
+  constexpr int LPR = D / 4;
+  constexpr int GPW = 64 / LPR;
+  __shared__ SmallRowIndex ix;
+  __shared__ uint32_t wsum[8];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int l = lane % LPR, grp = lane / LPR;
+  small_row_prefix(a.cnt, &ix, wsum);
+  const uint32_t R = ix.pre[kSmallPlanWgs];
+  const uint32_t n_waves = gridDim.x * (kBlock / 64);
+  const uint32_t wave = blockIdx.x * (kBlock / 64) + (tid >> 6);
+  const float4* src4 = reinterpret_cast<const float4*>(a.src);
+  for (uint32_t r0 = wave * GPW; r0 < R; r0 += n_waves * GPW) {
+    const uint32_t r = r0 + grp;
+    const bool on = r < R;
+    rc_plan_row e;
+    e.row = 0; e.start = 0; e.n = 0; e.reserved = 0;
+    if (on) e = small_row_at(a, ix, r);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool seq = on && e.n <= (uint32_t)kSmallSeq;
+    if (seq) {
+      acc = src4[(size_t)e.reserved * LPR + l];   // the record carries the row's first position
+      for (uint32_t k = 1; k < e.n; ++k) padd4s(acc, src4[(size_t)a.occ[e.start + k] * LPR + l]);
+    }
+    uint64_t hot = __ballot(on && !seq && l == 0);   // hot rows of this wave's groups, one after the other, by the whole wave
+    while (hot) {
+      const int srcl = __ffsll((long long)hot) - 1;
+      hot &= hot - 1;
+      const uint32_t hs = __shfl(e.start, srcl, 64), hn = __shfl(e.n, srcl, 64);
+      // four occurrences in flight per lane-group (fixed pattern -> fixed order): the chain occ[] -> gradient row is two dependent
+      // loads per trip, and a CTR field of a few values makes rows of hundreds of occurrences at B = 1,024
+      float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), p1 = p0, p2 = p0, p3 = p0;
+      for (uint32_t k = grp; k < hn; k += 4 * GPW) {
+        const uint32_t o0 = a.occ[hs + k];
+        const uint32_t o1 = k + GPW < hn ? a.occ[hs + k + GPW] : 0u;
+        const uint32_t o2 = k + 2 * GPW < hn ? a.occ[hs + k + 2 * GPW] : 0u;
+        const uint32_t o3 = k + 3 * GPW < hn ? a.occ[hs + k + 3 * GPW] : 0u;
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 v0 = src4[(size_t)o0 * LPR + l];
+        const float4 v1 = k + GPW < hn ? src4[(size_t)o1 * LPR + l] : z;
+        const float4 v2 = k + 2 * GPW < hn ? src4[(size_t)o2 * LPR + l] : z;
+        const float4 v3 = k + 3 * GPW < hn ? src4[(size_t)o3 * LPR + l] : z;
+        padd4s(p0, v0); padd4s(p1, v1); padd4s(p2, v2); padd4s(p3, v3);
+      }
+      padd4s(p0, p1); padd4s(p2, p3); padd4s(p0, p2);
+      float4 part = p0;
+      part.x = groups_allreduce_sum<LPR, 64>(part.x);
+      part.y = groups_allreduce_sum<LPR, 64>(part.y);
+      part.z = groups_allreduce_sum<LPR, 64>(part.z);
+      part.w = groups_allreduce_sum<LPR, 64>(part.w);
+      if (lane / LPR == srcl / LPR) acc = part;
+    }
+    if (on) reinterpret_cast<float4*>(a.out)[(size_t)e.row * LPR + l] = acc;
+  }
+}
+
+// d <= 4: one wave per row, lane k takes occurrences k, k + 64, ... (ascending), a fixed butterfly combines the lanes
+__global__ __launch_bounds__(kBlock) void small_row_sums_narrow_kernel(SmallSumArgs a) {
+  __shared__ SmallRowIndex ix;
+  __shared__ uint32_t wsum[8];
+  const int tid = threadIdx.x, lane = tid & 63;
+  small_row_prefix(a.cnt, &ix, wsum);
+  const uint32_t R = ix.pre[kSmallPlanWgs];
+  const uint32_t n_waves = gridDim.x * (kBlock / 64);
+  for (uint32_t r = blockIdx.x * (kBlock / 64) + (tid >> 6); r < R; r += n_waves) {
+    const rc_plan_row e = small_row_at(a, ix, r);
+    float part[4] = {0.f, 0.f, 0.f, 0.f};
+    for (uint32_t k = lane; k < e.n; k += 64) {
+      const float* sp = a.src + (size_t)a.occ[e.start + k] * a.d;
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (c < a.d) part[c] += sp[c];
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float t = wave_allreduce_sum(part[c]);
+      if (c < a.d && lane == c) a.out[(size_t)e.row * a.d + c] = t;
+    }
+  }
+}
+
 // workspace of the small-batch step beyond gpred / ugrad / loss_vec
 size_t small_step_extra_bytes(int64_t n, int64_t B, int d) {
   size_t t = 0;
@@ -238,3 +372,64 @@ int small_step_launch(float* U, float* I, float* mU, float* vU, float* mI, float
 }
 
 }  // namespace rc
+
+using namespace rc;
+
+extern "C" int rc_small_row_sums_supported(int64_t n, int64_t n_rows, int d) {
+  return (n >= 1 && n <= kSmallMaxKeys && n_rows >= 1 && n_rows < ((int64_t)1 << 32) - 1 &&
+          ((d >= 1 && d <= 4) || d == 16 || d == 32 || d == 64 || d == 128)) ? 1 : 0;
+}
+
+extern "C" size_t rc_small_row_sums_workspace_bytes(int64_t n) {
+  if (n < 1) n = 1;
+  return align_up((size_t)kSmallPlanWgs * (size_t)n * sizeof(rc_plan_row), 256) +
+         align_up((size_t)kSmallPlanWgs * (size_t)n * sizeof(uint32_t), 256) + align_up((size_t)kSmallPlanWgs * sizeof(SmallCnt), 256);
+}
+
+extern "C" int rc_small_row_sums(const int64_t* ids, int64_t n, int64_t n_rows, const float* src, int d, float* out, void* ws,
+                                 size_t ws_bytes, rc_stream_t stream) {
+  if (n == 0) return RC_OK;
+  RC_REQUIRE(ids && src && out && ws, "rc_small_row_sums: null pointer");
+  if (!rc_small_row_sums_supported(n, n_rows, d))
+    return fail(RC_ERR_UNSUPPORTED, "rc_small_row_sums: n=%lld (<= %d), n_rows=%lld, d=%d (1..4, 16, 32, 64, 128) not covered",
+                (long long)n, kSmallMaxKeys, (long long)n_rows, d);
+  if (ws_bytes < rc_small_row_sums_workspace_bytes(n))
+    return fail(RC_ERR_WORKSPACE, "rc_small_row_sums: workspace %zu < %zu", ws_bytes, rc_small_row_sums_workspace_bytes(n));
+  RC_REQUIRE(d <= 4 || (reinterpret_cast<uintptr_t>(src) % 16 == 0 && reinterpret_cast<uintptr_t>(out) % 16 == 0),
+             "rc_small_row_sums: src / out must be 16-byte aligned");
+  hipStream_t s = as_stream(stream);
+  Carver cv(ws);
+  rc_plan_row* rows = cv.take<rc_plan_row>((size_t)kSmallPlanWgs * (size_t)n);
+  uint32_t* occ = cv.take<uint32_t>((size_t)kSmallPlanWgs * (size_t)n);
+  SmallCnt* cnt = cv.take<SmallCnt>(kSmallPlanWgs);
+  SmallPlanArgs p;
+  memset(&p, 0, sizeof(p));
+  p.ids_a = ids; p.ids_b = nullptr; p.n_a = (uint32_t)n; p.n = (uint32_t)n; p.base_b = 0xFFFFFFFFu;   // one list: every key is a row of it
+  p.rows = rows; p.occ = occ; p.cnt = cnt;
+  static bool attr_done = false;
+  if (!attr_done) {
+    RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(small_plan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSmallLdsBytesBig));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(small_plan_kernel, dim3(kSmallPlanWgs), dim3(kSmallThreads), kSmallLdsBytesBig, s, p);
+  RC_LAUNCH_CHECK();
+  SmallSumArgs a;
+  a.rows = rows; a.occ = occ; a.cnt = cnt; a.n = (uint32_t)n; a.src = src; a.out = out; a.d = d;
+  if (d <= 4) {
+    unsigned blocks = (unsigned)((n + kBlock / 64 - 1) / (kBlock / 64));
+    if (blocks > 1024u) blocks = 1024u;
+    hipLaunchKernelGGL(small_row_sums_narrow_kernel, dim3(blocks), dim3(kBlock), 0, s, a);
+  } else {
+    const int gpb = kBlock / (d / 4);
+    unsigned blocks = (unsigned)((n + gpb - 1) / gpb);
+    if (blocks > 2048u) blocks = 2048u;
+    switch (d) {
+      case 16: hipLaunchKernelGGL((small_row_sums_kernel<16>), dim3(blocks), dim3(kBlock), 0, s, a); break;
+      case 32: hipLaunchKernelGGL((small_row_sums_kernel<32>), dim3(blocks), dim3(kBlock), 0, s, a); break;
+      case 64: hipLaunchKernelGGL((small_row_sums_kernel<64>), dim3(blocks), dim3(kBlock), 0, s, a); break;
+      default: hipLaunchKernelGGL((small_row_sums_kernel<128>), dim3(blocks), dim3(kBlock), 0, s, a); break;
+    }
+  }
+  RC_LAUNCH_CHECK();
+  return RC_OK;
+}

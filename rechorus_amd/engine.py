@@ -388,6 +388,8 @@ def segmented_pair_supported(d):
 
 
 _EDB_PLAN_MIN = int(os.environ.get("RC_EDB_PLAN_MIN", "8192"))
+_EDB_SMALL = os.environ.get("RC_EDB_SMALL", "1") != "0"   # embedding_dense_backward of a small id list: rc_small_row_sums
+_EDB_SMALL_MAX = int(os.environ.get("RC_EDB_SMALL_MAX", "8192"))
 # A/B switches: RC_TABLE_UPDATE=sort puts every trainer's table update behind the radix sort, =plan behind the bucket plan.
 # Default: NeuMF on the plan (hashed buckets: 0.33 M lookups over 10 M - 100 M rows); SASRec behind the sort -- 0.6 M
 # occurrences over 8.7 K rows are all hot rows, where the sort-driven update measured faster (table_update 0.27 ms against
@@ -424,6 +426,17 @@ def embedding_dense_backward(grad_out, ids, n_rows, route=None):
     if flat.numel() == 0:
         return G
     go = grad_out.reshape(-1, d).contiguous()
+    # route="small": a small id list WITHOUT very hot rows (the reference's own batch sizes: user / candidate ids, the fields of a
+    # CTR row) in two launches -- 128 workgroups group the ids in LDS, one lane-group per touched row sums its occurrences
+    # (rc_small_row_sums).  Up to 8,192 ids a plan workgroup's buffers hold the whole list, so the grouping cannot leave LDS; a row
+    # with thousands of occurrences (the padding id of a padded history: measured 0.27 against 0.11 s per SASRec epoch) is still
+    # summed by ONE wave there, which is why the caller has to ask for this route
+    n_ids = flat.numel()
+    if route == "small" and _EDB_SMALL and n_ids <= _EDB_SMALL_MAX and _lib.load().rc_small_row_sums_supported(n_ids, int(n_rows), d):
+        ws = workspace(_lib.load().rc_small_row_sums_workspace_bytes(n_ids), go.device, "edb_small")
+        _lib.call("rc_small_row_sums", _ptr(flat, torch.int64, "ids"), n_ids, int(n_rows), _ptr(go, torch.float32, "grad_out"), d,
+                  _ptr(G, torch.float32, "G"), C.c_void_p(ws.data_ptr()), ws.numel(), _stream())
+        return G
     # (below a few thousand ids both routes are a handful of latency-bound launches; the plan pays off with the batch)
     # route="sort": id lists with very hot rows (the categorical fields of the CTR models: 131,072 occurrences of 7 weekdays) --
     # a plan bucket counts its ids with LDS atomics, which such a row serialises (15.8 ms per DeepFM step at B = 131,072)

@@ -27,7 +27,11 @@ class _EmbeddingFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         (ids,) = ctx.saved_tensors
-        g = engine.embedding_dense_backward(grad_out.contiguous(), ids, ctx.n_rows)
+        # a [B] or [B, <= 2] id tensor is a user / candidate list (the reference's default --num_neg 1): a row repeats only by
+        # popularity, the two-launch small route fits.  A wider one may be a padded history window, whose padding id collects
+        # thousands of occurrences: those keep the plan / sort routes
+        route = "small" if (ids.dim() <= 1 or ids.shape[-1] <= 2) else None
+        g = engine.embedding_dense_backward(grad_out.contiguous(), ids, ctx.n_rows, route=route)
         return g, None
 
 
@@ -187,7 +191,8 @@ class _FieldGatherFn(torch.autograd.Function):
         ctx.cid, ctx.offs = cid, offs
         # a field whose vocabulary is small against the batch makes hot rows: the sort-driven reduction handles any skew
         n_ids = cid.numel() // max(1, n_fields)
-        ctx.route = "sort" if min(t.shape[0] for t in tables) * 8 <= n_ids else None
+        # (a field value occurs at most once per row: up to 8,192 ids in all the small route fits whatever the vocabularies)
+        ctx.route = "small" if cid.numel() <= 8192 else ("sort" if min(t.shape[0] for t in tables) * 8 <= n_ids else None)
         return out
 
     @staticmethod

@@ -510,6 +510,41 @@ def test_plan_row_sums_and_distinct(case, d, cuda, eng):
         assert torch.equal(G, G2)
 
 
+@pytest.mark.parametrize("n,n_rows,d,hot", [(8192, 279_000, 64, 0), (8192, 279_000, 1, 0), (25_600, 8_714, 64, 0), (1, 5, 16, 0),
+                                             (32_768, 1_000_000, 128, 0), (3000, 50, 32, 0), (8000, 300, 64, 6000), (8192, 40, 1, 7000),
+                                             (777, 1000, 3, 0), (5632, 8_714, 64, 3300)])
+def test_small_embedding_dense_backward(n, n_rows, d, hot, cuda, eng, monkeypatch):
+    """embedding_dense_backward of a small id list (rc_small_row_sums: the small-batch plan workgroups + one lane-group per touched
+    row) against a float64 index_add and the radix-sort route: CTR-sized and candidate-sized lists, the [vocab, 1] first-order
+    tables, a table of 50 rows (every row hot), one row with thousands of occurrences (a plan workgroup past its LDS budget)"""
+    rng = np.random.default_rng(n + d)
+    ids = rng.integers(0, n_rows, size=n).astype(np.int64)
+    if hot:
+        ids[rng.permutation(n)[:hot]] = n_rows // 2
+    src = rng.normal(size=(n, d)).astype(np.float32)
+    want = np.zeros((n_rows, d), np.float64)
+    np.add.at(want, ids, src.astype(np.float64))
+    ids_d, src_d = torch.from_numpy(ids).to(cuda), torch.from_numpy(src).to(cuda)
+    out = {}
+    for small in (True, False, True):
+        monkeypatch.setattr(eng, "_EDB_SMALL", small)
+        monkeypatch.setattr(eng, "_EDB_SMALL_MAX", 32768)   # (the engine's default keeps lists past 8,192 ids on the plan / sort routes)
+        G = eng.embedding_dense_backward(src_d, ids_d, n_rows, route="small" if small else ("sort" if hot else None))
+        torch.cuda.synchronize()
+        if small in out:
+            assert torch.equal(G, out[small]), "not reproducible"
+        out[small] = G
+    got = out[True].cpu().numpy()
+    cnt = np.bincount(ids, minlength=n_rows)
+    tol = 1e-6 * np.sqrt(np.maximum(cnt, 1))[:, None] * np.abs(src).max() * 4 + 1e-6
+    assert np.all(np.abs(got - want) <= tol + 1e-6 * np.abs(want))
+    assert np.all(got[cnt == 0] == 0)
+    if hot == 0 and d >= 16 and cnt.max() <= 32:
+        assert torch.equal(out[True], out[False])   # both routes sum a row's occurrences in ascending position
+    else:
+        assert np.all(np.abs(got - out[False].cpu().numpy()) <= 2 * tol)
+
+
 def test_neumf_trainer_plan_on_second_stream_equals_one_stream(cuda, eng, monkeypatch):
     """NeumfTrainer builds the batch's bucket plan on a second stream beside the head kernels (large batches); same kernels, same
     inputs: three row-wise Adam steps leave every table, dense parameter and optimizer state bit-identical to the one-stream order"""
