@@ -1185,9 +1185,7 @@ __global__ __launch_bounds__(kBlock) void sb_wgrad_kernel(SbWgradArgs a) {
   for (int s = 0; s < QPW; ++s)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
-  float bsum[NP];
-#pragma unroll
-  for (int p = 0; p < NP; ++p) bsum[p] = 0.f;
+  float bsum = 0.f;   // thread t < NP * D: db of pair t / D, column t % D (one wave per pair: the column sums of a tile do not pile up on wave 0)
 
   // the next tile's rows (X and the NP dY's) are requested while the current tile is multiplied
   constexpr int PF = kSbTile * (D / 4) / kBlock;
@@ -1245,13 +1243,11 @@ __global__ __launch_bounds__(kBlock) void sb_wgrad_kernel(SbWgradArgs a) {
         }
       }
     }
-    if ((int)threadIdx.x < D) {  // bias: column sums of dY, rows in ascending order
-#pragma unroll
-      for (int p = 0; p < NP; ++p) {
-        float t = 0.f;
-        for (int i = 0; i < m; ++i) t += Ys[(p * kSbTile + i) * SD + threadIdx.x];
-        bsum[p] += t;
-      }
+    if ((int)threadIdx.x < NP * D) {  // bias: column sums of dY, rows in ascending order
+      const int p = threadIdx.x / D, c = threadIdx.x % D;
+      float t = 0.f;
+      for (int i = 0; i < m; ++i) t += Ys[(p * kSbTile + i) * SD + c];
+      bsum += t;
     }
   }
 #pragma unroll
@@ -1268,9 +1264,7 @@ __global__ __launch_bounds__(kBlock) void sb_wgrad_kernel(SbWgradArgs a) {
       }
     }
   }
-  if ((int)threadIdx.x < D)
-#pragma unroll
-    for (int p = 0; p < NP; ++p) (a.gb[p] + (size_t)blockIdx.x * a.part_stride)[threadIdx.x] = bsum[p];
+  if ((int)threadIdx.x < NP * D) (a.gb[threadIdx.x / D] + (size_t)blockIdx.x * a.part_stride)[threadIdx.x % D] = bsum;
 }
 
 // ---- backward of the post-attention half in ONE row-space kernel -------------------------------------------------------
@@ -1454,9 +1448,9 @@ __global__ __launch_bounds__(kBlock) void sb_block_bwd_kernel(SbBlockBwdArgs a) 
         }
       }
     }
-    if ((int)threadIdx.x < D) {
+    if ((int)threadIdx.x >= D && (int)threadIdx.x < 2 * D) {   // (the second wave: db2's sums are the first wave's)
       float t = 0.f;
-      for (int i = 0; i < m; ++i) t += Hs[i * SD + threadIdx.x];
+      for (int i = 0; i < m; ++i) t += Hs[i * SD + threadIdx.x - D];
       bsum1 += t;
     }
     // ---- 5. dY1 = dHpre . W1 + dZ2 (the residual path), into Gs (step 4 reads Hs / Ys only: no barrier needed before)
@@ -1509,10 +1503,8 @@ __global__ __launch_bounds__(kBlock) void sb_block_bwd_kernel(SbBlockBwdArgs a) 
       }
     }
   }
-  if ((int)threadIdx.x < D) {
-    out[Cfg::ob2 + threadIdx.x] = bsum2;
-    out[Cfg::ob1 + threadIdx.x] = bsum1;
-  }
+  if ((int)threadIdx.x < D) out[Cfg::ob2 + threadIdx.x] = bsum2;
+  else if ((int)threadIdx.x < 2 * D) out[Cfg::ob1 + threadIdx.x - D] = bsum1;
   // LayerNorm weight / bias partials: lane-group accumulators combined over the groups in a fixed order through LDS
   __syncthreads();
   float* red = Gs;  // [4][GPB][SD] floats: 4 * 16 * 65 <= 2 tiles
