@@ -122,18 +122,30 @@ __device__ __forceinline__ void mlp_stage(float* tile, const MlpOperand& o, cons
 // 3,500 shader cycles per K step against 1,024 of MFMA work.  A thread's float4 of consecutive K steps lies a constant stride
 // apart, so its address and its range class are fixed before the loop: 0 = outside the matrix (always zero), 1 = one aligned
 // float4 whenever the K step is complete, 2 = edge / unaligned (the generic loader).
+// 3 = four columns past the matrix: a constant (zeros, or the 1 of the column of ones that carries the bias gradient -- the tile
+// that holds nothing but that column ran the generic loader for every float4 and set the duration of every weight-gradient
+// product: 20-25 us instead of ~9 at B = 1,024).
 struct MlpFastSrc {
   const float* p;
   int mode;
+  float4 cst;
 };
-__device__ __forceinline__ MlpFastSrc mlp_fast_src(const MlpOperand& o, int64_t outer, int64_t outer_n, int64_t k, bool vec_ok) {
+__device__ __forceinline__ MlpFastSrc mlp_fast_src(const MlpOperand& o, int64_t outer, int64_t outer_n, int64_t k, bool vec_ok,
+                                                   int ones_col = -1) {
   MlpFastSrc f;
+  f.cst = make_float4(0.f, 0.f, 0.f, 0.f);
   if (o.k_major) {   // thread's float4 runs along k
     f.p = o.p + outer * o.ld + k;
     f.mode = outer >= outer_n ? 0 : (vec_ok ? 1 : 2);
   } else {           // along outer, four columns outer .. outer + 3 of row k
     f.p = o.p + k * o.ld + outer;
-    f.mode = (vec_ok && outer + 3 < outer_n) ? 1 : 2;
+    if (outer >= outer_n) {
+      f.mode = 3;
+      f.cst = make_float4(outer == ones_col ? 1.f : 0.f, outer + 1 == ones_col ? 1.f : 0.f, outer + 2 == ones_col ? 1.f : 0.f,
+                          outer + 3 == ones_col ? 1.f : 0.f);
+    } else {
+      f.mode = (vec_ok && outer + 3 < outer_n) ? 1 : 2;
+    }
   }
   return f;
 }
@@ -195,7 +207,7 @@ __global__ __launch_bounds__(kBlock) void mlp_gemm_kernel(MlpGemm g, int vec_a, 
       fa[q] = g.A.k_major ? mlp_fast_src(g.A, m0 + (t >> 2), g.M, kb + 4 * (t & 3) + q * kMlpSub, vec_a != 0)
                           : mlp_fast_src(g.A, m0 + 4 * (t & 15), g.M, kb + (t >> 4) + q * kMlpSub, vec_a != 0);
       fb[q] = g.B.k_major ? mlp_fast_src(g.B, n0 + (t >> 2), bn, kb + 4 * (t & 3) + q * kMlpSub, vec_b != 0)
-                          : mlp_fast_src(g.B, n0 + 4 * (t & 15), bn, kb + (t >> 4) + q * kMlpSub, vec_b != 0);
+                          : mlp_fast_src(g.B, n0 + 4 * (t & 15), bn, kb + (t >> 4) + q * kMlpSub, vec_b != 0, g.ones_col);
     }
   }
   const int64_t stride_a = g.A.k_major ? (int64_t)kMlpBK : (int64_t)kMlpBK * g.A.ld;
@@ -204,15 +216,15 @@ __global__ __launch_bounds__(kBlock) void mlp_gemm_kernel(MlpGemm g, int vec_a, 
   // interior tile: every thread's float4s are plain aligned loads -- ONE uniform branch per K step instead of per-lane classes
   bool mine_fast = true;
 #pragma unroll
-  for (int q = 0; q < NP; ++q) mine_fast = mine_fast && fa[q].mode == 1 && fb[q].mode == 1;
+  for (int q = 0; q < NP; ++q) mine_fast = mine_fast && fa[q].mode != 2 && fb[q].mode != 2;
   const bool all_fast = __syncthreads_and(mine_fast ? 1 : 0) != 0;
   auto fetch = [&](float4 (&va)[NP], float4 (&vb)[NP], int64_t k0, int64_t off_a, int64_t off_b) {
     const bool full = k0 + kMlpBK <= ke;   // workgroup-uniform
     if (all_fast && full) {
 #pragma unroll
       for (int q = 0; q < NP; ++q) {
-        va[q] = *reinterpret_cast<const float4*>(fa[q].p + off_a);
-        vb[q] = *reinterpret_cast<const float4*>(fb[q].p + off_b);
+        va[q] = fa[q].mode == 1 ? *reinterpret_cast<const float4*>(fa[q].p + off_a) : fa[q].cst;
+        vb[q] = fb[q].mode == 1 ? *reinterpret_cast<const float4*>(fb[q].p + off_b) : fb[q].cst;
       }
       return;
     }
@@ -405,19 +417,19 @@ __global__ __launch_bounds__(kBlock) void mlp_gemm_big_kernel(MlpGemm g, int vec
       fa[q] = g.A.k_major ? mlp_fast_src(g.A, m0 + (t >> 2) + 64 * q, g.M, kb + 4 * (t & 3), vec_a != 0)
                           : mlp_fast_src(g.A, m0 + 4 * (t & 31), g.M, kb + (t >> 5) + 8 * q, vec_a != 0);
       fb[q] = g.B.k_major ? mlp_fast_src(g.B, n0 + (t >> 2) + 64 * q, bn, kb + 4 * (t & 3), vec_b != 0)
-                          : mlp_fast_src(g.B, n0 + 4 * (t & 31), bn, kb + (t >> 5) + 8 * q, vec_b != 0);
+                          : mlp_fast_src(g.B, n0 + 4 * (t & 31), bn, kb + (t >> 5) + 8 * q, vec_b != 0, g.ones_col);
     }
   }
   const int64_t stride_a = g.A.k_major ? (int64_t)kBigBK : (int64_t)kBigBK * g.A.ld;
   const int64_t stride_b = g.B.k_major ? (int64_t)kBigBK : (int64_t)kBigBK * g.B.ld;
-  const bool all_fast = __syncthreads_and((fa[0].mode == 1 && fa[1].mode == 1 && fb[0].mode == 1 && fb[1].mode == 1) ? 1 : 0) != 0;
+  const bool all_fast = __syncthreads_and((fa[0].mode != 2 && fa[1].mode != 2 && fb[0].mode != 2 && fb[1].mode != 2) ? 1 : 0) != 0;
   auto fetch = [&](int64_t k0, int64_t off_a, int64_t off_b) {
     const bool full = k0 + kBigBK <= ke;   // workgroup-uniform
     if (all_fast && full) {
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
-        ra[q] = *reinterpret_cast<const float4*>(fa[q].p + off_a);
-        rb[q] = *reinterpret_cast<const float4*>(fb[q].p + off_b);
+        ra[q] = fa[q].mode == 1 ? *reinterpret_cast<const float4*>(fa[q].p + off_a) : fa[q].cst;
+        rb[q] = fb[q].mode == 1 ? *reinterpret_cast<const float4*>(fb[q].p + off_b) : fb[q].cst;
       }
       return;
     }
