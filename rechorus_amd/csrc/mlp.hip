@@ -26,7 +26,9 @@ typedef float mlp_f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kMlpBM = 64, kMlpBN = 64, kMlpBK = 32, kMlpLD = 68;   // (K step 16: 22.8 us per GEMM at B = 1024 -- one L2 round trip per 8 MFMAs)
 constexpr int kMlpSub = 16;   // k rows one pass of the loaders covers; a K step is kMlpBK / kMlpSub passes
 constexpr int kMlpPD = 3;     // K steps in flight between global memory and LDS (register ring)
-// (tried and dropped, round 3: the operands of step s + 1 read from LDS into a second register set before the MFMAs of step s --
+// (tried and dropped, round 3: reduction-major operands transposed while they are staged so that every operand fetch is a
+//  ds_read_b128: 5.14 instead of 4.82 ms per DeepFM step at B = 131,072 -- the four strided ds_write_b32 cost more than the reads save;
+//  the operands of step s + 1 read from LDS into a second register set before the MFMAs of step s --
 //  2,090 instead of 1,890 cycles per K step, the compiler drains the reads before the first MFMA either way; two accumulator
 //  chains instead of one: no change, the dependent-issue gap is not what the step waits for)
 
