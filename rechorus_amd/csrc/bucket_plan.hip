@@ -540,6 +540,15 @@ __global__ __launch_bounds__(kBucketThreads) void plan_bucket_kernel(PlanArgs a)
 #ifdef RC_X_TIMING
   tq[1] = wall_clock64();
 #endif
+  if (a.bitmap_in_bucket && a.bitmap_a && bkt < a.g.nb_a) {   // block-uniform; same words as plan_bitmap_kernel
+    uint32_t* out = a.bitmap_a + ((size_t)bkt << (shift - 5));
+    for (uint32_t wd = tid; wd < (ids >> 5); wd += kBucketThreads) {
+      uint32_t bits = 0;
+#pragma unroll 8
+      for (uint32_t j = 0; j < 32; ++j) bits |= (cells.get(wd * 32 + j) >= 2u ? 1u : 0u) << j;
+      out[wd] = bits;
+    }
+  }
 
   // scan: counts -> cursors (listed rows) / marker (rows that are only flagged); row records
   uint32_t my_occ = 0, my_rows = 0;

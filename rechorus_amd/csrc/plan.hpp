@@ -91,6 +91,9 @@ struct PlanArgs {
   // reduce their chunks in the SAME launch as the short rows (plan_update.hip, BPRMF step); otherwise the row-update
   // kernel finds them while it walks the records
   int emit_long;
+  // the bucket kernel writes bitmap_a itself (it holds every id's count after its first pass): a plan that is prepared as a
+  // whole -- the look-ahead plan of the next batch -- needs no separate bitmap launch (a second zero + count pass per bucket)
+  int bitmap_in_bucket;
   PlanLongWs lw;
 };
 int plan_launch(const PlanArgs& a, hipStream_t s, hipEvent_t* ev_after_scatter);

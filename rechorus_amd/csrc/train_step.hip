@@ -82,6 +82,13 @@ StepSide* step_side(int* device_out = nullptr) {
 // latency-bound kernels stretches about 2.5 x beside the bandwidth-bound row kernels and needs the whole step as its
 // window -- 0.988 -> 0.945 ms/step at config 2, profiles/r03d_ab_overlap.txt), 0 = behind the fused kernel (beside this
 // step's row updates only); RC_AHEAD_FORK=late selects 0
+bool ahead_bitmap_in_bucket() {   // RC_AHEAD_BITMAP=separate: the bitmap kernel of the front for the look-ahead plan as well (A/B)
+  static int on = [] {
+    const char* v = getenv("RC_AHEAD_BITMAP");
+    return (v && strcmp(v, "separate") == 0) ? 0 : 1;
+  }();
+  return on != 0;
+}
 int ahead_fork_mode() {
   static int mode = [] {
     const char* v = getenv("RC_AHEAD_FORK");
@@ -326,10 +333,14 @@ static int train_step_impl(float* U, float* I, float* mU, float* vU, float* mI, 
       look_ahead = hipStreamIsCapturing(s, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone;
     }
     auto launch_ahead = [&]() -> int {
-      const PlanArgs pn = slot_plan_args(w, 1 - slot, next_uid, next_iid, n_i, B, n_users, n_items, geom, fused_upd);
+      PlanArgs pn = slot_plan_args(w, 1 - slot, next_uid, next_iid, n_i, B, n_users, n_items, geom, fused_upd);
       RC_HIP(hipEventRecord(side->fork2, s));
       RC_HIP(hipStreamWaitEvent(side->stream, side->fork2, 0));
-      RC_TRY(plan_launch_front(pn, fused_upd, side->stream));
+      // a plan prepared as a whole: the bucket kernel writes the multi-occurrence bitmap from the counts it holds anyway
+      // (the separate bitmap launch zeroes and counts every bucket a second time: 0.06 ms beside the row kernels)
+      const bool whole = flavour != 3 && fused_upd && !geom.hashed && !geom.narrow && ahead_bitmap_in_bucket();
+      pn.bitmap_in_bucket = whole ? 1 : 0;
+      RC_TRY(plan_launch_front(pn, fused_upd && !whole, side->stream));
       if (flavour != 3) RC_TRY(plan_launch_back(pn, side->stream));
       RC_HIP(hipEventRecord(side->front_done, side->stream));
       ticket->generation = next_generation;
