@@ -449,6 +449,12 @@ int rc_neumf_bwd_dropout(const float* mf_u, const float* mf_i, const float* mlp_
  *     row ranges whose partial sums are combined in a fixed order (no float atomics).                            */
 int rc_linear_fwd(const float* X, const float* W, const float* b, int64_t M, int N, int K, int relu, float drop_p,
                   const uint64_t* seed_dev, uint32_t site, float* Y, rc_stream_t stream);
+/* rc_linear_fwd with a workspace: a small batch (fewer than 256 output tiles of 64 x 64) is cut along the reduction -- split-K,
+ * the partial products summed in split order by a second launch that applies bias / ReLU / dropout -- so that a
+ * 1,024 x 512 x 512 product is 512 workgroups of four K steps instead of 128 of sixteen.  ws NULL: no split.             */
+size_t rc_linear_fwd_workspace_bytes(int64_t M, int N, int K);
+int rc_linear_fwd_ws(const float* X, const float* W, const float* b, int64_t M, int N, int K, int relu, float drop_p,
+                     const uint64_t* seed_dev, uint32_t site, float* Y, void* ws, size_t ws_bytes, rc_stream_t stream);
 size_t rc_linear_bwd_workspace_bytes(int64_t M, int N, int K);
 int rc_linear_bwd(const float* X, const float* W, const float* Y, const float* dY, int64_t M, int N, int K,
                   float drop_p, float* dX, float* dW, float* db, void* ws, size_t ws_bytes, rc_stream_t stream);

@@ -579,26 +579,111 @@ static int mlp_splits(int64_t M, int N, int K) {
   //  20 tiles x 39 splits the 128 x 128 kernel measured 1.87 ms against ~1.5 ms at B = 131,072)
   const int64_t tiles = ((int64_t)(N + kMlpBM - 1) / kMlpBM) * ((K + 1 + kMlpBN - 1) / kMlpBN);
   int64_t s = (1024 + tiles - 1) / tiles;              // ~4 workgroups per CU
-  const int64_t max_s = (M + 255) / 256;               // at least 256 batch rows per split
+  const int64_t max_s = (M + 127) / 128;               // at least 128 batch rows (four K steps) per split
   if (s > max_s) s = max_s;
   if (s < 1) s = 1;
   if (s > 64) s = 64;
   return (int)s;
 }
 
+// Split-K for the forward / dX products of a small batch: a 1,024 x 512 x 512 product is 128 tiles of 64 x 64 -- half the CUs
+// idle, each workgroup alone on its CU walking 16 dependent K steps.  Cut into `s` reduction ranges it is s x 128 workgroups of
+// 16 / s steps; the partial products [s][M][N] are summed in split order (no float atomics) by a second launch that also applies
+// bias, ReLU and dropout.  1 = no split (enough tiles, or a short reduction).
+static int mlp_k_splits(int64_t M, int N, int K) {
+  const int64_t tiles = ((M + kMlpBM - 1) / kMlpBM) * ((N + kMlpBN - 1) / kMlpBN);
+  if (tiles >= 256 || K < 128) return 1;
+  int64_t s = (512 + tiles - 1) / tiles;
+  if (s > K / 64) s = K / 64;
+  if (s > 8) s = 8;
+  return (int)(s < 1 ? 1 : s);
+}
+
+// Y[m, n] = drop(relu(sum_s part[s][m][n] + b[n])): thread (m4, n) owns rows 4 m4 .. 4 m4 + 3 of column n (the dropout mask's
+// four words of one Philox call, as in the GEMM epilogue)
+__global__ __launch_bounds__(kBlock) void mlp_split_epilogue_kernel(MlpGemm g, const float* __restrict__ part, int splits, float* __restrict__ Y) {
+  const int64_t m4n = (g.M + 3) / 4;
+  const int64_t total = m4n * g.N;
+  const uint64_t seed = g.seed ? *g.seed : 0;
+  const size_t plane = (size_t)g.M * (size_t)g.N;
+  for (int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * kBlock) {
+    const int64_t m4 = idx / g.N;
+    const int n = (int)(idx % g.N);
+    const float bn = g.bias ? g.bias[n] : 0.f;
+    float keep[4] = {1.f, 1.f, 1.f, 1.f};
+    if (g.seed) mlp_keep4(g, seed, m4, n, keep);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int64_t m = 4 * m4 + e;
+      if (m >= g.M) continue;
+      float v = 0.f;
+      for (int q = 0; q < splits; ++q) v += part[(size_t)q * plane + (size_t)m * g.N + n];
+      v += bn;
+      if (g.relu) v = fmaxf(v, 0.f);
+      if (g.seed) v *= keep[e];
+      Y[(size_t)m * g.N + n] = v;
+    }
+  }
+}
+
+// one product C = A . B with its epilogue in `g`, through split-K when `part` (room for mlp_k_splits planes) is given
+static int mlp_product(MlpGemm g, float* part, hipStream_t s) {
+  const int splits = part ? mlp_k_splits(g.M, g.N, g.K) : 1;
+  if (splits <= 1) return mlp_launch(g, 1, s);
+  MlpGemm p = g;   // the partial products: no epilogue
+  int64_t per = (g.K + splits - 1) / splits;
+  per = (per + kMlpBK - 1) / kMlpBK * kMlpBK;
+  const int used = (int)((g.K + per - 1) / per);
+  p.C = part; p.ldc = g.N; p.K = (int)per; p.split_stride_k = per; p.k_total = g.K;
+  p.bias = nullptr; p.relu = 0; p.seed = nullptr;
+  RC_TRY(mlp_launch(p, used, s));
+  const int64_t total = ((g.M + 3) / 4) * g.N;
+  int64_t blocks = (total + kBlock - 1) / kBlock;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(mlp_split_epilogue_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, s, g, part, used, g.C);
+  RC_LAUNCH_CHECK();
+  return RC_OK;
+}
+static size_t mlp_split_bytes(int64_t M, int N, int K) {
+  const int sp = mlp_k_splits(M, N, K);
+  return sp > 1 ? align_up((size_t)sp * (size_t)M * (size_t)N * sizeof(float), 256) : 0;
+}
+
 }  // namespace rc
 
 using namespace rc;
+
+extern "C" size_t rc_linear_fwd_workspace_bytes(int64_t M, int N, int K) {
+  if (M < 1 || N < 1 || K < 1) return 0;
+  return mlp_split_bytes(M, N, K) + 256;
+}
 
 extern "C" size_t rc_linear_bwd_workspace_bytes(int64_t M, int N, int K) {
   if (M < 1 || N < 1 || K < 1) return 0;
   const size_t dz = align_up((size_t)M * N * sizeof(float), 256);
   const size_t part = align_up((size_t)mlp_splits(M, N, K) * (size_t)N * (size_t)(K + 1) * sizeof(float), 256);
-  return dz + part;
+  return dz + part + mlp_split_bytes(M, K, N);   // (the dX product: [M, K] out, reduction over N)
 }
+
+static int linear_fwd_impl(const float* X, const float* W, const float* b, int64_t M, int N, int K, int relu, float drop_p,
+                           const uint64_t* seed_dev, uint32_t site, float* Y, void* ws, size_t ws_bytes, rc_stream_t stream);
 
 extern "C" int rc_linear_fwd(const float* X, const float* W, const float* b, int64_t M, int N, int K, int relu, float drop_p,
                              const uint64_t* seed_dev, uint32_t site, float* Y, rc_stream_t stream) {
+  return linear_fwd_impl(X, W, b, M, N, K, relu, drop_p, seed_dev, site, Y, nullptr, 0, stream);
+}
+
+// the same with a workspace (rc_linear_fwd_workspace_bytes): small batches are cut along the reduction (split-K)
+extern "C" int rc_linear_fwd_ws(const float* X, const float* W, const float* b, int64_t M, int N, int K, int relu, float drop_p,
+                                const uint64_t* seed_dev, uint32_t site, float* Y, void* ws, size_t ws_bytes, rc_stream_t stream) {
+  RC_REQUIRE(ws == nullptr || ws_bytes >= rc_linear_fwd_workspace_bytes(M, N, K), "rc_linear_fwd_ws: workspace %zu < %zu", ws_bytes,
+             rc_linear_fwd_workspace_bytes(M, N, K));
+  return linear_fwd_impl(X, W, b, M, N, K, relu, drop_p, seed_dev, site, Y, ws, ws_bytes, stream);
+}
+
+static int linear_fwd_impl(const float* X, const float* W, const float* b, int64_t M, int N, int K, int relu, float drop_p,
+                           const uint64_t* seed_dev, uint32_t site, float* Y, void* ws, size_t ws_bytes, rc_stream_t stream) {
+  (void)ws_bytes;
   if (M == 0) return RC_OK;
   RC_REQUIRE(X && W && Y, "rc_linear_fwd: null pointer");
   RC_REQUIRE(M > 0 && N >= 1 && K >= 1 && N < 65536, "rc_linear_fwd: bad shape M=%lld N=%d K=%d", (long long)M, N, K);
@@ -614,7 +699,7 @@ extern "C" int rc_linear_fwd(const float* X, const float* W, const float* b, int
     g.drop_thresh = (uint32_t)((double)drop_p * 4294967296.0);
     g.keep_scale = 1.0f / (1.0f - drop_p);
   }
-  return mlp_launch(g, 1, as_stream(stream));
+  return mlp_product(g, static_cast<float*>(ws), as_stream(stream));
 }
 
 extern "C" int rc_linear_bwd(const float* X, const float* W, const float* Y, const float* dY, int64_t M, int N, int K,
@@ -647,7 +732,8 @@ extern "C" int rc_linear_bwd(const float* X, const float* W, const float* Y, con
     g.A = MlpOperand{dZ, N, 1};
     g.B = MlpOperand{W, K, 0};
     g.M = M; g.N = K; g.K = N; g.ones_col = -1; g.C = dX; g.ldc = K; g.split_stride_k = N; g.k_total = N;
-    RC_TRY(mlp_launch(g, 1, s));
+    float* dx_part = mlp_k_splits(M, K, N) > 1 ? reinterpret_cast<float*>(reinterpret_cast<char*>(part) + align_up((size_t)mlp_splits(M, N, K) * (size_t)N * (size_t)(K + 1) * sizeof(float), 256)) : nullptr;
+    RC_TRY(mlp_product(g, dx_part, s));
   }
   {  // [dW | db][n, k] = sum_m dZ[m, n] [X | 1][m, k], the batch cut into splits
     const int splits = mlp_splits(M, N, K);

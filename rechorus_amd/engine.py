@@ -792,8 +792,9 @@ def linear_fwd(X, W, b=None, relu=False, drop_p=0.0, seed=None, site=0):
     M, K = X.shape
     N = W.shape[0]
     Y = torch.empty((M, N), dtype=f32, device=X.device)
-    _lib.call("rc_linear_fwd", _ptr(X, f32, "X"), _ptr(W, f32, "W"), _ptr(b, f32, "b", True), M, N, K, 1 if relu else 0,
-              *_drop_args(drop_p, seed), C.c_uint32(int(site)), _ptr(Y, f32, "Y"), _stream())
+    ws = workspace(_lib.load().rc_linear_fwd_workspace_bytes(M, N, K), X.device, "linear_fwd")   # split-K planes of a small batch
+    _lib.call("rc_linear_fwd_ws", _ptr(X, f32, "X"), _ptr(W, f32, "W"), _ptr(b, f32, "b", True), M, N, K, 1 if relu else 0,
+              *_drop_args(drop_p, seed), C.c_uint32(int(site)), _ptr(Y, f32, "Y"), C.c_void_p(ws.data_ptr()), ws.numel(), _stream())
     return Y
 
 
