@@ -318,6 +318,13 @@ size_t rc_small_row_sums_workspace_bytes(int64_t n);
 int rc_small_row_sums(const int64_t* ids, int64_t n, int64_t n_rows, const float* src, int d, float* out, void* ws,
                       size_t ws_bytes, rc_stream_t stream);
 
+/* The CTR head of the context models in one pass: z = bias[0] + sum_f lin[i, f] (+ term1[i]) (+ term2[i])
+ * (models/context/FM.py:59-60, DeepFM.py:27, WideDeep.py:46), p = sigmoid(z) (BaseContextModel.py:74-78), the per-row term of
+ * nn.BCELoss()(p, label) with torch's clamps (BaseModel.py:259-267; loss = mean of loss_vec) and gz = d loss / d z.
+ * lin [n, F] first-order values; term1 / term2 [n] or NULL; label int64 {0, 1}.                                          */
+int rc_ctr_head_fwd_bwd(const float* bias, const float* lin, int F, const float* term1, const float* term2,
+                        const int64_t* label, int64_t n, float* p, float* loss_vec, float* gz, rc_stream_t stream);
+
 /* ---- SASRec encoder (models/sequential/SASRec.py:51-86, utils/layers.py:9-63,92-118) ------- */
 
 /* Two tables that share their ids (NeuMF's mf / mlp embedding of a user or an item, models/general/NeuMF.py:37-40)

@@ -109,6 +109,7 @@ SIGNATURES = {
     "rc_step_increment": (_i, [_p, _p]),
     "rc_segmented_update2": (_i, [_p, _p, _p, _i, _p, _p, _i64, _p, _p, _p, _i, _p, _i64, _i64, _i64, _hp, _p, _p,
                                   _p, _i, _p, _sz, _p]),
+    "rc_ctr_head_fwd_bwd": (_i, [_p, _p, _i, _p, _p, _p, _i64, _p, _p, _p, _p]),
     "rc_small_row_sums_supported": (_i, [_i64, _i64, _i]),
     "rc_small_row_sums_workspace_bytes": (_sz, [_i64]),
     "rc_small_row_sums": (_i, [_p, _i64, _i64, _p, _i, _p, _p, _sz, _p]),

@@ -105,9 +105,48 @@ __global__ __launch_bounds__(kBlock) void bce_prob_kernel(const float* __restric
   }
 }
 
+// The CTR head in one pass (models/context/FM.py:59-60 / DeepFM.py:27 / WideDeep.py:46: prediction = overall_bias + sum_f
+// first-order value (+ pairwise term) (+ MLP output); BaseContextModel.py:74-78: sigmoid; BaseModel.py:259-267: nn.BCELoss
+// with torch's -100 clamps of the logs): z, p, the per-row loss term and d loss / d z.  Seven elementwise / reduction launches
+// of a few microseconds each otherwise -- a tenth of the replayed DeepFM step at B = 1,024.
+__global__ __launch_bounds__(kBlock) void ctr_head_kernel(const float* __restrict__ bias, const float* __restrict__ lin, int F,
+                                                          const float* __restrict__ t1, const float* __restrict__ t2,
+                                                          const int64_t* __restrict__ y, int64_t n, float inv_n,
+                                                          float* __restrict__ p_out, float* __restrict__ loss_vec,
+                                                          float* __restrict__ gz) {
+  const float b0 = bias[0];
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    float sl = 0.f;
+    for (int f = 0; f < F; ++f) sl += lin[i * F + f];
+    float z = b0 + sl;
+    if (t1) z += t1[i];
+    if (t2) z += t2[i];
+    const float pi = 1.0f / (1.0f + expf(-z));
+    const float yi = (float)y[i];
+    const float lp = fmaxf(logf(pi), -100.f), lq = fmaxf(log1pf(-pi), -100.f);
+    p_out[i] = pi;
+    loss_vec[i] = -(yi * lp + (1.0f - yi) * lq);
+    const float gp = (pi - yi) / fmaxf((1.0f - pi) * pi, 1e-12f) * inv_n;   // d loss / d p, as rc_bce_prob_fwd_bwd
+    gz[i] = gp * (1.0f - pi) * pi;                                          // sigmoid backward: grad * (1 - out) * out
+  }
+}
+
 }  // namespace rc
 
 using namespace rc;
+
+extern "C" int rc_ctr_head_fwd_bwd(const float* bias, const float* lin, int F, const float* term1, const float* term2,
+                                   const int64_t* label, int64_t n, float* p, float* loss_vec, float* gz, rc_stream_t stream) {
+  if (n == 0) return RC_OK;
+  RC_REQUIRE(bias && lin && label && p && loss_vec && gz, "rc_ctr_head_fwd_bwd: null pointer");
+  RC_REQUIRE(n > 0 && F >= 1, "rc_ctr_head_fwd_bwd: bad shape n=%lld F=%d", (long long)n, F);
+  int64_t blocks = (n + kBlock - 1) / kBlock;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(ctr_head_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, as_stream(stream), bias, lin, F, term1, term2, label, n,
+                     1.0f / (float)n, p, loss_vec, gz);
+  RC_LAUNCH_CHECK();
+  return RC_OK;
+}
 
 #define RC_FM_DISPATCH(KERN, ...)                                                                   \
   switch (d) {                                                                                      \

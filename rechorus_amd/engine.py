@@ -1235,6 +1235,20 @@ def bce_prob(p, y, need_grad=True):
     return reduce_sum(loss_vec, 1.0 / n), gp
 
 
+def ctr_head(bias, lin, term1, term2, label):
+    """rc_ctr_head_fwd_bwd: p = sigmoid(bias + lin.sum(-1) (+ term1) (+ term2)), BCE loss [1] and d loss / d logit [n].
+    lin [n, F] fp32; term1 / term2 [n] | None; label int64 [n]"""
+    n, F = lin.shape
+    f32 = torch.float32
+    p = torch.empty(n, dtype=f32, device=lin.device)
+    loss_vec = torch.empty(n, dtype=f32, device=lin.device)
+    gz = torch.empty(n, dtype=f32, device=lin.device)
+    _lib.call("rc_ctr_head_fwd_bwd", _ptr(bias, f32, "bias"), _ptr(lin, f32, "lin"), int(F), _ptr(term1, f32, "term1", True),
+              _ptr(term2, f32, "term2", True), _ptr(label, torch.int64, "label"), n, _ptr(p, f32, "p"), _ptr(loss_vec, f32, "loss_vec"),
+              _ptr(gz, f32, "gz"), _stream())
+    return p, reduce_sum(loss_vec, 1.0 / n), gz
+
+
 # ---- batch assembly on the device (csrc/sampler.hip) -------------------------------------------------------
 
 def sample_negatives(users, K, n_items, clicked_ptr=None, clicked_items=None, seed=0, base_index=0, out=None):

@@ -227,6 +227,39 @@ def bce_loss(p, y):
     return _BceProbFn.apply(p, y)
 
 
+class _CtrHeadFn(torch.autograd.Function):
+    """the CTR head of the context models in training: logit = bias + first-order sum (+ pairwise term) (+ MLP output), sigmoid,
+    nn.BCELoss -- one kernel forward, the closed-form d loss / d logit fanned out to the terms backward."""
+
+    @staticmethod
+    def forward(ctx, bias, lin, label, *terms):
+        n = label.numel()
+        t = [x.detach().reshape(-1).contiguous() for x in terms]
+        p, loss, gz = engine.ctr_head(bias.detach(), lin.detach().reshape(n, -1).contiguous(), t[0] if len(t) > 0 else None,
+                                      t[1] if len(t) > 1 else None, label.reshape(-1).contiguous())
+        ctx.save_for_backward(gz)
+        ctx.lin_shape, ctx.term_shapes = lin.shape, [x.shape for x in terms]
+        ctx.mark_non_differentiable(p)
+        return p, loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, _gp, g_loss):
+        (gz,) = ctx.saved_tensors
+        g = gz * g_loss
+        n = g.shape[0]
+        g_lin = g.reshape(n, *([1] * (len(ctx.lin_shape) - 1))).expand(ctx.lin_shape)
+        return (g.sum().reshape(1), g_lin, None) + tuple(g.reshape(sh) for sh in ctx.term_shapes)
+
+
+def ctr_head(bias, lin, label, terms):
+    """-> (p [n] probabilities, BCE loss scalar); lin: first-order values [n, ..., F] (summed over the trailing dims per row),
+    terms: up to two tensors of n elements added to the logit"""
+    if not lin.is_cuda:
+        raise RuntimeError("ctr_head runs on the GPU only (no CPU path)")
+    assert len(terms) <= 2
+    return _CtrHeadFn.apply(bias, lin, label, *terms)
+
+
 class _BceRankingFn(torch.autograd.Function):
     """ContextModel.loss, loss_n 'BCE' (models/BaseContextModel.py:53-56), closed-form backward"""
 

@@ -260,6 +260,8 @@ class CTRModel(GeneralModel):
     def loss(self, out_dict: dict) -> torch.Tensor:
         """BCE / MSE on (prediction, label), reference :262-274 (torch ops: not on the ranking path)"""
         if self.loss_n == 'BCE':  # one HIP kernel, closed-form backward
+            if 'loss' in out_dict:   # the context models' training forward computed it with the head (rc_ctr_head_fwd_bwd)
+                return out_dict['loss']
             if not out_dict['prediction'].is_cuda:
                 raise RuntimeError('CTRModel.loss: the HIP engine needs CUDA tensors (no CPU path)')
             return hnn.bce_loss(out_dict['prediction'], out_dict['label'])

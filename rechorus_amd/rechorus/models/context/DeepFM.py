@@ -18,6 +18,9 @@ class DeepFMBase(WideDeepBase):
         field_vectors, first_order = self._get_embeddings_FM(feed_dict)
         return {'prediction': first_order + hnn.fm_second_order(field_vectors) + self._deep(field_vectors)}
 
+    def _head_terms(self, field_vectors):
+        return [hnn.fm_second_order(field_vectors), self._deep(field_vectors)]
+
 
 _LOG = ['emb_size', 'layers', 'loss_n']
 DeepFMCTR = task_variant('DeepFMCTR', ContextCTRModel, DeepFMBase, 'ContextReader', 'CTRRunner', _LOG, __name__,

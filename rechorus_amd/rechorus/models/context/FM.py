@@ -84,9 +84,31 @@ class FMBase(object):
         fm_vectors, linear_value = self._get_embeddings_FM(feed_dict)
         return {'prediction': linear_value + hnn.fm_second_order(fm_vectors)}
 
+    def _fused_fields(self, feed_dict):
+        """(field vectors [B, C, F, d], first-order values [B, C, F, 1]) from the two one-launch gathers, or None where a field is
+        not categorical / the model is not on the GPU"""
+        if not (all(is_categorical(f) for f in self.context_features) and self.overall_bias.is_cuda):
+            return None
+        n_cand = feed_dict['item_id'].shape[1]
+        ids = [feed_dict[f] for f in self.context_features]
+        return (hnn.gather_fields([self.context_embedding[f].weight for f in self.context_features], ids, n_cand),
+                hnn.gather_fields([self.linear_embedding[f].weight for f in self.context_features], ids, n_cand))
+
+    def _head_terms(self, field_vectors):
+        """what `forward` adds to the first-order term, as a list of [B, C] tensors (at most two)"""
+        return [hnn.fm_second_order(field_vectors)]
+
 
 def ctr_forward(self, feed_dict, head_forward):
-    """CTR variants: one candidate per row, probability out, label passed through (reference :74-78)"""
+    """CTR variants: one candidate per row, probability out, label passed through (reference :74-78).
+    Training with --loss_n BCE: the sum of the head's terms, the sigmoid, nn.BCELoss and their backward are ONE kernel
+    (rc_ctr_head_fwd_bwd); the loss travels in the output dict and CTRModel.loss hands it on."""
+    if self.training and getattr(self, 'loss_n', None) == 'BCE' and feed_dict['label'].dtype == torch.int64:
+        fused = self._fused_fields(feed_dict)
+        if fused is not None:
+            field_vectors, lin = fused
+            p, loss = hnn.ctr_head(self.overall_bias, lin, feed_dict['label'], self._head_terms(field_vectors))
+            return {'prediction': p, 'label': feed_dict['label'].view(-1), 'loss': loss}
     out = head_forward(self, feed_dict)
     out['prediction'] = out['prediction'].view(-1).sigmoid()
     out['label'] = feed_dict['label'].view(-1)

@@ -40,6 +40,9 @@ class WideDeepBase(FMBase):
         field_vectors, wide = self._get_embeddings_FM(feed_dict)
         return {'prediction': self._deep(field_vectors) + wide}
 
+    def _head_terms(self, field_vectors):
+        return [self._deep(field_vectors)]
+
 
 _LOG = ['emb_size', 'layers', 'loss_n']
 # like the reference (:51-54) the CTR variant takes its task flags from ContextModel, so --loss_n defaults to 'BPR'

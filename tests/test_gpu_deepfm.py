@@ -124,6 +124,10 @@ def _build(case, g, cuda, loss_n=None):
     return model.to(cuda), B
 
 
+def case_is_ctr(case):
+    return "_ctr_" in case
+
+
 def _feed(g, n, B, cuda):
     f = {k: torch.from_numpy(v).to(cuda) for k, v in batch(g, n).items()}
     f.update(batch_size=B, phase="train")
@@ -134,17 +138,27 @@ def _feed(g, n, B, cuda):
 def test_model_file_matches_reference(case, cuda):
     g = load_golden(case)
     model, B = _build(case, g, cuda)
-    out = model(_feed(g, 1, B, cuda))
-    out["prediction"].retain_grad()
-    assert_close(out["prediction"].detach().cpu().numpy(), g["pred"], what="prediction", rtol=2e-5)
-    loss = model.loss(out)
-    loss.backward()
-    assert_close(loss.item(), g["loss"], what="loss", rtol=2e-5)
-    assert_close(out["prediction"].grad.cpu().numpy(), g["gpred"], what="dloss/dprediction", rtol=2e-5)
     b = batch(g, 1)
-    for name, p in model.named_parameters():
-        assert_close(p.grad.cpu().numpy(), g["G/" + name], what="grad " + name, rtol=2e-5, atol_scale=5e-5,
-                     abs_floor=cancel_floor(name, g, b))
+    # In training mode the CTR variants compute sum-of-terms + sigmoid + BCE in ONE kernel (rc_ctr_head_fwd_bwd): the
+    # probability leaves it without a graph of its own, so d loss / d prediction is checked on the op-by-op path (eval mode;
+    # dropout is 0 in the goldens) and the fused training path against prediction, loss and every parameter gradient.
+    for mode in ("eval", "train"):
+        model.train(mode == "train")
+        model.zero_grad()
+        out = model(_feed(g, 1, B, cuda))
+        fused = "loss" in out
+        assert fused == (mode == "train" and case_is_ctr(case)), (mode, case)
+        if not fused:
+            out["prediction"].retain_grad()
+        assert_close(out["prediction"].detach().cpu().numpy(), g["pred"], what=mode + " prediction", rtol=2e-5)
+        loss = model.loss(out)
+        loss.backward()
+        assert_close(loss.item(), g["loss"], what=mode + " loss", rtol=2e-5)
+        if not fused:
+            assert_close(out["prediction"].grad.cpu().numpy(), g["gpred"], what="dloss/dprediction", rtol=2e-5)
+        for name, p in model.named_parameters():
+            assert_close(p.grad.cpu().numpy(), g["G/" + name], what=mode + " grad " + name, rtol=2e-5, atol_scale=5e-5,
+                         abs_floor=cancel_floor(name, g, b))
 
 
 @pytest.mark.parametrize("case", CASES)
