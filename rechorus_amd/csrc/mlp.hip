@@ -591,6 +591,11 @@ static int mlp_splits(int64_t M, int N, int K) {
 // 16 / s steps; the partial products [s][M][N] are summed in split order (no float atomics) by a second launch that also applies
 // bias, ReLU and dropout.  1 = no split (enough tiles, or a short reduction).
 static int mlp_k_splits(int64_t M, int N, int K) {
+  static const int mode = [] {   // RC_MLP_SPLITK=0: no split-K of the forward / dX products (A/B)
+    const char* v = getenv("RC_MLP_SPLITK");
+    return (v && v[0] == '0') ? 0 : 1;
+  }();
+  if (mode == 0) return 1;
   const int64_t tiles = ((M + kMlpBM - 1) / kMlpBM) * ((N + kMlpBN - 1) / kMlpBN);
   if (tiles >= 256 || K < 128) return 1;
   int64_t s = (512 + tiles - 1) / tiles;
