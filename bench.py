@@ -439,7 +439,13 @@ def model_roofline(args, trainer, batches, engine):
         L, nl = args.hist, args.layers
         R = float(np.mean([int(l.sum()) for _, l, _ in batches]))        # valid history rows of a batch
         sq = float(np.mean([int((l.to(torch.float64) ** 2).sum()) for _, l, _ in batches]))
-        fwd = nl * (R * (6.0 * d * d + 4.0 * d * d) + 2.0 * sq * d)       # QKV + FFN projections, causal QK^T + AV
+        full = R * (6.0 * d * d + 4.0 * d * d) + 2.0 * sq * d            # a block on all rows: QKV + FFN projections, causal QK^T + AV
+        # the LAST block is needed at one position per sequence (SASRec.py:76): K / V projections on all rows, Q and the
+        # FFN on B rows, one attention row per sequence -- what the engine computes (the all-rows count would flatter the rate)
+        last = R * 4.0 * d * d + B * 6.0 * d * d + 4.0 * R * d
+        last_row = (os.environ.get("RC_SAS_LAST_ROW", "1") != "0" and 2 <= L <= 64 and (d // args.heads) in (16, 32, 64)
+                    and B * L >= int(os.environ.get("RC_SAS_LAST_ROW_MIN", "32768")))
+        fwd = (nl - 1) * full + (last if last_row else full)
         flops = {"encoder_fwd": fwd, "encoder_bwd": 2.0 * fwd}
         ids = [torch.cat([i.reshape(-1), h.reshape(-1)]) for h, _, i in batches]
         ui = float(np.mean([torch.unique(x).numel() for x in ids]))

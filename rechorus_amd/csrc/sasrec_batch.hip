@@ -24,7 +24,9 @@ constexpr int kSbTile = 64;  // rows per tile of the row-space kernels
 
 // off[b] = sum_{b' < b} min(len[b'], L) (exclusive), off[B] = R.  One workgroup; B <= 2^24.
 __global__ __launch_bounds__(kBlock) void sb_offsets_kernel(const int64_t* __restrict__ lengths, int B, int L,
-                                                            int32_t* __restrict__ off) {
+                                                            int32_t* __restrict__ off, int32_t* __restrict__ off_seq) {
+  // off_seq[B] = B: the "row space" of one row per sequence (the last layer's last-row path runs the same kernels on it)
+  if (threadIdx.x == 0 && off_seq) off_seq[B] = B;
   __shared__ int s_sum[kBlock];
   const int per = (B + kBlock - 1) / kBlock;
   const int lo = min((int)threadIdx.x * per, B), hi = min(lo + per, B);
@@ -290,13 +292,13 @@ __device__ __forceinline__ void sb16_product_pair(const float* Wl, int i, int g,
   }
 }
 
-// Y_w = X W_w^T + b_w for the three projections of one pass over X
-template <int D>
+// Y_w = X W_w^T + b_w for NW projections of one pass over X (3: q, k, v; 2: k, v of a last layer; 1: q of the last rows)
+template <int D, int NW>
 __global__ __launch_bounds__(64 * kSb16MaxWaves) void sb_qkv16_kernel(SbLinArgs a) {
   constexpr int S = D + 4;
   extern __shared__ float lds[];
-  float* Ws = lds;               // [3][D][S]
-  float* Bs = lds + 3 * D * S;   // [3][D]
+  float* Ws = lds;                // [NW][D][S]
+  float* Bs = lds + NW * D * S;   // [NW][D]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
   const int nw = blockDim.x >> 6;
   const int R = a.off[a.B];
@@ -305,18 +307,18 @@ __global__ __launch_bounds__(64 * kSb16MaxWaves) void sb_qkv16_kernel(SbLinArgs 
   int t = (int)blockIdx.x * nw + wave;
   float x[D / 16][4], xn[D / 16][4];
   if (t < tiles) sb16_load_rows<D>(a.X, 16 * t + i, R, g, x);   // the first tile's rows travel while the weights are staged
-  for (int idx = threadIdx.x; idx < 3 * D * (D / 4); idx += blockDim.x) {
+  for (int idx = threadIdx.x; idx < NW * D * (D / 4); idx += blockDim.x) {
     const int w = idx / (D * (D / 4)), rem = idx % (D * (D / 4)), o = rem / (D / 4), c4 = rem % (D / 4);
     *reinterpret_cast<float4*>(Ws + (w * D + o) * S + 4 * c4) = reinterpret_cast<const float4*>(a.W[w])[o * (D / 4) + c4];
   }
-  for (int idx = threadIdx.x; idx < 3 * D; idx += blockDim.x) Bs[idx] = a.bias[idx / D] ? a.bias[idx / D][idx % D] : 0.f;
+  for (int idx = threadIdx.x; idx < NW * D; idx += blockDim.x) Bs[idx] = a.bias[idx / D] ? a.bias[idx / D][idx % D] : 0.f;
   __syncthreads();
   for (; t < tiles; t += stride) {
     asm volatile("" ::: "memory");   // the weights are re-read from LDS per tile: hoisted out of this loop they are 192 registers (spills)
     const int row = 16 * t + i;
     if (t + stride < tiles) sb16_load_rows<D>(a.X, 16 * (t + stride) + i, R, g, xn);   // requested before this tile's stores
 #pragma unroll
-    for (int w = 0; w < 3; ++w) {
+    for (int w = 0; w < NW; ++w) {
       const float* Wl = Ws + w * D * S;
       float* Y = a.Y[w];
 #pragma unroll
@@ -340,11 +342,12 @@ __global__ __launch_bounds__(64 * kSb16MaxWaves) void sb_qkv16_kernel(SbLinArgs 
 }
 
 // Y = res + X_0 W_0 + X_1 W_1 + X_2 W_2 (dx = dy . W): the same tiles with the weights transposed while they are staged
-template <int D>
+// (NIN = 3: dq, dk, dv with the residual; 2: dk, dv of a last layer whose queries are the last rows only; 1: those rows' dq)
+template <int D, int NIN>
 __global__ __launch_bounds__(64 * kSb16MaxWaves) void sb_sum3_16_kernel(SbSum3Args a) {
   constexpr int S = D + 4;
   extern __shared__ float lds[];
-  float* Ws = lds;               // [3][D (in)][S (out)]
+  float* Ws = lds;               // [NIN][D (in)][S (out)]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
   const int nw = blockDim.x >> 6;
   const int R = a.off[a.B];
@@ -355,12 +358,13 @@ __global__ __launch_bounds__(64 * kSb16MaxWaves) void sb_sum3_16_kernel(SbSum3Ar
   auto fetch = [&](int tile) {
     const int row = 16 * tile + i;
     sb16_load_rows<D>(a.X[0], row, R, g, x0);
-    sb16_load_rows<D>(a.X[1], row, R, g, x1);
-    sb16_load_rows<D>(a.X[2], row, R, g, x2);
-    sb16_load_rows<D>(a.res, row, R, g, rs);   // (res may be Y: a lane reads exactly the float4s it writes, all before its first store)
+    if (NIN > 1) sb16_load_rows<D>(a.X[1], row, R, g, x1);
+    if (NIN > 2) sb16_load_rows<D>(a.X[2], row, R, g, x2);
+    // (res may be Y: a lane reads exactly the float4s it writes, all before its first store; null: no residual)
+    sb16_load_rows<D>(a.res, row, a.res ? R : 0, g, rs);
   };
   if (t < tiles) fetch(t);   // the first tile's rows travel while the weights are staged
-  for (int idx = threadIdx.x; idx < 3 * D * D; idx += blockDim.x) {
+  for (int idx = threadIdx.x; idx < NIN * D * D; idx += blockDim.x) {
     const int w = idx / (D * D), rem = idx % (D * D), o = rem / D, in = rem % D;
     Ws[(w * D + in) * S + o] = a.W[w][rem];
   }
@@ -376,12 +380,12 @@ __global__ __launch_bounds__(64 * kSb16MaxWaves) void sb_sum3_16_kernel(SbSum3Ar
       sas_f32x4 a0 = sas_zero4(), a1 = sas_zero4();
       if (n == 0) {
         sb16_product_pair<D, 0>(Ws, i, g, x0, a0, a1);
-        sb16_product_pair<D, 0>(Ws + D * S, i, g, x1, a0, a1);
-        sb16_product_pair<D, 0>(Ws + 2 * D * S, i, g, x2, a0, a1);
+        if (NIN > 1) sb16_product_pair<D, 0>(Ws + D * S, i, g, x1, a0, a1);
+        if (NIN > 2) sb16_product_pair<D, 0>(Ws + 2 * D * S, i, g, x2, a0, a1);
       } else if (n == 2) {
         sb16_product_pair<D, (D >= 64 ? 2 : 0)>(Ws, i, g, x0, a0, a1);
-        sb16_product_pair<D, (D >= 64 ? 2 : 0)>(Ws + D * S, i, g, x1, a0, a1);
-        sb16_product_pair<D, (D >= 64 ? 2 : 0)>(Ws + 2 * D * S, i, g, x2, a0, a1);
+        if (NIN > 1) sb16_product_pair<D, (D >= 64 ? 2 : 0)>(Ws + D * S, i, g, x1, a0, a1);
+        if (NIN > 2) sb16_product_pair<D, (D >= 64 ? 2 : 0)>(Ws + 2 * D * S, i, g, x2, a0, a1);
       }
       if (row < R) {
         *reinterpret_cast<float4*>(a.Y + (size_t)row * D + 16 * n + 4 * g) =
@@ -1623,6 +1627,145 @@ __global__ __launch_bounds__(kBlock) void sb_pos_reduce_kernel(const float* __re
 
 // ---- host side: buffer layout and launch sequences ---------------------------------------------------------
 
+// ---- the LAST layer needs one row per sequence -----------------------------------------------------------------------------
+// Only position len - 1 of the last block's output is consumed (models/sequential/SASRec.py:76) and the mask is causal, so
+// the last block needs ONE query row per sequence: its keys / values for all rows (two of the three projections), the last
+// row's query, one row of attention per head, and LayerNorm - FFN - LayerNorm on B rows instead of sum(len).  The backward
+// mirrors it: dK, dV for all rows (rank-one per head), dQ and the block's backward on B rows.  With --num_layers 1 (the
+// reference's default) that is the whole encoder.  Same arithmetic as the full path for that row; results differ only in
+// summation order.  (Off with dropout: the masks are keyed by the row index of the full row space.)
+struct SbLastAttnArgs {
+  const float* q;      // [B, D] query of each sequence's last row
+  const float *k, *v;  // [R, D]
+  float* ctx;          // fwd out [B, D]
+  const float* dctx;   // bwd in [B, D]
+  float* dq;           // bwd out [B, D]
+  float *dk, *dv;      // bwd out [R, D]
+  const int64_t* lengths;
+  const int32_t* off;
+  int B, L, n_heads;
+};
+
+// one wave per (sequence, head); lane j = key j (history_max <= 64)
+template <int D, int DK, bool BWD>
+__global__ __launch_bounds__(kBlock) void sb_attn_last_kernel(SbLastAttnArgs a) {
+  constexpr int NV = DK / 4;
+  const int lane = threadIdx.x & 63;
+  const int item = (int)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (item >= a.B * a.n_heads) return;   // wave-uniform
+  const int b = item / a.n_heads, hh = item % a.n_heads, hc = hh * DK;
+  const int n = sb_len(a.lengths, b, a.L);
+  if (n == 0) {   // an empty history: defined zeros for the kernels that follow (its output row is masked out at the end)
+    if (lane < DK) (BWD ? a.dq : a.ctx)[(size_t)b * D + hc + lane] = 0.f;
+    return;
+  }
+  const float sqrt_dk = sqrtf((float)DK);
+  const bool on = lane < n;
+  const size_t row = (size_t)a.off[b] + (on ? lane : 0);
+  float qv[DK], kv[DK], vv[DK];
+#pragma unroll
+  for (int c = 0; c < NV; ++c) {
+    const float4 q4 = reinterpret_cast<const float4*>(a.q + (size_t)b * D + hc)[c];
+    const float4 k4 = reinterpret_cast<const float4*>(a.k + row * D + hc)[c];
+    const float4 v4 = reinterpret_cast<const float4*>(a.v + row * D + hc)[c];
+    qv[4 * c] = q4.x; qv[4 * c + 1] = q4.y; qv[4 * c + 2] = q4.z; qv[4 * c + 3] = q4.w;
+    kv[4 * c] = k4.x; kv[4 * c + 1] = k4.y; kv[4 * c + 2] = k4.z; kv[4 * c + 3] = k4.w;
+    vv[4 * c] = v4.x; vv[4 * c + 1] = v4.y; vv[4 * c + 2] = v4.z; vv[4 * c + 3] = v4.w;
+  }
+  float sc = 0.f;
+#pragma unroll
+  for (int c = 0; c < DK; ++c) sc = fmaf(qv[c], kv[c], sc);
+  sc = sas_div_scale(sc, sqrt_dk);
+  const float m = wave_allreduce_max(on ? sc : -INFINITY);
+  const float e = on ? expf(sc - m) : 0.f;
+  const float rz = 1.0f / wave_allreduce_sum(e);
+  const float p = e * rz;
+  if (!BWD) {
+    float mine = 0.f;
+#pragma unroll
+    for (int c = 0; c < DK; ++c) {
+      const float t = wave_allreduce_sum(p * vv[c]);
+      if (lane == c) mine = t;
+    }
+    if (lane < DK) a.ctx[(size_t)b * D + hc + lane] = mine;
+    return;
+  }
+  float gv[DK];
+#pragma unroll
+  for (int c = 0; c < NV; ++c) {
+    const float4 g4 = reinterpret_cast<const float4*>(a.dctx + (size_t)b * D + hc)[c];
+    gv[4 * c] = g4.x; gv[4 * c + 1] = g4.y; gv[4 * c + 2] = g4.z; gv[4 * c + 3] = g4.w;
+  }
+  float dp = 0.f;
+#pragma unroll
+  for (int c = 0; c < DK; ++c) dp = fmaf(gv[c], vv[c], dp);
+  const float dot = wave_allreduce_sum(p * dp);
+  const float ds = sas_div_scale(p * (dp - dot), sqrt_dk);
+  if (on) {
+#pragma unroll
+    for (int c = 0; c < NV; ++c) {
+      reinterpret_cast<float4*>(a.dk + row * D + hc)[c] = make_float4(ds * qv[4 * c], ds * qv[4 * c + 1], ds * qv[4 * c + 2], ds * qv[4 * c + 3]);
+      reinterpret_cast<float4*>(a.dv + row * D + hc)[c] = make_float4(p * gv[4 * c], p * gv[4 * c + 1], p * gv[4 * c + 2], p * gv[4 * c + 3]);
+    }
+  }
+  float mine = 0.f;
+#pragma unroll
+  for (int c = 0; c < DK; ++c) {
+    const float t = wave_allreduce_sum(ds * kv[c]);
+    if (lane == c) mine = t;
+  }
+  if (lane < DK) a.dq[(size_t)b * D + hc + lane] = mine;
+}
+
+// out[b] = len[b] > 0 ? in[b] : 0  (in may be out)
+template <int D>
+__global__ __launch_bounds__(kBlock) void sb_mask_empty_kernel(const float* __restrict__ in, const int64_t* __restrict__ lengths, int B,
+                                                               float* __restrict__ out) {
+  constexpr int LPR = D / 4;
+  const int l = threadIdx.x % LPR;
+  for (int b = blockIdx.x * (kBlock / LPR) + threadIdx.x / LPR; b < B; b += gridDim.x * (kBlock / LPR)) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lengths[b] > 0) v = reinterpret_cast<const float4*>(in)[(size_t)b * LPR + l];
+    reinterpret_cast<float4*>(out)[(size_t)b * LPR + l] = v;
+  }
+}
+
+// G[off[b] + len - 1] += T[b] for every non-empty sequence (each row of G is touched by one lane-group: no atomics)
+template <int D>
+__global__ __launch_bounds__(kBlock) void sb_last_add_kernel(const float* __restrict__ T, const int64_t* __restrict__ lengths,
+                                                             const int32_t* __restrict__ off, int B, int L, float* __restrict__ G) {
+  constexpr int LPR = D / 4;
+  const int l = threadIdx.x % LPR;
+  for (int b = blockIdx.x * (kBlock / LPR) + threadIdx.x / LPR; b < B; b += gridDim.x * (kBlock / LPR)) {
+    const int n = sb_len(lengths, b, L);
+    if (n == 0) continue;
+    float4* g = reinterpret_cast<float4*>(G) + ((size_t)off[b] + n - 1) * LPR + l;
+    const float4 t = reinterpret_cast<const float4*>(T)[(size_t)b * LPR + l];
+    float4 x = *g;
+    x.x += t.x; x.y += t.y; x.z += t.z; x.w += t.w;
+    *g = x;
+  }
+}
+
+static bool sb_fused_block();
+// RC_SAS_LAST_ROW=0: the last layer on all rows like the others (A/B timing, equivalence test)
+static bool sb_last_row_enabled() {
+  const char* v = getenv("RC_SAS_LAST_ROW");
+  return !(v && v[0] == '0');
+}
+template <int D>
+static bool sb_last_row_path(int n_heads, int B, int L, bool drop) {
+  const int dk = D / n_heads;
+  // (small row spaces are launch-bound: the path's six extra launches cost more than its rows save -- B = 256, L = 50: 0.281
+  //  against 0.266 ms per step; RC_SAS_LAST_ROW_MIN overrides the threshold on B * history_max)
+  static const int64_t min_rows = [] {
+    const char* v = getenv("RC_SAS_LAST_ROW_MIN");
+    return v ? (int64_t)atoll(v) : (int64_t)32768;
+  }();
+  return sb_last_row_enabled() && !drop && L >= 2 && L <= 64 && (dk == 16 || dk == 32 || dk == 64) && D % n_heads == 0 &&
+         (int64_t)B * L >= min_rows && sb_fused_block() && sb_rows16();
+}
+
 static int sb_fill_layers(SasLayer* layer, const float* const* layer_params, int n_layers) {
   RC_REQUIRE(n_layers >= 1 && n_layers <= kSasMaxLayers, "SASRec: num_layers must be in [1, %d]", kSasMaxLayers);
   RC_REQUIRE(layer_params != nullptr, "SASRec: layer parameter table missing");
@@ -1656,10 +1799,11 @@ constexpr int kSbPartWg = 512;  // workgroups that own a partial-gradient slice
 // the row-space offsets and the length buckets are computed by the forward pass and kept in the tail of the saved
 // state: the backward pass reads them back instead of recomputing them
 static size_t sb_state_act_floats(size_t rmax, int d, int n_layers) { return (size_t)n_layers * sb_layer_floats(rmax, d) + rmax * d; }
-static size_t sb_state_int_floats(int B) { return 5 * (size_t)B + 72; }
+static size_t sb_state_int_floats(int B) { return 6 * (size_t)B + 80; }
 
 struct SbWs {
   int32_t *off, *bucket;  // live in the state buffer
+  int32_t* off_seq;       // [B + 1], only off_seq[B] = B is defined: the row space of one row per sequence
   float *t0, *t1, *t2, *t3, *t4;  // [Rmax, D] scratch (t4: the masked branch gradient when dropout is on)
   float* part;               // [kSbPartWg][n_layers * PL]
   size_t total;
@@ -1670,6 +1814,7 @@ static SbWs sb_carve(void* base, float* state, int B, int L, int d, int n_layers
   const size_t rmax = (size_t)B * L;
   w.off = state ? reinterpret_cast<int32_t*>(state + sb_state_act_floats(rmax, d, n_layers)) : nullptr;
   w.bucket = state ? w.off + (size_t)B + 4 : nullptr;
+  w.off_seq = state ? w.bucket + 4 * (size_t)B + 68 : nullptr;
   w.t0 = cv.take<float>(rmax * d);
   w.t1 = bwd ? cv.take<float>(rmax * d) : nullptr;
   w.t2 = bwd ? cv.take<float>(rmax * d) : nullptr;
@@ -1793,24 +1938,82 @@ static int sb_forward(const float* item_emb, const float* pos_emb, const SasLaye
   constexpr int LPR = D / 4;
   const bool drop = dr.seed != nullptr;
   const size_t rmax = (size_t)B * L;
-  hipLaunchKernelGGL(sb_offsets_kernel, dim3(1), dim3(kBlock), 0, s, lengths, B, L, w.off);
+  hipLaunchKernelGGL(sb_offsets_kernel, dim3(1), dim3(kBlock), 0, s, lengths, B, L, w.off, w.off_seq);
   RC_LAUNCH_CHECK();
   SbSaved sv = sb_saved(state, 0, rmax, D);
   hipLaunchKernelGGL((sb_embed_kernel<D>), dim3(sb_row_grid((int64_t)rmax, LPR)), dim3(kBlock), 0, s, item_emb, pos_emb, hist,
                      lengths, B, L, w.off, sv.x);
   RC_LAUNCH_CHECK();
+  const bool last_row = sb_last_row_path<D>(n_heads, B, L, drop);
   for (int l = 0; l < n_layers; ++l) {
     const SasLayer& p = layer[l];
     sv = sb_saved(state, l, rmax, D);
     float* xnext = l + 1 < n_layers ? sb_saved(state, l + 1, rmax, D).x : state + (size_t)n_layers * sb_layer_floats(rmax, D);
     SbLinArgs a;
     memset(&a, 0, sizeof(a));
+    if (last_row && l == n_layers - 1) {
+      // k, v for all rows; the last row's x and q; one attention row per (sequence, head); the block on B rows -> hv
+      float* xl = sv.q + (size_t)B * D;   // [B, D] the sequences' last rows (kept for the backward); sv.q[0, B): their queries
+      float* ctxl = w.t0;                 // [B, D]
+      a.off = w.off; a.B = B;
+      a.X = sv.x; a.W[0] = p.Wk; a.W[1] = p.Wv; a.bias[0] = p.bk; a.bias[1] = p.bv; a.Y[0] = sv.k; a.Y[1] = sv.v;
+      {
+        const size_t lds = (size_t)(2 * D * (D + 4) + 2 * D) * sizeof(float);
+        auto kern = sb_qkv16_kernel<D, 2>;
+        RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        int grid, block;
+        sb_rows16_geometry((int64_t)rmax, &grid, &block);
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3((unsigned)block), lds, s, a);
+        RC_LAUNCH_CHECK();
+      }
+      hipLaunchKernelGGL((sb_last_rows_kernel<D>), dim3(sb_row_grid(B, LPR)), dim3(kBlock), 0, s, sv.x, lengths, w.off, B, L, xl);
+      RC_LAUNCH_CHECK();
+      memset(&a, 0, sizeof(a));
+      a.off = w.off_seq; a.B = B;
+      a.X = xl; a.W[0] = p.Wq; a.bias[0] = p.bq; a.Y[0] = sv.q;
+      {
+        const size_t lds = (size_t)(D * (D + 4) + D) * sizeof(float);
+        auto kern = sb_qkv16_kernel<D, 1>;
+        RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        int grid, block;
+        sb_rows16_geometry((int64_t)B, &grid, &block);
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3((unsigned)block), lds, s, a);
+        RC_LAUNCH_CHECK();
+      }
+      SbLastAttnArgs la;
+      memset(&la, 0, sizeof(la));
+      la.q = sv.q; la.k = sv.k; la.v = sv.v; la.ctx = ctxl; la.lengths = lengths; la.off = w.off; la.B = B; la.L = L; la.n_heads = n_heads;
+      {
+        const int dk = D / n_heads;
+        const unsigned blocks = (unsigned)(((int64_t)B * n_heads + kBlock / 64 - 1) / (kBlock / 64));
+        if (dk == 16) hipLaunchKernelGGL((sb_attn_last_kernel<D, 16, false>), dim3(blocks), dim3(kBlock), 0, s, la);
+        else if (dk == 32) hipLaunchKernelGGL((sb_attn_last_kernel<D, 32, false>), dim3(blocks), dim3(kBlock), 0, s, la);
+        else hipLaunchKernelGGL((sb_attn_last_kernel<D, (D >= 64 ? 64 : 32), false>), dim3(blocks), dim3(kBlock), 0, s, la);
+        RC_LAUNCH_CHECK();
+      }
+      SbBlockArgs bk;
+      bk.ctx = ctxl; bk.x = xl; bk.ln1w = p.ln1w; bk.ln1b = p.ln1b; bk.W1 = p.W1; bk.b1 = p.b1; bk.W2 = p.W2; bk.b2 = p.b2;
+      bk.ln2w = p.ln2w; bk.ln2b = p.ln2b; bk.xh1 = sv.xh1; bk.rstd1 = sv.rstd1; bk.y1 = sv.y1; bk.h = sv.h; bk.xh2 = sv.xh2;
+      bk.rstd2 = sv.rstd2; bk.xnext = hv; bk.off = w.off_seq; bk.B = B; bk.dr = dr;
+      {
+        const size_t lds16 = ((size_t)2 * D * (D + 4) + 6 * (size_t)D) * sizeof(float);
+        auto kern16 = sb_block16_fwd_kernel<D>;
+        RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern16), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16));
+        int64_t gr = (((int64_t)B + 15) / 16 + 3) / 4;
+        if (gr > 768) gr = 768;
+        hipLaunchKernelGGL(kern16, dim3((unsigned)(gr < 1 ? 1 : gr)), dim3(256), lds16, s, bk);
+        RC_LAUNCH_CHECK();
+      }
+      hipLaunchKernelGGL((sb_mask_empty_kernel<D>), dim3(sb_row_grid(B, LPR)), dim3(kBlock), 0, s, hv, lengths, B, hv);
+      RC_LAUNCH_CHECK();
+      return RC_OK;
+    }
     a.off = w.off; a.B = B;
     a.X = sv.x; a.W[0] = p.Wq; a.W[1] = p.Wk; a.W[2] = p.Wv; a.bias[0] = p.bq; a.bias[1] = p.bk; a.bias[2] = p.bv;
     a.Y[0] = sv.q; a.Y[1] = sv.k; a.Y[2] = sv.v;
     if (sb_rows16()) {
       const size_t lds = (size_t)(3 * D * (D + 4) + 3 * D) * sizeof(float);
-      auto kern = sb_qkv16_kernel<D>;
+      auto kern = sb_qkv16_kernel<D, 3>;
       RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       int grid, block;
       sb_rows16_geometry((int64_t)rmax, &grid, &block);
@@ -1903,13 +2106,85 @@ static int sb_backward(const SasLayer* layer, int n_layers, int n_heads, const i
   const size_t stride = (size_t)n_layers * PL;  // floats between the slices of consecutive workgroups
   RC_HIP(hipMemsetAsync(w.part, 0, (size_t)kSbPartWg * stride * sizeof(float), s));
   float* G = w.t0;
-  hipLaunchKernelGGL((sb_seed_kernel<D>), dim3(sb_row_grid((int64_t)rmax, LPR)), dim3(kBlock), 0, s, dhv, lengths, w.off, B, L, G);
-  RC_LAUNCH_CHECK();
+  const bool last_row = sb_last_row_path<D>(n_heads, B, L, drop);
+  if (!last_row) {
+    hipLaunchKernelGGL((sb_seed_kernel<D>), dim3(sb_row_grid((int64_t)rmax, LPR)), dim3(kBlock), 0, s, dhv, lengths, w.off, B, L, G);
+    RC_LAUNCH_CHECK();
+  }
   const int ln_grid = sb_row_grid((int64_t)rmax, LPR) < kSbPartWg ? sb_row_grid((int64_t)rmax, LPR) : kSbPartWg;
   for (int l = n_layers - 1; l >= 0; --l) {
     const SasLayer& p = layer[l];
     const SbSaved sv = sb_saved(const_cast<float*>(state), l, rmax, D);
     float* gp = w.part + (size_t)l * PL;
+    if (last_row && l == n_layers - 1) {
+      // the last block saw one row per sequence (sb_forward): block backward on B rows, one attention row per (sequence, head)
+      // backward -> dQ [B], dK / dV [R]; dX = dK Wk + dV Wv on all rows, + (dQ Wq + dZ1) on the last rows
+      const float* xl = sv.q + (size_t)B * D;
+      float* gl = w.t1;                        // [B, D]: dhv (empty histories: 0), then dZ1
+      float* dql = w.t1 + (size_t)B * D;       // [B, D]
+      float* tl = w.t4;                        // [B, D]
+      hipLaunchKernelGGL((sb_mask_empty_kernel<D>), dim3(sb_row_grid(B, LPR)), dim3(kBlock), 0, s, dhv, lengths, B, gl);
+      RC_LAUNCH_CHECK();
+      {
+        SbBlockBwdArgs bb;
+        bb.G = gl; bb.Gb = gl; bb.xh2 = sv.xh2; bb.rstd2 = sv.rstd2; bb.h = sv.h; bb.y1 = sv.y1; bb.xh1 = sv.xh1; bb.rstd1 = sv.rstd1;
+        bb.ln2w = p.ln2w; bb.W2 = p.W2; bb.W1 = p.W1; bb.ln1w = p.ln1w; bb.part = gp; bb.part_stride = stride; bb.off = w.off_seq; bb.B = B;
+        bb.dr = dr;
+        bb.dr.site = 2u * (uint32_t)l;
+        const size_t lds = (size_t)(2 * D + 3 * kSbTile) * (D + 1) * sizeof(float);
+        auto kern = sb_block_bwd_kernel<D>;
+        RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        int64_t tiles = ((int64_t)B + kSbTile - 1) / kSbTile;
+        if (tiles > kSbPartWg) tiles = kSbPartWg;
+        hipLaunchKernelGGL(kern, dim3((unsigned)(tiles < 1 ? 1 : tiles)), dim3(kBlock), lds, s, bb);
+        RC_LAUNCH_CHECK();
+      }
+      SbLastAttnArgs la;
+      memset(&la, 0, sizeof(la));
+      la.q = sv.q; la.k = sv.k; la.v = sv.v; la.dctx = gl; la.dq = dql; la.dk = w.t2; la.dv = w.t3;
+      la.lengths = lengths; la.off = w.off; la.B = B; la.L = L; la.n_heads = n_heads;
+      {
+        const int dk = D / n_heads;
+        const unsigned blocks = (unsigned)(((int64_t)B * n_heads + kBlock / 64 - 1) / (kBlock / 64));
+        if (dk == 16) hipLaunchKernelGGL((sb_attn_last_kernel<D, 16, true>), dim3(blocks), dim3(kBlock), 0, s, la);
+        else if (dk == 32) hipLaunchKernelGGL((sb_attn_last_kernel<D, 32, true>), dim3(blocks), dim3(kBlock), 0, s, la);
+        else hipLaunchKernelGGL((sb_attn_last_kernel<D, (D >= 64 ? 64 : 32), true>), dim3(blocks), dim3(kBlock), 0, s, la);
+        RC_LAUNCH_CHECK();
+      }
+      SbWgradArgs g;
+      memset(&g, 0, sizeof(g));
+      g.off = w.off; g.B = B; g.part_stride = stride;
+      g.dY[0] = w.t2; g.dY[1] = w.t3; g.X = sv.x;
+      g.gW[0] = gp + Cfg::oWk; g.gb[0] = gp + Cfg::obk; g.gW[1] = gp + Cfg::oWv; g.gb[1] = gp + Cfg::obv;
+      RC_TRY((sb_wgrad<D, 2>(g, (int64_t)rmax, s)));
+      memset(&g, 0, sizeof(g));
+      g.off = w.off_seq; g.B = B; g.part_stride = stride;
+      g.dY[0] = dql; g.X = xl; g.gW[0] = gp + Cfg::oWq; g.gb[0] = gp + Cfg::obq;
+      RC_TRY((sb_wgrad<D, 1>(g, (int64_t)B, s)));
+      {
+        SbSum3Args q;
+        memset(&q, 0, sizeof(q));
+        q.X[0] = w.t2; q.X[1] = w.t3; q.W[0] = p.Wk; q.W[1] = p.Wv; q.res = nullptr; q.Y = G; q.off = w.off; q.B = B;
+        const size_t lds16 = (size_t)(2 * D * (D + 4)) * sizeof(float);
+        auto kern16 = sb_sum3_16_kernel<D, 2>;
+        RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern16), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16));
+        int grid, block;
+        sb_rows16_geometry((int64_t)rmax, &grid, &block);
+        hipLaunchKernelGGL(kern16, dim3((unsigned)grid), dim3((unsigned)block), lds16, s, q);
+        RC_LAUNCH_CHECK();
+        memset(&q, 0, sizeof(q));
+        q.X[0] = dql; q.W[0] = p.Wq; q.res = gl; q.Y = tl; q.off = w.off_seq; q.B = B;
+        const size_t lds1 = (size_t)(D * (D + 4)) * sizeof(float);
+        auto kern1 = sb_sum3_16_kernel<D, 1>;
+        RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+        sb_rows16_geometry((int64_t)B, &grid, &block);
+        hipLaunchKernelGGL(kern1, dim3((unsigned)grid), dim3((unsigned)block), lds1, s, q);
+        RC_LAUNCH_CHECK();
+      }
+      hipLaunchKernelGGL((sb_last_add_kernel<D>), dim3(sb_row_grid(B, LPR)), dim3(kBlock), 0, s, tl, lengths, w.off, B, L, G);
+      RC_LAUNCH_CHECK();
+      continue;
+    }
     // LayerNorm2
     // (dropout: G = dZ2 feeds the residual path, Gb = mask2 * dZ2 the FFN branch)
     float* Gb = drop ? w.t4 : G;
@@ -1974,7 +2249,7 @@ static int sb_backward(const SasLayer* layer, int n_layers, int n_heads, const i
       q.res = G; q.Y = G; q.off = w.off; q.B = B;
       if (sb_rows16()) {
         const size_t lds16 = (size_t)(3 * D * (D + 4)) * sizeof(float);
-        auto kern16 = sb_sum3_16_kernel<D>;
+        auto kern16 = sb_sum3_16_kernel<D, 3>;
         RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern16), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16));
         int grid, block;
         sb_rows16_geometry((int64_t)rmax, &grid, &block);

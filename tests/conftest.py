@@ -2,6 +2,10 @@ import os as _os
 
 # hipGraph launches must use the runtime's regular path (rechorus_amd/graph.py); set before HIP initialises
 _os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+# the SASRec batch encoder's last-row path (last block on one row per sequence) starts at B * history_max >= 32,768 in the product
+# (below that the extra launches cost more than they save); the tests run it at every size so that the reference goldens hold it
+# to account (tests of the all-rows kernels set RC_SAS_LAST_ROW=0)
+_os.environ.setdefault("RC_SAS_LAST_ROW_MIN", "0")
 import os
 import sys
 

@@ -200,6 +200,7 @@ def test_sasrec_register_attention_equals_lds_attention(d, n_layers, n_heads, L,
     """the register-resident attention (one wave per (sequence, head), 16 x 16 x 4 MFMA tiles, sas_attn_reg.hpp) against the LDS-tile
     kernels of rounds 1-3 (RC_SAS_REG_ATTN=0) on every tile count 1..4, lengths on both sides of each 16-row boundary, empty
     histories; shapes outside its envelope (d_k = 8, or too many operand tiles) must take the LDS kernels either way"""
+    monkeypatch.setenv("RC_SAS_LAST_ROW", "0")   # every layer on all rows: the attention kernels under test serve the last layer too
     rng = np.random.default_rng(1000 * d + 10 * L + n_heads)
     n_items = 300
     P = _random_sasrec(rng, n_items, d, n_layers, L)
@@ -340,6 +341,7 @@ def test_sasrec_16_row_projection_kernels_equal_lds_tile_kernels(d, n_layers, n_
     """the QKV projection and the dX = dZ + dQ Wq + dK Wk + dV Wv sum on 16 x 16 x 4 tiles with operands straight from global
     memory (sb_qkv16_kernel / sb_sum3_16_kernel) against the LDS-tile 32 x 32 x 2 kernels (RC_SAS_ROWS16=0); 16-wave workgroups
     (B * history_max >= 65,536 rows) and 4-wave ones, ragged last tiles, empty histories"""
+    monkeypatch.setenv("RC_SAS_LAST_ROW", "0")   # (as above: the all-rows kernels under test)
     rng = np.random.default_rng(77 * d + B)
     n_items = 300
     P = _random_sasrec(rng, n_items, d, n_layers, L)
@@ -358,6 +360,44 @@ def test_sasrec_16_row_projection_kernels_equal_lds_tile_kernels(d, n_layers, n_
         res = (hv.cpu().numpy(), g_hist.cpu().numpy(), [{k: v.cpu().numpy() for k, v in g.items()} for g in dg])
         if mode in out:
             assert np.array_equal(res[0], out[mode][0]) and np.array_equal(res[1], out[mode][1])
+        out[mode] = res
+    what = f"d={d} layers={n_layers} heads={n_heads} L={L} B={B}"
+    assert not np.array_equal(out["1"][1], out["0"][1]), what + ": the switch had no effect"
+    assert_close(out["1"][0], out["0"][0], what=what + " hv", rtol=2e-5, atol_scale=2e-5)
+    assert_close(out["1"][1], out["0"][1], what=what + " g_hist", rtol=5e-5, atol_scale=5e-5)
+    floor = 1e-6 * max(float(np.abs(v).max()) for g in out["0"][2] for v in g.values())
+    for l in range(n_layers):
+        for k in LAYER_NAMES:
+            assert_close(out["1"][2][l][k], out["0"][2][l][k], what=f"{what} layer {l} d{k}", rtol=5e-5, atol_scale=1e-4, abs_floor=floor)
+    assert np.all(out["1"][0][lengths == 0] == 0) and np.all(out["1"][1][lengths == 0] == 0)
+
+
+@pytest.mark.parametrize("d,n_layers,n_heads,L,B", [(64, 1, 4, 50, 700), (64, 2, 4, 50, 300), (64, 1, 1, 20, 90), (32, 1, 2, 64, 130),
+                                                    (64, 3, 2, 7, 40), (64, 1, 4, 2, 9)])
+def test_sasrec_last_row_path_equals_all_rows(d, n_layers, n_heads, L, B, cuda, eng, monkeypatch):
+    """Only position len - 1 of the last block is consumed (SASRec.py:76): the batch encoder runs the last block for one query
+    row per sequence (k / v on all rows, one attention row per head, LayerNorm - FFN - LayerNorm on B rows) and mirrors it in the
+    backward.  Against the all-rows path (RC_SAS_LAST_ROW=0): hv, the history gradient and every parameter gradient, empty
+    histories and single-item histories included; and the oracle on a sample."""
+    rng = np.random.default_rng(31 * d + L + B)
+    n_items = 300
+    P = _random_sasrec(rng, n_items, d, n_layers, L)
+    lengths = rng.integers(0, L + 1, size=B).astype(np.int64)
+    lengths[:4] = (L, 0, 1, min(2, L))
+    hist = rng.integers(1, n_items, size=(B, L)).astype(np.int64) * (np.arange(L)[None, :] < lengths[:, None])
+    Pd = to_dev(P, n_layers, cuda)
+    h_d, l_d = torch.from_numpy(hist).to(cuda), torch.from_numpy(lengths).to(cuda)
+    dhv = torch.from_numpy(rng.normal(size=(B, d)).astype(np.float32)).to(cuda)
+    out = {}
+    for mode in ("1", "0", "1"):
+        monkeypatch.setenv("RC_SAS_LAST_ROW", mode)
+        hv, saved = eng.sasrec_fwd(Pd["item_emb"], Pd["pos_emb"], Pd["layers"], n_heads, h_d, l_d, save=True, impl="batch")
+        g_hist, dg = eng.sasrec_bwd(Pd["layers"], n_heads, l_d, saved, dhv)
+        torch.cuda.synchronize()
+        res = (hv.cpu().numpy(), g_hist.cpu().numpy(), [{k: v.cpu().numpy() for k, v in g.items()} for g in dg])
+        if mode in out:
+            assert np.array_equal(res[0], out[mode][0]) and np.array_equal(res[1], out[mode][1])
+            assert all(np.array_equal(res[2][l][k], out[mode][2][l][k]) for l in range(n_layers) for k in LAYER_NAMES)
         out[mode] = res
     what = f"d={d} layers={n_layers} heads={n_heads} L={L} B={B}"
     assert not np.array_equal(out["1"][1], out["0"][1]), what + ": the switch had no effect"
