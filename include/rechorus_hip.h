@@ -364,7 +364,10 @@ int rc_sasrec_bwd(const float* const* layer_params, int n_layers, int n_heads, c
  * weights in LDS, only the attention runs per sequence.  Same arithmetic and results (to fp32 summation order)
  * as rc_sasrec_fwd / rc_sasrec_bwd, several times faster from a few hundred sequences up; the forward pass
  * SAVES the activations the backward needs in `state` (rc_sasrec_batch_state_floats floats, caller-owned)
- * instead of the backward recomputing them.  dense_grads / g_hist / hv as in rc_sasrec_fwd / rc_sasrec_bwd.   */
+ * instead of the backward recomputing them.  dense_grads / g_hist / hv as in rc_sasrec_fwd / rc_sasrec_bwd.
+ * From B * L >= 32,768 (and without dropout) the LAST block is computed for the one position per sequence that is consumed
+ * (models/sequential/SASRec.py:76: his_vector = his[arange(B), lengths - 1]; causal mask): keys / values on all rows, one
+ * query / attention / FFN row per sequence, mirrored in the backward -- same results to fp32 summation order.               */
 size_t rc_sasrec_batch_state_floats(int B, int L, int d, int n_layers);
 size_t rc_sasrec_batch_workspace_bytes(int B, int L, int d, int n_layers);
 int rc_sasrec_batch_fwd(const float* item_emb, const float* pos_emb, const float* const* layer_params,
