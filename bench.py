@@ -124,7 +124,9 @@ def make_sasrec(args, device, engine, seed):
         lay["ln2w"] += 1.0
         layers.append(lay)
     P = {"item_emb": mk(args.items, d), "pos_emb": mk(L + 1, d), "layers": layers}
-    trainer = engine.SasrecTrainer(P, args.heads, opt=args.opt, lr=args.lr, l2=args.l2, rowwise=True)
+    # the step replays from a hipGraph after two eager steps (SGD / Adagrad; RC_SAS_GRAPH=0: eager, bound by the host's launch rate)
+    args.sas_graph = args.opt != "Adam" and os.environ.get("RC_SAS_GRAPH", "1") != "0"
+    trainer = engine.SasrecTrainer(P, args.heads, opt=args.opt, lr=args.lr, l2=args.l2, rowwise=True, graph=args.sas_graph)
     gen.manual_seed(seed)
     batches = []
     for _ in range(args.pool):
@@ -440,13 +442,25 @@ def model_roofline(args, trainer, batches, engine):
         R = float(np.mean([int(l.sum()) for _, l, _ in batches]))        # valid history rows of a batch
         sq = float(np.mean([int((l.to(torch.float64) ** 2).sum()) for _, l, _ in batches]))
         full = R * (6.0 * d * d + 4.0 * d * d) + 2.0 * sq * d            # a block on all rows: QKV + FFN projections, causal QK^T + AV
-        # the LAST block is needed at one position per sequence (SASRec.py:76): K / V projections on all rows, Q and the
-        # FFN on B rows, one attention row per sequence -- what the engine computes (the all-rows count would flatter the rate)
-        last = R * 4.0 * d * d + B * 6.0 * d * d + 4.0 * R * d
-        last_row = (os.environ.get("RC_SAS_LAST_ROW", "1") != "0" and 2 <= L <= 64 and (d // args.heads) in (16, 32, 64)
-                    and B * L >= int(os.environ.get("RC_SAS_LAST_ROW_MIN", "32768")))
-        fwd = (nl - 1) * full + (last if last_row else full)
+        # the LAST block is needed at one position per sequence (SASRec.py:76) -- what the engine computes (the
+        # all-rows count would flatter the rate).  Version 1: K / V projections on all rows, Q and the FFN on B rows, one
+        # attention row per sequence.  Version 2 (default, csrc/sas_last_row.hpp): no K / V at all -- per row H dots of length d
+        # and H weighted sums; q, Wk^T q, Wv xbar and the FFN on B rows.  With one block version 2 is a streaming pass over the
+        # rows: it is rated against HBM below
+        H = args.heads
+        want = int(os.environ.get("RC_SAS_LAST_ROW", "2"))
+        ok = want > 0 and L <= 64 and d % H == 0 and B * L >= int(os.environ.get("RC_SAS_LAST_ROW_MIN", "32768"))
+        v2 = ok and want >= 2 and H in (1, 2, 4) and L >= max(3, H + 1) and (d // H) % (d * d // 256) == 0
+        v1 = ok and L >= 2 and (d // H) in (16, 32, 64)
+        mode = 2 if v2 else (1 if v1 else 0)
+        last = {0: full, 1: R * 4.0 * d * d + B * 6.0 * d * d + 4.0 * R * d, 2: B * 10.0 * d * d + 4.0 * R * H * d}[mode]
+        fwd = (nl - 1) * full + last
         flops = {"encoder_fwd": fwd, "encoder_bwd": 2.0 * fwd}
+        enc_bytes = {}
+        if mode == 2 and nl == 1:
+            per_seq = (2 * d + 2 * H * d + H * L) * 4.0          # x_last, q, Wk^T q, xbar, p
+            enc_bytes = {"encoder_fwd": R * (8 + 2 * d * 4) + B * (per_seq + 8 * d * 4),      # ids + table rows read, x rows written
+                         "encoder_bwd": R * d * 4 + B * L * d * 4 + B * (per_seq + 2 * H * d * 4 + 12 * d * 4)}   # x read, padded dX written
         ids = [torch.cat([i.reshape(-1), h.reshape(-1)]) for h, _, i in batches]
         ui = float(np.mean([torch.unique(x).numel() for x in ids]))
         n_state = {"SGD": 0, "Adagrad": 1, "Adam": 2}[args.opt]
@@ -454,10 +468,11 @@ def model_roofline(args, trainer, batches, engine):
         gather_bytes = {}
     compute = {k: ph[k] for k in flops if k in ph}
     dom = max(list(compute) + ["table_update"], key=lambda k: ph.get(k, 0.0))
-    if dom == "table_update":
-        ach = upd_bytes / (ph[dom] * 1e-3) / 1e9
+    hbm_bytes = dict(enc_bytes if args.workload == "sasrec" else {}, table_update=upd_bytes)
+    if dom in hbm_bytes:
+        ach = hbm_bytes[dom] / (ph[dom] * 1e-3) / 1e9
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                           "frac": ach / HBM_PEAK_GBPS, "traffic": None, "algorithmic_bytes_per_launch": upd_bytes,
+                           "frac": ach / HBM_PEAK_GBPS, "traffic": None, "algorithmic_bytes_per_launch": hbm_bytes[dom],
                            "avg_ms": ph[dom]}
     else:
         ach = flops[dom] / (ph[dom] * 1e-3) / 1e12
@@ -466,6 +481,8 @@ def model_roofline(args, trainer, batches, engine):
                            "avg_ms": ph[dom]}
     out["phases_tflops"] = {k: round(flops[k] / (ph[k] * 1e-3) / 1e12, 2) for k in flops if ph.get(k)}
     out["table_update_gbps"] = round(upd_bytes / (ph["table_update"] * 1e-3) / 1e9, 1) if ph.get("table_update") else None
+    if args.workload == "sasrec" and enc_bytes:
+        out["phases_gbps"] = {k: round(v / (ph[k] * 1e-3) / 1e9, 1) for k, v in enc_bytes.items() if ph.get(k)}
     if gather_bytes.get("head_fwd") and ph.get("head_fwd"):
         out["head_fwd_gather_gbps"] = round(gather_bytes["head_fwd"] / (ph["head_fwd"] * 1e-3) / 1e9, 1)
     return out
@@ -604,7 +621,7 @@ def main():
     if getattr(trainer, "lookahead", False):
         # the sharded steps exchange per-destination split sizes; given the following batch they do that one step ahead
         run_step = lambda s: trainer.step(*batches[s % len(batches)], next_batch=batches[(s + 1) % len(batches)])
-    if args.graph and world == 1:
+    if args.graph and world == 1 and args.workload != "sasrec":   # (SasrecTrainer(graph=True) captures its own step)
         # the whole step (about 20 launches, no host sync, shape-only grids) captured once per pooled
         # batch in a hipGraph and replayed: removes per-launch host cost, which dominates at B=256
         trainer.hyper.step = 1  # SGD/Adagrad ignore the step count; Adam's bias correction would freeze
@@ -649,7 +666,8 @@ def main():
         workload_text = (f"SASRec fit step: emb_size={args.emb_size}, history_max={args.hist} (lengths uniform on 1..{args.hist}), "
                          f"{args.heads} heads, {args.layers} layer(s), num_neg={args.num_neg}, {args.items}-item table, Zipf(1.0) "
                          f"histories+positives, uniform negatives, B={args.batch} sequences/GPU/step, optimizer={args.opt} "
-                         f"(row-wise, l2={args.l2:g}), int64 ids, fp32")
+                         f"(row-wise, l2={args.l2:g}), {'hipGraph replay of the step (batch copied into static buffers), ' if getattr(args, 'sas_graph', False) else ''}"
+                         f"int64 ids, fp32")
     else:
         workload_text = (f"{'NeuMF (hidden ' + str(args.hidden) + ')' if args.workload == 'neumf' else 'BPRMF'} fit step: emb_size={args.emb_size}, "
                          f"num_neg={args.num_neg}, {args.items}-item / {args.users}-user tables, Zipf(1.0) users+positives, "

@@ -198,12 +198,15 @@ __device__ __forceinline__ void sas_attn_probs_wave(float* A, const float* Q, co
 // with four interleaved accumulators (16 independent chains of n_wg/16 adds instead of ONE chain of n_wg,
 // which was pure load/add latency), then the 16 chain sums are combined in a fixed order through LDS:
 // deterministic, no float atomics.
+// (alt_lo <= i < alt_hi: that index range was written by n_wg_alt workgroups instead of n_wg)
 static __global__ __launch_bounds__(kBlock) void sas_reduce_partials_kernel(const float* __restrict__ p, int n_wg,
-                                                                     int count, float* __restrict__ out) {
+                                                                     int count, float* __restrict__ out, int alt_lo = 0,
+                                                                     int alt_hi = 0, int n_wg_alt = 0) {
   __shared__ float sm[4][4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = (int)blockIdx.x * 64 + lane;
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  if (i >= alt_lo && i < alt_hi) n_wg = n_wg_alt;
   if (i < count) {
     int w = wave;
     for (; w + 12 < n_wg; w += 16) {

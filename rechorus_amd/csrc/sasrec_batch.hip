@@ -535,6 +535,7 @@ struct SbBlockArgs {
   const int32_t* off;
   int B;
   SbDrop dr;          // dr.site = 2 * layer (dropout1); dropout2 uses site + 1
+  const int64_t* row_len = nullptr;   // sb_block16_fwd_kernel, one row per sequence: xnext[row] = 0 where row_len[row] <= 0 (empty history)
 };
 
 template <int D>
@@ -692,6 +693,7 @@ struct SbAttnArgs {
 
 }  // namespace rc
 #include "sas_attn_reg.hpp"   // register-resident attention (needs SbAttnArgs, sb_len)
+#include "sas_last_row.hpp"   // the last block on one query row per sequence, without keys / values
 namespace rc {
 
 __host__ __device__ inline int sb_buf_floats(int D, int lp) { return lp * ((D + 1) > (lp + 1) ? (D + 1) : (lp + 1)); }
@@ -1152,6 +1154,10 @@ __global__ __launch_bounds__(64 * kSb16BlockWaves) void sb_block16_fwd_kernel(Sb
     float xh2[NC][4], yo[NC][4], rs2;
     sb16_layernorm<D>(zc, Ps + 4 * D, Ps + 5 * D, g, xh2, yo, &rs2);
     if (valid) {
+      if (a.row_len && a.row_len[row] <= 0) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) yo[c][0] = yo[c][1] = yo[c][2] = yo[c][3] = 0.f;
+      }
       sb16_store_rows<D>(a.xh2, row, g, xh2);
       sb16_store_rows<D>(a.xnext, row, g, yo);
       if (g == 0) a.rstd2[row] = rs2;
@@ -1287,6 +1293,8 @@ struct SbBlockBwdArgs {
   const int32_t* off;
   int B;
   SbDrop dr;            // dr.site = 2 * layer (dropout1); dropout2 = site + 1
+  const float* Gin = nullptr;         // one row per sequence: the incoming gradient is read from here (G only receives dZ1) ...
+  const int64_t* row_len = nullptr;   // ... and is zero for the rows with row_len <= 0 (empty histories)
 };
 
 template <int D>
@@ -1332,7 +1340,8 @@ __global__ __launch_bounds__(kBlock) void sb_block_bwd_kernel(SbBlockBwdArgs a) 
     for (int q = 0; q < NPASS; ++q) {
       const int r = r0 + q * GPB + grp;
       if (r < R) {
-        pg[q] = reinterpret_cast<const float4*>(a.G)[(size_t)r * LPR + l];
+        pg[q] = reinterpret_cast<const float4*>(a.Gin ? a.Gin : a.G)[(size_t)r * LPR + l];
+        if (a.row_len && a.row_len[r] <= 0) pg[q] = make_float4(0.f, 0.f, 0.f, 0.f);
         pxh[q] = reinterpret_cast<const float4*>(a.xh2)[(size_t)r * LPR + l];
         ph[q] = reinterpret_cast<const float4*>(a.h)[(size_t)r * LPR + l];
         py[q] = reinterpret_cast<const float4*>(a.y1)[(size_t)r * LPR + l];
@@ -1730,7 +1739,8 @@ __global__ __launch_bounds__(kBlock) void sb_mask_empty_kernel(const float* __re
   }
 }
 
-// G[off[b] + len - 1] += T[b] for every non-empty sequence (each row of G is touched by one lane-group: no atomics)
+// G[off[b] + len - 1] += T[b] for every non-empty sequence (each row of G is touched by one lane-group: no atomics);
+// off == nullptr: G is the padded [B, L] layout
 template <int D>
 __global__ __launch_bounds__(kBlock) void sb_last_add_kernel(const float* __restrict__ T, const int64_t* __restrict__ lengths,
                                                              const int32_t* __restrict__ off, int B, int L, float* __restrict__ G) {
@@ -1739,7 +1749,7 @@ __global__ __launch_bounds__(kBlock) void sb_last_add_kernel(const float* __rest
   for (int b = blockIdx.x * (kBlock / LPR) + threadIdx.x / LPR; b < B; b += gridDim.x * (kBlock / LPR)) {
     const int n = sb_len(lengths, b, L);
     if (n == 0) continue;
-    float4* g = reinterpret_cast<float4*>(G) + ((size_t)off[b] + n - 1) * LPR + l;
+    float4* g = reinterpret_cast<float4*>(G) + ((off ? (size_t)off[b] : (size_t)b * L) + n - 1) * LPR + l;
     const float4 t = reinterpret_cast<const float4*>(T)[(size_t)b * LPR + l];
     float4 x = *g;
     x.x += t.x; x.y += t.y; x.z += t.z; x.w += t.w;
@@ -1748,22 +1758,30 @@ __global__ __launch_bounds__(kBlock) void sb_last_add_kernel(const float* __rest
 }
 
 static bool sb_fused_block();
-// RC_SAS_LAST_ROW=0: the last layer on all rows like the others (A/B timing, equivalence test)
-static bool sb_last_row_enabled() {
+// RC_SAS_LAST_ROW: 0 = the last layer on all rows like the others; 1 = one query row per sequence over materialised keys /
+// values (sb_attn_last_kernel); unset / 2 = the same without keys and values (sas_last_row.hpp).  (A/B timing, equivalence tests)
+static int sb_last_row_request() {
   const char* v = getenv("RC_SAS_LAST_ROW");
-  return !(v && v[0] == '0');
+  return v ? atoi(v) : 2;
 }
+// -> 0: all rows, 1: one query row over K / V, 2: one query row, no K / V
 template <int D>
-static bool sb_last_row_path(int n_heads, int B, int L, bool drop) {
-  const int dk = D / n_heads;
-  // (small row spaces are launch-bound: the path's six extra launches cost more than its rows save -- B = 256, L = 50: 0.281
-  //  against 0.266 ms per step; RC_SAS_LAST_ROW_MIN overrides the threshold on B * history_max)
+static int sb_last_row_mode(int n_heads, int B, int L, bool drop) {
+  // (small row spaces are launch-bound: the first version's six extra launches cost more than its rows save -- B = 256, L = 50:
+  //  0.281 against 0.266 ms per step; RC_SAS_LAST_ROW_MIN overrides the threshold on B * history_max)
   static const int64_t min_rows = [] {
     const char* v = getenv("RC_SAS_LAST_ROW_MIN");
     return v ? (int64_t)atoll(v) : (int64_t)32768;
   }();
-  return sb_last_row_enabled() && !drop && L >= 2 && L <= 64 && (dk == 16 || dk == 32 || dk == 64) && D % n_heads == 0 &&
-         (int64_t)B * L >= min_rows && sb_fused_block() && sb_rows16();
+  const int want = sb_last_row_request();
+  if (want <= 0 || drop || n_heads < 1 || D % n_heads != 0 || L > 64 || (int64_t)B * L < min_rows || !sb_fused_block() || !sb_rows16())
+    return 0;
+  const int dk = D / n_heads;
+  // the buffers of the K / V-free version live in the saved state's per-layer arrays: H * D + 4 <= L * D and 2 D + H L <= L D
+  const bool v2 = (n_heads == 1 || n_heads == 2 || n_heads == 4) && L >= 3 && L >= n_heads + 1 && dk % (D * D / kBlock) == 0;
+  const bool v1 = L >= 2 && (dk == 16 || dk == 32 || dk == 64);
+  if (want >= 2 && v2) return 2;
+  return v1 ? 1 : 0;
 }
 
 static int sb_fill_layers(SasLayer* layer, const float* const* layer_params, int n_layers) {
@@ -1931,6 +1949,189 @@ static bool sb_fused_block() {
   return !(v && v[0] == '0');
 }
 
+
+// ---- the K / V-free last block (sas_last_row.hpp): launch sequences ----------------------------------------------------------------------
+struct SbLastBufs {   // where its per-sequence arrays live inside the layer's saved state
+  float *q, *xl, *p, *qt, *cq, *xbar;
+};
+static SbLastBufs sb_last_bufs(const SbSaved& sv, int B, int L, int d, int n_heads) {
+  SbLastBufs u;
+  u.q = sv.q; u.xl = sv.q + (size_t)B * d; u.p = sv.q + 2 * (size_t)B * d;          // [B, D], [B, D], [B, H, L]
+  u.qt = sv.k; u.cq = sv.k + (size_t)B * n_heads * d;                                // [B, H, D], [B, 4]
+  u.xbar = sv.v;                                                                      // [B, H, D]
+  return u;
+}
+// partial-gradient slices the last block's backward writes when it runs on one row per sequence: every kernel of that path
+// launches exactly this many workgroups, so with one block no slice is left unwritten (no zero fill, a short reduction)
+static int sb_last_slots(int B) {
+  const int64_t tiles = ((int64_t)B + kSbTile - 1) / kSbTile;
+  return (int)(tiles < 1 ? 1 : (tiles > kSbPartWg ? kSbPartWg : tiles));
+}
+// ... except the key / value projections' gradients: sb_lr_wgrad_kernel sums 16 sequences per workgroup (64 would leave most
+// of the chip idle: 84 us at config 3), the reduction reads that index range with its own slice count
+static int sb_last_kv_slots(int B) {
+  const int64_t g = ((int64_t)B + kLrWgradSeqs - 1) / kLrWgradSeqs;
+  return (int)(g < 1 ? 1 : (g > kSbPartWg ? kSbPartWg : g));
+}
+static int sb_lr_grid8(int B) {   // workgroups of 8 waves, one sequence per wave and pass; the weights are staged once per workgroup
+  const int g = (B + 7) / 8;
+  return g < 1 ? 1 : (g > 1024 ? 1024 : g);
+}
+
+template <int D>
+static int sb_last_block_fwd(const float* item_emb, const float* pos_emb, const SasLayer& p, int n_heads, const int64_t* hist,
+                             const int64_t* lengths, int B, int L, bool gather, const SbSaved& sv, float* hv, const SbWs& w,
+                             SbDrop dr, hipStream_t s) {
+  const SbLastBufs u = sb_last_bufs(sv, B, L, D, n_heads);
+  float* ctxl = w.t0;
+  SbLrRows rows;
+  memset(&rows, 0, sizeof(rows));
+  rows.lengths = lengths; rows.B = B; rows.L = L;
+  if (gather) { rows.item_emb = item_emb; rows.pos_emb = pos_emb; rows.hist = hist; }
+  else { rows.X = sv.x; rows.off = w.off; }
+  {   // x_last, q = Wq x_last + bq, qt_h = Wk_h^T q_h, cq_h = q_h . bk_h
+    SbLrHeadTArgs a;
+    memset(&a, 0, sizeof(a));
+    a.rows = rows; a.Wq = p.Wq; a.bq = p.bq; a.W = p.Wk; a.bias = p.bk; a.xl = u.xl; a.q = u.q; a.outT = u.qt; a.cs = u.cq;
+    a.off_seq = w.off_seq; a.H = n_heads;
+    const size_t lds = ((size_t)2 * D * (D + 4) + (kLrBlock / 64) * 2 * D) * sizeof(float);
+    if (gather) hipLaunchKernelGGL((sb_lr_headT_kernel<D, 2>), dim3(sb_lr_grid8(B)), dim3(kLrBlock), lds, s, a);
+    else hipLaunchKernelGGL((sb_lr_headT_kernel<D, 1>), dim3(sb_lr_grid8(B)), dim3(kLrBlock), lds, s, a);
+    RC_LAUNCH_CHECK();
+  }
+  {   // probabilities and xbar_h = sum_j p_hj x_j: the one pass over the rows
+    SbLrAttnArgs a;
+    memset(&a, 0, sizeof(a));
+    a.rows = rows; a.Xsave = gather ? sv.x : nullptr; a.qt = u.qt; a.cq = u.cq; a.p = u.p; a.xbar = u.xbar;
+    const dim3 grid((unsigned)(B < 2048 ? (B < 1 ? 1 : B) : 2048)), block(kBlock);   // 19.5 KB of LDS per workgroup: eight per CU
+#define RC_LR_FWD(NH)                                                                                    \
+  do {                                                                                                   \
+    if (gather) hipLaunchKernelGGL((sb_lr_attn_fwd_kernel<D, NH, true>), grid, block, 0, s, a);          \
+    else hipLaunchKernelGGL((sb_lr_attn_fwd_kernel<D, NH, false>), grid, block, 0, s, a);                \
+  } while (0)
+    if (n_heads == 1) RC_LR_FWD(1);
+    else if (n_heads == 2) RC_LR_FWD(2);
+    else RC_LR_FWD(4);
+#undef RC_LR_FWD
+    RC_LAUNCH_CHECK();
+  }
+  {   // ctx_h = Wv_h xbar_h + bv_h
+    SbLrHeadNArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in = u.xbar; a.W = p.Wv; a.bias = p.bv; a.s = nullptr; a.lengths = lengths; a.out = ctxl; a.B = B; a.H = n_heads;
+    const size_t lds = ((size_t)D * (D + 4) + (kLrBlock / 64) * kLrMaxHeads * (D + 4)) * sizeof(float);
+    hipLaunchKernelGGL((sb_lr_headN_kernel<D>), dim3(sb_lr_grid8(B)), dim3(kLrBlock), lds, s, a);
+    RC_LAUNCH_CHECK();
+  }
+  SbBlockArgs bk;
+  bk.ctx = ctxl; bk.x = u.xl; bk.ln1w = p.ln1w; bk.ln1b = p.ln1b; bk.W1 = p.W1; bk.b1 = p.b1; bk.W2 = p.W2; bk.b2 = p.b2;
+  bk.ln2w = p.ln2w; bk.ln2b = p.ln2b; bk.xh1 = sv.xh1; bk.rstd1 = sv.rstd1; bk.y1 = sv.y1; bk.h = sv.h; bk.xh2 = sv.xh2;
+  bk.rstd2 = sv.rstd2; bk.xnext = hv; bk.off = w.off_seq; bk.B = B; bk.dr = dr;
+  bk.row_len = lengths;   // an empty history's output row is zero (SASRec.py:76 reads his[b, -1] of an all-padding row)
+  const size_t lds16 = ((size_t)2 * D * (D + 4) + 6 * (size_t)D) * sizeof(float);
+  auto kern16 = sb_block16_fwd_kernel<D>;
+  RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern16), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16));
+  int64_t gr = (((int64_t)B + 15) / 16 + 3) / 4;
+  if (gr > 768) gr = 768;
+  hipLaunchKernelGGL(kern16, dim3((unsigned)(gr < 1 ? 1 : gr)), dim3(256), lds16, s, bk);
+  RC_LAUNCH_CHECK();
+  return RC_OK;
+}
+
+template <int D, int NP>
+static int sb_wgrad(const SbWgradArgs& a, int64_t rmax, hipStream_t s);
+
+// Gout: the compact gradient rows of the block's input (padded == false), or the caller's padded [B, L, D] array (one block)
+template <int D>
+static int sb_last_block_bwd(const SasLayer& p, int n_heads, const int64_t* lengths, int B, int L, bool padded, const SbSaved& sv,
+                             const float* dhv, float* Gout, float* gp, size_t stride, const SbWs& w, SbDrop dr, hipStream_t s) {
+  using Cfg = SasCfg<D>;
+  constexpr int LPR = D / 4;
+  const SbLastBufs u = sb_last_bufs(sv, B, L, D, n_heads);
+  float* gl = w.t1;                                  // [B, D]: dhv (empty histories: 0), then dZ1 = d ctx
+  float* dql = w.t1 + (size_t)B * D;                 // [B, D]
+  float* gt = w.t2;                                  // [B, H, D]
+  float* cg = w.t2 + (size_t)B * n_heads * D;        // [B, 4]
+  float* ybar = w.t3;                                // [B, H, D]
+  float* sds = w.t3 + (size_t)B * n_heads * D;       // [B, 4]
+  float* tl = w.t4;                                  // [B, D]
+  {
+    SbBlockBwdArgs bb;
+    bb.G = gl; bb.Gb = gl; bb.xh2 = sv.xh2; bb.rstd2 = sv.rstd2; bb.h = sv.h; bb.y1 = sv.y1; bb.xh1 = sv.xh1; bb.rstd1 = sv.rstd1;
+    bb.ln2w = p.ln2w; bb.W2 = p.W2; bb.W1 = p.W1; bb.ln1w = p.ln1w; bb.part = gp; bb.part_stride = stride; bb.off = w.off_seq; bb.B = B;
+    bb.dr = dr;
+    bb.Gin = dhv; bb.row_len = lengths;   // d hv of an empty history is not propagated (its output row was zeroed)
+    const size_t lds = (size_t)(2 * D + 3 * kSbTile) * (D + 1) * sizeof(float);
+    auto kern = sb_block_bwd_kernel<D>;
+    RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int64_t tiles = ((int64_t)B + kSbTile - 1) / kSbTile;
+    if (tiles > kSbPartWg) tiles = kSbPartWg;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(tiles < 1 ? 1 : tiles)), dim3(kBlock), lds, s, bb);
+    RC_LAUNCH_CHECK();
+  }
+  {   // gt_h = Wv_h^T g_h, cg_h = g_h . bv_h
+    SbLrHeadTArgs a;
+    memset(&a, 0, sizeof(a));
+    a.rows.B = B; a.rows.L = L; a.rows.lengths = lengths;
+    a.in = gl; a.W = p.Wv; a.bias = p.bv; a.outT = gt; a.cs = cg; a.H = n_heads;
+    const size_t lds = ((size_t)D * (D + 4) + (kLrBlock / 64) * 2 * D) * sizeof(float);
+    hipLaunchKernelGGL((sb_lr_headT_kernel<D, 0>), dim3(sb_lr_grid8(B)), dim3(kLrBlock), lds, s, a);
+    RC_LAUNCH_CHECK();
+  }
+  {   // dX rows, ybar_h = sum_j ds_hj x_j, sum_j ds_hj
+    SbLrAttnArgs a;
+    memset(&a, 0, sizeof(a));
+    a.rows.X = sv.x; a.rows.off = padded ? nullptr : w.off; a.rows.lengths = lengths; a.rows.B = B; a.rows.L = L;
+    a.qt = u.qt; a.cq = u.cq; a.p = u.p; a.gt = gt; a.cg = cg; a.G = Gout; a.g_off = padded ? nullptr : w.off; a.ybar = ybar;
+    a.sds = sds;
+    const dim3 grid((unsigned)(B < 1792 ? (B < 1 ? 1 : B) : 1792)), block(kBlock);   // 21.6 KB of LDS per workgroup: seven per CU
+    if (n_heads == 1) hipLaunchKernelGGL((sb_lr_attn_bwd_kernel<D, 1>), grid, block, 0, s, a);
+    else if (n_heads == 2) hipLaunchKernelGGL((sb_lr_attn_bwd_kernel<D, 2>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((sb_lr_attn_bwd_kernel<D, 4>), grid, block, 0, s, a);
+    RC_LAUNCH_CHECK();
+  }
+  {   // dq_h = Wk_h ybar_h + bk_h sum_j ds_hj
+    SbLrHeadNArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in = ybar; a.W = p.Wk; a.bias = p.bk; a.s = sds; a.lengths = lengths; a.out = dql; a.B = B; a.H = n_heads;
+    const size_t lds = ((size_t)D * (D + 4) + (kLrBlock / 64) * kLrMaxHeads * (D + 4)) * sizeof(float);
+    hipLaunchKernelGGL((sb_lr_headN_kernel<D>), dim3(sb_lr_grid8(B)), dim3(kLrBlock), lds, s, a);
+    RC_LAUNCH_CHECK();
+  }
+  {   // dWk, dbk, dWv, dbv from the per-sequence sums
+    SbLrWgradArgs a;
+    memset(&a, 0, sizeof(a));
+    a.q = u.q; a.ybar = ybar; a.sds = sds; a.g = gl; a.xbar = u.xbar;
+    a.gWk = gp + Cfg::oWk; a.gbk = gp + Cfg::obk; a.gWv = gp + Cfg::oWv; a.gbv = gp + Cfg::obv; a.part_stride = stride;
+    a.B = B; a.H = n_heads;
+    const int grid = sb_last_kv_slots(B);
+    a.chunk = (B + grid - 1) / grid;   // (workgroups past the last sequence write zeros)
+    hipLaunchKernelGGL((sb_lr_wgrad_kernel<D>), dim3((unsigned)grid), dim3(kBlock), 0, s, a);
+    RC_LAUNCH_CHECK();
+  }
+  SbWgradArgs g;
+  memset(&g, 0, sizeof(g));
+  g.off = w.off_seq; g.B = B; g.part_stride = stride;
+  g.dY[0] = dql; g.X = u.xl; g.gW[0] = gp + Cfg::oWq; g.gb[0] = gp + Cfg::obq;
+  RC_TRY((sb_wgrad<D, 1>(g, (int64_t)B, s)));
+  {   // d x_last = dq Wq + dZ1, added to the last row's dX
+    SbSum3Args q;
+    memset(&q, 0, sizeof(q));
+    q.X[0] = dql; q.W[0] = p.Wq; q.res = gl; q.Y = tl; q.off = w.off_seq; q.B = B;
+    const size_t lds1 = (size_t)(D * (D + 4)) * sizeof(float);
+    auto kern1 = sb_sum3_16_kernel<D, 1>;
+    RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+    int grid, block;
+    sb_rows16_geometry((int64_t)B, &grid, &block);
+    hipLaunchKernelGGL(kern1, dim3((unsigned)grid), dim3((unsigned)block), lds1, s, q);
+    RC_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL((sb_last_add_kernel<D>), dim3(sb_row_grid(B, LPR)), dim3(kBlock), 0, s, tl, lengths,
+                     padded ? static_cast<const int32_t*>(nullptr) : static_cast<const int32_t*>(w.off), B, L, Gout);
+  RC_LAUNCH_CHECK();
+  return RC_OK;
+}
+
 template <int D>
 static int sb_forward(const float* item_emb, const float* pos_emb, const SasLayer* layer, int n_layers, int n_heads,
                       const int64_t* hist, const int64_t* lengths, int B, int L, float* hv, float* state,
@@ -1938,19 +2139,29 @@ static int sb_forward(const float* item_emb, const float* pos_emb, const SasLaye
   constexpr int LPR = D / 4;
   const bool drop = dr.seed != nullptr;
   const size_t rmax = (size_t)B * L;
-  hipLaunchKernelGGL(sb_offsets_kernel, dim3(1), dim3(kBlock), 0, s, lengths, B, L, w.off, w.off_seq);
-  RC_LAUNCH_CHECK();
+  const int last_mode = sb_last_row_mode<D>(n_heads, B, L, drop);
+  const bool last_row = last_mode != 0;
+  // one block, K / V-free last-row path: the block reads the table rows itself (and stores them padded, [B, L, D], for the
+  // backward) -- no compact row space, no embedding pass
+  const bool lr_gather = last_mode == 2 && n_layers == 1;
   SbSaved sv = sb_saved(state, 0, rmax, D);
-  hipLaunchKernelGGL((sb_embed_kernel<D>), dim3(sb_row_grid((int64_t)rmax, LPR)), dim3(kBlock), 0, s, item_emb, pos_emb, hist,
-                     lengths, B, L, w.off, sv.x);
-  RC_LAUNCH_CHECK();
-  const bool last_row = sb_last_row_path<D>(n_heads, B, L, drop);
+  if (!lr_gather) {
+    hipLaunchKernelGGL(sb_offsets_kernel, dim3(1), dim3(kBlock), 0, s, lengths, B, L, w.off, w.off_seq);
+    RC_LAUNCH_CHECK();
+    hipLaunchKernelGGL((sb_embed_kernel<D>), dim3(sb_row_grid((int64_t)rmax, LPR)), dim3(kBlock), 0, s, item_emb, pos_emb, hist,
+                       lengths, B, L, w.off, sv.x);
+    RC_LAUNCH_CHECK();
+  }
   for (int l = 0; l < n_layers; ++l) {
     const SasLayer& p = layer[l];
     sv = sb_saved(state, l, rmax, D);
     float* xnext = l + 1 < n_layers ? sb_saved(state, l + 1, rmax, D).x : state + (size_t)n_layers * sb_layer_floats(rmax, D);
     SbLinArgs a;
     memset(&a, 0, sizeof(a));
+    if (last_mode == 2 && l == n_layers - 1) {
+      RC_TRY((sb_last_block_fwd<D>(item_emb, pos_emb, p, n_heads, hist, lengths, B, L, lr_gather, sv, hv, w, dr, s)));
+      return RC_OK;
+    }
     if (last_row && l == n_layers - 1) {
       // k, v for all rows; the last row's x and q; one attention row per (sequence, head); the block on B rows -> hv
       float* xl = sv.q + (size_t)B * D;   // [B, D] the sequences' last rows (kept for the backward); sv.q[0, B): their queries
@@ -2104,9 +2315,12 @@ static int sb_backward(const SasLayer* layer, int n_layers, int n_heads, const i
   constexpr int LPR = D / 4, PL = Cfg::PL;
   const size_t rmax = (size_t)B * L;
   const size_t stride = (size_t)n_layers * PL;  // floats between the slices of consecutive workgroups
-  RC_HIP(hipMemsetAsync(w.part, 0, (size_t)kSbPartWg * stride * sizeof(float), s));
+  const int last_mode = sb_last_row_mode<D>(n_heads, B, L, drop);
+  const bool last_row = last_mode != 0;
+  const bool lean = last_mode == 2 && n_layers == 1;   // every launch writes the same sb_last_slots(B) slices
+  const int slots = lean ? sb_last_slots(B) : kSbPartWg;
+  if (!lean) RC_HIP(hipMemsetAsync(w.part, 0, (size_t)kSbPartWg * stride * sizeof(float), s));
   float* G = w.t0;
-  const bool last_row = sb_last_row_path<D>(n_heads, B, L, drop);
   if (!last_row) {
     hipLaunchKernelGGL((sb_seed_kernel<D>), dim3(sb_row_grid((int64_t)rmax, LPR)), dim3(kBlock), 0, s, dhv, lengths, w.off, B, L, G);
     RC_LAUNCH_CHECK();
@@ -2116,6 +2330,10 @@ static int sb_backward(const SasLayer* layer, int n_layers, int n_heads, const i
     const SasLayer& p = layer[l];
     const SbSaved sv = sb_saved(const_cast<float*>(state), l, rmax, D);
     float* gp = w.part + (size_t)l * PL;
+    if (last_mode == 2 && l == n_layers - 1) {
+      RC_TRY((sb_last_block_bwd<D>(p, n_heads, lengths, B, L, n_layers == 1, sv, dhv, n_layers == 1 ? g_hist : G, gp, stride, w, dr, s)));
+      continue;
+    }
     if (last_row && l == n_layers - 1) {
       // the last block saw one row per sequence (sb_forward): block backward on B rows, one attention row per (sequence, head)
       // backward -> dQ [B], dK / dV [R]; dX = dK Wk + dV Wv on all rows, + (dQ Wq + dZ1) on the last rows
@@ -2268,12 +2486,18 @@ static int sb_backward(const SasLayer* layer, int n_layers, int n_heads, const i
       RC_LAUNCH_CHECK();
     }
   }
-  hipLaunchKernelGGL((sb_unpack_kernel<D>), dim3(sb_row_grid((int64_t)rmax, LPR)), dim3(kBlock), 0, s, G, lengths, w.off, B, L,
-                     g_hist);
-  RC_LAUNCH_CHECK();
+  if (!(last_mode == 2 && n_layers == 1)) {   // (that path writes the padded layout itself)
+    hipLaunchKernelGGL((sb_unpack_kernel<D>), dim3(sb_row_grid((int64_t)rmax, LPR)), dim3(kBlock), 0, s, G, lengths, w.off, B, L,
+                       g_hist);
+    RC_LAUNCH_CHECK();
+  }
   const int count = n_layers * PL;
-  hipLaunchKernelGGL(sas_reduce_partials_kernel, dim3((count + 63) / 64), dim3(kBlock), 0, s, w.part, kSbPartWg, count,
-                     dense_out);
+  if (lean)   // (one block: the index range Wk .. bv of its parameter block has its own slice count)
+    hipLaunchKernelGGL(sas_reduce_partials_kernel, dim3((count + 63) / 64), dim3(kBlock), 0, s, w.part, slots, count,
+                       dense_out, (int)Cfg::oWk, (int)Cfg::oln1w, sb_last_kv_slots(B));
+  else
+    hipLaunchKernelGGL(sas_reduce_partials_kernel, dim3((count + 63) / 64), dim3(kBlock), 0, s, w.part, slots, count,
+                       dense_out, 0, 0, 0);
   RC_LAUNCH_CHECK();
   return RC_OK;
 }

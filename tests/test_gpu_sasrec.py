@@ -288,6 +288,41 @@ def test_segmented_update_rows_equals_head_list_route(d, n_rows, n_a, C, n_b, op
         assert_close(a, b, what=f"rows route vs head list (d={d}, opt={opt})", rtol=2e-5, atol_scale=2e-5)
 
 
+@pytest.mark.parametrize("opt,overlap", [("SGD", True), ("Adagrad", False)])
+def test_sasrec_trainer_graph_replay_equals_eager(opt, overlap, cuda, eng, monkeypatch):
+    """SasrecTrainer(graph=True) replays the step from a hipGraph (both streams captured, the batch copied into static
+    buffers): seven steps over different batches -- two eager, the capture, four replays -- leave the loss sequence and every
+    parameter bit-identical to the eager trainer"""
+    from rechorus_amd import graph as hgraph
+    if not hgraph.usable():
+        pytest.skip("hipGraph replay not enabled in this process")
+    rng = np.random.default_rng(17)
+    B, L, d, n_layers, n_heads, C, n_items = 500, 50, 64, 1, 4, 20, 400
+    P = _random_sasrec(rng, n_items, d, n_layers, L)
+    batches = []
+    for _ in range(7):
+        lengths = rng.integers(0, L + 1, size=B).astype(np.int64)
+        hist = rng.integers(1, n_items, size=(B, L)).astype(np.int64) * (np.arange(L)[None, :] < lengths[:, None])
+        iid = rng.integers(1, n_items, size=(B, C)).astype(np.int64)
+        batches.append(tuple(torch.from_numpy(x).to(cuda) for x in (hist, lengths, iid)))
+    monkeypatch.setattr(eng, "_SAS_OVERLAP", overlap)
+    monkeypatch.setattr(eng, "_SAS_OVERLAP_MIN", 0)
+    out = {}
+    for graph in (False, True):
+        Pd = to_dev(P, n_layers, cuda)
+        tr = eng.SasrecTrainer(Pd, n_heads, opt=opt, lr=1e-2, l2=1e-5, rowwise=True, graph=graph)
+        losses = [float(tr.step(*b)[0]) for b in batches]
+        torch.cuda.synchronize()
+        assert (len(tr._graphs) == 1) == graph
+        out[graph] = (losses, Pd["item_emb"].cpu().numpy(), Pd["pos_emb"].cpu().numpy(),
+                      [{k: v.cpu().numpy() for k, v in lay.items()} for lay in Pd["layers"]])
+    assert out[True][0] == out[False][0] and len(set(out[True][0])) == len(batches)
+    assert np.array_equal(out[True][1], out[False][1]) and np.array_equal(out[True][2], out[False][2])
+    assert all(np.array_equal(out[True][3][l][k], out[False][3][l][k]) for l in range(n_layers) for k in LAYER_NAMES)
+    with pytest.raises(ValueError):
+        eng.SasrecTrainer(to_dev(P, n_layers, cuda), n_heads, opt="Adam", graph=True)
+
+
 @pytest.mark.parametrize("rowwise", [False, True])
 def test_sasrec_trainer_two_streams_equal_one_stream(rowwise, cuda, eng, monkeypatch):
     """SasrecTrainer sorts the batch's ids beside the encoder and forms the position-table gradient beside the item-table
@@ -372,13 +407,19 @@ def test_sasrec_16_row_projection_kernels_equal_lds_tile_kernels(d, n_layers, n_
     assert np.all(out["1"][0][lengths == 0] == 0) and np.all(out["1"][1][lengths == 0] == 0)
 
 
-@pytest.mark.parametrize("d,n_layers,n_heads,L,B", [(64, 1, 4, 50, 700), (64, 2, 4, 50, 300), (64, 1, 1, 20, 90), (32, 1, 2, 64, 130),
-                                                    (64, 3, 2, 7, 40), (64, 1, 4, 2, 9)])
-def test_sasrec_last_row_path_equals_all_rows(d, n_layers, n_heads, L, B, cuda, eng, monkeypatch):
+# (d, layers, heads, L, B, versions of the last-row path the shape is eligible for)
+LAST_ROW_CASES = [(64, 1, 4, 50, 700, "12"), (64, 2, 4, 50, 300, "12"), (64, 1, 1, 20, 90, "12"), (32, 1, 2, 64, 130, "12"),
+                  (64, 3, 2, 7, 40, "12"), (64, 1, 4, 2, 9, "1"), (32, 1, 4, 12, 50, "2"), (64, 2, 2, 3, 33, "12"),
+                  (64, 1, 4, 4, 21, "1"), (32, 2, 1, 64, 70, "12"), (64, 1, 2, 64, 260, "12")]
+
+
+@pytest.mark.parametrize("d,n_layers,n_heads,L,B,eligible", LAST_ROW_CASES)
+def test_sasrec_last_row_path_equals_all_rows(d, n_layers, n_heads, L, B, eligible, cuda, eng, monkeypatch):
     """Only position len - 1 of the last block is consumed (SASRec.py:76): the batch encoder runs the last block for one query
-    row per sequence (k / v on all rows, one attention row per head, LayerNorm - FFN - LayerNorm on B rows) and mirrors it in the
-    backward.  Against the all-rows path (RC_SAS_LAST_ROW=0): hv, the history gradient and every parameter gradient, empty
-    histories and single-item histories included; and the oracle on a sample."""
+    row per sequence and mirrors it in the backward -- RC_SAS_LAST_ROW=1: k / v on all rows, one attention row per head;
+    =2 (default): without keys and values at all (csrc/sas_last_row.hpp: scores = (Wk_h^T q_h) . x_j, ctx = Wv_h sum_j p_j x_j;
+    with one block the rows come straight from the tables and the gradient rows are written padded).  Against the all-rows
+    path (RC_SAS_LAST_ROW=0): hv, the history gradient and every parameter gradient, empty and single-item histories included."""
     rng = np.random.default_rng(31 * d + L + B)
     n_items = 300
     P = _random_sasrec(rng, n_items, d, n_layers, L)
@@ -389,25 +430,31 @@ def test_sasrec_last_row_path_equals_all_rows(d, n_layers, n_heads, L, B, cuda, 
     h_d, l_d = torch.from_numpy(hist).to(cuda), torch.from_numpy(lengths).to(cuda)
     dhv = torch.from_numpy(rng.normal(size=(B, d)).astype(np.float32)).to(cuda)
     out = {}
-    for mode in ("1", "0", "1"):
+    for mode in ("2", "1", "0", "2", "1"):
         monkeypatch.setenv("RC_SAS_LAST_ROW", mode)
         hv, saved = eng.sasrec_fwd(Pd["item_emb"], Pd["pos_emb"], Pd["layers"], n_heads, h_d, l_d, save=True, impl="batch")
         g_hist, dg = eng.sasrec_bwd(Pd["layers"], n_heads, l_d, saved, dhv)
         torch.cuda.synchronize()
         res = (hv.cpu().numpy(), g_hist.cpu().numpy(), [{k: v.cpu().numpy() for k, v in g.items()} for g in dg])
-        if mode in out:
+        if mode in out:   # run to run: bit for bit
             assert np.array_equal(res[0], out[mode][0]) and np.array_equal(res[1], out[mode][1])
             assert all(np.array_equal(res[2][l][k], out[mode][2][l][k]) for l in range(n_layers) for k in LAYER_NAMES)
         out[mode] = res
-    what = f"d={d} layers={n_layers} heads={n_heads} L={L} B={B}"
-    assert not np.array_equal(out["1"][1], out["0"][1]), what + ": the switch had no effect"
-    assert_close(out["1"][0], out["0"][0], what=what + " hv", rtol=2e-5, atol_scale=2e-5)
-    assert_close(out["1"][1], out["0"][1], what=what + " g_hist", rtol=5e-5, atol_scale=5e-5)
     floor = 1e-6 * max(float(np.abs(v).max()) for g in out["0"][2] for v in g.values())
-    for l in range(n_layers):
-        for k in LAYER_NAMES:
-            assert_close(out["1"][2][l][k], out["0"][2][l][k], what=f"{what} layer {l} d{k}", rtol=5e-5, atol_scale=1e-4, abs_floor=floor)
-    assert np.all(out["1"][0][lengths == 0] == 0) and np.all(out["1"][1][lengths == 0] == 0)
+    for mode in ("1", "2"):
+        what = f"d={d} layers={n_layers} heads={n_heads} L={L} B={B} last-row version {mode}"
+        if mode in eligible:
+            assert not np.array_equal(out[mode][1], out["0"][1]), what + ": the switch had no effect"
+        if "1" in eligible and "2" in eligible:
+            assert not np.array_equal(out["1"][1], out["2"][1]), what + ": versions 1 and 2 ran the same kernels"
+        assert_close(out[mode][0], out["0"][0], what=what + " hv", rtol=2e-5, atol_scale=2e-5)
+        assert_close(out[mode][1], out["0"][1], what=what + " g_hist", rtol=5e-5, atol_scale=5e-5)
+        for l in range(n_layers):
+            for k in LAYER_NAMES:
+                assert_close(out[mode][2][l][k], out["0"][2][l][k], what=f"{what} layer {l} d{k}", rtol=5e-5, atol_scale=1e-4, abs_floor=floor)
+        assert np.all(out[mode][0][lengths == 0] == 0) and np.all(out[mode][1][lengths == 0] == 0)
+        pad = np.arange(L)[None, :] >= lengths[:, None]
+        assert np.all(out[mode][1][pad] == 0), what + ": gradient rows past the length"
 
 
 def test_sasrec_pos_grad_chunks(cuda, eng):
