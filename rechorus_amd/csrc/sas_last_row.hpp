@@ -182,6 +182,80 @@ __global__ __launch_bounds__(kLrBlock) void sb_lr_headN_kernel(SbLrHeadNArgs a) 
   }
 }
 
+// The tail of the block's backward on one row per sequence, in one pass: dq = Wk_h ybar_h + bk_h sum_j ds_hj (stored: the query
+// projection's weight gradient needs it), d x_last = dq Wq + dZ1, added to the last row's dX (each row of G is touched by one wave).
+// (Three launches before -- head product, 16-row-tile product, row add: 22 us of mostly launch latency at config 3.)
+struct SbLrTailArgs {
+  const float* ybar;        // [B, H, D]
+  const float* sds;         // [B, 4]
+  const float* gl;          // [B, D] dZ1
+  const float *Wk, *bk, *Wq;
+  const int64_t* lengths;
+  const int32_t* g_off;     // G row of (b, j): (g_off ? g_off[b] : b * L) + j
+  float* dq;                // [B, D] out
+  float* G;
+  int B, L, H;
+};
+
+template <int D>
+__global__ __launch_bounds__(kLrBlock) void sb_lr_tail_kernel(SbLrTailArgs a) {
+  constexpr int SW = D + 4, LPR = D / 4;
+  extern __shared__ float lds[];
+  float* Wks = lds;                // [D][SW]
+  float* Wqs = Wks + D * SW;       // [D][SW]
+  float* sin = Wqs + D * SW + (threadIdx.x >> 6) * (kLrMaxHeads * SW + D);   // this wave's [H][SW] head sums, then [D] dq
+  float* sdq = sin + kLrMaxHeads * SW;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int H = a.H, DK = D / H;
+  constexpr int NPRE = kLrMaxHeads * D / 64;
+  int b = (int)blockIdx.x * (kLrBlock / 64) + wave;
+  float pre[NPRE];   // the first sequence's input travels while the weights are staged
+#pragma unroll
+  for (int k = 0; k < NPRE; ++k) pre[k] = (b < a.B && lane + 64 * k < H * D) ? a.ybar[(size_t)b * H * D + lane + 64 * k] : 0.f;
+  for (int idx = threadIdx.x; idx < D * LPR; idx += kLrBlock) {
+    const int o = idx / LPR, c = idx % LPR;
+    *reinterpret_cast<float4*>(Wks + o * SW + 4 * c) = reinterpret_cast<const float4*>(a.Wk)[idx];
+    *reinterpret_cast<float4*>(Wqs + o * SW + 4 * c) = reinterpret_cast<const float4*>(a.Wq)[idx];
+  }
+  __syncthreads();
+  bool first = true;
+  for (; b < a.B; b += (int)gridDim.x * (kLrBlock / 64)) {
+#pragma unroll
+    for (int k = 0; k < NPRE; ++k) {
+      const int e = lane + 64 * k;
+      if (e < H * D) sin[(e / D) * SW + e % D] = first ? pre[k] : a.ybar[(size_t)b * H * D + e];
+    }
+    first = false;
+    const int64_t len = a.lengths[b];
+    const int n = (int)(len < 0 ? 0 : (len > a.L ? a.L : len));
+    const float gv = lane < D ? a.gl[(size_t)b * D + lane] : 0.f;
+    wave_lds_sync();
+    if (lane < D) {
+      const int h = lane / DK;
+      float acc = 0.f;
+#pragma unroll
+      for (int c = 0; c < LPR; ++c) {
+        const float4 w4 = *reinterpret_cast<const float4*>(Wks + lane * SW + 4 * c);
+        const float4 v4 = *reinterpret_cast<const float4*>(sin + h * SW + 4 * c);
+        acc = fmaf(w4.x, v4.x, acc); acc = fmaf(w4.y, v4.y, acc); acc = fmaf(w4.z, v4.z, acc); acc = fmaf(w4.w, v4.w, acc);
+      }
+      acc = fmaf(a.bk[lane], a.sds[(size_t)b * kLrMaxHeads + h], acc);
+      a.dq[(size_t)b * D + lane] = acc;
+      sdq[lane] = acc;
+    }
+    wave_lds_sync();
+    if (lane < D && n > 0) {
+      float acc = gv;
+      const float* wc = Wqs + lane;
+#pragma unroll 8
+      for (int o = 0; o < D; ++o) acc = fmaf(sdq[o], wc[o * SW], acc);
+      float* g = a.G + ((a.g_off ? (size_t)a.g_off[b] : (size_t)b * a.L) + n - 1) * D + lane;
+      *g += acc;
+    }
+    wave_lds_sync();
+  }
+}
+
 // ---- the streaming passes: one 4-wave workgroup per sequence ---------------------------------------------------------------------------
 // The sequence's rows are staged once in LDS (coalesced: D / 4 lanes per row).  Wave h owns head h: with lane = key it takes the
 // scores and the softmax of its head, with lane = feature the weighted row sum.  (First version: one wave per sequence doing
@@ -225,21 +299,35 @@ __device__ __forceinline__ float sb_lr_row_dot(const float* row, const float* ve
   return s;
 }
 
-// sum_{j < n} w[4 j + h] tile[j][lane]   (lane = feature)
+// sum_{j < n} w[4 j + h] tile[j][4 f .. 4 f + 3]: lane = (feature quad f = lane % (D / 4), key group g = lane / (D / 4)); group g takes
+// the keys j = g, g + NG, ...; the groups are added through xor-shuffles, every lane returns the total of its feature quad.
+// (First version: lane = feature, one 4-byte LDS read per key and lane -- 25 dependent read latencies per sequence, a quarter of
+// the forward kernel's time; one 16-byte read per 4 keys here.)
 template <int D>
-__device__ __forceinline__ float sb_lr_weighted_rows(const float* tile, const float* w, int h, int n, int lane) {
-  constexpr int ST = D + 4;
-  const float* col = tile + (lane < D ? lane : 0);
-  float a0 = 0.f, a1 = 0.f;
-  int j = 0;
-  for (; j + 4 <= n; j += 4) {
-    a0 = fmaf(w[4 * j + h], col[j * ST], a0);
-    a1 = fmaf(w[4 * (j + 1) + h], col[(j + 1) * ST], a1);
-    a0 = fmaf(w[4 * (j + 2) + h], col[(j + 2) * ST], a0);
-    a1 = fmaf(w[4 * (j + 3) + h], col[(j + 3) * ST], a1);
+__device__ __forceinline__ float4 sb_lr_weighted_rows(const float* tile, const float* w, int h, int n, int lane) {
+  constexpr int ST = D + 4, LPR = D / 4, NG = 64 / LPR;
+  const int f = lane % LPR, g = lane / LPR;
+  float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+  const float* col = tile + 4 * f;
+  int j = g;
+  for (; j + NG < n; j += 2 * NG) {
+    const float4 x0 = *reinterpret_cast<const float4*>(col + j * ST), x1 = *reinterpret_cast<const float4*>(col + (j + NG) * ST);
+    const float w0 = w[4 * j + h], w1 = w[4 * (j + NG) + h];
+    a0.x = fmaf(w0, x0.x, a0.x); a0.y = fmaf(w0, x0.y, a0.y); a0.z = fmaf(w0, x0.z, a0.z); a0.w = fmaf(w0, x0.w, a0.w);
+    a1.x = fmaf(w1, x1.x, a1.x); a1.y = fmaf(w1, x1.y, a1.y); a1.z = fmaf(w1, x1.z, a1.z); a1.w = fmaf(w1, x1.w, a1.w);
   }
-  for (; j < n; ++j) a0 = fmaf(w[4 * j + h], col[j * ST], a0);
-  return a0 + a1;
+  if (j < n) {
+    const float4 x0 = *reinterpret_cast<const float4*>(col + j * ST);
+    const float w0 = w[4 * j + h];
+    a0.x = fmaf(w0, x0.x, a0.x); a0.y = fmaf(w0, x0.y, a0.y); a0.z = fmaf(w0, x0.z, a0.z); a0.w = fmaf(w0, x0.w, a0.w);
+  }
+  a0.x += a1.x; a0.y += a1.y; a0.z += a1.z; a0.w += a1.w;
+#pragma unroll
+  for (int off = LPR; off < 64; off <<= 1) {
+    a0.x += __shfl_xor(a0.x, off, 64); a0.y += __shfl_xor(a0.y, off, 64);
+    a0.z += __shfl_xor(a0.z, off, 64); a0.w += __shfl_xor(a0.w, off, 64);
+  }
+  return a0;
 }
 
 template <int D, int NH, bool GATHER>
@@ -290,8 +378,8 @@ __global__ __launch_bounds__(kBlock) void sb_lr_attn_fwd_kernel(SbLrAttnArgs a) 
     }
     __syncthreads();
     if (wave < NH) {   // lane = feature
-      const float acc = sb_lr_weighted_rows<D>(tile, sp, wave, n, lane);
-      if (lane < D) a.xbar[((size_t)b * NH + wave) * D + lane] = acc;
+      const float4 acc = sb_lr_weighted_rows<D>(tile, sp, wave, n, lane);
+      if (lane < D / 4) reinterpret_cast<float4*>(a.xbar + ((size_t)b * NH + wave) * D)[lane] = acc;
     }
     __syncthreads();   // the tile is rewritten by the next sequence
   }
@@ -345,8 +433,8 @@ __global__ __launch_bounds__(kBlock) void sb_lr_attn_bwd_kernel(SbLrAttnArgs a) 
     }
     __syncthreads();
     if (wave < NH) {   // lane = feature
-      const float acc = sb_lr_weighted_rows<D>(tile, sw, wave, n, lane);
-      if (lane < D) a.ybar[((size_t)b * NH + wave) * D + lane] = acc;
+      const float4 acc = sb_lr_weighted_rows<D>(tile, sw, wave, n, lane);
+      if (lane < D / 4) reinterpret_cast<float4*>(a.ybar + ((size_t)b * NH + wave) * D)[lane] = acc;
     }
     __syncthreads();   // every wave is done with the x rows: the tile now takes the dX rows
     {   // row `lane`, columns [wave * D / 4, (wave + 1) * D / 4); rows past the length have ds = p = 0

@@ -2054,7 +2054,6 @@ static int sb_last_block_bwd(const SasLayer& p, int n_heads, const int64_t* leng
   float* cg = w.t2 + (size_t)B * n_heads * D;        // [B, 4]
   float* ybar = w.t3;                                // [B, H, D]
   float* sds = w.t3 + (size_t)B * n_heads * D;       // [B, 4]
-  float* tl = w.t4;                                  // [B, D]
   {
     SbBlockBwdArgs bb;
     bb.G = gl; bb.Gb = gl; bb.xh2 = sv.xh2; bb.rstd2 = sv.rstd2; bb.h = sv.h; bb.y1 = sv.y1; bb.xh1 = sv.xh1; bb.rstd1 = sv.rstd1;
@@ -2090,12 +2089,13 @@ static int sb_last_block_bwd(const SasLayer& p, int n_heads, const int64_t* leng
     else hipLaunchKernelGGL((sb_lr_attn_bwd_kernel<D, 4>), grid, block, 0, s, a);
     RC_LAUNCH_CHECK();
   }
-  {   // dq_h = Wk_h ybar_h + bk_h sum_j ds_hj
-    SbLrHeadNArgs a;
+  {   // dq_h = Wk_h ybar_h + bk_h sum_j ds_hj;  d x_last = dq Wq + dZ1, added to the last row's dX
+    SbLrTailArgs a;
     memset(&a, 0, sizeof(a));
-    a.in = ybar; a.W = p.Wk; a.bias = p.bk; a.s = sds; a.lengths = lengths; a.out = dql; a.B = B; a.H = n_heads;
-    const size_t lds = ((size_t)D * (D + 4) + (kLrBlock / 64) * kLrMaxHeads * (D + 4)) * sizeof(float);
-    hipLaunchKernelGGL((sb_lr_headN_kernel<D>), dim3(sb_lr_grid8(B)), dim3(kLrBlock), lds, s, a);
+    a.ybar = ybar; a.sds = sds; a.gl = gl; a.Wk = p.Wk; a.bk = p.bk; a.Wq = p.Wq; a.lengths = lengths;
+    a.g_off = padded ? nullptr : w.off; a.dq = dql; a.G = Gout; a.B = B; a.L = L; a.H = n_heads;
+    const size_t lds = ((size_t)2 * D * (D + 4) + (kLrBlock / 64) * (kLrMaxHeads * (D + 4) + D)) * sizeof(float);
+    hipLaunchKernelGGL((sb_lr_tail_kernel<D>), dim3(sb_lr_grid8(B)), dim3(kLrBlock), lds, s, a);
     RC_LAUNCH_CHECK();
   }
   {   // dWk, dbk, dWv, dbv from the per-sequence sums
@@ -2114,21 +2114,6 @@ static int sb_last_block_bwd(const SasLayer& p, int n_heads, const int64_t* leng
   g.off = w.off_seq; g.B = B; g.part_stride = stride;
   g.dY[0] = dql; g.X = u.xl; g.gW[0] = gp + Cfg::oWq; g.gb[0] = gp + Cfg::obq;
   RC_TRY((sb_wgrad<D, 1>(g, (int64_t)B, s)));
-  {   // d x_last = dq Wq + dZ1, added to the last row's dX
-    SbSum3Args q;
-    memset(&q, 0, sizeof(q));
-    q.X[0] = dql; q.W[0] = p.Wq; q.res = gl; q.Y = tl; q.off = w.off_seq; q.B = B;
-    const size_t lds1 = (size_t)(D * (D + 4)) * sizeof(float);
-    auto kern1 = sb_sum3_16_kernel<D, 1>;
-    RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
-    int grid, block;
-    sb_rows16_geometry((int64_t)B, &grid, &block);
-    hipLaunchKernelGGL(kern1, dim3((unsigned)grid), dim3((unsigned)block), lds1, s, q);
-    RC_LAUNCH_CHECK();
-  }
-  hipLaunchKernelGGL((sb_last_add_kernel<D>), dim3(sb_row_grid(B, LPR)), dim3(kBlock), 0, s, tl, lengths,
-                     padded ? static_cast<const int32_t*>(nullptr) : static_cast<const int32_t*>(w.off), B, L, Gout);
-  RC_LAUNCH_CHECK();
   return RC_OK;
 }
 

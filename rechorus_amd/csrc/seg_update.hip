@@ -866,7 +866,7 @@ extern "C" int rc_segmented_update2(float* W, float* m, float* v, int d, const u
 
 extern "C" size_t rc_segmented_rows_workspace_bytes(int64_t n_rows, int64_t n_occ, int d) {
   if (n_rows < 1) n_rows = 1;
-  return rc_segmented_workspace_bytes(n_occ, d) + align_up(2 * (size_t)n_rows * sizeof(uint32_t), 256) + 256;
+  return rc_segmented_workspace_bytes(n_occ, d) + align_up((2 * (size_t)n_rows + 64) * sizeof(uint32_t), 256) + 256;
 }
 
 // rc_segmented_update2 for a table of n_rows rows that collect many occurrences each (section 4 above); keys / perm
@@ -889,7 +889,9 @@ extern "C" int rc_segmented_update_rows(float* W, float* m, float* v, int d, int
     return fail(RC_ERR_WORKSPACE, "rc_segmented_update_rows: workspace %zu < %zu", ws_bytes,
                 rc_segmented_rows_workspace_bytes(n_rows, n_occ, d));
   const SegWs w = carve_seg_ws(ws, n_occ, d);
-  uint32_t* start = reinterpret_cast<uint32_t*>(static_cast<char*>(ws) + align_up(w.total, 256));
+  // [counters (64 words) | start | end]: zeroed by ONE fill (the counters of the long-row pass sit beside the bounds)
+  uint32_t* counters = reinterpret_cast<uint32_t*>(static_cast<char*>(ws) + align_up(w.total, 256));
+  uint32_t* start = counters + 64;
   uint32_t* end = start + n_rows;
   hipStream_t s = as_stream(stream);
   SegArgs a;
@@ -899,7 +901,7 @@ extern "C" int rc_segmented_update_rows(float* W, float* m, float* v, int d, int
   a.coef = coef; a.src = src; a.src_index = src_index; a.div = div; a.d = d;
   a.src2 = src2; a.n_split = (uint32_t)n_split;
   a.dense_grad = dense_grad;
-  a.counters = w.counters; a.long_list = w.long_list; a.rows = w.rows; a.chunks = w.chunks;
+  a.counters = counters; a.long_list = w.long_list; a.rows = w.rows; a.chunks = w.chunks;
   a.partial = w.partial;
   a.long_cap = w.long_cap; a.chunk_cap = w.chunk_cap; a.partial_cap = w.partial_cap;
   int mode = MODE_DENSE_GRAD;
@@ -909,8 +911,8 @@ extern "C" int rc_segmented_update_rows(float* W, float* m, float* v, int d, int
     RC_REQUIRE(mode != MODE_ADAM || (m && v), "rc_segmented_update_rows: Adam needs m and v");
     RC_REQUIRE(mode != MODE_ADAGRAD || m, "rc_segmented_update_rows: Adagrad needs m (state_sum)");
   }
-  RC_HIP(hipMemsetAsync(w.counters, 0, CNT_N * sizeof(uint32_t), s));
-  RC_HIP(hipMemsetAsync(start, 0, 2 * (size_t)n_rows * sizeof(uint32_t), s));   // absent rows: start = end = 0
+  static_assert(CNT_N <= 64, "counters beside the bounds");
+  RC_HIP(hipMemsetAsync(counters, 0, (64 + 2 * (size_t)n_rows) * sizeof(uint32_t), s));   // absent rows: start = end = 0
   hipLaunchKernelGGL(segment_bounds_kernel, dim3((unsigned)((n_occ + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, keys, n_occ, 0u,
                      (uint32_t)n_rows, start, end);
   RC_LAUNCH_CHECK();
