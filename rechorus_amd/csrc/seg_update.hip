@@ -525,14 +525,30 @@ __global__ __launch_bounds__(kBlock) void seg_rows_kernel(SegArgs a, const uint3
   }
   const uint32_t key = r + a.key_base;
   const float4 w = load_row4<D, MODE>(a, key, l);
+  // The segment's occurrence numbers first (at most kRowsWaveMax = 3 per lane, one round of independent loads), handed out by
+  // shuffles; then 8 gradient rows in flight per lane-group.  (Before: perm[j] -> row per occurrence, four per group and round:
+  // a row of 192 occurrences was twelve rounds of two dependent loads, and the longest rows set the kernel's time -- 36 us at
+  // SASRec config 3 for 40 MB of traffic.)
+  static_assert(kRowsWaveMax <= 192, "three occurrence numbers per lane");
+  const int cnt = (int)(j1 - j0);
+  uint32_t pm[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) pm[k] = 64 * k + lane < cnt ? a.perm[j0 + 64 * k + lane] : 0u;
   float4 acc = make_float4(0, 0, 0, 0);
-  for (int64_t jj = j0 + g; jj < j1; jj += 4 * G) {
-    const float4 z = make_float4(0, 0, 0, 0);
-    const float4 s0 = occ_grad4<D>(a, jj, l);
-    const float4 s1 = (jj + G < j1) ? occ_grad4<D>(a, jj + G, l) : z;
-    const float4 s2 = (jj + 2 * G < j1) ? occ_grad4<D>(a, jj + 2 * G, l) : z;
-    const float4 s3 = (jj + 3 * G < j1) ? occ_grad4<D>(a, jj + 3 * G, l) : z;
-    add4(acc, s0); add4(acc, s1); add4(acc, s2); add4(acc, s3);
+  constexpr int U = 8;   // (U * G = 32 or more occurrences per round; a round never straddles a multiple of 64)
+  for (int base = 0; base < cnt; base += U * G) {
+    const int k = base >> 6;   // wave-uniform
+    const uint32_t mine = k == 0 ? pm[0] : (k == 1 ? pm[1] : pm[2]);
+    const uint32_t next = k == 0 ? pm[1] : pm[2];   // (U * G > 64 only for D < 32: the round's second half)
+    float4 sv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int idx = base + u * G + g;
+      const uint32_t o = __shfl((idx >> 6) == k ? mine : next, idx & 63, 64);
+      sv[u] = idx < cnt ? occ_grad4_o<D>(a, o, l) : make_float4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) add4(acc, sv[u]);
   }
 #pragma unroll
   for (int off = LPR; off < 64; off <<= 1) {   // both partners form the same sum: every group ends with the row's total

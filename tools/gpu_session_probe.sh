@@ -6,7 +6,7 @@ R=$PWD
 export TMPDIR=/tmp
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
-timeout 900 python -m pytest tests/test_gpu_sasrec.py -m gpu -q --maxfail=30 --tb=short -p no:cacheprovider 2>&1 | tail -5
+timeout 900 python -m pytest tests/test_gpu_sasrec.py tests/test_gpu_plan.py -m gpu -q --maxfail=30 --tb=short -p no:cacheprovider 2>&1 | tail -5
 timeout 300 python tools/sasrec_host_probe.py 2>&1 | grep -v amdgpu.ids | tail -7
 B=256 timeout 300 python tools/sasrec_host_probe.py 2>&1 | grep -v amdgpu.ids | tail -4
 line() { python -c "
