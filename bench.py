@@ -124,8 +124,8 @@ def make_sasrec(args, device, engine, seed):
         lay["ln2w"] += 1.0
         layers.append(lay)
     P = {"item_emb": mk(args.items, d), "pos_emb": mk(L + 1, d), "layers": layers}
-    # the step replays from a hipGraph after two eager steps (SGD / Adagrad; RC_SAS_GRAPH=0: eager, bound by the host's launch rate)
-    args.sas_graph = args.opt != "Adam" and os.environ.get("RC_SAS_GRAPH", "1") != "0"
+    # the step replays from a hipGraph after two eager steps (RC_SAS_GRAPH=0: eager, bound by the host's launch rate)
+    args.sas_graph = os.environ.get("RC_SAS_GRAPH", "1") != "0"   # (Adam: step count in device memory)
     trainer = engine.SasrecTrainer(P, args.heads, opt=args.opt, lr=args.lr, l2=args.l2, rowwise=True, graph=args.sas_graph)
     gen.manual_seed(seed)
     batches = []
@@ -449,9 +449,9 @@ def model_roofline(args, trainer, batches, engine):
         # rows: it is rated against HBM below
         H = args.heads
         want = int(os.environ.get("RC_SAS_LAST_ROW", "2"))
-        ok = want > 0 and L <= 64 and d % H == 0 and B * L >= int(os.environ.get("RC_SAS_LAST_ROW_MIN", "32768"))
+        ok = want > 0 and L <= 64 and d % H == 0
         v2 = ok and want >= 2 and H in (1, 2, 4) and L >= max(3, H + 1) and (d // H) % (d * d // 256) == 0
-        v1 = ok and L >= 2 and (d // H) in (16, 32, 64)
+        v1 = ok and L >= 2 and (d // H) in (16, 32, 64) and B * L >= int(os.environ.get("RC_SAS_LAST_ROW_MIN", "32768"))
         mode = 2 if v2 else (1 if v1 else 0)
         last = {0: full, 1: R * 4.0 * d * d + B * 6.0 * d * d + 4.0 * R * d, 2: B * 10.0 * d * d + 4.0 * R * H * d}[mode]
         fwd = (nl - 1) * full + last

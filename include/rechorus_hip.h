@@ -304,6 +304,15 @@ int rc_segmented_update_rows(float* W, float* m, float* v, int d, int64_t n_rows
                              const uint32_t* perm, int64_t n_occ, const float* coef, const float* src,
                              const int64_t* src_index, int div, const float* src2, int64_t n_split,
                              const rc_opt_hyper* h, float* dense_grad, void* ws, size_t ws_bytes, rc_stream_t stream);
+/* The same with Adam's step count t read from device memory when the kernels run (step_dev[0] >= 1; h->step is not used; the
+ * bias corrections 1 - beta^t are formed in the kernel with fill-in-double arithmetic like the host's): the launch can be
+ * captured in a hipGraph and replayed while rc_step_increment advances the counter, as rc_dense_update_multi_dev does for
+ * the dense parameters (torch.optim.Adam(capturable=True) semantics, helpers/BaseRunner.py:110-114,206).  SGD / Adagrad: as above. */
+int rc_segmented_update_rows_dev(float* W, float* m, float* v, int d, int64_t n_rows, const uint32_t* keys,
+                                 const uint32_t* perm, int64_t n_occ, const float* coef, const float* src,
+                                 const int64_t* src_index, int div, const float* src2, int64_t n_split,
+                                 const rc_opt_hyper* h, const int64_t* step_dev, float* dense_grad, void* ws, size_t ws_bytes,
+                                 rc_stream_t stream);
 
 /* aten::embedding_dense_backward for a SMALL id list (n <= 32,768; helpers/BaseRunner.py:205 behind loss.backward() at the
  * reference's own batch sizes: 1,024 rows x 8 fields of a CTR step -- models/context/FM.py:49-52 --, 256 x (1 + K) candidates)

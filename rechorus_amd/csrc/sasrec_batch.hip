@@ -1768,18 +1768,19 @@ static int sb_last_row_request() {
 template <int D>
 static int sb_last_row_mode(int n_heads, int B, int L, bool drop) {
   // (small row spaces are launch-bound: the first version's six extra launches cost more than its rows save -- B = 256, L = 50:
-  //  0.281 against 0.266 ms per step; RC_SAS_LAST_ROW_MIN overrides the threshold on B * history_max)
+  //  0.281 against 0.266 ms per step; RC_SAS_LAST_ROW_MIN overrides its threshold on B * history_max.  The K / V-free version
+  //  has FEWER launches than the all-rows path (4 + 7 against 7 + 8 with one block) and is taken at every size: B = 256, L = 50
+  //  0.249 -> 0.190 ms per replayed step)
   static const int64_t min_rows = [] {
     const char* v = getenv("RC_SAS_LAST_ROW_MIN");
     return v ? (int64_t)atoll(v) : (int64_t)32768;
   }();
   const int want = sb_last_row_request();
-  if (want <= 0 || drop || n_heads < 1 || D % n_heads != 0 || L > 64 || (int64_t)B * L < min_rows || !sb_fused_block() || !sb_rows16())
-    return 0;
+  if (want <= 0 || drop || n_heads < 1 || D % n_heads != 0 || L > 64 || !sb_fused_block() || !sb_rows16()) return 0;
   const int dk = D / n_heads;
   // the buffers of the K / V-free version live in the saved state's per-layer arrays: H * D + 4 <= L * D and 2 D + H L <= L D
   const bool v2 = (n_heads == 1 || n_heads == 2 || n_heads == 4) && L >= 3 && L >= n_heads + 1 && dk % (D * D / kBlock) == 0;
-  const bool v1 = L >= 2 && (dk == 16 || dk == 32 || dk == 64);
+  const bool v1 = L >= 2 && (dk == 16 || dk == 32 || dk == 64) && (int64_t)B * L >= min_rows;
   if (want >= 2 && v2) return 2;
   return v1 ? 1 : 0;
 }

@@ -64,6 +64,10 @@ struct SegArgs {
   uint32_t long_cap, chunk_cap, partial_cap;
   int skip_single;
   OptScalars o;
+  // capturable mode (hipGraph replay, rc_segmented_update_rows_dev): Adam's step count is read from device memory and the two
+  // bias-correction scalars are derived from it in the kernel (as rc_dense_update_multi_dev does) instead of on the host
+  const int64_t* step_dev;
+  double beta1, beta2, lr;
   // pair mode (rc_segmented_update_pair): two tables of width D/2 that share keys / perm / heads are updated as
   // ONE row of width D -- the lower half of a row's lanes works on table a (W, M, V, src, dense_grad), the upper
   // half on table b.  Zero for the ordinary single-table call.
@@ -145,6 +149,19 @@ __global__ __launch_bounds__(kBlock) void segment_heads_kernel(
   }
 }
 
+// the optimizer scalars of this launch (same expressions as fill_opt_scalars: double, then narrowed like torch does)
+template <int MODE>
+__device__ __forceinline__ OptScalars seg_scalars(const SegArgs& a) {
+  OptScalars o = a.o;
+  if (MODE == MODE_ADAM && a.step_dev != nullptr) {
+    const double step = (double)*a.step_dev;
+    const double bc1 = 1.0 - pow(a.beta1, step), bc2 = 1.0 - pow(a.beta2, step);
+    o.neg_step = (float)(-(a.lr / bc1));
+    o.bc2_sqrt = (float)sqrt(bc2);
+  }
+  return o;
+}
+
 // ---- 2. one lane-group per head ---------------------------------------------------------
 template <int D, int MODE>
 __device__ __forceinline__ void apply_row4(const SegArgs& a, uint32_t key, int l, float4 w,
@@ -158,7 +175,7 @@ __device__ __forceinline__ void apply_row4(const SegArgs& a, uint32_t key, int l
       reinterpret_cast<float4*>(up ? a.dense_grad_b : a.dense_grad)[idx] = g;
       return;
     }
-    opt_row4<MODE>(a.o, up ? a.Wb : a.W, up ? a.Mb : a.M, up ? a.Vb : a.V, idx, w, g);
+    opt_row4<MODE>(seg_scalars<MODE>(a), up ? a.Wb : a.W, up ? a.Mb : a.M, up ? a.Vb : a.V, idx, w, g);
     return;
   }
   const size_t idx = (size_t)(key - a.key_base) * LPR + l;
@@ -166,7 +183,7 @@ __device__ __forceinline__ void apply_row4(const SegArgs& a, uint32_t key, int l
     reinterpret_cast<float4*>(a.dense_grad)[idx] = g;
     return;
   }
-  opt_row4<MODE>(a.o, a.W, a.M, a.V, idx, w, g);
+  opt_row4<MODE>(seg_scalars<MODE>(a), a.W, a.M, a.V, idx, w, g);
 }
 
 template <int D, int MODE>
@@ -605,7 +622,7 @@ __device__ __forceinline__ void apply_row_generic(const SegArgs& a, uint32_t key
     float w = a.W[idx], m = 0.f, v = 0.f;
     if (MODE == MODE_ADAM || MODE == MODE_ADAGRAD) m = a.M[idx];
     if (MODE == MODE_ADAM) v = a.V[idx];
-    opt_elem<MODE>(a.o, acc[q], w, m, v);
+    opt_elem<MODE>(seg_scalars<MODE>(a), acc[q], w, m, v);
     a.W[idx] = w;
     if (MODE == MODE_ADAM || MODE == MODE_ADAGRAD) a.M[idx] = m;
     if (MODE == MODE_ADAM) a.V[idx] = v;
@@ -887,11 +904,11 @@ extern "C" size_t rc_segmented_rows_workspace_bytes(int64_t n_rows, int64_t n_oc
 
 // rc_segmented_update2 for a table of n_rows rows that collect many occurrences each (section 4 above); keys / perm
 // from a plain rc_sort_ids.  Same gradient sources and outputs; d in {16, 32, 64, 128, 256}, 16-byte aligned buffers.
-extern "C" int rc_segmented_update_rows(float* W, float* m, float* v, int d, int64_t n_rows, const uint32_t* keys,
-                                        const uint32_t* perm, int64_t n_occ, const float* coef, const float* src,
-                                        const int64_t* src_index, int div, const float* src2, int64_t n_split,
-                                        const rc_opt_hyper* h, float* dense_grad, void* ws, size_t ws_bytes,
-                                        rc_stream_t stream) {
+static int segmented_update_rows(float* W, float* m, float* v, int d, int64_t n_rows, const uint32_t* keys,
+                                 const uint32_t* perm, int64_t n_occ, const float* coef, const float* src,
+                                 const int64_t* src_index, int div, const float* src2, int64_t n_split,
+                                 const rc_opt_hyper* h, const int64_t* step_dev, float* dense_grad, void* ws, size_t ws_bytes,
+                                 rc_stream_t stream) {
   if (n_occ == 0) return RC_OK;
   RC_REQUIRE(n_split >= 0 && n_split <= n_occ, "rc_segmented_update_rows: n_split out of range");
   RC_REQUIRE(keys && perm && src && ws, "rc_segmented_update_rows: null pointer");
@@ -926,6 +943,9 @@ extern "C" int rc_segmented_update_rows(float* W, float* m, float* v, int d, int
     mode = mode_of(h);
     RC_REQUIRE(mode != MODE_ADAM || (m && v), "rc_segmented_update_rows: Adam needs m and v");
     RC_REQUIRE(mode != MODE_ADAGRAD || m, "rc_segmented_update_rows: Adagrad needs m (state_sum)");
+    if (mode == MODE_ADAM && step_dev) {
+      a.step_dev = step_dev; a.beta1 = h->beta1; a.beta2 = h->beta2; a.lr = h->lr;
+    }
   }
   static_assert(CNT_N <= 64, "counters beside the bounds");
   RC_HIP(hipMemsetAsync(counters, 0, (64 + 2 * (size_t)n_rows) * sizeof(uint32_t), s));   // absent rows: start = end = 0
@@ -938,6 +958,27 @@ extern "C" int rc_segmented_update_rows(float* W, float* m, float* v, int d, int
     case MODE_ADAM: return launch_seg_rows_mode<MODE_ADAM>(a, start, end, (uint32_t)n_rows, s);
     default: return launch_seg_rows_mode<MODE_ADAGRAD>(a, start, end, (uint32_t)n_rows, s);
   }
+}
+
+extern "C" int rc_segmented_update_rows(float* W, float* m, float* v, int d, int64_t n_rows, const uint32_t* keys,
+                                        const uint32_t* perm, int64_t n_occ, const float* coef, const float* src,
+                                        const int64_t* src_index, int div, const float* src2, int64_t n_split,
+                                        const rc_opt_hyper* h, float* dense_grad, void* ws, size_t ws_bytes,
+                                        rc_stream_t stream) {
+  return segmented_update_rows(W, m, v, d, n_rows, keys, perm, n_occ, coef, src, src_index, div, src2, n_split, h, nullptr,
+                               dense_grad, ws, ws_bytes, stream);
+}
+
+// The same with Adam's step count in device memory (step_dev[0] >= 1 when the kernels run; h->step is not used): the launch can be
+// captured in a hipGraph and replayed while the host advances the counter with rc_step_increment.  Other optimizers: as above.
+extern "C" int rc_segmented_update_rows_dev(float* W, float* m, float* v, int d, int64_t n_rows, const uint32_t* keys,
+                                            const uint32_t* perm, int64_t n_occ, const float* coef, const float* src,
+                                            const int64_t* src_index, int div, const float* src2, int64_t n_split,
+                                            const rc_opt_hyper* h, const int64_t* step_dev, float* dense_grad, void* ws,
+                                            size_t ws_bytes, rc_stream_t stream) {
+  RC_REQUIRE(step_dev != nullptr, "rc_segmented_update_rows_dev: step_dev is null");
+  return segmented_update_rows(W, m, v, d, n_rows, keys, perm, n_occ, coef, src, src_index, div, src2, n_split, h, step_dev,
+                               dense_grad, ws, ws_bytes, stream);
 }
 
 // Two tables that share their ids (NeuMF's mf / mlp embedding of a user or an item: models/general/NeuMF.py:37-40

@@ -454,10 +454,10 @@ def dense_update(W, G, hyper, m=None, v=None):
               _ptr(v, torch.float32, "v", allow_none=True), W.numel(), C.byref(hyper), _stream())
 
 
-def dense_update_multi(items, opt, step_dev=None):
+def dense_update_multi(items, opt, step_dev=None, increment=True):
     """items: list of (W, G, hyper, m | None, v | None) -> one launch per 36 tensors (rc_dense_update_multi).
     step_dev: int64 device tensor [1] holding Adam's step count (hipGraph-capturable mode): it is incremented
-    on the stream, then read by the update kernel"""
+    on the stream (unless the caller already did: increment=False), then read by the update kernel"""
     T = len(items)
     if T == 0:
         return
@@ -471,7 +471,8 @@ def dense_update_multi(items, opt, step_dev=None):
     if step_dev is None:
         _lib.call("rc_dense_update_multi", Wa, Ga, Ma, Va, na, ha, T, _stream())
         return
-    _lib.call("rc_step_increment", _ptr(step_dev, torch.int64, "step_dev"), _stream())
+    if increment:
+        _lib.call("rc_step_increment", _ptr(step_dev, torch.int64, "step_dev"), _stream())
     _lib.call("rc_dense_update_multi_dev", Wa, Ga, Ma, Va, na, ha, T, _ptr(step_dev, torch.int64, "step_dev"), _stream())
 
 
@@ -844,12 +845,25 @@ class SasSaved:
 SASREC_BATCH_MIN_ROWS = 4096  # B * history_max from which the batch-level kernels are used (launch-bound below)
 
 
-def _sasrec_impl(B, L, impl):
-    """auto: the per-sequence kernels (3 launches per pass) while the whole batch is ONE round of resident
-    workgroups in the 32-row geometry (B <= 512, history_max <= 32: 0.138 vs 0.173 s per epoch at the reference's
-    demo flags under graph replay), the batch-level kernels (~35 launches, 2-3x the throughput) beyond"""
+def _sasrec_one_row_encoder(d, n_heads, n_layers, L):
+    """the batch encoder's K / V-free last-row path (csrc/sas_last_row.hpp; sb_last_row_mode) serves the WHOLE encoder:
+    one block, no dropout, head count 1 / 2 / 4, history_max 3 .. 64"""
+    if d is None or int(os.environ.get("RC_SAS_LAST_ROW", "2")) < 2 or os.environ.get("RC_SAS_FUSED_BLOCK") == "0" \
+            or os.environ.get("RC_SAS_ROWS16") == "0":
+        return False
+    return (n_layers == 1 and d in (32, 64) and n_heads in (1, 2, 4) and 3 <= L <= 64 and L >= n_heads + 1
+            and (d // n_heads) % (d * d // 256) == 0)
+
+
+def _sasrec_impl(B, L, impl, d=None, n_heads=None, n_layers=None):
+    """auto: the batch-level kernels whenever their one-row path is the whole encoder (4 + 7 launches that touch each history
+    row once: 0.18 against 0.28 ms per step at B = 256, history_max = 20, and ahead at every size measured, B = 128 .. 4096);
+    otherwise the per-sequence kernels (3 launches per pass) while the whole batch is ONE round of resident workgroups in the
+    32-row geometry (B <= 512, history_max <= 32), the batch-level kernels (~35 launches, 2-3x the throughput) beyond"""
     impl = impl or os.environ.get("RC_SASREC_IMPL", "auto")
     if impl == "auto":
+        if _sasrec_one_row_encoder(d, n_heads, n_layers, L):
+            return "batch"
         if B * L < SASREC_BATCH_MIN_ROWS or (B <= 512 and L <= 32):
             return "sequence"
         return "batch"
@@ -873,7 +887,7 @@ def sasrec_fwd(item_emb, pos_emb, layers, n_heads, hist, lengths, save=False, im
         if impl == "sequence":
             raise ValueError("SASRec dropout is implemented by the batch-level kernels only (impl='batch')")
         impl = "batch"
-    impl = _sasrec_impl(B, L, impl)
+    impl = _sasrec_impl(B, L, impl, *((d, int(n_heads), len(layers)) if drop_p == 0.0 else ()))
     if impl == "batch":
         # eval passes reuse one scratch state; training passes own theirs until the backward has run
         n_state = lib.rc_sasrec_batch_state_floats(B, L, d, len(layers))
@@ -945,8 +959,9 @@ def seg_rows_route(n_occ, n_rows, d):
 
 
 def segmented_update2(keys, perm, src, src2, n_split, hyper=None, W=None, m=None, v=None, coef=None,
-                      src_index=None, div=1, dense_grad=None):
-    """rc_segmented_update2: occurrences >= n_split take plain rows src2[o - n_split]"""
+                      src_index=None, div=1, dense_grad=None, step_dev=None):
+    """rc_segmented_update2: occurrences >= n_split take plain rows src2[o - n_split].
+    step_dev: int64 device tensor [1] with Adam's step count (hipGraph-capturable; one-wave-per-row route only)"""
     n_occ = keys.numel()
     d = src.shape[-1]
     f32 = torch.float32
@@ -955,12 +970,19 @@ def segmented_update2(keys, perm, src, src2, n_split, hyper=None, W=None, m=None
     if seg_rows_route(n_occ, n_rows, d):
         # every row collects many occurrences (a small catalogue under a large batch): one wave per table row
         ws = workspace(_lib.load().rc_segmented_rows_workspace_bytes(n_rows, n_occ, d), keys.device, "seg_rows")
-        _lib.call("rc_segmented_update_rows", _ptr(W, f32, "W", True), _ptr(m, f32, "m", True), _ptr(v, f32, "v", True), d,
-                  n_rows, _ptr(keys, torch.int32, "keys"), _ptr(perm, torch.int32, "perm"), n_occ,
-                  _ptr(coef, f32, "coef", True), _ptr(src, f32, "src"), _ptr(src_index, torch.int64, "src_index", True),
-                  int(div), _ptr(src2, f32, "src2"), int(n_split), C.byref(hyper) if hyper is not None else None,
-                  _ptr(dense_grad, f32, "dense_grad", True), C.c_void_p(ws.data_ptr()), ws.numel(), _stream())
+        head = (_ptr(W, f32, "W", True), _ptr(m, f32, "m", True), _ptr(v, f32, "v", True), d,
+                n_rows, _ptr(keys, torch.int32, "keys"), _ptr(perm, torch.int32, "perm"), n_occ,
+                _ptr(coef, f32, "coef", True), _ptr(src, f32, "src"), _ptr(src_index, torch.int64, "src_index", True),
+                int(div), _ptr(src2, f32, "src2"), int(n_split), C.byref(hyper) if hyper is not None else None)
+        tail = (_ptr(dense_grad, f32, "dense_grad", True), C.c_void_p(ws.data_ptr()), ws.numel(), _stream())
+        if step_dev is None:
+            _lib.call("rc_segmented_update_rows", *head, *tail)
+        else:
+            _lib.call("rc_segmented_update_rows_dev", *head, _ptr(step_dev, torch.int64, "step_dev"), *tail)
         return
+    if step_dev is not None:
+        raise RuntimeError("segmented_update2(step_dev=...): the device-side step count is carried by the one-wave-per-row "
+                           "update only (seg_rows_route: a small catalogue under a large batch)")
     ws = workspace(_lib.load().rc_segmented_workspace_bytes(n_occ, d), keys.device, "seg")
     _lib.call("rc_segmented_update2", _ptr(W, f32, "W", True), _ptr(m, f32, "m", True), _ptr(v, f32, "v", True), d,
               _ptr(keys, torch.int32, "keys"), _ptr(perm, torch.int32, "perm"), n_occ,
@@ -980,8 +1002,9 @@ class SasrecTrainer:
     def __init__(self, P, n_heads, opt="Adam", lr=1e-3, l2=0.0, rowwise=False, dropout=0.0, seed=0, graph=False):
         """graph=True: from the third step of a batch shape on, the step (about 45 launches on two streams, no host
         synchronisation, grids that depend on shapes only) is replayed from a hipGraph with the batch copied into static
-        buffers -- at config 3 the eager step is bound by the host's launch rate (0.42 ms enqueue against 0.32 ms of GPU work).
-        Same kernels, same results.  SGD / Adagrad only: Adam's bias-correction scalars are kernel arguments of the row updates."""
+        buffers -- at config 3 the eager step is bound by the host's launch rate (0.42 ms enqueue against 0.27 ms of GPU work).
+        Same kernels, same results.  With Adam the step count is kept in device memory (capturable semantics: bias corrections
+        formed in the kernels) and the item table must take the one-wave-per-row update (seg_rows_route), rowwise=True."""
         self.P, self.n_heads, self.opt, self.lr, self.l2, self.rowwise = P, n_heads, opt, lr, l2, rowwise
         self.dropout = float(dropout)
         self.seed = torch.tensor([seed], dtype=torch.int64, device=P["item_emb"].device) if self.dropout > 0 else None
@@ -990,8 +1013,14 @@ class SasrecTrainer:
         self.state = {}
         self._side = None
         self.graph = bool(graph)
+        # Adam under replay: the step count lives in device memory (torch.optim.Adam(capturable=True) semantics); carried by the
+        # row-wise one-wave-per-row item update and the multi-tensor dense step
+        self._step_dev = None
         if self.graph and opt == "Adam":
-            raise ValueError("SasrecTrainer(graph=True): Adam's step count is a kernel argument of the row updates; use SGD / Adagrad")
+            if not rowwise:
+                raise ValueError("SasrecTrainer(graph=True, opt='Adam') needs rowwise=True (the dense item-table step takes the "
+                                 "step count as a kernel argument)")
+            self._step_dev = torch.zeros(1, dtype=torch.int64, device=P["item_emb"].device)
         self._graphs, self._graph_seen = {}, {}
 
     def _st(self, t):
@@ -1012,8 +1041,18 @@ class SasrecTrainer:
             self._side = torch.cuda.Stream(device=dev)
         return self._side
 
+    def _dev_step_route(self, hist, iid):
+        """Adam with the step count in device memory: carried by the one-wave-per-row item update (seg_rows_route) only"""
+        if self._step_dev is None:
+            return False
+        I = self.P["item_emb"]
+        n_occ = iid.numel() + hist.numel()
+        use_plan = _SASREC_PLAN and n_occ >= _EDB_PLAN_MIN and plan_supported(n_occ, 0, I.shape[0], 0)
+        return not use_plan and seg_rows_route(n_occ, I.shape[0], I.shape[1])
+
     def step(self, hist, lengths, iid):
-        if not (self.graph and hist.is_cuda) or getattr(self, "timing", None) is not None:
+        if not (self.graph and hist.is_cuda) or getattr(self, "timing", None) is not None \
+                or (self._step_dev is not None and not self._dev_step_route(hist, iid)):
             return self._step(hist, lengths, iid)
         from . import graph as hgraph
         if not hgraph.usable():
@@ -1056,8 +1095,13 @@ class SasrecTrainer:
         h0 = make_hyper(self.opt, lr=self.lr, l2=0.0, step=self.step_count)
         if self.seed is not None:
             step_increment(self.seed)
+        if self._step_dev is not None:
+            step_increment(self._step_dev)
         n_occ = B * Cn + hist.numel()
         use_plan = _SASREC_PLAN and n_occ >= _EDB_PLAN_MIN and plan_supported(n_occ, 0, I.shape[0], 0)
+        # Adam under replay: the kernels read the step count from device memory where the route carries it (else this step takes
+        # the host's count -- both advance every step -- and is not captured)
+        step_dev = self._step_dev if self._dev_step_route(hist, iid) else None
         # (small batches are bound by the host's launch rate: the extra stream switches cost more than the overlap returns --
         #  B = 256: 0.39 against 0.30 ms; B = 4096: 0.66 against 0.72 ms)
         overlap = _SAS_OVERLAP and hist.is_cuda and not use_plan and n_occ >= _SAS_OVERLAP_MIN
@@ -1128,7 +1172,7 @@ class SasrecTrainer:
                 keys, perm = sorted_occurrences()
             if self.rowwise:
                 segmented_update2(keys, perm, hv, g_hist.view(-1, d), B * Cn, hyper=h, W=I, m=st.get("m"), v=st.get("v"),
-                                  coef=gpred.reshape(-1), div=Cn)
+                                  coef=gpred.reshape(-1), div=Cn, step_dev=step_dev)
             else:
                 G = torch.zeros_like(I)
                 segmented_update2(keys, perm, hv, g_hist.view(-1, d), B * Cn, coef=gpred.reshape(-1), div=Cn, dense_grad=G)
@@ -1147,7 +1191,7 @@ class SasrecTrainer:
             for name in SAS_LAYER_KEYS:
                 st = self._st(lay[name])
                 items.append((lay[name], g[name].contiguous(), h0 if name in SAS_NO_DECAY else h, st.get("m"), st.get("v")))
-        dense_update_multi(items, self.opt)  # position table + every block parameter: one launch
+        dense_update_multi(items, self.opt, step_dev=step_dev, increment=False)  # position table + every block parameter: one launch
         _dns.__exit__()
         return self.loss
 

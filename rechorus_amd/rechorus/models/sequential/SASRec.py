@@ -97,8 +97,12 @@ class SASRecBase(object):
         if tr is None or tr.opt != opt_name:
             P = {'item_emb': self.i_embeddings.weight.data, 'pos_emb': self.p_embeddings.weight.data,
                  'layers': hnn.sasrec_layer_params(self.transformer_block)}
+            from rechorus_amd import graph as hgraph
+            # the step replays from a hipGraph where that is possible in this process (rechorus_amd/graph.py); Adam's step
+            # count then lives in device memory
             tr = self._trainer = engine.SasrecTrainer(P, self.num_heads, opt=opt_name, lr=lr, l2=l2, rowwise=True,
-                                                      dropout=self.dropout, seed=int(self.drop_seed.item()))
+                                                      dropout=self.dropout, seed=int(self.drop_seed.item()),
+                                                      graph=hgraph.usable() and history.is_cuda and opt_name in ('SGD', 'Adam', 'Adagrad'))
         with torch.no_grad():
             return tr.step(history.contiguous(), lengths.contiguous(), feed_dict['item_id'].contiguous())
 

@@ -223,6 +223,13 @@ def test_sasrec_kernel_choice_by_batch_shape(monkeypatch):
     assert engine._sasrec_impl(256, 50, None) == "batch"
     assert engine._sasrec_impl(4096, 20, None) == "batch"
     assert engine._sasrec_impl(4096, 50, "sequence") == "sequence"
+    # one block without dropout: the batch encoder's one-row path is the whole encoder -> batch kernels at every size
+    assert engine._sasrec_impl(256, 20, None, 64, 4, 1) == "batch"
+    assert engine._sasrec_impl(256, 20, None, 64, 1, 1) == "batch"
+    assert engine._sasrec_impl(256, 20, None, 64, 4, 2) == "sequence"     # two blocks: the old rule
+    assert engine._sasrec_impl(256, 20, None, 64, 8, 1) == "sequence"     # eight heads: not covered by that path
+    assert engine._sasrec_impl(256, 4, None, 64, 4, 1) == "sequence"      # history_max < heads + 1
+    assert engine._sasrec_impl(256, 20, "sequence", 64, 4, 1) == "sequence"
     monkeypatch.setenv("RC_SASREC_IMPL", "batch")
     assert engine._sasrec_impl(16, 8, None) == "batch"
     with pytest.raises(ValueError):
