@@ -374,9 +374,11 @@ int rc_sasrec_bwd(const float* const* layer_params, int n_layers, int n_heads, c
  * as rc_sasrec_fwd / rc_sasrec_bwd, several times faster from a few hundred sequences up; the forward pass
  * SAVES the activations the backward needs in `state` (rc_sasrec_batch_state_floats floats, caller-owned)
  * instead of the backward recomputing them.  dense_grads / g_hist / hv as in rc_sasrec_fwd / rc_sasrec_bwd.
- * From B * L >= 32,768 (and without dropout) the LAST block is computed for the one position per sequence that is consumed
- * (models/sequential/SASRec.py:76: his_vector = his[arange(B), lengths - 1]; causal mask): keys / values on all rows, one
- * query / attention / FFN row per sequence, mirrored in the backward -- same results to fp32 summation order.               */
+ * Without dropout the LAST block is computed for the one position per sequence that is consumed (models/sequential/SASRec.py:76:
+ * his_vector = his[arange(B), lengths - 1]; causal mask): one query row per sequence and -- for 1 / 2 / 4 heads and
+ * max(3, heads + 1) <= L <= 64 -- no keys and values at all (score_j = (Wk_h^T q_h) . x_j, ctx_h = Wv_h sum_j p_j x_j: one pass
+ * over the layer input rows per direction; with one block the rows come straight from the tables and g_hist is written
+ * directly), mirrored in the backward -- same results to fp32 rounding (the products are associated differently).               */
 size_t rc_sasrec_batch_state_floats(int B, int L, int d, int n_layers);
 size_t rc_sasrec_batch_workspace_bytes(int B, int L, int d, int n_layers);
 int rc_sasrec_batch_fwd(const float* item_emb, const float* pos_emb, const float* const* layer_params,
