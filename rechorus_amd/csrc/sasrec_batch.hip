@@ -292,6 +292,21 @@ __device__ __forceinline__ void sb16_product_pair(const float* Wl, int i, int g,
   }
 }
 
+// acc += keep * W[16 n + i][.] . x for ONE output tile n (runtime); keep = 0 drops this lane's output row from the product
+template <int D>
+__device__ __forceinline__ void sb16_product_one(const float* Wl, int n, int i, int g, const float (&x)[D / 16][4], float keep,
+                                                 sas_f32x4& a0) {
+  constexpr int S = D + 4;
+#pragma unroll
+  for (int c = 0; c < D / 16; ++c) {
+    const float4 w0 = *reinterpret_cast<const float4*>(Wl + (16 * n + i) * S + 16 * c + 4 * g);
+    a0 = sas_mfma16(w0.x * keep, x[c][0], a0);
+    a0 = sas_mfma16(w0.y * keep, x[c][1], a0);
+    a0 = sas_mfma16(w0.z * keep, x[c][2], a0);
+    a0 = sas_mfma16(w0.w * keep, x[c][3], a0);
+  }
+}
+
 // Y_w = X W_w^T + b_w for NW projections of one pass over X (3: q, k, v; 2: k, v of a last layer; 1: q of the last rows)
 template <int D, int NW>
 __global__ __launch_bounds__(64 * kSb16MaxWaves) void sb_qkv16_kernel(SbLinArgs a) {
@@ -536,6 +551,11 @@ struct SbBlockArgs {
   int B;
   SbDrop dr;          // dr.site = 2 * layer (dropout1); dropout2 uses site + 1
   const int64_t* row_len = nullptr;   // sb_block16_fwd_kernel, one row per sequence: xnext[row] = 0 where row_len[row] <= 0 (empty history)
+  // sb_block16_fwd_kernel on the K / V-free last-row path: the attention output is formed here, ctx[row, o] = Wv[o, :] . xbar[row, h(o), :]
+  // + bv[o] (zero for an empty history), instead of being read from `ctx` (sas_last_row.hpp: ctx_h = Wv_h xbar_h + bv_h)
+  const float* xbar = nullptr;        // [R, H, D]
+  const float *Wv = nullptr, *bv = nullptr;
+  int H = 0;
 };
 
 template <int D>
@@ -1062,7 +1082,8 @@ __global__ __launch_bounds__(64 * kSb16BlockWaves) void sb_block16_fwd_kernel(Sb
   extern __shared__ float lds[];
   float* W1s = lds;               // [D][S]
   float* W2s = W1s + D * S;       // [D][S]
-  float* Ps = W2s + D * S;        // [6][D]: b1, b2, ln1w, ln1b, ln2w, ln2b
+  float* Wvs = W2s + D * S;       // [D][S], only with a.xbar
+  float* Ps = Wvs + (a.xbar ? D * S : 0);   // [7][D]: b1, b2, ln1w, ln1b, ln2w, ln2b, bv
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
   const int nw = blockDim.x >> 6;
   const int R = a.off[a.B];
@@ -1071,18 +1092,20 @@ __global__ __launch_bounds__(64 * kSb16BlockWaves) void sb_block16_fwd_kernel(Sb
   int t = (int)blockIdx.x * nw + wave;
   float zc[NC][4], zx[NC][4];
   if (t < tiles) {   // the first tile's rows travel while the weights are staged
-    sb16_load_rows<D>(a.ctx, 16 * t + i, R, g, zc);
+    if (!a.xbar) sb16_load_rows<D>(a.ctx, 16 * t + i, R, g, zc);
     sb16_load_rows<D>(a.x, 16 * t + i, R, g, zx);
   }
   for (int idx = threadIdx.x; idx < D * (D / 4); idx += blockDim.x) {
     const int o = idx / (D / 4), c4 = idx % (D / 4);
     *reinterpret_cast<float4*>(W1s + o * S + 4 * c4) = reinterpret_cast<const float4*>(a.W1)[idx];
     *reinterpret_cast<float4*>(W2s + o * S + 4 * c4) = reinterpret_cast<const float4*>(a.W2)[idx];
+    if (a.xbar) *reinterpret_cast<float4*>(Wvs + o * S + 4 * c4) = reinterpret_cast<const float4*>(a.Wv)[idx];
   }
   for (int idx = threadIdx.x; idx < D; idx += blockDim.x) {
     Ps[idx] = a.b1[idx]; Ps[D + idx] = a.b2[idx];
     Ps[2 * D + idx] = a.ln1w[idx]; Ps[3 * D + idx] = a.ln1b[idx];
     Ps[4 * D + idx] = a.ln2w[idx]; Ps[5 * D + idx] = a.ln2b[idx];
+    if (a.xbar) Ps[6 * D + idx] = a.bv[idx];
   }
   __syncthreads();
   const bool drop = a.dr.seed != nullptr;
@@ -1095,10 +1118,37 @@ __global__ __launch_bounds__(64 * kSb16BlockWaves) void sb_block16_fwd_kernel(Sb
     const int row = 16 * t + i;
     const bool valid = row < R;
     if (!first) {
-      sb16_load_rows<D>(a.ctx, row, R, g, zc);
+      if (!a.xbar) sb16_load_rows<D>(a.ctx, row, R, g, zc);
       sb16_load_rows<D>(a.x, row, R, g, zx);
     }
     first = false;
+    if (a.xbar) {   // ctx tile n = Wv[16 n .., :] . xbar[row, head of those outputs, :] + bv (0 for an empty history)
+      const int DK = D / a.H;
+      const int hpt = DK >= 16 ? 1 : 16 / DK;   // heads per 16-output tile (dk = 8: two, each product masked to its output rows)
+      const float live = (valid && !(a.row_len && a.row_len[row] <= 0)) ? 1.f : 0.f;
+      float xb[NC][4];
+      int cur = -1;
+#pragma unroll
+      for (int n = 0; n < NC; ++n) {
+        sas_f32x4 acc = sas_zero4();
+        for (int hl = 0; hl < hpt; ++hl) {
+          const int h = (16 * n) / DK + hl;   // wave-uniform
+          if (h != cur) {
+            cur = h;
+            const float* src = a.xbar + ((size_t)(valid ? row : 0) * a.H + h) * D;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+              const float4 v = valid ? *reinterpret_cast<const float4*>(src + 16 * c + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+              xb[c][0] = v.x; xb[c][1] = v.y; xb[c][2] = v.z; xb[c][3] = v.w;
+            }
+          }
+          sb16_product_one<D>(Wvs, n, i, g, xb, (hpt == 1 || i / DK == hl) ? 1.f : 0.f, acc);
+        }
+        const float4 b4 = *reinterpret_cast<const float4*>(Ps + 6 * D + 16 * n + 4 * g);
+        zc[n][0] = fmaf(b4.x, live, acc[0]); zc[n][1] = fmaf(b4.y, live, acc[1]);
+        zc[n][2] = fmaf(b4.z, live, acc[2]); zc[n][3] = fmaf(b4.w, live, acc[3]);
+      }
+    }
     // ---- y1 = LayerNorm1(drop1(ctx) + x)
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
@@ -1984,7 +2034,6 @@ static int sb_last_block_fwd(const float* item_emb, const float* pos_emb, const 
                              const int64_t* lengths, int B, int L, bool gather, const SbSaved& sv, float* hv, const SbWs& w,
                              SbDrop dr, hipStream_t s) {
   const SbLastBufs u = sb_last_bufs(sv, B, L, D, n_heads);
-  float* ctxl = w.t0;
   SbLrRows rows;
   memset(&rows, 0, sizeof(rows));
   rows.lengths = lengths; rows.B = B; rows.L = L;
@@ -2016,20 +2065,13 @@ static int sb_last_block_fwd(const float* item_emb, const float* pos_emb, const 
 #undef RC_LR_FWD
     RC_LAUNCH_CHECK();
   }
-  {   // ctx_h = Wv_h xbar_h + bv_h
-    SbLrHeadNArgs a;
-    memset(&a, 0, sizeof(a));
-    a.in = u.xbar; a.W = p.Wv; a.bias = p.bv; a.s = nullptr; a.lengths = lengths; a.out = ctxl; a.B = B; a.H = n_heads;
-    const size_t lds = ((size_t)D * (D + 4) + (kLrBlock / 64) * kLrMaxHeads * (D + 4)) * sizeof(float);
-    hipLaunchKernelGGL((sb_lr_headN_kernel<D>), dim3(sb_lr_grid8(B)), dim3(kLrBlock), lds, s, a);
-    RC_LAUNCH_CHECK();
-  }
   SbBlockArgs bk;
-  bk.ctx = ctxl; bk.x = u.xl; bk.ln1w = p.ln1w; bk.ln1b = p.ln1b; bk.W1 = p.W1; bk.b1 = p.b1; bk.W2 = p.W2; bk.b2 = p.b2;
+  bk.ctx = nullptr; bk.x = u.xl; bk.ln1w = p.ln1w; bk.ln1b = p.ln1b; bk.W1 = p.W1; bk.b1 = p.b1; bk.W2 = p.W2; bk.b2 = p.b2;
   bk.ln2w = p.ln2w; bk.ln2b = p.ln2b; bk.xh1 = sv.xh1; bk.rstd1 = sv.rstd1; bk.y1 = sv.y1; bk.h = sv.h; bk.xh2 = sv.xh2;
   bk.rstd2 = sv.rstd2; bk.xnext = hv; bk.off = w.off_seq; bk.B = B; bk.dr = dr;
   bk.row_len = lengths;   // an empty history's output row is zero (SASRec.py:76 reads his[b, -1] of an all-padding row)
-  const size_t lds16 = ((size_t)2 * D * (D + 4) + 6 * (size_t)D) * sizeof(float);
+  bk.xbar = u.xbar; bk.Wv = p.Wv; bk.bv = p.bv; bk.H = n_heads;   // ctx_h = Wv_h xbar_h + bv_h inside the block kernel
+  const size_t lds16 = ((size_t)3 * D * (D + 4) + 7 * (size_t)D) * sizeof(float);
   auto kern16 = sb_block16_fwd_kernel<D>;
   RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern16), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16));
   int64_t gr = (((int64_t)B + 15) / 16 + 3) / 4;
@@ -2047,7 +2089,6 @@ template <int D>
 static int sb_last_block_bwd(const SasLayer& p, int n_heads, const int64_t* lengths, int B, int L, bool padded, const SbSaved& sv,
                              const float* dhv, float* Gout, float* gp, size_t stride, const SbWs& w, SbDrop dr, hipStream_t s) {
   using Cfg = SasCfg<D>;
-  constexpr int LPR = D / 4;
   const SbLastBufs u = sb_last_bufs(sv, B, L, D, n_heads);
   float* gl = w.t1;                                  // [B, D]: dhv (empty histories: 0), then dZ1 = d ctx
   float* dql = w.t1 + (size_t)B * D;                 // [B, D]

@@ -1136,7 +1136,8 @@ class SasrecTrainer:
             if getattr(self, "_rows", None) is None or self._rows.numel() != B or self._rows.device != hist.device:
                 self._rows = torch.arange(B, device=hist.device)
             _, loss_vec, gpred, dhv = bprmf_fwd_bwd(hv, I, self._rows, iid, want_pred=False)
-            self.loss = reduce_sum(loss_vec, 1.0 / B)
+            if not overlap:
+                self.loss = reduce_sum(loss_vec, 1.0 / B)   # (two streams: the mean is formed on the side stream below)
         with _PhaseTimer(self, "encoder_bwd"):
             g_hist, dgrads = sasrec_bwd(layers, self.n_heads, lengths, xsave, dhv, drop_p=self.dropout, seed=self.seed)
         # item table: candidate occurrences (g * hv, rebuilt on the fly) + history occurrences (g_hist rows)
@@ -1144,6 +1145,7 @@ class SasrecTrainer:
         if overlap:
             side.wait_stream(main)   # g_hist is ready
             with torch.cuda.stream(side):
+                self.loss = reduce_sum(loss_vec, 1.0 / B)   # nothing on the main stream waits for the mean of the loss
                 Gp = sasrec_pos_grad(g_hist, lengths, Pe.shape[0])
         _upd = _PhaseTimer(self, "table_update")
         _upd.__enter__()
