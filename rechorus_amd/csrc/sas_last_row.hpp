@@ -40,6 +40,8 @@ __device__ __forceinline__ size_t sb_lr_rowbase(const SbLrRows& r, int b) { retu
 
 // ---- per-sequence head products against a weight matrix resident in LDS ------------------------------------------------------------
 // outT[b, h, i] = sum_c in[b, hc + c] W[hc + c, i]   (qt from q and Wk; gt from g and Wv),  cs[b, h] = sum_c in[b, hc + c] bias[hc + c].
+// (The products in the other direction -- ctx_h = Wv_h xbar_h + bv_h and dq_h = Wk_h ybar_h + bk_h sum ds -- are formed where they are
+// consumed: in sb_block16_fwd_kernel's prologue and in sb_lr_tail_kernel.)
 // MODE 0: `in` is given.  MODE 1 / 2: in = q = Wq x_last + bq, x_last read from X (1) or gathered from the tables (2);
 // x_last and q are stored too.
 struct SbLrHeadTArgs {
@@ -124,59 +126,6 @@ __global__ __launch_bounds__(kLrBlock) void sb_lr_headT_kernel(SbLrHeadTArgs a) 
       if (lane < H)
         for (int c = 0; c < DK; ++c) t = fmaf(sq[lane * DK + c], a.bias[lane * DK + c], t);
       a.cs[(size_t)b * kLrMaxHeads + lane] = t;
-    }
-    wave_lds_sync();
-  }
-}
-
-// out[b, o] = sum_i W[o, i] in[b, h(o), i] + bias[o] * s[b, h(o)]   (ctx from xbar, Wv, bv with s = [len > 0];  dq from ybar, Wk, bk, sum ds)
-struct SbLrHeadNArgs {
-  const float* in;          // [B, H, D]
-  const float *W, *bias;
-  const float* s;           // [B, 4], or nullptr: 1 for a non-empty history, 0 for an empty one
-  const int64_t* lengths;
-  float* out;               // [B, D]
-  int B, H;
-};
-
-template <int D>
-__global__ __launch_bounds__(kLrBlock) void sb_lr_headN_kernel(SbLrHeadNArgs a) {
-  constexpr int SW = D + 4, LPR = D / 4;
-  extern __shared__ float lds[];
-  float* Ws = lds;                                             // [D][SW]
-  float* sin = Ws + D * SW + (threadIdx.x >> 6) * kLrMaxHeads * SW;   // [H][SW] of this wave
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int H = a.H, DK = D / H;
-  constexpr int NPRE = kLrMaxHeads * D / 64;
-  int b = (int)blockIdx.x * (kLrBlock / 64) + wave;
-  float pre[NPRE];   // the first sequence's input travels while the weights are staged
-#pragma unroll
-  for (int k = 0; k < NPRE; ++k) pre[k] = (b < a.B && lane + 64 * k < H * D) ? a.in[(size_t)b * H * D + lane + 64 * k] : 0.f;
-  for (int idx = threadIdx.x; idx < D * LPR; idx += kLrBlock) {
-    const int o = idx / LPR, c = idx % LPR;
-    *reinterpret_cast<float4*>(Ws + o * SW + 4 * c) = reinterpret_cast<const float4*>(a.W)[idx];
-  }
-  __syncthreads();
-  bool first = true;
-  for (; b < a.B; b += (int)gridDim.x * (kLrBlock / 64)) {
-#pragma unroll
-    for (int k = 0; k < NPRE; ++k) {
-      const int e = lane + 64 * k;
-      if (e < H * D) sin[(e / D) * SW + e % D] = first ? pre[k] : a.in[(size_t)b * H * D + e];
-    }
-    first = false;
-    wave_lds_sync();
-    if (lane < D) {
-      const int h = lane / DK;
-      float acc = 0.f;
-#pragma unroll
-      for (int c = 0; c < LPR; ++c) {
-        const float4 w4 = *reinterpret_cast<const float4*>(Ws + lane * SW + 4 * c);
-        const float4 v4 = *reinterpret_cast<const float4*>(sin + h * SW + 4 * c);
-        acc = fmaf(w4.x, v4.x, acc); acc = fmaf(w4.y, v4.y, acc); acc = fmaf(w4.z, v4.z, acc); acc = fmaf(w4.w, v4.w, acc);
-      }
-      const float sc = a.s ? a.s[(size_t)b * kLrMaxHeads + h] : (a.lengths[b] > 0 ? 1.f : 0.f);
-      a.out[(size_t)b * D + lane] = fmaf(a.bias[lane], sc, acc);
     }
     wave_lds_sync();
   }

@@ -199,6 +199,22 @@ def test_loss_saturation_matches_clamp_semantics(cuda, eng):
     assert np.isfinite(host(loss)[0])
 
 
+@pytest.mark.parametrize("B,C", [(1, 2), (7, 5), (1000, 5), (259, 17), (130, 18), (65, 100)])
+def test_bpr_loss_row_geometries(B, C, cuda, eng):
+    """rc_bpr_loss_fwd_bwd packs four rows into a wave up to sixteen negatives (the reference's --num_neg 1, NeuMF's K = 4) and
+    takes a wave per row beyond: both against the oracle, on either side of the switch and with row counts that leave a
+    partly filled last wave / workgroup"""
+    rng = np.random.default_rng(B * 131 + C)
+    pred = (rng.normal(size=(B, C)) * 2.0).astype(np.float32)
+    loss, loss_vec, gpred = eng.bpr_loss(dev(pred, cuda))
+    rows, _, _, _ = O.bpr_loss_rows(pred)
+    assert_close(host(loss_vec), rows, what=f"loss_vec B={B} C={C}", atol_scale=2e-5)
+    assert_close(host(gpred), O.bpr_loss_grad(pred), what=f"gpred B={B} C={C}", atol_scale=2e-5)
+    assert_close(host(loss)[0], rows.mean(), what="loss")
+    loss2, loss_vec2, gpred2 = eng.bpr_loss(dev(pred, cuda))
+    assert torch.equal(loss_vec, loss_vec2) and torch.equal(gpred, gpred2)
+
+
 def test_long_segments_and_determinism(cuda, eng):
     """one hot row repeated thousands of times (deferred workgroup-per-row kernel), segments
     straddling the 32-occurrence threshold, and bit-reproducibility of the whole step"""
