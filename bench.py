@@ -449,9 +449,9 @@ def model_roofline(args, trainer, batches, engine):
         # rows: it is rated against HBM below
         H = args.heads
         want = int(os.environ.get("RC_SAS_LAST_ROW", "2"))
-        ok = want > 0 and L <= 64 and d % H == 0
-        v2 = ok and want >= 2 and H in (1, 2, 4) and L >= max(3, H + 1) and (d // H) % (d * d // 256) == 0
-        v1 = ok and L >= 2 and (d // H) in (16, 32, 64) and B * L >= int(os.environ.get("RC_SAS_LAST_ROW_MIN", "32768"))
+        ok = want > 0 and d % H == 0
+        v2 = ok and want >= 2 and H in (1, 2, 4) and max(3, H + 1) <= L <= 128 and (d // H) % (d * d // 256) == 0
+        v1 = ok and 2 <= L <= 64 and (d // H) in (16, 32, 64) and B * L >= int(os.environ.get("RC_SAS_LAST_ROW_MIN", "32768"))
         mode = 2 if v2 else (1 if v1 else 0)
         last = {0: full, 1: R * 4.0 * d * d + B * 6.0 * d * d + 4.0 * R * d, 2: B * 10.0 * d * d + 4.0 * R * H * d}[mode]
         fwd = (nl - 1) * full + last

@@ -346,7 +346,8 @@ int rc_segmented_update_pair(float* W_a, float* m_a, float* v_a, float* W_b, flo
                              const uint32_t* heads, const uint32_t* n_heads, void* ws, size_t ws_bytes,
                              rc_stream_t stream);
 
-/* 1 iff the kernels cover the shape: d in {32,64}, 1..4 layers, heads | d, L <= 64, dropout 0.   */
+/* 1 iff the kernels cover the shape: d in {32,64}, 1..4 layers, heads | d, L <= 64 (every entry point below); also
+ * 64 < L <= 128 with ONE layer and 1 / 2 / 4 heads, for rc_sasrec_batch_fwd / _bwd without dropout (their one-row path). */
 int rc_sasrec_supported(int d, int n_layers, int n_heads, int L);
 /* floats per layer in the dense-gradient block of rc_sasrec_bwd: 5*d*d + 9*d, in the order
  * Wq bq Wk bk Wv bv ln1.w ln1.b W1 b1 W2 b2 ln2.w ln2.b                                          */

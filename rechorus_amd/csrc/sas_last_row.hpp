@@ -25,6 +25,7 @@ __device__ __forceinline__ void wave_lds_sync() {   // LDS written by some lanes
 }
 
 constexpr int kLrMaxHeads = 4;
+constexpr int kLrMaxL = kSasLongLP;   // history_max the one-row path covers (a 128-row tile, two keys per lane)
 constexpr int kLrBlock = 512;   // the per-sequence head products: eight waves per workgroup, one sequence per wave and pass
 
 struct SbLrRows {          // where the rows of the block's input live
@@ -206,7 +207,7 @@ __global__ __launch_bounds__(kLrBlock) void sb_lr_tail_kernel(SbLrTailArgs a) {
 }
 
 // ---- the streaming passes: one 4-wave workgroup per sequence ---------------------------------------------------------------------------
-// The sequence's rows are staged once in LDS (coalesced: D / 4 lanes per row).  Wave h owns head h: with lane = key it takes the
+// The sequence's rows (history_max <= 128) are staged once in LDS (coalesced: D / 4 lanes per row).  Wave h owns head h: with lane = key it takes the
 // scores and the softmax of its head, with lane = feature the weighted row sum.  (First version: one wave per sequence doing
 // the four heads in turn -- eight waves per CU, each a chain of dependent global loads: 33 / 49 us forward / backward at
 // config 3.  Four waves per sequence put 28-32 waves on a CU and cut each chain to a quarter.)
@@ -394,6 +395,180 @@ __global__ __launch_bounds__(kBlock) void sb_lr_attn_bwd_kernel(SbLrAttnArgs a) 
         pvv[h] = sp[4 * lane + h];
       }
       float* row = tile + lane * ST + wave * (D / 4);
+#pragma unroll
+      for (int c = 0; c < D / 16; ++c) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+          const float4 q4 = *reinterpret_cast<const float4*>(sqt + h * ST + wave * (D / 4) + 4 * c);
+          const float4 g4 = *reinterpret_cast<const float4*>(sgt + h * ST + wave * (D / 4) + 4 * c);
+          v.x = fmaf(dsv[h], q4.x, v.x); v.y = fmaf(dsv[h], q4.y, v.y); v.z = fmaf(dsv[h], q4.z, v.z); v.w = fmaf(dsv[h], q4.w, v.w);
+          v.x = fmaf(pvv[h], g4.x, v.x); v.y = fmaf(pvv[h], g4.y, v.y); v.z = fmaf(pvv[h], g4.z, v.z); v.w = fmaf(pvv[h], g4.w, v.w);
+        }
+        *reinterpret_cast<float4*>(row + 4 * c) = v;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+      const int j = ps * RPP + jr;
+      if (j < rows_out) reinterpret_cast<float4*>(a.G)[(gbase + j) * LPR + cc] = *reinterpret_cast<const float4*>(tile + j * ST + 4 * cc);
+    }
+    __syncthreads();
+  }
+}
+
+// The same two passes for 64 < history_max <= 128: KPL = 2 keys per lane, a tile of 64 * KPL rows.  (Kept apart from the kernels above:
+// written with KPL = 1 the backward compiles to 146 instead of 108 registers -- three instead of four workgroups per CU on the path
+// every benchmark configuration takes.)
+template <int D, int NH, bool GATHER, int KPL>
+__global__ __launch_bounds__(kBlock) void sb_lr_attn_fwd_long_kernel(SbLrAttnArgs a) {
+  constexpr int ST = D + 4, LPR = D / 4, RPP = kBlock / LPR, TR = 64 * KPL, NPASS = TR / RPP;
+  __shared__ __attribute__((aligned(16))) float tile[TR * ST];
+  __shared__ __attribute__((aligned(16))) float sqt[NH * ST];
+  __shared__ __attribute__((aligned(16))) float sp[TR * kLrMaxHeads];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int B = a.rows.B, L = a.rows.L;
+  const float sqrt_dk = sqrtf((float)(D / NH));
+  const int jr = t / LPR, cc = t % LPR;
+  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    const int n = sb_len(a.rows.lengths, b, L);   // workgroup-uniform
+    if (n == 0) {   // empty history: defined zeros for the kernels that follow
+      for (int e = t; e < NH * D; e += kBlock) a.xbar[(size_t)b * NH * D + e] = 0.f;
+      for (int e = t; e < NH * L; e += kBlock) a.p[(size_t)b * NH * L + e] = 0.f;
+      continue;
+    }
+    for (int e = t; e < NH * D; e += kBlock) sqt[(e / D) * ST + e % D] = a.qt[(size_t)b * NH * D + e];
+    const size_t base = sb_lr_rowbase(a.rows, b);
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+      const int j = ps * RPP + jr;
+      if (j < n) {
+        float4 v;
+        if (GATHER) {
+          const float4 it = reinterpret_cast<const float4*>(a.rows.item_emb)[a.rows.hist[(size_t)b * L + j] * LPR + cc];
+          const float4 ps4 = reinterpret_cast<const float4*>(a.rows.pos_emb)[(size_t)(n - j) * LPR + cc];
+          v = make_float4(it.x + ps4.x, it.y + ps4.y, it.z + ps4.z, it.w + ps4.w);
+          reinterpret_cast<float4*>(a.Xsave)[(base + j) * LPR + cc] = v;
+        } else {
+          v = reinterpret_cast<const float4*>(a.rows.X)[(base + j) * LPR + cc];
+        }
+        *reinterpret_cast<float4*>(tile + j * ST + 4 * cc) = v;
+      }
+    }
+    __syncthreads();
+    if (wave < NH) {   // head `wave`, lane = key (+ 64 k)
+      const float cq = a.cq[(size_t)b * kLrMaxHeads + wave];
+      float sc[KPL], mx = -INFINITY;
+#pragma unroll
+      for (int k = 0; k < KPL; ++k) {
+        const int j = lane + 64 * k;
+        const bool on = j < n;
+        sc[k] = sas_div_scale(sb_lr_row_dot<D>(tile + (on ? j : 0) * ST, sqt + wave * ST, cq), sqrt_dk);
+        if (on) mx = fmaxf(mx, sc[k]);
+      }
+      const float m = lr_wave_max(mx);
+      float e[KPL], es = 0.f;
+#pragma unroll
+      for (int k = 0; k < KPL; ++k) {
+        e[k] = lane + 64 * k < n ? expf(sc[k] - m) : 0.f;
+        es += e[k];
+      }
+      const float rz = 1.0f / lr_wave_sum(es);
+#pragma unroll
+      for (int k = 0; k < KPL; ++k) {
+        const int j = lane + 64 * k;
+        const float pv = e[k] * rz;
+        if (j < L) a.p[((size_t)b * NH + wave) * L + j] = pv;
+        sp[4 * j + wave] = pv;
+      }
+    }
+    __syncthreads();
+    if (wave < NH) {   // lane = (feature quad, key group)
+      const float4 acc = sb_lr_weighted_rows<D>(tile, sp, wave, n, lane);
+      if (lane < D / 4) reinterpret_cast<float4*>(a.xbar + ((size_t)b * NH + wave) * D)[lane] = acc;
+    }
+    __syncthreads();   // the tile is rewritten by the next sequence
+  }
+}
+
+template <int D, int NH, int KPL>
+__global__ __launch_bounds__(kBlock) void sb_lr_attn_bwd_long_kernel(SbLrAttnArgs a) {
+  constexpr int ST = D + 4, LPR = D / 4, RPP = kBlock / LPR, TR = 64 * KPL, NPASS = TR / RPP;
+  __shared__ __attribute__((aligned(16))) float tile[TR * ST];
+  __shared__ __attribute__((aligned(16))) float sqt[NH * ST];
+  __shared__ __attribute__((aligned(16))) float sgt[NH * ST];
+  __shared__ __attribute__((aligned(16))) float sw[TR * kLrMaxHeads];   // ds by (key, head)
+  __shared__ __attribute__((aligned(16))) float sp[TR * kLrMaxHeads];   // p by (key, head)
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int B = a.rows.B, L = a.rows.L;
+  const float sqrt_dk = sqrtf((float)(D / NH));
+  const int jr = t / LPR, cc = t % LPR;
+  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    const int n = sb_len(a.rows.lengths, b, L);
+    const size_t gbase = a.g_off ? (size_t)a.g_off[b] : (size_t)b * L;
+    const int rows_out = a.g_off ? n : L;
+    if (n == 0) {
+      for (int e = t; e < NH * D; e += kBlock) a.ybar[(size_t)b * NH * D + e] = 0.f;
+      if (t < kLrMaxHeads) a.sds[(size_t)b * kLrMaxHeads + t] = 0.f;
+#pragma unroll
+      for (int ps = 0; ps < NPASS; ++ps)
+        if (ps * RPP + jr < rows_out) reinterpret_cast<float4*>(a.G)[(gbase + ps * RPP + jr) * LPR + cc] = make_float4(0.f, 0.f, 0.f, 0.f);
+      continue;
+    }
+    for (int e = t; e < NH * D; e += kBlock) {
+      sqt[(e / D) * ST + e % D] = a.qt[(size_t)b * NH * D + e];
+      sgt[(e / D) * ST + e % D] = a.gt[(size_t)b * NH * D + e];
+    }
+    const size_t base = sb_lr_rowbase(a.rows, b);
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+      const int j = ps * RPP + jr;
+      if (j < n) *reinterpret_cast<float4*>(tile + j * ST + 4 * cc) = reinterpret_cast<const float4*>(a.rows.X)[(base + j) * LPR + cc];
+    }
+    __syncthreads();
+    if (wave < NH) {   // head `wave`, lane = key (+ 64 k)
+      const float cg = a.cg[(size_t)b * kLrMaxHeads + wave];
+      float pv[KPL], dp[KPL], pd = 0.f;
+#pragma unroll
+      for (int k = 0; k < KPL; ++k) {
+        const int j = lane + 64 * k;
+        const bool on = j < n;
+        pv[k] = on ? a.p[((size_t)b * NH + wave) * L + j] : 0.f;
+        dp[k] = sb_lr_row_dot<D>(tile + (on ? j : 0) * ST, sgt + wave * ST, cg);
+        pd += pv[k] * dp[k];
+      }
+      const float dot = lr_wave_sum(pd);
+      float ds[KPL], dsum = 0.f;
+#pragma unroll
+      for (int k = 0; k < KPL; ++k) {
+        ds[k] = sas_div_scale(pv[k] * (dp[k] - dot), sqrt_dk);
+        dsum += ds[k];
+      }
+      const float tot = lr_wave_sum(dsum);
+      if (lane == 0) a.sds[(size_t)b * kLrMaxHeads + wave] = tot;
+#pragma unroll
+      for (int k = 0; k < KPL; ++k) {
+        sw[4 * (lane + 64 * k) + wave] = ds[k];
+        sp[4 * (lane + 64 * k) + wave] = pv[k];
+      }
+    }
+    __syncthreads();
+    if (wave < NH) {   // lane = (feature quad, key group)
+      const float4 acc = sb_lr_weighted_rows<D>(tile, sw, wave, n, lane);
+      if (lane < D / 4) reinterpret_cast<float4*>(a.ybar + ((size_t)b * NH + wave) * D)[lane] = acc;
+    }
+    __syncthreads();   // every wave is done with the x rows: the tile now takes the dX rows
+#pragma unroll
+    for (int k = 0; k < KPL; ++k) {   // row lane + 64 k, columns [wave * D / 4, (wave + 1) * D / 4); rows past the length have ds = p = 0
+      const int j = lane + 64 * k;
+      float dsv[NH], pvv[NH];
+#pragma unroll
+      for (int h = 0; h < NH; ++h) {
+        dsv[h] = sw[4 * j + h];
+        pvv[h] = sp[4 * j + h];
+      }
+      float* row = tile + j * ST + wave * (D / 4);
 #pragma unroll
       for (int c = 0; c < D / 16; ++c) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);

@@ -21,8 +21,20 @@ __device__ __forceinline__ sas_f32x4 sas_zero4() {
 }
 #endif
 
-constexpr int kSasLP = 64;        // max rows (history length) per sequence
+constexpr int kSasLP = 64;        // max rows (history length) per sequence of the all-rows kernels
+constexpr int kSasLongLP = 128;   // ... of the batch encoder's one-row path (one block, no dropout; csrc/sas_last_row.hpp)
 constexpr int kSasMaxLayers = 4;
+
+// shapes every path covers (per-sequence kernels, all-rows batch kernels, dropout)
+inline bool sas_core_supported(int d, int n_layers, int n_heads, int L) {
+  return (d == 32 || d == 64) && n_layers >= 1 && n_layers <= kSasMaxLayers && n_heads >= 1 && d % n_heads == 0 && L >= 1 &&
+         L <= kSasLP;
+}
+// 64 < history_max <= 128: the batch encoder when its K / V-free one-row path is the whole encoder
+inline bool sas_long_supported(int d, int n_layers, int n_heads, int L) {
+  return (d == 32 || d == 64) && n_layers == 1 && (n_heads == 1 || n_heads == 2 || n_heads == 4) && L > kSasLP && L <= kSasLongLP &&
+         (d / n_heads) % (d * d / 256) == 0;
+}
 constexpr float kLnEps = 1e-5f;   // nn.LayerNorm default
 
 struct SasLayer {  // device pointers, nn.Linear layout [out, in]

@@ -429,8 +429,7 @@ static int sas_launch_bwd(SasArgs a, float* dense_out, void* bucket_ws, hipStrea
 using namespace rc;
 
 extern "C" int rc_sasrec_supported(int d, int n_layers, int n_heads, int L) {
-  return ((d == 32 || d == 64) && n_layers >= 1 && n_layers <= kSasMaxLayers && n_heads >= 1 && d % n_heads == 0 &&
-          L >= 1 && L <= kSasLP) ? 1 : 0;
+  return (sas_core_supported(d, n_layers, n_heads, L) || sas_long_supported(d, n_layers, n_heads, L)) ? 1 : 0;
 }
 
 extern "C" int rc_sasrec_dense_param_count(int d) { return 5 * d * d + 9 * d; }
@@ -447,7 +446,7 @@ extern "C" int rc_sasrec_fwd(const float* item_emb, const float* pos_emb, const 
                              rc_stream_t stream) {
   if (B == 0) return RC_OK;
   RC_REQUIRE(item_emb && pos_emb && hist && lengths && hv && ws, "rc_sasrec_fwd: null pointer");
-  if (!rc_sasrec_supported(d, n_layers, n_heads, L))
+  if (!sas_core_supported(d, n_layers, n_heads, L))
     return fail(RC_ERR_UNSUPPORTED, "rc_sasrec_fwd: d=%d layers=%d heads=%d L=%d not supported (d in {32,64}, L<=%d)",
                 d, n_layers, n_heads, L, kSasLP);
   SasArgs a;
@@ -469,7 +468,7 @@ extern "C" int rc_sasrec_bwd(const float* const* layer_params, int n_layers, int
                              float* dense_grads, void* ws, size_t ws_bytes, rc_stream_t stream) {
   if (B == 0) return RC_OK;
   RC_REQUIRE(lengths && xsave && dhv && g_hist && dense_grads && ws, "rc_sasrec_bwd: null pointer");
-  if (!rc_sasrec_supported(d, n_layers, n_heads, L))
+  if (!sas_core_supported(d, n_layers, n_heads, L))
     return fail(RC_ERR_UNSUPPORTED, "rc_sasrec_bwd: d=%d layers=%d heads=%d L=%d not supported", d, n_layers, n_heads, L);
   if (ws_bytes < rc_sasrec_workspace_bytes(B, d, n_layers))
     return fail(RC_ERR_WORKSPACE, "rc_sasrec_bwd: workspace %zu < %zu", ws_bytes, rc_sasrec_workspace_bytes(B, d, n_layers));

@@ -1826,11 +1826,11 @@ static int sb_last_row_mode(int n_heads, int B, int L, bool drop) {
     return v ? (int64_t)atoll(v) : (int64_t)32768;
   }();
   const int want = sb_last_row_request();
-  if (want <= 0 || drop || n_heads < 1 || D % n_heads != 0 || L > 64 || !sb_fused_block() || !sb_rows16()) return 0;
+  if (want <= 0 || drop || n_heads < 1 || D % n_heads != 0 || L > kLrMaxL || !sb_fused_block() || !sb_rows16()) return 0;
   const int dk = D / n_heads;
   // the buffers of the K / V-free version live in the saved state's per-layer arrays: H * D + 4 <= L * D and 2 D + H L <= L D
   const bool v2 = (n_heads == 1 || n_heads == 2 || n_heads == 4) && L >= 3 && L >= n_heads + 1 && dk % (D * D / kBlock) == 0;
-  const bool v1 = L >= 2 && (dk == 16 || dk == 32 || dk == 64) && (int64_t)B * L >= min_rows;
+  const bool v1 = L >= 2 && L <= kSasLP && (dk == 16 || dk == 32 || dk == 64) && (int64_t)B * L >= min_rows;
   if (want >= 2 && v2) return 2;
   return v1 ? 1 : 0;
 }
@@ -2054,10 +2054,15 @@ static int sb_last_block_fwd(const float* item_emb, const float* pos_emb, const 
     memset(&a, 0, sizeof(a));
     a.rows = rows; a.Xsave = gather ? sv.x : nullptr; a.qt = u.qt; a.cq = u.cq; a.p = u.p; a.xbar = u.xbar;
     const dim3 grid((unsigned)(B < 2048 ? (B < 1 ? 1 : B) : 2048)), block(kBlock);   // 19.5 KB of LDS per workgroup: eight per CU
-#define RC_LR_FWD(NH)                                                                                    \
-  do {                                                                                                   \
-    if (gather) hipLaunchKernelGGL((sb_lr_attn_fwd_kernel<D, NH, true>), grid, block, 0, s, a);          \
-    else hipLaunchKernelGGL((sb_lr_attn_fwd_kernel<D, NH, false>), grid, block, 0, s, a);                \
+#define RC_LR_FWD(NH)                                                                                        \
+  do {                                                                                                       \
+    if (L > 64) {                                                                                            \
+      if (gather) hipLaunchKernelGGL((sb_lr_attn_fwd_long_kernel<D, NH, true, 2>), grid, block, 0, s, a);    \
+      else hipLaunchKernelGGL((sb_lr_attn_fwd_long_kernel<D, NH, false, 2>), grid, block, 0, s, a);          \
+    } else {                                                                                                 \
+      if (gather) hipLaunchKernelGGL((sb_lr_attn_fwd_kernel<D, NH, true>), grid, block, 0, s, a);            \
+      else hipLaunchKernelGGL((sb_lr_attn_fwd_kernel<D, NH, false>), grid, block, 0, s, a);                  \
+    }                                                                                                        \
   } while (0)
     if (n_heads == 1) RC_LR_FWD(1);
     else if (n_heads == 2) RC_LR_FWD(2);
@@ -2126,9 +2131,15 @@ static int sb_last_block_bwd(const SasLayer& p, int n_heads, const int64_t* leng
     a.qt = u.qt; a.cq = u.cq; a.p = u.p; a.gt = gt; a.cg = cg; a.G = Gout; a.g_off = padded ? nullptr : w.off; a.ybar = ybar;
     a.sds = sds;
     const dim3 grid((unsigned)(B < 1792 ? (B < 1 ? 1 : B) : 1792)), block(kBlock);   // 21.6 KB of LDS per workgroup: seven per CU
-    if (n_heads == 1) hipLaunchKernelGGL((sb_lr_attn_bwd_kernel<D, 1>), grid, block, 0, s, a);
-    else if (n_heads == 2) hipLaunchKernelGGL((sb_lr_attn_bwd_kernel<D, 2>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((sb_lr_attn_bwd_kernel<D, 4>), grid, block, 0, s, a);
+#define RC_LR_BWD(NH)                                                                                  \
+  do {                                                                                                 \
+    if (L > 64) hipLaunchKernelGGL((sb_lr_attn_bwd_long_kernel<D, NH, 2>), grid, block, 0, s, a);      \
+    else hipLaunchKernelGGL((sb_lr_attn_bwd_kernel<D, NH>), grid, block, 0, s, a);                     \
+  } while (0)
+    if (n_heads == 1) RC_LR_BWD(1);
+    else if (n_heads == 2) RC_LR_BWD(2);
+    else RC_LR_BWD(4);
+#undef RC_LR_BWD
     RC_LAUNCH_CHECK();
   }
   {   // dq_h = Wk_h ybar_h + bk_h sum_j ds_hj;  d x_last = dq Wq + dZ1, added to the last row's dX
@@ -2171,6 +2182,9 @@ static int sb_forward(const float* item_emb, const float* pos_emb, const SasLaye
   // one block, K / V-free last-row path: the block reads the table rows itself (and stores them padded, [B, L, D], for the
   // backward) -- no compact row space, no embedding pass
   const bool lr_gather = last_mode == 2 && n_layers == 1;
+  if (L > kSasLP && !lr_gather)
+    return fail(RC_ERR_UNSUPPORTED, "rc_sasrec_batch_fwd: history_max %d > %d is covered by the one-row path only (one block, no "
+                "dropout, 1 / 2 / 4 heads, RC_SAS_LAST_ROW unset)", L, kSasLP);
   SbSaved sv = sb_saved(state, 0, rmax, D);
   if (!lr_gather) {
     hipLaunchKernelGGL(sb_offsets_kernel, dim3(1), dim3(kBlock), 0, s, lengths, B, L, w.off, w.off_seq);
@@ -2345,6 +2359,9 @@ static int sb_backward(const SasLayer* layer, int n_layers, int n_heads, const i
   const int last_mode = sb_last_row_mode<D>(n_heads, B, L, drop);
   const bool last_row = last_mode != 0;
   const bool lean = last_mode == 2 && n_layers == 1;   // every launch writes the same sb_last_slots(B) slices
+  if (L > kSasLP && !lean)
+    return fail(RC_ERR_UNSUPPORTED, "rc_sasrec_batch_bwd: history_max %d > %d is covered by the one-row path only (one block, no "
+                "dropout, 1 / 2 / 4 heads, RC_SAS_LAST_ROW unset)", L, kSasLP);
   const int slots = lean ? sb_last_slots(B) : kSbPartWg;
   if (!lean) RC_HIP(hipMemsetAsync(w.part, 0, (size_t)kSbPartWg * stride * sizeof(float), s));
   float* G = w.t0;

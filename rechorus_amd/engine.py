@@ -822,7 +822,13 @@ SAS_LAYER_KEYS = ("Wq", "bq", "Wk", "bk", "Wv", "bv", "ln1w", "ln1b", "W1", "b1"
 SAS_NO_DECAY = ("bq", "bk", "bv", "ln1b", "b1", "b2", "ln2b")  # names containing 'bias' (BaseModel.py:64-73)
 
 
-def sasrec_supported(d, n_layers, n_heads, L):
+SASREC_CORE_MAX_HIS = 64   # history_max every encoder path covers; up to 128: one block without dropout (the batch encoder's one-row path)
+
+
+def sasrec_supported(d, n_layers, n_heads, L, dropout=0.0):
+    """the fused encoder covers the shape (rc_sasrec_supported); training-mode dropout needs the all-rows kernels (history <= 64)"""
+    if dropout > 0.0 and int(L) > SASREC_CORE_MAX_HIS:
+        return False
     return bool(_lib.load().rc_sasrec_supported(int(d), int(n_layers), int(n_heads), int(L)))
 
 
@@ -847,11 +853,11 @@ SASREC_BATCH_MIN_ROWS = 4096  # B * history_max from which the batch-level kerne
 
 def _sasrec_one_row_encoder(d, n_heads, n_layers, L):
     """the batch encoder's K / V-free last-row path (csrc/sas_last_row.hpp; sb_last_row_mode) serves the WHOLE encoder:
-    one block, no dropout, head count 1 / 2 / 4, history_max 3 .. 64"""
+    one block, no dropout, head count 1 / 2 / 4, history_max 3 .. 128"""
     if d is None or int(os.environ.get("RC_SAS_LAST_ROW", "2")) < 2 or os.environ.get("RC_SAS_FUSED_BLOCK") == "0" \
             or os.environ.get("RC_SAS_ROWS16") == "0":
         return False
-    return (n_layers == 1 and d in (32, 64) and n_heads in (1, 2, 4) and 3 <= L <= 64 and L >= n_heads + 1
+    return (n_layers == 1 and d in (32, 64) and n_heads in (1, 2, 4) and 3 <= L <= 128 and L >= n_heads + 1
             and (d // n_heads) % (d * d // 256) == 0)
 
 

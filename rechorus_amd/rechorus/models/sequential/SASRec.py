@@ -61,8 +61,8 @@ class SASRecBase(object):
     def _encode(self, feed_dict):
         history = feed_dict['history_items']    # [batch_size, <= history_max], right padded with 0
         lengths = feed_dict['lengths']          # [batch_size]
-        if engine.sasrec_supported(self.emb_size, self.num_layers, self.num_heads, history.shape[1]):
-            p = float(self.dropout) if self.training else 0.0
+        p = float(self.dropout) if self.training else 0.0
+        if engine.sasrec_supported(self.emb_size, self.num_layers, self.num_heads, history.shape[1], p):
             if p > 0:
                 engine.step_increment(self.drop_seed)  # new mask for this forward; its backward reads the same value
             return hnn.sasrec_encode(self.i_embeddings.weight, self.p_embeddings.weight,
@@ -85,14 +85,15 @@ class SASRecBase(object):
 
     # ---- large-table mode: row-wise update of the item table, dense step of everything small -----------
     def hip_rowwise_supported(self):
-        return bool(engine.sasrec_supported(self.emb_size, self.num_layers, self.num_heads, self.max_his))
+        return bool(engine.sasrec_supported(self.emb_size, self.num_layers, self.num_heads, self.max_his, float(self.dropout)))
 
     def hip_train_step(self, feed_dict, opt_name, lr, l2):
         """encoder fwd/bwd (MFMA) + scoring + BPR loss + ONE segmented pass over candidate and history
         occurrences of the item table (engine.SasrecTrainer); returns the device loss tensor"""
         history, lengths = feed_dict['history_items'], feed_dict['lengths']
-        if not engine.sasrec_supported(self.emb_size, self.num_layers, self.num_heads, history.shape[1]):
-            raise RuntimeError('SASRec --engine rowwise needs the fused encoder: emb_size in {32, 64}, history <= 64')
+        if not engine.sasrec_supported(self.emb_size, self.num_layers, self.num_heads, history.shape[1], float(self.dropout)):
+            raise RuntimeError('SASRec --engine rowwise needs the fused encoder: emb_size in {32, 64}, history <= 64 '
+                               '(<= 128 with one block, 1 / 2 / 4 heads and no dropout)')
         tr = getattr(self, '_trainer', None)
         if tr is None or tr.opt != opt_name:
             P = {'item_emb': self.i_embeddings.weight.data, 'pos_emb': self.p_embeddings.weight.data,

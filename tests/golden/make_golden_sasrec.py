@@ -149,6 +149,7 @@ CASES = [
     ("sasrec_d64_l1_h4_L50",  120, 64, 1, 4, 50, 8, 19, 32),
     ("sasrec_d64_l2_h2",       80, 64, 2, 2, 12, 10, 5, 33),
     ("sasrec_d32_l1_h4",       60, 32, 1, 4, 7, 9, 3, 34),
+    ("sasrec_d64_l1_h2_L100", 150, 64, 1, 2, 100, 9, 7, 35),    # more than 64 positions: one block, the one-row path's 128-row tile
 ]
 
 DROP_CASES = [
@@ -158,6 +159,12 @@ DROP_CASES = [
 ]
 
 if __name__ == "__main__":
+    only = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--only=")]
+    if only:   # one named case (the committed fixtures of the others stay as they are)
+        for c in CASES:
+            if c[0] in only:
+                make_case(*c)
+        sys.exit(0)
     if "--dropout-only" not in sys.argv:
         for c in CASES:
             make_case(*c)

@@ -215,7 +215,7 @@ def test_neumf_model_file_trains_with_dropout_in_the_kernels(case, cuda):
     assert_close(e1.cpu().numpy(), want_eval, what="eval prediction")
 
 
-@pytest.mark.parametrize("case", ["sasrec_d64_l1_h1", "sasrec_d64_l1_h4_L50", "sasrec_d64_l2_h2", "sasrec_d32_l1_h4"])
+@pytest.mark.parametrize("case", ["sasrec_d64_l1_h1", "sasrec_d64_l1_h4_L50", "sasrec_d64_l2_h2", "sasrec_d32_l1_h4", "sasrec_d64_l1_h2_L100"])
 def test_sasrec_model_file_matches_reference(case, cuda):
     from models.sequential.SASRec import SASRec
     g = load_golden(case)

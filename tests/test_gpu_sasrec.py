@@ -41,6 +41,10 @@ def test_sasrec_forward_backward(case, impl, cuda, eng):
     B, L = g["hist"].shape
     C, d = g["iid"].shape[1], P["item_emb"].shape[1]
     assert eng.sasrec_supported(d, n_layers, n_heads, L)
+    if L > 64 and impl == "sequence":   # more than 64 positions: the batch encoder's one-row path only (one block, no dropout)
+        with pytest.raises(Exception, match="not supported"):
+            eng.sasrec_fwd(P["item_emb"], P["pos_emb"], P["layers"], n_heads, hist, lengths, save=True, impl=impl)
+        return
     hv, xsave = eng.sasrec_fwd(P["item_emb"], P["pos_emb"], P["layers"], n_heads, hist, lengths, save=True, impl=impl)
     rows = torch.arange(B, device=cuda)
     pred = eng.gather_dot(hv, P["item_emb"], rows, iid)
@@ -160,6 +164,58 @@ def test_sasrec_length_buckets_vs_oracle(impl, cuda, eng):
     g_hist_b, dg_b = eng.sasrec_bwd(Pd["layers"], n_heads, l_d, xs_b, dhv)
     assert torch.equal(hv, hv_b) and torch.equal(g_hist, g_hist_b)
     assert all(torch.equal(dg[l][k], dg_b[l][k]) for l in range(n_layers) for k in LAYER_NAMES)
+
+
+@pytest.mark.parametrize("d,n_heads,L,B", [(64, 4, 128, 90), (64, 1, 65, 33), (32, 2, 100, 140), (32, 4, 128, 21)])
+def test_sasrec_more_than_64_positions_vs_oracle(d, n_heads, L, B, cuda, eng, monkeypatch):
+    """64 < history_max <= 128 with ONE block and no dropout: the batch encoder's one-row path with a 128-row tile (two keys per
+    lane) is the whole encoder.  Output, history gradient (incl. zero rows past the length), position-table and parameter
+    gradients against the numpy oracle, with empty, single-item, 64 / 65-item and full histories; other routes refuse the shape."""
+    from oracle import sasrec_oracle as SO
+    rng = np.random.default_rng(L * 7 + d + n_heads)
+    n_layers, C, n_items = 1, 4, 300
+    assert eng.sasrec_supported(d, n_layers, n_heads, L) and not eng.sasrec_supported(d, 2, n_heads, L)
+    assert not eng.sasrec_supported(d, n_layers, n_heads, L, dropout=0.2) and not eng.sasrec_supported(d, n_layers, n_heads, 129)
+    P = _random_sasrec(rng, n_items, d, n_layers, L)
+    lengths = rng.integers(1, L + 1, size=B).astype(np.int64)
+    lengths[:6] = (L, 0, 1, 64, 65, L - 1)
+    hist = rng.integers(1, n_items, size=(B, L)).astype(np.int64) * (np.arange(L)[None, :] < lengths[:, None])
+    iid = rng.integers(1, n_items, size=(B, C)).astype(np.int64)
+    gpred = rng.normal(size=(B, C)).astype(np.float32)
+    Pd = to_dev(P, n_layers, cuda)
+    h_d, l_d, i_d = (torch.from_numpy(x).to(cuda) for x in (hist, lengths, iid))
+    hv, xsave = eng.sasrec_fwd(Pd["item_emb"], Pd["pos_emb"], Pd["layers"], n_heads, h_d, l_d, save=True)
+    assert xsave.impl == "batch"
+    live = lengths > 0   # (the oracle, like the reference, reads position -1 of an all-padding row; the engine defines 0)
+    _, cache = SO.forward(P, hist[live], lengths[live], iid[live], n_heads, keep=True)
+    assert_close(hv.cpu().numpy()[live], cache["hv"], what="hv", rtol=2e-5, atol_scale=3e-5)
+    assert np.all(hv.cpu().numpy()[~live] == 0)
+    gp_d = torch.from_numpy(gpred).to(cuda)
+    dhv = eng.weighted_row_sum(Pd["item_emb"], i_d, gp_d)
+    g_hist, dg = eng.sasrec_bwd(Pd["layers"], n_heads, l_d, xsave, dhv)
+    _, G = SO.backward(P, hist[live], lengths[live], iid[live], n_heads, gpred[live])
+    floor = 1e-6 * max(float(np.abs(v).max()) for v in G.values())
+    for k, name in LAYER_NAMES.items():
+        assert_close(dg[0][k].cpu().numpy(), G["transformer_block.0.%s" % name], what=f"d{k}", rtol=3e-5, atol_scale=1e-4, abs_floor=floor)
+    gh = g_hist.cpu().numpy()
+    assert np.all(gh[np.arange(L)[None, :] >= lengths[:, None]] == 0)
+    valid = (h_d > 0).to(torch.int64)
+    position = ((l_d[:, None] - torch.arange(L, device=cuda)[None, :]) * valid).contiguous()
+    GP = eng.embedding_dense_backward(g_hist, position, Pd["pos_emb"].shape[0])
+    assert_close(GP.cpu().numpy(), G["p_embeddings.weight"], what="d pos_emb", rtol=3e-5, atol_scale=1e-4)
+    GI = eng.embedding_dense_backward(g_hist, h_d, n_items)
+    want_items = G["i_embeddings.weight"].copy()
+    np.subtract.at(want_items, iid[live].reshape(-1), (gpred[live][:, :, None] * cache["hv"][:, None, :]).reshape(-1, d))   # minus the candidates' part
+    assert_close(GI.cpu().numpy()[1:], want_items[1:], what="d item_emb (history part)", rtol=3e-5, atol_scale=1e-4)
+    hv_b, xs_b = eng.sasrec_fwd(Pd["item_emb"], Pd["pos_emb"], Pd["layers"], n_heads, h_d, l_d, save=True)
+    g_hist_b, _ = eng.sasrec_bwd(Pd["layers"], n_heads, l_d, xs_b, dhv)
+    assert torch.equal(hv, hv_b) and torch.equal(g_hist, g_hist_b)
+    for bad in ({"impl": "sequence"}, {"drop_p": 0.3, "seed": torch.zeros(1, dtype=torch.int64, device=cuda)}):
+        with pytest.raises(Exception):
+            eng.sasrec_fwd(Pd["item_emb"], Pd["pos_emb"], Pd["layers"], n_heads, h_d, l_d, save=True, **bad)
+    monkeypatch.setenv("RC_SAS_LAST_ROW", "0")
+    with pytest.raises(Exception, match="one-row path"):
+        eng.sasrec_fwd(Pd["item_emb"], Pd["pos_emb"], Pd["layers"], n_heads, h_d, l_d, save=True, impl="batch")
 
 
 def test_sasrec_batch_kernels_edge_shapes_vs_sequence_kernels(cuda, eng):
