@@ -52,6 +52,19 @@ def test_version_and_error_reporting(lib):
     assert b"C >= 2" in lib.rc_last_error_string()
 
 
+def test_sasrec_shape_envelope(lib):
+    """rc_sasrec_supported is host logic: d in {32, 64}, 1..4 blocks, heads | d, history_max <= 64 on every route; 65..128 with ONE
+    block and 1 / 2 / 4 heads (the batch encoder's one-row path).  engine.sasrec_supported adds: no training-mode dropout there."""
+    from rechorus_amd import engine
+    ok = lambda *a: bool(lib.rc_sasrec_supported(*a))   # (d, n_layers, n_heads, L)
+    assert ok(64, 1, 4, 50) and ok(32, 4, 2, 64) and ok(64, 2, 8, 20) and ok(64, 1, 1, 1)
+    assert not ok(128, 1, 4, 50) and not ok(64, 5, 4, 50) and not ok(64, 1, 3, 50) and not ok(64, 1, 4, 0)
+    assert ok(64, 1, 4, 65) and ok(64, 1, 1, 128) and ok(32, 1, 2, 100) and ok(32, 1, 4, 128)
+    assert not ok(64, 2, 4, 65) and not ok(64, 1, 8, 100) and not ok(64, 1, 4, 129)
+    assert engine.sasrec_supported(64, 1, 4, 100) and not engine.sasrec_supported(64, 1, 4, 100, dropout=0.1)
+    assert engine.sasrec_supported(64, 2, 4, 64, dropout=0.5)
+
+
 def test_opt_hyper_struct_layout():
     # struct rc_opt_hyper: 2 ints, 5 doubles, 1 int64 -> 56 bytes, natural alignment
     assert C.sizeof(_lib.OptHyper) == 56
