@@ -1010,7 +1010,8 @@ class SasrecTrainer:
         synchronisation, grids that depend on shapes only) is replayed from a hipGraph with the batch copied into static
         buffers -- at config 3 the eager step is bound by the host's launch rate (0.42 ms enqueue against 0.27 ms of GPU work).
         Same kernels, same results.  With Adam the step count is kept in device memory (capturable semantics: bias corrections
-        formed in the kernels) and the item table must take the one-wave-per-row update (seg_rows_route), rowwise=True."""
+        formed in the kernels) and the item table must take the one-wave-per-row update (seg_rows_route), rowwise=True.
+        The loss tensor a replayed step returns is the graph's own buffer: the next replay overwrites it (clone it to keep it)."""
         self.P, self.n_heads, self.opt, self.lr, self.l2, self.rowwise = P, n_heads, opt, lr, l2, rowwise
         self.dropout = float(dropout)
         self.seed = torch.tensor([seed], dtype=torch.int64, device=P["item_emb"].device) if self.dropout > 0 else None
