@@ -405,6 +405,110 @@ __global__ __launch_bounds__(kBlock) void neumf_reduce_partials_kernel(ReduceArg
   }
 }
 
+// ---- forward on 16-candidate tiles (no dropout) -----------------------------------------------------------------------------------------
+// The forward pass alone is bound by its gathers (4 table rows of d floats per candidate: 671 MB at the config-4 shape), not by
+// the 11 GFLOP of the hidden layer: neumf_kernel<.., false, ..> stages every 64-candidate tile through LDS behind barriers with ONE
+// wave per SIMD, so gather latency, staging and the MFMA chain take turns (0.25 ms: 2.7 TB/s of gathers).  Here a wave owns a
+// 16-candidate tile on its own: the mlp rows go from global memory straight into the B operand registers of v_mfma_f32_16x16x4_f32
+// (Z1^T = W1 h0^T: lane (i, g) holds h0[row i][16 c + 4 g ..], the layout a float4 load delivers), W1 waits in LDS (row stride
+// 2 d + 4: one ds_read_b128 feeds four MFMAs), the GMF product is formed from the two mf rows as they arrive, the epilogue
+// (bias, ReLU, output dot) runs on the accumulators and one xor-shuffle pair completes the row's prediction.  No LDS tile, no
+// barrier after the weights are staged, eight waves per workgroup whose gathers and MFMA chains overlap freely.
+typedef float f32x4m __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4m mfma16(float a, float b, f32x4m c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+constexpr int kFwd16Waves = 8;
+
+template <int D, int L1>
+__global__ __launch_bounds__(64 * kFwd16Waves) void neumf_fwd16_kernel(NeumfArgs a) {
+  constexpr int K0 = 2 * D, SW = K0 + 4, NCU = D / 16, NT = L1 / 16;
+  static_assert(NT % 2 == 0, "output tiles are processed in pairs");
+  extern __shared__ float lds[];
+  float* Ws = lds;                 // [L1][SW]
+  float* sb1 = Ws + L1 * SW;       // [L1]
+  float* swo = sb1 + L1;           // [D + L1]
+  for (int i = threadIdx.x; i < L1 * K0 / 4; i += blockDim.x)
+    *reinterpret_cast<float4*>(Ws + (i / (K0 / 4)) * SW + 4 * (i % (K0 / 4))) = reinterpret_cast<const float4*>(a.W1)[i];
+  for (int i = threadIdx.x; i < L1; i += blockDim.x) sb1[i] = a.b1[i];
+  for (int i = threadIdx.x; i < D + L1; i += blockDim.x) swo[i] = a.w_out[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
+  const int nw = blockDim.x >> 6;
+  const int64_t tiles = (a.n + 15) / 16;
+  for (int64_t t = (int64_t)blockIdx.x * nw + wave; t < tiles; t += (int64_t)gridDim.x * nw) {
+    asm volatile("" ::: "memory");   // the weights are re-read from LDS per tile (the compiler would hoist them into registers)
+    const int64_t n = 16 * t + i;
+    const bool valid = n < a.n;
+    const int64_t nn = valid ? n : a.n - 1;
+    const int64_t u = a.uid[nn / a.C], item = a.iid[nn];
+    float x[2 * NCU][4];
+    const float* hu = a.mlp_u + u * D + 4 * g;
+    const float* hi = a.mlp_i + item * D + 4 * g;
+#pragma unroll
+    for (int c = 0; c < NCU; ++c) {
+      const float4 v = *reinterpret_cast<const float4*>(hu + 16 * c), w = *reinterpret_cast<const float4*>(hi + 16 * c);
+      x[c][0] = v.x; x[c][1] = v.y; x[c][2] = v.z; x[c][3] = v.w;
+      x[NCU + c][0] = w.x; x[NCU + c][1] = w.y; x[NCU + c][2] = w.z; x[NCU + c][3] = w.w;
+    }
+    // GMF branch: the lane's share of w_mf . (mf_u * mf_i)
+    float pp = 0.f;
+    const float* mu = a.mf_u + u * D + 4 * g;
+    const float* mi = a.mf_i + item * D + 4 * g;
+#pragma unroll
+    for (int c = 0; c < NCU; ++c) {
+      const float4 p = *reinterpret_cast<const float4*>(mu + 16 * c), q = *reinterpret_cast<const float4*>(mi + 16 * c);
+      const float4 w = *reinterpret_cast<const float4*>(swo + 16 * c + 4 * g);
+      pp = fmaf(w.x, p.x * q.x, pp); pp = fmaf(w.y, p.y * q.y, pp); pp = fmaf(w.z, p.z * q.z, pp); pp = fmaf(w.w, p.w * q.w, pp);
+    }
+    // hidden layer: accumulator r of output tile nt = Z1[row i][16 nt + 4 g + r]
+#pragma unroll
+    for (int nt = 0; nt < NT; nt += 2) {
+      f32x4m a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+      const float* w0p = Ws + (16 * nt + i) * SW + 4 * g;
+      const float* w1p = Ws + (16 * (nt + 1) + i) * SW + 4 * g;
+#pragma unroll
+      for (int c = 0; c < 2 * NCU; ++c) {
+        const float4 w0 = *reinterpret_cast<const float4*>(w0p + 16 * c), w1 = *reinterpret_cast<const float4*>(w1p + 16 * c);
+        a0 = mfma16(w0.x, x[c][0], a0); a1 = mfma16(w1.x, x[c][0], a1);
+        a0 = mfma16(w0.y, x[c][1], a0); a1 = mfma16(w1.y, x[c][1], a1);
+        a0 = mfma16(w0.z, x[c][2], a0); a1 = mfma16(w1.z, x[c][2], a1);
+        a0 = mfma16(w0.w, x[c][3], a0); a1 = mfma16(w1.w, x[c][3], a1);
+      }
+      const float4 b0 = *reinterpret_cast<const float4*>(sb1 + 16 * nt + 4 * g), b1v = *reinterpret_cast<const float4*>(sb1 + 16 * (nt + 1) + 4 * g);
+      const float4 o0 = *reinterpret_cast<const float4*>(swo + D + 16 * nt + 4 * g), o1 = *reinterpret_cast<const float4*>(swo + D + 16 * (nt + 1) + 4 * g);
+      pp = fmaf(o0.x, fmaxf(a0[0] + b0.x, 0.f), pp); pp = fmaf(o0.y, fmaxf(a0[1] + b0.y, 0.f), pp);
+      pp = fmaf(o0.z, fmaxf(a0[2] + b0.z, 0.f), pp); pp = fmaf(o0.w, fmaxf(a0[3] + b0.w, 0.f), pp);
+      pp = fmaf(o1.x, fmaxf(a1[0] + b1v.x, 0.f), pp); pp = fmaf(o1.y, fmaxf(a1[1] + b1v.y, 0.f), pp);
+      pp = fmaf(o1.z, fmaxf(a1[2] + b1v.z, 0.f), pp); pp = fmaf(o1.w, fmaxf(a1[3] + b1v.w, 0.f), pp);
+    }
+    pp += __shfl_xor(pp, 16, 64);
+    pp += __shfl_xor(pp, 32, 64);
+    if (g == 0 && valid) a.pred[n] = pp;
+  }
+}
+
+// RC_NEUMF_FWD16=0: the 64-candidate-tile kernel for the forward pass as well (A/B timing)
+static bool neumf_fwd16_enabled() {
+  static const bool on = [] {
+    const char* v = getenv("RC_NEUMF_FWD16");
+    return !(v && v[0] == '0');
+  }();
+  return on;
+}
+
+template <int D, int L1>
+static int launch_neumf_fwd16(const NeumfArgs& a, hipStream_t s) {
+  const size_t lds_bytes = ((size_t)L1 * (2 * D + 4) + L1 + D + L1) * sizeof(float);
+  auto kern = neumf_fwd16_kernel<D, L1>;
+  RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  const int64_t tiles = (a.n + 15) / 16;
+  const int per_cu = (int)((160 * 1024) / lds_bytes) >= 2 ? 2 : 1;   // (128 registers per lane: two 8-wave workgroups share a CU)
+  int64_t grid = (tiles + kFwd16Waves - 1) / kFwd16Waves;
+  if (grid > 256 * per_cu) grid = 256 * per_cu;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(grid < 1 ? 1 : grid)), dim3(64 * kFwd16Waves), lds_bytes, s, a);
+  RC_LAUNCH_CHECK();
+  return RC_OK;
+}
+
 template <int D, int L1, bool BWD, bool DROP>
 static int launch_neumf(const NeumfArgs& a, int n_wg, hipStream_t s) {
   using Cfg = NeumfCfg<D, L1>;
@@ -438,6 +542,14 @@ static int neumf_grid(int64_t n, int d, int l1) {
 
 template <bool BWD>
 static int dispatch_neumf(const NeumfArgs& a, int d, int l1, int n_wg, hipStream_t s) {
+  if (!BWD && !a.seed_dev && neumf_fwd16_enabled()) {   // forward without dropout: 16-candidate tiles
+#define RC_NF(D_, L_) \
+  if (d == D_ && l1 == L_) return launch_neumf_fwd16<D_, L_>(a, s)
+    RC_NF(32, 32); RC_NF(32, 64); RC_NF(32, 128);
+    RC_NF(64, 32); RC_NF(64, 64); RC_NF(64, 128);
+    RC_NF(128, 32); RC_NF(128, 64);
+#undef RC_NF
+  }
 #define RC_NM(D_, L_) \
   if (d == D_ && l1 == L_)                                                                 \
     return a.seed_dev ? launch_neumf<D_, L_, BWD, true>(a, n_wg, s) : launch_neumf<D_, L_, BWD, false>(a, n_wg, s)
