@@ -7,7 +7,7 @@ cp $S/prof/kt_kernel_stats.csv $P/${TAG}_kernel_stats.csv
 for w in sasrec neumf deepfm; do cp $S/prof_$w/kt_kernel_stats.csv $P/${TAG}_${w}_kernel_stats.csv; done
 cp $S/env.txt $P/${TAG}_env.txt
 cp $S/plugin_epoch.json $P/${TAG}_plugin_epoch.json
-cp $S/pmc/pmc.json $P/${TAG}_pmc.json; cp $S/pmc/pmc_summary.txt $P/${TAG}_pmc_summary.txt
+[ -f $S/pmc/pmc.json ] && { cp $S/pmc/pmc.json $P/${TAG}_pmc.json; cp $S/pmc/pmc_summary.txt $P/${TAG}_pmc_summary.txt; }
 { tail -4 $S/pytest_gpu.log; tail -1 $S/smoke.log; } > $P/${TAG}_pytest_gpu_tail.txt
-cp $S/pmc/pmc.json $P/pmc_latest.json
+[ -f $S/pmc/pmc.json ] && cp $S/pmc/pmc.json $P/pmc_latest.json
 ls $P | grep "^${TAG}_" | wc -l

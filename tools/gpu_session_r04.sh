@@ -18,12 +18,14 @@ timeout 300 python bench.py --steps 100 --warmup 10 --batch 8192 --no-cpu-baseli
 timeout 300 python bench.py --steps 300 --warmup 20 --batch 256 --no-cpu-baseline > $OUT/bench_b256.json 2> $OUT/bench_b256.err
 timeout 400 python bench.py --workload neumf > $OUT/bench_neumf.json 2> $OUT/bench_neumf.err
 timeout 600 python bench.py --workload neumf --items 100000001 --users 10000001 --steps 30 --warmup 5 > $OUT/bench_neumf_100M.json 2> $OUT/bench_neumf_100M.err
+RC_NEUMF_FWD16=0 timeout 300 python bench.py --workload neumf --no-cpu-baseline > $OUT/bench_neumf_fwd64.json 2> $OUT/bench_neumf_fwd64.err
 timeout 400 python bench.py --workload sasrec > $OUT/bench_sasrec.json 2> $OUT/bench_sasrec.err
 timeout 300 python bench.py --workload sasrec --batch 256 --steps 200 --no-cpu-baseline > $OUT/bench_sasrec_b256.json 2> $OUT/bench_sasrec_b256.err
 timeout 300 python bench.py --workload sasrec --opt Adam --no-cpu-baseline > $OUT/bench_sasrec_adam.json 2> $OUT/bench_sasrec_adam.err
 RC_SAS_GRAPH=0 timeout 300 python bench.py --workload sasrec --no-cpu-baseline > $OUT/bench_sasrec_eager.json 2> $OUT/bench_sasrec_eager.err
 RC_SAS_LAST_ROW=0 timeout 300 python bench.py --workload sasrec --no-cpu-baseline > $OUT/bench_sasrec_allrows.json 2> $OUT/bench_sasrec_allrows.err
 timeout 300 python bench.py --workload sasrec --layers 2 --no-cpu-baseline > $OUT/bench_sasrec_2layers.json 2> $OUT/bench_sasrec_2layers.err
+timeout 300 python bench.py --workload sasrec --hist 100 --no-cpu-baseline > $OUT/bench_sasrec_L100.json 2> $OUT/bench_sasrec_L100.err
 timeout 400 python bench.py --workload deepfm > $OUT/bench_deepfm.json 2> $OUT/bench_deepfm.err
 timeout 300 python bench.py --workload deepfm --batch 16384 --steps 50 --warmup 5 --no-cpu-baseline > $OUT/bench_deepfm_b16384.json 2> $OUT/bench_deepfm_b16384.err
 timeout 300 python bench.py --workload deepfm --batch 131072 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_deepfm_b131072.json 2> $OUT/bench_deepfm_b131072.err
@@ -39,10 +41,10 @@ timeout 300 rocprofv3 --kernel-trace --stats -d $R/$OUT/prof_deepfm -o kt --outp
   python $R/bench.py --workload deepfm --batch 131072 --steps 20 --warmup 5 --no-cpu-baseline --no-roofline > $R/$OUT/prof_deepfm.log 2>&1
 cd $R
 find $OUT -name "*kernel_trace.csv" -size +20M -delete 2>/dev/null
-bash tools/pmc_collect.sh $TAG/pmc > /dev/null 2>&1
+[ -n "$SKIP_PMC" ] || bash tools/pmc_collect.sh $TAG/pmc > /dev/null 2>&1
 ls -laR $OUT > $OUT/ls.txt 2>&1
 tail -5 $OUT/pytest_gpu.log; tail -2 $OUT/smoke.log
-for f in bench bench_adam bench_b8192 bench_b256 bench_neumf bench_neumf_100M bench_sasrec bench_sasrec_b256 bench_sasrec_adam bench_sasrec_eager bench_sasrec_allrows bench_sasrec_2layers bench_deepfm bench_deepfm_b16384 bench_deepfm_b131072; do
+for f in bench bench_adam bench_b8192 bench_b256 bench_neumf bench_neumf_100M bench_neumf_fwd64 bench_sasrec_L100 bench_sasrec bench_sasrec_b256 bench_sasrec_adam bench_sasrec_eager bench_sasrec_allrows bench_sasrec_2layers bench_deepfm bench_deepfm_b16384 bench_deepfm_b131072; do
   python - <<PY
 import json
 try:
