@@ -213,6 +213,27 @@ def test_pipeline_host_side_pieces(corpus, ctx_corpus, tmp_path):
     assert int(user["u_age_c"][3]) == ctx_corpus.user_features[3]["u_age_c"]
 
 
+def test_sasrec_trainer_graph_mode_host_rules():
+    """SasrecTrainer(graph=True): host-side rules that need no GPU -- Adam keeps its step count in device memory only with
+    row-wise updates, and only batch shapes whose item update takes the one-wave-per-row route use it (others run eagerly on
+    the host's step count)"""
+    import torch
+    from rechorus_amd import engine
+    d, L, n_items = 64, 50, 1000
+    mk = lambda *s: torch.zeros(s)
+    lay = {k: (mk(d, d) if k.startswith("W") else mk(d)) for k in engine.SAS_LAYER_KEYS}
+    P = {"item_emb": mk(n_items, d), "pos_emb": mk(L + 1, d), "layers": [lay]}
+    with pytest.raises(ValueError):
+        engine.SasrecTrainer(P, 4, opt="Adam", rowwise=False, graph=True)
+    tr = engine.SasrecTrainer(P, 4, opt="Adam", rowwise=True, graph=True)
+    assert tr._step_dev is not None and int(tr._step_dev) == 0
+    big = (torch.zeros((512, L), dtype=torch.int64), torch.zeros((512, 100), dtype=torch.int64))    # 76,800 occurrences over 1,000 rows
+    small = (torch.zeros((4, L), dtype=torch.int64), torch.zeros((4, 2), dtype=torch.int64))         # 208 occurrences: head-list route
+    assert tr._dev_step_route(*big) and not tr._dev_step_route(*small)
+    sgd = engine.SasrecTrainer(P, 4, opt="SGD", rowwise=True, graph=True)
+    assert sgd._step_dev is None and not sgd._dev_step_route(*big)
+
+
 def test_sasrec_kernel_choice_by_batch_shape(monkeypatch):
     """engine._sasrec_impl: per-sequence kernels while the batch is one round of resident workgroups in the 32-row
     geometry, batch-level kernels beyond; explicit choice and the RC_SASREC_IMPL override win"""
