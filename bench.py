@@ -437,6 +437,22 @@ def model_roofline(args, trainer, batches, engine):
         n_state = {"SGD": 0, "Adagrad": 1, "Adam": 2}[args.opt]
         upd_bytes = 2 * (2 * B * C) * d * 4 + 2 * (1 + n_state) * 2 * (ui + uu) * d * 4 + 2 * 8 * B * C
         gather_bytes = {"head_fwd": (2 * B * C + 2 * B * C) * d * 4}
+        if "fused_step" in ph:
+            # rc_neumf_train_step (csrc/neumf_step.hip): ALGORITHMIC work of one fit iteration's head -- the hidden layer, dh0 and
+            # dW1 once each (the kernel's recomputation of the hidden layer in its second pass is not counted), the user half per
+            # tuple; bytes: every gathered row once, single-occurrence item rows written back once, one gradient row per tuple
+            # and user table, gradient rows of the multi-occurrence positions, ids, loss
+            cnt = [torch.unique(i, return_counts=True)[1] for _, i in batches]
+            single = float(np.mean([int((c == 1).sum()) for c in cnt]))
+            multi_occ = float(np.mean([int(c[c > 1].sum()) for c in cnt]))
+            multi_rows = float(np.mean([int((c > 1).sum()) for c in cnt]))
+            flops = {"fused_step": (B * C + B) * 6.0 * d * l1 + B * C * (6.0 * d + 4 * l1)}
+            fused_bytes = (2 * B * C + 2 * B) * d * 4 + 2 * (1 + 2 * n_state) * single * d * 4 + 2 * B * d * 4 + 2 * multi_occ * d * 4 + \
+                8 * (B * C + B) + 4 * B + 4 * B * C
+            upd_bytes = 2 * (multi_occ + B) * d * 4 + 2 * (1 + n_state) * 2 * (multi_rows + uu) * d * 4 + 2 * 4 * (B * C + B)
+            gather_bytes = {}
+            out["fused_step_algorithmic"] = {"flops": flops["fused_step"], "hbm_bytes": fused_bytes, "single_item_rows": single,
+                                             "multi_item_rows": multi_rows, "multi_item_occurrences": multi_occ}
     else:
         L, nl = args.hist, args.layers
         R = float(np.mean([int(l.sum()) for _, l, _ in batches]))        # valid history rows of a batch
@@ -469,7 +485,19 @@ def model_roofline(args, trainer, batches, engine):
     compute = {k: ph[k] for k in flops if k in ph}
     dom = max(list(compute) + ["table_update"], key=lambda k: ph.get(k, 0.0))
     hbm_bytes = dict(enc_bytes if args.workload == "sasrec" else {}, table_update=upd_bytes)
-    if dom in hbm_bytes:
+    if dom == "fused_step":
+        # the one kernel that does both: rated against the roof it is nearer to, the other fraction beside it
+        t = ph[dom] * 1e-3
+        f_mfma, f_hbm = flops[dom] / t / 1e12 / F32_MFMA_PEAK_TFLOPS, fused_bytes / t / 1e9 / HBM_PEAK_GBPS
+        if f_hbm >= f_mfma:
+            out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": fused_bytes / t / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                               "frac": f_hbm, "traffic": None, "algorithmic_bytes_per_launch": fused_bytes, "avg_ms": ph[dom],
+                               "frac_of_mfma_peak": f_mfma}
+        else:
+            out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": flops[dom] / t / 1e12, "peak": F32_MFMA_PEAK_TFLOPS,
+                               "unit": "TFLOP/s", "frac": f_mfma, "traffic": None, "algorithmic_flops_per_launch": flops[dom],
+                               "avg_ms": ph[dom], "frac_of_hbm_peak": f_hbm}
+    elif dom in hbm_bytes:
         ach = hbm_bytes[dom] / (ph[dom] * 1e-3) / 1e9
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                            "frac": ach / HBM_PEAK_GBPS, "traffic": None, "algorithmic_bytes_per_launch": hbm_bytes[dom],

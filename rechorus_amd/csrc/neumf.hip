@@ -405,6 +405,21 @@ __global__ __launch_bounds__(kBlock) void neumf_reduce_partials_kernel(ReduceArg
   }
 }
 
+// the three partial arrays of one backward call (also neumf_step.hip's) -> dW1, db1, dw_out
+int neumf_reduce_partials(const float* pW1, const float* pb1, const float* pwout, float* dW1, float* db1, float* dw_out, int cW, int cb,
+                          int co, int n_wg, hipStream_t s) {
+  ReduceArgs r;
+  r.p[0] = pW1; r.p[1] = pb1; r.p[2] = pwout;
+  r.out[0] = dW1; r.out[1] = db1; r.out[2] = dw_out;
+  r.count[0] = cW; r.count[1] = cb; r.count[2] = co;
+  r.first_block[0] = 0;
+  for (int k = 0; k < 3; ++k) r.first_block[k + 1] = r.first_block[k] + (r.count[k] + 63) / 64;
+  r.n_wg = n_wg;
+  hipLaunchKernelGGL(neumf_reduce_partials_kernel, dim3(r.first_block[3]), dim3(kBlock), 0, s, r);
+  RC_LAUNCH_CHECK();
+  return RC_OK;
+}
+
 // ---- forward on 16-candidate tiles (no dropout) -----------------------------------------------------------------------------------------
 // The forward pass alone is bound by its gathers (4 table rows of d floats per candidate: 671 MB at the config-4 shape), not by
 // the 11 GFLOP of the hidden layer: neumf_kernel<.., false, ..> stages every 64-candidate tile through LDS behind barriers with ONE
@@ -654,14 +669,5 @@ extern "C" int rc_neumf_bwd_dropout(const float* mf_u, const float* mf_i, const 
   a.pb1 = p + (size_t)n_wg * cW;
   a.pwout = a.pb1 + (size_t)n_wg * cb;
   RC_TRY(dispatch_neumf<true>(a, d, l1, n_wg, s));
-  ReduceArgs r;
-  r.p[0] = a.pW1; r.p[1] = a.pb1; r.p[2] = a.pwout;
-  r.out[0] = dW1; r.out[1] = db1; r.out[2] = dw_out;
-  r.count[0] = cW; r.count[1] = cb; r.count[2] = co;
-  r.first_block[0] = 0;
-  for (int k = 0; k < 3; ++k) r.first_block[k + 1] = r.first_block[k] + (r.count[k] + 63) / 64;
-  r.n_wg = n_wg;
-  hipLaunchKernelGGL(neumf_reduce_partials_kernel, dim3(r.first_block[3]), dim3(kBlock), 0, s, r);
-  RC_LAUNCH_CHECK();
-  return RC_OK;
+  return neumf_reduce_partials(a.pW1, a.pb1, a.pwout, dW1, db1, dw_out, cW, cb, co, n_wg, s);
 }

@@ -1,0 +1,591 @@
+// neumf_step.hip -- one BaseRunner.fit iteration of the NeuMF head in ONE kernel: forward, BPR loss, backward and the
+// optimizer update of every table row that only this batch position touches.
+//
+// Reference: models/general/NeuMF.py:56-76 (forward), models/BaseModel.py:182-185 (loss), loss.backward() +
+// optimizer.step() of helpers/BaseRunner.py:193-206.  What the three-kernel step (neumf.hip: forward kernel -> loss
+// kernel -> backward kernel) pays for and this one does not:
+//   * the backward re-gathers all four table rows of every candidate and writes four per-occurrence gradient rows
+//     ([B C, d] x 4 = 0.67 GB at the config-4 shape) that the table updates read back;
+//   * the user rows and the user half of the hidden layer are the same for the C candidates of a tuple
+//     (NeuMF.py:61 tiles the user ids): W1 [mlp_u ; mlp_i] = W1u mlp_u + W1i mlp_i, so W1u mlp_u, W1u^T sum_c dz_c and
+//     dW1u += (sum_c dz_c) mlp_u^T are per-TUPLE products -- 0.6 x the forward FLOPs, 0.45 x the backward's.
+//
+// Layout.  A wave owns 16 TUPLES: MFMA row i <-> tuple i, and the candidate loop c = 0 .. C-1 walks candidate c of all
+// sixteen, so a lane (i, g) meets every prediction of its tuple: the BPR loss and dL/dpred are computed in registers.
+// v_mfma_f32_16x16x4_f32 throughout (exact fp32 FMA chains); operands as in neumf_fwd16_kernel: the 16-byte slice a lane
+// loads from a table row, (row i, columns 16 c + 4 g ..), IS the B operand of Z^T = W1 h0^T, W1 waits in LDS.
+//   pass 1   per c: gather mlp_i / mf_i rows, z = Zu + W1i hi, pred -> LDS strip [C][16] of the wave
+//   loss     per lane over its tuple's C predictions -> dL/dpred back into the strip
+//   pass 2   per c: gather again (L2 / MALL: the wave touched the rows microseconds ago), recompute z, dz,
+//            dh0 = W1i^T dz lands in the SAME lane layout as the gathered row, so a single-occurrence row is updated in
+//            place from registers (opt_row4: SGD / Adam / Adagrad) and only multi-occurrence rows write a gradient row
+//            (to the per-occurrence arrays the bucket plan's pair update consumes; singleton / multi from a bitmap over
+//            item ids that a 10 us marking kernel fills with integer atomics -- order-free, deterministic);
+//            dW1i += dz^T hi contracts over CANDIDATES: dz and hi cross to "candidate in the K index" through a
+//            wave-private LDS strip (ds in-order per wave: no barrier), accumulators 64 x 128 per wave (AGPRs);
+//   tuple    dhu = W1u^T sum_c dz_c, d mf_u = w_mf * sum_c g_c mf_i: ONE gradient row per tuple and table (the plan's
+//            user side is per tuple already); dW1u: the four waves exchange (sum dz, mlp_u) through LDS and each owns
+//            a quarter of the 64 x 128 outputs (two workgroup barriers per 64 tuples -- the only ones in the loop).
+// One wave per SIMD (512 registers: 160 accumulators + the rows of two candidates in flight); the next candidate's
+// mlp_i rows are requested before the current one's MFMAs (1.2 K MFMA cycles per candidate cover the gather).
+// Dense gradients leave as per-workgroup partials, summed in fixed order by neumf_reduce_partials_kernel.
+#include "bpr_math.hpp"
+#include "common.hpp"
+#include "opt_math.hpp"
+
+namespace rc {
+
+typedef float f32x4s __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4s mma16(float a, float b, f32x4s c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+struct NeumfStepArgs {
+  float* mf_u;
+  float* mf_i;
+  float* mlp_u;
+  float* mlp_i;
+  float* m_mf_i;   // optimizer state of the item tables (in-place singleton updates); null where the optimizer has none
+  float* v_mf_i;
+  float* m_mlp_i;
+  float* v_mlp_i;
+  const float* W1;
+  const float* b1;
+  const float* w_out;
+  const int64_t* uid;
+  const int64_t* iid;
+  int B, C;
+  float inv_b;
+  const uint32_t* multi;   // bit (id & 31) of word id >> 5: item row id occurs at least twice in the batch
+  float* loss_vec;         // [B]
+  float* pred;             // [B, C] or null
+  float* g_mf_i;           // [B C, D] gradient rows of multi-occurrence item rows (other positions are not written)
+  float* g_mlp_i;
+  float* gu_mf;            // [B, D] per-tuple gradient rows of the user tables
+  float* gu_mlp;
+  float* pW1;              // per-workgroup partials [grid][L1 2D], [grid][L1], [grid][D + L1]
+  float* pb1;
+  float* pwout;
+  OptScalars opt;
+};
+
+template <int D, int L1>
+struct StepCfg {
+  static constexpr int K0 = 2 * D, SW = K0 + 4, NCU = D / 16, NT = L1 / 16;
+  static constexpr int SZ = L1 + 16, SH = D + 16;          // strides of the transposition strips: 16 (mod 32) floats, so the four
+                                                           // candidates a K step reads sit in four different 16-bank groups
+  static constexpr int NTU = NT * NCU / 4;                 // dW1u output tiles per wave
+  static constexpr int kFixedFloats = L1 * SW + L1 + (D + L1) + 4 * (2 * L1 + D);
+  static constexpr int kWaveFloats = 16 * SZ + 16 * SH;    // + 16 C for the prediction strip
+  static_assert(NT * NCU % 4 == 0, "dW1u tiles are dealt to four waves");
+};
+
+template <int N>
+__device__ __forceinline__ void load_row_slices(float (&x)[N][4], const float* p) {
+#pragma unroll
+  for (int c = 0; c < N; ++c) {
+    const float4 v = *reinterpret_cast<const float4*>(p + 16 * c);
+    x[c][0] = v.x; x[c][1] = v.y; x[c][2] = v.z; x[c][3] = v.w;
+  }
+}
+
+template <int D, int L1, int MODE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void neumf_step_kernel(NeumfStepArgs a) {
+  using Cfg = StepCfg<D, L1>;
+  constexpr int K0 = Cfg::K0, SW = Cfg::SW, NCU = Cfg::NCU, NT = Cfg::NT, SZ = Cfg::SZ, SH = Cfg::SH, NTU = Cfg::NTU;
+  extern __shared__ float lds[];
+  float* Ws = lds;                       // [L1][SW]  W1, user half in columns 0 .. D-1
+  float* sb1 = Ws + L1 * SW;             // [L1]
+  float* swo = sb1 + L1;                 // [D + L1]  w_mf | w_h
+  float* wred = swo + (D + L1);          // [4 waves][db1 L1 | dw_h L1 | dw_mf D]
+  float* tb = wred + 4 * (2 * L1 + D);   // per wave: Tz [16][SZ], Th [16][SH], sp [C][16]
+  const int C = a.C;
+  const int per_wave = Cfg::kWaveFloats + 16 * C;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
+  float* Tz = tb + wave * per_wave;
+  float* Th = Tz + 16 * SZ;
+  float* sp = Th + 16 * SH;
+  float* wr = wred + wave * (2 * L1 + D);
+
+  for (int k = threadIdx.x; k < L1 * K0 / 4; k += 256)
+    *reinterpret_cast<float4*>(Ws + (k / (K0 / 4)) * SW + 4 * (k % (K0 / 4))) = reinterpret_cast<const float4*>(a.W1)[k];
+  for (int k = threadIdx.x; k < L1; k += 256) sb1[k] = a.b1[k];
+  for (int k = threadIdx.x; k < D + L1; k += 256) swo[k] = a.w_out[k];
+  for (int k = threadIdx.x; k < 4 * (2 * L1 + D); k += 256) wred[k] = 0.f;
+  __syncthreads();
+
+  f32x4s accW[NT][NCU];   // dW1[:, D:] of this wave's tuples: tile (ft, kt), register r <-> W1[16 ft + 4 g + r][D + 16 kt + i]
+  f32x4s accU[NTU];       // dW1[:, :D] tiles wave + 4 q of the workgroup's tuples
+#pragma unroll
+  for (int ft = 0; ft < NT; ++ft)
+#pragma unroll
+    for (int kt = 0; kt < NCU; ++kt) accW[ft][kt] = f32x4s{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int q = 0; q < NTU; ++q) accU[q] = f32x4s{0.f, 0.f, 0.f, 0.f};
+
+  const int64_t n_tiles = ((int64_t)a.B + 15) / 16;
+  const int64_t n_rounds = (n_tiles + 3) / 4;
+  for (int64_t round = blockIdx.x; round < n_rounds; round += gridDim.x) {
+    asm volatile("" ::: "memory");   // LDS operands are re-read per use (hoisted, the weights alone are 128 registers)
+    const int64_t tup = (round * 4 + wave) * 16 + i;
+    const bool valid = tup < a.B;    // a tail lane works on the last tuple with dL/dpred = 0 and stores nothing
+    const int64_t tt = valid ? tup : (int64_t)a.B - 1;
+    const int64_t u = a.uid[tt];
+    const int64_t* ip = a.iid + tt * C;
+    const float* hup = a.mlp_u + u * D + 4 * g;
+    const float* mup = a.mf_u + u * D + 4 * g;
+
+    // ---- per tuple: Zu = W1u mlp_u (accumulator r of tile nt <-> hidden feature 16 nt + 4 g + r), w_mf * mf_u ----------
+    f32x4s Zu[NT];
+    {
+      float hu[NCU][4];
+      load_row_slices<NCU>(hu, hup);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        f32x4s z = {0.f, 0.f, 0.f, 0.f};
+        const float* wp = Ws + (16 * nt + i) * SW + 4 * g;
+#pragma unroll
+        for (int cc = 0; cc < NCU; ++cc) {
+          const float4 w = *reinterpret_cast<const float4*>(wp + 16 * cc);
+          z = mma16(w.x, hu[cc][0], z);
+          z = mma16(w.y, hu[cc][1], z);
+          z = mma16(w.z, hu[cc][2], z);
+          z = mma16(w.w, hu[cc][3], z);
+        }
+        Zu[nt] = z;
+      }
+    }
+    float muw[NCU][4];
+    load_row_slices<NCU>(muw, mup);
+#pragma unroll
+    for (int cc = 0; cc < NCU; ++cc) {
+      const float4 w = *reinterpret_cast<const float4*>(swo + 16 * cc + 4 * g);
+      muw[cc][0] *= w.x; muw[cc][1] *= w.y; muw[cc][2] *= w.z; muw[cc][3] *= w.w;
+    }
+
+    // ---- pass 1: predictions --------------------------------------------------------------------------------------
+    float hn[NCU][4];
+    int64_t item = ip[0];
+    load_row_slices<NCU>(hn, a.mlp_i + item * D + 4 * g);
+    for (int c = 0; c < C; ++c) {
+      asm volatile("" ::: "memory");
+      float hx[NCU][4], mx[NCU][4];
+#pragma unroll
+      for (int cc = 0; cc < NCU; ++cc)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) hx[cc][e] = hn[cc][e];
+      load_row_slices<NCU>(mx, a.mf_i + item * D + 4 * g);
+      if (c + 1 < C) {   // the next candidate's mlp rows travel during this one's MFMAs
+        item = ip[c + 1];
+        load_row_slices<NCU>(hn, a.mlp_i + item * D + 4 * g);
+      }
+      float pp = 0.f;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        f32x4s z = Zu[nt];
+        const float* wp = Ws + (16 * nt + i) * SW + D + 4 * g;
+#pragma unroll
+        for (int cc = 0; cc < NCU; ++cc) {
+          const float4 w = *reinterpret_cast<const float4*>(wp + 16 * cc);
+          z = mma16(w.x, hx[cc][0], z);
+          z = mma16(w.y, hx[cc][1], z);
+          z = mma16(w.z, hx[cc][2], z);
+          z = mma16(w.w, hx[cc][3], z);
+        }
+        const float4 b = *reinterpret_cast<const float4*>(sb1 + 16 * nt + 4 * g);
+        const float4 o = *reinterpret_cast<const float4*>(swo + D + 16 * nt + 4 * g);
+        pp = fmaf(o.x, fmaxf(z[0] + b.x, 0.f), pp);
+        pp = fmaf(o.y, fmaxf(z[1] + b.y, 0.f), pp);
+        pp = fmaf(o.z, fmaxf(z[2] + b.z, 0.f), pp);
+        pp = fmaf(o.w, fmaxf(z[3] + b.w, 0.f), pp);
+      }
+#pragma unroll
+      for (int cc = 0; cc < NCU; ++cc)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pp = fmaf(muw[cc][e], mx[cc][e], pp);
+      pp += __shfl_xor(pp, 16, 64);
+      pp += __shfl_xor(pp, 32, 64);
+      if (g == 0) {
+        sp[c * 16 + i] = pp;
+        if (a.pred && valid) a.pred[tup * C + c] = pp;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- GeneralModel.loss on the tuple's C predictions (every lane of row i computes the same values) ----------------
+    {
+      const float pos = sp[i];
+      float mxv = -INFINITY;
+      for (int c = 1; c < C; ++c) mxv = fmaxf(mxv, sp[c * 16 + i]);
+      float se = 0.f;
+      for (int c = 1; c < C; ++c) se += expf(sp[c * 16 + i] - mxv);
+      const float inv_se = 1.0f / se;
+      float P = 0.f, A = 0.f;
+      for (int c = 1; c < C; ++c) {
+        const float x = sp[c * 16 + i];
+        const float w = expf(x - mxv) * inv_se;
+        const float s = sigmoidf_(pos - x);
+        P = fmaf(w, s, P);
+        A = fmaf(w, s * (1.0f - s), A);
+      }
+      const BprRow br = bpr_row(P, a.inv_b);
+      if (g == 0 && valid) a.loss_vec[tup] = br.loss;
+      const float dl = valid ? br.dLdP : 0.f;
+      for (int c = 1; c < C; ++c) {
+        const float x = sp[c * 16 + i];
+        const float w = expf(x - mxv) * inv_se;
+        const float s = sigmoidf_(pos - x);
+        const float gc = dl * bpr_dP_dneg(w, s, P);
+        if (g == 0) sp[c * 16 + i] = gc;
+      }
+      if (g == 0) sp[i] = dl * A;
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- pass 2: backward and the row updates -----------------------------------------------------------------------
+    f32x4s dzs[NT];      // sum_c dz_c: db1, and the tuple-level products of the user half
+    float dwh[NT][4];    // sum_c g_c h1_c
+    float S[NCU][4];     // sum_c g_c mf_i[c]
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      dzs[nt] = f32x4s{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dwh[nt][r] = 0.f;
+    }
+#pragma unroll
+    for (int cc = 0; cc < NCU; ++cc)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) S[cc][e] = 0.f;
+    item = ip[0];
+    load_row_slices<NCU>(hn, a.mlp_i + item * D + 4 * g);
+    for (int c = 0; c < C; ++c) {
+      asm volatile("" ::: "memory");
+      float hx[NCU][4], mx[NCU][4];
+#pragma unroll
+      for (int cc = 0; cc < NCU; ++cc)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) hx[cc][e] = hn[cc][e];
+      const int64_t item_c = item;
+      load_row_slices<NCU>(mx, a.mf_i + item_c * D + 4 * g);
+      const uint32_t mword = a.multi[item_c >> 5];
+      if (c + 1 < C) {
+        item = ip[c + 1];
+        load_row_slices<NCU>(hn, a.mlp_i + item * D + 4 * g);
+      }
+      const float gc = sp[c * 16 + i];
+      const bool single = ((mword >> (item_c & 31)) & 1u) == 0u;
+      const int64_t n = tup * C + c;
+
+      // hidden layer again, dz = g w_h relu'(z)
+      f32x4s dz[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        f32x4s z = Zu[nt];
+        const float* wp = Ws + (16 * nt + i) * SW + D + 4 * g;
+#pragma unroll
+        for (int cc = 0; cc < NCU; ++cc) {
+          const float4 w = *reinterpret_cast<const float4*>(wp + 16 * cc);
+          z = mma16(w.x, hx[cc][0], z);
+          z = mma16(w.y, hx[cc][1], z);
+          z = mma16(w.z, hx[cc][2], z);
+          z = mma16(w.w, hx[cc][3], z);
+        }
+        const float4 b = *reinterpret_cast<const float4*>(sb1 + 16 * nt + 4 * g);
+        const float4 o = *reinterpret_cast<const float4*>(swo + D + 16 * nt + 4 * g);
+        const float bb[4] = {b.x, b.y, b.z, b.w}, oo[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float zz = z[r] + bb[r];
+          const float dv = zz > 0.f ? gc * oo[r] : 0.f;
+          z[r] = dv;
+          dzs[nt][r] += dv;
+          dwh[nt][r] = fmaf(gc, fmaxf(zz, 0.f), dwh[nt][r]);
+        }
+        dz[nt] = z;
+        *reinterpret_cast<float4*>(Tz + i * SZ + 16 * nt + 4 * g) = make_float4(z[0], z[1], z[2], z[3]);
+      }
+#pragma unroll
+      for (int cc = 0; cc < NCU; ++cc)
+        *reinterpret_cast<float4*>(Th + i * SH + 16 * cc + 4 * g) = make_float4(hx[cc][0], hx[cc][1], hx[cc][2], hx[cc][3]);
+
+      // d mlp_i = W1i^T dz: MFMA (nt, r) contracts the features 16 nt + 4 g' + r; register r' of tile kt <-> column 16 kt + 4 g + r',
+      // the slice this lane gathered -- update in place or hand the gradient row to the plan's update
+#pragma unroll
+      for (int kt = 0; kt < NCU; ++kt) {
+        f32x4s acc = {0.f, 0.f, 0.f, 0.f};
+        const float* wp = Ws + (4 * g) * SW + D + 16 * kt + i;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc = mma16(wp[(16 * nt + r) * SW], dz[nt][r], acc);
+        const float4 gr = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        if (valid) {
+          if (single)
+            opt_row4<MODE>(a.opt, a.mlp_i, a.m_mlp_i, a.v_mlp_i, (size_t)(item_c * D + 16 * kt + 4 * g) / 4,
+                           make_float4(hx[kt][0], hx[kt][1], hx[kt][2], hx[kt][3]), gr);
+          else
+            *reinterpret_cast<float4*>(a.g_mlp_i + n * D + 16 * kt + 4 * g) = gr;
+        }
+      }
+      // GMF branch: d mf_i = g w_mf mf_u, S += g mf_i
+#pragma unroll
+      for (int cc = 0; cc < NCU; ++cc) {
+        const float4 gr = make_float4(gc * muw[cc][0], gc * muw[cc][1], gc * muw[cc][2], gc * muw[cc][3]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) S[cc][e] = fmaf(gc, mx[cc][e], S[cc][e]);
+        if (valid) {
+          if (single)
+            opt_row4<MODE>(a.opt, a.mf_i, a.m_mf_i, a.v_mf_i, (size_t)(item_c * D + 16 * cc + 4 * g) / 4,
+                           make_float4(mx[cc][0], mx[cc][1], mx[cc][2], mx[cc][3]), gr);
+          else
+            *reinterpret_cast<float4*>(a.g_mf_i + n * D + 16 * cc + 4 * g) = gr;
+        }
+      }
+      // dW1i += dz^T hi over the 16 candidates of this step (K step s: candidates 4 s + g')
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        float av[NT], bv[NCU];
+#pragma unroll
+        for (int ft = 0; ft < NT; ++ft) av[ft] = Tz[(4 * s + g) * SZ + 16 * ft + i];
+#pragma unroll
+        for (int kt = 0; kt < NCU; ++kt) bv[kt] = Th[(4 * s + g) * SH + 16 * kt + i];
+#pragma unroll
+        for (int ft = 0; ft < NT; ++ft)
+#pragma unroll
+          for (int kt = 0; kt < NCU; ++kt) accW[ft][kt] = mma16(av[ft], bv[kt], accW[ft][kt]);
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+
+    // ---- per tuple: user-row gradients, per-wave sums of db1 / dw_h / dw_mf, dW1u -----------------------------------------
+    {
+      float hu[NCU][4];
+      load_row_slices<NCU>(hu, hup);
+      float mu[NCU][4];
+      load_row_slices<NCU>(mu, mup);
+#pragma unroll
+      for (int kt = 0; kt < NCU; ++kt) {
+        f32x4s acc = {0.f, 0.f, 0.f, 0.f};
+        const float* wp = Ws + (4 * g) * SW + 16 * kt + i;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc = mma16(wp[(16 * nt + r) * SW], dzs[nt][r], acc);
+        if (valid) *reinterpret_cast<float4*>(a.gu_mlp + tup * D + 16 * kt + 4 * g) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+      }
+#pragma unroll
+      for (int cc = 0; cc < NCU; ++cc) {
+        const float4 w = *reinterpret_cast<const float4*>(swo + 16 * cc + 4 * g);
+        if (valid)
+          *reinterpret_cast<float4*>(a.gu_mf + tup * D + 16 * cc + 4 * g) =
+              make_float4(w.x * S[cc][0], w.y * S[cc][1], w.z * S[cc][2], w.w * S[cc][3]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {   // dw_mf[k] += sum over the wave's tuples of mf_u[k] S[k]
+          const float t = row_allreduce_sum<16>(mu[cc][e] * S[cc][e]);
+          if (i == 0) wr[2 * L1 + 16 * cc + 4 * g + e] += t;
+        }
+      }
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float x = row_allreduce_sum<16>(dzs[nt][r]);
+          const float y = row_allreduce_sum<16>(dwh[nt][r]);
+          if (i == 0) {
+            wr[16 * nt + 4 * g + r] += x;
+            wr[L1 + 16 * nt + 4 * g + r] += y;
+          }
+        }
+      // dW1u += (sum_c dz_c)^T mlp_u over the workgroup's 64 tuples: strips of all four waves, a quarter of the tiles each
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        *reinterpret_cast<float4*>(Tz + i * SZ + 16 * nt + 4 * g) = make_float4(dzs[nt][0], dzs[nt][1], dzs[nt][2], dzs[nt][3]);
+#pragma unroll
+      for (int cc = 0; cc < NCU; ++cc)
+        *reinterpret_cast<float4*>(Th + i * SH + 16 * cc + 4 * g) = make_float4(hu[cc][0], hu[cc][1], hu[cc][2], hu[cc][3]);
+    }
+    __syncthreads();
+    for (int w2 = 0; w2 < 4; ++w2) {
+      const float* Tz2 = tb + w2 * per_wave;
+      const float* Th2 = Tz2 + 16 * SZ;
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int q = 0; q < NTU; ++q) {
+          const int tile = wave + 4 * q, ft = tile % NT, kt = tile / NT;
+          accU[q] = mma16(Tz2[(4 * s + g) * SZ + 16 * ft + i], Th2[(4 * s + g) * SH + 16 * kt + i], accU[q]);
+        }
+    }
+    __syncthreads();
+  }
+
+  // ---- per-workgroup partials of the dense gradients --------------------------------------------------------------
+  const size_t wg = blockIdx.x;
+  float* pw = a.pW1 + wg * (size_t)(L1 * K0);
+#pragma unroll
+  for (int q = 0; q < NTU; ++q) {
+    const int tile = wave + 4 * q, ft = tile % NT, kt = tile / NT;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) pw[(size_t)(16 * ft + 4 * g + r) * K0 + 16 * kt + i] = accU[q][r];
+  }
+  // the item half: the four waves' accumulators summed in wave order through LDS (W1 is not needed any more)
+  float* red = Ws;   // [L1][D]
+  for (int w2 = 0; w2 < 4; ++w2) {
+    if (wave == w2) {
+#pragma unroll
+      for (int ft = 0; ft < NT; ++ft)
+#pragma unroll
+        for (int kt = 0; kt < NCU; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float* p = red + (16 * ft + 4 * g + r) * D + 16 * kt + i;
+            *p = (w2 == 0 ? 0.f : *p) + accW[ft][kt][r];
+          }
+    }
+    __syncthreads();
+  }
+  for (int k = threadIdx.x; k < L1 * D; k += 256) pw[(size_t)(k / D) * K0 + D + (k % D)] = red[k];
+  for (int k = threadIdx.x; k < 2 * L1 + D; k += 256) {
+    const float t = ((wred[k] + wred[(2 * L1 + D) + k]) + wred[2 * (2 * L1 + D) + k]) + wred[3 * (2 * L1 + D) + k];
+    if (k < L1) a.pb1[wg * L1 + k] = t;
+    else if (k < 2 * L1) a.pwout[wg * (D + L1) + D + (k - L1)] = t;
+    else a.pwout[wg * (D + L1) + (k - 2 * L1)] = t;
+  }
+}
+
+// ---- singleton / multi-occurrence classification of the batch's item ids ------------------------------------------------
+// seen1 / seen2: bitmaps over item ids, all zero between steps.  bit(seen2, id) = 1 iff id occurs at least twice: the
+// second and every later occurrence finds the bit of the first in seen1.  Integer atomics, order-free: the final state
+// does not depend on the schedule.  neumf_unmark_kernel restores the zeros (words the batch touched only).
+__global__ __launch_bounds__(256) void neumf_mark_kernel(const int64_t* __restrict__ ids, int64_t n, uint32_t* seen1, uint32_t* seen2) {
+  const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= n) return;
+  const int64_t id = ids[k];
+  const uint32_t bit = 1u << (id & 31);
+  const uint32_t old = atomicOr(seen1 + (id >> 5), bit);
+  if (old & bit) atomicOr(seen2 + (id >> 5), bit);
+}
+
+__global__ __launch_bounds__(256) void neumf_unmark_kernel(const int64_t* __restrict__ ids, int64_t n, uint32_t* seen1, uint32_t* seen2) {
+  const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= n) return;
+  const int64_t id = ids[k];
+  seen1[id >> 5] = 0u;
+  seen2[id >> 5] = 0u;
+}
+
+// (defined in neumf.hip) out[i] = sum_w p[w][i] for the three partial arrays, fixed order
+int neumf_reduce_partials(const float* pW1, const float* pb1, const float* pwout, float* dW1, float* db1, float* dw_out, int cW, int cb,
+                          int co, int n_wg, hipStream_t s);
+
+static size_t step_lds_bytes(int d, int l1, int C) {
+  const size_t k0 = 2 * (size_t)d;
+  const size_t fixed = (size_t)l1 * (k0 + 4) + l1 + (d + l1) + 4 * (2 * (size_t)l1 + d);
+  const size_t per_wave = 16 * ((size_t)l1 + 16) + 16 * ((size_t)d + 16) + 16 * (size_t)C;
+  return sizeof(float) * (fixed + 4 * per_wave);
+}
+
+static bool step_shape(int d, int l1) { return (d == 32 || d == 64 || d == 128) && (l1 == 32 || l1 == 64) && !(d == 128 && l1 == 128); }
+
+int device_cus();   // bucket_plan.hip
+
+static int step_grid(int B) {
+  const int64_t rounds = ((int64_t)B + 63) / 64;
+  static const int per_cu = [] {
+    const char* v = getenv("RC_NEUMF_STEP_WGS_PER_CU");   // workgroups per CU over the launch (A/B: partial size vs balance)
+    const int k = (v && *v) ? atoi(v) : 2;
+    return k < 1 ? 1 : k;
+  }();
+  int64_t grid = (int64_t)device_cus() * per_cu;
+  if (grid > rounds) grid = rounds;
+  return (int)(grid < 1 ? 1 : grid);
+}
+
+template <int D, int L1, int MODE>
+static int launch_step(const NeumfStepArgs& a, int grid, hipStream_t s) {
+  const size_t lds_bytes = step_lds_bytes(D, L1, a.C);
+  auto kern = neumf_step_kernel<D, L1, MODE>;
+  RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, s, a);
+  RC_LAUNCH_CHECK();
+  return RC_OK;
+}
+
+template <int MODE>
+static int dispatch_step(const NeumfStepArgs& a, int d, int l1, int grid, hipStream_t s) {
+#define RC_NS(D_, L_) \
+  if (d == D_ && l1 == L_) return launch_step<D_, L_, MODE>(a, grid, s)
+  RC_NS(128, 64); RC_NS(128, 32);
+  RC_NS(64, 64); RC_NS(64, 32);
+  RC_NS(32, 64); RC_NS(32, 32);
+#undef RC_NS
+  return fail(RC_ERR_UNSUPPORTED, "rc_neumf_train_step: no kernel for d=%d, hidden=%d", d, l1);
+}
+
+}  // namespace rc
+
+using namespace rc;
+
+extern "C" int rc_neumf_train_step_supported(int C, int d, int l1) {
+  return (step_shape(d, l1) && C >= 2 && step_lds_bytes(d, l1, C) <= 160 * 1024) ? 1 : 0;
+}
+
+extern "C" size_t rc_neumf_train_step_workspace_bytes(int B, int C, int d, int l1) {
+  if (!rc_neumf_train_step_supported(C, d, l1) || B < 1) return 0;
+  const size_t per = (size_t)l1 * 2 * d + l1 + (d + l1);
+  return align_up((size_t)step_grid(B) * per * sizeof(float), 256) + 256;
+}
+
+extern "C" size_t rc_neumf_train_step_bitmap_bytes(int64_t n_items) {
+  return n_items < 1 ? 0 : 2 * align_up((size_t)((n_items + 31) / 32) * sizeof(uint32_t), 256);
+}
+
+extern "C" int rc_neumf_train_step(float* mf_u, float* mf_i, float* mlp_u, float* mlp_i, float* m_mf_i, float* v_mf_i,
+                                   float* m_mlp_i, float* v_mlp_i, const float* W1, const float* b1, const float* w_out,
+                                   const int64_t* uid, const int64_t* iid, int B, int C, int d, int l1, int64_t n_items,
+                                   void* bitmap, const rc_opt_hyper* h, float inv_b, float* loss_vec, float* pred,
+                                   float* g_mf_i, float* g_mlp_i, float* gu_mf, float* gu_mlp, float* dW1, float* db1,
+                                   float* dw_out, void* ws, size_t ws_bytes, rc_stream_t stream) {
+  if (B == 0) return RC_OK;
+  RC_REQUIRE(mf_u && mf_i && mlp_u && mlp_i && W1 && b1 && w_out && uid && iid && bitmap && loss_vec && g_mf_i && g_mlp_i && gu_mf &&
+                 gu_mlp && dW1 && db1 && dw_out && ws,
+             "rc_neumf_train_step: null pointer");
+  RC_REQUIRE(B > 0 && C >= 2 && n_items >= 1, "rc_neumf_train_step: bad shape B=%d C=%d n_items=%lld", B, C, (long long)n_items);
+  if (!rc_neumf_train_step_supported(C, d, l1))
+    return fail(RC_ERR_UNSUPPORTED, "rc_neumf_train_step: d=%d hidden=%d C=%d not supported (d in {32,64,128}, hidden in {32,64}, LDS <= 160 KB)",
+                d, l1, C);
+  if (ws_bytes < rc_neumf_train_step_workspace_bytes(B, C, d, l1))
+    return fail(RC_ERR_WORKSPACE, "rc_neumf_train_step: workspace %zu < %zu", ws_bytes, rc_neumf_train_step_workspace_bytes(B, C, d, l1));
+  NeumfStepArgs a;
+  memset(&a, 0, sizeof(a));
+  RC_TRY(fill_opt_scalars(h, &a.opt));
+  const int mode = mode_of(h);
+  RC_REQUIRE(!mode_has_m(mode) || (m_mf_i && m_mlp_i), "rc_neumf_train_step: optimizer %d needs the m state of the item tables", h->opt);
+  RC_REQUIRE(!mode_has_v(mode) || (v_mf_i && v_mlp_i), "rc_neumf_train_step: optimizer %d needs the v state of the item tables", h->opt);
+  hipStream_t s = as_stream(stream);
+  const int64_t n = (int64_t)B * C;
+  const size_t half = rc_neumf_train_step_bitmap_bytes(n_items) / 2;
+  uint32_t* seen1 = reinterpret_cast<uint32_t*>(bitmap);
+  uint32_t* seen2 = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(bitmap) + half);
+  const unsigned mark_blocks = (unsigned)((n + 255) / 256);
+  hipLaunchKernelGGL(neumf_mark_kernel, dim3(mark_blocks), dim3(256), 0, s, iid, n, seen1, seen2);
+  RC_LAUNCH_CHECK();
+  a.mf_u = mf_u; a.mf_i = mf_i; a.mlp_u = mlp_u; a.mlp_i = mlp_i;
+  a.m_mf_i = m_mf_i; a.v_mf_i = v_mf_i; a.m_mlp_i = m_mlp_i; a.v_mlp_i = v_mlp_i;
+  a.W1 = W1; a.b1 = b1; a.w_out = w_out; a.uid = uid; a.iid = iid; a.B = B; a.C = C; a.inv_b = inv_b;
+  a.multi = seen2; a.loss_vec = loss_vec; a.pred = pred; a.g_mf_i = g_mf_i; a.g_mlp_i = g_mlp_i; a.gu_mf = gu_mf; a.gu_mlp = gu_mlp;
+  const int grid = step_grid(B);
+  const int cW = l1 * 2 * d, cb = l1, co = d + l1;
+  float* p = reinterpret_cast<float*>(ws);
+  a.pW1 = p;
+  a.pb1 = p + (size_t)grid * cW;
+  a.pwout = a.pb1 + (size_t)grid * cb;
+  int rc = RC_OK;
+  if (mode == MODE_SGD) rc = dispatch_step<MODE_SGD>(a, d, l1, grid, s);
+  else if (mode == MODE_ADAM) rc = dispatch_step<MODE_ADAM>(a, d, l1, grid, s);
+  else rc = dispatch_step<MODE_ADAGRAD>(a, d, l1, grid, s);
+  // the bitmaps go back to zero whatever happened to the step
+  hipLaunchKernelGGL(neumf_unmark_kernel, dim3(mark_blocks), dim3(256), 0, s, iid, n, seen1, seen2);
+  RC_TRY(rc);
+  RC_LAUNCH_CHECK();
+  return neumf_reduce_partials(a.pW1, a.pb1, a.pwout, dW1, db1, dw_out, cW, cb, co, grid, s);
+}

@@ -400,6 +400,7 @@ _SEG_ROWS = os.environ.get("RC_SEG_ROWS", "1") != "0"
 # SasrecTrainer: id sort beside the encoder, position gradient beside the item update, on a second stream (RC_SAS_OVERLAP=0: one stream)
 _SAS_OVERLAP = os.environ.get("RC_SAS_OVERLAP", "1") != "0"
 _NEUMF_OVERLAP = os.environ.get("RC_NEUMF_OVERLAP", "1") != "0"   # NeumfTrainer: bucket plan beside the head kernels
+_NEUMF_FUSED = os.environ.get("RC_NEUMF_FUSED", "1") != "0"       # NeumfTrainer: rc_neumf_train_step (A/B against the three-kernel step)
 _SAS_OVERLAP_MIN = int(os.environ.get("RC_SAS_OVERLAP_MIN", "131072"))   # candidate + history occurrences of the batch
 _SEG_ROWS_MIN_PER_ROW = int(os.environ.get("RC_SEG_ROWS_MIN_PER_ROW", "8"))
 _SASREC_PLAN = os.environ.get("RC_TABLE_UPDATE", "auto") == "plan"
@@ -644,6 +645,32 @@ def neumf_bwd(P, uid, iid, gpred, drop_p=0.0, seed=None):
     return rows, dense
 
 
+def neumf_train_step_supported(Cn, d, l1):
+    return bool(_lib.load().rc_neumf_train_step_supported(int(Cn), int(d), int(l1)))
+
+
+def neumf_train_step(P, state, uid, iid, hyper, bitmap, out, inv_b=None, pred=None):
+    """rc_neumf_train_step: forward + BPR loss + backward + in-place update of single-occurrence item rows.
+    state: {table: {"m": .., "v": ..}} of the optimizer; bitmap: zeroed uint8 buffer of rc_neumf_train_step_bitmap_bytes(n_items)
+    (left zeroed); out: dict of preallocated buffers loss_vec [B], g_mf_i / g_mlp_i [B C, d], gu_mf / gu_mlp [B, d], W1 / b1 / w_out
+    gradients.  Returns nothing: the caller finishes the step with the plan's pair updates and the dense update."""
+    B, Cn = iid.shape
+    d, l1 = P["mf_u"].shape[1], P["W1"].shape[0]
+    f32 = torch.float32
+    lib = _lib.load()
+    ws = workspace(lib.rc_neumf_train_step_workspace_bytes(B, Cn, d, l1), iid.device, "neumf_step")
+    st = lambda t, k: _ptr(state[t].get(k), f32, k + "_" + t, True)
+    _lib.call("rc_neumf_train_step", _ptr(P["mf_u"], f32, "mf_u"), _ptr(P["mf_i"], f32, "mf_i"), _ptr(P["mlp_u"], f32, "mlp_u"),
+              _ptr(P["mlp_i"], f32, "mlp_i"), st("mf_i", "m"), st("mf_i", "v"), st("mlp_i", "m"), st("mlp_i", "v"),
+              _ptr(P["W1"], f32, "W1"), _ptr(P["b1"], f32, "b1"), _ptr(P["w_out"], f32, "w_out"),
+              _ptr(uid, torch.int64, "uid"), _ptr(iid, torch.int64, "iid"), B, Cn, d, l1, int(P["mf_i"].shape[0]),
+              C.c_void_p(bitmap.data_ptr()), C.byref(hyper), float(1.0 / B if inv_b is None else inv_b),
+              _ptr(out["loss_vec"], f32, "loss_vec"), _ptr(pred, f32, "pred", True),
+              _ptr(out["g_mf_i"], f32, "g_mf_i"), _ptr(out["g_mlp_i"], f32, "g_mlp_i"), _ptr(out["gu_mf"], f32, "gu_mf"),
+              _ptr(out["gu_mlp"], f32, "gu_mlp"), _ptr(out["W1"], f32, "dW1"), _ptr(out["b1"], f32, "db1"),
+              _ptr(out["w_out"], f32, "dw_out"), C.c_void_p(ws.data_ptr()), ws.numel(), _stream())
+
+
 class _PhaseTimer:
     """Optional per-phase timing of a trainer step with events on the launch stream (torch's current stream is the
     stream every kernel of the step is enqueued on).  trainer.timing = {} switches it on; read with phases_ms()."""
@@ -703,6 +730,9 @@ class NeumfTrainer:
         use_plan = self.rowwise and pair_ok and _USE_PLAN and plan_supported(iid.numel(), uid.numel(), n_i, n_u)
         # the bucket plan needs only the ids: on a second stream it runs beside the head kernels (large batches; a small step is
         # bound by the host's launch rate and the stream switches cost more than they return)
+        if (use_plan and _NEUMF_FUSED and self.dropout == 0.0 and self.opt in ("SGD", "Adam", "Adagrad") and Cn >= 2
+                and neumf_train_step_supported(Cn, P["mf_u"].shape[1], P["W1"].shape[0])):
+            return self._step_fused(uid, iid)
         overlap = use_plan and _NEUMF_OVERLAP and iid.is_cuda and iid.numel() >= _SAS_OVERLAP_MIN
         plan = plan_done = main = None
         if overlap:
@@ -747,6 +777,53 @@ class NeumfTrainer:
             self._step_tables_sorted(P, uid.repeat_interleave(Cn), iid, rows, h, pair_ok)
         with _PhaseTimer(self, "dense_update"):
             dense_update_multi([(P[k], dense[k], h0 if k == "b1" else h, self.state[k].get("m"), self.state[k].get("v"))
+                                for k in ("W1", "b1", "w_out")], self.opt)
+        return self.loss
+
+    def _step_fused(self, uid, iid):
+        """The step on rc_neumf_train_step (csrc/neumf_step.hip): ONE kernel for forward, loss, backward and the in-place update
+        of single-occurrence item rows; the bucket plan of the batch (item side: multi-occurrence rows only; user side per
+        tuple) is built on a second stream meanwhile and consumed by two pair updates."""
+        P = self.P
+        B, Cn = iid.shape
+        dev = iid.device
+        d = P["mf_u"].shape[1]
+        n_u, n_i = P["mf_u"].shape[0], P["mf_i"].shape[0]
+        if getattr(self, "_bitmap", None) is None:
+            self._bitmap = torch.zeros(max(int(_lib.load().rc_neumf_train_step_bitmap_bytes(n_i)), 1), dtype=torch.uint8, device=dev)
+        key = (B, Cn, str(dev))
+        if getattr(self, "_fused_out", (None,))[0] != key:
+            e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+            self._fused_out = (key, {"loss_vec": e(B), "g_mf_i": e(B * Cn, d), "g_mlp_i": e(B * Cn, d), "gu_mf": e(B, d), "gu_mlp": e(B, d),
+                                     "W1": torch.empty_like(P["W1"]), "b1": torch.empty_like(P["b1"]), "w_out": torch.empty_like(P["w_out"])})
+        out = self._fused_out[1]
+        overlap = _NEUMF_OVERLAP and iid.numel() >= _SAS_OVERLAP_MIN
+        plan = plan_done = main = None
+        if overlap:
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=dev)
+            main, side = torch.cuda.current_stream(dev), self._side
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                plan = Plan(iid, n_i, uid, n_u, tag="neumf", list_single_a=False)
+                plan_done = side.record_event()
+        h = make_hyper(self.opt, lr=self.lr, l2=self.l2, step=self.step_count)
+        h0 = make_hyper(self.opt, lr=self.lr, l2=0.0, step=self.step_count)
+        with _PhaseTimer(self, "fused_step"):
+            neumf_train_step(P, self.state, uid, iid, h, self._bitmap, out)
+        with _PhaseTimer(self, "loss"):
+            self.loss = reduce_sum(out["loss_vec"], 1.0 / B)
+        with _PhaseTimer(self, "sort"):
+            if overlap:
+                main.wait_event(plan_done)
+            else:
+                plan = Plan(iid, n_i, uid, n_u, tag="neumf", list_single_a=False)
+        with _PhaseTimer(self, "table_update"):
+            for side_, ta, tb, ga, gb in (("a", "mf_i", "mlp_i", out["g_mf_i"], out["g_mlp_i"]), ("b", "mf_u", "mlp_u", out["gu_mf"], out["gu_mlp"])):
+                sa, sb = self.state[ta], self.state[tb]
+                plan.update_pair(side_, P[ta], P[tb], ga, gb, h, ma=sa.get("m"), va=sa.get("v"), mb=sb.get("m"), vb=sb.get("v"))
+        with _PhaseTimer(self, "dense_update"):
+            dense_update_multi([(P[k], out[k], h0 if k == "b1" else h, self.state[k].get("m"), self.state[k].get("v"))
                                 for k in ("W1", "b1", "w_out")], self.opt)
         return self.loss
 

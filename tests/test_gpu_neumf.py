@@ -250,3 +250,153 @@ def test_segmented_update_pair_equals_two_single_updates(d, opt, cuda, eng):
     untouched = np.setdiff1d(np.arange(n_rows), ids)
     if len(untouched):
         assert np.array_equal(out[0][0][0].cpu().numpy()[untouched], W0[0][untouched])
+
+
+# ---- the fused fit step (rc_neumf_train_step, csrc/neumf_step.hip) --------------------------------------------------------
+
+def _fused_buffers(eng, Pd, B, C, cuda):
+    d = Pd["mf_u"].shape[1]
+    e = lambda *shape: torch.full(shape, float("nan"), dtype=torch.float32, device=cuda)
+    out = {"loss_vec": e(B), "g_mf_i": e(B * C, d), "g_mlp_i": e(B * C, d), "gu_mf": e(B, d), "gu_mlp": e(B, d),
+           "W1": torch.empty_like(Pd["W1"]), "b1": torch.empty_like(Pd["b1"]), "w_out": torch.empty_like(Pd["w_out"])}
+    from rechorus_amd import _lib
+    bitmap = torch.zeros(int(_lib.load().rc_neumf_train_step_bitmap_bytes(Pd["mf_i"].shape[0])), dtype=torch.uint8, device=cuda)
+    return out, bitmap
+
+
+def _check_fused_against(eng, P, Pd, state, uid, iid, opt, lr, l2, step, want_pred, want_loss_rows, G, tol, cuda, what):
+    """one rc_neumf_train_step call against reference / oracle quantities: predictions, per-tuple loss, dense gradients, per-tuple
+    user gradient rows, single-occurrence item rows after the row-wise optimizer step (and their state), multi-occurrence rows
+    untouched with their gradient rows written, bitmaps back to zero"""
+    from oracle import bprmf_oracle as BO
+    B, C = iid.shape
+    out, bitmap = _fused_buffers(eng, Pd, B, C, cuda)
+    pred = torch.empty((B, C), dtype=torch.float32, device=cuda)
+    W0 = {k: Pd[k].cpu().numpy().copy() for k in ("mf_i", "mlp_i", "mf_u", "mlp_u")}
+    S0 = {k: {s: t.cpu().numpy().copy() for s, t in state[k].items()} for k in ("mf_i", "mlp_i")}
+    u, i = torch.from_numpy(uid).to(cuda), torch.from_numpy(iid).to(cuda)
+    h = eng.make_hyper(opt, lr=lr, l2=l2, step=step)
+    eng.neumf_train_step(Pd, state, u, i, h, bitmap, out, pred=pred)
+    torch.cuda.synchronize()
+    assert not bitmap.any(), what + ": the id bitmaps must be zero again after the step"
+    assert_close(pred.cpu().numpy(), want_pred, what=what + " pred", atol_scale=tol)
+    assert_close(out["loss_vec"].cpu().numpy(), want_loss_rows, what=what + " loss rows", atol_scale=tol)
+    assert_close(out["W1"].cpu().numpy(), G["mlp.0.weight"], what=what + " dW1", atol_scale=tol)
+    assert_close(out["b1"].cpu().numpy(), G["mlp.0.bias"], what=what + " db1", atol_scale=tol)
+    assert_close(out["w_out"].cpu().numpy(), G["prediction.weight"][0], what=what + " dw_out", atol_scale=tol)
+    for key, tab in (("gu_mf", "mf_u"), ("gu_mlp", "mlp_u")):
+        T = np.zeros(W0[tab].shape, dtype=np.float64)
+        np.add.at(T, uid, out[key].cpu().numpy().astype(np.float64))
+        assert_close(T, G[NAMES[tab]], what=what + " grad " + tab, atol_scale=tol)
+        assert np.array_equal(Pd[tab].cpu().numpy(), W0[tab]), what + ": user tables are only read"
+    ids, cnt = np.unique(iid, return_counts=True)
+    single, multi = ids[cnt == 1], ids[cnt >= 2]
+    flat = iid.reshape(-1)
+    for key, tab in (("g_mf_i", "mf_i"), ("g_mlp_i", "mlp_i")):
+        Wn = Pd[tab].cpu().numpy()
+        Wref = W0[tab].copy()
+        sref = {s: a.copy() for s, a in S0[tab].items()}
+        BO.opt_step_dense(Wref, G[NAMES[tab]], sref, opt, lr, l2, step=step, rows=single)
+        assert_update_close(Wn, W0[tab], Wref, what=what + " " + tab, extra_atol=1e-3 * lr if opt != "SGD" else 0.0)
+        others = np.setdiff1d(np.arange(Wn.shape[0]), single)
+        assert np.array_equal(Wn[others], W0[tab][others]), what + ": rows that are not single-occurrence rows must not move"
+        for s in sref:
+            assert_close(state[tab][s].cpu().numpy(), sref[s], what=what + f" state {s} of {tab}", atol_scale=2e-5)
+        rows = out[key].cpu().numpy()
+        pos_multi = np.isin(flat, multi)
+        assert np.isnan(rows[~pos_multi]).all(), what + ": gradient rows are written for multi-occurrence positions only"
+        T = np.zeros(Wn.shape, dtype=np.float64)
+        np.add.at(T, flat[pos_multi], rows[pos_multi].astype(np.float64))
+        assert_close(T[multi], G[NAMES[tab]][multi], what=what + " multi rows of " + tab, atol_scale=tol)
+    return out
+
+
+def _state_for(eng, Pd, opt, rng, cuda):
+    st = {}
+    for k, t in Pd.items():
+        s = {}
+        if opt in ("Adam", "Adagrad"):
+            s["m"] = torch.from_numpy(rng.normal(0, 0.01, tuple(t.shape)).astype(np.float32) ** (2 if opt == "Adagrad" else 1)).to(cuda)
+        if opt == "Adam":
+            s["v"] = torch.from_numpy((rng.normal(0, 0.01, tuple(t.shape)).astype(np.float32)) ** 2).to(cuda)
+        st[k] = s
+    return st
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("opt", ["SGD", "Adam", "Adagrad"])
+def test_neumf_fused_step_matches_the_reference_run(case, opt, cuda, eng):
+    """the fused kernel on the golden batch: predictions, loss, every gradient the reference's autograd produced"""
+    g = load_golden(case)
+    P0 = params(g)
+    Pd = to_dev(P0, cuda)
+    B, C = g["iid"].shape
+    assert eng.neumf_train_step_supported(C, Pd["mf_u"].shape[1], Pd["W1"].shape[0])
+    from oracle import bprmf_oracle as BO
+    state = _state_for(eng, Pd, opt, np.random.default_rng(5), cuda)
+    out = _check_fused_against(eng, P0, Pd, state, g["uid"], g["iid"], opt, 0.05, 1e-3, 3, g["pred"], BO.bpr_loss_rows(g["pred"])[0],
+                               params(g, "G/"), 2e-5, cuda, case + " " + opt)
+    assert_close(out["loss_vec"].mean().cpu().numpy(), g["loss"], what="loss")
+
+
+def test_neumf_fused_step_random_shapes_vs_oracle(cuda, eng):
+    """shapes that span several workgroup rounds, ragged tails (B not a multiple of 16 / 64), hot rows and C from 2 to 100"""
+    from oracle import bprmf_oracle as BO
+    rng = np.random.default_rng(11)
+    for d, l1, B, C, n_items, opt in ((128, 64, 1000, 5, 3000, "SGD"), (64, 64, 777, 2, 500, "Adam"), (32, 32, 130, 17, 4000, "Adagrad"),
+                                      (64, 32, 65, 100, 900, "SGD"), (32, 64, 1, 3, 50, "SGD"), (128, 32, 200, 5, 100000, "Adam")):
+        n_users = 37
+        P = {"mf_u_embeddings.weight": rng.normal(0, 0.3, (n_users, d)), "mf_i_embeddings.weight": rng.normal(0, 0.3, (n_items, d)),
+             "mlp_u_embeddings.weight": rng.normal(0, 0.3, (n_users, d)), "mlp_i_embeddings.weight": rng.normal(0, 0.3, (n_items, d)),
+             "mlp.0.weight": rng.normal(0, 0.2, (l1, 2 * d)), "mlp.0.bias": rng.normal(0, 0.2, l1),
+             "prediction.weight": rng.normal(0, 0.2, (1, d + l1))}
+        P = {k: v.astype(np.float32) for k, v in P.items()}
+        uid = rng.integers(0, n_users, size=B).astype(np.int64)
+        iid = rng.integers(0, n_items, size=(B, C)).astype(np.int64)
+        iid[:, 0] = iid[:, 0] % 7      # hot positives
+        Pd = to_dev(P, cuda)
+        assert eng.neumf_train_step_supported(C, d, l1)
+        pred, _ = NO.forward(P, uid, iid)
+        gp = BO.bpr_loss_grad(pred)
+        _, G = NO.backward(P, uid, iid, gp)
+        state = _state_for(eng, Pd, opt, rng, cuda)
+        _check_fused_against(eng, P, Pd, state, uid, iid, opt, 0.03, 1e-4, 2, pred, BO.bpr_loss_rows(pred)[0], G, 3e-5, cuda,
+                             f"d={d} l1={l1} B={B} C={C} {opt}")
+    assert not eng.neumf_train_step_supported(1, 64, 64) and not eng.neumf_train_step_supported(5, 48, 64)
+    assert not eng.neumf_train_step_supported(5, 64, 128) and not eng.neumf_train_step_supported(200, 128, 64)
+
+
+@pytest.mark.parametrize("opt", ["SGD", "Adam", "Adagrad"])
+def test_neumf_trainer_fused_equals_three_kernel_step(opt, cuda, eng, monkeypatch):
+    """NeumfTrainer (row-wise) on the fused kernel vs the forward / loss / backward / update chain it replaces: two steps, same
+    tables, optimizer state and dense parameters to rounding (the kernels sum in different orders)"""
+    rng = np.random.default_rng(17)
+    d, l1, B, C, n_users, n_items = 64, 64, 3000, 5, 400, 20000
+    P0 = {"mf_u": rng.normal(0, 0.2, (n_users, d)), "mf_i": rng.normal(0, 0.2, (n_items, d)), "mlp_u": rng.normal(0, 0.2, (n_users, d)),
+          "mlp_i": rng.normal(0, 0.2, (n_items, d)), "W1": rng.normal(0, 0.2, (l1, 2 * d)), "b1": rng.normal(0, 0.2, l1),
+          "w_out": rng.normal(0, 0.2, d + l1)}
+    P0 = {k: v.astype(np.float32) for k, v in P0.items()}
+    batches = []
+    for _ in range(2):
+        uid = rng.integers(0, n_users, size=B).astype(np.int64)
+        iid = rng.integers(0, n_items, size=(B, C)).astype(np.int64)
+        iid[:, 0] = iid[:, 0] % 50
+        batches.append((torch.from_numpy(uid).to(cuda), torch.from_numpy(iid).to(cuda)))
+    lr = 0.05 if opt == "SGD" else 1e-2
+    res = []
+    for fused in (True, False):
+        monkeypatch.setattr(eng, "_NEUMF_FUSED", fused)
+        P = {k: torch.from_numpy(v).to(cuda) for k, v in P0.items()}
+        tr = eng.NeumfTrainer(P, opt=opt, lr=lr, l2=1e-4, rowwise=True)
+        tr.timing = {}
+        losses = [float(tr.step(u, i).item()) for u, i in batches]
+        assert ("fused_step" in tr.timing) == fused
+        res.append((P, tr.state, losses))
+    (Pa, Sa, La), (Pb, Sb, Lb) = res
+    assert_close(np.array(La), np.array(Lb), what="losses")
+    ex = 1e-3 * lr if opt != "SGD" else 0.0
+    for k in P0:
+        assert_update_close(Pa[k].cpu().numpy(), P0[k], Pb[k].cpu().numpy(), what=k, extra_atol=ex)
+        assert not np.array_equal(Pa[k].cpu().numpy(), P0[k])
+        for s in Sa[k]:
+            assert_close(Sa[k][s].cpu().numpy(), Sb[k][s].cpu().numpy(), what=f"state {s} of {k}", atol_scale=2e-5)
