@@ -7,7 +7,7 @@
 #   bench[:<name>:<bench.py args>]     a bench line -> <name>.json      (plain `bench` = the driver's default command)
 #   ab:<name>:<ENV=V,ENV=V>:<args>     the same bench line with environment switches set (A/B inside one call)
 #   prof:<name>:<bench.py args>        rocprofv3 --kernel-trace --stats of a bench command -> prof_<name>/
-#   pmc:<name>:<bench.py args>         FETCH_SIZE / WRITE_SIZE passes (tools/pmc_collect.sh conventions) of a bench command
+#   pmc                                FETCH_SIZE / WRITE_SIZE passes of the BPRMF step (tools/pmc_collect.sh) -> pmc/
 #   py:<name>:<script and args>        python <script> -> <name>.log
 TAG=${1:-run}
 shift
