@@ -247,7 +247,10 @@ def deepfm_roofline(args, trainer, batches, engine):
     """MLP_Block GEMMs (csrc/mlp.hip, fp32 MFMA) against the fp32 MFMA peak, over the eager forward + backward phases"""
     trainer.timing = {}
     for s in range(10):
-        trainer.step(*batches[s % len(batches)])
+        if args.workload == "neumf":   # steady state of the timed loop: every step announces the following batch
+            trainer.step(*batches[s % len(batches)], next_batch=batches[(s + 1) % len(batches)])
+        else:
+            trainer.step(*batches[s % len(batches)])
     ph = engine.phases_ms(trainer)
     trainer.timing = None
     F, d = len(DEEPFM_VOCAB), args.emb_size
@@ -645,6 +648,9 @@ def main():
     if world == 1 and args.workload == "bprmf" and not args.graph:
         # the step is given the following batch's ids (the reference's DataLoader runs ahead of the loop too): their grouping
         # front runs beside this step's row updates (rc_bprmf_train_step_ahead); same results bit for bit
+        run_step = lambda s: trainer.step(*batches[s % len(batches)], next_batch=batches[(s + 1) % len(batches)])
+    if world == 1 and args.workload == "neumf":
+        # same contract for the NeuMF step: the following batch's bucket plan is built beside this step's table updates
         run_step = lambda s: trainer.step(*batches[s % len(batches)], next_batch=batches[(s + 1) % len(batches)])
     if getattr(trainer, "lookahead", False):
         # the sharded steps exchange per-destination split sizes; given the following batch they do that one step ahead

@@ -467,8 +467,10 @@ int rc_neumf_bwd_dropout(const float* mf_u, const float* mf_i, const float* mlp_
  * layer (W1 [mlp_u ; mlp_i] = W1u mlp_u + W1i mlp_i) and the user-row gradients are per-tuple work.
  *   tables        mf_u, mlp_u are read; mf_i, mlp_i (and their optimizer state m_*, v_*: Adam both, Adagrad m, SGD none -> NULL)
  *                 are updated in place for single-occurrence rows (row-wise semantics: only touched rows move, l2 on them)
- *   bitmap        rc_neumf_train_step_bitmap_bytes(n_items) bytes, ALL ZERO on entry and all zero again on exit: two bitmaps
- *                 over the item ids, filled by a marking pass with integer atomics (order-free) -- bit = "id occurs twice"
+ *   marks         rc_neumf_train_step_marks_bytes(n_items) bytes, ALL ZERO before the first call; the call leaves it ready for
+ *                 the next one: an owner map (4 B per item id, written before it is read) and a flag byte per item id ("occurs
+ *                 at least twice", cleared again) filled by two marking passes with plain stores -- no atomics, and the
+ *                 flags do not depend on the schedule
  *   loss_vec [B]  per-tuple loss; dL/dpred uses inv_b (1/B = the reference's .mean()); pred [B, C] or NULL
  *   g_mf_i, g_mlp_i [B C, d]  gradient rows of the positions whose item row occurs more than once (other positions are NOT
  *                 written): feed them to rc_plan_update_pair on a plan of iid built with list_single_a = 0
@@ -478,11 +480,11 @@ int rc_neumf_bwd_dropout(const float* mf_u, const float* mf_i, const float* mlp_
  * (C <= 136 at d = 128, l1 = 64); no dropout (use rc_neumf_fwd_dropout / rc_neumf_bwd_dropout).                          */
 int rc_neumf_train_step_supported(int C, int d, int l1);
 size_t rc_neumf_train_step_workspace_bytes(int B, int C, int d, int l1);
-size_t rc_neumf_train_step_bitmap_bytes(int64_t n_items);
+size_t rc_neumf_train_step_marks_bytes(int64_t n_items);
 int rc_neumf_train_step(float* mf_u, float* mf_i, float* mlp_u, float* mlp_i, float* m_mf_i, float* v_mf_i,
                         float* m_mlp_i, float* v_mlp_i, const float* W1, const float* b1, const float* w_out,
                         const int64_t* uid, const int64_t* iid, int B, int C, int d, int l1, int64_t n_items,
-                        void* bitmap, const rc_opt_hyper* h, float inv_b, float* loss_vec, float* pred,
+                        void* marks, const rc_opt_hyper* h, float inv_b, float* loss_vec, float* pred,
                         float* g_mf_i, float* g_mlp_i, float* gu_mf, float* gu_mlp, float* dW1, float* db1,
                         float* dw_out, void* ws, size_t ws_bytes, rc_stream_t stream);
 

@@ -137,7 +137,7 @@ SIGNATURES = {
     "rc_neumf_bwd": (_i, [_p] * 10 + [_i, _i, _i, _i] + [_p] * 7 + [_p, _sz, _p]),
     "rc_neumf_train_step_supported": (_i, [_i, _i, _i]),
     "rc_neumf_train_step_workspace_bytes": (_sz, [_i, _i, _i, _i]),
-    "rc_neumf_train_step_bitmap_bytes": (_sz, [_i64]),
+    "rc_neumf_train_step_marks_bytes": (_sz, [_i64]),
     "rc_neumf_train_step": (_i, [_p] * 13 + [_i, _i, _i, _i, _i64, _p, _hp, _f] + [_p] * 9 + [_p, _sz, _p]),
     "rc_linear_fwd": (_i, [_p, _p, _p, _i64, _i, _i, _i, _f, _p, C.c_uint32, _p, _p]),
     "rc_linear_fwd_workspace_bytes": (_sz, [_i64, _i, _i]),

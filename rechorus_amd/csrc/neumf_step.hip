@@ -19,8 +19,8 @@
 //   pass 2   per c: gather again (L2 / MALL: the wave touched the rows microseconds ago), recompute z, dz,
 //            dh0 = W1i^T dz lands in the SAME lane layout as the gathered row, so a single-occurrence row is updated in
 //            place from registers (opt_row4: SGD / Adam / Adagrad) and only multi-occurrence rows write a gradient row
-//            (to the per-occurrence arrays the bucket plan's pair update consumes; singleton / multi from a bitmap over
-//            item ids that a 10 us marking kernel fills with integer atomics -- order-free, deterministic);
+//            (to the per-occurrence arrays the bucket plan's pair update consumes; singleton / multi from a byte map over
+//            item ids that two marking passes fill with plain stores -- schedule-independent, see below);
 //            dW1i += dz^T hi contracts over CANDIDATES: dz and hi cross to "candidate in the K index" through a
 //            wave-private LDS strip (ds in-order per wave: no barrier), accumulators 64 x 128 per wave (AGPRs);
 //   tuple    dhu = W1u^T sum_c dz_c, d mf_u = w_mf * sum_c g_c mf_i: ONE gradient row per tuple and table (the plan's
@@ -54,7 +54,7 @@ struct NeumfStepArgs {
   const int64_t* iid;
   int B, C;
   float inv_b;
-  const uint32_t* multi;   // bit (id & 31) of word id >> 5: item row id occurs at least twice in the batch
+  const uint8_t* multi;    // multi[id] != 0: item row id occurs at least twice in the batch
   float* loss_vec;         // [B]
   float* pred;             // [B, C] or null
   float* g_mf_i;           // [B C, D] gradient rows of multi-occurrence item rows (other positions are not written)
@@ -87,10 +87,70 @@ __device__ __forceinline__ void load_row_slices(float (&x)[N][4], const float* p
   }
 }
 
+__device__ __forceinline__ void lds4(float (&w)[4], const float* p) {
+  const float4 v = *reinterpret_cast<const float4*>(p);
+  w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+}
+
+// The three MFMA products of the step, each written as a software pipeline: the LDS operands of the NEXT group of MFMAs are
+// requested before the current group is issued, and a group holds several independent accumulator chains.  (The first version
+// left the order to the compiler, which at 256 + 255 registers placed every ds_read directly in front of its consumer:
+// "ds_read, s_waitcnt, 4 dependent MFMAs" 32 times per candidate in the hidden layer and "ds_read_b32, s_waitcnt, MFMA" 128
+// times in dh0 -- the matrix pipe idled for an LDS round trip per group.)
+
+// z[nt] += W[16 nt + i][col + 16 cc + 4 g + e] x[cc][e]: wp = Ws + i SW + col + 4 g; NT chains, operands of cc + 1 in flight
+template <int NT, int NCU, int SW>
+__device__ __forceinline__ void hidden_half(f32x4s (&z)[NT], const float* wp, const float (&x)[NCU][4]) {
+  float wc[NT][4], wn[NT][4];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) lds4(wc[nt], wp + 16 * nt * SW);
+#pragma unroll
+  for (int cc = 0; cc < NCU; ++cc) {
+    if (cc + 1 < NCU) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) lds4(wn[nt], wp + 16 * nt * SW + 16 * (cc + 1));
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) z[nt] = mma16(wc[nt][e], x[cc][e], z[nt]);
+    if (cc + 1 < NCU) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) wc[nt][e] = wn[nt][e];
+    }
+  }
+}
+
+// acc[k] += sum over (nt, r) of W[16 nt + 4 g + r][col + 16 (kt0 + k) + i] dz[nt][r]: wp = Ws + 4 g SW + col + 16 kt0 + i.
+// MFMA (nt, r) contracts the features 16 nt + 4 g' + r; register r' of acc[k] <-> column 16 (kt0 + k) + 4 g + r', the slice
+// this lane gathered.  KG chains, the KG operands of the next (nt, r) in flight.
+template <int NT, int KG, int SW>
+__device__ __forceinline__ void back_tiles(f32x4s (&acc)[KG], const float* wp, const f32x4s (&dz)[NT]) {
+  float ac[KG], an[KG];
+#pragma unroll
+  for (int k = 0; k < KG; ++k) ac[k] = wp[16 * k];
+#pragma unroll
+  for (int idx = 0; idx < 4 * NT; ++idx) {
+    if (idx + 1 < 4 * NT) {
+#pragma unroll
+      for (int k = 0; k < KG; ++k) an[k] = wp[(16 * ((idx + 1) / 4) + ((idx + 1) % 4)) * SW + 16 * k];
+    }
+#pragma unroll
+    for (int k = 0; k < KG; ++k) acc[k] = mma16(ac[k], dz[idx / 4][idx % 4], acc[k]);
+    if (idx + 1 < 4 * NT) {
+#pragma unroll
+      for (int k = 0; k < KG; ++k) ac[k] = an[k];
+    }
+  }
+}
+
 template <int D, int L1, int MODE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void neumf_step_kernel(NeumfStepArgs a) {
   using Cfg = StepCfg<D, L1>;
   constexpr int K0 = Cfg::K0, SW = Cfg::SW, NCU = Cfg::NCU, NT = Cfg::NT, SZ = Cfg::SZ, SH = Cfg::SH, NTU = Cfg::NTU;
+  constexpr int KG = NCU < 4 ? NCU : 4;   // dh0 column tiles per MFMA group
   extern __shared__ float lds[];
   float* Ws = lds;                       // [L1][SW]  W1, user half in columns 0 .. D-1
   float* sb1 = Ws + L1 * SW;             // [L1]
@@ -121,6 +181,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
   for (int q = 0; q < NTU; ++q) accU[q] = f32x4s{0.f, 0.f, 0.f, 0.f};
 
+  const float* wfwd_u = Ws + i * SW + 4 * g;            // hidden layer, user / item half
+  const float* wfwd_i = wfwd_u + D;
+  const float* wbwd_u = Ws + (4 * g) * SW + i;          // W1^T products, user / item half
+  const float* wbwd_i = wbwd_u + D;
+
   const int64_t n_tiles = ((int64_t)a.B + 15) / 16;
   const int64_t n_rounds = (n_tiles + 3) / 4;
   for (int64_t round = blockIdx.x; round < n_rounds; round += gridDim.x) {
@@ -133,79 +198,66 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const float* hup = a.mlp_u + u * D + 4 * g;
     const float* mup = a.mf_u + u * D + 4 * g;
 
-    // ---- per tuple: Zu = W1u mlp_u (accumulator r of tile nt <-> hidden feature 16 nt + 4 g + r), w_mf * mf_u ----------
+    // ---- per tuple: Zu = W1u mlp_u (accumulator r of tile nt <-> hidden feature 16 nt + 4 g + r) ------------------------
     f32x4s Zu[NT];
     {
       float hu[NCU][4];
       load_row_slices<NCU>(hu, hup);
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        f32x4s z = {0.f, 0.f, 0.f, 0.f};
-        const float* wp = Ws + (16 * nt + i) * SW + 4 * g;
-#pragma unroll
-        for (int cc = 0; cc < NCU; ++cc) {
-          const float4 w = *reinterpret_cast<const float4*>(wp + 16 * cc);
-          z = mma16(w.x, hu[cc][0], z);
-          z = mma16(w.y, hu[cc][1], z);
-          z = mma16(w.z, hu[cc][2], z);
-          z = mma16(w.w, hu[cc][3], z);
-        }
-        Zu[nt] = z;
-      }
-    }
-    float muw[NCU][4];
-    load_row_slices<NCU>(muw, mup);
-#pragma unroll
-    for (int cc = 0; cc < NCU; ++cc) {
-      const float4 w = *reinterpret_cast<const float4*>(swo + 16 * cc + 4 * g);
-      muw[cc][0] *= w.x; muw[cc][1] *= w.y; muw[cc][2] *= w.z; muw[cc][3] *= w.w;
+      for (int nt = 0; nt < NT; ++nt) Zu[nt] = f32x4s{0.f, 0.f, 0.f, 0.f};
+      hidden_half<NT, NCU, SW>(Zu, wfwd_u, hu);
     }
 
     // ---- pass 1: predictions --------------------------------------------------------------------------------------
-    float hn[NCU][4];
-    int64_t item = ip[0];
-    load_row_slices<NCU>(hn, a.mlp_i + item * D + 4 * g);
-    for (int c = 0; c < C; ++c) {
-      asm volatile("" ::: "memory");
-      float hx[NCU][4], mx[NCU][4];
+    // item ids run two candidates ahead of the rows, the mlp rows one candidate ahead of the MFMAs
+    {
+      float muw[NCU][4];
+      load_row_slices<NCU>(muw, mup);
 #pragma unroll
-      for (int cc = 0; cc < NCU; ++cc)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) hx[cc][e] = hn[cc][e];
-      load_row_slices<NCU>(mx, a.mf_i + item * D + 4 * g);
-      if (c + 1 < C) {   // the next candidate's mlp rows travel during this one's MFMAs
-        item = ip[c + 1];
-        load_row_slices<NCU>(hn, a.mlp_i + item * D + 4 * g);
+      for (int cc = 0; cc < NCU; ++cc) {
+        const float4 w = *reinterpret_cast<const float4*>(swo + 16 * cc + 4 * g);
+        muw[cc][0] *= w.x; muw[cc][1] *= w.y; muw[cc][2] *= w.z; muw[cc][3] *= w.w;
       }
-      float pp = 0.f;
+      float hn[NCU][4];
+      int64_t it0 = ip[0], it1 = ip[C > 1 ? 1 : 0];
+      load_row_slices<NCU>(hn, a.mlp_i + it0 * D + 4 * g);
+      for (int c = 0; c < C; ++c) {
+        asm volatile("" ::: "memory");
+        float hx[NCU][4], mx[NCU][4];
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        f32x4s z = Zu[nt];
-        const float* wp = Ws + (16 * nt + i) * SW + D + 4 * g;
+        for (int cc = 0; cc < NCU; ++cc)
 #pragma unroll
-        for (int cc = 0; cc < NCU; ++cc) {
-          const float4 w = *reinterpret_cast<const float4*>(wp + 16 * cc);
-          z = mma16(w.x, hx[cc][0], z);
-          z = mma16(w.y, hx[cc][1], z);
-          z = mma16(w.z, hx[cc][2], z);
-          z = mma16(w.w, hx[cc][3], z);
+          for (int e = 0; e < 4; ++e) hx[cc][e] = hn[cc][e];
+        load_row_slices<NCU>(mx, a.mf_i + it0 * D + 4 * g);
+        it0 = it1;
+        if (c + 1 < C) {   // the next candidate's mlp rows travel during this one's MFMAs
+          load_row_slices<NCU>(hn, a.mlp_i + it0 * D + 4 * g);
+          it1 = ip[c + 2 < C ? c + 2 : C - 1];
         }
-        const float4 b = *reinterpret_cast<const float4*>(sb1 + 16 * nt + 4 * g);
-        const float4 o = *reinterpret_cast<const float4*>(swo + D + 16 * nt + 4 * g);
-        pp = fmaf(o.x, fmaxf(z[0] + b.x, 0.f), pp);
-        pp = fmaf(o.y, fmaxf(z[1] + b.y, 0.f), pp);
-        pp = fmaf(o.z, fmaxf(z[2] + b.z, 0.f), pp);
-        pp = fmaf(o.w, fmaxf(z[3] + b.w, 0.f), pp);
-      }
+        f32x4s z[NT];
 #pragma unroll
-      for (int cc = 0; cc < NCU; ++cc)
+        for (int nt = 0; nt < NT; ++nt) z[nt] = Zu[nt];
+        hidden_half<NT, NCU, SW>(z, wfwd_i, hx);
+        float pp = 0.f;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) pp = fmaf(muw[cc][e], mx[cc][e], pp);
-      pp += __shfl_xor(pp, 16, 64);
-      pp += __shfl_xor(pp, 32, 64);
-      if (g == 0) {
-        sp[c * 16 + i] = pp;
-        if (a.pred && valid) a.pred[tup * C + c] = pp;
+        for (int nt = 0; nt < NT; ++nt) {
+          const float4 b = *reinterpret_cast<const float4*>(sb1 + 16 * nt + 4 * g);
+          const float4 o = *reinterpret_cast<const float4*>(swo + D + 16 * nt + 4 * g);
+          pp = fmaf(o.x, fmaxf(z[nt][0] + b.x, 0.f), pp);
+          pp = fmaf(o.y, fmaxf(z[nt][1] + b.y, 0.f), pp);
+          pp = fmaf(o.z, fmaxf(z[nt][2] + b.z, 0.f), pp);
+          pp = fmaf(o.w, fmaxf(z[nt][3] + b.w, 0.f), pp);
+        }
+#pragma unroll
+        for (int cc = 0; cc < NCU; ++cc)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) pp = fmaf(muw[cc][e], mx[cc][e], pp);
+        pp += __shfl_xor(pp, 16, 64);
+        pp += __shfl_xor(pp, 32, 64);
+        if (g == 0) {
+          sp[c * 16 + i] = pp;
+          if (a.pred && valid) a.pred[tup * C + c] = pp;
+        }
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -240,148 +292,133 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     __builtin_amdgcn_wave_barrier();
 
-    // ---- pass 2: backward and the row updates -----------------------------------------------------------------------
+    // ---- pass 2: backward of the MLP branch and the mlp_i row updates ---------------------------------------------------
     f32x4s dzs[NT];      // sum_c dz_c: db1, and the tuple-level products of the user half
     float dwh[NT][4];    // sum_c g_c h1_c
-    float S[NCU][4];     // sum_c g_c mf_i[c]
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       dzs[nt] = f32x4s{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int r = 0; r < 4; ++r) dwh[nt][r] = 0.f;
     }
+    {
+      float hn[NCU][4];
+      int64_t it0 = ip[0], it1 = ip[C > 1 ? 1 : 0];
+      load_row_slices<NCU>(hn, a.mlp_i + it0 * D + 4 * g);
+      for (int c = 0; c < C; ++c) {
+        asm volatile("" ::: "memory");
+        float hx[NCU][4];
 #pragma unroll
-    for (int cc = 0; cc < NCU; ++cc)
+        for (int cc = 0; cc < NCU; ++cc)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) S[cc][e] = 0.f;
-    item = ip[0];
-    load_row_slices<NCU>(hn, a.mlp_i + item * D + 4 * g);
-    for (int c = 0; c < C; ++c) {
-      asm volatile("" ::: "memory");
-      float hx[NCU][4], mx[NCU][4];
-#pragma unroll
-      for (int cc = 0; cc < NCU; ++cc)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) hx[cc][e] = hn[cc][e];
-      const int64_t item_c = item;
-      load_row_slices<NCU>(mx, a.mf_i + item_c * D + 4 * g);
-      const uint32_t mword = a.multi[item_c >> 5];
-      if (c + 1 < C) {
-        item = ip[c + 1];
-        load_row_slices<NCU>(hn, a.mlp_i + item * D + 4 * g);
-      }
-      const float gc = sp[c * 16 + i];
-      const bool single = ((mword >> (item_c & 31)) & 1u) == 0u;
-      const int64_t n = tup * C + c;
+          for (int e = 0; e < 4; ++e) hx[cc][e] = hn[cc][e];
+        const int64_t item_c = it0;
+        const uint8_t mflag = a.multi[item_c];
+        it0 = it1;
+        if (c + 1 < C) {
+          load_row_slices<NCU>(hn, a.mlp_i + it0 * D + 4 * g);
+          it1 = ip[c + 2 < C ? c + 2 : C - 1];
+        }
+        const float gc = sp[c * 16 + i];
+        const int64_t n = tup * C + c;
 
-      // hidden layer again, dz = g w_h relu'(z)
-      f32x4s dz[NT];
+        // hidden layer again, dz = g w_h relu'(z)
+        f32x4s dz[NT];
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        f32x4s z = Zu[nt];
-        const float* wp = Ws + (16 * nt + i) * SW + D + 4 * g;
+        for (int nt = 0; nt < NT; ++nt) dz[nt] = Zu[nt];
+        hidden_half<NT, NCU, SW>(dz, wfwd_i, hx);
 #pragma unroll
-        for (int cc = 0; cc < NCU; ++cc) {
-          const float4 w = *reinterpret_cast<const float4*>(wp + 16 * cc);
-          z = mma16(w.x, hx[cc][0], z);
-          z = mma16(w.y, hx[cc][1], z);
-          z = mma16(w.z, hx[cc][2], z);
-          z = mma16(w.w, hx[cc][3], z);
+        for (int nt = 0; nt < NT; ++nt) {
+          const float4 b = *reinterpret_cast<const float4*>(sb1 + 16 * nt + 4 * g);
+          const float4 o = *reinterpret_cast<const float4*>(swo + D + 16 * nt + 4 * g);
+          const float bb[4] = {b.x, b.y, b.z, b.w}, oo[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float zz = dz[nt][r] + bb[r];
+            const float dv = zz > 0.f ? gc * oo[r] : 0.f;
+            dz[nt][r] = dv;
+            dzs[nt][r] += dv;
+            dwh[nt][r] = fmaf(gc, fmaxf(zz, 0.f), dwh[nt][r]);
+          }
+          *reinterpret_cast<float4*>(Tz + i * SZ + 16 * nt + 4 * g) = make_float4(dz[nt][0], dz[nt][1], dz[nt][2], dz[nt][3]);
         }
-        const float4 b = *reinterpret_cast<const float4*>(sb1 + 16 * nt + 4 * g);
-        const float4 o = *reinterpret_cast<const float4*>(swo + D + 16 * nt + 4 * g);
-        const float bb[4] = {b.x, b.y, b.z, b.w}, oo[4] = {o.x, o.y, o.z, o.w};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float zz = z[r] + bb[r];
-          const float dv = zz > 0.f ? gc * oo[r] : 0.f;
-          z[r] = dv;
-          dzs[nt][r] += dv;
-          dwh[nt][r] = fmaf(gc, fmaxf(zz, 0.f), dwh[nt][r]);
-        }
-        dz[nt] = z;
-        *reinterpret_cast<float4*>(Tz + i * SZ + 16 * nt + 4 * g) = make_float4(z[0], z[1], z[2], z[3]);
-      }
-#pragma unroll
-      for (int cc = 0; cc < NCU; ++cc)
-        *reinterpret_cast<float4*>(Th + i * SH + 16 * cc + 4 * g) = make_float4(hx[cc][0], hx[cc][1], hx[cc][2], hx[cc][3]);
+        for (int cc = 0; cc < NCU; ++cc)
+          *reinterpret_cast<float4*>(Th + i * SH + 16 * cc + 4 * g) = make_float4(hx[cc][0], hx[cc][1], hx[cc][2], hx[cc][3]);
 
-      // d mlp_i = W1i^T dz: MFMA (nt, r) contracts the features 16 nt + 4 g' + r; register r' of tile kt <-> column 16 kt + 4 g + r',
-      // the slice this lane gathered -- update in place or hand the gradient row to the plan's update
+        // d mlp_i = W1i^T dz in the lane layout of the gathered row: update in place, or hand the gradient row to the plan's update.
+        // SGD: ONE store per slice either way (address and value selected per lane, no divergent branch)
+        const bool single = mflag == 0;
+        float* grow = a.g_mlp_i + n * D + 4 * g;
 #pragma unroll
-      for (int kt = 0; kt < NCU; ++kt) {
-        f32x4s acc = {0.f, 0.f, 0.f, 0.f};
-        const float* wp = Ws + (4 * g) * SW + D + 16 * kt + i;
+        for (int kt0 = 0; kt0 < NCU; kt0 += KG) {
+          f32x4s acc[KG];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+          for (int k = 0; k < KG; ++k) acc[k] = f32x4s{0.f, 0.f, 0.f, 0.f};
+          back_tiles<NT, KG, SW>(acc, wbwd_i + 16 * kt0, dz);
+          if (valid) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) acc = mma16(wp[(16 * nt + r) * SW], dz[nt][r], acc);
-        const float4 gr = make_float4(acc[0], acc[1], acc[2], acc[3]);
-        if (valid) {
-          if (single)
-            opt_row4<MODE>(a.opt, a.mlp_i, a.m_mlp_i, a.v_mlp_i, (size_t)(item_c * D + 16 * kt + 4 * g) / 4,
-                           make_float4(hx[kt][0], hx[kt][1], hx[kt][2], hx[kt][3]), gr);
-          else
-            *reinterpret_cast<float4*>(a.g_mlp_i + n * D + 16 * kt + 4 * g) = gr;
+            for (int k = 0; k < KG; ++k) {
+              const int kt = kt0 + k;
+              const float4 gr = make_float4(acc[k][0], acc[k][1], acc[k][2], acc[k][3]);
+              const float4 w0 = make_float4(hx[kt][0], hx[kt][1], hx[kt][2], hx[kt][3]);
+              if (MODE == MODE_SGD) {
+                float4 w1 = w0, m0 = w0, v0 = w0;
+                opt_apply4<MODE_SGD>(a.opt, w1, m0, v0, gr);
+                float* dst = single ? (a.mlp_i + item_c * D + 16 * kt + 4 * g) : (grow + 16 * kt);
+                store_row4(reinterpret_cast<float4*>(dst), single ? w1 : gr);
+              } else if (single) {
+                opt_row4<MODE>(a.opt, a.mlp_i, a.m_mlp_i, a.v_mlp_i, (size_t)(item_c * D + 16 * kt + 4 * g) / 4, w0, gr);
+              } else {
+                *reinterpret_cast<float4*>(grow + 16 * kt) = gr;
+              }
+            }
+          }
         }
-      }
-      // GMF branch: d mf_i = g w_mf mf_u, S += g mf_i
+        // dW1i += dz^T hi over the 16 candidates of this step (K step s: candidates 4 s + g'); operands of s + 1 in flight
+        __builtin_amdgcn_wave_barrier();
+        {
+          float av[NT], bv[NCU], an[NT], bn[NCU];
 #pragma unroll
-      for (int cc = 0; cc < NCU; ++cc) {
-        const float4 gr = make_float4(gc * muw[cc][0], gc * muw[cc][1], gc * muw[cc][2], gc * muw[cc][3]);
+          for (int ft = 0; ft < NT; ++ft) av[ft] = Tz[g * SZ + 16 * ft + i];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) S[cc][e] = fmaf(gc, mx[cc][e], S[cc][e]);
-        if (valid) {
-          if (single)
-            opt_row4<MODE>(a.opt, a.mf_i, a.m_mf_i, a.v_mf_i, (size_t)(item_c * D + 16 * cc + 4 * g) / 4,
-                           make_float4(mx[cc][0], mx[cc][1], mx[cc][2], mx[cc][3]), gr);
-          else
-            *reinterpret_cast<float4*>(a.g_mf_i + n * D + 16 * cc + 4 * g) = gr;
+          for (int kt = 0; kt < NCU; ++kt) bv[kt] = Th[g * SH + 16 * kt + i];
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            if (s + 1 < 4) {
+#pragma unroll
+              for (int ft = 0; ft < NT; ++ft) an[ft] = Tz[(4 * (s + 1) + g) * SZ + 16 * ft + i];
+#pragma unroll
+              for (int kt = 0; kt < NCU; ++kt) bn[kt] = Th[(4 * (s + 1) + g) * SH + 16 * kt + i];
+            }
+#pragma unroll
+            for (int ft = 0; ft < NT; ++ft)
+#pragma unroll
+              for (int kt = 0; kt < NCU; ++kt) accW[ft][kt] = mma16(av[ft], bv[kt], accW[ft][kt]);
+            if (s + 1 < 4) {
+#pragma unroll
+              for (int ft = 0; ft < NT; ++ft) av[ft] = an[ft];
+#pragma unroll
+              for (int kt = 0; kt < NCU; ++kt) bv[kt] = bn[kt];
+            }
+          }
         }
+        __builtin_amdgcn_wave_barrier();
       }
-      // dW1i += dz^T hi over the 16 candidates of this step (K step s: candidates 4 s + g')
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        float av[NT], bv[NCU];
-#pragma unroll
-        for (int ft = 0; ft < NT; ++ft) av[ft] = Tz[(4 * s + g) * SZ + 16 * ft + i];
-#pragma unroll
-        for (int kt = 0; kt < NCU; ++kt) bv[kt] = Th[(4 * s + g) * SH + 16 * kt + i];
-#pragma unroll
-        for (int ft = 0; ft < NT; ++ft)
-#pragma unroll
-          for (int kt = 0; kt < NCU; ++kt) accW[ft][kt] = mma16(av[ft], bv[kt], accW[ft][kt]);
-      }
-      __builtin_amdgcn_wave_barrier();
     }
 
-    // ---- per tuple: user-row gradients, per-wave sums of db1 / dw_h / dw_mf, dW1u -----------------------------------------
+    // ---- per tuple: mlp_u gradient row, per-wave sums of db1 / dw_h, the strips of the dW1u exchange -------------------------
     {
-      float hu[NCU][4];
-      load_row_slices<NCU>(hu, hup);
-      float mu[NCU][4];
-      load_row_slices<NCU>(mu, mup);
 #pragma unroll
-      for (int kt = 0; kt < NCU; ++kt) {
-        f32x4s acc = {0.f, 0.f, 0.f, 0.f};
-        const float* wp = Ws + (4 * g) * SW + 16 * kt + i;
+      for (int kt0 = 0; kt0 < NCU; kt0 += KG) {
+        f32x4s acc[KG];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+        for (int k = 0; k < KG; ++k) acc[k] = f32x4s{0.f, 0.f, 0.f, 0.f};
+        back_tiles<NT, KG, SW>(acc, wbwd_u + 16 * kt0, dzs);
+        if (valid) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) acc = mma16(wp[(16 * nt + r) * SW], dzs[nt][r], acc);
-        if (valid) *reinterpret_cast<float4*>(a.gu_mlp + tup * D + 16 * kt + 4 * g) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-      }
-#pragma unroll
-      for (int cc = 0; cc < NCU; ++cc) {
-        const float4 w = *reinterpret_cast<const float4*>(swo + 16 * cc + 4 * g);
-        if (valid)
-          *reinterpret_cast<float4*>(a.gu_mf + tup * D + 16 * cc + 4 * g) =
-              make_float4(w.x * S[cc][0], w.y * S[cc][1], w.z * S[cc][2], w.w * S[cc][3]);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {   // dw_mf[k] += sum over the wave's tuples of mf_u[k] S[k]
-          const float t = row_allreduce_sum<16>(mu[cc][e] * S[cc][e]);
-          if (i == 0) wr[2 * L1 + 16 * cc + 4 * g + e] += t;
+          for (int k = 0; k < KG; ++k)
+            *reinterpret_cast<float4*>(a.gu_mlp + tup * D + 16 * (kt0 + k) + 4 * g) = make_float4(acc[k][0], acc[k][1], acc[k][2], acc[k][3]);
         }
       }
 #pragma unroll
@@ -395,7 +432,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             wr[L1 + 16 * nt + 4 * g + r] += y;
           }
         }
-      // dW1u += (sum_c dz_c)^T mlp_u over the workgroup's 64 tuples: strips of all four waves, a quarter of the tiles each
+      float hu[NCU][4];
+      load_row_slices<NCU>(hu, hup);
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
         *reinterpret_cast<float4*>(Tz + i * SZ + 16 * nt + 4 * g) = make_float4(dzs[nt][0], dzs[nt][1], dzs[nt][2], dzs[nt][3]);
@@ -403,6 +441,70 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       for (int cc = 0; cc < NCU; ++cc)
         *reinterpret_cast<float4*>(Th + i * SH + 16 * cc + 4 * g) = make_float4(hu[cc][0], hu[cc][1], hu[cc][2], hu[cc][3]);
     }
+
+    // ---- pass 3: backward of the GMF branch (no MFMA: d mf_i = g w_mf mf_u, d mf_u = w_mf sum_c g_c mf_i) and the mf_i row
+    // updates -- kept out of pass 2, whose MFMA pipelines need the registers these rows would occupy ----------------------
+    {
+      float mu[NCU][4], S[NCU][4], mn[NCU][4];
+      load_row_slices<NCU>(mu, mup);
+#pragma unroll
+      for (int cc = 0; cc < NCU; ++cc)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) S[cc][e] = 0.f;
+      int64_t it0 = ip[0], it1 = ip[C > 1 ? 1 : 0];
+      load_row_slices<NCU>(mn, a.mf_i + it0 * D + 4 * g);
+      for (int c = 0; c < C; ++c) {
+        float mx[NCU][4];
+#pragma unroll
+        for (int cc = 0; cc < NCU; ++cc)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) mx[cc][e] = mn[cc][e];
+        const int64_t item_c = it0;
+        const uint8_t mflag = a.multi[item_c];
+        it0 = it1;
+        if (c + 1 < C) {
+          load_row_slices<NCU>(mn, a.mf_i + it0 * D + 4 * g);
+          it1 = ip[c + 2 < C ? c + 2 : C - 1];
+        }
+        const float gc = sp[c * 16 + i];
+        const bool single = mflag == 0;
+        float* grow = a.g_mf_i + (tup * C + c) * D + 4 * g;
+#pragma unroll
+        for (int cc = 0; cc < NCU; ++cc) {
+          const float4 w = *reinterpret_cast<const float4*>(swo + 16 * cc + 4 * g);
+          const float4 gr = make_float4(gc * (w.x * mu[cc][0]), gc * (w.y * mu[cc][1]), gc * (w.z * mu[cc][2]), gc * (w.w * mu[cc][3]));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) S[cc][e] = fmaf(gc, mx[cc][e], S[cc][e]);
+          if (valid) {
+            const float4 w0 = make_float4(mx[cc][0], mx[cc][1], mx[cc][2], mx[cc][3]);
+            if (MODE == MODE_SGD) {
+              float4 w1 = w0, m0 = w0, v0 = w0;
+              opt_apply4<MODE_SGD>(a.opt, w1, m0, v0, gr);
+              float* dst = single ? (a.mf_i + item_c * D + 16 * cc + 4 * g) : (grow + 16 * cc);
+              store_row4(reinterpret_cast<float4*>(dst), single ? w1 : gr);
+            } else if (single) {
+              opt_row4<MODE>(a.opt, a.mf_i, a.m_mf_i, a.v_mf_i, (size_t)(item_c * D + 16 * cc + 4 * g) / 4, w0, gr);
+            } else {
+              *reinterpret_cast<float4*>(grow + 16 * cc) = gr;
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int cc = 0; cc < NCU; ++cc) {
+        const float4 w = *reinterpret_cast<const float4*>(swo + 16 * cc + 4 * g);
+        if (valid)
+          *reinterpret_cast<float4*>(a.gu_mf + tup * D + 16 * cc + 4 * g) =
+              make_float4(w.x * S[cc][0], w.y * S[cc][1], w.z * S[cc][2], w.w * S[cc][3]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {   // dw_mf[k] += sum over the wave's tuples of mf_u[k] S[k]
+          const float t = row_allreduce_sum<16>(mu[cc][e] * S[cc][e]);
+          if (i == 0) wr[2 * L1 + 16 * cc + 4 * g + e] += t;
+        }
+      }
+    }
+
+    // ---- dW1u += (sum_c dz_c)^T mlp_u over the workgroup's 64 tuples: strips of all four waves, a quarter of the tiles each ----
     __syncthreads();
     for (int w2 = 0; w2 < 4; ++w2) {
       const float* Tz2 = tb + w2 * per_wave;
@@ -453,24 +555,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 }
 
 // ---- singleton / multi-occurrence classification of the batch's item ids ------------------------------------------------
-// seen1 / seen2: bitmaps over item ids, all zero between steps.  bit(seen2, id) = 1 iff id occurs at least twice: the
-// second and every later occurrence finds the bit of the first in seen1.  Integer atomics, order-free: the final state
-// does not depend on the schedule.  neumf_unmark_kernel restores the zeros (words the batch touched only).
-__global__ __launch_bounds__(256) void neumf_mark_kernel(const int64_t* __restrict__ ids, int64_t n, uint32_t* seen1, uint32_t* seen2) {
+// Plain stores only (the first version used atomicOr on two bitmaps: 60 us, the Zipf head's ~4 K occurrences of ONE id
+// serialise on one L2 address).  Pass 1: owner[id] = batch position -- whichever occurrence lands last owns the row.  Pass 2:
+// every occurrence that does not own its row marks it, multi[id] = 1.  A row with one occurrence has no loser; a row with k >= 2
+// has k - 1 of them, whoever won: the FLAGS do not depend on the schedule.  owner needs no initial value (read only where this
+// batch wrote it); multi is all zero between steps (neumf_unmark_kernel clears what the batch set).
+__global__ __launch_bounds__(256) void neumf_mark_owner_kernel(const int64_t* __restrict__ ids, int64_t n, uint32_t* __restrict__ owner) {
   const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (k >= n) return;
-  const int64_t id = ids[k];
-  const uint32_t bit = 1u << (id & 31);
-  const uint32_t old = atomicOr(seen1 + (id >> 5), bit);
-  if (old & bit) atomicOr(seen2 + (id >> 5), bit);
+  if (k < n) owner[ids[k]] = (uint32_t)k;
 }
 
-__global__ __launch_bounds__(256) void neumf_unmark_kernel(const int64_t* __restrict__ ids, int64_t n, uint32_t* seen1, uint32_t* seen2) {
+__global__ __launch_bounds__(256) void neumf_mark_multi_kernel(const int64_t* __restrict__ ids, int64_t n, const uint32_t* __restrict__ owner,
+                                                               uint8_t* __restrict__ multi) {
   const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (k >= n) return;
   const int64_t id = ids[k];
-  seen1[id >> 5] = 0u;
-  seen2[id >> 5] = 0u;
+  if (owner[id] != (uint32_t)k) multi[id] = 1;
+}
+
+__global__ __launch_bounds__(256) void neumf_unmark_kernel(const int64_t* __restrict__ ids, int64_t n, uint8_t* __restrict__ multi) {
+  const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (k < n) multi[ids[k]] = 0;
 }
 
 // (defined in neumf.hip) out[i] = sum_w p[w][i] for the three partial arrays, fixed order
@@ -492,7 +597,7 @@ static int step_grid(int B) {
   const int64_t rounds = ((int64_t)B + 63) / 64;
   static const int per_cu = [] {
     const char* v = getenv("RC_NEUMF_STEP_WGS_PER_CU");   // workgroups per CU over the launch (A/B: partial size vs balance)
-    const int k = (v && *v) ? atoi(v) : 2;
+    const int k = (v && *v) ? atoi(v) : 1;
     return k < 1 ? 1 : k;
   }();
   int64_t grid = (int64_t)device_cus() * per_cu;
@@ -535,18 +640,18 @@ extern "C" size_t rc_neumf_train_step_workspace_bytes(int B, int C, int d, int l
   return align_up((size_t)step_grid(B) * per * sizeof(float), 256) + 256;
 }
 
-extern "C" size_t rc_neumf_train_step_bitmap_bytes(int64_t n_items) {
-  return n_items < 1 ? 0 : 2 * align_up((size_t)((n_items + 31) / 32) * sizeof(uint32_t), 256);
+extern "C" size_t rc_neumf_train_step_marks_bytes(int64_t n_items) {
+  return n_items < 1 ? 0 : align_up((size_t)n_items * sizeof(uint32_t), 256) + align_up((size_t)n_items, 256);
 }
 
 extern "C" int rc_neumf_train_step(float* mf_u, float* mf_i, float* mlp_u, float* mlp_i, float* m_mf_i, float* v_mf_i,
                                    float* m_mlp_i, float* v_mlp_i, const float* W1, const float* b1, const float* w_out,
                                    const int64_t* uid, const int64_t* iid, int B, int C, int d, int l1, int64_t n_items,
-                                   void* bitmap, const rc_opt_hyper* h, float inv_b, float* loss_vec, float* pred,
+                                   void* marks, const rc_opt_hyper* h, float inv_b, float* loss_vec, float* pred,
                                    float* g_mf_i, float* g_mlp_i, float* gu_mf, float* gu_mlp, float* dW1, float* db1,
                                    float* dw_out, void* ws, size_t ws_bytes, rc_stream_t stream) {
   if (B == 0) return RC_OK;
-  RC_REQUIRE(mf_u && mf_i && mlp_u && mlp_i && W1 && b1 && w_out && uid && iid && bitmap && loss_vec && g_mf_i && g_mlp_i && gu_mf &&
+  RC_REQUIRE(mf_u && mf_i && mlp_u && mlp_i && W1 && b1 && w_out && uid && iid && marks && loss_vec && g_mf_i && g_mlp_i && gu_mf &&
                  gu_mlp && dW1 && db1 && dw_out && ws,
              "rc_neumf_train_step: null pointer");
   RC_REQUIRE(B > 0 && C >= 2 && n_items >= 1, "rc_neumf_train_step: bad shape B=%d C=%d n_items=%lld", B, C, (long long)n_items);
@@ -563,16 +668,17 @@ extern "C" int rc_neumf_train_step(float* mf_u, float* mf_i, float* mlp_u, float
   RC_REQUIRE(!mode_has_v(mode) || (v_mf_i && v_mlp_i), "rc_neumf_train_step: optimizer %d needs the v state of the item tables", h->opt);
   hipStream_t s = as_stream(stream);
   const int64_t n = (int64_t)B * C;
-  const size_t half = rc_neumf_train_step_bitmap_bytes(n_items) / 2;
-  uint32_t* seen1 = reinterpret_cast<uint32_t*>(bitmap);
-  uint32_t* seen2 = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(bitmap) + half);
+  RC_REQUIRE(n < ((int64_t)1 << 32), "rc_neumf_train_step: B C = %lld positions do not fit the 32-bit owner map", (long long)n);
+  uint32_t* owner = reinterpret_cast<uint32_t*>(marks);
+  uint8_t* multi = reinterpret_cast<uint8_t*>(marks) + align_up((size_t)n_items * sizeof(uint32_t), 256);
   const unsigned mark_blocks = (unsigned)((n + 255) / 256);
-  hipLaunchKernelGGL(neumf_mark_kernel, dim3(mark_blocks), dim3(256), 0, s, iid, n, seen1, seen2);
+  hipLaunchKernelGGL(neumf_mark_owner_kernel, dim3(mark_blocks), dim3(256), 0, s, iid, n, owner);
+  hipLaunchKernelGGL(neumf_mark_multi_kernel, dim3(mark_blocks), dim3(256), 0, s, iid, n, owner, multi);
   RC_LAUNCH_CHECK();
   a.mf_u = mf_u; a.mf_i = mf_i; a.mlp_u = mlp_u; a.mlp_i = mlp_i;
   a.m_mf_i = m_mf_i; a.v_mf_i = v_mf_i; a.m_mlp_i = m_mlp_i; a.v_mlp_i = v_mlp_i;
   a.W1 = W1; a.b1 = b1; a.w_out = w_out; a.uid = uid; a.iid = iid; a.B = B; a.C = C; a.inv_b = inv_b;
-  a.multi = seen2; a.loss_vec = loss_vec; a.pred = pred; a.g_mf_i = g_mf_i; a.g_mlp_i = g_mlp_i; a.gu_mf = gu_mf; a.gu_mlp = gu_mlp;
+  a.multi = multi; a.loss_vec = loss_vec; a.pred = pred; a.g_mf_i = g_mf_i; a.g_mlp_i = g_mlp_i; a.gu_mf = gu_mf; a.gu_mlp = gu_mlp;
   const int grid = step_grid(B);
   const int cW = l1 * 2 * d, cb = l1, co = d + l1;
   float* p = reinterpret_cast<float*>(ws);
@@ -583,8 +689,8 @@ extern "C" int rc_neumf_train_step(float* mf_u, float* mf_i, float* mlp_u, float
   if (mode == MODE_SGD) rc = dispatch_step<MODE_SGD>(a, d, l1, grid, s);
   else if (mode == MODE_ADAM) rc = dispatch_step<MODE_ADAM>(a, d, l1, grid, s);
   else rc = dispatch_step<MODE_ADAGRAD>(a, d, l1, grid, s);
-  // the bitmaps go back to zero whatever happened to the step
-  hipLaunchKernelGGL(neumf_unmark_kernel, dim3(mark_blocks), dim3(256), 0, s, iid, n, seen1, seen2);
+  // the flags go back to zero whatever happened to the step
+  hipLaunchKernelGGL(neumf_unmark_kernel, dim3(mark_blocks), dim3(256), 0, s, iid, n, multi);
   RC_TRY(rc);
   RC_LAUNCH_CHECK();
   return neumf_reduce_partials(a.pW1, a.pb1, a.pwout, dW1, db1, dw_out, cW, cb, co, grid, s);

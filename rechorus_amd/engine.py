@@ -268,12 +268,13 @@ class Plan:
     def _side(self, side):
         return (self.rows_a, self.cnt, 0) if side == "a" else (self.rows_b, self.cnt[4:], self.n_a)
 
-    def update_pair(self, side, Wa, Wb, src_a, src_b, hyper, ma=None, va=None, mb=None, vb=None):
-        """rc_plan_update_pair on list `side` ('a' | 'b'): two tables sharing the ids, per-occurrence gradient rows"""
+    def update_pair(self, side, Wa, Wb, src_a, src_b, hyper, ma=None, va=None, mb=None, vb=None, ws_tag=""):
+        """rc_plan_update_pair on list `side` ('a' | 'b'): two tables sharing the ids, per-occurrence gradient rows.
+        ws_tag: suffix of the scratch buffer's cache key -- two updates that run at the same time on two streams need two"""
         d = Wa.shape[1]
         n = self.n_a + self.n_b
         rows, cnt, base = self._side(side)
-        ws = workspace(_lib.load().rc_plan_update_workspace_bytes(n, 2 * d), Wa.device, self.tag + ".upd")
+        ws = workspace(_lib.load().rc_plan_update_workspace_bytes(n, 2 * d), Wa.device, self.tag + ".upd" + ws_tag)
         f32 = torch.float32
         p = lambda t: C.c_void_p(t.data_ptr())
         _lib.call("rc_plan_update_pair", _ptr(Wa, f32, "W_a"), _ptr(ma, f32, "m_a", True), _ptr(va, f32, "v_a", True),
@@ -649,10 +650,10 @@ def neumf_train_step_supported(Cn, d, l1):
     return bool(_lib.load().rc_neumf_train_step_supported(int(Cn), int(d), int(l1)))
 
 
-def neumf_train_step(P, state, uid, iid, hyper, bitmap, out, inv_b=None, pred=None):
+def neumf_train_step(P, state, uid, iid, hyper, marks, out, inv_b=None, pred=None):
     """rc_neumf_train_step: forward + BPR loss + backward + in-place update of single-occurrence item rows.
-    state: {table: {"m": .., "v": ..}} of the optimizer; bitmap: zeroed uint8 buffer of rc_neumf_train_step_bitmap_bytes(n_items)
-    (left zeroed); out: dict of preallocated buffers loss_vec [B], g_mf_i / g_mlp_i [B C, d], gu_mf / gu_mlp [B, d], W1 / b1 / w_out
+    state: {table: {"m": .., "v": ..}} of the optimizer; marks: uint8 buffer of rc_neumf_train_step_marks_bytes(n_items), zeroed
+    once (every call leaves it ready for the next); out: dict of preallocated buffers loss_vec [B], g_mf_i / g_mlp_i [B C, d], gu_mf / gu_mlp [B, d], W1 / b1 / w_out
     gradients.  Returns nothing: the caller finishes the step with the plan's pair updates and the dense update."""
     B, Cn = iid.shape
     d, l1 = P["mf_u"].shape[1], P["W1"].shape[0]
@@ -664,7 +665,7 @@ def neumf_train_step(P, state, uid, iid, hyper, bitmap, out, inv_b=None, pred=No
               _ptr(P["mlp_i"], f32, "mlp_i"), st("mf_i", "m"), st("mf_i", "v"), st("mlp_i", "m"), st("mlp_i", "v"),
               _ptr(P["W1"], f32, "W1"), _ptr(P["b1"], f32, "b1"), _ptr(P["w_out"], f32, "w_out"),
               _ptr(uid, torch.int64, "uid"), _ptr(iid, torch.int64, "iid"), B, Cn, d, l1, int(P["mf_i"].shape[0]),
-              C.c_void_p(bitmap.data_ptr()), C.byref(hyper), float(1.0 / B if inv_b is None else inv_b),
+              C.c_void_p(marks.data_ptr()), C.byref(hyper), float(1.0 / B if inv_b is None else inv_b),
               _ptr(out["loss_vec"], f32, "loss_vec"), _ptr(pred, f32, "pred", True),
               _ptr(out["g_mf_i"], f32, "g_mf_i"), _ptr(out["g_mlp_i"], f32, "g_mlp_i"), _ptr(out["gu_mf"], f32, "gu_mf"),
               _ptr(out["gu_mlp"], f32, "gu_mlp"), _ptr(out["W1"], f32, "dW1"), _ptr(out["b1"], f32, "db1"),
@@ -719,7 +720,9 @@ class NeumfTrainer:
         self.loss = None
         self._side = None
 
-    def step(self, uid, iid):
+    def step(self, uid, iid, next_batch=None):
+        """next_batch = (uid, iid) of the FOLLOWING call (the very tensors it will bring, unmodified until then): the fused step
+        builds their bucket plan beside this step's table updates, off the critical path."""
         P = self.P
         B, Cn = iid.shape
         self.step_count += 1
@@ -732,7 +735,7 @@ class NeumfTrainer:
         # bound by the host's launch rate and the stream switches cost more than they return)
         if (use_plan and _NEUMF_FUSED and self.dropout == 0.0 and self.opt in ("SGD", "Adam", "Adagrad") and Cn >= 2
                 and neumf_train_step_supported(Cn, P["mf_u"].shape[1], P["W1"].shape[0])):
-            return self._step_fused(uid, iid)
+            return self._step_fused(uid, iid, next_batch)
         overlap = use_plan and _NEUMF_OVERLAP and iid.is_cuda and iid.numel() >= _SAS_OVERLAP_MIN
         plan = plan_done = main = None
         if overlap:
@@ -780,48 +783,79 @@ class NeumfTrainer:
                                 for k in ("W1", "b1", "w_out")], self.opt)
         return self.loss
 
-    def _step_fused(self, uid, iid):
+    @staticmethod
+    def _batch_key(uid, iid):
+        """identity of a batch's id tensors (storage, shape and torch's in-place version counters): a plan prepared for them is
+        used only if the following call brings exactly these tensors, untouched"""
+        return (uid.data_ptr(), iid.data_ptr(), tuple(uid.shape), tuple(iid.shape), uid._version, iid._version)
+
+    def _step_fused(self, uid, iid, next_batch=None):
         """The step on rc_neumf_train_step (csrc/neumf_step.hip): ONE kernel for forward, loss, backward and the in-place update
-        of single-occurrence item rows; the bucket plan of the batch (item side: multi-occurrence rows only; user side per
-        tuple) is built on a second stream meanwhile and consumed by two pair updates."""
+        of single-occurrence item rows, then two pair updates from the bucket plan of the batch (item side: multi-occurrence rows
+        only; user side: one gradient row per tuple) on two streams.  The fused kernel leaves no register for a co-resident wave,
+        so a plan built beside it would wait for its workgroups to retire: the plan of the NEXT batch is built beside this
+        step's table updates instead (next_batch), the batch's own plan only when nobody announced it."""
         P = self.P
         B, Cn = iid.shape
         dev = iid.device
         d = P["mf_u"].shape[1]
         n_u, n_i = P["mf_u"].shape[0], P["mf_i"].shape[0]
-        if getattr(self, "_bitmap", None) is None:
-            self._bitmap = torch.zeros(max(int(_lib.load().rc_neumf_train_step_bitmap_bytes(n_i)), 1), dtype=torch.uint8, device=dev)
+        if getattr(self, "_marks", None) is None:
+            self._marks = torch.zeros(max(int(_lib.load().rc_neumf_train_step_marks_bytes(n_i)), 1), dtype=torch.uint8, device=dev)
         key = (B, Cn, str(dev))
         if getattr(self, "_fused_out", (None,))[0] != key:
             e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
             self._fused_out = (key, {"loss_vec": e(B), "g_mf_i": e(B * Cn, d), "g_mlp_i": e(B * Cn, d), "gu_mf": e(B, d), "gu_mlp": e(B, d),
                                      "W1": torch.empty_like(P["W1"]), "b1": torch.empty_like(P["b1"]), "w_out": torch.empty_like(P["w_out"])})
         out = self._fused_out[1]
-        overlap = _NEUMF_OVERLAP and iid.numel() >= _SAS_OVERLAP_MIN
-        plan = plan_done = main = None
-        if overlap:
-            if self._side is None:
-                self._side = torch.cuda.Stream(device=dev)
-            main, side = torch.cuda.current_stream(dev), self._side
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                plan = Plan(iid, n_i, uid, n_u, tag="neumf", list_single_a=False)
-                plan_done = side.record_event()
+        two_streams = _NEUMF_OVERLAP and iid.numel() >= _SAS_OVERLAP_MIN
+        main = torch.cuda.current_stream(dev)
+        if two_streams and self._side is None:
+            self._side, self._side2 = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+        ahead = getattr(self, "_ahead", None)
+        self._ahead = None
+        plan = plan_done = None
+        if ahead is not None and ahead[0] == self._batch_key(uid, iid):
+            _, plan, plan_done = ahead
+        elif two_streams:
+            self._side.wait_stream(main)
+            with torch.cuda.stream(self._side):
+                plan = Plan(iid, n_i, uid, n_u, tag="neumf%d" % (self.step_count & 1), list_single_a=False)
+                plan_done = self._side.record_event()
         h = make_hyper(self.opt, lr=self.lr, l2=self.l2, step=self.step_count)
         h0 = make_hyper(self.opt, lr=self.lr, l2=0.0, step=self.step_count)
         with _PhaseTimer(self, "fused_step"):
-            neumf_train_step(P, self.state, uid, iid, h, self._bitmap, out)
+            neumf_train_step(P, self.state, uid, iid, h, self._marks, out)
+        if two_streams and next_batch is not None:
+            # the following batch's plan: behind the fused kernel on the second stream, i.e. beside the updates below; its
+            # buffers alternate with this batch's (tag by step parity)
+            nu, ni = next_batch
+            self._side.wait_stream(main)
+            with torch.cuda.stream(self._side):
+                nplan = Plan(ni, n_i, nu, n_u, tag="neumf%d" % ((self.step_count + 1) & 1), list_single_a=False)
+                self._ahead = (self._batch_key(nu, ni), nplan, self._side.record_event())
         with _PhaseTimer(self, "loss"):
             self.loss = reduce_sum(out["loss_vec"], 1.0 / B)
         with _PhaseTimer(self, "sort"):
-            if overlap:
+            if plan is None:
+                plan = Plan(iid, n_i, uid, n_u, tag="neumf%d" % (self.step_count & 1), list_single_a=False)
+            elif plan_done is not None:
                 main.wait_event(plan_done)
-            else:
-                plan = Plan(iid, n_i, uid, n_u, tag="neumf", list_single_a=False)
         with _PhaseTimer(self, "table_update"):
-            for side_, ta, tb, ga, gb in (("a", "mf_i", "mlp_i", out["g_mf_i"], out["g_mlp_i"]), ("b", "mf_u", "mlp_u", out["gu_mf"], out["gu_mlp"])):
+            sides = (("a", "mf_i", "mlp_i", out["g_mf_i"], out["g_mlp_i"]), ("b", "mf_u", "mlp_u", out["gu_mf"], out["gu_mlp"]))
+
+            def upd(side_, ta, tb, ga, gb):
                 sa, sb = self.state[ta], self.state[tb]
-                plan.update_pair(side_, P[ta], P[tb], ga, gb, h, ma=sa.get("m"), va=sa.get("v"), mb=sb.get("m"), vb=sb.get("v"))
+                plan.update_pair(side_, P[ta], P[tb], ga, gb, h, ma=sa.get("m"), va=sa.get("v"), mb=sb.get("m"), vb=sb.get("v"), ws_tag=side_)
+            if two_streams:   # item tables and user tables are disjoint: the two updates run side by side
+                self._side2.wait_stream(main)
+                with torch.cuda.stream(self._side2):
+                    upd(*sides[1])
+                upd(*sides[0])
+                main.wait_stream(self._side2)
+            else:
+                upd(*sides[0])
+                upd(*sides[1])
         with _PhaseTimer(self, "dense_update"):
             dense_update_multi([(P[k], out[k], h0 if k == "b1" else h, self.state[k].get("m"), self.state[k].get("v"))
                                 for k in ("W1", "b1", "w_out")], self.opt)
@@ -1142,7 +1176,8 @@ class SasrecTrainer:
         if not hgraph.usable():
             raise RuntimeError("SasrecTrainer(graph=True): hipGraph replay needs DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 before HIP "
                                "initialises (rechorus_amd/graph.py); import rechorus_amd before touching the GPU")
-        key = (tuple(hist.shape), tuple(iid.shape))
+        # lr / l2 / the optimizer are kernel arguments frozen into a captured step: they are part of the key
+        key = (tuple(hist.shape), tuple(iid.shape), self.opt, float(self.lr), float(self.l2))
         entry = self._graphs.get(key)
         if entry is None:
             seen = self._graph_seen.get(key, 0)
@@ -1159,12 +1194,16 @@ class SasrecTrainer:
             with torch.cuda.stream(cap):
                 with torch.cuda.graph(g, stream=cap):
                     self._step(*static[:3])
+            self.step_count -= 1   # the capture recorded a step, it did not train one (its device-side increments are graph nodes)
             entry = self._graphs[key] = (g, static, self.loss)
             torch.cuda.synchronize(hist.device)
             # (the capture recorded the step without running it: this batch is trained by the replay below)
         g, static, loss = entry
         torch.cat([hist.reshape(-1), lengths.reshape(-1), iid.reshape(-1)], out=static[3])
         g.replay()
+        # the host's count follows every trained step -- replayed or eager -- so that a batch shape that leaves the captured route
+        # (the short last batch of an epoch) steps Adam with the right bias corrections
+        self.step_count += 1
         self.loss = loss
         return loss
 

@@ -86,9 +86,11 @@ class NeuMF(GeneralModel):
     def hip_rowwise_supported(self):
         return self._fused_ok()
 
-    def hip_train_step(self, feed_dict, opt_name, lr, l2):
-        """forward (MFMA) + BPR loss + backward (MFMA) + row-wise segmented update of touched table rows
-        + dense step of the MLP (engine.NeumfTrainer); returns the device loss tensor"""
+    def hip_train_step(self, feed_dict, opt_name, lr, l2, next_feed_dict=None):
+        """one fit iteration on engine.NeumfTrainer: without dropout ONE kernel for forward, BPR loss, backward and the in-place
+        update of single-occurrence item rows (rc_neumf_train_step) + the plan's pair updates + the dense step of the MLP;
+        returns the device loss tensor.  next_feed_dict: the batch the following call will bring (BaseRunner.fit passes it): its
+        bucket plan is built beside this step's table updates."""
         if not self._fused_ok():
             raise RuntimeError('NeuMF --engine rowwise needs the fused head: one hidden layer, emb_size and layer '
                                'size in {32, 64, 128}')
@@ -100,6 +102,11 @@ class NeuMF(GeneralModel):
                  'w_out': self.prediction.weight.data.view(-1)}
             tr = self._trainer = engine.NeumfTrainer(P, opt=opt_name, lr=lr, l2=l2, rowwise=True,
                                                      dropout=self.dropout, seed=int(self.drop_seed.item()))
+        nxt = None
+        if next_feed_dict is not None:
+            nu, ni = next_feed_dict['user_id'], next_feed_dict['item_id']
+            if nu.is_contiguous() and ni.is_contiguous():   # (the following call has to bring these very tensors)
+                nxt = (nu, ni)
         with torch.no_grad():
-            return tr.step(feed_dict['user_id'].contiguous(), feed_dict['item_id'].contiguous())
+            return tr.step(feed_dict['user_id'].contiguous(), feed_dict['item_id'].contiguous(), next_batch=nxt)
 

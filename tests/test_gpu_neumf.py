@@ -260,25 +260,26 @@ def _fused_buffers(eng, Pd, B, C, cuda):
     out = {"loss_vec": e(B), "g_mf_i": e(B * C, d), "g_mlp_i": e(B * C, d), "gu_mf": e(B, d), "gu_mlp": e(B, d),
            "W1": torch.empty_like(Pd["W1"]), "b1": torch.empty_like(Pd["b1"]), "w_out": torch.empty_like(Pd["w_out"])}
     from rechorus_amd import _lib
-    bitmap = torch.zeros(int(_lib.load().rc_neumf_train_step_bitmap_bytes(Pd["mf_i"].shape[0])), dtype=torch.uint8, device=cuda)
-    return out, bitmap
+    marks = torch.zeros(int(_lib.load().rc_neumf_train_step_marks_bytes(Pd["mf_i"].shape[0])), dtype=torch.uint8, device=cuda)
+    return out, marks
 
 
 def _check_fused_against(eng, P, Pd, state, uid, iid, opt, lr, l2, step, want_pred, want_loss_rows, G, tol, cuda, what):
     """one rc_neumf_train_step call against reference / oracle quantities: predictions, per-tuple loss, dense gradients, per-tuple
     user gradient rows, single-occurrence item rows after the row-wise optimizer step (and their state), multi-occurrence rows
-    untouched with their gradient rows written, bitmaps back to zero"""
+    untouched with their gradient rows written, the flag bytes back to zero"""
     from oracle import bprmf_oracle as BO
     B, C = iid.shape
-    out, bitmap = _fused_buffers(eng, Pd, B, C, cuda)
+    out, marks = _fused_buffers(eng, Pd, B, C, cuda)
     pred = torch.empty((B, C), dtype=torch.float32, device=cuda)
     W0 = {k: Pd[k].cpu().numpy().copy() for k in ("mf_i", "mlp_i", "mf_u", "mlp_u")}
     S0 = {k: {s: t.cpu().numpy().copy() for s, t in state[k].items()} for k in ("mf_i", "mlp_i")}
     u, i = torch.from_numpy(uid).to(cuda), torch.from_numpy(iid).to(cuda)
     h = eng.make_hyper(opt, lr=lr, l2=l2, step=step)
-    eng.neumf_train_step(Pd, state, u, i, h, bitmap, out, pred=pred)
+    eng.neumf_train_step(Pd, state, u, i, h, marks, out, pred=pred)
     torch.cuda.synchronize()
-    assert not bitmap.any(), what + ": the id bitmaps must be zero again after the step"
+    n_items = Pd["mf_i"].shape[0]
+    assert not marks[(4 * n_items + 255) // 256 * 256:].any(), what + ": the multi-occurrence flags must be zero again after the step"
     assert_close(pred.cpu().numpy(), want_pred, what=what + " pred", atol_scale=tol)
     assert_close(out["loss_vec"].cpu().numpy(), want_loss_rows, what=what + " loss rows", atol_scale=tol)
     assert_close(out["W1"].cpu().numpy(), G["mlp.0.weight"], what=what + " dW1", atol_scale=tol)
@@ -366,8 +367,8 @@ def test_neumf_fused_step_random_shapes_vs_oracle(cuda, eng):
     assert not eng.neumf_train_step_supported(5, 64, 128) and not eng.neumf_train_step_supported(200, 128, 64)
 
 
-@pytest.mark.parametrize("opt", ["SGD", "Adam", "Adagrad"])
-def test_neumf_trainer_fused_equals_three_kernel_step(opt, cuda, eng, monkeypatch):
+@pytest.mark.parametrize("opt,lookahead", [("SGD", True), ("Adam", False), ("Adagrad", True)])
+def test_neumf_trainer_fused_equals_three_kernel_step(opt, lookahead, cuda, eng, monkeypatch):
     """NeumfTrainer (row-wise) on the fused kernel vs the forward / loss / backward / update chain it replaces: two steps, same
     tables, optimizer state and dense parameters to rounding (the kernels sum in different orders)"""
     rng = np.random.default_rng(17)
@@ -384,12 +385,19 @@ def test_neumf_trainer_fused_equals_three_kernel_step(opt, cuda, eng, monkeypatc
         batches.append((torch.from_numpy(uid).to(cuda), torch.from_numpy(iid).to(cuda)))
     lr = 0.05 if opt == "SGD" else 1e-2
     res = []
+    monkeypatch.setattr(eng, "_SAS_OVERLAP_MIN", 0)     # the two-stream paths (plan ahead, the two update sides side by side) at test size
     for fused in (True, False):
         monkeypatch.setattr(eng, "_NEUMF_FUSED", fused)
         P = {k: torch.from_numpy(v).to(cuda) for k, v in P0.items()}
         tr = eng.NeumfTrainer(P, opt=opt, lr=lr, l2=1e-4, rowwise=True)
+        if opt == "Adagrad":
+            # torch's Adagrad starts from state_sum = 0 with eps = 1e-10: the first step of an element is lr * g / |g|, so an
+            # element whose gradient is summation-order noise (|g| ~ 1e-9) moves by a full lr in either implementation; a
+            # non-zero initial accumulator (initial_accumulator_value) makes the comparison well-conditioned
+            for st in tr.state.values():
+                st["m"].fill_(1e-6)
         tr.timing = {}
-        losses = [float(tr.step(u, i).item()) for u, i in batches]
+        losses = [float(tr.step(u, i, next_batch=batches[(k + 1) % 2] if lookahead else None).item()) for k, (u, i) in enumerate(batches)]
         assert ("fused_step" in tr.timing) == fused
         res.append((P, tr.state, losses))
     (Pa, Sa, La), (Pb, Sb, Lb) = res

@@ -396,6 +396,41 @@ def test_sasrec_trainer_graph_replay_equals_eager(opt, overlap, cuda, eng, monke
         eng.SasrecTrainer(to_dev(P, n_layers, cuda), n_heads, opt="Adam", rowwise=False, graph=True)
 
 
+def test_sasrec_trainer_graph_adam_counts_replayed_steps_on_the_host_too(cuda, eng, monkeypatch):
+    """Adam under replay keeps its step count in device memory; a batch shape that leaves the captured route (the short last
+    batch of an epoch: fewer occurrences than the one-wave-per-row update wants) runs eagerly with the HOST's count -- which
+    therefore has to follow the replays.  A stale count (t = 3 after a dozen replays) scales that step by the wrong bias
+    corrections; compared with the eager trainer on the same batch sequence."""
+    from rechorus_amd import graph as hgraph
+    if not hgraph.usable():
+        pytest.skip("hipGraph replay not enabled in this process")
+    rng = np.random.default_rng(23)
+    L, d, n_layers, n_heads, C, n_items = 50, 64, 1, 4, 20, 400
+    P = _random_sasrec(rng, n_items, d, n_layers, L)
+
+    def batch(B):
+        lengths = rng.integers(1, L + 1, size=B).astype(np.int64)
+        hist = rng.integers(1, n_items, size=(B, L)).astype(np.int64) * (np.arange(L)[None, :] < lengths[:, None])
+        iid = rng.integers(1, n_items, size=(B, C)).astype(np.int64)
+        return tuple(torch.from_numpy(x).to(cuda) for x in (hist, lengths, iid))
+    batches = [batch(500) for _ in range(9)] + [batch(24)] + [batch(500) for _ in range(2)]
+    monkeypatch.setattr(eng, "_SAS_OVERLAP_MIN", 0)
+    out = {}
+    for graph in (False, True):
+        Pd = to_dev(P, n_layers, cuda)
+        tr = eng.SasrecTrainer(Pd, n_heads, opt="Adam", lr=1e-2, l2=1e-5, rowwise=True, graph=graph)
+        assert not graph or not tr._dev_step_route(batches[9][0], batches[9][2])   # the short batch is off the captured route
+        losses = [float(tr.step(*b)[0]) for b in batches]
+        torch.cuda.synchronize()
+        assert tr.step_count == len(batches)
+        if graph:
+            assert int(tr._step_dev.item()) == len(batches) and len(tr._graphs) == 1
+        out[graph] = (losses, Pd["item_emb"].cpu().numpy(), Pd["pos_emb"].cpu().numpy())
+    assert np.allclose(out[True][0], out[False][0], rtol=1e-5, atol=0)
+    assert_close(out[True][1], out[False][1], what="item table", rtol=1e-5, atol_scale=1e-6)
+    assert_close(out[True][2], out[False][2], what="position table", rtol=1e-5, atol_scale=1e-6)
+
+
 @pytest.mark.parametrize("rowwise", [False, True])
 def test_sasrec_trainer_two_streams_equal_one_stream(rowwise, cuda, eng, monkeypatch):
     """SasrecTrainer sorts the batch's ids beside the encoder and forms the position-table gradient beside the item-table
