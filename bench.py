@@ -67,6 +67,10 @@ def parse():
     ap.add_argument("--parallel", default="sharded", choices=["sharded", "replicas"],
                     help="N>1: row-sharded tables + owner-computes exchange (default), or independent replicas")
     ap.add_argument("--mlp", default="[512,64]", help="deepfm: hidden layers of the deep tower (CTR_MIND.sh:8)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="the contract workload only: skip the short legs of the other BASELINE configs that the default run attaches "
+                         "as `secondary` (NeuMF at 10 M and 100 M items, SASRec, DeepFM at two batch sizes; N > 1: sharded NeuMF on the "
+                         "100 M-item table)")
     args = ap.parse_args()
     if args.workload == "deepfm":  # configs[4]: the reference's CTR script shape unless overridden
         if args.batch == 65536:
@@ -472,6 +476,11 @@ def model_roofline(args, trainer, batches, engine):
         v2 = ok and want >= 2 and H in (1, 2, 4) and max(3, H + 1) <= L <= 128 and (d // H) % (d * d // 256) == 0
         v1 = ok and 2 <= L <= 64 and (d // H) in (16, 32, 64) and B * L >= int(os.environ.get("RC_SAS_LAST_ROW_MIN", "32768"))
         mode = 2 if v2 else (1 if v1 else 0)
+        out["encoder_path"] = {2: "last block on ONE query row per sequence without keys / values (csrc/sas_last_row.hpp: wave reductions, "
+                                  "HBM-bound); lower blocks, if any, on all rows with fp32 MFMA attention",
+                               1: "last block: K / V projections on all rows (fp32 MFMA), attention for one query row per sequence",
+                               0: "every block on all rows: fp32 MFMA projections + register-resident MFMA attention "
+                                  "(csrc/sasrec_batch.hip, sas_attn_reg.hpp)"}[mode]
         last = {0: full, 1: R * 4.0 * d * d + B * 6.0 * d * d + 4.0 * R * d, 2: B * 10.0 * d * d + 4.0 * R * H * d}[mode]
         fwd = (nl - 1) * full + last
         flops = {"encoder_fwd": fwd, "encoder_bwd": 2.0 * fwd}
@@ -526,19 +535,25 @@ def _free_port():
         return sk.getsockname()[1]
 
 
-def launch_ranks(n):
-    """`python bench.py --gpus N` without a launcher: start N rank processes of this very command line (one per GPU,
-    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, rendezvous on 127.0.0.1), pass rank 0's output
-    through, and fail if any rank fails (the others are then stopped by their exact PIDs)."""
+def launch_ranks(n, argv=None, capture=False):
+    """`python bench.py --gpus N` without a launcher: start N rank processes of this command line (or of `argv`), one per GPU,
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, rendezvous on 127.0.0.1; fail if any rank fails (the
+    others are then stopped by their exact PIDs).  capture: return rank 0's stdout instead of passing it through.
+    -> (exit code, rank 0's stdout or None)"""
     import subprocess
+    import tempfile
+    argv = sys.argv[1:] if argv is None else argv
     port = os.environ.get("MASTER_PORT") or str(_free_port())
+    if capture and os.environ.get("MASTER_PORT"):
+        port = str(_free_port())     # several rank groups in one run: a fresh rendezvous port each
     procs = []
+    cap = tempfile.TemporaryFile(mode="w+") if capture else None
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RC_BENCH_CHILD="1")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the host driver only supports dmabuf IPC (RCCL needs it)
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=None if r == 0 else subprocess.DEVNULL))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=(cap if capture else None) if r == 0 else subprocess.DEVNULL))
     rc = 0
     try:
         pending = list(procs)
@@ -557,7 +572,94 @@ def launch_ranks(n):
         for p in procs:
             if p.poll() is None:
                 p.kill()
-    return rc
+    text = None
+    if cap is not None:
+        cap.seek(0)
+        text = cap.read()
+        cap.close()
+    return rc, text
+
+
+# ---- secondary legs: the other BASELINE configs, short, attached to the contract line -------------------------------------
+
+def secondary_wanted(args):
+    """the default invocation of the contract workload carries the other configs; any explicit workload / shape does not"""
+    return (not args.no_secondary and args.workload == "bprmf" and os.environ.get("RC_BENCH_LAUNCH_ONLY") != "1"
+            and not args.graph and args.parallel == "sharded")
+
+
+def _last_json(text):
+    for line in reversed((text or "").strip().splitlines()):
+        line = line.strip()
+        if line.startswith("{"):
+            try:
+                return json.loads(line)
+            except ValueError:
+                continue
+    return None
+
+
+def _summary(j):
+    """what a secondary leg contributes to the contract line"""
+    keep = ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "n_gpus", "dtype", "roofline", "phases_ms", "sharded_phases_ms",
+            "sharded_wire_bytes_rank0", "final_loss", "phases_tflops", "table_update_gbps", "encoder_path")
+    out = {k: j[k] for k in keep if k in j}
+    out["workload"] = (j.get("config") or {}).get("workload")
+    return out
+
+
+SECONDARY_LEGS = (   # name, bench.py arguments (BASELINE.json configs[3] at 10 M and at its full 100 M items, configs[2], configs[4])
+    ("neumf", ["--workload", "neumf"]),
+    ("neumf_100M", ["--workload", "neumf", "--items", "100000001", "--users", "10000001"]),
+    ("sasrec", ["--workload", "sasrec"]),
+    ("deepfm_b1024", ["--workload", "deepfm"]),
+    ("deepfm_b131072", ["--workload", "deepfm", "--batch", "131072", "--steps", "10", "--warmup", "3"]),
+)
+
+
+def secondary_single_gpu(args):
+    """N = 1: every leg is its own process (a fault in one of them cannot take the contract line with it), one after the other
+    on the same GPU, 20 timed steps after 5 of warm-up, live roofline phases, no CPU baseline; a wall-clock budget
+    (RC_BENCH_SECONDARY_BUDGET_S, default 75 s) keeps the driver's one command within minutes."""
+    import subprocess
+    budget = float(os.environ.get("RC_BENCH_SECONDARY_BUDGET_S", "75"))
+    t0 = time.perf_counter()
+    out = {}
+    for name, extra in SECONDARY_LEGS:
+        t_leg = time.perf_counter()
+        left = budget - (t_leg - t0)
+        if left < 8:
+            out[name] = {"skipped": f"wall-clock budget of {budget:.0f} s for the secondary legs used up"}
+            continue
+        cmd = [sys.executable, os.path.abspath(__file__), "--steps", "20", "--warmup", "5"] + extra + ["--no-cpu-baseline", "--no-secondary"]
+        try:
+            p = subprocess.run(cmd, capture_output=True, text=True, timeout=max(left, 10.0))
+            j = _last_json(p.stdout)
+            out[name] = _summary(j) if (p.returncode == 0 and j) else {"failed": (p.stderr or p.stdout or "")[-300:], "rc": p.returncode}
+        except subprocess.TimeoutExpired:
+            out[name] = {"failed": f"did not finish within {left:.0f} s"}
+        out[name]["wall_s"] = round(time.perf_counter() - t_leg, 1)
+    return out
+
+
+SHARDED_LEG = ["--workload", "neumf", "--items", "100000001", "--users", "10000001", "--steps", "20", "--warmup", "5",
+               "--no-cpu-baseline", "--no-secondary"]
+
+
+def secondary_sharded_in_process(args, rank, world, device, dist):
+    """N > 1 under torch.distributed.run: BASELINE configs[3] -- NeuMF emb_size 128, num_neg 4 on the 100,000,001-item /
+    10,000,001-user tables row-sharded over the ranks, SGD -- measured on the ranks of this job after the contract workload"""
+    import copy
+    import gc
+    a = copy.copy(args)
+    a.workload, a.items, a.users, a.emb_size, a.num_neg = "neumf", 100_000_001, 10_000_001, 128, 4
+    a.steps, a.warmup, a.no_cpu_baseline = 20, 5, True
+    gc.collect()
+    torch.cuda.empty_cache()
+    try:
+        return {"neumf_100M": _summary(measure(a, rank, world, device, dist))}
+    except Exception as e:   # the contract line survives a failure of this leg
+        return {"neumf_100M": {"failed": repr(e)[-300:]}}
 
 
 def launch_check(rank, world, backend):
@@ -574,36 +676,9 @@ def launch_check(rank, world, backend):
                           "env": {k: os.environ.get(k) for k in ("WORLD_SIZE", "MASTER_ADDR", "LOCAL_RANK")}}))
 
 
-def main():
-    args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        # not started by a launcher: be the launcher
-        raise SystemExit(launch_ranks(args.gpus))
-    if os.environ.get("RC_BENCH_LAUNCH_ONLY") == "1":
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        return launch_check(rank, world, "gloo")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
-    # RC_BENCH_ONE_DEVICE=1 + --dist-backend gloo: smoke-test the N>1 code path on a 1-GPU box
-    # (all ranks on cuda:0, collectives staged through the host) -- not a measurement mode
-    if os.environ.get("RC_BENCH_ONE_DEVICE") == "1":
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.dist_backend == "nccl":  # RCCL over xGMI
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-        else:
-            dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
-
+def measure(args, rank, world, device, dist):
+    """one workload on the ranks of this job: warm-up, the timed steps between barriers, then (outside the timed region) the
+    live roofline phases and the CPU baseline -> the JSON object of the line"""
     from rechorus_amd import engine
 
     batches = make_batches(args, device, seed=99 + rank) if args.workload not in ("sasrec", "deepfm") else None
@@ -785,6 +860,27 @@ def main():
             out["roofline"]["alone"] = {"avg_ms": alone[dom], "achieved": ab[dom] / (alone[dom] * 1e-3) / 1e9,
                                         "frac": ab[dom] / (alone[dom] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                                         "note": "same kernel with nothing beside it (bucket plan on one stream)"}
+        if dom == "fused_fwd_bwd" and args.emb_size in (32, 64, 128):
+            # what THIS box delivers for the kernel's access mix (rc_bench_mix: the batch's own ids, every occurrence reads its
+            # row, the single-occurrence share writes it back, no arithmetic), in the currency of `achieved`: the kernel's
+            # algorithmic bytes over the time the bare accesses take
+            try:
+                import ctypes as C
+                from rechorus_amd import _lib as _rl
+                ids = batches[0][1].reshape(-1)
+                wf = ab["single_items"] / float(ids.numel())
+                sink = torch.zeros(1, dtype=torch.float32, device=device)
+                ms = C.c_float(0.0)
+                _rl.call("rc_bench_mix", C.c_void_p(trainer.I.data_ptr()), args.emb_size, C.c_void_p(ids.data_ptr()), ids.numel(),
+                         C.c_float(wf), 10, C.c_void_p(sink.data_ptr()), C.byref(ms), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+                ceiling = ab[dom] / (ms.value * 1e-3) / 1e9
+                out["roofline"]["box_ceiling_gbps"] = ceiling
+                out["roofline"]["frac_of_box_ceiling"] = achieved / ceiling
+                out["roofline"]["box_ceiling_note"] = (f"rc_bench_mix on this box, in this run: the access mix of the kernel without its arithmetic "
+                                                       f"({ids.numel()} row reads of {4 * args.emb_size} B, {wf:.2f} of them written back, int64 ids) takes "
+                                                       f"{ms.value:.4f} ms; ceiling = the kernel's algorithmic bytes over that time")
+            except Exception as e:
+                out["roofline"]["box_ceiling_note"] = "rc_bench_mix failed: " + repr(e)[-200:]
         out["phases_gbps"] = {k: round(ab[k] / (acc[k] * 1e-3) / 1e9, 1)
                               for k in ("fused_fwd_bwd", "item_update", "user_update") if acc.get(k, 0) > 0}
         out["uniq_rows_per_step"] = {"items": ab["uniq_items"], "users": ab["uniq_users"],
@@ -833,6 +929,59 @@ def main():
         n_cpu = args.cpu_steps + 1
         out["cpu_baseline"] = cpu_baseline_model(args, [tuple(t.cpu() for t in batches[s % len(batches)]) for s in range(n_cpu)])
 
+    return out
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        # not started by a launcher: be the launcher.  The contract workload's ranks first; then -- its own rank group, so that a
+        # failure there cannot take the contract line with it -- the config-4 leg, attached as secondary.neumf_100M
+        if not secondary_wanted(args):
+            raise SystemExit(launch_ranks(args.gpus)[0])
+        rc, text = launch_ranks(args.gpus, sys.argv[1:] + ["--no-secondary"], capture=True)
+        line = _last_json(text)
+        if rc != 0 or line is None:
+            sys.stdout.write(text or "")
+            raise SystemExit(rc or 1)
+        rc2, text2 = launch_ranks(args.gpus, ["--gpus", str(args.gpus), "--dist-backend", args.dist_backend] + SHARDED_LEG, capture=True)
+        j2 = _last_json(text2)
+        line["secondary"] = {"neumf_100M": _summary(j2) if (rc2 == 0 and j2) else {"failed": (text2 or "")[-300:], "rc": rc2}}
+        print(json.dumps(line))
+        return
+    if os.environ.get("RC_BENCH_LAUNCH_ONLY") == "1":
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        return launch_check(rank, world, "gloo")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    # RC_BENCH_ONE_DEVICE=1 + --dist-backend gloo: smoke-test the N>1 code path on a 1-GPU box
+    # (all ranks on cuda:0, collectives staged through the host) -- not a measurement mode
+    if os.environ.get("RC_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.dist_backend == "nccl":  # RCCL over xGMI
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
+
+    out = measure(args, rank, world, device, dist)
+    if rank == 0 and world == 1 and secondary_wanted(args):
+        out["secondary"] = secondary_single_gpu(args)
+    if world > 1 and secondary_wanted(args):
+        # launched by torch.distributed.run: the config-4 leg on the same ranks (the self-launcher runs it as its own rank group)
+        sec = secondary_sharded_in_process(args, rank, world, device, dist)
+        if rank == 0:
+            out["secondary"] = sec
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

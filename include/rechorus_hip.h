@@ -734,6 +734,16 @@ int rc_bprmf_train_step_ahead(float* U, float* I, float* mU, float* vU, float* m
  * re-allocated): `stream` waits for the second stream's writes into that workspace; the ticket is cleared.        */
 int rc_bprmf_step_ahead_reset(rc_step_ticket* ticket, rc_stream_t stream);
 
+/* ---- measurement aid (bench.py only; not a step of the path) ------------------------------------------------------------------
+ * The access mix of the fused BPRMF kernel without its arithmetic, on the caller's table and id list: every occurrence reads
+ * its row (d in {32, 64, 128} floats, non-temporal, 8 rows in flight per lane group), the pseudo-random fraction write_frac of
+ * the occurrences writes the row back unchanged (the table keeps its contents).  Runs 3 + iters launches on `stream`, times
+ * the iters with HIP events, SYNCHRONISES, and returns the average milliseconds per launch in *ms_out (host memory).  bench.py
+ * prints the rate as roofline.box_ceiling_gbps: what this box delivers for the kernel's own ids, next to what the kernel
+ * reaches.  sink_dev: 4 device bytes (a store that never happens keeps the loads alive).                                     */
+int rc_bench_mix(float* table, int d, const int64_t* ids, int64_t n_occ, float write_frac, int iters, float* sink_dev,
+                 float* ms_out, rc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -37,6 +37,7 @@ SOURCES = [
     "sampler.hip",
     "eval_rank.hip",
     "owner_step.hip",
+    "bench_mix.hip",
 ]
 HEADERS = ["common.hpp", "bpr_math.hpp", "fused_body.hpp", "small_plan.hpp", "opt_math.hpp", "philox.hpp", "sas_mma.hpp", "plan.hpp", os.path.join("..", "..", "include", "rechorus_hip.h")]
 

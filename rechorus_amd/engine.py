@@ -811,7 +811,10 @@ class NeumfTrainer:
         two_streams = _NEUMF_OVERLAP and iid.numel() >= _SAS_OVERLAP_MIN
         main = torch.cuda.current_stream(dev)
         if two_streams and self._side is None:
-            self._side, self._side2 = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+            # RC_NEUMF_PLAN_PRIORITY=1: the plan's stream above the others (its small latency-bound kernels then go first where the
+            # update kernels compete for the same CUs)
+            prio = -1 if os.environ.get("RC_NEUMF_PLAN_PRIORITY", "0") == "1" else 0
+            self._side, self._side2 = torch.cuda.Stream(device=dev, priority=prio), torch.cuda.Stream(device=dev)
         ahead = getattr(self, "_ahead", None)
         self._ahead = None
         plan = plan_done = None
@@ -834,8 +837,15 @@ class NeumfTrainer:
             with torch.cuda.stream(self._side):
                 nplan = Plan(ni, n_i, nu, n_u, tag="neumf%d" % ((self.step_count + 1) & 1), list_single_a=False)
                 self._ahead = (self._batch_key(nu, ni), nplan, self._side.record_event())
-        with _PhaseTimer(self, "loss"):
-            self.loss = reduce_sum(out["loss_vec"], 1.0 / B)
+        if two_streams:
+            # the batch mean of the per-tuple losses (one workgroup, 10 us of latency) on the user side's stream, where it fills
+            # the wait for the plan instead of standing in front of the item update
+            self._side2.wait_stream(main)
+            with torch.cuda.stream(self._side2):
+                self.loss = reduce_sum(out["loss_vec"], 1.0 / B)
+        else:
+            with _PhaseTimer(self, "loss"):
+                self.loss = reduce_sum(out["loss_vec"], 1.0 / B)
         with _PhaseTimer(self, "sort"):
             if plan is None:
                 plan = Plan(iid, n_i, uid, n_u, tag="neumf%d" % (self.step_count & 1), list_single_a=False)
@@ -848,7 +858,8 @@ class NeumfTrainer:
                 sa, sb = self.state[ta], self.state[tb]
                 plan.update_pair(side_, P[ta], P[tb], ga, gb, h, ma=sa.get("m"), va=sa.get("v"), mb=sb.get("m"), vb=sb.get("v"), ws_tag=side_)
             if two_streams:   # item tables and user tables are disjoint: the two updates run side by side
-                self._side2.wait_stream(main)
+                if plan_done is not None:
+                    self._side2.wait_event(plan_done)
                 with torch.cuda.stream(self._side2):
                     upd(*sides[1])
                 upd(*sides[0])

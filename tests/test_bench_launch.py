@@ -65,3 +65,38 @@ def test_world_size_mismatch_is_refused():
     p = subprocess.run([sys.executable, BENCH, "--gpus", "4"], cwd=ROOT, env=_clean_env(WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"),
                        capture_output=True, text=True, timeout=120)
     assert p.returncode != 0 and "WORLD_SIZE=2" in p.stderr
+
+
+def test_secondary_leg_rules_and_the_launcher_that_captures_rank_zero(monkeypatch):
+    """host logic of the `secondary` object of the contract line: only the default contract workload carries the other configs;
+    a leg contributes a summary, never its whole line; the launcher can hand rank 0's output back (it runs a second rank group
+    for the sharded NeuMF leg and merges the two lines into ONE)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", BENCH)
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
+    a = bench.parse()
+    assert bench.secondary_wanted(a)
+    for argv in (["--workload", "neumf"], ["--no-secondary"], ["--parallel", "replicas"], ["--graph"]):
+        monkeypatch.setattr(sys, "argv", ["bench.py"] + argv)
+        assert not bench.secondary_wanted(bench.parse()), argv
+    names = [n for n, _ in bench.SECONDARY_LEGS]
+    assert names == ["neumf", "neumf_100M", "sasrec", "deepfm_b1024", "deepfm_b131072"]
+    for _, extra in bench.SECONDARY_LEGS:   # every leg parses, and none of them recurses
+        monkeypatch.setattr(sys, "argv", ["bench.py"] + extra + ["--no-secondary"])
+        assert not bench.secondary_wanted(bench.parse())
+    monkeypatch.setattr(sys, "argv", ["bench.py"] + bench.SHARDED_LEG)
+    leg = bench.parse()
+    assert (leg.workload, leg.items, leg.users, leg.emb_size, leg.num_neg, leg.opt) == ("neumf", 100_000_001, 10_000_001, 128, 4, "SGD")
+    j = {"metric": "m", "value": 2.0, "unit": "u", "ms_per_step": 0.5, "config": {"workload": "w", "n_items": 7}, "cpu_baseline": {"x": 1},
+         "roofline": {"frac": 0.3}, "phases_ms": {"a": 1.0}}
+    sm = bench._summary(j)
+    assert sm["workload"] == "w" and sm["roofline"] == {"frac": 0.3} and "cpu_baseline" not in sm and "config" not in sm
+    assert bench._last_json("noise\n{\"a\": 1}\ntrailing\n") == {"a": 1} and bench._last_json("nothing here") is None
+    # the capturing launcher on the rendezvous-only ranks (gloo, no GPU)
+    monkeypatch.setenv("RC_BENCH_LAUNCH_ONLY", "1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        monkeypatch.delenv(k, raising=False)
+    rc, text = bench.launch_ranks(2, ["--gpus", "2", "--dist-backend", "gloo"], capture=True)
+    assert rc == 0 and bench._last_json(text)["n_gpus"] == 2

@@ -585,6 +585,7 @@ def test_neumf_and_sasrec_trainers_plan_equals_sort(cuda, eng, monkeypatch):
     n_users, n_items, d, l1, B, Cn = 30_000, 6_000_000, 128, 64, 4096, 5
     def neumf(use_plan):
         monkeypatch.setattr(eng, "_USE_PLAN", use_plan)
+        monkeypatch.setattr(eng, "_NEUMF_FUSED", False)   # the three-kernel step on both routes (the fused kernel sums in its own order: tests/test_gpu_neumf.py)
         g.manual_seed(1)
         mk = lambda *sh: torch.empty(sh, device=cuda).normal_(0, 0.05, generator=g)
         P = {"mf_u": mk(n_users, d), "mlp_u": mk(n_users, d), "mf_i": mk(n_items, d), "mlp_i": mk(n_items, d),
