@@ -145,7 +145,7 @@ PlanLongWs carve_plan_long_ws(void* base, int64_t n, int d) {
   PlanLongWs w;
   if (n < 1) n = 1;
   w.long_cap = (uint32_t)(n / (kPlanLongSeg + 1)) + 1;
-  w.chunk_cap = (uint32_t)(n / kPlanChunk) + w.long_cap + 1;
+  w.chunk_cap = (uint32_t)(n / 64) + w.long_cap + 1;   // 64 = the smallest chunk any consumer cuts (plan_update.hip, side_chunk)
   w.lrows = cv.take<PlanLongRow>(w.long_cap);
   w.chunks = cv.take<PlanChunkInfo>(w.chunk_cap);
   w.partial = cv.take<float>((size_t)w.chunk_cap * (size_t)d);

@@ -146,15 +146,8 @@ __device__ __forceinline__ void back_tiles(f32x4s (&acc)[KG], const float* wp, c
   }
 }
 
-// timing experiments (tools/build_variant.py ... -DRC_X_NEUMF_SKIP=<mask>; results are WRONG, only the clock is read):
-// 1 pass-1 hidden layer, 2 pass-2 hidden layer, 4 dh0, 8 dW1i, 16 pass 3, 32 row stores of pass 2, 64 dW1u exchange
-#ifndef RC_X_NEUMF_SKIP
-#define RC_X_NEUMF_SKIP 0
-#endif
-
 template <int D, int L1, int MODE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void neumf_step_kernel(NeumfStepArgs a) {
-  constexpr int kSkip = RC_X_NEUMF_SKIP;
   using Cfg = StepCfg<D, L1>;
   constexpr int K0 = Cfg::K0, SW = Cfg::SW, NCU = Cfg::NCU, NT = Cfg::NT, SZ = Cfg::SZ, SH = Cfg::SH, NTU = Cfg::NTU;
   constexpr int KG = NCU < 4 ? NCU : 4;   // dh0 column tiles per MFMA group
@@ -216,8 +209,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
 
     // ---- pass 1: predictions --------------------------------------------------------------------------------------
-    // 128 MFMAs (1.7 us) per candidate do not cover a gather: the mlp_i rows run TWO candidates ahead of the MFMAs, the mf_i
-    // rows one, the item ids three
+    // item ids run two candidates ahead of the rows, the mlp rows one candidate ahead of the MFMAs
     {
       float muw[NCU][4];
       load_row_slices<NCU>(muw, mup);
@@ -226,32 +218,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const float4 w = *reinterpret_cast<const float4*>(swo + 16 * cc + 4 * g);
         muw[cc][0] *= w.x; muw[cc][1] *= w.y; muw[cc][2] *= w.z; muw[cc][3] *= w.w;
       }
-      float h1[NCU][4], h2[NCU][4], mn[NCU][4];
-      const int64_t id0 = ip[0], id1 = ip[C > 1 ? 1 : 0];
-      int64_t it2 = ip[C > 2 ? 2 : C - 1];
-      load_row_slices<NCU>(h1, a.mlp_i + id0 * D + 4 * g);
-      load_row_slices<NCU>(mn, a.mf_i + id0 * D + 4 * g);
-      load_row_slices<NCU>(h2, a.mlp_i + id1 * D + 4 * g);
-      int64_t it1 = id1;
+      float hn[NCU][4];
+      int64_t it0 = ip[0], it1 = ip[C > 1 ? 1 : 0];
+      load_row_slices<NCU>(hn, a.mlp_i + it0 * D + 4 * g);
       for (int c = 0; c < C; ++c) {
         asm volatile("" ::: "memory");
         float hx[NCU][4], mx[NCU][4];
 #pragma unroll
         for (int cc = 0; cc < NCU; ++cc)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            hx[cc][e] = h1[cc][e];
-            mx[cc][e] = mn[cc][e];
-            h1[cc][e] = h2[cc][e];
-          }
-        if (c + 1 < C) load_row_slices<NCU>(mn, a.mf_i + it1 * D + 4 * g);    // candidate c + 1
-        if (c + 2 < C) load_row_slices<NCU>(h2, a.mlp_i + it2 * D + 4 * g);   // candidate c + 2
-        it1 = it2;
-        it2 = ip[c + 3 < C ? c + 3 : C - 1];
+          for (int e = 0; e < 4; ++e) hx[cc][e] = hn[cc][e];
+        load_row_slices<NCU>(mx, a.mf_i + it0 * D + 4 * g);
+        it0 = it1;
+        if (c + 1 < C) {   // the next candidate's mlp rows travel during this one's MFMAs
+          load_row_slices<NCU>(hn, a.mlp_i + it0 * D + 4 * g);
+          it1 = ip[c + 2 < C ? c + 2 : C - 1];
+        }
         f32x4s z[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) z[nt] = Zu[nt];
-        if (!(kSkip & 1)) hidden_half<NT, NCU, SW>(z, wfwd_i, hx);
+        hidden_half<NT, NCU, SW>(z, wfwd_i, hx);
         float pp = 0.f;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -340,7 +326,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         f32x4s dz[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) dz[nt] = Zu[nt];
-        if (!(kSkip & 2)) hidden_half<NT, NCU, SW>(dz, wfwd_i, hx);
+        hidden_half<NT, NCU, SW>(dz, wfwd_i, hx);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
           const float4 b = *reinterpret_cast<const float4*>(sb1 + 16 * nt + 4 * g);
@@ -369,8 +355,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           f32x4s acc[KG];
 #pragma unroll
           for (int k = 0; k < KG; ++k) acc[k] = f32x4s{0.f, 0.f, 0.f, 0.f};
-          if (!(kSkip & 4)) back_tiles<NT, KG, SW>(acc, wbwd_i + 16 * kt0, dz);
-          if (valid && !(kSkip & 32)) {
+          back_tiles<NT, KG, SW>(acc, wbwd_i + 16 * kt0, dz);
+          if (valid) {
 #pragma unroll
             for (int k = 0; k < KG; ++k) {
               const int kt = kt0 + k;
@@ -398,7 +384,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
           for (int kt = 0; kt < NCU; ++kt) bv[kt] = Th[g * SH + 16 * kt + i];
 #pragma unroll
-          for (int s = 0; s < ((kSkip & 8) ? 0 : 4); ++s) {
+          for (int s = 0; s < 4; ++s) {
             if (s + 1 < 4) {
 #pragma unroll
               for (int ft = 0; ft < NT; ++ft) an[ft] = Tz[(4 * (s + 1) + g) * SZ + 16 * ft + i];
@@ -457,55 +443,52 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
 
     // ---- pass 3: backward of the GMF branch (no MFMA: d mf_i = g w_mf mf_u, d mf_u = w_mf sum_c g_c mf_i) and the mf_i row
-    // updates -- kept out of pass 2, whose MFMA pipelines need the registers these rows would occupy.  Pure streaming at one
-    // wave per SIMD: the rows of PF candidates are requested together (one exposed round trip per PF candidates, not per
-    // candidate: 65 -> 25 us of the kernel at the config-4 shape)
+    // updates -- kept out of pass 2, whose MFMA pipelines need the registers these rows would occupy.  (65 us of the kernel at
+    // the config-4 shape: 168 MB read + 168 MB written by one wave per SIMD.  Requesting the rows of four candidates together
+    // and running the mlp rows of pass 1 two candidates ahead measured SLOWER on the same box -- 0.573 against 0.553 ms per
+    // step, profiles/r05a_ab_neumf_step.txt; plain instead of non-temporal row stores: 0.655 ms.) -------------------------------
     {
-      constexpr int PF = 4;
-      float mu[NCU][4], S[NCU][4];
+      float mu[NCU][4], S[NCU][4], mn[NCU][4];
       load_row_slices<NCU>(mu, mup);
 #pragma unroll
       for (int cc = 0; cc < NCU; ++cc)
 #pragma unroll
         for (int e = 0; e < 4; ++e) S[cc][e] = 0.f;
-      for (int c0 = 0; c0 < ((kSkip & 16) ? 0 : C); c0 += PF) {
-        float mx[PF][NCU][4];
-        int64_t itm[PF];
-        uint8_t mfl[PF];
+      int64_t it0 = ip[0], it1 = ip[C > 1 ? 1 : 0];
+      load_row_slices<NCU>(mn, a.mf_i + it0 * D + 4 * g);
+      for (int c = 0; c < C; ++c) {
+        float mx[NCU][4];
 #pragma unroll
-        for (int q = 0; q < PF; ++q) itm[q] = ip[c0 + q < C ? c0 + q : C - 1];
+        for (int cc = 0; cc < NCU; ++cc)
 #pragma unroll
-        for (int q = 0; q < PF; ++q) {
-          load_row_slices<NCU>(mx[q], a.mf_i + itm[q] * D + 4 * g);
-          mfl[q] = a.multi[itm[q]];
+          for (int e = 0; e < 4; ++e) mx[cc][e] = mn[cc][e];
+        const int64_t item_c = it0;
+        const uint8_t mflag = a.multi[item_c];
+        it0 = it1;
+        if (c + 1 < C) {
+          load_row_slices<NCU>(mn, a.mf_i + it0 * D + 4 * g);
+          it1 = ip[c + 2 < C ? c + 2 : C - 1];
         }
+        const float gc = sp[c * 16 + i];
+        const bool single = mflag == 0;
+        float* grow = a.g_mf_i + (tup * C + c) * D + 4 * g;
 #pragma unroll
-        for (int q = 0; q < PF; ++q) {
-          const int c = c0 + q;
-          if (c < C) {   // wave-uniform
-            const float gc = sp[c * 16 + i];
-            const bool single = mfl[q] == 0;
-            const int64_t item_c = itm[q];
-            float* grow = a.g_mf_i + (tup * C + c) * D + 4 * g;
+        for (int cc = 0; cc < NCU; ++cc) {
+          const float4 w = *reinterpret_cast<const float4*>(swo + 16 * cc + 4 * g);
+          const float4 gr = make_float4(gc * (w.x * mu[cc][0]), gc * (w.y * mu[cc][1]), gc * (w.z * mu[cc][2]), gc * (w.w * mu[cc][3]));
 #pragma unroll
-            for (int cc = 0; cc < NCU; ++cc) {
-              const float4 w = *reinterpret_cast<const float4*>(swo + 16 * cc + 4 * g);
-              const float4 gr = make_float4(gc * (w.x * mu[cc][0]), gc * (w.y * mu[cc][1]), gc * (w.z * mu[cc][2]), gc * (w.w * mu[cc][3]));
-#pragma unroll
-              for (int e = 0; e < 4; ++e) S[cc][e] = fmaf(gc, mx[q][cc][e], S[cc][e]);
-              if (valid) {
-                const float4 w0 = make_float4(mx[q][cc][0], mx[q][cc][1], mx[q][cc][2], mx[q][cc][3]);
-                if (MODE == MODE_SGD) {
-                  float4 w1 = w0, m0 = w0, v0 = w0;
-                  opt_apply4<MODE_SGD>(a.opt, w1, m0, v0, gr);
-                  float* dst = single ? (a.mf_i + item_c * D + 16 * cc + 4 * g) : (grow + 16 * cc);
-                  store_row4(reinterpret_cast<float4*>(dst), single ? w1 : gr);
-                } else if (single) {
-                  opt_row4<MODE>(a.opt, a.mf_i, a.m_mf_i, a.v_mf_i, (size_t)(item_c * D + 16 * cc + 4 * g) / 4, w0, gr);
-                } else {
-                  *reinterpret_cast<float4*>(grow + 16 * cc) = gr;
-                }
-              }
+          for (int e = 0; e < 4; ++e) S[cc][e] = fmaf(gc, mx[cc][e], S[cc][e]);
+          if (valid) {
+            const float4 w0 = make_float4(mx[cc][0], mx[cc][1], mx[cc][2], mx[cc][3]);
+            if (MODE == MODE_SGD) {
+              float4 w1 = w0, m0 = w0, v0 = w0;
+              opt_apply4<MODE_SGD>(a.opt, w1, m0, v0, gr);
+              float* dst = single ? (a.mf_i + item_c * D + 16 * cc + 4 * g) : (grow + 16 * cc);
+              store_row4(reinterpret_cast<float4*>(dst), single ? w1 : gr);
+            } else if (single) {
+              opt_row4<MODE>(a.opt, a.mf_i, a.m_mf_i, a.v_mf_i, (size_t)(item_c * D + 16 * cc + 4 * g) / 4, w0, gr);
+            } else {
+              *reinterpret_cast<float4*>(grow + 16 * cc) = gr;
             }
           }
         }
@@ -525,8 +508,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
 
     // ---- dW1u += (sum_c dz_c)^T mlp_u over the workgroup's 64 tuples: strips of all four waves, a quarter of the tiles each ----
-    if (!(kSkip & 64)) __syncthreads();
-    for (int w2 = 0; w2 < ((kSkip & 64) ? 0 : 4); ++w2) {
+    __syncthreads();
+    for (int w2 = 0; w2 < 4; ++w2) {
       const float* Tz2 = tb + w2 * per_wave;
       const float* Th2 = Tz2 + 16 * SZ;
 #pragma unroll
@@ -537,7 +520,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           accU[q] = mma16(Tz2[(4 * s + g) * SZ + 16 * ft + i], Th2[(4 * s + g) * SH + 16 * kt + i], accU[q]);
         }
     }
-    if (!(kSkip & 64)) __syncthreads();
+    __syncthreads();
   }
 
   // ---- per-workgroup partials of the dense gradients --------------------------------------------------------------

@@ -41,7 +41,15 @@ struct PlanUpdArgs {
   // the plan registered the hot rows already (bucket_plan.hip, emit_long): their chunks are reduced by extra workgroups
   // of the row-update launch instead of a launch of their own
   int long_planned;
+  // occurrences per chunk of a hot row.  kPlanChunk where the plan registered the hot rows (emit_long); where this file does
+  // (rc_plan_update*, rc_plan_row_sums) it follows the row width: a chunk is walked 16 occurrences per lane-group and trip, and
+  // a 256-float row (a NeuMF table pair) has 4 lane-groups per workgroup -- 256 occurrences were 16 dependent trips (67 us for
+  // the few hot rows of a NeuMF batch), 64 are four
+  uint32_t chunk;
 };
+
+template <int D>
+constexpr uint32_t side_chunk() { return D >= 256 ? 64u : (D == 128 ? 128u : (uint32_t)kPlanChunk); }
 
 __device__ __forceinline__ void padd4(float4& x, const float4& y) {
   x.x += y.x; x.y += y.y; x.z += y.z; x.w += y.w;
@@ -83,7 +91,7 @@ __device__ __forceinline__ PlanTable plan_lane_table(const PlanSide& sd, uint32_
 // hot row: chunk records for plan_chunk_kernel / plan_final_kernel (lane-group cooperative, l = lane in group)
 template <int LPR>
 __device__ __forceinline__ void plan_long_row(const PlanUpdArgs& a, const rc_plan_row& e, int side, int l) {
-  const uint32_t nch = (e.n + kPlanChunk - 1) / kPlanChunk;
+  const uint32_t nch = (e.n + a.chunk - 1) / a.chunk;
   uint32_t slot = 0, cbase = 0;
   if (l == 0) {
     slot = atomicAdd(&a.counters[PC_LONG], 1u);
@@ -331,8 +339,8 @@ __device__ __forceinline__ void plan_chunk_body(const PlanUpdArgs& a, uint32_t f
     const PlanChunkInfo ci = a.lw.chunks[c];
     const PlanLongRow r = a.lw.lrows[ci.lrow];
     const PlanGrad& gs = a.side[r.side].g;
-    const uint32_t start = r.start + ci.k * kPlanChunk;
-    const uint32_t end = (start + kPlanChunk < r.start + r.n) ? start + kPlanChunk : r.start + r.n;
+    const uint32_t start = r.start + ci.k * a.chunk;
+    const uint32_t end = (start + a.chunk < r.start + r.n) ? start + a.chunk : r.start + r.n;
     // four independent occurrences per lane-group per trip (fixed pattern -> fixed order)
     float4 acc = make_float4(0, 0, 0, 0);
     for (uint32_t jj = start + g; jj < end; jj += 4 * GPB) {
@@ -417,7 +425,9 @@ __global__ __launch_bounds__(kBlock) void plan_final_kernel(PlanUpdArgs a, uint3
 
 // one table (or table pair) updated from its row list: rows, chunks of hot rows, hot rows
 template <int D, int MODE>
-static int launch_side_update(const PlanUpdArgs& a, int64_t n_occ, hipStream_t s) {
+static int launch_side_update(const PlanUpdArgs& a_in, int64_t n_occ, hipStream_t s) {
+  PlanUpdArgs a = a_in;
+  a.chunk = side_chunk<D>();
   const uint32_t cus = (uint32_t)device_cus();
   const uint32_t blocks_main = cus * 32;
   hipLaunchKernelGGL((plan_rows_kernel<D, MODE>), dim3(blocks_main), dim3(kBlock), 0, s, a, blocks_main, 0, 0, 0u);
@@ -497,6 +507,7 @@ int plan_bprmf_step_updates(float* U, float* mU, float* vU, float* I, float* mI,
   PlanUpdArgs a;
   memset(&a, 0, sizeof(a));
   a.long_planned = long_planned ? 1 : 0;
+  a.chunk = kPlanChunk;
   RC_TRY(fill_opt_scalars(h, &a.o));
   const int mode = mode_of(h);
   RC_REQUIRE(mode != MODE_ADAM || (mU && vU && mI && vI), "rc_bprmf_train_step: Adam needs m and v tables");

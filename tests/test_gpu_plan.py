@@ -503,11 +503,15 @@ def test_plan_row_sums_and_distinct(case, d, cuda, eng):
         tol = 1e-6 * np.sqrt(np.maximum(cnt, 1))[:, None] * np.abs(src).max() * 4 + 1e-6
         assert np.all(np.abs(G.cpu().numpy() - want) <= tol + 1e-6 * np.abs(want))
         assert np.all(G.cpu().numpy()[cnt == 0] == 0)
-        # bit-identical to the radix-sort route (same ascending-position order of the sums)
+        # bit-identical to the radix-sort route where both sum a row in one ascending chain (rows of at most 32 occurrences); hot
+        # rows are cut into chunks whose size follows the row width on the plan route (plan_update.hip, side_chunk) and is 256 on
+        # the sort route: the same numbers up to fp32 association
         keys, perm = eng.sort_ids(ids_d, n_rows)
         G2 = torch.zeros_like(G)
         eng.segmented_update(keys, perm, src_d, dense_grad=G2)
-        assert torch.equal(G, G2)
+        short = torch.from_numpy(cnt <= 32).to(cuda)
+        assert torch.equal(G[short], G2[short])
+        assert np.all(np.abs(G.cpu().numpy() - G2.cpu().numpy()) <= 2 * tol)
 
 
 @pytest.mark.parametrize("n,n_rows,d,hot", [(8192, 279_000, 64, 0), (8192, 279_000, 1, 0), (25_600, 8_714, 64, 0), (1, 5, 16, 0),
@@ -607,6 +611,14 @@ def test_neumf_and_sasrec_trainers_plan_equals_sort(cuda, eng, monkeypatch):
             # (Adam normalises the step: an element whose gradient is rounding noise may move by lr either way -- allow a few)
             diff = (Pa[k] - Pb[k]).abs()
             assert float((diff > 1e-6).float().mean()) < 5e-3 and float(diff.max()) <= 2 * 1e-2 + 1e-6, k
+            continue
+        if k.endswith("_i"):
+            # rows of at most 32 occurrences are summed in one ascending chain on both routes: bit-identical; the few hot rows are
+            # cut into chunks of 64 (plan, 256-float pair rows) against 256 (sort): equal to rounding (and Adam's normalised step)
+            same = (Pa[k] == Pb[k]).all(dim=1)
+            assert float((~same).float().mean()) < 1e-4, k
+            diff = (Pa[k] - Pb[k]).abs()
+            assert float(diff.max()) <= 2 * 1e-2 + 1e-6, k
             continue
         assert torch.equal(Pa[k], Pb[k]), k
         for st in ("m", "v"):
