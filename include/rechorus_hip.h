@@ -488,6 +488,18 @@ int rc_neumf_train_step(float* mf_u, float* mf_i, float* mlp_u, float* mlp_i, fl
                         float* g_mf_i, float* g_mlp_i, float* gu_mf, float* gu_mlp, float* dW1, float* db1,
                         float* dw_out, void* ws, size_t ws_bytes, rc_stream_t stream);
 
+/* The same kernel without table updates, on row blocks with a stride: forward, BPR loss and backward of the NeuMF head for
+ * callers that own neither the tables nor the optimizer -- the row-sharded step (rechorus_amd/sharded.py, ShardedNeumf), where
+ * the rows of a batch were fetched from their owners into blocks [rows, mf | mlp] (ld = 2 d) and the gradient rows travel back
+ * the same way.  uid [B] / iid [B, C] index the row blocks; every position writes its item gradient rows (g_mf_i / g_mlp_i at
+ * stride ld_gi), every tuple its two user gradient rows (stride ld_gu); loss_vec, pred, dense gradients, workspace and shapes
+ * as rc_neumf_train_step.  Strides are in floats, multiples of 4, at least d.                                                   */
+int rc_neumf_head_fwd_bwd(const float* mf_u, const float* mlp_u, int64_t ld_u, const float* mf_i, const float* mlp_i,
+                          int64_t ld_i, const float* W1, const float* b1, const float* w_out, const int64_t* uid,
+                          const int64_t* iid, int B, int C, int d, int l1, float inv_b, float* loss_vec, float* pred,
+                          float* g_mf_i, float* g_mlp_i, int64_t ld_gi, float* gu_mf, float* gu_mlp, int64_t ld_gu,
+                          float* dW1, float* db1, float* dw_out, void* ws, size_t ws_bytes, rc_stream_t stream);
+
 /* ---- dense layers of the heads (csrc/mlp.hip): fp32 MFMA GEMMs ------------------------------------
  * utils/layers.py:201-243 (MLP_Block: Linear -> ReLU -> Dropout per hidden layer + output Linear; the deep part of
  * models/context/DeepFM.py:25 / WideDeep.py:42-47) and the NeuMF tower for any --layers

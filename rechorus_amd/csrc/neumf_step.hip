@@ -54,13 +54,15 @@ struct NeumfStepArgs {
   const int64_t* iid;
   int B, C;
   float inv_b;
-  const uint8_t* multi;    // multi[id] != 0: item row id occurs at least twice in the batch
+  const uint8_t* multi;    // multi[id] != 0: item row id occurs at least twice in the batch; null: no row is updated in place
   float* loss_vec;         // [B]
   float* pred;             // [B, C] or null
   float* g_mf_i;           // [B C, D] gradient rows of multi-occurrence item rows (other positions are not written)
   float* g_mlp_i;
   float* gu_mf;            // [B, D] per-tuple gradient rows of the user tables
   float* gu_mlp;
+  int64_t ld_u, ld_i;      // row strides (floats) of the user / item tables: D for nn.Embedding weights; the sharded step's fetched
+  int64_t ld_gi, ld_gu;    // row blocks hold [mf | mlp] side by side (2 D), and so do the gradient rows it sends back
   float* pW1;              // per-workgroup partials [grid][L1 2D], [grid][L1], [grid][D + L1]
   float* pb1;
   float* pwout;
@@ -195,8 +197,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int64_t tt = valid ? tup : (int64_t)a.B - 1;
     const int64_t u = a.uid[tt];
     const int64_t* ip = a.iid + tt * C;
-    const float* hup = a.mlp_u + u * D + 4 * g;
-    const float* mup = a.mf_u + u * D + 4 * g;
+    const float* hup = a.mlp_u + u * a.ld_u + 4 * g;
+    const float* mup = a.mf_u + u * a.ld_u + 4 * g;
 
     // ---- per tuple: Zu = W1u mlp_u (accumulator r of tile nt <-> hidden feature 16 nt + 4 g + r) ------------------------
     f32x4s Zu[NT];
@@ -220,7 +222,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       }
       float hn[NCU][4];
       int64_t it0 = ip[0], it1 = ip[C > 1 ? 1 : 0];
-      load_row_slices<NCU>(hn, a.mlp_i + it0 * D + 4 * g);
+      load_row_slices<NCU>(hn, a.mlp_i + it0 * a.ld_i + 4 * g);
       for (int c = 0; c < C; ++c) {
         asm volatile("" ::: "memory");
         float hx[NCU][4], mx[NCU][4];
@@ -228,10 +230,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int cc = 0; cc < NCU; ++cc)
 #pragma unroll
           for (int e = 0; e < 4; ++e) hx[cc][e] = hn[cc][e];
-        load_row_slices<NCU>(mx, a.mf_i + it0 * D + 4 * g);
+        load_row_slices<NCU>(mx, a.mf_i + it0 * a.ld_i + 4 * g);
         it0 = it1;
         if (c + 1 < C) {   // the next candidate's mlp rows travel during this one's MFMAs
-          load_row_slices<NCU>(hn, a.mlp_i + it0 * D + 4 * g);
+          load_row_slices<NCU>(hn, a.mlp_i + it0 * a.ld_i + 4 * g);
           it1 = ip[c + 2 < C ? c + 2 : C - 1];
         }
         f32x4s z[NT];
@@ -304,7 +306,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     {
       float hn[NCU][4];
       int64_t it0 = ip[0], it1 = ip[C > 1 ? 1 : 0];
-      load_row_slices<NCU>(hn, a.mlp_i + it0 * D + 4 * g);
+      load_row_slices<NCU>(hn, a.mlp_i + it0 * a.ld_i + 4 * g);
       for (int c = 0; c < C; ++c) {
         asm volatile("" ::: "memory");
         float hx[NCU][4];
@@ -313,10 +315,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
           for (int e = 0; e < 4; ++e) hx[cc][e] = hn[cc][e];
         const int64_t item_c = it0;
-        const uint8_t mflag = a.multi[item_c];
+        const uint8_t mflag = a.multi ? a.multi[item_c] : (uint8_t)1;
         it0 = it1;
         if (c + 1 < C) {
-          load_row_slices<NCU>(hn, a.mlp_i + it0 * D + 4 * g);
+          load_row_slices<NCU>(hn, a.mlp_i + it0 * a.ld_i + 4 * g);
           it1 = ip[c + 2 < C ? c + 2 : C - 1];
         }
         const float gc = sp[c * 16 + i];
@@ -349,7 +351,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // d mlp_i = W1i^T dz in the lane layout of the gathered row: update in place, or hand the gradient row to the plan's update.
         // SGD: ONE store per slice either way (address and value selected per lane, no divergent branch)
         const bool single = mflag == 0;
-        float* grow = a.g_mlp_i + n * D + 4 * g;
+        float* grow = a.g_mlp_i + n * a.ld_gi + 4 * g;
 #pragma unroll
         for (int kt0 = 0; kt0 < NCU; kt0 += KG) {
           f32x4s acc[KG];
@@ -365,7 +367,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
               if (MODE == MODE_SGD) {
                 float4 w1 = w0, m0 = w0, v0 = w0;
                 opt_apply4<MODE_SGD>(a.opt, w1, m0, v0, gr);
-                float* dst = single ? (a.mlp_i + item_c * D + 16 * kt + 4 * g) : (grow + 16 * kt);
+                float* dst = single ? (a.mlp_i + item_c * a.ld_i + 16 * kt + 4 * g) : (grow + 16 * kt);
                 store_row4(reinterpret_cast<float4*>(dst), single ? w1 : gr);
               } else if (single) {
                 opt_row4<MODE>(a.opt, a.mlp_i, a.m_mlp_i, a.v_mlp_i, (size_t)(item_c * D + 16 * kt + 4 * g) / 4, w0, gr);
@@ -418,7 +420,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if (valid) {
 #pragma unroll
           for (int k = 0; k < KG; ++k)
-            *reinterpret_cast<float4*>(a.gu_mlp + tup * D + 16 * (kt0 + k) + 4 * g) = make_float4(acc[k][0], acc[k][1], acc[k][2], acc[k][3]);
+            *reinterpret_cast<float4*>(a.gu_mlp + tup * a.ld_gu + 16 * (kt0 + k) + 4 * g) = make_float4(acc[k][0], acc[k][1], acc[k][2], acc[k][3]);
         }
       }
 #pragma unroll
@@ -455,7 +457,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int e = 0; e < 4; ++e) S[cc][e] = 0.f;
       int64_t it0 = ip[0], it1 = ip[C > 1 ? 1 : 0];
-      load_row_slices<NCU>(mn, a.mf_i + it0 * D + 4 * g);
+      load_row_slices<NCU>(mn, a.mf_i + it0 * a.ld_i + 4 * g);
       for (int c = 0; c < C; ++c) {
         float mx[NCU][4];
 #pragma unroll
@@ -463,15 +465,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
           for (int e = 0; e < 4; ++e) mx[cc][e] = mn[cc][e];
         const int64_t item_c = it0;
-        const uint8_t mflag = a.multi[item_c];
+        const uint8_t mflag = a.multi ? a.multi[item_c] : (uint8_t)1;
         it0 = it1;
         if (c + 1 < C) {
-          load_row_slices<NCU>(mn, a.mf_i + it0 * D + 4 * g);
+          load_row_slices<NCU>(mn, a.mf_i + it0 * a.ld_i + 4 * g);
           it1 = ip[c + 2 < C ? c + 2 : C - 1];
         }
         const float gc = sp[c * 16 + i];
         const bool single = mflag == 0;
-        float* grow = a.g_mf_i + (tup * C + c) * D + 4 * g;
+        float* grow = a.g_mf_i + (tup * C + c) * a.ld_gi + 4 * g;
 #pragma unroll
         for (int cc = 0; cc < NCU; ++cc) {
           const float4 w = *reinterpret_cast<const float4*>(swo + 16 * cc + 4 * g);
@@ -483,7 +485,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             if (MODE == MODE_SGD) {
               float4 w1 = w0, m0 = w0, v0 = w0;
               opt_apply4<MODE_SGD>(a.opt, w1, m0, v0, gr);
-              float* dst = single ? (a.mf_i + item_c * D + 16 * cc + 4 * g) : (grow + 16 * cc);
+              float* dst = single ? (a.mf_i + item_c * a.ld_i + 16 * cc + 4 * g) : (grow + 16 * cc);
               store_row4(reinterpret_cast<float4*>(dst), single ? w1 : gr);
             } else if (single) {
               opt_row4<MODE>(a.opt, a.mf_i, a.m_mf_i, a.v_mf_i, (size_t)(item_c * D + 16 * cc + 4 * g) / 4, w0, gr);
@@ -497,7 +499,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       for (int cc = 0; cc < NCU; ++cc) {
         const float4 w = *reinterpret_cast<const float4*>(swo + 16 * cc + 4 * g);
         if (valid)
-          *reinterpret_cast<float4*>(a.gu_mf + tup * D + 16 * cc + 4 * g) =
+          *reinterpret_cast<float4*>(a.gu_mf + tup * a.ld_gu + 16 * cc + 4 * g) =
               make_float4(w.x * S[cc][0], w.y * S[cc][1], w.z * S[cc][2], w.w * S[cc][3]);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {   // dw_mf[k] += sum over the wave's tuples of mf_u[k] S[k]
@@ -679,6 +681,7 @@ extern "C" int rc_neumf_train_step(float* mf_u, float* mf_i, float* mlp_u, float
   hipLaunchKernelGGL(neumf_mark_multi_kernel, dim3(mark_blocks), dim3(256), 0, s, iid, n, owner, multi);
   RC_LAUNCH_CHECK();
   a.mf_u = mf_u; a.mf_i = mf_i; a.mlp_u = mlp_u; a.mlp_i = mlp_i;
+  a.ld_u = a.ld_i = a.ld_gi = a.ld_gu = d;
   a.m_mf_i = m_mf_i; a.v_mf_i = v_mf_i; a.m_mlp_i = m_mlp_i; a.v_mlp_i = v_mlp_i;
   a.W1 = W1; a.b1 = b1; a.w_out = w_out; a.uid = uid; a.iid = iid; a.B = B; a.C = C; a.inv_b = inv_b;
   a.multi = multi; a.loss_vec = loss_vec; a.pred = pred; a.g_mf_i = g_mf_i; a.g_mlp_i = g_mlp_i; a.gu_mf = gu_mf; a.gu_mlp = gu_mlp;
@@ -696,5 +699,39 @@ extern "C" int rc_neumf_train_step(float* mf_u, float* mf_i, float* mlp_u, float
   hipLaunchKernelGGL(neumf_unmark_kernel, dim3(mark_blocks), dim3(256), 0, s, iid, n, multi);
   RC_TRY(rc);
   RC_LAUNCH_CHECK();
+  return neumf_reduce_partials(a.pW1, a.pb1, a.pwout, dW1, db1, dw_out, cW, cb, co, grid, s);
+}
+
+extern "C" int rc_neumf_head_fwd_bwd(const float* mf_u, const float* mlp_u, int64_t ld_u, const float* mf_i, const float* mlp_i,
+                                     int64_t ld_i, const float* W1, const float* b1, const float* w_out, const int64_t* uid,
+                                     const int64_t* iid, int B, int C, int d, int l1, float inv_b, float* loss_vec, float* pred,
+                                     float* g_mf_i, float* g_mlp_i, int64_t ld_gi, float* gu_mf, float* gu_mlp, int64_t ld_gu,
+                                     float* dW1, float* db1, float* dw_out, void* ws, size_t ws_bytes, rc_stream_t stream) {
+  if (B == 0) return RC_OK;
+  RC_REQUIRE(mf_u && mf_i && mlp_u && mlp_i && W1 && b1 && w_out && uid && iid && loss_vec && g_mf_i && g_mlp_i && gu_mf && gu_mlp && dW1 &&
+                 db1 && dw_out && ws,
+             "rc_neumf_head_fwd_bwd: null pointer");
+  RC_REQUIRE(B > 0 && C >= 2, "rc_neumf_head_fwd_bwd: bad shape B=%d C=%d", B, C);
+  RC_REQUIRE(ld_u >= d && ld_i >= d && ld_gi >= d && ld_gu >= d && ld_u % 4 == 0 && ld_i % 4 == 0 && ld_gi % 4 == 0 && ld_gu % 4 == 0,
+             "rc_neumf_head_fwd_bwd: row strides must be multiples of 4 floats and at least d");
+  if (!rc_neumf_train_step_supported(C, d, l1))
+    return fail(RC_ERR_UNSUPPORTED, "rc_neumf_head_fwd_bwd: d=%d hidden=%d C=%d not supported (see rc_neumf_train_step_supported)", d, l1, C);
+  if (ws_bytes < rc_neumf_train_step_workspace_bytes(B, C, d, l1))
+    return fail(RC_ERR_WORKSPACE, "rc_neumf_head_fwd_bwd: workspace %zu < %zu", ws_bytes, rc_neumf_train_step_workspace_bytes(B, C, d, l1));
+  NeumfStepArgs a;
+  memset(&a, 0, sizeof(a));
+  a.opt.neg_lr = 0.f;   // no row is updated: every position writes its gradient row (multi == nullptr)
+  a.mf_u = const_cast<float*>(mf_u); a.mf_i = const_cast<float*>(mf_i); a.mlp_u = const_cast<float*>(mlp_u); a.mlp_i = const_cast<float*>(mlp_i);
+  a.ld_u = ld_u; a.ld_i = ld_i; a.ld_gi = ld_gi; a.ld_gu = ld_gu;
+  a.W1 = W1; a.b1 = b1; a.w_out = w_out; a.uid = uid; a.iid = iid; a.B = B; a.C = C; a.inv_b = inv_b;
+  a.multi = nullptr; a.loss_vec = loss_vec; a.pred = pred; a.g_mf_i = g_mf_i; a.g_mlp_i = g_mlp_i; a.gu_mf = gu_mf; a.gu_mlp = gu_mlp;
+  hipStream_t s = as_stream(stream);
+  const int grid = step_grid(B);
+  const int cW = l1 * 2 * d, cb = l1, co = d + l1;
+  float* p = reinterpret_cast<float*>(ws);
+  a.pW1 = p;
+  a.pb1 = p + (size_t)grid * cW;
+  a.pwout = a.pb1 + (size_t)grid * cb;
+  RC_TRY(dispatch_step<MODE_SGD>(a, d, l1, grid, s));
   return neumf_reduce_partials(a.pW1, a.pb1, a.pwout, dW1, db1, dw_out, cW, cb, co, grid, s);
 }

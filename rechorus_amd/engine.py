@@ -672,6 +672,36 @@ def neumf_train_step(P, state, uid, iid, hyper, marks, out, inv_b=None, pred=Non
               _ptr(out["w_out"], f32, "dw_out"), C.c_void_p(ws.data_ptr()), ws.numel(), _stream())
 
 
+def neumf_head_fwd_bwd(urows, irows, W1, b1, w_out, B, Cn, inv_b, want_pred=False):
+    """rc_neumf_head_fwd_bwd on fetched row blocks: urows [B, 2d] = [mf_u | mlp_u] of every tuple's user, irows [B C, 2d] =
+    [mf_i | mlp_i] of every candidate (the layout the sharded step's exchanges deliver).  -> (loss_vec [B], gu [B, 2d],
+    gi [B C, 2d], {W1, b1, w_out gradients}, pred | None): the gradient blocks in the same [mf | mlp] layout, ready to travel back."""
+    d2 = urows.shape[1]
+    d, l1 = d2 // 2, W1.shape[0]
+    dev, f32 = urows.device, torch.float32
+    if irows.shape != (B * Cn, d2) or urows.shape[0] != B:
+        raise ValueError("neumf_head_fwd_bwd: row blocks do not match B, C")
+    key = ("nhead", B, Cn, d2, str(dev))
+    ids = _ws_cache.get(key)
+    if ids is None:   # positional ids: tuple b uses user row b and item rows b C .. b C + C - 1
+        ids = _ws_cache[key] = (torch.arange(B, device=dev), torch.arange(B * Cn, device=dev).view(B, Cn))
+    loss_vec = torch.empty(B, dtype=f32, device=dev)
+    gu = torch.empty((B, d2), dtype=f32, device=dev)
+    gi = torch.empty((B * Cn, d2), dtype=f32, device=dev)
+    pred = torch.empty((B, Cn), dtype=f32, device=dev) if want_pred else None
+    dense = {"W1": torch.empty_like(W1), "b1": torch.empty_like(b1), "w_out": torch.empty_like(w_out)}
+    ws = workspace(_lib.load().rc_neumf_train_step_workspace_bytes(B, Cn, d, l1), dev, "neumf_step")
+    _ptr(urows, f32, "urows"); _ptr(irows, f32, "irows")
+    off = lambda t, k: C.c_void_p(t.data_ptr() + 4 * k)
+    _lib.call("rc_neumf_head_fwd_bwd", off(urows, 0), off(urows, d), d2, off(irows, 0), off(irows, d), d2,
+              _ptr(W1, f32, "W1"), _ptr(b1, f32, "b1"), _ptr(w_out, f32, "w_out"), _ptr(ids[0], torch.int64, "uid"),
+              _ptr(ids[1], torch.int64, "iid"), B, Cn, d, l1, float(inv_b), _ptr(loss_vec, f32, "loss_vec"),
+              _ptr(pred, f32, "pred", True), off(gi, 0), off(gi, d), d2, off(gu, 0), off(gu, d), d2,
+              _ptr(dense["W1"], f32, "dW1"), _ptr(dense["b1"], f32, "db1"), _ptr(dense["w_out"], f32, "dw_out"),
+              C.c_void_p(ws.data_ptr()), ws.numel(), _stream())
+    return loss_vec, gu, gi, dense, pred
+
+
 class _PhaseTimer:
     """Optional per-phase timing of a trainer step with events on the launch stream (torch's current stream is the
     stream every kernel of the step is enqueued on).  trainer.timing = {} switches it on; read with phases_ms()."""

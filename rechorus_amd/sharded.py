@@ -142,6 +142,16 @@ class HipOps:
     def neumf_bwd(self, P, uid, iid, gpred):
         return self.e.neumf_bwd(P, uid, iid, gpred)
 
+    def neumf_head(self, urows, irows, P, B, C, inv_b):
+        """forward + BPR loss + backward of the head on the fetched row blocks [rows, mf | mlp] in ONE kernel
+        (rc_neumf_head_fwd_bwd) -> (loss_vec, gu [B, 2d], gi [B C, 2d], dense grads), or None where the fused kernel has no
+        instance (the caller then runs neumf_fwd / bpr_loss / neumf_bwd)"""
+        d, l1 = urows.shape[1] // 2, P["W1"].shape[0]
+        if not self.e._NEUMF_FUSED or C < 2 or not self.e.neumf_train_step_supported(C, d, l1):
+            return None
+        loss_vec, gu, gi, dense, _ = self.e.neumf_head_fwd_bwd(urows, irows, P["W1"], P["b1"], P["w_out"], B, C, inv_b)
+        return loss_vec, gu, gi, dense
+
     def dense_update(self, W, G, hyper, state):
         self.e.dense_update(W, G, hyper, state.get("m"), state.get("v"))
 
@@ -878,20 +888,8 @@ class ShardedNeumf(_LookAhead):
             urows = ru.fetch([self.P["mf_u"], self.P["mlp_u"]], ops)      # [B, 2d]
             irows = rv.fetch([self.P["mf_i"], self.P["mlp_i"]], ops)      # [B*C, 2d]
         mark("fetch_rows")
-        # the head kernels see per-batch row blocks as their "tables", ids are positions in them
-        loc = {"mf_u": urows[:, :d].contiguous(), "mlp_u": urows[:, d:].contiguous(),
-               "mf_i": irows[:, :d].contiguous(), "mlp_i": irows[:, d:].contiguous(),
-               "W1": self.P["W1"], "b1": self.P["b1"], "w_out": self.P["w_out"]}
-        pos_u = torch.arange(B, device=dev)
-        pos_i = torch.arange(B * C, device=dev).view(B, C)
-        pred = ops.neumf_fwd(loc, pos_u, pos_i)
-        loss_vec, g = ops.bpr_loss(pred, 1.0 / n_tuples)
+        loss_vec, gu, gi, dense = self._head(urows, irows, B, C, n_tuples, mark)
         loss = loss_vec.sum().reshape(1) / n_tuples
-        mark("head_fwd_loss")
-        rows, dense = ops.neumf_bwd(loc, pos_u, pos_i, g)
-        gu = torch.cat([rows["g_mf_u"].view(B, C, d).sum(dim=1), rows["g_mlp_u"].view(B, C, d).sum(dim=1)], dim=1)
-        gi = torch.cat([rows["g_mf_i"], rows["g_mlp_i"]], dim=1)
-        mark("head_bwd")
         if W > 1:
             loss = _all_reduce_sum(loss, self.group)
             own_u, own_i, req_u, req_i = ru.push(gu, ops), rv.push(gi, ops), ru.req, rv.req
@@ -921,6 +919,32 @@ class ShardedNeumf(_LookAhead):
             ops.dense_update(self.P[k], dense[k].contiguous(), hyper0 if k == "b1" else hyper, self.state[k])
         mark("dense_update")
         return loss
+
+    def _head(self, urows, irows, B, C, n_tuples, mark):
+        """the head on the fetched row blocks urows [B, 2d], irows [B C, 2d] (layout [mf | mlp]) -> per-tuple loss, the user
+        and item gradient blocks in the same layout, the MLP's dense gradients.  ONE kernel where the fused step has an instance
+        (HipOps.neumf_head: the rows are read in place through their stride, the user half of the layer and the user gradients are
+        per-tuple work, the loss stays in registers); otherwise -- other widths, the oracle-backed ops of the CPU tests --
+        forward kernel, loss kernel, backward kernel on contiguous copies with positional ids."""
+        ops, d, dev = self.ops, self.d, urows.device
+        fused = ops.neumf_head(urows, irows, self.P, B, C, 1.0 / n_tuples) if hasattr(ops, "neumf_head") else None
+        if fused is not None:
+            mark("head_fwd_loss")
+            mark("head_bwd")
+            return fused
+        loc = {"mf_u": urows[:, :d].contiguous(), "mlp_u": urows[:, d:].contiguous(),
+               "mf_i": irows[:, :d].contiguous(), "mlp_i": irows[:, d:].contiguous(),
+               "W1": self.P["W1"], "b1": self.P["b1"], "w_out": self.P["w_out"]}
+        pos_u = torch.arange(B, device=dev)
+        pos_i = torch.arange(B * C, device=dev).view(B, C)
+        pred = ops.neumf_fwd(loc, pos_u, pos_i)
+        loss_vec, g = ops.bpr_loss(pred, 1.0 / n_tuples)
+        mark("head_fwd_loss")
+        rows, dense = ops.neumf_bwd(loc, pos_u, pos_i, g)
+        gu = torch.cat([rows["g_mf_u"].view(B, C, d).sum(dim=1), rows["g_mlp_u"].view(B, C, d).sum(dim=1)], dim=1)
+        gi = torch.cat([rows["g_mf_i"], rows["g_mlp_i"]], dim=1)
+        mark("head_bwd")
+        return loss_vec, gu, gi, dense
 
     def _account(self, routes):
         """bytes over the links of this step (this rank): every route moves rows of two tables (mf + mlp), 2 d floats"""
@@ -963,19 +987,8 @@ class ShardedNeumf(_LookAhead):
             urows, irows = ru.rows_in_lookup_order(pu.wait(), ops), rv.rows_in_lookup_order(pv.wait(), ops)
             mark("fetch_rows")
             Bk = uc[k].shape[0]
-            loc = {"mf_u": urows[:, :d].contiguous(), "mlp_u": urows[:, d:].contiguous(),
-                   "mf_i": irows[:, :d].contiguous(), "mlp_i": irows[:, d:].contiguous(),
-                   "W1": self.P["W1"], "b1": self.P["b1"], "w_out": self.P["w_out"]}
-            pos_u = torch.arange(Bk, device=dev)
-            pos_i = torch.arange(Bk * C, device=dev).view(Bk, C)
-            pred = ops.neumf_fwd(loc, pos_u, pos_i)
-            loss_vec, g = ops.bpr_loss(pred, 1.0 / n_tuples)
+            loss_vec, gu, gi, dense = self._head(urows, irows, Bk, C, n_tuples, mark)
             loss = loss + loss_vec.sum().reshape(1) / n_tuples
-            mark("head_fwd_loss")
-            rows, dense = ops.neumf_bwd(loc, pos_u, pos_i, g)
-            gu = torch.cat([rows["g_mf_u"].view(Bk, C, d).sum(dim=1), rows["g_mlp_u"].view(Bk, C, d).sum(dim=1)], dim=1)
-            gi = torch.cat([rows["g_mf_i"], rows["g_mlp_i"]], dim=1)
-            mark("head_bwd")
             pushes.append((ru.push_async(gu, ops), rv.push_async(gi, ops)))
             flat = torch.cat([dense[n].reshape(-1) for n in ("W1", "b1", "w_out")])
             dense_sum = flat if dense_sum is None else dense_sum + flat

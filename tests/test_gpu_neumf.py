@@ -408,3 +408,39 @@ def test_neumf_trainer_fused_equals_three_kernel_step(opt, lookahead, cuda, eng,
         assert not np.array_equal(Pa[k].cpu().numpy(), P0[k])
         for s in Sa[k]:
             assert_close(Sa[k][s].cpu().numpy(), Sb[k][s].cpu().numpy(), what=f"state {s} of {k}", atol_scale=2e-5)
+
+
+def test_neumf_head_on_strided_row_blocks_vs_oracle(cuda, eng):
+    """rc_neumf_head_fwd_bwd (the fused kernel without table updates, rows read through a stride -- what the row-sharded step runs
+    on the blocks it fetched): loss, every gradient row, dense gradients against the numpy oracle; the blocks are not modified"""
+    from oracle import bprmf_oracle as BO
+    rng = np.random.default_rng(29)
+    for d, l1, B, C in ((128, 64, 300, 5), (64, 32, 70, 2), (32, 64, 33, 11)):
+        urows = rng.normal(0, 0.3, (B, 2 * d)).astype(np.float32)
+        irows = rng.normal(0, 0.3, (B * C, 2 * d)).astype(np.float32)
+        W1, b1, wo = (rng.normal(0, 0.2, s).astype(np.float32) for s in ((l1, 2 * d), (l1,), (d + l1,)))
+        # the oracle's view: positional ids into per-batch tables
+        P = {"mf_u_embeddings.weight": urows[:, :d].copy(), "mlp_u_embeddings.weight": urows[:, d:].copy(),
+             "mf_i_embeddings.weight": irows[:, :d].copy(), "mlp_i_embeddings.weight": irows[:, d:].copy(),
+             "mlp.0.weight": W1, "mlp.0.bias": b1, "prediction.weight": wo[None]}
+        uid, iid = np.arange(B), np.arange(B * C).reshape(B, C)
+        pred, _ = NO.forward(P, uid, iid)
+        inv_b = 1.0 / (3 * B)      # (a rank's share of a global batch)
+        gp = BO.bpr_loss_grad(pred, inv_b)
+        _, G = NO.backward(P, uid, iid, gp)
+        t = lambda a: torch.from_numpy(a).to(cuda)
+        ur, ir = t(urows), t(irows)
+        loss_vec, gu, gi, dense, got_pred = eng.neumf_head_fwd_bwd(ur, ir, t(W1), t(b1), t(wo), B, C, inv_b, want_pred=True)
+        torch.cuda.synchronize()
+        assert torch.equal(ur, t(urows)) and torch.equal(ir, t(irows))
+        tol = 3e-5
+        assert_close(got_pred.cpu().numpy(), pred, what="pred", atol_scale=tol)
+        assert_close(loss_vec.cpu().numpy(), BO.bpr_loss_rows(pred)[0], what="loss rows", atol_scale=tol)
+        gu, gi = gu.cpu().numpy(), gi.cpu().numpy()
+        assert_close(gu[:, :d], G["mf_u_embeddings.weight"], what="gu mf", atol_scale=tol)
+        assert_close(gu[:, d:], G["mlp_u_embeddings.weight"], what="gu mlp", atol_scale=tol)
+        assert_close(gi[:, :d], G["mf_i_embeddings.weight"], what="gi mf", atol_scale=tol)
+        assert_close(gi[:, d:], G["mlp_i_embeddings.weight"], what="gi mlp", atol_scale=tol)
+        assert_close(dense["W1"].cpu().numpy(), G["mlp.0.weight"], what="dW1", atol_scale=tol)
+        assert_close(dense["b1"].cpu().numpy(), G["mlp.0.bias"], what="db1", atol_scale=tol)
+        assert_close(dense["w_out"].cpu().numpy(), G["prediction.weight"][0], what="dw_out", atol_scale=tol)
