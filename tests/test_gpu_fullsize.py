@@ -201,9 +201,32 @@ def test_step_ahead_at_the_bench_batch_sample_vs_oracle(world, cuda):
     picks = torch.cat([order[:8], torch.nonzero(cnt == 1).reshape(-1)[:: 40000][:40], torch.nonzero(cnt == 2).reshape(-1)[:: 15000][:40],
                        torch.nonzero(cnt == 3).reshape(-1)[:: 4000][:20]])
     assert int((cnt[picks] == 1).sum()) >= 20 and int((cnt[picks] == 2).sum()) >= 20 and int(cnt[picks].max()) > 32
+    # the numpy ORACLE (oracle/bprmf_oracle.py) on sampled tuples of this very batch: 100 tuples spread over the batch plus every
+    # tuple that touches a picked row with at most three occurrences -- their scores' gradient, loss rows and user gradients are
+    # compared directly, and the expected value of those item rows is rebuilt from the oracle's numbers alone
+    few = picks[cnt[picks] <= 3]
+    occ_few = torch.nonzero(torch.isin(flat, few)).reshape(-1)
+    tsel = torch.unique(torch.cat([torch.arange(0, Bb, Bb // 100, device=cuda), occ_few // (K + 1)]))
+    u_np, i_np = uid[tsel].cpu().numpy(), iid[tsel].cpu().numpy()
+    U_rows, I_rows = U1[uid[tsel]].cpu().numpy(), I1[iid[tsel]].cpu().numpy()           # [T, d], [T, C, d]
+    pred_o = np.einsum("td,tcd->tc", U_rows.astype(np.float64), I_rows.astype(np.float64)).astype(np.float32)
+    g_o = O.bpr_loss_grad(pred_o, inv_b=1.0 / Bb)
+    assert_close(gpred[tsel].cpu().numpy(), g_o, what="gpred of sampled tuples vs the oracle")
+    assert_close(lv[tsel].cpu().numpy(), O.bpr_loss_rows(pred_o)[0], what="loss rows of sampled tuples vs the oracle")
+    ug_o = np.einsum("tc,tcd->td", g_o.astype(np.float64), I_rows.astype(np.float64))
+    assert_close(ugrad[tsel].cpu().numpy(), ug_o, what="user gradients of sampled tuples vs the oracle")
+    where_t = {int(t): k for k, t in enumerate(tsel.tolist())}
     gp = gpred.reshape(-1).double()
     for r in picks.tolist():
         occ = torch.nonzero(flat == r).reshape(-1)
+        if int(cnt[r]) <= 3:     # from the oracle's gradients only
+            gsum = np.zeros(U_rows.shape[1])
+            for o in occ.tolist():
+                k = where_t[o // (K + 1)]
+                gsum += float(g_o[k, o % (K + 1)]) * U_rows[k].astype(np.float64)
+            want = (I1[r].double().cpu().numpy() - lr * gsum).astype(np.float32)
+            assert_update_close(I[r].cpu().numpy(), I1[r].cpu().numpy(), want, what=f"item row {r} (n={int(cnt[r])}) vs the oracle")
+            continue
         gsum = (gp[occ][:, None] * U1[uid[occ // (K + 1)]].double()).sum(0)
         want = (I1[r].double() - lr * gsum).float()
         assert_update_close(I[r].cpu().numpy(), I1[r].cpu().numpy(), want.cpu().numpy(), what=f"item row {r} (n={int(cnt[r])})")

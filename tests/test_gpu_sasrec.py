@@ -48,7 +48,7 @@ def test_sasrec_forward_backward(case, impl, cuda, eng):
     hv, xsave = eng.sasrec_fwd(P["item_emb"], P["pos_emb"], P["layers"], n_heads, hist, lengths, save=True, impl=impl)
     rows = torch.arange(B, device=cuda)
     pred = eng.gather_dot(hv, P["item_emb"], rows, iid)
-    assert_close(pred.cpu().numpy(), g["pred"], what="pred", atol_scale=2e-5)
+    assert_close(pred.cpu().numpy(), g["pred"], what="pred")      # north star: 1e-5 relative fp32
     hv2, _ = eng.sasrec_fwd(P["item_emb"], P["pos_emb"], P["layers"], n_heads, hist, lengths, save=False, impl=impl)
     assert torch.equal(hv, hv2)
 
@@ -89,6 +89,7 @@ def test_sasrec_two_fit_iterations_match_reference(case, tag, opt, cuda, eng):
         assert_close(loss.cpu().numpy()[0], g[tag + "_losses"][step - 1], what=f"loss {step}", rtol=2e-5)
     want = params(g, tag + "/")
     ex = 2e-3 * lr if opt == "Adam" else 0.0
+    G1 = params(g, "G/")     # the reference's autograd gradients of the first batch
     checks = [("item_emb", "i_embeddings.weight", P["item_emb"]), ("pos_emb", "p_embeddings.weight", P["pos_emb"])]
     for l in range(n_layers):
         checks += [(f"L{l}.{k}", "transformer_block.%d.%s" % (l, v), P["layers"][l][k]) for k, v in LAYER_NAMES.items()]
@@ -99,8 +100,17 @@ def test_sasrec_two_fit_iterations_match_reference(case, tag, opt, cuda, eng):
             # reference as well.  Not a comparable quantity; bounded by lr instead.
             assert float(np.abs(t.cpu().numpy() - P0[name]).max()) <= 2.5 * lr
             continue
-        assert_update_close(t.cpu().numpy(), P0[name], want[name], what=what, extra_atol=ex, rtol=2e-4,
-                            outlier_atol=2 * lr if opt == "Adam" else 0.0)
+        if opt == "Adam":
+            # Adam normalises a gradient to a step of about lr whatever its size: an element whose first gradient is summation-order
+            # noise (|g| < 1e-7, against eps = 1e-8) is not a comparable quantity -- those elements are LISTED and excluded, they
+            # must be few, and every other element is held to the tolerance without an outlier allowance
+            decay = 0.0 if "bias" in name else l2      # (the reference's 'bias' group has no weight decay, BaseModel.py:64-73)
+            ill = np.abs(G1[name] + decay * P0[name]) < 1e-7
+            moved = np.abs(want[name] - P0[name]) > 0
+            assert float((ill & moved).mean()) < 0.02, f"{what}: {int((ill & moved).sum())} ill-conditioned elements"
+            assert_update_close(t.cpu().numpy(), P0[name], want[name], what=what, extra_atol=ex, rtol=2e-4, exclude=ill, strict=True)
+        else:
+            assert_update_close(t.cpu().numpy(), P0[name], want[name], what=what, rtol=2e-4)
 
 
 def _random_sasrec(rng, n_items, d, n_layers, L):
