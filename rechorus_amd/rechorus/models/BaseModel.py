@@ -20,6 +20,13 @@ from torch.utils.data import Dataset as BaseDataset
 from rechorus_amd import nn as hnn
 from utils import utils
 
+# Model files written for the reference's pinned stack (numpy 1.x, requirements.txt) spell dtypes `np.int`, `np.object`, `np.float`,
+# `np.bool` (e.g. models/sequential/SASRec.py:69, models/BaseModel.py:141,146 of the reference); numpy >= 1.24 removed those
+# aliases.  Every model file imports this module first, so they are restored here and such files run unmodified.
+for _alias, _type in (("int", int), ("float", float), ("bool", bool), ("object", object)):
+    if _alias not in np.__dict__:
+        setattr(np, _alias, _type)
+
 
 def task_variant(name, task_base, head, reader, runner, log_args, module, forward=None, parse_from=None, doc=None):
     """Build the class `name` = task base (GeneralModel, SequentialModel, ImpressionModel, ContextCTRModel, ...)
