@@ -61,7 +61,9 @@ for st in "$@"; do
       name=${rest%%:*}; args=${rest#*:}
       [ -z "$rest" ] && name=bench && args=""
       [ "$args" == "$rest" ] && args=""
+      t0=$(date +%s.%N)
       timeout 900 python bench.py $args > $OUT/$name.json 2> $OUT/$name.err
+      echo "$name: $(python -c "import time,sys; print(round(time.time()-float(sys.argv[1]),1))" $t0) s wall" | tee $OUT/$name.wall.txt
       summ $OUT/$name.json
       ;;
     ab)
