@@ -642,7 +642,9 @@ def secondary_single_gpu(args):
     return out
 
 
-SHARDED_LEG = ["--workload", "neumf", "--items", "100000001", "--users", "10000001", "--steps", "20", "--warmup", "5",
+# (RC_BENCH_SECONDARY_ROWS="items,users": smaller tables for this leg -- the tests of the N > 1 code path on one GPU set it)
+_SEC_ITEMS, _SEC_USERS = (os.environ.get("RC_BENCH_SECONDARY_ROWS") or "100000001,10000001").split(",")
+SHARDED_LEG = ["--workload", "neumf", "--items", _SEC_ITEMS, "--users", _SEC_USERS, "--steps", "20", "--warmup", "5",
                "--no-cpu-baseline", "--no-secondary"]
 
 
@@ -652,7 +654,7 @@ def secondary_sharded_in_process(args, rank, world, device, dist):
     import copy
     import gc
     a = copy.copy(args)
-    a.workload, a.items, a.users, a.emb_size, a.num_neg = "neumf", 100_000_001, 10_000_001, 128, 4
+    a.workload, a.items, a.users, a.emb_size, a.num_neg = "neumf", int(_SEC_ITEMS), int(_SEC_USERS), 128, 4
     a.steps, a.warmup, a.no_cpu_baseline = 20, 5, True
     gc.collect()
     torch.cuda.empty_cache()

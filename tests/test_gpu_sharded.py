@@ -201,6 +201,7 @@ def test_bench_multi_rank_code_path_on_one_gpu(launcher, workload, extra, cuda):
     from conftest import ROOT
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
     env["RC_BENCH_ONE_DEVICE"] = "1"
+    env["RC_BENCH_SECONDARY_ROWS"] = "300001,30001"     # the config-4 leg of the contract workload's line, on small tables here
     tail = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--dist-backend", "gloo",
             "--workload", workload, "--no-cpu-baseline"] + extra
     if launcher == "torchrun":
@@ -217,6 +218,11 @@ def test_bench_multi_rank_code_path_on_one_gpu(launcher, workload, extra, cuda):
     ph = out["sharded_phases_ms"]
     if workload == "bprmf":
         assert len(ph) == 8
+        # the contract workload carries the sharded NeuMF leg of BASELINE configs[3] (its own rank group under the self-launcher,
+        # the same ranks under torch.distributed.run), summarised -- still ONE line
+        sec = out["secondary"]["neumf_100M"]
+        assert sec.get("value", 0) > 0 and sec["n_gpus"] == 2 and "NeuMF" in sec["workload"], sec
+        assert {"fetch_rows", "head_fwd_loss", "push_grads", "table_update"} <= set(sec["sharded_phases_ms"]) and sec["sharded_wire_bytes_rank0"]
     elif workload == "neumf":
         assert {"fetch_rows", "head_fwd_loss", "head_bwd", "push_grads", "table_update", "dense_update"} <= set(ph)
         assert out["sharded_wire_bytes_rank0"]
