@@ -500,15 +500,22 @@ def model_roofline(args, trainer, batches, engine):
     if dom == "fused_step":
         # the one kernel that does both: rated against the roof it is nearer to, the other fraction beside it
         t = ph[dom] * 1e-3
+        traffic = None     # FETCH_SIZE + WRITE_SIZE of the kernel from the committed PMC passes (tools/gpu_run.sh pmc:neumf), default shape only
+        if (args.items, args.users, args.emb_size, args.num_neg, args.batch, args.opt) == (10_000_001, 1_000_001, 128, 4, 65536, "SGD"):
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_neumf_latest.json")))
+                traffic = max(v["hbm_bytes_per_launch"] for k, v in pmc.items() if k.startswith("neumf_step_kernel"))
+            except Exception:
+                traffic = None
         f_mfma, f_hbm = flops[dom] / t / 1e12 / F32_MFMA_PEAK_TFLOPS, fused_bytes / t / 1e9 / HBM_PEAK_GBPS
         if f_hbm >= f_mfma:
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": fused_bytes / t / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                               "frac": f_hbm, "traffic": None, "algorithmic_bytes_per_launch": fused_bytes, "avg_ms": ph[dom],
+                               "frac": f_hbm, "traffic": traffic, "algorithmic_bytes_per_launch": fused_bytes, "avg_ms": ph[dom],
                                "frac_of_mfma_peak": f_mfma}
         else:
             out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": flops[dom] / t / 1e12, "peak": F32_MFMA_PEAK_TFLOPS,
-                               "unit": "TFLOP/s", "frac": f_mfma, "traffic": None, "algorithmic_flops_per_launch": flops[dom],
-                               "avg_ms": ph[dom], "frac_of_hbm_peak": f_hbm}
+                               "unit": "TFLOP/s", "frac": f_mfma, "traffic": traffic, "algorithmic_flops_per_launch": flops[dom],
+                               "avg_ms": ph[dom], "frac_of_hbm_peak": f_hbm, "algorithmic_bytes_per_launch": fused_bytes}
     elif dom in hbm_bytes:
         ach = hbm_bytes[dom] / (ph[dom] * 1e-3) / 1e9
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

@@ -81,9 +81,16 @@ for st in "$@"; do
       f=$(find $OUT/prof_$name -name "*kernel_stats.csv" | head -1)
       [ -n "$f" ] && cut -c1-110 "$f" | head -14
       ;;
-    pmc)   # the BPRMF step's FETCH_SIZE / WRITE_SIZE passes, calibrated on a table copy (tools/pmc_collect.sh, pmc_summarize.py)
-      bash tools/pmc_collect.sh $TAG/pmc > $OUT/pmc.log 2>&1
-      head -16 $OUT/pmc/pmc_summary.txt
+    pmc)   # FETCH_SIZE / WRITE_SIZE passes of a training step, calibrated on a table copy (tools/pmc_collect.sh, pmc_summarize.py);
+           # pmc = the BPRMF step -> pmc/, pmc:<name>:<workload args> e.g. pmc:neumf:--workload neumf -> pmc_<name>/
+      if [ -z "$rest" ]; then
+        bash tools/pmc_collect.sh $TAG/pmc > $OUT/pmc.log 2>&1
+        head -16 $OUT/pmc/pmc_summary.txt
+      else
+        name=${rest%%:*}; args=${rest#*:}
+        bash tools/pmc_collect.sh $TAG/pmc_$name "$args" > $OUT/pmc_$name.log 2>&1
+        head -16 $OUT/pmc_$name/pmc_summary.txt
+      fi
       ;;
     py)
       name=${rest%%:*}; args=${rest#*:}

@@ -25,7 +25,8 @@ def load(dirname, counter):
     return per
 
 
-KEYS = ("bprmf_fwd_bwd_kernel", "plan_rows_kernel", "plan_bucket_kernel", "plan_flags_kernel", "plan_bitmap_kernel", "plan_bucket_hash_kernel", "plan_scatter_kernel", "plan_count_kernel",
+KEYS = ("neumf_step_kernel", "neumf_mark_owner_kernel", "neumf_mark_multi_kernel", "neumf_unmark_kernel", "neumf_reduce_partials_kernel",
+        "bprmf_fwd_bwd_kernel", "plan_rows_kernel", "plan_bucket_kernel", "plan_flags_kernel", "plan_bitmap_kernel", "plan_bucket_hash_kernel", "plan_scatter_kernel", "plan_count_kernel",
         "plan_colscan_kernel", "plan_chunk_kernel", "plan_final_kernel", "seg_update_multi_x2_kernel", "seg_update_kernel", "long_chunk_kernel", "long_final_kernel",
         "long_plan_kernel", "segment_heads_kernel", "make_keys_kernel", "reduce_sum_kernel",
         "radix_sort_onesweep", "onesweep_histograms", "merge_sort", "block_sort")
