@@ -613,6 +613,11 @@ typedef struct rc_plan_row {
 int rc_bucket_plan_supported(int64_t n_a, int64_t n_b, int64_t range_a, int64_t range_b);
 size_t rc_bucket_plan_workspace_bytes(int64_t n_a, int64_t n_b);
 size_t rc_bucket_plan_flags_bytes(int64_t n_a); /* size of single_a: n_a rounded up to whole 8,192-byte tiles */
+/* Device address (inside the workspace rc_bucket_plan was given) of the plan's status word, valid once the plan's kernels have
+ * run: 0 = complete; 1 = an id lay outside its table (nn.Embedding would raise a device assert; the key was kept in bounds, the
+ * plan is NOT what the caller meant); 2 = a hashed bucket met more distinct rows than its table holds (plan incomplete; never at
+ * the sizes rc_bucket_plan_supported admits).  Reading it costs a device -> host copy: for tests and debugging.               */
+const uint32_t* rc_bucket_plan_status_ptr(const void* ws, int64_t n_a, int64_t n_b);
 
 /* ids_a[n_a] in [0, range_a), ids_b[n_b] in [0, range_b) (int64, reference layout).
  * list_single_a = 0: rows of list a that occur once are NOT listed; instead single_a[p] = 1 at their position

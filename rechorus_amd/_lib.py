@@ -152,6 +152,7 @@ SIGNATURES = {
     "rc_bucket_plan_supported": (_i, [_i64, _i64, _i64, _i64]),
     "rc_bucket_plan_workspace_bytes": (_sz, [_i64, _i64]),
     "rc_bucket_plan_flags_bytes": (_sz, [_i64]),
+    "rc_bucket_plan_status_ptr": (_p, [_p, _i64, _i64]),
     "rc_bucket_plan": (_i, [_p, _i64, _i64, _p, _i64, _i64, _i, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "rc_plan_update_workspace_bytes": (_sz, [_i64, _i]),
     "rc_plan_update": (_i, [_p, _p, _p, _i, _p, _p, _p, _i64, _p, _p, _p, _i, _p, _i64, _hp, _p, _sz, _p]),

@@ -169,6 +169,9 @@ __device__ __forceinline__ uint32_t plan_key(const PlanArgs& a, uint32_t p) {
 template <bool HASHED>
 __device__ __forceinline__ uint32_t plan_bucket_of(const PlanArgs& a, uint32_t key, bool side_b, bool* bad) {
   if (HASHED) {
+    // (the bucket of a hashed key is always in range; the id itself may still lie outside its table -- flagged like the direct
+    //  geometry's, so that PC_STATUS tells a caller that nn.Embedding would have raised)
+    if (bad && (int64_t)key >= (side_b ? a.range_b : a.range_a)) *bad = true;
     const uint32_t h = key * 0x9E3779B1u;
     const int lg = side_b ? a.g.log_nb_b : a.g.log_nb_a;
     const uint32_t b = lg ? h >> (32 - lg) : 0u;
@@ -1075,6 +1078,11 @@ extern "C" int rc_bucket_plan_supported(int64_t n_a, int64_t n_b, int64_t range_
 extern "C" size_t rc_bucket_plan_workspace_bytes(int64_t n_a, int64_t n_b) {
   if (n_a < 0 || n_b < 0) return 0;
   return carve_plan_ws(nullptr, n_a + n_b).total;
+}
+
+extern "C" const uint32_t* rc_bucket_plan_status_ptr(const void* ws, int64_t n_a, int64_t n_b) {
+  if (!ws || n_a < 0 || n_b < 0) return nullptr;
+  return carve_plan_ws(const_cast<void*>(ws), n_a + n_b).counters + PC_STATUS;
 }
 
 extern "C" size_t rc_bucket_plan_flags_bytes(int64_t n_a) {

@@ -12,6 +12,8 @@
 // Same arithmetic as the large-batch step for rows of up to 32 occurrences; hotter rows are summed by a whole wave
 // (lane-group g takes occurrences g, g + G, ...; groups combined in a fixed butterfly), still deterministic.
 // Reference semantics: helpers/BaseRunner.py:193-206 around models/general/BPRMF.py:34-45, models/BaseModel.py:182-185.
+#include <mutex>
+
 #include "opt_math.hpp"
 #include "small_plan.hpp"
 
@@ -375,9 +377,25 @@ int small_step_launch(float* U, float* I, float* mU, float* vU, float* mI, float
 
 using namespace rc;
 
+// the plan workgroups keep their tables in ~148 KB of dynamic LDS: a part with less (not gfx950) has no instance
+static bool small_lds_fits() {
+  static std::mutex mu;
+  static int fits[64];
+  static bool known[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!known[dev]) {
+    int lds = 0;
+    fits[dev] = hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess && (size_t)lds >= kSmallLdsBytesBig;
+    known[dev] = true;
+  }
+  return fits[dev] != 0;
+}
+
 extern "C" int rc_small_row_sums_supported(int64_t n, int64_t n_rows, int d) {
   return (n >= 1 && n <= kSmallMaxKeys && n_rows >= 1 && n_rows < ((int64_t)1 << 32) - 1 &&
-          ((d >= 1 && d <= 4) || d == 16 || d == 32 || d == 64 || d == 128)) ? 1 : 0;
+          ((d >= 1 && d <= 4) || d == 16 || d == 32 || d == 64 || d == 128) && small_lds_fits()) ? 1 : 0;
 }
 
 extern "C" size_t rc_small_row_sums_workspace_bytes(int64_t n) {
@@ -406,10 +424,16 @@ extern "C" int rc_small_row_sums(const int64_t* ids, int64_t n, int64_t n_rows, 
   memset(&p, 0, sizeof(p));
   p.ids_a = ids; p.ids_b = nullptr; p.n_a = (uint32_t)n; p.n = (uint32_t)n; p.base_b = 0xFFFFFFFFu;   // one list: every key is a row of it
   p.rows = rows; p.occ = occ; p.cnt = cnt;
-  static bool attr_done = false;
-  if (!attr_done) {
-    RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(small_plan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSmallLdsBytesBig));
-    attr_done = true;
+  {   // function attributes are per device: once per device of the process, under a lock (callers may drive several GPUs / threads)
+    static std::mutex mu;
+    static bool done[64] = {};
+    int dev = 0;
+    RC_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    if (dev < 0 || dev >= 64 || !done[dev]) {
+      RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(small_plan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSmallLdsBytesBig));
+      if (dev >= 0 && dev < 64) done[dev] = true;
+    }
   }
   hipLaunchKernelGGL(small_plan_kernel, dim3(kSmallPlanWgs), dim3(kSmallThreads), kSmallLdsBytesBig, s, p);
   RC_LAUNCH_CHECK();

@@ -236,6 +236,23 @@ class Plan:
                   _ptr(b, torch.int64, "ids_b") if self.n_b else None, self.n_b, int(range_b), 1 if list_single_a else 0,
                   None if list_single_a else p(buf[o_single:]),
                   p(self.rows_a), p(self.cnt), p(self.rows_b), p(self.cnt[4:]), p(self.occ), p(ws), ws.numel(), _stream())
+        self._ws = ws
+        if _PLAN_CHECK:     # RC_PLAN_CHECK=1: every plan reads its status word back (a host sync per plan: debugging only)
+            self.check()
+
+    def status(self):
+        """the plan's status word (rc_bucket_plan_status_ptr; synchronises): 0 ok, 1 an id outside its table, 2 hashed bucket overflow"""
+        if self.n_a + self.n_b == 0:
+            return 0
+        addr = _lib.load().rc_bucket_plan_status_ptr(C.c_void_p(self._ws.data_ptr()), self.n_a, self.n_b)
+        off = (addr - self._ws.data_ptr()) // 4
+        return int(self._ws.view(torch.int32)[off].item())
+
+    def check(self):
+        st = self.status()
+        if st:
+            raise _lib.RechorusHipError("rc_bucket_plan", -1, {1: "an id lies outside its table (nn.Embedding would raise)",
+                                                               2: "a hashed bucket overflowed: the plan is incomplete"}.get(st, str(st)))
 
     def row_sums(self, side, out, coef=None, src=None, src_index=None, div=1, src2=None, n_split=None):
         """rc_plan_row_sums on list `side`: out[row] = summed gradient row of every listed row (other rows untouched)"""
@@ -400,6 +417,7 @@ _USE_PLAN = os.environ.get("RC_TABLE_UPDATE", "auto") != "sort"
 _SEG_ROWS = os.environ.get("RC_SEG_ROWS", "1") != "0"
 # SasrecTrainer: id sort beside the encoder, position gradient beside the item update, on a second stream (RC_SAS_OVERLAP=0: one stream)
 _SAS_OVERLAP = os.environ.get("RC_SAS_OVERLAP", "1") != "0"
+_PLAN_CHECK = os.environ.get("RC_PLAN_CHECK", "0") == "1"        # every engine.Plan verifies its status word (host sync; debugging)
 _NEUMF_OVERLAP = os.environ.get("RC_NEUMF_OVERLAP", "1") != "0"   # NeumfTrainer: bucket plan beside the head kernels
 _NEUMF_FUSED = os.environ.get("RC_NEUMF_FUSED", "1") != "0"       # NeumfTrainer: rc_neumf_train_step (A/B against the three-kernel step)
 _SAS_OVERLAP_MIN = int(os.environ.get("RC_SAS_OVERLAP_MIN", "131072"))   # candidate + history occurrences of the batch

@@ -654,3 +654,21 @@ def test_neumf_and_sasrec_trainers_plan_equals_sort(cuda, eng, monkeypatch):
         assert torch.equal(Pa["layers"][0][k], Pb["layers"][0][k]), k
     sa, sb = ta._st(Pa["item_emb"]), tb._st(Pb["item_emb"])
     assert torch.equal(sa["m"], sb["m"]) and torch.equal(sa["v"], sb["v"])
+
+
+@pytest.mark.parametrize("hashed", [False, True])
+def test_plan_status_word_reports_ids_outside_their_table(hashed, cuda, eng):
+    """rc_bucket_plan_status_ptr: 0 for a complete plan, 1 when an id lies outside its table (nn.Embedding would raise a device assert),
+    in the id-range and in the hashed geometry; Plan.check() raises (RC_PLAN_CHECK=1 runs it on every plan)"""
+    from rechorus_amd import _lib
+    rng = np.random.default_rng(5)
+    n_rows = 50_000_000 if hashed else 200_000
+    ids = rng.integers(0, n_rows, size=20_000).astype(np.int64)
+    good = eng.Plan(torch.from_numpy(ids).to(cuda), n_rows, tag="t.status")
+    assert good.status() == 0
+    good.check()
+    ids[123] = n_rows + 5
+    bad = eng.Plan(torch.from_numpy(ids).to(cuda), n_rows, tag="t.status")
+    assert bad.status() == 1
+    with pytest.raises(_lib.RechorusHipError, match="outside its table"):
+        bad.check()
