@@ -182,6 +182,8 @@ __device__ __forceinline__ uint32_t plan_bucket_of(const PlanArgs& a, uint32_t k
     b = a.g.nb - 1;
     if (bad) *bad = true;
   }
+  // an id beyond its table that still falls into the last bucket's range (or into the other list's buckets) is flagged too
+  if (bad && (side_b ? (int64_t)key - (int64_t)a.g.base_b >= a.range_b || key < a.g.base_b : (int64_t)key >= a.range_a)) *bad = true;
   return b;
 }
 

@@ -1315,9 +1315,13 @@ class SasrecTrainer:
             # scores, BPR loss, d loss / d pred and d loss / d hv in ONE pass over the candidate rows: the fused BPRMF kernel
             # with the encoder output as the "user" row (SASRec.py:80-81, BaseModel.py:182-185); three launches and two
             # more passes over the [B, C] rows before
-            if getattr(self, "_rows", None) is None or self._rows.numel() != B or self._rows.device != hist.device:
-                self._rows = torch.arange(B, device=hist.device)
-            _, loss_vec, gpred, dhv = bprmf_fwd_bwd(hv, I, self._rows, iid, want_pred=False)
+            # (one tensor per batch size, kept for the trainer's life: a captured step holds its ADDRESS -- replacing it when another
+            #  batch size comes by, e.g. the short last batch of an epoch, would leave the graph of the first size reading freed memory)
+            rows_by = self.__dict__.setdefault("_rows_by", {})
+            key_rows = (B, str(hist.device))
+            if key_rows not in rows_by:
+                rows_by[key_rows] = torch.arange(B, device=hist.device)
+            _, loss_vec, gpred, dhv = bprmf_fwd_bwd(hv, I, rows_by[key_rows], iid, want_pred=False)
             if not overlap:
                 self.loss = reduce_sum(loss_vec, 1.0 / B)   # (two streams: the mean is formed on the side stream below)
         with _PhaseTimer(self, "encoder_bwd"):
