@@ -357,6 +357,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           f32x4s acc[KG];
 #pragma unroll
           for (int k = 0; k < KG; ++k) acc[k] = f32x4s{0.f, 0.f, 0.f, 0.f};
+          // Adam / Adagrad: the optimizer state of the slices this group updates is requested BEFORE the group's 64 MFMAs and
+          // consumed after them (opt_row4 at the point of use waited a full memory latency per slice with nothing beside it)
+          float4 pm[KG], pv[KG];
+          const bool upd = valid && single;
+          if (MODE != MODE_SGD) {
+#pragma unroll
+            for (int k = 0; k < KG; ++k) {
+              pm[k] = pv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+              const size_t idx4 = (size_t)(item_c * D + 16 * (kt0 + k) + 4 * g) / 4;
+              if (upd && mode_has_m(MODE)) pm[k] = load_stream4(reinterpret_cast<const float4*>(a.m_mlp_i) + idx4);
+              if (upd && mode_has_v(MODE)) pv[k] = load_stream4(reinterpret_cast<const float4*>(a.v_mlp_i) + idx4);
+            }
+          }
           back_tiles<NT, KG, SW>(acc, wbwd_i + 16 * kt0, dz);
           if (valid) {
 #pragma unroll
@@ -370,7 +383,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 float* dst = single ? (a.mlp_i + item_c * a.ld_i + 16 * kt + 4 * g) : (grow + 16 * kt);
                 store_row4(reinterpret_cast<float4*>(dst), single ? w1 : gr);
               } else if (single) {
-                opt_row4<MODE>(a.opt, a.mlp_i, a.m_mlp_i, a.v_mlp_i, (size_t)(item_c * D + 16 * kt + 4 * g) / 4, w0, gr);
+                const size_t idx4 = (size_t)(item_c * D + 16 * kt + 4 * g) / 4;
+                float4 w1 = w0;
+                opt_apply4<MODE>(a.opt, w1, pm[k], pv[k], gr);
+                store_row4(reinterpret_cast<float4*>(a.mlp_i) + idx4, w1);
+                if (mode_has_m(MODE)) store_row4(reinterpret_cast<float4*>(a.m_mlp_i) + idx4, pm[k]);
+                if (mode_has_v(MODE)) store_row4(reinterpret_cast<float4*>(a.v_mlp_i) + idx4, pv[k]);
               } else {
                 *reinterpret_cast<float4*>(grow + 16 * kt) = gr;
               }
@@ -474,6 +492,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const float gc = sp[c * 16 + i];
         const bool single = mflag == 0;
         float* grow = a.g_mf_i + (tup * C + c) * a.ld_gi + 4 * g;
+        // Adam / Adagrad: the state slices of this candidate's mf_i row, requested together before the arithmetic
+        float4 qm[MODE == MODE_SGD ? 1 : NCU], qv[MODE == MODE_SGD ? 1 : NCU];
+        if (MODE != MODE_SGD) {
+#pragma unroll
+          for (int cc = 0; cc < NCU; ++cc) {
+            qm[cc] = qv[cc] = make_float4(0.f, 0.f, 0.f, 0.f);
+            const size_t idx4 = (size_t)(item_c * D + 16 * cc + 4 * g) / 4;
+            if (valid && single && mode_has_m(MODE)) qm[cc] = load_stream4(reinterpret_cast<const float4*>(a.m_mf_i) + idx4);
+            if (valid && single && mode_has_v(MODE)) qv[cc] = load_stream4(reinterpret_cast<const float4*>(a.v_mf_i) + idx4);
+          }
+        }
 #pragma unroll
         for (int cc = 0; cc < NCU; ++cc) {
           const float4 w = *reinterpret_cast<const float4*>(swo + 16 * cc + 4 * g);
@@ -488,7 +517,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
               float* dst = single ? (a.mf_i + item_c * a.ld_i + 16 * cc + 4 * g) : (grow + 16 * cc);
               store_row4(reinterpret_cast<float4*>(dst), single ? w1 : gr);
             } else if (single) {
-              opt_row4<MODE>(a.opt, a.mf_i, a.m_mf_i, a.v_mf_i, (size_t)(item_c * D + 16 * cc + 4 * g) / 4, w0, gr);
+              const size_t idx4 = (size_t)(item_c * D + 16 * cc + 4 * g) / 4;
+              float4 w1 = w0;
+              opt_apply4<MODE>(a.opt, w1, qm[MODE == MODE_SGD ? 0 : cc], qv[MODE == MODE_SGD ? 0 : cc], gr);
+              store_row4(reinterpret_cast<float4*>(a.mf_i) + idx4, w1);
+              if (mode_has_m(MODE)) store_row4(reinterpret_cast<float4*>(a.m_mf_i) + idx4, qm[MODE == MODE_SGD ? 0 : cc]);
+              if (mode_has_v(MODE)) store_row4(reinterpret_cast<float4*>(a.v_mf_i) + idx4, qv[MODE == MODE_SGD ? 0 : cc]);
             } else {
               *reinterpret_cast<float4*>(grow + 16 * cc) = gr;
             }
