@@ -250,7 +250,8 @@ class DeepfmBench:
 def deepfm_roofline(args, trainer, batches, engine):
     """MLP_Block GEMMs (csrc/mlp.hip, fp32 MFMA) against the fp32 MFMA peak, over the eager forward + backward phases"""
     trainer.timing = {}
-    for s in range(10):
+    s0 = args.warmup + args.steps      # the batch sequence of the timed loop continues: its last step announced batch s0
+    for s in range(s0, s0 + 20):
         if args.workload == "neumf":   # steady state of the timed loop: every step announces the following batch
             trainer.step(*batches[s % len(batches)], next_batch=batches[(s + 1) % len(batches)])
         else:

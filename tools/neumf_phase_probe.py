@@ -1,0 +1,34 @@
+"""Does recording phase events change the NeuMF step?  Wall time per step of the same loop with trainer.timing off / on
+(bench.py's model_roofline records hipEvents around every phase): gpurun -- 'python tools/neumf_phase_probe.py'"""
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, ".")
+import bench  # noqa: E402
+from rechorus_amd import engine  # noqa: E402
+
+sys.argv = ["bench.py", "--workload", "neumf"]
+args = bench.parse()
+dev = torch.device("cuda:0")
+batches = bench.make_batches(args, dev, seed=99)
+tr = bench.make_neumf_trainer(args, 1, dev, engine)
+n = len(batches)
+
+
+def loop(steps, s0=0):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(s0, s0 + steps):
+        tr.step(*batches[s % n], next_batch=batches[(s + 1) % n])
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3
+
+
+loop(10)
+print("timing off: %.4f ms/step" % loop(40, 10))
+tr.timing = {}
+print("timing on : %.4f ms/step" % loop(40, 50), {k: round(v, 4) for k, v in engine.phases_ms(tr).items()})
+tr.timing = None
+print("timing off: %.4f ms/step" % loop(40, 90))
