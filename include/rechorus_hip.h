@@ -488,6 +488,20 @@ int rc_neumf_train_step(float* mf_u, float* mf_i, float* mlp_u, float* mlp_i, fl
                         float* g_mf_i, float* g_mlp_i, float* gu_mf, float* gu_mlp, float* dW1, float* db1,
                         float* dw_out, void* ws, size_t ws_bytes, rc_stream_t stream);
 
+/* The marking passes of rc_neumf_train_step on their own, for callers that know the FOLLOWING batch (BaseRunner.fit does: the
+ * reference's DataLoader runs ahead of the loop, helpers/BaseRunner.py:182-186): rc_neumf_mark_rows fills a marks buffer for iid
+ * [n = B C] on any stream -- e.g. beside the current step's table updates --, rc_neumf_train_step_marked is rc_neumf_train_step
+ * without its two marking launches and without the clearing pass (same arguments, same results bit for bit), and
+ * rc_neumf_unmark_rows clears the flags again before the buffer is marked for another batch.  Two buffers alternate.          */
+int rc_neumf_mark_rows(const int64_t* iid, int64_t n, int64_t n_items, void* marks, rc_stream_t stream);
+int rc_neumf_unmark_rows(const int64_t* iid, int64_t n, int64_t n_items, void* marks, rc_stream_t stream);
+int rc_neumf_train_step_marked(float* mf_u, float* mf_i, float* mlp_u, float* mlp_i, float* m_mf_i, float* v_mf_i,
+                               float* m_mlp_i, float* v_mlp_i, const float* W1, const float* b1, const float* w_out,
+                               const int64_t* uid, const int64_t* iid, int B, int C, int d, int l1, int64_t n_items,
+                               void* marks, const rc_opt_hyper* h, float inv_b, float* loss_vec, float* pred,
+                               float* g_mf_i, float* g_mlp_i, float* gu_mf, float* gu_mlp, float* dW1, float* db1,
+                               float* dw_out, void* ws, size_t ws_bytes, rc_stream_t stream);
+
 /* The same kernel without table updates, on row blocks with a stride: forward, BPR loss and backward of the NeuMF head for
  * callers that own neither the tables nor the optimizer -- the row-sharded step (rechorus_amd/sharded.py, ShardedNeumf), where
  * the rows of a batch were fetched from their owners into blocks [rows, mf | mlp] (ld = 2 d) and the gradient rows travel back

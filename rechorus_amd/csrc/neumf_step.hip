@@ -683,12 +683,35 @@ extern "C" size_t rc_neumf_train_step_marks_bytes(int64_t n_items) {
   return n_items < 1 ? 0 : align_up((size_t)n_items * sizeof(uint32_t), 256) + align_up((size_t)n_items, 256);
 }
 
-extern "C" int rc_neumf_train_step(float* mf_u, float* mf_i, float* mlp_u, float* mlp_i, float* m_mf_i, float* v_mf_i,
-                                   float* m_mlp_i, float* v_mlp_i, const float* W1, const float* b1, const float* w_out,
-                                   const int64_t* uid, const int64_t* iid, int B, int C, int d, int l1, int64_t n_items,
-                                   void* marks, const rc_opt_hyper* h, float inv_b, float* loss_vec, float* pred,
-                                   float* g_mf_i, float* g_mlp_i, float* gu_mf, float* gu_mlp, float* dW1, float* db1,
-                                   float* dw_out, void* ws, size_t ws_bytes, rc_stream_t stream) {
+// the two marking passes / the clearing pass on their own: a caller that knows the NEXT batch (BaseRunner.fit does) marks it on a
+// second stream while this step's updates run and hands the prepared buffer to rc_neumf_train_step_marked
+extern "C" int rc_neumf_mark_rows(const int64_t* iid, int64_t n, int64_t n_items, void* marks, rc_stream_t stream) {
+  if (n == 0) return RC_OK;
+  RC_REQUIRE(iid && marks && n > 0 && n < ((int64_t)1 << 32) && n_items >= 1, "rc_neumf_mark_rows: bad arguments");
+  uint32_t* owner = reinterpret_cast<uint32_t*>(marks);
+  uint8_t* multi = reinterpret_cast<uint8_t*>(marks) + align_up((size_t)n_items * sizeof(uint32_t), 256);
+  const unsigned blocks = (unsigned)((n + 255) / 256);
+  hipLaunchKernelGGL(neumf_mark_owner_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), iid, n, owner);
+  hipLaunchKernelGGL(neumf_mark_multi_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), iid, n, owner, multi);
+  RC_LAUNCH_CHECK();
+  return RC_OK;
+}
+
+extern "C" int rc_neumf_unmark_rows(const int64_t* iid, int64_t n, int64_t n_items, void* marks, rc_stream_t stream) {
+  if (n == 0) return RC_OK;
+  RC_REQUIRE(iid && marks && n > 0 && n_items >= 1, "rc_neumf_unmark_rows: bad arguments");
+  uint8_t* multi = reinterpret_cast<uint8_t*>(marks) + align_up((size_t)n_items * sizeof(uint32_t), 256);
+  hipLaunchKernelGGL(neumf_unmark_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), iid, n, multi);
+  RC_LAUNCH_CHECK();
+  return RC_OK;
+}
+
+static int neumf_train_step_impl(bool marked, float* mf_u, float* mf_i, float* mlp_u, float* mlp_i, float* m_mf_i, float* v_mf_i,
+                                 float* m_mlp_i, float* v_mlp_i, const float* W1, const float* b1, const float* w_out,
+                                 const int64_t* uid, const int64_t* iid, int B, int C, int d, int l1, int64_t n_items,
+                                 void* marks, const rc_opt_hyper* h, float inv_b, float* loss_vec, float* pred,
+                                 float* g_mf_i, float* g_mlp_i, float* gu_mf, float* gu_mlp, float* dW1, float* db1,
+                                 float* dw_out, void* ws, size_t ws_bytes, rc_stream_t stream) {
   if (B == 0) return RC_OK;
   RC_REQUIRE(mf_u && mf_i && mlp_u && mlp_i && W1 && b1 && w_out && uid && iid && marks && loss_vec && g_mf_i && g_mlp_i && gu_mf &&
                  gu_mlp && dW1 && db1 && dw_out && ws,
@@ -711,9 +734,11 @@ extern "C" int rc_neumf_train_step(float* mf_u, float* mf_i, float* mlp_u, float
   uint32_t* owner = reinterpret_cast<uint32_t*>(marks);
   uint8_t* multi = reinterpret_cast<uint8_t*>(marks) + align_up((size_t)n_items * sizeof(uint32_t), 256);
   const unsigned mark_blocks = (unsigned)((n + 255) / 256);
-  hipLaunchKernelGGL(neumf_mark_owner_kernel, dim3(mark_blocks), dim3(256), 0, s, iid, n, owner);
-  hipLaunchKernelGGL(neumf_mark_multi_kernel, dim3(mark_blocks), dim3(256), 0, s, iid, n, owner, multi);
-  RC_LAUNCH_CHECK();
+  if (!marked) {
+    hipLaunchKernelGGL(neumf_mark_owner_kernel, dim3(mark_blocks), dim3(256), 0, s, iid, n, owner);
+    hipLaunchKernelGGL(neumf_mark_multi_kernel, dim3(mark_blocks), dim3(256), 0, s, iid, n, owner, multi);
+    RC_LAUNCH_CHECK();
+  }
   a.mf_u = mf_u; a.mf_i = mf_i; a.mlp_u = mlp_u; a.mlp_i = mlp_i;
   a.ld_u = a.ld_i = a.ld_gi = a.ld_gu = d;
   a.m_mf_i = m_mf_i; a.v_mf_i = v_mf_i; a.m_mlp_i = m_mlp_i; a.v_mlp_i = v_mlp_i;
@@ -729,11 +754,31 @@ extern "C" int rc_neumf_train_step(float* mf_u, float* mf_i, float* mlp_u, float
   if (mode == MODE_SGD) rc = dispatch_step<MODE_SGD>(a, d, l1, grid, s);
   else if (mode == MODE_ADAM) rc = dispatch_step<MODE_ADAM>(a, d, l1, grid, s);
   else rc = dispatch_step<MODE_ADAGRAD>(a, d, l1, grid, s);
-  // the flags go back to zero whatever happened to the step
-  hipLaunchKernelGGL(neumf_unmark_kernel, dim3(mark_blocks), dim3(256), 0, s, iid, n, multi);
+  // the flags go back to zero whatever happened to the step (prepared marks: the caller clears them, rc_neumf_unmark_rows)
+  if (!marked) hipLaunchKernelGGL(neumf_unmark_kernel, dim3(mark_blocks), dim3(256), 0, s, iid, n, multi);
   RC_TRY(rc);
   RC_LAUNCH_CHECK();
   return neumf_reduce_partials(a.pW1, a.pb1, a.pwout, dW1, db1, dw_out, cW, cb, co, grid, s);
+}
+
+extern "C" int rc_neumf_train_step(float* mf_u, float* mf_i, float* mlp_u, float* mlp_i, float* m_mf_i, float* v_mf_i,
+                                   float* m_mlp_i, float* v_mlp_i, const float* W1, const float* b1, const float* w_out,
+                                   const int64_t* uid, const int64_t* iid, int B, int C, int d, int l1, int64_t n_items,
+                                   void* marks, const rc_opt_hyper* h, float inv_b, float* loss_vec, float* pred,
+                                   float* g_mf_i, float* g_mlp_i, float* gu_mf, float* gu_mlp, float* dW1, float* db1,
+                                   float* dw_out, void* ws, size_t ws_bytes, rc_stream_t stream) {
+  return neumf_train_step_impl(false, mf_u, mf_i, mlp_u, mlp_i, m_mf_i, v_mf_i, m_mlp_i, v_mlp_i, W1, b1, w_out, uid, iid, B, C, d, l1,
+                               n_items, marks, h, inv_b, loss_vec, pred, g_mf_i, g_mlp_i, gu_mf, gu_mlp, dW1, db1, dw_out, ws, ws_bytes, stream);
+}
+
+extern "C" int rc_neumf_train_step_marked(float* mf_u, float* mf_i, float* mlp_u, float* mlp_i, float* m_mf_i, float* v_mf_i,
+                                          float* m_mlp_i, float* v_mlp_i, const float* W1, const float* b1, const float* w_out,
+                                          const int64_t* uid, const int64_t* iid, int B, int C, int d, int l1, int64_t n_items,
+                                          void* marks, const rc_opt_hyper* h, float inv_b, float* loss_vec, float* pred,
+                                          float* g_mf_i, float* g_mlp_i, float* gu_mf, float* gu_mlp, float* dW1, float* db1,
+                                          float* dw_out, void* ws, size_t ws_bytes, rc_stream_t stream) {
+  return neumf_train_step_impl(true, mf_u, mf_i, mlp_u, mlp_i, m_mf_i, v_mf_i, m_mlp_i, v_mlp_i, W1, b1, w_out, uid, iid, B, C, d, l1,
+                               n_items, marks, h, inv_b, loss_vec, pred, g_mf_i, g_mlp_i, gu_mf, gu_mlp, dW1, db1, dw_out, ws, ws_bytes, stream);
 }
 
 extern "C" int rc_neumf_head_fwd_bwd(const float* mf_u, const float* mlp_u, int64_t ld_u, const float* mf_i, const float* mlp_i,

@@ -668,10 +668,16 @@ def neumf_train_step_supported(Cn, d, l1):
     return bool(_lib.load().rc_neumf_train_step_supported(int(Cn), int(d), int(l1)))
 
 
-def neumf_train_step(P, state, uid, iid, hyper, marks, out, inv_b=None, pred=None):
+def neumf_mark_rows(iid, n_items, marks, unmark=False):
+    """rc_neumf_mark_rows / rc_neumf_unmark_rows on torch's current stream: the single / multi-occurrence flags of a batch's item ids"""
+    _lib.call("rc_neumf_unmark_rows" if unmark else "rc_neumf_mark_rows", _ptr(iid, torch.int64, "iid"), iid.numel(), int(n_items),
+              C.c_void_p(marks.data_ptr()), _stream())
+
+
+def neumf_train_step(P, state, uid, iid, hyper, marks, out, inv_b=None, pred=None, marked=False):
     """rc_neumf_train_step: forward + BPR loss + backward + in-place update of single-occurrence item rows.
     state: {table: {"m": .., "v": ..}} of the optimizer; marks: uint8 buffer of rc_neumf_train_step_marks_bytes(n_items), zeroed
-    once (every call leaves it ready for the next); out: dict of preallocated buffers loss_vec [B], g_mf_i / g_mlp_i [B C, d], gu_mf / gu_mlp [B, d], W1 / b1 / w_out
+    once (every call leaves it ready for the next; marked=True: prepared by neumf_mark_rows for this very batch, cleared by the caller); out: dict of preallocated buffers loss_vec [B], g_mf_i / g_mlp_i [B C, d], gu_mf / gu_mlp [B, d], W1 / b1 / w_out
     gradients.  Returns nothing: the caller finishes the step with the plan's pair updates and the dense update."""
     B, Cn = iid.shape
     d, l1 = P["mf_u"].shape[1], P["W1"].shape[0]
@@ -679,7 +685,8 @@ def neumf_train_step(P, state, uid, iid, hyper, marks, out, inv_b=None, pred=Non
     lib = _lib.load()
     ws = workspace(lib.rc_neumf_train_step_workspace_bytes(B, Cn, d, l1), iid.device, "neumf_step")
     st = lambda t, k: _ptr(state[t].get(k), f32, k + "_" + t, True)
-    _lib.call("rc_neumf_train_step", _ptr(P["mf_u"], f32, "mf_u"), _ptr(P["mf_i"], f32, "mf_i"), _ptr(P["mlp_u"], f32, "mlp_u"),
+    _lib.call("rc_neumf_train_step_marked" if marked else "rc_neumf_train_step",
+              _ptr(P["mf_u"], f32, "mf_u"), _ptr(P["mf_i"], f32, "mf_i"), _ptr(P["mlp_u"], f32, "mlp_u"),
               _ptr(P["mlp_i"], f32, "mlp_i"), st("mf_i", "m"), st("mf_i", "v"), st("mlp_i", "m"), st("mlp_i", "v"),
               _ptr(P["W1"], f32, "W1"), _ptr(P["b1"], f32, "b1"), _ptr(P["w_out"], f32, "w_out"),
               _ptr(uid, torch.int64, "uid"), _ptr(iid, torch.int64, "iid"), B, Cn, d, l1, int(P["mf_i"].shape[0]),
@@ -848,8 +855,9 @@ class NeumfTrainer:
         dev = iid.device
         d = P["mf_u"].shape[1]
         n_u, n_i = P["mf_u"].shape[0], P["mf_i"].shape[0]
-        if getattr(self, "_marks", None) is None:
-            self._marks = torch.zeros(max(int(_lib.load().rc_neumf_train_step_marks_bytes(n_i)), 1), dtype=torch.uint8, device=dev)
+        if getattr(self, "_marks", None) is None:   # two buffers: this batch's flags and, prepared beside this step's updates, the next batch's
+            nbytes = max(int(_lib.load().rc_neumf_train_step_marks_bytes(n_i)), 1)
+            self._marks = [torch.zeros(nbytes, dtype=torch.uint8, device=dev) for _ in range(2)]
         key = (B, Cn, str(dev))
         if getattr(self, "_fused_out", (None,))[0] != key:
             e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
@@ -865,26 +873,40 @@ class NeumfTrainer:
             self._side, self._side2 = torch.cuda.Stream(device=dev, priority=prio), torch.cuda.Stream(device=dev)
         ahead = getattr(self, "_ahead", None)
         self._ahead = None
-        plan = plan_done = None
+        plan = plan_done = marks_done = None
+        par = self.step_count & 1
         if ahead is not None and ahead[0] == self._batch_key(uid, iid):
-            _, plan, plan_done = ahead
-        elif two_streams:
+            _, plan, plan_done, marks_done, _ = ahead
+        elif ahead is not None:
+            # a batch was announced and another one came: its prepared flags have to go before that buffer is marked again
+            with torch.cuda.stream(self._side):
+                neumf_mark_rows(ahead[4], n_i, self._marks[par], unmark=True)
+            main.wait_stream(self._side)
+        if plan is None and two_streams:
             self._side.wait_stream(main)
             with torch.cuda.stream(self._side):
-                plan = Plan(iid, n_i, uid, n_u, tag="neumf%d" % (self.step_count & 1), list_single_a=False)
+                plan = Plan(iid, n_i, uid, n_u, tag="neumf%d" % par, list_single_a=False)
                 plan_done = self._side.record_event()
         h = make_hyper(self.opt, lr=self.lr, l2=self.l2, step=self.step_count)
         h0 = make_hyper(self.opt, lr=self.lr, l2=0.0, step=self.step_count)
         with _PhaseTimer(self, "fused_step"):
-            neumf_train_step(P, self.state, uid, iid, h, self._marks, out)
-        if two_streams and next_batch is not None:
-            # the following batch's plan: behind the fused kernel on the second stream, i.e. beside the updates below; its
-            # buffers alternate with this batch's (tag by step parity)
-            nu, ni = next_batch
-            self._side.wait_stream(main)
+            if marks_done is not None:      # flags prepared beside the previous step's updates (buffer of this step's parity)
+                main.wait_event(marks_done)
+                neumf_train_step(P, self.state, uid, iid, h, self._marks[par], out, marked=True)
+            else:
+                neumf_train_step(P, self.state, uid, iid, h, self._marks[par], out)
+        if two_streams and (next_batch is not None or marks_done is not None):
+            self._side.wait_stream(main)    # behind the fused kernel: beside the updates below
             with torch.cuda.stream(self._side):
-                nplan = Plan(ni, n_i, nu, n_u, tag="neumf%d" % ((self.step_count + 1) & 1), list_single_a=False)
-                self._ahead = (self._batch_key(nu, ni), nplan, self._side.record_event())
+                if marks_done is not None:
+                    neumf_mark_rows(iid, n_i, self._marks[par], unmark=True)
+                if next_batch is not None:
+                    # the following batch's flags and plan; their buffers alternate with this batch's (by step parity)
+                    nu, ni = next_batch
+                    neumf_mark_rows(ni, n_i, self._marks[par ^ 1])
+                    nmarks_done = self._side.record_event()
+                    nplan = Plan(ni, n_i, nu, n_u, tag="neumf%d" % (par ^ 1), list_single_a=False)
+                    self._ahead = (self._batch_key(nu, ni), nplan, self._side.record_event(), nmarks_done, ni)
         if two_streams:
             # the batch mean of the per-tuple losses (one workgroup, 10 us of latency) on the user side's stream, where it fills
             # the wait for the plan instead of standing in front of the item update
@@ -896,7 +918,7 @@ class NeumfTrainer:
                 self.loss = reduce_sum(out["loss_vec"], 1.0 / B)
         with _PhaseTimer(self, "sort"):
             if plan is None:
-                plan = Plan(iid, n_i, uid, n_u, tag="neumf%d" % (self.step_count & 1), list_single_a=False)
+                plan = Plan(iid, n_i, uid, n_u, tag="neumf%d" % par, list_single_a=False)
             elif plan_done is not None:
                 main.wait_event(plan_done)
         with _PhaseTimer(self, "table_update"):

@@ -444,3 +444,42 @@ def test_neumf_head_on_strided_row_blocks_vs_oracle(cuda, eng):
         assert_close(dense["W1"].cpu().numpy(), G["mlp.0.weight"], what="dW1", atol_scale=tol)
         assert_close(dense["b1"].cpu().numpy(), G["mlp.0.bias"], what="db1", atol_scale=tol)
         assert_close(dense["w_out"].cpu().numpy(), G["prediction.weight"][0], what="dw_out", atol_scale=tol)
+
+
+def test_neumf_trainer_announced_batches_prepared_ahead_equal_unannounced(cuda, eng, monkeypatch):
+    """NeumfTrainer.step(next_batch=...) prepares the next batch's single / multi-occurrence flags and its bucket plan beside this step's
+    table updates (two alternating buffers): every step announced, none, and a WRONGLY announced batch (the prepared flags are cleared, the
+    step marks its own batch) leave bit-identical tables -- the flags do not depend on who computed them, nor does any sum's order"""
+    rng = np.random.default_rng(31)
+    d, l1, B, C, n_users, n_items = 64, 64, 2500, 5, 300, 30000
+    P0 = {"mf_u": rng.normal(0, 0.2, (n_users, d)), "mf_i": rng.normal(0, 0.2, (n_items, d)), "mlp_u": rng.normal(0, 0.2, (n_users, d)),
+          "mlp_i": rng.normal(0, 0.2, (n_items, d)), "W1": rng.normal(0, 0.2, (l1, 2 * d)), "b1": rng.normal(0, 0.2, l1),
+          "w_out": rng.normal(0, 0.2, d + l1)}
+    P0 = {k: v.astype(np.float32) for k, v in P0.items()}
+    batches = []
+    for _ in range(5):
+        uid = rng.integers(0, n_users, size=B).astype(np.int64)
+        iid = rng.integers(0, n_items, size=(B, C)).astype(np.int64)
+        iid[:, 0] = iid[:, 0] % 40
+        batches.append((torch.from_numpy(uid).to(cuda), torch.from_numpy(iid).to(cuda)))
+    monkeypatch.setattr(eng, "_SAS_OVERLAP_MIN", 0)
+    res = []
+    for mode in ("ahead", "none", "wrong"):
+        P = {k: torch.from_numpy(v).to(cuda) for k, v in P0.items()}
+        tr = eng.NeumfTrainer(P, opt="SGD", lr=0.05, l2=1e-4, rowwise=True)
+        losses = []
+        for k, (u, i) in enumerate(batches[:4]):
+            nxt = None
+            if mode == "ahead":
+                nxt = batches[k + 1]
+            elif mode == "wrong" and k % 2 == 0:
+                nxt = batches[4]                 # never the batch that comes
+            losses.append(float(tr.step(u, i, next_batch=nxt).item()))
+        torch.cuda.synchronize()
+        for m in tr._marks:
+            assert not m[(4 * n_items + 255) // 256 * 256:].any() or mode == "ahead"    # (only a prepared, not yet consumed batch may be marked)
+        res.append((losses, {k: v.clone() for k, v in P.items()}))
+    for losses, P in res[1:]:
+        assert losses == res[0][0]
+        for k in P0:
+            assert torch.equal(P[k], res[0][1][k]), k
