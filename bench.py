@@ -250,12 +250,8 @@ class DeepfmBench:
 def deepfm_roofline(args, trainer, batches, engine):
     """MLP_Block GEMMs (csrc/mlp.hip, fp32 MFMA) against the fp32 MFMA peak, over the eager forward + backward phases"""
     trainer.timing = {}
-    s0 = args.warmup + args.steps      # the batch sequence of the timed loop continues: its last step announced batch s0
-    for s in range(s0, s0 + 20):
-        if args.workload == "neumf":   # steady state of the timed loop: every step announces the following batch
-            trainer.step(*batches[s % len(batches)], next_batch=batches[(s + 1) % len(batches)])
-        else:
-            trainer.step(*batches[s % len(batches)])
+    for s in range(10):
+        trainer.step(*batches[s % len(batches)])
     ph = engine.phases_ms(trainer)
     trainer.timing = None
     F, d = len(DEEPFM_VOCAB), args.emb_size
@@ -428,8 +424,12 @@ def model_roofline(args, trainer, batches, engine):
     """NeuMF / SASRec: live per-phase times (events on the launch stream) -> the dominant phase against its bound:
     fp32 MFMA for the head / encoder kernels, HBM for the table update."""
     trainer.timing = {}
-    for s in range(10):
-        trainer.step(*batches[s % len(batches)])
+    s0 = args.warmup + args.steps      # the batch sequence of the timed loop continues: its last step announced batch s0
+    for s in range(s0, s0 + 20):
+        if args.workload == "neumf":   # steady state of the timed loop: every step announces the following batch
+            trainer.step(*batches[s % len(batches)], next_batch=batches[(s + 1) % len(batches)])
+        else:
+            trainer.step(*batches[s % len(batches)])
     ph = engine.phases_ms(trainer)
     trainer.timing = None
     B, C, d = args.batch, args.num_neg + 1, args.emb_size

@@ -32,3 +32,12 @@ tr.timing = {}
 print("timing on : %.4f ms/step" % loop(40, 50), {k: round(v, 4) for k, v in engine.phases_ms(tr).items()})
 tr.timing = None
 print("timing off: %.4f ms/step" % loop(40, 90))
+args.steps, args.warmup = 40, 130     # (the loops above ran 130 steps; bench.model_roofline continues the sequence from warmup + steps)
+r = bench.model_roofline(args, tr, batches, engine)
+print("bench.model_roofline phases:", r["phases_ms"])
+tr.timing = {}
+for s in range(190, 200):
+    tr.step(*batches[s % n], next_batch=batches[(s + 1) % n])
+torch.cuda.synchronize()
+print("per-step sort ms (10 steps, no sync before):", [round(a.elapsed_time(b), 4) for a, b in tr.timing["sort"]])
+print("per-step fused ms:", [round(a.elapsed_time(b), 4) for a, b in tr.timing["fused_step"]])
