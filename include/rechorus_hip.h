@@ -314,6 +314,26 @@ int rc_segmented_update_rows_dev(float* W, float* m, float* v, int d, int64_t n_
                                  const rc_opt_hyper* h, const int64_t* step_dev, float* dense_grad, void* ws, size_t ws_bytes,
                                  rc_stream_t stream);
 
+/* rc_segmented_update_rows without the radix sort: the per-row [start, end) and the grouped occurrence list come from a counting
+ * sort of the batch's own id tensors, as the reference hands them over (models/sequential/SASRec.py:69-81: feed_dict['item_id']
+ * [B, 1 + K], feed_dict['history_items'] [B, history_max] with feed_dict['lengths']; the gradient of i_embeddings reaches both,
+ * helpers/BaseRunner.py:205): occurrence o < n_a is ids_a[o], the others ids_b[o - n_a]; with lengths_b, ids_b is [n_b / L_b, L_b]
+ * and slots l >= lengths_b[b] are padding -- they take no part, except the first of the batch, which keeps row 0 among the
+ * touched rows (its gradient row is zero).  rc_rows_plan_build: three launches (tile histograms in LDS, prefix over the tiles,
+ * scatter in occurrence order = the stable sort's order, so that every row sum is bit-identical to the sorted route; the hot
+ * rows' chunk list is written on the way), no host synchronisation, capturable.  rc_rows_plan_update: rc_segmented_update_rows
+ * on that plan in two launches (n_split = n_a; step_dev as rc_segmented_update_rows_dev, null: h->step).  n_rows <= 12,288;
+ * ids outside [0, n_rows) take no part and are counted in status[0] (rc_rows_plan_views; the caller zeroes the workspace once).   */
+int rc_rows_plan_supported(int64_t n_rows, int64_t n_occ, int d);
+size_t rc_rows_plan_workspace_bytes(int64_t n_rows, int64_t n_occ, int d);
+int rc_rows_plan_build(const int64_t* ids_a, int64_t n_a, const int64_t* ids_b, int64_t n_b, const int64_t* lengths_b, int L_b,
+                       int64_t n_rows, int d, void* ws, size_t ws_bytes, rc_stream_t stream);
+int rc_rows_plan_views(void* ws, int64_t n_rows, int64_t n_occ, int d, const uint32_t** keys, const uint32_t** perm,
+                       const uint32_t** start, const uint32_t** end, const uint32_t** status);
+int rc_rows_plan_update(float* W, float* m, float* v, int d, int64_t n_rows, int64_t n_occ, const float* coef, const float* src,
+                        const int64_t* src_index, int div, const float* src2, int64_t n_split, const rc_opt_hyper* h,
+                        const int64_t* step_dev, float* dense_grad, void* ws, size_t ws_bytes, rc_stream_t stream);
+
 /* aten::embedding_dense_backward for a SMALL id list (n <= 32,768; helpers/BaseRunner.py:205 behind loss.backward() at the
  * reference's own batch sizes: 1,024 rows x 8 fields of a CTR step -- models/context/FM.py:49-52 --, 256 x (1 + K) candidates)
  * in TWO launches: 128 workgroups group the ids by row in LDS, one lane-group per touched row sums the gradient rows of its

@@ -116,6 +116,11 @@ SIGNATURES = {
     "rc_segmented_rows_workspace_bytes": (_sz, [_i64, _i64, _i]),
     "rc_segmented_update_rows": (_i, [_p, _p, _p, _i, _i64, _p, _p, _i64, _p, _p, _p, _i, _p, _i64, _hp, _p, _p, _sz, _p]),
     "rc_segmented_update_rows_dev": (_i, [_p, _p, _p, _i, _i64, _p, _p, _i64, _p, _p, _p, _i, _p, _i64, _hp, _p, _p, _p, _sz, _p]),
+    "rc_rows_plan_supported": (_i, [_i64, _i64, _i]),
+    "rc_rows_plan_workspace_bytes": (_sz, [_i64, _i64, _i]),
+    "rc_rows_plan_build": (_i, [_p, _i64, _p, _i64, _p, _i, _i64, _i, _p, _sz, _p]),
+    "rc_rows_plan_views": (_i, [_p, _i64, _i64, _i, _p, _p, _p, _p, _p]),
+    "rc_rows_plan_update": (_i, [_p, _p, _p, _i, _i64, _i64, _p, _p, _p, _i, _p, _i64, _hp, _p, _p, _p, _sz, _p]),
     "rc_segmented_update_pair": (_i, [_p] * 6 + [_i, _p, _p, _i64, _p, _p, _hp, _p, _p, _p, _p, _p, _sz, _p]),
     "rc_sort_ids2": (_i, [_p, _i64, _p, _i64, _i64, _i64, _p, _p, _p, _sz, _p]),
     "rc_sasrec_supported": (_i, [_i, _i, _i, _i]),

@@ -24,6 +24,8 @@
 //      (long_final).  Work per block is bounded whatever the skew.
 // The only atomics are INTEGER appends / slot reservations (list order does not influence
 // any floating-point result).
+#include <mutex>
+
 #include "common.hpp"
 #include "opt_math.hpp"
 
@@ -63,6 +65,7 @@ struct SegArgs {
   float* partial;
   uint32_t long_cap, chunk_cap, partial_cap;
   int skip_single;
+  int planned;   // rows route: the hot rows are already listed in rows[] / chunks[] (rc_rows_plan_build): no hand-over atomics
   OptScalars o;
   // capturable mode (hipGraph replay, rc_segmented_update_rows_dev): Adam's step count is read from device memory and the two
   // bias-correction scalars are derived from it in the kernel (as rc_dense_update_multi_dev does) instead of on the host
@@ -439,7 +442,7 @@ __device__ __forceinline__ void block_tree_sum(float4* part, int g) {
 }
 
 template <int D, int MODE>
-__global__ __launch_bounds__(kBlock) void long_chunk_kernel(SegArgs a) {
+__device__ __forceinline__ void long_chunk_body(const SegArgs& a, uint32_t block, uint32_t n_blocks) {
   constexpr int LPR = D / 4;
   constexpr int GPB = kBlock / LPR;
   __shared__ float4 part[kBlock];
@@ -447,7 +450,7 @@ __global__ __launch_bounds__(kBlock) void long_chunk_kernel(SegArgs a) {
   const int g = threadIdx.x / LPR;
   uint32_t n_chunks = a.counters[CNT_CHUNKS];
   if (n_chunks > a.chunk_cap) n_chunks = a.chunk_cap;
-  for (uint32_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+  for (uint32_t c = block; c < n_chunks; c += n_blocks) {
     const ChunkInfo ci = a.chunks[c];
     const RowInfo ri = a.rows[ci.row];
     const int64_t start = (int64_t)ri.j0 + (int64_t)ci.k * kChunk;
@@ -474,6 +477,11 @@ __global__ __launch_bounds__(kBlock) void long_chunk_kernel(SegArgs a) {
     }
     __syncthreads();  // part[] is reused by the next chunk
   }
+}
+
+template <int D, int MODE>
+__global__ __launch_bounds__(kBlock) void long_chunk_kernel(SegArgs a) {
+  long_chunk_body<D, MODE>(a, blockIdx.x, gridDim.x);
 }
 
 template <int D, int MODE>
@@ -524,17 +532,17 @@ __global__ __launch_bounds__(kBlock) void segment_bounds_kernel(const uint32_t* 
 }
 
 template <int D, int MODE>
-__global__ __launch_bounds__(kBlock) void seg_rows_kernel(SegArgs a, const uint32_t* __restrict__ start,
-                                                          const uint32_t* __restrict__ end, uint32_t n_rows) {
+__device__ __forceinline__ void seg_rows_body(const SegArgs& a, const uint32_t* __restrict__ start,
+                                              const uint32_t* __restrict__ end, uint32_t n_rows, uint32_t block) {
   constexpr int LPR = D / 4;
   constexpr int G = 64 / LPR;   // lane-groups per wave
   const int lane = threadIdx.x & 63, l = lane % LPR, g = lane / LPR;
-  const uint32_t r = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  const uint32_t r = block * (kBlock / 64) + (threadIdx.x >> 6);
   if (r >= n_rows) return;      // wave-uniform from here on
   const int64_t j0 = start[r], j1 = end[r];
   if (j1 <= j0) return;
   if (j1 - j0 > kRowsWaveMax) {
-    if (lane == 0) {
+    if (lane == 0 && !a.planned) {
       const uint32_t slot = atomicAdd(&a.counters[CNT_LONG], 1u);
       if (slot < a.long_cap) a.long_list[slot] = (uint32_t)j0;
     }
@@ -578,6 +586,45 @@ __global__ __launch_bounds__(kBlock) void seg_rows_kernel(SegArgs a, const uint3
 }
 
 template <int D, int MODE>
+__global__ __launch_bounds__(kBlock) void seg_rows_kernel(SegArgs a, const uint32_t* __restrict__ start,
+                                                          const uint32_t* __restrict__ end, uint32_t n_rows) {
+  seg_rows_body<D, MODE>(a, start, end, n_rows, blockIdx.x);
+}
+
+// rows route with the hot rows planned ahead (section 5): the chunks of the hot rows and the one-wave rows in ONE launch -- the
+// first n_chunk_blocks workgroups take the chunk list (they are the long ones: started first), the others four rows each
+template <int D, int MODE>
+__global__ __launch_bounds__(kBlock) void seg_planned_kernel(SegArgs a, const uint32_t* __restrict__ start,
+                                                             const uint32_t* __restrict__ end, uint32_t n_rows,
+                                                             uint32_t n_chunk_blocks) {
+  if (blockIdx.x < n_chunk_blocks) long_chunk_body<D, MODE>(a, blockIdx.x, n_chunk_blocks);   // (workgroup-uniform)
+  else seg_rows_body<D, MODE>(a, start, end, n_rows, blockIdx.x - n_chunk_blocks);
+}
+
+template <int D, int MODE>
+static int launch_seg_planned(const SegArgs& a, const uint32_t* start, const uint32_t* end, uint32_t n_rows, hipStream_t s) {
+  const unsigned row_blocks = (n_rows + (kBlock / 64) - 1) / (kBlock / 64);
+  const unsigned chunk_blocks = 1024;
+  hipLaunchKernelGGL((seg_planned_kernel<D, MODE>), dim3(chunk_blocks + row_blocks), dim3(kBlock), 0, s, a, start, end, n_rows,
+                     chunk_blocks);
+  RC_LAUNCH_CHECK();
+  hipLaunchKernelGGL((long_final_kernel<D, MODE>), dim3(256), dim3(kBlock), 0, s, a);
+  RC_LAUNCH_CHECK();
+  return RC_OK;
+}
+
+template <int MODE>
+static int launch_seg_planned_mode(const SegArgs& a, const uint32_t* start, const uint32_t* end, uint32_t n_rows, hipStream_t s) {
+  switch (a.d) {
+    case 16: return launch_seg_planned<16, MODE>(a, start, end, n_rows, s);
+    case 32: return launch_seg_planned<32, MODE>(a, start, end, n_rows, s);
+    case 64: return launch_seg_planned<64, MODE>(a, start, end, n_rows, s);
+    case 128: return launch_seg_planned<128, MODE>(a, start, end, n_rows, s);
+    default: return launch_seg_planned<256, MODE>(a, start, end, n_rows, s);
+  }
+}
+
+template <int D, int MODE>
 static int launch_seg_rows(const SegArgs& a, const uint32_t* start, const uint32_t* end, uint32_t n_rows, hipStream_t s) {
   const unsigned blocks = (n_rows + (kBlock / 64) - 1) / (kBlock / 64);
   hipLaunchKernelGGL((seg_rows_kernel<D, MODE>), dim3(blocks), dim3(kBlock), 0, s, a, start, end, n_rows);
@@ -601,6 +648,337 @@ static int launch_seg_rows_mode(const SegArgs& a, const uint32_t* start, const u
     case 64: return launch_seg_rows<64, MODE>(a, start, end, n_rows, s);
     case 128: return launch_seg_rows<128, MODE>(a, start, end, n_rows, s);
     default: return launch_seg_rows<256, MODE>(a, start, end, n_rows, s);
+  }
+}
+
+// ---- 5. the rows route without the radix sort: per-row [start, end) from a counting sort of the batch's ids ----------------
+// The table of section 4 is small (n_rows <= kRpMaxRows: SASRec on the reference's own datasets, 8.7 K items) and the occurrences
+// are the batch's two id tensors as the reference hands them over: ids_a (the candidates, [B, C]) and ids_b (the history windows,
+// [B, L], slots l >= lengths[b] are padding and take no part).  Three launches replace the radix sort of candidate + history ids
+// and the tensor glue that parked the padding behind the table:
+//   count    one workgroup per tile of kRpTile occurrences: histogram over the table's rows in LDS -> matrix[tile][row]
+//   prefix   one lane per row: exclusive prefix over the tiles in place, the row's total
+//   scatter  every tile forms the rows' starts (an LDS scan of the totals) + its own offsets, then hands out the positions of its
+//            occurrences IN OCCURRENCE ORDER: every wave owns a quarter of the tile, the waves' shares of a row follow from their
+//            own counts (16-bit counters in LDS), inside a wave round after round, inside a round the lanes that hold the same
+//            row find each other with one ballot per key bit -- perm is the stable sort's, so every row sum keeps its order and
+//            the update is bit-identical to the sorted route; workgroup 0 also lists the hot rows' chunks (what long_plan_kernel
+//            did with one atomic per row after the rows kernel had run).
+// The first padding slot of the batch stays an occurrence of row 0 (its gradient row is zero), as on the sorted route.
+constexpr int kRpTile = 4096;
+constexpr int kRpRounds = kRpTile / kBlock;
+constexpr int kRpMaxRows = 12288;   // LDS of the scatter: 4 B (first position) + 4 x 2 B (the waves' offsets) per row = 144 KB
+
+struct RowsPlanArgs {
+  const int64_t* ids_a;
+  const int64_t* ids_b;
+  const int64_t* len_b;
+  int64_t n_a, n_b;
+  int L_b;
+  uint32_t n_rows;
+  uint32_t n_tiles;
+  int key_bits;
+  uint32_t* matrix;     // [n_tiles][n_rows]
+  uint32_t* totals;     // [n_rows]
+  uint32_t* tile_pad;   // [n_tiles]: the tile's first padding occurrence, 0xFFFFFFFF if none
+  uint32_t* start;
+  uint32_t* end;
+  uint32_t* keys;
+  uint32_t* perm;
+  uint32_t* counters;
+  RowInfo* rows;
+  ChunkInfo* chunks;
+  uint32_t long_cap, chunk_cap;
+  uint32_t* status;     // [0]: ids outside the table (they take no part)
+};
+
+// occurrence o of the batch: its id and, for a slot of the history windows, lengths[b] - l (<= 0: padding).  No branches: the
+// address is clamped into the batch instead, so that a caller that asks for several occurrences has all their loads in flight at
+// once (with a branch per occurrence the sixteen loads of a lane went one round trip after the other: 32 us per pass over 0.6 M ids)
+template <bool HAS_LEN>
+__device__ __forceinline__ void rp_load(const RowsPlanArgs& a, int64_t o, int64_t n_occ, int64_t& id, int64_t& room) {
+  const int64_t oo = o < n_occ ? o : n_occ - 1;
+  const bool in_b = oo >= a.n_a;
+  const uint32_t j = in_b ? (uint32_t)(oo - a.n_a) : 0u;
+  const int64_t* p = in_b ? a.ids_b + j : a.ids_a + oo;
+  id = *p;
+  room = 1;
+  if (HAS_LEN) {
+    const uint32_t b = j / (uint32_t)a.L_b;
+    // (no select on the loaded value: the compiler turns a select with a load behind one arm back into a branch)
+    const int64_t slot = in_b ? (int64_t)(j - b * (uint32_t)a.L_b) : -((int64_t)1 << 40);
+    room = a.len_b[b] - slot;
+  }
+}
+// -> the table row, -1: takes no part (pad: a padding slot; bad: an id outside the table)
+__device__ __forceinline__ int rp_classify(const RowsPlanArgs& a, bool inside, int64_t id, int64_t room, bool& pad, bool& bad) {
+  pad = inside && room <= 0;
+  bad = inside && !pad && (id < 0 || id >= (int64_t)a.n_rows);
+  return (inside && !pad && !bad) ? (int)id : -1;
+}
+
+// occurrence of (wave, round, lane) inside a tile: every wave owns kRpTile / 4 consecutive occurrences (the scatter hands out
+// positions wave by wave without waiting: the waves' shares of a row are known from their counts)
+__device__ __forceinline__ int64_t rp_occ(int64_t tile0, int wave, int r, int lane) {
+  return tile0 + (int64_t)wave * (kRpTile / (kBlock / 64)) + r * 64 + lane;
+}
+
+template <bool HAS_LEN>
+__global__ __launch_bounds__(kBlock) void rp_count_kernel(RowsPlanArgs a) {
+  extern __shared__ uint32_t rp_hist[];
+  __shared__ uint32_t s_pad, s_bad;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t n_occ = a.n_a + a.n_b;
+  const int64_t tile0 = (int64_t)blockIdx.x * kRpTile;
+  int64_t id[kRpRounds], room[kRpRounds];
+#pragma unroll
+  for (int r = 0; r < kRpRounds; ++r) rp_load<HAS_LEN>(a, rp_occ(tile0, wave, r, lane), n_occ, id[r], room[r]);
+  for (uint32_t i = threadIdx.x; i < a.n_rows; i += kBlock) rp_hist[i] = 0;
+  if (threadIdx.x == 0) {
+    s_pad = 0xFFFFFFFFu;
+    s_bad = 0;
+  }
+  __syncthreads();
+  uint32_t first_pad = 0xFFFFFFFFu, n_bad = 0;
+#pragma unroll
+  for (int r = 0; r < kRpRounds; ++r) {
+    const int64_t o = rp_occ(tile0, wave, r, lane);
+    bool pad, bad;
+    const int k = rp_classify(a, o < n_occ, id[r], room[r], pad, bad);
+    if (k >= 0) atomicAdd(&rp_hist[k], 1u);
+    if (pad && (uint32_t)o < first_pad) first_pad = (uint32_t)o;
+    n_bad += bad ? 1u : 0u;
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {   // (half of the history slots are padding: one LDS atomic per wave, not per slot)
+    const uint32_t v = __shfl_xor(first_pad, off, 64);
+    first_pad = v < first_pad ? v : first_pad;
+    n_bad += __shfl_xor(n_bad, off, 64);
+  }
+  if (lane == 0) {
+    atomicMin(&s_pad, first_pad);
+    if (n_bad) atomicAdd(&s_bad, n_bad);
+  }
+  __syncthreads();
+  uint32_t* out = a.matrix + (size_t)blockIdx.x * a.n_rows;
+  for (uint32_t i = threadIdx.x; i < a.n_rows; i += kBlock) out[i] = rp_hist[i];
+  if (threadIdx.x == 0) {
+    a.tile_pad[blockIdx.x] = s_pad;
+    if (s_bad) atomicAdd(a.status, s_bad);   // (an error count, read by the host on request only)
+  }
+}
+
+__global__ __launch_bounds__(64) void rp_prefix_kernel(RowsPlanArgs a) {
+  const uint32_t r = blockIdx.x * 64 + threadIdx.x;
+  if (r >= a.n_rows) return;
+  uint32_t run = 0;
+  constexpr int U = 10;
+  uint32_t t = 0;
+  for (; t + U <= a.n_tiles; t += U) {
+    uint32_t v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = a.matrix[(size_t)(t + u) * a.n_rows + r];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      a.matrix[(size_t)(t + u) * a.n_rows + r] = run;
+      run += v[u];
+    }
+  }
+  for (; t < a.n_tiles; ++t) {
+    const uint32_t v = a.matrix[(size_t)t * a.n_rows + r];
+    a.matrix[(size_t)t * a.n_rows + r] = run;
+    run += v;
+  }
+  a.totals[r] = run;
+}
+
+// exclusive scan of one uint4 per thread over the workgroup (x, y, z, w independently), the totals in tot
+__device__ __forceinline__ uint4 rp_block_scan4(uint4 v, uint4* s_wave /* [kBlock / 64] */, uint4& tot) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint4 inc = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t x = __shfl_up(inc.x, off, 64), y = __shfl_up(inc.y, off, 64), z = __shfl_up(inc.z, off, 64),
+                   w = __shfl_up(inc.w, off, 64);
+    if (lane >= off) {
+      inc.x += x; inc.y += y; inc.z += z; inc.w += w;
+    }
+  }
+  if (lane == 63) s_wave[wave] = inc;
+  __syncthreads();
+  uint4 base = make_uint4(0, 0, 0, 0);
+  tot = make_uint4(0, 0, 0, 0);
+#pragma unroll
+  for (int w = 0; w < kBlock / 64; ++w) {
+    const uint4 t = s_wave[w];
+    if (w < wave) {
+      base.x += t.x; base.y += t.y; base.z += t.z; base.w += t.w;
+    }
+    tot.x += t.x; tot.y += t.y; tot.z += t.z; tot.w += t.w;
+  }
+  __syncthreads();
+  return make_uint4(base.x + inc.x - v.x, base.y + inc.y - v.y, base.z + inc.z - v.z, base.w + inc.w - v.w);
+}
+
+// dst[i] (LDS) = or += src[i] (global) for i < n over the workgroup, eight loads in flight per lane (a plain loop is one round
+// trip per element: the compiler does not overlap the iterations)
+template <bool ADD>
+__device__ __forceinline__ void rp_lds_from_global(uint32_t* dst, const uint32_t* __restrict__ src, uint32_t n) {
+  constexpr int U = 8;
+  for (uint32_t i0 = threadIdx.x; i0 < n; i0 += U * kBlock) {
+    uint32_t v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t i = i0 + u * kBlock;
+      v[u] = src[i < n ? i : n - 1];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t i = i0 + u * kBlock;
+      if (i < n) dst[i] = ADD ? dst[i] + v[u] : v[u];
+    }
+  }
+}
+
+template <bool HAS_LEN>
+__global__ __launch_bounds__(kBlock) void rp_scatter_kernel(RowsPlanArgs a) {
+  extern __shared__ uint32_t rp_hist[];   // totals -> starts -> this tile's first position in every row | the waves' shares
+  __shared__ uint4 s_wave[kBlock / 64];
+  __shared__ uint32_t s_min[kBlock / 64];
+  constexpr int NW = kBlock / 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool plan = blockIdx.x == 0;
+  const int64_t n_occ = a.n_a + a.n_b;
+  const int64_t tile0 = (int64_t)blockIdx.x * kRpTile;
+  int64_t id[kRpRounds], room[kRpRounds];   // the tile's ids: requested first, needed after the rows' starts are known
+#pragma unroll
+  for (int r = 0; r < kRpRounds; ++r) rp_load<HAS_LEN>(a, rp_occ(tile0, wave, r, lane), n_occ, id[r], room[r]);
+  // the batch's first padding slot (tiles are in occurrence order: the first tile that has one holds it)
+  uint32_t fp = 0xFFFFFFFFu;
+  for (uint32_t t = threadIdx.x; t < a.n_tiles; t += kBlock) {
+    const uint32_t v = a.tile_pad[t];
+    fp = v < fp ? v : fp;
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const uint32_t v = __shfl_xor(fp, off, 64);
+    fp = v < fp ? v : fp;
+  }
+  if (lane == 0) s_min[wave] = fp;
+  rp_lds_from_global<false>(rp_hist, a.totals, a.n_rows);
+  __syncthreads();
+#pragma unroll
+  for (int w = 0; w < NW; ++w) fp = s_min[w] < fp ? s_min[w] : fp;
+  const uint32_t has_pad = fp != 0xFFFFFFFFu ? 1u : 0u;
+  // rows [r0, r1) of this thread: sums, then the scan over the threads
+  const uint32_t seg = (a.n_rows + kBlock - 1) / kBlock;
+  const uint32_t r0 = threadIdx.x * seg < a.n_rows ? threadIdx.x * seg : a.n_rows;
+  const uint32_t r1 = r0 + seg < a.n_rows ? r0 + seg : a.n_rows;
+  uint4 mine = make_uint4(0, 0, 0, 0);   // occurrences, hot rows, chunks, partial rows
+  for (uint32_t r = r0; r < r1; ++r) {
+    const uint32_t cnt = rp_hist[r] + (r == 0 ? has_pad : 0u);
+    mine.x += cnt;
+    if (cnt > (uint32_t)kRowsWaveMax) {
+      const uint32_t nch = (cnt + kChunk - 1) / kChunk;
+      mine.y += 1;
+      mine.z += nch;
+      mine.w += nch >= 2 ? nch : 0u;
+    }
+  }
+  uint4 tot;
+  uint4 run = rp_block_scan4(mine, s_wave, tot);
+  for (uint32_t r = r0; r < r1; ++r) {
+    const uint32_t cnt = rp_hist[r] + (r == 0 ? has_pad : 0u);
+    const uint32_t st = run.x;
+    rp_hist[r] = st;
+    run.x += cnt;
+    if (plan) {
+      a.start[r] = st;
+      a.end[r] = st + cnt;
+      if (cnt > (uint32_t)kRowsWaveMax) {
+        const uint32_t nch = (cnt + kChunk - 1) / kChunk;
+        if (run.y < a.long_cap) {
+          RowInfo ri;
+          ri.j0 = st;
+          ri.end = st + cnt;
+          ri.nchunks = nch;
+          ri.pbase = nch >= 2 ? run.w : 0xFFFFFFFFu;
+          a.rows[run.y] = ri;
+          a.keys[st] = r;   // (the chunk kernels read a hot row's number at keys[j0]; nothing else reads keys on this route)
+          for (uint32_t k = 0; k < nch; ++k)
+            if (run.z + k < a.chunk_cap) {
+              ChunkInfo c;
+              c.row = run.y;
+              c.k = k;
+              a.chunks[run.z + k] = c;
+            }
+        }
+        run.y += 1;
+        run.z += nch;
+        run.w += nch >= 2 ? nch : 0u;
+      }
+    }
+  }
+  if (plan && threadIdx.x == 0) {
+    a.counters[CNT_LONG] = tot.y;
+    a.counters[CNT_CHUNKS] = tot.z;
+    a.counters[CNT_PARTIAL] = tot.w;
+    if (has_pad) a.perm[a.totals[0]] = fp;   // row 0 starts at 0: its list ends with the padding slot
+  }
+  __syncthreads();
+  // this tile's first position in every row
+  rp_lds_from_global<true>(rp_hist, a.matrix + (size_t)blockIdx.x * a.n_rows, a.n_rows);
+  // the waves' shares: every wave counts the rows of its own kRpTile / 4 occurrences (16-bit counters, two per word) ...
+  const uint32_t half = (a.n_rows + 1) / 2;              // words per wave
+  uint32_t* wcnt = rp_hist + a.n_rows;                   // [NW][half] words = [NW][2 half] uint16
+  for (uint32_t i = threadIdx.x; i < NW * half; i += kBlock) wcnt[i] = 0;
+  __syncthreads();
+  int key[kRpRounds];
+#pragma unroll
+  for (int r = 0; r < kRpRounds; ++r) {
+    bool pad, bad;
+    key[r] = rp_classify(a, rp_occ(tile0, wave, r, lane) < n_occ, id[r], room[r], pad, bad);
+    if (key[r] >= 0) atomicAdd(&wcnt[wave * half + (key[r] >> 1)], 1u << (16 * (key[r] & 1)));
+  }
+  __syncthreads();
+  // ... which become the waves' first offsets inside the tile's share of the row
+  uint16_t* wrel = reinterpret_cast<uint16_t*>(wcnt);    // [NW][2 half]
+  for (uint32_t i = threadIdx.x; i < a.n_rows; i += kBlock) {
+    uint32_t run16 = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const uint32_t c = wrel[(size_t)w * 2 * half + i];
+      wrel[(size_t)w * 2 * half + i] = (uint16_t)run16;
+      run16 += c;
+    }
+  }
+  __syncthreads();
+  // positions in occurrence order: round after round inside the wave, inside a round the lanes that hold the same row find each
+  // other with one ballot per key bit (ds operations of a wave are executed in order: no barrier between the rounds)
+  uint16_t* wmine = wrel + (size_t)wave * 2 * half;
+#pragma unroll 1
+  for (int r = 0; r < kRpRounds; ++r) {
+    const int k = key[r];
+    const bool valid = k >= 0;
+    const uint64_t vm = __ballot(valid);
+    if (!vm) continue;   // wave-uniform
+    uint64_t peers = vm;
+    for (int b = 0; b < a.key_bits; ++b) {
+      const bool bit = (k >> b) & 1;
+      const uint64_t m = __ballot(valid && bit);
+      peers &= bit ? m : ~m;
+    }
+    const uint32_t rank = __popcll(peers & ((1ull << lane) - 1ull));
+    const uint32_t cnt = __popcll(peers);
+    const int leader = valid ? __ffsll((long long)peers) - 1 : lane;
+    uint32_t base = 0;
+    if (valid && rank == 0) {
+      const uint32_t rel = wmine[k];
+      wmine[k] = (uint16_t)(rel + cnt);
+      base = rp_hist[k] + rel;
+    }
+    base = __shfl(base, leader, 64);
+    if (valid) a.perm[base + rank] = (uint32_t)rp_occ(tile0, wave, r, lane);
   }
 }
 
@@ -979,6 +1357,150 @@ extern "C" int rc_segmented_update_rows_dev(float* W, float* m, float* v, int d,
   RC_REQUIRE(step_dev != nullptr, "rc_segmented_update_rows_dev: step_dev is null");
   return segmented_update_rows(W, m, v, d, n_rows, keys, perm, n_occ, coef, src, src_index, div, src2, n_split, h, step_dev,
                                dense_grad, ws, ws_bytes, stream);
+}
+
+// ---- rows route from a counting sort (section 5) -----------------------------------------------------------------------------
+struct RowsPlanWs {
+  SegWs seg;
+  uint32_t *counters, *start, *end, *keys, *perm, *tile_pad, *totals, *matrix, *status;
+  uint32_t n_tiles;
+  size_t total;
+};
+
+static RowsPlanWs carve_rows_plan_ws(void* base, int64_t n_rows, int64_t n_occ, int d) {
+  RowsPlanWs w;
+  // [status (256 B: at the front, where a workspace that is reused for another shape finds it again) | SegWs | the plan]
+  w.status = reinterpret_cast<uint32_t*>(base);
+  w.seg = carve_seg_ws(base ? static_cast<char*>(base) + 256 : nullptr, n_occ, d);
+  Carver cv(base);
+  cv.off = 256 + align_up(w.seg.total, 256);
+  w.n_tiles = (uint32_t)((n_occ + kRpTile - 1) / kRpTile);
+  w.counters = cv.take<uint32_t>(64);
+  w.start = cv.take<uint32_t>((size_t)n_rows);
+  w.end = cv.take<uint32_t>((size_t)n_rows);
+  w.keys = cv.take<uint32_t>((size_t)n_occ + 1);
+  w.perm = cv.take<uint32_t>((size_t)n_occ + 1);
+  w.tile_pad = cv.take<uint32_t>(w.n_tiles);
+  w.totals = cv.take<uint32_t>((size_t)n_rows);
+  w.matrix = cv.take<uint32_t>((size_t)w.n_tiles * (size_t)n_rows);
+  w.total = cv.off;
+  return w;
+}
+
+extern "C" int rc_rows_plan_supported(int64_t n_rows, int64_t n_occ, int d) {
+  return (n_rows >= 1 && n_rows <= kRpMaxRows && n_occ >= 1 && n_occ < ((int64_t)1 << 31) && vector_kernel_for(d) &&
+          ((n_occ + kRpTile - 1) / kRpTile) * n_rows < ((int64_t)1 << 28)) ? 1 : 0;
+}
+
+extern "C" size_t rc_rows_plan_workspace_bytes(int64_t n_rows, int64_t n_occ, int d) {
+  if (!rc_rows_plan_supported(n_rows, n_occ, d)) return 0;
+  return carve_rows_plan_ws(nullptr, n_rows, n_occ, d).total + 256;
+}
+
+extern "C" int rc_rows_plan_build(const int64_t* ids_a, int64_t n_a, const int64_t* ids_b, int64_t n_b, const int64_t* lengths_b,
+                                  int L_b, int64_t n_rows, int d, void* ws, size_t ws_bytes, rc_stream_t stream) {
+  const int64_t n_occ = n_a + n_b;
+  RC_REQUIRE(n_a >= 0 && n_b >= 0 && (n_a == 0 || ids_a) && (n_b == 0 || ids_b) && ws, "rc_rows_plan_build: null pointer / negative count");
+  RC_REQUIRE(!lengths_b || (L_b >= 1 && n_b % L_b == 0), "rc_rows_plan_build: lengths_b needs ids_b as [n_b / L_b, L_b] (L_b=%d)", L_b);
+  if (!rc_rows_plan_supported(n_rows, n_occ, d))
+    return fail(RC_ERR_UNSUPPORTED, "rc_rows_plan_build: n_rows=%lld (1..%d), n_occ=%lld, d=%d (16/32/64/128/256)", (long long)n_rows,
+                kRpMaxRows, (long long)n_occ, d);
+  const RowsPlanWs w = carve_rows_plan_ws(ws, n_rows, n_occ, d);
+  if (ws_bytes < w.total) return fail(RC_ERR_WORKSPACE, "rc_rows_plan_build: workspace %zu < %zu", ws_bytes, w.total);
+  hipStream_t s = as_stream(stream);
+  RowsPlanArgs a;
+  memset(&a, 0, sizeof(a));
+  a.ids_a = ids_a; a.ids_b = ids_b; a.len_b = n_b ? lengths_b : nullptr; a.n_a = n_a; a.n_b = n_b; a.L_b = a.len_b ? L_b : 1;
+  a.n_rows = (uint32_t)n_rows; a.n_tiles = w.n_tiles;
+  a.key_bits = 1;
+  while (((int64_t)1 << a.key_bits) < n_rows) ++a.key_bits;
+  a.matrix = w.matrix; a.totals = w.totals; a.tile_pad = w.tile_pad; a.start = w.start; a.end = w.end; a.keys = w.keys; a.perm = w.perm;
+  a.counters = w.counters; a.rows = w.seg.rows; a.chunks = w.seg.chunks; a.long_cap = w.seg.long_cap; a.chunk_cap = w.seg.chunk_cap;
+  a.status = w.status;
+  const size_t lds = (size_t)n_rows * sizeof(uint32_t);
+  const size_t lds_scatter = lds + (kBlock / 64) * (size_t)((n_rows + 1) / 2) * sizeof(uint32_t);
+  // (per device: hipFuncSetAttribute acts on the current device's copy of the function)
+  static std::mutex mu;
+  static bool attr_done[64] = {};
+  int dev = 0;
+  RC_HIP(hipGetDevice(&dev));
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    if (dev >= 0 && dev < 64 && !attr_done[dev]) {
+      RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rp_count_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kRpMaxRows * 4));
+      RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rp_count_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kRpMaxRows * 4));
+      RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rp_scatter_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kRpMaxRows * 12));
+      RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rp_scatter_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kRpMaxRows * 12));
+      attr_done[dev] = true;
+    }
+  }
+  if (a.len_b) hipLaunchKernelGGL(rp_count_kernel<true>, dim3(w.n_tiles), dim3(kBlock), lds, s, a);
+  else hipLaunchKernelGGL(rp_count_kernel<false>, dim3(w.n_tiles), dim3(kBlock), lds, s, a);
+  RC_LAUNCH_CHECK();
+  hipLaunchKernelGGL(rp_prefix_kernel, dim3((unsigned)((n_rows + 63) / 64)), dim3(64), 0, s, a);
+  RC_LAUNCH_CHECK();
+  if (a.len_b) hipLaunchKernelGGL(rp_scatter_kernel<true>, dim3(w.n_tiles), dim3(kBlock), lds_scatter, s, a);
+  else hipLaunchKernelGGL(rp_scatter_kernel<false>, dim3(w.n_tiles), dim3(kBlock), lds_scatter, s, a);
+  RC_LAUNCH_CHECK();
+  return RC_OK;
+}
+
+// device pointers into a built plan (tests, and callers that want the grouping itself): perm [n_live], start / end [n_rows] (keys:
+// only keys[start[r]] of the hot rows is written), status [1] = ids outside the table since the caller zeroed the workspace
+extern "C" int rc_rows_plan_views(void* ws, int64_t n_rows, int64_t n_occ, int d, const uint32_t** keys, const uint32_t** perm,
+                                  const uint32_t** start, const uint32_t** end, const uint32_t** status) {
+  RC_REQUIRE(ws && rc_rows_plan_supported(n_rows, n_occ, d), "rc_rows_plan_views: bad arguments");
+  const RowsPlanWs w = carve_rows_plan_ws(ws, n_rows, n_occ, d);
+  if (keys) *keys = w.keys;
+  if (perm) *perm = w.perm;
+  if (start) *start = w.start;
+  if (end) *end = w.end;
+  if (status) *status = w.status;
+  return RC_OK;
+}
+
+// rc_segmented_update_rows on a plan of rc_rows_plan_build (same ws, same n_rows / n_occ / d; occurrence o < n_split = position o
+// of ids_a, the others position o - n_split of ids_b): two launches, nothing to zero.  step_dev as rc_segmented_update_rows_dev
+// (null: h->step).
+extern "C" int rc_rows_plan_update(float* W, float* m, float* v, int d, int64_t n_rows, int64_t n_occ, const float* coef,
+                                   const float* src, const int64_t* src_index, int div, const float* src2, int64_t n_split,
+                                   const rc_opt_hyper* h, const int64_t* step_dev, float* dense_grad, void* ws, size_t ws_bytes,
+                                   rc_stream_t stream) {
+  RC_REQUIRE(src && ws && div >= 1 && n_split >= 0 && n_split <= n_occ, "rc_rows_plan_update: bad arguments");
+  RC_REQUIRE(dense_grad != nullptr || W != nullptr, "rc_rows_plan_update: no output (W or dense_grad)");
+  if (!rc_rows_plan_supported(n_rows, n_occ, d)) return fail(RC_ERR_UNSUPPORTED, "rc_rows_plan_update: shape not supported");
+  auto al = [](const void* p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; };
+  RC_REQUIRE(al(src) && al(src2) && al(W) && al(m) && al(v) && al(dense_grad), "rc_rows_plan_update: buffers must be 16-byte aligned");
+  const RowsPlanWs w = carve_rows_plan_ws(ws, n_rows, n_occ, d);
+  if (ws_bytes < w.total) return fail(RC_ERR_WORKSPACE, "rc_rows_plan_update: workspace %zu < %zu", ws_bytes, w.total);
+  hipStream_t s = as_stream(stream);
+  SegArgs a;
+  memset(&a, 0, sizeof(a));
+  a.W = W; a.M = m; a.V = v;
+  a.keys = w.keys; a.perm = w.perm; a.n_occ = n_occ;
+  a.coef = coef; a.src = src; a.src_index = src_index; a.div = div; a.d = d;
+  a.src2 = src2; a.n_split = (uint32_t)n_split;
+  a.dense_grad = dense_grad;
+  a.counters = w.counters; a.long_list = w.seg.long_list; a.rows = w.seg.rows; a.chunks = w.seg.chunks;
+  a.partial = w.seg.partial;
+  a.long_cap = w.seg.long_cap; a.chunk_cap = w.seg.chunk_cap; a.partial_cap = w.seg.partial_cap;
+  a.planned = 1;
+  int mode = MODE_DENSE_GRAD;
+  if (!dense_grad) {
+    RC_TRY(fill_opt_scalars(h, &a.o));
+    mode = mode_of(h);
+    RC_REQUIRE(mode != MODE_ADAM || (m && v), "rc_rows_plan_update: Adam needs m and v");
+    RC_REQUIRE(mode != MODE_ADAGRAD || m, "rc_rows_plan_update: Adagrad needs m (state_sum)");
+    if (mode == MODE_ADAM && step_dev) {
+      a.step_dev = step_dev; a.beta1 = h->beta1; a.beta2 = h->beta2; a.lr = h->lr;
+    }
+  }
+  switch (mode) {
+    case MODE_DENSE_GRAD: return launch_seg_planned_mode<MODE_DENSE_GRAD>(a, w.start, w.end, (uint32_t)n_rows, s);
+    case MODE_SGD: return launch_seg_planned_mode<MODE_SGD>(a, w.start, w.end, (uint32_t)n_rows, s);
+    case MODE_ADAM: return launch_seg_planned_mode<MODE_ADAM>(a, w.start, w.end, (uint32_t)n_rows, s);
+    default: return launch_seg_planned_mode<MODE_ADAGRAD>(a, w.start, w.end, (uint32_t)n_rows, s);
+  }
 }
 
 // Two tables that share their ids (NeuMF's mf / mlp embedding of a user or an item: models/general/NeuMF.py:37-40

@@ -423,6 +423,9 @@ _NEUMF_FUSED = os.environ.get("RC_NEUMF_FUSED", "1") != "0"       # NeumfTrainer
 _SAS_OVERLAP_MIN = int(os.environ.get("RC_SAS_OVERLAP_MIN", "131072"))   # candidate + history occurrences of the batch
 _SEG_ROWS_MIN_PER_ROW = int(os.environ.get("RC_SEG_ROWS_MIN_PER_ROW", "8"))
 _SASREC_PLAN = os.environ.get("RC_TABLE_UPDATE", "auto") == "plan"
+# SasrecTrainer on the one-wave-per-row route: row bounds from a counting sort of item_id + history_items (RowsPlan) instead of the
+# radix sort and its tensor glue (RC_SAS_ROWS_PLAN=0: the sorted route, same results bit for bit)
+_SAS_ROWS_PLAN = os.environ.get("RC_SAS_ROWS_PLAN", "1") != "0"
 
 
 def unique_ids(ids, n_rows, tag="unique"):
@@ -1189,6 +1192,51 @@ def segmented_update2(keys, perm, src, src2, n_split, hyper=None, W=None, m=None
               _ptr(dense_grad, f32, "dense_grad", True), None, None, 0, C.c_void_p(ws.data_ptr()), ws.numel(), _stream())
 
 
+def rows_plan_supported(n_rows, n_occ, d):
+    return bool(_lib.load().rc_rows_plan_supported(int(n_rows), int(n_occ), int(d)))
+
+
+_rows_plan_zeroed = set()
+
+
+class RowsPlan:
+    """rc_rows_plan_build: the occurrences of a small table's rows grouped by row, straight from the batch's id tensors
+    (ids_a [.., C] then ids_b [B, L]; lengths_b marks the padding slots of ids_b, which take no part) -- three launches, no sort;
+    update(): rc_rows_plan_update, the one-wave-per-row reduction of segmented_update2 on that grouping (bit-identical to it)."""
+
+    def __init__(self, ids_a, ids_b, lengths_b, n_rows, d, tag="rows_plan"):
+        self.n_a, self.n_b = ids_a.numel(), (ids_b.numel() if ids_b is not None else 0)
+        self.n_occ, self.n_rows, self.d = self.n_a + self.n_b, int(n_rows), int(d)
+        dev = ids_a.device
+        lib = _lib.load()
+        self.ws = workspace(lib.rc_rows_plan_workspace_bytes(self.n_rows, self.n_occ, self.d), dev, tag)
+        if self.ws.data_ptr() not in _rows_plan_zeroed:   # status counter; everything else is written before it is read
+            self.ws.zero_()
+            _rows_plan_zeroed.add(self.ws.data_ptr())
+        L = ids_b.shape[-1] if (ids_b is not None and lengths_b is not None) else 1
+        _lib.call("rc_rows_plan_build", _ptr(ids_a, torch.int64, "ids_a"), self.n_a, _ptr(ids_b, torch.int64, "ids_b", True), self.n_b,
+                  _ptr(lengths_b, torch.int64, "lengths_b", True), int(L), self.n_rows, self.d, C.c_void_p(self.ws.data_ptr()),
+                  self.ws.numel(), _stream())
+
+    def update(self, src, hyper=None, W=None, m=None, v=None, coef=None, src_index=None, div=1, src2=None, dense_grad=None,
+               step_dev=None):
+        f32 = torch.float32
+        _lib.call("rc_rows_plan_update", _ptr(W, f32, "W", True), _ptr(m, f32, "m", True), _ptr(v, f32, "v", True), self.d, self.n_rows,
+                  self.n_occ, _ptr(coef, f32, "coef", True), _ptr(src, f32, "src"), _ptr(src_index, torch.int64, "src_index", True),
+                  int(div), _ptr(src2, f32, "src2", True), self.n_a, C.byref(hyper) if hyper is not None else None,
+                  _ptr(step_dev, torch.int64, "step_dev", True), _ptr(dense_grad, f32, "dense_grad", True),
+                  C.c_void_p(self.ws.data_ptr()), self.ws.numel(), _stream())
+
+    def views(self):
+        """(keys, perm, start, end, status) as int32 tensors copied out of the workspace (tests)"""
+        ptrs = [C.c_void_p() for _ in range(5)]
+        _lib.call("rc_rows_plan_views", C.c_void_p(self.ws.data_ptr()), self.n_rows, self.n_occ, self.d, *[C.byref(p) for p in ptrs])
+        base = self.ws.data_ptr()
+        words = self.ws.view(torch.int32)
+        sizes = [self.n_occ + 1, self.n_occ + 1, self.n_rows, self.n_rows, 1]
+        return tuple(words[(p.value - base) // 4:(p.value - base) // 4 + n].clone() for p, n in zip(ptrs, sizes))
+
+
 class SasrecTrainer:
     """One BaseRunner.fit iteration for SASRec on device tensors.
     P = {"item_emb": [n_items,d], "pos_emb": [max_his+1,d], "layers": [dict(SAS_LAYER_KEYS) ...]}.
@@ -1310,6 +1358,9 @@ class SasrecTrainer:
         #  B = 256: 0.39 against 0.30 ms; B = 4096: 0.66 against 0.72 ms)
         overlap = _SAS_OVERLAP and hist.is_cuda and not use_plan and n_occ >= _SAS_OVERLAP_MIN
         sorted_ids = sort_done = main = side = None
+        # one wave per table row with the rows' bounds from a counting sort of the id tensors themselves (no radix sort, no glue)
+        rows_plan = (_SAS_ROWS_PLAN and hist.is_cuda and not use_plan and seg_rows_route(n_occ, I.shape[0], d)
+                     and rows_plan_supported(I.shape[0], n_occ, d))
 
         def sorted_occurrences():
             """candidate + history ids, sorted.  On the one-wave-per-row route the padding slots of the history windows (id 0, zero
@@ -1329,7 +1380,7 @@ class SasrecTrainer:
             main, side = torch.cuda.current_stream(hist.device), self._side_stream(hist.device)
             side.wait_stream(main)   # the batch is ready; last step's readers of the side stream's buffers are done
             with torch.cuda.stream(side):
-                sorted_ids = sorted_occurrences()
+                sorted_ids = RowsPlan(iid, hist, lengths, I.shape[0], d, tag="sasrec_rows") if rows_plan else sorted_occurrences()
                 sort_done = side.record_event()
         with _PhaseTimer(self, "encoder_fwd"):
             hv, xsave = sasrec_fwd(I, Pe, layers, self.n_heads, hist, lengths, save=True, drop_p=self.dropout, seed=self.seed)
@@ -1377,13 +1428,24 @@ class SasrecTrainer:
         else:
             if overlap:
                 main.wait_event(sort_done)
-                keys, perm = sorted_ids
+            elif rows_plan:
+                sorted_ids = RowsPlan(iid, hist, lengths, I.shape[0], d, tag="sasrec_rows")
             else:
-                keys, perm = sorted_occurrences()
-            if self.rowwise:
+                sorted_ids = sorted_occurrences()
+            if rows_plan:
+                src = dict(coef=gpred.reshape(-1), div=Cn, src2=g_hist.view(-1, d))
+                if self.rowwise:
+                    sorted_ids.update(hv, hyper=h, W=I, m=st.get("m"), v=st.get("v"), step_dev=step_dev, **src)
+                else:
+                    G = torch.zeros_like(I)
+                    sorted_ids.update(hv, dense_grad=G, **src)
+                    dense_update(I, G, h, st.get("m"), st.get("v"))
+            elif self.rowwise:
+                keys, perm = sorted_ids
                 segmented_update2(keys, perm, hv, g_hist.view(-1, d), B * Cn, hyper=h, W=I, m=st.get("m"), v=st.get("v"),
                                   coef=gpred.reshape(-1), div=Cn, step_dev=step_dev)
             else:
+                keys, perm = sorted_ids
                 G = torch.zeros_like(I)
                 segmented_update2(keys, perm, hv, g_hist.view(-1, d), B * Cn, coef=gpred.reshape(-1), div=Cn, dense_grad=G)
                 dense_update(I, G, h, st.get("m"), st.get("v"))

@@ -358,6 +358,121 @@ def test_segmented_update_rows_equals_head_list_route(d, n_rows, n_a, C, n_b, op
         assert_close(a, b, what=f"rows route vs head list (d={d}, opt={opt})", rtol=2e-5, atol_scale=2e-5)
 
 
+@pytest.mark.parametrize("d,n_rows,B,C,L,opt", [(64, 300, 700, 5, 12, None), (64, 97, 500, 4, 3, "Adam"), (16, 50, 200, 3, 4, "SGD"),
+                                                 (128, 40, 450, 2, 0, "Adagrad"), (32, 1000, 600, 6, 9, None),
+                                                 (64, 8714, 1100, 100, 50, "SGD"), (64, 12288, 2100, 64, 7, None)])
+def test_rows_plan_equals_the_sorted_rows_route(d, n_rows, B, C, L, opt, cuda, eng, monkeypatch):
+    """rc_rows_plan_build / rc_rows_plan_update (row bounds from a counting sort of the id tensors themselves) against the route it
+    replaces: the grouping is the stable sort's (keys ascending, occurrence numbers ascending inside a row; padding slots of the
+    history windows left out except the batch's first, which closes row 0's list), and the update is bit-identical to
+    rc_segmented_update_rows on the radix-sorted keys.  Hot rows (chunked path), rows that never occur, no history at all (L = 0),
+    the table-size limit (12,288 rows), several tiles of 4,096 occurrences, ids outside the table (counted, no part)."""
+    rng = np.random.default_rng(d + n_rows + B)
+    ids_a = rng.integers(1, n_rows, size=(B, C)).astype(np.int64)
+    ids_a[ids_a == 3] = 4                       # row 3 never occurs
+    ids_a[: B // 3, 0] = 7                      # a hot row (chunked path)
+    lengths = rng.integers(0, L + 1, size=B).astype(np.int64)
+    hist = rng.integers(1, n_rows, size=(B, max(L, 1))).astype(np.int64)[:, :L]
+    hist[hist == 3] = 5
+    hist = hist * (np.arange(L)[None, :] < lengths[:, None])
+    n_a, n_b = B * C, B * L
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
+    assert eng.rows_plan_supported(n_rows, n_a + n_b, d)
+    rp = eng.RowsPlan(t(ids_a), t(hist) if L else None, t(lengths) if L else None, n_rows, d, tag=f"test_rows_plan_{d}_{n_rows}")
+    keys, perm, start, end, status = (x.cpu().numpy().astype(np.int64) for x in rp.views())
+    # the grouping
+    pad = (np.arange(L)[None, :] >= lengths[:, None]).reshape(-1)
+    occ_key = np.concatenate([ids_a.reshape(-1), hist.reshape(-1)])
+    live = np.concatenate([np.ones(n_a, bool), ~pad])
+    order = np.argsort(occ_key[live], kind="stable")
+    want_perm = np.nonzero(live)[0][order]
+    want_keys = occ_key[live][order]
+    if pad.any():                               # the first padding slot closes row 0's list
+        first = n_a + int(np.argmax(pad))
+        n0 = int((want_keys == 0).sum())
+        want_perm = np.concatenate([want_perm[:n0], [first], want_perm[n0:]])
+        want_keys = np.concatenate([want_keys[:n0], [0], want_keys[n0:]])
+    n_live = len(want_perm)
+    assert np.array_equal(perm[:n_live], want_perm)
+    cnt = np.bincount(want_keys, minlength=n_rows)
+    assert np.array_equal(end - start, cnt) and np.array_equal(start, np.cumsum(cnt) - cnt) and status[0] == 0
+    hot = np.nonzero(cnt > 192)[0]
+    assert (len(hot) or B * C < 1500) and np.array_equal(keys[start[hot]], hot)   # (all the route keeps of the keys: the hot rows' numbers)
+    # the update, against rc_segmented_update_rows on the radix-sorted keys of the same occurrences (padding parked behind the table)
+    coef = rng.normal(size=(B, C)).astype(np.float32)
+    src = rng.normal(size=(B, d)).astype(np.float32)
+    src2 = rng.normal(size=(max(n_b, 1), d)).astype(np.float32)
+    src2[:n_b][pad] = 0                         # the encoder's backward leaves zero rows at the padding slots
+    parked = occ_key.copy()
+    parked[~live] = n_rows
+    if pad.any():
+        parked[first] = 0
+    skeys, sperm = eng.sort_ids(t(parked), n_rows + 1)
+    monkeypatch.setattr(eng, "_SEG_ROWS_MIN_PER_ROW", 0)
+    W0 = rng.normal(size=(n_rows, d)).astype(np.float32)
+    res = {}
+    for route in ("plan", "sorted", "plan"):
+        if opt is None:
+            G = torch.zeros((n_rows, d), device=cuda)
+            if route == "plan":
+                rp.update(t(src), coef=t(coef).reshape(-1), div=C, src2=t(src2), dense_grad=G)
+            else:
+                eng.segmented_update2(skeys, sperm, t(src), t(src2), n_a, coef=t(coef).reshape(-1), div=C, dense_grad=G)
+            got = (G.cpu().numpy(),)
+        else:
+            W, m, v = t(W0), torch.zeros((n_rows, d), device=cuda), torch.zeros((n_rows, d), device=cuda)
+            h = eng.make_hyper(opt, lr=0.01, l2=1e-4, step=3)
+            kw = dict(hyper=h, W=W, m=m if opt != "SGD" else None, v=v if opt == "Adam" else None, coef=t(coef).reshape(-1), div=C)
+            if route == "plan":
+                rp.update(t(src), src2=t(src2), **kw)
+            else:
+                eng.segmented_update2(skeys, sperm, t(src), t(src2), n_a, **kw)
+            got = (W.cpu().numpy(), m.cpu().numpy(), v.cpu().numpy())
+        if route in res:
+            assert all(np.array_equal(a, b) for a, b in zip(got, res[route])), "not reproducible"
+        res[route] = got
+    for a, b in zip(res["plan"], res["sorted"]):
+        assert np.array_equal(a, b), f"rows plan vs sorted rows route (d={d}, opt={opt})"
+    if opt is not None:
+        assert np.array_equal(res["plan"][0][3], W0[3]) and not np.array_equal(res["plan"][0][7], W0[7])
+    # ids outside the table take no part and are counted
+    bad = ids_a.copy()
+    bad[0, 0], bad[1, 1] = n_rows, -2
+    rp2 = eng.RowsPlan(t(bad), t(hist) if L else None, t(lengths) if L else None, n_rows, d, tag=f"test_rows_plan_bad_{d}_{n_rows}")
+    k2, p2, s2, e2, st2 = (x.cpu().numpy().astype(np.int64) for x in rp2.views())
+    assert st2[0] == 2 and int((e2 - s2).sum()) == n_live - 2
+
+
+@pytest.mark.parametrize("opt,rowwise", [("SGD", True), ("Adam", True), ("Adam", False)])
+def test_sasrec_trainer_rows_plan_equals_sorted_route(opt, rowwise, cuda, eng, monkeypatch):
+    """SasrecTrainer with the counting-sort row bounds (default) against RC_SAS_ROWS_PLAN=0 (radix sort + glue): three steps leave
+    every parameter bit-identical, on one stream and on two"""
+    rng = np.random.default_rng(11)
+    B, L, d, n_layers, n_heads, C, n_items = 600, 50, 64, 1, 4, 20, 400
+    P = _random_sasrec(rng, n_items, d, n_layers, L)
+    batches = []
+    for _ in range(3):
+        lengths = rng.integers(1, L + 1, size=B).astype(np.int64)
+        hist = rng.integers(1, n_items, size=(B, L)).astype(np.int64) * (np.arange(L)[None, :] < lengths[:, None])
+        iid = rng.integers(1, n_items, size=(B, C)).astype(np.int64)
+        batches.append(tuple(torch.from_numpy(x).to(cuda) for x in (hist, lengths, iid)))
+    out = {}
+    for overlap in (True, False):
+        for plan in (True, False):
+            monkeypatch.setattr(eng, "_SAS_ROWS_PLAN", plan)
+            monkeypatch.setattr(eng, "_SAS_OVERLAP", overlap)
+            monkeypatch.setattr(eng, "_SAS_OVERLAP_MIN", 0)
+            Pd = to_dev(P, n_layers, cuda)
+            tr = eng.SasrecTrainer(Pd, n_heads, opt=opt, lr=1e-3, l2=1e-5, rowwise=rowwise)
+            losses = [float(tr.step(*b)[0]) for b in batches]
+            torch.cuda.synchronize()
+            out[(overlap, plan)] = (losses, Pd["item_emb"].cpu().numpy(), Pd["pos_emb"].cpu().numpy())
+    ref = out[(False, False)]
+    assert not np.array_equal(ref[1], P["i_embeddings.weight"])
+    for k, got in out.items():
+        assert got[0] == ref[0] and np.array_equal(got[1], ref[1]) and np.array_equal(got[2], ref[2]), k
+
+
 @pytest.mark.parametrize("opt,overlap", [("SGD", True), ("Adagrad", False), ("Adam", True)])
 def test_sasrec_trainer_graph_replay_equals_eager(opt, overlap, cuda, eng, monkeypatch):
     """SasrecTrainer(graph=True) replays the step from a hipGraph (both streams captured, the batch copied into static
@@ -580,7 +695,7 @@ def test_sasrec_last_row_path_equals_all_rows(d, n_layers, n_heads, L, B, eligib
 
 
 def test_sasrec_pos_grad_chunks(cuda, eng):
-    """more than 1024 sequences: several chunks per position + the chunk reduction; vs the generic sort + segmented sum"""
+    """more than 256 sequences: several chunks per position + the chunk reduction; vs the generic sort + segmented sum"""
     rng = np.random.default_rng(4)
     for B, L, d in ((2500, 50, 64), (1030, 7, 32), (3, 20, 64)):
         lengths = torch.from_numpy(rng.integers(0, L + 1, size=B).astype(np.int64)).to(cuda)

@@ -7,6 +7,7 @@
 #   bench[:<name>:<bench.py args>]     a bench line -> <name>.json      (plain `bench` = the driver's default command)
 #   ab:<name>:<ENV=V,ENV=V>:<args>     the same bench line with environment switches set (A/B inside one call)
 #   prof:<name>:<bench.py args>        rocprofv3 --kernel-trace --stats of a bench command -> prof_<name>/
+#   profenv:<name>:<ENV=V,..>:<args>   the same with environment switches set
 #   pmc                                FETCH_SIZE / WRITE_SIZE passes of the BPRMF step (tools/pmc_collect.sh) -> pmc/
 #   py:<name>:<script and args>        python <script> -> <name>.log
 TAG=${1:-run}
@@ -76,6 +77,15 @@ for st in "$@"; do
       name=${rest%%:*}; args=${rest#*:}
       [ "$args" == "$rest" ] && args=""
       ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_$name -o kt --output-format csv -- \
+          python $R/bench.py $args --no-cpu-baseline --no-roofline > $OUT/prof_$name.log 2>&1 )
+      find $OUT/prof_$name -name "*kernel_trace.csv" -size +20M -delete 2>/dev/null
+      f=$(find $OUT/prof_$name -name "*kernel_stats.csv" | head -1)
+      [ -n "$f" ] && cut -c1-110 "$f" | head -14
+      ;;
+    profenv)   # prof with environment switches: profenv:<name>:<ENV=V,ENV=V>:<bench.py args>
+      name=${rest%%:*}; r2=${rest#*:}; envs=${r2%%:*}; args=${r2#*:}
+      [ "$args" == "$r2" ] && args=""
+      ( for kv in ${envs//,/ }; do export "$kv"; done; cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_$name -o kt --output-format csv -- \
           python $R/bench.py $args --no-cpu-baseline --no-roofline > $OUT/prof_$name.log 2>&1 )
       find $OUT/prof_$name -name "*kernel_trace.csv" -size +20M -delete 2>/dev/null
       f=$(find $OUT/prof_$name -name "*kernel_stats.csv" | head -1)
