@@ -276,6 +276,10 @@ int rc_dense_update_multi_dev(float* const* W, const float* const* G, float* con
                               const int64_t* n, const rc_opt_hyper* h, int n_tensors, const int64_t* step_dev,
                               rc_stream_t stream);
 int rc_step_increment(int64_t* step_dev, rc_stream_t stream);
+/* dst = [a | b | c] (int64): the id tensors of a batch (feed_dict['history_items'], ['lengths'], ['item_id'],
+ * models/sequential/SASRec.py:58-60) copied into the static buffer a captured step reads, in one launch. */
+int rc_stage_batch(const int64_t* a, int64_t na, const int64_t* b, int64_t nb, const int64_t* c, int64_t nc, int64_t* dst,
+                   rc_stream_t stream);
 
 /* ---- whole BPRMF training step ----------------------------------------------------- */
 

@@ -1685,11 +1685,14 @@ __global__ __launch_bounds__(kBlock) void sb_pos_grad_kernel(const float* __rest
   }
 }
 
-__global__ __launch_bounds__(kBlock) void sb_pos_reduce_kernel(const float* __restrict__ part, int chunks, int count,
+// out[i] = sum of the chunks for i < count, 0 for count <= i < total (the table's rows past history_max: the gradient buffer needs
+// no separate fill)
+__global__ __launch_bounds__(kBlock) void sb_pos_reduce_kernel(const float* __restrict__ part, int chunks, int count, int total,
                                                                float* __restrict__ out) {
-  for (int i = blockIdx.x * kBlock + threadIdx.x; i < count; i += gridDim.x * kBlock) {
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < total; i += gridDim.x * kBlock) {
     float t = 0.f;
-    for (int c = 0; c < chunks; ++c) t += part[(size_t)c * count + i];
+    if (i < count)
+      for (int c = 0; c < chunks; ++c) t += part[(size_t)c * count + i];
     out[i] = t;
   }
 }
@@ -2647,21 +2650,23 @@ extern "C" int rc_sasrec_pos_grad(const float* g_hist, const int64_t* lengths, i
   RC_REQUIRE(grad_pos != nullptr && n_pos >= L + 1 && L >= 1 && (d == 32 || d == 64),
              "rc_sasrec_pos_grad: bad arguments (n_pos=%d, L=%d, d=%d)", n_pos, L, d);
   hipStream_t s = as_stream(stream);
-  RC_HIP(hipMemsetAsync(grad_pos, 0, (size_t)n_pos * d * sizeof(float), s));  // rows past history_max, and B == 0
-  if (B == 0) return RC_OK;
+  if (B == 0) {
+    RC_HIP(hipMemsetAsync(grad_pos, 0, (size_t)n_pos * d * sizeof(float), s));
+    return RC_OK;
+  }
   RC_REQUIRE(g_hist && lengths && ws, "rc_sasrec_pos_grad: null pointer");
   if (ws_bytes < rc_sasrec_pos_grad_workspace_bytes(B, L, d))
     return fail(RC_ERR_WORKSPACE, "rc_sasrec_pos_grad: workspace %zu < %zu", ws_bytes, rc_sasrec_pos_grad_workspace_bytes(B, L, d));
   const int chunks = (B + kPosChunk - 1) / kPosChunk;
-  float* part = chunks == 1 ? grad_pos : static_cast<float*>(ws);
+  float* part = (chunks == 1 && n_pos == L + 1) ? grad_pos : static_cast<float*>(ws);   // (one chunk, no rows to zero: written in place)
   if (d == 64)
     hipLaunchKernelGGL((sb_pos_grad_kernel<64>), dim3(L + 1, chunks), dim3(kBlock), 0, s, g_hist, lengths, B, L, part);
   else
     hipLaunchKernelGGL((sb_pos_grad_kernel<32>), dim3(L + 1, chunks), dim3(kBlock), 0, s, g_hist, lengths, B, L, part);
   RC_LAUNCH_CHECK();
-  if (chunks > 1) {
-    const int count = (L + 1) * d;
-    hipLaunchKernelGGL(sb_pos_reduce_kernel, dim3((count + kBlock - 1) / kBlock), dim3(kBlock), 0, s, part, chunks, count, grad_pos);
+  if (part != grad_pos) {
+    const int count = (L + 1) * d, total = n_pos * d;
+    hipLaunchKernelGGL(sb_pos_reduce_kernel, dim3((total + kBlock - 1) / kBlock), dim3(kBlock), 0, s, part, chunks, count, total, grad_pos);
     RC_LAUNCH_CHECK();
   }
   return RC_OK;

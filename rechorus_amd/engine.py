@@ -1328,7 +1328,8 @@ class SasrecTrainer:
             torch.cuda.synchronize(hist.device)
             # (the capture recorded the step without running it: this batch is trained by the replay below)
         g, static, loss = entry
-        torch.cat([hist.reshape(-1), lengths.reshape(-1), iid.reshape(-1)], out=static[3])
+        _lib.call("rc_stage_batch", _ptr(hist, torch.int64, "hist"), hist.numel(), _ptr(lengths, torch.int64, "lengths"), lengths.numel(),
+                  _ptr(iid, torch.int64, "iid"), iid.numel(), _ptr(static[3], torch.int64, "static"), _stream())
         g.replay()
         # the host's count follows every trained step -- replayed or eager -- so that a batch shape that leaves the captured route
         # (the short last batch of an epoch) steps Adam with the right bias corrections
