@@ -560,6 +560,11 @@ int rc_linear_fwd_ws(const float* X, const float* W, const float* b, int64_t M, 
 size_t rc_linear_bwd_workspace_bytes(int64_t M, int N, int K);
 int rc_linear_bwd(const float* X, const float* W, const float* Y, const float* dY, int64_t M, int N, int K,
                   float drop_p, float* dX, float* dW, float* db, void* ws, size_t ws_bytes, rc_stream_t stream);
+/* rc_linear_bwd inside a chain of layers (utils/layers.py:201-243 builds Linear -> ReLU -> Dropout groups): with x_act != 0 the
+ * input X is the drop(relu(.)) output of the layer below and dX comes out already multiplied by that layer's mask
+ * (X > 0 ? 1 / (1 - x_drop_p) : 0) in the product's epilogue; the layer below is then called with Y = NULL (its dY is its dZ). */
+int rc_linear_bwd_chain(const float* X, const float* W, const float* Y, const float* dY, int64_t M, int N, int K, float drop_p,
+                        int x_act, float x_drop_p, float* dX, float* dW, float* db, void* ws, size_t ws_bytes, rc_stream_t stream);
 
 /* ---- training-batch assembly on the device (csrc/sampler.hip) -------------------------------- */
 

@@ -16,6 +16,8 @@
 // or reduction-minor.  Tile 64 x 64 per workgroup (2 x 2 waves, one 32 x 32 MFMA block each), K step 32: the tiles are
 // staged in LDS reduction-major ([k][i], row stride 68), K step 32 (two 16-row loader passes), so an MFMA operand fetch is one conflict-free ds_read_b32
 // across the lanes; the next K step's global loads are in flight while the current one is multiplied.
+#include <mutex>
+
 #include "common.hpp"
 #include "philox.hpp"
 
@@ -54,6 +56,10 @@ struct MlpGemm {
   uint32_t drop_thresh;
   float keep_scale;
   uint32_t site;
+  // dX products: the output is the gradient w.r.t. a drop(relu(.)) activation whose saved value is `mask` ([M][ldc], same layout
+  // as C): C = acc * (mask > 0 ? mask_scale : 0) -- the separate masking pass of the layer below, fused (null: off)
+  const float* mask;
+  float mask_scale;
 };
 
 // dropout mask of element (m, n): dropped iff word (m & 3) of Philox4x32-10(key = seed, counter = (m >> 2, site * 65536 + n))
@@ -316,6 +322,7 @@ __global__ __launch_bounds__(kBlock) void mlp_gemm_kernel(MlpGemm g, int vec_a, 
       float v = acc[4 * q + e] + bj_;
       if (g.relu) v = fmaxf(v, 0.f);
       if (g.seed) v *= keep[e];
+      if (g.mask) v = g.mask[m * g.ldc + j] > 0.f ? v * g.mask_scale : 0.f;
       C[m * g.ldc + j] = v;
     }
   }
@@ -520,6 +527,267 @@ __global__ __launch_bounds__(kBlock) void mlp_gemm_big_kernel(MlpGemm g, int vec
           float v = acc[a][b][4 * q + e] + bj_;
           if (g.relu) v = fmaxf(v, 0.f);
           if (g.seed) v *= keep[e];
+          if (g.mask) v = g.mask[m * g.ldc + j] > 0.f ? v * g.mask_scale : 0.f;
+          C[m * g.ldc + j] = v;
+        }
+      }
+  }
+}
+
+// ---- 128 x 128 tiles, second cut: K step 32, operand registers double-buffered against the MFMAs ---------------------------------
+// Device timing of the kernel above at 131,072 x 512 x 512 (tools/gemm_probe.py with the pieces switched off one at a time):
+// 824-900 us in all, 604 us with nothing but its LDS reads and MFMAs (72 % of the matrix peak), 409 us with everything BUT the
+// MFMAs -- the two barely overlap: a K step is 32 LDS reads, a wait, 32 MFMAs, the staging writes, a barrier, and with two
+// workgroups per CU the other one is usually in the same phase.  Here a K step is 32 wide (64 MFMAs per wave, half the barriers
+// per flop) and cut into four groups of 16 MFMAs; the operands of group u + 1 are read from LDS while group u runs (two register
+// sets), the next K step's tile is staged under group 2 and the first operands of the next buffer are read behind the barrier
+// under group 3.  Operand layouts and the k = 8 u + 4 kh + e contraction order as in the 64 x 64 kernel (a reduction-minor
+// operand gives four reduction indices per ds_read_b128).  Fast path only -- 16-byte aligned operands, K steps complete, a
+// column count of B that is a multiple of four (the column of ones of the weight-gradient products included) -- everything else
+// takes the kernel above.  Workgroup -> (tile, split) map: XCD-aware for many row tiles as above; for the weight-gradient
+// products (few tiles, many splits of the batch) the tiles of ONE split run side by side on ONE XCD, so that the split's slices
+// of dZ and X are fetched from HBM once and found in that XCD's L2 by the other tiles.
+constexpr int kB2K = 32;
+constexpr int kB2LDK = kB2K + 4;     // [outer][k] layout (reduction-minor operands)
+constexpr int kB2LD = 132;           // [k][outer] layout (reduction-major operands)
+constexpr int kB2Tile = 128 * kB2LDK > kB2K * kB2LD ? 128 * kB2LDK : kB2K * kB2LD;   // floats per buffer
+
+struct B2Src {   // one float4 of the tile per thread and K step: its address and class (0 constant, 1 load)
+  const float* p;
+  int load;
+  float4 cst;
+};
+
+template <bool KM>
+__device__ __forceinline__ B2Src b2_src(const MlpOperand& o, int64_t outer0, int64_t outer_n, int64_t k0, int ones_col, int q) {
+  const int t = threadIdx.x;
+  B2Src f;
+  f.cst = make_float4(0.f, 0.f, 0.f, 0.f);
+  f.load = 1;
+  if (KM) {   // row t / 8 + 32 q of the tile, k = 4 (t % 8) ..: rows past the matrix read its last row (never stored)
+    int64_t i = outer0 + (t >> 3) + 32 * q;
+    if (i >= outer_n) i = outer_n - 1;
+    f.p = o.p + i * o.ld + k0 + 4 * (t & 7);
+  } else {    // k row t / 32 + 8 q, columns 4 (t % 32) ..: columns past the matrix are constants
+    const int64_t i = outer0 + 4 * (t & 31);
+    f.p = o.p + (k0 + (t >> 5) + 8 * q) * o.ld + i;
+    if (i >= outer_n) {
+      f.load = 0;
+      f.p = o.p;
+      f.cst = make_float4(i == ones_col ? 1.f : 0.f, i + 1 == ones_col ? 1.f : 0.f, i + 2 == ones_col ? 1.f : 0.f,
+                          i + 3 == ones_col ? 1.f : 0.f);
+    }
+  }
+  return f;
+}
+
+template <bool KM>
+__device__ __forceinline__ void b2_stage(float* tile, const float4& v, int q) {
+  const int t = threadIdx.x;
+  if (KM) *reinterpret_cast<float4*>(tile + ((t >> 3) + 32 * q) * kB2LDK + 4 * (t & 7)) = v;
+  else *reinterpret_cast<float4*>(tile + ((t >> 5) + 8 * q) * kB2LD + 4 * (t & 31)) = v;
+}
+
+// the operand values of MFMAs (u, 0..3) for this lane: rows / columns o and o + 32 of the tile
+template <bool KM>
+__device__ __forceinline__ void b2_operands(const float* tile, int o, int kh, int u, float (&x)[2][4]) {
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    if (KM) {
+      const float4 v = *reinterpret_cast<const float4*>(tile + (o + 32 * h) * kB2LDK + 8 * u + 4 * kh);
+      x[h][0] = v.x; x[h][1] = v.y; x[h][2] = v.z; x[h][3] = v.w;
+    } else {
+      const float* p = tile + (8 * u + 4 * kh) * kB2LD + o + 32 * h;
+      x[h][0] = p[0]; x[h][1] = p[kB2LD]; x[h][2] = p[2 * kB2LD]; x[h][3] = p[3 * kB2LD];
+    }
+  }
+}
+
+template <bool AKM, bool BKM>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 2))) void mlp_gemm_big2_kernel(MlpGemm g, int m_tiles, int n_tiles, int splits) {
+  extern __shared__ __attribute__((aligned(16))) float b2_lds[];   // As[2] | Bs[2]
+  float* As = b2_lds;
+  float* Bs = b2_lds + 2 * kB2Tile;
+  // ---- workgroup -> (row tile, column tile, split)
+  const int L = blockIdx.x, xcd = L & 7, slot = L >> 3;
+  int mt, nt, sp;
+  if (splits > 1) {            // the tiles of a split side by side on one XCD
+    const int tiles = m_tiles * n_tiles;
+    sp = (slot / tiles) * 8 + xcd;
+    const int tile = slot % tiles;
+    mt = tile / n_tiles;
+    nt = tile % n_tiles;
+    if (sp >= splits) return;
+  } else if (m_tiles >= 16) {  // a row tile's column tiles side by side on one XCD
+    sp = 0;
+    mt = (slot / n_tiles) * 8 + xcd;
+    nt = slot % n_tiles;
+    if (mt >= m_tiles) return;
+  } else {
+    sp = 0;
+    mt = L / n_tiles;
+    nt = L % n_tiles;
+    if (mt >= m_tiles) return;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wr = wave >> 1, wc = wave & 1;   // this wave's 64 x 64 quarter
+  const int64_t m0 = (int64_t)mt * 128, n0 = (int64_t)nt * 128;
+  const int64_t kb = (int64_t)sp * g.split_stride_k;
+  const int64_t ke = (kb + g.K < g.k_total) ? kb + g.K : g.k_total;
+  const int64_t bn = g.ones_col >= 0 ? (int64_t)g.ones_col : (int64_t)g.N;          // columns of B in memory
+  const int64_t ncols = g.ones_col >= 0 ? (int64_t)g.ones_col + 1 : (int64_t)g.N;   // columns of the product
+  // 32-column blocks of this wave that hold a column of the product (the tile of the column of ones: one block of one wave)
+  const int nb_live = n0 + wc * 64 + 32 < ncols ? 2 : (n0 + wc * 64 < ncols ? 1 : 0);
+  mlp_f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  // this thread's four float4 per operand and K step: address, class (load / constant), the constant
+  const float* pa[4];
+  const float* pb[4];
+  bool lb[4];
+  float4 cb[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const B2Src sa = b2_src<AKM>(g.A, m0, g.M, kb, -1, q);
+    const B2Src sb = b2_src<BKM>(g.B, n0, bn, kb, g.ones_col, q);
+    pa[q] = sa.p;   // (A: rows past the matrix read its last row, always a load)
+    pb[q] = sb.p; lb[q] = sb.load != 0; cb[q] = sb.cst;
+  }
+  const int64_t stride_a = AKM ? (int64_t)kB2K : (int64_t)kB2K * g.A.ld;
+  const int64_t stride_b = BKM ? (int64_t)kB2K : (int64_t)kB2K * g.B.ld;
+  float4 ra[4], rb[4];
+#define B2_FETCH(OA, OB)                                                              \
+  _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                     \
+    ra[q] = *reinterpret_cast<const float4*>(pa[q] + (OA));                           \
+    rb[q] = *reinterpret_cast<const float4*>(pb[q] + (lb[q] ? (OB) : 0));             \
+  }
+#define B2_STAGE(BUF)                                                                 \
+  _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                     \
+    /* (component selects: a select between two array elements makes both arrays stack objects) */ \
+    b2_stage<AKM>(As + (BUF) * kB2Tile, make_float4(ra[q].x, ra[q].y, ra[q].z, ra[q].w), q); \
+    b2_stage<BKM>(Bs + (BUF) * kB2Tile, make_float4(lb[q] ? rb[q].x : cb[q].x, lb[q] ? rb[q].y : cb[q].y, \
+                                                    lb[q] ? rb[q].z : cb[q].z, lb[q] ? rb[q].w : cb[q].w), q); \
+  }
+  int64_t off_a = 0, off_b = 0;
+  B2_FETCH(off_a, off_b)
+  B2_STAGE(0)
+  __syncthreads();
+  const int ai = wr * 64 + (lane & 31), bj = wc * 64 + (lane & 31), kh = lane >> 5;
+  float xa[2][2][4], xb[2][2][4];   // [register set][32-row / 32-column block][e]
+  b2_operands<AKM>(As, ai, kh, 0, xa[0]);
+  b2_operands<BKM>(Bs, bj, kh, 0, xb[0]);
+  int buf = 0;
+  for (int64_t k0 = kb; k0 < ke; k0 += kB2K) {
+    const bool more = k0 + kB2K < ke;   // workgroup-uniform
+    if (more) {
+      off_a += stride_a;
+      off_b += stride_b;
+      B2_FETCH(off_a, off_b)
+    }
+    const float* at = As + buf * kB2Tile;
+    const float* bt = Bs + buf * kB2Tile;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int cur = u & 1, nxt = cur ^ 1;
+      if (u < 3) {
+        b2_operands<AKM>(at, ai, kh, u + 1, xa[nxt]);
+        b2_operands<BKM>(bt, bj, kh, u + 1, xb[nxt]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#define B2_MFMAS(E0, E1)                                                                                          \
+  if (nb_live == 2) {                                                                                             \
+    _Pragma("unroll") for (int e = (E0); e < (E1); ++e) {                                                         \
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[cur][0][e], xb[cur][0][e], acc[0][0], 0, 0, 0);         \
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[cur][0][e], xb[cur][1][e], acc[0][1], 0, 0, 0);         \
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[cur][1][e], xb[cur][0][e], acc[1][0], 0, 0, 0);         \
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[cur][1][e], xb[cur][1][e], acc[1][1], 0, 0, 0);         \
+    }                                                                                                             \
+  } else if (nb_live == 1) {                                                                                      \
+    _Pragma("unroll") for (int e = (E0); e < (E1); ++e) {                                                         \
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[cur][0][e], xb[cur][0][e], acc[0][0], 0, 0, 0);         \
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[cur][1][e], xb[cur][0][e], acc[1][0], 0, 0, 0);         \
+    }                                                                                                             \
+  }
+      if (u < 3) {
+        B2_MFMAS(0, 4)
+        __builtin_amdgcn_sched_barrier(0);
+        if (u == 2 && more) { B2_STAGE(buf ^ 1) }
+      } else {
+        // the barrier and the first operands of the next buffer go between the two halves of the last group: the matrix pipe
+        // still holds eight MFMAs while the waves meet and the reads travel
+        B2_MFMAS(0, 2)
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        if (more) {   // (u == 3: cur = 1, the set the next K step starts from is 0)
+          b2_operands<AKM>(As + (buf ^ 1) * kB2Tile, ai, kh, 0, xa[0]);
+          b2_operands<BKM>(Bs + (buf ^ 1) * kB2Tile, bj, kh, 0, xb[0]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        B2_MFMAS(2, 4)
+      }
+#undef B2_MFMAS
+    }
+    buf ^= 1;
+  }
+#undef B2_FETCH
+#undef B2_STAGE
+  // ---- epilogue: acc[a][b][r] is C(m0 + wr*64 + a*32 + (r & 3) + 8 (r >> 2) + 4 kh, n0 + wc*64 + b*32 + (lane & 31))
+  const uint64_t seed = g.seed ? *g.seed : 0;
+  float* C = g.C + (size_t)sp * (size_t)g.M * (size_t)g.ldc;
+  if (m0 + 128 <= g.M && n0 + 128 <= ncols && g.seed == nullptr) {   // a tile inside the product, no dropout: no range checks
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int64_t j = n0 + wc * 64 + b * 32 + (lane & 31);
+      const float bj_ = (g.bias != nullptr && j < g.N) ? g.bias[j] : 0.f;
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        float* row = C + (m0 + wr * 64 + a * 32 + 4 * kh) * g.ldc + j;
+        const float* mrow = g.mask ? g.mask + (m0 + wr * 64 + a * 32 + 4 * kh) * g.ldc + j : nullptr;
+        float mk[16];
+        if (g.mask) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) mk[r] = mrow[((r & 3) + 8 * (r >> 2)) * g.ldc];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = acc[a][b][r] + bj_;
+          if (g.relu) v = fmaxf(v, 0.f);
+          if (g.mask) v = mk[r] > 0.f ? v * g.mask_scale : 0.f;
+          row[((r & 3) + 8 * (r >> 2)) * g.ldc] = v;
+        }
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int64_t j = n0 + wc * 64 + b * 32 + (lane & 31);
+    if (j >= ncols) continue;
+    const float bj_ = (g.bias != nullptr && j < g.N) ? g.bias[j] : 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int64_t mb = m0 + wr * 64 + a * 32 + 8 * q + 4 * kh;
+        float keep[4] = {1.f, 1.f, 1.f, 1.f};
+        if (g.seed && mb < g.M) mlp_keep4(g, seed, mb >> 2, (int)j, keep);
+        float mk[4] = {1.f, 1.f, 1.f, 1.f};
+        if (g.mask) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) mk[e] = (mb + e < g.M && g.mask[(mb + e) * g.ldc + j] > 0.f) ? g.mask_scale : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int64_t m = mb + e;
+          if (m >= g.M) continue;
+          float v = acc[a][b][4 * q + e] + bj_;
+          if (g.relu) v = fmaxf(v, 0.f);
+          if (g.seed) v *= keep[e];
+          if (g.mask) v *= mk[e];
           C[m * g.ldc + j] = v;
         }
       }
@@ -546,6 +814,91 @@ __global__ __launch_bounds__(kBlock) void mlp_reduce_kernel(const float* __restr
   }
 }
 
+// ---- weight gradient of a layer with one to four outputs (the last Linear of every tower: width -> 1) ------------------------------
+// [dW | db][n, k] = sum_m dZ[m, n] [X | 1][m, k] for N <= 4 is a column reduction of X weighted by dZ, not a matrix product: a
+// 64 x 64 tile spent 147 us on the 131,072 x 64 -> 1 layer with 63 of its 64 rows empty.  Here a lane-group of K / 4 lanes owns a
+// row of X per trip (float4 per lane, four rows in flight), the groups of a workgroup are summed in a fixed tree, and the
+// partial sums of the workgroups go through mlp_reduce_kernel like the splits of the tiled product (fixed order, no atomics).
+constexpr int kNarrowWgs = 512;
+
+template <int NOUT>
+__global__ __launch_bounds__(kBlock) void mlp_dw_narrow_kernel(const float* __restrict__ dZ, const float* __restrict__ X, int64_t M,
+                                                               int K, float* __restrict__ part /* [gridDim.x][NOUT][K + 1] */) {
+  const int lpr = K / 4;                 // lanes per row
+  const int gpb = kBlock / lpr;          // rows per trip of the workgroup
+  const int l = threadIdx.x % lpr, grp = threadIdx.x / lpr;
+  float4 acc[NOUT];
+  float accb[NOUT];
+#pragma unroll
+  for (int n = 0; n < NOUT; ++n) {
+    acc[n] = make_float4(0.f, 0.f, 0.f, 0.f);
+    accb[n] = 0.f;
+  }
+  const bool live = grp < gpb;           // (K / 4 need not divide 256)
+  constexpr int U = 4;
+  for (int64_t m0 = (int64_t)blockIdx.x * gpb + grp; live && m0 < M; m0 += (int64_t)U * gridDim.x * gpb) {
+    float4 x[U];
+    float z[U][NOUT];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t m = m0 + (int64_t)u * gridDim.x * gpb;
+      const int64_t mc = m < M ? m : M - 1;
+      x[u] = reinterpret_cast<const float4*>(X + mc * K)[l];
+#pragma unroll
+      for (int n = 0; n < NOUT; ++n) z[u][n] = m < M ? dZ[mc * NOUT + n] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int n = 0; n < NOUT; ++n) {
+        acc[n].x = fmaf(z[u][n], x[u].x, acc[n].x);
+        acc[n].y = fmaf(z[u][n], x[u].y, acc[n].y);
+        acc[n].z = fmaf(z[u][n], x[u].z, acc[n].z);
+        acc[n].w = fmaf(z[u][n], x[u].w, acc[n].w);
+        accb[n] += z[u][n];
+      }
+  }
+  // sum over the lane-groups of the workgroup, fixed order, through LDS (one column quad at a time: K / 4 passes of the small buffer)
+  extern __shared__ float nr_lds[];      // [gpb][NOUT][K + 1]
+  float* mine = nr_lds + (size_t)grp * NOUT * (K + 1);
+  if (live) {
+#pragma unroll
+    for (int n = 0; n < NOUT; ++n) {
+      mine[n * (K + 1) + 4 * l + 0] = acc[n].x;
+      mine[n * (K + 1) + 4 * l + 1] = acc[n].y;
+      mine[n * (K + 1) + 4 * l + 2] = acc[n].z;
+      mine[n * (K + 1) + 4 * l + 3] = acc[n].w;
+      if (l == 0) mine[n * (K + 1) + K] = accb[n];
+    }
+  }
+  __syncthreads();
+  const int total = NOUT * (K + 1);
+  for (int i = threadIdx.x; i < total; i += kBlock) {
+    float t = 0.f;
+    for (int q = 0; q < gpb; ++q) t += nr_lds[(size_t)q * total + i];
+    part[(size_t)blockIdx.x * total + i] = t;
+  }
+}
+
+// mlp_reduce_kernel for many planes of few elements (the narrow route: up to 512 workgroup partials of N (K + 1) <= 4,100 sums):
+// one wave per element, the lanes take planes q = lane, lane + 64, ..., the lane sums meet in a fixed xor tree
+__global__ __launch_bounds__(kBlock) void mlp_reduce_wave_kernel(const float* __restrict__ part, int splits, int N, int K,
+                                                                 float* __restrict__ dW, float* __restrict__ db) {
+  const int64_t total = (int64_t)N * (K + 1);
+  const int lane = threadIdx.x & 63;
+  const int64_t i = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (i >= total) return;   // wave-uniform
+  float s = 0.f;
+  for (int q = lane; q < splits; q += 64) s += part[(size_t)q * total + i];
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+  if (lane == 0) {
+    const int n = (int)(i / (K + 1)), k = (int)(i % (K + 1));
+    if (k < K) dW[(size_t)n * K + k] = s;
+    else if (db != nullptr) db[n] = s;
+  }
+}
+
 static bool vec4_ok(const MlpOperand& o) { return reinterpret_cast<uintptr_t>(o.p) % 16 == 0 && o.ld % 4 == 0; }
 
 // RC_MLP_BIG=0: 64 x 64 tiles for every product (round 2), for A/B timing
@@ -554,12 +907,48 @@ static bool mlp_big_enabled() {
   return !(v && v[0] == '0');
 }
 
-static int mlp_launch(const MlpGemm& g, int splits, hipStream_t s) {
+// RC_MLP_BIG2=0: the first 128 x 128 kernel for every large product (A/B timing)
+static bool mlp_big2_enabled() {
+  const char* v = getenv("RC_MLP_BIG2");
+  return !(v && v[0] == '0');
+}
+
+// dynamic LDS beyond 64 KB needs the attribute, once per (device, kernel variant)
+static int b2_set_lds_limit(const void* kern, int variant, size_t lds) {
+  static std::mutex mu;
+  static bool done[64][4] = {};
+  int dev = 0;
+  RC_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(mu);
+  if (dev >= 0 && dev < 64 && !done[dev][variant]) {
+    RC_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    done[dev][variant] = true;
+  }
+  return RC_OK;
+}
+
+static int mlp_launch(const MlpGemm& g, int splits, hipStream_t s, bool want_big2 = false) {
   const int64_t ncols = g.ones_col >= 0 ? (int64_t)g.ones_col + 1 : (int64_t)g.N;
   // 128 x 128 tiles once they fill the chip (>= 2048 of them, 8 per CU: below that the 64 x 64 tiles' finer grain wins -- B = 16,384:
   // 1.05 against 1.14 ms per step) and the product is at least a tile wide
   const int64_t mt = (g.M + kBigBM - 1) / kBigBM, nt = (ncols + kBigBN - 1) / kBigBN;
-  if (mlp_big_enabled() && g.M >= kBigBM && ncols >= kBigBN && mt * nt * splits >= 2048 && mt < (1 << 24)) {
+  if (mlp_big_enabled() && g.M >= kBigBM && ncols >= kBigBN && (mt * nt * splits >= 2048 || want_big2) && mt < (1 << 24)) {
+    const int64_t bn = g.ones_col >= 0 ? (int64_t)g.ones_col : (int64_t)g.N;
+    const bool steps_complete = g.K % kB2K == 0 && (splits == 1 ? g.k_total == g.K : (g.split_stride_k == g.K && g.k_total % kB2K == 0));
+    if (mlp_big2_enabled() && vec4_ok(g.A) && vec4_ok(g.B) && steps_complete && (g.B.k_major || bn % 4 == 0) && g.K >= kB2K &&
+        mt * nt * (int64_t)((splits + 7) / 8 * 8) < (1 << 28)) {
+      const size_t lds = 4 * (size_t)kB2Tile * sizeof(float);
+      void (*kern)(MlpGemm, int, int, int) =
+          g.A.k_major ? (g.B.k_major ? mlp_gemm_big2_kernel<true, true> : mlp_gemm_big2_kernel<true, false>)
+                      : (g.B.k_major ? mlp_gemm_big2_kernel<false, true> : mlp_gemm_big2_kernel<false, false>);
+      RC_TRY(b2_set_lds_limit(reinterpret_cast<const void*>(kern), (g.A.k_major ? 2 : 0) + (g.B.k_major ? 1 : 0), lds));
+      int64_t blocks;
+      if (splits > 1) blocks = (int64_t)((splits + 7) / 8) * 8 * mt * nt;
+      else blocks = mt >= 16 ? ((mt + 7) / 8) * nt * 8 : mt * nt;
+      hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kBlock), lds, s, g, (int)mt, (int)nt, splits);
+      RC_LAUNCH_CHECK();
+      return RC_OK;
+    }
     const int64_t groups = (mt + 7) / 8;   // row tiles per XCD
     dim3 grid((unsigned)(mt >= 16 ? groups * nt * 8 : mt * nt), 1, (unsigned)splits);
     hipLaunchKernelGGL(mlp_gemm_big_kernel, grid, dim3(kBlock), 0, s, g, vec4_ok(g.A) ? 1 : 0, vec4_ok(g.B) ? 1 : 0, (int)mt, (int)nt);
@@ -572,6 +961,18 @@ static int mlp_launch(const MlpGemm& g, int splits, hipStream_t s) {
   hipLaunchKernelGGL(kern, grid, dim3(kBlock), 0, s, g, vec4_ok(g.A) ? 1 : 0, vec4_ok(g.B) ? 1 : 0);
   RC_LAUNCH_CHECK();
   return RC_OK;
+}
+
+// The weight-gradient product of a large batch on the 128 x 128 tiles (mlp_gemm_big2_kernel, the tiles of a split side by side
+// on one XCD): at most two workgroups per CU -- one round --, a multiple of eight splits.  0 = stays on the 64 x 64 tiles.
+static int mlp_dw_big_splits(int64_t M, int N, int K) {
+  if (!mlp_big_enabled() || !mlp_big2_enabled() || M < 16384 || M % kB2K != 0 || N < 128 || K < 127 || K % 4 != 0 || N % 4 != 0) return 0;
+  const int64_t tiles = ((int64_t)(N + 127) / 128) * ((K + 1 + 127) / 128);
+  int64_t s = 512 / tiles / 8 * 8;   // one round of two workgroups per CU, a multiple of eight splits (one XCD each)
+  const int64_t max_s = M / 1024;   // at least 32 K steps per split
+  if (s > max_s) s = max_s / 8 * 8;
+  if (s > 64) s = 64;
+  return s >= 8 ? (int)s : 0;
 }
 
 static int mlp_splits(int64_t M, int N, int K) {
@@ -626,6 +1027,7 @@ __global__ __launch_bounds__(kBlock) void mlp_split_epilogue_kernel(MlpGemm g, c
       v += bn;
       if (g.relu) v = fmaxf(v, 0.f);
       if (g.seed) v *= keep[e];
+      if (g.mask) v = g.mask[(size_t)m * g.N + n] > 0.f ? v * g.mask_scale : 0.f;   // (ldc = N for every product that takes this path)
       Y[(size_t)m * g.N + n] = v;
     }
   }
@@ -640,7 +1042,7 @@ static int mlp_product(MlpGemm g, float* part, hipStream_t s) {
   per = (per + kMlpBK - 1) / kMlpBK * kMlpBK;
   const int used = (int)((g.K + per - 1) / per);
   p.C = part; p.ldc = g.N; p.K = (int)per; p.split_stride_k = per; p.k_total = g.K;
-  p.bias = nullptr; p.relu = 0; p.seed = nullptr;
+  p.bias = nullptr; p.relu = 0; p.seed = nullptr; p.mask = nullptr;
   RC_TRY(mlp_launch(p, used, s));
   const int64_t total = ((g.M + 3) / 4) * g.N;
   int64_t blocks = (total + kBlock - 1) / kBlock;
@@ -648,6 +1050,19 @@ static int mlp_product(MlpGemm g, float* part, hipStream_t s) {
   hipLaunchKernelGGL(mlp_split_epilogue_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, s, g, part, used, g.C);
   RC_LAUNCH_CHECK();
   return RC_OK;
+}
+// the weighted column sum for one to four outputs (mlp_dw_narrow_kernel): K a multiple of 4 up to 1,024 whose lane-groups fit the
+// workgroup's LDS buffer, a batch large enough to fill the workgroups
+static bool mlp_dw_narrow_ok(int64_t M, int N, int K) {
+  if (N < 1 || N > 4 || K % 4 != 0 || K < 4 || K > 1024 || M < 4096) return false;
+  const int gpb = kBlock / (K / 4);
+  return gpb >= 1 && (size_t)gpb * N * (K + 1) * sizeof(float) <= 48 * 1024;
+}
+
+// planes of partial weight gradients the workspace holds (any route)
+static int mlp_dw_parts(int64_t M, int N, int K) {
+  const int a = mlp_splits(M, N, K), b = mlp_dw_big_splits(M, N, K), c = mlp_dw_narrow_ok(M, N, K) ? kNarrowWgs : 0;
+  return a > b ? (a > c ? a : c) : (b > c ? b : c);
 }
 static size_t mlp_split_bytes(int64_t M, int N, int K) {
   const int sp = mlp_k_splits(M, N, K);
@@ -666,7 +1081,7 @@ extern "C" size_t rc_linear_fwd_workspace_bytes(int64_t M, int N, int K) {
 extern "C" size_t rc_linear_bwd_workspace_bytes(int64_t M, int N, int K) {
   if (M < 1 || N < 1 || K < 1) return 0;
   const size_t dz = align_up((size_t)M * N * sizeof(float), 256);
-  const size_t part = align_up((size_t)mlp_splits(M, N, K) * (size_t)N * (size_t)(K + 1) * sizeof(float), 256);
+  const size_t part = align_up((size_t)mlp_dw_parts(M, N, K) * (size_t)N * (size_t)(K + 1) * sizeof(float), 256);
   return dz + part + mlp_split_bytes(M, K, N);   // (the dX product: [M, K] out, reduction over N)
 }
 
@@ -707,8 +1122,26 @@ static int linear_fwd_impl(const float* X, const float* W, const float* b, int64
   return mlp_product(g, static_cast<float*>(ws), as_stream(stream));
 }
 
+static int linear_bwd_impl(const float* X, const float* W, const float* Y, const float* dY, int64_t M, int N, int K, float drop_p,
+                           int x_act, float x_drop_p, float* dX, float* dW, float* db, void* ws, size_t ws_bytes, rc_stream_t stream);
+
 extern "C" int rc_linear_bwd(const float* X, const float* W, const float* Y, const float* dY, int64_t M, int N, int K,
                              float drop_p, float* dX, float* dW, float* db, void* ws, size_t ws_bytes, rc_stream_t stream) {
+  return linear_bwd_impl(X, W, Y, dY, M, N, K, drop_p, 0, 0.f, dX, dW, db, ws, ws_bytes, stream);
+}
+
+// rc_linear_bwd inside a chain of layers: with x_act != 0 the input X of this layer is the drop(relu(.)) output of the layer
+// below, and dX comes out already multiplied by that layer's mask (X > 0 ? 1 / (1 - x_drop_p) : 0) in the product's epilogue --
+// the layer below is then called with Y = NULL (its dY is its dZ): one pass over [M, K] less per layer boundary.
+extern "C" int rc_linear_bwd_chain(const float* X, const float* W, const float* Y, const float* dY, int64_t M, int N, int K,
+                                   float drop_p, int x_act, float x_drop_p, float* dX, float* dW, float* db, void* ws,
+                                   size_t ws_bytes, rc_stream_t stream) {
+  RC_REQUIRE(x_drop_p >= 0.f && x_drop_p < 1.f, "rc_linear_bwd_chain: dropout p=%g of the layer below outside [0, 1)", (double)x_drop_p);
+  return linear_bwd_impl(X, W, Y, dY, M, N, K, drop_p, x_act, x_drop_p, dX, dW, db, ws, ws_bytes, stream);
+}
+
+static int linear_bwd_impl(const float* X, const float* W, const float* Y, const float* dY, int64_t M, int N, int K, float drop_p,
+                           int x_act, float x_drop_p, float* dX, float* dW, float* db, void* ws, size_t ws_bytes, rc_stream_t stream) {
   RC_REQUIRE(X && W && dY && dW, "rc_linear_bwd: null pointer");
   RC_REQUIRE(M >= 0 && N >= 1 && K >= 1, "rc_linear_bwd: bad shape M=%lld N=%d K=%d", (long long)M, N, K);
   hipStream_t s = as_stream(stream);
@@ -737,11 +1170,29 @@ extern "C" int rc_linear_bwd(const float* X, const float* W, const float* Y, con
     g.A = MlpOperand{dZ, N, 1};
     g.B = MlpOperand{W, K, 0};
     g.M = M; g.N = K; g.K = N; g.ones_col = -1; g.C = dX; g.ldc = K; g.split_stride_k = N; g.k_total = N;
-    float* dx_part = mlp_k_splits(M, K, N) > 1 ? reinterpret_cast<float*>(reinterpret_cast<char*>(part) + align_up((size_t)mlp_splits(M, N, K) * (size_t)N * (size_t)(K + 1) * sizeof(float), 256)) : nullptr;
+    if (x_act) {
+      g.mask = X;
+      g.mask_scale = 1.0f / (1.0f - x_drop_p);
+    }
+    float* dx_part = mlp_k_splits(M, K, N) > 1 ? reinterpret_cast<float*>(reinterpret_cast<char*>(part) + align_up((size_t)mlp_dw_parts(M, N, K) * (size_t)N * (size_t)(K + 1) * sizeof(float), 256)) : nullptr;
     RC_TRY(mlp_product(g, dx_part, s));
   }
-  {  // [dW | db][n, k] = sum_m dZ[m, n] [X | 1][m, k], the batch cut into splits
-    const int splits = mlp_splits(M, N, K);
+  if (mlp_dw_narrow_ok(M, N, K) && reinterpret_cast<uintptr_t>(X) % 16 == 0) {   // one to four outputs: a weighted column sum
+    const int gpb = kBlock / (K / 4);
+    int64_t wgs = (M + gpb - 1) / gpb;
+    if (wgs > kNarrowWgs) wgs = kNarrowWgs;
+    const size_t lds = (size_t)gpb * N * (K + 1) * sizeof(float);
+    void (*kern)(const float*, const float*, int64_t, int, float*) =
+        N == 1 ? mlp_dw_narrow_kernel<1> : (N == 2 ? mlp_dw_narrow_kernel<2> : (N == 3 ? mlp_dw_narrow_kernel<3> : mlp_dw_narrow_kernel<4>));
+    hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(kBlock), lds, s, dZ, X, M, K, part);
+    RC_LAUNCH_CHECK();
+    const int64_t total = (int64_t)N * (K + 1);
+    hipLaunchKernelGGL(mlp_reduce_wave_kernel, dim3((unsigned)((total + kBlock / 64 - 1) / (kBlock / 64))), dim3(kBlock), 0, s, part,
+                       (int)wgs, N, K, dW, db);
+    RC_LAUNCH_CHECK();
+  } else {  // [dW | db][n, k] = sum_m dZ[m, n] [X | 1][m, k], the batch cut into splits
+    const int big = (reinterpret_cast<uintptr_t>(dZ) % 16 == 0 && reinterpret_cast<uintptr_t>(X) % 16 == 0) ? mlp_dw_big_splits(M, N, K) : 0;
+    const int splits = big ? big : mlp_splits(M, N, K);
     int64_t per = (M + splits - 1) / splits;
     per = (per + kMlpBK - 1) / kMlpBK * kMlpBK;
     MlpGemm g;
@@ -750,7 +1201,7 @@ extern "C" int rc_linear_bwd(const float* X, const float* W, const float* Y, con
     g.B = MlpOperand{X, K, 0};
     g.M = N; g.N = K; g.K = (int)per; g.ones_col = K; g.C = part; g.ldc = K + 1; g.split_stride_k = per; g.k_total = M;
     const int used = (int)((M + per - 1) / per);
-    RC_TRY(mlp_launch(g, used, s));
+    RC_TRY(mlp_launch(g, used, s, big != 0));
     const int64_t total = (int64_t)N * (K + 1);
     int64_t blocks = (total + kBlock - 1) / kBlock;
     if (blocks > 2048) blocks = 2048;

@@ -430,11 +430,59 @@ def mlp_plan(modules):
     return plan or None
 
 
+class _MlpFn(torch.autograd.Function):
+    """a whole mlp_plan as ONE autograd node: forward = one rc_linear_fwd per layer; backward = rc_linear_bwd_chain per layer,
+    top down, where the dX product of layer i + 1 applies the ReLU / dropout mask of layer i in its epilogue (the saved output of
+    layer i is the input of layer i + 1), so no layer but the top one makes a separate masking pass over [M, width]."""
+
+    @staticmethod
+    def forward(ctx, x, spec, seed, *params):
+        # spec: tuple of (relu, drop_p, has_bias) per layer; params: W_0, b_0 | None, W_1, ...
+        xs = x.detach().reshape(-1, x.shape[-1]).contiguous()
+        saved, h = [], xs
+        for site, (relu, p, has_b) in enumerate(spec):
+            W = params[2 * site].detach().contiguous()
+            b = params[2 * site + 1].detach().contiguous() if has_b else None
+            y = engine.linear_fwd(h, W, b, relu, p, seed, site)
+            saved += [h, W]
+            h = y
+        ctx.save_for_backward(*saved, h)
+        ctx.spec, ctx.xshape, ctx.need_dx = spec, x.shape, x.requires_grad
+        return h.view(*x.shape[:-1], h.shape[-1])
+
+    @staticmethod
+    def backward(ctx, dy):
+        spec = ctx.spec
+        *saved, y_top = ctx.saved_tensors
+        n = len(spec)
+        dz = dy.reshape(-1, dy.shape[-1]).contiguous()
+        grads = [None] * (2 * n)
+        for i in range(n - 1, -1, -1):
+            X, W = saved[2 * i], saved[2 * i + 1]
+            relu, p, has_b = spec[i]
+            # the top layer masks its own dY (Y = its saved output); every other layer receives a dY that the layer above
+            # already masked in its dX product (x_act)
+            y = y_top if (i == n - 1 and (relu or p > 0)) else None
+            below = spec[i - 1] if i > 0 else None
+            x_act = below is not None and (below[0] or below[1] > 0)
+            need_dx = i > 0 or ctx.need_dx
+            dX, dW, db = engine.linear_bwd(X, W, y, dz, p, need_dx=need_dx, need_db=has_b, x_act=x_act,
+                                           x_drop_p=below[1] if x_act else 0.0)
+            grads[2 * i], grads[2 * i + 1] = dW, db
+            dz = dX
+        return (dz.view(ctx.xshape) if dz is not None else None, None, None, *grads)
+
+
 def mlp_forward(x, plan, training, seed):
-    """run a mlp_plan: one rc_linear_fwd per layer (dropout only in training mode; `seed` bumped by the caller)"""
-    for site, (lin, relu, p) in enumerate(plan):
-        x = linear(x, lin.weight, lin.bias, relu, p if training else 0.0, seed, site)
-    return x
+    """run a mlp_plan (Linear [-> ReLU] [-> Dropout] groups) as one autograd node (dropout only in training mode; `seed` bumped
+    by the caller)"""
+    if not x.is_cuda:
+        raise RuntimeError("mlp_forward runs on the GPU only (no CPU path)")
+    spec = tuple((bool(relu), float(p) if training else 0.0, lin.bias is not None) for lin, relu, p in plan)
+    params = []
+    for lin, _, _ in plan:
+        params += [lin.weight, lin.bias]
+    return _MlpFn.apply(x, spec, seed, *params)
 
 
 class HipOptimizer:

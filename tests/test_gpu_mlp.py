@@ -20,7 +20,11 @@ def eng(cuda):
 SHAPES = [(1, 1, 1), (3, 5, 7), (64, 64, 16), (65, 63, 17), (100, 1, 96), (257, 130, 66), (1024, 512, 512), (777, 64, 512),
           (500, 33, 128), (2048, 32, 64),
           # 128 x 128 tiles (mlp_gemm_big_kernel: from 2048 workgroups) in the forward / the dX product, ragged edges, odd K
-          (66000, 512, 96), (66000, 64, 512), (140000, 130, 127)]
+          (66000, 512, 96), (66000, 64, 512), (140000, 130, 127),
+          # the weight-gradient product on 128 x 128 tiles as well (batch >= 16,384 rows, a multiple of 32; N, K multiples of 4)
+          (16480, 132, 128), (32768, 256, 192),
+          # one to four outputs over a large batch: the weight gradient as a weighted column sum (mlp_dw_narrow_kernel)
+          (20000, 1, 64), (9000, 3, 128), (70000, 4, 512), (5000, 2, 20)]
 
 
 @pytest.mark.parametrize("M,N,K", SHAPES)
@@ -88,6 +92,44 @@ def test_linear_is_deterministic_and_matches_torch_modules(cuda, eng):
     # chains the kernels do not cover stay on torch
     assert hnn.mlp_plan([lin1, torch.nn.BatchNorm1d(512), torch.nn.ReLU()]) is None
     assert hnn.mlp_plan([lin1, torch.nn.Dropout(0.2)]) is None
+
+
+@pytest.mark.parametrize("M,widths,p", [(300, (96, 512, 64, 1), 0.0), (1024, (512, 512, 64), 0.3), (66000, (64, 512, 130), 0.0),
+                                        (20000, (128, 256, 128, 8), 0.25)])
+def test_mlp_chain_with_fused_masks_equals_layer_by_layer(M, widths, p, cuda, eng):
+    """the whole-MLP autograd node (rc_linear_bwd_chain: the dX product of layer i + 1 applies layer i's ReLU / dropout mask in its
+    epilogue) against one autograd node per layer with the separate masking pass (rc_linear_bwd): same products, same mask
+    arithmetic -- every gradient bit-identical; small and 128 x 128-tile shapes, split-K shapes, with and without dropout"""
+    from rechorus_amd import nn as hnn
+    torch.manual_seed(M)
+    lins = [torch.nn.Linear(a, b).to(cuda) for a, b in zip(widths[:-1], widths[1:])]
+    mods = []
+    for k, lin in enumerate(lins):
+        mods.append(lin)
+        if k + 1 < len(lins):
+            mods.append(torch.nn.ReLU())
+            if p > 0:
+                mods.append(torch.nn.Dropout(p))
+    plan = hnn.mlp_plan(mods)
+    assert plan is not None and len(plan) == len(lins)
+    x = torch.randn(M, widths[0], device=cuda, requires_grad=True)
+    seed = torch.tensor([77], dtype=torch.int64, device=cuda) if p > 0 else None
+    params = [x] + [q for lin in lins for q in (lin.weight, lin.bias)]
+
+    def grads_of(y):
+        for q in params:
+            q.grad = None
+        (y * torch.linspace(-1, 1, y.shape[-1], device=cuda)).sum().backward()
+        return [q.grad.clone() for q in params]
+    y1 = hnn.mlp_forward(x, plan, training=p > 0, seed=seed)
+    g1 = grads_of(y1)
+    h = x
+    for site, (lin, relu, pp) in enumerate(plan):
+        h = hnn.linear(h, lin.weight, lin.bias, relu, pp, seed, site)
+    g2 = grads_of(h)
+    assert torch.equal(y1, h)
+    for a, b, name in zip(g1, g2, ["x"] + [f"{n}{k}" for k in range(len(lins)) for n in ("W", "b")]):
+        assert torch.equal(a, b), name
 
 
 def test_mlp_block_runs_on_the_engine_and_draws_fresh_masks(cuda):
