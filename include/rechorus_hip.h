@@ -101,6 +101,10 @@ int rc_bpr_loss_fwd_bwd(const float* pred, int B, int C, float inv_b, float* los
 int rc_fm_second_order_fwd(const float* V, int64_t n, int F, int d, float* out, rc_stream_t stream);
 int rc_fm_second_order_bwd(const float* V, const float* gout, int64_t n, int F, int d, float* dV,
                            rc_stream_t stream);
+/* dV = add + d fm2 / dV in one pass: the field vectors' gradient through the FM term on top of their gradient through the deep
+ * tower (models/context/DeepFM.py:19-28 feeds the same stacked vectors to both); add [n, F, d] may be dV itself. */
+int rc_fm_second_order_bwd_add(const float* V, const float* gout, int64_t n, int F, int d, const float* add, float* dV,
+                               rc_stream_t stream);
 
 /* All F categorical field lookups of a context model in one launch (FMBase._get_embeddings_FM,
  * models/context/FM.py:44-57): tables / ids / per_row / row_offset are HOST arrays of length F holding device

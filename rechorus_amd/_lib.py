@@ -80,6 +80,7 @@ SIGNATURES = {
     "rc_list_loss_fwd_bwd": (_i, [_p, _p, _i, _i, _i, _i, _f, _p, _p, _p, _p]),
     "rc_fm_second_order_fwd": (_i, [_p, _i64, _i, _i, _p, _p]),
     "rc_fm_second_order_bwd": (_i, [_p, _p, _i64, _i, _i, _p, _p]),
+    "rc_fm_second_order_bwd_add": (_i, [_p, _p, _i64, _i, _i, _p, _p, _p]),
     "rc_gather_fields": (_i, [_p, _p, _p, _p, _i, _i64, _i, _i, _p, _p, _p]),
     "rc_bce_ranking_fwd_bwd": (_i, [_p, _i64, _i, _f, _p, _p, _p]),
     "rc_bce_prob_fwd_bwd": (_i, [_p, _p, _i64, _f, _p, _p, _p]),

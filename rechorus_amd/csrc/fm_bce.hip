@@ -37,7 +37,7 @@ __global__ __launch_bounds__(kBlock) void fm2_fwd_kernel(const float* __restrict
 
 template <int D>
 __global__ __launch_bounds__(kBlock) void fm2_bwd_kernel(const float* __restrict__ V, const float* __restrict__ g,
-                                                         int64_t n, int F, float* __restrict__ dV) {
+                                                         int64_t n, int F, const float* add, float* dV) {
   constexpr int LPR = D / 4;
   constexpr int GPB = kBlock / LPR;
   const int l = threadIdx.x % LPR;
@@ -45,6 +45,21 @@ __global__ __launch_bounds__(kBlock) void fm2_bwd_kernel(const float* __restrict
   if (i >= n) return;  // no cross-lane ops here
   const float4* v = reinterpret_cast<const float4*>(V + i * F * D) + l;
   float4* dv = reinterpret_cast<float4*>(dV + i * F * D) + l;
+  if (add) {   // dV = add + d fm2 / dV (the gradient of the same field vectors through another consumer; add may be dV itself)
+    const float4* ad = reinterpret_cast<const float4*>(add + i * F * D) + l;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int f = 0; f < F; ++f) {
+      const float4 x = v[f * LPR];
+      s.x += x.x; s.y += x.y; s.z += x.z; s.w += x.w;
+    }
+    const float gi = g[i];
+    for (int f = 0; f < F; ++f) {
+      const float4 x = v[f * LPR];
+      const float4 a = ad[f * LPR];
+      dv[f * LPR] = make_float4(a.x + gi * (s.x - x.x), a.y + gi * (s.y - x.y), a.z + gi * (s.z - x.z), a.w + gi * (s.w - x.w));
+    }
+    return;
+  }
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int f = 0; f < F; ++f) {
     const float4 x = v[f * LPR];
@@ -80,17 +95,18 @@ __global__ __launch_bounds__(kBlock) void fm2_fwd_generic_kernel(const float* __
 }
 
 __global__ __launch_bounds__(kBlock) void fm2_bwd_generic_kernel(const float* __restrict__ V, const float* __restrict__ g,
-                                                                 int64_t n, int F, int d, float* __restrict__ dV) {
+                                                                 int64_t n, int F, int d, const float* add, float* dV) {
   const int lane = threadIdx.x & 63;
   const int64_t i = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   if (i >= n) return;
   const float* v = V + i * F * d;
+  const float* ad = add ? add + i * F * d : nullptr;
   float* dv = dV + i * F * d;
   const float gi = g[i];
   for (int k = lane; k < d; k += 64) {
     float s = 0.f;
     for (int f = 0; f < F; ++f) s += v[f * d + k];
-    for (int f = 0; f < F; ++f) dv[f * d + k] = gi * (s - v[f * d + k]);
+    for (int f = 0; f < F; ++f) dv[f * d + k] = (ad ? ad[f * d + k] : 0.f) + gi * (s - v[f * d + k]);
   }
 }
 
@@ -174,8 +190,24 @@ extern "C" int rc_fm_second_order_fwd(const float* V, int64_t n, int F, int d, f
   return RC_OK;
 }
 
+static int fm_second_order_bwd_impl(const float* V, const float* gout, int64_t n, int F, int d, const float* add, float* dV,
+                                    rc_stream_t stream);
+
 extern "C" int rc_fm_second_order_bwd(const float* V, const float* gout, int64_t n, int F, int d, float* dV,
                                       rc_stream_t stream) {
+  return fm_second_order_bwd_impl(V, gout, n, F, d, nullptr, dV, stream);
+}
+
+// dV = add + d fm2 / dV: the field vectors' gradient through the FM term on top of their gradient through another consumer
+// (the deep tower of DeepFM, models/context/DeepFM.py:19-28) in one pass -- autograd would form the two and add them
+extern "C" int rc_fm_second_order_bwd_add(const float* V, const float* gout, int64_t n, int F, int d, const float* add, float* dV,
+                                          rc_stream_t stream) {
+  RC_REQUIRE(add != nullptr && reinterpret_cast<uintptr_t>(add) % 16 == 0, "rc_fm_second_order_bwd_add: add is null / not 16-byte aligned");
+  return fm_second_order_bwd_impl(V, gout, n, F, d, add, dV, stream);
+}
+
+static int fm_second_order_bwd_impl(const float* V, const float* gout, int64_t n, int F, int d, const float* add, float* dV,
+                                    rc_stream_t stream) {
   if (n == 0) return RC_OK;
   RC_REQUIRE(V && gout && dV, "rc_fm_second_order_bwd: null pointer");
   RC_REQUIRE(n > 0 && F >= 1, "rc_fm_second_order_bwd: bad shape n=%lld F=%d", (long long)n, F);
@@ -184,10 +216,10 @@ extern "C" int rc_fm_second_order_bwd(const float* V, const float* gout, int64_t
   hipStream_t s = as_stream(stream);
   auto blocks = [&](int dd) { return (unsigned)((n + (kBlock / (dd / 4)) - 1) / (kBlock / (dd / 4))); };
   bool generic = false;
-  RC_FM_DISPATCH(fm2_bwd_kernel, V, gout, n, F, dV);
+  RC_FM_DISPATCH(fm2_bwd_kernel, V, gout, n, F, add, dV);
   if (generic) {
     RC_REQUIRE(d >= 1, "rc_fm_second_order_bwd: bad emb_size %d", d);
-    hipLaunchKernelGGL(fm2_bwd_generic_kernel, dim3((unsigned)((n + 3) / 4)), dim3(kBlock), 0, s, V, gout, n, F, d, dV);
+    hipLaunchKernelGGL(fm2_bwd_generic_kernel, dim3((unsigned)((n + 3) / 4)), dim3(kBlock), 0, s, V, gout, n, F, d, add, dV);
   }
   RC_LAUNCH_CHECK();
   return RC_OK;

@@ -65,6 +65,7 @@ struct SegArgs {
   float* partial;
   uint32_t long_cap, chunk_cap, partial_cap;
   int skip_single;
+  uint32_t* narrow_ws;   // narrow rows, dense gradient: room for the tiles' boundary sums (seg_narrow_tiles_kernel); null = one wave per segment
   int planned;   // rows route: the hot rows are already listed in rows[] / chunks[] (rc_rows_plan_build): no hand-over atomics
   OptScalars o;
   // capturable mode (hipGraph replay, rc_segmented_update_rows_dev): Adam's step count is read from device memory and the two
@@ -1078,6 +1079,157 @@ __global__ __launch_bounds__(kBlock) void seg_update_narrow_kernel(SegArgs a) {
   apply_row_generic<MODE>(a, key, lane, acc);
 }
 
+// ---- narrow rows, dense gradient, any skew: tiles of sorted positions instead of one wave per segment ---------------------------
+// seg_update_narrow_kernel gives a segment to ONE wave: the seven weekdays of a CTR batch of 131,072 rows are seven segments of
+// 18,700 occurrences, each walked by one wave 64 positions (three dependent loads) at a time -- 306 us for 1 M occurrences of a
+// [vocab, 1] table, all of it the tail of those waves.  Here a wave owns a TILE of 512 consecutive sorted positions whatever
+// the segments: eight rounds of 64 positions, all loads of the tile in flight at once, a segmented scan over the lanes (keys are
+// sorted: equal keys are neighbours) with the running sum carried from round to round.  A segment that lies inside the tile is
+// written to the gradient at once; the piece of a segment that crosses the tile's border goes to one of the tile's two slots --
+// `head`: the segment came in from the left (it may also leave to the right), `tail`: it starts here and leaves to the right --
+// and seg_narrow_chains_kernel adds a segment's pieces (its tail slot, then the head slots of the following tiles) in a fixed
+// order.  No atomics, every sum in a fixed order.
+constexpr int kNtRounds = 8;
+constexpr int kNtTile = 64 * kNtRounds;
+struct NarrowSlot { uint32_t key, flag; float v[4]; };   // flag: 0 empty, 1 the segment ends in this tile, 2 it goes on
+
+__device__ __forceinline__ void narrow_occ_val(const SegArgs& a, uint32_t o, float (&v)[4]) {
+  o -= a.occ_base;
+  float c = a.coef ? a.coef[o] : 1.0f;
+  int64_t sr = (a.div == 1) ? (int64_t)o : (int64_t)(o / (uint32_t)a.div);
+  if (a.src_index) sr = a.src_index[sr];
+  const float* src = a.src + (size_t)sr * a.d;
+  if (a.src2 && o >= a.n_split) {
+    src = a.src2 + (size_t)(o - a.n_split) * a.d;
+    c = 1.0f;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v[k] = k < a.d ? c * src[k] : 0.f;
+}
+
+__global__ __launch_bounds__(kBlock) void seg_narrow_tiles_kernel(SegArgs a, NarrowSlot* __restrict__ slots) {
+  const int lane = threadIdx.x & 63;
+  const int64_t w = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  const int64_t j0 = w * kNtTile, n = a.n_occ;
+  if (j0 >= n) return;   // wave-uniform
+  // the tile's keys, the keys one position to the right, and the gradient rows: everything in flight at once
+  uint32_t key[kNtRounds], knext[kNtRounds], occ[kNtRounds];
+  float val[kNtRounds][4];
+#pragma unroll
+  for (int r = 0; r < kNtRounds; ++r) {
+    const int64_t j = j0 + 64 * r + lane;
+    const int64_t jc = j < n ? j : n - 1;
+    key[r] = a.keys[jc];
+    knext[r] = a.keys[jc + 1 < n ? jc + 1 : jc];
+    occ[r] = a.perm[jc];
+  }
+  const uint32_t first_key = __shfl(key[0], 0, 64);
+  const bool first_cont = j0 > 0 && a.keys[j0 - 1] == first_key;
+#pragma unroll
+  for (int r = 0; r < kNtRounds; ++r) narrow_occ_val(a, occ[r], val[r]);
+  const int64_t je = (j0 + kNtTile < n ? j0 + kNtTile : n) - 1;   // the tile's last position
+  uint32_t carry_key = 0xFFFFFFFFu;
+  float carry[4] = {0.f, 0.f, 0.f, 0.f};
+  NarrowSlot head, tail;
+  head.flag = tail.flag = 0;
+  head.key = tail.key = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) head.v[k] = tail.v[k] = 0.f;
+#pragma unroll
+  for (int r = 0; r < kNtRounds; ++r) {
+    const int64_t j = j0 + 64 * r + lane;
+    const bool valid = j < n;
+    const uint32_t k_ = valid ? key[r] : 0xFFFFFFFFu;   // (no table has this row: positions past the end form their own segment)
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = valid ? val[r][k] : 0.f;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {             // segmented inclusive scan: equal keys are neighbours
+      const uint32_t pk = __shfl_up(k_, off, 64);
+      float pv[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) pv[k] = __shfl_up(v[k], off, 64);
+      if (lane >= off && pk == k_) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] += pv[k];
+      }
+    }
+    if (k_ == carry_key) {                               // the round's first segment goes on from the round before
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] += carry[k];
+    }
+    const bool last_of_tile = valid && j == je;
+    const bool goes_on = last_of_tile && je + 1 < n && knext[r] == k_;     // leaves the tile to the right
+    const bool ends = valid && !goes_on && (j + 1 >= n || knext[r] != k_);
+    const bool from_left = k_ == first_key && first_cont;
+    if (ends && !from_left) {                            // a whole segment (or the rest of one that began in this tile)
+      for (int k = 0; k < a.d; ++k) a.dense_grad[(size_t)(k_ - a.key_base) * a.d + k] = v[k];
+    }
+    // at most one lane of the tile ends a segment that came in from the left, at most one is the tile's last position going on
+    const uint64_t mh = __ballot((ends && from_left) || (goes_on && from_left));
+    const uint64_t mt = __ballot(goes_on && !from_left);
+    if (mh) {
+      const int src = __ffsll((long long)mh) - 1;
+      head.key = __shfl(k_, src, 64);
+      head.flag = __shfl(goes_on ? 2u : 1u, src, 64);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) head.v[k] = __shfl(v[k], src, 64);
+    }
+    if (mt) {
+      const int src = __ffsll((long long)mt) - 1;
+      tail.key = __shfl(k_, src, 64);
+      tail.flag = 2u;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) tail.v[k] = __shfl(v[k], src, 64);
+    }
+    carry_key = __shfl(k_, 63, 64);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) carry[k] = __shfl(v[k], 63, 64);
+  }
+  if (lane == 0) {
+    slots[2 * w] = head;
+    slots[2 * w + 1] = tail;
+  }
+}
+
+// one wave per tile whose tail slot is set: the segment's pieces are that slot and the head slots of the tiles that follow, up to
+// and including the first one where the segment ends
+__global__ __launch_bounds__(kBlock) void seg_narrow_chains_kernel(SegArgs a, const NarrowSlot* __restrict__ slots, int64_t n_tiles) {
+  const int lane = threadIdx.x & 63;
+  const int64_t w = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (w >= n_tiles) return;
+  const NarrowSlot t = slots[2 * w + 1];
+  if (t.flag == 0) return;   // wave-uniform
+  float sum[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int64_t base = w + 1; base < n_tiles; base += 64) {
+    const int64_t x = base + lane;
+    NarrowSlot h;
+    h.flag = 0;
+    h.key = 0;
+    if (x < n_tiles) h = slots[2 * x];
+    const bool mine = x < n_tiles && h.flag != 0 && h.key == t.key;
+    const uint64_t m = __ballot(mine);
+    const uint64_t done = __ballot(mine && h.flag == 1);
+    // the chain is the run of set lanes from lane 0 up to the first that ends the segment
+    int len = m == ~0ull ? 64 : __ffsll((long long)~m) - 1;
+    if (done) {
+      const int e = __ffsll((long long)done) - 1;
+      if (e < len) len = e + 1;
+    }
+    if (lane < len) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) sum[k] += h.v[k];
+    }
+    if (len < 64 || done) break;   // wave-uniform
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) sum[k] = wave_allreduce_sum(sum[k]);
+  if (lane < a.d) {
+    const float total = (lane == 0 ? sum[0] + t.v[0] : lane == 1 ? sum[1] + t.v[1] : lane == 2 ? sum[2] + t.v[2] : sum[3] + t.v[3]);
+    a.dense_grad[(size_t)(t.key - a.key_base) * a.d + lane] = total;
+  }
+}
+
 // ---- launchers ------------------------------------------------------------------------------
 static int launch_heads(const uint32_t* keys, const uint32_t* perm, int64_t n, int only_multi,
                         uint8_t* single, uint32_t* heads, uint32_t* n_heads, hipStream_t s) {
@@ -1137,7 +1289,14 @@ static int launch_seg_mode(const SegArgs& a, bool vec_ok, hipStream_t s) {
     return fail(RC_ERR_UNSUPPORTED, "rc_segmented_update: d=%d > %d", a.d, 64 * kGenChunks);
   const int64_t blocks = (a.n_occ + (kBlock / 64) - 1) / (kBlock / 64);
   if (blocks > kMaxGridX) return fail(RC_ERR_UNSUPPORTED, "seg_update: grid too large");
-  if (a.d <= 4)
+  if (a.d <= 4 && MODE == MODE_DENSE_GRAD && a.narrow_ws != nullptr && !a.skip_single && !a.pair && a.n_occ >= 4 * kNtTile) {
+    const int64_t n_tiles = (a.n_occ + kNtTile - 1) / kNtTile;
+    const int64_t wg = (n_tiles + (kBlock / 64) - 1) / (kBlock / 64);
+    NarrowSlot* slots = reinterpret_cast<NarrowSlot*>(a.narrow_ws);
+    hipLaunchKernelGGL(seg_narrow_tiles_kernel, dim3((unsigned)wg), dim3(kBlock), 0, s, a, slots);
+    RC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(seg_narrow_chains_kernel, dim3((unsigned)wg), dim3(kBlock), 0, s, a, slots, n_tiles);
+  } else if (a.d <= 4)
     hipLaunchKernelGGL((seg_update_narrow_kernel<MODE>), dim3((unsigned)blocks), dim3(kBlock), 0, s,
                        a);
   else
@@ -1256,6 +1415,8 @@ extern "C" int rc_segmented_update2(float* W, float* m, float* v, int d, const u
     vec_ok = vec_ok && al(W) && al(m) && al(v);
   }
   RC_HIP(hipMemsetAsync(w.counters, 0, CNT_N * sizeof(uint32_t), s));
+  // (off the vector route the head list's room -- n_occ words -- is free: 2 slots of 6 words per 512 positions fit)
+  if (!vec_ok && n_occ >= 4 * kNtTile) a.narrow_ws = w.heads;
   if (vec_ok) {
     if (heads) {
       a.heads = heads;

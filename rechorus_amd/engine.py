@@ -439,10 +439,10 @@ def unique_ids(ids, n_rows, tag="unique"):
     return uniq[:int(cnt.item())], inverse
 
 
-def embedding_dense_backward(grad_out, ids, n_rows, route=None):
+def embedding_dense_backward(grad_out, ids, n_rows, route=None, presorted=None):
     """aten::embedding_dense_backward: G [n_rows, d] = index_add of the per-occurrence gradient rows, in ascending
     position order per row (no float atomics) -- bucket plan + rc_plan_row_sums; radix sort + segmented sum where no
-    plan geometry exists."""
+    plan geometry exists.  presorted = sort_ids(ids, n_rows) of a caller that sorted the same ids already (route "sort")."""
     d = grad_out.shape[-1]
     flat = ids.reshape(-1)
     G = torch.zeros((n_rows, d), dtype=torch.float32, device=grad_out.device)
@@ -465,7 +465,7 @@ def embedding_dense_backward(grad_out, ids, n_rows, route=None):
     # a plan bucket counts its ids with LDS atomics, which such a row serialises (15.8 ms per DeepFM step at B = 131,072)
     if route != "sort" and d in (16, 32, 64, 128, 256) and flat.numel() >= _EDB_PLAN_MIN and plan_supported(flat.numel(), 0, n_rows, 0):
         return Plan(flat, n_rows, tag="edb").row_sums("a", G, src2=go)
-    keys, perm = sort_ids(flat, n_rows)
+    keys, perm = presorted if presorted is not None else sort_ids(flat, n_rows)
     segmented_update(keys, perm, go, dense_grad=G)
     return G
 
@@ -1542,12 +1542,17 @@ def fm_second_order(V):
     return out
 
 
-def fm_second_order_bwd(V, gout):
+def fm_second_order_bwd(V, gout, add=None):
+    """d fm_second_order / dV times gout, plus `add` (the same vectors' gradient through another consumer) when given"""
     F, d = V.shape[-2], V.shape[-1]
     n = V.numel() // (F * d)
     dV = torch.empty_like(V)
-    _lib.call("rc_fm_second_order_bwd", _ptr(V, torch.float32, "V"), _ptr(gout, torch.float32, "gout"), n, F, d,
-              _ptr(dV, torch.float32, "dV"), _stream())
+    if add is None:
+        _lib.call("rc_fm_second_order_bwd", _ptr(V, torch.float32, "V"), _ptr(gout, torch.float32, "gout"), n, F, d,
+                  _ptr(dV, torch.float32, "dV"), _stream())
+    else:
+        _lib.call("rc_fm_second_order_bwd_add", _ptr(V, torch.float32, "V"), _ptr(gout, torch.float32, "gout"), n, F, d,
+                  _ptr(add, torch.float32, "add"), _ptr(dV, torch.float32, "dV"), _stream())
     return dV
 
 

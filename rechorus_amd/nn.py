@@ -180,14 +180,61 @@ def fm_second_order(V):
     return _FmSecondOrderFn.apply(V)  # float4 lane-group kernels for emb_size 16/32/64/128, a generic kernel otherwise
 
 
+class _FmTapFn(torch.autograd.Function):
+    """the FM pairwise term AND the flattened field vectors for a second consumer (DeepFM's deep tower, models/context/DeepFM.py:
+    19-28) as one autograd node: its backward forms d fm2 / dV on top of the gradient the second consumer sends back in ONE pass
+    (rc_fm_second_order_bwd_add) -- as two nodes autograd writes both gradients out and adds them (three more passes over
+    [B, C, F, d])."""
+
+    @staticmethod
+    def forward(ctx, V):
+        Vc = V.detach().contiguous()
+        ctx.save_for_backward(Vc)
+        flat = Vc.view(*Vc.shape[:-2], Vc.shape[-2] * Vc.shape[-1])
+        return engine.fm_second_order(Vc), flat
+
+    @staticmethod
+    def backward(ctx, g_fm, g_flat):
+        (Vc,) = ctx.saved_tensors
+        if g_fm is None:
+            return None if g_flat is None else g_flat.reshape(Vc.shape)
+        add = None if g_flat is None else g_flat.contiguous().view(Vc.shape)
+        return engine.fm_second_order_bwd(Vc, g_fm.contiguous(), add=add)
+
+
+def fm_second_order_and_flat(V):
+    """(fm_second_order(V), V.flatten(start_dim=-2)) as one autograd node"""
+    if not V.is_cuda:
+        raise RuntimeError("fm_second_order_and_flat runs on the GPU only (no CPU path)")
+    return _FmTapFn.apply(V)
+
+
 class _FieldGatherFn(torch.autograd.Function):
     """stacked field vectors [B, C, F, d] of F embedding tables (models/context/FM.py:49-52); the backward
     builds all F dense gradients with one sort + one segmented sum over the composite (field, id) key."""
 
+    # Two table families gathered with the SAME id tensors (FM-family models: the [vocab, d] vectors and the [vocab, 1] first-order
+    # weights of every field, models/context/FM.py:44-57) share the composite keys and, in the backward pass, their sort: the
+    # last forward's (ids, key tensor) and the last backward's sorted keys are remembered.  The entries hold the tensors
+    # themselves (identity + version are compared, never addresses: a freed tensor's address can come back).
+    _last_cid = None      # (ids tuple, versions, n_cand, offsets, cid)
+    _last_sort = None     # (cid, n_rows, keys, perm)
+
     @staticmethod
     def forward(ctx, n_cand, n_fields, *args):
         ids, tables = args[:n_fields], args[n_fields:]
-        out, cid, offs = engine.gather_fields([t.detach() for t in tables], [x.contiguous() for x in ids], n_cand)
+        ids_c = [x.contiguous() for x in ids]
+        offs_now = [0]
+        for t in tables:
+            offs_now.append(offs_now[-1] + t.shape[0])
+        last = _FieldGatherFn._last_cid
+        hit = (last is not None and len(last[0]) == len(ids_c) and all(a is b for a, b in zip(last[0], ids_c))
+               and last[1] == tuple(x._version for x in ids_c) and last[2] == n_cand and last[3] == offs_now)
+        out, cid, offs = engine.gather_fields([t.detach() for t in tables], ids_c, n_cand, want_cid=not hit)
+        if hit:
+            cid = last[4]
+        else:
+            _FieldGatherFn._last_cid = (tuple(ids_c), tuple(x._version for x in ids_c), n_cand, offs_now, cid)
         ctx.cid, ctx.offs = cid, offs
         # a field whose vocabulary is small against the batch makes hot rows: the sort-driven reduction handles any skew
         n_ids = cid.numel() // max(1, n_fields)
@@ -198,7 +245,16 @@ class _FieldGatherFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gout):
         offs = ctx.offs
-        G = engine.embedding_dense_backward(gout.contiguous(), ctx.cid, offs[-1], route=ctx.route)  # virtual concatenated table
+        presorted = None
+        if ctx.route == "sort":
+            last = _FieldGatherFn._last_sort
+            if last is not None and last[0] is ctx.cid and last[1] == offs[-1]:
+                presorted = last[2:]
+            else:
+                presorted = engine.sort_ids(ctx.cid.reshape(-1), offs[-1])
+                _FieldGatherFn._last_sort = (ctx.cid, offs[-1]) + tuple(presorted)
+        G = engine.embedding_dense_backward(gout.contiguous(), ctx.cid, offs[-1], route=ctx.route,
+                                            presorted=presorted)  # virtual concatenated table
         grads = tuple(G[offs[f]:offs[f + 1]] for f in range(len(offs) - 1))
         return (None, None) + (None,) * len(grads) + grads
 

@@ -289,6 +289,26 @@ def test_embedding_dense_backward_vs_index_add(cuda, eng):
         assert_close(host(G), want, what=f"dense grad d={d}")
 
 
+@pytest.mark.parametrize("d,n_rows,n,hot", [(1, 300, 70000, 0.5), (1, 7, 131072, 0.0), (4, 100000, 40000, 0.2), (3, 50, 2048, 0.9),
+                                            (2, 1, 5000, 0.0), (1, 5000, 513 * 17, 0.0)])
+def test_narrow_embedding_dense_backward_in_tiles(d, n_rows, n, hot, cuda, eng):
+    """[vocab, 1..4] tables (the first-order weights of the FM family, models/context/FM.py:49-57) under a large batch: the sorted
+    positions are summed tile by tile (seg_narrow_tiles_kernel + seg_narrow_chains_kernel) -- rows whose occurrences span many
+    tiles, rows inside one tile, a single row for everything, a ragged last tile; against a float64 index_add, twice (same bits)"""
+    rng = np.random.default_rng(d * 1000 + n_rows)
+    ids = rng.integers(0, n_rows, size=n).astype(np.int64)
+    ids[rng.random(n) < hot] = n_rows // 2          # one very hot row
+    go = rng.normal(size=(n, d)).astype(np.float32)
+    G = eng.embedding_dense_backward(dev(go, cuda), dev(ids, cuda), n_rows, route="sort")
+    G2 = eng.embedding_dense_backward(dev(go, cuda), dev(ids, cuda), n_rows, route="sort")
+    assert torch.equal(G, G2)
+    want = np.zeros((n_rows, d), dtype=np.float64)
+    np.add.at(want, ids, go.astype(np.float64))
+    cnt = np.bincount(ids, minlength=n_rows).max()
+    assert_close(host(G), want, what=f"narrow dense grad d={d}", rtol=1e-5, abs_floor=2e-7 * np.sqrt(cnt) * 4)
+    assert np.all(host(G)[np.bincount(ids, minlength=n_rows) == 0] == 0)
+
+
 @pytest.mark.parametrize("opt,lr,l2", [("SGD", 0.05, 1e-3), ("Adam", 1e-3, 1e-4), ("Adagrad", 0.01, 1e-4)])
 @pytest.mark.parametrize("d,B,C,n_items", [(64, 300, 100, 20000), (64, 513, 2, 700), (32, 100, 9, 300),
                                            (128, 64, 40, 2000), (16, 50, 100, 4000)])
