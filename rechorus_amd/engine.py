@@ -435,6 +435,8 @@ def unique_ids(ids, n_rows, tag="unique"):
     flat = ids.reshape(-1)
     if flat.numel() == 0:
         return flat.clone(), flat.clone()
+    if not plan_supported(flat.numel(), 0, n_rows, 0):   # no plan geometry for this list: torch's sort-based unique (sorted ids)
+        return torch.unique(flat, return_inverse=True)
     uniq, inverse, cnt = Plan(flat, n_rows, tag=tag).distinct("a")
     return uniq[:int(cnt.item())], inverse
 

@@ -36,6 +36,32 @@ import torch
 import torch.distributed as dist
 
 
+class _SortPlan:
+    """The interface of engine.Plan the sharded steps use -- row_sums / update on list "a", .single -- on the radix sort +
+    segmented sum (rc_sort_ids, rc_segmented_update): for id lists the bucket plan has no geometry for and row widths without a
+    plan kernel.  Same results up to the summation order inside a row (both fixed)."""
+
+    def __init__(self, e, ids, n_rows, want_single=False):
+        self.e, self.n_a, self.n_b = e, ids.numel(), 0
+        self.keys, self.perm = e.sort_ids(ids.reshape(-1), n_rows)
+        self.single = None
+        if want_single:   # uint8 per position: 1 = the row occurs once in the list (updated by the caller, skipped here)
+            self.single, _, _ = e.segment_heads(self.keys, self.perm, want_single=True, want_heads=False)
+
+    def _src(self, coef, src, src_index, div, src2):
+        if src2 is not None:
+            return dict(src=src2)
+        return dict(src=src, coef=coef, src_index=src_index, div=div)
+
+    def row_sums(self, side, out, coef=None, src=None, src_index=None, div=1, src2=None):
+        self.e.segmented_update(self.keys, self.perm, dense_grad=out, **self._src(coef, src, src_index, div, src2))
+        return out
+
+    def update(self, side, W, hyper, m=None, v=None, coef=None, src=None, src_index=None, div=1, src2=None):
+        self.e.segmented_update(self.keys, self.perm, hyper=hyper, W=W, m=m, v=v, skip_singletons=self.single is not None,
+                                **self._src(coef, src, src_index, div, src2))
+
+
 class HipOps:
     """local kernels of the sharded step, all through librechorus_hip.so"""
 
@@ -53,19 +79,26 @@ class HipOps:
         _, loss_vec, g = self.e.bpr_loss(pred, inv_b=inv_b)
         return loss_vec, g
 
-    # Grouping occurrences by row is the bucket plan everywhere (engine.Plan: id-range or hashed buckets, no device-wide
-    # sort, no host round trip); tags keep the cached buffers of plans that are alive together apart.
+    # Grouping occurrences by row is the bucket plan wherever it has a geometry and a kernel for the row width (engine.Plan:
+    # id-range or hashed buckets, no device-wide sort, no host round trip); lists beyond that (more than ~8.4 M ids under a hashed
+    # geometry, widths other than 16 / 32 / 64 / 128 / 256) take the radix sort + segmented sum behind the same interface
+    # (_SortPlan).  Tags keep the cached buffers of plans that are alive together apart.
+    def _grouping(self, ids, n_rows, d, tag, list_single_a=True):
+        if d in (16, 32, 64, 128, 256) and self.e.plan_supported(ids.numel(), 0, n_rows, 0):
+            return self.e.Plan(ids, n_rows, tag=tag, list_single_a=list_single_a)
+        return _SortPlan(self.e, ids, n_rows, want_single=not list_single_a)
+
     def partial_user_grads(self, I_loc, rows, g, t_idx, n_tuples):
         out = torch.zeros((n_tuples, I_loc.shape[1]), dtype=torch.float32, device=I_loc.device)
         if t_idx.numel():
-            self.e.Plan(t_idx, n_tuples, tag="pug").row_sums("a", out, coef=g, src=I_loc, src_index=rows, div=1)
+            self._grouping(t_idx, n_tuples, I_loc.shape[1], "pug").row_sums("a", out, coef=g, src=I_loc, src_index=rows, div=1)
         return out
 
     def sum_rows_by_index(self, rows, index, n_out):
         """out[k] = sum of rows[p] over p with index[p] = k, in ascending p (atomic-free segmented sum)"""
         out = torch.zeros((n_out, rows.shape[1]), dtype=torch.float32, device=rows.device)
         if index.numel():
-            self.e.Plan(index, n_out, tag="srbi").row_sums("a", out, src2=rows.contiguous())
+            self._grouping(index, n_out, rows.shape[1], "srbi").row_sums("a", out, src2=rows.contiguous())
         return out
 
     def unique(self, ids, n_rows):
@@ -73,17 +106,18 @@ class HipOps:
         ahead, on their side stream)"""
         return self.e.unique_ids(ids, n_rows, tag="route.unique")
 
-    def prepare_rows(self, rows, n_rows, tag="rows"):
-        """bucket plan of a row-id list, reusable by several update_rows calls on tables that share the ids"""
+    def prepare_rows(self, rows, n_rows, tag="rows", d=64):
+        """grouping of a row-id list (bucket plan, or the sorted route where the plan has no geometry / no kernel for width d),
+        reusable by several update_rows calls on tables that share the ids"""
         if rows.numel() == 0:
             return None
-        return self.e.Plan(rows, n_rows, tag=tag)
+        return self._grouping(rows, n_rows, d, tag)
 
     def update_rows(self, W, state, rows, src, hyper, coef=None, src_index=None, prep=None):
         """W[r] <- opt(W[r], sum_{o: rows[o]=r} coef[o] * src[src_index[o] or o])"""
         if rows.numel() == 0:
             return
-        plan = prep if prep is not None else self.prepare_rows(rows, W.shape[0])
+        plan = prep if prep is not None else self.prepare_rows(rows, W.shape[0], d=W.shape[1])
         if coef is None and src_index is None:
             plan.update("a", W, hyper, m=state.get("m"), v=state.get("v"), src2=src)
         else:
@@ -93,7 +127,7 @@ class HipOps:
         """two tables that share `rows` (NeuMF's mf / mlp embeddings) in one pass; False if the width has no pair kernel"""
         if rows.numel() == 0:
             return True
-        if not self.e.segmented_pair_supported(Wa.shape[1]):
+        if not self.e.segmented_pair_supported(Wa.shape[1]) or isinstance(prep, _SortPlan):
             return False
         prep.update_pair("a", Wa, Wb, src_a, src_b, hyper, ma=sa.get("m"), va=sa.get("v"), mb=sb.get("m"), vb=sb.get("v"))
         return True
@@ -110,7 +144,7 @@ class HipOps:
     def prepare_owner(self, rows, n_rows):
         """bucket plan of the received rows: singleton flags + the multi-occurrence rows listed (independent of the
         scores: issued while they travel)"""
-        return self.e.Plan(rows, n_rows, tag="owner", list_single_a=False)
+        return self._grouping(rows, n_rows, 64, "owner", list_single_a=False)   # (rc_owner_backward itself: widths with a kernel)
 
     def owner_backward(self, I_loc, state, rows, g, t_idx, t32, Uall, n_tuples, hyper, prep):
         """partial user grads + the item-row update in two passes over the received occurrences"""

@@ -130,12 +130,15 @@ def test_owner_backward_equals_the_unfused_owner_ops(opt, d, cuda):
         assert_close(st_b[k], st_a[k], what="state " + k, atol_scale=1e-5)
 
 
-def _loopback_worker(port, out_q, mode="owner", C=30):
+def _loopback_worker(port, out_q, mode="owner", C=30, sorted_route=False):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=0, world_size=1)
     try:
         from oracle import bprmf_oracle as O
         from rechorus_amd.sharded import ShardedBprmf
+        if sorted_route:   # as if the bucket plan had no geometry for these lists: HipOps falls back to sort + segmented sum
+            from rechorus_amd import engine
+            engine.plan_supported = lambda *a: False
         dev = torch.device("cuda:0")
         rng = np.random.default_rng(8)
         n_users, n_items, d, B = 301, 2003, 64, 256
@@ -163,14 +166,16 @@ def _loopback_worker(port, out_q, mode="owner", C=30):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode,C,n_phases", [("owner", 30, 8), ("rows", 30, 5), ("rows", 2, 5)])
-def test_world_of_one_through_the_exchange_path(mode, C, n_phases, cuda):
+@pytest.mark.parametrize("mode,C,n_phases,sorted_route", [("owner", 30, 8, False), ("rows", 30, 5, False), ("rows", 2, 5, False),
+                                                          ("owner", 30, 8, True), ("rows", 30, 5, True)])
+def test_world_of_one_through_the_exchange_path(mode, C, n_phases, sorted_route, cuda):
     """force_exchange: the full routed step on one rank vs the oracle, both plans -- "owner" (HIP counting sort,
-    unpack, owner backward) and "rows" (routes, row fetch, fused kernel on compact row blocks, gradient push)"""
+    unpack, owner backward) and "rows" (routes, row fetch, fused kernel on compact row blocks, gradient push); sorted_route: the
+    same with the bucket plan reported unavailable (HipOps' sort + segmented-sum fallback, sharded._SortPlan)"""
     from conftest import assert_update_close
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    p = ctx.Process(target=_loopback_worker, args=(_free_port(), q, mode, C))
+    p = ctx.Process(target=_loopback_worker, args=(_free_port(), q, mode, C, sorted_route))
     p.start()
     U0, I0, out = q.get(timeout=300)
     p.join(timeout=60)
