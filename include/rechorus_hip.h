@@ -566,7 +566,9 @@ int rc_linear_bwd(const float* X, const float* W, const float* Y, const float* d
                   float drop_p, float* dX, float* dW, float* db, void* ws, size_t ws_bytes, rc_stream_t stream);
 /* rc_linear_bwd inside a chain of layers (utils/layers.py:201-243 builds Linear -> ReLU -> Dropout groups): with x_act != 0 the
  * input X is the drop(relu(.)) output of the layer below and dX comes out already multiplied by that layer's mask
- * (X > 0 ? 1 / (1 - x_drop_p) : 0) in the product's epilogue; the layer below is then called with Y = NULL (its dY is its dZ). */
+ * (X > 0 ? 1 / (1 - x_drop_p) : 0) in the product's epilogue; the layer below is then called with Y = NULL (its dY is its dZ).
+ * Either of dX / dW (+ db) may be NULL here: the two products of a layer are independent given dZ, and a caller may issue them in
+ * two calls on two streams (the dX chain is the critical path of a small batch; workspaces must then differ). */
 int rc_linear_bwd_chain(const float* X, const float* W, const float* Y, const float* dY, int64_t M, int N, int K, float drop_p,
                         int x_act, float x_drop_p, float* dX, float* dW, float* db, void* ws, size_t ws_bytes, rc_stream_t stream);
 

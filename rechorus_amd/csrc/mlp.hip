@@ -1142,11 +1142,11 @@ extern "C" int rc_linear_bwd_chain(const float* X, const float* W, const float* 
 
 static int linear_bwd_impl(const float* X, const float* W, const float* Y, const float* dY, int64_t M, int N, int K, float drop_p,
                            int x_act, float x_drop_p, float* dX, float* dW, float* db, void* ws, size_t ws_bytes, rc_stream_t stream) {
-  RC_REQUIRE(X && W && dY && dW, "rc_linear_bwd: null pointer");
+  RC_REQUIRE(X && W && dY && (dW || dX), "rc_linear_bwd: null pointer");
   RC_REQUIRE(M >= 0 && N >= 1 && K >= 1, "rc_linear_bwd: bad shape M=%lld N=%d K=%d", (long long)M, N, K);
   hipStream_t s = as_stream(stream);
   if (M == 0) {
-    RC_HIP(hipMemsetAsync(dW, 0, (size_t)N * K * sizeof(float), s));
+    if (dW) RC_HIP(hipMemsetAsync(dW, 0, (size_t)N * K * sizeof(float), s));
     if (db) RC_HIP(hipMemsetAsync(db, 0, (size_t)N * sizeof(float), s));
     return RC_OK;
   }
@@ -1177,6 +1177,7 @@ static int linear_bwd_impl(const float* X, const float* W, const float* Y, const
     float* dx_part = mlp_k_splits(M, K, N) > 1 ? reinterpret_cast<float*>(reinterpret_cast<char*>(part) + align_up((size_t)mlp_dw_parts(M, N, K) * (size_t)N * (size_t)(K + 1) * sizeof(float), 256)) : nullptr;
     RC_TRY(mlp_product(g, dx_part, s));
   }
+  if (dW == nullptr) return RC_OK;   // (rc_linear_bwd_chain: the caller forms the weight gradient in another call, e.g. on another stream)
   if (mlp_dw_narrow_ok(M, N, K) && reinterpret_cast<uintptr_t>(X) % 16 == 0) {   // one to four outputs: a weighted column sum
     const int gpb = kBlock / (K / 4);
     int64_t wgs = (M + gpb - 1) / gpb;

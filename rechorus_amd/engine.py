@@ -996,22 +996,23 @@ def linear_fwd(X, W, b=None, relu=False, drop_p=0.0, seed=None, site=0):
     return Y
 
 
-def linear_bwd(X, W, Y, dY, drop_p=0.0, need_dx=True, need_db=True, x_act=False, x_drop_p=0.0):
+def linear_bwd(X, W, Y, dY, drop_p=0.0, need_dx=True, need_db=True, x_act=False, x_drop_p=0.0, need_dw=True, ws_tag="linear_bwd"):
     """backward of linear_fwd -> (dX | None, dW, db | None).  Y: the layer's saved output when it went through
     relu (+ dropout) -- it is its own mask -- or None for a plain Linear (or when dY is already masked, see below).
     x_act: X is the drop(relu(.)) output of the layer below (dropout x_drop_p): dX comes out multiplied by that layer's mask
-    in the product's epilogue (rc_linear_bwd_chain), and the layer below is called with Y=None."""
+    in the product's epilogue (rc_linear_bwd_chain), and the layer below is called with Y=None.
+    need_dw=False: only dX (the weight gradient comes from a second call, e.g. on another stream with its own ws_tag)."""
     f32 = torch.float32
     M, K = X.shape
     N = W.shape[0]
     dev = X.device
     dX = torch.empty((M, K), dtype=f32, device=dev) if need_dx else None
-    dW = torch.empty((N, K), dtype=f32, device=dev)
-    db = torch.empty(N, dtype=f32, device=dev) if need_db else None
-    ws = workspace(_lib.load().rc_linear_bwd_workspace_bytes(M, N, K), dev, "linear_bwd")
+    dW = torch.empty((N, K), dtype=f32, device=dev) if need_dw else None
+    db = torch.empty(N, dtype=f32, device=dev) if (need_db and need_dw) else None
+    ws = workspace(_lib.load().rc_linear_bwd_workspace_bytes(M, N, K), dev, ws_tag)
     _lib.call("rc_linear_bwd_chain", _ptr(X, f32, "X"), _ptr(W, f32, "W"), _ptr(Y, f32, "Y", True), _ptr(dY, f32, "dY"), M, N, K,
               C.c_float(float(drop_p)), 1 if (x_act and need_dx) else 0, C.c_float(float(x_drop_p)), _ptr(dX, f32, "dX", True),
-              _ptr(dW, f32, "dW"), _ptr(db, f32, "db", True), C.c_void_p(ws.data_ptr()), ws.numel(), _stream())
+              _ptr(dW, f32, "dW", True), _ptr(db, f32, "db", True), C.c_void_p(ws.data_ptr()), ws.numel(), _stream())
     return dX, dW, db
 
 

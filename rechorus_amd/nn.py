@@ -11,6 +11,8 @@ Gradients reaching a table are DENSE `[n_rows, d]` tensors like autograd's
 torch optimizer or `HipOptimizer` (rc_dense_update, exact torch.optim maths) can consume them.
 The large-table row-wise path bypasses autograd entirely (`engine.BprmfTrainer`).
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -513,6 +515,8 @@ class _MlpFn(torch.autograd.Function):
         n = len(spec)
         dz = dy.reshape(-1, dy.shape[-1]).contiguous()
         grads = [None] * (2 * n)
+        # (the weight-gradient products on a second stream beside the dX chain -- rc_linear_bwd_chain takes dX / dW separately --
+        #  measured SLOWER inside the replayed graph at B = 1,024: 0.389 against 0.377 ms, profiles/r05h_gemm_probe.txt)
         for i in range(n - 1, -1, -1):
             X, W = saved[2 * i], saved[2 * i + 1]
             relu, p, has_b = spec[i]
