@@ -933,6 +933,24 @@ def measure(args, rank, world, device, dist):
                      for s in range(args.cpu_steps + 1)]
             out["cpu_baseline"] = cpu_baseline_deepfm(args, cpu_b)
 
+    # MFMA-bound legs: what the matrix pipes of THIS box sustain (rc_bench_mfma: back-to-back fp32 MFMAs on every SIMD, no operand
+    # traffic), measured in this run, beside the datasheet peak the fraction is quoted on
+    rl = out.get("roofline")
+    if rank == 0 and world == 1 and isinstance(rl, dict) and (rl.get("bound") == "mfma" or "frac_of_mfma_peak" in rl):
+        try:
+            import ctypes as C
+            from rechorus_amd import _lib as _rl
+            sink = torch.zeros(1, dtype=torch.float32, device=device)
+            tf = C.c_float(0.0)
+            _rl.call("rc_bench_mfma", 20000, C.c_void_p(sink.data_ptr()), C.byref(tf), C.c_void_p(torch.cuda.current_stream(device).cuda_stream))
+            rl["box_mfma_tflops"] = round(float(tf.value), 1)
+            ach_tf = rl["achieved"] if rl.get("unit") == "TFLOP/s" else rl["frac_of_mfma_peak"] * F32_MFMA_PEAK_TFLOPS
+            rl["frac_of_box_mfma"] = ach_tf / float(tf.value)
+            rl["box_mfma_note"] = ("rc_bench_mfma on this box, in this run: v_mfma_f32_32x32x2_f32 back to back on every SIMD (two waves, four "
+                                   "accumulators each, no operand traffic)")
+        except Exception as e:   # the ceiling is context, not the measurement
+            rl["box_mfma_note"] = "rc_bench_mfma failed: " + repr(e)[-200:]
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "bprmf":
         out["cpu_baseline"] = cpu_baseline(args)
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload in ("neumf", "sasrec"):

@@ -809,6 +809,10 @@ int rc_bprmf_step_ahead_reset(rc_step_ticket* ticket, rc_stream_t stream);
  * reaches.  sink_dev: 4 device bytes (a store that never happens keeps the loads alive).                                     */
 int rc_bench_mix(float* table, int d, const int64_t* ids, int64_t n_occ, float write_frac, int iters, float* sink_dev,
                  float* ms_out, rc_stream_t stream);
+/* The matrix pipes' sustained fp32 rate on this box (v_mfma_f32_32x32x2_f32 back to back on every SIMD, two waves each, no operand
+ * traffic; `iters` x 16 MFMAs per wave, one warm-up launch, one timed launch; SYNCHRONISES) -> *tflops_out (host memory); bench.py
+ * prints it as roofline.box_mfma_tflops beside the datasheet's 157.3 TFLOP/s for the MFMA-bound legs.  sink_dev: 4 device bytes. */
+int rc_bench_mfma(int iters, float* sink_dev, float* tflops_out, rc_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -152,6 +152,7 @@ SIGNATURES = {
     "rc_neumf_head_fwd_bwd": (_i, [_p, _p, _i64, _p, _p, _i64, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p, _p, _p, _p, _i64, _p, _p, _i64,
                                    _p, _p, _p, _p, _sz, _p]),
     "rc_bench_mix": (_i, [_p, _i, _p, _i64, _f, _i, _p, C.POINTER(C.c_float), _p]),
+    "rc_bench_mfma": (_i, [_i, _p, C.POINTER(C.c_float), _p]),
     "rc_linear_fwd": (_i, [_p, _p, _p, _i64, _i, _i, _i, _f, _p, C.c_uint32, _p, _p]),
     "rc_linear_fwd_workspace_bytes": (_sz, [_i64, _i, _i]),
     "rc_linear_fwd_ws": (_i, [_p, _p, _p, _i64, _i, _i, _i, _f, _p, C.c_uint32, _p, _p, _sz, _p]),

@@ -44,9 +44,62 @@ static void launch_mix(float* tab, const int64_t* ids, int64_t n_occ, uint32_t w
   hipLaunchKernelGGL((bench_mix_kernel<LPR, R>), dim3((unsigned)blocks), dim3(256), 0, s, tab, ids, n_occ, wthresh, sink);
 }
 
+// The matrix pipes' sustained fp32 rate on this box: every SIMD of the chip issues v_mfma_f32_32x32x2_f32 back to back from two
+// waves, four independent accumulators per wave (no operand traffic at all: the operands are two registers).  What bench.py prints as
+// roofline.box_mfma_tflops next to the datasheet's 157.3: clocks under a sustained matrix load are below the peak clock.
+typedef float bm_f32x16 __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(256) void bench_mfma_kernel(int iters, float a0, float b0, float* sink) {
+  bm_f32x16 acc[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+  float a = a0 + (float)(threadIdx.x & 7), b = b0;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b, a, acc[1], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, a, acc[2], 0, 0, 0);
+      acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(b, b, acc[3], 0, 0, 0);
+    }
+  }
+  float t = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t += acc[k][r];
+  if (t == 12345.678f) sink[0] = t;   // keeps the accumulators alive
+}
+
+int device_cus();   // bucket_plan.hip
+
 }  // namespace rc
 
 using namespace rc;
+
+extern "C" int rc_bench_mfma(int iters, float* sink_dev, float* tflops_out, rc_stream_t stream) {
+  RC_REQUIRE(sink_dev && tflops_out && iters >= 1, "rc_bench_mfma: bad arguments");
+  hipStream_t s = as_stream(stream);
+  const int wgs = device_cus() * 2;   // two waves per SIMD
+  hipEvent_t a, b;
+  RC_HIP(hipEventCreate(&a));
+  RC_HIP(hipEventCreate(&b));
+  hipLaunchKernelGGL(bench_mfma_kernel, dim3(wgs), dim3(256), 0, s, iters, 1.0f, 0.5f, sink_dev);   // warm-up (clocks)
+  RC_HIP(hipEventRecord(a, s));
+  hipLaunchKernelGGL(bench_mfma_kernel, dim3(wgs), dim3(256), 0, s, iters, 1.0f, 0.5f, sink_dev);
+  RC_HIP(hipEventRecord(b, s));
+  RC_HIP(hipEventSynchronize(b));
+  float ms = 0.f;
+  RC_HIP(hipEventElapsedTime(&ms, a, b));
+  hipEventDestroy(a);
+  hipEventDestroy(b);
+  RC_LAUNCH_CHECK();
+  const double flops = (double)wgs * 4.0 * (double)iters * 16.0 * 4096.0;   // waves x MFMAs x 32 * 32 * 2 * 2
+  *tflops_out = (float)(flops / ((double)ms * 1e-3) / 1e12);
+  return RC_OK;
+}
 
 extern "C" int rc_bench_mix(float* table, int d, const int64_t* ids, int64_t n_occ, float write_frac, int iters, float* sink_dev,
                             float* ms_out, rc_stream_t stream) {
