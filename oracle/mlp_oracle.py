@@ -46,3 +46,16 @@ def linear_bwd(X, W, cache, dY):
     if cache["keep"] is not None:
         dz = dz * cache["keep"]
     return (dz @ W.astype(np.float64)).astype(F32), (dz.T @ X.astype(np.float64)).astype(F32), dz.sum(0).astype(F32)
+
+
+def linear_bwd_chain(X, W, dZ, x_mask=None, x_scale=1.0):
+    """rc_linear_bwd_chain in float64: the layer receives dZ (its dY already masked by the layer above's dX product) and hands
+    down dX multiplied by the mask of the layer BELOW -- x_mask = (X > 0) of the saved activation X = drop(relu(.)), x_scale =
+    1 / (1 - p) of that layer's dropout -- i.e. the dZ of the layer below (utils/layers.py:201-243 chains Linear -> ReLU -> Dropout).
+    -> (dX masked [M, K], dW [N, K], db [N])"""
+    dz = dZ.astype(np.float64)
+    dX = dz @ W.astype(np.float64)
+    if x_mask is not None:
+        dX = np.where(x_mask, dX * x_scale, 0.0)
+    return dX.astype(F32), (dz.T @ X.astype(np.float64)).astype(F32), dz.sum(0).astype(F32)
+

@@ -37,6 +37,44 @@ def test_oracle_layer_matches_torch_autograd(M, N, K, relu, p):
     assert_close(db, lin.bias.grad.numpy(), what="db", rtol=1e-6, abs_floor=1e-5)
 
 
+@pytest.mark.parametrize("p", [0.0, 0.3])
+def test_chain_backward_with_the_mask_in_the_dx_product_equals_layer_by_layer(p):
+    """the algebra behind rc_linear_bwd_chain (one autograd node per MLP): masking dX of layer i + 1 with layer i's saved
+    output (X > 0, scale 1 / (1 - p)) and handing it down as that layer's dZ gives the gradients of the layer-by-layer backward,
+    where every layer masks its own dY -- the saved output of drop(relu(.)) is its own mask (dropped or clipped elements are 0)"""
+    rng = np.random.default_rng(7)
+    M, dims = 37, (20, 48, 16, 3)
+    Ws = [rng.normal(0, 0.4, (b, a)).astype(np.float32) for a, b in zip(dims[:-1], dims[1:])]
+    bs = [rng.normal(0, 0.2, b).astype(np.float32) for b in dims[1:]]
+    X0 = rng.normal(0, 1, (M, dims[0])).astype(np.float32)
+    n = len(Ws)
+    relu = [True] * (n - 1) + [False]
+    xs, caches, h = [X0], [], X0
+    for i in range(n):
+        keep = MO.dropout_keep(99, i, M, dims[i + 1], p) if (p > 0 and relu[i]) else None
+        h, c = MO.linear_fwd(h, Ws[i], bs[i], relu[i], keep)
+        xs.append(h)
+        caches.append(c)
+    dY = rng.normal(0, 1, (M, dims[-1])).astype(np.float32)
+    # layer by layer: every layer masks its own dY
+    want, d = [], dY
+    for i in range(n - 1, -1, -1):
+        d, dW, db = MO.linear_bwd(xs[i], Ws[i], caches[i], d)
+        want.append((dW, db))
+    want_dx0 = d
+    # chain: the top layer has no activation (dZ = dY); each dX product applies the mask of the layer below
+    got, dz = [], dY
+    for i in range(n - 1, -1, -1):
+        below_act = i > 0 and relu[i - 1]
+        dz, dW, db = MO.linear_bwd_chain(xs[i], Ws[i], dz, x_mask=(xs[i] > 0) if below_act else None,
+                                         x_scale=1.0 / (1.0 - p) if below_act else 1.0)
+        got.append((dW, db))
+    for (a, b), (c, e) in zip(got, want):
+        assert_close(a, c, what="dW", rtol=1e-6, abs_floor=1e-6)
+        assert_close(b, e, what="db", rtol=1e-6, abs_floor=1e-6)
+    assert_close(dz, want_dx0, what="dX of the first layer", rtol=1e-6, abs_floor=1e-6)
+
+
 def test_dropout_mask_is_counter_based():
     a = MO.dropout_keep(7, 2, 37, 20, 0.25)
     assert a.shape == (37, 20) and set(np.unique(a)) <= {np.float32(0), np.float32(1) / (np.float32(1) - np.float32(0.25))}
