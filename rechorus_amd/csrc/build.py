@@ -17,6 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 OBJ_DIR = os.path.join(HERE, "build")
 LIB_PATH = os.path.join(PKG, "librechorus_hip.so")
+INFO_PATH = os.path.join(PKG, "librechorus_hip.build.json")   # flags / compiler / sha256 of the library as built (bench.py's "build" object)
 ARCH = "gfx950"
 
 SOURCES = [
@@ -39,7 +40,9 @@ SOURCES = [
     "owner_step.hip",
     "bench_mix.hip",
 ]
-HEADERS = ["common.hpp", "bpr_math.hpp", "fused_body.hpp", "small_plan.hpp", "opt_math.hpp", "philox.hpp", "sas_mma.hpp", "plan.hpp", os.path.join("..", "..", "include", "rechorus_hip.h")]
+# every header of this directory is a dependency of every object (a hand-kept list went stale once: sas_attn_reg.hpp /
+# sas_last_row.hpp were missing, so editing them did not rebuild sasrec_batch.o)
+HEADERS = sorted(f for f in os.listdir(HERE) if f.endswith(".hpp")) + [os.path.join("..", "..", "include", "rechorus_hip.h")]
 
 
 def _hipcc():
@@ -54,6 +57,34 @@ def _newer(target, deps):
         return False
     t = os.path.getmtime(target)
     return all(os.path.getmtime(d) <= t for d in deps)
+
+
+def sha256_of(path):
+    import hashlib
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 20), b""):
+            h.update(blk)
+    return h.hexdigest()
+
+
+def _write_info(hipcc, flag_str):
+    """what the library was built from, next to it (git-ignored like the .so, travels to the GPU box with it)"""
+    import json
+    try:
+        ver = subprocess.run([hipcc, "--version"], capture_output=True, text=True).stdout.strip().splitlines()
+    except Exception as e:
+        ver = [repr(e)]
+    sha = sha256_of(LIB_PATH)
+    try:
+        old = json.load(open(INFO_PATH))
+        if old.get("so_sha256") == sha and old.get("flags") == flag_str:
+            return
+    except Exception:
+        pass
+    with open(INFO_PATH, "w") as f:
+        json.dump({"flags": flag_str, "hipcc_version": [l for l in ver if l][:3], "so_sha256": sha, "arch": ARCH,
+                   "sources": SOURCES}, f, indent=1)
 
 
 def build(force=False, no_dpp=False, resource_usage=False, verbose=True, defines=()):
@@ -99,6 +130,7 @@ def build(force=False, no_dpp=False, resource_usage=False, verbose=True, defines
             raise RuntimeError(f"link failed:\n{p.stderr[-8000:]}")
     with open(tag, "w") as f:
         f.write(flag_str)
+    _write_info(hipcc, flag_str)
     if verbose:
         print(f"built {LIB_PATH} ({os.path.getsize(LIB_PATH) >> 10} KiB)")
     return LIB_PATH

@@ -599,22 +599,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // every occurrence that does not own its row marks it, multi[id] = 1.  A row with one occurrence has no loser; a row with k >= 2
 // has k - 1 of them, whoever won: the FLAGS do not depend on the schedule.  owner needs no initial value (read only where this
 // batch wrote it); multi is all zero between steps (neumf_unmark_kernel clears what the batch set).
-__global__ __launch_bounds__(256) void neumf_mark_owner_kernel(const int64_t* __restrict__ ids, int64_t n, uint32_t* __restrict__ owner) {
-  const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (k < n) owner[ids[k]] = (uint32_t)k;
-}
-
-__global__ __launch_bounds__(256) void neumf_mark_multi_kernel(const int64_t* __restrict__ ids, int64_t n, const uint32_t* __restrict__ owner,
-                                                               uint8_t* __restrict__ multi) {
+// Ids outside [0, n_items) touch nothing here (nn.Embedding raises on them in the reference; the plan's status word reports them).
+__global__ __launch_bounds__(256) void neumf_mark_owner_kernel(const int64_t* __restrict__ ids, int64_t n, uint64_t n_items,
+                                                               uint32_t* __restrict__ owner) {
   const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (k >= n) return;
   const int64_t id = ids[k];
-  if (owner[id] != (uint32_t)k) multi[id] = 1;
+  if ((uint64_t)id < n_items) owner[id] = (uint32_t)k;
 }
 
-__global__ __launch_bounds__(256) void neumf_unmark_kernel(const int64_t* __restrict__ ids, int64_t n, uint8_t* __restrict__ multi) {
+__global__ __launch_bounds__(256) void neumf_mark_multi_kernel(const int64_t* __restrict__ ids, int64_t n, uint64_t n_items,
+                                                               const uint32_t* __restrict__ owner, uint8_t* __restrict__ multi) {
   const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (k < n) multi[ids[k]] = 0;
+  if (k >= n) return;
+  const int64_t id = ids[k];
+  if ((uint64_t)id < n_items && owner[id] != (uint32_t)k) multi[id] = 1;
+}
+
+__global__ __launch_bounds__(256) void neumf_unmark_kernel(const int64_t* __restrict__ ids, int64_t n, uint64_t n_items,
+                                                           uint8_t* __restrict__ multi) {
+  const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= n) return;
+  const int64_t id = ids[k];
+  if ((uint64_t)id < n_items) multi[id] = 0;
 }
 
 // (defined in neumf.hip) out[i] = sum_w p[w][i] for the three partial arrays, fixed order
@@ -691,8 +698,8 @@ extern "C" int rc_neumf_mark_rows(const int64_t* iid, int64_t n, int64_t n_items
   uint32_t* owner = reinterpret_cast<uint32_t*>(marks);
   uint8_t* multi = reinterpret_cast<uint8_t*>(marks) + align_up((size_t)n_items * sizeof(uint32_t), 256);
   const unsigned blocks = (unsigned)((n + 255) / 256);
-  hipLaunchKernelGGL(neumf_mark_owner_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), iid, n, owner);
-  hipLaunchKernelGGL(neumf_mark_multi_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), iid, n, owner, multi);
+  hipLaunchKernelGGL(neumf_mark_owner_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), iid, n, (uint64_t)n_items, owner);
+  hipLaunchKernelGGL(neumf_mark_multi_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), iid, n, (uint64_t)n_items, owner, multi);
   RC_LAUNCH_CHECK();
   return RC_OK;
 }
@@ -701,7 +708,7 @@ extern "C" int rc_neumf_unmark_rows(const int64_t* iid, int64_t n, int64_t n_ite
   if (n == 0) return RC_OK;
   RC_REQUIRE(iid && marks && n > 0 && n_items >= 1, "rc_neumf_unmark_rows: bad arguments");
   uint8_t* multi = reinterpret_cast<uint8_t*>(marks) + align_up((size_t)n_items * sizeof(uint32_t), 256);
-  hipLaunchKernelGGL(neumf_unmark_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), iid, n, multi);
+  hipLaunchKernelGGL(neumf_unmark_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), iid, n, (uint64_t)n_items, multi);
   RC_LAUNCH_CHECK();
   return RC_OK;
 }
@@ -735,8 +742,8 @@ static int neumf_train_step_impl(bool marked, float* mf_u, float* mf_i, float* m
   uint8_t* multi = reinterpret_cast<uint8_t*>(marks) + align_up((size_t)n_items * sizeof(uint32_t), 256);
   const unsigned mark_blocks = (unsigned)((n + 255) / 256);
   if (!marked) {
-    hipLaunchKernelGGL(neumf_mark_owner_kernel, dim3(mark_blocks), dim3(256), 0, s, iid, n, owner);
-    hipLaunchKernelGGL(neumf_mark_multi_kernel, dim3(mark_blocks), dim3(256), 0, s, iid, n, owner, multi);
+    hipLaunchKernelGGL(neumf_mark_owner_kernel, dim3(mark_blocks), dim3(256), 0, s, iid, n, (uint64_t)n_items, owner);
+    hipLaunchKernelGGL(neumf_mark_multi_kernel, dim3(mark_blocks), dim3(256), 0, s, iid, n, (uint64_t)n_items, owner, multi);
     RC_LAUNCH_CHECK();
   }
   a.mf_u = mf_u; a.mf_i = mf_i; a.mlp_u = mlp_u; a.mlp_i = mlp_i;
@@ -755,7 +762,7 @@ static int neumf_train_step_impl(bool marked, float* mf_u, float* mf_i, float* m
   else if (mode == MODE_ADAM) rc = dispatch_step<MODE_ADAM>(a, d, l1, grid, s);
   else rc = dispatch_step<MODE_ADAGRAD>(a, d, l1, grid, s);
   // the flags go back to zero whatever happened to the step (prepared marks: the caller clears them, rc_neumf_unmark_rows)
-  if (!marked) hipLaunchKernelGGL(neumf_unmark_kernel, dim3(mark_blocks), dim3(256), 0, s, iid, n, multi);
+  if (!marked) hipLaunchKernelGGL(neumf_unmark_kernel, dim3(mark_blocks), dim3(256), 0, s, iid, n, (uint64_t)n_items, multi);
   RC_TRY(rc);
   RC_LAUNCH_CHECK();
   return neumf_reduce_partials(a.pW1, a.pb1, a.pwout, dW1, db1, dw_out, cW, cb, co, grid, s);

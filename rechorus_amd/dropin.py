@@ -1,0 +1,219 @@
+"""Known-head recognition: an UNMODIFIED reference model file reaches the fused engine steps.
+
+`hnn.adopt_embeddings` moves the tables of any model file onto the engine; its head then still runs as torch ops and its
+backward as autograd.  For the three heads of the hot path -- the reference's own `models/general/BPRMF.py:34-63`,
+`models/general/NeuMF.py:56-76`, `models/sequential/SASRec.py:51-86` -- this module recognises the instance and puts the
+plugin's head in front of the model file's in the method resolution order: the fused `forward` (one kernel per head with a
+HIP backward), `hip_train_step` (the one-call fit() iteration BaseRunner.fit uses for row-wise updates:
+rc_bprmf_train_step_ahead / rc_neumf_train_step / engine.SasrecTrainer), `full_catalogue_vectors` (--test_all on the MFMA
+scorer) and `candidate_permutation_equivariant` (no host-side candidate shuffle).  SURVEY.md 8(b2): "fused engine modules
+selected when a model class matches a known head".
+
+A model is bound only when ALL of these hold, otherwise it keeps the adopted-tables route unchanged:
+  * structure: the state_dict keys and parameter shapes are exactly the head's (`u_embeddings / i_embeddings`;
+    `mf_* / mlp_* / mlp.k / prediction`; `i_embeddings / p_embeddings / transformer_block.*`), the hyper-parameter attributes
+    the head reads exist (`emb_size`, `layers`, `num_heads`, ...), and the loss is the inherited `GeneralModel.loss` (BPR);
+  * behaviour: on a probe batch, in eval mode, the model file's own forward and the fused forward agree to 1e-4 relative;
+  * source: the syntax tree of the model file's forward is one of the known ones (the reference at the surveyed commit) --
+    or, if the file was edited, dropout is 0, where the probe is a complete check of the function being replaced (a moved
+    dropout layer is the one change the eval-mode probe cannot see).
+"""
+import ast
+import hashlib
+import importlib
+import inspect
+import logging
+import os
+import sys
+import textwrap
+
+import torch
+import torch.nn as nn
+
+PLUGIN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "rechorus")
+
+# sha256 of ast.dump of the forward functions of the reference's model files (tests/golden/make_reference_model_copies.py prints them;
+# comments, blank lines and indentation style do not enter)
+KNOWN_FORWARD_HASHES = {
+    "BPRMF": {"346a573d92bfe65d1176f7f1ebcbc5c9313108ce9e082bb4b34c5077823c43d6"},
+    "NeuMF": {"74e9a03825ddedf9be6b9476f8ea1465e1c62a4a5ff6bd0dfb642ff76cc0fe4c"},
+    "SASRec": {"0be9d019aa2162328ce8b550d2b3ccd98c9c3ef15303891e386ac9ffc91219b0"},
+}
+
+SAS_BLOCK_KEYS = ("masked_attn_head.q_linear.weight", "masked_attn_head.q_linear.bias", "masked_attn_head.k_linear.weight",
+                  "masked_attn_head.k_linear.bias", "masked_attn_head.v_linear.weight", "masked_attn_head.v_linear.bias",
+                  "layer_norm1.weight", "layer_norm1.bias", "linear1.weight", "linear1.bias", "linear2.weight", "linear2.bias",
+                  "layer_norm2.weight", "layer_norm2.bias")
+
+
+def forward_hash(cls):
+    """sha256 over the syntax trees of every `forward` defined along the class's own chain up to (excluding) the plugin's base
+    classes and nn.Module -- for the reference files: <Head>Base.forward + <Head>.forward"""
+    parts = []
+    for k in cls.__mro__:
+        mod = getattr(k, "__module__", "") or ""
+        if k is object or mod.startswith("torch.") or mod.startswith("models.") or mod.startswith("rechorus_amd"):
+            continue
+        fn = k.__dict__.get("forward")
+        if fn is None:
+            continue
+        try:
+            tree = ast.parse(textwrap.dedent(inspect.getsource(fn)))
+        except (OSError, TypeError, SyntaxError, IndentationError):
+            return None
+        parts.append(k.__name__ + ":" + ast.dump(tree, annotate_fields=False, include_attributes=False))
+    if not parts:
+        return None
+    return hashlib.sha256("\n".join(parts).encode()).hexdigest()
+
+
+def _mirror(module):
+    if PLUGIN not in sys.path:
+        sys.path.insert(0, PLUGIN)
+    return importlib.import_module(module)
+
+
+def _shapes(model):
+    return {k: tuple(v.shape) for k, v in model.state_dict().items()}
+
+
+def _is_int(x):
+    return isinstance(x, int) and not isinstance(x, bool)
+
+
+def _kind(model):
+    """'BPRMF' | 'NeuMF' | 'SASRec' | None from state_dict keys, shapes and the attributes the plugin's head reads"""
+    sh = _shapes(model)
+    keys = set(sh)
+    d = getattr(model, "emb_size", None)
+    if not _is_int(d) or not hasattr(model, "dropout"):
+        return None
+    if keys == {"u_embeddings.weight", "i_embeddings.weight"}:
+        ok = sh["u_embeddings.weight"][1:] == (d,) and sh["i_embeddings.weight"][1:] == (d,)
+        return "BPRMF" if ok else None
+    tables = {"mf_u_embeddings.weight", "mf_i_embeddings.weight", "mlp_u_embeddings.weight", "mlp_i_embeddings.weight"}
+    if tables <= keys and "prediction.weight" in keys:
+        layers = getattr(model, "layers", None)
+        if not (isinstance(layers, (list, tuple)) and len(layers) >= 1 and all(_is_int(x) for x in layers)):
+            return None
+        want = set(tables) | {"prediction.weight"}
+        pre = 2 * d
+        for k, size in enumerate(layers):
+            want |= {"mlp.%d.weight" % k, "mlp.%d.bias" % k}
+            if sh.get("mlp.%d.weight" % k) != (size, pre) or sh.get("mlp.%d.bias" % k) != (size,):
+                return None
+            pre = size
+        ok = (keys == want and sh["prediction.weight"] == (1, pre + d) and all(sh[t][1:] == (d,) for t in tables)
+              and sh["mf_u_embeddings.weight"][0] == sh["mlp_u_embeddings.weight"][0]
+              and sh["mf_i_embeddings.weight"][0] == sh["mlp_i_embeddings.weight"][0]
+              and isinstance(getattr(model, "mlp", None), nn.ModuleList) and all(type(m) is nn.Linear for m in model.mlp)
+              and type(getattr(model, "prediction", None)) is nn.Linear and model.prediction.bias is None
+              and type(getattr(model, "dropout_layer", None)) is nn.Dropout
+              and float(model.dropout_layer.p) == float(model.dropout))
+        return "NeuMF" if ok else None
+    if {"i_embeddings.weight", "p_embeddings.weight"} <= keys:
+        nl, nh, max_his = (getattr(model, a, None) for a in ("num_layers", "num_heads", "max_his"))
+        if not (_is_int(nl) and _is_int(nh) and _is_int(max_his) and nl >= 1 and nh >= 1 and d % nh == 0):
+            return None
+        want = {"i_embeddings.weight", "p_embeddings.weight"} | {"transformer_block.%d.%s" % (l, k) for l in range(nl) for k in SAS_BLOCK_KEYS}
+        blocks = getattr(model, "transformer_block", None)
+        layers_mod = _mirror("utils.layers")
+        ok = (keys == want and sh["i_embeddings.weight"][1:] == (d,) and sh["p_embeddings.weight"] == (max_his + 1, d)
+              and all(sh["transformer_block.%d.%s" % (l, k)] == ((d, d) if k.endswith("linear.weight") or k in ("linear1.weight", "linear2.weight") else (d,))
+                      for l in range(nl) for k in SAS_BLOCK_KEYS)
+              and isinstance(blocks, nn.ModuleList) and all(type(b) is layers_mod.TransformerLayer for b in blocks)
+              and all(getattr(b.masked_attn_head, "h", nh) == nh and not getattr(b.masked_attn_head, "kq_same", False) for b in blocks))
+        return "SASRec" if ok else None
+    return None
+
+
+def _head_mixin(kind):
+    """the plugin's head of this kind as a mixin class: the methods of the mirror's model file that replace the model file's"""
+    if kind == "BPRMF":
+        return _mirror("models.general.BPRMF").BPRMFBase
+    if kind == "SASRec":
+        return _mirror("models.sequential.SASRec").SASRecBase
+    m = _mirror("models.general.NeuMF").NeuMF
+    names = ("_fused_ok", "_drop_p", "forward", "hip_rowwise_supported", "hip_train_step", "candidate_permutation_equivariant")
+    return type("NeuMFHead", (object,), {n: m.__dict__[n] for n in names})
+
+
+def _probe_feed(model, kind, device):
+    g = torch.Generator(device="cpu")
+    g.manual_seed(20240917)
+    B, C = 6, 4
+    sh = _shapes(model)
+    if kind == "SASRec":
+        n_items, L = sh["i_embeddings.weight"][0], max(1, min(model.max_his, 9))
+        lengths = torch.randint(1, L + 1, (B,), generator=g)
+        hist = torch.randint(1, max(n_items, 2), (B, L), generator=g) * (torch.arange(L)[None, :] < lengths[:, None])
+        feed = {"history_items": hist.to(device), "lengths": lengths.to(device)}
+        n_users = 2
+    else:
+        n_users = sh["u_embeddings.weight" if kind == "BPRMF" else "mf_u_embeddings.weight"][0]
+        n_items = sh["i_embeddings.weight" if kind == "BPRMF" else "mf_i_embeddings.weight"][0]
+        feed = {}
+    feed.update(user_id=torch.randint(0, max(n_users, 1), (B,), generator=g).to(device),
+                item_id=torch.randint(0, max(n_items, 1), (B, C), generator=g).to(device), batch_size=B, phase="test")
+    return feed
+
+
+def bind_known_head(model, log=logging.getLogger(__name__)):
+    """Recognise a BPRMF / NeuMF / SASRec head (see the module docstring) and bind the plugin's fused head to the instance.
+    Returns the kind that was bound, or None (the model is left exactly as it was).  The model must be on the GPU with its
+    tables adopted (hnn.adopt_embeddings)."""
+    if hasattr(model, "hip_train_step"):
+        return None     # the plugin's own class (or a model file that brings its own fused step)
+    try:
+        base = _mirror("models.BaseModel")
+        if not isinstance(model, base.GeneralModel) or type(model).loss is not base.GeneralModel.loss:
+            return None     # list-wise / CTR losses: no fused step of these heads implements them
+        kind = _kind(model)
+    except Exception as e:     # a model file this module does not understand keeps its route
+        log.debug("known-head recognition skipped: %r", e)
+        return None
+    if kind is None:
+        return None
+    p = next(model.parameters())
+    if not p.is_cuda:
+        return None
+    h = forward_hash(type(model))
+    known = h is not None and h in KNOWN_FORWARD_HASHES[kind]
+    if not known and float(model.dropout) > 0:
+        log.info("%s-shaped model with an edited forward and dropout > 0: keeping the model file's own head", kind)
+        return None
+    cls = type(model)
+    was_training = model.training
+    seed_added = False
+    try:
+        model.eval()
+        feed = _probe_feed(model, kind, p.device)
+        with torch.no_grad():
+            ref = model(dict(feed))["prediction"].float().clone()
+        if kind in ("NeuMF", "SASRec") and not hasattr(model, "drop_seed"):
+            from . import nn as hnn
+            # key of the heads' counter-based dropout masks; not a parameter and not in the state_dict (checkpoints keep the
+            # reference's keys)
+            model.register_buffer("drop_seed", hnn.fresh_drop_seed().to(p.device), persistent=False)
+            seed_added = True
+        model.__class__ = type(cls.__name__, (_head_mixin(kind), cls), {"__module__": cls.__module__, "_rc_bound_head": kind,
+                                                                         "_rc_model_file_class": cls})
+        with torch.no_grad():
+            got = model(dict(feed))["prediction"].float()
+        torch.cuda.synchronize(p.device)
+        scale = float(ref.abs().max())
+        err = float((got - ref).abs().max()) if got.shape == ref.shape else float("inf")
+        if not (err <= 1e-4 * scale + 1e-7):
+            raise RuntimeError("probe mismatch: max |fused - model file| = %.3e at scale %.3e" % (err, scale))
+    except Exception as e:
+        model.__class__ = cls
+        if seed_added:
+            del model._buffers["drop_seed"]
+            model._non_persistent_buffers_set.discard("drop_seed")
+        model.train(was_training)
+        log.warning("%s-shaped model, but the fused head does not reproduce its forward (%s): keeping the model file's own head", kind, e)
+        return None
+    model.train(was_training)
+    log.info("Recognised the %s head%s: fused forward / hip_train_step / --test_all scorer bound to %s", kind,
+             "" if known else " (edited forward, verified on a probe batch)", cls.__name__)
+    return kind

@@ -779,6 +779,17 @@ class NeumfTrainer:
         self.step_count = 0
         self.loss = None
         self._side = None
+        NeumfTrainer._n_trainers += 1
+        self._serial = NeumfTrainer._n_trainers     # plan workspaces are cached by tag: one set per trainer
+
+    _n_trainers = 0
+
+    def __del__(self):
+        try:
+            for key in [k for k in _ws_cache if isinstance(k[1], str) and k[1].startswith("neumf%d." % self._serial)]:
+                _ws_cache.pop(key, None)
+        except Exception:
+            pass
 
     def step(self, uid, iid, next_batch=None):
         """next_batch = (uid, iid) of the FOLLOWING call (the very tensors it will bring, unmodified until then): the fused step
@@ -879,39 +890,55 @@ class NeumfTrainer:
         ahead = getattr(self, "_ahead", None)
         self._ahead = None
         plan = plan_done = marks_done = None
-        par = self.step_count & 1
-        if ahead is not None and ahead[0] == self._batch_key(uid, iid):
-            _, plan, plan_done, marks_done, _ = ahead
+        # which of the two flag buffers / plan workspaces this step uses travels WITH the announcement (not with step_count:
+        # a non-fused step in between, or a second trainer, must not shift it); with nothing pending both buffers are clean
+        buf = 0
+        if ahead is not None and ahead["key"] == self._batch_key(uid, iid):
+            plan, plan_done, marks_done, buf = ahead["plan"], ahead["plan_done"], ahead["marks_done"], ahead["buf"]
         elif ahead is not None:
             # a batch was announced and another one came: its prepared flags have to go before that buffer is marked again
             with torch.cuda.stream(self._side):
-                neumf_mark_rows(ahead[4], n_i, self._marks[par], unmark=True)
+                neumf_mark_rows(ahead["iid"], n_i, self._marks[ahead["buf"]], unmark=True)
             main.wait_stream(self._side)
+        ahead = None    # (drops the reference to the announced id tensors kept for the side stream's reads)
+        tag = lambda k: "neumf%d.%d" % (self._serial, k)
         if plan is None and two_streams:
             self._side.wait_stream(main)
             with torch.cuda.stream(self._side):
-                plan = Plan(iid, n_i, uid, n_u, tag="neumf%d" % par, list_single_a=False)
+                plan = Plan(iid, n_i, uid, n_u, tag=tag(buf), list_single_a=False)
                 plan_done = self._side.record_event()
+            iid.record_stream(self._side)
+            uid.record_stream(self._side)
         h = make_hyper(self.opt, lr=self.lr, l2=self.l2, step=self.step_count)
         h0 = make_hyper(self.opt, lr=self.lr, l2=0.0, step=self.step_count)
         with _PhaseTimer(self, "fused_step"):
-            if marks_done is not None:      # flags prepared beside the previous step's updates (buffer of this step's parity)
+            if marks_done is not None:      # flags prepared beside the previous step's updates
                 main.wait_event(marks_done)
-                neumf_train_step(P, self.state, uid, iid, h, self._marks[par], out, marked=True)
+                neumf_train_step(P, self.state, uid, iid, h, self._marks[buf], out, marked=True)
             else:
-                neumf_train_step(P, self.state, uid, iid, h, self._marks[par], out)
+                neumf_train_step(P, self.state, uid, iid, h, self._marks[buf], out)
+        if marks_done is not None and not two_streams:
+            # prepared flags are ALWAYS cleared by the step that consumed them -- also a short step (a ragged last batch of an
+            # epoch announced by a large one) that runs on one stream: a flag left behind would make a later single occurrence
+            # of that row look like a multiple one, and its update would be dropped
+            neumf_mark_rows(iid, n_i, self._marks[buf], unmark=True)
         if two_streams and (next_batch is not None or marks_done is not None):
             self._side.wait_stream(main)    # behind the fused kernel: beside the updates below
             with torch.cuda.stream(self._side):
                 if marks_done is not None:
-                    neumf_mark_rows(iid, n_i, self._marks[par], unmark=True)
+                    neumf_mark_rows(iid, n_i, self._marks[buf], unmark=True)
+                    iid.record_stream(self._side)   # the runner drops the batch when step() returns; the allocator must not
+                                                    # hand its block out while the side stream still reads it
                 if next_batch is not None:
-                    # the following batch's flags and plan; their buffers alternate with this batch's (by step parity)
+                    # the following batch's flags and plan; their buffers alternate with this batch's
                     nu, ni = next_batch
-                    neumf_mark_rows(ni, n_i, self._marks[par ^ 1])
+                    neumf_mark_rows(ni, n_i, self._marks[buf ^ 1])
                     nmarks_done = self._side.record_event()
-                    nplan = Plan(ni, n_i, nu, n_u, tag="neumf%d" % (par ^ 1), list_single_a=False)
-                    self._ahead = (self._batch_key(nu, ni), nplan, self._side.record_event(), nmarks_done, ni)
+                    nplan = Plan(ni, n_i, nu, n_u, tag=tag(buf ^ 1), list_single_a=False)
+                    ni.record_stream(self._side)
+                    nu.record_stream(self._side)
+                    self._ahead = {"key": self._batch_key(nu, ni), "plan": nplan, "plan_done": self._side.record_event(),
+                                   "marks_done": nmarks_done, "iid": ni, "buf": buf ^ 1}
         if two_streams:
             # the batch mean of the per-tuple losses (one workgroup, 10 us of latency) on the user side's stream, where it fills
             # the wait for the plan instead of standing in front of the item update
@@ -923,7 +950,7 @@ class NeumfTrainer:
                 self.loss = reduce_sum(out["loss_vec"], 1.0 / B)
         with _PhaseTimer(self, "sort"):
             if plan is None:
-                plan = Plan(iid, n_i, uid, n_u, tag="neumf%d" % par, list_single_a=False)
+                plan = Plan(iid, n_i, uid, n_u, tag=tag(buf), list_single_a=False)
             elif plan_done is not None:
                 main.wait_event(plan_done)
         with _PhaseTimer(self, "table_update"):

@@ -229,14 +229,20 @@ class _FieldGatherFn(torch.autograd.Function):
         offs_now = [0]
         for t in tables:
             offs_now.append(offs_now[-1] + t.shape[0])
+        # The caches live for ONE forward / backward of a model: a hit consumes the entry, a backward drops it, and nothing is
+        # remembered without autograd (an evaluation loop over a static id buffer rewritten through raw pointers -- which
+        # does not bump _version -- can therefore never meet a stale key tensor).
         last = _FieldGatherFn._last_cid
+        _FieldGatherFn._last_cid = None
         hit = (last is not None and len(last[0]) == len(ids_c) and all(a is b for a, b in zip(last[0], ids_c))
                and last[1] == tuple(x._version for x in ids_c) and last[2] == n_cand and last[3] == offs_now)
         out, cid, offs = engine.gather_fields([t.detach() for t in tables], ids_c, n_cand, want_cid=not hit)
         if hit:
             cid = last[4]
         else:
-            _FieldGatherFn._last_cid = (tuple(ids_c), tuple(x._version for x in ids_c), n_cand, offs_now, cid)
+            _FieldGatherFn._last_sort = None
+            if torch.is_grad_enabled():
+                _FieldGatherFn._last_cid = (tuple(ids_c), tuple(x._version for x in ids_c), n_cand, offs_now, cid)
         ctx.cid, ctx.offs = cid, offs
         # a field whose vocabulary is small against the batch makes hot rows: the sort-driven reduction handles any skew
         n_ids = cid.numel() // max(1, n_fields)
@@ -248,10 +254,12 @@ class _FieldGatherFn(torch.autograd.Function):
     def backward(ctx, gout):
         offs = ctx.offs
         presorted = None
+        _FieldGatherFn._last_cid = None     # the forward this belongs to is over
         if ctx.route == "sort":
             last = _FieldGatherFn._last_sort
             if last is not None and last[0] is ctx.cid and last[1] == offs[-1]:
                 presorted = last[2:]
+                _FieldGatherFn._last_sort = None    # second (last) user of this sort
             else:
                 presorted = engine.sort_ids(ctx.cid.reshape(-1), offs[-1])
                 _FieldGatherFn._last_sort = (ctx.cid, offs[-1]) + tuple(presorted)

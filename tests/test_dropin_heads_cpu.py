@@ -1,0 +1,86 @@
+"""CPU: the known-head recognition of rechorus_amd/dropin.py on the reference's own model files (verbatim copies under
+tests/golden/reference_models/, tests/golden/make_reference_model_copies.py): the fixtures are what the manifest says (and, in
+the build container, byte-identical to /root/reference), their forward syntax trees are the listed ones, the structural
+recogniser names the three heads and rejects near misses.  Binding itself needs the GPU (tests/test_gpu_reference_heads.py)."""
+import argparse
+import hashlib
+import json
+import os
+import sys
+
+import pytest
+import torch
+
+from conftest import ROOT
+
+FIX = os.path.join(ROOT, "tests", "golden", "reference_models")
+PLUGIN = os.path.join(ROOT, "rechorus_amd", "rechorus")
+CASES = [("general", "BPRMF", ["--emb_size", "32"]), ("general", "NeuMF", ["--emb_size", "32", "--layers", "[64]", "--dropout", "0.2"]),
+         ("sequential", "SASRec", ["--emb_size", "32", "--num_layers", "2", "--num_heads", "2", "--history_max", "7"])]
+
+
+def _build(sub, name, argv, monkeypatch, model_dir=None):
+    monkeypatch.setattr(sys, "dont_write_bytecode", True)
+    monkeypatch.setenv("RECHORUS_MODEL_DIRS", model_dir or os.path.join(FIX, sub))
+    if PLUGIN not in sys.path:
+        monkeypatch.syspath_prepend(PLUGIN)
+    import main
+    cls = main.find_class("model", (name, ""))
+    args = cls.parse_model_args(argparse.ArgumentParser()).parse_args(argv)
+    args.device, args.model_path, args.buffer = torch.device("cpu"), "", 1
+    torch.manual_seed(0)
+    return cls, cls(args, argparse.Namespace(n_users=20, n_items=50))
+
+
+def test_fixtures_are_the_reference_files():
+    man = json.load(open(os.path.join(FIX, "MANIFEST.json")))
+    assert sorted(man) == ["general/BPRMF.py", "general/NeuMF.py", "sequential/SASRec.py"]
+    for rel, rec in man.items():
+        data = open(os.path.join(FIX, rel), "rb").read()
+        assert hashlib.sha256(data).hexdigest() == rec["sha256"], rel
+        ref = os.path.join("/root/reference/src/models", rel)
+        if os.path.exists(ref):      # build container: byte-identical to the reference
+            assert open(ref, "rb").read() == data, rel
+        assert b"rechorus_amd" not in data and b"HipEmbedding" not in data
+
+
+@pytest.mark.parametrize("sub,name,argv", CASES)
+def test_reference_model_files_are_recognised(sub, name, argv, monkeypatch):
+    from rechorus_amd import dropin
+    cls, model = _build(sub, name, argv, monkeypatch)
+    assert os.path.realpath(cls.__init__.__globals__["__file__"]).startswith(os.path.realpath(FIX))
+    h = dropin.forward_hash(cls)
+    assert h in dropin.KNOWN_FORWARD_HASHES[name]
+    assert h == json.load(open(os.path.join(FIX, "MANIFEST.json")))[sub + "/" + name + ".py"]["forward_hash"]
+    assert dropin._kind(model) == name
+    assert not hasattr(model, "hip_train_step")
+    assert dropin.bind_known_head(model) is None and not hasattr(model, "hip_train_step")   # CPU model: nothing is bound
+    # the plugin's own class of the same name brings its fused step and is left alone
+    monkeypatch.delenv("RECHORUS_MODEL_DIRS")
+    import main
+    mirror = main.find_class("model", (name, ""))
+    assert hasattr(mirror, "hip_train_step") and mirror.__module__.startswith("models.")
+
+
+def test_near_misses_are_not_recognised(monkeypatch, tmp_path):
+    from rechorus_amd import dropin
+    _, bpr = _build("general", "BPRMF", ["--emb_size", "32"], monkeypatch)
+    bpr.extra = torch.nn.Linear(4, 4)                     # one more parameter than the head has
+    assert dropin._kind(bpr) is None
+    _, neu = _build("general", "NeuMF", ["--emb_size", "32", "--layers", "[64,16]"], monkeypatch)
+    assert dropin._kind(neu) == "NeuMF"                   # (towers of any depth are the NeuMF head; the mirror picks the kernels)
+    neu.dropout_layer = torch.nn.Identity()
+    assert dropin._kind(neu) is None
+    _, sas = _build("sequential", "SASRec", ["--emb_size", "32", "--num_heads", "2", "--history_max", "7"], monkeypatch)
+    sas.num_heads = 3                                     # 32 is not divisible by 3 heads
+    assert dropin._kind(sas) is None
+    # an edited forward is not one of the known syntax trees (comments and whitespace do not count as edits)
+    src = open(os.path.join(FIX, "general", "BPRMF.py")).read()
+    d1, d2 = tmp_path / "a", tmp_path / "b"
+    d1.mkdir(), d2.mkdir()
+    (d1 / "BPRMF.py").write_text(src.replace("cf_u_vectors = self.u_embeddings(u_ids)", "cf_u_vectors = self.u_embeddings(u_ids)  # a comment"))
+    (d2 / "BPRMF.py").write_text(src.replace("cf_u_vectors = self.u_embeddings(u_ids)", "cf_u_vectors = 2 * self.u_embeddings(u_ids)"))
+    cls1, _ = _build("general", "BPRMF", ["--emb_size", "32"], monkeypatch, str(d1))
+    cls2, _ = _build("general", "BPRMF", ["--emb_size", "32"], monkeypatch, str(d2))
+    assert dropin.forward_hash(cls1) in dropin.KNOWN_FORWARD_HASHES["BPRMF"]
+    assert dropin.forward_hash(cls2) not in dropin.KNOWN_FORWARD_HASHES["BPRMF"]

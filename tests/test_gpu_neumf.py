@@ -483,3 +483,44 @@ def test_neumf_trainer_announced_batches_prepared_ahead_equal_unannounced(cuda, 
         assert losses == res[0][0]
         for k in P0:
             assert torch.equal(P[k], res[0][1][k]), k
+
+
+def test_neumf_trainer_short_step_consumes_prepared_flags_and_clears_them(cuda, eng, monkeypatch):
+    """A large step (two streams) announces the ragged LAST batch of an epoch, which is below the two-stream threshold: the short
+    step consumes the prepared flags and must clear them itself (on its one stream) -- a flag left behind would turn a later
+    single occurrence of that row into a 'multiple' one that no plan lists, and its update would be lost.  Checked: flags all zero
+    after the short step, and the following epoch's first batch (every hot row of the short batch exactly once) leaves tables
+    bit-identical to a run without any announcement."""
+    rng = np.random.default_rng(41)
+    d, l1, B, C, n_users, n_items = 64, 64, 2048, 5, 200, 20000
+    P0 = {"mf_u": rng.normal(0, 0.2, (n_users, d)), "mf_i": rng.normal(0, 0.2, (n_items, d)), "mlp_u": rng.normal(0, 0.2, (n_users, d)),
+          "mlp_i": rng.normal(0, 0.2, (n_items, d)), "W1": rng.normal(0, 0.2, (l1, 2 * d)), "b1": rng.normal(0, 0.2, l1),
+          "w_out": rng.normal(0, 0.2, d + l1)}
+    P0 = {k: v.astype(np.float32) for k, v in P0.items()}
+    t = lambda a: torch.from_numpy(a).to(cuda)
+    big = (rng.integers(0, n_users, size=B).astype(np.int64), rng.integers(0, n_items, size=(B, C)).astype(np.int64))
+    Bs = 100
+    short_i = rng.integers(1000, n_items, size=(Bs, C)).astype(np.int64)
+    short_i[:, 0] = short_i[:, 0] % 10 + 500            # rows 500..509 occur many times in the short batch
+    short = (rng.integers(0, n_users, size=Bs).astype(np.int64), short_i)
+    after_i = rng.integers(1000, n_items, size=(B, C)).astype(np.int64)
+    after_i[:10, 1] = np.arange(500, 510)                # ... and exactly once in the batch after it
+    after = (rng.integers(0, n_users, size=B).astype(np.int64), after_i)
+    assert all((after_i == r).sum() == 1 for r in range(500, 510))
+    batches = [tuple(map(t, b)) for b in (big, short, after)]
+    monkeypatch.setattr(eng, "_SAS_OVERLAP_MIN", B * C)   # big and `after` run on two streams, the short step on one
+    res = []
+    for announce in (True, False):
+        P = {k: t(v) for k, v in P0.items()}
+        tr = eng.NeumfTrainer(P, opt="SGD", lr=0.05, l2=0.0, rowwise=True)
+        for k, (u, i) in enumerate(batches):
+            tr.step(u, i, next_batch=batches[k + 1] if announce and k + 1 < len(batches) else None)
+            torch.cuda.synchronize()
+            if announce and k == 1:
+                assert getattr(tr, "_ahead", None) is None, "a one-stream step prepares nothing"
+                for m in tr._marks:
+                    assert not m[(4 * n_items + 255) // 256 * 256:].any(), "the short step left prepared flags behind"
+        res.append({k: v.clone() for k, v in P.items()})
+    for k in P0:
+        assert torch.equal(res[0][k], res[1][k]), k
+    assert not torch.equal(res[0]["mf_i"][500:510], t(P0["mf_i"])[500:510])
