@@ -81,9 +81,13 @@ def test_secondary_leg_rules_and_the_launcher_that_captures_rank_zero(monkeypatc
     for argv in (["--workload", "neumf"], ["--no-secondary"], ["--parallel", "replicas"], ["--graph"]):
         monkeypatch.setattr(sys, "argv", ["bench.py"] + argv)
         assert not bench.secondary_wanted(bench.parse()), argv
-    names = [n for n, _ in bench.SECONDARY_LEGS]
-    assert names == ["neumf", "neumf_100M", "sasrec", "deepfm_b1024", "deepfm_b131072"]
-    for _, extra in bench.SECONDARY_LEGS:   # every leg parses, and none of them recurses
+    names = [n for n, _, _ in bench.SECONDARY_LEGS]
+    assert names == ["neumf", "sasrec", "deepfm_b1024", "neumf_100M", "deepfm_b131072"]
+    # the legs whose CPU port finishes in seconds carry their own cpu_baseline; the 113 GB tables / the 131,072-row batch do not
+    assert [c is not None for _, _, c in bench.SECONDARY_LEGS] == [True, True, True, False, False]
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--workload", "deepfm"])
+    assert bench.parse().dropout == 0.2      # docs/demo_scripts_results/CTR_MIND.sh:8
+    for _, extra, _ in bench.SECONDARY_LEGS:   # every leg parses, and none of them recurses
         monkeypatch.setattr(sys, "argv", ["bench.py"] + extra + ["--no-secondary"])
         assert not bench.secondary_wanted(bench.parse())
     monkeypatch.setattr(sys, "argv", ["bench.py"] + bench.SHARDED_LEG)
@@ -92,7 +96,7 @@ def test_secondary_leg_rules_and_the_launcher_that_captures_rank_zero(monkeypatc
     j = {"metric": "m", "value": 2.0, "unit": "u", "ms_per_step": 0.5, "config": {"workload": "w", "n_items": 7}, "cpu_baseline": {"x": 1},
          "roofline": {"frac": 0.3}, "phases_ms": {"a": 1.0}}
     sm = bench._summary(j)
-    assert sm["workload"] == "w" and sm["roofline"] == {"frac": 0.3} and "cpu_baseline" not in sm and "config" not in sm
+    assert sm["workload"] == "w" and sm["roofline"] == {"frac": 0.3} and sm["cpu_baseline"] == {"x": 1} and "config" not in sm
     assert bench._last_json("noise\n{\"a\": 1}\ntrailing\n") == {"a": 1} and bench._last_json("nothing here") is None
     # the capturing launcher on the rendezvous-only ranks (gloo, no GPU)
     monkeypatch.setenv("RC_BENCH_LAUNCH_ONLY", "1")
