@@ -196,6 +196,8 @@ def bind_known_head(model, log=logging.getLogger(__name__)):
             # reference's keys)
             model.register_buffer("drop_seed", hnn.fresh_drop_seed().to(p.device), persistent=False)
             seed_added = True
+        if kind == "BPRMF" and not hasattr(model, "_trainer"):
+            model._trainer = None      # (the plugin's _base_init creates the slot its hip_train_step fills)
         model.__class__ = type(cls.__name__, (_head_mixin(kind), cls), {"__module__": cls.__module__, "_rc_bound_head": kind,
                                                                          "_rc_model_file_class": cls})
         with torch.no_grad():

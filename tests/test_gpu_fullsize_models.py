@@ -213,5 +213,8 @@ def test_deepfm_step_at_the_large_bench_batch_whole_batch_vs_oracle(cuda):
     assert_close(float(loss.item()), float(want_loss), rtol=1e-5, what="BCE loss")
     scale = max(float(np.abs(v).max()) for k, v in G.items() if k.startswith("deep_layers"))
     for name, prm in m.named_parameters():
-        assert_close(prm.grad.cpu().numpy().reshape(G[name].shape), G[name], what="grad " + name, rtol=2e-5, atol_scale=5e-5,
+        # dense layers at 5e-5; table rows at 1e-4 of the table's largest gradient: an element of a rarely seen row is ONE 512-long fp32
+        # dot product (dh = dz W) plus the FM term, which nearly cancel in places -- summation-order noise of a different K order
+        table = name.startswith("context_embedding") or name.startswith("linear_embedding")
+        assert_close(prm.grad.cpu().numpy().reshape(G[name].shape), G[name], what="grad " + name, rtol=2e-5, atol_scale=1e-4 if table else 5e-5,
                      abs_floor=1e-6 * scale if name.startswith("deep_layers") else 0.0)
