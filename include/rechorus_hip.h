@@ -505,7 +505,8 @@ int rc_neumf_bwd_dropout(const float* mf_u, const float* mf_i, const float* mlp_
  *   gu_mf, gu_mlp [B, d]      ONE gradient row per tuple for the user tables (plan the user ids per tuple)
  *   dW1, db1, dw_out          dense gradients, per-workgroup partials summed in fixed order; no float atomics anywhere
  * Shapes: rc_neumf_train_step_supported(C, d, l1): d in {32,64,128}, l1 in {32,64}, C >= 2 and the LDS image <= 160 KB
- * (C <= 136 at d = 128, l1 = 64); no dropout (use rc_neumf_fwd_dropout / rc_neumf_bwd_dropout).                          */
+ * (C <= 136 at d = 128, l1 = 64).  Training-mode dropout (the reference's own NeuMF command line runs --dropout 0.2,
+ * docs/demo_scripts_results/Topk_Amazon.sh:8; NeuMF.py:58,70): rc_neumf_train_step_dropout below.                          */
 int rc_neumf_train_step_supported(int C, int d, int l1);
 size_t rc_neumf_train_step_workspace_bytes(int B, int C, int d, int l1);
 size_t rc_neumf_train_step_marks_bytes(int64_t n_items);
@@ -529,6 +530,20 @@ int rc_neumf_train_step_marked(float* mf_u, float* mf_i, float* mlp_u, float* ml
                                void* marks, const rc_opt_hyper* h, float inv_b, float* loss_vec, float* pred,
                                float* g_mf_i, float* g_mlp_i, float* gu_mf, float* gu_mlp, float* dW1, float* db1,
                                float* dw_out, void* ws, size_t ws_bytes, rc_stream_t stream);
+
+/* rc_neumf_train_step with nn.Dropout(p) on the hidden layer (models/general/NeuMF.py:58, 70) inside the kernel: the mask of
+ * rc_neumf_fwd_dropout / rc_neumf_bwd_dropout -- feature f of candidate n = b C + c is dropped iff word (f & 3) of
+ * Philox4x32-10(key = *seed_dev, counter = (n, f >> 2)) < p 2^32, kept values scaled by 1 / (1 - p) -- generated in the forward
+ * pass of a candidate and regenerated, not stored, in its backward pass.  *seed_dev is read by the kernel (bump it with
+ * rc_step_increment for a fresh mask per step; capturable).  drop_p = 0: exactly rc_neumf_train_step.  marks_prepared != 0: the
+ * marks buffer was filled by rc_neumf_mark_rows for this very batch (as rc_neumf_train_step_marked).                          */
+int rc_neumf_train_step_dropout(float* mf_u, float* mf_i, float* mlp_u, float* mlp_i, float* m_mf_i, float* v_mf_i,
+                                float* m_mlp_i, float* v_mlp_i, const float* W1, const float* b1, const float* w_out,
+                                const int64_t* uid, const int64_t* iid, int B, int C, int d, int l1, int64_t n_items,
+                                void* marks, int marks_prepared, const rc_opt_hyper* h, float inv_b, float drop_p,
+                                const uint64_t* seed_dev, float* loss_vec, float* pred, float* g_mf_i, float* g_mlp_i,
+                                float* gu_mf, float* gu_mlp, float* dW1, float* db1, float* dw_out, void* ws,
+                                size_t ws_bytes, rc_stream_t stream);
 
 /* The same kernel without table updates, on row blocks with a stride: forward, BPR loss and backward of the NeuMF head for
  * callers that own neither the tables nor the optimizer -- the row-sharded step (rechorus_amd/sharded.py, ShardedNeumf), where

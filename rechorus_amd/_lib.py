@@ -148,6 +148,7 @@ SIGNATURES = {
     "rc_neumf_train_step": (_i, [_p] * 13 + [_i, _i, _i, _i, _i64, _p, _hp, _f] + [_p] * 9 + [_p, _sz, _p]),
     "rc_neumf_mark_rows": (_i, [_p, _i64, _i64, _p, _p]),
     "rc_neumf_unmark_rows": (_i, [_p, _i64, _i64, _p, _p]),
+    "rc_neumf_train_step_dropout": (_i, [_p] * 13 + [_i, _i, _i, _i, _i64, _p, _i, _hp, _f, _f, _p] + [_p] * 9 + [_p, _sz, _p]),
     "rc_neumf_train_step_marked": (_i, [_p] * 13 + [_i, _i, _i, _i, _i64, _p, _hp, _f] + [_p] * 9 + [_p, _sz, _p]),
     "rc_neumf_head_fwd_bwd": (_i, [_p, _p, _i64, _p, _p, _i64, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p, _p, _p, _p, _i64, _p, _p, _i64,
                                    _p, _p, _p, _p, _sz, _p]),

@@ -32,6 +32,7 @@
 #include "bpr_math.hpp"
 #include "common.hpp"
 #include "opt_math.hpp"
+#include "philox.hpp"
 
 namespace rc {
 
@@ -67,6 +68,12 @@ struct NeumfStepArgs {
   float* pb1;
   float* pwout;
   OptScalars opt;
+  // DROP instantiations: training-mode dropout on the hidden layer (NeuMF.py:58/70, nn.Dropout after the ReLU) with the mask of
+  // rc_neumf_fwd_dropout: feature f of candidate n = b C + c is dropped iff word (f & 3) of Philox4x32-10(key = *seed_dev,
+  // counter = (n, f >> 2)) < drop_thresh; kept values are scaled by keep_scale.  Pass 2 regenerates pass 1's mask.
+  const uint64_t* seed_dev;
+  uint32_t drop_thresh;
+  float keep_scale;
 };
 
 template <int D, int L1>
@@ -148,7 +155,22 @@ __device__ __forceinline__ void back_tiles(f32x4s (&acc)[KG], const float* wp, c
   }
 }
 
-template <int D, int L1, int MODE>
+// keep bits of the lane's hidden features of candidate n: bit 4 nt + r <-> feature 16 nt + 4 g + r, i.e. word r of the Philox block
+// 4 nt + g -- one block per MFMA tile, exactly the four features the lane holds of it
+template <int NT>
+__device__ __forceinline__ uint32_t keep_bits(uint64_t seed, uint64_t n, int g, uint32_t thresh) {
+  uint32_t bits = 0;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    uint32_t w[4];
+    philox4x32_10(seed, n, (uint32_t)(4 * nt + g), w);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bits |= (w[r] < thresh ? 0u : 1u) << (4 * nt + r);
+  }
+  return bits;
+}
+
+template <int D, int L1, int MODE, bool DROP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void neumf_step_kernel(NeumfStepArgs a) {
   using Cfg = StepCfg<D, L1>;
   constexpr int K0 = Cfg::K0, SW = Cfg::SW, NCU = Cfg::NCU, NT = Cfg::NT, SZ = Cfg::SZ, SH = Cfg::SH, NTU = Cfg::NTU;
@@ -173,6 +195,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   for (int k = threadIdx.x; k < D + L1; k += 256) swo[k] = a.w_out[k];
   for (int k = threadIdx.x; k < 4 * (2 * L1 + D); k += 256) wred[k] = 0.f;
   __syncthreads();
+  const uint64_t seed = DROP ? *a.seed_dev : 0;
 
   f32x4s accW[NT][NCU];   // dW1[:, D:] of this wave's tuples: tile (ft, kt), register r <-> W1[16 ft + 4 g + r][D + 16 kt + i]
   f32x4s accU[NTU];       // dW1[:, :D] tiles wave + 4 q of the workgroup's tuples
@@ -239,16 +262,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         f32x4s z[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) z[nt] = Zu[nt];
+        // (the mask does not depend on anything loaded: its integer arithmetic can issue beside the MFMAs below)
+        const uint32_t kb = DROP ? keep_bits<NT>(seed, (uint64_t)(tt * C + c), g, a.drop_thresh) : 0u;
         hidden_half<NT, NCU, SW>(z, wfwd_i, hx);
         float pp = 0.f;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
           const float4 b = *reinterpret_cast<const float4*>(sb1 + 16 * nt + 4 * g);
           const float4 o = *reinterpret_cast<const float4*>(swo + D + 16 * nt + 4 * g);
-          pp = fmaf(o.x, fmaxf(z[nt][0] + b.x, 0.f), pp);
-          pp = fmaf(o.y, fmaxf(z[nt][1] + b.y, 0.f), pp);
-          pp = fmaf(o.z, fmaxf(z[nt][2] + b.z, 0.f), pp);
-          pp = fmaf(o.w, fmaxf(z[nt][3] + b.w, 0.f), pp);
+          if (DROP) {
+            const float bb[4] = {b.x, b.y, b.z, b.w}, oo[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              pp = fmaf(oo[r], fmaxf(z[nt][r] + bb[r], 0.f) * (((kb >> (4 * nt + r)) & 1u) ? a.keep_scale : 0.f), pp);
+          } else {
+            pp = fmaf(o.x, fmaxf(z[nt][0] + b.x, 0.f), pp);
+            pp = fmaf(o.y, fmaxf(z[nt][1] + b.y, 0.f), pp);
+            pp = fmaf(o.z, fmaxf(z[nt][2] + b.z, 0.f), pp);
+            pp = fmaf(o.w, fmaxf(z[nt][3] + b.w, 0.f), pp);
+          }
         }
 #pragma unroll
         for (int cc = 0; cc < NCU; ++cc)
@@ -328,6 +360,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         f32x4s dz[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) dz[nt] = Zu[nt];
+        const uint32_t kb = DROP ? keep_bits<NT>(seed, (uint64_t)(tt * C + c), g, a.drop_thresh) : 0u;   // pass 1's mask again
         hidden_half<NT, NCU, SW>(dz, wfwd_i, hx);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -337,10 +370,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float zz = dz[nt][r] + bb[r];
-            const float dv = zz > 0.f ? gc * oo[r] : 0.f;
+            float dv, hh;
+            if (DROP) {    // as the three-kernel step (neumf.hip): dz = g w_h keep, h1 = relu(z) keep
+              const float kp = ((kb >> (4 * nt + r)) & 1u) ? a.keep_scale : 0.f;
+              dv = zz > 0.f ? gc * oo[r] * kp : 0.f;
+              hh = fmaxf(zz, 0.f) * kp;
+            } else {
+              dv = zz > 0.f ? gc * oo[r] : 0.f;
+              hh = fmaxf(zz, 0.f);
+            }
             dz[nt][r] = dv;
             dzs[nt][r] += dv;
-            dwh[nt][r] = fmaf(gc, fmaxf(zz, 0.f), dwh[nt][r]);
+            dwh[nt][r] = fmaf(gc, hh, dwh[nt][r]);
           }
           *reinterpret_cast<float4*>(Tz + i * SZ + 16 * nt + 4 * g) = make_float4(dz[nt][0], dz[nt][1], dz[nt][2], dz[nt][3]);
         }
@@ -651,10 +692,10 @@ static int step_grid(int B) {
   return (int)(grid < 1 ? 1 : grid);
 }
 
-template <int D, int L1, int MODE>
+template <int D, int L1, int MODE, bool DROP>
 static int launch_step(const NeumfStepArgs& a, int grid, hipStream_t s) {
   const size_t lds_bytes = step_lds_bytes(D, L1, a.C);
-  auto kern = neumf_step_kernel<D, L1, MODE>;
+  auto kern = neumf_step_kernel<D, L1, MODE, DROP>;
   RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, s, a);
   RC_LAUNCH_CHECK();
@@ -664,7 +705,7 @@ static int launch_step(const NeumfStepArgs& a, int grid, hipStream_t s) {
 template <int MODE>
 static int dispatch_step(const NeumfStepArgs& a, int d, int l1, int grid, hipStream_t s) {
 #define RC_NS(D_, L_) \
-  if (d == D_ && l1 == L_) return launch_step<D_, L_, MODE>(a, grid, s)
+  if (d == D_ && l1 == L_) return a.seed_dev ? launch_step<D_, L_, MODE, true>(a, grid, s) : launch_step<D_, L_, MODE, false>(a, grid, s)
   RC_NS(128, 64); RC_NS(128, 32);
   RC_NS(64, 64); RC_NS(64, 32);
   RC_NS(32, 64); RC_NS(32, 32);
@@ -713,7 +754,7 @@ extern "C" int rc_neumf_unmark_rows(const int64_t* iid, int64_t n, int64_t n_ite
   return RC_OK;
 }
 
-static int neumf_train_step_impl(bool marked, float* mf_u, float* mf_i, float* mlp_u, float* mlp_i, float* m_mf_i, float* v_mf_i,
+static int neumf_train_step_impl(bool marked, float drop_p, const uint64_t* seed_dev, float* mf_u, float* mf_i, float* mlp_u, float* mlp_i, float* m_mf_i, float* v_mf_i,
                                  float* m_mlp_i, float* v_mlp_i, const float* W1, const float* b1, const float* w_out,
                                  const int64_t* uid, const int64_t* iid, int B, int C, int d, int l1, int64_t n_items,
                                  void* marks, const rc_opt_hyper* h, float inv_b, float* loss_vec, float* pred,
@@ -732,6 +773,13 @@ static int neumf_train_step_impl(bool marked, float* mf_u, float* mf_i, float* m
   NeumfStepArgs a;
   memset(&a, 0, sizeof(a));
   RC_TRY(fill_opt_scalars(h, &a.opt));
+  if (!(drop_p >= 0.f && drop_p < 1.f)) return fail(RC_ERR_INVALID_ARG, "rc_neumf_train_step: dropout p=%g outside [0, 1)", (double)drop_p);
+  if (drop_p > 0.f) {
+    if (!seed_dev) return fail(RC_ERR_INVALID_ARG, "rc_neumf_train_step: dropout p=%g needs a device seed", (double)drop_p);
+    a.seed_dev = seed_dev;      // (as rc_neumf_fwd_dropout)
+    a.drop_thresh = (uint32_t)((double)drop_p * 4294967296.0);
+    a.keep_scale = 1.0f / (1.0f - drop_p);
+  }
   const int mode = mode_of(h);
   RC_REQUIRE(!mode_has_m(mode) || (m_mf_i && m_mlp_i), "rc_neumf_train_step: optimizer %d needs the m state of the item tables", h->opt);
   RC_REQUIRE(!mode_has_v(mode) || (v_mf_i && v_mlp_i), "rc_neumf_train_step: optimizer %d needs the v state of the item tables", h->opt);
@@ -774,7 +822,7 @@ extern "C" int rc_neumf_train_step(float* mf_u, float* mf_i, float* mlp_u, float
                                    void* marks, const rc_opt_hyper* h, float inv_b, float* loss_vec, float* pred,
                                    float* g_mf_i, float* g_mlp_i, float* gu_mf, float* gu_mlp, float* dW1, float* db1,
                                    float* dw_out, void* ws, size_t ws_bytes, rc_stream_t stream) {
-  return neumf_train_step_impl(false, mf_u, mf_i, mlp_u, mlp_i, m_mf_i, v_mf_i, m_mlp_i, v_mlp_i, W1, b1, w_out, uid, iid, B, C, d, l1,
+  return neumf_train_step_impl(false, 0.f, nullptr, mf_u, mf_i, mlp_u, mlp_i, m_mf_i, v_mf_i, m_mlp_i, v_mlp_i, W1, b1, w_out, uid, iid, B, C, d, l1,
                                n_items, marks, h, inv_b, loss_vec, pred, g_mf_i, g_mlp_i, gu_mf, gu_mlp, dW1, db1, dw_out, ws, ws_bytes, stream);
 }
 
@@ -784,8 +832,20 @@ extern "C" int rc_neumf_train_step_marked(float* mf_u, float* mf_i, float* mlp_u
                                           void* marks, const rc_opt_hyper* h, float inv_b, float* loss_vec, float* pred,
                                           float* g_mf_i, float* g_mlp_i, float* gu_mf, float* gu_mlp, float* dW1, float* db1,
                                           float* dw_out, void* ws, size_t ws_bytes, rc_stream_t stream) {
-  return neumf_train_step_impl(true, mf_u, mf_i, mlp_u, mlp_i, m_mf_i, v_mf_i, m_mlp_i, v_mlp_i, W1, b1, w_out, uid, iid, B, C, d, l1,
+  return neumf_train_step_impl(true, 0.f, nullptr, mf_u, mf_i, mlp_u, mlp_i, m_mf_i, v_mf_i, m_mlp_i, v_mlp_i, W1, b1, w_out, uid, iid, B, C, d, l1,
                                n_items, marks, h, inv_b, loss_vec, pred, g_mf_i, g_mlp_i, gu_mf, gu_mlp, dW1, db1, dw_out, ws, ws_bytes, stream);
+}
+
+extern "C" int rc_neumf_train_step_dropout(float* mf_u, float* mf_i, float* mlp_u, float* mlp_i, float* m_mf_i, float* v_mf_i,
+                                           float* m_mlp_i, float* v_mlp_i, const float* W1, const float* b1, const float* w_out,
+                                           const int64_t* uid, const int64_t* iid, int B, int C, int d, int l1, int64_t n_items,
+                                           void* marks, int marks_prepared, const rc_opt_hyper* h, float inv_b, float drop_p,
+                                           const uint64_t* seed_dev, float* loss_vec, float* pred, float* g_mf_i, float* g_mlp_i,
+                                           float* gu_mf, float* gu_mlp, float* dW1, float* db1, float* dw_out, void* ws,
+                                           size_t ws_bytes, rc_stream_t stream) {
+  return neumf_train_step_impl(marks_prepared != 0, drop_p, seed_dev, mf_u, mf_i, mlp_u, mlp_i, m_mf_i, v_mf_i, m_mlp_i, v_mlp_i, W1, b1, w_out,
+                               uid, iid, B, C, d, l1, n_items, marks, h, inv_b, loss_vec, pred, g_mf_i, g_mlp_i, gu_mf, gu_mlp, dW1, db1,
+                               dw_out, ws, ws_bytes, stream);
 }
 
 extern "C" int rc_neumf_head_fwd_bwd(const float* mf_u, const float* mlp_u, int64_t ld_u, const float* mf_i, const float* mlp_i,

@@ -679,27 +679,33 @@ def neumf_mark_rows(iid, n_items, marks, unmark=False):
               C.c_void_p(marks.data_ptr()), _stream())
 
 
-def neumf_train_step(P, state, uid, iid, hyper, marks, out, inv_b=None, pred=None, marked=False):
+def neumf_train_step(P, state, uid, iid, hyper, marks, out, inv_b=None, pred=None, marked=False, drop_p=0.0, seed=None):
     """rc_neumf_train_step: forward + BPR loss + backward + in-place update of single-occurrence item rows.
     state: {table: {"m": .., "v": ..}} of the optimizer; marks: uint8 buffer of rc_neumf_train_step_marks_bytes(n_items), zeroed
     once (every call leaves it ready for the next; marked=True: prepared by neumf_mark_rows for this very batch, cleared by the caller); out: dict of preallocated buffers loss_vec [B], g_mf_i / g_mlp_i [B C, d], gu_mf / gu_mlp [B, d], W1 / b1 / w_out
-    gradients.  Returns nothing: the caller finishes the step with the plan's pair updates and the dense update."""
+    gradients.  drop_p > 0: training-mode dropout on the hidden layer inside the kernel (rc_neumf_train_step_dropout; `seed` int64 [1]
+    on the device, the mask stream of neumf_fwd / neumf_bwd).  Returns nothing: the caller finishes the step with the plan's pair
+    updates and the dense update."""
     B, Cn = iid.shape
     d, l1 = P["mf_u"].shape[1], P["W1"].shape[0]
     f32 = torch.float32
     lib = _lib.load()
     ws = workspace(lib.rc_neumf_train_step_workspace_bytes(B, Cn, d, l1), iid.device, "neumf_step")
     st = lambda t, k: _ptr(state[t].get(k), f32, k + "_" + t, True)
-    _lib.call("rc_neumf_train_step_marked" if marked else "rc_neumf_train_step",
-              _ptr(P["mf_u"], f32, "mf_u"), _ptr(P["mf_i"], f32, "mf_i"), _ptr(P["mlp_u"], f32, "mlp_u"),
-              _ptr(P["mlp_i"], f32, "mlp_i"), st("mf_i", "m"), st("mf_i", "v"), st("mlp_i", "m"), st("mlp_i", "v"),
-              _ptr(P["W1"], f32, "W1"), _ptr(P["b1"], f32, "b1"), _ptr(P["w_out"], f32, "w_out"),
-              _ptr(uid, torch.int64, "uid"), _ptr(iid, torch.int64, "iid"), B, Cn, d, l1, int(P["mf_i"].shape[0]),
-              C.c_void_p(marks.data_ptr()), C.byref(hyper), float(1.0 / B if inv_b is None else inv_b),
-              _ptr(out["loss_vec"], f32, "loss_vec"), _ptr(pred, f32, "pred", True),
-              _ptr(out["g_mf_i"], f32, "g_mf_i"), _ptr(out["g_mlp_i"], f32, "g_mlp_i"), _ptr(out["gu_mf"], f32, "gu_mf"),
-              _ptr(out["gu_mlp"], f32, "gu_mlp"), _ptr(out["W1"], f32, "dW1"), _ptr(out["b1"], f32, "db1"),
-              _ptr(out["w_out"], f32, "dw_out"), C.c_void_p(ws.data_ptr()), ws.numel(), _stream())
+    head = [_ptr(P["mf_u"], f32, "mf_u"), _ptr(P["mf_i"], f32, "mf_i"), _ptr(P["mlp_u"], f32, "mlp_u"),
+            _ptr(P["mlp_i"], f32, "mlp_i"), st("mf_i", "m"), st("mf_i", "v"), st("mlp_i", "m"), st("mlp_i", "v"),
+            _ptr(P["W1"], f32, "W1"), _ptr(P["b1"], f32, "b1"), _ptr(P["w_out"], f32, "w_out"),
+            _ptr(uid, torch.int64, "uid"), _ptr(iid, torch.int64, "iid"), B, Cn, d, l1, int(P["mf_i"].shape[0]),
+            C.c_void_p(marks.data_ptr())]
+    tail = [_ptr(out["loss_vec"], f32, "loss_vec"), _ptr(pred, f32, "pred", True),
+            _ptr(out["g_mf_i"], f32, "g_mf_i"), _ptr(out["g_mlp_i"], f32, "g_mlp_i"), _ptr(out["gu_mf"], f32, "gu_mf"),
+            _ptr(out["gu_mlp"], f32, "gu_mlp"), _ptr(out["W1"], f32, "dW1"), _ptr(out["b1"], f32, "db1"),
+            _ptr(out["w_out"], f32, "dw_out"), C.c_void_p(ws.data_ptr()), ws.numel(), _stream()]
+    inv = float(1.0 / B if inv_b is None else inv_b)
+    if drop_p:
+        _lib.call("rc_neumf_train_step_dropout", *head, 1 if marked else 0, C.byref(hyper), inv, *_drop_args(drop_p, seed), *tail)
+    else:
+        _lib.call("rc_neumf_train_step_marked" if marked else "rc_neumf_train_step", *head, C.byref(hyper), inv, *tail)
 
 
 def neumf_head_fwd_bwd(urows, irows, W1, b1, w_out, B, Cn, inv_b, want_pred=False):
@@ -804,7 +810,7 @@ class NeumfTrainer:
         use_plan = self.rowwise and pair_ok and _USE_PLAN and plan_supported(iid.numel(), uid.numel(), n_i, n_u)
         # the bucket plan needs only the ids: on a second stream it runs beside the head kernels (large batches; a small step is
         # bound by the host's launch rate and the stream switches cost more than they return)
-        if (use_plan and _NEUMF_FUSED and self.dropout == 0.0 and self.opt in ("SGD", "Adam", "Adagrad") and Cn >= 2
+        if (use_plan and _NEUMF_FUSED and self.opt in ("SGD", "Adam", "Adagrad") and Cn >= 2
                 and neumf_train_step_supported(Cn, P["mf_u"].shape[1], P["W1"].shape[0])):
             return self._step_fused(uid, iid, next_batch)
         overlap = use_plan and _NEUMF_OVERLAP and iid.is_cuda and iid.numel() >= _SAS_OVERLAP_MIN
@@ -914,9 +920,9 @@ class NeumfTrainer:
         with _PhaseTimer(self, "fused_step"):
             if marks_done is not None:      # flags prepared beside the previous step's updates
                 main.wait_event(marks_done)
-                neumf_train_step(P, self.state, uid, iid, h, self._marks[buf], out, marked=True)
+                neumf_train_step(P, self.state, uid, iid, h, self._marks[buf], out, marked=True, drop_p=self.dropout, seed=self.seed)
             else:
-                neumf_train_step(P, self.state, uid, iid, h, self._marks[buf], out)
+                neumf_train_step(P, self.state, uid, iid, h, self._marks[buf], out, drop_p=self.dropout, seed=self.seed)
         if marks_done is not None and not two_streams:
             # prepared flags are ALWAYS cleared by the step that consumed them -- also a short step (a ragged last batch of an
             # epoch announced by a large one) that runs on one stream: a flag left behind would make a later single occurrence

@@ -264,7 +264,7 @@ def _fused_buffers(eng, Pd, B, C, cuda):
     return out, marks
 
 
-def _check_fused_against(eng, P, Pd, state, uid, iid, opt, lr, l2, step, want_pred, want_loss_rows, G, tol, cuda, what):
+def _check_fused_against(eng, P, Pd, state, uid, iid, opt, lr, l2, step, want_pred, want_loss_rows, G, tol, cuda, what, drop=None):
     """one rc_neumf_train_step call against reference / oracle quantities: predictions, per-tuple loss, dense gradients, per-tuple
     user gradient rows, single-occurrence item rows after the row-wise optimizer step (and their state), multi-occurrence rows
     untouched with their gradient rows written, the flag bytes back to zero"""
@@ -276,7 +276,10 @@ def _check_fused_against(eng, P, Pd, state, uid, iid, opt, lr, l2, step, want_pr
     S0 = {k: {s: t.cpu().numpy().copy() for s, t in state[k].items()} for k in ("mf_i", "mlp_i")}
     u, i = torch.from_numpy(uid).to(cuda), torch.from_numpy(iid).to(cuda)
     h = eng.make_hyper(opt, lr=lr, l2=l2, step=step)
-    eng.neumf_train_step(Pd, state, u, i, h, marks, out, pred=pred)
+    if drop is None:
+        eng.neumf_train_step(Pd, state, u, i, h, marks, out, pred=pred)
+    else:      # (p, device seed): rc_neumf_train_step_dropout
+        eng.neumf_train_step(Pd, state, u, i, h, marks, out, pred=pred, drop_p=drop[0], seed=drop[1])
     torch.cuda.synchronize()
     n_items = Pd["mf_i"].shape[0]
     assert not marks[(4 * n_items + 255) // 256 * 256:].any(), what + ": the multi-occurrence flags must be zero again after the step"
@@ -524,3 +527,102 @@ def test_neumf_trainer_short_step_consumes_prepared_flags_and_clears_them(cuda, 
     for k in P0:
         assert torch.equal(res[0][k], res[1][k]), k
     assert not torch.equal(res[0]["mf_i"][500:510], t(P0["mf_i"])[500:510])
+
+
+# ---- dropout inside the fused step (rc_neumf_train_step_dropout) -------------------------------------------------------------
+
+@pytest.mark.parametrize("opt", ["SGD", "Adam", "Adagrad"])
+def test_neumf_fused_step_with_dropout_matches_the_reference_run_with_the_same_mask(opt, cuda, eng):
+    """the reference's own command line trains NeuMF with --dropout 0.2 (docs/demo_scripts_results/Topk_Amazon.sh:8): the golden
+    batch of tests/golden/neumfdrop_d64_l64_k4_p0.2.npz (the reference's forward under this mask) through the ONE-kernel step --
+    predictions equal the reference's, loss rows / every gradient / the single-occurrence rows after the optimizer step equal the
+    oracle's backward under the same mask (pass 2 of the kernel regenerates pass 1's mask)"""
+    from oracle import bprmf_oracle as BO
+    case = "neumfdrop_d64_l64_k4_p0.2"
+    g = load_golden(case)
+    P0 = params(g)
+    Pd = to_dev(P0, cuda)
+    B, C = g["iid"].shape
+    p, sv = float(g["p"]), int(g["mask_seed"])
+    assert eng.neumf_train_step_supported(C, Pd["mf_u"].shape[1], Pd["W1"].shape[0])
+    keep = NO.dropout_keep(sv, B * C, P0["mlp.0.weight"].shape[0], p)
+    pred_o, _ = NO.forward(P0, g["uid"], g["iid"], keep)
+    assert_close(pred_o, g["pred"], what="oracle under the mask vs the reference's own output")
+    _, G = NO.backward(P0, g["uid"], g["iid"], BO.bpr_loss_grad(pred_o), keep)
+    state = _state_for(eng, Pd, opt, np.random.default_rng(5), cuda)
+    _check_fused_against(eng, P0, Pd, state, g["uid"], g["iid"], opt, 0.05, 1e-3, 3, g["pred"], BO.bpr_loss_rows(g["pred"])[0], G, 2e-5, cuda,
+                         case + " " + opt, drop=(p, _seed(cuda, sv)))
+
+
+def test_neumf_fused_step_with_dropout_random_shapes_vs_oracle(cuda, eng):
+    """every (d, hidden) instantiation, ragged tails, hot rows, C from 2 to 100, p from 0.1 to 0.75; p = 0 through the dropout entry
+    point is the plain step bit for bit; the same seed repeats the mask, another seed draws another"""
+    from oracle import bprmf_oracle as BO
+    rng = np.random.default_rng(23)
+    for k, (d, l1, B, C, n_items, opt, p) in enumerate(((128, 64, 700, 5, 3000, "SGD", 0.2), (64, 64, 333, 2, 500, "Adam", 0.5), (32, 32, 130, 17, 4000, "Adagrad", 0.1),
+                                                        (64, 32, 65, 100, 900, "SGD", 0.75), (32, 64, 1, 3, 50, "SGD", 0.2), (128, 32, 200, 5, 100000, "Adam", 0.3))):
+        n_users = 37
+        P = {"mf_u_embeddings.weight": rng.normal(0, 0.3, (n_users, d)), "mf_i_embeddings.weight": rng.normal(0, 0.3, (n_items, d)),
+             "mlp_u_embeddings.weight": rng.normal(0, 0.3, (n_users, d)), "mlp_i_embeddings.weight": rng.normal(0, 0.3, (n_items, d)),
+             "mlp.0.weight": rng.normal(0, 0.2, (l1, 2 * d)), "mlp.0.bias": rng.normal(0, 0.2, l1),
+             "prediction.weight": rng.normal(0, 0.2, (1, d + l1))}
+        P = {kk: v.astype(np.float32) for kk, v in P.items()}
+        uid = rng.integers(0, n_users, size=B).astype(np.int64)
+        iid = rng.integers(0, n_items, size=(B, C)).astype(np.int64)
+        iid[:, 0] = iid[:, 0] % 7
+        sv = 1000003 * (k + 1) + (k << 41)
+        keep = NO.dropout_keep(sv, B * C, l1, p)
+        pred, _ = NO.forward(P, uid, iid, keep)
+        _, G = NO.backward(P, uid, iid, BO.bpr_loss_grad(pred), keep)
+        Pd = to_dev(P, cuda)
+        state = _state_for(eng, Pd, opt, rng, cuda)
+        _check_fused_against(eng, P, Pd, state, uid, iid, opt, 0.03, 1e-4, 2, pred, BO.bpr_loss_rows(pred)[0], G, 3e-5, cuda,
+                             f"d={d} l1={l1} B={B} C={C} {opt} p={p}", drop=(p, _seed(cuda, sv)))
+    # p = 0 == the plain entry point; seeds
+    u, i = torch.from_numpy(uid).to(cuda), torch.from_numpy(iid).to(cuda)
+    h = eng.make_hyper("SGD", lr=0.03, l2=0.0, step=1)
+    res = []
+    for drop in (None, (0.0, _seed(cuda, 9)), (0.3, _seed(cuda, 9)), (0.3, _seed(cuda, 9)), (0.3, _seed(cuda, 10))):
+        Pd = to_dev(P, cuda)
+        out, marks = _fused_buffers(eng, Pd, B, C, cuda)
+        kw = {} if drop is None else dict(drop_p=drop[0], seed=drop[1])
+        eng.neumf_train_step(Pd, {kk: {} for kk in Pd}, u, i, h, marks, out, **kw)
+        res.append((Pd["mlp_i"].clone(), out["loss_vec"].clone(), out["W1"].clone()))
+    same = lambda a, b: all(torch.equal(x, y) for x, y in zip(a, b))
+    assert same(res[0], res[1]) and same(res[2], res[3]) and not same(res[2], res[4]) and not same(res[0], res[2])
+
+
+@pytest.mark.parametrize("opt", ["SGD", "Adam"])
+def test_neumf_trainer_with_dropout_fused_equals_three_kernel_step(opt, cuda, eng, monkeypatch):
+    """NeumfTrainer(dropout=0.2): the fused kernel and the forward / loss / backward chain draw the same masks from the same seed
+    counter -- three steps, same losses, tables and dense parameters to rounding"""
+    rng = np.random.default_rng(19)
+    d, l1, B, C, n_users, n_items = 64, 64, 2000, 5, 300, 15000
+    P0 = {"mf_u": rng.normal(0, 0.2, (n_users, d)), "mf_i": rng.normal(0, 0.2, (n_items, d)), "mlp_u": rng.normal(0, 0.2, (n_users, d)),
+          "mlp_i": rng.normal(0, 0.2, (n_items, d)), "W1": rng.normal(0, 0.2, (l1, 2 * d)), "b1": rng.normal(0, 0.2, l1),
+          "w_out": rng.normal(0, 0.2, d + l1)}
+    P0 = {k: v.astype(np.float32) for k, v in P0.items()}
+    batches = []
+    for _ in range(3):
+        uid = rng.integers(0, n_users, size=B).astype(np.int64)
+        iid = rng.integers(0, n_items, size=(B, C)).astype(np.int64)
+        iid[:, 0] = iid[:, 0] % 50
+        batches.append((torch.from_numpy(uid).to(cuda), torch.from_numpy(iid).to(cuda)))
+    lr = 0.05 if opt == "SGD" else 1e-2
+    monkeypatch.setattr(eng, "_SAS_OVERLAP_MIN", 0)
+    res = []
+    for fused in (True, False):
+        monkeypatch.setattr(eng, "_NEUMF_FUSED", fused)
+        P = {k: torch.from_numpy(v).to(cuda) for k, v in P0.items()}
+        tr = eng.NeumfTrainer(P, opt=opt, lr=lr, l2=1e-4, rowwise=True, dropout=0.2, seed=77)
+        tr.timing = {}
+        losses = [float(tr.step(u, i, next_batch=batches[(k + 1) % 3]).item()) for k, (u, i) in enumerate(batches)]
+        assert ("fused_step" in tr.timing) == fused
+        assert int(tr.seed.item()) == 77 + 3
+        res.append((P, losses))
+    (Pa, La), (Pb, Lb) = res
+    assert_close(np.array(La), np.array(Lb), what="losses")
+    assert len(set(La)) == 3
+    ex = 1e-3 * lr if opt != "SGD" else 0.0
+    for k in P0:
+        assert_update_close(Pa[k].cpu().numpy(), P0[k], Pb[k].cpu().numpy(), what=k, extra_atol=ex)
