@@ -587,6 +587,23 @@ int rc_linear_bwd(const float* X, const float* W, const float* Y, const float* d
 int rc_linear_bwd_chain(const float* X, const float* W, const float* Y, const float* dY, int64_t M, int N, int K, float drop_p,
                         int x_act, float x_drop_p, float* dX, float* dW, float* db, void* ws, size_t ws_bytes, rc_stream_t stream);
 
+/* The TAIL of an MLP tower at a small batch (csrc/tower_tail.hip): the last hidden layer Linear(K -> N2) -> ReLU -> Dropout(p) and
+ * the output layer Linear(N2 -> 1) of utils/layers.py:201-243 (MLP_Block: models/context/DeepFM.py:25, WideDeep.py:42-47 at
+ * --layers [512,64] / [64]; models/general/NeuMF.py:47-52 for multi-layer towers) as ONE forward and ONE backward kernel (+ the
+ * fixed-order sum of the per-workgroup partials) instead of eleven GEMM / epilogue launches of 5-15 us each.
+ *   rc_tower_tail_fwd: H2 [M, N2] = drop(relu(X [M, K] W2^T + b2)) (the mask of rc_linear_fwd, layer index `site`), z [M] = H2 w3 + b3
+ *   rc_tower_tail_bwd: given dz [M] = d loss / d z: dX [M, K] = ((dz w3^T * mask(H2)) W2), multiplied by the mask of the layer below
+ *     when x_act != 0 (X > 0 ? 1 / (1 - x_drop_p) : 0, as rc_linear_bwd_chain); dW2 [N2, K], db2 [N2], dw3 [N2], db3 [1].
+ *     dX, db2, db3 may be NULL.  ws: rc_tower_tail_workspace_bytes(M, K, N2).  No float atomics.
+ * Shapes: rc_tower_tail_supported: N2 in {16, 32, 64}, K in {64, 128, 256, 512}; X, W2, H2, w3 16-byte aligned.                 */
+int rc_tower_tail_supported(int64_t M, int K, int N2);
+size_t rc_tower_tail_workspace_bytes(int64_t M, int K, int N2);
+int rc_tower_tail_fwd(const float* X, const float* W2, const float* b2, const float* w3, const float* b3, int64_t M, int K,
+                      int N2, float drop_p, const uint64_t* seed_dev, uint32_t site, float* H2, float* z, rc_stream_t stream);
+int rc_tower_tail_bwd(const float* X, const float* W2, const float* w3, const float* H2, const float* dz, int64_t M, int K,
+                      int N2, float drop_p, int x_act, float x_drop_p, float* dX, float* dW2, float* db2, float* dw3,
+                      float* db3, void* ws, size_t ws_bytes, rc_stream_t stream);
+
 /* ---- training-batch assembly on the device (csrc/sampler.hip) -------------------------------- */
 
 /* GeneralModel.Dataset.actions_before_epoch (models/BaseModel.py:206-214): neg[i,k] ~ uniform over

@@ -160,6 +160,10 @@ SIGNATURES = {
     "rc_linear_bwd_workspace_bytes": (_sz, [_i64, _i, _i]),
     "rc_linear_bwd": (_i, [_p, _p, _p, _p, _i64, _i, _i, _f, _p, _p, _p, _p, _sz, _p]),
     "rc_linear_bwd_chain": (_i, [_p, _p, _p, _p, _i64, _i, _i, _f, _i, _f, _p, _p, _p, _p, _sz, _p]),
+    "rc_tower_tail_supported": (_i, [_i64, _i, _i]),
+    "rc_tower_tail_workspace_bytes": (_sz, [_i64, _i, _i]),
+    "rc_tower_tail_fwd": (_i, [_p, _p, _p, _p, _p, _i64, _i, _i, _f, _p, C.c_uint32, _p, _p, _p]),
+    "rc_tower_tail_bwd": (_i, [_p, _p, _p, _p, _p, _i64, _i, _i, _f, _i, _f, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "rc_neumf_fwd_dropout": (_i, [_p] * 9 + [_i, _i, _i, _i, _f, _p, _p, _p]),
     "rc_neumf_bwd_dropout": (_i, [_p] * 10 + [_i, _i, _i, _i, _f, _p] + [_p] * 7 + [_p, _sz, _p]),
     "rc_bucket_plan_supported": (_i, [_i64, _i64, _i64, _i64]),

@@ -1049,6 +1049,48 @@ def linear_bwd(X, W, Y, dY, drop_p=0.0, need_dx=True, need_db=True, x_act=False,
     return dX, dW, db
 
 
+_TOWER_TAIL = os.environ.get("RC_TOWER_TAIL", "1") != "0"      # A/B switch: the tail of a tower as two kernels (csrc/tower_tail.hip)
+_TOWER_TAIL_MAX_M = int(os.environ.get("RC_TOWER_TAIL_MAX_M", "16384"))   # larger batches fill the 64 x 64 / 128 x 128 GEMM tiles
+
+
+def tower_tail_supported(M, K, N2):
+    """the last hidden layer [K -> N2] + the output layer [N2 -> 1] of a tower run as rc_tower_tail_fwd / _bwd"""
+    return bool(_TOWER_TAIL and 1 <= M <= _TOWER_TAIL_MAX_M and _lib.load().rc_tower_tail_supported(int(M), int(K), int(N2)))
+
+
+def tower_tail_fwd(X, W2, b2, w3, b3, drop_p=0.0, seed=None, site=0):
+    """-> (H2 [M, N2] = drop(relu(X W2^T + b2)), z [M, 1] = H2 w3^T + b3); w3 [1, N2] (nn.Linear(N2, 1).weight), b3 [1] | None;
+    dropout mask as linear_fwd with layer index `site`"""
+    f32 = torch.float32
+    M, K = X.shape
+    N2 = W2.shape[0]
+    H2 = torch.empty((M, N2), dtype=f32, device=X.device)
+    z = torch.empty((M, 1), dtype=f32, device=X.device)
+    _lib.call("rc_tower_tail_fwd", _ptr(X, f32, "X"), _ptr(W2, f32, "W2"), _ptr(b2, f32, "b2", True), _ptr(w3, f32, "w3"), _ptr(b3, f32, "b3", True),
+              M, K, N2, *_drop_args(drop_p, seed), C.c_uint32(int(site)), _ptr(H2, f32, "H2"), _ptr(z, f32, "z"), _stream())
+    return H2, z
+
+
+def tower_tail_bwd(X, W2, w3, H2, dz, drop_p=0.0, need_dx=True, x_act=False, x_drop_p=0.0, need_db2=True, need_db3=True):
+    """backward of tower_tail_fwd given dz [M, 1] -> (dX | None, dW2, db2 | None, dW3 [1, N2], db3 [1] | None); x_act: X is the
+    drop(relu(.)) output of the layer below and dX comes out multiplied by its mask (as linear_bwd)"""
+    f32 = torch.float32
+    M, K = X.shape
+    N2 = W2.shape[0]
+    dev = X.device
+    dX = torch.empty((M, K), dtype=f32, device=dev) if need_dx else None
+    dW2 = torch.empty((N2, K), dtype=f32, device=dev)
+    db2 = torch.empty(N2, dtype=f32, device=dev) if need_db2 else None
+    dW3 = torch.empty((1, N2), dtype=f32, device=dev)
+    db3 = torch.empty(1, dtype=f32, device=dev) if need_db3 else None
+    ws = workspace(_lib.load().rc_tower_tail_workspace_bytes(M, K, N2), dev, "tower_tail")
+    _lib.call("rc_tower_tail_bwd", _ptr(X, f32, "X"), _ptr(W2, f32, "W2"), _ptr(w3, f32, "w3"), _ptr(H2, f32, "H2"), _ptr(dz, f32, "dz"), M, K, N2,
+              C.c_float(float(drop_p)), 1 if (x_act and need_dx) else 0, C.c_float(float(x_drop_p)), _ptr(dX, f32, "dX", True),
+              _ptr(dW2, f32, "dW2"), _ptr(db2, f32, "db2", True), _ptr(dW3, f32, "dw3"), _ptr(db3, f32, "db3", True),
+              C.c_void_p(ws.data_ptr()), ws.numel(), _stream())
+    return dX, dW2, db2, dW3, db3
+
+
 # ---- SASRec encoder ---------------------------------------------------------------------------------
 
 SAS_LAYER_KEYS = ("Wq", "bq", "Wk", "bk", "Wv", "bv", "ln1w", "ln1b", "W1", "b1", "W2", "b2", "ln2w", "ln2b")

@@ -502,18 +502,38 @@ class _MlpFn(torch.autograd.Function):
     layer i is the input of layer i + 1), so no layer but the top one makes a separate masking pass over [M, width]."""
 
     @staticmethod
+    def _tail(spec, params, M):
+        """the last hidden layer + a width -> 1 output layer as the two tower-tail kernels (csrc/tower_tail.hip)?"""
+        n = len(spec)
+        if n < 2:
+            return False
+        (relu2, _, _), (relu3, p3, _) = spec[n - 2], spec[n - 1]
+        W2, W3 = params[2 * (n - 2)], params[2 * (n - 1)]
+        return bool(relu2 and not relu3 and p3 == 0.0 and W3.shape[0] == 1 and engine.tower_tail_supported(M, W2.shape[1], W2.shape[0]))
+
+    @staticmethod
     def forward(ctx, x, spec, seed, *params):
         # spec: tuple of (relu, drop_p, has_bias) per layer; params: W_0, b_0 | None, W_1, ...
         xs = x.detach().reshape(-1, x.shape[-1]).contiguous()
         saved, h = [], xs
+        n = len(spec)
+        tail = _MlpFn._tail(spec, params, xs.shape[0])
         for site, (relu, p, has_b) in enumerate(spec):
             W = params[2 * site].detach().contiguous()
             b = params[2 * site + 1].detach().contiguous() if has_b else None
+            if tail and site == n - 2:
+                # one kernel for this layer and the output layer: H2 (saved: the output layer's input and this layer's mask), z
+                W3 = params[2 * (n - 1)].detach().contiguous()
+                b3 = params[2 * (n - 1) + 1].detach().contiguous() if spec[n - 1][2] else None
+                H2, z = engine.tower_tail_fwd(h, W, b, W3, b3, p, seed, site)
+                saved += [h, W, H2, W3]
+                h = z
+                break
             y = engine.linear_fwd(h, W, b, relu, p, seed, site)
             saved += [h, W]
             h = y
         ctx.save_for_backward(*saved, h)
-        ctx.spec, ctx.xshape, ctx.need_dx = spec, x.shape, x.requires_grad
+        ctx.spec, ctx.xshape, ctx.need_dx, ctx.tail = spec, x.shape, x.requires_grad, tail
         return h.view(*x.shape[:-1], h.shape[-1])
 
     @staticmethod
@@ -523,9 +543,18 @@ class _MlpFn(torch.autograd.Function):
         n = len(spec)
         dz = dy.reshape(-1, dy.shape[-1]).contiguous()
         grads = [None] * (2 * n)
+        top = n - 1
+        if ctx.tail:
+            X2, W2, H2, W3 = saved[2 * (n - 2)], saved[2 * (n - 2) + 1], saved[2 * (n - 1)], saved[2 * (n - 1) + 1]
+            below = spec[n - 3] if n > 2 else None
+            x_act = below is not None and (below[0] or below[1] > 0)
+            dX, dW2, db2, dW3, db3 = engine.tower_tail_bwd(X2, W2, W3, H2, dz, spec[n - 2][1], need_dx=(n > 2 or ctx.need_dx), x_act=x_act,
+                                                           x_drop_p=below[1] if x_act else 0.0, need_db2=spec[n - 2][2], need_db3=spec[n - 1][2])
+            grads[2 * (n - 2)], grads[2 * (n - 2) + 1], grads[2 * (n - 1)], grads[2 * (n - 1) + 1] = dW2, db2, dW3, db3
+            dz, top = dX, n - 3
         # (the weight-gradient products on a second stream beside the dX chain -- rc_linear_bwd_chain takes dX / dW separately --
         #  measured SLOWER inside the replayed graph at B = 1,024: 0.389 against 0.377 ms, profiles/r05h_gemm_probe.txt)
-        for i in range(n - 1, -1, -1):
+        for i in range(top, -1, -1):
             X, W = saved[2 * i], saved[2 * i + 1]
             relu, p, has_b = spec[i]
             # the top layer masks its own dY (Y = its saved output); every other layer receives a dY that the layer above

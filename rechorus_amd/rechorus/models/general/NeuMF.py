@@ -87,7 +87,7 @@ class NeuMF(GeneralModel):
         return self._fused_ok()
 
     def hip_train_step(self, feed_dict, opt_name, lr, l2, next_feed_dict=None):
-        """one fit iteration on engine.NeumfTrainer: without dropout ONE kernel for forward, BPR loss, backward and the in-place
+        """one fit iteration on engine.NeumfTrainer: ONE kernel for forward (dropout mask included), BPR loss, backward and the in-place
         update of single-occurrence item rows (rc_neumf_train_step) + the plan's pair updates + the dense step of the MLP;
         returns the device loss tensor.  next_feed_dict: the batch the following call will bring (BaseRunner.fit passes it): its
         bucket plan is built beside this step's table updates."""
