@@ -354,6 +354,11 @@ int rc_small_row_sums_supported(int64_t n, int64_t n_rows, int d);
 size_t rc_small_row_sums_workspace_bytes(int64_t n);
 int rc_small_row_sums(const int64_t* ids, int64_t n, int64_t n_rows, const float* src, int d, float* out, void* ws,
                       size_t ws_bytes, rc_stream_t stream);
+/* A second table gathered with the SAME ids (the [vocab, d] vectors and the [vocab, 1] first-order weights of the FM family,
+ * models/context/FM.py:44-57): the row sums of another src / out pair on the grouping that the preceding rc_small_row_sums call
+ * left in `ws` (same n, same n_rows, ws untouched in between) -- one launch instead of two.                                    */
+int rc_small_row_sums_again(int64_t n, int64_t n_rows, const float* src, int d, float* out, void* ws, size_t ws_bytes,
+                            rc_stream_t stream);
 
 /* The CTR head of the context models in one pass: z = bias[0] + sum_f lin[i, f] (+ term1[i]) (+ term2[i])
  * (models/context/FM.py:59-60, DeepFM.py:27, WideDeep.py:46), p = sigmoid(z) (BaseContextModel.py:74-78), the per-row term of

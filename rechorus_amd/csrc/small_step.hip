@@ -404,10 +404,10 @@ extern "C" size_t rc_small_row_sums_workspace_bytes(int64_t n) {
          align_up((size_t)kSmallPlanWgs * (size_t)n * sizeof(uint32_t), 256) + align_up((size_t)kSmallPlanWgs * sizeof(SmallCnt), 256);
 }
 
-extern "C" int rc_small_row_sums(const int64_t* ids, int64_t n, int64_t n_rows, const float* src, int d, float* out, void* ws,
-                                 size_t ws_bytes, rc_stream_t stream) {
+static int small_row_sums_impl(bool build_plan, const int64_t* ids, int64_t n, int64_t n_rows, const float* src, int d, float* out, void* ws,
+                               size_t ws_bytes, rc_stream_t stream) {
   if (n == 0) return RC_OK;
-  RC_REQUIRE(ids && src && out && ws, "rc_small_row_sums: null pointer");
+  RC_REQUIRE((ids || !build_plan) && src && out && ws, "rc_small_row_sums: null pointer");
   if (!rc_small_row_sums_supported(n, n_rows, d))
     return fail(RC_ERR_UNSUPPORTED, "rc_small_row_sums: n=%lld (<= %d), n_rows=%lld, d=%d (1..4, 16, 32, 64, 128) not covered",
                 (long long)n, kSmallMaxKeys, (long long)n_rows, d);
@@ -420,23 +420,25 @@ extern "C" int rc_small_row_sums(const int64_t* ids, int64_t n, int64_t n_rows, 
   rc_plan_row* rows = cv.take<rc_plan_row>((size_t)kSmallPlanWgs * (size_t)n);
   uint32_t* occ = cv.take<uint32_t>((size_t)kSmallPlanWgs * (size_t)n);
   SmallCnt* cnt = cv.take<SmallCnt>(kSmallPlanWgs);
-  SmallPlanArgs p;
-  memset(&p, 0, sizeof(p));
-  p.ids_a = ids; p.ids_b = nullptr; p.n_a = (uint32_t)n; p.n = (uint32_t)n; p.base_b = 0xFFFFFFFFu;   // one list: every key is a row of it
-  p.rows = rows; p.occ = occ; p.cnt = cnt;
-  {   // function attributes are per device: once per device of the process, under a lock (callers may drive several GPUs / threads)
-    static std::mutex mu;
-    static bool done[64] = {};
-    int dev = 0;
-    RC_HIP(hipGetDevice(&dev));
-    std::lock_guard<std::mutex> lock(mu);
-    if (dev < 0 || dev >= 64 || !done[dev]) {
-      RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(small_plan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSmallLdsBytesBig));
-      if (dev >= 0 && dev < 64) done[dev] = true;
+  if (build_plan) {
+    SmallPlanArgs p;
+    memset(&p, 0, sizeof(p));
+    p.ids_a = ids; p.ids_b = nullptr; p.n_a = (uint32_t)n; p.n = (uint32_t)n; p.base_b = 0xFFFFFFFFu;   // one list: every key is a row of it
+    p.rows = rows; p.occ = occ; p.cnt = cnt;
+    {   // function attributes are per device: once per device of the process, under a lock (callers may drive several GPUs / threads)
+      static std::mutex mu;
+      static bool done[64] = {};
+      int dev = 0;
+      RC_HIP(hipGetDevice(&dev));
+      std::lock_guard<std::mutex> lock(mu);
+      if (dev < 0 || dev >= 64 || !done[dev]) {
+        RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(small_plan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSmallLdsBytesBig));
+        if (dev >= 0 && dev < 64) done[dev] = true;
+      }
     }
+    hipLaunchKernelGGL(small_plan_kernel, dim3(kSmallPlanWgs), dim3(kSmallThreads), kSmallLdsBytesBig, s, p);
+    RC_LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL(small_plan_kernel, dim3(kSmallPlanWgs), dim3(kSmallThreads), kSmallLdsBytesBig, s, p);
-  RC_LAUNCH_CHECK();
   SmallSumArgs a;
   a.rows = rows; a.occ = occ; a.cnt = cnt; a.n = (uint32_t)n; a.src = src; a.out = out; a.d = d;
   if (d <= 4) {
@@ -456,4 +458,14 @@ extern "C" int rc_small_row_sums(const int64_t* ids, int64_t n, int64_t n_rows, 
   }
   RC_LAUNCH_CHECK();
   return RC_OK;
+}
+
+extern "C" int rc_small_row_sums(const int64_t* ids, int64_t n, int64_t n_rows, const float* src, int d, float* out, void* ws,
+                                 size_t ws_bytes, rc_stream_t stream) {
+  return small_row_sums_impl(true, ids, n, n_rows, src, d, out, ws, ws_bytes, stream);
+}
+
+extern "C" int rc_small_row_sums_again(int64_t n, int64_t n_rows, const float* src, int d, float* out, void* ws, size_t ws_bytes,
+                                       rc_stream_t stream) {
+  return small_row_sums_impl(false, nullptr, n, n_rows, src, d, out, ws, ws_bytes, stream);
 }

@@ -47,25 +47,31 @@ struct TailFwdArgs {
 
 __device__ __forceinline__ float4 tt_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
-__global__ __launch_bounds__(kBlock) void tower_tail_fwd_kernel(TailFwdArgs a) {
+constexpr int kTailFwdThreads = 512;   // 8 waves: column slab w = wave & 3, half kh = wave >> 2 of the reduction
+
+__global__ __launch_bounds__(kTailFwdThreads) void tower_tail_fwd_kernel(TailFwdArgs a) {
   __shared__ float zs[4][kTailRows];
+  __shared__ tt4 half1[4][64];     // the accumulators of the second half of the reduction
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
+  const int w = wave & 3, kh = wave >> 2;
   const int64_t r0 = (int64_t)blockIdx.x * kTailRows;
-  const bool active = 16 * wave < a.N2;
+  const bool active = 16 * w < a.N2;
   tt4 acc = {0.f, 0.f, 0.f, 0.f};
   if (active) {
     int64_t row = r0 + i;
     if (row >= a.M) row = a.M - 1;                 // a tail row multiplies the last row; nothing of it is stored
     const float* xa = a.X + row * a.K + 4 * g;     // A(row i, k): X[r0 + i][k]
-    const float* wb = a.W2 + (int64_t)(16 * wave + i) * a.K + 4 * g;   // B(k, col i): W2[16 w + i][k]
+    const float* wb = a.W2 + (int64_t)(16 * w + i) * a.K + 4 * g;   // B(k, col i): W2[16 w + i][k]
     // MFMA e of K step s contracts k = 16 s + 4 g' + e for the four lane groups g' (both operands agree: any order of the
-    // reduction index is a valid product)
+    // reduction index is a valid product).  K = 512: 16 steps per half, i.e. both register sets are requested before the first
+    // MFMA -- ONE operand round trip per workgroup (four waves walking all 32 steps paid four: 11.4 us per launch).
+    const int all_steps = a.K / 16, per = (all_steps + 1) / 2;
+    const int s_lo = kh * per, n_steps = (s_lo + per < all_steps ? s_lo + per : all_steps);
     float4 xa0[kTailU], wb0[kTailU], xa1[kTailU], wb1[kTailU];
-    const int n_steps = a.K / 16;
 #pragma unroll
     for (int u = 0; u < kTailU; ++u)
-      if (u < n_steps) { xa0[u] = tt_ld4(xa + 16 * u); wb0[u] = tt_ld4(wb + 16 * u); }
-    for (int s0 = 0; s0 < n_steps; s0 += 2 * kTailU) {
+      if (s_lo + u < n_steps) { xa0[u] = tt_ld4(xa + 16 * (s_lo + u)); wb0[u] = tt_ld4(wb + 16 * (s_lo + u)); }
+    for (int s0 = s_lo; s0 < n_steps; s0 += 2 * kTailU) {
 #pragma unroll
       for (int u = 0; u < kTailU; ++u)
         if (s0 + kTailU + u < n_steps) { xa1[u] = tt_ld4(xa + 16 * (s0 + kTailU + u)); wb1[u] = tt_ld4(wb + 16 * (s0 + kTailU + u)); }
@@ -86,17 +92,21 @@ __global__ __launch_bounds__(kBlock) void tower_tail_fwd_kernel(TailFwdArgs a) {
         }
     }
   }
-  // epilogue: acc[r] is (row r0 + 4 g + r, column n = 16 wave + i)
+  if (kh == 1) half1[w][lane] = acc;
+  __syncthreads();
+  // epilogue (first four waves): acc[r] is (row r0 + 4 g + r, column n = 16 w + i)
   float zp[4] = {0.f, 0.f, 0.f, 0.f};
-  if (active) {
-    const int n = 16 * wave + i;
+  if (active && kh == 0) {
+    const tt4 h = half1[w][lane];
+    acc[0] += h[0]; acc[1] += h[1]; acc[2] += h[2]; acc[3] += h[3];
+    const int n = 16 * w + i;
     const float bn = a.b2 ? a.b2[n] : 0.f, wn = a.w3[n];
     float keep[4] = {1.f, 1.f, 1.f, 1.f};
     if (a.seed) {
-      uint32_t w[4];
-      philox4x32_10(*a.seed, (uint64_t)((r0 + 4 * g) >> 2), a.site * 65536u + (uint32_t)n, w);
+      uint32_t wd[4];
+      philox4x32_10(*a.seed, (uint64_t)((r0 + 4 * g) >> 2), a.site * 65536u + (uint32_t)n, wd);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) keep[e] = w[e] < a.drop_thresh ? 0.f : a.keep_scale;
+      for (int e = 0; e < 4; ++e) keep[e] = wd[e] < a.drop_thresh ? 0.f : a.keep_scale;
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -107,16 +117,18 @@ __global__ __launch_bounds__(kBlock) void tower_tail_fwd_kernel(TailFwdArgs a) {
       zp[r] = v * wn;
     }
   }
+  if (kh == 0) {
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const float t = row_allreduce_sum<16>(zp[r]);
-    if (i == 0) zs[wave][4 * g + r] = t;
+    for (int r = 0; r < 4; ++r) {
+      const float t = row_allreduce_sum<16>(zp[r]);
+      if (i == 0) zs[w][4 * g + r] = t;
+    }
   }
   __syncthreads();
   if (threadIdx.x < kTailRows) {
     const int64_t m = r0 + threadIdx.x;
     float t = zs[0][threadIdx.x];
-    for (int w = 1; 16 * w < a.N2; ++w) t += zs[w][threadIdx.x];
+    for (int q = 1; 16 * q < a.N2; ++q) t += zs[q][threadIdx.x];
     if (a.b3) t += a.b3[0];
     if (m < a.M) a.z[m] = t;
   }
@@ -158,6 +170,23 @@ __global__ __launch_bounds__(kBlock) void tower_tail_bwd_kernel(TailBwdArgs a) {
   float4 w3v = make_float4(0.f, 0.f, 0.f, 0.f);
   if (zrole) w3v = tt_ld4(a.w3 + 4 * tn);
   float sb2[4] = {0.f, 0.f, 0.f, 0.f}, sw3[4] = {0.f, 0.f, 0.f, 0.f}, sb3 = 0.f;
+  // Product 1's weights do not depend on the row block: requested ONCE, before anything is staged, one float4 per (n, 64-column
+  // group) -- the lane's four columns 64 J + 4 i + c.  MFMA column i of "slab" c then stands for column 64 J + 4 i + c (any
+  // assignment of columns to MFMA lanes is a valid product), so a lane ends up with four ADJACENT columns of its rows: float4
+  // mask reads and float4 stores.  (First version: one scalar load per MFMA, requested slab by slab behind the barrier -- eight
+  // dependent round trips, 24.5 us per launch.)
+  constexpr int NJ = (KS + 3) / 4;    // 64-column groups J = wave + 4 jj of this wave
+  float4 wv[NJ][NA][4];
+  if (a.dX != nullptr) {
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj)
+      if (wave + 4 * jj < KS) {
+#pragma unroll
+        for (int q = 0; q < NA; ++q)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) wv[jj][q][e] = tt_ld4(a.W2 + (int64_t)(16 * q + 4 * g + e) * K + 64 * (wave + 4 * jj) + 4 * i);
+      }
+  }
 
   for (int64_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
     const int64_t r0 = blk * kTailRows;
@@ -195,24 +224,33 @@ __global__ __launch_bounds__(kBlock) void tower_tail_bwd_kernel(TailBwdArgs a) {
         za[q][0] = v.x; za[q][1] = v.y; za[q][2] = v.z; za[q][3] = v.w;
       }
 #pragma unroll
-      for (int j = 0; j < KS; ++j) {
-        const int col = 16 * (wave + 4 * j) + i;
-        float wv[NA][4];
+      for (int jj = 0; jj < NJ; ++jj) {
+        const int J = wave + 4 * jj;
+        if (J < KS) {
+          tt4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0, c2 = c0, c3 = c0;
 #pragma unroll
-        for (int q = 0; q < NA; ++q)
+          for (int q = 0; q < NA; ++q)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) wv[q][e] = a.W2[(int64_t)(16 * q + 4 * g + e) * K + col];
-        tt4 c = {0.f, 0.f, 0.f, 0.f};
+            for (int e = 0; e < 4; ++e) {
+              c0 = tt_mma(za[q][e], wv[jj][q][e].x, c0);
+              c1 = tt_mma(za[q][e], wv[jj][q][e].y, c1);
+              c2 = tt_mma(za[q][e], wv[jj][q][e].z, c2);
+              c3 = tt_mma(za[q][e], wv[jj][q][e].w, c3);
+            }
+          const int col = 64 * J + 4 * i;
 #pragma unroll
-        for (int q = 0; q < NA; ++q)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) c = tt_mma(za[q][e], wv[q][e], c);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int64_t m = r0 + 4 * g + r;
-          float v = c[r];
-          if (a.x_act) v = Xs[(4 * g + r) * LX + col] > 0.f ? v * a.x_scale : 0.f;
-          if (m < a.M) a.dX[m * K + col] = v;
+          for (int r = 0; r < 4; ++r) {
+            const int64_t m = r0 + 4 * g + r;
+            float4 v = make_float4(c0[r], c1[r], c2[r], c3[r]);
+            if (a.x_act) {
+              const float4 x = *reinterpret_cast<const float4*>(Xs + (4 * g + r) * LX + col);
+              v.x = x.x > 0.f ? v.x * a.x_scale : 0.f;
+              v.y = x.y > 0.f ? v.y * a.x_scale : 0.f;
+              v.z = x.z > 0.f ? v.z * a.x_scale : 0.f;
+              v.w = x.w > 0.f ? v.w * a.x_scale : 0.f;
+            }
+            if (m < a.M) *reinterpret_cast<float4*>(a.dX + m * K + col) = v;
+          }
         }
       }
     }
@@ -324,7 +362,7 @@ extern "C" int rc_tower_tail_fwd(const float* X, const float* W2, const float* b
   }
   const int64_t blocks = (M + kTailRows - 1) / kTailRows;
   RC_REQUIRE(blocks < kMaxGridX, "rc_tower_tail_fwd: batch too large");
-  hipLaunchKernelGGL(tower_tail_fwd_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, as_stream(stream), a);
+  hipLaunchKernelGGL(tower_tail_fwd_kernel, dim3((unsigned)blocks), dim3(kTailFwdThreads), 0, as_stream(stream), a);
   RC_LAUNCH_CHECK();
   return RC_OK;
 }
@@ -346,8 +384,9 @@ extern "C" int rc_tower_tail_bwd(const float* X, const float* W2, const float* w
   RC_REQUIRE(ws != nullptr && ws_bytes >= rc_tower_tail_workspace_bytes(M, K, N2), "rc_tower_tail_bwd: workspace %zu < %zu", ws_bytes,
              rc_tower_tail_workspace_bytes(M, K, N2));
   RC_REQUIRE(drop_p >= 0.f && drop_p < 1.f && x_drop_p >= 0.f && x_drop_p < 1.f, "rc_tower_tail_bwd: dropout p outside [0, 1)");
-  RC_REQUIRE(reinterpret_cast<uintptr_t>(X) % 16 == 0 && reinterpret_cast<uintptr_t>(H2) % 16 == 0 && reinterpret_cast<uintptr_t>(w3) % 16 == 0,
-             "rc_tower_tail_bwd: X / H2 / w3 must be 16-byte aligned");
+  RC_REQUIRE(reinterpret_cast<uintptr_t>(X) % 16 == 0 && reinterpret_cast<uintptr_t>(H2) % 16 == 0 && reinterpret_cast<uintptr_t>(w3) % 16 == 0 &&
+                 reinterpret_cast<uintptr_t>(W2) % 16 == 0 && (dX == nullptr || reinterpret_cast<uintptr_t>(dX) % 16 == 0),
+             "rc_tower_tail_bwd: X / W2 / H2 / w3 / dX must be 16-byte aligned");
   const int parts = tail_parts(M);
   TailBwdArgs a;
   memset(&a, 0, sizeof(a));

@@ -441,10 +441,17 @@ def unique_ids(ids, n_rows, tag="unique"):
     return uniq[:int(cnt.item())], inverse
 
 
-def embedding_dense_backward(grad_out, ids, n_rows, route=None, presorted=None):
+def small_route_ok(n_ids, n_rows, d):
+    """embedding_dense_backward(route="small") takes rc_small_row_sums for this shape"""
+    return bool(_EDB_SMALL and 0 < n_ids <= _EDB_SMALL_MAX and _lib.load().rc_small_row_sums_supported(int(n_ids), int(n_rows), int(d)))
+
+
+def embedding_dense_backward(grad_out, ids, n_rows, route=None, presorted=None, small_again=False, small_tag="edb_small"):
     """aten::embedding_dense_backward: G [n_rows, d] = index_add of the per-occurrence gradient rows, in ascending
     position order per row (no float atomics) -- bucket plan + rc_plan_row_sums; radix sort + segmented sum where no
-    plan geometry exists.  presorted = sort_ids(ids, n_rows) of a caller that sorted the same ids already (route "sort")."""
+    plan geometry exists.  presorted = sort_ids(ids, n_rows) of a caller that sorted the same ids already (route "sort").
+    route "small" with small_again=True: the caller vouches that the preceding call on workspace `small_tag` grouped these very
+    ids (a second table family gathered with the same ids): only the row sums run (rc_small_row_sums_again)."""
     d = grad_out.shape[-1]
     flat = ids.reshape(-1)
     G = torch.zeros((n_rows, d), dtype=torch.float32, device=grad_out.device)
@@ -457,10 +464,14 @@ def embedding_dense_backward(grad_out, ids, n_rows, route=None, presorted=None):
     # with thousands of occurrences (the padding id of a padded history: measured 0.27 against 0.11 s per SASRec epoch) is still
     # summed by ONE wave there, which is why the caller has to ask for this route
     n_ids = flat.numel()
-    if route == "small" and _EDB_SMALL and n_ids <= _EDB_SMALL_MAX and _lib.load().rc_small_row_sums_supported(n_ids, int(n_rows), d):
-        ws = workspace(_lib.load().rc_small_row_sums_workspace_bytes(n_ids), go.device, "edb_small")
-        _lib.call("rc_small_row_sums", _ptr(flat, torch.int64, "ids"), n_ids, int(n_rows), _ptr(go, torch.float32, "grad_out"), d,
-                  _ptr(G, torch.float32, "G"), C.c_void_p(ws.data_ptr()), ws.numel(), _stream())
+    if route == "small" and small_route_ok(n_ids, n_rows, d):
+        ws = workspace(_lib.load().rc_small_row_sums_workspace_bytes(n_ids), go.device, small_tag)
+        if small_again:
+            _lib.call("rc_small_row_sums_again", n_ids, int(n_rows), _ptr(go, torch.float32, "grad_out"), d,
+                      _ptr(G, torch.float32, "G"), C.c_void_p(ws.data_ptr()), ws.numel(), _stream())
+        else:
+            _lib.call("rc_small_row_sums", _ptr(flat, torch.int64, "ids"), n_ids, int(n_rows), _ptr(go, torch.float32, "grad_out"), d,
+                      _ptr(G, torch.float32, "G"), C.c_void_p(ws.data_ptr()), ws.numel(), _stream())
         return G
     # (below a few thousand ids both routes are a handful of latency-bound launches; the plan pays off with the batch)
     # route="sort": id lists with very hot rows (the categorical fields of the CTR models: 131,072 occurrences of 7 weekdays) --

@@ -221,6 +221,7 @@ class _FieldGatherFn(torch.autograd.Function):
     # themselves (identity + version are compared, never addresses: a freed tensor's address can come back).
     _last_cid = None      # (ids tuple, versions, n_cand, offsets, cid)
     _last_sort = None     # (cid, n_rows, keys, perm)
+    _last_small = None    # (cid, n_rows): the small route's grouping of these keys sits in the workspace "edb_small_fields"
 
     @staticmethod
     def forward(ctx, n_cand, n_fields, *args):
@@ -241,6 +242,7 @@ class _FieldGatherFn(torch.autograd.Function):
             cid = last[4]
         else:
             _FieldGatherFn._last_sort = None
+            _FieldGatherFn._last_small = None
             if torch.is_grad_enabled():
                 _FieldGatherFn._last_cid = (tuple(ids_c), tuple(x._version for x in ids_c), n_cand, offs_now, cid)
         ctx.cid, ctx.offs = cid, offs
@@ -263,8 +265,15 @@ class _FieldGatherFn(torch.autograd.Function):
             else:
                 presorted = engine.sort_ids(ctx.cid.reshape(-1), offs[-1])
                 _FieldGatherFn._last_sort = (ctx.cid, offs[-1]) + tuple(presorted)
-        G = engine.embedding_dense_backward(gout.contiguous(), ctx.cid, offs[-1], route=ctx.route,
-                                            presorted=presorted)  # virtual concatenated table
+        again = False
+        if ctx.route == "small" and engine.small_route_ok(ctx.cid.numel(), offs[-1], gout.shape[-1]):
+            # the small route groups the composite keys in its first launch: the second family gathered with the same keys
+            # (same key tensor, nothing else used that workspace in between: it has a tag of its own) runs the sums only
+            last = _FieldGatherFn._last_small
+            again = last is not None and last[0] is ctx.cid and last[1] == offs[-1]
+            _FieldGatherFn._last_small = None if again else (ctx.cid, offs[-1])
+        G = engine.embedding_dense_backward(gout.contiguous(), ctx.cid, offs[-1], route=ctx.route, presorted=presorted,
+                                            small_again=again, small_tag="edb_small_fields")  # virtual concatenated table
         grads = tuple(G[offs[f]:offs[f + 1]] for f in range(len(offs) - 1))
         return (None, None) + (None,) * len(grads) + grads
 

@@ -96,11 +96,14 @@ def test_linear_is_deterministic_and_matches_torch_modules(cuda, eng):
 
 @pytest.mark.parametrize("M,widths,p", [(300, (96, 512, 64, 1), 0.0), (1024, (512, 512, 64), 0.3), (66000, (64, 512, 130), 0.0),
                                         (20000, (128, 256, 128, 8), 0.25)])
-def test_mlp_chain_with_fused_masks_equals_layer_by_layer(M, widths, p, cuda, eng):
+def test_mlp_chain_with_fused_masks_equals_layer_by_layer(M, widths, p, cuda, eng, monkeypatch):
     """the whole-MLP autograd node (rc_linear_bwd_chain: the dX product of layer i + 1 applies layer i's ReLU / dropout mask in its
     epilogue) against one autograd node per layer with the separate masking pass (rc_linear_bwd): same products, same mask
     arithmetic -- every gradient bit-identical; small and 128 x 128-tile shapes, split-K shapes, with and without dropout"""
     from rechorus_amd import nn as hnn
+    # (the products compared bit for bit are the GEMM route's: a tower that ends hidden <= 64 -> 1 at a small batch takes the
+    #  tower-tail kernels instead, held to the same reference in tests/test_gpu_tower_tail.py)
+    monkeypatch.setattr(eng, "_TOWER_TAIL", False)
     torch.manual_seed(M)
     lins = [torch.nn.Linear(a, b).to(cuda) for a, b in zip(widths[:-1], widths[1:])]
     mods = []
@@ -146,15 +149,16 @@ def test_mlp_block_runs_on_the_engine_and_draws_fresh_masks(cuda):
     assert list(blk.state_dict()) == ["mlp.0.weight", "mlp.0.bias", "mlp.3.weight", "mlp.3.bias", "mlp.6.weight", "mlp.6.bias"]
     x = torch.randn(200, 40, device=cuda)
     calls = []
-    real = hnn.engine.linear_fwd
+    real, real_tail = hnn.engine.linear_fwd, hnn.engine.tower_tail_fwd
     hnn.engine.linear_fwd = lambda *a, **k: calls.append(1) or real(*a, **k)
+    hnn.engine.tower_tail_fwd = lambda *a, **k: calls.append(2) or real_tail(*a, **k)   # (the last hidden layer + the output layer)
     try:
         blk.train()
         a, b = blk(x), blk(x)
         blk.eval()
         e1, e2 = blk(x), blk(x)
     finally:
-        hnn.engine.linear_fwd = real
-    assert len(calls) == 12 and not torch.equal(a, b) and torch.equal(e1, e2)
+        hnn.engine.linear_fwd, hnn.engine.tower_tail_fwd = real, real_tail
+    assert sum(calls) == 12 and calls.count(2) == 4 and not torch.equal(a, b) and torch.equal(e1, e2)
     want = blk.mlp(x)  # torch's modules in eval mode: same parameters
     assert_close(e1.detach().cpu().numpy(), want.detach().cpu().numpy(), what="eval vs torch modules", rtol=1e-4, abs_floor=1e-5)
