@@ -116,6 +116,11 @@ int rc_fm_second_order_bwd_add(const float* V, const float* gout, int64_t n, int
 int rc_gather_fields(const float* const* tables, const int64_t* const* ids, const int* per_row,
                      const int64_t* row_offset, int F, int64_t B, int C, int d, float* out, int64_t* cid,
                      rc_stream_t stream);
+/* rc_gather_fields for the TWO table families the FM models gather with the same ids (models/context/FM.py:44-57: the [vocab, d]
+ * field vectors and the [vocab, 1] first-order weights): out [B, C, F, d] and out1 [B, C, F] in one launch.                      */
+int rc_gather_fields_pair(const float* const* tables, const float* const* tables1, const int64_t* const* ids, const int* per_row,
+                          const int64_t* row_offset, int F, int64_t B, int C, int d, float* out, float* out1, int64_t* cid,
+                          rc_stream_t stream);
 
 /* nn.BCELoss on probabilities (CTRModel.loss, models/BaseModel.py:259-267), torch's log clamp (-100) and
  * backward denominator clamp (1e-12): loss_vec[i] = -(y log p + (1-y) log(1-p)); gp[i] = dmean/dp_i
@@ -366,6 +371,15 @@ int rc_small_row_sums_again(int64_t n, int64_t n_rows, const float* src, int d, 
  * lin [n, F] first-order values; term1 / term2 [n] or NULL; label int64 {0, 1}.                                          */
 int rc_ctr_head_fwd_bwd(const float* bias, const float* lin, int F, const float* term1, const float* term2,
                         const int64_t* label, int64_t n, float* p, float* loss_vec, float* gz, rc_stream_t stream);
+/* rc_ctr_head_fwd_bwd for n <= 65,536 rows in ONE workgroup that also forms sums[0] = the BCE loss (mean of loss_vec, nn.BCELoss's
+ * reduction, BaseModel.py:262-267) and sums[1] = sum gz (= d loss / d overall_bias) -- two launches fewer per step; and the
+ * backward fan-out of the head: g [n] = gz g_loss[0], g_lin [n, F] = g broadcast over the F first-order weights of a row
+ * (contiguous), g_bias [1] = sums[1] g_loss[0] (autograd's mul / sum / expand-copy in one launch).                              */
+int rc_ctr_head_fwd_bwd_sums(const float* bias, const float* lin, int F, const float* term1, const float* term2,
+                             const int64_t* label, int64_t n, float* p, float* loss_vec, float* gz, float* sums,
+                             rc_stream_t stream);
+int rc_ctr_head_bwd(const float* gz, const float* sums, const float* g_loss, int64_t n, int F, float* g, float* g_lin,
+                    float* g_bias, rc_stream_t stream);
 
 /* ---- SASRec encoder (models/sequential/SASRec.py:51-86, utils/layers.py:9-63,92-118) ------- */
 

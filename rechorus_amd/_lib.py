@@ -82,6 +82,7 @@ SIGNATURES = {
     "rc_fm_second_order_bwd": (_i, [_p, _p, _i64, _i, _i, _p, _p]),
     "rc_fm_second_order_bwd_add": (_i, [_p, _p, _i64, _i, _i, _p, _p, _p]),
     "rc_gather_fields": (_i, [_p, _p, _p, _p, _i, _i64, _i, _i, _p, _p, _p]),
+    "rc_gather_fields_pair": (_i, [_p, _p, _p, _p, _p, _i, _i64, _i, _i, _p, _p, _p, _p]),
     "rc_bce_ranking_fwd_bwd": (_i, [_p, _i64, _i, _f, _p, _p, _p]),
     "rc_bce_prob_fwd_bwd": (_i, [_p, _p, _i64, _f, _p, _p, _p]),
     "rc_sample_negatives": (_i, [_p, _i64, _i, _i64, _p, _p, C.c_uint64, C.c_uint64, _p, _p]),
@@ -112,6 +113,8 @@ SIGNATURES = {
     "rc_segmented_update2": (_i, [_p, _p, _p, _i, _p, _p, _i64, _p, _p, _p, _i, _p, _i64, _i64, _i64, _hp, _p, _p,
                                   _p, _i, _p, _sz, _p]),
     "rc_ctr_head_fwd_bwd": (_i, [_p, _p, _i, _p, _p, _p, _i64, _p, _p, _p, _p]),
+    "rc_ctr_head_fwd_bwd_sums": (_i, [_p, _p, _i, _p, _p, _p, _i64, _p, _p, _p, _p, _p]),
+    "rc_ctr_head_bwd": (_i, [_p, _p, _p, _i64, _i, _p, _p, _p, _p]),
     "rc_small_row_sums_supported": (_i, [_i64, _i64, _i]),
     "rc_small_row_sums_workspace_bytes": (_sz, [_i64]),
     "rc_small_row_sums": (_i, [_p, _i64, _i64, _p, _i, _p, _p, _sz, _p]),

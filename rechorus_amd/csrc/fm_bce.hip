@@ -147,9 +147,92 @@ __global__ __launch_bounds__(kBlock) void ctr_head_kernel(const float* __restric
   }
 }
 
+// The same with the two sums the step needs next to it: loss = mean of the loss terms (nn.BCELoss's reduction) and sum gz (the
+// gradient of overall_bias), in ONE workgroup for a batch of the reference's size -- a thread walks its rows in ascending order,
+// the threads' partials meet in a fixed LDS tree.  (reduce_sum for the loss and torch's sum for the bias were two more launches of
+// ~4.7 us in a replayed step whose arithmetic takes 1 us.)
+constexpr int kCtrOneWg = 1024;
+__global__ __launch_bounds__(kCtrOneWg) void ctr_head_sums_kernel(const float* __restrict__ bias, const float* __restrict__ lin, int F,
+                                                                const float* __restrict__ t1, const float* __restrict__ t2,
+                                                                const int64_t* __restrict__ y, int64_t n, float inv_n,
+                                                                float* __restrict__ p_out, float* __restrict__ loss_vec,
+                                                                float* __restrict__ gz, float* __restrict__ sums /* loss mean, sum gz */) {
+  __shared__ float red[2][kCtrOneWg];
+  const float b0 = bias[0];
+  float sl_loss = 0.f, sl_gz = 0.f;
+  for (int64_t i = threadIdx.x; i < n; i += kCtrOneWg) {
+    float sl = 0.f;
+    for (int f = 0; f < F; ++f) sl += lin[i * F + f];
+    float z = b0 + sl;
+    if (t1) z += t1[i];
+    if (t2) z += t2[i];
+    const float pi = 1.0f / (1.0f + expf(-z));
+    const float yi = (float)y[i];
+    const float lp = fmaxf(logf(pi), -100.f), lq = fmaxf(log1pf(-pi), -100.f);
+    const float li = -(yi * lp + (1.0f - yi) * lq);
+    p_out[i] = pi;
+    loss_vec[i] = li;
+    const float gp = (pi - yi) / fmaxf((1.0f - pi) * pi, 1e-12f) * inv_n;
+    const float gi = gp * (1.0f - pi) * pi;
+    gz[i] = gi;
+    sl_loss += li;
+    sl_gz += gi;
+  }
+  red[0][threadIdx.x] = sl_loss;
+  red[1][threadIdx.x] = sl_gz;
+  __syncthreads();
+  for (int s = kCtrOneWg / 2; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+      red[0][threadIdx.x] += red[0][threadIdx.x + s];
+      red[1][threadIdx.x] += red[1][threadIdx.x + s];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    sums[0] = red[0][0] * inv_n;
+    sums[1] = red[1][0];
+  }
+}
+
+// backward fan-out of the head: g = gz * g_loss[0] to the [n] terms, the same value to each of the F first-order weights of a row
+// (written out as the contiguous [n, F] block the field-gradient kernels read), d bias = (sum gz) * g_loss[0]
+__global__ __launch_bounds__(kBlock) void ctr_head_bwd_kernel(const float* __restrict__ gz, const float* __restrict__ sums,
+                                                              const float* __restrict__ g_loss, int64_t n, int F, float* __restrict__ g,
+                                                              float* __restrict__ g_lin, float* __restrict__ g_bias) {
+  const float gl = g_loss[0];
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    const float v = gz[i] * gl;
+    g[i] = v;
+    for (int f = 0; f < F; ++f) g_lin[i * F + f] = v;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) g_bias[0] = sums[1] * gl;
+}
+
 }  // namespace rc
 
 using namespace rc;
+
+extern "C" int rc_ctr_head_fwd_bwd_sums(const float* bias, const float* lin, int F, const float* term1, const float* term2,
+                                        const int64_t* label, int64_t n, float* p, float* loss_vec, float* gz, float* sums,
+                                        rc_stream_t stream) {
+  RC_REQUIRE(bias && lin && label && p && loss_vec && gz && sums, "rc_ctr_head_fwd_bwd_sums: null pointer");
+  RC_REQUIRE(n > 0 && n <= 65536 && F >= 1, "rc_ctr_head_fwd_bwd_sums: n=%lld (1 .. 65,536 rows: one workgroup) F=%d", (long long)n, F);
+  hipLaunchKernelGGL(ctr_head_sums_kernel, dim3(1), dim3(kCtrOneWg), 0, as_stream(stream), bias, lin, F, term1, term2, label, n,
+                     1.0f / (float)n, p, loss_vec, gz, sums);
+  RC_LAUNCH_CHECK();
+  return RC_OK;
+}
+
+extern "C" int rc_ctr_head_bwd(const float* gz, const float* sums, const float* g_loss, int64_t n, int F, float* g, float* g_lin,
+                               float* g_bias, rc_stream_t stream) {
+  RC_REQUIRE(gz && sums && g_loss && g && g_lin && g_bias, "rc_ctr_head_bwd: null pointer");
+  RC_REQUIRE(n > 0 && F >= 1, "rc_ctr_head_bwd: bad shape n=%lld F=%d", (long long)n, F);
+  int64_t blocks = (n + kBlock - 1) / kBlock;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(ctr_head_bwd_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, as_stream(stream), gz, sums, g_loss, n, F, g, g_lin, g_bias);
+  RC_LAUNCH_CHECK();
+  return RC_OK;
+}
 
 extern "C" int rc_ctr_head_fwd_bwd(const float* bias, const float* lin, int F, const float* term1, const float* term2,
                                    const int64_t* label, int64_t n, float* p, float* loss_vec, float* gz, rc_stream_t stream) {
@@ -252,6 +335,7 @@ struct FieldArgs {
   const int64_t* ids[kMaxFields];
   int64_t row_offset[kMaxFields];
   int per_row[kMaxFields];  // 1: ids [B] (user / situation field, broadcast over candidates); 0: ids [B, C]
+  const float* table1[kMaxFields];   // rc_gather_fields_pair: the [vocab, 1] tables gathered with the same ids (FM.py:44-57), else unused
   int F;
   int C;
   int d;
@@ -264,7 +348,7 @@ struct FieldArgs {
 // the compiler keeps such an array in scratch -- and paid three 64-bit divisions per element: 93 us for 268 MB out at B = 131,072.)
 template <int VEC>
 __global__ __launch_bounds__(kBlock) void gather_fields_kernel(FieldArgs a, float* __restrict__ out,
-                                                               int64_t* __restrict__ cid) {
+                                                               int64_t* __restrict__ cid, float* __restrict__ out1) {
   const int dq = a.d / VEC;
   const int64_t total = a.n * dq;
   for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += (int64_t)gridDim.x * kBlock) {
@@ -305,25 +389,38 @@ __global__ __launch_bounds__(kBlock) void gather_fields_kernel(FieldArgs a, floa
         for (int u = 0; u < U; ++u)
           if (f0 + u < a.F) cid[r * a.F + f0 + u] = a.row_offset[f0 + u] + id[u];
       }
+      if (q == 0 && out1) {   // the first-order weights of the same ids: [n, F]
+        float w1[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int f = f0 + u < a.F ? f0 + u : a.F - 1;
+          w1[u] = a.table1[f][id[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          if (f0 + u < a.F) out1[r * a.F + f0 + u] = w1[u];
+      }
     }
   }
 }
 
 }  // namespace rc
 
-extern "C" int rc_gather_fields(const float* const* tables, const int64_t* const* ids, const int* per_row,
-                                const int64_t* row_offset, int F, int64_t B, int C, int d, float* out, int64_t* cid,
-                                rc_stream_t stream) {
+static int gather_fields_impl(const float* const* tables, const float* const* tables1, const int64_t* const* ids, const int* per_row,
+                              const int64_t* row_offset, int F, int64_t B, int C, int d, float* out, float* out1, int64_t* cid,
+                              rc_stream_t stream) {
   if (B == 0) return RC_OK;
   RC_REQUIRE(tables && ids && per_row && row_offset && out, "rc_gather_fields: null pointer");
+  RC_REQUIRE((tables1 == nullptr) == (out1 == nullptr), "rc_gather_fields_pair: the second table family and its output come together");
   RC_REQUIRE(F >= 1 && F <= kMaxFields, "rc_gather_fields: F must be in [1, %d], got %d", kMaxFields, F);
   RC_REQUIRE(B > 0 && C >= 1 && d >= 1, "rc_gather_fields: bad shape B=%lld C=%d d=%d", (long long)B, C, d);
   FieldArgs a;
   memset(&a, 0, sizeof(a));
   bool vec = d % 4 == 0 && reinterpret_cast<uintptr_t>(out) % 16 == 0;
   for (int f = 0; f < F; ++f) {
-    RC_REQUIRE(tables[f] && ids[f], "rc_gather_fields: null table / ids for field %d", f);
+    RC_REQUIRE(tables[f] && ids[f] && (!tables1 || tables1[f]), "rc_gather_fields: null table / ids for field %d", f);
     a.table[f] = tables[f];
+    a.table1[f] = tables1 ? tables1[f] : nullptr;
     a.ids[f] = ids[f];
     a.row_offset[f] = row_offset[f];
     a.per_row[f] = per_row[f];
@@ -334,11 +431,24 @@ extern "C" int rc_gather_fields(const float* const* tables, const int64_t* const
   int64_t blocks = (total + kBlock - 1) / kBlock;
   if (blocks > 256 * 32) blocks = 256 * 32;
   if (vec)
-    hipLaunchKernelGGL((gather_fields_kernel<4>), dim3((unsigned)blocks), dim3(kBlock), 0, as_stream(stream), a, out, cid);
+    hipLaunchKernelGGL((gather_fields_kernel<4>), dim3((unsigned)blocks), dim3(kBlock), 0, as_stream(stream), a, out, cid, out1);
   else
-    hipLaunchKernelGGL((gather_fields_kernel<1>), dim3((unsigned)blocks), dim3(kBlock), 0, as_stream(stream), a, out, cid);
+    hipLaunchKernelGGL((gather_fields_kernel<1>), dim3((unsigned)blocks), dim3(kBlock), 0, as_stream(stream), a, out, cid, out1);
   RC_LAUNCH_CHECK();
   return RC_OK;
+}
+
+extern "C" int rc_gather_fields(const float* const* tables, const int64_t* const* ids, const int* per_row,
+                                const int64_t* row_offset, int F, int64_t B, int C, int d, float* out, int64_t* cid,
+                                rc_stream_t stream) {
+  return gather_fields_impl(tables, nullptr, ids, per_row, row_offset, F, B, C, d, out, nullptr, cid, stream);
+}
+
+extern "C" int rc_gather_fields_pair(const float* const* tables, const float* const* tables1, const int64_t* const* ids, const int* per_row,
+                                     const int64_t* row_offset, int F, int64_t B, int C, int d, float* out, float* out1, int64_t* cid,
+                                     rc_stream_t stream) {
+  RC_REQUIRE(tables1 && out1, "rc_gather_fields_pair: null pointer");
+  return gather_fields_impl(tables, tables1, ids, per_row, row_offset, F, B, C, d, out, out1, cid, stream);
 }
 
 // ---- point-wise BCE over a ranking list (ContextModel.loss, loss_n == 'BCE': models/BaseContextModel.py:53-56)

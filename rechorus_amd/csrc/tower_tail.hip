@@ -9,11 +9,12 @@
 //   rc_tower_tail_fwd:  H2 = drop(relu(X W2^T + b2)) [M, N2] and z = H2 w3 + b3 [M]
 //   rc_tower_tail_bwd:  dZ2 = dz w3^T * mask(H2) (never stored), dX = (dZ2 W2) * mask(X), dW2 = dZ2^T X, db2, dw3 = H2^T dz, db3
 // A workgroup owns 16 batch rows (one v_mfma_f32_16x16x4_f32 row block; exact fp32 FMA chains like every product of the engine).
-// Forward: wave w owns output columns 16 w .. 16 w + 15; both operands stream from L2 as one float4 per lane and K step of 16
-// (two 8-step register sets: one in flight while the other is multiplied); bias / ReLU / dropout in registers (the mask of
+// Forward: eight waves -- wave (w, kh) owns output columns 16 w .. 16 w + 15 and half kh of the reduction; both operands stream
+// from L2 as one float4 per lane and K step of 16, all of a wave's steps requested before its first MFMA (K <= 512); the halves
+// meet in LDS; bias / ReLU / dropout in registers (the mask of
 // rc_linear_fwd: element (m, n) dropped iff word (m & 3) of Philox4x32-10(seed, (m >> 2, site 65536 + n)) < p 2^32 -- the four
 // rows a lane holds share one Philox block), the output layer as a 16-lane DPP sum + a sum over the waves in LDS.
-// Backward: the row block's dZ2 and X go to LDS once; product 1 (reduction over N2) walks the K / 16 column slabs, its epilogue
+// Backward: the row block's dZ2 and X go to LDS once; product 1 (reduction over N2) walks 64-column groups, its epilogue
 // applies the mask of the layer below (X is that layer's saved output) -- what rc_linear_bwd_chain does in its dX product;
 // product 2 (reduction over the 16 rows) accumulates dW2 in registers across the row blocks of the workgroup; per-workgroup
 // partials are summed in fixed order by tower_tail_reduce_kernel.  No float atomics.
@@ -293,18 +294,40 @@ __global__ __launch_bounds__(kBlock) void tower_tail_bwd_kernel(TailBwdArgs a) {
   }
 }
 
-// out[i] = sum over the workgroups' partials, in workgroup order
+// out = sum over the workgroups' partials in a FIXED order: wave q of a workgroup adds the q-th quarter of the partials in
+// ascending order (independent loads, sixteen in flight), the four quarter sums are added in order q = 0..3.  (One thread per
+// element walking all 64 partials one load after the other took 16.8 us for the 64 x 512 weight gradient.)
 __global__ __launch_bounds__(kBlock) void tower_tail_reduce_kernel(const float* __restrict__ pW2, const float* __restrict__ pvec, int parts,
                                                                   int N2, int K, float* __restrict__ dW2, float* __restrict__ db2,
                                                                   float* __restrict__ dw3, float* __restrict__ db3) {
-  const int64_t nw = (int64_t)N2 * K, nv = 2 * N2 + 1;
-  for (int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x; k < nw + nv; k += (int64_t)gridDim.x * kBlock) {
-    float t = 0.f;
-    if (k < nw) {
-      for (int p = 0; p < parts; ++p) t += pW2[(size_t)p * nw + k];
-      dW2[k] = t;
-    } else {
-      const int64_t v = k - nw;
+  __shared__ float4 sm[4][64];
+  const int q = threadIdx.x >> 6, o = threadIdx.x & 63;
+  const int64_t nw4 = (int64_t)N2 * K / 4;
+  const int per = (parts + 3) / 4, p0 = q * per, p1 = (p0 + per < parts ? p0 + per : parts);
+  const float4* src = reinterpret_cast<const float4*>(pW2);
+  for (int64_t base = (int64_t)blockIdx.x * 64; base < nw4; base += (int64_t)gridDim.x * 64) {
+    const int64_t idx = base + o;
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (idx < nw4) {
+#pragma unroll 16
+      for (int p = p0; p < p1; ++p) {
+        const float4 v = src[(size_t)p * nw4 + idx];
+        t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+      }
+    }
+    sm[q][o] = t;
+    __syncthreads();
+    if (q == 0 && idx < nw4) {
+      const float4 a = sm[0][o], b = sm[1][o], c = sm[2][o], d = sm[3][o];
+      reinterpret_cast<float4*>(dW2)[idx] = make_float4(((a.x + b.x) + c.x) + d.x, ((a.y + b.y) + c.y) + d.y, ((a.z + b.z) + c.z) + d.z,
+                                                        ((a.w + b.w) + c.w) + d.w);
+    }
+    __syncthreads();
+  }
+  if (blockIdx.x == 0) {
+    const int nv = 2 * N2 + 1;
+    for (int v = threadIdx.x; v < nv; v += kBlock) {
+      float t = 0.f;
       for (int p = 0; p < parts; ++p) t += pvec[(size_t)p * nv + v];
       if (v < N2) { if (db2) db2[v] = t; }
       else if (v < 2 * N2) dw3[v - N2] = t;
@@ -385,7 +408,7 @@ extern "C" int rc_tower_tail_bwd(const float* X, const float* W2, const float* w
              rc_tower_tail_workspace_bytes(M, K, N2));
   RC_REQUIRE(drop_p >= 0.f && drop_p < 1.f && x_drop_p >= 0.f && x_drop_p < 1.f, "rc_tower_tail_bwd: dropout p outside [0, 1)");
   RC_REQUIRE(reinterpret_cast<uintptr_t>(X) % 16 == 0 && reinterpret_cast<uintptr_t>(H2) % 16 == 0 && reinterpret_cast<uintptr_t>(w3) % 16 == 0 &&
-                 reinterpret_cast<uintptr_t>(W2) % 16 == 0 && (dX == nullptr || reinterpret_cast<uintptr_t>(dX) % 16 == 0),
+                 reinterpret_cast<uintptr_t>(W2) % 16 == 0 && reinterpret_cast<uintptr_t>(dW2) % 16 == 0 && (dX == nullptr || reinterpret_cast<uintptr_t>(dX) % 16 == 0),
              "rc_tower_tail_bwd: X / W2 / H2 / w3 / dX must be 16-byte aligned");
   const int parts = tail_parts(M);
   TailBwdArgs a;
@@ -405,8 +428,7 @@ extern "C" int rc_tower_tail_bwd(const float* X, const float* W2, const float* w
   RC_TT(4, 1); RC_TT(4, 2); RC_TT(4, 4); RC_TT(4, 8);
 #undef RC_TT
   RC_TRY(rc);
-  const int64_t total = (int64_t)N2 * K + 2 * N2 + 1;
-  int64_t blocks = (total + kBlock - 1) / kBlock;
+  int64_t blocks = ((int64_t)N2 * K / 4 + 63) / 64;
   if (blocks > 1024) blocks = 1024;
   hipLaunchKernelGGL(tower_tail_reduce_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, s, a.pW2, a.pvec, parts, N2, K, dW2, db2, dw3, db3);
   RC_LAUNCH_CHECK();

@@ -483,6 +483,22 @@ def embedding_dense_backward(grad_out, ids, n_rows, route=None, presorted=None, 
     return G
 
 
+def small_row_sums_pair(cid, n_rows, src_a, src_b):
+    """two dense gradients [n_rows, d_a], [n_rows, d_b] of per-occurrence rows src_a [n, d_a], src_b [n, d_b] that share their ids:
+    ONE zero fill (both live in one buffer), ONE grouping (rc_small_row_sums, then rc_small_row_sums_again for the second)"""
+    n = cid.numel()
+    d_a, d_b = src_a.shape[1], src_b.shape[1]
+    G = torch.zeros(n_rows * (d_a + d_b), dtype=torch.float32, device=src_a.device)
+    Ga, Gb = G[:n_rows * d_a].view(n_rows, d_a), G[n_rows * d_a:].view(n_rows, d_b)
+    ws = workspace(_lib.load().rc_small_row_sums_workspace_bytes(n), src_a.device, "edb_small_pair")
+    flat = cid.reshape(-1)
+    _lib.call("rc_small_row_sums", _ptr(flat, torch.int64, "ids"), n, int(n_rows), _ptr(src_a, torch.float32, "src_a"), d_a,
+              C.c_void_p(Ga.data_ptr()), C.c_void_p(ws.data_ptr()), ws.numel(), _stream())
+    _lib.call("rc_small_row_sums_again", n, int(n_rows), _ptr(src_b, torch.float32, "src_b"), d_b, C.c_void_p(Gb.data_ptr()),
+              C.c_void_p(ws.data_ptr()), ws.numel(), _stream())
+    return Ga, Gb
+
+
 def dense_update(W, G, hyper, m=None, v=None):
     """Exact torch.optim step over a whole tensor (helpers/BaseRunner.py:206)."""
     _lib.call("rc_dense_update", _ptr(W, torch.float32, "W"), _ptr(G, torch.float32, "G"),
@@ -1656,9 +1672,10 @@ def bce_ranking(pred, need_grad=True):
     return reduce_sum(loss_vec, 1.0 / B), gpred
 
 
-def gather_fields(tables, ids, n_cand, want_cid=True):
+def gather_fields(tables, ids, n_cand, want_cid=True, tables1=None):
     """tables: list of F [vocab_f, d] tensors; ids: list of F int64 tensors, [B] (per-row field) or [B, C]
-    -> (out [B, C, F, d], cid [B, C, F] | None, row_offset list): all field lookups in one launch"""
+    -> (out [B, C, F, d], cid [B, C, F] | None, row_offset list): all field lookups in one launch.
+    tables1: F [vocab_f, 1] tables looked up with the same ids (rc_gather_fields_pair) -> (out, out1 [B, C, F, 1], cid, offsets)"""
     F = len(tables)
     d = tables[0].shape[1]
     B = ids[0].shape[0]
@@ -1675,6 +1692,14 @@ def gather_fields(tables, ids, n_cand, want_cid=True):
     ids_arr = (C.c_void_p * F)(*[_ptr(x, i64, "ids").value for x in ids])
     per_row = (C.c_int * F)(*[1 if x.dim() == 1 else 0 for x in ids])
     off_arr = (C.c_int64 * F)(*offs)
+    if tables1 is not None:
+        if len(tables1) != F or any(t1.shape != (t.shape[0], 1) for t, t1 in zip(tables, tables1)):
+            raise ValueError("gather_fields: the second family must be [vocab_f, 1] tables of the same vocabularies")
+        out1 = torch.empty((B, n_cand, F, 1), dtype=f32, device=dev)
+        tab1_arr = (C.c_void_p * F)(*[_ptr(t, f32, "table1").value for t in tables1])
+        _lib.call("rc_gather_fields_pair", tab_arr, tab1_arr, ids_arr, per_row, off_arr, F, B, int(n_cand), d, _ptr(out, f32, "out"),
+                  _ptr(out1, f32, "out1"), _ptr(cid, i64, "cid", True), _stream())
+        return out, out1, cid, offs + [run]
     _lib.call("rc_gather_fields", tab_arr, ids_arr, per_row, off_arr, F, B, int(n_cand), d, _ptr(out, f32, "out"),
               _ptr(cid, i64, "cid", True), _stream())
     return out, cid, offs + [run]
@@ -1703,6 +1728,35 @@ def ctr_head(bias, lin, term1, term2, label):
               _ptr(term2, f32, "term2", True), _ptr(label, torch.int64, "label"), n, _ptr(p, f32, "p"), _ptr(loss_vec, f32, "loss_vec"),
               _ptr(gz, f32, "gz"), _stream())
     return p, reduce_sum(loss_vec, 1.0 / n), gz
+
+
+CTR_HEAD_ONE_WG_MAX = 65536   # rows the one-workgroup head (rc_ctr_head_fwd_bwd_sums) takes
+
+
+def ctr_head_sums(bias, lin, term1, term2, label):
+    """ctr_head in one workgroup that also forms the loss mean and sum gz: -> (p [n], sums [2] = (loss, sum gz), gz [n])"""
+    n, F = lin.shape
+    f32 = torch.float32
+    p = torch.empty(n, dtype=f32, device=lin.device)
+    loss_vec = torch.empty(n, dtype=f32, device=lin.device)
+    gz = torch.empty(n, dtype=f32, device=lin.device)
+    sums = torch.empty(2, dtype=f32, device=lin.device)
+    _lib.call("rc_ctr_head_fwd_bwd_sums", _ptr(bias, f32, "bias"), _ptr(lin, f32, "lin"), int(F), _ptr(term1, f32, "term1", True),
+              _ptr(term2, f32, "term2", True), _ptr(label, torch.int64, "label"), n, _ptr(p, f32, "p"), _ptr(loss_vec, f32, "loss_vec"),
+              _ptr(gz, f32, "gz"), _ptr(sums, f32, "sums"), _stream())
+    return p, sums, gz
+
+
+def ctr_head_bwd(gz, sums, g_loss, F):
+    """backward fan-out of the head: -> (g [n] = gz * g_loss, g_lin [n, F] (contiguous), g_bias [1])"""
+    n = gz.shape[0]
+    f32 = torch.float32
+    g = torch.empty(n, dtype=f32, device=gz.device)
+    g_lin = torch.empty((n, F), dtype=f32, device=gz.device)
+    g_bias = torch.empty(1, dtype=f32, device=gz.device)
+    _lib.call("rc_ctr_head_bwd", _ptr(gz, f32, "gz"), _ptr(sums, f32, "sums"), _ptr(g_loss, f32, "g_loss"), n, int(F), _ptr(g, f32, "g"),
+              _ptr(g_lin, f32, "g_lin"), _ptr(g_bias, f32, "g_bias"), _stream())
+    return g, g_lin, g_bias
 
 
 # ---- batch assembly on the device (csrc/sampler.hip) -------------------------------------------------------

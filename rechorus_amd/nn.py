@@ -283,6 +283,45 @@ def gather_fields(tables, ids, n_cand):
     return _FieldGatherFn.apply(n_cand, len(tables), *ids, *tables)
 
 
+class _FieldGatherPairFn(torch.autograd.Function):
+    """the TWO table families the FM models gather with the same ids (models/context/FM.py:44-57: field vectors [vocab, d] and
+    first-order weights [vocab, 1]) as one autograd node: one gather launch forward (rc_gather_fields_pair); backward, ONE
+    grouping of the composite (field, id) keys serves both dense gradients -- the small route's plan (rc_small_row_sums +
+    rc_small_row_sums_again on one zero-filled buffer), or one sort -- instead of one per family."""
+
+    @staticmethod
+    def forward(ctx, n_cand, n_fields, *args):
+        ids = [x.contiguous() for x in args[:n_fields]]
+        tables, tables1 = args[n_fields:2 * n_fields], args[2 * n_fields:]
+        V, L, cid, offs = engine.gather_fields([t.detach() for t in tables], ids, n_cand, want_cid=True, tables1=[t.detach() for t in tables1])
+        ctx.cid, ctx.offs, ctx.d = cid, offs, tables[0].shape[1]
+        n_ids = cid.numel() // max(1, n_fields)
+        ctx.route = "small" if cid.numel() <= 8192 else ("sort" if min(t.shape[0] for t in tables) * 8 <= n_ids else None)
+        return V, L
+
+    @staticmethod
+    def backward(ctx, gV, gL):
+        offs, d = ctx.offs, ctx.d
+        n_rows, n = offs[-1], ctx.cid.numel()
+        gV = None if gV is None else gV.contiguous()
+        gL = None if gL is None else gL.contiguous()
+        if gV is not None and gL is not None and ctx.route == "small" and engine.small_route_ok(n, n_rows, d) and d % 4 == 0:
+            Gv, Gl = engine.small_row_sums_pair(ctx.cid, n_rows, gV.view(n, d), gL.view(n, 1))
+        else:
+            presorted = engine.sort_ids(ctx.cid.reshape(-1), n_rows) if ctx.route == "sort" else None
+            Gv = None if gV is None else engine.embedding_dense_backward(gV, ctx.cid, n_rows, route=ctx.route, presorted=presorted)
+            Gl = None if gL is None else engine.embedding_dense_backward(gL, ctx.cid, n_rows, route=ctx.route, presorted=presorted)
+        F = len(offs) - 1
+        gv = tuple(None if Gv is None else Gv[offs[f]:offs[f + 1]] for f in range(F))
+        gl = tuple(None if Gl is None else Gl[offs[f]:offs[f + 1]] for f in range(F))
+        return (None, None) + (None,) * F + gv + gl
+
+
+def gather_fields_pair(tables, tables1, ids, n_cand):
+    """-> (field vectors [B, C, F, d], first-order values [B, C, F, 1]) of the two table families looked up with the same ids"""
+    return _FieldGatherPairFn.apply(n_cand, len(tables), *ids, *tables, *tables1)
+
+
 class _BceProbFn(torch.autograd.Function):
     """nn.BCELoss on probabilities (models/BaseModel.py:259-267), closed-form backward."""
 
@@ -310,15 +349,30 @@ class _CtrHeadFn(torch.autograd.Function):
     def forward(ctx, bias, lin, label, *terms):
         n = label.numel()
         t = [x.detach().reshape(-1).contiguous() for x in terms]
-        p, loss, gz = engine.ctr_head(bias.detach(), lin.detach().reshape(n, -1).contiguous(), t[0] if len(t) > 0 else None,
+        lin2 = lin.detach().reshape(n, -1).contiguous()
+        ctx.lin_shape, ctx.term_shapes = lin.shape, [x.shape for x in terms]
+        ctx.one_wg = n <= engine.CTR_HEAD_ONE_WG_MAX and lin2.numel() == lin.numel()
+        if ctx.one_wg:
+            # one workgroup: probabilities, loss MEAN and sum gz (the bias gradient) in the same launch
+            p, sums, gz = engine.ctr_head_sums(bias.detach(), lin2, t[0] if len(t) > 0 else None, t[1] if len(t) > 1 else None,
+                                               label.reshape(-1).contiguous())
+            ctx.save_for_backward(gz, sums)
+            ctx.mark_non_differentiable(p)
+            return p, sums[0].reshape(())
+        p, loss, gz = engine.ctr_head(bias.detach(), lin2, t[0] if len(t) > 0 else None,
                                       t[1] if len(t) > 1 else None, label.reshape(-1).contiguous())
         ctx.save_for_backward(gz)
-        ctx.lin_shape, ctx.term_shapes = lin.shape, [x.shape for x in terms]
         ctx.mark_non_differentiable(p)
         return p, loss.reshape(())
 
     @staticmethod
     def backward(ctx, _gp, g_loss):
+        if ctx.one_wg:
+            gz, sums = ctx.saved_tensors
+            n = gz.shape[0]
+            # one launch: g = gz * g_loss for the terms, the contiguous [n, F] block of the first-order weights, the bias gradient
+            g, g_lin, g_bias = engine.ctr_head_bwd(gz, sums, g_loss.reshape(1).float().contiguous(), ctx.lin_shape.numel() // n)
+            return (g_bias, g_lin.view(ctx.lin_shape), None) + tuple(g.reshape(sh) for sh in ctx.term_shapes)
         (gz,) = ctx.saved_tensors
         g = gz * g_loss
         n = g.shape[0]

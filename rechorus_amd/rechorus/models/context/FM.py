@@ -73,8 +73,8 @@ class FMBase(object):
             # every field in ONE gather launch per table family (rc_gather_fields); the backward is one
             # composite-key sort + segmented sum for all F dense gradients
             ids = [feed_dict[f] for f in self.context_features]
-            fm_vectors = hnn.gather_fields([self.context_embedding[f].weight for f in self.context_features], ids, n_cand)
-            linear_value = hnn.gather_fields([self.linear_embedding[f].weight for f in self.context_features], ids, n_cand)
+            fm_vectors, linear_value = hnn.gather_fields_pair([self.context_embedding[f].weight for f in self.context_features],
+                                                              [self.linear_embedding[f].weight for f in self.context_features], ids, n_cand)
             return fm_vectors, self.overall_bias + linear_value.squeeze(-1).sum(dim=-1)
         fm_vectors = torch.stack(self._lookup(self.context_embedding, feed_dict, n_cand), dim=-2)
         linear_value = torch.cat(self._lookup(self.linear_embedding, feed_dict, n_cand), dim=-1)
@@ -91,8 +91,9 @@ class FMBase(object):
             return None
         n_cand = feed_dict['item_id'].shape[1]
         ids = [feed_dict[f] for f in self.context_features]
-        return (hnn.gather_fields([self.context_embedding[f].weight for f in self.context_features], ids, n_cand),
-                hnn.gather_fields([self.linear_embedding[f].weight for f in self.context_features], ids, n_cand))
+        # both table families in ONE gather launch, and one grouping of their shared keys in the backward pass
+        return hnn.gather_fields_pair([self.context_embedding[f].weight for f in self.context_features],
+                                      [self.linear_embedding[f].weight for f in self.context_features], ids, n_cand)
 
     def _head_terms(self, field_vectors):
         """what `forward` adds to the first-order term, as a list of [B, C] tensors (at most two)"""

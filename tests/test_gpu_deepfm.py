@@ -272,3 +272,66 @@ def test_bce_ranking_kernel_matches_the_reference(cuda):
         loss.backward()
         assert_close(loss.item(), g["%d/loss" % i], what="loss", rtol=2e-5)
         assert_close(p.grad.cpu().numpy(), g["%d/gpred" % i], what="grad", rtol=2e-5, atol_scale=2e-5)
+
+
+def test_two_table_families_share_keys_and_grouping(cuda, monkeypatch):
+    """the [vocab, d] vectors and the [vocab, 1] first-order weights of the FM family are gathered with the same id tensors
+    (models/context/FM.py:44-57): ONE gather launch (rc_gather_fields_pair), and in the backward pass ONE grouping of the composite
+    keys serves both dense gradients (rc_small_row_sums + rc_small_row_sums_again) -- values and gradients bit-identical to two
+    separate gathers"""
+    from rechorus_amd import _lib, nn as hnn
+    rng = np.random.default_rng(4)
+    for vocab, B, C in (([50, 7, 300], 96, 1), ([11, 300, 5, 70, 2], 33, 5), ([40000, 9], 1024, 1)):
+        mk = lambda d: [torch.from_numpy(rng.normal(size=(v, d)).astype(np.float32)).to(cuda).requires_grad_(True) for v in vocab]
+        vec, lin = mk(64), mk(1)
+        ids = [torch.from_numpy(rng.integers(0, v, size=(B,) if k % 2 == 0 else (B, C)).astype(np.int64)).to(cuda) for k, v in enumerate(vocab)]
+        names = []
+        real = _lib.call
+        monkeypatch.setattr(_lib, "call", lambda fn, *a: names.append(fn) or real(fn, *a))
+        V, L = hnn.gather_fields_pair(vec, lin, ids, C)
+        wv, wl = torch.randn_like(V), torch.randn_like(L)
+        ((V * wv).sum() + (L * wl).sum()).backward()
+        monkeypatch.undo()
+        assert names.count("rc_gather_fields_pair") == 1 and "rc_gather_fields" not in names
+        assert names.count("rc_small_row_sums") == 1 and names.count("rc_small_row_sums_again") == 1, names
+        got = [t.grad.clone() for t in vec + lin]
+        for t in vec + lin:
+            t.grad = None
+        V2 = hnn.gather_fields(vec, [x.clone() for x in ids], C)      # the one-family node
+        L2 = hnn.gather_fields(lin, [x.clone() for x in ids], C)
+        assert torch.equal(V2, V) and torch.equal(L2, L)
+        ((V2 * wv).sum() + (L2 * wl).sum()).backward()
+        for a, t in zip(got, vec + lin):
+            assert torch.equal(a, t.grad)
+        # only one of the two outputs used: the other family's gradient is absent, not garbage
+        for t in vec + lin:
+            t.grad = None
+        V3, _ = hnn.gather_fields_pair(vec, lin, ids, C)
+        (V3 * wv).sum().backward()
+        assert all(torch.equal(a, t.grad) for a, t in zip(got[:len(vec)], vec))
+        assert all(t.grad is None or not bool(t.grad.any()) for t in lin)
+
+
+def test_ctr_head_one_workgroup_equals_the_two_kernel_head(cuda, monkeypatch):
+    """rc_ctr_head_fwd_bwd_sums / rc_ctr_head_bwd (probabilities, loss mean, sum gz and the backward fan-out in two launches) against
+    rc_ctr_head_fwd_bwd + reduce + autograd's mul / sum / expand: same probabilities and gradients, loss to rounding"""
+    from rechorus_amd import engine, nn as hnn
+    rng = np.random.default_rng(8)
+    for n, F, n_terms in ((1024, 8, 2), (37, 3, 1), (5000, 1, 0)):
+        res = []
+        for one_wg in (True, False):
+            monkeypatch.setattr(engine, "CTR_HEAD_ONE_WG_MAX", 65536 if one_wg else 0)
+            bias = torch.tensor([0.05], device=cuda, requires_grad=True)
+            lin = torch.from_numpy(rng.normal(0, 0.3, (n, 1, F, 1)).astype(np.float32)).to(cuda).requires_grad_(True)
+            terms = [torch.from_numpy(rng.normal(0, 1.0, (n, 1)).astype(np.float32)).to(cuda).requires_grad_(True) for _ in range(n_terms)]
+            label = torch.from_numpy(rng.integers(0, 2, n).astype(np.int64)).to(cuda)
+            rng = np.random.default_rng(8)      # (same inputs for the second variant)
+            p, loss = hnn.ctr_head(bias, lin, label, terms)
+            (loss * 1.7).backward()
+            res.append((p.detach(), loss.detach(), bias.grad, lin.grad, [t.grad for t in terms]))
+            rng = np.random.default_rng(8)
+        (pa, la, ba, ga, ta), (pb, lb, bb, gb, tb) = res
+        assert torch.equal(pa, pb)
+        assert_close(la.cpu().numpy(), lb.cpu().numpy(), what="loss", rtol=1e-6)
+        assert_close(ba.cpu().numpy(), bb.cpu().numpy(), what="bias grad", rtol=1e-5, atol_scale=1e-6)
+        assert torch.equal(ga, gb) and all(torch.equal(x, y) for x, y in zip(ta, tb))
