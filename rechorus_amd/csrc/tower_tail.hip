@@ -324,14 +324,31 @@ __global__ __launch_bounds__(kBlock) void tower_tail_reduce_kernel(const float* 
     }
     __syncthreads();
   }
-  if (blockIdx.x == 0) {
+  if (blockIdx.x == gridDim.x - 1) {   // the three small vectors, same scheme (a thread walking all partials one dependent load
+                                      // after the other made this block the kernel's critical path: 18 us)
+    __shared__ float sv[4][64];
     const int nv = 2 * N2 + 1;
-    for (int v = threadIdx.x; v < nv; v += kBlock) {
+    for (int base = 0; base < nv; base += 64) {
+      const int v = base + o;
       float t = 0.f;
-      for (int p = 0; p < parts; ++p) t += pvec[(size_t)p * nv + v];
-      if (v < N2) { if (db2) db2[v] = t; }
-      else if (v < 2 * N2) dw3[v - N2] = t;
-      else if (db3) db3[0] = t;
+      if (v < nv) {
+        for (int pb = p0; pb < p1; pb += 16) {
+          float tmp[16];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) tmp[u] = pb + u < p1 ? pvec[(size_t)(pb + u) * nv + v] : 0.f;
+#pragma unroll
+          for (int u = 0; u < 16; ++u) t += tmp[u];
+        }
+      }
+      sv[q][o] = t;
+      __syncthreads();
+      if (q == 0 && v < nv) {
+        const float r = ((sv[0][o] + sv[1][o]) + sv[2][o]) + sv[3][o];
+        if (v < N2) { if (db2) db2[v] = r; }
+        else if (v < 2 * N2) dw3[v - N2] = r;
+        else if (db3) db3[0] = r;
+      }
+      __syncthreads();
     }
   }
 }

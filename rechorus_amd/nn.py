@@ -352,6 +352,7 @@ class _CtrHeadFn(torch.autograd.Function):
         lin2 = lin.detach().reshape(n, -1).contiguous()
         ctx.lin_shape, ctx.term_shapes = lin.shape, [x.shape for x in terms]
         ctx.one_wg = n <= engine.CTR_HEAD_ONE_WG_MAX and lin2.numel() == lin.numel()
+        ctx.set_materialize_grads(False)    # p is not differentiable: no [n] block of zeros is filled for it in every backward pass
         if ctx.one_wg:
             # one workgroup: probabilities, loss MEAN and sum gz (the bias gradient) in the same launch
             p, sums, gz = engine.ctr_head_sums(bias.detach(), lin2, t[0] if len(t) > 0 else None, t[1] if len(t) > 1 else None,
@@ -367,6 +368,8 @@ class _CtrHeadFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, _gp, g_loss):
+        if g_loss is None:      # the loss did not reach the objective
+            return (None, None, None) + (None,) * len(ctx.term_shapes)
         if ctx.one_wg:
             gz, sums = ctx.saved_tensors
             n = gz.shape[0]
