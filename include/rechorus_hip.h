@@ -523,7 +523,7 @@ int rc_neumf_bwd_dropout(const float* mf_u, const float* mf_i, const float* mlp_
  *                 written): feed them to rc_plan_update_pair on a plan of iid built with list_single_a = 0
  *   gu_mf, gu_mlp [B, d]      ONE gradient row per tuple for the user tables (plan the user ids per tuple)
  *   dW1, db1, dw_out          dense gradients, per-workgroup partials summed in fixed order; no float atomics anywhere
- * Shapes: rc_neumf_train_step_supported(C, d, l1): d in {32,64,128}, l1 in {32,64}, C >= 2 and the LDS image <= 160 KB
+ * Shapes: rc_neumf_train_step_supported(C, d, l1): d in {32,64,128}, l1 in {16,32,64} (l1 = 16: d >= 64), C >= 2 and the LDS image <= 160 KB
  * (C <= 136 at d = 128, l1 = 64).  Training-mode dropout (the reference's own NeuMF command line runs --dropout 0.2,
  * docs/demo_scripts_results/Topk_Amazon.sh:8; NeuMF.py:58,70): rc_neumf_train_step_dropout below.                          */
 int rc_neumf_train_step_supported(int C, int d, int l1);

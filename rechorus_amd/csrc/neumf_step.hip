@@ -676,7 +676,14 @@ static size_t step_lds_bytes(int d, int l1, int C) {
   return sizeof(float) * (fixed + 4 * per_wave);
 }
 
-static bool step_shape(int d, int l1) { return (d == 32 || d == 64 || d == 128) && (l1 == 32 || l1 == 64) && !(d == 128 && l1 == 128); }
+static bool step_shape(int d, int l1) {
+  if (!(d == 32 || d == 64 || d == 128)) return false;
+  if (l1 == 32 || l1 == 64) return true;
+  // (hidden 128: eight MFMA chains per product keep 64 operand registers in flight -- built, 64 to 900 bytes of scratch per lane
+  //  in every instantiation: those towers stay on the three-kernel step)
+  if (l1 == 16) return d != 32;      // (the dW1u tiles are dealt to four waves: 16 (d / 16) / 16 tiles must be a multiple of 4)
+  return false;
+}
 
 int device_cus();   // bucket_plan.hip
 
@@ -706,8 +713,8 @@ template <int MODE>
 static int dispatch_step(const NeumfStepArgs& a, int d, int l1, int grid, hipStream_t s) {
 #define RC_NS(D_, L_) \
   if (d == D_ && l1 == L_) return a.seed_dev ? launch_step<D_, L_, MODE, true>(a, grid, s) : launch_step<D_, L_, MODE, false>(a, grid, s)
-  RC_NS(128, 64); RC_NS(128, 32);
-  RC_NS(64, 64); RC_NS(64, 32);
+  RC_NS(128, 64); RC_NS(128, 32); RC_NS(128, 16);
+  RC_NS(64, 64); RC_NS(64, 32); RC_NS(64, 16);
   RC_NS(32, 64); RC_NS(32, 32);
 #undef RC_NS
   return fail(RC_ERR_UNSUPPORTED, "rc_neumf_train_step: no kernel for d=%d, hidden=%d", d, l1);
@@ -766,7 +773,7 @@ static int neumf_train_step_impl(bool marked, float drop_p, const uint64_t* seed
              "rc_neumf_train_step: null pointer");
   RC_REQUIRE(B > 0 && C >= 2 && n_items >= 1, "rc_neumf_train_step: bad shape B=%d C=%d n_items=%lld", B, C, (long long)n_items);
   if (!rc_neumf_train_step_supported(C, d, l1))
-    return fail(RC_ERR_UNSUPPORTED, "rc_neumf_train_step: d=%d hidden=%d C=%d not supported (d in {32,64,128}, hidden in {32,64}, LDS <= 160 KB)",
+    return fail(RC_ERR_UNSUPPORTED, "rc_neumf_train_step: d=%d hidden=%d C=%d not supported (d in {32,64,128}, hidden in {16,32,64}; hidden 16 needs d >= 64; LDS <= 160 KB)",
                 d, l1, C);
   if (ws_bytes < rc_neumf_train_step_workspace_bytes(B, C, d, l1))
     return fail(RC_ERR_WORKSPACE, "rc_neumf_train_step: workspace %zu < %zu", ws_bytes, rc_neumf_train_step_workspace_bytes(B, C, d, l1));

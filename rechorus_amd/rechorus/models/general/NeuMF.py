@@ -83,17 +83,21 @@ class NeuMF(GeneralModel):
         return {'prediction': pred.view(feed_dict['batch_size'], -1)}
 
     # ---- large-table mode: row-wise update of the four tables, no dense [n_rows, d] gradient -----------
+    def _step_ok(self):
+        """the one-kernel fit() iteration covers this tower (hidden 16 is a shape of the fused step only)"""
+        return len(self.layers) == 1 and (self._fused_ok() or engine.neumf_train_step_supported(2, self.emb_size, self.layers[0]))
+
     def hip_rowwise_supported(self):
-        return self._fused_ok()
+        return self._step_ok()
 
     def hip_train_step(self, feed_dict, opt_name, lr, l2, next_feed_dict=None):
         """one fit iteration on engine.NeumfTrainer: ONE kernel for forward (dropout mask included), BPR loss, backward and the in-place
         update of single-occurrence item rows (rc_neumf_train_step) + the plan's pair updates + the dense step of the MLP;
         returns the device loss tensor.  next_feed_dict: the batch the following call will bring (BaseRunner.fit passes it): its
         bucket plan is built beside this step's table updates."""
-        if not self._fused_ok():
-            raise RuntimeError('NeuMF --engine rowwise needs the fused head: one hidden layer, emb_size and layer '
-                               'size in {32, 64, 128}')
+        if not self._step_ok():
+            raise RuntimeError('NeuMF --engine rowwise needs the fused head: one hidden layer, emb_size in {32, 64, 128} and layer '
+                               'size in {16, 32, 64, 128}')
         tr = getattr(self, '_trainer', None)
         if tr is None or tr.opt != opt_name:
             P = {'mf_u': self.mf_u_embeddings.weight.data, 'mf_i': self.mf_i_embeddings.weight.data,

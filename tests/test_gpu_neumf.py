@@ -348,7 +348,8 @@ def test_neumf_fused_step_random_shapes_vs_oracle(cuda, eng):
     from oracle import bprmf_oracle as BO
     rng = np.random.default_rng(11)
     for d, l1, B, C, n_items, opt in ((128, 64, 1000, 5, 3000, "SGD"), (64, 64, 777, 2, 500, "Adam"), (32, 32, 130, 17, 4000, "Adagrad"),
-                                      (64, 32, 65, 100, 900, "SGD"), (32, 64, 1, 3, 50, "SGD"), (128, 32, 200, 5, 100000, "Adam")):
+                                      (64, 32, 65, 100, 900, "SGD"), (32, 64, 1, 3, 50, "SGD"), (128, 32, 200, 5, 100000, "Adam"),
+                                      (64, 16, 300, 5, 2000, "Adam"), (128, 16, 150, 9, 700, "SGD")):
         n_users = 37
         P = {"mf_u_embeddings.weight": rng.normal(0, 0.3, (n_users, d)), "mf_i_embeddings.weight": rng.normal(0, 0.3, (n_items, d)),
              "mlp_u_embeddings.weight": rng.normal(0, 0.3, (n_users, d)), "mlp_i_embeddings.weight": rng.normal(0, 0.3, (n_items, d)),
@@ -368,6 +369,7 @@ def test_neumf_fused_step_random_shapes_vs_oracle(cuda, eng):
                              f"d={d} l1={l1} B={B} C={C} {opt}")
     assert not eng.neumf_train_step_supported(1, 64, 64) and not eng.neumf_train_step_supported(5, 48, 64)
     assert not eng.neumf_train_step_supported(5, 64, 128) and not eng.neumf_train_step_supported(200, 128, 64)
+    assert eng.neumf_train_step_supported(5, 64, 16) and not eng.neumf_train_step_supported(5, 32, 16)
 
 
 @pytest.mark.parametrize("opt,lookahead", [("SGD", True), ("Adam", False), ("Adagrad", True)])
