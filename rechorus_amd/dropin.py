@@ -134,8 +134,10 @@ def _head_mixin(kind):
     if kind == "SASRec":
         return _mirror("models.sequential.SASRec").SASRecBase
     m = _mirror("models.general.NeuMF").NeuMF
-    names = ("_fused_ok", "_drop_p", "forward", "hip_rowwise_supported", "hip_train_step", "candidate_permutation_equivariant")
-    return type("NeuMFHead", (object,), {n: m.__dict__[n] for n in names})
+    # everything the plugin's class defines except construction (the model file built its own parameters, with the same names)
+    skip = ("__init__", "__module__", "__doc__", "__qualname__", "__dict__", "__weakref__", "parse_model_args", "_define_params",
+            "reader", "runner", "extra_log_args")
+    return type("NeuMFHead", (object,), {n: v for n, v in m.__dict__.items() if n not in skip})
 
 
 def _probe_feed(model, kind, device):
