@@ -136,12 +136,13 @@ __device__ __forceinline__ void mlp_stage(float* tile, const MlpOperand& o, cons
 struct MlpFastSrc {
   const float* p;
   int mode;
-  float4 cst;
+  float c0, c1, c2, c3;   // mode 3: the constant float4 (four scalars: a float4 member was kept in a stack slot -- 80 bytes of scratch)
 };
+__device__ __forceinline__ float4 mlp_cst(const MlpFastSrc& f) { return make_float4(f.c0, f.c1, f.c2, f.c3); }
 __device__ __forceinline__ MlpFastSrc mlp_fast_src(const MlpOperand& o, int64_t outer, int64_t outer_n, int64_t k, bool vec_ok,
                                                    int ones_col = -1) {
   MlpFastSrc f;
-  f.cst = make_float4(0.f, 0.f, 0.f, 0.f);
+  f.c0 = f.c1 = f.c2 = f.c3 = 0.f;
   if (o.k_major) {   // thread's float4 runs along k
     f.p = o.p + outer * o.ld + k;
     f.mode = outer >= outer_n ? 0 : (vec_ok ? 1 : 2);
@@ -149,8 +150,10 @@ __device__ __forceinline__ MlpFastSrc mlp_fast_src(const MlpOperand& o, int64_t 
     f.p = o.p + k * o.ld + outer;
     if (outer >= outer_n) {
       f.mode = 3;
-      f.cst = make_float4(outer == ones_col ? 1.f : 0.f, outer + 1 == ones_col ? 1.f : 0.f, outer + 2 == ones_col ? 1.f : 0.f,
-                          outer + 3 == ones_col ? 1.f : 0.f);
+      f.c0 = outer == ones_col ? 1.f : 0.f;
+      f.c1 = outer + 1 == ones_col ? 1.f : 0.f;
+      f.c2 = outer + 2 == ones_col ? 1.f : 0.f;
+      f.c3 = outer + 3 == ones_col ? 1.f : 0.f;
     } else {
       f.mode = (vec_ok && outer + 3 < outer_n) ? 1 : 2;
     }
@@ -231,8 +234,8 @@ __global__ __launch_bounds__(kBlock) void mlp_gemm_kernel(MlpGemm g, int vec_a, 
     if (all_fast && full) {
 #pragma unroll
       for (int q = 0; q < NP; ++q) {
-        va[q] = fa[q].mode == 1 ? *reinterpret_cast<const float4*>(fa[q].p + off_a) : fa[q].cst;
-        vb[q] = fb[q].mode == 1 ? *reinterpret_cast<const float4*>(fb[q].p + off_b) : fb[q].cst;
+        va[q] = fa[q].mode == 1 ? *reinterpret_cast<const float4*>(fa[q].p + off_a) : mlp_cst(fa[q]);
+        vb[q] = fb[q].mode == 1 ? *reinterpret_cast<const float4*>(fb[q].p + off_b) : mlp_cst(fb[q]);
       }
       return;
     }
@@ -330,209 +333,13 @@ __global__ __launch_bounds__(kBlock) void mlp_gemm_kernel(MlpGemm g, int vec_a, 
 
 // ---- 128 x 128 tiles for the large products -------------------------------------------------------------------------------
 // A 64 x 64 tile re-reads each operand element once per 64 columns of the other one and issues two ds_read_b32 per MFMA; at
-// B = 131,072 the three products of a layer ran at 20-34 % of the matrix peak.  Here a wave owns a 64 x 64 quarter of a
-// 128 x 128 tile as 2 x 2 MFMA blocks: every operand register feeds two MFMAs (one LDS read per MFMA) and every element fetched
-// from L2 is used against 128 columns.  K step 16, LDS reduction-major as above (row stride 132).  The workgroup -> tile map is
-// XCD-aware: workgroup L runs on XCD L % 8, and the tiles of one XCD walk all column tiles of a row tile before the next row tile,
-// so the A rows of a tile are fetched from HBM once and found in that XCD's L2 by the other column tiles.
-constexpr int kBigBM = 128, kBigBN = 128, kBigBK = 16, kBigLD = 132;
-
-__device__ __forceinline__ float4 mlp_big_load4(const MlpOperand& o, int64_t outer0, int64_t outer_n, int64_t k0, int64_t k_end,
-                                                int ones_col, bool vec_ok, int q) {
-  const int t = threadIdx.x;
-  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (o.k_major) {  // thread -> (outer = t / 4 + 64 q, k = 4 (t % 4) ..)
-    const int64_t i = outer0 + (t >> 2) + 64 * q, k = k0 + 4 * (t & 3);
-    if (i < outer_n) {
-      const float* src = o.p + i * o.ld + k;
-      if (vec_ok && k + 3 < k_end) v = *reinterpret_cast<const float4*>(src);
-      else {
-        if (k < k_end) v.x = src[0];
-        if (k + 1 < k_end) v.y = src[1];
-        if (k + 2 < k_end) v.z = src[2];
-        if (k + 3 < k_end) v.w = src[3];
-      }
-    }
-  } else {          // thread -> (k = t / 32 + 8 q, outer = 4 (t % 32) ..)
-    const int64_t k = k0 + (t >> 5) + 8 * q, i = outer0 + 4 * (t & 31);
-    if (k < k_end) {
-      const float* src = o.p + k * o.ld + i;
-      if (vec_ok && i + 3 < outer_n) v = *reinterpret_cast<const float4*>(src);
-      else {
-        if (i < outer_n) v.x = src[0];
-        if (i + 1 < outer_n) v.y = src[1];
-        if (i + 2 < outer_n) v.z = src[2];
-        if (i + 3 < outer_n) v.w = src[3];
-      }
-      if (ones_col >= 0) {
-        if (i == ones_col) v.x = 1.f;
-        if (i + 1 == ones_col) v.y = 1.f;
-        if (i + 2 == ones_col) v.z = 1.f;
-        if (i + 3 == ones_col) v.w = 1.f;
-      }
-    }
-  }
-  return v;
-}
-
-__device__ __forceinline__ void mlp_big_stage(float* tile, const MlpOperand& o, const float4& v, int q) {
-  const int t = threadIdx.x;
-  if (o.k_major) {
-    const int i = (t >> 2) + 64 * q, k = 4 * (t & 3);
-    tile[(k + 0) * kBigLD + i] = v.x;
-    tile[(k + 1) * kBigLD + i] = v.y;
-    tile[(k + 2) * kBigLD + i] = v.z;
-    tile[(k + 3) * kBigLD + i] = v.w;
-  } else {
-    const int k = (t >> 5) + 8 * q, i = 4 * (t & 31);
-    *reinterpret_cast<float4*>(tile + k * kBigLD + i) = v;
-  }
-}
-
-__global__ __launch_bounds__(kBlock) void mlp_gemm_big_kernel(MlpGemm g, int vec_a, int vec_b, int m_tiles, int n_tiles) {
-  __shared__ __attribute__((aligned(16))) float As[2][kBigBK * kBigLD];
-  __shared__ __attribute__((aligned(16))) float Bs[2][kBigBK * kBigLD];
-  // XCD-aware tile map (see above)
-  // (few row tiles -- the weight-gradient products, whose reduction over the batch is cut into splits -- take the plain order:
-  //  the grouped one would leave XCDs without a row tile idle)
-  const int L = blockIdx.x, xcd = L & 7, slot = L >> 3;
-  const bool grouped = m_tiles >= 16;
-  const int mt = grouped ? (slot / n_tiles) * 8 + xcd : L / n_tiles;
-  const int nt = grouped ? slot % n_tiles : L % n_tiles;
-  if (mt >= m_tiles) return;   // workgroup-uniform
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wr = wave >> 1, wc = wave & 1;                     // this wave's 64 x 64 quarter
-  const int64_t m0 = (int64_t)mt * kBigBM;
-  const int64_t n0 = (int64_t)nt * kBigBN;
-  const int64_t kb = (int64_t)blockIdx.z * g.split_stride_k;
-  const int64_t ke = (kb + g.K < g.k_total) ? kb + g.K : g.k_total;
-  const int64_t bn = g.ones_col >= 0 ? (int64_t)g.ones_col : (int64_t)g.N;
-  // 32-column blocks of this wave past the last column (the tile that holds only the column of ones): no MFMAs for them
-  const int64_t ncols_all = g.ones_col >= 0 ? (int64_t)g.ones_col + 1 : (int64_t)g.N;
-  const bool live0 = n0 + wc * 64 < ncols_all, live1 = n0 + wc * 64 + 32 < ncols_all;
-  mlp_f32x16 acc[2][2];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-  float4 ra[2], rb[2];
-  MlpFastSrc fa[2], fb[2];
-  {
-    const int t = threadIdx.x;
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      fa[q] = g.A.k_major ? mlp_fast_src(g.A, m0 + (t >> 2) + 64 * q, g.M, kb + 4 * (t & 3), vec_a != 0)
-                          : mlp_fast_src(g.A, m0 + 4 * (t & 31), g.M, kb + (t >> 5) + 8 * q, vec_a != 0);
-      fb[q] = g.B.k_major ? mlp_fast_src(g.B, n0 + (t >> 2) + 64 * q, bn, kb + 4 * (t & 3), vec_b != 0)
-                          : mlp_fast_src(g.B, n0 + 4 * (t & 31), bn, kb + (t >> 5) + 8 * q, vec_b != 0, g.ones_col);
-    }
-  }
-  const int64_t stride_a = g.A.k_major ? (int64_t)kBigBK : (int64_t)kBigBK * g.A.ld;
-  const int64_t stride_b = g.B.k_major ? (int64_t)kBigBK : (int64_t)kBigBK * g.B.ld;
-  const bool all_fast = __syncthreads_and((fa[0].mode != 2 && fa[1].mode != 2 && fb[0].mode != 2 && fb[1].mode != 2) ? 1 : 0) != 0;
-  auto fetch = [&](int64_t k0, int64_t off_a, int64_t off_b) {
-    const bool full = k0 + kBigBK <= ke;   // workgroup-uniform
-    if (all_fast && full) {
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        ra[q] = fa[q].mode == 1 ? *reinterpret_cast<const float4*>(fa[q].p + off_a) : fa[q].cst;
-        rb[q] = fb[q].mode == 1 ? *reinterpret_cast<const float4*>(fb[q].p + off_b) : fb[q].cst;
-      }
-      return;
-    }
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      if (fa[q].mode == 0) ra[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-      else if (full && fa[q].mode == 1) ra[q] = *reinterpret_cast<const float4*>(fa[q].p + off_a);
-      else ra[q] = mlp_big_load4(g.A, m0, g.M, k0, ke, -1, vec_a != 0, q);
-      if (fb[q].mode == 0) rb[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-      else if (full && fb[q].mode == 1) rb[q] = *reinterpret_cast<const float4*>(fb[q].p + off_b);
-      else rb[q] = mlp_big_load4(g.B, n0, bn, k0, ke, g.ones_col, vec_b != 0, q);
-    }
-  };
-  int64_t off_a = 0, off_b = 0;
-  fetch(kb, off_a, off_b);
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    mlp_big_stage(As[0], g.A, ra[q], q);
-    mlp_big_stage(Bs[0], g.B, rb[q], q);
-  }
-  __syncthreads();
-  int buf = 0;
-  const int ai = wr * 64 + (lane & 31), bj = wc * 64 + (lane & 31), kh = lane >> 5;
-  for (int64_t k0 = kb; k0 < ke; k0 += kBigBK) {
-    const bool more = k0 + kBigBK < ke;
-    if (more) {
-      off_a += stride_a;
-      off_b += stride_b;
-      fetch(k0 + kBigBK, off_a, off_b);
-    }
-    const float* as = As[buf] + kh * kBigLD + ai;
-    const float* bs = Bs[buf] + kh * kBigLD + bj;
-    float av[2][kBigBK / 2], bv[2][kBigBK / 2];
-#pragma unroll
-    for (int t = 0; t < kBigBK / 2; ++t) {
-      av[0][t] = as[2 * t * kBigLD];
-      av[1][t] = as[2 * t * kBigLD + 32];
-      bv[0][t] = bs[2 * t * kBigLD];
-      bv[1][t] = bs[2 * t * kBigLD + 32];
-    }
-    if (live1) {
-#pragma unroll
-      for (int t = 0; t < kBigBK / 2; ++t) {
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0][t], bv[0][t], acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0][t], bv[1][t], acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1][t], bv[0][t], acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1][t], bv[1][t], acc[1][1], 0, 0, 0);
-      }
-    } else if (live0) {
-#pragma unroll
-      for (int t = 0; t < kBigBK / 2; ++t) {
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0][t], bv[0][t], acc[0][0], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1][t], bv[0][t], acc[1][0], 0, 0, 0);
-      }
-    }
-    if (more) {
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        mlp_big_stage(As[buf ^ 1], g.A, ra[q], q);
-        mlp_big_stage(Bs[buf ^ 1], g.B, rb[q], q);
-      }
-    }
-    __syncthreads();
-    buf ^= 1;
-  }
-  // ---- epilogue: acc[a][b][r] is C(m0 + wr*64 + a*32 + (r & 3) + 8 (r >> 2) + 4 kh, n0 + wc*64 + b*32 + (lane & 31))
-  const int64_t ncols = g.ones_col >= 0 ? (int64_t)g.ones_col + 1 : (int64_t)g.N;
-  const uint64_t seed = g.seed ? *g.seed : 0;
-  float* C = g.C + (size_t)blockIdx.z * (size_t)g.M * (size_t)g.ldc;
-#pragma unroll
-  for (int b = 0; b < 2; ++b) {
-    const int64_t j = n0 + wc * 64 + b * 32 + (lane & 31);
-    if (j >= ncols) continue;
-    const float bj_ = (g.bias != nullptr && j < g.N) ? g.bias[j] : 0.f;
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int64_t mb = m0 + wr * 64 + a * 32 + 8 * q + 4 * kh;
-        float keep[4] = {1.f, 1.f, 1.f, 1.f};
-        if (g.seed && mb < g.M) mlp_keep4(g, seed, mb >> 2, (int)j, keep);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int64_t m = mb + e;
-          if (m >= g.M) continue;
-          float v = acc[a][b][4 * q + e] + bj_;
-          if (g.relu) v = fmaxf(v, 0.f);
-          if (g.seed) v *= keep[e];
-          if (g.mask) v = g.mask[m * g.ldc + j] > 0.f ? v * g.mask_scale : 0.f;
-          C[m * g.ldc + j] = v;
-        }
-      }
-  }
-}
+// B = 131,072 the three products of a layer ran at 20-34 % of the matrix peak.  On 128 x 128 tiles a wave owns a 64 x 64 quarter as
+// 2 x 2 MFMA blocks: every operand register feeds two MFMAs and every element fetched from L2 is used against 128 columns.  The
+// workgroup -> tile map is XCD-aware: workgroup L runs on XCD L % 8, and the tiles of one XCD walk all column tiles of a row tile
+// before the next row tile, so the A rows of a tile are fetched from HBM once and found in that XCD's L2 by the other column tiles.
+// (The first cut of this kernel -- K step 16, operands read right before their MFMAs, 80 bytes of scratch per lane -- is gone:
+//  mlp_gemm_big2_kernel below replaced it in round 4; shapes it does not take run on the 64 x 64 tiles.)
+constexpr int kBigBM = 128, kBigBN = 128;
 
 // ---- 128 x 128 tiles, second cut: K step 32, operand registers double-buffered against the MFMAs ---------------------------------
 // Device timing of the kernel above at 131,072 x 512 x 512 (tools/gemm_probe.py with the pieces switched off one at a time):
@@ -949,11 +756,6 @@ static int mlp_launch(const MlpGemm& g, int splits, hipStream_t s, bool want_big
       RC_LAUNCH_CHECK();
       return RC_OK;
     }
-    const int64_t groups = (mt + 7) / 8;   // row tiles per XCD
-    dim3 grid((unsigned)(mt >= 16 ? groups * nt * 8 : mt * nt), 1, (unsigned)splits);
-    hipLaunchKernelGGL(mlp_gemm_big_kernel, grid, dim3(kBlock), 0, s, g, vec4_ok(g.A) ? 1 : 0, vec4_ok(g.B) ? 1 : 0, (int)mt, (int)nt);
-    RC_LAUNCH_CHECK();
-    return RC_OK;
   }
   dim3 grid((unsigned)((g.M + kMlpBM - 1) / kMlpBM), (unsigned)((ncols + kMlpBN - 1) / kMlpBN), (unsigned)splits);
   void (*kern)(MlpGemm, int, int) = g.A.k_major ? (g.B.k_major ? mlp_gemm_kernel<true, true> : mlp_gemm_kernel<true, false>)
