@@ -306,11 +306,36 @@ class BaseRunner(object):
             rank = self._full_catalogue_ranks(dataset)
             if rank is not None:
                 return engine.rank_metrics(rank, topks, metrics)
-        pred = self._predict_device(dataset)
         if model.test_all:
-            rows, cols = self._clicked_cells(dataset, pred.device)
-            pred[rows, cols] = -float('inf')
+            # any other head (NeuMF, a user's model file): the scores of ONE evaluation batch against the catalogue, masked and
+            # ranked before the next batch is scored -- [eval_batch_size, n_items] alive at a time, not the reference's
+            # [n_instances, n_items] matrix (helpers/BaseRunner.py:225-252)
+            return engine.rank_metrics(self._streamed_test_all_ranks(dataset), topks, metrics)
+        pred = self._predict_device(dataset)
         return engine.rank_metrics(engine.target_rank(pred.contiguous()), topks, metrics)
+
+    def _streamed_test_all_ranks(self, dataset) -> torch.Tensor:
+        """rank of the ground truth (column 0) of every instance under --test_all, clicked items masked (reference :243-250),
+        one evaluation batch at a time"""
+        model = dataset.model
+        dev = torch.device(model.device)
+        ptr, flat = pipeline.clicked_csr(dataset.corpus, dev, 'all')
+        model.eval()
+        ranks = list()
+        with torch.no_grad():
+            for batch in self._batches(dataset, self.eval_batch_size, train=False):
+                out = model.inference(batch) if hasattr(model, 'inference') else model(batch)
+                pred = out['prediction'].contiguous()
+                users = batch['user_id'].to(dev).reshape(-1)
+                lo, hi = ptr[users], ptr[users + 1]
+                cnt = hi - lo
+                rows = torch.repeat_interleave(torch.arange(users.numel(), device=dev), cnt)
+                # position of every clicked item inside the flat CSR: lo[row] + (running index within the row)
+                within = torch.arange(rows.numel(), device=dev) - torch.repeat_interleave(torch.cumsum(cnt, 0) - cnt, cnt)
+                cols = flat[lo[rows] + within]
+                pred[rows, cols] = -float('inf')
+                ranks.append(engine.target_rank(pred))
+        return torch.cat(ranks)
 
     def _predict_device(self, dataset) -> torch.Tensor:
         """[n_instances, n_candidates] scores on the GPU, ground truth in column 0"""

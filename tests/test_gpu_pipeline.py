@@ -126,6 +126,23 @@ def test_test_all_full_catalogue_rank_matches_materialised_path(model_name, extr
         assert abs(fast[k] - slow[k]) < 0.02, (k, fast[k], slow[k])
 
 
+def test_test_all_streamed_ranks_for_a_head_without_catalogue_vectors(data_root, cuda):
+    """--test_all on NeuMF (no dot-product head: no full_catalogue_vectors): the runner masks and ranks one evaluation batch at a time
+    -- [eval_batch_size, n_items] scores alive, not [N, n_items] -- and gets exactly the ranks of the reference's materialised matrix
+    (helpers/BaseRunner.py:225-252 + evaluate_method :52-78)"""
+    args, corpus, model, data, runner = _setup(data_root, cuda, "NeuMF", ["--layers", "[32]"], test_all=1)
+    assert not hasattr(model, "full_catalogue_vectors")
+    runner.eval_batch_size = 37          # several ragged batches
+    ds = data["test"]
+    got = runner.evaluate(ds, runner.topk, runner.metrics)
+    pred = runner.predict(ds)            # [N, n_items], clicked columns -inf
+    assert pred.shape == (len(ds), corpus.n_items) and np.isinf(pred).any()
+    want = runner.evaluate_method(pred, runner.topk, runner.metrics)
+    assert got.keys() == want.keys() and all(abs(got[k] - want[k]) < 1e-9 for k in got), (got, want)
+    ranks = runner._streamed_test_all_ranks(ds).cpu().numpy()
+    assert np.array_equal(ranks, (pred >= pred[:, :1]).sum(axis=-1))
+
+
 def test_cli_dataloader_path_still_trains(data_root, tmp_path, cuda):
     import main
     log = str(tmp_path / "log" / "run.txt")
