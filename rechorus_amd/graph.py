@@ -125,13 +125,19 @@ class GraphedStep:
                 o += n
             self.groups.append((flat, keys))
         model.optimizer.zero_grad()  # grads must be None: the captured backward allocates them in the graph's pool
+        dev = next((v.device for v in batch.values() if isinstance(v, torch.Tensor)), None)
+        self._one = torch.ones((), dtype=torch.float32, device=dev)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         with warnings.catch_warnings():
             # autograd notes that the AccumulateGrad nodes were created on the default stream (warm-up); the
             # capture stream joins it before and after, which is what we want
             warnings.simplefilter('ignore', UserWarning)
+            one = None
             with torch.cuda.graph(self.graph):
                 self.loss = self.loss_of(model, self.static)
-                self.loss.backward()
+                # the seed gradient of the scalar loss from a buffer filled once, not a ones_like fill in every replay (a launch of
+                # its own: ~4.6 us of a 0.26 ms DeepFM step)
+                one = self._one if (self.loss.dim() == 0 and self.loss.dtype == torch.float32) else None
+                self.loss.backward(gradient=one) if one is not None else self.loss.backward()
                 model.optimizer.step()
