@@ -331,6 +331,139 @@ __global__ __launch_bounds__(kBlock) void mlp_gemm_kernel(MlpGemm g, int vec_a, 
   }
 }
 
+// ---- 32 x 64 tiles for the forward / dX products of a SMALL batch ---------------------------------------------------------------
+// A 1,024 x 512 x 512 product is 128 tiles of 64 x 64: half the CUs idle, each wave walking 256 MFMAs (6.8 us of matrix pipe) --
+// which is why round 2 cut the reduction into splits (512 workgroups, short K loops) and paid a second launch that sums the
+// partial planes and applies the epilogue: 15 + 7 us per product at the reference's CTR batch, where a launch costs 4.5 us whatever it
+// does.  Here a workgroup owns 32 x 64 outputs (256 workgroups for that product: one per CU, every SIMD busy), a wave 16 x 32 as two
+// v_mfma_f32_16x16x4_f32 blocks over the FULL reduction (3.4 us of matrix pipe), epilogue in the kernel: one launch, no partial planes.
+// A is stored [row][reduction] (X of the forward product, dZ of the dX product); B either way (W[n][k] forward, W[red][k] for dX).
+// LDS: A [32][36], B [64][36] or [32][68] per buffer, two buffers; K step 32 = two groups of 16 (MFMA e of group u contracts
+// k = 16 u + 4 g + e: reduction-contiguous operands are one ds_read_b128 per group); register ring of three K steps like the 64 x 64 kernel.
+constexpr int kSmBM = 32, kSmBN = 64, kSmBK = 32, kSmLDK = kSmBK + 4, kSmLDN = kSmBN + 4, kSmPD = 3;
+typedef float mlp_f32x4 __attribute__((ext_vector_type(4)));
+
+template <bool BKM>
+__global__ __launch_bounds__(kBlock) void mlp_gemm_small_kernel(MlpGemm g) {
+  __shared__ __attribute__((aligned(16))) float As[2][kSmBM * kSmLDK];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BKM ? kSmBN * kSmLDK : kSmBK * kSmLDN];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, i = lane & 15, gq = lane >> 4;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int64_t m0 = (int64_t)blockIdx.x * kSmBM;
+  const int64_t n0 = (int64_t)blockIdx.y * kSmBN;
+  // this thread's float4s of a K step: A (row t / 8, k 4 (t % 8)); B reduction-contiguous: rows t / 8 and t / 8 + 32, same k;
+  // B outer-contiguous: reduction rows t / 16 and t / 16 + 16, columns 4 (t % 16)
+  int64_t arow = m0 + (t >> 3);
+  if (arow >= g.M) arow = g.M - 1;                       // (a row past the batch repeats the last one; nothing of it is stored)
+  const float* pa = g.A.p + arow * g.A.ld + 4 * (t & 7);
+  const float* pb0;
+  const float* pb1;
+  bool b_on = true;
+  int64_t bstep;
+  if (BKM) {
+    int64_t r0 = n0 + (t >> 3), r1 = r0 + 32;
+    if (r0 >= g.N) r0 = g.N - 1;
+    if (r1 >= g.N) r1 = g.N - 1;
+    pb0 = g.B.p + r0 * g.B.ld + 4 * (t & 7);
+    pb1 = g.B.p + r1 * g.B.ld + 4 * (t & 7);
+    bstep = kSmBK;
+  } else {
+    const int64_t col = n0 + 4 * (t & 15);
+    b_on = col < g.N;                                     // (N % 4 == 0: a float4 is inside or outside)
+    pb0 = g.B.p + (int64_t)(t >> 4) * g.B.ld + (b_on ? col : 0);
+    pb1 = pb0 + 16 * g.B.ld;
+    bstep = (int64_t)kSmBK * g.B.ld;
+  }
+  const int n_steps = g.K / kSmBK;
+  // the register ring as NAMED slots (an indexed array behind a lambda stayed in a stack slot: 160 bytes of scratch per lane)
+  float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, p0 = a0, p1 = a0, p2 = a0, q0 = a0, q1 = a0, q2 = a0;
+#define RC_SM_LOAD(A_, P_, Q_, STEP_)                                                      \
+  do {                                                                                     \
+    A_ = *reinterpret_cast<const float4*>(pa + (int64_t)(STEP_) * kSmBK);                  \
+    P_ = *reinterpret_cast<const float4*>(pb0 + (STEP_) * bstep);                          \
+    Q_ = *reinterpret_cast<const float4*>(pb1 + (STEP_) * bstep);                          \
+    if (!b_on) P_ = Q_ = make_float4(0.f, 0.f, 0.f, 0.f);                                  \
+  } while (0)
+#define RC_SM_STAGE(BUF_, A_, P_, Q_)                                                                          \
+  do {                                                                                                         \
+    *reinterpret_cast<float4*>(As[BUF_] + (t >> 3) * kSmLDK + 4 * (t & 7)) = A_;                               \
+    if (BKM) {                                                                                                 \
+      *reinterpret_cast<float4*>(Bs[BUF_] + (t >> 3) * kSmLDK + 4 * (t & 7)) = P_;                             \
+      *reinterpret_cast<float4*>(Bs[BUF_] + ((t >> 3) + 32) * kSmLDK + 4 * (t & 7)) = Q_;                      \
+    } else {                                                                                                   \
+      *reinterpret_cast<float4*>(Bs[BUF_] + (t >> 4) * kSmLDN + 4 * (t & 15)) = P_;                            \
+      *reinterpret_cast<float4*>(Bs[BUF_] + ((t >> 4) + 16) * kSmLDN + 4 * (t & 15)) = Q_;                     \
+    }                                                                                                          \
+  } while (0)
+  if (0 < n_steps) RC_SM_LOAD(a0, p0, q0, 0);
+  if (1 < n_steps) RC_SM_LOAD(a1, p1, q1, 1);
+  if (2 < n_steps) RC_SM_LOAD(a2, p2, q2, 2);
+  mlp_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  RC_SM_STAGE(0, a0, p0, q0);
+  __syncthreads();
+  int buf = 0;
+  // one K step: refill the slot that went to LDS before this step's barrier, multiply the staged tile, stage the next slot
+#define RC_SM_STEP(S_, A_, P_, Q_, NA_, NP_, NQ_)                                                                        \
+  if ((S_) < n_steps) {                                                                                                  \
+    if ((S_) + kSmPD < n_steps) RC_SM_LOAD(A_, P_, Q_, (S_) + kSmPD);                                                    \
+    const float* as = As[buf] + (16 * wr + i) * kSmLDK + 4 * gq;                                                         \
+    float4 av[2], bv[2][2];                                                                                              \
+    _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                                      \
+      av[u] = *reinterpret_cast<const float4*>(as + 16 * u);                                                             \
+      _Pragma("unroll") for (int cb = 0; cb < 2; ++cb) {                                                                 \
+        if (BKM) {                                                                                                       \
+          bv[u][cb] = *reinterpret_cast<const float4*>(Bs[buf] + (32 * wc + 16 * cb + i) * kSmLDK + 16 * u + 4 * gq);   \
+        } else {                                                                                                         \
+          const float* bp = Bs[buf] + (16 * u + 4 * gq) * kSmLDN + 32 * wc + 16 * cb + i;                                \
+          bv[u][cb] = make_float4(bp[0], bp[kSmLDN], bp[2 * kSmLDN], bp[3 * kSmLDN]);                                   \
+        }                                                                                                                \
+      }                                                                                                                  \
+    }                                                                                                                    \
+    _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                                      \
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].x, bv[u][0].x, acc0, 0, 0, 0);                                   \
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].x, bv[u][1].x, acc1, 0, 0, 0);                                   \
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].y, bv[u][0].y, acc0, 0, 0, 0);                                   \
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].y, bv[u][1].y, acc1, 0, 0, 0);                                   \
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].z, bv[u][0].z, acc0, 0, 0, 0);                                   \
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].z, bv[u][1].z, acc1, 0, 0, 0);                                   \
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].w, bv[u][0].w, acc0, 0, 0, 0);                                   \
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].w, bv[u][1].w, acc1, 0, 0, 0);                                   \
+    }                                                                                                                    \
+    if ((S_) + 1 < n_steps) RC_SM_STAGE(buf ^ 1, NA_, NP_, NQ_);                                                         \
+    __syncthreads();                                                                                                     \
+    buf ^= 1;                                                                                                            \
+  }
+  for (int s0 = 0; s0 < n_steps; s0 += kSmPD) {
+    RC_SM_STEP(s0, a0, p0, q0, a1, p1, q1)
+    RC_SM_STEP(s0 + 1, a1, p1, q1, a2, p2, q2)
+    RC_SM_STEP(s0 + 2, a2, p2, q2, a0, p0, q0)
+  }
+#undef RC_SM_STEP
+#undef RC_SM_STAGE
+#undef RC_SM_LOAD
+  // epilogue: acc{cb}[r] is C(m0 + 16 wr + 4 gq + r, n0 + 32 wc + 16 cb + i)
+  const uint64_t seed = g.seed ? *g.seed : 0;
+  const int64_t mb = m0 + 16 * wr + 4 * gq;
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb) {
+    const int64_t j = n0 + 32 * wc + 16 * cb + i;
+    if (j >= g.N) continue;
+    const float bj = g.bias ? g.bias[j] : 0.f;
+    float keep[4] = {1.f, 1.f, 1.f, 1.f};
+    if (g.seed && mb < g.M) mlp_keep4(g, seed, mb >> 2, (int)j, keep);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t m = mb + r;
+      if (m >= g.M) continue;
+      float v = (cb == 0 ? acc0[r] : acc1[r]) + bj;
+      if (g.relu) v = fmaxf(v, 0.f);
+      if (g.seed) v *= keep[r];
+      if (g.mask) v = g.mask[m * g.ldc + j] > 0.f ? v * g.mask_scale : 0.f;
+      g.C[m * g.ldc + j] = v;
+    }
+  }
+}
+
 // ---- 128 x 128 tiles for the large products -------------------------------------------------------------------------------
 // A 64 x 64 tile re-reads each operand element once per 64 columns of the other one and issues two ds_read_b32 per MFMA; at
 // B = 131,072 the three products of a layer ran at 20-34 % of the matrix peak.  On 128 x 128 tiles a wave owns a 64 x 64 quarter as
@@ -836,7 +969,26 @@ __global__ __launch_bounds__(kBlock) void mlp_split_epilogue_kernel(MlpGemm g, c
 }
 
 // one product C = A . B with its epilogue in `g`, through split-K when `part` (room for mlp_k_splits planes) is given
+// RC_MLP_SMALL=0: the 64 x 64 tiles (+ split-K) for every small product (A/B)
+static bool mlp_small_ok(const MlpGemm& g) {
+  static const int mode = [] {
+    const char* v = getenv("RC_MLP_SMALL");
+    return (v && v[0] == '0') ? 0 : 1;
+  }();
+  if (mode == 0 || g.ones_col >= 0 || !g.A.k_major || g.k_total != g.K || g.K % kSmBK != 0 || g.K < 2 * kSmBK) return false;
+  if (!vec4_ok(g.A) || !vec4_ok(g.B) || (!g.B.k_major && g.N % 4 != 0)) return false;
+  const int64_t tiles64 = ((g.M + kMlpBM - 1) / kMlpBM) * ((g.N + kMlpBN - 1) / kMlpBN);
+  return tiles64 < 512 && g.N >= 16;      // (beyond that the 64 x 64 tiles fill the chip by themselves)
+}
+
 static int mlp_product(MlpGemm g, float* part, hipStream_t s) {
+  if (mlp_small_ok(g)) {
+    dim3 grid((unsigned)((g.M + kSmBM - 1) / kSmBM), (unsigned)((g.N + kSmBN - 1) / kSmBN), 1);
+    if (g.B.k_major) hipLaunchKernelGGL(mlp_gemm_small_kernel<true>, grid, dim3(kBlock), 0, s, g);
+    else hipLaunchKernelGGL(mlp_gemm_small_kernel<false>, grid, dim3(kBlock), 0, s, g);
+    RC_LAUNCH_CHECK();
+    return RC_OK;
+  }
   const int splits = part ? mlp_k_splits(g.M, g.N, g.K) : 1;
   if (splits <= 1) return mlp_launch(g, 1, s);
   MlpGemm p = g;   // the partial products: no epilogue
