@@ -364,6 +364,10 @@ int rc_small_row_sums(const int64_t* ids, int64_t n, int64_t n_rows, const float
  * left in `ws` (same n, same n_rows, ws untouched in between) -- one launch instead of two.                                    */
 int rc_small_row_sums_again(int64_t n, int64_t n_rows, const float* src, int d, float* out, void* ws, size_t ws_bytes,
                             rc_stream_t stream);
+/* ... and where the second table is one float wide (the [vocab, 1] first-order weights, src1 [n], out1 [n_rows]) and d >= 16, both
+ * sums in the SAME launch: grouping + one row-sums kernel.                                                                     */
+int rc_small_row_sums_pair(const int64_t* ids, int64_t n, int64_t n_rows, const float* src, int d, float* out,
+                           const float* src1, float* out1, void* ws, size_t ws_bytes, rc_stream_t stream);
 
 /* The CTR head of the context models in one pass: z = bias[0] + sum_f lin[i, f] (+ term1[i]) (+ term2[i])
  * (models/context/FM.py:59-60, DeepFM.py:27, WideDeep.py:46), p = sigmoid(z) (BaseContextModel.py:74-78), the per-row term of

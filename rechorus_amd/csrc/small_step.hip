@@ -212,6 +212,8 @@ struct SmallSumArgs {
   const float* src;          // [n, d] gradient row of every occurrence
   float* out;                // [n_rows, d]; only touched rows are written
   int d;
+  const float* src1;         // optional second, ONE-float-wide gradient of the same occurrences ([n]) and its table [n_rows]:
+  float* out1;               // the [vocab, 1] first-order weights of the FM family ride along with the [vocab, d] vectors
 };
 
 // flat row index -> record (rows of plan workgroup w are the w-th segment; per-workgroup counts prefix-summed here)
@@ -262,10 +264,16 @@ __global__ __launch_bounds__(kBlock) void small_row_sums_kernel(SmallSumArgs a) 
     e.row = 0; e.start = 0; e.n = 0; e.reserved = 0;
     if (on) e = small_row_at(a, ix, r);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float acc1 = 0.f;
     const bool seq = on && e.n <= (uint32_t)kSmallSeq;
     if (seq) {
       acc = src4[(size_t)e.reserved * LPR + l];   // the record carries the row's first position
-      for (uint32_t k = 1; k < e.n; ++k) padd4s(acc, src4[(size_t)a.occ[e.start + k] * LPR + l]);
+      if (a.src1) acc1 = a.src1[e.reserved];
+      for (uint32_t k = 1; k < e.n; ++k) {
+        const uint32_t o = a.occ[e.start + k];
+        padd4s(acc, src4[(size_t)o * LPR + l]);
+        if (a.src1) acc1 += a.src1[o];
+      }
     }
     uint64_t hot = __ballot(on && !seq && l == 0);   // hot rows of this wave's groups, one after the other, by the whole wave
     while (hot) {
@@ -275,6 +283,7 @@ __global__ __launch_bounds__(kBlock) void small_row_sums_kernel(SmallSumArgs a) 
       // four occurrences in flight per lane-group (fixed pattern -> fixed order): the chain occ[] -> gradient row is two dependent
       // loads per trip, and a CTR field of a few values makes rows of hundreds of occurrences at B = 1,024
       float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), p1 = p0, p2 = p0, p3 = p0;
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
       for (uint32_t k = grp; k < hn; k += 4 * GPW) {
         const uint32_t o0 = a.occ[hs + k];
         const uint32_t o1 = k + GPW < hn ? a.occ[hs + k + GPW] : 0u;
@@ -286,8 +295,16 @@ __global__ __launch_bounds__(kBlock) void small_row_sums_kernel(SmallSumArgs a) 
         const float4 v2 = k + 2 * GPW < hn ? src4[(size_t)o2 * LPR + l] : z;
         const float4 v3 = k + 3 * GPW < hn ? src4[(size_t)o3 * LPR + l] : z;
         padd4s(p0, v0); padd4s(p1, v1); padd4s(p2, v2); padd4s(p3, v3);
+        if (a.src1) {
+          s0 += a.src1[o0];
+          if (k + GPW < hn) s1 += a.src1[o1];
+          if (k + 2 * GPW < hn) s2 += a.src1[o2];
+          if (k + 3 * GPW < hn) s3 += a.src1[o3];
+        }
       }
       padd4s(p0, p1); padd4s(p2, p3); padd4s(p0, p2);
+      const float part1 = groups_allreduce_sum<LPR, 64>((s0 + s1) + (s2 + s3));
+      if (lane / LPR == srcl / LPR) acc1 = part1;
       float4 part = p0;
       part.x = groups_allreduce_sum<LPR, 64>(part.x);
       part.y = groups_allreduce_sum<LPR, 64>(part.y);
@@ -296,6 +313,7 @@ __global__ __launch_bounds__(kBlock) void small_row_sums_kernel(SmallSumArgs a) 
       if (lane / LPR == srcl / LPR) acc = part;
     }
     if (on) reinterpret_cast<float4*>(a.out)[(size_t)e.row * LPR + l] = acc;
+    if (on && l == 0 && a.out1) a.out1[e.row] = acc1;
   }
 }
 
@@ -405,7 +423,7 @@ extern "C" size_t rc_small_row_sums_workspace_bytes(int64_t n) {
 }
 
 static int small_row_sums_impl(bool build_plan, const int64_t* ids, int64_t n, int64_t n_rows, const float* src, int d, float* out, void* ws,
-                               size_t ws_bytes, rc_stream_t stream) {
+                               size_t ws_bytes, rc_stream_t stream, const float* src1 = nullptr, float* out1 = nullptr) {
   if (n == 0) return RC_OK;
   RC_REQUIRE((ids || !build_plan) && src && out && ws, "rc_small_row_sums: null pointer");
   if (!rc_small_row_sums_supported(n, n_rows, d))
@@ -441,6 +459,8 @@ static int small_row_sums_impl(bool build_plan, const int64_t* ids, int64_t n, i
   }
   SmallSumArgs a;
   a.rows = rows; a.occ = occ; a.cnt = cnt; a.n = (uint32_t)n; a.src = src; a.out = out; a.d = d;
+  a.src1 = src1; a.out1 = out1;
+  RC_REQUIRE((src1 == nullptr) == (out1 == nullptr) && (src1 == nullptr || d >= 16), "rc_small_row_sums_pair: the one-float-wide pair rides with d >= 16 only");
   if (d <= 4) {
     unsigned blocks = (unsigned)((n + kBlock / 64 - 1) / (kBlock / 64));
     if (blocks > 1024u) blocks = 1024u;
@@ -468,4 +488,10 @@ extern "C" int rc_small_row_sums(const int64_t* ids, int64_t n, int64_t n_rows, 
 extern "C" int rc_small_row_sums_again(int64_t n, int64_t n_rows, const float* src, int d, float* out, void* ws, size_t ws_bytes,
                                        rc_stream_t stream) {
   return small_row_sums_impl(false, nullptr, n, n_rows, src, d, out, ws, ws_bytes, stream);
+}
+
+extern "C" int rc_small_row_sums_pair(const int64_t* ids, int64_t n, int64_t n_rows, const float* src, int d, float* out,
+                                      const float* src1, float* out1, void* ws, size_t ws_bytes, rc_stream_t stream) {
+  RC_REQUIRE(src1 && out1, "rc_small_row_sums_pair: null pointer");
+  return small_row_sums_impl(true, ids, n, n_rows, src, d, out, ws, ws_bytes, stream, src1, out1);
 }

@@ -492,6 +492,11 @@ def small_row_sums_pair(cid, n_rows, src_a, src_b):
     Ga, Gb = G[:n_rows * d_a].view(n_rows, d_a), G[n_rows * d_a:].view(n_rows, d_b)
     ws = workspace(_lib.load().rc_small_row_sums_workspace_bytes(n), src_a.device, "edb_small_pair")
     flat = cid.reshape(-1)
+    if d_b == 1 and d_a >= 16:     # the one-float-wide table rides in the vectors' row-sums launch
+        _lib.call("rc_small_row_sums_pair", _ptr(flat, torch.int64, "ids"), n, int(n_rows), _ptr(src_a, torch.float32, "src_a"), d_a,
+                  C.c_void_p(Ga.data_ptr()), _ptr(src_b, torch.float32, "src_b"), C.c_void_p(Gb.data_ptr()), C.c_void_p(ws.data_ptr()),
+                  ws.numel(), _stream())
+        return Ga, Gb
     _lib.call("rc_small_row_sums", _ptr(flat, torch.int64, "ids"), n, int(n_rows), _ptr(src_a, torch.float32, "src_a"), d_a,
               C.c_void_p(Ga.data_ptr()), C.c_void_p(ws.data_ptr()), ws.numel(), _stream())
     _lib.call("rc_small_row_sums_again", n, int(n_rows), _ptr(src_b, torch.float32, "src_b"), d_b, C.c_void_p(Gb.data_ptr()),
