@@ -38,12 +38,16 @@ CASES = [
      r"rc_neumf_train_step(_marked)?"),
     ("sequential", "SASRec", ["--emb_size", "32", "--num_layers", "1", "--num_heads", "2", "--history_max", "10", "--lr", "3e-3",
                               "--l2", "1e-6", "--dropout", "0"], "SasrecTrainer", r"rc_sasrec\w*"),
+    # the reference's own NeuMF command line (docs/demo_scripts_results/Topk_Amazon.sh:8): --dropout 0.2 -> the mask inside the fused kernel
+    ("general", "NeuMF", ["--emb_size", "64", "--layers", "[64]", "--lr", "5e-4", "--l2", "1e-7", "--dropout", "0.2"], "NeumfTrainer",
+     r"rc_neumf_train_step_dropout"),
 ]
 
 
 def _run(model_args, name, dataset_root, out, monkeypatch, model_dir):
     import main
-    from rechorus_amd import _lib, engine
+    from rechorus_amd import _lib, engine, nn as hnn
+    monkeypatch.setattr(hnn, "_DROP_SEED_GEN", None)    # both runs draw the same first dropout seed (the generator follows --random_seed)
     if model_dir:
         monkeypatch.setenv("RECHORUS_MODEL_DIRS", model_dir)
     else:
