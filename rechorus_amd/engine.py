@@ -960,16 +960,9 @@ class NeumfTrainer:
             # epoch announced by a large one) that runs on one stream: a flag left behind would make a later single occurrence
             # of that row look like a multiple one, and its update would be dropped
             neumf_mark_rows(iid, n_i, self._marks[buf], unmark=True)
-        loss_done = None
         if two_streams and (next_batch is not None or marks_done is not None):
             self._side.wait_stream(main)    # behind the fused kernel: beside the updates below
             with torch.cuda.stream(self._side):
-                # the batch mean of the per-tuple losses (one workgroup walking 65,536 values written by every XCD: 25 us of latency)
-                # goes FIRST on this stream, whose work -- the next batch's flags and plan -- is nobody's critical path; in front of
-                # the user-side update (where it stood) it delayed the stream that ends the step by its full 25 us
-                self.loss = reduce_sum(out["loss_vec"], 1.0 / B)
-                self.loss.record_stream(main)       # (allocated on this stream's pool, read by the caller on its own)
-                loss_done = self._side.record_event()
                 if marks_done is not None:
                     neumf_mark_rows(iid, n_i, self._marks[buf], unmark=True)
                     iid.record_stream(self._side)   # the runner drops the batch when step() returns; the allocator must not
@@ -985,10 +978,11 @@ class NeumfTrainer:
                     self._ahead = {"key": self._batch_key(nu, ni), "plan": nplan, "plan_done": self._side.record_event(),
                                    "marks_done": nmarks_done, "iid": ni, "buf": buf ^ 1}
         if two_streams:
+            # the batch mean of the per-tuple losses (one workgroup, 10 us of latency) on the user side's stream, where it fills
+            # the wait for the plan instead of standing in front of the item update
             self._side2.wait_stream(main)
-            if loss_done is None:     # nothing runs on the plan's stream in this step: the mean on the user side's stream
-                with torch.cuda.stream(self._side2):
-                    self.loss = reduce_sum(out["loss_vec"], 1.0 / B)
+            with torch.cuda.stream(self._side2):
+                self.loss = reduce_sum(out["loss_vec"], 1.0 / B)
         else:
             with _PhaseTimer(self, "loss"):
                 self.loss = reduce_sum(out["loss_vec"], 1.0 / B)
@@ -1010,8 +1004,6 @@ class NeumfTrainer:
                     upd(*sides[1])
                 upd(*sides[0])
                 main.wait_stream(self._side2)
-                if loss_done is not None:
-                    main.wait_event(loss_done)    # the loss is the caller's on its own stream (long done: 25 us behind the fused kernel)
             else:
                 upd(*sides[0])
                 upd(*sides[1])
