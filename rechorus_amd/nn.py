@@ -591,10 +591,12 @@ class _MlpFn(torch.autograd.Function):
                 # one kernel for this layer and the output layer: H2 (saved: the output layer's input and this layer's mask), z
                 W3 = params[2 * (n - 1)].detach().contiguous()
                 b3 = params[2 * (n - 1) + 1].detach().contiguous() if spec[n - 1][2] else None
-                H2, z = engine.tower_tail_fwd(h, W, b, W3, b3, p, seed, site)
-                saved += [h, W, H2, W3]
-                h = z
-                break
+                if all(t.data_ptr() % 16 == 0 for t in (h, W, W3)):   # (float4 operand loads; an offset view keeps the GEMM route)
+                    H2, z = engine.tower_tail_fwd(h, W, b, W3, b3, p, seed, site)
+                    saved += [h, W, H2, W3]
+                    h = z
+                    break
+                tail = False
             y = engine.linear_fwd(h, W, b, relu, p, seed, site)
             saved += [h, W]
             h = y
