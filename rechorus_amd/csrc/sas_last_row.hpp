@@ -630,9 +630,13 @@ __global__ __launch_bounds__(kBlock) void sb_lr_wgrad_kernel(SbLrWgradArgs a) {
     __syncthreads();   // the previous pass's readers are done
     for (int e = threadIdx.x; e < CH * D / 4; e += kBlock) {
       const bool on = e / (D / 4) < m;
-      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-      reinterpret_cast<float4*>(sq)[e] = on ? reinterpret_cast<const float4*>(a.q + (size_t)c0 * D)[e] : z;
-      reinterpret_cast<float4*>(sg)[e] = on ? reinterpret_cast<const float4*>(a.g + (size_t)c0 * D)[e] : z;
+      float4 vq = make_float4(0.f, 0.f, 0.f, 0.f), vg = vq;     // (no named zero in a ternary: it was kept in a stack slot)
+      if (on) {
+        vq = reinterpret_cast<const float4*>(a.q + (size_t)c0 * D)[e];
+        vg = reinterpret_cast<const float4*>(a.g + (size_t)c0 * D)[e];
+      }
+      reinterpret_cast<float4*>(sq)[e] = vq;
+      reinterpret_cast<float4*>(sg)[e] = vg;
     }
     if ((int)threadIdx.x < CH * kLrMaxHeads)
       ssd[threadIdx.x] = (int)threadIdx.x / kLrMaxHeads < m ? a.sds[(size_t)c0 * kLrMaxHeads + threadIdx.x] : 0.f;

@@ -1256,11 +1256,15 @@ __global__ __launch_bounds__(kBlock) void sb_wgrad_kernel(SbWgradArgs a) {
 #pragma unroll
     for (int q = 0; q < PF; ++q) {
       const int idx = threadIdx.x + q * kBlock, i = idx / (D / 4), c = idx % (D / 4);
-      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);  // rows past m are zero-filled
-      pfx[q] = i < m ? reinterpret_cast<const float4*>(a.X)[(size_t)(r0 + i) * (D / 4) + c] : z;
+      // rows past m are zero-filled (assigned, not selected from a named zero: a const float4 in the ternary was kept in a stack slot --
+      // 32 bytes of scratch per lane for one dead store)
+      pfx[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i < m) pfx[q] = reinterpret_cast<const float4*>(a.X)[(size_t)(r0 + i) * (D / 4) + c];
 #pragma unroll
-      for (int p = 0; p < NP; ++p)
-        pfy[p][q] = i < m ? reinterpret_cast<const float4*>(a.dY[p])[(size_t)(r0 + i) * (D / 4) + c] : z;
+      for (int p = 0; p < NP; ++p) {
+        pfy[p][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < m) pfy[p][q] = reinterpret_cast<const float4*>(a.dY[p])[(size_t)(r0 + i) * (D / 4) + c];
+      }
     }
   };
   if ((int)blockIdx.x < tiles) fetch(blockIdx.x);
