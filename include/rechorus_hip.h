@@ -121,6 +121,13 @@ int rc_gather_fields(const float* const* tables, const int64_t* const* ids, cons
 int rc_gather_fields_pair(const float* const* tables, const float* const* tables1, const int64_t* const* ids, const int* per_row,
                           const int64_t* row_offset, int F, int64_t B, int C, int d, float* out, float* out1, int64_t* cid,
                           rc_stream_t stream);
+/* The same, and every composite row the batch looks up is stamped row_flags[row_offset[f] + id] = (int32) (step_dev[0] + step_add):
+ * the rows of THIS step for rc_dense_update_rows_dev (row_flags [sum of vocab sizes], never reset: a stamp of an earlier step is
+ * not equal to the current one; step_add = 1 when the optimizer increments its count after the backward pass).                    */
+int rc_gather_fields_pair_mark(const float* const* tables, const float* const* tables1, const int64_t* const* ids,
+                               const int* per_row, const int64_t* row_offset, int F, int64_t B, int C, int d, float* out,
+                               float* out1, int64_t* cid, int32_t* row_flags, const int64_t* step_dev, int step_add,
+                               rc_stream_t stream);
 
 /* nn.BCELoss on probabilities (CTRModel.loss, models/BaseModel.py:259-267), torch's log clamp (-100) and
  * backward denominator clamp (1e-12): loss_vec[i] = -(y log p + (1-y) log(1-p)); gp[i] = dmean/dp_i
@@ -285,6 +292,19 @@ int rc_dense_update_multi_dev(float* const* W, const float* const* G, float* con
                               const int64_t* n, const rc_opt_hyper* h, int n_tensors, const int64_t* step_dev,
                               rc_stream_t stream);
 int rc_step_increment(int64_t* step_dev, rc_stream_t stream);
+/* torch.optim.Adam over dense gradients of embedding tables whose batch touches few rows (helpers/BaseRunner.py:110-114,206 with
+ * the nn.Embedding tables of models/context/FM.py:33-41 at batch_size 1024: 0.4 % of the rows have a gradient), WITHOUT a dense
+ * gradient: tensor t is [n[t] / row_w[t], row_w[t]] with one int32 flag per row, and a row whose flag equals (int32) step_dev[0]
+ * was looked up by this step's batch (rc_gather_fields_pair_mark); only those rows of G[t] hold (and are read for) a gradient, the
+ * rest of G[t] is never read -- so nothing zero-fills it.  touched = 2: every row takes its Adam step, g = G's row where stamped
+ * and 0 elsewhere (Adam still decays m, v and steps along m there): bit-identical to rc_dense_update_multi_dev on a zero-filled
+ * dense gradient.  touched = 0 / 1 are the two halves of that pass -- the unstamped rows with g = 0 (G[t] may be NULL) / the
+ * stamped rows from G[t] -- for a caller that wants them on different streams.  flags[t] == NULL makes tensor t a plain tensor
+ * (all of it updated from G[t] whatever `touched`).  Adam only; step count in device memory, already incremented for this step.
+ * max_blocks > 0 caps the grid (workgroups then walk the 4096-element chunks with the grid's stride).                          */
+int rc_dense_update_rows_dev(float* const* W, const float* const* G, float* const* m, float* const* v, const int64_t* n,
+                             const int32_t* const* flags, const int* row_w, const rc_opt_hyper* h, int n_tensors, int touched,
+                             int max_blocks, const int64_t* step_dev, rc_stream_t stream);
 /* dst = [a | b | c] (int64): the id tensors of a batch (feed_dict['history_items'], ['lengths'], ['item_id'],
  * models/sequential/SASRec.py:58-60) copied into the static buffer a captured step reads, in one launch. */
 int rc_stage_batch(const int64_t* a, int64_t na, const int64_t* b, int64_t nb, const int64_t* c, int64_t nc, int64_t* dst,

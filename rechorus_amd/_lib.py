@@ -83,6 +83,7 @@ SIGNATURES = {
     "rc_fm_second_order_bwd_add": (_i, [_p, _p, _i64, _i, _i, _p, _p, _p]),
     "rc_gather_fields": (_i, [_p, _p, _p, _p, _i, _i64, _i, _i, _p, _p, _p]),
     "rc_gather_fields_pair": (_i, [_p, _p, _p, _p, _p, _i, _i64, _i, _i, _p, _p, _p, _p]),
+    "rc_gather_fields_pair_mark": (_i, [_p, _p, _p, _p, _p, _i, _i64, _i, _i, _p, _p, _p, _p, _p, _i, _p]),
     "rc_bce_ranking_fwd_bwd": (_i, [_p, _i64, _i, _f, _p, _p, _p]),
     "rc_bce_prob_fwd_bwd": (_i, [_p, _p, _i64, _f, _p, _p, _p]),
     "rc_sample_negatives": (_i, [_p, _i64, _i, _i64, _p, _p, C.c_uint64, C.c_uint64, _p, _p]),
@@ -109,6 +110,7 @@ SIGNATURES = {
     "rc_dense_update_multi": (_i, [_p, _p, _p, _p, _p, _p, _i, _p]),
     "rc_dense_update_multi_dev": (_i, [_p, _p, _p, _p, _p, _p, _i, _p, _p]),
     "rc_step_increment": (_i, [_p, _p]),
+    "rc_dense_update_rows_dev": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p]),
     "rc_stage_batch": (_i, [_p, _i64, _p, _i64, _p, _i64, _p, _p]),
     "rc_segmented_update2": (_i, [_p, _p, _p, _i, _p, _p, _i64, _p, _p, _p, _i, _p, _i64, _i64, _i64, _hp, _p, _p,
                                   _p, _i, _p, _sz, _p]),

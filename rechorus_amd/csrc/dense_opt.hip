@@ -138,6 +138,103 @@ __global__ __launch_bounds__(kBlock) void dense_update_multi_kernel(MultiArgs a)
   }
 }
 
+// ---- row-flagged dense update: the [vocab, d] field tables of a step that touches few rows -------------------------------
+// torch.optim.Adam over a dense gradient moves EVERY row every step (g = 0 still decays m, v and steps along m), so the pass
+// over the tables cannot be skipped -- but it only depends on the gradient for the rows the batch looked up.  Those rows are
+// flagged by the gather (flags[row] == the step's number); `touched = 0` updates every OTHER row with g = 0 (no gradient buffer
+// is read, so none is zero-filled, and the pass can run beside forward / backward on a second stream), `touched = 1` the
+// flagged rows with their row sums.  Items with flags == nullptr are plain tensors (every element, from G).  Element
+// arithmetic: opt_elem, as in dense_update_multi_kernel -- the two passes together are bit-identical to the dense step.
+constexpr int kRowsMax = 24;
+
+struct RowsArgs {
+  float* W[kRowsMax];
+  const float* G[kRowsMax];
+  float* M[kRowsMax];
+  float* V[kRowsMax];
+  const int32_t* flags[kRowsMax];
+  int64_t n[kRowsMax];
+  OptScalars o[kRowsMax];
+  uint32_t blk0[kRowsMax + 1];
+  int row_w[kRowsMax];
+  float lr[kRowsMax];
+  uint8_t aligned[kRowsMax];
+  int T;
+  int touched;
+  const int64_t* step_dev;
+  double beta1, beta2;
+};
+
+template <int MODE>
+__device__ __forceinline__ void rows_elem(const OptScalars& o, float* W, const float* G, float* M, float* V, const int32_t* flags,
+                                          int64_t row0, uint32_t rem0, uint32_t row_w, int32_t gen, int mode, int i) {
+  bool has_g = true;
+  if (flags) {
+    const bool hit = flags[row0 + (rem0 + (uint32_t)i) / row_w] == gen;
+    if (mode != 2 && hit != (mode == 1)) return;
+    has_g = hit && mode != 0;
+  }
+  float w1 = W[i], m1 = M[i], v1 = V[i];
+  opt_elem<MODE>(o, has_g ? G[i] : 0.f, w1, m1, v1);
+  W[i] = w1; M[i] = m1; V[i] = v1;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void dense_update_rows_kernel(RowsArgs a) {
+  const int64_t step64 = *a.step_dev;
+  const int32_t gen = (int32_t)step64;
+  const int mode = a.touched;     // 0: the rows without this step's stamp (g = 0); 1: the stamped rows (from G); 2: every row
+  const uint32_t n_chunks = a.blk0[a.T];
+  int t = 0;
+  // (the grid may be smaller than the number of chunks: the pass over the untouched rows shares the chip with the step's other
+  // kernels -- a few resident workgroups per CU that stream, instead of a grid that fills every wave slot)
+  for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+    while (t + 1 < a.T && chunk >= a.blk0[t + 1]) ++t;  // block-uniform, chunks ascend
+    const int64_t base = (int64_t)(chunk - a.blk0[t]) * kMultiChunk;
+    const int64_t n = a.n[t];
+    const int len = (int)(base + kMultiChunk < n ? kMultiChunk : n - base);
+    float* W = a.W[t] + base;
+    const float* G = a.G[t] ? a.G[t] + base : nullptr;
+    float* M = a.M[t] + base;
+    float* V = a.V[t] + base;
+    const int32_t* flags = a.flags[t];
+    const uint32_t row_w = (uint32_t)a.row_w[t];
+    OptScalars o = a.o[t];
+    auto bias_corrections = [&]() {
+      if (MODE == MODE_ADAM) {
+        const double step = (double)step64;
+        const double bc1 = 1.0 - pow(a.beta1, step), bc2 = 1.0 - pow(a.beta2, step);
+        o.neg_step = (float)(-((double)a.lr[t] / bc1));
+        o.bc2_sqrt = (float)sqrt(bc2);
+      }
+    };
+    const int64_t row0 = flags ? base / row_w : 0;
+    const uint32_t rem0 = flags ? (uint32_t)(base - row0 * row_w) : 0u;
+    if (a.aligned[t]) {   // 16-byte aligned pointers and row_w % 4 == 0: a float4 never straddles two rows
+      const int len4 = (len / 4) * 4;
+      bias_corrections();
+      // (the loop of dense_update_multi_kernel plus the flag test: holding a chunk's four float4 per thread in registers to batch
+      // the loads cost occupancy -- 138 VGPRs, 5.5 TB/s against this loop's 7)
+      for (int i = 4 * (int)threadIdx.x; i < len4; i += 4 * kBlock) {
+        bool has_g = true;
+        if (flags) {
+          const bool hit = flags[row0 + (rem0 + (uint32_t)i) / row_w] == gen;
+          if (mode != 2 && hit != (mode == 1)) continue;
+          has_g = hit && mode != 0;
+        }
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (has_g) g = *reinterpret_cast<const float4*>(G + i);
+        const float4 w = *reinterpret_cast<const float4*>(W + i);
+        opt_row4<MODE>(o, W, M, V, (size_t)(i / 4), w, g);
+      }
+      for (int i = len4 + (int)threadIdx.x; i < len; i += kBlock) rows_elem<MODE>(o, W, G, M, V, flags, row0, rem0, row_w, gen, mode, i);
+    } else {
+      bias_corrections();
+      for (int i = (int)threadIdx.x; i < len; i += kBlock) rows_elem<MODE>(o, W, G, M, V, flags, row0, rem0, row_w, gen, mode, i);
+    }
+  }
+}
+
 }  // namespace rc
 
 using namespace rc;
@@ -191,12 +288,12 @@ extern "C" int rc_dense_update_multi_dev(float* const* W, const float* const* G,
   hipStream_t s = as_stream(stream);
   auto al = [](const void* p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; };
   const int opt = h[0].opt;
-  for (int t0 = 0; t0 < n_tensors; t0 += kMultiMax) {
+  for (int t0 = 0; t0 < n_tensors;) {
     MultiArgs a;
     memset(&a, 0, sizeof(a));
     uint32_t blocks = 0;
-    int T = 0;
-    for (int t = t0; t < n_tensors && T < kMultiMax; ++t) {
+    int T = 0, t = t0;
+    for (; t < n_tensors && T < kMultiMax; ++t) {
       RC_REQUIRE(h[t].opt == opt, "rc_dense_update_multi: one optimizer kind per call");
       RC_REQUIRE(n[t] >= 0, "rc_dense_update_multi: n < 0");
       if (n[t] == 0) continue;
@@ -217,6 +314,7 @@ extern "C" int rc_dense_update_multi_dev(float* const* W, const float* const* G,
       blocks += (uint32_t)nb;
       ++T;
     }
+    t0 = t;   // (empty tensors do not take a slot: the next launch starts where this one stopped)
     if (T == 0) continue;
     a.blk0[T] = blocks;
     a.T = T;
@@ -239,6 +337,57 @@ extern "C" int rc_dense_update_multi_dev(float* const* W, const float* const* G,
       default:
         return fail(RC_ERR_INVALID_ARG, "rc_dense_update_multi: unknown optimizer %d", opt);
     }
+    RC_LAUNCH_CHECK();
+  }
+  return RC_OK;
+}
+
+extern "C" int rc_dense_update_rows_dev(float* const* W, const float* const* G, float* const* m, float* const* v,
+                                        const int64_t* n, const int32_t* const* flags, const int* row_w, const rc_opt_hyper* h,
+                                        int n_tensors, int touched, int max_blocks, const int64_t* step_dev, rc_stream_t stream) {
+  if (n_tensors == 0) return RC_OK;
+  RC_REQUIRE(W && n && h && flags && row_w && n_tensors > 0, "rc_dense_update_rows_dev: bad arguments");
+  RC_REQUIRE(step_dev != nullptr, "rc_dense_update_rows_dev: the step count lives in device memory (step_dev)");
+  RC_REQUIRE(touched >= 0 && touched <= 2, "rc_dense_update_rows_dev: touched is 0, 1 or 2");
+  hipStream_t s = as_stream(stream);
+  auto al = [](const void* p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; };
+  for (int t0 = 0; t0 < n_tensors;) {
+    RowsArgs a;
+    memset(&a, 0, sizeof(a));
+    uint32_t blocks = 0;
+    int T = 0, t = t0;
+    for (; t < n_tensors && T < kRowsMax; ++t) {
+      RC_REQUIRE(h[t].opt == RC_OPT_ADAM, "rc_dense_update_rows_dev: Adam only (the other optimizers leave rows with g = 0 and "
+                 "no weight decay alone -- their sparse-aware step is rc_segmented_update)");
+      RC_REQUIRE(n[t] >= 0, "rc_dense_update_rows_dev: n < 0");
+      if (n[t] == 0) continue;
+      const bool needs_g = flags[t] == nullptr || touched != 0;
+      RC_REQUIRE(W[t] && m && v && m[t] && v[t], "rc_dense_update_rows_dev: null pointer (tensor %d)", t);
+      RC_REQUIRE(!needs_g || (G && G[t]), "rc_dense_update_rows_dev: null gradient (tensor %d)", t);
+      RC_REQUIRE(flags[t] == nullptr || (row_w[t] >= 1 && n[t] % row_w[t] == 0), "rc_dense_update_rows_dev: n is not rows x row_w (tensor %d)", t);
+      RC_REQUIRE(h[t].beta1 == h[0].beta1 && h[t].beta2 == h[0].beta2, "rc_dense_update_rows_dev: one (beta1, beta2) per call");
+      a.W[T] = W[t]; a.G[T] = needs_g ? G[t] : nullptr; a.M[T] = m[t]; a.V[T] = v[t]; a.n[T] = n[t];
+      a.flags[T] = flags[t];
+      a.row_w[T] = flags[t] ? row_w[t] : 4;
+      RC_TRY(fill_opt_scalars(&h[t], &a.o[T], /*dense=*/true));
+      a.lr[T] = (float)h[t].lr;
+      a.aligned[T] = al(W[t]) && (!needs_g || al(G[t])) && al(m[t]) && al(v[t]) && a.row_w[T] % 4 == 0;
+      a.blk0[T] = blocks;
+      const int64_t nb = (n[t] + kMultiChunk - 1) / kMultiChunk;
+      RC_REQUIRE(nb < ((int64_t)1 << 30) - blocks, "rc_dense_update_rows_dev: grid too large");
+      blocks += (uint32_t)nb;
+      ++T;
+    }
+    t0 = t;
+    if (T == 0) continue;
+    a.blk0[T] = blocks;
+    a.T = T;
+    a.touched = touched;
+    a.step_dev = step_dev;
+    a.beta1 = h[0].beta1;
+    a.beta2 = h[0].beta2;
+    const uint32_t grid = max_blocks > 0 && blocks > (uint32_t)max_blocks ? (uint32_t)max_blocks : blocks;
+    hipLaunchKernelGGL((dense_update_rows_kernel<MODE_ADAM>), dim3(grid), dim3(kBlock), 0, s, a);
     RC_LAUNCH_CHECK();
   }
   return RC_OK;

@@ -348,8 +348,13 @@ struct FieldArgs {
 // the compiler keeps such an array in scratch -- and paid three 64-bit divisions per element: 93 us for 268 MB out at B = 131,072.)
 template <int VEC>
 __global__ __launch_bounds__(kBlock) void gather_fields_kernel(FieldArgs a, float* __restrict__ out,
-                                                               int64_t* __restrict__ cid, float* __restrict__ out1) {
+                                                               int64_t* __restrict__ cid, float* __restrict__ out1,
+                                                               int32_t* __restrict__ row_flags, const int64_t* __restrict__ step_dev,
+                                                               int step_add) {
   const int dq = a.d / VEC;
+  // rc_gather_fields_pair_mark: every looked-up composite row is stamped with the step's number (the row-flagged dense update,
+  // dense_opt.hip, tells the rows of this batch from the rest by it; equal stamps from duplicate ids race benignly)
+  const int32_t gen = row_flags ? (int32_t)(*step_dev + step_add) : 0;
   const int64_t total = a.n * dq;
   for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += (int64_t)gridDim.x * kBlock) {
     const int64_t r = e / dq;            // b * C + c
@@ -389,6 +394,11 @@ __global__ __launch_bounds__(kBlock) void gather_fields_kernel(FieldArgs a, floa
         for (int u = 0; u < U; ++u)
           if (f0 + u < a.F) cid[r * a.F + f0 + u] = a.row_offset[f0 + u] + id[u];
       }
+      if (q == 0 && row_flags) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          if (f0 + u < a.F) row_flags[a.row_offset[f0 + u] + id[u]] = gen;
+      }
       if (q == 0 && out1) {   // the first-order weights of the same ids: [n, F]
         float w1[U];
 #pragma unroll
@@ -408,8 +418,9 @@ __global__ __launch_bounds__(kBlock) void gather_fields_kernel(FieldArgs a, floa
 
 static int gather_fields_impl(const float* const* tables, const float* const* tables1, const int64_t* const* ids, const int* per_row,
                               const int64_t* row_offset, int F, int64_t B, int C, int d, float* out, float* out1, int64_t* cid,
-                              rc_stream_t stream) {
+                              int32_t* row_flags, const int64_t* step_dev, int step_add, rc_stream_t stream) {
   if (B == 0) return RC_OK;
+  RC_REQUIRE((row_flags == nullptr) == (step_dev == nullptr), "rc_gather_fields_pair_mark: the row flags and the step count come together");
   RC_REQUIRE(tables && ids && per_row && row_offset && out, "rc_gather_fields: null pointer");
   RC_REQUIRE((tables1 == nullptr) == (out1 == nullptr), "rc_gather_fields_pair: the second table family and its output come together");
   RC_REQUIRE(F >= 1 && F <= kMaxFields, "rc_gather_fields: F must be in [1, %d], got %d", kMaxFields, F);
@@ -431,9 +442,9 @@ static int gather_fields_impl(const float* const* tables, const float* const* ta
   int64_t blocks = (total + kBlock - 1) / kBlock;
   if (blocks > 256 * 32) blocks = 256 * 32;
   if (vec)
-    hipLaunchKernelGGL((gather_fields_kernel<4>), dim3((unsigned)blocks), dim3(kBlock), 0, as_stream(stream), a, out, cid, out1);
+    hipLaunchKernelGGL((gather_fields_kernel<4>), dim3((unsigned)blocks), dim3(kBlock), 0, as_stream(stream), a, out, cid, out1, row_flags, step_dev, step_add);
   else
-    hipLaunchKernelGGL((gather_fields_kernel<1>), dim3((unsigned)blocks), dim3(kBlock), 0, as_stream(stream), a, out, cid, out1);
+    hipLaunchKernelGGL((gather_fields_kernel<1>), dim3((unsigned)blocks), dim3(kBlock), 0, as_stream(stream), a, out, cid, out1, row_flags, step_dev, step_add);
   RC_LAUNCH_CHECK();
   return RC_OK;
 }
@@ -441,14 +452,22 @@ static int gather_fields_impl(const float* const* tables, const float* const* ta
 extern "C" int rc_gather_fields(const float* const* tables, const int64_t* const* ids, const int* per_row,
                                 const int64_t* row_offset, int F, int64_t B, int C, int d, float* out, int64_t* cid,
                                 rc_stream_t stream) {
-  return gather_fields_impl(tables, nullptr, ids, per_row, row_offset, F, B, C, d, out, nullptr, cid, stream);
+  return gather_fields_impl(tables, nullptr, ids, per_row, row_offset, F, B, C, d, out, nullptr, cid, nullptr, nullptr, 0, stream);
 }
 
 extern "C" int rc_gather_fields_pair(const float* const* tables, const float* const* tables1, const int64_t* const* ids, const int* per_row,
                                      const int64_t* row_offset, int F, int64_t B, int C, int d, float* out, float* out1, int64_t* cid,
                                      rc_stream_t stream) {
   RC_REQUIRE(tables1 && out1, "rc_gather_fields_pair: null pointer");
-  return gather_fields_impl(tables, tables1, ids, per_row, row_offset, F, B, C, d, out, out1, cid, stream);
+  return gather_fields_impl(tables, tables1, ids, per_row, row_offset, F, B, C, d, out, out1, cid, nullptr, nullptr, 0, stream);
+}
+
+extern "C" int rc_gather_fields_pair_mark(const float* const* tables, const float* const* tables1, const int64_t* const* ids,
+                                          const int* per_row, const int64_t* row_offset, int F, int64_t B, int C, int d, float* out,
+                                          float* out1, int64_t* cid, int32_t* row_flags, const int64_t* step_dev, int step_add,
+                                          rc_stream_t stream) {
+  RC_REQUIRE(tables1 && out1 && row_flags && step_dev, "rc_gather_fields_pair_mark: null pointer");
+  return gather_fields_impl(tables, tables1, ids, per_row, row_offset, F, B, C, d, out, out1, cid, row_flags, step_dev, step_add, stream);
 }
 
 // ---- point-wise BCE over a ranking list (ContextModel.loss, loss_n == 'BCE': models/BaseContextModel.py:53-56)

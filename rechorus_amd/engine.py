@@ -483,12 +483,14 @@ def embedding_dense_backward(grad_out, ids, n_rows, route=None, presorted=None, 
     return G
 
 
-def small_row_sums_pair(cid, n_rows, src_a, src_b):
+def small_row_sums_pair(cid, n_rows, src_a, src_b, into=None):
     """two dense gradients [n_rows, d_a], [n_rows, d_b] of per-occurrence rows src_a [n, d_a], src_b [n, d_b] that share their ids:
-    ONE zero fill (both live in one buffer), ONE grouping (rc_small_row_sums, then rc_small_row_sums_again for the second)"""
+    ONE zero fill (both live in one buffer), ONE grouping (rc_small_row_sums, then rc_small_row_sums_again for the second).
+    into: a float buffer of n_rows * (d_a + d_b) elements that is NOT zero-filled -- only the rows of `cid` are written (the
+    kernels assign row sums), for a consumer that reads only those (dense_update_rows(touched=True))"""
     n = cid.numel()
     d_a, d_b = src_a.shape[1], src_b.shape[1]
-    G = torch.zeros(n_rows * (d_a + d_b), dtype=torch.float32, device=src_a.device)
+    G = torch.zeros(n_rows * (d_a + d_b), dtype=torch.float32, device=src_a.device) if into is None else into
     Ga, Gb = G[:n_rows * d_a].view(n_rows, d_a), G[n_rows * d_a:].view(n_rows, d_b)
     ws = workspace(_lib.load().rc_small_row_sums_workspace_bytes(n), src_a.device, "edb_small_pair")
     flat = cid.reshape(-1)
@@ -531,6 +533,27 @@ def dense_update_multi(items, opt, step_dev=None, increment=True):
     if increment:
         _lib.call("rc_step_increment", _ptr(step_dev, torch.int64, "step_dev"), _stream())
     _lib.call("rc_dense_update_multi_dev", Wa, Ga, Ma, Va, na, ha, T, _ptr(step_dev, torch.int64, "step_dev"), _stream())
+
+
+def dense_update_rows(items, step_dev, touched=2, max_blocks=0):
+    """items: list of (W, G | None, hyper, m, v, flags | None, row_w) -> rc_dense_update_rows_dev: Adam over W without a dense
+    gradient -- touched=2: every row, g = G's row where the row's int32 flag equals the step and 0 elsewhere (the rest of G is
+    never read); touched=1 / 0: only the stamped rows (from G) / only the others (g = 0).  flags None = the whole tensor from G.
+    The step count was already incremented for this step.  max_blocks > 0: grid cap."""
+    T = len(items)
+    if T == 0:
+        return
+    f32 = torch.float32
+    Wa = (C.c_void_p * T)(*[_ptr(it[0], f32, "W").value for it in items])
+    Ga = (C.c_void_p * T)(*[_ptr(it[1], f32, "G", True).value for it in items])
+    Ma = (C.c_void_p * T)(*[_ptr(it[3], f32, "m").value for it in items])
+    Va = (C.c_void_p * T)(*[_ptr(it[4], f32, "v").value for it in items])
+    na = (C.c_int64 * T)(*[it[0].numel() for it in items])
+    Fa = (C.c_void_p * T)(*[_ptr(it[5], torch.int32, "flags", True).value for it in items])
+    ra = (C.c_int * T)(*[int(it[6]) for it in items])
+    ha = (OptHyper * T)(*[it[2] for it in items])
+    _lib.call("rc_dense_update_rows_dev", Wa, Ga, Ma, Va, na, Fa, ra, ha, T, int(touched), int(max_blocks),
+              _ptr(step_dev, torch.int64, "step_dev"), _stream())
 
 
 # ---- whole BPRMF step -----------------------------------------------------------------------
@@ -1677,10 +1700,12 @@ def bce_ranking(pred, need_grad=True):
     return reduce_sum(loss_vec, 1.0 / B), gpred
 
 
-def gather_fields(tables, ids, n_cand, want_cid=True, tables1=None):
+def gather_fields(tables, ids, n_cand, want_cid=True, tables1=None, mark=None):
     """tables: list of F [vocab_f, d] tensors; ids: list of F int64 tensors, [B] (per-row field) or [B, C]
     -> (out [B, C, F, d], cid [B, C, F] | None, row_offset list): all field lookups in one launch.
-    tables1: F [vocab_f, 1] tables looked up with the same ids (rc_gather_fields_pair) -> (out, out1 [B, C, F, 1], cid, offsets)"""
+    tables1: F [vocab_f, 1] tables looked up with the same ids (rc_gather_fields_pair) -> (out, out1 [B, C, F, 1], cid, offsets)
+    mark = (row_flags int32 [sum of vocab sizes], step_dev int64 [1]): the looked-up rows are stamped with the number of the
+    step in progress, step_dev + 1 (rc_gather_fields_pair_mark, for dense_update_rows)"""
     F = len(tables)
     d = tables[0].shape[1]
     B = ids[0].shape[0]
@@ -1702,6 +1727,14 @@ def gather_fields(tables, ids, n_cand, want_cid=True, tables1=None):
             raise ValueError("gather_fields: the second family must be [vocab_f, 1] tables of the same vocabularies")
         out1 = torch.empty((B, n_cand, F, 1), dtype=f32, device=dev)
         tab1_arr = (C.c_void_p * F)(*[_ptr(t, f32, "table1").value for t in tables1])
+        if mark is not None:
+            flags, step_dev = mark
+            if flags.numel() != run:
+                raise ValueError("gather_fields: one row flag per row of the concatenated tables")
+            _lib.call("rc_gather_fields_pair_mark", tab_arr, tab1_arr, ids_arr, per_row, off_arr, F, B, int(n_cand), d,
+                      _ptr(out, f32, "out"), _ptr(out1, f32, "out1"), _ptr(cid, i64, "cid", True), _ptr(flags, torch.int32, "row_flags"),
+                      _ptr(step_dev, i64, "step_dev"), 1, _stream())
+            return out, out1, cid, offs + [run]
         _lib.call("rc_gather_fields_pair", tab_arr, tab1_arr, ids_arr, per_row, off_arr, F, B, int(n_cand), d, _ptr(out, f32, "out"),
                   _ptr(out1, f32, "out1"), _ptr(cid, i64, "cid", True), _stream())
         return out, out1, cid, offs + [run]

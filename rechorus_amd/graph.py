@@ -80,12 +80,26 @@ class GraphedStep:
     def signature(batch):
         return tuple((k, tuple(v.shape), v.dtype) for k, v in sorted(batch.items()) if isinstance(v, torch.Tensor))
 
+    def _announce(self, on):
+        """while a whole step (forward, backward, optimizer.step()) runs under this object's control, the model may see its
+        optimizer (`_step_optimizer`): the FM family's field gather then hands small batches to HipOptimizer's rows mode, which
+        is only correct when backward and step() are certain to follow the forward (the tables get no .grad)"""
+        opt = getattr(self.model, 'optimizer', None)
+        if on and getattr(opt, 'rows_ok', None) is not None and opt.rows_ok():
+            object.__setattr__(self.model, '_step_optimizer', opt)
+        elif '_step_optimizer' in self.model.__dict__:
+            object.__delattr__(self.model, '_step_optimizer')
+
     def _eager(self, batch):
         model = self.model
         model.optimizer.zero_grad()
-        loss = self.loss_of(model, batch)
-        loss.backward()
-        model.optimizer.step()
+        self._announce(True)
+        try:
+            loss = self.loss_of(model, batch)
+            loss.backward()
+            model.optimizer.step()
+        finally:
+            self._announce(False)
         return loss.detach().reshape(1)
 
     def run(self, batch):
@@ -134,10 +148,14 @@ class GraphedStep:
             # capture stream joins it before and after, which is what we want
             warnings.simplefilter('ignore', UserWarning)
             one = None
-            with torch.cuda.graph(self.graph):
-                self.loss = self.loss_of(model, self.static)
-                # the seed gradient of the scalar loss from a buffer filled once, not a ones_like fill in every replay (a launch of
-                # its own: ~4.6 us of a 0.26 ms DeepFM step)
-                one = self._one if (self.loss.dim() == 0 and self.loss.dtype == torch.float32) else None
-                self.loss.backward(gradient=one) if one is not None else self.loss.backward()
-                model.optimizer.step()
+            self._announce(True)
+            try:
+                with torch.cuda.graph(self.graph):
+                    self.loss = self.loss_of(model, self.static)
+                    # the seed gradient of the scalar loss from a buffer filled once, not a ones_like fill in every replay (a launch
+                    # of its own: ~4.6 us of a 0.26 ms DeepFM step)
+                    one = self._one if (self.loss.dim() == 0 and self.loss.dtype == torch.float32) else None
+                    self.loss.backward(gradient=one) if one is not None else self.loss.backward()
+                    model.optimizer.step()
+            finally:
+                self._announce(False)

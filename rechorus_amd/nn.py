@@ -290,11 +290,20 @@ class _FieldGatherPairFn(torch.autograd.Function):
     rc_small_row_sums_again on one zero-filled buffer), or one sort -- instead of one per family."""
 
     @staticmethod
-    def forward(ctx, n_cand, n_fields, *args):
+    def forward(ctx, n_cand, n_fields, rows_opt, *args):
         ids = [x.contiguous() for x in args[:n_fields]]
         tables, tables1 = args[n_fields:2 * n_fields], args[2 * n_fields:]
-        V, L, cid, offs = engine.gather_fields([t.detach() for t in tables], ids, n_cand, want_cid=True, tables1=[t.detach() for t in tables1])
-        ctx.cid, ctx.offs, ctx.d = cid, offs, tables[0].shape[1]
+        d = tables[0].shape[1]
+        n = ids[0].shape[0] * n_cand * n_fields
+        mark = None
+        if rows_opt is not None and n <= 8192 and d % 4 == 0 and engine.small_route_ok(n, sum(t.shape[0] for t in tables), d):
+            # rows mode (HipOptimizer.rows_begin): the gather stamps the looked-up rows, and the backward pass below hands their row
+            # sums to the optimizer in a scratch that nothing zero-fills, instead of a dense gradient
+            mark = rows_opt.rows_begin(tables, tables1)
+        V, L, cid, offs = engine.gather_fields([t.detach() for t in tables], ids, n_cand, want_cid=True,
+                                               tables1=[t.detach() for t in tables1], mark=mark)
+        ctx.rows_opt = rows_opt if mark is not None else None
+        ctx.cid, ctx.offs, ctx.d = cid, offs, d
         n_ids = cid.numel() // max(1, n_fields)
         ctx.route = "small" if cid.numel() <= 8192 else ("sort" if min(t.shape[0] for t in tables) * 8 <= n_ids else None)
         return V, L
@@ -305,6 +314,12 @@ class _FieldGatherPairFn(torch.autograd.Function):
         n_rows, n = offs[-1], ctx.cid.numel()
         gV = None if gV is None else gV.contiguous()
         gL = None if gL is None else gL.contiguous()
+        if ctx.rows_opt is not None:
+            if gV is None or gL is None:
+                raise RuntimeError("gather_fields_pair (rows mode): both table families must reach the loss")
+            Gv, Gl = engine.small_row_sums_pair(ctx.cid, n_rows, gV.view(n, d), gL.view(n, 1), into=ctx.rows_opt.rows_scratch())
+            ctx.rows_opt.rows_grads(Gv, Gl)
+            return (None, None, None) + (None,) * (3 * (len(offs) - 1))
         if gV is not None and gL is not None and ctx.route == "small" and engine.small_route_ok(n, n_rows, d) and d % 4 == 0:
             Gv, Gl = engine.small_row_sums_pair(ctx.cid, n_rows, gV.view(n, d), gL.view(n, 1))
         else:
@@ -314,12 +329,14 @@ class _FieldGatherPairFn(torch.autograd.Function):
         F = len(offs) - 1
         gv = tuple(None if Gv is None else Gv[offs[f]:offs[f + 1]] for f in range(F))
         gl = tuple(None if Gl is None else Gl[offs[f]:offs[f + 1]] for f in range(F))
-        return (None, None) + (None,) * F + gv + gl
+        return (None, None, None) + (None,) * F + gv + gl
 
 
-def gather_fields_pair(tables, tables1, ids, n_cand):
-    """-> (field vectors [B, C, F, d], first-order values [B, C, F, 1]) of the two table families looked up with the same ids"""
-    return _FieldGatherPairFn.apply(n_cand, len(tables), *ids, *tables, *tables1)
+def gather_fields_pair(tables, tables1, ids, n_cand, rows_opt=None):
+    """-> (field vectors [B, C, F, d], first-order values [B, C, F, 1]) of the two table families looked up with the same ids.
+    rows_opt: the HipOptimizer that owns the tables, when this forward is part of a whole training step whose optimizer.step()
+    follows (graph.GraphedStep sets it): small batches then take the optimizer's rows mode"""
+    return _FieldGatherPairFn.apply(n_cand, len(tables), rows_opt, *ids, *tables, *tables1)
 
 
 class _BceProbFn(torch.autograd.Function):
@@ -672,6 +689,80 @@ class HipOptimizer:
             self.param_groups.append(g)
         self.state = {}
         self.step_count = 0
+        self._rows = None           # the rows-mode step in flight (rows_begin .. step)
+        self._rows_state = None     # its persistent buffers: row flags, the touched rows' gradient scratch
+
+    # ---- rows mode: Adam over embedding tables of which a small batch touches a fraction of a percent ----------------------
+    # torch.optim.Adam on a dense gradient updates every row every step (helpers/BaseRunner.py:110-114,206), so the pass over
+    # tables and state cannot be skipped -- but the dense GRADIENT can.  At batch_size 1024 DeepFM's tables are 71 MB of which
+    # 10 K rows have a gradient: the step zero-filled 71 MB, wrote row sums into it and read all of it back.  Here the gather
+    # stamps the rows it looks up with the step's number, the backward pass writes the row sums into a scratch that is never
+    # cleared, and the update reads a gradient only where the stamp matches (g = 0 elsewhere): rc_dense_update_rows_dev,
+    # bit-identical to the dense step.  (Splitting the pass -- unstamped rows on a second stream beside forward / backward,
+    # stamped rows at the end -- was measured and lost: profiles/r08_rows_adam_split_vs_single.txt.)
+    def rows_ok(self):
+        return self.name == "Adam" and self.capturable and os.environ.get("RC_ROWS_ADAM", "1") != "0"
+
+    def _hyper_of(self, p):
+        for g in self.param_groups:
+            if any(q is p for q in g["params"]):
+                return engine.make_hyper(self.name, lr=g["lr"], l2=g["weight_decay"], step=max(self.step_count, 1))
+        return None
+
+    def rows_begin(self, tables, tables1):
+        """-> (row flags, step count on the device) for the gather to stamp, or None (rows mode not available: dense step)"""
+        if not self.rows_ok():
+            return None
+        if self._rows is not None:
+            raise RuntimeError("HipOptimizer rows mode: the previous training forward was not followed by backward + step()")
+        params = list(tables) + list(tables1)
+        hypers = [self._hyper_of(p) for p in params]
+        if any(h is None for h in hypers):
+            return None
+        dev = params[0].device
+        key = tuple(id(p) for p in params)
+        st = self._rows_state
+        capturing = torch.cuda.is_current_stream_capturing()    # (buffers are created by an eager step)
+        if st is None or st["key"] != key:
+            if capturing:
+                return None
+            n_rows, d = sum(t.shape[0] for t in tables), tables[0].shape[1]
+            st = self._rows_state = {"key": key, "flags": torch.zeros(n_rows, dtype=torch.int32, device=dev),
+                                     "G": torch.empty(n_rows * (d + 1), dtype=torch.float32, device=dev)}
+        if self._step_dev is None:
+            if capturing:
+                return None
+            self._step_dev = torch.full((1,), self.step_count, dtype=torch.int64, device=dev)
+        for p in params:
+            ps = self.state.setdefault(p, {})
+            for k in ("m", "v"):
+                if k not in ps:
+                    if capturing:
+                        return None
+                    ps[k] = torch.zeros_like(p)
+        offs, run = [], 0
+        for t in tables:
+            offs.append(run)
+            run += t.shape[0]
+        offs.append(run)
+        self._rows = {"params": params, "hypers": hypers, "offs": offs, "F": len(tables), "G": None}
+        return st["flags"], self._step_dev
+
+    def _rows_items(self, Gs):
+        r, st = self._rows, self._rows_state
+        F, offs, flags = r["F"], r["offs"], st["flags"]
+        items = []
+        for i, (p, h) in enumerate(zip(r["params"], r["hypers"])):
+            f = i % F
+            ps = self.state[p]
+            items.append((p.data, Gs[i // F][offs[f]:offs[f + 1]], h, ps["m"], ps["v"], flags[offs[f]:offs[f + 1]], p.shape[1]))
+        return items
+
+    def rows_scratch(self):
+        return self._rows_state["G"]
+
+    def rows_grads(self, Gv, Gl):
+        self._rows["G"] = (Gv, Gl)
 
     def zero_grad(self, set_to_none=True):
         for g in self.param_groups:
@@ -684,11 +775,16 @@ class HipOptimizer:
         self.step_count += 1
         items = []
         dev = None
+        rows = self._rows
+        if rows is not None and rows["G"] is None:
+            raise RuntimeError("HipOptimizer rows mode: step() without the backward pass of the training forward")
         for g in self.param_groups:
             h = engine.make_hyper(self.name, lr=g["lr"], l2=g["weight_decay"], step=max(self.step_count, 1))
             for p in g["params"]:
                 if p.grad is None:
                     continue
+                if rows is not None and any(q is p for q in rows["params"]):
+                    raise RuntimeError("HipOptimizer rows mode: a table of the rows-mode gather also received a dense gradient")
                 st = self.state.setdefault(p, {})
                 m = v = None
                 # (state created once: `st.setdefault(k, torch.zeros_like(p))` would allocate and zero-fill a tensor of the
@@ -705,6 +801,13 @@ class HipOptimizer:
                 grad = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                 items.append((p.data, grad, h, m, v))
                 dev = p.device
+        if rows is not None:
+            # the tables (gradient rows where stamped, g = 0 elsewhere) and every other parameter in one launch
+            everything = [(w, gr, h, m, v, None, 0) for w, gr, h, m, v in items] + self._rows_items(rows["G"])
+            engine.step_increment(self._step_dev)
+            engine.dense_update_rows(everything, self._step_dev, touched=2)
+            self._rows = None
+            return
         if self.capturable and items:
             if self._step_dev is None:  # (allocated outside any capture: the first step runs eagerly)
                 self._step_dev = torch.full((1,), self.step_count - 1, dtype=torch.int64, device=dev)

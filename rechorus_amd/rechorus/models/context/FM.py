@@ -74,7 +74,8 @@ class FMBase(object):
             # composite-key sort + segmented sum for all F dense gradients
             ids = [feed_dict[f] for f in self.context_features]
             fm_vectors, linear_value = hnn.gather_fields_pair([self.context_embedding[f].weight for f in self.context_features],
-                                                              [self.linear_embedding[f].weight for f in self.context_features], ids, n_cand)
+                                                              [self.linear_embedding[f].weight for f in self.context_features], ids, n_cand,
+                                                              rows_opt=self._rows_opt())
             return fm_vectors, self.overall_bias + linear_value.squeeze(-1).sum(dim=-1)
         fm_vectors = torch.stack(self._lookup(self.context_embedding, feed_dict, n_cand), dim=-2)
         linear_value = torch.cat(self._lookup(self.linear_embedding, feed_dict, n_cand), dim=-1)
@@ -93,7 +94,13 @@ class FMBase(object):
         ids = [feed_dict[f] for f in self.context_features]
         # both table families in ONE gather launch, and one grouping of their shared keys in the backward pass
         return hnn.gather_fields_pair([self.context_embedding[f].weight for f in self.context_features],
-                                      [self.linear_embedding[f].weight for f in self.context_features], ids, n_cand)
+                                      [self.linear_embedding[f].weight for f in self.context_features], ids, n_cand,
+                                      rows_opt=self._rows_opt())
+
+    def _rows_opt(self):
+        """the optimizer, while this forward is part of a whole training step driven by graph.GraphedStep (forward, backward and
+        optimizer.step() as one unit): small batches then take HipOptimizer's rows mode"""
+        return getattr(self, '_step_optimizer', None) if self.training else None
 
     def _head_terms(self, field_vectors):
         """what `forward` adds to the first-order term, as a list of [B, C] tensors (at most two)"""
