@@ -9,6 +9,12 @@ rc_bprmf_train_step_ahead / rc_neumf_train_step / engine.SasrecTrainer), `full_c
 scorer) and `candidate_permutation_equivariant` (no host-side candidate shuffle).  SURVEY.md 8(b2): "fused engine modules
 selected when a model class matches a known head".
 
+The CTR path's model files are recognised the same way: the reference's own `models/context/FM.py:33-78`, `WideDeep.py:29-60`,
+`DeepFM.py:18-41` (their CTR and top-k classes, by class name -- WideDeep and DeepFM own the same parameters -- plus exactly the
+parameter set `_define_params_FM` / `_define_params_WD` create, the inherited context loss, syntax tree and probe) get the plugin's
+head methods of the class of the same name: every field of a table family in one gather launch, the fused FM term, the
+one-kernel CTR head under `--loss_n BCE`, and through them HipOptimizer's rows mode at small batches.
+
 A model is bound only when ALL of these hold, otherwise it keeps the adopted-tables route unchanged:
   * structure: the state_dict keys and parameter shapes are exactly the head's (`u_embeddings / i_embeddings`;
     `mf_* / mlp_* / mlp.k / prediction`; `i_embeddings / p_embeddings / transformer_block.*`), the hyper-parameter attributes
@@ -38,7 +44,15 @@ KNOWN_FORWARD_HASHES = {
     "BPRMF": {"346a573d92bfe65d1176f7f1ebcbc5c9313108ce9e082bb4b34c5077823c43d6"},
     "NeuMF": {"74e9a03825ddedf9be6b9476f8ea1465e1c62a4a5ff6bd0dfb642ff76cc0fe4c"},
     "SASRec": {"0be9d019aa2162328ce8b550d2b3ccd98c9c3ef15303891e386ac9ffc91219b0"},
+    # the CTR / top-k heads of models/context/{FM,WideDeep,DeepFM}.py (keyed by class name: WideDeep and DeepFM own the same parameters)
+    "FMCTR": {"adf56d37116f128e90e9984a53191ac3e24581997ad7177b1a574632732cf2a3"},
+    "FMTopK": {"f96e3b561c6c16f4ef5fd79e2680164f59e02222bcde71ce6acac227fd374434"},
+    "WideDeepCTR": {"80156254c2d77f7c92f8b7fec0cafd2780929f9f214866cdf524f558d778d892"},
+    "WideDeepTopK": {"41b8c7f594e5ac79146add432a6a7675e734f4447dbea0e61ec08860c2f410d6"},
+    "DeepFMCTR": {"6893fc755c37fee261fa41c0bf58ea6821bdf670f0af3710add6d35f77f2c02a"},
+    "DeepFMTopK": {"f5d19151bbf5e245ca2d368e69a6fd33f878fd71b40a51f6382afef93bdaef48"},
 }
+CONTEXT_HEADS = ("FMCTR", "FMTopK", "WideDeepCTR", "WideDeepTopK", "DeepFMCTR", "DeepFMTopK")
 
 SAS_BLOCK_KEYS = ("masked_attn_head.q_linear.weight", "masked_attn_head.q_linear.bias", "masked_attn_head.k_linear.weight",
                   "masked_attn_head.k_linear.bias", "masked_attn_head.v_linear.weight", "masked_attn_head.v_linear.bias",
@@ -127,8 +141,80 @@ def _kind(model):
     return None
 
 
+def _context_base(kind):
+    return kind[:-3] if kind.endswith("CTR") else kind[:-4]
+
+
+def _context_kind(model):
+    """'FMCTR' | ... | 'DeepFMTopK' | None: a model file's FM / WideDeep / DeepFM class over the plugin's context task bases, with
+    exactly the parameters the plugin's class of the same name owns (models/context/FM.py:33-41, WideDeep.py:34-39)"""
+    kind = type(model).__name__
+    if kind not in CONTEXT_HEADS:
+        return None
+    bc = _mirror("models.BaseContextModel")
+    task = bc.ContextCTRModel if kind.endswith("CTR") else bc.ContextModel
+    if not isinstance(model, task) or type(model).loss is not task.loss:
+        return None
+    feats, fmax, d = getattr(model, "context_features", None), getattr(model, "feature_max", None), getattr(model, "vec_size", None)
+    if not (isinstance(feats, (list, tuple)) and len(feats) >= 1 and isinstance(fmax, dict) and _is_int(d) and hasattr(model, "dropout")):
+        return None
+    cat = lambda f: f.endswith("_c") or f.endswith("_id")
+    sh = _shapes(model)
+    want = {"overall_bias": (1,)}
+    for f in feats:
+        if cat(f) and not _is_int(fmax.get(f)):
+            return None
+        want["context_embedding.%s.weight" % f] = (fmax[f], d) if cat(f) else (d, 1)
+        want["linear_embedding.%s.weight" % f] = (fmax[f], 1) if cat(f) else (1, 1)
+    rest = {k: v for k, v in sh.items() if k not in want}
+    if any(sh.get(k) != v for k, v in want.items()):
+        return None
+    if _context_base(kind) == "FM":
+        return kind if not rest else None
+    layers_mod = _mirror("utils.layers")
+    layers = getattr(model, "layers", None)
+    ok = (isinstance(layers, (list, tuple)) and len(layers) >= 1 and all(_is_int(x) for x in layers)
+          and type(getattr(model, "deep_layers", None)) is layers_mod.MLP_Block and rest and all(k.startswith("deep_layers.") for k in rest))
+    return kind if ok else None
+
+
+def _context_mixin(kind):
+    """the plugin's class of the same name as a mixin: every method of its head chain (FMBase .. DeepFMBase) and its task forward,
+    without construction (the model file built its own parameters, with the same names)"""
+    m = getattr(_mirror("models.context." + _context_base(kind)), kind)
+    skip = ("parse_model_args", "parse_model_args_FM", "parse_model_args_WD", "_base_init", "_define_init", "_define_init_params",
+            "_define_params_FM", "_define_params_WD", "reader", "runner", "extra_log_args")
+    body = {}
+    for k in reversed(m.__mro__):       # base-most first: the derived head's methods win
+        if (getattr(k, "__module__", "") or "").startswith("models.context."):
+            body.update({n: v for n, v in k.__dict__.items() if n not in skip and not (n.startswith("__") and n.endswith("__"))})
+    body["forward"] = m.__dict__["forward"]
+    return type(kind + "Head", (object,), body)
+
+
+def _context_probe_feed(model, kind, device):
+    g = torch.Generator(device="cpu")
+    g.manual_seed(20240917)
+    B, C = 6, (1 if kind.endswith("CTR") else 4)
+    feed = {}
+    for f in list(model.context_features) + ["user_id", "item_id"]:
+        if f in feed:
+            continue
+        shape = (B, C) if (f == "item_id" or f.startswith("i_")) else (B,)
+        if f.endswith("_c") or f.endswith("_id"):
+            feed[f] = torch.randint(0, max(int(model.feature_max.get(f, 2)), 1), shape, generator=g).to(device)
+        else:
+            feed[f] = torch.rand(shape, generator=g).to(device)
+    if kind.endswith("CTR"):
+        feed["label"] = torch.randint(0, 2, (B, C), generator=g).to(device)
+    feed.update(batch_size=B, phase="test")
+    return feed
+
+
 def _head_mixin(kind):
     """the plugin's head of this kind as a mixin class: the methods of the mirror's model file that replace the model file's"""
+    if kind in CONTEXT_HEADS:
+        return _context_mixin(kind)
     if kind == "BPRMF":
         return _mirror("models.general.BPRMF").BPRMFBase
     if kind == "SASRec":
@@ -161,16 +247,20 @@ def _probe_feed(model, kind, device):
 
 
 def bind_known_head(model, log=logging.getLogger(__name__)):
-    """Recognise a BPRMF / NeuMF / SASRec head (see the module docstring) and bind the plugin's fused head to the instance.
+    """Recognise a BPRMF / NeuMF / SASRec / FM-family head (see the module docstring) and bind the plugin's fused head to the instance.
     Returns the kind that was bound, or None (the model is left exactly as it was).  The model must be on the GPU with its
     tables adopted (hnn.adopt_embeddings)."""
-    if hasattr(model, "hip_train_step"):
-        return None     # the plugin's own class (or a model file that brings its own fused step)
+    if hasattr(model, "hip_train_step") or getattr(type(model), "_rc_bound_head", None) is not None:
+        return None     # the plugin's own class (or a model file that brings its own fused step); bound already
+    if (type(model).__module__ or "").startswith("models."):
+        return None     # the plugin's own model files
     try:
-        base = _mirror("models.BaseModel")
-        if not isinstance(model, base.GeneralModel) or type(model).loss is not base.GeneralModel.loss:
-            return None     # list-wise / CTR losses: no fused step of these heads implements them
-        kind = _kind(model)
+        kind = _context_kind(model)
+        if kind is None:
+            base = _mirror("models.BaseModel")
+            if not isinstance(model, base.GeneralModel) or type(model).loss is not base.GeneralModel.loss:
+                return None     # list-wise losses: no fused step of these heads implements them
+            kind = _kind(model)
     except Exception as e:     # a model file this module does not understand keeps its route
         log.debug("known-head recognition skipped: %r", e)
         return None
@@ -189,7 +279,7 @@ def bind_known_head(model, log=logging.getLogger(__name__)):
     seed_added = False
     try:
         model.eval()
-        feed = _probe_feed(model, kind, p.device)
+        feed = _context_probe_feed(model, kind, p.device) if kind in CONTEXT_HEADS else _probe_feed(model, kind, p.device)
         with torch.no_grad():
             ref = model(dict(feed))["prediction"].float().clone()
         if kind in ("NeuMF", "SASRec") and not hasattr(model, "drop_seed"):
@@ -218,6 +308,7 @@ def bind_known_head(model, log=logging.getLogger(__name__)):
         log.warning("%s-shaped model, but the fused head does not reproduce its forward (%s): keeping the model file's own head", kind, e)
         return None
     model.train(was_training)
-    log.info("Recognised the %s head%s: fused forward / hip_train_step / --test_all scorer bound to %s", kind,
-             "" if known else " (edited forward, verified on a probe batch)", cls.__name__)
+    what = "one-launch field gathers / fused FM term and CTR head" if kind in CONTEXT_HEADS else "fused forward / hip_train_step / --test_all scorer"
+    log.info("Recognised the %s head%s: %s bound to %s", kind, "" if known else " (edited forward, verified on a probe batch)", what,
+             cls.__name__)
     return kind

@@ -169,8 +169,10 @@ def run(argv=None):
     adopted = hnn.adopt_embeddings(model) if torch.device(args.device).type == 'cuda' else 0
     if adopted:
         logging.info('Adopted {} nn.Embedding table(s) onto the HIP engine'.format(adopted))
-        # a model file whose head is one of the hot path's three (the reference's own BPRMF.py / NeuMF.py / SASRec.py, unmodified)
-        # gets the fused forward, the one-call fit() iteration and the --test_all scorer (rechorus_amd/dropin.py)
+    if torch.device(args.device).type == 'cuda' and (adopted or type(model).__module__.startswith('rechorus_user_models')):
+        # a model file whose head is one of the hot path's (the reference's own BPRMF.py / NeuMF.py / SASRec.py, unmodified; its
+        # FM.py / WideDeep.py / DeepFM.py) gets the fused forward -- and, for the first three, the one-call fit() iteration and the
+        # --test_all scorer (rechorus_amd/dropin.py)
         from rechorus_amd import dropin
         dropin.bind_known_head(model, log=logging.getLogger())
     logging.info('#params: {}'.format(model.count_variables()))

@@ -1,4 +1,5 @@
-"""Run in the build container (needs /root/reference): copies the reference's three headline model files VERBATIM into
+"""Run in the build container (needs /root/reference): copies the reference's headline model files (BPRMF / NeuMF / SASRec and the
+FM / WideDeep / DeepFM context family) VERBATIM into
 tests/golden/reference_models/ -- category (b) test fixtures: the GPU box has no /root/reference, and the drop-in test
 (tests/test_gpu_reference_heads.py) must feed the plugin the reference's OWN, unmodified files.  Nothing under rechorus_amd/
 imports or reads them.  Also writes MANIFEST.json (sha256 of each file + the syntax-tree hash of its forward functions, which
@@ -14,7 +15,8 @@ sys.path.insert(0, ROOT)
 sys.dont_write_bytecode = True
 REF = "/root/reference/src/models"
 OUT = os.path.join(ROOT, "tests", "golden", "reference_models")
-FILES = (("general", "BPRMF"), ("general", "NeuMF"), ("sequential", "SASRec"))
+FILES = (("general", "BPRMF", ("",)), ("general", "NeuMF", ("",)), ("sequential", "SASRec", ("",)),
+         ("context", "FM", ("CTR", "TopK")), ("context", "WideDeep", ("CTR", "TopK")), ("context", "DeepFM", ("CTR", "TopK")))
 
 
 def main():
@@ -22,17 +24,25 @@ def main():
     sys.path.insert(0, dropin.PLUGIN)
     import main as plugin_main
     manifest = {}
-    for sub, name in FILES:
+    for sub, name, modes in FILES:
         src = os.path.join(REF, sub, name + ".py")
         dst_dir = os.path.join(OUT, sub)
         os.makedirs(dst_dir, exist_ok=True)
         shutil.copyfile(src, os.path.join(dst_dir, name + ".py"))
         os.environ["RECHORUS_MODEL_DIRS"] = dst_dir
-        cls = plugin_main.find_class("model", (name, ""))
-        h = dropin.forward_hash(cls)
-        manifest[sub + "/" + name + ".py"] = {"sha256": hashlib.sha256(open(src, "rb").read()).hexdigest(), "forward_hash": h,
-                                              "source": "THUwangcy/ReChorus src/models/%s/%s.py (verbatim)" % (sub, name)}
-        print(name, h, "listed" if h in dropin.KNOWN_FORWARD_HASHES[name] else "NOT LISTED in rechorus_amd/dropin.py")
+        hashes = {}
+        for mode in modes:
+            cls = plugin_main.find_class("model", (name, mode))
+            h = dropin.forward_hash(cls)
+            hashes[name + mode] = h
+            print(name + mode, h, "listed" if h in dropin.KNOWN_FORWARD_HASHES[name + mode] else "NOT LISTED in rechorus_amd/dropin.py")
+        entry = {"sha256": hashlib.sha256(open(src, "rb").read()).hexdigest(),
+                 "source": "THUwangcy/ReChorus src/models/%s/%s.py (verbatim)" % (sub, name)}
+        if modes == ("",):
+            entry["forward_hash"] = hashes[name]
+        else:
+            entry["forward_hashes"] = hashes
+        manifest[sub + "/" + name + ".py"] = entry
     json.dump(manifest, open(os.path.join(OUT, "MANIFEST.json"), "w"), indent=1)
 
 

@@ -34,7 +34,8 @@ def _build(sub, name, argv, monkeypatch, model_dir=None):
 
 def test_fixtures_are_the_reference_files():
     man = json.load(open(os.path.join(FIX, "MANIFEST.json")))
-    assert sorted(man) == ["general/BPRMF.py", "general/NeuMF.py", "sequential/SASRec.py"]
+    assert sorted(man) == ["context/DeepFM.py", "context/FM.py", "context/WideDeep.py", "general/BPRMF.py", "general/NeuMF.py",
+                           "sequential/SASRec.py"]
     for rel, rec in man.items():
         data = open(os.path.join(FIX, rel), "rb").read()
         assert hashlib.sha256(data).hexdigest() == rec["sha256"], rel
@@ -84,3 +85,59 @@ def test_near_misses_are_not_recognised(monkeypatch, tmp_path):
     cls2, _ = _build("general", "BPRMF", ["--emb_size", "32"], monkeypatch, str(d2))
     assert dropin.forward_hash(cls1) in dropin.KNOWN_FORWARD_HASHES["BPRMF"]
     assert dropin.forward_hash(cls2) not in dropin.KNOWN_FORWARD_HASHES["BPRMF"]
+
+
+CTX_CASES = [("FM", mode, argv) for mode in ("CTR", "TopK") for argv in (["--emb_size", "16"],)] + \
+            [(name, mode, ["--emb_size", "16", "--layers", "[32,8]", "--dropout", "0.2"]) for name in ("WideDeep", "DeepFM") for mode in ("CTR", "TopK")]
+
+
+def _build_context(name, mode, argv, monkeypatch, numeric=False):
+    monkeypatch.setattr(sys, "dont_write_bytecode", True)
+    monkeypatch.setenv("RECHORUS_MODEL_DIRS", os.path.join(FIX, "context"))
+    if PLUGIN not in sys.path:
+        monkeypatch.syspath_prepend(PLUGIN)
+    import main
+    cls = main.find_class("model", (name, mode))
+    args = cls.parse_model_args(argparse.ArgumentParser()).parse_args(argv + ["--loss_n", "BCE" if mode == "CTR" else "BPR"])
+    args.device, args.model_path, args.buffer = torch.device("cpu"), "", 1
+    args.include_item_features = args.include_user_features = args.include_situation_features = 1
+    fmax = {"user_id": 20, "item_id": 50, "i_cat_c": 7, "u_grp_c": 4, "c_hour_c": 24}
+    corpus = argparse.Namespace(n_users=20, n_items=50, feature_max=fmax, item_feature_names=["i_cat_c"] + (["i_price_f"] if numeric else []),
+                                user_feature_names=["u_grp_c"], situation_feature_names=["c_hour_c"])
+    torch.manual_seed(0)
+    return cls, cls(args, corpus)
+
+
+@pytest.mark.parametrize("name,mode,argv", CTX_CASES)
+def test_reference_context_model_files_are_recognised(name, mode, argv, monkeypatch):
+    """the reference's own FM.py / WideDeep.py / DeepFM.py: class found in the fixture, forward syntax trees listed, the structural
+    recogniser names the head (also with a numeric field), the mixin carries the plugin's head methods and no construction"""
+    from rechorus_amd import dropin
+    cls, model = _build_context(name, mode, argv, monkeypatch)
+    kind = name + mode
+    assert os.path.realpath(sys.modules.get(cls.__module__, None).__file__ if cls.__module__ in sys.modules else
+                            cls.forward.__globals__["__file__"]).startswith(os.path.realpath(FIX))
+    h = dropin.forward_hash(cls)
+    assert h in dropin.KNOWN_FORWARD_HASHES[kind]
+    assert h == json.load(open(os.path.join(FIX, "MANIFEST.json")))["context/" + name + ".py"]["forward_hashes"][kind]
+    assert dropin._context_kind(model) == kind
+    assert dropin.bind_known_head(model) is None and getattr(type(model), "_rc_bound_head", None) is None   # CPU model: nothing is bound
+    mix = dropin._context_mixin(kind)
+    for meth in ("forward", "_get_embeddings_FM", "_fused_fields", "_head_terms", "_rows_opt"):
+        assert meth in mix.__dict__, meth
+    assert not any(n.startswith("_define") or n.startswith("parse_model_args") or n == "__init__" for n in mix.__dict__)
+    _, with_numeric = _build_context(name, mode, argv, monkeypatch, numeric=True)
+    assert dropin._context_kind(with_numeric) == kind
+    feed = dropin._context_probe_feed(with_numeric, kind, torch.device("cpu"))
+    assert feed["i_price_f"].dtype == torch.float32 and feed["i_cat_c"].shape == feed["item_id"].shape and feed["u_grp_c"].dim() == 1
+    if name == "FM":      # (FM.py builds its own nn.Embedding tables; WideDeep.py / DeepFM.py inherit the plugin's FMBase: GPU-only tables)
+        with torch.no_grad():
+            with_numeric.eval()
+            out = with_numeric(dict(feed))["prediction"]       # the model file's own forward runs on the probe feed
+        assert out.numel() == feed["item_id"].numel()
+    # near misses: one more parameter; a class of another name
+    model.extra = torch.nn.Linear(3, 3)
+    assert dropin._context_kind(model) is None
+    del model.extra
+    model.__class__ = type("Something" + mode, (cls,), {})
+    assert dropin._context_kind(model) is None

@@ -1,4 +1,5 @@
-"""GPU: north star "existing model files drop in" for the three heads of the hot path.  The reference's OWN BPRMF.py / NeuMF.py /
+"""GPU: north star "existing model files drop in" for the heads of the hot path (BPRMF / NeuMF / SASRec, and the FM / WideDeep /
+DeepFM context family at the end of this file).  The reference's OWN BPRMF.py / NeuMF.py /
 SASRec.py (verbatim copies, tests/golden/reference_models/, checked against their manifest by tests/test_dropin_heads_cpu.py)
 are given to the plugin's main.py through RECHORUS_MODEL_DIRS.  rechorus_amd/dropin.py recognises the head, and the run
 (i) trains through the fused one-call fit() iteration (rc_bprmf_train_step_ahead / rc_neumf_train_step* / engine.SasrecTrainer),
@@ -126,3 +127,104 @@ def test_an_edited_head_keeps_its_own_route(dataset_root, tmp_path, monkeypatch,
     assert dropin.bind_known_head(m2) == "BPRMF"
     assert isinstance(m2, cls2) and type(m2).__name__ == "BPRMF" and hasattr(m2, "hip_train_step") and m2.candidate_permutation_equivariant
     assert dropin.bind_known_head(m2) is None       # idempotent: already bound
+
+
+# ---- the context family: models/context/FM.py, WideDeep.py, DeepFM.py ---------------------------------------------------------
+
+@pytest.fixture(scope="module")
+def ctx_root(tmp_path_factory):
+    from synth_data import make_context_dataset
+    root = str(tmp_path_factory.mktemp("ctx"))
+    make_context_dataset(root, "ctr", n_users=90, n_items=70, per_user=12, ctr=True, seed=3)
+    make_context_dataset(root, "topk", n_users=90, n_items=70, per_user=10, ctr=False, seed=4)
+    return root
+
+
+CTX_CASES = [
+    ("DeepFM", "CTR", ["--emb_size", "16", "--layers", "[32,16]", "--dropout", "0.2"], {"rc_gather_fields_pair", "rc_fm_second_order_bwd_add"},
+     r"rc_ctr_head_fwd_bwd(_sums)?"),
+    ("DeepFM", "TopK", ["--emb_size", "16", "--layers", "[32]", "--dropout", "0"], {"rc_gather_fields_pair", "rc_fm_second_order_bwd_add"}, None),
+    ("FM", "CTR", ["--emb_size", "16"], {"rc_gather_fields_pair", "rc_fm_second_order_fwd"}, r"rc_ctr_head_fwd_bwd(_sums)?"),
+    ("WideDeep", "CTR", ["--emb_size", "16", "--layers", "[32]", "--dropout", "0.1"], {"rc_gather_fields_pair"}, r"rc_ctr_head_fwd_bwd(_sums)?"),
+]
+
+
+def _run_ctx(name, mode, model_args, ctx_root, out, monkeypatch, model_dir):
+    import main
+    from rechorus_amd import _lib, nn as hnn
+    monkeypatch.setattr(hnn, "_DROP_SEED_GEN", None)
+    if model_dir:
+        monkeypatch.setenv("RECHORUS_MODEL_DIRS", model_dir)
+    else:
+        monkeypatch.delenv("RECHORUS_MODEL_DIRS", raising=False)
+    names = set()
+    real_call = _lib.call
+
+    def call(fn_name, *a):
+        names.add(fn_name)
+        return real_call(fn_name, *a)
+    monkeypatch.setattr(_lib, "call", call)
+    log = str(out / "log" / "run.txt")
+    ctr = mode == "CTR"
+    res = main.run(["--model_name", name, "--model_mode", mode] + model_args +
+                   ["--dataset", "ctr" if ctr else "topk", "--path", ctx_root + "/", "--epoch", "3", "--num_neg", "3", "--batch_size", "64",
+                    "--num_workers", "0", "--regenerate", "1", "--random_seed", "11", "--log_file", log, "--lr", "2e-3", "--l2", "1e-6",
+                    "--loss_n", "BCE" if ctr else "BPR", "--metric", "AUC,ACC" if ctr else "NDCG,HR", "--include_item_features", "1",
+                    "--include_user_features", "1", "--include_situation_features", "1",
+                    "--model_path", str(out / "model" / "m.pt"), "--topk", "5,10", "--save_final_results", "0"])
+    monkeypatch.undo()
+    return res, open(log).read(), torch.load(str(out / "model" / "m.pt"), map_location="cpu"), names
+
+
+@pytest.mark.parametrize("name,mode,model_args,entries,head_entry", CTX_CASES)
+def test_unmodified_reference_context_model_file_reaches_the_fused_head(name, mode, model_args, entries, head_entry, ctx_root, tmp_path,
+                                                                         monkeypatch, cuda):
+    """the reference's OWN FM.py / WideDeep.py / DeepFM.py through main.py: the head is recognised, training runs on the one-launch
+    field gathers, the fused FM term and (CTR, --loss_n BCE) the one-kernel CTR head, and the checkpoint equals the one the plugin's
+    class of the same name leaves from the same seed, bit for bit, under the reference's state_dict keys"""
+    (tmp_path / "ref").mkdir(), (tmp_path / "mirror").mkdir()
+    res_a, text_a, sd_a, names_a = _run_ctx(name, mode, model_args, ctx_root, tmp_path / "ref", monkeypatch, os.path.join(FIX, "context"))
+    assert "Recognised the %s%s head" % (name, mode) in text_a, text_a[-1500:]
+    assert entries <= names_a, sorted(names_a)
+    if head_entry:
+        assert any(re.fullmatch(head_entry, n) for n in names_a), sorted(names_a)
+    losses = [float(x) for x in re.findall(r"Epoch \d+\s+loss=([0-9.]+)", text_a)]
+    assert len(losses) >= 2 and losses[-1] < losses[0], losses
+    res_b, text_b, sd_b, names_b = _run_ctx(name, mode, model_args, ctx_root, tmp_path / "mirror", monkeypatch, None)
+    assert "Recognised the" not in text_b
+    assert set(sd_a) == set(sd_b)
+    for k in sd_a:
+        assert torch.equal(sd_a[k], sd_b[k]), k
+    assert res_a == res_b
+
+
+def test_an_edited_context_head_keeps_its_own_route(tmp_path, monkeypatch, cuda):
+    """a DeepFM.py whose forward drops the FM term still has DeepFM's parameters and class name; the probe batch disagrees with the
+    fused head -> no binding"""
+    import main
+    from rechorus_amd import dropin
+    src = open(os.path.join(FIX, "context", "DeepFM.py")).read()
+    d = tmp_path / "edited"
+    d.mkdir()
+    edited = src.replace("fm_prediction = fm_vectors.sum(dim=-1) + linear_vectors", "fm_prediction = linear_vectors")
+    assert edited != src
+    (d / "DeepFM.py").write_text(edited)
+    fmax = {"user_id": 20, "item_id": 50, "i_cat_c": 7, "u_grp_c": 4, "c_hour_c": 24}
+    corpus = argparse.Namespace(n_users=20, n_items=50, feature_max=fmax, item_feature_names=["i_cat_c"], user_feature_names=["u_grp_c"],
+                                situation_feature_names=["c_hour_c"])
+    built = []
+    for model_dir in (str(d), os.path.join(FIX, "context")):
+        monkeypatch.setenv("RECHORUS_MODEL_DIRS", model_dir)
+        cls = main.find_class("model", ("DeepFM", "CTR"))
+        args = cls.parse_model_args(argparse.ArgumentParser()).parse_args(["--emb_size", "16", "--layers", "[32]", "--dropout", "0", "--loss_n", "BCE"])
+        args.device, args.model_path, args.buffer = cuda, "", 1
+        args.include_item_features = args.include_user_features = args.include_situation_features = 1
+        torch.manual_seed(0)
+        model = cls(args, corpus).to(cuda)
+        assert dropin._context_kind(model) == "DeepFMCTR"
+        built.append((cls, model))
+    (cls_e, edited_model), (cls_r, ref_model) = built
+    assert dropin.bind_known_head(edited_model) is None and type(edited_model) is cls_e
+    assert dropin.bind_known_head(ref_model) == "DeepFMCTR"
+    assert isinstance(ref_model, cls_r) and type(ref_model).__name__ == "DeepFMCTR" and type(ref_model)._rc_bound_head == "DeepFMCTR"
+    assert dropin.bind_known_head(ref_model) is None     # idempotent
