@@ -265,47 +265,78 @@ __global__ __launch_bounds__(kBlock) void small_row_sums_kernel(SmallSumArgs a) 
     if (on) e = small_row_at(a, ix, r);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     float acc1 = 0.f;
+    // Rows of up to kSmallSeq occurrences: the lane-group on its own, in ascending position like the sort route (bit-identical to it),
+    // eight gradient rows in flight and the next eight occurrence numbers requested beside them -- 1 + ceil(n / 8) memory latencies.
+    // (The first version walked "occ[k] -> gradient row" one after the other: a field of 50 values at B = 1,024 is 20 dependent
+    // round trips per row, and such rows set the kernel's 20 us.)
+    constexpr int kB = 8;
     const bool seq = on && e.n <= (uint32_t)kSmallSeq;
     if (seq) {
-      acc = src4[(size_t)e.reserved * LPR + l];   // the record carries the row's first position
-      if (a.src1) acc1 = a.src1[e.reserved];
-      for (uint32_t k = 1; k < e.n; ++k) {
-        const uint32_t o = a.occ[e.start + k];
-        padd4s(acc, src4[(size_t)o * LPR + l]);
-        if (a.src1) acc1 += a.src1[o];
+      uint32_t oc[kB], on_[kB];
+#pragma unroll
+      for (int j = 0; j < kB; ++j) oc[j] = (j > 0 && (uint32_t)j < e.n) ? a.occ[e.start + j] : 0u;
+      oc[0] = e.reserved;   // the record carries the row's first position
+      for (uint32_t k0 = 0; k0 < e.n; k0 += kB) {
+#pragma unroll
+        for (int j = 0; j < kB; ++j) on_[j] = k0 + kB + j < e.n ? a.occ[e.start + k0 + kB + j] : 0u;
+        float4 v[kB];
+        float s1[kB];
+#pragma unroll
+        for (int j = 0; j < kB; ++j) {
+          const bool in = k0 + j < e.n;
+          v[j] = in ? src4[(size_t)oc[j] * LPR + l] : make_float4(0.f, 0.f, 0.f, 0.f);
+          s1[j] = (a.src1 && in) ? a.src1[oc[j]] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < kB; ++j) {
+          if (k0 + j < e.n) {
+            if (k0 + j == 0) { acc = v[0]; acc1 = s1[0]; }
+            else { padd4s(acc, v[j]); acc1 += s1[j]; }
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < kB; ++j) oc[j] = on_[j];
       }
     }
-    uint64_t hot = __ballot(on && !seq && l == 0);   // hot rows of this wave's groups, one after the other, by the whole wave
+    // Longer rows of this wave's groups, one after the other, by the whole wave: up to 192 occurrence numbers in one round of
+    // coalesced loads (three per lane), handed out by shuffles; then 32 gradient rows in flight per round (U per lane-group, fixed
+    // pattern -> fixed order).  A row of 146 occurrences (a field of 7 values at B = 1,024) is 1 + 5 memory latencies.
+    uint64_t hot = __ballot(on && !seq && l == 0);
     while (hot) {
       const int srcl = __ffsll((long long)hot) - 1;
       hot &= hot - 1;
       const uint32_t hs = __shfl(e.start, srcl, 64), hn = __shfl(e.n, srcl, 64);
-      // four occurrences in flight per lane-group (fixed pattern -> fixed order): the chain occ[] -> gradient row is two dependent
-      // loads per trip, and a CTR field of a few values makes rows of hundreds of occurrences at B = 1,024
-      float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), p1 = p0, p2 = p0, p3 = p0;
-      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-      for (uint32_t k = grp; k < hn; k += 4 * GPW) {
-        const uint32_t o0 = a.occ[hs + k];
-        const uint32_t o1 = k + GPW < hn ? a.occ[hs + k + GPW] : 0u;
-        const uint32_t o2 = k + 2 * GPW < hn ? a.occ[hs + k + 2 * GPW] : 0u;
-        const uint32_t o3 = k + 3 * GPW < hn ? a.occ[hs + k + 3 * GPW] : 0u;
-        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-        const float4 v0 = src4[(size_t)o0 * LPR + l];
-        const float4 v1 = k + GPW < hn ? src4[(size_t)o1 * LPR + l] : z;
-        const float4 v2 = k + 2 * GPW < hn ? src4[(size_t)o2 * LPR + l] : z;
-        const float4 v3 = k + 3 * GPW < hn ? src4[(size_t)o3 * LPR + l] : z;
-        padd4s(p0, v0); padd4s(p1, v1); padd4s(p2, v2); padd4s(p3, v3);
-        if (a.src1) {
-          s0 += a.src1[o0];
-          if (k + GPW < hn) s1 += a.src1[o1];
-          if (k + 2 * GPW < hn) s2 += a.src1[o2];
-          if (k + 3 * GPW < hn) s3 += a.src1[o3];
+      constexpr int U = 32 / GPW >= 1 ? 32 / GPW : 1;     // U * GPW = 32 (d = 16 .. 128): a round never straddles a multiple of 64
+      static_assert(U * GPW == 32 || GPW > 32, "rounds of 32 occurrences");
+      float4 part = make_float4(0.f, 0.f, 0.f, 0.f);
+      float part1 = 0.f;
+      for (uint32_t c0 = 0; c0 < hn; c0 += 192) {   // (wave-uniform)
+        const uint32_t cn = hn - c0 < 192u ? hn - c0 : 192u;
+        const uint32_t pm0 = (uint32_t)lane < cn ? a.occ[hs + c0 + lane] : 0u;
+        const uint32_t pm1 = 64u + lane < cn ? a.occ[hs + c0 + 64 + lane] : 0u;
+        const uint32_t pm2 = 128u + lane < cn ? a.occ[hs + c0 + 128 + lane] : 0u;
+        for (uint32_t base = 0; base < cn; base += U * GPW) {
+          const uint32_t k64 = base >> 6;   // wave-uniform: the whole round reads one of the three registers
+          const uint32_t mine = k64 == 0 ? pm0 : (k64 == 1 ? pm1 : pm2);
+          float4 sv[U];
+          float s1[U];
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const uint32_t idx = base + u * GPW + grp;
+            const uint32_t o = __shfl(mine, idx & 63, 64);
+            const bool in = idx < cn;
+            sv[u] = in ? src4[(size_t)o * LPR + l] : make_float4(0.f, 0.f, 0.f, 0.f);
+            s1[u] = (a.src1 && in) ? a.src1[o] : 0.f;
+          }
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            padd4s(part, sv[u]);
+            part1 += s1[u];
+          }
         }
       }
-      padd4s(p0, p1); padd4s(p2, p3); padd4s(p0, p2);
-      const float part1 = groups_allreduce_sum<LPR, 64>((s0 + s1) + (s2 + s3));
+      part1 = groups_allreduce_sum<LPR, 64>(part1);
       if (lane / LPR == srcl / LPR) acc1 = part1;
-      float4 part = p0;
       part.x = groups_allreduce_sum<LPR, 64>(part.x);
       part.y = groups_allreduce_sum<LPR, 64>(part.y);
       part.z = groups_allreduce_sum<LPR, 64>(part.z);
