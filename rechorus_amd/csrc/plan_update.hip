@@ -178,6 +178,10 @@ __device__ __forceinline__ void plan_rows_indexed_body(const PlanUpdArgs& a, int
   constexpr int LPR = D / 4;
   constexpr int GPW = 64 / LPR;   // lane-groups per wave
   constexpr int H = 2;            // rows per lane-group per step
+#ifndef RC_PLAN_IDX_OCC
+#define RC_PLAN_IDX_OCC 4
+#endif
+  constexpr uint32_t kIdxOcc = RC_PLAN_IDX_OCC;   // occurrences per row resolved in the index phase (2: the round-4 kernel, for A/B)
   const PlanSide& sd = a.side[side];
   const PlanGrad& gr = sd.g;
   const int lane = threadIdx.x & 63;
@@ -193,29 +197,38 @@ __device__ __forceinline__ void plan_rows_indexed_body(const PlanUpdArgs& a, int
     e.row = 0; e.start = 0; e.n = 0; e.reserved = 0;
     if (gi < nr) e = sd.rows[gi];
     const bool shortrow = e.n >= 1 && e.n <= (uint32_t)kPlanLongSeg;
-    uint32_t o0 = 0, o1 = 0;
+    // the first FOUR occurrences of the row are resolved here (64 rows' chains together); a row's fifth and later ones walk the
+    // chain on their own in the data phase.  (With two, a third occurrence -- 17 % of the multi-occurrence rows of config 2, so
+    // 85 % of the eight-row steps had one -- stalled its wave for three dependent loads.)
+    uint32_t o0 = 0, o1 = 0, o2 = 0, o3 = 0;
     if (shortrow) {
       o0 = a.occ[e.start];
       if (e.n > 1) o1 = a.occ[e.start + 1];
+      if (kIdxOcc > 2 && e.n > 2) o2 = a.occ[e.start + 2];
+      if (kIdxOcc > 2 && e.n > 3) o3 = a.occ[e.start + 3];
     }
-    float c0 = 1.0f, c1 = 1.0f;
-    int64_t s0 = 0, s1 = 0;
+    float c0 = 1.0f, c1 = 1.0f, c2 = 1.0f, c3 = 1.0f;
+    int64_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
     if (shortrow) {
-      s0 = (gr.div == 1) ? (int64_t)o0 : (int64_t)(o0 / (uint32_t)gr.div);
-      if (gr.src_index) s0 = gr.src_index[s0];
-      if (gr.coef) c0 = gr.coef[o0];
-      if (e.n > 1) {
-        s1 = (gr.div == 1) ? (int64_t)o1 : (int64_t)(o1 / (uint32_t)gr.div);
-        if (gr.src_index) s1 = gr.src_index[s1];
-        if (gr.coef) c1 = gr.coef[o1];
-      }
+      auto resolve = [&](uint32_t o, float& c, int64_t& sr) {
+        sr = (gr.div == 1) ? (int64_t)o : (int64_t)(o / (uint32_t)gr.div);
+        if (gr.src_index) sr = gr.src_index[sr];
+        if (gr.coef) c = gr.coef[o];
+      };
+      resolve(o0, c0, s0);
+      if (e.n > 1) resolve(o1, c1, s1);
+      if (kIdxOcc > 2 && e.n > 2) resolve(o2, c2, s2);
+      if (kIdxOcc > 2 && e.n > 3) resolve(o3, c3, s3);
     }
     // ---- data phase: GPW * H rows per step
     for (int r0 = 0; r0 < 64; r0 += GPW * H) {
       if (base + (uint32_t)r0 >= nr) break;  // wave-uniform
       rc_plan_row eh[H];
-      float ch0[H], ch1[H];
-      int64_t sh0[H], sh1[H];
+      float ch0[H], ch1[H], ch2[H], ch3[H];
+      int64_t sh0[H], sh1[H], sh2[H], sh3[H];
+      auto shfl64 = [](int64_t x, int sl) {
+        return (int64_t)(((uint64_t)(uint32_t)__shfl((int)(uint32_t)(x >> 32), sl, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)x, sl, 64));
+      };
       bool on[H];
 #pragma unroll
       for (int h = 0; h < H; ++h) {
@@ -226,11 +239,15 @@ __device__ __forceinline__ void plan_rows_indexed_body(const PlanUpdArgs& a, int
         eh[h].reserved = 0;
         ch0[h] = __shfl(c0, sl, 64);
         ch1[h] = __shfl(c1, sl, 64);
-        sh0[h] = (int64_t)(((uint64_t)(uint32_t)__shfl((int)(uint32_t)(s0 >> 32), sl, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)s0, sl, 64));
-        sh1[h] = (int64_t)(((uint64_t)(uint32_t)__shfl((int)(uint32_t)(s1 >> 32), sl, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)s1, sl, 64));
+        ch2[h] = __shfl(c2, sl, 64);
+        ch3[h] = __shfl(c3, sl, 64);
+        sh0[h] = shfl64(s0, sl);
+        sh1[h] = shfl64(s1, sl);
+        sh2[h] = shfl64(s2, sl);
+        sh3[h] = shfl64(s3, sl);
         on[h] = eh[h].n >= 1 && eh[h].n <= (uint32_t)kPlanLongSeg;
       }
-      float4 w[H], m[H], v[H], u0[H], u1[H];
+      float4 w[H], m[H], v[H], u0[H], u1[H], u2[H], u3[H];
       size_t idx4[H];
 #pragma unroll
       for (int h = 0; h < H; ++h) {
@@ -242,6 +259,8 @@ __device__ __forceinline__ void plan_rows_indexed_body(const PlanUpdArgs& a, int
           if (mode_has_v(MODE)) v[h] = load_stream4(reinterpret_cast<const float4*>(sd.t.V) + idx4[h]);
           u0[h] = src4[(size_t)sh0[h] * LPR + l];
           if (eh[h].n > 1) u1[h] = src4[(size_t)sh1[h] * LPR + l];
+          if (kIdxOcc > 2 && eh[h].n > 2) u2[h] = src4[(size_t)sh2[h] * LPR + l];
+          if (kIdxOcc > 2 && eh[h].n > 3) u3[h] = src4[(size_t)sh3[h] * LPR + l];
         }
       }
 #pragma unroll
@@ -257,7 +276,17 @@ __device__ __forceinline__ void plan_rows_indexed_body(const PlanUpdArgs& a, int
           t.x *= ch1[h]; t.y *= ch1[h]; t.z *= ch1[h]; t.w *= ch1[h];
           padd4(acc, t);
         }
-        for (uint32_t k = 2; k < eh[h].n; ++k) padd4(acc, plan_grad4<D>(gr, a.occ, eh[h].start + k, l));
+        if (kIdxOcc > 2 && eh[h].n > 2) {
+          float4 t = u2[h];
+          t.x *= ch2[h]; t.y *= ch2[h]; t.z *= ch2[h]; t.w *= ch2[h];
+          padd4(acc, t);
+        }
+        if (kIdxOcc > 2 && eh[h].n > 3) {
+          float4 t = u3[h];
+          t.x *= ch3[h]; t.y *= ch3[h]; t.z *= ch3[h]; t.w *= ch3[h];
+          padd4(acc, t);
+        }
+        for (uint32_t k = kIdxOcc; k < eh[h].n; ++k) padd4(acc, plan_grad4<D>(gr, a.occ, eh[h].start + k, l));
         opt_apply4<MODE>(a.o, w[h], m[h], v[h], acc);
         store_row4(reinterpret_cast<float4*>(sd.t.W) + idx4[h], w[h]);
         if (mode_has_m(MODE)) store_row4(reinterpret_cast<float4*>(sd.t.M) + idx4[h], m[h]);
