@@ -286,6 +286,8 @@ __device__ __forceinline__ void plan_rows_indexed_body(const PlanUpdArgs& a, int
           t.x *= ch3[h]; t.y *= ch3[h]; t.z *= ch3[h]; t.w *= ch3[h];
           padd4(acc, t);
         }
+        // (the later occurrences one after the other: keeping eight of their chains in flight costs 22 registers and a wave per SIMD,
+        //  and measured 7 % SLOWER on this launch and on NeuMF's pair update -- profiles/r08_plan_rows_index_four_occurrences.txt)
         for (uint32_t k = kIdxOcc; k < eh[h].n; ++k) padd4(acc, plan_grad4<D>(gr, a.occ, eh[h].start + k, l));
         opt_apply4<MODE>(a.o, w[h], m[h], v[h], acc);
         store_row4(reinterpret_cast<float4*>(sd.t.W) + idx4[h], w[h]);
