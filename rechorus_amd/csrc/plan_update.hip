@@ -205,27 +205,29 @@ __device__ __forceinline__ void plan_rows_indexed_body(const PlanUpdArgs& a, int
       o0 = a.occ[e.start];
       if (e.n > 1) o1 = a.occ[e.start + 1];
       if (kIdxOcc > 2 && e.n > 2) o2 = a.occ[e.start + 2];
-      if (kIdxOcc > 2 && e.n > 3) o3 = a.occ[e.start + 3];
+      if (kIdxOcc > 3 && e.n > 3) o3 = a.occ[e.start + 3];
     }
     float c0 = 1.0f, c1 = 1.0f, c2 = 1.0f, c3 = 1.0f;
-    int64_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    typedef int64_t src_row_t;     // (32-bit source rows: the same 108 registers)
+    src_row_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
     if (shortrow) {
-      auto resolve = [&](uint32_t o, float& c, int64_t& sr) {
-        sr = (gr.div == 1) ? (int64_t)o : (int64_t)(o / (uint32_t)gr.div);
-        if (gr.src_index) sr = gr.src_index[sr];
+      auto resolve = [&](uint32_t o, float& c, src_row_t& sr) {
+        int64_t t = (gr.div == 1) ? (int64_t)o : (int64_t)(o / (uint32_t)gr.div);
+        if (gr.src_index) t = gr.src_index[t];
+        sr = (src_row_t)t;
         if (gr.coef) c = gr.coef[o];
       };
       resolve(o0, c0, s0);
       if (e.n > 1) resolve(o1, c1, s1);
       if (kIdxOcc > 2 && e.n > 2) resolve(o2, c2, s2);
-      if (kIdxOcc > 2 && e.n > 3) resolve(o3, c3, s3);
+      if (kIdxOcc > 3 && e.n > 3) resolve(o3, c3, s3);
     }
     // ---- data phase: GPW * H rows per step
     for (int r0 = 0; r0 < 64; r0 += GPW * H) {
       if (base + (uint32_t)r0 >= nr) break;  // wave-uniform
       rc_plan_row eh[H];
       float ch0[H], ch1[H], ch2[H], ch3[H];
-      int64_t sh0[H], sh1[H], sh2[H], sh3[H];
+      src_row_t sh0[H], sh1[H], sh2[H], sh3[H];
       auto shfl64 = [](int64_t x, int sl) {
         return (int64_t)(((uint64_t)(uint32_t)__shfl((int)(uint32_t)(x >> 32), sl, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)x, sl, 64));
       };
@@ -260,7 +262,7 @@ __device__ __forceinline__ void plan_rows_indexed_body(const PlanUpdArgs& a, int
           u0[h] = src4[(size_t)sh0[h] * LPR + l];
           if (eh[h].n > 1) u1[h] = src4[(size_t)sh1[h] * LPR + l];
           if (kIdxOcc > 2 && eh[h].n > 2) u2[h] = src4[(size_t)sh2[h] * LPR + l];
-          if (kIdxOcc > 2 && eh[h].n > 3) u3[h] = src4[(size_t)sh3[h] * LPR + l];
+          if (kIdxOcc > 3 && eh[h].n > 3) u3[h] = src4[(size_t)sh3[h] * LPR + l];
         }
       }
 #pragma unroll
@@ -281,7 +283,7 @@ __device__ __forceinline__ void plan_rows_indexed_body(const PlanUpdArgs& a, int
           t.x *= ch2[h]; t.y *= ch2[h]; t.z *= ch2[h]; t.w *= ch2[h];
           padd4(acc, t);
         }
-        if (kIdxOcc > 2 && eh[h].n > 3) {
+        if (kIdxOcc > 3 && eh[h].n > 3) {
           float4 t = u3[h];
           t.x *= ch3[h]; t.y *= ch3[h]; t.z *= ch3[h]; t.w *= ch3[h];
           padd4(acc, t);
