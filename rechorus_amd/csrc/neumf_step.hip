@@ -517,6 +517,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int e = 0; e < 4; ++e) S[cc][e] = 0.f;
       int64_t it0 = ip[0], it1 = ip[C > 1 ? 1 : 0];
       load_row_slices<NCU>(mn, a.mf_i + it0 * a.ld_i + 4 * g);
+      // the singleton flag of a candidate travels one candidate ahead, like its row: this pass has no MFMA group to cover a load
+      // that the very next store's address depends on
+      uint8_t mflag_next = a.multi ? a.multi[it0] : (uint8_t)1;
       for (int c = 0; c < C; ++c) {
         float mx[NCU][4];
 #pragma unroll
@@ -524,10 +527,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
           for (int e = 0; e < 4; ++e) mx[cc][e] = mn[cc][e];
         const int64_t item_c = it0;
+#ifdef RC_NEUMF_FLAG_LATE     // (experiment switch: the flag requested where it is used, as before)
         const uint8_t mflag = a.multi ? a.multi[item_c] : (uint8_t)1;
+#else
+        const uint8_t mflag = mflag_next;
+#endif
         it0 = it1;
         if (c + 1 < C) {
           load_row_slices<NCU>(mn, a.mf_i + it0 * a.ld_i + 4 * g);
+#ifndef RC_NEUMF_FLAG_LATE
+          mflag_next = a.multi ? a.multi[it0] : (uint8_t)1;
+#endif
           it1 = ip[c + 2 < C ? c + 2 : C - 1];
         }
         const float gc = sp[c * 16 + i];
