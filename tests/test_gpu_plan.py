@@ -516,7 +516,8 @@ def test_plan_row_sums_and_distinct(case, d, cuda, eng):
 
 @pytest.mark.parametrize("n,n_rows,d,hot", [(8192, 279_000, 64, 0), (8192, 279_000, 1, 0), (25_600, 8_714, 64, 0), (1, 5, 16, 0),
                                              (32_768, 1_000_000, 128, 0), (3000, 50, 32, 0), (8000, 300, 64, 6000), (8192, 40, 1, 7000),
-                                             (777, 1000, 3, 0), (5632, 8_714, 64, 3300)])
+                                             (777, 1000, 3, 0), (5632, 8_714, 64, 3300),
+                                             (6000, 40, 16, 0), (4000, 30, 128, 2500), (8192, 9, 32, 0)])
 def test_small_embedding_dense_backward(n, n_rows, d, hot, cuda, eng, monkeypatch):
     """embedding_dense_backward of a small id list (rc_small_row_sums: the small-batch plan workgroups + one lane-group per touched
     row) against a float64 index_add and the radix-sort route: CTR-sized and candidate-sized lists, the [vocab, 1] first-order
