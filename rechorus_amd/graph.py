@@ -89,6 +89,8 @@ class GraphedStep:
             object.__setattr__(self.model, '_step_optimizer', opt)
         elif '_step_optimizer' in self.model.__dict__:
             object.__delattr__(self.model, '_step_optimizer')
+        if not on and getattr(opt, 'rows_abort', None) is not None:
+            opt.rows_abort()    # a step that raised between the forward and step() must not poison the next one
 
     def _eager(self, batch):
         model = self.model

@@ -758,6 +758,15 @@ class HipOptimizer:
             items.append((p.data, Gs[i // F][offs[f]:offs[f + 1]], h, ps["m"], ps["v"], flags[offs[f]:offs[f + 1]], p.shape[1]))
         return items
 
+    def rows_abort(self):
+        """forget a rows-mode step that did not reach step() (the caller's step raised).  The tables took no update, but the gather
+        stamped its rows with the number the NEXT step will carry too (the count was not incremented): the stamps are cleared, or
+        rows of the abandoned batch would read stale gradient rows"""
+        if self._rows is not None:
+            self._rows = None
+            if self._rows_state is not None and not torch.cuda.is_current_stream_capturing():
+                self._rows_state["flags"].zero_()
+
     def rows_scratch(self):
         return self._rows_state["G"]
 

@@ -161,3 +161,40 @@ def test_rows_mode_is_not_taken_outside_a_whole_step_or_at_large_batches(cuda):
             assert w2.model.optimizer._rows_state is None
     finally:
         os.environ.pop("RC_ROWS_ADAM", None)
+
+
+def test_a_step_that_raises_between_forward_and_step_does_not_poison_the_next_one(cuda):
+    """a loss function that raises after the forward (the gather has stamped its rows, the optimizer holds a pending rows-mode step):
+    GraphedStep clears the pending step and the stamps; the following steps train exactly like a run that never saw the failed batch"""
+    from rechorus_amd import graph as hgraph
+    if not hgraph.usable():
+        pytest.skip("hipGraph capture not usable in this process")
+    try:
+        res = []
+        for fail in (True, False):
+            w, batches = _deepfm(cuda, 1024, 0.0, True)
+            w.model.train()
+            g = w.graphed
+            losses = [float(g.run(dict(batches[0])))]
+            if fail:
+                real = g.loss_of
+
+                def boom(m, b):
+                    m(b)
+                    raise RuntimeError("boom")
+                g.loss_of = boom
+                with pytest.raises(RuntimeError, match="boom"):
+                    g.run(dict(batches[1]))
+                g.loss_of = real
+                g.seen -= 1        # the failed call was not a training step
+                opt = w.model.optimizer
+                assert opt._rows is None and int(opt._rows_state["flags"].max().item()) == 0
+            losses += [float(g.run(dict(batches[i % 4]))) for i in range(2, 7)]
+            torch.cuda.synchronize()
+            res.append((losses, {k: v.detach().clone() for k, v in w.model.state_dict().items()}))
+        (la, pa), (lb, pb) = res
+        assert la == lb
+        for k in pa:
+            assert torch.equal(pa[k], pb[k]), k
+    finally:
+        os.environ.pop("RC_ROWS_ADAM", None)
