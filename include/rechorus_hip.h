@@ -129,6 +129,30 @@ int rc_gather_fields_pair_mark(const float* const* tables, const float* const* t
                                float* out1, int64_t* cid, int32_t* row_flags, const int64_t* step_dev, int step_add,
                                rc_stream_t stream);
 
+/* Field kinds of rc_gather_fields_mixed.  A numeric context feature (a name ending neither '_c' nor '_id', e.g. MIND's c_day_f) is
+ * nn.Linear(1, d, bias=False) / nn.Linear(1, 1, bias=False) applied to feed_dict[f].float().unsqueeze(-1)
+ * (models/context/FM.py:38-41,47-48,51-52): the value type says how the feature arrives in the feed dict.                          */
+enum rc_field_kind { RC_FIELD_IDS = 0, RC_FIELD_F32 = 1, RC_FIELD_F64 = 2, RC_FIELD_I64 = 3 };
+/* rc_gather_fields_pair(_mark) for a field list that holds numeric features (FMBase._get_embeddings_FM, models/context/FM.py:44-57,
+ * both branches of its conditional expressions): kind[f] = RC_FIELD_IDS as before; otherwise ids[f] points at the feature's VALUES
+ * (float / double / int64, [B] if per_row[f] else [B, C]), tables[f] at the d weights of context_embedding[f] ([d, 1] contiguous),
+ * tables1[f] at the one weight of linear_embedding[f]: out[b, c, f, :] = x * W[:, 0], out1[b, c, f] = x * w1.  Numeric fields own no
+ * row of the virtual concatenated table (row_offset[f] is ignored, no flag is stamped): their occurrences carry numeric_key in cid
+ * -- -1 for the groupings that skip negative keys (rc_small_row_sums, rc_bucket_plan), or the total row count, which sorts them
+ * behind every real row (rc_sort_ids).  tables1 / out1, cid and row_flags / step_dev are optional (NULL) as in the calls above.     */
+int rc_gather_fields_mixed(const float* const* tables, const float* const* tables1, const void* const* ids, const int* per_row,
+                           const int* kind, int64_t numeric_key, const int64_t* row_offset, int F, int64_t B, int C, int d, float* out,
+                           float* out1, int64_t* cid, int32_t* row_flags, const int64_t* step_dev, int step_add, rc_stream_t stream);
+/* Weight gradients of the numeric fields (autograd's Linear backward behind loss.backward(), helpers/BaseRunner.py:205, for the
+ * modules of models/context/FM.py:38-41): dW[j][k] = sum_n x_j[n] * gV[n, field[j], k] and dw1[j][0] = sum_n x_j[n] * gL[n, field[j]]
+ * over the n = B * C rows of the per-occurrence gradient blocks gV [n, F, d] / gL [n, F] (either may be NULL with its outputs).
+ * values / per_row / kind / field / dW / dw1 are HOST arrays of length n_numeric (device pointers / constants per numeric field).
+ * Fixed summation order, no atomics; ws: rc_numeric_field_grads_workspace_bytes (unused up to 1,024 rows).                          */
+size_t rc_numeric_field_grads_workspace_bytes(int64_t n, int n_numeric, int d);
+int rc_numeric_field_grads(const float* gV, const float* gL, const void* const* values, const int* per_row, const int* kind,
+                           const int* field, int n_numeric, int F, int64_t B, int C, int d, float* const* dW, float* const* dw1,
+                           void* ws, size_t ws_bytes, rc_stream_t stream);
+
 /* nn.BCELoss on probabilities (CTRModel.loss, models/BaseModel.py:259-267), torch's log clamp (-100) and
  * backward denominator clamp (1e-12): loss_vec[i] = -(y log p + (1-y) log(1-p)); gp[i] = dmean/dp_i
  * with inv_n = 1/n.  The loss is rc_reduce_sum(loss_vec, n, inv_n).                                    */

@@ -6,9 +6,11 @@ the gradients autograd derives, fp32:
     models/context/WideDeep.py:42-47  wide + MLP_Block(ReLU, output_dim=1)
     models/context/DeepFM.py:19-28    first-order + pairwise + MLP on the same field vectors
     models/BaseModel.py:259-274       nn.BCELoss on sigmoid(prediction)
-Only categorical fields ('*_c', '*_id') are restated (the numeric Linear(1, d) fields are torch
-plumbing in the product too).  Pinned against the reference itself through
-tests/golden/deepfm_*.npz (tests/golden/make_golden_deepfm.py).
+Categorical fields ('*_c', '*_id': nn.Embedding) and numeric fields (any other name, e.g. MIND's
+c_day_f: nn.Linear(1, d, bias=False) / nn.Linear(1, 1, bias=False) on feed_dict[f].float(),
+FM.py:38-41,47-48,51-52) are both restated.  Pinned against the reference itself through
+tests/golden/deepfm_*.npz (tests/golden/make_golden_deepfm.py; the deepfm_mind_* cases carry
+MIND's field set with its numeric feature).
 """
 import numpy as np
 
@@ -52,12 +54,25 @@ def _broadcast(v, n_cand):
     return v if v.ndim == 3 else np.repeat(v[:, None, :], n_cand, axis=1)
 
 
+def is_categorical(f):
+    """FM.py:38-41: a feature named '*_c' / '*_id' owns embedding tables, any other a Linear on its value"""
+    return f.endswith("_c") or f.endswith("_id")
+
+
+def _field(P, family, f, x):
+    """one field of one family (FM.py:47-48 / 51-52): table rows, or Linear(1, w, bias=False) on x.float().unsqueeze(-1)"""
+    W = P["%s.%s.weight" % (family, f)]
+    if is_categorical(f):
+        return W[x]
+    return (x.astype(F32)[..., None] * W[:, 0].astype(F32)).astype(F32)      # [..., 1] @ W.T, W [w, 1]
+
+
 def forward(P, feats, kind, field_order):
-    """P: numpy params named like the reference's state_dict; feats: {field: int ids [B] or [B, C]}
+    """P: numpy params named like the reference's state_dict; feats: {field: int ids (or numeric values) [B] or [B, C]}
     (must include item_id [B, C]); kind in {'FM', 'WideDeep', 'DeepFM'}.  -> raw prediction [B, C]"""
     n_cand = feats["item_id"].shape[1]
-    vec = [_broadcast(P["context_embedding.%s.weight" % f][feats[f]], n_cand) for f in field_order]
-    lin = [_broadcast(P["linear_embedding.%s.weight" % f][feats[f]], n_cand) for f in field_order]
+    vec = [_broadcast(_field(P, "context_embedding", f, feats[f]), n_cand) for f in field_order]
+    lin = [_broadcast(_field(P, "linear_embedding", f, feats[f]), n_cand) for f in field_order]
     V = np.stack(vec, axis=-2).astype(F32)                                  # [B, C, F, d]
     first = (P["overall_bias"] + np.concatenate(lin, axis=-1).sum(axis=-1, dtype=F32)).astype(F32)
     cache = dict(V=V)
@@ -107,7 +122,11 @@ def backward(P, feats, kind, field_order, gpred):
         ids = feats[f]
         T = np.zeros_like(P["context_embedding.%s.weight" % f], dtype=F32)
         L = np.zeros_like(P["linear_embedding.%s.weight" % f], dtype=F32)
-        if ids.ndim == 2:
+        if not is_categorical(f):   # Linear backward: dW[:, 0] = sum_n x[n] * dV[n, k, :],  dw1 = sum_n x[n] * g[n]
+            x = _broadcast(ids.astype(F32)[..., None], C)[..., 0] if ids.ndim == 1 else ids.astype(F32)
+            T[:, 0] = (x[..., None] * dV[:, :, k, :]).reshape(-1, d).sum(axis=0, dtype=F32)
+            L[0, 0] = (x * g).sum(dtype=F32)
+        elif ids.ndim == 2:
             np.add.at(T, ids.reshape(-1), dV[:, :, k, :].reshape(-1, d))
             np.add.at(L, ids.reshape(-1), g.reshape(-1, 1))
         else:  # per-row field broadcast over candidates: its gradient sums over them

@@ -336,6 +336,8 @@ struct FieldArgs {
   int64_t row_offset[kMaxFields];
   int per_row[kMaxFields];  // 1: ids [B] (user / situation field, broadcast over candidates); 0: ids [B, C]
   const float* table1[kMaxFields];   // rc_gather_fields_pair: the [vocab, 1] tables gathered with the same ids (FM.py:44-57), else unused
+  int kind[kMaxFields];     // rc_gather_fields_mixed: RC_FIELD_IDS, or the value type of a numeric field (ids[f] then points at the values)
+  int64_t numeric_key;      // what a numeric field's occurrences carry in cid (they are no rows of the virtual table)
   int F;
   int C;
   int d;
@@ -346,7 +348,17 @@ struct FieldArgs {
 // over the wave, so the table / id pointers are scalar loads from the kernel arguments and the lookups of four fields are in flight
 // together.  (One thread per output element with the field decoded from the element index indexed the pointer arrays per lane --
 // the compiler keeps such an array in scratch -- and paid three 64-bit divisions per element: 93 us for 268 MB out at B = 131,072.)
-template <int VEC>
+// the value of a numeric field ('*_f' features, models/context/FM.py:47-48: feed_dict[f].float()) at batch position i
+__device__ __forceinline__ float field_value(int kind, const void* p, int64_t i) {
+  if (kind == RC_FIELD_F32) return static_cast<const float*>(p)[i];
+  if (kind == RC_FIELD_F64) return (float)static_cast<const double*>(p)[i];
+  return (float)static_cast<const int64_t*>(p)[i];
+}
+
+// MIXED: some field is numeric -- nn.Linear(1, d, bias=False) on the feature's value (FM.py:38-41): its "row" is x * W[:, 0]
+// (table[f] = the d weights), its first-order value x * w1; cid carries numeric_key, no row flag is stamped.  The field index
+// is uniform over the wave, so the kind test is a scalar branch.
+template <int VEC, bool MIXED>
 __global__ __launch_bounds__(kBlock) void gather_fields_kernel(FieldArgs a, float* __restrict__ out,
                                                                int64_t* __restrict__ cid, float* __restrict__ out1,
                                                                int32_t* __restrict__ row_flags, const int64_t* __restrict__ step_dev,
@@ -363,10 +375,18 @@ __global__ __launch_bounds__(kBlock) void gather_fields_kernel(FieldArgs a, floa
     constexpr int U = 4;
     for (int f0 = 0; f0 < a.F; f0 += U) {
       int64_t id[U];
+      float xv[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int f = f0 + u < a.F ? f0 + u : a.F - 1;   // (uniform)
-        id[u] = a.ids[f][a.per_row[f] ? rb : r];
+        const int64_t at = a.per_row[f] ? rb : r;
+        if (MIXED && a.kind[f] != RC_FIELD_IDS) {
+          xv[u] = field_value(a.kind[f], a.ids[f], at);
+          id[u] = 0;            // the d weights are row 0 of the field's "table"
+        } else {
+          xv[u] = 1.0f;
+          id[u] = a.ids[f][at];
+        }
       }
       if (VEC == 4) {
         float4 v[U];
@@ -376,8 +396,12 @@ __global__ __launch_bounds__(kBlock) void gather_fields_kernel(FieldArgs a, floa
           v[u] = reinterpret_cast<const float4*>(a.table[f])[id[u] * dq + q];
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u)
+        for (int u = 0; u < U; ++u) {
+          if (MIXED && a.kind[f0 + u < a.F ? f0 + u : a.F - 1] != RC_FIELD_IDS) {
+            v[u].x *= xv[u]; v[u].y *= xv[u]; v[u].z *= xv[u]; v[u].w *= xv[u];
+          }
           if (f0 + u < a.F) reinterpret_cast<float4*>(out)[(r * a.F + f0 + u) * dq + q] = v[u];
+        }
       } else {
         float v[U];
 #pragma unroll
@@ -386,18 +410,21 @@ __global__ __launch_bounds__(kBlock) void gather_fields_kernel(FieldArgs a, floa
           v[u] = a.table[f][id[u] * dq + q];
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u)
+        for (int u = 0; u < U; ++u) {
+          if (MIXED && a.kind[f0 + u < a.F ? f0 + u : a.F - 1] != RC_FIELD_IDS) v[u] *= xv[u];
           if (f0 + u < a.F) out[(r * a.F + f0 + u) * dq + q] = v[u];
+        }
       }
       if (q == 0 && cid) {
 #pragma unroll
         for (int u = 0; u < U; ++u)
-          if (f0 + u < a.F) cid[r * a.F + f0 + u] = a.row_offset[f0 + u] + id[u];
+          if (f0 + u < a.F)
+            cid[r * a.F + f0 + u] = (MIXED && a.kind[f0 + u] != RC_FIELD_IDS) ? a.numeric_key : a.row_offset[f0 + u] + id[u];
       }
       if (q == 0 && row_flags) {
 #pragma unroll
         for (int u = 0; u < U; ++u)
-          if (f0 + u < a.F) row_flags[a.row_offset[f0 + u] + id[u]] = gen;
+          if (f0 + u < a.F && !(MIXED && a.kind[f0 + u] != RC_FIELD_IDS)) row_flags[a.row_offset[f0 + u] + id[u]] = gen;
       }
       if (q == 0 && out1) {   // the first-order weights of the same ids: [n, F]
         float w1[U];
@@ -407,8 +434,10 @@ __global__ __launch_bounds__(kBlock) void gather_fields_kernel(FieldArgs a, floa
           w1[u] = a.table1[f][id[u]];
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u)
+        for (int u = 0; u < U; ++u) {
+          if (MIXED && a.kind[f0 + u < a.F ? f0 + u : a.F - 1] != RC_FIELD_IDS) w1[u] *= xv[u];
           if (f0 + u < a.F) out1[r * a.F + f0 + u] = w1[u];
+        }
       }
     }
   }
@@ -416,9 +445,9 @@ __global__ __launch_bounds__(kBlock) void gather_fields_kernel(FieldArgs a, floa
 
 }  // namespace rc
 
-static int gather_fields_impl(const float* const* tables, const float* const* tables1, const int64_t* const* ids, const int* per_row,
-                              const int64_t* row_offset, int F, int64_t B, int C, int d, float* out, float* out1, int64_t* cid,
-                              int32_t* row_flags, const int64_t* step_dev, int step_add, rc_stream_t stream) {
+static int gather_fields_impl(const float* const* tables, const float* const* tables1, const void* const* ids, const int* per_row,
+                              const int* kind, int64_t numeric_key, const int64_t* row_offset, int F, int64_t B, int C, int d, float* out,
+                              float* out1, int64_t* cid, int32_t* row_flags, const int64_t* step_dev, int step_add, rc_stream_t stream) {
   if (B == 0) return RC_OK;
   RC_REQUIRE((row_flags == nullptr) == (step_dev == nullptr), "rc_gather_fields_pair_mark: the row flags and the step count come together");
   RC_REQUIRE(tables && ids && per_row && row_offset && out, "rc_gather_fields: null pointer");
@@ -428,23 +457,28 @@ static int gather_fields_impl(const float* const* tables, const float* const* ta
   FieldArgs a;
   memset(&a, 0, sizeof(a));
   bool vec = d % 4 == 0 && reinterpret_cast<uintptr_t>(out) % 16 == 0;
+  bool mixed = false;
   for (int f = 0; f < F; ++f) {
     RC_REQUIRE(tables[f] && ids[f] && (!tables1 || tables1[f]), "rc_gather_fields: null table / ids for field %d", f);
     a.table[f] = tables[f];
     a.table1[f] = tables1 ? tables1[f] : nullptr;
-    a.ids[f] = ids[f];
+    a.ids[f] = static_cast<const int64_t*>(ids[f]);
     a.row_offset[f] = row_offset[f];
     a.per_row[f] = per_row[f];
+    a.kind[f] = kind ? kind[f] : RC_FIELD_IDS;
+    RC_REQUIRE(a.kind[f] >= RC_FIELD_IDS && a.kind[f] <= RC_FIELD_I64, "rc_gather_fields_mixed: kind[%d] = %d is no rc_field_kind", f, a.kind[f]);
+    mixed = mixed || a.kind[f] != RC_FIELD_IDS;
     vec = vec && reinterpret_cast<uintptr_t>(tables[f]) % 16 == 0;
   }
+  a.numeric_key = numeric_key;
   a.F = F; a.C = C; a.d = d; a.n = B * C;
   const int64_t total = a.n * (vec ? d / 4 : d);   // one thread per (row, float4 | float), walking the fields
   int64_t blocks = (total + kBlock - 1) / kBlock;
   if (blocks > 256 * 32) blocks = 256 * 32;
-  if (vec)
-    hipLaunchKernelGGL((gather_fields_kernel<4>), dim3((unsigned)blocks), dim3(kBlock), 0, as_stream(stream), a, out, cid, out1, row_flags, step_dev, step_add);
-  else
-    hipLaunchKernelGGL((gather_fields_kernel<1>), dim3((unsigned)blocks), dim3(kBlock), 0, as_stream(stream), a, out, cid, out1, row_flags, step_dev, step_add);
+  void (*kern)(FieldArgs, float*, int64_t*, float*, int32_t*, const int64_t*, int) =
+      vec ? (mixed ? gather_fields_kernel<4, true> : gather_fields_kernel<4, false>)
+          : (mixed ? gather_fields_kernel<1, true> : gather_fields_kernel<1, false>);
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kBlock), 0, as_stream(stream), a, out, cid, out1, row_flags, step_dev, step_add);
   RC_LAUNCH_CHECK();
   return RC_OK;
 }
@@ -452,14 +486,14 @@ static int gather_fields_impl(const float* const* tables, const float* const* ta
 extern "C" int rc_gather_fields(const float* const* tables, const int64_t* const* ids, const int* per_row,
                                 const int64_t* row_offset, int F, int64_t B, int C, int d, float* out, int64_t* cid,
                                 rc_stream_t stream) {
-  return gather_fields_impl(tables, nullptr, ids, per_row, row_offset, F, B, C, d, out, nullptr, cid, nullptr, nullptr, 0, stream);
+  return gather_fields_impl(tables, nullptr, reinterpret_cast<const void* const*>(ids), per_row, nullptr, -1, row_offset, F, B, C, d, out, nullptr, cid, nullptr, nullptr, 0, stream);
 }
 
 extern "C" int rc_gather_fields_pair(const float* const* tables, const float* const* tables1, const int64_t* const* ids, const int* per_row,
                                      const int64_t* row_offset, int F, int64_t B, int C, int d, float* out, float* out1, int64_t* cid,
                                      rc_stream_t stream) {
   RC_REQUIRE(tables1 && out1, "rc_gather_fields_pair: null pointer");
-  return gather_fields_impl(tables, tables1, ids, per_row, row_offset, F, B, C, d, out, out1, cid, nullptr, nullptr, 0, stream);
+  return gather_fields_impl(tables, tables1, reinterpret_cast<const void* const*>(ids), per_row, nullptr, -1, row_offset, F, B, C, d, out, out1, cid, nullptr, nullptr, 0, stream);
 }
 
 extern "C" int rc_gather_fields_pair_mark(const float* const* tables, const float* const* tables1, const int64_t* const* ids,
@@ -467,7 +501,191 @@ extern "C" int rc_gather_fields_pair_mark(const float* const* tables, const floa
                                           float* out1, int64_t* cid, int32_t* row_flags, const int64_t* step_dev, int step_add,
                                           rc_stream_t stream) {
   RC_REQUIRE(tables1 && out1 && row_flags && step_dev, "rc_gather_fields_pair_mark: null pointer");
-  return gather_fields_impl(tables, tables1, ids, per_row, row_offset, F, B, C, d, out, out1, cid, row_flags, step_dev, step_add, stream);
+  return gather_fields_impl(tables, tables1, reinterpret_cast<const void* const*>(ids), per_row, nullptr, -1, row_offset, F, B, C, d, out, out1, cid, row_flags, step_dev, step_add, stream);
+}
+
+extern "C" int rc_gather_fields_mixed(const float* const* tables, const float* const* tables1, const void* const* ids,
+                                      const int* per_row, const int* kind, int64_t numeric_key, const int64_t* row_offset, int F,
+                                      int64_t B, int C, int d, float* out, float* out1, int64_t* cid, int32_t* row_flags,
+                                      const int64_t* step_dev, int step_add, rc_stream_t stream) {
+  RC_REQUIRE(kind, "rc_gather_fields_mixed: null pointer");
+  return gather_fields_impl(tables, tables1, ids, per_row, kind, numeric_key, row_offset, F, B, C, d, out, out1, cid, row_flags, step_dev,
+                            step_add, stream);
+}
+
+// ---- weight gradients of the numeric fields ---------------------------------------------------------------------------
+// A numeric field is nn.Linear(1, d, bias=False) applied to the feature's value (models/context/FM.py:38-41,47-48); autograd's
+// Linear backward gives dW[:, 0] = sum_n x[n] * gV[n, f, :] and, for the first-order Linear(1, 1), dw1 = sum_n x[n] * gL[n, f].
+// Weighted column sums over a strided slice of the per-occurrence gradient blocks: chunks of kNumericChunk rows per workgroup,
+// every lane-group its rows in ascending order, the groups combined in a fixed order through LDS, the chunks by a second
+// launch in ascending order (a batch of up to kNumericChunk rows: one launch writes the gradients themselves).  No atomics.
+namespace rc {
+
+constexpr int kNumericChunk = 1024;
+
+struct NumericGradArgs {
+  const void* values[kMaxFields];   // per numeric slot j
+  float* dW[kMaxFields];            // [d]
+  float* dw1[kMaxFields];           // [1]
+  int kind[kMaxFields];
+  int per_row[kMaxFields];
+  int field[kMaxFields];            // the slot's field index in [0, F)
+  const float* gV;                  // [n, F, d] | null
+  const float* gL;                  // [n, F] | null
+  float* part;                      // [chunks][n_numeric][d + 1]
+  int64_t n;                        // B * C
+  int n_numeric, F, C, d;
+};
+
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void numeric_field_grads_kernel(NumericGradArgs a) {
+  __shared__ float red[kBlock * VEC];
+  __shared__ float red1[kBlock];
+  const int j = blockIdx.y, f = a.field[j];
+  const int dq = a.d / VEC;
+  const int lpr = dq < kBlock ? dq : kBlock;   // lanes per row
+  const int slots = kBlock / lpr;              // rows in flight per step
+  const int tid = threadIdx.x, l = tid % lpr, rs = tid / lpr;
+  const bool live = rs < slots;
+  const int64_t r0 = (int64_t)blockIdx.x * kNumericChunk;
+  const int64_t r1 = r0 + kNumericChunk < a.n ? r0 + kNumericChunk : a.n;
+  const int kind = a.kind[j], per_row = a.per_row[j];
+  const void* xs = a.values[j];
+  const bool direct = gridDim.x == 1;
+  float* part = a.part + ((size_t)blockIdx.x * a.n_numeric + j) * (a.d + 1);
+  for (int c0 = 0; c0 < dq; c0 += lpr) {       // (one trip unless d > 256 * VEC; workgroup-uniform)
+    const int cq = c0 + l < dq ? c0 + l : dq - 1;
+    const bool col = c0 + l < dq;
+    float acc[VEC];
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) acc[c] = 0.f;
+    float acc1 = 0.f;
+    const bool first = c0 == 0 && l == 0 && a.gL != nullptr;   // this lane also forms the first-order weight's sum
+    if (live && a.gV) {
+      constexpr int U = 8;
+      for (int64_t r = r0 + rs; r < r1; r += (int64_t)slots * U) {
+        float x[U], g1[U];
+        float gv[U][VEC];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int64_t rr = r + (int64_t)u * slots;
+          const bool in = rr < r1;
+          x[u] = in ? field_value(kind, xs, per_row ? rr / a.C : rr) : 0.f;
+          const float* src = a.gV + ((size_t)(in ? rr : r0) * a.F + f) * a.d + (size_t)cq * VEC;
+          if (VEC == 4) {
+            const float4 t = *reinterpret_cast<const float4*>(src);
+            gv[u][0] = t.x; gv[u][1 % VEC] = t.y; gv[u][2 % VEC] = t.z; gv[u][3 % VEC] = t.w;
+          } else {
+            gv[u][0] = src[0];
+          }
+          g1[u] = (first && in) ? a.gL[(size_t)rr * a.F + f] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+          for (int c = 0; c < VEC; ++c) acc[c] += x[u] * gv[u][c];
+          acc1 += x[u] * g1[u];
+        }
+      }
+    } else if (live && first) {   // (only the first-order family reached the loss)
+      for (int64_t r = r0 + rs; r < r1; r += slots) acc1 += field_value(kind, xs, per_row ? r / a.C : r) * a.gL[(size_t)r * a.F + f];
+    }
+    __syncthreads();   // (the previous trip's reads of red[])
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) red[tid * VEC + c] = acc[c];
+    red1[tid] = acc1;
+    __syncthreads();
+    if (live && rs == 0) {
+      float t[VEC];
+#pragma unroll
+      for (int c = 0; c < VEC; ++c) t[c] = red[l * VEC + c];
+      float t1 = red1[l];
+      for (int q = 1; q < slots; ++q) {   // fixed order: slot 0, 1, ...
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) t[c] += red[(q * lpr + l) * VEC + c];
+        t1 += red1[q * lpr + l];
+      }
+      if (a.gV && col) {
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) {
+          if (direct) a.dW[j][cq * VEC + c] = t[c];
+          else part[cq * VEC + c] = t[c];
+        }
+      }
+      if (first) {
+        if (direct) a.dw1[j][0] = t1;
+        else part[a.d] = t1;
+      }
+    }
+  }
+}
+
+// chunk partials -> gradients, ascending chunk order; one thread per (slot, column)
+__global__ __launch_bounds__(kBlock) void numeric_field_reduce_kernel(NumericGradArgs a, int chunks) {
+  const int w = a.d + 1;
+  const int t = blockIdx.x * kBlock + threadIdx.x;
+  if (t >= a.n_numeric * w) return;
+  const int j = t / w, c = t - j * w;
+  if (c == a.d ? a.gL == nullptr : a.gV == nullptr) return;
+  float s = 0.f;
+  for (int k = 0; k < chunks; ++k) s += a.part[((size_t)k * a.n_numeric + j) * w + c];
+  if (c == a.d) a.dw1[j][0] = s;
+  else a.dW[j][c] = s;
+}
+
+}  // namespace rc
+
+extern "C" size_t rc_numeric_field_grads_workspace_bytes(int64_t n, int n_numeric, int d) {
+  if (n < 1 || n_numeric < 1 || d < 1) return 256;
+  const int64_t chunks = (n + kNumericChunk - 1) / kNumericChunk;
+  return align_up((size_t)chunks * (size_t)n_numeric * (size_t)(d + 1) * sizeof(float), 256);
+}
+
+extern "C" int rc_numeric_field_grads(const float* gV, const float* gL, const void* const* values, const int* per_row, const int* kind,
+                                      const int* field, int n_numeric, int F, int64_t B, int C, int d, float* const* dW,
+                                      float* const* dw1, void* ws, size_t ws_bytes, rc_stream_t stream) {
+  if (n_numeric == 0) return RC_OK;
+  RC_REQUIRE(values && per_row && kind && field && (gV || gL), "rc_numeric_field_grads: null pointer");
+  RC_REQUIRE((gV == nullptr || dW) && (gL == nullptr || dw1), "rc_numeric_field_grads: a gradient block without its outputs");
+  RC_REQUIRE(n_numeric >= 1 && n_numeric <= F && F <= kMaxFields, "rc_numeric_field_grads: n_numeric=%d of F=%d fields (<= %d)", n_numeric, F, kMaxFields);
+  RC_REQUIRE(B >= 0 && C >= 1 && d >= 1, "rc_numeric_field_grads: bad shape B=%lld C=%d d=%d", (long long)B, C, d);
+  NumericGradArgs a;
+  memset(&a, 0, sizeof(a));
+  hipStream_t s = as_stream(stream);
+  for (int j = 0; j < n_numeric; ++j) {
+    RC_REQUIRE(values[j] && (!gV || dW[j]) && (!gL || dw1[j]), "rc_numeric_field_grads: null pointer for numeric field %d", j);
+    RC_REQUIRE(field[j] >= 0 && field[j] < F, "rc_numeric_field_grads: field[%d] = %d outside [0, %d)", j, field[j], F);
+    RC_REQUIRE(kind[j] >= RC_FIELD_F32 && kind[j] <= RC_FIELD_I64, "rc_numeric_field_grads: kind[%d] = %d is no numeric rc_field_kind", j, kind[j]);
+    a.values[j] = values[j]; a.kind[j] = kind[j]; a.per_row[j] = per_row[j]; a.field[j] = field[j];
+    a.dW[j] = dW ? dW[j] : nullptr; a.dw1[j] = dw1 ? dw1[j] : nullptr;
+  }
+  a.gV = gV; a.gL = gL; a.n = B * C; a.n_numeric = n_numeric; a.F = F; a.C = C; a.d = d;
+  if (a.n == 0) {   // an empty batch: zero gradients
+    for (int j = 0; j < n_numeric; ++j) {
+      if (gV) RC_HIP(hipMemsetAsync(a.dW[j], 0, (size_t)d * sizeof(float), s));
+      if (gL) RC_HIP(hipMemsetAsync(a.dw1[j], 0, sizeof(float), s));
+    }
+    return RC_OK;
+  }
+  const int64_t chunks = (a.n + kNumericChunk - 1) / kNumericChunk;
+  RC_REQUIRE(chunks <= kMaxGridX, "rc_numeric_field_grads: too many rows");
+  if (chunks > 1) {
+    RC_REQUIRE(ws != nullptr && ws_bytes >= rc_numeric_field_grads_workspace_bytes(a.n, n_numeric, d), "rc_numeric_field_grads: workspace %zu < %zu",
+               ws_bytes, rc_numeric_field_grads_workspace_bytes(a.n, n_numeric, d));
+    a.part = static_cast<float*>(ws);
+  }
+  const bool vec = d % 4 == 0 && (gV == nullptr || reinterpret_cast<uintptr_t>(gV) % 16 == 0);
+  if (vec)
+    hipLaunchKernelGGL((numeric_field_grads_kernel<4>), dim3((unsigned)chunks, (unsigned)n_numeric), dim3(kBlock), 0, s, a);
+  else
+    hipLaunchKernelGGL((numeric_field_grads_kernel<1>), dim3((unsigned)chunks, (unsigned)n_numeric), dim3(kBlock), 0, s, a);
+  RC_LAUNCH_CHECK();
+  if (chunks > 1) {
+    const int total = n_numeric * (d + 1);
+    hipLaunchKernelGGL(numeric_field_reduce_kernel, dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, a, (int)chunks);
+    RC_LAUNCH_CHECK();
+  }
+  return RC_OK;
 }
 
 // ---- point-wise BCE over a ranking list (ContextModel.loss, loss_n == 'BCE': models/BaseContextModel.py:53-56)

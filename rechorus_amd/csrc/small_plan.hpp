@@ -35,6 +35,10 @@ constexpr size_t kSmallLdsBytes = small_lds_bytes(kSmallCap, kSmallWaveCap);
 constexpr int kSmallCapBig = 8192, kSmallWaveCapBig = 1024;
 constexpr size_t kSmallLdsBytesBig = small_lds_bytes(kSmallCapBig, kSmallWaveCapBig);
 
+// a key no row can have (n_rows < 2^32 - 1): an id of -1 narrows to it and takes no part in the grouping -- the occurrences of a
+// context model's numeric fields, which own no row of the virtual concatenated table (rc_gather_fields_mixed)
+constexpr uint32_t kSmallSkipKey = 0xFFFFFFFFu;
+
 struct SmallCnt { uint32_t rows_a, rows_b, occ, pad; };   // per plan workgroup
 
 struct SmallPlanArgs {
@@ -90,7 +94,7 @@ __device__ __forceinline__ void small_plan_block(const SmallPlanArgs& a, uint32_
     for (int q = 0; q < kBatch; ++q) {
       if (p0 + q * 64 >= p_end) break;  // wave-uniform
       const uint32_t p = p0 + q * 64 + lane;
-      const bool mine = p < p_end && (key[q] & (kSmallPlanWgs - 1)) == w;
+      const bool mine = p < p_end && key[q] != kSmallSkipKey && (key[q] & (kSmallPlanWgs - 1)) == w;
       const uint64_t m = __ballot(mine);
       const uint32_t at = cnt + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
       if (mine && at < (uint32_t)kSmallWaveCap) region[(size_t)wave * kSmallWaveCap + at] = ((uint64_t)key[q] << 15) | p;
@@ -228,7 +232,7 @@ __device__ __forceinline__ void small_plan_block(const SmallPlanArgs& a, uint32_
     bool any = false;
     for (uint32_t p = tid; p < a.n; p += kSmallThreads) {
       const uint32_t key = small_key(a, p);
-      if ((key & (kSmallPlanWgs - 1)) == w && (uint64_t)key + 1 > last && (!any || key < best)) { best = key; any = true; }
+      if (key != kSmallSkipKey && (key & (kSmallPlanWgs - 1)) == w && (uint64_t)key + 1 > last && (!any || key < best)) { best = key; any = true; }
     }
     // block min
     for (int off = 32; off >= 1; off >>= 1) {

@@ -1700,47 +1700,103 @@ def bce_ranking(pred, need_grad=True):
     return reduce_sum(loss_vec, 1.0 / B), gpred
 
 
-def gather_fields(tables, ids, n_cand, want_cid=True, tables1=None, mark=None):
+FIELD_IDS, FIELD_F32, FIELD_F64, FIELD_I64 = 0, 1, 2, 3   # enum rc_field_kind
+
+
+def field_kind(values):
+    """rc_field_kind of a numeric feature's value tensor (what `feed_dict[f].float()` of models/context/FM.py:47-48 starts from)"""
+    kind = {torch.float32: FIELD_F32, torch.float64: FIELD_F64, torch.int64: FIELD_I64}.get(values.dtype)
+    if kind is None:
+        raise ValueError("numeric field values must be float32, float64 or int64, got {}".format(values.dtype))
+    return kind
+
+
+def gather_fields(tables, ids, n_cand, want_cid=True, tables1=None, mark=None, kinds=None, numeric_key=-1):
     """tables: list of F [vocab_f, d] tensors; ids: list of F int64 tensors, [B] (per-row field) or [B, C]
     -> (out [B, C, F, d], cid [B, C, F] | None, row_offset list): all field lookups in one launch.
     tables1: F [vocab_f, 1] tables looked up with the same ids (rc_gather_fields_pair) -> (out, out1 [B, C, F, 1], cid, offsets)
     mark = (row_flags int32 [sum of vocab sizes], step_dev int64 [1]): the looked-up rows are stamped with the number of the
-    step in progress, step_dev + 1 (rc_gather_fields_pair_mark, for dense_update_rows)"""
+    step in progress, step_dev + 1 (rc_gather_fields_pair_mark, for dense_update_rows)
+    kinds: per field FIELD_IDS or the value type of a NUMERIC field (rc_gather_fields_mixed; models/context/FM.py:38-41,47-48):
+    tables[f] is then the Linear(1, d) weight [d, 1], tables1[f] the Linear(1, 1) weight [1, 1], ids[f] the feature's values;
+    such a field owns no row of the concatenated table and its occurrences carry `numeric_key` in cid"""
     F = len(tables)
-    d = tables[0].shape[1]
+    kinds = [FIELD_IDS] * F if kinds is None else [int(k) for k in kinds]
+    mixed = any(k != FIELD_IDS for k in kinds)
+    d = next((t.shape[1] for t, k in zip(tables, kinds) if k == FIELD_IDS), tables[0].shape[0])
     B = ids[0].shape[0]
     dev, f32, i64 = tables[0].device, torch.float32, torch.int64
     out = torch.empty((B, n_cand, F, d), dtype=f32, device=dev)
     cid = torch.empty((B, n_cand, F), dtype=i64, device=dev) if want_cid else None
     offs, run = [], 0
-    for t in tables:
-        if t.shape[1] != d:
-            raise ValueError("gather_fields: all tables need the same width")
+    for t, k in zip(tables, kinds):
+        if tuple(t.shape[-2:]) != ((t.shape[0], d) if k == FIELD_IDS else (d, 1)):
+            raise ValueError("gather_fields: all tables need the same width (a numeric field's weight is [d, 1])")
         offs.append(run)
-        run += t.shape[0]
+        run += t.shape[0] if k == FIELD_IDS else 0
+    for x, k in zip(ids, kinds):
+        if k != FIELD_IDS and field_kind(x) != k:
+            raise ValueError("gather_fields: kind {} does not match the value dtype {}".format(k, x.dtype))
     tab_arr = (C.c_void_p * F)(*[_ptr(t, f32, "table").value for t in tables])
-    ids_arr = (C.c_void_p * F)(*[_ptr(x, i64, "ids").value for x in ids])
+    ids_arr = (C.c_void_p * F)(*[_ptr(x, i64 if k == FIELD_IDS else x.dtype, "ids").value for x, k in zip(ids, kinds)])
     per_row = (C.c_int * F)(*[1 if x.dim() == 1 else 0 for x in ids])
     off_arr = (C.c_int64 * F)(*offs)
+    out1 = tab1_arr = None
     if tables1 is not None:
-        if len(tables1) != F or any(t1.shape != (t.shape[0], 1) for t, t1 in zip(tables, tables1)):
+        if len(tables1) != F or any(t1.shape != ((t.shape[0], 1) if k == FIELD_IDS else (1, 1)) for t, t1, k in zip(tables, tables1, kinds)):
             raise ValueError("gather_fields: the second family must be [vocab_f, 1] tables of the same vocabularies")
         out1 = torch.empty((B, n_cand, F, 1), dtype=f32, device=dev)
         tab1_arr = (C.c_void_p * F)(*[_ptr(t, f32, "table1").value for t in tables1])
-        if mark is not None:
-            flags, step_dev = mark
-            if flags.numel() != run:
-                raise ValueError("gather_fields: one row flag per row of the concatenated tables")
-            _lib.call("rc_gather_fields_pair_mark", tab_arr, tab1_arr, ids_arr, per_row, off_arr, F, B, int(n_cand), d,
-                      _ptr(out, f32, "out"), _ptr(out1, f32, "out1"), _ptr(cid, i64, "cid", True), _ptr(flags, torch.int32, "row_flags"),
-                      _ptr(step_dev, i64, "step_dev"), 1, _stream())
-            return out, out1, cid, offs + [run]
+    flags = step_dev = None
+    if mark is not None:
+        flags, step_dev = mark
+        if tables1 is None:
+            raise ValueError("gather_fields: row flags come with the pair gather")
+        if flags.numel() != run:
+            raise ValueError("gather_fields: one row flag per row of the concatenated tables")
+    if mixed:
+        kind_arr = (C.c_int * F)(*kinds)
+        _lib.call("rc_gather_fields_mixed", tab_arr, tab1_arr, ids_arr, per_row, kind_arr, int(numeric_key), off_arr, F, B, int(n_cand), d,
+                  _ptr(out, f32, "out"), _ptr(out1, f32, "out1", True), _ptr(cid, i64, "cid", True), _ptr(flags, torch.int32, "row_flags", True),
+                  _ptr(step_dev, i64, "step_dev", True), 1, _stream())
+    elif mark is not None:
+        _lib.call("rc_gather_fields_pair_mark", tab_arr, tab1_arr, ids_arr, per_row, off_arr, F, B, int(n_cand), d,
+                  _ptr(out, f32, "out"), _ptr(out1, f32, "out1"), _ptr(cid, i64, "cid", True), _ptr(flags, torch.int32, "row_flags"),
+                  _ptr(step_dev, i64, "step_dev"), 1, _stream())
+    elif tables1 is not None:
         _lib.call("rc_gather_fields_pair", tab_arr, tab1_arr, ids_arr, per_row, off_arr, F, B, int(n_cand), d, _ptr(out, f32, "out"),
                   _ptr(out1, f32, "out1"), _ptr(cid, i64, "cid", True), _stream())
+    else:
+        _lib.call("rc_gather_fields", tab_arr, ids_arr, per_row, off_arr, F, B, int(n_cand), d, _ptr(out, f32, "out"),
+                  _ptr(cid, i64, "cid", True), _stream())
+    if tables1 is not None:
         return out, out1, cid, offs + [run]
-    _lib.call("rc_gather_fields", tab_arr, ids_arr, per_row, off_arr, F, B, int(n_cand), d, _ptr(out, f32, "out"),
-              _ptr(cid, i64, "cid", True), _stream())
     return out, cid, offs + [run]
+
+
+def numeric_field_grads(gV, gL, values, fields, n_fields, n_cand, d):
+    """weight gradients of the numeric fields (rc_numeric_field_grads): gV [n, F, d] | None, gL [n, F] | None per-occurrence
+    gradient blocks, values[j] / fields[j] the value tensor and field index of numeric field j
+    -> (list of dW [d, 1] | None, list of dw1 [1, 1] | None)"""
+    J = len(values)
+    src = gV if gV is not None else gL
+    dev, f32 = src.device, torch.float32
+    B = values[0].shape[0]
+    n = B * n_cand
+    dW = torch.empty((J, d, 1), dtype=f32, device=dev) if gV is not None else None
+    dw1 = torch.empty((J, 1, 1), dtype=f32, device=dev) if gL is not None else None
+    kinds = [field_kind(x) for x in values]
+    val_arr = (C.c_void_p * J)(*[_ptr(x, x.dtype, "values").value for x in values])
+    per_row = (C.c_int * J)(*[1 if x.dim() == 1 else 0 for x in values])
+    kind_arr = (C.c_int * J)(*kinds)
+    field_arr = (C.c_int * J)(*[int(f) for f in fields])
+    dW_arr = (C.c_void_p * J)(*[dW[j].data_ptr() for j in range(J)]) if dW is not None else None
+    dw1_arr = (C.c_void_p * J)(*[dw1[j].data_ptr() for j in range(J)]) if dw1 is not None else None
+    nbytes = _lib.load().rc_numeric_field_grads_workspace_bytes(n, J, d)
+    ws = workspace(nbytes, dev, "numeric_fields")
+    _lib.call("rc_numeric_field_grads", _ptr(gV, f32, "gV", True), _ptr(gL, f32, "gL", True), val_arr, per_row, kind_arr, field_arr, J,
+              int(n_fields), B, int(n_cand), int(d), dW_arr, dw1_arr, C.c_void_p(ws.data_ptr()), ws.numel(), _stream())
+    return (None if dW is None else [dW[j] for j in range(J)]), (None if dw1 is None else [dw1[j] for j in range(J)])
 
 
 def bce_prob(p, y, need_grad=True):

@@ -287,56 +287,97 @@ class _FieldGatherPairFn(torch.autograd.Function):
     """the TWO table families the FM models gather with the same ids (models/context/FM.py:44-57: field vectors [vocab, d] and
     first-order weights [vocab, 1]) as one autograd node: one gather launch forward (rc_gather_fields_pair); backward, ONE
     grouping of the composite (field, id) keys serves both dense gradients -- the small route's plan (rc_small_row_sums +
-    rc_small_row_sums_again on one zero-filled buffer), or one sort -- instead of one per family."""
+    rc_small_row_sums_again on one zero-filled buffer), or one sort -- instead of one per family.
+    Numeric fields (kinds[f] != 0; FM.py:38-41,47-48: Linear(1, d) / Linear(1, 1) on the feature's value) ride in the same gather
+    launch (rc_gather_fields_mixed: their "row" is x * W[:, 0]); they own no row of the concatenated table, their occurrences
+    take no part in the grouping, and their weight gradients are one weighted column sum (rc_numeric_field_grads)."""
 
     @staticmethod
-    def forward(ctx, n_cand, n_fields, rows_opt, *args):
+    def forward(ctx, n_cand, n_fields, rows_opt, kinds, *args):
         ids = [x.contiguous() for x in args[:n_fields]]
         tables, tables1 = args[n_fields:2 * n_fields], args[2 * n_fields:]
-        d = tables[0].shape[1]
-        n = ids[0].shape[0] * n_cand * n_fields
+        kinds = tuple(kinds) if kinds is not None else (engine.FIELD_IDS,) * n_fields
+        cat = [f for f in range(n_fields) if kinds[f] == engine.FIELD_IDS]
+        num = [f for f in range(n_fields) if kinds[f] != engine.FIELD_IDS]
+        d = tables[cat[0]].shape[1] if cat else tables[0].shape[0]
+        rows = ids[0].shape[0] * n_cand
+        n = rows * n_fields
+        n_rows = sum(tables[f].shape[0] for f in cat)
         mark = None
-        if rows_opt is not None and n <= 8192 and d % 4 == 0 and engine.small_route_ok(n, sum(t.shape[0] for t in tables), d):
+        if rows_opt is not None and cat and n <= 8192 and d % 4 == 0 and engine.small_route_ok(n, n_rows, d):
             # rows mode (HipOptimizer.rows_begin): the gather stamps the looked-up rows, and the backward pass below hands their row
             # sums to the optimizer in a scratch that nothing zero-fills, instead of a dense gradient
-            mark = rows_opt.rows_begin(tables, tables1)
+            mark = rows_opt.rows_begin([tables[f] for f in cat], [tables1[f] for f in cat])
+        n_ids = rows
+        ctx.route = "small" if n <= 8192 else ("sort" if cat and min(tables[f].shape[0] for f in cat) * 8 <= n_ids else None)
+        if num and not (ctx.route == "small" and engine.small_route_ok(n, max(n_rows, 1), d)):
+            ctx.route = "sort"    # (the other groupings of embedding_dense_backward have no key that stands for "no row")
+        # what the numeric occurrences carry in cid: the small route and the bucket plan skip negative keys; a sort puts the key
+        # past the last row behind every real row (the grouping below stops in front of that tail)
+        numeric_key = n_rows if (ctx.route == "sort" and num) else -1
         V, L, cid, offs = engine.gather_fields([t.detach() for t in tables], ids, n_cand, want_cid=True,
-                                               tables1=[t.detach() for t in tables1], mark=mark)
+                                               tables1=[t.detach() for t in tables1], mark=mark,
+                                               kinds=kinds if num else None, numeric_key=numeric_key)
         ctx.rows_opt = rows_opt if mark is not None else None
         ctx.cid, ctx.offs, ctx.d = cid, offs, d
-        n_ids = cid.numel() // max(1, n_fields)
-        ctx.route = "small" if cid.numel() <= 8192 else ("sort" if min(t.shape[0] for t in tables) * 8 <= n_ids else None)
+        ctx.kinds, ctx.num, ctx.n_cand = kinds, num, n_cand
+        ctx.values = [ids[f] for f in num]
         return V, L
 
     @staticmethod
     def backward(ctx, gV, gL):
         offs, d = ctx.offs, ctx.d
         n_rows, n = offs[-1], ctx.cid.numel()
+        F = len(offs) - 1
         gV = None if gV is None else gV.contiguous()
         gL = None if gL is None else gL.contiguous()
+        num = ctx.num
+        gw = gw1 = None
+        if num and (gV is not None or gL is not None):
+            gw, gw1 = engine.numeric_field_grads(None if gV is None else gV.view(n // F, F, d), None if gL is None else gL.view(n // F, F),
+                                                 ctx.values, num, F, ctx.n_cand, d)
+
+        def numeric(grads, family):
+            """the tables' gradient tuple with the numeric fields' Linear weights filled in"""
+            if family is None:
+                return grads
+            out = list(grads)
+            for j, f in enumerate(num):
+                out[f] = family[j]
+            return tuple(out)
+
         if ctx.rows_opt is not None:
             if gV is None or gL is None:
                 raise RuntimeError("gather_fields_pair (rows mode): both table families must reach the loss")
             Gv, Gl = engine.small_row_sums_pair(ctx.cid, n_rows, gV.view(n, d), gL.view(n, 1), into=ctx.rows_opt.rows_scratch())
             ctx.rows_opt.rows_grads(Gv, Gl)
-            return (None, None, None) + (None,) * (3 * (len(offs) - 1))
-        if gV is not None and gL is not None and ctx.route == "small" and engine.small_route_ok(n, n_rows, d) and d % 4 == 0:
+            return (None, None, None, None) + (None,) * F + numeric((None,) * F, gw) + numeric((None,) * F, gw1)
+        if n_rows == 0:       # numeric fields only
+            Gv = Gl = None
+        elif gV is not None and gL is not None and ctx.route == "small" and engine.small_route_ok(n, n_rows, d) and d % 4 == 0:
             Gv, Gl = engine.small_row_sums_pair(ctx.cid, n_rows, gV.view(n, d), gL.view(n, 1))
         else:
-            presorted = engine.sort_ids(ctx.cid.reshape(-1), n_rows) if ctx.route == "sort" else None
+            presorted = None
+            if ctx.route == "sort":
+                # the numeric occurrences (key n_rows) sort behind every row of the virtual table: the grouping takes the head
+                keys, perm = engine.sort_ids(ctx.cid.reshape(-1), n_rows + (1 if num else 0))
+                n_cat = (n // F) * (F - len(num))
+                presorted = (keys[:n_cat], perm[:n_cat])
             Gv = None if gV is None else engine.embedding_dense_backward(gV, ctx.cid, n_rows, route=ctx.route, presorted=presorted)
             Gl = None if gL is None else engine.embedding_dense_backward(gL, ctx.cid, n_rows, route=ctx.route, presorted=presorted)
-        F = len(offs) - 1
-        gv = tuple(None if Gv is None else Gv[offs[f]:offs[f + 1]] for f in range(F))
-        gl = tuple(None if Gl is None else Gl[offs[f]:offs[f + 1]] for f in range(F))
-        return (None, None, None) + (None,) * F + gv + gl
+        cat = lambda G, f: None if (G is None or ctx.kinds[f] != engine.FIELD_IDS) else G[offs[f]:offs[f + 1]]
+        gv = numeric(tuple(cat(Gv, f) for f in range(F)), gw)
+        gl = numeric(tuple(cat(Gl, f) for f in range(F)), gw1)
+        return (None, None, None, None) + (None,) * F + gv + gl
 
 
-def gather_fields_pair(tables, tables1, ids, n_cand, rows_opt=None):
+def gather_fields_pair(tables, tables1, ids, n_cand, rows_opt=None, kinds=None):
     """-> (field vectors [B, C, F, d], first-order values [B, C, F, 1]) of the two table families looked up with the same ids.
     rows_opt: the HipOptimizer that owns the tables, when this forward is part of a whole training step whose optimizer.step()
-    follows (graph.GraphedStep sets it): small batches then take the optimizer's rows mode"""
-    return _FieldGatherPairFn.apply(n_cand, len(tables), rows_opt, *ids, *tables, *tables1)
+    follows (graph.GraphedStep sets it): small batches then take the optimizer's rows mode.
+    kinds: per field engine.FIELD_IDS (a table looked up by ids) or the value type of a numeric field (engine.field_kind): then
+    tables[f] / tables1[f] are the weights of its Linear(1, d) / Linear(1, 1) and ids[f] holds the feature's values"""
+    return _FieldGatherPairFn.apply(n_cand, len(tables), rows_opt, None if kinds is None else tuple(kinds), *ids, *tables, *tables1)
 
 
 class _BceProbFn(torch.autograd.Function):

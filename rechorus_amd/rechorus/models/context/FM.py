@@ -6,18 +6,19 @@ Mirror of the reference's models/context/FM.py (same class / arg / state_dict na
 Every categorical field ('*_c', '*_id') owns two tables: context_embedding[f] [feature_max[f], d]
 and linear_embedding[f] [feature_max[f], 1]; all F lookups of a table family (:49-55) are ONE
 rc_gather_fields launch writing the stacked [B, C, F, d] block, their gradients ONE atomic-free
-sort + segmented sum over the composite (field, id) key (per-field rc_gather_rows when a numeric
-field is present).  The pairwise-interaction term (:61)
+sort + segmented sum over the composite (field, id) key.  The pairwise-interaction term (:61)
     0.5 * sum_k ((sum_f v_fk)^2 - sum_f v_fk^2)
 is one kernel pair (rc_fm_second_order_fwd / _bwd) over the stacked field vectors.  Numeric
-fields keep the reference's Linear(1, d, bias=False).
+fields (:38-41: Linear(1, d, bias=False) on the feature's value, e.g. MIND's c_day_f) keep the
+reference's parameters and ride in the same gather launch (rc_gather_fields_mixed: the field's
+"row" is x * W[:, 0]); their weight gradients are one weighted column sum (rc_numeric_field_grads).
 """
 import torch
 import torch.nn as nn
 
 from models.BaseContextModel import ContextCTRModel, ContextModel
 from models.BaseModel import task_variant
-from rechorus_amd import nn as hnn
+from rechorus_amd import engine, nn as hnn
 
 
 def is_categorical(feature_name):
@@ -66,17 +67,19 @@ class FMBase(object):
             out.append(v if v.dim() == 3 else v.unsqueeze(-2).expand(-1, n_cand, -1))
         return out
 
+    def _field_kinds(self, feed_dict):
+        """per field engine.FIELD_IDS, or the value type of a numeric feature (what `.float()` of :47-48 starts from); None when
+        every field is categorical"""
+        if all(is_categorical(f) for f in self.context_features):
+            return None
+        return [engine.FIELD_IDS if is_categorical(f) else engine.field_kind(feed_dict[f]) for f in self.context_features]
+
     def _get_embeddings_FM(self, feed_dict):
         """-> field vectors [B, C, F, d], first-order term [B, C]"""
-        n_cand = feed_dict['item_id'].shape[1]
-        if all(is_categorical(f) for f in self.context_features) and self.overall_bias.is_cuda:
-            # every field in ONE gather launch per table family (rc_gather_fields); the backward is one
-            # composite-key sort + segmented sum for all F dense gradients
-            ids = [feed_dict[f] for f in self.context_features]
-            fm_vectors, linear_value = hnn.gather_fields_pair([self.context_embedding[f].weight for f in self.context_features],
-                                                              [self.linear_embedding[f].weight for f in self.context_features], ids, n_cand,
-                                                              rows_opt=self._rows_opt())
+        if self.overall_bias.is_cuda:
+            fm_vectors, linear_value = self._fused_fields(feed_dict)
             return fm_vectors, self.overall_bias + linear_value.squeeze(-1).sum(dim=-1)
+        n_cand = feed_dict['item_id'].shape[1]
         fm_vectors = torch.stack(self._lookup(self.context_embedding, feed_dict, n_cand), dim=-2)
         linear_value = torch.cat(self._lookup(self.linear_embedding, feed_dict, n_cand), dim=-1)
         return fm_vectors, self.overall_bias + linear_value.sum(dim=-1)
@@ -86,16 +89,17 @@ class FMBase(object):
         return {'prediction': linear_value + hnn.fm_second_order(fm_vectors)}
 
     def _fused_fields(self, feed_dict):
-        """(field vectors [B, C, F, d], first-order values [B, C, F, 1]) from the two one-launch gathers, or None where a field is
-        not categorical / the model is not on the GPU"""
-        if not (all(is_categorical(f) for f in self.context_features) and self.overall_bias.is_cuda):
+        """(field vectors [B, C, F, d], first-order values [B, C, F, 1]): every field of both families (:49-55) -- the [vocab, d] /
+        [vocab, 1] tables of the categorical fields and the Linear(1, d) / Linear(1, 1) of the numeric ones -- in ONE gather launch;
+        the backward is one grouping of the composite (field, id) keys for all dense table gradients plus one weighted column sum
+        for the numeric fields' weights.  None where the model is not on the GPU"""
+        if not self.overall_bias.is_cuda:
             return None
         n_cand = feed_dict['item_id'].shape[1]
         ids = [feed_dict[f] for f in self.context_features]
-        # both table families in ONE gather launch, and one grouping of their shared keys in the backward pass
         return hnn.gather_fields_pair([self.context_embedding[f].weight for f in self.context_features],
                                       [self.linear_embedding[f].weight for f in self.context_features], ids, n_cand,
-                                      rows_opt=self._rows_opt())
+                                      rows_opt=self._rows_opt(), kinds=self._field_kinds(feed_dict))
 
     def _rows_opt(self):
         """the optimizer, while this forward is part of a whole training step driven by graph.GraphedStep (forward, backward and

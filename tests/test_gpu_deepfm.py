@@ -99,13 +99,11 @@ def test_narrow_tables_with_hot_rows(d, cuda):
 
 # ---- model files ---------------------------------------------------------------------------------------
 
-VOCAB = {"u_age_c": 7, "u_gender_c": 3, "i_category_c": 11, "c_hour_c": 24, "c_weekday_c": 7}
-
-
 def _build(case, g, cuda, loss_n=None):
     import importlib
     cls_name = {"deepfm_ctr": "DeepFMCTR", "deepfm_fm_ctr": "FMCTR", "deepfm_wd_ctr": "WideDeepCTR",
-                "deepfm_topk": "DeepFMTopK", "deepfm_fm_topk": "FMTopK"}[re.match(r"(.*?)_d\d+", case).group(1)]
+                "deepfm_topk": "DeepFMTopK", "deepfm_fm_topk": "FMTopK", "deepfm_wd_topk": "WideDeepTopK"}[
+        re.match(r"(.*?)_d\d+", case).group(1).replace("_mind", "")]
     module = cls_name.replace("CTR", "").replace("TopK", "")
     cls = getattr(importlib.import_module("models.context." + module), cls_name)
     n_users, n_items, d, B, C = (int(x) for x in g["meta"][:5])
@@ -113,11 +111,15 @@ def _build(case, g, cuda, loss_n=None):
     ctr = cls_name.endswith("CTR")
     args = argparse.Namespace(device=cuda, model_path="", buffer=1, num_neg=C - 1, dropout=0, test_all=0, emb_size=d,
                               layers=str(layers), loss_n="BCE" if ctr else "BPR")
-    corpus = argparse.Namespace(n_users=n_users, n_items=n_items, user_feature_names=["u_age_c", "u_gender_c"],
-                                item_feature_names=["i_category_c"], situation_feature_names=["c_hour_c", "c_weekday_c"],
-                                feature_max=dict(VOCAB, user_id=n_users, item_id=n_items))
+    # the corpus the golden's model was built on, read back from the golden itself: feature groups by prefix (sorted inside their
+    # groups, helpers/ContextReader.py:43-50), vocabularies = the tables' row counts (numeric '*_f' features own no table)
+    fields = [str(f) for f in g["fields"]]
+    group = lambda pre: [f for f in fields if f.startswith(pre)]
+    fmax = {f: int(g["P0/context_embedding.%s.weight" % f].shape[0]) if DO.is_categorical(f) else 7 for f in fields}
+    corpus = argparse.Namespace(n_users=n_users, n_items=n_items, user_feature_names=group("u_"), item_feature_names=group("i_"),
+                                situation_feature_names=group("c_"), feature_max=fmax)
     model = cls(args, corpus)
-    assert model.context_features == [str(f) for f in g["fields"]]
+    assert model.context_features == fields
     sd = {k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("P0/")}
     assert set(sd) == set(model.state_dict()), "state_dict keys differ from the reference's"
     model.load_state_dict(sd)
@@ -185,7 +187,11 @@ def test_two_fit_iterations_match_reference(case, tag, opt, cuda):
         if opt == "Adam" and cancel_floor(name, g, batch(g, 1)) > 0:
             assert np.abs(p.cpu().numpy() - P0[name]).max() <= 2.5 * lr
             continue
-        assert_update_close(p.cpu().numpy(), P0[name], want[name], what=name, extra_atol=ex, outlier_atol=2 * lr)
+        # elements whose first-step gradient is summation-order noise (|g| < 1e-7 in the reference's own autograd: e.g. a hidden unit
+        # whose BPR gradients cancel over the row's candidates) are normalised by Adam to a step of size ~lr in either direction
+        ill = (np.abs(g["G/" + name]) < 1e-7) if opt == "Adam" else None
+        assert ill is None or ill.mean() <= 0.02, (name, float(ill.mean()))
+        assert_update_close(p.cpu().numpy(), P0[name], want[name], what=name, extra_atol=ex, outlier_atol=2 * lr, exclude=ill)
 
 
 # ---- CLI ------------------------------------------------------------------------------------------------
@@ -260,6 +266,95 @@ def test_gather_fields_equals_per_field_gathers(cuda):
             else:
                 np.add.at(G, xi.reshape(-1), wf.reshape(-1, d))
             assert_close(t.grad.cpu().numpy(), G, what=f"field {f} grad d={d}", abs_floor=1e-6 * float(np.abs(wf).sum()) / t.shape[0])
+
+
+def _numeric_values(rng, dtype, shape):
+    if dtype == torch.int64:
+        return torch.from_numpy(rng.integers(0, 7, size=shape).astype(np.int64))
+    return torch.from_numpy((rng.random(size=shape) * 6).astype(np.float64)).to(dtype)
+
+
+@pytest.mark.parametrize("d,B,C", [(64, 48, 1), (16, 33, 5), (6, 7, 3), (32, 1024, 1), (64, 3000, 1), (32, 700, 4), (128, 9000, 2)])
+def test_numeric_fields_ride_in_the_gather_and_get_linear_gradients(d, B, C, cuda, monkeypatch):
+    """rc_gather_fields_mixed / rc_numeric_field_grads: a field list with numeric features (nn.Linear(1, d) / nn.Linear(1, 1) on
+    the value, models/context/FM.py:38-41,47-48,51-52) in int64 / float32 / float64, per row and per candidate, against torch's
+    own Embedding / Linear ops in float64 -- one gather launch, one weighted column sum, every grouping route (small plan,
+    sort with the numeric tail, more than one chunk of 1,024 rows)"""
+    from rechorus_amd import _lib, engine, nn as hnn
+    rng = np.random.default_rng(d * 1000 + B)
+    #         kind                vocab  per_row
+    spec = [(engine.FIELD_IDS, 11, True), (engine.FIELD_I64, 0, True), (engine.FIELD_IDS, 300, False), (engine.FIELD_F64, 0, False),
+            (engine.FIELD_IDS, 5, True), (engine.FIELD_F32, 0, True), (engine.FIELD_IDS, 70, False)]
+    F = len(spec)
+    mk = lambda shape: torch.from_numpy(rng.normal(0, 0.5, size=shape).astype(np.float32)).to(cuda).requires_grad_(True)
+    vec = [mk((v, d)) if k == engine.FIELD_IDS else mk((d, 1)) for k, v, _ in spec]
+    lin = [mk((v, 1)) if k == engine.FIELD_IDS else mk((1, 1)) for k, v, _ in spec]
+    dt = {engine.FIELD_I64: torch.int64, engine.FIELD_F64: torch.float64, engine.FIELD_F32: torch.float32}
+    ids = [(torch.from_numpy(rng.integers(0, v, size=(B,) if pr else (B, C)).astype(np.int64)) if k == engine.FIELD_IDS
+            else _numeric_values(rng, dt[k], (B,) if pr else (B, C))).to(cuda) for k, v, pr in spec]
+    kinds = [k for k, _, _ in spec]
+    assert [engine.FIELD_IDS if k == engine.FIELD_IDS else engine.field_kind(x) for k, x in zip(kinds, ids)] == kinds
+    names = []
+    real = _lib.call
+    monkeypatch.setattr(_lib, "call", lambda fn, *a: names.append(fn) or real(fn, *a))
+    V, L = hnn.gather_fields_pair(vec, lin, ids, C, kinds=kinds)
+    wv, wl = torch.randn_like(V), torch.randn_like(L)
+    ((V * wv).sum() + (L * wl).sum()).backward()
+    monkeypatch.undo()
+    assert names.count("rc_gather_fields_mixed") == 1 and names.count("rc_numeric_field_grads") == 1
+    assert not any(n in names for n in ("rc_gather_fields", "rc_gather_fields_pair", "rc_gather_rows")), names
+    assert V.shape == (B, C, F, d) and L.shape == (B, C, F, 1)
+    # what the reference computes, field by field (FM.py:47-55), in float64 from the same fp32 inputs
+    bc = lambda t: t if t.dim() == 3 else t.unsqueeze(-2).expand(-1, C, -1)
+    v64 = [t.detach().double().requires_grad_(True) for t in vec]
+    l64 = [t.detach().double().requires_grad_(True) for t in lin]
+    look = lambda W, x, k: W[x] if k == engine.FIELD_IDS else torch.nn.functional.linear(x.float().double().unsqueeze(-1), W)
+    V64 = torch.stack([bc(look(W, x, k)) for W, x, k in zip(v64, ids, kinds)], dim=-2)
+    L64 = torch.stack([bc(look(W, x, k)) for W, x, k in zip(l64, ids, kinds)], dim=-2)
+    ((V64 * wv.double()).sum() + (L64 * wl.double()).sum()).backward()
+    assert_close(V.detach().cpu().numpy(), V64.detach().cpu().numpy(), what="field vectors", rtol=2e-7, atol_scale=0)
+    assert_close(L.detach().cpu().numpy(), L64.detach().cpu().numpy(), what="first-order values", rtol=2e-7, atol_scale=0)
+    for f, (k, _, _) in enumerate(spec):
+        n_terms = B * C / (vec[f].shape[0] if k == engine.FIELD_IDS else 1)
+        for fam, got, want, w in (("vec", vec[f].grad, v64[f].grad, wv), ("lin", lin[f].grad, l64[f].grad, wl)):
+            assert got.shape == want.shape
+            # a sum of n signed terms: the floor is the round-off of that sum (numeric fields: B * C terms of |x| <= 6)
+            floor = 3e-7 * (6.0 if k != engine.FIELD_IDS else 1.0) * float(w.abs().max()) * n_terms ** 0.5 * 4
+            assert_close(got.cpu().numpy(), want.cpu().numpy(), what=f"field {f} ({fam}) kind {k}", rtol=1e-5, atol_scale=1e-5, abs_floor=floor)
+    # only the first-order family reaches the loss (WideDeep's wide part alone): the other family's gradients are absent
+    for t in vec + lin:
+        t.grad = None
+    _, L3 = hnn.gather_fields_pair(vec, lin, ids, C, kinds=kinds)
+    (L3 * wl).sum().backward()
+    for f in range(F):
+        assert vec[f].grad is None or not bool(vec[f].grad.any())
+        assert_close(lin[f].grad.cpu().numpy(), l64[f].grad.cpu().numpy(), what=f"first-order only, field {f}", rtol=1e-5, atol_scale=1e-5,
+                     abs_floor=3e-7 * 6.0 * float(wl.abs().max()) * (B * C) ** 0.5 * 4)
+
+
+def test_numeric_field_model_path_uses_no_torch_stack_or_cat(cuda, monkeypatch):
+    """with a '*_f' feature among the fields the FM family stays on the one-launch gather, the fused FM term and the one-kernel
+    CTR head: no torch.stack / torch.cat / nn.Linear call on the training path (the round-5 route did all three)"""
+    from rechorus_amd import _lib
+    g = load_golden("deepfm_mind_ctr_d64")
+    model, B = _build("deepfm_mind_ctr_d64", g, cuda)
+    model.train()
+    names = []
+    real = _lib.call
+    monkeypatch.setattr(_lib, "call", lambda fn, *a: names.append(fn) or real(fn, *a))
+
+    def forbidden(*a, **k):
+        raise AssertionError("torch.stack / torch.cat / F.linear on the numeric-field path")
+    monkeypatch.setattr(torch, "stack", forbidden)
+    monkeypatch.setattr(torch, "cat", forbidden)
+    monkeypatch.setattr(torch.nn.functional, "linear", forbidden)
+    out = model(_feed(g, 1, B, cuda))
+    model.loss(out).backward()
+    monkeypatch.undo()
+    assert "loss" in out, "the one-kernel CTR head did not run"
+    assert names.count("rc_gather_fields_mixed") == 1 and names.count("rc_numeric_field_grads") == 1, names
+    assert any(n.startswith("rc_ctr_head_fwd_bwd") for n in names), names
+    assert_close(out["loss"].item(), g["loss"], what="loss", rtol=2e-5)
 
 
 def test_bce_ranking_kernel_matches_the_reference(cuda):
