@@ -174,8 +174,14 @@ def make_neumf_trainer(args, world, device, engine):
     return trainer
 
 
-DEEPFM_VOCAB = {"user_id": 269312, "item_id": 9373, "c_hour_c": 24, "c_weekday_c": 7, "c_period_c": 9,
-                "i_category_c": 18, "i_subcategory_c": 300, "u_group_c": 50}   # MIND-like cardinalities, SURVEY.md 8(d) row 5
+# MIND's own field set (data/MIND_Large/MIND-large.ipynb cells 10-17; CTR_MIND.sh:8 passes --include_item_features 1
+# --include_situation_features 1): item_meta's category / subcategory, the situation features hour / weekday / period and the
+# NUMERIC c_day_f (days since the first impression: an integer csv column, i.e. an int64 tensor that models/context/FM.py:47-48
+# turns into nn.Linear(1, d)(x.float())), user_id, item_id -- in the order ContextCTRModel lists them (BaseContextModel.py:82-83).
+# Cardinalities: SURVEY.md 8(d) row 5 (the notebook prints users / items / hour / weekday / period / 7 days; category and
+# subcategory counts are not printed: 18 / 300).  Values = vocabulary size, or the exclusive upper bound of a numeric feature.
+DEEPFM_VOCAB = {"i_category_c": 18, "i_subcategory_c": 300, "c_day_f": 7, "c_hour_c": 24, "c_period_c": 9, "c_weekday_c": 7,
+                "user_id": 269312, "item_id": 9373}
 
 
 class DeepfmBench:
@@ -193,11 +199,12 @@ class DeepfmBench:
         margs = ap.Namespace(device=device, model_path="", buffer=0, num_neg=0, dropout=float(getattr(args, "dropout", 0.0) or 0.0), test_all=0,
                              emb_size=args.emb_size,
                              layers=args.mlp, loss_n="BCE")
-        corpus = ap.Namespace(n_users=self.vocab["user_id"], n_items=self.vocab["item_id"], user_feature_names=["u_group_c"],
+        corpus = ap.Namespace(n_users=self.vocab["user_id"], n_items=self.vocab["item_id"], user_feature_names=[],
                               item_feature_names=["i_category_c", "i_subcategory_c"],
-                              situation_feature_names=["c_hour_c", "c_period_c", "c_weekday_c"], feature_max=self.vocab)
+                              situation_feature_names=["c_day_f", "c_hour_c", "c_period_c", "c_weekday_c"], feature_max=self.vocab)
         torch.manual_seed(1234)   # replicated parameters: the same initial values on every rank
         self.model = DeepFMCTR(margs, corpus).to(device)
+        assert self.model.context_features == list(DEEPFM_VOCAB)
         ra = BaseRunner.parse_runner_args(ap.ArgumentParser()).parse_args([])
         ra.train, ra.log_file, ra.lr, ra.l2, ra.optimizer = 1, "/tmp/rc_bench/l.txt", args.lr, args.l2, args.opt
         self.model.optimizer = BaseRunner(ra)._build_optimizer(self.model)
@@ -799,7 +806,8 @@ def measure(args, rank, world, device, dist):
 
     if args.workload == "deepfm":
         args.items, args.users, args.num_neg = DEEPFM_VOCAB["item_id"], DEEPFM_VOCAB["user_id"], 0
-        workload_text = (f"DeepFMCTR fit step: F={len(DEEPFM_VOCAB)} single-valued fields (MIND-like cardinalities, {DEEPFM_VOCAB['user_id']} users / "
+        workload_text = (f"DeepFMCTR fit step: MIND's F={len(DEEPFM_VOCAB)} single-valued fields {'/'.join(DEEPFM_VOCAB)} (c_day_f numeric: "
+                         f"int64 days -> nn.Linear(1, d); MIND-like cardinalities, {DEEPFM_VOCAB['user_id']} users / "
                          f"{DEEPFM_VOCAB['item_id']} items), emb_size={args.emb_size}, MLP {args.mlp}, dropout={args.dropout:g}, BCE, B={args.batch} rows/GPU/step, "
                          f"optimizer={args.opt} (dense = torch.optim semantics, l2={args.l2:g}), hipGraph replay of the step, int64 ids, fp32")
     elif args.workload == "sasrec":

@@ -232,15 +232,19 @@ class _MlpBlock(nn.Module):
 
 
 class DeepfmCtrTorchPort(nn.Module):
-    """DeepFMCTR over categorical fields with the reference's module names and operator sequence:
-    models/context/FM.py:34-57 (per-field nn.Embedding(vocab, d) + nn.Embedding(vocab, 1), overall_bias, stacking),
-    DeepFM.py:19-28 (FM second order + linear + deep), :37-41 (sigmoid), models/BaseModel.py:259-267 (nn.BCELoss)."""
+    """DeepFMCTR with the reference's module names and operator sequence:
+    models/context/FM.py:34-57 (per field nn.Embedding(vocab, d) + nn.Embedding(vocab, 1) -- or, for a feature named neither '*_c'
+    nor '*_id', nn.Linear(1, d, bias=False) + nn.Linear(1, 1, bias=False) on feed[f].float().unsqueeze(-1) --, overall_bias,
+    stacking), DeepFM.py:19-28 (FM second order + linear + deep), :37-41 (sigmoid), models/BaseModel.py:259-267 (nn.BCELoss)."""
 
     def __init__(self, fields, feature_max, emb_size, layers=(512, 64), dropout=0.0):
         super().__init__()
         self.fields = list(fields)
-        self.context_embedding = nn.ModuleDict({f: nn.Embedding(feature_max[f], emb_size) for f in self.fields})
-        self.linear_embedding = nn.ModuleDict({f: nn.Embedding(feature_max[f], 1) for f in self.fields})
+        cat = self.categorical
+        self.context_embedding = nn.ModuleDict({f: nn.Embedding(feature_max[f], emb_size) if cat(f) else nn.Linear(1, emb_size, bias=False)
+                                                for f in self.fields})
+        self.linear_embedding = nn.ModuleDict({f: nn.Embedding(feature_max[f], 1) if cat(f) else nn.Linear(1, 1, bias=False)
+                                               for f in self.fields})
         self.overall_bias = nn.Parameter(torch.tensor([0.01]))
         self.deep_layers = _MlpBlock(len(self.fields) * emb_size, list(layers), dropout)
         for m in self.modules():
@@ -249,11 +253,16 @@ class DeepfmCtrTorchPort(nn.Module):
                 if getattr(m, "bias", None) is not None:
                     nn.init.normal_(m.bias, mean=0.0, std=0.01)
 
+    @staticmethod
+    def categorical(f):
+        return f.endswith("_c") or f.endswith("_id")
+
     def forward(self, feed):
         item_num = feed["item_id"].shape[1]
-        vec = [self.context_embedding[f](feed[f]) for f in self.fields]
+        cat = self.categorical
+        vec = [self.context_embedding[f](feed[f]) if cat(f) else self.context_embedding[f](feed[f].float().unsqueeze(-1)) for f in self.fields]
         vec = torch.stack([v if v.dim() == 3 else v.unsqueeze(-2).repeat(1, item_num, 1) for v in vec], dim=-2)
-        lin = [self.linear_embedding[f](feed[f]) for f in self.fields]
+        lin = [self.linear_embedding[f](feed[f]) if cat(f) else self.linear_embedding[f](feed[f].float().unsqueeze(-1)) for f in self.fields]
         lin = torch.cat([v if v.dim() == 3 else v.unsqueeze(-2).repeat(1, item_num, 1) for v in lin], dim=-1)
         lin = self.overall_bias + lin.sum(dim=-1)
         fm = 0.5 * (vec.sum(dim=-2).pow(2) - vec.pow(2).sum(dim=-2))

@@ -38,9 +38,11 @@ def make_dataset(root, name="synth", n_users=60, n_items=200, per_user=12, n_neg
     return d
 
 
-def make_context_dataset(root, name="synth_ctx", n_users=80, n_items=120, per_user=16, ctr=True, n_neg=20, seed=0):
+def make_context_dataset(root, name="synth_ctx", n_users=80, n_items=120, per_user=16, ctr=True, n_neg=20, seed=0, numeric=False):
     """Context-aware data in the reference's layout (data/README.md, MIND_Large/MINDCTR):
     interactions carry situation columns c_*_c; item_meta.csv / user_meta.csv carry i_*_c / u_*_c.
+    numeric=True adds the features FM.py:38-41 treats as numbers: c_day_f (whole days, an int64 column like MIND's,
+    data/MIND_Large/MIND-large.ipynb cell 10) among the situation columns and i_age_f (a float64 column) in item_meta.csv.
     ctr=True: every row has a binary `label` (clicks depend on user-group x item-category affinity);
     ctr=False: top-k format (positives only, neg_items lists in dev/test)."""
     rng = np.random.default_rng(seed)
@@ -70,6 +72,8 @@ def make_context_dataset(root, name="synth_ctx", n_users=80, n_items=120, per_us
     os.makedirs(d, exist_ok=True)
     for phase, r in rows.items():
         df = pd.DataFrame(r, columns=["user_id", "item_id", "time", "label", "c_hour_c", "c_weekday_c"])
+        if numeric:
+            df["c_day_f"] = (df["time"] - 1_000_000) // 86400
         if not ctr:
             df = df.drop(columns=["label"])
             if phase != "train":
@@ -79,8 +83,10 @@ def make_context_dataset(root, name="synth_ctx", n_users=80, n_items=120, per_us
                     negs.append(rng.choice(cand, size=min(n_neg, len(cand)), replace=False).tolist())
                 df["neg_items"] = negs
         df.to_csv(os.path.join(d, phase + ".csv"), sep="\t", index=False)
-    pd.DataFrame({"item_id": np.arange(1, n_items + 1), "i_category_c": item_cat[1:]}).to_csv(
-        os.path.join(d, "item_meta.csv"), sep="\t", index=False)
+    item_meta = {"item_id": np.arange(1, n_items + 1), "i_category_c": item_cat[1:]}
+    if numeric:
+        item_meta["i_age_f"] = np.round(np.random.default_rng(seed + 1).random(n_items) * 3.0, 3)
+    pd.DataFrame(item_meta).to_csv(os.path.join(d, "item_meta.csv"), sep="\t", index=False)
     pd.DataFrame({"user_id": np.arange(1, n_users + 1), "u_age_c": user_age[1:], "u_gender_c": user_gender[1:]}).to_csv(
         os.path.join(d, "user_meta.csv"), sep="\t", index=False)
     return d

@@ -212,9 +212,18 @@ def test_deepfm_step_at_the_large_bench_batch_whole_batch_vs_oracle(cuda):
     assert_close(out["prediction"].detach().cpu().numpy().reshape(-1), p, what="probabilities", rtol=1e-5, atol_scale=1e-5)
     assert_close(float(loss.item()), float(want_loss), rtol=1e-5, what="BCE loss")
     scale = max(float(np.abs(v).max()) for k, v in G.items() if k.startswith("deep_layers"))
+    # ReLU flips: of the 67 M hidden pre-activations of this batch a dozen lie within fp32 round-off of 0, and a unit that is on in
+    # one summation order and off in the other adds or drops ONE row's dz in that unit's bias / weight gradient -- at most
+    # |d loss / d logit| <= 1 / B times the absolute weights between the unit and the output.  Two flips per unit are allowed.
+    lin_ids = sorted(int(n.split(".")[2]) for n in Pn if n.startswith("deep_layers.mlp.") and n.endswith(".weight"))
+    reach, flip = np.abs(Pn["deep_layers.mlp.%d.weight" % lin_ids[-1]]), {}
+    for idx in reversed(lin_ids[:-1]):
+        flip[idx] = 2.0 * float(reach.max()) / B
+        reach = reach @ np.abs(Pn["deep_layers.mlp.%d.weight" % idx])
     for name, prm in m.named_parameters():
         # dense layers at 5e-5; table rows at 1e-4 of the table's largest gradient: an element of a rarely seen row is ONE 512-long fp32
         # dot product (dh = dz W) plus the FM term, which nearly cancel in places -- summation-order noise of a different K order
         table = name.startswith("context_embedding") or name.startswith("linear_embedding")
         assert_close(prm.grad.cpu().numpy().reshape(G[name].shape), G[name], what="grad " + name, rtol=2e-5, atol_scale=1e-4 if table else 5e-5,
-                     abs_floor=1e-6 * scale if name.startswith("deep_layers") else 0.0)
+                     abs_floor=(1e-6 * scale + (flip.get(int(name.split(".")[2]), 0.0) if name.endswith(".bias") else 0.0))
+                     if name.startswith("deep_layers") else 0.0)

@@ -212,10 +212,13 @@ def ctx_root(tmp_path_factory):
     root = str(tmp_path_factory.mktemp("pipe_ctx"))
     make_context_dataset(root, "ctr", n_users=90, n_items=70, per_user=12, ctr=True, seed=3)
     make_context_dataset(root, "topk", n_users=90, n_items=70, per_user=10, ctr=False, seed=4)
+    make_context_dataset(root, "ctrf", n_users=90, n_items=70, per_user=12, ctr=True, seed=5, numeric=True)
+    make_context_dataset(root, "topkf", n_users=90, n_items=70, per_user=10, ctr=False, seed=6, numeric=True)
     return root
 
 
-@pytest.mark.parametrize("mode,dataset", [("CTR", "ctr"), ("TopK", "topk")])
+# (ctrf / topkf: with the numeric features c_day_f -- int64 -- and i_age_f -- float64 --, models/context/FM.py:38-41)
+@pytest.mark.parametrize("mode,dataset", [("CTR", "ctr"), ("TopK", "topk"), ("CTR", "ctrf"), ("TopK", "topkf")])
 def test_context_device_batches_equal_the_collated_ones(mode, dataset, ctx_root, cuda):
     """context features (user / item / situation columns) gathered on the device == the reference-style
     Dataset -> collate_batch path, for the CTR and the top-k feed dicts"""
@@ -244,8 +247,11 @@ def test_context_device_batches_equal_the_collated_ones(mode, dataset, ctx_root,
         feed = dd.feed(torch.arange(len(ds), device=cuda))
         want = ds.collate_batch([ds[i] for i in range(len(ds))])
         assert set(feed) == set(want), (sorted(feed), sorted(want))
+        if dataset.endswith("f"):
+            assert want["c_day_f"].dtype == torch.int64 and want["i_age_f"].dtype == torch.float64
         for k, v in want.items():
             if isinstance(v, torch.Tensor):
+                assert feed[k].dtype == v.dtype, (k, feed[k].dtype, v.dtype)
                 assert torch.equal(feed[k].cpu(), v), k
             else:
                 assert feed[k] == v, k

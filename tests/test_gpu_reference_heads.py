@@ -137,6 +137,8 @@ def ctx_root(tmp_path_factory):
     root = str(tmp_path_factory.mktemp("ctx"))
     make_context_dataset(root, "ctr", n_users=90, n_items=70, per_user=12, ctr=True, seed=3)
     make_context_dataset(root, "topk", n_users=90, n_items=70, per_user=10, ctr=False, seed=4)
+    make_context_dataset(root, "ctrf", n_users=90, n_items=70, per_user=12, ctr=True, seed=5, numeric=True)     # + c_day_f (int64), i_age_f (float64)
+    make_context_dataset(root, "topkf", n_users=90, n_items=70, per_user=10, ctr=False, seed=6, numeric=True)
     return root
 
 
@@ -146,6 +148,10 @@ CTX_CASES = [
     ("DeepFM", "TopK", ["--emb_size", "16", "--layers", "[32]", "--dropout", "0"], {"rc_gather_fields_pair", "rc_fm_second_order_bwd_add"}, None),
     ("FM", "CTR", ["--emb_size", "16"], {"rc_gather_fields_pair", "rc_fm_second_order_fwd"}, r"rc_ctr_head_fwd_bwd(_sums)?"),
     ("WideDeep", "CTR", ["--emb_size", "16", "--layers", "[32]", "--dropout", "0.1"], {"rc_gather_fields_pair"}, r"rc_ctr_head_fwd_bwd(_sums)?"),
+    # the same heads over a field list with numeric features (models/context/FM.py:38-41: Linear(1, d) on c_day_f / i_age_f)
+    ("DeepFM", "CTR:f", ["--emb_size", "16", "--layers", "[32,16]", "--dropout", "0.2"],
+     {"rc_gather_fields_mixed", "rc_numeric_field_grads", "rc_fm_second_order_bwd_add"}, r"rc_ctr_head_fwd_bwd(_sums)?"),
+    ("FM", "TopK:f", ["--emb_size", "16"], {"rc_gather_fields_mixed", "rc_numeric_field_grads", "rc_fm_second_order_fwd"}, None),
 ]
 
 
@@ -165,9 +171,10 @@ def _run_ctx(name, mode, model_args, ctx_root, out, monkeypatch, model_dir):
         return real_call(fn_name, *a)
     monkeypatch.setattr(_lib, "call", call)
     log = str(out / "log" / "run.txt")
+    mode, _, numeric = mode.partition(":")
     ctr = mode == "CTR"
     res = main.run(["--model_name", name, "--model_mode", mode] + model_args +
-                   ["--dataset", "ctr" if ctr else "topk", "--path", ctx_root + "/", "--epoch", "3", "--num_neg", "3", "--batch_size", "64",
+                   ["--dataset", ("ctr" if ctr else "topk") + numeric, "--path", ctx_root + "/", "--epoch", "3", "--num_neg", "3", "--batch_size", "64",
                     "--num_workers", "0", "--regenerate", "1", "--random_seed", "11", "--log_file", log, "--lr", "2e-3", "--l2", "1e-6",
                     "--loss_n", "BCE" if ctr else "BPR", "--metric", "AUC,ACC" if ctr else "NDCG,HR", "--include_item_features", "1",
                     "--include_user_features", "1", "--include_situation_features", "1",
@@ -184,7 +191,7 @@ def test_unmodified_reference_context_model_file_reaches_the_fused_head(name, mo
     class of the same name leaves from the same seed, bit for bit, under the reference's state_dict keys"""
     (tmp_path / "ref").mkdir(), (tmp_path / "mirror").mkdir()
     res_a, text_a, sd_a, names_a = _run_ctx(name, mode, model_args, ctx_root, tmp_path / "ref", monkeypatch, os.path.join(FIX, "context"))
-    assert "Recognised the %s%s head" % (name, mode) in text_a, text_a[-1500:]
+    assert "Recognised the %s%s head" % (name, mode.partition(":")[0]) in text_a, text_a[-1500:]
     assert entries <= names_a, sorted(names_a)
     if head_entry:
         assert any(re.fullmatch(head_entry, n) for n in names_a), sorted(names_a)

@@ -63,13 +63,13 @@ def test_sasrec_port_matches_the_reference(path):
     _check_grads(m, g, os.path.basename(path))
 
 
-@pytest.mark.parametrize("name", ["deepfm_ctr_d64", "deepfm_ctr_d16"])
+@pytest.mark.parametrize("name", ["deepfm_ctr_d64", "deepfm_ctr_d16", "deepfm_mind_ctr_d64"])   # (mind: with the numeric c_day_f)
 def test_deepfm_ctr_port_matches_the_reference(name):
     from oracle.torch_port import DeepfmCtrTorchPort
     g = np.load(os.path.join(GOLD, name + ".npz"), allow_pickle=True)
     fields = [str(f) for f in g["fields"]]
     fmax = {f: g[f"P0/context_embedding.{f}.weight"].shape[0] for f in fields}
-    d = g[f"P0/context_embedding.{fields[0]}.weight"].shape[1]
+    d = g["P0/context_embedding.item_id.weight"].shape[1]
     hidden = [g[k].shape[0] for k in sorted((k for k in g.files if k.startswith("P0/deep_layers.mlp.") and k.endswith(".weight")),
                                             key=lambda k: int(k.split(".")[2]))][:-1]
     m = DeepfmCtrTorchPort(fields, fmax, d, layers=hidden)
