@@ -182,6 +182,8 @@ def make_neumf_trainer(args, world, device, engine):
 # subcategory counts are not printed: 18 / 300).  Values = vocabulary size, or the exclusive upper bound of a numeric feature.
 DEEPFM_VOCAB = {"i_category_c": 18, "i_subcategory_c": 300, "c_day_f": 7, "c_hour_c": 24, "c_period_c": 9, "c_weekday_c": 7,
                 "user_id": 269312, "item_id": 9373}
+if os.environ.get("RC_BENCH_DEEPFM_DAY") == "categorical":   # A/B only: the day as an eighth categorical field (c_day_c) -- NOT MIND's set
+    DEEPFM_VOCAB = {("c_day_c" if k == "c_day_f" else k): v for k, v in DEEPFM_VOCAB.items()}
 
 
 class DeepfmBench:
@@ -201,7 +203,7 @@ class DeepfmBench:
                              layers=args.mlp, loss_n="BCE")
         corpus = ap.Namespace(n_users=self.vocab["user_id"], n_items=self.vocab["item_id"], user_feature_names=[],
                               item_feature_names=["i_category_c", "i_subcategory_c"],
-                              situation_feature_names=["c_day_f", "c_hour_c", "c_period_c", "c_weekday_c"], feature_max=self.vocab)
+                              situation_feature_names=[k for k in self.vocab if k.startswith("c_")], feature_max=self.vocab)
         torch.manual_seed(1234)   # replicated parameters: the same initial values on every rank
         self.model = DeepFMCTR(margs, corpus).to(device)
         assert self.model.context_features == list(DEEPFM_VOCAB)

@@ -537,23 +537,26 @@ struct NumericGradArgs {
   int n_numeric, F, C, d;
 };
 
+constexpr int kNumericThreads = 1024;   // sixteen waves: 64 rows of a 64-float field vector per step, a 1,024-row chunk in two trips of eight
+
 template <int VEC>
-__global__ __launch_bounds__(kBlock) void numeric_field_grads_kernel(NumericGradArgs a) {
-  __shared__ float red[kBlock * VEC];
-  __shared__ float red1[kBlock];
+__global__ __launch_bounds__(kNumericThreads) void numeric_field_grads_kernel(NumericGradArgs a) {
+  __shared__ float red[kNumericThreads * VEC];
+  __shared__ float red1[kNumericThreads];
   const int j = blockIdx.y, f = a.field[j];
   const int dq = a.d / VEC;
-  const int lpr = dq < kBlock ? dq : kBlock;   // lanes per row
-  const int slots = kBlock / lpr;              // rows in flight per step
+  const int lpr = dq < kNumericThreads ? dq : kNumericThreads;   // lanes per row
+  const int slots = kNumericThreads / lpr;                       // rows in flight per step
   const int tid = threadIdx.x, l = tid % lpr, rs = tid / lpr;
   const bool live = rs < slots;
-  const int64_t r0 = (int64_t)blockIdx.x * kNumericChunk;
-  const int64_t r1 = r0 + kNumericChunk < a.n ? r0 + kNumericChunk : a.n;
-  const int kind = a.kind[j], per_row = a.per_row[j];
+  const uint32_t r0 = blockIdx.x * (uint32_t)kNumericChunk;     // (n < 2^31: 32-bit row arithmetic, no 64-bit division per row)
+  const uint32_t r1 = (int64_t)r0 + kNumericChunk < a.n ? r0 + kNumericChunk : (uint32_t)a.n;
+  const int kind = a.kind[j];
+  const uint32_t cdiv = a.per_row[j] ? (uint32_t)a.C : 1u;      // a per-row feature's value sits at row / C
   const void* xs = a.values[j];
   const bool direct = gridDim.x == 1;
   float* part = a.part + ((size_t)blockIdx.x * a.n_numeric + j) * (a.d + 1);
-  for (int c0 = 0; c0 < dq; c0 += lpr) {       // (one trip unless d > 256 * VEC; workgroup-uniform)
+  for (int c0 = 0; c0 < dq; c0 += lpr) {       // (one trip unless d > 1024 * VEC; workgroup-uniform)
     const int cq = c0 + l < dq ? c0 + l : dq - 1;
     const bool col = c0 + l < dq;
     float acc[VEC];
@@ -563,15 +566,16 @@ __global__ __launch_bounds__(kBlock) void numeric_field_grads_kernel(NumericGrad
     const bool first = c0 == 0 && l == 0 && a.gL != nullptr;   // this lane also forms the first-order weight's sum
     if (live && a.gV) {
       constexpr int U = 8;
-      for (int64_t r = r0 + rs; r < r1; r += (int64_t)slots * U) {
+      for (uint32_t r = r0 + rs; r < r1; r += (uint32_t)slots * U) {
         float x[U], g1[U];
         float gv[U][VEC];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-          const int64_t rr = r + (int64_t)u * slots;
+          const uint32_t rr = r + (uint32_t)u * slots;
           const bool in = rr < r1;
-          x[u] = in ? field_value(kind, xs, per_row ? rr / a.C : rr) : 0.f;
-          const float* src = a.gV + ((size_t)(in ? rr : r0) * a.F + f) * a.d + (size_t)cq * VEC;
+          const uint32_t ra = in ? rr : r0;
+          x[u] = in ? field_value(kind, xs, cdiv == 1u ? ra : ra / cdiv) : 0.f;
+          const float* src = a.gV + ((size_t)ra * a.F + f) * a.d + (size_t)cq * VEC;
           if (VEC == 4) {
             const float4 t = *reinterpret_cast<const float4*>(src);
             gv[u][0] = t.x; gv[u][1 % VEC] = t.y; gv[u][2 % VEC] = t.z; gv[u][3 % VEC] = t.w;
@@ -588,7 +592,7 @@ __global__ __launch_bounds__(kBlock) void numeric_field_grads_kernel(NumericGrad
         }
       }
     } else if (live && first) {   // (only the first-order family reached the loss)
-      for (int64_t r = r0 + rs; r < r1; r += slots) acc1 += field_value(kind, xs, per_row ? r / a.C : r) * a.gL[(size_t)r * a.F + f];
+      for (uint32_t r = r0 + rs; r < r1; r += slots) acc1 += field_value(kind, xs, cdiv == 1u ? r : r / cdiv) * a.gL[(size_t)r * a.F + f];
     }
     __syncthreads();   // (the previous trip's reads of red[])
 #pragma unroll
@@ -668,7 +672,7 @@ extern "C" int rc_numeric_field_grads(const float* gV, const float* gL, const vo
     return RC_OK;
   }
   const int64_t chunks = (a.n + kNumericChunk - 1) / kNumericChunk;
-  RC_REQUIRE(chunks <= kMaxGridX, "rc_numeric_field_grads: too many rows");
+  RC_REQUIRE(a.n < ((int64_t)1 << 31), "rc_numeric_field_grads: too many rows");
   if (chunks > 1) {
     RC_REQUIRE(ws != nullptr && ws_bytes >= rc_numeric_field_grads_workspace_bytes(a.n, n_numeric, d), "rc_numeric_field_grads: workspace %zu < %zu",
                ws_bytes, rc_numeric_field_grads_workspace_bytes(a.n, n_numeric, d));
@@ -676,9 +680,9 @@ extern "C" int rc_numeric_field_grads(const float* gV, const float* gL, const vo
   }
   const bool vec = d % 4 == 0 && (gV == nullptr || reinterpret_cast<uintptr_t>(gV) % 16 == 0);
   if (vec)
-    hipLaunchKernelGGL((numeric_field_grads_kernel<4>), dim3((unsigned)chunks, (unsigned)n_numeric), dim3(kBlock), 0, s, a);
+    hipLaunchKernelGGL((numeric_field_grads_kernel<4>), dim3((unsigned)chunks, (unsigned)n_numeric), dim3(kNumericThreads), 0, s, a);
   else
-    hipLaunchKernelGGL((numeric_field_grads_kernel<1>), dim3((unsigned)chunks, (unsigned)n_numeric), dim3(kBlock), 0, s, a);
+    hipLaunchKernelGGL((numeric_field_grads_kernel<1>), dim3((unsigned)chunks, (unsigned)n_numeric), dim3(kNumericThreads), 0, s, a);
   RC_LAUNCH_CHECK();
   if (chunks > 1) {
     const int total = n_numeric * (d + 1);
