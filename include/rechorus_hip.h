@@ -702,6 +702,17 @@ int rc_gather_history(const int64_t* idx, int64_t B, int L, const int64_t* users
  * (ground truth in column 0, ties count against it).  HR@k / NDCG@k are means over rank.             */
 int rc_target_rank(const float* pred, int64_t n, int C, int32_t* rank, rc_stream_t stream);
 
+/* ImpressionRunner.evaluate / evaluate_method with HR_at_k / NDCG_at_k / AP_at_k (helpers/ImpressionRunner.py:18-66,74-133,135-168)
+ * on the device: pred [N, n] scores of impression lists -- positives in columns [0, pos_num[i]) (pos_num NULL: one per row,
+ * :85-86), negatives in [max_pos, max_pos + neg_num[i]), counts clipped to max_pos / n - max_pos (:99-102), every other column
+ * ignored (the reference masks it to -inf, :156-168).  A positive that ties with a negative ranks below it (the 1e-6 shift of
+ * :89-96), ties inside a group keep column order (the stable merge sort of :98).  per_row [N, 3, n_k] float64 = NDCG@k, MAP@k,
+ * HR@k of every row for k = topk[0 .. n_k) (HOST array, n_k <= 16) -- what evaluate_method returns with ret_all = 1; mean
+ * [3, n_k] (optional) = their means over the rows (ret_all = 0).  n <= 2,048 (rc_list_metrics_supported).                        */
+int rc_list_metrics_supported(int n, int max_pos, int n_k);
+int rc_list_metrics(const float* pred, const int64_t* pos_num, const int64_t* neg_num, int64_t N, int n, int max_pos,
+                    const int* topk, int n_k, double* per_row, double* mean, rc_stream_t stream);
+
 /* --test_all (models/BaseModel.py:194-195, helpers/BaseRunner.py:243-250) for dot-product heads
  * (BPRMF: Uvec = gathered user rows; SASRec: the encoder outputs) without materialising [N, n_items]:
  * rank[i] = 1 + #{j in [1,n_items), j != targets[i], j not in clicked(users[i]) : <Uvec[i], I[j]> >= <Uvec[i], I[targets[i]]>}

@@ -84,6 +84,8 @@ SIGNATURES = {
     "rc_gather_fields": (_i, [_p, _p, _p, _p, _i, _i64, _i, _i, _p, _p, _p]),
     "rc_gather_fields_pair": (_i, [_p, _p, _p, _p, _p, _i, _i64, _i, _i, _p, _p, _p, _p]),
     "rc_gather_fields_pair_mark": (_i, [_p, _p, _p, _p, _p, _i, _i64, _i, _i, _p, _p, _p, _p, _p, _i, _p]),
+    "rc_list_metrics_supported": (_i, [_i, _i, _i]),
+    "rc_list_metrics": (_i, [_p, _p, _p, _i64, _i, _i, _p, _i, _p, _p, _p]),
     "rc_gather_fields_mixed": (_i, [_p, _p, _p, _p, _p, _i64, _p, _i, _i64, _i, _i, _p, _p, _p, _p, _p, _i, _p]),
     "rc_numeric_field_grads_workspace_bytes": (_sz, [_i64, _i, _i]),
     "rc_numeric_field_grads": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i64, _i, _i, _p, _p, _p, _sz, _p]),

@@ -13,6 +13,8 @@
 // on the fly; clicked items are subtracted afterwards from the user's (sorted) clicked list.
 #include "common.hpp"
 
+#include <mutex>
+
 namespace rc {
 
 __global__ __launch_bounds__(kBlock) void target_rank_kernel(const float* __restrict__ pred, int64_t n, int C,
@@ -162,6 +164,124 @@ __global__ __launch_bounds__(kBlock) void full_rank_finish_kernel(
 
 }  // namespace rc
 
+// ---- impression lists: HR / NDCG / MAP @k with a variable number of positives and negatives per row ----------------------
+// Reference: ImpressionRunner.evaluate + evaluate_method + HR_at_k / NDCG_at_k / AP_at_k (helpers/ImpressionRunner.py:18-66,
+// 74-133,135-168).  A row holds its positives in columns [0, pos_num) and its negatives in [max_pos, max_pos + neg_num); the
+// reference masks everything else to -inf, subtracts 1e-6 from the positive columns (so a positive that ties with a negative
+// ranks below it, :89-96), argsorts -score with a stable merge sort, truncates the ranked 0/1 labels to pos + neg entries and
+// forms the metrics in float64.  Only the positions of the POSITIVES in that order matter:
+//   r_i   = #{valid j : key_j > key_i} + #{valid j < i : key_j == key_i}          (key = (double) score - 1e-6 [column < max_pos])
+//   HR@k  = [min_i r_i < k];   DCG@k = sum_{r_i < k} 1 / log2(r_i + 2);   IDCG@k = sum_{t < min(p, k)} 1 / log2(t + 2)
+//   AP@k  = sum_{r_i < k} #{i' : r_i' <= r_i} / (r_i + 1)  /  clip(p, 1, k)           (p = number of valid positives)
+// One wave per row: keys of the row in LDS, a positive's rank by a strided count + wave sum, the per-k sums in float64.
+namespace rc {
+
+constexpr int kListMetricsMaxK = 16;
+constexpr int kListMetricsMaxN = 2048;   // columns per row the LDS staging holds (4 waves x 2048 doubles + ranks = 80 KB)
+
+struct ListMetricArgs {
+  const float* pred;        // [N, n]
+  const int64_t* pos_num;   // [N] | null (one positive per row)
+  const int64_t* neg_num;   // [N]
+  int64_t N;
+  int n, max_pos, n_k;
+  int topk[kListMetricsMaxK];
+  double* out;              // [N, 3, n_k]: NDCG, MAP, HR
+};
+
+__device__ __forceinline__ double wave_sum_f64(double x) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off, 64);
+  return x;
+}
+__device__ __forceinline__ int wave_sum_i32(int x) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off, 64);
+  return x;
+}
+
+__global__ __launch_bounds__(kBlock) void list_metrics_kernel(ListMetricArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char list_metrics_smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double* key = reinterpret_cast<double*>(list_metrics_smem) + (size_t)wave * a.n;
+  int* rnk = reinterpret_cast<int*>(reinterpret_cast<double*>(list_metrics_smem) + (size_t)(kBlock / 64) * a.n) + (size_t)wave * 2 * a.max_pos;
+  int* cnt = rnk + a.max_pos;
+  const int64_t row = (int64_t)blockIdx.x * (kBlock / 64) + wave;
+  if (row >= a.N) return;   // wave-uniform; no workgroup barrier below
+  const int64_t pn = a.pos_num ? a.pos_num[row] : 1;
+  const int64_t nn = a.neg_num[row];
+  const int p = (int)(pn < 0 ? 0 : (pn > a.max_pos ? a.max_pos : pn));                      // (:99-102)
+  const int q = (int)(nn < 0 ? 0 : (nn > a.n - a.max_pos ? a.n - a.max_pos : nn));
+  const float* x = a.pred + row * a.n;
+  for (int c = lane; c < a.n; c += 64) {
+    const bool valid = c < p || (c >= a.max_pos && c < a.max_pos + q);
+    key[c] = valid ? (double)x[c] - (c < a.max_pos ? 1e-6 : 0.0) : -__builtin_inf();
+  }
+  __builtin_amdgcn_wave_barrier();   // (ds operations of one wave complete in order)
+  // ranks of the positives among the valid entries
+  for (int i = 0; i < p; ++i) {
+    const double ki = key[i];
+    int c = 0;
+    for (int j = lane; j < a.n; j += 64) {
+      const bool valid = j < p || (j >= a.max_pos && j < a.max_pos + q);
+      const double kj = key[j];
+      c += (valid && (kj > ki || (kj == ki && j < i))) ? 1 : 0;
+    }
+    c = wave_sum_i32(c);
+    if (lane == 0) rnk[i] = c;
+  }
+  __builtin_amdgcn_wave_barrier();
+  for (int i = lane; i < p; i += 64) {     // positives ranked at or before positive i (itself included)
+    int c = 0;
+    const int ri = rnk[i];
+    for (int t = 0; t < p; ++t) c += rnk[t] <= ri ? 1 : 0;
+    cnt[i] = c;
+  }
+  __builtin_amdgcn_wave_barrier();
+  double* out = a.out + row * 3 * a.n_k;
+  for (int kk = 0; kk < a.n_k; ++kk) {
+    const int k = a.topk[kk];
+    double dcg = 0.0, ap = 0.0, idcg = 0.0;
+    int hit = 0;
+    for (int i = lane; i < p; i += 64) {
+      const int ri = rnk[i];
+      if (ri < k) {
+        dcg += 1.0 / log2((double)(ri + 2));
+        ap += (double)cnt[i] / (double)(ri + 1);
+        hit = 1;
+      }
+    }
+    const int ideal = p < k ? p : k;
+    for (int t = lane; t < ideal; t += 64) idcg += 1.0 / log2((double)(t + 2));
+    dcg = wave_sum_f64(dcg); ap = wave_sum_f64(ap); idcg = wave_sum_f64(idcg);
+    hit = wave_sum_i32(hit);
+    if (lane == 0) {
+      const int cap = p < 1 ? 1 : (p > k ? k : p);
+      out[0 * a.n_k + kk] = dcg / (idcg == 0.0 ? 1.0 : idcg);
+      out[1 * a.n_k + kk] = ap / (double)cap;
+      out[2 * a.n_k + kk] = hit > 0 ? 1.0 : 0.0;
+    }
+  }
+}
+
+// column means of per-row metrics [N, w] -> [w]: one workgroup per column, a fixed tree over fixed strides
+__global__ __launch_bounds__(kBlock) void list_metrics_mean_kernel(const double* __restrict__ per_row, int64_t N, int w, double* __restrict__ mean) {
+  __shared__ double part[kBlock / 64];
+  const int col = blockIdx.x;
+  double s = 0.0;
+  for (int64_t r = threadIdx.x; r < N; r += kBlock) s += per_row[r * w + col];
+  s = wave_sum_f64(s);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int q = 0; q < kBlock / 64; ++q) t += part[q];
+    mean[col] = N > 0 ? t / (double)N : 0.0;
+  }
+}
+
+}  // namespace rc
+
 using namespace rc;
 
 extern "C" int rc_target_rank(const float* pred, int64_t n, int C, int32_t* rank, rc_stream_t stream) {
@@ -226,4 +346,49 @@ extern "C" int rc_full_catalogue_rank(const float* Uvec, const float* I, const i
     case 128: return launch_full_rank<128>(Uvec, I, users, targets, N, n_items, clicked_ptr, clicked_items, target_score, rank, s);
     default: return fail(RC_ERR_UNSUPPORTED, "rc_full_catalogue_rank: emb_size must be 32, 64 or 128, got %d", d);
   }
+}
+
+extern "C" int rc_list_metrics_supported(int n, int max_pos, int n_k) {
+  return (n >= 1 && n <= kListMetricsMaxN && max_pos >= 0 && max_pos <= n && n_k >= 1 && n_k <= kListMetricsMaxK) ? 1 : 0;
+}
+
+extern "C" int rc_list_metrics(const float* pred, const int64_t* pos_num, const int64_t* neg_num, int64_t N, int n, int max_pos,
+                               const int* topk, int n_k, double* per_row, double* mean, rc_stream_t stream) {
+  RC_REQUIRE(topk && (N == 0 || (pred && neg_num && per_row)), "rc_list_metrics: null pointer");
+  if (!rc_list_metrics_supported(n, max_pos, n_k))
+    return fail(RC_ERR_UNSUPPORTED, "rc_list_metrics: n=%d (<= %d), max_pos=%d, %d values of k (<= %d) not covered", n, kListMetricsMaxN, max_pos,
+                n_k, kListMetricsMaxK);
+  RC_REQUIRE(N >= 0, "rc_list_metrics: N=%lld", (long long)N);
+  hipStream_t s = as_stream(stream);
+  ListMetricArgs a;
+  memset(&a, 0, sizeof(a));
+  a.pred = pred; a.pos_num = pos_num; a.neg_num = neg_num; a.N = N; a.n = n; a.max_pos = max_pos; a.n_k = n_k; a.out = per_row;
+  for (int i = 0; i < n_k; ++i) {
+    RC_REQUIRE(topk[i] >= 1, "rc_list_metrics: k = %d", topk[i]);
+    a.topk[i] = topk[i];
+  }
+  if (N > 0) {
+    const size_t lds = (size_t)(kBlock / 64) * ((size_t)n * sizeof(double) + 2 * (size_t)max_pos * sizeof(int));
+    {   // more than 64 KB of dynamic LDS needs the attribute, once per device of the process
+      static std::mutex mu;
+      static bool done[64] = {};
+      int dev = 0;
+      RC_HIP(hipGetDevice(&dev));
+      std::lock_guard<std::mutex> lock(mu);
+      if (dev < 0 || dev >= 64 || !done[dev]) {
+        RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(list_metrics_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)((kBlock / 64) * ((size_t)kListMetricsMaxN * (sizeof(double) + 2 * sizeof(int))))));
+        if (dev >= 0 && dev < 64) done[dev] = true;
+      }
+    }
+    const int64_t blocks = (N + kBlock / 64 - 1) / (kBlock / 64);
+    RC_REQUIRE(blocks <= kMaxGridX, "rc_list_metrics: too many rows");
+    hipLaunchKernelGGL(list_metrics_kernel, dim3((unsigned)blocks), dim3(kBlock), lds, s, a);
+    RC_LAUNCH_CHECK();
+  }
+  if (mean) {
+    hipLaunchKernelGGL(list_metrics_mean_kernel, dim3((unsigned)(3 * n_k)), dim3(kBlock), 0, s, per_row, N, 3 * n_k, mean);
+    RC_LAUNCH_CHECK();
+  }
+  return RC_OK;
 }

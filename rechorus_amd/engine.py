@@ -1938,6 +1938,26 @@ def rank_metrics(rank, topk, metrics):
     return {k: float(v) for k, v in zip(keys, out)}
 
 
+def list_metrics_supported(n, max_pos, n_k):
+    return bool(_lib.load().rc_list_metrics_supported(int(n), int(max_pos), int(n_k)))
+
+
+def list_metrics(pred, pos_num, neg_num, max_pos, topk, want_mean=True):
+    """ImpressionRunner's HR / NDCG / MAP @k (helpers/ImpressionRunner.py:18-66,74-133) on the device:
+    pred [N, n] fp32, pos_num [N] int64 | None, neg_num [N] int64 -> (per_row float64 [N, 3, K], mean float64 [3, K] | None),
+    metric order NDCG, MAP, HR"""
+    N, n = pred.shape
+    K = len(topk)
+    dev, f64, i64 = pred.device, torch.float64, torch.int64
+    per_row = torch.empty((N, 3, K), dtype=f64, device=dev)
+    mean = torch.empty((3, K), dtype=f64, device=dev) if want_mean else None
+    ks = (C.c_int * K)(*[int(k) for k in topk])
+    _lib.call("rc_list_metrics", _ptr(pred, torch.float32, "pred") if N else None, _ptr(pos_num, i64, "pos_num", True),
+              _ptr(neg_num, i64, "neg_num") if N else None, N, int(n), int(max_pos), ks, K, _ptr(per_row, f64, "per_row") if N else None,
+              _ptr(mean, f64, "mean", True), _stream())
+    return per_row, mean
+
+
 # ---- row-sharded step: local kernels (csrc/owner_step.hip) --------------------------------------------------
 
 def route_by_owner(ids, world, tuple_base=None, div=1):

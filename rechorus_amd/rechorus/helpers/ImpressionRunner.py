@@ -4,8 +4,8 @@ same metrics HR@k / NDCG@k / MAP@k).
 
 `fit` builds the {1 positive slot, 0 negative slot, -1 padding} label matrix of :187-190 on the device and
 hands it to `model.loss(out_dict, labels)`; the forward is the model's HIP gather-dot, the default
-list-level BPR loss one HIP kernel.  Evaluation sorts each list on the device and computes the three
-metrics there; `evaluate_method` keeps the reference's numpy signature for callers that hold predictions.
+list-level BPR loss one HIP kernel.  `evaluate` ranks each list's positives and forms the three metrics on the
+device (rc_list_metrics); `evaluate_method` keeps the reference's numpy signature for callers that hold predictions.
 """
 from typing import Dict
 
@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from helpers.BaseRunner import BaseRunner
-from rechorus_amd import graph as hgraph, nn as hnn
+from rechorus_amd import engine, graph as hgraph, nn as hnn
 from models.BaseModel import BaseModel
 
 
@@ -69,8 +69,22 @@ class ImpressionRunner(BaseRunner):
         return ordered
 
     def evaluate(self, data: BaseModel.Dataset, topks: list, metrics: list, check_sort_idx=0, all=0) -> Dict[str, float]:
-        predictions = self.predict(data)
+        """reference :135-172.  On the GPU the predictions never leave the device: rc_list_metrics ranks every list's valid
+        positives among its valid entries (the reference's -inf mask, 1e-6 tie shift and stable sort restated as counts) and
+        forms NDCG / MAP / HR @k in float64 there; the host reads 3 * len(topks) means (all=1: the per-row values)."""
         model = data.model
+        mp, mn = model.test_max_pos_item, model.test_max_neg_item
+        if not model.test_all and torch.device(model.device).type == 'cuda' and engine.list_metrics_supported(mp + mn, mp, len(topks)):
+            pred = self._predict_device(data).float().contiguous()
+            if pred.shape[1] == mp + mn:
+                dev = pred.device
+                pos = torch.from_numpy(np.asarray(data.data['pos_num'], dtype=np.int64)).to(dev) if 'pos_num' in data.data else None
+                neg = torch.from_numpy(np.asarray(data.data['neg_num'], dtype=np.int64)).to(dev)
+                per_row, mean = engine.list_metrics(pred, pos, neg, mp, topks, want_mean=not all)
+                vals = (per_row.permute(1, 2, 0) if all else mean).cpu().numpy()      # [3, K(, N)]
+                return {'{}@{}'.format(name, k): (vals[m, j] if all else float(vals[m, j]))
+                        for m, name in enumerate(('NDCG', 'MAP', 'HR')) for j, k in enumerate(topks)}
+        predictions = self.predict(data)
         if model.test_all:
             rows, cols = list(), list()
             for i, u in enumerate(data.data['user_id']):
@@ -78,7 +92,6 @@ class ImpressionRunner(BaseRunner):
                 rows.extend([i] * len(clicked))
                 cols.extend(clicked)
             predictions[rows, cols] = -np.inf
-        mp, mn = model.test_max_pos_item, model.test_max_neg_item
         pos_num = np.asarray(data.data['pos_num']) if 'pos_num' in data.data else np.ones(len(predictions), dtype=np.int64)
         neg_num = np.asarray(data.data['neg_num'])
         col = np.arange(predictions.shape[1])[None, :]

@@ -167,3 +167,93 @@ def test_bprmf_impression_returns_u_v_and_i_v(cuda):
     assert np.array_equal(out["i_v"].detach().cpu().numpy(), I[iid])
     assert_close(out["prediction"].detach().cpu().numpy(), (U[uid][:, None, :] * I[iid]).sum(-1), what="prediction")
     assert set(BPRMF(args, corpus).to(cuda)(feed)) == {"prediction"}
+
+
+# ---- list metrics on the device (rc_list_metrics) -----------------------------------------------------------------------
+
+def _device_metrics(c_pred, pos, neg, mp, topk, cuda):
+    from rechorus_amd import engine
+    per_row, mean = engine.list_metrics(torch.from_numpy(np.ascontiguousarray(c_pred, dtype=np.float32)).to(cuda),
+                                        None if pos is None else torch.from_numpy(np.asarray(pos, dtype=np.int64)).to(cuda),
+                                        torch.from_numpy(np.asarray(neg, dtype=np.int64)).to(cuda), mp, topk)
+    return per_row.cpu().numpy(), mean.cpu().numpy()
+
+
+@pytest.mark.parametrize("key", ["metric/0", "metric/1"])
+def test_list_metrics_on_the_device_match_the_reference(key, cuda):
+    """rc_list_metrics vs the reference's own evaluate_method(ret_all=1) (tests/golden/impression_losses_metrics.npz): per-row
+    NDCG / MAP / HR @k in float64 to 1e-12, the means to 1e-12"""
+    c = case(key)
+    topk = [1, 2, 3, 5, 10]
+    per_row, mean = _device_metrics(c["pred"], c["pos_num"], c["neg_num"], int(c["max_pos"]), topk, cuda)
+    for m, name in enumerate(("NDCG", "MAP", "HR")):
+        for j, k in enumerate(topk):
+            want = c["res/%s@%d" % (name, k)]
+            assert np.allclose(per_row[:, m, j], want, atol=1e-12, rtol=0), (name, k, np.abs(per_row[:, m, j] - want).max())
+            assert abs(mean[m, j] - want.mean()) < 1e-12, (name, k)
+
+
+def test_list_metrics_on_the_device_ties_empty_groups_and_wide_lists(cuda):
+    """against the mirror's numpy evaluate_method (itself pinned to the reference's, tests/test_impression_cpu.py) on what the
+    golden lists do not hold: scores drawn from four values (ties between positives and negatives and inside a group), rows
+    without positives or without negatives, counts beyond the slot widths, garbage (inf / huge) in the unused columns, one
+    positive per row (pos_num None), a single column, 2,048 columns, no rows"""
+    from helpers.ImpressionRunner import ImpressionRunner
+    from rechorus_amd import engine
+    rng = np.random.default_rng(5)
+    for N, mp, mn, topk, with_pos in ((200, 20, 20, [1, 2, 3, 5, 10, 20, 50], True), (64, 3, 70, [1, 5, 100], True), (50, 1, 9, [1, 3], False),
+                                      (17, 1, 0, [1, 2], True), (9, 40, 2008, [1, 10, 1000], True), (33, 0, 5, [2], True)):
+        n = mp + mn
+        pred = rng.choice(np.array([-1.5, 0.0, 0.25, 2.0], dtype=np.float32), size=(N, n))
+        pos = rng.integers(0, mp + 3, size=N) if with_pos else None
+        neg = rng.integers(0, mn + 3, size=N)
+        # the reference sees -inf outside the valid slots (ImpressionRunner.evaluate :156-168); the kernel must not look there
+        p_eff = np.minimum(pos if pos is not None else 1, mp)
+        col = np.arange(n)[None, :]
+        keep = (col < p_eff[:, None] if pos is not None else col < min(1, mp)) | ((col >= mp) & (col < mp + np.minimum(neg, mn)[:, None]))
+        want = ImpressionRunner.evaluate_method(np.where(keep, pred, -np.inf), topk, [], False, neg, mp, pos, ret_all=1)
+        dirty = np.where(keep, pred, rng.choice(np.array([np.inf, 1e30, -3.0], dtype=np.float32), size=(N, n)))
+        per_row, mean = _device_metrics(dirty, pos, neg, mp, topk, cuda)
+        for m, name in enumerate(("NDCG", "MAP", "HR")):
+            for j, k in enumerate(topk):
+                w = want["%s@%d" % (name, k)]
+                assert np.allclose(per_row[:, m, j], w, atol=1e-12, rtol=0), (N, mp, mn, name, k, np.abs(per_row[:, m, j] - w).max())
+                assert abs(mean[m, j] - w.mean()) < 1e-12
+    per_row, mean = _device_metrics(np.zeros((0, 8), dtype=np.float32), np.zeros(0), np.zeros(0), 3, [1, 2], cuda)
+    assert per_row.shape == (0, 3, 2) and not mean.any()
+    assert not engine.list_metrics_supported(4096, 20, 3) and not engine.list_metrics_supported(40, 20, 17)
+
+
+def test_impression_runner_evaluates_on_the_device(tmp_path, cuda, monkeypatch):
+    """ImpressionRunner.evaluate: the predictions stay on the device (no BaseRunner.predict, i.e. no [N, n] D2H copy) and the
+    result equals the numpy route on the same predictions, means and per-row values (all=1)"""
+    import main
+    from helpers.BaseRunner import BaseRunner
+    make_impression_dataset(str(tmp_path), "imp")
+    model_cls = main.find_class("model", ("BPRMF", "Impression"))
+    reader_cls, runner_cls = main.find_class("helper", model_cls.reader), main.find_class("helper", model_cls.runner)
+    p = main.parse_global_args(argparse.ArgumentParser())
+    p = model_cls.parse_model_args(runner_cls.parse_runner_args(reader_cls.parse_data_args(p)))
+    args = p.parse_args(["--path", str(tmp_path) + "/", "--dataset", "imp", "--emb_size", "32", "--num_workers", "0", "--train_max_pos_item", "3",
+                         "--train_max_neg_item", "4", "--test_max_pos_item", "2", "--test_max_neg_item", "5", "--metric", "NDCG,HR", "--topk", "1,2,5"])
+    args.device, args.model_path, args.log_file, args.train = cuda, "/tmp/rechorus_amd_test/m.pt", "/tmp/rechorus_amd_test/l.txt", 1
+    corpus = reader_cls(args)
+    model = model_cls(args, corpus).to(cuda)
+    runner = runner_cls(args)
+    runner.fit(model_cls.Dataset(model, corpus, "train"), epoch=1)
+    ds = model_cls.Dataset(model, corpus, "dev")
+    predictions = BaseRunner.predict(runner, ds)
+    pos, neg = np.asarray(ds.data["pos_num"]), np.asarray(ds.data["neg_num"])
+    col = np.arange(predictions.shape[1])[None, :]
+    keep = (col < np.minimum(pos, 2)[:, None]) | ((col >= 2) & (col < 2 + np.minimum(neg, 5)[:, None]))
+    masked = np.where(keep, predictions, -np.inf)
+
+    def no_host_predictions(*a, **k):
+        raise AssertionError("ImpressionRunner.evaluate copied the predictions to the host")
+    monkeypatch.setattr(BaseRunner, "predict", no_host_predictions)
+    for ret_all in (0, 1):
+        got = runner.evaluate(ds, [1, 2, 5], ["NDCG", "HR"], all=ret_all)
+        want = runner.evaluate_method(masked, [1, 2, 5], ["NDCG", "HR"], False, neg, 2, pos, ret_all=ret_all)
+        assert list(got) == list(want)
+        for k in want:
+            assert np.allclose(got[k], want[k], atol=1e-12, rtol=0), (k, got[k], want[k])
