@@ -509,6 +509,52 @@ size_t rc_sasrec_pos_grad_workspace_bytes(int B, int L, int d);
 int rc_sasrec_pos_grad(const float* g_hist, const int64_t* lengths, int B, int L, int d, int n_pos,
                        float* grad_pos, void* ws, size_t ws_bytes, rc_stream_t stream);
 
+/* ---- shape-generic sequence-encoder layers (csrc/seq_layers.hip) --------------------------------------------
+ * The pieces of utils/layers.py TransformerLayer :92-118 / MultiHeadAttention :9-63 and of SASRec.py:58-76 that are not GEMMs, for
+ * the shapes the register-resident encoders above do not cover (any emb_size that is a multiple of 4, any head count and number of
+ * blocks, history up to 1,024 positions, dropout): together with rc_linear_fwd / rc_linear_bwd they replace the plugin's torch
+ * layers there.  The batch is the padded [B, L, d] block seen as B * L rows; row (b, i) is VALID iff i < min(len_b, L); rows that
+ * are not valid hold zeros at every layer boundary and receive zero gradients (the reference zeroes them at the end, SASRec.py:74,
+ * and no valid row attends to one).                                                                                              */
+
+/* off[b] = sum_{b' < b} min(lengths[b'], L), b in [0, B]: a valid row's compact index off[b] + i keys the dropout mask like
+ * rc_sasrec_batch_fwd_dropout does, and off[b + 1] - off[b] is the sequence's valid row count.                                   */
+int rc_seq_offsets(const int64_t* lengths, int64_t B, int L, int32_t* off, rc_stream_t stream);
+/* SASRec.py:58-66: X[b, i, :] = item_emb[hist[b, i]] + pos_emb[len_b - i] for i < len_b, 0 on the padding.                       */
+int rc_seq_embed_fwd(const float* item_emb, const float* pos_emb, const int64_t* hist, const int64_t* lengths, int64_t B, int L, int d,
+                     float* X, rc_stream_t stream);
+/* SASRec.py:76: hv[b, :] = X[b, len_b - 1, :] (0 for an empty sequence); backward: dX [B * L, d] = 0 except those rows = dhv.     */
+int rc_seq_pick_last_fwd(const float* X, const int64_t* lengths, int64_t B, int L, int d, float* hv, rc_stream_t stream);
+int rc_seq_pick_last_bwd(const float* dhv, const int64_t* lengths, int64_t B, int L, int d, float* dX, rc_stream_t stream);
+/* rc_sasrec_pos_grad for any row width: grad_pos [n_pos, d], row p = sum_b dX[b, len_b - p] over the sequences with
+ * min(len_b, L) >= p >= 1, every other row 0 (the position ids of SASRec.py:64; fixed summation order, ascending b).               */
+int rc_seq_pos_grad(const float* dX, const int64_t* lengths, int64_t B, int L, int d, int n_pos, float* grad_pos, rc_stream_t stream);
+/* scaled_dot_product_attention (utils/layers.py:52-63) of H heads over Q / K / V [B * L, H * dk] (head h = columns [h * dk,
+ * (h + 1) * dk), the layout head_split :30-32 views): ctx[b, i, h] = softmax_j(q_i . k_j / sqrt(dk)) @ v_j over the keys the mask
+ * shows -- mask uint8 [mask_batch ? B : 1][L][L] (0 = hidden; NULL = none), causal != 0 additionally hides j > i (and skips that
+ * work), off (NULL = every row valid) restricts queries and keys to valid rows; a row that sees no key yields 0 (the reference's
+ * NaN -> 0, :61).  lse [B, H, L] = log-sum-exp of a row's scaled scores, saved for the backward pass, which recomputes the
+ * probabilities: Dv [B, H, L] is scratch (sum_j p_ij dP_ij), dQ / dK / dV get every element written.  L <= 1,024, dk <= 256.       */
+int rc_seq_attention_supported(int L, int dk);
+int rc_seq_attention_fwd(const float* Q, const float* K, const float* V, const int32_t* off, const uint8_t* mask, int mask_batch,
+                         int causal, int64_t B, int L, int H, int dk, float* ctx, float* lse, rc_stream_t stream);
+int rc_seq_attention_bwd(const float* Q, const float* K, const float* V, const int32_t* off, const uint8_t* mask, int mask_batch,
+                         int causal, int64_t B, int L, int H, int dk, const float* lse, const float* dctx, float* Dv, float* dQ,
+                         float* dK, float* dV, rc_stream_t stream);
+/* TransformerLayer.forward :110,117: Y = LayerNorm(dropout(A) + R) over rows of d floats (R NULL: no residual); xhat [rows, d] and
+ * rstd [rows] are kept for the backward pass.  off NULL: every row is valid and its compact index is the row number; otherwise rows
+ * = B * L and invalid rows give Y = xhat = 0.  drop_p > 0: element (compact row r, feature f) of `site` is dropped iff word (f & 3)
+ * of Philox4x32-10(key = *seed_dev, counter = (r, site * d / 4 + (f >> 2))) < drop_p * 2^32, kept values scaled by 1 / (1 - p) --
+ * the stream of rc_sasrec_batch_fwd_dropout (site = 2 * layer + {0: dropout1, 1: dropout2}).  Backward: dA = mask * dZ (NULL:
+ * not wanted), dR = dZ, dw = sum_rows dY * xhat, db = sum_rows dY in a fixed order.  d a multiple of 4 up to 1,024.                */
+int rc_seq_add_layernorm_fwd(const float* A, const float* R, const float* w, const float* b, const int32_t* off, int64_t rows, int L,
+                             int d, float drop_p, const uint64_t* seed_dev, uint32_t site, float* Y, float* xhat, float* rstd,
+                             rc_stream_t stream);
+size_t rc_seq_add_layernorm_bwd_workspace_bytes(int d);
+int rc_seq_add_layernorm_bwd(const float* dY, const float* xhat, const float* rstd, const float* w, const int32_t* off, int64_t rows,
+                             int L, int d, float drop_p, const uint64_t* seed_dev, uint32_t site, float* dA, float* dR, float* dw,
+                             float* db, void* ws, size_t ws_bytes, rc_stream_t stream);
+
 /* ---- NeuMF head (models/general/NeuMF.py:56-76), one hidden layer ------------------------- */
 
 /* 1 iff the fp32-MFMA kernels cover (emb_size d, hidden size l1): d, l1 in {32,64,128} and the

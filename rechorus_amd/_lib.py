@@ -84,6 +84,17 @@ SIGNATURES = {
     "rc_gather_fields": (_i, [_p, _p, _p, _p, _i, _i64, _i, _i, _p, _p, _p]),
     "rc_gather_fields_pair": (_i, [_p, _p, _p, _p, _p, _i, _i64, _i, _i, _p, _p, _p, _p]),
     "rc_gather_fields_pair_mark": (_i, [_p, _p, _p, _p, _p, _i, _i64, _i, _i, _p, _p, _p, _p, _p, _i, _p]),
+    "rc_seq_offsets": (_i, [_p, _i64, _i, _p, _p]),
+    "rc_seq_embed_fwd": (_i, [_p, _p, _p, _p, _i64, _i, _i, _p, _p]),
+    "rc_seq_pick_last_fwd": (_i, [_p, _p, _i64, _i, _i, _p, _p]),
+    "rc_seq_pick_last_bwd": (_i, [_p, _p, _i64, _i, _i, _p, _p]),
+    "rc_seq_pos_grad": (_i, [_p, _p, _i64, _i, _i, _i, _p, _p]),
+    "rc_seq_attention_supported": (_i, [_i, _i]),
+    "rc_seq_attention_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i64, _i, _i, _i, _p, _p, _p]),
+    "rc_seq_attention_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i64, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p]),
+    "rc_seq_add_layernorm_fwd": (_i, [_p, _p, _p, _p, _p, _i64, _i, _i, _f, _p, C.c_uint32, _p, _p, _p, _p]),
+    "rc_seq_add_layernorm_bwd_workspace_bytes": (_sz, [_i]),
+    "rc_seq_add_layernorm_bwd": (_i, [_p, _p, _p, _p, _p, _i64, _i, _i, _f, _p, C.c_uint32, _p, _p, _p, _p, _p, _sz, _p]),
     "rc_list_metrics_supported": (_i, [_i, _i, _i]),
     "rc_list_metrics": (_i, [_p, _p, _p, _i64, _i, _i, _p, _i, _p, _p, _p]),
     "rc_gather_fields_mixed": (_i, [_p, _p, _p, _p, _p, _i64, _p, _i, _i64, _i, _i, _p, _p, _p, _p, _p, _i, _p]),

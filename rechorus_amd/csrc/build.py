@@ -32,7 +32,7 @@ SOURCES = [
     "plan_update.hip",
     "train_step.hip", "small_step.hip",
     "neumf.hip", "neumf_step.hip", "mlp.hip", "tower_tail.hip",
-    "sasrec.hip", "sasrec_batch.hip",
+    "sasrec.hip", "sasrec_batch.hip", "seq_layers.hip",
     "listwise_loss.hip",
     "fm_bce.hip",
     "sampler.hip",

@@ -728,6 +728,13 @@ def neumf_train_step_supported(Cn, d, l1):
     return bool(_lib.load().rc_neumf_train_step_supported(int(Cn), int(d), int(l1)))
 
 
+def neumf_fused_step_selected(Cn, d, l1, opt="SGD"):
+    """would NeumfTrainer.step take the one-kernel step (rc_neumf_train_step) for Cn candidates per tuple?  Everything its
+    selection tests except the batch's plan geometry (known only with the batch)"""
+    return bool(_USE_PLAN and _NEUMF_FUSED and opt in ("SGD", "Adam", "Adagrad") and Cn >= 2 and segmented_pair_supported(d)
+                and neumf_train_step_supported(Cn, d, l1))
+
+
 def neumf_mark_rows(iid, n_items, marks, unmark=False):
     """rc_neumf_mark_rows / rc_neumf_unmark_rows on torch's current stream: the single / multi-occurrence flags of a batch's item ids"""
     _lib.call("rc_neumf_unmark_rows" if unmark else "rc_neumf_mark_rows", _ptr(iid, torch.int64, "iid"), iid.numel(), int(n_items),
@@ -868,6 +875,14 @@ class NeumfTrainer:
         if (use_plan and _NEUMF_FUSED and self.opt in ("SGD", "Adam", "Adagrad") and Cn >= 2
                 and neumf_train_step_supported(Cn, P["mf_u"].shape[1], P["W1"].shape[0])):
             return self._step_fused(uid, iid, next_batch)
+        if not neumf_supported(P["mf_u"].shape[1], P["W1"].shape[0]):
+            # (a tower that exists only inside the one-kernel step, e.g. hidden 16: say why this call cannot take it instead of
+            # failing with RC_ERR_UNSUPPORTED inside rc_neumf_fwd)
+            raise RuntimeError("NeumfTrainer: emb_size {} / hidden {} is a shape of the one-kernel step (rc_neumf_train_step) only, which this call "
+                               "cannot take: {} candidates per tuple (needs >= 2 and the kernel's LDS budget: rc_neumf_train_step_supported), "
+                               "plan {} (RC_TABLE_UPDATE, row-wise updates, a plan geometry for {} + {} ids), RC_NEUMF_FUSED={} -- use --engine "
+                               "dense for this configuration".format(P["mf_u"].shape[1], P["W1"].shape[0], Cn, "on" if use_plan else "off",
+                                                                      iid.numel(), uid.numel(), int(_NEUMF_FUSED)))
         overlap = use_plan and _NEUMF_OVERLAP and iid.is_cuda and iid.numel() >= _SAS_OVERLAP_MIN
         plan = plan_done = main = None
         if overlap:
@@ -1286,6 +1301,112 @@ def sasrec_pos_grad(g_hist, lengths, n_pos):
     _lib.call("rc_sasrec_pos_grad", _ptr(g_hist, torch.float32, "g_hist"), _ptr(lengths, torch.int64, "lengths"), B, L, d,
               int(n_pos), _ptr(out, torch.float32, "grad_pos"), C.c_void_p(ws.data_ptr()), ws.numel(), _stream())
     return out
+
+
+# ---- shape-generic sequence-encoder layers (csrc/seq_layers.hip) ------------------------------------------------------
+
+def seq_offsets(lengths, L):
+    """off int32 [B + 1]: exclusive prefix sums of min(len_b, L) -- valid row counts and compact row indices of the padded batch"""
+    B = lengths.numel()
+    off = torch.empty(B + 1, dtype=torch.int32, device=lengths.device)
+    _lib.call("rc_seq_offsets", _ptr(lengths, torch.int64, "lengths"), B, int(L), _ptr(off, torch.int32, "off"), _stream())
+    return off
+
+
+def seq_embed(item_emb, pos_emb, hist, lengths):
+    """X [B * L, d] = item rows + position rows (position id = length - index) on valid rows, 0 on the padding (SASRec.py:58-66)"""
+    B, L = hist.shape
+    d = item_emb.shape[1]
+    f32, i64 = torch.float32, torch.int64
+    X = torch.empty((B * L, d), dtype=f32, device=hist.device)
+    _lib.call("rc_seq_embed_fwd", _ptr(item_emb, f32, "item_emb"), _ptr(pos_emb, f32, "pos_emb"), _ptr(hist, i64, "hist"),
+              _ptr(lengths, i64, "lengths"), B, L, d, _ptr(X, f32, "X"), _stream())
+    return X
+
+
+def seq_pick_last(X, lengths, B, L):
+    """hv [B, d] = X[b * L + len_b - 1] (SASRec.py:76)"""
+    d = X.shape[1]
+    hv = torch.empty((B, d), dtype=torch.float32, device=X.device)
+    _lib.call("rc_seq_pick_last_fwd", _ptr(X, torch.float32, "X"), _ptr(lengths, torch.int64, "lengths"), B, int(L), d, _ptr(hv, torch.float32, "hv"), _stream())
+    return hv
+
+
+def seq_pick_last_bwd(dhv, lengths, B, L):
+    d = dhv.shape[1]
+    dX = torch.empty((B * L, d), dtype=torch.float32, device=dhv.device)
+    _lib.call("rc_seq_pick_last_bwd", _ptr(dhv, torch.float32, "dhv"), _ptr(lengths, torch.int64, "lengths"), B, int(L), d, _ptr(dX, torch.float32, "dX"), _stream())
+    return dX
+
+
+def seq_pos_grad(dX, lengths, B, L, n_pos):
+    """dense gradient [n_pos, d] of the position table from the rows' gradients dX [B * L, d] (position id = length - index)"""
+    d = dX.shape[1]
+    out = torch.empty((n_pos, d), dtype=torch.float32, device=dX.device)
+    _lib.call("rc_seq_pos_grad", _ptr(dX, torch.float32, "dX"), _ptr(lengths, torch.int64, "lengths"), B, int(L), d, int(n_pos),
+              _ptr(out, torch.float32, "grad_pos"), _stream())
+    return out
+
+
+def seq_attention_supported(L, dk):
+    return bool(_lib.load().rc_seq_attention_supported(int(L), int(dk)))
+
+
+def _seq_attn_head(Q, K, V, off, mask, causal, B, L, H):
+    f32 = torch.float32
+    dk = Q.shape[1] // H
+    mb = 0
+    if mask is not None:
+        if mask.dtype != torch.uint8 or mask.shape[-2:] != (L, L) or mask.numel() not in (L * L, B * L * L):
+            raise ValueError("seq_attention: mask must be uint8 [L, L] or [B, L, L]")
+        mb = 1 if mask.numel() == B * L * L and B > 1 else 0
+    return (_ptr(Q, f32, "Q"), _ptr(K, f32, "K"), _ptr(V, f32, "V"), _ptr(off, torch.int32, "off", True), _ptr(mask, torch.uint8, "mask", True),
+            mb, 1 if causal else 0, B, L, H, dk)
+
+
+def seq_attention_fwd(Q, K, V, off, B, L, H, mask=None, causal=True):
+    """Q, K, V [B * L, H * dk] -> (ctx [B * L, H * dk], lse [B, H, L])  (utils/layers.py:52-63, per head)"""
+    f32 = torch.float32
+    ctx = torch.empty_like(Q)
+    lse = torch.empty((B, H, L), dtype=f32, device=Q.device)
+    _lib.call("rc_seq_attention_fwd", *_seq_attn_head(Q, K, V, off, mask, causal, B, L, H), _ptr(ctx, f32, "ctx"), _ptr(lse, f32, "lse"), _stream())
+    return ctx, lse
+
+
+def seq_attention_bwd(Q, K, V, off, B, L, H, lse, dctx, mask=None, causal=True):
+    """-> (dQ, dK, dV); probabilities recomputed from lse"""
+    f32 = torch.float32
+    dQ, dK, dV = torch.empty_like(Q), torch.empty_like(Q), torch.empty_like(Q)
+    Dv = torch.empty((B, H, L), dtype=f32, device=Q.device)
+    _lib.call("rc_seq_attention_bwd", *_seq_attn_head(Q, K, V, off, mask, causal, B, L, H), _ptr(lse, f32, "lse"), _ptr(dctx, f32, "dctx"),
+              _ptr(Dv, f32, "Dv"), _ptr(dQ, f32, "dQ"), _ptr(dK, f32, "dK"), _ptr(dV, f32, "dV"), _stream())
+    return dQ, dK, dV
+
+
+def seq_add_layernorm_fwd(A, R, w, b, off, L, drop_p=0.0, seed=None, site=0):
+    """Y = LayerNorm(dropout(A) + R) over the rows of A [rows, d] -> (Y, xhat, rstd)  (utils/layers.py:110,117)"""
+    f32 = torch.float32
+    rows, d = A.shape
+    Y, xhat = torch.empty_like(A), torch.empty_like(A)
+    rstd = torch.empty(rows, dtype=f32, device=A.device)
+    _lib.call("rc_seq_add_layernorm_fwd", _ptr(A, f32, "A"), _ptr(R, f32, "R", True), _ptr(w, f32, "w"), _ptr(b, f32, "b"),
+              _ptr(off, torch.int32, "off", True), rows, int(L), d, *_drop_args(drop_p, seed), C.c_uint32(int(site)), _ptr(Y, f32, "Y"),
+              _ptr(xhat, f32, "xhat"), _ptr(rstd, f32, "rstd"), _stream())
+    return Y, xhat, rstd
+
+
+def seq_add_layernorm_bwd(dY, xhat, rstd, w, off, L, drop_p=0.0, seed=None, site=0, need_dA=True, need_dR=True):
+    """-> (dA | None, dR | None, dw [d], db [d])"""
+    f32 = torch.float32
+    rows, d = dY.shape
+    dA = torch.empty_like(dY) if need_dA else None
+    dR = torch.empty_like(dY) if need_dR else None
+    dw, db = torch.empty(d, dtype=f32, device=dY.device), torch.empty(d, dtype=f32, device=dY.device)
+    ws = workspace(_lib.load().rc_seq_add_layernorm_bwd_workspace_bytes(d), dY.device, "seq_ln_bwd")
+    _lib.call("rc_seq_add_layernorm_bwd", _ptr(dY, f32, "dY"), _ptr(xhat, f32, "xhat"), _ptr(rstd, f32, "rstd"), _ptr(w, f32, "w"),
+              _ptr(off, torch.int32, "off", True), rows, int(L), d, *_drop_args(drop_p, seed), C.c_uint32(int(site)), _ptr(dA, f32, "dA", True),
+              _ptr(dR, f32, "dR", True), _ptr(dw, f32, "dw"), _ptr(db, f32, "db"), C.c_void_p(ws.data_ptr()), ws.numel(), _stream())
+    return dA, dR, dw, db
 
 
 def seg_rows_route(n_occ, n_rows, d):

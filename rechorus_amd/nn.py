@@ -568,6 +568,109 @@ def sasrec_encode(item_emb, pos_emb, blocks, n_heads, hist, lengths, drop_p=0.0,
     return _SasrecEncodeFn.apply(item_emb, pos_emb, n_heads, hist.contiguous(), lengths.contiguous(), float(drop_p), seed, *flat)
 
 
+# ---- the encoder layer by layer, any shape (csrc/seq_layers.hip + the GEMMs of csrc/mlp.hip) ---------------------------------
+
+class _SeqEmbedFn(torch.autograd.Function):
+    """item rows + position rows of a right-padded history (SASRec.py:58-66) as B * L rows; the backward is the two dense
+    embedding gradients (the rows' gradients are zero on the padding)"""
+
+    @staticmethod
+    def forward(ctx, item_emb, pos_emb, hist, lengths):
+        ctx.hist, ctx.lengths = hist, lengths
+        ctx.n_items, ctx.n_pos = item_emb.shape[0], pos_emb.shape[0]
+        return engine.seq_embed(item_emb.detach(), pos_emb.detach(), hist, lengths)
+
+    @staticmethod
+    def backward(ctx, gX):
+        B, L = ctx.hist.shape
+        g = gX.contiguous()
+        GI = engine.embedding_dense_backward(g.view(B, L, -1), ctx.hist, ctx.n_items)
+        GP = engine.seq_pos_grad(g, ctx.lengths, B, L, ctx.n_pos)
+        return GI, GP, None, None
+
+
+class _SeqAttentionFn(torch.autograd.Function):
+    """scaled_dot_product_attention of every head (utils/layers.py:52-63) on Q / K / V [B * L, H * dk]; nothing of size L x L is
+    kept: the backward recomputes the probabilities from the saved log-sum-exp"""
+
+    @staticmethod
+    def forward(ctx, q, k, v, off, B, L, H, mask, causal):
+        qc, kc, vc = q.detach().contiguous(), k.detach().contiguous(), v.detach().contiguous()
+        out, lse = engine.seq_attention_fwd(qc, kc, vc, off, B, L, H, mask=mask, causal=causal)
+        ctx.save_for_backward(qc, kc, vc, lse)
+        ctx.args = (off, B, L, H, mask, causal)
+        return out
+
+    @staticmethod
+    def backward(ctx, dctx):
+        qc, kc, vc, lse = ctx.saved_tensors
+        off, B, L, H, mask, causal = ctx.args
+        dQ, dK, dV = engine.seq_attention_bwd(qc, kc, vc, off, B, L, H, lse, dctx.contiguous(), mask=mask, causal=causal)
+        return dQ, dK, dV, None, None, None, None, None, None
+
+
+class _AddLayerNormFn(torch.autograd.Function):
+    """LayerNorm(dropout(branch) + residual) (utils/layers.py:110,117) in one kernel each way; the dropout mask is the
+    counter-based stream of the batch encoder (never stored)"""
+
+    @staticmethod
+    def forward(ctx, a, r, w, b, off, L, drop_p, seed, site):
+        ac = a.detach().contiguous()
+        y, xhat, rstd = engine.seq_add_layernorm_fwd(ac, None if r is None else r.detach().contiguous(), w.detach(), b.detach(), off, L,
+                                                     drop_p, seed, site)
+        ctx.save_for_backward(xhat, rstd, w.detach())
+        ctx.args = (off, L, drop_p, seed, site, r is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xhat, rstd, w = ctx.saved_tensors
+        off, L, drop_p, seed, site, has_r = ctx.args
+        dA, dR, dw, db = engine.seq_add_layernorm_bwd(dy.contiguous(), xhat, rstd, w, off, L, drop_p, seed, site, need_dR=has_r)
+        return dA, dR, dw, db, None, None, None, None, None
+
+
+class _SeqPickLastFn(torch.autograd.Function):
+    """hv[b] = x[b, len_b - 1] (SASRec.py:76)"""
+
+    @staticmethod
+    def forward(ctx, x, lengths, B, L):
+        ctx.args = (lengths, B, L)
+        return engine.seq_pick_last(x.detach().contiguous(), lengths, B, L)
+
+    @staticmethod
+    def backward(ctx, dhv):
+        lengths, B, L = ctx.args
+        return engine.seq_pick_last_bwd(dhv.contiguous(), lengths, B, L), None, None, None
+
+
+def sasrec_encode_layers(item_emb, pos_emb, blocks, n_heads, hist, lengths, drop_p=0.0, seed=None):
+    """The SASRec encoder (SASRec.py:58-76) block by block for the shapes outside the register-resident kernels' envelope
+    (engine.sasrec_supported): embeddings, every Linear (fp32 MFMA GEMMs, bias / ReLU in the epilogue), the attention of every
+    head, LayerNorm(dropout(.) + residual) -- all HIP kernels, autograd only strings them together.  -> hv [B, d], the output
+    row at position length - 1 of every sequence"""
+    hist, lengths = hist.contiguous(), lengths.contiguous()
+    B, L = hist.shape
+    off = engine.seq_offsets(lengths, L)
+    x = _SeqEmbedFn.apply(item_emb, pos_emb, hist, lengths)
+    for l, blk in enumerate(blocks):
+        a = blk.masked_attn_head
+        q = linear(x, a.q_linear.weight, a.q_linear.bias)
+        k = linear(x, a.k_linear.weight, a.k_linear.bias)
+        v = linear(x, a.v_linear.weight, a.v_linear.bias)
+        c = _SeqAttentionFn.apply(q, k, v, off, B, L, n_heads, None, True)        # causal mask only (SASRec.py:69-70)
+        y1 = _AddLayerNormFn.apply(c, x, blk.layer_norm1.weight, blk.layer_norm1.bias, off, L, float(drop_p), seed, 2 * l)
+        h = linear(y1, blk.linear1.weight, blk.linear1.bias, relu=True)
+        f = linear(h, blk.linear2.weight, blk.linear2.bias)
+        x = _AddLayerNormFn.apply(f, y1, blk.layer_norm2.weight, blk.layer_norm2.bias, off, L, float(drop_p), seed, 2 * l + 1)
+    return _SeqPickLastFn.apply(x, lengths, B, L)
+
+
+def sasrec_layers_supported(d, n_heads, L):
+    """sasrec_encode_layers covers this shape: emb_size a multiple of 4 up to 1,024 whose heads divide it, history up to 1,024"""
+    return d % 4 == 0 and 4 <= d <= 1024 and n_heads >= 1 and d % n_heads == 0 and engine.seq_attention_supported(L, d // n_heads)
+
+
 class _LinearFn(torch.autograd.Function):
     """drop(relu(x W^T + b)) as one fp32 MFMA GEMM with the epilogue fused (rc_linear_fwd); backward = mask + two GEMMs
     (rc_linear_bwd).  The saved output is its own ReLU / dropout mask."""

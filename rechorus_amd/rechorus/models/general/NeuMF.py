@@ -84,8 +84,11 @@ class NeuMF(GeneralModel):
 
     # ---- large-table mode: row-wise update of the four tables, no dense [n_rows, d] gradient -----------
     def _step_ok(self):
-        """the one-kernel fit() iteration covers this tower (hidden 16 is a shape of the fused step only)"""
-        return len(self.layers) == 1 and (self._fused_ok() or engine.neumf_train_step_supported(2, self.emb_size, self.layers[0]))
+        """engine.NeumfTrainer can train this tower: the three-kernel chain covers it (_fused_ok), or -- hidden 16, a shape of the
+        one-kernel step only -- NeumfTrainer.step would really select that step for this model's 1 + num_neg candidates per tuple
+        and the process's switches (the same tests it runs: engine.neumf_fused_step_selected)"""
+        return len(self.layers) == 1 and (self._fused_ok() or
+                                          engine.neumf_fused_step_selected(1 + int(self.num_neg), self.emb_size, self.layers[0]))
 
     def hip_rowwise_supported(self):
         return self._step_ok()

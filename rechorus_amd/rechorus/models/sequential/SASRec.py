@@ -8,8 +8,10 @@ rc_sasrec_fwd / rc_sasrec_bwd; the candidate scoring of :80-81 is the BPRMF gath
 the encoder output as the "user" row.  Training with --dropout p runs the batch-level kernels with the
 two nn.Dropout sites of every TransformerLayer (utils/layers.py:104-117) inside them: the mask comes from a
 counter-based stream keyed by a device-side seed (rc_sasrec_batch_fwd_dropout), never from torch's RNG.
-Unsupported shapes (emb_size not in {32, 64}, history longer than 64) run the same parameters through
-torch layers.
+Shapes outside those kernels' envelope (emb_size other than 32 / 64, history beyond 64 -- 128 with one block and no dropout --,
+more than four blocks) run the same parameters layer by layer on the shape-generic HIP kernels of csrc/seq_layers.hip and the
+fp32 MFMA GEMMs of csrc/mlp.hip (rechorus_amd.nn.sasrec_encode_layers): any emb_size that is a multiple of 4, any head / block
+count, history up to 1,024, dropout.  Torch layers remain for CPU tensors only.
 """
 import numpy as np
 import torch
@@ -68,7 +70,16 @@ class SASRecBase(object):
             return hnn.sasrec_encode(self.i_embeddings.weight, self.p_embeddings.weight,
                                      self.transformer_block, self.num_heads, history, lengths,
                                      p, self.drop_seed if p > 0 else None)
-        return self._encode_torch(history, lengths)
+        if history.is_cuda:
+            if not hnn.sasrec_layers_supported(self.emb_size, self.num_heads, history.shape[1]):
+                raise RuntimeError('SASRec on the HIP engine: emb_size {} / {} heads / history {} is outside every kernel (emb_size a '
+                                   'multiple of 4 up to 1024 that the heads divide, head width <= 256, history <= 1024)'.format(
+                                       self.emb_size, self.num_heads, history.shape[1]))
+            if p > 0:
+                engine.step_increment(self.drop_seed)
+            return hnn.sasrec_encode_layers(self.i_embeddings.weight, self.p_embeddings.weight, self.transformer_block, self.num_heads,
+                                            history, lengths, p, self.drop_seed if p > 0 else None)
+        return self._encode_torch(history, lengths)     # CPU tensors (construction-time checks, tests without a GPU)
 
     def full_catalogue_vectors(self, feed_dict):
         """(sequence vectors [B, d], item table) of the dot-product head, for --test_all ranking"""

@@ -150,12 +150,20 @@ CASES = [
     ("sasrec_d64_l2_h2",       80, 64, 2, 2, 12, 10, 5, 33),
     ("sasrec_d32_l1_h4",       60, 32, 1, 4, 7, 9, 3, 34),
     ("sasrec_d64_l1_h2_L100", 150, 64, 1, 2, 100, 9, 7, 35),    # more than 64 positions: one block, the one-row path's 128-row tile
+    # outside the register-resident kernels' envelope: the shape-generic layers of csrc/seq_layers.hip
+    ("sasrec_d128_l1_h4",     100, 128, 1, 4, 20, 10, 7, 36),
+    ("sasrec_d128_l2_h8_L100", 150, 128, 2, 8, 100, 6, 5, 37),
+    ("sasrec_d64_l3_h4_L200", 200, 64, 3, 4, 200, 5, 5, 38),   # history beyond 128, three blocks
+    ("sasrec_d48_l2_h3",       70, 48, 2, 3, 15, 9, 4, 39),    # an emb_size that is no power of two, three heads of 16
+    ("sasrec_d64_l5_h2",       60, 64, 5, 2, 10, 7, 3, 40),    # five blocks
 ]
 
 DROP_CASES = [
     # name,                        n_items, d, layers, heads, hist_max, B, K, p, seed
     ("sasrecdrop_d64_l1_h4_p0.2",     90, 64, 1, 4, 50, 10, 9, 0.2, 41),
     ("sasrecdrop_d32_l2_h2_p0.5",     60, 32, 2, 2, 11, 12, 4, 0.5, 42),
+    ("sasrecdrop_d64_l2_h4_L100_p0.2", 120, 64, 2, 4, 100, 8, 6, 0.2, 43),    # dropout with a history beyond 64 and two blocks
+    ("sasrecdrop_d128_l1_h2_p0.3",    90, 128, 1, 2, 30, 8, 6, 0.3, 44),
 ]
 
 if __name__ == "__main__":
@@ -164,6 +172,9 @@ if __name__ == "__main__":
         for c in CASES:
             if c[0] in only:
                 make_case(*c)
+        for c in DROP_CASES:
+            if c[0] in only:
+                make_dropout_case(*c)
         sys.exit(0)
     if "--dropout-only" not in sys.argv:
         for c in CASES:

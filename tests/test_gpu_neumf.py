@@ -1,10 +1,12 @@
 """GPU parity of the NeuMF head kernels (fp32 MFMA) vs the reference's own outputs
 (tests/golden/neumf_*.npz) and the numpy oracle."""
+import os
+
 import numpy as np
 import pytest
 import torch
 
-from conftest import assert_close, assert_update_close, load_golden
+from conftest import ROOT, assert_close, assert_update_close, load_golden
 from oracle import neumf_oracle as NO
 from test_oracle_neumf import CASES, params
 
@@ -628,3 +630,37 @@ def test_neumf_trainer_with_dropout_fused_equals_three_kernel_step(opt, cuda, en
     ex = 1e-3 * lr if opt != "SGD" else 0.0
     for k in P0:
         assert_update_close(Pa[k].cpu().numpy(), P0[k], Pb[k].cpu().numpy(), what=k, extra_atol=ex)
+
+
+def test_hidden_16_goes_rowwise_only_where_the_fused_step_is_really_selected(cuda, eng, monkeypatch):
+    """hidden 16 exists only inside the one-kernel step (rc_neumf_supported refuses it): `--engine auto` may pick the row-wise route only
+    when NeumfTrainer.step would select that step for the model's 1 + num_neg candidates and the process's switches; a trainer that
+    cannot take it says why instead of failing with RC_ERR_UNSUPPORTED inside rc_neumf_fwd"""
+    import argparse
+    import sys
+    plugin = os.path.join(ROOT, "rechorus_amd", "rechorus")
+    if plugin not in sys.path:
+        sys.path.insert(0, plugin)
+    from models.general.NeuMF import NeuMF
+    from rechorus_amd import engine
+
+    def model(num_neg):
+        args = argparse.Namespace(device=cuda, model_path="", buffer=1, num_neg=num_neg, dropout=0, test_all=0, emb_size=64, layers="[16]")
+        return NeuMF(args, argparse.Namespace(n_users=50, n_items=90)).to(cuda)
+    assert not eng.neumf_supported(64, 16) and eng.neumf_train_step_supported(5, 64, 16)
+    assert model(4).hip_rowwise_supported()
+    assert not model(0).hip_rowwise_supported()          # one candidate per tuple: the fused step needs two
+    assert not model(5000).hip_rowwise_supported()       # the candidates' LDS strips do not fit
+    monkeypatch.setattr(engine, "_NEUMF_FUSED", False)
+    assert not model(4).hip_rowwise_supported()          # RC_NEUMF_FUSED=0
+    m = model(4)
+    rng = np.random.default_rng(0)
+    feed = {"user_id": torch.from_numpy(rng.integers(1, 50, 32)).to(cuda), "item_id": torch.from_numpy(rng.integers(1, 90, (32, 5))).to(cuda),
+            "batch_size": 32, "phase": "train"}
+    with pytest.raises(RuntimeError, match="one-kernel step"):     # explicit --engine rowwise on a configuration it cannot train
+        m._step_ok = lambda: True
+        m.hip_train_step(feed, "SGD", 0.01, 0.0)
+    monkeypatch.undo()
+    m2 = model(4)
+    loss = m2.hip_train_step(feed, "SGD", 0.01, 0.0)
+    assert np.isfinite(float(loss))
