@@ -254,6 +254,10 @@ def test_sasrec_model_file_matches_reference(case, cuda):
      "--dropout", "0.2"],
     ["--model_name", "SASRec", "--emb_size", "32", "--num_layers", "2", "--num_heads", "2", "--history_max", "10", "--lr", "3e-3",
      "--dropout", "0.2", "--engine", "rowwise"],
+    # outside the register-resident encoders' envelope: the shape-generic layers (csrc/seq_layers.hip), dense updates, hipGraph replay
+    ["--model_name", "SASRec", "--emb_size", "128", "--num_layers", "2", "--num_heads", "8", "--history_max", "10", "--lr", "2e-3",
+     "--dropout", "0.2"],
+    ["--model_name", "SASRec", "--emb_size", "48", "--num_layers", "5", "--num_heads", "3", "--history_max", "10", "--lr", "2e-3"],
 ])
 def test_cli_neumf_and_sasrec(model_args, dataset_root, tmp_path, cuda):
     import main
