@@ -645,9 +645,22 @@ SECONDARY_LEGS = (   # name, bench.py arguments, seconds of CPU baseline (None: 
     ("neumf", ["--workload", "neumf"], 22.0),
     ("sasrec", ["--workload", "sasrec"], 12.0),
     ("deepfm_b1024", ["--workload", "deepfm"], 2.0),
-    ("neumf_100M", ["--workload", "neumf", "--items", "100000001", "--users", "10000001"], None),
-    ("deepfm_b131072", ["--workload", "deepfm", "--batch", "131072", "--steps", "10", "--warmup", "3"], None),
+    ("neumf_100M", ["--workload", "neumf", "--items", "100000001", "--users", "10000001"], None),    # CPU: see _borrow_cpu_baseline
+    ("deepfm_b131072", ["--workload", "deepfm", "--batch", "131072", "--steps", "10", "--warmup", "3"], 9.0),
 )
+
+
+def _borrow_cpu_baseline(out):
+    """`neumf_100M` gets the CPU figure of the `neumf` leg as an UPPER BOUND: the port's dense step (zero-filled [n_rows, d]
+    gradients, index_add, torch.optim over every row -- the reference's semantics) costs at least as much on tables ten times
+    the size, and the four 100 M / 10 M-row tables with their dense gradients (226 GB) do not fit the time this command may take"""
+    src, dst = out.get("neumf") or {}, out.get("neumf_100M")
+    if isinstance(dst, dict) and "cpu_baseline" not in dst and isinstance(src.get("cpu_baseline"), dict) and "value" in dst:
+        cb = dict(src["cpu_baseline"])
+        cb["bound"] = "upper"
+        cb["sample"] = ("UPPER BOUND, taken from the `neumf` leg of this run (same batch, same head, 10,000,001-item / 1,000,001-user tables): "
+                        + str(cb.get("sample", "")) + " -- the dense optimizer step the port restates grows with the table rows")
+        dst["cpu_baseline"] = cb
 
 
 def secondary_single_gpu(args):
@@ -655,9 +668,9 @@ def secondary_single_gpu(args):
     on the same GPU, 20 timed steps after 5 of warm-up, live roofline phases; the three legs whose CPU port finishes in seconds
     (NeuMF on the 10 M-item tables, SASRec, DeepFM at the reference's B = 1,024) carry their own `cpu_baseline` (2 timed fit()
     iterations of oracle/torch_port.py after one warm-up iteration) while the wall-clock budget (RC_BENCH_SECONDARY_BUDGET_S,
-    default 70 s) has room for it; the budget keeps the driver's one command within minutes."""
+    default 85 s) has room for it; the budget keeps the driver's one command within minutes."""
     import subprocess
-    budget = float(os.environ.get("RC_BENCH_SECONDARY_BUDGET_S", "70"))
+    budget = float(os.environ.get("RC_BENCH_SECONDARY_BUDGET_S", "85"))
     t0 = time.perf_counter()
     out = {}
     for name, extra, cpu_s in SECONDARY_LEGS:
@@ -677,6 +690,7 @@ def secondary_single_gpu(args):
         except subprocess.TimeoutExpired:
             out[name] = {"failed": f"did not finish within {left:.0f} s"}
         out[name]["wall_s"] = round(time.perf_counter() - t_leg, 1)
+    _borrow_cpu_baseline(out)
     return out
 
 

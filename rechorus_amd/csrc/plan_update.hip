@@ -196,6 +196,11 @@ __device__ __forceinline__ void plan_rows_indexed_body(const PlanUpdArgs& a, int
     rc_plan_row e;
     e.row = 0; e.start = 0; e.n = 0; e.reserved = 0;
     if (gi < nr) e = sd.rows[gi];
+#ifdef RC_X_SKIP_PAIR_ROWS
+    // EXPERIMENT ONLY (wrong results): rows with exactly two occurrences are dropped -- the upper bound of what this launch would save
+    // if they were resolved inside the fused kernel (profiles/r09_bprmf_pair_ticket_negative.txt)
+    if (e.n == 2) e.n = 0;
+#endif
     const bool shortrow = e.n >= 1 && e.n <= (uint32_t)kPlanLongSeg;
     // the first FOUR occurrences of the row are resolved here (64 rows' chains together); a row's fifth and later ones walk the
     // chain on their own in the data phase.  (With two, a third occurrence -- 17 % of the multi-occurrence rows of config 2, so

@@ -246,34 +246,64 @@ def _probe_feed(model, kind, device):
     return feed
 
 
+last_miss_reason = None     # why the last bind_known_head call left a model file on its own route (None: it bound, or was not asked)
+
+
+def _miss(log, model, reason):
+    """a model file keeps its own (adopted-tables) route: say so once, with the reason, where main.py's log shows it"""
+    global last_miss_reason
+    last_miss_reason = reason
+    log.info("Known-head recognition: %s keeps the model file's own head (torch layers over the engine's tables): %s",
+             type(model).__name__, reason)
+    return None
+
+
+def _overridden_hooks(model, base_cls):
+    """training hooks of the model file that the fused step would bypass: per-group optimizer settings (customize_parameters, e.g.
+    the reference's Chorus.py:179-196) and per-epoch actions"""
+    out = []
+    for hook in ("customize_parameters", "actions_before_epoch", "actions_after_train"):
+        theirs, ours = getattr(type(model), hook, None), getattr(base_cls, hook, None)
+        if theirs is not None and ours is not None and getattr(theirs, "__func__", theirs) is not getattr(ours, "__func__", ours):
+            out.append(hook)
+    return out
+
+
 def bind_known_head(model, log=logging.getLogger(__name__)):
     """Recognise a BPRMF / NeuMF / SASRec / FM-family head (see the module docstring) and bind the plugin's fused head to the instance.
-    Returns the kind that was bound, or None (the model is left exactly as it was).  The model must be on the GPU with its
-    tables adopted (hnn.adopt_embeddings)."""
+    Returns the kind that was bound, or None (the model is left exactly as it was; for a model file the reason is logged and kept
+    in `last_miss_reason`).  The model must be on the GPU with its tables adopted (hnn.adopt_embeddings)."""
+    global last_miss_reason
+    last_miss_reason = None
     if hasattr(model, "hip_train_step") or getattr(type(model), "_rc_bound_head", None) is not None:
         return None     # the plugin's own class (or a model file that brings its own fused step); bound already
     if (type(model).__module__ or "").startswith("models."):
         return None     # the plugin's own model files
     try:
         kind = _context_kind(model)
+        base = _mirror("models.BaseModel")
         if kind is None:
-            base = _mirror("models.BaseModel")
-            if not isinstance(model, base.GeneralModel) or type(model).loss is not base.GeneralModel.loss:
-                return None     # list-wise losses: no fused step of these heads implements them
+            if not isinstance(model, base.GeneralModel):
+                return _miss(log, model, "not a GeneralModel / ContextModel / ContextCTRModel head")
+            if type(model).loss is not base.GeneralModel.loss:
+                return _miss(log, model, "its loss is not GeneralModel's BPR loss (list-wise / custom losses have no fused step)")
             kind = _kind(model)
     except Exception as e:     # a model file this module does not understand keeps its route
-        log.debug("known-head recognition skipped: %r", e)
-        return None
+        return _miss(log, model, "recognition raised %r" % (e,))
     if kind is None:
-        return None
+        return _miss(log, model, "parameters / attributes match none of BPRMF, NeuMF, SASRec, FM, WideDeep, DeepFM")
+    if kind not in CONTEXT_HEADS:      # hip_train_step trains with one (lr, l2) pair and calls none of these hooks
+        hooks = _overridden_hooks(model, base.BaseModel)
+        if hooks:
+            return _miss(log, model, "%s-shaped, but it overrides %s, which the fused step would bypass" % (kind, ", ".join(hooks)))
     p = next(model.parameters())
     if not p.is_cuda:
-        return None
+        return _miss(log, model, "%s-shaped, but the model is not on the GPU" % kind)
     h = forward_hash(type(model))
     known = h is not None and h in KNOWN_FORWARD_HASHES[kind]
     if not known and float(model.dropout) > 0:
-        log.info("%s-shaped model with an edited forward and dropout > 0: keeping the model file's own head", kind)
-        return None
+        return _miss(log, model, "%s-shaped, but its forward is not one of the known syntax trees and dropout > 0 (a probe batch cannot "
+                                 "verify a stochastic forward)" % kind)
     cls = type(model)
     was_training = model.training
     seed_added = False
@@ -305,8 +335,7 @@ def bind_known_head(model, log=logging.getLogger(__name__)):
             del model._buffers["drop_seed"]
             model._non_persistent_buffers_set.discard("drop_seed")
         model.train(was_training)
-        log.warning("%s-shaped model, but the fused head does not reproduce its forward (%s): keeping the model file's own head", kind, e)
-        return None
+        return _miss(log, model, "%s-shaped, but the fused head does not reproduce its forward on a probe batch (%s)" % (kind, e))
     model.train(was_training)
     what = "one-launch field gathers / fused FM term and CTR head" if kind in CONTEXT_HEADS else "fused forward / hip_train_step / --test_all scorer"
     log.info("Recognised the %s head%s: %s bound to %s", kind, "" if known else " (edited forward, verified on a probe batch)", what,

@@ -56,6 +56,14 @@ def test_reference_model_files_are_recognised(sub, name, argv, monkeypatch):
     assert dropin._kind(model) == name
     assert not hasattr(model, "hip_train_step")
     assert dropin.bind_known_head(model) is None and not hasattr(model, "hip_train_step")   # CPU model: nothing is bound
+    assert "not on the GPU" in dropin.last_miss_reason          # ... and main.py's log says why
+    # a model file that overrides a training hook the fused step would bypass (per-group optimizer settings, e.g. the reference's
+    # Chorus.py:179-196) keeps its own route whatever its forward looks like
+    sub_cls = type(name, (cls,), {"customize_parameters": lambda self: [{"params": list(self.parameters()), "lr": 1e-2}],
+                                  "__module__": cls.__module__})
+    hooked = sub_cls.__new__(sub_cls)
+    hooked.__dict__.update(model.__dict__)
+    assert dropin.bind_known_head(hooked) is None and "customize_parameters" in dropin.last_miss_reason
     # the plugin's own class of the same name brings its fused step and is left alone
     monkeypatch.delenv("RECHORUS_MODEL_DIRS")
     import main

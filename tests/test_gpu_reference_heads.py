@@ -117,6 +117,7 @@ def test_an_edited_head_keeps_its_own_route(dataset_root, tmp_path, monkeypatch,
     assert hnn.adopt_embeddings(model) == 2
     assert dropin._kind(model) == "BPRMF"
     assert dropin.bind_known_head(model) is None
+    assert "does not reproduce its forward on a probe batch" in dropin.last_miss_reason      # (main.py's log carries the reason)
     assert type(model) is cls and not hasattr(model, "hip_train_step") and "drop_seed" not in dict(model.named_buffers())
     # ... and the unedited file binds, with the model file's class still underneath
     monkeypatch.setenv("RECHORUS_MODEL_DIRS", os.path.join(FIX, "general"))
@@ -124,7 +125,7 @@ def test_an_edited_head_keeps_its_own_route(dataset_root, tmp_path, monkeypatch,
     torch.manual_seed(0)
     m2 = cls2(args, argparse.Namespace(n_users=20, n_items=50)).to(cuda)
     hnn.adopt_embeddings(m2)
-    assert dropin.bind_known_head(m2) == "BPRMF"
+    assert dropin.bind_known_head(m2) == "BPRMF" and dropin.last_miss_reason is None
     assert isinstance(m2, cls2) and type(m2).__name__ == "BPRMF" and hasattr(m2, "hip_train_step") and m2.candidate_permutation_equivariant
     assert dropin.bind_known_head(m2) is None       # idempotent: already bound
 
