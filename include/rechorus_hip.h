@@ -316,6 +316,8 @@ int rc_dense_update_multi_dev(float* const* W, const float* const* G, float* con
                               const int64_t* n, const rc_opt_hyper* h, int n_tensors, const int64_t* step_dev,
                               rc_stream_t stream);
 int rc_step_increment(int64_t* step_dev, rc_stream_t stream);
+/* the same for two counters in one launch (a tower's dropout seed and Adam's step count of the same training step) */
+int rc_step_increment2(int64_t* a_dev, int64_t* b_dev, rc_stream_t stream);
 /* torch.optim.Adam over dense gradients of embedding tables whose batch touches few rows (helpers/BaseRunner.py:110-114,206 with
  * the nn.Embedding tables of models/context/FM.py:33-41 at batch_size 1024: 0.4 % of the rows have a gradient), WITHOUT a dense
  * gradient: tensor t is [n[t] / row_w[t], row_w[t]] with one int32 flag per row, and a row whose flag equals (int32) step_dev[0]

@@ -126,6 +126,7 @@ SIGNATURES = {
     "rc_dense_update_multi": (_i, [_p, _p, _p, _p, _p, _p, _i, _p]),
     "rc_dense_update_multi_dev": (_i, [_p, _p, _p, _p, _p, _p, _i, _p, _p]),
     "rc_step_increment": (_i, [_p, _p]),
+    "rc_step_increment2": (_i, [_p, _p, _p]),
     "rc_dense_update_rows_dev": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p]),
     "rc_stage_batch": (_i, [_p, _i64, _p, _i64, _p, _i64, _p, _p]),
     "rc_segmented_update2": (_i, [_p, _p, _p, _i, _p, _p, _i64, _p, _p, _p, _i, _p, _i64, _i64, _i64, _hp, _p, _p,

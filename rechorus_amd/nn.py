@@ -890,6 +890,9 @@ class HipOptimizer:
             run += t.shape[0]
         offs.append(run)
         self._rows = {"params": params, "hypers": hypers, "offs": offs, "F": len(tables), "G": None}
+        # step() increments the count in front of its update launch; nothing between this gather (which reads count + 1) and that
+        # launch reads it, so a tower's dropout-seed increment may take it along (engine.defer_increment)
+        engine.defer_increment(self._step_dev)
         return st["flags"], self._step_dev
 
     def _rows_items(self, Gs):
@@ -908,8 +911,11 @@ class HipOptimizer:
         rows of the abandoned batch would read stale gradient rows"""
         if self._rows is not None:
             self._rows = None
+            folded = engine.take_deferred(self._step_dev)
             if self._rows_state is not None and not torch.cuda.is_current_stream_capturing():
                 self._rows_state["flags"].zero_()
+                if folded:      # the count went up with a tower's seed although no update followed: the step is forgotten
+                    self._step_dev.sub_(1)
 
     def rows_scratch(self):
         return self._rows_state["G"]
@@ -925,19 +931,21 @@ class HipOptimizer:
     @torch.no_grad()
     def step(self):
         """every parameter with a gradient in ONE rc_dense_update_multi call (per 36 tensors)"""
-        self.step_count += 1
         items = []
         dev = None
         rows = self._rows
         if rows is not None and rows["G"] is None:
             raise RuntimeError("HipOptimizer rows mode: step() without the backward pass of the training forward")
+        if rows is not None:      # (validated before anything is counted: a refused step leaves the optimizer as it was)
+            mine = {id(q) for q in rows["params"]}
+            if any(p.grad is not None and id(p) in mine for g in self.param_groups for p in g["params"]):
+                raise RuntimeError("HipOptimizer rows mode: a table of the rows-mode gather also received a dense gradient")
+        self.step_count += 1
         for g in self.param_groups:
             h = engine.make_hyper(self.name, lr=g["lr"], l2=g["weight_decay"], step=max(self.step_count, 1))
             for p in g["params"]:
                 if p.grad is None:
                     continue
-                if rows is not None and any(q is p for q in rows["params"]):
-                    raise RuntimeError("HipOptimizer rows mode: a table of the rows-mode gather also received a dense gradient")
                 st = self.state.setdefault(p, {})
                 m = v = None
                 # (state created once: `st.setdefault(k, torch.zeros_like(p))` would allocate and zero-fill a tensor of the
@@ -957,7 +965,8 @@ class HipOptimizer:
         if rows is not None:
             # the tables (gradient rows where stamped, g = 0 elsewhere) and every other parameter in one launch
             everything = [(w, gr, h, m, v, None, 0) for w, gr, h, m, v in items] + self._rows_items(rows["G"])
-            engine.step_increment(self._step_dev)
+            if not engine.take_deferred(self._step_dev):      # (else a tower's seed increment took the count along)
+                engine.step_increment(self._step_dev)
             engine.dense_update_rows(everything, self._step_dev, touched=2)
             self._rows = None
             return

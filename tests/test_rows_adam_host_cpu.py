@@ -108,9 +108,10 @@ def test_rows_mode_refusals_and_abort(monkeypatch):
     flags, step_dev = opt.rows_begin(t, t1)
     with pytest.raises(RuntimeError, match="not followed by backward"):
         opt.rows_begin(t, t1)
+    count = opt.step_count
     with pytest.raises(RuntimeError, match="without the backward pass"):
         opt.step()
-    opt.step_count -= 1
+    assert opt.step_count == count       # a refused step is not counted
     flags[2] = 1
     opt.rows_abort()
     assert opt._rows is None and int(flags.max().item()) == 0
@@ -118,5 +119,32 @@ def test_rows_mode_refusals_and_abort(monkeypatch):
     flags, step_dev = opt.rows_begin(t, t1)
     opt.rows_grads(opt.rows_scratch()[:20].view(5, 4), opt.rows_scratch()[20:].view(5, 1))
     t[0].grad = torch.zeros(5, 4)
+    count = opt.step_count
     with pytest.raises(RuntimeError, match="also received a dense gradient"):
         opt.step()
+    assert opt.step_count == count
+
+
+def test_a_towers_seed_increment_takes_adams_step_count_along(monkeypatch):
+    """engine.defer_increment / step_increment / take_deferred: between the gather of a rows-mode step (which reads count + 1) and the
+    update launch nothing reads Adam's device step count, so the next increment of ANOTHER counter (a tower's dropout seed) bumps both
+    in one launch (rc_step_increment2); without such an increment the optimizer bumps its own; an aborted step gives the count back"""
+    from rechorus_amd import _lib, engine, nn as hnn
+    launches = []
+
+    def call(name, *a):
+        launches.append(name)
+    monkeypatch.setattr(_lib, "call", call)
+    monkeypatch.setattr(engine, "_ptr", lambda t, *a, **k: t)
+    monkeypatch.setattr(engine, "_stream", lambda: None)
+    seed, count, other = torch.zeros(1, dtype=torch.int64), torch.zeros(1, dtype=torch.int64), torch.zeros(1, dtype=torch.int64)
+    engine.defer_increment(count)
+    engine.step_increment(seed)                     # folds the promised increment in
+    assert launches == ["rc_step_increment2"]
+    engine.step_increment(other)                    # a later increment is on its own again
+    assert launches[-1] == "rc_step_increment" and engine.take_deferred(count) and not engine.take_deferred(count)
+    engine.defer_increment(count)
+    assert not engine.take_deferred(count)          # nobody came by: the owner increments itself
+    engine.defer_increment(count)
+    engine.step_increment(count)                    # the owner's own counter is never "another counter"
+    assert launches[-1] == "rc_step_increment" and not engine.take_deferred(count)
