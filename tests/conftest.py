@@ -32,18 +32,48 @@ def load_golden(name):
         return {k: z[k] for k in z.files}
 
 
-def assert_close(got, want, rtol=1e-5, atol_scale=1e-5, what="", abs_floor=0.0):
+def _tolerance_record(kind, what, rtol, atol_scale, abs_floor, err, tol, want):
+    """RC_TOL_REPORT=<file>: every comparison appends what it allowed and what it observed (tools/tolerance_report.py turns the
+    file into profiles/r09_tolerances.txt: the largest observed error next to every tolerance above 1e-5)"""
+    path = os.environ.get("RC_TOL_REPORT")
+    if not path or not err.size:
+        return
+    import json
+    scale = float(np.max(np.abs(want))) if want.size else 0.0
+    with np.errstate(divide="ignore", invalid="ignore"):
+        used = float(np.nanmax(np.where(tol > 0, err / tol, np.where(err > 0, np.inf, 0.0))))
+    rec = {"test": os.environ.get("PYTEST_CURRENT_TEST", "").split(" ")[0], "kind": kind, "what": str(what), "rtol": float(rtol),
+           "atol_scale": float(atol_scale), "abs_floor": float(abs_floor), "n": int(err.size), "max_err": float(err.max()), "max_err_over_scale": float(err.max() / scale) if scale > 0 else 0.0,
+           "tolerance_used": used}
+    try:
+        with open(path, "a") as f:
+            f.write(json.dumps(rec) + "\n")
+    except Exception:      # the record is evidence, never the reason a comparison fails
+        pass
+
+
+# Round 6: every comparison of the GPU suite was recorded once (RC_TOL_REPORT, profiles/r09_tolerances.txt).  Of 4,218 fp32
+# comparisons only those of three tests ever used more than a third of what 2e-5 allows (whole-batch sums at B = 65,536 / 131,072,
+# parameters after two Adam steps): whatever a call site asks for, rtol and atol_scale are CAPPED here at 2e-5 -- twice the north
+# star's 1e-5, the headroom being what a different fp32 summation order costs -- unless it passes loose="<why>".
+TOL_CAP = 2e-5
+
+
+def assert_close(got, want, rtol=1e-5, atol_scale=1e-5, what="", abs_floor=0.0, loose=None):
     """|got-want| <= rtol*|want| + atol_scale*max|want|  (north_star: 1e-5 relative fp32;
     the absolute term covers near-cancelling dot products whose magnitude is far below the
     tensor's scale).  abs_floor: for tensors that are pure round-off in the reference (e.g. the
     key-bias gradient of softmax attention, exactly 0 in exact arithmetic), a floor tied to the
-    magnitude of the sibling gradients."""
+    magnitude of the sibling gradients.  rtol / atol_scale above TOL_CAP take effect only with loose="<reason>"."""
+    if loose is None:
+        rtol, atol_scale = min(rtol, TOL_CAP), min(atol_scale, TOL_CAP)
     got = np.asarray(got, dtype=np.float64)
     want = np.asarray(want, dtype=np.float64)
     assert got.shape == want.shape, f"{what}: shape {got.shape} != {want.shape}"
     scale = float(np.max(np.abs(want))) if want.size else 0.0
     err = np.abs(got - want)
     tol = rtol * np.abs(want) + atol_scale * scale + abs_floor
+    _tolerance_record("close", what, rtol, atol_scale, abs_floor, err, np.broadcast_to(tol, err.shape), want)
     bad = err > tol
     if bad.any():
         i = np.unravel_index(np.argmax(err - tol), err.shape)
@@ -64,6 +94,8 @@ def assert_update_close(W, W0, Wref, what="", rtol=1e-4, extra_atol=0.0, outlier
     floor = 8 * np.finfo(np.float32).eps * float(np.max(np.abs(Wref)))
     err = np.abs(got - want)
     tol = rtol * np.abs(want) + 1e-5 * float(np.max(np.abs(want))) + floor + extra_atol
+    _tolerance_record("update", what, rtol, 1e-5, floor + extra_atol,
+                      err if exclude is None else np.where(np.asarray(exclude, dtype=bool), 0.0, err), tol, want)
     bad = err > tol
     if exclude is not None:
         # the caller NAMES the ill-conditioned elements (e.g. |g| < 1e-7 under Adam: a gradient that is summation-order noise is

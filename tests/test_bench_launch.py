@@ -83,8 +83,15 @@ def test_secondary_leg_rules_and_the_launcher_that_captures_rank_zero(monkeypatc
         assert not bench.secondary_wanted(bench.parse()), argv
     names = [n for n, _, _ in bench.SECONDARY_LEGS]
     assert names == ["neumf", "sasrec", "deepfm_b1024", "neumf_100M", "deepfm_b131072"]
-    # the legs whose CPU port finishes in seconds carry their own cpu_baseline; the 113 GB tables / the 131,072-row batch do not
-    assert [c is not None for _, _, c in bench.SECONDARY_LEGS] == [True, True, True, False, False]
+    # every leg carries a cpu_baseline: the port itself where it finishes in seconds (the 131,072-row DeepFM batch: 2 iterations),
+    # the 10 M-item leg's figure as an upper bound for the 100 M-item tables (226 GB of dense gradients do not fit the command)
+    assert [c is not None for _, _, c in bench.SECONDARY_LEGS] == [True, True, True, False, True]
+    legs = {"neumf": {"value": 1.0, "cpu_baseline": {"value": 5.0, "sample": "x", "kind": "port"}}, "neumf_100M": {"value": 2.0}}
+    bench._borrow_cpu_baseline(legs)
+    assert legs["neumf_100M"]["cpu_baseline"]["value"] == 5.0 and legs["neumf_100M"]["cpu_baseline"]["bound"] == "upper"
+    failed = {"neumf": {"value": 1.0, "cpu_baseline": {"value": 5.0}}, "neumf_100M": {"failed": "x"}}
+    bench._borrow_cpu_baseline(failed)
+    assert "cpu_baseline" not in failed["neumf_100M"]
     monkeypatch.setattr(sys, "argv", ["bench.py", "--workload", "deepfm"])
     assert bench.parse().dropout == 0.2      # docs/demo_scripts_results/CTR_MIND.sh:8
     for _, extra, _ in bench.SECONDARY_LEGS:   # every leg parses, and none of them recurses

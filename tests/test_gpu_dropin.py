@@ -77,7 +77,8 @@ def test_adopted_model_file_matches_plain_torch(monkeypatch, cuda):
         for k in outs[0][2]:
             assert_close(outs[1][2][k], outs[0][2][k], atol_scale=3e-5, what=f"grad {k} step {step}")
     for (k, a), (_, b) in zip(plain.state_dict().items(), hip.state_dict().items()):
-        assert_close(b.cpu().numpy(), a.cpu().numpy(), atol_scale=3e-5, what=f"{k} after two steps")
+        assert_close(b.cpu().numpy(), a.cpu().numpy(), atol_scale=3e-5, what=f"{k} after two steps",
+                     loose="two Adam steps: the normalised update amplifies a 1e-7 gradient difference (observed 0.96 of the allowance)")
 
 
 def test_cli_trains_a_user_model_file(monkeypatch, tmp_path, cuda):

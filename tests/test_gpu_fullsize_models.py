@@ -14,6 +14,10 @@ import torch
 
 from conftest import assert_close, assert_update_close
 
+# why these comparisons keep more than conftest.TOL_CAP: a dense-layer gradient at the bench's batch is a sum of 65,536 x 5 (131,072)
+# signed fp32 terms, in a different order than numpy's; observed at most 0.7 of the allowance (profiles/r09_tolerances.txt)
+BIG_SUM = "whole-batch fp32 sums at B = 65,536 / 131,072"
+
 pytestmark = pytest.mark.gpu
 
 
@@ -100,9 +104,9 @@ def test_neumf_fused_step_at_the_bench_shape_whole_batch_vs_oracle(n_items, n_us
     tol = 3e-5
     assert_close(out["loss_vec"].cpu().numpy(), rows, what="loss rows", atol_scale=tol)
     assert_close(float(loss.item()), float(rows.astype(np.float64).mean()), rtol=1e-5, what="loss")
-    assert_close(out["W1"].cpu().numpy(), G["mlp.0.weight"], what="dW1", rtol=2e-5, atol_scale=5e-5)
-    assert_close(out["b1"].cpu().numpy(), G["mlp.0.bias"], what="db1", rtol=2e-5, atol_scale=5e-5)
-    assert_close(out["w_out"].cpu().numpy(), G["prediction.weight"][0], what="dw_out", rtol=2e-5, atol_scale=5e-5)
+    assert_close(out["W1"].cpu().numpy(), G["mlp.0.weight"], what="dW1", rtol=2e-5, atol_scale=5e-5, loose=BIG_SUM)
+    assert_close(out["b1"].cpu().numpy(), G["mlp.0.bias"], what="db1", rtol=2e-5, atol_scale=5e-5, loose=BIG_SUM)
+    assert_close(out["w_out"].cpu().numpy(), G["prediction.weight"][0], what="dw_out", rtol=2e-5, atol_scale=5e-5, loose=BIG_SUM)
     for key, tab in (("gu_mf", "mf_u"), ("gu_mlp", "mlp_u")):
         T = np.zeros(Pn[NAMES[tab]].shape, dtype=np.float64)
         np.add.at(T, uid_c, out[key].cpu().numpy().astype(np.float64))
@@ -224,6 +228,6 @@ def test_deepfm_step_at_the_large_bench_batch_whole_batch_vs_oracle(cuda):
         # dense layers at 5e-5; table rows at 1e-4 of the table's largest gradient: an element of a rarely seen row is ONE 512-long fp32
         # dot product (dh = dz W) plus the FM term, which nearly cancel in places -- summation-order noise of a different K order
         table = name.startswith("context_embedding") or name.startswith("linear_embedding")
-        assert_close(prm.grad.cpu().numpy().reshape(G[name].shape), G[name], what="grad " + name, rtol=2e-5, atol_scale=1e-4 if table else 5e-5,
+        assert_close(prm.grad.cpu().numpy().reshape(G[name].shape), G[name], what="grad " + name, rtol=2e-5, atol_scale=1e-4 if table else 5e-5, loose=BIG_SUM,
                      abs_floor=(1e-6 * scale + (flip.get(int(name.split(".")[2]), 0.0) if name.endswith(".bias") else 0.0))
                      if name.startswith("deep_layers") else 0.0)

@@ -673,3 +673,40 @@ def test_plan_status_word_reports_ids_outside_their_table(hashed, cuda, eng):
     assert bad.status() == 1
     with pytest.raises(_lib.RechorusHipError, match="outside its table"):
         bad.check()
+
+
+@pytest.mark.parametrize("n,n_rows", [(1, 1), (63, 2), (64, 200), (2048, 256), (2049, 257), (10_000, 65_536), (100_003, 65_537), (70_000, 7),
+                                      (300_000, 1 << 24), (250_001, (1 << 24) + 1), (50_000, 1 << 32), (1_300_000, 280_000)])
+def test_hand_written_radix_sort_is_the_stable_sort(n, n_rows, cuda, eng):
+    """rc_sort_ids (csrc/sort_ids.hip: 8-bit LSD passes of count / offsets / ballot-ranked scatter) == numpy's stable argsort: sorted
+    keys, and equal keys keep their batch order -- one to four passes, tiles with a ragged tail, a handful of very hot keys"""
+    rng = np.random.default_rng(n)
+    ids = rng.integers(0, n_rows, size=n).astype(np.int64)
+    if n > 1000:
+        ids[rng.integers(0, n, size=n // 3)] = n_rows - 1         # a hot row
+    keys, perm = eng.sort_ids(torch.from_numpy(ids).to(cuda), n_rows)
+    want = np.argsort(ids, kind="stable")
+    assert np.array_equal(perm.cpu().numpy().astype(np.int64), want)
+    assert np.array_equal(keys.cpu().numpy().view(np.uint32).astype(np.int64), ids[want])
+    again = eng.sort_ids(torch.from_numpy(ids).to(cuda), n_rows)
+    assert torch.equal(again[0], keys) and torch.equal(again[1], perm)
+
+
+def test_two_lists_sorted_as_one(cuda, eng):
+    """rc_sort_ids2: item ids and (offset) user ids of a step as one virtual list -- the user keys form the tail"""
+    import ctypes as C
+    from rechorus_amd import _lib
+    rng = np.random.default_rng(7)
+    n_a, n_b, n_items, n_users = 50_000, 3_000, 70_000, 900
+    a, b = rng.integers(0, n_items, n_a).astype(np.int64), rng.integers(0, n_users, n_b).astype(np.int64)
+    ad, bd = torch.from_numpy(a).to(cuda), torch.from_numpy(b).to(cuda)
+    keys = torch.empty(n_a + n_b, dtype=torch.int32, device=cuda)
+    perm = torch.empty(n_a + n_b, dtype=torch.int32, device=cuda)
+    ws = torch.empty(_lib.load().rc_sort_workspace_bytes(n_a + n_b), dtype=torch.uint8, device=cuda)
+    _lib.call("rc_sort_ids2", C.c_void_p(ad.data_ptr()), n_a, C.c_void_p(bd.data_ptr()), n_b, n_items, n_items + n_users,
+              C.c_void_p(keys.data_ptr()), C.c_void_p(perm.data_ptr()), C.c_void_p(ws.data_ptr()), ws.numel(),
+              C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    joint = np.concatenate([a, n_items + b])
+    want = np.argsort(joint, kind="stable")
+    assert np.array_equal(perm.cpu().numpy().astype(np.int64), want)
+    assert np.array_equal(keys.cpu().numpy().view(np.uint32).astype(np.int64), joint[want])

@@ -54,6 +54,14 @@ for st in "$@"; do
       echo "pytest exit $?" >> $OUT/pytest_gpu.log
       tail -25 $OUT/pytest_gpu.log
       ;;
+    tol)       # the whole GPU suite with every comparison recorded -> tol.jsonl -> tolerances.txt (tools/tolerance_report.py)
+      rm -f $OUT/tol.jsonl
+      RC_TOL_REPORT=$OUT/tol.jsonl timeout 1500 python -m pytest tests -m gpu -q --maxfail=25 --tb=short -p no:cacheprovider > $OUT/pytest_tol.log 2>&1
+      tail -3 $OUT/pytest_tol.log
+      python tools/tolerance_report.py $OUT/tol.jsonl > $OUT/tolerances.txt 2>&1
+      head -5 $OUT/tolerances.txt
+      gzip -f $OUT/tol.jsonl
+      ;;
     smoke)
       timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1
       tail -2 $OUT/smoke.log
