@@ -414,6 +414,14 @@ int rc_small_row_sums_again(int64_t n, int64_t n_rows, const float* src, int d, 
  * sums in the SAME launch: grouping + one row-sums kernel.                                                                     */
 int rc_small_row_sums_pair(const int64_t* ids, int64_t n, int64_t n_rows, const float* src, int d, float* out,
                            const float* src1, float* out1, void* ws, size_t ws_bytes, rc_stream_t stream);
+/* rc_small_row_sums_pair over the gradient blocks of a field list that holds numeric features (rc_gather_fields_mixed: their
+ * occurrences carry id -1 and take no part in the grouping): src = gV [B * C, F, d] as n = B * C * F occurrence rows, src1 = gL, and
+ * the numeric fields' weight gradients (rc_numeric_field_grads: values / per_row / kind / field / dW / dw1, HOST arrays of length
+ * n_numeric <= 4) are formed by one extra workgroup each of the SAME launch.  d a multiple of 4, 16 <= d <= 128.                   */
+int rc_small_row_sums_pair_numeric(const int64_t* ids, int64_t n, int64_t n_rows, const float* src, int d, float* out,
+                                   const float* src1, float* out1, const void* const* values, const int* per_row, const int* kind,
+                                   const int* field, int n_numeric, int F, int64_t B, int C, float* const* dW, float* const* dw1,
+                                   void* ws, size_t ws_bytes, rc_stream_t stream);
 
 /* The CTR head of the context models in one pass: z = bias[0] + sum_f lin[i, f] (+ term1[i]) (+ term2[i])
  * (models/context/FM.py:59-60, DeepFM.py:27, WideDeep.py:46), p = sigmoid(z) (BaseContextModel.py:74-78), the per-row term of

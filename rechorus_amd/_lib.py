@@ -139,6 +139,7 @@ SIGNATURES = {
     "rc_small_row_sums": (_i, [_p, _i64, _i64, _p, _i, _p, _p, _sz, _p]),
     "rc_small_row_sums_again": (_i, [_i64, _i64, _p, _i, _p, _p, _sz, _p]),
     "rc_small_row_sums_pair": (_i, [_p, _i64, _i64, _p, _i, _p, _p, _p, _p, _sz, _p]),
+    "rc_small_row_sums_pair_numeric": (_i, [_p, _i64, _i64, _p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i64, _i, _p, _p, _p, _sz, _p]),
     "rc_segmented_rows_workspace_bytes": (_sz, [_i64, _i64, _i]),
     "rc_segmented_update_rows": (_i, [_p, _p, _p, _i, _i64, _p, _p, _i64, _p, _p, _p, _i, _p, _i64, _hp, _p, _p, _sz, _p]),
     "rc_segmented_update_rows_dev": (_i, [_p, _p, _p, _i, _i64, _p, _p, _i64, _p, _p, _p, _i, _p, _i64, _hp, _p, _p, _p, _sz, _p]),

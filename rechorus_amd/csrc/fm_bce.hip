@@ -11,6 +11,7 @@
 // Both are HBM-bound streaming kernels: one lane-group (d/4 lanes, a float4 each) per instance walks
 // the F field vectors once (forward) or twice (backward: the field sum, then the per-field gradient).
 #include "common.hpp"
+#include "numeric_grads.hpp"
 
 namespace rc {
 
@@ -328,8 +329,6 @@ extern "C" int rc_bce_prob_fwd_bwd(const float* p, const float* y, int64_t n, fl
 // ONE sort + ONE segmented sum for all F dense gradients instead of F of each).
 namespace rc {
 
-constexpr int kMaxFields = 48;
-
 struct FieldArgs {
   const float* table[kMaxFields];
   const int64_t* ids[kMaxFields];
@@ -348,13 +347,6 @@ struct FieldArgs {
 // over the wave, so the table / id pointers are scalar loads from the kernel arguments and the lookups of four fields are in flight
 // together.  (One thread per output element with the field decoded from the element index indexed the pointer arrays per lane --
 // the compiler keeps such an array in scratch -- and paid three 64-bit divisions per element: 93 us for 268 MB out at B = 131,072.)
-// the value of a numeric field ('*_f' features, models/context/FM.py:47-48: feed_dict[f].float()) at batch position i
-__device__ __forceinline__ float field_value(int kind, const void* p, int64_t i) {
-  if (kind == RC_FIELD_F32) return static_cast<const float*>(p)[i];
-  if (kind == RC_FIELD_F64) return (float)static_cast<const double*>(p)[i];
-  return (float)static_cast<const int64_t*>(p)[i];
-}
-
 // MIXED: some field is numeric -- nn.Linear(1, d, bias=False) on the feature's value (FM.py:38-41): its "row" is x * W[:, 0]
 // (table[f] = the d weights), its first-order value x * w1; cid carries numeric_key, no row flag is stamped.  The field index
 // is uniform over the wave, so the kind test is a scalar branch.
@@ -521,119 +513,36 @@ extern "C" int rc_gather_fields_mixed(const float* const* tables, const float* c
 // launch in ascending order (a batch of up to kNumericChunk rows: one launch writes the gradients themselves).  No atomics.
 namespace rc {
 
-constexpr int kNumericChunk = 1024;
-
 struct NumericGradArgs {
+  NumericCommon c;
   const void* values[kMaxFields];   // per numeric slot j
   float* dW[kMaxFields];            // [d]
   float* dw1[kMaxFields];           // [1]
   int kind[kMaxFields];
   int per_row[kMaxFields];
   int field[kMaxFields];            // the slot's field index in [0, F)
-  const float* gV;                  // [n, F, d] | null
-  const float* gL;                  // [n, F] | null
-  float* part;                      // [chunks][n_numeric][d + 1]
-  int64_t n;                        // B * C
-  int n_numeric, F, C, d;
 };
 
 constexpr int kNumericThreads = 1024;   // sixteen waves: 64 rows of a 64-float field vector per step, a 1,024-row chunk in two trips of eight
 
 template <int VEC>
 __global__ __launch_bounds__(kNumericThreads) void numeric_field_grads_kernel(NumericGradArgs a) {
-  __shared__ float red[kNumericThreads * VEC];
-  __shared__ float red1[kNumericThreads];
-  const int j = blockIdx.y, f = a.field[j];
-  const int dq = a.d / VEC;
-  const int lpr = dq < kNumericThreads ? dq : kNumericThreads;   // lanes per row
-  const int slots = kNumericThreads / lpr;                       // rows in flight per step
-  const int tid = threadIdx.x, l = tid % lpr, rs = tid / lpr;
-  const bool live = rs < slots;
-  const uint32_t r0 = blockIdx.x * (uint32_t)kNumericChunk;     // (n < 2^31: 32-bit row arithmetic, no 64-bit division per row)
-  const uint32_t r1 = (int64_t)r0 + kNumericChunk < a.n ? r0 + kNumericChunk : (uint32_t)a.n;
-  const int kind = a.kind[j];
-  const uint32_t cdiv = a.per_row[j] ? (uint32_t)a.C : 1u;      // a per-row feature's value sits at row / C
-  const void* xs = a.values[j];
-  const bool direct = gridDim.x == 1;
-  float* part = a.part + ((size_t)blockIdx.x * a.n_numeric + j) * (a.d + 1);
-  for (int c0 = 0; c0 < dq; c0 += lpr) {       // (one trip unless d > 1024 * VEC; workgroup-uniform)
-    const int cq = c0 + l < dq ? c0 + l : dq - 1;
-    const bool col = c0 + l < dq;
-    float acc[VEC];
-#pragma unroll
-    for (int c = 0; c < VEC; ++c) acc[c] = 0.f;
-    float acc1 = 0.f;
-    const bool first = c0 == 0 && l == 0 && a.gL != nullptr;   // this lane also forms the first-order weight's sum
-    if (live && a.gV) {
-      constexpr int U = 8;
-      for (uint32_t r = r0 + rs; r < r1; r += (uint32_t)slots * U) {
-        float x[U], g1[U];
-        float gv[U][VEC];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const uint32_t rr = r + (uint32_t)u * slots;
-          const bool in = rr < r1;
-          const uint32_t ra = in ? rr : r0;
-          x[u] = in ? field_value(kind, xs, cdiv == 1u ? ra : ra / cdiv) : 0.f;
-          const float* src = a.gV + ((size_t)ra * a.F + f) * a.d + (size_t)cq * VEC;
-          if (VEC == 4) {
-            const float4 t = *reinterpret_cast<const float4*>(src);
-            gv[u][0] = t.x; gv[u][1 % VEC] = t.y; gv[u][2 % VEC] = t.z; gv[u][3 % VEC] = t.w;
-          } else {
-            gv[u][0] = src[0];
-          }
-          g1[u] = (first && in) ? a.gL[(size_t)rr * a.F + f] : 0.f;
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-#pragma unroll
-          for (int c = 0; c < VEC; ++c) acc[c] += x[u] * gv[u][c];
-          acc1 += x[u] * g1[u];
-        }
-      }
-    } else if (live && first) {   // (only the first-order family reached the loss)
-      for (uint32_t r = r0 + rs; r < r1; r += slots) acc1 += field_value(kind, xs, cdiv == 1u ? r : r / cdiv) * a.gL[(size_t)r * a.F + f];
-    }
-    __syncthreads();   // (the previous trip's reads of red[])
-#pragma unroll
-    for (int c = 0; c < VEC; ++c) red[tid * VEC + c] = acc[c];
-    red1[tid] = acc1;
-    __syncthreads();
-    if (live && rs == 0) {
-      float t[VEC];
-#pragma unroll
-      for (int c = 0; c < VEC; ++c) t[c] = red[l * VEC + c];
-      float t1 = red1[l];
-      for (int q = 1; q < slots; ++q) {   // fixed order: slot 0, 1, ...
-#pragma unroll
-        for (int c = 0; c < VEC; ++c) t[c] += red[(q * lpr + l) * VEC + c];
-        t1 += red1[q * lpr + l];
-      }
-      if (a.gV && col) {
-#pragma unroll
-        for (int c = 0; c < VEC; ++c) {
-          if (direct) a.dW[j][cq * VEC + c] = t[c];
-          else part[cq * VEC + c] = t[c];
-        }
-      }
-      if (first) {
-        if (direct) a.dw1[j][0] = t1;
-        else part[a.d] = t1;
-      }
-    }
-  }
+  const int j = blockIdx.y;
+  NumericSlot sl;
+  sl.values = a.values[j]; sl.dW = a.dW[j]; sl.dw1 = a.dw1[j]; sl.kind = a.kind[j]; sl.per_row = a.per_row[j]; sl.field = a.field[j];
+  numeric_slot_grads<VEC, kNumericThreads, 8>(sl, a.c, j, blockIdx.x, gridDim.x == 1 && a.c.n <= kNumericChunk);
 }
 
 // chunk partials -> gradients, ascending chunk order; one thread per (slot, column)
 __global__ __launch_bounds__(kBlock) void numeric_field_reduce_kernel(NumericGradArgs a, int chunks) {
-  const int w = a.d + 1;
+  const int w = a.c.d + 1;
   const int t = blockIdx.x * kBlock + threadIdx.x;
-  if (t >= a.n_numeric * w) return;
+  if (t >= a.c.n_numeric * w) return;
   const int j = t / w, c = t - j * w;
-  if (c == a.d ? a.gL == nullptr : a.gV == nullptr) return;
+  if (c == a.c.d ? a.c.gL == nullptr : a.c.gV == nullptr) return;
   float s = 0.f;
-  for (int k = 0; k < chunks; ++k) s += a.part[((size_t)k * a.n_numeric + j) * w + c];
-  if (c == a.d) a.dw1[j][0] = s;
+  for (int k = 0; k < chunks; ++k) s += a.c.part[((size_t)k * a.c.n_numeric + j) * w + c];
+  if (c == a.c.d) a.dw1[j][0] = s;
   else a.dW[j][c] = s;
 }
 
@@ -663,20 +572,20 @@ extern "C" int rc_numeric_field_grads(const float* gV, const float* gL, const vo
     a.values[j] = values[j]; a.kind[j] = kind[j]; a.per_row[j] = per_row[j]; a.field[j] = field[j];
     a.dW[j] = dW ? dW[j] : nullptr; a.dw1[j] = dw1 ? dw1[j] : nullptr;
   }
-  a.gV = gV; a.gL = gL; a.n = B * C; a.n_numeric = n_numeric; a.F = F; a.C = C; a.d = d;
-  if (a.n == 0) {   // an empty batch: zero gradients
+  a.c.gV = gV; a.c.gL = gL; a.c.n = B * C; a.c.n_numeric = n_numeric; a.c.F = F; a.c.C = C; a.c.d = d;
+  if (a.c.n == 0) {   // an empty batch: zero gradients
     for (int j = 0; j < n_numeric; ++j) {
       if (gV) RC_HIP(hipMemsetAsync(a.dW[j], 0, (size_t)d * sizeof(float), s));
       if (gL) RC_HIP(hipMemsetAsync(a.dw1[j], 0, sizeof(float), s));
     }
     return RC_OK;
   }
-  const int64_t chunks = (a.n + kNumericChunk - 1) / kNumericChunk;
-  RC_REQUIRE(a.n < ((int64_t)1 << 31), "rc_numeric_field_grads: too many rows");
+  const int64_t chunks = (a.c.n + kNumericChunk - 1) / kNumericChunk;
+  RC_REQUIRE(a.c.n < ((int64_t)1 << 31), "rc_numeric_field_grads: too many rows");
   if (chunks > 1) {
-    RC_REQUIRE(ws != nullptr && ws_bytes >= rc_numeric_field_grads_workspace_bytes(a.n, n_numeric, d), "rc_numeric_field_grads: workspace %zu < %zu",
-               ws_bytes, rc_numeric_field_grads_workspace_bytes(a.n, n_numeric, d));
-    a.part = static_cast<float*>(ws);
+    RC_REQUIRE(ws != nullptr && ws_bytes >= rc_numeric_field_grads_workspace_bytes(a.c.n, n_numeric, d), "rc_numeric_field_grads: workspace %zu < %zu",
+               ws_bytes, rc_numeric_field_grads_workspace_bytes(a.c.n, n_numeric, d));
+    a.c.part = static_cast<float*>(ws);
   }
   const bool vec = d % 4 == 0 && (gV == nullptr || reinterpret_cast<uintptr_t>(gV) % 16 == 0);
   if (vec)

@@ -16,6 +16,7 @@
 
 #include "opt_math.hpp"
 #include "small_plan.hpp"
+#include "numeric_grads.hpp"
 
 namespace rc {
 
@@ -204,6 +205,9 @@ __global__ __launch_bounds__(kSmallThreads) void small_plan_kernel(SmallPlanArgs
   small_plan_block<kSmallCapBig, kSmallWaveCapBig>(plan, blockIdx.x, small_plan_smem);
 }
 
+constexpr int kSmallNumeric = 4;
+constexpr int kSmallNumericSplits = 4;    // workgroups per numeric field (disjoint column ranges)
+
 struct SmallSumArgs {
   const rc_plan_row* rows;   // [kSmallPlanWgs][n]
   const uint32_t* occ;       // [kSmallPlanWgs][n]
@@ -214,6 +218,13 @@ struct SmallSumArgs {
   int d;
   const float* src1;         // optional second, ONE-float-wide gradient of the same occurrences ([n]) and its table [n_rows]:
   float* out1;               // the [vocab, 1] first-order weights of the FM family ride along with the [vocab, d] vectors
+  // rc_small_row_sums_pair_numeric: the weight gradients of up to kSmallNumeric numeric fields (numeric_grads.hpp) by one extra
+  // workgroup each behind the row workgroups -- independent work that would otherwise be a launch of its own (~13 us of a replayed
+  // DeepFM step at B = 1,024 on MIND's field set)
+  uint32_t blocks_rows;      // workgroups of the row sums (the grid may be longer)
+  int n_numeric;
+  NumericSlot num[kSmallNumeric];
+  NumericCommon numc;
 };
 
 // flat row index -> record (rows of plan workgroup w are the w-th segment; per-workgroup counts prefix-summed here)
@@ -248,13 +259,20 @@ template <int D>
 __global__ __launch_bounds__(kBlock) void small_row_sums_kernel(SmallSumArgs a) {
   constexpr int LPR = D / 4;
   constexpr int GPW = 64 / LPR;
+  if (blockIdx.x >= a.blocks_rows) {   // (workgroup-uniform) a numeric field's weight gradients over the whole batch
+    // kSmallNumericSplits workgroups per field, each a quarter of the columns: 4 lanes per row at d = 64, i.e. 64 rows per load
+    // instruction and 1,024 rows -- the whole batch at B = 1,024 -- in flight in ONE trip of sixteen
+    const int w = (int)(blockIdx.x - a.blocks_rows), j = w / kSmallNumericSplits;
+    numeric_slot_grads<4, kBlock, 16>(a.num[j], a.numc, j, 0u, true, w % kSmallNumericSplits, kSmallNumericSplits);
+    return;
+  }
   __shared__ SmallRowIndex ix;
   __shared__ uint32_t wsum[8];
   const int tid = threadIdx.x, lane = tid & 63;
   const int l = lane % LPR, grp = lane / LPR;
   small_row_prefix(a.cnt, &ix, wsum);
   const uint32_t R = ix.pre[kSmallPlanWgs];
-  const uint32_t n_waves = gridDim.x * (kBlock / 64);
+  const uint32_t n_waves = a.blocks_rows * (kBlock / 64);
   const uint32_t wave = blockIdx.x * (kBlock / 64) + (tid >> 6);
   const float4* src4 = reinterpret_cast<const float4*>(a.src);
   for (uint32_t r0 = wave * GPW; r0 < R; r0 += n_waves * GPW) {
@@ -453,8 +471,15 @@ extern "C" size_t rc_small_row_sums_workspace_bytes(int64_t n) {
          align_up((size_t)kSmallPlanWgs * (size_t)n * sizeof(uint32_t), 256) + align_up((size_t)kSmallPlanWgs * sizeof(SmallCnt), 256);
 }
 
+struct SmallNumericCall {     // host-side description of the numeric fields that ride in the launch
+  int n_numeric;
+  NumericSlot num[kSmallNumeric];
+  NumericCommon c;
+};
+
 static int small_row_sums_impl(bool build_plan, const int64_t* ids, int64_t n, int64_t n_rows, const float* src, int d, float* out, void* ws,
-                               size_t ws_bytes, rc_stream_t stream, const float* src1 = nullptr, float* out1 = nullptr) {
+                               size_t ws_bytes, rc_stream_t stream, const float* src1 = nullptr, float* out1 = nullptr,
+                               const SmallNumericCall* numeric = nullptr) {
   if (n == 0) return RC_OK;
   RC_REQUIRE((ids || !build_plan) && src && out && ws, "rc_small_row_sums: null pointer");
   if (!rc_small_row_sums_supported(n, n_rows, d))
@@ -491,7 +516,14 @@ static int small_row_sums_impl(bool build_plan, const int64_t* ids, int64_t n, i
   SmallSumArgs a;
   a.rows = rows; a.occ = occ; a.cnt = cnt; a.n = (uint32_t)n; a.src = src; a.out = out; a.d = d;
   a.src1 = src1; a.out1 = out1;
+  a.n_numeric = 0;
   RC_REQUIRE((src1 == nullptr) == (out1 == nullptr) && (src1 == nullptr || d >= 16), "rc_small_row_sums_pair: the one-float-wide pair rides with d >= 16 only");
+  RC_REQUIRE(numeric == nullptr || d >= 16, "rc_small_row_sums_pair_numeric: the numeric fields ride with the d >= 16 kernels only");
+  if (numeric != nullptr) {
+    a.n_numeric = numeric->n_numeric;
+    for (int j = 0; j < numeric->n_numeric; ++j) a.num[j] = numeric->num[j];
+    a.numc = numeric->c;
+  }
   if (d <= 4) {
     unsigned blocks = (unsigned)((n + kBlock / 64 - 1) / (kBlock / 64));
     if (blocks > 1024u) blocks = 1024u;
@@ -500,11 +532,13 @@ static int small_row_sums_impl(bool build_plan, const int64_t* ids, int64_t n, i
     const int gpb = kBlock / (d / 4);
     unsigned blocks = (unsigned)((n + gpb - 1) / gpb);
     if (blocks > 2048u) blocks = 2048u;
+    a.blocks_rows = blocks;
+    const unsigned grid = blocks + (unsigned)(a.n_numeric * kSmallNumericSplits);     // the numeric fields' workgroups come last: the rows' are dispatched first
     switch (d) {
-      case 16: hipLaunchKernelGGL((small_row_sums_kernel<16>), dim3(blocks), dim3(kBlock), 0, s, a); break;
-      case 32: hipLaunchKernelGGL((small_row_sums_kernel<32>), dim3(blocks), dim3(kBlock), 0, s, a); break;
-      case 64: hipLaunchKernelGGL((small_row_sums_kernel<64>), dim3(blocks), dim3(kBlock), 0, s, a); break;
-      default: hipLaunchKernelGGL((small_row_sums_kernel<128>), dim3(blocks), dim3(kBlock), 0, s, a); break;
+      case 16: hipLaunchKernelGGL((small_row_sums_kernel<16>), dim3(grid), dim3(kBlock), 0, s, a); break;
+      case 32: hipLaunchKernelGGL((small_row_sums_kernel<32>), dim3(grid), dim3(kBlock), 0, s, a); break;
+      case 64: hipLaunchKernelGGL((small_row_sums_kernel<64>), dim3(grid), dim3(kBlock), 0, s, a); break;
+      default: hipLaunchKernelGGL((small_row_sums_kernel<128>), dim3(grid), dim3(kBlock), 0, s, a); break;
     }
   }
   RC_LAUNCH_CHECK();
@@ -525,4 +559,28 @@ extern "C" int rc_small_row_sums_pair(const int64_t* ids, int64_t n, int64_t n_r
                                       const float* src1, float* out1, void* ws, size_t ws_bytes, rc_stream_t stream) {
   RC_REQUIRE(src1 && out1, "rc_small_row_sums_pair: null pointer");
   return small_row_sums_impl(true, ids, n, n_rows, src, d, out, ws, ws_bytes, stream, src1, out1);
+}
+
+/* rc_small_row_sums_pair with the weight gradients of the numeric fields of the same gradient blocks (rc_numeric_field_grads)
+ * riding in the row-sums launch: src = gV [rows, F, d] seen as n = rows * F occurrence rows, src1 = gL [rows * F]. */
+extern "C" int rc_small_row_sums_pair_numeric(const int64_t* ids, int64_t n, int64_t n_rows, const float* src, int d, float* out,
+                                              const float* src1, float* out1, const void* const* values, const int* per_row,
+                                              const int* kind, const int* field, int n_numeric, int F, int64_t B, int C,
+                                              float* const* dW, float* const* dw1, void* ws, size_t ws_bytes, rc_stream_t stream) {
+  RC_REQUIRE(src1 && out1 && values && per_row && kind && field && dW && dw1, "rc_small_row_sums_pair_numeric: null pointer");
+  RC_REQUIRE(n_numeric >= 1 && n_numeric <= kSmallNumeric && n_numeric <= F && F <= kMaxFields,
+             "rc_small_row_sums_pair_numeric: %d numeric fields (1 .. %d) of F = %d", n_numeric, kSmallNumeric, F);
+  RC_REQUIRE(B >= 1 && C >= 1 && B * C * F == n && d % 4 == 0 && d <= 4 * kBlock, "rc_small_row_sums_pair_numeric: bad shape B=%lld C=%d F=%d n=%lld d=%d",
+             (long long)B, C, F, (long long)n, d);
+  SmallNumericCall nc;
+  memset(&nc, 0, sizeof(nc));
+  nc.n_numeric = n_numeric;
+  for (int j = 0; j < n_numeric; ++j) {
+    RC_REQUIRE(values[j] && dW[j] && dw1[j] && field[j] >= 0 && field[j] < F && kind[j] >= RC_FIELD_F32 && kind[j] <= RC_FIELD_I64,
+               "rc_small_row_sums_pair_numeric: bad numeric field %d", j);
+    nc.num[j].values = values[j]; nc.num[j].dW = dW[j]; nc.num[j].dw1 = dw1[j];
+    nc.num[j].kind = kind[j]; nc.num[j].per_row = per_row[j]; nc.num[j].field = field[j];
+  }
+  nc.c.gV = src; nc.c.gL = src1; nc.c.part = nullptr; nc.c.n = B * C; nc.c.n_numeric = n_numeric; nc.c.F = F; nc.c.C = C; nc.c.d = d;
+  return small_row_sums_impl(true, ids, n, n_rows, src, d, out, ws, ws_bytes, stream, src1, out1, &nc);
 }

@@ -483,7 +483,10 @@ def embedding_dense_backward(grad_out, ids, n_rows, route=None, presorted=None, 
     return G
 
 
-def small_row_sums_pair(cid, n_rows, src_a, src_b, into=None):
+SMALL_NUMERIC_MAX = 4      # numeric fields that can ride in the small route's row-sums launch (kSmallNumeric)
+
+
+def small_row_sums_pair(cid, n_rows, src_a, src_b, into=None, numeric=None):
     """two dense gradients [n_rows, d_a], [n_rows, d_b] of per-occurrence rows src_a [n, d_a], src_b [n, d_b] that share their ids:
     ONE zero fill (both live in one buffer), ONE grouping (rc_small_row_sums, then rc_small_row_sums_again for the second).
     into: a float buffer of n_rows * (d_a + d_b) elements that is NOT zero-filled -- only the rows of `cid` are written (the
@@ -494,6 +497,27 @@ def small_row_sums_pair(cid, n_rows, src_a, src_b, into=None):
     Ga, Gb = G[:n_rows * d_a].view(n_rows, d_a), G[n_rows * d_a:].view(n_rows, d_b)
     ws = workspace(_lib.load().rc_small_row_sums_workspace_bytes(n), src_a.device, "edb_small_pair")
     flat = cid.reshape(-1)
+    if numeric is not None:
+        # numeric = (values, fields, F, n_cand): the weight gradients of the numeric fields of the same gradient blocks (src_a = gV
+        # [rows * F, d], src_b = gL [rows * F, 1]) by extra workgroups of the row-sums launch -> (Ga, Gb, dW list, dw1 list)
+        values, fields, F, n_cand = numeric
+        J = len(values)
+        if not (d_b == 1 and 16 <= d_a <= 128 and d_a % 4 == 0 and 1 <= J <= SMALL_NUMERIC_MAX):
+            raise ValueError("small_row_sums_pair: the numeric fields ride with d in 16 .. 128 and at most %d of them" % SMALL_NUMERIC_MAX)
+        f32 = torch.float32
+        B = values[0].shape[0]
+        dW = torch.empty((J, d_a, 1), dtype=f32, device=src_a.device)
+        dw1 = torch.empty((J, 1, 1), dtype=f32, device=src_a.device)
+        val_arr = (C.c_void_p * J)(*[_ptr(x, x.dtype, "values").value for x in values])
+        per_row = (C.c_int * J)(*[1 if x.dim() == 1 else 0 for x in values])
+        kind_arr = (C.c_int * J)(*[field_kind(x) for x in values])
+        field_arr = (C.c_int * J)(*[int(f) for f in fields])
+        dW_arr = (C.c_void_p * J)(*[dW[j].data_ptr() for j in range(J)])
+        dw1_arr = (C.c_void_p * J)(*[dw1[j].data_ptr() for j in range(J)])
+        _lib.call("rc_small_row_sums_pair_numeric", _ptr(flat, torch.int64, "ids"), n, int(n_rows), _ptr(src_a, f32, "src_a"), d_a,
+                  C.c_void_p(Ga.data_ptr()), _ptr(src_b, f32, "src_b"), C.c_void_p(Gb.data_ptr()), val_arr, per_row, kind_arr, field_arr, J,
+                  int(F), B, int(n_cand), dW_arr, dw1_arr, C.c_void_p(ws.data_ptr()), ws.numel(), _stream())
+        return Ga, Gb, [dW[j] for j in range(J)], [dw1[j] for j in range(J)]
     if d_b == 1 and d_a >= 16:     # the one-float-wide table rides in the vectors' row-sums launch
         _lib.call("rc_small_row_sums_pair", _ptr(flat, torch.int64, "ids"), n, int(n_rows), _ptr(src_a, torch.float32, "src_a"), d_a,
                   C.c_void_p(Ga.data_ptr()), _ptr(src_b, torch.float32, "src_b"), C.c_void_p(Gb.data_ptr()), C.c_void_p(ws.data_ptr()),

@@ -333,7 +333,12 @@ class _FieldGatherPairFn(torch.autograd.Function):
         gL = None if gL is None else gL.contiguous()
         num = ctx.num
         gw = gw1 = None
-        if num and (gV is not None or gL is not None):
+        # small batches: the numeric fields' weight gradients ride in the row-sums launch of the small route (a launch of their own
+        # is ~13 us of a replayed DeepFM step at B = 1,024); otherwise rc_numeric_field_grads on its own
+        ride = (num and gV is not None and gL is not None and n_rows > 0 and ctx.route == "small" and 16 <= d <= 128 and d % 4 == 0
+                and len(num) <= engine.SMALL_NUMERIC_MAX and engine.small_route_ok(n, n_rows, d))
+        riding = (ctx.values, num, F, ctx.n_cand) if ride else None
+        if num and not ride and (gV is not None or gL is not None):
             gw, gw1 = engine.numeric_field_grads(None if gV is None else gV.view(n // F, F, d), None if gL is None else gL.view(n // F, F),
                                                  ctx.values, num, F, ctx.n_cand, d)
 
@@ -349,13 +354,19 @@ class _FieldGatherPairFn(torch.autograd.Function):
         if ctx.rows_opt is not None:
             if gV is None or gL is None:
                 raise RuntimeError("gather_fields_pair (rows mode): both table families must reach the loss")
-            Gv, Gl = engine.small_row_sums_pair(ctx.cid, n_rows, gV.view(n, d), gL.view(n, 1), into=ctx.rows_opt.rows_scratch())
+            res = engine.small_row_sums_pair(ctx.cid, n_rows, gV.view(n, d), gL.view(n, 1), into=ctx.rows_opt.rows_scratch(), numeric=riding)
+            Gv, Gl = res[:2]
+            if ride:
+                gw, gw1 = res[2:]
             ctx.rows_opt.rows_grads(Gv, Gl)
             return (None, None, None, None) + (None,) * F + numeric((None,) * F, gw) + numeric((None,) * F, gw1)
         if n_rows == 0:       # numeric fields only
             Gv = Gl = None
         elif gV is not None and gL is not None and ctx.route == "small" and engine.small_route_ok(n, n_rows, d) and d % 4 == 0:
-            Gv, Gl = engine.small_row_sums_pair(ctx.cid, n_rows, gV.view(n, d), gL.view(n, 1))
+            res = engine.small_row_sums_pair(ctx.cid, n_rows, gV.view(n, d), gL.view(n, 1), numeric=riding)
+            Gv, Gl = res[:2]
+            if ride:
+                gw, gw1 = res[2:]
         else:
             presorted = None
             if ctx.route == "sort":

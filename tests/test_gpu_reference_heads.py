@@ -151,8 +151,8 @@ CTX_CASES = [
     ("WideDeep", "CTR", ["--emb_size", "16", "--layers", "[32]", "--dropout", "0.1"], {"rc_gather_fields_pair"}, r"rc_ctr_head_fwd_bwd(_sums)?"),
     # the same heads over a field list with numeric features (models/context/FM.py:38-41: Linear(1, d) on c_day_f / i_age_f)
     ("DeepFM", "CTR:f", ["--emb_size", "16", "--layers", "[32,16]", "--dropout", "0.2"],
-     {"rc_gather_fields_mixed", "rc_numeric_field_grads", "rc_fm_second_order_bwd_add"}, r"rc_ctr_head_fwd_bwd(_sums)?"),
-    ("FM", "TopK:f", ["--emb_size", "16"], {"rc_gather_fields_mixed", "rc_numeric_field_grads", "rc_fm_second_order_fwd"}, None),
+     {"rc_gather_fields_mixed", "rc_small_row_sums_pair_numeric", "rc_fm_second_order_bwd_add"}, r"rc_ctr_head_fwd_bwd(_sums)?"),
+    ("FM", "TopK:f", ["--emb_size", "16"], {"rc_gather_fields_mixed", "rc_small_row_sums_pair_numeric", "rc_fm_second_order_fwd"}, None),
 ]
 
 
