@@ -284,9 +284,13 @@ def deepfm_roofline(args, trainer, batches, engine, ms_per_step=None):
             "rc_tower_tail_*, hand-written fp32 MFMA) + field gathers, FM term, field gradients, dense Adam") if host_bound else \
            ("MLP_Block forward + backward (rc_linear_fwd / rc_linear_bwd, hand-written fp32 MFMA GEMMs; eager phases incl. the field "
             "gathers, FM term and their backward)")
-    return {"phases_ms": {k: round(v, 4) for k, v in ph.items()},
-            "roofline": {"bound": "mfma", "kernel": what, "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / F32_MFMA_PEAK_TFLOPS, "traffic": None, "algorithmic_flops_per_launch": 3.0 * fwd, "avg_ms": t}}
+    rl = {"bound": "mfma", "kernel": what, "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+          "frac": ach / F32_MFMA_PEAK_TFLOPS, "traffic": None, "algorithmic_flops_per_launch": 3.0 * fwd, "avg_ms": t}
+    default = (args.emb_size, args.mlp.replace(" ", ""), args.opt, abs(float(args.dropout) - 0.2) < 1e-9) == (64, "[512,64]", "Adam", True) and \
+        "c_day_f" in DEEPFM_VOCAB
+    if default and args.batch in (1024, 131072):
+        rl.update(pmc_step_traffic("deepfm_b%d" % args.batch, True))
+    return {"phases_ms": {k: round(v, 4) for k, v in ph.items()}, "roofline": rl}
 
 
 def cpu_baseline_deepfm(args, batches_cpu):
@@ -353,6 +357,24 @@ def algorithmic_bytes(args, batches):
 def default_workload(args):
     return (args.opt == "SGD" and args.batch == 65536 and args.num_neg == 99 and args.emb_size == 64
             and args.items == 10_000_001 and args.users == 1_000_001)
+
+
+def pmc_step_traffic(name, default_shape):
+    """{"traffic": HBM bytes of the WHOLE training step, "traffic_scope": ...} from a committed whole-step PMC pass
+    (profiles/pmc_<name>_latest.json: tools/pmc_collect.sh / pmc_workload.py run eager steps behind a marker copy, FETCH_SIZE and
+    WRITE_SIZE passes calibrated on a table copy) -- only for the shape the pass was taken on"""
+    if not default_shape:
+        return {"traffic": None}
+    try:
+        st = json.load(open(os.path.join(ROOT, "profiles", "pmc_%s_latest.json" % name)))["_step"]
+        top = sorted(st["kernels"].items(), key=lambda kv: -(kv[1]["hbm_read_bytes_per_step"] + kv[1]["hbm_write_bytes_per_step"]))[:4]
+        return {"traffic": st["hbm_bytes_per_step"],
+                "traffic_scope": "every kernel of one training step (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over %d eager steps, "
+                                 "profiles/pmc_%s_latest.json); largest: %s" % (st["steps"], name, "; ".join(
+                                     "%s %.0f MB" % (k.replace("rc::", "")[:40], (v["hbm_read_bytes_per_step"] + v["hbm_write_bytes_per_step"]) / 1e6)
+                                     for k, v in top))}
+    except Exception:
+        return {"traffic": None}
 
 
 def load_pmc_traffic(kernel):
@@ -551,6 +573,9 @@ def model_roofline(args, trainer, batches, engine):
         out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                            "frac": ach / F32_MFMA_PEAK_TFLOPS, "traffic": None, "algorithmic_flops_per_launch": flops[dom],
                            "avg_ms": ph[dom]}
+    if args.workload == "sasrec" and isinstance(out.get("roofline"), dict):
+        default = (args.items, args.emb_size, args.hist, args.num_neg, args.batch, args.layers, args.heads, args.opt) == (8714, 64, 50, 99, 4096, 1, 4, "SGD")
+        out["roofline"].update(pmc_step_traffic("sasrec", default))
     out["phases_tflops"] = {k: round(flops[k] / (ph[k] * 1e-3) / 1e12, 2) for k in flops if ph.get(k)}
     out["table_update_gbps"] = round(upd_bytes / (ph["table_update"] * 1e-3) / 1e9, 1) if ph.get("table_update") else None
     if args.workload == "sasrec" and enc_bytes:
