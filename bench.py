@@ -161,8 +161,11 @@ def make_neumf_trainer(args, world, device, engine):
              "W1": mk(l1, 2 * d), "b1": mk(l1), "w_out": mk(d + l1)}
         return engine.NeumfTrainer(P, opt=args.opt, lr=args.lr, l2=args.l2, rowwise=True, dropout=args.dropout)
     from rechorus_amd.sharded import ShardedNeumf
+    # RC_SHARDED_ITEM_HALF=rows: both item rows travel and the MFMA head runs at home (round 5); default "auto": the owners of the
+    # item rows compute the item half of the hidden layer (d + hidden floats per distinct id each way instead of 2 d)
     trainer = ShardedNeumf(args.users, args.items, d, l1, opt=args.opt, lr=args.lr, l2=args.l2, device=device, seed=1234,
-                           micro_batches=args.micro_batches or (4 if world > 1 else 1))
+                           micro_batches=args.micro_batches or (4 if world > 1 else 1),
+                           item_half=os.environ.get("RC_SHARDED_ITEM_HALF", "auto"))
     trainer.loss = None
     _step = trainer.step
 

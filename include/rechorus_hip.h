@@ -680,6 +680,20 @@ int rc_neumf_head_fwd_bwd(const float* mf_u, const float* mlp_u, int64_t ld_u, c
                           float* g_mf_i, float* g_mlp_i, int64_t ld_gi, float* gu_mf, float* gu_mlp, int64_t ld_gu,
                           float* dW1, float* db1, float* dw_out, void* ws, size_t ws_bytes, rc_stream_t stream);
 
+/* The head of a row-sharded NeuMF step whose ITEM half of the hidden layer was computed by the rows' owners (csrc/neumf_zhead.hip;
+ * models/general/NeuMF.py:61-75: the user ids are tiled over the candidates, so h = relu(W1u mlp_u + W1i mlp_i + b1)): the fetched
+ * item rows hold (mf_i [d] | zi = W1i mlp_i [l1]) instead of both table rows, zu [B, l1] = W1u mlp_u + b1 comes from rc_linear_fwd.
+ * Forward, GeneralModel.loss (BaseModel.py:182-185) and the backward in one launch: loss_vec [B], pred [B, C] (optional), gi [B C]
+ * rows (d mf_i | dz) -- what travels back to the owners, who form d mlp_i = W1i^T dz and their share of dW1i = dz^T mlp_i with
+ * rc_linear_bwd --, gu_mf [B, d] = d mf_u, dzu [B, l1] = sum_c dz_c (the caller's rc_linear_bwd turns it into d mlp_u, dW1u, db1),
+ * dw_out [d + l1].  Row strides in floats (the blocks of the sharded step hold their halves side by side).  2 <= C <= 256,
+ * d, l1 <= 1,024; ws: rc_neumf_zhead_workspace_bytes.                                                                              */
+int rc_neumf_zhead_supported(int C, int d, int l1);
+size_t rc_neumf_zhead_workspace_bytes(int d, int l1);
+int rc_neumf_zhead_fwd_bwd(const float* mf_u, int64_t ld_u, const float* zu, const float* irows, int64_t ld_i, const float* w_out, int B,
+                           int C, int d, int l1, float inv_b, float* loss_vec, float* pred, float* gi, int64_t ld_gi, float* gu_mf,
+                           int64_t ld_gu, float* dzu, float* dw_out, void* ws, size_t ws_bytes, rc_stream_t stream);
+
 /* ---- dense layers of the heads (csrc/mlp.hip): fp32 MFMA GEMMs ------------------------------------
  * utils/layers.py:201-243 (MLP_Block: Linear -> ReLU -> Dropout per hidden layer + output Linear; the deep part of
  * models/context/DeepFM.py:25 / WideDeep.py:42-47) and the NeuMF tower for any --layers

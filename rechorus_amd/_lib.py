@@ -84,6 +84,9 @@ SIGNATURES = {
     "rc_gather_fields": (_i, [_p, _p, _p, _p, _i, _i64, _i, _i, _p, _p, _p]),
     "rc_gather_fields_pair": (_i, [_p, _p, _p, _p, _p, _i, _i64, _i, _i, _p, _p, _p, _p]),
     "rc_gather_fields_pair_mark": (_i, [_p, _p, _p, _p, _p, _i, _i64, _i, _i, _p, _p, _p, _p, _p, _i, _p]),
+    "rc_neumf_zhead_supported": (_i, [_i, _i, _i]),
+    "rc_neumf_zhead_workspace_bytes": (_sz, [_i, _i]),
+    "rc_neumf_zhead_fwd_bwd": (_i, [_p, _i64, _p, _p, _i64, _p, _i, _i, _i, _i, _f, _p, _p, _p, _i64, _p, _i64, _p, _p, _p, _sz, _p]),
     "rc_seq_offsets": (_i, [_p, _i64, _i, _p, _p]),
     "rc_seq_embed_fwd": (_i, [_p, _p, _p, _p, _i64, _i, _i, _p, _p]),
     "rc_seq_pick_last_fwd": (_i, [_p, _p, _i64, _i, _i, _p, _p]),

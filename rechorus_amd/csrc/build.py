@@ -31,7 +31,7 @@ SOURCES = [
     "bucket_plan.hip",
     "plan_update.hip",
     "train_step.hip", "small_step.hip",
-    "neumf.hip", "neumf_step.hip", "mlp.hip", "tower_tail.hip",
+    "neumf.hip", "neumf_step.hip", "neumf_zhead.hip", "mlp.hip", "tower_tail.hip",
     "sasrec.hip", "sasrec_batch.hip", "seq_layers.hip",
     "listwise_loss.hip",
     "fm_bce.hip",

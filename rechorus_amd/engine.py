@@ -849,6 +849,39 @@ def neumf_head_fwd_bwd(urows, irows, W1, b1, w_out, B, Cn, inv_b, want_pred=Fals
     return loss_vec, gu, gi, dense, pred
 
 
+def neumf_zhead_supported(Cn, d, l1):
+    return bool(_lib.load().rc_neumf_zhead_supported(int(Cn), int(d), int(l1)))
+
+
+def neumf_zhead(urows, irows, W1, b1, w_out, B, Cn, inv_b, want_pred=False):
+    """the head of a sharded NeuMF step whose item half of the hidden layer came from the rows' owners (csrc/neumf_zhead.hip):
+    urows [B, 2d] = [mf_u | mlp_u], irows [B C, d + l1] = [mf_i | zi = W1i mlp_i].  zu = W1u mlp_u + b1 and the backward of the
+    user half are GEMMs (rc_linear_fwd / rc_linear_bwd), everything per candidate is rc_neumf_zhead_fwd_bwd.
+    -> (loss_vec [B], gu [B, 2d] = [d mf_u | d mlp_u], gi [B C, d + l1] = [d mf_i | dz], {W1u [l1, d], b1, w_out gradients}, pred | None)"""
+    d = urows.shape[1] // 2
+    l1 = W1.shape[0]
+    dev, f32 = urows.device, torch.float32
+    if irows.shape != (B * Cn, d + l1) or urows.shape != (B, 2 * d):
+        raise ValueError("neumf_zhead: row blocks do not match B, C, d, hidden")
+    W1u = W1[:, :d].contiguous()
+    mlp_u = urows[:, d:].contiguous()
+    zu = linear_fwd(mlp_u, W1u, b1)
+    loss_vec = torch.empty(B, dtype=f32, device=dev)
+    gu = torch.empty((B, 2 * d), dtype=f32, device=dev)
+    gi = torch.empty((B * Cn, d + l1), dtype=f32, device=dev)
+    dzu = torch.empty((B, l1), dtype=f32, device=dev)
+    dw_out = torch.empty(d + l1, dtype=f32, device=dev)
+    pred = torch.empty((B, Cn), dtype=f32, device=dev) if want_pred else None
+    ws = workspace(_lib.load().rc_neumf_zhead_workspace_bytes(d, l1), dev, "neumf_zhead")
+    _lib.call("rc_neumf_zhead_fwd_bwd", _ptr(urows, f32, "urows"), 2 * d, _ptr(zu, f32, "zu"), _ptr(irows, f32, "irows"), d + l1,
+              _ptr(w_out, f32, "w_out"), B, Cn, d, l1, float(inv_b), _ptr(loss_vec, f32, "loss_vec"), _ptr(pred, f32, "pred", True),
+              _ptr(gi, f32, "gi"), d + l1, _ptr(gu, f32, "gu"), 2 * d, _ptr(dzu, f32, "dzu"), _ptr(dw_out, f32, "dw_out"),
+              C.c_void_p(ws.data_ptr()), ws.numel(), _stream())
+    dmlp_u, dW1u, db1 = linear_bwd(mlp_u, W1u, None, dzu, ws_tag="zhead_bwd")
+    gu[:, d:] = dmlp_u
+    return loss_vec, gu, gi, {"W1u": dW1u, "b1": db1, "w_out": dw_out}, pred
+
+
 class _PhaseTimer:
     """Optional per-phase timing of a trainer step with events on the launch stream (torch's current stream is the
     stream every kernel of the step is enqueued on).  trainer.timing = {} switches it on; read with phases_ms()."""

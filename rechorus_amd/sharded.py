@@ -186,6 +186,27 @@ class HipOps:
         loss_vec, gu, gi, dense, _ = self.e.neumf_head_fwd_bwd(urows, irows, P["W1"], P["b1"], P["w_out"], B, C, inv_b)
         return loss_vec, gu, gi, dense
 
+    # ---- owner-computed item half of the NeuMF hidden layer (ShardedNeumf, item_half = "owner") -----------------
+    def item_half_fwd(self, mlp_rows, W1i):
+        """zi [n, l1] = mlp_rows [n, d] W1i^T: what travels to the tuples instead of the mlp_i rows (rc_linear_fwd, no bias)"""
+        return self.e.linear_fwd(mlp_rows, W1i)
+
+    def item_half_bwd(self, mlp_rows, W1i, dz):
+        """-> (d mlp_i [n, d] = dz W1i, this rank's share of dW1i [l1, d] = dz^T mlp_rows)  (rc_linear_bwd)"""
+        if mlp_rows.shape[0] == 0:
+            return torch.zeros_like(mlp_rows), torch.zeros_like(W1i)
+        dX, dW, _ = self.e.linear_bwd(mlp_rows, W1i, None, dz, need_db=False, ws_tag="item_half_bwd")
+        return dX, dW
+
+    def neumf_zhead(self, urows, irows, P, B, C, inv_b):
+        """the head on (mf_u | mlp_u) user blocks and (mf_i | zi) item blocks (csrc/neumf_zhead.hip + the user half's GEMMs)
+        -> (loss_vec, gu [B, 2d], gi [B C, d + l1] = (d mf_i | dz), {"W1u", "b1", "w_out"}) or None (shape not covered)"""
+        d, l1 = urows.shape[1] // 2, P["W1"].shape[0]
+        if not self.e.neumf_zhead_supported(C, d, l1):
+            return None
+        loss_vec, gu, gi, dense, _ = self.e.neumf_zhead(urows, irows, P["W1"], P["b1"], P["w_out"], B, C, inv_b)
+        return loss_vec, gu, gi, dense
+
     def dense_update(self, W, G, hyper, state):
         self.e.dense_update(W, G, hyper, state.get("m"), state.get("v"))
 
@@ -800,6 +821,14 @@ class _Route:
     def rows_in_lookup_order(self, back, ops):
         return self._expand(back, ops)
 
+    def fetch_block(self, served, ops):
+        """fetch() of a block the caller built for self.req itself (rows of several tables side by side, or values computed
+        from them at the owner: ShardedNeumf's (mf_i | W1i mlp_i))"""
+        return self._expand(_exchange_back(served, self.recv, self.send, self.group), ops)
+
+    def fetch_block_async(self, served):
+        return _exchange_async(served, self.recv, self.send, self.group)
+
     def push_async(self, grads, ops):
         return _exchange_async(self._reduce(grads, ops), self.send, self.recv, self.group)
 
@@ -814,7 +843,7 @@ class _Route:
         return own
 
     def wire_bytes(self, row_bytes):
-        """bytes this rank moves over the links for this lookup: ids out, rows in, gradient rows out"""
+        """bytes this rank moves over the links for this lookup: ids out, rows in, gradient rows out (row_bytes each way)"""
         return {"ids_out": 8 * self.remote_out, "rows_in": row_bytes * self.remote_out, "grads_out": row_bytes * self.remote_out,
                 "rows_served_out": row_bytes * self.remote_in, "lookups": self.n_lookup, "ids_sent": self.n_sent}
 
@@ -832,9 +861,10 @@ class ShardedNeumf(_LookAhead):
     TABLES = ("mf_u", "mlp_u", "mf_i", "mlp_i")
 
     def __init__(self, n_users, n_items, emb_size, hidden, opt="SGD", lr=1e-3, l2=0.0, device=None, ops=None,
-                 group=None, init_std=0.01, seed=0, micro_batches=1, dedup=True):
+                 group=None, init_std=0.01, seed=0, micro_batches=1, dedup=True, item_half="auto"):
         self.micro_batches = max(1, int(micro_batches))
         self.dedup = bool(dedup)
+        self._item_half_arg = item_half
         self.wire = None  # {"ids_out", "rows_in", "grads_out", ...} bytes of the last step (this rank), W > 1
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -852,6 +882,22 @@ class ShardedNeumf(_LookAhead):
         self.P.update(W1=mk(hidden, 2 * emb_size), b1=mk(hidden), w_out=mk(emb_size + hidden))
         self.state = {k: self.ops.new_state(v, opt) for k, v in self.P.items()}
         self.step_count = 0
+        # "owner": the item half of the hidden layer is computed where the item rows live -- NeuMF.py:61 tiles the user ids over
+        # the candidates, so W1 [mlp_u ; mlp_i] = W1u mlp_u + W1i mlp_i: an owner returns (mf_i | zi = W1i mlp_i), d + hidden floats
+        # instead of 2 d, receives (d mf_i | dz) back, and forms d mlp_i = W1i^T dz and its share of dW1i = dz^T mlp_i itself.
+        # Fewer bytes each way whenever hidden < emb_size (config 4: 192 instead of 256 floats per distinct item id, -25 %).
+        if item_half not in ("auto", "owner", "rows"):
+            raise ValueError("item_half must be auto | owner | rows")
+        if item_half == "owner" and not (self.world > 1 and all(hasattr(self.ops, m) for m in ("item_half_fwd", "item_half_bwd", "neumf_zhead"))):
+            raise ValueError("item_half='owner' needs W > 1 and ops with item_half_fwd / item_half_bwd / neumf_zhead")
+        # "auto" = "rows" for now: on one GPU the owner's three small-K GEMMs per chunk (0.087 ms) and the lighter home head
+        # (0.11 against the MFMA head's 0.15 ms) add 0.05 ms per chunk and save 9.6 MB each way -- even at ~400 GB/s per GPU, and
+        # no link rate has been measured yet (profiles/r09_sharded_neumf_item_half.txt); RC_SHARDED_ITEM_HALF=owner selects it
+        self.item_half = "owner" if item_half == "owner" else "rows"
+
+    def _item_row_floats(self):
+        """floats per distinct item id on the wire, each way"""
+        return self.d + self.l1 if self.item_half == "owner" else 2 * self.d
 
     def load_global(self, P):
         """full tables / MLP -> this rank's shards (global row = local * W + rank)"""
@@ -920,13 +966,23 @@ class ShardedNeumf(_LookAhead):
             self._account([ru, rv])
             mark("route")
             urows = ru.fetch([self.P["mf_u"], self.P["mlp_u"]], ops)      # [B, 2d]
-            irows = rv.fetch([self.P["mf_i"], self.P["mlp_i"]], ops)      # [B*C, 2d]
+            if self.item_half == "owner":
+                W1i = self.P["W1"][:, d:].contiguous()
+                mlp_req = ops.gather_rows(self.P["mlp_i"], rv.req)          # the rows this rank serves (kept for the backward)
+                served = torch.cat([ops.gather_rows(self.P["mf_i"], rv.req), ops.item_half_fwd(mlp_req, W1i)], dim=1)
+                irows = rv.fetch_block(served, ops)                         # [B*C, d + l1] = (mf_i | W1i mlp_i)
+            else:
+                irows = rv.fetch([self.P["mf_i"], self.P["mlp_i"]], ops)      # [B*C, 2d]
         mark("fetch_rows")
         loss_vec, gu, gi, dense = self._head(urows, irows, B, C, n_tuples, mark)
         loss = loss_vec.sum().reshape(1) / n_tuples
         if W > 1:
             loss = _all_reduce_sum(loss, self.group)
             own_u, own_i, req_u, req_i = ru.push(gu, ops), rv.push(gi, ops), ru.req, rv.req
+            if self.item_half == "owner":     # (d mf_i | dz) arrived: d mlp_i and this rank's share of dW1i are formed here
+                dmlp, dW1i = ops.item_half_bwd(mlp_req, W1i, own_i[:, d:].contiguous())
+                own_i = torch.cat([own_i[:, :d], dmlp], dim=1)
+                dense["W1"] = torch.cat([dense.pop("W1u"), dW1i], dim=1)
             flat = torch.cat([dense[k].reshape(-1) for k in ("W1", "b1", "w_out")])
             flat = _all_reduce_sum(flat, self.group)  # replicated MLP: summed gradients, identical step everywhere
             o = 0
@@ -961,6 +1017,13 @@ class ShardedNeumf(_LookAhead):
         per-tuple work, the loss stays in registers); otherwise -- other widths, the oracle-backed ops of the CPU tests --
         forward kernel, loss kernel, backward kernel on contiguous copies with positional ids."""
         ops, d, dev = self.ops, self.d, urows.device
+        if self.item_half == "owner":     # irows = (mf_i | zi): dense carries "W1u" (the user half; the owners add theirs)
+            out = ops.neumf_zhead(urows, irows, self.P, B, C, 1.0 / n_tuples)
+            if out is None:
+                raise RuntimeError("ShardedNeumf(item_half='owner'): no head kernel for C=%d d=%d hidden=%d" % (C, d, self.l1))
+            mark("head_fwd_loss")
+            mark("head_bwd")
+            return out
         fused = ops.neumf_head(urows, irows, self.P, B, C, 1.0 / n_tuples) if hasattr(ops, "neumf_head") else None
         if fused is not None:
             mark("head_fwd_loss")
@@ -981,10 +1044,12 @@ class ShardedNeumf(_LookAhead):
         return loss_vec, gu, gi, dense
 
     def _account(self, routes):
-        """bytes over the links of this step (this rank): every route moves rows of two tables (mf + mlp), 2 d floats"""
+        """bytes over the links of this step (this rank): a user route moves (mf_u | mlp_u) rows, 2 d floats; an item route
+        (mf_i | mlp_i), or (mf_i | W1i mlp_i) = d + hidden floats with the owner-computed item half"""
         tot = {}
-        for r in routes:
-            for k, v in r.wire_bytes(2 * self.d * 4).items():
+        for k_route, r in enumerate(routes):      # routes alternate user, item (one pair per chunk)
+            floats = 2 * self.d if k_route % 2 == 0 else self._item_row_floats()
+            for k, v in r.wire_bytes(floats * 4).items():
                 tot[k] = tot.get(k, 0) + v
         self.wire = tot
 
@@ -1005,11 +1070,23 @@ class ShardedNeumf(_LookAhead):
         mark = self._mark
         mark("route")
 
+        owner = self.item_half == "owner"
+        W1i = self.P["W1"][:, d:].contiguous() if owner else None
+        mlp_reqs = []
+
         def start(k):  # routes of chunk k, its rows requested (transfers may stay in flight)
             ru = _Route(uc[k], W, ops, group, prepared=grouped[k][0], splits=(sends[2 * k], recvs[2 * k]))
             rv = _Route(ic[k].reshape(-1), W, ops, group, prepared=grouped[k][1], splits=(sends[2 * k + 1], recvs[2 * k + 1]))
-            routes.append((ru, rv, ru.fetch_async([self.P["mf_u"], self.P["mlp_u"]], ops),
-                           rv.fetch_async([self.P["mf_i"], self.P["mlp_i"]], ops)))
+            mark("route_ids")     # (the id exchanges of the two routes)
+            if owner:
+                mlp_req = ops.gather_rows(self.P["mlp_i"], rv.req)
+                mlp_reqs.append(mlp_req)
+                served_i = torch.cat([ops.gather_rows(self.P["mf_i"], rv.req), ops.item_half_fwd(mlp_req, W1i)], dim=1)
+            else:
+                served_i = torch.cat([ops.gather_rows(T, rv.req) for T in (self.P["mf_i"], self.P["mlp_i"])], dim=1)
+            served_u = torch.cat([ops.gather_rows(T, ru.req) for T in (self.P["mf_u"], self.P["mlp_u"])], dim=1)
+            mark("serve_rows")    # (owner side, local: row gathers, and the item half of the hidden layer where the owners compute it)
+            routes.append((ru, rv, ru.fetch_block_async(served_u), rv.fetch_block_async(served_i)))
 
         start(0)
         loss = torch.zeros(1, dtype=torch.float32, device=dev)
@@ -1024,16 +1101,24 @@ class ShardedNeumf(_LookAhead):
             loss_vec, gu, gi, dense = self._head(urows, irows, Bk, C, n_tuples, mark)
             loss = loss + loss_vec.sum().reshape(1) / n_tuples
             pushes.append((ru.push_async(gu, ops), rv.push_async(gi, ops)))
-            flat = torch.cat([dense[n].reshape(-1) for n in ("W1", "b1", "w_out")])
+            flat = torch.cat([dense[n].reshape(-1) for n in (("W1u" if owner else "W1"), "b1", "w_out")])
             dense_sum = flat if dense_sum is None else dense_sum + flat
         loss = _all_reduce_sum(loss, group)
-        dense_sum = _all_reduce_sum(dense_sum, group)
         self._account([r for pair in routes for r in pair[:2]])
         own_u = torch.cat([p[0].wait() for p in pushes])
         own_i = torch.cat([p[1].wait() for p in pushes])
         req_u = torch.cat([r[0].req for r in routes])
         req_i = torch.cat([r[1].req for r in routes])
         mark("push_grads")
+        if owner:   # (d mf_i | dz) of every chunk arrived: ONE pair of GEMMs forms d mlp_i and this rank's share of dW1i
+            dmlp, dW1i = ops.item_half_bwd(torch.cat(mlp_reqs), W1i, own_i[:, d:].contiguous())
+            own_i = torch.cat([own_i[:, :d], dmlp], dim=1)
+            n_u = self.l1 * d
+            dW1 = torch.cat([dense_sum[:n_u].view(self.l1, d), dW1i], dim=1)
+            dense_sum = torch.cat([dW1.reshape(-1), dense_sum[n_u:]])
+            mark("owner_bwd")
+        dense_sum = _all_reduce_sum(dense_sum, group)
+        mark("dense_allreduce")
         shared = hasattr(ops, "prepare_rows")
         prep_u = ops.prepare_rows(req_u, self.P["mf_u"].shape[0], tag="rows.u") if shared else None
         prep_i = ops.prepare_rows(req_i, self.P["mf_i"].shape[0], tag="rows.i") if shared else None

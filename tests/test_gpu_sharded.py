@@ -237,7 +237,7 @@ def test_bench_multi_rank_code_path_on_one_gpu(launcher, workload, extra, cuda):
         assert "replicated" in out["config"]["parallelism"]
 
 
-def _neumf_worker(rank, world, port, opt, lr, l2, n_users, n_items, d, l1, B, C, steps, out_q, micro_batches=1):
+def _neumf_worker(rank, world, port, opt, lr, l2, n_users, n_items, d, l1, B, C, steps, out_q, micro_batches=1, item_half="owner"):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -245,7 +245,8 @@ def _neumf_worker(rank, world, port, opt, lr, l2, n_users, n_items, d, l1, B, C,
         from test_sharded_gloo import _neumf_problem
         dev = torch.device("cuda:0")
         rng, P = _neumf_problem(n_users, n_items, d, l1)
-        m = ShardedNeumf(n_users, n_items, d, l1, opt=opt, lr=lr, l2=l2, device=dev, micro_batches=micro_batches)
+        m = ShardedNeumf(n_users, n_items, d, l1, opt=opt, lr=lr, l2=l2, device=dev, micro_batches=micro_batches, item_half=item_half)
+        assert m.item_half == item_half
         m.load_global({k: torch.from_numpy(v).to(dev) for k, v in P.items()})
         losses = []
         for s in range(steps):
@@ -260,17 +261,20 @@ def _neumf_worker(rank, world, port, opt, lr, l2, n_users, n_items, d, l1, B, C,
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,opt,lr,l2,micro_batches", [(2, "SGD", 0.1, 1e-3, 1), (2, "Adam", 1e-2, 0.0, 1), (1, "SGD", 0.1, 1e-3, 1),
-                                                           (2, "SGD", 0.1, 1e-3, 3)])
-def test_sharded_neumf_hip_ops_equal_single_table_training(world, opt, lr, l2, micro_batches, cuda):
-    """ShardedNeumf with the real kernels (routing, gathers, MFMA head on per-batch row blocks, segmented
-    updates), ranks sharing cuda:0 over gloo, vs single-table training of the global batch (numpy oracle)"""
+@pytest.mark.parametrize("world,opt,lr,l2,micro_batches,item_half", [
+    (2, "SGD", 0.1, 1e-3, 1, "owner"), (2, "Adam", 1e-2, 0.0, 1, "owner"), (1, "SGD", 0.1, 1e-3, 1, "rows"), (2, "SGD", 0.1, 1e-3, 3, "owner"),
+    (2, "SGD", 0.1, 1e-3, 1, "rows"), (2, "Adam", 1e-2, 0.0, 1, "rows"), (2, "SGD", 0.1, 1e-3, 3, "rows")])
+def test_sharded_neumf_hip_ops_equal_single_table_training(world, opt, lr, l2, micro_batches, item_half, cuda):
+    """ShardedNeumf with the real kernels (routing, gathers, the head on per-batch row blocks, segmented updates), ranks sharing
+    cuda:0 over gloo, vs single-table training of the global batch (numpy oracle).  item_half "owner" (the
+    owners compute W1i mlp_i -- rc_linear_fwd / rc_linear_bwd on the served rows, rc_neumf_zhead_fwd_bwd at home), "rows": both item
+    rows travel and the MFMA head runs at home"""
     from test_sharded_gloo import _neumf_reference
     shape = dict(n_users=203, n_items=1001, d=64, l1=32, B=96, C=5, steps=2)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_neumf_worker, args=(r, world, port, opt, lr, l2, *shape.values(), q, micro_batches))
+    procs = [ctx.Process(target=_neumf_worker, args=(r, world, port, opt, lr, l2, *shape.values(), q, micro_batches, item_half))
              for r in range(world)]
     for p in procs:
         p.start()
@@ -283,3 +287,24 @@ def test_sharded_neumf_hip_ops_equal_single_table_training(world, opt, lr, l2, m
     atol = 3e-5 if opt == "Adam" else 2e-6  # Adam: |g| ~ eps elements (see conftest.assert_update_close)
     for k, v in P.items():
         np.testing.assert_allclose(G[k], v, rtol=1e-4, atol=atol, err_msg=k)
+
+
+@pytest.mark.parametrize("B,C,d,l1", [(96, 5, 64, 32), (7, 2, 8, 6), (300, 100, 128, 64), (33, 9, 48, 20), (2000, 5, 128, 64)])
+def test_neumf_zhead_kernel_vs_numpy(B, C, d, l1, cuda):
+    """engine.neumf_zhead (rc_linear_fwd -> rc_neumf_zhead_fwd_bwd -> rc_linear_bwd) against the float64 restatement the gloo tests use
+    as the home rank's head (tests/test_sharded_gloo.py::NeumfOracleOps.neumf_zhead): loss rows, both gradient blocks, the dense grads"""
+    from rechorus_amd import engine
+    from test_sharded_gloo import NeumfOracleOps
+    rng = np.random.default_rng(B + C)
+    mk = lambda *s: torch.from_numpy(rng.normal(0, 0.4, s).astype(np.float32))
+    urows, irows = mk(B, 2 * d), mk(B * C, d + l1)
+    P = {"W1": mk(l1, 2 * d), "b1": mk(l1), "w_out": mk(d + l1)}
+    want = NeumfOracleOps().neumf_zhead(urows, irows, P, B, C, 1.0 / B)
+    got = engine.neumf_zhead(urows.to(cuda), irows.to(cuda), P["W1"].to(cuda), P["b1"].to(cuda), P["w_out"].to(cuda), B, C, 1.0 / B, want_pred=True)
+    from conftest import assert_close
+    assert_close(got[0].cpu().numpy(), want[0].numpy(), what="loss rows")
+    assert_close(got[1].cpu().numpy(), want[1].numpy(), what="gu", atol_scale=2e-5)
+    assert_close(got[2].cpu().numpy(), want[2].numpy(), what="gi", atol_scale=2e-5)
+    for k in ("W1u", "b1", "w_out"):
+        assert_close(got[3][k].cpu().numpy(), want[3][k].numpy(), what="d" + k, rtol=2e-5, atol_scale=2e-5, abs_floor=3e-7 * (B * C) ** 0.5)
+    assert not engine.neumf_zhead_supported(1, 64, 32) and not engine.neumf_zhead_supported(300, 64, 32) and engine.neumf_zhead_supported(5, 128, 64)

@@ -228,6 +228,35 @@ class NeumfOracleOps(OracleOps):
         O.opt_step_dense(W.numpy(), G.numpy(), {k: v.numpy() for k, v in state.items()}, hyper["opt"], hyper["lr"],
                          hyper["l2"], step=hyper["step"])
 
+    # ---- owner-computed item half (ShardedNeumf item_half="owner"): numpy restatements of rc_linear_fwd / rc_linear_bwd on the
+    # served rows and of rc_neumf_zhead_fwd_bwd (models/general/NeuMF.py:61-75 with W1 [mlp_u ; mlp_i] = W1u mlp_u + W1i mlp_i)
+    def item_half_fwd(self, mlp_rows, W1i):
+        return torch.from_numpy((mlp_rows.numpy().astype(np.float64) @ W1i.numpy().T.astype(np.float64)).astype(np.float32))
+
+    def item_half_bwd(self, mlp_rows, W1i, dz):
+        dz64 = dz.numpy().astype(np.float64)
+        return (torch.from_numpy((dz64 @ W1i.numpy()).astype(np.float32)),
+                torch.from_numpy((dz64.T @ mlp_rows.numpy().astype(np.float64)).astype(np.float32)))
+
+    def neumf_zhead(self, urows, irows, P, B, C, inv_b):
+        d, l1 = urows.shape[1] // 2, P["W1"].shape[0]
+        u, it = urows.numpy().astype(np.float64), irows.numpy().astype(np.float64)
+        mf_u, mlp_u = u[:, :d], u[:, d:]
+        mf_i, zi = it[:, :d].reshape(B, C, d), it[:, d:].reshape(B, C, l1)
+        W1u, b1, w = P["W1"].numpy().astype(np.float64)[:, :d], P["b1"].numpy().astype(np.float64), P["w_out"].numpy().astype(np.float64)
+        h = np.maximum((mlp_u @ W1u.T + b1)[:, None, :] + zi, 0.0)
+        gmf = mf_u[:, None, :] * mf_i
+        pred = ((gmf * w[:d]).sum(-1) + (h * w[d:]).sum(-1)).astype(np.float32)
+        loss_vec, g = self.bpr_loss(torch.from_numpy(pred), inv_b)
+        g = g.numpy().astype(np.float64)[..., None]
+        dz = g * w[d:] * (h > 0)
+        dzu = dz.sum(1)
+        gu = np.concatenate([(g * mf_i).sum(1) * w[:d], dzu @ W1u], axis=1)
+        gi = np.concatenate([(g * w[:d] * mf_u[:, None, :]).reshape(-1, d), dz.reshape(-1, l1)], axis=1)
+        dense = {"W1u": dzu.T @ mlp_u, "b1": dzu.sum(0), "w_out": np.concatenate([(g * gmf).sum((0, 1)), (g * h).sum((0, 1))])}
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+        return loss_vec, t(gu), t(gi), {k: t(v) for k, v in dense.items()}
+
 
 def _neumf_problem(n_users, n_items, d, l1):
     rng = np.random.default_rng(9)
@@ -237,13 +266,15 @@ def _neumf_problem(n_users, n_items, d, l1):
     return rng, {k: v.astype(np.float32) for k, v in P.items()}
 
 
-def _neumf_worker(rank, world, port, opt, lr, l2, n_users, n_items, d, l1, B, C, steps, out_q, micro_batches=1):
+def _neumf_worker(rank, world, port, opt, lr, l2, n_users, n_items, d, l1, B, C, steps, out_q, micro_batches=1, item_half="owner"):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from rechorus_amd.sharded import ShardedNeumf
         rng, P = _neumf_problem(n_users, n_items, d, l1)
-        m = ShardedNeumf(n_users, n_items, d, l1, opt=opt, lr=lr, l2=l2, ops=NeumfOracleOps(), micro_batches=micro_batches)
+        m = ShardedNeumf(n_users, n_items, d, l1, opt=opt, lr=lr, l2=l2, ops=NeumfOracleOps(), micro_batches=micro_batches,
+                         item_half=item_half)
+        assert m.item_half == item_half
         m.load_global({k: torch.from_numpy(v) for k, v in P.items()})
         losses, batches = [], []
         for s in range(steps):
@@ -258,8 +289,12 @@ def _neumf_worker(rank, world, port, opt, lr, l2, n_users, n_items, d, l1, B, C,
         # ids of a lookup that live on OTHER ranks travel, one row of both tables back, one gradient row out
         if micro_batches == 1 and world > 1:
             u_last, i_last = (t.numpy() for t in batches[-1])
-            remote = sum(int((np.unique(x) % world != rank).sum()) for x in (u_last, i_last.reshape(-1)))
-            want = {"ids_out": 8 * remote, "rows_in": 2 * d * 4 * remote, "grads_out": 2 * d * 4 * remote}
+            remote_u, remote_i = (int((np.unique(x) % world != rank).sum()) for x in (u_last, i_last.reshape(-1)))
+            # a user id moves (mf_u | mlp_u) = 2 d floats each way; an item id (mf_i | mlp_i) = 2 d, or -- item half computed by the
+            # owner -- (mf_i | W1i mlp_i) = d + l1 floats in and (d mf_i | dz) out
+            item_floats = (d + l1) if m.item_half == "owner" else 2 * d
+            rows = 4 * (2 * d * remote_u + item_floats * remote_i)
+            want = {"ids_out": 8 * (remote_u + remote_i), "rows_in": rows, "grads_out": rows}
             got = {k: m.wire[k] for k in want}
             assert got == want, (got, want)
             assert m.wire["ids_sent"] == len(np.unique(u_last)) + len(np.unique(i_last)) < m.wire["lookups"]
@@ -295,16 +330,19 @@ def _neumf_reference(world, opt, lr, l2, n_users, n_items, d, l1, B, C, steps):
     return losses, P
 
 
-@pytest.mark.parametrize("world,opt,lr,l2,micro_batches", [(2, "SGD", 0.1, 1e-3, 1), (3, "Adam", 1e-2, 1e-4, 1),
-                                                           (2, "Adam", 1e-2, 1e-4, 2), (3, "SGD", 0.1, 1e-3, 3)])
-def test_sharded_neumf_equals_single_table_training(world, opt, lr, l2, micro_batches):
+@pytest.mark.parametrize("world,opt,lr,l2,micro_batches,item_half", [
+    (2, "SGD", 0.1, 1e-3, 1, "owner"), (3, "Adam", 1e-2, 1e-4, 1, "owner"), (2, "Adam", 1e-2, 1e-4, 2, "owner"), (3, "SGD", 0.1, 1e-3, 3, "owner"),
+    (2, "SGD", 0.1, 1e-3, 1, "rows"), (3, "Adam", 1e-2, 1e-4, 1, "rows"), (2, "Adam", 1e-2, 1e-4, 2, "rows"), (3, "SGD", 0.1, 1e-3, 3, "rows")])
+def test_sharded_neumf_equals_single_table_training(world, opt, lr, l2, micro_batches, item_half):
     """micro_batches > 1: the pipelined step (chunks scored against the pre-step parameters, ONE update over the
-    gradients of all chunks) must equal the same single-table training"""
+    gradients of all chunks) must equal the same single-table training.  item_half "owner":
+    the owners return (mf_i | W1i mlp_i) and receive (d mf_i | dz) -- d + l1 instead of 2 d floats per distinct item id each way,
+    asserted on the byte counters -- and form d mlp_i and their share of dW1i themselves; "rows": both item rows travel"""
     shape = dict(n_users=19, n_items=37, d=8, l1=6, B=7, C=4, steps=3)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_neumf_worker, args=(r, world, port, opt, lr, l2, *shape.values(), q, micro_batches))
+    procs = [ctx.Process(target=_neumf_worker, args=(r, world, port, opt, lr, l2, *shape.values(), q, micro_batches, item_half))
              for r in range(world)]
     for p in procs:
         p.start()
@@ -318,7 +356,8 @@ def test_sharded_neumf_equals_single_table_training(world, opt, lr, l2, micro_ba
     # gradient itself is rounding noise (|g| ~ eps: one element of b1 here) -- ill-conditioned in any implementation
     atol = 1e-6 if (opt == "SGD" or micro_batches == 1) else 0.05 * lr
     for k, v in P.items():
-        np.testing.assert_allclose(G[k], v, rtol=2e-5, atol=atol, err_msg=k)
+        # (that element of b1: Adam normalises its noise gradient to a step of up to lr per step in either direction)
+        np.testing.assert_allclose(G[k], v, rtol=2e-5, atol=(0.3 * lr if (k == "b1" and atol > 1e-6) else atol), err_msg=k)
 
 
 def test_sharded_neumf_single_rank():

@@ -27,11 +27,16 @@ def main():
     ap.add_argument("--users", type=int, default=10_000_001)
     ap.add_argument("--compute-ms", type=float, default=1.50)
     ap.add_argument("--micro-batches", type=int, default=4)
+    ap.add_argument("--hidden", type=int, default=64)
+    ap.add_argument("--item-half", default="rows", choices=["rows", "owner"],
+                    help="owner: an item id moves (mf_i | W1i mlp_i) = emb_size + hidden floats each way instead of 2 emb_size "
+                         "(ShardedNeumf item_half='owner', profiles/r09_sharded_neumf_item_half.txt)")
     a = ap.parse_args()
-    row_bytes = 2 * a.emb_size * 4   # the mf and mlp rows of an id travel together
+    row_bytes = 2 * a.emb_size * 4   # the mf and mlp rows of a USER id travel together; an item id: see --item-half
+    item_row_bytes = (a.emb_size + a.hidden) * 4 if a.item_half == "owner" else row_bytes
     gen = torch.Generator().manual_seed(99)
     dev = torch.device("cpu")
-    out = {"config": vars(a), "row_bytes": row_bytes, "worlds": {}}
+    out = {"config": vars(a), "row_bytes": row_bytes, "item_row_bytes": item_row_bytes, "worlds": {}}
     for W in (2, 4, 8):
         # one rank's batch (every rank draws from the same distributions)
         uid = bench.zipf_ids(a.users, (a.batch,), gen, dev)
@@ -46,7 +51,7 @@ def main():
             n_remote = remote(ids_u) + remote(ids_i)
             res["dedup" if dedup else "every_occurrence"] = {
                 "lookups": int(uid.numel() + iid.numel()), "ids_sent": int(ids_u.numel() + ids_i.numel()), "ids_remote": n_remote,
-                "bytes_each_way": n_remote * row_bytes, "bytes_ids": n_remote * 8}
+                "bytes_each_way": remote(ids_u) * row_bytes + remote(ids_i) * item_row_bytes, "bytes_ids": n_remote * 8}
         b = res["dedup"]["bytes_each_way"]
         # the owners of the OTHER ranks' ids serve as many rows as this rank fetches (symmetric load): in + out per direction
         t = {}
