@@ -143,6 +143,18 @@ enum rc_field_kind { RC_FIELD_IDS = 0, RC_FIELD_F32 = 1, RC_FIELD_F64 = 2, RC_FI
 int rc_gather_fields_mixed(const float* const* tables, const float* const* tables1, const void* const* ids, const int* per_row,
                            const int* kind, int64_t numeric_key, const int64_t* row_offset, int F, int64_t B, int C, int d, float* out,
                            float* out1, int64_t* cid, int32_t* row_flags, const int64_t* step_dev, int step_add, rc_stream_t stream);
+/* rc_gather_fields_mixed with what the rest of a SMALL training step needs from the same ids, in the same launch (each optional):
+ *   fm_out [B * C], fm_sum [B * C, d]  the FM pairwise term of every row (models/context/FM.py:61; rc_fm_second_order_fwd's value bit
+ *                                      for bit) and the field sum sum_f out[r, f, :] its backward needs;
+ *   plan_ws                            the grouping of the composite (field, id) keys that aten::embedding_dense_backward's sort
+ *                                      does (rc_small_row_sums' first launch), by 128 workgroups beside the gather's, left where
+ *                                      rc_small_row_sums_planned reads it (rc_small_row_sums_workspace_bytes(B * C * F) bytes;
+ *                                      B * C * F <= 32,768 keys).
+ * d in {16, 32, 64, 128}; kind may be NULL (every field a table); the other arguments as rc_gather_fields_mixed.                     */
+int rc_gather_fields_fused(const float* const* tables, const float* const* tables1, const void* const* ids, const int* per_row,
+                           const int* kind, int64_t numeric_key, const int64_t* row_offset, int F, int64_t B, int C, int d, float* out,
+                           float* out1, int64_t* cid, int32_t* row_flags, const int64_t* step_dev, int step_add, float* fm_out,
+                           float* fm_sum, void* plan_ws, size_t plan_ws_bytes, rc_stream_t stream);
 /* Weight gradients of the numeric fields (autograd's Linear backward behind loss.backward(), helpers/BaseRunner.py:205, for the
  * modules of models/context/FM.py:38-41): dW[j][k] = sum_n x_j[n] * gV[n, field[j], k] and dw1[j][0] = sum_n x_j[n] * gL[n, field[j]]
  * over the n = B * C rows of the per-occurrence gradient blocks gV [n, F, d] / gL [n, F] (either may be NULL with its outputs).
@@ -422,6 +434,17 @@ int rc_small_row_sums_pair_numeric(const int64_t* ids, int64_t n, int64_t n_rows
                                    const float* src1, float* out1, const void* const* values, const int* per_row, const int* kind,
                                    const int* field, int n_numeric, int F, int64_t B, int C, float* const* dW, float* const* dw1,
                                    void* ws, size_t ws_bytes, rc_stream_t stream);
+
+/* The row sums of a backward pass whose grouping rc_gather_fields_fused left in ws (no plan launch): both table families of the FM
+ * models (src = gV [B * C, F, d] as n = B * C * F occurrence rows, src1 = gL [n]), with -- each optional -- the numeric fields' weight
+ * gradients riding along (n_numeric > 0, arguments as rc_small_row_sums_pair_numeric) and the FM pairwise term's backward folded in
+ * (fm_V != NULL: the stacked field vectors [B * C, F, d], fm_S their field sums [B * C, d], fm_g = d loss / d fm [B * C]):
+ * occurrence o = r F + f then contributes src[o] + fm_g[r] * (fm_S[r] - fm_V[o]) -- rc_fm_second_order_bwd_add's rows, never
+ * written out (models/context/FM.py:61, DeepFM.py:19-28); src may be NULL when nothing else consumed the field vectors.            */
+int rc_small_row_sums_planned(int64_t n, int64_t n_rows, const float* src, int d, float* out, const float* src1, float* out1,
+                              const void* const* values, const int* per_row, const int* kind, const int* field, int n_numeric, int F,
+                              int64_t B, int C, float* const* dW, float* const* dw1, const float* fm_V, const float* fm_S,
+                              const float* fm_g, void* ws, size_t ws_bytes, rc_stream_t stream);
 
 /* The CTR head of the context models in one pass: z = bias[0] + sum_f lin[i, f] (+ term1[i]) (+ term2[i])
  * (models/context/FM.py:59-60, DeepFM.py:27, WideDeep.py:46), p = sigmoid(z) (BaseContextModel.py:74-78), the per-row term of

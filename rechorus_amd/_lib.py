@@ -101,6 +101,7 @@ SIGNATURES = {
     "rc_list_metrics_supported": (_i, [_i, _i, _i]),
     "rc_list_metrics": (_i, [_p, _p, _p, _i64, _i, _i, _p, _i, _p, _p, _p]),
     "rc_gather_fields_mixed": (_i, [_p, _p, _p, _p, _p, _i64, _p, _i, _i64, _i, _i, _p, _p, _p, _p, _p, _i, _p]),
+    "rc_gather_fields_fused": (_i, [_p, _p, _p, _p, _p, _i64, _p, _i, _i64, _i, _i, _p, _p, _p, _p, _p, _i, _p, _p, _p, _sz, _p]),
     "rc_numeric_field_grads_workspace_bytes": (_sz, [_i64, _i, _i]),
     "rc_numeric_field_grads": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i64, _i, _i, _p, _p, _p, _sz, _p]),
     "rc_bce_ranking_fwd_bwd": (_i, [_p, _i64, _i, _f, _p, _p, _p]),
@@ -143,6 +144,7 @@ SIGNATURES = {
     "rc_small_row_sums_again": (_i, [_i64, _i64, _p, _i, _p, _p, _sz, _p]),
     "rc_small_row_sums_pair": (_i, [_p, _i64, _i64, _p, _i, _p, _p, _p, _p, _sz, _p]),
     "rc_small_row_sums_pair_numeric": (_i, [_p, _i64, _i64, _p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i64, _i, _p, _p, _p, _sz, _p]),
+    "rc_small_row_sums_planned": (_i, [_i64, _i64, _p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i64, _i, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "rc_segmented_rows_workspace_bytes": (_sz, [_i64, _i64, _i]),
     "rc_segmented_update_rows": (_i, [_p, _p, _p, _i, _i64, _p, _p, _i64, _p, _p, _p, _i, _p, _i64, _hp, _p, _p, _sz, _p]),
     "rc_segmented_update_rows_dev": (_i, [_p, _p, _p, _i, _i64, _p, _p, _i64, _p, _p, _p, _i, _p, _i64, _hp, _p, _p, _p, _sz, _p]),

@@ -10,8 +10,11 @@
 //
 // Both are HBM-bound streaming kernels: one lane-group (d/4 lanes, a float4 each) per instance walks
 // the F field vectors once (forward) or twice (backward: the field sum, then the per-field gradient).
+#include <mutex>
+
 #include "common.hpp"
 #include "numeric_grads.hpp"
+#include "small_plan.hpp"
 
 namespace rc {
 
@@ -350,21 +353,28 @@ struct FieldArgs {
 // MIXED: some field is numeric -- nn.Linear(1, d, bias=False) on the feature's value (FM.py:38-41): its "row" is x * W[:, 0]
 // (table[f] = the d weights), its first-order value x * w1; cid carries numeric_key, no row flag is stamped.  The field index
 // is uniform over the wave, so the kind test is a scalar branch.
-template <int VEC, bool MIXED>
-__global__ __launch_bounds__(kBlock) void gather_fields_kernel(FieldArgs a, float* __restrict__ out,
-                                                               int64_t* __restrict__ cid, float* __restrict__ out1,
-                                                               int32_t* __restrict__ row_flags, const int64_t* __restrict__ step_dev,
-                                                               int step_add) {
-  const int dq = a.d / VEC;
+// FMQ > 0 (VEC = 4, d = 4 FMQ in {16, 32, 64, 128}): the thread also keeps the field sum and the sum of squares of its four columns
+// and the row's lane-group forms the FM pairwise term 0.5 sum_k ((sum_f v)^2 - sum_f v^2) (FM.py:61) -- the arithmetic of
+// fm2_fwd_kernel, order for order, without the second pass over the stacked block -- and writes the field sum S[r, :] out for the
+// backward pass (d fm / d v[r, f, :] = S[r, :] - v[r, f, :]).
+// block / n_blocks / n_threads: this workgroup's place among the launch's gather workgroups (the launch may hold others).
+template <int VEC, bool MIXED, int FMQ>
+__device__ __forceinline__ void gather_fields_body(const FieldArgs& a, float* __restrict__ out, int64_t* __restrict__ cid,
+                                                   float* __restrict__ out1, int32_t* __restrict__ row_flags,
+                                                   const int64_t* __restrict__ step_dev, int step_add, float* __restrict__ fm_out,
+                                                   float* __restrict__ fm_sum, unsigned block, unsigned n_blocks, int n_threads) {
+  static_assert(FMQ == 0 || VEC == 4, "the FM term rides with the float4 tiling only");
+  const int dq = FMQ > 0 ? FMQ : a.d / VEC;
   // rc_gather_fields_pair_mark: every looked-up composite row is stamped with the step's number (the row-flagged dense update,
   // dense_opt.hip, tells the rows of this batch from the rest by it; equal stamps from duplicate ids race benignly)
   const int32_t gen = row_flags ? (int32_t)(*step_dev + step_add) : 0;
   const int64_t total = a.n * dq;
-  for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += (int64_t)gridDim.x * kBlock) {
+  for (int64_t e = (int64_t)block * n_threads + threadIdx.x; e < total; e += (int64_t)n_blocks * n_threads) {
     const int64_t r = e / dq;            // b * C + c
     const int q = (int)(e - r * dq);
     const int64_t rb = r / a.C;          // b (fields given per row)
     constexpr int U = 4;
+    float4 fs = make_float4(0.f, 0.f, 0.f, 0.f), fq = fs;
     for (int f0 = 0; f0 < a.F; f0 += U) {
       int64_t id[U];
       float xv[U];
@@ -392,7 +402,14 @@ __global__ __launch_bounds__(kBlock) void gather_fields_kernel(FieldArgs a, floa
           if (MIXED && a.kind[f0 + u < a.F ? f0 + u : a.F - 1] != RC_FIELD_IDS) {
             v[u].x *= xv[u]; v[u].y *= xv[u]; v[u].z *= xv[u]; v[u].w *= xv[u];
           }
-          if (f0 + u < a.F) reinterpret_cast<float4*>(out)[(r * a.F + f0 + u) * dq + q] = v[u];
+          if (f0 + u < a.F) {
+            reinterpret_cast<float4*>(out)[(r * a.F + f0 + u) * dq + q] = v[u];
+            if (FMQ > 0) {
+              const float4 x = v[u];
+              fs.x += x.x; fs.y += x.y; fs.z += x.z; fs.w += x.w;
+              fq.x = fmaf(x.x, x.x, fq.x); fq.y = fmaf(x.y, x.y, fq.y); fq.z = fmaf(x.z, x.z, fq.z); fq.w = fmaf(x.w, x.w, fq.w);
+            }
+          }
         }
       } else {
         float v[U];
@@ -432,14 +449,154 @@ __global__ __launch_bounds__(kBlock) void gather_fields_kernel(FieldArgs a, floa
         }
       }
     }
+    if (FMQ > 0) {
+      float part = 0.5f * (fs.x * fs.x - fq.x) + 0.5f * (fs.y * fs.y - fq.y) + 0.5f * (fs.z * fs.z - fq.z) + 0.5f * (fs.w * fs.w - fq.w);
+      part = row_allreduce_sum<(FMQ > 0 ? FMQ : 1)>(part);   // (a row's lanes are all in the loop together: total = n * FMQ)
+      if (q == 0) fm_out[r] = part;
+      reinterpret_cast<float4*>(fm_sum)[r * dq + q] = fs;
+    }
   }
+}
+
+template <int VEC, bool MIXED>
+__global__ __launch_bounds__(kBlock) void gather_fields_kernel(FieldArgs a, float* __restrict__ out,
+                                                               int64_t* __restrict__ cid, float* __restrict__ out1,
+                                                               int32_t* __restrict__ row_flags, const int64_t* __restrict__ step_dev,
+                                                               int step_add) {
+  gather_fields_body<VEC, MIXED, 0>(a, out, cid, out1, row_flags, step_dev, step_add, nullptr, nullptr, blockIdx.x, gridDim.x, kBlock);
+}
+
+// ---- the gather of a SMALL batch with the backward pass's grouping in the same launch -------------------------------------
+// At the reference's own batch size (B = 1,024, CTR_MIND.sh:8) a replayed step is a chain of launches of ~5-10 us each, so work that
+// depends on the batch's ids alone should not be a link of its own: the 128 plan workgroups of the small route (small_plan.hpp:
+// group the composite (field, id) keys by row, what embedding_dense_backward's sort does) run BESIDE the gather workgroups here and
+// leave the plan in the workspace the backward pass's row sums read (rc_small_row_sums_planned).  The plan workgroups form the keys
+// from the fields' id tensors themselves -- position p = r F + f, key = row_offset[f] + ids[f][r or r / C], kSmallSkipKey for a
+// numeric field -- through a copy of the field descriptors in LDS (a per-lane index into the kernel-argument arrays would put them
+// in scratch).
+struct FieldKeyLds {
+  const int64_t* ids[kMaxFields];
+  uint32_t row_offset[kMaxFields];
+  uint8_t per_row[kMaxFields], numeric[kMaxFields];
+};
+// scan index s = f * n + r (field-major: a wave's 64 consecutive s share the field but for one boundary, so the descriptor reads are
+// LDS broadcasts and the id loads coalesced), recorded position r * F + f (the occurrence's row in the [n, F, .] gradient blocks);
+// a key belongs to one field, so its positions ascend with s
+struct FieldPlanKey {
+  const FieldKeyLds* fk;
+  uint32_t F, n, magic_n, magic_c;
+  __device__ __forceinline__ uint32_t operator()(const SmallPlanArgs&, uint32_t s) const {
+    const uint32_t f = small_div(s, magic_n), r = s - f * n;
+    if (fk->numeric[f]) return kSmallSkipKey;
+    return fk->row_offset[f] + (uint32_t)fk->ids[f][fk->per_row[f] ? small_div(r, magic_c) : r];
+  }
+  __device__ __forceinline__ uint32_t pos(uint32_t s) const {
+    const uint32_t f = small_div(s, magic_n), r = s - f * n;
+    return r * F + f;
+  }
+};
+
+template <bool MIXED, int FMQ>
+__global__ __launch_bounds__(kSmallThreads) void gather_fields_plan_kernel(FieldArgs a, float* __restrict__ out, int64_t* __restrict__ cid,
+                                                                           float* __restrict__ out1, int32_t* __restrict__ row_flags,
+                                                                           const int64_t* __restrict__ step_dev, int step_add,
+                                                                           float* __restrict__ fm_out, float* __restrict__ fm_sum,
+                                                                           unsigned gather_blocks, SmallPlanArgs plan) {
+  if (blockIdx.x < gather_blocks) {   // (workgroup-uniform)
+    gather_fields_body<4, MIXED, FMQ>(a, out, cid, out1, row_flags, step_dev, step_add, fm_out, fm_sum, blockIdx.x, gather_blocks, kSmallThreads);
+    return;
+  }
+  extern __shared__ __attribute__((aligned(16))) unsigned char gather_plan_smem[];
+  __shared__ FieldKeyLds fk;
+  for (int f = threadIdx.x; f < a.F; f += kSmallThreads) {
+    fk.ids[f] = a.ids[f];
+    fk.row_offset[f] = (uint32_t)a.row_offset[f];
+    fk.per_row[f] = (uint8_t)(a.per_row[f] != 0);
+    fk.numeric[f] = (uint8_t)(a.kind[f] != RC_FIELD_IDS);
+  }
+  __syncthreads();
+  FieldPlanKey key;
+  key.fk = &fk; key.F = (uint32_t)a.F; key.n = (uint32_t)a.n;
+  key.magic_n = small_div_magic((uint32_t)a.n);      // s < n F <= 32,768 keys and r < n: n * d < 2^32 for both divisions
+  key.magic_c = small_div_magic((uint32_t)a.C);
+  small_plan_block<kSmallCapBig, kSmallWaveCapBig, FieldPlanKey>(plan, blockIdx.x - gather_blocks, gather_plan_smem, key);
 }
 
 }  // namespace rc
 
+// the FM term and / or the small route's plan inside the gather launch (rc_gather_fields_fused)
+template <bool MIXED, int FMQ>
+static int gather_fused_launch_t(const FieldArgs& a, float* out, int64_t* cid, float* out1, int32_t* row_flags, const int64_t* step_dev,
+                                 int step_add, float* fm_out, float* fm_sum, unsigned gather_blocks, const SmallPlanArgs* plan, hipStream_t s) {
+  auto kern = gather_fields_plan_kernel<MIXED, FMQ>;
+  SmallPlanArgs p;
+  memset(&p, 0, sizeof(p));
+  size_t lds = 0;
+  unsigned grid = gather_blocks;
+  if (plan != nullptr) {
+    p = *plan;
+    lds = kSmallLdsBytesBig;
+    grid += kSmallPlanWgs;
+    static std::mutex mu;       // function attributes are per device: once per device of the process
+    static bool done[64] = {};
+    int dev = 0;
+    RC_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    if (dev < 0 || dev >= 64 || !done[dev]) {
+      RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSmallLdsBytesBig));
+      if (dev >= 0 && dev < 64) done[dev] = true;
+    }
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(kSmallThreads), lds, s, a, out, cid, out1, row_flags, step_dev, step_add, fm_out, fm_sum, gather_blocks, p);
+  RC_LAUNCH_CHECK();
+  return RC_OK;
+}
+
+static int gather_fields_fused_launch(const FieldArgs& a, bool vec, bool mixed, float* out, int64_t* cid, float* out1, int32_t* row_flags,
+                                      const int64_t* step_dev, int step_add, float* fm_out, float* fm_sum, void* plan_ws,
+                                      size_t plan_ws_bytes, rc_stream_t stream) {
+  const int d = a.d;
+  RC_REQUIRE(vec && (d == 16 || d == 32 || d == 64 || d == 128), "rc_gather_fields_fused: d = %d (16 / 32 / 64 / 128, 16-byte aligned tables and output)", d);
+  RC_REQUIRE((fm_out == nullptr) == (fm_sum == nullptr), "rc_gather_fields_fused: the FM term and the field sums come together");
+  RC_REQUIRE(fm_sum == nullptr || reinterpret_cast<uintptr_t>(fm_sum) % 16 == 0, "rc_gather_fields_fused: fm_sum must be 16-byte aligned");
+  const int64_t n_keys = a.n * a.F;
+  SmallPlanArgs p;
+  memset(&p, 0, sizeof(p));
+  if (plan_ws != nullptr) {
+    int64_t n_rows = 0;
+    for (int f = 0; f < a.F; ++f) n_rows = a.row_offset[f] > n_rows ? a.row_offset[f] : n_rows;
+    RC_REQUIRE(n_rows < ((int64_t)1 << 32) - 1, "rc_gather_fields_fused: the concatenated table has too many rows for 32-bit keys");
+    if (!rc_small_row_sums_supported(n_keys, 1, d))
+      return fail(RC_ERR_UNSUPPORTED, "rc_gather_fields_fused: %lld keys are not a small batch (<= %d) or the LDS of this device is too small", (long long)n_keys, kSmallMaxKeys);
+    if (plan_ws_bytes < rc_small_row_sums_workspace_bytes(n_keys))
+      return fail(RC_ERR_WORKSPACE, "rc_gather_fields_fused: plan workspace %zu < %zu", plan_ws_bytes, rc_small_row_sums_workspace_bytes(n_keys));
+    Carver cv(plan_ws);     // the layout rc_small_row_sums_planned reads (small_step.hip)
+    p.rows = cv.take<rc_plan_row>((size_t)kSmallPlanWgs * (size_t)n_keys);
+    p.occ = cv.take<uint32_t>((size_t)kSmallPlanWgs * (size_t)n_keys);
+    p.cnt = cv.take<SmallCnt>(kSmallPlanWgs);
+    p.n_a = (uint32_t)n_keys; p.n = (uint32_t)n_keys; p.base_b = 0xFFFFFFFFu;     // one list: every key is a row of it
+  }
+  const int64_t total = a.n * (d / 4);
+  int64_t blocks = (total + kSmallThreads - 1) / kSmallThreads;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipStream_t s = as_stream(stream);
+  const SmallPlanArgs* pp = plan_ws != nullptr ? &p : nullptr;
+  const bool fm = fm_out != nullptr;
+#define RC_GF(M_, Q_) return gather_fused_launch_t<M_, Q_>(a, out, cid, out1, row_flags, step_dev, step_add, fm_out, fm_sum, (unsigned)blocks, pp, s)
+  if (!fm) { if (mixed) RC_GF(true, 0); RC_GF(false, 0); }
+  switch (d) {
+    case 16: if (mixed) RC_GF(true, 4); RC_GF(false, 4);
+    case 32: if (mixed) RC_GF(true, 8); RC_GF(false, 8);
+    case 64: if (mixed) RC_GF(true, 16); RC_GF(false, 16);
+    default: if (mixed) RC_GF(true, 32); RC_GF(false, 32);
+  }
+#undef RC_GF
+}
+
 static int gather_fields_impl(const float* const* tables, const float* const* tables1, const void* const* ids, const int* per_row,
                               const int* kind, int64_t numeric_key, const int64_t* row_offset, int F, int64_t B, int C, int d, float* out,
-                              float* out1, int64_t* cid, int32_t* row_flags, const int64_t* step_dev, int step_add, rc_stream_t stream) {
+                              float* out1, int64_t* cid, int32_t* row_flags, const int64_t* step_dev, int step_add, rc_stream_t stream,
+                              float* fm_out = nullptr, float* fm_sum = nullptr, void* plan_ws = nullptr, size_t plan_ws_bytes = 0) {
   if (B == 0) return RC_OK;
   RC_REQUIRE((row_flags == nullptr) == (step_dev == nullptr), "rc_gather_fields_pair_mark: the row flags and the step count come together");
   RC_REQUIRE(tables && ids && per_row && row_offset && out, "rc_gather_fields: null pointer");
@@ -464,6 +621,7 @@ static int gather_fields_impl(const float* const* tables, const float* const* ta
   }
   a.numeric_key = numeric_key;
   a.F = F; a.C = C; a.d = d; a.n = B * C;
+  if (fm_out != nullptr || plan_ws != nullptr) return gather_fields_fused_launch(a, vec, mixed, out, cid, out1, row_flags, step_dev, step_add, fm_out, fm_sum, plan_ws, plan_ws_bytes, stream);
   const int64_t total = a.n * (vec ? d / 4 : d);   // one thread per (row, float4 | float), walking the fields
   int64_t blocks = (total + kBlock - 1) / kBlock;
   if (blocks > 256 * 32) blocks = 256 * 32;
@@ -503,6 +661,22 @@ extern "C" int rc_gather_fields_mixed(const float* const* tables, const float* c
   RC_REQUIRE(kind, "rc_gather_fields_mixed: null pointer");
   return gather_fields_impl(tables, tables1, ids, per_row, kind, numeric_key, row_offset, F, B, C, d, out, out1, cid, row_flags, step_dev,
                             step_add, stream);
+}
+
+/* rc_gather_fields_mixed with what the rest of a small step needs from the same pass (each part optional):
+ *   fm_out [B * C], fm_sum [B * C, d]   the FM pairwise term of every row (rc_fm_second_order_fwd's value, bit for bit) and the field
+ *                                       sum its backward needs -- no second pass over the stacked block;
+ *   plan_ws                             the grouping of the composite keys (rc_small_row_sums' first launch) by 128 workgroups
+ *                                       beside the gather's, left where rc_small_row_sums_planned reads it.
+ * d in {16, 32, 64, 128}; the plan: B * C * F <= 32,768 keys.  kind may be null (every field a table). */
+extern "C" int rc_gather_fields_fused(const float* const* tables, const float* const* tables1, const void* const* ids,
+                                      const int* per_row, const int* kind, int64_t numeric_key, const int64_t* row_offset, int F,
+                                      int64_t B, int C, int d, float* out, float* out1, int64_t* cid, int32_t* row_flags,
+                                      const int64_t* step_dev, int step_add, float* fm_out, float* fm_sum, void* plan_ws,
+                                      size_t plan_ws_bytes, rc_stream_t stream) {
+  RC_REQUIRE(fm_out != nullptr || plan_ws != nullptr, "rc_gather_fields_fused: neither the FM term nor the plan was asked for");
+  return gather_fields_impl(tables, tables1, ids, per_row, kind, numeric_key, row_offset, F, B, C, d, out, out1, cid, row_flags, step_dev,
+                            step_add, stream, fm_out, fm_sum, plan_ws, plan_ws_bytes);
 }
 
 // ---- weight gradients of the numeric fields ---------------------------------------------------------------------------

@@ -26,9 +26,24 @@ struct NumericSlot {       // one numeric field
   float* dw1;              // [1]
   int kind, per_row, field;
 };
+// The FM pairwise term's backward folded into a consumer of the field vectors' gradient (rc_small_row_sums_planned): the gradient
+// row of occurrence o = r F + f is  base[o] + g[r] * (S[r] - V[o])  (fm2_bwd_kernel's expression; base: the gradient through the
+// other consumer of the field vectors -- DeepFM's deep tower -- or nothing), formed in registers where the row is read.
+struct FmTap {
+  const float* V;          // [n, F, d] the stacked field vectors | null: no FM term
+  const float* S;          // [n, d] their sum over the fields (the gather wrote it)
+  const float* g;          // [n] d loss / d fm
+  uint32_t F;
+  uint32_t magic_F;        // ceil(2^32 / F) (0: F = 1): o / F by one v_mul_hi_u32 for o < 32,768 occurrences
+};
+__device__ __forceinline__ float4 fm_tap4(const float4& base, float g, const float4& s, const float4& x) {
+  return make_float4(base.x + g * (s.x - x.x), base.y + g * (s.y - x.y), base.z + g * (s.z - x.z), base.w + g * (s.w - x.w));
+}
+
 struct NumericCommon {
   const float* gV;         // [n, F, d] | null
   const float* gL;         // [n, F] | null
+  FmTap fm;                // gV's rows take the FM term's backward on top (fm.V != null; gV may then be null)
   float* part;             // [chunks][n_numeric][d + 1] (several chunks only)
   int64_t n;               // B * C
   int n_numeric, F, C, d;
@@ -66,7 +81,7 @@ __device__ __forceinline__ void numeric_slot_grads(const NumericSlot& sl, const 
     for (int c = 0; c < VEC; ++c) acc[c] = 0.f;
     float acc1 = 0.f;
     const bool first = c0 == 0 && l == 0 && split == 0 && a.gL != nullptr;   // this lane also forms the first-order weight's sum
-    if (live && a.gV) {
+    if (live && (a.gV || (VEC == 4 && a.fm.V))) {
       for (uint32_t r = r0 + rs; r < r1; r += (uint32_t)slots * U) {
         float x[U], g1[U];
         float gv[U][VEC];
@@ -76,12 +91,15 @@ __device__ __forceinline__ void numeric_slot_grads(const NumericSlot& sl, const 
           const bool in = rr < r1;
           const uint32_t ra = in ? rr : r0;
           x[u] = in ? field_value(kind, xs, cdiv == 1u ? ra : ra / cdiv) : 0.f;
-          const float* src = a.gV + ((size_t)ra * a.F + f) * a.d + (size_t)(q_lo + cq) * VEC;
+          const size_t at = ((size_t)ra * a.F + f) * a.d + (size_t)(q_lo + cq) * VEC;
           if (VEC == 4) {
-            const float4 t = *reinterpret_cast<const float4*>(src);
+            float4 t = a.gV ? *reinterpret_cast<const float4*>(a.gV + at) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a.fm.V)
+              t = fm_tap4(t, a.fm.g[ra], *reinterpret_cast<const float4*>(a.fm.S + (size_t)ra * a.d + (size_t)(q_lo + cq) * VEC),
+                          *reinterpret_cast<const float4*>(a.fm.V + at));
             gv[u][0] = t.x; gv[u][1 % VEC] = t.y; gv[u][2 % VEC] = t.z; gv[u][3 % VEC] = t.w;
           } else {
-            gv[u][0] = src[0];
+            gv[u][0] = a.gV[at];
           }
           g1[u] = (first && in) ? a.gL[(size_t)rr * a.F + f] : 0.f;
         }
@@ -127,7 +145,7 @@ __device__ __forceinline__ void numeric_slot_grads(const NumericSlot& sl, const 
         for (int c = 0; c < VEC; ++c) t[c] += red[(q * lpr + l) * VEC + c];
         t1 += red1[q * lpr + l];
       }
-      if (a.gV && col) {
+      if ((a.gV || (VEC == 4 && a.fm.V)) && col) {
 #pragma unroll
         for (int c = 0; c < VEC; ++c) {
           if (direct) sl.dW[(q_lo + cq) * VEC + c] = t[c];

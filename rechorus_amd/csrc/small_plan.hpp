@@ -57,13 +57,24 @@ struct SmallPlanArgs {
 #define RC_T(k) do { } while (0)
 #endif
 
-__device__ __forceinline__ uint32_t small_key(const SmallPlanArgs& a, uint32_t p) {
-  return p < a.n_a ? (uint32_t)a.ids_a[p] : a.base_b + (uint32_t)a.ids_b[p - a.n_a];
-}
+// where position p's key comes from: one or two id lists (the default), or whatever a caller's functor derives it from (the
+// composite (field, id) keys of a context model's gather, formed from the fields' own id tensors: fm_bce.hip)
+// (a functor enumerates the keys by a SCAN index s in [0, n): key(a, s) and the position pos(s) the plan records for it -- the scan
+// order is free, the sort below orders by (key, position); positions of one key must ascend with s)
+struct SmallListKey {
+  __device__ __forceinline__ uint32_t operator()(const SmallPlanArgs& a, uint32_t p) const {
+    return p < a.n_a ? (uint32_t)a.ids_a[p] : a.base_b + (uint32_t)a.ids_b[p - a.n_a];
+  }
+  __device__ __forceinline__ uint32_t pos(uint32_t s) const { return s; }
+};
+
+// exact n / d for n * d < 2^32 by one v_mul_hi_u32 (magic = ceil(2^32 / d), d >= 2; d == 1: magic 0 stands for "n itself")
+__host__ __device__ __forceinline__ uint32_t small_div_magic(uint32_t d) { return d <= 1u ? 0u : (uint32_t)((((uint64_t)1 << 32) + d - 1) / d); }
+__device__ __forceinline__ uint32_t small_div(uint32_t n, uint32_t magic) { return magic == 0u ? n : __umulhi(n, magic); }
 
 // one plan workgroup (blockDim = kSmallThreads); smem: small_lds_bytes(CAP, WCAP) of dynamic LDS
-template <int CAP = kSmallCap, int WCAP = kSmallWaveCap>
-__device__ __forceinline__ void small_plan_block(const SmallPlanArgs& a, uint32_t w, unsigned char* smem) {
+template <int CAP = kSmallCap, int WCAP = kSmallWaveCap, class KEY = SmallListKey>
+__device__ __forceinline__ void small_plan_block(const SmallPlanArgs& a, uint32_t w, unsigned char* smem, const KEY& small_key = KEY()) {
   constexpr int kSmallCap = CAP, kSmallWaveCap = WCAP;   // (shadow the defaults below)
   uint64_t* region = reinterpret_cast<uint64_t*>(smem);                       // [kSmallWaves][kSmallWaveCap]
   uint64_t* buf = region + (size_t)kSmallWaves * kSmallWaveCap;               // [kSmallCap]
@@ -97,7 +108,7 @@ __device__ __forceinline__ void small_plan_block(const SmallPlanArgs& a, uint32_
       const bool mine = p < p_end && key[q] != kSmallSkipKey && (key[q] & (kSmallPlanWgs - 1)) == w;
       const uint64_t m = __ballot(mine);
       const uint32_t at = cnt + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-      if (mine && at < (uint32_t)kSmallWaveCap) region[(size_t)wave * kSmallWaveCap + at] = ((uint64_t)key[q] << 15) | p;
+      if (mine && at < (uint32_t)kSmallWaveCap) region[(size_t)wave * kSmallWaveCap + at] = ((uint64_t)key[q] << 15) | small_key.pos(p);
       cnt += (uint32_t)__popcll(m);
     }
   }
@@ -262,8 +273,8 @@ __device__ __forceinline__ void small_plan_block(const SmallPlanArgs& a, uint32_
       }
       if (hit) {
         const uint32_t at = before + (uint32_t)__popcll(hb & ((1ull << lane) - 1ull));
-        occ[n_occ + at] = p;
-        if (at == 0) sc[40] = p;   // the row's first position
+        occ[n_occ + at] = small_key.pos(p);
+        if (at == 0) sc[40] = small_key.pos(p);   // the row's first position
       }
       taken += total;
       __syncthreads();

@@ -225,6 +225,7 @@ struct SmallSumArgs {
   int n_numeric;
   NumericSlot num[kSmallNumeric];
   NumericCommon numc;
+  FmTap fm;                  // rc_small_row_sums_planned: the FM term's backward on top of src's rows (src may then be null)
 };
 
 // flat row index -> record (rows of plan workgroup w are the w-th segment; per-workgroup counts prefix-summed here)
@@ -255,7 +256,37 @@ __device__ __forceinline__ rc_plan_row small_row_at(const SmallSumArgs& a, const
   return a.rows[(size_t)lo * a.n + (q - ix.pre[lo])];
 }
 
-template <int D>
+// the float4 of NB occurrences' gradient rows this lane sums (o[j]; in[j]: the slot is in use); FM: the FM term's backward added
+// where the rows are read (numeric_grads.hpp) -- every load of the batch is requested before the first is used (an unused slot reads
+// occurrence 0: no branch between the requests)
+template <int D, bool FM, int NB>
+__device__ __forceinline__ void small_occ_rows4(const SmallSumArgs& a, const float4* src4, const uint32_t (&o)[NB], const bool (&in)[NB], int l,
+                                                float4 (&v)[NB]) {
+  constexpr int LPR = D / 4;
+  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (!FM) {
+#pragma unroll
+    for (int j = 0; j < NB; ++j) v[j] = in[j] ? src4[(size_t)o[j] * LPR + l] : zero;
+    return;
+  }
+  const float4* V4 = reinterpret_cast<const float4*>(a.fm.V);
+  const float4* S4 = reinterpret_cast<const float4*>(a.fm.S);
+  float4 x[NB], sv[NB];
+  float g[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const uint32_t oj = in[j] ? o[j] : 0u;
+    const uint32_t r = a.fm.magic_F == 0u ? oj : __umulhi(oj, a.fm.magic_F);
+    v[j] = src4 != nullptr ? src4[(size_t)oj * LPR + l] : zero;
+    x[j] = V4[(size_t)oj * LPR + l];
+    sv[j] = S4[(size_t)r * LPR + l];
+    g[j] = a.fm.g[r];
+  }
+#pragma unroll
+  for (int j = 0; j < NB; ++j) v[j] = in[j] ? fm_tap4(v[j], g[j], sv[j], x[j]) : zero;
+}
+
+template <int D, bool FM>
 __global__ __launch_bounds__(kBlock) void small_row_sums_kernel(SmallSumArgs a) {
   constexpr int LPR = D / 4;
   constexpr int GPW = 64 / LPR;
@@ -299,12 +330,12 @@ __global__ __launch_bounds__(kBlock) void small_row_sums_kernel(SmallSumArgs a) 
         for (int j = 0; j < kB; ++j) on_[j] = k0 + kB + j < e.n ? a.occ[e.start + k0 + kB + j] : 0u;
         float4 v[kB];
         float s1[kB];
+        bool in_[kB];
 #pragma unroll
-        for (int j = 0; j < kB; ++j) {
-          const bool in = k0 + j < e.n;
-          v[j] = in ? src4[(size_t)oc[j] * LPR + l] : make_float4(0.f, 0.f, 0.f, 0.f);
-          s1[j] = (a.src1 && in) ? a.src1[oc[j]] : 0.f;
-        }
+        for (int j = 0; j < kB; ++j) in_[j] = k0 + j < e.n;
+        small_occ_rows4<D, FM, kB>(a, src4, oc, in_, l, v);
+#pragma unroll
+        for (int j = 0; j < kB; ++j) s1[j] = (a.src1 && in_[j]) ? a.src1[oc[j]] : 0.f;
 #pragma unroll
         for (int j = 0; j < kB; ++j) {
           if (k0 + j < e.n) {
@@ -338,14 +369,17 @@ __global__ __launch_bounds__(kBlock) void small_row_sums_kernel(SmallSumArgs a) 
           const uint32_t mine = k64 == 0 ? pm0 : (k64 == 1 ? pm1 : pm2);
           float4 sv[U];
           float s1[U];
+          uint32_t ou[U];
+          bool in_[U];
 #pragma unroll
           for (int u = 0; u < U; ++u) {
             const uint32_t idx = base + u * GPW + grp;
-            const uint32_t o = __shfl(mine, idx & 63, 64);
-            const bool in = idx < cn;
-            sv[u] = in ? src4[(size_t)o * LPR + l] : make_float4(0.f, 0.f, 0.f, 0.f);
-            s1[u] = (a.src1 && in) ? a.src1[o] : 0.f;
+            ou[u] = __shfl(mine, idx & 63, 64);
+            in_[u] = idx < cn;
           }
+          small_occ_rows4<D, FM, U>(a, src4, ou, in_, l, sv);
+#pragma unroll
+          for (int u = 0; u < U; ++u) s1[u] = (a.src1 && in_[u]) ? a.src1[ou[u]] : 0.f;
 #pragma unroll
           for (int u = 0; u < U; ++u) {
             padd4s(part, sv[u]);
@@ -479,9 +513,9 @@ struct SmallNumericCall {     // host-side description of the numeric fields tha
 
 static int small_row_sums_impl(bool build_plan, const int64_t* ids, int64_t n, int64_t n_rows, const float* src, int d, float* out, void* ws,
                                size_t ws_bytes, rc_stream_t stream, const float* src1 = nullptr, float* out1 = nullptr,
-                               const SmallNumericCall* numeric = nullptr) {
+                               const SmallNumericCall* numeric = nullptr, const FmTap* fm = nullptr) {
   if (n == 0) return RC_OK;
-  RC_REQUIRE((ids || !build_plan) && src && out && ws, "rc_small_row_sums: null pointer");
+  RC_REQUIRE((ids || !build_plan) && (src || fm) && out && ws, "rc_small_row_sums: null pointer");
   if (!rc_small_row_sums_supported(n, n_rows, d))
     return fail(RC_ERR_UNSUPPORTED, "rc_small_row_sums: n=%lld (<= %d), n_rows=%lld, d=%d (1..4, 16, 32, 64, 128) not covered",
                 (long long)n, kSmallMaxKeys, (long long)n_rows, d);
@@ -489,6 +523,9 @@ static int small_row_sums_impl(bool build_plan, const int64_t* ids, int64_t n, i
     return fail(RC_ERR_WORKSPACE, "rc_small_row_sums: workspace %zu < %zu", ws_bytes, rc_small_row_sums_workspace_bytes(n));
   RC_REQUIRE(d <= 4 || (reinterpret_cast<uintptr_t>(src) % 16 == 0 && reinterpret_cast<uintptr_t>(out) % 16 == 0),
              "rc_small_row_sums: src / out must be 16-byte aligned");
+  RC_REQUIRE(fm == nullptr || (d >= 16 && fm->V && fm->S && fm->g && fm->F >= 1 && n % fm->F == 0 && reinterpret_cast<uintptr_t>(fm->V) % 16 == 0 &&
+                               reinterpret_cast<uintptr_t>(fm->S) % 16 == 0),
+             "rc_small_row_sums_planned: the FM term's backward needs d >= 16, 16-byte aligned V [n / F, F, d] and S [n / F, d], and g [n / F]");
   hipStream_t s = as_stream(stream);
   Carver cv(ws);
   rc_plan_row* rows = cv.take<rc_plan_row>((size_t)kSmallPlanWgs * (size_t)n);
@@ -517,12 +554,16 @@ static int small_row_sums_impl(bool build_plan, const int64_t* ids, int64_t n, i
   a.rows = rows; a.occ = occ; a.cnt = cnt; a.n = (uint32_t)n; a.src = src; a.out = out; a.d = d;
   a.src1 = src1; a.out1 = out1;
   a.n_numeric = 0;
+  memset(&a.numc, 0, sizeof(a.numc));
+  memset(&a.fm, 0, sizeof(a.fm));
+  if (fm != nullptr) a.fm = *fm;
   RC_REQUIRE((src1 == nullptr) == (out1 == nullptr) && (src1 == nullptr || d >= 16), "rc_small_row_sums_pair: the one-float-wide pair rides with d >= 16 only");
   RC_REQUIRE(numeric == nullptr || d >= 16, "rc_small_row_sums_pair_numeric: the numeric fields ride with the d >= 16 kernels only");
   if (numeric != nullptr) {
     a.n_numeric = numeric->n_numeric;
     for (int j = 0; j < numeric->n_numeric; ++j) a.num[j] = numeric->num[j];
     a.numc = numeric->c;
+    a.numc.fm = a.fm;
   }
   if (d <= 4) {
     unsigned blocks = (unsigned)((n + kBlock / 64 - 1) / (kBlock / 64));
@@ -534,11 +575,20 @@ static int small_row_sums_impl(bool build_plan, const int64_t* ids, int64_t n, i
     if (blocks > 2048u) blocks = 2048u;
     a.blocks_rows = blocks;
     const unsigned grid = blocks + (unsigned)(a.n_numeric * kSmallNumericSplits);     // the numeric fields' workgroups come last: the rows' are dispatched first
-    switch (d) {
-      case 16: hipLaunchKernelGGL((small_row_sums_kernel<16>), dim3(grid), dim3(kBlock), 0, s, a); break;
-      case 32: hipLaunchKernelGGL((small_row_sums_kernel<32>), dim3(grid), dim3(kBlock), 0, s, a); break;
-      case 64: hipLaunchKernelGGL((small_row_sums_kernel<64>), dim3(grid), dim3(kBlock), 0, s, a); break;
-      default: hipLaunchKernelGGL((small_row_sums_kernel<128>), dim3(grid), dim3(kBlock), 0, s, a); break;
+    if (fm != nullptr) {
+      switch (d) {
+        case 16: hipLaunchKernelGGL((small_row_sums_kernel<16, true>), dim3(grid), dim3(kBlock), 0, s, a); break;
+        case 32: hipLaunchKernelGGL((small_row_sums_kernel<32, true>), dim3(grid), dim3(kBlock), 0, s, a); break;
+        case 64: hipLaunchKernelGGL((small_row_sums_kernel<64, true>), dim3(grid), dim3(kBlock), 0, s, a); break;
+        default: hipLaunchKernelGGL((small_row_sums_kernel<128, true>), dim3(grid), dim3(kBlock), 0, s, a); break;
+      }
+    } else {
+      switch (d) {
+        case 16: hipLaunchKernelGGL((small_row_sums_kernel<16, false>), dim3(grid), dim3(kBlock), 0, s, a); break;
+        case 32: hipLaunchKernelGGL((small_row_sums_kernel<32, false>), dim3(grid), dim3(kBlock), 0, s, a); break;
+        case 64: hipLaunchKernelGGL((small_row_sums_kernel<64, false>), dim3(grid), dim3(kBlock), 0, s, a); break;
+        default: hipLaunchKernelGGL((small_row_sums_kernel<128, false>), dim3(grid), dim3(kBlock), 0, s, a); break;
+      }
     }
   }
   RC_LAUNCH_CHECK();
@@ -583,4 +633,38 @@ extern "C" int rc_small_row_sums_pair_numeric(const int64_t* ids, int64_t n, int
   }
   nc.c.gV = src; nc.c.gL = src1; nc.c.part = nullptr; nc.c.n = B * C; nc.c.n_numeric = n_numeric; nc.c.F = F; nc.c.C = C; nc.c.d = d;
   return small_row_sums_impl(true, ids, n, n_rows, src, d, out, ws, ws_bytes, stream, src1, out1, &nc);
+}
+
+/* The row sums of a backward pass whose grouping rc_gather_fields_fused already left in `ws` (no plan launch), for both table
+ * families of the FM models, with -- each optional -- the numeric fields' weight gradients riding along (n_numeric > 0, as
+ * rc_small_row_sums_pair_numeric) and the FM pairwise term's backward folded in (fm_V != null): occurrence o = r F + f then
+ * contributes  src[o] + fm_g[r] * (fm_S[r] - fm_V[o])  (rc_fm_second_order_bwd_add's rows, never written out; src may be null:
+ * no other consumer of the field vectors). */
+extern "C" int rc_small_row_sums_planned(int64_t n, int64_t n_rows, const float* src, int d, float* out, const float* src1, float* out1,
+                                         const void* const* values, const int* per_row, const int* kind, const int* field,
+                                         int n_numeric, int F, int64_t B, int C, float* const* dW, float* const* dw1, const float* fm_V,
+                                         const float* fm_S, const float* fm_g, void* ws, size_t ws_bytes, rc_stream_t stream) {
+  RC_REQUIRE(src1 && out1, "rc_small_row_sums_planned: null pointer");
+  RC_REQUIRE(n_numeric >= 0 && n_numeric <= kSmallNumeric && n_numeric <= F && F >= 1 && F <= kMaxFields,
+             "rc_small_row_sums_planned: %d numeric fields (0 .. %d) of F = %d", n_numeric, kSmallNumeric, F);
+  RC_REQUIRE(B >= 1 && C >= 1 && B * C * F == n && d % 4 == 0 && d >= 16, "rc_small_row_sums_planned: bad shape B=%lld C=%d F=%d n=%lld d=%d",
+             (long long)B, C, F, (long long)n, d);
+  RC_REQUIRE((fm_V == nullptr) == (fm_S == nullptr) && (fm_V == nullptr) == (fm_g == nullptr), "rc_small_row_sums_planned: fm_V, fm_S and fm_g come together");
+  FmTap fm;
+  fm.V = fm_V; fm.S = fm_S; fm.g = fm_g; fm.F = (uint32_t)F; fm.magic_F = small_div_magic((uint32_t)F);
+  SmallNumericCall nc;
+  memset(&nc, 0, sizeof(nc));
+  if (n_numeric > 0) {
+    RC_REQUIRE(values && per_row && kind && field && dW && dw1, "rc_small_row_sums_planned: null pointer (numeric fields)");
+    nc.n_numeric = n_numeric;
+    for (int j = 0; j < n_numeric; ++j) {
+      RC_REQUIRE(values[j] && dW[j] && dw1[j] && field[j] >= 0 && field[j] < F && kind[j] >= RC_FIELD_F32 && kind[j] <= RC_FIELD_I64,
+                 "rc_small_row_sums_planned: bad numeric field %d", j);
+      nc.num[j].values = values[j]; nc.num[j].dW = dW[j]; nc.num[j].dw1 = dw1[j];
+      nc.num[j].kind = kind[j]; nc.num[j].per_row = per_row[j]; nc.num[j].field = field[j];
+    }
+    nc.c.gV = src; nc.c.gL = src1; nc.c.part = nullptr; nc.c.n = B * C; nc.c.n_numeric = n_numeric; nc.c.F = F; nc.c.C = C; nc.c.d = d;
+  }
+  return small_row_sums_impl(false, nullptr, n, n_rows, src, d, out, ws, ws_bytes, stream, src1, out1, n_numeric > 0 ? &nc : nullptr,
+                             fm_V != nullptr ? &fm : nullptr);
 }

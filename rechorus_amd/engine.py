@@ -530,6 +530,43 @@ def small_row_sums_pair(cid, n_rows, src_a, src_b, into=None, numeric=None):
     return Ga, Gb
 
 
+def small_row_sums_planned(plan_ws, n, n_rows, src_a, src_b, d, shape, into=None, numeric=None, fm=None):
+    """small_row_sums_pair on a grouping that gather_fields(plan=True) built during the forward pass (rc_small_row_sums_planned: ONE
+    launch): src_a [n, d] | None, src_b [n, 1]; shape = (F, B, n_cand) with n = B * n_cand * F; numeric = (values, fields, F, n_cand)
+    as small_row_sums_pair;
+    fm = (V [rows, F, d], S [rows, d], g [rows]): the FM pairwise term's backward is added to src_a's rows where they are read
+    (src_a may then be None) -> (Ga, Gb) or (Ga, Gb, dW list, dw1 list)"""
+    dev, f32 = src_b.device, torch.float32
+    G = torch.zeros(n_rows * (d + 1), dtype=f32, device=dev) if into is None else into
+    Ga, Gb = G[:n_rows * d].view(n_rows, d), G[n_rows * d:].view(n_rows, 1)
+    J = 0
+    val_arr = per_row = kind_arr = field_arr = dW_arr = dw1_arr = dW = dw1 = None
+    F, B, n_cand = shape
+    if numeric is not None:
+        values, fields = numeric[:2]
+        J = len(values)
+        if not (1 <= J <= SMALL_NUMERIC_MAX):
+            raise ValueError("small_row_sums_planned: at most %d numeric fields ride along" % SMALL_NUMERIC_MAX)
+        dW = torch.empty((J, d, 1), dtype=f32, device=dev)
+        dw1 = torch.empty((J, 1, 1), dtype=f32, device=dev)
+        val_arr = (C.c_void_p * J)(*[_ptr(x, x.dtype, "values").value for x in values])
+        per_row = (C.c_int * J)(*[1 if x.dim() == 1 else 0 for x in values])
+        kind_arr = (C.c_int * J)(*[field_kind(x) for x in values])
+        field_arr = (C.c_int * J)(*[int(f) for f in fields])
+        dW_arr = (C.c_void_p * J)(*[dW[j].data_ptr() for j in range(J)])
+        dw1_arr = (C.c_void_p * J)(*[dw1[j].data_ptr() for j in range(J)])
+    fm_V = fm_S = fm_g = None
+    if fm is not None:
+        fm_V, fm_S, fm_g = fm
+    _lib.call("rc_small_row_sums_planned", n, int(n_rows), _ptr(src_a, f32, "src_a", True), int(d), C.c_void_p(Ga.data_ptr()),
+              _ptr(src_b, f32, "src_b"), C.c_void_p(Gb.data_ptr()), val_arr, per_row, kind_arr, field_arr, J, int(F), int(B), int(n_cand),
+              dW_arr, dw1_arr, _ptr(fm_V, f32, "fm_V", True), _ptr(fm_S, f32, "fm_S", True), _ptr(fm_g, f32, "fm_g", True),
+              C.c_void_p(plan_ws.data_ptr()), plan_ws.numel(), _stream())
+    if J:
+        return Ga, Gb, [dW[j] for j in range(J)], [dw1[j] for j in range(J)]
+    return Ga, Gb
+
+
 def dense_update(W, G, hyper, m=None, v=None):
     """Exact torch.optim step over a whole tensor (helpers/BaseRunner.py:206)."""
     _lib.call("rc_dense_update", _ptr(W, torch.float32, "W"), _ptr(G, torch.float32, "G"),
@@ -1914,7 +1951,7 @@ def field_kind(values):
     return kind
 
 
-def gather_fields(tables, ids, n_cand, want_cid=True, tables1=None, mark=None, kinds=None, numeric_key=-1):
+def gather_fields(tables, ids, n_cand, want_cid=True, tables1=None, mark=None, kinds=None, numeric_key=-1, fm=False, plan=False):
     """tables: list of F [vocab_f, d] tensors; ids: list of F int64 tensors, [B] (per-row field) or [B, C]
     -> (out [B, C, F, d], cid [B, C, F] | None, row_offset list): all field lookups in one launch.
     tables1: F [vocab_f, 1] tables looked up with the same ids (rc_gather_fields_pair) -> (out, out1 [B, C, F, 1], cid, offsets)
@@ -1922,7 +1959,10 @@ def gather_fields(tables, ids, n_cand, want_cid=True, tables1=None, mark=None, k
     step in progress, step_dev + 1 (rc_gather_fields_pair_mark, for dense_update_rows)
     kinds: per field FIELD_IDS or the value type of a NUMERIC field (rc_gather_fields_mixed; models/context/FM.py:38-41,47-48):
     tables[f] is then the Linear(1, d) weight [d, 1], tables1[f] the Linear(1, 1) weight [1, 1], ids[f] the feature's values;
-    such a field owns no row of the concatenated table and its occurrences carry `numeric_key` in cid"""
+    such a field owns no row of the concatenated table and its occurrences carry `numeric_key` in cid
+    fm / plan (rc_gather_fields_fused; d in 16 / 32 / 64 / 128, tables1 given): the same launch also forms the FM pairwise term
+    [B, C] + the field sums [B, C, d], and / or groups the composite keys for the backward pass's row sums (small batches) into a
+    fresh workspace -> (out, out1, cid, offsets, fm_term | None, fm_sum | None, plan_ws | None)"""
     F = len(tables)
     kinds = [FIELD_IDS] * F if kinds is None else [int(k) for k in kinds]
     mixed = any(k != FIELD_IDS for k in kinds)
@@ -1957,6 +1997,21 @@ def gather_fields(tables, ids, n_cand, want_cid=True, tables1=None, mark=None, k
             raise ValueError("gather_fields: row flags come with the pair gather")
         if flags.numel() != run:
             raise ValueError("gather_fields: one row flag per row of the concatenated tables")
+    if fm or plan:
+        if tables1 is None or d not in (16, 32, 64, 128):
+            raise ValueError("gather_fields: the FM term / the plan ride with the pair gather at d in 16 / 32 / 64 / 128")
+        kind_arr = (C.c_int * F)(*kinds)
+        fm_term = torch.empty((B, n_cand), dtype=f32, device=dev) if fm else None
+        fm_sum = torch.empty((B, n_cand, d), dtype=f32, device=dev) if fm else None
+        plan_ws = None
+        if plan:
+            # not the name-keyed workspace cache: the plan lives from this forward to its backward
+            plan_ws = torch.empty(_lib.load().rc_small_row_sums_workspace_bytes(B * n_cand * F), dtype=torch.uint8, device=dev)
+        _lib.call("rc_gather_fields_fused", tab_arr, tab1_arr, ids_arr, per_row, kind_arr, int(numeric_key), off_arr, F, B, int(n_cand), d,
+                  _ptr(out, f32, "out"), _ptr(out1, f32, "out1"), _ptr(cid, i64, "cid", True), _ptr(flags, torch.int32, "row_flags", True),
+                  _ptr(step_dev, i64, "step_dev", True), 1, _ptr(fm_term, f32, "fm_out", True), _ptr(fm_sum, f32, "fm_sum", True),
+                  C.c_void_p(plan_ws.data_ptr()) if plan else None, plan_ws.numel() if plan else 0, _stream())
+        return out, out1, cid, offs + [run], fm_term, fm_sum, plan_ws
     if mixed:
         kind_arr = (C.c_int * F)(*kinds)
         _lib.call("rc_gather_fields_mixed", tab_arr, tab1_arr, ids_arr, per_row, kind_arr, int(numeric_key), off_arr, F, B, int(n_cand), d,

@@ -293,7 +293,7 @@ class _FieldGatherPairFn(torch.autograd.Function):
     take no part in the grouping, and their weight gradients are one weighted column sum (rc_numeric_field_grads)."""
 
     @staticmethod
-    def forward(ctx, n_cand, n_fields, rows_opt, kinds, *args):
+    def forward(ctx, n_cand, n_fields, rows_opt, kinds, want_fm, *args):
         ids = [x.contiguous() for x in args[:n_fields]]
         tables, tables1 = args[n_fields:2 * n_fields], args[2 * n_fields:]
         kinds = tuple(kinds) if kinds is not None else (engine.FIELD_IDS,) * n_fields
@@ -315,17 +315,36 @@ class _FieldGatherPairFn(torch.autograd.Function):
         # what the numeric occurrences carry in cid: the small route and the bucket plan skip negative keys; a sort puts the key
         # past the last row behind every real row (the grouping below stops in front of that tail)
         numeric_key = n_rows if (ctx.route == "sort" and num) else -1
-        V, L, cid, offs = engine.gather_fields([t.detach() for t in tables], ids, n_cand, want_cid=True,
-                                               tables1=[t.detach() for t in tables1], mark=mark,
-                                               kinds=kinds if num else None, numeric_key=numeric_key)
+        fusable = d in (16, 32, 64, 128)
+        # small batches: the backward pass's grouping of the composite keys depends on the ids alone -- it runs in the gather's
+        # launch (rc_gather_fields_fused) instead of as a launch of its own in front of the row sums
+        plan = bool(fusable and cat and ctx.route == "small" and any(ctx.needs_input_grad) and engine.small_route_ok(n, n_rows, d))
+        fm_here = bool(want_fm and fusable)
+        S = fm = plan_ws = None
+        if plan or fm_here:
+            V, L, cid, offs, fm, S, plan_ws = engine.gather_fields([t.detach() for t in tables], ids, n_cand, want_cid=True,
+                                                                   tables1=[t.detach() for t in tables1], mark=mark, kinds=kinds,
+                                                                   numeric_key=numeric_key, fm=fm_here, plan=plan)
+        else:
+            V, L, cid, offs = engine.gather_fields([t.detach() for t in tables], ids, n_cand, want_cid=True,
+                                                   tables1=[t.detach() for t in tables1], mark=mark,
+                                                   kinds=kinds if num else None, numeric_key=numeric_key)
+        if want_fm and fm is None:
+            fm = engine.fm_second_order(V)      # (a width without the float4 lane-group tiling: its own launch)
         ctx.rows_opt = rows_opt if mark is not None else None
         ctx.cid, ctx.offs, ctx.d = cid, offs, d
         ctx.kinds, ctx.num, ctx.n_cand = kinds, num, n_cand
         ctx.values = [ids[f] for f in num]
+        ctx.want_fm, ctx.plan_ws = bool(want_fm), plan_ws
+        ctx.has_S = S is not None
+        ctx.set_materialize_grads(False)
+        if want_fm:
+            ctx.save_for_backward(*((V, S) if S is not None else (V,)))
+            return V, L, fm
         return V, L
 
     @staticmethod
-    def backward(ctx, gV, gL):
+    def backward(ctx, gV, gL, g_fm=None):
         offs, d = ctx.offs, ctx.d
         n_rows, n = offs[-1], ctx.cid.numel()
         F = len(offs) - 1
@@ -333,10 +352,24 @@ class _FieldGatherPairFn(torch.autograd.Function):
         gL = None if gL is None else gL.contiguous()
         num = ctx.num
         gw = gw1 = None
+        small = ctx.route == "small" and n_rows > 0 and d % 4 == 0 and engine.small_route_ok(n, n_rows, d)
+        planned = small and ctx.plan_ws is not None and gL is not None
+        # the FM term's backward: added to the tower's gradient rows where the row sums read them (planned small route: never
+        # written out), else one pass of its own (rc_fm_second_order_bwd_add)
+        tap = None
+        if ctx.want_fm and g_fm is not None:
+            saved = ctx.saved_tensors
+            Vs = saved[0]
+            rideable = (not num) or (16 <= d <= 128 and len(num) <= engine.SMALL_NUMERIC_MAX)
+            if planned and ctx.has_S and rideable:
+                tap = (Vs.view(n // F, F, d), saved[1].view(n // F, d), g_fm.contiguous().view(-1))
+            else:
+                gV = engine.fm_second_order_bwd(Vs, g_fm.contiguous(), add=None if gV is None else gV.view(Vs.shape))
+        have_v = gV is not None or tap is not None
         # small batches: the numeric fields' weight gradients ride in the row-sums launch of the small route (a launch of their own
         # is ~13 us of a replayed DeepFM step at B = 1,024); otherwise rc_numeric_field_grads on its own
-        ride = (num and gV is not None and gL is not None and n_rows > 0 and ctx.route == "small" and 16 <= d <= 128 and d % 4 == 0
-                and len(num) <= engine.SMALL_NUMERIC_MAX and engine.small_route_ok(n, n_rows, d))
+        ride = (num and have_v and gL is not None and small and 16 <= d <= 128
+                and len(num) <= engine.SMALL_NUMERIC_MAX)
         riding = (ctx.values, num, F, ctx.n_cand) if ride else None
         if num and not ride and (gV is not None or gL is not None):
             gw, gw1 = engine.numeric_field_grads(None if gV is None else gV.view(n // F, F, d), None if gL is None else gL.view(n // F, F),
@@ -351,22 +384,29 @@ class _FieldGatherPairFn(torch.autograd.Function):
                 out[f] = family[j]
             return tuple(out)
 
-        if ctx.rows_opt is not None:
-            if gV is None or gL is None:
-                raise RuntimeError("gather_fields_pair (rows mode): both table families must reach the loss")
-            res = engine.small_row_sums_pair(ctx.cid, n_rows, gV.view(n, d), gL.view(n, 1), into=ctx.rows_opt.rows_scratch(), numeric=riding)
-            Gv, Gl = res[:2]
+        def row_sums(into=None):
+            """(Gv, Gl) of the small route; the numeric fields' gradients land in gw / gw1 when they ride"""
+            nonlocal gw, gw1
+            if planned and have_v:
+                res = engine.small_row_sums_planned(ctx.plan_ws, n, n_rows, None if gV is None else gV.view(n, d), gL.view(n, 1), d,
+                                                    (F, n // (F * ctx.n_cand), ctx.n_cand), into=into, numeric=riding, fm=tap)
+            else:
+                res = engine.small_row_sums_pair(ctx.cid, n_rows, gV.view(n, d), gL.view(n, 1), into=into, numeric=riding)
             if ride:
                 gw, gw1 = res[2:]
+            return res[:2]
+
+        lead = (None,) * 5
+        if ctx.rows_opt is not None:
+            if not have_v or gL is None:
+                raise RuntimeError("gather_fields_pair (rows mode): both table families must reach the loss")
+            Gv, Gl = row_sums(into=ctx.rows_opt.rows_scratch())
             ctx.rows_opt.rows_grads(Gv, Gl)
-            return (None, None, None, None) + (None,) * F + numeric((None,) * F, gw) + numeric((None,) * F, gw1)
+            return lead + (None,) * F + numeric((None,) * F, gw) + numeric((None,) * F, gw1)
         if n_rows == 0:       # numeric fields only
             Gv = Gl = None
-        elif gV is not None and gL is not None and ctx.route == "small" and engine.small_route_ok(n, n_rows, d) and d % 4 == 0:
-            res = engine.small_row_sums_pair(ctx.cid, n_rows, gV.view(n, d), gL.view(n, 1), numeric=riding)
-            Gv, Gl = res[:2]
-            if ride:
-                gw, gw1 = res[2:]
+        elif have_v and gL is not None and small:
+            Gv, Gl = row_sums()
         else:
             presorted = None
             if ctx.route == "sort":
@@ -379,16 +419,18 @@ class _FieldGatherPairFn(torch.autograd.Function):
         cat = lambda G, f: None if (G is None or ctx.kinds[f] != engine.FIELD_IDS) else G[offs[f]:offs[f + 1]]
         gv = numeric(tuple(cat(Gv, f) for f in range(F)), gw)
         gl = numeric(tuple(cat(Gl, f) for f in range(F)), gw1)
-        return (None, None, None, None) + (None,) * F + gv + gl
+        return lead + (None,) * F + gv + gl
 
 
-def gather_fields_pair(tables, tables1, ids, n_cand, rows_opt=None, kinds=None):
+def gather_fields_pair(tables, tables1, ids, n_cand, rows_opt=None, kinds=None, fm=False):
     """-> (field vectors [B, C, F, d], first-order values [B, C, F, 1]) of the two table families looked up with the same ids.
+    fm=True: -> (vectors, values, FM pairwise term [B, C]) -- models/context/FM.py:61's 0.5 sum_k ((sum_f v)^2 - sum_f v^2) formed
+    in the gather's launch; its backward is added to the vectors' other gradient (DeepFM's tower) where the row sums read it.
     rows_opt: the HipOptimizer that owns the tables, when this forward is part of a whole training step whose optimizer.step()
     follows (graph.GraphedStep sets it): small batches then take the optimizer's rows mode.
     kinds: per field engine.FIELD_IDS (a table looked up by ids) or the value type of a numeric field (engine.field_kind): then
     tables[f] / tables1[f] are the weights of its Linear(1, d) / Linear(1, 1) and ids[f] holds the feature's values"""
-    return _FieldGatherPairFn.apply(n_cand, len(tables), rows_opt, None if kinds is None else tuple(kinds), *ids, *tables, *tables1)
+    return _FieldGatherPairFn.apply(n_cand, len(tables), rows_opt, None if kinds is None else tuple(kinds), bool(fm), *ids, *tables, *tables1)
 
 
 class _BceProbFn(torch.autograd.Function):

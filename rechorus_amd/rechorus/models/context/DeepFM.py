@@ -14,12 +14,20 @@ from rechorus_amd import nn as hnn
 
 
 class DeepFMBase(WideDeepBase):
+    fm_term = True
+
     def forward(self, feed_dict):
-        field_vectors, first_order = self._get_embeddings_FM(feed_dict)
-        fm, deep = self._head_terms(field_vectors)
+        if self.overall_bias.is_cuda:
+            field_vectors, linear_value, fm = self._fused_fields(feed_dict)
+            first_order = self.overall_bias + linear_value.squeeze(-1).sum(dim=-1)
+        else:
+            (field_vectors, first_order), fm = self._get_embeddings_FM(feed_dict), None
+        fm, deep = self._head_terms(field_vectors, fm)
         return {'prediction': first_order + fm + deep}
 
-    def _head_terms(self, field_vectors):
+    def _head_terms(self, field_vectors, fm=None):
+        if fm is not None:          # the gather formed the pairwise term; its backward meets the tower's gradient in the row sums
+            return [fm, self._deep(field_vectors)]
         if field_vectors.is_cuda:   # one autograd node for both consumers of the field vectors (their gradients meet in one pass)
             fm, flat = hnn.fm_second_order_and_flat(field_vectors)
             return [fm, self.deep_layers(flat).squeeze(dim=-1)]

@@ -77,38 +77,48 @@ class FMBase(object):
     def _get_embeddings_FM(self, feed_dict):
         """-> field vectors [B, C, F, d], first-order term [B, C]"""
         if self.overall_bias.is_cuda:
-            fm_vectors, linear_value = self._fused_fields(feed_dict)
+            fm_vectors, linear_value = self._fused_fields(feed_dict)[:2]
             return fm_vectors, self.overall_bias + linear_value.squeeze(-1).sum(dim=-1)
         n_cand = feed_dict['item_id'].shape[1]
         fm_vectors = torch.stack(self._lookup(self.context_embedding, feed_dict, n_cand), dim=-2)
         linear_value = torch.cat(self._lookup(self.linear_embedding, feed_dict, n_cand), dim=-1)
         return fm_vectors, self.overall_bias + linear_value.sum(dim=-1)
 
+    fm_term = True      # the head adds the pairwise term of :61 (WideDeep: no)
+
     def forward(self, feed_dict):
+        if self.overall_bias.is_cuda:
+            fm_vectors, linear_value, fm = self._fused_fields(feed_dict)
+            first_order = self.overall_bias + linear_value.squeeze(-1).sum(dim=-1)
+            return {'prediction': first_order + sum(self._head_terms(fm_vectors, fm))}
         fm_vectors, linear_value = self._get_embeddings_FM(feed_dict)
         return {'prediction': linear_value + hnn.fm_second_order(fm_vectors)}
 
     def _fused_fields(self, feed_dict):
-        """(field vectors [B, C, F, d], first-order values [B, C, F, 1]): every field of both families (:49-55) -- the [vocab, d] /
-        [vocab, 1] tables of the categorical fields and the Linear(1, d) / Linear(1, 1) of the numeric ones -- in ONE gather launch;
-        the backward is one grouping of the composite (field, id) keys for all dense table gradients plus one weighted column sum
-        for the numeric fields' weights.  None where the model is not on the GPU"""
+        """(field vectors [B, C, F, d], first-order values [B, C, F, 1], FM pairwise term [B, C] | None): every field of both
+        families (:49-55) -- the [vocab, d] / [vocab, 1] tables of the categorical fields and the Linear(1, d) / Linear(1, 1) of
+        the numeric ones -- in ONE gather launch, which also forms the pairwise term of :61 for the heads that add it (and, at small
+        batches, groups the composite (field, id) keys for the backward pass); the backward is one row-sums launch for all dense
+        table gradients with the numeric fields' weighted column sums and the pairwise term's backward inside it.  None where the
+        model is not on the GPU"""
         if not self.overall_bias.is_cuda:
             return None
         n_cand = feed_dict['item_id'].shape[1]
         ids = [feed_dict[f] for f in self.context_features]
-        return hnn.gather_fields_pair([self.context_embedding[f].weight for f in self.context_features],
-                                      [self.linear_embedding[f].weight for f in self.context_features], ids, n_cand,
-                                      rows_opt=self._rows_opt(), kinds=self._field_kinds(feed_dict))
+        out = hnn.gather_fields_pair([self.context_embedding[f].weight for f in self.context_features],
+                                     [self.linear_embedding[f].weight for f in self.context_features], ids, n_cand,
+                                     rows_opt=self._rows_opt(), kinds=self._field_kinds(feed_dict), fm=self.fm_term)
+        return out if self.fm_term else out + (None,)
 
     def _rows_opt(self):
         """the optimizer, while this forward is part of a whole training step driven by graph.GraphedStep (forward, backward and
         optimizer.step() as one unit): small batches then take HipOptimizer's rows mode"""
         return getattr(self, '_step_optimizer', None) if self.training else None
 
-    def _head_terms(self, field_vectors):
-        """what `forward` adds to the first-order term, as a list of [B, C] tensors (at most two)"""
-        return [hnn.fm_second_order(field_vectors)]
+    def _head_terms(self, field_vectors, fm=None):
+        """what `forward` adds to the first-order term, as a list of [B, C] tensors (at most two); fm: the pairwise term where the
+        gather formed it"""
+        return [fm if fm is not None else hnn.fm_second_order(field_vectors)]
 
 
 def ctr_forward(self, feed_dict, head_forward):
@@ -118,8 +128,8 @@ def ctr_forward(self, feed_dict, head_forward):
     if self.training and getattr(self, 'loss_n', None) == 'BCE' and feed_dict['label'].dtype == torch.int64:
         fused = self._fused_fields(feed_dict)
         if fused is not None:
-            field_vectors, lin = fused
-            p, loss = hnn.ctr_head(self.overall_bias, lin, feed_dict['label'], self._head_terms(field_vectors))
+            field_vectors, lin, fm = fused
+            p, loss = hnn.ctr_head(self.overall_bias, lin, feed_dict['label'], self._head_terms(field_vectors, fm))
             return {'prediction': p, 'label': feed_dict['label'].view(-1), 'loss': loss}
     out = head_forward(self, feed_dict)
     out['prediction'] = out['prediction'].view(-1).sigmoid()

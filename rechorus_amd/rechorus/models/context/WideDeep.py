@@ -13,6 +13,8 @@ from utils.layers import MLP_Block
 
 
 class WideDeepBase(FMBase):
+    fm_term = False
+
     @staticmethod
     def parse_model_args_WD(parser):
         parser.add_argument('--emb_size', type=int, default=64, help='Size of embedding vectors.')
@@ -40,7 +42,7 @@ class WideDeepBase(FMBase):
         field_vectors, wide = self._get_embeddings_FM(feed_dict)
         return {'prediction': self._deep(field_vectors) + wide}
 
-    def _head_terms(self, field_vectors):
+    def _head_terms(self, field_vectors, fm=None):
         return [self._deep(field_vectors)]
 
 

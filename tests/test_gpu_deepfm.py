@@ -303,9 +303,11 @@ def test_numeric_fields_ride_in_the_gather_and_get_linear_gradients(d, B, C, cud
     monkeypatch.undo()
     # the Linear weights' gradients: riding in the small route's row-sums launch, or rc_numeric_field_grads on its own (large batches)
     rides = B * C * F <= 8192 and d in (16, 32, 64, 128)
-    assert names.count("rc_gather_fields_mixed") == 1
-    assert names.count("rc_small_row_sums_pair_numeric") == (1 if rides else 0) and names.count("rc_numeric_field_grads") == (0 if rides else 1), names
-    assert not any(n in names for n in ("rc_gather_fields", "rc_gather_fields_pair", "rc_gather_rows")), names
+    # small batches: the grouping of the composite keys runs inside the gather's launch (rc_gather_fields_fused), the backward is ONE launch
+    assert names.count("rc_gather_fields_fused" if rides else "rc_gather_fields_mixed") == 1
+    assert names.count("rc_small_row_sums_planned") == (1 if rides else 0) and names.count("rc_numeric_field_grads") == (0 if rides else 1), names
+    assert not any(n in names for n in ("rc_gather_fields", "rc_gather_fields_pair", "rc_gather_rows", "rc_small_row_sums_pair_numeric",
+                                        "rc_small_row_sums_pair", "rc_small_row_sums")), names
     assert V.shape == (B, C, F, d) and L.shape == (B, C, F, 1)
     # what the reference computes, field by field (FM.py:47-55), in float64 from the same fp32 inputs
     bc = lambda t: t if t.dim() == 3 else t.unsqueeze(-2).expand(-1, C, -1)
@@ -335,6 +337,99 @@ def test_numeric_fields_ride_in_the_gather_and_get_linear_gradients(d, B, C, cud
                      abs_floor=3e-7 * 6.0 * float(wl.abs().max()) * (B * C) ** 0.5 * 4)
 
 
+@pytest.mark.parametrize("d,B,C,numeric,tower", [(64, 1024, 1, True, True), (64, 1024, 1, False, True), (16, 37, 5, True, True),
+                                                  (32, 700, 2, True, False), (128, 100, 3, False, False), (64, 5000, 1, True, True),
+                                                  (24, 50, 2, True, True)])
+def test_fm_term_and_plan_inside_the_gather_launch(d, B, C, numeric, tower, cuda, monkeypatch):
+    """rc_gather_fields_fused / rc_small_row_sums_planned: the FM pairwise term (models/context/FM.py:61) formed in the gather's
+    launch is rc_fm_second_order_fwd's value bit for bit; its backward folded into the row sums (on the grouping the gather's launch
+    left behind) gives the gradients of the three-launch route -- rc_fm_second_order_bwd_add, grouping, row sums -- bit for bit,
+    and both agree with torch's own ops in float64.  tower: a second consumer of the field vectors (DeepFM) sends a gradient too."""
+    from rechorus_amd import _lib, engine, nn as hnn
+    rng = np.random.default_rng(d * 7919 + B + C)
+    spec = [(engine.FIELD_IDS, 11, True), (engine.FIELD_I64 if numeric else engine.FIELD_IDS, 0 if numeric else 9, True),
+            (engine.FIELD_IDS, 300, False), (engine.FIELD_IDS, 5, True), (engine.FIELD_F32 if numeric else engine.FIELD_IDS, 0 if numeric else 40, False),
+            (engine.FIELD_IDS, 70, False)]
+    F = len(spec)
+    mk = lambda shape: torch.from_numpy(rng.normal(0, 0.5, size=shape).astype(np.float32)).to(cuda).requires_grad_(True)
+    vec = [mk((v, d)) if k == engine.FIELD_IDS else mk((d, 1)) for k, v, _ in spec]
+    lin = [mk((v, 1)) if k == engine.FIELD_IDS else mk((1, 1)) for k, v, _ in spec]
+    dt = {engine.FIELD_I64: torch.int64, engine.FIELD_F32: torch.float32}
+    ids = [(torch.from_numpy(rng.integers(0, v, size=(B,) if pr else (B, C)).astype(np.int64)) if k == engine.FIELD_IDS
+            else _numeric_values(rng, dt[k], (B,) if pr else (B, C))).to(cuda) for k, v, pr in spec]
+    kinds = [k for k, _, _ in spec] if numeric else None
+    names = []
+    real = _lib.call
+    monkeypatch.setattr(_lib, "call", lambda fn, *a: names.append(fn) or real(fn, *a))
+    V, L, fm = hnn.gather_fields_pair(vec, lin, ids, C, kinds=kinds, fm=True)
+    wv, wl, wf = torch.randn_like(V) * (1.0 if tower else 0.0), torch.randn_like(L), torch.randn_like(fm)
+    loss = (L * wl).sum() + (fm * wf).sum()
+    if tower:
+        loss = loss + (V * wv).sum()
+    loss.backward()
+    monkeypatch.undo()
+    small, lanes = B * C * F <= 8192, d in (16, 32, 64, 128)
+    if lanes:
+        assert names.count("rc_gather_fields_fused") == 1 and "rc_fm_second_order_fwd" not in names, names
+    else:
+        assert names.count("rc_fm_second_order_fwd") == 1 and "rc_gather_fields_fused" not in names, names
+    if small and lanes:     # one launch forward, one launch backward
+        assert names.count("rc_small_row_sums_planned") == 1 and "rc_fm_second_order_bwd" not in names and "rc_fm_second_order_bwd_add" not in names, names
+        assert not any(n.startswith("rc_small_row_sums") and n != "rc_small_row_sums_planned" and not n.endswith("_bytes") and not n.endswith("_supported") for n in names), names
+    else:
+        assert names.count("rc_fm_second_order_bwd_add" if tower else "rc_fm_second_order_bwd") == 1, names
+    got = {"vec": [t.grad.clone() for t in vec], "lin": [t.grad.clone() for t in lin]}
+    # ---- the separate kernels on the same inputs: bit for bit
+    assert torch.equal(fm, engine.fm_second_order(V.detach())), "FM term differs from rc_fm_second_order_fwd"
+    for t in vec + lin:
+        t.grad = None
+    V2, L2 = hnn.gather_fields_pair(vec, lin, ids, C, kinds=kinds)
+    assert torch.equal(V2, V) and torch.equal(L2, L)
+    fm2, flat = hnn.fm_second_order_and_flat(V2)
+    loss2 = (L2 * wl).sum() + (fm2 * wf).sum()
+    if tower:
+        loss2 = loss2 + (flat.view(V2.shape) * wv).sum()
+    loss2.backward()
+    for f in range(F):
+        assert torch.equal(got["vec"][f], vec[f].grad), f"field {f}: vector gradient differs from the separate kernels"
+        assert torch.equal(got["lin"][f], lin[f].grad), f"field {f}: first-order gradient differs from the separate kernels"
+    if small and lanes:
+        # ---- the grouping the gather's launch leaves behind against the plan launch of rc_small_row_sums_pair(_numeric)
+        kd = [k for k, _, _ in spec]
+        num = [f for f in range(F) if kd[f] != engine.FIELD_IDS]
+        with torch.no_grad():
+            Vd, Ld, cid, offs, _, _, ws = engine.gather_fields([t.detach() for t in vec], ids, C, tables1=[t.detach() for t in lin], kinds=kd,
+                                                              numeric_key=-1, plan=True)
+            n, n_rows = cid.numel(), offs[-1]
+            gv, gl = torch.randn(n, d, device=cuda), torch.randn(n, 1, device=cuda)
+            riding = ([ids[f] for f in num], num, F, C) if num else None
+            a = engine.small_row_sums_planned(ws, n, n_rows, gv, gl, d, (F, B, C), numeric=riding)
+            b = engine.small_row_sums_pair(cid, n_rows, gv, gl, numeric=riding)
+            for x, y in zip(a[:2], b[:2]):
+                assert torch.equal(x, y), "row sums on the gather's plan differ from the plan launch's"
+            for xs, ys in zip(a[2:], b[2:]):
+                assert all(torch.equal(x, y) for x, y in zip(xs, ys))
+    # ---- torch's own ops in float64
+    bc = lambda t: t if t.dim() == 3 else t.unsqueeze(-2).expand(-1, C, -1)
+    v64 = [t.detach().double().requires_grad_(True) for t in vec]
+    l64 = [t.detach().double().requires_grad_(True) for t in lin]
+    kk = [k for k, _, _ in spec]
+    look = lambda W, x, k: W[x] if k == engine.FIELD_IDS else torch.nn.functional.linear(x.float().double().unsqueeze(-1), W)
+    V64 = torch.stack([bc(look(W, x, k)) for W, x, k in zip(v64, ids, kk)], dim=-2)
+    L64 = torch.stack([bc(look(W, x, k)) for W, x, k in zip(l64, ids, kk)], dim=-2)
+    fm64 = 0.5 * (V64.sum(dim=-2).pow(2) - V64.pow(2).sum(dim=-2)).sum(dim=-1)
+    ((V64 * wv.double()).sum() + (L64 * wl.double()).sum() + (fm64 * wf.double()).sum()).backward()
+    scale = float(V64.abs().max()) ** 2 * F * d
+    assert_close(fm.detach().cpu().numpy(), fm64.detach().cpu().numpy(), what="FM term", rtol=1e-5, atol_scale=0, abs_floor=3e-7 * scale)
+    for f, (k, _, _) in enumerate(spec):
+        n_terms = B * C / (vec[f].shape[0] if k == engine.FIELD_IDS else 1)
+        gmax = float(wv.abs().max()) + float(wf.abs().max()) * F * float(V64.abs().max())
+        floor = 3e-7 * (6.0 if k != engine.FIELD_IDS else 1.0) * gmax * max(n_terms, 1.0) ** 0.5 * 4
+        assert_close(got["vec"][f].cpu().numpy(), v64[f].grad.cpu().numpy(), what=f"field {f} vectors", rtol=1e-5, atol_scale=1e-5, abs_floor=floor)
+        assert_close(got["lin"][f].cpu().numpy(), l64[f].grad.cpu().numpy(), what=f"field {f} first-order", rtol=1e-5, atol_scale=1e-5,
+                     abs_floor=3e-7 * 6.0 * float(wl.abs().max()) * max(n_terms, 1.0) ** 0.5 * 4)
+
+
 def test_numeric_field_model_path_uses_no_torch_stack_or_cat(cuda, monkeypatch):
     """with a '*_f' feature among the fields the FM family stays on the one-launch gather, the fused FM term and the one-kernel
     CTR head: no torch.stack / torch.cat / nn.Linear call on the training path (the round-5 route did all three)"""
@@ -355,8 +450,10 @@ def test_numeric_field_model_path_uses_no_torch_stack_or_cat(cuda, monkeypatch):
     model.loss(out).backward()
     monkeypatch.undo()
     assert "loss" in out, "the one-kernel CTR head did not run"
-    assert names.count("rc_gather_fields_mixed") == 1 and names.count("rc_small_row_sums_pair_numeric") == 1, names    # (B = 48: the small route)
-    assert "rc_numeric_field_grads" not in names
+    # (B = 48: the small route -- the gather's launch also forms the FM term and groups the keys, ONE row-sums launch backward)
+    assert names.count("rc_gather_fields_fused") == 1 and names.count("rc_small_row_sums_planned") == 1, names
+    assert not any(n in names for n in ("rc_numeric_field_grads", "rc_fm_second_order_fwd", "rc_fm_second_order_bwd", "rc_fm_second_order_bwd_add",
+                                        "rc_small_row_sums_pair_numeric", "rc_gather_fields_mixed")), names
     assert any(n.startswith("rc_ctr_head_fwd_bwd") for n in names), names
     assert_close(out["loss"].item(), g["loss"], what="loss", rtol=2e-5)
 
@@ -375,9 +472,9 @@ def test_bce_ranking_kernel_matches_the_reference(cuda):
 
 def test_two_table_families_share_keys_and_grouping(cuda, monkeypatch):
     """the [vocab, d] vectors and the [vocab, 1] first-order weights of the FM family are gathered with the same id tensors
-    (models/context/FM.py:44-57): ONE gather launch (rc_gather_fields_pair), and in the backward pass ONE grouping of the composite
-    keys serves both dense gradients (rc_small_row_sums + rc_small_row_sums_again) -- values and gradients bit-identical to two
-    separate gathers"""
+    (models/context/FM.py:44-57): ONE gather launch (rc_gather_fields_fused: the grouping of the composite keys runs beside it), and
+    in the backward pass ONE row-sums launch for both dense gradients (rc_small_row_sums_planned) -- values and gradients
+    bit-identical to two separate gathers"""
     from rechorus_amd import _lib, nn as hnn
     rng = np.random.default_rng(4)
     for vocab, B, C in (([50, 7, 300], 96, 1), ([11, 300, 5, 70, 2], 33, 5), ([40000, 9], 1024, 1)):
@@ -391,8 +488,8 @@ def test_two_table_families_share_keys_and_grouping(cuda, monkeypatch):
         wv, wl = torch.randn_like(V), torch.randn_like(L)
         ((V * wv).sum() + (L * wl).sum()).backward()
         monkeypatch.undo()
-        assert names.count("rc_gather_fields_pair") == 1 and "rc_gather_fields" not in names
-        assert names.count("rc_small_row_sums_pair") == 1 and "rc_small_row_sums" not in names, names   # one grouping, one sums launch
+        assert names.count("rc_gather_fields_fused") == 1 and "rc_gather_fields" not in names and "rc_gather_fields_pair" not in names
+        assert names.count("rc_small_row_sums_planned") == 1 and "rc_small_row_sums" not in names and "rc_small_row_sums_pair" not in names, names
         got = [t.grad.clone() for t in vec + lin]
         for t in vec + lin:
             t.grad = None
