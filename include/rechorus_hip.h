@@ -150,11 +150,14 @@ int rc_gather_fields_mixed(const float* const* tables, const float* const* table
  *                                      does (rc_small_row_sums' first launch), by 128 workgroups beside the gather's, left where
  *                                      rc_small_row_sums_planned reads it (rc_small_row_sums_workspace_bytes(B * C * F) bytes;
  *                                      B * C * F <= 32,768 keys).
+ *   bump                               a device counter that one thread of the launch increments (NULL: none) -- the dropout seed
+ *                                      of the deep tower that runs next (utils/layers.py:201-243's nn.Dropout sites), which would
+ *                                      otherwise be a one-thread launch of its own; nothing in this launch may read it (not step_dev).
  * d in {16, 32, 64, 128}; kind may be NULL (every field a table); the other arguments as rc_gather_fields_mixed.                     */
 int rc_gather_fields_fused(const float* const* tables, const float* const* tables1, const void* const* ids, const int* per_row,
                            const int* kind, int64_t numeric_key, const int64_t* row_offset, int F, int64_t B, int C, int d, float* out,
                            float* out1, int64_t* cid, int32_t* row_flags, const int64_t* step_dev, int step_add, float* fm_out,
-                           float* fm_sum, void* plan_ws, size_t plan_ws_bytes, rc_stream_t stream);
+                           float* fm_sum, void* plan_ws, size_t plan_ws_bytes, int64_t* bump, rc_stream_t stream);
 /* Weight gradients of the numeric fields (autograd's Linear backward behind loss.backward(), helpers/BaseRunner.py:205, for the
  * modules of models/context/FM.py:38-41): dW[j][k] = sum_n x_j[n] * gV[n, field[j], k] and dw1[j][0] = sum_n x_j[n] * gL[n, field[j]]
  * over the n = B * C rows of the per-occurrence gradient blocks gV [n, F, d] / gL [n, F] (either may be NULL with its outputs).
@@ -459,6 +462,13 @@ int rc_ctr_head_fwd_bwd(const float* bias, const float* lin, int F, const float*
 int rc_ctr_head_fwd_bwd_sums(const float* bias, const float* lin, int F, const float* term1, const float* term2,
                              const int64_t* label, int64_t n, float* p, float* loss_vec, float* gz, float* sums,
                              rc_stream_t stream);
+/* rc_ctr_head_fwd_bwd_sums that also leaves the backward fan-out for a seed gradient of exactly one (a whole training step calls
+ * loss.backward() on the scalar loss, helpers/BaseRunner.py:205): g_lin [n, F] = gz broadcast over a row's first-order weights,
+ * g_bias [1] = sum gz -- rc_ctr_head_bwd's outputs for g_loss = 1, bit for bit (g itself is gz) -- and optionally increments a
+ * device counter nothing in this launch reads (bump, may be NULL: Adam's step count, read next by the update kernel).            */
+int rc_ctr_head_fwd_full(const float* bias, const float* lin, int F, const float* term1, const float* term2, const int64_t* label,
+                         int64_t n, float* p, float* loss_vec, float* gz, float* sums, float* g_lin, float* g_bias, int64_t* bump,
+                         rc_stream_t stream);
 int rc_ctr_head_bwd(const float* gz, const float* sums, const float* g_loss, int64_t n, int F, float* g, float* g_lin,
                     float* g_bias, rc_stream_t stream);
 

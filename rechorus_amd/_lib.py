@@ -101,7 +101,7 @@ SIGNATURES = {
     "rc_list_metrics_supported": (_i, [_i, _i, _i]),
     "rc_list_metrics": (_i, [_p, _p, _p, _i64, _i, _i, _p, _i, _p, _p, _p]),
     "rc_gather_fields_mixed": (_i, [_p, _p, _p, _p, _p, _i64, _p, _i, _i64, _i, _i, _p, _p, _p, _p, _p, _i, _p]),
-    "rc_gather_fields_fused": (_i, [_p, _p, _p, _p, _p, _i64, _p, _i, _i64, _i, _i, _p, _p, _p, _p, _p, _i, _p, _p, _p, _sz, _p]),
+    "rc_gather_fields_fused": (_i, [_p, _p, _p, _p, _p, _i64, _p, _i, _i64, _i, _i, _p, _p, _p, _p, _p, _i, _p, _p, _p, _sz, _p, _p]),
     "rc_numeric_field_grads_workspace_bytes": (_sz, [_i64, _i, _i]),
     "rc_numeric_field_grads": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i64, _i, _i, _p, _p, _p, _sz, _p]),
     "rc_bce_ranking_fwd_bwd": (_i, [_p, _i64, _i, _f, _p, _p, _p]),
@@ -137,6 +137,7 @@ SIGNATURES = {
                                   _p, _i, _p, _sz, _p]),
     "rc_ctr_head_fwd_bwd": (_i, [_p, _p, _i, _p, _p, _p, _i64, _p, _p, _p, _p]),
     "rc_ctr_head_fwd_bwd_sums": (_i, [_p, _p, _i, _p, _p, _p, _i64, _p, _p, _p, _p, _p]),
+    "rc_ctr_head_fwd_full": (_i, [_p, _p, _i, _p, _p, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p]),
     "rc_ctr_head_bwd": (_i, [_p, _p, _p, _i64, _i, _p, _p, _p, _p]),
     "rc_small_row_sums_supported": (_i, [_i64, _i64, _i]),
     "rc_small_row_sums_workspace_bytes": (_sz, [_i64]),

@@ -160,7 +160,8 @@ __global__ __launch_bounds__(kCtrOneWg) void ctr_head_sums_kernel(const float* _
                                                                 const float* __restrict__ t1, const float* __restrict__ t2,
                                                                 const int64_t* __restrict__ y, int64_t n, float inv_n,
                                                                 float* __restrict__ p_out, float* __restrict__ loss_vec,
-                                                                float* __restrict__ gz, float* __restrict__ sums /* loss mean, sum gz */) {
+                                                                float* __restrict__ gz, float* __restrict__ sums /* loss mean, sum gz */,
+                                                                float* __restrict__ g_lin, float* __restrict__ g_bias, int64_t* __restrict__ bump) {
   __shared__ float red[2][kCtrOneWg];
   const float b0 = bias[0];
   float sl_loss = 0.f, sl_gz = 0.f;
@@ -179,6 +180,8 @@ __global__ __launch_bounds__(kCtrOneWg) void ctr_head_sums_kernel(const float* _
     const float gp = (pi - yi) / fmaxf((1.0f - pi) * pi, 1e-12f) * inv_n;
     const float gi = gp * (1.0f - pi) * pi;
     gz[i] = gi;
+    if (g_lin)      // rc_ctr_head_fwd_full: the backward fan-out for a seed gradient of exactly 1 (gz * 1.0f is gz)
+      for (int f = 0; f < F; ++f) g_lin[i * F + f] = gi;
     sl_loss += li;
     sl_gz += gi;
   }
@@ -195,6 +198,8 @@ __global__ __launch_bounds__(kCtrOneWg) void ctr_head_sums_kernel(const float* _
   if (threadIdx.x == 0) {
     sums[0] = red[0][0] * inv_n;
     sums[1] = red[1][0];
+    if (g_bias) g_bias[0] = red[1][0];
+    if (bump) bump[0] += 1;     // a device counter nobody reads in this launch (Adam's step count: its reader is the update kernel)
   }
 }
 
@@ -222,7 +227,22 @@ extern "C" int rc_ctr_head_fwd_bwd_sums(const float* bias, const float* lin, int
   RC_REQUIRE(bias && lin && label && p && loss_vec && gz && sums, "rc_ctr_head_fwd_bwd_sums: null pointer");
   RC_REQUIRE(n > 0 && n <= 65536 && F >= 1, "rc_ctr_head_fwd_bwd_sums: n=%lld (1 .. 65,536 rows: one workgroup) F=%d", (long long)n, F);
   hipLaunchKernelGGL(ctr_head_sums_kernel, dim3(1), dim3(kCtrOneWg), 0, as_stream(stream), bias, lin, F, term1, term2, label, n,
-                     1.0f / (float)n, p, loss_vec, gz, sums);
+                     1.0f / (float)n, p, loss_vec, gz, sums, (float*)nullptr, (float*)nullptr, (int64_t*)nullptr);
+  RC_LAUNCH_CHECK();
+  return RC_OK;
+}
+
+/* rc_ctr_head_fwd_bwd_sums that also leaves the backward fan-out of a seed gradient of exactly one -- g_lin [n, F] = gz broadcast
+ * over a row's first-order weights, g_bias [1] = sum gz (rc_ctr_head_bwd's outputs for g_loss = 1, bit for bit; g itself is gz) --
+ * and, optionally, increments a device counter that nothing in this launch reads (bump, may be NULL): a whole training step that
+ * seeds loss.backward() with 1 needs no rc_ctr_head_bwd launch and no launch for Adam's step count. */
+extern "C" int rc_ctr_head_fwd_full(const float* bias, const float* lin, int F, const float* term1, const float* term2,
+                                    const int64_t* label, int64_t n, float* p, float* loss_vec, float* gz, float* sums, float* g_lin,
+                                    float* g_bias, int64_t* bump, rc_stream_t stream) {
+  RC_REQUIRE(bias && lin && label && p && loss_vec && gz && sums && g_lin && g_bias, "rc_ctr_head_fwd_full: null pointer");
+  RC_REQUIRE(n > 0 && n <= 65536 && F >= 1, "rc_ctr_head_fwd_full: n=%lld (1 .. 65,536 rows: one workgroup) F=%d", (long long)n, F);
+  hipLaunchKernelGGL(ctr_head_sums_kernel, dim3(1), dim3(kCtrOneWg), 0, as_stream(stream), bias, lin, F, term1, term2, label, n,
+                     1.0f / (float)n, p, loss_vec, gz, sums, g_lin, g_bias, bump);
   RC_LAUNCH_CHECK();
   return RC_OK;
 }
@@ -472,27 +492,43 @@ __global__ __launch_bounds__(kBlock) void gather_fields_kernel(FieldArgs a, floa
 // group the composite (field, id) keys by row, what embedding_dense_backward's sort does) run BESIDE the gather workgroups here and
 // leave the plan in the workspace the backward pass's row sums read (rc_small_row_sums_planned).  The plan workgroups form the keys
 // from the fields' id tensors themselves -- position p = r F + f, key = row_offset[f] + ids[f][r or r / C], kSmallSkipKey for a
-// numeric field -- through a copy of the field descriptors in LDS (a per-lane index into the kernel-argument arrays would put them
-// in scratch).
-struct FieldKeyLds {
-  const int64_t* ids[kMaxFields];
-  uint32_t row_offset[kMaxFields];
-  uint8_t per_row[kMaxFields], numeric[kMaxFields];
-};
-// scan index s = f * n + r (field-major: a wave's 64 consecutive s share the field but for one boundary, so the descriptor reads are
-// LDS broadcasts and the id loads coalesced), recorded position r * F + f (the occurrence's row in the [n, F, .] gradient blocks);
-// a key belongs to one field, so its positions ascend with s
+// numeric field --, a chunk of 64 rows of one field at a time, so that the field's descriptors are scalar loads from the kernel
+// arguments (a per-lane index into those arrays would put them in scratch).
+// chunk c = 64 consecutive rows of ONE field (f = c / chunks-per-field, wave-uniform: the field's id pointer, row offset and kind are
+// scalar loads from the kernel arguments, the id loads coalesced), recorded position r * F + f (the occurrence's row in the
+// [n, F, .] gradient blocks); a key belongs to one field, so its positions ascend with the scan
 struct FieldPlanKey {
-  const FieldKeyLds* fk;
-  uint32_t F, n, magic_n, magic_c;
-  __device__ __forceinline__ uint32_t operator()(const SmallPlanArgs&, uint32_t s) const {
-    const uint32_t f = small_div(s, magic_n), r = s - f * n;
-    if (fk->numeric[f]) return kSmallSkipKey;
-    return fk->row_offset[f] + (uint32_t)fk->ids[f][fk->per_row[f] ? small_div(r, magic_c) : r];
+  const FieldArgs* fa;
+  uint32_t cpf;      // chunks per field = ceil(n / 64)
+  uint32_t magic_c;  // r / C by one v_mul_hi_u32
+  struct Ctx {       // one field's descriptors (scalar registers)
+    const int64_t* ids;
+    uint32_t row_offset, f, first_chunk;
+    bool per_row, numeric;
+  };
+  __device__ __forceinline__ uint32_t chunks(const SmallPlanArgs&) const { return cpf * (uint32_t)fa->F; }
+  __device__ __forceinline__ uint32_t group_end(const SmallPlanArgs&, uint32_t c) const {
+    const uint32_t cu = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+    return (cu / cpf + 1u) * cpf;
   }
-  __device__ __forceinline__ uint32_t pos(uint32_t s) const {
-    const uint32_t f = small_div(s, magic_n), r = s - f * n;
-    return r * F + f;
+  __device__ __forceinline__ Ctx open(const SmallPlanArgs&, uint32_t c) const {
+    const uint32_t cu = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+    Ctx x;
+    x.f = cu / cpf;
+    x.first_chunk = x.f * cpf;
+    x.ids = fa->ids[x.f];
+    x.row_offset = (uint32_t)fa->row_offset[x.f];
+    x.per_row = fa->per_row[x.f] != 0;
+    x.numeric = fa->kind[x.f] != RC_FIELD_IDS;
+    return x;
+  }
+  __device__ __forceinline__ uint32_t key(const SmallPlanArgs&, const Ctx& x, uint32_t c, uint32_t lane) const {
+    const uint32_t r = (c - x.first_chunk) * 64u + lane;
+    if (r >= (uint32_t)fa->n || x.numeric) return kSmallSkipKey;
+    return x.row_offset + (uint32_t)x.ids[x.per_row ? small_div(r, magic_c) : r];
+  }
+  __device__ __forceinline__ uint32_t pos(const SmallPlanArgs&, const Ctx& x, uint32_t c, uint32_t lane) const {
+    return ((c - x.first_chunk) * 64u + lane) * (uint32_t)fa->F + x.f;
   }
 };
 
@@ -501,24 +537,18 @@ __global__ __launch_bounds__(kSmallThreads) void gather_fields_plan_kernel(Field
                                                                            float* __restrict__ out1, int32_t* __restrict__ row_flags,
                                                                            const int64_t* __restrict__ step_dev, int step_add,
                                                                            float* __restrict__ fm_out, float* __restrict__ fm_sum,
-                                                                           unsigned gather_blocks, SmallPlanArgs plan) {
+                                                                           unsigned gather_blocks, SmallPlanArgs plan, int64_t* __restrict__ bump) {
+  // a device counter nothing in this launch reads (the deep tower's dropout seed: its first reader is the tower's first kernel)
+  if (bump != nullptr && blockIdx.x == 0 && threadIdx.x == 0) bump[0] += 1;
   if (blockIdx.x < gather_blocks) {   // (workgroup-uniform)
     gather_fields_body<4, MIXED, FMQ>(a, out, cid, out1, row_flags, step_dev, step_add, fm_out, fm_sum, blockIdx.x, gather_blocks, kSmallThreads);
     return;
   }
   extern __shared__ __attribute__((aligned(16))) unsigned char gather_plan_smem[];
-  __shared__ FieldKeyLds fk;
-  for (int f = threadIdx.x; f < a.F; f += kSmallThreads) {
-    fk.ids[f] = a.ids[f];
-    fk.row_offset[f] = (uint32_t)a.row_offset[f];
-    fk.per_row[f] = (uint8_t)(a.per_row[f] != 0);
-    fk.numeric[f] = (uint8_t)(a.kind[f] != RC_FIELD_IDS);
-  }
-  __syncthreads();
   FieldPlanKey key;
-  key.fk = &fk; key.F = (uint32_t)a.F; key.n = (uint32_t)a.n;
-  key.magic_n = small_div_magic((uint32_t)a.n);      // s < n F <= 32,768 keys and r < n: n * d < 2^32 for both divisions
-  key.magic_c = small_div_magic((uint32_t)a.C);
+  key.fa = &a;
+  key.cpf = ((uint32_t)a.n + 63u) >> 6;
+  key.magic_c = small_div_magic((uint32_t)a.C);      // r < n <= 32,768 rows, C <= n: r * C < 2^32
   small_plan_block<kSmallCapBig, kSmallWaveCapBig, FieldPlanKey>(plan, blockIdx.x - gather_blocks, gather_plan_smem, key);
 }
 
@@ -527,7 +557,8 @@ __global__ __launch_bounds__(kSmallThreads) void gather_fields_plan_kernel(Field
 // the FM term and / or the small route's plan inside the gather launch (rc_gather_fields_fused)
 template <bool MIXED, int FMQ>
 static int gather_fused_launch_t(const FieldArgs& a, float* out, int64_t* cid, float* out1, int32_t* row_flags, const int64_t* step_dev,
-                                 int step_add, float* fm_out, float* fm_sum, unsigned gather_blocks, const SmallPlanArgs* plan, hipStream_t s) {
+                                 int step_add, float* fm_out, float* fm_sum, unsigned gather_blocks, const SmallPlanArgs* plan, int64_t* bump,
+                                 hipStream_t s) {
   auto kern = gather_fields_plan_kernel<MIXED, FMQ>;
   SmallPlanArgs p;
   memset(&p, 0, sizeof(p));
@@ -547,15 +578,16 @@ static int gather_fused_launch_t(const FieldArgs& a, float* out, int64_t* cid, f
       if (dev >= 0 && dev < 64) done[dev] = true;
     }
   }
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(kSmallThreads), lds, s, a, out, cid, out1, row_flags, step_dev, step_add, fm_out, fm_sum, gather_blocks, p);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(kSmallThreads), lds, s, a, out, cid, out1, row_flags, step_dev, step_add, fm_out, fm_sum, gather_blocks, p, bump);
   RC_LAUNCH_CHECK();
   return RC_OK;
 }
 
 static int gather_fields_fused_launch(const FieldArgs& a, bool vec, bool mixed, float* out, int64_t* cid, float* out1, int32_t* row_flags,
                                       const int64_t* step_dev, int step_add, float* fm_out, float* fm_sum, void* plan_ws,
-                                      size_t plan_ws_bytes, rc_stream_t stream) {
+                                      size_t plan_ws_bytes, int64_t* bump, rc_stream_t stream) {
   const int d = a.d;
+  RC_REQUIRE(bump == nullptr || bump != step_dev, "rc_gather_fields_fused: the gather reads step_dev, it cannot be the counter to increment");
   RC_REQUIRE(vec && (d == 16 || d == 32 || d == 64 || d == 128), "rc_gather_fields_fused: d = %d (16 / 32 / 64 / 128, 16-byte aligned tables and output)", d);
   RC_REQUIRE((fm_out == nullptr) == (fm_sum == nullptr), "rc_gather_fields_fused: the FM term and the field sums come together");
   RC_REQUIRE(fm_sum == nullptr || reinterpret_cast<uintptr_t>(fm_sum) % 16 == 0, "rc_gather_fields_fused: fm_sum must be 16-byte aligned");
@@ -582,7 +614,7 @@ static int gather_fields_fused_launch(const FieldArgs& a, bool vec, bool mixed, 
   hipStream_t s = as_stream(stream);
   const SmallPlanArgs* pp = plan_ws != nullptr ? &p : nullptr;
   const bool fm = fm_out != nullptr;
-#define RC_GF(M_, Q_) return gather_fused_launch_t<M_, Q_>(a, out, cid, out1, row_flags, step_dev, step_add, fm_out, fm_sum, (unsigned)blocks, pp, s)
+#define RC_GF(M_, Q_) return gather_fused_launch_t<M_, Q_>(a, out, cid, out1, row_flags, step_dev, step_add, fm_out, fm_sum, (unsigned)blocks, pp, bump, s)
   if (!fm) { if (mixed) RC_GF(true, 0); RC_GF(false, 0); }
   switch (d) {
     case 16: if (mixed) RC_GF(true, 4); RC_GF(false, 4);
@@ -596,7 +628,8 @@ static int gather_fields_fused_launch(const FieldArgs& a, bool vec, bool mixed, 
 static int gather_fields_impl(const float* const* tables, const float* const* tables1, const void* const* ids, const int* per_row,
                               const int* kind, int64_t numeric_key, const int64_t* row_offset, int F, int64_t B, int C, int d, float* out,
                               float* out1, int64_t* cid, int32_t* row_flags, const int64_t* step_dev, int step_add, rc_stream_t stream,
-                              float* fm_out = nullptr, float* fm_sum = nullptr, void* plan_ws = nullptr, size_t plan_ws_bytes = 0) {
+                              float* fm_out = nullptr, float* fm_sum = nullptr, void* plan_ws = nullptr, size_t plan_ws_bytes = 0,
+                              int64_t* bump = nullptr) {
   if (B == 0) return RC_OK;
   RC_REQUIRE((row_flags == nullptr) == (step_dev == nullptr), "rc_gather_fields_pair_mark: the row flags and the step count come together");
   RC_REQUIRE(tables && ids && per_row && row_offset && out, "rc_gather_fields: null pointer");
@@ -621,7 +654,7 @@ static int gather_fields_impl(const float* const* tables, const float* const* ta
   }
   a.numeric_key = numeric_key;
   a.F = F; a.C = C; a.d = d; a.n = B * C;
-  if (fm_out != nullptr || plan_ws != nullptr) return gather_fields_fused_launch(a, vec, mixed, out, cid, out1, row_flags, step_dev, step_add, fm_out, fm_sum, plan_ws, plan_ws_bytes, stream);
+  if (fm_out != nullptr || plan_ws != nullptr) return gather_fields_fused_launch(a, vec, mixed, out, cid, out1, row_flags, step_dev, step_add, fm_out, fm_sum, plan_ws, plan_ws_bytes, bump, stream);
   const int64_t total = a.n * (vec ? d / 4 : d);   // one thread per (row, float4 | float), walking the fields
   int64_t blocks = (total + kBlock - 1) / kBlock;
   if (blocks > 256 * 32) blocks = 256 * 32;
@@ -668,15 +701,16 @@ extern "C" int rc_gather_fields_mixed(const float* const* tables, const float* c
  *                                       sum its backward needs -- no second pass over the stacked block;
  *   plan_ws                             the grouping of the composite keys (rc_small_row_sums' first launch) by 128 workgroups
  *                                       beside the gather's, left where rc_small_row_sums_planned reads it.
+ *   bump                                a device counter incremented by one thread of the launch (nothing in it may read it).
  * d in {16, 32, 64, 128}; the plan: B * C * F <= 32,768 keys.  kind may be null (every field a table). */
 extern "C" int rc_gather_fields_fused(const float* const* tables, const float* const* tables1, const void* const* ids,
                                       const int* per_row, const int* kind, int64_t numeric_key, const int64_t* row_offset, int F,
                                       int64_t B, int C, int d, float* out, float* out1, int64_t* cid, int32_t* row_flags,
                                       const int64_t* step_dev, int step_add, float* fm_out, float* fm_sum, void* plan_ws,
-                                      size_t plan_ws_bytes, rc_stream_t stream) {
+                                      size_t plan_ws_bytes, int64_t* bump, rc_stream_t stream) {
   RC_REQUIRE(fm_out != nullptr || plan_ws != nullptr, "rc_gather_fields_fused: neither the FM term nor the plan was asked for");
   return gather_fields_impl(tables, tables1, ids, per_row, kind, numeric_key, row_offset, F, B, C, d, out, out1, cid, row_flags, step_dev,
-                            step_add, stream, fm_out, fm_sum, plan_ws, plan_ws_bytes);
+                            step_add, stream, fm_out, fm_sum, plan_ws, plan_ws_bytes, bump);
 }
 
 // ---- weight gradients of the numeric fields ---------------------------------------------------------------------------

@@ -59,13 +59,21 @@ struct SmallPlanArgs {
 
 // where position p's key comes from: one or two id lists (the default), or whatever a caller's functor derives it from (the
 // composite (field, id) keys of a context model's gather, formed from the fields' own id tensors: fm_bce.hip)
-// (a functor enumerates the keys by a SCAN index s in [0, n): key(a, s) and the position pos(s) the plan records for it -- the scan
-// order is free, the sort below orders by (key, position); positions of one key must ascend with s)
+// (a functor enumerates the keys in CHUNKS of 64 -- one per lane of a wave --, the chunks in GROUPS that share a wave-uniform context
+// (loaded once per group: open()): chunks(a), group_end(a, c) (first chunk behind the group of chunk c), key(a, ctx, c, lane)
+// (kSmallSkipKey: no key in this slot) and the position pos(a, ctx, c, lane) the plan records for it.  The scan order is free -- the
+// sort below orders by (key, position) -- but the positions of one key must ascend with (c, lane).)
 struct SmallListKey {
-  __device__ __forceinline__ uint32_t operator()(const SmallPlanArgs& a, uint32_t p) const {
+  struct Ctx {};
+  __device__ __forceinline__ uint32_t chunks(const SmallPlanArgs& a) const { return (a.n + 63u) >> 6; }
+  __device__ __forceinline__ uint32_t group_end(const SmallPlanArgs& a, uint32_t) const { return (a.n + 63u) >> 6; }
+  __device__ __forceinline__ Ctx open(const SmallPlanArgs&, uint32_t) const { return Ctx(); }
+  __device__ __forceinline__ uint32_t key(const SmallPlanArgs& a, const Ctx&, uint32_t c, uint32_t lane) const {
+    const uint32_t p = c * 64u + lane;
+    if (p >= a.n) return 0xFFFFFFFFu;
     return p < a.n_a ? (uint32_t)a.ids_a[p] : a.base_b + (uint32_t)a.ids_b[p - a.n_a];
   }
-  __device__ __forceinline__ uint32_t pos(uint32_t s) const { return s; }
+  __device__ __forceinline__ uint32_t pos(const SmallPlanArgs&, const Ctx&, uint32_t c, uint32_t lane) const { return c * 64u + lane; }
 };
 
 // exact n / d for n * d < 2^32 by one v_mul_hi_u32 (magic = ceil(2^32 / d), d >= 2; d == 1: magic 0 stands for "n itself")
@@ -89,28 +97,32 @@ __device__ __forceinline__ void small_plan_block(const SmallPlanArgs& a, uint32_
 #endif
   RC_T(0);
 
-  // ---- 1. scan: every wave a contiguous slice, owned keys into its region in position order
-  const uint32_t slice = ((a.n + kSmallWaves * 64 - 1) / (kSmallWaves * 64)) * 64;
-  const uint32_t p_beg = wave * slice, p_end = (p_beg + slice < a.n) ? p_beg + slice : a.n;
+  // ---- 1. scan: every wave a contiguous range of chunks, owned keys into its region in scan order
+  const uint32_t n_chunks = small_key.chunks(a);
+  const uint32_t per_wave = (n_chunks + kSmallWaves - 1) / kSmallWaves;
+  const uint32_t c_beg = wave * per_wave, c_end = (c_beg + per_wave < n_chunks) ? c_beg + per_wave : n_chunks;
   uint32_t cnt = 0;
-  constexpr int kBatch = 32;  // rounds of 64 keys requested together: a 32,768-key batch is two trips per wave
-  for (uint32_t p0 = p_beg; p0 < p_end; p0 += 64 * kBatch) {
-    uint32_t key[kBatch];
+  constexpr int kBatch = 32;  // chunks requested together: a 32,768-key batch is two trips per wave
+  for (uint32_t cg = c_beg; cg < c_end;) {
+    const typename KEY::Ctx ctx = small_key.open(a, cg);
+    uint32_t g_end = small_key.group_end(a, cg);
+    if (g_end > c_end) g_end = c_end;
+    for (uint32_t c0 = cg; c0 < g_end; c0 += kBatch) {
+      uint32_t key[kBatch];
 #pragma unroll
-    for (int q = 0; q < kBatch; ++q) {
-      const uint32_t p = p0 + q * 64 + lane;
-      key[q] = p < p_end ? small_key(a, p) : 0xFFFFFFFFu;
-    }
+      for (int q = 0; q < kBatch; ++q) key[q] = c0 + q < g_end ? small_key.key(a, ctx, c0 + q, (uint32_t)lane) : 0xFFFFFFFFu;
 #pragma unroll
-    for (int q = 0; q < kBatch; ++q) {
-      if (p0 + q * 64 >= p_end) break;  // wave-uniform
-      const uint32_t p = p0 + q * 64 + lane;
-      const bool mine = p < p_end && key[q] != kSmallSkipKey && (key[q] & (kSmallPlanWgs - 1)) == w;
-      const uint64_t m = __ballot(mine);
-      const uint32_t at = cnt + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-      if (mine && at < (uint32_t)kSmallWaveCap) region[(size_t)wave * kSmallWaveCap + at] = ((uint64_t)key[q] << 15) | small_key.pos(p);
-      cnt += (uint32_t)__popcll(m);
+      for (int q = 0; q < kBatch; ++q) {
+        if (c0 + q >= g_end) break;  // wave-uniform
+        const bool mine = key[q] != kSmallSkipKey && (key[q] & (kSmallPlanWgs - 1)) == w;
+        const uint64_t m = __ballot(mine);
+        const uint32_t at = cnt + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        if (mine && at < (uint32_t)kSmallWaveCap)
+          region[(size_t)wave * kSmallWaveCap + at] = ((uint64_t)key[q] << 15) | small_key.pos(a, ctx, c0 + q, (uint32_t)lane);
+        cnt += (uint32_t)__popcll(m);
+      }
     }
+    cg = g_end;
   }
   if (lane == 0) sc[wave] = cnt;
   RC_T(1);
@@ -241,8 +253,8 @@ __device__ __forceinline__ void small_plan_block(const SmallPlanArgs& a, uint32_
   for (;;) {
     uint32_t best = 0xFFFFFFFFu;
     bool any = false;
-    for (uint32_t p = tid; p < a.n; p += kSmallThreads) {
-      const uint32_t key = small_key(a, p);
+    for (uint32_t c = wave; c < n_chunks; c += kSmallWaves) {
+      const uint32_t key = small_key.key(a, small_key.open(a, c), c, (uint32_t)lane);
       if (key != kSmallSkipKey && (key & (kSmallPlanWgs - 1)) == w && (uint64_t)key + 1 > last && (!any || key < best)) { best = key; any = true; }
     }
     // block min
@@ -258,11 +270,13 @@ __device__ __forceinline__ void small_plan_block(const SmallPlanArgs& a, uint32_
       if (sc[24 + q] && (!any || sc[16 + q] < best)) { best = sc[16 + q]; any = true; }
     __syncthreads();
     if (!any) break;
-    // positions of `best`, ascending: tiles of kSmallThreads consecutive positions
+    // occurrences of `best` in scan order (ascending positions): tiles of kSmallWaves consecutive chunks, wave q the q-th
     uint32_t taken = 0;
-    for (uint32_t p0 = 0; p0 < a.n; p0 += kSmallThreads) {
-      const uint32_t p = p0 + tid;
-      const bool hit = p < a.n && small_key(a, p) == best;
+    for (uint32_t c0 = 0; c0 < n_chunks; c0 += kSmallWaves) {
+      const uint32_t c = c0 + wave;
+      const uint32_t cc = c < n_chunks ? c : 0u;      // (wave-uniform; a wave past the end re-reads chunk 0 and drops it)
+      const typename KEY::Ctx hctx = small_key.open(a, cc);
+      const bool hit = c < n_chunks && small_key.key(a, hctx, cc, (uint32_t)lane) == best;
       const uint64_t hb = __ballot(hit);
       if (lane == 0) sc[32 + wave] = (uint32_t)__popcll(hb);
       __syncthreads();
@@ -273,8 +287,9 @@ __device__ __forceinline__ void small_plan_block(const SmallPlanArgs& a, uint32_
       }
       if (hit) {
         const uint32_t at = before + (uint32_t)__popcll(hb & ((1ull << lane) - 1ull));
-        occ[n_occ + at] = small_key.pos(p);
-        if (at == 0) sc[40] = small_key.pos(p);   // the row's first position
+        const uint32_t p = small_key.pos(a, hctx, cc, (uint32_t)lane);
+        occ[n_occ + at] = p;
+        if (at == 0) sc[40] = p;   // the row's first position
       }
       taken += total;
       __syncthreads();

@@ -771,8 +771,33 @@ def take_deferred(counter):
     return d is not None and d[0] is counter and d[1]
 
 
+_bumped_early = []        # counters a carrier launch has already incremented for their owner's NEXT step_increment call
+
+
+def clear_bumped_early():
+    """forget early increments nobody collected (a step that raised between the carrier launch and the owner's step_increment)"""
+    del _bumped_early[:]
+
+
+def pending_deferred():
+    """the counter of an unsettled defer_increment that no launch has taken along yet, or None -- a launch with a slot for a counter
+    it does not read may take it (fold_deferred after the launch is enqueued)"""
+    d = _deferred_inc
+    return d[0] if (d is not None and not d[1]) else None
+
+
+def fold_deferred(counter):
+    d = _deferred_inc
+    if d is not None and d[0] is counter:
+        d[1] = True
+
+
 def step_increment(counter):
     """counter[0] += 1 on the device (rc_step_increment): Adam's step, the dropout seed; capturable"""
+    for k, c in enumerate(_bumped_early):
+        if c is counter:      # an earlier launch of this step (the field gather) incremented it on the owner's behalf
+            del _bumped_early[k]
+            return
     d = _deferred_inc
     if d is not None and not d[1] and d[0] is not counter and d[0].device == counter.device:
         _lib.call("rc_step_increment2", _ptr(counter, torch.int64, "counter"), _ptr(d[0], torch.int64, "deferred counter"), _stream())
@@ -1951,7 +1976,7 @@ def field_kind(values):
     return kind
 
 
-def gather_fields(tables, ids, n_cand, want_cid=True, tables1=None, mark=None, kinds=None, numeric_key=-1, fm=False, plan=False):
+def gather_fields(tables, ids, n_cand, want_cid=True, tables1=None, mark=None, kinds=None, numeric_key=-1, fm=False, plan=False, bump=None):
     """tables: list of F [vocab_f, d] tensors; ids: list of F int64 tensors, [B] (per-row field) or [B, C]
     -> (out [B, C, F, d], cid [B, C, F] | None, row_offset list): all field lookups in one launch.
     tables1: F [vocab_f, 1] tables looked up with the same ids (rc_gather_fields_pair) -> (out, out1 [B, C, F, 1], cid, offsets)
@@ -1962,7 +1987,8 @@ def gather_fields(tables, ids, n_cand, want_cid=True, tables1=None, mark=None, k
     such a field owns no row of the concatenated table and its occurrences carry `numeric_key` in cid
     fm / plan (rc_gather_fields_fused; d in 16 / 32 / 64 / 128, tables1 given): the same launch also forms the FM pairwise term
     [B, C] + the field sums [B, C, d], and / or groups the composite keys for the backward pass's row sums (small batches) into a
-    fresh workspace -> (out, out1, cid, offsets, fm_term | None, fm_sum | None, plan_ws | None)"""
+    fresh workspace -> (out, out1, cid, offsets, fm_term | None, fm_sum | None, plan_ws | None); bump: an int64 [1] device counter
+    the same launch increments (the caller promises nothing in the launch reads it; recorded for step_increment: bumped_early)"""
     F = len(tables)
     kinds = [FIELD_IDS] * F if kinds is None else [int(k) for k in kinds]
     mixed = any(k != FIELD_IDS for k in kinds)
@@ -2010,8 +2036,12 @@ def gather_fields(tables, ids, n_cand, want_cid=True, tables1=None, mark=None, k
         _lib.call("rc_gather_fields_fused", tab_arr, tab1_arr, ids_arr, per_row, kind_arr, int(numeric_key), off_arr, F, B, int(n_cand), d,
                   _ptr(out, f32, "out"), _ptr(out1, f32, "out1"), _ptr(cid, i64, "cid", True), _ptr(flags, torch.int32, "row_flags", True),
                   _ptr(step_dev, i64, "step_dev", True), 1, _ptr(fm_term, f32, "fm_out", True), _ptr(fm_sum, f32, "fm_sum", True),
-                  C.c_void_p(plan_ws.data_ptr()) if plan else None, plan_ws.numel() if plan else 0, _stream())
+                  C.c_void_p(plan_ws.data_ptr()) if plan else None, plan_ws.numel() if plan else 0, _ptr(bump, i64, "bump", True), _stream())
+        if bump is not None:
+            _bumped_early.append(bump)
         return out, out1, cid, offs + [run], fm_term, fm_sum, plan_ws
+    if bump is not None:
+        raise ValueError("gather_fields: a counter rides in the fused launch only (fm / plan)")
     if mixed:
         kind_arr = (C.c_int * F)(*kinds)
         _lib.call("rc_gather_fields_mixed", tab_arr, tab1_arr, ids_arr, per_row, kind_arr, int(numeric_key), off_arr, F, B, int(n_cand), d,
@@ -2085,14 +2115,29 @@ def ctr_head(bias, lin, term1, term2, label):
 CTR_HEAD_ONE_WG_MAX = 65536   # rows the one-workgroup head (rc_ctr_head_fwd_bwd_sums) takes
 
 
-def ctr_head_sums(bias, lin, term1, term2, label):
-    """ctr_head in one workgroup that also forms the loss mean and sum gz: -> (p [n], sums [2] = (loss, sum gz), gz [n])"""
+def ctr_head_sums(bias, lin, term1, term2, label, full=False):
+    """ctr_head in one workgroup that also forms the loss mean and sum gz: -> (p [n], sums [2] = (loss, sum gz), gz [n]).
+    full=True (rc_ctr_head_fwd_full): the same launch leaves the backward fan-out for a seed gradient of exactly one --
+    -> (p, sums, gz, g_lin [n, F], g_bias [1]) -- and takes a pending deferred counter increment along (Adam's step count)"""
     n, F = lin.shape
     f32 = torch.float32
     p = torch.empty(n, dtype=f32, device=lin.device)
     loss_vec = torch.empty(n, dtype=f32, device=lin.device)
     gz = torch.empty(n, dtype=f32, device=lin.device)
     sums = torch.empty(2, dtype=f32, device=lin.device)
+    if full:
+        g_lin = torch.empty((n, F), dtype=f32, device=lin.device)
+        g_bias = torch.empty(1, dtype=f32, device=lin.device)
+        bump = pending_deferred()
+        if bump is not None and bump.device != lin.device:
+            bump = None
+        _lib.call("rc_ctr_head_fwd_full", _ptr(bias, f32, "bias"), _ptr(lin, f32, "lin"), int(F), _ptr(term1, f32, "term1", True),
+                  _ptr(term2, f32, "term2", True), _ptr(label, torch.int64, "label"), n, _ptr(p, f32, "p"), _ptr(loss_vec, f32, "loss_vec"),
+                  _ptr(gz, f32, "gz"), _ptr(sums, f32, "sums"), _ptr(g_lin, f32, "g_lin"), _ptr(g_bias, f32, "g_bias"),
+                  _ptr(bump, torch.int64, "bump", True), _stream())
+        if bump is not None:
+            fold_deferred(bump)
+        return p, sums, gz, g_lin, g_bias
     _lib.call("rc_ctr_head_fwd_bwd_sums", _ptr(bias, f32, "bias"), _ptr(lin, f32, "lin"), int(F), _ptr(term1, f32, "term1", True),
               _ptr(term2, f32, "term2", True), _ptr(label, torch.int64, "label"), n, _ptr(p, f32, "p"), _ptr(loss_vec, f32, "loss_vec"),
               _ptr(gz, f32, "gz"), _ptr(sums, f32, "sums"), _stream())

@@ -91,6 +91,10 @@ class GraphedStep:
             object.__delattr__(self.model, '_step_optimizer')
         if not on and getattr(opt, 'rows_abort', None) is not None:
             opt.rows_abort()    # a step that raised between the forward and step() must not poison the next one
+        from . import engine, nn as hnn
+        engine.clear_bumped_early()
+        # the head's forward launch may leave the backward fan-out for exactly this seed buffer (nn._CtrHeadFn)
+        hnn.UNIT_LOSS_GRAD = getattr(self, '_one', None) if on else None
 
     def _eager(self, batch):
         model = self.model
@@ -98,7 +102,11 @@ class GraphedStep:
         self._announce(True)
         try:
             loss = self.loss_of(model, batch)
-            loss.backward()
+            one = getattr(self, '_one', None)
+            if one is not None and loss.dim() == 0 and loss.dtype == torch.float32 and loss.device == one.device:
+                loss.backward(gradient=one)
+            else:
+                loss.backward()
             model.optimizer.step()
         finally:
             self._announce(False)

@@ -293,7 +293,7 @@ class _FieldGatherPairFn(torch.autograd.Function):
     take no part in the grouping, and their weight gradients are one weighted column sum (rc_numeric_field_grads)."""
 
     @staticmethod
-    def forward(ctx, n_cand, n_fields, rows_opt, kinds, want_fm, *args):
+    def forward(ctx, n_cand, n_fields, rows_opt, kinds, want_fm, bump, *args):
         ids = [x.contiguous() for x in args[:n_fields]]
         tables, tables1 = args[n_fields:2 * n_fields], args[2 * n_fields:]
         kinds = tuple(kinds) if kinds is not None else (engine.FIELD_IDS,) * n_fields
@@ -324,7 +324,7 @@ class _FieldGatherPairFn(torch.autograd.Function):
         if plan or fm_here:
             V, L, cid, offs, fm, S, plan_ws = engine.gather_fields([t.detach() for t in tables], ids, n_cand, want_cid=True,
                                                                    tables1=[t.detach() for t in tables1], mark=mark, kinds=kinds,
-                                                                   numeric_key=numeric_key, fm=fm_here, plan=plan)
+                                                                   numeric_key=numeric_key, fm=fm_here, plan=plan, bump=bump)
         else:
             V, L, cid, offs = engine.gather_fields([t.detach() for t in tables], ids, n_cand, want_cid=True,
                                                    tables1=[t.detach() for t in tables1], mark=mark,
@@ -396,7 +396,7 @@ class _FieldGatherPairFn(torch.autograd.Function):
                 gw, gw1 = res[2:]
             return res[:2]
 
-        lead = (None,) * 5
+        lead = (None,) * 6
         if ctx.rows_opt is not None:
             if not have_v or gL is None:
                 raise RuntimeError("gather_fields_pair (rows mode): both table families must reach the loss")
@@ -422,15 +422,18 @@ class _FieldGatherPairFn(torch.autograd.Function):
         return lead + (None,) * F + gv + gl
 
 
-def gather_fields_pair(tables, tables1, ids, n_cand, rows_opt=None, kinds=None, fm=False):
+def gather_fields_pair(tables, tables1, ids, n_cand, rows_opt=None, kinds=None, fm=False, bump=None):
     """-> (field vectors [B, C, F, d], first-order values [B, C, F, 1]) of the two table families looked up with the same ids.
     fm=True: -> (vectors, values, FM pairwise term [B, C]) -- models/context/FM.py:61's 0.5 sum_k ((sum_f v)^2 - sum_f v^2) formed
     in the gather's launch; its backward is added to the vectors' other gradient (DeepFM's tower) where the row sums read it.
+    bump: an int64 [1] device counter whose next engine.step_increment the gather's launch performs early, where it has a slot for
+    it (the dropout seed of the tower that consumes the vectors: one one-thread launch fewer per step); nothing the gather launches
+    may read it.
     rows_opt: the HipOptimizer that owns the tables, when this forward is part of a whole training step whose optimizer.step()
     follows (graph.GraphedStep sets it): small batches then take the optimizer's rows mode.
     kinds: per field engine.FIELD_IDS (a table looked up by ids) or the value type of a numeric field (engine.field_kind): then
     tables[f] / tables1[f] are the weights of its Linear(1, d) / Linear(1, 1) and ids[f] holds the feature's values"""
-    return _FieldGatherPairFn.apply(n_cand, len(tables), rows_opt, None if kinds is None else tuple(kinds), bool(fm), *ids, *tables, *tables1)
+    return _FieldGatherPairFn.apply(n_cand, len(tables), rows_opt, None if kinds is None else tuple(kinds), bool(fm), bump, *ids, *tables, *tables1)
 
 
 class _BceProbFn(torch.autograd.Function):
@@ -452,6 +455,9 @@ def bce_loss(p, y):
     return _BceProbFn.apply(p, y)
 
 
+UNIT_LOSS_GRAD = None     # float32 scalar buffer holding 1.0 that the step in progress seeds loss.backward() with (graph.GraphedStep)
+
+
 class _CtrHeadFn(torch.autograd.Function):
     """the CTR head of the context models in training: logit = bias + first-order sum (+ pairwise term) (+ MLP output), sigmoid,
     nn.BCELoss -- one kernel forward, the closed-form d loss / d logit fanned out to the terms backward."""
@@ -465,10 +471,14 @@ class _CtrHeadFn(torch.autograd.Function):
         ctx.one_wg = n <= engine.CTR_HEAD_ONE_WG_MAX and lin2.numel() == lin.numel()
         ctx.set_materialize_grads(False)    # p is not differentiable: no [n] block of zeros is filled for it in every backward pass
         if ctx.one_wg:
-            # one workgroup: probabilities, loss MEAN and sum gz (the bias gradient) in the same launch
-            p, sums, gz = engine.ctr_head_sums(bias.detach(), lin2, t[0] if len(t) > 0 else None, t[1] if len(t) > 1 else None,
-                                               label.reshape(-1).contiguous())
-            ctx.save_for_backward(gz, sums)
+            # one workgroup: probabilities, loss MEAN and sum gz (the bias gradient) in the same launch.  Inside a whole training
+            # step whose backward is seeded with the constant 1 (graph.GraphedStep announces its buffer: UNIT_LOSS_GRAD) the launch
+            # also leaves the backward fan-out and takes Adam's pending step-count increment along
+            ctx.full = UNIT_LOSS_GRAD is not None and UNIT_LOSS_GRAD.device == lin2.device
+            res = engine.ctr_head_sums(bias.detach(), lin2, t[0] if len(t) > 0 else None, t[1] if len(t) > 1 else None,
+                                       label.reshape(-1).contiguous(), full=ctx.full)
+            p, sums, gz = res[:3]
+            ctx.save_for_backward(gz, sums, *res[3:])
             ctx.mark_non_differentiable(p)
             return p, sums[0].reshape(())
         p, loss, gz = engine.ctr_head(bias.detach(), lin2, t[0] if len(t) > 0 else None,
@@ -482,8 +492,12 @@ class _CtrHeadFn(torch.autograd.Function):
         if g_loss is None:      # the loss did not reach the objective
             return (None, None, None) + (None,) * len(ctx.term_shapes)
         if ctx.one_wg:
-            gz, sums = ctx.saved_tensors
+            gz, sums = ctx.saved_tensors[:2]
             n = gz.shape[0]
+            unit = UNIT_LOSS_GRAD
+            if ctx.full and unit is not None and g_loss.data_ptr() == unit.data_ptr() and g_loss.numel() == 1:
+                g_lin, g_bias = ctx.saved_tensors[2:]       # the forward launch wrote them for exactly this seed
+                return (g_bias, g_lin.view(ctx.lin_shape), None) + tuple(gz.reshape(sh) for sh in ctx.term_shapes)
             # one launch: g = gz * g_loss for the terms, the contiguous [n, F] block of the first-order weights, the bias gradient
             g, g_lin, g_bias = engine.ctr_head_bwd(gz, sums, g_loss.reshape(1).float().contiguous(), ctx.lin_shape.numel() // n)
             return (g_bias, g_lin.view(ctx.lin_shape), None) + tuple(g.reshape(sh) for sh in ctx.term_shapes)

@@ -107,8 +107,14 @@ class FMBase(object):
         ids = [feed_dict[f] for f in self.context_features]
         out = hnn.gather_fields_pair([self.context_embedding[f].weight for f in self.context_features],
                                      [self.linear_embedding[f].weight for f in self.context_features], ids, n_cand,
-                                     rows_opt=self._rows_opt(), kinds=self._field_kinds(feed_dict), fm=self.fm_term)
+                                     rows_opt=self._rows_opt(), kinds=self._field_kinds(feed_dict), fm=self.fm_term,
+                                     bump=self._early_seed())
         return out if self.fm_term else out + (None,)
+
+    def _early_seed(self):
+        """a device counter whose per-forward increment the gather's launch can perform on its owner's behalf (WideDeep / DeepFM:
+        the dropout seed of the deep tower, which runs right after the gather)"""
+        return None
 
     def _rows_opt(self):
         """the optimizer, while this forward is part of a whole training step driven by graph.GraphedStep (forward, backward and

@@ -35,6 +35,11 @@ class WideDeepBase(FMBase):
         self.deep_layers = MLP_Block(width, self.layers, hidden_activations="ReLU", batch_norm=False,
                                      dropout_rates=self.dropout, output_dim=1)
 
+    def _early_seed(self):
+        # MLP_Block.forward bumps its dropout seed before its first layer (engine.step_increment); every forward of this head runs
+        # the tower after the gather, so the gather's launch does it (engine.step_increment then finds it done)
+        return getattr(self.deep_layers, 'drop_seed', None) if (self.training and self._rows_opt() is not None) else None
+
     def _deep(self, field_vectors):
         return self.deep_layers(field_vectors.flatten(start_dim=-2)).squeeze(dim=-1)
 
