@@ -544,6 +544,15 @@ int rc_sasrec_batch_bwd_dropout(const float* const* layer_params, int n_layers, 
                                 const int64_t* lengths, int B, int L, int d, float drop_p,
                                 const uint64_t* seed_dev, const float* state, const float* dhv, float* g_hist,
                                 float* dense_grads, void* ws, size_t ws_bytes, rc_stream_t stream);
+/* rc_sasrec_batch_bwd_dropout in two calls, for a caller that lets the item-table update start (on another stream) as soon as the
+ * history rows' gradient g_hist is complete while the encoder's parameter gradients are still being formed: part 1 = every launch
+ * up to and including the one that completes g_hist, part 2 = the rest (dense_grads is complete after part 2; both parts take the
+ * same arguments).  rc_sasrec_batch_bwd_splits: 1 where part 2 is not empty (one block on the last-row path), else part 1 is the
+ * whole backward pass.  Same kernels, same results as the one-call form.                                                       */
+int rc_sasrec_batch_bwd_splits(int d, int n_layers, int n_heads, int B, int L, float drop_p);
+int rc_sasrec_batch_bwd_part(const float* const* layer_params, int n_layers, int n_heads, const int64_t* lengths, int B, int L, int d,
+                             float drop_p, const uint64_t* seed_dev, const float* state, const float* dhv, float* g_hist,
+                             float* dense_grads, void* ws, size_t ws_bytes, int part, rc_stream_t stream);
 
 /* Gradient of the position table p_embeddings (SASRec.py:64: position id = length - index on valid slots, 0 on
  * padding): grad_pos[p] = sum_b g_hist[b, len_b - p] over the sequences with len_b >= p, rows 0 and > L are zero.

@@ -169,6 +169,8 @@ SIGNATURES = {
     "rc_sasrec_batch_bwd": (_i, [_p, _i, _i, _p, _i, _i, _i, _p, _p, _p, _p, _p, _sz, _p]),
     "rc_sasrec_batch_fwd_dropout": (_i, [_p, _p, _p, _i, _i, _p, _p, _i, _i, _i, _f, _p, _p, _p, _p, _sz, _p]),
     "rc_sasrec_batch_bwd_dropout": (_i, [_p, _i, _i, _p, _i, _i, _i, _f, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "rc_sasrec_batch_bwd_part": (_i, [_p, _i, _i, _p, _i, _i, _i, _f, _p, _p, _p, _p, _p, _p, _sz, _i, _p]),
+    "rc_sasrec_batch_bwd_splits": (_i, [_i, _i, _i, _i, _i, _f]),
     "rc_neumf_supported": (_i, [_i, _i]),
     "rc_neumf_fwd": (_i, [_p] * 9 + [_i, _i, _i, _i, _p, _p]),
     "rc_neumf_workspace_bytes": (_sz, [_i, _i, _i, _i]),

@@ -2109,7 +2109,9 @@ static int sb_wgrad(const SbWgradArgs& a, int64_t rmax, hipStream_t s);
 // Gout: the compact gradient rows of the block's input (padded == false), or the caller's padded [B, L, D] array (one block)
 template <int D>
 static int sb_last_block_bwd(const SasLayer& p, int n_heads, const int64_t* lengths, int B, int L, bool padded, const SbSaved& sv,
-                             const float* dhv, float* Gout, float* gp, size_t stride, const SbWs& w, SbDrop dr, hipStream_t s) {
+                             const float* dhv, float* Gout, float* gp, size_t stride, const SbWs& w, SbDrop dr, hipStream_t s, int part = 0) {
+  // part (rc_sasrec_batch_bwd_part): 0 everything; 1 the four launches that end with the input gradient rows complete (Gout); 2 the
+  // two parameter-gradient launches behind them, which nothing downstream of Gout waits for
   using Cfg = SasCfg<D>;
   const SbLastBufs u = sb_last_bufs(sv, B, L, D, n_heads);
   float* gl = w.t1;                                  // [B, D]: dhv (empty histories: 0), then dZ1 = d ctx
@@ -2118,6 +2120,7 @@ static int sb_last_block_bwd(const SasLayer& p, int n_heads, const int64_t* leng
   float* cg = w.t2 + (size_t)B * n_heads * D;        // [B, 4]
   float* ybar = w.t3;                                // [B, H, D]
   float* sds = w.t3 + (size_t)B * n_heads * D;       // [B, 4]
+  if (part != 2) {
   {
     SbBlockBwdArgs bb;
     bb.G = gl; bb.Gb = gl; bb.xh2 = sv.xh2; bb.rstd2 = sv.rstd2; bb.h = sv.h; bb.y1 = sv.y1; bb.xh1 = sv.xh1; bb.rstd1 = sv.rstd1;
@@ -2168,6 +2171,8 @@ static int sb_last_block_bwd(const SasLayer& p, int n_heads, const int64_t* leng
     hipLaunchKernelGGL((sb_lr_tail_kernel<D>), dim3(sb_lr_grid8(B)), dim3(kLrBlock), lds, s, a);
     RC_LAUNCH_CHECK();
   }
+  }
+  if (part == 1) return RC_OK;
   {   // dWk, dbk, dWv, dbv from the per-sequence sums
     SbLrWgradArgs a;
     memset(&a, 0, sizeof(a));
@@ -2367,7 +2372,7 @@ static int sb_wgrad(const SbWgradArgs& a, int64_t rmax, hipStream_t s) {
 template <int D>
 static int sb_backward(const SasLayer* layer, int n_layers, int n_heads, const int64_t* lengths, int B, int L,
                        const float* state, const float* dhv, float* g_hist, float* dense_out, const SbWs& w,
-                       SbDrop dr, hipStream_t s) {
+                       SbDrop dr, hipStream_t s, int part = 0) {
   using Cfg = SasCfg<D>;
   const bool drop = dr.seed != nullptr;
   constexpr int LPR = D / 4, PL = Cfg::PL;
@@ -2380,6 +2385,10 @@ static int sb_backward(const SasLayer* layer, int n_layers, int n_heads, const i
     return fail(RC_ERR_UNSUPPORTED, "rc_sasrec_batch_bwd: history_max %d > %d is covered by the one-row path only (one block, no "
                 "dropout, 1 / 2 / 4 heads, RC_SAS_LAST_ROW unset)", L, kSasLP);
   const int slots = lean ? sb_last_slots(B) : kSbPartWg;
+  if (!lean) {      // only the one-block last-row path splits: here part 1 is the whole backward pass, part 2 nothing
+    if (part == 2) return RC_OK;
+    part = 0;
+  }
   if (!lean) RC_HIP(hipMemsetAsync(w.part, 0, (size_t)kSbPartWg * stride * sizeof(float), s));
   float* G = w.t0;
   if (!last_row) {
@@ -2392,7 +2401,7 @@ static int sb_backward(const SasLayer* layer, int n_layers, int n_heads, const i
     const SbSaved sv = sb_saved(const_cast<float*>(state), l, rmax, D);
     float* gp = w.part + (size_t)l * PL;
     if (last_mode == 2 && l == n_layers - 1) {
-      RC_TRY((sb_last_block_bwd<D>(p, n_heads, lengths, B, L, n_layers == 1, sv, dhv, n_layers == 1 ? g_hist : G, gp, stride, w, dr, s)));
+      RC_TRY((sb_last_block_bwd<D>(p, n_heads, lengths, B, L, n_layers == 1, sv, dhv, n_layers == 1 ? g_hist : G, gp, stride, w, dr, s, part)));
       continue;
     }
     if (last_row && l == n_layers - 1) {
@@ -2552,6 +2561,7 @@ static int sb_backward(const SasLayer* layer, int n_layers, int n_heads, const i
                        g_hist);
     RC_LAUNCH_CHECK();
   }
+  if (part == 1) return RC_OK;     // (lean: the unpack above does not run; the parameter gradients and their reduction are part 2)
   const int count = n_layers * PL;
   if (lean)   // (one block: the index range Wk .. bv of its parameter block has its own slice count)
     hipLaunchKernelGGL(sas_reduce_partials_kernel, dim3((count + 63) / 64), dim3(kBlock), 0, s, w.part, slots, count,
@@ -2634,6 +2644,35 @@ extern "C" int rc_sasrec_batch_bwd_dropout(const float* const* layer_params, int
   hipStream_t s = as_stream(stream);
   return d == 64 ? sb_backward<64>(layer, n_layers, n_heads, lengths, B, L, state, dhv, g_hist, dense_grads, w, dr, s)
                  : sb_backward<32>(layer, n_layers, n_heads, lengths, B, L, state, dhv, g_hist, dense_grads, w, dr, s);
+}
+
+/* The backward pass in two calls, for a caller that lets other work start as soon as the history rows' gradient g_hist is complete
+ * (the item-table update on another stream) while the encoder's parameter gradients are still being formed: part 1 = every launch up
+ * to and including the one that completes g_hist, part 2 = the rest (dense_grads is complete after part 2).  Only the one-block
+ * last-row path has such a tail (rc_sasrec_batch_bwd_splits: 1); elsewhere part 1 is the whole pass and part 2 nothing. */
+extern "C" int rc_sasrec_batch_bwd_splits(int d, int n_layers, int n_heads, int B, int L, float drop_p) {
+  if (!rc_sasrec_supported(d, n_layers, n_heads, L) || n_layers != 1) return 0;
+  const int mode = d == 64 ? sb_last_row_mode<64>(n_heads, B, L, drop_p > 0.f) : sb_last_row_mode<32>(n_heads, B, L, drop_p > 0.f);
+  return mode == 2 ? 1 : 0;
+}
+
+extern "C" int rc_sasrec_batch_bwd_part(const float* const* layer_params, int n_layers, int n_heads, const int64_t* lengths, int B,
+                                        int L, int d, float drop_p, const uint64_t* seed_dev, const float* state, const float* dhv,
+                                        float* g_hist, float* dense_grads, void* ws, size_t ws_bytes, int part, rc_stream_t stream) {
+  if (B == 0) return RC_OK;
+  RC_REQUIRE(part == 1 || part == 2, "rc_sasrec_batch_bwd_part: part %d (1 or 2)", part);
+  RC_REQUIRE(lengths && state && dhv && g_hist && dense_grads && ws, "rc_sasrec_batch_bwd_part: null pointer");
+  if (!rc_sasrec_supported(d, n_layers, n_heads, L))
+    return fail(RC_ERR_UNSUPPORTED, "rc_sasrec_batch_bwd_part: d=%d layers=%d heads=%d L=%d not supported", d, n_layers, n_heads, L);
+  SasLayer layer[kSasMaxLayers];
+  RC_TRY(sb_fill_layers(layer, layer_params, n_layers));
+  SbDrop dr;
+  RC_TRY(sb_set_dropout(dr, drop_p, seed_dev, "rc_sasrec_batch_bwd_part"));
+  const SbWs w = sb_carve(ws, const_cast<float*>(state), B, L, d, n_layers, true);
+  if (ws_bytes < w.total) return fail(RC_ERR_WORKSPACE, "rc_sasrec_batch_bwd_part: workspace %zu < %zu", ws_bytes, w.total);
+  hipStream_t s = as_stream(stream);
+  return d == 64 ? sb_backward<64>(layer, n_layers, n_heads, lengths, B, L, state, dhv, g_hist, dense_grads, w, dr, s, part)
+                 : sb_backward<32>(layer, n_layers, n_heads, lengths, B, L, state, dhv, g_hist, dense_grads, w, dr, s, part);
 }
 
 extern "C" int rc_sasrec_batch_bwd(const float* const* layer_params, int n_layers, int n_heads, const int64_t* lengths,

@@ -426,6 +426,13 @@ _SASREC_PLAN = os.environ.get("RC_TABLE_UPDATE", "auto") == "plan"
 # SasrecTrainer on the one-wave-per-row route: row bounds from a counting sort of item_id + history_items (RowsPlan) instead of the
 # radix sort and its tensor glue (RC_SAS_ROWS_PLAN=0: the sorted route, same results bit for bit)
 _SAS_ROWS_PLAN = os.environ.get("RC_SAS_ROWS_PLAN", "1") != "0"
+# the two-stream schedule of SasrecTrainer (SasrecTrainer._step_item_stream): one stream owns everything about the item table -- the
+# plan beside the encoder, then the table update as soon as the history rows' gradient is complete (rc_sasrec_batch_bwd_part) -- while
+# the other finishes the encoder's parameter gradients, the position gradient and the dense step: ONE join at the end of the step.
+# "2" (default): the encoder rides the caller's stream; "3": the item-table work does; "1": the round-5 schedule (plan on the side
+# stream, joined before the table update on the main stream, position gradient on the side).  Same box, config 3, ms per replayed
+# step: "1" 0.240, "2" 0.219, "3" 0.225 (profiles/r09_sasrec_two_stream_schedules.txt)
+_SAS_SCHED = os.environ.get("RC_SAS_SCHED", "2")
 
 
 def unique_ids(ids, n_rows, tag="unique"):
@@ -1403,9 +1410,24 @@ def sasrec_fwd(item_emb, pos_emb, layers, n_heads, hist, lengths, save=False, im
     return hv, (SasSaved("sequence", xsave, B, len(layers), L, d) if save else None)
 
 
-def sasrec_bwd(layers, n_heads, lengths, saved, dhv, drop_p=0.0, seed=None):
+def _sas_dense_views(dense, n_layers, d):
+    grads = []
+    for l in range(n_layers):
+        off, g = 0, {}
+        for name in SAS_LAYER_KEYS:
+            n = d * d if name.startswith("W") else d
+            g[name] = dense[l, off:off + n].view(d, d) if name.startswith("W") else dense[l, off:off + n]
+            off += n
+        grads.append(g)
+    return grads
+
+
+def sasrec_bwd(layers, n_heads, lengths, saved, dhv, drop_p=0.0, seed=None, split=False):
     """-> (g_hist [B,L,d], list of per-layer dicts of dense gradients); `saved` from sasrec_fwd(save=True);
-    drop_p / seed as given to the forward this is the backward of (the mask is regenerated, not stored)"""
+    drop_p / seed as given to the forward this is the backward of (the mask is regenerated, not stored).
+    split=True (batch-level kernels): only the launches up to the one that completes g_hist are enqueued (rc_sasrec_batch_bwd_part,
+    part 1) -> (g_hist, grads, finish): the caller forks whatever waits for g_hist alone, then calls finish() on the same stream
+    for the rest (the dense gradient views are complete after it)"""
     B, n_layers, L, d = saved.B, saved.n_layers, saved.L, saved.d
     dev, f32 = dhv.device, torch.float32
     g_hist = torch.empty((B, L, d), dtype=f32, device=dev)
@@ -1414,6 +1436,13 @@ def sasrec_bwd(layers, n_heads, lengths, saved, dhv, drop_p=0.0, seed=None):
     dense = torch.empty((n_layers, pl), dtype=f32, device=dev)
     if saved.impl == "batch":
         ws = workspace(lib.rc_sasrec_batch_workspace_bytes(B, L, d, n_layers), dev, "sasrec_batch")
+        if split:
+            args = (_sas_ptr_table(layers), n_layers, int(n_heads), _ptr(lengths, torch.int64, "lengths"), B, L, d, *_drop_args(drop_p, seed),
+                    _ptr(saved.data, f32, "state"), _ptr(dhv, f32, "dhv"), _ptr(g_hist, f32, "g_hist"), _ptr(dense, f32, "dense"),
+                    C.c_void_p(ws.data_ptr()), ws.numel())
+            _lib.call("rc_sasrec_batch_bwd_part", *args, 1, _stream())
+            keep = (layers, lengths, saved, dhv, g_hist, dense, ws)      # alive until part 2 is enqueued
+            return g_hist, _sas_dense_views(dense, n_layers, d), (lambda: (_lib.call("rc_sasrec_batch_bwd_part", *args, 2, _stream()), keep)[0])
         _lib.call("rc_sasrec_batch_bwd_dropout", _sas_ptr_table(layers), n_layers, int(n_heads),
                   _ptr(lengths, torch.int64, "lengths"), B, L, d, *_drop_args(drop_p, seed), _ptr(saved.data, f32, "state"),
                   _ptr(dhv, f32, "dhv"), _ptr(g_hist, f32, "g_hist"), _ptr(dense, f32, "dense"), C.c_void_p(ws.data_ptr()),
@@ -1425,15 +1454,9 @@ def sasrec_bwd(layers, n_heads, lengths, saved, dhv, drop_p=0.0, seed=None):
         _lib.call("rc_sasrec_bwd", _sas_ptr_table(layers), n_layers, int(n_heads), _ptr(lengths, torch.int64, "lengths"),
                   B, L, d, _ptr(saved.data, f32, "xsave"), _ptr(dhv, f32, "dhv"), _ptr(g_hist, f32, "g_hist"),
                   _ptr(dense, f32, "dense"), C.c_void_p(ws.data_ptr()), ws.numel(), _stream())
-    grads = []
-    for l in range(n_layers):
-        off, g = 0, {}
-        for name in SAS_LAYER_KEYS:
-            n = d * d if name.startswith("W") else d
-            g[name] = dense[l, off:off + n].view(d, d) if name.startswith("W") else dense[l, off:off + n]
-            off += n
-        grads.append(g)
-    return g_hist, grads
+    if split:
+        return g_hist, _sas_dense_views(dense, n_layers, d), (lambda: None)
+    return g_hist, _sas_dense_views(dense, n_layers, d)
 
 
 def sasrec_pos_grad(g_hist, lengths, n_pos):
@@ -1737,6 +1760,121 @@ class SasrecTrainer:
         self.loss = loss
         return loss
 
+    def _sorted_occurrences(self, hist, lengths, iid):
+        """candidate + history ids, sorted.  On the one-wave-per-row route the padding slots of the history windows (id 0, zero
+        gradient rows: half of B * history_max occurrences of ONE row, a 400-chunk hot row) are parked behind the table (key =
+        n_items, ignored there) except the first of them, which keeps row 0 among the touched rows exactly as before -- a sum of
+        zero rows is zero either way."""
+        I = self.P["item_emb"]
+        n_items, d = I.shape
+        L = hist.shape[1]
+        n_occ = iid.numel() + hist.numel()
+        if not seg_rows_route(n_occ, n_items, d):
+            return sort_ids(torch.cat([iid.reshape(-1), hist.reshape(-1)]), n_items)
+        pad = (torch.arange(L, device=hist.device)[None, :] >= lengths[:, None]).reshape(-1)
+        hid = torch.where(pad, hist.new_full((), n_items), hist.reshape(-1))
+        first_pad = pad.to(torch.int32).argmax().reshape(1)   # position of the first padding slot (0 if there is none)
+        hid.scatter_(0, first_pad, hist.reshape(-1).gather(0, first_pad))   # (tensor-indexed assignment would read the index back: a host sync)
+        return sort_ids(torch.cat([iid.reshape(-1), hid]), n_items + 1)
+
+    def _item_table_update(self, sorted_ids, rows_plan, hv, gpred, g_hist, h, step_dev, B, Cn):
+        """candidate occurrences (g * hv, rebuilt on the fly) + history occurrences (g_hist rows) of the item table, grouped by
+        `sorted_ids` (a RowsPlan, or (keys, perm) of the sort): row-wise optimizer step, or dense gradient + dense step"""
+        I = self.P["item_emb"]
+        d = I.shape[1]
+        st = self._st(I)
+        if rows_plan:
+            src = dict(coef=gpred.reshape(-1), div=Cn, src2=g_hist.view(-1, d))
+            if self.rowwise:
+                sorted_ids.update(hv, hyper=h, W=I, m=st.get("m"), v=st.get("v"), step_dev=step_dev, **src)
+            else:
+                G = torch.zeros_like(I)
+                sorted_ids.update(hv, dense_grad=G, **src)
+                dense_update(I, G, h, st.get("m"), st.get("v"))
+        elif self.rowwise:
+            keys, perm = sorted_ids
+            segmented_update2(keys, perm, hv, g_hist.view(-1, d), B * Cn, hyper=h, W=I, m=st.get("m"), v=st.get("v"),
+                              coef=gpred.reshape(-1), div=Cn, step_dev=step_dev)
+        else:
+            keys, perm = sorted_ids
+            G = torch.zeros_like(I)
+            segmented_update2(keys, perm, hv, g_hist.view(-1, d), B * Cn, coef=gpred.reshape(-1), div=Cn, dense_grad=G)
+            dense_update(I, G, h, st.get("m"), st.get("v"))
+
+    def _dense_step(self, Gp, dgrads, h, h0, step_dev):
+        """position table + every block parameter: one launch"""
+        P = self.P
+        Pe, layers = P["pos_emb"], P["layers"]
+        st = self._st(Pe)
+        items = [(Pe, Gp, h, st.get("m"), st.get("v"))]
+        for lay, g in zip(layers, dgrads):
+            for name in SAS_LAYER_KEYS:
+                st = self._st(lay[name])
+                items.append((lay[name], g[name].contiguous(), h0 if name in SAS_NO_DECAY else h, st.get("m"), st.get("v")))
+        dense_update_multi(items, self.opt, step_dev=step_dev, increment=False)
+
+    def _score_loss(self, hv, iid, B):
+        # scores, BPR loss, d loss / d pred and d loss / d hv in ONE pass over the candidate rows: the fused BPRMF kernel
+        # with the encoder output as the "user" row (SASRec.py:80-81, BaseModel.py:182-185); three launches and two
+        # more passes over the [B, C] rows before
+        # (one tensor per batch size, kept for the trainer's life: a captured step holds its ADDRESS -- replacing it when another
+        #  batch size comes by, e.g. the short last batch of an epoch, would leave the graph of the first size reading freed memory)
+        rows_by = self.__dict__.setdefault("_rows_by", {})
+        key_rows = (B, str(hv.device))
+        if key_rows not in rows_by:
+            rows_by[key_rows] = torch.arange(B, device=hv.device)
+        _, loss_vec, gpred, dhv = bprmf_fwd_bwd(hv, self.P["item_emb"], rows_by[key_rows], iid, want_pred=False)
+        return loss_vec, gpred, dhv
+
+    def _step_item_stream(self, hist, lengths, iid, h, h0, step_dev, rows_plan, encoder_first):
+        """The step on two streams, one of which owns everything about the ITEM TABLE: the grouping of the batch's ids beside the
+        encoder, then -- as soon as the history rows' gradient is complete (rc_sasrec_batch_bwd_part) -- the table update, while the
+        other stream finishes the encoder's parameter gradients, the position gradient and the dense step.  One fork, one
+        hand-over (g_hist ready), one join.  (Round 5: the table update ran on the encoder's stream behind a second join, the
+        position gradient on the side: two more cross-queue edges of ~11 us each on the critical path of a replayed step.)
+        encoder_first: the encoder rides the caller's stream (in a captured step: the launch stream, the other branch starts behind a
+        cross-queue barrier); else the item-table work does, and the LAST kernels of the step -- the table update's -- are on the
+        launch stream, where the graph ends without waiting for another queue."""
+        P = self.P
+        I, Pe, layers = P["item_emb"], P["pos_emb"], P["layers"]
+        B, L = hist.shape
+        Cn = iid.shape[1]
+        d = I.shape[1]
+        cur, other = torch.cuda.current_stream(hist.device), self._side_stream(hist.device)
+        enc, tab = (cur, other) if encoder_first else (other, cur)
+        # the batch is ready; last step's users of the other stream's buffers are done (the step ends with a join)
+        other.wait_event(cur.record_event())
+        box = {}
+
+        def plan():
+            with torch.cuda.stream(tab):
+                box["ids"] = RowsPlan(iid, hist, lengths, I.shape[0], d, tag="sasrec_rows") if rows_plan else self._sorted_occurrences(hist, lengths, iid)
+
+        def forward():
+            with torch.cuda.stream(enc), _PhaseTimer(self, "encoder_fwd"):
+                box["hv"], box["x"] = sasrec_fwd(I, Pe, layers, self.n_heads, hist, lengths, save=True, drop_p=self.dropout, seed=self.seed)
+
+        for part in ((forward, plan) if encoder_first else (plan, forward)):   # (capture order: see encoder_first)
+            part()
+        hv = box["hv"]
+        with torch.cuda.stream(enc):
+            with _PhaseTimer(self, "score_loss"):
+                loss_vec, gpred, dhv = self._score_loss(hv, iid, B)
+            with _PhaseTimer(self, "encoder_bwd"):
+                g_hist, dgrads, finish_bwd = sasrec_bwd(layers, self.n_heads, lengths, box["x"], dhv, drop_p=self.dropout, seed=self.seed, split=True)
+            ready = enc.record_event()     # g_hist, gpred, hv: what the table update reads
+            with _PhaseTimer(self, "dense_update"):
+                finish_bwd()               # the encoder's parameter gradients ...
+                Gp = sasrec_pos_grad(g_hist, lengths, Pe.shape[0])     # ... the position table's, and the dense step of both
+                self._dense_step(Gp, dgrads, h, h0, step_dev)
+        with torch.cuda.stream(tab):
+            tab.wait_event(ready)
+            self.loss = reduce_sum(loss_vec, 1.0 / B)
+            with _PhaseTimer(self, "table_update"):
+                self._item_table_update(box["ids"], rows_plan, hv, gpred, g_hist, h, step_dev, B, Cn)
+        cur.wait_stream(other)             # the step's one join
+        return self.loss
+
     def _step(self, hist, lengths, iid):
         P = self.P
         I, Pe, layers = P["item_emb"], P["pos_emb"], P["layers"]
@@ -1762,40 +1900,19 @@ class SasrecTrainer:
         # one wave per table row with the rows' bounds from a counting sort of the id tensors themselves (no radix sort, no glue)
         rows_plan = (_SAS_ROWS_PLAN and hist.is_cuda and not use_plan and seg_rows_route(n_occ, I.shape[0], d)
                      and rows_plan_supported(I.shape[0], n_occ, d))
+        if overlap and _SAS_SCHED in ("2", "3"):
+            return self._step_item_stream(hist, lengths, iid, h, h0, step_dev, rows_plan, encoder_first=_SAS_SCHED == "2")
 
-        def sorted_occurrences():
-            """candidate + history ids, sorted.  On the one-wave-per-row route the padding slots of the history windows (id 0, zero
-            gradient rows: half of B * history_max occurrences of ONE row, a 400-chunk hot row) are parked behind the table (key =
-            n_items, ignored there) except the first of them, which keeps row 0 among the touched rows exactly as before -- a sum of
-            zero rows is zero either way."""
-            n_items = I.shape[0]
-            if not seg_rows_route(n_occ, n_items, d):
-                return sort_ids(torch.cat([iid.reshape(-1), hist.reshape(-1)]), n_items)
-            pad = (torch.arange(L, device=hist.device)[None, :] >= lengths[:, None]).reshape(-1)
-            hid = torch.where(pad, hist.new_full((), n_items), hist.reshape(-1))
-            first_pad = pad.to(torch.int32).argmax().reshape(1)   # position of the first padding slot (0 if there is none)
-            hid.scatter_(0, first_pad, hist.reshape(-1).gather(0, first_pad))   # (tensor-indexed assignment would read the index back: a host sync)
-            return sort_ids(torch.cat([iid.reshape(-1), hid]), n_items + 1)
-
-        if overlap:
+        if overlap:      # RC_SAS_SCHED=1, the round-5 schedule: plan on the side stream, joined before the table update
             main, side = torch.cuda.current_stream(hist.device), self._side_stream(hist.device)
             side.wait_stream(main)   # the batch is ready; last step's readers of the side stream's buffers are done
             with torch.cuda.stream(side):
-                sorted_ids = RowsPlan(iid, hist, lengths, I.shape[0], d, tag="sasrec_rows") if rows_plan else sorted_occurrences()
+                sorted_ids = RowsPlan(iid, hist, lengths, I.shape[0], d, tag="sasrec_rows") if rows_plan else self._sorted_occurrences(hist, lengths, iid)
                 sort_done = side.record_event()
         with _PhaseTimer(self, "encoder_fwd"):
             hv, xsave = sasrec_fwd(I, Pe, layers, self.n_heads, hist, lengths, save=True, drop_p=self.dropout, seed=self.seed)
         with _PhaseTimer(self, "score_loss"):
-            # scores, BPR loss, d loss / d pred and d loss / d hv in ONE pass over the candidate rows: the fused BPRMF kernel
-            # with the encoder output as the "user" row (SASRec.py:80-81, BaseModel.py:182-185); three launches and two
-            # more passes over the [B, C] rows before
-            # (one tensor per batch size, kept for the trainer's life: a captured step holds its ADDRESS -- replacing it when another
-            #  batch size comes by, e.g. the short last batch of an epoch, would leave the graph of the first size reading freed memory)
-            rows_by = self.__dict__.setdefault("_rows_by", {})
-            key_rows = (B, str(hist.device))
-            if key_rows not in rows_by:
-                rows_by[key_rows] = torch.arange(B, device=hist.device)
-            _, loss_vec, gpred, dhv = bprmf_fwd_bwd(hv, I, rows_by[key_rows], iid, want_pred=False)
+            loss_vec, gpred, dhv = self._score_loss(hv, iid, B)
             if not overlap:
                 self.loss = reduce_sum(loss_vec, 1.0 / B)   # (two streams: the mean is formed on the side stream below)
         with _PhaseTimer(self, "encoder_bwd"):
@@ -1832,24 +1949,8 @@ class SasrecTrainer:
             elif rows_plan:
                 sorted_ids = RowsPlan(iid, hist, lengths, I.shape[0], d, tag="sasrec_rows")
             else:
-                sorted_ids = sorted_occurrences()
-            if rows_plan:
-                src = dict(coef=gpred.reshape(-1), div=Cn, src2=g_hist.view(-1, d))
-                if self.rowwise:
-                    sorted_ids.update(hv, hyper=h, W=I, m=st.get("m"), v=st.get("v"), step_dev=step_dev, **src)
-                else:
-                    G = torch.zeros_like(I)
-                    sorted_ids.update(hv, dense_grad=G, **src)
-                    dense_update(I, G, h, st.get("m"), st.get("v"))
-            elif self.rowwise:
-                keys, perm = sorted_ids
-                segmented_update2(keys, perm, hv, g_hist.view(-1, d), B * Cn, hyper=h, W=I, m=st.get("m"), v=st.get("v"),
-                                  coef=gpred.reshape(-1), div=Cn, step_dev=step_dev)
-            else:
-                keys, perm = sorted_ids
-                G = torch.zeros_like(I)
-                segmented_update2(keys, perm, hv, g_hist.view(-1, d), B * Cn, coef=gpred.reshape(-1), div=Cn, dense_grad=G)
-                dense_update(I, G, h, st.get("m"), st.get("v"))
+                sorted_ids = self._sorted_occurrences(hist, lengths, iid)
+            self._item_table_update(sorted_ids, rows_plan, hv, gpred, g_hist, h, step_dev, B, Cn)
         _upd.__exit__()
         # position table (tiny): dense gradient, dense step
         _dns = _PhaseTimer(self, "dense_update")
@@ -1858,13 +1959,7 @@ class SasrecTrainer:
             main.wait_stream(side)
         else:
             Gp = sasrec_pos_grad(g_hist, lengths, Pe.shape[0])
-        st = self._st(Pe)
-        items = [(Pe, Gp, h, st.get("m"), st.get("v"))]
-        for lay, g in zip(layers, dgrads):
-            for name in SAS_LAYER_KEYS:
-                st = self._st(lay[name])
-                items.append((lay[name], g[name].contiguous(), h0 if name in SAS_NO_DECAY else h, st.get("m"), st.get("v")))
-        dense_update_multi(items, self.opt, step_dev=step_dev, increment=False)  # position table + every block parameter: one launch
+        self._dense_step(Gp, dgrads, h, h0, step_dev)
         _dns.__exit__()
         return self.loss
 
