@@ -933,6 +933,13 @@ int rc_plan_update_pair(float* W_a, float* m_a, float* v_a, float* W_b, float* m
                         const rc_plan_row* rows, const uint32_t* n_rows, const uint32_t* occ, int64_t n_occ,
                         const float* src_a, const float* src_b, int64_t occ_base, const rc_opt_hyper* h, void* ws,
                         size_t ws_bytes, rc_stream_t stream);
+/* rc_plan_update_pair with the update's eight ticket counters supplied by the caller (8 uint32 on the device), ZERO-FILLED where
+ * that cost nothing -- with the plan's buffers, beside other work on another stream -- and used by nobody since: the memset in
+ * front of the update, a launch of its own between a step's fused kernel and its table updates, is left out.                     */
+int rc_plan_update_pair_zeroed(float* W_a, float* m_a, float* v_a, float* W_b, float* m_b, float* v_b, int d,
+                               const rc_plan_row* rows, const uint32_t* n_rows, const uint32_t* occ, int64_t n_occ,
+                               const float* src_a, const float* src_b, int64_t occ_base, const rc_opt_hyper* h,
+                               uint32_t* counters, void* ws, size_t ws_bytes, rc_stream_t stream);
 
 /* The same walk without an optimizer: out[row, :] = the summed gradient row of every LISTED row (other rows of `out` are
  * left as they are) -- aten::embedding_dense_backward's index_add (helpers/BaseRunner.py:205) as a plan consumer, and the

@@ -97,19 +97,7 @@ __global__ __launch_bounds__(kBlock) void reduce_sum_kernel(const float* __restr
                                                             int64_t n, float scale,
                                                             float* __restrict__ out) {
   __shared__ float sm[kBlock];
-  float acc = 0.f;
-  int64_t done = 0;
-  if (reinterpret_cast<uintptr_t>(x) % 16 == 0) {
-    const int64_t n4 = n / 4;
-    const float4* x4 = reinterpret_cast<const float4*>(x);
-#pragma unroll 8
-    for (int64_t i = threadIdx.x; i < n4; i += kBlock) {
-      const float4 v = x4[i];
-      acc += (v.x + v.y) + (v.z + v.w);
-    }
-    done = n4 * 4;
-  }
-  for (int64_t i = done + threadIdx.x; i < n; i += kBlock) acc += x[i];
+  const float acc = fixed_order_partial<kBlock>(x, n, (int)threadIdx.x);
   sm[threadIdx.x] = acc;
   __syncthreads();
   for (int off = kBlock / 2; off >= 1; off >>= 1) {

@@ -439,19 +439,7 @@ __global__ __launch_bounds__(kBlock) void plan_final_kernel(PlanUpdArgs a, uint3
   // loss mean: thread t sums elements t, t+256, ... then a fixed LDS tree (same order as reduce_sum_kernel)
   if (a.loss_out == nullptr) return;
   float* sm = reinterpret_cast<float*>(part);
-  float acc = 0.f;
-  int64_t done = 0;
-  if (reinterpret_cast<uintptr_t>(a.loss_vec) % 16 == 0) {
-    const int64_t n4 = a.loss_n / 4;
-    const float4* x4 = reinterpret_cast<const float4*>(a.loss_vec);
-#pragma unroll 8
-    for (int64_t i = threadIdx.x; i < n4; i += kBlock) {
-      const float4 v = x4[i];
-      acc += (v.x + v.y) + (v.z + v.w);
-    }
-    done = n4 * 4;
-  }
-  for (int64_t i = done + threadIdx.x; i < a.loss_n; i += kBlock) acc += a.loss_vec[i];
+  const float acc = fixed_order_partial<kBlock>(a.loss_vec, a.loss_n, (int)threadIdx.x);
   sm[threadIdx.x] = acc;
   __syncthreads();
   for (int off = kBlock / 2; off >= 1; off >>= 1) {
@@ -593,15 +581,17 @@ UpdWs carve_upd_ws(void* base, int64_t n_occ, int d) {
 }
 
 // h == nullptr: no optimizer, the listed rows of "W" receive the summed gradient rows (MODE_DENSE_GRAD)
+// zeroed_counters: PC_N words the caller has zero-filled where it cost nothing (beside other work, on another stream) and that nobody
+// has used since -- the memset in front of the update (a launch of its own on the step's critical path) is then left out
 int run_side_update(PlanUpdArgs& a, const rc_opt_hyper* h, int d_eff, int64_t n_occ, void* ws, size_t ws_bytes,
-                    rc_stream_t stream, const char* who) {
+                    rc_stream_t stream, const char* who, uint32_t* zeroed_counters = nullptr) {
   const UpdWs w = carve_upd_ws(ws, n_occ, d_eff);
   if (ws_bytes < w.total) return fail(RC_ERR_WORKSPACE, "%s: workspace %zu < %zu", who, ws_bytes, w.total);
   if (h != nullptr) RC_TRY(fill_opt_scalars(h, &a.o));
-  a.counters = w.counters;
+  a.counters = zeroed_counters != nullptr ? zeroed_counters : w.counters;
   a.lw = w.lw;
   hipStream_t s = as_stream(stream);
-  RC_HIP(hipMemsetAsync(w.counters, 0, PC_N * sizeof(uint32_t), s));
+  if (zeroed_counters == nullptr) RC_HIP(hipMemsetAsync(w.counters, 0, PC_N * sizeof(uint32_t), s));
   if (h == nullptr) return launch_side_update_d<MODE_DENSE_GRAD>(a, d_eff, n_occ, s);
   switch (mode_of(h)) {
     case MODE_SGD: return launch_side_update_d<MODE_SGD>(a, d_eff, n_occ, s);
@@ -640,7 +630,7 @@ extern "C" int rc_plan_update(float* W, float* m, float* v, int d, const rc_plan
   return run_side_update(a, h, d, n_occ, ws, ws_bytes, stream, "rc_plan_update");
 }
 
-extern "C" int rc_plan_update_pair(float* W_a, float* m_a, float* v_a, float* W_b, float* m_b, float* v_b, int d,
+static int plan_update_pair_impl(uint32_t* zeroed_counters, float* W_a, float* m_a, float* v_a, float* W_b, float* m_b, float* v_b, int d,
                                    const rc_plan_row* rows, const uint32_t* n_rows, const uint32_t* occ, int64_t n_occ,
                                    const float* src_a, const float* src_b, int64_t occ_base, const rc_opt_hyper* h,
                                    void* ws, size_t ws_bytes, rc_stream_t stream) {
@@ -662,7 +652,25 @@ extern "C" int rc_plan_update_pair(float* W_a, float* m_a, float* v_a, float* W_
   a.side[0].rows = rows;
   a.side[0].n_rows = n_rows;
   a.occ = occ;
-  return run_side_update(a, h, 2 * d, n_occ, ws, ws_bytes, stream, "rc_plan_update_pair");
+  return run_side_update(a, h, 2 * d, n_occ, ws, ws_bytes, stream, "rc_plan_update_pair", zeroed_counters);
+}
+
+extern "C" int rc_plan_update_pair(float* W_a, float* m_a, float* v_a, float* W_b, float* m_b, float* v_b, int d,
+                                   const rc_plan_row* rows, const uint32_t* n_rows, const uint32_t* occ, int64_t n_occ,
+                                   const float* src_a, const float* src_b, int64_t occ_base, const rc_opt_hyper* h,
+                                   void* ws, size_t ws_bytes, rc_stream_t stream) {
+  return plan_update_pair_impl(nullptr, W_a, m_a, v_a, W_b, m_b, v_b, d, rows, n_rows, occ, n_occ, src_a, src_b, occ_base, h, ws, ws_bytes, stream);
+}
+
+/* rc_plan_update_pair with the update's eight ticket counters supplied by the caller, ZERO-FILLED where that cost nothing (with the
+ * plan's own buffers, beside other work on another stream) and used by nobody since: the one-launch memset in front of the update --
+ * on the critical path of a step between its fused kernel and its table updates -- is left out.  counters: 8 uint32, device. */
+extern "C" int rc_plan_update_pair_zeroed(float* W_a, float* m_a, float* v_a, float* W_b, float* m_b, float* v_b, int d,
+                                          const rc_plan_row* rows, const uint32_t* n_rows, const uint32_t* occ, int64_t n_occ,
+                                          const float* src_a, const float* src_b, int64_t occ_base, const rc_opt_hyper* h,
+                                          uint32_t* counters, void* ws, size_t ws_bytes, rc_stream_t stream) {
+  RC_REQUIRE(counters != nullptr, "rc_plan_update_pair_zeroed: null pointer");
+  return plan_update_pair_impl(counters, W_a, m_a, v_a, W_b, m_b, v_b, d, rows, n_rows, occ, n_occ, src_a, src_b, occ_base, h, ws, ws_bytes, stream);
 }
 
 /* out[row, :] = sum over the row's occurrences of their gradient rows, for the rows the plan lists (other rows of `out`

@@ -74,18 +74,8 @@ __global__ __launch_bounds__(kBlock) void small_update_kernel(SmallUpdArgs a) {
 
   if (blockIdx.x == gridDim.x - 1) {  // the loss mean: fixed order (thread t sums t, t + 256, ...; LDS tree)
     if (a.loss_out == nullptr) return;
-    float acc = 0.f;   // same order as plan_final_kernel / reduce_sum_kernel: the step's loss is bit-identical across pipelines
-    int64_t done = 0;
-    if (reinterpret_cast<uintptr_t>(a.loss_vec) % 16 == 0) {
-      const int64_t n4 = a.B / 4;
-      const float4* x4 = reinterpret_cast<const float4*>(a.loss_vec);
-      for (int64_t i = tid; i < n4; i += kBlock) {
-        const float4 v = x4[i];
-        acc += (v.x + v.y) + (v.z + v.w);
-      }
-      done = n4 * 4;
-    }
-    for (int64_t i = done + tid; i < a.B; i += kBlock) acc += a.loss_vec[i];
+    // same order as plan_final_kernel / reduce_sum_kernel: the step's loss is bit-identical across pipelines
+    const float acc = fixed_order_partial<kBlock>(a.loss_vec, (int64_t)a.B, tid);
     red[tid] = acc;
     __syncthreads();
     for (int off = kBlock / 2; off >= 1; off >>= 1) {

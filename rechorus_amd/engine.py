@@ -294,9 +294,25 @@ class Plan:
         ws = workspace(_lib.load().rc_plan_update_workspace_bytes(n, 2 * d), Wa.device, self.tag + ".upd" + ws_tag)
         f32 = torch.float32
         p = lambda t: C.c_void_p(t.data_ptr())
+        zc = getattr(self, "upd_counters", None)
+        if zc is not None and side in zc:
+            # the update's ticket counters were zero-filled with the plan (prezero_update_counters: beside other work, on the plan's
+            # stream); one use each -- the memset in front of the update, a launch on the step's critical path, is left out
+            c = zc.pop(side)
+            c.record_stream(torch.cuda.current_stream(c.device))
+            _lib.call("rc_plan_update_pair_zeroed", _ptr(Wa, f32, "W_a"), _ptr(ma, f32, "m_a", True), _ptr(va, f32, "v_a", True),
+                      _ptr(Wb, f32, "W_b"), _ptr(mb, f32, "m_b", True), _ptr(vb, f32, "v_b", True), d, p(rows), p(cnt), p(self.occ), n,
+                      _ptr(src_a, f32, "src_a"), _ptr(src_b, f32, "src_b"), base, C.byref(hyper), p(c), p(ws), ws.numel(), _stream())
+            return
         _lib.call("rc_plan_update_pair", _ptr(Wa, f32, "W_a"), _ptr(ma, f32, "m_a", True), _ptr(va, f32, "v_a", True),
                   _ptr(Wb, f32, "W_b"), _ptr(mb, f32, "m_b", True), _ptr(vb, f32, "v_b", True), d, p(rows), p(cnt), p(self.occ), n,
                   _ptr(src_a, f32, "src_a"), _ptr(src_b, f32, "src_b"), base, C.byref(hyper), p(ws), ws.numel(), _stream())
+
+    def prezero_update_counters(self):
+        """zero-fill the ticket counters of one later update_pair per side NOW, on the current stream (the plan's: beside the work the
+        plan is built beside) -- update_pair then runs without its own memset"""
+        z = torch.zeros(16, dtype=torch.int32, device=self.occ.device)
+        self.upd_counters = {"a": z[:8], "b": z[8:]}
 
     def update(self, side, W, hyper, m=None, v=None, coef=None, src=None, src_index=None, div=1, src2=None, n_split=None):
         """rc_plan_update on list `side`: gradient sources as in segmented_update2 (positions of list b start at n_a)"""
@@ -1133,6 +1149,7 @@ class NeumfTrainer:
             self._side.wait_stream(main)
             with torch.cuda.stream(self._side):
                 plan = Plan(iid, n_i, uid, n_u, tag=tag(buf), list_single_a=False)
+                plan.prezero_update_counters()
                 plan_done = self._side.record_event()
             iid.record_stream(self._side)
             uid.record_stream(self._side)
@@ -1149,8 +1166,16 @@ class NeumfTrainer:
             # epoch announced by a large one) that runs on one stream: a flag left behind would make a later single occurrence
             # of that row look like a multiple one, and its update would be dropped
             neumf_mark_rows(iid, n_i, self._marks[buf], unmark=True)
-        if two_streams and (next_batch is not None or marks_done is not None):
+        loss_done = None
+        if two_streams:
             self._side.wait_stream(main)    # behind the fused kernel: beside the updates below
+            with torch.cuda.stream(self._side):
+                # the batch mean of the per-tuple losses (one workgroup) FIRST on the plan's stream: nothing of this step waits for it
+                # (main joins it at the very end), and the streams that carry the two table updates start those at once.  (Round 5
+                # had it in front of the user-side update: 28 us on the critical path of the step.)
+                self.loss = reduce_sum(out["loss_vec"], 1.0 / B)
+                loss_done = self._side.record_event()
+        if two_streams and (next_batch is not None or marks_done is not None):
             with torch.cuda.stream(self._side):
                 if marks_done is not None:
                     neumf_mark_rows(iid, n_i, self._marks[buf], unmark=True)
@@ -1162,16 +1187,13 @@ class NeumfTrainer:
                     neumf_mark_rows(ni, n_i, self._marks[buf ^ 1])
                     nmarks_done = self._side.record_event()
                     nplan = Plan(ni, n_i, nu, n_u, tag=tag(buf ^ 1), list_single_a=False)
+                    nplan.prezero_update_counters()
                     ni.record_stream(self._side)
                     nu.record_stream(self._side)
                     self._ahead = {"key": self._batch_key(nu, ni), "plan": nplan, "plan_done": self._side.record_event(),
                                    "marks_done": nmarks_done, "iid": ni, "buf": buf ^ 1}
         if two_streams:
-            # the batch mean of the per-tuple losses (one workgroup, 10 us of latency) on the user side's stream, where it fills
-            # the wait for the plan instead of standing in front of the item update
             self._side2.wait_stream(main)
-            with torch.cuda.stream(self._side2):
-                self.loss = reduce_sum(out["loss_vec"], 1.0 / B)
         else:
             with _PhaseTimer(self, "loss"):
                 self.loss = reduce_sum(out["loss_vec"], 1.0 / B)
@@ -1199,6 +1221,8 @@ class NeumfTrainer:
         with _PhaseTimer(self, "dense_update"):
             dense_update_multi([(P[k], out[k], h0 if k == "b1" else h, self.state[k].get("m"), self.state[k].get("v"))
                                 for k in ("W1", "b1", "w_out")], self.opt)
+        if loss_done is not None:
+            main.wait_event(loss_done)      # (long complete: the caller reads the loss on this stream)
         return self.loss
 
     def _step_tables_sorted(self, P, uid_occ, iid, rows, h, pair_ok):
