@@ -1021,6 +1021,11 @@ class NeumfTrainer:
 
     def __del__(self):
         try:
+            # the trainer's plan workspaces leave the cache -- once the side streams that wrote them have drained (a block freed
+            # with side-stream work in flight could be handed out again on the main stream)
+            for st in (getattr(self, "_side", None), getattr(self, "_side2", None)):
+                if st is not None:
+                    st.synchronize()
             for key in [k for k in _ws_cache if isinstance(k[1], str) and k[1].startswith("neumf%d." % self._serial)]:
                 _ws_cache.pop(key, None)
         except Exception:

@@ -149,7 +149,9 @@ class GraphedStep:
                 o += n
             self.groups.append((flat, keys))
         model.optimizer.zero_grad()  # grads must be None: the captured backward allocates them in the graph's pool
-        dev = next((v.device for v in batch.values() if isinstance(v, torch.Tensor)), None)
+        dev = next((p.device for p in model.parameters()), None)      # where the loss will live (a batch may hold no tensor)
+        if dev is None:
+            dev = next((v.device for v in batch.values() if isinstance(v, torch.Tensor)), None)
         self._one = torch.ones((), dtype=torch.float32, device=dev)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
@@ -164,7 +166,7 @@ class GraphedStep:
                     self.loss = self.loss_of(model, self.static)
                     # the seed gradient of the scalar loss from a buffer filled once, not a ones_like fill in every replay (a launch
                     # of its own: ~4.6 us of a 0.26 ms DeepFM step)
-                    one = self._one if (self.loss.dim() == 0 and self.loss.dtype == torch.float32) else None
+                    one = self._one if (self.loss.dim() == 0 and self.loss.dtype == torch.float32 and self.loss.device == self._one.device) else None
                     self.loss.backward(gradient=one) if one is not None else self.loss.backward()
                     model.optimizer.step()
             finally:

@@ -861,8 +861,9 @@ class ShardedNeumf(_LookAhead):
     TABLES = ("mf_u", "mlp_u", "mf_i", "mlp_i")
 
     def __init__(self, n_users, n_items, emb_size, hidden, opt="SGD", lr=1e-3, l2=0.0, device=None, ops=None,
-                 group=None, init_std=0.01, seed=0, micro_batches=1, dedup=True, item_half="auto"):
+                 group=None, init_std=0.01, seed=0, micro_batches=1, dedup=True, item_half="auto", force_exchange=False):
         self.micro_batches = max(1, int(micro_batches))
+        self.force_exchange = bool(force_exchange)   # W = 1 through the general exchange path (loop-back profiling of one rank alone)
         self.dedup = bool(dedup)
         self._item_half_arg = item_half
         self.wire = None  # {"ids_out", "rows_in", "grads_out", ...} bytes of the last step (this rank), W > 1
@@ -888,7 +889,7 @@ class ShardedNeumf(_LookAhead):
         # Fewer bytes each way whenever hidden < emb_size (config 4: 192 instead of 256 floats per distinct item id, -25 %).
         if item_half not in ("auto", "owner", "rows"):
             raise ValueError("item_half must be auto | owner | rows")
-        if item_half == "owner" and not (self.world > 1 and all(hasattr(self.ops, m) for m in ("item_half_fwd", "item_half_bwd", "neumf_zhead"))):
+        if item_half == "owner" and not ((self.world > 1 or self.force_exchange) and all(hasattr(self.ops, m) for m in ("item_half_fwd", "item_half_bwd", "neumf_zhead"))):
             raise ValueError("item_half='owner' needs W > 1 and ops with item_half_fwd / item_half_bwd / neumf_zhead")
         # "auto" = "rows" for now: on one GPU the owner's three small-K GEMMs per chunk (0.087 ms) and the lighter home head
         # (0.11 against the MFMA head's 0.15 ms) add 0.05 ms per chunk and save 9.6 MB each way -- even at ~400 GB/s per GPU, and
@@ -927,7 +928,7 @@ class ShardedNeumf(_LookAhead):
     def _prepare(self, uid, iid):
         """group the batch's ids by owner (per micro-batch chunk) and START the exchange of the split sizes"""
         W, ops = self.world, self.ops
-        M = self.micro_batches if (W > 1 and self.micro_batches > 1 and iid.shape[0] >= self.micro_batches) else 1
+        M = self.micro_batches if ((W > 1 or self.force_exchange) and self.micro_batches > 1 and iid.shape[0] >= self.micro_batches) else 1
         uc, ic = (torch.chunk(uid, M), torch.chunk(iid, M)) if M > 1 else ((uid,), (iid,))
         grouped = [(_Route.prepare(u, W, ops, self.dedup, self.n_users), _Route.prepare(i.reshape(-1), W, ops, self.dedup, self.n_items))
                    for u, i in zip(uc, ic)]
@@ -951,9 +952,10 @@ class ShardedNeumf(_LookAhead):
         mark = self._mark
         mark("start")
         self._mark_step_begin(uid)
-        if W > 1 and self.micro_batches > 1 and B >= self.micro_batches:
+        multi = W > 1 or self.force_exchange
+        if multi and self.micro_batches > 1 and B >= self.micro_batches:
             return self._step_pipelined(uid, iid, hyper, hyper0, self._routes_of(uid, iid, next_batch))
-        if W == 1:
+        if not multi:
             ru = rv = None
             urows = torch.cat([ops.gather_rows(self.P[k], uid) for k in ("mf_u", "mlp_u")], dim=1)
             irows = torch.cat([ops.gather_rows(self.P[k], iid.reshape(-1)) for k in ("mf_i", "mlp_i")], dim=1)
@@ -976,7 +978,7 @@ class ShardedNeumf(_LookAhead):
         mark("fetch_rows")
         loss_vec, gu, gi, dense = self._head(urows, irows, B, C, n_tuples, mark)
         loss = loss_vec.sum().reshape(1) / n_tuples
-        if W > 1:
+        if multi:
             loss = _all_reduce_sum(loss, self.group)
             own_u, own_i, req_u, req_i = ru.push(gu, ops), rv.push(gi, ops), ru.req, rv.req
             if self.item_half == "owner":     # (d mf_i | dz) arrived: d mlp_i and this rank's share of dW1i are formed here
