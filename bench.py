@@ -670,11 +670,13 @@ def _summary(j):
 
 SECONDARY_LEGS = (   # name, bench.py arguments, seconds of CPU baseline (None: no CPU leg -- 113 GB of tables / minutes per iteration)
     # BASELINE.json configs[3] at 10 M items, configs[2], configs[4] at the reference's batch size; then the large shapes
-    ("neumf", ["--workload", "neumf"], 22.0),
-    ("sasrec", ["--workload", "sasrec"], 12.0),
-    ("deepfm_b1024", ["--workload", "deepfm"], 2.0),
-    ("neumf_100M", ["--workload", "neumf", "--items", "100000001", "--users", "10000001"], None),    # CPU: see _borrow_cpu_baseline
-    ("deepfm_b131072", ["--workload", "deepfm", "--batch", "131072", "--steps", "10", "--warmup", "3"], 9.0),
+    # (steps / warm-up per leg: a hipGraph-replayed step of 0.2 ms is timed over 200 replays after 20 -- the first replays of a freshly
+    #  captured graph run slower, and 20 steps of 0.2 ms are 4 ms of measurement)
+    ("neumf", ["--workload", "neumf", "--steps", "40", "--warmup", "8"], 22.0),
+    ("sasrec", ["--workload", "sasrec", "--steps", "200", "--warmup", "20"], 12.0),
+    ("deepfm_b1024", ["--workload", "deepfm", "--steps", "200", "--warmup", "20"], 2.0),
+    ("neumf_100M", ["--workload", "neumf", "--items", "100000001", "--users", "10000001", "--steps", "40", "--warmup", "8"], None),    # CPU: see _borrow_cpu_baseline
+    ("deepfm_b131072", ["--workload", "deepfm", "--batch", "131072", "--steps", "20", "--warmup", "6"], 9.0),
 )
 
 
@@ -693,7 +695,7 @@ def _borrow_cpu_baseline(out):
 
 def secondary_single_gpu(args):
     """N = 1: every leg is its own process (a fault in one of them cannot take the contract line with it), one after the other
-    on the same GPU, 20 timed steps after 5 of warm-up, live roofline phases; the three legs whose CPU port finishes in seconds
+    on the same GPU, the steps / warm-up of SECONDARY_LEGS (20 after 5 unless the leg says otherwise), live roofline phases; the three legs whose CPU port finishes in seconds
     (NeuMF on the 10 M-item tables, SASRec, DeepFM at the reference's B = 1,024) carry their own `cpu_baseline` (2 timed fit()
     iterations of oracle/torch_port.py after one warm-up iteration) while the wall-clock budget (RC_BENCH_SECONDARY_BUDGET_S,
     default 85 s) has room for it; the budget keeps the driver's one command within minutes."""
