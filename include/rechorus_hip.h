@@ -72,6 +72,9 @@ int rc_device_count(void);               /* >= 0, or a negative rc_status       
 /* nn.Embedding forward, out[i,:] = W[ids[i],:]      (models/general/BPRMF.py:39-40) */
 int rc_gather_rows(const float* W, int d, const int64_t* ids, int64_t n, float* out,
                    rc_stream_t stream);
+/* the same for two tables that share the ids, rows side by side: out[i, :] = (Wa[ids[i], :] | Wb[ids[i], :]), out [n, 2 d] -- NeuMF's
+ * mf / mlp tables (models/general/NeuMF.py:39-42,61-66) as the block a row-sharded rank serves for the ids it owns; d % 4 == 0.      */
+int rc_gather_rows_pair(const float* Wa, const float* Wb, int d, const int64_t* ids, int64_t n, float* out, rc_stream_t stream);
 
 /* BPRMF scores, pred[b,c] = <U[uid[b]], I[iid[b,c]]>  (models/general/BPRMF.py:39-42).
  * Any C >= 1 (eval uses C = 100 or C = n_items-1 with --test_all).                  */

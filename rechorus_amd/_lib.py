@@ -72,6 +72,7 @@ SIGNATURES = {
     "rc_last_error_string": (C.c_char_p, []),
     "rc_device_count": (_i, []),
     "rc_gather_rows": (_i, [_p, _i, _p, _i64, _p, _p]),
+    "rc_gather_rows_pair": (_i, [_p, _p, _i, _p, _i64, _p, _p]),
     "rc_gather_dot_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _p]),
     "rc_weighted_row_sum": (_i, [_p, _p, _p, _i, _i, _i, _p, _p]),
     "rc_bpr_loss_fwd_bwd": (_i, [_p, _i, _i, _f, _p, _p, _p]),

@@ -21,6 +21,18 @@ __global__ __launch_bounds__(kBlock) void gather_rows_vec4_kernel(
   }
 }
 
+// two tables that share the ids, rows side by side: out[i, :] = (Wa[ids[i], :] | Wb[ids[i], :]) -- the block a sharded NeuMF rank
+// serves for the ids it owns (mf | mlp), written once instead of two gathers and a concatenation
+__global__ __launch_bounds__(kBlock) void gather_rows_pair_vec4_kernel(const float4* __restrict__ Wa, const float4* __restrict__ Wb, int dq,
+                                                                      const int64_t* __restrict__ ids, int64_t n, float4* __restrict__ out) {
+  const int64_t total = n * 2 * dq;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+    const int64_t r = i / (2 * dq);
+    const int q = (int)(i - r * 2 * dq);
+    out[i] = q < dq ? Wa[ids[r] * dq + q] : Wb[ids[r] * dq + (q - dq)];
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void gather_rows_scalar_kernel(
     const float* __restrict__ W, int d, const int64_t* __restrict__ ids, int64_t n,
     float* __restrict__ out) {
@@ -170,6 +182,21 @@ extern "C" int rc_gather_rows(const float* W, int d, const int64_t* ids, int64_t
     hipLaunchKernelGGL(gather_rows_scalar_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, s,
                        W, d, ids, n, out);
   }
+  RC_LAUNCH_CHECK();
+  return RC_OK;
+}
+
+extern "C" int rc_gather_rows_pair(const float* Wa, const float* Wb, int d, const int64_t* ids, int64_t n, float* out, rc_stream_t stream) {
+  if (n == 0) return RC_OK;
+  RC_REQUIRE(Wa && Wb && ids && out, "rc_gather_rows_pair: null pointer");
+  RC_REQUIRE(d >= 4 && d % 4 == 0 && n > 0, "rc_gather_rows_pair: bad shape d=%d (a multiple of 4) n=%lld", d, (long long)n);
+  RC_REQUIRE(reinterpret_cast<uintptr_t>(Wa) % 16 == 0 && reinterpret_cast<uintptr_t>(Wb) % 16 == 0 && reinterpret_cast<uintptr_t>(out) % 16 == 0,
+             "rc_gather_rows_pair: tables and output must be 16-byte aligned");
+  const int64_t total = n * (d / 2);
+  int64_t blocks = (total + kBlock - 1) / kBlock;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  hipLaunchKernelGGL(gather_rows_pair_vec4_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, as_stream(stream), reinterpret_cast<const float4*>(Wa),
+                     reinterpret_cast<const float4*>(Wb), d / 4, ids, n, reinterpret_cast<float4*>(out));
   RC_LAUNCH_CHECK();
   return RC_OK;
 }

@@ -75,6 +75,18 @@ def gather_rows(W, ids):
     return out.view(*ids.shape, d)
 
 
+def gather_rows_pair(Wa, Wb, ids):
+    """(Wa[ids] | Wb[ids]) as one [n, 2 d] block (rc_gather_rows_pair): two tables that share the ids"""
+    ids_flat = ids.reshape(-1)
+    d = Wa.shape[1]
+    if Wb.shape[1] != d or d % 4:
+        raise ValueError("gather_rows_pair: two tables of the same width, a multiple of 4")
+    out = torch.empty((ids_flat.numel(), 2 * d), dtype=torch.float32, device=Wa.device)
+    _lib.call("rc_gather_rows_pair", _ptr(Wa, torch.float32, "Wa"), _ptr(Wb, torch.float32, "Wb"), d, _ptr(ids_flat, torch.int64, "ids"),
+              ids_flat.numel(), _ptr(out, torch.float32, "out"), _stream())
+    return out
+
+
 def gather_dot(U, I, uid, iid):
     """pred[b,c] = <U[uid[b]], I[iid[b,c]]> (reference: models/general/BPRMF.py:39-42)."""
     B, Cn = iid.shape

@@ -69,6 +69,12 @@ class HipOps:
         from . import engine
         self.e = engine
 
+    def gather_rows_pair(self, Wa, Wb, rows):
+        """(Wa[rows] | Wb[rows]) as one block: two tables that share the row ids (rc_gather_rows_pair)"""
+        if rows.numel() == 0:
+            return torch.empty((0, 2 * Wa.shape[1]), dtype=torch.float32, device=Wa.device)
+        return self.e.gather_rows_pair(Wa, Wb, rows.contiguous())
+
     def gather_rows(self, W, rows):
         return self.e.gather_rows(W, rows)
 
@@ -776,7 +782,8 @@ class _Route:
     def __init__(self, ids, world, ops, group, grouped=None, splits=None, dedup=True, prepared=None, n_rows=None):
         if prepared is None:
             prepared = self.prepare(ids, world, ops, dedup, n_rows) if grouped is None else (grouped, None, ids.numel())
-        (order, counts, local), self.inverse, self.n_lookup = prepared
+        (order, counts, local), self.inverse, self.n_lookup = prepared[:3]
+        self.back_index = prepared[3] if len(prepared) > 3 else None    # lookup position -> row of the block that comes back
         if splits is None:
             (self.send,), (self.recv,) = _exchange_counts([counts], group)
         else:  # split sizes exchanged by the caller together with those of other lookups (one host sync for all)
@@ -796,7 +803,16 @@ class _Route:
         inverse = None
         if dedup:
             ids, inverse = ops_unique(ops, ids, n_rows)
-        return _Route.group_by_owner(ids, world, ops), inverse, n
+        grouped = _Route.group_by_owner(ids, world, ops)
+        # The rows come back in SEND order (row k answers the k-th id sent, id number order[k]) and are wanted in lookup order:
+        # lookup position j reads row inv_order[inverse[j]].  The composed index is formed here, with the route (off the critical
+        # path under look-ahead), so that a fetched block is expanded by ONE gather and the gradient rows are summed straight into
+        # send order -- instead of a row-wide index_put into send-independent order plus a gather each way.
+        order = grouped[0].long()
+        inv_order = torch.empty_like(order)
+        inv_order[order] = torch.arange(order.numel(), device=order.device, dtype=torch.int64)
+        back_index = inv_order if inverse is None else inv_order[inverse.long()]
+        return grouped, inverse, n, back_index
 
     @staticmethod
     def group_by_owner(ids, world, ops):
@@ -804,19 +820,28 @@ class _Route:
         return ops.route(ids, world, None, 1)
 
     def _expand(self, back, ops):
+        if self.back_index is not None:
+            return ops.gather_rows(back, self.back_index)
         out = torch.empty_like(back)
         out[self.order] = back
         return out if self.inverse is None else ops.gather_rows(out, self.inverse)
 
     def _reduce(self, grads, ops):
+        if self.back_index is not None and self.inverse is not None:
+            return ops.sum_rows_by_index(grads, self.back_index, self.n_sent)     # per-id sums, already in send order
         if self.inverse is not None:
             grads = ops.sum_rows_by_index(grads, self.inverse, self.n_sent)
         return grads[self.order]
 
+    def _serve(self, tables, ops):
+        """the rows of `tables` (same row space) this rank owes the others, side by side"""
+        if len(tables) == 2 and hasattr(ops, "gather_rows_pair") and tables[0].shape[1] == tables[1].shape[1] and tables[0].shape[1] % 4 == 0:
+            return ops.gather_rows_pair(tables[0], tables[1], self.req)
+        return torch.cat([ops.gather_rows(T, self.req) for T in tables], dim=1)
+
     def fetch_async(self, tables, ops):
         """fetch() whose rows-back transfer may stay in flight: -> _Pending; finish with rows_in_lookup_order()"""
-        served = torch.cat([ops.gather_rows(T, self.req) for T in tables], dim=1)
-        return _exchange_async(served, self.recv, self.send, self.group)
+        return _exchange_async(self._serve(tables, ops), self.recv, self.send, self.group)
 
     def rows_in_lookup_order(self, back, ops):
         return self._expand(back, ops)
@@ -834,8 +859,7 @@ class _Route:
 
     def fetch(self, tables, ops):
         """rows of `tables` (this rank's shards, same row space) for the ids of the lookup, in lookup order"""
-        served = torch.cat([ops.gather_rows(T, self.req) for T in tables], dim=1)
-        return self._expand(_exchange_back(served, self.recv, self.send, self.group), ops)
+        return self._expand(_exchange_back(self._serve(tables, ops), self.recv, self.send, self.group), ops)
 
     def push(self, grads, ops):
         """per-lookup-position gradient rows -> the owners, aligned with self.req (one row per id sent)"""
