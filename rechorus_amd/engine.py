@@ -1913,9 +1913,11 @@ class SasrecTrainer:
                 finish_bwd()               # the encoder's parameter gradients ...
                 Gp = sasrec_pos_grad(g_hist, lengths, Pe.shape[0])     # ... the position table's, and the dense step of both
                 self._dense_step(Gp, dgrads, h, h0, step_dev)
+            # the batch mean of the losses last on this stream: it ends ~20 us before the item-table stream does, and 5 us in front of
+            # the table update were 5 us of the step
+            self.loss = reduce_sum(loss_vec, 1.0 / B)
         with torch.cuda.stream(tab):
             tab.wait_event(ready)
-            self.loss = reduce_sum(loss_vec, 1.0 / B)
             with _PhaseTimer(self, "table_update"):
                 self._item_table_update(box["ids"], rows_plan, hv, gpred, g_hist, h, step_dev, B, Cn)
         cur.wait_stream(other)             # the step's one join
