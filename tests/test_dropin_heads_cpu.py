@@ -3,7 +3,7 @@
     (/root/reference/src/models -- build container only; nothing of them is kept in this repository);
   * the structural recogniser names the heads of model files written by a user (tests/user_models/: plain torch layers over the
     plugin's task bases, this repository's own code) and rejects near misses.
-Binding itself needs the GPU (tests/test_gpu_reference_heads.py)."""
+Binding itself needs the GPU (tests/test_gpu_model_file_heads.py)."""
 import argparse
 import difflib
 import os
