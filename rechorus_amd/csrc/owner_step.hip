@@ -69,12 +69,20 @@ __global__ __launch_bounds__(kBlock) void route_hist_kernel(const int64_t* __res
 __global__ __launch_bounds__(kBlock) void route_scan_kernel(uint32_t* __restrict__ hist, int world, int n_tiles,
                                                             int64_t* __restrict__ counts) {
   __shared__ uint32_t s_part[kBlock];
-  if ((int)threadIdx.x < world) {
-    int64_t c = 0;
-    for (int i = 0; i < n_tiles; ++i) c += hist[(size_t)threadIdx.x * n_tiles + i];
-    counts[threadIdx.x] = c;
+  // counts[w]: integer sums, order-free -- the whole workgroup per owner (one thread per owner walking all tiles one dependent load
+  // after the other took 51 us for the 1,600 tiles of a 6.5 M-id batch)
+  for (int w = 0; w < world; ++w) {
+    uint32_t c = 0;
+    for (int i = threadIdx.x; i < n_tiles; i += kBlock) c += hist[(size_t)w * n_tiles + i];
+    s_part[threadIdx.x] = c;
+    __syncthreads();
+    for (int off = kBlock / 2; off >= 1; off >>= 1) {
+      if ((int)threadIdx.x < off) s_part[threadIdx.x] += s_part[threadIdx.x + off];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) counts[w] = (int64_t)s_part[0];
+    __syncthreads();
   }
-  __syncthreads();
   const int64_t total = (int64_t)world * n_tiles;
   const int64_t per = (total + kBlock - 1) / kBlock;
   const int64_t lo = (int64_t)threadIdx.x * per < total ? (int64_t)threadIdx.x * per : total;
