@@ -230,6 +230,12 @@ __global__ __launch_bounds__(kPlanThreads) void plan_count_kernel(PlanArgs a) {
   extern __shared__ uint32_t s_hist[];  // [nb]
   const uint32_t nb = a.g.nb;
   if (blockIdx.x == 0 && threadIdx.x < PC_N) a.w.counters[threadIdx.x] = 0;
+  // the row counts the back kernels add to (rc_bucket_plan hands them in from outside the workspace): zeroed here, by the plan's first
+  // kernel, not by two memset launches in front of it
+  if (blockIdx.x == 0 && threadIdx.x == PC_N) {
+    if (a.n_rows_a) *a.n_rows_a = 0;
+    if (a.n_rows_b) *a.n_rows_b = 0;
+  }
   const uint32_t tile = plan_tile_of_block(blockIdx.x, a.g.tiles);
   if (tile == a.g.tiles) return;
   for (uint32_t i = threadIdx.x; i < nb; i += kPlanThreads) s_hist[i] = 0;
@@ -1098,9 +1104,11 @@ extern "C" int rc_bucket_plan(const int64_t* ids_a, int64_t n_a, int64_t range_a
                               size_t ws_bytes, rc_stream_t stream) {
   RC_REQUIRE(n_a >= 0 && n_b >= 0 && n_a + n_b < ((int64_t)1 << 31), "rc_bucket_plan: sizes out of range");
   hipStream_t s = as_stream(stream);
-  if (n_rows_a) RC_HIP(hipMemsetAsync(n_rows_a, 0, sizeof(uint32_t), s));
-  if (n_rows_b) RC_HIP(hipMemsetAsync(n_rows_b, 0, sizeof(uint32_t), s));
-  if (n_a + n_b == 0) return RC_OK;
+  if (n_a + n_b == 0) {     // (a plan of something zeroes the counts in its first kernel)
+    if (n_rows_a) RC_HIP(hipMemsetAsync(n_rows_a, 0, sizeof(uint32_t), s));
+    if (n_rows_b) RC_HIP(hipMemsetAsync(n_rows_b, 0, sizeof(uint32_t), s));
+    return RC_OK;
+  }
   RC_REQUIRE((n_a == 0 || (ids_a && rows_a && n_rows_a)) && (n_b == 0 || (ids_b && rows_b && n_rows_b)) && occ && ws,
              "rc_bucket_plan: null pointer");
   RC_REQUIRE(list_single_a || single_a || n_a == 0, "rc_bucket_plan: single_a is needed when single-occurrence rows are not listed");
