@@ -471,9 +471,16 @@ class _LookAhead(_Timed):
             # routed on the caller's stream (first step, or no look-ahead): the side stream's routing of the next batch
             # shares the engine's cached scratch buffers with it and must start after it
             self._mark_step_begin(uid)
-        if next_batch is not None and self.world > 1:
-            self._ahead = self._prepare_ahead(*next_batch)
+        # the NEXT batch is routed when this step's own launches are enqueued (_look_ahead, called at the end of step()): the host
+        # side of the routing -- a millisecond of Python and small launches at the config-4 shape -- then runs while the GPU works on
+        # this step, instead of in front of its first kernel
+        self._next_batch = next_batch if (next_batch is not None and (self.world > 1 or getattr(self, "force_exchange", False))) else None
         return prep
+
+    def _look_ahead(self):
+        nb, self._next_batch = getattr(self, "_next_batch", None), None
+        if nb is not None:
+            self._ahead = self._prepare_ahead(*nb)
 
     def _prepare_ahead(self, uid, iid):
         if not uid.is_cuda:
@@ -678,6 +685,7 @@ class ShardedBprmf(_LookAhead):
         ug_own, _ = _exchange(ugrad[order_u], cnt_u, self.group, recv_counts=rcnt_u)
         ops.update_rows(self.U, self.sU, req_u, ug_own, hyper)
         mark("7 user grads reduce + update")
+        self._look_ahead()
         return loss
 
     def _plan(self, C):
@@ -741,6 +749,7 @@ class ShardedBprmf(_LookAhead):
         ops.update_rows(self.I, self.sI, req_i, own_i, hyper)
         ops.update_rows(self.U, self.sU, req_u, own_u, hyper)
         mark("4 owner updates")
+        self._look_ahead()
         return loss
 
     def _route(self, ids, tuple_base=None, div=1):
@@ -1034,6 +1043,7 @@ class ShardedNeumf(_LookAhead):
         for k in ("W1", "b1", "w_out"):
             ops.dense_update(self.P[k], dense[k].contiguous(), hyper0 if k == "b1" else hyper, self.state[k])
         mark("dense_update")
+        self._look_ahead()
         return loss
 
     def _head(self, urows, irows, B, C, n_tuples, mark):
@@ -1109,8 +1119,8 @@ class ShardedNeumf(_LookAhead):
                 mlp_reqs.append(mlp_req)
                 served_i = torch.cat([ops.gather_rows(self.P["mf_i"], rv.req), ops.item_half_fwd(mlp_req, W1i)], dim=1)
             else:
-                served_i = torch.cat([ops.gather_rows(T, rv.req) for T in (self.P["mf_i"], self.P["mlp_i"])], dim=1)
-            served_u = torch.cat([ops.gather_rows(T, ru.req) for T in (self.P["mf_u"], self.P["mlp_u"])], dim=1)
+                served_i = rv._serve([self.P["mf_i"], self.P["mlp_i"]], ops)     # (mf | mlp) blocks from one kernel where the ops have it
+            served_u = ru._serve([self.P["mf_u"], self.P["mlp_u"]], ops)
             mark("serve_rows")    # (owner side, local: row gathers, and the item half of the hidden layer where the owners compute it)
             routes.append((ru, rv, ru.fetch_block_async(served_u), rv.fetch_block_async(served_i)))
 
@@ -1164,6 +1174,7 @@ class ShardedNeumf(_LookAhead):
                              self.state[n])
             o += cnt
         mark("dense_update")
+        self._look_ahead()
         return loss
 
 

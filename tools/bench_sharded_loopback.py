@@ -24,11 +24,11 @@ def main(B=65536, K=99, d=64, n_items=10_000_001, n_users=1_000_001, steps=10, m
                 torch.randint(1, n_items, (B, 1 + K), device=dev, generator=g)) for _ in range(4)]
     m = ShardedBprmf(n_users, n_items, d, opt="SGD", lr=0.01, device=dev, force_exchange=True, timing=True, mode=mode)
     for w in range(3):
-        m.step(*batches[w % 4])
+        m.step(*batches[w % 4], next_batch=batches[(w + 1) % 4])
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(steps):
-        m.step(*batches[k % 4])
+        m.step(*batches[(k + 3) % 4], next_batch=batches[(k + 4) % 4])     # (every step announces the following batch: look-ahead routing)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / steps * 1e3
     print(json.dumps({"mode": mode, "K": K, "loopback_ms_per_step": ms, "phases_ms": {k: round(v, 3) for k, v in m.timing_ms().items()}}))
