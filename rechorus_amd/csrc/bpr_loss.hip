@@ -97,7 +97,7 @@ __global__ __launch_bounds__(kBlock) void reduce_sum_kernel(const float* __restr
                                                             int64_t n, float scale,
                                                             float* __restrict__ out) {
   __shared__ float sm[kBlock];
-  const float acc = fixed_order_partial<kBlock>(x, n, (int)threadIdx.x);
+  const float acc = fixed_order_partial<kBlock, true>(x, n, (int)threadIdx.x);
   sm[threadIdx.x] = acc;
   __syncthreads();
   for (int off = kBlock / 2; off >= 1; off >>= 1) {

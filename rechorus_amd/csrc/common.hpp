@@ -93,26 +93,36 @@ __device__ __forceinline__ float dpp_mov(float x) {
 // This thread's share of a fixed-order sum over x[0, n) by a workgroup of NT threads: elements t, t + NT, ... as float4 chunks
 // ((v.x + v.y) + (v.z + v.w) per chunk, chunks in ascending order; a tail of single floats behind them) -- the order every loss
 // mean of the library uses (reduce_sum_kernel, plan_final_kernel, small_update_kernel), so the step's loss is bit-identical across
-// pipelines.  Up to 32 chunks are REQUESTED together before the first is added (the adds stay in order): a batch of 65,536 losses
-// is two memory latencies per thread instead of eight (27 us -> 8 us for the one workgroup that forms the mean).
-template <int NT>
+// pipelines.  STAGED: up to 32 chunks are REQUESTED together before the first is added (the adds stay in order): a batch of 65,536
+// losses is two memory latencies per thread instead of eight -- 27 -> 8 us for a kernel that is nothing but this sum
+// (reduce_sum_kernel).  Not for kernels that do other work beside it: the staging's registers cost the small-batch step's update
+// kernel 1.8 us of 13 (same-box A/B), and plan_final_kernel's duration is set by its row workgroups, not by this one.
+template <int NT, bool STAGED>
 __device__ __forceinline__ float fixed_order_partial(const float* __restrict__ x, int64_t n, int tid) {
   float acc = 0.f;
   int64_t done = 0;
   if (reinterpret_cast<uintptr_t>(x) % 16 == 0) {
     const int64_t n4 = n / 4;
     const float4* x4 = reinterpret_cast<const float4*>(x);
-    constexpr int Q = 32;
-    for (int64_t i0 = tid; i0 < n4; i0 += (int64_t)Q * NT) {
-      float4 v[Q];
-#pragma unroll
-      for (int q = 0; q < Q; ++q) {
-        const int64_t i = i0 + (int64_t)q * NT;
-        v[q] = x4[i < n4 ? i : i0];      // (no branch between the requests; an unused slot re-reads the first chunk)
+    if (!STAGED || n4 <= (int64_t)4 * NT) {      // (workgroup-uniform)
+#pragma unroll 8
+      for (int64_t i = tid; i < n4; i += NT) {
+        const float4 v = x4[i];
+        acc += (v.x + v.y) + (v.z + v.w);
       }
+    } else {
+      constexpr int Q = 32;
+      for (int64_t i0 = tid; i0 < n4; i0 += (int64_t)Q * NT) {
+        float4 v[Q];
 #pragma unroll
-      for (int q = 0; q < Q; ++q)
-        if (i0 + (int64_t)q * NT < n4) acc += (v[q].x + v[q].y) + (v[q].z + v[q].w);
+        for (int q = 0; q < Q; ++q) {
+          const int64_t i = i0 + (int64_t)q * NT;
+          v[q] = x4[i < n4 ? i : i0];      // (no branch between the requests; an unused slot re-reads the first chunk)
+        }
+#pragma unroll
+        for (int q = 0; q < Q; ++q)
+          if (i0 + (int64_t)q * NT < n4) acc += (v[q].x + v[q].y) + (v[q].z + v[q].w);
+      }
     }
     done = n4 * 4;
   }

@@ -439,7 +439,7 @@ __global__ __launch_bounds__(kBlock) void plan_final_kernel(PlanUpdArgs a, uint3
   // loss mean: thread t sums elements t, t+256, ... then a fixed LDS tree (same order as reduce_sum_kernel)
   if (a.loss_out == nullptr) return;
   float* sm = reinterpret_cast<float*>(part);
-  const float acc = fixed_order_partial<kBlock>(a.loss_vec, a.loss_n, (int)threadIdx.x);
+  const float acc = fixed_order_partial<kBlock, false>(a.loss_vec, a.loss_n, (int)threadIdx.x);
   sm[threadIdx.x] = acc;
   __syncthreads();
   for (int off = kBlock / 2; off >= 1; off >>= 1) {

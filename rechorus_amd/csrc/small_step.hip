@@ -75,7 +75,7 @@ __global__ __launch_bounds__(kBlock) void small_update_kernel(SmallUpdArgs a) {
   if (blockIdx.x == gridDim.x - 1) {  // the loss mean: fixed order (thread t sums t, t + 256, ...; LDS tree)
     if (a.loss_out == nullptr) return;
     // same order as plan_final_kernel / reduce_sum_kernel: the step's loss is bit-identical across pipelines
-    const float acc = fixed_order_partial<kBlock>(a.loss_vec, (int64_t)a.B, tid);
+    const float acc = fixed_order_partial<kBlock, false>(a.loss_vec, (int64_t)a.B, tid);
     red[tid] = acc;
     __syncthreads();
     for (int off = kBlock / 2; off >= 1; off >>= 1) {
