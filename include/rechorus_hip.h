@@ -943,6 +943,13 @@ int rc_plan_update_pair_zeroed(float* W_a, float* m_a, float* v_a, float* W_b, f
                                const rc_plan_row* rows, const uint32_t* n_rows, const uint32_t* occ, int64_t n_occ,
                                const float* src_a, const float* src_b, int64_t occ_base, const rc_opt_hyper* h,
                                uint32_t* counters, void* ws, size_t ws_bytes, rc_stream_t stream);
+/* rc_plan_update_pair with both gradient sources in ONE block: occurrence o reads src_block[o - occ_base, 0 .. d) for table a and
+ * [d .. 2 d) for table b, rows src_ld floats apart (a multiple of 4, >= 2 d) -- the (d mf | d mlp) rows of models/general/NeuMF.py:39-42's
+ * two table families as a row-sharded rank receives them, used where they lie.  counters: as rc_plan_update_pair_zeroed, or NULL.  */
+int rc_plan_update_pair_block(float* W_a, float* m_a, float* v_a, float* W_b, float* m_b, float* v_b, int d,
+                              const rc_plan_row* rows, const uint32_t* n_rows, const uint32_t* occ, int64_t n_occ,
+                              const float* src_block, int64_t src_ld, int64_t occ_base, const rc_opt_hyper* h,
+                              uint32_t* counters, void* ws, size_t ws_bytes, rc_stream_t stream);
 
 /* The same walk without an optimizer: out[row, :] = the summed gradient row of every LISTED row (other rows of `out` are
  * left as they are) -- aten::embedding_dense_backward's index_add (helpers/BaseRunner.py:205) as a plan consumer, and the

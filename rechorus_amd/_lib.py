@@ -209,6 +209,7 @@ SIGNATURES = {
     "rc_plan_update": (_i, [_p, _p, _p, _i, _p, _p, _p, _i64, _p, _p, _p, _i, _p, _i64, _hp, _p, _sz, _p]),
     "rc_plan_update_pair": (_i, [_p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _i64, _p, _p, _i64, _hp, _p, _sz, _p]),
     "rc_plan_update_pair_zeroed": (_i, [_p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _i64, _p, _p, _i64, _hp, _p, _p, _sz, _p]),
+    "rc_plan_update_pair_block": (_i, [_p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _i64, _p, _i64, _i64, _hp, _p, _p, _sz, _p]),
     "rc_plan_row_sums": (_i, [_p, _i, _p, _p, _p, _i64, _p, _p, _p, _i, _p, _i64, _p, _sz, _p]),
     "rc_plan_distinct": (_i, [_p, _p, _p, _i64, _i64, _p, _p, _p]),
     "rc_bprmf_step_workspace_bytes": (_sz, [_i, _i, _i]),

@@ -119,6 +119,8 @@ struct PlanGrad {
   // width D is [table a | table b]; lanes of the lower half read src2 / update table a, the upper half src2b / table b
   const float* src2b;
   int pair;
+  uint32_t pair_ld4;   // pair mode: row stride of src2 / src2b in float4 units (0: D / 8, two contiguous [n, D / 2] arrays) -- both
+                       // halves of one [n, ld] block, e.g. the (d mf | d mlp) gradient rows a sharded NeuMF rank receives
 };
 
 

@@ -63,7 +63,8 @@ __device__ __forceinline__ float4 plan_grad4(const PlanGrad& s, const uint32_t* 
   if (s.pair) {  // kernel-uniform
     constexpr int H = LPR / 2;
     const bool up = l >= H;
-    return reinterpret_cast<const float4*>(up ? s.src2b : s.src2)[(size_t)(o - s.n_split) * H + (up ? l - H : l)];
+    const size_t ldq = s.pair_ld4 ? (size_t)s.pair_ld4 : (size_t)H;
+    return reinterpret_cast<const float4*>(up ? s.src2b : s.src2)[(size_t)(o - s.n_split) * ldq + (up ? l - H : l)];
   }
   if (o >= s.n_split) return reinterpret_cast<const float4*>(s.src2)[(size_t)(o - s.n_split) * LPR + l];
   int64_t sr = (s.div == 1) ? (int64_t)o : (int64_t)(o / (uint32_t)s.div);
@@ -630,7 +631,7 @@ extern "C" int rc_plan_update(float* W, float* m, float* v, int d, const rc_plan
   return run_side_update(a, h, d, n_occ, ws, ws_bytes, stream, "rc_plan_update");
 }
 
-static int plan_update_pair_impl(uint32_t* zeroed_counters, float* W_a, float* m_a, float* v_a, float* W_b, float* m_b, float* v_b, int d,
+static int plan_update_pair_impl(uint32_t* zeroed_counters, int64_t src_ld, float* W_a, float* m_a, float* v_a, float* W_b, float* m_b, float* v_b, int d,
                                    const rc_plan_row* rows, const uint32_t* n_rows, const uint32_t* occ, int64_t n_occ,
                                    const float* src_a, const float* src_b, int64_t occ_base, const rc_opt_hyper* h,
                                    void* ws, size_t ws_bytes, rc_stream_t stream) {
@@ -648,7 +649,7 @@ static int plan_update_pair_impl(uint32_t* zeroed_counters, float* W_a, float* m
   memset(&a, 0, sizeof(a));
   a.side[0].t = PlanTable{W_a, m_a, v_a};
   a.side[0].tb = PlanTable{W_b, m_b, v_b};
-  a.side[0].g = PlanGrad{nullptr, nullptr, nullptr, 1, src_a, (uint32_t)occ_base, src_b, 1};
+  a.side[0].g = PlanGrad{nullptr, nullptr, nullptr, 1, src_a, (uint32_t)occ_base, src_b, 1, (uint32_t)(src_ld / 4)};
   a.side[0].rows = rows;
   a.side[0].n_rows = n_rows;
   a.occ = occ;
@@ -659,7 +660,21 @@ extern "C" int rc_plan_update_pair(float* W_a, float* m_a, float* v_a, float* W_
                                    const rc_plan_row* rows, const uint32_t* n_rows, const uint32_t* occ, int64_t n_occ,
                                    const float* src_a, const float* src_b, int64_t occ_base, const rc_opt_hyper* h,
                                    void* ws, size_t ws_bytes, rc_stream_t stream) {
-  return plan_update_pair_impl(nullptr, W_a, m_a, v_a, W_b, m_b, v_b, d, rows, n_rows, occ, n_occ, src_a, src_b, occ_base, h, ws, ws_bytes, stream);
+  return plan_update_pair_impl(nullptr, 0, W_a, m_a, v_a, W_b, m_b, v_b, d, rows, n_rows, occ, n_occ, src_a, src_b, occ_base, h, ws, ws_bytes, stream);
+}
+
+/* rc_plan_update_pair with both gradient sources in ONE block: occurrence o reads src_block[o - occ_base, 0 .. d) for table a and
+ * [d .. 2 d) for table b, rows src_ld floats apart (a multiple of 4, >= 2 d) -- the (d mf | d mlp) rows a row-sharded NeuMF rank
+ * receives from the others, used where they lie instead of through two contiguous copies.  counters: as rc_plan_update_pair_zeroed,
+ * or NULL (the call zeroes its own). */
+extern "C" int rc_plan_update_pair_block(float* W_a, float* m_a, float* v_a, float* W_b, float* m_b, float* v_b, int d,
+                                         const rc_plan_row* rows, const uint32_t* n_rows, const uint32_t* occ, int64_t n_occ,
+                                         const float* src_block, int64_t src_ld, int64_t occ_base, const rc_opt_hyper* h,
+                                         uint32_t* counters, void* ws, size_t ws_bytes, rc_stream_t stream) {
+  RC_REQUIRE(src_block != nullptr && src_ld >= 2 * (int64_t)d && src_ld % 4 == 0 && src_ld / 4 < ((int64_t)1 << 32),
+             "rc_plan_update_pair_block: src_ld = %lld floats (a multiple of 4, at least 2 d)", (long long)src_ld);
+  return plan_update_pair_impl(counters, src_ld, W_a, m_a, v_a, W_b, m_b, v_b, d, rows, n_rows, occ, n_occ, src_block, src_block + d, occ_base, h, ws,
+                               ws_bytes, stream);
 }
 
 /* rc_plan_update_pair with the update's eight ticket counters supplied by the caller, ZERO-FILLED where that cost nothing (with the
@@ -670,7 +685,7 @@ extern "C" int rc_plan_update_pair_zeroed(float* W_a, float* m_a, float* v_a, fl
                                           const float* src_a, const float* src_b, int64_t occ_base, const rc_opt_hyper* h,
                                           uint32_t* counters, void* ws, size_t ws_bytes, rc_stream_t stream) {
   RC_REQUIRE(counters != nullptr, "rc_plan_update_pair_zeroed: null pointer");
-  return plan_update_pair_impl(counters, W_a, m_a, v_a, W_b, m_b, v_b, d, rows, n_rows, occ, n_occ, src_a, src_b, occ_base, h, ws, ws_bytes, stream);
+  return plan_update_pair_impl(counters, 0, W_a, m_a, v_a, W_b, m_b, v_b, d, rows, n_rows, occ, n_occ, src_a, src_b, occ_base, h, ws, ws_bytes, stream);
 }
 
 /* out[row, :] = sum over the row's occurrences of their gradient rows, for the rows the plan lists (other rows of `out`

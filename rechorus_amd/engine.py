@@ -299,8 +299,27 @@ class Plan:
 
     def update_pair(self, side, Wa, Wb, src_a, src_b, hyper, ma=None, va=None, mb=None, vb=None, ws_tag=""):
         """rc_plan_update_pair on list `side` ('a' | 'b'): two tables sharing the ids, per-occurrence gradient rows.
-        ws_tag: suffix of the scratch buffer's cache key -- two updates that run at the same time on two streams need two"""
+        ws_tag: suffix of the scratch buffer's cache key -- two updates that run at the same time on two streams need two.
+        src_b=None: src_a is ONE block [n, >= 2 d] whose rows hold (gradient of table a | gradient of table b) side by side
+        (rc_plan_update_pair_block: the block is read where it lies, no contiguous halves)"""
         d = Wa.shape[1]
+        if src_b is None:
+            if src_a.dim() != 2 or src_a.stride(1) != 1 or src_a.shape[1] < 2 * d or src_a.stride(0) % 4:
+                raise ValueError("update_pair: a block source is [n, >= 2 d] with unit column stride and a row stride that is a multiple of 4")
+            n = self.n_a + self.n_b
+            rows, cnt, base = self._side(side)
+            ws = workspace(_lib.load().rc_plan_update_workspace_bytes(n, 2 * d), Wa.device, self.tag + ".upd" + ws_tag)
+            f32 = torch.float32
+            p = lambda t: C.c_void_p(t.data_ptr())
+            zc = getattr(self, "upd_counters", None)
+            c = zc.pop(side) if (zc is not None and side in zc) else None
+            if c is not None:
+                c.record_stream(torch.cuda.current_stream(c.device))
+            _lib.call("rc_plan_update_pair_block", _ptr(Wa, f32, "W_a"), _ptr(ma, f32, "m_a", True), _ptr(va, f32, "v_a", True),
+                      _ptr(Wb, f32, "W_b"), _ptr(mb, f32, "m_b", True), _ptr(vb, f32, "v_b", True), d, p(rows), p(cnt), p(self.occ), n,
+                      C.c_void_p(src_a.data_ptr()), int(src_a.stride(0)), base, C.byref(hyper), p(c) if c is not None else None,
+                      p(ws), ws.numel(), _stream())
+            return
         n = self.n_a + self.n_b
         rows, cnt, base = self._side(side)
         ws = workspace(_lib.load().rc_plan_update_workspace_bytes(n, 2 * d), Wa.device, self.tag + ".upd" + ws_tag)

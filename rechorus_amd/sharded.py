@@ -130,13 +130,16 @@ class HipOps:
             plan.update("a", W, hyper, m=state.get("m"), v=state.get("v"), coef=coef, src=src, src_index=src_index, div=1)
 
     def update_rows_pair(self, Wa, Wb, sa, sb, rows, src_a, src_b, hyper, prep):
-        """two tables that share `rows` (NeuMF's mf / mlp embeddings) in one pass; False if the width has no pair kernel"""
+        """two tables that share `rows` (NeuMF's mf / mlp embeddings) in one pass; False if the width has no pair kernel.
+        src_b=None: src_a is the [n, 2 d] block of both gradients side by side, read where it lies"""
         if rows.numel() == 0:
             return True
         if not self.e.segmented_pair_supported(Wa.shape[1]) or isinstance(prep, _SortPlan):
             return False
         prep.update_pair("a", Wa, Wb, src_a, src_b, hyper, ma=sa.get("m"), va=sa.get("v"), mb=sb.get("m"), vb=sb.get("v"))
         return True
+
+    pair_block_updates = True     # update_rows_pair takes the (d a | d b) block itself
 
     # ---- csrc/owner_step.hip
     def route(self, ids, world, tuple_base=None, div=1):
@@ -1032,6 +1035,9 @@ class ShardedNeumf(_LookAhead):
         prep_u = ops.prepare_rows(req_u, self.P["mf_u"].shape[0], tag="rows.u") if shared else None
         prep_i = ops.prepare_rows(req_i, self.P["mf_i"].shape[0], tag="rows.i") if shared else None
         for ta, tb, own, req, prep in (("mf_u", "mlp_u", own_u, req_u, prep_u), ("mf_i", "mlp_i", own_i, req_i, prep_i)):
+            if (shared and getattr(ops, "pair_block_updates", False) and own.shape[1] == 2 * d and own.is_contiguous() and not isinstance(prep, _SortPlan)
+                    and ops.update_rows_pair(self.P[ta], self.P[tb], self.state[ta], self.state[tb], req, own, None, hyper, prep)):
+                continue      # (the received (d mf | d mlp) block read where it lies: no contiguous halves)
             ga, gb = own[:, :d].contiguous(), own[:, d:].contiguous()
             if shared and hasattr(ops, "update_rows_pair") and ops.update_rows_pair(
                     self.P[ta], self.P[tb], self.state[ta], self.state[tb], req, ga, gb, hyper, prep):
@@ -1159,6 +1165,9 @@ class ShardedNeumf(_LookAhead):
         prep_u = ops.prepare_rows(req_u, self.P["mf_u"].shape[0], tag="rows.u") if shared else None
         prep_i = ops.prepare_rows(req_i, self.P["mf_i"].shape[0], tag="rows.i") if shared else None
         for ta, tb, own, req, prep in (("mf_u", "mlp_u", own_u, req_u, prep_u), ("mf_i", "mlp_i", own_i, req_i, prep_i)):
+            if (shared and getattr(ops, "pair_block_updates", False) and own.shape[1] == 2 * d and own.is_contiguous() and not isinstance(prep, _SortPlan)
+                    and ops.update_rows_pair(self.P[ta], self.P[tb], self.state[ta], self.state[tb], req, own, None, hyper, prep)):
+                continue      # (the received (d mf | d mlp) block read where it lies: no contiguous halves)
             ga, gb = own[:, :d].contiguous(), own[:, d:].contiguous()
             if shared and hasattr(ops, "update_rows_pair") and ops.update_rows_pair(
                     self.P[ta], self.P[tb], self.state[ta], self.state[tb], req, ga, gb, hyper, prep):

@@ -1,5 +1,6 @@
 """GPU: the entry points round 6 added, each against the call sequence it replaces, bit for bit --
 rc_gather_rows_pair (two rc_gather_rows + a concatenation), rc_plan_update_pair_zeroed (rc_plan_update_pair without its memset),
+rc_plan_update_pair_block (the same update reading both gradients from one strided block),
 rc_sasrec_batch_bwd_part (the backward pass of rc_sasrec_batch_bwd_dropout in two calls), rc_ctr_head_fwd_full (rc_ctr_head_fwd_bwd_sums
 + rc_ctr_head_bwd for a seed gradient of one, and the counter that rides along).  The fused field gather and the planned row sums
 have their own tests in test_gpu_deepfm.py.
@@ -57,6 +58,38 @@ def test_pair_update_with_prezeroed_counters_equals_the_plain_call(opt, cuda):
     for a, b in zip(st1, st0):
         for k in a:
             assert torch.equal(a[k], b[k]), k
+
+
+@pytest.mark.parametrize("opt", ["SGD", "Adam"])
+def test_pair_update_from_one_block_equals_two_contiguous_sources(opt, cuda):
+    """rc_plan_update_pair_block: the (gradient of table a | gradient of table b) rows of one [n, 2 d] block (also with a wider row
+    stride) against rc_plan_update_pair on contiguous copies of the halves"""
+    from rechorus_amd import engine
+    g = torch.Generator(device=cuda).manual_seed(5)
+    n_rows, d, n = 3000, 128, 30000
+    ids = torch.randint(0, n_rows, (n,), device=cuda, generator=g)
+    ids[:2500] = 11
+    for ld in (2 * d, 2 * d + 64):
+        block = torch.randn(n, ld, device=cuda, generator=g)
+        h = engine.make_hyper(opt, lr=0.05, l2=1e-4, step=2)
+        results = []
+        for as_block in (True, False):
+            Wa, Wb = (torch.randn(n_rows, d, device=cuda, generator=torch.Generator(device=cuda).manual_seed(20 + k)) for k in range(2))
+            gs = torch.Generator(device=cuda).manual_seed(78)
+            st = [{k: torch.rand(W.shape, device=cuda, generator=gs) * 0.1 for k in (("m", "v") if opt == "Adam" else ())} for W in (Wa, Wb)]
+            plan = engine.Plan(ids, n_rows, tag="t_r6_block%d" % as_block)
+            kw = dict(ma=st[0].get("m"), va=st[0].get("v"), mb=st[1].get("m"), vb=st[1].get("v"))
+            if as_block:
+                plan.update_pair("a", Wa, Wb, block, None, h, **kw)
+            else:
+                plan.update_pair("a", Wa, Wb, block[:, :d].contiguous(), block[:, d:2 * d].contiguous(), h, **kw)
+            torch.cuda.synchronize()
+            results.append((Wa, Wb, st))
+        (Wa1, Wb1, st1), (Wa0, Wb0, st0) = results
+        assert torch.equal(Wa1, Wa0) and torch.equal(Wb1, Wb0), ld
+        for a, b in zip(st1, st0):
+            for k in a:
+                assert torch.equal(a[k], b[k]), (ld, k)
 
 
 @pytest.mark.parametrize("B,L,heads,drop", [(300, 50, 4, 0.0), (64, 20, 2, 0.2), (257, 64, 1, 0.0), (40, 33, 4, 0.0)])
