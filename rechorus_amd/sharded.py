@@ -290,10 +290,14 @@ def _exchange(send, send_counts, group=None, recv_counts=None):
     return recv, recv_counts
 
 
-def _exchange_async(send, send_counts, recv_counts, group=None):
+def _exchange_async(send, send_counts, recv_counts, group=None, out=None):
     """_exchange with known split sizes whose transfer may stay in flight (RCCL): -> _Pending of the received rows.
-    Other backends (the gloo emulation of the CPU tests) complete it on the spot."""
-    recv = torch.empty((sum(recv_counts),) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
+    Other backends (the gloo emulation of the CPU tests) complete it on the spot.
+    out: where the rows are received (a contiguous slice of a larger buffer the caller assembles from several exchanges)"""
+    shape = (sum(recv_counts),) + tuple(send.shape[1:])
+    if out is not None and (tuple(out.shape) != shape or out.dtype != send.dtype or not out.is_contiguous()):
+        raise ValueError("_exchange_async: out does not fit the rows to receive")
+    recv = out if out is not None else torch.empty(shape, dtype=send.dtype, device=send.device)
     if _is_nccl(group):
         work = dist.all_to_all_single(recv, send.contiguous(), output_split_sizes=list(recv_counts),
                                       input_split_sizes=list(send_counts), group=group, async_op=True)
@@ -866,8 +870,8 @@ class _Route:
     def fetch_block_async(self, served):
         return _exchange_async(served, self.recv, self.send, self.group)
 
-    def push_async(self, grads, ops):
-        return _exchange_async(self._reduce(grads, ops), self.send, self.recv, self.group)
+    def push_async(self, grads, ops, out=None):
+        return _exchange_async(self._reduce(grads, ops), self.send, self.recv, self.group, out=out)
 
     def fetch(self, tables, ops):
         """rows of `tables` (this rank's shards, same row space) for the ids of the lookup, in lookup order"""
@@ -1133,6 +1137,12 @@ class ShardedNeumf(_LookAhead):
         start(0)
         loss = torch.zeros(1, dtype=torch.float32, device=dev)
         dense_sum, pushes = None, []
+        # the gradient rows the other ranks push to this one arrive chunk by chunk: they are received straight into their slices of
+        # ONE block per side (the owner-side update reads that block), not into a buffer per chunk that a 171 MB cat assembles later
+        tot_u, tot_i = [sum(recvs[2 * k]) for k in range(M)], [sum(recvs[2 * k + 1]) for k in range(M)]
+        own_u = torch.empty((sum(tot_u), 2 * d), dtype=torch.float32, device=dev)
+        own_i = torch.empty((sum(tot_i), self._item_row_floats()), dtype=torch.float32, device=dev)
+        off_u, off_i = 0, 0
         for k in range(M):
             if k + 1 < M:
                 start(k + 1)
@@ -1142,13 +1152,15 @@ class ShardedNeumf(_LookAhead):
             Bk = uc[k].shape[0]
             loss_vec, gu, gi, dense = self._head(urows, irows, Bk, C, n_tuples, mark)
             loss = loss + loss_vec.sum().reshape(1) / n_tuples
-            pushes.append((ru.push_async(gu, ops), rv.push_async(gi, ops)))
+            pushes.append((ru.push_async(gu, ops, out=own_u[off_u:off_u + tot_u[k]]), rv.push_async(gi, ops, out=own_i[off_i:off_i + tot_i[k]])))
+            off_u, off_i = off_u + tot_u[k], off_i + tot_i[k]
             flat = torch.cat([dense[n].reshape(-1) for n in (("W1u" if owner else "W1"), "b1", "w_out")])
             dense_sum = flat if dense_sum is None else dense_sum + flat
         loss = _all_reduce_sum(loss, group)
         self._account([r for pair in routes for r in pair[:2]])
-        own_u = torch.cat([p[0].wait() for p in pushes])
-        own_i = torch.cat([p[1].wait() for p in pushes])
+        for pu_, pv_ in pushes:
+            pu_.wait()
+            pv_.wait()
         req_u = torch.cat([r[0].req for r in routes])
         req_i = torch.cat([r[1].req for r in routes])
         mark("push_grads")
