@@ -495,6 +495,17 @@ def unique_ids(ids, n_rows, tag="unique"):
     return uniq[:int(cnt.item())], inverse
 
 
+def unique_ids_begin(ids, n_rows, tag="unique"):
+    """unique_ids without the host sync: -> (uniq_full int64 [n] (the first count entries are valid), inverse, count int32 [1] on the
+    device -- a copy: the plan's own counter is overwritten by the next plan with this tag), or None where the list has no plan
+    geometry (the caller falls back to unique_ids).  Several lists' counts can then be read back with ONE synchronisation."""
+    flat = ids.reshape(-1)
+    if flat.numel() == 0 or not plan_supported(flat.numel(), 0, n_rows, 0):
+        return None
+    uniq, inverse, cnt = Plan(flat, n_rows, tag=tag).distinct("a")
+    return uniq, inverse, cnt[:1].clone()
+
+
 def small_route_ok(n_ids, n_rows, d):
     """embedding_dense_backward(route="small") takes rc_small_row_sums for this shape"""
     return bool(_EDB_SMALL and 0 < n_ids <= _EDB_SMALL_MAX and _lib.load().rc_small_row_sums_supported(int(n_ids), int(n_rows), int(d)))

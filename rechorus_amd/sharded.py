@@ -112,6 +112,15 @@ class HipOps:
         ahead, on their side stream)"""
         return self.e.unique_ids(ids, n_rows, tag="route.unique")
 
+    def unique_many(self, lists):
+        """unique() of several (ids, n_rows) lists with ONE host synchronisation for all their counts (a sync per list otherwise:
+        eight per sharded NeuMF step, each a wait for the side stream's small kernels)"""
+        begun = [self.e.unique_ids_begin(ids, n_rows, tag="route.unique") for ids, n_rows in lists]
+        if any(b is None for b in begun):
+            return [self.unique(ids, n_rows) for ids, n_rows in lists]
+        counts = torch.cat([b[2] for b in begun]).tolist()       # the one device -> host copy
+        return [(b[0][:int(c)], b[1]) for b, c in zip(begun, counts)]
+
     def prepare_rows(self, rows, n_rows, tag="rows", d=64):
         """grouping of a row-id list (bucket plan, or the sorted route where the plan has no geometry / no kernel for width d),
         reusable by several update_rows calls on tables that share the ids"""
@@ -428,6 +437,8 @@ def _record_stream(obj, stream):
     elif isinstance(obj, (list, tuple)):
         for v in obj:
             _record_stream(v, stream)
+    elif type(obj).__name__ == "_Route":      # (routes completed ahead of their step: ids exchanged on the side stream)
+        _record_stream(vars(obj), stream)
 
 
 class _Timed:
@@ -501,6 +512,11 @@ class _LookAhead(_Timed):
             self._side.wait_event(begin)
         with torch.cuda.stream(self._side):
             prep = self._prepare(uid, iid)
+            finish = getattr(self, "_finish_routes", None)
+            if finish is not None:
+                # the id exchanges of the routes too: they depend on the batch alone.  The host waits here for the split sizes -- a few
+                # small kernels on this stream, while the main stream still works on the step whose launches were just enqueued
+                finish(prep)
             done = torch.cuda.Event()
             done.record(self._side)
         prep["ready"] = done
@@ -812,13 +828,22 @@ class _Route:
         self.req, _ = _exchange(local, self.send, group, recv_counts=self.recv)  # local rows this rank must serve
 
     @staticmethod
-    def prepare(ids, world, ops, dedup=True, n_rows=None):
+    def prepare_many(lists, world, ops, dedup=True):
+        """prepare() of several (ids, n_rows) lookups; with ops.unique_many the de-duplications share ONE host synchronisation"""
+        if dedup and hasattr(ops, "unique_many") and len(lists) > 1:
+            uniq = ops.unique_many([(ids.reshape(-1), n_rows) for ids, n_rows in lists])
+            return [_Route.prepare(ids, world, ops, True, n_rows, unique=u) for (ids, n_rows), u in zip(lists, uniq)]
+        return [_Route.prepare(ids, world, ops, dedup, n_rows) for ids, n_rows in lists]
+
+    @staticmethod
+    def prepare(ids, world, ops, dedup=True, n_rows=None, unique=None):
         """-> ((send order, per-owner counts, local rows in send order), inverse index | None, lookup length);
-        n_rows: size of the (global) id space, needed for the de-duplication's bucket plan"""
+        n_rows: size of the (global) id space, needed for the de-duplication's bucket plan; unique: (distinct ids, inverse) where the
+        caller has them already (prepare_many)"""
         n = ids.numel()
         inverse = None
         if dedup:
-            ids, inverse = ops_unique(ops, ids, n_rows)
+            ids, inverse = unique if unique is not None else ops_unique(ops, ids, n_rows)
         grouped = _Route.group_by_owner(ids, world, ops)
         # The rows come back in SEND order (row k answers the k-th id sent, id number order[k]) and are wanted in lookup order:
         # lookup position j reads row inv_order[inverse[j]].  The composed index is formed here, with the route (off the critical
@@ -970,10 +995,21 @@ class ShardedNeumf(_LookAhead):
         W, ops = self.world, self.ops
         M = self.micro_batches if ((W > 1 or self.force_exchange) and self.micro_batches > 1 and iid.shape[0] >= self.micro_batches) else 1
         uc, ic = (torch.chunk(uid, M), torch.chunk(iid, M)) if M > 1 else ((uid,), (iid,))
-        grouped = [(_Route.prepare(u, W, ops, self.dedup, self.n_users), _Route.prepare(i.reshape(-1), W, ops, self.dedup, self.n_items))
-                   for u, i in zip(uc, ic)]
+        flat = _Route.prepare_many([x for u, i in zip(uc, ic) for x in ((u, self.n_users), (i.reshape(-1), self.n_items))], W, ops, self.dedup)
+        grouped = [(flat[2 * k], flat[2 * k + 1]) for k in range(len(uc))]
         counts = _Counts([g[0][1] for pair in grouped for g in pair], self.group)
         return {"uc": uc, "ic": ic, "grouped": grouped, "counts": counts}
+
+    def _finish_routes(self, prep):
+        """complete the routes of a prepared batch on the current (side) stream: split sizes from the host, ids to their owners"""
+        W, ops, group = self.world, self.ops, self.group
+        sends, recvs = prep["counts"].get()
+        routes = []
+        for k, (gu, gi) in enumerate(prep["grouped"]):
+            ru = _Route(prep["uc"][k], W, ops, group, prepared=gu, splits=(sends[2 * k], recvs[2 * k]))
+            rv = _Route(prep["ic"][k].reshape(-1), W, ops, group, prepared=gi, splits=(sends[2 * k + 1], recvs[2 * k + 1]))
+            routes.append((ru, rv))
+        prep["routes"] = routes
 
     def step(self, uid, iid, next_batch=None):
         """uid [B], iid [B, C]: this rank's tuples (same B everywhere) -> global mean loss, device tensor [1].
@@ -1003,8 +1039,11 @@ class ShardedNeumf(_LookAhead):
             prep = self._routes_of(uid, iid, next_batch)
             (pu_, pv_), = prep["grouped"]
             sends, recvs = prep["counts"].get()   # split sizes of both lookups (on the host already with look-ahead)
-            ru = _Route(uid, W, ops, self.group, splits=(sends[0], recvs[0]), prepared=pu_)
-            rv = _Route(iid.reshape(-1), W, ops, self.group, splits=(sends[1], recvs[1]), prepared=pv_)
+            if prep.get("routes") is not None:
+                (ru, rv), = prep["routes"]
+            else:
+                ru = _Route(uid, W, ops, self.group, splits=(sends[0], recvs[0]), prepared=pu_)
+                rv = _Route(iid.reshape(-1), W, ops, self.group, splits=(sends[1], recvs[1]), prepared=pv_)
             self._account([ru, rv])
             mark("route")
             urows = ru.fetch([self.P["mf_u"], self.P["mlp_u"]], ops)      # [B, 2d]
@@ -1120,9 +1159,14 @@ class ShardedNeumf(_LookAhead):
         W1i = self.P["W1"][:, d:].contiguous() if owner else None
         mlp_reqs = []
 
+        ready_routes = prep.get("routes")      # (completed ahead of this step, look-ahead: _finish_routes)
+
         def start(k):  # routes of chunk k, its rows requested (transfers may stay in flight)
-            ru = _Route(uc[k], W, ops, group, prepared=grouped[k][0], splits=(sends[2 * k], recvs[2 * k]))
-            rv = _Route(ic[k].reshape(-1), W, ops, group, prepared=grouped[k][1], splits=(sends[2 * k + 1], recvs[2 * k + 1]))
+            if ready_routes is not None:
+                ru, rv = ready_routes[k]
+            else:
+                ru = _Route(uc[k], W, ops, group, prepared=grouped[k][0], splits=(sends[2 * k], recvs[2 * k]))
+                rv = _Route(ic[k].reshape(-1), W, ops, group, prepared=grouped[k][1], splits=(sends[2 * k + 1], recvs[2 * k + 1]))
             mark("route_ids")     # (the id exchanges of the two routes)
             if owner:
                 mlp_req = ops.gather_rows(self.P["mlp_i"], rv.req)
