@@ -5,8 +5,9 @@ the remote fraction (W - 1) / W, and the pipeline of `micro_batches` chunks whos
 
     python tools/scale_model.py [--batch 65536] > profiles/r02_scale_model.json
 
-compute_ms is the MEASURED single-GPU step at the same per-GPU batch (profiles/r02y_bench_neumf.json); the link rates are
-parameters (xGMI: 7 links x ~153 GB/s peak per GPU).  No GPU needed."""
+compute_ms is what a RANK's step costs locally (round 2 put the single-GPU step there; since round 6 the measured cost of one rank
+alone through the exchange path, profiles/r09_sharded_loopback.txt), single_gpu_ms the single-GPU step of the same per-GPU batch
+the speed-ups are taken against; the link rates are parameters (xGMI: 7 links x ~153 GB/s peak per GPU).  No GPU needed."""
 import argparse
 import json
 import os
@@ -25,13 +26,15 @@ def main():
     ap.add_argument("--num-neg", type=int, default=4)
     ap.add_argument("--items", type=int, default=100_000_001)
     ap.add_argument("--users", type=int, default=10_000_001)
-    ap.add_argument("--compute-ms", type=float, default=1.50)
+    ap.add_argument("--compute-ms", type=float, default=1.50, help="local cost of a rank's sharded step")
+    ap.add_argument("--single-gpu-ms", type=float, default=None, help="the single-GPU step the speed-ups are relative to (default: compute-ms)")
     ap.add_argument("--micro-batches", type=int, default=4)
     ap.add_argument("--hidden", type=int, default=64)
     ap.add_argument("--item-half", default="rows", choices=["rows", "owner"],
                     help="owner: an item id moves (mf_i | W1i mlp_i) = emb_size + hidden floats each way instead of 2 emb_size "
                          "(ShardedNeumf item_half='owner', profiles/r09_sharded_neumf_item_half.txt)")
     a = ap.parse_args()
+    single = a.single_gpu_ms if a.single_gpu_ms is not None else a.compute_ms
     row_bytes = 2 * a.emb_size * 4   # the mf and mlp rows of a USER id travel together; an item id: see --item-half
     item_row_bytes = (a.emb_size + a.hidden) * 4 if a.item_half == "owner" else row_bytes
     gen = torch.Generator().manual_seed(99)
@@ -60,8 +63,8 @@ def main():
             M = a.micro_batches
             step_ms = max(a.compute_ms, exch_ms) + min(a.compute_ms, exch_ms) / M   # pipeline fill / drain of one chunk
             t[f"{bw}GBps"] = {"exchange_ms": round(exch_ms, 3), "step_ms": round(step_ms, 3),
-                              "speedup_vs_1gpu": round(W * a.compute_ms / step_ms, 2),
-                              "unpipelined_speedup": round(W * a.compute_ms / (a.compute_ms + exch_ms), 2)}
+                              "speedup_vs_1gpu": round(W * single / step_ms, 2),
+                              "unpipelined_speedup": round(W * single / (a.compute_ms + exch_ms), 2)}
         res["time_model"] = t
         # what the topology offers: W - 1 direct xGMI links of ~153 GB/s per GPU, all used by an all-to-all
         links = {}
@@ -70,7 +73,7 @@ def main():
             exch_ms = 2 * b / (bw * 1e9) * 1e3
             step_ms = max(a.compute_ms, exch_ms) + min(a.compute_ms, exch_ms) / a.micro_batches
             links[f"{W - 1}_links_at_{int(eff * 100)}pct"] = {"GBps": round(bw), "exchange_ms": round(exch_ms, 3), "step_ms": round(step_ms, 3),
-                                                            "speedup_vs_1gpu": round(W * a.compute_ms / step_ms, 2)}
+                                                            "speedup_vs_1gpu": round(W * single / step_ms, 2)}
         res["xgmi_links"] = links
         out["worlds"][str(W)] = res
     print(json.dumps(out, indent=1))
